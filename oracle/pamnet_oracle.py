@@ -1,0 +1,544 @@
+"""CPU oracle for PAMNet's multiplex message-passing hot path.
+
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may
+import this file.  The product (physics-aware-multiplex-gnn_amd/) never imports it and has no CPU fallback.
+
+What it is: a from-scratch, pure-torch (CPU, no PyG / torch_scatter / torch_sparse / torch_cluster) restatement of the
+reference algorithm, written functionally over a reference-layout ``state_dict`` and generic in dtype (fp32 = "the
+reference CPU forward"; fp64 = the noise-free arbiter, see DESIGN.md "Parity protocol").  Each function cites the
+reference file:line it follows (paths relative to /root/reference).
+
+How it is pinned (tests/test_oracle_golden.py, `-m "not gpu"`): against golden vectors produced in the build container
+by importing the reference's own models.py / layers/*.py (tests/golden/gen/gen_golden.py; the four absent third-party
+wheels are replaced by documented-semantics stand-ins, tests/golden/gen/thirdparty_standins.py):
+  * the 21-graph RNA-Puzzles data + shipped checkpoint save/pamnet_rna.pt (3 smallest graphs committed), end to end;
+  * seeded random-init QM9-schema, PDBbind-schema batches with all intermediates (fp32 and fp64);
+  * indices() on a 4-node star, basis tables, zeros / normalisers of the spherical Bessel basis.
+The third-party semantics themselves (radius tie rule, neighbour order, PyG 1.4.2 flow convention) have no golden in
+the reference tree: "parity unpinned" at that level.
+"""
+import math
+
+import numpy as np
+import torch
+
+NUM_SPHERICAL = 7
+NUM_RADIAL = 6
+NUM_RBF = 16
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Basis constants (utils/sbf.py:14-61, 64-67, 94-138).  Computed here, not read from the reference.
+# ----------------------------------------------------------------------------------------------------------------------
+def _sph_jn_f64(l, x):
+    """Spherical Bessel j_l(x) in float64 via scipy (utils/sbf.py:10-11 uses sqrt(pi/2r) J_{l+1/2}(r))."""
+    from scipy import special as sp
+    return sp.spherical_jn(l, np.asarray(x, dtype=np.float64))
+
+
+def bessel_zeros_f32(n=NUM_SPHERICAL, k=NUM_RADIAL):
+    """First k positive zeros of j_0..j_{n-1}, ROUNDED TO FLOAT32 as utils/sbf.py:15-26 stores them.
+
+    Interlacing (zeros of j_l lie between consecutive zeros of j_{l-1}) brackets each root exactly as the reference's
+    brentq sweep does; bisection + Newton polish in float64 gives the same float32 value."""
+    from scipy.optimize import brentq
+    zeros = np.zeros((n, k), dtype=np.float64)
+    zeros[0] = np.arange(1, k + 1) * np.pi
+    points = np.arange(1, k + n) * np.pi
+    for l in range(1, n):
+        roots = np.zeros(k + n - 1 - l)
+        for j in range(k + n - 1 - l):
+            roots[j] = brentq(lambda r: float(_sph_jn_f64(l, r)), points[j], points[j + 1], xtol=1e-14, rtol=1e-15)
+        points = roots
+        zeros[l] = roots[:k]
+    return zeros.astype(np.float32)
+
+
+def bessel_normalizers(zeros_f32):
+    """N_ln = 1/sqrt(0.5 * j_{l+1}(z_ln)^2)  (utils/sbf.py:43-49), evaluated in float64 on the float32 zeros."""
+    z = zeros_f32.astype(np.float64)
+    out = np.zeros_like(z)
+    for l in range(z.shape[0]):
+        out[l] = 1.0 / np.sqrt(0.5 * _sph_jn_f64(l + 1, z[l]) ** 2)
+    return out
+
+
+def legendre_coeffs(n=NUM_SPHERICAL):
+    """Monomial coefficients c[l][p] of Y_l0(theta) = sum_p c[l][p] cos(theta)^p with the prefactor
+    sqrt((2l+1)/(4 pi)) folded in (utils/sbf.py:64-67, 70-79, 127)."""
+    P = [np.array([1.0]), np.array([0.0, 1.0])]
+    for j in range(2, n):
+        a = np.zeros(j + 1)
+        a[1:] += (2 * j - 1) * P[j - 1]
+        a[:j - 1] -= (j - 1) * P[j - 2]
+        P.append(a / j)
+    out = np.zeros((n, n))
+    for l in range(n):
+        out[l, :l + 1] = math.sqrt((2 * l + 1) / (4 * math.pi)) * P[l]
+    return out
+
+
+_CONST_CACHE = {}
+
+
+def basis_constants():
+    if not _CONST_CACHE:
+        z = bessel_zeros_f32()
+        _CONST_CACHE['zeros'] = z
+        _CONST_CACHE['norm'] = bessel_normalizers(z)
+        _CONST_CACHE['legendre'] = legendre_coeffs()
+    return _CONST_CACHE
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Basis layers (layers/basic.py)
+# ----------------------------------------------------------------------------------------------------------------------
+def silu(x):
+    """layers/basic.py:11-16."""
+    return x * torch.sigmoid(x)
+
+
+def envelope(x, p=5):
+    """layers/basic.py:36-51: 1/x + a x^p + b x^(p+1) + c x^(p+2) for x<1 else 0 (p=5: a=-21,b=35,c=-15)."""
+    a = -(p + 1) * (p + 2) / 2
+    b = p * (p + 2)
+    c = -p * (p + 1) / 2
+    xp0 = x.pow(p)
+    xp1 = xp0 * x
+    env = 1.0 / x + a * xp0 + b * xp1 + c * xp1 * x
+    return torch.where(x < 1, env, torch.zeros_like(x))
+
+
+def bessel_rbf(dist, freq, cutoff, p=5):
+    """layers/basic.py:74-76: env(d/c) * sin(freq * d/c), [E] -> [E,16]."""
+    d = dist.unsqueeze(-1) / cutoff
+    return envelope(d, p) * (freq * d).sin()
+
+
+def _sph_jl_closed(lmax, z):
+    """j_0..j_lmax(z) in z's dtype via the closed sin/cos forms the reference obtains symbolically
+    (utils/sbf.py:29-38): j_0=sin z/z, j_1=sin z/z^2-cos z/z, j_{l+1}=(2l+1)/z j_l - j_{l-1}.  Evaluated in the working
+    precision like the reference's lambdified expressions (layers/basic.py:104,109), so fp32 carries the same class of
+    cancellation noise; fp64 is the arbiter."""
+    s, c = torch.sin(z), torch.cos(z)
+    out = [s / z]
+    if lmax >= 1:
+        out.append(s / (z * z) - c / z)
+    for l in range(1, lmax):
+        out.append((2 * l + 1) / z * out[l] - out[l - 1])
+    return out
+
+
+def sbf_radial(dist, cutoff, p=5):
+    """layers/basic.py:107-109: rbf[e, l*6+n] = env(x) * N_ln * j_l(z_ln x), x = d/cutoff -> [E,42]."""
+    k = basis_constants()
+    x = dist / cutoff
+    zeros = torch.as_tensor(k['zeros'].astype(np.float64), dtype=dist.dtype)      # fp32-rounded values
+    norm = torch.as_tensor(k['norm'], dtype=dist.dtype)
+    cols = []
+    for l in range(NUM_SPHERICAL):
+        zx = x.unsqueeze(-1) * zeros[l]                                         # [E,6]
+        cols.append(norm[l] * _sph_jl_closed(l, zx)[l])
+    rbf = torch.cat(cols, dim=1)
+    return envelope(x, p).unsqueeze(-1) * rbf
+
+
+def sbf_angular(angle):
+    """layers/basic.py:111: cbf[t, l] = Y_l0(angle_t) -> [T,7] (utils/sbf.py:127)."""
+    c = torch.as_tensor(basis_constants()['legendre'], dtype=angle.dtype)
+    ct = torch.cos(angle)
+    pw = torch.stack([ct.pow(i) for i in range(NUM_SPHERICAL)], dim=1)            # [T,7]
+    return pw @ c.t()
+
+
+def spherical_basis(dist, angle, idx, cutoff, p=5):
+    """layers/basic.py:107-116: out[t, l*6+n] = rbf[idx[t], l, n] * cbf[t, l] -> [T,42]."""
+    rbf = sbf_radial(dist, cutoff, p)
+    cbf = sbf_angular(angle)
+    n, k = NUM_SPHERICAL, NUM_RADIAL
+    return (rbf[idx].view(-1, n, k) * cbf.view(-1, n, 1)).view(-1, n * k)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Graph construction (third-party torch_cluster / torch_sparse / PyG utils restated; models.py:62-98, 110, 128, 143)
+# ----------------------------------------------------------------------------------------------------------------------
+def _graph_slices(batch):
+    cnt = torch.bincount(batch)
+    ptr = torch.cat([cnt.new_zeros(1), cnt.cumsum(0)])
+    return [(int(ptr[b]), int(ptr[b + 1])) for b in range(cnt.numel())]
+
+
+def radius_graph(pos, batch, r):
+    """torch_cluster.radius(pos,pos,r,batch,batch) (models.py:110,128): [2,M] = (query idx, neighbour idx), self
+    included, `dist <= r`, ordered by (query, neighbour).  `batch` sorted."""
+    rows, cols = [], []
+    for s, e in _graph_slices(batch):
+        p = pos[s:e].double()
+        d = (p.unsqueeze(1) - p.unsqueeze(0)).pow(2).sum(-1).sqrt()
+        q, n = (d <= r).nonzero(as_tuple=True)
+        rows.append(q + s)
+        cols.append(n + s)
+    return torch.stack([torch.cat(rows), torch.cat(cols)], 0)
+
+
+def knn_graph(pos, batch, k):
+    """torch_cluster.knn(pos,pos,k,batch,batch) (models.py:143): for every query its k nearest (self included),
+    ordered by (query, ascending distance)."""
+    rows, cols = [], []
+    for s, e in _graph_slices(batch):
+        p = pos[s:e].double()
+        d = (p.unsqueeze(1) - p.unsqueeze(0)).pow(2).sum(-1)
+        kk = min(k, e - s)
+        nn_idx = d.topk(kk, dim=1, largest=False, sorted=True).indices
+        rows.append(torch.arange(s, e).repeat_interleave(kk))
+        cols.append(nn_idx.reshape(-1) + s)
+    return torch.stack([torch.cat(rows), torch.cat(cols)], 0)
+
+
+def get_edge_info(edge_index, pos):
+    """models.py:62-66: drop self loops; dist = ||pos[i] - pos[j]|| with (j, i) = edge_index."""
+    mask = edge_index[0] != edge_index[1]
+    edge_index = edge_index[:, mask]
+    j, i = edge_index
+    dist = (pos[i] - pos[j]).pow(2).sum(dim=-1).sqrt()
+    return edge_index, dist
+
+
+def _csr_by_target(edge_index, num_nodes):
+    """torch_sparse.SparseTensor(row=col, col=row, value=arange(E)) (models.py:71-73): entries sorted by
+    (target i, source j); returns rowptr [N+1], src [E], eid [E]."""
+    row, col = edge_index
+    perm = (col * num_nodes + row).argsort(stable=True)
+    cnt = torch.bincount(col, minlength=num_nodes)
+    rowptr = torch.cat([cnt.new_zeros(1), cnt.cumsum(0)])
+    return rowptr, row[perm], perm
+
+
+def _expand(rowptr, nodes):
+    """adj_t[nodes] (models.py:74, 85): for each position p, all CSR entries of row nodes[p]."""
+    start = rowptr[nodes]
+    cnt = rowptr[nodes + 1] - start
+    owner = torch.arange(nodes.numel()).repeat_interleave(cnt)
+    off = torch.arange(int(cnt.sum())) - (cnt.cumsum(0) - cnt).repeat_interleave(cnt)
+    return owner, start.repeat_interleave(cnt) + off
+
+
+def indices(edge_index, num_nodes):
+    """models.py:68-98.  Returns the same 10 tensors in the same order."""
+    row, col = edge_index
+    rowptr, src, eid = _csr_by_target(edge_index, num_nodes)
+    # triplets k->j->i: for edge e=(j->i) every edge e'=(k->j), k != i          (models.py:74-83)
+    owner, ent = _expand(rowptr, row)
+    idx_i, idx_j, idx_k = col[owner], row[owner], src[ent]
+    mask = idx_i != idx_k
+    idx_i, idx_j, idx_k = idx_i[mask], idx_j[mask], idx_k[mask]
+    idx_kj, idx_ji = eid[ent][mask], owner[mask]
+    # pairs: for edge e=(j->i) every edge e'=(j'->i) incl. e'=e                  (models.py:85-96)
+    owner_p, ent_p = _expand(rowptr, col)
+    idx_i_pair, idx_j1_pair, idx_j2_pair = row[owner_p], col[owner_p], src[ent_p]
+    mask_j = idx_j1_pair != idx_j2_pair
+    idx_i_pair, idx_j1_pair, idx_j2_pair = idx_i_pair[mask_j], idx_j1_pair[mask_j], idx_j2_pair[mask_j]
+    idx_ji_pair, idx_jj_pair = owner_p[mask_j], eid[ent_p][mask_j]
+    return idx_i, idx_j, idx_k, idx_kj, idx_ji, idx_i_pair, idx_j1_pair, idx_j2_pair, idx_jj_pair, idx_ji_pair
+
+
+def angle_between(a, b):
+    """models.py:165-168 / 175-177: atan2(|a x b|, a.b), cross along the last dim."""
+    dot = (a * b).sum(dim=-1)
+    crs = torch.linalg.cross(a, b, dim=-1).norm(dim=-1)
+    return torch.atan2(crs, dot)
+
+
+def segment_add(src, index, dim_size):
+    """torch_scatter.scatter(src, index, dim=0, dim_size, reduce='add') (layers/local_message_passing.py:50,54)."""
+    out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype)
+    return out.index_add_(0, index, src)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Layers (layers/basic.py:19-33, layers/global_message_passing.py, layers/local_message_passing.py)
+# ----------------------------------------------------------------------------------------------------------------------
+def _lin(sd, key, x, bias=True):
+    y = x @ sd[key + '.weight'].t()
+    return y + sd[key + '.bias'] if bias else y
+
+
+def mlp(sd, prefix, x, n_layers):
+    """layers/basic.py:19-22: Sequential(Sequential(Linear, SiLU), ...) -> keys `<prefix>.<k>.0.{weight,bias}`."""
+    for k in range(n_layers):
+        x = silu(_lin(sd, '%s.%d.0' % (prefix, k), x))
+    return x
+
+
+def res(sd, prefix, x):
+    """layers/basic.py:25-33."""
+    return mlp(sd, prefix + '.mlp', x, 2) + x
+
+
+def _update_and_heads(sd, p, x, res_x):
+    """Shared tail of both layers (global_message_passing.py:39-50, local_message_passing.py:55-66)."""
+    x = mlp(sd, p + '.mlp_x2', x, 1)
+    x = res(sd, p + '.res1', x) + res_x
+    x = res(sd, p + '.res2', x)
+    x = res(sd, p + '.res3', x)
+    out = mlp(sd, p + '.mlp_out', x, 3)
+    att = (out @ sd[p + '.W']).unsqueeze(0)
+    out = _lin(sd, p + '.W_out', out).unsqueeze(0)
+    return x, out, att
+
+
+def global_mp(sd, p, x, edge_attr, edge_index, flow):
+    """layers/global_message_passing.py:33-56 + PyG 1.4.2 propagate: (i,j)=(edge_index[1],edge_index[0]) for
+    'source_to_target', (edge_index[0],edge_index[1]) for 'target_to_source'; add-aggregate at i."""
+    res_x = x
+    x = mlp(sd, p + '.mlp_x1', x, 1)
+    i, j = (edge_index[0], edge_index[1]) if flow == 'target_to_source' else (edge_index[1], edge_index[0])
+    m = torch.cat((x[i], x[j], edge_attr), -1)
+    m = mlp(sd, p + '.mlp_m', m, 1) * _lin(sd, p + '.W_edge_attr', edge_attr, bias=False)
+    x = x + segment_add(m, i, x.size(0))
+    return _update_and_heads(sd, p, x, res_x)
+
+
+def local_mp(sd, p, x, rbf, sbf2, sbf1, idx_kj, idx_ji, idx_jj_pair, idx_ji_pair, edge_index):
+    """layers/local_message_passing.py:36-66."""
+    j, i = edge_index
+    idx = torch.cat((idx_kj, idx_jj_pair), 0)
+    idx_scatter = torch.cat((idx_ji, idx_ji_pair), 0)
+    sbf = torch.cat((sbf2, sbf1), 0)
+    res_x = x
+    x = mlp(sd, p + '.mlp_x1', x, 1)
+    m = torch.cat([x[i], x[j], rbf], dim=-1)
+    m_ji = mlp(sd, p + '.mlp_m_ji', m, 1)
+    m_neighbor = mlp(sd, p + '.mlp_m_kj', m, 1) * _lin(sd, p + '.lin_rbf', rbf, bias=False)
+    m_other = m_neighbor[idx] * mlp(sd, p + '.mlp_sbf', sbf, 2)
+    m_other = segment_add(m_other, idx_scatter, m.size(0))
+    m = m_ji + m_other
+    m = _lin(sd, p + '.lin_rbf_out', rbf, bias=False) * m
+    x = x + segment_add(m, i, x.size(0))
+    return _update_and_heads(sd, p, x, res_x)
+
+
+def local_mp_s(sd, p, x, rbf, sbf, idx_jj_pair, idx_ji_pair, edge_index):
+    """layers/local_message_passing.py:96-123 (pairs only; `mlp_m_jj` instead of `mlp_m_kj`)."""
+    j, i = edge_index
+    res_x = x
+    x = mlp(sd, p + '.mlp_x1', x, 1)
+    m = torch.cat([x[i], x[j], rbf], dim=-1)
+    m_ji = mlp(sd, p + '.mlp_m_ji', m, 1)
+    m_neighbor = mlp(sd, p + '.mlp_m_jj', m, 1) * _lin(sd, p + '.lin_rbf', rbf, bias=False)
+    m_other = m_neighbor[idx_jj_pair] * mlp(sd, p + '.mlp_sbf', sbf, 2)
+    m_other = segment_add(m_other, idx_ji_pair, m.size(0))
+    m = _lin(sd, p + '.lin_rbf_out', rbf, bias=False) * (m_ji + m_other)
+    x = x + segment_add(m, i, x.size(0))
+    return _update_and_heads(sd, p, x, res_x)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Model forward (models.py:100-224, 283-353)
+# ----------------------------------------------------------------------------------------------------------------------
+class Config(object):
+    """models.py:12-19."""
+
+    def __init__(self, dataset, dim, n_layer, cutoff_l, cutoff_g, flow='source_to_target'):
+        self.dataset, self.dim, self.n_layer = dataset, dim, n_layer
+        self.cutoff_l, self.cutoff_g, self.flow = cutoff_l, cutoff_g, flow
+
+
+def build_graph(cfg, x_raw, batch, pos=None, edge_index_l=None, dtype=torch.float32, max_nb=1000):
+    """Graph-construction part of forward (models.py:104-160).  Returns a dict with pos, edge lists, distances,
+    `all_index` (PDBbind) and the node-embedding selector."""
+    g = {}
+    if cfg.dataset == 'QM9':
+        pos = pos.to(dtype)
+        ei_g = radius_graph(pos, batch, cfg.cutoff_g)
+        ei_g, dist_g = get_edge_info(ei_g, pos)
+        ei_l, dist_l = get_edge_info(edge_index_l, pos)
+        g['emb_index'] = x_raw.long()
+    elif cfg.dataset == 'PDBbind':
+        x_raw = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
+        x_raw = x_raw.to(dtype)
+        g['feat'] = x_raw[:, 3:]
+        pos = x_raw[:, :3].contiguous()
+        g['all_index'] = torch.where(pos[:, 0] > 40.0, -torch.ones_like(pos[:, 0]), torch.ones_like(pos[:, 0]))
+        ei_g = radius_graph(pos, batch, cfg.cutoff_g)
+        ei_g, dist_g = get_edge_info(ei_g, pos)
+        ei_l = ei_g[:, dist_g <= cfg.cutoff_l]
+        ei_l, dist_l = get_edge_info(ei_l, pos)
+    elif cfg.dataset[:3].lower() == 'rna':
+        x_raw = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
+        g['emb_index'] = x_raw[:, -1].long()
+        pos = x_raw[:, :3].contiguous().to(dtype)
+        ei_knn = knn_graph(pos, batch, 50)
+        ei_knn, dist_knn = get_edge_info(ei_knn, pos)
+        ei_g = ei_knn[:, dist_knn <= cfg.cutoff_g]
+        ei_g, dist_g = get_edge_info(ei_g, pos)
+        ei_l = ei_knn[:, dist_knn <= cfg.cutoff_l]
+        ei_l, dist_l = get_edge_info(ei_l, pos)
+    else:
+        raise ValueError("Invalid dataset. If you are using any dataset related to RNA 3D structure prediction, "
+                         "be sure to use 'rna' as the first 3 characters of the dataset name.")
+    g.update(pos=pos, edge_index_g=ei_g, dist_g=dist_g, edge_index_l=ei_l, dist_l=dist_l)
+    return g
+
+
+def pamnet_forward(sd, cfg, x_raw, batch, pos=None, edge_index=None, dtype=None, intermediates=None):
+    """models.py:100-224.  `sd`: reference-layout state_dict (tensors of the working dtype).  Returns [num_graphs]."""
+    dtype = dtype or sd['embeddings'].dtype
+    g = build_graph(cfg, x_raw, batch, pos, edge_index, dtype)
+    pos, ei_g, dist_g, ei_l, dist_l = g['pos'], g['edge_index_g'], g['dist_g'], g['edge_index_l'], g['dist_l']
+    if 'emb_index' in g:
+        x = torch.index_select(sd['embeddings'], 0, g['emb_index'])                       # models.py:107,140
+    else:
+        x = g['feat'] @ sd['init_linear.weight'].t()                                       # models.py:119
+    n_nodes = x.size(0)
+
+    (idx_i, idx_j, idx_k, idx_kj, idx_ji,
+     idx_i_pair, idx_j1_pair, idx_j2_pair, idx_jj_pair, idx_ji_pair) = indices(ei_l, n_nodes)
+
+    angle2 = angle_between(pos[idx_j] - pos[idx_i], pos[idx_k] - pos[idx_j])              # models.py:165-168
+    angle1 = angle_between(pos[idx_j1_pair] - pos[idx_i_pair], pos[idx_j2_pair] - pos[idx_j1_pair])  # :171-177
+
+    rbf_l = bessel_rbf(dist_l, sd['rbf_l.freq'], cfg.cutoff_l)                            # models.py:180
+    rbf_g = bessel_rbf(dist_g, sd['rbf_g.freq'], cfg.cutoff_g)
+    sbf1 = spherical_basis(dist_l, angle1, idx_jj_pair, cfg.cutoff_l)
+    sbf2 = spherical_basis(dist_l, angle2, idx_kj, cfg.cutoff_l)
+
+    e_rbf_l = mlp(sd, 'mlp_rbf_l', rbf_l, 1)                                              # models.py:185-188
+    e_rbf_g = mlp(sd, 'mlp_rbf_g', rbf_g, 1)
+    e_sbf1 = mlp(sd, 'mlp_sbf1', sbf1, 1)
+    e_sbf2 = mlp(sd, 'mlp_sbf2', sbf2, 1)
+
+    out_g, out_l, att_g, att_l, xs = [], [], [], [], []
+    for k in range(cfg.n_layer):                                                          # models.py:196-204
+        x, o, a = global_mp(sd, 'global_layer.%d' % k, x, e_rbf_g, ei_g, cfg.flow)
+        out_g.append(o), att_g.append(a), xs.append(x)
+        x, o, a = local_mp(sd, 'local_layer.%d' % k, x, e_rbf_l, e_sbf2, e_sbf1,
+                           idx_kj, idx_ji, idx_jj_pair, idx_ji_pair, ei_l)
+        out_l.append(o), att_l.append(a), xs.append(x)
+
+    node_out = fuse(out_g, out_l, att_g, att_l)                                           # models.py:207-213
+    out = pool(cfg, node_out, batch, g.get('all_index'))                                  # models.py:215-224
+    if intermediates is not None:
+        intermediates.update(
+            edge_index_g=ei_g, dist_g=dist_g, edge_index_l=ei_l, dist_l=dist_l, idx_kj=idx_kj, idx_ji=idx_ji,
+            idx_jj_pair=idx_jj_pair, idx_ji_pair=idx_ji_pair, angle1=angle1, angle2=angle2, rbf_l=rbf_l, rbf_g=rbf_g,
+            sbf1=sbf1, sbf2=sbf2, x_layers=torch.stack(xs), node_out=node_out.view(-1), out=out,
+            pool_in=(node_out.view(-1) * g['all_index'] if 'all_index' in g else node_out.view(-1)))
+    return out
+
+
+def fuse(out_g, out_l, att_g, att_l):
+    """models.py:207-213: softmax over {global, local} of leaky_relu(att, 0.2), weighted sum, sum over layers."""
+    att = torch.cat((torch.cat(att_g, 0), torch.cat(att_l, 0)), -1)
+    att = torch.nn.functional.leaky_relu(att, 0.2)
+    w = torch.softmax(att, dim=-1)
+    out = torch.cat((torch.cat(out_g, 0), torch.cat(out_l, 0)), -1)
+    out = (out * w).sum(dim=-1)
+    return out.sum(dim=0).unsqueeze(-1)
+
+
+def pool(cfg, node_out, batch, all_index=None):
+    """models.py:215-224."""
+    nb = int(batch.max()) + 1
+    if cfg.dataset == 'QM9':
+        out = segment_add(node_out, batch, nb)
+    elif cfg.dataset == 'PDBbind':
+        out = segment_add(node_out * all_index.unsqueeze(-1), batch, nb)
+    elif cfg.dataset[:3].lower() == 'rna':
+        cnt = torch.bincount(batch, minlength=nb).to(node_out.dtype).clamp(min=1)
+        out = segment_add(node_out, batch, nb) / cnt.unsqueeze(-1)
+    else:
+        raise ValueError("Invalid dataset.")
+    return out.view(-1)
+
+
+def pamnet_s_forward(sd, cfg, x_raw, batch, pos, edge_index, dtype=None, intermediates=None):
+    """models.py:283-353 (PAMNet_s: QM9 only, pairs only, single `mlp_sbf`)."""
+    if cfg.dataset != 'QM9':
+        raise ValueError("Invalid dataset. The current PAMNet_s is only for QM9 experiments.")
+    dtype = dtype or sd['embeddings'].dtype
+    pos = pos.to(dtype)
+    x = torch.index_select(sd['embeddings'], 0, x_raw.long())
+    ei_l, dist_l = get_edge_info(edge_index, pos)
+    ei_g, dist_g = get_edge_info(radius_graph(pos, batch, cfg.cutoff_g), pos)
+    (_, _, _, _, _, idx_i_pair, idx_j1_pair, idx_j2_pair, idx_jj_pair, idx_ji_pair) = indices(ei_l, x.size(0))
+    angle = angle_between(pos[idx_j1_pair] - pos[idx_i_pair], pos[idx_j2_pair] - pos[idx_j1_pair])
+    rbf_l = bessel_rbf(dist_l, sd['rbf_l.freq'], cfg.cutoff_l)
+    rbf_g = bessel_rbf(dist_g, sd['rbf_g.freq'], cfg.cutoff_g)
+    sbf = spherical_basis(dist_l, angle, idx_jj_pair, cfg.cutoff_l)
+    e_rbf_l = mlp(sd, 'mlp_rbf_l', rbf_l, 1)
+    e_rbf_g = mlp(sd, 'mlp_rbf_g', rbf_g, 1)
+    e_sbf = mlp(sd, 'mlp_sbf', sbf, 1)
+    out_g, out_l, att_g, att_l, xs = [], [], [], [], []
+    for k in range(cfg.n_layer):
+        x, o, a = global_mp(sd, 'global_layer.%d' % k, x, e_rbf_g, ei_g, cfg.flow)
+        out_g.append(o), att_g.append(a), xs.append(x)
+        x, o, a = local_mp_s(sd, 'local_layer.%d' % k, x, e_rbf_l, e_sbf, idx_jj_pair, idx_ji_pair, ei_l)
+        out_l.append(o), att_l.append(a), xs.append(x)
+    node_out = fuse(out_g, out_l, att_g, att_l)
+    out = segment_add(node_out, batch, int(batch.max()) + 1).view(-1)
+    if intermediates is not None:
+        intermediates.update(x_layers=torch.stack(xs), node_out=node_out.view(-1), pool_in=node_out.view(-1), out=out)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Parameter construction with the reference's key names / shapes / init laws (models.py:21-60, layers/*.py __init__)
+# ----------------------------------------------------------------------------------------------------------------------
+def init_state_dict(cfg, seed=0, dtype=torch.float32, small=False):
+    """Random state_dict with the reference's keys and init distributions (not bitwise the reference's RNG stream;
+    goldens carry the reference's own tensors).  `small=True` selects PAMNet_s's key set."""
+    g = torch.Generator().manual_seed(seed)
+    d = cfg.dim
+    sd = {}
+
+    def uni(shape, bound):
+        return ((torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * bound).to(dtype)
+
+    def linear(key, fan_in, fan_out, bias=True):
+        bound = 1.0 / math.sqrt(fan_in)                  # torch.nn.Linear default: kaiming_uniform(a=sqrt(5))
+        sd[key + '.weight'] = uni((fan_out, fan_in), bound)
+        if bias:
+            sd[key + '.bias'] = uni((fan_out,), bound)
+
+    def mlp_keys(prefix, chans):
+        for k in range(1, len(chans)):
+            linear('%s.%d.0' % (prefix, k - 1), chans[k - 1], chans[k])
+
+    rna = cfg.dataset[:3].lower() == 'rna'
+    sd['embeddings'] = uni((3 if rna else 5, d), math.sqrt(3))                            # models.py:58-60
+    if not rna and not small:
+        linear('init_linear', 18, d, bias=False)
+    freq = (torch.arange(1, NUM_RBF + 1, dtype=torch.float64) * math.pi).to(dtype)        # basic.py:69-72
+    sd['rbf_g.freq'], sd['rbf_l.freq'] = freq.clone(), freq.clone()
+    mlp_keys('mlp_rbf_g', [NUM_RBF, d])
+    mlp_keys('mlp_rbf_l', [NUM_RBF, d])
+    if small:
+        mlp_keys('mlp_sbf', [NUM_SPHERICAL * NUM_RADIAL, d])
+    else:
+        mlp_keys('mlp_sbf1', [NUM_SPHERICAL * NUM_RADIAL, d])
+        mlp_keys('mlp_sbf2', [NUM_SPHERICAL * NUM_RADIAL, d])
+    for k in range(cfg.n_layer):
+        for kind in ('global_layer', 'local_layer'):
+            p = '%s.%d' % (kind, k)
+            mlp_keys(p + '.mlp_x1', [d, d])
+            mlp_keys(p + '.mlp_x2', [d, d])
+            for r in ('res1', 'res2', 'res3'):
+                mlp_keys('%s.%s.mlp' % (p, r), [d, d, d])
+            mlp_keys(p + '.mlp_out', [d, d, d, d])
+            linear(p + '.W_out', d, 1)
+            sd[p + '.W'] = uni((d, 1), math.sqrt(6.0 / (d + 1)))                          # glorot
+            if kind == 'global_layer':
+                mlp_keys(p + '.mlp_m', [3 * d, d])
+                linear(p + '.W_edge_attr', d, d, bias=False)
+            else:
+                mlp_keys(p + '.mlp_m_ji', [3 * d, d])
+                mlp_keys(p + ('.mlp_m_jj' if small else '.mlp_m_kj'), [3 * d, d])
+                mlp_keys(p + '.mlp_sbf', [d, d, d])
+                linear(p + '.lin_rbf', d, d, bias=False)
+                linear(p + '.lin_rbf_out', d, d, bias=False)
+    return sd
+
+
+def as_params(sd, requires_grad=True):
+    return {k: v.clone().requires_grad_(requires_grad) for k, v in sd.items()}

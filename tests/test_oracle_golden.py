@@ -1,0 +1,146 @@
+"""Pin the CPU oracle (oracle/pamnet_oracle.py) against golden vectors produced by the reference's own code
+(tests/golden/gen/gen_golden.py).  CPU only.
+
+Tolerances (max-normalised error, max|a-b|/max|b|):
+  fp64 oracle vs fp64 reference : 1e-9   (same algorithm, different summation order / basis evaluation route)
+  fp32 oracle vs fp32 reference : 1e-5   (the north-star tolerance; the reference's own fp32 noise floor vs its fp64
+                                          run is ~2e-6)
+Index lists: bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import maxnorm_err
+from oracle import pamnet_oracle as O
+
+
+def _cfg(g):
+    return O.Config(dataset=str(g['cfg_dataset']), dim=int(g['cfg_dim']), n_layer=int(g['cfg_n_layer']),
+                    cutoff_l=float(g['cfg_cutoff_l']), cutoff_g=float(g['cfg_cutoff_g']), flow=str(g['cfg_flow']))
+
+
+def _inputs(g):
+    t = lambda k: torch.from_numpy(g['in/' + k]) if ('in/' + k) in g.files else None
+    return t('x'), t('batch'), t('pos'), t('edge_index'), t('y')
+
+
+def test_star_indices_bit_exact(golden):
+    g = golden('star_indices')
+    res = O.indices(torch.from_numpy(g['edge_index']), 4)
+    names = ['idx_i', 'idx_j', 'idx_k', 'idx_kj', 'idx_ji', 'idx_i_pair', 'idx_j1_pair', 'idx_j2_pair',
+             'idx_jj_pair', 'idx_ji_pair']
+    for n, r in zip(names, res):
+        assert np.array_equal(r.numpy(), g[n]), n
+    # the worked example of SURVEY.md section 4
+    assert g['idx_kj'].tolist() == [4, 5, 0, 5, 0, 4]
+    assert g['idx_ji_pair'].tolist() == [0, 0, 0, 1, 2, 3, 4, 4, 4, 5, 5, 5]
+
+
+def test_basis_constants(golden):
+    g = golden('basis_tables')
+    k = O.basis_constants()
+    assert np.array_equal(k['zeros'], g['zeros'])                  # fp32-rounded zeros: bit-exact
+    # the reference evaluates the normaliser on float32 scalars under numpy 2 (utils/sbf.py:47) -> 1e-7-class noise
+    assert np.max(np.abs(k['norm'] / g['norm'] - 1)) < 3e-7
+
+
+def test_basis_tables(golden):
+    g = golden('basis_tables')
+    dist, ang = torch.from_numpy(g['dist']), torch.from_numpy(g['angle'])
+    idx = torch.arange(dist.numel())
+    c = float(g['cutoff'])
+    sbf = O.spherical_basis(dist, ang, idx, c)
+    # compare per l-block: magnitudes differ by orders between blocks
+    for l in range(7):
+        blk = slice(6 * l, 6 * l + 6)
+        assert maxnorm_err(sbf[:, blk], g['sbf64'][:, blk]) < 1e-6, l      # bounded by the 3e-7 normaliser noise
+    freq = torch.arange(1, 17, dtype=torch.float32) * np.pi        # the layer's fp32 parameter (basic.py:69-72)
+    assert maxnorm_err(O.bessel_rbf(dist, freq.double(), c), g['rbf64']) < 1e-12
+    assert maxnorm_err(O.bessel_rbf(dist.float(), freq, c), g['rbf32']) < 1e-6
+
+
+@pytest.mark.parametrize('name,small', [('qm9_d32_l2', False), ('pdbbind_d32_l2', False), ('qm9s_d32_l2', True),
+                                        ('qm9_d128_l6', False)])
+def test_random_init_forward(golden, name, small):
+    g = golden(name)
+    cfg = _cfg(g)
+    sd32 = O.init_state_dict(cfg, seed=int(g['seed']), small=small)
+    assert abs(sum(float(v.double().abs().sum()) for v in sd32.values()) - float(g['weights_checksum'])) < 1e-6
+    x, batch, pos, ei, y = _inputs(g)
+    fwd = O.pamnet_s_forward if small else O.pamnet_forward
+    for tag, dt, tol in (('64', torch.float64, 1e-6), ('32', torch.float32, 1e-5)):
+        sd = {k: v.to(dt) for k, v in sd32.items()}
+        inter = {}
+        xin = x.to(dt) if cfg.dataset == 'PDBbind' else x
+        out = fwd(sd, cfg, xin, batch, pos, ei, dtype=dt, intermediates=inter)
+        if cfg.dataset == 'PDBbind':
+            # complex - pocket - ligand cancels ~1000x (|out| ~1e-2 from summands totalling ~9): the reference's own
+            # fp32 run is 4e-5 (max-normalised) away from its fp64 run.  Parity is relative to the summed magnitude.
+            scale = max(float(np.abs(g['node_out64'][g['in/batch'] == b]).sum()) for b in range(len(g['out64'])))
+            assert float(np.max(np.abs(out.numpy() - g['out' + tag]))) / scale < tol, (tag, 'out')
+        else:
+            assert maxnorm_err(out, g['out' + tag]) < tol, (tag, 'out')
+        assert maxnorm_err(inter['pool_in'], g['node_out' + tag]) < tol, (tag, 'node_out')   # golden = pool input
+        if ('x_layers' + tag) in g.files:
+            assert maxnorm_err(inter['x_layers'], g['x_layers' + tag]) < tol, (tag, 'x_layers')
+        if tag == '32' and not small:
+            assert inter['edge_index_l'].shape[1] == int(g['num_edges_l'])
+            assert inter['idx_kj'].numel() == int(g['num_triplets'])
+            assert inter['idx_jj_pair'].numel() == int(g['num_pairs'])
+            if 'ref/idx_kj' in g.files:
+                for k in ('idx_kj', 'idx_ji', 'idx_jj_pair', 'idx_ji_pair'):
+                    assert np.array_equal(inter[k].numpy(), g['ref/' + k]), k
+
+
+@pytest.mark.parametrize('name', ['qm9_d32_l2', 'pdbbind_d32_l2'])
+def test_loss_gradient_fp64(golden, name):
+    """d L1-loss / d params through the oracle == through the reference (fp64)."""
+    g = golden(name)
+    cfg = _cfg(g)
+    sd = O.as_params({k: v.double() for k, v in O.init_state_dict(cfg, seed=int(g['seed'])).items()})
+    x, batch, pos, ei, y = _inputs(g)
+    xin = x.double() if cfg.dataset == 'PDBbind' else x
+    out = O.pamnet_forward(sd, cfg, xin, batch, pos, ei, dtype=torch.float64)
+    loss = torch.nn.functional.l1_loss(out, y.double())
+    loss.backward()
+    assert abs(loss.item() - float(g['loss64'])) < 1e-7 * max(1.0, abs(float(g['loss64'])))
+    gn = float(torch.sqrt(sum((p.grad ** 2).sum() for p in sd.values() if p.grad is not None)))
+    assert abs(gn / float(g['grad_norm64']) - 1) < 1e-6
+    for k in g.files:
+        if k.startswith('grad64/'):
+            assert maxnorm_err(sd[k[7:]].grad, g[k]) < 1e-6, k
+
+
+def test_rna_checkpoint_end_to_end(golden):
+    """Shipped RNA-Puzzles graphs + shipped checkpoint (the only real end-to-end golden in the reference tree)."""
+    g = golden('rna_native')
+    cfg = O.Config(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
+    sd32 = {k: torch.from_numpy(g['ckpt/' + k]) for k in g['ckpt_keys'].tolist()}
+    assert len(sd32) == 74 and sum(v.numel() for v in sd32.values()) == 11714
+    # survey probe values, fp32, one graph per batch
+    assert abs(float(g['g6/out32'][0]) - 2.912703) < 2e-6 and abs(float(g['g4/out32'][0]) - 2.248216) < 2e-6
+    for gid in (6, 4, 17):
+        x = torch.from_numpy(g['g%d/x' % gid])
+        batch = torch.zeros(x.size(0), dtype=torch.long)
+        for tag, dt, tol in (('64', torch.float64, 1e-7), ('32', torch.float32, 1e-5)):
+            sd = {k: v.to(dt) for k, v in sd32.items()}
+            inter = {}
+            out = O.pamnet_forward(sd, cfg, x.to(dt), batch, dtype=dt, intermediates=inter)
+            assert maxnorm_err(out, g['g%d/out%s' % (gid, tag)]) < tol, (gid, tag)
+            assert inter['edge_index_l'].shape[1] == int(g['g%d/num_edges_l' % gid])
+            assert inter['idx_kj'].numel() == int(g['g%d/num_triplets' % gid])
+            if gid == 6:
+                assert maxnorm_err(inter['x_layers'], g['g6/x_layers' + tag]) < tol
+                assert maxnorm_err(inter['node_out'], g['g6/node_out' + tag]) < tol
+    # two graphs in one batch == the same graphs alone (independent units)
+    x = torch.cat([torch.from_numpy(g['g4/x']), torch.from_numpy(g['g6/x'])])
+    batch = torch.cat([torch.zeros(g['g4/x'].shape[0], dtype=torch.long), torch.ones(g['g6/x'].shape[0], dtype=torch.long)])
+    out = O.pamnet_forward(sd32, cfg, x, batch)
+    assert maxnorm_err(out, g['batched_4_6_out32']) < 1e-5
+
+
+def test_unknown_dataset_raises():
+    cfg = O.Config(dataset='nope', dim=8, n_layer=1, cutoff_l=2.0, cutoff_g=5.0)
+    with pytest.raises(ValueError):
+        O.build_graph(cfg, torch.zeros(3), torch.zeros(3, dtype=torch.long), torch.zeros(3, 3), torch.zeros(2, 0, dtype=torch.long))
