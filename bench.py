@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""bench.py -- molecules/sec of one PAMNet training step (QM9 schema, dim=128, n_layer=6) on N MI355X GPUs.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch with inputs already resident in HBM: zero_grad -> forward
+(device graph construction, bases, 6x(global+local) message passing, fusion, pooling) -> L1 loss -> backward -> RCCL
+all-reduce of the flat gradient (N>1) -> clip -> Adam -> EMA, i.e. the reference loop main_qm9.py:103-118.
+Workload (config.workload): BASELINE.json configs[1] -- 128 molecules per GPU (weak scaling: global batch 128*N).
+One JSON line on rank 0: whole-job molecules/s + `roofline` (segment-sum = scatter-add kernel, HIP-event timed) +
+`cpu_baseline` (the oracle = port of the reference CPU forward+backward, bounded sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, 'physics-aware-multiplex-gnn_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+FP32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch-per-gpu', type=int, default=128)
+    ap.add_argument('--dim', type=int, default=128)
+    ap.add_argument('--n-layer', type=int, default=6)
+    ap.add_argument('--n-batches', type=int, default=4, help='distinct resident batches cycled through')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--stream-gb', type=float, default=2.0, help='size of the streamed scatter-add roofline probe')
+    return ap.parse_args()
+
+
+def event_time_ms(fn, reps):
+    """Average duration of fn() in ms with HIP events on torch's current stream (the stream the kernels launch on)."""
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    e.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def scatter_add_roofline(dev, g, d, stream_gb):
+    """Roofline of the scatter-add kernel (pamnet_segment_sum_f32).
+    (1) at the workload's own global-aggregation shape [E_g, d] -> [N, d]  (fits the 256 MB Infinity Cache);
+    (2) on a >= stream_gb streamed input with the same segment-length distribution (honest HBM number).
+    Algorithmic bytes per launch = 4*d*M (src) + 4*(R+1) (CSR ptr) + 4*d*R (out)  (SURVEY.md 8d)."""
+    from pamnet_amd import ops
+    res = {}
+    csr = g.glob
+    m, r = csr.m, csr.rows
+    src = torch.randn(m, d, device=dev)
+    out = torch.empty(r, d, device=dev)
+    fn = lambda: ops.segment_sum_raw(out, None, src, None, None, None, None, csr.ptr, r, d)
+    fn()
+    ms = event_time_ms(fn, 50)
+    by = 4.0 * d * m + 4.0 * (r + 1) + 4.0 * d * r
+    res['workload'] = dict(rows_in=m, rows_out=r, bytes=by, ms=ms, gbs=by / ms / 1e6)
+    # streamed probe: replicate the CSR until the source exceeds stream_gb
+    rep = max(1, int(stream_gb * 1e9 / (4.0 * d * m)) + 1)
+    lens = (csr.ptr[1:] - csr.ptr[:-1]).repeat(rep)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), lens.long().cumsum(0)]).to(torch.int32)
+    M, R = m * rep, r * rep
+    src = torch.randn(M, d, device=dev)
+    out = torch.empty(R, d, device=dev)
+    fn = lambda: ops.segment_sum_raw(out, None, src, None, None, None, None, ptr, R, d)
+    fn()
+    ms = event_time_ms(fn, 10)
+    by = 4.0 * d * M + 4.0 * (R + 1) + 4.0 * d * R
+    res['streamed'] = dict(rows_in=M, rows_out=R, bytes=by, ms=ms, gbs=by / ms / 1e6)
+    return res
+
+
+def cpu_baseline(args, seconds):
+    """The oracle (pure-torch CPU port of the reference forward, oracle/pamnet_oracle.py) timed on the host cores:
+    BASELINE.json configs[0]: B=32, d=128, L=6, forward+backward, bounded to ~`seconds` of CPU work."""
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.Config(dataset='QM9', dim=args.dim, n_layer=args.n_layer, cutoff_l=5.0, cutoff_g=5.0)
+    sd = O.as_params(O.init_state_dict(cfg, seed=0))
+    b = synth.qm9_batch(0, 0, 32)
+
+    def one(train):
+        out = O.pamnet_forward(sd, cfg, b.x, b.batch, b.pos, b.edge_index)
+        if train:
+            for p in sd.values():
+                p.grad = None
+            torch.nn.functional.l1_loss(out, b.y).backward()
+    one(True)
+    t0, n = time.time(), 0
+    while time.time() - t0 < seconds * 0.7 or n < 2:
+        one(True)
+        n += 1
+    train_mps = 32.0 * n / (time.time() - t0)
+    t0, n = time.time(), 0
+    with torch.no_grad():
+        while time.time() - t0 < seconds * 0.3 or n < 2:
+            one(False)
+            n += 1
+    fwd_mps = 32.0 * n / (time.time() - t0)
+    return dict(value=train_mps, unit='molecules/s', cores=cores, kind='port',
+                sample='oracle fwd+bwd, QM9-schema B=32 d=%d L=%d, ~%ds on %d threads' % (args.dim, args.n_layer, int(seconds), cores),
+                forward_only=fwd_mps)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl')
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    import models
+    from pamnet_amd import lib, synth
+    from pamnet_amd.train import Trainer
+    lib.load()
+
+    torch.manual_seed(1234)                        # identical random-init weights on every rank
+    cfg = models.Config(dataset='QM9', dim=args.dim, n_layer=args.n_layer, cutoff_l=5.0, cutoff_g=5.0)
+    model = models.PAMNet(cfg).to(dev)
+    trainer = Trainer(model, lr=1e-4, world_size=world)
+    B = args.batch_per_gpu
+    gB = B * world
+    # resident batches: global batch k = molecules [k*gB, (k+1)*gB); this rank's shard = its contiguous slice
+    batches = []
+    for k in range(args.n_batches):
+        lo = k * gB + rank * B
+        batches.append(synth.qm9_batch(0, lo, B).to(dev))
+    torch.cuda.synchronize()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(batches[i % len(batches)], global_graphs=gB)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.step(batches[i % len(batches)], global_graphs=gB)
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t[0])
+    ms_per_step = dt / args.steps * 1e3
+    value = gB * args.steps / dt
+
+    # forward-only rate (reported beside the training rate; not `value`)
+    with torch.no_grad():
+        for i in range(2):
+            model(batches[i % len(batches)])
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            model(batches[i % len(batches)])
+        sync()
+        fwd_ms = (time.perf_counter() - t0) / args.steps * 1e3
+
+    line = None
+    if rank == 0:
+        with torch.no_grad():
+            model(batches[0])
+        g = model._graph_cache
+        roof = scatter_add_roofline(dev, g, args.dim, args.stream_gb)
+        s = roof['streamed']
+        line = {
+            'metric': 'molecules/sec (QM9 dim=128 n_layer=6) at 1/2/4/8 GPU; scatter-add HBM GB/s vs peak',
+            'value': value, 'unit': 'molecules/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'QM9-schema synthetic radius-graph batches, PAMNet dim=%d n_layer=%d, %d molecules/GPU '
+                                   '(BASELINE configs[1]), full training step fwd+bwd+allreduce+clip+Adam+EMA'
+                                   % (args.dim, args.n_layer, B),
+                       'global_batch': gB, 'parallelism': 'dp%d (molecule-sharded, RCCL all-reduce of flat grad)' % world,
+                       'nodes_per_batch': int(g.n), 'global_edges': int(g.glob.m), 'local_edges': int(g.loc.m),
+                       'triplets': int(g.n_trip), 'pairs': int(g.n_pair)},
+            'forward_only_molecules_per_s': gB / (fwd_ms / 1e3), 'forward_ms': fwd_ms,
+            'roofline': {'bound': 'hbm', 'kernel': 'segment_sum_kernel (pamnet_segment_sum_f32, scatter-add)',
+                         'achieved': s['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': s['gbs'] / HBM_PEAK_GBS,
+                         'traffic': None, 'bytes_per_launch': s['bytes'], 'ms_per_launch': s['ms'],
+                         'shape': '[%d,%d]->[%d,%d] streamed (%.2f GB)' % (s['rows_in'], args.dim, s['rows_out'], args.dim, s['bytes'] / 1e9),
+                         'at_workload_shape': roof['workload']},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
+            line['speedup_vs_cpu'] = value / line['cpu_baseline']['value']
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

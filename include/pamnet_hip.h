@@ -1,0 +1,141 @@
+/*
+ * pamnet_hip.h -- C ABI of libpamnet_hip.so: PAMNet's multiplex message-passing hot path as gfx950 (MI355X) kernels.
+ *
+ * The reference (XieResearchGroup/Physics-aware-Multiplex-GNN) has no FFI of its own: its hot path reaches native code
+ * through four third-party wheels (torch_scatter, torch_sparse, torch_cluster, torch_geometric) and torch ATen.  Each
+ * entry point below replaces one of those native call sites; the reference file:line it stands in for is cited.
+ *
+ * Conventions (every function):
+ *   - arguments are raw DEVICE pointers, 64-bit sizes and a hipStream_t (passed as void*); no torch types;
+ *   - the caller owns every buffer; the library allocates nothing, keeps no global state, never synchronises;
+ *   - work is enqueued on `stream`; return value 0 = OK, >0 = hipError_t of the failed launch, <0 = argument error
+ *     (PAMNET_EINVAL: bad size / unsupported width; PAMNET_ENULL: required pointer is null);
+ *   - float tensors are fp32 row-major [rows, d]; index tensors are int32; CSR pointers have rows+1 entries;
+ *   - re-entrant and thread-safe by statelessness.  Segment reductions are sorted-CSR, atomics-free, deterministic.
+ */
+#ifndef PAMNET_HIP_H
+#define PAMNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAMNET_OK 0
+#define PAMNET_EINVAL (-1)
+#define PAMNET_ENULL (-2)
+
+typedef void* pamnet_stream_t; /* hipStream_t */
+
+/* Library / ABI version (bumped on any signature change). */
+int pamnet_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Segment reduction / gather  (torch_scatter.scatter(src, index, dim=0, dim_size, reduce='add'):
+ *   layers/local_message_passing.py:50,54,107,111;  PyG MessagePassing aggregate: layers/global_message_passing.py:38;
+ *   global_add_pool / global_mean_pool: models.py:216,219,221,351;  row gathers x[i], m[idx]: local...:46,49)
+ *
+ * out[r, :] = (init ? init[r, :] : 0) + sum_{q = ptr[r] .. ptr[r+1]-1}  A[ia(k), :] * (B ? B[ib(k), :] : 1),
+ *             k = perm ? perm[q] : q,   ia(k) = ia ? ia[k] : k,   ib(k) = ib ? ib[k] : k.
+ * With ia=ib=perm=B=init=NULL this is exactly scatter(src=A, index=sorted segment ids) -- the scatter-add roofline
+ * kernel.  The same entry serves every backward (gather^T) through a transposed CSR (`perm`).
+ * d must be a multiple of 4.  `out` may not alias A or B.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pamnet_segment_sum_f32(float* out, const float* init, const float* A, const int32_t* ia, const float* B,
+                           const int32_t* ib, const int32_t* perm, const int32_t* ptr, int64_t rows, int64_t d,
+                           pamnet_stream_t stream);
+
+/* out[k, :] = A[ia ? ia[k] : k, :] * (B ? B[ib ? ib[k] : k, :] : 1)   for k < m.   (x[i], x[j], m_neighbor[idx]) */
+int pamnet_gather_mul_f32(float* out, const float* A, const int32_t* ia, const float* B, const int32_t* ib,
+                          int64_t m, int64_t d, pamnet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Index plumbing for graph construction (torch_sparse.SparseTensor CSR build: models.py:71-73, 267-269)
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* out[0]=0, out[i+1]=sum_{j<=i} in[j]  (n inputs -> n+1 outputs).  `tmp` needs ceil(n/4096)+1 ints. */
+int pamnet_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* tmp, pamnet_stream_t stream);
+
+/* Stable counting sort of m keys in [0, rows): ptr[rows+1] (CSR) and perm[m] with keys[perm[q]] non-decreasing and
+ * perm ascending inside a row.  Scratch: `cursor` rows ints, `perm_tmp` m ints, `tmp` as for the scan.  Deterministic. */
+int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t rows, int32_t* ptr, int32_t* perm,
+                             int32_t* cursor, int32_t* perm_tmp, int32_t* tmp, pamnet_stream_t stream);
+
+/* row_of[q] = r for q in [ptr[r], ptr[r+1])  (repeat_interleave of row ids, models.py:76-77, 88-89) */
+int pamnet_expand_rows_i32(const int32_t* ptr, int64_t rows, int32_t* row_of, pamnet_stream_t stream);
+
+/* CSR row filter: keep entries with nbr >= 0 and dist <= cut  (the cutoff masks, models.py:131-134, 147-156).
+ * count -> (caller scans) -> fill. */
+int pamnet_csr_filter_count_i32(const int32_t* ptr_in, const int32_t* nbr, const float* dist, int64_t rows, float cut,
+                                int32_t* count, pamnet_stream_t stream);
+int pamnet_csr_filter_fill_i32(const int32_t* ptr_in, const int32_t* nbr, const float* dist, int64_t rows, float cut,
+                               const int32_t* ptr_out, int32_t* nbr_out, float* dist_out, pamnet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Neighbour search (torch_cluster.radius / knn: models.py:110,128,143,301), self loops removed (models.py:63).
+ * `gptr[b..b+1]` = node range of graph b (batch sorted).  Two-pass: count -> (caller scans) -> fill.
+ * radius: neighbours j != i of the same graph with ||pos_i - pos_j|| <= r, ascending j.  Symmetric by construction.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pamnet_radius_count_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n, float r,
+                            int32_t* count, pamnet_stream_t stream);
+int pamnet_radius_fill_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n, float r,
+                           const int32_t* ptr, int32_t* nbr, float* dist, pamnet_stream_t stream);
+
+/* knn: for every query node its k nearest nodes of the same graph (itself included, as torch_cluster.knn does),
+ * ordered by (distance, index); then the self entry is dropped and entries with dist > cutoff are masked out:
+ * nbr[i*k + s] = neighbour index or -1, dist[i*k + s] = distance.  (models.py:143-150) */
+int pamnet_knn_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n, int32_t k,
+                   float cutoff, int32_t* nbr, float* dist, pamnet_stream_t stream);
+
+/* Edge distances  dist[e] = ||pos[a[e]] - pos[b[e]]||   (PAMNet.get_edge_info, models.py:62-66) */
+int pamnet_edge_dist_f32(const float* pos, const int32_t* a, const int32_t* b, int64_t m, float* dist,
+                         pamnet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Triplet / pair enumeration + angles  (PAMNet.indices, models.py:68-98, 263-281; angles models.py:165-177)
+ * Local edges e = (src[e] -> dst[e]) are stored CSR by dst (lptr[n+1]).  For every edge e=(j->i) the combined row list
+ * [tp_ptr[e], tp_ptr[e+1]) holds
+ *   its triplets: every e'=(k->j), k != i       kind 0, tp_idx = e' (= idx_kj), tp_edge = e (= idx_ji), angle2
+ *   its pairs:    every e'=(j'->i) incl. e'=e    kind 1, tp_idx = e' (= idx_jj_pair), tp_edge = e (= idx_ji_pair), angle1
+ * i.e. the reference's cat(idx_kj, idx_jj_pair) / cat(idx_ji, idx_ji_pair) (local_message_passing.py:38-39) regrouped
+ * by target edge.  with_triplets = 0 enumerates pairs only (PAMNet_s).  count -> (caller scans tpcount) -> fill.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pamnet_triplet_count_i32(const int32_t* lptr, const int32_t* src, const int32_t* dst, int64_t n_edges,
+                             int32_t with_triplets, int32_t* tcount, int32_t* tpcount, pamnet_stream_t stream);
+int pamnet_triplet_fill_f32(const float* pos, const int32_t* lptr, const int32_t* src, const int32_t* dst,
+                            int64_t n_edges, int32_t with_triplets, const int32_t* tp_ptr, int32_t* tp_idx,
+                            int32_t* tp_edge, float* tp_angle, int32_t* tp_kind, pamnet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Basis functions  (layers/basic.py:36-51 Envelope, :59-76 BesselBasisLayer, :79-116 SphericalBasisLayer; utils/sbf.py)
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* rbf[e, n] = env(d_e/c) * sin(freq[n] * d_e/c),  n < 16, envelope exponent p = 5 */
+int pamnet_rbf_fwd_f32(const float* dist, const float* freq, float cutoff, int64_t m, float* rbf,
+                       pamnet_stream_t stream);
+/* dfreq[n] = sum_e grad[e, n] * env(x_e) * x_e * cos(freq[n] x_e)   (freq is trainable: basic.py:65-72).
+ * `partial` needs 16*256 floats of scratch. */
+int pamnet_rbf_bwd_f32(const float* dist, const float* freq, float cutoff, int64_t m, const float* grad,
+                       float* dfreq, float* partial, pamnet_stream_t stream);
+/* radial table rad[e, l*6+n] = env(x) * N_ln * j_l(z_ln x), x = d_e/c, evaluated in fp64 and rounded once to fp32 */
+int pamnet_sbf_radial_f32(const float* dist, float cutoff, int64_t m, float* rad, pamnet_stream_t stream);
+/* sbf[t, l*6+n] = rad[idx[t], l*6+n] * Y_l0(angle[t]) */
+int pamnet_sbf_combine_f32(const float* rad, const int32_t* idx, const float* angle, int64_t m, float* sbf,
+                           pamnet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Attention fusion + per-graph pooling  (models.py:206-224)
+ * outs/atts: [2L, n] rows ordered (global_0, local_0, global_1, local_1, ...).
+ *   node_out[n] = sign[n] * sum_l sum_c outs[l,c,n] * softmax_c(leaky_relu(atts[l,c,n], 0.2))
+ *   graph_out[b] = (mean ? 1/|b| : 1) * sum_{n in b} node_out[n];  sign may be NULL (=1).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pamnet_fuse_pool_fwd_f32(const float* outs, const float* atts, int64_t n_layer, int64_t n, const float* sign,
+                             const int32_t* gptr, int64_t n_graphs, int32_t mean, float* node_out, float* graph_out,
+                             pamnet_stream_t stream);
+int pamnet_fuse_pool_bwd_f32(const float* outs, const float* atts, int64_t n_layer, int64_t n, const float* sign,
+                             const int32_t* node_graph, const int32_t* gptr, int32_t mean, const float* grad_graph,
+                             float* grad_outs, float* grad_atts, pamnet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAMNET_HIP_H */

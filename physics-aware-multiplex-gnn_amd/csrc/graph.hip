@@ -1,0 +1,447 @@
+// Device-side graph construction for PAMNet.forward (models.py:62-98, 104-157):
+//   * exclusive scan + stable counting sort into CSR (stands in for torch_sparse.SparseTensor, models.py:71-73)
+//   * batched fixed-radius and k-NN neighbour search (stands in for torch_cluster.radius / knn, models.py:110,128,143)
+//   * CSR row filter by distance (the `dist <= cutoff` masks, models.py:131-134, 147-156)
+//   * triplet (k->j->i) / pair (j,j'->i) enumeration with their angles (models.py:68-98, 165-177)
+// Integer work: bit-exact against the oracle.  Everything is two-pass (count -> caller scans -> fill), atomics are
+// used only for histogram counts and slot claiming whose result is re-sorted, so outputs are deterministic.
+#include "common.h"
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_ITEMS;   // 4096
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+
+// inclusive scan of one 4096-element chunk; out[i+1] = chunk-local inclusive sum, sums[b] = chunk total
+__global__ __launch_bounds__(SCAN_THREADS) void scan_chunk_kernel(const int32_t* __restrict__ in,
+                                                                  int32_t* __restrict__ out, int64_t n,
+                                                                  int32_t* __restrict__ sums) {
+    __shared__ int wave_tot[SCAN_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)tid * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int run = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t g = base + i;
+        run += (g < n) ? in[g] : 0;
+        v[i] = run;
+    }
+    const int incl = wave_incl_scan(run, lane);
+    if (lane == 63) wave_tot[w] = incl;
+    __syncthreads();
+    int off = incl - run;
+    for (int k = 0; k < w; ++k) off += wave_tot[k];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t g = base + i;
+        if (g < n) out[g + 1] = v[i] + off;
+    }
+    if (tid == SCAN_THREADS - 1) sums[blockIdx.x] = off + run;
+}
+
+// single block: exclusive scan of the chunk totals in place
+__global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(int32_t* __restrict__ sums, int64_t nb) {
+    __shared__ int wave_tot[SCAN_THREADS / 64];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += SCAN_THREADS) {
+        const int64_t g = base + tid;
+        const int x = (g < nb) ? sums[g] : 0;
+        const int incl = wave_incl_scan(x, lane);
+        if (lane == 63) wave_tot[w] = incl;
+        __syncthreads();
+        int off = carry_s;
+        for (int k = 0; k < w; ++k) off += wave_tot[k];
+        if (g < nb) sums[g] = off + incl - x;
+        __syncthreads();
+        if (tid == SCAN_THREADS - 1) carry_s = off + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_add_kernel(int32_t* __restrict__ out, int64_t n,
+                                                       const int32_t* __restrict__ sums) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) out[0] = 0;
+    if (g < n) out[g + 1] += sums[g / SCAN_CHUNK];
+}
+
+__global__ __launch_bounds__(256) void hist_kernel(const int32_t* __restrict__ keys, int64_t m,
+                                                   int32_t* __restrict__ count) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < m) atomicAdd(&count[keys[k]], 1);
+}
+
+__global__ __launch_bounds__(256) void copy_i32_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst,
+                                                       int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) dst[k] = src[k];
+}
+
+__global__ __launch_bounds__(256) void claim_kernel(const int32_t* __restrict__ keys, int64_t m,
+                                                    int32_t* __restrict__ cursor, int32_t* __restrict__ perm_tmp) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < m) perm_tmp[atomicAdd(&cursor[keys[k]], 1)] = (int32_t)k;
+}
+
+// one wave per row: rank each claimed entry among its row (entries are distinct) -> ascending perm
+__global__ __launch_bounds__(256) void sort_rows_kernel(const int32_t* __restrict__ ptr,
+                                                        const int32_t* __restrict__ perm_tmp,
+                                                        int32_t* __restrict__ perm, int64_t rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= rows) return;
+    const int beg = ptr[r], end = ptr[r + 1], len = end - beg;
+    if (len <= 64) {
+        const int v = (lane < len) ? perm_tmp[beg + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int t = 0; t < len; ++t) rank += (__shfl(v, t, 64) < v) ? 1 : 0;
+        if (lane < len) perm[beg + rank] = v;
+    } else {
+        for (int a = lane; a < len; a += 64) {
+            const int v = perm_tmp[beg + a];
+            int rank = 0;
+            for (int t = 0; t < len; ++t) rank += (perm_tmp[beg + t] < v) ? 1 : 0;
+            perm[beg + rank] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ float dist3(const float* __restrict__ pos, int64_t a, int64_t b) {
+    const float dx = pos[3 * a + 0] - pos[3 * b + 0];
+    const float dy = pos[3 * a + 1] - pos[3 * b + 1];
+    const float dz = pos[3 * a + 2] - pos[3 * b + 2];
+    // same association as (pos_i - pos_j).pow(2).sum(-1).sqrt() (models.py:65); no fma contraction
+    const float s = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    return __fsqrt_rn(s);
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void radius_kernel(const float* __restrict__ pos,
+                                                     const int32_t* __restrict__ node_graph,
+                                                     const int32_t* __restrict__ gptr, int64_t n, float r,
+                                                     int32_t* __restrict__ count, const int32_t* __restrict__ ptr,
+                                                     int32_t* __restrict__ nbr, float* __restrict__ dist) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int g = node_graph[i];
+    const int beg = gptr[g], end = gptr[g + 1];
+    int c = 0;
+    int64_t w = FILL ? ptr[i] : 0;
+    for (int j = beg; j < end; ++j) {
+        if (j == i) continue;
+        const float d = dist3(pos, i, j);
+        if (d <= r) {
+            if (FILL) { nbr[w] = j; dist[w] = d; ++w; }
+            ++c;
+        }
+    }
+    if (!FILL) count[i] = c;
+}
+
+__device__ __forceinline__ bool pair_less(float da, int ja, float db, int jb) {
+    return (da < db) || (da == db && ja < jb);
+}
+
+// one wave per query: lanes 0..K-1 hold the running K best (squared distance, index) in ascending order
+__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pos, const int32_t* __restrict__ node_graph,
+                                                  const int32_t* __restrict__ gptr, int64_t n, int K, float cutoff,
+                                                  int32_t* __restrict__ nbr, float* __restrict__ dist) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= n) return;
+    const int g = node_graph[i];
+    const int beg = gptr[g], end = gptr[g + 1];
+    const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+    float bd = INFINITY;
+    int bj = 0x7fffffff;
+    float kd = INFINITY;            // current K-th best
+    int kj = 0x7fffffff;
+    for (int base = beg; base < end; base += 64) {
+        const int j = base + lane;
+        const bool valid = j < end;
+        float d = INFINITY;
+        if (valid) {
+            const float dx = xi - pos[3 * (int64_t)j], dy = yi - pos[3 * (int64_t)j + 1], dz = zi - pos[3 * (int64_t)j + 2];
+            d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        }
+        unsigned long long mask = __ballot(valid && pair_less(d, j, kd, kj));
+        while (mask) {
+            const int src = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const float cd = __shfl(d, src, 64);
+            const int cj = __shfl(j, src, 64);
+            if (!pair_less(cd, cj, kd, kj)) continue;                        // wave-uniform
+            const bool lt = (lane < K) && pair_less(bd, bj, cd, cj);
+            const int p = __popcll(__ballot(lt));
+            const float ud = __shfl_up(bd, 1, 64);
+            const int uj = __shfl_up(bj, 1, 64);
+            if (lane > p) { bd = ud; bj = uj; }
+            else if (lane == p) { bd = cd; bj = cj; }
+            kd = __shfl(bd, K - 1, 64);
+            kj = __shfl(bj, K - 1, 64);
+        }
+    }
+    if (lane < K) {
+        const float d = __fsqrt_rn(bd);
+        const bool keep = (bj != 0x7fffffff) && (bj != (int)i) && (d <= cutoff);
+        nbr[i * K + lane] = keep ? bj : -1;
+        dist[i * K + lane] = d;
+    }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void csr_filter_kernel(const int32_t* __restrict__ ptr_in,
+                                                         const int32_t* __restrict__ nbr,
+                                                         const float* __restrict__ dist, int64_t rows, float cut,
+                                                         int32_t* __restrict__ count,
+                                                         const int32_t* __restrict__ ptr_out,
+                                                         int32_t* __restrict__ nbr_out, float* __restrict__ dist_out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    int c = 0;
+    int64_t w = FILL ? ptr_out[r] : 0;
+    for (int q = ptr_in[r]; q < ptr_in[r + 1]; ++q) {
+        const int j = nbr[q];
+        const float d = dist[q];
+        if (j >= 0 && d <= cut) {
+            if (FILL) { nbr_out[w] = j; dist_out[w] = d; ++w; }
+            ++c;
+        }
+    }
+    if (!FILL) count[r] = c;
+}
+
+__global__ __launch_bounds__(256) void edge_dist_kernel(const float* __restrict__ pos, const int32_t* __restrict__ a,
+                                                        const int32_t* __restrict__ b, int64_t m,
+                                                        float* __restrict__ dist) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < m) dist[e] = dist3(pos, a[e], b[e]);
+}
+
+__global__ __launch_bounds__(256) void expand_rows_kernel(const int32_t* __restrict__ ptr, int64_t rows,
+                                                          int32_t* __restrict__ row_of) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    for (int q = ptr[r]; q < ptr[r + 1]; ++q) row_of[q] = (int32_t)r;
+}
+
+__global__ __launch_bounds__(256) void triplet_count_kernel(const int32_t* __restrict__ lptr,
+                                                            const int32_t* __restrict__ src,
+                                                            const int32_t* __restrict__ dst, int64_t n_edges,
+                                                            int with_triplets, int32_t* __restrict__ tcount,
+                                                            int32_t* __restrict__ tpcount) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    const int j = src[e], i = dst[e];
+    int t = 0;
+    if (with_triplets)
+        for (int q = lptr[j]; q < lptr[j + 1]; ++q) t += (src[q] != i) ? 1 : 0;  // edges k->j, k != i
+    tcount[e] = t;
+    tpcount[e] = t + (lptr[i + 1] - lptr[i]);                                     // + edges j'->i, incl. e itself
+}
+
+__device__ __forceinline__ float angle3(float ax, float ay, float az, float bx, float by, float bz) {
+    // atan2(|a x b|, a.b)  (models.py:165-168)
+    const float dot = ax * bx + ay * by + az * bz;
+    const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+    return atan2f(sqrtf(cx * cx + cy * cy + cz * cz), dot);
+}
+
+// rows of edge e: [tp_ptr[e], tp_ptr[e+1]) = its triplets (kind 0) followed by its pairs (kind 1)
+__global__ __launch_bounds__(256) void triplet_fill_kernel(const float* __restrict__ pos,
+                                                           const int32_t* __restrict__ lptr,
+                                                           const int32_t* __restrict__ src,
+                                                           const int32_t* __restrict__ dst, int64_t n_edges,
+                                                           int with_triplets, const int32_t* __restrict__ tp_ptr,
+                                                           int32_t* __restrict__ tp_idx, int32_t* __restrict__ tp_edge,
+                                                           float* __restrict__ tp_angle, int32_t* __restrict__ tp_kind) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    const int j = src[e], i = dst[e];
+    const float pix = pos[3 * (int64_t)i], piy = pos[3 * (int64_t)i + 1], piz = pos[3 * (int64_t)i + 2];
+    const float pjx = pos[3 * (int64_t)j], pjy = pos[3 * (int64_t)j + 1], pjz = pos[3 * (int64_t)j + 2];
+    int64_t w = tp_ptr[e];
+    if (with_triplets) {
+        // triplets: pos_ji = p_j - p_i, pos_kj = p_k - p_j                        (models.py:165)
+        for (int q = lptr[j]; q < lptr[j + 1]; ++q) {
+            const int k = src[q];
+            if (k == i) continue;
+            const float pkx = pos[3 * (int64_t)k], pky = pos[3 * (int64_t)k + 1], pkz = pos[3 * (int64_t)k + 2];
+            tp_idx[w] = q;
+            tp_edge[w] = (int32_t)e;
+            tp_kind[w] = 0;
+            tp_angle[w] = angle3(pjx - pix, pjy - piy, pjz - piz, pkx - pjx, pky - pjy, pkz - pjz);
+            ++w;
+        }
+    }
+    // pairs: idx_i_pair = j, idx_j1_pair = i, idx_j2_pair = j'  ->  a = p_i - p_j, b = p_j' - p_i  (models.py:171-177)
+    for (int q = lptr[i]; q < lptr[i + 1]; ++q) {
+        const int j2 = src[q];
+        const float px = pos[3 * (int64_t)j2], py = pos[3 * (int64_t)j2 + 1], pz = pos[3 * (int64_t)j2 + 2];
+        tp_idx[w] = q;
+        tp_edge[w] = (int32_t)e;
+        tp_kind[w] = 1;
+        tp_angle[w] = angle3(pix - pjx, piy - pjy, piz - pjz, px - pix, py - piy, pz - piz);
+        ++w;
+    }
+}
+
+inline unsigned blocks_for(int64_t n, int per = 256) { return (unsigned)(n > 0 ? ceil_div(n, per) : 1); }
+
+}  // namespace
+
+extern "C" int pamnet_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* tmp,
+                                         pamnet_stream_t stream) {
+    if (n < 0) return PAMNET_EINVAL;
+    if (!out || (n > 0 && (!in || !tmp))) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(int32_t), st);
+        return (int)e;
+    }
+    const int64_t nb = ceil_div(n, SCAN_CHUNK);
+    hipLaunchKernelGGL(scan_chunk_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, out, n, tmp);
+    PAMNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, tmp, nb);
+    PAMNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_add_kernel, dim3(blocks_for(n)), dim3(256), 0, st, out, n, tmp);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t rows, int32_t* ptr, int32_t* perm,
+                                        int32_t* cursor, int32_t* perm_tmp, int32_t* tmp, pamnet_stream_t stream) {
+    if (m < 0 || rows <= 0) return PAMNET_EINVAL;
+    if (!ptr || !cursor || !tmp || (m > 0 && (!keys || !perm || !perm_tmp))) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemsetAsync(cursor, 0, sizeof(int32_t) * rows, st);
+    if (e != hipSuccess) return (int)e;
+    if (m > 0) {
+        hipLaunchKernelGGL(hist_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, cursor);
+        PAMNET_LAUNCH_CHECK();
+    }
+    int rc = pamnet_exclusive_scan_i32(cursor, ptr, rows, tmp, stream);
+    if (rc) return rc;
+    if (m == 0) return PAMNET_OK;
+    hipLaunchKernelGGL(copy_i32_kernel, dim3(blocks_for(rows)), dim3(256), 0, st, ptr, cursor, rows);
+    PAMNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(claim_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, cursor, perm_tmp);
+    PAMNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sort_rows_kernel, dim3(blocks_for(rows, 4)), dim3(256), 0, st, ptr, perm_tmp, perm, rows);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_expand_rows_i32(const int32_t* ptr, int64_t rows, int32_t* row_of, pamnet_stream_t stream) {
+    if (rows < 0) return PAMNET_EINVAL;
+    if (rows == 0) return PAMNET_OK;
+    if (!ptr || !row_of) return PAMNET_ENULL;
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(blocks_for(rows)), dim3(256), 0, as_stream(stream), ptr, rows, row_of);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_radius_count_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n,
+                                       float r, int32_t* count, pamnet_stream_t stream) {
+    if (n < 0) return PAMNET_EINVAL;
+    if (n == 0) return PAMNET_OK;
+    if (!pos || !node_graph || !gptr || !count) return PAMNET_ENULL;
+    hipLaunchKernelGGL((radius_kernel<false>), dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), pos, node_graph,
+                       gptr, n, r, count, (const int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_radius_fill_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n,
+                                      float r, const int32_t* ptr, int32_t* nbr, float* dist,
+                                      pamnet_stream_t stream) {
+    if (n < 0) return PAMNET_EINVAL;
+    if (n == 0) return PAMNET_OK;
+    if (!pos || !node_graph || !gptr || !ptr || !nbr || !dist) return PAMNET_ENULL;
+    hipLaunchKernelGGL((radius_kernel<true>), dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), pos, node_graph,
+                       gptr, n, r, (int32_t*)nullptr, ptr, nbr, dist);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_knn_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n, int32_t k,
+                              float cutoff, int32_t* nbr, float* dist, pamnet_stream_t stream) {
+    if (n < 0 || k < 1 || k > 64) return PAMNET_EINVAL;
+    if (n == 0) return PAMNET_OK;
+    if (!pos || !node_graph || !gptr || !nbr || !dist) return PAMNET_ENULL;
+    hipLaunchKernelGGL(knn_kernel, dim3(blocks_for(n, 4)), dim3(256), 0, as_stream(stream), pos, node_graph, gptr, n,
+                       (int)k, cutoff, nbr, dist);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_csr_filter_count_i32(const int32_t* ptr_in, const int32_t* nbr, const float* dist, int64_t rows,
+                                           float cut, int32_t* count, pamnet_stream_t stream) {
+    if (rows < 0) return PAMNET_EINVAL;
+    if (rows == 0) return PAMNET_OK;
+    if (!ptr_in || !nbr || !dist || !count) return PAMNET_ENULL;
+    hipLaunchKernelGGL((csr_filter_kernel<false>), dim3(blocks_for(rows)), dim3(256), 0, as_stream(stream), ptr_in, nbr,
+                       dist, rows, cut, count, (const int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_csr_filter_fill_i32(const int32_t* ptr_in, const int32_t* nbr, const float* dist, int64_t rows,
+                                          float cut, const int32_t* ptr_out, int32_t* nbr_out, float* dist_out,
+                                          pamnet_stream_t stream) {
+    if (rows < 0) return PAMNET_EINVAL;
+    if (rows == 0) return PAMNET_OK;
+    if (!ptr_in || !nbr || !dist || !ptr_out || !nbr_out || !dist_out) return PAMNET_ENULL;
+    hipLaunchKernelGGL((csr_filter_kernel<true>), dim3(blocks_for(rows)), dim3(256), 0, as_stream(stream), ptr_in, nbr,
+                       dist, rows, cut, (int32_t*)nullptr, ptr_out, nbr_out, dist_out);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_edge_dist_f32(const float* pos, const int32_t* a, const int32_t* b, int64_t m, float* dist,
+                                    pamnet_stream_t stream) {
+    if (m < 0) return PAMNET_EINVAL;
+    if (m == 0) return PAMNET_OK;
+    if (!pos || !a || !b || !dist) return PAMNET_ENULL;
+    hipLaunchKernelGGL(edge_dist_kernel, dim3(blocks_for(m)), dim3(256), 0, as_stream(stream), pos, a, b, m, dist);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_triplet_count_i32(const int32_t* lptr, const int32_t* src, const int32_t* dst, int64_t n_edges,
+                                        int32_t with_triplets, int32_t* tcount, int32_t* tpcount,
+                                        pamnet_stream_t stream) {
+    if (n_edges < 0) return PAMNET_EINVAL;
+    if (n_edges == 0) return PAMNET_OK;
+    if (!lptr || !src || !dst || !tcount || !tpcount) return PAMNET_ENULL;
+    hipLaunchKernelGGL(triplet_count_kernel, dim3(blocks_for(n_edges)), dim3(256), 0, as_stream(stream), lptr, src, dst,
+                       n_edges, (int)with_triplets, tcount, tpcount);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_triplet_fill_f32(const float* pos, const int32_t* lptr, const int32_t* src, const int32_t* dst,
+                                       int64_t n_edges, int32_t with_triplets, const int32_t* tp_ptr, int32_t* tp_idx,
+                                       int32_t* tp_edge, float* tp_angle, int32_t* tp_kind, pamnet_stream_t stream) {
+    if (n_edges < 0) return PAMNET_EINVAL;
+    if (n_edges == 0) return PAMNET_OK;
+    if (!pos || !lptr || !src || !dst || !tp_ptr || !tp_idx || !tp_edge || !tp_angle || !tp_kind) return PAMNET_ENULL;
+    hipLaunchKernelGGL(triplet_fill_kernel, dim3(blocks_for(n_edges)), dim3(256), 0, as_stream(stream), pos, lptr, src,
+                       dst, n_edges, (int)with_triplets, tp_ptr, tp_idx, tp_edge, tp_angle, tp_kind);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}

@@ -1,0 +1,191 @@
+// Sorted-CSR segment reduction and row gather: the scatter-add / gather of PAMNet's message passing.
+//
+// Replaces torch_scatter.scatter(..., reduce='add') (layers/local_message_passing.py:50,54,107,111), PyG's
+// MessagePassing add-aggregation (layers/global_message_passing.py:38) and the x[i] / m[idx] row gathers.
+//
+// Design (HBM-bound; MI355X_MICROARCH: 16 B/lane coalesced loads, many loads in flight, no atomics):
+//   * a row of d floats is covered by LPR = d/4 lanes holding one float4 each, so a wave64 owns 64/LPR output rows
+//     (d=128: two rows per wave, every global access is a full 512 B row segment = 4 cache lines, 16 B per lane);
+//   * each lane group walks its CSR segment with a 4-deep unrolled software pipeline (4 independent 16 B loads in
+//     flight per lane, 8 waves/SIMD at this register footprint) and accumulates in registers -> one store per row;
+//   * deterministic: summation order = CSR order, run-to-run bitwise identical.
+#include "common.h"
+
+namespace {
+
+template <bool HAS_IA, bool HAS_B, bool HAS_IB, bool HAS_PERM>
+__device__ __forceinline__ float4 load_term(const float4* __restrict__ A, const int32_t* __restrict__ ia,
+                                            const float4* __restrict__ B, const int32_t* __restrict__ ib,
+                                            const int32_t* __restrict__ perm, int64_t q, int64_t d4, int c) {
+    int64_t k = HAS_PERM ? (int64_t)perm[q] : q;
+    int64_t ra = HAS_IA ? (int64_t)ia[k] : k;
+    float4 a = A[ra * d4 + c];
+    if (HAS_B) {
+        int64_t rb = HAS_IB ? (int64_t)ib[k] : k;
+        float4 b = B[rb * d4 + c];
+        a.x *= b.x; a.y *= b.y; a.z *= b.z; a.w *= b.w;
+    }
+    return a;
+}
+
+__device__ __forceinline__ void acc4(float4& s, const float4& v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+
+// LPR lanes per row (power of two <= 64).  blockDim.x = 256.
+template <int LPR, bool HAS_IA, bool HAS_B, bool HAS_IB, bool HAS_PERM>
+__global__ __launch_bounds__(256) void segment_sum_kernel(float4* __restrict__ out, const float4* __restrict__ init,
+                                                          const float4* __restrict__ A, const int32_t* __restrict__ ia,
+                                                          const float4* __restrict__ B, const int32_t* __restrict__ ib,
+                                                          const int32_t* __restrict__ perm,
+                                                          const int32_t* __restrict__ ptr, int64_t rows, int64_t d4) {
+    constexpr int ROWS_PER_BLOCK = 256 / LPR;
+    const int c = threadIdx.x % LPR;                       // float4 column owned by this lane
+    const int sub = threadIdx.x / LPR;                     // row slot inside the block
+    for (int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + sub; r < rows; r += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
+        const int64_t beg = ptr[r], end = ptr[r + 1];
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+        if (init) s0 = init[r * d4 + c];
+        int64_t q = beg;
+        for (; q + 4 <= end; q += 4) {                     // 4 independent 16 B loads (x2 with B) in flight per lane
+            float4 v0 = load_term<HAS_IA, HAS_B, HAS_IB, HAS_PERM>(A, ia, B, ib, perm, q + 0, d4, c);
+            float4 v1 = load_term<HAS_IA, HAS_B, HAS_IB, HAS_PERM>(A, ia, B, ib, perm, q + 1, d4, c);
+            float4 v2 = load_term<HAS_IA, HAS_B, HAS_IB, HAS_PERM>(A, ia, B, ib, perm, q + 2, d4, c);
+            float4 v3 = load_term<HAS_IA, HAS_B, HAS_IB, HAS_PERM>(A, ia, B, ib, perm, q + 3, d4, c);
+            acc4(s0, v0); acc4(s1, v1); acc4(s2, v2); acc4(s3, v3);
+        }
+        for (; q < end; ++q) acc4(s0, load_term<HAS_IA, HAS_B, HAS_IB, HAS_PERM>(A, ia, B, ib, perm, q, d4, c));
+        acc4(s0, s1); acc4(s2, s3); acc4(s0, s2);
+        out[r * d4 + c] = s0;
+    }
+}
+
+// Fallback for d/4 not a power of two (e.g. d = 12, 20, 40): one wave per row, lanes stride over float4 columns;
+// optional operands resolved at run time (rare widths, not a tuned path).
+__global__ __launch_bounds__(256) void segment_sum_generic_kernel(float4* __restrict__ out,
+                                                                  const float4* __restrict__ init,
+                                                                  const float4* __restrict__ A,
+                                                                  const int32_t* __restrict__ ia,
+                                                                  const float4* __restrict__ B,
+                                                                  const int32_t* __restrict__ ib,
+                                                                  const int32_t* __restrict__ perm,
+                                                                  const int32_t* __restrict__ ptr, int64_t rows,
+                                                                  int64_t d4) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < rows; r += n_waves) {
+        const int64_t beg = ptr[r], end = ptr[r + 1];
+        for (int c = lane; c < d4; c += 64) {
+            float4 s = init ? init[r * d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int64_t q = beg; q < end; ++q) {
+                const int64_t k = perm ? (int64_t)perm[q] : q;
+                float4 a = A[(ia ? (int64_t)ia[k] : k) * d4 + c];
+                if (B) {
+                    const float4 b = B[(ib ? (int64_t)ib[k] : k) * d4 + c];
+                    a.x *= b.x; a.y *= b.y; a.z *= b.z; a.w *= b.w;
+                }
+                acc4(s, a);
+            }
+            out[r * d4 + c] = s;
+        }
+    }
+}
+
+template <bool HAS_IA, bool HAS_B, bool HAS_IB>
+__global__ __launch_bounds__(256) void gather_mul_kernel(float4* __restrict__ out, const float4* __restrict__ A,
+                                                         const int32_t* __restrict__ ia, const float4* __restrict__ B,
+                                                         const int32_t* __restrict__ ib, int64_t m, int64_t d4) {
+    const int64_t total = m * d4;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = t / d4;
+        const int c = (int)(t - k * d4);
+        out[t] = load_term<HAS_IA, HAS_B, HAS_IB, false>(A, ia, B, ib, nullptr, k, d4, c);
+    }
+}
+
+template <int LPR>
+int launch_segment_sum(float* out, const float* init, const float* A, const int32_t* ia, const float* B,
+                       const int32_t* ib, const int32_t* perm, const int32_t* ptr, int64_t rows, int64_t d4,
+                       hipStream_t st) {
+    constexpr int RPB = 256 / LPR;
+    int64_t grid = ceil_div(rows, RPB);
+    if (grid > 256 * 64) grid = 256 * 64;                  // grid-stride above 64 blocks / CU
+    if (grid < 1) grid = 1;
+#define PAMNET_SEG_CASE(IA, BB, IB, PM)                                                                          \
+    hipLaunchKernelGGL((segment_sum_kernel<LPR, IA, BB, IB, PM>), dim3((unsigned)grid), dim3(256), 0, st,        \
+                       (float4*)out, (const float4*)init, (const float4*)A, ia, (const float4*)B, ib, perm, ptr, \
+                       rows, d4)
+    const int key = (ia ? 8 : 0) | (B ? 4 : 0) | ((B && ib) ? 2 : 0) | (perm ? 1 : 0);
+    switch (key) {
+        case 0: PAMNET_SEG_CASE(false, false, false, false); break;
+        case 1: PAMNET_SEG_CASE(false, false, false, true); break;
+        case 4: PAMNET_SEG_CASE(false, true, false, false); break;
+        case 5: PAMNET_SEG_CASE(false, true, false, true); break;
+        case 6: PAMNET_SEG_CASE(false, true, true, false); break;
+        case 7: PAMNET_SEG_CASE(false, true, true, true); break;
+        case 8: PAMNET_SEG_CASE(true, false, false, false); break;
+        case 9: PAMNET_SEG_CASE(true, false, false, true); break;
+        case 12: PAMNET_SEG_CASE(true, true, false, false); break;
+        case 13: PAMNET_SEG_CASE(true, true, false, true); break;
+        case 14: PAMNET_SEG_CASE(true, true, true, false); break;
+        case 15: PAMNET_SEG_CASE(true, true, true, true); break;
+        default: return PAMNET_EINVAL;
+    }
+#undef PAMNET_SEG_CASE
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+}  // namespace
+
+extern "C" int pamnet_segment_sum_f32(float* out, const float* init, const float* A, const int32_t* ia,
+                                      const float* B, const int32_t* ib, const int32_t* perm, const int32_t* ptr,
+                                      int64_t rows, int64_t d, pamnet_stream_t stream) {
+    if (rows < 0 || d <= 0 || (d & 3)) return PAMNET_EINVAL;
+    if (rows == 0) return PAMNET_OK;
+    if (!out || !A || !ptr) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const int64_t d4 = d / 4;
+    switch (d4) {
+        case 1: return launch_segment_sum<1>(out, init, A, ia, B, ib, perm, ptr, rows, d4, st);
+        case 2: return launch_segment_sum<2>(out, init, A, ia, B, ib, perm, ptr, rows, d4, st);
+        case 4: return launch_segment_sum<4>(out, init, A, ia, B, ib, perm, ptr, rows, d4, st);
+        case 8: return launch_segment_sum<8>(out, init, A, ia, B, ib, perm, ptr, rows, d4, st);
+        case 16: return launch_segment_sum<16>(out, init, A, ia, B, ib, perm, ptr, rows, d4, st);
+        case 32: return launch_segment_sum<32>(out, init, A, ia, B, ib, perm, ptr, rows, d4, st);
+        case 64: return launch_segment_sum<64>(out, init, A, ia, B, ib, perm, ptr, rows, d4, st);
+        default: break;
+    }
+    int64_t grid = ceil_div(rows, 4);
+    if (grid > 256 * 32) grid = 256 * 32;
+    hipLaunchKernelGGL(segment_sum_generic_kernel, dim3((unsigned)grid), dim3(256), 0, st, (float4*)out,
+                       (const float4*)init, (const float4*)A, ia, (const float4*)B, ib, perm, ptr, rows, d4);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_gather_mul_f32(float* out, const float* A, const int32_t* ia, const float* B,
+                                     const int32_t* ib, int64_t m, int64_t d, pamnet_stream_t stream) {
+    if (m < 0 || d <= 0 || (d & 3)) return PAMNET_EINVAL;
+    if (m == 0) return PAMNET_OK;
+    if (!out || !A) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const int64_t d4 = d / 4;
+    int64_t grid = ceil_div(m * d4, 256);
+    if (grid > 256 * 64) grid = 256 * 64;
+#define PAMNET_GM_CASE(IA, BB, IB)                                                                               \
+    hipLaunchKernelGGL((gather_mul_kernel<IA, BB, IB>), dim3((unsigned)grid), dim3(256), 0, st, (float4*)out,    \
+                       (const float4*)A, ia, (const float4*)B, ib, m, d4)
+    const int key = (ia ? 4 : 0) | (B ? 2 : 0) | ((B && ib) ? 1 : 0);
+    switch (key) {
+        case 0: PAMNET_GM_CASE(false, false, false); break;
+        case 2: PAMNET_GM_CASE(false, true, false); break;
+        case 3: PAMNET_GM_CASE(false, true, true); break;
+        case 4: PAMNET_GM_CASE(true, false, false); break;
+        case 6: PAMNET_GM_CASE(true, true, false); break;
+        case 7: PAMNET_GM_CASE(true, true, true); break;
+        default: return PAMNET_EINVAL;
+    }
+#undef PAMNET_GM_CASE
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}

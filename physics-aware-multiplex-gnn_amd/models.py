@@ -1,0 +1,178 @@
+"""Drop-in for the reference's `models` module: `from models import PAMNet, PAMNet_s, Config`
+(reference main_qm9.py:13, main_pdbbind.py, main_rna_puzzles.py, inference_rna_puzzles.py:10).
+
+Same constructor arguments, attribute names, `state_dict()` keys/shapes and `forward(data)` contract as the reference
+(models.py:12-224, 227-353), but the forward runs on hand-written gfx950 kernels through the C ABI of libpamnet_hip.so
+(include/pamnet_hip.h).  Put this directory on sys.path in place of the reference checkout's root.
+
+forward(data): duck-typed `data` with `.x`, `.batch` (sorted) and, for QM9, `.pos` [N,3] and `.edge_index` [2,E]
+(optionally `.num_graphs`).  Returns fp32 [num_graphs], differentiable w.r.t. every parameter.  MI355X only: tensors must
+live on a HIP device -- there is no CPU path (the CPU oracle in oracle/ is test infrastructure and is never imported
+from here).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from pamnet_amd import graph as G
+from pamnet_amd import ops
+from pamnet_amd.modules import MLP, BesselBasis, GlobalMP, LocalMP, mlp_apply
+
+
+class Config(object):
+    def __init__(self, dataset, dim, n_layer, cutoff_l, cutoff_g, flow='source_to_target'):
+        self.dataset = dataset
+        self.dim = dim
+        self.n_layer = n_layer
+        self.cutoff_l = cutoff_l
+        self.cutoff_g = cutoff_g
+        self.flow = flow
+
+
+class SphericalBasis(nn.Module):
+    """Parameter-free stand-in for `self.sbf` (layers/basic.py:79-116).  The reference spends 12-16 s of sympy here;
+    the closed forms ship as constants inside the library (csrc/basis_constants.h)."""
+
+    def __init__(self, num_spherical, num_radial, cutoff, envelope_exponent):
+        super().__init__()
+        if (num_spherical, num_radial, envelope_exponent) != (7, 6, 5):
+            raise ValueError('libpamnet_hip ships the num_spherical=7, num_radial=6, envelope_exponent=5 basis')
+        self.cutoff = cutoff
+
+    def forward(self, graph):
+        return G.spherical_basis(graph, self.cutoff)
+
+
+class _PAMNetBase(nn.Module):
+    small = False
+
+    def __init__(self, config, num_spherical=7, num_radial=6, envelope_exponent=5):
+        super().__init__()
+        self.dataset = config.dataset
+        self.dim = config.dim
+        self.n_layer = config.n_layer
+        self.cutoff_l = config.cutoff_l
+        self.cutoff_g = config.cutoff_g
+        self.flow = getattr(config, 'flow', 'source_to_target')
+        if self.dim % 4 != 0:
+            raise ValueError('dim must be a multiple of 4 (16-byte vector lanes of the gfx950 kernels)')
+        if envelope_exponent != 5:
+            raise ValueError('envelope_exponent=5 is compiled into the kernels')
+        self._rna = self.dataset[:3].lower() == 'rna'
+
+    def _build_common(self, num_spherical, num_radial, envelope_exponent):
+        d = self.dim
+        self.rbf_g = BesselBasis(16, self.cutoff_g)
+        self.rbf_l = BesselBasis(16, self.cutoff_l)
+        self.sbf = SphericalBasis(num_spherical, num_radial, self.cutoff_l, envelope_exponent)
+        self.mlp_rbf_g = MLP([16, d])
+        self.mlp_rbf_l = MLP([16, d])
+
+    def init(self):
+        stdv = math.sqrt(3)
+        self.embeddings.data.uniform_(-stdv, stdv)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _graph(self, data):
+        ng = getattr(data, 'num_graphs', None)
+        return G.build_graph(self.dataset, self.cutoff_l, self.cutoff_g, self.flow, data.x, data.batch,
+                             getattr(data, 'pos', None), getattr(data, 'edge_index', None), num_graphs=ng,
+                             need_grad=torch.is_grad_enabled(), with_triplets=not self.small)
+
+    def _embed(self, data, g):
+        x_raw = data.x
+        if self.dataset == 'PDBbind':
+            xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
+            return F.linear(xr[:, 3:].to(torch.float32), self.init_linear.weight)          # models.py:119
+        col = x_raw if self.dataset == 'QM9' else (x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw)[:, -1]
+        idx = col.to(torch.int32).contiguous()
+        tr = G.Transpose(idx, self.embeddings.size(0)) if torch.is_grad_enabled() else None
+        return ops.gather(self.embeddings, idx, tr.ptr if tr else None, tr.perm if tr else None)  # models.py:107,140
+
+    def _edge_embeddings(self, g):
+        rbf_l = self.rbf_l(g.dist_l)
+        rbf_g = self.rbf_g(g.dist_g)
+        sbf = self.sbf(g)                                                                    # [T+P, 42], no grad
+        e_l = mlp_apply(self.mlp_rbf_l, rbf_l)
+        e_g = mlp_apply(self.mlp_rbf_g, rbf_g)
+        return e_l, e_g, sbf
+
+    def _run_layers(self, x, e_l, e_g, e_sbf, g):
+        outs, atts = [], []
+        self._x_layers = []
+        for k in range(self.n_layer):
+            x, o, a = self.global_layer[k](x, e_g, g)
+            outs.append(o), atts.append(a), self._x_layers.append(x)
+            x, o, a = self.local_layer[k](x, e_l, e_sbf, g)
+            outs.append(o), atts.append(a), self._x_layers.append(x)
+        return torch.stack(outs), torch.stack(atts)                                          # [2L, N]
+
+    def _check_dataset(self):
+        if not (self.dataset in ('QM9', 'PDBbind') or self._rna):
+            raise ValueError("Invalid dataset. If you are using any dataset related to RNA 3D structure prediction, "
+                             "be sure to use 'rna' as the first 3 characters of the dataset name.")
+
+
+class PAMNet(_PAMNetBase):
+    """models.py:21-224."""
+
+    def __init__(self, config, num_spherical=7, num_radial=6, envelope_exponent=5):
+        super().__init__(config, num_spherical, num_radial, envelope_exponent)
+        d = self.dim
+        if self._rna:
+            self.embeddings = nn.Parameter(torch.ones((3, d)))       # C, N, O
+        else:
+            self.embeddings = nn.Parameter(torch.ones((5, d)))
+            self.init_linear = nn.Linear(18, d, bias=False)
+        self._build_common(num_spherical, num_radial, envelope_exponent)
+        self.mlp_sbf1 = MLP([num_spherical * num_radial, d])
+        self.mlp_sbf2 = MLP([num_spherical * num_radial, d])
+        self.global_layer = nn.ModuleList([GlobalMP(d) for _ in range(self.n_layer)])
+        self.local_layer = nn.ModuleList([LocalMP(d) for _ in range(self.n_layer)])
+        self.softmax = nn.Softmax(dim=-1)
+        self.init()
+
+    def forward(self, data):
+        self._check_dataset()
+        g = self._graph(data)
+        x = self._embed(data, g)
+        e_l, e_g, sbf = self._edge_embeddings(g)
+        # mlp_sbf2 on triplet rows, mlp_sbf1 on pair rows (models.py:187-188), rows grouped by target edge
+        y2 = mlp_apply(self.mlp_sbf2, sbf.index_select(0, g.trip_rows))
+        y1 = mlp_apply(self.mlp_sbf1, sbf.index_select(0, g.pair_rows))
+        e_sbf = torch.zeros((sbf.size(0), self.dim), dtype=sbf.dtype, device=sbf.device)
+        e_sbf = e_sbf.index_copy(0, g.trip_rows, y2).index_copy(0, g.pair_rows, y1)
+        outs, atts = self._run_layers(x, e_l, e_g, e_sbf, g)
+        out, node_out = ops.fuse_pool(outs, atts, g, mean=self._rna)                       # models.py:206-224
+        self._graph_cache, self._node_out = g, node_out
+        return out.view(-1)
+
+
+class PAMNet_s(_PAMNetBase):
+    """models.py:227-353 (QM9 only; one-hop pairs only)."""
+    small = True
+
+    def __init__(self, config, num_spherical=7, num_radial=6, envelope_exponent=5):
+        super().__init__(config, num_spherical, num_radial, envelope_exponent)
+        d = self.dim
+        self.embeddings = nn.Parameter(torch.ones((5, d)))
+        self._build_common(num_spherical, num_radial, envelope_exponent)
+        self.mlp_sbf = MLP([num_spherical * num_radial, d])
+        self.global_layer = nn.ModuleList([GlobalMP(d) for _ in range(self.n_layer)])
+        self.local_layer = nn.ModuleList([LocalMP(d, small=True) for _ in range(self.n_layer)])
+        self.softmax = nn.Softmax(dim=-1)
+        self.init()
+
+    def forward(self, data):
+        if self.dataset != "QM9":
+            raise ValueError("Invalid dataset. The current PAMNet_s is only for QM9 experiments.")
+        g = self._graph(data)
+        x = self._embed(data, g)
+        e_l, e_g, sbf = self._edge_embeddings(g)
+        e_sbf = mlp_apply(self.mlp_sbf, sbf)
+        outs, atts = self._run_layers(x, e_l, e_g, e_sbf, g)
+        out, node_out = ops.fuse_pool(outs, atts, g, mean=False)
+        self._graph_cache, self._node_out = g, node_out
+        return out.view(-1)

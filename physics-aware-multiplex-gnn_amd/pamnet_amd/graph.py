@@ -1,0 +1,214 @@
+"""Device-side graph construction for PAMNet.forward (reference models.py:62-98, 104-177).
+
+Everything here runs as HIP kernels from libpamnet_hip.so (csrc/graph.hip, csrc/basis.hip); torch only allocates the
+buffers and reads the data-dependent sizes back (E_g, E_l, T+P) -- the reference has the same host round trips hidden in
+`repeat_interleave` / boolean masks (models.py:76-96).
+
+Edge storage differs from the reference on purpose: edges are kept in CSR order of the node they are *aggregated at*
+(deterministic, atomics-free segment sums), i.e. a permutation of the reference's edge list.  Results are invariant to
+that permutation up to fp32 summation order.
+"""
+import torch
+
+from . import lib
+
+I32 = torch.int32
+
+
+def _i32(n, dev):
+    return torch.empty(int(n), dtype=I32, device=dev)
+
+
+def _f32(n, dev):
+    return torch.empty(int(n), dtype=torch.float32, device=dev)
+
+
+def exclusive_scan(counts):
+    n = counts.numel()
+    out = _i32(n + 1, counts.device)
+    tmp = _i32((n + 4095) // 4096 + 1, counts.device)
+    lib.call('pamnet_exclusive_scan_i32', lib.ptr(counts), lib.ptr(out), n, lib.ptr(tmp), lib.stream_of(counts))
+    return out
+
+
+def csr_from_keys(keys, rows):
+    """Stable counting sort: (ptr [rows+1], perm [m]) with keys[perm] non-decreasing."""
+    m = keys.numel()
+    dev = keys.device
+    ptr, perm = _i32(rows + 1, dev), _i32(m, dev)
+    cursor, perm_tmp, tmp = _i32(rows, dev), _i32(m, dev), _i32((rows + 4095) // 4096 + 1, dev)
+    lib.call('pamnet_csr_from_keys_i32', lib.ptr(keys), m, rows, lib.ptr(ptr), lib.ptr(perm), lib.ptr(cursor),
+             lib.ptr(perm_tmp), lib.ptr(tmp), lib.stream_of(keys))
+    return ptr, perm
+
+
+def expand_rows(ptr, total):
+    rows = ptr.numel() - 1
+    out = _i32(total, ptr.device)
+    lib.call('pamnet_expand_rows_i32', lib.ptr(ptr), rows, lib.ptr(out), lib.stream_of(ptr))
+    return out
+
+
+def csr_filter(ptr_in, nbr, dist, cut):
+    rows = ptr_in.numel() - 1
+    st = lib.stream_of(nbr)
+    count = _i32(rows, nbr.device)
+    lib.call('pamnet_csr_filter_count_i32', lib.ptr(ptr_in), lib.ptr(nbr), lib.ptr(dist), rows, float(cut),
+             lib.ptr(count), st)
+    ptr = exclusive_scan(count)
+    total = int(ptr[-1])
+    nbr_out, dist_out = _i32(total, nbr.device), _f32(total, nbr.device)
+    lib.call('pamnet_csr_filter_fill_i32', lib.ptr(ptr_in), lib.ptr(nbr), lib.ptr(dist), rows, float(cut),
+             lib.ptr(ptr), lib.ptr(nbr_out), lib.ptr(dist_out), st)
+    return ptr, nbr_out, dist_out
+
+
+def edge_dist(pos, a, b):
+    out = _f32(a.numel(), pos.device)
+    lib.call('pamnet_edge_dist_f32', lib.ptr(pos), lib.ptr(a), lib.ptr(b), a.numel(), lib.ptr(out), lib.stream_of(pos))
+    return out
+
+
+class CSR(object):
+    """Rows = aggregation targets.  ptr [rows+1]; row_of [m] (expanded row id); col [m] (the other endpoint)."""
+    __slots__ = ('ptr', 'row_of', 'col', 'm', 'rows')
+
+    def __init__(self, ptr, row_of, col):
+        self.ptr, self.row_of, self.col = ptr, row_of, col
+        self.m, self.rows = int(row_of.numel()), int(ptr.numel() - 1)
+
+
+class Transpose(object):
+    """Transposed CSR of an index list idx [m] over `rows`: entries q of row r are perm[ptr[r]:ptr[r+1]], idx[perm]=r."""
+    __slots__ = ('ptr', 'perm', 'rows')
+
+    def __init__(self, idx, rows):
+        self.ptr, self.perm = csr_from_keys(idx, rows)
+        self.rows = rows
+
+
+class Graph(object):
+    """All index / geometry tensors one forward needs (int32 / fp32 on the device)."""
+    pass
+
+
+def radius_graph(pos, node_graph, gptr, r):
+    n = pos.size(0)
+    st = lib.stream_of(pos)
+    count = _i32(n, pos.device)
+    lib.call('pamnet_radius_count_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), n, float(r), lib.ptr(count), st)
+    ptr = exclusive_scan(count)
+    total = int(ptr[-1])
+    nbr, dist = _i32(total, pos.device), _f32(total, pos.device)
+    lib.call('pamnet_radius_fill_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), n, float(r), lib.ptr(ptr),
+             lib.ptr(nbr), lib.ptr(dist), st)
+    return ptr, nbr, dist
+
+
+def knn_table(pos, node_graph, gptr, k, cutoff):
+    n = pos.size(0)
+    nbr, dist = _i32(n * k, pos.device), _f32(n * k, pos.device)
+    lib.call('pamnet_knn_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), n, k, float(cutoff), lib.ptr(nbr),
+             lib.ptr(dist), lib.stream_of(pos))
+    ptr = (torch.arange(n + 1, device=pos.device, dtype=torch.int64) * k).to(I32)
+    return ptr, nbr, dist
+
+
+def _transpose_edges(ptr, nbr, dist, n):
+    """CSR by query (q -> nbr) turned into CSR by nbr (aggregate at nbr, other endpoint q)."""
+    total = nbr.numel()
+    q = expand_rows(ptr, total)
+    tptr, perm = csr_from_keys(nbr, n)
+    pl = perm.long()
+    return tptr, q[pl].contiguous(), dist[pl].contiguous()
+
+
+def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_index=None, num_graphs=None,
+                need_grad=True, knn_k=50, with_triplets=True):
+    """Graph-construction part of PAMNet.forward (models.py:104-177).  Returns a Graph."""
+    dev = batch.device
+    g = Graph()
+    n = int(batch.numel())
+    g.n = n
+    node_graph = batch.to(I32).contiguous()
+    g.n_graphs = int(num_graphs) if num_graphs is not None else int(batch[-1]) + 1
+    g.node_graph = node_graph
+    g.gptr, _ = csr_from_keys(node_graph, g.n_graphs)
+    rna = dataset[:3].lower() == 'rna'
+    g.sign = None
+
+    if dataset == 'QM9':
+        pos = pos.to(torch.float32).contiguous()
+        gp, gn, gd = radius_graph(pos, node_graph, g.gptr, cutoff_g)          # symmetric: agg = query, other = nbr
+        ei = edge_index
+        keep = ei[0] != ei[1]                                                  # remove_self_loops (models.py:63)
+        if not bool(keep.all()):
+            ei = ei[:, keep]
+        src0, dst0 = ei[0].to(I32).contiguous(), ei[1].to(I32).contiguous()    # j, i = edge_index (models.py:64)
+        lp, perm = csr_from_keys(dst0, n)
+        pl = perm.long()
+        l_src, l_dst = src0[pl].contiguous(), dst0[pl].contiguous()
+        l_dist = edge_dist(pos, l_dst, l_src)
+    elif dataset == 'PDBbind':
+        xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
+        pos = xr[:, :3].to(torch.float32).contiguous()
+        g.sign = torch.where(pos[:, 0] > 40.0, -torch.ones_like(pos[:, 0]), torch.ones_like(pos[:, 0])).contiguous()
+        gp, gn, gd = radius_graph(pos, node_graph, g.gptr, cutoff_g)
+        lp, l_src, l_dist = csr_filter(gp, gn, gd, cutoff_l)                   # symmetric subset (models.py:131-134)
+        l_dst = expand_rows(lp, l_src.numel())
+    elif rna:
+        xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
+        pos = xr[:, :3].to(torch.float32).contiguous()
+        kp, kn, kd = knn_table(pos, node_graph, g.gptr, knn_k, float('inf'))   # (query, neighbour) rows, self dropped
+        gp, gn, gd = csr_filter(kp, kn, kd, cutoff_g)                          # models.py:147-150
+        if flow != 'target_to_source':                                          # aggregate at edge_index[1] = neighbour
+            gp, gn, gd = _transpose_edges(gp, gn, gd, n)
+        qp, qn, qd = csr_filter(kp, kn, kd, cutoff_l)                          # models.py:153-156: (j=query, i=nbr)
+        lp, l_src, l_dist = _transpose_edges(qp, qn, qd, n)                    # local layer always aggregates at i
+        l_dst = expand_rows(lp, l_src.numel())
+    else:
+        raise ValueError("Invalid dataset. If you are using any dataset related to RNA 3D structure prediction, "
+                         "be sure to use 'rna' as the first 3 characters of the dataset name.")
+
+    g.pos = pos
+    g.glob = CSR(gp, expand_rows(gp, gn.numel()), gn)
+    g.dist_g = gd
+    g.loc = CSR(lp, l_dst, l_src)
+    g.dist_l = l_dist
+
+    # triplets / pairs + angles (models.py:68-98, 165-177); combined rows grouped by target edge
+    e_l = g.loc.m
+    st = lib.stream_of(pos)
+    wt = 1 if with_triplets else 0
+    tcount, tpcount = _i32(e_l, dev), _i32(e_l, dev)
+    lib.call('pamnet_triplet_count_i32', lib.ptr(lp), lib.ptr(l_src), lib.ptr(l_dst), e_l, wt, lib.ptr(tcount),
+             lib.ptr(tpcount), st)
+    tp_ptr = exclusive_scan(tpcount)
+    tot = int(tp_ptr[-1])
+    tp_idx, tp_edge, tp_angle, tp_kind = _i32(tot, dev), _i32(tot, dev), _f32(tot, dev), _i32(tot, dev)
+    lib.call('pamnet_triplet_fill_f32', lib.ptr(pos), lib.ptr(lp), lib.ptr(l_src), lib.ptr(l_dst), e_l, wt,
+             lib.ptr(tp_ptr), lib.ptr(tp_idx), lib.ptr(tp_edge), lib.ptr(tp_angle), lib.ptr(tp_kind), st)
+    g.tp = CSR(tp_ptr, tp_edge, tp_idx)               # rows = target edge e, col = source edge e'
+    g.tp_angle, g.tp_kind = tp_angle, tp_kind
+    g.trip_rows = (tp_kind == 0).nonzero().view(-1)   # rows fed to mlp_sbf2 (models.py:188)
+    g.pair_rows = (tp_kind == 1).nonzero().view(-1)   # rows fed to mlp_sbf1 (models.py:187)
+    g.n_trip, g.n_pair = int(g.trip_rows.numel()), int(g.pair_rows.numel())
+
+    if need_grad:
+        g.glob_T = Transpose(g.glob.col, n)           # d x[j] of the global gather
+        g.loc_T = Transpose(g.loc.col, n)             # d x[j] of the local gather
+        g.tp_T = Transpose(tp_idx, max(e_l, 1))       # d m_neighbor[e'] of the triplet/pair gather
+    return g
+
+
+def spherical_basis(g, cutoff_l):
+    """SphericalBasisLayer on the combined triplet/pair rows (layers/basic.py:107-116): returns [T+P, 42]."""
+    dev = g.pos.device
+    st = lib.stream_of(g.pos)
+    e_l = g.loc.m
+    rad = _f32(e_l * 42, dev)
+    lib.call('pamnet_sbf_radial_f32', lib.ptr(g.dist_l), float(cutoff_l), e_l, lib.ptr(rad), st)
+    tot = g.tp.m
+    sbf = torch.empty((tot, 42), dtype=torch.float32, device=dev)
+    lib.call('pamnet_sbf_combine_f32', lib.ptr(rad), lib.ptr(g.tp.col), lib.ptr(g.tp_angle), tot, lib.ptr(sbf), st)
+    return sbf

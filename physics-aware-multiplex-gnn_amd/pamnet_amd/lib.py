@@ -1,0 +1,77 @@
+"""ctypes binding of libpamnet_hip.so (C ABI declared in include/pamnet_hip.h).
+
+There is NO fallback: if the library is missing or a call returns non-zero, a RuntimeError is raised.  The product
+path never imports oracle/ and never computes on the CPU.
+"""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libpamnet_hip.so')
+HEADER = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include', 'pamnet_hip.h')
+
+_lib = None
+_CT = {'float*': ctypes.c_void_p, 'int32_t*': ctypes.c_void_p, 'void*': ctypes.c_void_p,
+       'int64_t': ctypes.c_int64, 'int32_t': ctypes.c_int32, 'float': ctypes.c_float, 'double': ctypes.c_double,
+       'pamnet_stream_t': ctypes.c_void_p, 'int': ctypes.c_int}
+
+
+def declared_functions(header=HEADER):
+    """Parse `int pamnet_xxx(args);` prototypes out of the public header -> {name: [ctypes arg types]}."""
+    text = open(header).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    out = {}
+    for m in re.finditer(r'\bint\s+(pamnet_\w+)\s*\(([^)]*)\)\s*;', text):
+        name, args = m.group(1), m.group(2).strip()
+        types = []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.replace('const', ' ').strip()
+                base = a.rsplit(None, 1)[0].strip() if not a.endswith('*') else a
+                if '*' in a:
+                    base = a.split('*')[0].strip() + '*'
+                types.append(_CT[base])
+        out[name] = types
+    return out
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libpamnet_hip.so is not built (%s). Run `python __graft_entry__.py` or '
+                               'pamnet_amd.build.build(); there is no CPU fallback.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, types in declared_functions().items():
+            fn = getattr(lib, name)            # AttributeError here = header/library mismatch: fail loudly
+            fn.argtypes = types
+            fn.restype = ctypes.c_int
+        _lib = lib
+    return _lib
+
+
+def check(rc, name):
+    if rc != 0:
+        kind = {-1: 'PAMNET_EINVAL (bad size / unsupported width)', -2: 'PAMNET_ENULL (null pointer)'}.get(
+            rc, 'hipError_t %d' % rc)
+        raise RuntimeError('%s failed: %s' % (name, kind))
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor, or NULL for None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'pamnet_hip: tensor must be contiguous'
+    return t.data_ptr()
+
+
+def stream_of(t):
+    import torch
+    if not t.is_cuda:
+        raise RuntimeError('pamnet_hip kernels run on an MI355X only: tensor is on %s (no CPU fallback)' % t.device)
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,171 @@
+"""torch.autograd glue around the C-ABI kernels of libpamnet_hip.so.
+
+torch is plumbing here: it owns device memory, the stream and the autograd tape; every forward/backward body below is a
+HIP kernel call.  No CPU fallback: tensors that are not on an MI355X raise in lib.stream_of.
+"""
+import torch
+
+from . import lib
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def segment_sum_raw(out, init, A, ia, B, ib, perm, ptr, rows, d):
+    lib.call('pamnet_segment_sum_f32', lib.ptr(out), lib.ptr(init), lib.ptr(A), lib.ptr(ia), lib.ptr(B), lib.ptr(ib),
+             lib.ptr(perm), lib.ptr(ptr), rows, d, lib.stream_of(A))
+    return out
+
+
+def gather_mul_raw(out, A, ia, B, ib, m, d):
+    lib.call('pamnet_gather_mul_f32', lib.ptr(out), lib.ptr(A), lib.ptr(ia), lib.ptr(B), lib.ptr(ib), m, d,
+             lib.stream_of(A))
+    return out
+
+
+class _Aggregate(torch.autograd.Function):
+    """out[r] = (init[r]) + sum_{q in CSR row r} src[q]        (torch_scatter.scatter add with sorted index;
+    layers/local_message_passing.py:54, layers/global_message_passing.py:38)."""
+
+    @staticmethod
+    def forward(ctx, src, init, csr):
+        src = _c(src)
+        d = src.size(1)
+        out = torch.empty((csr.rows, d), dtype=src.dtype, device=src.device)
+        segment_sum_raw(out, _c(init) if init is not None else None, src, None, None, None, None, csr.ptr, csr.rows, d)
+        ctx.csr, ctx.has_init = csr, init is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        csr = ctx.csr
+        d = g.size(1)
+        gsrc = torch.empty((csr.m, d), dtype=g.dtype, device=g.device)
+        gather_mul_raw(gsrc, g, csr.row_of, None, None, csr.m, d)
+        return gsrc, (g if ctx.has_init else None), None
+
+
+class _Gather(torch.autograd.Function):
+    """out[k] = x[idx[k]]  (x[i], x[j] in MessagePassing.propagate / local_message_passing.py:46).
+    `tr` is the transposed CSR of idx (graph.Transpose); when idx is a CSR's row_of, pass (ptr, None)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, tr_ptr, tr_perm):
+        x = _c(x)
+        m, d = idx.numel(), x.size(1)
+        out = torch.empty((m, d), dtype=x.dtype, device=x.device)
+        gather_mul_raw(out, x, idx, None, None, m, d)
+        ctx.tr_ptr, ctx.tr_perm, ctx.rows = tr_ptr, tr_perm, x.size(0)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        d = g.size(1)
+        gx = torch.empty((ctx.rows, d), dtype=g.dtype, device=g.device)
+        segment_sum_raw(gx, None, g, None, None, None, ctx.tr_perm, ctx.tr_ptr, ctx.rows, d)
+        return gx, None, None, None
+
+
+class _GatherMulAggregate(torch.autograd.Function):
+    """out[r] = sum_{q in CSR row r} A[col[q]] * B[q]
+    (m_neighbor[idx] * mlp_sbf(sbf) -> scatter to edges, layers/local_message_passing.py:49-50)."""
+
+    @staticmethod
+    def forward(ctx, A, B, csr, tr):
+        A, B = _c(A), _c(B)
+        d = A.size(1)
+        out = torch.empty((csr.rows, d), dtype=A.dtype, device=A.device)
+        segment_sum_raw(out, None, A, csr.col, B, None, None, csr.ptr, csr.rows, d)
+        ctx.save_for_backward(A, B)
+        ctx.csr, ctx.tr = csr, tr
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        A, B = ctx.saved_tensors
+        g = _c(g)
+        csr, tr = ctx.csr, ctx.tr
+        d = g.size(1)
+        gB = torch.empty_like(B)
+        gather_mul_raw(gB, A, csr.col, g, csr.row_of, csr.m, d)                 # dB[q] = A[col[q]] * g[row_of[q]]
+        gA = torch.empty_like(A)
+        # dA[n] = sum_{q: col[q]=n} B[q] * g[row_of[q]]  -- transposed CSR walk
+        segment_sum_raw(gA, None, B, None, g, csr.row_of, tr.perm, tr.ptr, A.size(0), d)
+        return gA, gB, None, None
+
+
+class _RBF(torch.autograd.Function):
+    """BesselBasisLayer (layers/basic.py:59-76); freq is trainable, dist is not differentiated (pos has no grad)."""
+
+    @staticmethod
+    def forward(ctx, dist, freq, cutoff):
+        m = dist.numel()
+        out = torch.empty((m, 16), dtype=torch.float32, device=dist.device)
+        lib.call('pamnet_rbf_fwd_f32', lib.ptr(dist), lib.ptr(_c(freq)), float(cutoff), m, lib.ptr(out),
+                 lib.stream_of(dist))
+        ctx.save_for_backward(dist, freq)
+        ctx.cutoff = float(cutoff)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        dist, freq = ctx.saved_tensors
+        g = _c(g)
+        dfreq = torch.empty(16, dtype=torch.float32, device=g.device)
+        partial = torch.empty(16 * 256, dtype=torch.float32, device=g.device)
+        lib.call('pamnet_rbf_bwd_f32', lib.ptr(dist), lib.ptr(_c(freq)), ctx.cutoff, dist.numel(), lib.ptr(g),
+                 lib.ptr(dfreq), lib.ptr(partial), lib.stream_of(g))
+        return None, dfreq, None
+
+
+class _FusePool(torch.autograd.Function):
+    """Attention fusion + pooling (models.py:206-224).  outs / atts: [2L, N] rows (global_0, local_0, global_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, outs, atts, graph, mean):
+        outs, atts = _c(outs), _c(atts)
+        n_layer, n = outs.size(0) // 2, outs.size(1)
+        node_out = torch.empty(n, dtype=outs.dtype, device=outs.device)
+        gout = torch.empty(graph.n_graphs, dtype=outs.dtype, device=outs.device)
+        lib.call('pamnet_fuse_pool_fwd_f32', lib.ptr(outs), lib.ptr(atts), n_layer, n, lib.ptr(graph.sign),
+                 lib.ptr(graph.gptr), graph.n_graphs, 1 if mean else 0, lib.ptr(node_out), lib.ptr(gout),
+                 lib.stream_of(outs))
+        ctx.save_for_backward(outs, atts)
+        ctx.graph, ctx.mean = graph, mean
+        ctx.mark_non_differentiable(node_out)
+        return gout, node_out
+
+    @staticmethod
+    def backward(ctx, g, _g_node):
+        outs, atts = ctx.saved_tensors
+        graph = ctx.graph
+        g = _c(g)
+        n_layer, n = outs.size(0) // 2, outs.size(1)
+        go, ga = torch.empty_like(outs), torch.empty_like(atts)
+        lib.call('pamnet_fuse_pool_bwd_f32', lib.ptr(outs), lib.ptr(atts), n_layer, n, lib.ptr(graph.sign),
+                 lib.ptr(graph.node_graph), lib.ptr(graph.gptr), 1 if ctx.mean else 0, lib.ptr(g), lib.ptr(go),
+                 lib.ptr(ga), lib.stream_of(g))
+        return go, ga, None, None
+
+
+def aggregate(src, csr, init=None):
+    return _Aggregate.apply(src, init, csr)
+
+
+def gather(x, idx, tr_ptr, tr_perm=None):
+    return _Gather.apply(x, idx, tr_ptr, tr_perm)
+
+
+def gather_mul_aggregate(A, B, csr, tr):
+    return _GatherMulAggregate.apply(A, B, csr, tr)
+
+
+def rbf(dist, freq, cutoff):
+    return _RBF.apply(dist, freq, cutoff)
+
+
+def fuse_pool(outs, atts, graph, mean):
+    return _FusePool.apply(outs, atts, graph, mean)

@@ -1,0 +1,140 @@
+"""Training step with the semantics of the reference loop (main_qm9.py:99-118, utils/ema.py:3-32) and molecule-sharded
+data parallelism (one process per GPU, RCCL over xGMI).
+
+Per step:  zero_grad -> forward -> F.l1_loss (mean over graphs) -> backward -> [all-reduce of the flat fp32 gradient]
+           -> clip_grad_norm_(max 1000, L2) -> Adam(lr, wd=0, amsgrad=False) -> warm-up/exponential LR -> EMA(0.999).
+
+MI355X-first layout: all parameters, their gradients, both Adam moments and the EMA shadow live in five flat fp32
+buffers (3.58 M floats = 14.3 MB each at d=128/L=6).  Parameters / .grad are views into them, so
+  * the gradient all-reduce is ONE RCCL call on one contiguous buffer (ring all-reduce moves 2(n-1)/n * 14.3 MB per GPU,
+    per-xGMI-link bound; no bucketing copies),
+  * clip / Adam / EMA are a fixed handful of launches over one tensor instead of ~300 per-parameter launches.
+Each rank pre-scales its gradient by local_graphs/global_graphs so the summed gradient equals that of the global-batch
+mean L1 loss (main_qm9.py:108), then every rank applies the identical update.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+
+class FlatParams(object):
+    """Re-home a module's parameters (and their .grad) as views of two flat buffers."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.names = [n for n, p in module.named_parameters() if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev, dt = self.params[0].device, self.params[0].dtype
+        pad = (-n) % 1024
+        self.numel = n
+        self.flat = torch.zeros(n + pad, device=dev, dtype=dt)
+        self.grad = torch.zeros(n + pad, device=dev, dtype=dt)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p)
+            p.grad = self.grad[off:off + k].view_as(p)
+            off += k
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+class WarmupExpLR(object):
+    """lr(t) = lr0 * t for fractional epoch t <= 1, then lr0 * gamma**(t-1): GradualWarmupScheduler(multiplier=1,
+    total_epoch=1, after=ExponentialLR(gamma)) stepped per iteration with the fractional epoch (main_qm9.py:93-94,
+    113-114).  The warmup_scheduler package is not in the reference tree: semantics restated, parity unpinned."""
+
+    def __init__(self, lr0, gamma=0.9961697, steps_per_epoch=1.0):
+        self.lr0, self.gamma, self.spe = lr0, gamma, float(steps_per_epoch)
+
+    def lr_at(self, epoch, step):
+        t = epoch + step / self.spe
+        return self.lr0 * t if t <= 1.0 else self.lr0 * self.gamma ** (t - 1.0)
+
+
+class Trainer(object):
+    def __init__(self, model, lr=1e-4, weight_decay=0.0, ema_decay=0.999, max_grad_norm=1000.0, betas=(0.9, 0.999),
+                 eps=1e-8, world_size=1, process_group=None):
+        self.model = model
+        self.fp = FlatParams(model)
+        self.opt = torch.optim.Adam([torch.nn.Parameter(self.fp.flat)], lr=lr, betas=betas, eps=eps,
+                                    weight_decay=weight_decay, amsgrad=False, fused=self.fp.flat.is_cuda)
+        self._p = self.opt.param_groups[0]['params'][0]
+        self._p.grad = self.fp.grad
+        self.ema_decay = ema_decay
+        self.shadow = self.fp.flat.clone()                                 # utils/ema.py:9-11
+        self.max_grad_norm = max_grad_norm
+        self.world_size, self.pg = world_size, process_group
+
+    # -- pieces (also timed individually by bench.py) ---------------------------------------------------------------
+    def forward_backward(self, data, global_graphs=None):
+        self.fp.zero_grad()
+        out = self.model(data)
+        loss = F.l1_loss(out, data.y)
+        if self.world_size > 1:
+            # local mean -> contribution to the global-batch mean
+            (loss * (float(out.numel()) / float(global_graphs))).backward()
+        else:
+            loss.backward()
+        return loss
+
+    def sync_gradients(self):
+        if self.world_size > 1:
+            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def clip(self):
+        norm = torch.linalg.vector_norm(self.fp.grad)
+        coef = torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0)    # clip_grad_norm_ (main_qm9.py:111)
+        self.fp.grad.mul_(coef)
+        return norm
+
+    def optimizer_step(self, lr=None):
+        if lr is not None:
+            self.opt.param_groups[0]['lr'] = lr
+        self.opt.step()
+
+    def ema_update(self, num_updates=99999):
+        decay = min(self.ema_decay, (1.0 + num_updates) / (10.0 + num_updates))     # utils/ema.py:14
+        self.shadow.mul_(decay).add_(self.fp.flat, alpha=1.0 - decay)
+
+    def step(self, data, lr=None, global_graphs=None):
+        loss = self.forward_backward(data, global_graphs)
+        self.sync_gradients()
+        self.clip()
+        self.optimizer_step(lr)
+        self.ema_update()
+        return loss
+
+    # -- evaluation under the EMA weights (main_qm9.py:29-37) ---------------------------------------------------------
+    def ema_assign(self):
+        self._saved = self.fp.flat.clone()
+        self.fp.flat.copy_(self.shadow)
+
+    def ema_resume(self):
+        self.fp.flat.copy_(self._saved)
+        del self._saved
+
+    @torch.no_grad()
+    def evaluate(self, batches):
+        """Sum |out - y| over batches / #graphs under EMA weights, all-reduced across ranks."""
+        self.ema_assign()
+        tot = torch.zeros(2, device=self.fp.flat.device, dtype=torch.float64)
+        for data in batches:
+            out = self.model(data)
+            tot[0] += (out - data.y).abs().sum().double()
+            tot[1] += out.numel()
+        self.ema_resume()
+        if self.world_size > 1:
+            dist.all_reduce(tot, group=self.pg)
+        return float(tot[0] / tot[1])
+
+
+def shard_range(total, rank, world):
+    """Contiguous molecule shard [lo, hi) of a global batch (graphs are independent units: no halo)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

@@ -1,0 +1,261 @@
+"""GPU parity tests of the individual C-ABI kernels against the CPU oracle / plain torch on seeded inputs.
+Integer / index work: bit-exact.  fp32 work: tolerance stated per test.  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import maxnorm_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'needs an MI355X'
+    from pamnet_amd import lib
+    lib.load()                                    # fail loudly if the HIP library is missing
+    return torch.device('cuda:0')
+
+
+def _csr(rng, rows, max_len, dev):
+    lens = rng.integers(0, max_len + 1, size=rows)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    return torch.from_numpy(ptr).to(dev), int(ptr[-1]), torch.from_numpy(np.repeat(np.arange(rows), lens)).to(dev)
+
+
+@pytest.mark.parametrize('d', [4, 16, 32, 128, 256, 48])
+@pytest.mark.parametrize('rows,max_len', [(1, 0), (7, 3), (1000, 20), (333, 70)])
+def test_segment_sum_plain(dev, d, rows, max_len):
+    """pamnet_segment_sum_f32 == torch_scatter.scatter(src, sorted index, reduce='add') semantics."""
+    from pamnet_amd import ops
+    rng = np.random.default_rng(rows * 131 + d)
+    ptr, m, seg = _csr(rng, rows, max_len, dev)
+    src = torch.randn(m, d, device=dev)
+    out = torch.full((rows, d), float('nan'), device=dev)
+    ops.segment_sum_raw(out, None, src, None, None, None, None, ptr, rows, d)
+    ref = torch.zeros(rows, d, dtype=torch.float64, device=dev).index_add_(0, seg, src.double())
+    assert torch.isfinite(out).all()                  # empty segments are written as zeros
+    assert maxnorm_err(out.cpu(), ref.cpu()) < 2e-6 or m == 0
+    out2 = torch.empty_like(out)
+    ops.segment_sum_raw(out2, None, src, None, None, None, None, ptr, rows, d)
+    assert torch.equal(out, out2)                     # deterministic, run-to-run bitwise
+
+
+@pytest.mark.parametrize('d', [16, 128])
+def test_segment_sum_all_operands(dev, d):
+    from pamnet_amd import ops
+    rng = np.random.default_rng(5)
+    rows, ra, rb = 500, 300, 200
+    ptr, m, seg = _csr(rng, rows, 12, dev)
+    A, B, init = torch.randn(ra, d, device=dev), torch.randn(rb, d, device=dev), torch.randn(rows, d, device=dev)
+    ia = torch.from_numpy(rng.integers(0, ra, m).astype(np.int32)).to(dev)
+    ib = torch.from_numpy(rng.integers(0, rb, m).astype(np.int32)).to(dev)
+    perm = torch.from_numpy(rng.permutation(m).astype(np.int32)).to(dev)
+    out = torch.empty(rows, d, device=dev)
+    ops.segment_sum_raw(out, init, A, ia, B, ib, perm, ptr, rows, d)
+    k = perm.long()
+    terms = A.double()[ia.long()[k]] * B.double()[ib.long()[k]]
+    ref = init.double().clone().index_add_(0, seg, terms)
+    assert maxnorm_err(out.cpu(), ref.cpu()) < 2e-6
+    # gather_mul
+    g = torch.empty(m, d, device=dev)
+    ops.gather_mul_raw(g, A, ia, B, ib, m, d)
+    assert torch.equal(g, A[ia.long()] * B[ib.long()])
+
+
+def test_segment_ops_autograd(dev):
+    """Backward kernels == autograd of the equivalent torch expression."""
+    from pamnet_amd import graph as G, ops
+    rng = np.random.default_rng(9)
+    rows, ra, d = 200, 150, 32
+    ptr, m, seg = _csr(rng, rows, 9, dev)
+    col = torch.from_numpy(rng.integers(0, ra, m).astype(np.int32)).to(dev)
+    csr = G.CSR(ptr, seg.to(torch.int32), col)
+    tr = G.Transpose(col, ra)
+    A = torch.randn(ra, d, device=dev, requires_grad=True)
+    B = torch.randn(m, d, device=dev, requires_grad=True)
+    init = torch.randn(rows, d, device=dev, requires_grad=True)
+    w = torch.randn(rows, d, device=dev)
+    y = ops.aggregate(ops.gather(A, col, tr.ptr, tr.perm) * B, csr, init=init) + ops.gather_mul_aggregate(A, B, csr, tr)
+    (y * w).sum().backward()
+    got = [A.grad.clone(), B.grad.clone(), init.grad.clone()]
+    A.grad = B.grad = init.grad = None
+    t = A[col.long()] * B
+    y2 = init + torch.zeros_like(init).index_add(0, seg, t) + torch.zeros_like(init).index_add(0, seg, t)
+    (y2 * w).sum().backward()
+    assert maxnorm_err(y.detach().cpu(), y2.detach().cpu()) < 2e-6
+    for a, b in zip(got, [A.grad, B.grad, init.grad]):
+        assert maxnorm_err(a.cpu(), b.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize('n', [0, 1, 5, 4096, 4097, 100000, 1 << 20])
+def test_exclusive_scan_bit_exact(dev, n):
+    from pamnet_amd import graph as G
+    x = torch.randint(0, 50, (n,), dtype=torch.int32, device=dev)
+    out = G.exclusive_scan(x)
+    ref = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), x.long().cumsum(0)])
+    assert torch.equal(out.long(), ref)
+
+
+@pytest.mark.parametrize('m,rows', [(0, 3), (10, 1), (5000, 700), (200000, 50), (100000, 100000)])
+def test_csr_from_keys_stable(dev, m, rows):
+    from pamnet_amd import graph as G
+    keys = torch.randint(0, rows, (m,), dtype=torch.int32, device=dev)
+    ptr, perm = G.csr_from_keys(keys, rows)
+    ref_perm = torch.sort(keys.long(), stable=True).indices
+    assert torch.equal(perm.long(), ref_perm)
+    assert torch.equal(ptr.long(), torch.cat([torch.zeros(1, dtype=torch.int64, device=dev),
+                                              torch.bincount(keys.long(), minlength=rows).cumsum(0)]))
+
+
+def _edge_set(row, col):
+    return set(zip(row.tolist(), col.tolist()))
+
+
+def test_radius_graph_matches_oracle(dev):
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import graph as G, synth
+    b = synth.qm9_batch(3, 0, 40)
+    ei, dist = O.get_edge_info(O.radius_graph(b.pos, b.batch, 5.0), b.pos)
+    nodeg = b.batch.to(torch.int32).to(dev)
+    gptr, _ = G.csr_from_keys(nodeg, 40)
+    ptr, nbr, d = G.radius_graph(b.pos.to(dev), nodeg, gptr, 5.0)
+    q = G.expand_rows(ptr, nbr.numel())
+    assert _edge_set(q.cpu(), nbr.cpu()) == _edge_set(ei[0], ei[1])                    # bit-exact edge set
+    # distances: same edges -> same fp32 values (sorted by (row, col) on both sides)
+    key = (ei[0] * 100000 + ei[1]).argsort()
+    assert torch.equal(d.cpu(), dist[key])
+
+
+def test_knn_matches_oracle(dev):
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import graph as G, synth
+    b = synth.rna_batch(1, 0, 2, n_nodes=300)
+    pos = b.x[:, :3].contiguous()
+    ei = O.knn_graph(pos, b.batch, 50)
+    ei, dist = O.get_edge_info(ei, pos)
+    nodeg = b.batch.to(torch.int32).to(dev)
+    gptr, _ = G.csr_from_keys(nodeg, 2)
+    kp, kn, kd = G.knn_table(pos.to(dev), nodeg, gptr, 50, float('inf'))
+    q = G.expand_rows(kp, kn.numel())
+    keep = kn >= 0
+    assert _edge_set(q[keep].cpu(), kn[keep].cpu()) == _edge_set(ei[0], ei[1])
+    assert int(keep.sum()) == 49 * 600
+    # small graph (fewer nodes than k) and cutoff masking
+    b2 = synth.rna_batch(2, 0, 1, n_nodes=20)
+    pos2 = b2.x[:, :3].contiguous()
+    g1 = torch.zeros(20, dtype=torch.int32, device=dev)
+    kp, kn, kd = G.knn_table(pos2.to(dev), g1, torch.tensor([0, 20], dtype=torch.int32, device=dev), 50, 3.0)
+    ei2, d2 = O.get_edge_info(O.knn_graph(pos2, b2.batch, 50), pos2)
+    m = d2 <= 3.0
+    q = G.expand_rows(kp, kn.numel())
+    keep = kn >= 0
+    assert _edge_set(q[keep].cpu(), kn[keep].cpu()) == _edge_set(ei2[0][m], ei2[1][m])
+
+
+def test_triplets_pairs_angles_match_oracle(dev):
+    """Same (k,j,i) triplets / (j,i,j') pairs and the same angles as PAMNet.indices (models.py:68-98)."""
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import graph as G, synth
+    b = synth.qm9_batch(7, 0, 16)
+    n = b.x.numel()
+    g = G.build_graph('QM9', 5.0, 5.0, 'source_to_target', b.x.to(dev), b.batch.to(dev), b.pos.to(dev),
+                      b.edge_index.to(dev), num_graphs=16)
+    ei_l, _ = O.get_edge_info(b.edge_index, b.pos)
+    (idx_i, idx_j, idx_k, idx_kj, idx_ji, i_p, j1_p, j2_p, jj_p, ji_p) = O.indices(ei_l, n)
+    a2 = O.angle_between(b.pos[idx_j] - b.pos[idx_i], b.pos[idx_k] - b.pos[idx_j])
+    a1 = O.angle_between(b.pos[j1_p] - b.pos[i_p], b.pos[j2_p] - b.pos[j1_p])
+    src, dst = g.loc.col.cpu().long(), g.loc.row_of.cpu().long()
+    e, e2 = g.tp.row_of.cpu().long(), g.tp.col.cpu().long()
+    kind, ang = g.tp_kind.cpu(), g.tp_angle.cpu()
+    assert g.n_trip == idx_kj.numel() and g.n_pair == jj_p.numel()
+    mine_t = {(int(src[b_]), int(src[a_]), int(dst[a_])): float(x) for a_, b_, k_, x in zip(e, e2, kind, ang) if k_ == 0}
+    ref_t = {(int(k), int(j), int(i)): float(x) for k, j, i, x in zip(idx_k, idx_j, idx_i, a2)}
+    assert mine_t.keys() == ref_t.keys()
+    assert max(abs(mine_t[k] - ref_t[k]) for k in ref_t) < 2e-6
+    mine_p = {(int(src[a_]), int(dst[a_]), int(src[b_])): float(x) for a_, b_, k_, x in zip(e, e2, kind, ang) if k_ == 1}
+    ref_p = {(int(i), int(j1), int(j2)): float(x) for i, j1, j2, x in zip(i_p, j1_p, j2_p, a1)}
+    assert mine_p.keys() == ref_p.keys()
+    assert max(abs(mine_p[k] - ref_p[k]) for k in ref_p) < 2e-3        # self-pairs: atan2(~0, -1): pi up to sqrt noise
+    # rows are grouped by target edge, triplets before pairs
+    assert torch.equal(e, torch.sort(e).values)
+
+
+def test_star_indices_golden(dev, golden):
+    from pamnet_amd import graph as G
+    gd = golden('star_indices')
+    ei = torch.from_numpy(gd['edge_index']).to(dev)
+    pos = torch.tensor([[0., 0, 0], [1., 0, 0], [1.5, 1, 0], [1.5, -1, 0.3]], device=dev)
+    g = G.build_graph('QM9', 5.0, 5.0, 'source_to_target', torch.zeros(4, device=dev),
+                      torch.zeros(4, dtype=torch.long, device=dev), pos, ei, num_graphs=1)
+    src, dst = g.loc.col.cpu().long(), g.loc.row_of.cpu().long()
+    ref_e = list(zip(gd['edge_index'][0].tolist(), gd['edge_index'][1].tolist()))
+    mine = sorted((ref_e.index((int(src[b]), int(dst[b]))), ref_e.index((int(src[a]), int(dst[a]))), int(k))
+                  for a, b, k in zip(g.tp.row_of.cpu(), g.tp.col.cpu(), g.tp_kind.cpu()))
+    ref = sorted([(int(a), int(b), 0) for a, b in zip(gd['idx_kj'], gd['idx_ji'])] +
+                 [(int(a), int(b), 1) for a, b in zip(gd['idx_jj_pair'], gd['idx_ji_pair'])])
+    assert mine == ref
+
+
+def test_basis_vs_golden_tables(dev, golden):
+    """RBF / SBF kernels vs the reference's own layers evaluated in fp64 (basis_tables.npz)."""
+    from pamnet_amd import lib, ops
+    gd = golden('basis_tables')
+    dist = torch.from_numpy(gd['dist']).float().to(dev)
+    ang = torch.from_numpy(gd['angle']).float().to(dev)
+    m = dist.numel()
+    c = float(gd['cutoff'])
+    freq = (torch.arange(1, 17, dtype=torch.float32) * np.pi).to(dev)
+    rbf = ops.rbf(dist, freq, c)
+    assert maxnorm_err(rbf.cpu(), gd['rbf64']) < 2e-6
+    rad = torch.empty(m * 42, device=dev)
+    lib.call('pamnet_sbf_radial_f32', lib.ptr(dist), c, m, lib.ptr(rad), lib.stream_of(dist))
+    sbf = torch.empty(m, 42, device=dev)
+    idx = torch.arange(m, dtype=torch.int32, device=dev)
+    lib.call('pamnet_sbf_combine_f32', lib.ptr(rad), lib.ptr(idx), lib.ptr(ang), m, lib.ptr(sbf), lib.stream_of(dist))
+    ref32_err = [maxnorm_err(gd['sbf32'][:, 6 * l:6 * l + 6], gd['sbf64'][:, 6 * l:6 * l + 6]) for l in range(7)]
+    for l in range(7):
+        blk = slice(6 * l, 6 * l + 6)
+        err = maxnorm_err(sbf[:, blk].cpu(), gd['sbf64'][:, blk])
+        # fp32 inputs (dist, angle rounded to fp32) bound this at ~1e-6; never worse than the reference's own fp32 run
+        assert err < max(3e-6, 2 * ref32_err[l]), (l, err, ref32_err[l])
+
+
+def test_rbf_backward_freq(dev):
+    from pamnet_amd import ops
+    from oracle import pamnet_oracle as O
+    dist = torch.rand(3000, device=dev) * 5.2 + 0.5
+    freq = (torch.arange(1, 17, dtype=torch.float32, device=dev) * np.pi).requires_grad_()
+    w = torch.randn(3000, 16, device=dev)
+    (ops.rbf(dist, freq, 5.0) * w).sum().backward()
+    f64 = (torch.arange(1, 17, dtype=torch.float32) * np.pi).double().requires_grad_()
+    (O.bessel_rbf(dist.cpu().double(), f64, 5.0) * w.cpu().double()).sum().backward()
+    assert maxnorm_err(freq.grad.cpu(), f64.grad) < 1e-5
+
+
+def test_fuse_pool_fwd_bwd(dev):
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import graph as G, ops
+    L, n, B = 3, 500, 17
+    batch = torch.sort(torch.randint(0, B, (n,))).values
+    g = G.Graph()
+    g.n_graphs, g.node_graph = B, batch.to(torch.int32).to(dev)
+    g.gptr, _ = G.csr_from_keys(g.node_graph, B)
+    g.sign = torch.where(torch.rand(n) > 0.5, 1.0, -1.0).to(dev)
+    outs = torch.randn(2 * L, n, device=dev, requires_grad=True)
+    atts = torch.randn(2 * L, n, device=dev, requires_grad=True)
+    w = torch.randn(B, device=dev)
+    for mean in (False, True):
+        out, node_out = ops.fuse_pool(outs, atts, g, mean)
+        (out * w).sum().backward()
+        o64, a64 = outs.detach().cpu().double().requires_grad_(), atts.detach().cpu().double().requires_grad_()
+        node = O.fuse([o64[2 * l].view(1, n, 1) for l in range(L)], [o64[2 * l + 1].view(1, n, 1) for l in range(L)],
+                      [a64[2 * l].view(1, n, 1) for l in range(L)], [a64[2 * l + 1].view(1, n, 1) for l in range(L)])
+        node = node * g.sign.cpu().double().unsqueeze(-1)
+        ref = O.segment_add(node, batch, B).view(-1)
+        if mean:
+            ref = ref / torch.bincount(batch, minlength=B).clamp(min=1)
+        (ref * w.cpu().double()).sum().backward()
+        assert maxnorm_err(out.detach().cpu(), ref.detach()) < 5e-6
+        assert maxnorm_err(outs.grad.cpu(), o64.grad) < 5e-6 and maxnorm_err(atts.grad.cpu(), a64.grad) < 5e-6
+        outs.grad = atts.grad = None

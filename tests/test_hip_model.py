@@ -1,0 +1,219 @@
+"""End-to-end parity of the MI355X path (models.PAMNet / PAMNet_s through libpamnet_hip.so) against
+
+  * golden vectors produced by the reference's own code (tests/golden/*.npz: fp32 and fp64 reference runs), and
+  * the CPU oracle on fresh seeded inputs at sizes it finishes in seconds,
+
+plus size-independent properties at the BASELINE configuration (B=128, d=128, L=6).
+
+Parity protocol: per tensor, err(a, b) = max|a-b| / max|b|.  The HIP path must satisfy
+    err(hip, ref_fp64) <= max(1e-5, 2 * err(ref_fp32, ref_fp64))
+i.e. the north star's 1e-5, never tighter than the reference's own fp32 noise.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import maxnorm_err
+
+TOL = 1e-5
+
+
+def _cfg_from(g, Config):
+    return Config(dataset=str(g['cfg_dataset']), dim=int(g['cfg_dim']), n_layer=int(g['cfg_n_layer']),
+                  cutoff_l=float(g['cfg_cutoff_l']), cutoff_g=float(g['cfg_cutoff_g']), flow=str(g['cfg_flow']))
+
+
+def _batch_from(g, dev):
+    from pamnet_amd.synth import Batch
+    kw = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('in/')}
+    kw['num_graphs'] = int(kw['batch'].max()) + 1
+    return Batch(**kw).to(dev)
+
+
+def _ok(a, ref32, ref64, scale=None):
+    if scale is not None:
+        e = float(np.max(np.abs(np.asarray(a, np.float64) - ref64))) / scale
+        floor = float(np.max(np.abs(ref32.astype(np.float64) - ref64))) / scale
+    else:
+        e, floor = maxnorm_err(a, ref64), maxnorm_err(ref32, ref64)
+    return e <= max(TOL, 2 * floor), (e, floor)
+
+
+# ------------------------------------------------------------------------------------------------------ CPU (not gpu)
+def test_state_dict_layout_matches_reference(golden):
+    """Keys and shapes == the reference's (oracle.init_state_dict mirrors them; the RNA checkpoint is the real thing)."""
+    import models
+    from oracle import pamnet_oracle as O
+    for cls, small, ds in ((models.PAMNet, False, 'QM9'), (models.PAMNet_s, True, 'QM9'), (models.PAMNet, False, 'PDBbind')):
+        cfg = models.Config(dataset=ds, dim=32, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+        sd = cls(cfg).state_dict()
+        ref = O.init_state_dict(cfg, seed=0, small=small)
+        assert set(sd.keys()) == set(ref.keys())
+        assert all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in ref)
+    g = golden('rna_native')
+    cfg = models.Config(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
+    m = models.PAMNet(cfg)
+    ck = {k: torch.from_numpy(g['ckpt/' + k]) for k in g['ckpt_keys'].tolist()}
+    m.load_state_dict(ck, strict=True)
+    assert sum(p.numel() for p in m.parameters()) == 11714
+    big = models.PAMNet(models.Config(dataset='QM9', dim=128, n_layer=6, cutoff_l=5.0, cutoff_g=5.0))
+    assert sum(p.numel() for p in big.parameters() if p.requires_grad) == 3581100
+
+
+def test_invalid_dataset_raises():
+    import models
+    cfg = models.Config(dataset='nope', dim=16, n_layer=1, cutoff_l=2.0, cutoff_g=5.0)
+    m = models.PAMNet(cfg)
+
+    class D:
+        x = torch.zeros(3)
+        batch = torch.zeros(3, dtype=torch.long)
+    with pytest.raises(ValueError):
+        m(D())
+    with pytest.raises(ValueError):
+        models.PAMNet_s(models.Config(dataset='PDBbind', dim=16, n_layer=1, cutoff_l=2.0, cutoff_g=5.0))(D())
+
+
+# ------------------------------------------------------------------------------------------------------ GPU
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'needs an MI355X'
+    return torch.device('cuda:0')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,small', [('qm9_d32_l2', False), ('qm9s_d32_l2', True), ('pdbbind_d32_l2', False),
+                                        ('qm9_d128_l6', False)])
+def test_forward_vs_reference_golden(dev, golden, name, small):
+    import models
+    from oracle import pamnet_oracle as O
+    g = golden(name)
+    cfg = _cfg_from(g, models.Config)
+    model = (models.PAMNet_s if small else models.PAMNet)(cfg)
+    model.load_state_dict(O.init_state_dict(cfg, seed=int(g['seed']), small=small), strict=True)
+    model = model.to(dev)
+    data = _batch_from(g, dev)
+    with torch.no_grad():
+        out = model(data)
+    pool_in = model._node_out.cpu().numpy()
+    ok, info = _ok(pool_in, g['node_out32'], g['node_out64'])
+    assert ok, ('node_out', info)
+    if 'x_layers64' in g.files:
+        xl = torch.stack(model._x_layers).cpu().numpy()
+        ok, info = _ok(xl, g['x_layers32'], g['x_layers64'])
+        assert ok, ('x_layers', info)
+    scale = None
+    if cfg.dataset == 'PDBbind':       # complex - pocket - ligand cancellation: normalise by the summed magnitude
+        scale = max(float(np.abs(g['node_out64'][g['in/batch'] == b]).sum()) for b in range(len(g['out64'])))
+    ok, info = _ok(out.cpu().numpy(), g['out32'], g['out64'], scale)
+    assert ok, ('out', info)
+    # graph sizes are integers: exact
+    assert model._graph_cache.loc.m == int(g['num_edges_l'])
+    assert model._graph_cache.n_pair == int(g['num_pairs'])
+    if not small:
+        assert model._graph_cache.n_trip == int(g['num_triplets'])
+    # deterministic: bitwise identical on a second run
+    with torch.no_grad():
+        assert torch.equal(out, model(data))
+
+
+@pytest.mark.gpu
+def test_rna_checkpoint_end_to_end(dev, golden):
+    """Shipped checkpoint + shipped RNA-Puzzles graphs: kNN graph, both cutoffs, flow=target_to_source, mean pool."""
+    import models
+    from pamnet_amd.synth import Batch
+    g = golden('rna_native')
+    cfg = models.Config(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
+    model = models.PAMNet(cfg)
+    model.load_state_dict({k: torch.from_numpy(g['ckpt/' + k]) for k in g['ckpt_keys'].tolist()}, strict=True)
+    model = model.to(dev).eval()
+    for gid in (6, 4, 17):
+        x = torch.from_numpy(g['g%d/x' % gid]).to(dev)
+        data = Batch(x=x, batch=torch.zeros(x.size(0), dtype=torch.long, device=dev), num_graphs=1)
+        with torch.no_grad():
+            out = model(data)
+        ok, info = _ok(out.cpu().numpy(), g['g%d/out32' % gid], g['g%d/out64' % gid])
+        assert ok, (gid, info)
+        gc = model._graph_cache
+        assert gc.loc.m == int(g['g%d/num_edges_l' % gid]) and gc.n_trip == int(g['g%d/num_triplets' % gid])
+        assert gc.n_pair == int(g['g%d/num_pairs' % gid])
+        if gid == 6:
+            ok, info = _ok(torch.stack(model._x_layers).cpu().numpy(), g['g6/x_layers32'], g['g6/x_layers64'])
+            assert ok, info
+            ok, info = _ok(model._node_out.cpu().numpy(), g['g6/node_out32'], g['g6/node_out64'])
+            assert ok, info
+    # two graphs batched == each alone
+    x = torch.cat([torch.from_numpy(g['g4/x']), torch.from_numpy(g['g6/x'])]).to(dev)
+    batch = torch.cat([torch.zeros(g['g4/x'].shape[0], dtype=torch.long), torch.ones(g['g6/x'].shape[0], dtype=torch.long)])
+    with torch.no_grad():
+        out = model(Batch(x=x, batch=batch.to(dev), num_graphs=2))
+    assert maxnorm_err(out.cpu().numpy(), g['batched_4_6_out32']) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['qm9_d32_l2', 'pdbbind_d32_l2'])
+def test_gradients_vs_reference_golden(dev, golden, name):
+    """d L1-loss / d params through the HIP backward kernels vs the reference's fp64 autograd."""
+    import models
+    from oracle import pamnet_oracle as O
+    g = golden(name)
+    cfg = _cfg_from(g, models.Config)
+    model = models.PAMNet(cfg)
+    model.load_state_dict(O.init_state_dict(cfg, seed=int(g['seed'])), strict=True)
+    model = model.to(dev)
+    data = _batch_from(g, dev)
+    out = model(data)
+    loss = torch.nn.functional.l1_loss(out, data.y)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss64'])) < 2e-5 * max(1.0, abs(float(g['loss64'])))
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+    assert abs(gn / float(g['grad_norm64']) - 1) < 1e-4
+    sd = dict(model.named_parameters())
+    for k in g.files:
+        if k.startswith('grad64/'):
+            assert maxnorm_err(sd[k[7:]].grad.cpu().numpy(), g[k]) < 1e-4, k       # fp32 backward vs fp64 reference
+
+
+@pytest.mark.gpu
+def test_fresh_inputs_vs_oracle_rna_flow_variants(dev):
+    """Seeded synthetic RNA-schema graphs, both flow conventions (asymmetric kNN graph -> the flow matters)."""
+    import models
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import synth
+    b = synth.rna_batch(3, 0, 2, n_nodes=260)
+    for flow in ('target_to_source', 'source_to_target'):
+        cfg = models.Config(dataset='rna_x', dim=16, n_layer=2, cutoff_l=2.6, cutoff_g=20.0, flow=flow)
+        sd = O.init_state_dict(cfg, seed=21)
+        model = models.PAMNet(cfg)
+        model.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            out = model.to(dev)(b.to(dev))
+        ref64 = O.pamnet_forward({k: v.double() for k, v in sd.items()}, cfg, b.x.double(), b.batch, dtype=torch.float64)
+        ref32 = O.pamnet_forward(sd, cfg, b.x, b.batch)
+        ok, info = _ok(out.cpu().numpy(), ref32.numpy(), ref64.numpy())
+        assert ok, (flow, info)
+
+
+@pytest.mark.gpu
+def test_baseline_config_properties(dev):
+    """BASELINE configs[1] (QM9, d=128, L=6, B=128): properties that need no oracle at full size."""
+    import models
+    from pamnet_amd import synth
+    torch.manual_seed(0)
+    cfg = models.Config(dataset='QM9', dim=128, n_layer=6, cutoff_l=5.0, cutoff_g=5.0)
+    model = models.PAMNet(cfg).to(dev)
+    mols = [synth.qm9_molecule(0, i) for i in range(128)]
+    with torch.no_grad():
+        full = model(synth.collate(mols).to(dev))
+        assert full.shape == (128,) and torch.isfinite(full).all()
+        # molecules are independent units: any sub-batch / permutation reproduces the same per-molecule outputs
+        perm = np.random.default_rng(0).permutation(128)
+        shuf = model(synth.collate([mols[i] for i in perm]).to(dev))
+        assert maxnorm_err(shuf.cpu().numpy(), full.cpu().numpy()[perm]) < 2e-6
+        sub = model(synth.collate(mols[40:50]).to(dev))
+        assert maxnorm_err(sub.cpu().numpy(), full.cpu().numpy()[40:50]) < 2e-6
+        # rigid motion invariance (distances / angles only)
+        rot = torch.linalg.qr(torch.randn(3, 3))[0]
+        moved = synth.collate(mols)
+        moved.pos = moved.pos @ rot + torch.tensor([3.0, -2.0, 0.5])
+        assert maxnorm_err(model(moved.to(dev)).cpu().numpy(), full.cpu().numpy()) < 1e-4
