@@ -13,7 +13,11 @@
         if (e__ != hipSuccess) return (int)e__;                \
     } while (0)
 
-static inline hipStream_t as_stream(pamnet_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+// Clears the thread's sticky last-error (torch's own probing calls can leave one behind) and returns the stream.
+static inline hipStream_t as_stream(pamnet_stream_t s) {
+    (void)hipGetLastError();
+    return reinterpret_cast<hipStream_t>(s);
+}
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

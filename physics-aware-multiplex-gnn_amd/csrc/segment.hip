@@ -142,7 +142,7 @@ extern "C" int pamnet_segment_sum_f32(float* out, const float* init, const float
                                       int64_t rows, int64_t d, pamnet_stream_t stream) {
     if (rows < 0 || d <= 0 || (d & 3)) return PAMNET_EINVAL;
     if (rows == 0) return PAMNET_OK;
-    if (!out || !A || !ptr) return PAMNET_ENULL;
+    if (!out || !ptr) return PAMNET_ENULL;          // A may be null when every segment is empty (m == 0)
     hipStream_t st = as_stream(stream);
     const int64_t d4 = d / 4;
     switch (d4) {

@@ -87,6 +87,13 @@ class Transpose(object):
         self.rows = rows
 
 
+class _NoTransposeT(object):
+    ptr = perm = None
+
+
+_NoTranspose = _NoTransposeT()
+
+
 class Graph(object):
     """All index / geometry tensors one forward needs (int32 / fp32 on the device)."""
     pass
@@ -194,6 +201,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     g.pair_rows = (tp_kind == 1).nonzero().view(-1)   # rows fed to mlp_sbf1 (models.py:187)
     g.n_trip, g.n_pair = int(g.trip_rows.numel()), int(g.pair_rows.numel())
 
+    g.glob_T = g.loc_T = g.tp_T = _NoTranspose    # forward-only: backward index structures are not built
     if need_grad:
         g.glob_T = Transpose(g.glob.col, n)           # d x[j] of the global gather
         g.loc_T = Transpose(g.loc.col, n)             # d x[j] of the local gather

@@ -42,6 +42,8 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError('libpamnet_hip.so is not built (%s). Run `python __graft_entry__.py` or '
                                'pamnet_amd.build.build(); there is no CPU fallback.' % LIB_PATH)
+        import torch  # noqa: F401  -- FIRST: the library must bind to the HIP runtime torch ships (one runtime per
+        #                              process; loading /opt/rocm's copy beside torch's yields hipErrorNoDevice)
         lib = ctypes.CDLL(LIB_PATH)
         for name, types in declared_functions().items():
             fn = getattr(lib, name)            # AttributeError here = header/library mismatch: fail loudly

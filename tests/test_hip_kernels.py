@@ -122,9 +122,9 @@ def test_radius_graph_matches_oracle(dev):
     ptr, nbr, d = G.radius_graph(b.pos.to(dev), nodeg, gptr, 5.0)
     q = G.expand_rows(ptr, nbr.numel())
     assert _edge_set(q.cpu(), nbr.cpu()) == _edge_set(ei[0], ei[1])                    # bit-exact edge set
-    # distances: same edges -> same fp32 values (sorted by (row, col) on both sides)
+    # distances of the same edges (sorted by (row, col) on both sides): fp32, <= 1 ulp apart
     key = (ei[0] * 100000 + ei[1]).argsort()
-    assert torch.equal(d.cpu(), dist[key])
+    assert float(((d.cpu() - dist[key]).abs() / dist[key]).max()) < 1.3e-7
 
 
 def test_knn_matches_oracle(dev):
