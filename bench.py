@@ -93,7 +93,6 @@ def cpu_baseline(args, seconds):
     from oracle import pamnet_oracle as O
     from pamnet_amd import synth
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     cfg = O.Config(dataset='QM9', dim=args.dim, n_layer=args.n_layer, cutoff_l=5.0, cutoff_g=5.0)
     sd = O.as_params(O.init_state_dict(cfg, seed=0))
     b = synth.qm9_batch(0, 0, 32)
@@ -104,6 +103,23 @@ def cpu_baseline(args, seconds):
             for p in sd.values():
                 p.grad = None
             torch.nn.functional.l1_loss(out, b.y).backward()
+
+    # torch's intra-op pool oversubscribes badly on many-core hosts for these small ops (256 threads: ~400 s/step):
+    # calibrate the thread count on one forward each and keep the fastest -- the baseline gets its best configuration.
+    best = None
+    for nt in sorted({min(cores, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        with torch.no_grad():
+            one(False)
+            t0 = time.time()
+            one(False)
+            dt = time.time() - t0
+        if best is None or dt < best[0]:
+            best = (dt, nt)
+        if dt > 5.0:
+            break
+    threads = best[1]
+    torch.set_num_threads(threads)
     one(True)
     t0, n = time.time(), 0
     while time.time() - t0 < seconds * 0.7 or n < 2:
@@ -116,8 +132,8 @@ def cpu_baseline(args, seconds):
             one(False)
             n += 1
     fwd_mps = 32.0 * n / (time.time() - t0)
-    return dict(value=train_mps, unit='molecules/s', cores=cores, kind='port',
-                sample='oracle fwd+bwd, QM9-schema B=32 d=%d L=%d, ~%ds on %d threads' % (args.dim, args.n_layer, int(seconds), cores),
+    return dict(value=train_mps, unit='molecules/s', cores=threads, host_cores=cores, kind='port',
+                sample='oracle fwd+bwd, QM9-schema B=32 d=%d L=%d, ~%ds on %d threads (best of 8/16/32/64)' % (args.dim, args.n_layer, int(seconds), threads),
                 forward_only=fwd_mps)
 
 

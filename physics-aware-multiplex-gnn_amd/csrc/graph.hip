@@ -97,27 +97,20 @@ __global__ __launch_bounds__(256) void claim_kernel(const int32_t* __restrict__ 
     if (k < m) perm_tmp[atomicAdd(&cursor[keys[k]], 1)] = (int32_t)k;
 }
 
-// one wave per row: rank each claimed entry among its row (entries are distinct) -> ascending perm
-__global__ __launch_bounds__(256) void sort_rows_kernel(const int32_t* __restrict__ ptr,
+// one thread per claimed entry: its rank among the (distinct) entries of its row -> ascending perm inside each row.
+// Cost sum(len^2) L2-resident loads; rows here are short (node degrees), long rows (e.g. 5 embedding rows) stay parallel.
+__global__ __launch_bounds__(256) void sort_rows_kernel(const int32_t* __restrict__ keys,
+                                                        const int32_t* __restrict__ ptr,
                                                         const int32_t* __restrict__ perm_tmp,
-                                                        int32_t* __restrict__ perm, int64_t rows) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (r >= rows) return;
-    const int beg = ptr[r], end = ptr[r + 1], len = end - beg;
-    if (len <= 64) {
-        const int v = (lane < len) ? perm_tmp[beg + lane] : 0x7fffffff;
-        int rank = 0;
-        for (int t = 0; t < len; ++t) rank += (__shfl(v, t, 64) < v) ? 1 : 0;
-        if (lane < len) perm[beg + rank] = v;
-    } else {
-        for (int a = lane; a < len; a += 64) {
-            const int v = perm_tmp[beg + a];
-            int rank = 0;
-            for (int t = 0; t < len; ++t) rank += (perm_tmp[beg + t] < v) ? 1 : 0;
-            perm[beg + rank] = v;
-        }
-    }
+                                                        int32_t* __restrict__ perm, int64_t m) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    const int v = perm_tmp[q];
+    const int r = keys[v];
+    const int beg = ptr[r], end = ptr[r + 1];
+    int rank = 0;
+    for (int t = beg; t < end; ++t) rank += (perm_tmp[t] < v) ? 1 : 0;
+    perm[beg + rank] = v;
 }
 
 __device__ __forceinline__ float dist3(const float* __restrict__ pos, int64_t a, int64_t b) {
@@ -341,7 +334,7 @@ extern "C" int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t 
     PAMNET_LAUNCH_CHECK();
     hipLaunchKernelGGL(claim_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, cursor, perm_tmp);
     PAMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sort_rows_kernel, dim3(blocks_for(rows, 4)), dim3(256), 0, st, ptr, perm_tmp, perm, rows);
+    hipLaunchKernelGGL(sort_rows_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, ptr, perm_tmp, perm, m);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
