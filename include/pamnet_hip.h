@@ -135,6 +135,35 @@ int pamnet_fuse_pool_bwd_f32(const float* outs, const float* atts, int64_t n_lay
                              const int32_t* node_graph, const int32_t* gptr, int32_t mean, const float* grad_graph,
                              float* grad_outs, float* grad_atts, pamnet_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Fused dense chains (dim = 128 only), fp32 MFMA.  Weight pointers are HOST arrays of DEVICE pointers to row-major
+ * [out=128][in] blocks (torch Linear layout, row stride 128 unless an ld is given).
+ *
+ * node_tail: the 10-Linear update stack + heads shared by both layer kinds
+ *   (layers/global_message_passing.py:39-50, layers/local_message_passing.py:55-66; Res: layers/basic.py:25-33):
+ *   weights/biases order: mlp_x2, res1.0, res1.1, res2.0, res2.1, res3.0, res3.1, mlp_out.0, mlp_out.1, mlp_out.2.
+ *   Saves Z[10][n][128] (pre-activations) and R[2][n][128] (r1, r2) for the backward.
+ * node_pre: x1 = SiLU(mlp_x1 x) and the node-level halves P = x1 * Wp_b^T (b < nblk <= 4) of the split message MLPs
+ *   (mlp_m / mlp_m_ji / mlp_m_kj on [x_i | x_j | e]: layers/global_message_passing.py:52-56, local...:46-48).
+ * wgrad_batched: dW_j = dZ_j^T * A_j (A_j optionally SiLU'd on load), db_j = colsum(dZ_j) for up to 24 jobs.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int64_t n, const float* const* weights,
+                             const float* const* biases, const float* w_out, const float* b_out, const float* w_att,
+                             float* Z, float* R, float* x_out, float* out, float* att, pamnet_stream_t stream);
+int pamnet_node_tail_bwd_f32(const float* d_xout, const float* d_out, const float* d_att, int64_t n,
+                             const float* const* weights, const float* w_out, const float* w_att, const float* Z,
+                             float* dZ, float* d_x2, float* d_resx, float* head_partial, float* d_wout, float* d_watt,
+                             float* d_bout, pamnet_stream_t stream);
+int pamnet_node_pre_fwd_f32(const float* x, int64_t n, const float* Wx1, const float* bx1, const float* const* wp,
+                            int64_t ldwp, int64_t nblk, float* Zx1, float* x1, float* P, pamnet_stream_t stream);
+int pamnet_node_pre_bwd_f32(const float* dP, const float* dx1_direct, const float* d_add, int64_t n, const float* Wx1,
+                            const float* const* wp, int64_t ldwp, int64_t nblk, const float* Zx1, float* dZx1,
+                            float* dx, pamnet_stream_t stream);
+int pamnet_wgrad_batched_f32(int64_t njobs, const float* const* dZ, const int64_t* ld_dz, const float* const* A,
+                             const int64_t* ld_a, const int32_t* a_mode, const int64_t* rows, float* const* dW,
+                             const int64_t* ld_dw, float* const* db, int64_t split, float* partial,
+                             pamnet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

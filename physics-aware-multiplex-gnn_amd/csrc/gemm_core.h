@@ -1,0 +1,141 @@
+// fp32 MFMA tile-GEMM core shared by the fused PAMNet kernels (gfx950).
+//
+// Every dense layer of PAMNet is  Y[rows, 128] = X[rows, K] * W[128, K]^T  with K = 128 (layers/basic.py:19-22 with
+// dim=128; the 3*dim-wide message MLPs are split algebraically into 128-wide blocks).  fp32 inputs are mandatory
+// (1e-5 parity), so the matrix unit is v_mfma_f32_16x16x4_f32: exact fp32, 32-cycle issue, 157 TF/s chip peak.
+//
+// Work split: a workgroup = 4 waves owns a tile of BM = 16*MT rows; wave w owns output columns [32w, 32w+32) (two
+// 16-wide N tiles).  The X tile lives in LDS ([BM][LDT] floats, LDT = 132: the 4-float pad spreads ds_read_b128 rows
+// over the 64 banks).  W is streamed straight from L2 as MFMA B fragments -- it is shared by every workgroup and
+// stays L2 resident (64 KB per matrix) -- so LDS holds activations only and chains of layers keep their row tile
+// on-chip from the first GEMM to the last.
+//
+// Fragment mapping (cdna_hip_programming.md section 3): for 16x16x4, lane l supplies A[i = l&15][k = l>>4] and
+// B[k = l>>4][j = l&15]; D[reg r] is row (l>>4)*4 + r, column l&15.  k is a summation index, so each lane may fetch
+// four consecutive k (one 16-byte load) and feed them to four consecutive MFMAs: lane l covers
+// k = 16q + 4*(l>>4) + t, t = 0..3, identically for A (LDS row-major) and W ([out][in] row-major) -- both operands are
+// read as float4 with no transposition anywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pamnet {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int DIM = 128;          // feature width handled by the fused kernels
+constexpr int LDT = 132;          // LDS tile leading dimension (floats)
+constexpr int WG = 256;           // threads per workgroup (4 waves)
+
+__device__ __forceinline__ float silu(float z) { return z / (1.0f + expf(-z)); }
+// d/dz [z * sigmoid(z)] = s * (1 + z * (1 - s))
+__device__ __forceinline__ float dsilu(float z) {
+    const float s = 1.0f / (1.0f + expf(-z));
+    return s * (1.0f + z * (1.0f - s));
+}
+
+template <int MT>
+__device__ __forceinline__ void acc_zero(f32x4 (&acc)[MT][2]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// acc[m][n] += As[m*16 .. , 0:128] * W(block)^T for this wave's 32 output columns [wcol0, wcol0 + 32).
+//   TRANS = false: W is [out][in] (row stride ldw): Y = X * W^T   (forward:  Linear)
+//   TRANS = true : W is [in'][out'] and we need Y = X * W, i.e. B[k][j] = W[k][j] (backward: dX = dZ * W)
+template <int MT, bool TRANS>
+__device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ W, int ldw, int wcol0,
+                                         f32x4 (&acc)[MT][2]) {
+    const int lane = threadIdx.x & 63;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const float* ap = As + r16 * LDT + 4 * kg;
+#pragma unroll
+    for (int q = 0; q < DIM / 16; ++q) {
+        float4 b0, b1;
+        if (!TRANS) {
+            const float* wp = W + (size_t)(wcol0 + r16) * ldw + 4 * kg + 16 * q;
+            b0 = *reinterpret_cast<const float4*>(wp);
+            b1 = *reinterpret_cast<const float4*>(wp + (size_t)16 * ldw);
+        } else {
+            const float* wp = W + (size_t)(16 * q + 4 * kg) * ldw + wcol0 + r16;
+            b0 = make_float4(wp[0], wp[ldw], wp[2 * (size_t)ldw], wp[3 * (size_t)ldw]);
+            b1 = make_float4(wp[16], wp[ldw + 16], wp[2 * (size_t)ldw + 16], wp[3 * (size_t)ldw + 16]);
+        }
+        float4 a[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const float4*>(ap + m * 16 * LDT + 16 * q);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, b0.x, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, b1.x, acc[m][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, b0.y, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, b1.y, acc[m][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, b0.z, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, b1.z, acc[m][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, b0.w, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, b1.w, acc[m][1], 0, 0, 0);
+        }
+    }
+}
+
+// Scatter the wave's accumulators (+ optional per-column bias) into an LDS tile Ds[BM][LDT], columns [dcol0, dcol0+32).
+template <int MT>
+__device__ __forceinline__ void acc_to_lds(const f32x4 (&acc)[MT][2], float* __restrict__ Ds, int dcol0,
+                                           const float* __restrict__ bias /* indexed by dcol, may be null */) {
+    const int lane = threadIdx.x & 63;
+    const int r16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int col = dcol0 + 16 * n + r16;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float* d = Ds + (m * 16 + kg * 4) * LDT + col;
+            d[0 * LDT] = acc[m][n][0] + bv;
+            d[1 * LDT] = acc[m][n][1] + bv;
+            d[2 * LDT] = acc[m][n][2] + bv;
+            d[3 * LDT] = acc[m][n][3] + bv;
+        }
+    }
+}
+
+// Cooperative row-major sweep over a [BM][128] tile: thread t owns float4 column c4 = t & 31 of rows (t >> 5) + 8*i.
+// f(row_in_tile, c4) is called BM/8 times per thread; global accesses inside f are 512-byte coalesced rows.
+template <int BM, typename F>
+__device__ __forceinline__ void sweep_rows(F&& f) {
+    const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < BM / 8; ++i) f(r0 + 8 * i, c4);
+}
+
+__device__ __forceinline__ float4 lds4(const float* tile, int row, int c4) {
+    return *reinterpret_cast<const float4*>(tile + row * LDT + 4 * c4);
+}
+__device__ __forceinline__ void st_lds4(float* tile, int row, int c4, float4 v) {
+    *reinterpret_cast<float4*>(tile + row * LDT + 4 * c4) = v;
+}
+__device__ __forceinline__ float4 ldg4(const float* p, int64_t row, int ld, int c4) {
+    return *reinterpret_cast<const float4*>(p + row * ld + 4 * c4);
+}
+__device__ __forceinline__ void stg4(float* p, int64_t row, int ld, int c4, float4 v) {
+    *reinterpret_cast<float4*>(p + row * ld + 4 * c4) = v;
+}
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 f4silu(float4 z) { return make_float4(silu(z.x), silu(z.y), silu(z.z), silu(z.w)); }
+__device__ __forceinline__ float4 f4dsilu(float4 z) { return make_float4(dsilu(z.x), dsilu(z.y), dsilu(z.z), dsilu(z.w)); }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+}  // namespace pamnet

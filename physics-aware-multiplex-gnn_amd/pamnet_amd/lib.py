@@ -28,10 +28,10 @@ def declared_functions(header=HEADER):
         if args and args != 'void':
             for a in args.split(','):
                 a = a.replace('const', ' ').strip()
-                base = a.rsplit(None, 1)[0].strip() if not a.endswith('*') else a
-                if '*' in a:
-                    base = a.split('*')[0].strip() + '*'
-                types.append(_CT[base])
+                if '*' in a:                      # every pointer (device or host array) travels as void*
+                    types.append(ctypes.c_void_p)
+                else:
+                    types.append(_CT[a.rsplit(None, 1)[0].strip()])
         out[name] = types
     return out
 

@@ -15,7 +15,17 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+import os
+
+from . import fused, ops
+
+# 'fused' (default): fp32-MFMA chain kernels for dim=128.  'torch': the same maths with dense layers on torch ops --
+# kept as the plain-PyTorch fp32 reference the kernel tests compare against (GPU only; not a CPU fallback).
+IMPL = os.environ.get('PAMNET_IMPL', 'fused')
+
+
+def _fused(x):
+    return IMPL == 'fused' and x.is_cuda and x.size(-1) == fused.D
 
 
 class Act(nn.Module):
@@ -75,6 +85,8 @@ def res_apply(res, x):
 
 def update_and_heads(layer, x, res_x):
     """Shared tail of both layer kinds (global_message_passing.py:39-50 / local_message_passing.py:55-66)."""
+    if _fused(x):
+        return fused.node_tail(layer, x, res_x)
     x = mlp_apply(layer.mlp_x2, x)
     x = res_apply(layer.res1, x) + res_x
     x = res_apply(layer.res2, x)
@@ -116,9 +128,12 @@ class GlobalMP(_LayerBase):
     def forward(self, x, e, g):
         d = self.dim
         res_x = x
-        x = mlp_apply(self.mlp_x1, x)
         wm, bm = self.mlp_m[0][0].weight, self.mlp_m[0][0].bias
-        p = F.linear(x, torch.cat([wm[:, :d], wm[:, d:2 * d]], 0))               # [N, 2d]: W_i x | W_j x
+        if _fused(x):
+            x, p = fused.node_pre(x, self.mlp_x1[0][0], [wm[:, :d], wm[:, d:2 * d]], 3 * d)
+        else:
+            x = mlp_apply(self.mlp_x1, x)
+            p = F.linear(x, torch.cat([wm[:, :d], wm[:, d:2 * d]], 0))           # [N, 2d]: W_i x | W_j x
         q = F.linear(e, torch.cat([wm[:, 2 * d:], self.W_edge_attr.weight], 0),   # [E_g, 2d]: W_e e + b | W_ea e
                      torch.cat([bm, torch.zeros_like(bm)]))
         csr = g.glob
@@ -154,12 +169,15 @@ class LocalMP(_LayerBase):
     def forward(self, x, rbf, sbf, g):
         d = self.dim
         res_x = x
-        x = mlp_apply(self.mlp_x1, x)
         lin_ji = self.mlp_m_ji[0][0]
         lin_kj = (self.mlp_m_jj if self.small else self.mlp_m_kj)[0][0]
         wj, wk = lin_ji.weight, lin_kj.weight
         # node-level projections [N, 4d]: ji_i | kj_i | ji_j | kj_j ; edge-level [E_l, 4d]: ji_e | kj_e | lin_rbf | lin_rbf_out
-        p = F.linear(x, torch.cat([wj[:, :d], wk[:, :d], wj[:, d:2 * d], wk[:, d:2 * d]], 0))
+        if _fused(x):
+            x, p = fused.node_pre(x, self.mlp_x1[0][0], [wj[:, :d], wk[:, :d], wj[:, d:2 * d], wk[:, d:2 * d]], 3 * d)
+        else:
+            x = mlp_apply(self.mlp_x1, x)
+            p = F.linear(x, torch.cat([wj[:, :d], wk[:, :d], wj[:, d:2 * d], wk[:, d:2 * d]], 0))
         zero = torch.zeros_like(lin_ji.bias)
         q = F.linear(rbf, torch.cat([wj[:, 2 * d:], wk[:, 2 * d:], self.lin_rbf.weight, self.lin_rbf_out.weight], 0),
                      torch.cat([lin_ji.bias, lin_kj.bias, zero, zero]))
