@@ -137,7 +137,7 @@ int pamnet_fuse_pool_bwd_f32(const float* outs, const float* atts, int64_t n_lay
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Fused dense chains (dim = 128 only), fp32 MFMA.  Weight pointers are HOST arrays of DEVICE pointers to row-major
- * [out=128][in] blocks (torch Linear layout, row stride 128 unless an ld is given).
+ * [out=128][in] blocks (the layout of an nn.Linear weight; row stride 128 unless an ld is given).
  *
  * node_tail: the 10-Linear update stack + heads shared by both layer kinds
  *   (layers/global_message_passing.py:39-50, layers/local_message_passing.py:55-66; Res: layers/basic.py:25-33):
@@ -163,6 +163,38 @@ int pamnet_wgrad_batched_f32(int64_t njobs, const float* const* dZ, const int64_
                              const int64_t* ld_a, const int32_t* a_mode, const int64_t* rows, float* const* dW,
                              const int64_t* ld_dw, float* const* db, int64_t split, float* partial,
                              pamnet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Fused edge-level kernels (dim = 128), fp32 MFMA.  P planes are node_pre outputs ([N][128] each).
+ * global edge (layers/global_message_passing.py:52-56 + PyG propagate gathers):
+ *     z = W_e e + b_m + Pi[row_of] + Pj[col];  ea = W_ea e;  msg = SiLU(z) * ea          (z, ea saved for backward)
+ *   bwd: dm = d_agg[row_of]; dz = dm*ea*SiLU'(z); dea = dm*SiLU(z); d_e (+)= dz W_e + dea W_ea
+ * local edge (layers/local_message_passing.py:46-48,53):  Wq = {W_ji[:,2d:], W_kj[:,2d:], lin_rbf, lin_rbf_out},
+ *     P = {ji_i, kj_i, ji_j, kj_j}:  z_ji, z_kj, q2 = lin_rbf r, q3 = lin_rbf_out r, m_ji = SiLU(z_ji),
+ *     m_nb = SiLU(z_kj) * q2
+ * mlp2 (layers/local_message_passing.py:49 `mlp_sbf`): y = SiLU(W2 SiLU(W1 x + b1) + b2); z1, z2 saved.
+ * `accumulate` != 0: the input-gradient output is added to (edge embeddings are shared by all layers).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pamnet_global_edge_fwd_f32(const float* e, int64_t n_edges, const float* We, int64_t ld_we, const float* bm,
+                               const float* Wea, int64_t ld_wea, const float* Pi, const float* Pj,
+                               const int32_t* row_of, const int32_t* col, float* z, float* ea, float* msg,
+                               pamnet_stream_t stream);
+int pamnet_global_edge_bwd_f32(const float* d_agg, const int32_t* row_of, int64_t n_edges, const float* z,
+                               const float* ea, const float* We, int64_t ld_we, const float* Wea, int64_t ld_wea,
+                               float* dz, float* dea, float* d_e, int32_t accumulate, pamnet_stream_t stream);
+int pamnet_local_edge_fwd_f32(const float* rbf, int64_t n_edges, const float* const* Wq, const int64_t* ldq,
+                              const float* b_ji, const float* b_kj, const float* const* P, const int32_t* row_of,
+                              const int32_t* col, float* z_ji, float* z_kj, float* q2, float* q3, float* m_ji,
+                              float* m_nb, pamnet_stream_t stream);
+int pamnet_local_edge_bwd_f32(const float* d_mji, const float* d_mnb, const float* d_q3, int64_t n_edges,
+                              const float* z_ji, const float* z_kj, const float* q2, const float* const* Wq,
+                              const int64_t* ldq, float* dz_ji, float* dz_kj, float* dq2, float* d_rbf,
+                              int32_t accumulate, pamnet_stream_t stream);
+int pamnet_mlp2_fwd_f32(const float* x, int64_t rows, const float* W1, const float* b1, const float* W2,
+                        const float* b2, float* z1, float* z2, float* y, pamnet_stream_t stream);
+int pamnet_mlp2_bwd_f32(const float* dy, int64_t rows, const float* z1, const float* z2, const float* W1,
+                        const float* W2, float* dz1, float* dz2, float* dx, int32_t accumulate,
+                        pamnet_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(WG) void node_pre_fwd_kernel(const float* __restric
     });
     __syncthreads();
     const float* wps[4] = {wp0, wp1, wp2, wp3};
-    const int ldp = nblk * DIM;
+    const int64_t plane_p = n * DIM;                       // P is stored as nblk planes [N][128]
     for (int b = 0; b < nblk; ++b) {
         f32x4 acc[1][2];
         acc_zero<1>(acc);
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(WG) void node_pre_fwd_kernel(const float* __restric
         __syncthreads();
         sweep_rows<BMN>([&](int r, int c4) {
             const int64_t g = row0 + r;
-            if (g < n) stg4(P + b * DIM, g, ldp, c4, lds4(S2, r, c4));
+            if (g < n) stg4(P + (int64_t)b * plane_p, g, DIM, c4, lds4(S2, r, c4));
         });
         __syncthreads();
     }
@@ -289,14 +289,14 @@ __global__ __launch_bounds__(WG) void node_pre_bwd_kernel(const float* __restric
     float* S2 = lds + 2 * SLOT;
     const int64_t row0 = (int64_t)blockIdx.x * BMN;
     const float* wps[4] = {wp0, wp1, wp2, wp3};
-    const int ldp = nblk * DIM;
+    const int64_t plane_p = n * DIM;                       // dP: nblk planes [N][128]
     const int wcol0 = (threadIdx.x >> 6) * 32;
     f32x4 acc[1][2];
     acc_zero<1>(acc);
     for (int b = 0; b < nblk; ++b) {
         sweep_rows<BMN>([&](int r, int c4) {
             const int64_t g = row0 + r;
-            st_lds4(S0, r, c4, g < n ? ldg4(dP + b * DIM, g, ldp, c4) : f4zero());
+            st_lds4(S0, r, c4, g < n ? ldg4(dP + (int64_t)b * plane_p, g, DIM, c4) : f4zero());
         });
         __syncthreads();
         mma_tile<1, true>(S0, wps[b], ldwp, wcol0, acc);      // accumulate over the projection blocks

@@ -30,13 +30,20 @@ struct WBatch {
     WJob job[MAXJ];
 };
 
+__host__ __device__ inline int job_split(int64_t rows, int split) {
+    const int64_t want = (rows + 511) / 512;
+    return (int)(want < 1 ? 1 : (want > split ? split : want));
+}
+
 __global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, int split, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float lds[2 * RB * LDW];
     float* Zs = lds;
     float* As = lds + RB * LDW;
     const WJob jb = batch.job[blockIdx.y];
     const int s = blockIdx.x;
-    const int64_t chunk = ((jb.rows + split - 1) / split + RB - 1) / RB * RB;
+    const int js = job_split(jb.rows, split);               // short jobs use (and later sum) fewer partial slots
+    if (s >= js) return;
+    const int64_t chunk = ((jb.rows + js - 1) / js + RB - 1) / RB * RB;
     const int64_t beg = (int64_t)s * chunk;
     const int64_t end = beg + chunk < jb.rows ? beg + chunk : jb.rows;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -103,13 +110,14 @@ __global__ __launch_bounds__(WG) void wgrad_reduce_kernel(WBatch batch, int spli
     const WJob jb = batch.job[blockIdx.y];
     const float* base = partial + (int64_t)blockIdx.y * split * (DIM * DIM + DIM);
     const int t = blockIdx.x * WG + threadIdx.x;                 // 0 .. 128*128 + 128
+    const int js = job_split(jb.rows, split);
     if (t < DIM * DIM) {
         float s = 0.f;
-        for (int q = 0; q < split; ++q) s += base[(int64_t)q * (DIM * DIM + DIM) + t];
+        for (int q = 0; q < js; ++q) s += base[(int64_t)q * (DIM * DIM + DIM) + t];
         jb.dW[(int64_t)(t >> 7) * jb.ld_dw + (t & 127)] = s;
     } else if (t < DIM * DIM + DIM && jb.db) {
         double s = 0.0;
-        for (int q = 0; q < split; ++q) s += (double)base[(int64_t)q * (DIM * DIM + DIM) + t];
+        for (int q = 0; q < js; ++q) s += (double)base[(int64_t)q * (DIM * DIM + DIM) + t];
         jb.db[t - DIM * DIM] = (float)s;
     }
 }

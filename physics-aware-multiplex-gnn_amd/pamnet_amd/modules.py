@@ -127,13 +127,12 @@ class GlobalMP(_LayerBase):
 
     def forward(self, x, e, g):
         d = self.dim
+        if _fused(x):
+            return fused.global_layer(self, x, e, g)          # whole layer: 4 fused launches forward
         res_x = x
         wm, bm = self.mlp_m[0][0].weight, self.mlp_m[0][0].bias
-        if _fused(x):
-            x, p = fused.node_pre(x, self.mlp_x1[0][0], [wm[:, :d], wm[:, d:2 * d]], 3 * d)
-        else:
-            x = mlp_apply(self.mlp_x1, x)
-            p = F.linear(x, torch.cat([wm[:, :d], wm[:, d:2 * d]], 0))           # [N, 2d]: W_i x | W_j x
+        x = mlp_apply(self.mlp_x1, x)
+        p = F.linear(x, torch.cat([wm[:, :d], wm[:, d:2 * d]], 0))               # [N, 2d]: W_i x | W_j x
         q = F.linear(e, torch.cat([wm[:, 2 * d:], self.W_edge_attr.weight], 0),   # [E_g, 2d]: W_e e + b | W_ea e
                      torch.cat([bm, torch.zeros_like(bm)]))
         csr = g.glob
@@ -168,16 +167,15 @@ class LocalMP(_LayerBase):
 
     def forward(self, x, rbf, sbf, g):
         d = self.dim
+        if _fused(x):
+            return fused.local_layer(self, x, rbf, sbf, g)    # whole layer: 6 fused launches forward
         res_x = x
         lin_ji = self.mlp_m_ji[0][0]
         lin_kj = (self.mlp_m_jj if self.small else self.mlp_m_kj)[0][0]
         wj, wk = lin_ji.weight, lin_kj.weight
         # node-level projections [N, 4d]: ji_i | kj_i | ji_j | kj_j ; edge-level [E_l, 4d]: ji_e | kj_e | lin_rbf | lin_rbf_out
-        if _fused(x):
-            x, p = fused.node_pre(x, self.mlp_x1[0][0], [wj[:, :d], wk[:, :d], wj[:, d:2 * d], wk[:, d:2 * d]], 3 * d)
-        else:
-            x = mlp_apply(self.mlp_x1, x)
-            p = F.linear(x, torch.cat([wj[:, :d], wk[:, :d], wj[:, d:2 * d], wk[:, d:2 * d]], 0))
+        x = mlp_apply(self.mlp_x1, x)
+        p = F.linear(x, torch.cat([wj[:, :d], wk[:, :d], wj[:, d:2 * d], wk[:, d:2 * d]], 0))
         zero = torch.zeros_like(lin_ji.bias)
         q = F.linear(rbf, torch.cat([wj[:, 2 * d:], wk[:, 2 * d:], self.lin_rbf.weight, self.lin_rbf_out.weight], 0),
                      torch.cat([lin_ji.bias, lin_kj.bias, zero, zero]))

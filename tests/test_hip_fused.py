@@ -67,28 +67,61 @@ def test_node_tail_and_pre(dev, n):
             assert ok, (nm, info)
 
 
-@pytest.mark.parametrize('n', [5, 2286])
-def test_node_pre(dev, n):
-    from pamnet_amd import fused
-    torch.manual_seed(3)
-    lin = torch.nn.Linear(D, D).to(dev)
-    wm = torch.randn(D, 3 * D, device=dev, requires_grad=True)
-    wk = torch.randn(D, 3 * D, device=dev, requires_grad=True)
-    x = torch.randn(n, D, device=dev, requires_grad=True)
-    blocks = lambda: [wm[:, :D], wk[:, :D], wm[:, D:2 * D], wk[:, D:2 * D]]
-    x1, P = fused.node_pre(x, lin, blocks(), 3 * D)
-    w1, w2 = torch.randn_like(x1), torch.randn_like(P)
-    ((x1 * w1).sum() + (P * w2).sum()).backward()
-    got = [x1.detach(), P.detach(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone(), wm.grad.clone(), wk.grad.clone()]
-    res = {}
-    for dt in (torch.float32, torch.float64):
-        xx = x.detach().to(dt).requires_grad_()
-        W, b = lin.weight.detach().to(dt).requires_grad_(), lin.bias.detach().to(dt).requires_grad_()
-        m, k = wm.detach().to(dt).requires_grad_(), wk.detach().to(dt).requires_grad_()
-        a = torch.nn.functional.silu(xx @ W.t() + b)
-        p = a @ torch.cat([m[:, :D], k[:, :D], m[:, D:2 * D], k[:, D:2 * D]], 0).t()
-        ((a * w1.to(dt)).sum() + (p * w2.to(dt)).sum()).backward()
-        res[dt] = [a.detach(), p.detach(), xx.grad, W.grad, b.grad, m.grad, k.grad]
-    for a, b, c in zip(got, res[torch.float32], res[torch.float64]):
-        ok, info = _ok(a, b, c, floor=5e-6)
-        assert ok, info
+def _layer_case(dev, n_mol, seed):
+    from pamnet_amd import graph as G, synth
+    b = synth.qm9_batch(seed, 0, n_mol).to(dev)
+    g = G.build_graph('QM9', 5.0, 5.0, 'source_to_target', b.x, b.batch, b.pos, b.edge_index, num_graphs=n_mol)
+    gen = torch.Generator().manual_seed(seed)
+    mk = lambda r: (0.5 * torch.randn(r, D, generator=gen)).to(dev).requires_grad_()
+    return g, mk(g.n), mk(g.glob.m), mk(g.loc.m), mk(g.tp.m)
+
+
+def _oracle_layer(kind, layer, g, x, e, rbf, sbf, w):
+    """fp64 CPU evaluation of the same layer through the oracle (reference formulation with cat / Linear on 3*dim)."""
+    from oracle import pamnet_oracle as O
+    sd = {('L.' + k): v.detach().cpu().double().requires_grad_() for k, v in layer.state_dict().items()}
+    ins = [t.detach().cpu().double().requires_grad_() for t in (x, e, rbf, sbf)]
+    if kind == 'global':
+        ei = torch.stack([g.glob.col.cpu().long(), g.glob.row_of.cpu().long()])
+        outs = O.global_mp(sd, 'L', ins[0], ins[1], ei, 'source_to_target')
+    else:
+        ei = torch.stack([g.loc.col.cpu().long(), g.loc.row_of.cpu().long()])
+        empty_i = torch.zeros(0, dtype=torch.long)
+        outs = O.local_mp(sd, 'L', ins[0], ins[2], ins[3], ins[3][:0], g.tp.col.cpu().long(), g.tp.row_of.cpu().long(),
+                          empty_i, empty_i, ei)
+    outs = [outs[0], outs[1].view(-1), outs[2].view(-1)]
+    sum((o * ww.cpu().double()).sum() for o, ww in zip(outs, w)).backward()
+    return outs, ins, sd
+
+
+@pytest.mark.parametrize('n_mol', [3, 128])
+@pytest.mark.parametrize('kind', ['global', 'local'])
+def test_full_layer_fused_vs_torch_vs_fp64(dev, kind, n_mol):
+    """Whole message-passing layer through the fused kernels: outputs, input gradients and every parameter gradient."""
+    from pamnet_amd import modules
+    torch.manual_seed(11)
+    layer = (modules.GlobalMP(D) if kind == 'global' else modules.LocalMP(D)).to(dev)
+    g, x, e, rbf, sbf = _layer_case(dev, n_mol, 5)
+    ins = [x, e, rbf, sbf]
+    params = list(layer.parameters())
+    fn = (lambda: layer(x, e, g)) if kind == 'global' else (lambda: layer(x, rbf, sbf, g))
+    of, gf = _run(fn, ins, params, 'fused')
+    ot, gt = _run(fn, ins, params, 'torch')
+    gen = torch.Generator().manual_seed(7)
+    w = [torch.randn(o.shape, generator=gen, dtype=torch.float64) for o in of]
+    o64, i64, sd64 = _oracle_layer(kind, layer, g, x, e, rbf, sbf, w)
+    for a, b, c in zip(of, ot, o64):
+        ok, info = _ok(a, b, c, floor=3e-6)
+        assert ok, ('out', info)
+    g64 = [t.grad for t in i64] + [sd64['L.' + k].grad for k, _ in layer.named_parameters()]
+    names = ['x', 'e', 'rbf', 'sbf'] + [k for k, _ in layer.named_parameters()]
+    for nm, a, b, c in zip(names, gf, gt, g64):
+        if a is None and c is None:
+            continue
+        assert a is not None and c is not None, nm
+        ok, info = _ok(a, b, c, floor=1e-5)
+        assert ok, (nm, info)
+    # deterministic
+    of2, gf2 = _run(fn, ins, params, 'fused')
+    assert all(torch.equal(a, b) for a, b in zip(of, of2))
+    assert all(torch.equal(a, b) for a, b in zip(gf, gf2) if a is not None)
