@@ -196,6 +196,34 @@ int pamnet_mlp2_bwd_f32(const float* dy, int64_t rows, const float* z1, const fl
                         const float* W2, float* dz1, float* dz2, float* dx, int32_t accumulate,
                         pamnet_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Layer-stack engine: the n_layer x (global, local) loop of PAMNet.forward (models.py:196-204) in ONE call per
+ * direction (dim = 128).  Host-side C++ enqueues ~10 (fwd) / ~20 (bwd) fused launches per layer pair on `stream`.
+ *   sizes      : {n, e_g, e_l, tp}
+ *   graph_idx  : 15 device index arrays {g_ptr, g_row, g_col, gT_ptr, gT_perm, l_ptr, l_row, l_col, lT_ptr, lT_perm,
+ *                tp_ptr, tp_row, tp_col, tpT_ptr, tpT_perm}  (the *T_* entries are only read by the backward)
+ *   gparams    : n_layer x 28 device pointers  {mlp_x1.W, .b, mlp_m.W [128,384], .b, W_edge_attr.W, tail W[10], b[10],
+ *                W_out.weight, W_out.bias, W}
+ *   lparams    : n_layer x 35 device pointers  {mlp_x1.W, .b, mlp_m_ji.W, .b, mlp_m_kj.W, .b, mlp_sbf.0.W, .b,
+ *                mlp_sbf.1.W, .b, lin_rbf.W, lin_rbf_out.W, tail ...}
+ *   saved/temp : caller-owned arenas sized by pamnet_stack_workspace (floats); `saved` must survive until the backward
+ *   outs/atts  : [2*n_layer, n] rows ordered (global_0, local_0, global_1, ...)
+ * Backward: ggrads / lgrads are gradient buffers laid out like the parameter tables (written, not accumulated);
+ * d_x0, d_eg, d_rbf, d_sbf are written.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pamnet_stack_workspace(int64_t n, int64_t eg, int64_t el, int64_t tp, int64_t n_layer, int64_t* saved_floats,
+                           int64_t* temp_floats_out);
+int pamnet_stack_layout(int64_t n, int64_t eg, int64_t el, int64_t tp, int64_t* layout);
+int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, int64_t n_layer, const float* x0,
+                         const float* e_g, const float* rbf_e, const float* e_sbf, const float* const* gparams,
+                         const float* const* lparams, float* saved, float* temp, float* outs, float* atts,
+                         pamnet_stream_t stream);
+int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, int64_t n_layer, const float* x0,
+                         const float* e_g, const float* rbf_e, const float* e_sbf, const float* const* gparams,
+                         const float* const* lparams, const float* saved, float* temp, const float* d_outs,
+                         const float* d_atts, float* const* ggrads, float* const* lgrads, float* d_x0, float* d_eg,
+                         float* d_rbf, float* d_sbf, pamnet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

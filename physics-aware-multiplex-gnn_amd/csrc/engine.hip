@@ -1,0 +1,333 @@
+// Layer-stack engine: the whole n_layer x (global, local) message-passing loop of PAMNet.forward (models.py:196-204)
+// -- forward or backward -- enqueued by ONE C call.
+//
+// The reference drives this loop from Python, one small op at a time (~150 launches per layer pair); even with fused
+// kernels a Python-level loop leaves the MI355X idle behind the interpreter.  Here the host side is a straight C++
+// sequence of ~10 (forward) / ~20 (backward) kernel launches per layer pair on the caller's stream, working out of two
+// caller-owned arenas:
+//   saved : activations the backward needs (pre-activations, gates, residual taps), one slab per layer
+//   temp  : scratch reused by every layer (projections, messages, gradient staging, split-K partials)
+// Nothing is allocated, no state is kept, nothing synchronises: the caller sizes the arenas with
+// pamnet_stack_workspace and keeps them alive until the backward has been enqueued.
+// The shared edge embeddings (e_g, rbf_e, e_sbf feed all layers) get their gradients accumulated in place by the
+// backward kernels themselves (accumulate flag), in a fixed layer order -> deterministic.
+#include "common.h"
+
+namespace {
+
+constexpr int64_t D = 128;
+constexpr int NG = 28;      // pointers per global layer: Wx1 bx1 Wm bm Wea | tail W[10] b[10] w_out b_out w_att
+constexpr int NL = 35;      // pointers per local layer : Wx1 bx1 Wji bji Wkj bkj Ws1 bs1 Ws2 bs2 Wlr Wlo | tail ...
+constexpr int GT = 5, LT = 12;   // offset of the tail block
+
+struct Graph {
+    int64_t n, eg, el, tp;
+    const int32_t *g_ptr, *g_row, *g_col, *gT_ptr, *gT_perm;
+    const int32_t *l_ptr, *l_row, *l_col, *lT_ptr, *lT_perm;
+    const int32_t *t_ptr, *t_row, *t_col, *tT_ptr, *tT_perm;
+};
+
+inline int64_t al(int64_t x) { return (x + 63) / 64 * 64; }       // 256-byte aligned slabs
+
+struct GlobalSaved { float *Zx1, *z, *ea, *x2, *Z, *R, *xout; };
+struct LocalSaved { float *Zx1, *zji, *zkj, *q2, *q3, *mnb, *mt, *s, *z1, *z2, *x2, *Z, *R, *xout; };
+
+inline int64_t global_saved_floats(const Graph& g) { return al(g.n * D) * 15 + al(g.eg * D) * 2; }
+inline int64_t local_saved_floats(const Graph& g) { return al(g.n * D) * 15 + al(g.el * D) * 6 + al(g.tp * D) * 3; }
+
+inline GlobalSaved carve_global(float* p, const Graph& g) {
+    GlobalSaved s;
+    const int64_t nd = al(g.n * D), ed = al(g.eg * D);
+    s.Zx1 = p; p += nd;
+    s.z = p; p += ed;
+    s.ea = p; p += ed;
+    s.x2 = p; p += nd;
+    s.Z = p; p += 10 * nd;       // NB: planes are n*D apart (not padded): 10*nd >= 10*n*D
+    s.R = p; p += 2 * nd;
+    s.xout = p;
+    return s;
+}
+
+inline LocalSaved carve_local(float* p, const Graph& g) {
+    LocalSaved s;
+    const int64_t nd = al(g.n * D), ed = al(g.el * D), td = al(g.tp * D);
+    s.Zx1 = p; p += nd;
+    s.zji = p; p += ed;
+    s.zkj = p; p += ed;
+    s.q2 = p; p += ed;
+    s.q3 = p; p += ed;
+    s.mnb = p; p += ed;
+    s.mt = p; p += ed;
+    s.s = p; p += td;
+    s.z1 = p; p += td;
+    s.z2 = p; p += td;
+    s.x2 = p; p += nd;
+    s.Z = p; p += 10 * nd;
+    s.R = p; p += 2 * nd;
+    s.xout = p;
+    return s;
+}
+
+// temp arena carving (forward and backward share it; the backward needs more)
+struct Temp {
+    float *x1, *P, *msg, *mji;                                         // forward
+    float *dZ, *dx2, *dresx, *head, *dz, *dea, *dP, *dZx1, *dxa, *dxb;    // backward (global + shared)
+    float *dzji, *dzkj, *dq2, *dmt, *dq3, *dmnb, *ds, *dz1, *dz2;      // backward (local)
+    float* partial;
+};
+
+constexpr int WSPLIT = 64;
+constexpr int WJOBS = 24;
+
+inline int64_t temp_floats(const Graph& g) {
+    const int64_t nd = al(g.n * D), gd = al(g.eg * D), ld = al(g.el * D), td = al(g.tp * D);
+    int64_t t = 0;
+    t += nd + 4 * nd + gd + ld;                                        // x1 P msg mji
+    t += 10 * nd + nd + nd + al(((g.n + 15) / 16) * 257) + gd + gd + 4 * nd + nd + nd + nd;
+    t += 6 * ld + 3 * td;
+    t += (int64_t)WJOBS * WSPLIT * (D * D + D);
+    return t;
+}
+
+inline Temp carve_temp(float* p, const Graph& g) {
+    Temp t;
+    const int64_t nd = al(g.n * D), gd = al(g.eg * D), ld = al(g.el * D), td = al(g.tp * D);
+    t.x1 = p; p += nd;
+    t.P = p; p += 4 * nd;
+    t.msg = p; p += gd;
+    t.mji = p; p += ld;
+    t.dZ = p; p += 10 * nd;
+    t.dx2 = p; p += nd;
+    t.dresx = p; p += nd;
+    t.head = p; p += al(((g.n + 15) / 16) * 257);
+    t.dz = p; p += gd;
+    t.dea = p; p += gd;
+    t.dP = p; p += 4 * nd;
+    t.dZx1 = p; p += nd;
+    t.dxa = p; p += nd;
+    t.dxb = p; p += nd;
+    t.dzji = p; p += ld;
+    t.dzkj = p; p += ld;
+    t.dq2 = p; p += ld;
+    t.dmt = p; p += ld;
+    t.dq3 = p; p += ld;
+    t.dmnb = p; p += ld;
+    t.ds = p; p += td;
+    t.dz1 = p; p += td;
+    t.dz2 = p; p += td;
+    t.partial = p;
+    return t;
+}
+
+#define CK(call)                 \
+    do {                         \
+        int rc__ = (call);       \
+        if (rc__) return rc__;   \
+    } while (0)
+
+// weight-gradient job list builder
+struct Jobs {
+    const float* dZ[WJOBS];
+    const float* A[WJOBS];
+    float* dW[WJOBS];
+    float* db[WJOBS];
+    int64_t ld_dz[WJOBS], ld_a[WJOBS], ld_dw[WJOBS], rows[WJOBS];
+    int32_t mode[WJOBS];
+    int n = 0;
+    void add(const float* dz, const float* a, int mode_, int64_t rows_, float* dw, int64_t ld_dw_, float* db_) {
+        dZ[n] = dz; A[n] = a; dW[n] = dw; db[n] = db_;
+        ld_dz[n] = D; ld_a[n] = D; ld_dw[n] = ld_dw_; rows[n] = rows_; mode[n] = mode_;
+        ++n;
+    }
+};
+
+inline void tail_jobs(Jobs& j, const Graph& g, const float* dZ, const float* x2, const float* Z, const float* R,
+                      const float* xout, float* const* gt /* tail block of the gradient table */) {
+    const int64_t pl = g.n * D;
+    const float* src[10] = {x2, Z, Z + pl, R, Z + 3 * pl, R + pl, Z + 5 * pl, xout, Z + 7 * pl, Z + 8 * pl};
+    const int mode[10] = {0, 1, 1, 0, 1, 0, 1, 0, 1, 1};
+    for (int k = 0; k < 10; ++k) j.add(dZ + k * pl, src[k], mode[k], g.n, gt[k], D, gt[10 + k]);
+}
+
+inline int run_jobs(Jobs& j, float* partial, pamnet_stream_t st) {
+    int64_t rows_max = 0;
+    for (int k = 0; k < j.n; ++k) rows_max = j.rows[k] > rows_max ? j.rows[k] : rows_max;
+    int64_t split = (rows_max + 511) / 512;
+    split = split < 1 ? 1 : (split > WSPLIT ? WSPLIT : split);
+    return pamnet_wgrad_batched_f32(j.n, j.dZ, j.ld_dz, j.A, j.ld_a, j.mode, j.rows, j.dW, j.ld_dw, j.db, split, partial,
+                                    st);
+}
+
+}  // namespace
+
+extern "C" int pamnet_stack_workspace(int64_t n, int64_t eg, int64_t el, int64_t tp, int64_t n_layer,
+                                      int64_t* saved_floats, int64_t* temp_floats_out) {
+    if (n < 0 || eg < 0 || el < 0 || tp < 0 || n_layer < 1 || !saved_floats || !temp_floats_out) return PAMNET_EINVAL;
+    Graph g{};
+    g.n = n; g.eg = eg; g.el = el; g.tp = tp;
+    *saved_floats = n_layer * (al(global_saved_floats(g)) + al(local_saved_floats(g)));
+    *temp_floats_out = temp_floats(g);
+    return PAMNET_OK;
+}
+
+// layout[0] = floats per layer pair in `saved`; layout[1] / layout[2] = offset of the global / local layer's output
+// node features x_out inside a pair's slab (for inspection: x after every layer).
+extern "C" int pamnet_stack_layout(int64_t n, int64_t eg, int64_t el, int64_t tp, int64_t* layout) {
+    if (n < 0 || eg < 0 || el < 0 || tp < 0 || !layout) return PAMNET_EINVAL;
+    Graph g{};
+    g.n = n; g.eg = eg; g.el = el; g.tp = tp;
+    const int64_t gs = al(global_saved_floats(g)), ls = al(local_saved_floats(g));
+    float* base = nullptr;
+    layout[0] = gs + ls;
+    layout[1] = carve_global(base, g).xout - base;
+    layout[2] = gs + (carve_local(base, g).xout - base);
+    return PAMNET_OK;
+}
+
+// graph_desc: 4 x int64 sizes {n, eg, el, tp}; graph_idx: 15 device pointers in the order of struct Graph.
+static int fill_graph(Graph& g, const int64_t* sizes, const int32_t* const* idx) {
+    if (!sizes || !idx) return PAMNET_ENULL;
+    g.n = sizes[0]; g.eg = sizes[1]; g.el = sizes[2]; g.tp = sizes[3];
+    const int32_t** f = &g.g_ptr;
+    for (int k = 0; k < 15; ++k) f[k] = idx[k];
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, int64_t n_layer,
+                                    const float* x0, const float* e_g, const float* rbf_e, const float* e_sbf,
+                                    const float* const* gparams, const float* const* lparams, float* saved, float* temp,
+                                    float* outs, float* atts, pamnet_stream_t st) {
+    Graph g;
+    CK(fill_graph(g, sizes, graph_idx));
+    if (n_layer < 1) return PAMNET_EINVAL;
+    if (!x0 || !e_g || !rbf_e || !e_sbf || !gparams || !lparams || !saved || !temp || !outs || !atts) return PAMNET_ENULL;
+    const Temp t = carve_temp(temp, g);
+    const int64_t gs = al(global_saved_floats(g)), ls = al(local_saved_floats(g));
+    const float* x = x0;
+    for (int64_t k = 0; k < n_layer; ++k) {
+        // ---------------- global layer (layers/global_message_passing.py:33-56)
+        const float* const* gp = gparams + k * NG;
+        const GlobalSaved s = carve_global(saved + k * (gs + ls), g);
+        const float* wpg[2] = {gp[2], gp[2] + D};
+        CK(pamnet_node_pre_fwd_f32(x, g.n, gp[0], gp[1], wpg, 3 * D, 2, s.Zx1, t.x1, t.P, st));
+        CK(pamnet_global_edge_fwd_f32(e_g, g.eg, gp[2] + 2 * D, 3 * D, gp[3], gp[4], D, t.P, t.P + g.n * D, g.g_row,
+                                      g.g_col, s.z, s.ea, t.msg, st));
+        CK(pamnet_segment_sum_f32(s.x2, t.x1, t.msg, nullptr, nullptr, nullptr, nullptr, g.g_ptr, g.n, D, st));
+        CK(pamnet_node_tail_fwd_f32(s.x2, x, g.n, gp + GT, gp + GT + 10, gp[GT + 20], gp[GT + 21], gp[GT + 22], s.Z, s.R,
+                                    s.xout, outs + (2 * k) * g.n, atts + (2 * k) * g.n, st));
+        x = s.xout;
+        // ---------------- local layer (layers/local_message_passing.py:36-66)
+        const float* const* lp = lparams + k * NL;
+        const LocalSaved q = carve_local(saved + k * (gs + ls) + gs, g);
+        const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
+        CK(pamnet_node_pre_fwd_f32(x, g.n, lp[0], lp[1], wpl, 3 * D, 4, q.Zx1, t.x1, t.P, st));
+        const float* wq[4] = {lp[2] + 2 * D, lp[4] + 2 * D, lp[10], lp[11]};
+        const int64_t ldq[4] = {3 * D, 3 * D, D, D};
+        const float* planes[4] = {t.P, t.P + g.n * D, t.P + 2 * g.n * D, t.P + 3 * g.n * D};
+        CK(pamnet_local_edge_fwd_f32(rbf_e, g.el, wq, ldq, lp[3], lp[5], planes, g.l_row, g.l_col, q.zji, q.zkj, q.q2,
+                                     q.q3, t.mji, q.mnb, st));
+        CK(pamnet_mlp2_fwd_f32(e_sbf, g.tp, lp[6], lp[7], lp[8], lp[9], q.z1, q.z2, q.s, st));
+        CK(pamnet_segment_sum_f32(q.mt, t.mji, q.mnb, g.t_col, q.s, nullptr, nullptr, g.t_ptr, g.el, D, st));
+        CK(pamnet_segment_sum_f32(q.x2, t.x1, q.mt, nullptr, q.q3, nullptr, nullptr, g.l_ptr, g.n, D, st));
+        CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22], q.Z, q.R,
+                                    q.xout, outs + (2 * k + 1) * g.n, atts + (2 * k + 1) * g.n, st));
+        x = q.xout;
+    }
+    return PAMNET_OK;
+}
+
+// d_outs / d_atts: [2L][n].  ggrads / lgrads: gradient buffers in the same tables as the parameters (written, not
+// accumulated).  d_x0 [n,128] written; d_eg, d_rbf, d_sbf written (first layer processed) then accumulated.
+extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, int64_t n_layer,
+                                    const float* x0, const float* e_g, const float* rbf_e, const float* e_sbf,
+                                    const float* const* gparams, const float* const* lparams, const float* saved,
+                                    float* temp, const float* d_outs, const float* d_atts, float* const* ggrads,
+                                    float* const* lgrads, float* d_x0, float* d_eg, float* d_rbf, float* d_sbf,
+                                    pamnet_stream_t st) {
+    Graph g;
+    CK(fill_graph(g, sizes, graph_idx));
+    if (n_layer < 1) return PAMNET_EINVAL;
+    if (!x0 || !e_g || !rbf_e || !e_sbf || !gparams || !lparams || !saved || !temp || !d_outs || !d_atts || !ggrads ||
+        !lgrads || !d_x0 || !d_eg || !d_rbf || !d_sbf)
+        return PAMNET_ENULL;
+    const Temp t = carve_temp(temp, g);
+    const int64_t gs = al(global_saved_floats(g)), ls = al(local_saved_floats(g));
+    const float* d_xout = nullptr;        // nothing consumes the last layer's node features (models.py:196-224)
+    float* dx_bufs[2] = {t.dxa, t.dxb};
+    int flip = 0;
+    for (int64_t k = n_layer - 1; k >= 0; --k) {
+        const GlobalSaved s = carve_global(const_cast<float*>(saved) + k * (gs + ls), g);
+        const LocalSaved q = carve_local(const_cast<float*>(saved) + k * (gs + ls) + gs, g);
+        const int acc = (k != n_layer - 1) ? 1 : 0;
+        // ================= local layer backward
+        {
+            const float* const* lp = lparams + k * NL;
+            float* const* lg = lgrads + k * NL;
+            const float* x_in = s.xout;           // input of the local layer = output of this pair's global layer
+            CK(pamnet_node_tail_bwd_f32(d_xout, d_outs + (2 * k + 1) * g.n, d_atts + (2 * k + 1) * g.n, g.n, lp + LT,
+                                        lp[LT + 20], lp[LT + 22], q.Z, t.dZ, t.dx2, t.dresx, t.head, lg[LT + 20],
+                                        lg[LT + 22], lg[LT + 21], st));
+            CK(pamnet_gather_mul_f32(t.dmt, t.dx2, g.l_row, q.q3, nullptr, g.el, D, st));       // d m_t = d x2[i] * q3
+            CK(pamnet_gather_mul_f32(t.dq3, t.dx2, g.l_row, q.mt, nullptr, g.el, D, st));       // d q3  = d x2[i] * m_t
+            CK(pamnet_gather_mul_f32(t.ds, q.mnb, g.t_col, t.dmt, g.t_row, g.tp, D, st));       // d s   = m_nb[idx] * d m_t[e]
+            CK(pamnet_segment_sum_f32(t.dmnb, nullptr, q.s, nullptr, t.dmt, g.t_row, g.tT_perm, g.tT_ptr, g.el, D, st));
+            CK(pamnet_mlp2_bwd_f32(t.ds, g.tp, q.z1, q.z2, lp[6], lp[8], t.dz1, t.dz2, d_sbf, acc, st));
+            const float* wq[4] = {lp[2] + 2 * D, lp[4] + 2 * D, lp[10], lp[11]};
+            const int64_t ldq[4] = {3 * D, 3 * D, D, D};
+            CK(pamnet_local_edge_bwd_f32(t.dmt, t.dmnb, t.dq3, g.el, q.zji, q.zkj, q.q2, wq, ldq, t.dzji, t.dzkj, t.dq2,
+                                         d_rbf, acc, st));
+            const int64_t pl = g.n * D;
+            CK(pamnet_segment_sum_f32(t.dP, nullptr, t.dzji, nullptr, nullptr, nullptr, nullptr, g.l_ptr, g.n, D, st));
+            CK(pamnet_segment_sum_f32(t.dP + pl, nullptr, t.dzkj, nullptr, nullptr, nullptr, nullptr, g.l_ptr, g.n, D, st));
+            CK(pamnet_segment_sum_f32(t.dP + 2 * pl, nullptr, t.dzji, nullptr, nullptr, nullptr, g.lT_perm, g.lT_ptr, g.n, D, st));
+            CK(pamnet_segment_sum_f32(t.dP + 3 * pl, nullptr, t.dzkj, nullptr, nullptr, nullptr, g.lT_perm, g.lT_ptr, g.n, D, st));
+            const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
+            float* dx = dx_bufs[flip];
+            CK(pamnet_node_pre_bwd_f32(t.dP, t.dx2, t.dresx, g.n, lp[0], wpl, 3 * D, 4, q.Zx1, t.dZx1, dx, st));
+            Jobs j;
+            tail_jobs(j, g, t.dZ, q.x2, q.Z, q.R, q.xout, lg + LT);
+            j.add(t.dZx1, x_in, 0, g.n, lg[0], D, lg[1]);
+            j.add(t.dP, q.Zx1, 1, g.n, lg[2], 3 * D, nullptr);
+            j.add(t.dP + pl, q.Zx1, 1, g.n, lg[4], 3 * D, nullptr);
+            j.add(t.dP + 2 * pl, q.Zx1, 1, g.n, lg[2] + D, 3 * D, nullptr);
+            j.add(t.dP + 3 * pl, q.Zx1, 1, g.n, lg[4] + D, 3 * D, nullptr);
+            j.add(t.dzji, rbf_e, 0, g.el, lg[2] + 2 * D, 3 * D, lg[3]);
+            j.add(t.dzkj, rbf_e, 0, g.el, lg[4] + 2 * D, 3 * D, lg[5]);
+            j.add(t.dq2, rbf_e, 0, g.el, lg[10], D, nullptr);
+            j.add(t.dq3, rbf_e, 0, g.el, lg[11], D, nullptr);
+            j.add(t.dz2, q.z1, 1, g.tp, lg[8], D, lg[9]);
+            j.add(t.dz1, e_sbf, 0, g.tp, lg[6], D, lg[7]);
+            CK(run_jobs(j, t.partial, st));
+            d_xout = dx;
+            flip ^= 1;
+        }
+        // ================= global layer backward
+        {
+            const float* const* gp = gparams + k * NG;
+            float* const* gg = ggrads + k * NG;
+            const float* x_in = (k == 0) ? x0 : carve_local(const_cast<float*>(saved) + (k - 1) * (gs + ls) + gs, g).xout;
+            CK(pamnet_node_tail_bwd_f32(d_xout, d_outs + (2 * k) * g.n, d_atts + (2 * k) * g.n, g.n, gp + GT,
+                                        gp[GT + 20], gp[GT + 22], s.Z, t.dZ, t.dx2, t.dresx, t.head, gg[GT + 20],
+                                        gg[GT + 22], gg[GT + 21], st));
+            CK(pamnet_global_edge_bwd_f32(t.dx2, g.g_row, g.eg, s.z, s.ea, gp[2] + 2 * D, 3 * D, gp[4], D, t.dz, t.dea,
+                                          d_eg, acc, st));
+            const int64_t pl = g.n * D;
+            CK(pamnet_segment_sum_f32(t.dP, nullptr, t.dz, nullptr, nullptr, nullptr, nullptr, g.g_ptr, g.n, D, st));
+            CK(pamnet_segment_sum_f32(t.dP + pl, nullptr, t.dz, nullptr, nullptr, nullptr, g.gT_perm, g.gT_ptr, g.n, D, st));
+            const float* wpg[2] = {gp[2], gp[2] + D};
+            float* dx = (k == 0) ? d_x0 : dx_bufs[flip];
+            CK(pamnet_node_pre_bwd_f32(t.dP, t.dx2, t.dresx, g.n, gp[0], wpg, 3 * D, 2, s.Zx1, t.dZx1, dx, st));
+            Jobs j;
+            tail_jobs(j, g, t.dZ, s.x2, s.Z, s.R, s.xout, gg + GT);
+            j.add(t.dZx1, x_in, 0, g.n, gg[0], D, gg[1]);
+            j.add(t.dP, s.Zx1, 1, g.n, gg[2], 3 * D, nullptr);
+            j.add(t.dP + pl, s.Zx1, 1, g.n, gg[2] + D, 3 * D, nullptr);
+            j.add(t.dz, e_g, 0, g.eg, gg[2] + 2 * D, 3 * D, gg[3]);
+            j.add(t.dea, e_g, 0, g.eg, gg[4], D, nullptr);
+            CK(run_jobs(j, t.partial, st));
+            d_xout = dx;
+            flip ^= 1;
+        }
+    }
+    return PAMNET_OK;
+}

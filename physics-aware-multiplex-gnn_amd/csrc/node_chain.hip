@@ -217,15 +217,25 @@ __global__ __launch_bounds__(WG) void node_tail_bwd_kernel(const float* __restri
 }
 
 // columns: [0,128) d w_out, [128,256) d w_att, [256] d b_out
+// one workgroup per 16 columns: 16 row-slices x 16 columns, fixed-order tree in LDS (deterministic)
 __global__ __launch_bounds__(WG) void head_reduce_kernel(const float* __restrict__ partial, int nblocks,
                                                          float* __restrict__ d_wout, float* __restrict__ d_watt,
                                                          float* __restrict__ d_bout) {
-    for (int c = threadIdx.x; c < 257; c += WG) {
-        float s = 0.f;
-        for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * 257 + c];
-        if (c < 128) d_wout[c] = s;
-        else if (c < 256) d_watt[c - 128] = s;
-        else d_bout[0] = s;
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float s = 0.f;
+    if (c < 257)
+        for (int b = sl; b < nblocks; b += 16) s += partial[(int64_t)b * 257 + c];
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < 257) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][cl];
+        if (c < 128) d_wout[c] = t;
+        else if (c < 256) d_watt[c - 128] = t;
+        else d_bout[0] = t;
     }
 }
 
@@ -371,7 +381,7 @@ extern "C" int pamnet_node_tail_bwd_f32(const float* d_xout, const float* d_out,
     hipLaunchKernelGGL(node_tail_bwd_kernel, dim3(grid), dim3(WG), 0, st, d_xout, d_out, d_att, n,
                        make_tail(weights, nullptr, w_out, nullptr, w_att), Z, dZ, d_x2, d_resx, head_partial);
     PAMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(WG), 0, st, head_partial, (int)grid, d_wout, d_watt, d_bout);
+    hipLaunchKernelGGL(head_reduce_kernel, dim3(17), dim3(WG), 0, st, head_partial, (int)grid, d_wout, d_watt, d_bout);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

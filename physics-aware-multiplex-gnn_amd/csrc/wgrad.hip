@@ -56,23 +56,34 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, int split, floa
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     double colsum = 0.0;      // threads 0..127: bias gradient of column threadIdx.x (fp64: long, cancelling sums)
 
+    // register double buffer: the next 32-row block is in flight from L2/HBM while the MFMAs chew on the current one
+    const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;
+    float4 zr[RB / 8], ar[RB / 8];
+    auto fetch = [&](int64_t r0) {
+#pragma unroll
+        for (int i = 0; i < RB / 8; ++i) {
+            const int64_t g = r0 + rr + 8 * i;
+            zr[i] = f4zero();
+            ar[i] = f4zero();
+            if (g < end) {
+                zr[i] = ldg4(jb.dZ, g, jb.ld_dz, c4);
+                ar[i] = ldg4(jb.A, g, jb.ld_a, c4);
+            }
+        }
+    };
+    if (beg < end) fetch(beg);
     for (int64_t r0 = beg; r0 < end; r0 += RB) {
         // stage dZ[r0:r0+32, :] and A[r0:r0+32, :] (coalesced float4, zero padded)
-        const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;
 #pragma unroll
         for (int i = 0; i < RB / 8; ++i) {
             const int r = rr + 8 * i;
-            const int64_t g = r0 + r;
-            float4 z = f4zero(), a = f4zero();
-            if (g < end) {
-                z = ldg4(jb.dZ, g, jb.ld_dz, c4);
-                a = ldg4(jb.A, g, jb.ld_a, c4);
-                if (jb.a_mode == 1) a = f4silu(a);
-            }
-            *reinterpret_cast<float4*>(Zs + r * LDW + 4 * c4) = z;
+            float4 a = ar[i];
+            if (jb.a_mode == 1 && r0 + r < end) a = f4silu(a);
+            *reinterpret_cast<float4*>(Zs + r * LDW + 4 * c4) = zr[i];
             *reinterpret_cast<float4*>(As + r * LDW + 4 * c4) = a;
         }
         __syncthreads();
+        if (r0 + RB < end) fetch(r0 + RB);
         if (jb.db && threadIdx.x < 128) {
 #pragma unroll 8
             for (int r = 0; r < RB; ++r) colsum += (double)Zs[r * LDW + threadIdx.x];

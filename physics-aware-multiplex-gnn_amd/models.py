@@ -45,6 +45,26 @@ class SphericalBasis(nn.Module):
         return G.spherical_basis(graph, self.cutoff)
 
 
+class _LazyLayers(object):
+    """x after every layer, materialised from the engine's saved-activation arena only when somebody looks."""
+
+    def __init__(self, saved, graph, n_layer):
+        self._args = (saved, graph, n_layer)
+
+    def _views(self):
+        from pamnet_amd import fused
+        return fused.stack_x_layers(*self._args)
+
+    def __iter__(self):
+        return iter(self._views())
+
+    def __len__(self):
+        return 2 * self._args[2]
+
+    def __getitem__(self, i):
+        return self._views()[i]
+
+
 class _PAMNetBase(nn.Module):
     small = False
 
@@ -100,6 +120,11 @@ class _PAMNetBase(nn.Module):
         return e_l, e_g, sbf
 
     def _run_layers(self, x, e_l, e_g, e_sbf, g):
+        from pamnet_amd import fused, modules
+        if modules._fused(x):                      # dim = 128 on an MI355X: the whole loop is one engine call
+            outs, atts, saved = fused.layer_stack(self.global_layer, self.local_layer, x, e_g, e_l, e_sbf, g)
+            self._x_layers = _LazyLayers(saved, g, self.n_layer)
+            return outs, atts
         outs, atts = [], []
         self._x_layers = []
         for k in range(self.n_layer):

@@ -17,9 +17,15 @@ from .ops import gather_mul_raw, segment_sum_raw
 
 D = 128
 
+# When True and every parameter of a layer already owns a preallocated `.grad` (train.FlatParams: views of one flat
+# fp32 buffer), the backward kernels write the gradients straight into those buffers and return None to autograd -- no
+# per-parameter AccumulateGrad add (~330 launches per step at L=6).  Semantics: overwrite; valid because every parameter
+# is used exactly once per forward and the trainer runs one backward per step.  Off by default (plain autograd).
+DIRECT_GRAD = False
+
 
 def _parr(tensors):
-    """Host array of device pointers (NULL for None)."""
+    """Host array of device pointers (NULL for None; ints are raw addresses)."""
     arr = (ctypes.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
         arr[i] = None if t is None else (t if isinstance(t, int) else t.data_ptr())
@@ -35,23 +41,29 @@ def _empty(*shape, like):
 
 
 def _sub(w, c0):
-    """Pointer to the 128-column block starting at column c0 of a row-major weight."""
+    """Address of the 128-column block starting at column c0 of a row-major weight."""
     return w.data_ptr() + 4 * c0
 
 
+def _grad_buffers(params):
+    """(direct, buffers): where the gradients of `params` (a list of Parameters / tensors) are written."""
+    if DIRECT_GRAD and all(getattr(p, 'grad', None) is not None and p.grad.is_contiguous() for p in params):
+        return True, [p.grad for p in params]
+    return False, [torch.empty_like(p) for p in params]
+
+
 def wgrad(jobs, ref):
-    """jobs: list of (dZ, ld_dz, A, ld_a, a_mode, rows, dW(ptr or tensor), ld_dw, db).  One launch for all of them."""
+    """jobs: list of (dZ, ld_dz, A, ld_a, a_mode, rows, dW(tensor or address), ld_dw, db).  One launch for all."""
     if not jobs:
         return
     rows_max = max(j[5] for j in jobs)
     split = int(min(64, max(1, (rows_max + 511) // 512)))
     n = len(jobs)
     partial = torch.empty(n * split * (D * D + D), dtype=torch.float32, device=ref.device)
-    args = [_parr([j[0] for j in jobs]), _iarr([j[1] for j in jobs]), _parr([j[2] for j in jobs]),
-            _iarr([j[3] for j in jobs]), _iarr([j[4] for j in jobs], ctypes.c_int32), _iarr([j[5] for j in jobs]),
-            _parr([j[6] for j in jobs]), _iarr([j[7] for j in jobs]), _parr([j[8] for j in jobs])]
-    lib.call('pamnet_wgrad_batched_f32', n, args[0], args[1], args[2], args[3], args[4], args[5], args[6], args[7],
-             args[8], split, lib.ptr(partial), lib.stream_of(ref))
+    lib.call('pamnet_wgrad_batched_f32', n, _parr([j[0] for j in jobs]), _iarr([j[1] for j in jobs]),
+             _parr([j[2] for j in jobs]), _iarr([j[3] for j in jobs]), _iarr([j[4] for j in jobs], ctypes.c_int32),
+             _iarr([j[5] for j in jobs]), _parr([j[6] for j in jobs]), _iarr([j[7] for j in jobs]),
+             _parr([j[8] for j in jobs]), split, lib.ptr(partial), lib.stream_of(ref))
 
 
 # ---------------------------------------------------------------------------------------------------- raw kernel calls
@@ -82,7 +94,8 @@ def k_tail_fwd(x2, res_x, tp):
     return Z, R, x_out, out, att
 
 
-def k_tail_bwd(g_x, g_out, g_att, tp, Z):
+def k_tail_bwd(g_x, g_out, g_att, tp, Z, d_wout, d_bout, d_watt):
+    """Backward chain of the tail; head-vector gradients go to the given buffers."""
     n = Z.size(1)
     W, w_out, w_att = tp[:10], tp[20], tp[22]
     g_out = torch.zeros(n, device=Z.device) if g_out is None else g_out.contiguous()
@@ -91,11 +104,10 @@ def k_tail_bwd(g_x, g_out, g_att, tp, Z):
     dZ = _empty(10, n, D, like=Z)
     d_x2, d_resx = _empty(n, D, like=Z), _empty(n, D, like=Z)
     head_partial = _empty(((n + 15) // 16) * 257, like=Z)
-    d_wout, d_watt, d_bout = torch.empty_like(w_out), torch.empty_like(w_att), _empty(1, like=Z)
     lib.call('pamnet_node_tail_bwd_f32', lib.ptr(g_x), lib.ptr(g_out), lib.ptr(g_att), n, _parr(W), lib.ptr(w_out),
              lib.ptr(w_att), lib.ptr(Z), lib.ptr(dZ), lib.ptr(d_x2), lib.ptr(d_resx), lib.ptr(head_partial),
              lib.ptr(d_wout), lib.ptr(d_watt), lib.ptr(d_bout), lib.stream_of(Z))
-    return dZ, d_x2, d_resx, d_wout, d_watt, d_bout
+    return dZ, d_x2, d_resx
 
 
 def tail_jobs(dZ, x2, Z, R, x_out, gW, gb):
@@ -114,10 +126,8 @@ def tail_params(layer):
     return [l.weight for l in lins] + [l.bias for l in lins] + [layer.W_out.weight, layer.W_out.bias, layer.W]
 
 
-def _tail_grads(tp, dev):
-    gW = [torch.empty_like(w) for w in tp[:10]]
-    gb = [_empty(D, like=dev) for _ in range(10)]
-    return gW, gb
+def _ret(direct, grads):
+    return tuple(None for _ in grads) if direct else tuple(grads)
 
 
 # ---------------------------------------------------------------------------------------------------- node tail alone
@@ -125,32 +135,37 @@ class _NodeTail(torch.autograd.Function):
     """x2, res_x -> x_out, out, att  (layers/global_message_passing.py:39-50 / local_message_passing.py:55-66)."""
 
     @staticmethod
-    def forward(ctx, x2, res_x, *tp):
+    def forward(ctx, x2, res_x, plist, *tp):
         x2, res_x = x2.contiguous(), res_x.contiguous()
         Z, R, x_out, out, att = k_tail_fwd(x2, res_x, tp)
         ctx.save_for_backward(x2, Z, R, x_out, *tp)
+        ctx.plist = plist
         return x_out, out, att
 
     @staticmethod
     def backward(ctx, g_x, g_out, g_att):
         x2, Z, R, x_out = ctx.saved_tensors[:4]
         tp = ctx.saved_tensors[4:]
-        dZ, d_x2, d_resx, d_wout, d_watt, d_bout = k_tail_bwd(g_x, g_out, g_att, tp, Z)
-        gW, gb = _tail_grads(tp, x2)
-        wgrad(tail_jobs(dZ, x2, Z, R, x_out, gW, gb), x2)
-        return (d_x2, d_resx) + tuple(gW) + tuple(gb) + (d_wout, d_bout, d_watt)
+        direct, g = _grad_buffers(ctx.plist)
+        dZ, d_x2, d_resx = k_tail_bwd(g_x, g_out, g_att, tp, Z, g[20], g[21], g[22])
+        wgrad(tail_jobs(dZ, x2, Z, R, x_out, g[:10], g[10:20]), x2)
+        return (d_x2, d_resx, None) + _ret(direct, g)
 
 
 def node_tail(layer, x2, res_x):
-    return _NodeTail.apply(x2, res_x, *tail_params(layer))
+    tp = tail_params(layer)
+    return _NodeTail.apply(x2, res_x, tp, *tp)
 
 
 # ---------------------------------------------------------------------------------------------------- global layer
 class _GlobalLayer(torch.autograd.Function):
-    """Global_MessagePassing.forward (layers/global_message_passing.py:33-56): x, e -> x_out, out, att."""
+    """Global_MessagePassing.forward (layers/global_message_passing.py:33-56): x, e -> x_out, out, att.
+    params = [Wx1, bx1, Wm, bm, Wea] + tail(23)."""
 
     @staticmethod
-    def forward(ctx, x, e, graph, Wx1, bx1, Wm, bm, Wea, *tp):
+    def forward(ctx, x, e, graph, plist, *params):
+        Wx1, bx1, Wm, bm, Wea = params[:5]
+        tp = params[5:]
         x, e = x.contiguous(), e.contiguous()
         csr = graph.glob
         n, m = x.size(0), e.size(0)
@@ -164,52 +179,58 @@ class _GlobalLayer(torch.autograd.Function):
         x2 = _empty(n, D, like=x)
         segment_sum_raw(x2, x1, msg, None, None, None, None, csr.ptr, n, D)            # x1 + sum_{e -> i} msg_e
         Z, R, x_out, out, att = k_tail_fwd(x2, x, tp)
-        ctx.save_for_backward(x, e, Zx1, z, ea, x2, Z, R, x_out, Wx1, Wm, Wea, *tp)
-        ctx.graph = graph
+        ctx.save_for_backward(x, e, Zx1, z, ea, x2, Z, R, x_out, *params)
+        ctx.graph, ctx.plist = graph, plist
         return x_out, out, att
 
     @staticmethod
     def backward(ctx, g_x, g_out, g_att):
-        x, e, Zx1, z, ea, x2, Z, R, x_out, Wx1, Wm, Wea = ctx.saved_tensors[:12]
-        tp = ctx.saved_tensors[12:]
+        x, e, Zx1, z, ea, x2, Z, R, x_out = ctx.saved_tensors[:9]
+        params = ctx.saved_tensors[9:]
+        Wx1, bx1, Wm, bm, Wea = params[:5]
+        tp = params[5:]
         graph = ctx.graph
         csr, tr = graph.glob, graph.glob_T
         n, m = x.size(0), e.size(0)
         st = lib.stream_of(x)
-        dZ, d_x2, d_resx, d_wout, d_watt, d_bout = k_tail_bwd(g_x, g_out, g_att, tp, Z)
+        direct, g = _grad_buffers(ctx.plist)
+        gWx1, gbx1, gWm, gbm, gWea = g[:5]
+        gt = g[5:]
+        dZ, d_x2, d_resx = k_tail_bwd(g_x, g_out, g_att, tp, Z, gt[20], gt[21], gt[22])
         dz, dea, d_e = _empty(m, D, like=x), _empty(m, D, like=x), _empty(m, D, like=x)
         lib.call('pamnet_global_edge_bwd_f32', lib.ptr(d_x2), lib.ptr(csr.row_of), m, lib.ptr(z), lib.ptr(ea),
                  _sub(Wm, 2 * D), 3 * D, lib.ptr(Wea), D, lib.ptr(dz), lib.ptr(dea), lib.ptr(d_e), 0, st)
         dP = _empty(2, n, D, like=x)
-        segment_sum_raw(dP[0], None, dz, None, None, None, None, csr.ptr, n, D)         # d P_i = sum over edges into i
-        segment_sum_raw(dP[1], None, dz, None, None, None, tr.perm, tr.ptr, n, D)       # d P_j = sum over edges out of j
+        segment_sum_raw(dP[0], None, dz, None, None, None, None, csr.ptr, n, D)         # d P_i: edges into i
+        segment_sum_raw(dP[1], None, dz, None, None, None, tr.perm, tr.ptr, n, D)       # d P_j: edges out of j
         wps = [_sub(Wm, 0), _sub(Wm, D)]
         dZx1, dx = k_pre_bwd(dP, d_x2, d_resx, Wx1, wps, 3 * D, Zx1)
-        gWx1, gbx1 = torch.empty_like(Wx1), _empty(D, like=x)
-        gWm, gbm, gWea = torch.empty_like(Wm), _empty(D, like=x), torch.empty_like(Wea)
-        gW, gb = _tail_grads(tp, x)
-        jobs = tail_jobs(dZ, x2, Z, R, x_out, gW, gb)
+        jobs = tail_jobs(dZ, x2, Z, R, x_out, gt[:10], gt[10:20])
         jobs += [(dZx1, D, x, D, 0, n, gWx1, D, gbx1),
                  (dP[0], D, Zx1, D, 1, n, _sub(gWm, 0), 3 * D, None),
                  (dP[1], D, Zx1, D, 1, n, _sub(gWm, D), 3 * D, None),
                  (dz, D, e, D, 0, m, _sub(gWm, 2 * D), 3 * D, gbm),
                  (dea, D, e, D, 0, m, gWea, D, None)]
         wgrad(jobs, x)
-        return (dx, d_e, None, gWx1, gbx1, gWm, gbm, gWea) + tuple(gW) + tuple(gb) + (d_wout, d_bout, d_watt)
+        return (dx, d_e, None, None) + _ret(direct, g)
 
 
 def global_layer(layer, x, e, graph):
     lin_m = layer.mlp_m[0][0]
-    return _GlobalLayer.apply(x, e, graph, layer.mlp_x1[0][0].weight, layer.mlp_x1[0][0].bias, lin_m.weight,
-                              lin_m.bias, layer.W_edge_attr.weight, *tail_params(layer))
+    params = [layer.mlp_x1[0][0].weight, layer.mlp_x1[0][0].bias, lin_m.weight, lin_m.bias,
+              layer.W_edge_attr.weight] + tail_params(layer)
+    return _GlobalLayer.apply(x, e, graph, params, *params)
 
 
 # ---------------------------------------------------------------------------------------------------- local layer
 class _LocalLayer(torch.autograd.Function):
-    """Local_MessagePassing(_s).forward (layers/local_message_passing.py:36-66, 96-123)."""
+    """Local_MessagePassing(_s).forward (layers/local_message_passing.py:36-66, 96-123).
+    params = [Wx1, bx1, Wji, bji, Wkj, bkj, Ws1, bs1, Ws2, bs2, Wlr, Wlo] + tail(23)."""
 
     @staticmethod
-    def forward(ctx, x, rbf, sbf, graph, Wx1, bx1, Wji, bji, Wkj, bkj, Ws1, bs1, Ws2, bs2, Wlr, Wlo, *tp):
+    def forward(ctx, x, rbf, sbf, graph, plist, *params):
+        Wx1, bx1, Wji, bji, Wkj, bkj, Ws1, bs1, Ws2, bs2, Wlr, Wlo = params[:12]
+        tp = params[12:]
         x, rbf, sbf = x.contiguous(), rbf.contiguous(), sbf.contiguous()
         loc, tpc = graph.loc, graph.tp
         n, m, t = x.size(0), rbf.size(0), sbf.size(0)
@@ -229,21 +250,24 @@ class _LocalLayer(torch.autograd.Function):
         x2 = _empty(n, D, like=x)           # x1 + sum_{e -> i} q3 * m_t                    (local_message_passing.py:53-54)
         segment_sum_raw(x2, x1, m_t, None, q3, None, None, loc.ptr, n, D)
         Z, R, x_out, out, att = k_tail_fwd(x2, x, tp)
-        ctx.save_for_backward(x, rbf, sbf, Zx1, z_ji, z_kj, q2, q3, m_nb, s, m_t, z1, z2, x2, Z, R, x_out,
-                              Wx1, Wji, Wkj, Ws1, Ws2, Wlr, Wlo, *tp)
-        ctx.graph = graph
+        ctx.save_for_backward(x, rbf, sbf, Zx1, z_ji, z_kj, q2, q3, m_nb, s, m_t, z1, z2, x2, Z, R, x_out, *params)
+        ctx.graph, ctx.plist = graph, plist
         return x_out, out, att
 
     @staticmethod
     def backward(ctx, g_x, g_out, g_att):
-        (x, rbf, sbf, Zx1, z_ji, z_kj, q2, q3, m_nb, s, m_t, z1, z2, x2, Z, R, x_out,
-         Wx1, Wji, Wkj, Ws1, Ws2, Wlr, Wlo) = ctx.saved_tensors[:24]
-        tp = ctx.saved_tensors[24:]
+        x, rbf, sbf, Zx1, z_ji, z_kj, q2, q3, m_nb, s, m_t, z1, z2, x2, Z, R, x_out = ctx.saved_tensors[:17]
+        params = ctx.saved_tensors[17:]
+        Wx1, bx1, Wji, bji, Wkj, bkj, Ws1, bs1, Ws2, bs2, Wlr, Wlo = params[:12]
+        tp = params[12:]
         graph = ctx.graph
         loc, loc_T, tpc, tp_T = graph.loc, graph.loc_T, graph.tp, graph.tp_T
         n, m, t = x.size(0), rbf.size(0), sbf.size(0)
         st = lib.stream_of(x)
-        dZ, d_x2, d_resx, d_wout, d_watt, d_bout = k_tail_bwd(g_x, g_out, g_att, tp, Z)
+        direct, g = _grad_buffers(ctx.plist)
+        gWx1, gbx1, gWji, gbji, gWkj, gbkj, gWs1, gbs1, gWs2, gbs2, gWlr, gWlo = g[:12]
+        gt = g[12:]
+        dZ, d_x2, d_resx = k_tail_bwd(g_x, g_out, g_att, tp, Z, gt[20], gt[21], gt[22])
         d_mt, d_q3 = _empty(m, D, like=x), _empty(m, D, like=x)
         gather_mul_raw(d_mt, d_x2, loc.row_of, q3, None, m, D)                          # d m_t = d x2[i] * q3
         gather_mul_raw(d_q3, d_x2, loc.row_of, m_t, None, m, D)                         # d q3  = d x2[i] * m_t
@@ -265,12 +289,7 @@ class _LocalLayer(torch.autograd.Function):
         segment_sum_raw(dP[3], None, dz_kj, None, None, None, loc_T.perm, loc_T.ptr, n, D)
         wps = [_sub(Wji, 0), _sub(Wkj, 0), _sub(Wji, D), _sub(Wkj, D)]
         dZx1, dx = k_pre_bwd(dP, d_x2, d_resx, Wx1, wps, 3 * D, Zx1)
-        gWx1, gbx1 = torch.empty_like(Wx1), _empty(D, like=x)
-        gWji, gbji, gWkj, gbkj = torch.empty_like(Wji), _empty(D, like=x), torch.empty_like(Wkj), _empty(D, like=x)
-        gWs1, gbs1, gWs2, gbs2 = torch.empty_like(Ws1), _empty(D, like=x), torch.empty_like(Ws2), _empty(D, like=x)
-        gWlr, gWlo = torch.empty_like(Wlr), torch.empty_like(Wlo)
-        gW, gb = _tail_grads(tp, x)
-        jobs = tail_jobs(dZ, x2, Z, R, x_out, gW, gb)
+        jobs = tail_jobs(dZ, x2, Z, R, x_out, gt[:10], gt[10:20])
         jobs += [(dZx1, D, x, D, 0, n, gWx1, D, gbx1),
                  (dP[0], D, Zx1, D, 1, n, _sub(gWji, 0), 3 * D, None),
                  (dP[1], D, Zx1, D, 1, n, _sub(gWkj, 0), 3 * D, None),
@@ -283,14 +302,119 @@ class _LocalLayer(torch.autograd.Function):
                  (dz2, D, z1, D, 1, t, gWs2, D, gbs2),
                  (dz1, D, sbf, D, 0, t, gWs1, D, gbs1)]
         wgrad(jobs, x)
-        return ((dx, d_rbf, d_sbf, None, gWx1, gbx1, gWji, gbji, gWkj, gbkj, gWs1, gbs1, gWs2, gbs2, gWlr, gWlo)
-                + tuple(gW) + tuple(gb) + (d_wout, d_bout, d_watt))
+        return (dx, d_rbf, d_sbf, None, None) + _ret(direct, g)
 
 
 def local_layer(layer, x, rbf, sbf, graph):
     lin_ji = layer.mlp_m_ji[0][0]
     lin_kj = (layer.mlp_m_jj if layer.small else layer.mlp_m_kj)[0][0]
     s1, s2 = layer.mlp_sbf[0][0], layer.mlp_sbf[1][0]
-    return _LocalLayer.apply(x, rbf, sbf, graph, layer.mlp_x1[0][0].weight, layer.mlp_x1[0][0].bias, lin_ji.weight,
-                             lin_ji.bias, lin_kj.weight, lin_kj.bias, s1.weight, s1.bias, s2.weight, s2.bias,
-                             layer.lin_rbf.weight, layer.lin_rbf_out.weight, *tail_params(layer))
+    params = [layer.mlp_x1[0][0].weight, layer.mlp_x1[0][0].bias, lin_ji.weight, lin_ji.bias, lin_kj.weight,
+              lin_kj.bias, s1.weight, s1.bias, s2.weight, s2.bias, layer.lin_rbf.weight,
+              layer.lin_rbf_out.weight] + tail_params(layer)
+    return _LocalLayer.apply(x, rbf, sbf, graph, params, *params)
+
+
+# ---------------------------------------------------------------------------------------------------- whole layer stack
+def global_params(layer):
+    lin_m = layer.mlp_m[0][0]
+    return [layer.mlp_x1[0][0].weight, layer.mlp_x1[0][0].bias, lin_m.weight, lin_m.bias,
+            layer.W_edge_attr.weight] + tail_params(layer)
+
+
+def local_params(layer):
+    lin_ji = layer.mlp_m_ji[0][0]
+    lin_kj = (layer.mlp_m_jj if layer.small else layer.mlp_m_kj)[0][0]
+    s1, s2 = layer.mlp_sbf[0][0], layer.mlp_sbf[1][0]
+    return [layer.mlp_x1[0][0].weight, layer.mlp_x1[0][0].bias, lin_ji.weight, lin_ji.bias, lin_kj.weight,
+            lin_kj.bias, s1.weight, s1.bias, s2.weight, s2.bias, layer.lin_rbf.weight,
+            layer.lin_rbf_out.weight] + tail_params(layer)
+
+
+_TEMP = {}
+
+
+def _temp_arena(n_floats, dev):
+    """Scratch arena reused by every call on a device (stream-ordered use; grown on demand)."""
+    t = _TEMP.get(dev)
+    if t is None or t.numel() < n_floats:
+        t = torch.empty(int(n_floats * 1.25) + 1024, dtype=torch.float32, device=dev)
+        _TEMP[dev] = t
+    return t
+
+
+def _graph_tables(graph):
+    sizes = _iarr([graph.n, graph.glob.m, graph.loc.m, graph.tp.m])
+    idx = _parr([graph.glob.ptr, graph.glob.row_of, graph.glob.col, graph.glob_T.ptr, graph.glob_T.perm,
+                 graph.loc.ptr, graph.loc.row_of, graph.loc.col, graph.loc_T.ptr, graph.loc_T.perm,
+                 graph.tp.ptr, graph.tp.row_of, graph.tp.col, graph.tp_T.ptr, graph.tp_T.perm])
+    return sizes, idx
+
+
+class _Stack(torch.autograd.Function):
+    """The n_layer x (global, local) loop (models.py:196-204): x0, e_g, rbf_e, e_sbf -> outs [2L,N], atts [2L,N].
+    One C call forward, one backward (csrc/engine.hip)."""
+
+    @staticmethod
+    def forward(ctx, x0, e_g, rbf_e, e_sbf, graph, gl, ll, *params):
+        x0, e_g, rbf_e, e_sbf = x0.contiguous(), e_g.contiguous(), rbf_e.contiguous(), e_sbf.contiguous()
+        L = len(gl)
+        n = x0.size(0)
+        sizes, idx = _graph_tables(graph)
+        need = (ctypes.c_int64 * 2)()
+        lib.call('pamnet_stack_workspace', n, e_g.size(0), rbf_e.size(0), e_sbf.size(0), L,
+                 ctypes.addressof(need), ctypes.addressof(need) + 8)
+        saved = torch.empty(max(int(need[0]), 1), dtype=torch.float32, device=x0.device)
+        temp = _temp_arena(int(need[1]), x0.device)
+        outs, atts = _empty(2 * L, n, like=x0), _empty(2 * L, n, like=x0)
+        gtab = _parr([p for lay in gl for p in lay])
+        ltab = _parr([p for lay in ll for p in lay])
+        lib.call('pamnet_stack_fwd_f32', sizes, idx, L, lib.ptr(x0), lib.ptr(e_g), lib.ptr(rbf_e), lib.ptr(e_sbf),
+                 gtab, ltab, lib.ptr(saved), lib.ptr(temp), lib.ptr(outs), lib.ptr(atts), lib.stream_of(x0))
+        ctx.save_for_backward(x0, e_g, rbf_e, e_sbf, saved)
+        ctx.graph, ctx.gl, ctx.ll = graph, gl, ll
+        ctx.mark_non_differentiable(saved)
+        return outs, atts, saved
+
+    @staticmethod
+    def backward(ctx, g_outs, g_atts, _g_saved):
+        x0, e_g, rbf_e, e_sbf, saved = ctx.saved_tensors
+        graph, gl, ll = ctx.graph, ctx.gl, ctx.ll
+        L = len(gl)
+        flat = [p for lay in gl for p in lay] + [p for lay in ll for p in lay]
+        direct, g = _grad_buffers(flat)
+        ng = sum(len(lay) for lay in gl)
+        sizes, idx = _graph_tables(graph)
+        need = (ctypes.c_int64 * 2)()
+        lib.call('pamnet_stack_workspace', x0.size(0), e_g.size(0), rbf_e.size(0), e_sbf.size(0), L,
+                 ctypes.addressof(need), ctypes.addressof(need) + 8)
+        temp = _temp_arena(int(need[1]), x0.device)
+        d_x0, d_eg, d_rbf, d_sbf = (torch.empty_like(t) for t in (x0, e_g, rbf_e, e_sbf))
+        g_outs = torch.zeros(2 * L, x0.size(0), device=x0.device) if g_outs is None else g_outs.contiguous()
+        g_atts = torch.zeros_like(g_outs) if g_atts is None else g_atts.contiguous()
+        lib.call('pamnet_stack_bwd_f32', sizes, idx, L, lib.ptr(x0), lib.ptr(e_g), lib.ptr(rbf_e), lib.ptr(e_sbf),
+                 _parr([p for lay in gl for p in lay]), _parr([p for lay in ll for p in lay]), lib.ptr(saved),
+                 lib.ptr(temp), lib.ptr(g_outs), lib.ptr(g_atts), _parr(g[:ng]), _parr(g[ng:]), lib.ptr(d_x0),
+                 lib.ptr(d_eg), lib.ptr(d_rbf), lib.ptr(d_sbf), lib.stream_of(x0))
+        return (d_x0, d_eg, d_rbf, d_sbf, None, None, None) + _ret(direct, g)
+
+
+def layer_stack(global_layers, local_layers, x0, e_g, rbf_e, e_sbf, graph):
+    """Returns outs [2L,N], atts [2L,N] and the saved-activation arena (see stack_x_layers)."""
+    gl = [global_params(l) for l in global_layers]
+    ll = [local_params(l) for l in local_layers]
+    params = [p for lay in gl for p in lay] + [p for lay in ll for p in lay]
+    return _Stack.apply(x0, e_g, rbf_e, e_sbf, graph, gl, ll, *params)
+
+
+def stack_x_layers(saved, graph, n_layer):
+    """Node features after every layer (global_0, local_0, ...) as views into the saved arena."""
+    lay = (ctypes.c_int64 * 3)()
+    lib.call('pamnet_stack_layout', graph.n, graph.glob.m, graph.loc.m, graph.tp.m, ctypes.addressof(lay))
+    pair, og, ol = int(lay[0]), int(lay[1]), int(lay[2])
+    n = graph.n
+    xs = []
+    for k in range(n_layer):
+        for off in (og, ol):
+            xs.append(saved[k * pair + off:k * pair + off + n * D].view(n, D))
+    return xs

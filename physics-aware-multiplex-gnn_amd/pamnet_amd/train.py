@@ -25,19 +25,21 @@ class FlatParams(object):
     def __init__(self, module):
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.names = [n for n, p in module.named_parameters() if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
         dev, dt = self.params[0].device, self.params[0].dtype
-        pad = (-n) % 1024
-        self.numel = n
-        self.flat = torch.zeros(n + pad, device=dev, dtype=dt)
-        self.grad = torch.zeros(n + pad, device=dev, dtype=dt)
-        off = 0
+        align = 64                                        # floats: every parameter starts on a 256-byte boundary
+        offs, off = [], 0                                 # (the kernels read weights as 16-byte vectors)
         for p in self.params:
+            offs.append(off)
+            off += (p.numel() + align - 1) // align * align
+        self.numel = sum(p.numel() for p in self.params)
+        self.offsets = dict(zip(self.names, offs))
+        self.flat = torch.zeros(off, device=dev, dtype=dt)          # padding stays zero: no effect on norms / Adam
+        self.grad = torch.zeros(off, device=dev, dtype=dt)
+        for p, o in zip(self.params, offs):
             k = p.numel()
-            self.flat[off:off + k].copy_(p.data.reshape(-1))
-            p.data = self.flat[off:off + k].view_as(p)
-            p.grad = self.grad[off:off + k].view_as(p)
-            off += k
+            self.flat[o:o + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + k].view_as(p)
+            p.grad = self.grad[o:o + k].view_as(p)
 
     def zero_grad(self):
         self.grad.zero_()
@@ -61,6 +63,11 @@ class Trainer(object):
                  eps=1e-8, world_size=1, process_group=None):
         self.model = model
         self.fp = FlatParams(model)
+        try:                                               # fused layers write gradients straight into fp.grad
+            from . import fused
+            fused.DIRECT_GRAD = True
+        except Exception:                                  # (gloo/CPU unit tests drive the trainer with a plain module)
+            pass
         self.opt = torch.optim.Adam([torch.nn.Parameter(self.fp.flat)], lr=lr, betas=betas, eps=eps,
                                     weight_decay=weight_decay, amsgrad=False, fused=self.fp.flat.is_cuda)
         self._p = self.opt.param_groups[0]['params'][0]

@@ -1,0 +1,143 @@
+"""Training-step harness (pamnet_amd.train): reference loop semantics (main_qm9.py:99-118, utils/ema.py) and
+molecule-sharded data parallelism.
+
+CPU part (`-m "not gpu"`): world_size-2 `gloo` run of the Trainer on a stand-in module -- the DP algebra (shard,
+pre-scale by local/global graphs, all-reduce of the flat gradient, identical update on every rank) must reproduce the
+single-process global-batch step.  The HIP model itself cannot run on CPU (no fallback), so the stand-in is a plain
+torch module with the same `model(data) -> [num_graphs]` contract.
+GPU part: the flat / direct-gradient path of the real model equals plain autograd.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+class Tiny(nn.Module):
+    """Per-graph scalar from node features: sum-pool of an MLP (graphs are independent units, like PAMNet)."""
+
+    def __init__(self):
+        super().__init__()
+        self.a, self.b = nn.Linear(6, 16), nn.Linear(16, 1)
+
+    def forward(self, data):
+        h = self.b(torch.tanh(self.a(data.x))).view(-1)
+        return torch.zeros(data.num_graphs, dtype=h.dtype).index_add_(0, data.batch, h)
+
+
+class D(object):
+    pass
+
+
+def _batch(lo, hi, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    sizes = torch.randint(3, 9, (64,), generator=g)
+    xs = [torch.randn(int(s), 6, generator=g) for s in sizes]
+    ys = torch.randn(64, generator=g)
+    d = D()
+    d.x = torch.cat(xs[lo:hi])
+    d.batch = torch.repeat_interleave(torch.arange(hi - lo), sizes[lo:hi])
+    d.y, d.num_graphs = ys[lo:hi], hi - lo
+    return d
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, out):
+    from pamnet_amd.train import Trainer, shard_range
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = Tiny()
+    tr = Trainer(model, lr=1e-2, world_size=world)
+    lo, hi = shard_range(total, rank, world)
+    for step in range(3):
+        tr.step(_batch(lo, hi), global_graphs=total)
+    mae = tr.evaluate([_batch(lo, hi)])
+    if rank == 0:
+        torch.save({'flat': tr.fp.flat.clone(), 'shadow': tr.shadow.clone(), 'mae': mae}, out)
+    # every rank must hold identical parameters
+    ref = tr.fp.flat.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(ref, tr.fp.flat)
+    dist.destroy_process_group()
+
+
+def test_dp_world2_matches_single_process(tmp_path):
+    from pamnet_amd.train import Trainer, shard_range
+    total = 13                                   # uneven shards: 7 + 6
+    assert [shard_range(total, r, 2) for r in range(2)] == [(0, 7), (7, 13)]
+    out = str(tmp_path / 'dp.pt')
+    mp.spawn(_worker, args=(2, _free_port(), total, out), nprocs=2, join=True)
+    got = torch.load(out)
+    torch.manual_seed(0)
+    model = Tiny()
+    tr = Trainer(model, lr=1e-2, world_size=1)
+    for step in range(3):
+        tr.step(_batch(0, total))
+    assert torch.allclose(got['flat'], tr.fp.flat, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(got['shadow'], tr.shadow, rtol=1e-5, atol=1e-6)
+    assert abs(got['mae'] - tr.evaluate([_batch(0, total)])) < 1e-5
+
+
+def test_trainer_step_semantics():
+    """clip at max_norm, Adam update, EMA decay = min(0.999, (1+n)/(10+n)) with n=99999 (utils/ema.py:14)."""
+    from pamnet_amd.train import Trainer, WarmupExpLR
+    torch.manual_seed(1)
+    model, ref = Tiny(), Tiny()
+    ref.load_state_dict(model.state_dict())
+    tr = Trainer(model, lr=1e-2, max_grad_norm=0.05)
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    shadow = {k: p.data.clone() for k, p in ref.named_parameters()}
+    b = _batch(0, 10)
+    for _ in range(2):
+        tr.step(b)
+        opt.zero_grad()
+        torch.nn.functional.l1_loss(ref(b), b.y).backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm=0.05, norm_type=2)
+        opt.step()
+        for k, p in ref.named_parameters():
+            shadow[k] = (1.0 - 0.999) * p.data + 0.999 * shadow[k]
+    for (k, p), q in zip(ref.named_parameters(), model.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), k
+    sched = WarmupExpLR(1e-4, steps_per_epoch=100)
+    assert abs(sched.lr_at(0, 50) - 0.5e-4) < 1e-12 and abs(sched.lr_at(2, 0) - 1e-4 * 0.9961697) < 1e-12
+    for (k, p) in model.named_parameters():
+        o = tr.fp.offsets[k]
+        assert torch.allclose(tr.shadow[o:o + p.numel()].view_as(p), shadow[k], rtol=1e-5, atol=1e-7), k
+
+
+@pytest.mark.gpu
+def test_direct_gradient_path_equals_autograd():
+    import models
+    from pamnet_amd import fused, synth
+    from pamnet_amd.train import FlatParams
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    cfg = models.Config(dataset='QM9', dim=128, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+    model = models.PAMNet(cfg).to(dev)
+    b = synth.qm9_batch(2, 0, 8).to(dev)
+    fused.DIRECT_GRAD = False
+    torch.nn.functional.l1_loss(model(b), b.y).backward()
+    ref = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    fp = FlatParams(model)
+    try:
+        fused.DIRECT_GRAD = True
+        fp.zero_grad()
+        torch.nn.functional.l1_loss(model(b), b.y).backward()
+        for k, p in model.named_parameters():
+            if k in ref:
+                assert torch.equal(p.grad, ref[k]), k
+        assert float(fp.grad.abs().sum()) > 0
+    finally:
+        fused.DIRECT_GRAD = False
