@@ -159,10 +159,10 @@ int pamnet_node_pre_fwd_f32(const float* x, int64_t n, const float* Wx1, const f
 int pamnet_node_pre_bwd_f32(const float* dP, const float* dx1_direct, const float* d_add, int64_t n, const float* Wx1,
                             const float* const* wp, int64_t ldwp, int64_t nblk, const float* Zx1, float* dZx1,
                             float* dx, pamnet_stream_t stream);
+int pamnet_wgrad_scratch_floats(int64_t njobs, const int64_t* rows, int64_t* floats);
 int pamnet_wgrad_batched_f32(int64_t njobs, const float* const* dZ, const int64_t* ld_dz, const float* const* A,
                              const int64_t* ld_a, const int32_t* a_mode, const int64_t* rows, float* const* dW,
-                             const int64_t* ld_dw, float* const* db, int64_t split, float* partial,
-                             pamnet_stream_t stream);
+                             const int64_t* ld_dw, float* const* db, float* partial, pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Fused edge-level kernels (dim = 128), fp32 MFMA.  P planes are node_pre outputs ([N][128] each).

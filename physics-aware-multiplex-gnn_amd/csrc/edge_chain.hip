@@ -11,6 +11,8 @@
 // epilogue while the tile is written out in coalesced 512-byte rows -- the [E,3d] concatenations and the per-edge
 // GEMM outputs of the reference never exist in memory.  P_* are the node-level projections (node_chain.hip), edges
 // are sorted by target so P_i rows repeat within a tile (L1/L2 hits).
+// Weight slices are prefetched into registers (gemm_core.h WFrag): the first two matrices at kernel entry, the next
+// ones as soon as the MFMAs that consumed a slice have been issued.
 #include "common.h"
 #include "gemm_core.h"
 
@@ -23,6 +25,7 @@ constexpr int MTE = BME / 16;
 constexpr int SLOTE = BME * LDT;
 
 __device__ __forceinline__ int wave_col0() { return (threadIdx.x >> 6) * 32; }
+__device__ __forceinline__ Bias2 no_bias() { return load_bias2(nullptr, 0); }
 
 // -------------------------------------------------------------------------------------------------- global edges
 __global__ __launch_bounds__(WG) void global_edge_fwd_kernel(const float* __restrict__ e, int64_t m,
@@ -37,19 +40,21 @@ __global__ __launch_bounds__(WG) void global_edge_fwd_kernel(const float* __rest
     float* S0 = lds;
     float* S1 = lds + SLOTE;
     const int64_t row0 = (int64_t)blockIdx.x * BME;
-    sweep_rows<BME>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        st_lds4(S0, r, c4, g < m ? ldg4(e, g, DIM, c4) : f4zero());
-    });
+    const int wc = wave_col0();
+    const Bias2 bv = load_bias2(bm, wc);
+    WFrag f1, f2;
+    load_wfrag<false>(f1, We, ld_we, wc);
+    load_wfrag<false>(f2, Wea, ld_wea, wc);
+    sweep_rows<BME>([&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(e, row0 + r, m, DIM, c4)); });
     __syncthreads();
     f32x4 au[MTE][2], aa[MTE][2];
     acc_zero<MTE>(au);
     acc_zero<MTE>(aa);
-    mma_tile<MTE, false>(S0, We, ld_we, wave_col0(), au);
-    mma_tile<MTE, false>(S0, Wea, ld_wea, wave_col0(), aa);
+    mma_tile_frag<MTE>(S0, f1, au);
+    mma_tile_frag<MTE>(S0, f2, aa);
     __syncthreads();                                   // every wave is done reading the e tile
-    acc_to_lds<MTE>(au, S0, wave_col0(), bm);
-    acc_to_lds<MTE>(aa, S1, wave_col0(), nullptr);
+    acc_to_lds<MTE>(au, S0, wc, bv);
+    acc_to_lds<MTE>(aa, S1, wc, no_bias());
     __syncthreads();
     sweep_rows<BME>([&](int r, int c4) {
         const int64_t g = row0 + r;
@@ -75,6 +80,10 @@ __global__ __launch_bounds__(WG) void global_edge_bwd_kernel(const float* __rest
     float* S0 = lds;
     float* S1 = lds + SLOTE;
     const int64_t row0 = (int64_t)blockIdx.x * BME;
+    const int wc = wave_col0();
+    WFrag f1, f2;
+    load_wfrag<true>(f1, We, ld_we, wc);
+    load_wfrag<true>(f2, Wea, ld_wea, wc);
     sweep_rows<BME>([&](int r, int c4) {
         const int64_t g = row0 + r;
         float4 a = f4zero(), b = f4zero();
@@ -92,10 +101,10 @@ __global__ __launch_bounds__(WG) void global_edge_bwd_kernel(const float* __rest
     __syncthreads();
     f32x4 acc[MTE][2];
     acc_zero<MTE>(acc);
-    mma_tile<MTE, true>(S0, We, ld_we, wave_col0(), acc);
-    mma_tile<MTE, true>(S1, Wea, ld_wea, wave_col0(), acc);
+    mma_tile_frag<MTE>(S0, f1, acc);
+    mma_tile_frag<MTE>(S1, f2, acc);
     __syncthreads();
-    acc_to_lds<MTE>(acc, S0, wave_col0(), nullptr);
+    acc_to_lds<MTE>(acc, S0, wc, no_bias());
     __syncthreads();
     sweep_rows<BME>([&](int r, int c4) {
         const int64_t g = row0 + r;
@@ -126,20 +135,24 @@ __global__ __launch_bounds__(WG) void local_edge_fwd_kernel(const float* __restr
     float* S1 = lds + SLOTE;
     float* S2 = lds + 2 * SLOTE;
     const int64_t row0 = (int64_t)blockIdx.x * BME;
-    sweep_rows<BME>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        st_lds4(S0, r, c4, g < m ? ldg4(rbf, g, DIM, c4) : f4zero());
-    });
+    const int wc = wave_col0();
+    const Bias2 bkj = load_bias2(b_kj, wc), bji = load_bias2(b_ji, wc);
+    WFrag fa, fb;
+    load_wfrag<false>(fa, w.W[2], w.ld[2], wc);
+    load_wfrag<false>(fb, w.W[1], w.ld[1], wc);
+    sweep_rows<BME>([&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(rbf, row0 + r, m, DIM, c4)); });
     __syncthreads();
-    auto gemm = [&](int b, const float* bias, float* D) {
+    // one GEMM on the rbf tile with the slice in `f`; then `f` is refilled with the slice of matrix `next` (or left)
+    auto gemm = [&](WFrag& f, Bias2 bias, float* D, int next) {
         f32x4 acc[MTE][2];
         acc_zero<MTE>(acc);
-        mma_tile<MTE, false>(S0, w.W[b], w.ld[b], wave_col0(), acc);
-        acc_to_lds<MTE>(acc, D, wave_col0(), bias);
+        mma_tile_frag<MTE>(S0, f, acc);
+        if (next >= 0) load_wfrag<false>(f, w.W[next], w.ld[next], wc);
+        acc_to_lds<MTE>(acc, D, wc, bias);
         __syncthreads();
     };
-    gemm(2, nullptr, S2);                               // q2 = lin_rbf r           (kept for the gate)
-    gemm(1, b_kj, S1);                                  // W_kj,e r + b_kj
+    gemm(fa, no_bias(), S2, 0);                         // q2 = lin_rbf r (kept for the gate);   fa <- W_ji,e
+    gemm(fb, bkj, S1, 3);                               // W_kj,e r + b_kj;                      fb <- lin_rbf_out
     sweep_rows<BME>([&](int r, int c4) {
         const int64_t g = row0 + r;
         if (g >= m) return;
@@ -151,8 +164,8 @@ __global__ __launch_bounds__(WG) void local_edge_fwd_kernel(const float* __restr
         stg4(m_nb, g, DIM, c4, f4mul(f4silu(zz), gate));
     });
     __syncthreads();
-    gemm(0, b_ji, S1);                                  // W_ji,e r + b_ji
-    gemm(3, nullptr, S2);                               // q3 = lin_rbf_out r
+    gemm(fa, bji, S1, -1);                              // W_ji,e r + b_ji
+    gemm(fb, no_bias(), S2, -1);                        // q3 = lin_rbf_out r
     sweep_rows<BME>([&](int r, int c4) {
         const int64_t g = row0 + r;
         if (g >= m) return;
@@ -179,6 +192,10 @@ __global__ __launch_bounds__(WG) void local_edge_bwd_kernel(const float* __restr
     float* S0 = lds;
     float* S1 = lds + SLOTE;
     const int64_t row0 = (int64_t)blockIdx.x * BME;
+    const int wc = wave_col0();
+    WFrag fa, fb;
+    load_wfrag<true>(fa, w.W[0], w.ld[0], wc);
+    load_wfrag<true>(fb, w.W[1], w.ld[1], wc);
     f32x4 acc[MTE][2];
     acc_zero<MTE>(acc);
     // pass A: dz_ji -> S0, dz_kj -> S1
@@ -195,8 +212,10 @@ __global__ __launch_bounds__(WG) void local_edge_bwd_kernel(const float* __restr
         st_lds4(S1, r, c4, b);
     });
     __syncthreads();
-    mma_tile<MTE, true>(S0, w.W[0], w.ld[0], wave_col0(), acc);
-    mma_tile<MTE, true>(S1, w.W[1], w.ld[1], wave_col0(), acc);
+    mma_tile_frag<MTE>(S0, fa, acc);
+    load_wfrag<true>(fa, w.W[2], w.ld[2], wc);
+    mma_tile_frag<MTE>(S1, fb, acc);
+    load_wfrag<true>(fb, w.W[3], w.ld[3], wc);
     __syncthreads();
     // pass B: dq2 -> S0, dq3 -> S1
     sweep_rows<BME>([&](int r, int c4) {
@@ -211,10 +230,10 @@ __global__ __launch_bounds__(WG) void local_edge_bwd_kernel(const float* __restr
         st_lds4(S1, r, c4, b);
     });
     __syncthreads();
-    mma_tile<MTE, true>(S0, w.W[2], w.ld[2], wave_col0(), acc);
-    mma_tile<MTE, true>(S1, w.W[3], w.ld[3], wave_col0(), acc);
+    mma_tile_frag<MTE>(S0, fa, acc);
+    mma_tile_frag<MTE>(S1, fb, acc);
     __syncthreads();
-    acc_to_lds<MTE>(acc, S0, wave_col0(), nullptr);
+    acc_to_lds<MTE>(acc, S0, wc, no_bias());
     __syncthreads();
     sweep_rows<BME>([&](int r, int c4) {
         const int64_t g = row0 + r;
@@ -235,16 +254,18 @@ __global__ __launch_bounds__(WG) void mlp2_fwd_kernel(const float* __restrict__ 
     float* S0 = lds;
     float* S1 = lds + SLOTE;
     const int64_t row0 = (int64_t)blockIdx.x * BME;
-    sweep_rows<BME>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        st_lds4(S0, r, c4, g < m ? ldg4(x, g, DIM, c4) : f4zero());
-    });
+    const int wc = wave_col0();
+    const Bias2 bv1 = load_bias2(b1, wc), bv2 = load_bias2(b2, wc);
+    WFrag f;
+    load_wfrag<false>(f, W1, DIM, wc);
+    sweep_rows<BME>([&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(x, row0 + r, m, DIM, c4)); });
     __syncthreads();
     {
         f32x4 acc[MTE][2];
         acc_zero<MTE>(acc);
-        mma_tile<MTE, false>(S0, W1, DIM, wave_col0(), acc);
-        acc_to_lds<MTE>(acc, S1, wave_col0(), b1);
+        mma_tile_frag<MTE>(S0, f, acc);
+        load_wfrag<false>(f, W2, DIM, wc);              // in flight during the activation sweep
+        acc_to_lds<MTE>(acc, S1, wc, bv1);
         __syncthreads();
     }
     sweep_rows<BME>([&](int r, int c4) {
@@ -257,8 +278,8 @@ __global__ __launch_bounds__(WG) void mlp2_fwd_kernel(const float* __restrict__ 
     {
         f32x4 acc[MTE][2];
         acc_zero<MTE>(acc);
-        mma_tile<MTE, false>(S1, W2, DIM, wave_col0(), acc);
-        acc_to_lds<MTE>(acc, S0, wave_col0(), b2);
+        mma_tile_frag<MTE>(S1, f, acc);
+        acc_to_lds<MTE>(acc, S0, wc, bv2);
         __syncthreads();
     }
     sweep_rows<BME>([&](int r, int c4) {
@@ -279,6 +300,9 @@ __global__ __launch_bounds__(WG) void mlp2_bwd_kernel(const float* __restrict__ 
     float* S0 = lds;
     float* S1 = lds + SLOTE;
     const int64_t row0 = (int64_t)blockIdx.x * BME;
+    const int wc = wave_col0();
+    WFrag f;
+    load_wfrag<true>(f, W2, DIM, wc);
     sweep_rows<BME>([&](int r, int c4) {
         const int64_t g = row0 + r;
         float4 a = f4zero();
@@ -292,8 +316,9 @@ __global__ __launch_bounds__(WG) void mlp2_bwd_kernel(const float* __restrict__ 
     {
         f32x4 acc[MTE][2];
         acc_zero<MTE>(acc);
-        mma_tile<MTE, true>(S0, W2, DIM, wave_col0(), acc);
-        acc_to_lds<MTE>(acc, S1, wave_col0(), nullptr);
+        mma_tile_frag<MTE>(S0, f, acc);
+        load_wfrag<true>(f, W1, DIM, wc);
+        acc_to_lds<MTE>(acc, S1, wc, no_bias());
         __syncthreads();
     }
     sweep_rows<BME>([&](int r, int c4) {
@@ -309,9 +334,9 @@ __global__ __launch_bounds__(WG) void mlp2_bwd_kernel(const float* __restrict__ 
     {
         f32x4 acc[MTE][2];
         acc_zero<MTE>(acc);
-        mma_tile<MTE, true>(S1, W1, DIM, wave_col0(), acc);
+        mma_tile_frag<MTE>(S1, f, acc);
         __syncthreads();
-        acc_to_lds<MTE>(acc, S0, wave_col0(), nullptr);
+        acc_to_lds<MTE>(acc, S0, wc, no_bias());
         __syncthreads();
     }
     sweep_rows<BME>([&](int r, int c4) {

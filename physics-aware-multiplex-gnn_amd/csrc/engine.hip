@@ -76,8 +76,15 @@ struct Temp {
     float* partial;
 };
 
-constexpr int WSPLIT = 64;
 constexpr int WJOBS = 24;
+
+// split-K scratch of the largest weight-gradient batch of a layer (slots of 128*128 + 256 floats, <= 256 rows each)
+inline int64_t wgrad_floats(const Graph& g) {
+    auto slots = [](int64_t rows) { int64_t s = (rows + 255) / 256; return s < 1 ? 1 : (s > 256 ? 256 : s); };
+    const int64_t glob = 15 * slots(g.n) + 2 * slots(g.eg);
+    const int64_t loc = 15 * slots(g.n) + 4 * slots(g.el) + 2 * slots(g.tp);
+    return (glob > loc ? glob : loc) * (D * D + 2 * D);
+}
 
 inline int64_t temp_floats(const Graph& g) {
     const int64_t nd = al(g.n * D), gd = al(g.eg * D), ld = al(g.el * D), td = al(g.tp * D);
@@ -85,7 +92,7 @@ inline int64_t temp_floats(const Graph& g) {
     t += nd + 4 * nd + gd + ld;                                        // x1 P msg mji
     t += 10 * nd + nd + nd + al(((g.n + 15) / 16) * 257) + gd + gd + 4 * nd + nd + nd + nd;
     t += 6 * ld + 3 * td;
-    t += (int64_t)WJOBS * WSPLIT * (D * D + D);
+    t += wgrad_floats(g);
     return t;
 }
 
@@ -150,12 +157,7 @@ inline void tail_jobs(Jobs& j, const Graph& g, const float* dZ, const float* x2,
 }
 
 inline int run_jobs(Jobs& j, float* partial, pamnet_stream_t st) {
-    int64_t rows_max = 0;
-    for (int k = 0; k < j.n; ++k) rows_max = j.rows[k] > rows_max ? j.rows[k] : rows_max;
-    int64_t split = (rows_max + 511) / 512;
-    split = split < 1 ? 1 : (split > WSPLIT ? WSPLIT : split);
-    return pamnet_wgrad_batched_f32(j.n, j.dZ, j.ld_dz, j.A, j.ld_a, j.mode, j.rows, j.dW, j.ld_dw, j.db, split, partial,
-                                    st);
+    return pamnet_wgrad_batched_f32(j.n, j.dZ, j.ld_dz, j.A, j.ld_a, j.mode, j.rows, j.dW, j.ld_dw, j.db, partial, st);
 }
 
 }  // namespace

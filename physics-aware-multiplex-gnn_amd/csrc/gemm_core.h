@@ -27,10 +27,13 @@ constexpr int DIM = 128;          // feature width handled by the fused kernels
 constexpr int LDT = 132;          // LDS tile leading dimension (floats)
 constexpr int WG = 256;           // threads per workgroup (4 waves)
 
-__device__ __forceinline__ float silu(float z) { return z / (1.0f + expf(-z)); }
+// sigmoid through the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each) -- the activation epilogues run
+// once per GEMM output element and were a visible VALU cost with the libm expf + IEEE divide sequences.
+__device__ __forceinline__ float sigmoidf_fast(float z) { return __frcp_rn(1.0f + __expf(-z)); }
+__device__ __forceinline__ float silu(float z) { return z * sigmoidf_fast(z); }
 // d/dz [z * sigmoid(z)] = s * (1 + z * (1 - s))
 __device__ __forceinline__ float dsilu(float z) {
-    const float s = 1.0f / (1.0f + expf(-z));
+    const float s = sigmoidf_fast(z);
     return s * (1.0f + z * (1.0f - s));
 }
 
@@ -90,16 +93,99 @@ __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const flo
     }
 }
 
-// Scatter the wave's accumulators (+ optional per-column bias) into an LDS tile Ds[BM][LDT], columns [dcol0, dcol0+32).
+// ---- explicit weight-fragment prefetch ------------------------------------------------------------------------------
+// Left to itself the compiler fetches each B fragment right before the MFMAs that use it, so every k-step of a GEMM
+// waits a full L2 round trip (8 per layer; measured 44 us for the 10-layer node chain whose MFMAs need ~9 us).  A
+// WFrag holds one whole 128x32 weight slice of a wave (16 x float4 = 64 VGPRs): all 16 loads are issued back to back,
+// and the NEXT layer's slice is requested as soon as the current MFMAs are issued, so its latency hides behind the
+// epilogue (LDS scatter, barrier, activation sweep).
+struct WFrag {
+    float4 b[DIM / 16][2];
+};
+
+template <bool TRANS>
+__device__ __forceinline__ void load_wfrag(WFrag& f, const float* __restrict__ W, int ldw, int wcol0) {
+    const int lane = threadIdx.x & 63;
+    const int r16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < DIM / 16; ++q) {
+        if (!TRANS) {
+            const float* wp = W + (size_t)(wcol0 + r16) * ldw + 4 * kg + 16 * q;
+            f.b[q][0] = *reinterpret_cast<const float4*>(wp);
+            f.b[q][1] = *reinterpret_cast<const float4*>(wp + (size_t)16 * ldw);
+        } else {
+            const float* wp = W + (size_t)(16 * q + 4 * kg) * ldw + wcol0 + r16;
+            f.b[q][0] = make_float4(wp[0], wp[ldw], wp[2 * (size_t)ldw], wp[3 * (size_t)ldw]);
+            f.b[q][1] = make_float4(wp[16], wp[ldw + 16], wp[2 * (size_t)ldw + 16], wp[3 * (size_t)ldw + 16]);
+        }
+    }
+}
+
 template <int MT>
-__device__ __forceinline__ void acc_to_lds(const f32x4 (&acc)[MT][2], float* __restrict__ Ds, int dcol0,
-                                           const float* __restrict__ bias /* indexed by dcol, may be null */) {
+__device__ __forceinline__ void mma_tile_frag(const float* __restrict__ As, const WFrag& f, f32x4 (&acc)[MT][2]) {
+    const int lane = threadIdx.x & 63;
+    const float* ap = As + (lane & 15) * LDT + 4 * (lane >> 4);
+    // A fragments: for the 16-row chains (MT = 1) the whole K = 128 strip is 8 x float4 = 32 VGPRs -- read it with
+    // eight back-to-back ds_read_b128 so the LDS latency is paid once per GEMM, not once per k-step.
+    constexpr int QA = (MT <= 2) ? DIM / 16 : 1;
+    float4 apre[QA][MT];
+    if (MT <= 2) {
+#pragma unroll
+        for (int q = 0; q < DIM / 16; ++q)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) apre[q % QA][m] = *reinterpret_cast<const float4*>(ap + m * 16 * LDT + 16 * q);
+    }
+#pragma unroll
+    for (int q = 0; q < DIM / 16; ++q) {
+        float4 a[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            a[m] = (MT <= 2) ? apre[q % QA][m] : *reinterpret_cast<const float4*>(ap + m * 16 * LDT + 16 * q);
+        const float4 b0 = f.b[q][0], b1 = f.b[q][1];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, b0.x, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, b1.x, acc[m][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, b0.y, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, b1.y, acc[m][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, b0.z, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, b1.z, acc[m][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, b0.w, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, b1.w, acc[m][1], 0, 0, 0);
+        }
+    }
+}
+
+// The two bias values a lane needs (columns dcol0 + r16 and + 16).  Fetch them BEFORE issuing a weight prefetch: vmcnt
+// retires in order, so a bias load issued after the prefetch would make its s_waitcnt drain the whole prefetch.
+struct Bias2 {
+    float v[2];
+};
+__device__ __forceinline__ Bias2 load_bias2(const float* __restrict__ bias, int dcol0) {
+    Bias2 b;
+    const int r16 = threadIdx.x & 15;
+    b.v[0] = bias ? bias[dcol0 + r16] : 0.f;
+    b.v[1] = bias ? bias[dcol0 + 16 + r16] : 0.f;
+    return b;
+}
+
+template <int MT>
+__device__ __forceinline__ void acc_to_lds(const f32x4 (&acc)[MT][2], float* __restrict__ Ds, int dcol0, Bias2 bias) {
     const int lane = threadIdx.x & 63;
     const int r16 = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int col = dcol0 + 16 * n + r16;
-        const float bv = bias ? bias[col] : 0.f;
+        const float bv = bias.v[n];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             float* d = Ds + (m * 16 + kg * 4) * LDT + col;
@@ -128,6 +214,14 @@ __device__ __forceinline__ void st_lds4(float* tile, int row, int c4, float4 v) 
 }
 __device__ __forceinline__ float4 ldg4(const float* p, int64_t row, int ld, int c4) {
     return *reinterpret_cast<const float4*>(p + row * ld + 4 * c4);
+}
+// Row-guarded load without a branch: out-of-range rows read row 0 and are zeroed, so the loads of a sweep stay
+// independent and are issued back to back (a branch per row makes the compiler wait for each load separately).
+__device__ __forceinline__ float4 ldg4z(const float* p, int64_t row, int64_t nrows, int ld, int c4) {
+    const bool ok = row < nrows;
+    float4 v = *reinterpret_cast<const float4*>(p + (ok ? row : 0) * ld + 4 * c4);
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
 }
 __device__ __forceinline__ void stg4(float* p, int64_t row, int ld, int c4, float4 v) {
     *reinterpret_cast<float4*>(p + row * ld + 4 * c4) = v;

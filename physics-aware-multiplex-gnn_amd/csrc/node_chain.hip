@@ -31,13 +31,18 @@ struct TailParams {
 constexpr int BMN = 16;                       // rows per workgroup in node-level chains
 constexpr int SLOT = BMN * LDT;               // floats per LDS slot
 
-__device__ __forceinline__ void gemm16(const float* As, const float* W, const float* bias, float* Ds, bool trans) {
+// One GEMM of a chain with the weights already in registers (f); as soon as its MFMAs are issued the NEXT layer's
+// weight slice is requested into the same registers, so the L2 latency overlaps the epilogue + activation sweep.
+template <bool TRANS>
+__device__ __forceinline__ void gemm16(const float* As, WFrag& f, const float* bias, float* Ds, const float* Wnext,
+                                       int ld_next = DIM) {
     f32x4 acc[1][2];
     acc_zero<1>(acc);
     const int wcol0 = (threadIdx.x >> 6) * 32;
-    if (trans) mma_tile<1, true>(As, W, DIM, wcol0, acc);
-    else mma_tile<1, false>(As, W, DIM, wcol0, acc);
-    acc_to_lds<1>(acc, Ds, wcol0, bias);
+    const Bias2 bv = load_bias2(bias, wcol0);             // before the prefetch (in-order vmcnt)
+    mma_tile_frag<1>(As, f, acc);
+    if (Wnext) load_wfrag<TRANS>(f, Wnext, ld_next, wcol0);
+    acc_to_lds<1>(acc, Ds, wcol0, bv);
     __syncthreads();
 }
 
@@ -54,11 +59,12 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
     const int64_t row0 = (int64_t)blockIdx.x * BMN;
     const int64_t plane = n * DIM;
 
+    WFrag wf;
+    load_wfrag<false>(wf, p.W[0], DIM, (threadIdx.x >> 6) * 32);
     sweep_rows<BMN>([&](int r, int c4) {
         const int64_t g = row0 + r;
-        const bool ok = g < n;
-        st_lds4(S0, r, c4, ok ? ldg4(x2, g, DIM, c4) : f4zero());
-        st_lds4(S3, r, c4, ok ? ldg4(res_x, g, DIM, c4) : f4zero());
+        st_lds4(S0, r, c4, ldg4z(x2, g, n, DIM, c4));
+        st_lds4(S3, r, c4, ldg4z(res_x, g, n, DIM, c4));
     });
     __syncthreads();
 
@@ -79,16 +85,16 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
         __syncthreads();
     };
 
-    gemm16(S0, p.W[0], p.b[0], S1, false); act(S1, 0, nullptr, nullptr, nullptr);        // h0      -> S1
-    gemm16(S1, p.W[1], p.b[1], S2, false); act(S2, 1, nullptr, nullptr, nullptr);        // a1      -> S2
-    gemm16(S2, p.W[2], p.b[2], S0, false); act(S0, 2, S1, S3, R);                        // r1      -> S0
-    gemm16(S0, p.W[3], p.b[3], S1, false); act(S1, 3, nullptr, nullptr, nullptr);        // a3      -> S1
-    gemm16(S1, p.W[4], p.b[4], S2, false); act(S2, 4, S0, nullptr, R + plane);           // r2      -> S2
-    gemm16(S2, p.W[5], p.b[5], S0, false); act(S0, 5, nullptr, nullptr, nullptr);        // a5      -> S0
-    gemm16(S0, p.W[6], p.b[6], S1, false); act(S1, 6, S2, nullptr, x_out);               // r3      -> S1
-    gemm16(S1, p.W[7], p.b[7], S0, false); act(S0, 7, nullptr, nullptr, nullptr);        // o1      -> S0
-    gemm16(S0, p.W[8], p.b[8], S2, false); act(S2, 8, nullptr, nullptr, nullptr);        // o2      -> S2
-    gemm16(S2, p.W[9], p.b[9], S0, false); act(S0, 9, nullptr, nullptr, nullptr);        // o3      -> S0
+    gemm16<false>(S0, wf, p.b[0], S1, p.W[1]); act(S1, 0, nullptr, nullptr, nullptr);       // h0      -> S1
+    gemm16<false>(S1, wf, p.b[1], S2, p.W[2]); act(S2, 1, nullptr, nullptr, nullptr);       // a1      -> S2
+    gemm16<false>(S2, wf, p.b[2], S0, p.W[3]); act(S0, 2, S1, S3, R);                       // r1      -> S0
+    gemm16<false>(S0, wf, p.b[3], S1, p.W[4]); act(S1, 3, nullptr, nullptr, nullptr);       // a3      -> S1
+    gemm16<false>(S1, wf, p.b[4], S2, p.W[5]); act(S2, 4, S0, nullptr, R + plane);          // r2      -> S2
+    gemm16<false>(S2, wf, p.b[5], S0, p.W[6]); act(S0, 5, nullptr, nullptr, nullptr);       // a5      -> S0
+    gemm16<false>(S0, wf, p.b[6], S1, p.W[7]); act(S1, 6, S2, nullptr, x_out);              // r3      -> S1
+    gemm16<false>(S1, wf, p.b[7], S0, p.W[8]); act(S0, 7, nullptr, nullptr, nullptr);       // o1      -> S0
+    gemm16<false>(S0, wf, p.b[8], S2, p.W[9]); act(S2, 8, nullptr, nullptr, nullptr);       // o2      -> S2
+    gemm16<false>(S2, wf, p.b[9], S0, nullptr); act(S0, 9, nullptr, nullptr, nullptr);      // o3      -> S0
 
     // heads: 16 lanes per row, 8 columns each, butterfly over the 16-lane group
     {
@@ -146,6 +152,8 @@ __global__ __launch_bounds__(WG) void node_tail_bwd_kernel(const float* __restri
     __syncthreads();
 
     // d a (S0) [+ S2, optionally re-stored to S2 / a global tensor]  ->  dz_k = d a * SiLU'(z_k)  -> S1 and dZ_k
+    WFrag wf;
+    load_wfrag<true>(wf, p.W[9], DIM, (threadIdx.x >> 6) * 32);
     auto back = [&](int k, bool add_s2, bool keep_s2, float* extra_out) {
         sweep_rows<BMN>([&](int r, int c4) {
             const int64_t g = row0 + r;
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(WG) void node_tail_bwd_kernel(const float* __restri
             st_lds4(S1, r, c4, dz);
         });
         __syncthreads();
-        gemm16(S1, p.W[k], nullptr, S0, true);                 // d(input of layer k) = dz_k * W_k
+        gemm16<true>(S1, wf, nullptr, S0, k > 0 ? p.W[k - 1] : nullptr);   // d(input of layer k) = dz_k * W_k
     };
 
     // head-vector partials: sum_rows d_out * o3, sum_rows d_att * o3, sum_rows d_out  (o3 = SiLU(z9))
@@ -254,10 +262,13 @@ __global__ __launch_bounds__(WG) void node_pre_fwd_kernel(const float* __restric
     const int64_t row0 = (int64_t)blockIdx.x * BMN;
     sweep_rows<BMN>([&](int r, int c4) {
         const int64_t g = row0 + r;
-        st_lds4(S0, r, c4, g < n ? ldg4(x, g, DIM, c4) : f4zero());
+        st_lds4(S0, r, c4, ldg4z(x, g, n, DIM, c4));
     });
     __syncthreads();
-    gemm16(S0, Wx1, bx1, S1, false);
+    const float* wps[4] = {wp0, wp1, wp2, wp3};
+    WFrag wf;
+    load_wfrag<false>(wf, Wx1, DIM, (threadIdx.x >> 6) * 32);
+    gemm16<false>(S0, wf, bx1, S1, wps[0], ldwp);
     sweep_rows<BMN>([&](int r, int c4) {
         const int64_t g = row0 + r;
         const float4 z = lds4(S1, r, c4);
@@ -269,15 +280,9 @@ __global__ __launch_bounds__(WG) void node_pre_fwd_kernel(const float* __restric
         }
     });
     __syncthreads();
-    const float* wps[4] = {wp0, wp1, wp2, wp3};
     const int64_t plane_p = n * DIM;                       // P is stored as nblk planes [N][128]
     for (int b = 0; b < nblk; ++b) {
-        f32x4 acc[1][2];
-        acc_zero<1>(acc);
-        const int wcol0 = (threadIdx.x >> 6) * 32;
-        mma_tile<1, false>(S1, wps[b], ldwp, wcol0, acc);
-        acc_to_lds<1>(acc, S2, wcol0, nullptr);
-        __syncthreads();
+        gemm16<false>(S1, wf, nullptr, S2, b + 1 < nblk ? wps[b + 1] : nullptr, ldwp);
         sweep_rows<BMN>([&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g < n) stg4(P + (int64_t)b * plane_p, g, DIM, c4, lds4(S2, r, c4));
@@ -303,16 +308,20 @@ __global__ __launch_bounds__(WG) void node_pre_bwd_kernel(const float* __restric
     const int wcol0 = (threadIdx.x >> 6) * 32;
     f32x4 acc[1][2];
     acc_zero<1>(acc);
+    WFrag wf;
+    load_wfrag<true>(wf, wps[0], ldwp, wcol0);
     for (int b = 0; b < nblk; ++b) {
         sweep_rows<BMN>([&](int r, int c4) {
             const int64_t g = row0 + r;
-            st_lds4(S0, r, c4, g < n ? ldg4(dP + (int64_t)b * plane_p, g, DIM, c4) : f4zero());
+            st_lds4(S0, r, c4, ldg4z(dP + (int64_t)b * plane_p, g, n, DIM, c4));
         });
         __syncthreads();
-        mma_tile<1, true>(S0, wps[b], ldwp, wcol0, acc);      // accumulate over the projection blocks
+        mma_tile_frag<1>(S0, wf, acc);                        // accumulate over the projection blocks
+        if (b + 1 < nblk) load_wfrag<true>(wf, wps[b + 1], ldwp, wcol0);
+        else load_wfrag<true>(wf, Wx1, DIM, wcol0);           // weights of the final GEMM: in flight during the sweep
         __syncthreads();
     }
-    acc_to_lds<1>(acc, S1, wcol0, nullptr);
+    acc_to_lds<1>(acc, S1, wcol0, load_bias2(nullptr, wcol0));
     __syncthreads();
     sweep_rows<BMN>([&](int r, int c4) {
         const int64_t g = row0 + r;
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(WG) void node_pre_bwd_kernel(const float* __restric
         st_lds4(S2, r, c4, dz);
     });
     __syncthreads();
-    gemm16(S2, Wx1, nullptr, S0, true);
+    gemm16<true>(S2, wf, nullptr, S0, nullptr);
     sweep_rows<BMN>([&](int r, int c4) {
         const int64_t g = row0 + r;
         if (g < n) {

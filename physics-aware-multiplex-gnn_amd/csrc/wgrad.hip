@@ -2,9 +2,10 @@
 //
 // The backward of every Linear in a PAMNet layer needs one of these; the reference launches one GEMM + one reduce per
 // Linear (~60 per layer pair, most with only 2-4 K rows: launch-latency bound).  Here all jobs of a layer are ONE
-// launch: grid = (split, jobs).  Each workgroup reduces a contiguous chunk of rows into a full 128x128 fp32 tile with
-// v_mfma_f32_16x16x4_f32 (the row index is the MFMA k dimension), writes it to a partial buffer, and a second small
-// kernel sums the partials in a fixed order -> deterministic, atomics-free.
+// launch over a compact 1-D grid: job j owns ceil(rows_j / 256) consecutive workgroups ("slots"); each reduces its
+// contiguous <=256-row chunk into a full 128x128 fp32 tile with v_mfma_f32_16x16x4_f32 (the row index is the MFMA k
+// dimension) and writes it to its slot of a partial buffer; a second small kernel sums each job's slots in a fixed
+// order -> deterministic, atomics-free.
 // A may be given as a pre-activation (a_mode 1: A = SiLU(Z_prev) applied while staging), so activations that are a
 // pure SiLU of a saved z are never stored twice.
 #include "common.h"
@@ -15,8 +16,10 @@ using namespace pamnet;
 namespace {
 
 constexpr int MAXJ = 24;
-constexpr int RB = 32;            // rows staged per step
+constexpr int RB = 64;            // rows staged per step (2 x 36 KB LDS: 64 rows of dZ and A in flight per fetch)
 constexpr int LDW = 144;          // LDS leading dim: 144 mod 32 = 16 -> conflict-free ds_read_b32 fragment reads
+constexpr int ROWS_PER_WG = 256;
+constexpr int MAX_SLOTS_PER_JOB = 256;
 
 struct WJob {
     const float* dZ;
@@ -28,21 +31,24 @@ struct WJob {
 };
 struct WBatch {
     WJob job[MAXJ];
+    int start[MAXJ + 1];          // slot prefix: job j owns slots [start[j], start[j+1])
+    int njobs;
 };
 
-__host__ __device__ inline int job_split(int64_t rows, int split) {
-    const int64_t want = (rows + 511) / 512;
-    return (int)(want < 1 ? 1 : (want > split ? split : want));
+inline int job_slots(int64_t rows) {
+    const int64_t want = (rows + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    return (int)(want < 1 ? 1 : (want > MAX_SLOTS_PER_JOB ? MAX_SLOTS_PER_JOB : want));
 }
 
-__global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, int split, float* __restrict__ partial) {
+__global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float lds[2 * RB * LDW];
     float* Zs = lds;
     float* As = lds + RB * LDW;
-    const WJob jb = batch.job[blockIdx.y];
-    const int s = blockIdx.x;
-    const int js = job_split(jb.rows, split);               // short jobs use (and later sum) fewer partial slots
-    if (s >= js) return;
+    int j = 0;
+    while (j + 1 < batch.njobs && (int)blockIdx.x >= batch.start[j + 1]) ++j;       // wave-uniform scalar search
+    const WJob jb = batch.job[j];
+    const int s = blockIdx.x - batch.start[j];
+    const int js = batch.start[j + 1] - batch.start[j];
     const int64_t chunk = ((jb.rows + js - 1) / js + RB - 1) / RB * RB;
     const int64_t beg = (int64_t)s * chunk;
     const int64_t end = beg + chunk < jb.rows ? beg + chunk : jb.rows;
@@ -54,7 +60,10 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, int split, floa
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    double colsum = 0.0;      // threads 0..127: bias gradient of column threadIdx.x (fp64: long, cancelling sums)
+    // bias gradient: thread t = (column t & 127, row half t >> 7); fp32 inside a 16-row half block, fp64 across blocks
+    double colsum = 0.0;
+    const int bc = threadIdx.x & 127, bh = threadIdx.x >> 7;
+    const bool want_bias = jb.db != nullptr;
 
     // register double buffer: the next 32-row block is in flight from L2/HBM while the MFMAs chew on the current one
     const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;
@@ -63,30 +72,35 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, int split, floa
 #pragma unroll
         for (int i = 0; i < RB / 8; ++i) {
             const int64_t g = r0 + rr + 8 * i;
-            zr[i] = f4zero();
-            ar[i] = f4zero();
-            if (g < end) {
-                zr[i] = ldg4(jb.dZ, g, jb.ld_dz, c4);
-                ar[i] = ldg4(jb.A, g, jb.ld_a, c4);
-            }
+            const bool ok = g < end;
+            const int64_t gg = ok ? g : beg;                  // clamp instead of branching: loads stay unconditional
+            zr[i] = ldg4(jb.dZ, gg, jb.ld_dz, c4);
+            ar[i] = ldg4(jb.A, gg, jb.ld_a, c4);
+            if (!ok) { zr[i] = f4zero(); ar[i] = f4zero(); }
         }
     };
     if (beg < end) fetch(beg);
     for (int64_t r0 = beg; r0 < end; r0 += RB) {
-        // stage dZ[r0:r0+32, :] and A[r0:r0+32, :] (coalesced float4, zero padded)
 #pragma unroll
         for (int i = 0; i < RB / 8; ++i) {
             const int r = rr + 8 * i;
             float4 a = ar[i];
-            if (jb.a_mode == 1 && r0 + r < end) a = f4silu(a);
+            if (jb.a_mode == 1) a = f4silu(a);                 // SiLU(0) = 0 keeps the zero padding
             *reinterpret_cast<float4*>(Zs + r * LDW + 4 * c4) = zr[i];
             *reinterpret_cast<float4*>(As + r * LDW + 4 * c4) = a;
         }
         __syncthreads();
         if (r0 + RB < end) fetch(r0 + RB);
-        if (jb.db && threadIdx.x < 128) {
-#pragma unroll 8
-            for (int r = 0; r < RB; ++r) colsum += (double)Zs[r * LDW + threadIdx.x];
+        if (want_bias) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int r = 0; r < RB / 2; r += 4) {
+                s0 += Zs[((RB / 2) * bh + r) * LDW + bc];
+                s1 += Zs[((RB / 2) * bh + r + 1) * LDW + bc];
+                s2 += Zs[((RB / 2) * bh + r + 2) * LDW + bc];
+                s3 += Zs[((RB / 2) * bh + r + 3) * LDW + bc];
+            }
+            colsum += (double)((s0 + s1) + (s2 + s3));
         }
 #pragma unroll
         for (int st = 0; st < RB / 4; ++st) {
@@ -105,54 +119,105 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, int split, floa
         }
         __syncthreads();
     }
-    // partial[job][split][128][128] (+ bias partial behind it)
-    float* out = partial + ((int64_t)blockIdx.y * split + s) * (DIM * DIM + DIM);
+    // partial[slot][128*128 + 2*128]: the tile, then the two row-half bias partials
+    // The accumulator layout (4 rows x 16 columns per store) would hit memory as 64-byte fragments; transpose through
+    // LDS (the staging buffers are free now: 128 x 132 floats fit) and write the tile as coalesced 512-byte rows.
+    float* out = partial + (int64_t)blockIdx.x * (DIM * DIM + 2 * DIM);
+    float* T = lds;
+    static_assert(2 * RB * LDW >= DIM * LDT, "tile must fit in the staging buffers");
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                out[(i0 + 16 * a + kg * 4 + r) * DIM + j0 + 16 * b + r16] = acc[a][b][r];
-    if (threadIdx.x < 128) out[DIM * DIM + threadIdx.x] = (float)colsum;
+                T[(i0 + 16 * a + kg * 4 + r) * LDT + j0 + 16 * b + r16] = acc[a][b][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < DIM / 8; ++i) {
+        const int row = rr + 8 * i;
+        *reinterpret_cast<float4*>(out + row * DIM + 4 * c4) = *reinterpret_cast<const float4*>(T + row * LDT + 4 * c4);
+    }
+    out[DIM * DIM + threadIdx.x] = (float)colsum;
 }
 
-__global__ __launch_bounds__(WG) void wgrad_reduce_kernel(WBatch batch, int split, const float* __restrict__ partial) {
+// Fixed-order two-level sum of a job's slots.  A block owns 64 consecutive tile elements (16 float4 columns) and
+// splits the slots over 16 groups (group g takes slots s0+g, s0+g+16, ...), then adds the 16 group sums in order.
+__global__ __launch_bounds__(WG) void wgrad_reduce_kernel(WBatch batch, const float* __restrict__ partial) {
+    __shared__ float4 red[16][16];
     const WJob jb = batch.job[blockIdx.y];
-    const float* base = partial + (int64_t)blockIdx.y * split * (DIM * DIM + DIM);
-    const int t = blockIdx.x * WG + threadIdx.x;                 // 0 .. 128*128 + 128
-    const int js = job_split(jb.rows, split);
-    if (t < DIM * DIM) {
-        float s = 0.f;
-        for (int q = 0; q < js; ++q) s += base[(int64_t)q * (DIM * DIM + DIM) + t];
-        jb.dW[(int64_t)(t >> 7) * jb.ld_dw + (t & 127)] = s;
-    } else if (t < DIM * DIM + DIM && jb.db) {
-        double s = 0.0;
-        for (int q = 0; q < js; ++q) s += (double)base[(int64_t)q * (DIM * DIM + DIM) + t];
-        jb.db[t - DIM * DIM] = (float)s;
+    const int s0 = batch.start[blockIdx.y], s1 = batch.start[blockIdx.y + 1];
+    constexpr int64_t SLOT = DIM * DIM + 2 * DIM;
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int e4 = blockIdx.x * 16 + c;                           // float4 index inside the 128x128 tile (grid covers it)
+    float4 s = f4zero();
+    for (int q = s0 + g; q < s1; q += 16)
+        s = f4add(s, *reinterpret_cast<const float4*>(partial + (int64_t)q * SLOT + 4 * e4));
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0) {
+        float4 t = red[0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t = f4add(t, red[k][c]);
+        const int el = 4 * e4;
+        *reinterpret_cast<float4*>(jb.dW + (int64_t)(el >> 7) * jb.ld_dw + (el & 127)) = t;
+    }
+}
+
+// bias gradients: db[c] = sum over slots of both row-half partials.  128 columns x 8 slot groups, fp64, fixed order.
+__global__ __launch_bounds__(1024) void wgrad_bias_kernel(WBatch batch, const float* __restrict__ partial) {
+    __shared__ double red[8][128];
+    const WJob jb = batch.job[blockIdx.x];
+    if (!jb.db) return;
+    const int s0 = batch.start[blockIdx.x], s1 = batch.start[blockIdx.x + 1];
+    constexpr int64_t SLOT = DIM * DIM + 2 * DIM;
+    const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+    double s = 0.0;
+    for (int q = s0 + g; q < s1; q += 8)
+        s += (double)partial[(int64_t)q * SLOT + DIM * DIM + c] + (double)partial[(int64_t)q * SLOT + DIM * DIM + DIM + c];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0) {
+        double t = red[0][c];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][c];
+        jb.db[c] = (float)t;
     }
 }
 
 }  // namespace
 
-// jobs described by parallel host arrays (njobs <= 24).  partial: njobs * split * (128*128 + 128) floats of scratch.
+// Scratch needed for a batch: sum_j clamp(ceil(rows_j/256), 1, 256) slots of (128*128 + 256) floats.
+extern "C" int pamnet_wgrad_scratch_floats(int64_t njobs, const int64_t* rows, int64_t* floats) {
+    if (njobs < 0 || njobs > MAXJ || !floats || (njobs > 0 && !rows)) return PAMNET_EINVAL;
+    int64_t slots = 0;
+    for (int64_t j = 0; j < njobs; ++j) slots += job_slots(rows[j]);
+    *floats = slots * (int64_t)(DIM * DIM + 2 * DIM);
+    return PAMNET_OK;
+}
+
+// jobs described by parallel host arrays (njobs <= 24).  partial: pamnet_wgrad_scratch_floats(njobs, rows) floats.
 extern "C" int pamnet_wgrad_batched_f32(int64_t njobs, const float* const* dZ, const int64_t* ld_dz,
                                         const float* const* A, const int64_t* ld_a, const int32_t* a_mode,
                                         const int64_t* rows, float* const* dW, const int64_t* ld_dw, float* const* db,
-                                        int64_t split, float* partial, pamnet_stream_t stream) {
-    if (njobs < 0 || njobs > MAXJ || split < 1 || split > 1024) return PAMNET_EINVAL;
+                                        float* partial, pamnet_stream_t stream) {
+    if (njobs < 0 || njobs > MAXJ) return PAMNET_EINVAL;
     if (njobs == 0) return PAMNET_OK;
     if (!dZ || !ld_dz || !A || !ld_a || !a_mode || !rows || !dW || !ld_dw || !db || !partial) return PAMNET_ENULL;
     WBatch b;
+    b.njobs = (int)njobs;
+    b.start[0] = 0;
     for (int j = 0; j < njobs; ++j) {
         if (!dZ[j] || !A[j] || !dW[j]) return PAMNET_ENULL;
         b.job[j] = WJob{dZ[j], A[j], dW[j], db[j], rows[j], (int)ld_dz[j], (int)ld_a[j], (int)ld_dw[j], a_mode[j]};
+        b.start[j + 1] = b.start[j] + job_slots(rows[j]);
     }
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)split, (unsigned)njobs), dim3(WG), 0, st, b, (int)split, partial);
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)b.start[njobs]), dim3(WG), 0, st, b, partial);
     PAMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((DIM * DIM + DIM + WG - 1) / WG, (unsigned)njobs), dim3(WG), 0, st, b,
-                       (int)split, partial);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(DIM * DIM / 64, (unsigned)njobs), dim3(WG), 0, st, b, partial);
+    PAMNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_bias_kernel, dim3((unsigned)njobs), dim3(1024), 0, st, b, partial);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

@@ -56,14 +56,15 @@ def wgrad(jobs, ref):
     """jobs: list of (dZ, ld_dz, A, ld_a, a_mode, rows, dW(tensor or address), ld_dw, db).  One launch for all."""
     if not jobs:
         return
-    rows_max = max(j[5] for j in jobs)
-    split = int(min(64, max(1, (rows_max + 511) // 512)))
     n = len(jobs)
-    partial = torch.empty(n * split * (D * D + D), dtype=torch.float32, device=ref.device)
+    rows = _iarr([j[5] for j in jobs])
+    need = ctypes.c_int64(0)
+    lib.call('pamnet_wgrad_scratch_floats', n, rows, ctypes.addressof(need))
+    partial = torch.empty(int(need.value), dtype=torch.float32, device=ref.device)
     lib.call('pamnet_wgrad_batched_f32', n, _parr([j[0] for j in jobs]), _iarr([j[1] for j in jobs]),
              _parr([j[2] for j in jobs]), _iarr([j[3] for j in jobs]), _iarr([j[4] for j in jobs], ctypes.c_int32),
-             _iarr([j[5] for j in jobs]), _parr([j[6] for j in jobs]), _iarr([j[7] for j in jobs]),
-             _parr([j[8] for j in jobs]), split, lib.ptr(partial), lib.stream_of(ref))
+             rows, _parr([j[6] for j in jobs]), _iarr([j[7] for j in jobs]), _parr([j[8] for j in jobs]),
+             lib.ptr(partial), lib.stream_of(ref))
 
 
 # ---------------------------------------------------------------------------------------------------- raw kernel calls
