@@ -96,10 +96,27 @@ class _PAMNetBase(nn.Module):
 
     # ------------------------------------------------------------------------------------------------------------
     def _graph(self, data):
+        pre = getattr(data, '_pamnet_prepared', None)
+        if pre is not None and (pre.need_grad or not torch.is_grad_enabled()):
+            return pre                                   # built ahead of time by prepare() (possibly on a side stream)
         ng = getattr(data, 'num_graphs', None)
-        return G.build_graph(self.dataset, self.cutoff_l, self.cutoff_g, self.flow, data.x, data.batch,
-                             getattr(data, 'pos', None), getattr(data, 'edge_index', None), num_graphs=ng,
-                             need_grad=torch.is_grad_enabled(), with_triplets=not self.small)
+        g = G.build_graph(self.dataset, self.cutoff_l, self.cutoff_g, self.flow, data.x, data.batch,
+                          getattr(data, 'pos', None), getattr(data, 'edge_index', None), num_graphs=ng,
+                          need_grad=torch.is_grad_enabled(), with_triplets=not self.small)
+        g.need_grad = torch.is_grad_enabled()
+        g.sbf = self.sbf(g)                              # [T+P, 42]; geometry only, no parameters
+        return g
+
+    def prepare(self, data, need_grad=True):
+        """Parameter-independent part of forward(data): graph construction (models.py:104-177) and the spherical
+        basis.  It depends on the batch only, so an input pipeline can run it ahead of time -- e.g. on a side stream
+        while the previous step is still executing (pamnet_amd.train.Trainer.step(..., next_data=...)).  The result
+        is attached to `data` and picked up by forward()."""
+        self._check_dataset()
+        with torch.set_grad_enabled(need_grad):
+            data._pamnet_prepared = None
+            data._pamnet_prepared = self._graph(data)
+        return data
 
     def _embed(self, data, g):
         x_raw = data.x
@@ -114,7 +131,7 @@ class _PAMNetBase(nn.Module):
     def _edge_embeddings(self, g):
         rbf_l = self.rbf_l(g.dist_l)
         rbf_g = self.rbf_g(g.dist_g)
-        sbf = self.sbf(g)                                                                    # [T+P, 42], no grad
+        sbf = g.sbf                                                                          # [T+P, 42], no grad
         e_l = mlp_apply(self.mlp_rbf_l, rbf_l)
         e_g = mlp_apply(self.mlp_rbf_g, rbf_g)
         return e_l, e_g, sbf

@@ -108,13 +108,42 @@ class Trainer(object):
         decay = min(self.ema_decay, (1.0 + num_updates) / (10.0 + num_updates))     # utils/ema.py:14
         self.shadow.mul_(decay).add_(self.fp.flat, alpha=1.0 - decay)
 
-    def step(self, data, lr=None, global_graphs=None):
+    def step(self, data, lr=None, global_graphs=None, next_data=None):
+        """One training step.  `next_data`: the batch of the following step; its graph is built on a side stream
+        while this step's kernels run (input pipelining -- graph construction needs host round trips for the
+        data-dependent sizes, which would otherwise drain the GPU queue at the start of every step)."""
+        self._wait_prepared(data)
         loss = self.forward_backward(data, global_graphs)
         self.sync_gradients()
         self.clip()
         self.optimizer_step(lr)
         self.ema_update()
+        if next_data is not None:
+            self.prefetch(next_data)
         return loss
+
+    # -- input pipelining -----------------------------------------------------------------------------------------------
+    def prefetch(self, data):
+        """Build `data`'s graph on the side stream (model.prepare); forward() picks it up."""
+        if not hasattr(self.model, 'prepare') or not self.fp.flat.is_cuda:
+            return
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=self.fp.flat.device)
+        main = torch.cuda.current_stream(self.fp.flat.device)
+        with torch.cuda.stream(self._side):
+            self.model.prepare(data)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        data._pamnet_ready = ev
+        # the tensors were allocated on the side stream but will be consumed on the main stream
+        for v in _graph_tensors(data._pamnet_prepared):
+            v.record_stream(main)
+
+    def _wait_prepared(self, data):
+        ev = getattr(data, '_pamnet_ready', None)
+        if ev is not None:
+            torch.cuda.current_stream(self.fp.flat.device).wait_event(ev)
+            data._pamnet_ready = None
 
     # -- evaluation under the EMA weights (main_qm9.py:29-37) ---------------------------------------------------------
     def ema_assign(self):
@@ -138,6 +167,17 @@ class Trainer(object):
         if self.world_size > 1:
             dist.all_reduce(tot, group=self.pg)
         return float(tot[0] / tot[1])
+
+
+def _graph_tensors(g):
+    """Every tensor hanging off a prepared graph (one level of nested index structures)."""
+    out = []
+    for v in vars(g).values():
+        if isinstance(v, torch.Tensor):
+            out.append(v)
+        elif hasattr(v, '__slots__'):
+            out += [getattr(v, k) for k in v.__slots__ if isinstance(getattr(v, k, None), torch.Tensor)]
+    return out
 
 
 def shard_range(total, rank, world):
