@@ -1,0 +1,377 @@
+// Fused node-update tail of PAMNet's message-passing layers (dim = 128), forward and backward.
+//
+// Both layer kinds end with the same 10-Linear stack per node (layers/global_message_passing.py:39-50 /
+// layers/local_message_passing.py:55-66; Res: layers/basic.py:25-33):
+//     h0 = SiLU(L0 x)                                 mlp_x2
+//     r1 = SiLU(L2 SiLU(L1 h0)) + h0 + res_x          res1 (+ the layer's residual input)
+//     r2 = SiLU(L4 SiLU(L3 r1)) + r1                  res2
+//     r3 = SiLU(L6 SiLU(L5 r2)) + r2                  res3  -> x_out
+//     o3 = SiLU(L9 SiLU(L8 SiLU(L7 r3)))              mlp_out
+//     out = W_out . o3 + b_out,  att = W . o3
+// One workgroup keeps a 16-row tile on-chip from the first GEMM to the last: ten fp32-MFMA GEMMs, bias / SiLU /
+// residual epilogues and both heads in ONE launch (the reference issues ~40 kernels for the same work).
+//
+// The chain is latency-bound (a 16x128x128 GEMM is 256 MFMAs in total), so each layer is the shortest dependent
+// sequence:  A fragments (ds_read_b128)  ->  MFMAs  ->  epilogue IN THE ACCUMULATOR REGISTERS (bias, SiLU, residuals
+// read from LDS in fragment layout, z_k / taps stored to global)  ->  one LDS write  ->  ONE barrier.
+// What bounds it: a 16-row tile re-reads the whole 64 KB weight matrix for every layer (8 FLOP per L2 byte), so the
+// chain runs at L2 / texture-path rate, not at MFMA rate (measured ~29 us for 10 layers on 143 workgroups; the MFMAs
+// alone need ~9 us).  The next layer's weight slice is therefore requested right after the MFMAs are issued, and the
+// backward -- whose transposed weight reads are scalar, 4x more load instructions -- uses 8 waves x 16 columns so two
+// waves per SIMD overlap loads, MFMAs and epilogue (27 us vs 29 us); its z_k are fetched before the MFMAs start.
+#include "common.h"
+#include "gemm_core.h"
+
+using namespace pamnet;
+
+namespace {
+
+struct TailParams {
+    const float* W[10];
+    const float* b[10];
+    const float* w_out;   // [128]
+    const float* b_out;   // [1]
+    const float* w_att;   // [128]
+};
+
+constexpr int BMN = 16;                       // rows per workgroup
+constexpr int SLOT = BMN * LDT;               // floats per LDS slot
+constexpr int TWG = 512;                      // 8 waves
+
+// fragment coordinates of accumulator element r of this lane: row = 4*(lane>>4) + r, col = 16*wave + (lane&15)
+struct Frag {
+    int wc, r16, kg;
+    __device__ __forceinline__ Frag() {
+        const int lane = threadIdx.x & 63;
+        wc = (threadIdx.x >> 6) * 16;
+        r16 = lane & 15;
+        kg = lane >> 4;
+    }
+    __device__ __forceinline__ int row(int r) const { return 4 * kg + r; }
+    __device__ __forceinline__ int col() const { return wc + r16; }
+};
+
+// one 128 x 16 weight slice of a wave: 8 x float4 = 32 VGPRs
+struct WFrag1 {
+    float4 b[DIM / 16];
+};
+
+template <bool TRANS>
+__device__ __forceinline__ void load_wfrag1(WFrag1& f, const float* __restrict__ W, int wc) {
+    const int lane = threadIdx.x & 63;
+    const int r16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < DIM / 16; ++q) {
+        if (!TRANS) {
+            f.b[q] = *reinterpret_cast<const float4*>(W + (size_t)(wc + r16) * DIM + 4 * kg + 16 * q);
+        } else {
+            const float* wp = W + (size_t)(16 * q + 4 * kg) * DIM + wc + r16;
+            f.b[q] = make_float4(wp[0], wp[DIM], wp[2 * DIM], wp[3 * DIM]);
+        }
+    }
+}
+
+// [16 x 128] (LDS) x [128 x 16] (registers) -> one 16x16 accumulator; two interleaved chains
+__device__ __forceinline__ f32x4 mma_strip(const float* __restrict__ As, const WFrag1& f) {
+    const int lane = threadIdx.x & 63;
+    const float* ap = As + (lane & 15) * LDT + 4 * (lane >> 4);
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < DIM / 16; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(ap + 16 * q);
+        const float4 b = f.b[q];
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c1, 0, 0, 0);
+    }
+    return c0 + c1;
+}
+
+// Forward: 4 waves x 32 columns (float4 weight loads are cheap per byte, so fewer, wider waves win: 29 us vs 33 us).
+__global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restrict__ x2,
+                                                           const float* __restrict__ res_x, int64_t n, TailParams p,
+                                                           float* __restrict__ Z, float* __restrict__ R,
+                                                           float* __restrict__ x_out, float* __restrict__ out,
+                                                           float* __restrict__ att) {
+    __shared__ __attribute__((aligned(16))) float lds[5 * SLOT];
+    float* X0 = lds;
+    float* RX = lds + SLOT;
+    float* A = lds + 2 * SLOT;
+    float* B = lds + 3 * SLOT;
+    float* C = lds + 4 * SLOT;
+    const int64_t row0 = (int64_t)blockIdx.x * BMN;
+    const int64_t plane = n * DIM;
+    const int lane = threadIdx.x & 63, r16 = lane & 15, kg = lane >> 4;
+    const int wc = (threadIdx.x >> 6) * 32;
+
+    WFrag wf;
+    load_wfrag<false>(wf, p.W[0], DIM, wc);
+    sweep_rows<BMN>([&](int r, int c4) {
+        const int64_t g = row0 + r;
+        st_lds4(X0, r, c4, ldg4z(x2, g, n, DIM, c4));
+        st_lds4(RX, r, c4, ldg4z(res_x, g, n, DIM, c4));
+    });
+    __syncthreads();
+
+    // layer k: in -> dst = SiLU(W_k in + b_k) (+ add1 + add2); z_k saved; optional save of the result (residual taps)
+    auto layer = [&](const float* in, float* dst, int k, const float* add1, const float* add2, float* save,
+                     const float* Wnext) {
+        const Bias2 bv = load_bias2(p.b[k], wc);               // before the prefetch (in-order vmcnt)
+        f32x4 acc[1][2];
+        acc_zero<1>(acc);
+        mma_tile_frag<1>(in, wf, acc);
+        if (Wnext) load_wfrag<false>(wf, Wnext, DIM, wc);
+        float* zk = Z + (int64_t)k * plane;
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+            const int c = wc + 16 * n2 + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rw = 4 * kg + r;
+                const float z = acc[0][n2][r] + bv.v[n2];
+                float a = silu(z);
+                if (add1) a += add1[rw * LDT + c];
+                if (add2) a += add2[rw * LDT + c];
+                dst[rw * LDT + c] = a;
+                const int64_t g = row0 + rw;
+                if (g < n) {
+                    zk[g * DIM + c] = z;
+                    if (save) save[g * DIM + c] = a;
+                }
+            }
+        }
+        __syncthreads();
+    };
+
+    layer(X0, A, 0, nullptr, nullptr, nullptr, p.W[1]);        // h0 -> A
+    layer(A, B, 1, nullptr, nullptr, nullptr, p.W[2]);         // a1 -> B
+    layer(B, C, 2, A, RX, R, p.W[3]);                          // r1 -> C   (+ h0 + res_x)
+    layer(C, A, 3, nullptr, nullptr, nullptr, p.W[4]);         // a3 -> A
+    layer(A, B, 4, C, nullptr, R + plane, p.W[5]);             // r2 -> B   (+ r1)
+    layer(B, A, 5, nullptr, nullptr, nullptr, p.W[6]);         // a5 -> A
+    layer(A, C, 6, B, nullptr, x_out, p.W[7]);                 // r3 -> C   (+ r2)  = x_out
+    layer(C, A, 7, nullptr, nullptr, nullptr, p.W[8]);         // o1 -> A
+    layer(A, B, 8, nullptr, nullptr, nullptr, p.W[9]);         // o2 -> B
+    layer(B, A, 9, nullptr, nullptr, nullptr, nullptr);        // o3 -> A
+
+    // heads: 16 lanes per row, 8 columns each, butterfly over the 16-lane group
+    {
+        const int r = threadIdx.x >> 4, part = threadIdx.x & 15;
+        float so = 0.f, sa = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float v = A[r * LDT + part * 8 + c];
+            so += v * p.w_out[part * 8 + c];
+            sa += v * p.w_att[part * 8 + c];
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) {
+            so += __shfl_xor(so, o, 64);
+            sa += __shfl_xor(sa, o, 64);
+        }
+        const int64_t g = row0 + r;
+        if (part == 0 && g < n) {
+            out[g] = so + p.b_out[0];
+            att[g] = sa;
+        }
+    }
+}
+
+// Backward of the chain.  Produces dZ_k for every layer (consumed by the batched weight-gradient kernel), d x2 (gradient
+// of the chain input), d res_x, and per-workgroup partial sums for the two head vectors.
+__global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restrict__ d_xout /* may be null */,
+                                                            const float* __restrict__ d_out,
+                                                            const float* __restrict__ d_att, int64_t n, TailParams p,
+                                                            const float* __restrict__ Z, float* __restrict__ dZ,
+                                                            float* __restrict__ d_x2, float* __restrict__ d_resx,
+                                                            float* __restrict__ head_partial /* [grid][257] */) {
+    __shared__ __attribute__((aligned(16))) float lds[3 * SLOT + 16 * 256 + 16];
+    float* D0 = lds;                  // dz ping
+    float* D1 = lds + SLOT;           // dz pong
+    float* K = lds + 2 * SLOT;        // residual gradient kept across a Res block
+    float* red = lds + 3 * SLOT;      // [16][256] head partials (+16 for d b_out)
+    const int64_t row0 = (int64_t)blockIdx.x * BMN;
+    const int64_t plane = n * DIM;
+    const Frag fr;
+    const int c = fr.col();
+
+    WFrag1 wf;
+    load_wfrag1<true>(wf, p.W[9], fr.wc);
+
+    // pre-activation fragment of layer k (4 scalar loads per lane, issued early)
+    auto load_z = [&](int k) {
+        f32x4 z;
+        const float* zk = Z + (int64_t)k * plane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t g = row0 + fr.row(r);
+            z[r] = zk[(g < n ? g : 0) * DIM + c];
+        }
+        return z;
+    };
+
+    // head-vector partials: sum_rows d_out * o3, sum_rows d_att * o3, sum_rows d_out  (o3 = SiLU(z9))
+    {
+        const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;      // one row per thread
+        float4 so = f4zero(), sa = f4zero();
+        float sb = 0.f;
+        const int64_t g = row0 + r0;
+        if (g < n) {
+            const float4 o3 = f4silu(ldg4(Z + 9 * plane, g, DIM, c4));
+            const float go = d_out[g], ga = d_att[g];
+            so = make_float4(go * o3.x, go * o3.y, go * o3.z, go * o3.w);
+            sa = make_float4(ga * o3.x, ga * o3.y, ga * o3.z, ga * o3.w);
+            sb = go;
+        }
+        float* mine = red + r0 * 256;
+        *reinterpret_cast<float4*>(mine + 4 * c4) = so;
+        *reinterpret_cast<float4*>(mine + 128 + 4 * c4) = sa;
+        if (c4 == 0) red[16 * 256 + r0] = sb;
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tot += red[q * 256 + threadIdx.x];
+            head_partial[(int64_t)blockIdx.x * 257 + threadIdx.x] = tot;
+        } else if (threadIdx.x == 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += red[16 * 256 + q];
+            head_partial[(int64_t)blockIdx.x * 257 + 256] = t;
+        }
+    }
+
+    // dz9 = (d_out * w_out + d_att * w_att) * SiLU'(z9) -> D0, dZ_9 ; K = d x_out (or 0)
+    {
+        const f32x4 z9 = load_z(9);
+        const float wo = p.w_out[c], wa = p.w_att[c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rw = fr.row(r);
+            const int64_t g = row0 + rw;
+            float dz = 0.f, kx = 0.f;
+            if (g < n) {
+                dz = (d_out[g] * wo + d_att[g] * wa) * dsilu(z9[r]);
+                dZ[9 * plane + g * DIM + c] = dz;
+                if (d_xout) kx = d_xout[g * DIM + c];
+            }
+            D0[rw * LDT + c] = dz;
+            K[rw * LDT + c] = kx;
+        }
+        __syncthreads();
+    }
+
+    // One backward step: v = dz_k * W_k (+ K) ; optionally K <- v, extra <- v ; then dz_{k-1} = v * SiLU'(z_{k-1}).
+    // k == 0 ends the chain: v = d x2.
+    auto back = [&](const float* in, float* dst, int k, bool add_k, bool keep_k, float* extra) {
+        f32x4 zn = {0.f, 0.f, 0.f, 0.f};
+        if (k > 0) zn = load_z(k - 1);                           // older than the weight prefetch (in-order vmcnt)
+        const f32x4 acc = mma_strip(in, wf);
+        if (k > 0) load_wfrag1<true>(wf, p.W[k - 1], fr.wc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rw = fr.row(r);
+            const int64_t g = row0 + rw;
+            float v = acc[r];
+            if (add_k) v += K[rw * LDT + c];
+            if (keep_k) K[rw * LDT + c] = v;
+            if (k == 0) {
+                if (g < n) d_x2[g * DIM + c] = v;
+            } else {
+                const float dz = (g < n) ? v * dsilu(zn[r]) : 0.f;
+                dst[rw * LDT + c] = dz;
+                if (g < n) {
+                    dZ[(int64_t)(k - 1) * plane + g * DIM + c] = dz;
+                    if (extra) extra[g * DIM + c] = v;
+                }
+            }
+        }
+        __syncthreads();
+    };
+
+    back(D0, D1, 9, false, false, nullptr);        // d o2          -> dz8
+    back(D1, D0, 8, false, false, nullptr);        // d o1          -> dz7
+    back(D0, D1, 7, true, true, nullptr);          // d r3 = . + d x_out (kept)   -> dz6
+    back(D1, D0, 6, false, false, nullptr);        // d a5          -> dz5
+    back(D0, D1, 5, true, true, nullptr);          // d r2 = . + d r3 (kept)      -> dz4
+    back(D1, D0, 4, false, false, nullptr);        // d a3          -> dz3
+    back(D0, D1, 3, true, true, d_resx);           // d r1 = . + d r2 (kept, = d res_x) -> dz2
+    back(D1, D0, 2, false, false, nullptr);        // d a1          -> dz1
+    back(D0, D1, 1, true, false, nullptr);         // d h0 = . + d r1             -> dz0
+    back(D1, D0, 0, false, false, nullptr);        // d x2
+}
+
+// columns: [0,128) d w_out, [128,256) d w_att, [256] d b_out
+// one workgroup per 16 columns: 16 row-slices x 16 columns, fixed-order tree in LDS (deterministic)
+__global__ __launch_bounds__(WG) void head_reduce_kernel(const float* __restrict__ partial, int nblocks,
+                                                         float* __restrict__ d_wout, float* __restrict__ d_watt,
+                                                         float* __restrict__ d_bout) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float s = 0.f;
+    if (c < 257)
+        for (int b = sl; b < nblocks; b += 16) s += partial[(int64_t)b * 257 + c];
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < 257) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][cl];
+        if (c < 128) d_wout[c] = t;
+        else if (c < 256) d_watt[c - 128] = t;
+        else d_bout[0] = t;
+    }
+}
+
+inline TailParams make_tail(const float* const* weights, const float* const* biases, const float* w_out,
+                            const float* b_out, const float* w_att) {
+    TailParams p;
+    for (int k = 0; k < 10; ++k) {
+        p.W[k] = weights[k];
+        p.b[k] = biases ? biases[k] : nullptr;
+    }
+    p.w_out = w_out;
+    p.b_out = b_out;
+    p.w_att = w_att;
+    return p;
+}
+
+}  // namespace
+
+extern "C" int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int64_t n, const float* const* weights,
+                                        const float* const* biases, const float* w_out, const float* b_out,
+                                        const float* w_att, float* Z, float* R, float* x_out, float* out, float* att,
+                                        pamnet_stream_t stream) {
+    if (n < 0) return PAMNET_EINVAL;
+    if (n == 0) return PAMNET_OK;
+    if (!x2 || !res_x || !weights || !biases || !w_out || !b_out || !w_att || !Z || !R || !x_out || !out || !att)
+        return PAMNET_ENULL;
+    for (int k = 0; k < 10; ++k)
+        if (!weights[k] || !biases[k]) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(node_tail_fwd_kernel, dim3((unsigned)ceil_div(n, BMN)), dim3(WG), 0, st, x2, res_x, n,
+                       make_tail(weights, biases, w_out, b_out, w_att), Z, R, x_out, out, att);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_node_tail_bwd_f32(const float* d_xout, const float* d_out, const float* d_att, int64_t n,
+                                        const float* const* weights, const float* w_out, const float* w_att,
+                                        const float* Z, float* dZ, float* d_x2, float* d_resx, float* head_partial,
+                                        float* d_wout, float* d_watt, float* d_bout, pamnet_stream_t stream) {
+    if (n < 0) return PAMNET_EINVAL;
+    if (n == 0) return PAMNET_OK;
+    if (!d_out || !d_att || !weights || !w_out || !w_att || !Z || !dZ || !d_x2 || !d_resx || !head_partial || !d_wout ||
+        !d_watt || !d_bout)
+        return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const unsigned grid = (unsigned)ceil_div(n, BMN);
+    hipLaunchKernelGGL(node_tail_bwd_kernel, dim3(grid), dim3(TWG), 0, st, d_xout, d_out, d_att, n,
+                       make_tail(weights, nullptr, w_out, nullptr, w_att), Z, dZ, d_x2, d_resx, head_partial);
+    PAMNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_reduce_kernel, dim3(17), dim3(WG), 0, st, head_partial, (int)grid, d_wout, d_watt, d_bout);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
