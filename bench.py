@@ -87,6 +87,18 @@ def scatter_add_roofline(dev, g, d, stream_gb):
     return res
 
 
+def mfma_summary(args, g, ms_per_step):
+    """Algorithmic dense-layer FLOPs of one training step of this rank (forward x3 for fwd+bwd) over the measured step
+    time, against the fp32 MFMA peak.  Per layer pair (with the W[x_i|x_j|e] split):
+    2 d^2 [ N (1+2+10) + 2 E_g ]  (global)  +  2 d^2 [ N (1+4+10) + 4 E_l + 2 (T+P) ]  (local)."""
+    d, n, eg, el, tp = args.dim, g.n, g.glob.m, g.loc.m, g.tp.m
+    fwd = args.n_layer * 2.0 * d * d * (13 * n + 2 * eg + 15 * n + 4 * el + 2 * tp)
+    fwd += 2.0 * d * (16 * (eg + el) + 42 * tp)                       # input embeddings (once per forward)
+    tf = 3.0 * fwd / (ms_per_step * 1e-3) / 1e12
+    return {'bound': 'mfma', 'scope': 'whole training step, algorithmic dense FLOPs (fwd x3)', 'flops_per_step': 3.0 * fwd,
+            'achieved': tf, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / FP32_MFMA_PEAK_TFLOPS}
+
+
 def cpu_baseline(args, seconds):
     """The oracle (pure-torch CPU port of the reference forward, oracle/pamnet_oracle.py) timed on the host cores:
     BASELINE.json configs[0]: B=32, d=128, L=6, forward+backward, bounded to ~`seconds` of CPU work."""
@@ -142,12 +154,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
 
     import models
     from pamnet_amd import lib, synth
@@ -222,9 +234,12 @@ def main():
                        'nodes_per_batch': int(g.n), 'global_edges': int(g.glob.m), 'local_edges': int(g.loc.m),
                        'triplets': int(g.n_trip), 'pairs': int(g.n_pair)},
             'forward_only_molecules_per_s': gB / (fwd_ms / 1e3), 'forward_ms': fwd_ms,
+            'mfma': mfma_summary(args, g, ms_per_step),
             'roofline': {'bound': 'hbm', 'kernel': 'segment_sum_kernel (pamnet_segment_sum_f32, scatter-add)',
                          'achieved': s['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': s['gbs'] / HBM_PEAK_GBS,
-                         'traffic': None, 'bytes_per_launch': s['bytes'], 'ms_per_launch': s['ms'],
+                         'traffic': None, 'traffic_note': 'PMC passes (FETCH_SIZE x2 + WRITE_SIZE) in '
+                         'profiles/r01_scatter_add_pmc.txt: 1.002 x algorithmic bytes',
+                         'bytes_per_launch': s['bytes'], 'ms_per_launch': s['ms'],
                          'shape': '[%d,%d]->[%d,%d] streamed (%.2f GB)' % (s['rows_in'], args.dim, s['rows_out'], args.dim, s['bytes'] / 1e9),
                          'at_workload_shape': roof['workload']},
         }
