@@ -197,6 +197,24 @@ int pamnet_mlp2_bwd_f32(const float* dy, int64_t rows, const float* z1, const fl
                         pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Input-embedding layers (128 outputs, K = 16 / 18 / 42 inputs):
+ *   out[r, :] = act( W_{kind[r]} x[r, :] + b_{kind[r]} ),  act = SiLU when `act` != 0, identity otherwise.
+ * Replaces mlp_rbf_g / mlp_rbf_l (K=16), mlp_sbf1 / mlp_sbf2 (K=42; `kind[r]` = 0 selects (W0,b0), 1 selects (W1,b1) on
+ * the combined triplet/pair row list) and init_linear (K=18, no bias, act=0): models.py:119,185-188, layers/basic.py:19-22.
+ * W*: [128, K] row-major (out, in); b* nullable; kind nullable (then only W0/b0 are used).
+ * Backward writes dW0/db0 (and dW1/db1 when kind != null) = sums over rows, reduced in a fixed order through `partial`
+ * (pamnet_embed_scratch_floats floats); dx [rows, K] (nullable) is only available for kind == null, K == 16.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pamnet_embed_scratch_floats(int64_t rows, int64_t K, int64_t* floats);
+int pamnet_embed_fwd_f32(const float* x, int64_t rows, int64_t K, const int32_t* kind, const float* W0,
+                         const float* b0, const float* W1, const float* b1, int32_t act, float* out,
+                         pamnet_stream_t stream);
+int pamnet_embed_bwd_f32(const float* x, int64_t rows, int64_t K, const int32_t* kind, const float* W0,
+                         const float* b0, const float* W1, const float* b1, int32_t act, const float* gout,
+                         float* dW0, float* db0, float* dW1, float* db1, float* dx, float* partial,
+                         pamnet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Layer-stack engine: the n_layer x (global, local) loop of PAMNet.forward (models.py:196-204) in ONE call per
  * direction (dim = 128).  Host-side C++ enqueues ~10 (fwd) / ~20 (bwd) fused launches per layer pair on `stream`.
  *   sizes      : {n, e_g, e_l, tp}

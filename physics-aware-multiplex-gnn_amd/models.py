@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from pamnet_amd import fused, modules
 from pamnet_amd import graph as G
 from pamnet_amd import ops
 from pamnet_amd.modules import MLP, BesselBasis, GlobalMP, LocalMP, mlp_apply
@@ -122,7 +123,10 @@ class _PAMNetBase(nn.Module):
         x_raw = data.x
         if self.dataset == 'PDBbind':
             xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
-            return F.linear(xr[:, 3:].to(torch.float32), self.init_linear.weight)          # models.py:119
+            feats = xr[:, 3:].to(torch.float32)
+            if modules.IMPL == 'fused' and fused.embed_supported(feats, self.init_linear):
+                return fused.embed(feats, self.init_linear, act=False)                     # models.py:119
+            return F.linear(feats, self.init_linear.weight)
         col = x_raw if self.dataset == 'QM9' else (x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw)[:, -1]
         idx = col.to(torch.int32).contiguous()
         tr = G.Transpose(idx, self.embeddings.size(0)) if torch.is_grad_enabled() else None
@@ -132,12 +136,19 @@ class _PAMNetBase(nn.Module):
         rbf_l = self.rbf_l(g.dist_l)
         rbf_g = self.rbf_g(g.dist_g)
         sbf = g.sbf                                                                          # [T+P, 42], no grad
-        e_l = mlp_apply(self.mlp_rbf_l, rbf_l)
-        e_g = mlp_apply(self.mlp_rbf_g, rbf_g)
+        if self._embed_fused(rbf_l, self.mlp_rbf_l):
+            e_l = fused.embed(rbf_l, self.mlp_rbf_l[0][0])                                   # models.py:186
+            e_g = fused.embed(rbf_g, self.mlp_rbf_g[0][0])                                   # models.py:185
+        else:
+            e_l = mlp_apply(self.mlp_rbf_l, rbf_l)
+            e_g = mlp_apply(self.mlp_rbf_g, rbf_g)
         return e_l, e_g, sbf
 
+    @staticmethod
+    def _embed_fused(x, seq):
+        return modules.IMPL == 'fused' and len(seq) == 1 and fused.embed_supported(x, seq[0][0])
+
     def _run_layers(self, x, e_l, e_g, e_sbf, g):
-        from pamnet_amd import fused, modules
         if modules._fused(x):                      # dim = 128 on an MI355X: the whole loop is one engine call
             outs, atts, saved = fused.layer_stack(self.global_layer, self.local_layer, x, e_g, e_l, e_sbf, g)
             self._x_layers = _LazyLayers(saved, g, self.n_layer)
@@ -182,10 +193,13 @@ class PAMNet(_PAMNetBase):
         x = self._embed(data, g)
         e_l, e_g, sbf = self._edge_embeddings(g)
         # mlp_sbf2 on triplet rows, mlp_sbf1 on pair rows (models.py:187-188), rows grouped by target edge
-        y2 = mlp_apply(self.mlp_sbf2, sbf.index_select(0, g.trip_rows))
-        y1 = mlp_apply(self.mlp_sbf1, sbf.index_select(0, g.pair_rows))
-        e_sbf = torch.zeros((sbf.size(0), self.dim), dtype=sbf.dtype, device=sbf.device)
-        e_sbf = e_sbf.index_copy(0, g.trip_rows, y2).index_copy(0, g.pair_rows, y1)
+        if self._embed_fused(sbf, self.mlp_sbf2):
+            e_sbf = fused.embed(sbf, self.mlp_sbf2[0][0], self.mlp_sbf1[0][0], kind=g.tp_kind)
+        else:
+            y2 = mlp_apply(self.mlp_sbf2, sbf.index_select(0, g.trip_rows))
+            y1 = mlp_apply(self.mlp_sbf1, sbf.index_select(0, g.pair_rows))
+            e_sbf = torch.zeros((sbf.size(0), self.dim), dtype=sbf.dtype, device=sbf.device)
+            e_sbf = e_sbf.index_copy(0, g.trip_rows, y2).index_copy(0, g.pair_rows, y1)
         outs, atts = self._run_layers(x, e_l, e_g, e_sbf, g)
         out, node_out = ops.fuse_pool(outs, atts, g, mean=self._rna)                       # models.py:206-224
         self._graph_cache, self._node_out = g, node_out
@@ -213,7 +227,8 @@ class PAMNet_s(_PAMNetBase):
         g = self._graph(data)
         x = self._embed(data, g)
         e_l, e_g, sbf = self._edge_embeddings(g)
-        e_sbf = mlp_apply(self.mlp_sbf, sbf)
+        e_sbf = fused.embed(sbf, self.mlp_sbf[0][0]) if self._embed_fused(sbf, self.mlp_sbf) \
+            else mlp_apply(self.mlp_sbf, sbf)
         outs, atts = self._run_layers(x, e_l, e_g, e_sbf, g)
         out, node_out = ops.fuse_pool(outs, atts, g, mean=False)
         self._graph_cache, self._node_out = g, node_out

@@ -158,6 +158,63 @@ def node_tail(layer, x2, res_x):
     return _NodeTail.apply(x2, res_x, tp, *tp)
 
 
+# ---------------------------------------------------------------------------------------------------- input embeddings
+class _Embed(torch.autograd.Function):
+    """act(W_kind x + b_kind) for the thin input layers (csrc/embed.hip): mlp_rbf_g/l (K=16), mlp_sbf1/2 (K=42, weight
+    set chosen per row by `kind`), init_linear (K=18, no bias / activation) -- models.py:119,185-188."""
+
+    @staticmethod
+    def forward(ctx, x, kind, act, plist, *params):
+        # params: W0, b0 (or None), [W1, b1]
+        x = x.contiguous()
+        rows, K = x.shape
+        W0, b0 = params[0], params[1]
+        W1, b1 = (params[2], params[3]) if len(params) > 2 else (None, None)
+        out = _empty(rows, D, like=x)
+        lib.call('pamnet_embed_fwd_f32', lib.ptr(x), rows, K, lib.ptr(kind), lib.ptr(W0), lib.ptr(b0), lib.ptr(W1),
+                 lib.ptr(b1), 1 if act else 0, lib.ptr(out), lib.stream_of(out))
+        ctx.save_for_backward(x, kind, *[p for p in params if p is not None])
+        ctx.layout = [p is not None for p in params]
+        ctx.act, ctx.plist, ctx.need_dx = act, plist, ctx.needs_input_grad[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, kind = ctx.saved_tensors[:2]
+        it = iter(ctx.saved_tensors[2:])
+        params = [next(it) if has else None for has in ctx.layout]
+        W0, b0 = params[0], params[1]
+        W1, b1 = (params[2], params[3]) if len(params) > 2 else (None, None)
+        gout = gout.contiguous()
+        rows, K = x.shape
+        direct, g = _grad_buffers(ctx.plist)
+        gi = iter(g)
+        gp = [next(gi) if has else None for has in ctx.layout]
+        need = ctypes.c_int64(0)
+        lib.call('pamnet_embed_scratch_floats', rows, K, ctypes.addressof(need))
+        partial = _empty(int(need.value), like=gout)
+        dx = _empty(rows, K, like=gout) if ctx.need_dx else None
+        lib.call('pamnet_embed_bwd_f32', lib.ptr(x), rows, K, lib.ptr(kind), lib.ptr(W0), lib.ptr(b0), lib.ptr(W1),
+                 lib.ptr(b1), 1 if ctx.act else 0, lib.ptr(gout), lib.ptr(gp[0]), lib.ptr(gp[1]),
+                 lib.ptr(gp[2]) if len(gp) > 2 else None, lib.ptr(gp[3]) if len(gp) > 3 else None, lib.ptr(dx),
+                 lib.ptr(partial), lib.stream_of(gout))
+        grads = tuple(None if (direct or has is False) else gp[i] for i, has in enumerate(ctx.layout))
+        return (dx, None, None, None) + grads
+
+
+def embed(x, lin0, lin1=None, kind=None, act=True):
+    """lin0 / lin1: nn.Linear(K -> 128); lin1 with `kind` (int32 [rows], 0 -> lin0, 1 -> lin1)."""
+    params = [lin0.weight, lin0.bias]
+    if lin1 is not None:
+        params += [lin1.weight, lin1.bias]
+    plist = [p for p in params if p is not None]
+    return _Embed.apply(x, kind, act, plist, *params)
+
+
+def embed_supported(x, lin):
+    return x.is_cuda and lin.out_features == D and lin.in_features in (16, 18, 42)
+
+
 # ---------------------------------------------------------------------------------------------------- global layer
 class _GlobalLayer(torch.autograd.Function):
     """Global_MessagePassing.forward (layers/global_message_passing.py:33-56): x, e -> x_out, out, att.

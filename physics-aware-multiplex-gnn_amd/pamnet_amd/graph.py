@@ -96,7 +96,28 @@ _NoTranspose = _NoTransposeT()
 
 class Graph(object):
     """All index / geometry tensors one forward needs (int32 / fp32 on the device)."""
-    pass
+
+    # Row lists / counts per kind are only needed by the generic (non-fused) path and by tests: built on first use so
+    # the fused path (which selects weights per row from `tp_kind` inside the kernel) pays no host sync for them.
+    @property
+    def trip_rows(self):                              # rows fed to mlp_sbf2 (models.py:188)
+        if '_trip_rows' not in self.__dict__:
+            self._trip_rows = (self.tp_kind == 0).nonzero().view(-1)
+        return self._trip_rows
+
+    @property
+    def pair_rows(self):                              # rows fed to mlp_sbf1 (models.py:187)
+        if '_pair_rows' not in self.__dict__:
+            self._pair_rows = (self.tp_kind == 1).nonzero().view(-1)
+        return self._pair_rows
+
+    @property
+    def n_trip(self):
+        return int(self.trip_rows.numel())
+
+    @property
+    def n_pair(self):
+        return int(self.pair_rows.numel())
 
 
 def radius_graph(pos, node_graph, gptr, r):
@@ -197,9 +218,6 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
              lib.ptr(tp_ptr), lib.ptr(tp_idx), lib.ptr(tp_edge), lib.ptr(tp_angle), lib.ptr(tp_kind), st)
     g.tp = CSR(tp_ptr, tp_edge, tp_idx)               # rows = target edge e, col = source edge e'
     g.tp_angle, g.tp_kind = tp_angle, tp_kind
-    g.trip_rows = (tp_kind == 0).nonzero().view(-1)   # rows fed to mlp_sbf2 (models.py:188)
-    g.pair_rows = (tp_kind == 1).nonzero().view(-1)   # rows fed to mlp_sbf1 (models.py:187)
-    g.n_trip, g.n_pair = int(g.trip_rows.numel()), int(g.pair_rows.numel())
 
     g.glob_T = g.loc_T = g.tp_T = _NoTranspose    # forward-only: backward index structures are not built
     if need_grad:

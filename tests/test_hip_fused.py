@@ -125,3 +125,57 @@ def test_full_layer_fused_vs_torch_vs_fp64(dev, kind, n_mol):
     of2, gf2 = _run(fn, ins, params, 'fused')
     assert all(torch.equal(a, b) for a, b in zip(of, of2))
     assert all(torch.equal(a, b) for a, b in zip(gf, gf2) if a is not None)
+
+
+@pytest.mark.parametrize('rows', [0, 1, 63, 64, 65, 4316, 40001])
+@pytest.mark.parametrize('case', ['rbf16', 'init18', 'sbf42_kind', 'sbf42'])
+def test_embed_layers(dev, rows, case):
+    """csrc/embed.hip vs torch Linear+SiLU (fp32 and fp64): forward, weight/bias gradients, dx for the rbf layer."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from pamnet_amd import fused
+    torch.manual_seed(rows + len(case))
+    K = {'rbf16': 16, 'init18': 18, 'sbf42_kind': 42, 'sbf42': 42}[case]
+    act, bias = case != 'init18', case != 'init18'
+    two = case == 'sbf42_kind'
+    lin0 = nn.Linear(K, D, bias=bias).to(dev)
+    lin1 = nn.Linear(K, D, bias=bias).to(dev) if two else None
+    x = torch.randn(rows, K, device=dev, requires_grad=(case == 'rbf16'))
+    kind = (torch.rand(rows, device=dev) < 0.4).to(torch.int32) if two else None
+    w = torch.randn(rows, D, device=dev, dtype=torch.float64)
+
+    def ref(dtype):
+        l0 = nn.Linear(K, D, bias=bias).to(dev).to(dtype)
+        l0.load_state_dict({k: v.to(dtype) for k, v in lin0.state_dict().items()})
+        xx = x.detach().to(dtype).requires_grad_(x.requires_grad)
+        z = F.linear(xx, l0.weight, l0.bias)
+        ps = list(l0.parameters())
+        if two:
+            l1 = nn.Linear(K, D, bias=bias).to(dev).to(dtype)
+            l1.load_state_dict({k: v.to(dtype) for k, v in lin1.state_dict().items()})
+            z = torch.where(kind.bool().unsqueeze(1), F.linear(xx, l1.weight, l1.bias), z)
+            ps += list(l1.parameters())
+        y = F.silu(z) if act else z
+        (y * w.to(dtype)).sum().backward()
+        return y.detach(), [p.grad if p.grad is not None else torch.zeros_like(p) for p in ps], xx.grad
+
+    y = fused.embed(x, lin0, lin1, kind=kind, act=act)
+    (y * w.float()).sum().backward()
+    ps = list(lin0.parameters()) + (list(lin1.parameters()) if two else [])
+    y32, g32, dx32 = ref(torch.float32)
+    y64, g64, dx64 = ref(torch.float64)
+    assert y.shape == (rows, D)
+    if rows == 0:
+        for p in ps:
+            assert float(p.grad.abs().max()) == 0.0
+        return
+    ok, info = _ok(y, y32, y64)
+    assert ok, ('y', info)
+    for p, a, b in zip(ps, g32, g64):
+        ok, info = _ok(p.grad, a, b, floor=5e-6)
+        assert ok, (tuple(p.shape), info)
+    if case == 'rbf16':
+        ok, info = _ok(x.grad, dx32, dx64)
+        assert ok, ('dx', info)
+    else:
+        assert x.grad is None
