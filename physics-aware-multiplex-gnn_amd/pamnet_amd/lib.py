@@ -60,11 +60,21 @@ def check(rc, name):
         raise RuntimeError('%s failed: %s' % (name, kind))
 
 
+_EMPTY = {}
+
+
 def ptr(t):
-    """Device pointer of a contiguous tensor, or NULL for None."""
+    """Device pointer of a contiguous tensor, or NULL for None.  A zero-length tensor has no storage (data_ptr() == 0),
+    which the library would report as a missing argument: it gets the address of a small per-device placeholder that is
+    never dereferenced (every kernel is bounded by the row count, which is 0)."""
     if t is None:
         return None
     assert t.is_contiguous(), 'pamnet_hip: tensor must be contiguous'
+    if t.numel() == 0 and t.is_cuda:
+        import torch
+        if t.device not in _EMPTY:
+            _EMPTY[t.device] = torch.zeros(64, dtype=torch.float32, device=t.device)
+        return _EMPTY[t.device].data_ptr()
     return t.data_ptr()
 
 

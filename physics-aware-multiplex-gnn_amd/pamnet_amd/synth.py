@@ -204,3 +204,21 @@ def pdbbind_batch(seed, start, count, **kw):
 
 def rna_batch(seed, start, count, **kw):
     return collate([rna_chain(seed, start + i, **kw) for i in range(count)])
+
+
+def ragged_qm9_batch(seed=21):
+    """Degenerate / ragged molecules in one QM9-schema batch (edge cases of the graph code, models.py:62-98,104-113):
+    a single atom (no edges of either kind), a single bond (no triplets; self-pairs only), three atoms farther apart than
+    any cutoff, a 3-chain (the smallest graph with triplets), between two ordinary molecules."""
+    def mol(x, pos, bonds, y):
+        ei = np.array([[a, b] for a, b in bonds] + [[b, a] for a, b in bonds], dtype=np.int64).reshape(-1, 2).T
+        if ei.size:
+            ei = ei[:, np.lexsort((ei[1], ei[0]))]
+        return dict(x=np.asarray(x, np.float32), pos=np.asarray(pos, np.float32), edge_index=ei.reshape(2, -1),
+                    y=np.float32(y))
+    return collate([mol([1], [[0, 0, 0]], [], 0.3),
+                    mol([0, 2], [[0, 0, 0], [1.1, 0, 0]], [(0, 1)], -0.2),
+                    qm9_molecule(seed, 0),
+                    mol([3, 3, 3], [[0, 0, 0], [9, 0, 0], [0, 9, 0]], [], 1.0),
+                    mol([0, 1, 4], [[0, 0, 0], [1.2, 0, 0], [2.0, 0.9, 0]], [(0, 1), (1, 2)], 0.5),
+                    qm9_molecule(seed, 1)])

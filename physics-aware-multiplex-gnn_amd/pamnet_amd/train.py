@@ -115,7 +115,7 @@ class Trainer(object):
         self._wait_prepared(data)
         loss = self.forward_backward(data, global_graphs)
         self.sync_gradients()
-        self.clip()
+        self.last_grad_norm = self.clip()          # pre-clip L2 norm (device scalar; no host sync here)
         self.optimizer_step(lr)
         self.ema_update()
         if next_data is not None:

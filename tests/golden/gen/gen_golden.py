@@ -299,8 +299,82 @@ def fixture_random(name, cls, cfg_kw, batch, seed, capture, small=False):
     save(name, **arrs)
 
 
+def fixture_train(name, cfg_kw, batch, seed, lrs, max_norm):
+    """K optimiser steps of the reference training loop body (main_qm9.py:103-118) on one fixed batch: reference model,
+    torch Adam (wd=0, amsgrad=False), clip_grad_norm_, the reference's own EMA class (utils/ema.py); per-step learning
+    rates are given explicitly (the warm-up scheduler wheel is absent).  fp32 and fp64."""
+    from torch.nn.utils import clip_grad_norm_
+    from utils.ema import EMA as RefEMA
+    cfg = ref_models.Config(**cfg_kw)
+    sd = oracle.init_state_dict(cfg, seed=seed)
+    arrs = dict(seed=np.int64(seed), weights_checksum=np.float64(checksum(sd)), lrs=np.asarray(lrs, np.float64),
+                max_norm=np.float64(max_norm), cfg_dataset=np.array(cfg_kw['dataset']), cfg_dim=np.int64(cfg_kw['dim']),
+                cfg_n_layer=np.int64(cfg_kw['n_layer']), cfg_cutoff_l=np.float64(cfg_kw['cutoff_l']),
+                cfg_cutoff_g=np.float64(cfg_kw['cutoff_g']))
+    for k in ('x', 'batch', 'pos', 'edge_index', 'y'):
+        arrs['in/' + k] = getattr(batch, k).numpy()
+    for tag, dtype in (('32', torch.float32), ('64', torch.float64)):
+        model = build_model(ref_models.PAMNet, cfg)
+        model.load_state_dict(sd)
+        if dtype == torch.float64:
+            model = model.double()
+        opt = torch.optim.Adam(model.parameters(), lr=lrs[0], weight_decay=0, amsgrad=False)
+        ema = RefEMA(model, decay=0.999)
+        data, y = make_data(batch, dtype), batch.y.to(dtype)
+        losses, norms = [], []
+        for lr in lrs:
+            for grp in opt.param_groups:
+                grp['lr'] = lr
+            opt.zero_grad()
+            out = model(data)
+            loss = torch.nn.functional.l1_loss(out, y)
+            loss.backward()
+            norms.append(float(clip_grad_norm_(model.parameters(), max_norm=max_norm, norm_type=2)))
+            opt.step()
+            ema(model)
+            losses.append(float(loss))
+        arrs['loss' + tag] = np.asarray(losses, np.float64)
+        arrs['grad_norm' + tag] = np.asarray(norms, np.float64)
+        arrs['param_l2_' + tag] = np.float64(torch.sqrt(sum((p.double() ** 2).sum() for p in model.parameters())))
+        arrs['shadow_l2_' + tag] = np.float64(torch.sqrt(sum((v.double() ** 2).sum() for v in ema.shadow.values())))
+        arrs['delta_l2_' + tag] = np.float64(torch.sqrt(sum(((p.double() - sd[k].double()) ** 2).sum()
+                                                           for k, p in model.named_parameters())))
+        with torch.no_grad():
+            arrs['out_final' + tag] = model(data).numpy()
+            ema.assign(model)
+            arrs['out_ema' + tag] = model(data).numpy()
+            ema.resume(model)
+    save(name, **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if '--train-only' in sys.argv:
+        return main_train()
+    if '--ragged-only' in sys.argv:
+        return main_ragged()
+    main_forward()
+    main_train()
+
+
+def main_train():
+    qm9 = dict(dataset='QM9', dim=32, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+    lrs = [1e-3, 2e-3, 3e-3, 3e-3, 2.5e-3]
+    fixture_train('train_qm9_d32_l2', qm9, synth.qm9_batch(11, 0, 6), seed=3, lrs=lrs, max_norm=1000.0)
+    big = dict(dataset='QM9', dim=128, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+    # max_norm below the first gradient norm so that the clip is exercised
+    fixture_train('train_qm9_d128_l2', big, synth.qm9_batch(0, 0, 8), seed=6, lrs=lrs, max_norm=0.5)
+
+
+def main_ragged():
+    qm9 = dict(dataset='QM9', dim=32, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+    fixture_random('qm9_ragged_d32_l2', ref_models.PAMNet, qm9, synth.ragged_qm9_batch(), seed=8, capture=True)
+    fixture_random('qm9s_ragged_d32_l2', ref_models.PAMNet_s, qm9, synth.ragged_qm9_batch(), seed=9, capture=True,
+                   small=True)
+
+
+def main_forward():
+    main_ragged()
     fixture_star()
     fixture_basis()
     fixture_rna()

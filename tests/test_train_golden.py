@@ -1,0 +1,114 @@
+"""Training-loop parity: K optimiser steps on one fixed batch against sequences produced by the
+reference's own model + torch Adam + clip_grad_norm_ + the reference's EMA class (tests/golden/gen/gen_golden.py
+fixture_train): per-step loss, pre-clip gradient norm, L2 norm of the parameter displacement / parameters / EMA shadow,
+and the outputs under the final and the EMA weights.
+
+  * CPU: the oracle's restatement of the loop body (main_qm9.py:103-118, utils/ema.py:13-20) in fp64 vs the fp64 fixture.
+  * GPU: pamnet_amd.train.Trainer (flat buffers, direct gradient writes, fused Adam) vs the fixtures, with
+    err(hip, ref64) <= max(tol, 2 * err(ref32, ref64)).
+"""
+import numpy as np
+import pytest
+import torch
+
+from test_hip_model import _batch_from
+
+NAMES = ['train_qm9_d32_l2', 'train_qm9_d128_l2']
+
+
+def _cfg(g, Config):
+    return Config(dataset=str(g['cfg_dataset']), dim=int(g['cfg_dim']), n_layer=int(g['cfg_n_layer']),
+                  cutoff_l=float(g['cfg_cutoff_l']), cutoff_g=float(g['cfg_cutoff_g']))
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_oracle_training_loop_vs_reference(golden, name):
+    from oracle import pamnet_oracle as O
+    g = golden(name)
+    cfg = _cfg(g, O.Config)
+    sd0 = {k: v.double() for k, v in O.init_state_dict(cfg, seed=int(g['seed'])).items()}
+    assert abs(sum(float(v.abs().sum()) for v in sd0.values()) - float(g['weights_checksum'])) < 1e-6 * float(g['weights_checksum'])
+    params = O.as_params(sd0)
+    names = list(params.keys())
+    opt = torch.optim.Adam([params[k] for k in names], lr=float(g['lrs'][0]), weight_decay=0, amsgrad=False)
+    shadow = {k: params[k].data.clone() for k in names}                                   # utils/ema.py:9-11
+    x, batch = torch.from_numpy(g['in/x']), torch.from_numpy(g['in/batch'])
+    pos, ei, y = torch.from_numpy(g['in/pos']).double(), torch.from_numpy(g['in/edge_index']), torch.from_numpy(g['in/y']).double()
+    losses, norms = [], []
+    for lr in g['lrs']:
+        opt.param_groups[0]['lr'] = float(lr)
+        opt.zero_grad()
+        out = O.pamnet_forward(params, cfg, x, batch, pos, ei, dtype=torch.float64)
+        loss = (out - y).abs().mean()                                                     # F.l1_loss, main_qm9.py:108
+        loss.backward()
+        grads = [params[k].grad for k in names if params[k].grad is not None]
+        norm = torch.sqrt(sum((gr ** 2).sum() for gr in grads))                           # clip_grad_norm_, main_qm9.py:111
+        coef = min(1.0, float(g['max_norm']) / (float(norm) + 1e-6))
+        for gr in grads:
+            gr.mul_(coef)
+        opt.step()
+        decay = min(0.999, (1.0 + 99999) / (10.0 + 99999))                                # utils/ema.py:14
+        for k in names:
+            shadow[k] = (1.0 - decay) * params[k].data + decay * shadow[k]
+        losses.append(float(loss.detach())), norms.append(float(norm))
+    # fp64 on both sides; Adam's g/|g| updates amplify last-bit differences of the first step, hence 2e-7 and not 1e-12
+    assert _rel(losses, g['loss64']) < 2e-7 and _rel(norms, g['grad_norm64']) < 2e-7
+    l2 = lambda d: float(torch.sqrt(sum((v.double() ** 2).sum() for v in d.values())))
+    assert abs(l2({k: params[k].data for k in names}) - float(g['param_l2_64'])) < 1e-9 * float(g['param_l2_64'])
+    assert abs(l2(shadow) - float(g['shadow_l2_64'])) < 1e-9 * float(g['shadow_l2_64'])
+    assert abs(l2({k: params[k].data - sd0[k] for k in names}) - float(g['delta_l2_64'])) < 1e-7 * float(g['delta_l2_64'])
+    with torch.no_grad():
+        out_ema = O.pamnet_forward(shadow, cfg, x, batch, pos, ei, dtype=torch.float64)
+    assert _rel(out_ema.numpy(), g['out_ema64']) < 2e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', NAMES)
+def test_trainer_vs_reference_training_loop(golden, name):
+    import models
+    from oracle import pamnet_oracle as O
+    from pamnet_amd.train import Trainer
+    dev = torch.device('cuda:0')
+    g = golden(name)
+    cfg = _cfg(g, models.Config)
+    model = models.PAMNet(cfg)
+    sd0 = O.init_state_dict(cfg, seed=int(g['seed']))
+    model.load_state_dict(sd0, strict=True)
+    model = model.to(dev)
+    tr = Trainer(model, lr=float(g['lrs'][0]), weight_decay=0.0, ema_decay=0.999, max_grad_norm=float(g['max_norm']))
+    data = _batch_from(g, dev)
+    losses, norms = [], []
+    for lr in g['lrs']:
+        loss = tr.step(data, lr=float(lr))
+        losses.append(float(loss.detach())), norms.append(float(tr.last_grad_norm))
+
+    def ok(a, k, tol):
+        e, floor = _rel(a, g[k + '64']), _rel(g[k + '32'], g[k + '64'])
+        return e <= max(tol, 2 * floor), (k, e, floor)
+
+    # losses / norms of later steps inherit the fp32 noise of the earlier Adam updates (update ~ lr * g/|g|)
+    for a, k, tol in ((losses, 'loss', 1e-5), (norms, 'grad_norm', 1e-5)):
+        good, info = ok(a, k, tol)
+        assert good, info
+    cur = {k: p.detach().cpu().double() for k, p in model.named_parameters()}
+    l2 = lambda d: float(torch.sqrt(sum((v ** 2).sum() for v in d.values())))
+    for val, k in ((l2(cur), 'param_l2_'), (float(torch.linalg.vector_norm(tr.shadow.double())), 'shadow_l2_'),
+                   (l2({k: cur[k] - sd0[k].double() for k in cur}), 'delta_l2_')):
+        good, info = ok([val], k, 1e-5)
+        assert good, info
+    with torch.no_grad():
+        good, info = ok(model(data).cpu().numpy(), 'out_final', 1e-5)
+        assert good, info
+        tr.ema_assign()
+        out_ema = model(data).cpu().numpy()
+        tr.ema_resume()
+    good, info = ok(out_ema, 'out_ema', 1e-5)
+    assert good, info
+    # evaluate() = MAE under EMA weights (main_qm9.py:29-37)
+    mae = tr.evaluate([data])
+    assert abs(mae - float(np.abs(g['out_ema64'] - g['in/y']).mean())) < 1e-5 * max(1.0, float(np.abs(g['in/y']).mean()))
