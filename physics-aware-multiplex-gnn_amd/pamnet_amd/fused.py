@@ -432,6 +432,7 @@ class _Stack(torch.autograd.Function):
         ctx.save_for_backward(x0, e_g, rbf_e, e_sbf, saved)
         ctx.graph, ctx.gl, ctx.ll = graph, gl, ll
         ctx.mark_non_differentiable(saved)
+        ctx.set_materialize_grads(False)       # else autograd zero-fills a gradient the size of `saved` every step
         return outs, atts, saved
 
     @staticmethod
