@@ -40,6 +40,8 @@ def parse():
     ap.add_argument('--n-layer', type=int, default=6)
     ap.add_argument('--n-batches', type=int, default=4, help='distinct resident batches cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-comm', action='store_true',
+                    help='N=1 only: run the bucketed gradient all-reduce through a 1-rank RCCL group (overhead check)')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--stream-gb', type=float, default=2.0, help='size of the streamed scatter-add roofline probe')
     return ap.parse_args()
@@ -160,6 +162,8 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
+    elif args.force_comm:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29517', rank=0, world_size=1, device_id=dev)
 
     import models
     from pamnet_amd import lib, synth
@@ -169,7 +173,9 @@ def main():
     torch.manual_seed(1234)                        # identical random-init weights on every rank
     cfg = models.Config(dataset='QM9', dim=args.dim, n_layer=args.n_layer, cutoff_l=5.0, cutoff_g=5.0)
     model = models.PAMNet(cfg).to(dev)
-    trainer = Trainer(model, lr=1e-4, world_size=world)
+    overlap = os.environ.get('PAMNET_OVERLAP_COMM', '1') != '0'
+    trainer = Trainer(model, lr=1e-4, world_size=world,
+                      overlap_comm=('force' if args.force_comm else overlap))
     B = args.batch_per_gpu
     gB = B * world
     # resident batches: global batch k = molecules [k*gB, (k+1)*gB); this rank's shard = its contiguous slice

@@ -227,7 +227,10 @@ int pamnet_embed_bwd_f32(const float* x, int64_t rows, int64_t K, const int32_t*
  *   saved/temp : caller-owned arenas sized by pamnet_stack_workspace (floats); `saved` must survive until the backward
  *   outs/atts  : [2*n_layer, n] rows ordered (global_0, local_0, global_1, ...)
  * Backward: ggrads / lgrads are gradient buffers laid out like the parameter tables (written, not accumulated);
- * d_x0, d_eg, d_rbf, d_sbf are written.
+ * d_x0, d_eg, d_rbf, d_sbf are written.  `layer_done` (nullable): n_layer hipEvent_t handles; event k is recorded on
+ * `stream` once every gradient of layer pair k (global_layer.k, local_layer.k) has been enqueued -- the backward runs
+ * k = n_layer-1 .. 0, so a data-parallel caller can start reducing the last layers' gradients on another stream while
+ * the earlier layers are still being differentiated.
  * ------------------------------------------------------------------------------------------------------------------ */
 int pamnet_stack_workspace(int64_t n, int64_t eg, int64_t el, int64_t tp, int64_t n_layer, int64_t* saved_floats,
                            int64_t* temp_floats_out);
@@ -240,7 +243,7 @@ int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, 
                          const float* e_g, const float* rbf_e, const float* e_sbf, const float* const* gparams,
                          const float* const* lparams, const float* saved, float* temp, const float* d_outs,
                          const float* d_atts, float* const* ggrads, float* const* lgrads, float* d_x0, float* d_eg,
-                         float* d_rbf, float* d_sbf, pamnet_stream_t stream);
+                         float* d_rbf, float* d_sbf, void* const* layer_done, pamnet_stream_t stream);
 
 #ifdef __cplusplus
 }

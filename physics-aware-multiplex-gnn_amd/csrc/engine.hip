@@ -245,7 +245,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                                     const float* const* gparams, const float* const* lparams, const float* saved,
                                     float* temp, const float* d_outs, const float* d_atts, float* const* ggrads,
                                     float* const* lgrads, float* d_x0, float* d_eg, float* d_rbf, float* d_sbf,
-                                    pamnet_stream_t st) {
+                                    void* const* layer_done, pamnet_stream_t st) {
     Graph g;
     CK(fill_graph(g, sizes, graph_idx));
     if (n_layer < 1) return PAMNET_EINVAL;
@@ -329,6 +329,10 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             CK(run_jobs(j, t.partial, st));
             d_xout = dx;
             flip ^= 1;
+        }
+        if (layer_done && layer_done[k]) {
+            const hipError_t e = hipEventRecord(reinterpret_cast<hipEvent_t>(layer_done[k]), as_stream(st));
+            if (e != hipSuccess) return (int)e;
         }
     }
     return PAMNET_OK;

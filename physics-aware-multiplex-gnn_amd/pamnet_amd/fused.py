@@ -23,6 +23,12 @@ D = 128
 # is used exactly once per forward and the trainer runs one backward per step.  Off by default (plain autograd).
 DIRECT_GRAD = False
 
+# Optional list of n_layer torch.cuda.Event (already recorded once, so their handles exist): the layer-stack backward
+# records event k when all gradients of layer pair k are enqueued (train.Trainer overlaps the gradient all-reduce of
+# the last layers with the backward of the first ones).
+LAYER_EVENTS = None
+EVENTS_RECORDED = False     # set by the backward when it handed LAYER_EVENTS to the engine (checked by the trainer)
+
 
 def _parr(tensors):
     """Host array of device pointers (NULL for None; ints are raw addresses)."""
@@ -449,12 +455,17 @@ class _Stack(torch.autograd.Function):
                  ctypes.addressof(need), ctypes.addressof(need) + 8)
         temp = _temp_arena(int(need[1]), x0.device)
         d_x0, d_eg, d_rbf, d_sbf = (torch.empty_like(t) for t in (x0, e_g, rbf_e, e_sbf))
+        evs = None
+        if LAYER_EVENTS is not None and len(LAYER_EVENTS) == L and direct:
+            global EVENTS_RECORDED
+            evs = _parr([int(e.cuda_event) for e in LAYER_EVENTS])
+            EVENTS_RECORDED = True
         g_outs = torch.zeros(2 * L, x0.size(0), device=x0.device) if g_outs is None else g_outs.contiguous()
         g_atts = torch.zeros_like(g_outs) if g_atts is None else g_atts.contiguous()
         lib.call('pamnet_stack_bwd_f32', sizes, idx, L, lib.ptr(x0), lib.ptr(e_g), lib.ptr(rbf_e), lib.ptr(e_sbf),
                  _parr([p for lay in gl for p in lay]), _parr([p for lay in ll for p in lay]), lib.ptr(saved),
                  lib.ptr(temp), lib.ptr(g_outs), lib.ptr(g_atts), _parr(g[:ng]), _parr(g[ng:]), lib.ptr(d_x0),
-                 lib.ptr(d_eg), lib.ptr(d_rbf), lib.ptr(d_sbf), lib.stream_of(x0))
+                 lib.ptr(d_eg), lib.ptr(d_rbf), lib.ptr(d_sbf), evs, lib.stream_of(x0))
         return (d_x0, d_eg, d_rbf, d_sbf, None, None, None) + _ret(direct, g)
 
 

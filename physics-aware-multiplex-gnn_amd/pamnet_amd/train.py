@@ -13,18 +13,35 @@ Each rank pre-scales its gradient by local_graphs/global_graphs so the summed gr
 mean L1 loss (main_qm9.py:108), then every rank applies the identical update.
 """
 import math
+import re
 
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
 
+_LAYER_RE = re.compile(r'^(?:global_layer|local_layer)\.(\d+)\.')
+
+
+def _layer_of(name):
+    m = _LAYER_RE.match(name)
+    return int(m.group(1)) if m else None
+
+
 class FlatParams(object):
-    """Re-home a module's parameters (and their .grad) as views of two flat buffers."""
+    """Re-home a module's parameters (and their .grad) as views of two flat buffers.
+
+    Buffer order = the order in which the backward finishes gradients: layer pair n_layer-1 first (global_layer.k and
+    local_layer.k adjacent), ..., layer pair 0, then the top-level parameters (embeddings, basis frequencies, input
+    embeddings).  `layer_ranges[k]` = [lo, hi) of layer pair k, so the gradients of any run of consecutive layers are
+    one contiguous slice that can be all-reduced while earlier layers are still being differentiated."""
 
     def __init__(self, module):
-        self.params = [p for p in module.parameters() if p.requires_grad]
-        self.names = [n for n, p in module.named_parameters() if p.requires_grad]
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        rank = lambda n: (1, 0) if _layer_of(n) is None else (0, -_layer_of(n))
+        named.sort(key=lambda np_: rank(np_[0]))          # stable: declaration order inside a group
+        self.params = [p for _, p in named]
+        self.names = [n for n, _ in named]
         dev, dt = self.params[0].device, self.params[0].dtype
         align = 64                                        # floats: every parameter starts on a 256-byte boundary
         offs, off = [], 0                                 # (the kernels read weights as 16-byte vectors)
@@ -33,6 +50,13 @@ class FlatParams(object):
             off += (p.numel() + align - 1) // align * align
         self.numel = sum(p.numel() for p in self.params)
         self.offsets = dict(zip(self.names, offs))
+        self.layer_ranges = {}
+        for n, o, p in zip(self.names, offs, self.params):
+            k = _layer_of(n)
+            if k is not None:
+                end = o + (p.numel() + align - 1) // align * align
+                lo, hi = self.layer_ranges.get(k, (o, end))
+                self.layer_ranges[k] = (min(lo, o), max(hi, end))
         self.flat = torch.zeros(off, device=dev, dtype=dt)          # padding stays zero: no effect on norms / Adam
         self.grad = torch.zeros(off, device=dev, dtype=dt)
         for p, o in zip(self.params, offs):
@@ -60,7 +84,7 @@ class WarmupExpLR(object):
 
 class Trainer(object):
     def __init__(self, model, lr=1e-4, weight_decay=0.0, ema_decay=0.999, max_grad_norm=1000.0, betas=(0.9, 0.999),
-                 eps=1e-8, world_size=1, process_group=None):
+                 eps=1e-8, world_size=1, process_group=None, overlap_comm=True, n_buckets=3):
         self.model = model
         self.fp = FlatParams(model)
         try:                                               # fused layers write gradients straight into fp.grad
@@ -76,10 +100,17 @@ class Trainer(object):
         self.shadow = self.fp.flat.clone()                                 # utils/ema.py:9-11
         self.max_grad_norm = max_grad_norm
         self.world_size, self.pg = world_size, process_group
+        self._buckets = None
+        if overlap_comm and self.fp.flat.is_cuda and dist.is_available() and dist.is_initialized() \
+                and (world_size > 1 or overlap_comm == 'force'):
+            self._setup_buckets(n_buckets)
 
     # -- pieces (also timed individually by bench.py) ---------------------------------------------------------------
     def forward_backward(self, data, global_graphs=None):
         self.fp.zero_grad()
+        if self._buckets is not None:
+            from . import fused
+            fused.EVENTS_RECORDED = False
         out = self.model(data)
         loss = F.l1_loss(out, data.y)
         if self.world_size > 1:
@@ -89,9 +120,59 @@ class Trainer(object):
             loss.backward()
         return loss
 
+    # -- gradient all-reduce -------------------------------------------------------------------------------------------
+    def _setup_buckets(self, n_buckets):
+        """Split the flat gradient into `n_buckets` contiguous slices by layer pair, last layers first (the order the
+        backward completes them); the layer-stack backward records one event per layer pair (fused.LAYER_EVENTS)."""
+        from . import fused
+        L = len(self.fp.layer_ranges)
+        if L == 0 or sorted(self.fp.layer_ranges) != list(range(L)):
+            return
+        dev = self.fp.flat.device
+        events = [torch.cuda.Event() for _ in range(L)]
+        for e in events:
+            e.record(torch.cuda.current_stream(dev))      # materialise the handles the C side records into
+        per = max(1, math.ceil(L / float(n_buckets)))
+        buckets, k_hi = [], L - 1
+        while k_hi >= 0:
+            k_lo = max(0, k_hi - per + 1)
+            lo = self.fp.layer_ranges[k_hi][0]
+            hi = self.fp.layer_ranges[k_lo][1]
+            buckets.append((lo, hi, k_lo))                 # ready when layer pair k_lo is done
+            k_hi = k_lo - 1
+        covered = buckets[-1][1]
+        # the last layer bucket is merged with the top-level parameters (ready only when the whole backward is done)
+        lo_last = buckets.pop()[0]
+        self._tail_range = (lo_last, self.fp.grad.numel())
+        assert buckets == [] or buckets[0][0] == 0
+        assert covered <= self.fp.grad.numel()
+        self._buckets, self._events = buckets, events
+        self._comm = torch.cuda.Stream(device=dev)
+        fused.LAYER_EVENTS = events
+
     def sync_gradients(self):
-        if self.world_size > 1:
-            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM, group=self.pg)
+        """Sum the gradient over ranks.  With buckets: slices of the last layers are reduced on a side stream as soon as
+        the backward has produced them (the host has already enqueued the whole backward when this runs; the device is
+        still working through it), the remainder after the backward's end; the main stream then waits for all of it."""
+        bucketed = self._buckets is not None
+        if bucketed:
+            from . import fused
+            bucketed = fused.EVENTS_RECORDED       # this backward did not go through the engine: no per-layer events
+        if not bucketed:
+            if self.world_size > 1:
+                dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM, group=self.pg)
+            return
+        main = torch.cuda.current_stream(self.fp.flat.device)
+        done = torch.cuda.Event()
+        done.record(main)
+        with torch.cuda.stream(self._comm):
+            for lo, hi, k in self._buckets:
+                self._comm.wait_event(self._events[k])
+                dist.all_reduce(self.fp.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+            self._comm.wait_event(done)
+            lo, hi = self._tail_range
+            dist.all_reduce(self.fp.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+        main.wait_stream(self._comm)
 
     def clip(self):
         norm = torch.linalg.vector_norm(self.fp.grad)

@@ -141,3 +141,53 @@ def test_direct_gradient_path_equals_autograd():
         assert float(fp.grad.abs().sum()) > 0
     finally:
         fused.DIRECT_GRAD = False
+
+
+@pytest.mark.gpu
+def test_bucketed_overlapped_allreduce_single_rank_rccl():
+    """The bucketed gradient all-reduce (slices of the last layers reduced on a side stream at per-layer events recorded
+    inside the engine's backward) run through a 1-rank RCCL group: same parameters after 3 steps as the plain path, and
+    the buckets tile the flat buffer in backward-completion order."""
+    import torch.distributed as dist
+    import models
+    from pamnet_amd import fused, synth
+    from pamnet_amd.train import Trainer
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % _free_port(), rank=0, world_size=1,
+                                device_id=dev)
+        created = True
+    try:
+        cfg = models.Config(dataset='QM9', dim=128, n_layer=4, cutoff_l=5.0, cutoff_g=5.0)
+        batches = [synth.qm9_batch(3, 8 * i, 8).to(dev) for i in range(3)]
+
+        def run(overlap):
+            torch.manual_seed(9)
+            model = models.PAMNet(cfg).to(dev)
+            tr = Trainer(model, lr=1e-3, world_size=1, overlap_comm=overlap, n_buckets=3)
+            for b in batches:
+                tr.step(b, global_graphs=8)
+            torch.cuda.synchronize()
+            return tr, tr.fp.flat.clone()
+
+        fused.LAYER_EVENTS = None
+        tr0, plain = run(False)
+        assert tr0._buckets is None
+        tr1, over = run('force')
+        assert tr1._buckets is not None and fused.EVENTS_RECORDED
+        assert torch.equal(plain, over)
+        # buckets: contiguous from offset 0, last layers first; the tail slice reaches the end of the buffer
+        edges = [0]
+        for lo, hi, k in tr1._buckets:
+            assert lo == edges[-1] and hi > lo
+            edges.append(hi)
+        assert tr1._tail_range == (edges[-1], tr1.fp.grad.numel())
+        assert [k for _, _, k in tr1._buckets] == sorted((k for _, _, k in tr1._buckets), reverse=True)
+        names = tr1.fp.names
+        assert names[0].startswith('global_layer.3.') and names[-1].split('.')[0] not in ('global_layer', 'local_layer')
+    finally:
+        fused.LAYER_EVENTS = None
+        if created:
+            dist.destroy_process_group()
