@@ -245,6 +245,18 @@ int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, 
                          const float* d_atts, float* const* ggrads, float* const* lgrads, float* d_x0, float* d_eg,
                          float* d_rbf, float* d_sbf, void* const* layer_done, pamnet_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Optimiser tail of the reference loop on flat fp32 buffers, one pass (main_qm9.py:111-112,116; utils/ema.py:13-20):
+ *   g *= min(1, max_norm / (*grad_norm + 1e-6))                      clip_grad_norm_ (grad_norm: device scalar, nullable)
+ *   Adam(lr, betas, eps, weight_decay, amsgrad=False), update number `step_count` >= 1
+ *   shadow = ema_decay * shadow + (1 - ema_decay) * p_new
+ *   g = 0 when zero_grad != 0 (the next step's zero_grad, main_qm9.py:105)
+ * n % 4 == 0; buffers 16-byte aligned.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pamnet_adam_ema_f32(float* p, float* g, float* m, float* v, float* shadow, int64_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int64_t step_count, float ema_decay,
+                        const float* grad_norm, float max_norm, int32_t zero_grad, pamnet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,7 +84,7 @@ class WarmupExpLR(object):
 
 class Trainer(object):
     def __init__(self, model, lr=1e-4, weight_decay=0.0, ema_decay=0.999, max_grad_norm=1000.0, betas=(0.9, 0.999),
-                 eps=1e-8, world_size=1, process_group=None, overlap_comm=True, n_buckets=3):
+                 eps=1e-8, world_size=1, process_group=None, overlap_comm=True, n_buckets=3, native_optimizer=True):
         self.model = model
         self.fp = FlatParams(model)
         try:                                               # fused layers write gradients straight into fp.grad
@@ -92,10 +92,19 @@ class Trainer(object):
             fused.DIRECT_GRAD = True
         except Exception:                                  # (gloo/CPU unit tests drive the trainer with a plain module)
             pass
-        self.opt = torch.optim.Adam([torch.nn.Parameter(self.fp.flat)], lr=lr, betas=betas, eps=eps,
-                                    weight_decay=weight_decay, amsgrad=False, fused=self.fp.flat.is_cuda)
-        self._p = self.opt.param_groups[0]['params'][0]
-        self._p.grad = self.fp.grad
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        # On the GPU clip + Adam + EMA (+ the next zero_grad) are one pass of csrc/optim.hip over the flat buffers;
+        # torch.optim.Adam on the flat tensor is the CPU path (gloo unit tests) and the cross-check of the kernel.
+        self.native_opt = bool(native_optimizer and self.fp.flat.is_cuda)
+        if self.native_opt:
+            self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.fp.flat), torch.zeros_like(self.fp.flat)
+            self.step_count = 0
+        else:
+            self.opt = torch.optim.Adam([torch.nn.Parameter(self.fp.flat)], lr=lr, betas=betas, eps=eps,
+                                        weight_decay=weight_decay, amsgrad=False, fused=self.fp.flat.is_cuda)
+            self._p = self.opt.param_groups[0]['params'][0]
+            self._p.grad = self.fp.grad
+        self._grad_clean = True                            # fp.grad is all zeros (fresh buffer / zeroed by the update)
         self.ema_decay = ema_decay
         self.shadow = self.fp.flat.clone()                                 # utils/ema.py:9-11
         self.max_grad_norm = max_grad_norm
@@ -107,7 +116,9 @@ class Trainer(object):
 
     # -- pieces (also timed individually by bench.py) ---------------------------------------------------------------
     def forward_backward(self, data, global_graphs=None):
-        self.fp.zero_grad()
+        if not self._grad_clean:
+            self.fp.zero_grad()
+        self._grad_clean = False
         if self._buckets is not None:
             from . import fused
             fused.EVENTS_RECORDED = False
@@ -185,6 +196,22 @@ class Trainer(object):
             self.opt.param_groups[0]['lr'] = lr
         self.opt.step()
 
+    def native_update(self, lr=None, num_updates=99999):
+        """clip -> Adam -> EMA -> zero the gradient, one kernel; the norm stays on the device."""
+        from . import lib
+        if lr is not None:
+            self.lr = lr
+        norm = torch.linalg.vector_norm(self.fp.grad)
+        self.step_count += 1
+        decay = min(self.ema_decay, (1.0 + num_updates) / (10.0 + num_updates))     # utils/ema.py:14
+        lib.call('pamnet_adam_ema_f32', lib.ptr(self.fp.flat), lib.ptr(self.fp.grad), lib.ptr(self.exp_avg),
+                 lib.ptr(self.exp_avg_sq), lib.ptr(self.shadow), self.fp.flat.numel(), float(self.lr),
+                 float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                 self.step_count, float(decay), lib.ptr(norm), float(self.max_grad_norm), 1,
+                 lib.stream_of(self.fp.flat))
+        self._grad_clean = True
+        return norm
+
     def ema_update(self, num_updates=99999):
         decay = min(self.ema_decay, (1.0 + num_updates) / (10.0 + num_updates))     # utils/ema.py:14
         self.shadow.mul_(decay).add_(self.fp.flat, alpha=1.0 - decay)
@@ -196,9 +223,12 @@ class Trainer(object):
         self._wait_prepared(data)
         loss = self.forward_backward(data, global_graphs)
         self.sync_gradients()
-        self.last_grad_norm = self.clip()          # pre-clip L2 norm (device scalar; no host sync here)
-        self.optimizer_step(lr)
-        self.ema_update()
+        if self.native_opt:
+            self.last_grad_norm = self.native_update(lr)       # pre-clip L2 norm (device scalar; no host sync here)
+        else:
+            self.last_grad_norm = self.clip()
+            self.optimizer_step(lr)
+            self.ema_update()
         if next_data is not None:
             self.prefetch(next_data)
         return loss

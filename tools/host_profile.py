@@ -31,7 +31,7 @@ with torch.no_grad():
     print('graph build   %.3f ms' % timed(lambda i: model._graph(bs[i % 4])))
     print('forward       %.3f ms' % timed(lambda i: model(bs[i % 4])))
 print('fwd+bwd       %.3f ms' % timed(lambda i: tr.forward_backward(bs[i % 4])))
-print('clip+adam+ema %.3f ms' % timed(lambda i: (tr.clip(), tr.optimizer_step(), tr.ema_update())))
+print('clip+adam+ema %.3f ms' % timed(lambda i: tr.native_update()))
 pr = cProfile.Profile(); pr.enable()
 for i in range(20):
     tr.step(bs[i % 4])
