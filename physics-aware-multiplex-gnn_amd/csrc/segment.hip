@@ -28,6 +28,9 @@ __device__ __forceinline__ float4 load_term(const float4* __restrict__ A, const 
     return a;
 }
 
+// rows * lanes-per-row at or below this use the split kernel: less than one full wave of lanes per SIMD on 256 CUs
+constexpr int64_t SPLIT_MAX_LANES = 256 * 4 * 64 * 4;
+
 __device__ __forceinline__ void acc4(float4& s, const float4& v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
 
 // LPR lanes per row (power of two <= 64).  blockDim.x = 256.
@@ -55,6 +58,58 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(float4* __restrict__ o
         for (; q < end; ++q) acc4(s0, load_term<HAS_IA, HAS_B, HAS_IB, HAS_PERM>(A, ia, B, ib, perm, q, d4, c));
         acc4(s0, s1); acc4(s2, s3); acc4(s0, s2);
         out[r * d4 + c] = s0;
+    }
+}
+
+// Few output rows (node-level reductions at batch size 128: ~2 K rows x ~14 terms) leave most of the chip idle and make
+// the serial CSR walk the whole cost.  Here SPLIT lane groups share a row: each walks a contiguous quarter of the
+// segment, the partial sums meet in LDS and are added in part order (fixed order -> deterministic).
+template <int LPR, int SPLIT, bool HAS_IA, bool HAS_B, bool HAS_IB, bool HAS_PERM>
+__global__ __launch_bounds__(256) void segment_sum_split_kernel(float4* __restrict__ out,
+                                                                const float4* __restrict__ init,
+                                                                const float4* __restrict__ A,
+                                                                const int32_t* __restrict__ ia,
+                                                                const float4* __restrict__ B,
+                                                                const int32_t* __restrict__ ib,
+                                                                const int32_t* __restrict__ perm,
+                                                                const int32_t* __restrict__ ptr, int64_t rows,
+                                                                int64_t d4) {
+    constexpr int SLOTS = 256 / LPR;
+    constexpr int RPB = SLOTS / SPLIT;
+    static_assert(RPB >= 1, "SPLIT too large for this row width");
+    __shared__ float4 red[SLOTS][LPR];
+    const int c = threadIdx.x % LPR;
+    const int slot = threadIdx.x / LPR;
+    const int part = slot % SPLIT, rsub = slot / SPLIT;
+    for (int64_t r0 = (int64_t)blockIdx.x * RPB; r0 < rows; r0 += (int64_t)gridDim.x * RPB) {
+        const int64_t r = r0 + rsub;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+        if (r < rows) {
+            const int64_t beg = ptr[r], end = ptr[r + 1];
+            const int64_t per = (end - beg + SPLIT - 1) / SPLIT;
+            int64_t q = beg + part * per;
+            const int64_t stop = q + per < end ? q + per : end;
+            for (; q + 4 <= stop; q += 4) {
+                float4 v0 = load_term<HAS_IA, HAS_B, HAS_IB, HAS_PERM>(A, ia, B, ib, perm, q + 0, d4, c);
+                float4 v1 = load_term<HAS_IA, HAS_B, HAS_IB, HAS_PERM>(A, ia, B, ib, perm, q + 1, d4, c);
+                float4 v2 = load_term<HAS_IA, HAS_B, HAS_IB, HAS_PERM>(A, ia, B, ib, perm, q + 2, d4, c);
+                float4 v3 = load_term<HAS_IA, HAS_B, HAS_IB, HAS_PERM>(A, ia, B, ib, perm, q + 3, d4, c);
+                acc4(s0, v0); acc4(s1, v1); acc4(s2, v2); acc4(s3, v3);
+            }
+            if (q < stop) acc4(s0, load_term<HAS_IA, HAS_B, HAS_IB, HAS_PERM>(A, ia, B, ib, perm, q, d4, c));
+            if (q + 1 < stop) acc4(s1, load_term<HAS_IA, HAS_B, HAS_IB, HAS_PERM>(A, ia, B, ib, perm, q + 1, d4, c));
+            if (q + 2 < stop) acc4(s2, load_term<HAS_IA, HAS_B, HAS_IB, HAS_PERM>(A, ia, B, ib, perm, q + 2, d4, c));
+            acc4(s0, s1); acc4(s2, s3); acc4(s0, s2);
+        }
+        red[slot][c] = s0;
+        __syncthreads();
+        if (part == 0 && r < rows) {
+            float4 t = init ? init[r * d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int p = 0; p < SPLIT; ++p) acc4(t, red[rsub * SPLIT + p][c]);
+            out[r * d4 + c] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -106,14 +161,23 @@ template <int LPR>
 int launch_segment_sum(float* out, const float* init, const float* A, const int32_t* ia, const float* B,
                        const int32_t* ib, const int32_t* perm, const int32_t* ptr, int64_t rows, int64_t d4,
                        hipStream_t st) {
-    constexpr int RPB = 256 / LPR;
+    constexpr int SPLIT = (256 / LPR >= 4) ? 4 : 1;
+    // few rows: split every segment over SPLIT lane groups (see segment_sum_split_kernel)
+    const bool split = SPLIT > 1 && rows * LPR <= (int64_t)SPLIT_MAX_LANES;
+    constexpr int RPB_FULL = 256 / LPR;
+    const int RPB = split ? RPB_FULL / SPLIT : RPB_FULL;
     int64_t grid = ceil_div(rows, RPB);
     if (grid > 256 * 64) grid = 256 * 64;                  // grid-stride above 64 blocks / CU
     if (grid < 1) grid = 1;
-#define PAMNET_SEG_CASE(IA, BB, IB, PM)                                                                          \
-    hipLaunchKernelGGL((segment_sum_kernel<LPR, IA, BB, IB, PM>), dim3((unsigned)grid), dim3(256), 0, st,        \
-                       (float4*)out, (const float4*)init, (const float4*)A, ia, (const float4*)B, ib, perm, ptr, \
-                       rows, d4)
+#define PAMNET_SEG_CASE(IA, BB, IB, PM)                                                                              \
+    if (split)                                                                                                       \
+        hipLaunchKernelGGL((segment_sum_split_kernel<LPR, SPLIT, IA, BB, IB, PM>), dim3((unsigned)grid), dim3(256),  \
+                           0, st, (float4*)out, (const float4*)init, (const float4*)A, ia, (const float4*)B, ib,     \
+                           perm, ptr, rows, d4);                                                                     \
+    else                                                                                                             \
+        hipLaunchKernelGGL((segment_sum_kernel<LPR, IA, BB, IB, PM>), dim3((unsigned)grid), dim3(256), 0, st,        \
+                           (float4*)out, (const float4*)init, (const float4*)A, ia, (const float4*)B, ib, perm, ptr, \
+                           rows, d4)
     const int key = (ia ? 8 : 0) | (B ? 4 : 0) | ((B && ib) ? 2 : 0) | (perm ? 1 : 0);
     switch (key) {
         case 0: PAMNET_SEG_CASE(false, false, false, false); break;

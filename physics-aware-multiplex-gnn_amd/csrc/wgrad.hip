@@ -8,6 +8,8 @@
 // order -> deterministic, atomics-free.
 // A may be given as a pre-activation (a_mode 1: A = SiLU(Z_prev) applied while staging), so activations that are a
 // pure SiLU of a saved z are never stored twice.
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm_core.h"
 
@@ -35,9 +37,25 @@ struct WBatch {
     int njobs;
 };
 
-inline int job_slots(int64_t rows) {
-    const int64_t want = (rows + ROWS_PER_WG - 1) / ROWS_PER_WG;
+inline int job_slots(int64_t rows, int64_t chunk) {
+    const int64_t want = (rows + chunk - 1) / chunk;
     return (int)(want < 1 ? 1 : (want > MAX_SLOTS_PER_JOB ? MAX_SLOTS_PER_JOB : want));
+}
+
+// Rows per slot for a batch: 256, or the smallest multiple of 64 above it for which the whole batch fits in
+// TARGET_SLOTS workgroups -- one wave of workgroups over the 256 CUs instead of a full round plus a ragged tail
+// (345 workgroups at the QM9 B=128 shape ran as 2 rounds: 49 us; one round of 256 x 384 rows: see DESIGN.md).
+inline int target_slots() {
+    static int t = [] { const char* e = getenv("PAMNET_WGRAD_SLOTS"); return e ? atoi(e) : 256; }();
+    return t;
+}
+inline int64_t plan_chunk(int64_t njobs, const int64_t* rows) {
+    int64_t chunk = ROWS_PER_WG;
+    for (;; chunk += RB) {
+        int64_t slots = 0;
+        for (int64_t j = 0; j < njobs; ++j) slots += job_slots(rows[j], chunk);
+        if (slots <= target_slots() || chunk >= 16384) return chunk;
+    }
 }
 
 __global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, float* __restrict__ partial) {
@@ -191,7 +209,7 @@ __global__ __launch_bounds__(1024) void wgrad_bias_kernel(WBatch batch, const fl
 extern "C" int pamnet_wgrad_scratch_floats(int64_t njobs, const int64_t* rows, int64_t* floats) {
     if (njobs < 0 || njobs > MAXJ || !floats || (njobs > 0 && !rows)) return PAMNET_EINVAL;
     int64_t slots = 0;
-    for (int64_t j = 0; j < njobs; ++j) slots += job_slots(rows[j]);
+    for (int64_t j = 0; j < njobs; ++j) slots += job_slots(rows[j], ROWS_PER_WG);       // upper bound for any plan
     *floats = slots * (int64_t)(DIM * DIM + 2 * DIM);
     return PAMNET_OK;
 }
@@ -207,10 +225,11 @@ extern "C" int pamnet_wgrad_batched_f32(int64_t njobs, const float* const* dZ, c
     WBatch b;
     b.njobs = (int)njobs;
     b.start[0] = 0;
+    const int64_t chunk = plan_chunk(njobs, rows);
     for (int j = 0; j < njobs; ++j) {
         if (!dZ[j] || !A[j] || !dW[j]) return PAMNET_ENULL;
         b.job[j] = WJob{dZ[j], A[j], dW[j], db[j], rows[j], (int)ld_dz[j], (int)ld_a[j], (int)ld_dw[j], a_mode[j]};
-        b.start[j + 1] = b.start[j] + job_slots(rows[j]);
+        b.start[j + 1] = b.start[j] + job_slots(rows[j], chunk);
     }
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)b.start[njobs]), dim3(WG), 0, st, b, partial);
