@@ -7,112 +7,270 @@
 //       z_ji = W_ji,e r + b_ji + P0[i] + P2[j]      m_ji = SiLU(z_ji)
 //       z_kj = W_kj,e r + b_kj + P1[i] + P3[j]      m_nb = SiLU(z_kj) * (lin_rbf r)       q3 = lin_rbf_out r
 //   triplet/pair MLP (layers/local_message_passing.py:49):  s = SiLU(W2 SiLU(W1 sbf + b1) + b2)
-// Each kernel keeps a 64-row tile in LDS, runs its 2-4 fp32-MFMA GEMMs on it and applies the gather-add / SiLU / gate
-// epilogue while the tile is written out in coalesced 512-byte rows -- the [E,3d] concatenations and the per-edge
-// GEMM outputs of the reference never exist in memory.  P_* are the node-level projections (node_chain.hip), edges
-// are sorted by target so P_i rows repeat within a tile (L1/L2 hits).
-// Weight slices are prefetched into registers (gemm_core.h WFrag): the first two matrices at kernel entry, the next
-// ones as soon as the MFMAs that consumed a slice have been issued.
+// A kernel keeps a row tile in LDS, runs its 2-4 fp32-MFMA GEMMs on it and applies the gather-add / SiLU / gate epilogue
+// while the tile is written out in coalesced 512-byte rows -- the [E,3d] concatenations and the per-edge GEMM outputs
+// of the reference never exist in memory.  P_* are the node-level projections (node_chain.hip); edges are sorted by
+// target so P_i rows repeat within a tile (L1/L2 hits).
+//
+// Launch shape (measured with tools/phase_probe.py): the hardware hands workgroups to CUs round-robin
+// and two workgroups on one CU share its matrix pipes, so a fixed 64-row tiling ran as long as its unluckiest CU --
+// 276 tiles on 256 CUs took twice a tile's time, 514 tiles three times.  Here every launch is ONE balanced wave:
+//   * the rows are cut into 16-row MFMA tiles and dealt evenly to <= 256 workgroups (one per CU);
+//   * a workgroup is 8 waves, wave w owns output columns [16w, 16w+16): every weight slice a kernel needs (up to four
+//     128x16 slices = 128 VGPRs) is loaded ONCE per workgroup and stays in registers;
+//   * the workgroup walks its rows in chunks of up to 128 (two-slot kernels) / 96 (three-slot) rows of LDS.
 #include "common.h"
 #include "gemm_core.h"
 
 using namespace pamnet;
 
+#ifdef PAMNET_PHASE_PROBE
+// Development aid (tools/phase_probe.py builds a private copy of this file with -DPAMNET_PHASE_PROBE): timestamps of one
+// workgroup at phase boundaries and of every workgroup's start / end.  Never compiled into libpamnet_hip.so.
+__device__ long long pamnet_probe_buf[32];
+__device__ long long pamnet_probe_wg[2 * 4096];     // wall clock (100 MHz) at start / end of every workgroup
+#define PROBE(i)                                                                                   \
+    do {                                                                                           \
+        if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) {                                     \
+            pamnet_probe_buf[i] = clock64();                                                       \
+            pamnet_probe_buf[16 + i] = wall_clock64(); /* constant 100 MHz */                      \
+        }                                                                                          \
+    } while (0)
+#define PROBE_WG(slot)                                                                                        \
+    do {                                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) pamnet_probe_wg[2 * blockIdx.x + slot] = wall_clock64();   \
+    } while (0)
+extern "C" int pamnet_probe_read(long long* host32) {
+    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(pamnet_probe_buf), sizeof(long long) * 32);
+}
+extern "C" int pamnet_probe_read_wg(long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pamnet_probe_wg), sizeof(long long) * 2 * n);
+}
+#else
+#define PROBE(i)
+#define PROBE_WG(slot)
+#endif
+
 namespace {
 
-constexpr int BME = 64;                 // edge rows per workgroup
-constexpr int MTE = BME / 16;
-constexpr int SLOTE = BME * LDT;
+constexpr int WG8 = 512;                  // 8 waves
+constexpr int N_CU = 256;                 // MI355X
+constexpr int MT2 = 8;                    // 16-row tiles per chunk, kernels with two LDS slots (2 x 128 rows = 132 KB)
+constexpr int MT3 = 6;                    // ... with three LDS slots (3 x 96 rows = 149 KB)
 
-__device__ __forceinline__ int wave_col0() { return (threadIdx.x >> 6) * 32; }
-__device__ __forceinline__ Bias2 no_bias() { return load_bias2(nullptr, 0); }
+// one 128 x 16 weight slice of a wave: 8 x float4 = 32 VGPRs
+struct WFrag1 {
+    float4 b[DIM / 16];
+};
+//   TRANS = false: W is [out][in] (row stride ldw): Y = X * W^T   (forward:  Linear)
+//   TRANS = true : Y = X * W                                       (backward: dX = dZ * W)
+template <bool TRANS>
+__device__ __forceinline__ void load_wfrag1(WFrag1& f, const float* __restrict__ W, int ldw, int wc) {
+    const int lane = threadIdx.x & 63;
+    const int r16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < DIM / 16; ++q) {
+        if (!TRANS) {
+            f.b[q] = *reinterpret_cast<const float4*>(W + (size_t)(wc + r16) * ldw + 4 * kg + 16 * q);
+        } else {
+            const float* wp = W + (size_t)(16 * q + 4 * kg) * ldw + wc + r16;
+            f.b[q] = make_float4(wp[0], wp[ldw], wp[2 * (size_t)ldw], wp[3 * (size_t)ldw]);
+        }
+    }
+}
+
+template <int MTX>
+struct Acc {
+    f32x4 v[MTX];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < MTX; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+};
+
+// acc[0..MT) += As[16 m .. 16 m + 16, 0:128] * slice   (MT independent MFMA chains per k-step)
+template <int MT, int MTX>
+__device__ __forceinline__ void mma_strip(const float* __restrict__ As, const WFrag1& f, Acc<MTX>& acc) {
+    const int lane = threadIdx.x & 63;
+    const float* ap = As + (lane & 15) * LDT + 4 * (lane >> 4);
+#pragma unroll
+    for (int q = 0; q < DIM / 16; ++q) {
+        float4 a[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const float4*>(ap + m * 16 * LDT + 16 * q);
+        const float4 b = f.b[q];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc.v[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, b.x, acc.v[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc.v[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, b.y, acc.v[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc.v[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, b.z, acc.v[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc.v[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, b.w, acc.v[m], 0, 0, 0);
+    }
+}
+// mt (1..MTX) live 16-row tiles; mt is uniform over the workgroup
+template <int MTX>
+__device__ __forceinline__ void mma_n(const float* __restrict__ As, const WFrag1& f, Acc<MTX>& acc, int mt) {
+    switch (mt) {
+        case 1: mma_strip<1, MTX>(As, f, acc); break;
+        case 2: mma_strip<2, MTX>(As, f, acc); break;
+        case 3: mma_strip<3, MTX>(As, f, acc); break;
+        case 4: mma_strip<4, MTX>(As, f, acc); break;
+        case 5: mma_strip<5, MTX>(As, f, acc); break;
+        case 6: mma_strip<6, MTX>(As, f, acc); break;
+        case 7:
+            if constexpr (MTX >= 7) mma_strip<7, MTX>(As, f, acc);
+            break;
+        default:
+            if constexpr (MTX >= 8) mma_strip<8, MTX>(As, f, acc);
+            break;
+    }
+}
+// D[row][wc + col] = acc + bias for the live tiles (accumulator layout: rows 4*(lane>>4) + r, column lane & 15)
+template <int MTX>
+__device__ __forceinline__ void acc_store(const Acc<MTX>& acc, float* __restrict__ Ds, int wc, float bias, int mt) {
+    const int lane = threadIdx.x & 63;
+    const int col = wc + (lane & 15), kg = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < MTX; ++m) {
+        if (m < mt) {
+            float* d = Ds + (m * 16 + kg * 4) * LDT + col;
+            d[0 * LDT] = acc.v[m][0] + bias;
+            d[1 * LDT] = acc.v[m][1] + bias;
+            d[2 * LDT] = acc.v[m][2] + bias;
+            d[3 * LDT] = acc.v[m][3] + bias;
+        }
+    }
+}
+// 512 threads sweep a [16 mt][128] tile: thread t owns float4 column t & 31 of rows (t >> 5) + 16 i, i < mt.
+// f(row_in_chunk, c4); global accesses inside f are 512-byte coalesced rows.
+template <int MTX, typename F>
+__device__ __forceinline__ void sweep(int mt, F&& f) {
+    const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < MTX; ++i)
+        if (i < mt) f(r0 + 16 * i, c4);
+}
+
+// rows [beg, end) of this workgroup and its chunking: per = 16-row tiles per workgroup, cmt = tiles per chunk
+struct Span {
+    int64_t beg, end;
+    int cmt;
+    __device__ __forceinline__ Span(int64_t m, int per, int cmt_) : cmt(cmt_) {
+        beg = (int64_t)blockIdx.x * per * 16;
+        const int64_t e = beg + (int64_t)per * 16;
+        end = e < m ? e : m;
+    }
+};
+#define CHUNK_LOOP(sp)                                                             \
+    for (int64_t row0 = (sp).beg; row0 < (sp).end; row0 += (int64_t)(sp).cmt * 16)
+__device__ __forceinline__ int chunk_mt(const Span& sp, int64_t row0) {
+    const int64_t left = sp.end - row0;
+    const int rows = left < (int64_t)sp.cmt * 16 ? (int)left : sp.cmt * 16;
+    return (rows + 15) >> 4;
+}
+
+__device__ __forceinline__ int wave_col() { return (threadIdx.x >> 6) * 16; }
+__device__ __forceinline__ float lane_bias(const float* __restrict__ b, int wc) {
+    return b ? b[wc + (threadIdx.x & 15)] : 0.f;
+}
 
 // -------------------------------------------------------------------------------------------------- global edges
-__global__ __launch_bounds__(WG) void global_edge_fwd_kernel(const float* __restrict__ e, int64_t m,
-                                                             const float* __restrict__ We, int ld_we,
-                                                             const float* __restrict__ bm,
-                                                             const float* __restrict__ Wea, int ld_wea,
-                                                             const float* __restrict__ Pi, const float* __restrict__ Pj,
-                                                             const int32_t* __restrict__ row_of,
-                                                             const int32_t* __restrict__ col, float* __restrict__ z,
-                                                             float* __restrict__ ea, float* __restrict__ msg) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * SLOTE];
+__global__ __launch_bounds__(WG8) void global_edge_fwd_kernel(const float* __restrict__ e, int64_t m,
+                                                              const float* __restrict__ We, int ld_we,
+                                                              const float* __restrict__ bm,
+                                                              const float* __restrict__ Wea, int ld_wea,
+                                                              const float* __restrict__ Pi, const float* __restrict__ Pj,
+                                                              const int32_t* __restrict__ row_of,
+                                                              const int32_t* __restrict__ col, float* __restrict__ z,
+                                                              float* __restrict__ ea, float* __restrict__ msg, int per,
+                                                              int cmt) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * MT2 * 16 * LDT];
     float* S0 = lds;
-    float* S1 = lds + SLOTE;
-    const int64_t row0 = (int64_t)blockIdx.x * BME;
-    const int wc = wave_col0();
-    const Bias2 bv = load_bias2(bm, wc);
-    WFrag f1, f2;
-    load_wfrag<false>(f1, We, ld_we, wc);
-    load_wfrag<false>(f2, Wea, ld_wea, wc);
-    sweep_rows<BME>([&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(e, row0 + r, m, DIM, c4)); });
-    __syncthreads();
-    f32x4 au[MTE][2], aa[MTE][2];
-    acc_zero<MTE>(au);
-    acc_zero<MTE>(aa);
-    mma_tile_frag<MTE>(S0, f1, au);
-    mma_tile_frag<MTE>(S0, f2, aa);
-    __syncthreads();                                   // every wave is done reading the e tile
-    acc_to_lds<MTE>(au, S0, wc, bv);
-    acc_to_lds<MTE>(aa, S1, wc, no_bias());
-    __syncthreads();
-    sweep_rows<BME>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        if (g >= m) return;
-        const int64_t i = row_of[g], j = col[g];
-        const float4 zz = f4add(f4add(lds4(S0, r, c4), ldg4(Pi, i, DIM, c4)), ldg4(Pj, j, DIM, c4));
-        const float4 gate = lds4(S1, r, c4);
-        stg4(z, g, DIM, c4, zz);
-        stg4(ea, g, DIM, c4, gate);
-        stg4(msg, g, DIM, c4, f4mul(f4silu(zz), gate));
-    });
+    float* S1 = lds + MT2 * 16 * LDT;
+    const int wc = wave_col();
+    const float bv = lane_bias(bm, wc);
+    WFrag1 f1, f2;
+    load_wfrag1<false>(f1, We, ld_we, wc);
+    load_wfrag1<false>(f2, Wea, ld_wea, wc);
+    const Span sp(m, per, cmt);
+    CHUNK_LOOP(sp) {
+        const int mt = chunk_mt(sp, row0);
+        sweep<MT2>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(e, row0 + r, sp.end, DIM, c4)); });
+        __syncthreads();
+        Acc<MT2> au, aa;
+        au.zero();
+        aa.zero();
+        mma_n<MT2>(S0, f1, au, mt);
+        mma_n<MT2>(S0, f2, aa, mt);
+        __syncthreads();                                   // every wave is done reading the e tile
+        acc_store<MT2>(au, S0, wc, bv, mt);
+        acc_store<MT2>(aa, S1, wc, 0.f, mt);
+        __syncthreads();
+        sweep<MT2>(mt, [&](int r, int c4) {
+            const int64_t g = row0 + r;
+            if (g >= sp.end) return;
+            const int64_t i = row_of[g], j = col[g];
+            const float4 zz = f4add(f4add(lds4(S0, r, c4), ldg4(Pi, i, DIM, c4)), ldg4(Pj, j, DIM, c4));
+            const float4 gate = lds4(S1, r, c4);
+            stg4(z, g, DIM, c4, zz);
+            stg4(ea, g, DIM, c4, gate);
+            stg4(msg, g, DIM, c4, f4mul(f4silu(zz), gate));
+        });
+        __syncthreads();
+    }
 }
 
 // dm[e] = d_agg[i(e)];  dz = dm * ea * SiLU'(z);  dea = dm * SiLU(z);  d_e (+)= dz * W_e + dea * W_ea
-__global__ __launch_bounds__(WG) void global_edge_bwd_kernel(const float* __restrict__ d_agg,
-                                                             const int32_t* __restrict__ row_of, int64_t m,
-                                                             const float* __restrict__ z, const float* __restrict__ ea,
-                                                             const float* __restrict__ We, int ld_we,
-                                                             const float* __restrict__ Wea, int ld_wea,
-                                                             float* __restrict__ dz, float* __restrict__ dea,
-                                                             float* __restrict__ d_e, int accumulate) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * SLOTE];
+__global__ __launch_bounds__(WG8) void global_edge_bwd_kernel(const float* __restrict__ d_agg,
+                                                              const int32_t* __restrict__ row_of, int64_t m,
+                                                              const float* __restrict__ z, const float* __restrict__ ea,
+                                                              const float* __restrict__ We, int ld_we,
+                                                              const float* __restrict__ Wea, int ld_wea,
+                                                              float* __restrict__ dz, float* __restrict__ dea,
+                                                              float* __restrict__ d_e, int accumulate, int per, int cmt) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * MT2 * 16 * LDT];
     float* S0 = lds;
-    float* S1 = lds + SLOTE;
-    const int64_t row0 = (int64_t)blockIdx.x * BME;
-    const int wc = wave_col0();
-    WFrag f1, f2;
-    load_wfrag<true>(f1, We, ld_we, wc);
-    load_wfrag<true>(f2, Wea, ld_wea, wc);
-    sweep_rows<BME>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        float4 a = f4zero(), b = f4zero();
-        if (g < m) {
-            const float4 dm = ldg4(d_agg, row_of[g], DIM, c4);
-            const float4 zz = ldg4(z, g, DIM, c4);
-            a = f4mul(f4mul(dm, ldg4(ea, g, DIM, c4)), f4dsilu(zz));
-            b = f4mul(dm, f4silu(zz));
-            stg4(dz, g, DIM, c4, a);
-            stg4(dea, g, DIM, c4, b);
-        }
-        st_lds4(S0, r, c4, a);
-        st_lds4(S1, r, c4, b);
-    });
-    __syncthreads();
-    f32x4 acc[MTE][2];
-    acc_zero<MTE>(acc);
-    mma_tile_frag<MTE>(S0, f1, acc);
-    mma_tile_frag<MTE>(S1, f2, acc);
-    __syncthreads();
-    acc_to_lds<MTE>(acc, S0, wc, no_bias());
-    __syncthreads();
-    sweep_rows<BME>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        if (g >= m) return;
-        float4 v = lds4(S0, r, c4);
-        if (accumulate) v = f4add(v, ldg4(d_e, g, DIM, c4));
-        stg4(d_e, g, DIM, c4, v);
-    });
+    float* S1 = lds + MT2 * 16 * LDT;
+    const int wc = wave_col();
+    WFrag1 f1, f2;
+    load_wfrag1<true>(f1, We, ld_we, wc);
+    load_wfrag1<true>(f2, Wea, ld_wea, wc);
+    const Span sp(m, per, cmt);
+    CHUNK_LOOP(sp) {
+        const int mt = chunk_mt(sp, row0);
+        sweep<MT2>(mt, [&](int r, int c4) {
+            const int64_t g = row0 + r;
+            float4 a = f4zero(), b = f4zero();
+            if (g < sp.end) {
+                const float4 dm = ldg4(d_agg, row_of[g], DIM, c4);
+                const float4 zz = ldg4(z, g, DIM, c4);
+                a = f4mul(f4mul(dm, ldg4(ea, g, DIM, c4)), f4dsilu(zz));
+                b = f4mul(dm, f4silu(zz));
+                stg4(dz, g, DIM, c4, a);
+                stg4(dea, g, DIM, c4, b);
+            }
+            st_lds4(S0, r, c4, a);
+            st_lds4(S1, r, c4, b);
+        });
+        __syncthreads();
+        Acc<MT2> acc;
+        acc.zero();
+        mma_n<MT2>(S0, f1, acc, mt);
+        mma_n<MT2>(S1, f2, acc, mt);
+        __syncthreads();
+        acc_store<MT2>(acc, S0, wc, 0.f, mt);
+        __syncthreads();
+        sweep<MT2>(mt, [&](int r, int c4) {
+            const int64_t g = row0 + r;
+            if (g >= sp.end) return;
+            float4 v = lds4(S0, r, c4);
+            if (accumulate) v = f4add(v, ldg4(d_e, g, DIM, c4));
+            stg4(d_e, g, DIM, c4, v);
+        });
+        __syncthreads();
+    }
 }
 
 // -------------------------------------------------------------------------------------------------- local edges
@@ -122,233 +280,266 @@ struct LocalW {
     const float* P[4];      // node planes: ji_i, kj_i, ji_j, kj_j  ([N][128] each)
 };
 
-__global__ __launch_bounds__(WG) void local_edge_fwd_kernel(const float* __restrict__ rbf, int64_t m, LocalW w,
-                                                            const float* __restrict__ b_ji,
-                                                            const float* __restrict__ b_kj,
-                                                            const int32_t* __restrict__ row_of,
-                                                            const int32_t* __restrict__ col, float* __restrict__ z_ji,
-                                                            float* __restrict__ z_kj, float* __restrict__ q2,
-                                                            float* __restrict__ q3, float* __restrict__ m_ji,
-                                                            float* __restrict__ m_nb) {
-    __shared__ __attribute__((aligned(16))) float lds[3 * SLOTE];
+__global__ __launch_bounds__(WG8) void local_edge_fwd_kernel(const float* __restrict__ rbf, int64_t m, LocalW w,
+                                                             const float* __restrict__ b_ji,
+                                                             const float* __restrict__ b_kj,
+                                                             const int32_t* __restrict__ row_of,
+                                                             const int32_t* __restrict__ col, float* __restrict__ z_ji,
+                                                             float* __restrict__ z_kj, float* __restrict__ q2,
+                                                             float* __restrict__ q3, float* __restrict__ m_ji,
+                                                             float* __restrict__ m_nb, int per, int cmt) {
+    __shared__ __attribute__((aligned(16))) float lds[3 * MT3 * 16 * LDT];
     float* S0 = lds;
-    float* S1 = lds + SLOTE;
-    float* S2 = lds + 2 * SLOTE;
-    const int64_t row0 = (int64_t)blockIdx.x * BME;
-    const int wc = wave_col0();
-    const Bias2 bkj = load_bias2(b_kj, wc), bji = load_bias2(b_ji, wc);
-    WFrag fa, fb;
-    load_wfrag<false>(fa, w.W[2], w.ld[2], wc);
-    load_wfrag<false>(fb, w.W[1], w.ld[1], wc);
-    sweep_rows<BME>([&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(rbf, row0 + r, m, DIM, c4)); });
-    __syncthreads();
-    // one GEMM on the rbf tile with the slice in `f`; then `f` is refilled with the slice of matrix `next` (or left)
-    auto gemm = [&](WFrag& f, Bias2 bias, float* D, int next) {
-        f32x4 acc[MTE][2];
-        acc_zero<MTE>(acc);
-        mma_tile_frag<MTE>(S0, f, acc);
-        if (next >= 0) load_wfrag<false>(f, w.W[next], w.ld[next], wc);
-        acc_to_lds<MTE>(acc, D, wc, bias);
+    float* S1 = lds + MT3 * 16 * LDT;
+    float* S2 = lds + 2 * MT3 * 16 * LDT;
+    const int wc = wave_col();
+    const float bkj = lane_bias(b_kj, wc), bji = lane_bias(b_ji, wc);
+    WFrag1 f0, f1, f2, f3;
+    load_wfrag1<false>(f2, w.W[2], w.ld[2], wc);
+    load_wfrag1<false>(f1, w.W[1], w.ld[1], wc);
+    load_wfrag1<false>(f0, w.W[0], w.ld[0], wc);
+    load_wfrag1<false>(f3, w.W[3], w.ld[3], wc);
+    const Span sp(m, per, cmt);
+    CHUNK_LOOP(sp) {
+        const int mt = chunk_mt(sp, row0);
+        sweep<MT3>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(rbf, row0 + r, sp.end, DIM, c4)); });
         __syncthreads();
-    };
-    gemm(fa, no_bias(), S2, 0);                         // q2 = lin_rbf r (kept for the gate);   fa <- W_ji,e
-    gemm(fb, bkj, S1, 3);                               // W_kj,e r + b_kj;                      fb <- lin_rbf_out
-    sweep_rows<BME>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        if (g >= m) return;
-        const int64_t i = row_of[g], j = col[g];
-        const float4 zz = f4add(f4add(lds4(S1, r, c4), ldg4(w.P[1], i, DIM, c4)), ldg4(w.P[3], j, DIM, c4));
-        const float4 gate = lds4(S2, r, c4);
-        stg4(z_kj, g, DIM, c4, zz);
-        stg4(q2, g, DIM, c4, gate);
-        stg4(m_nb, g, DIM, c4, f4mul(f4silu(zz), gate));
-    });
-    __syncthreads();
-    gemm(fa, bji, S1, -1);                              // W_ji,e r + b_ji
-    gemm(fb, no_bias(), S2, -1);                        // q3 = lin_rbf_out r
-    sweep_rows<BME>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        if (g >= m) return;
-        const int64_t i = row_of[g], j = col[g];
-        const float4 zz = f4add(f4add(lds4(S1, r, c4), ldg4(w.P[0], i, DIM, c4)), ldg4(w.P[2], j, DIM, c4));
-        stg4(z_ji, g, DIM, c4, zz);
-        stg4(m_ji, g, DIM, c4, f4silu(zz));
-        stg4(q3, g, DIM, c4, lds4(S2, r, c4));
-    });
+        Acc<MT3> acc;
+        acc.zero();
+        mma_n<MT3>(S0, f2, acc, mt);                          // q2 = lin_rbf r (the gate)
+        acc_store<MT3>(acc, S2, wc, 0.f, mt);
+        acc.zero();
+        mma_n<MT3>(S0, f1, acc, mt);                          // W_kj,e r + b_kj
+        acc_store<MT3>(acc, S1, wc, bkj, mt);
+        __syncthreads();
+        sweep<MT3>(mt, [&](int r, int c4) {
+            const int64_t g = row0 + r;
+            if (g >= sp.end) return;
+            const int64_t i = row_of[g], j = col[g];
+            const float4 zz = f4add(f4add(lds4(S1, r, c4), ldg4(w.P[1], i, DIM, c4)), ldg4(w.P[3], j, DIM, c4));
+            const float4 gate = lds4(S2, r, c4);
+            stg4(z_kj, g, DIM, c4, zz);
+            stg4(q2, g, DIM, c4, gate);
+            stg4(m_nb, g, DIM, c4, f4mul(f4silu(zz), gate));
+        });
+        __syncthreads();
+        acc.zero();
+        mma_n<MT3>(S0, f0, acc, mt);                          // W_ji,e r + b_ji
+        acc_store<MT3>(acc, S1, wc, bji, mt);
+        acc.zero();
+        mma_n<MT3>(S0, f3, acc, mt);                          // q3 = lin_rbf_out r
+        acc_store<MT3>(acc, S2, wc, 0.f, mt);
+        __syncthreads();
+        sweep<MT3>(mt, [&](int r, int c4) {
+            const int64_t g = row0 + r;
+            if (g >= sp.end) return;
+            const int64_t i = row_of[g], j = col[g];
+            const float4 zz = f4add(f4add(lds4(S1, r, c4), ldg4(w.P[0], i, DIM, c4)), ldg4(w.P[2], j, DIM, c4));
+            stg4(z_ji, g, DIM, c4, zz);
+            stg4(m_ji, g, DIM, c4, f4silu(zz));
+            stg4(q3, g, DIM, c4, lds4(S2, r, c4));
+        });
+        __syncthreads();
+    }
 }
 
 // dz_ji = d_mji * SiLU'(z_ji);  dz_kj = d_mnb * q2 * SiLU'(z_kj);  dq2 = d_mnb * SiLU(z_kj);  dq3 given.
 // d_rbf (+)= dz_ji W_ji,e + dz_kj W_kj,e + dq2 W_lin_rbf + dq3 W_lin_rbf_out
-__global__ __launch_bounds__(WG) void local_edge_bwd_kernel(const float* __restrict__ d_mji,
-                                                            const float* __restrict__ d_mnb,
-                                                            const float* __restrict__ d_q3, int64_t m,
-                                                            const float* __restrict__ z_ji,
-                                                            const float* __restrict__ z_kj,
-                                                            const float* __restrict__ q2, LocalW w,
-                                                            float* __restrict__ dz_ji, float* __restrict__ dz_kj,
-                                                            float* __restrict__ dq2, float* __restrict__ d_rbf,
-                                                            int accumulate) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * SLOTE];
+__global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(const float* __restrict__ d_mji,
+                                                             const float* __restrict__ d_mnb,
+                                                             const float* __restrict__ d_q3, int64_t m,
+                                                             const float* __restrict__ z_ji,
+                                                             const float* __restrict__ z_kj,
+                                                             const float* __restrict__ q2, LocalW w,
+                                                             float* __restrict__ dz_ji, float* __restrict__ dz_kj,
+                                                             float* __restrict__ dq2, float* __restrict__ d_rbf,
+                                                             int accumulate, int per, int cmt) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * MT2 * 16 * LDT];
     float* S0 = lds;
-    float* S1 = lds + SLOTE;
-    const int64_t row0 = (int64_t)blockIdx.x * BME;
-    const int wc = wave_col0();
-    WFrag fa, fb;
-    load_wfrag<true>(fa, w.W[0], w.ld[0], wc);
-    load_wfrag<true>(fb, w.W[1], w.ld[1], wc);
-    f32x4 acc[MTE][2];
-    acc_zero<MTE>(acc);
-    // pass A: dz_ji -> S0, dz_kj -> S1
-    sweep_rows<BME>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        float4 a = f4zero(), b = f4zero();
-        if (g < m) {
-            a = f4mul(ldg4(d_mji, g, DIM, c4), f4dsilu(ldg4(z_ji, g, DIM, c4)));
-            b = f4mul(f4mul(ldg4(d_mnb, g, DIM, c4), ldg4(q2, g, DIM, c4)), f4dsilu(ldg4(z_kj, g, DIM, c4)));
-            stg4(dz_ji, g, DIM, c4, a);
-            stg4(dz_kj, g, DIM, c4, b);
-        }
-        st_lds4(S0, r, c4, a);
-        st_lds4(S1, r, c4, b);
-    });
-    __syncthreads();
-    mma_tile_frag<MTE>(S0, fa, acc);
-    load_wfrag<true>(fa, w.W[2], w.ld[2], wc);
-    mma_tile_frag<MTE>(S1, fb, acc);
-    load_wfrag<true>(fb, w.W[3], w.ld[3], wc);
-    __syncthreads();
-    // pass B: dq2 -> S0, dq3 -> S1
-    sweep_rows<BME>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        float4 a = f4zero(), b = f4zero();
-        if (g < m) {
-            a = f4mul(ldg4(d_mnb, g, DIM, c4), f4silu(ldg4(z_kj, g, DIM, c4)));
-            b = ldg4(d_q3, g, DIM, c4);
-            stg4(dq2, g, DIM, c4, a);
-        }
-        st_lds4(S0, r, c4, a);
-        st_lds4(S1, r, c4, b);
-    });
-    __syncthreads();
-    mma_tile_frag<MTE>(S0, fa, acc);
-    mma_tile_frag<MTE>(S1, fb, acc);
-    __syncthreads();
-    acc_to_lds<MTE>(acc, S0, wc, no_bias());
-    __syncthreads();
-    sweep_rows<BME>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        if (g >= m) return;
-        float4 v = lds4(S0, r, c4);
-        if (accumulate) v = f4add(v, ldg4(d_rbf, g, DIM, c4));
-        stg4(d_rbf, g, DIM, c4, v);
-    });
+    float* S1 = lds + MT2 * 16 * LDT;
+    const int wc = wave_col();
+    WFrag1 f0, f1, f2, f3;
+    load_wfrag1<true>(f0, w.W[0], w.ld[0], wc);
+    load_wfrag1<true>(f1, w.W[1], w.ld[1], wc);
+    load_wfrag1<true>(f2, w.W[2], w.ld[2], wc);
+    load_wfrag1<true>(f3, w.W[3], w.ld[3], wc);
+    const Span sp(m, per, cmt);
+    CHUNK_LOOP(sp) {
+        const int mt = chunk_mt(sp, row0);
+        Acc<MT2> acc;
+        acc.zero();
+        // pass A: dz_ji -> S0, dz_kj -> S1
+        sweep<MT2>(mt, [&](int r, int c4) {
+            const int64_t g = row0 + r;
+            float4 a = f4zero(), b = f4zero();
+            if (g < sp.end) {
+                a = f4mul(ldg4(d_mji, g, DIM, c4), f4dsilu(ldg4(z_ji, g, DIM, c4)));
+                b = f4mul(f4mul(ldg4(d_mnb, g, DIM, c4), ldg4(q2, g, DIM, c4)), f4dsilu(ldg4(z_kj, g, DIM, c4)));
+                stg4(dz_ji, g, DIM, c4, a);
+                stg4(dz_kj, g, DIM, c4, b);
+            }
+            st_lds4(S0, r, c4, a);
+            st_lds4(S1, r, c4, b);
+        });
+        __syncthreads();
+        mma_n<MT2>(S0, f0, acc, mt);
+        mma_n<MT2>(S1, f1, acc, mt);
+        __syncthreads();
+        // pass B: dq2 -> S0, dq3 -> S1
+        sweep<MT2>(mt, [&](int r, int c4) {
+            const int64_t g = row0 + r;
+            float4 a = f4zero(), b = f4zero();
+            if (g < sp.end) {
+                a = f4mul(ldg4(d_mnb, g, DIM, c4), f4silu(ldg4(z_kj, g, DIM, c4)));
+                b = ldg4(d_q3, g, DIM, c4);
+                stg4(dq2, g, DIM, c4, a);
+            }
+            st_lds4(S0, r, c4, a);
+            st_lds4(S1, r, c4, b);
+        });
+        __syncthreads();
+        mma_n<MT2>(S0, f2, acc, mt);
+        mma_n<MT2>(S1, f3, acc, mt);
+        __syncthreads();
+        acc_store<MT2>(acc, S0, wc, 0.f, mt);
+        __syncthreads();
+        sweep<MT2>(mt, [&](int r, int c4) {
+            const int64_t g = row0 + r;
+            if (g >= sp.end) return;
+            float4 v = lds4(S0, r, c4);
+            if (accumulate) v = f4add(v, ldg4(d_rbf, g, DIM, c4));
+            stg4(d_rbf, g, DIM, c4, v);
+        });
+        __syncthreads();
+    }
 }
 
 // -------------------------------------------------------------------------------------------------- 2-layer MLP
-__global__ __launch_bounds__(WG) void mlp2_fwd_kernel(const float* __restrict__ x, int64_t m,
-                                                      const float* __restrict__ W1, const float* __restrict__ b1,
-                                                      const float* __restrict__ W2, const float* __restrict__ b2,
-                                                      float* __restrict__ z1, float* __restrict__ z2,
-                                                      float* __restrict__ y) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * SLOTE];
+__global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__ x, int64_t m,
+                                                       const float* __restrict__ W1, const float* __restrict__ b1,
+                                                       const float* __restrict__ W2, const float* __restrict__ b2,
+                                                       float* __restrict__ z1, float* __restrict__ z2,
+                                                       float* __restrict__ y, int per, int cmt) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * MT2 * 16 * LDT];
     float* S0 = lds;
-    float* S1 = lds + SLOTE;
-    const int64_t row0 = (int64_t)blockIdx.x * BME;
-    const int wc = wave_col0();
-    const Bias2 bv1 = load_bias2(b1, wc), bv2 = load_bias2(b2, wc);
-    WFrag f;
-    load_wfrag<false>(f, W1, DIM, wc);
-    sweep_rows<BME>([&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(x, row0 + r, m, DIM, c4)); });
-    __syncthreads();
-    {
-        f32x4 acc[MTE][2];
-        acc_zero<MTE>(acc);
-        mma_tile_frag<MTE>(S0, f, acc);
-        load_wfrag<false>(f, W2, DIM, wc);              // in flight during the activation sweep
-        acc_to_lds<MTE>(acc, S1, wc, bv1);
+    float* S1 = lds + MT2 * 16 * LDT;
+    const int wc = wave_col();
+    const float bv1 = lane_bias(b1, wc), bv2 = lane_bias(b2, wc);
+    PROBE(0);
+    PROBE_WG(0);
+    WFrag1 f1, f2;
+    load_wfrag1<false>(f1, W1, DIM, wc);
+    load_wfrag1<false>(f2, W2, DIM, wc);
+    const Span sp(m, per, cmt);
+    CHUNK_LOOP(sp) {
+        const int mt = chunk_mt(sp, row0);
+        sweep<MT2>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(x, row0 + r, sp.end, DIM, c4)); });
+        __syncthreads();
+        PROBE(1);
+        Acc<MT2> acc;
+        acc.zero();
+        mma_n<MT2>(S0, f1, acc, mt);
+        PROBE(2);
+        acc_store<MT2>(acc, S1, wc, bv1, mt);
+        __syncthreads();
+        PROBE(3);
+        sweep<MT2>(mt, [&](int r, int c4) {
+            const int64_t g = row0 + r;
+            const float4 zz = lds4(S1, r, c4);
+            st_lds4(S1, r, c4, f4silu(zz));
+            if (g < sp.end) stg4(z1, g, DIM, c4, zz);
+        });
+        __syncthreads();
+        PROBE(4);
+        acc.zero();
+        mma_n<MT2>(S1, f2, acc, mt);
+        PROBE(5);
+        acc_store<MT2>(acc, S0, wc, bv2, mt);
+        __syncthreads();
+        PROBE(6);
+        sweep<MT2>(mt, [&](int r, int c4) {
+            const int64_t g = row0 + r;
+            if (g >= sp.end) return;
+            const float4 zz = lds4(S0, r, c4);
+            stg4(z2, g, DIM, c4, zz);
+            stg4(y, g, DIM, c4, f4silu(zz));
+        });
         __syncthreads();
     }
-    sweep_rows<BME>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        const float4 zz = lds4(S1, r, c4);
-        st_lds4(S1, r, c4, f4silu(zz));
-        if (g < m) stg4(z1, g, DIM, c4, zz);
-    });
-    __syncthreads();
-    {
-        f32x4 acc[MTE][2];
-        acc_zero<MTE>(acc);
-        mma_tile_frag<MTE>(S1, f, acc);
-        acc_to_lds<MTE>(acc, S0, wc, bv2);
-        __syncthreads();
-    }
-    sweep_rows<BME>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        if (g >= m) return;
-        const float4 zz = lds4(S0, r, c4);
-        stg4(z2, g, DIM, c4, zz);
-        stg4(y, g, DIM, c4, f4silu(zz));
-    });
+    PROBE(7);
+    PROBE_WG(1);
 }
 
-__global__ __launch_bounds__(WG) void mlp2_bwd_kernel(const float* __restrict__ dy, int64_t m,
-                                                      const float* __restrict__ z1, const float* __restrict__ z2,
-                                                      const float* __restrict__ W1, const float* __restrict__ W2,
-                                                      float* __restrict__ dz1, float* __restrict__ dz2,
-                                                      float* __restrict__ dx, int accumulate) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * SLOTE];
+__global__ __launch_bounds__(WG8) void mlp2_bwd_kernel(const float* __restrict__ dy, int64_t m,
+                                                       const float* __restrict__ z1, const float* __restrict__ z2,
+                                                       const float* __restrict__ W1, const float* __restrict__ W2,
+                                                       float* __restrict__ dz1, float* __restrict__ dz2,
+                                                       float* __restrict__ dx, int accumulate, int per, int cmt) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * MT2 * 16 * LDT];
     float* S0 = lds;
-    float* S1 = lds + SLOTE;
-    const int64_t row0 = (int64_t)blockIdx.x * BME;
-    const int wc = wave_col0();
-    WFrag f;
-    load_wfrag<true>(f, W2, DIM, wc);
-    sweep_rows<BME>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        float4 a = f4zero();
-        if (g < m) {
-            a = f4mul(ldg4(dy, g, DIM, c4), f4dsilu(ldg4(z2, g, DIM, c4)));
-            stg4(dz2, g, DIM, c4, a);
-        }
-        st_lds4(S0, r, c4, a);
-    });
-    __syncthreads();
-    {
-        f32x4 acc[MTE][2];
-        acc_zero<MTE>(acc);
-        mma_tile_frag<MTE>(S0, f, acc);
-        load_wfrag<true>(f, W1, DIM, wc);
-        acc_to_lds<MTE>(acc, S1, wc, no_bias());
+    float* S1 = lds + MT2 * 16 * LDT;
+    const int wc = wave_col();
+    WFrag1 f1, f2;
+    load_wfrag1<true>(f2, W2, DIM, wc);
+    load_wfrag1<true>(f1, W1, DIM, wc);
+    const Span sp(m, per, cmt);
+    CHUNK_LOOP(sp) {
+        const int mt = chunk_mt(sp, row0);
+        sweep<MT2>(mt, [&](int r, int c4) {
+            const int64_t g = row0 + r;
+            float4 a = f4zero();
+            if (g < sp.end) {
+                a = f4mul(ldg4(dy, g, DIM, c4), f4dsilu(ldg4(z2, g, DIM, c4)));
+                stg4(dz2, g, DIM, c4, a);
+            }
+            st_lds4(S0, r, c4, a);
+        });
+        __syncthreads();
+        Acc<MT2> acc;
+        acc.zero();
+        mma_n<MT2>(S0, f2, acc, mt);
+        acc_store<MT2>(acc, S1, wc, 0.f, mt);
+        __syncthreads();
+        sweep<MT2>(mt, [&](int r, int c4) {
+            const int64_t g = row0 + r;
+            float4 a = f4zero();
+            if (g < sp.end) {
+                a = f4mul(lds4(S1, r, c4), f4dsilu(ldg4(z1, g, DIM, c4)));
+                stg4(dz1, g, DIM, c4, a);
+            }
+            st_lds4(S1, r, c4, a);
+        });
+        __syncthreads();
+        acc.zero();
+        mma_n<MT2>(S1, f1, acc, mt);
+        acc_store<MT2>(acc, S0, wc, 0.f, mt);                 // S0 (dz2 tile) was last read before the previous barrier
+        __syncthreads();
+        sweep<MT2>(mt, [&](int r, int c4) {
+            const int64_t g = row0 + r;
+            if (g >= sp.end) return;
+            float4 v = lds4(S0, r, c4);
+            if (accumulate) v = f4add(v, ldg4(dx, g, DIM, c4));
+            stg4(dx, g, DIM, c4, v);
+        });
         __syncthreads();
     }
-    sweep_rows<BME>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        float4 a = f4zero();
-        if (g < m) {
-            a = f4mul(lds4(S1, r, c4), f4dsilu(ldg4(z1, g, DIM, c4)));
-            stg4(dz1, g, DIM, c4, a);
-        }
-        st_lds4(S1, r, c4, a);
-    });
-    __syncthreads();
-    {
-        f32x4 acc[MTE][2];
-        acc_zero<MTE>(acc);
-        mma_tile_frag<MTE>(S1, f, acc);
-        __syncthreads();
-        acc_to_lds<MTE>(acc, S0, wc, no_bias());
-        __syncthreads();
-    }
-    sweep_rows<BME>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        if (g >= m) return;
-        float4 v = lds4(S0, r, c4);
-        if (accumulate) v = f4add(v, ldg4(dx, g, DIM, c4));
-        stg4(dx, g, DIM, c4, v);
-    });
 }
 
-inline unsigned tiles(int64_t m) { return (unsigned)ceil_div(m, BME); }
+// One balanced wave of workgroups: `per` 16-row tiles each (<= N_CU workgroups), walked in chunks of `cmt` <= cap tiles.
+struct Plan {
+    unsigned grid;
+    int per, cmt;
+};
+inline Plan plan(int64_t rows, int cap) {
+    const int64_t tiles16 = ceil_div(rows, 16);
+    const int64_t per = ceil_div(tiles16, N_CU);
+    const int64_t nchunk = ceil_div(per, cap);
+    Plan p;
+    p.per = (int)per;
+    p.cmt = (int)ceil_div(per, nchunk);
+    p.grid = (unsigned)ceil_div(tiles16, per);
+    return p;
+}
 
 }  // namespace
 
@@ -359,8 +550,9 @@ extern "C" int pamnet_global_edge_fwd_f32(const float* e, int64_t n_edges, const
     if (n_edges < 0) return PAMNET_EINVAL;
     if (n_edges == 0) return PAMNET_OK;
     if (!e || !We || !bm || !Wea || !Pi || !Pj || !row_of || !col || !z || !ea || !msg) return PAMNET_ENULL;
-    hipLaunchKernelGGL(global_edge_fwd_kernel, dim3(tiles(n_edges)), dim3(WG), 0, as_stream(stream), e, n_edges, We,
-                       (int)ld_we, bm, Wea, (int)ld_wea, Pi, Pj, row_of, col, z, ea, msg);
+    const Plan p = plan(n_edges, MT2);
+    hipLaunchKernelGGL(global_edge_fwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), e, n_edges, We, (int)ld_we,
+                       bm, Wea, (int)ld_wea, Pi, Pj, row_of, col, z, ea, msg, p.per, p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -372,8 +564,9 @@ extern "C" int pamnet_global_edge_bwd_f32(const float* d_agg, const int32_t* row
     if (n_edges < 0) return PAMNET_EINVAL;
     if (n_edges == 0) return PAMNET_OK;
     if (!d_agg || !row_of || !z || !ea || !We || !Wea || !dz || !dea || !d_e) return PAMNET_ENULL;
-    hipLaunchKernelGGL(global_edge_bwd_kernel, dim3(tiles(n_edges)), dim3(WG), 0, as_stream(stream), d_agg, row_of,
-                       n_edges, z, ea, We, (int)ld_we, Wea, (int)ld_wea, dz, dea, d_e, (int)accumulate);
+    const Plan p = plan(n_edges, MT2);
+    hipLaunchKernelGGL(global_edge_bwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), d_agg, row_of, n_edges, z,
+                       ea, We, (int)ld_we, Wea, (int)ld_wea, dz, dea, d_e, (int)accumulate, p.per, p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -400,8 +593,9 @@ extern "C" int pamnet_local_edge_fwd_f32(const float* rbf, int64_t n_edges, cons
     LocalW w;
     int rc = fill_local(w, Wq, ldq, P);
     if (rc) return rc;
-    hipLaunchKernelGGL(local_edge_fwd_kernel, dim3(tiles(n_edges)), dim3(WG), 0, as_stream(stream), rbf, n_edges, w,
-                       b_ji, b_kj, row_of, col, z_ji, z_kj, q2, q3, m_ji, m_nb);
+    const Plan p = plan(n_edges, MT3);
+    hipLaunchKernelGGL(local_edge_fwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), rbf, n_edges, w, b_ji, b_kj,
+                       row_of, col, z_ji, z_kj, q2, q3, m_ji, m_nb, p.per, p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -417,8 +611,9 @@ extern "C" int pamnet_local_edge_bwd_f32(const float* d_mji, const float* d_mnb,
     LocalW w;
     int rc = fill_local(w, Wq, ldq, nullptr);
     if (rc) return rc;
-    hipLaunchKernelGGL(local_edge_bwd_kernel, dim3(tiles(n_edges)), dim3(WG), 0, as_stream(stream), d_mji, d_mnb, d_q3,
-                       n_edges, z_ji, z_kj, q2, w, dz_ji, dz_kj, dq2, d_rbf, (int)accumulate);
+    const Plan p = plan(n_edges, MT2);
+    hipLaunchKernelGGL(local_edge_bwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), d_mji, d_mnb, d_q3, n_edges,
+                       z_ji, z_kj, q2, w, dz_ji, dz_kj, dq2, d_rbf, (int)accumulate, p.per, p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -428,8 +623,9 @@ extern "C" int pamnet_mlp2_fwd_f32(const float* x, int64_t rows, const float* W1
     if (rows < 0) return PAMNET_EINVAL;
     if (rows == 0) return PAMNET_OK;
     if (!x || !W1 || !b1 || !W2 || !b2 || !z1 || !z2 || !y) return PAMNET_ENULL;
-    hipLaunchKernelGGL(mlp2_fwd_kernel, dim3(tiles(rows)), dim3(WG), 0, as_stream(stream), x, rows, W1, b1, W2, b2, z1,
-                       z2, y);
+    const Plan p = plan(rows, MT2);
+    hipLaunchKernelGGL(mlp2_fwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), x, rows, W1, b1, W2, b2, z1, z2, y,
+                       p.per, p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -440,8 +636,9 @@ extern "C" int pamnet_mlp2_bwd_f32(const float* dy, int64_t rows, const float* z
     if (rows < 0) return PAMNET_EINVAL;
     if (rows == 0) return PAMNET_OK;
     if (!dy || !z1 || !z2 || !W1 || !W2 || !dz1 || !dz2 || !dx) return PAMNET_ENULL;
-    hipLaunchKernelGGL(mlp2_bwd_kernel, dim3(tiles(rows)), dim3(WG), 0, as_stream(stream), dy, rows, z1, z2, W1, W2,
-                       dz1, dz2, dx, (int)accumulate);
+    const Plan p = plan(rows, MT2);
+    hipLaunchKernelGGL(mlp2_bwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), dy, rows, z1, z2, W1, W2, dz1, dz2,
+                       dx, (int)accumulate, p.per, p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

@@ -132,6 +132,12 @@ inline Temp carve_temp(float* p, const Graph& g) {
         if (rc__) return rc__;   \
     } while (0)
 
+#define HK(call)                                   \
+    do {                                           \
+        const hipError_t e__ = (call);             \
+        if (e__ != hipSuccess) return (int)e__;    \
+    } while (0)
+
 // weight-gradient job list builder
 struct Jobs {
     const float* dZ[WJOBS];
@@ -198,7 +204,8 @@ static int fill_graph(Graph& g, const int64_t* sizes, const int32_t* const* idx)
 extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, int64_t n_layer,
                                     const float* x0, const float* e_g, const float* rbf_e, const float* e_sbf,
                                     const float* const* gparams, const float* const* lparams, float* saved, float* temp,
-                                    float* outs, float* atts, pamnet_stream_t st) {
+                                    float* outs, float* atts, pamnet_stream_t aux, void* const* aux_events,
+                                    pamnet_stream_t st) {
     Graph g;
     CK(fill_graph(g, sizes, graph_idx));
     if (n_layer < 1) return PAMNET_EINVAL;
@@ -206,6 +213,21 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
     const Temp t = carve_temp(temp, g);
     const int64_t gs = al(global_saved_floats(g)), ls = al(local_saved_floats(g));
     const float* x = x0;
+    // The triplet/pair MLP s_k = mlp_sbf_k(e_sbf) does not depend on the node features: with an auxiliary stream all
+    // n_layer of them are enqueued up front and run beside the node-level kernels of the first layers, which occupy
+    // only ceil(n/16) of the 256 CUs.  Event 0 = inputs ready, event 1+k = s_k ready.
+    const bool forked = aux && aux_events && g.tp > 0;
+    if (forked) {
+        hipStream_t a = as_stream(aux);
+        HK(hipEventRecord(reinterpret_cast<hipEvent_t>(aux_events[0]), as_stream(st)));
+        HK(hipStreamWaitEvent(a, reinterpret_cast<hipEvent_t>(aux_events[0]), 0));
+        for (int64_t k = 0; k < n_layer; ++k) {
+            const float* const* lp = lparams + k * NL;
+            const LocalSaved q = carve_local(saved + k * (gs + ls) + gs, g);
+            CK(pamnet_mlp2_fwd_f32(e_sbf, g.tp, lp[6], lp[7], lp[8], lp[9], q.z1, q.z2, q.s, aux));
+            HK(hipEventRecord(reinterpret_cast<hipEvent_t>(aux_events[1 + k]), a));
+        }
+    }
     for (int64_t k = 0; k < n_layer; ++k) {
         // ---------------- global layer (layers/global_message_passing.py:33-56)
         const float* const* gp = gparams + k * NG;
@@ -228,7 +250,10 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         const float* planes[4] = {t.P, t.P + g.n * D, t.P + 2 * g.n * D, t.P + 3 * g.n * D};
         CK(pamnet_local_edge_fwd_f32(rbf_e, g.el, wq, ldq, lp[3], lp[5], planes, g.l_row, g.l_col, q.zji, q.zkj, q.q2,
                                      q.q3, t.mji, q.mnb, st));
-        CK(pamnet_mlp2_fwd_f32(e_sbf, g.tp, lp[6], lp[7], lp[8], lp[9], q.z1, q.z2, q.s, st));
+        if (forked)
+            HK(hipStreamWaitEvent(as_stream(st), reinterpret_cast<hipEvent_t>(aux_events[1 + k]), 0));
+        else
+            CK(pamnet_mlp2_fwd_f32(e_sbf, g.tp, lp[6], lp[7], lp[8], lp[9], q.z1, q.z2, q.s, st));
         CK(pamnet_segment_sum_f32(q.mt, t.mji, q.mnb, g.t_col, q.s, nullptr, nullptr, g.t_ptr, g.el, D, st));
         CK(pamnet_segment_sum_f32(q.x2, t.x1, q.mt, nullptr, q.q3, nullptr, nullptr, g.l_ptr, g.n, D, st));
         CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22], q.Z, q.R,
@@ -331,8 +356,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             flip ^= 1;
         }
         if (layer_done && layer_done[k]) {
-            const hipError_t e = hipEventRecord(reinterpret_cast<hipEvent_t>(layer_done[k]), as_stream(st));
-            if (e != hipSuccess) return (int)e;
+            HK(hipEventRecord(reinterpret_cast<hipEvent_t>(layer_done[k]), as_stream(st)));
         }
     }
     return PAMNET_OK;

@@ -9,6 +9,7 @@ Kernel count per layer pair (forward): 2 x node_pre, global_edge, local_edge, ml
 launches -- the reference issues ~150 for the same work.
 """
 import ctypes
+import os
 
 import torch
 
@@ -407,6 +408,25 @@ def _temp_arena(n_floats, dev):
     return t
 
 
+_AUX = {}
+AUX_FORK = os.environ.get('PAMNET_AUX_FWD', '0') != '0'      # measured: no gain at B=128 (host-side event cost, CU contention)
+
+
+def _aux_fork(dev, n_layer):
+    """(aux stream handle, event handle array) for the forward's x-independent branch; (None, None) when disabled."""
+    if not AUX_FORK:
+        return None, None
+    key = (dev, n_layer)
+    if key not in _AUX:
+        stream = torch.cuda.Stream(device=dev)
+        events = [torch.cuda.Event() for _ in range(n_layer + 1)]
+        for e in events:
+            e.record(torch.cuda.current_stream(dev))      # materialise the handles
+        _AUX[key] = (stream, events, _parr([int(e.cuda_event) for e in events]))
+    stream, _, arr = _AUX[key]
+    return stream.cuda_stream, arr
+
+
 def _graph_tables(graph):
     sizes = _iarr([graph.n, graph.glob.m, graph.loc.m, graph.tp.m])
     idx = _parr([graph.glob.ptr, graph.glob.row_of, graph.glob.col, graph.glob_T.ptr, graph.glob_T.perm,
@@ -415,14 +435,52 @@ def _graph_tables(graph):
     return sizes, idx
 
 
+class StackPlan(object):
+    """Parameter tables of a layer stack, built once per model: walking the nn.Module tree (~400 attribute / Sequential
+    lookups) and re-creating the pointer arrays cost ~0.5 ms of host time per step, comparable to enqueueing the kernels.
+    The pointer arrays are rebuilt only when a parameter (or, in direct-gradient mode, a .grad) has moved."""
+
+    def __init__(self, global_layers, local_layers):
+        self.gl = [global_params(l) for l in global_layers]
+        self.ll = [local_params(l) for l in local_layers]
+        self.L = len(self.gl)
+        self.gflat = [p for lay in self.gl for p in lay]
+        self.lflat = [p for lay in self.ll for p in lay]
+        self.flat = self.gflat + self.lflat
+        self._probe = [self.flat[0], self.flat[len(self.flat) // 2], self.flat[-1]]
+        self._pkey = self._gkey = None
+
+    def param_tables(self):
+        key = tuple(p.data_ptr() for p in self._probe)
+        if key != self._pkey:
+            self._gtab, self._ltab, self._pkey = _parr(self.gflat), _parr(self.lflat), key
+        return self._gtab, self._ltab
+
+    def direct(self):
+        """True when every parameter owns a preallocated contiguous .grad and DIRECT_GRAD is on."""
+        if not DIRECT_GRAD:
+            return False
+        grads = [p.grad for p in self._probe]
+        if any(g is None for g in grads):
+            return False
+        key = tuple(g.data_ptr() for g in grads)
+        if key != self._gkey:
+            if not all(getattr(p, 'grad', None) is not None and p.grad.is_contiguous() for p in self.flat):
+                return False
+            self._ggrad, self._lgrad = _parr([p.grad for p in self.gflat]), _parr([p.grad for p in self.lflat])
+            self._gkey = key
+        return True
+
+
 class _Stack(torch.autograd.Function):
     """The n_layer x (global, local) loop (models.py:196-204): x0, e_g, rbf_e, e_sbf -> outs [2L,N], atts [2L,N].
-    One C call forward, one backward (csrc/engine.hip)."""
+    One C call forward, one backward (csrc/engine.hip).  In direct-gradient mode the parameters are not autograd inputs
+    (their gradients are written straight into the flat buffer): ~400 fewer edges for the autograd engine to walk."""
 
     @staticmethod
-    def forward(ctx, x0, e_g, rbf_e, e_sbf, graph, gl, ll, *params):
+    def forward(ctx, x0, e_g, rbf_e, e_sbf, graph, plan, direct, *params):
         x0, e_g, rbf_e, e_sbf = x0.contiguous(), e_g.contiguous(), rbf_e.contiguous(), e_sbf.contiguous()
-        L = len(gl)
+        L = plan.L
         n = x0.size(0)
         sizes, idx = _graph_tables(graph)
         need = (ctypes.c_int64 * 2)()
@@ -431,12 +489,12 @@ class _Stack(torch.autograd.Function):
         saved = torch.empty(max(int(need[0]), 1), dtype=torch.float32, device=x0.device)
         temp = _temp_arena(int(need[1]), x0.device)
         outs, atts = _empty(2 * L, n, like=x0), _empty(2 * L, n, like=x0)
-        gtab = _parr([p for lay in gl for p in lay])
-        ltab = _parr([p for lay in ll for p in lay])
+        gtab, ltab = plan.param_tables()
+        aux, evs = _aux_fork(x0.device, L)
         lib.call('pamnet_stack_fwd_f32', sizes, idx, L, lib.ptr(x0), lib.ptr(e_g), lib.ptr(rbf_e), lib.ptr(e_sbf),
-                 gtab, ltab, lib.ptr(saved), lib.ptr(temp), lib.ptr(outs), lib.ptr(atts), lib.stream_of(x0))
+                 gtab, ltab, lib.ptr(saved), lib.ptr(temp), lib.ptr(outs), lib.ptr(atts), aux, evs, lib.stream_of(x0))
         ctx.save_for_backward(x0, e_g, rbf_e, e_sbf, saved)
-        ctx.graph, ctx.gl, ctx.ll = graph, gl, ll
+        ctx.graph, ctx.plan, ctx.direct, ctx.temp_floats = graph, plan, direct, int(need[1])
         ctx.mark_non_differentiable(saved)
         ctx.set_materialize_grads(False)       # else autograd zero-fills a gradient the size of `saved` every step
         return outs, atts, saved
@@ -444,37 +502,39 @@ class _Stack(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_outs, g_atts, _g_saved):
         x0, e_g, rbf_e, e_sbf, saved = ctx.saved_tensors
-        graph, gl, ll = ctx.graph, ctx.gl, ctx.ll
-        L = len(gl)
-        flat = [p for lay in gl for p in lay] + [p for lay in ll for p in lay]
-        direct, g = _grad_buffers(flat)
-        ng = sum(len(lay) for lay in gl)
+        graph, plan, direct = ctx.graph, ctx.plan, ctx.direct
+        L = plan.L
         sizes, idx = _graph_tables(graph)
-        need = (ctypes.c_int64 * 2)()
-        lib.call('pamnet_stack_workspace', x0.size(0), e_g.size(0), rbf_e.size(0), e_sbf.size(0), L,
-                 ctypes.addressof(need), ctypes.addressof(need) + 8)
-        temp = _temp_arena(int(need[1]), x0.device)
+        temp = _temp_arena(ctx.temp_floats, x0.device)
         d_x0, d_eg, d_rbf, d_sbf = (torch.empty_like(t) for t in (x0, e_g, rbf_e, e_sbf))
+        gtab, ltab = plan.param_tables()
         evs = None
-        if LAYER_EVENTS is not None and len(LAYER_EVENTS) == L and direct:
-            global EVENTS_RECORDED
-            evs = _parr([int(e.cuda_event) for e in LAYER_EVENTS])
-            EVENTS_RECORDED = True
+        if direct:
+            ggrad, lgrad, g = plan._ggrad, plan._lgrad, ()
+            if LAYER_EVENTS is not None and len(LAYER_EVENTS) == L:
+                global EVENTS_RECORDED
+                evs = _parr([int(e.cuda_event) for e in LAYER_EVENTS])
+                EVENTS_RECORDED = True
+        else:
+            g = [torch.empty_like(p) for p in plan.flat]
+            ggrad, lgrad = _parr(g[:len(plan.gflat)]), _parr(g[len(plan.gflat):])
         g_outs = torch.zeros(2 * L, x0.size(0), device=x0.device) if g_outs is None else g_outs.contiguous()
         g_atts = torch.zeros_like(g_outs) if g_atts is None else g_atts.contiguous()
         lib.call('pamnet_stack_bwd_f32', sizes, idx, L, lib.ptr(x0), lib.ptr(e_g), lib.ptr(rbf_e), lib.ptr(e_sbf),
-                 _parr([p for lay in gl for p in lay]), _parr([p for lay in ll for p in lay]), lib.ptr(saved),
-                 lib.ptr(temp), lib.ptr(g_outs), lib.ptr(g_atts), _parr(g[:ng]), _parr(g[ng:]), lib.ptr(d_x0),
-                 lib.ptr(d_eg), lib.ptr(d_rbf), lib.ptr(d_sbf), evs, lib.stream_of(x0))
-        return (d_x0, d_eg, d_rbf, d_sbf, None, None, None) + _ret(direct, g)
+                 gtab, ltab, lib.ptr(saved), lib.ptr(temp), lib.ptr(g_outs), lib.ptr(g_atts), ggrad, lgrad,
+                 lib.ptr(d_x0), lib.ptr(d_eg), lib.ptr(d_rbf), lib.ptr(d_sbf), evs, lib.stream_of(x0))
+        return (d_x0, d_eg, d_rbf, d_sbf, None, None, None) + tuple(g)
 
 
 def layer_stack(global_layers, local_layers, x0, e_g, rbf_e, e_sbf, graph):
     """Returns outs [2L,N], atts [2L,N] and the saved-activation arena (see stack_x_layers)."""
-    gl = [global_params(l) for l in global_layers]
-    ll = [local_params(l) for l in local_layers]
-    params = [p for lay in gl for p in lay] + [p for lay in ll for p in lay]
-    return _Stack.apply(x0, e_g, rbf_e, e_sbf, graph, gl, ll, *params)
+    plan = getattr(global_layers, '_pamnet_plan', None)
+    if plan is None or plan.L != len(global_layers):
+        plan = StackPlan(global_layers, local_layers)
+        global_layers._pamnet_plan = plan
+    if torch.is_grad_enabled() and plan.direct():
+        return _Stack.apply(x0, e_g, rbf_e, e_sbf, graph, plan, True)
+    return _Stack.apply(x0, e_g, rbf_e, e_sbf, graph, plan, False, *plan.flat)
 
 
 def stack_x_layers(saved, graph, n_layer):
