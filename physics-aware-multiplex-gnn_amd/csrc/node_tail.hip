@@ -24,6 +24,20 @@
 
 using namespace pamnet;
 
+#ifdef PAMNET_PHASE_PROBE
+// Development aid (tools/tail_probe.py): shader-clock timestamps of the middle workgroup, 4 per layer.
+__device__ long long pamnet_tail_probe[64];
+#define TPROBE(i)                                                                                      \
+    do {                                                                                               \
+        if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) pamnet_tail_probe[i] = clock64();          \
+    } while (0)
+extern "C" int pamnet_tail_probe_read(long long* host64) {
+    return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(pamnet_tail_probe), sizeof(long long) * 64);
+}
+#else
+#define TPROBE(i)
+#endif
+
 namespace {
 
 struct TailParams {
@@ -88,18 +102,25 @@ __device__ __forceinline__ f32x4 mma_strip(const float* __restrict__ As, const W
     return c0 + c1;
 }
 
-// Forward: 4 waves x 32 columns (float4 weight loads are cheap per byte, so fewer, wider waves win: 29 us vs 33 us).
+// Forward: 4 waves x 32 columns (float4 weight loads are cheap per byte, so fewer, wider waves win; an 8-wave x 16-column
+// version measured 35 us against 31 us: two waves per SIMD only take turns on the matrix pipe and then idle at the
+// barrier -- tools/tail_probe.py).
 __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restrict__ x2,
                                                            const float* __restrict__ res_x, int64_t n, TailParams p,
                                                            float* __restrict__ Z, float* __restrict__ R,
                                                            float* __restrict__ x_out, float* __restrict__ out,
                                                            float* __restrict__ att) {
-    __shared__ __attribute__((aligned(16))) float lds[5 * SLOT];
+    // 5 working slots + 10 pre-activation tiles + 3 residual taps: everything the backward needs is parked in LDS and
+    // written out once, as coalesced 512-byte rows, after the chain -- no global store (and no wait for its
+    // acknowledgement, vmcnt retires in order) sits between one layer's MFMAs and the next layer's weight slice.
+    __shared__ __attribute__((aligned(16))) float lds[18 * SLOT];
     float* X0 = lds;
     float* RX = lds + SLOT;
     float* A = lds + 2 * SLOT;
     float* B = lds + 3 * SLOT;
     float* C = lds + 4 * SLOT;
+    float* ZL = lds + 5 * SLOT;               // [10] z_k tiles
+    float* TL = lds + 15 * SLOT;              // [3]  r1, r2, x_out tiles
     const int64_t row0 = (int64_t)blockIdx.x * BMN;
     const int64_t plane = n * DIM;
     const int lane = threadIdx.x & 63, r16 = lane & 15, kg = lane >> 4;
@@ -114,15 +135,17 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
     });
     __syncthreads();
 
-    // layer k: in -> dst = SiLU(W_k in + b_k) (+ add1 + add2); z_k saved; optional save of the result (residual taps)
-    auto layer = [&](const float* in, float* dst, int k, const float* add1, const float* add2, float* save,
+    // layer k: in -> dst = SiLU(W_k in + b_k) (+ add1 + add2); z_k parked; optional tap of the result
+    auto layer = [&](const float* in, float* dst, int k, const float* add1, const float* add2, float* tap,
                      const float* Wnext) {
+        TPROBE(4 * k);
         const Bias2 bv = load_bias2(p.b[k], wc);               // before the prefetch (in-order vmcnt)
         f32x4 acc[1][2];
         acc_zero<1>(acc);
         mma_tile_frag<1>(in, wf, acc);
+        TPROBE(4 * k + 1);
         if (Wnext) load_wfrag<false>(wf, Wnext, DIM, wc);
-        float* zk = Z + (int64_t)k * plane;
+        float* zk = ZL + k * SLOT;
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) {
             const int c = wc + 16 * n2 + r16;
@@ -134,26 +157,36 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
                 if (add1) a += add1[rw * LDT + c];
                 if (add2) a += add2[rw * LDT + c];
                 dst[rw * LDT + c] = a;
-                const int64_t g = row0 + rw;
-                if (g < n) {
-                    zk[g * DIM + c] = z;
-                    if (save) save[g * DIM + c] = a;
-                }
+                zk[rw * LDT + c] = z;
+                if (tap) tap[rw * LDT + c] = a;
             }
         }
+        TPROBE(4 * k + 2);
         __syncthreads();
+        TPROBE(4 * k + 3);
     };
 
     layer(X0, A, 0, nullptr, nullptr, nullptr, p.W[1]);        // h0 -> A
     layer(A, B, 1, nullptr, nullptr, nullptr, p.W[2]);         // a1 -> B
-    layer(B, C, 2, A, RX, R, p.W[3]);                          // r1 -> C   (+ h0 + res_x)
+    layer(B, C, 2, A, RX, TL, p.W[3]);                         // r1 -> C   (+ h0 + res_x)
     layer(C, A, 3, nullptr, nullptr, nullptr, p.W[4]);         // a3 -> A
-    layer(A, B, 4, C, nullptr, R + plane, p.W[5]);             // r2 -> B   (+ r1)
+    layer(A, B, 4, C, nullptr, TL + SLOT, p.W[5]);             // r2 -> B   (+ r1)
     layer(B, A, 5, nullptr, nullptr, nullptr, p.W[6]);         // a5 -> A
-    layer(A, C, 6, B, nullptr, x_out, p.W[7]);                 // r3 -> C   (+ r2)  = x_out
+    layer(A, C, 6, B, nullptr, TL + 2 * SLOT, p.W[7]);         // r3 -> C   (+ r2)  = x_out
     layer(C, A, 7, nullptr, nullptr, nullptr, p.W[8]);         // o1 -> A
     layer(A, B, 8, nullptr, nullptr, nullptr, p.W[9]);         // o2 -> B
     layer(B, A, 9, nullptr, nullptr, nullptr, nullptr);        // o3 -> A
+
+    // park -> memory: Z[10][n][128], R[2][n][128], x_out[n][128]
+    sweep_rows<BMN>([&](int r, int c4) {
+        const int64_t g = row0 + r;
+        if (g >= n) return;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) stg4(Z + (int64_t)k * plane, g, DIM, c4, lds4(ZL + k * SLOT, r, c4));
+        stg4(R, g, DIM, c4, lds4(TL, r, c4));
+        stg4(R + plane, g, DIM, c4, lds4(TL + SLOT, r, c4));
+        stg4(x_out, g, DIM, c4, lds4(TL + 2 * SLOT, r, c4));
+    });
 
     // heads: 16 lanes per row, 8 columns each, butterfly over the 16-lane group
     {
@@ -186,11 +219,16 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
                                                             const float* __restrict__ Z, float* __restrict__ dZ,
                                                             float* __restrict__ d_x2, float* __restrict__ d_resx,
                                                             float* __restrict__ head_partial /* [grid][257] */) {
-    __shared__ __attribute__((aligned(16))) float lds[3 * SLOT + 16 * 256 + 16];
+    // All ten pre-activation tiles are fetched up front (one burst of coalesced rows) and every dz_k overwrites its z_k
+    // in place; d x2 / d res_x are parked too and the tiles leave as coalesced rows after the chain: like the forward,
+    // the per-layer critical path holds no global access except the next weight slice.
+    __shared__ __attribute__((aligned(16))) float lds[14 * SLOT + 16 * 256 + 16];
     float* D0 = lds;                  // dz ping
     float* D1 = lds + SLOT;           // dz pong
     float* K = lds + 2 * SLOT;        // residual gradient kept across a Res block
-    float* red = lds + 3 * SLOT;      // [16][256] head partials (+16 for d b_out)
+    float* EX = lds + 3 * SLOT;       // d res_x
+    float* ZL = lds + 4 * SLOT;       // [10] z_k, then dz_k
+    float* red = lds + 14 * SLOT;     // [16][256] head partials (+16 for d b_out)
     const int64_t row0 = (int64_t)blockIdx.x * BMN;
     const int64_t plane = n * DIM;
     const Frag fr;
@@ -198,36 +236,37 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
 
     WFrag1 wf;
     load_wfrag1<true>(wf, p.W[9], fr.wc);
+    const int sc4 = threadIdx.x & 31, sr = threadIdx.x >> 5;          // sweep coordinates: 512 threads = 16 rows x 32 float4
+    const int64_t sg = row0 + sr;
+    {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) st_lds4(ZL + k * SLOT, sr, sc4, ldg4z(Z + (int64_t)k * plane, sg, n, DIM, sc4));
+        st_lds4(K, sr, sc4, d_xout ? ldg4z(d_xout, sg, n, DIM, sc4) : f4zero());
+    }
+    __syncthreads();
 
-    // pre-activation fragment of layer k (4 scalar loads per lane, issued early)
     auto load_z = [&](int k) {
         f32x4 z;
-        const float* zk = Z + (int64_t)k * plane;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t g = row0 + fr.row(r);
-            z[r] = zk[(g < n ? g : 0) * DIM + c];
-        }
+        for (int r = 0; r < 4; ++r) z[r] = ZL[k * SLOT + fr.row(r) * LDT + c];
         return z;
     };
 
     // head-vector partials: sum_rows d_out * o3, sum_rows d_att * o3, sum_rows d_out  (o3 = SiLU(z9))
     {
-        const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;      // one row per thread
         float4 so = f4zero(), sa = f4zero();
         float sb = 0.f;
-        const int64_t g = row0 + r0;
-        if (g < n) {
-            const float4 o3 = f4silu(ldg4(Z + 9 * plane, g, DIM, c4));
-            const float go = d_out[g], ga = d_att[g];
+        if (sg < n) {
+            const float4 o3 = f4silu(lds4(ZL + 9 * SLOT, sr, sc4));
+            const float go = d_out[sg], ga = d_att[sg];
             so = make_float4(go * o3.x, go * o3.y, go * o3.z, go * o3.w);
             sa = make_float4(ga * o3.x, ga * o3.y, ga * o3.z, ga * o3.w);
             sb = go;
         }
-        float* mine = red + r0 * 256;
-        *reinterpret_cast<float4*>(mine + 4 * c4) = so;
-        *reinterpret_cast<float4*>(mine + 128 + 4 * c4) = sa;
-        if (c4 == 0) red[16 * 256 + r0] = sb;
+        float* mine = red + sr * 256;
+        *reinterpret_cast<float4*>(mine + 4 * sc4) = so;
+        *reinterpret_cast<float4*>(mine + 128 + 4 * sc4) = sa;
+        if (sc4 == 0) red[16 * 256 + sr] = sb;
         __syncthreads();
         if (threadIdx.x < 256) {
             float tot = 0.f;
@@ -242,7 +281,7 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
         }
     }
 
-    // dz9 = (d_out * w_out + d_att * w_att) * SiLU'(z9) -> D0, dZ_9 ; K = d x_out (or 0)
+    // dz9 = (d_out * w_out + d_att * w_att) * SiLU'(z9) -> D0 and in place of z9
     {
         const f32x4 z9 = load_z(9);
         const float wo = p.w_out[c], wa = p.w_att[c];
@@ -250,23 +289,18 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
         for (int r = 0; r < 4; ++r) {
             const int rw = fr.row(r);
             const int64_t g = row0 + rw;
-            float dz = 0.f, kx = 0.f;
-            if (g < n) {
-                dz = (d_out[g] * wo + d_att[g] * wa) * dsilu(z9[r]);
-                dZ[9 * plane + g * DIM + c] = dz;
-                if (d_xout) kx = d_xout[g * DIM + c];
-            }
+            const float dz = (g < n) ? (d_out[g] * wo + d_att[g] * wa) * dsilu(z9[r]) : 0.f;
             D0[rw * LDT + c] = dz;
-            K[rw * LDT + c] = kx;
+            ZL[9 * SLOT + rw * LDT + c] = dz;
         }
         __syncthreads();
     }
 
     // One backward step: v = dz_k * W_k (+ K) ; optionally K <- v, extra <- v ; then dz_{k-1} = v * SiLU'(z_{k-1}).
-    // k == 0 ends the chain: v = d x2.
+    // k == 0 ends the chain: v = d x2 (left in dst).
     auto back = [&](const float* in, float* dst, int k, bool add_k, bool keep_k, float* extra) {
         f32x4 zn = {0.f, 0.f, 0.f, 0.f};
-        if (k > 0) zn = load_z(k - 1);                           // older than the weight prefetch (in-order vmcnt)
+        if (k > 0) zn = load_z(k - 1);
         const f32x4 acc = mma_strip(in, wf);
         if (k > 0) load_wfrag1<true>(wf, p.W[k - 1], fr.wc);
 #pragma unroll
@@ -276,15 +310,13 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
             float v = acc[r];
             if (add_k) v += K[rw * LDT + c];
             if (keep_k) K[rw * LDT + c] = v;
+            if (extra) extra[rw * LDT + c] = v;
             if (k == 0) {
-                if (g < n) d_x2[g * DIM + c] = v;
+                dst[rw * LDT + c] = v;
             } else {
                 const float dz = (g < n) ? v * dsilu(zn[r]) : 0.f;
                 dst[rw * LDT + c] = dz;
-                if (g < n) {
-                    dZ[(int64_t)(k - 1) * plane + g * DIM + c] = dz;
-                    if (extra) extra[g * DIM + c] = v;
-                }
+                ZL[(k - 1) * SLOT + rw * LDT + c] = dz;
             }
         }
         __syncthreads();
@@ -296,10 +328,17 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
     back(D1, D0, 6, false, false, nullptr);        // d a5          -> dz5
     back(D0, D1, 5, true, true, nullptr);          // d r2 = . + d r3 (kept)      -> dz4
     back(D1, D0, 4, false, false, nullptr);        // d a3          -> dz3
-    back(D0, D1, 3, true, true, d_resx);           // d r1 = . + d r2 (kept, = d res_x) -> dz2
+    back(D0, D1, 3, true, true, EX);               // d r1 = . + d r2 (kept, = d res_x) -> dz2
     back(D1, D0, 2, false, false, nullptr);        // d a1          -> dz1
     back(D0, D1, 1, true, false, nullptr);         // d h0 = . + d r1             -> dz0
-    back(D1, D0, 0, false, false, nullptr);        // d x2
+    back(D1, D0, 0, false, false, nullptr);        // d x2 -> D0
+
+    if (sg < n) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) stg4(dZ + (int64_t)k * plane, sg, DIM, sc4, lds4(ZL + k * SLOT, sr, sc4));
+        stg4(d_x2, sg, DIM, sc4, lds4(D0, sr, sc4));
+        stg4(d_resx, sg, DIM, sc4, lds4(EX, sr, sc4));
+    }
 }
 
 // columns: [0,128) d w_out, [128,256) d w_att, [256] d b_out
