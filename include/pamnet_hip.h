@@ -50,6 +50,14 @@ int pamnet_segment_sum_f32(float* out, const float* init, const float* A, const 
 int pamnet_gather_mul_f32(float* out, const float* A, const int32_t* ia, const float* B, const int32_t* ib,
                           int64_t m, int64_t d, pamnet_stream_t stream);
 
+/* Batched forms used by the layer backward (d = 128): up to 4 plain segment sums over the same number of rows in one
+ * launch (host arrays of device pointers; perm[j] nullable), and one gather feeding two products
+ * (out1 = A[ia]*B1, out2 = A[ia]*B2: d m_t and d q3 of layers/local_message_passing.py:53). */
+int pamnet_segment_sum_multi_f32(int64_t njobs, float* const* out, const float* const* A, const int32_t* const* perm,
+                                 const int32_t* const* ptr, int64_t rows, int64_t d, pamnet_stream_t stream);
+int pamnet_gather_mul2_f32(float* out1, float* out2, const float* A, const int32_t* ia, const float* B1,
+                           const float* B2, int64_t m, int64_t d, pamnet_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Index plumbing for graph construction (torch_sparse.SparseTensor CSR build: models.py:71-73, 267-269)
  * ------------------------------------------------------------------------------------------------------------------ */
@@ -145,7 +153,10 @@ int pamnet_fuse_pool_bwd_f32(const float* outs, const float* atts, int64_t n_lay
  *   Saves Z[10][n][128] (pre-activations) and R[2][n][128] (r1, r2) for the backward.
  * node_pre: x1 = SiLU(mlp_x1 x) and the node-level halves P = x1 * Wp_b^T (b < nblk <= 4) of the split message MLPs
  *   (mlp_m / mlp_m_ji / mlp_m_kj on [x_i | x_j | e]: layers/global_message_passing.py:52-56, local...:46-48).
- * wgrad_batched: dW_j = dZ_j^T * A_j (A_j optionally SiLU'd on load), db_j = colsum(dZ_j) for up to 24 jobs.
+ * wgrad_batched: dW_j = dZ_j^T * A_j (A_j optionally SiLU'd on load), db_j = colsum(dZ_j) for up to 24 jobs, in two
+ *   launches (split-K partial tiles, then one fixed-order reduction).  The reduction launch can also finish a node_tail
+ *   backward: pass that call's head_partial / workgroup count (= ceil(n/16)) and the three head-gradient outputs here and
+ *   give node_tail_bwd null d_wout/d_watt/d_bout (then it launches no reduction of its own).
  * ------------------------------------------------------------------------------------------------------------------ */
 int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int64_t n, const float* const* weights,
                              const float* const* biases, const float* w_out, const float* b_out, const float* w_att,
@@ -162,7 +173,8 @@ int pamnet_node_pre_bwd_f32(const float* dP, const float* dx1_direct, const floa
 int pamnet_wgrad_scratch_floats(int64_t njobs, const int64_t* rows, int64_t* floats);
 int pamnet_wgrad_batched_f32(int64_t njobs, const float* const* dZ, const int64_t* ld_dz, const float* const* A,
                              const int64_t* ld_a, const int32_t* a_mode, const int64_t* rows, float* const* dW,
-                             const int64_t* ld_dw, float* const* db, float* partial, pamnet_stream_t stream);
+                             const int64_t* ld_dw, float* const* db, float* partial, const float* head_partial,
+                             int64_t head_blocks, float* d_wout, float* d_watt, float* d_bout, pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Fused edge-level kernels (dim = 128), fp32 MFMA.  P planes are node_pre outputs ([N][128] each).

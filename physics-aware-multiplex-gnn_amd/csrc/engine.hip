@@ -162,8 +162,11 @@ inline void tail_jobs(Jobs& j, const Graph& g, const float* dZ, const float* x2,
     for (int k = 0; k < 10; ++k) j.add(dZ + k * pl, src[k], mode[k], g.n, gt[k], D, gt[10 + k]);
 }
 
-inline int run_jobs(Jobs& j, float* partial, pamnet_stream_t st) {
-    return pamnet_wgrad_batched_f32(j.n, j.dZ, j.ld_dz, j.A, j.ld_a, j.mode, j.rows, j.dW, j.ld_dw, j.db, partial, st);
+// all weight gradients of a layer + the head-vector gradients of its node chain (partials left by node_tail_bwd)
+inline int run_jobs(Jobs& j, float* partial, const Graph& g, const float* head, float* d_wout, float* d_watt,
+                    float* d_bout, pamnet_stream_t st) {
+    return pamnet_wgrad_batched_f32(j.n, j.dZ, j.ld_dz, j.A, j.ld_a, j.mode, j.rows, j.dW, j.ld_dw, j.db, partial, head,
+                                    (g.n + 15) / 16, d_wout, d_watt, d_bout, st);
 }
 
 }  // namespace
@@ -292,10 +295,10 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             float* const* lg = lgrads + k * NL;
             const float* x_in = s.xout;           // input of the local layer = output of this pair's global layer
             CK(pamnet_node_tail_bwd_f32(d_xout, d_outs + (2 * k + 1) * g.n, d_atts + (2 * k + 1) * g.n, g.n, lp + LT,
-                                        lp[LT + 20], lp[LT + 22], q.Z, t.dZ, t.dx2, t.dresx, t.head, lg[LT + 20],
-                                        lg[LT + 22], lg[LT + 21], st));
-            CK(pamnet_gather_mul_f32(t.dmt, t.dx2, g.l_row, q.q3, nullptr, g.el, D, st));       // d m_t = d x2[i] * q3
-            CK(pamnet_gather_mul_f32(t.dq3, t.dx2, g.l_row, q.mt, nullptr, g.el, D, st));       // d q3  = d x2[i] * m_t
+                                        lp[LT + 20], lp[LT + 22], q.Z, t.dZ, t.dx2, t.dresx, t.head, nullptr, nullptr,
+                                        nullptr, st));
+            // d m_t = d x2[i] * q3 ,  d q3 = d x2[i] * m_t
+            CK(pamnet_gather_mul2_f32(t.dmt, t.dq3, t.dx2, g.l_row, q.q3, q.mt, g.el, D, st));
             CK(pamnet_gather_mul_f32(t.ds, q.mnb, g.t_col, t.dmt, g.t_row, g.tp, D, st));       // d s   = m_nb[idx] * d m_t[e]
             CK(pamnet_segment_sum_f32(t.dmnb, nullptr, q.s, nullptr, t.dmt, g.t_row, g.tT_perm, g.tT_ptr, g.el, D, st));
             CK(pamnet_mlp2_bwd_f32(t.ds, g.tp, q.z1, q.z2, lp[6], lp[8], t.dz1, t.dz2, d_sbf, acc, st));
@@ -304,10 +307,13 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             CK(pamnet_local_edge_bwd_f32(t.dmt, t.dmnb, t.dq3, g.el, q.zji, q.zkj, q.q2, wq, ldq, t.dzji, t.dzkj, t.dq2,
                                          d_rbf, acc, st));
             const int64_t pl = g.n * D;
-            CK(pamnet_segment_sum_f32(t.dP, nullptr, t.dzji, nullptr, nullptr, nullptr, nullptr, g.l_ptr, g.n, D, st));
-            CK(pamnet_segment_sum_f32(t.dP + pl, nullptr, t.dzkj, nullptr, nullptr, nullptr, nullptr, g.l_ptr, g.n, D, st));
-            CK(pamnet_segment_sum_f32(t.dP + 2 * pl, nullptr, t.dzji, nullptr, nullptr, nullptr, g.lT_perm, g.lT_ptr, g.n, D, st));
-            CK(pamnet_segment_sum_f32(t.dP + 3 * pl, nullptr, t.dzkj, nullptr, nullptr, nullptr, g.lT_perm, g.lT_ptr, g.n, D, st));
+            {
+                float* so[4] = {t.dP, t.dP + pl, t.dP + 2 * pl, t.dP + 3 * pl};
+                const float* sa[4] = {t.dzji, t.dzkj, t.dzji, t.dzkj};
+                const int32_t* sp[4] = {nullptr, nullptr, g.lT_perm, g.lT_perm};
+                const int32_t* sr[4] = {g.l_ptr, g.l_ptr, g.lT_ptr, g.lT_ptr};
+                CK(pamnet_segment_sum_multi_f32(4, so, sa, sp, sr, g.n, D, st));
+            }
             const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
             float* dx = dx_bufs[flip];
             CK(pamnet_node_pre_bwd_f32(t.dP, t.dx2, t.dresx, g.n, lp[0], wpl, 3 * D, 4, q.Zx1, t.dZx1, dx, st));
@@ -324,7 +330,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             j.add(t.dq3, rbf_e, 0, g.el, lg[11], D, nullptr);
             j.add(t.dz2, q.z1, 1, g.tp, lg[8], D, lg[9]);
             j.add(t.dz1, e_sbf, 0, g.tp, lg[6], D, lg[7]);
-            CK(run_jobs(j, t.partial, st));
+            CK(run_jobs(j, t.partial, g, t.head, lg[LT + 20], lg[LT + 22], lg[LT + 21], st));
             d_xout = dx;
             flip ^= 1;
         }
@@ -334,13 +340,18 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             float* const* gg = ggrads + k * NG;
             const float* x_in = (k == 0) ? x0 : carve_local(const_cast<float*>(saved) + (k - 1) * (gs + ls) + gs, g).xout;
             CK(pamnet_node_tail_bwd_f32(d_xout, d_outs + (2 * k) * g.n, d_atts + (2 * k) * g.n, g.n, gp + GT,
-                                        gp[GT + 20], gp[GT + 22], s.Z, t.dZ, t.dx2, t.dresx, t.head, gg[GT + 20],
-                                        gg[GT + 22], gg[GT + 21], st));
+                                        gp[GT + 20], gp[GT + 22], s.Z, t.dZ, t.dx2, t.dresx, t.head, nullptr, nullptr,
+                                        nullptr, st));
             CK(pamnet_global_edge_bwd_f32(t.dx2, g.g_row, g.eg, s.z, s.ea, gp[2] + 2 * D, 3 * D, gp[4], D, t.dz, t.dea,
                                           d_eg, acc, st));
             const int64_t pl = g.n * D;
-            CK(pamnet_segment_sum_f32(t.dP, nullptr, t.dz, nullptr, nullptr, nullptr, nullptr, g.g_ptr, g.n, D, st));
-            CK(pamnet_segment_sum_f32(t.dP + pl, nullptr, t.dz, nullptr, nullptr, nullptr, g.gT_perm, g.gT_ptr, g.n, D, st));
+            {
+                float* so[2] = {t.dP, t.dP + pl};
+                const float* sa[2] = {t.dz, t.dz};
+                const int32_t* sp[2] = {nullptr, g.gT_perm};
+                const int32_t* sr[2] = {g.g_ptr, g.gT_ptr};
+                CK(pamnet_segment_sum_multi_f32(2, so, sa, sp, sr, g.n, D, st));
+            }
             const float* wpg[2] = {gp[2], gp[2] + D};
             float* dx = (k == 0) ? d_x0 : dx_bufs[flip];
             CK(pamnet_node_pre_bwd_f32(t.dP, t.dx2, t.dresx, g.n, gp[0], wpg, 3 * D, 2, s.Zx1, t.dZx1, dx, st));
@@ -351,7 +362,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             j.add(t.dP + pl, s.Zx1, 1, g.n, gg[2] + D, 3 * D, nullptr);
             j.add(t.dz, e_g, 0, g.eg, gg[2] + 2 * D, 3 * D, gg[3]);
             j.add(t.dea, e_g, 0, g.eg, gg[4], D, nullptr);
-            CK(run_jobs(j, t.partial, st));
+            CK(run_jobs(j, t.partial, g, t.head, gg[GT + 20], gg[GT + 22], gg[GT + 21], st));
             d_xout = dx;
             flip ^= 1;
         }

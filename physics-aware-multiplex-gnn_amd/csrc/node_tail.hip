@@ -402,15 +402,18 @@ extern "C" int pamnet_node_tail_bwd_f32(const float* d_xout, const float* d_out,
                                         float* d_wout, float* d_watt, float* d_bout, pamnet_stream_t stream) {
     if (n < 0) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
-    if (!d_out || !d_att || !weights || !w_out || !w_att || !Z || !dZ || !d_x2 || !d_resx || !head_partial || !d_wout ||
-        !d_watt || !d_bout)
+    if (!d_out || !d_att || !weights || !w_out || !w_att || !Z || !dZ || !d_x2 || !d_resx || !head_partial)
         return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
     const unsigned grid = (unsigned)ceil_div(n, BMN);
     hipLaunchKernelGGL(node_tail_bwd_kernel, dim3(grid), dim3(TWG), 0, st, d_xout, d_out, d_att, n,
                        make_tail(weights, nullptr, w_out, nullptr, w_att), Z, dZ, d_x2, d_resx, head_partial);
     PAMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(head_reduce_kernel, dim3(17), dim3(WG), 0, st, head_partial, (int)grid, d_wout, d_watt, d_bout);
-    PAMNET_LAUNCH_CHECK();
+    if (d_wout || d_watt || d_bout) {      // all null: the caller reduces head_partial itself (pamnet_wgrad_batched_f32)
+        if (!d_wout || !d_watt || !d_bout) return PAMNET_ENULL;
+        hipLaunchKernelGGL(head_reduce_kernel, dim3(17), dim3(WG), 0, st, head_partial, (int)grid, d_wout, d_watt,
+                           d_bout);
+        PAMNET_LAUNCH_CHECK();
+    }
     return PAMNET_OK;
 }

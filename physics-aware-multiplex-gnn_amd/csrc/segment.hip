@@ -199,7 +199,114 @@ int launch_segment_sum(float* out, const float* init, const float* A, const int3
     return PAMNET_OK;
 }
 
+// Up to 4 plain segment sums (d = 128) over the same number of output rows in one launch (blockIdx.y = job): the
+// backward of a layer reduces the same edge gradients by target and by source (transposed CSR) into node planes --
+// 2 (global) / 4 (local) launches become one.
+struct MultiSeg {
+    float4* out[4];
+    const float4* A[4];
+    const int32_t* perm[4];     // nullable per job
+    const int32_t* ptr[4];
+};
+__global__ __launch_bounds__(256) void segment_sum_multi_kernel(MultiSeg js, int64_t rows) {
+    constexpr int LPR = 32, SPLIT = 4, SLOTS = 8, RPB = 2;
+    __shared__ float4 red[SLOTS][LPR];
+    float4* __restrict__ out = js.out[blockIdx.y];
+    const float4* __restrict__ A = js.A[blockIdx.y];
+    const int32_t* __restrict__ perm = js.perm[blockIdx.y];
+    const int32_t* __restrict__ ptr = js.ptr[blockIdx.y];
+    const int c = threadIdx.x % LPR;
+    const int slot = threadIdx.x / LPR;
+    const int part = slot % SPLIT, rsub = slot / SPLIT;
+    for (int64_t r0 = (int64_t)blockIdx.x * RPB; r0 < rows; r0 += (int64_t)gridDim.x * RPB) {
+        const int64_t r = r0 + rsub;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+        if (r < rows) {
+            const int64_t beg = ptr[r], end = ptr[r + 1];
+            const int64_t per = (end - beg + SPLIT - 1) / SPLIT;
+            int64_t q = beg + part * per;
+            const int64_t stop = q + per < end ? q + per : end;
+            if (perm) {
+                for (; q + 4 <= stop; q += 4) {
+                    const int64_t k0 = perm[q], k1 = perm[q + 1], k2 = perm[q + 2], k3 = perm[q + 3];
+                    acc4(s0, A[k0 * LPR + c]); acc4(s1, A[k1 * LPR + c]); acc4(s2, A[k2 * LPR + c]); acc4(s3, A[k3 * LPR + c]);
+                }
+                for (; q < stop; ++q) acc4(s0, A[(int64_t)perm[q] * LPR + c]);
+            } else {
+                for (; q + 4 <= stop; q += 4) {
+                    acc4(s0, A[q * LPR + c]); acc4(s1, A[(q + 1) * LPR + c]); acc4(s2, A[(q + 2) * LPR + c]); acc4(s3, A[(q + 3) * LPR + c]);
+                }
+                for (; q < stop; ++q) acc4(s0, A[q * LPR + c]);
+            }
+            acc4(s0, s1); acc4(s2, s3); acc4(s0, s2);
+        }
+        red[slot][c] = s0;
+        __syncthreads();
+        if (part == 0 && r < rows) {
+            float4 t = red[rsub * SPLIT][c];
+#pragma unroll
+            for (int p = 1; p < SPLIT; ++p) acc4(t, red[rsub * SPLIT + p][c]);
+            out[r * LPR + c] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// out1 = A[ia] * B1, out2 = A[ia] * B2 (one gather of A feeding two products), d = 128
+__global__ __launch_bounds__(256) void gather_mul2_kernel(float4* __restrict__ out1, float4* __restrict__ out2,
+                                                          const float4* __restrict__ A, const int32_t* __restrict__ ia,
+                                                          const float4* __restrict__ B1, const float4* __restrict__ B2,
+                                                          int64_t m) {
+    const int64_t total = m * 32;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = t >> 5;
+        const int c = (int)(t & 31);
+        const float4 a = A[(int64_t)ia[k] * 32 + c], b1 = B1[t], b2 = B2[t];
+        out1[t] = make_float4(a.x * b1.x, a.y * b1.y, a.z * b1.z, a.w * b1.w);
+        out2[t] = make_float4(a.x * b2.x, a.y * b2.y, a.z * b2.z, a.w * b2.w);
+    }
+}
+
 }  // namespace
+
+// njobs <= 4 plain segment sums out_j[r,:] = sum_{q in [ptr_j[r], ptr_j[r+1])} A_j[perm_j ? perm_j[q] : q, :], d = 128.
+// Summation order inside a row: four contiguous quarters of the segment, added in order (deterministic).
+extern "C" int pamnet_segment_sum_multi_f32(int64_t njobs, float* const* out, const float* const* A,
+                                            const int32_t* const* perm, const int32_t* const* ptr, int64_t rows,
+                                            int64_t d, pamnet_stream_t stream) {
+    if (njobs < 1 || njobs > 4 || rows < 0 || d != 128) return PAMNET_EINVAL;
+    if (rows == 0) return PAMNET_OK;
+    if (!out || !A || !perm || !ptr) return PAMNET_ENULL;
+    MultiSeg js;
+    for (int j = 0; j < 4; ++j) {
+        const int s = j < njobs ? j : 0;
+        if (!out[s] || !ptr[s]) return PAMNET_ENULL;
+        js.out[j] = (float4*)out[s];
+        js.A[j] = (const float4*)A[s];
+        js.perm[j] = perm[s];
+        js.ptr[j] = ptr[s];
+    }
+    int64_t grid = ceil_div(rows, 2);
+    if (grid > 256 * 32) grid = 256 * 32;
+    hipLaunchKernelGGL(segment_sum_multi_kernel, dim3((unsigned)grid, (unsigned)njobs), dim3(256), 0, as_stream(stream),
+                       js, rows);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+// out1[k,:] = A[ia[k],:] * B1[k,:],  out2[k,:] = A[ia[k],:] * B2[k,:]   (d = 128)
+extern "C" int pamnet_gather_mul2_f32(float* out1, float* out2, const float* A, const int32_t* ia, const float* B1,
+                                      const float* B2, int64_t m, int64_t d, pamnet_stream_t stream) {
+    if (m < 0 || d != 128) return PAMNET_EINVAL;
+    if (m == 0) return PAMNET_OK;
+    if (!out1 || !out2 || !A || !ia || !B1 || !B2) return PAMNET_ENULL;
+    int64_t grid = ceil_div(m * 32, 256);
+    if (grid > 256 * 64) grid = 256 * 64;
+    hipLaunchKernelGGL(gather_mul2_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), (float4*)out1,
+                       (float4*)out2, (const float4*)A, ia, (const float4*)B1, (const float4*)B2, m);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
 
 extern "C" int pamnet_segment_sum_f32(float* out, const float* init, const float* A, const int32_t* ia,
                                       const float* B, const int32_t* ib, const int32_t* perm, const int32_t* ptr,

@@ -15,6 +15,20 @@
 
 using namespace pamnet;
 
+#ifdef PAMNET_PHASE_PROBE
+// Development aid (tools/wgrad_probe.py): shader-clock timestamps of one workgroup, 4 per 64-row iteration.
+__device__ long long pamnet_wgrad_probe[64];
+#define WPROBE(i)                                                                                        \
+    do {                                                                                                 \
+        if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0 && (i) < 64) pamnet_wgrad_probe[i] = clock64(); \
+    } while (0)
+extern "C" int pamnet_wgrad_probe_read(long long* host64) {
+    return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(pamnet_wgrad_probe), sizeof(long long) * 64);
+}
+#else
+#define WPROBE(i)
+#endif
+
 namespace {
 
 constexpr int MAXJ = 24;
@@ -98,7 +112,9 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, float* __restri
         }
     };
     if (beg < end) fetch(beg);
-    for (int64_t r0 = beg; r0 < end; r0 += RB) {
+    int it = 0;
+    for (int64_t r0 = beg; r0 < end; r0 += RB, ++it) {
+        WPROBE(4 * it);
 #pragma unroll
         for (int i = 0; i < RB / 8; ++i) {
             const int r = rr + 8 * i;
@@ -108,6 +124,7 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, float* __restri
             *reinterpret_cast<float4*>(As + r * LDW + 4 * c4) = a;
         }
         __syncthreads();
+        WPROBE(4 * it + 1);
         if (r0 + RB < end) fetch(r0 + RB);
         if (want_bias) {
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -135,8 +152,11 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, float* __restri
                 for (int b = 0; b < 4; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a], ab[b], acc[a][b], 0, 0, 0);
         }
+        WPROBE(4 * it + 2);
         __syncthreads();
+        WPROBE(4 * it + 3);
     }
+    WPROBE(4 * it);
     // partial[slot][128*128 + 2*128]: the tile, then the two row-half bias partials
     // The accumulator layout (4 rows x 16 columns per store) would hit memory as 64-byte fragments; transpose through
     // LDS (the staging buffers are free now: 128 x 132 floats fit) and write the tile as coalesced 512-byte rows.
@@ -157,49 +177,72 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, float* __restri
         *reinterpret_cast<float4*>(out + row * DIM + 4 * c4) = *reinterpret_cast<const float4*>(T + row * LDT + 4 * c4);
     }
     out[DIM * DIM + threadIdx.x] = (float)colsum;
+    WPROBE(4 * it + 1);
 }
 
-// Fixed-order two-level sum of a job's slots.  A block owns 64 consecutive tile elements (16 float4 columns) and
-// splits the slots over 16 groups (group g takes slots s0+g, s0+g+16, ...), then adds the 16 group sums in order.
-__global__ __launch_bounds__(WG) void wgrad_reduce_kernel(WBatch batch, const float* __restrict__ partial) {
+// Second pass, ONE launch per batch (grid 258 x (njobs + 1)), every sum in a fixed order (deterministic):
+//   x <  256, y < njobs : 64 consecutive elements of job y's 128x128 tile, summed over its slots -- the slots are split
+//                          over 16 groups (group g takes slots s0+g, s0+g+16, ...), then the 16 group sums are added;
+//   x == 256, y < njobs : job y's bias gradient (two row-half partials per slot), fp64 across slots;
+//   y == njobs, x < 17  : optional extra reduction riding along -- the node chain's head-vector partials
+//                          ([blocks][257]: d w_out | d w_att | d b_out), so the chain's backward needs no launch of its own.
+struct HeadJob {
+    const float* partial;     // null: none
+    int blocks;
+    float *d_wout, *d_watt, *d_bout;
+};
+
+__global__ __launch_bounds__(WG) void wgrad_finish_kernel(WBatch batch, const float* __restrict__ partial, HeadJob head) {
     __shared__ float4 red[16][16];
+    constexpr int64_t SLOT = DIM * DIM + 2 * DIM;
+    if ((int)blockIdx.y == batch.njobs) {
+        if (!head.partial || blockIdx.x >= 17) return;
+        float(*r1)[17] = reinterpret_cast<float(*)[17]>(&red[0][0]);      // 16 x 17 floats fit in the float4 array
+        const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+        const int c = blockIdx.x * 16 + cl;
+        float s = 0.f;
+        if (c < 257)
+            for (int b = sl; b < head.blocks; b += 16) s += head.partial[(int64_t)b * 257 + c];
+        r1[sl][cl] = s;
+        __syncthreads();
+        if (sl == 0 && c < 257) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += r1[q][cl];
+            if (c < 128) head.d_wout[c] = t;
+            else if (c < 256) head.d_watt[c - 128] = t;
+            else head.d_bout[0] = t;
+        }
+        return;
+    }
     const WJob jb = batch.job[blockIdx.y];
     const int s0 = batch.start[blockIdx.y], s1 = batch.start[blockIdx.y + 1];
-    constexpr int64_t SLOT = DIM * DIM + 2 * DIM;
-    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int e4 = blockIdx.x * 16 + c;                           // float4 index inside the 128x128 tile (grid covers it)
-    float4 s = f4zero();
-    for (int q = s0 + g; q < s1; q += 16)
-        s = f4add(s, *reinterpret_cast<const float4*>(partial + (int64_t)q * SLOT + 4 * e4));
-    red[g][c] = s;
-    __syncthreads();
-    if (g == 0) {
-        float4 t = red[0][c];
+    if (blockIdx.x < 256) {
+        const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+        const int e4 = blockIdx.x * 16 + c;                       // float4 index inside the 128x128 tile
+        float4 s = f4zero();
+        for (int q = s0 + g; q < s1; q += 16)
+            s = f4add(s, *reinterpret_cast<const float4*>(partial + (int64_t)q * SLOT + 4 * e4));
+        red[g][c] = s;
+        __syncthreads();
+        if (g == 0) {
+            float4 t = red[0][c];
 #pragma unroll
-        for (int k = 1; k < 16; ++k) t = f4add(t, red[k][c]);
-        const int el = 4 * e4;
-        *reinterpret_cast<float4*>(jb.dW + (int64_t)(el >> 7) * jb.ld_dw + (el & 127)) = t;
-    }
-}
-
-// bias gradients: db[c] = sum over slots of both row-half partials.  128 columns x 8 slot groups, fp64, fixed order.
-__global__ __launch_bounds__(1024) void wgrad_bias_kernel(WBatch batch, const float* __restrict__ partial) {
-    __shared__ double red[8][128];
-    const WJob jb = batch.job[blockIdx.x];
-    if (!jb.db) return;
-    const int s0 = batch.start[blockIdx.x], s1 = batch.start[blockIdx.x + 1];
-    constexpr int64_t SLOT = DIM * DIM + 2 * DIM;
-    const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
-    double s = 0.0;
-    for (int q = s0 + g; q < s1; q += 8)
-        s += (double)partial[(int64_t)q * SLOT + DIM * DIM + c] + (double)partial[(int64_t)q * SLOT + DIM * DIM + DIM + c];
-    red[g][c] = s;
-    __syncthreads();
-    if (g == 0) {
-        double t = red[0][c];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) t += red[k][c];
-        jb.db[c] = (float)t;
+            for (int k = 1; k < 16; ++k) t = f4add(t, red[k][c]);
+            const int el = 4 * e4;
+            *reinterpret_cast<float4*>(jb.dW + (int64_t)(el >> 7) * jb.ld_dw + (el & 127)) = t;
+        }
+    } else if (blockIdx.x == 256) {
+        if (!jb.db) return;
+        double* rd = reinterpret_cast<double*>(&red[0][0]);       // [2][128] doubles = 2 KB of the 4 KB array
+        const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+        double s = 0.0;
+        for (int q = s0 + g; q < s1; q += 2)
+            s += (double)partial[(int64_t)q * SLOT + DIM * DIM + c] +
+                 (double)partial[(int64_t)q * SLOT + DIM * DIM + DIM + c];
+        rd[g * 128 + c] = s;
+        __syncthreads();
+        if (g == 0) jb.db[c] = (float)(rd[c] + rd[128 + c]);
     }
 }
 
@@ -218,9 +261,11 @@ extern "C" int pamnet_wgrad_scratch_floats(int64_t njobs, const int64_t* rows, i
 extern "C" int pamnet_wgrad_batched_f32(int64_t njobs, const float* const* dZ, const int64_t* ld_dz,
                                         const float* const* A, const int64_t* ld_a, const int32_t* a_mode,
                                         const int64_t* rows, float* const* dW, const int64_t* ld_dw, float* const* db,
-                                        float* partial, pamnet_stream_t stream) {
+                                        float* partial, const float* head_partial, int64_t head_blocks,
+                                        float* d_wout, float* d_watt, float* d_bout, pamnet_stream_t stream) {
     if (njobs < 0 || njobs > MAXJ) return PAMNET_EINVAL;
-    if (njobs == 0) return PAMNET_OK;
+    if (njobs == 0) return head_partial ? PAMNET_EINVAL : PAMNET_OK;
+    if (head_partial && (!d_wout || !d_watt || !d_bout || head_blocks < 0)) return PAMNET_ENULL;
     if (!dZ || !ld_dz || !A || !ld_a || !a_mode || !rows || !dW || !ld_dw || !db || !partial) return PAMNET_ENULL;
     WBatch b;
     b.njobs = (int)njobs;
@@ -234,9 +279,9 @@ extern "C" int pamnet_wgrad_batched_f32(int64_t njobs, const float* const* dZ, c
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)b.start[njobs]), dim3(WG), 0, st, b, partial);
     PAMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(DIM * DIM / 64, (unsigned)njobs), dim3(WG), 0, st, b, partial);
-    PAMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_bias_kernel, dim3((unsigned)njobs), dim3(1024), 0, st, b, partial);
+    const HeadJob head{head_partial, (int)head_blocks, d_wout, d_watt, d_bout};
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(DIM * DIM / 64 + 2, (unsigned)njobs + 1), dim3(WG), 0, st, b, partial,
+                       head);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

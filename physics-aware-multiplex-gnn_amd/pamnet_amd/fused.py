@@ -71,7 +71,7 @@ def wgrad(jobs, ref):
     lib.call('pamnet_wgrad_batched_f32', n, _parr([j[0] for j in jobs]), _iarr([j[1] for j in jobs]),
              _parr([j[2] for j in jobs]), _iarr([j[3] for j in jobs]), _iarr([j[4] for j in jobs], ctypes.c_int32),
              rows, _parr([j[6] for j in jobs]), _iarr([j[7] for j in jobs]), _parr([j[8] for j in jobs]),
-             lib.ptr(partial), lib.stream_of(ref))
+             lib.ptr(partial), None, 0, None, None, None, lib.stream_of(ref))
 
 
 # ---------------------------------------------------------------------------------------------------- raw kernel calls

@@ -63,6 +63,40 @@ def test_segment_sum_all_operands(dev, d):
     assert torch.equal(g, A[ia.long()] * B[ib.long()])
 
 
+@pytest.mark.parametrize('rows,max_len', [(1, 0), (37, 9), (2286, 30), (20000, 6)])
+def test_segment_sum_multi_and_gather_mul2(dev, rows, max_len):
+    """Batched plain segment sums (with and without a transposed-CSR permutation) and the two-product gather."""
+    import ctypes
+    from pamnet_amd import lib
+    rng = np.random.default_rng(rows)
+    d = 128
+    jobs = []
+    for j in range(4):
+        ptr, m, seg = _csr(rng, rows, max_len, dev)
+        A = torch.randn(max(m, 1), d, device=dev)
+        perm = torch.from_numpy(rng.permutation(m).astype(np.int32)).to(dev) if j % 2 else None
+        jobs.append((ptr, m, seg, A, perm, torch.empty(rows, d, device=dev)))
+    P = ctypes.c_void_p * 4
+    st = lib.stream_of(jobs[0][3])
+    for nj in (1, 2, 4):
+        for jb in jobs:
+            jb[5].fill_(float('nan'))
+        lib.call('pamnet_segment_sum_multi_f32', nj, P(*[lib.ptr(jb[5]) for jb in jobs]), P(*[lib.ptr(jb[3]) for jb in jobs]),
+                 P(*[None if jb[4] is None else lib.ptr(jb[4]) for jb in jobs]), P(*[lib.ptr(jb[0]) for jb in jobs]),
+                 rows, d, st)
+        for ptr, m, seg, A, perm, out in jobs[:nj]:
+            src = A[:m].double() if perm is None else A[:m].double()[perm.long()]
+            ref = torch.zeros(rows, d, device=dev, dtype=torch.float64).index_add_(0, seg, src)
+            assert maxnorm_err(out.cpu(), ref.cpu()) < 2e-6 or float(ref.abs().max()) == 0.0
+    m = max(jobs[0][1], 1)
+    ia = torch.from_numpy(rng.integers(0, rows, m).astype(np.int32)).to(dev)
+    Asrc, B1, B2 = torch.randn(rows, d, device=dev), torch.randn(m, d, device=dev), torch.randn(m, d, device=dev)
+    o1, o2 = torch.empty(m, d, device=dev), torch.empty(m, d, device=dev)
+    lib.call('pamnet_gather_mul2_f32', lib.ptr(o1), lib.ptr(o2), lib.ptr(Asrc), lib.ptr(ia), lib.ptr(B1), lib.ptr(B2),
+             m, d, st)
+    assert torch.equal(o1, Asrc[ia.long()] * B1) and torch.equal(o2, Asrc[ia.long()] * B2)
+
+
 def test_segment_ops_autograd(dev):
     """Backward kernels == autograd of the equivalent torch expression."""
     from pamnet_amd import graph as G, ops
