@@ -204,6 +204,10 @@ int pamnet_local_edge_bwd_f32(const float* d_mji, const float* d_mnb, const floa
                               int32_t accumulate, pamnet_stream_t stream);
 int pamnet_mlp2_fwd_f32(const float* x, int64_t rows, const float* W1, const float* b1, const float* W2,
                         const float* b2, float* z1, float* z2, float* y, pamnet_stream_t stream);
+/* nsets <= 8 such MLPs on the same input rows in one launch: params[4k..4k+3] = {W1, b1, W2, b2} of set k,
+ * outs[3k..3k+2] = {z1, z2, y} (host arrays of device pointers).  The per-layer mlp_sbf of all layers take the same input. */
+int pamnet_mlp2_fwd_multi_f32(const float* x, int64_t rows, int64_t nsets, const float* const* params,
+                              float* const* outs, pamnet_stream_t stream);
 int pamnet_mlp2_bwd_f32(const float* dy, int64_t rows, const float* z1, const float* z2, const float* W1,
                         const float* W2, float* dz1, float* dz2, float* dx, int32_t accumulate,
                         pamnet_stream_t stream);

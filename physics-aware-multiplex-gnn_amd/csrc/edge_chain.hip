@@ -415,11 +415,24 @@ __global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(const float* __rest
 }
 
 // -------------------------------------------------------------------------------------------------- 2-layer MLP
-__global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__ x, int64_t m,
-                                                       const float* __restrict__ W1, const float* __restrict__ b1,
-                                                       const float* __restrict__ W2, const float* __restrict__ b2,
-                                                       float* __restrict__ z1, float* __restrict__ z2,
-                                                       float* __restrict__ y, int per, int cmt) {
+// blockIdx.y selects one of up to 8 independent (weights, outputs) sets applied to the same input rows: the triplet/pair
+// MLPs of all layers depend only on the basis embedding, so the engine runs them in one launch up front.
+struct Mlp2Set {
+    const float *W1, *b1, *W2, *b2;
+    float *z1, *z2, *y;
+};
+struct Mlp2Batch {
+    Mlp2Set s[8];
+};
+__global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__ x, int64_t m, Mlp2Batch batch, int per,
+                                                       int cmt) {
+    const float* __restrict__ W1 = batch.s[blockIdx.y].W1;
+    const float* __restrict__ b1 = batch.s[blockIdx.y].b1;
+    const float* __restrict__ W2 = batch.s[blockIdx.y].W2;
+    const float* __restrict__ b2 = batch.s[blockIdx.y].b2;
+    float* __restrict__ z1 = batch.s[blockIdx.y].z1;
+    float* __restrict__ z2 = batch.s[blockIdx.y].z2;
+    float* __restrict__ y = batch.s[blockIdx.y].y;
     __shared__ __attribute__((aligned(16))) float lds[2 * MT2 * 16 * LDT];
     float* S0 = lds;
     float* S1 = lds + MT2 * 16 * LDT;
@@ -624,8 +637,32 @@ extern "C" int pamnet_mlp2_fwd_f32(const float* x, int64_t rows, const float* W1
     if (rows == 0) return PAMNET_OK;
     if (!x || !W1 || !b1 || !W2 || !b2 || !z1 || !z2 || !y) return PAMNET_ENULL;
     const Plan p = plan(rows, MT2);
-    hipLaunchKernelGGL(mlp2_fwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), x, rows, W1, b1, W2, b2, z1, z2, y,
-                       p.per, p.cmt);
+    Mlp2Batch b;
+    for (int k = 0; k < 8; ++k) b.s[k] = Mlp2Set{W1, b1, W2, b2, z1, z2, y};
+    hipLaunchKernelGGL(mlp2_fwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), x, rows, b, p.per, p.cmt);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+// nsets <= 8 two-layer MLPs on the same input rows in one launch; params[k] = {W1, b1, W2, b2}, outs[k] = {z1, z2, y}.
+extern "C" int pamnet_mlp2_fwd_multi_f32(const float* x, int64_t rows, int64_t nsets, const float* const* params,
+                                         float* const* outs, pamnet_stream_t stream) {
+    if (rows < 0 || nsets < 1 || nsets > 8) return PAMNET_EINVAL;
+    if (rows == 0) return PAMNET_OK;
+    if (!x || !params || !outs) return PAMNET_ENULL;
+    Mlp2Batch b;
+    for (int k = 0; k < 8; ++k) {
+        const int s = k < nsets ? k : 0;
+        for (int i = 0; i < 4; ++i)
+            if (!params[4 * s + i]) return PAMNET_ENULL;
+        for (int i = 0; i < 3; ++i)
+            if (!outs[3 * s + i]) return PAMNET_ENULL;
+        b.s[k] = Mlp2Set{params[4 * s], params[4 * s + 1], params[4 * s + 2], params[4 * s + 3],
+                         outs[3 * s], outs[3 * s + 1], outs[3 * s + 2]};
+    }
+    const Plan p = plan(rows, MT2);
+    hipLaunchKernelGGL(mlp2_fwd_kernel, dim3(p.grid, (unsigned)nsets), dim3(WG8), 0, as_stream(stream), x, rows, b, p.per,
+                       p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

@@ -220,6 +220,21 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
     // n_layer of them are enqueued up front and run beside the node-level kernels of the first layers, which occupy
     // only ceil(n/16) of the 256 CUs.  Event 0 = inputs ready, event 1+k = s_k ready.
     const bool forked = aux && aux_events && g.tp > 0;
+    // Without the fork: the triplet/pair MLPs of up to 8 layers at a time as one launch ahead of the layer loop.
+    if (!forked && g.tp > 0) {
+        for (int64_t k0 = 0; k0 < n_layer; k0 += 8) {
+            const int64_t nk = n_layer - k0 < 8 ? n_layer - k0 : 8;
+            const float* prm[32];
+            float* out[24];
+            for (int64_t k = 0; k < nk; ++k) {
+                const float* const* lp = lparams + (k0 + k) * NL;
+                const LocalSaved q = carve_local(saved + (k0 + k) * (gs + ls) + gs, g);
+                prm[4 * k] = lp[6], prm[4 * k + 1] = lp[7], prm[4 * k + 2] = lp[8], prm[4 * k + 3] = lp[9];
+                out[3 * k] = q.z1, out[3 * k + 1] = q.z2, out[3 * k + 2] = q.s;
+            }
+            CK(pamnet_mlp2_fwd_multi_f32(e_sbf, g.tp, nk, prm, out, st));
+        }
+    }
     if (forked) {
         hipStream_t a = as_stream(aux);
         HK(hipEventRecord(reinterpret_cast<hipEvent_t>(aux_events[0]), as_stream(st)));
@@ -253,10 +268,7 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         const float* planes[4] = {t.P, t.P + g.n * D, t.P + 2 * g.n * D, t.P + 3 * g.n * D};
         CK(pamnet_local_edge_fwd_f32(rbf_e, g.el, wq, ldq, lp[3], lp[5], planes, g.l_row, g.l_col, q.zji, q.zkj, q.q2,
                                      q.q3, t.mji, q.mnb, st));
-        if (forked)
-            HK(hipStreamWaitEvent(as_stream(st), reinterpret_cast<hipEvent_t>(aux_events[1 + k]), 0));
-        else
-            CK(pamnet_mlp2_fwd_f32(e_sbf, g.tp, lp[6], lp[7], lp[8], lp[9], q.z1, q.z2, q.s, st));
+        if (forked) HK(hipStreamWaitEvent(as_stream(st), reinterpret_cast<hipEvent_t>(aux_events[1 + k]), 0));
         CK(pamnet_segment_sum_f32(q.mt, t.mji, q.mnb, g.t_col, q.s, nullptr, nullptr, g.t_ptr, g.el, D, st));
         CK(pamnet_segment_sum_f32(q.x2, t.x1, q.mt, nullptr, q.q3, nullptr, nullptr, g.l_ptr, g.n, D, st));
         CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22], q.Z, q.R,

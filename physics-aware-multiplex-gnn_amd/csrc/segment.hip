@@ -162,15 +162,22 @@ int launch_segment_sum(float* out, const float* init, const float* A, const int3
                        const int32_t* ib, const int32_t* perm, const int32_t* ptr, int64_t rows, int64_t d4,
                        hipStream_t st) {
     constexpr int SPLIT = (256 / LPR >= 4) ? 4 : 1;
-    // few rows: split every segment over SPLIT lane groups (see segment_sum_split_kernel)
+    constexpr int SPLIT_WIDE = 256 / LPR;                  // a whole workgroup per row
+    // few rows: split every segment over SPLIT lane groups (see segment_sum_split_kernel); a handful of rows (the
+    // gradient of the 5-row atom-type embedding sums ~450 node rows per type): the whole workgroup shares one row
+    const bool wide = SPLIT_WIDE > SPLIT && rows <= 64;
     const bool split = SPLIT > 1 && rows * LPR <= (int64_t)SPLIT_MAX_LANES;
     constexpr int RPB_FULL = 256 / LPR;
-    const int RPB = split ? RPB_FULL / SPLIT : RPB_FULL;
+    const int RPB = wide ? 1 : (split ? RPB_FULL / SPLIT : RPB_FULL);
     int64_t grid = ceil_div(rows, RPB);
     if (grid > 256 * 64) grid = 256 * 64;                  // grid-stride above 64 blocks / CU
     if (grid < 1) grid = 1;
 #define PAMNET_SEG_CASE(IA, BB, IB, PM)                                                                              \
-    if (split)                                                                                                       \
+    if (wide)                                                                                                        \
+        hipLaunchKernelGGL((segment_sum_split_kernel<LPR, SPLIT_WIDE, IA, BB, IB, PM>), dim3((unsigned)grid),        \
+                           dim3(256), 0, st, (float4*)out, (const float4*)init, (const float4*)A, ia,                \
+                           (const float4*)B, ib, perm, ptr, rows, d4);                                               \
+    else if (split)                                                                                                  \
         hipLaunchKernelGGL((segment_sum_split_kernel<LPR, SPLIT, IA, BB, IB, PM>), dim3((unsigned)grid), dim3(256),  \
                            0, st, (float4*)out, (const float4*)init, (const float4*)A, ia, (const float4*)B, ib,     \
                            perm, ptr, rows, d4);                                                                     \

@@ -234,15 +234,27 @@ __global__ __launch_bounds__(WG) void wgrad_finish_kernel(WBatch batch, const fl
         }
     } else if (blockIdx.x == 256) {
         if (!jb.db) return;
-        double* rd = reinterpret_cast<double*>(&red[0][0]);       // [2][128] doubles = 2 KB of the 4 KB array
-        const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
-        double s = 0.0;
-        for (int q = s0 + g; q < s1; q += 2)
-            s += (double)partial[(int64_t)q * SLOT + DIM * DIM + c] +
-                 (double)partial[(int64_t)q * SLOT + DIM * DIM + DIM + c];
-        rd[g * 128 + c] = s;
+        // 32 float4 columns x 8 slot groups, fp64 across slots, fixed order
+        __shared__ double rd[8][128];
+        const int c4 = threadIdx.x & 31, g = threadIdx.x >> 5;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int q = s0 + g; q < s1; q += 8) {
+            const float* p = partial + (int64_t)q * SLOT + DIM * DIM;
+            const float4 u = *reinterpret_cast<const float4*>(p + 4 * c4);
+            const float4 v = *reinterpret_cast<const float4*>(p + DIM + 4 * c4);
+            a0 += (double)u.x + (double)v.x;
+            a1 += (double)u.y + (double)v.y;
+            a2 += (double)u.z + (double)v.z;
+            a3 += (double)u.w + (double)v.w;
+        }
+        rd[g][4 * c4] = a0, rd[g][4 * c4 + 1] = a1, rd[g][4 * c4 + 2] = a2, rd[g][4 * c4 + 3] = a3;
         __syncthreads();
-        if (g == 0) jb.db[c] = (float)(rd[c] + rd[128 + c]);
+        if (threadIdx.x < 128) {
+            double t = rd[0][threadIdx.x];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) t += rd[k][threadIdx.x];
+            jb.db[threadIdx.x] = (float)t;
+        }
     }
 }
 
