@@ -151,6 +151,8 @@ int pamnet_fuse_pool_bwd_f32(const float* outs, const float* atts, int64_t n_lay
  *   (layers/global_message_passing.py:39-50, layers/local_message_passing.py:55-66; Res: layers/basic.py:25-33):
  *   weights/biases order: mlp_x2, res1.0, res1.1, res2.0, res2.1, res3.0, res3.1, mlp_out.0, mlp_out.1, mlp_out.2.
  *   Saves Z[10][n][128] (pre-activations) and R[2][n][128] (r1, r2) for the backward.
+ *   next_* (next_nblk = 0: none): the node_pre of the FOLLOWING layer applied to x_out while its tile is still on chip
+ *   (same outputs as pamnet_node_pre_fwd_f32 on x_out) -- the layer loop then needs one node-level launch per layer.
  * node_pre: x1 = SiLU(mlp_x1 x) and the node-level halves P = x1 * Wp_b^T (b < nblk <= 4) of the split message MLPs
  *   (mlp_m / mlp_m_ji / mlp_m_kj on [x_i | x_j | e]: layers/global_message_passing.py:52-56, local...:46-48).
  * wgrad_batched: dW_j = dZ_j^T * A_j (A_j optionally SiLU'd on load), db_j = colsum(dZ_j) for up to 24 jobs, in two
@@ -160,7 +162,9 @@ int pamnet_fuse_pool_bwd_f32(const float* outs, const float* atts, int64_t n_lay
  * ------------------------------------------------------------------------------------------------------------------ */
 int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int64_t n, const float* const* weights,
                              const float* const* biases, const float* w_out, const float* b_out, const float* w_att,
-                             float* Z, float* R, float* x_out, float* out, float* att, pamnet_stream_t stream);
+                             float* Z, float* R, float* x_out, float* out, float* att, const float* next_Wx1,
+                             const float* next_bx1, const float* const* next_wp, int64_t next_ldwp, int64_t next_nblk,
+                             float* next_Zx1, float* next_x1, float* next_P, pamnet_stream_t stream);
 int pamnet_node_tail_bwd_f32(const float* d_xout, const float* d_out, const float* d_att, int64_t n,
                              const float* const* weights, const float* w_out, const float* w_att, const float* Z,
                              float* dZ, float* d_x2, float* d_resx, float* head_partial, float* d_wout, float* d_watt,

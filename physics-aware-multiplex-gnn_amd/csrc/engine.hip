@@ -251,18 +251,19 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         const float* const* gp = gparams + k * NG;
         const GlobalSaved s = carve_global(saved + k * (gs + ls), g);
         const float* wpg[2] = {gp[2], gp[2] + D};
-        CK(pamnet_node_pre_fwd_f32(x, g.n, gp[0], gp[1], wpg, 3 * D, 2, s.Zx1, t.x1, t.P, st));
+        // the head of every layer but the first runs inside the preceding layer's node chain (x_out tile still on chip)
+        if (k == 0) CK(pamnet_node_pre_fwd_f32(x, g.n, gp[0], gp[1], wpg, 3 * D, 2, s.Zx1, t.x1, t.P, st));
         CK(pamnet_global_edge_fwd_f32(e_g, g.eg, gp[2] + 2 * D, 3 * D, gp[3], gp[4], D, t.P, t.P + g.n * D, g.g_row,
                                       g.g_col, s.z, s.ea, t.msg, st));
         CK(pamnet_segment_sum_f32(s.x2, t.x1, t.msg, nullptr, nullptr, nullptr, nullptr, g.g_ptr, g.n, D, st));
-        CK(pamnet_node_tail_fwd_f32(s.x2, x, g.n, gp + GT, gp + GT + 10, gp[GT + 20], gp[GT + 21], gp[GT + 22], s.Z, s.R,
-                                    s.xout, outs + (2 * k) * g.n, atts + (2 * k) * g.n, st));
-        x = s.xout;
-        // ---------------- local layer (layers/local_message_passing.py:36-66)
         const float* const* lp = lparams + k * NL;
         const LocalSaved q = carve_local(saved + k * (gs + ls) + gs, g);
         const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
-        CK(pamnet_node_pre_fwd_f32(x, g.n, lp[0], lp[1], wpl, 3 * D, 4, q.Zx1, t.x1, t.P, st));
+        CK(pamnet_node_tail_fwd_f32(s.x2, x, g.n, gp + GT, gp + GT + 10, gp[GT + 20], gp[GT + 21], gp[GT + 22], s.Z, s.R,
+                                    s.xout, outs + (2 * k) * g.n, atts + (2 * k) * g.n, lp[0], lp[1], wpl, 3 * D, 4,
+                                    q.Zx1, t.x1, t.P, st));
+        x = s.xout;
+        // ---------------- local layer (layers/local_message_passing.py:36-66); its head ran in the chain above
         const float* wq[4] = {lp[2] + 2 * D, lp[4] + 2 * D, lp[10], lp[11]};
         const int64_t ldq[4] = {3 * D, 3 * D, D, D};
         const float* planes[4] = {t.P, t.P + g.n * D, t.P + 2 * g.n * D, t.P + 3 * g.n * D};
@@ -271,8 +272,18 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         if (forked) HK(hipStreamWaitEvent(as_stream(st), reinterpret_cast<hipEvent_t>(aux_events[1 + k]), 0));
         CK(pamnet_segment_sum_f32(q.mt, t.mji, q.mnb, g.t_col, q.s, nullptr, nullptr, g.t_ptr, g.el, D, st));
         CK(pamnet_segment_sum_f32(q.x2, t.x1, q.mt, nullptr, q.q3, nullptr, nullptr, g.l_ptr, g.n, D, st));
-        CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22], q.Z, q.R,
-                                    q.xout, outs + (2 * k + 1) * g.n, atts + (2 * k + 1) * g.n, st));
+        if (k + 1 < n_layer) {
+            const float* const* gn = gparams + (k + 1) * NG;
+            const GlobalSaved sn = carve_global(saved + (k + 1) * (gs + ls), g);
+            const float* wpn[2] = {gn[2], gn[2] + D};
+            CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22], q.Z,
+                                        q.R, q.xout, outs + (2 * k + 1) * g.n, atts + (2 * k + 1) * g.n, gn[0], gn[1],
+                                        wpn, 3 * D, 2, sn.Zx1, t.x1, t.P, st));
+        } else {
+            CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22], q.Z,
+                                        q.R, q.xout, outs + (2 * k + 1) * g.n, atts + (2 * k + 1) * g.n, nullptr, nullptr,
+                                        nullptr, 0, 0, nullptr, nullptr, nullptr, st));
+        }
         x = q.xout;
     }
     return PAMNET_OK;

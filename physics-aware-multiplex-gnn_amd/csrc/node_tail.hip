@@ -48,6 +48,16 @@ struct TailParams {
     const float* w_att;   // [128]
 };
 
+// Head of the NEXT layer applied to this chain's x_out while the tile is still in LDS (nblk = 0: none):
+//   x1 = SiLU(Wx1 x_out + bx1),  P_b = x1 * wp[b]^T  (the node-level halves of the next layer's split message MLPs).
+struct PreNext {
+    const float* Wx1;
+    const float* bx1;
+    const float* wp[4];
+    int ldwp, nblk;
+    float *Zx1, *x1, *P;      // [n][128], [n][128], [nblk][n][128]
+};
+
 constexpr int BMN = 16;                       // rows per workgroup
 constexpr int SLOT = BMN * LDT;               // floats per LDS slot
 constexpr int TWG = 512;                      // 8 waves
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
                                                            const float* __restrict__ res_x, int64_t n, TailParams p,
                                                            float* __restrict__ Z, float* __restrict__ R,
                                                            float* __restrict__ x_out, float* __restrict__ out,
-                                                           float* __restrict__ att) {
+                                                           float* __restrict__ att, PreNext nx) {
     // 5 working slots + 10 pre-activation tiles + 3 residual taps: everything the backward needs is parked in LDS and
     // written out once, as coalesced 512-byte rows, after the chain -- no global store (and no wait for its
     // acknowledgement, vmcnt retires in order) sits between one layer's MFMAs and the next layer's weight slice.
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
     layer(A, C, 6, B, nullptr, TL + 2 * SLOT, p.W[7]);         // r3 -> C   (+ r2)  = x_out
     layer(C, A, 7, nullptr, nullptr, nullptr, p.W[8]);         // o1 -> A
     layer(A, B, 8, nullptr, nullptr, nullptr, p.W[9]);         // o2 -> B
-    layer(B, A, 9, nullptr, nullptr, nullptr, nullptr);        // o3 -> A
+    layer(B, A, 9, nullptr, nullptr, nullptr, nx.nblk > 0 ? nx.Wx1 : nullptr);   // o3 -> A
 
     // park -> memory: Z[10][n][128], R[2][n][128], x_out[n][128]
     sweep_rows<BMN>([&](int r, int c4) {
@@ -208,6 +218,53 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
             out[g] = so + p.b_out[0];
             att[g] = sa;
         }
+    }
+
+    // ---- the next layer's head on the x_out tile (still in TL[2]); its outputs reuse the z_k parking slots, which the
+    // sweep above has already read -> barrier, then one GEMM for x1 and nblk for the projections, then a second flush.
+    if (nx.nblk > 0) {
+        __syncthreads();
+        const float* xin = TL + 2 * SLOT;
+        {
+            const Bias2 bv = load_bias2(nx.bx1, wc);
+            f32x4 acc[1][2];
+            acc_zero<1>(acc);
+            mma_tile_frag<1>(xin, wf, acc);
+            load_wfrag<false>(wf, nx.wp[0], nx.ldwp, wc);
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) {
+                const int c = wc + 16 * n2 + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rw = 4 * kg + r;
+                    const float z = acc[0][n2][r] + bv.v[n2];
+                    ZL[rw * LDT + c] = z;                       // Zx1
+                    ZL[SLOT + rw * LDT + c] = silu(z);          // x1
+                }
+            }
+            __syncthreads();
+        }
+        for (int b = 0; b < nx.nblk; ++b) {
+            f32x4 acc[1][2];
+            acc_zero<1>(acc);
+            mma_tile_frag<1>(ZL + SLOT, wf, acc);
+            if (b + 1 < nx.nblk) load_wfrag<false>(wf, nx.wp[b + 1], nx.ldwp, wc);
+            float* pb = ZL + (2 + b) * SLOT;
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) {
+                const int c = wc + 16 * n2 + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pb[(4 * kg + r) * LDT + c] = acc[0][n2][r];
+            }
+        }
+        __syncthreads();
+        sweep_rows<BMN>([&](int r, int c4) {
+            const int64_t g = row0 + r;
+            if (g >= n) return;
+            stg4(nx.Zx1, g, DIM, c4, lds4(ZL, r, c4));
+            stg4(nx.x1, g, DIM, c4, lds4(ZL + SLOT, r, c4));
+            for (int b = 0; b < nx.nblk; ++b) stg4(nx.P + (int64_t)b * plane, g, DIM, c4, lds4(ZL + (2 + b) * SLOT, r, c4));
+        });
     }
 }
 
@@ -382,16 +439,29 @@ inline TailParams make_tail(const float* const* weights, const float* const* bia
 extern "C" int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int64_t n, const float* const* weights,
                                         const float* const* biases, const float* w_out, const float* b_out,
                                         const float* w_att, float* Z, float* R, float* x_out, float* out, float* att,
-                                        pamnet_stream_t stream) {
-    if (n < 0) return PAMNET_EINVAL;
+                                        const float* next_Wx1, const float* next_bx1, const float* const* next_wp,
+                                        int64_t next_ldwp, int64_t next_nblk, float* next_Zx1, float* next_x1,
+                                        float* next_P, pamnet_stream_t stream) {
+    if (n < 0 || next_nblk < 0 || next_nblk > 4) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
     if (!x2 || !res_x || !weights || !biases || !w_out || !b_out || !w_att || !Z || !R || !x_out || !out || !att)
         return PAMNET_ENULL;
     for (int k = 0; k < 10; ++k)
         if (!weights[k] || !biases[k]) return PAMNET_ENULL;
+    PreNext nx{};
+    nx.nblk = (int)next_nblk;
+    if (next_nblk > 0) {
+        if (!next_Wx1 || !next_bx1 || !next_wp || !next_Zx1 || !next_x1 || !next_P) return PAMNET_ENULL;
+        nx.Wx1 = next_Wx1, nx.bx1 = next_bx1, nx.ldwp = (int)next_ldwp;
+        nx.Zx1 = next_Zx1, nx.x1 = next_x1, nx.P = next_P;
+        for (int b = 0; b < next_nblk; ++b) {
+            if (!next_wp[b]) return PAMNET_ENULL;
+            nx.wp[b] = next_wp[b];
+        }
+    }
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(node_tail_fwd_kernel, dim3((unsigned)ceil_div(n, BMN)), dim3(WG), 0, st, x2, res_x, n,
-                       make_tail(weights, biases, w_out, b_out, w_att), Z, R, x_out, out, att);
+                       make_tail(weights, biases, w_out, b_out, w_att), Z, R, x_out, out, att, nx);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

@@ -98,7 +98,7 @@ def k_tail_fwd(x2, res_x, tp):
     x_out, out, att = _empty(n, D, like=x2), _empty(n, like=x2), _empty(n, like=x2)
     lib.call('pamnet_node_tail_fwd_f32', lib.ptr(x2), lib.ptr(res_x), n, _parr(W), _parr(b), lib.ptr(w_out),
              lib.ptr(b_out), lib.ptr(w_att), lib.ptr(Z), lib.ptr(R), lib.ptr(x_out), lib.ptr(out), lib.ptr(att),
-             lib.stream_of(x2))
+             None, None, None, 0, 0, None, None, None, lib.stream_of(x2))
     return Z, R, x_out, out, att
 
 
