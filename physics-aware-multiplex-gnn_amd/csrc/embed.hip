@@ -2,30 +2,112 @@
 //   edge_attr_rbf_{l,g} = SiLU(Linear(16 -> d)(rbf))                       models.py:185-186, layers/basic.py:19-22
 //   edge_attr_sbf{1,2}  = SiLU(Linear(42 -> d)(sbf))  (mlp_sbf1 on pair rows, mlp_sbf2 on triplet rows)  models.py:187-188
 //   x = init_linear(x_raw[:, 3:])   (18 -> d, no bias, no activation; PDBbind)                           models.py:119
-// K is 16 / 18 / 42: too thin for a matrix-core tile to pay off, so this is a VALU kernel shaped for bandwidth:
-// thread t owns output column c = t & 127 with its whole weight row (K floats) in registers; a workgroup stages 32
-// input rows in LDS and reads them as wave-wide broadcasts; outputs leave as coalesced 512-byte rows.  The combined
-// triplet/pair row list selects between two weight sets per row (`kind`), which replaces the reference's two separate
-// Linear calls + the index_select / index_copy traffic of a host-side split.
-// Backward: z is recomputed (cheaper than storing it), dW / db accumulate per thread across a grid-stride loop and are
-// reduced over workgroups in a fixed order (deterministic); dx (only needed for the trainable Bessel frequencies) is a
-// second LDS phase.
+//
+// K is 16 / 18 / 42: the GEMM is thin, the traffic is not (E_g x 128 outputs), so these are bandwidth kernels with the
+// arithmetic on the matrix unit (v_mfma_f32_16x16x4_f32, exact fp32):
+//   * a workgroup (4 waves) owns 64-row tiles; the input rows are staged in LDS zero-padded to KP = 16*ceil(K/16)
+//     columns, the weight slices of a wave (32 output columns, KP/16 float4 per 16-column tile) stay in registers;
+//   * the combined triplet/pair row list selects between two weight sets per row (`kind`): the row's A fragment is
+//     masked into two operands that accumulate W0- and W1-products into the same tile -- this replaces the reference's
+//     two Linear calls plus the index_select / index_copy traffic of a host-side split;
+//   * outputs leave as coalesced 512-byte rows through an LDS transpose.
+// Backward: z is recomputed (cheaper than storing it); dW = dz^T x runs on the matrix unit with the row index as the
+// MFMA k dimension, accumulating across a workgroup's tiles in registers; workgroup partials are reduced in a fixed
+// order (deterministic); dx (only needed for the trainable Bessel frequencies, K = 16) is a third small GEMM.
 #include "common.h"
+#include "gemm_core.h"
+
+using namespace pamnet;
 
 namespace {
 
 constexpr int DOUT = 128;
-constexpr int TR = 32;                 // rows per tile
-constexpr int RU = 4;                  // rows in flight per thread
-
-__device__ __forceinline__ float sigmoid_fast(float z) { return __frcp_rn(1.0f + __expf(-z)); }
+constexpr int TR = 64;                 // rows per tile (4 MFMA row tiles)
+constexpr int MT = TR / 16;
 
 template <int K>
+struct Dims {
+    static constexpr int G = (K + 15) / 16;     // 16-wide k groups
+    static constexpr int KP = 16 * G;
+    static constexpr int LDX = KP + 4;          // LDS row stride of the staged inputs (16-byte aligned rows)
+};
+
+// weight slice of a wave: columns [wc, wc+32) as two 16-column tiles, k zero-padded to KP
+template <int K>
+struct WSlice {
+    float4 b[Dims<K>::G][2];
+};
+template <int K>
+__device__ __forceinline__ void load_wslice(WSlice<K>& f, const float* __restrict__ W, int wc) {
+    const int lane = threadIdx.x & 63, r16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int g = 0; g < Dims<K>::G; ++g)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+            const float* wp = W + (size_t)(wc + 16 * n2 + r16) * K;
+            const int k0 = 16 * g + 4 * kg;
+            f.b[g][n2] = make_float4(k0 < K ? wp[k0] : 0.f, k0 + 1 < K ? wp[k0 + 1] : 0.f, k0 + 2 < K ? wp[k0 + 2] : 0.f,
+                                     k0 + 3 < K ? wp[k0 + 3] : 0.f);
+        }
+}
+
+// rows [row0, row0+64) x K floats (contiguous in memory) -> xs[r][k], rows beyond `rows` zero; pad columns untouched
+template <int K>
 __device__ __forceinline__ void stage_rows(const float* __restrict__ x, int64_t row0, int64_t rows, float* xs) {
-    // TR x K floats, contiguous in memory (row stride K): coalesced linear copy, zero padded
     const int64_t base = row0 * K;
     const int64_t lim = rows * K;
-    for (int i = threadIdx.x; i < TR * K; i += 256) xs[i] = (base + i < lim) ? x[base + i] : 0.f;
+    for (int i = threadIdx.x; i < TR * K; i += 256) {
+        const int r = i / K, k = i - r * K;
+        xs[r * Dims<K>::LDX + k] = (base + i < lim) ? x[base + i] : 0.f;
+    }
+}
+template <int K>
+__device__ __forceinline__ void zero_pad(float* xs) {
+    constexpr int PADW = Dims<K>::LDX - K;
+    for (int i = threadIdx.x; i < TR * PADW; i += 256) {
+        const int r = i / PADW, k = K + (i - r * PADW);
+        xs[r * Dims<K>::LDX + k] = 0.f;
+    }
+}
+
+// acc[m][n2] = x_tile * W_kind^T for this wave's 32 columns (no bias)
+template <int K, bool TWO>
+__device__ __forceinline__ void z_tile(const float* xs, const int* ks, const WSlice<K>& w0, const WSlice<K>& w1,
+                                       f32x4 (&acc)[MT][2]) {
+    const int lane = threadIdx.x & 63, r16 = lane & 15, kg = lane >> 4;
+    acc_zero<MT>(acc);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const bool k1 = TWO && ks[16 * m + r16] != 0;
+#pragma unroll
+        for (int g = 0; g < Dims<K>::G; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(xs + (16 * m + r16) * Dims<K>::LDX + 16 * g + 4 * kg);
+            const float4 a0 = k1 ? f4zero() : a;
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) {
+                const float4 b = w0.b[g][n2];
+                acc[m][n2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc[m][n2], 0, 0, 0);
+                acc[m][n2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc[m][n2], 0, 0, 0);
+                acc[m][n2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc[m][n2], 0, 0, 0);
+                acc[m][n2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc[m][n2], 0, 0, 0);
+            }
+            if (TWO) {
+                const float4 a1 = k1 ? a : f4zero();
+#pragma unroll
+                for (int n2 = 0; n2 < 2; ++n2) {
+                    const float4 b = w1.b[g][n2];
+                    acc[m][n2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, acc[m][n2], 0, 0, 0);
+                    acc[m][n2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, acc[m][n2], 0, 0, 0);
+                    acc[m][n2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, acc[m][n2], 0, 0, 0);
+                    acc[m][n2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, acc[m][n2], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float4 ld4_or_zero(const float* p, int c4) {
+    return p ? *reinterpret_cast<const float4*>(p + 4 * c4) : f4zero();
 }
 
 template <int K, bool TWO>
@@ -34,16 +116,17 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
                                                         const float* __restrict__ W0, const float* __restrict__ b0,
                                                         const float* __restrict__ W1, const float* __restrict__ b1,
                                                         int act, float* __restrict__ out) {
-    __shared__ float xs[TR * K];
+    __shared__ __attribute__((aligned(16))) float xs[TR * Dims<K>::LDX];
+    __shared__ __attribute__((aligned(16))) float Ds[TR * LDT];
     __shared__ int ks[TR];
-    const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
-    float w0[K], w1[TWO ? K : 1];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        w0[k] = W0[c * K + k];
-        if (TWO) w1[k] = W1[c * K + k];
-    }
-    const float bias0 = b0 ? b0[c] : 0.f, bias1 = (TWO && b1) ? b1[c] : 0.f;
+    const int wc = (threadIdx.x >> 6) * 32;
+    WSlice<K> w0, w1;
+    load_wslice<K>(w0, W0, wc);
+    if (TWO) load_wslice<K>(w1, W1, wc);
+    const int c4 = threadIdx.x & 31;
+    const float4 bias0 = ld4_or_zero(b0, c4), bias1 = TWO ? ld4_or_zero(b1, c4) : f4zero();
+    zero_pad<K>(xs);
+    if (threadIdx.x < TR) ks[threadIdx.x] = 0;
     const int64_t ntiles = (rows + TR - 1) / TR;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row0 = tile * TR;
@@ -51,29 +134,16 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
         stage_rows<K>(x, row0, rows, xs);
         if (TWO && threadIdx.x < TR) ks[threadIdx.x] = (row0 + threadIdx.x < rows) ? kind[row0 + threadIdx.x] : 0;
         __syncthreads();
-        // RU rows in flight per thread: independent accumulators hide the LDS-broadcast + FMA latency
-        for (int r0 = half * (TR / 2); r0 < (half + 1) * (TR / 2); r0 += RU) {
-            float z[RU];
-            bool k1[RU];
-#pragma unroll
-            for (int u = 0; u < RU; ++u) {
-                k1[u] = TWO && ks[r0 + u] != 0;
-                z[u] = k1[u] ? bias1 : bias0;
-            }
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-#pragma unroll
-                for (int u = 0; u < RU; ++u) {
-                    const float w = TWO ? (k1[u] ? w1[k] : w0[k]) : w0[k];
-                    z[u] = fmaf(w, xs[(r0 + u) * K + k], z[u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < RU; ++u) {
-                const int64_t g = row0 + r0 + u;
-                if (g < rows) out[g * DOUT + c] = act ? z[u] * sigmoid_fast(z[u]) : z[u];
-            }
-        }
+        f32x4 acc[MT][2];
+        z_tile<K, TWO>(xs, ks, w0, w1, acc);
+        acc_to_lds<MT>(acc, Ds, wc, load_bias2(nullptr, 0));
+        __syncthreads();
+        sweep_rows<TR>([&](int r, int c) {
+            const int64_t g = row0 + r;
+            if (g >= rows) return;
+            const float4 z = f4add(lds4(Ds, r, c), (TWO && ks[r]) ? bias1 : bias0);
+            stg4(out, g, DOUT, c, act ? f4silu(z) : z);
+        });
     }
 }
 
@@ -85,27 +155,38 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ W1, const float* __restrict__ b1,
                                                         int act, const float* __restrict__ gout,
                                                         float* __restrict__ partial, float* __restrict__ dx) {
-    constexpr int RED = DOUT * (2 * K + 2);           // final cross-half reduction scratch
-    constexpr int DZ = DX ? TR * (DOUT + 1) : 0;      // dz tile for the dx phase
-    __shared__ float xs[TR * K];
+    constexpr int G = Dims<K>::G, LDX = Dims<K>::LDX;
+    __shared__ __attribute__((aligned(16))) float xs[TR * LDX];
+    __shared__ __attribute__((aligned(16))) float Ds[TR * LDT];
     __shared__ int ks[TR];
-    __shared__ float dzs[RED > DZ ? RED : DZ];
-    __shared__ float ws[DX ? DOUT * K : 1];           // W0 for the dx phase (single-kind layers only)
-    const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
-    float w0[K], g0[K], w1[TWO ? K : 1], g1[TWO ? K : 1];
-    float gb0 = 0.f, gb1 = 0.f;
+    const int lane = threadIdx.x & 63, r16 = lane & 15, kg = lane >> 4;
+    const int wave = threadIdx.x >> 6, wc = wave * 32;
+    WSlice<K> w0, w1;
+    load_wslice<K>(w0, W0, wc);
+    if (TWO) load_wslice<K>(w1, W1, wc);
+    const int c4 = threadIdx.x & 31;
+    const float4 bias0 = ld4_or_zero(b0, c4), bias1 = TWO ? ld4_or_zero(b1, c4) : f4zero();
+    // dx = dz * W0: B[k = c][j = input k] for this wave's row tile; c runs over all 128 columns (K == 16 only)
+    float4 wdx[DX ? DOUT / 16 : 1];
+    if (DX) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        w0[k] = W0[c * K + k];
-        g0[k] = 0.f;
-        if (TWO) {
-            w1[k] = W1[c * K + k];
-            g1[k] = 0.f;
+        for (int q = 0; q < DOUT / 16; ++q) {
+            const float* wp = W0 + (size_t)(16 * q + 4 * kg) * K + r16;
+            wdx[q] = make_float4(wp[0], wp[K], wp[2 * K], wp[3 * K]);
         }
     }
-    if (DX)
-        for (int i = threadIdx.x; i < DOUT * K; i += 256) ws[i] = W0[i];
-    const float bias0 = b0 ? b0[c] : 0.f, bias1 = (TWO && b1) ? b1[c] : 0.f;
+    // dW accumulators: columns [wc, wc+32) as two 16-row (c) tiles x G k-tiles, per kind
+    f32x4 dw0[2][G], dw1[TWO ? 2 : 1][TWO ? G : 1];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            dw0[a][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (TWO) dw1[a][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    float4 dbs0 = f4zero(), dbs1 = f4zero();              // bias gradients of this thread's float4 column, its rows
+    zero_pad<K>(xs);
+    if (threadIdx.x < TR) ks[threadIdx.x] = 0;
     const int64_t ntiles = (rows + TR - 1) / TR;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row0 = tile * TR;
@@ -113,87 +194,91 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
         stage_rows<K>(x, row0, rows, xs);
         if (TWO && threadIdx.x < TR) ks[threadIdx.x] = (row0 + threadIdx.x < rows) ? kind[row0 + threadIdx.x] : 0;
         __syncthreads();
-        for (int r0 = half * (TR / 2); r0 < (half + 1) * (TR / 2); r0 += RU) {
-            float z[RU], dz[RU];
-            bool k1[RU];
-#pragma unroll
-            for (int u = 0; u < RU; ++u) {
-                const int64_t g = row0 + r0 + u;
-                k1[u] = TWO && ks[r0 + u] != 0;
-                z[u] = k1[u] ? bias1 : bias0;
-                dz[u] = g < rows ? gout[g * DOUT + c] : 0.f;
+        {
+            f32x4 acc[MT][2];
+            z_tile<K, TWO>(xs, ks, w0, w1, acc);
+            acc_to_lds<MT>(acc, Ds, wc, load_bias2(nullptr, 0));
+        }
+        __syncthreads();
+        // dz = g * act'(z), in place; bias gradients
+        sweep_rows<TR>([&](int r, int c) {
+            const int64_t g = row0 + r;
+            float4 dz = f4zero();
+            if (g < rows) {
+                const bool k1 = TWO && ks[r];
+                dz = ldg4(gout, g, DOUT, c);
+                if (act) dz = f4mul(dz, f4dsilu(f4add(lds4(Ds, r, c), k1 ? bias1 : bias0)));
+                if (k1) dbs1 = f4add(dbs1, dz);
+                else dbs0 = f4add(dbs0, dz);
             }
+            st_lds4(Ds, r, c, dz);
+        });
+        __syncthreads();
+        // dW[c][k] += sum_r dz[r][c] * x[r][k]: MFMA with the row index as the reduction dimension
+#pragma unroll 4
+        for (int s = 0; s < TR / 4; ++s) {
+            const int r = 4 * s + kg;
+            const bool k1 = TWO && ks[r] != 0;
+            float av[2], bv[G];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
+            for (int a = 0; a < 2; ++a) av[a] = Ds[r * LDT + wc + 16 * a + r16];
 #pragma unroll
-                for (int u = 0; u < RU; ++u) {
-                    const float w = TWO ? (k1[u] ? w1[k] : w0[k]) : w0[k];
-                    z[u] = fmaf(w, xs[(r0 + u) * K + k], z[u]);
+            for (int g = 0; g < G; ++g) bv[g] = xs[r * LDX + 16 * g + r16];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    dw0[a][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(k1 ? 0.f : av[a], bv[g], dw0[a][g], 0, 0, 0);
+                    if (TWO) dw1[a][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(k1 ? av[a] : 0.f, bv[g], dw1[a][g], 0, 0, 0);
                 }
-            }
-#pragma unroll
-            for (int u = 0; u < RU; ++u) {
-                if (act) {
-                    const float sg = sigmoid_fast(z[u]);
-                    dz[u] *= sg * (1.0f + z[u] * (1.0f - sg));
-                }
-                if (DX) dzs[(r0 + u) * (DOUT + 1) + c] = dz[u];
-                if (k1[u]) gb1 += dz[u];
-                else gb0 += dz[u];
-            }
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-#pragma unroll
-                for (int u = 0; u < RU; ++u) {
-                    const float xv = xs[(r0 + u) * K + k];
-                    if (TWO) {
-                        g0[k] = fmaf(k1[u] ? 0.f : dz[u], xv, g0[k]);
-                        g1[k] = fmaf(k1[u] ? dz[u] : 0.f, xv, g1[k]);
-                    } else {
-                        g0[k] = fmaf(dz[u], xv, g0[k]);
-                    }
-                }
-            }
         }
         if (DX) {
-            __syncthreads();
-            // dx[row][k] = sum_c dz[row][c] * W0[c][k]
-            for (int o = threadIdx.x; o < TR * K; o += 256) {
-                const int r = o / K, k = o - r * K;
-                const int64_t g = row0 + r;
-                if (g >= rows) continue;
-                float s0 = 0.f, s1 = 0.f;
-#pragma unroll 8
-                for (int cc = 0; cc < DOUT; cc += 2) {
-                    s0 = fmaf(dzs[r * (DOUT + 1) + cc], ws[cc * K + k], s0);
-                    s1 = fmaf(dzs[r * (DOUT + 1) + cc + 1], ws[(cc + 1) * K + k], s1);
-                }
-                dx[g * K + k] = s0 + s1;
+            // dx[r][k] = sum_c dz[r][c] * W0[c][k]; wave w owns rows [16w, 16w+16) of the tile
+            f32x4 ax = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < DOUT / 16; ++q) {
+                const float4 a = *reinterpret_cast<const float4*>(Ds + (16 * wave + r16) * LDT + 16 * q + 4 * kg);
+                ax = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wdx[q].x, ax, 0, 0, 0);
+                ax = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wdx[q].y, ax, 0, 0, 0);
+                ax = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wdx[q].z, ax, 0, 0, 0);
+                ax = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wdx[q].w, ax, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t g = row0 + 16 * wave + 4 * kg + r;
+                if (g < rows) dx[g * K + r16] = ax[r];
             }
         }
     }
-    // the two row-halves of a column are combined through LDS (reuse dzs), then written as this workgroup's partial
-    __syncthreads();
-    float* red = dzs;
-    if (half == 1) {
+    // workgroup partial: dW tiles straight from the accumulators (element (c = wc + 16a + 4kg + r, k = 16g + r16)),
+    // bias gradients through LDS (8 row groups x 128 columns per kind, summed in order)
+    float* p = partial + (int64_t)blockIdx.x * (2 * DOUT * K + 2 * DOUT);
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            red[c * (2 * K + 2) + k] = g0[k];
-            if (TWO) red[c * (2 * K + 2) + K + k] = g1[k];
-        }
-        red[c * (2 * K + 2) + 2 * K] = gb0;
-        red[c * (2 * K + 2) + 2 * K + 1] = gb1;
-    }
-    __syncthreads();
-    if (half == 0) {
-        float* p = partial + (int64_t)blockIdx.x * (2 * DOUT * K + 2 * DOUT);
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            p[c * K + k] = g0[k] + red[c * (2 * K + 2) + k];
-            if (TWO) p[DOUT * K + c * K + k] = g1[k] + red[c * (2 * K + 2) + K + k];
+        for (int g = 0; g < G; ++g) {
+            const int k = 16 * g + r16;
+            if (k < K) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = wc + 16 * a + 4 * kg + r;
+                    p[c * K + k] = dw0[a][g][r];
+                    if (TWO) p[DOUT * K + c * K + k] = dw1[a][g][r];
+                }
+            }
         }
-        p[2 * DOUT * K + c] = gb0 + red[c * (2 * K + 2) + 2 * K];
-        p[2 * DOUT * K + DOUT + c] = gb1 + red[c * (2 * K + 2) + 2 * K + 1];
+    __syncthreads();
+    float* red = Ds;                                        // [2][8][128]
+    const int rg = threadIdx.x >> 5;
+    *reinterpret_cast<float4*>(red + rg * DOUT + 4 * c4) = dbs0;
+    *reinterpret_cast<float4*>(red + 8 * DOUT + rg * DOUT + 4 * c4) = dbs1;
+    __syncthreads();
+    {
+        const int kd = threadIdx.x >> 7, c = threadIdx.x & 127;
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[kd * 8 * DOUT + q * DOUT + c];
+        p[2 * DOUT * K + kd * DOUT + c] = t;
     }
 }
 
@@ -233,7 +318,7 @@ constexpr int FWD_CAP = 1024, BWD_CAP = 256;
 template <int K>
 int launch_fwd(const float* x, int64_t rows, const int32_t* kind, const float* W0, const float* b0, const float* W1,
                const float* b1, int act, float* out, hipStream_t st) {
-    if (kind)
+    if (W1)
         hipLaunchKernelGGL((embed_fwd_kernel<K, true>), dim3(grid_for(rows, FWD_CAP)), dim3(256), 0, st, x, rows, kind,
                            W0, b0, W1, b1, act, out);
     else
@@ -283,7 +368,7 @@ extern "C" int pamnet_embed_fwd_f32(const float* x, int64_t rows, int64_t K, con
                                     pamnet_stream_t stream) {
     if (rows < 0 || (K != 16 && K != 18 && K != 42)) return PAMNET_EINVAL;
     if (rows == 0) return PAMNET_OK;
-    if (!x || !W0 || !out || (kind && !W1)) return PAMNET_ENULL;
+    if (!x || !W0 || !out || (kind && !W1) || (W1 && !kind)) return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
     if (K == 16) return launch_fwd<16>(x, rows, kind, W0, b0, W1, b1, act, out, st);
     if (K == 18) return launch_fwd<18>(x, rows, kind, W0, b0, W1, b1, act, out, st);
