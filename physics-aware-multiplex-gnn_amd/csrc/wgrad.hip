@@ -137,20 +137,32 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, float* __restri
             }
             colsum += (double)((s0 + s1) + (s2 + s3));
         }
+        // operands of k-step st+1 are requested before the MFMAs of step st are issued (explicit register double
+        // buffer): left alone, the compiler issues each ds_read right before its s_waitcnt and the LDS latency shows up
+        // twice per k-step (12 400 instead of 8 192 cycles per 64-row block, tools/wgrad_probe.py)
+        float za[2][4], ab[2][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            za[0][t] = Zs[kg * LDW + i0 + 16 * t + r16];
+            ab[0][t] = As[kg * LDW + j0 + 16 * t + r16];
+        }
 #pragma unroll
         for (int st = 0; st < RB / 4; ++st) {
-            const int r = 4 * st + kg;
-            float za[4], ab[4];
+            const int cur = st & 1, nxt = cur ^ 1;
+            if (st + 1 < RB / 4) {
+                const int r = 4 * (st + 1) + kg;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                za[t] = Zs[r * LDW + i0 + 16 * t + r16];
-                ab[t] = As[r * LDW + j0 + 16 * t + r16];
+                for (int t = 0; t < 4; ++t) {
+                    za[nxt][t] = Zs[r * LDW + i0 + 16 * t + r16];
+                    ab[nxt][t] = As[r * LDW + j0 + 16 * t + r16];
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);                 // keep the requests above this step's MFMAs
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a], ab[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[cur][a], ab[cur][b], acc[a][b], 0, 0, 0);
         }
         WPROBE(4 * it + 2);
         __syncthreads();
