@@ -154,12 +154,16 @@ __device__ __forceinline__ void sweep(int mt, F&& f) {
 }
 
 // rows [beg, end) of this workgroup and its chunking: per = 16-row tiles per workgroup, cmt = tiles per chunk
+// workgroup b owns base (+1 for the first `rem` workgroups) consecutive 16-row tiles
 struct Span {
     int64_t beg, end;
     int cmt;
-    __device__ __forceinline__ Span(int64_t m, int per, int cmt_) : cmt(cmt_) {
-        beg = (int64_t)blockIdx.x * per * 16;
-        const int64_t e = beg + (int64_t)per * 16;
+    __device__ __forceinline__ Span(int64_t m, int base, int rem, int cmt_) : cmt(cmt_) {
+        const int b = blockIdx.x;
+        const int64_t t0 = (int64_t)b * base + (b < rem ? b : rem);
+        const int64_t cnt = base + (b < rem ? 1 : 0);
+        beg = t0 * 16;
+        const int64_t e = (t0 + cnt) * 16;
         end = e < m ? e : m;
     }
 };
@@ -184,8 +188,8 @@ __global__ __launch_bounds__(WG8) void global_edge_fwd_kernel(const float* __res
                                                               const float* __restrict__ Pi, const float* __restrict__ Pj,
                                                               const int32_t* __restrict__ row_of,
                                                               const int32_t* __restrict__ col, float* __restrict__ z,
-                                                              float* __restrict__ ea, float* __restrict__ msg, int per,
-                                                              int cmt) {
+                                                              float* __restrict__ ea, float* __restrict__ msg, int base,
+                                                              int rem, int cmt) {
     __shared__ __attribute__((aligned(16))) float lds[2 * MT2 * 16 * LDT];
     float* S0 = lds;
     float* S1 = lds + MT2 * 16 * LDT;
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(WG8) void global_edge_fwd_kernel(const float* __res
     WFrag1 f1, f2;
     load_wfrag1<false>(f1, We, ld_we, wc);
     load_wfrag1<false>(f2, Wea, ld_wea, wc);
-    const Span sp(m, per, cmt);
+    const Span sp(m, base, rem, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
         sweep<MT2>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(e, row0 + r, sp.end, DIM, c4)); });
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(WG8) void global_edge_bwd_kernel(const float* __res
                                                               const float* __restrict__ We, int ld_we,
                                                               const float* __restrict__ Wea, int ld_wea,
                                                               float* __restrict__ dz, float* __restrict__ dea,
-                                                              float* __restrict__ d_e, int accumulate, int per, int cmt) {
+                                                              float* __restrict__ d_e, int accumulate, int base, int rem, int cmt) {
     __shared__ __attribute__((aligned(16))) float lds[2 * MT2 * 16 * LDT];
     float* S0 = lds;
     float* S1 = lds + MT2 * 16 * LDT;
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(WG8) void global_edge_bwd_kernel(const float* __res
     WFrag1 f1, f2;
     load_wfrag1<true>(f1, We, ld_we, wc);
     load_wfrag1<true>(f2, Wea, ld_wea, wc);
-    const Span sp(m, per, cmt);
+    const Span sp(m, base, rem, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
         sweep<MT2>(mt, [&](int r, int c4) {
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(WG8) void local_edge_fwd_kernel(const float* __rest
                                                              const int32_t* __restrict__ col, float* __restrict__ z_ji,
                                                              float* __restrict__ z_kj, float* __restrict__ q2,
                                                              float* __restrict__ q3, float* __restrict__ m_ji,
-                                                             float* __restrict__ m_nb, int per, int cmt) {
+                                                             float* __restrict__ m_nb, int base, int rem, int cmt) {
     __shared__ __attribute__((aligned(16))) float lds[3 * MT3 * 16 * LDT];
     float* S0 = lds;
     float* S1 = lds + MT3 * 16 * LDT;
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(WG8) void local_edge_fwd_kernel(const float* __rest
     load_wfrag1<false>(f1, w.W[1], w.ld[1], wc);
     load_wfrag1<false>(f0, w.W[0], w.ld[0], wc);
     load_wfrag1<false>(f3, w.W[3], w.ld[3], wc);
-    const Span sp(m, per, cmt);
+    const Span sp(m, base, rem, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
         sweep<MT3>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(rbf, row0 + r, sp.end, DIM, c4)); });
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(const float* __rest
                                                              const float* __restrict__ q2, LocalW w,
                                                              float* __restrict__ dz_ji, float* __restrict__ dz_kj,
                                                              float* __restrict__ dq2, float* __restrict__ d_rbf,
-                                                             int accumulate, int per, int cmt) {
+                                                             int accumulate, int base, int rem, int cmt) {
     __shared__ __attribute__((aligned(16))) float lds[2 * MT2 * 16 * LDT];
     float* S0 = lds;
     float* S1 = lds + MT2 * 16 * LDT;
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(const float* __rest
     load_wfrag1<true>(f1, w.W[1], w.ld[1], wc);
     load_wfrag1<true>(f2, w.W[2], w.ld[2], wc);
     load_wfrag1<true>(f3, w.W[3], w.ld[3], wc);
-    const Span sp(m, per, cmt);
+    const Span sp(m, base, rem, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
         Acc<MT2> acc;
@@ -424,8 +428,8 @@ struct Mlp2Set {
 struct Mlp2Batch {
     Mlp2Set s[8];
 };
-__global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__ x, int64_t m, Mlp2Batch batch, int per,
-                                                       int cmt) {
+__global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__ x, int64_t m, Mlp2Batch batch, int base,
+                                                       int rem, int cmt) {
     const float* __restrict__ W1 = batch.s[blockIdx.y].W1;
     const float* __restrict__ b1 = batch.s[blockIdx.y].b1;
     const float* __restrict__ W2 = batch.s[blockIdx.y].W2;
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__
     WFrag1 f1, f2;
     load_wfrag1<false>(f1, W1, DIM, wc);
     load_wfrag1<false>(f2, W2, DIM, wc);
-    const Span sp(m, per, cmt);
+    const Span sp(m, base, rem, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
         sweep<MT2>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(x, row0 + r, sp.end, DIM, c4)); });
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(WG8) void mlp2_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ z1, const float* __restrict__ z2,
                                                        const float* __restrict__ W1, const float* __restrict__ W2,
                                                        float* __restrict__ dz1, float* __restrict__ dz2,
-                                                       float* __restrict__ dx, int accumulate, int per, int cmt) {
+                                                       float* __restrict__ dx, int accumulate, int base, int rem, int cmt) {
     __shared__ __attribute__((aligned(16))) float lds[2 * MT2 * 16 * LDT];
     float* S0 = lds;
     float* S1 = lds + MT2 * 16 * LDT;
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(WG8) void mlp2_bwd_kernel(const float* __restrict__
     WFrag1 f1, f2;
     load_wfrag1<true>(f2, W2, DIM, wc);
     load_wfrag1<true>(f1, W1, DIM, wc);
-    const Span sp(m, per, cmt);
+    const Span sp(m, base, rem, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
         sweep<MT2>(mt, [&](int r, int c4) {
@@ -541,16 +545,20 @@ __global__ __launch_bounds__(WG8) void mlp2_bwd_kernel(const float* __restrict__
 // One balanced wave of workgroups: `per` 16-row tiles each (<= N_CU workgroups), walked in chunks of `cmt` <= cap tiles.
 struct Plan {
     unsigned grid;
-    int per, cmt;
+    int base, rem, cmt;
 };
+// (Two co-resident workgroups per CU with half the rows each -- 4-tile chunks, 128 VGPRs -- measured slower: 40 / 55 us
+//  against 36 / 41 us for the global edge kernels; they contend for the matrix pipe instead of overlapping phases.)
 inline Plan plan(int64_t rows, int cap) {
     const int64_t tiles16 = ceil_div(rows, 16);
     const int64_t per = ceil_div(tiles16, N_CU);
+    const int64_t grid = ceil_div(tiles16, per);
     const int64_t nchunk = ceil_div(per, cap);
     Plan p;
-    p.per = (int)per;
+    p.grid = (unsigned)grid;
+    p.base = (int)(tiles16 / grid);
+    p.rem = (int)(tiles16 % grid);
     p.cmt = (int)ceil_div(per, nchunk);
-    p.grid = (unsigned)ceil_div(tiles16, per);
     return p;
 }
 
@@ -565,7 +573,7 @@ extern "C" int pamnet_global_edge_fwd_f32(const float* e, int64_t n_edges, const
     if (!e || !We || !bm || !Wea || !Pi || !Pj || !row_of || !col || !z || !ea || !msg) return PAMNET_ENULL;
     const Plan p = plan(n_edges, MT2);
     hipLaunchKernelGGL(global_edge_fwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), e, n_edges, We, (int)ld_we,
-                       bm, Wea, (int)ld_wea, Pi, Pj, row_of, col, z, ea, msg, p.per, p.cmt);
+                       bm, Wea, (int)ld_wea, Pi, Pj, row_of, col, z, ea, msg, p.base, p.rem, p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -579,7 +587,7 @@ extern "C" int pamnet_global_edge_bwd_f32(const float* d_agg, const int32_t* row
     if (!d_agg || !row_of || !z || !ea || !We || !Wea || !dz || !dea || !d_e) return PAMNET_ENULL;
     const Plan p = plan(n_edges, MT2);
     hipLaunchKernelGGL(global_edge_bwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), d_agg, row_of, n_edges, z,
-                       ea, We, (int)ld_we, Wea, (int)ld_wea, dz, dea, d_e, (int)accumulate, p.per, p.cmt);
+                       ea, We, (int)ld_we, Wea, (int)ld_wea, dz, dea, d_e, (int)accumulate, p.base, p.rem, p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -608,7 +616,7 @@ extern "C" int pamnet_local_edge_fwd_f32(const float* rbf, int64_t n_edges, cons
     if (rc) return rc;
     const Plan p = plan(n_edges, MT3);
     hipLaunchKernelGGL(local_edge_fwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), rbf, n_edges, w, b_ji, b_kj,
-                       row_of, col, z_ji, z_kj, q2, q3, m_ji, m_nb, p.per, p.cmt);
+                       row_of, col, z_ji, z_kj, q2, q3, m_ji, m_nb, p.base, p.rem, p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -626,7 +634,7 @@ extern "C" int pamnet_local_edge_bwd_f32(const float* d_mji, const float* d_mnb,
     if (rc) return rc;
     const Plan p = plan(n_edges, MT2);
     hipLaunchKernelGGL(local_edge_bwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), d_mji, d_mnb, d_q3, n_edges,
-                       z_ji, z_kj, q2, w, dz_ji, dz_kj, dq2, d_rbf, (int)accumulate, p.per, p.cmt);
+                       z_ji, z_kj, q2, w, dz_ji, dz_kj, dq2, d_rbf, (int)accumulate, p.base, p.rem, p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -639,7 +647,7 @@ extern "C" int pamnet_mlp2_fwd_f32(const float* x, int64_t rows, const float* W1
     const Plan p = plan(rows, MT2);
     Mlp2Batch b;
     for (int k = 0; k < 8; ++k) b.s[k] = Mlp2Set{W1, b1, W2, b2, z1, z2, y};
-    hipLaunchKernelGGL(mlp2_fwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), x, rows, b, p.per, p.cmt);
+    hipLaunchKernelGGL(mlp2_fwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), x, rows, b, p.base, p.rem, p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -661,8 +669,8 @@ extern "C" int pamnet_mlp2_fwd_multi_f32(const float* x, int64_t rows, int64_t n
                          outs[3 * s], outs[3 * s + 1], outs[3 * s + 2]};
     }
     const Plan p = plan(rows, MT2);
-    hipLaunchKernelGGL(mlp2_fwd_kernel, dim3(p.grid, (unsigned)nsets), dim3(WG8), 0, as_stream(stream), x, rows, b, p.per,
-                       p.cmt);
+    hipLaunchKernelGGL(mlp2_fwd_kernel, dim3(p.grid, (unsigned)nsets), dim3(WG8), 0, as_stream(stream), x, rows, b, p.base,
+                       p.rem, p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -675,7 +683,7 @@ extern "C" int pamnet_mlp2_bwd_f32(const float* dy, int64_t rows, const float* z
     if (!dy || !z1 || !z2 || !W1 || !W2 || !dz1 || !dz2 || !dx) return PAMNET_ENULL;
     const Plan p = plan(rows, MT2);
     hipLaunchKernelGGL(mlp2_bwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), dy, rows, z1, z2, W1, W2, dz1, dz2,
-                       dx, (int)accumulate, p.per, p.cmt);
+                       dx, (int)accumulate, p.base, p.rem, p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
