@@ -82,8 +82,9 @@ def scatter_add_roofline(dev, g, d, stream_gb):
     src = torch.randn(M, d, device=dev)
     out = torch.empty(R, d, device=dev)
     fn = lambda: ops.segment_sum_raw(out, None, src, None, None, None, None, ptr, R, d)
-    fn()
-    ms = event_time_ms(fn, 10)
+    for _ in range(3):
+        fn()
+    ms = event_time_ms(fn, 20)
     by = 4.0 * d * M + 4.0 * (R + 1) + 4.0 * d * R
     res['streamed'] = dict(rows_in=M, rows_out=R, bytes=by, ms=ms, gbs=by / ms / 1e6)
     return res
