@@ -90,10 +90,15 @@ __global__ __launch_bounds__(WG) void node_pre_bwd_kernel(const float* __restric
                                                           const float* wp1, const float* wp2, const float* wp3,
                                                           int ldwp, int nblk, const float* __restrict__ Zx1,
                                                           float* __restrict__ dZx1, float* __restrict__ dx) {
-    __shared__ __attribute__((aligned(16))) float lds[3 * SLOT];
-    float* S0 = lds;
+    // every input tile (up to 4 projection-gradient planes, z_x1, the direct d x1 and the residual gradient) is
+    // requested in ONE burst up front: the chain below then holds no global load except the weight slices
+    __shared__ __attribute__((aligned(16))) float lds[9 * SLOT];
+    float* S0 = lds;                       // GEMM output / final d x
     float* S1 = lds + SLOT;
     float* S2 = lds + 2 * SLOT;
+    float* PL = lds + 3 * SLOT;            // [4] dP planes
+    float* ZT = lds + 7 * SLOT;            // z_x1 tile
+    float* DT = lds + 8 * SLOT;            // d x1_direct tile
     const int64_t row0 = (int64_t)blockIdx.x * BMN;
     const float* wps[4] = {wp0, wp1, wp2, wp3};
     const int64_t plane_p = n * DIM;                       // dP: nblk planes [N][128]
@@ -102,39 +107,38 @@ __global__ __launch_bounds__(WG) void node_pre_bwd_kernel(const float* __restric
     acc_zero<1>(acc);
     WFrag wf;
     load_wfrag<true>(wf, wps[0], ldwp, wcol0);
+    sweep_rows<BMN>([&](int r, int c4) {
+        const int64_t g = row0 + r;
+        for (int b = 0; b < nblk; ++b) st_lds4(PL + b * SLOT, r, c4, ldg4z(dP + (int64_t)b * plane_p, g, n, DIM, c4));
+        st_lds4(ZT, r, c4, ldg4z(Zx1, g, n, DIM, c4));
+        st_lds4(DT, r, c4, dx1_direct ? ldg4z(dx1_direct, g, n, DIM, c4) : f4zero());
+        st_lds4(S0, r, c4, d_add ? ldg4z(d_add, g, n, DIM, c4) : f4zero());
+    });
+    __syncthreads();
     for (int b = 0; b < nblk; ++b) {
-        sweep_rows<BMN>([&](int r, int c4) {
-            const int64_t g = row0 + r;
-            st_lds4(S0, r, c4, ldg4z(dP + (int64_t)b * plane_p, g, n, DIM, c4));
-        });
-        __syncthreads();
-        mma_tile_frag<1>(S0, wf, acc);                        // accumulate over the projection blocks
+        mma_tile_frag<1>(PL + b * SLOT, wf, acc);             // accumulate over the projection blocks
         if (b + 1 < nblk) load_wfrag<true>(wf, wps[b + 1], ldwp, wcol0);
-        else load_wfrag<true>(wf, Wx1, DIM, wcol0);           // weights of the final GEMM: in flight during the sweep
-        __syncthreads();
+        else load_wfrag<true>(wf, Wx1, DIM, wcol0);           // weights of the final GEMM
     }
     acc_to_lds<1>(acc, S1, wcol0, load_bias2(nullptr, wcol0));
     __syncthreads();
     sweep_rows<BMN>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        float4 dz = f4zero();
-        if (g < n) {
-            float4 d1 = lds4(S1, r, c4);
-            if (dx1_direct) d1 = f4add(d1, ldg4(dx1_direct, g, DIM, c4));
-            dz = f4mul(d1, f4dsilu(ldg4(Zx1, g, DIM, c4)));
-            stg4(dZx1, g, DIM, c4, dz);
-        }
-        st_lds4(S2, r, c4, dz);
+        const float4 d1 = f4add(lds4(S1, r, c4), lds4(DT, r, c4));
+        st_lds4(S2, r, c4, f4mul(d1, f4dsilu(lds4(ZT, r, c4))));      // dz (zero rows beyond n: dP, DT are zero there)
     });
     __syncthreads();
-    gemm16<true>(S2, wf, nullptr, S0, nullptr);
+    {
+        f32x4 a2[1][2];
+        acc_zero<1>(a2);
+        mma_tile_frag<1>(S2, wf, a2);
+        acc_to_lds<1>(a2, S1, wcol0, load_bias2(nullptr, wcol0));
+    }
+    __syncthreads();
     sweep_rows<BMN>([&](int r, int c4) {
         const int64_t g = row0 + r;
-        if (g < n) {
-            float4 v = lds4(S0, r, c4);
-            if (d_add) v = f4add(v, ldg4(d_add, g, DIM, c4));
-            stg4(dx, g, DIM, c4, v);
-        }
+        if (g >= n) return;
+        stg4(dZx1, g, DIM, c4, lds4(S2, r, c4));
+        stg4(dx, g, DIM, c4, f4add(lds4(S1, r, c4), lds4(S0, r, c4)));
     });
 }
 
