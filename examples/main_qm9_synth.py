@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""The reference's QM9 driver loop (main_qm9.py:79-132) on the MI355X path, with QM9-schema synthetic molecules standing
+in for the dataset (QM9 itself needs the RDKit-based reader + download, out of scope):
+
+    python examples/main_qm9_synth.py --epochs 2 --train 2048 --val 256 --batch_size 128
+    python -m torch.distributed.run --nproc-per-node 8 examples/main_qm9_synth.py ...      # molecule-sharded DP
+
+Same hyper-parameters and schedule as the reference: Adam(lr, wd=0), warm-up over the first epoch then
+ExponentialLR(0.9961697) stepped per iteration with the fractional epoch, clip_grad_norm_(1000), EMA(0.999) evaluated
+under assign/resume, best-validation checkpoint of `model.state_dict()` (keys identical to the reference's).
+"""
+import argparse
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, 'physics-aware-multiplex-gnn_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from models import PAMNet, PAMNet_s, Config  # noqa: E402   (the drop-in for the reference's `models`)
+from pamnet_amd import synth  # noqa: E402
+from pamnet_amd.train import Trainer, WarmupExpLR, shard_range  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--model', default='PAMNet', choices=['PAMNet', 'PAMNet_s'])
+    ap.add_argument('--epochs', type=int, default=2)
+    ap.add_argument('--lr', type=float, default=1e-4)
+    ap.add_argument('--wd', type=float, default=0.0)
+    ap.add_argument('--n_layer', type=int, default=6)
+    ap.add_argument('--dim', type=int, default=128)
+    ap.add_argument('--batch_size', type=int, default=128, help='global batch (split over the ranks)')
+    ap.add_argument('--cutoff_l', type=float, default=5.0)
+    ap.add_argument('--cutoff_g', type=float, default=5.0)
+    ap.add_argument('--train', type=int, default=2048, help='synthetic training molecules')
+    ap.add_argument('--val', type=int, default=256)
+    ap.add_argument('--seed', type=int, default=480)
+    ap.add_argument('--save', default='')
+    args = ap.parse_args()
+
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    torch.manual_seed(args.seed)                                   # identical initial weights on every rank
+
+    cfg = Config(dataset='QM9', dim=args.dim, n_layer=args.n_layer, cutoff_l=args.cutoff_l, cutoff_g=args.cutoff_g)
+    model = (PAMNet if args.model == 'PAMNet' else PAMNet_s)(cfg).to(dev)
+    trainer = Trainer(model, lr=args.lr, weight_decay=args.wd, ema_decay=0.999, max_grad_norm=1000.0, world_size=world)
+    if rank == 0:
+        print('Number of model parameters: ', sum(p.numel() for p in model.parameters() if p.requires_grad))
+
+    gb = args.batch_size
+    steps_per_epoch = args.train // gb
+    sched = WarmupExpLR(args.lr, gamma=0.9961697, steps_per_epoch=args.train / gb)
+
+    def train_batch(step):                                         # this rank's shard of global batch `step`
+        lo, hi = shard_range(gb, rank, world)
+        return synth.qm9_batch(args.seed, step * gb + lo, hi - lo).to(dev)
+
+    vlo, vhi = shard_range(args.val, rank, world)
+    val = [synth.qm9_batch(args.seed + 1, args.train + vlo + i, min(gb, vhi - vlo - i)).to(dev)
+           for i in range(0, vhi - vlo, gb)]
+
+    best = None
+    for epoch in range(args.epochs):
+        model.train()
+        loss_sum = torch.zeros((), device=dev)
+        nxt = train_batch(0)
+        for step in range(steps_per_epoch):
+            data, nxt = nxt, (train_batch(step + 1) if step + 1 < steps_per_epoch else None)
+            loss = trainer.step(data, lr=sched.lr_at(epoch, step) if (epoch or step) else args.lr / steps_per_epoch,
+                                global_graphs=gb, next_data=nxt)
+            loss_sum += loss.detach() * data.num_graphs
+        if world > 1:
+            dist.all_reduce(loss_sum)
+        val_mae = trainer.evaluate(val)                            # under the EMA weights (main_qm9.py:29-37)
+        if best is None or val_mae <= best:
+            best = val_mae
+            if args.save and rank == 0:
+                torch.save(model.state_dict(), args.save)
+        if rank == 0:
+            print('Epoch: {:03d}, Train MAE: {:.7f}, Val MAE: {:.7f}'.format(epoch + 1, float(loss_sum) / args.train, val_mae))
+    if rank == 0:
+        print('Best Validation MAE:', best)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
