@@ -246,6 +246,9 @@ int pamnet_embed_bwd_f32(const float* x, int64_t rows, int64_t K, const int32_t*
  *                mlp_sbf.1.W, .b, lin_rbf.W, lin_rbf_out.W, tail ...}
  *   saved/temp : caller-owned arenas sized by pamnet_stack_workspace (floats); `saved` must survive until the backward
  *   outs/atts  : [2*n_layer, n] rows ordered (global_0, local_0, global_1, ...)
+ * Forward, save_for_backward = 0 (inference): tensors only the backward reads are not written (the single kernels take
+ * null for those outputs: z / ea, z_ji / z_kj / q2, z1 / z2, Z / R, Zx1); `saved` still holds the forward's own
+ * intermediates and the per-layer node features.
  * Forward, optional fork: `aux_stream` + `aux_events` (n_layer + 1 hipEvent_t handles, both nullable): the per-layer
  * triplet/pair MLPs (independent of the node features) are enqueued on aux_stream up front and joined by event where
  * each layer consumes them; event 0 marks the inputs ready on `stream`.
@@ -261,7 +264,8 @@ int pamnet_stack_layout(int64_t n, int64_t eg, int64_t el, int64_t tp, int64_t* 
 int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, int64_t n_layer, const float* x0,
                          const float* e_g, const float* rbf_e, const float* e_sbf, const float* const* gparams,
                          const float* const* lparams, float* saved, float* temp, float* outs, float* atts,
-                         pamnet_stream_t aux_stream, void* const* aux_events, pamnet_stream_t stream);
+                         int32_t save_for_backward, pamnet_stream_t aux_stream, void* const* aux_events,
+                         pamnet_stream_t stream);
 int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, int64_t n_layer, const float* x0,
                          const float* e_g, const float* rbf_e, const float* e_sbf, const float* const* gparams,
                          const float* const* lparams, const float* saved, float* temp, const float* d_outs,

@@ -218,8 +218,8 @@ __global__ __launch_bounds__(WG8) void global_edge_fwd_kernel(const float* __res
             const int64_t i = row_of[g], j = col[g];
             const float4 zz = f4add(f4add(lds4(S0, r, c4), ldg4(Pi, i, DIM, c4)), ldg4(Pj, j, DIM, c4));
             const float4 gate = lds4(S1, r, c4);
-            stg4(z, g, DIM, c4, zz);
-            stg4(ea, g, DIM, c4, gate);
+            if (z) stg4(z, g, DIM, c4, zz);                    // backward-only saves: null in inference mode
+            if (ea) stg4(ea, g, DIM, c4, gate);
             stg4(msg, g, DIM, c4, f4mul(f4silu(zz), gate));
         });
         __syncthreads();
@@ -322,8 +322,8 @@ __global__ __launch_bounds__(WG8) void local_edge_fwd_kernel(const float* __rest
             const int64_t i = row_of[g], j = col[g];
             const float4 zz = f4add(f4add(lds4(S1, r, c4), ldg4(w.P[1], i, DIM, c4)), ldg4(w.P[3], j, DIM, c4));
             const float4 gate = lds4(S2, r, c4);
-            stg4(z_kj, g, DIM, c4, zz);
-            stg4(q2, g, DIM, c4, gate);
+            if (z_kj) stg4(z_kj, g, DIM, c4, zz);
+            if (q2) stg4(q2, g, DIM, c4, gate);
             stg4(m_nb, g, DIM, c4, f4mul(f4silu(zz), gate));
         });
         __syncthreads();
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(WG8) void local_edge_fwd_kernel(const float* __rest
             if (g >= sp.end) return;
             const int64_t i = row_of[g], j = col[g];
             const float4 zz = f4add(f4add(lds4(S1, r, c4), ldg4(w.P[0], i, DIM, c4)), ldg4(w.P[2], j, DIM, c4));
-            stg4(z_ji, g, DIM, c4, zz);
+            if (z_ji) stg4(z_ji, g, DIM, c4, zz);
             stg4(m_ji, g, DIM, c4, f4silu(zz));
             stg4(q3, g, DIM, c4, lds4(S2, r, c4));
         });
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__
             const int64_t g = row0 + r;
             const float4 zz = lds4(S1, r, c4);
             st_lds4(S1, r, c4, f4silu(zz));
-            if (g < sp.end) stg4(z1, g, DIM, c4, zz);
+            if (z1 && g < sp.end) stg4(z1, g, DIM, c4, zz);
         });
         __syncthreads();
         PROBE(4);
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__
             const int64_t g = row0 + r;
             if (g >= sp.end) return;
             const float4 zz = lds4(S0, r, c4);
-            stg4(z2, g, DIM, c4, zz);
+            if (z2) stg4(z2, g, DIM, c4, zz);
             stg4(y, g, DIM, c4, f4silu(zz));
         });
         __syncthreads();
@@ -570,7 +570,7 @@ extern "C" int pamnet_global_edge_fwd_f32(const float* e, int64_t n_edges, const
                                           float* ea, float* msg, pamnet_stream_t stream) {
     if (n_edges < 0) return PAMNET_EINVAL;
     if (n_edges == 0) return PAMNET_OK;
-    if (!e || !We || !bm || !Wea || !Pi || !Pj || !row_of || !col || !z || !ea || !msg) return PAMNET_ENULL;
+    if (!e || !We || !bm || !Wea || !Pi || !Pj || !row_of || !col || !msg) return PAMNET_ENULL;   // z, ea: optional saves
     const Plan p = plan(n_edges, MT2);
     hipLaunchKernelGGL(global_edge_fwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), e, n_edges, We, (int)ld_we,
                        bm, Wea, (int)ld_wea, Pi, Pj, row_of, col, z, ea, msg, p.base, p.rem, p.cmt);
@@ -609,7 +609,7 @@ extern "C" int pamnet_local_edge_fwd_f32(const float* rbf, int64_t n_edges, cons
                                          float* q3, float* m_ji, float* m_nb, pamnet_stream_t stream) {
     if (n_edges < 0) return PAMNET_EINVAL;
     if (n_edges == 0) return PAMNET_OK;
-    if (!rbf || !Wq || !ldq || !b_ji || !b_kj || !P || !row_of || !col || !z_ji || !z_kj || !q2 || !q3 || !m_ji || !m_nb)
+    if (!rbf || !Wq || !ldq || !b_ji || !b_kj || !P || !row_of || !col || !q3 || !m_ji || !m_nb)   // z_ji, z_kj, q2: optional
         return PAMNET_ENULL;
     LocalW w;
     int rc = fill_local(w, Wq, ldq, P);
@@ -643,7 +643,7 @@ extern "C" int pamnet_mlp2_fwd_f32(const float* x, int64_t rows, const float* W1
                                    const float* b2, float* z1, float* z2, float* y, pamnet_stream_t stream) {
     if (rows < 0) return PAMNET_EINVAL;
     if (rows == 0) return PAMNET_OK;
-    if (!x || !W1 || !b1 || !W2 || !b2 || !z1 || !z2 || !y) return PAMNET_ENULL;
+    if (!x || !W1 || !b1 || !W2 || !b2 || !y) return PAMNET_ENULL;                  // z1, z2: optional saves
     const Plan p = plan(rows, MT2);
     Mlp2Batch b;
     for (int k = 0; k < 8; ++k) b.s[k] = Mlp2Set{W1, b1, W2, b2, z1, z2, y};
@@ -663,8 +663,7 @@ extern "C" int pamnet_mlp2_fwd_multi_f32(const float* x, int64_t rows, int64_t n
         const int s = k < nsets ? k : 0;
         for (int i = 0; i < 4; ++i)
             if (!params[4 * s + i]) return PAMNET_ENULL;
-        for (int i = 0; i < 3; ++i)
-            if (!outs[3 * s + i]) return PAMNET_ENULL;
+        if (!outs[3 * s + 2]) return PAMNET_ENULL;            // z1, z2 (outs[3s], outs[3s+1]) are optional saves
         b.s[k] = Mlp2Set{params[4 * s], params[4 * s + 1], params[4 * s + 2], params[4 * s + 3],
                          outs[3 * s], outs[3 * s + 1], outs[3 * s + 2]};
     }

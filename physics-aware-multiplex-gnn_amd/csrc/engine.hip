@@ -207,8 +207,8 @@ static int fill_graph(Graph& g, const int64_t* sizes, const int32_t* const* idx)
 extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, int64_t n_layer,
                                     const float* x0, const float* e_g, const float* rbf_e, const float* e_sbf,
                                     const float* const* gparams, const float* const* lparams, float* saved, float* temp,
-                                    float* outs, float* atts, pamnet_stream_t aux, void* const* aux_events,
-                                    pamnet_stream_t st) {
+                                    float* outs, float* atts, int32_t save_for_backward, pamnet_stream_t aux,
+                                    void* const* aux_events, pamnet_stream_t st) {
     Graph g;
     CK(fill_graph(g, sizes, graph_idx));
     if (n_layer < 1) return PAMNET_EINVAL;
@@ -216,6 +216,10 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
     const Temp t = carve_temp(temp, g);
     const int64_t gs = al(global_saved_floats(g)), ls = al(local_saved_floats(g));
     const float* x = x0;
+    // Inference mode (save_for_backward = 0): tensors only the backward reads (pre-activations, gates, residual taps)
+    // are not written at all -- about half of the forward's HBM writes.  `sv(p)` = p or null.
+    const bool keep = save_for_backward != 0;
+    auto sv = [keep](float* p) -> float* { return keep ? p : nullptr; };
     // The triplet/pair MLP s_k = mlp_sbf_k(e_sbf) does not depend on the node features: with an auxiliary stream all
     // n_layer of them are enqueued up front and run beside the node-level kernels of the first layers, which occupy
     // only ceil(n/16) of the 256 CUs.  Event 0 = inputs ready, event 1+k = s_k ready.
@@ -230,7 +234,7 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
                 const float* const* lp = lparams + (k0 + k) * NL;
                 const LocalSaved q = carve_local(saved + (k0 + k) * (gs + ls) + gs, g);
                 prm[4 * k] = lp[6], prm[4 * k + 1] = lp[7], prm[4 * k + 2] = lp[8], prm[4 * k + 3] = lp[9];
-                out[3 * k] = q.z1, out[3 * k + 1] = q.z2, out[3 * k + 2] = q.s;
+                out[3 * k] = sv(q.z1), out[3 * k + 1] = sv(q.z2), out[3 * k + 2] = q.s;
             }
             CK(pamnet_mlp2_fwd_multi_f32(e_sbf, g.tp, nk, prm, out, st));
         }
@@ -242,7 +246,7 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         for (int64_t k = 0; k < n_layer; ++k) {
             const float* const* lp = lparams + k * NL;
             const LocalSaved q = carve_local(saved + k * (gs + ls) + gs, g);
-            CK(pamnet_mlp2_fwd_f32(e_sbf, g.tp, lp[6], lp[7], lp[8], lp[9], q.z1, q.z2, q.s, aux));
+            CK(pamnet_mlp2_fwd_f32(e_sbf, g.tp, lp[6], lp[7], lp[8], lp[9], sv(q.z1), sv(q.z2), q.s, aux));
             HK(hipEventRecord(reinterpret_cast<hipEvent_t>(aux_events[1 + k]), a));
         }
     }
@@ -252,23 +256,23 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         const GlobalSaved s = carve_global(saved + k * (gs + ls), g);
         const float* wpg[2] = {gp[2], gp[2] + D};
         // the head of every layer but the first runs inside the preceding layer's node chain (x_out tile still on chip)
-        if (k == 0) CK(pamnet_node_pre_fwd_f32(x, g.n, gp[0], gp[1], wpg, 3 * D, 2, s.Zx1, t.x1, t.P, st));
+        if (k == 0) CK(pamnet_node_pre_fwd_f32(x, g.n, gp[0], gp[1], wpg, 3 * D, 2, sv(s.Zx1), t.x1, t.P, st));
         CK(pamnet_global_edge_fwd_f32(e_g, g.eg, gp[2] + 2 * D, 3 * D, gp[3], gp[4], D, t.P, t.P + g.n * D, g.g_row,
-                                      g.g_col, s.z, s.ea, t.msg, st));
+                                      g.g_col, sv(s.z), sv(s.ea), t.msg, st));
         CK(pamnet_segment_sum_f32(s.x2, t.x1, t.msg, nullptr, nullptr, nullptr, nullptr, g.g_ptr, g.n, D, st));
         const float* const* lp = lparams + k * NL;
         const LocalSaved q = carve_local(saved + k * (gs + ls) + gs, g);
         const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
-        CK(pamnet_node_tail_fwd_f32(s.x2, x, g.n, gp + GT, gp + GT + 10, gp[GT + 20], gp[GT + 21], gp[GT + 22], s.Z, s.R,
-                                    s.xout, outs + (2 * k) * g.n, atts + (2 * k) * g.n, lp[0], lp[1], wpl, 3 * D, 4,
-                                    q.Zx1, t.x1, t.P, st));
+        CK(pamnet_node_tail_fwd_f32(s.x2, x, g.n, gp + GT, gp + GT + 10, gp[GT + 20], gp[GT + 21], gp[GT + 22], sv(s.Z),
+                                    sv(s.R), s.xout, outs + (2 * k) * g.n, atts + (2 * k) * g.n, lp[0], lp[1], wpl, 3 * D,
+                                    4, sv(q.Zx1), t.x1, t.P, st));
         x = s.xout;
         // ---------------- local layer (layers/local_message_passing.py:36-66); its head ran in the chain above
         const float* wq[4] = {lp[2] + 2 * D, lp[4] + 2 * D, lp[10], lp[11]};
         const int64_t ldq[4] = {3 * D, 3 * D, D, D};
         const float* planes[4] = {t.P, t.P + g.n * D, t.P + 2 * g.n * D, t.P + 3 * g.n * D};
-        CK(pamnet_local_edge_fwd_f32(rbf_e, g.el, wq, ldq, lp[3], lp[5], planes, g.l_row, g.l_col, q.zji, q.zkj, q.q2,
-                                     q.q3, t.mji, q.mnb, st));
+        CK(pamnet_local_edge_fwd_f32(rbf_e, g.el, wq, ldq, lp[3], lp[5], planes, g.l_row, g.l_col, sv(q.zji), sv(q.zkj),
+                                     sv(q.q2), q.q3, t.mji, q.mnb, st));
         if (forked) HK(hipStreamWaitEvent(as_stream(st), reinterpret_cast<hipEvent_t>(aux_events[1 + k]), 0));
         CK(pamnet_segment_sum_f32(q.mt, t.mji, q.mnb, g.t_col, q.s, nullptr, nullptr, g.t_ptr, g.el, D, st));
         CK(pamnet_segment_sum_f32(q.x2, t.x1, q.mt, nullptr, q.q3, nullptr, nullptr, g.l_ptr, g.n, D, st));
@@ -276,13 +280,13 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
             const float* const* gn = gparams + (k + 1) * NG;
             const GlobalSaved sn = carve_global(saved + (k + 1) * (gs + ls), g);
             const float* wpn[2] = {gn[2], gn[2] + D};
-            CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22], q.Z,
-                                        q.R, q.xout, outs + (2 * k + 1) * g.n, atts + (2 * k + 1) * g.n, gn[0], gn[1],
-                                        wpn, 3 * D, 2, sn.Zx1, t.x1, t.P, st));
+            CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22],
+                                        sv(q.Z), sv(q.R), q.xout, outs + (2 * k + 1) * g.n, atts + (2 * k + 1) * g.n,
+                                        gn[0], gn[1], wpn, 3 * D, 2, sv(sn.Zx1), t.x1, t.P, st));
         } else {
-            CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22], q.Z,
-                                        q.R, q.xout, outs + (2 * k + 1) * g.n, atts + (2 * k + 1) * g.n, nullptr, nullptr,
-                                        nullptr, 0, 0, nullptr, nullptr, nullptr, st));
+            CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22],
+                                        sv(q.Z), sv(q.R), q.xout, outs + (2 * k + 1) * g.n, atts + (2 * k + 1) * g.n,
+                                        nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, st));
         }
         x = q.xout;
     }

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(WG) void node_pre_fwd_kernel(const float* __restric
         const float4 a = f4silu(z);
         st_lds4(S1, r, c4, a);
         if (g < n) {
-            stg4(Zx1, g, DIM, c4, z);
+            if (Zx1) stg4(Zx1, g, DIM, c4, z);                // backward-only save: null in inference mode
             stg4(x1, g, DIM, c4, a);
         }
     });
@@ -149,7 +149,7 @@ extern "C" int pamnet_node_pre_fwd_f32(const float* x, int64_t n, const float* W
                                        float* P, pamnet_stream_t stream) {
     if (n < 0 || nblk < 1 || nblk > 4) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
-    if (!x || !Wx1 || !bx1 || !wp || !Zx1 || !x1 || !P) return PAMNET_ENULL;
+    if (!x || !Wx1 || !bx1 || !wp || !x1 || !P) return PAMNET_ENULL;           // Zx1: optional save
     const float* w[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int b = 0; b < nblk; ++b) w[b] = wp[b];
     hipLaunchKernelGGL(node_pre_fwd_kernel, dim3((unsigned)ceil_div(n, BMN)), dim3(WG), 0, as_stream(stream), x, n, Wx1,

@@ -191,10 +191,12 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
     sweep_rows<BMN>([&](int r, int c4) {
         const int64_t g = row0 + r;
         if (g >= n) return;
+        if (Z) {                                              // backward-only saves: null in inference mode
 #pragma unroll
-        for (int k = 0; k < 10; ++k) stg4(Z + (int64_t)k * plane, g, DIM, c4, lds4(ZL + k * SLOT, r, c4));
-        stg4(R, g, DIM, c4, lds4(TL, r, c4));
-        stg4(R + plane, g, DIM, c4, lds4(TL + SLOT, r, c4));
+            for (int k = 0; k < 10; ++k) stg4(Z + (int64_t)k * plane, g, DIM, c4, lds4(ZL + k * SLOT, r, c4));
+            stg4(R, g, DIM, c4, lds4(TL, r, c4));
+            stg4(R + plane, g, DIM, c4, lds4(TL + SLOT, r, c4));
+        }
         stg4(x_out, g, DIM, c4, lds4(TL + 2 * SLOT, r, c4));
     });
 
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
         sweep_rows<BMN>([&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g >= n) return;
-            stg4(nx.Zx1, g, DIM, c4, lds4(ZL, r, c4));
+            if (nx.Zx1) stg4(nx.Zx1, g, DIM, c4, lds4(ZL, r, c4));
             stg4(nx.x1, g, DIM, c4, lds4(ZL + SLOT, r, c4));
             for (int b = 0; b < nx.nblk; ++b) stg4(nx.P + (int64_t)b * plane, g, DIM, c4, lds4(ZL + (2 + b) * SLOT, r, c4));
         });
@@ -444,14 +446,14 @@ extern "C" int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int
                                         float* next_P, pamnet_stream_t stream) {
     if (n < 0 || next_nblk < 0 || next_nblk > 4) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
-    if (!x2 || !res_x || !weights || !biases || !w_out || !b_out || !w_att || !Z || !R || !x_out || !out || !att)
+    if (!x2 || !res_x || !weights || !biases || !w_out || !b_out || !w_att || (Z && !R) || !x_out || !out || !att)
         return PAMNET_ENULL;
     for (int k = 0; k < 10; ++k)
         if (!weights[k] || !biases[k]) return PAMNET_ENULL;
     PreNext nx{};
     nx.nblk = (int)next_nblk;
     if (next_nblk > 0) {
-        if (!next_Wx1 || !next_bx1 || !next_wp || !next_Zx1 || !next_x1 || !next_P) return PAMNET_ENULL;
+        if (!next_Wx1 || !next_bx1 || !next_wp || !next_x1 || !next_P) return PAMNET_ENULL;   // next_Zx1: optional save
         nx.Wx1 = next_Wx1, nx.bx1 = next_bx1, nx.ldwp = (int)next_ldwp;
         nx.Zx1 = next_Zx1, nx.x1 = next_x1, nx.P = next_P;
         for (int b = 0; b < next_nblk; ++b) {

@@ -478,7 +478,7 @@ class _Stack(torch.autograd.Function):
     (their gradients are written straight into the flat buffer): ~400 fewer edges for the autograd engine to walk."""
 
     @staticmethod
-    def forward(ctx, x0, e_g, rbf_e, e_sbf, graph, plan, direct, *params):
+    def forward(ctx, x0, e_g, rbf_e, e_sbf, graph, plan, direct, save, *params):
         x0, e_g, rbf_e, e_sbf = x0.contiguous(), e_g.contiguous(), rbf_e.contiguous(), e_sbf.contiguous()
         L = plan.L
         n = x0.size(0)
@@ -492,7 +492,8 @@ class _Stack(torch.autograd.Function):
         gtab, ltab = plan.param_tables()
         aux, evs = _aux_fork(x0.device, L)
         lib.call('pamnet_stack_fwd_f32', sizes, idx, L, lib.ptr(x0), lib.ptr(e_g), lib.ptr(rbf_e), lib.ptr(e_sbf),
-                 gtab, ltab, lib.ptr(saved), lib.ptr(temp), lib.ptr(outs), lib.ptr(atts), aux, evs, lib.stream_of(x0))
+                 gtab, ltab, lib.ptr(saved), lib.ptr(temp), lib.ptr(outs), lib.ptr(atts),
+                 1 if save else 0, aux, evs, lib.stream_of(x0))
         ctx.save_for_backward(x0, e_g, rbf_e, e_sbf, saved)
         ctx.graph, ctx.plan, ctx.direct, ctx.temp_floats = graph, plan, direct, int(need[1])
         ctx.mark_non_differentiable(saved)
@@ -523,7 +524,7 @@ class _Stack(torch.autograd.Function):
         lib.call('pamnet_stack_bwd_f32', sizes, idx, L, lib.ptr(x0), lib.ptr(e_g), lib.ptr(rbf_e), lib.ptr(e_sbf),
                  gtab, ltab, lib.ptr(saved), lib.ptr(temp), lib.ptr(g_outs), lib.ptr(g_atts), ggrad, lgrad,
                  lib.ptr(d_x0), lib.ptr(d_eg), lib.ptr(d_rbf), lib.ptr(d_sbf), evs, lib.stream_of(x0))
-        return (d_x0, d_eg, d_rbf, d_sbf, None, None, None) + tuple(g)
+        return (d_x0, d_eg, d_rbf, d_sbf, None, None, None, None) + tuple(g)
 
 
 def layer_stack(global_layers, local_layers, x0, e_g, rbf_e, e_sbf, graph):
@@ -532,9 +533,11 @@ def layer_stack(global_layers, local_layers, x0, e_g, rbf_e, e_sbf, graph):
     if plan is None or plan.L != len(global_layers):
         plan = StackPlan(global_layers, local_layers)
         global_layers._pamnet_plan = plan
-    if torch.is_grad_enabled() and plan.direct():
-        return _Stack.apply(x0, e_g, rbf_e, e_sbf, graph, plan, True)
-    return _Stack.apply(x0, e_g, rbf_e, e_sbf, graph, plan, False, *plan.flat)
+    # inference (no gradient mode): the engine skips every store only the backward would read
+    save = torch.is_grad_enabled()
+    if save and plan.direct():
+        return _Stack.apply(x0, e_g, rbf_e, e_sbf, graph, plan, True, True)
+    return _Stack.apply(x0, e_g, rbf_e, e_sbf, graph, plan, False, save, *plan.flat)
 
 
 def stack_x_layers(saved, graph, n_layer):
