@@ -293,3 +293,31 @@ def test_fuse_pool_fwd_bwd(dev):
         assert maxnorm_err(out.detach().cpu(), ref.detach()) < 5e-6
         assert maxnorm_err(outs.grad.cpu(), o64.grad) < 5e-6 and maxnorm_err(atts.grad.cpu(), a64.grad) < 5e-6
         outs.grad = atts.grad = None
+
+
+def test_cabi_argument_errors(dev):
+    """Every entry point validates its arguments before launching: negative sizes / unsupported widths -> PAMNET_EINVAL,
+    missing required pointers -> PAMNET_ENULL (surfaced as RuntimeError by the binding); zero rows are a no-op."""
+    from pamnet_amd import lib
+    x = torch.randn(8, 128, device=dev)
+    ptr = torch.tensor([0, 3, 8], dtype=torch.int32, device=dev)
+    out = torch.empty(2, 128, device=dev)
+    st = lib.stream_of(x)
+    with pytest.raises(RuntimeError, match='EINVAL'):
+        lib.call('pamnet_segment_sum_f32', lib.ptr(out), None, lib.ptr(x), None, None, None, None, lib.ptr(ptr), 2, 126, st)
+    with pytest.raises(RuntimeError, match='ENULL'):
+        lib.call('pamnet_segment_sum_f32', None, None, lib.ptr(x), None, None, None, None, lib.ptr(ptr), 2, 128, st)
+    with pytest.raises(RuntimeError, match='EINVAL'):
+        lib.call('pamnet_embed_fwd_f32', lib.ptr(x), 8, 17, None, lib.ptr(x), None, None, None, 1, lib.ptr(out), st)
+    with pytest.raises(RuntimeError, match='ENULL'):
+        lib.call('pamnet_mlp2_fwd_f32', lib.ptr(x), 8, None, None, None, None, None, None, lib.ptr(out), st)
+    with pytest.raises(RuntimeError, match='EINVAL'):
+        lib.call('pamnet_adam_ema_f32', lib.ptr(x), lib.ptr(x), lib.ptr(x), lib.ptr(x), lib.ptr(x), 1023, 1e-3, 0.9, 0.999,
+                 1e-8, 0.0, 1, 0.999, None, 1000.0, 0, st)
+    # zero rows: nothing is launched, nothing is touched
+    out.fill_(7.0)
+    lib.call('pamnet_segment_sum_f32', lib.ptr(out), None, lib.ptr(x), None, None, None, None, lib.ptr(ptr), 0, 128, st)
+    lib.call('pamnet_mlp2_fwd_f32', lib.ptr(x), 0, None, None, None, None, None, None, lib.ptr(out), st)
+    assert float(out.min()) == 7.0
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        lib.stream_of(torch.zeros(3))
