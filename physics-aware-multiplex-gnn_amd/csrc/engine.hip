@@ -3,7 +3,7 @@
 //
 // The reference drives this loop from Python, one small op at a time (~150 launches per layer pair); even with fused
 // kernels a Python-level loop leaves the MI355X idle behind the interpreter.  Here the host side is a straight C++
-// sequence of ~10 (forward) / ~20 (backward) kernel launches per layer pair on the caller's stream, working out of two
+// sequence of ~7 (forward) / ~16 (backward) kernel launches per layer pair on the caller's stream, working out of two
 // caller-owned arenas:
 //   saved : activations the backward needs (pre-activations, gates, residual taps), one slab per layer
 //   temp  : scratch reused by every layer (projections, messages, gradient staging, split-K partials)

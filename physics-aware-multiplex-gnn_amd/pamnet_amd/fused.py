@@ -1,12 +1,12 @@
-"""Per-layer autograd functions built from the fused fp32-MFMA kernels (csrc/node_chain.hip, csrc/edge_chain.hip,
-csrc/wgrad.hip) and the sorted segment-sum kernels (csrc/segment.hip).  dim = 128 only.
+"""Autograd functions over the fused fp32-MFMA kernels (csrc/*.hip through the C ABI).  dim = 128 only.
 
-One torch.autograd.Function per message-passing layer: its forward/backward are straight sequences of C-ABI kernel
-launches (no torch ops, no autograd tape inside a layer), and every parameter gradient of the layer is produced by
-ONE batched weight-gradient launch.  torch only provides the buffers and the tape between layers.
-
-Kernel count per layer pair (forward): 2 x node_pre, global_edge, local_edge, mlp2, 3 x segment-sum, 2 x node_tail = 10
-launches -- the reference issues ~150 for the same work.
+  * `layer_stack` / `_Stack`: the whole n_layer x (global, local) loop as ONE engine call per direction
+    (csrc/engine.hip) -- what models.PAMNet uses.  ~7 launches per layer pair forward, ~16 backward; the reference
+    issues ~150 per layer pair for the same work.
+  * `embed` / `_Embed`: the thin input-embedding layers (csrc/embed.hip).
+  * `global_layer`, `local_layer`, `node_tail`: one autograd function per layer / per node chain, built from the same
+    kernels -- the granularity the kernel-level parity tests (tests/test_hip_fused.py) exercise.
+torch only provides the buffers and the tape between these functions.
 """
 import ctypes
 import os
