@@ -284,6 +284,9 @@ struct LocalW {
     const float* P[4];      // node planes: ji_i, kj_i, ji_j, kj_j  ([N][128] each)
 };
 
+// blockIdx.y = 0: the k->j half (z_kj, q2, m_nb);  1: the j->i half (z_ji, m_ji, q3).  The two halves share only the
+// input tile, so they run as separate workgroups: two weight slices (64 VGPRs) and one epilogue each instead of four
+// slices and two dependent epilogues in a row -- E_l rows give only ~135 workgroups per half, the chip has room.
 __global__ __launch_bounds__(WG8) void local_edge_fwd_kernel(const float* __restrict__ rbf, int64_t m, LocalW w,
                                                              const float* __restrict__ b_ji,
                                                              const float* __restrict__ b_kj,
@@ -297,12 +300,13 @@ __global__ __launch_bounds__(WG8) void local_edge_fwd_kernel(const float* __rest
     float* S1 = lds + MT3 * 16 * LDT;
     float* S2 = lds + 2 * MT3 * 16 * LDT;
     const int wc = wave_col();
-    const float bkj = lane_bias(b_kj, wc), bji = lane_bias(b_ji, wc);
-    WFrag1 f0, f1, f2, f3;
-    load_wfrag1<false>(f2, w.W[2], w.ld[2], wc);
-    load_wfrag1<false>(f1, w.W[1], w.ld[1], wc);
-    load_wfrag1<false>(f0, w.W[0], w.ld[0], wc);
-    load_wfrag1<false>(f3, w.W[3], w.ld[3], wc);
+    const bool kj = blockIdx.y == 0;
+    const float bz = lane_bias(kj ? b_kj : b_ji, wc);
+    WFrag1 fz, fq;                                            // slice producing z (with bias), slice producing the gate
+    load_wfrag1<false>(fz, w.W[kj ? 1 : 0], w.ld[kj ? 1 : 0], wc);
+    load_wfrag1<false>(fq, w.W[kj ? 2 : 3], w.ld[kj ? 2 : 3], wc);
+    const float* __restrict__ Pi = w.P[kj ? 1 : 0];
+    const float* __restrict__ Pj = w.P[kj ? 3 : 2];
     const Span sp(m, base, rem, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
@@ -310,38 +314,27 @@ __global__ __launch_bounds__(WG8) void local_edge_fwd_kernel(const float* __rest
         __syncthreads();
         Acc<MT3> acc;
         acc.zero();
-        mma_n<MT3>(S0, f2, acc, mt);                          // q2 = lin_rbf r (the gate)
+        mma_n<MT3>(S0, fq, acc, mt);                          // q2 = lin_rbf r   |  q3 = lin_rbf_out r
         acc_store<MT3>(acc, S2, wc, 0.f, mt);
         acc.zero();
-        mma_n<MT3>(S0, f1, acc, mt);                          // W_kj,e r + b_kj
-        acc_store<MT3>(acc, S1, wc, bkj, mt);
+        mma_n<MT3>(S0, fz, acc, mt);                          // W_kj,e r + b_kj  |  W_ji,e r + b_ji
+        acc_store<MT3>(acc, S1, wc, bz, mt);
         __syncthreads();
         sweep<MT3>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g >= sp.end) return;
             const int64_t i = row_of[g], j = col[g];
-            const float4 zz = f4add(f4add(lds4(S1, r, c4), ldg4(w.P[1], i, DIM, c4)), ldg4(w.P[3], j, DIM, c4));
+            const float4 zz = f4add(f4add(lds4(S1, r, c4), ldg4(Pi, i, DIM, c4)), ldg4(Pj, j, DIM, c4));
             const float4 gate = lds4(S2, r, c4);
-            if (z_kj) stg4(z_kj, g, DIM, c4, zz);
-            if (q2) stg4(q2, g, DIM, c4, gate);
-            stg4(m_nb, g, DIM, c4, f4mul(f4silu(zz), gate));
-        });
-        __syncthreads();
-        acc.zero();
-        mma_n<MT3>(S0, f0, acc, mt);                          // W_ji,e r + b_ji
-        acc_store<MT3>(acc, S1, wc, bji, mt);
-        acc.zero();
-        mma_n<MT3>(S0, f3, acc, mt);                          // q3 = lin_rbf_out r
-        acc_store<MT3>(acc, S2, wc, 0.f, mt);
-        __syncthreads();
-        sweep<MT3>(mt, [&](int r, int c4) {
-            const int64_t g = row0 + r;
-            if (g >= sp.end) return;
-            const int64_t i = row_of[g], j = col[g];
-            const float4 zz = f4add(f4add(lds4(S1, r, c4), ldg4(w.P[0], i, DIM, c4)), ldg4(w.P[2], j, DIM, c4));
-            if (z_ji) stg4(z_ji, g, DIM, c4, zz);
-            stg4(m_ji, g, DIM, c4, f4silu(zz));
-            stg4(q3, g, DIM, c4, lds4(S2, r, c4));
+            if (kj) {
+                if (z_kj) stg4(z_kj, g, DIM, c4, zz);         // z_*, q2: backward-only saves, null in inference mode
+                if (q2) stg4(q2, g, DIM, c4, gate);
+                stg4(m_nb, g, DIM, c4, f4mul(f4silu(zz), gate));
+            } else {
+                if (z_ji) stg4(z_ji, g, DIM, c4, zz);
+                stg4(m_ji, g, DIM, c4, f4silu(zz));
+                stg4(q3, g, DIM, c4, gate);
+            }
         });
         __syncthreads();
     }
@@ -549,9 +542,9 @@ struct Plan {
 };
 // (Two co-resident workgroups per CU with half the rows each -- 4-tile chunks, 128 VGPRs -- measured slower: 40 / 55 us
 //  against 36 / 41 us for the global edge kernels; they contend for the matrix pipe instead of overlapping phases.)
-inline Plan plan(int64_t rows, int cap) {
+inline Plan plan(int64_t rows, int cap, int target_wgs = N_CU) {
     const int64_t tiles16 = ceil_div(rows, 16);
-    const int64_t per = ceil_div(tiles16, N_CU);
+    const int64_t per = ceil_div(tiles16, target_wgs);
     const int64_t grid = ceil_div(tiles16, per);
     const int64_t nchunk = ceil_div(per, cap);
     Plan p;
@@ -614,8 +607,8 @@ extern "C" int pamnet_local_edge_fwd_f32(const float* rbf, int64_t n_edges, cons
     LocalW w;
     int rc = fill_local(w, Wq, ldq, P);
     if (rc) return rc;
-    const Plan p = plan(n_edges, MT3);
-    hipLaunchKernelGGL(local_edge_fwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), rbf, n_edges, w, b_ji, b_kj,
+    const Plan p = plan(n_edges, MT3, N_CU / 2);            // two halves (grid.y): together one workgroup per CU
+    hipLaunchKernelGGL(local_edge_fwd_kernel, dim3(p.grid, 2), dim3(WG8), 0, as_stream(stream), rbf, n_edges, w, b_ji, b_kj,
                        row_of, col, z_ji, z_kj, q2, q3, m_ji, m_nb, p.base, p.rem, p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
