@@ -342,6 +342,9 @@ __global__ __launch_bounds__(WG8) void local_edge_fwd_kernel(const float* __rest
 
 // dz_ji = d_mji * SiLU'(z_ji);  dz_kj = d_mnb * q2 * SiLU'(z_kj);  dq2 = d_mnb * SiLU(z_kj);  dq3 given.
 // d_rbf (+)= dz_ji W_ji,e + dz_kj W_kj,e + dq2 W_lin_rbf + dq3 W_lin_rbf_out
+// MTX = tiles per chunk (LDS and register footprint follow it): the local graph is small, 3 is plenty and keeps the four
+// weight slices + accumulators free of scratch spills (the 8-tile instantiation needed 172 B/lane)
+template <int MTX>
 __global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(const float* __restrict__ d_mji,
                                                              const float* __restrict__ d_mnb,
                                                              const float* __restrict__ d_q3, int64_t m,
@@ -351,9 +354,9 @@ __global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(const float* __rest
                                                              float* __restrict__ dz_ji, float* __restrict__ dz_kj,
                                                              float* __restrict__ dq2, float* __restrict__ d_rbf,
                                                              int accumulate, int base, int rem, int cmt) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * MT2 * 16 * LDT];
+    __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
     float* S0 = lds;
-    float* S1 = lds + MT2 * 16 * LDT;
+    float* S1 = lds + MTX * 16 * LDT;
     const int wc = wave_col();
     WFrag1 f0, f1, f2, f3;
     load_wfrag1<true>(f0, w.W[0], w.ld[0], wc);
@@ -363,10 +366,10 @@ __global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(const float* __rest
     const Span sp(m, base, rem, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
-        Acc<MT2> acc;
+        Acc<MTX> acc;
         acc.zero();
         // pass A: dz_ji -> S0, dz_kj -> S1
-        sweep<MT2>(mt, [&](int r, int c4) {
+        sweep<MTX>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             float4 a = f4zero(), b = f4zero();
             if (g < sp.end) {
@@ -379,11 +382,11 @@ __global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(const float* __rest
             st_lds4(S1, r, c4, b);
         });
         __syncthreads();
-        mma_n<MT2>(S0, f0, acc, mt);
-        mma_n<MT2>(S1, f1, acc, mt);
+        mma_n<MTX>(S0, f0, acc, mt);
+        mma_n<MTX>(S1, f1, acc, mt);
         __syncthreads();
         // pass B: dq2 -> S0, dq3 -> S1
-        sweep<MT2>(mt, [&](int r, int c4) {
+        sweep<MTX>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             float4 a = f4zero(), b = f4zero();
             if (g < sp.end) {
@@ -395,12 +398,12 @@ __global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(const float* __rest
             st_lds4(S1, r, c4, b);
         });
         __syncthreads();
-        mma_n<MT2>(S0, f2, acc, mt);
-        mma_n<MT2>(S1, f3, acc, mt);
+        mma_n<MTX>(S0, f2, acc, mt);
+        mma_n<MTX>(S1, f3, acc, mt);
         __syncthreads();
-        acc_store<MT2>(acc, S0, wc, 0.f, mt);
+        acc_store<MTX>(acc, S0, wc, 0.f, mt);
         __syncthreads();
-        sweep<MT2>(mt, [&](int r, int c4) {
+        sweep<MTX>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g >= sp.end) return;
             float4 v = lds4(S0, r, c4);
@@ -625,8 +628,9 @@ extern "C" int pamnet_local_edge_bwd_f32(const float* d_mji, const float* d_mnb,
     LocalW w;
     int rc = fill_local(w, Wq, ldq, nullptr);
     if (rc) return rc;
-    const Plan p = plan(n_edges, MT2);
-    hipLaunchKernelGGL(local_edge_bwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), d_mji, d_mnb, d_q3, n_edges,
+    constexpr int MTL = 3;
+    const Plan p = plan(n_edges, MTL);
+    hipLaunchKernelGGL(local_edge_bwd_kernel<MTL>, dim3(p.grid), dim3(WG8), 0, as_stream(stream), d_mji, d_mnb, d_q3, n_edges,
                        z_ji, z_kj, q2, w, dz_ji, dz_kj, dq2, d_rbf, (int)accumulate, p.base, p.rem, p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
