@@ -55,8 +55,7 @@ namespace {
 
 constexpr int WG8 = 512;                  // 8 waves
 constexpr int N_CU = 256;                 // MI355X
-constexpr int MT2 = 8;                    // 16-row tiles per chunk, kernels with two LDS slots (2 x 128 rows = 132 KB)
-constexpr int MT3 = 6;                    // ... with three LDS slots (3 x 96 rows = 149 KB)
+constexpr int MT2 = 8;                    // largest chunk (16-row tiles) of the two-slot kernels (2 x 128 rows = 132 KB)
 
 // one 128 x 16 weight slice of a wave: 8 x float4 = 32 VGPRs
 struct WFrag1 {
@@ -181,6 +180,7 @@ __device__ __forceinline__ float lane_bias(const float* __restrict__ b, int wc) 
 }
 
 // -------------------------------------------------------------------------------------------------- global edges
+template <int MTX>
 __global__ __launch_bounds__(WG8) void global_edge_fwd_kernel(const float* __restrict__ e, int64_t m,
                                                               const float* __restrict__ We, int ld_we,
                                                               const float* __restrict__ bm,
@@ -190,9 +190,9 @@ __global__ __launch_bounds__(WG8) void global_edge_fwd_kernel(const float* __res
                                                               const int32_t* __restrict__ col, float* __restrict__ z,
                                                               float* __restrict__ ea, float* __restrict__ msg, int base,
                                                               int rem, int cmt) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * MT2 * 16 * LDT];
+    __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
     float* S0 = lds;
-    float* S1 = lds + MT2 * 16 * LDT;
+    float* S1 = lds + MTX * 16 * LDT;
     const int wc = wave_col();
     const float bv = lane_bias(bm, wc);
     WFrag1 f1, f2;
@@ -201,18 +201,18 @@ __global__ __launch_bounds__(WG8) void global_edge_fwd_kernel(const float* __res
     const Span sp(m, base, rem, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
-        sweep<MT2>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(e, row0 + r, sp.end, DIM, c4)); });
+        sweep<MTX>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(e, row0 + r, sp.end, DIM, c4)); });
         __syncthreads();
-        Acc<MT2> au, aa;
+        Acc<MTX> au, aa;
         au.zero();
         aa.zero();
-        mma_n<MT2>(S0, f1, au, mt);
-        mma_n<MT2>(S0, f2, aa, mt);
+        mma_n<MTX>(S0, f1, au, mt);
+        mma_n<MTX>(S0, f2, aa, mt);
         __syncthreads();                                   // every wave is done reading the e tile
-        acc_store<MT2>(au, S0, wc, bv, mt);
-        acc_store<MT2>(aa, S1, wc, 0.f, mt);
+        acc_store<MTX>(au, S0, wc, bv, mt);
+        acc_store<MTX>(aa, S1, wc, 0.f, mt);
         __syncthreads();
-        sweep<MT2>(mt, [&](int r, int c4) {
+        sweep<MTX>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g >= sp.end) return;
             const int64_t i = row_of[g], j = col[g];
@@ -227,6 +227,7 @@ __global__ __launch_bounds__(WG8) void global_edge_fwd_kernel(const float* __res
 }
 
 // dm[e] = d_agg[i(e)];  dz = dm * ea * SiLU'(z);  dea = dm * SiLU(z);  d_e (+)= dz * W_e + dea * W_ea
+template <int MTX>
 __global__ __launch_bounds__(WG8) void global_edge_bwd_kernel(const float* __restrict__ d_agg,
                                                               const int32_t* __restrict__ row_of, int64_t m,
                                                               const float* __restrict__ z, const float* __restrict__ ea,
@@ -234,9 +235,9 @@ __global__ __launch_bounds__(WG8) void global_edge_bwd_kernel(const float* __res
                                                               const float* __restrict__ Wea, int ld_wea,
                                                               float* __restrict__ dz, float* __restrict__ dea,
                                                               float* __restrict__ d_e, int accumulate, int base, int rem, int cmt) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * MT2 * 16 * LDT];
+    __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
     float* S0 = lds;
-    float* S1 = lds + MT2 * 16 * LDT;
+    float* S1 = lds + MTX * 16 * LDT;
     const int wc = wave_col();
     WFrag1 f1, f2;
     load_wfrag1<true>(f1, We, ld_we, wc);
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(WG8) void global_edge_bwd_kernel(const float* __res
     const Span sp(m, base, rem, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
-        sweep<MT2>(mt, [&](int r, int c4) {
+        sweep<MTX>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             float4 a = f4zero(), b = f4zero();
             if (g < sp.end) {
@@ -259,14 +260,14 @@ __global__ __launch_bounds__(WG8) void global_edge_bwd_kernel(const float* __res
             st_lds4(S1, r, c4, b);
         });
         __syncthreads();
-        Acc<MT2> acc;
+        Acc<MTX> acc;
         acc.zero();
-        mma_n<MT2>(S0, f1, acc, mt);
-        mma_n<MT2>(S1, f2, acc, mt);
+        mma_n<MTX>(S0, f1, acc, mt);
+        mma_n<MTX>(S1, f2, acc, mt);
         __syncthreads();
-        acc_store<MT2>(acc, S0, wc, 0.f, mt);
+        acc_store<MTX>(acc, S0, wc, 0.f, mt);
         __syncthreads();
-        sweep<MT2>(mt, [&](int r, int c4) {
+        sweep<MTX>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g >= sp.end) return;
             float4 v = lds4(S0, r, c4);
@@ -287,6 +288,7 @@ struct LocalW {
 // blockIdx.y = 0: the k->j half (z_kj, q2, m_nb);  1: the j->i half (z_ji, m_ji, q3).  The two halves share only the
 // input tile, so they run as separate workgroups: two weight slices (64 VGPRs) and one epilogue each instead of four
 // slices and two dependent epilogues in a row -- E_l rows give only ~135 workgroups per half, the chip has room.
+template <int MTX>
 __global__ __launch_bounds__(WG8) void local_edge_fwd_kernel(const float* __restrict__ rbf, int64_t m, LocalW w,
                                                              const float* __restrict__ b_ji,
                                                              const float* __restrict__ b_kj,
@@ -295,10 +297,10 @@ __global__ __launch_bounds__(WG8) void local_edge_fwd_kernel(const float* __rest
                                                              float* __restrict__ z_kj, float* __restrict__ q2,
                                                              float* __restrict__ q3, float* __restrict__ m_ji,
                                                              float* __restrict__ m_nb, int base, int rem, int cmt) {
-    __shared__ __attribute__((aligned(16))) float lds[3 * MT3 * 16 * LDT];
+    __shared__ __attribute__((aligned(16))) float lds[3 * MTX * 16 * LDT];
     float* S0 = lds;
-    float* S1 = lds + MT3 * 16 * LDT;
-    float* S2 = lds + 2 * MT3 * 16 * LDT;
+    float* S1 = lds + MTX * 16 * LDT;
+    float* S2 = lds + 2 * MTX * 16 * LDT;
     const int wc = wave_col();
     const bool kj = blockIdx.y == 0;
     const float bz = lane_bias(kj ? b_kj : b_ji, wc);
@@ -310,17 +312,17 @@ __global__ __launch_bounds__(WG8) void local_edge_fwd_kernel(const float* __rest
     const Span sp(m, base, rem, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
-        sweep<MT3>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(rbf, row0 + r, sp.end, DIM, c4)); });
+        sweep<MTX>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(rbf, row0 + r, sp.end, DIM, c4)); });
         __syncthreads();
-        Acc<MT3> acc;
+        Acc<MTX> acc;
         acc.zero();
-        mma_n<MT3>(S0, fq, acc, mt);                          // q2 = lin_rbf r   |  q3 = lin_rbf_out r
-        acc_store<MT3>(acc, S2, wc, 0.f, mt);
+        mma_n<MTX>(S0, fq, acc, mt);                          // q2 = lin_rbf r   |  q3 = lin_rbf_out r
+        acc_store<MTX>(acc, S2, wc, 0.f, mt);
         acc.zero();
-        mma_n<MT3>(S0, fz, acc, mt);                          // W_kj,e r + b_kj  |  W_ji,e r + b_ji
-        acc_store<MT3>(acc, S1, wc, bz, mt);
+        mma_n<MTX>(S0, fz, acc, mt);                          // W_kj,e r + b_kj  |  W_ji,e r + b_ji
+        acc_store<MTX>(acc, S1, wc, bz, mt);
         __syncthreads();
-        sweep<MT3>(mt, [&](int r, int c4) {
+        sweep<MTX>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g >= sp.end) return;
             const int64_t i = row_of[g], j = col[g];
@@ -424,6 +426,7 @@ struct Mlp2Set {
 struct Mlp2Batch {
     Mlp2Set s[8];
 };
+template <int MTX>
 __global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__ x, int64_t m, Mlp2Batch batch, int base,
                                                        int rem, int cmt) {
     const float* __restrict__ W1 = batch.s[blockIdx.y].W1;
@@ -433,9 +436,9 @@ __global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__
     float* __restrict__ z1 = batch.s[blockIdx.y].z1;
     float* __restrict__ z2 = batch.s[blockIdx.y].z2;
     float* __restrict__ y = batch.s[blockIdx.y].y;
-    __shared__ __attribute__((aligned(16))) float lds[2 * MT2 * 16 * LDT];
+    __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
     float* S0 = lds;
-    float* S1 = lds + MT2 * 16 * LDT;
+    float* S1 = lds + MTX * 16 * LDT;
     const int wc = wave_col();
     const float bv1 = lane_bias(b1, wc), bv2 = lane_bias(b2, wc);
     PROBE(0);
@@ -446,17 +449,17 @@ __global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__
     const Span sp(m, base, rem, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
-        sweep<MT2>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(x, row0 + r, sp.end, DIM, c4)); });
+        sweep<MTX>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(x, row0 + r, sp.end, DIM, c4)); });
         __syncthreads();
         PROBE(1);
-        Acc<MT2> acc;
+        Acc<MTX> acc;
         acc.zero();
-        mma_n<MT2>(S0, f1, acc, mt);
+        mma_n<MTX>(S0, f1, acc, mt);
         PROBE(2);
-        acc_store<MT2>(acc, S1, wc, bv1, mt);
+        acc_store<MTX>(acc, S1, wc, bv1, mt);
         __syncthreads();
         PROBE(3);
-        sweep<MT2>(mt, [&](int r, int c4) {
+        sweep<MTX>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             const float4 zz = lds4(S1, r, c4);
             st_lds4(S1, r, c4, f4silu(zz));
@@ -465,12 +468,12 @@ __global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__
         __syncthreads();
         PROBE(4);
         acc.zero();
-        mma_n<MT2>(S1, f2, acc, mt);
+        mma_n<MTX>(S1, f2, acc, mt);
         PROBE(5);
-        acc_store<MT2>(acc, S0, wc, bv2, mt);
+        acc_store<MTX>(acc, S0, wc, bv2, mt);
         __syncthreads();
         PROBE(6);
-        sweep<MT2>(mt, [&](int r, int c4) {
+        sweep<MTX>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g >= sp.end) return;
             const float4 zz = lds4(S0, r, c4);
@@ -483,14 +486,15 @@ __global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__
     PROBE_WG(1);
 }
 
+template <int MTX>
 __global__ __launch_bounds__(WG8) void mlp2_bwd_kernel(const float* __restrict__ dy, int64_t m,
                                                        const float* __restrict__ z1, const float* __restrict__ z2,
                                                        const float* __restrict__ W1, const float* __restrict__ W2,
                                                        float* __restrict__ dz1, float* __restrict__ dz2,
                                                        float* __restrict__ dx, int accumulate, int base, int rem, int cmt) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * MT2 * 16 * LDT];
+    __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
     float* S0 = lds;
-    float* S1 = lds + MT2 * 16 * LDT;
+    float* S1 = lds + MTX * 16 * LDT;
     const int wc = wave_col();
     WFrag1 f1, f2;
     load_wfrag1<true>(f2, W2, DIM, wc);
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(WG8) void mlp2_bwd_kernel(const float* __restrict__
     const Span sp(m, base, rem, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
-        sweep<MT2>(mt, [&](int r, int c4) {
+        sweep<MTX>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             float4 a = f4zero();
             if (g < sp.end) {
@@ -508,12 +512,12 @@ __global__ __launch_bounds__(WG8) void mlp2_bwd_kernel(const float* __restrict__
             st_lds4(S0, r, c4, a);
         });
         __syncthreads();
-        Acc<MT2> acc;
+        Acc<MTX> acc;
         acc.zero();
-        mma_n<MT2>(S0, f2, acc, mt);
-        acc_store<MT2>(acc, S1, wc, 0.f, mt);
+        mma_n<MTX>(S0, f2, acc, mt);
+        acc_store<MTX>(acc, S1, wc, 0.f, mt);
         __syncthreads();
-        sweep<MT2>(mt, [&](int r, int c4) {
+        sweep<MTX>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             float4 a = f4zero();
             if (g < sp.end) {
@@ -524,10 +528,10 @@ __global__ __launch_bounds__(WG8) void mlp2_bwd_kernel(const float* __restrict__
         });
         __syncthreads();
         acc.zero();
-        mma_n<MT2>(S1, f1, acc, mt);
-        acc_store<MT2>(acc, S0, wc, 0.f, mt);                 // S0 (dz2 tile) was last read before the previous barrier
+        mma_n<MTX>(S1, f1, acc, mt);
+        acc_store<MTX>(acc, S0, wc, 0.f, mt);                 // S0 (dz2 tile) was last read before the previous barrier
         __syncthreads();
-        sweep<MT2>(mt, [&](int r, int c4) {
+        sweep<MTX>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g >= sp.end) return;
             float4 v = lds4(S0, r, c4);
@@ -558,6 +562,32 @@ inline Plan plan(int64_t rows, int cap, int target_wgs = N_CU) {
     return p;
 }
 
+// Instantiations by chunk size: registers (accumulators, A fragments, unrolled sweeps) and LDS follow the template
+// bound, so a launch uses the smallest one that holds its chunks (3 / 5 / 8 tiles of 16 rows; a 9-tile single chunk for E_g measured the same as 5 + 4).
+#define PAMNET_EDGE_LAUNCH(KERNEL, PLAN, GRID, ...)                                                          \
+    do {                                                                                                     \
+        if ((PLAN).cmt <= 3)                                                                                 \
+            hipLaunchKernelGGL(KERNEL<3>, GRID, dim3(WG8), 0, as_stream(stream), __VA_ARGS__, (PLAN).base,   \
+                               (PLAN).rem, (PLAN).cmt);                                                      \
+        else if ((PLAN).cmt <= 5)                                                                            \
+            hipLaunchKernelGGL(KERNEL<5>, GRID, dim3(WG8), 0, as_stream(stream), __VA_ARGS__, (PLAN).base,   \
+                               (PLAN).rem, (PLAN).cmt);                                                      \
+        else                                                                                                 \
+            hipLaunchKernelGGL(KERNEL<8>, GRID, dim3(WG8), 0, as_stream(stream), __VA_ARGS__, (PLAN).base,   \
+                               (PLAN).rem, (PLAN).cmt);                                                      \
+    } while (0)
+
+// three-slot kernel: 5 tiles per chunk is the LDS limit (the plan caps its chunks there)
+#define PAMNET_EDGE_LAUNCH35(KERNEL, PLAN, GRID, ...)                                                        \
+    do {                                                                                                     \
+        if ((PLAN).cmt <= 3)                                                                                 \
+            hipLaunchKernelGGL(KERNEL<3>, GRID, dim3(WG8), 0, as_stream(stream), __VA_ARGS__, (PLAN).base,   \
+                               (PLAN).rem, (PLAN).cmt);                                                      \
+        else                                                                                                 \
+            hipLaunchKernelGGL(KERNEL<5>, GRID, dim3(WG8), 0, as_stream(stream), __VA_ARGS__, (PLAN).base,   \
+                               (PLAN).rem, (PLAN).cmt);                                                      \
+    } while (0)
+
 }  // namespace
 
 extern "C" int pamnet_global_edge_fwd_f32(const float* e, int64_t n_edges, const float* We, int64_t ld_we,
@@ -568,8 +598,8 @@ extern "C" int pamnet_global_edge_fwd_f32(const float* e, int64_t n_edges, const
     if (n_edges == 0) return PAMNET_OK;
     if (!e || !We || !bm || !Wea || !Pi || !Pj || !row_of || !col || !msg) return PAMNET_ENULL;   // z, ea: optional saves
     const Plan p = plan(n_edges, MT2);
-    hipLaunchKernelGGL(global_edge_fwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), e, n_edges, We, (int)ld_we,
-                       bm, Wea, (int)ld_wea, Pi, Pj, row_of, col, z, ea, msg, p.base, p.rem, p.cmt);
+    PAMNET_EDGE_LAUNCH(global_edge_fwd_kernel, p, dim3(p.grid), e, n_edges, We, (int)ld_we, bm, Wea, (int)ld_wea, Pi, Pj,
+                       row_of, col, z, ea, msg);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -582,8 +612,8 @@ extern "C" int pamnet_global_edge_bwd_f32(const float* d_agg, const int32_t* row
     if (n_edges == 0) return PAMNET_OK;
     if (!d_agg || !row_of || !z || !ea || !We || !Wea || !dz || !dea || !d_e) return PAMNET_ENULL;
     const Plan p = plan(n_edges, MT2);
-    hipLaunchKernelGGL(global_edge_bwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), d_agg, row_of, n_edges, z,
-                       ea, We, (int)ld_we, Wea, (int)ld_wea, dz, dea, d_e, (int)accumulate, p.base, p.rem, p.cmt);
+    PAMNET_EDGE_LAUNCH(global_edge_bwd_kernel, p, dim3(p.grid), d_agg, row_of, n_edges, z, ea, We, (int)ld_we, Wea,
+                       (int)ld_wea, dz, dea, d_e, (int)accumulate);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -610,9 +640,9 @@ extern "C" int pamnet_local_edge_fwd_f32(const float* rbf, int64_t n_edges, cons
     LocalW w;
     int rc = fill_local(w, Wq, ldq, P);
     if (rc) return rc;
-    const Plan p = plan(n_edges, MT3, N_CU / 2);            // two halves (grid.y): together one workgroup per CU
-    hipLaunchKernelGGL(local_edge_fwd_kernel, dim3(p.grid, 2), dim3(WG8), 0, as_stream(stream), rbf, n_edges, w, b_ji, b_kj,
-                       row_of, col, z_ji, z_kj, q2, q3, m_ji, m_nb, p.base, p.rem, p.cmt);
+    const Plan p = plan(n_edges, 5, N_CU / 2);              // two halves (grid.y): together one workgroup per CU
+    PAMNET_EDGE_LAUNCH35(local_edge_fwd_kernel, p, dim3(p.grid, 2), rbf, n_edges, w, b_ji, b_kj, row_of, col, z_ji, z_kj, q2,
+                       q3, m_ji, m_nb);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -644,7 +674,7 @@ extern "C" int pamnet_mlp2_fwd_f32(const float* x, int64_t rows, const float* W1
     const Plan p = plan(rows, MT2);
     Mlp2Batch b;
     for (int k = 0; k < 8; ++k) b.s[k] = Mlp2Set{W1, b1, W2, b2, z1, z2, y};
-    hipLaunchKernelGGL(mlp2_fwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), x, rows, b, p.base, p.rem, p.cmt);
+    PAMNET_EDGE_LAUNCH(mlp2_fwd_kernel, p, dim3(p.grid), x, rows, b);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -665,8 +695,7 @@ extern "C" int pamnet_mlp2_fwd_multi_f32(const float* x, int64_t rows, int64_t n
                          outs[3 * s], outs[3 * s + 1], outs[3 * s + 2]};
     }
     const Plan p = plan(rows, MT2);
-    hipLaunchKernelGGL(mlp2_fwd_kernel, dim3(p.grid, (unsigned)nsets), dim3(WG8), 0, as_stream(stream), x, rows, b, p.base,
-                       p.rem, p.cmt);
+    PAMNET_EDGE_LAUNCH(mlp2_fwd_kernel, p, dim3(p.grid, (unsigned)nsets), x, rows, b);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -678,8 +707,7 @@ extern "C" int pamnet_mlp2_bwd_f32(const float* dy, int64_t rows, const float* z
     if (rows == 0) return PAMNET_OK;
     if (!dy || !z1 || !z2 || !W1 || !W2 || !dz1 || !dz2 || !dx) return PAMNET_ENULL;
     const Plan p = plan(rows, MT2);
-    hipLaunchKernelGGL(mlp2_bwd_kernel, dim3(p.grid), dim3(WG8), 0, as_stream(stream), dy, rows, z1, z2, W1, W2, dz1, dz2,
-                       dx, (int)accumulate, p.base, p.rem, p.cmt);
+    PAMNET_EDGE_LAUNCH(mlp2_bwd_kernel, p, dim3(p.grid), dy, rows, z1, z2, W1, W2, dz1, dz2, dx, (int)accumulate);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
