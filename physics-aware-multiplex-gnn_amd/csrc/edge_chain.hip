@@ -199,9 +199,27 @@ __global__ __launch_bounds__(WG8) void global_edge_fwd_kernel(const float* __res
     load_wfrag1<false>(f1, We, ld_we, wc);
     load_wfrag1<false>(f2, Wea, ld_wea, wc);
     const Span sp(m, base, rem, cmt);
+    // the NEXT chunk's input rows travel in registers while this chunk's GEMMs run (a workgroup with 9 tiles walks them
+    // as 5 + 4: without this its second load phase is fully exposed)
+    float4 pre[MTX];
+    {
+        const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+        for (int i = 0; i < MTX; ++i) pre[i] = ldg4z(e, sp.beg + r0 + 16 * i, sp.end, DIM, c4);
+    }
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
-        sweep<MTX>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(e, row0 + r, sp.end, DIM, c4)); });
+        {
+            const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+            for (int i = 0; i < MTX; ++i)
+                if (i < mt) st_lds4(S0, r0 + 16 * i, c4, pre[i]);
+            const int64_t nxt = row0 + (int64_t)sp.cmt * 16;
+            if (nxt < sp.end) {
+#pragma unroll
+                for (int i = 0; i < MTX; ++i) pre[i] = ldg4z(e, nxt + r0 + 16 * i, sp.end, DIM, c4);
+            }
+        }
         __syncthreads();
         Acc<MTX> au, aa;
         au.zero();
