@@ -164,11 +164,17 @@ int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int64_t n, con
                              const float* const* biases, const float* w_out, const float* b_out, const float* w_att,
                              float* Z, float* R, float* x_out, float* out, float* att, const float* next_Wx1,
                              const float* next_bx1, const float* const* next_wp, int64_t next_ldwp, int64_t next_nblk,
-                             float* next_Zx1, float* next_x1, float* next_P, pamnet_stream_t stream);
+                             float* next_Zx1, float* next_x1, float* next_P, int32_t packed, pamnet_stream_t stream);
 int pamnet_node_tail_bwd_f32(const float* d_xout, const float* d_out, const float* d_att, int64_t n,
                              const float* const* weights, const float* w_out, const float* w_att, const float* Z,
                              float* dZ, float* d_x2, float* d_resx, float* head_partial, float* d_wout, float* d_watt,
-                             float* d_bout, pamnet_stream_t stream);
+                             float* d_bout, int32_t packed, pamnet_stream_t stream);
+/* Fragment-ordered weight images for the node chains: n (<= 192) 128x128 matrices (row stride ld[i]) -> images[i*16384..],
+ * transposed = 0 for the forward (Y = X W^T), 1 for the backward (Y = X W).  With packed != 0 the `weights` (and, in the
+ * forward, next_Wx1 / next_wp) arguments of node_tail_fwd / node_tail_bwd are such images: every weight-slice request of
+ * a wave is then one contiguous 1 KB read instead of 16 half-used cache lines of the row-major matrix. */
+int pamnet_pack_weights_f32(int64_t n, const float* const* W, const int64_t* ld, int32_t transposed, float* images,
+                            pamnet_stream_t stream);
 int pamnet_node_pre_fwd_f32(const float* x, int64_t n, const float* Wx1, const float* bx1, const float* const* wp,
                             int64_t ldwp, int64_t nblk, float* Zx1, float* x1, float* P, pamnet_stream_t stream);
 int pamnet_node_pre_bwd_f32(const float* dP, const float* dx1_direct, const float* d_add, int64_t n, const float* Wx1,
@@ -246,6 +252,9 @@ int pamnet_embed_bwd_f32(const float* x, int64_t rows, int64_t K, const int32_t*
  *                mlp_sbf.1.W, .b, lin_rbf.W, lin_rbf_out.W, tail ...}
  *   saved/temp : caller-owned arenas sized by pamnet_stack_workspace (floats); `saved` must survive until the backward
  *   outs/atts  : [2*n_layer, n] rows ordered (global_0, local_0, global_1, ...)
+ * wpack (nullable, both directions): scratch of pamnet_stack_pack_floats(n_layer) floats; when given, the call first
+ * re-packs the node chains' weight matrices into fragment-ordered images (pamnet_pack_weights_f32, one launch) and the
+ * chains read those.  Contents need not survive the call.
  * Forward, save_for_backward = 0 (inference): tensors only the backward reads are not written (the single kernels take
  * null for those outputs: z / ea, z_ji / z_kj / q2, z1 / z2, Z / R, Zx1); `saved` still holds the forward's own
  * intermediates and the per-layer node features.
@@ -260,17 +269,18 @@ int pamnet_embed_bwd_f32(const float* x, int64_t rows, int64_t K, const int32_t*
  * ------------------------------------------------------------------------------------------------------------------ */
 int pamnet_stack_workspace(int64_t n, int64_t eg, int64_t el, int64_t tp, int64_t n_layer, int64_t* saved_floats,
                            int64_t* temp_floats_out);
+int pamnet_stack_pack_floats(int64_t n_layer, int64_t* floats);
 int pamnet_stack_layout(int64_t n, int64_t eg, int64_t el, int64_t tp, int64_t* layout);
 int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, int64_t n_layer, const float* x0,
                          const float* e_g, const float* rbf_e, const float* e_sbf, const float* const* gparams,
                          const float* const* lparams, float* saved, float* temp, float* outs, float* atts,
-                         int32_t save_for_backward, pamnet_stream_t aux_stream, void* const* aux_events,
+                         int32_t save_for_backward, float* wpack, pamnet_stream_t aux_stream, void* const* aux_events,
                          pamnet_stream_t stream);
 int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, int64_t n_layer, const float* x0,
                          const float* e_g, const float* rbf_e, const float* e_sbf, const float* const* gparams,
                          const float* const* lparams, const float* saved, float* temp, const float* d_outs,
                          const float* d_atts, float* const* ggrads, float* const* lgrads, float* d_x0, float* d_eg,
-                         float* d_rbf, float* d_sbf, void* const* layer_done, pamnet_stream_t stream);
+                         float* d_rbf, float* d_sbf, float* wpack, void* const* layer_done, pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Optimiser tail of the reference loop on flat fp32 buffers, one pass (main_qm9.py:111-112,116; utils/ema.py:13-20):

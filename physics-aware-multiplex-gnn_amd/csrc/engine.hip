@@ -11,6 +11,8 @@
 // pamnet_stack_workspace and keeps them alive until the backward has been enqueued.
 // The shared edge embeddings (e_g, rbf_e, e_sbf feed all layers) get their gradients accumulated in place by the
 // backward kernels themselves (accumulate flag), in a fixed layer order -> deterministic.
+#include <alloca.h>
+
 #include "common.h"
 
 namespace {
@@ -138,6 +140,32 @@ inline Temp carve_temp(float* p, const Graph& g) {
         if (e__ != hipSuccess) return (int)e__;    \
     } while (0)
 
+// fragment-ordered weight images for the node chains (pamnet_pack_weights_f32), packed in launches of <= 192 matrices
+struct PackList {
+    const float* src[192];
+    int64_t ld[192];
+    int n = 0;
+    float* base;
+    int64_t done = 0;          // images already packed by earlier launches
+    int32_t transposed;
+    pamnet_stream_t st;
+    int rc = 0;
+    PackList(float* b, int32_t t, pamnet_stream_t s) : base(b), transposed(t), st(s) {}
+    // returns the image the matrix will occupy
+    const float* add(const float* W, int64_t ldw) {
+        if (n == 192) flush();
+        src[n] = W;
+        ld[n] = ldw;
+        return base + (done + n++) * (D * D);
+    }
+    void flush() {
+        if (n && !rc) rc = pamnet_pack_weights_f32(n, src, ld, transposed, base + done * (D * D), st);
+        done += n;
+        n = 0;
+    }
+};
+constexpr int64_t PACK_PER_PAIR = 28;       // forward: 10 + 5 (global chain + local head) + 10 + 3 (local chain + next global head)
+
 // weight-gradient job list builder
 struct Jobs {
     const float* dZ[WJOBS];
@@ -170,6 +198,13 @@ inline int run_jobs(Jobs& j, float* partial, const Graph& g, const float* head, 
 }
 
 }  // namespace
+
+// floats of the optional weight-image arena (`wpack`) of pamnet_stack_fwd_f32 / pamnet_stack_bwd_f32
+extern "C" int pamnet_stack_pack_floats(int64_t n_layer, int64_t* floats) {
+    if (n_layer < 1 || !floats) return PAMNET_EINVAL;
+    *floats = n_layer * PACK_PER_PAIR * D * D;
+    return PAMNET_OK;
+}
 
 extern "C" int pamnet_stack_workspace(int64_t n, int64_t eg, int64_t el, int64_t tp, int64_t n_layer,
                                       int64_t* saved_floats, int64_t* temp_floats_out) {
@@ -207,8 +242,8 @@ static int fill_graph(Graph& g, const int64_t* sizes, const int32_t* const* idx)
 extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, int64_t n_layer,
                                     const float* x0, const float* e_g, const float* rbf_e, const float* e_sbf,
                                     const float* const* gparams, const float* const* lparams, float* saved, float* temp,
-                                    float* outs, float* atts, int32_t save_for_backward, pamnet_stream_t aux,
-                                    void* const* aux_events, pamnet_stream_t st) {
+                                    float* outs, float* atts, int32_t save_for_backward, float* wpack,
+                                    pamnet_stream_t aux, void* const* aux_events, pamnet_stream_t st) {
     Graph g;
     CK(fill_graph(g, sizes, graph_idx));
     if (n_layer < 1) return PAMNET_EINVAL;
@@ -250,6 +285,33 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
             HK(hipEventRecord(reinterpret_cast<hipEvent_t>(aux_events[1 + k]), a));
         }
     }
+    // Fragment-ordered weight images for the node chains (optional `wpack` arena): one pack launch for all layers.
+    // img[k] = {global chain W[10], local head Wx1 + 4 blocks, local chain W[10], next global head Wx1 + 2 blocks}
+    const bool packed = wpack != nullptr;
+    struct PairImg {
+        const float *gt[10], *lh[5], *lt[10], *nh[3];
+    };
+    PairImg* img = packed ? static_cast<PairImg*>(alloca(sizeof(PairImg) * n_layer)) : nullptr;
+    if (packed) {
+        PackList pl(wpack, 0, st);
+        for (int64_t k = 0; k < n_layer; ++k) {
+            const float* const* gp = gparams + k * NG;
+            const float* const* lp = lparams + k * NL;
+            for (int i = 0; i < 10; ++i) img[k].gt[i] = pl.add(gp[GT + i], D);
+            img[k].lh[0] = pl.add(lp[0], D);
+            img[k].lh[1] = pl.add(lp[2], 3 * D), img[k].lh[2] = pl.add(lp[4], 3 * D);
+            img[k].lh[3] = pl.add(lp[2] + D, 3 * D), img[k].lh[4] = pl.add(lp[4] + D, 3 * D);
+            for (int i = 0; i < 10; ++i) img[k].lt[i] = pl.add(lp[LT + i], D);
+            if (k + 1 < n_layer) {
+                const float* const* gn = gparams + (k + 1) * NG;
+                img[k].nh[0] = pl.add(gn[0], D);
+                img[k].nh[1] = pl.add(gn[2], 3 * D), img[k].nh[2] = pl.add(gn[2] + D, 3 * D);
+            }
+        }
+        pl.flush();
+        CK(pl.rc);
+    }
+    const int32_t pk = packed ? 1 : 0;
     for (int64_t k = 0; k < n_layer; ++k) {
         // ---------------- global layer (layers/global_message_passing.py:33-56)
         const float* const* gp = gparams + k * NG;
@@ -263,9 +325,10 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         const float* const* lp = lparams + k * NL;
         const LocalSaved q = carve_local(saved + k * (gs + ls) + gs, g);
         const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
-        CK(pamnet_node_tail_fwd_f32(s.x2, x, g.n, gp + GT, gp + GT + 10, gp[GT + 20], gp[GT + 21], gp[GT + 22], sv(s.Z),
-                                    sv(s.R), s.xout, outs + (2 * k) * g.n, atts + (2 * k) * g.n, lp[0], lp[1], wpl, 3 * D,
-                                    4, sv(q.Zx1), t.x1, t.P, st));
+        CK(pamnet_node_tail_fwd_f32(s.x2, x, g.n, packed ? img[k].gt : gp + GT, gp + GT + 10, gp[GT + 20], gp[GT + 21],
+                                    gp[GT + 22], sv(s.Z), sv(s.R), s.xout, outs + (2 * k) * g.n, atts + (2 * k) * g.n,
+                                    packed ? img[k].lh[0] : lp[0], lp[1], packed ? img[k].lh + 1 : wpl, 3 * D, 4,
+                                    sv(q.Zx1), t.x1, t.P, pk, st));
         x = s.xout;
         // ---------------- local layer (layers/local_message_passing.py:36-66); its head ran in the chain above
         const float* wq[4] = {lp[2] + 2 * D, lp[4] + 2 * D, lp[10], lp[11]};
@@ -280,13 +343,15 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
             const float* const* gn = gparams + (k + 1) * NG;
             const GlobalSaved sn = carve_global(saved + (k + 1) * (gs + ls), g);
             const float* wpn[2] = {gn[2], gn[2] + D};
-            CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22],
-                                        sv(q.Z), sv(q.R), q.xout, outs + (2 * k + 1) * g.n, atts + (2 * k + 1) * g.n,
-                                        gn[0], gn[1], wpn, 3 * D, 2, sv(sn.Zx1), t.x1, t.P, st));
+            CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, packed ? img[k].lt : lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21],
+                                        lp[LT + 22], sv(q.Z), sv(q.R), q.xout, outs + (2 * k + 1) * g.n,
+                                        atts + (2 * k + 1) * g.n, packed ? img[k].nh[0] : gn[0], gn[1],
+                                        packed ? img[k].nh + 1 : wpn, 3 * D, 2, sv(sn.Zx1), t.x1, t.P, pk, st));
         } else {
-            CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22],
-                                        sv(q.Z), sv(q.R), q.xout, outs + (2 * k + 1) * g.n, atts + (2 * k + 1) * g.n,
-                                        nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, st));
+            CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, packed ? img[k].lt : lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21],
+                                        lp[LT + 22], sv(q.Z), sv(q.R), q.xout, outs + (2 * k + 1) * g.n,
+                                        atts + (2 * k + 1) * g.n, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr,
+                                        nullptr, pk, st));
         }
         x = q.xout;
     }
@@ -300,7 +365,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                                     const float* const* gparams, const float* const* lparams, const float* saved,
                                     float* temp, const float* d_outs, const float* d_atts, float* const* ggrads,
                                     float* const* lgrads, float* d_x0, float* d_eg, float* d_rbf, float* d_sbf,
-                                    void* const* layer_done, pamnet_stream_t st) {
+                                    float* wpack, void* const* layer_done, pamnet_stream_t st) {
     Graph g;
     CK(fill_graph(g, sizes, graph_idx));
     if (n_layer < 1) return PAMNET_EINVAL;
@@ -309,6 +374,22 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
         return PAMNET_ENULL;
     const Temp t = carve_temp(temp, g);
     const int64_t gs = al(global_saved_floats(g)), ls = al(local_saved_floats(g));
+    // transposed weight images of both node chains of every layer (optional `wpack` arena), one pack launch
+    const bool packed = wpack != nullptr;
+    struct PairImgT {
+        const float *gt[10], *lt[10];
+    };
+    PairImgT* img = packed ? static_cast<PairImgT*>(alloca(sizeof(PairImgT) * n_layer)) : nullptr;
+    if (packed) {
+        PackList pl(wpack, 1, st);
+        for (int64_t k = n_layer - 1; k >= 0; --k) {
+            for (int i = 0; i < 10; ++i) img[k].lt[i] = pl.add(lparams[k * NL + LT + i], D);
+            for (int i = 0; i < 10; ++i) img[k].gt[i] = pl.add(gparams[k * NG + GT + i], D);
+        }
+        pl.flush();
+        CK(pl.rc);
+    }
+    const int32_t pk = packed ? 1 : 0;
     const float* d_xout = nullptr;        // nothing consumes the last layer's node features (models.py:196-224)
     float* dx_bufs[2] = {t.dxa, t.dxb};
     int flip = 0;
@@ -321,9 +402,9 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             const float* const* lp = lparams + k * NL;
             float* const* lg = lgrads + k * NL;
             const float* x_in = s.xout;           // input of the local layer = output of this pair's global layer
-            CK(pamnet_node_tail_bwd_f32(d_xout, d_outs + (2 * k + 1) * g.n, d_atts + (2 * k + 1) * g.n, g.n, lp + LT,
-                                        lp[LT + 20], lp[LT + 22], q.Z, t.dZ, t.dx2, t.dresx, t.head, nullptr, nullptr,
-                                        nullptr, st));
+            CK(pamnet_node_tail_bwd_f32(d_xout, d_outs + (2 * k + 1) * g.n, d_atts + (2 * k + 1) * g.n, g.n,
+                                        packed ? img[k].lt : lp + LT, lp[LT + 20], lp[LT + 22], q.Z, t.dZ, t.dx2, t.dresx,
+                                        t.head, nullptr, nullptr, nullptr, pk, st));
             // d m_t = d x2[i] * q3 ,  d q3 = d x2[i] * m_t
             CK(pamnet_gather_mul2_f32(t.dmt, t.dq3, t.dx2, g.l_row, q.q3, q.mt, g.el, D, st));
             CK(pamnet_gather_mul_f32(t.ds, q.mnb, g.t_col, t.dmt, g.t_row, g.tp, D, st));       // d s   = m_nb[idx] * d m_t[e]
@@ -366,9 +447,9 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             const float* const* gp = gparams + k * NG;
             float* const* gg = ggrads + k * NG;
             const float* x_in = (k == 0) ? x0 : carve_local(const_cast<float*>(saved) + (k - 1) * (gs + ls) + gs, g).xout;
-            CK(pamnet_node_tail_bwd_f32(d_xout, d_outs + (2 * k) * g.n, d_atts + (2 * k) * g.n, g.n, gp + GT,
-                                        gp[GT + 20], gp[GT + 22], s.Z, t.dZ, t.dx2, t.dresx, t.head, nullptr, nullptr,
-                                        nullptr, st));
+            CK(pamnet_node_tail_bwd_f32(d_xout, d_outs + (2 * k) * g.n, d_atts + (2 * k) * g.n, g.n,
+                                        packed ? img[k].gt : gp + GT, gp[GT + 20], gp[GT + 22], s.Z, t.dZ, t.dx2, t.dresx,
+                                        t.head, nullptr, nullptr, nullptr, pk, st));
             CK(pamnet_global_edge_bwd_f32(t.dx2, g.g_row, g.eg, s.z, s.ea, gp[2] + 2 * D, 3 * D, gp[4], D, t.dz, t.dea,
                                           d_eg, acc, st));
             const int64_t pl = g.n * D;

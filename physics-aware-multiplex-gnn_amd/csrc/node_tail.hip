@@ -41,8 +41,9 @@ extern "C" int pamnet_tail_probe_read(long long* host64) {
 namespace {
 
 struct TailParams {
-    const float* W[10];
+    const float* W[10];       // row-major [128][128] matrices, or fragment-ordered images when `packed`
     const float* b[10];
+    int packed;
     const float* w_out;   // [128]
     const float* b_out;   // [1]
     const float* w_att;   // [128]
@@ -75,6 +76,30 @@ struct Frag {
     __device__ __forceinline__ int col() const { return wc + r16; }
 };
 
+// ---- fragment-ordered weight images (pamnet_pack_weights_f32) -----------------------------------------------------------
+// Requesting a weight slice from the row-major matrix costs ~1 150 cycles of every ~5 000-cycle layer: each of the 16
+// 1 KB requests touches 16 half-used cache lines.  An image stores, for 16-column tile j and k-group q, the 64 lanes'
+// float4 fragments back to back: img4[(j*8 + q)*64 + lane] -- every request is one contiguous 1 KB read.
+//   forward orientation  (Y = X W^T): lane's float4 = W[16j + (lane&15)][16q + 4(lane>>4) + 0..3]
+//   transposed orientation (Y = X W): lane's float4 = W[16q + 4(lane>>4) + 0..3][16j + (lane&15)]
+constexpr int IMG = DIM * DIM;               // floats per image
+__device__ __forceinline__ void load_wfrag_img(WFrag& f, const float* __restrict__ img) {       // 4 waves x 32 columns
+    const float4* p4 = reinterpret_cast<const float4*>(img) + (threadIdx.x & 63);
+    const int j = (threadIdx.x >> 6) * 2;
+#pragma unroll
+    for (int q = 0; q < DIM / 16; ++q) {
+        f.b[q][0] = p4[(j * 8 + q) * 64];
+        f.b[q][1] = p4[((j + 1) * 8 + q) * 64];
+    }
+}
+
+// next weight slice of a 4-wave chain: fragment-ordered image, or row-major matrix with row stride ld
+template <bool PACKED>
+__device__ __forceinline__ void load_w(WFrag& f, const float* __restrict__ W, int ld, int wc) {
+    if constexpr (PACKED) load_wfrag_img(f, W);
+    else load_wfrag<false>(f, W, ld, wc);
+}
+
 // one 128 x 16 weight slice of a wave: 8 x float4 = 32 VGPRs
 struct WFrag1 {
     float4 b[DIM / 16];
@@ -93,6 +118,13 @@ __device__ __forceinline__ void load_wfrag1(WFrag1& f, const float* __restrict__
             f.b[q] = make_float4(wp[0], wp[DIM], wp[2 * DIM], wp[3 * DIM]);
         }
     }
+}
+
+__device__ __forceinline__ void load_wfrag1_img(WFrag1& f, const float* __restrict__ img) {     // 8 waves x 16 columns
+    const float4* p4 = reinterpret_cast<const float4*>(img) + (threadIdx.x & 63);
+    const int j = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < DIM / 16; ++q) f.b[q] = p4[(j * 8 + q) * 64];
 }
 
 // [16 x 128] (LDS) x [128 x 16] (registers) -> one 16x16 accumulator; two interleaved chains
@@ -115,6 +147,7 @@ __device__ __forceinline__ f32x4 mma_strip(const float* __restrict__ As, const W
 // Forward: 4 waves x 32 columns (float4 weight loads are cheap per byte, so fewer, wider waves win; an 8-wave x 16-column
 // version measured 35 us against 31 us: two waves per SIMD only take turns on the matrix pipe and then idle at the
 // barrier -- tools/tail_probe.py).
+template <bool PACKED>
 __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restrict__ x2,
                                                            const float* __restrict__ res_x, int64_t n, TailParams p,
                                                            float* __restrict__ Z, float* __restrict__ R,
@@ -137,7 +170,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
     const int wc = (threadIdx.x >> 6) * 32;
 
     WFrag wf;
-    load_wfrag<false>(wf, p.W[0], DIM, wc);
+    load_w<PACKED>(wf, p.W[0], DIM, wc);
     sweep_rows<BMN>([&](int r, int c4) {
         const int64_t g = row0 + r;
         st_lds4(X0, r, c4, ldg4z(x2, g, n, DIM, c4));
@@ -154,7 +187,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
         acc_zero<1>(acc);
         mma_tile_frag<1>(in, wf, acc);
         TPROBE(4 * k + 1);
-        if (Wnext) load_wfrag<false>(wf, Wnext, DIM, wc);
+        if (Wnext) load_w<PACKED>(wf, Wnext, DIM, wc);
         float* zk = ZL + k * SLOT;
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) {
@@ -232,7 +265,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
             f32x4 acc[1][2];
             acc_zero<1>(acc);
             mma_tile_frag<1>(xin, wf, acc);
-            load_wfrag<false>(wf, nx.wp[0], nx.ldwp, wc);
+            load_w<PACKED>(wf, nx.wp[0], nx.ldwp, wc);
 #pragma unroll
             for (int n2 = 0; n2 < 2; ++n2) {
                 const int c = wc + 16 * n2 + r16;
@@ -250,7 +283,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
             f32x4 acc[1][2];
             acc_zero<1>(acc);
             mma_tile_frag<1>(ZL + SLOT, wf, acc);
-            if (b + 1 < nx.nblk) load_wfrag<false>(wf, nx.wp[b + 1], nx.ldwp, wc);
+            if (b + 1 < nx.nblk) load_w<PACKED>(wf, nx.wp[b + 1], nx.ldwp, wc);
             float* pb = ZL + (2 + b) * SLOT;
 #pragma unroll
             for (int n2 = 0; n2 < 2; ++n2) {
@@ -272,6 +305,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
 
 // Backward of the chain.  Produces dZ_k for every layer (consumed by the batched weight-gradient kernel), d x2 (gradient
 // of the chain input), d res_x, and per-workgroup partial sums for the two head vectors.
+template <bool PACKED>
 __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restrict__ d_xout /* may be null */,
                                                             const float* __restrict__ d_out,
                                                             const float* __restrict__ d_att, int64_t n, TailParams p,
@@ -294,7 +328,8 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
     const int c = fr.col();
 
     WFrag1 wf;
-    load_wfrag1<true>(wf, p.W[9], fr.wc);
+    if constexpr (PACKED) load_wfrag1_img(wf, p.W[9]);
+    else load_wfrag1<true>(wf, p.W[9], fr.wc);
     const int sc4 = threadIdx.x & 31, sr = threadIdx.x >> 5;          // sweep coordinates: 512 threads = 16 rows x 32 float4
     const int64_t sg = row0 + sr;
     {
@@ -361,7 +396,10 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
         f32x4 zn = {0.f, 0.f, 0.f, 0.f};
         if (k > 0) zn = load_z(k - 1);
         const f32x4 acc = mma_strip(in, wf);
-        if (k > 0) load_wfrag1<true>(wf, p.W[k - 1], fr.wc);
+        if (k > 0) {
+            if constexpr (PACKED) load_wfrag1_img(wf, p.W[k - 1]);
+            else load_wfrag1<true>(wf, p.W[k - 1], fr.wc);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rw = fr.row(r);
@@ -424,8 +462,9 @@ __global__ __launch_bounds__(WG) void head_reduce_kernel(const float* __restrict
 }
 
 inline TailParams make_tail(const float* const* weights, const float* const* biases, const float* w_out,
-                            const float* b_out, const float* w_att) {
+                            const float* b_out, const float* w_att, int packed) {
     TailParams p;
+    p.packed = packed;
     for (int k = 0; k < 10; ++k) {
         p.W[k] = weights[k];
         p.b[k] = biases ? biases[k] : nullptr;
@@ -436,14 +475,52 @@ inline TailParams make_tail(const float* const* weights, const float* const* bia
     return p;
 }
 
+struct PackJobs {
+    const float* src[192];
+    int ld[192];
+};
+// grid (njobs, 8): block (job, j) writes the 512 float4 fragments of 16-column tile j
+__global__ __launch_bounds__(512) void pack_weights_kernel(PackJobs jobs, int transposed, float* __restrict__ images) {
+    const float* __restrict__ W = jobs.src[blockIdx.x];
+    const int ld = jobs.ld[blockIdx.x];
+    const int j = blockIdx.y, q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = 16 * j + (lane & 15), k0 = 16 * q + 4 * (lane >> 4);
+    float4 v;
+    if (!transposed) v = *reinterpret_cast<const float4*>(W + (size_t)c * ld + k0);
+    else v = make_float4(W[(size_t)k0 * ld + c], W[(size_t)(k0 + 1) * ld + c], W[(size_t)(k0 + 2) * ld + c],
+                         W[(size_t)(k0 + 3) * ld + c]);
+    reinterpret_cast<float4*>(images + (size_t)blockIdx.x * IMG)[(j * 8 + q) * 64 + lane] = v;
+}
+
 }  // namespace
+
+// Fragment-ordered images of n (<= 192) 128x128 matrices (row stride ld[i] floats) into images[i * 16384 ...]; see the
+// layout note above.  transposed = 0: images for Y = X W^T (forward), 1: for Y = X W (backward).
+extern "C" int pamnet_pack_weights_f32(int64_t n, const float* const* W, const int64_t* ld, int32_t transposed,
+                                       float* images, pamnet_stream_t stream) {
+    if (n < 0 || n > 192) return PAMNET_EINVAL;
+    if (n == 0) return PAMNET_OK;
+    if (!W || !ld || !images) return PAMNET_ENULL;
+    PackJobs jobs;
+    for (int i = 0; i < 192; ++i) {
+        const int s = i < n ? i : 0;
+        if (!W[s]) return PAMNET_ENULL;
+        if (ld[s] < DIM || (ld[s] & 3)) return PAMNET_EINVAL;
+        jobs.src[i] = W[s];
+        jobs.ld[i] = (int)ld[s];
+    }
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)n, 8), dim3(512), 0, as_stream(stream), jobs, (int)transposed,
+                       images);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
 
 extern "C" int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int64_t n, const float* const* weights,
                                         const float* const* biases, const float* w_out, const float* b_out,
                                         const float* w_att, float* Z, float* R, float* x_out, float* out, float* att,
                                         const float* next_Wx1, const float* next_bx1, const float* const* next_wp,
                                         int64_t next_ldwp, int64_t next_nblk, float* next_Zx1, float* next_x1,
-                                        float* next_P, pamnet_stream_t stream) {
+                                        float* next_P, int32_t packed, pamnet_stream_t stream) {
     if (n < 0 || next_nblk < 0 || next_nblk > 4) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
     if (!x2 || !res_x || !weights || !biases || !w_out || !b_out || !w_att || (Z && !R) || !x_out || !out || !att)
@@ -462,8 +539,12 @@ extern "C" int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int
         }
     }
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(node_tail_fwd_kernel, dim3((unsigned)ceil_div(n, BMN)), dim3(WG), 0, st, x2, res_x, n,
-                       make_tail(weights, biases, w_out, b_out, w_att), Z, R, x_out, out, att, nx);
+    if (packed)
+        hipLaunchKernelGGL(node_tail_fwd_kernel<true>, dim3((unsigned)ceil_div(n, BMN)), dim3(WG), 0, st, x2, res_x, n,
+                           make_tail(weights, biases, w_out, b_out, w_att, 1), Z, R, x_out, out, att, nx);
+    else
+        hipLaunchKernelGGL(node_tail_fwd_kernel<false>, dim3((unsigned)ceil_div(n, BMN)), dim3(WG), 0, st, x2, res_x, n,
+                           make_tail(weights, biases, w_out, b_out, w_att, 0), Z, R, x_out, out, att, nx);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -471,15 +552,20 @@ extern "C" int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int
 extern "C" int pamnet_node_tail_bwd_f32(const float* d_xout, const float* d_out, const float* d_att, int64_t n,
                                         const float* const* weights, const float* w_out, const float* w_att,
                                         const float* Z, float* dZ, float* d_x2, float* d_resx, float* head_partial,
-                                        float* d_wout, float* d_watt, float* d_bout, pamnet_stream_t stream) {
+                                        float* d_wout, float* d_watt, float* d_bout, int32_t packed,
+                                        pamnet_stream_t stream) {
     if (n < 0) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
     if (!d_out || !d_att || !weights || !w_out || !w_att || !Z || !dZ || !d_x2 || !d_resx || !head_partial)
         return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
     const unsigned grid = (unsigned)ceil_div(n, BMN);
-    hipLaunchKernelGGL(node_tail_bwd_kernel, dim3(grid), dim3(TWG), 0, st, d_xout, d_out, d_att, n,
-                       make_tail(weights, nullptr, w_out, nullptr, w_att), Z, dZ, d_x2, d_resx, head_partial);
+    if (packed)
+        hipLaunchKernelGGL(node_tail_bwd_kernel<true>, dim3(grid), dim3(TWG), 0, st, d_xout, d_out, d_att, n,
+                           make_tail(weights, nullptr, w_out, nullptr, w_att, 1), Z, dZ, d_x2, d_resx, head_partial);
+    else
+        hipLaunchKernelGGL(node_tail_bwd_kernel<false>, dim3(grid), dim3(TWG), 0, st, d_xout, d_out, d_att, n,
+                           make_tail(weights, nullptr, w_out, nullptr, w_att, 0), Z, dZ, d_x2, d_resx, head_partial);
     PAMNET_LAUNCH_CHECK();
     if (d_wout || d_watt || d_bout) {      // all null: the caller reduces head_partial itself (pamnet_wgrad_batched_f32)
         if (!d_wout || !d_watt || !d_bout) return PAMNET_ENULL;

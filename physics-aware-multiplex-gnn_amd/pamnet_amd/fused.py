@@ -98,7 +98,7 @@ def k_tail_fwd(x2, res_x, tp):
     x_out, out, att = _empty(n, D, like=x2), _empty(n, like=x2), _empty(n, like=x2)
     lib.call('pamnet_node_tail_fwd_f32', lib.ptr(x2), lib.ptr(res_x), n, _parr(W), _parr(b), lib.ptr(w_out),
              lib.ptr(b_out), lib.ptr(w_att), lib.ptr(Z), lib.ptr(R), lib.ptr(x_out), lib.ptr(out), lib.ptr(att),
-             None, None, None, 0, 0, None, None, None, lib.stream_of(x2))
+             None, None, None, 0, 0, None, None, None, 0, lib.stream_of(x2))
     return Z, R, x_out, out, att
 
 
@@ -114,7 +114,7 @@ def k_tail_bwd(g_x, g_out, g_att, tp, Z, d_wout, d_bout, d_watt):
     head_partial = _empty(((n + 15) // 16) * 257, like=Z)
     lib.call('pamnet_node_tail_bwd_f32', lib.ptr(g_x), lib.ptr(g_out), lib.ptr(g_att), n, _parr(W), lib.ptr(w_out),
              lib.ptr(w_att), lib.ptr(Z), lib.ptr(dZ), lib.ptr(d_x2), lib.ptr(d_resx), lib.ptr(head_partial),
-             lib.ptr(d_wout), lib.ptr(d_watt), lib.ptr(d_bout), lib.stream_of(Z))
+             lib.ptr(d_wout), lib.ptr(d_watt), lib.ptr(d_bout), 0, lib.stream_of(Z))
     return dZ, d_x2, d_resx
 
 
@@ -409,6 +409,7 @@ def _temp_arena(n_floats, dev):
 
 
 _AUX = {}
+PACK_WEIGHTS = os.environ.get('PAMNET_PACK_WEIGHTS', '1') != '0'
 AUX_FORK = os.environ.get('PAMNET_AUX_FWD', '0') != '0'      # measured: no gain at B=128 (host-side event cost, CU contention)
 
 
@@ -449,6 +450,17 @@ class StackPlan(object):
         self.flat = self.gflat + self.lflat
         self._probe = [self.flat[0], self.flat[len(self.flat) // 2], self.flat[-1]]
         self._pkey = self._gkey = None
+        self._pack = None
+
+    def pack_arena(self, dev):
+        """Scratch for the fragment-ordered weight images the node chains read (re-packed by every engine call)."""
+        if not PACK_WEIGHTS:
+            return None
+        if self._pack is None or self._pack.device != dev:
+            need = ctypes.c_int64(0)
+            lib.call('pamnet_stack_pack_floats', self.L, ctypes.addressof(need))
+            self._pack = torch.empty(int(need.value), dtype=torch.float32, device=dev)
+        return self._pack
 
     def param_tables(self):
         key = tuple(p.data_ptr() for p in self._probe)
@@ -493,7 +505,7 @@ class _Stack(torch.autograd.Function):
         aux, evs = _aux_fork(x0.device, L)
         lib.call('pamnet_stack_fwd_f32', sizes, idx, L, lib.ptr(x0), lib.ptr(e_g), lib.ptr(rbf_e), lib.ptr(e_sbf),
                  gtab, ltab, lib.ptr(saved), lib.ptr(temp), lib.ptr(outs), lib.ptr(atts),
-                 1 if save else 0, aux, evs, lib.stream_of(x0))
+                 1 if save else 0, lib.ptr(plan.pack_arena(x0.device)), aux, evs, lib.stream_of(x0))
         ctx.save_for_backward(x0, e_g, rbf_e, e_sbf, saved)
         ctx.graph, ctx.plan, ctx.direct, ctx.temp_floats = graph, plan, direct, int(need[1])
         ctx.mark_non_differentiable(saved)
@@ -523,7 +535,8 @@ class _Stack(torch.autograd.Function):
         g_atts = torch.zeros_like(g_outs) if g_atts is None else g_atts.contiguous()
         lib.call('pamnet_stack_bwd_f32', sizes, idx, L, lib.ptr(x0), lib.ptr(e_g), lib.ptr(rbf_e), lib.ptr(e_sbf),
                  gtab, ltab, lib.ptr(saved), lib.ptr(temp), lib.ptr(g_outs), lib.ptr(g_atts), ggrad, lgrad,
-                 lib.ptr(d_x0), lib.ptr(d_eg), lib.ptr(d_rbf), lib.ptr(d_sbf), evs, lib.stream_of(x0))
+                 lib.ptr(d_x0), lib.ptr(d_eg), lib.ptr(d_rbf), lib.ptr(d_sbf), lib.ptr(plan.pack_arena(x0.device)), evs,
+                 lib.stream_of(x0))
         return (d_x0, d_eg, d_rbf, d_sbf, None, None, None, None) + tuple(g)
 
 

@@ -25,14 +25,14 @@ xo, out, att = torch.empty(n, 128, device=dev), torch.empty(n, device=dev), torc
 PA = ctypes.c_void_p * 10
 P = ctypes.c_void_p
 lib.pamnet_node_tail_fwd_f32.argtypes = [P, P, ctypes.c_int64, P, P, P, P, P, P, P, P, P, P, P, P, P, ctypes.c_int64,
-                                         ctypes.c_int64, P, P, P, P]
+                                         ctypes.c_int64, P, P, P, ctypes.c_int32, P]
 Wp, bp = PA(*[t.data_ptr() for t in W]), PA(*[t.data_ptr() for t in b])
 st = torch.cuda.current_stream().cuda_stream
 for it in range(3):
     for _ in range(100 if it else 1):
         rc = lib.pamnet_node_tail_fwd_f32(x2.data_ptr(), rx.data_ptr(), n, Wp, bp, w_out.data_ptr(), b_out.data_ptr(),
                                           w_att.data_ptr(), Z.data_ptr(), R.data_ptr(), xo.data_ptr(), out.data_ptr(),
-                                          att.data_ptr(), None, None, None, 0, 0, None, None, None, st)
+                                          att.data_ptr(), None, None, None, 0, 0, None, None, None, 0, st)
         assert rc == 0, rc
     torch.cuda.synchronize()
     buf = (ctypes.c_longlong * 64)()
