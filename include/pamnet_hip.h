@@ -171,7 +171,8 @@ int pamnet_node_tail_bwd_f32(const float* d_xout, const float* d_out, const floa
                              float* d_bout, int32_t packed, pamnet_stream_t stream);
 /* Fragment-ordered weight images for the node chains: n (<= 192) 128x128 matrices (row stride ld[i]) -> images[i*16384..],
  * transposed = 0 for the forward (Y = X W^T), 1 for the backward (Y = X W).  With packed != 0 the `weights` (and, in the
- * forward, next_Wx1 / next_wp) arguments of node_tail_fwd / node_tail_bwd are such images: every weight-slice request of
+ * forward, next_Wx1 / next_wp) arguments of node_tail_fwd / node_tail_bwd, and Wx1 / wp of node_pre_bwd (transposed
+ * images), are such images: every weight-slice request of
  * a wave is then one contiguous 1 KB read instead of 16 half-used cache lines of the row-major matrix. */
 int pamnet_pack_weights_f32(int64_t n, const float* const* W, const int64_t* ld, int32_t transposed, float* images,
                             pamnet_stream_t stream);
@@ -179,7 +180,7 @@ int pamnet_node_pre_fwd_f32(const float* x, int64_t n, const float* Wx1, const f
                             int64_t ldwp, int64_t nblk, float* Zx1, float* x1, float* P, pamnet_stream_t stream);
 int pamnet_node_pre_bwd_f32(const float* dP, const float* dx1_direct, const float* d_add, int64_t n, const float* Wx1,
                             const float* const* wp, int64_t ldwp, int64_t nblk, const float* Zx1, float* dZx1,
-                            float* dx, pamnet_stream_t stream);
+                            float* dx, int32_t packed, pamnet_stream_t stream);
 int pamnet_wgrad_scratch_floats(int64_t njobs, const int64_t* rows, int64_t* floats);
 int pamnet_wgrad_batched_f32(int64_t njobs, const float* const* dZ, const int64_t* ld_dz, const float* const* A,
                              const int64_t* ld_a, const int32_t* a_mode, const int64_t* rows, float* const* dW,

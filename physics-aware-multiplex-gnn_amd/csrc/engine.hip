@@ -377,14 +377,21 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
     // transposed weight images of both node chains of every layer (optional `wpack` arena), one pack launch
     const bool packed = wpack != nullptr;
     struct PairImgT {
-        const float *gt[10], *lt[10];
+        const float *gt[10], *lt[10], *gh[3], *lh[5];      // chains; heads: {projection blocks ..., Wx1}
     };
     PairImgT* img = packed ? static_cast<PairImgT*>(alloca(sizeof(PairImgT) * n_layer)) : nullptr;
     if (packed) {
         PackList pl(wpack, 1, st);
         for (int64_t k = n_layer - 1; k >= 0; --k) {
-            for (int i = 0; i < 10; ++i) img[k].lt[i] = pl.add(lparams[k * NL + LT + i], D);
-            for (int i = 0; i < 10; ++i) img[k].gt[i] = pl.add(gparams[k * NG + GT + i], D);
+            const float* const* lp = lparams + k * NL;
+            const float* const* gp = gparams + k * NG;
+            for (int i = 0; i < 10; ++i) img[k].lt[i] = pl.add(lp[LT + i], D);
+            img[k].lh[0] = pl.add(lp[2], 3 * D), img[k].lh[1] = pl.add(lp[4], 3 * D);
+            img[k].lh[2] = pl.add(lp[2] + D, 3 * D), img[k].lh[3] = pl.add(lp[4] + D, 3 * D);
+            img[k].lh[4] = pl.add(lp[0], D);
+            for (int i = 0; i < 10; ++i) img[k].gt[i] = pl.add(gp[GT + i], D);
+            img[k].gh[0] = pl.add(gp[2], 3 * D), img[k].gh[1] = pl.add(gp[2] + D, 3 * D);
+            img[k].gh[2] = pl.add(gp[0], D);
         }
         pl.flush();
         CK(pl.rc);
@@ -424,7 +431,8 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             }
             const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
             float* dx = dx_bufs[flip];
-            CK(pamnet_node_pre_bwd_f32(t.dP, t.dx2, t.dresx, g.n, lp[0], wpl, 3 * D, 4, q.Zx1, t.dZx1, dx, st));
+            CK(pamnet_node_pre_bwd_f32(t.dP, t.dx2, t.dresx, g.n, packed ? img[k].lh[4] : lp[0], packed ? img[k].lh : wpl,
+                                       3 * D, 4, q.Zx1, t.dZx1, dx, pk, st));
             Jobs j;
             tail_jobs(j, g, t.dZ, q.x2, q.Z, q.R, q.xout, lg + LT);
             j.add(t.dZx1, x_in, 0, g.n, lg[0], D, lg[1]);
@@ -462,7 +470,8 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             }
             const float* wpg[2] = {gp[2], gp[2] + D};
             float* dx = (k == 0) ? d_x0 : dx_bufs[flip];
-            CK(pamnet_node_pre_bwd_f32(t.dP, t.dx2, t.dresx, g.n, gp[0], wpg, 3 * D, 2, s.Zx1, t.dZx1, dx, st));
+            CK(pamnet_node_pre_bwd_f32(t.dP, t.dx2, t.dresx, g.n, packed ? img[k].gh[2] : gp[0], packed ? img[k].gh : wpg,
+                                       3 * D, 2, s.Zx1, t.dZx1, dx, pk, st));
             Jobs j;
             tail_jobs(j, g, t.dZ, s.x2, s.Z, s.R, s.xout, gg + GT);
             j.add(t.dZx1, x_in, 0, g.n, gg[0], D, gg[1]);

@@ -121,6 +121,27 @@ __device__ __forceinline__ void load_wfrag(WFrag& f, const float* __restrict__ W
     }
 }
 
+// Fragment-ordered weight image (pamnet_pack_weights_f32): img4[(j*8 + q)*64 + lane] holds, for 16-column tile j and
+// k-group q, the float4 each lane feeds to the MFMAs -- a wave's request for one k-group is one contiguous 1 KB read.
+constexpr int IMG = DIM * DIM;               // floats per image
+__device__ __forceinline__ void load_wfrag_img(WFrag& f, const float* __restrict__ img) {       // 4 waves x 32 columns
+    const float4* p4 = reinterpret_cast<const float4*>(img) + (threadIdx.x & 63);
+    const int j = (threadIdx.x >> 6) * 2;
+#pragma unroll
+    for (int q = 0; q < DIM / 16; ++q) {
+        f.b[q][0] = p4[(j * 8 + q) * 64];
+        f.b[q][1] = p4[((j + 1) * 8 + q) * 64];
+    }
+}
+
+// next weight slice of a 4-wave chain (TRANS selects the row-major access pattern; images carry their orientation): fragment-ordered image, or row-major matrix with row stride ld
+template <bool PACKED, bool TRANS = false>
+__device__ __forceinline__ void load_w(WFrag& f, const float* __restrict__ W, int ld, int wc) {
+    if constexpr (PACKED) load_wfrag_img(f, W);
+    else load_wfrag<TRANS>(f, W, ld, wc);
+}
+
+
 template <int MT>
 __device__ __forceinline__ void mma_tile_frag(const float* __restrict__ As, const WFrag& f, f32x4 (&acc)[MT][2]) {
     const int lane = threadIdx.x & 63;

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(WG) void node_pre_fwd_kernel(const float* __restric
 }
 
 // backward of the head: d x1 = dP * Wp + d x1_direct ; dz = d x1 * SiLU'(z_x1) ; d x = dz * Wx1 (+ d_add)
+template <bool PACKED>
 __global__ __launch_bounds__(WG) void node_pre_bwd_kernel(const float* __restrict__ dP, const float* __restrict__ dx1_direct,
                                                           const float* __restrict__ d_add /* may be null */, int64_t n,
                                                           const float* __restrict__ Wx1, const float* wp0,
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(WG) void node_pre_bwd_kernel(const float* __restric
     f32x4 acc[1][2];
     acc_zero<1>(acc);
     WFrag wf;
-    load_wfrag<true>(wf, wps[0], ldwp, wcol0);
+    load_w<PACKED, true>(wf, wps[0], ldwp, wcol0);
     sweep_rows<BMN>([&](int r, int c4) {
         const int64_t g = row0 + r;
         for (int b = 0; b < nblk; ++b) st_lds4(PL + b * SLOT, r, c4, ldg4z(dP + (int64_t)b * plane_p, g, n, DIM, c4));
@@ -117,8 +118,8 @@ __global__ __launch_bounds__(WG) void node_pre_bwd_kernel(const float* __restric
     __syncthreads();
     for (int b = 0; b < nblk; ++b) {
         mma_tile_frag<1>(PL + b * SLOT, wf, acc);             // accumulate over the projection blocks
-        if (b + 1 < nblk) load_wfrag<true>(wf, wps[b + 1], ldwp, wcol0);
-        else load_wfrag<true>(wf, Wx1, DIM, wcol0);           // weights of the final GEMM
+        if (b + 1 < nblk) load_w<PACKED, true>(wf, wps[b + 1], ldwp, wcol0);
+        else load_w<PACKED, true>(wf, Wx1, DIM, wcol0);       // weights of the final GEMM
     }
     acc_to_lds<1>(acc, S1, wcol0, load_bias2(nullptr, wcol0));
     __syncthreads();
@@ -160,14 +161,19 @@ extern "C" int pamnet_node_pre_fwd_f32(const float* x, int64_t n, const float* W
 
 extern "C" int pamnet_node_pre_bwd_f32(const float* dP, const float* dx1_direct, const float* d_add, int64_t n,
                                        const float* Wx1, const float* const* wp, int64_t ldwp, int64_t nblk,
-                                       const float* Zx1, float* dZx1, float* dx, pamnet_stream_t stream) {
+                                       const float* Zx1, float* dZx1, float* dx, int32_t packed,
+                                       pamnet_stream_t stream) {
     if (n < 0 || nblk < 1 || nblk > 4) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
     if (!dP || !Wx1 || !wp || !Zx1 || !dZx1 || !dx) return PAMNET_ENULL;
     const float* w[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int b = 0; b < nblk; ++b) w[b] = wp[b];
-    hipLaunchKernelGGL(node_pre_bwd_kernel, dim3((unsigned)ceil_div(n, BMN)), dim3(WG), 0, as_stream(stream), dP,
-                       dx1_direct, d_add, n, Wx1, w[0], w[1], w[2], w[3], (int)ldwp, (int)nblk, Zx1, dZx1, dx);
+    if (packed)
+        hipLaunchKernelGGL(node_pre_bwd_kernel<true>, dim3((unsigned)ceil_div(n, BMN)), dim3(WG), 0, as_stream(stream), dP,
+                           dx1_direct, d_add, n, Wx1, w[0], w[1], w[2], w[3], (int)ldwp, (int)nblk, Zx1, dZx1, dx);
+    else
+        hipLaunchKernelGGL(node_pre_bwd_kernel<false>, dim3((unsigned)ceil_div(n, BMN)), dim3(WG), 0, as_stream(stream),
+                           dP, dx1_direct, d_add, n, Wx1, w[0], w[1], w[2], w[3], (int)ldwp, (int)nblk, Zx1, dZx1, dx);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

@@ -82,24 +82,6 @@ struct Frag {
 // float4 fragments back to back: img4[(j*8 + q)*64 + lane] -- every request is one contiguous 1 KB read.
 //   forward orientation  (Y = X W^T): lane's float4 = W[16j + (lane&15)][16q + 4(lane>>4) + 0..3]
 //   transposed orientation (Y = X W): lane's float4 = W[16q + 4(lane>>4) + 0..3][16j + (lane&15)]
-constexpr int IMG = DIM * DIM;               // floats per image
-__device__ __forceinline__ void load_wfrag_img(WFrag& f, const float* __restrict__ img) {       // 4 waves x 32 columns
-    const float4* p4 = reinterpret_cast<const float4*>(img) + (threadIdx.x & 63);
-    const int j = (threadIdx.x >> 6) * 2;
-#pragma unroll
-    for (int q = 0; q < DIM / 16; ++q) {
-        f.b[q][0] = p4[(j * 8 + q) * 64];
-        f.b[q][1] = p4[((j + 1) * 8 + q) * 64];
-    }
-}
-
-// next weight slice of a 4-wave chain: fragment-ordered image, or row-major matrix with row stride ld
-template <bool PACKED>
-__device__ __forceinline__ void load_w(WFrag& f, const float* __restrict__ W, int ld, int wc) {
-    if constexpr (PACKED) load_wfrag_img(f, W);
-    else load_wfrag<false>(f, W, ld, wc);
-}
-
 // one 128 x 16 weight slice of a wave: 8 x float4 = 32 VGPRs
 struct WFrag1 {
     float4 b[DIM / 16];

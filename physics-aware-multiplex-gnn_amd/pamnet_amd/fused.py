@@ -87,7 +87,7 @@ def k_pre_bwd(dP, dx1_direct, d_add, Wx1, wps, ldwp, Zx1):
     n, nblk = Zx1.size(0), len(wps)
     dZ, dx = _empty(n, D, like=Zx1), _empty(n, D, like=Zx1)
     lib.call('pamnet_node_pre_bwd_f32', lib.ptr(dP), lib.ptr(dx1_direct), lib.ptr(d_add), n, lib.ptr(Wx1), _parr(wps),
-             ldwp, nblk, lib.ptr(Zx1), lib.ptr(dZ), lib.ptr(dx), lib.stream_of(Zx1))
+             ldwp, nblk, lib.ptr(Zx1), lib.ptr(dZ), lib.ptr(dx), 0, lib.stream_of(Zx1))
     return dZ, dx
 
 
