@@ -520,42 +520,60 @@ __global__ __launch_bounds__(WG8) void mlp2_bwd_kernel(const float* __restrict__
     const Span sp(m, base, rem, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
-        sweep<MTX>(mt, [&](int r, int c4) {
-            const int64_t g = row0 + r;
-            float4 a = f4zero();
-            if (g < sp.end) {
-                a = f4mul(ldg4(dy, g, DIM, c4), f4dsilu(ldg4(z2, g, DIM, c4)));
-                stg4(dz2, g, DIM, c4, a);
+        // z1 and the accumulate operand are requested together with dy / z2: no global load waits mid-chunk
+        float4 z1r[MTX], dxr[MTX];
+        {
+            const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+            for (int i = 0; i < MTX; ++i) {
+                const int64_t g = row0 + r0 + 16 * i;
+                float4 a = f4zero();
+                z1r[i] = f4zero();
+                dxr[i] = f4zero();
+                if (i < mt && g < sp.end) {
+                    a = f4mul(ldg4(dy, g, DIM, c4), f4dsilu(ldg4(z2, g, DIM, c4)));
+                    z1r[i] = ldg4(z1, g, DIM, c4);
+                    if (accumulate) dxr[i] = ldg4(dx, g, DIM, c4);
+                    stg4(dz2, g, DIM, c4, a);
+                }
+                if (i < mt) st_lds4(S0, r0 + 16 * i, c4, a);
             }
-            st_lds4(S0, r, c4, a);
-        });
+        }
         __syncthreads();
         Acc<MTX> acc;
         acc.zero();
         mma_n<MTX>(S0, f2, acc, mt);
         acc_store<MTX>(acc, S1, wc, 0.f, mt);
         __syncthreads();
-        sweep<MTX>(mt, [&](int r, int c4) {
-            const int64_t g = row0 + r;
-            float4 a = f4zero();
-            if (g < sp.end) {
-                a = f4mul(lds4(S1, r, c4), f4dsilu(ldg4(z1, g, DIM, c4)));
-                stg4(dz1, g, DIM, c4, a);
+        {
+            const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+            for (int i = 0; i < MTX; ++i) {
+                if (i >= mt) continue;
+                const int r = r0 + 16 * i;
+                const int64_t g = row0 + r;
+                float4 a = f4zero();
+                if (g < sp.end) {
+                    a = f4mul(lds4(S1, r, c4), f4dsilu(z1r[i]));
+                    stg4(dz1, g, DIM, c4, a);
+                }
+                st_lds4(S1, r, c4, a);
             }
-            st_lds4(S1, r, c4, a);
-        });
+        }
         __syncthreads();
         acc.zero();
         mma_n<MTX>(S1, f1, acc, mt);
         acc_store<MTX>(acc, S0, wc, 0.f, mt);                 // S0 (dz2 tile) was last read before the previous barrier
         __syncthreads();
-        sweep<MTX>(mt, [&](int r, int c4) {
-            const int64_t g = row0 + r;
-            if (g >= sp.end) return;
-            float4 v = lds4(S0, r, c4);
-            if (accumulate) v = f4add(v, ldg4(dx, g, DIM, c4));
-            stg4(dx, g, DIM, c4, v);
-        });
+        {
+            const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+            for (int i = 0; i < MTX; ++i) {
+                const int r = r0 + 16 * i;
+                const int64_t g = row0 + r;
+                if (i < mt && g < sp.end) stg4(dx, g, DIM, c4, f4add(lds4(S0, r, c4), dxr[i]));
+            }
+        }
         __syncthreads();
     }
 }
