@@ -353,6 +353,8 @@ def main():
         return main_train()
     if '--ragged-only' in sys.argv:
         return main_ragged()
+    if '--d128-only' in sys.argv:
+        return main_d128()
     main_forward()
     main_train()
 
@@ -373,8 +375,19 @@ def main_ragged():
                    small=True)
 
 
+def main_d128():
+    """dim = 128 (the fused MI355X engine's width) straight from the reference: PDBbind branch and PAMNet_s; outputs and
+    pooled-node values only (small files)."""
+    pdb = dict(dataset='PDBbind', dim=128, n_layer=3, cutoff_l=2.0, cutoff_g=6.0)
+    fixture_random('pdbbind_d128_l3', ref_models.PAMNet, pdb, synth.pdbbind_batch(9, 0, 2, n_pocket=90, n_ligand=16),
+                   seed=31, capture=False)
+    qm9 = dict(dataset='QM9', dim=128, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+    fixture_random('qm9s_d128_l2', ref_models.PAMNet_s, qm9, synth.qm9_batch(13, 0, 12), seed=31, capture=False, small=True)
+
+
 def main_forward():
     main_ragged()
+    main_d128()
     fixture_star()
     fixture_basis()
     fixture_rna()

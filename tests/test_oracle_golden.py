@@ -62,6 +62,7 @@ def test_basis_tables(golden):
 
 @pytest.mark.parametrize('name,small', [('qm9_d32_l2', False), ('pdbbind_d32_l2', False), ('qm9s_d32_l2', True),
                                         ('qm9_ragged_d32_l2', False), ('qm9s_ragged_d32_l2', True),
+                                        ('pdbbind_d128_l3', False), ('qm9s_d128_l2', True),
                                         ('qm9_d128_l6', False)])
 def test_random_init_forward(golden, name, small):
     g = golden(name)
