@@ -19,6 +19,8 @@
 //   * a workgroup is 8 waves, wave w owns output columns [16w, 16w+16): every weight slice a kernel needs (up to four
 //     128x16 slices = 128 VGPRs) is loaded ONCE per workgroup and stays in registers;
 //   * the workgroup walks its rows in chunks of up to 128 (two-slot kernels) / 96 (three-slot) rows of LDS.
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm_core.h"
 
@@ -142,28 +144,87 @@ __device__ __forceinline__ void acc_store(const Acc<MTX>& acc, float* __restrict
         }
     }
 }
-// 512 threads sweep a [16 mt][128] tile: thread t owns float4 column t & 31 of rows (t >> 5) + 16 i, i < mt.
+// A workgroup is NW waves (8 or 4); wave w owns NS = 8 / NW consecutive 16-column slices.  Two 4-wave workgroups with
+// half the rows each share a CU: same waves per SIMD as one 8-wave workgroup, but their barriers are independent, so one
+// workgroup's load / epilogue sweeps overlap the other's GEMMs (measured -16 % on the triplet/pair MLP).
+// NW*64 threads sweep a [16 mt][128] tile: thread t owns float4 column t & 31 of rows (t >> 5) + 2 NW i.
 // f(row_in_chunk, c4); global accesses inside f are 512-byte coalesced rows.
-template <int MTX, typename F>
+template <int MTX, int NW, typename F>
 __device__ __forceinline__ void sweep(int mt, F&& f) {
     const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    constexpr int RPP = 2 * NW;                               // rows per pass
 #pragma unroll
-    for (int i = 0; i < MTX; ++i)
-        if (i < mt) f(r0 + 16 * i, c4);
+    for (int i = 0; i < 16 * MTX / RPP; ++i)
+        if (RPP * i < 16 * mt) f(r0 + RPP * i, c4);
+}
+
+template <int NS>
+struct WSet {                                                 // a wave's NS slices of one weight matrix
+    WFrag1 s[NS];
+};
+template <bool TRANS, int NS>
+__device__ __forceinline__ void load_wset(WSet<NS>& w, const float* __restrict__ W, int ldw, int wc) {
+#pragma unroll
+    for (int h = 0; h < NS; ++h) load_wfrag1<TRANS>(w.s[h], W, ldw, wc + 16 * h);
+}
+template <int MTX, int NS>
+struct AccSet {
+    Acc<MTX> a[NS];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int h = 0; h < NS; ++h) a[h].zero();
+    }
+};
+template <int MTX, int NS>
+__device__ __forceinline__ void mma_set(const float* __restrict__ As, const WSet<NS>& w, AccSet<MTX, NS>& acc, int mt) {
+#pragma unroll
+    for (int h = 0; h < NS; ++h) mma_n<MTX>(As, w.s[h], acc.a[h], mt);
+}
+template <int NS>
+struct BiasSet {
+    float v[NS];
+};
+template <int NS>
+__device__ __forceinline__ BiasSet<NS> lane_biases(const float* __restrict__ b, int wc) {
+    BiasSet<NS> r;
+#pragma unroll
+    for (int h = 0; h < NS; ++h) r.v[h] = b ? b[wc + 16 * h + (threadIdx.x & 15)] : 0.f;
+    return r;
+}
+template <int MTX, int NS>
+__device__ __forceinline__ void store_set(const AccSet<MTX, NS>& acc, float* __restrict__ Ds, int wc, const BiasSet<NS>& b,
+                                          int mt) {
+#pragma unroll
+    for (int h = 0; h < NS; ++h) acc_store<MTX>(acc.a[h], Ds, wc + 16 * h, b.v[h], mt);
 }
 
 // rows [beg, end) of this workgroup and its chunking: per = 16-row tiles per workgroup, cmt = tiles per chunk
 // workgroup b owns base (+1 for the first `rem` workgroups) consecutive 16-row tiles
+// NW = 4 (paired split, two co-resident workgroups per CU): "CU" c owns pa consecutive tiles; workgroup c takes the first
+// pc of them, workgroup pb + c the rest (pb = number of pairs).
 struct Span {
     int64_t beg, end;
     int cmt;
-    __device__ __forceinline__ Span(int64_t m, int base, int rem, int cmt_) : cmt(cmt_) {
+    template <int NW>
+    static __device__ __forceinline__ Span make(int64_t m, int pa, int pb, int pc, int cmt_) {
+        Span sp;
+        sp.cmt = cmt_;
         const int b = blockIdx.x;
-        const int64_t t0 = (int64_t)b * base + (b < rem ? b : rem);
-        const int64_t cnt = base + (b < rem ? 1 : 0);
-        beg = t0 * 16;
+        int64_t t0, cnt;
+        if (NW == 8) {                                        // pa = base, pb = rem
+            t0 = (int64_t)b * pa + (b < pb ? b : pb);
+            cnt = pa + (b < pb ? 1 : 0);
+        } else {                                              // pa = tiles per pair, pb = pairs, pc = first share
+            const bool second = b >= pb;
+            const int c = second ? b - pb : b;
+            t0 = (int64_t)c * pa + (second ? pc : 0);
+            cnt = second ? pa - pc : pc;
+        }
+        sp.beg = t0 * 16;
         const int64_t e = (t0 + cnt) * 16;
-        end = e < m ? e : m;
+        sp.end = e < m ? e : m;
+        if (sp.beg > sp.end) sp.beg = sp.end;
+        return sp;
     }
 };
 #define CHUNK_LOOP(sp)                                                             \
@@ -174,63 +235,67 @@ __device__ __forceinline__ int chunk_mt(const Span& sp, int64_t row0) {
     return (rows + 15) >> 4;
 }
 
-__device__ __forceinline__ int wave_col() { return (threadIdx.x >> 6) * 16; }
+template <int NW>
+__device__ __forceinline__ int wave_col() { return (threadIdx.x >> 6) * (128 / NW); }
 __device__ __forceinline__ float lane_bias(const float* __restrict__ b, int wc) {
     return b ? b[wc + (threadIdx.x & 15)] : 0.f;
 }
 
 // -------------------------------------------------------------------------------------------------- global edges
-template <int MTX>
-__global__ __launch_bounds__(WG8) void global_edge_fwd_kernel(const float* __restrict__ e, int64_t m,
+template <int MTX, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void global_edge_fwd_kernel(const float* __restrict__ e, int64_t m,
                                                               const float* __restrict__ We, int ld_we,
                                                               const float* __restrict__ bm,
                                                               const float* __restrict__ Wea, int ld_wea,
                                                               const float* __restrict__ Pi, const float* __restrict__ Pj,
                                                               const int32_t* __restrict__ row_of,
                                                               const int32_t* __restrict__ col, float* __restrict__ z,
-                                                              float* __restrict__ ea, float* __restrict__ msg, int base,
-                                                              int rem, int cmt) {
+                                                              float* __restrict__ ea, float* __restrict__ msg, int pa,
+                                                              int pb, int pc, int cmt) {
     __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
     float* S0 = lds;
     float* S1 = lds + MTX * 16 * LDT;
-    const int wc = wave_col();
-    const float bv = lane_bias(bm, wc);
-    WFrag1 f1, f2;
-    load_wfrag1<false>(f1, We, ld_we, wc);
-    load_wfrag1<false>(f2, Wea, ld_wea, wc);
-    const Span sp(m, base, rem, cmt);
+    constexpr int NS = 8 / NW;
+    const int wc = wave_col<NW>();
+    const BiasSet<NS> zero_bias = lane_biases<NS>(nullptr, wc);
+    const BiasSet<NS> bv = lane_biases<NS>(bm, wc);
+    WSet<NS> f1, f2;
+    load_wset<false>(f1, We, ld_we, wc);
+    load_wset<false>(f2, Wea, ld_wea, wc);
+    const Span sp = Span::make<NW>(m, pa, pb, pc, cmt);
     // the NEXT chunk's input rows travel in registers while this chunk's GEMMs run (a workgroup with 9 tiles walks them
     // as 5 + 4: without this its second load phase is fully exposed)
-    float4 pre[MTX];
+    constexpr int RPP = 2 * NW, NI = 16 * MTX / RPP;          // sweep geometry: rows per pass, passes per chunk
+    float4 pre[NI];
     {
         const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
 #pragma unroll
-        for (int i = 0; i < MTX; ++i) pre[i] = ldg4z(e, sp.beg + r0 + 16 * i, sp.end, DIM, c4);
+        for (int i = 0; i < NI; ++i) pre[i] = ldg4z(e, sp.beg + r0 + RPP * i, sp.end, DIM, c4);
     }
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
         {
             const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
 #pragma unroll
-            for (int i = 0; i < MTX; ++i)
-                if (i < mt) st_lds4(S0, r0 + 16 * i, c4, pre[i]);
+            for (int i = 0; i < NI; ++i)
+                if (RPP * i < 16 * mt) st_lds4(S0, r0 + RPP * i, c4, pre[i]);
             const int64_t nxt = row0 + (int64_t)sp.cmt * 16;
             if (nxt < sp.end) {
 #pragma unroll
-                for (int i = 0; i < MTX; ++i) pre[i] = ldg4z(e, nxt + r0 + 16 * i, sp.end, DIM, c4);
+                for (int i = 0; i < NI; ++i) pre[i] = ldg4z(e, nxt + r0 + RPP * i, sp.end, DIM, c4);
             }
         }
         __syncthreads();
-        Acc<MTX> au, aa;
+        AccSet<MTX, NS> au, aa;
         au.zero();
         aa.zero();
-        mma_n<MTX>(S0, f1, au, mt);
-        mma_n<MTX>(S0, f2, aa, mt);
+        mma_set<MTX, NS>(S0, f1, au, mt);
+        mma_set<MTX, NS>(S0, f2, aa, mt);
         __syncthreads();                                   // every wave is done reading the e tile
-        acc_store<MTX>(au, S0, wc, bv, mt);
-        acc_store<MTX>(aa, S1, wc, 0.f, mt);
+        store_set<MTX, NS>(au, S0, wc, bv, mt);
+        store_set<MTX, NS>(aa, S1, wc, zero_bias, mt);
         __syncthreads();
-        sweep<MTX>(mt, [&](int r, int c4) {
+        sweep<MTX, NW>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g >= sp.end) return;
             const int64_t i = row_of[g], j = col[g];
@@ -245,25 +310,27 @@ __global__ __launch_bounds__(WG8) void global_edge_fwd_kernel(const float* __res
 }
 
 // dm[e] = d_agg[i(e)];  dz = dm * ea * SiLU'(z);  dea = dm * SiLU(z);  d_e (+)= dz * W_e + dea * W_ea
-template <int MTX>
-__global__ __launch_bounds__(WG8) void global_edge_bwd_kernel(const float* __restrict__ d_agg,
+template <int MTX, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void global_edge_bwd_kernel(const float* __restrict__ d_agg,
                                                               const int32_t* __restrict__ row_of, int64_t m,
                                                               const float* __restrict__ z, const float* __restrict__ ea,
                                                               const float* __restrict__ We, int ld_we,
                                                               const float* __restrict__ Wea, int ld_wea,
                                                               float* __restrict__ dz, float* __restrict__ dea,
-                                                              float* __restrict__ d_e, int accumulate, int base, int rem, int cmt) {
+                                                              float* __restrict__ d_e, int accumulate, int pa, int pb, int pc, int cmt) {
     __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
     float* S0 = lds;
     float* S1 = lds + MTX * 16 * LDT;
-    const int wc = wave_col();
-    WFrag1 f1, f2;
-    load_wfrag1<true>(f1, We, ld_we, wc);
-    load_wfrag1<true>(f2, Wea, ld_wea, wc);
-    const Span sp(m, base, rem, cmt);
+    constexpr int NS = 8 / NW;
+    const int wc = wave_col<NW>();
+    const BiasSet<NS> zero_bias = lane_biases<NS>(nullptr, wc);
+    WSet<NS> f1, f2;
+    load_wset<true>(f1, We, ld_we, wc);
+    load_wset<true>(f2, Wea, ld_wea, wc);
+    const Span sp = Span::make<NW>(m, pa, pb, pc, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
-        sweep<MTX>(mt, [&](int r, int c4) {
+        sweep<MTX, NW>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             float4 a = f4zero(), b = f4zero();
             if (g < sp.end) {
@@ -278,14 +345,14 @@ __global__ __launch_bounds__(WG8) void global_edge_bwd_kernel(const float* __res
             st_lds4(S1, r, c4, b);
         });
         __syncthreads();
-        Acc<MTX> acc;
+        AccSet<MTX, NS> acc;
         acc.zero();
-        mma_n<MTX>(S0, f1, acc, mt);
-        mma_n<MTX>(S1, f2, acc, mt);
+        mma_set<MTX, NS>(S0, f1, acc, mt);
+        mma_set<MTX, NS>(S1, f2, acc, mt);
         __syncthreads();
-        acc_store<MTX>(acc, S0, wc, 0.f, mt);
+        store_set<MTX, NS>(acc, S0, wc, zero_bias, mt);
         __syncthreads();
-        sweep<MTX>(mt, [&](int r, int c4) {
+        sweep<MTX, NW>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g >= sp.end) return;
             float4 v = lds4(S0, r, c4);
@@ -306,41 +373,43 @@ struct LocalW {
 // blockIdx.y = 0: the k->j half (z_kj, q2, m_nb);  1: the j->i half (z_ji, m_ji, q3).  The two halves share only the
 // input tile, so they run as separate workgroups: two weight slices (64 VGPRs) and one epilogue each instead of four
 // slices and two dependent epilogues in a row -- E_l rows give only ~135 workgroups per half, the chip has room.
-template <int MTX>
-__global__ __launch_bounds__(WG8) void local_edge_fwd_kernel(const float* __restrict__ rbf, int64_t m, LocalW w,
+template <int MTX, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void local_edge_fwd_kernel(const float* __restrict__ rbf, int64_t m, LocalW w,
                                                              const float* __restrict__ b_ji,
                                                              const float* __restrict__ b_kj,
                                                              const int32_t* __restrict__ row_of,
                                                              const int32_t* __restrict__ col, float* __restrict__ z_ji,
                                                              float* __restrict__ z_kj, float* __restrict__ q2,
                                                              float* __restrict__ q3, float* __restrict__ m_ji,
-                                                             float* __restrict__ m_nb, int base, int rem, int cmt) {
+                                                             float* __restrict__ m_nb, int pa, int pb, int pc, int cmt) {
     __shared__ __attribute__((aligned(16))) float lds[3 * MTX * 16 * LDT];
     float* S0 = lds;
     float* S1 = lds + MTX * 16 * LDT;
     float* S2 = lds + 2 * MTX * 16 * LDT;
-    const int wc = wave_col();
+    constexpr int NS = 8 / NW;
+    const int wc = wave_col<NW>();
+    const BiasSet<NS> zero_bias = lane_biases<NS>(nullptr, wc);
     const bool kj = blockIdx.y == 0;
-    const float bz = lane_bias(kj ? b_kj : b_ji, wc);
-    WFrag1 fz, fq;                                            // slice producing z (with bias), slice producing the gate
-    load_wfrag1<false>(fz, w.W[kj ? 1 : 0], w.ld[kj ? 1 : 0], wc);
-    load_wfrag1<false>(fq, w.W[kj ? 2 : 3], w.ld[kj ? 2 : 3], wc);
+    const BiasSet<NS> bz = lane_biases<NS>(kj ? b_kj : b_ji, wc);
+    WSet<NS> fz, fq;                                            // slice producing z (with bias), slice producing the gate
+    load_wset<false>(fz, w.W[kj ? 1 : 0], w.ld[kj ? 1 : 0], wc);
+    load_wset<false>(fq, w.W[kj ? 2 : 3], w.ld[kj ? 2 : 3], wc);
     const float* __restrict__ Pi = w.P[kj ? 1 : 0];
     const float* __restrict__ Pj = w.P[kj ? 3 : 2];
-    const Span sp(m, base, rem, cmt);
+    const Span sp = Span::make<NW>(m, pa, pb, pc, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
-        sweep<MTX>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(rbf, row0 + r, sp.end, DIM, c4)); });
+        sweep<MTX, NW>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(rbf, row0 + r, sp.end, DIM, c4)); });
         __syncthreads();
-        Acc<MTX> acc;
+        AccSet<MTX, NS> acc;
         acc.zero();
-        mma_n<MTX>(S0, fq, acc, mt);                          // q2 = lin_rbf r   |  q3 = lin_rbf_out r
-        acc_store<MTX>(acc, S2, wc, 0.f, mt);
+        mma_set<MTX, NS>(S0, fq, acc, mt);                          // q2 = lin_rbf r   |  q3 = lin_rbf_out r
+        store_set<MTX, NS>(acc, S2, wc, zero_bias, mt);
         acc.zero();
-        mma_n<MTX>(S0, fz, acc, mt);                          // W_kj,e r + b_kj  |  W_ji,e r + b_ji
-        acc_store<MTX>(acc, S1, wc, bz, mt);
+        mma_set<MTX, NS>(S0, fz, acc, mt);                          // W_kj,e r + b_kj  |  W_ji,e r + b_ji
+        store_set<MTX, NS>(acc, S1, wc, bz, mt);
         __syncthreads();
-        sweep<MTX>(mt, [&](int r, int c4) {
+        sweep<MTX, NW>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g >= sp.end) return;
             const int64_t i = row_of[g], j = col[g];
@@ -377,19 +446,19 @@ __global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(const float* __rest
     __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
     float* S0 = lds;
     float* S1 = lds + MTX * 16 * LDT;
-    const int wc = wave_col();
+    const int wc = wave_col<8>();
     WFrag1 f0, f1, f2, f3;
     load_wfrag1<true>(f0, w.W[0], w.ld[0], wc);
     load_wfrag1<true>(f1, w.W[1], w.ld[1], wc);
     load_wfrag1<true>(f2, w.W[2], w.ld[2], wc);
     load_wfrag1<true>(f3, w.W[3], w.ld[3], wc);
-    const Span sp(m, base, rem, cmt);
+    const Span sp = Span::make<8>(m, base, rem, 0, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
         Acc<MTX> acc;
         acc.zero();
         // pass A: dz_ji -> S0, dz_kj -> S1
-        sweep<MTX>(mt, [&](int r, int c4) {
+        sweep<MTX, 8>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             float4 a = f4zero(), b = f4zero();
             if (g < sp.end) {
@@ -406,7 +475,7 @@ __global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(const float* __rest
         mma_n<MTX>(S1, f1, acc, mt);
         __syncthreads();
         // pass B: dq2 -> S0, dq3 -> S1
-        sweep<MTX>(mt, [&](int r, int c4) {
+        sweep<MTX, 8>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             float4 a = f4zero(), b = f4zero();
             if (g < sp.end) {
@@ -423,7 +492,7 @@ __global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(const float* __rest
         __syncthreads();
         acc_store<MTX>(acc, S0, wc, 0.f, mt);
         __syncthreads();
-        sweep<MTX>(mt, [&](int r, int c4) {
+        sweep<MTX, 8>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g >= sp.end) return;
             float4 v = lds4(S0, r, c4);
@@ -444,9 +513,9 @@ struct Mlp2Set {
 struct Mlp2Batch {
     Mlp2Set s[8];
 };
-template <int MTX>
-__global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__ x, int64_t m, Mlp2Batch batch, int base,
-                                                       int rem, int cmt) {
+template <int MTX, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlp2_fwd_kernel(const float* __restrict__ x, int64_t m, Mlp2Batch batch, int pa,
+                                                       int pb, int pc, int cmt) {
     const float* __restrict__ W1 = batch.s[blockIdx.y].W1;
     const float* __restrict__ b1 = batch.s[blockIdx.y].b1;
     const float* __restrict__ W2 = batch.s[blockIdx.y].W2;
@@ -457,27 +526,29 @@ __global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__
     __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
     float* S0 = lds;
     float* S1 = lds + MTX * 16 * LDT;
-    const int wc = wave_col();
-    const float bv1 = lane_bias(b1, wc), bv2 = lane_bias(b2, wc);
+    constexpr int NS = 8 / NW;
+    const int wc = wave_col<NW>();
+    const BiasSet<NS> zero_bias = lane_biases<NS>(nullptr, wc);
+    const BiasSet<NS> bv1 = lane_biases<NS>(b1, wc), bv2 = lane_biases<NS>(b2, wc);
     PROBE(0);
     PROBE_WG(0);
-    WFrag1 f1, f2;
-    load_wfrag1<false>(f1, W1, DIM, wc);
-    load_wfrag1<false>(f2, W2, DIM, wc);
-    const Span sp(m, base, rem, cmt);
+    WSet<NS> f1, f2;
+    load_wset<false>(f1, W1, DIM, wc);
+    load_wset<false>(f2, W2, DIM, wc);
+    const Span sp = Span::make<NW>(m, pa, pb, pc, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
-        sweep<MTX>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(x, row0 + r, sp.end, DIM, c4)); });
+        sweep<MTX, NW>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(x, row0 + r, sp.end, DIM, c4)); });
         __syncthreads();
         PROBE(1);
-        Acc<MTX> acc;
+        AccSet<MTX, NS> acc;
         acc.zero();
-        mma_n<MTX>(S0, f1, acc, mt);
+        mma_set<MTX, NS>(S0, f1, acc, mt);
         PROBE(2);
-        acc_store<MTX>(acc, S1, wc, bv1, mt);
+        store_set<MTX, NS>(acc, S1, wc, bv1, mt);
         __syncthreads();
         PROBE(3);
-        sweep<MTX>(mt, [&](int r, int c4) {
+        sweep<MTX, NW>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             const float4 zz = lds4(S1, r, c4);
             st_lds4(S1, r, c4, f4silu(zz));
@@ -486,12 +557,12 @@ __global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__
         __syncthreads();
         PROBE(4);
         acc.zero();
-        mma_n<MTX>(S1, f2, acc, mt);
+        mma_set<MTX, NS>(S1, f2, acc, mt);
         PROBE(5);
-        acc_store<MTX>(acc, S0, wc, bv2, mt);
+        store_set<MTX, NS>(acc, S0, wc, bv2, mt);
         __syncthreads();
         PROBE(6);
-        sweep<MTX>(mt, [&](int r, int c4) {
+        sweep<MTX, NW>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g >= sp.end) return;
             const float4 zz = lds4(S0, r, c4);
@@ -504,53 +575,56 @@ __global__ __launch_bounds__(WG8) void mlp2_fwd_kernel(const float* __restrict__
     PROBE_WG(1);
 }
 
-template <int MTX>
-__global__ __launch_bounds__(WG8) void mlp2_bwd_kernel(const float* __restrict__ dy, int64_t m,
+template <int MTX, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlp2_bwd_kernel(const float* __restrict__ dy, int64_t m,
                                                        const float* __restrict__ z1, const float* __restrict__ z2,
                                                        const float* __restrict__ W1, const float* __restrict__ W2,
                                                        float* __restrict__ dz1, float* __restrict__ dz2,
-                                                       float* __restrict__ dx, int accumulate, int base, int rem, int cmt) {
+                                                       float* __restrict__ dx, int accumulate, int pa, int pb, int pc, int cmt) {
     __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
     float* S0 = lds;
     float* S1 = lds + MTX * 16 * LDT;
-    const int wc = wave_col();
-    WFrag1 f1, f2;
-    load_wfrag1<true>(f2, W2, DIM, wc);
-    load_wfrag1<true>(f1, W1, DIM, wc);
-    const Span sp(m, base, rem, cmt);
+    constexpr int NS = 8 / NW;
+    const int wc = wave_col<NW>();
+    const BiasSet<NS> zero_bias = lane_biases<NS>(nullptr, wc);
+    WSet<NS> f1, f2;
+    load_wset<true>(f2, W2, DIM, wc);
+    load_wset<true>(f1, W1, DIM, wc);
+    const Span sp = Span::make<NW>(m, pa, pb, pc, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
         // z1 and the accumulate operand are requested together with dy / z2: no global load waits mid-chunk
-        float4 z1r[MTX], dxr[MTX];
+        constexpr int RPP = 2 * NW, NI = 16 * MTX / RPP;      // sweep geometry: rows per pass, passes per chunk
+        float4 z1r[NI], dxr[NI];
         {
             const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
 #pragma unroll
-            for (int i = 0; i < MTX; ++i) {
-                const int64_t g = row0 + r0 + 16 * i;
+            for (int i = 0; i < NI; ++i) {
+                const int64_t g = row0 + r0 + RPP * i;
                 float4 a = f4zero();
                 z1r[i] = f4zero();
                 dxr[i] = f4zero();
-                if (i < mt && g < sp.end) {
+                if (RPP * i < 16 * mt && g < sp.end) {
                     a = f4mul(ldg4(dy, g, DIM, c4), f4dsilu(ldg4(z2, g, DIM, c4)));
                     z1r[i] = ldg4(z1, g, DIM, c4);
                     if (accumulate) dxr[i] = ldg4(dx, g, DIM, c4);
                     stg4(dz2, g, DIM, c4, a);
                 }
-                if (i < mt) st_lds4(S0, r0 + 16 * i, c4, a);
+                if (RPP * i < 16 * mt) st_lds4(S0, r0 + RPP * i, c4, a);
             }
         }
         __syncthreads();
-        Acc<MTX> acc;
+        AccSet<MTX, NS> acc;
         acc.zero();
-        mma_n<MTX>(S0, f2, acc, mt);
-        acc_store<MTX>(acc, S1, wc, 0.f, mt);
+        mma_set<MTX, NS>(S0, f2, acc, mt);
+        store_set<MTX, NS>(acc, S1, wc, zero_bias, mt);
         __syncthreads();
         {
             const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
 #pragma unroll
-            for (int i = 0; i < MTX; ++i) {
-                if (i >= mt) continue;
-                const int r = r0 + 16 * i;
+            for (int i = 0; i < NI; ++i) {
+                if (RPP * i >= 16 * mt) continue;
+                const int r = r0 + RPP * i;
                 const int64_t g = row0 + r;
                 float4 a = f4zero();
                 if (g < sp.end) {
@@ -562,16 +636,16 @@ __global__ __launch_bounds__(WG8) void mlp2_bwd_kernel(const float* __restrict__
         }
         __syncthreads();
         acc.zero();
-        mma_n<MTX>(S1, f1, acc, mt);
-        acc_store<MTX>(acc, S0, wc, 0.f, mt);                 // S0 (dz2 tile) was last read before the previous barrier
+        mma_set<MTX, NS>(S1, f1, acc, mt);
+        store_set<MTX, NS>(acc, S0, wc, zero_bias, mt);                 // S0 (dz2 tile) was last read before the previous barrier
         __syncthreads();
         {
             const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
 #pragma unroll
-            for (int i = 0; i < MTX; ++i) {
-                const int r = r0 + 16 * i;
+            for (int i = 0; i < NI; ++i) {
+                const int r = r0 + RPP * i;
                 const int64_t g = row0 + r;
-                if (i < mt && g < sp.end) stg4(dx, g, DIM, c4, f4add(lds4(S0, r, c4), dxr[i]));
+                if (RPP * i < 16 * mt && g < sp.end) stg4(dx, g, DIM, c4, f4add(lds4(S0, r, c4), dxr[i]));
             }
         }
         __syncthreads();
@@ -581,47 +655,94 @@ __global__ __launch_bounds__(WG8) void mlp2_bwd_kernel(const float* __restrict__
 // One balanced wave of workgroups: `per` 16-row tiles each (<= N_CU workgroups), walked in chunks of `cmt` <= cap tiles.
 struct Plan {
     unsigned grid;
-    int base, rem, cmt;
+    int pa, pb, pc, cmt;       // Span::make arguments
+    bool paired;
 };
-// (Two co-resident workgroups per CU with half the rows each -- 4-tile chunks, 128 VGPRs -- measured slower: 40 / 55 us
-//  against 36 / 41 us for the global edge kernels; they contend for the matrix pipe instead of overlapping phases.)
-inline Plan plan(int64_t rows, int cap, int target_wgs = N_CU) {
+// One wave of 8-wave workgroups, one per CU (or per `target_wgs`): pa = base, pb = rem tiles per workgroup.
+inline Plan plan8(int64_t rows, int cap, int target_wgs = N_CU) {
     const int64_t tiles16 = ceil_div(rows, 16);
     const int64_t per = ceil_div(tiles16, target_wgs);
     const int64_t grid = ceil_div(tiles16, per);
     const int64_t nchunk = ceil_div(per, cap);
     Plan p;
     p.grid = (unsigned)grid;
-    p.base = (int)(tiles16 / grid);
-    p.rem = (int)(tiles16 % grid);
+    p.pa = (int)(tiles16 / grid);
+    p.pb = (int)(tiles16 % grid);
+    p.pc = 0;
     p.cmt = (int)ceil_div(per, nchunk);
+    p.paired = false;
     return p;
 }
+// Pairs of 4-wave workgroups: pair c owns pa tiles (pa = ceil(tiles / target pairs)), split pc + (pa - pc).
+inline Plan plan4(int64_t rows, int cap, int target_pairs = N_CU) {
+    const int64_t tiles16 = ceil_div(rows, 16);
+    const int64_t per = ceil_div(tiles16, target_pairs);
+    const int64_t pairs = ceil_div(tiles16, per);
+    const int64_t hi = (per + 1) / 2;
+    Plan p;
+    p.pa = (int)per;
+    p.pb = (int)pairs;
+    p.pc = (int)hi;
+    p.grid = (unsigned)(per > hi ? 2 * pairs : pairs);
+    p.cmt = (int)ceil_div(hi, ceil_div(hi, cap));
+    p.paired = true;
+    return p;
+}
+// Measured at the QM9 B=128 shape (tools/step_profile.py): the paired 4-wave geometry wins where a launch spans several
+// rounds of workgroups (the all-layers triplet/pair MLP: 104 vs 120 us) and loses or ties on the single-round kernels
+// (17 -> 20 us local edge forward, 25 -> 29 us mlp2 backward), so it is the default only for the former.
+// PAMNET_EDGE_WAVES=4 / 8 forces one geometry everywhere (tests cover both).
+inline int forced_waves() {
+    static const int v = [] { const char* e = getenv("PAMNET_EDGE_WAVES"); return e ? atoi(e) : 0; }();
+    return v;
+}
+inline bool four_waves(bool preferred = false) {
+    const int f = forced_waves();
+    return f == 4 || (f != 8 && preferred);
+}
+inline Plan plan(int64_t rows, int cap8, int cap4, int target = N_CU, bool prefer4 = false) {
+    return four_waves(prefer4) ? plan4(rows, cap4, target) : plan8(rows, cap8, target);
+}
 
-// Instantiations by chunk size: registers (accumulators, A fragments, unrolled sweeps) and LDS follow the template
-// bound, so a launch uses the smallest one that holds its chunks (3 / 5 / 8 tiles of 16 rows; a 9-tile single chunk for E_g measured the same as 5 + 4).
-#define PAMNET_EDGE_LAUNCH(KERNEL, PLAN, GRID, ...)                                                          \
-    do {                                                                                                     \
-        if ((PLAN).cmt <= 3)                                                                                 \
-            hipLaunchKernelGGL(KERNEL<3>, GRID, dim3(WG8), 0, as_stream(stream), __VA_ARGS__, (PLAN).base,   \
-                               (PLAN).rem, (PLAN).cmt);                                                      \
-        else if ((PLAN).cmt <= 5)                                                                            \
-            hipLaunchKernelGGL(KERNEL<5>, GRID, dim3(WG8), 0, as_stream(stream), __VA_ARGS__, (PLAN).base,   \
-                               (PLAN).rem, (PLAN).cmt);                                                      \
-        else                                                                                                 \
-            hipLaunchKernelGGL(KERNEL<8>, GRID, dim3(WG8), 0, as_stream(stream), __VA_ARGS__, (PLAN).base,   \
-                               (PLAN).rem, (PLAN).cmt);                                                      \
+// Instantiations by geometry and chunk size: registers (accumulators, A fragments, unrolled sweeps) and LDS follow the
+// template bound, so a launch uses the smallest one that holds its chunks: 8 waves x {3, 5, 8} tiles of 16 rows, or
+// 4 waves x {2, 3} (two workgroups per CU; larger 4-wave chunks spill: the sweeps unroll twice as far).
+#define PAMNET_EDGE_LAUNCH(KERNEL, PLAN, GRIDY, ...)                                                                   \
+    do {                                                                                                               \
+        const dim3 grid__((PLAN).grid, GRIDY);                                                                         \
+        if ((PLAN).paired) {                                                                                           \
+            if ((PLAN).cmt <= 2)                                                                                       \
+                hipLaunchKernelGGL((KERNEL<2, 4>), grid__, dim3(256), 0, as_stream(stream), __VA_ARGS__, (PLAN).pa,    \
+                                   (PLAN).pb, (PLAN).pc, (PLAN).cmt);                                                  \
+            else                                                                                                       \
+                hipLaunchKernelGGL((KERNEL<3, 4>), grid__, dim3(256), 0, as_stream(stream), __VA_ARGS__, (PLAN).pa,    \
+                                   (PLAN).pb, (PLAN).pc, (PLAN).cmt);                                                  \
+        } else if ((PLAN).cmt <= 3) {                                                                                  \
+            hipLaunchKernelGGL((KERNEL<3, 8>), grid__, dim3(WG8), 0, as_stream(stream), __VA_ARGS__, (PLAN).pa,        \
+                               (PLAN).pb, (PLAN).pc, (PLAN).cmt);                                                      \
+        } else if ((PLAN).cmt <= 5) {                                                                                  \
+            hipLaunchKernelGGL((KERNEL<5, 8>), grid__, dim3(WG8), 0, as_stream(stream), __VA_ARGS__, (PLAN).pa,        \
+                               (PLAN).pb, (PLAN).pc, (PLAN).cmt);                                                      \
+        } else {                                                                                                       \
+            hipLaunchKernelGGL((KERNEL<8, 8>), grid__, dim3(WG8), 0, as_stream(stream), __VA_ARGS__, (PLAN).pa,        \
+                               (PLAN).pb, (PLAN).pc, (PLAN).cmt);                                                      \
+        }                                                                                                              \
     } while (0)
 
-// three-slot kernel: 5 tiles per chunk is the LDS limit (the plan caps its chunks there)
-#define PAMNET_EDGE_LAUNCH35(KERNEL, PLAN, GRID, ...)                                                        \
-    do {                                                                                                     \
-        if ((PLAN).cmt <= 3)                                                                                 \
-            hipLaunchKernelGGL(KERNEL<3>, GRID, dim3(WG8), 0, as_stream(stream), __VA_ARGS__, (PLAN).base,   \
-                               (PLAN).rem, (PLAN).cmt);                                                      \
-        else                                                                                                 \
-            hipLaunchKernelGGL(KERNEL<5>, GRID, dim3(WG8), 0, as_stream(stream), __VA_ARGS__, (PLAN).base,   \
-                               (PLAN).rem, (PLAN).cmt);                                                      \
+// three-slot kernel (local edge forward): chunks of <= 5 tiles with 8 waves (149 KB... 3 x 5 x 16 rows), <= 2 with 4 waves
+#define PAMNET_EDGE_LAUNCH3(KERNEL, PLAN, GRIDY, ...)                                                                  \
+    do {                                                                                                               \
+        const dim3 grid__((PLAN).grid, GRIDY);                                                                         \
+        if ((PLAN).paired) {                                                                                           \
+            hipLaunchKernelGGL((KERNEL<2, 4>), grid__, dim3(256), 0, as_stream(stream), __VA_ARGS__, (PLAN).pa,        \
+                               (PLAN).pb, (PLAN).pc, (PLAN).cmt);                                                      \
+        } else if ((PLAN).cmt <= 3) {                                                                                  \
+            hipLaunchKernelGGL((KERNEL<3, 8>), grid__, dim3(WG8), 0, as_stream(stream), __VA_ARGS__, (PLAN).pa,        \
+                               (PLAN).pb, (PLAN).pc, (PLAN).cmt);                                                      \
+        } else {                                                                                                       \
+            hipLaunchKernelGGL((KERNEL<5, 8>), grid__, dim3(WG8), 0, as_stream(stream), __VA_ARGS__, (PLAN).pa,        \
+                               (PLAN).pb, (PLAN).pc, (PLAN).cmt);                                                      \
+        }                                                                                                              \
     } while (0)
 
 }  // namespace
@@ -633,8 +754,8 @@ extern "C" int pamnet_global_edge_fwd_f32(const float* e, int64_t n_edges, const
     if (n_edges < 0) return PAMNET_EINVAL;
     if (n_edges == 0) return PAMNET_OK;
     if (!e || !We || !bm || !Wea || !Pi || !Pj || !row_of || !col || !msg) return PAMNET_ENULL;   // z, ea: optional saves
-    const Plan p = plan(n_edges, MT2);
-    PAMNET_EDGE_LAUNCH(global_edge_fwd_kernel, p, dim3(p.grid), e, n_edges, We, (int)ld_we, bm, Wea, (int)ld_wea, Pi, Pj,
+    const Plan p = plan(n_edges, MT2, 3);
+    PAMNET_EDGE_LAUNCH(global_edge_fwd_kernel, p, 1, e, n_edges, We, (int)ld_we, bm, Wea, (int)ld_wea, Pi, Pj,
                        row_of, col, z, ea, msg);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
@@ -647,8 +768,8 @@ extern "C" int pamnet_global_edge_bwd_f32(const float* d_agg, const int32_t* row
     if (n_edges < 0) return PAMNET_EINVAL;
     if (n_edges == 0) return PAMNET_OK;
     if (!d_agg || !row_of || !z || !ea || !We || !Wea || !dz || !dea || !d_e) return PAMNET_ENULL;
-    const Plan p = plan(n_edges, MT2);
-    PAMNET_EDGE_LAUNCH(global_edge_bwd_kernel, p, dim3(p.grid), d_agg, row_of, n_edges, z, ea, We, (int)ld_we, Wea,
+    const Plan p = plan(n_edges, MT2, 3);
+    PAMNET_EDGE_LAUNCH(global_edge_bwd_kernel, p, 1, d_agg, row_of, n_edges, z, ea, We, (int)ld_we, Wea,
                        (int)ld_wea, dz, dea, d_e, (int)accumulate);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
@@ -676,8 +797,8 @@ extern "C" int pamnet_local_edge_fwd_f32(const float* rbf, int64_t n_edges, cons
     LocalW w;
     int rc = fill_local(w, Wq, ldq, P);
     if (rc) return rc;
-    const Plan p = plan(n_edges, 5, N_CU / 2);              // two halves (grid.y): together one workgroup per CU
-    PAMNET_EDGE_LAUNCH35(local_edge_fwd_kernel, p, dim3(p.grid, 2), rbf, n_edges, w, b_ji, b_kj, row_of, col, z_ji, z_kj, q2,
+    const Plan p = plan(n_edges, 5, 2, N_CU / 2);           // two halves (grid.y) share the CUs
+    PAMNET_EDGE_LAUNCH3(local_edge_fwd_kernel, p, 2, rbf, n_edges, w, b_ji, b_kj, row_of, col, z_ji, z_kj, q2,
                        q3, m_ji, m_nb);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
@@ -695,9 +816,9 @@ extern "C" int pamnet_local_edge_bwd_f32(const float* d_mji, const float* d_mnb,
     int rc = fill_local(w, Wq, ldq, nullptr);
     if (rc) return rc;
     constexpr int MTL = 3;
-    const Plan p = plan(n_edges, MTL);
+    const Plan p = plan8(n_edges, MTL);                     // four weight matrices: stays one 8-wave workgroup per CU
     hipLaunchKernelGGL(local_edge_bwd_kernel<MTL>, dim3(p.grid), dim3(WG8), 0, as_stream(stream), d_mji, d_mnb, d_q3, n_edges,
-                       z_ji, z_kj, q2, w, dz_ji, dz_kj, dq2, d_rbf, (int)accumulate, p.base, p.rem, p.cmt);
+                       z_ji, z_kj, q2, w, dz_ji, dz_kj, dq2, d_rbf, (int)accumulate, p.pa, p.pb, p.cmt);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -707,10 +828,10 @@ extern "C" int pamnet_mlp2_fwd_f32(const float* x, int64_t rows, const float* W1
     if (rows < 0) return PAMNET_EINVAL;
     if (rows == 0) return PAMNET_OK;
     if (!x || !W1 || !b1 || !W2 || !b2 || !y) return PAMNET_ENULL;                  // z1, z2: optional saves
-    const Plan p = plan(rows, MT2);
+    const Plan p = plan(rows, MT2, 3);
     Mlp2Batch b;
     for (int k = 0; k < 8; ++k) b.s[k] = Mlp2Set{W1, b1, W2, b2, z1, z2, y};
-    PAMNET_EDGE_LAUNCH(mlp2_fwd_kernel, p, dim3(p.grid), x, rows, b);
+    PAMNET_EDGE_LAUNCH(mlp2_fwd_kernel, p, 1, x, rows, b);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -730,8 +851,8 @@ extern "C" int pamnet_mlp2_fwd_multi_f32(const float* x, int64_t rows, int64_t n
         b.s[k] = Mlp2Set{params[4 * s], params[4 * s + 1], params[4 * s + 2], params[4 * s + 3],
                          outs[3 * s], outs[3 * s + 1], outs[3 * s + 2]};
     }
-    const Plan p = plan(rows, MT2);
-    PAMNET_EDGE_LAUNCH(mlp2_fwd_kernel, p, dim3(p.grid, (unsigned)nsets), x, rows, b);
+    const Plan p = plan(rows, MT2, 3, N_CU, nsets > 1);      // several sets = several rounds: paired 4-wave workgroups
+    PAMNET_EDGE_LAUNCH(mlp2_fwd_kernel, p, (unsigned)nsets, x, rows, b);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -742,8 +863,8 @@ extern "C" int pamnet_mlp2_bwd_f32(const float* dy, int64_t rows, const float* z
     if (rows < 0) return PAMNET_EINVAL;
     if (rows == 0) return PAMNET_OK;
     if (!dy || !z1 || !z2 || !W1 || !W2 || !dz1 || !dz2 || !dx) return PAMNET_ENULL;
-    const Plan p = plan(rows, MT2);
-    PAMNET_EDGE_LAUNCH(mlp2_bwd_kernel, p, dim3(p.grid), dy, rows, z1, z2, W1, W2, dz1, dz2, dx, (int)accumulate);
+    const Plan p = plan(rows, MT2, 3);
+    PAMNET_EDGE_LAUNCH(mlp2_bwd_kernel, p, 1, dy, rows, z1, z2, W1, W2, dz1, dz2, dx, (int)accumulate);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

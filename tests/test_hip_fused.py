@@ -179,3 +179,19 @@ def test_embed_layers(dev, rows, case):
         assert ok, ('dx', info)
     else:
         assert x.grad is None
+
+
+@pytest.mark.parametrize('waves', ['4', '8'])
+def test_edge_kernel_geometries(waves):
+    """Both workgroup geometries of the edge kernels (8 waves, one per CU / paired 4-wave workgroups) give the same
+    parity: the layer-level and model-level checks re-run in a subprocess with the geometry forced."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PAMNET_EDGE_WAVES=waves)
+    out = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', os.path.join(here, 'test_hip_fused.py'),
+                          os.path.join(here, 'test_hip_model.py'), '-k',
+                          'full_layer or fused_engine or forward_vs_reference or gradients_vs_reference'],
+                         capture_output=True, text=True, env=env, timeout=900, cwd=os.path.dirname(here))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
