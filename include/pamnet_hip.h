@@ -65,7 +65,8 @@ int pamnet_gather_mul2_f32(float* out1, float* out2, const float* A, const int32
 int pamnet_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* tmp, pamnet_stream_t stream);
 
 /* Stable counting sort of m keys in [0, rows): ptr[rows+1] (CSR) and perm[m] with keys[perm[q]] non-decreasing and
- * perm ascending inside a row.  Scratch: `cursor` rows ints, `perm_tmp` m ints, `tmp` as for the scan.  Deterministic. */
+ * perm ascending inside a row.  Scratch: `cursor` rows ints, `perm_tmp` m ints, `tmp` ceil(rows/4096)+1 ints (the scan's
+ * chunk sums plus one flag: an already non-decreasing key sequence takes the identity-permutation path).  Deterministic. */
 int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t rows, int32_t* ptr, int32_t* perm,
                              int32_t* cursor, int32_t* perm_tmp, int32_t* tmp, pamnet_stream_t stream);
 

@@ -79,10 +79,34 @@ __global__ __launch_bounds__(256) void scan_add_kernel(int32_t* __restrict__ out
     if (g < n) out[g + 1] += sums[g / SCAN_CHUNK];
 }
 
+// Runs of equal keys inside a wavefront (the common case: keys emitted row by row) are folded into one atomic by the
+// run's first lane; `head_of` / `run_len` describe the run a lane belongs to.
+struct Run { int head; int len; };
+__device__ __forceinline__ Run wave_run(int key, bool valid, int lane) {
+    const int prev = __shfl_up(key, 1, 64);
+    const bool head = valid && (lane == 0 || prev != key);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long live = __ballot(valid);
+    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    Run r;
+    r.head = 63 - __builtin_clzll(below | 1ull);
+    const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+    const int nlive = __builtin_popcountll(live);            // valid lanes are a prefix of the wavefront
+    const int next = above ? (lane + 1 + __builtin_ctzll(above)) : nlive;
+    r.len = next - lane;                                     // meaningful on head lanes only
+    return r;
+}
+
+// count[key] += multiplicity; *unsorted = 1 if the key sequence ever decreases (then the sort below is needed)
 __global__ __launch_bounds__(256) void hist_kernel(const int32_t* __restrict__ keys, int64_t m,
-                                                   int32_t* __restrict__ count) {
+                                                   int32_t* __restrict__ count, int32_t* __restrict__ unsorted) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < m) atomicAdd(&count[keys[k]], 1);
+    const int lane = threadIdx.x & 63;
+    const bool valid = k < m;
+    const int key = valid ? keys[k] : -1;
+    const Run r = wave_run(key, valid, lane);
+    if (valid && r.head == lane) atomicAdd(&count[key], r.len);
+    if (valid && k + 1 < m && keys[k + 1] < key) *unsorted = 1;
 }
 
 __global__ __launch_bounds__(256) void copy_i32_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst,
@@ -91,10 +115,23 @@ __global__ __launch_bounds__(256) void copy_i32_kernel(const int32_t* __restrict
     if (k < n) dst[k] = src[k];
 }
 
+// sorted key sequence: the stable permutation is the identity.  Otherwise every run claims a block of slots.
 __global__ __launch_bounds__(256) void claim_kernel(const int32_t* __restrict__ keys, int64_t m,
-                                                    int32_t* __restrict__ cursor, int32_t* __restrict__ perm_tmp) {
+                                                    int32_t* __restrict__ cursor, int32_t* __restrict__ perm_tmp,
+                                                    int32_t* __restrict__ perm, const int32_t* __restrict__ unsorted) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < m) perm_tmp[atomicAdd(&cursor[keys[k]], 1)] = (int32_t)k;
+    if (*unsorted == 0) {
+        if (k < m) perm[k] = (int32_t)k;
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const bool valid = k < m;
+    const int key = valid ? keys[k] : -1;
+    const Run r = wave_run(key, valid, lane);
+    int base = 0;
+    if (valid && r.head == lane) base = atomicAdd(&cursor[key], r.len);
+    base = __shfl(base, r.head, 64);
+    if (valid) perm_tmp[base + (lane - r.head)] = (int32_t)k;
 }
 
 // one thread per claimed entry: its rank among the (distinct) entries of its row -> ascending perm inside each row.
@@ -102,14 +139,23 @@ __global__ __launch_bounds__(256) void claim_kernel(const int32_t* __restrict__ 
 __global__ __launch_bounds__(256) void sort_rows_kernel(const int32_t* __restrict__ keys,
                                                         const int32_t* __restrict__ ptr,
                                                         const int32_t* __restrict__ perm_tmp,
-                                                        int32_t* __restrict__ perm, int64_t m) {
+                                                        int32_t* __restrict__ perm, int64_t m,
+                                                        const int32_t* __restrict__ unsorted) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= m) return;
+    if (*unsorted == 0 || q >= m) return;
     const int v = perm_tmp[q];
     const int r = keys[v];
     const int beg = ptr[r], end = ptr[r + 1];
     int rank = 0;
-    for (int t = beg; t < end; ++t) rank += (perm_tmp[t] < v) ? 1 : 0;
+    int t = beg;
+    for (; t + 8 <= end; t += 8) {                           // eight independent loads in flight
+        int a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = perm_tmp[t + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rank += (a[u] < v) ? 1 : 0;
+    }
+    for (; t < end; ++t) rank += (perm_tmp[t] < v) ? 1 : 0;
     perm[beg + rank] = v;
 }
 
@@ -323,8 +369,11 @@ extern "C" int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t 
     hipStream_t st = as_stream(stream);
     hipError_t e = hipMemsetAsync(cursor, 0, sizeof(int32_t) * rows, st);
     if (e != hipSuccess) return (int)e;
+    int32_t* unsorted = tmp + ceil_div(rows, SCAN_CHUNK);    // the spare int behind the scan's chunk sums
+    e = hipMemsetAsync(unsorted, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return (int)e;
     if (m > 0) {
-        hipLaunchKernelGGL(hist_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, cursor);
+        hipLaunchKernelGGL(hist_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, cursor, unsorted);
         PAMNET_LAUNCH_CHECK();
     }
     int rc = pamnet_exclusive_scan_i32(cursor, ptr, rows, tmp, stream);
@@ -332,9 +381,9 @@ extern "C" int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t 
     if (m == 0) return PAMNET_OK;
     hipLaunchKernelGGL(copy_i32_kernel, dim3(blocks_for(rows)), dim3(256), 0, st, ptr, cursor, rows);
     PAMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(claim_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, cursor, perm_tmp);
+    hipLaunchKernelGGL(claim_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, cursor, perm_tmp, perm, unsorted);
     PAMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sort_rows_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, ptr, perm_tmp, perm, m);
+    hipLaunchKernelGGL(sort_rows_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, ptr, perm_tmp, perm, m, unsorted);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
