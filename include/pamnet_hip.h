@@ -296,6 +296,46 @@ int pamnet_adam_ema_f32(float* p, float* g, float* m, float* v, float* shadow, i
                         float beta2, float eps, float weight_decay, int64_t step_count, float ema_decay,
                         const float* grad_norm, float max_norm, int32_t zero_grad, pamnet_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Narrow widths (d = 16 / 32 / 64: the reference's RNA configurations, inference_rna_puzzles.py:29-30,
+ * main_rna_puzzles.py:52-53).  Row-wise kernels, one wavefront per 16-row tile; backward kernels recompute the forward
+ * pre-activations and return weight gradients reduced in fixed order.  `partial` scratch: *blocks (from
+ * pamnet_narrow_blocks(rows, &blocks)) rows of the stride given per call.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pamnet_narrow_blocks(int64_t rows, int64_t* blocks /* host */);
+
+/* Global message (layers/global_message_passing.py:52-53, W_m split into node / edge blocks):
+ *   msg[q] = SiLU(P[tgt[q], :d] + P[src[q], d:] + e[q] We^T + b) * (e[q] Wea^T);  P is [N, 2d], We/Wea [d, d] with row
+ *   strides ldwe / ldwea (multiples of 4).  The caller segment-sums msg over tgt. */
+int pamnet_narrow_global_fwd_f32(const float* e, int64_t m, int64_t d, const int32_t* tgt, const int32_t* src,
+                                 const float* P, const float* We, int64_t ldwe, const float* bias, const float* Wea,
+                                 int64_t ldwea, float* msg, pamnet_stream_t stream);
+/* dagg [N, d] = gradient of the aggregated message (d msg[q] = dagg[tgt[q]]).  Outputs: dz [m, d] (the caller
+ * segment-sums it over tgt and over src into dP), de [m, d], dWe/dWea [d, d] dense, db [d].
+ * partial: pamnet_narrow_blocks(m) x (2 d^2 + d) floats. */
+int pamnet_narrow_global_bwd_f32(const float* e, int64_t m, int64_t d, const int32_t* tgt, const int32_t* src,
+                                 const float* P, const float* We, int64_t ldwe, const float* bias, const float* Wea,
+                                 int64_t ldwea, const float* dagg, float* dz, float* de, float* partial, float* dWe,
+                                 float* dWea, float* db, pamnet_stream_t stream);
+
+/* y = SiLU(W2 SiLU(W1 x + b1) + b2) on [m, d] rows (mlp_sbf, layers/local_message_passing.py:24,49); dense [d, d]. */
+int pamnet_narrow_mlp2_fwd_f32(const float* x, int64_t m, int64_t d, const float* W1, const float* b1, const float* W2,
+                               const float* b2, float* y, pamnet_stream_t stream);
+/* dx optional (null: not needed); dW [2, d, d], db [2, d]; partial: blocks x (2 d^2 + 2 d) floats. */
+int pamnet_narrow_mlp2_bwd_f32(const float* x, int64_t m, int64_t d, const float* W1, const float* b1, const float* W2,
+                               const float* b2, const float* dy, float* dx, float* partial, float* dW, float* db,
+                               pamnet_stream_t stream);
+
+/* Edge-embedding MLPs (models.py:185-188): y = SiLU(W f + b), f [m, k], k = 16 or 42, W [d, k] dense.  With `kind`
+ * [m] rows of kind 0 use (Wa, ba) and rows of kind != 0 use (Wb, bb); kind null: one set. */
+int pamnet_narrow_embed_fwd_f32(const float* F, int64_t m, int64_t k, int64_t d, const int32_t* kind, const float* Wa,
+                                const float* ba, const float* Wb, const float* bb, float* y, pamnet_stream_t stream);
+/* dW [sets, d, k], db [sets, d]; df [m, 16] optional (k = 16, one set: the Bessel frequencies are trainable).
+ * partial: blocks x sets (d * kp + d) floats, kp = 16 or 48. */
+int pamnet_narrow_embed_bwd_f32(const float* F, int64_t m, int64_t k, int64_t d, const int32_t* kind, const float* Wa,
+                                const float* ba, const float* Wb, const float* bb, const float* dy, float* df,
+                                float* partial, float* dW, float* db, pamnet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

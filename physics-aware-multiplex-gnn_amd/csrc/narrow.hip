@@ -1,0 +1,901 @@
+// Narrow-width (dim = 16 / 32 / 64) message kernels: the RNA configurations of the reference (inference_rna_puzzles.py:
+// dim 16, n_layer 1; main_rna_puzzles.py: dim 64, n_layer 2) have a few thousand nodes but ~10^6 global edges and
+// triplet/pair rows per batch, so the row-wise work is HBM-bound, not MFMA-bound as at dim = 128.
+//
+// Design (different from the 128-wide kernels on purpose):
+//   * one wavefront owns a 16-row tile end to end; workgroups are just 4 independent waves that share the weight
+//     images, there is no barrier inside the row loop;
+//   * rows are read once as MFMA A fragments straight from HBM (lane l: row l&15, floats 16q + 4(l>>4) .. +3 = one
+//     16-byte load per 16 columns), all GEMMs of a stage chain through registers, and the D->A relayout between two
+//     GEMMs goes through a wave-private LDS tile;
+//   * backward kernels recompute the forward pre-activations from the row tile instead of reading saved ones
+//     (a [rows, D] store + load costs more than D/16 extra MFMA groups), and form the weight gradients in the same
+//     pass: the D-layout accumulators of dZ are exactly the A operand of dW = dZ^T X with the row index as k;
+//   * weight gradients are reduced wave -> workgroup (LDS, fixed order) -> grid (second kernel, fixed order):
+//     deterministic, no atomics.
+//
+// Reference semantics: layers/global_message_passing.py:52-53 (message), layers/local_message_passing.py:48-49
+// (mlp_sbf), models.py:185-188 (edge-embedding MLPs).
+#include "common.h"
+#include "gemm_core.h"
+
+namespace {
+
+using pamnet::f32x4;
+using pamnet::sigmoidf_fast;
+
+constexpr int NWG = 256;                      // threads per workgroup (4 independent waves)
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- weight images in LDS ------------------------------------------------------------------------------------------
+// img[(jt * NQ + q) * 64 + lane] = the float4 lane feeds to the four MFMAs of (output tile jt, k-group q).
+//   TRANS = false: Y = X W^T, W [out][in] (row stride ld, `kin` valid input columns): b.t = W[16jt + c][16q + 4kg + t]
+//   TRANS = true : Y = X W,   W [k][out]:                                            b.t = W[16q + 4kg + t][16jt + c]
+template <int NJ, int NQ, bool TRANS>
+__device__ __forceinline__ void build_image(float4* img, const float* __restrict__ W, int ld, int kin) {
+    for (int idx = threadIdx.x; idx < NJ * NQ * 64; idx += NWG) {
+        const int lane = idx & 63, t = idx >> 6;
+        const int q = t % NQ, jt = t / NQ;
+        const int c = lane & 15, kg = lane >> 4;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!TRANS) {
+                const int k = 16 * q + 4 * kg + u;
+                v[u] = (k < kin) ? W[(size_t)(16 * jt + c) * ld + k] : 0.f;
+            } else {
+                const int col = 16 * jt + c;
+                v[u] = (col < kin) ? W[(size_t)(16 * q + 4 * kg + u) * ld + col] : 0.f;
+            }
+        }
+        img[idx] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <int NJ, int NQ>
+__device__ __forceinline__ void mma_img(f32x4 (&acc)[NJ], const float4 (&a)[NQ], const float4* img, int lane) {
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float4 b = img[(jt * NQ + q) * 64 + lane];
+            acc[jt] = mfma4(a[q].x, b.x, acc[jt]);
+            acc[jt] = mfma4(a[q].y, b.y, acc[jt]);
+            acc[jt] = mfma4(a[q].z, b.z, acc[jt]);
+            acc[jt] = mfma4(a[q].w, b.w, acc[jt]);
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void zero(f32x4 (&acc)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// rows as A fragments (row stride D floats, 16-byte aligned); rows >= m read as zero
+template <int D>
+__device__ __forceinline__ void load_a(float4 (&a)[D / 16], const float* __restrict__ X, int64_t row0, int64_t m, int lane) {
+    const int64_t row = row0 + (lane & 15);
+    const bool ok = row < m;
+    const float* p = X + (ok ? row : 0) * D + 4 * (lane >> 4);
+#pragma unroll
+    for (int q = 0; q < D / 16; ++q)
+        a[q] = ok ? *reinterpret_cast<const float4*>(p + 16 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// rows in accumulator ("D") layout: v[jt][r] = X[row0 + 4kg + r][16jt + c]; rows >= m read as zero
+template <int D>
+__device__ __forceinline__ void load_d(f32x4 (&v)[D / 16], const float* __restrict__ X, int64_t row0, int64_t m, int lane) {
+    const int c = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + 4 * kg + r;
+        const bool ok = row < m;
+        const float* p = X + (ok ? row : 0) * D + c;
+#pragma unroll
+        for (int jt = 0; jt < D / 16; ++jt) v[jt][r] = ok ? p[16 * jt] : 0.f;
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void store_d(const f32x4 (&v)[D / 16], float* __restrict__ Y, int64_t row0, int64_t m, int lane) {
+    const int c = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + 4 * kg + r;
+        if (row < m) {
+            float* p = Y + row * D + c;
+#pragma unroll
+            for (int jt = 0; jt < D / 16; ++jt) p[16 * jt] = v[jt][r];
+        }
+    }
+}
+
+// accumulator layout -> A fragments through the wave's private LDS tile ([16][D + 4] floats)
+template <int D>
+__device__ __forceinline__ void d_to_a(float4 (&a)[D / 16], const f32x4 (&v)[D / 16], float* tile, int lane) {
+    constexpr int LD = D + 4;
+    const int c = lane & 15, kg = lane >> 4;
+    wave_lds_sync();
+#pragma unroll
+    for (int jt = 0; jt < D / 16; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[(4 * kg + r) * LD + 16 * jt + c] = v[jt][r];
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < D / 16; ++q) a[q] = *reinterpret_cast<const float4*>(tile + c * LD + 16 * q + 4 * kg);
+}
+
+// dW[o][k] += sum_rows dz[row][o] * x[row][k], both operands in accumulator layout (rows are the MFMA k index)
+template <int NJ, int NK>
+__device__ __forceinline__ void wgrad_acc(f32x4 (&w)[NJ][NK], const f32x4 (&dz)[NJ], const f32x4 (&x)[NK]) {
+#pragma unroll
+    for (int jo = 0; jo < NJ; ++jo)
+#pragma unroll
+        for (int jk = 0; jk < NK; ++jk) {
+            w[jo][jk] = mfma4(dz[jo][0], x[jk][0], w[jo][jk]);
+            w[jo][jk] = mfma4(dz[jo][1], x[jk][1], w[jo][jk]);
+            w[jo][jk] = mfma4(dz[jo][2], x[jk][2], w[jo][jk]);
+            w[jo][jk] = mfma4(dz[jo][3], x[jk][3], w[jo][jk]);
+        }
+}
+
+// column sums of an accumulator-layout tile over the wave's rows: result valid on every lane for column 16jt + c
+template <int NJ>
+__device__ __forceinline__ void colsum_acc(float (&s)[NJ], const f32x4 (&dz)[NJ]) {
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) s[jt] += (dz[jt][0] + dz[jt][1]) + (dz[jt][2] + dz[jt][3]);
+}
+
+// ---- workgroup reduction of per-wave gradient accumulators -----------------------------------------------------------
+// `red` (LDS, reused image area) is laid out [matrix fragments ...][bias columns ...]; waves add in wave order.
+template <int NJ, int NK>
+__device__ __forceinline__ void red_add_mat(float* red, const f32x4 (&w)[NJ][NK], int lane, bool first) {
+#pragma unroll
+    for (int jo = 0; jo < NJ; ++jo)
+#pragma unroll
+        for (int jk = 0; jk < NK; ++jk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* p = red + ((jo * NK + jk) * 4 + r) * 64 + lane;
+                *p = first ? w[jo][jk][r] : (*p + w[jo][jk][r]);
+            }
+}
+
+template <int NJ>
+__device__ __forceinline__ void red_add_bias(float* red, float (&s)[NJ], int lane, bool first) {
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) {
+        float v = s[jt];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 16) red[16 * jt + lane] = first ? v : (red[16 * jt + lane] + v);
+    }
+}
+
+// out[mat][o][k] (k < kvalid) = sum_b partial[b][fragment(o, k)];  bias[j] = sum_b partial[b][bias_off + j]
+__global__ __launch_bounds__(256) void narrow_reduce_kernel(const float* __restrict__ partial, int nblk, int stride,
+                                                            int nmat, int D, int KP, int kvalid, int nbias,
+                                                            float* __restrict__ mats, float* __restrict__ bias) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = D * KP;
+    if (t < nmat * per) {
+        const int mat = t / per, o = (t % per) / KP, k = t % KP;
+        const int jo = o >> 4, kg = (o & 15) >> 2, r = o & 3, jk = k >> 4, c = k & 15;
+        const int frag = mat * per + (((jo * (KP / 16) + jk) * 4 + r) * 64) + kg * 16 + c;
+        float s = 0.f;
+        for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * stride + frag];
+        if (k < kvalid) mats[(size_t)mat * D * kvalid + (size_t)o * kvalid + k] = s;
+    } else if (t < nmat * per + nbias) {
+        const int j = t - nmat * per;
+        float s = 0.f;
+        for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * stride + nmat * per + j];
+        bias[j] = s;
+    }
+}
+
+// ====================================================================================================================
+// Global message (layers/global_message_passing.py:52-53 with W_m split into node and edge blocks):
+//   z = P[tgt, :D] + P[src, D:] + e We^T + b ;  msg = SiLU(z) * (e Wea^T)
+// ====================================================================================================================
+template <int D>
+__global__ __launch_bounds__(NWG) void nglobal_fwd_kernel(const float* __restrict__ e, int64_t m,
+                                                          const int32_t* __restrict__ tgt, const int32_t* __restrict__ src,
+                                                          const float* __restrict__ P, const float* __restrict__ We, int ldwe,
+                                                          const float* __restrict__ bias, const float* __restrict__ Wea,
+                                                          int ldwea, float* __restrict__ msg) {
+    constexpr int NT = D / 16;
+    extern __shared__ float4 lds4[];
+    float4* img_e = lds4;
+    float4* img_a = lds4 + NT * NT * 64;
+    build_image<NT, NT, false>(img_e, We, ldwe, D);
+    build_image<NT, NT, false>(img_a, Wea, ldwea, D);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
+    const int64_t ntiles = (m + 15) / 16;
+    float bj[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) bj[jt] = bias[16 * jt + c];
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = tile * 16;
+        float4 a[NT];
+        load_a<D>(a, e, row0, m, lane);
+        f32x4 q1[NT], q2[NT];
+        zero(q1);
+        zero(q2);
+        mma_img<NT, NT>(q1, a, img_e, lane);
+        mma_img<NT, NT>(q2, a, img_a, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 4 * kg + r;
+            if (row < m) {
+                const float* pi = P + (size_t)tgt[row] * (2 * D) + c;
+                const float* pj = P + (size_t)src[row] * (2 * D) + D + c;
+                float* out = msg + row * D + c;
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt) {
+                    const float z = q1[jt][r] + bj[jt] + pi[16 * jt] + pj[16 * jt];
+                    out[16 * jt] = z * sigmoidf_fast(z) * q2[jt][r];
+                }
+            }
+        }
+    }
+}
+
+// backward: dmsg[row] = dagg[tgt[row]].  Outputs dz [m, D] (for the two node-side segment sums), de [m, D],
+// and per-workgroup partials of dWe, dWea (fragment order) and db.
+template <int D>
+__global__ __launch_bounds__(NWG) void nglobal_bwd_kernel(const float* __restrict__ e, int64_t m,
+                                                          const int32_t* __restrict__ tgt, const int32_t* __restrict__ src,
+                                                          const float* __restrict__ P, const float* __restrict__ We, int ldwe,
+                                                          const float* __restrict__ bias, const float* __restrict__ Wea,
+                                                          int ldwea, const float* __restrict__ dagg,
+                                                          float* __restrict__ dz_out, float* __restrict__ de,
+                                                          float* __restrict__ partial, int stride) {
+    constexpr int NT = D / 16;
+    constexpr int IMG = NT * NT * 64;
+    extern __shared__ float4 lds4[];
+    float4* img_e = lds4;
+    float4* img_a = lds4 + IMG;
+    float4* img_et = lds4 + 2 * IMG;
+    float4* img_at = lds4 + 3 * IMG;
+    float* tile = reinterpret_cast<float*>(lds4 + 4 * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
+    build_image<NT, NT, false>(img_e, We, ldwe, D);
+    build_image<NT, NT, false>(img_a, Wea, ldwea, D);
+    build_image<NT, NT, true>(img_et, We, ldwe, D);
+    build_image<NT, NT, true>(img_at, Wea, ldwea, D);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
+    const int64_t ntiles = (m + 15) / 16;
+    float bj[NT], dbs[NT];
+    f32x4 gwe[NT][NT], gwa[NT][NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        bj[jt] = bias[16 * jt + c];
+        dbs[jt] = 0.f;
+        zero(gwe[jt]);
+        zero(gwa[jt]);
+    }
+    for (int64_t tile_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile_id < ntiles;
+         tile_id += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = tile_id * 16;
+        float4 a[NT];
+        load_a<D>(a, e, row0, m, lane);
+        f32x4 q1[NT], q2[NT], ed[NT];
+        zero(q1);
+        zero(q2);
+        mma_img<NT, NT>(q1, a, img_e, lane);
+        mma_img<NT, NT>(q2, a, img_a, lane);
+        load_d<D>(ed, e, row0, m, lane);
+        // q1 -> dz, q2 -> dq2 (in place)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 4 * kg + r;
+            const bool ok = row < m;
+            const int ti = ok ? tgt[row] : 0, sj = ok ? src[row] : 0;
+            const float* pi = P + (size_t)ti * (2 * D) + c;
+            const float* pj = P + (size_t)sj * (2 * D) + D + c;
+            const float* dg = dagg + (size_t)ti * D + c;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const float z = q1[jt][r] + bj[jt] + pi[16 * jt] + pj[16 * jt];
+                const float s = sigmoidf_fast(z);
+                const float dm = ok ? dg[16 * jt] : 0.f;
+                const float gate = q2[jt][r];
+                q1[jt][r] = dm * gate * (s * (1.0f + z * (1.0f - s)));
+                q2[jt][r] = dm * (z * s);
+            }
+        }
+        store_d<D>(q1, dz_out, row0, m, lane);
+        wgrad_acc<NT, NT>(gwe, q1, ed);
+        wgrad_acc<NT, NT>(gwa, q2, ed);
+        colsum_acc<NT>(dbs, q1);
+        f32x4 dx[NT];
+        zero(dx);
+        d_to_a<D>(a, q1, tile, lane);
+        mma_img<NT, NT>(dx, a, img_et, lane);
+        d_to_a<D>(a, q2, tile, lane);
+        mma_img<NT, NT>(dx, a, img_at, lane);
+        store_d<D>(dx, de, row0, m, lane);
+    }
+    // workgroup reduction in wave order, then one partial row per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds4);
+    constexpr int MAT = D * D;
+    for (int w = 0; w < 4; ++w) {
+        if ((threadIdx.x >> 6) == w) {
+            red_add_mat<NT, NT>(red, gwe, lane, w == 0);
+            red_add_mat<NT, NT>(red + MAT, gwa, lane, w == 0);
+            red_add_bias<NT>(red + 2 * MAT, dbs, lane, w == 0);
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 2 * MAT + D; i += NWG) partial[(size_t)blockIdx.x * stride + i] = red[i];
+}
+
+// ====================================================================================================================
+// Two-layer SiLU MLP on rows (mlp_sbf of the local layer, layers/local_message_passing.py:24,49):
+//   y = SiLU(W2 SiLU(W1 x + b1) + b2)
+// ====================================================================================================================
+template <int D>
+__global__ __launch_bounds__(NWG) void nmlp2_fwd_kernel(const float* __restrict__ x, int64_t m,
+                                                        const float* __restrict__ W1, const float* __restrict__ b1,
+                                                        const float* __restrict__ W2, const float* __restrict__ b2,
+                                                        float* __restrict__ y) {
+    constexpr int NT = D / 16;
+    constexpr int IMG = NT * NT * 64;
+    extern __shared__ float4 lds4[];
+    float4* img1 = lds4;
+    float4* img2 = lds4 + IMG;
+    float* tile = reinterpret_cast<float*>(lds4 + 2 * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
+    build_image<NT, NT, false>(img1, W1, D, D);
+    build_image<NT, NT, false>(img2, W2, D, D);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15;
+    const int64_t ntiles = (m + 15) / 16;
+    float bj1[NT], bj2[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        bj1[jt] = b1[16 * jt + c];
+        bj2[jt] = b2[16 * jt + c];
+    }
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = t * 16;
+        float4 a[NT];
+        load_a<D>(a, x, row0, m, lane);
+        f32x4 h[NT], o[NT];
+        zero(h);
+        mma_img<NT, NT>(h, a, img1, lane);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = h[jt][r] + bj1[jt];
+                h[jt][r] = z * sigmoidf_fast(z);
+            }
+        d_to_a<D>(a, h, tile, lane);
+        zero(o);
+        mma_img<NT, NT>(o, a, img2, lane);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = o[jt][r] + bj2[jt];
+                o[jt][r] = z * sigmoidf_fast(z);
+            }
+        store_d<D>(o, y, row0, m, lane);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(NWG) void nmlp2_bwd_kernel(const float* __restrict__ x, int64_t m,
+                                                        const float* __restrict__ W1, const float* __restrict__ b1,
+                                                        const float* __restrict__ W2, const float* __restrict__ b2,
+                                                        const float* __restrict__ dy, float* __restrict__ dx,
+                                                        float* __restrict__ partial, int stride) {
+    constexpr int NT = D / 16;
+    constexpr int IMG = NT * NT * 64;
+    extern __shared__ float4 lds4[];
+    float4* img1 = lds4;
+    float4* img2 = lds4 + IMG;
+    float4* img1t = lds4 + 2 * IMG;
+    float4* img2t = lds4 + 3 * IMG;
+    float* tile = reinterpret_cast<float*>(lds4 + 4 * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
+    build_image<NT, NT, false>(img1, W1, D, D);
+    build_image<NT, NT, false>(img2, W2, D, D);
+    build_image<NT, NT, true>(img1t, W1, D, D);
+    build_image<NT, NT, true>(img2t, W2, D, D);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15;
+    const int64_t ntiles = (m + 15) / 16;
+    float bj1[NT], bj2[NT], db1[NT], db2[NT];
+    f32x4 gw1[NT][NT], gw2[NT][NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        bj1[jt] = b1[16 * jt + c];
+        bj2[jt] = b2[16 * jt + c];
+        db1[jt] = db2[jt] = 0.f;
+        zero(gw1[jt]);
+        zero(gw2[jt]);
+    }
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = t * 16;
+        float4 a[NT];
+        load_a<D>(a, x, row0, m, lane);
+        f32x4 z1[NT], h[NT], g[NT];
+        zero(z1);
+        mma_img<NT, NT>(z1, a, img1, lane);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                z1[jt][r] += bj1[jt];
+                h[jt][r] = z1[jt][r] * sigmoidf_fast(z1[jt][r]);
+            }
+        d_to_a<D>(a, h, tile, lane);
+        zero(g);
+        mma_img<NT, NT>(g, a, img2, lane);                   // z2 - b2
+        f32x4 dyv[NT];
+        load_d<D>(dyv, dy, row0, m, lane);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = g[jt][r] + bj2[jt];
+                const float s = sigmoidf_fast(z);
+                g[jt][r] = dyv[jt][r] * (s * (1.0f + z * (1.0f - s)));      // dz2 (zero on padded rows: dy = 0)
+            }
+        wgrad_acc<NT, NT>(gw2, g, h);
+        colsum_acc<NT>(db2, g);
+        d_to_a<D>(a, g, tile, lane);
+        zero(g);
+        mma_img<NT, NT>(g, a, img2t, lane);                  // dh1
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = z1[jt][r];
+                const float s = sigmoidf_fast(z);
+                g[jt][r] *= s * (1.0f + z * (1.0f - s));     // dz1
+            }
+        load_d<D>(h, x, row0, m, lane);
+        wgrad_acc<NT, NT>(gw1, g, h);
+        colsum_acc<NT>(db1, g);
+        if (dx) {
+            d_to_a<D>(a, g, tile, lane);
+            zero(g);
+            mma_img<NT, NT>(g, a, img1t, lane);
+            store_d<D>(g, dx, row0, m, lane);
+        }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds4);
+    constexpr int MAT = D * D;
+    for (int w = 0; w < 4; ++w) {
+        if ((threadIdx.x >> 6) == w) {
+            red_add_mat<NT, NT>(red, gw1, lane, w == 0);
+            red_add_mat<NT, NT>(red + MAT, gw2, lane, w == 0);
+            red_add_bias<NT>(red + 2 * MAT, db1, lane, w == 0);
+            red_add_bias<NT>(red + 2 * MAT + D, db2, lane, w == 0);
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 2 * MAT + 2 * D; i += NWG) partial[(size_t)blockIdx.x * stride + i] = red[i];
+}
+
+// ====================================================================================================================
+// Edge-embedding MLPs (models.py:185-188): y = SiLU(W f + b), f [rows, K] with K = 16 (Bessel) or 42 (spherical);
+// with `kind` the row picks (Wa, ba) for kind 0 (triplet rows, mlp_sbf2) or (Wb, bb) for kind 1 (pair rows, mlp_sbf1).
+// ====================================================================================================================
+template <int K>
+__device__ __forceinline__ void load_feat_a(float4 (&a)[(K + 15) / 16], const float* __restrict__ F, int64_t row0,
+                                            int64_t m, int lane) {
+    const int64_t row = row0 + (lane & 15);
+    const bool ok = row < m;
+    const float* p = F + (ok ? row : 0) * K + 4 * (lane >> 4);
+#pragma unroll
+    for (int q = 0; q < (K + 15) / 16; ++q) {
+        const int k = 16 * q + 4 * (lane >> 4);
+        float2 lo = make_float2(0.f, 0.f), hi = make_float2(0.f, 0.f);
+        if (ok && k + 1 < K) lo = *reinterpret_cast<const float2*>(p + 16 * q);
+        if (ok && k + 3 < K) hi = *reinterpret_cast<const float2*>(p + 16 * q + 2);
+        a[q] = make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void load_feat_d(f32x4 (&v)[(K + 15) / 16], const float* __restrict__ F, int64_t row0,
+                                            int64_t m, int lane) {
+    const int c = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + 4 * kg + r;
+        const bool ok = row < m;
+        const float* p = F + (ok ? row : 0) * K + c;
+#pragma unroll
+        for (int jk = 0; jk < (K + 15) / 16; ++jk) v[jk][r] = (ok && 16 * jk + c < K) ? p[16 * jk] : 0.f;
+    }
+}
+
+template <int D, int K, bool TWO>
+__global__ __launch_bounds__(NWG) void nembed_fwd_kernel(const float* __restrict__ F, int64_t m,
+                                                         const int32_t* __restrict__ kind,
+                                                         const float* __restrict__ Wa, const float* __restrict__ ba,
+                                                         const float* __restrict__ Wb, const float* __restrict__ bb,
+                                                         float* __restrict__ y) {
+    constexpr int NT = D / 16, NQ = (K + 15) / 16;
+    constexpr int IMG = NT * NQ * 64;
+    extern __shared__ float4 lds4[];
+    build_image<NT, NQ, false>(lds4, Wa, K, K);
+    if (TWO) build_image<NT, NQ, false>(lds4 + IMG, Wb, K, K);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
+    const int64_t ntiles = (m + 15) / 16;
+    float bja[NT], bjb[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        bja[jt] = ba[16 * jt + c];
+        bjb[jt] = TWO ? bb[16 * jt + c] : 0.f;
+    }
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = t * 16;
+        float4 a[NQ];
+        load_feat_a<K>(a, F, row0, m, lane);
+        f32x4 acc[NT];
+        zero(acc);
+        if (!TWO) {
+            mma_img<NT, NQ>(acc, a, lds4, lane);
+        } else {
+            const int64_t row = row0 + c;
+            const bool second = (row < m) && kind[row] != 0;
+            float4 a0[NQ], a1[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                a0[q] = second ? make_float4(0.f, 0.f, 0.f, 0.f) : a[q];
+                a1[q] = second ? a[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            mma_img<NT, NQ>(acc, a0, lds4, lane);
+            mma_img<NT, NQ>(acc, a1, lds4 + IMG, lane);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 4 * kg + r;
+            const bool second = TWO && (row < m) && kind[row] != 0;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const float z = acc[jt][r] + (second ? bjb[jt] : bja[jt]);
+                acc[jt][r] = z * sigmoidf_fast(z);
+            }
+        }
+        store_d<D>(acc, y, row0, m, lane);
+    }
+}
+
+// backward: partial = [dWa fragments (D x KP)][dWb fragments if TWO][dba (D)][dbb (D) if TWO]; df [m, K] only for
+// the single-set K = 16 case (the Bessel frequencies are trainable, layers/basic.py:65-72).
+template <int D, int K, bool TWO, bool DX>
+__global__ __launch_bounds__(NWG) void nembed_bwd_kernel(const float* __restrict__ F, int64_t m,
+                                                         const int32_t* __restrict__ kind,
+                                                         const float* __restrict__ Wa, const float* __restrict__ ba,
+                                                         const float* __restrict__ Wb, const float* __restrict__ bb,
+                                                         const float* __restrict__ dy, float* __restrict__ df,
+                                                         float* __restrict__ partial, int stride) {
+    static_assert(!DX || (K == 16 && !TWO), "df only for the single-set 16-wide embedding");
+    constexpr int NT = D / 16, NQ = (K + 15) / 16, KP = NQ * 16;
+    constexpr int IMG = NT * NQ * 64;
+    constexpr int IMGT = NQ * NT * 64;
+    extern __shared__ float4 lds4[];
+    float4* img_t = lds4 + (TWO ? 2 : 1) * IMG;
+    float* tile = reinterpret_cast<float*>(lds4 + (TWO ? 2 : 1) * IMG + (DX ? IMGT : 0)) + (threadIdx.x >> 6) * 16 * (D + 4);
+    build_image<NT, NQ, false>(lds4, Wa, K, K);
+    if (TWO) build_image<NT, NQ, false>(lds4 + IMG, Wb, K, K);
+    if constexpr (DX) build_image<NQ, NT, true>(img_t, Wa, K, K);       // df = dz Wa: output tiles over K, k-groups over D
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
+    const int64_t ntiles = (m + 15) / 16;
+    float bja[NT], bjb[NT], dba[NT], dbb[NT];
+    f32x4 gwa[NT][NQ], gwb[TWO ? NT : 1][NQ];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        bja[jt] = ba[16 * jt + c];
+        bjb[jt] = TWO ? bb[16 * jt + c] : 0.f;
+        dba[jt] = dbb[jt] = 0.f;
+        zero(gwa[jt]);
+        if constexpr (TWO) zero(gwb[jt]);
+    }
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = t * 16;
+        float4 a[NQ];
+        load_feat_a<K>(a, F, row0, m, lane);
+        f32x4 acc[NT];
+        zero(acc);
+        if (!TWO) {
+            mma_img<NT, NQ>(acc, a, lds4, lane);
+        } else {
+            const int64_t row = row0 + c;
+            const bool second = (row < m) && kind[row] != 0;
+            float4 a0[NQ], a1[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                a0[q] = second ? make_float4(0.f, 0.f, 0.f, 0.f) : a[q];
+                a1[q] = second ? a[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            mma_img<NT, NQ>(acc, a0, lds4, lane);
+            mma_img<NT, NQ>(acc, a1, lds4 + IMG, lane);
+        }
+        f32x4 dyv[NT], dza[NT], dzb[TWO ? NT : 1];
+        load_d<D>(dyv, dy, row0, m, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 4 * kg + r;
+            const bool second = TWO && (row < m) && kind[row] != 0;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const float z = acc[jt][r] + (second ? bjb[jt] : bja[jt]);
+                const float s = sigmoidf_fast(z);
+                const float dz = dyv[jt][r] * (s * (1.0f + z * (1.0f - s)));
+                dza[jt][r] = second ? 0.f : dz;
+                if constexpr (TWO) dzb[jt][r] = second ? dz : 0.f;
+            }
+        }
+        f32x4 fd[NQ];
+        load_feat_d<K>(fd, F, row0, m, lane);
+        wgrad_acc<NT, NQ>(gwa, dza, fd);
+        colsum_acc<NT>(dba, dza);
+        if constexpr (TWO) {
+            wgrad_acc<NT, NQ>(gwb, dzb, fd);
+            colsum_acc<NT>(dbb, dzb);
+        }
+        if constexpr (DX) {
+            float4 az[NT];
+            d_to_a<D>(az, dza, tile, lane);
+            f32x4 o[NQ];
+            zero(o);
+            mma_img<NQ, NT>(o, az, img_t, lane);
+            // K = 16: one 16-column tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + 4 * kg + r;
+                if (row < m) df[row * K + c] = o[0][r];
+            }
+        }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds4);
+    constexpr int MAT = D * KP;
+    constexpr int NM = TWO ? 2 : 1;
+    for (int w = 0; w < 4; ++w) {
+        if ((threadIdx.x >> 6) == w) {
+            red_add_mat<NT, NQ>(red, gwa, lane, w == 0);
+            red_add_bias<NT>(red + NM * MAT, dba, lane, w == 0);
+            if constexpr (TWO) {
+                red_add_mat<NT, NQ>(red + MAT, gwb, lane, w == 0);
+                red_add_bias<NT>(red + NM * MAT + D, dbb, lane, w == 0);
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < NM * (MAT + D); i += NWG) partial[(size_t)blockIdx.x * stride + i] = red[i];
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+inline int grid_for(int64_t m, int per_cu) {
+    const int64_t tiles = (m + 15) / 16;
+    const int64_t want = (tiles + 3) / 4;                    // one tile per wave
+    const int64_t cap = 256 * (int64_t)per_cu;
+    return (int)(want < cap ? (want > 0 ? want : 1) : cap);
+}
+
+inline bool width_ok(int64_t d) { return d == 16 || d == 32 || d == 64; }
+
+template <typename Kern>
+inline hipError_t allow_lds(Kern k, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+#define NARROW_DISPATCH(d, CALL)     \
+    switch ((int)(d)) {              \
+        case 16: { CALL(16); } break; \
+        case 32: { CALL(32); } break; \
+        default: { CALL(64); } break; \
+    }
+
+}  // namespace
+
+extern "C" int pamnet_narrow_blocks(int64_t rows, int64_t* blocks) {
+    if (rows < 0) return PAMNET_EINVAL;
+    if (!blocks) return PAMNET_ENULL;
+    *blocks = grid_for(rows, 2);
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_narrow_global_fwd_f32(const float* e, int64_t m, int64_t d, const int32_t* tgt, const int32_t* src,
+                                            const float* P, const float* We, int64_t ldwe, const float* bias,
+                                            const float* Wea, int64_t ldwea, float* msg, pamnet_stream_t stream) {
+    if (m < 0 || !width_ok(d) || ldwe < d || ldwea < d || (ldwe & 3) || (ldwea & 3)) return PAMNET_EINVAL;
+    if (m == 0) return PAMNET_OK;
+    if (!e || !tgt || !src || !P || !We || !bias || !Wea || !msg) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for(m, 4);
+#define CALL(DD)                                                                                                     \
+    {                                                                                                                \
+        const size_t lds = 2 * (size_t)DD * DD * sizeof(float);                                                      \
+        hipLaunchKernelGGL((nglobal_fwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, e, m, tgt, src, P, We, (int)ldwe, \
+                           bias, Wea, (int)ldwea, msg);                                                              \
+    }
+    NARROW_DISPATCH(d, CALL)
+#undef CALL
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_narrow_global_bwd_f32(const float* e, int64_t m, int64_t d, const int32_t* tgt, const int32_t* src,
+                                            const float* P, const float* We, int64_t ldwe, const float* bias,
+                                            const float* Wea, int64_t ldwea, const float* dagg, float* dz, float* de,
+                                            float* partial, float* dWe, float* dWea, float* db,
+                                            pamnet_stream_t stream) {
+    if (m <= 0 || !width_ok(d) || ldwe < d || ldwea < d || (ldwe & 3) || (ldwea & 3)) return PAMNET_EINVAL;
+    if (!e || !tgt || !src || !P || !We || !bias || !Wea || !dagg || !dz || !de || !partial || !dWe || !dWea || !db)
+        return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for(m, 2);
+    const int stride = (int)(2 * d * d + d);
+#define CALL(DD)                                                                                                     \
+    {                                                                                                                \
+        const size_t lds = 4 * (size_t)DD * DD * sizeof(float) + 4 * 16 * (DD + 4) * sizeof(float);                  \
+        hipError_t e_ = allow_lds(nglobal_bwd_kernel<DD>, lds);                                                      \
+        if (e_ != hipSuccess) return (int)e_;                                                                        \
+        hipLaunchKernelGGL((nglobal_bwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, e, m, tgt, src, P, We, (int)ldwe, \
+                           bias, Wea, (int)ldwea, dagg, dz, de, partial, stride);                                    \
+    }
+    NARROW_DISPATCH(d, CALL)
+#undef CALL
+    PAMNET_LAUNCH_CHECK();
+    // dWe and dWea are separate outputs: two reduce launches over the same partial rows (matrix 0 / matrix 1 + bias)
+    const int per = (int)(d * d);
+    hipLaunchKernelGGL(narrow_reduce_kernel, dim3((per + 255) / 256), dim3(256), 0, st, partial, grid, stride, 1, (int)d,
+                       (int)d, (int)d, 0, dWe, (float*)nullptr);
+    PAMNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(narrow_reduce_kernel, dim3((per + (int)d + 255) / 256), dim3(256), 0, st, partial + per, grid,
+                       stride, 1, (int)d, (int)d, (int)d, (int)d, dWea, db);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_narrow_mlp2_fwd_f32(const float* x, int64_t m, int64_t d, const float* W1, const float* b1,
+                                          const float* W2, const float* b2, float* y, pamnet_stream_t stream) {
+    if (m < 0 || !width_ok(d)) return PAMNET_EINVAL;
+    if (m == 0) return PAMNET_OK;
+    if (!x || !W1 || !b1 || !W2 || !b2 || !y) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for(m, 4);
+#define CALL(DD)                                                                                                  \
+    {                                                                                                             \
+        const size_t lds = 2 * (size_t)DD * DD * sizeof(float) + 4 * 16 * (DD + 4) * sizeof(float);               \
+        hipLaunchKernelGGL((nmlp2_fwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, x, m, W1, b1, W2, b2, y);      \
+    }
+    NARROW_DISPATCH(d, CALL)
+#undef CALL
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_narrow_mlp2_bwd_f32(const float* x, int64_t m, int64_t d, const float* W1, const float* b1,
+                                          const float* W2, const float* b2, const float* dy, float* dx, float* partial,
+                                          float* dW /* [2, d, d] */, float* db /* [2, d] */, pamnet_stream_t stream) {
+    if (m <= 0 || !width_ok(d)) return PAMNET_EINVAL;
+    if (!x || !W1 || !b1 || !W2 || !b2 || !dy || !partial || !dW || !db) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for(m, 2);
+    const int stride = (int)(2 * d * d + 2 * d);
+#define CALL(DD)                                                                                                       \
+    {                                                                                                                  \
+        const size_t lds = 4 * (size_t)DD * DD * sizeof(float) + 4 * 16 * (DD + 4) * sizeof(float);                    \
+        hipError_t e_ = allow_lds(nmlp2_bwd_kernel<DD>, lds);                                                          \
+        if (e_ != hipSuccess) return (int)e_;                                                                          \
+        hipLaunchKernelGGL((nmlp2_bwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, x, m, W1, b1, W2, b2, dy, dx, partial, \
+                           stride);                                                                                    \
+    }
+    NARROW_DISPATCH(d, CALL)
+#undef CALL
+    PAMNET_LAUNCH_CHECK();
+    const int total = (int)(2 * d * d + 2 * d);
+    hipLaunchKernelGGL(narrow_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, partial, grid, stride, 2, (int)d,
+                       (int)d, (int)d, (int)(2 * d), dW, db);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_narrow_embed_fwd_f32(const float* F, int64_t m, int64_t k, int64_t d, const int32_t* kind,
+                                           const float* Wa, const float* ba, const float* Wb, const float* bb, float* y,
+                                           pamnet_stream_t stream) {
+    if (m < 0 || !width_ok(d) || (k != 16 && k != 42)) return PAMNET_EINVAL;
+    if (m == 0) return PAMNET_OK;
+    if (!F || !Wa || !ba || !y || (kind && (!Wb || !bb))) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for(m, 4);
+    const bool two = kind != nullptr;
+#define CALL(DD)                                                                                                         \
+    {                                                                                                                    \
+        if (k == 16) {                                                                                                   \
+            const size_t lds = (two ? 2 : 1) * (size_t)DD * 16 * sizeof(float);                                          \
+            if (two)                                                                                                     \
+                hipLaunchKernelGGL((nembed_fwd_kernel<DD, 16, true>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa, ba, Wb, \
+                                   bb, y);                                                                               \
+            else                                                                                                         \
+                hipLaunchKernelGGL((nembed_fwd_kernel<DD, 16, false>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa, ba,  \
+                                   Wb, bb, y);                                                                           \
+        } else {                                                                                                         \
+            const size_t lds = (two ? 2 : 1) * (size_t)DD * 48 * sizeof(float);                                          \
+            if (two)                                                                                                     \
+                hipLaunchKernelGGL((nembed_fwd_kernel<DD, 42, true>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa, ba, Wb, \
+                                   bb, y);                                                                               \
+            else                                                                                                         \
+                hipLaunchKernelGGL((nembed_fwd_kernel<DD, 42, false>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa, ba,  \
+                                   Wb, bb, y);                                                                           \
+        }                                                                                                                \
+    }
+    NARROW_DISPATCH(d, CALL)
+#undef CALL
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+/* dW: [sets, d, k] (set 0 = Wa, set 1 = Wb when `kind` is given), db: [sets, d]; df [m, 16] optional (k = 16, one set) */
+extern "C" int pamnet_narrow_embed_bwd_f32(const float* F, int64_t m, int64_t k, int64_t d, const int32_t* kind,
+                                           const float* Wa, const float* ba, const float* Wb, const float* bb,
+                                           const float* dy, float* df, float* partial, float* dW, float* db,
+                                           pamnet_stream_t stream) {
+    if (m <= 0 || !width_ok(d) || (k != 16 && k != 42)) return PAMNET_EINVAL;
+    if (!F || !Wa || !ba || !dy || !partial || !dW || !db || (kind && (!Wb || !bb))) return PAMNET_ENULL;
+    if (df && (k != 16 || kind)) return PAMNET_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for(m, 2);
+    const bool two = kind != nullptr;
+    const int kp = (k == 16) ? 16 : 48;
+    const int sets = two ? 2 : 1;
+    const int stride = (int)(sets * (d * kp + d));
+#define CALL(DD)                                                                                                          \
+    {                                                                                                                     \
+        const size_t scratch = 4 * 16 * (DD + 4) * sizeof(float);                                                         \
+        if (k == 16 && df) {                                                                                              \
+            const size_t lds = 2 * (size_t)DD * 16 * sizeof(float) + scratch;                                             \
+            hipLaunchKernelGGL((nembed_bwd_kernel<DD, 16, false, true>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa, ba, \
+                               Wb, bb, dy, df, partial, stride);                                                          \
+        } else if (k == 16 && !two) {                                                                                     \
+            const size_t lds = (size_t)DD * 16 * sizeof(float) + scratch;                                                 \
+            hipLaunchKernelGGL((nembed_bwd_kernel<DD, 16, false, false>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa,    \
+                               ba, Wb, bb, dy, df, partial, stride);                                                      \
+        } else if (k == 16) {                                                                                             \
+            const size_t lds = 2 * (size_t)DD * 16 * sizeof(float) + scratch;                                             \
+            hipLaunchKernelGGL((nembed_bwd_kernel<DD, 16, true, false>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa, ba, \
+                               Wb, bb, dy, df, partial, stride);                                                          \
+        } else if (!two) {                                                                                                \
+            const size_t lds = (size_t)DD * 48 * sizeof(float) + scratch;                                                 \
+            hipLaunchKernelGGL((nembed_bwd_kernel<DD, 42, false, false>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa,    \
+                               ba, Wb, bb, dy, df, partial, stride);                                                      \
+        } else {                                                                                                          \
+            const size_t lds = 2 * (size_t)DD * 48 * sizeof(float) + scratch;                                             \
+            hipLaunchKernelGGL((nembed_bwd_kernel<DD, 42, true, false>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa, ba, \
+                               Wb, bb, dy, df, partial, stride);                                                          \
+        }                                                                                                                 \
+    }
+    NARROW_DISPATCH(d, CALL)
+#undef CALL
+    PAMNET_LAUNCH_CHECK();
+    const int total = (int)(sets * (d * kp + d));
+    hipLaunchKernelGGL(narrow_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, partial, grid, stride, sets,
+                       (int)d, kp, (int)k, (int)(sets * d), dW, db);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}

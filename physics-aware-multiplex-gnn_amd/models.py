@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from pamnet_amd import fused, modules
+from pamnet_amd import fused, modules, narrow
 from pamnet_amd import graph as G
 from pamnet_amd import ops
 from pamnet_amd.modules import MLP, BesselBasis, GlobalMP, LocalMP, mlp_apply
@@ -139,10 +139,16 @@ class _PAMNetBase(nn.Module):
         if self._embed_fused(rbf_l, self.mlp_rbf_l):
             e_l = fused.embed(rbf_l, self.mlp_rbf_l[0][0])                                   # models.py:186
             e_g = fused.embed(rbf_g, self.mlp_rbf_g[0][0])                                   # models.py:185
+        elif self._narrow(rbf_l):
+            e_l = narrow.embed(rbf_l, self.mlp_rbf_l[0][0])
+            e_g = narrow.embed(rbf_g, self.mlp_rbf_g[0][0])
         else:
             e_l = mlp_apply(self.mlp_rbf_l, rbf_l)
             e_g = mlp_apply(self.mlp_rbf_g, rbf_g)
         return e_l, e_g, sbf
+
+    def _narrow(self, x):
+        return modules.IMPL == 'fused' and narrow.supported(x, self.dim)
 
     @staticmethod
     def _embed_fused(x, seq):
@@ -195,6 +201,8 @@ class PAMNet(_PAMNetBase):
         # mlp_sbf2 on triplet rows, mlp_sbf1 on pair rows (models.py:187-188), rows grouped by target edge
         if self._embed_fused(sbf, self.mlp_sbf2):
             e_sbf = fused.embed(sbf, self.mlp_sbf2[0][0], self.mlp_sbf1[0][0], kind=g.tp_kind)
+        elif self._narrow(sbf):
+            e_sbf = narrow.embed(sbf, self.mlp_sbf2[0][0], self.mlp_sbf1[0][0], kind=g.tp_kind)
         else:
             y2 = mlp_apply(self.mlp_sbf2, sbf.index_select(0, g.trip_rows))
             y1 = mlp_apply(self.mlp_sbf1, sbf.index_select(0, g.pair_rows))
@@ -227,8 +235,12 @@ class PAMNet_s(_PAMNetBase):
         g = self._graph(data)
         x = self._embed(data, g)
         e_l, e_g, sbf = self._edge_embeddings(g)
-        e_sbf = fused.embed(sbf, self.mlp_sbf[0][0]) if self._embed_fused(sbf, self.mlp_sbf) \
-            else mlp_apply(self.mlp_sbf, sbf)
+        if self._embed_fused(sbf, self.mlp_sbf):
+            e_sbf = fused.embed(sbf, self.mlp_sbf[0][0])
+        elif self._narrow(sbf):
+            e_sbf = narrow.embed(sbf, self.mlp_sbf[0][0])
+        else:
+            e_sbf = mlp_apply(self.mlp_sbf, sbf)
         outs, atts = self._run_layers(x, e_l, e_g, e_sbf, g)
         out, node_out = ops.fuse_pool(outs, atts, g, mean=False)
         self._graph_cache, self._node_out = g, node_out

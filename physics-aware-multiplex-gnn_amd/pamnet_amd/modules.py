@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 import os
 
-from . import fused, ops
+from . import fused, narrow, ops
 
 # 'fused' (default): fp32-MFMA chain kernels for dim=128.  'torch': the same maths with dense layers on torch ops --
 # kept as the plain-PyTorch fp32 reference the kernel tests compare against (GPU only; not a CPU fallback).
@@ -26,6 +26,11 @@ IMPL = os.environ.get('PAMNET_IMPL', 'fused')
 
 def _fused(x):
     return IMPL == 'fused' and x.is_cuda and x.size(-1) == fused.D
+
+
+def _narrow(x):
+    """dim 16 / 32 / 64 on an MI355X: row kernels of csrc/narrow.hip for everything of edge / triplet size."""
+    return IMPL == 'fused' and narrow.supported(x, x.size(-1))
 
 
 class Act(nn.Module):
@@ -133,6 +138,9 @@ class GlobalMP(_LayerBase):
         wm, bm = self.mlp_m[0][0].weight, self.mlp_m[0][0].bias
         x = mlp_apply(self.mlp_x1, x)
         p = F.linear(x, torch.cat([wm[:, :d], wm[:, d:2 * d]], 0))               # [N, 2d]: W_i x | W_j x
+        if _narrow(x):
+            x = narrow.global_message(x, p, e, wm, bm, self.W_edge_attr.weight, g.glob, g.glob_T)
+            return update_and_heads(self, x, res_x)
         q = F.linear(e, torch.cat([wm[:, 2 * d:], self.W_edge_attr.weight], 0),   # [E_g, 2d]: W_e e + b | W_ea e
                      torch.cat([bm, torch.zeros_like(bm)]))
         csr = g.glob
@@ -185,7 +193,7 @@ class LocalMP(_LayerBase):
         a = F.silu(z)
         m_ji = a[:, :d]
         m_nb = a[:, d:] * q[:, 2 * d:3 * d]                                       # mlp_m_kj(m) * lin_rbf(rbf)
-        s = mlp_apply(self.mlp_sbf, sbf)                                          # [T+P, d]
+        s = narrow.mlp2(sbf, self.mlp_sbf) if _narrow(sbf) else mlp_apply(self.mlp_sbf, sbf)   # [T+P, d]
         m_other = ops.gather_mul_aggregate(m_nb, s, g.tp, g.tp_T)                 # -> [E_l, d]
         m = q[:, 3 * d:] * (m_ji + m_other)
         x = ops.aggregate(m, csr, init=x)
