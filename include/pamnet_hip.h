@@ -319,12 +319,24 @@ int pamnet_narrow_global_bwd_f32(const float* e, int64_t m, int64_t d, const int
                                  float* dWea, float* db, pamnet_stream_t stream);
 
 /* y = SiLU(W2 SiLU(W1 x + b1) + b2) on [m, d] rows (mlp_sbf, layers/local_message_passing.py:24,49); dense [d, d]. */
+/* res_x != 0 adds x (the Res block of layers/basic.py:25-33); `res` (optional, [m, d]) adds one more residual row. */
 int pamnet_narrow_mlp2_fwd_f32(const float* x, int64_t m, int64_t d, const float* W1, const float* b1, const float* W2,
-                               const float* b2, float* y, pamnet_stream_t stream);
-/* dx optional (null: not needed); dW [2, d, d], db [2, d]; partial: blocks x (2 d^2 + 2 d) floats. */
+                               const float* b2, int32_t res_x, const float* res, float* y, pamnet_stream_t stream);
+/* dx optional (null: not needed; with res_x it includes the + dy of the skip); dW [2, d, d], db [2, d];
+ * partial: blocks x (2 d^2 + 2 d) floats. */
 int pamnet_narrow_mlp2_bwd_f32(const float* x, int64_t m, int64_t d, const float* W1, const float* b1, const float* W2,
-                               const float* b2, const float* dy, float* dx, float* partial, float* dW, float* db,
-                               pamnet_stream_t stream);
+                               const float* b2, const float* dy, int32_t res_x, float* dx, float* partial, float* dW,
+                               float* db, pamnet_stream_t stream);
+
+/* One dense layer y = act(x W^T + b) (layers/basic.py:19-22): W is a [d, d] block with row stride ldw (a column slice of
+ * the [d, 3d] message weights included), b optional, act 1 = SiLU / 0 = identity, y with row stride ldy (blocks of a
+ * [m, n d] projection).  Backward: dy with row stride lddy; dx optional, accumulate != 0 adds into dx; dW [d, d], db [d]
+ * (null without bias); partial: blocks x (d^2 + d) floats. */
+int pamnet_narrow_linear_fwd_f32(const float* x, int64_t m, int64_t d, const float* W, int64_t ldw, const float* b,
+                                 int32_t act, float* y, int64_t ldy, pamnet_stream_t stream);
+int pamnet_narrow_linear_bwd_f32(const float* x, int64_t m, int64_t d, const float* W, int64_t ldw, const float* b,
+                                 int32_t act, const float* dy, int64_t lddy, float* dx, int32_t accumulate,
+                                 float* partial, float* dW, float* db, pamnet_stream_t stream);
 
 /* Edge-embedding MLPs (models.py:185-188): y = SiLU(W f + b), f [m, k], k = 16 or 42, W [d, k] dense.  With `kind`
  * [m] rows of kind 0 use (Wa, ba) and rows of kind != 0 use (Wb, bb); kind null: one set. */

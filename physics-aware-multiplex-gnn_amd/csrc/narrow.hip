@@ -94,26 +94,28 @@ __device__ __forceinline__ void load_a(float4 (&a)[D / 16], const float* __restr
 
 // rows in accumulator ("D") layout: v[jt][r] = X[row0 + 4kg + r][16jt + c]; rows >= m read as zero
 template <int D>
-__device__ __forceinline__ void load_d(f32x4 (&v)[D / 16], const float* __restrict__ X, int64_t row0, int64_t m, int lane) {
+__device__ __forceinline__ void load_d(f32x4 (&v)[D / 16], const float* __restrict__ X, int64_t row0, int64_t m, int lane,
+                                       int64_t ld = D) {
     const int c = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t row = row0 + 4 * kg + r;
         const bool ok = row < m;
-        const float* p = X + (ok ? row : 0) * D + c;
+        const float* p = X + (ok ? row : 0) * ld + c;
 #pragma unroll
         for (int jt = 0; jt < D / 16; ++jt) v[jt][r] = ok ? p[16 * jt] : 0.f;
     }
 }
 
 template <int D>
-__device__ __forceinline__ void store_d(const f32x4 (&v)[D / 16], float* __restrict__ Y, int64_t row0, int64_t m, int lane) {
+__device__ __forceinline__ void store_d(const f32x4 (&v)[D / 16], float* __restrict__ Y, int64_t row0, int64_t m, int lane,
+                                        int64_t ld = D) {
     const int c = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t row = row0 + 4 * kg + r;
         if (row < m) {
-            float* p = Y + row * D + c;
+            float* p = Y + row * ld + c;
 #pragma unroll
             for (int jt = 0; jt < D / 16; ++jt) p[16 * jt] = v[jt][r];
         }
@@ -182,24 +184,34 @@ __device__ __forceinline__ void red_add_bias(float* red, float (&s)[NJ], int lan
     }
 }
 
-// out[mat][o][k] (k < kvalid) = sum_b partial[b][fragment(o, k)];  bias[j] = sum_b partial[b][bias_off + j]
-__global__ __launch_bounds__(256) void narrow_reduce_kernel(const float* __restrict__ partial, int nblk, int stride,
+// out[mat][o][k] (k < kvalid) = sum_b partial[b][fragment(o, k)];  bias[j] = sum_b partial[b][bias_off + j].
+// Block (64, 8): 64 consecutive positions of the partial row (coalesced) x 8 slices over the workgroup rows, combined
+// through LDS in slice order -- fixed summation order.
+__global__ __launch_bounds__(512) void narrow_reduce_kernel(const float* __restrict__ partial, int nblk, int stride,
                                                             int nmat, int D, int KP, int kvalid, int nbias,
                                                             float* __restrict__ mats, float* __restrict__ bias) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float part[8][64];
+    const int x = threadIdx.x, y = threadIdx.y;
+    const int p = blockIdx.x * 64 + x;
     const int per = D * KP;
-    if (t < nmat * per) {
-        const int mat = t / per, o = (t % per) / KP, k = t % KP;
-        const int jo = o >> 4, kg = (o & 15) >> 2, r = o & 3, jk = k >> 4, c = k & 15;
-        const int frag = mat * per + (((jo * (KP / 16) + jk) * 4 + r) * 64) + kg * 16 + c;
-        float s = 0.f;
-        for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * stride + frag];
+    const int total = nmat * per + nbias;
+    float s = 0.f;
+    if (p < total)
+        for (int b = y; b < nblk; b += 8) s += partial[(size_t)b * stride + p];
+    part[y][x] = s;
+    __syncthreads();
+    if (y != 0 || p >= total) return;
+#pragma unroll
+    for (int u = 1; u < 8; ++u) s += part[u][x];
+    if (p < nmat * per) {
+        const int mat = p / per, rem = p % per;
+        const int t = rem >> 8, r = (rem >> 6) & 3, lane = rem & 63;
+        const int nk = KP / 16;
+        const int jo = t / nk, jk = t % nk;
+        const int o = 16 * jo + 4 * (lane >> 4) + r, k = 16 * jk + (lane & 15);
         if (k < kvalid) mats[(size_t)mat * D * kvalid + (size_t)o * kvalid + k] = s;
-    } else if (t < nmat * per + nbias) {
-        const int j = t - nmat * per;
-        float s = 0.f;
-        for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * stride + nmat * per + j];
-        bias[j] = s;
+    } else {
+        bias[p - nmat * per] = s;
     }
 }
 
@@ -350,6 +362,7 @@ template <int D>
 __global__ __launch_bounds__(NWG) void nmlp2_fwd_kernel(const float* __restrict__ x, int64_t m,
                                                         const float* __restrict__ W1, const float* __restrict__ b1,
                                                         const float* __restrict__ W2, const float* __restrict__ b2,
+                                                        int res_x, const float* __restrict__ res,
                                                         float* __restrict__ y) {
     constexpr int NT = D / 16;
     constexpr int IMG = NT * NT * 64;
@@ -392,6 +405,16 @@ __global__ __launch_bounds__(NWG) void nmlp2_fwd_kernel(const float* __restrict_
                 const float z = o[jt][r] + bj2[jt];
                 o[jt][r] = z * sigmoidf_fast(z);
             }
+        if (res_x) {                                         // Res block: MLP2(x) + x (layers/basic.py:32-33)
+            load_d<D>(h, x, row0, m, lane);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) o[jt] += h[jt];
+        }
+        if (res) {
+            load_d<D>(h, res, row0, m, lane);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) o[jt] += h[jt];
+        }
         store_d<D>(o, y, row0, m, lane);
     }
 }
@@ -400,8 +423,9 @@ template <int D>
 __global__ __launch_bounds__(NWG) void nmlp2_bwd_kernel(const float* __restrict__ x, int64_t m,
                                                         const float* __restrict__ W1, const float* __restrict__ b1,
                                                         const float* __restrict__ W2, const float* __restrict__ b2,
-                                                        const float* __restrict__ dy, float* __restrict__ dx,
-                                                        float* __restrict__ partial, int stride) {
+                                                        const float* __restrict__ dy, int res_x,
+                                                        float* __restrict__ dx, float* __restrict__ partial,
+                                                        int stride) {
     constexpr int NT = D / 16;
     constexpr int IMG = NT * NT * 64;
     extern __shared__ float4 lds4[];
@@ -474,6 +498,10 @@ __global__ __launch_bounds__(NWG) void nmlp2_bwd_kernel(const float* __restrict_
             d_to_a<D>(a, g, tile, lane);
             zero(g);
             mma_img<NT, NT>(g, a, img1t, lane);
+            if (res_x) {
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt) g[jt] += dyv[jt];
+            }
             store_d<D>(g, dx, row0, m, lane);
         }
     }
@@ -490,6 +518,116 @@ __global__ __launch_bounds__(NWG) void nmlp2_bwd_kernel(const float* __restrict_
         __syncthreads();
     }
     for (int i = threadIdx.x; i < 2 * MAT + 2 * D; i += NWG) partial[(size_t)blockIdx.x * stride + i] = red[i];
+}
+
+// ====================================================================================================================
+// One dense layer on rows: y = act(x W^T + b), W a [D, D] block with row stride ldw (slices of the 3d-wide message
+// weights included), y with row stride ldy (so several blocks can fill one [rows, n D] projection).
+// ====================================================================================================================
+template <int D>
+__global__ __launch_bounds__(NWG) void nlinear_fwd_kernel(const float* __restrict__ x, int64_t m,
+                                                          const float* __restrict__ W, int ldw,
+                                                          const float* __restrict__ b, int act, float* __restrict__ y,
+                                                          int64_t ldy) {
+    constexpr int NT = D / 16;
+    extern __shared__ float4 lds4[];
+    build_image<NT, NT, false>(lds4, W, ldw, D);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15;
+    const int64_t ntiles = (m + 15) / 16;
+    float bj[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) bj[jt] = b ? b[16 * jt + c] : 0.f;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = t * 16;
+        float4 a[NT];
+        load_a<D>(a, x, row0, m, lane);
+        f32x4 o[NT];
+        zero(o);
+        mma_img<NT, NT>(o, a, lds4, lane);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = o[jt][r] + bj[jt];
+                o[jt][r] = act ? z * sigmoidf_fast(z) : z;
+            }
+        store_d<D>(o, y, row0, m, lane, ldy);
+    }
+}
+
+// dx (+)= dz W;  partial = [dW fragments (D x D)][db (D)]
+template <int D>
+__global__ __launch_bounds__(NWG) void nlinear_bwd_kernel(const float* __restrict__ x, int64_t m,
+                                                          const float* __restrict__ W, int ldw,
+                                                          const float* __restrict__ b, int act,
+                                                          const float* __restrict__ dy, int64_t lddy,
+                                                          float* __restrict__ dx, int accumulate,
+                                                          float* __restrict__ partial, int stride) {
+    constexpr int NT = D / 16;
+    constexpr int IMG = NT * NT * 64;
+    extern __shared__ float4 lds4[];
+    float4* img = lds4;
+    float4* imgt = lds4 + IMG;
+    float* tile = reinterpret_cast<float*>(lds4 + 2 * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
+    build_image<NT, NT, false>(img, W, ldw, D);
+    build_image<NT, NT, true>(imgt, W, ldw, D);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15;
+    const int64_t ntiles = (m + 15) / 16;
+    float bj[NT], dbs[NT];
+    f32x4 gw[NT][NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        bj[jt] = b ? b[16 * jt + c] : 0.f;
+        dbs[jt] = 0.f;
+        zero(gw[jt]);
+    }
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = t * 16;
+        float4 a[NT];
+        f32x4 g[NT], xd[NT];
+        load_d<D>(g, dy, row0, m, lane, lddy);
+        if (act) {
+            f32x4 z[NT];
+            load_a<D>(a, x, row0, m, lane);
+            zero(z);
+            mma_img<NT, NT>(z, a, img, lane);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float zz = z[jt][r] + bj[jt];
+                    const float s = sigmoidf_fast(zz);
+                    g[jt][r] *= s * (1.0f + zz * (1.0f - s));
+                }
+        }
+        load_d<D>(xd, x, row0, m, lane);
+        wgrad_acc<NT, NT>(gw, g, xd);
+        colsum_acc<NT>(dbs, g);
+        if (dx) {
+            d_to_a<D>(a, g, tile, lane);
+            zero(g);
+            mma_img<NT, NT>(g, a, imgt, lane);
+            if (accumulate) {
+                load_d<D>(xd, dx, row0, m, lane);
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt) g[jt] += xd[jt];
+            }
+            store_d<D>(g, dx, row0, m, lane);
+        }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds4);
+    constexpr int MAT = D * D;
+    for (int w = 0; w < 4; ++w) {
+        if ((threadIdx.x >> 6) == w) {
+            red_add_mat<NT, NT>(red, gw, lane, w == 0);
+            red_add_bias<NT>(red + MAT, dbs, lane, w == 0);
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < MAT + D; i += NWG) partial[(size_t)blockIdx.x * stride + i] = red[i];
 }
 
 // ====================================================================================================================
@@ -763,17 +901,18 @@ extern "C" int pamnet_narrow_global_bwd_f32(const float* e, int64_t m, int64_t d
     PAMNET_LAUNCH_CHECK();
     // dWe and dWea are separate outputs: two reduce launches over the same partial rows (matrix 0 / matrix 1 + bias)
     const int per = (int)(d * d);
-    hipLaunchKernelGGL(narrow_reduce_kernel, dim3((per + 255) / 256), dim3(256), 0, st, partial, grid, stride, 1, (int)d,
+    hipLaunchKernelGGL(narrow_reduce_kernel, dim3((per + 63) / 64), dim3(64, 8), 0, st, partial, grid, stride, 1, (int)d,
                        (int)d, (int)d, 0, dWe, (float*)nullptr);
     PAMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(narrow_reduce_kernel, dim3((per + (int)d + 255) / 256), dim3(256), 0, st, partial + per, grid,
+    hipLaunchKernelGGL(narrow_reduce_kernel, dim3((per + (int)d + 63) / 64), dim3(64, 8), 0, st, partial + per, grid,
                        stride, 1, (int)d, (int)d, (int)d, (int)d, dWea, db);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
 
 extern "C" int pamnet_narrow_mlp2_fwd_f32(const float* x, int64_t m, int64_t d, const float* W1, const float* b1,
-                                          const float* W2, const float* b2, float* y, pamnet_stream_t stream) {
+                                          const float* W2, const float* b2, int32_t res_x, const float* res, float* y,
+                                          pamnet_stream_t stream) {
     if (m < 0 || !width_ok(d)) return PAMNET_EINVAL;
     if (m == 0) return PAMNET_OK;
     if (!x || !W1 || !b1 || !W2 || !b2 || !y) return PAMNET_ENULL;
@@ -782,7 +921,7 @@ extern "C" int pamnet_narrow_mlp2_fwd_f32(const float* x, int64_t m, int64_t d, 
 #define CALL(DD)                                                                                                  \
     {                                                                                                             \
         const size_t lds = 2 * (size_t)DD * DD * sizeof(float) + 4 * 16 * (DD + 4) * sizeof(float);               \
-        hipLaunchKernelGGL((nmlp2_fwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, x, m, W1, b1, W2, b2, y);      \
+        hipLaunchKernelGGL((nmlp2_fwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, x, m, W1, b1, W2, b2, (int)res_x, res, y); \
     }
     NARROW_DISPATCH(d, CALL)
 #undef CALL
@@ -791,8 +930,9 @@ extern "C" int pamnet_narrow_mlp2_fwd_f32(const float* x, int64_t m, int64_t d, 
 }
 
 extern "C" int pamnet_narrow_mlp2_bwd_f32(const float* x, int64_t m, int64_t d, const float* W1, const float* b1,
-                                          const float* W2, const float* b2, const float* dy, float* dx, float* partial,
-                                          float* dW /* [2, d, d] */, float* db /* [2, d] */, pamnet_stream_t stream) {
+                                          const float* W2, const float* b2, const float* dy, int32_t res_x, float* dx,
+                                          float* partial, float* dW /* [2, d, d] */, float* db /* [2, d] */,
+                                          pamnet_stream_t stream) {
     if (m <= 0 || !width_ok(d)) return PAMNET_EINVAL;
     if (!x || !W1 || !b1 || !W2 || !b2 || !dy || !partial || !dW || !db) return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
@@ -803,15 +943,60 @@ extern "C" int pamnet_narrow_mlp2_bwd_f32(const float* x, int64_t m, int64_t d, 
         const size_t lds = 4 * (size_t)DD * DD * sizeof(float) + 4 * 16 * (DD + 4) * sizeof(float);                    \
         hipError_t e_ = allow_lds(nmlp2_bwd_kernel<DD>, lds);                                                          \
         if (e_ != hipSuccess) return (int)e_;                                                                          \
-        hipLaunchKernelGGL((nmlp2_bwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, x, m, W1, b1, W2, b2, dy, dx, partial, \
-                           stride);                                                                                    \
+        hipLaunchKernelGGL((nmlp2_bwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, x, m, W1, b1, W2, b2, dy, (int)res_x, dx, \
+                           partial, stride);                                                                           \
     }
     NARROW_DISPATCH(d, CALL)
 #undef CALL
     PAMNET_LAUNCH_CHECK();
     const int total = (int)(2 * d * d + 2 * d);
-    hipLaunchKernelGGL(narrow_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, partial, grid, stride, 2, (int)d,
+    hipLaunchKernelGGL(narrow_reduce_kernel, dim3((total + 63) / 64), dim3(64, 8), 0, st, partial, grid, stride, 2, (int)d,
                        (int)d, (int)d, (int)(2 * d), dW, db);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_narrow_linear_fwd_f32(const float* x, int64_t m, int64_t d, const float* W, int64_t ldw,
+                                            const float* b, int32_t act, float* y, int64_t ldy,
+                                            pamnet_stream_t stream) {
+    if (m < 0 || !width_ok(d) || ldw < d || ldy < d) return PAMNET_EINVAL;
+    if (m == 0) return PAMNET_OK;
+    if (!x || !W || !y) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for(m, 4);
+#define CALL(DD)                                                                                                       \
+    {                                                                                                                  \
+        const size_t lds = (size_t)DD * DD * sizeof(float);                                                            \
+        hipLaunchKernelGGL((nlinear_fwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, x, m, W, (int)ldw, b, (int)act, y, ldy); \
+    }
+    NARROW_DISPATCH(d, CALL)
+#undef CALL
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+/* dx optional; accumulate != 0: dx += ...; dW [d, d] dense, db [d] (null when the layer has no bias) */
+extern "C" int pamnet_narrow_linear_bwd_f32(const float* x, int64_t m, int64_t d, const float* W, int64_t ldw,
+                                            const float* b, int32_t act, const float* dy, int64_t lddy, float* dx,
+                                            int32_t accumulate, float* partial, float* dW, float* db,
+                                            pamnet_stream_t stream) {
+    if (m <= 0 || !width_ok(d) || ldw < d || lddy < d) return PAMNET_EINVAL;
+    if (!x || !W || !dy || !partial || !dW) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for(m, 2);
+    const int stride = (int)(d * d + d);
+#define CALL(DD)                                                                                                        \
+    {                                                                                                                   \
+        const size_t lds = 2 * (size_t)DD * DD * sizeof(float) + 4 * 16 * (DD + 4) * sizeof(float);                     \
+        hipLaunchKernelGGL((nlinear_bwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, x, m, W, (int)ldw, b, (int)act, dy, lddy, \
+                           dx, (int)accumulate, partial, stride);                                                       \
+    }
+    NARROW_DISPATCH(d, CALL)
+#undef CALL
+    PAMNET_LAUNCH_CHECK();
+    const int total = (int)(d * d + (db ? d : 0));
+    hipLaunchKernelGGL(narrow_reduce_kernel, dim3((total + 63) / 64), dim3(64, 8), 0, st, partial, grid, stride, 1, (int)d,
+                       (int)d, (int)d, db ? (int)d : 0, dW, db);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -894,7 +1079,7 @@ extern "C" int pamnet_narrow_embed_bwd_f32(const float* F, int64_t m, int64_t k,
 #undef CALL
     PAMNET_LAUNCH_CHECK();
     const int total = (int)(sets * (d * kp + d));
-    hipLaunchKernelGGL(narrow_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, partial, grid, stride, sets,
+    hipLaunchKernelGGL(narrow_reduce_kernel, dim3((total + 63) / 64), dim3(64, 8), 0, st, partial, grid, stride, sets,
                        (int)d, kp, (int)k, (int)(sets * d), dW, db);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;

@@ -92,11 +92,14 @@ def update_and_heads(layer, x, res_x):
     """Shared tail of both layer kinds (global_message_passing.py:39-50 / local_message_passing.py:55-66)."""
     if _fused(x):
         return fused.node_tail(layer, x, res_x)
-    x = mlp_apply(layer.mlp_x2, x)
-    x = res_apply(layer.res1, x) + res_x
-    x = res_apply(layer.res2, x)
-    x = res_apply(layer.res3, x)
-    o = mlp_apply(layer.mlp_out, x)
+    if _narrow(x):
+        x, o = narrow.tail(layer, x, res_x)
+    else:
+        x = mlp_apply(layer.mlp_x2, x)
+        x = res_apply(layer.res1, x) + res_x
+        x = res_apply(layer.res2, x)
+        x = res_apply(layer.res3, x)
+        o = mlp_apply(layer.mlp_out, x)
     att = (o @ layer.W).view(-1)
     out = F.linear(o, layer.W_out.weight, layer.W_out.bias).view(-1)
     return x, out, att
@@ -136,11 +139,13 @@ class GlobalMP(_LayerBase):
             return fused.global_layer(self, x, e, g)          # whole layer: 4 fused launches forward
         res_x = x
         wm, bm = self.mlp_m[0][0].weight, self.mlp_m[0][0].bias
-        x = mlp_apply(self.mlp_x1, x)
-        p = F.linear(x, torch.cat([wm[:, :d], wm[:, d:2 * d]], 0))               # [N, 2d]: W_i x | W_j x
         if _narrow(x):
+            x = narrow.linear(x, self.mlp_x1[0][0])
+            p = narrow.project(x, ((0, 0), (0, d)), wm)                          # [N, 2d]: W_i x | W_j x
             x = narrow.global_message(x, p, e, wm, bm, self.W_edge_attr.weight, g.glob, g.glob_T)
             return update_and_heads(self, x, res_x)
+        x = mlp_apply(self.mlp_x1, x)
+        p = F.linear(x, torch.cat([wm[:, :d], wm[:, d:2 * d]], 0))               # [N, 2d]: W_i x | W_j x
         q = F.linear(e, torch.cat([wm[:, 2 * d:], self.W_edge_attr.weight], 0),   # [E_g, 2d]: W_e e + b | W_ea e
                      torch.cat([bm, torch.zeros_like(bm)]))
         csr = g.glob
@@ -182,8 +187,12 @@ class LocalMP(_LayerBase):
         lin_kj = (self.mlp_m_jj if self.small else self.mlp_m_kj)[0][0]
         wj, wk = lin_ji.weight, lin_kj.weight
         # node-level projections [N, 4d]: ji_i | kj_i | ji_j | kj_j ; edge-level [E_l, 4d]: ji_e | kj_e | lin_rbf | lin_rbf_out
-        x = mlp_apply(self.mlp_x1, x)
-        p = F.linear(x, torch.cat([wj[:, :d], wk[:, :d], wj[:, d:2 * d], wk[:, d:2 * d]], 0))
+        if _narrow(x):
+            x = narrow.linear(x, self.mlp_x1[0][0])
+            p = narrow.project(x, ((0, 0), (1, 0), (0, d), (1, d)), wj, wk)
+        else:
+            x = mlp_apply(self.mlp_x1, x)
+            p = F.linear(x, torch.cat([wj[:, :d], wk[:, :d], wj[:, d:2 * d], wk[:, d:2 * d]], 0))
         zero = torch.zeros_like(lin_ji.bias)
         q = F.linear(rbf, torch.cat([wj[:, 2 * d:], wk[:, 2 * d:], self.lin_rbf.weight, self.lin_rbf_out.weight], 0),
                      torch.cat([lin_ji.bias, lin_kj.bias, zero, zero]))

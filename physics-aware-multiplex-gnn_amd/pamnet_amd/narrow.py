@@ -84,16 +84,19 @@ def global_message(x1, P, e, wm, bm, wea, csr, tr):
 
 
 class _Mlp2(torch.autograd.Function):
-    """SiLU(W2 SiLU(W1 x + b1) + b2) on rows (mlp_sbf, layers/local_message_passing.py:24,49)."""
+    """SiLU(W2 SiLU(W1 x + b1) + b2) [+ x] [+ r] on rows: mlp_sbf (layers/local_message_passing.py:24,49), the Res blocks
+    (layers/basic.py:25-33) and the first two layers of mlp_out."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, res_x, r):
         x, w1, b1, w2, b2 = _c(x), _c(w1), _c(b1), _c(w2), _c(b2)
+        r = _c(r) if r is not None else None
         m, d = x.shape
         y = _empty(m, d, like=x)
         lib.call('pamnet_narrow_mlp2_fwd_f32', lib.ptr(x), m, d, lib.ptr(w1), lib.ptr(b1), lib.ptr(w2), lib.ptr(b2),
-                 lib.ptr(y), lib.stream_of(x))
+                 1 if res_x else 0, lib.ptr(r), lib.ptr(y), lib.stream_of(x))
         ctx.save_for_backward(x, w1, b1, w2, b2)
+        ctx.res_x, ctx.has_r = bool(res_x), r is not None
         return y
 
     @staticmethod
@@ -101,21 +104,88 @@ class _Mlp2(torch.autograd.Function):
         x, w1, b1, w2, b2 = ctx.saved_tensors
         g = _c(g)
         m, d = x.shape
+        gr = g if ctx.has_r else None
         if m == 0:
             return torch.zeros_like(x), torch.zeros_like(w1), torch.zeros_like(b1), torch.zeros_like(w2), \
-                torch.zeros_like(b2)
+                torch.zeros_like(b2), None, gr
         dx = _empty(m, d, like=g) if ctx.needs_input_grad[0] else None
         partial = _empty(_blocks(m), 2 * d * d + 2 * d, like=g)
         dw, db = _empty(2, d, d, like=g), _empty(2, d, like=g)
         lib.call('pamnet_narrow_mlp2_bwd_f32', lib.ptr(x), m, d, lib.ptr(w1), lib.ptr(b1), lib.ptr(w2), lib.ptr(b2),
-                 lib.ptr(g), lib.ptr(dx), lib.ptr(partial), lib.ptr(dw), lib.ptr(db), lib.stream_of(g))
-        return dx, dw[0], db[0], dw[1], db[1]
+                 lib.ptr(g), 1 if ctx.res_x else 0, lib.ptr(dx), lib.ptr(partial), lib.ptr(dw), lib.ptr(db),
+                 lib.stream_of(g))
+        return dx, dw[0], db[0], dw[1], db[1], None, gr
 
 
-def mlp2(x, seq):
-    """seq = MLP([d, d, d]) (two Sequential(Linear, SiLU) blocks)."""
+def mlp2(x, seq, res_x=False, r=None):
+    """seq = two Sequential(Linear, SiLU) blocks (MLP([d, d, d]) or the first two of a longer MLP)."""
     l1, l2 = seq[0][0], seq[1][0]
-    return _Mlp2.apply(x, l1.weight, l1.bias, l2.weight, l2.bias)
+    return _Mlp2.apply(x, l1.weight, l1.bias, l2.weight, l2.bias, res_x, r)
+
+
+class _Project(torch.autograd.Function):
+    """y[:, k d:(k+1) d] = act(x W_k^T (+ b)) for [d, d] blocks W_k = weights[wi][:, c0:c0 + d]: one dense layer
+    (k = 1) or the node-side projections of the split message weights (global_message_passing.py:52,
+    local_message_passing.py:46-48 after W[x_i | x_j | e] = W_i x_i + W_j x_j + W_e e)."""
+
+    @staticmethod
+    def forward(ctx, x, blocks, bias, act, *weights):
+        x = _c(x)
+        m, d = x.shape
+        nb = len(blocks)
+        y = _empty(m, nb * d, like=x)
+        st = lib.stream_of(x)
+        for k, (wi, c0) in enumerate(blocks):
+            w = weights[wi]
+            assert w.stride(1) == 1 and w.size(0) == d
+            lib.call('pamnet_narrow_linear_fwd_f32', lib.ptr(x), m, d, w.data_ptr() + 4 * c0, w.stride(0),
+                     lib.ptr(bias), 1 if act else 0, y.data_ptr() + 4 * k * d, nb * d, st)
+        ctx.save_for_backward(x, bias, *weights)
+        ctx.blocks, ctx.act = blocks, act
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bias = ctx.saved_tensors[:2]
+        weights = ctx.saved_tensors[2:]
+        g = _c(g)
+        m, d = x.shape
+        nb = len(ctx.blocks)
+        dws = [torch.zeros_like(w) for w in weights]
+        if m == 0:
+            return (torch.zeros_like(x), None, (torch.zeros_like(bias) if bias is not None else None), None) + tuple(dws)
+        st = lib.stream_of(g)
+        dx = _empty(m, d, like=g) if ctx.needs_input_grad[0] else None
+        partial = _empty(_blocks(m), d * d + d, like=g)
+        db = _empty(d, like=g) if bias is not None else None
+        for k, (wi, c0) in enumerate(ctx.blocks):
+            w = weights[wi]
+            dw = _empty(d, d, like=g)
+            lib.call('pamnet_narrow_linear_bwd_f32', lib.ptr(x), m, d, w.data_ptr() + 4 * c0, w.stride(0),
+                     lib.ptr(bias), 1 if ctx.act else 0, g.data_ptr() + 4 * k * d, nb * d, lib.ptr(dx),
+                     1 if k > 0 else 0, lib.ptr(partial), lib.ptr(dw), lib.ptr(db), st)
+            dws[wi][:, c0:c0 + d] += dw
+        return (dx, None, db, None) + tuple(dws)
+
+
+def linear(x, lin, act=True):
+    """One Sequential(Linear, SiLU) block (act) or a bare Linear."""
+    return _Project.apply(x, ((0, 0),), lin.bias, act, lin.weight)
+
+
+def project(x, blocks, *weights):
+    """blocks: ((weight index, first column), ...) -> [rows, len(blocks) * d], no bias, no activation."""
+    return _Project.apply(x, tuple(blocks), None, False, *weights)
+
+
+def tail(layer, x, res_x):
+    """mlp_x2 -> Res1 (+ the layer input) -> Res2 -> Res3 -> mlp_out (global_message_passing.py:40-50)."""
+    x = linear(x, layer.mlp_x2[0][0])
+    x = mlp2(x, layer.res1.mlp, res_x=True, r=res_x)
+    x = mlp2(x, layer.res2.mlp, res_x=True)
+    x = mlp2(x, layer.res3.mlp, res_x=True)
+    o = linear(mlp2(x, layer.mlp_out), layer.mlp_out[2][0])
+    return x, o
 
 
 class _Embed(torch.autograd.Function):

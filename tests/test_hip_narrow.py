@@ -80,20 +80,58 @@ def test_global_message(dev, d, n, max_deg):
 
 @pytest.mark.parametrize('d', [16, 32, 64])
 @pytest.mark.parametrize('m', [1, 17, 4099])
-def test_mlp2(dev, d, m):
+@pytest.mark.parametrize('res_x,with_r', [(False, False), (True, False), (True, True)])
+def test_mlp2(dev, d, m, res_x, with_r):
+    """mlp_sbf (plain) and the Res blocks (MLP2(x) + x [+ layer input], layers/basic.py:25-33)."""
     from pamnet_amd import narrow
     torch.manual_seed(d * 3 + m)
     mk = lambda *s: (torch.randn(*s, device=dev) * 0.4).requires_grad_(True)
-    x, w1, b1, w2, b2 = mk(m, d), mk(d, d), mk(d), mk(d, d), mk(d)
-    y = narrow._Mlp2.apply(x, w1, b1, w2, b2)
+    x, w1, b1, w2, b2, r = mk(m, d), mk(d, d), mk(d), mk(d, d), mk(d), mk(m, d)
+    y = narrow._Mlp2.apply(x, w1, b1, w2, b2, res_x, r if with_r else None)
     g = torch.randn_like(y)
     y.backward(g)
-    ref_in = [t.detach().double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
-    rx, rw1, rb1, rw2, rb2 = ref_in
+    ref_in = [t.detach().double().requires_grad_(True) for t in (x, w1, b1, w2, b2, r)]
+    rx, rw1, rb1, rw2, rb2, rr = ref_in
     ref = F.silu(F.linear(F.silu(F.linear(rx, rw1, rb1)), rw2, rb2))
+    if res_x:
+        ref = ref + rx
+    if with_r:
+        ref = ref + rr
     ref.backward(g.double())
     assert maxnorm_err(y.detach().cpu(), ref.detach().cpu()) < TOL
-    _check_grads((x, w1, b1, w2, b2), ref_in, ('x', 'w1', 'b1', 'w2', 'b2'))
+    n = 6 if with_r else 5
+    _check_grads((x, w1, b1, w2, b2, r)[:n], ref_in[:n], ('x', 'w1', 'b1', 'w2', 'b2', 'r')[:n])
+
+
+@pytest.mark.parametrize('d', [16, 32, 64])
+@pytest.mark.parametrize('m', [1, 1000, 4099])
+def test_linear_and_projection(dev, d, m):
+    """One dense block (bias + SiLU) and the four node-side projections of the split 3d-wide message weights."""
+    from pamnet_amd import narrow
+    torch.manual_seed(d + m)
+    mk = lambda *s: (torch.randn(*s, device=dev) * 0.4).requires_grad_(True)
+    x, w, b = mk(m, d), mk(d, d), mk(d)
+    lin = torch.nn.Linear(d, d).to(dev)
+    with torch.no_grad():
+        lin.weight.copy_(w), lin.bias.copy_(b)
+    y = narrow.linear(x, lin, act=True)
+    g = torch.randn_like(y)
+    y.backward(g)
+    rx, rw, rb = [t.detach().double().requires_grad_(True) for t in (x, w, b)]
+    ref = F.silu(F.linear(rx, rw, rb))
+    ref.backward(g.double())
+    assert maxnorm_err(y.detach().cpu(), ref.detach().cpu()) < TOL
+    _check_grads((x, lin.weight, lin.bias), (rx, rw, rb), ('x', 'w', 'b'))
+
+    x2, wj, wk = mk(m, d), mk(d, 3 * d), mk(d, 3 * d)
+    p = narrow.project(x2, ((0, 0), (1, 0), (0, d), (1, d)), wj, wk)
+    g = torch.randn_like(p)
+    p.backward(g)
+    rx2, rwj, rwk = [t.detach().double().requires_grad_(True) for t in (x2, wj, wk)]
+    ref = F.linear(rx2, torch.cat([rwj[:, :d], rwk[:, :d], rwj[:, d:2 * d], rwk[:, d:2 * d]], 0))
+    ref.backward(g.double())
+    assert maxnorm_err(p.detach().cpu(), ref.detach().cpu()) < TOL
+    _check_grads((x2, wj, wk), (rx2, rwj, rwk), ('x', 'wj', 'wk'))
 
 
 @pytest.mark.parametrize('d', [16, 32, 64])
