@@ -835,6 +835,11 @@ inline int grid_for(int64_t m, int per_cu) {
 
 inline bool width_ok(int64_t d) { return d == 16 || d == 32 || d == 64; }
 
+// Workgroups that are co-resident per CU: the backward kernels at d = 64 hold ~350 registers per lane and ~80 KB of
+// weight images, so one 4-wave workgroup fills a CU; a grid beyond that only adds a second, nearly empty round.
+inline int fwd_per_cu(int64_t d) { return d == 64 ? 2 : 4; }
+inline int bwd_per_cu(int64_t d) { return d == 64 ? 1 : (d == 32 ? 2 : 4); }
+
 template <typename Kern>
 inline hipError_t allow_lds(Kern k, size_t bytes) {
     if (bytes <= 64 * 1024) return hipSuccess;
@@ -853,7 +858,7 @@ inline hipError_t allow_lds(Kern k, size_t bytes) {
 extern "C" int pamnet_narrow_blocks(int64_t rows, int64_t* blocks) {
     if (rows < 0) return PAMNET_EINVAL;
     if (!blocks) return PAMNET_ENULL;
-    *blocks = grid_for(rows, 2);
+    *blocks = grid_for(rows, 4);                             // upper bound over all widths
     return PAMNET_OK;
 }
 
@@ -864,7 +869,7 @@ extern "C" int pamnet_narrow_global_fwd_f32(const float* e, int64_t m, int64_t d
     if (m == 0) return PAMNET_OK;
     if (!e || !tgt || !src || !P || !We || !bias || !Wea || !msg) return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for(m, 4);
+    const int grid = grid_for(m, fwd_per_cu(d));
 #define CALL(DD)                                                                                                     \
     {                                                                                                                \
         const size_t lds = 2 * (size_t)DD * DD * sizeof(float);                                                      \
@@ -886,7 +891,7 @@ extern "C" int pamnet_narrow_global_bwd_f32(const float* e, int64_t m, int64_t d
     if (!e || !tgt || !src || !P || !We || !bias || !Wea || !dagg || !dz || !de || !partial || !dWe || !dWea || !db)
         return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for(m, 2);
+    const int grid = grid_for(m, bwd_per_cu(d));
     const int stride = (int)(2 * d * d + d);
 #define CALL(DD)                                                                                                     \
     {                                                                                                                \
@@ -917,7 +922,7 @@ extern "C" int pamnet_narrow_mlp2_fwd_f32(const float* x, int64_t m, int64_t d, 
     if (m == 0) return PAMNET_OK;
     if (!x || !W1 || !b1 || !W2 || !b2 || !y) return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for(m, 4);
+    const int grid = grid_for(m, fwd_per_cu(d));
 #define CALL(DD)                                                                                                  \
     {                                                                                                             \
         const size_t lds = 2 * (size_t)DD * DD * sizeof(float) + 4 * 16 * (DD + 4) * sizeof(float);               \
@@ -936,7 +941,7 @@ extern "C" int pamnet_narrow_mlp2_bwd_f32(const float* x, int64_t m, int64_t d, 
     if (m <= 0 || !width_ok(d)) return PAMNET_EINVAL;
     if (!x || !W1 || !b1 || !W2 || !b2 || !dy || !partial || !dW || !db) return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for(m, 2);
+    const int grid = grid_for(m, bwd_per_cu(d));
     const int stride = (int)(2 * d * d + 2 * d);
 #define CALL(DD)                                                                                                       \
     {                                                                                                                  \
@@ -963,7 +968,7 @@ extern "C" int pamnet_narrow_linear_fwd_f32(const float* x, int64_t m, int64_t d
     if (m == 0) return PAMNET_OK;
     if (!x || !W || !y) return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for(m, 4);
+    const int grid = grid_for(m, fwd_per_cu(d));
 #define CALL(DD)                                                                                                       \
     {                                                                                                                  \
         const size_t lds = (size_t)DD * DD * sizeof(float);                                                            \
@@ -983,7 +988,7 @@ extern "C" int pamnet_narrow_linear_bwd_f32(const float* x, int64_t m, int64_t d
     if (m <= 0 || !width_ok(d) || ldw < d || lddy < d) return PAMNET_EINVAL;
     if (!x || !W || !dy || !partial || !dW) return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for(m, 2);
+    const int grid = grid_for(m, bwd_per_cu(d));
     const int stride = (int)(d * d + d);
 #define CALL(DD)                                                                                                        \
     {                                                                                                                   \
@@ -1008,7 +1013,7 @@ extern "C" int pamnet_narrow_embed_fwd_f32(const float* F, int64_t m, int64_t k,
     if (m == 0) return PAMNET_OK;
     if (!F || !Wa || !ba || !y || (kind && (!Wb || !bb))) return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for(m, 4);
+    const int grid = grid_for(m, fwd_per_cu(d));
     const bool two = kind != nullptr;
 #define CALL(DD)                                                                                                         \
     {                                                                                                                    \
@@ -1045,7 +1050,7 @@ extern "C" int pamnet_narrow_embed_bwd_f32(const float* F, int64_t m, int64_t k,
     if (!F || !Wa || !ba || !dy || !partial || !dW || !db || (kind && (!Wb || !bb))) return PAMNET_ENULL;
     if (df && (k != 16 || kind)) return PAMNET_EINVAL;
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for(m, 2);
+    const int grid = grid_for(m, bwd_per_cu(d));
     const bool two = kind != nullptr;
     const int kp = (k == 16) ? 16 : 48;
     const int sets = two ? 2 : 1;

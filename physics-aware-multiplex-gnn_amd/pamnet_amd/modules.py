@@ -193,12 +193,19 @@ class LocalMP(_LayerBase):
         else:
             x = mlp_apply(self.mlp_x1, x)
             p = F.linear(x, torch.cat([wj[:, :d], wk[:, :d], wj[:, d:2 * d], wk[:, d:2 * d]], 0))
-        zero = torch.zeros_like(lin_ji.bias)
-        q = F.linear(rbf, torch.cat([wj[:, 2 * d:], wk[:, 2 * d:], self.lin_rbf.weight, self.lin_rbf_out.weight], 0),
-                     torch.cat([lin_ji.bias, lin_kj.bias, zero, zero]))
+        if _narrow(x):
+            q = narrow.project(rbf, ((0, 2 * d), (1, 2 * d), (2, 0), (3, 0)), wj, wk, self.lin_rbf.weight,
+                               self.lin_rbf_out.weight)
+            zb = torch.cat([lin_ji.bias, lin_kj.bias])       # the projection blocks carry no bias: added to z below
+        else:
+            zero, zb = torch.zeros_like(lin_ji.bias), None
+            q = F.linear(rbf, torch.cat([wj[:, 2 * d:], wk[:, 2 * d:], self.lin_rbf.weight, self.lin_rbf_out.weight], 0),
+                         torch.cat([lin_ji.bias, lin_kj.bias, zero, zero]))
         csr = g.loc
         z = ops.gather(p[:, :2 * d], csr.row_of, csr.ptr) + ops.gather(p[:, 2 * d:], csr.col, g.loc_T.ptr, g.loc_T.perm) \
             + q[:, :2 * d]
+        if zb is not None:
+            z = z + zb
         a = F.silu(z)
         m_ji = a[:, :d]
         m_nb = a[:, d:] * q[:, 2 * d:3 * d]                                       # mlp_m_kj(m) * lin_rbf(rbf)
