@@ -24,7 +24,10 @@ namespace {
 using pamnet::f32x4;
 using pamnet::sigmoidf_fast;
 
-constexpr int NWG = 256;                      // threads per workgroup (4 independent waves)
+constexpr int NWG = 256;                      // forward kernels: 4 independent waves per workgroup
+// Backward kernels end with one partial gradient row per workgroup, so they run at most one workgroup per CU and get
+// their occupancy from more waves per workgroup where the register budget allows (d = 64 needs ~350 registers a lane).
+__host__ __device__ constexpr int bwd_waves(int d) { return d == 16 ? 16 : (d == 32 ? 8 : 4); }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -41,7 +44,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 //   TRANS = true : Y = X W,   W [k][out]:                                            b.t = W[16q + 4kg + t][16jt + c]
 template <int NJ, int NQ, bool TRANS>
 __device__ __forceinline__ void build_image(float4* img, const float* __restrict__ W, int ld, int kin) {
-    for (int idx = threadIdx.x; idx < NJ * NQ * 64; idx += NWG) {
+    for (int idx = threadIdx.x; idx < NJ * NQ * 64; idx += blockDim.x) {
         const int lane = idx & 63, t = idx >> 6;
         const int q = t % NQ, jt = t / NQ;
         const int c = lane & 15, kg = lane >> 4;
@@ -196,8 +199,18 @@ __global__ __launch_bounds__(512) void narrow_reduce_kernel(const float* __restr
     const int per = D * KP;
     const int total = nmat * per + nbias;
     float s = 0.f;
-    if (p < total)
-        for (int b = y; b < nblk; b += 8) s += partial[(size_t)b * stride + p];
+    if (p < total) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;        // four loads in flight per thread, fixed association
+        int b = y;
+        for (; b + 24 < nblk; b += 32) {
+            s0 += partial[(size_t)b * stride + p];
+            s1 += partial[(size_t)(b + 8) * stride + p];
+            s2 += partial[(size_t)(b + 16) * stride + p];
+            s3 += partial[(size_t)(b + 24) * stride + p];
+        }
+        for (; b < nblk; b += 8) s0 += partial[(size_t)b * stride + p];
+        s = (s0 + s1) + (s2 + s3);
+    }
     part[y][x] = s;
     __syncthreads();
     if (y != 0 || p >= total) return;
@@ -266,7 +279,7 @@ __global__ __launch_bounds__(NWG) void nglobal_fwd_kernel(const float* __restric
 // backward: dmsg[row] = dagg[tgt[row]].  Outputs dz [m, D] (for the two node-side segment sums), de [m, D],
 // and per-workgroup partials of dWe, dWea (fragment order) and db.
 template <int D>
-__global__ __launch_bounds__(NWG) void nglobal_bwd_kernel(const float* __restrict__ e, int64_t m,
+__global__ __launch_bounds__(64 * bwd_waves(D)) void nglobal_bwd_kernel(const float* __restrict__ e, int64_t m,
                                                           const int32_t* __restrict__ tgt, const int32_t* __restrict__ src,
                                                           const float* __restrict__ P, const float* __restrict__ We, int ldwe,
                                                           const float* __restrict__ bias, const float* __restrict__ Wea,
@@ -275,6 +288,7 @@ __global__ __launch_bounds__(NWG) void nglobal_bwd_kernel(const float* __restric
                                                           float* __restrict__ partial, int stride) {
     constexpr int NT = D / 16;
     constexpr int IMG = NT * NT * 64;
+    constexpr int NW = bwd_waves(D);
     extern __shared__ float4 lds4[];
     float4* img_e = lds4;
     float4* img_a = lds4 + IMG;
@@ -297,8 +311,8 @@ __global__ __launch_bounds__(NWG) void nglobal_bwd_kernel(const float* __restric
         zero(gwe[jt]);
         zero(gwa[jt]);
     }
-    for (int64_t tile_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile_id < ntiles;
-         tile_id += (int64_t)gridDim.x * 4) {
+    for (int64_t tile_id = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6); tile_id < ntiles;
+         tile_id += (int64_t)gridDim.x * NW) {
         const int64_t row0 = tile_id * 16;
         float4 a[NT];
         load_a<D>(a, e, row0, m, lane);
@@ -343,7 +357,7 @@ __global__ __launch_bounds__(NWG) void nglobal_bwd_kernel(const float* __restric
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds4);
     constexpr int MAT = D * D;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
         if ((threadIdx.x >> 6) == w) {
             red_add_mat<NT, NT>(red, gwe, lane, w == 0);
             red_add_mat<NT, NT>(red + MAT, gwa, lane, w == 0);
@@ -351,7 +365,7 @@ __global__ __launch_bounds__(NWG) void nglobal_bwd_kernel(const float* __restric
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < 2 * MAT + D; i += NWG) partial[(size_t)blockIdx.x * stride + i] = red[i];
+    for (int i = threadIdx.x; i < 2 * MAT + D; i += 64 * NW) partial[(size_t)blockIdx.x * stride + i] = red[i];
 }
 
 // ====================================================================================================================
@@ -420,7 +434,7 @@ __global__ __launch_bounds__(NWG) void nmlp2_fwd_kernel(const float* __restrict_
 }
 
 template <int D>
-__global__ __launch_bounds__(NWG) void nmlp2_bwd_kernel(const float* __restrict__ x, int64_t m,
+__global__ __launch_bounds__(64 * bwd_waves(D)) void nmlp2_bwd_kernel(const float* __restrict__ x, int64_t m,
                                                         const float* __restrict__ W1, const float* __restrict__ b1,
                                                         const float* __restrict__ W2, const float* __restrict__ b2,
                                                         const float* __restrict__ dy, int res_x,
@@ -428,6 +442,7 @@ __global__ __launch_bounds__(NWG) void nmlp2_bwd_kernel(const float* __restrict_
                                                         int stride) {
     constexpr int NT = D / 16;
     constexpr int IMG = NT * NT * 64;
+    constexpr int NW = bwd_waves(D);
     extern __shared__ float4 lds4[];
     float4* img1 = lds4;
     float4* img2 = lds4 + IMG;
@@ -451,7 +466,7 @@ __global__ __launch_bounds__(NWG) void nmlp2_bwd_kernel(const float* __restrict_
         zero(gw1[jt]);
         zero(gw2[jt]);
     }
-    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * 4) {
+    for (int64_t t = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * NW) {
         const int64_t row0 = t * 16;
         float4 a[NT];
         load_a<D>(a, x, row0, m, lane);
@@ -508,7 +523,7 @@ __global__ __launch_bounds__(NWG) void nmlp2_bwd_kernel(const float* __restrict_
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds4);
     constexpr int MAT = D * D;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
         if ((threadIdx.x >> 6) == w) {
             red_add_mat<NT, NT>(red, gw1, lane, w == 0);
             red_add_mat<NT, NT>(red + MAT, gw2, lane, w == 0);
@@ -517,7 +532,7 @@ __global__ __launch_bounds__(NWG) void nmlp2_bwd_kernel(const float* __restrict_
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < 2 * MAT + 2 * D; i += NWG) partial[(size_t)blockIdx.x * stride + i] = red[i];
+    for (int i = threadIdx.x; i < 2 * MAT + 2 * D; i += 64 * NW) partial[(size_t)blockIdx.x * stride + i] = red[i];
 }
 
 // ====================================================================================================================
@@ -558,7 +573,7 @@ __global__ __launch_bounds__(NWG) void nlinear_fwd_kernel(const float* __restric
 
 // dx (+)= dz W;  partial = [dW fragments (D x D)][db (D)]
 template <int D>
-__global__ __launch_bounds__(NWG) void nlinear_bwd_kernel(const float* __restrict__ x, int64_t m,
+__global__ __launch_bounds__(64 * bwd_waves(D)) void nlinear_bwd_kernel(const float* __restrict__ x, int64_t m,
                                                           const float* __restrict__ W, int ldw,
                                                           const float* __restrict__ b, int act,
                                                           const float* __restrict__ dy, int64_t lddy,
@@ -566,6 +581,7 @@ __global__ __launch_bounds__(NWG) void nlinear_bwd_kernel(const float* __restric
                                                           float* __restrict__ partial, int stride) {
     constexpr int NT = D / 16;
     constexpr int IMG = NT * NT * 64;
+    constexpr int NW = bwd_waves(D);
     extern __shared__ float4 lds4[];
     float4* img = lds4;
     float4* imgt = lds4 + IMG;
@@ -583,7 +599,7 @@ __global__ __launch_bounds__(NWG) void nlinear_bwd_kernel(const float* __restric
         dbs[jt] = 0.f;
         zero(gw[jt]);
     }
-    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * 4) {
+    for (int64_t t = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * NW) {
         const int64_t row0 = t * 16;
         float4 a[NT];
         f32x4 g[NT], xd[NT];
@@ -620,14 +636,14 @@ __global__ __launch_bounds__(NWG) void nlinear_bwd_kernel(const float* __restric
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds4);
     constexpr int MAT = D * D;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
         if ((threadIdx.x >> 6) == w) {
             red_add_mat<NT, NT>(red, gw, lane, w == 0);
             red_add_bias<NT>(red + MAT, dbs, lane, w == 0);
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < MAT + D; i += NWG) partial[(size_t)blockIdx.x * stride + i] = red[i];
+    for (int i = threadIdx.x; i < MAT + D; i += 64 * NW) partial[(size_t)blockIdx.x * stride + i] = red[i];
 }
 
 // ====================================================================================================================
@@ -721,7 +737,7 @@ __global__ __launch_bounds__(NWG) void nembed_fwd_kernel(const float* __restrict
 // backward: partial = [dWa fragments (D x KP)][dWb fragments if TWO][dba (D)][dbb (D) if TWO]; df [m, K] only for
 // the single-set K = 16 case (the Bessel frequencies are trainable, layers/basic.py:65-72).
 template <int D, int K, bool TWO, bool DX>
-__global__ __launch_bounds__(NWG) void nembed_bwd_kernel(const float* __restrict__ F, int64_t m,
+__global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const float* __restrict__ F, int64_t m,
                                                          const int32_t* __restrict__ kind,
                                                          const float* __restrict__ Wa, const float* __restrict__ ba,
                                                          const float* __restrict__ Wb, const float* __restrict__ bb,
@@ -731,6 +747,7 @@ __global__ __launch_bounds__(NWG) void nembed_bwd_kernel(const float* __restrict
     constexpr int NT = D / 16, NQ = (K + 15) / 16, KP = NQ * 16;
     constexpr int IMG = NT * NQ * 64;
     constexpr int IMGT = NQ * NT * 64;
+    constexpr int NW = bwd_waves(D);
     extern __shared__ float4 lds4[];
     float4* img_t = lds4 + (TWO ? 2 : 1) * IMG;
     float* tile = reinterpret_cast<float*>(lds4 + (TWO ? 2 : 1) * IMG + (DX ? IMGT : 0)) + (threadIdx.x >> 6) * 16 * (D + 4);
@@ -750,7 +767,7 @@ __global__ __launch_bounds__(NWG) void nembed_bwd_kernel(const float* __restrict
         zero(gwa[jt]);
         if constexpr (TWO) zero(gwb[jt]);
     }
-    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * 4) {
+    for (int64_t t = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * NW) {
         const int64_t row0 = t * 16;
         float4 a[NQ];
         load_feat_a<K>(a, F, row0, m, lane);
@@ -811,7 +828,7 @@ __global__ __launch_bounds__(NWG) void nembed_bwd_kernel(const float* __restrict
     float* red = reinterpret_cast<float*>(lds4);
     constexpr int MAT = D * KP;
     constexpr int NM = TWO ? 2 : 1;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
         if ((threadIdx.x >> 6) == w) {
             red_add_mat<NT, NQ>(red, gwa, lane, w == 0);
             red_add_bias<NT>(red + NM * MAT, dba, lane, w == 0);
@@ -822,13 +839,13 @@ __global__ __launch_bounds__(NWG) void nembed_bwd_kernel(const float* __restrict
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < NM * (MAT + D); i += NWG) partial[(size_t)blockIdx.x * stride + i] = red[i];
+    for (int i = threadIdx.x; i < NM * (MAT + D); i += 64 * NW) partial[(size_t)blockIdx.x * stride + i] = red[i];
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-inline int grid_for(int64_t m, int per_cu) {
+inline int grid_for(int64_t m, int per_cu, int waves = 4) {
     const int64_t tiles = (m + 15) / 16;
-    const int64_t want = (tiles + 3) / 4;                    // one tile per wave
+    const int64_t want = (tiles + waves - 1) / waves;        // one tile per wave
     const int64_t cap = 256 * (int64_t)per_cu;
     return (int)(want < cap ? (want > 0 ? want : 1) : cap);
 }
@@ -838,7 +855,7 @@ inline bool width_ok(int64_t d) { return d == 16 || d == 32 || d == 64; }
 // Workgroups that are co-resident per CU: the backward kernels at d = 64 hold ~350 registers per lane and ~80 KB of
 // weight images, so one 4-wave workgroup fills a CU; a grid beyond that only adds a second, nearly empty round.
 inline int fwd_per_cu(int64_t d) { return d == 64 ? 2 : 4; }
-inline int bwd_per_cu(int64_t d) { return d == 64 ? 1 : (d == 32 ? 2 : 4); }
+
 
 template <typename Kern>
 inline hipError_t allow_lds(Kern k, size_t bytes) {
@@ -858,7 +875,7 @@ inline hipError_t allow_lds(Kern k, size_t bytes) {
 extern "C" int pamnet_narrow_blocks(int64_t rows, int64_t* blocks) {
     if (rows < 0) return PAMNET_EINVAL;
     if (!blocks) return PAMNET_ENULL;
-    *blocks = grid_for(rows, 4);                             // upper bound over all widths
+    *blocks = 256;                                           // backward kernels: at most one workgroup per CU
     return PAMNET_OK;
 }
 
@@ -891,14 +908,14 @@ extern "C" int pamnet_narrow_global_bwd_f32(const float* e, int64_t m, int64_t d
     if (!e || !tgt || !src || !P || !We || !bias || !Wea || !dagg || !dz || !de || !partial || !dWe || !dWea || !db)
         return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for(m, bwd_per_cu(d));
+    const int grid = grid_for(m, 1, bwd_waves((int)d));
     const int stride = (int)(2 * d * d + d);
 #define CALL(DD)                                                                                                     \
     {                                                                                                                \
-        const size_t lds = 4 * (size_t)DD * DD * sizeof(float) + 4 * 16 * (DD + 4) * sizeof(float);                  \
+        const size_t lds = 4 * (size_t)DD * DD * sizeof(float) + bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);      \
         hipError_t e_ = allow_lds(nglobal_bwd_kernel<DD>, lds);                                                      \
         if (e_ != hipSuccess) return (int)e_;                                                                        \
-        hipLaunchKernelGGL((nglobal_bwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, e, m, tgt, src, P, We, (int)ldwe, \
+        hipLaunchKernelGGL((nglobal_bwd_kernel<DD>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, e, m, tgt, src, P, We, (int)ldwe, \
                            bias, Wea, (int)ldwea, dagg, dz, de, partial, stride);                                    \
     }
     NARROW_DISPATCH(d, CALL)
@@ -941,14 +958,14 @@ extern "C" int pamnet_narrow_mlp2_bwd_f32(const float* x, int64_t m, int64_t d, 
     if (m <= 0 || !width_ok(d)) return PAMNET_EINVAL;
     if (!x || !W1 || !b1 || !W2 || !b2 || !dy || !partial || !dW || !db) return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for(m, bwd_per_cu(d));
+    const int grid = grid_for(m, 1, bwd_waves((int)d));
     const int stride = (int)(2 * d * d + 2 * d);
 #define CALL(DD)                                                                                                       \
     {                                                                                                                  \
-        const size_t lds = 4 * (size_t)DD * DD * sizeof(float) + 4 * 16 * (DD + 4) * sizeof(float);                    \
+        const size_t lds = 4 * (size_t)DD * DD * sizeof(float) + bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);        \
         hipError_t e_ = allow_lds(nmlp2_bwd_kernel<DD>, lds);                                                          \
         if (e_ != hipSuccess) return (int)e_;                                                                          \
-        hipLaunchKernelGGL((nmlp2_bwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, x, m, W1, b1, W2, b2, dy, (int)res_x, dx, \
+        hipLaunchKernelGGL((nmlp2_bwd_kernel<DD>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, x, m, W1, b1, W2, b2, dy, (int)res_x, dx, \
                            partial, stride);                                                                           \
     }
     NARROW_DISPATCH(d, CALL)
@@ -988,12 +1005,12 @@ extern "C" int pamnet_narrow_linear_bwd_f32(const float* x, int64_t m, int64_t d
     if (m <= 0 || !width_ok(d) || ldw < d || lddy < d) return PAMNET_EINVAL;
     if (!x || !W || !dy || !partial || !dW) return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for(m, bwd_per_cu(d));
+    const int grid = grid_for(m, 1, bwd_waves((int)d));
     const int stride = (int)(d * d + d);
 #define CALL(DD)                                                                                                        \
     {                                                                                                                   \
-        const size_t lds = 2 * (size_t)DD * DD * sizeof(float) + 4 * 16 * (DD + 4) * sizeof(float);                     \
-        hipLaunchKernelGGL((nlinear_bwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, x, m, W, (int)ldw, b, (int)act, dy, lddy, \
+        const size_t lds = 2 * (size_t)DD * DD * sizeof(float) + bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);         \
+        hipLaunchKernelGGL((nlinear_bwd_kernel<DD>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, x, m, W, (int)ldw, b, (int)act, dy, lddy, \
                            dx, (int)accumulate, partial, stride);                                                       \
     }
     NARROW_DISPATCH(d, CALL)
@@ -1050,33 +1067,33 @@ extern "C" int pamnet_narrow_embed_bwd_f32(const float* F, int64_t m, int64_t k,
     if (!F || !Wa || !ba || !dy || !partial || !dW || !db || (kind && (!Wb || !bb))) return PAMNET_ENULL;
     if (df && (k != 16 || kind)) return PAMNET_EINVAL;
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for(m, bwd_per_cu(d));
+    const int grid = grid_for(m, 1, bwd_waves((int)d));
     const bool two = kind != nullptr;
     const int kp = (k == 16) ? 16 : 48;
     const int sets = two ? 2 : 1;
     const int stride = (int)(sets * (d * kp + d));
 #define CALL(DD)                                                                                                          \
     {                                                                                                                     \
-        const size_t scratch = 4 * 16 * (DD + 4) * sizeof(float);                                                         \
+        const size_t scratch = bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);                                                         \
         if (k == 16 && df) {                                                                                              \
             const size_t lds = 2 * (size_t)DD * 16 * sizeof(float) + scratch;                                             \
-            hipLaunchKernelGGL((nembed_bwd_kernel<DD, 16, false, true>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa, ba, \
+            hipLaunchKernelGGL((nembed_bwd_kernel<DD, 16, false, true>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, F, m, kind, Wa, ba, \
                                Wb, bb, dy, df, partial, stride);                                                          \
         } else if (k == 16 && !two) {                                                                                     \
             const size_t lds = (size_t)DD * 16 * sizeof(float) + scratch;                                                 \
-            hipLaunchKernelGGL((nembed_bwd_kernel<DD, 16, false, false>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa,    \
+            hipLaunchKernelGGL((nembed_bwd_kernel<DD, 16, false, false>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, F, m, kind, Wa,    \
                                ba, Wb, bb, dy, df, partial, stride);                                                      \
         } else if (k == 16) {                                                                                             \
             const size_t lds = 2 * (size_t)DD * 16 * sizeof(float) + scratch;                                             \
-            hipLaunchKernelGGL((nembed_bwd_kernel<DD, 16, true, false>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa, ba, \
+            hipLaunchKernelGGL((nembed_bwd_kernel<DD, 16, true, false>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, F, m, kind, Wa, ba, \
                                Wb, bb, dy, df, partial, stride);                                                          \
         } else if (!two) {                                                                                                \
             const size_t lds = (size_t)DD * 48 * sizeof(float) + scratch;                                                 \
-            hipLaunchKernelGGL((nembed_bwd_kernel<DD, 42, false, false>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa,    \
+            hipLaunchKernelGGL((nembed_bwd_kernel<DD, 42, false, false>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, F, m, kind, Wa,    \
                                ba, Wb, bb, dy, df, partial, stride);                                                      \
         } else {                                                                                                          \
             const size_t lds = 2 * (size_t)DD * 48 * sizeof(float) + scratch;                                             \
-            hipLaunchKernelGGL((nembed_bwd_kernel<DD, 42, true, false>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa, ba, \
+            hipLaunchKernelGGL((nembed_bwd_kernel<DD, 42, true, false>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, F, m, kind, Wa, ba, \
                                Wb, bb, dy, df, partial, stride);                                                          \
         }                                                                                                                 \
     }
