@@ -195,28 +195,32 @@ __device__ __forceinline__ bool pair_less(float da, int ja, float db, int jb) {
     return (da < db) || (da == db && ja < jb);
 }
 
-// one wave per query: lanes 0..K-1 hold the running K best (squared distance, index) in ascending order
-__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pos, const int32_t* __restrict__ node_graph,
-                                                  const int32_t* __restrict__ gptr, int64_t n, int K, float cutoff,
-                                                  int32_t* __restrict__ nbr, float* __restrict__ dist) {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (i >= n) return;
-    const int g = node_graph[i];
-    const int beg = gptr[g], end = gptr[g + 1];
-    const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
-    float bd = INFINITY;
-    int bj = 0x7fffffff;
+// ---- k nearest neighbours (torch_cluster.knn stand-in, models.py:143) ---------------------------------------------------
+// One wave per query, candidates = the nodes of the query's graph (self included, as the reference's knn returns it).
+// Result: the K smallest (squared distance, index) pairs in ascending order.
+//
+// Selection path (graphs up to 64 * KNN_CACHE nodes): every lane caches the squared distances of its candidates in
+// registers, the K-th smallest distance is found by bisection on the float bit pattern (non-negative floats order like
+// unsigned integers; each probe is one compare + ballot count per cached value, no cross-lane traffic), the selected
+// candidates (ties broken by index = scan order) are compacted through LDS and sorted by a 64-lane bitonic network.
+// Streaming path (larger graphs): running sorted top-K across lanes with serial insertion.
+constexpr int KNN_CACHE = 64;
+
+__device__ __forceinline__ float sqdist(const float* __restrict__ pos, float xi, float yi, float zi, int64_t j) {
+    const float dx = xi - pos[3 * j], dy = yi - pos[3 * j + 1], dz = zi - pos[3 * j + 2];
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+__device__ __forceinline__ void knn_stream(const float* __restrict__ pos, float xi, float yi, float zi, int beg, int end,
+                                           int K, int lane, float& bd, int& bj) {
+    bd = INFINITY;
+    bj = 0x7fffffff;
     float kd = INFINITY;            // current K-th best
     int kj = 0x7fffffff;
     for (int base = beg; base < end; base += 64) {
         const int j = base + lane;
         const bool valid = j < end;
-        float d = INFINITY;
-        if (valid) {
-            const float dx = xi - pos[3 * (int64_t)j], dy = yi - pos[3 * (int64_t)j + 1], dz = zi - pos[3 * (int64_t)j + 2];
-            d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        }
+        const float d = valid ? sqdist(pos, xi, yi, zi, j) : INFINITY;
         unsigned long long mask = __ballot(valid && pair_less(d, j, kd, kj));
         while (mask) {
             const int src = __ffsll((long long)mask) - 1;
@@ -234,6 +238,91 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pos,
             kj = __shfl(bj, K - 1, 64);
         }
     }
+}
+
+__device__ __forceinline__ void knn_select(const float* __restrict__ pos, float xi, float yi, float zi, int beg, int end,
+                                           int K, int lane, float* sd, int* sj, float& bd, int& bj) {
+    const int iters = (end - beg + 63) >> 6;
+    unsigned dc[KNN_CACHE];
+#pragma unroll
+    for (int c = 0; c < KNN_CACHE; ++c) {
+        dc[c] = 0xffffffffu;
+        if (c < iters) {
+            const int j = beg + c * 64 + lane;
+            if (j < end) dc[c] = __float_as_uint(sqdist(pos, xi, yi, zi, j));
+        }
+    }
+    const int kk = (end - beg < K) ? (end - beg) : K;       // entries that exist
+    // smallest T with #(d <= T) >= kk
+    unsigned lo = 0u, hi = 0x7f800000u;
+    while (lo < hi) {
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        int cnt = 0;
+#pragma unroll
+        for (int c = 0; c < KNN_CACHE; ++c)
+            if (c < iters) cnt += __popcll(__ballot(dc[c] <= mid));
+        if (cnt >= kk) hi = mid; else lo = mid + 1;
+    }
+    const unsigned T = lo;
+    int less = 0;
+#pragma unroll
+    for (int c = 0; c < KNN_CACHE; ++c)
+        if (c < iters) less += __popcll(__ballot(dc[c] < T));
+    const int need_ties = kk - less;
+    // compact the selected pairs in scan order (ascending index): all d < T, then the first need_ties with d == T
+    sd[lane] = INFINITY;
+    sj[lane] = 0x7fffffff;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int out = 0, ties = 0;
+#pragma unroll
+    for (int c = 0; c < KNN_CACHE; ++c) {
+        if (c < iters) {
+            const unsigned long long tie_m = __ballot(dc[c] == T);
+            const int my_tie = ties + __popcll(tie_m & below);
+            const bool sel = (dc[c] < T) || (dc[c] == T && my_tie < need_ties);
+            const unsigned long long sel_m = __ballot(sel);
+            if (sel) {
+                const int slot = out + __popcll(sel_m & below);
+                sd[slot] = __uint_as_float(dc[c]);
+                sj[slot] = beg + c * 64 + lane;
+            }
+            out += __popcll(sel_m);
+            ties += __popcll(tie_m);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bd = sd[lane];
+    bj = sj[lane];
+    // 64-lane bitonic sort by (distance, index); padding (inf, INT_MAX) sinks to the end
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int s = k >> 1; s > 0; s >>= 1) {
+            const float od = __shfl_xor(bd, s, 64);
+            const int oj = __shfl_xor(bj, s, 64);
+            const bool keep_min = (((lane & k) == 0) == ((lane & s) == 0));
+            const bool take = keep_min ? pair_less(od, oj, bd, bj) : pair_less(bd, bj, od, oj);
+            if (take) { bd = od; bj = oj; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pos, const int32_t* __restrict__ node_graph,
+                                                  const int32_t* __restrict__ gptr, int64_t n, int K, float cutoff,
+                                                  int32_t* __restrict__ nbr, float* __restrict__ dist) {
+    __shared__ float sd[4][64];
+    __shared__ int sj[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= n) return;
+    const int g = node_graph[i];
+    const int beg = gptr[g], end = gptr[g + 1];
+    const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+    float bd;
+    int bj;
+    if (end - beg <= 64 * KNN_CACHE) knn_select(pos, xi, yi, zi, beg, end, K, lane, sd[w], sj[w], bd, bj);
+    else knn_stream(pos, xi, yi, zi, beg, end, K, lane, bd, bj);
     if (lane < K) {
         const float d = __fsqrt_rn(bd);
         const bool keep = (bj != 0x7fffffff) && (bj != (int)i) && (d <= cutoff);

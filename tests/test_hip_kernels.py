@@ -187,6 +187,33 @@ def test_knn_matches_oracle(dev):
     assert _edge_set(q[keep].cpu(), kn[keep].cpu()) == _edge_set(ei2[0][m], ei2[1][m])
 
 
+@pytest.mark.parametrize('n,lattice', [(300, False), (700, True), (4100, False), (5000, True)])
+def test_knn_order_ties_and_large_graphs(dev, n, lattice):
+    """The table rows hold the k smallest (squared distance, index) pairs in ascending order: exact integer check
+    against a torch sort of the same fp32 squared distances.  Lattice points give many exact ties (broken by index);
+    graphs above 4096 nodes take the streaming path, the others the register-cached selection path."""
+    from pamnet_amd import graph as G
+    gen = torch.Generator().manual_seed(n)
+    if lattice:
+        pos = torch.randint(0, 7, (n, 3), generator=gen).float()
+    else:
+        pos = torch.rand(n, 3, generator=gen) * 30
+    K = 50
+    nodeg = torch.zeros(n, dtype=torch.int32, device=dev)
+    gptr = torch.tensor([0, n], dtype=torch.int32, device=dev)
+    kp, kn, kd = G.knn_table(pos.to(dev), nodeg, gptr, K, float('inf'))
+    p = pos.to(dev)
+    dx, dy, dz = (p[:, None, 0] - p[None, :, 0]), (p[:, None, 1] - p[None, :, 1]), (p[:, None, 2] - p[None, :, 2])
+    d2 = (dx * dx + dy * dy) + dz * dz                      # same association as the kernel, no fma: exact products
+    order = torch.sort(d2, dim=1, stable=True).indices[:, :K]       # (d2, index) lexicographic: stable sort
+    want_d = torch.gather(d2, 1, order).sqrt()
+    self_idx = torch.arange(n, device=dev)[:, None]
+    want_n = torch.where(order == self_idx, torch.full_like(order, -1), order).to(torch.int32)
+    assert torch.equal(kn.view(n, K), want_n)
+    # the kernel's sqrt is correctly rounded (__fsqrt_rn); torch's device sqrt may differ in the last bit
+    assert torch.allclose(kd.view(n, K), want_d, rtol=2.5e-7, atol=0)
+
+
 def test_triplets_pairs_angles_match_oracle(dev):
     """Same (k,j,i) triplets / (j,i,j') pairs and the same angles as PAMNet.indices (models.py:68-98)."""
     from oracle import pamnet_oracle as O
