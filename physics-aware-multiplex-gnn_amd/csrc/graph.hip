@@ -240,51 +240,68 @@ __device__ __forceinline__ void knn_stream(const float* __restrict__ pos, float 
     }
 }
 
-__device__ __forceinline__ void knn_select(const float* __restrict__ pos, float xi, float yi, float zi, int beg, int end,
-                                           int K, int lane, float* sd, int* sj, float& bd, int& bj) {
-    const int iters = (end - beg + 63) >> 6;
-    unsigned dc[KNN_CACHE];
+// K smallest (distance bits, index) pairs out of NC values per lane (padding = 0xffffffff), values in scan order
+// (slot-major, lane-minor = ascending candidate index): bisection on the bit pattern for the K-th smallest distance,
+// ties by scan order, compaction into sd/sj[64], then a 64-lane bitonic sort.  G = slots per guarded group
+// (`slots` = number of slots that can hold values).
+template <int NC, int G, bool EXPLICIT_J>
+__device__ __forceinline__ void knn_topk(const unsigned (&dv)[NC], const int (&jv)[EXPLICIT_J ? NC : 1], int j0, int slots,
+                                         int kk, int lane, float* sd, int* sj, float& bd, int& bj) {
+    // Counting stays on the vector unit (per-lane counters, padding never counts); the scalar unit is shared by the
+    // four SIMDs of a CU and a ballot + s_bcnt per value made it the bottleneck of the first version (353 us).
+    auto wave_count = [&](unsigned bound, bool inclusive) -> int {
+        int c_lane = 0;
 #pragma unroll
-    for (int c = 0; c < KNN_CACHE; ++c) {
-        dc[c] = 0xffffffffu;
-        if (c < iters) {
-            const int j = beg + c * 64 + lane;
-            if (j < end) dc[c] = __float_as_uint(sqdist(pos, xi, yi, zi, j));
+        for (int c0 = 0; c0 < NC; c0 += G) {
+            if (c0 < slots) {
+#pragma unroll
+                for (int c = c0; c < c0 + G; ++c) c_lane += (inclusive ? (dv[c] <= bound) : (dv[c] < bound)) ? 1 : 0;
+            }
+        }
+        int tot = 0;                                         // lane counters are <= 64: seven bit planes
+#pragma unroll
+        for (int b = 0; b < 7; ++b)
+            if ((1 << b) <= NC) tot += __popcll(__ballot((c_lane >> b) & 1)) << b;
+        return tot;
+    };
+    unsigned mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (dv[c] != 0xffffffffu) {
+            mn = dv[c] < mn ? dv[c] : mn;
+            mx = dv[c] > mx ? dv[c] : mx;
         }
     }
-    const int kk = (end - beg < K) ? (end - beg) : K;       // entries that exist
-    // smallest T with #(d <= T) >= kk
-    unsigned lo = 0u, hi = 0x7f800000u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned a = (unsigned)__shfl_xor((int)mn, o, 64), b = (unsigned)__shfl_xor((int)mx, o, 64);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    // smallest T with #(d <= T) >= kk, searched inside the wave's [min, max] distance bits
+    unsigned lo = mn, hi = mx;
     while (lo < hi) {
         const unsigned mid = lo + ((hi - lo) >> 1);
-        int cnt = 0;
-#pragma unroll
-        for (int c = 0; c < KNN_CACHE; ++c)
-            if (c < iters) cnt += __popcll(__ballot(dc[c] <= mid));
-        if (cnt >= kk) hi = mid; else lo = mid + 1;
+        if (wave_count(mid, true) >= kk) hi = mid; else lo = mid + 1;
     }
     const unsigned T = lo;
-    int less = 0;
-#pragma unroll
-    for (int c = 0; c < KNN_CACHE; ++c)
-        if (c < iters) less += __popcll(__ballot(dc[c] < T));
-    const int need_ties = kk - less;
-    // compact the selected pairs in scan order (ascending index): all d < T, then the first need_ties with d == T
+    const int need_ties = kk - wave_count(T, false);
+    // compact the selected pairs in scan order: all d < T, then the first need_ties with d == T
     sd[lane] = INFINITY;
     sj[lane] = 0x7fffffff;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int out = 0, ties = 0;
 #pragma unroll
-    for (int c = 0; c < KNN_CACHE; ++c) {
-        if (c < iters) {
-            const unsigned long long tie_m = __ballot(dc[c] == T);
+    for (int c = 0; c < NC; ++c) {
+        if (c < slots) {
+            const unsigned long long tie_m = __ballot(dv[c] == T);
             const int my_tie = ties + __popcll(tie_m & below);
-            const bool sel = (dc[c] < T) || (dc[c] == T && my_tie < need_ties);
+            const bool sel = (dv[c] < T) || (dv[c] == T && my_tie < need_ties);
             const unsigned long long sel_m = __ballot(sel);
             if (sel) {
                 const int slot = out + __popcll(sel_m & below);
-                sd[slot] = __uint_as_float(dc[c]);
-                sj[slot] = beg + c * 64 + lane;
+                sd[slot] = __uint_as_float(dv[c]);
+                sj[slot] = EXPLICIT_J ? jv[EXPLICIT_J ? c : 0] : (j0 + c * 64);
             }
             out += __popcll(sel_m);
             ties += __popcll(tie_m);
@@ -298,14 +315,97 @@ __device__ __forceinline__ void knn_select(const float* __restrict__ pos, float 
 #pragma unroll
     for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
-        for (int s = k >> 1; s > 0; s >>= 1) {
-            const float od = __shfl_xor(bd, s, 64);
-            const int oj = __shfl_xor(bj, s, 64);
-            const bool keep_min = (((lane & k) == 0) == ((lane & s) == 0));
+        for (int st = k >> 1; st > 0; st >>= 1) {
+            const float od = __shfl_xor(bd, st, 64);
+            const int oj = __shfl_xor(bj, st, 64);
+            const bool keep_min = (((lane & k) == 0) == ((lane & st) == 0));
             const bool take = keep_min ? pair_less(od, oj, bd, bj) : pair_less(bd, bj, od, oj);
             if (take) { bd = od; bj = oj; }
         }
     }
+}
+
+// Selection path.  Bisection over all cached candidates costs two vector instructions per candidate and probe, so it
+// only runs until the upper end of the search interval admits at most KNN_SURV candidates (about five probes: the
+// count grows like d^3); those survivors are compacted into LDS, four per lane, and the remaining ~20 probes, the tie
+// handling and the sort work on them alone.  Massive ties (interval closed with more than KNN_SURV survivors) take
+// the same code over the whole cache.
+constexpr int KNN_SURV = 256;
+
+__device__ __forceinline__ void knn_select(const float* __restrict__ pos, float xi, float yi, float zi, int beg, int end,
+                                           int K, int lane, float* sd, int* sj, unsigned* vd, int* vj, float& bd,
+                                           int& bj) {
+    const int iters = (end - beg + 63) >> 6;
+    const int kk = (end - beg < K) ? (end - beg) : K;       // entries that exist
+    unsigned dc[KNN_CACHE];
+    unsigned mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+    for (int c = 0; c < KNN_CACHE; ++c) {
+        dc[c] = 0xffffffffu;
+        if (c < iters) {
+            const int j = beg + c * 64 + lane;
+            if (j < end) {
+                dc[c] = __float_as_uint(sqdist(pos, xi, yi, zi, j));
+                mn = dc[c] < mn ? dc[c] : mn;
+                mx = dc[c] > mx ? dc[c] : mx;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned a = (unsigned)__shfl_xor((int)mn, o, 64), b = (unsigned)__shfl_xor((int)mx, o, 64);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    unsigned lo = mn, hi = mx;
+    int cnt_hi = end - beg;                                 // #(d <= hi), always >= kk
+    while (lo < hi && cnt_hi > KNN_SURV) {
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        int c_lane = 0;
+#pragma unroll
+        for (int c0 = 0; c0 < KNN_CACHE; c0 += 8) {
+            if (c0 < iters) {
+#pragma unroll
+                for (int c = c0; c < c0 + 8; ++c) c_lane += (dc[c] <= mid) ? 1 : 0;
+            }
+        }
+        int tot = 0;
+#pragma unroll
+        for (int b = 0; b < 7; ++b) tot += __popcll(__ballot((c_lane >> b) & 1)) << b;
+        if (tot >= kk) { hi = mid; cnt_hi = tot; } else lo = mid + 1;
+    }
+    if (cnt_hi > KNN_SURV) {                                // wave-uniform; more than KNN_SURV candidates tie at lo
+        const int none[1] = {0};
+        knn_topk<KNN_CACHE, 8, false>(dc, none, beg + lane, iters, kk, lane, sd, sj, bd, bj);
+        return;
+    }
+    // survivors d <= hi, in scan order
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int nsurv = 0;
+#pragma unroll
+    for (int c = 0; c < KNN_CACHE; ++c) {
+        if (c < iters) {
+            const bool sel = dc[c] <= hi;
+            const unsigned long long m = __ballot(sel);
+            if (sel) {
+                const int slot = nsurv + __popcll(m & below);
+                vd[slot] = dc[c];
+                vj[slot] = beg + c * 64 + lane;
+            }
+            nsurv += __popcll(m);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    unsigned sv[KNN_SURV / 64];
+    int svj[KNN_SURV / 64];
+#pragma unroll
+    for (int t = 0; t < KNN_SURV / 64; ++t) {
+        const int slot = t * 64 + lane;
+        sv[t] = slot < nsurv ? vd[slot] : 0xffffffffu;
+        svj[t] = slot < nsurv ? vj[slot] : 0x7fffffff;
+    }
+    knn_topk<KNN_SURV / 64, KNN_SURV / 64, true>(sv, svj, 0, KNN_SURV / 64, kk, lane, sd, sj, bd, bj);
 }
 
 __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pos, const int32_t* __restrict__ node_graph,
@@ -313,6 +413,8 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pos,
                                                   int32_t* __restrict__ nbr, float* __restrict__ dist) {
     __shared__ float sd[4][64];
     __shared__ int sj[4][64];
+    __shared__ unsigned vd[4][KNN_SURV];
+    __shared__ int vj[4][KNN_SURV];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= n) return;
@@ -321,7 +423,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pos,
     const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
     float bd;
     int bj;
-    if (end - beg <= 64 * KNN_CACHE) knn_select(pos, xi, yi, zi, beg, end, K, lane, sd[w], sj[w], bd, bj);
+    if (end - beg <= 64 * KNN_CACHE) knn_select(pos, xi, yi, zi, beg, end, K, lane, sd[w], sj[w], vd[w], vj[w], bd, bj);
     else knn_stream(pos, xi, yi, zi, beg, end, K, lane, bd, bj);
     if (lane < K) {
         const float d = __fsqrt_rn(bd);
