@@ -54,7 +54,8 @@ def _sub(w, c0):
 
 def _grad_buffers(params):
     """(direct, buffers): where the gradients of `params` (a list of Parameters / tensors) are written."""
-    if DIRECT_GRAD and all(getattr(p, 'grad', None) is not None and p.grad.is_contiguous() for p in params):
+    if DIRECT_GRAD and all(getattr(p, '_pamnet_direct', False) and getattr(p, 'grad', None) is not None
+                           and p.grad.is_contiguous() for p in params):
         return True, [p.grad for p in params]
     return False, [torch.empty_like(p) for p in params]
 
@@ -469,15 +470,17 @@ class StackPlan(object):
         return self._gtab, self._ltab
 
     def direct(self):
-        """True when every parameter owns a preallocated contiguous .grad and DIRECT_GRAD is on."""
-        if not DIRECT_GRAD:
+        """True when every parameter owns a preallocated contiguous .grad handed out by train.FlatParams (which zeroes
+        it every step: direct writes overwrite, they do not accumulate) and DIRECT_GRAD is on."""
+        if not DIRECT_GRAD or not getattr(self._probe[0], '_pamnet_direct', False):
             return False
         grads = [p.grad for p in self._probe]
         if any(g is None for g in grads):
             return False
         key = tuple(g.data_ptr() for g in grads)
         if key != self._gkey:
-            if not all(getattr(p, 'grad', None) is not None and p.grad.is_contiguous() for p in self.flat):
+            if not all(getattr(p, '_pamnet_direct', False) and getattr(p, 'grad', None) is not None
+                       and p.grad.is_contiguous() for p in self.flat):
                 return False
             self._ggrad, self._lgrad = _parr([p.grad for p in self.gflat]), _parr([p.grad for p in self.lflat])
             self._gkey = key

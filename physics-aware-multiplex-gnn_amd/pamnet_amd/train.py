@@ -59,14 +59,34 @@ class FlatParams(object):
                 self.layer_ranges[k] = (min(lo, o), max(hi, end))
         self.flat = torch.zeros(off, device=dev, dtype=dt)          # padding stays zero: no effect on norms / Adam
         self.grad = torch.zeros(off, device=dev, dtype=dt)
+        self.grad_views = []
         for p, o in zip(self.params, offs):
             k = p.numel()
             self.flat[o:o + k].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + k].view_as(p)
-            p.grad = self.grad[o:o + k].view_as(p)
+            self.grad_views.append(self.grad[o:o + k].view_as(p))
+            p.grad = self.grad_views[-1]
+            p._pamnet_direct = True        # the fused kernels may write this gradient in place (see fused.DIRECT_GRAD)
 
     def zero_grad(self):
         self.grad.zero_()
+
+    # Per-operator autograd paths (widths other than 128) would add every parameter's gradient into its view with one
+    # small kernel each (~150 launches per step); instead autograd hands the gradient tensors over (p.grad = None
+    # before the backward) and one multi-tensor add packs them into the flat buffer.
+    def release_grads(self):
+        for p in self.params:
+            p.grad = None
+
+    def pack_grads(self):
+        views, grads = [], []
+        for p, v in zip(self.params, self.grad_views):
+            if p.grad is not None:
+                views.append(v)
+                grads.append(p.grad)
+            p.grad = v
+        if views:
+            torch._foreach_add_(views, grads)
 
 
 class WarmupExpLR(object):
@@ -105,6 +125,7 @@ class Trainer(object):
             self._p = self.opt.param_groups[0]['params'][0]
             self._p.grad = self.fp.grad
         self._grad_clean = True                            # fp.grad is all zeros (fresh buffer / zeroed by the update)
+        self._pack = bool(self.fp.flat.is_cuda and getattr(model, 'dim', 128) != 128)   # no direct-gradient engine
         self.ema_decay = ema_decay
         self.shadow = self.fp.flat.clone()                                 # utils/ema.py:9-11
         self.max_grad_norm = max_grad_norm
@@ -122,6 +143,8 @@ class Trainer(object):
         if self._buckets is not None:
             from . import fused
             fused.EVENTS_RECORDED = False
+        if self._pack:
+            self.fp.release_grads()
         out = self.model(data)
         loss = F.l1_loss(out, data.y)
         if self.world_size > 1:
@@ -129,6 +152,8 @@ class Trainer(object):
             (loss * (float(out.numel()) / float(global_graphs))).backward()
         else:
             loss.backward()
+        if self._pack:
+            self.fp.pack_grads()
         return loss
 
     # -- gradient all-reduce -------------------------------------------------------------------------------------------
