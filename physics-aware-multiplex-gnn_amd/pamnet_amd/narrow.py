@@ -178,14 +178,93 @@ def project(x, blocks, *weights):
     return _Project.apply(x, tuple(blocks), None, False, *weights)
 
 
+# ---- the node-update tail as ONE autograd node ------------------------------------------------------------------------
+# Same six kernels per direction as linear() / mlp2() composed by hand, but a single autograd.Function: at these widths
+# a training step is bound by the host (each Function.apply / backward hop costs more than its kernel), and the tail
+# alone is twelve hops per layer.
+def _lin_fwd(x, w, b, act, st):
+    m, d = x.shape
+    y = _empty(m, d, like=x)
+    lib.call('pamnet_narrow_linear_fwd_f32', lib.ptr(x), m, d, lib.ptr(w), d, lib.ptr(b), 1 if act else 0, lib.ptr(y), d, st)
+    return y
+
+
+def _mlp2_fwd(x, w1, b1, w2, b2, res_x, r, st):
+    m, d = x.shape
+    y = _empty(m, d, like=x)
+    lib.call('pamnet_narrow_mlp2_fwd_f32', lib.ptr(x), m, d, lib.ptr(w1), lib.ptr(b1), lib.ptr(w2), lib.ptr(b2),
+             1 if res_x else 0, lib.ptr(r), lib.ptr(y), st)
+    return y
+
+
+def _lin_bwd(x, w, b, act, g, partial, st, need_dx=True):
+    m, d = x.shape
+    dx = _empty(m, d, like=x) if need_dx else None
+    dw, db = _empty(d, d, like=x), _empty(d, like=x)
+    lib.call('pamnet_narrow_linear_bwd_f32', lib.ptr(x), m, d, lib.ptr(w), d, lib.ptr(b), 1 if act else 0, lib.ptr(g), d,
+             lib.ptr(dx), 0, lib.ptr(partial), lib.ptr(dw), lib.ptr(db), st)
+    return dx, dw, db
+
+
+def _mlp2_bwd(x, w1, b1, w2, b2, g, res_x, partial, st):
+    m, d = x.shape
+    dx = _empty(m, d, like=x)
+    dw, db = _empty(2, d, d, like=x), _empty(2, d, like=x)
+    lib.call('pamnet_narrow_mlp2_bwd_f32', lib.ptr(x), m, d, lib.ptr(w1), lib.ptr(b1), lib.ptr(w2), lib.ptr(b2),
+             lib.ptr(g), 1 if res_x else 0, lib.ptr(dx), lib.ptr(partial), lib.ptr(dw), lib.ptr(db), st)
+    return dx, dw[0], db[0], dw[1], db[1]
+
+
+class _Tail(torch.autograd.Function):
+    """(x_out, o) = tail(x, res_x): mlp_x2 -> Res1 (+ res_x) -> Res2 -> Res3 -> mlp_out
+    (layers/global_message_passing.py:40-50, layers/local_message_passing.py:56-66).
+    params: x2 (w, b), res1 / res2 / res3 (w1, b1, w2, b2 each), mlp_out (w1, b1, w2, b2, w3, b3) = 20 tensors."""
+
+    @staticmethod
+    def forward(ctx, x, res_x, *params):
+        x, res_x = _c(x), _c(res_x)
+        pr = [_c(t) for t in params]
+        st = lib.stream_of(x)
+        h0 = _lin_fwd(x, pr[0], pr[1], True, st)
+        r1 = _mlp2_fwd(h0, pr[2], pr[3], pr[4], pr[5], True, res_x, st)
+        r2 = _mlp2_fwd(r1, pr[6], pr[7], pr[8], pr[9], True, None, st)
+        r3 = _mlp2_fwd(r2, pr[10], pr[11], pr[12], pr[13], True, None, st)
+        t = _mlp2_fwd(r3, pr[14], pr[15], pr[16], pr[17], False, None, st)
+        o = _lin_fwd(t, pr[18], pr[19], True, st)
+        ctx.save_for_backward(x, h0, r1, r2, r3, t, *pr)
+        return r3, o
+
+    @staticmethod
+    def backward(ctx, g_x, g_o):
+        x, h0, r1, r2, r3, t = ctx.saved_tensors[:6]
+        pr = ctx.saved_tensors[6:]
+        m, d = x.shape
+        st = lib.stream_of(x)
+        if m == 0:
+            return (torch.zeros_like(x), torch.zeros_like(x)) + tuple(torch.zeros_like(q) for q in pr)
+        partial = _empty(_blocks(m), 2 * d * d + 2 * d, like=x)
+        if g_o is None:
+            g_o = torch.zeros_like(t)
+        dt, dw3, db3 = _lin_bwd(t, pr[18], pr[19], True, _c(g_o), partial, st)
+        g3, ow1, ob1, ow2, ob2 = _mlp2_bwd(r3, pr[14], pr[15], pr[16], pr[17], dt, False, partial, st)
+        if g_x is not None:
+            g3 = g3 + g_x
+        g2, cw1, cb1, cw2, cb2 = _mlp2_bwd(r2, pr[10], pr[11], pr[12], pr[13], g3, True, partial, st)
+        g1, bw1, bb1, bw2, bb2 = _mlp2_bwd(r1, pr[6], pr[7], pr[8], pr[9], g2, True, partial, st)
+        g0, aw1, ab1, aw2, ab2 = _mlp2_bwd(h0, pr[2], pr[3], pr[4], pr[5], g1, True, partial, st)
+        dx, dwx, dbx = _lin_bwd(x, pr[0], pr[1], True, g0, partial, st)
+        return (dx, g1, dwx, dbx, aw1, ab1, aw2, ab2, bw1, bb1, bw2, bb2, cw1, cb1, cw2, cb2,
+                ow1, ob1, ow2, ob2, dw3, db3)
+
+
 def tail(layer, x, res_x):
     """mlp_x2 -> Res1 (+ the layer input) -> Res2 -> Res3 -> mlp_out (global_message_passing.py:40-50)."""
-    x = linear(x, layer.mlp_x2[0][0])
-    x = mlp2(x, layer.res1.mlp, res_x=True, r=res_x)
-    x = mlp2(x, layer.res2.mlp, res_x=True)
-    x = mlp2(x, layer.res3.mlp, res_x=True)
-    o = linear(mlp2(x, layer.mlp_out), layer.mlp_out[2][0])
-    return x, o
+    ps = [layer.mlp_x2[0][0].weight, layer.mlp_x2[0][0].bias]
+    for res in (layer.res1, layer.res2, layer.res3):
+        ps += [res.mlp[0][0].weight, res.mlp[0][0].bias, res.mlp[1][0].weight, res.mlp[1][0].bias]
+    for k in range(3):
+        ps += [layer.mlp_out[k][0].weight, layer.mlp_out[k][0].bias]
+    return _Tail.apply(x, res_x, *ps)
 
 
 class _Embed(torch.autograd.Function):

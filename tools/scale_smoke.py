@@ -5,12 +5,12 @@ import torch, models
 from pamnet_amd import synth
 from pamnet_amd.train import Trainer
 dev=torch.device('cuda:0')
-def run(name, cfg, batch, steps=5):
+def run(name, cfg, batch, steps=20):
     torch.manual_seed(0)
     model=models.PAMNet(cfg).to(dev)
     tr=Trainer(model, lr=1e-4)
     b=batch.to(dev)
-    for _ in range(2): loss=tr.step(b)
+    for _ in range(5): loss=tr.step(b)
     torch.cuda.synchronize(); t0=time.perf_counter()
     for _ in range(steps): loss=tr.step(b)
     torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/steps*1e3
