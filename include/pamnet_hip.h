@@ -338,6 +338,14 @@ int pamnet_narrow_linear_bwd_f32(const float* x, int64_t m, int64_t d, const flo
                                  int32_t act, const float* dy, int64_t lddy, float* dx, int32_t accumulate,
                                  float* partial, float* dW, float* db, pamnet_stream_t stream);
 
+/* Layer heads (layers/global_message_passing.py:47-50): out[n] = o[n] . w_out + b_out, att[n] = o[n] . w_att.
+ * Backward: d_o [m, d] and dvec [2 d + 1] = [d w_out | d w_att | d b_out]; partial: blocks x (2 d + 1) floats. */
+int pamnet_narrow_heads_fwd_f32(const float* o, int64_t m, int64_t d, const float* w_out, const float* b_out,
+                                const float* w_att, float* out, float* att, pamnet_stream_t stream);
+int pamnet_narrow_heads_bwd_f32(const float* o, int64_t m, int64_t d, const float* w_out, const float* w_att,
+                                const float* g_out, const float* g_att, float* d_o, float* partial, float* dvec,
+                                pamnet_stream_t stream);
+
 /* Edge-embedding MLPs (models.py:185-188): y = SiLU(W f + b), f [m, k], k = 16 or 42, W [d, k] dense.  With `kind`
  * [m] rows of kind 0 use (Wa, ba) and rows of kind != 0 use (Wb, bb); kind null: one set. */
 int pamnet_narrow_embed_fwd_f32(const float* F, int64_t m, int64_t k, int64_t d, const int32_t* kind, const float* Wa,

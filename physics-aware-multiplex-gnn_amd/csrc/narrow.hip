@@ -647,6 +647,76 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nlinear_bwd_kernel(const fl
 }
 
 // ====================================================================================================================
+// Layer heads (layers/global_message_passing.py:47-50): out[n] = o[n] . w_out + b_out, att[n] = o[n] . w_att
+// D/4 lanes per row (one float4 each); backward: d o = g_out w_out + g_att w_att and the three parameter gradients
+// reduced lane -> workgroup (LDS, fixed order) -> grid (narrow_reduce_kernel).
+// ====================================================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void nheads_fwd_kernel(const float* __restrict__ o, int64_t m,
+                                                         const float* __restrict__ w_out, const float* __restrict__ b_out,
+                                                         const float* __restrict__ w_att, float* __restrict__ out,
+                                                         float* __restrict__ att) {
+    constexpr int LPR = D / 4, RPB = 256 / LPR;
+    const int sub = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+    const float4 wo = *reinterpret_cast<const float4*>(w_out + 4 * sub);
+    const float4 wa = *reinterpret_cast<const float4*>(w_att + 4 * sub);
+    const float bo = b_out[0];
+    for (int64_t row = (int64_t)blockIdx.x * RPB + rl; row < m; row += (int64_t)gridDim.x * RPB) {   // uniform per lane group
+        const float4 v = *reinterpret_cast<const float4*>(o + row * D + 4 * sub);
+        float so = (v.x * wo.x + v.y * wo.y) + (v.z * wo.z + v.w * wo.w);
+        float sa = (v.x * wa.x + v.y * wa.y) + (v.z * wa.z + v.w * wa.w);
+#pragma unroll
+        for (int s = LPR / 2; s >= 1; s >>= 1) {
+            so += __shfl_xor(so, s, 64);
+            sa += __shfl_xor(sa, s, 64);
+        }
+        if (sub == 0) {
+            out[row] = so + bo;
+            att[row] = sa;
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void nheads_bwd_kernel(const float* __restrict__ o, int64_t m,
+                                                         const float* __restrict__ w_out, const float* __restrict__ w_att,
+                                                         const float* __restrict__ g_out, const float* __restrict__ g_att,
+                                                         float* __restrict__ d_o, float* __restrict__ partial) {
+    constexpr int LPR = D / 4, RPB = 256 / LPR;
+    __shared__ float red[256][9];
+    const int sub = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+    const float4 wo = *reinterpret_cast<const float4*>(w_out + 4 * sub);
+    const float4 wa = *reinterpret_cast<const float4*>(w_att + 4 * sub);
+    float4 so = make_float4(0.f, 0.f, 0.f, 0.f), sa = so;
+    float sb = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * RPB + rl; row < m; row += (int64_t)gridDim.x * RPB) {
+        const float4 v = *reinterpret_cast<const float4*>(o + row * D + 4 * sub);
+        const float go = g_out[row], ga = g_att[row];
+        *reinterpret_cast<float4*>(d_o + row * D + 4 * sub) =
+            make_float4(go * wo.x + ga * wa.x, go * wo.y + ga * wa.y, go * wo.z + ga * wa.z, go * wo.w + ga * wa.w);
+        so.x += go * v.x; so.y += go * v.y; so.z += go * v.z; so.w += go * v.w;
+        sa.x += ga * v.x; sa.y += ga * v.y; sa.z += ga * v.z; sa.w += ga * v.w;
+        sb += go;
+    }
+    float* mine = red[threadIdx.x];
+    mine[0] = so.x; mine[1] = so.y; mine[2] = so.z; mine[3] = so.w;
+    mine[4] = sa.x; mine[5] = sa.y; mine[6] = sa.z; mine[7] = sa.w;
+    mine[8] = sb;
+    __syncthreads();
+    // partial row: [dw_out (D)][dw_att (D)][db_out]
+    for (int p = threadIdx.x; p < 2 * D + 1; p += 256) {
+        float s = 0.f;
+        if (p < 2 * D) {
+            const int which = p / D, c = p % D, su = c / 4, comp = which * 4 + (c & 3);
+            for (int r = 0; r < RPB; ++r) s += red[r * LPR + su][comp];
+        } else {
+            for (int r = 0; r < RPB; ++r) s += red[r * LPR][8];
+        }
+        partial[(size_t)blockIdx.x * (2 * D + 1) + p] = s;
+    }
+}
+
+// ====================================================================================================================
 // Edge-embedding MLPs (models.py:185-188): y = SiLU(W f + b), f [rows, K] with K = 16 (Bessel) or 42 (spherical);
 // with `kind` the row picks (Wa, ba) for kind 0 (triplet rows, mlp_sbf2) or (Wb, bb) for kind 1 (pair rows, mlp_sbf1).
 // ====================================================================================================================
@@ -1019,6 +1089,43 @@ extern "C" int pamnet_narrow_linear_bwd_f32(const float* x, int64_t m, int64_t d
     const int total = (int)(d * d + (db ? d : 0));
     hipLaunchKernelGGL(narrow_reduce_kernel, dim3((total + 63) / 64), dim3(64, 8), 0, st, partial, grid, stride, 1, (int)d,
                        (int)d, (int)d, db ? (int)d : 0, dW, db);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_narrow_heads_fwd_f32(const float* o, int64_t m, int64_t d, const float* w_out, const float* b_out,
+                                           const float* w_att, float* out, float* att, pamnet_stream_t stream) {
+    if (m < 0 || !width_ok(d)) return PAMNET_EINVAL;
+    if (m == 0) return PAMNET_OK;
+    if (!o || !w_out || !b_out || !w_att || !out || !att) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const int rpb = 256 / (int)(d / 4);
+    const int64_t want = (m + rpb - 1) / rpb;
+    const int grid = (int)(want < 1024 ? want : 1024);
+#define CALL(DD) hipLaunchKernelGGL((nheads_fwd_kernel<DD>), dim3(grid), dim3(256), 0, st, o, m, w_out, b_out, w_att, out, att);
+    NARROW_DISPATCH(d, CALL)
+#undef CALL
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+/* dvec [2 d + 1] = [d w_out | d w_att | d b_out]; partial: pamnet_narrow_blocks x (2 d + 1) floats */
+extern "C" int pamnet_narrow_heads_bwd_f32(const float* o, int64_t m, int64_t d, const float* w_out, const float* w_att,
+                                           const float* g_out, const float* g_att, float* d_o, float* partial,
+                                           float* dvec, pamnet_stream_t stream) {
+    if (m <= 0 || !width_ok(d)) return PAMNET_EINVAL;
+    if (!o || !w_out || !w_att || !g_out || !g_att || !d_o || !partial || !dvec) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const int rpb = 256 / (int)(d / 4);
+    const int64_t want = (m + rpb - 1) / rpb;
+    const int grid = (int)(want < 256 ? want : 256);
+#define CALL(DD) hipLaunchKernelGGL((nheads_bwd_kernel<DD>), dim3(grid), dim3(256), 0, st, o, m, w_out, w_att, g_out, g_att, d_o, partial);
+    NARROW_DISPATCH(d, CALL)
+#undef CALL
+    PAMNET_LAUNCH_CHECK();
+    const int total = (int)(2 * d + 1);
+    hipLaunchKernelGGL(narrow_reduce_kernel, dim3((total + 63) / 64), dim3(64, 8), 0, st, partial, grid, total, 0, (int)d,
+                       (int)d, (int)d, total, (float*)nullptr, dvec);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

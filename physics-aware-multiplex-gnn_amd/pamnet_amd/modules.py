@@ -93,13 +93,12 @@ def update_and_heads(layer, x, res_x):
     if _fused(x):
         return fused.node_tail(layer, x, res_x)
     if _narrow(x):
-        x, o = narrow.tail(layer, x, res_x)
-    else:
-        x = mlp_apply(layer.mlp_x2, x)
-        x = res_apply(layer.res1, x) + res_x
-        x = res_apply(layer.res2, x)
-        x = res_apply(layer.res3, x)
-        o = mlp_apply(layer.mlp_out, x)
+        return narrow.tail(layer, x, res_x)                   # one autograd node: chain + both heads
+    x = mlp_apply(layer.mlp_x2, x)
+    x = res_apply(layer.res1, x) + res_x
+    x = res_apply(layer.res2, x)
+    x = res_apply(layer.res3, x)
+    o = mlp_apply(layer.mlp_out, x)
     att = (o @ layer.W).view(-1)
     out = F.linear(o, layer.W_out.weight, layer.W_out.bias).view(-1)
     return x, out, att

@@ -216,9 +216,10 @@ def _mlp2_bwd(x, w1, b1, w2, b2, g, res_x, partial, st):
 
 
 class _Tail(torch.autograd.Function):
-    """(x_out, o) = tail(x, res_x): mlp_x2 -> Res1 (+ res_x) -> Res2 -> Res3 -> mlp_out
+    """(x_out, out, att) = tail(x, res_x): mlp_x2 -> Res1 (+ res_x) -> Res2 -> Res3 -> mlp_out -> the two heads
     (layers/global_message_passing.py:40-50, layers/local_message_passing.py:56-66).
-    params: x2 (w, b), res1 / res2 / res3 (w1, b1, w2, b2 each), mlp_out (w1, b1, w2, b2, w3, b3) = 20 tensors."""
+    params: x2 (w, b), res1 / res2 / res3 (w1, b1, w2, b2 each), mlp_out (w1, b1, w2, b2, w3, b3),
+    W_out.weight [1, d], W_out.bias [1], W [d, 1] = 23 tensors."""
 
     @staticmethod
     def forward(ctx, x, res_x, *params):
@@ -231,21 +232,28 @@ class _Tail(torch.autograd.Function):
         r3 = _mlp2_fwd(r2, pr[10], pr[11], pr[12], pr[13], True, None, st)
         t = _mlp2_fwd(r3, pr[14], pr[15], pr[16], pr[17], False, None, st)
         o = _lin_fwd(t, pr[18], pr[19], True, st)
-        ctx.save_for_backward(x, h0, r1, r2, r3, t, *pr)
-        return r3, o
+        m, d = x.shape
+        out, att = _empty(m, like=x), _empty(m, like=x)
+        lib.call('pamnet_narrow_heads_fwd_f32', lib.ptr(o), m, d, lib.ptr(pr[20]), lib.ptr(pr[21]), lib.ptr(pr[22]),
+                 lib.ptr(out), lib.ptr(att), st)
+        ctx.save_for_backward(x, h0, r1, r2, r3, t, o, *pr)
+        return r3, out, att
 
     @staticmethod
-    def backward(ctx, g_x, g_o):
-        x, h0, r1, r2, r3, t = ctx.saved_tensors[:6]
-        pr = ctx.saved_tensors[6:]
+    def backward(ctx, g_x, g_out, g_att):
+        x, h0, r1, r2, r3, t, o = ctx.saved_tensors[:7]
+        pr = ctx.saved_tensors[7:]
         m, d = x.shape
         st = lib.stream_of(x)
         if m == 0:
             return (torch.zeros_like(x), torch.zeros_like(x)) + tuple(torch.zeros_like(q) for q in pr)
         partial = _empty(_blocks(m), 2 * d * d + 2 * d, like=x)
-        if g_o is None:
-            g_o = torch.zeros_like(t)
-        dt, dw3, db3 = _lin_bwd(t, pr[18], pr[19], True, _c(g_o), partial, st)
+        g_out = _c(g_out) if g_out is not None else torch.zeros(m, dtype=x.dtype, device=x.device)
+        g_att = _c(g_att) if g_att is not None else torch.zeros(m, dtype=x.dtype, device=x.device)
+        g_o, dvec = _empty(m, d, like=x), _empty(2 * d + 1, like=x)
+        lib.call('pamnet_narrow_heads_bwd_f32', lib.ptr(o), m, d, lib.ptr(pr[20]), lib.ptr(pr[22]), lib.ptr(g_out),
+                 lib.ptr(g_att), lib.ptr(g_o), lib.ptr(partial), lib.ptr(dvec), st)
+        dt, dw3, db3 = _lin_bwd(t, pr[18], pr[19], True, g_o, partial, st)
         g3, ow1, ob1, ow2, ob2 = _mlp2_bwd(r3, pr[14], pr[15], pr[16], pr[17], dt, False, partial, st)
         if g_x is not None:
             g3 = g3 + g_x
@@ -254,7 +262,7 @@ class _Tail(torch.autograd.Function):
         g0, aw1, ab1, aw2, ab2 = _mlp2_bwd(h0, pr[2], pr[3], pr[4], pr[5], g1, True, partial, st)
         dx, dwx, dbx = _lin_bwd(x, pr[0], pr[1], True, g0, partial, st)
         return (dx, g1, dwx, dbx, aw1, ab1, aw2, ab2, bw1, bb1, bw2, bb2, cw1, cb1, cw2, cb2,
-                ow1, ob1, ow2, ob2, dw3, db3)
+                ow1, ob1, ow2, ob2, dw3, db3, dvec[:d].view(1, d), dvec[2 * d:], dvec[d:2 * d].view(d, 1))
 
 
 def tail(layer, x, res_x):
@@ -264,6 +272,7 @@ def tail(layer, x, res_x):
         ps += [res.mlp[0][0].weight, res.mlp[0][0].bias, res.mlp[1][0].weight, res.mlp[1][0].bias]
     for k in range(3):
         ps += [layer.mlp_out[k][0].weight, layer.mlp_out[k][0].bias]
+    ps += [layer.W_out.weight, layer.W_out.bias, layer.W]
     return _Tail.apply(x, res_x, *ps)
 
 

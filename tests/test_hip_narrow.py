@@ -167,6 +167,44 @@ def test_embed(dev, d, k, two, m):
     _check_grads(ps, rs, names)
 
 
+@pytest.mark.parametrize('d', [16, 32, 64])
+@pytest.mark.parametrize('n', [5, 1000, 2287])
+def test_node_tail_and_heads(dev, d, n):
+    """The whole node-update tail (10 dense layers, three residual blocks, both heads) as one autograd node against
+    the fp64 composition of the reference formulas (layers/global_message_passing.py:39-50)."""
+    import copy
+    from pamnet_amd import modules, narrow
+    torch.manual_seed(d + n)
+    layer = modules.GlobalMP(d).to(dev)
+    ref = copy.deepcopy(layer).double()
+    x = (torch.randn(n, d, device=dev) * 0.7).requires_grad_(True)
+    res = (torch.randn(n, d, device=dev) * 0.7).requires_grad_(True)
+    xo, out, att = narrow.tail(layer, x, res)
+    gx, go, ga = torch.randn_like(xo), torch.randn_like(out), torch.randn_like(att)
+    torch.autograd.backward([xo, out, att], [gx, go, ga])
+    rx, rres = x.detach().double().requires_grad_(True), res.detach().double().requires_grad_(True)
+    h = modules.mlp_apply(ref.mlp_x2, rx)
+    h = modules.res_apply(ref.res1, h) + rres
+    h = modules.res_apply(ref.res2, h)
+    h = modules.res_apply(ref.res3, h)
+    o = modules.mlp_apply(ref.mlp_out, h)
+    r_att = (o @ ref.W).view(-1)
+    r_out = F.linear(o, ref.W_out.weight, ref.W_out.bias).view(-1)
+    torch.autograd.backward([h, r_out, r_att], [gx.double(), go.double(), ga.double()])
+    for a, b, nm in ((xo, h, 'x'), (out, r_out, 'out'), (att, r_att, 'att')):
+        assert maxnorm_err(a.detach().cpu(), b.detach().cpu()) < TOL, nm
+    assert maxnorm_err(x.grad.cpu(), rx.grad.cpu()) < TOL
+    assert maxnorm_err(res.grad.cpu(), rres.grad.cpu()) < TOL
+    rp = dict(ref.named_parameters())
+    used = 0
+    for nm, p in layer.named_parameters():
+        if p.grad is None:
+            continue                                       # message-side parameters are not part of the tail
+        used += 1
+        assert maxnorm_err(p.grad.cpu(), rp[nm].grad.cpu()) < TOL, nm
+    assert used == 23
+
+
 @pytest.mark.parametrize('dim,n_layer', [(16, 1), (64, 2)])
 def test_rna_model_matches_generic_path(dev, dim, n_layer):
     """Whole model at the reference's RNA widths: narrow kernels vs the generic path (torch dense layers + HIP
