@@ -84,15 +84,20 @@ __device__ __forceinline__ void zero(f32x4 (&acc)[N]) {
     for (int i = 0; i < N; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+// Row loads never sit under a branch: out-of-range rows read row m - 1 (a valid address, m > 0) and are zeroed by a
+// select afterwards.  (`ok ? *p : 0` made the compiler wrap every element load in its own exec-masked block with a
+// vmcnt(0) wait and whole-fragment register copies: 3x slower kernels.)
 // rows as A fragments (row stride D floats, 16-byte aligned); rows >= m read as zero
 template <int D>
 __device__ __forceinline__ void load_a(float4 (&a)[D / 16], const float* __restrict__ X, int64_t row0, int64_t m, int lane) {
     const int64_t row = row0 + (lane & 15);
     const bool ok = row < m;
-    const float* p = X + (ok ? row : 0) * D + 4 * (lane >> 4);
+    const float* p = X + (ok ? row : m - 1) * D + 4 * (lane >> 4);
 #pragma unroll
-    for (int q = 0; q < D / 16; ++q)
-        a[q] = ok ? *reinterpret_cast<const float4*>(p + 16 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < D / 16; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(p + 16 * q);
+        a[q] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
 }
 
 // rows in accumulator ("D") layout: v[jt][r] = X[row0 + 4kg + r][16jt + c]; rows >= m read as zero
@@ -100,13 +105,19 @@ template <int D>
 __device__ __forceinline__ void load_d(f32x4 (&v)[D / 16], const float* __restrict__ X, int64_t row0, int64_t m, int lane,
                                        int64_t ld = D) {
     const int c = lane & 15, kg = lane >> 4;
+    float t[4][D / 16];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t row = row0 + 4 * kg + r;
-        const bool ok = row < m;
-        const float* p = X + (ok ? row : 0) * ld + c;
+        const float* p = X + (row < m ? row : m - 1) * ld + c;
 #pragma unroll
-        for (int jt = 0; jt < D / 16; ++jt) v[jt][r] = ok ? p[16 * jt] : 0.f;
+        for (int jt = 0; jt < D / 16; ++jt) t[r][jt] = p[16 * jt];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool ok = row0 + 4 * kg + r < m;
+#pragma unroll
+        for (int jt = 0; jt < D / 16; ++jt) v[jt][r] = ok ? t[r][jt] : 0.f;
     }
 }
 
@@ -254,6 +265,25 @@ __global__ __launch_bounds__(NWG) void nglobal_fwd_kernel(const float* __restric
         const int64_t row0 = tile * 16;
         float4 a[NT];
         load_a<D>(a, e, row0, m, lane);
+        // all index and projection loads of the tile are issued before the GEMMs (their latency hides behind the MFMAs)
+        int ti[4], sj[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 4 * kg + r;
+            ti[r] = tgt[row < m ? row : m - 1];
+            sj[r] = src[row < m ? row : m - 1];
+        }
+        float pv[4][NT], qv[4][NT];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* pi = P + (size_t)ti[r] * (2 * D) + c;
+            const float* pj = P + (size_t)sj[r] * (2 * D) + D + c;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                pv[r][jt] = pi[16 * jt];
+                qv[r][jt] = pj[16 * jt];
+            }
+        }
         f32x4 q1[NT], q2[NT];
         zero(q1);
         zero(q2);
@@ -263,12 +293,10 @@ __global__ __launch_bounds__(NWG) void nglobal_fwd_kernel(const float* __restric
         for (int r = 0; r < 4; ++r) {
             const int64_t row = row0 + 4 * kg + r;
             if (row < m) {
-                const float* pi = P + (size_t)tgt[row] * (2 * D) + c;
-                const float* pj = P + (size_t)src[row] * (2 * D) + D + c;
                 float* out = msg + row * D + c;
 #pragma unroll
                 for (int jt = 0; jt < NT; ++jt) {
-                    const float z = q1[jt][r] + bj[jt] + pi[16 * jt] + pj[16 * jt];
+                    const float z = q1[jt][r] + bj[jt] + pv[r][jt] + qv[r][jt];
                     out[16 * jt] = z * sigmoidf_fast(z) * q2[jt][r];
                 }
             }
@@ -316,6 +344,27 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nglobal_bwd_kernel(const fl
         const int64_t row0 = tile_id * 16;
         float4 a[NT];
         load_a<D>(a, e, row0, m, lane);
+        // all gathers of the tile are issued before the GEMMs
+        int ti[4], sj[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 4 * kg + r;
+            ti[r] = tgt[row < m ? row : m - 1];
+            sj[r] = src[row < m ? row : m - 1];
+        }
+        float pv[4][NT], qv[4][NT], gv[4][NT];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* pi = P + (size_t)ti[r] * (2 * D) + c;
+            const float* pj = P + (size_t)sj[r] * (2 * D) + D + c;
+            const float* dg = dagg + (size_t)ti[r] * D + c;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                pv[r][jt] = pi[16 * jt];
+                qv[r][jt] = pj[16 * jt];
+                gv[r][jt] = dg[16 * jt];
+            }
+        }
         f32x4 q1[NT], q2[NT], ed[NT];
         zero(q1);
         zero(q2);
@@ -325,17 +374,12 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nglobal_bwd_kernel(const fl
         // q1 -> dz, q2 -> dq2 (in place)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t row = row0 + 4 * kg + r;
-            const bool ok = row < m;
-            const int ti = ok ? tgt[row] : 0, sj = ok ? src[row] : 0;
-            const float* pi = P + (size_t)ti * (2 * D) + c;
-            const float* pj = P + (size_t)sj * (2 * D) + D + c;
-            const float* dg = dagg + (size_t)ti * D + c;
+            const bool ok = row0 + 4 * kg + r < m;
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
-                const float z = q1[jt][r] + bj[jt] + pi[16 * jt] + pj[16 * jt];
+                const float z = q1[jt][r] + bj[jt] + pv[r][jt] + qv[r][jt];
                 const float s = sigmoidf_fast(z);
-                const float dm = ok ? dg[16 * jt] : 0.f;
+                const float dm = ok ? gv[r][jt] : 0.f;
                 const float gate = q2[jt][r];
                 q1[jt][r] = dm * gate * (s * (1.0f + z * (1.0f - s)));
                 q2[jt][r] = dm * (z * s);
@@ -599,14 +643,27 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nlinear_bwd_kernel(const fl
         dbs[jt] = 0.f;
         zero(gw[jt]);
     }
-    for (int64_t t = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * NW) {
+    // the next tile's rows are requested before this tile's GEMMs: at d = 64 a wave holds ~350 registers, one wave per
+    // SIMD, so nothing else hides the HBM latency of its loads
+    const int64_t tstep = (int64_t)gridDim.x * NW;
+    int64_t t = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+    float4 a[NT], a_n[NT];
+    f32x4 g[NT], xd[NT], g_n[NT], xd_n[NT];
+    if (t < ntiles) {
+        load_d<D>(g, dy, t * 16, m, lane, lddy);
+        if (act) load_a<D>(a, x, t * 16, m, lane);
+        load_d<D>(xd, x, t * 16, m, lane);
+    }
+    for (; t < ntiles; t += tstep) {
         const int64_t row0 = t * 16;
-        float4 a[NT];
-        f32x4 g[NT], xd[NT];
-        load_d<D>(g, dy, row0, m, lane, lddy);
+        const bool more = t + tstep < ntiles;
+        if (more) {
+            load_d<D>(g_n, dy, (t + tstep) * 16, m, lane, lddy);
+            if (act) load_a<D>(a_n, x, (t + tstep) * 16, m, lane);
+            load_d<D>(xd_n, x, (t + tstep) * 16, m, lane);
+        }
         if (act) {
             f32x4 z[NT];
-            load_a<D>(a, x, row0, m, lane);
             zero(z);
             mma_img<NT, NT>(z, a, img, lane);
 #pragma unroll
@@ -618,7 +675,6 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nlinear_bwd_kernel(const fl
                     g[jt][r] *= s * (1.0f + zz * (1.0f - s));
                 }
         }
-        load_d<D>(xd, x, row0, m, lane);
         wgrad_acc<NT, NT>(gw, g, xd);
         colsum_acc<NT>(dbs, g);
         if (dx) {
@@ -631,6 +687,14 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nlinear_bwd_kernel(const fl
                 for (int jt = 0; jt < NT; ++jt) g[jt] += xd[jt];
             }
             store_d<D>(g, dx, row0, m, lane);
+        }
+        if (more) {
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                g[jt] = g_n[jt];
+                xd[jt] = xd_n[jt];
+                a[jt] = a_n[jt];
+            }
         }
     }
     __syncthreads();
@@ -725,14 +789,15 @@ __device__ __forceinline__ void load_feat_a(float4 (&a)[(K + 15) / 16], const fl
                                             int64_t m, int lane) {
     const int64_t row = row0 + (lane & 15);
     const bool ok = row < m;
-    const float* p = F + (ok ? row : 0) * K + 4 * (lane >> 4);
+    const float* p = F + (ok ? row : m - 1) * K;
 #pragma unroll
     for (int q = 0; q < (K + 15) / 16; ++q) {
         const int k = 16 * q + 4 * (lane >> 4);
-        float2 lo = make_float2(0.f, 0.f), hi = make_float2(0.f, 0.f);
-        if (ok && k + 1 < K) lo = *reinterpret_cast<const float2*>(p + 16 * q);
-        if (ok && k + 3 < K) hi = *reinterpret_cast<const float2*>(p + 16 * q + 2);
-        a[q] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        // columns beyond K: read the row's last pair instead (valid address), zeroed by the selects
+        const float2 lo = *reinterpret_cast<const float2*>(p + (k + 1 < K ? k : K - 2));
+        const float2 hi = *reinterpret_cast<const float2*>(p + (k + 3 < K ? k + 2 : K - 2));
+        const bool okl = ok && k + 1 < K, okh = ok && k + 3 < K;
+        a[q] = make_float4(okl ? lo.x : 0.f, okl ? lo.y : 0.f, okh ? hi.x : 0.f, okh ? hi.y : 0.f);
     }
 }
 
@@ -740,13 +805,19 @@ template <int K>
 __device__ __forceinline__ void load_feat_d(f32x4 (&v)[(K + 15) / 16], const float* __restrict__ F, int64_t row0,
                                             int64_t m, int lane) {
     const int c = lane & 15, kg = lane >> 4;
+    float t[4][(K + 15) / 16];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t row = row0 + 4 * kg + r;
-        const bool ok = row < m;
-        const float* p = F + (ok ? row : 0) * K + c;
+        const float* p = F + (row < m ? row : m - 1) * K;
 #pragma unroll
-        for (int jk = 0; jk < (K + 15) / 16; ++jk) v[jk][r] = (ok && 16 * jk + c < K) ? p[16 * jk] : 0.f;
+        for (int jk = 0; jk < (K + 15) / 16; ++jk) t[r][jk] = p[16 * jk + c < K ? 16 * jk + c : K - 1];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool ok = row0 + 4 * kg + r < m;
+#pragma unroll
+        for (int jk = 0; jk < (K + 15) / 16; ++jk) v[jk][r] = (ok && 16 * jk + c < K) ? t[r][jk] : 0.f;
     }
 }
 
@@ -780,7 +851,7 @@ __global__ __launch_bounds__(NWG) void nembed_fwd_kernel(const float* __restrict
             mma_img<NT, NQ>(acc, a, lds4, lane);
         } else {
             const int64_t row = row0 + c;
-            const bool second = (row < m) && kind[row] != 0;
+            const bool second = kind[row < m ? row : m - 1] != 0;
             float4 a0[NQ], a1[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -793,7 +864,7 @@ __global__ __launch_bounds__(NWG) void nembed_fwd_kernel(const float* __restrict
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t row = row0 + 4 * kg + r;
-            const bool second = TWO && (row < m) && kind[row] != 0;
+            const bool second = TWO && kind[row < m ? row : m - 1] != 0;
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
                 const float z = acc[jt][r] + (second ? bjb[jt] : bja[jt]);
@@ -847,7 +918,7 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const flo
             mma_img<NT, NQ>(acc, a, lds4, lane);
         } else {
             const int64_t row = row0 + c;
-            const bool second = (row < m) && kind[row] != 0;
+            const bool second = kind[row < m ? row : m - 1] != 0;
             float4 a0[NQ], a1[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -862,7 +933,7 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const flo
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t row = row0 + 4 * kg + r;
-            const bool second = TWO && (row < m) && kind[row] != 0;
+            const bool second = TWO && kind[row < m ? row : m - 1] != 0;
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
                 const float z = acc[jt][r] + (second ? bjb[jt] : bja[jt]);
