@@ -28,6 +28,9 @@ constexpr int NWG = 256;                      // forward kernels: 4 independent 
 // Backward kernels end with one partial gradient row per workgroup, so they run at most one workgroup per CU and get
 // their occupancy from more waves per workgroup where the register budget allows (d = 64 needs ~350 registers a lane).
 __host__ __device__ constexpr int bwd_waves(int d) { return d == 16 ? 16 : (d == 32 ? 8 : 4); }
+// (two waves per SIMD for the single-layer backward at d = 64 fit in 256 registers but measured slower on node-sized
+// inputs: 25.7 vs 23.3 us at 17.7 k rows, 230 vs 239 us at 669 k)
+__host__ __device__ constexpr int lin_bwd_waves(int d) { return bwd_waves(d); }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -63,18 +66,22 @@ __device__ __forceinline__ void build_image(float4* img, const float* __restrict
     }
 }
 
+// consecutive MFMAs go to different accumulators (a dependent 16x16x4 pair issues 40 cycles apart, independent ones 32)
 template <int NJ, int NQ>
 __device__ __forceinline__ void mma_img(f32x4 (&acc)[NJ], const float4 (&a)[NQ], const float4* img, int lane) {
 #pragma unroll
-    for (int jt = 0; jt < NJ; ++jt) {
+    for (int q = 0; q < NQ; ++q) {
+        float4 b[NJ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const float4 b = img[(jt * NQ + q) * 64 + lane];
-            acc[jt] = mfma4(a[q].x, b.x, acc[jt]);
-            acc[jt] = mfma4(a[q].y, b.y, acc[jt]);
-            acc[jt] = mfma4(a[q].z, b.z, acc[jt]);
-            acc[jt] = mfma4(a[q].w, b.w, acc[jt]);
-        }
+        for (int jt = 0; jt < NJ; ++jt) b[jt] = img[(jt * NQ + q) * 64 + lane];
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) acc[jt] = mfma4(a[q].x, b[jt].x, acc[jt]);
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) acc[jt] = mfma4(a[q].y, b[jt].y, acc[jt]);
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) acc[jt] = mfma4(a[q].z, b[jt].z, acc[jt]);
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) acc[jt] = mfma4(a[q].w, b[jt].w, acc[jt]);
     }
 }
 
@@ -155,14 +162,11 @@ __device__ __forceinline__ void d_to_a(float4 (&a)[D / 16], const f32x4 (&v)[D /
 template <int NJ, int NK>
 __device__ __forceinline__ void wgrad_acc(f32x4 (&w)[NJ][NK], const f32x4 (&dz)[NJ], const f32x4 (&x)[NK]) {
 #pragma unroll
-    for (int jo = 0; jo < NJ; ++jo)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int jk = 0; jk < NK; ++jk) {
-            w[jo][jk] = mfma4(dz[jo][0], x[jk][0], w[jo][jk]);
-            w[jo][jk] = mfma4(dz[jo][1], x[jk][1], w[jo][jk]);
-            w[jo][jk] = mfma4(dz[jo][2], x[jk][2], w[jo][jk]);
-            w[jo][jk] = mfma4(dz[jo][3], x[jk][3], w[jo][jk]);
-        }
+        for (int jo = 0; jo < NJ; ++jo)
+#pragma unroll
+            for (int jk = 0; jk < NK; ++jk) w[jo][jk] = mfma4(dz[jo][r], x[jk][r], w[jo][jk]);
 }
 
 // column sums of an accumulator-layout tile over the wave's rows: result valid on every lane for column 16jt + c
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(NWG) void nlinear_fwd_kernel(const float* __restric
 
 // dx (+)= dz W;  partial = [dW fragments (D x D)][db (D)]
 template <int D>
-__global__ __launch_bounds__(64 * bwd_waves(D)) void nlinear_bwd_kernel(const float* __restrict__ x, int64_t m,
+__global__ __launch_bounds__(64 * lin_bwd_waves(D)) void nlinear_bwd_kernel(const float* __restrict__ x, int64_t m,
                                                           const float* __restrict__ W, int ldw,
                                                           const float* __restrict__ b, int act,
                                                           const float* __restrict__ dy, int64_t lddy,
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nlinear_bwd_kernel(const fl
                                                           float* __restrict__ partial, int stride) {
     constexpr int NT = D / 16;
     constexpr int IMG = NT * NT * 64;
-    constexpr int NW = bwd_waves(D);
+    constexpr int NW = lin_bwd_waves(D);
     extern __shared__ float4 lds4[];
     float4* img = lds4;
     float4* imgt = lds4 + IMG;
@@ -1146,12 +1150,12 @@ extern "C" int pamnet_narrow_linear_bwd_f32(const float* x, int64_t m, int64_t d
     if (m <= 0 || !width_ok(d) || ldw < d || lddy < d) return PAMNET_EINVAL;
     if (!x || !W || !dy || !partial || !dW) return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for(m, 1, bwd_waves((int)d));
+    const int grid = grid_for(m, 1, lin_bwd_waves((int)d));
     const int stride = (int)(d * d + d);
 #define CALL(DD)                                                                                                        \
     {                                                                                                                   \
-        const size_t lds = 2 * (size_t)DD * DD * sizeof(float) + bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);         \
-        hipLaunchKernelGGL((nlinear_bwd_kernel<DD>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, x, m, W, (int)ldw, b, (int)act, dy, lddy, \
+        const size_t lds = 2 * (size_t)DD * DD * sizeof(float) + lin_bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);         \
+        hipLaunchKernelGGL((nlinear_bwd_kernel<DD>), dim3(grid), dim3(64 * lin_bwd_waves(DD)), lds, st, x, m, W, (int)ldw, b, (int)act, dy, lddy, \
                            dx, (int)accumulate, partial, stride);                                                       \
     }
     NARROW_DISPATCH(d, CALL)
