@@ -295,14 +295,46 @@ class Trainer(object):
         """Sum |out - y| over batches / #graphs under EMA weights, all-reduced across ranks."""
         self.ema_assign()
         tot = torch.zeros(2, device=self.fp.flat.device, dtype=torch.float64)
-        for data in batches:
-            out = self.model(data)
+        for data, out in predict(self.model, batches):
             tot[0] += (out - data.y).abs().sum().double()
             tot[1] += out.numel()
         self.ema_resume()
         if self.world_size > 1:
             dist.all_reduce(tot, group=self.pg)
         return float(tot[0] / tot[1])
+
+
+@torch.no_grad()
+def predict(model, batches):
+    """Forward-only loop (test() of main_qm9.py:29-37, inference_rna_puzzles.py:60-67) with the input pipeline of
+    Trainer.step: while batch i runs, the graph of batch i+1 is built on a side stream (forward-only variant: no
+    transposed index lists).  Yields (data, output)."""
+    it = iter(batches)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    dev = next(model.parameters()).device
+    pipelined = dev.type == 'cuda' and hasattr(model, 'prepare')
+    side = torch.cuda.Stream(device=dev) if pipelined else None
+    while cur is not None:
+        nxt = next(it, None)
+        ev = getattr(cur, '_pamnet_ready', None)
+        if ev is not None:
+            torch.cuda.current_stream(dev).wait_event(ev)
+            cur._pamnet_ready = None
+        out = model(cur)
+        if pipelined and nxt is not None:
+            main = torch.cuda.current_stream(dev)
+            with torch.cuda.stream(side):
+                model.prepare(nxt, need_grad=False)
+                e = torch.cuda.Event()
+                e.record(side)
+            nxt._pamnet_ready = e
+            for v in _graph_tensors(nxt._pamnet_prepared):
+                v.record_stream(main)
+        yield cur, out
+        cur = nxt
 
 
 def _graph_tensors(g):
