@@ -158,6 +158,23 @@ __device__ __forceinline__ void d_to_a(float4 (&a)[D / 16], const f32x4 (&v)[D /
     for (int q = 0; q < D / 16; ++q) a[q] = *reinterpret_cast<const float4*>(tile + c * LD + 16 * q + 4 * kg);
 }
 
+// A fragments -> accumulator layout through the wave's private LDS tile (the reverse of d_to_a): lets a row tile that
+// was fetched with four coalesced 16-byte loads per lane also serve as the weight-gradient operand, instead of
+// sixteen more 4-byte loads per lane
+template <int D>
+__device__ __forceinline__ void a_to_d(f32x4 (&v)[D / 16], const float4 (&a)[D / 16], float* tile, int lane) {
+    constexpr int LD = D + 4;
+    const int c = lane & 15, kg = lane >> 4;
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < D / 16; ++q) *reinterpret_cast<float4*>(tile + c * LD + 16 * q + 4 * kg) = a[q];
+    wave_lds_sync();
+#pragma unroll
+    for (int jt = 0; jt < D / 16; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[jt][r] = tile[(4 * kg + r) * LD + 16 * jt + c];
+}
+
 // dW[o][k] += sum_rows dz[row][o] * x[row][k], both operands in accumulator layout (rows are the MFMA k index)
 template <int NJ, int NK>
 __device__ __forceinline__ void wgrad_acc(f32x4 (&w)[NJ][NK], const f32x4 (&dz)[NJ], const f32x4 (&x)[NK]) {
@@ -651,21 +668,23 @@ __global__ __launch_bounds__(64 * lin_bwd_waves(D)) void nlinear_bwd_kernel(cons
     // SIMD, so nothing else hides the HBM latency of its loads
     const int64_t tstep = (int64_t)gridDim.x * NW;
     int64_t t = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
-    float4 a[NT], a_n[NT];
-    f32x4 g[NT], xd[NT], g_n[NT], xd_n[NT];
+    float4 a[NT], ga[NT], a_n[NT], ga_n[NT];                // x and dy row tiles as A fragments (coalesced 16-byte loads)
+    f32x4 g[NT], xd[NT];
+    const bool dense_dy = lddy == D;
     if (t < ntiles) {
-        load_d<D>(g, dy, t * 16, m, lane, lddy);
-        if (act) load_a<D>(a, x, t * 16, m, lane);
-        load_d<D>(xd, x, t * 16, m, lane);
+        load_a<D>(a, x, t * 16, m, lane);
+        if (dense_dy) load_a<D>(ga, dy, t * 16, m, lane);
     }
     for (; t < ntiles; t += tstep) {
         const int64_t row0 = t * 16;
         const bool more = t + tstep < ntiles;
         if (more) {
-            load_d<D>(g_n, dy, (t + tstep) * 16, m, lane, lddy);
-            if (act) load_a<D>(a_n, x, (t + tstep) * 16, m, lane);
-            load_d<D>(xd_n, x, (t + tstep) * 16, m, lane);
+            load_a<D>(a_n, x, (t + tstep) * 16, m, lane);
+            if (dense_dy) load_a<D>(ga_n, dy, (t + tstep) * 16, m, lane);
         }
+        if (dense_dy) a_to_d<D>(g, ga, tile, lane);
+        else load_d<D>(g, dy, row0, m, lane, lddy);          // a column block of a wider gradient
+        a_to_d<D>(xd, a, tile, lane);
         if (act) {
             f32x4 z[NT];
             zero(z);
@@ -695,9 +714,8 @@ __global__ __launch_bounds__(64 * lin_bwd_waves(D)) void nlinear_bwd_kernel(cons
         if (more) {
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
-                g[jt] = g_n[jt];
-                xd[jt] = xd_n[jt];
                 a[jt] = a_n[jt];
+                ga[jt] = ga_n[jt];
             }
         }
     }
