@@ -223,33 +223,38 @@ def test_baseline_config_properties(dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', ['pdbbind_d128_l3', 'qm9s_d128_l2', 'qm9_d128_l6_b16', 'qm9_ragged_d128_l2',
-                                  'qm9s_ragged_d128_l2', 'qm9_no_edges_d128_l2', 'qm9_d128_l1'])
+                                  'qm9s_ragged_d128_l2', 'qm9_no_edges_d128_l2', 'qm9_d128_l1',
+                                  'pdbbind_d64_l3', 'qm9s_d64_l2', 'qm9_d16_l6_b16', 'qm9_ragged_d64_l2',
+                                  'qm9s_ragged_d16_l2', 'qm9_no_edges_d16_l2', 'qm9_d64_l1'])
 def test_fused_engine_fresh_inputs_vs_oracle(dev, case):
-    """dim=128 (fused MFMA engine) on fresh seeded inputs vs the CPU oracle: forward (fp32+fp64 oracle) and the fp64
-    loss gradient, for the PDBbind branch (init_linear, +-1 pooling signs, local = global edges <= cutoff_l),
-    PAMNet_s (pairs only) and the headline QM9 configuration."""
+    """dim=128 (fused MFMA engine) and dim=16/64 (narrow-width row kernels) on fresh seeded inputs vs the CPU oracle:
+    forward (fp32+fp64 oracle) and the fp64 loss gradient, for the PDBbind branch (init_linear, +-1 pooling signs,
+    local = global edges <= cutoff_l), PAMNet_s (pairs only), the headline QM9 configuration, degenerate molecules and
+    a batch without any edge."""
+    import re
     import models
+    dim = int(re.search(r'_d(\d+)_', case).group(1))
     from oracle import pamnet_oracle as O
     from pamnet_amd import synth
     small = case.startswith('qm9s')
     if 'ragged' in case or 'no_edges' in case:
         # degenerate molecules: single atoms, a single bond, atoms out of range; and a batch without any edge at all
-        cfg = models.Config(dataset='QM9', dim=128, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+        cfg = models.Config(dataset='QM9', dim=dim, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
         b = synth.ragged_qm9_batch()
         if 'no_edges' in case:
             b = synth.collate([dict(x=np.array([k % 5], np.float32), pos=np.array([[20.0 * k, 0, 0]], np.float32),
                                     edge_index=np.zeros((2, 0), np.int64), y=np.float32(k)) for k in range(3)])
-    elif case == 'qm9_d128_l1':                  # single layer pair: no fused next-layer head, no layer-to-layer hand-over
-        cfg = models.Config(dataset='QM9', dim=128, n_layer=1, cutoff_l=5.0, cutoff_g=5.0)
+    elif case.endswith('_l1'):                  # single layer pair: no fused next-layer head, no layer-to-layer hand-over
+        cfg = models.Config(dataset='QM9', dim=dim, n_layer=1, cutoff_l=5.0, cutoff_g=5.0)
         b = synth.qm9_batch(19, 0, 5)
     elif case.startswith('pdbbind'):
-        cfg = models.Config(dataset='PDBbind', dim=128, n_layer=3, cutoff_l=2.0, cutoff_g=6.0)
+        cfg = models.Config(dataset='PDBbind', dim=dim, n_layer=3, cutoff_l=2.0, cutoff_g=6.0)
         b = synth.pdbbind_batch(9, 0, 2, n_pocket=90, n_ligand=16)
     elif small:
-        cfg = models.Config(dataset='QM9', dim=128, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+        cfg = models.Config(dataset='QM9', dim=dim, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
         b = synth.qm9_batch(13, 0, 12)
     else:
-        cfg = models.Config(dataset='QM9', dim=128, n_layer=6, cutoff_l=5.0, cutoff_g=5.0)
+        cfg = models.Config(dataset='QM9', dim=dim, n_layer=6, cutoff_l=5.0, cutoff_g=5.0)
         b = synth.qm9_batch(17, 0, 16)
     sd = O.init_state_dict(cfg, seed=31, small=small)
     model = (models.PAMNet_s if small else models.PAMNet)(cfg)
@@ -279,12 +284,19 @@ def test_fused_engine_fresh_inputs_vs_oracle(dev, case):
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
     gn64 = float(torch.sqrt(sum((p.grad ** 2).sum() for p in p64.values() if p.grad is not None)))
     assert abs(gn / gn64 - 1) < 2e-4, (gn, gn64)
-    worst = 0.0
+    worst, worst_scalar = 0.0, 0.0
     for k, p in model.named_parameters():
         if p64[k].grad is None:
             continue
-        worst = max(worst, maxnorm_err(p.grad.cpu().numpy(), p64[k].grad.numpy()))
+        e = maxnorm_err(p.grad.cpu().numpy(), p64[k].grad.numpy())
+        if p.numel() == 1:
+            # W_out.bias: d loss / d b = sum over nodes of signed pooling weights (PDBbind: complex - pocket - ligand)
+            # -> cancellation; the fp32 oracle itself is 3.6e-4 off here and torch's own fp32 backward 1.4e-3
+            worst_scalar = max(worst_scalar, e)
+        else:
+            worst = max(worst, e)
     assert worst < 5e-4, worst            # fp32 backward through 2L layers vs fp64 autograd of the reference maths
+    assert worst_scalar < 5e-3, worst_scalar
 
 
 @pytest.mark.gpu
