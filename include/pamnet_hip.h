@@ -346,6 +346,18 @@ int pamnet_narrow_heads_bwd_f32(const float* o, int64_t m, int64_t d, const floa
                                 const float* g_out, const float* g_att, float* d_o, float* partial, float* dvec,
                                 pamnet_stream_t stream);
 
+/* Local-edge gates (layers/local_message_passing.py:46-48 with the split message weights): for local edge q = (src -> tgt)
+ *   m_ji[q] = SiLU(P[tgt, 0:d] + P[src, 2d:3d] + Q[q, 0:d] + b_ji)
+ *   m_nb[q] = SiLU(P[tgt, d:2d] + P[src, 3d:4d] + Q[q, d:2d] + b_kj) * Q[q, 2d:3d]
+ * P [N, 4d], Q [m, 4d].  Backward: dz [m, 2d] (segment-summed by the caller into dP, column-summed into the biases)
+ * and dQ [m, 4d] (last block zero). */
+int pamnet_narrow_local_gate_fwd_f32(const float* P, const float* Q, const int32_t* tgt, const int32_t* src,
+                                     const float* b_ji, const float* b_kj, int64_t m, int64_t d, float* m_ji,
+                                     float* m_nb, pamnet_stream_t stream);
+int pamnet_narrow_local_gate_bwd_f32(const float* P, const float* Q, const int32_t* tgt, const int32_t* src,
+                                     const float* b_ji, const float* b_kj, int64_t m, int64_t d, const float* g_ji,
+                                     const float* g_nb, float* dz, float* dQ, pamnet_stream_t stream);
+
 /* Edge-embedding MLPs (models.py:185-188): y = SiLU(W f + b), f [m, k], k = 16 or 42, W [d, k] dense.  With `kind`
  * [m] rows of kind 0 use (Wa, ba) and rows of kind != 0 use (Wb, bb); kind null: one set. */
 int pamnet_narrow_embed_fwd_f32(const float* F, int64_t m, int64_t k, int64_t d, const int32_t* kind, const float* Wa,

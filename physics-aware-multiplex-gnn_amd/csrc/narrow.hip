@@ -803,6 +803,79 @@ __global__ __launch_bounds__(256) void nheads_bwd_kernel(const float* __restrict
 }
 
 // ====================================================================================================================
+// Local-edge gates (layers/local_message_passing.py:46-48 after the W[x_i | x_j | rbf] split): per local edge q = (j -> i)
+//   z1 = P[i, 0:D] + P[j, 2D:3D] + Q[q, 0:D] + b_ji          m_ji = SiLU(z1)
+//   z2 = P[i, D:2D] + P[j, 3D:4D] + Q[q, D:2D] + b_kj         m_nb = SiLU(z2) * Q[q, 2D:3D]      (mlp_m_kj * lin_rbf)
+// P [N, 4D] node-side projections, Q [E, 4D] edge-side projections (column block 3 = lin_rbf_out is used later).
+// Elementwise: D/4 lanes per edge, float4 each.  Backward writes dz [E, 2D] (the caller segment-sums it into dP and
+// column-sums it into the biases) and dQ[:, 0:3D] (block 3 zeroed).
+// ====================================================================================================================
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float silu1(float z) { return z * sigmoidf_fast(z); }
+__device__ __forceinline__ float dsilu1(float z) { const float s = sigmoidf_fast(z); return s * (1.0f + z * (1.0f - s)); }
+
+template <int D>
+__global__ __launch_bounds__(256) void nlocal_gate_fwd_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                              const int32_t* __restrict__ tgt, const int32_t* __restrict__ src,
+                                                              const float* __restrict__ bji, const float* __restrict__ bkj,
+                                                              int64_t m, float* __restrict__ m_ji, float* __restrict__ m_nb) {
+    constexpr int LPR = D / 4;
+    const int64_t total = m * LPR;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t q = t / LPR;
+        const int c = (int)(t % LPR) * 4;
+        const float* pi = P + (size_t)tgt[q] * (4 * D) + c;
+        const float* pj = P + (size_t)src[q] * (4 * D) + 2 * D + c;
+        const float* qq = Q + q * (4 * D) + c;
+        const float4 a1 = ld4(pi), a2 = ld4(pi + D), c1 = ld4(pj), c2 = ld4(pj + D);
+        const float4 q1 = ld4(qq), q2 = ld4(qq + D), q3 = ld4(qq + 2 * D), b1 = ld4(bji + c), b2 = ld4(bkj + c);
+        st4(m_ji + q * D + c, make_float4(silu1(a1.x + c1.x + q1.x + b1.x), silu1(a1.y + c1.y + q1.y + b1.y),
+                                          silu1(a1.z + c1.z + q1.z + b1.z), silu1(a1.w + c1.w + q1.w + b1.w)));
+        st4(m_nb + q * D + c, make_float4(silu1(a2.x + c2.x + q2.x + b2.x) * q3.x, silu1(a2.y + c2.y + q2.y + b2.y) * q3.y,
+                                          silu1(a2.z + c2.z + q2.z + b2.z) * q3.z, silu1(a2.w + c2.w + q2.w + b2.w) * q3.w));
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void nlocal_gate_bwd_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                              const int32_t* __restrict__ tgt, const int32_t* __restrict__ src,
+                                                              const float* __restrict__ bji, const float* __restrict__ bkj,
+                                                              int64_t m, const float* __restrict__ g_ji,
+                                                              const float* __restrict__ g_nb, float* __restrict__ dz,
+                                                              float* __restrict__ dQ) {
+    constexpr int LPR = D / 4;
+    const int64_t total = m * LPR;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t q = t / LPR;
+        const int c = (int)(t % LPR) * 4;
+        const float* pi = P + (size_t)tgt[q] * (4 * D) + c;
+        const float* pj = P + (size_t)src[q] * (4 * D) + 2 * D + c;
+        const float* qq = Q + q * (4 * D) + c;
+        const float4 a1 = ld4(pi), a2 = ld4(pi + D), c1 = ld4(pj), c2 = ld4(pj + D);
+        const float4 q1 = ld4(qq), q2 = ld4(qq + D), q3 = ld4(qq + 2 * D), b1 = ld4(bji + c), b2 = ld4(bkj + c);
+        const float4 gj = ld4(g_ji + q * D + c), gn = ld4(g_nb + q * D + c);
+        const float z1[4] = {a1.x + c1.x + q1.x + b1.x, a1.y + c1.y + q1.y + b1.y, a1.z + c1.z + q1.z + b1.z, a1.w + c1.w + q1.w + b1.w};
+        const float z2[4] = {a2.x + c2.x + q2.x + b2.x, a2.y + c2.y + q2.y + b2.y, a2.z + c2.z + q2.z + b2.z, a2.w + c2.w + q2.w + b2.w};
+        const float gjv[4] = {gj.x, gj.y, gj.z, gj.w}, gnv[4] = {gn.x, gn.y, gn.z, gn.w}, q3v[4] = {q3.x, q3.y, q3.z, q3.w};
+        float d1[4], d2[4], d3[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            d1[u] = gjv[u] * dsilu1(z1[u]);
+            d2[u] = gnv[u] * q3v[u] * dsilu1(z2[u]);
+            d3[u] = gnv[u] * silu1(z2[u]);
+        }
+        st4(dz + q * (2 * D) + c, make_float4(d1[0], d1[1], d1[2], d1[3]));
+        st4(dz + q * (2 * D) + D + c, make_float4(d2[0], d2[1], d2[2], d2[3]));
+        float* dq = dQ + q * (4 * D) + c;
+        st4(dq, make_float4(d1[0], d1[1], d1[2], d1[3]));
+        st4(dq + D, make_float4(d2[0], d2[1], d2[2], d2[3]));
+        st4(dq + 2 * D, make_float4(d3[0], d3[1], d3[2], d3[3]));
+        st4(dq + 3 * D, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+}
+
+// ====================================================================================================================
 // Edge-embedding MLPs (models.py:185-188): y = SiLU(W f + b), f [rows, K] with K = 16 (Bessel) or 42 (spherical);
 // with `kind` the row picks (Wa, ba) for kind 0 (triplet rows, mlp_sbf2) or (Wb, bb) for kind 1 (pair rows, mlp_sbf1).
 // ====================================================================================================================
@@ -1219,6 +1292,39 @@ extern "C" int pamnet_narrow_heads_bwd_f32(const float* o, int64_t m, int64_t d,
     const int total = (int)(2 * d + 1);
     hipLaunchKernelGGL(narrow_reduce_kernel, dim3((total + 63) / 64), dim3(64, 8), 0, st, partial, grid, total, 0, (int)d,
                        (int)d, (int)d, total, (float*)nullptr, dvec);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_narrow_local_gate_fwd_f32(const float* P, const float* Q, const int32_t* tgt, const int32_t* src,
+                                                const float* b_ji, const float* b_kj, int64_t m, int64_t d, float* m_ji,
+                                                float* m_nb, pamnet_stream_t stream) {
+    if (m < 0 || !width_ok(d)) return PAMNET_EINVAL;
+    if (m == 0) return PAMNET_OK;
+    if (!P || !Q || !tgt || !src || !b_ji || !b_kj || !m_ji || !m_nb) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const int64_t want = (m * (d / 4) + 255) / 256;
+    const int grid = (int)(want < 4096 ? want : 4096);
+#define CALL(DD) hipLaunchKernelGGL((nlocal_gate_fwd_kernel<DD>), dim3(grid), dim3(256), 0, st, P, Q, tgt, src, b_ji, b_kj, m, m_ji, m_nb);
+    NARROW_DISPATCH(d, CALL)
+#undef CALL
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_narrow_local_gate_bwd_f32(const float* P, const float* Q, const int32_t* tgt, const int32_t* src,
+                                                const float* b_ji, const float* b_kj, int64_t m, int64_t d,
+                                                const float* g_ji, const float* g_nb, float* dz, float* dQ,
+                                                pamnet_stream_t stream) {
+    if (m < 0 || !width_ok(d)) return PAMNET_EINVAL;
+    if (m == 0) return PAMNET_OK;
+    if (!P || !Q || !tgt || !src || !b_ji || !b_kj || !g_ji || !g_nb || !dz || !dQ) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const int64_t want = (m * (d / 4) + 255) / 256;
+    const int grid = (int)(want < 4096 ? want : 4096);
+#define CALL(DD) hipLaunchKernelGGL((nlocal_gate_bwd_kernel<DD>), dim3(grid), dim3(256), 0, st, P, Q, tgt, src, b_ji, b_kj, m, g_ji, g_nb, dz, dQ);
+    NARROW_DISPATCH(d, CALL)
+#undef CALL
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

@@ -195,19 +195,20 @@ class LocalMP(_LayerBase):
         if _narrow(x):
             q = narrow.project(rbf, ((0, 2 * d), (1, 2 * d), (2, 0), (3, 0)), wj, wk, self.lin_rbf.weight,
                                self.lin_rbf_out.weight)
-            zb = torch.cat([lin_ji.bias, lin_kj.bias])       # the projection blocks carry no bias: added to z below
+            zb = True                                         # the projection blocks carry no bias: added with the gates
         else:
             zero, zb = torch.zeros_like(lin_ji.bias), None
             q = F.linear(rbf, torch.cat([wj[:, 2 * d:], wk[:, 2 * d:], self.lin_rbf.weight, self.lin_rbf_out.weight], 0),
                          torch.cat([lin_ji.bias, lin_kj.bias, zero, zero]))
         csr = g.loc
-        z = ops.gather(p[:, :2 * d], csr.row_of, csr.ptr) + ops.gather(p[:, 2 * d:], csr.col, g.loc_T.ptr, g.loc_T.perm) \
-            + q[:, :2 * d]
-        if zb is not None:
-            z = z + zb
-        a = F.silu(z)
-        m_ji = a[:, :d]
-        m_nb = a[:, d:] * q[:, 2 * d:3 * d]                                       # mlp_m_kj(m) * lin_rbf(rbf)
+        if zb is not None:                                    # narrow widths: gathers + gates in one kernel
+            m_ji, m_nb = narrow.local_gate(p, q, lin_ji.bias, lin_kj.bias, csr, g.loc_T)
+        else:
+            z = ops.gather(p[:, :2 * d], csr.row_of, csr.ptr) + ops.gather(p[:, 2 * d:], csr.col, g.loc_T.ptr, g.loc_T.perm) \
+                + q[:, :2 * d]
+            a = F.silu(z)
+            m_ji = a[:, :d]
+            m_nb = a[:, d:] * q[:, 2 * d:3 * d]                                   # mlp_m_kj(m) * lin_rbf(rbf)
         s = narrow.mlp2(sbf, self.mlp_sbf) if _narrow(sbf) else mlp_apply(self.mlp_sbf, sbf)   # [T+P, d]
         m_other = ops.gather_mul_aggregate(m_nb, s, g.tp, g.tp_T)                 # -> [E_l, d]
         m = q[:, 3 * d:] * (m_ji + m_other)

@@ -83,6 +83,45 @@ def global_message(x1, P, e, wm, bm, wea, csr, tr):
     return _GlobalMessage.apply(x1, P, e, wm, bm, wea, csr, tr)
 
 
+class _LocalGate(torch.autograd.Function):
+    """m_ji, m_nb of the local layer (layers/local_message_passing.py:46-48) from the node-side projections P [N, 4d] and
+    the edge-side projections Q [E_l, 4d]: m_ji = SiLU(z_ji), m_nb = SiLU(z_kj) * lin_rbf(rbf)."""
+
+    @staticmethod
+    def forward(ctx, P, Q, b_ji, b_kj, csr, tr):
+        P, Q, b_ji, b_kj = _c(P), _c(Q), _c(b_ji), _c(b_kj)
+        m, d = csr.m, b_ji.numel()
+        m_ji, m_nb = _empty(m, d, like=Q), _empty(m, d, like=Q)
+        lib.call('pamnet_narrow_local_gate_fwd_f32', lib.ptr(P), lib.ptr(Q), lib.ptr(csr.row_of), lib.ptr(csr.col),
+                 lib.ptr(b_ji), lib.ptr(b_kj), m, d, lib.ptr(m_ji), lib.ptr(m_nb), lib.stream_of(Q))
+        ctx.save_for_backward(P, Q, b_ji, b_kj)
+        ctx.csr, ctx.tr = csr, tr
+        return m_ji, m_nb
+
+    @staticmethod
+    def backward(ctx, g_ji, g_nb):
+        P, Q, b_ji, b_kj = ctx.saved_tensors
+        csr, tr = ctx.csr, ctx.tr
+        m, d, n = csr.m, b_ji.numel(), P.size(0)
+        if m == 0:
+            return torch.zeros_like(P), torch.zeros_like(Q), torch.zeros_like(b_ji), torch.zeros_like(b_kj), None, None
+        g_ji = _c(g_ji) if g_ji is not None else torch.zeros(m, d, dtype=Q.dtype, device=Q.device)
+        g_nb = _c(g_nb) if g_nb is not None else torch.zeros(m, d, dtype=Q.dtype, device=Q.device)
+        dz, dQ = _empty(m, 2 * d, like=Q), _empty(m, 4 * d, like=Q)
+        lib.call('pamnet_narrow_local_gate_bwd_f32', lib.ptr(P), lib.ptr(Q), lib.ptr(csr.row_of), lib.ptr(csr.col),
+                 lib.ptr(b_ji), lib.ptr(b_kj), m, d, lib.ptr(g_ji), lib.ptr(g_nb), lib.ptr(dz), lib.ptr(dQ),
+                 lib.stream_of(Q))
+        dpi, dpj = _empty(n, 2 * d, like=Q), _empty(n, 2 * d, like=Q)
+        ops.segment_sum_raw(dpi, None, dz, None, None, None, None, csr.ptr, n, 2 * d)          # edges with tgt = i
+        ops.segment_sum_raw(dpj, None, dz, None, None, None, tr.perm, tr.ptr, n, 2 * d)        # edges with src = j
+        db = dz.sum(0)
+        return torch.cat([dpi, dpj], 1), dQ, db[:d], db[d:], None, None
+
+
+def local_gate(P, Q, b_ji, b_kj, csr, tr):
+    return _LocalGate.apply(P, Q, b_ji, b_kj, csr, tr)
+
+
 class _Mlp2(torch.autograd.Function):
     """SiLU(W2 SiLU(W1 x + b1) + b2) [+ x] [+ r] on rows: mlp_sbf (layers/local_message_passing.py:24,49), the Res blocks
     (layers/basic.py:25-33) and the first two layers of mlp_out."""

@@ -168,6 +168,32 @@ def test_embed(dev, d, k, two, m):
 
 
 @pytest.mark.parametrize('d', [16, 32, 64])
+@pytest.mark.parametrize('n,max_deg', [(4, 2), (500, 7)])
+def test_local_gate(dev, d, n, max_deg):
+    """m_ji / m_nb of the local layer from node- and edge-side projections (layers/local_message_passing.py:46-48)."""
+    from pamnet_amd import narrow
+    rng = np.random.default_rng(d + n)
+    csr, tr = _graph(rng, n, max_deg, dev)
+    m = csr.m
+    torch.manual_seed(d * n)
+    mk = lambda *s: (torch.randn(*s, device=dev) * 0.6).requires_grad_(True)
+    P, Q, b1, b2 = mk(n, 4 * d), mk(m, 4 * d), mk(d), mk(d)
+    m_ji, m_nb = narrow.local_gate(P, Q, b1, b2, csr, tr)
+    g1, g2 = torch.randn_like(m_ji), torch.randn_like(m_nb)
+    torch.autograd.backward([m_ji, m_nb], [g1, g2])
+    ref_in = [t.detach().double().requires_grad_(True) for t in (P, Q, b1, b2)]
+    rP, rQ, rb1, rb2 = ref_in
+    i, j = csr.row_of.long(), csr.col.long()
+    z1 = rP[i, :d] + rP[j, 2 * d:3 * d] + rQ[:, :d] + rb1
+    z2 = rP[i, d:2 * d] + rP[j, 3 * d:] + rQ[:, d:2 * d] + rb2
+    r_ji, r_nb = F.silu(z1), F.silu(z2) * rQ[:, 2 * d:3 * d]
+    torch.autograd.backward([r_ji, r_nb], [g1.double(), g2.double()])
+    assert maxnorm_err(m_ji.detach().cpu(), r_ji.detach().cpu()) < TOL
+    assert maxnorm_err(m_nb.detach().cpu(), r_nb.detach().cpu()) < TOL
+    _check_grads((P, Q, b1, b2), ref_in, ('P', 'Q', 'b_ji', 'b_kj'))
+
+
+@pytest.mark.parametrize('d', [16, 32, 64])
 @pytest.mark.parametrize('n', [5, 1000, 2287])
 def test_node_tail_and_heads(dev, d, n):
     """The whole node-update tail (10 dense layers, three residual blocks, both heads) as one autograd node against
