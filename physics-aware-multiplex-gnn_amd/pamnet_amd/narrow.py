@@ -80,7 +80,7 @@ class _GlobalMessage(torch.autograd.Function):
 
 
 def global_message(x1, P, e, wm, bm, wea, csr, tr):
-    return _GlobalMessage.apply(x1, P, e, wm, bm, wea, csr, tr)
+    return ops.apply(_GlobalMessage, x1, P, e, wm, bm, wea, csr, tr)
 
 
 class _LocalGate(torch.autograd.Function):
@@ -119,7 +119,7 @@ class _LocalGate(torch.autograd.Function):
 
 
 def local_gate(P, Q, b_ji, b_kj, csr, tr):
-    return _LocalGate.apply(P, Q, b_ji, b_kj, csr, tr)
+    return ops.apply(_LocalGate, P, Q, b_ji, b_kj, csr, tr)
 
 
 class _Mlp2(torch.autograd.Function):
@@ -159,7 +159,7 @@ class _Mlp2(torch.autograd.Function):
 def mlp2(x, seq, res_x=False, r=None):
     """seq = two Sequential(Linear, SiLU) blocks (MLP([d, d, d]) or the first two of a longer MLP)."""
     l1, l2 = seq[0][0], seq[1][0]
-    return _Mlp2.apply(x, l1.weight, l1.bias, l2.weight, l2.bias, res_x, r)
+    return ops.apply(_Mlp2, x, l1.weight, l1.bias, l2.weight, l2.bias, res_x, r)
 
 
 class _Project(torch.autograd.Function):
@@ -209,12 +209,12 @@ class _Project(torch.autograd.Function):
 
 def linear(x, lin, act=True):
     """One Sequential(Linear, SiLU) block (act) or a bare Linear."""
-    return _Project.apply(x, ((0, 0),), lin.bias, act, lin.weight)
+    return ops.apply(_Project, x, ((0, 0),), lin.bias, act, lin.weight)
 
 
 def project(x, blocks, *weights):
     """blocks: ((weight index, first column), ...) -> [rows, len(blocks) * d], no bias, no activation."""
-    return _Project.apply(x, tuple(blocks), None, False, *weights)
+    return ops.apply(_Project, x, tuple(blocks), None, False, *weights)
 
 
 # ---- the node-update tail as ONE autograd node ------------------------------------------------------------------------
@@ -312,7 +312,7 @@ def tail(layer, x, res_x):
     for k in range(3):
         ps += [layer.mlp_out[k][0].weight, layer.mlp_out[k][0].bias]
     ps += [layer.W_out.weight, layer.W_out.bias, layer.W]
-    return _Tail.apply(x, res_x, *ps)
+    return ops.apply(_Tail, x, res_x, *ps)
 
 
 class _Embed(torch.autograd.Function):
@@ -363,5 +363,5 @@ class _Embed(torch.autograd.Function):
 
 def embed(f, lin_a, lin_b=None, kind=None):
     if kind is None:
-        return _Embed.apply(f, None, lin_a.weight, lin_a.bias, None, None)
-    return _Embed.apply(f, kind, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias)
+        return ops.apply(_Embed, f, None, lin_a.weight, lin_a.bias, None, None)
+    return ops.apply(_Embed, f, kind, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias)

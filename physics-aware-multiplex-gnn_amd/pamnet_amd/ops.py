@@ -12,6 +12,24 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+class _NoGradCtx(object):
+    """Stand-in for the autograd context when gradients are disabled: forward() bodies are called directly, skipping
+    Function.apply (forward-only loops at the narrow widths are bound by the host, not the GPU)."""
+    needs_input_grad = ()
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+def apply(fn, *args):
+    if torch.is_grad_enabled():
+        return fn.apply(*args)
+    return fn.forward(_NoGradCtx(), *args)
+
+
 def segment_sum_raw(out, init, A, ia, B, ib, perm, ptr, rows, d):
     lib.call('pamnet_segment_sum_f32', lib.ptr(out), lib.ptr(init), lib.ptr(A), lib.ptr(ia), lib.ptr(B), lib.ptr(ib),
              lib.ptr(perm), lib.ptr(ptr), rows, d, lib.stream_of(A))
@@ -152,20 +170,20 @@ class _FusePool(torch.autograd.Function):
 
 
 def aggregate(src, csr, init=None):
-    return _Aggregate.apply(src, init, csr)
+    return apply(_Aggregate, src, init, csr)
 
 
 def gather(x, idx, tr_ptr, tr_perm=None):
-    return _Gather.apply(x, idx, tr_ptr, tr_perm)
+    return apply(_Gather, x, idx, tr_ptr, tr_perm)
 
 
 def gather_mul_aggregate(A, B, csr, tr):
-    return _GatherMulAggregate.apply(A, B, csr, tr)
+    return apply(_GatherMulAggregate, A, B, csr, tr)
 
 
 def rbf(dist, freq, cutoff):
-    return _RBF.apply(dist, freq, cutoff)
+    return apply(_RBF, dist, freq, cutoff)
 
 
 def fuse_pool(outs, atts, graph, mean):
-    return _FusePool.apply(outs, atts, graph, mean)
+    return apply(_FusePool, outs, atts, graph, mean)

@@ -17,6 +17,7 @@ with torch.no_grad():
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): out = model(b)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps * 1e3
+g = model._graph_cache
 # same loop with the input pipeline (graph of batch i+1 built on a side stream while batch i runs)
 from pamnet_amd.train import predict
 bs = [synth.rna_batch(2, 8 * k, 8).to(dev) for k in range(4)]
@@ -26,6 +27,5 @@ n = 0
 for _d, o in predict(model, bs * (steps // 2)): n += 1
 torch.cuda.synchronize(); dtp = (time.perf_counter() - t0) / n * 1e3
 print('pipelined: %.2f ms/forward (%.0f graphs/s) over %d distinct batches' % (dtp, 8e3 / dtp, len(bs)))
-g = model._graph_cache
 print('rna infer d=%d L=%d  N=%d E_g=%d E_l=%d TP=%d  %.2f ms/forward  (%.0f graphs/s)  out[0]=%.6f' % (
     dim, nl, g.n, g.glob.m, g.loc.m, g.tp.m, dt, 8e3 / dt, float(out[0])))
