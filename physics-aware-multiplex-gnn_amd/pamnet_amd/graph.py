@@ -49,18 +49,39 @@ def expand_rows(ptr, total):
     return out
 
 
-def csr_filter(ptr_in, nbr, dist, cut):
+def host_ints(*scalars):
+    """Data-dependent sizes come back to the host in ONE round trip: every call is a stream synchronisation that drains
+    the launch queue, and forward-only runs are bound by exactly these."""
+    return [int(v) for v in torch.stack([s.reshape(()).to(torch.int64) for s in scalars]).tolist()]
+
+
+def _filter_count(ptr_in, nbr, dist, cut):
     rows = ptr_in.numel() - 1
-    st = lib.stream_of(nbr)
     count = _i32(rows, nbr.device)
     lib.call('pamnet_csr_filter_count_i32', lib.ptr(ptr_in), lib.ptr(nbr), lib.ptr(dist), rows, float(cut),
-             lib.ptr(count), st)
-    ptr = exclusive_scan(count)
-    total = int(ptr[-1])
+             lib.ptr(count), lib.stream_of(nbr))
+    return exclusive_scan(count)
+
+
+def _filter_fill(ptr_in, nbr, dist, cut, ptr, total):
+    rows = ptr_in.numel() - 1
     nbr_out, dist_out = _i32(total, nbr.device), _f32(total, nbr.device)
     lib.call('pamnet_csr_filter_fill_i32', lib.ptr(ptr_in), lib.ptr(nbr), lib.ptr(dist), rows, float(cut),
-             lib.ptr(ptr), lib.ptr(nbr_out), lib.ptr(dist_out), st)
+             lib.ptr(ptr), lib.ptr(nbr_out), lib.ptr(dist_out), lib.stream_of(nbr))
     return ptr, nbr_out, dist_out
+
+
+def csr_filter(ptr_in, nbr, dist, cut):
+    ptr = _filter_count(ptr_in, nbr, dist, cut)
+    return _filter_fill(ptr_in, nbr, dist, cut, ptr, int(ptr[-1]))
+
+
+def csr_filter2(ptr_in, nbr, dist, cut_a, cut_b):
+    """Two cutoffs on the same table (the RNA global / local graphs, models.py:147-156): both counts first, one host
+    round trip for the two sizes."""
+    pa, pb = _filter_count(ptr_in, nbr, dist, cut_a), _filter_count(ptr_in, nbr, dist, cut_b)
+    ta, tb = host_ints(pa[-1], pb[-1])
+    return _filter_fill(ptr_in, nbr, dist, cut_a, pa, ta), _filter_fill(ptr_in, nbr, dist, cut_b, pb, tb)
 
 
 def edge_dist(pos, a, b):
@@ -120,16 +141,22 @@ class Graph(object):
         return int(self.pair_rows.numel())
 
 
-def radius_graph(pos, node_graph, gptr, r):
+def radius_graph(pos, node_graph, gptr, r, also=None):
+    """`also`: an extra device scalar to fetch in the same host round trip as the edge count (returned last)."""
     n = pos.size(0)
     st = lib.stream_of(pos)
     count = _i32(n, pos.device)
     lib.call('pamnet_radius_count_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), n, float(r), lib.ptr(count), st)
     ptr = exclusive_scan(count)
-    total = int(ptr[-1])
+    if also is None:
+        total = int(ptr[-1])
+    else:
+        total, extra = host_ints(ptr[-1], also)
     nbr, dist = _i32(total, pos.device), _f32(total, pos.device)
     lib.call('pamnet_radius_fill_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), n, float(r), lib.ptr(ptr),
              lib.ptr(nbr), lib.ptr(dist), st)
+    if also is not None:
+        return ptr, nbr, dist, extra
     return ptr, nbr, dist
 
 
@@ -167,10 +194,11 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
 
     if dataset == 'QM9':
         pos = pos.to(torch.float32).contiguous()
-        gp, gn, gd = radius_graph(pos, node_graph, g.gptr, cutoff_g)          # symmetric: agg = query, other = nbr
         ei = edge_index
         keep = ei[0] != ei[1]                                                  # remove_self_loops (models.py:63)
-        if not bool(keep.all()):
+        # symmetric: agg = query, other = nbr; the self-loop flag rides on the edge count's round trip
+        gp, gn, gd, all_kept = radius_graph(pos, node_graph, g.gptr, cutoff_g, also=keep.all())
+        if not all_kept:
             ei = ei[:, keep]
         src0, dst0 = ei[0].to(I32).contiguous(), ei[1].to(I32).contiguous()    # j, i = edge_index (models.py:64)
         lp, perm = csr_from_keys(dst0, n)
@@ -188,10 +216,10 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
         pos = xr[:, :3].to(torch.float32).contiguous()
         kp, kn, kd = knn_table(pos, node_graph, g.gptr, knn_k, float('inf'))   # (query, neighbour) rows, self dropped
-        gp, gn, gd = csr_filter(kp, kn, kd, cutoff_g)                          # models.py:147-150
+        # models.py:147-150 (global) and 153-156 (local: j = query, i = nbr)
+        (gp, gn, gd), (qp, qn, qd) = csr_filter2(kp, kn, kd, cutoff_g, cutoff_l)
         if flow != 'target_to_source':                                          # aggregate at edge_index[1] = neighbour
             gp, gn, gd = _transpose_edges(gp, gn, gd, n)
-        qp, qn, qd = csr_filter(kp, kn, kd, cutoff_l)                          # models.py:153-156: (j=query, i=nbr)
         lp, l_src, l_dist = _transpose_edges(qp, qn, qd, n)                    # local layer always aggregates at i
         l_dst = expand_rows(lp, l_src.numel())
     else:
