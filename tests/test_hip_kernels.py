@@ -187,6 +187,21 @@ def test_knn_matches_oracle(dev):
     assert _edge_set(q[keep].cpu(), kn[keep].cpu()) == _edge_set(ei2[0][m], ei2[1][m])
 
 
+def test_csr_filter_pair_equals_two_filters(dev):
+    """csr_filter2 (both RNA cutoffs, one host round trip) == two csr_filter calls, bit for bit."""
+    from pamnet_amd import graph as G, synth
+    b = synth.rna_batch(3, 0, 2, n_nodes=200)
+    pos = b.x[:, :3].contiguous().to(dev)
+    nodeg = b.batch.to(torch.int32).to(dev)
+    gptr, _ = G.csr_from_keys(nodeg, 2)
+    kp, kn, kd = G.knn_table(pos, nodeg, gptr, 50, float('inf'))
+    a, c = G.csr_filter2(kp, kn, kd, 20.0, 2.6)
+    for got, cut in ((a, 20.0), (c, 2.6)):
+        want = G.csr_filter(kp, kn, kd, cut)
+        assert all(torch.equal(x, y) for x, y in zip(got, want))
+    assert G.host_ints(kp[-1], torch.tensor(True, device=dev), torch.tensor(7, device=dev)) == [int(kp[-1]), 1, 7]
+
+
 @pytest.mark.parametrize('n,lattice', [(300, False), (700, True), (4100, False), (5000, True)])
 def test_knn_order_ties_and_large_graphs(dev, n, lattice):
     """The table rows hold the k smallest (squared distance, index) pairs in ascending order: exact integer check
