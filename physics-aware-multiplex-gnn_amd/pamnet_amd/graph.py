@@ -141,23 +141,24 @@ class Graph(object):
         return int(self.pair_rows.numel())
 
 
-def radius_graph(pos, node_graph, gptr, r, also=None):
-    """`also`: an extra device scalar to fetch in the same host round trip as the edge count (returned last)."""
+def radius_count(pos, node_graph, gptr, r):
     n = pos.size(0)
-    st = lib.stream_of(pos)
     count = _i32(n, pos.device)
-    lib.call('pamnet_radius_count_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), n, float(r), lib.ptr(count), st)
-    ptr = exclusive_scan(count)
-    if also is None:
-        total = int(ptr[-1])
-    else:
-        total, extra = host_ints(ptr[-1], also)
+    lib.call('pamnet_radius_count_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), n, float(r), lib.ptr(count),
+             lib.stream_of(pos))
+    return exclusive_scan(count)
+
+
+def radius_fill(pos, node_graph, gptr, r, ptr, total):
     nbr, dist = _i32(total, pos.device), _f32(total, pos.device)
-    lib.call('pamnet_radius_fill_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), n, float(r), lib.ptr(ptr),
-             lib.ptr(nbr), lib.ptr(dist), st)
-    if also is not None:
-        return ptr, nbr, dist, extra
+    lib.call('pamnet_radius_fill_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), pos.size(0), float(r), lib.ptr(ptr),
+             lib.ptr(nbr), lib.ptr(dist), lib.stream_of(pos))
     return ptr, nbr, dist
+
+
+def radius_graph(pos, node_graph, gptr, r):
+    ptr = radius_count(pos, node_graph, gptr, r)
+    return radius_fill(pos, node_graph, gptr, r, ptr, int(ptr[-1]))
 
 
 def knn_table(pos, node_graph, gptr, k, cutoff):
@@ -178,6 +179,15 @@ def _transpose_edges(ptr, nbr, dist, n):
     return tptr, q[pl].contiguous(), dist[pl].contiguous()
 
 
+def _triplet_ptr(lp, l_src, l_dst, with_triplets):
+    """CSR pointer of the combined triplet / pair rows per local edge (models.py:68-98), on the device."""
+    e_l = l_src.numel()
+    tcount, tpcount = _i32(e_l, l_src.device), _i32(e_l, l_src.device)
+    lib.call('pamnet_triplet_count_i32', lib.ptr(lp), lib.ptr(l_src), lib.ptr(l_dst), e_l, 1 if with_triplets else 0,
+             lib.ptr(tcount), lib.ptr(tpcount), lib.stream_of(l_src))
+    return exclusive_scan(tpcount)
+
+
 def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_index=None, num_graphs=None,
                 need_grad=True, knn_k=50, with_triplets=True):
     """Graph-construction part of PAMNet.forward (models.py:104-177).  Returns a Graph."""
@@ -191,20 +201,32 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     g.gptr, _ = csr_from_keys(node_graph, g.n_graphs)
     rna = dataset[:3].lower() == 'rna'
     g.sign = None
+    tp_pre = None
 
     if dataset == 'QM9':
         pos = pos.to(torch.float32).contiguous()
+        # One host round trip for all three data-dependent sizes: the bond graph's CSR and its triplet / pair counts do
+        # not depend on the radius graph, so they are computed first, on the assumption that the bond list has no self
+        # loops (remove_self_loops, models.py:63, is a no-op for QM9 bond graphs); the flag that verifies it comes back
+        # with the sizes, and a batch that does have self loops is redone the slow way.
+        def bonds(ei):
+            src0, dst0 = ei[0].to(I32).contiguous(), ei[1].to(I32).contiguous()    # j, i = edge_index (models.py:64)
+            lp_, perm = csr_from_keys(dst0, n)
+            pl = perm.long()
+            src_, dst_ = src0[pl].contiguous(), dst0[pl].contiguous()
+            return lp_, src_, dst_, _triplet_ptr(lp_, src_, dst_, with_triplets)
+
         ei = edge_index
-        keep = ei[0] != ei[1]                                                  # remove_self_loops (models.py:63)
-        # symmetric: agg = query, other = nbr; the self-loop flag rides on the edge count's round trip
-        gp, gn, gd, all_kept = radius_graph(pos, node_graph, g.gptr, cutoff_g, also=keep.all())
+        keep = ei[0] != ei[1]
+        lp, l_src, l_dst, tp_ptr = bonds(ei)
+        gptr_g = radius_count(pos, node_graph, g.gptr, cutoff_g)               # symmetric: agg = query, other = nbr
+        total_g, all_kept, tp_total = host_ints(gptr_g[-1], keep.all(), tp_ptr[-1])
         if not all_kept:
-            ei = ei[:, keep]
-        src0, dst0 = ei[0].to(I32).contiguous(), ei[1].to(I32).contiguous()    # j, i = edge_index (models.py:64)
-        lp, perm = csr_from_keys(dst0, n)
-        pl = perm.long()
-        l_src, l_dst = src0[pl].contiguous(), dst0[pl].contiguous()
+            lp, l_src, l_dst, tp_ptr = bonds(ei[:, keep])
+            tp_total = int(tp_ptr[-1])
+        gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g)
         l_dist = edge_dist(pos, l_dst, l_src)
+        tp_pre = (tp_ptr, tp_total)
     elif dataset == 'PDBbind':
         xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
         pos = xr[:, :3].to(torch.float32).contiguous()
@@ -236,11 +258,11 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     e_l = g.loc.m
     st = lib.stream_of(pos)
     wt = 1 if with_triplets else 0
-    tcount, tpcount = _i32(e_l, dev), _i32(e_l, dev)
-    lib.call('pamnet_triplet_count_i32', lib.ptr(lp), lib.ptr(l_src), lib.ptr(l_dst), e_l, wt, lib.ptr(tcount),
-             lib.ptr(tpcount), st)
-    tp_ptr = exclusive_scan(tpcount)
-    tot = int(tp_ptr[-1])
+    if tp_pre is None:
+        tp_ptr = _triplet_ptr(lp, l_src, l_dst, with_triplets)
+        tot = int(tp_ptr[-1])
+    else:
+        tp_ptr, tot = tp_pre
     tp_idx, tp_edge, tp_angle, tp_kind = _i32(tot, dev), _i32(tot, dev), _f32(tot, dev), _i32(tot, dev)
     lib.call('pamnet_triplet_fill_f32', lib.ptr(pos), lib.ptr(lp), lib.ptr(l_src), lib.ptr(l_dst), e_l, wt,
              lib.ptr(tp_ptr), lib.ptr(tp_idx), lib.ptr(tp_edge), lib.ptr(tp_angle), lib.ptr(tp_kind), st)

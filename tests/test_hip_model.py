@@ -300,6 +300,35 @@ def test_fused_engine_fresh_inputs_vs_oracle(dev, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dim', [128, 32])
+def test_self_loops_in_the_bond_list_are_dropped(dev, dim):
+    """remove_self_loops (models.py:63): a bond list with self loops gives the same graph, outputs and gradients as the
+    clean one (the graph builder assumes a clean list and redoes the local graph when the device-side check fails)."""
+    import copy
+    import models
+    from pamnet_amd import synth
+    cfg = models.Config(dataset='QM9', dim=dim, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+    torch.manual_seed(11)
+    model = models.PAMNet(cfg).to(dev)
+    clean = synth.qm9_batch(23, 0, 6).to(dev)
+    dirty = copy.copy(clean)
+    n = clean.x.numel()
+    loops = torch.tensor([[0, 3, n - 1], [0, 3, n - 1]], dtype=clean.edge_index.dtype, device=dev)
+    dirty.edge_index = torch.cat([clean.edge_index[:, :5], loops[:, :2], clean.edge_index[:, 5:], loops[:, 2:]], 1)
+    res = []
+    for b in (clean, dirty):
+        model.zero_grad()
+        out = model(b)
+        out.sum().backward()
+        g = model._graph_cache
+        res.append((out.detach().clone(), [p.grad.clone() for p in model.parameters() if p.grad is not None],
+                    g.loc.m, g.tp.m))
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3]
+    assert torch.equal(res[0][0], res[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(res[0][1], res[1][1]))
+
+
+@pytest.mark.gpu
 def test_large_batch_equals_its_shards(dev):
     """Size-independent property well above the BASELINE batch (1 024 molecules, N ~ 18 k, E_g ~ 260 k: multi-chunk edge
     workgroups, unsplit segment sums, many weight-gradient slots): outputs and the loss gradient of the big batch equal
