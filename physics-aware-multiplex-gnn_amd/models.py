@@ -98,8 +98,10 @@ class _PAMNetBase(nn.Module):
     # ------------------------------------------------------------------------------------------------------------
     def _graph(self, data):
         pre = getattr(data, '_pamnet_prepared', None)
-        if pre is not None and (pre.need_grad or not torch.is_grad_enabled()):
-            return pre                                   # built ahead of time by prepare() (possibly on a side stream)
+        if pre is not None:
+            data._pamnet_prepared = None                 # a prepared graph serves exactly one forward: nothing is cached
+            if pre.need_grad or not torch.is_grad_enabled():
+                return pre                               # built ahead of time by prepare() (possibly on a side stream)
         ng = getattr(data, 'num_graphs', None)
         g = G.build_graph(self.dataset, self.cutoff_l, self.cutoff_g, self.flow, data.x, data.batch,
                           getattr(data, 'pos', None), getattr(data, 'edge_index', None), num_graphs=ng,

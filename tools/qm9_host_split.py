@@ -1,3 +1,4 @@
+"""QM9 B=128 forward-only: where the time goes (graph + basis construction vs the engine forward)."""
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (REPO, os.path.join(REPO, 'physics-aware-multiplex-gnn_amd')): sys.path.insert(0, p)
@@ -5,9 +6,9 @@ import torch, models
 from pamnet_amd import synth
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
-model = models.PAMNet(models.Config(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')).to(dev).eval()
-b = synth.rna_batch(2, 0, 8).to(dev)
-def t(fn, n=20):
+model = models.PAMNet(models.Config(dataset='QM9', dim=128, n_layer=6, cutoff_l=5.0, cutoff_g=5.0)).to(dev).eval()
+b = synth.qm9_batch(0, 0, 128).to(dev)
+def t(fn, n=30):
     for _ in range(3): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
@@ -16,16 +17,13 @@ with torch.no_grad():
     tp = t(lambda: model.prepare(b, need_grad=False))
     gp = model.prepare(b, need_grad=False)._pamnet_prepared
     def fwd():
-        b._pamnet_prepared = gp   # re-attach: a prepared graph is consumed by the forward that uses it
+        b._pamnet_prepared = gp       # re-attach: a prepared graph is consumed by the forward that uses it
         model(b)
     tf = t(fwd)
-    def fwd_host():
-        model(b)
-    # host-only enqueue time of the forward (no sync inside the loop)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(20):
-        b._pamnet_prepared = gp
-        model(b)
-    th = (time.perf_counter() - t0) / 20 * 1e3
+    for _ in range(30): fwd()
+    th = (time.perf_counter() - t0) / 30 * 1e3
     torch.cuda.synchronize()
-print('prepare (graph + basis, syncs inside): %.2f ms   forward on prepared graph: %.2f ms (host enqueue %.2f ms)' % (tp, tf, th))
+    b._pamnet_prepared = None
+    tall = t(lambda: model(b))
+print('QM9 B=128 forward-only: prepare (graph+basis) %.3f ms | engine forward on a prepared graph %.3f ms (host enqueue %.3f) | end to end %.3f ms' % (tp, tf, th, tall))
