@@ -323,8 +323,9 @@ def predict(model, batches):
         if ev is not None:
             torch.cuda.current_stream(dev).wait_event(ev)
             cur._pamnet_ready = None
-        out = model(cur)
         if pipelined and nxt is not None:
+            # queued BEFORE this batch's forward: the graph kernels are small, and their one host round trip resolves
+            # while the previous forward is still running instead of waiting behind this one
             main = torch.cuda.current_stream(dev)
             with torch.cuda.stream(side):
                 model.prepare(nxt, need_grad=False)
@@ -333,6 +334,7 @@ def predict(model, batches):
             nxt._pamnet_ready = e
             for v in _graph_tensors(nxt._pamnet_prepared):
                 v.record_stream(main)
+        out = model(cur)
         yield cur, out
         cur = nxt
 
