@@ -166,6 +166,15 @@ int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int64_t n, con
                              float* Z, float* R, float* x_out, float* out, float* att, const float* next_Wx1,
                              const float* next_bx1, const float* const* next_wp, int64_t next_ldwp, int64_t next_nblk,
                              float* next_Zx1, float* next_x1, float* next_P, int32_t packed, pamnet_stream_t stream);
+/* out = att = null in pamnet_node_tail_fwd_f32 leaves the head branch of the chain (mlp_out, W_out, W:
+ * layers/global_message_passing.py:46-50) to this call, which runs it for n_layers chains in one launch (nothing
+ * downstream of a layer depends on its heads): per layer l  x_out[l] [n,128] -> out[l] [n], att[l] [n], and slots 7..9
+ * of that layer's pre-activation block Z[l] ([10][n][128]; Z or Z[l] null: not saved).  weights / biases: 3 per layer
+ * (mlp_out), fragment images when `packed`. */
+int pamnet_node_heads_fwd_f32(int64_t n_layers, const float* const* x_out, const float* const* weights,
+                              const float* const* biases, const float* const* w_out, const float* const* b_out,
+                              const float* const* w_att, float* const* Z, float* const* out, float* const* att, int64_t n,
+                              int32_t packed, pamnet_stream_t stream);
 int pamnet_node_tail_bwd_f32(const float* d_xout, const float* d_out, const float* d_att, int64_t n,
                              const float* const* weights, const float* w_out, const float* w_att, const float* Z,
                              float* dZ, float* d_x2, float* d_resx, float* head_partial, float* d_wout, float* d_watt,

@@ -13,6 +13,8 @@
 // backward kernels themselves (accumulate flag), in a fixed layer order -> deterministic.
 #include <alloca.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -326,7 +328,7 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         const LocalSaved q = carve_local(saved + k * (gs + ls) + gs, g);
         const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
         CK(pamnet_node_tail_fwd_f32(s.x2, x, g.n, packed ? img[k].gt : gp + GT, gp + GT + 10, gp[GT + 20], gp[GT + 21],
-                                    gp[GT + 22], sv(s.Z), sv(s.R), s.xout, outs + (2 * k) * g.n, atts + (2 * k) * g.n,
+                                    gp[GT + 22], sv(s.Z), sv(s.R), s.xout, nullptr, nullptr,
                                     packed ? img[k].lh[0] : lp[0], lp[1], packed ? img[k].lh + 1 : wpl, 3 * D, 4,
                                     sv(q.Zx1), t.x1, t.P, pk, st));
         x = s.xout;
@@ -344,16 +346,41 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
             const GlobalSaved sn = carve_global(saved + (k + 1) * (gs + ls), g);
             const float* wpn[2] = {gn[2], gn[2] + D};
             CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, packed ? img[k].lt : lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21],
-                                        lp[LT + 22], sv(q.Z), sv(q.R), q.xout, outs + (2 * k + 1) * g.n,
-                                        atts + (2 * k + 1) * g.n, packed ? img[k].nh[0] : gn[0], gn[1],
+                                        lp[LT + 22], sv(q.Z), sv(q.R), q.xout, nullptr, nullptr,
+                                        packed ? img[k].nh[0] : gn[0], gn[1],
                                         packed ? img[k].nh + 1 : wpn, 3 * D, 2, sv(sn.Zx1), t.x1, t.P, pk, st));
         } else {
             CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, packed ? img[k].lt : lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21],
-                                        lp[LT + 22], sv(q.Z), sv(q.R), q.xout, outs + (2 * k + 1) * g.n,
-                                        atts + (2 * k + 1) * g.n, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr,
-                                        nullptr, pk, st));
+                                        lp[LT + 22], sv(q.Z), sv(q.R), q.xout, nullptr, nullptr, nullptr, nullptr,
+                                        nullptr, 0, 0, nullptr, nullptr, nullptr, pk, st));
         }
         x = q.xout;
+    }
+    // the head branch (mlp_out + W_out / W) of all 2 n_layer chains in one launch: 2L x ceil(n/16) workgroups
+    {
+        const int64_t nh = 2 * n_layer;
+        std::vector<const float*> hx(nh), hw(3 * nh), hb(3 * nh), hwo(nh), hbo(nh), hwa(nh);
+        std::vector<float*> hz(nh), ho(nh), ha(nh);
+        for (int64_t k = 0; k < n_layer; ++k) {
+            const float* const* gp = gparams + k * NG;
+            const float* const* lp = lparams + k * NL;
+            const GlobalSaved s = carve_global(saved + k * (gs + ls), g);
+            const LocalSaved q = carve_local(saved + k * (gs + ls) + gs, g);
+            for (int side = 0; side < 2; ++side) {
+                const int64_t l = 2 * k + side;
+                const float* const* tp = side ? lp + LT : gp + GT;
+                hx[l] = side ? q.xout : s.xout;
+                for (int i = 0; i < 3; ++i) {
+                    hw[3 * l + i] = packed ? (side ? img[k].lt[7 + i] : img[k].gt[7 + i]) : tp[7 + i];
+                    hb[3 * l + i] = tp[10 + 7 + i];
+                }
+                hwo[l] = tp[20], hbo[l] = tp[21], hwa[l] = tp[22];
+                hz[l] = sv(side ? q.Z : s.Z);
+                ho[l] = outs + l * g.n, ha[l] = atts + l * g.n;
+            }
+        }
+        CK(pamnet_node_heads_fwd_f32(nh, hx.data(), hw.data(), hb.data(), hwo.data(), hbo.data(), hwa.data(), hz.data(),
+                                     ho.data(), ha.data(), g.n, pk, st));
     }
     return PAMNET_OK;
 }

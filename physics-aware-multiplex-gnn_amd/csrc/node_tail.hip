@@ -129,7 +129,11 @@ __device__ __forceinline__ f32x4 mma_strip(const float* __restrict__ As, const W
 // Forward: 4 waves x 32 columns (float4 weight loads are cheap per byte, so fewer, wider waves win; an 8-wave x 16-column
 // version measured 35 us against 31 us: two waves per SIMD only take turns on the matrix pipe and then idle at the
 // barrier -- tools/tail_probe.py).
-template <bool PACKED>
+// HEADS = false: the head branch (mlp_out + the two dot products, layers 7-9) is left to node_heads_fwd_kernel, which
+// runs it for every layer of the model in one launch after the layer loop: nothing downstream of a layer depends on
+// its heads, the chain gets three dependent GEMMs shorter, and the batched launch has 2L x ceil(n/16) workgroups
+// instead of the chain's ceil(n/16) (143 of 256 CUs at the QM9 batch).
+template <bool PACKED, bool HEADS>
 __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restrict__ x2,
                                                            const float* __restrict__ res_x, int64_t n, TailParams p,
                                                            float* __restrict__ Z, float* __restrict__ R,
@@ -197,10 +201,13 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
     layer(C, A, 3, nullptr, nullptr, nullptr, p.W[4]);         // a3 -> A
     layer(A, B, 4, C, nullptr, TL + SLOT, p.W[5]);             // r2 -> B   (+ r1)
     layer(B, A, 5, nullptr, nullptr, nullptr, p.W[6]);         // a5 -> A
-    layer(A, C, 6, B, nullptr, TL + 2 * SLOT, p.W[7]);         // r3 -> C   (+ r2)  = x_out
-    layer(C, A, 7, nullptr, nullptr, nullptr, p.W[8]);         // o1 -> A
-    layer(A, B, 8, nullptr, nullptr, nullptr, p.W[9]);         // o2 -> B
-    layer(B, A, 9, nullptr, nullptr, nullptr, nx.nblk > 0 ? nx.Wx1 : nullptr);   // o3 -> A
+    constexpr int NZ = HEADS ? 10 : 7;                         // z_k tiles this kernel produces
+    layer(A, C, 6, B, nullptr, TL + 2 * SLOT, HEADS ? p.W[7] : (nx.nblk > 0 ? nx.Wx1 : nullptr));   // r3 -> C = x_out
+    if constexpr (HEADS) {
+        layer(C, A, 7, nullptr, nullptr, nullptr, p.W[8]);         // o1 -> A
+        layer(A, B, 8, nullptr, nullptr, nullptr, p.W[9]);         // o2 -> B
+        layer(B, A, 9, nullptr, nullptr, nullptr, nx.nblk > 0 ? nx.Wx1 : nullptr);   // o3 -> A
+    }
 
     // park -> memory: Z[10][n][128], R[2][n][128], x_out[n][128]
     sweep_rows<BMN>([&](int r, int c4) {
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
         if (g >= n) return;
         if (Z) {                                              // backward-only saves: null in inference mode
 #pragma unroll
-            for (int k = 0; k < 10; ++k) stg4(Z + (int64_t)k * plane, g, DIM, c4, lds4(ZL + k * SLOT, r, c4));
+            for (int k = 0; k < NZ; ++k) stg4(Z + (int64_t)k * plane, g, DIM, c4, lds4(ZL + k * SLOT, r, c4));
             stg4(R, g, DIM, c4, lds4(TL, r, c4));
             stg4(R + plane, g, DIM, c4, lds4(TL + SLOT, r, c4));
         }
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
     });
 
     // heads: 16 lanes per row, 8 columns each, butterfly over the 16-lane group
-    {
+    if constexpr (HEADS) {
         const int r = threadIdx.x >> 4, part = threadIdx.x & 15;
         float so = 0.f, sa = 0.f;
 #pragma unroll
@@ -282,6 +289,93 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
             stg4(nx.x1, g, DIM, c4, lds4(ZL + SLOT, r, c4));
             for (int b = 0; b < nx.nblk; ++b) stg4(nx.P + (int64_t)b * plane, g, DIM, c4, lds4(ZL + (2 + b) * SLOT, r, c4));
         });
+    }
+}
+
+// Head branch of every layer in one launch: o3 = mlp_out(x_out), out = W_out . o3 + b_out, att = W . o3
+// (layers/global_message_passing.py:46-50).  grid = (ceil(n/16), layers).
+constexpr int MAX_HEAD_LAYERS = 16;
+struct HeadLayer {
+    const float* x_out;       // [n][128] chain output of this layer
+    const float* W[3];        // mlp_out matrices (row-major, or fragment images when packed)
+    const float* b[3];
+    const float* w_out;
+    const float* b_out;
+    const float* w_att;
+    float* Z;                 // this layer's [10][n][128] pre-activation block (slots 7..9 written) or null
+    float* out;
+    float* att;
+};
+struct HeadBatch {
+    HeadLayer l[MAX_HEAD_LAYERS];
+};
+
+template <bool PACKED>
+__global__ __launch_bounds__(WG) void node_heads_fwd_kernel(HeadBatch hb, int64_t n) {
+    __shared__ __attribute__((aligned(16))) float lds[6 * SLOT];
+    float* X = lds;
+    float* A = lds + SLOT;
+    float* B = lds + 2 * SLOT;
+    float* ZL = lds + 3 * SLOT;               // [3] z7, z8, z9
+    const HeadLayer& hl = hb.l[blockIdx.y];
+    const int64_t row0 = (int64_t)blockIdx.x * BMN;
+    const int64_t plane = n * DIM;
+    const int lane = threadIdx.x & 63, r16 = lane & 15, kg = lane >> 4;
+    const int wc = (threadIdx.x >> 6) * 32;
+    WFrag wf;
+    load_w<PACKED>(wf, hl.W[0], DIM, wc);
+    sweep_rows<BMN>([&](int r, int c4) { st_lds4(X, r, c4, ldg4z(hl.x_out, row0 + r, n, DIM, c4)); });
+    __syncthreads();
+    auto layer = [&](const float* in, float* dst, int k, const float* Wnext) {
+        const Bias2 bv = load_bias2(hl.b[k], wc);
+        f32x4 acc[1][2];
+        acc_zero<1>(acc);
+        mma_tile_frag<1>(in, wf, acc);
+        if (Wnext) load_w<PACKED>(wf, Wnext, DIM, wc);
+        float* zk = ZL + k * SLOT;
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+            const int c = wc + 16 * n2 + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rw = 4 * kg + r;
+                const float z = acc[0][n2][r] + bv.v[n2];
+                dst[rw * LDT + c] = silu(z);
+                zk[rw * LDT + c] = z;
+            }
+        }
+        __syncthreads();
+    };
+    layer(X, A, 0, hl.W[1]);                  // o1
+    layer(A, B, 1, hl.W[2]);                  // o2
+    layer(B, A, 2, nullptr);                  // o3 -> A
+    if (hl.Z) {
+        sweep_rows<BMN>([&](int r, int c4) {
+            const int64_t g = row0 + r;
+            if (g >= n) return;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) stg4(hl.Z + (int64_t)(7 + k) * plane, g, DIM, c4, lds4(ZL + k * SLOT, r, c4));
+        });
+    }
+    {
+        const int r = threadIdx.x >> 4, part = threadIdx.x & 15;
+        float so = 0.f, sa = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float v = A[r * LDT + part * 8 + c];
+            so += v * hl.w_out[part * 8 + c];
+            sa += v * hl.w_att[part * 8 + c];
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) {
+            so += __shfl_xor(so, o, 64);
+            sa += __shfl_xor(sa, o, 64);
+        }
+        const int64_t g = row0 + r;
+        if (part == 0 && g < n) {
+            hl.out[g] = so + hl.b_out[0];
+            hl.att[g] = sa;
+        }
     }
 }
 
@@ -505,8 +599,9 @@ extern "C" int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int
                                         float* next_P, int32_t packed, pamnet_stream_t stream) {
     if (n < 0 || next_nblk < 0 || next_nblk > 4) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
-    if (!x2 || !res_x || !weights || !biases || !w_out || !b_out || !w_att || (Z && !R) || !x_out || !out || !att)
+    if (!x2 || !res_x || !weights || !biases || !w_out || !b_out || !w_att || (Z && !R) || !x_out || (!out != !att))
         return PAMNET_ENULL;
+    const bool heads = out != nullptr;        // out = att = null: the head branch is run later by pamnet_node_heads_fwd_f32
     for (int k = 0; k < 10; ++k)
         if (!weights[k] || !biases[k]) return PAMNET_ENULL;
     PreNext nx{};
@@ -521,13 +616,45 @@ extern "C" int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int
         }
     }
     hipStream_t st = as_stream(stream);
-    if (packed)
-        hipLaunchKernelGGL(node_tail_fwd_kernel<true>, dim3((unsigned)ceil_div(n, BMN)), dim3(WG), 0, st, x2, res_x, n,
-                           make_tail(weights, biases, w_out, b_out, w_att, 1), Z, R, x_out, out, att, nx);
-    else
-        hipLaunchKernelGGL(node_tail_fwd_kernel<false>, dim3((unsigned)ceil_div(n, BMN)), dim3(WG), 0, st, x2, res_x, n,
-                           make_tail(weights, biases, w_out, b_out, w_att, 0), Z, R, x_out, out, att, nx);
+    const dim3 grid((unsigned)ceil_div(n, BMN));
+    const TailParams tp = make_tail(weights, biases, w_out, b_out, w_att, packed ? 1 : 0);
+    if (packed && heads) hipLaunchKernelGGL((node_tail_fwd_kernel<true, true>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
+    else if (packed) hipLaunchKernelGGL((node_tail_fwd_kernel<true, false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
+    else if (heads) hipLaunchKernelGGL((node_tail_fwd_kernel<false, true>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
+    else hipLaunchKernelGGL((node_tail_fwd_kernel<false, false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
     PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_node_heads_fwd_f32(int64_t n_layers, const float* const* x_out, const float* const* weights,
+                                         const float* const* biases, const float* const* w_out,
+                                         const float* const* b_out, const float* const* w_att, float* const* Z,
+                                         float* const* out, float* const* att, int64_t n, int32_t packed,
+                                         pamnet_stream_t stream) {
+    if (n < 0 || n_layers < 0) return PAMNET_EINVAL;
+    if (n == 0 || n_layers == 0) return PAMNET_OK;
+    if (!x_out || !weights || !biases || !w_out || !b_out || !w_att || !out || !att) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    for (int64_t l0 = 0; l0 < n_layers; l0 += MAX_HEAD_LAYERS) {
+        const int nl = (int)(n_layers - l0 < MAX_HEAD_LAYERS ? n_layers - l0 : MAX_HEAD_LAYERS);
+        HeadBatch hb{};
+        for (int i = 0; i < nl; ++i) {
+            const int64_t l = l0 + i;
+            HeadLayer& h = hb.l[i];
+            h.x_out = x_out[l];
+            for (int k = 0; k < 3; ++k) h.W[k] = weights[3 * l + k], h.b[k] = biases[3 * l + k];
+            h.w_out = w_out[l], h.b_out = b_out[l], h.w_att = w_att[l];
+            h.Z = Z ? Z[l] : nullptr;
+            h.out = out[l], h.att = att[l];
+            if (!h.x_out || !h.W[0] || !h.W[1] || !h.W[2] || !h.b[0] || !h.b[1] || !h.b[2] || !h.w_out || !h.b_out ||
+                !h.w_att || !h.out || !h.att)
+                return PAMNET_ENULL;
+        }
+        const dim3 grid((unsigned)ceil_div(n, BMN), (unsigned)nl);
+        if (packed) hipLaunchKernelGGL(node_heads_fwd_kernel<true>, grid, dim3(WG), 0, st, hb, n);
+        else hipLaunchKernelGGL(node_heads_fwd_kernel<false>, grid, dim3(WG), 0, st, hb, n);
+        PAMNET_LAUNCH_CHECK();
+    }
     return PAMNET_OK;
 }
 
