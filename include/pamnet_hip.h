@@ -179,6 +179,18 @@ int pamnet_node_tail_bwd_f32(const float* d_xout, const float* d_out, const floa
                              const float* const* weights, const float* w_out, const float* w_att, const float* Z,
                              float* dZ, float* d_x2, float* d_resx, float* head_partial, float* d_wout, float* d_watt,
                              float* d_bout, int32_t packed, pamnet_stream_t stream);
+/* Backward counterparts of the deferred head branch.  heads_bwd (all layers, one launch; needs only d out / d att):
+ * per layer l the head-vector partials (head_partial[l]: ceil(n/16) x 257 floats, reduced by pamnet_wgrad_batched_f32),
+ * dZ3[l] = [dz7, dz8, dz9] ([3][n][128]) and g_head[l] = the branch's contribution to d x_out ([n][128]); weights: the
+ * mlp_out matrices 7, 8, 9 of every layer (transposed-orientation images when `packed`).  tail_main_bwd: the rest of
+ * the chain (layers 6..0) from d x_out = d_xout (may be null) + g_head; writes dZ slots 0..6. */
+int pamnet_node_heads_bwd_f32(int64_t n_layers, const float* const* d_out, const float* const* d_att,
+                              const float* const* weights, const float* const* w_out, const float* const* w_att,
+                              const float* const* Z, float* const* dZ3, float* const* g_head, float* const* head_partial,
+                              int64_t n, int32_t packed, pamnet_stream_t stream);
+int pamnet_node_tail_main_bwd_f32(const float* d_xout, const float* g_head, int64_t n, const float* const* weights,
+                                  const float* Z, float* dZ, float* d_x2, float* d_resx, int32_t packed,
+                                  pamnet_stream_t stream);
 /* Fragment-ordered weight images for the node chains: n (<= 192) 128x128 matrices (row stride ld[i]) -> images[i*16384..],
  * transposed = 0 for the forward (Y = X W^T), 1 for the backward (Y = X W).  With packed != 0 the `weights` (and, in the
  * forward, next_Wx1 / next_wp) arguments of node_tail_fwd / node_tail_bwd, and Wx1 / wp of node_pre_bwd (transposed

@@ -33,11 +33,16 @@ struct Graph {
 
 inline int64_t al(int64_t x) { return (x + 63) / 64 * 64; }       // 256-byte aligned slabs
 
-struct GlobalSaved { float *Zx1, *z, *ea, *x2, *Z, *R, *xout; };
-struct LocalSaved { float *Zx1, *zji, *zkj, *q2, *q3, *mnb, *mt, *s, *z1, *z2, *x2, *Z, *R, *xout; };
+// hdz / gh / hp: backward scratch of the layer's head branch (dz7..dz9, its d x_out contribution, head-vector partials),
+// filled for all layers by one launch at the start of the backward
+struct GlobalSaved { float *Zx1, *z, *ea, *x2, *Z, *R, *xout, *hdz, *gh, *hp; };
+struct LocalSaved { float *Zx1, *zji, *zkj, *q2, *q3, *mnb, *mt, *s, *z1, *z2, *x2, *Z, *R, *xout, *hdz, *gh, *hp; };
+inline int64_t head_partial_floats(const Graph& g) { return al(((g.n + 15) / 16) * 257); }
 
-inline int64_t global_saved_floats(const Graph& g) { return al(g.n * D) * 15 + al(g.eg * D) * 2; }
-inline int64_t local_saved_floats(const Graph& g) { return al(g.n * D) * 15 + al(g.el * D) * 6 + al(g.tp * D) * 3; }
+inline int64_t global_saved_floats(const Graph& g) { return al(g.n * D) * 19 + al(g.eg * D) * 2 + head_partial_floats(g); }
+inline int64_t local_saved_floats(const Graph& g) {
+    return al(g.n * D) * 19 + al(g.el * D) * 6 + al(g.tp * D) * 3 + head_partial_floats(g);
+}
 
 inline GlobalSaved carve_global(float* p, const Graph& g) {
     GlobalSaved s;
@@ -48,7 +53,10 @@ inline GlobalSaved carve_global(float* p, const Graph& g) {
     s.x2 = p; p += nd;
     s.Z = p; p += 10 * nd;       // NB: planes are n*D apart (not padded): 10*nd >= 10*n*D
     s.R = p; p += 2 * nd;
-    s.xout = p;
+    s.xout = p; p += nd;
+    s.hdz = p; p += 3 * nd;
+    s.gh = p; p += nd;
+    s.hp = p;
     return s;
 }
 
@@ -68,7 +76,10 @@ inline LocalSaved carve_local(float* p, const Graph& g) {
     s.x2 = p; p += nd;
     s.Z = p; p += 10 * nd;
     s.R = p; p += 2 * nd;
-    s.xout = p;
+    s.xout = p; p += nd;
+    s.hdz = p; p += 3 * nd;
+    s.gh = p; p += nd;
+    s.hp = p;
     return s;
 }
 
@@ -184,12 +195,13 @@ struct Jobs {
     }
 };
 
-inline void tail_jobs(Jobs& j, const Graph& g, const float* dZ, const float* x2, const float* Z, const float* R,
-                      const float* xout, float* const* gt /* tail block of the gradient table */) {
+inline void tail_jobs(Jobs& j, const Graph& g, const float* dZ, const float* hdz, const float* x2, const float* Z,
+                      const float* R, const float* xout, float* const* gt /* tail block of the gradient table */) {
     const int64_t pl = g.n * D;
     const float* src[10] = {x2, Z, Z + pl, R, Z + 3 * pl, R + pl, Z + 5 * pl, xout, Z + 7 * pl, Z + 8 * pl};
     const int mode[10] = {0, 1, 1, 0, 1, 0, 1, 0, 1, 1};
-    for (int k = 0; k < 10; ++k) j.add(dZ + k * pl, src[k], mode[k], g.n, gt[k], D, gt[10 + k]);
+    for (int k = 0; k < 10; ++k)          // dz7..dz9 come from the batched head-branch backward
+        j.add(k < 7 ? dZ + k * pl : hdz + (k - 7) * pl, src[k], mode[k], g.n, gt[k], D, gt[10 + k]);
 }
 
 // all weight gradients of a layer + the head-vector gradients of its node chain (partials left by node_tail_bwd)
@@ -424,6 +436,29 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
         CK(pl.rc);
     }
     const int32_t pk = packed ? 1 : 0;
+    // head branch of all 2 n_layer chains first, in one launch: it needs only d out / d att
+    {
+        const int64_t nh = 2 * n_layer;
+        std::vector<const float*> ho(nh), ha(nh), hw(3 * nh), hwo(nh), hwa(nh), hz(nh);
+        std::vector<float*> hd(nh), hg(nh), hp(nh);
+        for (int64_t k = 0; k < n_layer; ++k) {
+            const float* const* gp = gparams + k * NG;
+            const float* const* lp = lparams + k * NL;
+            const GlobalSaved s = carve_global(const_cast<float*>(saved) + k * (gs + ls), g);
+            const LocalSaved q = carve_local(const_cast<float*>(saved) + k * (gs + ls) + gs, g);
+            for (int side = 0; side < 2; ++side) {
+                const int64_t l = 2 * k + side;
+                const float* const* tp = side ? lp + LT : gp + GT;
+                ho[l] = d_outs + l * g.n, ha[l] = d_atts + l * g.n;
+                for (int i = 0; i < 3; ++i) hw[3 * l + i] = packed ? (side ? img[k].lt[7 + i] : img[k].gt[7 + i]) : tp[7 + i];
+                hwo[l] = tp[20], hwa[l] = tp[22];
+                hz[l] = side ? q.Z : s.Z;
+                hd[l] = side ? q.hdz : s.hdz, hg[l] = side ? q.gh : s.gh, hp[l] = side ? q.hp : s.hp;
+            }
+        }
+        CK(pamnet_node_heads_bwd_f32(nh, ho.data(), ha.data(), hw.data(), hwo.data(), hwa.data(), hz.data(), hd.data(),
+                                     hg.data(), hp.data(), g.n, pk, st));
+    }
     const float* d_xout = nullptr;        // nothing consumes the last layer's node features (models.py:196-224)
     float* dx_bufs[2] = {t.dxa, t.dxb};
     int flip = 0;
@@ -436,9 +471,8 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             const float* const* lp = lparams + k * NL;
             float* const* lg = lgrads + k * NL;
             const float* x_in = s.xout;           // input of the local layer = output of this pair's global layer
-            CK(pamnet_node_tail_bwd_f32(d_xout, d_outs + (2 * k + 1) * g.n, d_atts + (2 * k + 1) * g.n, g.n,
-                                        packed ? img[k].lt : lp + LT, lp[LT + 20], lp[LT + 22], q.Z, t.dZ, t.dx2, t.dresx,
-                                        t.head, nullptr, nullptr, nullptr, pk, st));
+            CK(pamnet_node_tail_main_bwd_f32(d_xout, q.gh, g.n, packed ? img[k].lt : lp + LT, q.Z, t.dZ, t.dx2, t.dresx, pk,
+                                             st));
             // d m_t = d x2[i] * q3 ,  d q3 = d x2[i] * m_t
             CK(pamnet_gather_mul2_f32(t.dmt, t.dq3, t.dx2, g.l_row, q.q3, q.mt, g.el, D, st));
             CK(pamnet_gather_mul_f32(t.ds, q.mnb, g.t_col, t.dmt, g.t_row, g.tp, D, st));       // d s   = m_nb[idx] * d m_t[e]
@@ -461,7 +495,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             CK(pamnet_node_pre_bwd_f32(t.dP, t.dx2, t.dresx, g.n, packed ? img[k].lh[4] : lp[0], packed ? img[k].lh : wpl,
                                        3 * D, 4, q.Zx1, t.dZx1, dx, pk, st));
             Jobs j;
-            tail_jobs(j, g, t.dZ, q.x2, q.Z, q.R, q.xout, lg + LT);
+            tail_jobs(j, g, t.dZ, q.hdz, q.x2, q.Z, q.R, q.xout, lg + LT);
             j.add(t.dZx1, x_in, 0, g.n, lg[0], D, lg[1]);
             j.add(t.dP, q.Zx1, 1, g.n, lg[2], 3 * D, nullptr);
             j.add(t.dP + pl, q.Zx1, 1, g.n, lg[4], 3 * D, nullptr);
@@ -473,7 +507,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             j.add(t.dq3, rbf_e, 0, g.el, lg[11], D, nullptr);
             j.add(t.dz2, q.z1, 1, g.tp, lg[8], D, lg[9]);
             j.add(t.dz1, e_sbf, 0, g.tp, lg[6], D, lg[7]);
-            CK(run_jobs(j, t.partial, g, t.head, lg[LT + 20], lg[LT + 22], lg[LT + 21], st));
+            CK(run_jobs(j, t.partial, g, q.hp, lg[LT + 20], lg[LT + 22], lg[LT + 21], st));
             d_xout = dx;
             flip ^= 1;
         }
@@ -482,9 +516,8 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             const float* const* gp = gparams + k * NG;
             float* const* gg = ggrads + k * NG;
             const float* x_in = (k == 0) ? x0 : carve_local(const_cast<float*>(saved) + (k - 1) * (gs + ls) + gs, g).xout;
-            CK(pamnet_node_tail_bwd_f32(d_xout, d_outs + (2 * k) * g.n, d_atts + (2 * k) * g.n, g.n,
-                                        packed ? img[k].gt : gp + GT, gp[GT + 20], gp[GT + 22], s.Z, t.dZ, t.dx2, t.dresx,
-                                        t.head, nullptr, nullptr, nullptr, pk, st));
+            CK(pamnet_node_tail_main_bwd_f32(d_xout, s.gh, g.n, packed ? img[k].gt : gp + GT, s.Z, t.dZ, t.dx2, t.dresx, pk,
+                                             st));
             CK(pamnet_global_edge_bwd_f32(t.dx2, g.g_row, g.eg, s.z, s.ea, gp[2] + 2 * D, 3 * D, gp[4], D, t.dz, t.dea,
                                           d_eg, acc, st));
             const int64_t pl = g.n * D;
@@ -500,13 +533,13 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             CK(pamnet_node_pre_bwd_f32(t.dP, t.dx2, t.dresx, g.n, packed ? img[k].gh[2] : gp[0], packed ? img[k].gh : wpg,
                                        3 * D, 2, s.Zx1, t.dZx1, dx, pk, st));
             Jobs j;
-            tail_jobs(j, g, t.dZ, s.x2, s.Z, s.R, s.xout, gg + GT);
+            tail_jobs(j, g, t.dZ, s.hdz, s.x2, s.Z, s.R, s.xout, gg + GT);
             j.add(t.dZx1, x_in, 0, g.n, gg[0], D, gg[1]);
             j.add(t.dP, s.Zx1, 1, g.n, gg[2], 3 * D, nullptr);
             j.add(t.dP + pl, s.Zx1, 1, g.n, gg[2] + D, 3 * D, nullptr);
             j.add(t.dz, e_g, 0, g.eg, gg[2] + 2 * D, 3 * D, gg[3]);
             j.add(t.dea, e_g, 0, g.eg, gg[4], D, nullptr);
-            CK(run_jobs(j, t.partial, g, t.head, gg[GT + 20], gg[GT + 22], gg[GT + 21], st));
+            CK(run_jobs(j, t.partial, g, s.hp, gg[GT + 20], gg[GT + 22], gg[GT + 21], st));
             d_xout = dx;
             flip ^= 1;
         }

@@ -381,7 +381,10 @@ __global__ __launch_bounds__(WG) void node_heads_fwd_kernel(HeadBatch hb, int64_
 
 // Backward of the chain.  Produces dZ_k for every layer (consumed by the batched weight-gradient kernel), d x2 (gradient
 // of the chain input), d res_x, and per-workgroup partial sums for the two head vectors.
-template <bool PACKED>
+// HEADS = false: the head branch was differentiated by node_heads_bwd_kernel (all layers in one launch at the start of
+// the backward: it only needs d out / d att, which the loss hands over for every layer at once); `d_out` then carries
+// its contribution to d x_out ([n][128]) and the chain starts at layer 6.
+template <bool PACKED, bool HEADS>
 __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restrict__ d_xout /* may be null */,
                                                             const float* __restrict__ d_out,
                                                             const float* __restrict__ d_att, int64_t n, TailParams p,
@@ -403,15 +406,19 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
     const Frag fr;
     const int c = fr.col();
 
+    constexpr int KTOP = HEADS ? 9 : 6;                       // first matrix of the backward chain
+    constexpr int NZ = HEADS ? 10 : 7;
     WFrag1 wf;
-    if constexpr (PACKED) load_wfrag1_img(wf, p.W[9]);
-    else load_wfrag1<true>(wf, p.W[9], fr.wc);
+    if constexpr (PACKED) load_wfrag1_img(wf, p.W[KTOP]);
+    else load_wfrag1<true>(wf, p.W[KTOP], fr.wc);
     const int sc4 = threadIdx.x & 31, sr = threadIdx.x >> 5;          // sweep coordinates: 512 threads = 16 rows x 32 float4
     const int64_t sg = row0 + sr;
     {
 #pragma unroll
-        for (int k = 0; k < 10; ++k) st_lds4(ZL + k * SLOT, sr, sc4, ldg4z(Z + (int64_t)k * plane, sg, n, DIM, sc4));
-        st_lds4(K, sr, sc4, d_xout ? ldg4z(d_xout, sg, n, DIM, sc4) : f4zero());
+        for (int k = 0; k < NZ; ++k) st_lds4(ZL + k * SLOT, sr, sc4, ldg4z(Z + (int64_t)k * plane, sg, n, DIM, sc4));
+        float4 kx = d_xout ? ldg4z(d_xout, sg, n, DIM, sc4) : f4zero();
+        if constexpr (!HEADS) kx = f4add(kx, ldg4z(d_out, sg, n, DIM, sc4));      // + the head branch's d x_out
+        st_lds4(K, sr, sc4, kx);
     }
     __syncthreads();
 
@@ -422,6 +429,7 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
         return z;
     };
 
+    if constexpr (HEADS) {
     // head-vector partials: sum_rows d_out * o3, sum_rows d_att * o3, sum_rows d_out  (o3 = SiLU(z9))
     {
         float4 so = f4zero(), sa = f4zero();
@@ -465,6 +473,19 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
         }
         __syncthreads();
     }
+    } else {
+        // dz6 = d r3 * SiLU'(z6), d r3 = d x_out (next layer + head branch) already in K
+        const f32x4 z6 = load_z(6);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rw = fr.row(r);
+            const int64_t g = row0 + rw;
+            const float dz = (g < n) ? K[rw * LDT + c] * dsilu(z6[r]) : 0.f;
+            D1[rw * LDT + c] = dz;
+            ZL[6 * SLOT + rw * LDT + c] = dz;
+        }
+        __syncthreads();
+    }
 
     // One backward step: v = dz_k * W_k (+ K) ; optionally K <- v, extra <- v ; then dz_{k-1} = v * SiLU'(z_{k-1}).
     // k == 0 ends the chain: v = d x2 (left in dst).
@@ -495,9 +516,11 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
         __syncthreads();
     };
 
-    back(D0, D1, 9, false, false, nullptr);        // d o2          -> dz8
-    back(D1, D0, 8, false, false, nullptr);        // d o1          -> dz7
-    back(D0, D1, 7, true, true, nullptr);          // d r3 = . + d x_out (kept)   -> dz6
+    if constexpr (HEADS) {
+        back(D0, D1, 9, false, false, nullptr);    // d o2          -> dz8
+        back(D1, D0, 8, false, false, nullptr);    // d o1          -> dz7
+        back(D0, D1, 7, true, true, nullptr);      // d r3 = . + d x_out (kept)   -> dz6
+    }
     back(D1, D0, 6, false, false, nullptr);        // d a5          -> dz5
     back(D0, D1, 5, true, true, nullptr);          // d r2 = . + d r3 (kept)      -> dz4
     back(D1, D0, 4, false, false, nullptr);        // d a3          -> dz3
@@ -508,9 +531,126 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
 
     if (sg < n) {
 #pragma unroll
-        for (int k = 0; k < 10; ++k) stg4(dZ + (int64_t)k * plane, sg, DIM, sc4, lds4(ZL + k * SLOT, sr, sc4));
+        for (int k = 0; k < NZ; ++k) stg4(dZ + (int64_t)k * plane, sg, DIM, sc4, lds4(ZL + k * SLOT, sr, sc4));
         stg4(d_x2, sg, DIM, sc4, lds4(D0, sr, sc4));
         stg4(d_resx, sg, DIM, sc4, lds4(EX, sr, sc4));
+    }
+}
+
+// Backward of the head branch of every layer in one launch (grid = (ceil(n/16), layers)): from d out / d att
+//   head partials (d w_out, d w_att, d b_out), dz9, dz8, dz7 (-> dZ3[l][0..2] for the weight gradients) and the branch's
+//   contribution to d x_out, g_head[l] = dz7 * W7.
+struct HeadBwdLayer {
+    const float* d_out;       // [n]
+    const float* d_att;       // [n]
+    const float* W[3];        // mlp_out matrices 7, 8, 9 (row-major, or transposed-orientation images when packed)
+    const float* w_out;
+    const float* w_att;
+    const float* Z;           // the layer's [10][n][128] pre-activation block (slots 7..9 read)
+    float* dZ3;               // [3][n][128]: dz7, dz8, dz9
+    float* g_head;            // [n][128]
+    float* head_partial;      // [ceil(n/16)][257]
+};
+struct HeadBwdBatch {
+    HeadBwdLayer l[MAX_HEAD_LAYERS];
+};
+
+template <bool PACKED>
+__global__ __launch_bounds__(TWG) void node_heads_bwd_kernel(HeadBwdBatch hb, int64_t n) {
+    __shared__ __attribute__((aligned(16))) float lds[5 * SLOT + 16 * 256 + 16];
+    float* D0 = lds;
+    float* D1 = lds + SLOT;
+    float* ZL = lds + 2 * SLOT;       // [3] z7, z8, z9, then dz7, dz8, dz9
+    float* red = lds + 5 * SLOT;
+    const HeadBwdLayer& hl = hb.l[blockIdx.y];
+    const int64_t row0 = (int64_t)blockIdx.x * BMN;
+    const int64_t plane = n * DIM;
+    const Frag fr;
+    const int c = fr.col();
+    WFrag1 wf;
+    if constexpr (PACKED) load_wfrag1_img(wf, hl.W[2]);
+    else load_wfrag1<true>(wf, hl.W[2], fr.wc);
+    const int sc4 = threadIdx.x & 31, sr = threadIdx.x >> 5;
+    const int64_t sg = row0 + sr;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st_lds4(ZL + k * SLOT, sr, sc4, ldg4z(hl.Z + (int64_t)(7 + k) * plane, sg, n, DIM, sc4));
+    __syncthreads();
+    auto load_z = [&](int k) {
+        f32x4 z;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[r] = ZL[k * SLOT + fr.row(r) * LDT + c];
+        return z;
+    };
+    {
+        float4 so = f4zero(), sa = f4zero();
+        float sb = 0.f;
+        if (sg < n) {
+            const float4 o3 = f4silu(lds4(ZL + 2 * SLOT, sr, sc4));
+            const float go = hl.d_out[sg], ga = hl.d_att[sg];
+            so = make_float4(go * o3.x, go * o3.y, go * o3.z, go * o3.w);
+            sa = make_float4(ga * o3.x, ga * o3.y, ga * o3.z, ga * o3.w);
+            sb = go;
+        }
+        float* mine = red + sr * 256;
+        *reinterpret_cast<float4*>(mine + 4 * sc4) = so;
+        *reinterpret_cast<float4*>(mine + 128 + 4 * sc4) = sa;
+        if (sc4 == 0) red[16 * 256 + sr] = sb;
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tot += red[q * 256 + threadIdx.x];
+            hl.head_partial[(int64_t)blockIdx.x * 257 + threadIdx.x] = tot;
+        } else if (threadIdx.x == 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += red[16 * 256 + q];
+            hl.head_partial[(int64_t)blockIdx.x * 257 + 256] = t;
+        }
+    }
+    {
+        const f32x4 z9 = load_z(2);
+        const float wo = hl.w_out[c], wa = hl.w_att[c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rw = fr.row(r);
+            const int64_t g = row0 + rw;
+            const float dz = (g < n) ? (hl.d_out[g] * wo + hl.d_att[g] * wa) * dsilu(z9[r]) : 0.f;
+            D0[rw * LDT + c] = dz;
+            ZL[2 * SLOT + rw * LDT + c] = dz;
+        }
+        __syncthreads();
+    }
+    // v = dz_k * W_k; k > 7: dz_{k-1} = v * SiLU'(z_{k-1}); k == 7: v = the branch's d x_out
+    auto back = [&](const float* in, float* dst, int k) {
+        f32x4 zn = {0.f, 0.f, 0.f, 0.f};
+        if (k > 7) zn = load_z(k - 8);
+        const f32x4 acc = mma_strip(in, wf);
+        if (k > 7) {
+            if constexpr (PACKED) load_wfrag1_img(wf, hl.W[k - 8]);
+            else load_wfrag1<true>(wf, hl.W[k - 8], fr.wc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rw = fr.row(r);
+            const int64_t g = row0 + rw;
+            if (k == 7) {
+                dst[rw * LDT + c] = acc[r];
+            } else {
+                const float dz = (g < n) ? acc[r] * dsilu(zn[r]) : 0.f;
+                dst[rw * LDT + c] = dz;
+                ZL[(k - 8) * SLOT + rw * LDT + c] = dz;
+            }
+        }
+        __syncthreads();
+    };
+    back(D0, D1, 9);          // -> dz8
+    back(D1, D0, 8);          // -> dz7
+    back(D0, D1, 7);          // -> g_head
+    if (sg < n) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) stg4(hl.dZ3 + (int64_t)k * plane, sg, DIM, sc4, lds4(ZL + k * SLOT, sr, sc4));
+        stg4(hl.g_head, sg, DIM, sc4, lds4(D1, sr, sc4));
     }
 }
 
@@ -670,16 +810,70 @@ extern "C" int pamnet_node_tail_bwd_f32(const float* d_xout, const float* d_out,
     hipStream_t st = as_stream(stream);
     const unsigned grid = (unsigned)ceil_div(n, BMN);
     if (packed)
-        hipLaunchKernelGGL(node_tail_bwd_kernel<true>, dim3(grid), dim3(TWG), 0, st, d_xout, d_out, d_att, n,
+        hipLaunchKernelGGL((node_tail_bwd_kernel<true, true>), dim3(grid), dim3(TWG), 0, st, d_xout, d_out, d_att, n,
                            make_tail(weights, nullptr, w_out, nullptr, w_att, 1), Z, dZ, d_x2, d_resx, head_partial);
     else
-        hipLaunchKernelGGL(node_tail_bwd_kernel<false>, dim3(grid), dim3(TWG), 0, st, d_xout, d_out, d_att, n,
+        hipLaunchKernelGGL((node_tail_bwd_kernel<false, true>), dim3(grid), dim3(TWG), 0, st, d_xout, d_out, d_att, n,
                            make_tail(weights, nullptr, w_out, nullptr, w_att, 0), Z, dZ, d_x2, d_resx, head_partial);
     PAMNET_LAUNCH_CHECK();
     if (d_wout || d_watt || d_bout) {      // all null: the caller reduces head_partial itself (pamnet_wgrad_batched_f32)
         if (!d_wout || !d_watt || !d_bout) return PAMNET_ENULL;
         hipLaunchKernelGGL(head_reduce_kernel, dim3(17), dim3(WG), 0, st, head_partial, (int)grid, d_wout, d_watt,
                            d_bout);
+        PAMNET_LAUNCH_CHECK();
+    }
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_node_tail_main_bwd_f32(const float* d_xout, const float* g_head, int64_t n,
+                                             const float* const* weights, const float* Z, float* dZ, float* d_x2,
+                                             float* d_resx, int32_t packed, pamnet_stream_t stream) {
+    if (n < 0) return PAMNET_EINVAL;
+    if (n == 0) return PAMNET_OK;
+    if (!g_head || !weights || !Z || !dZ || !d_x2 || !d_resx) return PAMNET_ENULL;
+    for (int k = 0; k < 7; ++k)
+        if (!weights[k]) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const unsigned grid = (unsigned)ceil_div(n, BMN);
+    TailParams tp{};
+    for (int k = 0; k < 7; ++k) tp.W[k] = weights[k];
+    tp.packed = packed ? 1 : 0;
+    if (packed)
+        hipLaunchKernelGGL((node_tail_bwd_kernel<true, false>), dim3(grid), dim3(TWG), 0, st, d_xout, g_head,
+                           (const float*)nullptr, n, tp, Z, dZ, d_x2, d_resx, (float*)nullptr);
+    else
+        hipLaunchKernelGGL((node_tail_bwd_kernel<false, false>), dim3(grid), dim3(TWG), 0, st, d_xout, g_head,
+                           (const float*)nullptr, n, tp, Z, dZ, d_x2, d_resx, (float*)nullptr);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_node_heads_bwd_f32(int64_t n_layers, const float* const* d_out, const float* const* d_att,
+                                         const float* const* weights, const float* const* w_out,
+                                         const float* const* w_att, const float* const* Z, float* const* dZ3,
+                                         float* const* g_head, float* const* head_partial, int64_t n, int32_t packed,
+                                         pamnet_stream_t stream) {
+    if (n < 0 || n_layers < 0) return PAMNET_EINVAL;
+    if (n == 0 || n_layers == 0) return PAMNET_OK;
+    if (!d_out || !d_att || !weights || !w_out || !w_att || !Z || !dZ3 || !g_head || !head_partial) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    for (int64_t l0 = 0; l0 < n_layers; l0 += MAX_HEAD_LAYERS) {
+        const int nl = (int)(n_layers - l0 < MAX_HEAD_LAYERS ? n_layers - l0 : MAX_HEAD_LAYERS);
+        HeadBwdBatch hb{};
+        for (int i = 0; i < nl; ++i) {
+            const int64_t l = l0 + i;
+            HeadBwdLayer& h = hb.l[i];
+            h.d_out = d_out[l], h.d_att = d_att[l];
+            for (int k = 0; k < 3; ++k) h.W[k] = weights[3 * l + k];
+            h.w_out = w_out[l], h.w_att = w_att[l], h.Z = Z[l];
+            h.dZ3 = dZ3[l], h.g_head = g_head[l], h.head_partial = head_partial[l];
+            if (!h.d_out || !h.d_att || !h.W[0] || !h.W[1] || !h.W[2] || !h.w_out || !h.w_att || !h.Z || !h.dZ3 ||
+                !h.g_head || !h.head_partial)
+                return PAMNET_ENULL;
+        }
+        const dim3 grid((unsigned)ceil_div(n, BMN), (unsigned)nl);
+        if (packed) hipLaunchKernelGGL(node_heads_bwd_kernel<true>, grid, dim3(TWG), 0, st, hb, n);
+        else hipLaunchKernelGGL(node_heads_bwd_kernel<false>, grid, dim3(TWG), 0, st, hb, n);
         PAMNET_LAUNCH_CHECK();
     }
     return PAMNET_OK;
