@@ -225,7 +225,7 @@ def test_baseline_config_properties(dev):
 @pytest.mark.parametrize('case', ['pdbbind_d128_l3', 'qm9s_d128_l2', 'qm9_d128_l6_b16', 'qm9_ragged_d128_l2',
                                   'qm9s_ragged_d128_l2', 'qm9_no_edges_d128_l2', 'qm9_d128_l1',
                                   'pdbbind_d64_l3', 'qm9s_d64_l2', 'qm9_d16_l6_b16', 'qm9_ragged_d64_l2',
-                                  'qm9s_ragged_d16_l2', 'qm9_no_edges_d16_l2', 'qm9_d64_l1'])
+                                  'qm9s_ragged_d16_l2', 'qm9_no_edges_d16_l2', 'qm9_d64_l1', 'qm9_d128_l9'])
 def test_fused_engine_fresh_inputs_vs_oracle(dev, case):
     """dim=128 (fused MFMA engine) and dim=16/64 (narrow-width row kernels) on fresh seeded inputs vs the CPU oracle:
     forward (fp32+fp64 oracle) and the fp64 loss gradient, for the PDBbind branch (init_linear, +-1 pooling signs,
@@ -244,8 +244,10 @@ def test_fused_engine_fresh_inputs_vs_oracle(dev, case):
         if 'no_edges' in case:
             b = synth.collate([dict(x=np.array([k % 5], np.float32), pos=np.array([[20.0 * k, 0, 0]], np.float32),
                                     edge_index=np.zeros((2, 0), np.int64), y=np.float32(k)) for k in range(3)])
-    elif case.endswith('_l1'):                  # single layer pair: no fused next-layer head, no layer-to-layer hand-over
-        cfg = models.Config(dataset='QM9', dim=dim, n_layer=1, cutoff_l=5.0, cutoff_g=5.0)
+    elif case.endswith('_l1') or case.endswith('_l9'):
+        # single layer pair: no fused next-layer head, no layer-to-layer hand-over; nine pairs: 18 chains = two launches of
+        # the batched head kernels (16 chains per launch)
+        cfg = models.Config(dataset='QM9', dim=dim, n_layer=int(case[-1]), cutoff_l=5.0, cutoff_g=5.0)
         b = synth.qm9_batch(19, 0, 5)
     elif case.startswith('pdbbind'):
         cfg = models.Config(dataset='PDBbind', dim=dim, n_layer=3, cutoff_l=2.0, cutoff_g=6.0)
