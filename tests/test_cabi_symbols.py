@@ -40,6 +40,17 @@ def test_no_cpu_fallback():
     from pamnet_amd import graph as G
     with pytest.raises(RuntimeError):
         G.exclusive_scan(torch.zeros(4, dtype=torch.int32))
+    # the narrow-width operators and a whole narrow model likewise (no silent torch path for CPU tensors)
+    from pamnet_amd import narrow
+    lin = torch.nn.Linear(16, 16)
+    assert not narrow.supported(torch.zeros(3, 16), 16)
+    with pytest.raises(RuntimeError):
+        narrow.linear(torch.zeros(3, 16), lin)
+    import models
+    from pamnet_amd import synth
+    model = models.PAMNet(models.Config(dataset='QM9', dim=16, n_layer=1, cutoff_l=5.0, cutoff_g=5.0))
+    with pytest.raises(RuntimeError):
+        model(synth.qm9_batch(1, 0, 2))
 
 
 def test_product_does_not_import_oracle():
