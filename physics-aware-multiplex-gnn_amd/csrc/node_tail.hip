@@ -312,11 +312,13 @@ struct HeadBatch {
 
 template <bool PACKED>
 __global__ __launch_bounds__(WG) void node_heads_fwd_kernel(HeadBatch hb, int64_t n) {
-    __shared__ __attribute__((aligned(16))) float lds[6 * SLOT];
+    // Three LDS tiles only: unlike the chains, this launch has several workgroups per CU to hide a store behind, so the
+    // pre-activations go to memory straight from the accumulators (after the next weight slice has been requested:
+    // vmcnt retires in order, the prefetch does not wait for them) -- 25 KB per workgroup instead of 50.
+    __shared__ __attribute__((aligned(16))) float lds[3 * SLOT];
     float* X = lds;
     float* A = lds + SLOT;
     float* B = lds + 2 * SLOT;
-    float* ZL = lds + 3 * SLOT;               // [3] z7, z8, z9
     const HeadLayer& hl = hb.l[blockIdx.y];
     const int64_t row0 = (int64_t)blockIdx.x * BMN;
     const int64_t plane = n * DIM;
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(WG) void node_heads_fwd_kernel(HeadBatch hb, int64_
         acc_zero<1>(acc);
         mma_tile_frag<1>(in, wf, acc);
         if (Wnext) load_w<PACKED>(wf, Wnext, DIM, wc);
-        float* zk = ZL + k * SLOT;
+        float* zg = hl.Z ? hl.Z + (int64_t)(7 + k) * plane : nullptr;
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) {
             const int c = wc + 16 * n2 + r16;
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(WG) void node_heads_fwd_kernel(HeadBatch hb, int64_
                 const int rw = 4 * kg + r;
                 const float z = acc[0][n2][r] + bv.v[n2];
                 dst[rw * LDT + c] = silu(z);
-                zk[rw * LDT + c] = z;
+                if (zg && row0 + rw < n) zg[(row0 + rw) * DIM + c] = z;
             }
         }
         __syncthreads();
@@ -349,14 +351,6 @@ __global__ __launch_bounds__(WG) void node_heads_fwd_kernel(HeadBatch hb, int64_
     layer(X, A, 0, hl.W[1]);                  // o1
     layer(A, B, 1, hl.W[2]);                  // o2
     layer(B, A, 2, nullptr);                  // o3 -> A
-    if (hl.Z) {
-        sweep_rows<BMN>([&](int r, int c4) {
-            const int64_t g = row0 + r;
-            if (g >= n) return;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) stg4(hl.Z + (int64_t)(7 + k) * plane, g, DIM, c4, lds4(ZL + k * SLOT, r, c4));
-        });
-    }
     {
         const int r = threadIdx.x >> 4, part = threadIdx.x & 15;
         float so = 0.f, sa = 0.f;
