@@ -310,49 +310,58 @@ struct HeadBatch {
     HeadLayer l[MAX_HEAD_LAYERS];
 };
 
-template <bool PACKED>
+// HM 16-row tiles per workgroup share every weight slice (3 x 64 KB per workgroup from L2).  Measured at the QM9 batch
+// (1 716 tiles): HM = 1 39.6 us, 2 42.3 us, 4 54.4 us -- neither the L2 weight stream nor occupancy (25 vs 50 KB of LDS:
+// no change) bounds it, the three dependent GEMMs per tile do; PAMNET_HEADS_TILES=2|4 selects the wider forms.
+template <bool PACKED, int HM>
 __global__ __launch_bounds__(WG) void node_heads_fwd_kernel(HeadBatch hb, int64_t n) {
-    // Three LDS tiles only: unlike the chains, this launch has several workgroups per CU to hide a store behind, so the
-    // pre-activations go to memory straight from the accumulators (after the next weight slice has been requested:
-    // vmcnt retires in order, the prefetch does not wait for them) -- 25 KB per workgroup instead of 50.
-    __shared__ __attribute__((aligned(16))) float lds[3 * SLOT];
+    // Unlike the chains, this launch has several workgroups per CU to hide a store behind, so the pre-activations go to
+    // memory straight from the accumulators (after the next weight slice has been requested: vmcnt retires in order,
+    // the prefetch does not wait for them).
+    constexpr int BM = 16 * HM;
+    constexpr int HSLOT = BM * LDT;
+    __shared__ __attribute__((aligned(16))) float lds[3 * HSLOT];
     float* X = lds;
-    float* A = lds + SLOT;
-    float* B = lds + 2 * SLOT;
+    float* A = lds + HSLOT;
+    float* B = lds + 2 * HSLOT;
     const HeadLayer& hl = hb.l[blockIdx.y];
-    const int64_t row0 = (int64_t)blockIdx.x * BMN;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
     const int64_t plane = n * DIM;
     const int lane = threadIdx.x & 63, r16 = lane & 15, kg = lane >> 4;
     const int wc = (threadIdx.x >> 6) * 32;
     WFrag wf;
     load_w<PACKED>(wf, hl.W[0], DIM, wc);
-    sweep_rows<BMN>([&](int r, int c4) { st_lds4(X, r, c4, ldg4z(hl.x_out, row0 + r, n, DIM, c4)); });
+    sweep_rows<BM>([&](int r, int c4) { st_lds4(X, r, c4, ldg4z(hl.x_out, row0 + r, n, DIM, c4)); });
     __syncthreads();
     auto layer = [&](const float* in, float* dst, int k, const float* Wnext) {
         const Bias2 bv = load_bias2(hl.b[k], wc);
-        f32x4 acc[1][2];
-        acc_zero<1>(acc);
-        mma_tile_frag<1>(in, wf, acc);
+        f32x4 acc[HM][2];
+        acc_zero<HM>(acc);
+        mma_tile_frag<HM>(in, wf, acc);
         if (Wnext) load_w<PACKED>(wf, Wnext, DIM, wc);
         float* zg = hl.Z ? hl.Z + (int64_t)(7 + k) * plane : nullptr;
 #pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2) {
-            const int c = wc + 16 * n2 + r16;
+        for (int m = 0; m < HM; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rw = 4 * kg + r;
-                const float z = acc[0][n2][r] + bv.v[n2];
-                dst[rw * LDT + c] = silu(z);
-                if (zg && row0 + rw < n) zg[(row0 + rw) * DIM + c] = z;
+            for (int n2 = 0; n2 < 2; ++n2) {
+                const int c = wc + 16 * n2 + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rw = 16 * m + 4 * kg + r;
+                    const float z = acc[m][n2][r] + bv.v[n2];
+                    dst[rw * LDT + c] = silu(z);
+                    if (zg && row0 + rw < n) zg[(row0 + rw) * DIM + c] = z;
+                }
             }
-        }
         __syncthreads();
     };
     layer(X, A, 0, hl.W[1]);                  // o1
     layer(A, B, 1, hl.W[2]);                  // o2
     layer(B, A, 2, nullptr);                  // o3 -> A
-    {
-        const int r = threadIdx.x >> 4, part = threadIdx.x & 15;
+    // heads: 16 lanes per row, 8 columns each, butterfly over the 16-lane group; 16 rows per pass
+#pragma unroll
+    for (int m = 0; m < HM; ++m) {
+        const int r = 16 * m + (threadIdx.x >> 4), part = threadIdx.x & 15;
         float so = 0.f, sa = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -784,9 +793,20 @@ extern "C" int pamnet_node_heads_fwd_f32(int64_t n_layers, const float* const* x
                 !h.w_att || !h.out || !h.att)
                 return PAMNET_ENULL;
         }
-        const dim3 grid((unsigned)ceil_div(n, BMN), (unsigned)nl);
-        if (packed) hipLaunchKernelGGL(node_heads_fwd_kernel<true>, grid, dim3(WG), 0, st, hb, n);
-        else hipLaunchKernelGGL(node_heads_fwd_kernel<false>, grid, dim3(WG), 0, st, hb, n);
+        static const int hm = [] { const char* e = getenv("PAMNET_HEADS_TILES"); return e ? atoi(e) : 1; }();
+        if (hm == 4) {
+            const dim3 grid((unsigned)ceil_div(n, 64), (unsigned)nl);
+            if (packed) hipLaunchKernelGGL((node_heads_fwd_kernel<true, 4>), grid, dim3(WG), 0, st, hb, n);
+            else hipLaunchKernelGGL((node_heads_fwd_kernel<false, 4>), grid, dim3(WG), 0, st, hb, n);
+        } else if (hm == 2) {
+            const dim3 grid((unsigned)ceil_div(n, 32), (unsigned)nl);
+            if (packed) hipLaunchKernelGGL((node_heads_fwd_kernel<true, 2>), grid, dim3(WG), 0, st, hb, n);
+            else hipLaunchKernelGGL((node_heads_fwd_kernel<false, 2>), grid, dim3(WG), 0, st, hb, n);
+        } else {
+            const dim3 grid((unsigned)ceil_div(n, BMN), (unsigned)nl);
+            if (packed) hipLaunchKernelGGL((node_heads_fwd_kernel<true, 1>), grid, dim3(WG), 0, st, hb, n);
+            else hipLaunchKernelGGL((node_heads_fwd_kernel<false, 1>), grid, dim3(WG), 0, st, hb, n);
+        }
         PAMNET_LAUNCH_CHECK();
     }
     return PAMNET_OK;
