@@ -222,6 +222,33 @@ def test_baseline_config_properties(dev):
 
 
 @pytest.mark.gpu
+def test_rna_baseline_config_properties(dev):
+    """BASELINE configs[4] (RNA-Puzzles schema, dim=16, n_layer=1, 8 graphs of 800-3900 nodes, kNN global graph) at
+    full size: graphs are independent units (a graph's score does not depend on what it is batched with, in any order),
+    scores are invariant to rigid motion, and the whole forward is run-to-run bitwise deterministic."""
+    import models
+    from pamnet_amd import synth
+    torch.manual_seed(0)
+    cfg = models.Config(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
+    model = models.PAMNet(cfg).to(dev).eval()
+    graphs = [synth.rna_chain(2, i) for i in range(8)]
+    with torch.no_grad():
+        full = model(synth.collate(graphs).to(dev))
+        assert full.shape == (8,) and torch.isfinite(full).all()
+        assert torch.equal(full, model(synth.collate(graphs).to(dev)))
+        perm = [5, 2, 7, 0, 3, 6, 1, 4]
+        shuf = model(synth.collate([graphs[i] for i in perm]).to(dev))
+        assert maxnorm_err(shuf.cpu().numpy(), full.cpu().numpy()[perm]) < 2e-6
+        for i in (1, 4):                                   # the smallest graphs of the batch, alone
+            one = model(synth.collate([graphs[i]]).to(dev))
+            assert maxnorm_err(one.cpu().numpy(), full.cpu().numpy()[i:i + 1]) < 2e-6
+        rot = torch.linalg.qr(torch.randn(3, 3))[0]
+        moved = synth.collate(graphs)
+        moved.x = torch.cat([moved.x[:, :3] @ rot + torch.tensor([11.0, -4.0, 2.5]), moved.x[:, 3:]], 1)
+        assert maxnorm_err(model(moved.to(dev)).cpu().numpy(), full.cpu().numpy()) < 2e-4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('case', ['pdbbind_d128_l3', 'qm9s_d128_l2', 'qm9_d128_l6_b16', 'qm9_ragged_d128_l2',
                                   'qm9s_ragged_d128_l2', 'qm9_no_edges_d128_l2', 'qm9_d128_l1',
                                   'pdbbind_d64_l3', 'qm9s_d64_l2', 'qm9_d16_l6_b16', 'qm9_ragged_d64_l2',
