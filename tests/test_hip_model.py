@@ -222,6 +222,42 @@ def test_baseline_config_properties(dev):
 
 
 @pytest.mark.gpu
+def test_pdbbind_baseline_config_properties(dev):
+    """BASELINE configs[3] (PDBbind schema, dim=128, n_layer=3, 32 complexes, ~19 k nodes, ~0.7 M global edges) at full
+    size: complexes are independent units (outputs and, through the loss, parameter gradients of the batch equal those
+    accumulated over its four 8-complex shards) and the step is run-to-run bitwise deterministic.  The pooled output
+    is complex - pocket - ligand (a ~1000x cancellation), so it is compared relative to the summed magnitude."""
+    import models
+    from pamnet_amd import synth
+    torch.manual_seed(0)
+    cfg = models.Config(dataset='PDBbind', dim=128, n_layer=3, cutoff_l=2.0, cutoff_g=6.0)
+    model = models.PAMNet(cfg).to(dev)
+    graphs = [synth.pdbbind_complex(1, i) for i in range(32)]
+
+    def run(gs, scale):
+        b = synth.collate(gs).to(dev)
+        out = model(b)
+        (torch.nn.functional.l1_loss(out, b.y, reduction='sum') * scale).backward()
+        return out.detach()
+
+    model.zero_grad()
+    full = run(graphs, 1.0 / 32)
+    batch_ids = synth.collate(graphs).batch.to(dev)
+    mag = float(torch.zeros(32, device=dev).index_add_(0, batch_ids, model._node_out.detach().abs()).max())
+    g_full = [p.grad.clone() for p in model.parameters() if p.grad is not None]
+    model.zero_grad()
+    again = run(graphs, 1.0 / 32)
+    assert torch.equal(full, again)
+    assert all(torch.equal(a, p.grad) for a, p in zip(g_full, [p for p in model.parameters() if p.grad is not None]))
+    model.zero_grad()
+    parts = torch.cat([run(graphs[8 * i:8 * i + 8], 1.0 / 32) for i in range(4)])
+    assert float((parts - full).abs().max()) < 2e-6 * mag      # relative to the summed per-complex magnitude
+    for a, p in zip(g_full, [p for p in model.parameters() if p.grad is not None]):
+        if a.numel() > 1:                                  # scalar W_out.bias: signed-sum cancellation (see above)
+            assert maxnorm_err(p.grad.cpu().numpy(), a.cpu().numpy()) < 5e-5
+
+
+@pytest.mark.gpu
 def test_rna_baseline_config_properties(dev):
     """BASELINE configs[4] (RNA-Puzzles schema, dim=16, n_layer=1, 8 graphs of 800-3900 nodes, kNN global graph) at
     full size: graphs are independent units (a graph's score does not depend on what it is batched with, in any order),
