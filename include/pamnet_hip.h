@@ -191,6 +191,13 @@ int pamnet_node_heads_bwd_f32(int64_t n_layers, const float* const* d_out, const
 int pamnet_node_tail_main_bwd_f32(const float* d_xout, const float* g_head, int64_t n, const float* const* weights,
                                   const float* Z, float* dZ, float* d_x2, float* d_resx, int32_t packed,
                                   pamnet_stream_t stream);
+/* pamnet_node_pre_bwd_f32 (backward of a layer's head: dP [nblk][n][128], d x1_direct, d_add -> dZx1 and d x) fused
+ * with pamnet_node_tail_main_bwd_f32 of the chain that produced that layer's input: the head's d x becomes the chain's
+ * d x_out on chip.  All weights are transposed-orientation images (pamnet_pack_weights_f32). */
+int pamnet_node_pre_tail_bwd_f32(const float* dP, const float* dx1_direct, const float* d_add, int64_t n,
+                                 const float* Wx1, const float* const* wp, int64_t nblk, const float* Zx1, float* dZx1,
+                                 const float* g_head, const float* const* weights, const float* Z, float* dZ,
+                                 float* d_x2, float* d_resx, pamnet_stream_t stream);
 /* Fragment-ordered weight images for the node chains: n (<= 192) 128x128 matrices (row stride ld[i]) -> images[i*16384..],
  * transposed = 0 for the forward (Y = X W^T), 1 for the backward (Y = X W).  With packed != 0 the `weights` (and, in the
  * forward, next_Wx1 / next_wp) arguments of node_tail_fwd / node_tail_bwd, and Wx1 / wp of node_pre_bwd (transposed

@@ -86,7 +86,7 @@ inline LocalSaved carve_local(float* p, const Graph& g) {
 // temp arena carving (forward and backward share it; the backward needs more)
 struct Temp {
     float *x1, *P, *msg, *mji;                                         // forward
-    float *dZ, *dx2, *dresx, *head, *dz, *dea, *dP, *dZx1, *dxa, *dxb;    // backward (global + shared)
+    float *dZ, *dZ2, *dx2, *dresx, *head, *dz, *dea, *dP, *dZx1, *dxa, *dxb;    // backward (global + shared)
     float *dzji, *dzkj, *dq2, *dmt, *dq3, *dmnb, *ds, *dz1, *dz2;      // backward (local)
     float* partial;
 };
@@ -105,7 +105,7 @@ inline int64_t temp_floats(const Graph& g) {
     const int64_t nd = al(g.n * D), gd = al(g.eg * D), ld = al(g.el * D), td = al(g.tp * D);
     int64_t t = 0;
     t += nd + 4 * nd + gd + ld;                                        // x1 P msg mji
-    t += 10 * nd + nd + nd + al(((g.n + 15) / 16) * 257) + gd + gd + 4 * nd + nd + nd + nd;
+    t += 10 * nd + 7 * nd + nd + nd + al(((g.n + 15) / 16) * 257) + gd + gd + 4 * nd + nd + nd + nd;
     t += 6 * ld + 3 * td;
     t += wgrad_floats(g);
     return t;
@@ -119,6 +119,8 @@ inline Temp carve_temp(float* p, const Graph& g) {
     t.msg = p; p += gd;
     t.mji = p; p += ld;
     t.dZ = p; p += 10 * nd;
+    t.dZ2 = p; p += 7 * nd;      // second chain-gradient buffer: a fused head+chain launch writes the next chain's dZ
+                                 // while the previous chain's is still waiting for its weight-gradient launch
     t.dx2 = p; p += nd;
     t.dresx = p; p += nd;
     t.head = p; p += al(((g.n + 15) / 16) * 257);
@@ -459,20 +461,35 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
         CK(pamnet_node_heads_bwd_f32(nh, ho.data(), ha.data(), hw.data(), hwo.data(), hwa.data(), hz.data(), hd.data(),
                                      hg.data(), hp.data(), g.n, pk, st));
     }
+    // Chain backward launches.  With packed weights the backward of a layer's head (node_pre_bwd) is fused into the
+    // backward of the chain that produced that layer's input (same row tiles, the head's d x stays on chip): per layer
+    // pair  [chain L_k] local edges [head L_k + chain G_k] wgrad L_k  global edges [head G_k + chain L_{k-1}] wgrad G_k.
+    // The chain gradients alternate between two buffers because a fused launch writes the next chain's dZ before the
+    // previous chain's weight-gradient launch (which also needs that launch's dZx1) has consumed its own.
+    const bool fuse = packed;
     const float* d_xout = nullptr;        // nothing consumes the last layer's node features (models.py:196-224)
     float* dx_bufs[2] = {t.dxa, t.dxb};
-    int flip = 0;
+    float* dz_bufs[2] = {t.dZ, t.dZ2};
+    int flip = 0, zflip = 0;
+    float* dz_local = dz_bufs[zflip];     // dZ of the local chain of the current pair
+    if (fuse) {
+        const LocalSaved ql = carve_local(const_cast<float*>(saved) + (n_layer - 1) * (gs + ls) + gs, g);
+        CK(pamnet_node_tail_main_bwd_f32(nullptr, ql.gh, g.n, img[n_layer - 1].lt, ql.Z, dz_local, t.dx2, t.dresx, pk, st));
+    }
     for (int64_t k = n_layer - 1; k >= 0; --k) {
         const GlobalSaved s = carve_global(const_cast<float*>(saved) + k * (gs + ls), g);
         const LocalSaved q = carve_local(const_cast<float*>(saved) + k * (gs + ls) + gs, g);
         const int acc = (k != n_layer - 1) ? 1 : 0;
+        float* dz_global = nullptr;
         // ================= local layer backward
         {
             const float* const* lp = lparams + k * NL;
             float* const* lg = lgrads + k * NL;
             const float* x_in = s.xout;           // input of the local layer = output of this pair's global layer
-            CK(pamnet_node_tail_main_bwd_f32(d_xout, q.gh, g.n, packed ? img[k].lt : lp + LT, q.Z, t.dZ, t.dx2, t.dresx, pk,
-                                             st));
+            if (!fuse) {
+                dz_local = t.dZ;
+                CK(pamnet_node_tail_main_bwd_f32(d_xout, q.gh, g.n, lp + LT, q.Z, dz_local, t.dx2, t.dresx, pk, st));
+            }
             // d m_t = d x2[i] * q3 ,  d q3 = d x2[i] * m_t
             CK(pamnet_gather_mul2_f32(t.dmt, t.dq3, t.dx2, g.l_row, q.q3, q.mt, g.el, D, st));
             CK(pamnet_gather_mul_f32(t.ds, q.mnb, g.t_col, t.dmt, g.t_row, g.tp, D, st));       // d s   = m_nb[idx] * d m_t[e]
@@ -490,12 +507,21 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 const int32_t* sr[4] = {g.l_ptr, g.l_ptr, g.lT_ptr, g.lT_ptr};
                 CK(pamnet_segment_sum_multi_f32(4, so, sa, sp, sr, g.n, D, st));
             }
-            const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
-            float* dx = dx_bufs[flip];
-            CK(pamnet_node_pre_bwd_f32(t.dP, t.dx2, t.dresx, g.n, packed ? img[k].lh[4] : lp[0], packed ? img[k].lh : wpl,
-                                       3 * D, 4, q.Zx1, t.dZx1, dx, pk, st));
+            if (fuse) {
+                // head of the local layer + the global chain of this pair
+                zflip ^= 1;
+                dz_global = dz_bufs[zflip];
+                CK(pamnet_node_pre_tail_bwd_f32(t.dP, t.dx2, t.dresx, g.n, img[k].lh[4], img[k].lh, 4, q.Zx1, t.dZx1, s.gh,
+                                                img[k].gt, s.Z, dz_global, t.dx2, t.dresx, st));
+            } else {
+                const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
+                float* dx = dx_bufs[flip];
+                CK(pamnet_node_pre_bwd_f32(t.dP, t.dx2, t.dresx, g.n, lp[0], wpl, 3 * D, 4, q.Zx1, t.dZx1, dx, pk, st));
+                d_xout = dx;
+                flip ^= 1;
+            }
             Jobs j;
-            tail_jobs(j, g, t.dZ, q.hdz, q.x2, q.Z, q.R, q.xout, lg + LT);
+            tail_jobs(j, g, dz_local, q.hdz, q.x2, q.Z, q.R, q.xout, lg + LT);
             j.add(t.dZx1, x_in, 0, g.n, lg[0], D, lg[1]);
             j.add(t.dP, q.Zx1, 1, g.n, lg[2], 3 * D, nullptr);
             j.add(t.dP + pl, q.Zx1, 1, g.n, lg[4], 3 * D, nullptr);
@@ -508,16 +534,16 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             j.add(t.dz2, q.z1, 1, g.tp, lg[8], D, lg[9]);
             j.add(t.dz1, e_sbf, 0, g.tp, lg[6], D, lg[7]);
             CK(run_jobs(j, t.partial, g, q.hp, lg[LT + 20], lg[LT + 22], lg[LT + 21], st));
-            d_xout = dx;
-            flip ^= 1;
         }
         // ================= global layer backward
         {
             const float* const* gp = gparams + k * NG;
             float* const* gg = ggrads + k * NG;
             const float* x_in = (k == 0) ? x0 : carve_local(const_cast<float*>(saved) + (k - 1) * (gs + ls) + gs, g).xout;
-            CK(pamnet_node_tail_main_bwd_f32(d_xout, s.gh, g.n, packed ? img[k].gt : gp + GT, s.Z, t.dZ, t.dx2, t.dresx, pk,
-                                             st));
+            if (!fuse) {
+                dz_global = t.dZ;
+                CK(pamnet_node_tail_main_bwd_f32(d_xout, s.gh, g.n, gp + GT, s.Z, dz_global, t.dx2, t.dresx, pk, st));
+            }
             CK(pamnet_global_edge_bwd_f32(t.dx2, g.g_row, g.eg, s.z, s.ea, gp[2] + 2 * D, 3 * D, gp[4], D, t.dz, t.dea,
                                           d_eg, acc, st));
             const int64_t pl = g.n * D;
@@ -528,20 +554,29 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 const int32_t* sr[2] = {g.g_ptr, g.gT_ptr};
                 CK(pamnet_segment_sum_multi_f32(2, so, sa, sp, sr, g.n, D, st));
             }
-            const float* wpg[2] = {gp[2], gp[2] + D};
-            float* dx = (k == 0) ? d_x0 : dx_bufs[flip];
-            CK(pamnet_node_pre_bwd_f32(t.dP, t.dx2, t.dresx, g.n, packed ? img[k].gh[2] : gp[0], packed ? img[k].gh : wpg,
-                                       3 * D, 2, s.Zx1, t.dZx1, dx, pk, st));
+            if (fuse && k > 0) {
+                // head of the global layer + the local chain of the previous pair
+                const LocalSaved qp = carve_local(const_cast<float*>(saved) + (k - 1) * (gs + ls) + gs, g);
+                zflip ^= 1;
+                dz_local = dz_bufs[zflip];
+                CK(pamnet_node_pre_tail_bwd_f32(t.dP, t.dx2, t.dresx, g.n, img[k].gh[2], img[k].gh, 2, s.Zx1, t.dZx1, qp.gh,
+                                                img[k - 1].lt, qp.Z, dz_local, t.dx2, t.dresx, st));
+            } else {
+                const float* wpg[2] = {gp[2], gp[2] + D};
+                float* dx = (k == 0) ? d_x0 : dx_bufs[flip];
+                CK(pamnet_node_pre_bwd_f32(t.dP, t.dx2, t.dresx, g.n, packed ? img[k].gh[2] : gp[0],
+                                           packed ? img[k].gh : wpg, 3 * D, 2, s.Zx1, t.dZx1, dx, pk, st));
+                d_xout = dx;
+                flip ^= 1;
+            }
             Jobs j;
-            tail_jobs(j, g, t.dZ, s.hdz, s.x2, s.Z, s.R, s.xout, gg + GT);
+            tail_jobs(j, g, dz_global, s.hdz, s.x2, s.Z, s.R, s.xout, gg + GT);
             j.add(t.dZx1, x_in, 0, g.n, gg[0], D, gg[1]);
             j.add(t.dP, s.Zx1, 1, g.n, gg[2], 3 * D, nullptr);
             j.add(t.dP + pl, s.Zx1, 1, g.n, gg[2] + D, 3 * D, nullptr);
             j.add(t.dz, e_g, 0, g.eg, gg[2] + 2 * D, 3 * D, gg[3]);
             j.add(t.dea, e_g, 0, g.eg, gg[4], D, nullptr);
             CK(run_jobs(j, t.partial, g, s.hp, gg[GT + 20], gg[GT + 22], gg[GT + 21], st));
-            d_xout = dx;
-            flip ^= 1;
         }
         if (layer_done && layer_done[k]) {
             HK(hipEventRecord(reinterpret_cast<hipEvent_t>(layer_done[k]), as_stream(st)));

@@ -387,13 +387,30 @@ __global__ __launch_bounds__(WG) void node_heads_fwd_kernel(HeadBatch hb, int64_
 // HEADS = false: the head branch was differentiated by node_heads_bwd_kernel (all layers in one launch at the start of
 // the backward: it only needs d out / d att, which the loss hands over for every layer at once); `d_out` then carries
 // its contribution to d x_out ([n][128]) and the chain starts at layer 6.
-template <bool PACKED, bool HEADS>
+// PRE = true (packed weights, HEADS = false): the kernel first runs the backward of the NEXT layer's head on the same
+// row tile (what node_pre_bwd_kernel does: d x1 = sum_b dP_b Wp_b + d x1_direct, dz_x1 = d x1 * SiLU'(z_x1),
+// d x = dz_x1 Wx1 + d_add) and feeds its d x straight into this chain as d x_out -- the two kernels ran back to back on
+// the same tiles with a [n,128] round trip and a launch between them.
+struct PreBwd {
+    const float* dP;          // [nblk][n][128]
+    const float* wp[4];       // transposed-orientation images of the projection blocks
+    const float* Wx1;         // transposed-orientation image
+    const float* Zx1;         // [n][128]
+    const float* dx1_direct;  // [n][128]
+    const float* d_add;       // [n][128]
+    float* dZx1;              // [n][128] out
+    int nblk;
+};
+
+template <bool PACKED, bool HEADS, bool PRE = false>
 __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restrict__ d_xout /* may be null */,
                                                             const float* __restrict__ d_out,
                                                             const float* __restrict__ d_att, int64_t n, TailParams p,
                                                             const float* __restrict__ Z, float* __restrict__ dZ,
                                                             float* __restrict__ d_x2, float* __restrict__ d_resx,
-                                                            float* __restrict__ head_partial /* [grid][257] */) {
+                                                            float* __restrict__ head_partial /* [grid][257] */,
+                                                            PreBwd pb = PreBwd{}) {
+    static_assert(!PRE || (PACKED && !HEADS), "the fused head backward needs packed weights and deferred heads");
     // All ten pre-activation tiles are fetched up front (one burst of coalesced rows) and every dz_k overwrites its z_k
     // in place; d x2 / d res_x are parked too and the tiles leave as coalesced rows after the chain: like the forward,
     // the per-layer critical path holds no global access except the next weight slice.
@@ -412,7 +429,8 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
     constexpr int KTOP = HEADS ? 9 : 6;                       // first matrix of the backward chain
     constexpr int NZ = HEADS ? 10 : 7;
     WFrag1 wf;
-    if constexpr (PACKED) load_wfrag1_img(wf, p.W[KTOP]);
+    if constexpr (PRE) load_wfrag1_img(wf, pb.wp[0]);
+    else if constexpr (PACKED) load_wfrag1_img(wf, p.W[KTOP]);
     else load_wfrag1<true>(wf, p.W[KTOP], fr.wc);
     const int sc4 = threadIdx.x & 31, sr = threadIdx.x >> 5;          // sweep coordinates: 512 threads = 16 rows x 32 float4
     const int64_t sg = row0 + sr;
@@ -421,9 +439,42 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
         for (int k = 0; k < NZ; ++k) st_lds4(ZL + k * SLOT, sr, sc4, ldg4z(Z + (int64_t)k * plane, sg, n, DIM, sc4));
         float4 kx = d_xout ? ldg4z(d_xout, sg, n, DIM, sc4) : f4zero();
         if constexpr (!HEADS) kx = f4add(kx, ldg4z(d_out, sg, n, DIM, sc4));      // + the head branch's d x_out
+        if constexpr (PRE) {
+            // tiles of the head backward: dP planes -> ZL[7..9] + the (unused) head-partial area, z_x1 -> EX,
+            // d x1_direct -> D1, d_add joins K (K = d_add + g_head; the head's d x is added below)
+            float* const pl[4] = {ZL + 7 * SLOT, ZL + 8 * SLOT, ZL + 9 * SLOT, red};
+            for (int b = 0; b < pb.nblk; ++b) st_lds4(pl[b], sr, sc4, ldg4z(pb.dP + (int64_t)b * plane, sg, n, DIM, sc4));
+            st_lds4(EX, sr, sc4, ldg4z(pb.Zx1, sg, n, DIM, sc4));
+            st_lds4(D1, sr, sc4, ldg4z(pb.dx1_direct, sg, n, DIM, sc4));
+            kx = f4add(kx, ldg4z(pb.d_add, sg, n, DIM, sc4));
+        }
         st_lds4(K, sr, sc4, kx);
     }
     __syncthreads();
+
+    if constexpr (PRE) {
+        float* const pl[4] = {ZL + 7 * SLOT, ZL + 8 * SLOT, ZL + 9 * SLOT, red};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < pb.nblk; ++b) {
+            acc += mma_strip(pl[b], wf);
+            load_wfrag1_img(wf, b + 1 < pb.nblk ? pb.wp[b + 1] : pb.Wx1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) D0[fr.row(r) * LDT + c] = acc[r];
+        __syncthreads();
+        {   // dz_x1 = (d x1) * SiLU'(z_x1): over D1 in place, and parked in `red` for the final coalesced store
+            const float4 d1 = f4add(lds4(D0, sr, sc4), lds4(D1, sr, sc4));
+            const float4 dzx = f4mul(d1, f4dsilu(lds4(EX, sr, sc4)));
+            st_lds4(D1, sr, sc4, dzx);
+            st_lds4(red, sr, sc4, dzx);
+        }
+        __syncthreads();
+        const f32x4 a2 = mma_strip(D1, wf);
+        load_wfrag1_img(wf, p.W[KTOP]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) K[fr.row(r) * LDT + c] += a2[r];     // d x_out = head's d x + d_add + g_head
+        __syncthreads();
+    }
 
     auto load_z = [&](int k) {
         f32x4 z;
@@ -537,6 +588,7 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
         for (int k = 0; k < NZ; ++k) stg4(dZ + (int64_t)k * plane, sg, DIM, sc4, lds4(ZL + k * SLOT, sr, sc4));
         stg4(d_x2, sg, DIM, sc4, lds4(D0, sr, sc4));
         stg4(d_resx, sg, DIM, sc4, lds4(EX, sr, sc4));
+        if constexpr (PRE) stg4(pb.dZx1, sg, DIM, sc4, lds4(red, sr, sc4));
     }
 }
 
@@ -858,6 +910,38 @@ extern "C" int pamnet_node_tail_main_bwd_f32(const float* d_xout, const float* g
     else
         hipLaunchKernelGGL((node_tail_bwd_kernel<false, false>), dim3(grid), dim3(TWG), 0, st, d_xout, g_head,
                            (const float*)nullptr, n, tp, Z, dZ, d_x2, d_resx, (float*)nullptr);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+/* tail_main_bwd preceded, on the same row tiles, by the backward of the next layer's head (pamnet_node_pre_bwd_f32 with
+ * its d x feeding this chain's d x_out; d_xout of the chain is that d x, so there is no d_xout argument).  Packed
+ * (transposed-orientation) weight images only. */
+extern "C" int pamnet_node_pre_tail_bwd_f32(const float* dP, const float* dx1_direct, const float* d_add, int64_t n,
+                                            const float* Wx1, const float* const* wp, int64_t nblk, const float* Zx1,
+                                            float* dZx1, const float* g_head, const float* const* weights,
+                                            const float* Z, float* dZ, float* d_x2, float* d_resx,
+                                            pamnet_stream_t stream) {
+    if (n < 0 || nblk < 1 || nblk > 4) return PAMNET_EINVAL;
+    if (n == 0) return PAMNET_OK;
+    if (!dP || !dx1_direct || !d_add || !Wx1 || !wp || !Zx1 || !dZx1 || !g_head || !weights || !Z || !dZ || !d_x2 || !d_resx)
+        return PAMNET_ENULL;
+    PreBwd pb{};
+    pb.dP = dP, pb.Wx1 = Wx1, pb.Zx1 = Zx1, pb.dx1_direct = dx1_direct, pb.d_add = d_add, pb.dZx1 = dZx1;
+    pb.nblk = (int)nblk;
+    for (int b = 0; b < nblk; ++b) {
+        if (!wp[b]) return PAMNET_ENULL;
+        pb.wp[b] = wp[b];
+    }
+    TailParams tp{};
+    for (int k = 0; k < 7; ++k) {
+        if (!weights[k]) return PAMNET_ENULL;
+        tp.W[k] = weights[k];
+    }
+    tp.packed = 1;
+    hipLaunchKernelGGL((node_tail_bwd_kernel<true, false, true>), dim3((unsigned)ceil_div(n, BMN)), dim3(TWG), 0,
+                       as_stream(stream), (const float*)nullptr, g_head, (const float*)nullptr, n, tp, Z, dZ, d_x2, d_resx,
+                       (float*)nullptr, pb);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
