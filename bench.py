@@ -154,6 +154,10 @@ def cpu_baseline(args, seconds):
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio on fd 1 (flushed at exit,
+    # i.e. after our line), so fd 1 is pointed at stderr for everything but that line.
+    result_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -254,7 +258,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
             line['speedup_vs_cpu'] = value / line['cpu_baseline']['value']
-        print(json.dumps(line), flush=True)
+        result_out.write(json.dumps(line) + '\n')
+        result_out.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

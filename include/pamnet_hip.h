@@ -215,6 +215,17 @@ int pamnet_wgrad_batched_f32(int64_t njobs, const float* const* dZ, const int64_
                              const int64_t* ld_a, const int32_t* a_mode, const int64_t* rows, float* const* dW,
                              const int64_t* ld_dw, float* const* db, float* partial, const float* head_partial,
                              int64_t head_blocks, float* d_wout, float* d_watt, float* d_bout, pamnet_stream_t stream);
+/* Deferred form for a sequence of batches (the layers of one backward pass): the fixed-order reduction of batch i runs
+ * inside the launch of batch i+1's split-K pass; pamnet_wgrad_flush_f32 reduces the last one.  ctx: caller-owned HOST
+ * memory of *bytes (pamnet_wgrad_ctx_bytes) bytes, zeroed before the first call -- the library keeps no state of its
+ * own.  Consecutive calls must pass different `partial` buffers. */
+int pamnet_wgrad_ctx_bytes(int64_t* bytes /* host */);
+int pamnet_wgrad_deferred_f32(int64_t njobs, const float* const* dZ, const int64_t* ld_dz, const float* const* A,
+                              const int64_t* ld_a, const int32_t* a_mode, const int64_t* rows, float* const* dW,
+                              const int64_t* ld_dw, float* const* db, float* partial, const float* head_partial,
+                              int64_t head_blocks, float* d_wout, float* d_watt, float* d_bout, void* ctx /* host */,
+                              pamnet_stream_t stream);
+int pamnet_wgrad_flush_f32(void* ctx /* host */, pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Fused edge-level kernels (dim = 128), fp32 MFMA.  P planes are node_pre outputs ([N][128] each).

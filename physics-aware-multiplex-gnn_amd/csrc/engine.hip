@@ -88,7 +88,8 @@ struct Temp {
     float *x1, *P, *msg, *mji;                                         // forward
     float *dZ, *dZ2, *dx2, *dresx, *head, *dz, *dea, *dP, *dZx1, *dxa, *dxb;    // backward (global + shared)
     float *dzji, *dzkj, *dq2, *dmt, *dq3, *dmnb, *ds, *dz1, *dz2;      // backward (local)
-    float* partial;
+    float *partial, *partial2;   // split-K scratch of two consecutive weight-gradient batches (the reduction of one runs
+                                 // inside the launch of the next)
 };
 
 constexpr int WJOBS = 24;
@@ -107,7 +108,7 @@ inline int64_t temp_floats(const Graph& g) {
     t += nd + 4 * nd + gd + ld;                                        // x1 P msg mji
     t += 10 * nd + 7 * nd + nd + nd + al(((g.n + 15) / 16) * 257) + gd + gd + 4 * nd + nd + nd + nd;
     t += 6 * ld + 3 * td;
-    t += wgrad_floats(g);
+    t += 2 * wgrad_floats(g);
     return t;
 }
 
@@ -139,7 +140,8 @@ inline Temp carve_temp(float* p, const Graph& g) {
     t.ds = p; p += td;
     t.dz1 = p; p += td;
     t.dz2 = p; p += td;
-    t.partial = p;
+    t.partial = p; p += wgrad_floats(g);
+    t.partial2 = p;
     return t;
 }
 
@@ -208,9 +210,9 @@ inline void tail_jobs(Jobs& j, const Graph& g, const float* dZ, const float* hdz
 
 // all weight gradients of a layer + the head-vector gradients of its node chain (partials left by node_tail_bwd)
 inline int run_jobs(Jobs& j, float* partial, const Graph& g, const float* head, float* d_wout, float* d_watt,
-                    float* d_bout, pamnet_stream_t st) {
-    return pamnet_wgrad_batched_f32(j.n, j.dZ, j.ld_dz, j.A, j.ld_a, j.mode, j.rows, j.dW, j.ld_dw, j.db, partial, head,
-                                    (g.n + 15) / 16, d_wout, d_watt, d_bout, st);
+                    float* d_bout, void* ctx, pamnet_stream_t st) {
+    return pamnet_wgrad_deferred_f32(j.n, j.dZ, j.ld_dz, j.A, j.ld_a, j.mode, j.rows, j.dW, j.ld_dw, j.db, partial, head,
+                                     (g.n + 15) / 16, d_wout, d_watt, d_bout, ctx, st);
 }
 
 }  // namespace
@@ -467,6 +469,12 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
     // The chain gradients alternate between two buffers because a fused launch writes the next chain's dZ before the
     // previous chain's weight-gradient launch (which also needs that launch's dZx1) has consumed its own.
     const bool fuse = packed;
+    // weight-gradient batches: the fixed-order reduction of each batch rides in the next batch's launch
+    int64_t ctx_bytes = 0;
+    CK(pamnet_wgrad_ctx_bytes(&ctx_bytes));
+    std::vector<char> wctx((size_t)ctx_bytes, 0);
+    float* parts[2] = {t.partial, t.partial2};
+    int pflip = 0;
     const float* d_xout = nullptr;        // nothing consumes the last layer's node features (models.py:196-224)
     float* dx_bufs[2] = {t.dxa, t.dxb};
     float* dz_bufs[2] = {t.dZ, t.dZ2};
@@ -533,7 +541,12 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             j.add(t.dq3, rbf_e, 0, g.el, lg[11], D, nullptr);
             j.add(t.dz2, q.z1, 1, g.tp, lg[8], D, lg[9]);
             j.add(t.dz1, e_sbf, 0, g.tp, lg[6], D, lg[7]);
-            CK(run_jobs(j, t.partial, g, q.hp, lg[LT + 20], lg[LT + 22], lg[LT + 21], st));
+            CK(run_jobs(j, parts[pflip], g, q.hp, lg[LT + 20], lg[LT + 22], lg[LT + 21], wctx.data(), st));
+            pflip ^= 1;
+            // that launch also reduced the weight gradients of the previous pair's global layer: pair k+1 is complete
+            if (k + 1 < n_layer && layer_done && layer_done[k + 1]) {
+                HK(hipEventRecord(reinterpret_cast<hipEvent_t>(layer_done[k + 1]), as_stream(st)));
+            }
         }
         // ================= global layer backward
         {
@@ -576,11 +589,13 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             j.add(t.dP + pl, s.Zx1, 1, g.n, gg[2] + D, 3 * D, nullptr);
             j.add(t.dz, e_g, 0, g.eg, gg[2] + 2 * D, 3 * D, gg[3]);
             j.add(t.dea, e_g, 0, g.eg, gg[4], D, nullptr);
-            CK(run_jobs(j, t.partial, g, s.hp, gg[GT + 20], gg[GT + 22], gg[GT + 21], st));
+            CK(run_jobs(j, parts[pflip], g, s.hp, gg[GT + 20], gg[GT + 22], gg[GT + 21], wctx.data(), st));
+            pflip ^= 1;
         }
-        if (layer_done && layer_done[k]) {
-            HK(hipEventRecord(reinterpret_cast<hipEvent_t>(layer_done[k]), as_stream(st)));
-        }
+    }
+    CK(pamnet_wgrad_flush_f32(wctx.data(), st));
+    if (layer_done && layer_done[0]) {
+        HK(hipEventRecord(reinterpret_cast<hipEvent_t>(layer_done[0]), as_stream(st)));
     }
     return PAMNET_OK;
 }

@@ -72,14 +72,13 @@ inline int64_t plan_chunk(int64_t njobs, const int64_t* rows) {
     }
 }
 
-__global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * RB * LDW];
+__device__ __forceinline__ void wgrad_body(const WBatch& batch, float* __restrict__ partial, const int bid, float* lds) {
     float* Zs = lds;
     float* As = lds + RB * LDW;
     int j = 0;
-    while (j + 1 < batch.njobs && (int)blockIdx.x >= batch.start[j + 1]) ++j;       // wave-uniform scalar search
+    while (j + 1 < batch.njobs && bid >= batch.start[j + 1]) ++j;       // wave-uniform scalar search
     const WJob jb = batch.job[j];
-    const int s = blockIdx.x - batch.start[j];
+    const int s = bid - batch.start[j];
     const int js = batch.start[j + 1] - batch.start[j];
     const int64_t chunk = ((jb.rows + js - 1) / js + RB - 1) / RB * RB;
     const int64_t beg = (int64_t)s * chunk;
@@ -172,7 +171,7 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, float* __restri
     // partial[slot][128*128 + 2*128]: the tile, then the two row-half bias partials
     // The accumulator layout (4 rows x 16 columns per store) would hit memory as 64-byte fragments; transpose through
     // LDS (the staging buffers are free now: 128 x 132 floats fit) and write the tile as coalesced 512-byte rows.
-    float* out = partial + (int64_t)blockIdx.x * (DIM * DIM + 2 * DIM);
+    float* out = partial + (int64_t)bid * (DIM * DIM + 2 * DIM);
     float* T = lds;
     static_assert(2 * RB * LDW >= DIM * LDT, "tile must fit in the staging buffers");
 #pragma unroll
@@ -192,6 +191,11 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, float* __restri
     WPROBE(4 * it + 1);
 }
 
+__global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * RB * LDW];
+    wgrad_body(batch, partial, (int)blockIdx.x, lds);
+}
+
 // Second pass, ONE launch per batch (grid 258 x (njobs + 1)), every sum in a fixed order (deterministic):
 //   x <  256, y < njobs : 64 consecutive elements of job y's 128x128 tile, summed over its slots -- the slots are split
 //                          over 16 groups (group g takes slots s0+g, s0+g+16, ...), then the 16 group sums are added;
@@ -204,14 +208,15 @@ struct HeadJob {
     float *d_wout, *d_watt, *d_bout;
 };
 
-__global__ __launch_bounds__(WG) void wgrad_finish_kernel(WBatch batch, const float* __restrict__ partial, HeadJob head) {
-    __shared__ float4 red[16][16];
+__device__ __forceinline__ void finish_body(const WBatch& batch, const float* __restrict__ partial, const HeadJob& head,
+                                            const int bx, const int by, float* lds) {
+    float4(*red)[16] = reinterpret_cast<float4(*)[16]>(lds);                 // [16][16] float4 = 4 KB
     constexpr int64_t SLOT = DIM * DIM + 2 * DIM;
-    if ((int)blockIdx.y == batch.njobs) {
-        if (!head.partial || blockIdx.x >= 17) return;
+    if (by == batch.njobs) {
+        if (!head.partial || bx >= 17) return;
         float(*r1)[17] = reinterpret_cast<float(*)[17]>(&red[0][0]);      // 16 x 17 floats fit in the float4 array
         const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-        const int c = blockIdx.x * 16 + cl;
+        const int c = bx * 16 + cl;
         float s = 0.f;
         if (c < 257)
             for (int b = sl; b < head.blocks; b += 16) s += head.partial[(int64_t)b * 257 + c];
@@ -227,11 +232,11 @@ __global__ __launch_bounds__(WG) void wgrad_finish_kernel(WBatch batch, const fl
         }
         return;
     }
-    const WJob jb = batch.job[blockIdx.y];
-    const int s0 = batch.start[blockIdx.y], s1 = batch.start[blockIdx.y + 1];
-    if (blockIdx.x < 256) {
+    const WJob jb = batch.job[by];
+    const int s0 = batch.start[by], s1 = batch.start[by + 1];
+    if (bx < 256) {
         const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
-        const int e4 = blockIdx.x * 16 + c;                       // float4 index inside the 128x128 tile
+        const int e4 = bx * 16 + c;                       // float4 index inside the 128x128 tile
         float4 s = f4zero();
         for (int q = s0 + g; q < s1; q += 16)
             s = f4add(s, *reinterpret_cast<const float4*>(partial + (int64_t)q * SLOT + 4 * e4));
@@ -244,10 +249,10 @@ __global__ __launch_bounds__(WG) void wgrad_finish_kernel(WBatch batch, const fl
             const int el = 4 * e4;
             *reinterpret_cast<float4*>(jb.dW + (int64_t)(el >> 7) * jb.ld_dw + (el & 127)) = t;
         }
-    } else if (blockIdx.x == 256) {
+    } else if (bx == 256) {
         if (!jb.db) return;
         // 32 float4 columns x 8 slot groups, fp64 across slots, fixed order
-        __shared__ double rd[8][128];
+        double(*rd)[128] = reinterpret_cast<double(*)[128]>(lds + 1024);          // [8][128] doubles behind `red`
         const int c4 = threadIdx.x & 31, g = threadIdx.x >> 5;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         for (int q = s0 + g; q < s1; q += 8) {
@@ -270,6 +275,27 @@ __global__ __launch_bounds__(WG) void wgrad_finish_kernel(WBatch batch, const fl
     }
 }
 
+__global__ __launch_bounds__(WG) void wgrad_finish_kernel(WBatch batch, const float* __restrict__ partial, HeadJob head) {
+    __shared__ __attribute__((aligned(16))) float lds[1024 + 2 * 8 * 128];
+    finish_body(batch, partial, head, (int)blockIdx.x, (int)blockIdx.y, lds);
+}
+
+// One launch = the split-K pass of the current batch (blocks [0, cur slots)) + the fixed-order reduction of the
+// PREVIOUS batch (the remaining blocks, 258 per job): the reduction is ~16 MB of L2-resident reads that ran as a
+// launch of its own between two weight-gradient passes; here its small workgroups fill in beside the current pass.
+constexpr int FIN_X = DIM * DIM / 64 + 2;
+__global__ __launch_bounds__(WG) void wgrad_fused_kernel(WBatch cur, float* __restrict__ cur_partial, WBatch prev,
+                                                         const float* __restrict__ prev_partial, HeadJob prev_head) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * RB * LDW];
+    const int slots = cur.start[cur.njobs];
+    if ((int)blockIdx.x < slots) {
+        wgrad_body(cur, cur_partial, (int)blockIdx.x, lds);
+    } else {
+        const int fb = (int)blockIdx.x - slots;
+        finish_body(prev, prev_partial, prev_head, fb % FIN_X, fb / FIN_X, lds);
+    }
+}
+
 }  // namespace
 
 // Scratch needed for a batch: sum_j clamp(ceil(rows_j/256), 1, 256) slots of (128*128 + 256) floats.
@@ -280,6 +306,29 @@ extern "C" int pamnet_wgrad_scratch_floats(int64_t njobs, const int64_t* rows, i
     *floats = slots * (int64_t)(DIM * DIM + 2 * DIM);
     return PAMNET_OK;
 }
+
+namespace {
+struct WgradPending {
+    WBatch batch;
+    const float* partial;
+    HeadJob head;
+    int valid;
+};
+
+inline int build_batch(WBatch& b, int64_t njobs, const float* const* dZ, const int64_t* ld_dz, const float* const* A,
+                       const int64_t* ld_a, const int32_t* a_mode, const int64_t* rows, float* const* dW,
+                       const int64_t* ld_dw, float* const* db) {
+    b.njobs = (int)njobs;
+    b.start[0] = 0;
+    const int64_t chunk = plan_chunk(njobs, rows);
+    for (int j = 0; j < njobs; ++j) {
+        if (!dZ[j] || !A[j] || !dW[j]) return PAMNET_ENULL;
+        b.job[j] = WJob{dZ[j], A[j], dW[j], db[j], rows[j], (int)ld_dz[j], (int)ld_a[j], (int)ld_dw[j], a_mode[j]};
+        b.start[j + 1] = b.start[j] + job_slots(rows[j], chunk);
+    }
+    return PAMNET_OK;
+}
+}  // namespace
 
 // jobs described by parallel host arrays (njobs <= 24).  partial: pamnet_wgrad_scratch_floats(njobs, rows) floats.
 extern "C" int pamnet_wgrad_batched_f32(int64_t njobs, const float* const* dZ, const int64_t* ld_dz,
@@ -292,20 +341,63 @@ extern "C" int pamnet_wgrad_batched_f32(int64_t njobs, const float* const* dZ, c
     if (head_partial && (!d_wout || !d_watt || !d_bout || head_blocks < 0)) return PAMNET_ENULL;
     if (!dZ || !ld_dz || !A || !ld_a || !a_mode || !rows || !dW || !ld_dw || !db || !partial) return PAMNET_ENULL;
     WBatch b;
-    b.njobs = (int)njobs;
-    b.start[0] = 0;
-    const int64_t chunk = plan_chunk(njobs, rows);
-    for (int j = 0; j < njobs; ++j) {
-        if (!dZ[j] || !A[j] || !dW[j]) return PAMNET_ENULL;
-        b.job[j] = WJob{dZ[j], A[j], dW[j], db[j], rows[j], (int)ld_dz[j], (int)ld_a[j], (int)ld_dw[j], a_mode[j]};
-        b.start[j + 1] = b.start[j] + job_slots(rows[j], chunk);
-    }
+    const int rc = build_batch(b, njobs, dZ, ld_dz, A, ld_a, a_mode, rows, dW, ld_dw, db);
+    if (rc) return rc;
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)b.start[njobs]), dim3(WG), 0, st, b, partial);
     PAMNET_LAUNCH_CHECK();
     const HeadJob head{head_partial, (int)head_blocks, d_wout, d_watt, d_bout};
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(DIM * DIM / 64 + 2, (unsigned)njobs + 1), dim3(WG), 0, st, b, partial,
-                       head);
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(FIN_X, (unsigned)njobs + 1), dim3(WG), 0, st, b, partial, head);
     PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+// Deferred form for a sequence of batches (one per layer of a backward pass): the reduction of batch i rides along in
+// the launch of batch i+1's split-K pass; pamnet_wgrad_flush_f32 reduces the last one.  `ctx`: caller-owned host memory
+// of pamnet_wgrad_ctx_bytes bytes, zeroed before the first call (the library itself keeps no state); consecutive calls
+// must use different `partial` buffers (the previous one is still being read).
+extern "C" int pamnet_wgrad_ctx_bytes(int64_t* bytes) {
+    if (!bytes) return PAMNET_ENULL;
+    *bytes = (int64_t)sizeof(WgradPending);
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_wgrad_deferred_f32(int64_t njobs, const float* const* dZ, const int64_t* ld_dz,
+                                         const float* const* A, const int64_t* ld_a, const int32_t* a_mode,
+                                         const int64_t* rows, float* const* dW, const int64_t* ld_dw, float* const* db,
+                                         float* partial, const float* head_partial, int64_t head_blocks, float* d_wout,
+                                         float* d_watt, float* d_bout, void* ctx, pamnet_stream_t stream) {
+    if (njobs < 1 || njobs > MAXJ) return PAMNET_EINVAL;
+    if (head_partial && (!d_wout || !d_watt || !d_bout || head_blocks < 0)) return PAMNET_ENULL;
+    if (!dZ || !ld_dz || !A || !ld_a || !a_mode || !rows || !dW || !ld_dw || !db || !partial || !ctx) return PAMNET_ENULL;
+    WgradPending* pend = static_cast<WgradPending*>(ctx);
+    if (pend->valid && pend->partial == partial) return PAMNET_EINVAL;
+    WBatch b;
+    const int rc = build_batch(b, njobs, dZ, ld_dz, A, ld_a, a_mode, rows, dW, ld_dw, db);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    if (pend->valid) {
+        const unsigned grid = (unsigned)b.start[njobs] + (unsigned)(FIN_X * (pend->batch.njobs + 1));
+        hipLaunchKernelGGL(wgrad_fused_kernel, dim3(grid), dim3(WG), 0, st, b, partial, pend->batch, pend->partial,
+                           pend->head);
+    } else {
+        hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)b.start[njobs]), dim3(WG), 0, st, b, partial);
+    }
+    PAMNET_LAUNCH_CHECK();
+    pend->batch = b;
+    pend->partial = partial;
+    pend->head = HeadJob{head_partial, (int)head_blocks, d_wout, d_watt, d_bout};
+    pend->valid = 1;
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_wgrad_flush_f32(void* ctx, pamnet_stream_t stream) {
+    if (!ctx) return PAMNET_ENULL;
+    WgradPending* pend = static_cast<WgradPending*>(ctx);
+    if (!pend->valid) return PAMNET_OK;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(FIN_X, (unsigned)pend->batch.njobs + 1), dim3(WG), 0, as_stream(stream),
+                       pend->batch, pend->partial, pend->head);
+    PAMNET_LAUNCH_CHECK();
+    pend->valid = 0;
     return PAMNET_OK;
 }
