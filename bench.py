@@ -181,7 +181,8 @@ def main():
     overlap = os.environ.get('PAMNET_OVERLAP_COMM', '1') != '0'
     trainer = Trainer(model, lr=1e-4, world_size=world,
                       overlap_comm=('force' if args.force_comm else overlap),
-                      native_optimizer=os.environ.get('PAMNET_NATIVE_OPT', '1') != '0')
+                      native_optimizer=os.environ.get('PAMNET_NATIVE_OPT', '1') != '0',
+                      n_buckets=int(os.environ.get('PAMNET_BUCKETS', '3')))
     B = args.batch_per_gpu
     gB = B * world
     # resident batches: global batch k = molecules [k*gB, (k+1)*gB); this rank's shard = its contiguous slice
