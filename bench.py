@@ -180,7 +180,7 @@ def main():
     model = models.PAMNet(cfg).to(dev)
     overlap = os.environ.get('PAMNET_OVERLAP_COMM', '1') != '0'
     trainer = Trainer(model, lr=1e-4, world_size=world,
-                      overlap_comm=('force' if args.force_comm else overlap),
+                      overlap_comm=(('force' if overlap else 'force_single') if args.force_comm else overlap),
                       native_optimizer=os.environ.get('PAMNET_NATIVE_OPT', '1') != '0',
                       n_buckets=int(os.environ.get('PAMNET_BUCKETS', '3')))
     B = args.batch_per_gpu

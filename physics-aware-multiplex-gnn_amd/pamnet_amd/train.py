@@ -131,7 +131,8 @@ class Trainer(object):
         self.max_grad_norm = max_grad_norm
         self.world_size, self.pg = world_size, process_group
         self._buckets = None
-        if overlap_comm and self.fp.flat.is_cuda and dist.is_available() and dist.is_initialized() \
+        self._force_single = overlap_comm == 'force_single'     # measurement aid: one all-reduce even on a 1-rank group
+        if overlap_comm and overlap_comm != 'force_single' and self.fp.flat.is_cuda and dist.is_available() and dist.is_initialized() \
                 and (world_size > 1 or overlap_comm == 'force'):
             self._setup_buckets(n_buckets)
 
@@ -195,7 +196,7 @@ class Trainer(object):
             from . import fused
             bucketed = fused.EVENTS_RECORDED       # this backward did not go through the engine: no per-layer events
         if not bucketed:
-            if self.world_size > 1:
+            if self.world_size > 1 or self._force_single:
                 dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM, group=self.pg)
             return
         main = torch.cuda.current_stream(self.fp.flat.device)
