@@ -253,6 +253,27 @@ int pamnet_local_edge_bwd_f32(const float* d_mji, const float* d_mnb, const floa
                               const float* z_ji, const float* z_kj, const float* q2, const float* const* Wq,
                               const int64_t* ldq, float* dz_ji, float* dz_kj, float* dq2, float* d_rbf,
                               int32_t accumulate, pamnet_stream_t stream);
+/* Edge MLP -> node segment-sum as ONE kernel (csrc/edge_agg.hip; layers/global_message_passing.py:38,52-56): the
+ * message tile is reduced over its target node from LDS, the [E,128] message tensor is never written.
+ *   fwd: out[i] = init[i] + sum_{e -> i} SiLU(W_e e + b_m + Pi[i] + Pj[col[e]]) * (W_ea e)  for all i < n_nodes
+ *        (init nullable = 0; z / ea [E,128]: optional saves for the backward; ptr [n_nodes+1], row_of, col: CSR by target)
+ *   bwd: dz, dea, d_e as pamnet_global_edge_bwd_f32, plus dPi[i] = sum_{e -> i} dz[e] (the target-side reduction).
+ * Node-aligned work split: every output row has one owner and a fixed CSR summation order (no atomics, no carries;
+ * results do not depend on the launch geometry).
+ * pamnet_local_agg_fwd_f32 (layers/local_message_passing.py:49-54, one launch for both aggregations):
+ *   m_t[e] = m_ji[e] + sum_{r in [t_ptr[e], t_ptr[e+1])} m_nb[t_col[r]] * s[r]     (m_t nullable: backward-only save)
+ *   out[i] = init[i] + sum_{e in [l_ptr[i], l_ptr[i+1])} q3[e] * m_t[e] */
+int pamnet_global_edge_agg_fwd_f32(const float* e, int64_t n_edges, int64_t n_nodes, const float* We, int64_t ld_we,
+                                   const float* bm, const float* Wea, int64_t ld_wea, const float* Pi, const float* Pj,
+                                   const int32_t* ptr, const int32_t* row_of, const int32_t* col, const float* init,
+                                   float* z, float* ea, float* out, pamnet_stream_t stream);
+int pamnet_global_edge_agg_bwd_f32(const float* d_agg, int64_t n_edges, int64_t n_nodes, const int32_t* ptr,
+                                   const int32_t* row_of, const float* z, const float* ea, const float* We,
+                                   int64_t ld_we, const float* Wea, int64_t ld_wea, float* dz, float* dea, float* d_e,
+                                   int32_t accumulate, float* dPi, pamnet_stream_t stream);
+int pamnet_local_agg_fwd_f32(const float* m_ji, const float* m_nb, const float* s, const float* q3,
+                             const int32_t* t_ptr, const int32_t* t_col, const int32_t* l_ptr, const float* init,
+                             int64_t n_nodes, float* m_t, float* out, pamnet_stream_t stream);
 int pamnet_mlp2_fwd_f32(const float* x, int64_t rows, const float* W1, const float* b1, const float* W2,
                         const float* b2, float* z1, float* z2, float* y, pamnet_stream_t stream);
 /* nsets <= 8 such MLPs on the same input rows in one launch: params[4k..4k+3] = {W1, b1, W2, b2} of set k,

@@ -1,0 +1,457 @@
+// Edge MLP -> node segment-sum as ONE kernel (dim = 128): the message of layers/global_message_passing.py:52-56 is
+// reduced over its target node (PyG add-aggregation, global_message_passing.py:38) while the message tile is still in
+// LDS -- the [E,128] message tensor of the reference (and of pamnet_global_edge_fwd_f32 + pamnet_segment_sum_f32)
+// never exists in memory.
+//
+// Work split.  Edges are stored in CSR order of their target node, so a node's messages are consecutive rows.  The
+// kernels of edge_chain.hip cut the rows into 16-row tiles regardless of the nodes; here the cuts are NODE-ALIGNED:
+//   * workgroup b of G owns the nodes [cut(b), cut(b+1)), cut(k) = the node boundary nearest to row k*E/G
+//     (two loads: row_of[k*E/G], ptr[.]), i.e. ~E/G rows give or take half a node degree;
+//   * it walks its rows in chunks of whole nodes (<= 16*MTX rows, <= 511 nodes): e rows -> LDS, two fp32-MFMA GEMMs,
+//     epilogue z = W_e e + b + P_i[i] + P_j[j], msg = SiLU(z) * (W_ea e) written back into the LDS tile, then one
+//     32-lane group per node adds the node's rows IN CSR ORDER onto init[node] and stores the 512-byte output row.
+//   Every output row is produced by exactly one lane group with a fixed summation order: no atomics, no carry between
+//   workgroups, bitwise identical from run to run and independent of how the batch is cut into workgroups / chunks
+//   (a node with more rows than a chunk is walked in pieces with the running sum kept in registers: same order).
+// The backward kernel mirrors it: d z rows are reduced per target node (d P_i) from the LDS tile before the dX GEMMs
+// overwrite it; only the reduction by SOURCE node (transposed CSR) remains a separate segment sum.
+//
+// local_agg: the two chained aggregations of the local layer (layers/local_message_passing.py:49-54),
+//   m_t[e] = m_ji[e] + sum_{r in rows(e)} m_nb[idx[r]] * s[r],   x2[i] = x1[i] + sum_{e -> i} q3[e] * m_t[e],
+// as one launch (one lane group per edge, node sums through LDS in CSR order).
+#include "edge_core.h"
+
+namespace {
+
+constexpr int NMAX = 511;                 // nodes per chunk (their CSR offsets are staged in LDS)
+
+// node boundary nearest to row k*m/G (0 for k = 0, n for k = G): monotone in k, so the ranges tile [0, n)
+__device__ __forceinline__ int seg_cut(const int32_t* __restrict__ ptr, const int32_t* __restrict__ row_of, int64_t n,
+                                       int64_t m, int k, int G) {
+    if (k <= 0) return 0;
+    if (k >= G || m == 0) return (int)n;
+    const int64_t t = (int64_t)k * m / G;
+    const int node = row_of[t];
+    const int64_t a = ptr[node], b = ptr[node + 1];
+    return (t - a <= b - t) ? node : node + 1;
+}
+
+struct Chunk {
+    int c0, c1;            // whole nodes [c0, c1)  (giant: the single node c0)
+    int64_t r0, r1;        // rows [r0, r1)
+    bool giant, finish;    // giant: a piece of one node's segment; finish: the piece reaches the segment's end
+};
+
+// next chunk from (c0, r0); `mid`: r0 lies inside node c0's segment (continuation of a giant node)
+__device__ __forceinline__ Chunk plan_chunk(const int32_t* __restrict__ ptr, const int32_t* __restrict__ row_of, int c0,
+                                            int64_t r0, bool mid, int ne, int64_t re, int cap) {
+    Chunk ch;
+    ch.c0 = c0, ch.r0 = r0, ch.giant = false, ch.finish = false;
+    if (mid) {
+        const int64_t se = ptr[c0 + 1];
+        ch.giant = true;
+        ch.r1 = r0 + cap < se ? r0 + cap : se;
+        ch.finish = ch.r1 == se;
+        ch.c1 = c0;
+        return ch;
+    }
+    const int64_t rem = re - r0;
+    const int64_t nch = rem > cap ? (rem + cap - 1) / cap : 1;
+    const int64_t tgt = rem > 0 ? (rem + nch - 1) / nch : 1;          // balanced chunks of <= cap rows
+    const int64_t t = r0 + tgt;
+    if (t >= re) {
+        ch.c1 = ne, ch.r1 = re;
+    } else {
+        const int node = row_of[t];
+        const int64_t a = ptr[node], b = ptr[node + 1];
+        if (b - r0 <= cap) {
+            ch.c1 = node + 1, ch.r1 = b;
+        } else if (node > c0) {
+            ch.c1 = node, ch.r1 = a;
+        } else {                                                       // node c0 alone has more than cap rows
+            ch.giant = true, ch.c1 = c0, ch.r1 = r0 + cap;
+            return ch;
+        }
+    }
+    if (ch.c1 - c0 > NMAX) {
+        ch.c1 = c0 + NMAX;
+        ch.r1 = ptr[ch.c1];
+    }
+    return ch;
+}
+
+__device__ __forceinline__ void seq_add(float4& s, const float* __restrict__ tile, int q0, int q1, int c4) {
+    int q = q0;
+    for (; q + 4 <= q1; q += 4) {                                      // loads independent, adds strictly in row order
+        const float4 v0 = lds4(tile, q, c4), v1 = lds4(tile, q + 1, c4), v2 = lds4(tile, q + 2, c4),
+                     v3 = lds4(tile, q + 3, c4);
+        s = f4add(f4add(f4add(f4add(s, v0), v1), v2), v3);
+    }
+    for (; q < q1; ++q) s = f4add(s, lds4(tile, q, c4));
+}
+
+// out[node] = init[node] + sum of the node's rows of `tile` (rows relative to the chunk), one 32-lane group per node
+template <int NGRP>
+__device__ __forceinline__ void reduce_nodes(int c0, int nn, bool giant, bool finish, int rows,
+                                             const float* __restrict__ tile, const int* __restrict__ sptr,
+                                             const float* __restrict__ init, float* __restrict__ out, f32x4& carry,
+                                             bool mid) {
+    const int grp = threadIdx.x >> 5, c4 = threadIdx.x & 31;
+    if (!giant) {
+        for (int k = grp; k < nn; k += NGRP) {
+            float4 s = init ? ldg4(init, c0 + k, DIM, c4) : f4zero();
+            seq_add(s, tile, sptr[k], sptr[k + 1], c4);
+            stg4(out, c0 + k, DIM, c4, s);
+        }
+    } else if (grp == 0) {
+        float4 s = init ? ldg4(init, c0, DIM, c4) : f4zero();
+        if (mid) s = make_float4(carry[0], carry[1], carry[2], carry[3]);
+        seq_add(s, tile, 0, rows, c4);
+        if (finish) stg4(out, c0, DIM, c4, s);
+        else carry = f32x4{s.x, s.y, s.z, s.w};
+    }
+}
+
+struct GAggFwd {
+    const float *e, *We, *bm, *Wea, *Pi, *Pj, *init;
+    const int32_t *ptr, *row_of, *col;
+    float *z, *ea, *out;
+    int64_t m, n;
+    int ld_we, ld_wea;
+};
+
+// PRE: the next chunk's e rows travel in registers while this chunk's GEMMs run (multi-chunk workgroups); the 9-tile
+// instantiation (one chunk per workgroup at ~128 rows give or take half a node) has no registers to spare for it.
+template <int MTX, bool PRE>
+__global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
+    __shared__ int sptr[NMAX + 1];
+    float* S0 = lds;
+    float* S1 = lds + MTX * 16 * LDT;
+    constexpr int CAP = MTX * 16;
+    const float* __restrict__ e = a.e;
+    const float* __restrict__ Pi = a.Pi;
+    const float* __restrict__ Pj = a.Pj;
+    const int32_t* __restrict__ ptr = a.ptr;
+    const int32_t* __restrict__ row_of = a.row_of;
+    const int32_t* __restrict__ col = a.col;
+    float* __restrict__ zs = a.z;
+    float* __restrict__ eas = a.ea;
+    const int wc = wave_col<8>();
+    const BiasSet<1> zero_bias = lane_biases<1>(nullptr, wc);
+    const BiasSet<1> bv = lane_biases<1>(a.bm, wc);
+    WSet<1> f1, f2;
+    load_wset<false>(f1, a.We, a.ld_we, wc);
+    load_wset<false>(f2, a.Wea, a.ld_wea, wc);
+    const int nb = seg_cut(ptr, row_of, a.n, a.m, blockIdx.x, gridDim.x);
+    const int ne = seg_cut(ptr, row_of, a.n, a.m, blockIdx.x + 1, gridDim.x);
+    const int64_t rb = ptr[nb], re = ptr[ne];
+    constexpr int RPP = 16, NI = MTX;                       // sweep geometry of 512 threads: 16 rows per pass
+    const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;
+    float4 pre[PRE ? NI : 1];
+    if (PRE && rb < re) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) pre[i] = ldg4z(e, rb + rr + RPP * i, re, DIM, c4);
+    }
+    int c0 = nb;
+    int64_t r0 = rb;
+    bool mid = false;
+    f32x4 carry = f32x4{0.f, 0.f, 0.f, 0.f};         // running sum of a node that spans several chunks
+    while (c0 < ne) {
+        const Chunk ch = plan_chunk(ptr, row_of, c0, r0, mid, ne, re, CAP);
+        const int64_t r1 = ch.r1;
+        const int c1 = ch.c1;
+        const bool giant = ch.giant, finish = ch.finish;
+        const int rows = (int)(r1 - r0);
+        const int mt = (rows + 15) >> 4;
+        // CSR offsets of the chunk's nodes: requested now, parked in LDS before the reduction
+        const int nn = giant ? 0 : c1 - c0;
+        const int myp = (int)threadIdx.x <= nn ? ptr[c0 + threadIdx.x] - (int)r0 : 0;
+        if (rows > 0) {
+            if (PRE) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    if (RPP * i < 16 * mt) st_lds4(S0, rr + RPP * i, c4, pre[i]);
+                if (r1 < re) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) pre[i] = ldg4z(e, r1 + rr + RPP * i, re, DIM, c4);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    if (RPP * i < 16 * mt) st_lds4(S0, rr + RPP * i, c4, ldg4z(e, r0 + rr + RPP * i, r1, DIM, c4));
+            }
+            __syncthreads();
+            AccSet<MTX, 1> acc;                                // one accumulator set: the gate tile goes straight to S1
+            acc.zero();                                        // (nobody reads S1 during the GEMMs)
+            mma_set<MTX, 1>(S0, f2, acc, mt);
+            store_set<MTX, 1>(acc, S1, wc, zero_bias, mt);
+            acc.zero();
+            mma_set<MTX, 1>(S0, f1, acc, mt);
+            __syncthreads();                                   // every wave is done reading the e tile
+            store_set<MTX, 1>(acc, S0, wc, bv, mt);
+            if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = myp;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int r = rr + RPP * i;
+                const int64_t g = r0 + r;
+                if (RPP * i < 16 * mt && g < r1) {
+                    const int64_t ii = row_of[g], jj = col[g];
+                    const float4 zz = f4add(f4add(lds4(S0, r, c4), ldg4(Pi, ii, DIM, c4)), ldg4(Pj, jj, DIM, c4));
+                    const float4 gate = lds4(S1, r, c4);
+                    if (zs) stg4(zs, g, DIM, c4, zz);          // backward-only saves: null in inference mode
+                    if (eas) stg4(eas, g, DIM, c4, gate);
+                    st_lds4(S1, r, c4, f4mul(f4silu(zz), gate));   // the message stays on chip
+                }
+            }
+        } else if ((int)threadIdx.x <= nn) {
+            sptr[threadIdx.x] = myp;
+        }
+        __syncthreads();
+        reduce_nodes<16>(c0, nn, giant, finish, rows, S1, sptr, a.init, a.out, carry, mid);
+        __syncthreads();
+        if (giant) {
+            r0 = r1;
+            mid = !finish;
+            if (finish) ++c0;
+        } else {
+            c0 = c1, r0 = r1;
+        }
+    }
+}
+
+struct GAggBwd {
+    const float *d_agg, *z, *ea, *We, *Wea;
+    const int32_t *ptr, *row_of;
+    float *dz, *dea, *d_e, *dPi;
+    int64_t m, n;
+    int ld_we, ld_wea, accumulate;
+};
+
+// dm[e] = d_agg[i(e)];  dz = dm * ea * SiLU'(z);  dea = dm * SiLU(z);  d_e (+)= dz W_e + dea W_ea;
+// dPi[i] = sum_{e -> i} dz[e]   (the gradient of the target-side node projection, reduced from the LDS tile)
+template <int MTX>
+__global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
+    __shared__ int sptr[NMAX + 1];
+    float* S0 = lds;
+    float* S1 = lds + MTX * 16 * LDT;
+    constexpr int CAP = MTX * 16;
+    const float* __restrict__ d_agg = a.d_agg;
+    const float* __restrict__ zs = a.z;
+    const float* __restrict__ eas = a.ea;
+    const int32_t* __restrict__ ptr = a.ptr;
+    const int32_t* __restrict__ row_of = a.row_of;
+    float* __restrict__ dz = a.dz;
+    float* __restrict__ dea = a.dea;
+    float* __restrict__ d_e = a.d_e;
+    const int accumulate = a.accumulate;
+    const int wc = wave_col<8>();
+    const BiasSet<1> zero_bias = lane_biases<1>(nullptr, wc);
+    WSet<1> f1, f2;
+    load_wset<true>(f1, a.We, a.ld_we, wc);
+    load_wset<true>(f2, a.Wea, a.ld_wea, wc);
+    const int nb = seg_cut(ptr, row_of, a.n, a.m, blockIdx.x, gridDim.x);
+    const int ne = seg_cut(ptr, row_of, a.n, a.m, blockIdx.x + 1, gridDim.x);
+    const int64_t re = ptr[ne];
+    constexpr int RPP = 16, NI = MTX;
+    const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;
+    int c0 = nb;
+    int64_t r0 = ptr[nb];
+    bool mid = false;
+    f32x4 carry = f32x4{0.f, 0.f, 0.f, 0.f};         // running sum of a node that spans several chunks
+    while (c0 < ne) {
+        const Chunk ch = plan_chunk(ptr, row_of, c0, r0, mid, ne, re, CAP);
+        const int64_t r1 = ch.r1;
+        const int c1 = ch.c1;
+        const bool giant = ch.giant, finish = ch.finish;
+        const int rows = (int)(r1 - r0);
+        const int mt = (rows + 15) >> 4;
+        const int nn = giant ? 0 : c1 - c0;
+        if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = ptr[c0 + threadIdx.x] - (int)r0;
+        if (rows > 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                if (RPP * i >= 16 * mt) continue;
+                const int r = rr + RPP * i;
+                const int64_t g = r0 + r;
+                float4 x = f4zero(), y = f4zero();
+                if (g < r1) {
+                    const float4 dm = ldg4(d_agg, row_of[g], DIM, c4);
+                    const float4 zz = ldg4(zs, g, DIM, c4);
+                    x = f4mul(f4mul(dm, ldg4(eas, g, DIM, c4)), f4dsilu(zz));
+                    y = f4mul(dm, f4silu(zz));
+                    stg4(dz, g, DIM, c4, x);
+                    stg4(dea, g, DIM, c4, y);
+                }
+                st_lds4(S0, r, c4, x);
+                st_lds4(S1, r, c4, y);
+            }
+        }
+        __syncthreads();
+        reduce_nodes<16>(c0, nn, giant, finish, rows, S0, sptr, nullptr, a.dPi, carry, mid);   // reads S0 only
+        if (rows > 0) {
+            AccSet<MTX, 1> acc;
+            acc.zero();
+            mma_set<MTX, 1>(S0, f1, acc, mt);
+            mma_set<MTX, 1>(S1, f2, acc, mt);
+            __syncthreads();
+            store_set<MTX, 1>(acc, S0, wc, zero_bias, mt);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int r = rr + RPP * i;
+                const int64_t g = r0 + r;
+                if (RPP * i < 16 * mt && g < r1) {
+                    float4 v = lds4(S0, r, c4);
+                    if (accumulate) v = f4add(v, ldg4(d_e, g, DIM, c4));
+                    stg4(d_e, g, DIM, c4, v);
+                }
+            }
+        }
+        __syncthreads();
+        if (giant) {
+            r0 = r1;
+            mid = !finish;
+            if (finish) ++c0;
+        } else {
+            c0 = c1, r0 = r1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ local aggregation
+// Workgroup = 8 lane groups of 32; it owns NPW consecutive nodes and walks their local edges 8 at a time: group k
+// computes v = q3[e] * (m_ji[e] + sum_r m_nb[idx[r]] * s[r]) for its edge (rows of e in CSR order), the node owners add
+// the round's values in edge order.
+constexpr int NPW = 4;
+__global__ __launch_bounds__(256) void local_agg_fwd_kernel(const float4* __restrict__ m_ji, const float4* __restrict__ m_nb,
+                                                            const float4* __restrict__ s, const float4* __restrict__ q3,
+                                                            const int32_t* __restrict__ t_ptr,
+                                                            const int32_t* __restrict__ t_col,
+                                                            const int32_t* __restrict__ l_ptr,
+                                                            const float4* __restrict__ init, float4* __restrict__ m_t,
+                                                            float4* __restrict__ out, int64_t n) {
+    __shared__ float4 val[8][32];
+    const int grp = threadIdx.x >> 5, c = threadIdx.x & 31;
+    const int64_t n0 = (int64_t)blockIdx.x * NPW;
+    const int64_t n1 = n0 + NPW < n ? n0 + NPW : n;
+    const int eb = l_ptr[n0], ee = l_ptr[n1];
+    const int64_t node = n0 + grp;                           // groups 0..NPW-1 own a node each
+    const bool owner = grp < NPW && node < n1;
+    int nb0 = 0, nb1 = 0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (owner) {
+        nb0 = l_ptr[node], nb1 = l_ptr[node + 1];
+        if (init) acc = init[node * 32 + c];
+    }
+    for (int e0 = eb; e0 < ee || e0 == eb; e0 += 8) {
+        const int e = e0 + grp;
+        if (e < ee) {
+            const int t0 = t_ptr[e], t1 = t_ptr[e + 1];
+            float4 v = m_ji[(int64_t)e * 32 + c];
+            const float4 gate = q3[(int64_t)e * 32 + c];
+            int t = t0;
+            for (; t + 4 <= t1; t += 4) {
+                const int64_t k0 = t_col[t], k1 = t_col[t + 1], k2 = t_col[t + 2], k3 = t_col[t + 3];
+                const float4 a0 = m_nb[k0 * 32 + c], a1 = m_nb[k1 * 32 + c], a2 = m_nb[k2 * 32 + c], a3 = m_nb[k3 * 32 + c];
+                const float4 b0 = s[(int64_t)t * 32 + c], b1 = s[(int64_t)(t + 1) * 32 + c],
+                             b2 = s[(int64_t)(t + 2) * 32 + c], b3 = s[(int64_t)(t + 3) * 32 + c];
+                v = pamnet::f4add(v, pamnet::f4mul(a0, b0));
+                v = pamnet::f4add(v, pamnet::f4mul(a1, b1));
+                v = pamnet::f4add(v, pamnet::f4mul(a2, b2));
+                v = pamnet::f4add(v, pamnet::f4mul(a3, b3));
+            }
+            for (; t < t1; ++t)
+                v = pamnet::f4add(v, pamnet::f4mul(m_nb[(int64_t)t_col[t] * 32 + c], s[(int64_t)t * 32 + c]));
+            if (m_t) m_t[(int64_t)e * 32 + c] = v;             // backward-only save
+            val[grp][c] = pamnet::f4mul(v, gate);
+        }
+        __syncthreads();
+        if (owner) {
+            const int lo = nb0 > e0 ? nb0 : e0, hi = nb1 < e0 + 8 ? nb1 : e0 + 8;
+            for (int q = lo; q < hi; ++q) acc = pamnet::f4add(acc, val[q - e0][c]);
+        }
+        __syncthreads();
+        if (e0 + 8 >= ee) break;
+    }
+    if (owner) out[node * 32 + c] = acc;
+}
+
+inline int pick_mtx(int64_t m, int64_t grid) {
+    const int64_t per = ceil_div(m, grid);
+    // 9 tiles: one chunk per workgroup when ~E/256 rows give or take half a node degree fit 144 rows; beyond that the
+    // workgroups walk several balanced chunks of <= 128 rows
+    return per <= 40 ? 3 : (per <= 72 ? 5 : (per <= 132 ? 9 : 8));
+}
+inline int64_t agg_grid(int64_t m) {
+    const int64_t g = ceil_div(m, 16);
+    return g < 1 ? 1 : (g > N_CU ? N_CU : g);
+}
+
+}  // namespace
+
+// out[i] = init[i] + sum_{e -> i} SiLU(W_e e + b_m + Pi[i] + Pj[col[e]]) * (W_ea e)   for every node i < n_nodes
+// (nodes without edges get init).  z, ea: optional saves for the backward.  ptr [n_nodes + 1] / row_of / col: CSR by target.
+extern "C" int pamnet_global_edge_agg_fwd_f32(const float* e, int64_t n_edges, int64_t n_nodes, const float* We,
+                                              int64_t ld_we, const float* bm, const float* Wea, int64_t ld_wea,
+                                              const float* Pi, const float* Pj, const int32_t* ptr, const int32_t* row_of,
+                                              const int32_t* col, const float* init, float* z, float* ea, float* out,
+                                              pamnet_stream_t stream) {
+    if (n_edges < 0 || n_nodes < 0) return PAMNET_EINVAL;
+    if (n_nodes == 0) return PAMNET_OK;
+    if (!We || !bm || !Wea || !Pi || !Pj || !ptr || !out) return PAMNET_ENULL;      // init, z, ea: optional
+    if (n_edges > 0 && (!e || !row_of || !col)) return PAMNET_ENULL;
+    GAggFwd a{e, We, bm, Wea, Pi, Pj, init, ptr, row_of, col, z, ea, out, n_edges, n_nodes, (int)ld_we, (int)ld_wea};
+    const int64_t grid = agg_grid(n_edges);
+    hipStream_t st = as_stream(stream);
+    switch (pick_mtx(n_edges, grid)) {
+        case 3: hipLaunchKernelGGL((global_edge_agg_fwd_kernel<3, true>), dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
+        case 5: hipLaunchKernelGGL((global_edge_agg_fwd_kernel<5, true>), dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
+        case 9: hipLaunchKernelGGL((global_edge_agg_fwd_kernel<9, false>), dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
+        default: hipLaunchKernelGGL((global_edge_agg_fwd_kernel<8, true>), dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
+    }
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+// Backward of the fused global edge step: dz, dea [E,128] written (the weight gradients and the source-side reduction
+// read them), d_e written / accumulated, dPi[i] = sum_{e -> i} dz[e] for every node (zero for nodes without edges).
+extern "C" int pamnet_global_edge_agg_bwd_f32(const float* d_agg, int64_t n_edges, int64_t n_nodes, const int32_t* ptr,
+                                              const int32_t* row_of, const float* z, const float* ea, const float* We,
+                                              int64_t ld_we, const float* Wea, int64_t ld_wea, float* dz, float* dea,
+                                              float* d_e, int32_t accumulate, float* dPi, pamnet_stream_t stream) {
+    if (n_edges < 0 || n_nodes < 0) return PAMNET_EINVAL;
+    if (n_nodes == 0) return PAMNET_OK;
+    if (!d_agg || !ptr || !We || !Wea || !dPi) return PAMNET_ENULL;
+    if (n_edges > 0 && (!row_of || !z || !ea || !dz || !dea || !d_e)) return PAMNET_ENULL;
+    GAggBwd a{d_agg, z, ea, We, Wea, ptr, row_of, dz, dea, d_e, dPi, n_edges, n_nodes, (int)ld_we, (int)ld_wea,
+              (int)accumulate};
+    const int64_t grid = agg_grid(n_edges);
+    hipStream_t st = as_stream(stream);
+    switch (pick_mtx(n_edges, grid)) {
+        case 3: hipLaunchKernelGGL(global_edge_agg_bwd_kernel<3>, dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
+        case 5: hipLaunchKernelGGL(global_edge_agg_bwd_kernel<5>, dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
+        case 9: hipLaunchKernelGGL(global_edge_agg_bwd_kernel<9>, dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
+        default: hipLaunchKernelGGL(global_edge_agg_bwd_kernel<8>, dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
+    }
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+// m_t[e] = m_ji[e] + sum_{r in [t_ptr[e], t_ptr[e+1])} m_nb[t_col[r]] * s[r]      (m_t: optional save)
+// out[i] = init[i] + sum_{e in [l_ptr[i], l_ptr[i+1])} q3[e] * m_t[e]
+extern "C" int pamnet_local_agg_fwd_f32(const float* m_ji, const float* m_nb, const float* s, const float* q3,
+                                        const int32_t* t_ptr, const int32_t* t_col, const int32_t* l_ptr,
+                                        const float* init, int64_t n_nodes, float* m_t, float* out,
+                                        pamnet_stream_t stream) {
+    if (n_nodes < 0) return PAMNET_EINVAL;
+    if (n_nodes == 0) return PAMNET_OK;
+    if (!l_ptr || !t_ptr || !out) return PAMNET_ENULL;        // the float inputs may be null when there are no edges
+    hipLaunchKernelGGL(local_agg_fwd_kernel, dim3((unsigned)ceil_div(n_nodes, NPW)), dim3(256), 0, as_stream(stream),
+                       (const float4*)m_ji, (const float4*)m_nb, (const float4*)s, (const float4*)q3, t_ptr, t_col, l_ptr,
+                       (const float4*)init, (float4*)m_t, (float4*)out, n_nodes);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}

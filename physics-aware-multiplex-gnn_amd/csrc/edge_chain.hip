@@ -53,193 +53,10 @@ extern "C" int pamnet_probe_read_wg(long long* host, int n) {
 #define PROBE_WG(slot)
 #endif
 
+#include "edge_core.h"
+
 namespace {
 
-constexpr int WG8 = 512;                  // 8 waves
-constexpr int N_CU = 256;                 // MI355X
-constexpr int MT2 = 8;                    // largest chunk (16-row tiles) of the two-slot kernels (2 x 128 rows = 132 KB)
-
-// one 128 x 16 weight slice of a wave: 8 x float4 = 32 VGPRs
-struct WFrag1 {
-    float4 b[DIM / 16];
-};
-//   TRANS = false: W is [out][in] (row stride ldw): Y = X * W^T   (forward:  Linear)
-//   TRANS = true : Y = X * W                                       (backward: dX = dZ * W)
-template <bool TRANS>
-__device__ __forceinline__ void load_wfrag1(WFrag1& f, const float* __restrict__ W, int ldw, int wc) {
-    const int lane = threadIdx.x & 63;
-    const int r16 = lane & 15, kg = lane >> 4;
-#pragma unroll
-    for (int q = 0; q < DIM / 16; ++q) {
-        if (!TRANS) {
-            f.b[q] = *reinterpret_cast<const float4*>(W + (size_t)(wc + r16) * ldw + 4 * kg + 16 * q);
-        } else {
-            const float* wp = W + (size_t)(16 * q + 4 * kg) * ldw + wc + r16;
-            f.b[q] = make_float4(wp[0], wp[ldw], wp[2 * (size_t)ldw], wp[3 * (size_t)ldw]);
-        }
-    }
-}
-
-template <int MTX>
-struct Acc {
-    f32x4 v[MTX];
-    __device__ __forceinline__ void zero() {
-#pragma unroll
-        for (int i = 0; i < MTX; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-};
-
-// acc[0..MT) += As[16 m .. 16 m + 16, 0:128] * slice   (MT independent MFMA chains per k-step)
-template <int MT, int MTX>
-__device__ __forceinline__ void mma_strip(const float* __restrict__ As, const WFrag1& f, Acc<MTX>& acc) {
-    const int lane = threadIdx.x & 63;
-    const float* ap = As + (lane & 15) * LDT + 4 * (lane >> 4);
-#pragma unroll
-    for (int q = 0; q < DIM / 16; ++q) {
-        float4 a[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const float4*>(ap + m * 16 * LDT + 16 * q);
-        const float4 b = f.b[q];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc.v[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, b.x, acc.v[m], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc.v[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, b.y, acc.v[m], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc.v[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, b.z, acc.v[m], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc.v[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, b.w, acc.v[m], 0, 0, 0);
-    }
-}
-// mt (1..MTX) live 16-row tiles; mt is uniform over the workgroup
-template <int MTX>
-__device__ __forceinline__ void mma_n(const float* __restrict__ As, const WFrag1& f, Acc<MTX>& acc, int mt) {
-    switch (mt) {
-        case 1: mma_strip<1, MTX>(As, f, acc); break;
-        case 2: mma_strip<2, MTX>(As, f, acc); break;
-        case 3: mma_strip<3, MTX>(As, f, acc); break;
-        case 4: mma_strip<4, MTX>(As, f, acc); break;
-        case 5: mma_strip<5, MTX>(As, f, acc); break;
-        case 6: mma_strip<6, MTX>(As, f, acc); break;
-        case 7:
-            if constexpr (MTX >= 7) mma_strip<7, MTX>(As, f, acc);
-            break;
-        default:
-            if constexpr (MTX >= 8) mma_strip<8, MTX>(As, f, acc);
-            break;
-    }
-}
-// D[row][wc + col] = acc + bias for the live tiles (accumulator layout: rows 4*(lane>>4) + r, column lane & 15)
-template <int MTX>
-__device__ __forceinline__ void acc_store(const Acc<MTX>& acc, float* __restrict__ Ds, int wc, float bias, int mt) {
-    const int lane = threadIdx.x & 63;
-    const int col = wc + (lane & 15), kg = lane >> 4;
-#pragma unroll
-    for (int m = 0; m < MTX; ++m) {
-        if (m < mt) {
-            float* d = Ds + (m * 16 + kg * 4) * LDT + col;
-            d[0 * LDT] = acc.v[m][0] + bias;
-            d[1 * LDT] = acc.v[m][1] + bias;
-            d[2 * LDT] = acc.v[m][2] + bias;
-            d[3 * LDT] = acc.v[m][3] + bias;
-        }
-    }
-}
-// A workgroup is NW waves (8 or 4); wave w owns NS = 8 / NW consecutive 16-column slices.  Two 4-wave workgroups with
-// half the rows each share a CU: same waves per SIMD as one 8-wave workgroup, but their barriers are independent, so one
-// workgroup's load / epilogue sweeps overlap the other's GEMMs (measured -16 % on the triplet/pair MLP).
-// NW*64 threads sweep a [16 mt][128] tile: thread t owns float4 column t & 31 of rows (t >> 5) + 2 NW i.
-// f(row_in_chunk, c4); global accesses inside f are 512-byte coalesced rows.
-template <int MTX, int NW, typename F>
-__device__ __forceinline__ void sweep(int mt, F&& f) {
-    const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
-    constexpr int RPP = 2 * NW;                               // rows per pass
-#pragma unroll
-    for (int i = 0; i < 16 * MTX / RPP; ++i)
-        if (RPP * i < 16 * mt) f(r0 + RPP * i, c4);
-}
-
-template <int NS>
-struct WSet {                                                 // a wave's NS slices of one weight matrix
-    WFrag1 s[NS];
-};
-template <bool TRANS, int NS>
-__device__ __forceinline__ void load_wset(WSet<NS>& w, const float* __restrict__ W, int ldw, int wc) {
-#pragma unroll
-    for (int h = 0; h < NS; ++h) load_wfrag1<TRANS>(w.s[h], W, ldw, wc + 16 * h);
-}
-template <int MTX, int NS>
-struct AccSet {
-    Acc<MTX> a[NS];
-    __device__ __forceinline__ void zero() {
-#pragma unroll
-        for (int h = 0; h < NS; ++h) a[h].zero();
-    }
-};
-template <int MTX, int NS>
-__device__ __forceinline__ void mma_set(const float* __restrict__ As, const WSet<NS>& w, AccSet<MTX, NS>& acc, int mt) {
-#pragma unroll
-    for (int h = 0; h < NS; ++h) mma_n<MTX>(As, w.s[h], acc.a[h], mt);
-}
-template <int NS>
-struct BiasSet {
-    float v[NS];
-};
-template <int NS>
-__device__ __forceinline__ BiasSet<NS> lane_biases(const float* __restrict__ b, int wc) {
-    BiasSet<NS> r;
-#pragma unroll
-    for (int h = 0; h < NS; ++h) r.v[h] = b ? b[wc + 16 * h + (threadIdx.x & 15)] : 0.f;
-    return r;
-}
-template <int MTX, int NS>
-__device__ __forceinline__ void store_set(const AccSet<MTX, NS>& acc, float* __restrict__ Ds, int wc, const BiasSet<NS>& b,
-                                          int mt) {
-#pragma unroll
-    for (int h = 0; h < NS; ++h) acc_store<MTX>(acc.a[h], Ds, wc + 16 * h, b.v[h], mt);
-}
-
-// rows [beg, end) of this workgroup and its chunking: per = 16-row tiles per workgroup, cmt = tiles per chunk
-// workgroup b owns base (+1 for the first `rem` workgroups) consecutive 16-row tiles
-// NW = 4 (paired split, two co-resident workgroups per CU): "CU" c owns pa consecutive tiles; workgroup c takes the first
-// pc of them, workgroup pb + c the rest (pb = number of pairs).
-struct Span {
-    int64_t beg, end;
-    int cmt;
-    template <int NW>
-    static __device__ __forceinline__ Span make(int64_t m, int pa, int pb, int pc, int cmt_) {
-        Span sp;
-        sp.cmt = cmt_;
-        const int b = blockIdx.x;
-        int64_t t0, cnt;
-        if (NW == 8) {                                        // pa = base, pb = rem
-            t0 = (int64_t)b * pa + (b < pb ? b : pb);
-            cnt = pa + (b < pb ? 1 : 0);
-        } else {                                              // pa = tiles per pair, pb = pairs, pc = first share
-            const bool second = b >= pb;
-            const int c = second ? b - pb : b;
-            t0 = (int64_t)c * pa + (second ? pc : 0);
-            cnt = second ? pa - pc : pc;
-        }
-        sp.beg = t0 * 16;
-        const int64_t e = (t0 + cnt) * 16;
-        sp.end = e < m ? e : m;
-        if (sp.beg > sp.end) sp.beg = sp.end;
-        return sp;
-    }
-};
-#define CHUNK_LOOP(sp)                                                             \
-    for (int64_t row0 = (sp).beg; row0 < (sp).end; row0 += (int64_t)(sp).cmt * 16)
-__device__ __forceinline__ int chunk_mt(const Span& sp, int64_t row0) {
-    const int64_t left = sp.end - row0;
-    const int rows = left < (int64_t)sp.cmt * 16 ? (int)left : sp.cmt * 16;
-    return (rows + 15) >> 4;
-}
-
-template <int NW>
-__device__ __forceinline__ int wave_col() { return (threadIdx.x >> 6) * (128 / NW); }
-__device__ __forceinline__ float lane_bias(const float* __restrict__ b, int wc) {
-    return b ? b[wc + (threadIdx.x & 15)] : 0.f;
-}
 
 // -------------------------------------------------------------------------------------------------- global edges
 template <int MTX, int NW>

@@ -337,9 +337,9 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         const float* wpg[2] = {gp[2], gp[2] + D};
         // the head of every layer but the first runs inside the preceding layer's node chain (x_out tile still on chip)
         if (k == 0) CK(pamnet_node_pre_fwd_f32(x, g.n, gp[0], gp[1], wpg, 3 * D, 2, sv(s.Zx1), t.x1, t.P, st));
-        CK(pamnet_global_edge_fwd_f32(e_g, g.eg, gp[2] + 2 * D, 3 * D, gp[3], gp[4], D, t.P, t.P + g.n * D, g.g_row,
-                                      g.g_col, sv(s.z), sv(s.ea), t.msg, st));
-        CK(pamnet_segment_sum_f32(s.x2, t.x1, t.msg, nullptr, nullptr, nullptr, nullptr, g.g_ptr, g.n, D, st));
+        // message MLP + add-aggregation in one kernel: x2 = x1 + sum_{e -> i} msg_e, the messages never leave the chip
+        CK(pamnet_global_edge_agg_fwd_f32(e_g, g.eg, g.n, gp[2] + 2 * D, 3 * D, gp[3], gp[4], D, t.P, t.P + g.n * D,
+                                          g.g_ptr, g.g_row, g.g_col, t.x1, sv(s.z), sv(s.ea), s.x2, st));
         const float* const* lp = lparams + k * NL;
         const LocalSaved q = carve_local(saved + k * (gs + ls) + gs, g);
         const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
@@ -355,8 +355,8 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         CK(pamnet_local_edge_fwd_f32(rbf_e, g.el, wq, ldq, lp[3], lp[5], planes, g.l_row, g.l_col, sv(q.zji), sv(q.zkj),
                                      sv(q.q2), q.q3, t.mji, q.mnb, st));
         if (forked) HK(hipStreamWaitEvent(as_stream(st), reinterpret_cast<hipEvent_t>(aux_events[1 + k]), 0));
-        CK(pamnet_segment_sum_f32(q.mt, t.mji, q.mnb, g.t_col, q.s, nullptr, nullptr, g.t_ptr, g.el, D, st));
-        CK(pamnet_segment_sum_f32(q.x2, t.x1, q.mt, nullptr, q.q3, nullptr, nullptr, g.l_ptr, g.n, D, st));
+        // both aggregations of the local layer (rows -> edges -> nodes) in one launch; m_t is a backward-only save
+        CK(pamnet_local_agg_fwd_f32(t.mji, q.mnb, q.s, q.q3, g.t_ptr, g.t_col, g.l_ptr, t.x1, g.n, sv(q.mt), q.x2, st));
         if (k + 1 < n_layer) {
             const float* const* gn = gparams + (k + 1) * NG;
             const GlobalSaved sn = carve_global(saved + (k + 1) * (gs + ls), g);
@@ -557,16 +557,11 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 dz_global = t.dZ;
                 CK(pamnet_node_tail_main_bwd_f32(d_xout, s.gh, g.n, gp + GT, s.Z, dz_global, t.dx2, t.dresx, pk, st));
             }
-            CK(pamnet_global_edge_bwd_f32(t.dx2, g.g_row, g.eg, s.z, s.ea, gp[2] + 2 * D, 3 * D, gp[4], D, t.dz, t.dea,
-                                          d_eg, acc, st));
+            // d z, d ea, d e and the target-side reduction d P_i in one kernel; the source-side one walks the transposed CSR
             const int64_t pl = g.n * D;
-            {
-                float* so[2] = {t.dP, t.dP + pl};
-                const float* sa[2] = {t.dz, t.dz};
-                const int32_t* sp[2] = {nullptr, g.gT_perm};
-                const int32_t* sr[2] = {g.g_ptr, g.gT_ptr};
-                CK(pamnet_segment_sum_multi_f32(2, so, sa, sp, sr, g.n, D, st));
-            }
+            CK(pamnet_global_edge_agg_bwd_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, s.z, s.ea, gp[2] + 2 * D, 3 * D, gp[4], D,
+                                              t.dz, t.dea, d_eg, acc, t.dP, st));
+            CK(pamnet_segment_sum_f32(t.dP + pl, nullptr, t.dz, nullptr, nullptr, nullptr, g.gT_perm, g.gT_ptr, g.n, D, st));
             if (fuse && k > 0) {
                 // head of the global layer + the local chain of the previous pair
                 const LocalSaved qp = carve_local(const_cast<float*>(saved) + (k - 1) * (gs + ls) + gs, g);

@@ -238,12 +238,11 @@ class _GlobalLayer(torch.autograd.Function):
         st = lib.stream_of(x)
         wps = [_sub(Wm, 0), _sub(Wm, D)]
         Zx1, x1, P = k_pre_fwd(x, Wx1, bx1, wps, 3 * D)
-        z, ea, msg = _empty(m, D, like=x), _empty(m, D, like=x), _empty(m, D, like=x)
-        lib.call('pamnet_global_edge_fwd_f32', lib.ptr(e), m, _sub(Wm, 2 * D), 3 * D, lib.ptr(bm), lib.ptr(Wea), D,
-                 lib.ptr(P[0]), lib.ptr(P[1]), lib.ptr(csr.row_of), lib.ptr(csr.col), lib.ptr(z), lib.ptr(ea),
-                 lib.ptr(msg), st)
-        x2 = _empty(n, D, like=x)
-        segment_sum_raw(x2, x1, msg, None, None, None, None, csr.ptr, n, D)            # x1 + sum_{e -> i} msg_e
+        z, ea, x2 = _empty(m, D, like=x), _empty(m, D, like=x), _empty(n, D, like=x)
+        # message MLP + add-aggregation, one kernel: x2 = x1 + sum_{e -> i} msg_e   (global_message_passing.py:38,52-56)
+        lib.call('pamnet_global_edge_agg_fwd_f32', lib.ptr(e), m, n, _sub(Wm, 2 * D), 3 * D, lib.ptr(bm), lib.ptr(Wea), D,
+                 lib.ptr(P[0]), lib.ptr(P[1]), lib.ptr(csr.ptr), lib.ptr(csr.row_of), lib.ptr(csr.col), lib.ptr(x1),
+                 lib.ptr(z), lib.ptr(ea), lib.ptr(x2), st)
         Z, R, x_out, out, att = k_tail_fwd(x2, x, tp)
         ctx.save_for_backward(x, e, Zx1, z, ea, x2, Z, R, x_out, *params)
         ctx.graph, ctx.plist = graph, plist
@@ -264,10 +263,10 @@ class _GlobalLayer(torch.autograd.Function):
         gt = g[5:]
         dZ, d_x2, d_resx = k_tail_bwd(g_x, g_out, g_att, tp, Z, gt[20], gt[21], gt[22])
         dz, dea, d_e = _empty(m, D, like=x), _empty(m, D, like=x), _empty(m, D, like=x)
-        lib.call('pamnet_global_edge_bwd_f32', lib.ptr(d_x2), lib.ptr(csr.row_of), m, lib.ptr(z), lib.ptr(ea),
-                 _sub(Wm, 2 * D), 3 * D, lib.ptr(Wea), D, lib.ptr(dz), lib.ptr(dea), lib.ptr(d_e), 0, st)
         dP = _empty(2, n, D, like=x)
-        segment_sum_raw(dP[0], None, dz, None, None, None, None, csr.ptr, n, D)         # d P_i: edges into i
+        lib.call('pamnet_global_edge_agg_bwd_f32', lib.ptr(d_x2), m, n, lib.ptr(csr.ptr), lib.ptr(csr.row_of), lib.ptr(z),
+                 lib.ptr(ea), _sub(Wm, 2 * D), 3 * D, lib.ptr(Wea), D, lib.ptr(dz), lib.ptr(dea), lib.ptr(d_e), 0,
+                 lib.ptr(dP[0]), st)                                                    # d P_i (edges into i) fused
         segment_sum_raw(dP[1], None, dz, None, None, None, tr.perm, tr.ptr, n, D)       # d P_j: edges out of j
         wps = [_sub(Wm, 0), _sub(Wm, D)]
         dZx1, dx = k_pre_bwd(dP, d_x2, d_resx, Wx1, wps, 3 * D, Zx1)
@@ -311,10 +310,10 @@ class _LocalLayer(torch.autograd.Function):
         z1, z2, s = _empty(t, D, like=x), _empty(t, D, like=x), _empty(t, D, like=x)
         lib.call('pamnet_mlp2_fwd_f32', lib.ptr(sbf), t, lib.ptr(Ws1), lib.ptr(bs1), lib.ptr(Ws2), lib.ptr(bs2),
                  lib.ptr(z1), lib.ptr(z2), lib.ptr(s), st)
-        m_t = _empty(m, D, like=x)          # m_ji + sum_{rows of e} m_nb[idx] * s        (local_message_passing.py:49-51)
-        segment_sum_raw(m_t, m_ji, m_nb, tpc.col, s, None, None, tpc.ptr, m, D)
-        x2 = _empty(n, D, like=x)           # x1 + sum_{e -> i} q3 * m_t                    (local_message_passing.py:53-54)
-        segment_sum_raw(x2, x1, m_t, None, q3, None, None, loc.ptr, n, D)
+        # m_t = m_ji + sum_{rows of e} m_nb[idx] * s;  x2 = x1 + sum_{e -> i} q3 * m_t     (local_message_passing.py:49-54)
+        m_t, x2 = _empty(m, D, like=x), _empty(n, D, like=x)
+        lib.call('pamnet_local_agg_fwd_f32', lib.ptr(m_ji), lib.ptr(m_nb), lib.ptr(s), lib.ptr(q3), lib.ptr(tpc.ptr),
+                 lib.ptr(tpc.col), lib.ptr(loc.ptr), lib.ptr(x1), n, lib.ptr(m_t), lib.ptr(x2), st)
         Z, R, x_out, out, att = k_tail_fwd(x2, x, tp)
         ctx.save_for_backward(x, rbf, sbf, Zx1, z_ji, z_kj, q2, q3, m_nb, s, m_t, z1, z2, x2, Z, R, x_out, *params)
         ctx.graph, ctx.plist = graph, plist

@@ -1,0 +1,200 @@
+"""Edge MLP -> node segment-sum as one kernel (csrc/edge_agg.hip) vs an fp64 torch evaluation of
+layers/global_message_passing.py:38,52-56 (message + add-aggregation) and local_message_passing.py:49-54 on the same
+GPU, and vs the unfused kernels (pamnet_global_edge_fwd_f32 + pamnet_segment_sum_f32).  Degree patterns the reference's
+graphs produce plus the adversarial ones for a node-aligned work split: nodes without edges (leading, trailing, runs in
+the middle), one node with more rows than a chunk holds, no edges at all, every launch geometry (3/5/9/8-tile chunks)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import maxnorm_err
+
+pytestmark = pytest.mark.gpu
+D = 128
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _csr(deg, n_src, seed, dev):
+    """Random CSR-by-target graph with the given in-degrees; sources uniform in [0, n_src)."""
+    rng = np.random.default_rng(seed)
+    deg = np.asarray(deg, dtype=np.int64)
+    ptr = np.concatenate([[0], np.cumsum(deg)])
+    m = int(ptr[-1])
+    row_of = np.repeat(np.arange(len(deg)), deg)
+    col = rng.integers(0, n_src, size=m)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch.int32).to(dev)
+    return t(ptr), t(row_of), t(col), m
+
+
+DEGREE_CASES = {
+    'qm9_like': lambda rng: rng.integers(8, 22, size=2286),
+    'tiny': lambda rng: rng.integers(0, 5, size=40),
+    'mid': lambda rng: rng.integers(5, 30, size=700),          # 5-tile geometry
+    'small3': lambda rng: rng.integers(3, 12, size=900),        # 3-tile geometry
+    'pdbbind_like': lambda rng: rng.integers(20, 60, size=3000),   # several chunks per workgroup (8-tile geometry)
+    'holes': lambda rng: np.concatenate([np.zeros(7, int), rng.integers(0, 3, size=500) * rng.integers(0, 20, size=500),
+                                         np.zeros(40, int), rng.integers(10, 20, size=300), np.zeros(5, int)]),
+    'giant': lambda rng: np.concatenate([rng.integers(5, 20, size=100), [700], rng.integers(5, 20, size=100), [150, 0, 0, 145],
+                                         rng.integers(5, 20, size=50)]),
+    'one_giant': lambda rng: np.array([1000]),
+    'no_edges': lambda rng: np.zeros(33, int),
+    'single_edge': lambda rng: np.array([0, 0, 1, 0]),
+}
+
+
+def _weights(dev, seed):
+    gen = torch.Generator().manual_seed(seed)
+    mk = lambda *s: (torch.randn(*s, generator=gen) / 8.0).to(dev)
+    return mk(D, 3 * D), mk(D), mk(D, D)          # mlp_m.weight [128,384], bias, W_edge_attr
+
+
+def _ref_fwd(e, Wm, bm, Wea, Pi, Pj, row_of, col, init, n):
+    dd = lambda t: t.double()
+    z = dd(e) @ dd(Wm[:, 2 * D:]).t() + dd(bm) + dd(Pi)[row_of.long()] + dd(Pj)[col.long()]
+    ea = dd(e) @ dd(Wea).t()
+    msg = torch.nn.functional.silu(z) * ea
+    out = dd(init).clone()
+    out.index_add_(0, row_of.long(), msg)
+    return z, ea, msg, out
+
+
+@pytest.mark.parametrize('case', sorted(DEGREE_CASES))
+def test_global_edge_agg_fwd_bwd(dev, case):
+    from pamnet_amd import lib
+    from pamnet_amd.ops import segment_sum_raw
+    rng = np.random.default_rng(3)
+    deg = DEGREE_CASES[case](rng)
+    n = len(deg)
+    ptr, row_of, col, m = _csr(deg, n, 5, dev)
+    gen = torch.Generator().manual_seed(11)
+    mk = lambda *s: (0.5 * torch.randn(*s, generator=gen)).to(dev)
+    e, Pi, Pj, init = mk(max(m, 1), D)[:m], mk(n, D), mk(n, D), mk(n, D)
+    Wm, bm, Wea = _weights(dev, 2)
+    st = lib.stream_of(Pi)
+    sub = lambda w, c0: w.data_ptr() + 4 * c0
+    z, ea = (torch.full((max(m, 1), D), float('nan'), device=dev)[:m] for _ in range(2))
+    out = torch.full((n, D), float('nan'), device=dev)
+    lib.call('pamnet_global_edge_agg_fwd_f32', lib.ptr(e), m, n, sub(Wm, 2 * D), 3 * D, lib.ptr(bm), lib.ptr(Wea), D,
+             lib.ptr(Pi), lib.ptr(Pj), lib.ptr(ptr), lib.ptr(row_of), lib.ptr(col), lib.ptr(init), lib.ptr(z),
+             lib.ptr(ea), lib.ptr(out), st)
+    z64, ea64, msg64, out64 = _ref_fwd(e, Wm, bm, Wea, Pi, Pj, row_of, col, init, n)
+    assert torch.isfinite(out).all()
+    assert maxnorm_err(out.cpu(), out64.cpu()) < 2e-6
+    if m:
+        assert maxnorm_err(z.cpu(), z64.cpu()) < 2e-6 and maxnorm_err(ea.cpu(), ea64.cpu()) < 2e-6
+    # inference mode: no saves, same result bit for bit; run-to-run bitwise identical
+    out2 = torch.empty_like(out)
+    lib.call('pamnet_global_edge_agg_fwd_f32', lib.ptr(e), m, n, sub(Wm, 2 * D), 3 * D, lib.ptr(bm), lib.ptr(Wea), D,
+             lib.ptr(Pi), lib.ptr(Pj), lib.ptr(ptr), lib.ptr(row_of), lib.ptr(col), lib.ptr(init), None, None,
+             lib.ptr(out2), st)
+    assert torch.equal(out, out2)
+    # against the unfused pair (edge kernel + scatter-add kernel): same maths, different summation order
+    if m:
+        z3, ea3, msg3 = (torch.empty(m, D, device=dev) for _ in range(3))
+        lib.call('pamnet_global_edge_fwd_f32', lib.ptr(e), m, sub(Wm, 2 * D), 3 * D, lib.ptr(bm), lib.ptr(Wea), D,
+                 lib.ptr(Pi), lib.ptr(Pj), lib.ptr(row_of), lib.ptr(col), lib.ptr(z3), lib.ptr(ea3), lib.ptr(msg3), st)
+        out3 = torch.empty_like(out)
+        segment_sum_raw(out3, init, msg3, None, None, None, None, ptr, n, D)
+        assert torch.equal(z, z3) and torch.equal(ea, ea3)
+        assert maxnorm_err(out.cpu(), out3.cpu()) < 2e-6
+
+    # ---- backward
+    d_agg = mk(n, D)
+    dz, dea, d_e = (torch.full((max(m, 1), D), float('nan'), device=dev)[:m] for _ in range(3))
+    dPi = torch.full((n, D), float('nan'), device=dev)
+    lib.call('pamnet_global_edge_agg_bwd_f32', lib.ptr(d_agg), m, n, lib.ptr(ptr), lib.ptr(row_of), lib.ptr(z),
+             lib.ptr(ea), sub(Wm, 2 * D), 3 * D, lib.ptr(Wea), D, lib.ptr(dz), lib.ptr(dea), lib.ptr(d_e), 0,
+             lib.ptr(dPi), st)
+    dm = d_agg.double()[row_of.long()]
+    sg = torch.sigmoid(z64)
+    dz64 = dm * ea64 * (sg * (1 + z64 * (1 - sg)))
+    dea64 = dm * torch.nn.functional.silu(z64)
+    de64 = dz64 @ Wm[:, 2 * D:].double() + dea64 @ Wea.double()
+    dPi64 = torch.zeros(n, D, dtype=torch.float64, device=dev).index_add_(0, row_of.long(), dz64)
+    assert torch.isfinite(dPi).all()
+    assert maxnorm_err(dPi.cpu(), dPi64.cpu()) < 3e-6 or float(dPi64.abs().max()) == 0.0
+    if m:
+        for a, b in ((dz, dz64), (dea, dea64), (d_e, de64)):
+            assert maxnorm_err(a.cpu(), b.cpu()) < 3e-6
+        # accumulate flag
+        d_e2 = d_e.clone()
+        lib.call('pamnet_global_edge_agg_bwd_f32', lib.ptr(d_agg), m, n, lib.ptr(ptr), lib.ptr(row_of), lib.ptr(z),
+                 lib.ptr(ea), sub(Wm, 2 * D), 3 * D, lib.ptr(Wea), D, lib.ptr(dz), lib.ptr(dea), lib.ptr(d_e2), 1,
+                 lib.ptr(dPi), st)
+        assert maxnorm_err(d_e2.cpu(), (2 * de64).cpu()) < 3e-6
+
+
+def test_fused_result_independent_of_batching(dev):
+    """A node's sum has one owner and CSR order whatever the launch geometry: a graph evaluated alone and as part of
+    a larger batch (different workgroup cuts, different chunk instantiation) gives bitwise identical rows."""
+    from pamnet_amd import lib
+    rng = np.random.default_rng(9)
+    deg_a = rng.integers(4, 25, size=300)
+    deg_b = rng.integers(4, 25, size=2500)
+    Wm, bm, Wea = _weights(dev, 4)
+    sub = lambda w, c0: w.data_ptr() + 4 * c0
+    gen = torch.Generator().manual_seed(1)
+    mk = lambda *s: (0.5 * torch.randn(*s, generator=gen)).to(dev)
+
+    def run(deg, e, Pi, Pj, init, col_np):
+        n = len(deg)
+        ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(deg)])).to(torch.int32).to(dev)
+        row_of = torch.from_numpy(np.repeat(np.arange(n), deg)).to(torch.int32).to(dev)
+        col = torch.from_numpy(col_np).to(torch.int32).to(dev)
+        out = torch.empty(n, D, device=dev)
+        lib.call('pamnet_global_edge_agg_fwd_f32', lib.ptr(e), e.size(0), n, sub(Wm, 2 * D), 3 * D, lib.ptr(bm),
+                 lib.ptr(Wea), D, lib.ptr(Pi), lib.ptr(Pj), lib.ptr(ptr), lib.ptr(row_of), lib.ptr(col), lib.ptr(init),
+                 None, None, lib.ptr(out), lib.stream_of(e))
+        return out
+
+    ma, mb = int(deg_a.sum()), int(deg_b.sum())
+    na, nb = len(deg_a), len(deg_b)
+    e, Pi, Pj, init = mk(ma + mb, D), mk(na + nb, D), mk(na + nb, D), mk(na + nb, D)
+    col_a = rng.integers(0, na, size=ma)
+    col_b = rng.integers(0, nb, size=mb) + na
+    alone = run(deg_a, e[:ma].contiguous(), Pi, Pj, init, col_a)
+    both = run(np.concatenate([deg_a, deg_b]), e, Pi, Pj, init, np.concatenate([col_a, col_b]))
+    assert torch.equal(alone, both[:na])
+
+
+@pytest.mark.parametrize('case', ['qm9_like', 'holes', 'tiny', 'no_edges', 'giant'])
+def test_local_agg_fwd(dev, case):
+    """m_t = m_ji + sum_r m_nb[idx[r]] * s[r];  x2 = x1 + sum_{e -> i} q3[e] * m_t[e]  (local_message_passing.py:49-54)."""
+    from pamnet_amd import lib
+    from pamnet_amd.ops import segment_sum_raw
+    rng = np.random.default_rng(21)
+    deg = np.minimum(DEGREE_CASES[case](rng), 40) // 4                # local in-degrees 0..10
+    n = len(deg)
+    l_ptr, l_row, l_col, m = _csr(deg, n, 2, dev)
+    tdeg = rng.integers(0, 9, size=m) if m else np.zeros(0, int)
+    if case == 'giant' and m:
+        tdeg[m // 2] = 300
+    t_ptr, t_row, t_col, t = _csr(tdeg, max(m, 1), 3, dev) if m else (torch.zeros(1, dtype=torch.int32, device=dev), None, None, 0)
+    gen = torch.Generator().manual_seed(5)
+    mk = lambda r: (0.5 * torch.randn(max(r, 1), D, generator=gen)).to(dev)[:r]
+    m_ji, m_nb, q3, s, x1 = mk(m), mk(m), mk(m), mk(t), mk(n)
+    m_t = torch.full((max(m, 1), D), float('nan'), device=dev)[:m]
+    out = torch.full((n, D), float('nan'), device=dev)
+    lib.call('pamnet_local_agg_fwd_f32', lib.ptr(m_ji), lib.ptr(m_nb), lib.ptr(s), lib.ptr(q3), lib.ptr(t_ptr),
+             lib.ptr(t_col), lib.ptr(l_ptr), lib.ptr(x1), n, lib.ptr(m_t), lib.ptr(out), lib.stream_of(x1))
+    mt64 = m_ji.double().clone()
+    if t:
+        mt64.index_add_(0, t_row.long(), m_nb.double()[t_col.long()] * s.double())
+    out64 = x1.double().clone()
+    if m:
+        out64.index_add_(0, l_row.long(), q3.double() * mt64)
+    assert torch.isfinite(out).all()
+    assert maxnorm_err(out.cpu(), out64.cpu()) < 2e-6
+    if m:
+        assert maxnorm_err(m_t.cpu(), mt64.cpu()) < 2e-6
+    out2 = torch.empty_like(out)
+    lib.call('pamnet_local_agg_fwd_f32', lib.ptr(m_ji), lib.ptr(m_nb), lib.ptr(s), lib.ptr(q3), lib.ptr(t_ptr),
+             lib.ptr(t_col), lib.ptr(l_ptr), lib.ptr(x1), n, None, lib.ptr(out2), lib.stream_of(x1))
+    assert torch.equal(out, out2)
