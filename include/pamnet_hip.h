@@ -274,6 +274,13 @@ int pamnet_global_edge_agg_bwd_f32(const float* d_agg, int64_t n_edges, int64_t 
 int pamnet_local_agg_fwd_f32(const float* m_ji, const float* m_nb, const float* s, const float* q3,
                              const int32_t* t_ptr, const int32_t* t_col, const int32_t* l_ptr, const float* init,
                              int64_t n_nodes, float* m_t, float* out, pamnet_stream_t stream);
+/* backward of pamnet_local_agg_fwd_f32, one launch: d_mt[e] = d_x2[l_row[e]] * q3[e];  d_q3[e] = d_x2[l_row[e]] * m_t[e];
+ * d_s[r] = m_nb[t_col[r]] * d_mt[t_row[r]];  d_mnb[e'] = sum_{r: t_col[r] = e'} s[r] * d_mt[t_row[r]]
+ * (tT_ptr / tT_perm: transposed CSR of t_col over the local edges). */
+int pamnet_local_agg_bwd_f32(const float* d_x2, const int32_t* l_row, const float* q3, const float* m_t,
+                             const float* m_nb, const float* s, const int32_t* t_ptr, const int32_t* t_col,
+                             const int32_t* t_row, const int32_t* tT_ptr, const int32_t* tT_perm, int64_t n_edges,
+                             float* d_mt, float* d_q3, float* d_s, float* d_mnb, pamnet_stream_t stream);
 int pamnet_mlp2_fwd_f32(const float* x, int64_t rows, const float* W1, const float* b1, const float* W2,
                         const float* b2, float* z1, float* z2, float* y, pamnet_stream_t stream);
 /* nsets <= 8 such MLPs on the same input rows in one launch: params[4k..4k+3] = {W1, b1, W2, b2} of set k,

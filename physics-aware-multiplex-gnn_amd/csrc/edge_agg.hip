@@ -7,12 +7,12 @@
 // kernels of edge_chain.hip cut the rows into 16-row tiles regardless of the nodes; here the cuts are NODE-ALIGNED:
 //   * workgroup b of G owns the nodes [cut(b), cut(b+1)), cut(k) = the node boundary nearest to row k*E/G
 //     (two loads: row_of[k*E/G], ptr[.]), i.e. ~E/G rows give or take half a node degree;
-//   * it walks its rows in chunks of whole nodes (<= 16*MTX rows, <= 511 nodes): e rows -> LDS, two fp32-MFMA GEMMs,
-//     epilogue z = W_e e + b + P_i[i] + P_j[j], msg = SiLU(z) * (W_ea e) written back into the LDS tile, then one
-//     32-lane group per node adds the node's rows IN CSR ORDER onto init[node] and stores the 512-byte output row.
-//   Every output row is produced by exactly one lane group with a fixed summation order: no atomics, no carry between
-//   workgroups, bitwise identical from run to run and independent of how the batch is cut into workgroups / chunks
-//   (a node with more rows than a chunk is walked in pieces with the running sum kept in registers: same order).
+//   * it walks its rows in chunks of 16*MTX rows (full MFMA tiles): e rows -> LDS, two fp32-MFMA GEMMs, epilogue
+//     z = W_e e + b + P_i[i] + P_j[j], msg = SiLU(z) * (W_ea e) written back into the LDS tile, then one 32-lane
+//     group per node adds the node's rows IN CSR ORDER onto init[node] and stores the 512-byte output row; a node
+//     cut by a chunk boundary hands its running sum to the next chunk through LDS (same order).
+//   Every output row has exactly one owner and a fixed summation order: no atomics, no carry between workgroups,
+//   bitwise identical from run to run and independent of how the batch is cut into workgroups / chunks.
 // The backward kernel mirrors it: d z rows are reduced per target node (d P_i) from the LDS tile before the dX GEMMs
 // overwrite it; only the reduction by SOURCE node (transposed CSR) remains a separate segment sum.
 //
@@ -36,46 +36,24 @@ __device__ __forceinline__ int seg_cut(const int32_t* __restrict__ ptr, const in
     return (t - a <= b - t) ? node : node + 1;
 }
 
+// A workgroup walks its rows [rb, re) in chunks of CAP rows (full MFMA tiles; the last one may be short).  A chunk
+// touches the nodes [c0, c1]: c0 may have begun in the previous chunk (its running sum arrives in `carry`), c1 may
+// continue in the next one (its running sum leaves in `carry`); every node in between is complete.  Workgroup
+// boundaries are node-aligned, so nothing is ever carried between workgroups.
 struct Chunk {
-    int c0, c1;            // whole nodes [c0, c1)  (giant: the single node c0)
-    int64_t r0, r1;        // rows [r0, r1)
-    bool giant, finish;    // giant: a piece of one node's segment; finish: the piece reaches the segment's end
+    int c1;                // last node of the chunk (inclusive)
+    int64_t r1;            // rows [r0, r1)
 };
 
-// next chunk from (c0, r0); `mid`: r0 lies inside node c0's segment (continuation of a giant node)
 __device__ __forceinline__ Chunk plan_chunk(const int32_t* __restrict__ ptr, const int32_t* __restrict__ row_of, int c0,
-                                            int64_t r0, bool mid, int ne, int64_t re, int cap) {
+                                            int64_t r0, int ne, int64_t re, int cap) {
     Chunk ch;
-    ch.c0 = c0, ch.r0 = r0, ch.giant = false, ch.finish = false;
-    if (mid) {
-        const int64_t se = ptr[c0 + 1];
-        ch.giant = true;
-        ch.r1 = r0 + cap < se ? r0 + cap : se;
-        ch.finish = ch.r1 == se;
-        ch.c1 = c0;
-        return ch;
-    }
-    const int64_t rem = re - r0;
-    const int64_t nch = rem > cap ? (rem + cap - 1) / cap : 1;
-    const int64_t tgt = rem > 0 ? (rem + nch - 1) / nch : 1;          // balanced chunks of <= cap rows
-    const int64_t t = r0 + tgt;
-    if (t >= re) {
-        ch.c1 = ne, ch.r1 = re;
-    } else {
-        const int node = row_of[t];
-        const int64_t a = ptr[node], b = ptr[node + 1];
-        if (b - r0 <= cap) {
-            ch.c1 = node + 1, ch.r1 = b;
-        } else if (node > c0) {
-            ch.c1 = node, ch.r1 = a;
-        } else {                                                       // node c0 alone has more than cap rows
-            ch.giant = true, ch.c1 = c0, ch.r1 = r0 + cap;
-            return ch;
-        }
-    }
-    if (ch.c1 - c0 > NMAX) {
-        ch.c1 = c0 + NMAX;
-        ch.r1 = ptr[ch.c1];
+    ch.r1 = r0 + cap < re ? r0 + cap : re;
+    ch.c1 = ch.r1 < re ? row_of[ch.r1 - 1] : ne - 1;       // the workgroup's last chunk also takes trailing empty nodes
+    if (ch.c1 - c0 + 1 > NMAX) {                            // a long run of nodes without edges
+        ch.c1 = c0 + NMAX - 1;
+        const int64_t e1 = ptr[ch.c1 + 1];
+        if (e1 < ch.r1) ch.r1 = e1;
     }
     return ch;
 }
@@ -90,25 +68,22 @@ __device__ __forceinline__ void seq_add(float4& s, const float* __restrict__ til
     for (; q < q1; ++q) s = f4add(s, lds4(tile, q, c4));
 }
 
-// out[node] = init[node] + sum of the node's rows of `tile` (rows relative to the chunk), one 32-lane group per node
+// out[node] = init[node] + sum of the node's rows of `tile`, one 32-lane group per node, rows in CSR order.
+// sptr[k] = ptr[c0 + k] - r0 for k = 0 .. nn (raw: negative = the node began before the chunk, > rows = it goes on).
 template <int NGRP>
-__device__ __forceinline__ void reduce_nodes(int c0, int nn, bool giant, bool finish, int rows,
-                                             const float* __restrict__ tile, const int* __restrict__ sptr,
-                                             const float* __restrict__ init, float* __restrict__ out, f32x4& carry,
-                                             bool mid) {
+__device__ __forceinline__ void reduce_nodes(int c0, int nn, int rows, const float* __restrict__ tile,
+                                             const int* __restrict__ sptr, const float4* __restrict__ carry_in,
+                                             float4* __restrict__ carry_out, const float* __restrict__ init,
+                                             float* __restrict__ out) {
     const int grp = threadIdx.x >> 5, c4 = threadIdx.x & 31;
-    if (!giant) {
-        for (int k = grp; k < nn; k += NGRP) {
-            float4 s = init ? ldg4(init, c0 + k, DIM, c4) : f4zero();
-            seq_add(s, tile, sptr[k], sptr[k + 1], c4);
-            stg4(out, c0 + k, DIM, c4, s);
-        }
-    } else if (grp == 0) {
-        float4 s = init ? ldg4(init, c0, DIM, c4) : f4zero();
-        if (mid) s = make_float4(carry[0], carry[1], carry[2], carry[3]);
-        seq_add(s, tile, 0, rows, c4);
-        if (finish) stg4(out, c0, DIM, c4, s);
-        else carry = f32x4{s.x, s.y, s.z, s.w};
+    for (int k = grp; k < nn; k += NGRP) {
+        const int b = sptr[k], e = sptr[k + 1];
+        float4 s;
+        if (b < 0) s = carry_in[c4];                                    // only k = 0
+        else s = init ? ldg4(init, c0 + k, DIM, c4) : f4zero();
+        seq_add(s, tile, b < 0 ? 0 : b, e > rows ? rows : e, c4);
+        if (e > rows) carry_out[c4] = s;                                // only k = nn - 1 (another lane group than k = 0)
+        else stg4(out, c0 + k, DIM, c4, s);
     }
 }
 
@@ -126,6 +101,7 @@ template <int MTX, bool PRE>
 __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
     __shared__ int sptr[NMAX + 1];
+    __shared__ float4 carry[2][32];                         // running sum of a node that spans two chunks (in / out)
     float* S0 = lds;
     float* S1 = lds + MTX * 16 * LDT;
     constexpr int CAP = MTX * 16;
@@ -153,19 +129,16 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
 #pragma unroll
         for (int i = 0; i < NI; ++i) pre[i] = ldg4z(e, rb + rr + RPP * i, re, DIM, c4);
     }
-    int c0 = nb;
+    int c0 = nb, par = 0;
     int64_t r0 = rb;
-    bool mid = false;
-    f32x4 carry = f32x4{0.f, 0.f, 0.f, 0.f};         // running sum of a node that spans several chunks
     while (c0 < ne) {
-        const Chunk ch = plan_chunk(ptr, row_of, c0, r0, mid, ne, re, CAP);
+        const Chunk ch = plan_chunk(ptr, row_of, c0, r0, ne, re, CAP);
         const int64_t r1 = ch.r1;
         const int c1 = ch.c1;
-        const bool giant = ch.giant, finish = ch.finish;
         const int rows = (int)(r1 - r0);
         const int mt = (rows + 15) >> 4;
         // CSR offsets of the chunk's nodes: requested now, parked in LDS before the reduction
-        const int nn = giant ? 0 : c1 - c0;
+        const int nn = c1 - c0 + 1;
         const int myp = (int)threadIdx.x <= nn ? ptr[c0 + threadIdx.x] - (int)r0 : 0;
         if (rows > 0) {
             if (PRE) {
@@ -209,15 +182,12 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
             sptr[threadIdx.x] = myp;
         }
         __syncthreads();
-        reduce_nodes<16>(c0, nn, giant, finish, rows, S1, sptr, a.init, a.out, carry, mid);
+        const bool open_end = sptr[nn] > rows;                 // the last node continues in the next chunk
+        reduce_nodes<16>(c0, nn, rows, S1, sptr, carry[par], carry[par ^ 1], a.init, a.out);
+        par ^= 1;
         __syncthreads();
-        if (giant) {
-            r0 = r1;
-            mid = !finish;
-            if (finish) ++c0;
-        } else {
-            c0 = c1, r0 = r1;
-        }
+        c0 = open_end ? c1 : c1 + 1;
+        r0 = r1;
     }
 }
 
@@ -235,6 +205,7 @@ template <int MTX>
 __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
     __shared__ int sptr[NMAX + 1];
+    __shared__ float4 carry[2][32];
     float* S0 = lds;
     float* S1 = lds + MTX * 16 * LDT;
     constexpr int CAP = MTX * 16;
@@ -257,18 +228,15 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
     const int64_t re = ptr[ne];
     constexpr int RPP = 16, NI = MTX;
     const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;
-    int c0 = nb;
+    int c0 = nb, par = 0;
     int64_t r0 = ptr[nb];
-    bool mid = false;
-    f32x4 carry = f32x4{0.f, 0.f, 0.f, 0.f};         // running sum of a node that spans several chunks
     while (c0 < ne) {
-        const Chunk ch = plan_chunk(ptr, row_of, c0, r0, mid, ne, re, CAP);
+        const Chunk ch = plan_chunk(ptr, row_of, c0, r0, ne, re, CAP);
         const int64_t r1 = ch.r1;
         const int c1 = ch.c1;
-        const bool giant = ch.giant, finish = ch.finish;
         const int rows = (int)(r1 - r0);
         const int mt = (rows + 15) >> 4;
-        const int nn = giant ? 0 : c1 - c0;
+        const int nn = c1 - c0 + 1;
         if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = ptr[c0 + threadIdx.x] - (int)r0;
         if (rows > 0) {
 #pragma unroll
@@ -290,7 +258,9 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
             }
         }
         __syncthreads();
-        reduce_nodes<16>(c0, nn, giant, finish, rows, S0, sptr, nullptr, a.dPi, carry, mid);   // reads S0 only
+        const bool open_end = sptr[nn] > rows;
+        reduce_nodes<16>(c0, nn, rows, S0, sptr, carry[par], carry[par ^ 1], nullptr, a.dPi);   // reads S0 only
+        par ^= 1;
         if (rows > 0) {
             AccSet<MTX, 1> acc;
             acc.zero();
@@ -311,13 +281,8 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
             }
         }
         __syncthreads();
-        if (giant) {
-            r0 = r1;
-            mid = !finish;
-            if (finish) ++c0;
-        } else {
-            c0 = c1, r0 = r1;
-        }
+        c0 = open_end ? c1 : c1 + 1;
+        r0 = r1;
     }
 }
 
@@ -377,6 +342,62 @@ __global__ __launch_bounds__(256) void local_agg_fwd_kernel(const float4* __rest
         if (e0 + 8 >= ee) break;
     }
     if (owner) out[node * 32 + c] = acc;
+}
+
+// Backward of local_agg_fwd up to the inputs of the MLP kernels, one launch (blockIdx.y selects the direction):
+//   y = 0, one lane group per edge e (target i):  d m_t[e] = d x2[i] * q3[e],  d q3[e] = d x2[i] * m_t[e],
+//          d s[r] = m_nb[idx[r]] * d m_t[e] for the rows r of e;
+//   y = 1, one lane group per edge e' walking the transposed row list:  d m_nb[e'] = sum_{r: idx[r] = e'} s[r] * d m_t[edge(r)]
+//          with d m_t recomputed from d x2 and q3 (no dependency on the y = 0 half), rows in transposed-CSR order.
+__global__ __launch_bounds__(256) void local_agg_bwd_kernel(const float4* __restrict__ d_x2, const int32_t* __restrict__ l_row,
+                                                            const float4* __restrict__ q3, const float4* __restrict__ m_t,
+                                                            const float4* __restrict__ m_nb, const float4* __restrict__ s,
+                                                            const int32_t* __restrict__ t_ptr,
+                                                            const int32_t* __restrict__ t_col,
+                                                            const int32_t* __restrict__ t_row,
+                                                            const int32_t* __restrict__ tT_ptr,
+                                                            const int32_t* __restrict__ tT_perm, int64_t el,
+                                                            float4* __restrict__ d_mt, float4* __restrict__ d_q3,
+                                                            float4* __restrict__ d_s, float4* __restrict__ d_mnb) {
+    const int c = threadIdx.x & 31;
+    const int64_t e = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (e >= el) return;
+    if (blockIdx.y == 0) {
+        const float4 dx = d_x2[(int64_t)l_row[e] * 32 + c];
+        const float4 g = pamnet::f4mul(dx, q3[e * 32 + c]);
+        d_mt[e * 32 + c] = g;
+        d_q3[e * 32 + c] = pamnet::f4mul(dx, m_t[e * 32 + c]);
+        const int t0 = t_ptr[e], t1 = t_ptr[e + 1];
+        int t = t0;
+        for (; t + 4 <= t1; t += 4) {
+            const int64_t k0 = t_col[t], k1 = t_col[t + 1], k2 = t_col[t + 2], k3 = t_col[t + 3];
+            const float4 a0 = m_nb[k0 * 32 + c], a1 = m_nb[k1 * 32 + c], a2 = m_nb[k2 * 32 + c], a3 = m_nb[k3 * 32 + c];
+            d_s[(int64_t)t * 32 + c] = pamnet::f4mul(a0, g);
+            d_s[(int64_t)(t + 1) * 32 + c] = pamnet::f4mul(a1, g);
+            d_s[(int64_t)(t + 2) * 32 + c] = pamnet::f4mul(a2, g);
+            d_s[(int64_t)(t + 3) * 32 + c] = pamnet::f4mul(a3, g);
+        }
+        for (; t < t1; ++t) d_s[(int64_t)t * 32 + c] = pamnet::f4mul(m_nb[(int64_t)t_col[t] * 32 + c], g);
+    } else {
+        const int q0 = tT_ptr[e], q1 = tT_ptr[e + 1];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        int q = q0;
+        for (; q + 2 <= q1; q += 2) {
+            const int64_t ta = tT_perm[q], tb = tT_perm[q + 1];
+            const int64_t ra = t_row[ta], rb = t_row[tb];
+            const float4 sa = s[ta * 32 + c], sb = s[tb * 32 + c];
+            const float4 ga = pamnet::f4mul(d_x2[(int64_t)l_row[ra] * 32 + c], q3[ra * 32 + c]);
+            const float4 gb = pamnet::f4mul(d_x2[(int64_t)l_row[rb] * 32 + c], q3[rb * 32 + c]);
+            v = pamnet::f4add(v, pamnet::f4mul(sa, ga));
+            v = pamnet::f4add(v, pamnet::f4mul(sb, gb));
+        }
+        if (q < q1) {
+            const int64_t ta = tT_perm[q];
+            const int64_t ra = t_row[ta];
+            v = pamnet::f4add(v, pamnet::f4mul(s[ta * 32 + c], pamnet::f4mul(d_x2[(int64_t)l_row[ra] * 32 + c], q3[ra * 32 + c])));
+        }
+        d_mnb[e * 32 + c] = v;
+    }
 }
 
 inline int pick_mtx(int64_t m, int64_t grid) {
@@ -452,6 +473,25 @@ extern "C" int pamnet_local_agg_fwd_f32(const float* m_ji, const float* m_nb, co
     hipLaunchKernelGGL(local_agg_fwd_kernel, dim3((unsigned)ceil_div(n_nodes, NPW)), dim3(256), 0, as_stream(stream),
                        (const float4*)m_ji, (const float4*)m_nb, (const float4*)s, (const float4*)q3, t_ptr, t_col, l_ptr,
                        (const float4*)init, (float4*)m_t, (float4*)out, n_nodes);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+// Backward of pamnet_local_agg_fwd_f32 (one launch): d_mt[e] = d_x2[l_row[e]] * q3[e], d_q3[e] = d_x2[l_row[e]] * m_t[e],
+// d_s[r] = m_nb[t_col[r]] * d_mt[t_row[r]], d_mnb[e'] = sum_{r: t_col[r] = e'} s[r] * d_mt[t_row[r]]  (tT_*: transposed
+// CSR of t_col over the edges).
+extern "C" int pamnet_local_agg_bwd_f32(const float* d_x2, const int32_t* l_row, const float* q3, const float* m_t,
+                                        const float* m_nb, const float* s, const int32_t* t_ptr, const int32_t* t_col,
+                                        const int32_t* t_row, const int32_t* tT_ptr, const int32_t* tT_perm,
+                                        int64_t n_edges, float* d_mt, float* d_q3, float* d_s, float* d_mnb,
+                                        pamnet_stream_t stream) {
+    if (n_edges < 0) return PAMNET_EINVAL;
+    if (n_edges == 0) return PAMNET_OK;
+    if (!d_x2 || !l_row || !q3 || !m_t || !m_nb || !t_ptr || !tT_ptr || !d_mt || !d_q3 || !d_mnb) return PAMNET_ENULL;
+    hipLaunchKernelGGL(local_agg_bwd_kernel, dim3((unsigned)ceil_div(n_edges, 8), 2), dim3(256), 0, as_stream(stream),
+                       (const float4*)d_x2, l_row, (const float4*)q3, (const float4*)m_t, (const float4*)m_nb,
+                       (const float4*)s, t_ptr, t_col, t_row, tT_ptr, tT_perm, n_edges, (float4*)d_mt, (float4*)d_q3,
+                       (float4*)d_s, (float4*)d_mnb);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

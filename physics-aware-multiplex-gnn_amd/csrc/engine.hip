@@ -498,10 +498,9 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 dz_local = t.dZ;
                 CK(pamnet_node_tail_main_bwd_f32(d_xout, q.gh, g.n, lp + LT, q.Z, dz_local, t.dx2, t.dresx, pk, st));
             }
-            // d m_t = d x2[i] * q3 ,  d q3 = d x2[i] * m_t
-            CK(pamnet_gather_mul2_f32(t.dmt, t.dq3, t.dx2, g.l_row, q.q3, q.mt, g.el, D, st));
-            CK(pamnet_gather_mul_f32(t.ds, q.mnb, g.t_col, t.dmt, g.t_row, g.tp, D, st));       // d s   = m_nb[idx] * d m_t[e]
-            CK(pamnet_segment_sum_f32(t.dmnb, nullptr, q.s, nullptr, t.dmt, g.t_row, g.tT_perm, g.tT_ptr, g.el, D, st));
+            // d m_t = d x2[i] * q3,  d q3 = d x2[i] * m_t,  d s = m_nb[idx] * d m_t[e],  d m_nb = transposed sum: one launch
+            CK(pamnet_local_agg_bwd_f32(t.dx2, g.l_row, q.q3, q.mt, q.mnb, q.s, g.t_ptr, g.t_col, g.t_row, g.tT_ptr,
+                                        g.tT_perm, g.el, t.dmt, t.dq3, t.ds, t.dmnb, st));
             CK(pamnet_mlp2_bwd_f32(t.ds, g.tp, q.z1, q.z2, lp[6], lp[8], t.dz1, t.dz2, d_sbf, acc, st));
             const float* wq[4] = {lp[2] + 2 * D, lp[4] + 2 * D, lp[10], lp[11]};
             const int64_t ldq[4] = {3 * D, 3 * D, D, D};

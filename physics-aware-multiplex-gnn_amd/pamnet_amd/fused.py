@@ -334,11 +334,11 @@ class _LocalLayer(torch.autograd.Function):
         gt = g[12:]
         dZ, d_x2, d_resx = k_tail_bwd(g_x, g_out, g_att, tp, Z, gt[20], gt[21], gt[22])
         d_mt, d_q3 = _empty(m, D, like=x), _empty(m, D, like=x)
-        gather_mul_raw(d_mt, d_x2, loc.row_of, q3, None, m, D)                          # d m_t = d x2[i] * q3
-        gather_mul_raw(d_q3, d_x2, loc.row_of, m_t, None, m, D)                         # d q3  = d x2[i] * m_t
         d_s, d_mnb = _empty(t, D, like=x), _empty(m, D, like=x)
-        gather_mul_raw(d_s, m_nb, tpc.col, d_mt, tpc.row_of, t, D)                      # d s[r] = m_nb[idx] * d m_t[edge]
-        segment_sum_raw(d_mnb, None, s, None, d_mt, tpc.row_of, tp_T.perm, tp_T.ptr, m, D)
+        # d m_t = d x2[i] * q3;  d q3 = d x2[i] * m_t;  d s[r] = m_nb[idx] * d m_t[edge];  d m_nb = transposed sum
+        lib.call('pamnet_local_agg_bwd_f32', lib.ptr(d_x2), lib.ptr(loc.row_of), lib.ptr(q3), lib.ptr(m_t), lib.ptr(m_nb),
+                 lib.ptr(s), lib.ptr(tpc.ptr), lib.ptr(tpc.col), lib.ptr(tpc.row_of), lib.ptr(tp_T.ptr),
+                 lib.ptr(tp_T.perm), m, lib.ptr(d_mt), lib.ptr(d_q3), lib.ptr(d_s), lib.ptr(d_mnb), st)
         dz1, dz2, d_sbf = _empty(t, D, like=x), _empty(t, D, like=x), _empty(t, D, like=x)
         lib.call('pamnet_mlp2_bwd_f32', lib.ptr(d_s), t, lib.ptr(z1), lib.ptr(z2), lib.ptr(Ws1), lib.ptr(Ws2),
                  lib.ptr(dz1), lib.ptr(dz2), lib.ptr(d_sbf), 0, st)

@@ -198,3 +198,34 @@ def test_local_agg_fwd(dev, case):
     lib.call('pamnet_local_agg_fwd_f32', lib.ptr(m_ji), lib.ptr(m_nb), lib.ptr(s), lib.ptr(q3), lib.ptr(t_ptr),
              lib.ptr(t_col), lib.ptr(l_ptr), lib.ptr(x1), n, None, lib.ptr(out2), lib.stream_of(x1))
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize('case', ['qm9_like', 'holes', 'tiny', 'giant'])
+def test_local_agg_bwd(dev, case):
+    """d m_t, d q3, d s, d m_nb of the local aggregations vs fp64 autograd of the same expression."""
+    from pamnet_amd import graph as G, lib
+    rng = np.random.default_rng(22)
+    deg = np.minimum(DEGREE_CASES[case](rng), 40) // 4
+    n = len(deg)
+    l_ptr, l_row, l_col, m = _csr(deg, n, 2, dev)
+    tdeg = rng.integers(0, 9, size=m)
+    if case == 'giant':
+        tdeg[m // 2] = 300
+    t_ptr, t_row, t_col, t = _csr(tdeg, m, 3, dev)
+    tT = G.Transpose(t_col, m)
+    gen = torch.Generator().manual_seed(6)
+    mk = lambda r: (0.5 * torch.randn(r, D, generator=gen)).to(dev)
+    m_ji, m_nb, q3, s, d_x2 = mk(m), mk(m), mk(m), mk(t), mk(n)
+    v = [x.double().requires_grad_() for x in (m_ji, m_nb, q3, s)]
+    mt64 = v[0] + torch.zeros(m, D, dtype=torch.float64, device=dev).index_add(0, t_row.long(), v[1][t_col.long()] * v[3])
+    x2 = torch.zeros(n, D, dtype=torch.float64, device=dev).index_add(0, l_row.long(), v[2] * mt64)
+    (x2 * d_x2.double()).sum().backward()
+    m_t = mt64.detach().float().contiguous()
+    d_mt, d_q3, d_mnb = (torch.full((m, D), float('nan'), device=dev) for _ in range(3))
+    d_s = torch.full((t, D), float('nan'), device=dev)
+    lib.call('pamnet_local_agg_bwd_f32', lib.ptr(d_x2), lib.ptr(l_row), lib.ptr(q3), lib.ptr(m_t), lib.ptr(m_nb),
+             lib.ptr(s), lib.ptr(t_ptr), lib.ptr(t_col), lib.ptr(t_row), lib.ptr(tT.ptr), lib.ptr(tT.perm), m,
+             lib.ptr(d_mt), lib.ptr(d_q3), lib.ptr(d_s), lib.ptr(d_mnb), lib.stream_of(d_x2))
+    for got, ref in ((d_mt, v[0].grad), (d_mnb, v[1].grad), (d_q3, v[2].grad), (d_s, v[3].grad)):
+        assert torch.isfinite(got).all()
+        assert maxnorm_err(got.cpu(), ref.cpu()) < 2e-6
