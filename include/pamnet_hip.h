@@ -352,6 +352,22 @@ int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, 
                          float* d_rbf, float* d_sbf, float* wpack, void* const* layer_done, pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Small whole-buffer reductions of the training step (csrc/reduce.hip), one launch each, fixed summation order.
+ * `scratch`: caller-owned device memory of pamnet_reduce_scratch_bytes bytes, zeroed once before its first use, one per
+ * stream (a device counter elects the last workgroup, which adds the partials in workgroup order and resets the counter).
+ *   pamnet_grad_norm_f32      : norm_out[0] = ||g[0:n]||_2          (clip_grad_norm_, main_qm9.py:111)
+ *   pamnet_l1_loss_f32        : loss[0] = mean|out - y|; d_out[i] = grad_scale * sign(out[i] - y[i]) / n  (main_qm9.py:108)
+ *   pamnet_type_rows_grad_f32 : out[t,:] = sum_{r: idx[r] = t} g[r,:], t < n_types <= 8   (gradient of embeddings[x],
+ *                               models.py:107,140)
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pamnet_reduce_scratch_bytes(int64_t* bytes);
+int pamnet_grad_norm_f32(const float* g, int64_t n, void* scratch, float* norm_out, pamnet_stream_t stream);
+int pamnet_l1_loss_f32(const float* out, const float* y, int64_t n, float grad_scale, float* loss, float* d_out,
+                       pamnet_stream_t stream);
+int pamnet_type_rows_grad_f32(const float* g, const int32_t* idx, int64_t n, int64_t n_types, int64_t d, void* scratch,
+                              float* out, pamnet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Optimiser tail of the reference loop on flat fp32 buffers, one pass (main_qm9.py:111-112,116; utils/ema.py:13-20):
  *   g *= min(1, max_norm / (*grad_norm + 1e-6))                      clip_grad_norm_ (grad_norm: device scalar, nullable)
  *   Adam(lr, betas, eps, weight_decay, amsgrad=False), update number `step_count` >= 1

@@ -131,8 +131,13 @@ class _PAMNetBase(nn.Module):
             return F.linear(feats, self.init_linear.weight)
         col = x_raw if self.dataset == 'QM9' else (x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw)[:, -1]
         idx = col.to(torch.int32).contiguous()
+        if ops.type_rows_supported(self.embeddings):                                    # models.py:107,140
+            direct = self.embeddings.grad if (fused.DIRECT_GRAD and torch.is_grad_enabled()
+                                              and getattr(self.embeddings, '_pamnet_direct', False)
+                                              and self.embeddings.grad is not None) else None
+            return ops.type_rows(self.embeddings, idx, direct)
         tr = G.Transpose(idx, self.embeddings.size(0)) if torch.is_grad_enabled() else None
-        return ops.gather(self.embeddings, idx, tr.ptr if tr else None, tr.perm if tr else None)  # models.py:107,140
+        return ops.gather(self.embeddings, idx, tr.ptr if tr else None, tr.perm if tr else None)
 
     def _edge_embeddings(self, g):
         rbf_l = self.rbf_l(g.dist_l)

@@ -115,6 +115,72 @@ class _GatherMulAggregate(torch.autograd.Function):
         return gA, gB, None, None
 
 
+_SCRATCH = {}
+
+
+def reduce_scratch(dev):
+    """Zero-initialised scratch of the one-launch reductions (csrc/reduce.hip), one per (device, stream)."""
+    import ctypes
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    t = _SCRATCH.get(key)
+    if t is None:
+        need = ctypes.c_int64(0)
+        lib.call('pamnet_reduce_scratch_bytes', ctypes.addressof(need))
+        t = _SCRATCH[key] = torch.zeros(int(need.value) // 4, dtype=torch.int32, device=dev)
+    return t
+
+
+class _TypeRows(torch.autograd.Function):
+    """out[k] = table[idx[k]] for a table of <= 8 rows (`embeddings[x]`, models.py:107,140).  The backward sums the rows
+    of the incoming gradient per type in one launch -- no transposed index list to build."""
+
+    @staticmethod
+    def forward(ctx, table, idx, direct):
+        table = _c(table)
+        m, d = idx.numel(), table.size(1)
+        out = torch.empty((m, d), dtype=table.dtype, device=table.device)
+        gather_mul_raw(out, table, idx, None, None, m, d)
+        ctx.idx, ctx.shape, ctx.direct = idx, table.shape, direct
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        rows, d = ctx.shape
+        gt = ctx.direct if ctx.direct is not None else torch.empty((rows, d), dtype=g.dtype, device=g.device)
+        lib.call('pamnet_type_rows_grad_f32', lib.ptr(g), lib.ptr(ctx.idx), ctx.idx.numel(), rows, d,
+                 lib.ptr(reduce_scratch(g.device)), lib.ptr(gt), lib.stream_of(g))
+        return (None if ctx.direct is not None else gt), None, None
+
+
+def type_rows_supported(table):
+    d4 = table.size(1) // 4
+    return table.is_cuda and table.size(0) <= 8 and table.size(1) % 4 == 0 and 1 <= d4 <= 64 and (d4 & (d4 - 1)) == 0
+
+
+def type_rows(table, idx, direct_grad=None):
+    """direct_grad: a preallocated gradient buffer of `table` to be overwritten in place (train.FlatParams), or None."""
+    return apply(_TypeRows, table, idx, direct_grad)
+
+
+def l1_loss_with_grad(out, y, grad_scale=1.0):
+    """(loss, d loss / d out * grad_scale) of F.l1_loss(out, y) (mean reduction, main_qm9.py:108) in one launch."""
+    out, y = _c(out.detach()), _c(y)
+    loss = torch.empty(1, dtype=torch.float32, device=out.device)
+    d_out = torch.empty_like(out)
+    lib.call('pamnet_l1_loss_f32', lib.ptr(out), lib.ptr(y), out.numel(), float(grad_scale), lib.ptr(loss),
+             lib.ptr(d_out), lib.stream_of(out))
+    return loss[0], d_out
+
+
+def grad_norm(flat):
+    """L2 norm of a flat fp32 buffer as a fresh device scalar (one launch, fp64 partials, fixed order)."""
+    norm = torch.empty(1, dtype=torch.float32, device=flat.device)
+    lib.call('pamnet_grad_norm_f32', lib.ptr(flat), flat.numel(), lib.ptr(reduce_scratch(flat.device)), lib.ptr(norm),
+             lib.stream_of(flat))
+    return norm[0]
+
+
 class _RBF(torch.autograd.Function):
     """BesselBasisLayer (layers/basic.py:59-76); freq is trainable, dist is not differentiated (pos has no grad)."""
 

@@ -363,3 +363,57 @@ def test_cabi_argument_errors(dev):
     assert float(out.min()) == 7.0
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         lib.stream_of(torch.zeros(3))
+
+
+# ------------------------------------------------------------------------------------------- one-launch reductions
+@pytest.mark.parametrize('n', [4, 1000, 65536 + 12, 3581100 // 4 * 4])
+def test_grad_norm(dev, n):
+    from pamnet_amd import ops
+    torch.manual_seed(n)
+    g = torch.randn(n, device=dev) * 3.0
+    a = ops.grad_norm(g)
+    ref = g.double().norm()
+    assert abs(float(a) - float(ref)) <= 2e-7 * float(ref)
+    assert float(ops.grad_norm(g)) == float(a)                      # counter reset + bitwise repeatable
+
+
+@pytest.mark.parametrize('n', [1, 7, 128, 1024, 5000])
+def test_l1_loss_with_grad(dev, n):
+    from pamnet_amd import ops
+    torch.manual_seed(n)
+    out = torch.randn(n, device=dev)
+    y = torch.randn(n, device=dev)
+    if n > 4:
+        y[3] = out[3]                                                # sign(0) = 0, as torch
+    o = out.clone().requires_grad_()
+    ref = torch.nn.functional.l1_loss(o, y)
+    (ref * 0.25).backward()
+    loss, d_out = ops.l1_loss_with_grad(out, y, 0.25)
+    assert abs(float(loss) - float(ref)) <= 2e-7 * abs(float(ref)) + 1e-12
+    assert torch.allclose(d_out, o.grad, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize('d', [16, 64, 128])
+@pytest.mark.parametrize('n,types', [(1, 3), (37, 5), (2286, 5), (17700, 3)])
+def test_type_rows_gather_and_grad(dev, n, types, d):
+    """embeddings[x] (models.py:107,140) and its gradient (rows of d x summed per type)."""
+    from pamnet_amd import ops
+    torch.manual_seed(n + d)
+    table = torch.randn(types, d, device=dev, requires_grad=True)
+    idx = torch.randint(0, types, (n,), device=dev, dtype=torch.int32)
+    if n > 10:
+        idx[idx == types - 1] = 0                                    # a type that never occurs -> zero gradient row
+    out = ops.type_rows(table, idx)
+    assert torch.equal(out, table.detach()[idx.long()])
+    w = torch.randn(n, d, device=dev)
+    (out * w).sum().backward()
+    ref = torch.zeros(types, d, dtype=torch.float64, device=dev).index_add_(0, idx.long(), w.double())
+    assert maxnorm_err(table.grad.cpu(), ref.cpu()) < 2e-6
+    g1 = table.grad.clone()
+    table.grad = None
+    (ops.type_rows(table, idx) * w).sum().backward()
+    assert torch.equal(g1, table.grad)                               # deterministic
+    buf = torch.full((types, d), float('nan'), device=dev)           # direct-gradient mode: written in place
+    t2 = table.detach().clone().requires_grad_()
+    (ops.type_rows(t2, idx, buf) * w).sum().backward()
+    assert t2.grad is None and torch.equal(buf, g1)
