@@ -352,16 +352,15 @@ int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, 
                          float* d_rbf, float* d_sbf, float* wpack, void* const* layer_done, pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * Small whole-buffer reductions of the training step (csrc/reduce.hip), one launch each, fixed summation order.
- * `scratch`: caller-owned device memory of pamnet_reduce_scratch_bytes bytes, zeroed once before its first use, one per
- * stream (a device counter elects the last workgroup, which adds the partials in workgroup order and resets the counter).
- *   pamnet_grad_norm_f32      : norm_out[0] = ||g[0:n]||_2          (clip_grad_norm_, main_qm9.py:111)
+ * Small whole-buffer reductions of the training step (csrc/reduce.hip), fixed summation order.
+ *   pamnet_sumsq_partials_f32 : partials[0:256] (fp64) = sums of squares of 256 contiguous slices of g[0:n]; the L2 norm
+ *                               (clip_grad_norm_, main_qm9.py:111) is finished inside pamnet_adam_ema_norm_f32
  *   pamnet_l1_loss_f32        : loss[0] = mean|out - y|; d_out[i] = grad_scale * sign(out[i] - y[i]) / n  (main_qm9.py:108)
  *   pamnet_type_rows_grad_f32 : out[t,:] = sum_{r: idx[r] = t} g[r,:], t < n_types <= 8   (gradient of embeddings[x],
- *                               models.py:107,140)
+ *                               models.py:107,140); scratch: pamnet_reduce_scratch_bytes bytes of device memory
  * ------------------------------------------------------------------------------------------------------------------ */
 int pamnet_reduce_scratch_bytes(int64_t* bytes);
-int pamnet_grad_norm_f32(const float* g, int64_t n, void* scratch, float* norm_out, pamnet_stream_t stream);
+int pamnet_sumsq_partials_f32(const float* g, int64_t n, double* partials, pamnet_stream_t stream);
 int pamnet_l1_loss_f32(const float* out, const float* y, int64_t n, float grad_scale, float* loss, float* d_out,
                        pamnet_stream_t stream);
 int pamnet_type_rows_grad_f32(const float* g, const int32_t* idx, int64_t n, int64_t n_types, int64_t d, void* scratch,
@@ -378,6 +377,12 @@ int pamnet_type_rows_grad_f32(const float* g, const int32_t* idx, int64_t n, int
 int pamnet_adam_ema_f32(float* p, float* g, float* m, float* v, float* shadow, int64_t n, float lr, float beta1,
                         float beta2, float eps, float weight_decay, int64_t step_count, float ema_decay,
                         const float* grad_norm, float max_norm, int32_t zero_grad, pamnet_stream_t stream);
+/* same update, gradient norm = sqrt(sum of the 256 fp64 partials of pamnet_sumsq_partials_f32) added inside the kernel;
+ * norm_out[0] (nullable) receives the pre-clip norm */
+int pamnet_adam_ema_norm_f32(float* p, float* g, float* m, float* v, float* shadow, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int64_t step_count, float ema_decay,
+                             const double* sumsq_partials, float* norm_out, float max_norm, int32_t zero_grad,
+                             pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Narrow widths (d = 16 / 32 / 64: the reference's RNA configurations, inference_rna_puzzles.py:29-30,

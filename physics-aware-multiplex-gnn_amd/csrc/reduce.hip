@@ -1,31 +1,19 @@
-// Small whole-buffer reductions of the training step, each ONE launch with a fixed summation order (deterministic):
-//   * pamnet_grad_norm_f32   : L2 norm of the flat gradient (clip_grad_norm_, main_qm9.py:111) -- 14 MB, HBM-bound
-//   * pamnet_l1_loss_f32     : F.l1_loss(out, y) and its gradient w.r.t. out (main_qm9.py:108), a few hundred floats
+// Small whole-buffer reductions of the training step, fixed summation order (deterministic):
+//   * pamnet_sumsq_partials_f32 : 256 fp64 partial sums of squares of the flat gradient (clip_grad_norm_,
+//                                 main_qm9.py:111); the optimiser kernel (optim.hip) adds them itself -- no finish launch
+//   * pamnet_l1_loss_f32        : F.l1_loss(out, y) and its gradient w.r.t. out (main_qm9.py:108), a few hundred floats
 //   * pamnet_type_rows_grad_f32 : gradient of `embeddings[x]` (models.py:107,140): rows of d x summed per atom type
-// Pattern: every workgroup writes a partial, the LAST one to finish (device counter, reset for the next call) adds the
-// partials in workgroup order -- the order of arrival only decides who does the final sum, never its value.
+//                                 (partials per workgroup + a one-workgroup finish, workgroup order)
+// (A single launch with a "last workgroup finishes" counter was measured and rejected: the device-scope fence it needs
+// writes back the whole L2 on this multi-XCD part -- 40 us for the norm against 7.5 us for the partials launch.)
 #include "common.h"
 
 namespace {
 
-__device__ __forceinline__ bool last_block(unsigned* counter) {
-    __shared__ bool last;
-    __threadfence();                                   // this block's partial is visible device-wide
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned done = atomicAdd(counter, 1u);
-        last = done + 1 == gridDim.x;
-        if (last) *counter = 0;                        // ready for the next call on this stream
-    }
-    __syncthreads();
-    __threadfence();
-    return last;
-}
-
 constexpr int NORM_BLOCKS = 256;
 
-__global__ __launch_bounds__(256) void grad_norm_kernel(const float4* __restrict__ g, int64_t n4, double* __restrict__ partial,
-                                                        unsigned* __restrict__ counter, float* __restrict__ norm_out) {
+__global__ __launch_bounds__(256) void sumsq_partials_kernel(const float4* __restrict__ g, int64_t n4,
+                                                             double* __restrict__ partial) {
     __shared__ double red[256];
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
     const int64_t per = (n4 + gridDim.x - 1) / gridDim.x;
@@ -48,14 +36,6 @@ __global__ __launch_bounds__(256) void grad_norm_kernel(const float4* __restrict
         __syncthreads();
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
-    if (!last_block(counter)) return;
-    red[threadIdx.x] = threadIdx.x < gridDim.x ? partial[threadIdx.x] : 0.0;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) norm_out[0] = (float)sqrt(red[0]);
 }
 
 // one workgroup: loss = mean |out - y| ; d_out = sign(out - y) * grad_scale / n     (n graphs: a few hundred)
@@ -83,10 +63,9 @@ constexpr int TYPE_MAX = 8, TYPE_BLOCKS = 64;
 
 // out[t, :] = sum_{r: idx[r] = t} g[r, :],  t < n_types <= 8.  Lane group (d4 lanes) per row slot; a workgroup owns a
 // contiguous slice of rows, slot s walks rows s, s + slots, ... (fixed), slots meet in LDS in slot order, workgroups in
-// the last block in workgroup order.
+// type_rows_finish_kernel in workgroup order.
 __global__ __launch_bounds__(256) void type_rows_grad_kernel(const float4* __restrict__ g, const int32_t* __restrict__ idx,
-                                                             int64_t n, int n_types, int d4, float4* __restrict__ partial,
-                                                             unsigned* __restrict__ counter, float4* __restrict__ out) {
+                                                             int64_t n, int n_types, int d4, float4* __restrict__ partial) {
     __shared__ float4 red[256];
     const int c = threadIdx.x % d4, slot = threadIdx.x / d4, slots = 256 / d4;
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
@@ -119,11 +98,22 @@ __global__ __launch_bounds__(256) void type_rows_grad_kernel(const float4* __res
         }
         __syncthreads();
     }
-    if (!last_block(counter)) return;
-    for (int e = threadIdx.x; e < n_types * d4; e += 256) {
-        float4 s = partial[e];
-        for (int b = 1; b < (int)gridDim.x; ++b) {
-            const float4 v = partial[(int64_t)b * n_types * d4 + e];
+}
+
+__global__ __launch_bounds__(256) void type_rows_finish_kernel(const float4* __restrict__ partial, int blocks, int cells,
+                                                               float4* __restrict__ out) {
+    for (int e = threadIdx.x; e < cells; e += 256) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int b = 0;
+        for (; b + 8 <= blocks; b += 8) {                  // 8 independent loads in flight, added in workgroup order
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = partial[(int64_t)(b + k) * cells + e];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s.x += v[k].x, s.y += v[k].y, s.z += v[k].z, s.w += v[k].w;
+        }
+        for (; b < blocks; ++b) {
+            const float4 v = partial[(int64_t)b * cells + e];
             s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
         }
         out[e] = s;
@@ -132,24 +122,20 @@ __global__ __launch_bounds__(256) void type_rows_grad_kernel(const float4* __res
 
 }  // namespace
 
-// scratch (caller-owned, device): pamnet_reduce_scratch_bytes bytes, ZEROED ONCE before the first call (the kernels
-// leave the counter at zero); one scratch per stream.  Layout: [0,8) counter | [256, ...) partials.
+// scratch (caller-owned, device) of pamnet_type_rows_grad_f32: pamnet_reduce_scratch_bytes bytes, no initialisation needed
 extern "C" int pamnet_reduce_scratch_bytes(int64_t* bytes) {
     if (!bytes) return PAMNET_ENULL;
-    *bytes = 256 + (int64_t)TYPE_BLOCKS * TYPE_MAX * 64 * 16;      // >= NORM_BLOCKS doubles, >= type partials up to d = 256
+    *bytes = (int64_t)TYPE_BLOCKS * TYPE_MAX * 64 * 16;
     return PAMNET_OK;
 }
 
-// norm_out[0] = || g[0:n] ||_2  (fp64 across lanes / workgroups).  n % 4 == 0, g 16-byte aligned.
-extern "C" int pamnet_grad_norm_f32(const float* g, int64_t n, void* scratch, float* norm_out, pamnet_stream_t stream) {
+// partials[0:256] (fp64) = sums of squares of 256 contiguous slices of g[0:n] (unused slices: 0).  n % 4 == 0.
+// || g ||_2 = sqrt(sum of the partials in index order) -- pamnet_adam_ema_norm_f32 does that sum itself.
+extern "C" int pamnet_sumsq_partials_f32(const float* g, int64_t n, double* partials, pamnet_stream_t stream) {
     if (n < 0 || (n & 3)) return PAMNET_EINVAL;
-    if (!g || !scratch || !norm_out) return PAMNET_ENULL;
-    const int64_t n4 = n / 4;
-    int64_t blocks = ceil_div(n4, 2048);
-    blocks = blocks < 1 ? 1 : (blocks > NORM_BLOCKS ? NORM_BLOCKS : blocks);
-    hipLaunchKernelGGL(grad_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float4*)g, n4,
-                       reinterpret_cast<double*>(static_cast<char*>(scratch) + 256), static_cast<unsigned*>(scratch),
-                       norm_out);
+    if (!g || !partials) return PAMNET_ENULL;
+    hipLaunchKernelGGL(sumsq_partials_kernel, dim3(NORM_BLOCKS), dim3(256), 0, as_stream(stream), (const float4*)g, n / 4,
+                       partials);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -171,11 +157,13 @@ extern "C" int pamnet_type_rows_grad_f32(const float* g, const int32_t* idx, int
     const int64_t d4 = d / 4;
     if (n < 0 || n_types < 1 || n_types > TYPE_MAX || d < 4 || (d & 3) || d4 > 64 || (d4 & (d4 - 1))) return PAMNET_EINVAL;
     if (!out || !scratch || (n > 0 && (!g || !idx))) return PAMNET_ENULL;
-    int64_t blocks = ceil_div(n, 32);
+    int64_t blocks = ceil_div(n, 128);                        // >= 128 rows per workgroup: few partials for the finish
     blocks = blocks < 1 ? 1 : (blocks > TYPE_BLOCKS ? TYPE_BLOCKS : blocks);
-    hipLaunchKernelGGL(type_rows_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float4*)g, idx,
-                       n, (int)n_types, (int)d4, reinterpret_cast<float4*>(static_cast<char*>(scratch) + 256),
-                       static_cast<unsigned*>(scratch), (float4*)out);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(type_rows_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4*)g, idx, n,
+                       (int)n_types, (int)d4, static_cast<float4*>(scratch));
+    hipLaunchKernelGGL(type_rows_finish_kernel, dim3(1), dim3(256), 0, st, static_cast<const float4*>(scratch), (int)blocks,
+                       (int)(n_types * d4), (float4*)out);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

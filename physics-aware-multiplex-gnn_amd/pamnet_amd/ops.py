@@ -119,7 +119,7 @@ _SCRATCH = {}
 
 
 def reduce_scratch(dev):
-    """Zero-initialised scratch of the one-launch reductions (csrc/reduce.hip), one per (device, stream)."""
+    """Scratch of pamnet_type_rows_grad_f32 (csrc/reduce.hip), one per (device, stream)."""
     import ctypes
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     t = _SCRATCH.get(key)
@@ -173,12 +173,12 @@ def l1_loss_with_grad(out, y, grad_scale=1.0):
     return loss[0], d_out
 
 
-def grad_norm(flat):
-    """L2 norm of a flat fp32 buffer as a fresh device scalar (one launch, fp64 partials, fixed order)."""
-    norm = torch.empty(1, dtype=torch.float32, device=flat.device)
-    lib.call('pamnet_grad_norm_f32', lib.ptr(flat), flat.numel(), lib.ptr(reduce_scratch(flat.device)), lib.ptr(norm),
-             lib.stream_of(flat))
-    return norm[0]
+def sumsq_partials(flat):
+    """256 fp64 partial sums of squares of a flat fp32 buffer (one launch); ||flat|| = sqrt(partials.sum()).  The
+    optimiser kernel (pamnet_adam_ema_norm_f32) finishes the sum itself."""
+    part = torch.empty(256, dtype=torch.float64, device=flat.device)
+    lib.call('pamnet_sumsq_partials_f32', lib.ptr(flat), flat.numel(), lib.ptr(part), lib.stream_of(flat))
+    return part
 
 
 class _RBF(torch.autograd.Function):

@@ -231,14 +231,16 @@ class Trainer(object):
         if lr is not None:
             self.lr = lr
         from . import ops
-        norm = ops.grad_norm(self.fp.grad)
+        part = ops.sumsq_partials(self.fp.grad)            # the kernel below adds the 256 partials and clips by the norm
+        norm = torch.empty(1, dtype=torch.float32, device=self.fp.flat.device)
         self.step_count += 1
         decay = min(self.ema_decay, (1.0 + num_updates) / (10.0 + num_updates))     # utils/ema.py:14
-        lib.call('pamnet_adam_ema_f32', lib.ptr(self.fp.flat), lib.ptr(self.fp.grad), lib.ptr(self.exp_avg),
+        lib.call('pamnet_adam_ema_norm_f32', lib.ptr(self.fp.flat), lib.ptr(self.fp.grad), lib.ptr(self.exp_avg),
                  lib.ptr(self.exp_avg_sq), lib.ptr(self.shadow), self.fp.flat.numel(), float(self.lr),
                  float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
-                 self.step_count, float(decay), lib.ptr(norm), float(self.max_grad_norm), 1,
+                 self.step_count, float(decay), lib.ptr(part), lib.ptr(norm), float(self.max_grad_norm), 1,
                  lib.stream_of(self.fp.flat))
+        norm = norm[0]
         self._grad_clean = True
         return norm
 

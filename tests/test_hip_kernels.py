@@ -368,13 +368,25 @@ def test_cabi_argument_errors(dev):
 # ------------------------------------------------------------------------------------------- one-launch reductions
 @pytest.mark.parametrize('n', [4, 1000, 65536 + 12, 3581100 // 4 * 4])
 def test_grad_norm(dev, n):
-    from pamnet_amd import ops
+    """Partial sums of squares + the optimiser kernel's own finish: the norm it reports and clips by."""
+    from pamnet_amd import lib, ops
     torch.manual_seed(n)
     g = torch.randn(n, device=dev) * 3.0
-    a = ops.grad_norm(g)
+    part = ops.sumsq_partials(g)
     ref = g.double().norm()
-    assert abs(float(a) - float(ref)) <= 2e-7 * float(ref)
-    assert float(ops.grad_norm(g)) == float(a)                      # counter reset + bitwise repeatable
+    assert abs(float(part.sum().sqrt()) - float(ref)) <= 2e-7 * float(ref)
+    assert torch.equal(part, ops.sumsq_partials(g))                  # bitwise repeatable
+    p, m, v, sh = (torch.zeros(n, device=dev) for _ in range(4))
+    norm = torch.zeros(1, device=dev)
+    g2 = g.clone()
+    lib.call('pamnet_adam_ema_norm_f32', lib.ptr(p), lib.ptr(g2), lib.ptr(m), lib.ptr(v), lib.ptr(sh), n, 1e-3, 0.9, 0.999,
+             1e-8, 0.0, 1, 0.999, lib.ptr(part), lib.ptr(norm), 1.0, 0, lib.stream_of(g))
+    assert abs(float(norm) - float(ref)) <= 2e-7 * float(ref)
+    # same update as the device-scalar form of the kernel given the same norm
+    p1, m1, v1, sh1 = (torch.zeros(n, device=dev) for _ in range(4))
+    lib.call('pamnet_adam_ema_f32', lib.ptr(p1), lib.ptr(g.clone()), lib.ptr(m1), lib.ptr(v1), lib.ptr(sh1), n, 1e-3, 0.9,
+             0.999, 1e-8, 0.0, 1, 0.999, lib.ptr(norm), 1.0, 0, lib.stream_of(g))
+    assert torch.equal(p, p1) and torch.equal(m, m1) and torch.equal(v, v1) and torch.equal(sh, sh1)
 
 
 @pytest.mark.parametrize('n', [1, 7, 128, 1024, 5000])
