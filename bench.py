@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- molecules/sec of one PAMNet training step (QM9 schema, dim=128, n_layer=6) on N MI355X GPUs.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 400 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -9,8 +9,9 @@ A "step" is one pass of the hot path over one batch with inputs already resident
 (device graph construction, bases, 6x(global+local) message passing, fusion, pooling) -> L1 loss -> backward -> RCCL
 all-reduce of the flat gradient (N>1) -> clip -> Adam -> EMA, i.e. the reference loop main_qm9.py:103-118.
 Workload (config.workload): BASELINE.json configs[1] -- 128 molecules per GPU (weak scaling: global batch 128*N).
-One JSON line on rank 0: whole-job molecules/s + `roofline` (segment-sum = scatter-add kernel, HIP-event timed) +
-`cpu_baseline` (the oracle = port of the reference CPU forward+backward, bounded sample, N=1 only).
+One JSON line on rank 0: whole-job molecules/s + `roofline` (the scatter-add kernel, HIP-event timed, PMC traffic from
+profiles/) + `step_kernels` (rooflines of the step's dominant kernels at the workload shapes) + `cpu_baseline` (the
+oracle = port of the reference CPU forward+backward, bounded sample, N=1 only).
 """
 import argparse
 import json
@@ -28,34 +29,44 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 FP32_MFMA_PEAK_TFLOPS = 157.3
+METRIC = 'molecules/sec (QM9 dim=128 n_layer=6) at 1/2/4/8 GPU; scatter-add HBM GB/s vs peak'
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=400, help='timed steps (default: a timed region of >= 1 s)')
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch-per-gpu', type=int, default=128)
     ap.add_argument('--dim', type=int, default=128)
     ap.add_argument('--n-layer', type=int, default=6)
     ap.add_argument('--n-batches', type=int, default=4, help='distinct resident batches cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-rooflines', action='store_true', help='skip the kernel roofline probes (profiling runs)')
     ap.add_argument('--force-comm', action='store_true',
                     help='N=1 only: run the bucketed gradient all-reduce through a 1-rank RCCL group (overhead check)')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--stream-gb', type=float, default=2.0, help='size of the streamed scatter-add roofline probe')
+    ap.add_argument('--cpu-dry-run', action='store_true',
+                    help='NOT a measurement: exercise the multi-rank control flow (sharding, barriers, max-over-ranks '
+                         'timing, gradient all-reduce) on CPU with the gloo backend and a stand-in module (tests/standin.py)')
     return ap.parse_args()
 
 
-def event_time_ms(fn, reps):
-    """Average duration of fn() in ms with HIP events on torch's current stream (the stream the kernels launch on)."""
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(reps):
-        fn()
-    e.record()
-    e.synchronize()
-    return s.elapsed_time(e) / reps
+def event_time_ms(fn, reps, groups=1):
+    """Duration of fn() in ms with HIP events on torch's current stream (the stream the kernels launch on): `groups`
+    runs of `reps` back-to-back calls; returns (median, min) of the per-call averages."""
+    vals = []
+    for _ in range(groups):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        e.synchronize()
+        vals.append(s.elapsed_time(e) / reps)
+    vals.sort()
+    return vals[len(vals) // 2], vals[0]
 
 
 def scatter_add_roofline(dev, g, d, stream_gb):
@@ -71,7 +82,7 @@ def scatter_add_roofline(dev, g, d, stream_gb):
     out = torch.empty(r, d, device=dev)
     fn = lambda: ops.segment_sum_raw(out, None, src, None, None, None, None, csr.ptr, r, d)
     fn()
-    ms = event_time_ms(fn, 50)
+    ms, _ = event_time_ms(fn, 50, 3)
     by = 4.0 * d * m + 4.0 * (r + 1) + 4.0 * d * r
     res['workload'] = dict(rows_in=m, rows_out=r, bytes=by, ms=ms, gbs=by / ms / 1e6)
     # streamed probe: replicate the CSR until the source exceeds stream_gb
@@ -82,12 +93,85 @@ def scatter_add_roofline(dev, g, d, stream_gb):
     src = torch.randn(M, d, device=dev)
     out = torch.empty(R, d, device=dev)
     fn = lambda: ops.segment_sum_raw(out, None, src, None, None, None, None, ptr, R, d)
-    for _ in range(3):
+    for _ in range(10):                     # first touches of 2 GB and the clock ramp stay out of the timed groups
         fn()
-    ms = event_time_ms(fn, 20)
+    torch.cuda.synchronize()
+    # median of 7 groups of 20 launches: single-group timings differed by 0.65-0.73 of peak between fresh boxes in round 1
+    ms, ms_min = event_time_ms(fn, 20, 7)
     by = 4.0 * d * M + 4.0 * (R + 1) + 4.0 * d * R
-    res['streamed'] = dict(rows_in=M, rows_out=R, bytes=by, ms=ms, gbs=by / ms / 1e6)
+    res['streamed'] = dict(rows_in=M, rows_out=R, bytes=by, ms=ms, ms_best=ms_min, gbs=by / ms / 1e6,
+                           gbs_best=by / ms_min / 1e6)
     return res
+
+
+def step_kernel_rooflines(dev, g, d, n_layer):
+    """Rooflines of the kernels that dominate the timed step, each timed with HIP events at THIS workload's shapes through
+    the same C-ABI entry points the engine calls (profiles/ holds the rocprofv3 kernel trace of the bench command with the
+    in-step averages of the same kernels):
+      * the weight-gradient launch (dominant kernel of the step): all dW = dZ^T A of one global layer -- MFMA bound;
+      * edge MLP -> node segment-sum (the fused kernel north_star names): 2 GEMMs per global edge -- MFMA bound, its
+        algorithmic HBM bytes beside it;
+      * the local layer's two chained scatter-adds as one launch -- gather / latency bound (bytes)."""
+    from pamnet_amd import fused, lib
+    n, eg, el, tp = g.n, g.glob.m, g.loc.m, g.tp.m
+    rnd = lambda *s: torch.randn(*s, device=dev) * 0.5
+    out = []
+    keep, jobs = [], []
+    for rows, cnt in ((n, 15), (eg, 2)):        # engine.hip, global layer backward: 15 node-level + 2 edge-level jobs
+        for _ in range(cnt):
+            dz, a, dw = rnd(rows, d), rnd(rows, d), torch.empty(d, d, device=dev)
+            keep += [dz, a, dw]
+            jobs.append((dz, d, a, d, 0, rows, dw, d, None))
+    fn = lambda: fused.wgrad(jobs, keep[0])
+    fn()
+    ms, _ = event_time_ms(fn, 30, 3)
+    fl = 2.0 * d * d * (15 * n + 2 * eg)
+    out.append({'kernel': 'wgrad_kernel + wgrad_finish_kernel (all dW of one global layer, one batch)', 'bound': 'mfma',
+                'flops_per_launch': fl, 'us_per_launch': ms * 1e3, 'achieved': fl / ms / 1e9, 'peak': FP32_MFMA_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 'launches_per_step': 2 * n_layer})
+    Wm, bm, Wea = rnd(d, 3 * d) / 8, rnd(d), rnd(d, d) / 8
+    e, Pi, Pj, x1 = rnd(eg, d), rnd(n, d), rnd(n, d), rnd(n, d)
+    z, ea, x2 = torch.empty(eg, d, device=dev), torch.empty(eg, d, device=dev), torch.empty(n, d, device=dev)
+    csr = g.glob
+    st = lib.stream_of(e)
+
+    def agg(save):
+        lib.call('pamnet_global_edge_agg_fwd_f32', lib.ptr(e), eg, n, Wm.data_ptr() + 8 * d, 3 * d, lib.ptr(bm), lib.ptr(Wea),
+                 d, lib.ptr(Pi), lib.ptr(Pj), lib.ptr(csr.ptr), lib.ptr(csr.row_of), lib.ptr(csr.col), lib.ptr(x1),
+                 lib.ptr(z) if save else None, lib.ptr(ea) if save else None, lib.ptr(x2), st)
+
+    for save, tag in ((True, 'training (z, ea saved)'), (False, 'inference')):
+        agg(save)
+        ms, _ = event_time_ms(lambda: agg(save), 30, 3)
+        fl = 2.0 * 2.0 * d * d * eg
+        by = 4.0 * d * eg + 8.0 * eg + 4.0 * (n + 1) + 4.0 * d * n * 4 + (8.0 * d * eg if save else 0.0)
+        out.append({'kernel': 'global_edge_agg_fwd_kernel (edge MLP -> node segment-sum), ' + tag, 'bound': 'mfma',
+                    'flops_per_launch': fl, 'us_per_launch': ms * 1e3, 'achieved': fl / ms / 1e9,
+                    'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS,
+                    'algorithmic_bytes': by, 'gbs': by / ms / 1e6, 'hbm_frac': by / ms / 1e6 / HBM_PEAK_GBS,
+                    'launches_per_step': n_layer if save else 0})
+    m_ji, m_nb, q3, s_, mt = rnd(el, d), rnd(el, d), rnd(el, d), rnd(tp, d), torch.empty(el, d, device=dev)
+    fn = lambda: lib.call('pamnet_local_agg_fwd_f32', lib.ptr(m_ji), lib.ptr(m_nb), lib.ptr(s_), lib.ptr(q3),
+                          lib.ptr(g.tp.ptr), lib.ptr(g.tp.col), lib.ptr(g.loc.ptr), lib.ptr(x1), n, lib.ptr(mt),
+                          lib.ptr(x2), st)
+    fn()
+    ms, _ = event_time_ms(fn, 50, 3)
+    by = 4.0 * d * (2 * tp + 3 * el + 2 * n) + 4.0 * (tp + el + n)     # s + gathered m_nb rows, m_ji/q3/m_t, x1/x2, indices
+    out.append({'kernel': 'local_agg_fwd_kernel (rows -> edges -> nodes scatter-adds, one launch)', 'bound': 'hbm',
+                'bytes_per_launch': by, 'us_per_launch': ms * 1e3, 'achieved': by / ms / 1e6, 'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s', 'frac': by / ms / 1e6 / HBM_PEAK_GBS, 'launches_per_step': n_layer,
+                'note': 'every operand fits the 256 MB Infinity Cache at this batch size: latency bound'})
+    return out
+
+
+def pmc_record(name):
+    """The committed PMC pass of the roofline kernel (profiles/<name>.json, written on the GPU box by tools/pmc_scatter.sh:
+    separate --pmc passes, FETCH_SIZE x2 correction as MI355X_MICROARCH.md prescribes), or None."""
+    path = os.path.join(REPO, 'profiles', name + '.json')
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
 
 
 def mfma_summary(args, g, ms_per_step):
@@ -162,22 +246,34 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
-    elif args.force_comm:
-        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29517', rank=0, world_size=1, device_id=dev)
+    dry = args.cpu_dry_run
+    if dry:
+        dev = torch.device('cpu')
+        if world > 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group('gloo')
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+        if world > 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group('nccl', device_id=dev)
+        elif args.force_comm:
+            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29517', rank=0, world_size=1, device_id=dev)
 
-    import models
-    from pamnet_amd import lib, synth
-    from pamnet_amd.train import Trainer
-    lib.load()
-
+    from pamnet_amd import synth
+    from pamnet_amd.train import Trainer, shard_range
     torch.manual_seed(1234)                        # identical random-init weights on every rank
-    cfg = models.Config(dataset='QM9', dim=args.dim, n_layer=args.n_layer, cutoff_l=5.0, cutoff_g=5.0)
-    model = models.PAMNet(cfg).to(dev)
+    if dry:
+        sys.path.insert(0, os.path.join(REPO, 'tests'))
+        from standin import LayeredStandIn          # test infrastructure: only reachable through --cpu-dry-run
+        model = LayeredStandIn(n_layer=args.n_layer)
+    else:
+        import models
+        from pamnet_amd import lib
+        lib.load()
+        cfg = models.Config(dataset='QM9', dim=args.dim, n_layer=args.n_layer, cutoff_l=5.0, cutoff_g=5.0)
+        model = models.PAMNet(cfg).to(dev)
     overlap = os.environ.get('PAMNET_OVERLAP_COMM', '1') != '0'
     trainer = Trainer(model, lr=1e-4, world_size=world,
                       overlap_comm=(('force' if overlap else 'force_single') if args.force_comm else overlap),
@@ -188,15 +284,19 @@ def main():
     # resident batches: global batch k = molecules [k*gB, (k+1)*gB); this rank's shard = its contiguous slice
     batches = []
     for k in range(args.n_batches):
-        lo = k * gB + rank * B
-        batches.append(synth.qm9_batch(0, lo, B).to(dev))
-    torch.cuda.synchronize()
+        lo, hi = shard_range(gB, rank, world)
+        assert hi - lo == B
+        batches.append(synth.qm9_batch(0, k * gB + lo, B).to(dev))
+    if not dry:
+        torch.cuda.synchronize()
 
     def sync():
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     nb = len(batches)
     # Input pipelining: while step i runs, the graph of batch i+1 is constructed on a side stream (what a loader
@@ -217,26 +317,39 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = gB * args.steps / dt
 
+    if dry:
+        if rank == 0:
+            line = {'metric': 'DRY RUN on CPU with a stand-in module -- control-flow check, NOT a measurement',
+                    'value': value, 'unit': 'molecules/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                    'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                    'dtype': 'f32', 'data': 'synthetic', 'dry_run': True,
+                    'config': {'workload': 'cpu dry run, %d molecules/rank' % B, 'global_batch': gB,
+                               'parallelism': 'dp%d (molecule-sharded, gloo all-reduce of flat grad)' % world}}
+            result_out.write(json.dumps(line) + '\n')
+            result_out.flush()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     # forward-only rate (reported beside the training rate; not `value`)
+    fsteps = min(args.steps, 100)
     with torch.no_grad():
         for i in range(2):
             model(batches[i % len(batches)])
         sync()
         t0 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(fsteps):
             model(batches[i % len(batches)])
         sync()
-        fwd_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        fwd_ms = (time.perf_counter() - t0) / fsteps * 1e3
 
-    line = None
     if rank == 0:
         with torch.no_grad():
             model(batches[0])
         g = model._graph_cache
-        roof = scatter_add_roofline(dev, g, args.dim, args.stream_gb)
-        s = roof['streamed']
         line = {
-            'metric': 'molecules/sec (QM9 dim=128 n_layer=6) at 1/2/4/8 GPU; scatter-add HBM GB/s vs peak',
+            'metric': METRIC,
             'value': value, 'unit': 'molecules/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
@@ -246,16 +359,24 @@ def main():
                        'global_batch': gB, 'parallelism': 'dp%d (molecule-sharded, RCCL all-reduce of flat grad)' % world,
                        'nodes_per_batch': int(g.n), 'global_edges': int(g.glob.m), 'local_edges': int(g.loc.m),
                        'triplets': int(g.n_trip), 'pairs': int(g.n_pair)},
+            'timed_region_s': dt,
             'forward_only_molecules_per_s': gB / (fwd_ms / 1e3), 'forward_ms': fwd_ms,
             'mfma': mfma_summary(args, g, ms_per_step),
-            'roofline': {'bound': 'hbm', 'kernel': 'segment_sum_kernel (pamnet_segment_sum_f32, scatter-add)',
-                         'achieved': s['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': s['gbs'] / HBM_PEAK_GBS,
-                         'traffic': None, 'traffic_note': 'PMC passes (FETCH_SIZE x2 + WRITE_SIZE) in '
-                         'profiles/r01_scatter_add_pmc.txt: 1.002 x algorithmic bytes',
-                         'bytes_per_launch': s['bytes'], 'ms_per_launch': s['ms'],
-                         'shape': '[%d,%d]->[%d,%d] streamed (%.2f GB)' % (s['rows_in'], args.dim, s['rows_out'], args.dim, s['bytes'] / 1e9),
-                         'at_workload_shape': roof['workload']},
         }
+        if not args.no_rooflines:
+            roof = scatter_add_roofline(dev, g, args.dim, args.stream_gb)
+            s = roof['streamed']
+            pmc = pmc_record('r02_scatter_add_pmc')
+            line['roofline'] = {
+                'bound': 'hbm', 'kernel': 'segment_sum_kernel (pamnet_segment_sum_f32, scatter-add)',
+                'achieved': s['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': s['gbs'] / HBM_PEAK_GBS,
+                'traffic': (pmc['traffic_bytes_per_launch'] * s['bytes'] / pmc['algorithmic_bytes_per_launch']) if pmc else None,
+                'traffic_over_algorithmic': pmc['traffic_over_algorithmic'] if pmc else None,
+                'traffic_source': pmc['source'] if pmc else 'no PMC record under profiles/',
+                'bytes_per_launch': s['bytes'], 'ms_per_launch': s['ms'], 'best_group_gbs': s['gbs_best'],
+                'shape': '[%d,%d]->[%d,%d] streamed (%.2f GB)' % (s['rows_in'], args.dim, s['rows_out'], args.dim, s['bytes'] / 1e9),
+                'at_workload_shape': roof['workload']}
+            line['step_kernels'] = step_kernel_rooflines(dev, g, args.dim, args.n_layer)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
             line['speedup_vs_cpu'] = value / line['cpu_baseline']['value']

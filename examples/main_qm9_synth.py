@@ -26,6 +26,48 @@ from pamnet_amd import synth  # noqa: E402
 from pamnet_amd.train import Trainer, WarmupExpLR, shard_range  # noqa: E402
 
 
+def run_target(args, cfg, target, dev, world, rank):
+    """The body of main_qm9.py:84-132 for one target."""
+    model = (PAMNet if args.model == 'PAMNet' else PAMNet_s)(cfg).to(dev)
+    trainer = Trainer(model, lr=args.lr, weight_decay=args.wd, ema_decay=0.999, max_grad_norm=1000.0, world_size=world)
+    if rank == 0:
+        print('Target %d. Number of model parameters: ' % target, sum(p.numel() for p in model.parameters() if p.requires_grad))
+    gb = args.batch_size
+    steps_per_epoch = args.train // gb
+    sched = WarmupExpLR(args.lr, gamma=0.9961697, steps_per_epoch=args.train / gb)
+
+    def train_batch(step):                                         # this rank's shard of global batch `step`
+        lo, hi = shard_range(gb, rank, world)
+        return synth.qm9_batch(args.seed, step * gb + lo, hi - lo, target=target).to(dev)
+
+    vlo, vhi = shard_range(args.val, rank, world)
+    val = [synth.qm9_batch(args.seed + 1, args.train + vlo + i, min(gb, vhi - vlo - i), target=target).to(dev)
+           for i in range(0, vhi - vlo, gb)]
+
+    best = None
+    for epoch in range(args.epochs):
+        model.train()
+        loss_sum = torch.zeros((), device=dev)
+        nxt = train_batch(0)
+        for step in range(steps_per_epoch):
+            data, nxt = nxt, (train_batch(step + 1) if step + 1 < steps_per_epoch else None)
+            # the LR the reference's optimiser has AT this step (scheduler stepped after optimizer.step, main_qm9.py:112-114)
+            loss = trainer.step(data, lr=sched.lr_for_step(epoch, step, steps_per_epoch), global_graphs=gb, next_data=nxt)
+            loss_sum += loss.detach() * data.num_graphs
+        if world > 1:
+            dist.all_reduce(loss_sum)
+        val_mae = trainer.evaluate(val)                            # under the EMA weights (main_qm9.py:29-37)
+        if best is None or val_mae <= best:
+            best = val_mae
+            if args.save and rank == 0:
+                torch.save(model.state_dict(), args.save if len(str(args.target)) < 3 else '%s.t%d' % (args.save, target))
+        if rank == 0:
+            print('Epoch: {:03d}, Train MAE: {:.7f}, Val MAE: {:.7f}'.format(epoch + 1, float(loss_sum) / args.train, val_mae))
+    if rank == 0:
+        print('Best Validation MAE:', best)
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--model', default='PAMNet', choices=['PAMNet', 'PAMNet_s'])
@@ -40,6 +82,8 @@ def main():
     ap.add_argument('--train', type=int, default=2048, help='synthetic training molecules')
     ap.add_argument('--val', type=int, default=256)
     ap.add_argument('--seed', type=int, default=480)
+    ap.add_argument('--target', default='7', help="index of the target (0-11; 7-10 read label columns 12-15 as in "
+                    "main_qm9.py:60-66), or 'all': the 12 targets one after the other (BASELINE configs[2])")
     ap.add_argument('--save', default='')
     args = ap.parse_args()
 
@@ -49,47 +93,14 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
-    torch.manual_seed(args.seed)                                   # identical initial weights on every rank
-
     cfg = Config(dataset='QM9', dim=args.dim, n_layer=args.n_layer, cutoff_l=args.cutoff_l, cutoff_g=args.cutoff_g)
-    model = (PAMNet if args.model == 'PAMNet' else PAMNet_s)(cfg).to(dev)
-    trainer = Trainer(model, lr=args.lr, weight_decay=args.wd, ema_decay=0.999, max_grad_norm=1000.0, world_size=world)
-    if rank == 0:
-        print('Number of model parameters: ', sum(p.numel() for p in model.parameters() if p.requires_grad))
-
-    gb = args.batch_size
-    steps_per_epoch = args.train // gb
-    sched = WarmupExpLR(args.lr, gamma=0.9961697, steps_per_epoch=args.train / gb)
-
-    def train_batch(step):                                         # this rank's shard of global batch `step`
-        lo, hi = shard_range(gb, rank, world)
-        return synth.qm9_batch(args.seed, step * gb + lo, hi - lo).to(dev)
-
-    vlo, vhi = shard_range(args.val, rank, world)
-    val = [synth.qm9_batch(args.seed + 1, args.train + vlo + i, min(gb, vhi - vlo - i)).to(dev)
-           for i in range(0, vhi - vlo, gb)]
-
-    best = None
-    for epoch in range(args.epochs):
-        model.train()
-        loss_sum = torch.zeros((), device=dev)
-        nxt = train_batch(0)
-        for step in range(steps_per_epoch):
-            data, nxt = nxt, (train_batch(step + 1) if step + 1 < steps_per_epoch else None)
-            loss = trainer.step(data, lr=sched.lr_at(epoch, step) if (epoch or step) else args.lr / steps_per_epoch,
-                                global_graphs=gb, next_data=nxt)
-            loss_sum += loss.detach() * data.num_graphs
-        if world > 1:
-            dist.all_reduce(loss_sum)
-        val_mae = trainer.evaluate(val)                            # under the EMA weights (main_qm9.py:29-37)
-        if best is None or val_mae <= best:
-            best = val_mae
-            if args.save and rank == 0:
-                torch.save(model.state_dict(), args.save)
-        if rank == 0:
-            print('Epoch: {:03d}, Train MAE: {:.7f}, Val MAE: {:.7f}'.format(epoch + 1, float(loss_sum) / args.train, val_mae))
-    if rank == 0:
-        print('Best Validation MAE:', best)
+    targets = list(range(12)) if args.target == 'all' else [int(args.target)]
+    results = {}
+    for target in targets:                                         # 12 independent scalar-output runs
+        torch.manual_seed(args.seed)                               # identical initial weights on every rank
+        results[target] = run_target(args, cfg, target, dev, world, rank)
+    if rank == 0 and len(targets) > 1:
+        print('Best Validation MAE per target:', {t: round(v, 6) for t, v in results.items()})
     if world > 1:
         dist.destroy_process_group()
 

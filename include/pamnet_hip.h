@@ -7,7 +7,8 @@
  *
  * Conventions (every function):
  *   - arguments are raw DEVICE pointers, 64-bit sizes and a hipStream_t (passed as void*); no torch types;
- *   - the caller owns every buffer; the library allocates nothing, keeps no global state, never synchronises;
+ *   - the caller owns every device buffer; the library allocates no device memory, keeps no global state and never
+ *     synchronises (the pamnet_stack_* engine calls build small host-side pointer tables on the stack / heap per call);
  *   - work is enqueued on `stream`; return value 0 = OK, >0 = hipError_t of the failed launch, <0 = argument error
  *     (PAMNET_EINVAL: bad size / unsupported width; PAMNET_ENULL: required pointer is null);
  *   - float tensors are fp32 row-major [rows, d]; index tensors are int32; CSR pointers have rows+1 entries;

@@ -98,14 +98,16 @@ __device__ __forceinline__ Run wave_run(int key, bool valid, int lane) {
 }
 
 // count[key] += multiplicity; *unsorted = 1 if the key sequence ever decreases (then the sort below is needed)
-__global__ __launch_bounds__(256) void hist_kernel(const int32_t* __restrict__ keys, int64_t m,
+// Keys outside [0, rows) are skipped here and in claim_kernel (no out-of-bounds write); the Python side validates the
+// index inputs on the device and raises IndexError with the batch's size round trip (graph._input_flag).
+__global__ __launch_bounds__(256) void hist_kernel(const int32_t* __restrict__ keys, int64_t m, int64_t rows,
                                                    int32_t* __restrict__ count, int32_t* __restrict__ unsorted) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool valid = k < m;
     const int key = valid ? keys[k] : -1;
     const Run r = wave_run(key, valid, lane);
-    if (valid && r.head == lane) atomicAdd(&count[key], r.len);
+    if (valid && r.head == lane && (uint64_t)key < (uint64_t)rows) atomicAdd(&count[key], r.len);
     if (valid && k + 1 < m && keys[k + 1] < key) *unsorted = 1;
 }
 
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void copy_i32_kernel(const int32_t* __restrict
 }
 
 // sorted key sequence: the stable permutation is the identity.  Otherwise every run claims a block of slots.
-__global__ __launch_bounds__(256) void claim_kernel(const int32_t* __restrict__ keys, int64_t m,
+__global__ __launch_bounds__(256) void claim_kernel(const int32_t* __restrict__ keys, int64_t m, int64_t rows,
                                                     int32_t* __restrict__ cursor, int32_t* __restrict__ perm_tmp,
                                                     int32_t* __restrict__ perm, const int32_t* __restrict__ unsorted) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -128,10 +130,11 @@ __global__ __launch_bounds__(256) void claim_kernel(const int32_t* __restrict__ 
     const bool valid = k < m;
     const int key = valid ? keys[k] : -1;
     const Run r = wave_run(key, valid, lane);
+    const bool in_range = (uint64_t)key < (uint64_t)rows;
     int base = 0;
-    if (valid && r.head == lane) base = atomicAdd(&cursor[key], r.len);
+    if (valid && in_range && r.head == lane) base = atomicAdd(&cursor[key], r.len);
     base = __shfl(base, r.head, 64);
-    if (valid) perm_tmp[base + (lane - r.head)] = (int32_t)k;
+    if (valid && in_range) perm_tmp[base + (lane - r.head)] = (int32_t)k;
 }
 
 // one thread per claimed entry: its rank among the (distinct) entries of its row -> ascending perm inside each row.
@@ -139,12 +142,14 @@ __global__ __launch_bounds__(256) void claim_kernel(const int32_t* __restrict__ 
 __global__ __launch_bounds__(256) void sort_rows_kernel(const int32_t* __restrict__ keys,
                                                         const int32_t* __restrict__ ptr,
                                                         const int32_t* __restrict__ perm_tmp,
-                                                        int32_t* __restrict__ perm, int64_t m,
+                                                        int32_t* __restrict__ perm, int64_t m, int64_t rows,
                                                         const int32_t* __restrict__ unsorted) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (*unsorted == 0 || q >= m) return;
     const int v = perm_tmp[q];
+    if ((uint64_t)v >= (uint64_t)m) return;                  // slot never claimed (only with out-of-range keys)
     const int r = keys[v];
+    if ((uint64_t)r >= (uint64_t)rows) return;
     const int beg = ptr[r], end = ptr[r + 1];
     int rank = 0;
     int t = beg;
@@ -564,7 +569,7 @@ extern "C" int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t 
     e = hipMemsetAsync(unsorted, 0, sizeof(int32_t), st);
     if (e != hipSuccess) return (int)e;
     if (m > 0) {
-        hipLaunchKernelGGL(hist_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, cursor, unsorted);
+        hipLaunchKernelGGL(hist_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, rows, cursor, unsorted);
         PAMNET_LAUNCH_CHECK();
     }
     int rc = pamnet_exclusive_scan_i32(cursor, ptr, rows, tmp, stream);
@@ -572,9 +577,9 @@ extern "C" int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t 
     if (m == 0) return PAMNET_OK;
     hipLaunchKernelGGL(copy_i32_kernel, dim3(blocks_for(rows)), dim3(256), 0, st, ptr, cursor, rows);
     PAMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(claim_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, cursor, perm_tmp, perm, unsorted);
+    hipLaunchKernelGGL(claim_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, rows, cursor, perm_tmp, perm, unsorted);
     PAMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sort_rows_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, ptr, perm_tmp, perm, m, unsorted);
+    hipLaunchKernelGGL(sort_rows_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, ptr, perm_tmp, perm, m, rows, unsorted);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

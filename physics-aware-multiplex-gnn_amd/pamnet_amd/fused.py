@@ -18,17 +18,29 @@ from .ops import gather_mul_raw, segment_sum_raw
 
 D = 128
 
-# When True and every parameter of a layer already owns a preallocated `.grad` (train.FlatParams: views of one flat
-# fp32 buffer), the backward kernels write the gradients straight into those buffers and return None to autograd -- no
-# per-parameter AccumulateGrad add (~330 launches per step at L=6).  Semantics: overwrite; valid because every parameter
-# is used exactly once per forward and the trainer runs one backward per step.  Off by default (plain autograd).
-DIRECT_GRAD = False
+# Direct gradients: when every parameter of a layer owns a preallocated `.grad` and carries `_pamnet_direct = True`
+# (train.FlatParams hands both out: views of one flat fp32 buffer), the backward kernels write the gradients straight
+# into those buffers and return None to autograd -- no per-parameter AccumulateGrad add (~330 launches per step at L=6).
+# Semantics: overwrite; valid because every parameter is used exactly once per forward and the trainer runs one backward
+# per zero_grad.  The permission is a property of the parameters (i.e. of one model), not of the process.
 
-# Optional list of n_layer torch.cuda.Event (already recorded once, so their handles exist): the layer-stack backward
-# records event k when all gradients of layer pair k are enqueued (train.Trainer overlaps the gradient all-reduce of
-# the last layers with the backward of the first ones).
-LAYER_EVENTS = None
-EVENTS_RECORDED = False     # set by the backward when it handed LAYER_EVENTS to the engine (checked by the trainer)
+
+class StackCtx(object):
+    """Per-model hand-over between a trainer and the layer-stack backward: `events` = n_layer torch.cuda.Event (already
+    recorded once, so their handles exist) the engine records as each layer pair's gradients are enqueued -- the trainer
+    overlaps the gradient all-reduce of the last layers with the backward of the first ones; `recorded` is set by the
+    backward when it handed the events to the engine."""
+
+    def __init__(self):
+        self.events, self.recorded = None, False
+
+
+def stack_ctx(global_layers):
+    """The StackCtx of a model's layer stack (created on first use, stored on the global_layer ModuleList)."""
+    ctx = getattr(global_layers, '_pamnet_ctx', None)
+    if ctx is None:
+        ctx = global_layers._pamnet_ctx = StackCtx()
+    return ctx
 
 
 def _parr(tensors):
@@ -54,8 +66,8 @@ def _sub(w, c0):
 
 def _grad_buffers(params):
     """(direct, buffers): where the gradients of `params` (a list of Parameters / tensors) are written."""
-    if DIRECT_GRAD and all(getattr(p, '_pamnet_direct', False) and getattr(p, 'grad', None) is not None
-                           and p.grad.is_contiguous() for p in params):
+    if all(getattr(p, '_pamnet_direct', False) and getattr(p, 'grad', None) is not None
+           and p.grad.is_contiguous() for p in params):
         return True, [p.grad for p in params]
     return False, [torch.empty_like(p) for p in params]
 
@@ -396,18 +408,6 @@ def local_params(layer):
             layer.lin_rbf_out.weight] + tail_params(layer)
 
 
-_TEMP = {}
-
-
-def _temp_arena(n_floats, dev):
-    """Scratch arena reused by every call on a device (stream-ordered use; grown on demand)."""
-    t = _TEMP.get(dev)
-    if t is None or t.numel() < n_floats:
-        t = torch.empty(int(n_floats * 1.25) + 1024, dtype=torch.float32, device=dev)
-        _TEMP[dev] = t
-    return t
-
-
 _AUX = {}
 PACK_WEIGHTS = os.environ.get('PAMNET_PACK_WEIGHTS', '1') != '0'
 AUX_FORK = os.environ.get('PAMNET_AUX_FWD', '0') != '0'      # measured: no gain at B=128 (host-side event cost, CU contention)
@@ -450,7 +450,15 @@ class StackPlan(object):
         self.flat = self.gflat + self.lflat
         self._probe = [self.flat[0], self.flat[len(self.flat) // 2], self.flat[-1]]
         self._pkey = self._gkey = None
-        self._pack = None
+        self._pack = self._temp = None
+        self.ctx = stack_ctx(global_layers)
+
+    def temp_arena(self, n_floats, dev):
+        """Scratch arena of this model's engine calls (stream-ordered use; grown on demand)."""
+        t = self._temp
+        if t is None or t.numel() < n_floats or t.device != dev:
+            t = self._temp = torch.empty(int(n_floats * 1.25) + 1024, dtype=torch.float32, device=dev)
+        return t
 
     def pack_arena(self, dev):
         """Scratch for the fragment-ordered weight images the node chains read (re-packed by every engine call)."""
@@ -470,8 +478,8 @@ class StackPlan(object):
 
     def direct(self):
         """True when every parameter owns a preallocated contiguous .grad handed out by train.FlatParams (which zeroes
-        it every step: direct writes overwrite, they do not accumulate) and DIRECT_GRAD is on."""
-        if not DIRECT_GRAD or not getattr(self._probe[0], '_pamnet_direct', False):
+        it every step: direct writes overwrite, they do not accumulate) with direct writes allowed."""
+        if not all(getattr(p, '_pamnet_direct', False) for p in self._probe):
             return False
         grads = [p.grad for p in self._probe]
         if any(g is None for g in grads):
@@ -501,7 +509,7 @@ class _Stack(torch.autograd.Function):
         lib.call('pamnet_stack_workspace', n, e_g.size(0), rbf_e.size(0), e_sbf.size(0), L,
                  ctypes.addressof(need), ctypes.addressof(need) + 8)
         saved = torch.empty(max(int(need[0]), 1), dtype=torch.float32, device=x0.device)
-        temp = _temp_arena(int(need[1]), x0.device)
+        temp = plan.temp_arena(int(need[1]), x0.device)
         outs, atts = _empty(2 * L, n, like=x0), _empty(2 * L, n, like=x0)
         gtab, ltab = plan.param_tables()
         aux, evs = _aux_fork(x0.device, L)
@@ -520,16 +528,16 @@ class _Stack(torch.autograd.Function):
         graph, plan, direct = ctx.graph, ctx.plan, ctx.direct
         L = plan.L
         sizes, idx = _graph_tables(graph)
-        temp = _temp_arena(ctx.temp_floats, x0.device)
+        temp = plan.temp_arena(ctx.temp_floats, x0.device)
         d_x0, d_eg, d_rbf, d_sbf = (torch.empty_like(t) for t in (x0, e_g, rbf_e, e_sbf))
         gtab, ltab = plan.param_tables()
         evs = None
         if direct:
             ggrad, lgrad, g = plan._ggrad, plan._lgrad, ()
-            if LAYER_EVENTS is not None and len(LAYER_EVENTS) == L:
-                global EVENTS_RECORDED
-                evs = _parr([int(e.cuda_event) for e in LAYER_EVENTS])
-                EVENTS_RECORDED = True
+            sc = plan.ctx
+            if sc.events is not None and len(sc.events) == L:
+                evs = _parr([int(e.cuda_event) for e in sc.events])
+                sc.recorded = True
         else:
             g = [torch.empty_like(p) for p in plan.flat]
             ggrad, lgrad = _parr(g[:len(plan.gflat)]), _parr(g[len(plan.gflat):])

@@ -71,16 +71,26 @@ def _filter_fill(ptr_in, nbr, dist, cut, ptr, total):
     return ptr, nbr_out, dist_out
 
 
-def csr_filter(ptr_in, nbr, dist, cut):
+def csr_filter(ptr_in, nbr, dist, cut, flag=None):
     ptr = _filter_count(ptr_in, nbr, dist, cut)
-    return _filter_fill(ptr_in, nbr, dist, cut, ptr, int(ptr[-1]))
+    if flag is None:
+        return _filter_fill(ptr_in, nbr, dist, cut, ptr, int(ptr[-1]))
+    total, bad = host_ints(ptr[-1], flag)
+    if bad:
+        _raise_bad_inputs()
+    return _filter_fill(ptr_in, nbr, dist, cut, ptr, total)
 
 
-def csr_filter2(ptr_in, nbr, dist, cut_a, cut_b):
+def csr_filter2(ptr_in, nbr, dist, cut_a, cut_b, flag=None):
     """Two cutoffs on the same table (the RNA global / local graphs, models.py:147-156): both counts first, one host
-    round trip for the two sizes."""
+    round trip for the two sizes (and the input-validity flag)."""
     pa, pb = _filter_count(ptr_in, nbr, dist, cut_a), _filter_count(ptr_in, nbr, dist, cut_b)
-    ta, tb = host_ints(pa[-1], pb[-1])
+    if flag is None:
+        ta, tb = host_ints(pa[-1], pb[-1])
+    else:
+        ta, tb, bad = host_ints(pa[-1], pb[-1], flag)
+        if bad:
+            _raise_bad_inputs()
     return _filter_fill(ptr_in, nbr, dist, cut_a, pa, ta), _filter_fill(ptr_in, nbr, dist, cut_b, pb, tb)
 
 
@@ -188,8 +198,26 @@ def _triplet_ptr(lp, l_src, l_dst, with_triplets):
     return exclusive_scan(tpcount)
 
 
+def _input_flag(batch, n_graphs, types=None, n_types=None, edge_index=None):
+    """Device-side validity flag of the index inputs (the kernels write count[key] / cursor[key] for whatever key they
+    are given): `batch` sorted with ids in [0, n_graphs), atom types in [0, n_types), edge endpoints in [0, N).  Returned
+    as a 0-dim bool tensor that travels back with the data-dependent sizes in the SAME host round trip."""
+    n = batch.numel()
+    bad = (batch[-1] >= n_graphs) | (batch[0] < 0) | (batch[1:] < batch[:-1]).any()
+    if types is not None and n_types is not None:
+        bad = bad | (types < 0).any() | (types >= n_types).any()
+    if edge_index is not None and edge_index.numel():
+        bad = bad | (edge_index.min() < 0) | (edge_index.max() >= n)
+    return bad
+
+
+def _raise_bad_inputs():
+    raise IndexError('index out of range in the batch handed to PAMNet.forward: `batch` must be sorted with ids in '
+                     '[0, num_graphs), atom types in [0, embeddings.size(0)), edge_index in [0, num_nodes)')
+
+
 def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_index=None, num_graphs=None,
-                need_grad=True, knn_k=50, with_triplets=True):
+                need_grad=True, knn_k=50, with_triplets=True, n_types=None):
     """Graph-construction part of PAMNet.forward (models.py:104-177).  Returns a Graph."""
     dev = batch.device
     g = Graph()
@@ -220,7 +248,10 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         keep = ei[0] != ei[1]
         lp, l_src, l_dst, tp_ptr = bonds(ei)
         gptr_g = radius_count(pos, node_graph, g.gptr, cutoff_g)               # symmetric: agg = query, other = nbr
-        total_g, all_kept, tp_total = host_ints(gptr_g[-1], keep.all(), tp_ptr[-1])
+        total_g, all_kept, tp_total, bad = host_ints(gptr_g[-1], keep.all(), tp_ptr[-1],
+                                                     _input_flag(batch, g.n_graphs, x_raw, n_types, ei))
+        if bad:
+            _raise_bad_inputs()
         if not all_kept:
             lp, l_src, l_dst, tp_ptr = bonds(ei[:, keep])
             tp_total = int(tp_ptr[-1])
@@ -232,14 +263,15 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         pos = xr[:, :3].to(torch.float32).contiguous()
         g.sign = torch.where(pos[:, 0] > 40.0, -torch.ones_like(pos[:, 0]), torch.ones_like(pos[:, 0])).contiguous()
         gp, gn, gd = radius_graph(pos, node_graph, g.gptr, cutoff_g)
-        lp, l_src, l_dist = csr_filter(gp, gn, gd, cutoff_l)                   # symmetric subset (models.py:131-134)
+        lp, l_src, l_dist = csr_filter(gp, gn, gd, cutoff_l, _input_flag(batch, g.n_graphs))   # models.py:131-134
         l_dst = expand_rows(lp, l_src.numel())
     elif rna:
         xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
         pos = xr[:, :3].to(torch.float32).contiguous()
         kp, kn, kd = knn_table(pos, node_graph, g.gptr, knn_k, float('inf'))   # (query, neighbour) rows, self dropped
         # models.py:147-150 (global) and 153-156 (local: j = query, i = nbr)
-        (gp, gn, gd), (qp, qn, qd) = csr_filter2(kp, kn, kd, cutoff_g, cutoff_l)
+        (gp, gn, gd), (qp, qn, qd) = csr_filter2(kp, kn, kd, cutoff_g, cutoff_l,
+                                                 _input_flag(batch, g.n_graphs, xr[:, -1], n_types))
         if flow != 'target_to_source':                                          # aggregate at edge_index[1] = neighbour
             gp, gn, gd = _transpose_edges(gp, gn, gd, n)
         lp, l_src, l_dist = _transpose_edges(qp, qn, qd, n)                    # local layer always aggregates at i

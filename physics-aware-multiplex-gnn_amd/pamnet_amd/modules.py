@@ -19,9 +19,11 @@ import os
 
 from . import fused, narrow, ops
 
-# 'fused' (default): fp32-MFMA chain kernels for dim=128.  'torch': the same maths with dense layers on torch ops --
-# kept as the plain-PyTorch fp32 reference the kernel tests compare against (GPU only; not a CPU fallback).
-IMPL = os.environ.get('PAMNET_IMPL', 'fused')
+# 'fused': fp32-MFMA chain kernels for dim = 128, row kernels for dim = 16 / 32 / 64.  Any other width runs the generic
+# formulation below (dense layers on torch ops between the HIP graph / basis / segment kernels; GPU only, not a CPU
+# fallback).  Not configurable at run time: the kernel tests (tests/test_hip_fused.py) flip this module attribute to force
+# the generic formulation at dim = 128 as their plain-PyTorch fp32 comparand.
+IMPL = 'fused'
 
 
 def _fused(x):

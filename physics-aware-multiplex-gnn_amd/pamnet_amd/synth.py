@@ -161,9 +161,16 @@ class Batch(object):
     def __init__(self, **kw):
         self.__dict__.update(kw)
 
-    def to(self, device):
+    def to(self, device, non_blocking=False):
+        """non_blocking=True: asynchronous copies on the current stream; the returned batch carries `inputs_ready`, an
+        event recorded behind them, which the trainer's side-stream graph construction waits for (train.Trainer.prefetch)."""
         import torch
-        return Batch(**{k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in self.__dict__.items()})
+        b = Batch(**{k: (v.to(device, non_blocking=non_blocking) if isinstance(v, torch.Tensor) else v)
+                     for k, v in self.__dict__.items() if k != 'inputs_ready'})
+        if non_blocking and torch.device(device).type == 'cuda':
+            b.inputs_ready = torch.cuda.Event()
+            b.inputs_ready.record(torch.cuda.current_stream(torch.device(device)))
+        return b
 
     def keys(self):
         return list(self.__dict__.keys())
@@ -194,8 +201,22 @@ def collate(graphs):
     return Batch(**kw)
 
 
-def qm9_batch(seed, start, count):
-    return collate([qm9_molecule(seed, start + i) for i in range(count)])
+def qm9_batch(seed, start, count, target=None):
+    """target: None -> the molecule's scalar label; 0..11 -> that column of the synthetic 16-column label table with the
+    reference's column map (main_qm9.py:60-66: targets 7-10 read columns 12-15)."""
+    b = collate([qm9_molecule(seed, start + i) for i in range(count)])
+    if target is not None:
+        import torch
+        col = target + 5 if target in (7, 8, 9, 10) else target
+        b.y = torch.from_numpy(qm9_label_table(seed, start, count)[:, col].copy())
+    return b
+
+
+def qm9_label_table(seed, start, count):
+    """[count, 16] synthetic label table (QM9's `data.y` has 16+ columns, qm9_dataset.py; values ~N(0,1) per molecule,
+    reproducible from the molecule index alone so that shards agree across ranks)."""
+    return np.stack([np.random.default_rng([seed, 7919, start + i]).standard_normal(16).astype(np.float32)
+                     for i in range(count)])
 
 
 def pdbbind_batch(seed, start, count, **kw):

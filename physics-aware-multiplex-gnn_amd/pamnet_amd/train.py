@@ -36,7 +36,7 @@ class FlatParams(object):
     embeddings).  `layer_ranges[k]` = [lo, hi) of layer pair k, so the gradients of any run of consecutive layers are
     one contiguous slice that can be all-reduced while earlier layers are still being differentiated."""
 
-    def __init__(self, module):
+    def __init__(self, module, direct=True):
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
         rank = lambda n: (1, 0) if _layer_of(n) is None else (0, -_layer_of(n))
         named.sort(key=lambda np_: rank(np_[0]))          # stable: declaration order inside a group
@@ -66,7 +66,14 @@ class FlatParams(object):
             p.data = self.flat[o:o + k].view_as(p)
             self.grad_views.append(self.grad[o:o + k].view_as(p))
             p.grad = self.grad_views[-1]
-            p._pamnet_direct = True        # the fused kernels may write this gradient in place (see fused.DIRECT_GRAD)
+        self.set_direct(direct)
+
+    def set_direct(self, on):
+        """Allow (or forbid) the fused kernels to write these parameters' gradients in place (overwrite semantics: one
+        backward per zero_grad).  The permission travels with the parameters of THIS module -- nothing process-global."""
+        self.direct = bool(on)
+        for p in self.params:
+            p._pamnet_direct = self.direct
 
     def zero_grad(self):
         self.grad.zero_()
@@ -101,17 +108,46 @@ class WarmupExpLR(object):
         t = epoch + step / self.spe
         return self.lr0 * t if t <= 1.0 else self.lr0 * self.gamma ** (t - 1.0)
 
+    def lr_for_step(self, epoch, step, steps_in_epoch):
+        """Learning rate the optimiser uses AT (epoch, step) in the reference loop: the scheduler is stepped after
+        optimizer.step() with the fractional epoch of the step just done (main_qm9.py:112-114), and the warm-up scheduler
+        starts from 0 -- so step s runs with lr_at of step s-1, the very first step with 0."""
+        if step > 0:
+            return self.lr_at(epoch, step - 1)
+        if epoch == 0:
+            return 0.0
+        return self.lr_at(epoch - 1, steps_in_epoch - 1)
+
+
+def plan_buckets(layer_ranges, numel, n_buckets):
+    """Tile the flat gradient [0, numel) into contiguous all-reduce slices by layer pair, in the order the backward
+    completes them (FlatParams lays layer pair L-1 first).  Returns (buckets, tail): buckets = [(lo, hi, k_ready)] --
+    slice [lo, hi) is final once layer pair k_ready is done -- and tail = (lo, numel): the first layers together with
+    the top-level parameters, final only when the whole backward is.  None when the layers are not 0..L-1."""
+    L = len(layer_ranges)
+    if L == 0 or sorted(layer_ranges) != list(range(L)):
+        return None
+    per = max(1, math.ceil(L / float(n_buckets)))
+    buckets, k_hi = [], L - 1
+    while k_hi >= 0:
+        k_lo = max(0, k_hi - per + 1)
+        buckets.append((layer_ranges[k_hi][0], layer_ranges[k_lo][1], k_lo))
+        k_hi = k_lo - 1
+    lo_last = buckets.pop()[0]               # merged with the top-level parameters
+    tail = (lo_last, numel)
+    pos = 0
+    for lo, hi, _ in buckets:                # contiguous, in order, no overlap
+        assert lo == pos and hi > lo
+        pos = hi
+    assert pos == tail[0] <= numel
+    return buckets, tail
+
 
 class Trainer(object):
     def __init__(self, model, lr=1e-4, weight_decay=0.0, ema_decay=0.999, max_grad_norm=1000.0, betas=(0.9, 0.999),
                  eps=1e-8, world_size=1, process_group=None, overlap_comm=True, n_buckets=3, native_optimizer=True):
         self.model = model
-        self.fp = FlatParams(model)
-        try:                                               # fused layers write gradients straight into fp.grad
-            from . import fused
-            fused.DIRECT_GRAD = True
-        except Exception:                                  # (gloo/CPU unit tests drive the trainer with a plain module)
-            pass
+        self.fp = FlatParams(model, direct=True)           # fused layers write gradients straight into fp.grad
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         # On the GPU clip + Adam + EMA (+ the next zero_grad) are one pass of csrc/optim.hip over the flat buffers;
         # torch.optim.Adam on the flat tensor is the CPU path (gloo unit tests) and the cross-check of the kernel.
@@ -130,20 +166,25 @@ class Trainer(object):
         self.shadow = self.fp.flat.clone()                                 # utils/ema.py:9-11
         self.max_grad_norm = max_grad_norm
         self.world_size, self.pg = world_size, process_group
-        self._buckets = None
+        self._buckets = self._stack_ctx = None
         self._force_single = overlap_comm == 'force_single'     # measurement aid: one all-reduce even on a 1-rank group
-        if overlap_comm and overlap_comm != 'force_single' and self.fp.flat.is_cuda and dist.is_available() and dist.is_initialized() \
-                and (world_size > 1 or overlap_comm == 'force'):
+        distributed = dist.is_available() and dist.is_initialized()
+        if world_size > 1 and distributed:
+            # identical initial parameters on every rank whatever the seeds were (main_qm9.py has a single process)
+            dist.broadcast(self.fp.flat, 0, group=process_group)
+            self.shadow.copy_(self.fp.flat)
+        if overlap_comm and overlap_comm != 'force_single' and distributed and (world_size > 1 or overlap_comm == 'force'):
             self._setup_buckets(n_buckets)
 
     # -- pieces (also timed individually by bench.py) ---------------------------------------------------------------
     def forward_backward(self, data, global_graphs=None):
+        """One forward + backward into the flat gradient.  Overwrite semantics (the fused kernels write gradients in
+        place): a call always starts from a zeroed buffer, there is no gradient accumulation across calls."""
         if not self._grad_clean:
             self.fp.zero_grad()
         self._grad_clean = False
-        if self._buckets is not None:
-            from . import fused
-            fused.EVENTS_RECORDED = False
+        if self._stack_ctx is not None:
+            self._stack_ctx.recorded = False
         if self._pack:
             self.fp.release_grads()
         out = self.model(data)
@@ -162,45 +203,46 @@ class Trainer(object):
 
     # -- gradient all-reduce -------------------------------------------------------------------------------------------
     def _setup_buckets(self, n_buckets):
-        """Split the flat gradient into `n_buckets` contiguous slices by layer pair, last layers first (the order the
-        backward completes them); the layer-stack backward records one event per layer pair (fused.LAYER_EVENTS)."""
-        from . import fused
-        L = len(self.fp.layer_ranges)
-        if L == 0 or sorted(self.fp.layer_ranges) != list(range(L)):
+        """Split the flat gradient into contiguous slices by layer pair, last layers first (plan_buckets).  On the GPU
+        the layer-stack backward records one event per layer pair (handed to it through the model's fused.StackCtx) and
+        the slices are reduced on a side stream behind those events; on CPU (gloo tests) the same slices are reduced
+        one after the other."""
+        plan = plan_buckets(self.fp.layer_ranges, self.fp.grad.numel(), n_buckets)
+        if plan is None:
             return
+        self._buckets, self._tail_range = plan
+        if not self.fp.flat.is_cuda:
+            return
+        from . import fused
         dev = self.fp.flat.device
+        L = len(self.fp.layer_ranges)
         events = [torch.cuda.Event() for _ in range(L)]
         for e in events:
             e.record(torch.cuda.current_stream(dev))      # materialise the handles the C side records into
-        per = max(1, math.ceil(L / float(n_buckets)))
-        buckets, k_hi = [], L - 1
-        while k_hi >= 0:
-            k_lo = max(0, k_hi - per + 1)
-            lo = self.fp.layer_ranges[k_hi][0]
-            hi = self.fp.layer_ranges[k_lo][1]
-            buckets.append((lo, hi, k_lo))                 # ready when layer pair k_lo is done
-            k_hi = k_lo - 1
-        covered = buckets[-1][1]
-        # the last layer bucket is merged with the top-level parameters (ready only when the whole backward is done)
-        lo_last = buckets.pop()[0]
-        self._tail_range = (lo_last, self.fp.grad.numel())
-        assert buckets == [] or buckets[0][0] == 0
-        assert covered <= self.fp.grad.numel()
-        self._buckets, self._events = buckets, events
+        self._events = events
         self._comm = torch.cuda.Stream(device=dev)
-        fused.LAYER_EVENTS = events
+        layers = getattr(self.model, 'global_layer', None)
+        if layers is not None:
+            self._stack_ctx = fused.stack_ctx(layers)
+            self._stack_ctx.events = events
 
     def sync_gradients(self):
         """Sum the gradient over ranks.  With buckets: slices of the last layers are reduced on a side stream as soon as
         the backward has produced them (the host has already enqueued the whole backward when this runs; the device is
         still working through it), the remainder after the backward's end; the main stream then waits for all of it."""
-        bucketed = self._buckets is not None
-        if bucketed:
-            from . import fused
-            bucketed = fused.EVENTS_RECORDED       # this backward did not go through the engine: no per-layer events
-        if not bucketed:
+        if self._buckets is None:
             if self.world_size > 1 or self._force_single:
                 dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM, group=self.pg)
+            return
+        if not self.fp.flat.is_cuda:                       # same tiling, no streams
+            for lo, hi, _ in self._buckets:
+                dist.all_reduce(self.fp.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+            lo, hi = self._tail_range
+            dist.all_reduce(self.fp.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+            return
+        if self._stack_ctx is None or not self._stack_ctx.recorded:
+            # this backward did not go through the engine (no per-layer events): one all-reduce
+            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM, group=self.pg)
             return
         main = torch.cuda.current_stream(self.fp.flat.device)
         done = torch.cuda.Event()
@@ -267,12 +309,17 @@ class Trainer(object):
 
     # -- input pipelining -----------------------------------------------------------------------------------------------
     def prefetch(self, data):
-        """Build `data`'s graph on the side stream (model.prepare); forward() picks it up."""
+        """Build `data`'s graph on the side stream (model.prepare); forward() picks it up.
+        The side stream does not wait for the main stream (that would serialise it behind the whole step), so the batch
+        tensors must be complete when this is called -- OR carry `data.inputs_ready`, a torch.cuda.Event recorded on the
+        stream that produces them (pinned .to(device, non_blocking=True), GPU-side collation): the side stream then waits
+        for exactly that event (synth.Batch.to(..., non_blocking=True) records it)."""
         if not hasattr(self.model, 'prepare') or not self.fp.flat.is_cuda:
             return
         if getattr(self, '_side', None) is None:
             self._side = torch.cuda.Stream(device=self.fp.flat.device)
         main = torch.cuda.current_stream(self.fp.flat.device)
+        _wait_inputs(self._side, data)
         with torch.cuda.stream(self._side):
             self.model.prepare(data)
             ev = torch.cuda.Event()
@@ -334,6 +381,7 @@ def predict(model, batches):
             # queued BEFORE this batch's forward: the graph kernels are small, and their one host round trip resolves
             # while the previous forward is still running instead of waiting behind this one
             main = torch.cuda.current_stream(dev)
+            _wait_inputs(side, nxt)
             with torch.cuda.stream(side):
                 model.prepare(nxt, need_grad=False)
                 e = torch.cuda.Event()
@@ -344,6 +392,13 @@ def predict(model, batches):
         out = model(cur)
         yield cur, out
         cur = nxt
+
+
+def _wait_inputs(stream, data):
+    """Make `stream` wait for the producer of a batch's tensors when the batch says who that is (data.inputs_ready)."""
+    ev = getattr(data, 'inputs_ready', None)
+    if ev is not None:
+        stream.wait_event(ev)
 
 
 def _graph_tensors(g):
@@ -362,3 +417,18 @@ def shard_range(total, rank, world):
     base, rem = divmod(total, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def balanced_shards(sizes, world):
+    """Node-balanced molecule sharding for graphs of very different sizes (RNA-Puzzles: 841-3 823 nodes, PDBbind
+    complexes): greedy longest-first bin packing by number of nodes -- every rank gets the list of graph
+    indices whose node counts sum to roughly total / world.  Deterministic (ties broken by index), identical on every
+    rank; each rank's list is returned sorted so that a shard keeps the dataset's order.  QM9-sized molecules are
+    uniform enough for shard_range (equal counts)."""
+    order = sorted(range(len(sizes)), key=lambda i: (-int(sizes[i]), i))
+    loads, shards = [0] * world, [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        loads[r] += int(sizes[i])
+        shards[r].append(i)
+    return [sorted(s) for s in shards]

@@ -39,6 +39,37 @@ def _ok(a, ref32, ref64, scale=None):
     return e <= max(TOL, 2 * floor), (e, floor)
 
 
+GRAD_TOL = 1e-4          # gradients within 1e-4 of the reference's fp64 autograd ...
+
+
+def _check_gradients(model, p64, fwd, sd, cfg, b, report=None):
+    """Every parameter gradient of the HIP backward against the oracle's fp64 autograd (p64[k].grad already filled):
+        err(hip, fp64) <= max(GRAD_TOL, 2 * err(oracle_fp32, fp64))
+    -- the 1e-4 of DESIGN.md, never tighter than what the reference's OWN fp32 backward achieves on the same inputs
+    (its sympy closed forms and the signed PDBbind pooling cancel catastrophically for a few tensors; the fp32 oracle
+    is run here to measure exactly that floor instead of hard-coding a looser bound)."""
+    p32 = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    pos, ei = getattr(b, 'pos', None), getattr(b, 'edge_index', None)
+    torch.nn.functional.l1_loss(fwd(p32, cfg, b.x, b.batch, pos, ei), b.y).backward()
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+    gn64 = float(torch.sqrt(sum((p.grad ** 2).sum() for p in p64.values() if p.grad is not None)))
+    gn32 = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in p32.values() if p.grad is not None)))
+    assert abs(gn / gn64 - 1) <= max(GRAD_TOL, 2 * abs(gn32 / gn64 - 1)), (gn, gn64, gn32)
+    worst = (0.0, 0.0, None)
+    for k, p in model.named_parameters():
+        if p64[k].grad is None:
+            continue
+        e = maxnorm_err(p.grad.cpu().numpy(), p64[k].grad.numpy())
+        floor = maxnorm_err(p32[k].grad.numpy(), p64[k].grad.numpy())
+        assert e <= max(GRAD_TOL, 2 * floor), (k, e, floor)
+        if e > worst[0]:
+            worst = (e, floor, k)
+    if report is not None:
+        report['grad_worst'] = worst
+        report['grad_norm_rel'] = abs(gn / gn64 - 1)
+    return worst
+
+
 # ------------------------------------------------------------------------------------------------------ CPU (not gpu)
 def test_state_dict_layout_matches_reference(golden):
     """Keys and shapes == the reference's (oracle.init_state_dict mirrors them; the RNA checkpoint is the real thing)."""
@@ -109,6 +140,12 @@ def test_forward_vs_reference_golden(dev, golden, name, small):
         scale = max(float(np.abs(g['node_out64'][g['in/batch'] == b]).sum()) for b in range(len(g['out64'])))
     ok, info = _ok(out.cpu().numpy(), g['out32'], g['out64'], scale)
     assert ok, ('out', info)
+    if scale is not None:
+        # the raw figure max|d| / max|out| beside the magnitude-normalised one: held to the reference's own fp32 noise
+        raw, raw_floor = maxnorm_err(out.cpu().numpy(), g['out64']), maxnorm_err(g['out32'], g['out64'])
+        print('PDBbind %s: err/sum|node_out| = %.2e (ref fp32 %.2e);  raw max|d|/max|out| = %.2e (ref fp32 %.2e)'
+              % (name, info[0], info[1], raw, raw_floor))
+        assert raw <= max(TOL, 2 * raw_floor), (raw, raw_floor)
     # graph sizes are integers: exact
     assert model._graph_cache.loc.m == int(g['num_edges_l'])
     assert model._graph_cache.n_pair == int(g['num_pairs'])
@@ -284,6 +321,131 @@ def test_rna_baseline_config_properties(dev):
         assert maxnorm_err(model(moved.to(dev)).cpu().numpy(), full.cpu().numpy()) < 2e-4
 
 
+def _oracle_threads():
+    """The oracle's small CPU ops oversubscribe badly on the GPU box's 256-core host: a bounded pool."""
+    import os
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+
+
+@pytest.mark.gpu
+def test_baseline_qm9_b128_vs_oracle(dev):
+    """BASELINE configs[1] EXACTLY (QM9 schema, dim=128, n_layer=6, B=128 -- the batch bench.py times): graph outputs,
+    node features after every layer and every parameter gradient of the L1 loss against the CPU oracle (fp32 + fp64)."""
+    import models
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import synth
+    _oracle_threads()
+    cfg = models.Config(dataset='QM9', dim=128, n_layer=6, cutoff_l=5.0, cutoff_g=5.0)
+    b = synth.qm9_batch(0, 0, 128)
+    sd = O.init_state_dict(cfg, seed=0)
+    model = models.PAMNet(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    data = b.to(dev)
+    out = model(data)
+    torch.nn.functional.l1_loss(out, data.y).backward()
+    ref32 = O.pamnet_forward(sd, cfg, b.x, b.batch, b.pos, b.edge_index)
+    p64 = O.as_params({k: v.double() for k, v in sd.items()})
+    inter = {}
+    ref64 = O.pamnet_forward(p64, cfg, b.x, b.batch, b.pos, b.edge_index, dtype=torch.float64, intermediates=inter)
+    torch.nn.functional.l1_loss(ref64, b.y.double()).backward()
+    gc = model._graph_cache
+    assert gc.n == b.x.numel() and gc.glob.m == inter['edge_index_g'].size(1) and gc.loc.m == inter['edge_index_l'].size(1)
+    assert gc.n_trip == inter['idx_kj'].numel() and gc.n_pair == inter['idx_jj_pair'].numel()
+    ok, info = _ok(out.detach().cpu().numpy(), ref32.numpy(), ref64.detach().numpy())
+    assert ok, ('out', info)
+    ok, info_x = _ok(torch.stack(list(model._x_layers)).detach().cpu().numpy(),
+                     inter['x_layers'].detach().float().numpy(), inter['x_layers'].detach().numpy())
+    assert ok, ('x_layers', info_x)
+    ok, info_n = _ok(model._node_out.detach().cpu().numpy(), inter['node_out'].detach().float().numpy(),
+                     inter['node_out'].detach().numpy())
+    assert ok, ('node_out', info_n)
+    rep = {}
+    _check_gradients(model, p64, O.pamnet_forward, sd, cfg, b, rep)
+    print('QM9 B=128 d128 L6 vs oracle: out %.2e (ref fp32 %.2e), x_layers %.2e, node_out %.2e, worst grad %.2e '
+          '(ref fp32 %.2e, %s), |grad| rel %.1e' % (info + (info_x[0], info_n[0]) + rep['grad_worst'] + (rep['grad_norm_rel'],)))
+
+
+@pytest.mark.gpu
+def test_baseline_rna_b8_vs_oracle(dev):
+    """BASELINE configs[4] EXACTLY (RNA-Puzzles schema, dim=16, n_layer=1, B=8 graphs of 800-3 900 nodes, kNN global
+    graph, flow=target_to_source, mean pool): scores and gradients against the CPU oracle."""
+    import models
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import synth
+    _oracle_threads()
+    cfg = models.Config(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
+    b = synth.rna_batch(2, 0, 8)
+    sd = O.init_state_dict(cfg, seed=5)
+    model = models.PAMNet(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    data = b.to(dev)
+    out = model(data)
+    torch.nn.functional.l1_loss(out, data.y).backward()
+    ref32 = O.pamnet_forward(sd, cfg, b.x, b.batch)
+    p64 = O.as_params({k: v.double() for k, v in sd.items()})
+    inter = {}
+    ref64 = O.pamnet_forward(p64, cfg, b.x.double(), b.batch, dtype=torch.float64, intermediates=inter)
+    torch.nn.functional.l1_loss(ref64, b.y.double()).backward()
+    gc = model._graph_cache
+    assert gc.glob.m == inter['edge_index_g'].size(1) and gc.loc.m == inter['edge_index_l'].size(1)
+    assert gc.n_trip == inter['idx_kj'].numel() and gc.n_pair == inter['idx_jj_pair'].numel()
+    ok, info = _ok(out.detach().cpu().numpy(), ref32.numpy(), ref64.detach().numpy())
+    assert ok, ('out', info)
+    ok, info_x = _ok(torch.stack(list(model._x_layers)).detach().cpu().numpy(),
+                     inter['x_layers'].detach().float().numpy(), inter['x_layers'].detach().numpy())
+    assert ok, ('x_layers', info_x)
+    rep = {}
+    _check_gradients(model, p64, O.pamnet_forward, sd, cfg, b, rep)
+    print('RNA B=8 d16 L1 vs oracle: out %.2e (ref fp32 %.2e), x_layers %.2e, worst grad %.2e (ref fp32 %.2e, %s)'
+          % (info + (info_x[0],) + rep['grad_worst']))
+
+
+@pytest.mark.gpu
+def test_baseline_pdbbind_b32_vs_oracle_by_shard(dev):
+    """BASELINE configs[3] (PDBbind schema, dim=128, n_layer=3, 32 complexes, ~19 k nodes, ~0.7 M global edges): the
+    full batch on the GPU against the CPU oracle evaluated shard by shard (4 x 8 complexes: complexes are independent
+    units, and an 8-complex shard is what the oracle finishes in seconds).  Outputs are reported both relative to the
+    per-complex summed |node_out| (complex - pocket - ligand cancels ~1000x) and raw."""
+    import models
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import synth
+    _oracle_threads()
+    cfg = models.Config(dataset='PDBbind', dim=128, n_layer=3, cutoff_l=2.0, cutoff_g=6.0)
+    graphs = [synth.pdbbind_complex(1, i) for i in range(32)]
+    sd = O.init_state_dict(cfg, seed=3)
+    model = models.PAMNet(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    with torch.no_grad():
+        out = model(synth.collate(graphs).to(dev)).cpu().numpy()
+        node_out = model._node_out.cpu().numpy()
+    p64 = {k: v.double() for k, v in sd.items()}
+    worst = (0.0, 0.0)
+    raw = (0.0, 0.0)
+    n0 = 0
+    for s in range(4):
+        b = synth.collate(graphs[8 * s:8 * s + 8])
+        with torch.no_grad():
+            inter = {}
+            r64 = O.pamnet_forward(p64, cfg, b.x.double(), b.batch, dtype=torch.float64, intermediates=inter).numpy()
+            r32 = O.pamnet_forward(sd, cfg, b.x, b.batch).numpy()
+        n = b.x.size(0)
+        ok, info = _ok(node_out[n0:n0 + n], inter['node_out'].float().numpy(), inter['node_out'].numpy())
+        assert ok, ('node_out shard %d' % s, info)
+        pin = inter['pool_in'].abs()
+        scale = max(float(pin[b.batch == g].sum()) for g in range(8))
+        ok, info = _ok(out[8 * s:8 * s + 8], r32, r64, scale)
+        assert ok, ('out shard %d' % s, info)
+        worst = max(worst, info)
+        raw = max(raw, (maxnorm_err(out[8 * s:8 * s + 8], r64), maxnorm_err(r32, r64)))
+        n0 += n
+    assert raw[0] <= max(TOL, 2 * raw[1]), raw
+    print('PDBbind B=32 d128 L3 vs oracle (4 shards): err/sum|node_out| %.2e (ref fp32 %.2e); raw max|d|/max|out| %.2e '
+          '(ref fp32 %.2e)' % (worst + raw))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', ['pdbbind_d128_l3', 'qm9s_d128_l2', 'qm9_d128_l6_b16', 'qm9_ragged_d128_l2',
                                   'qm9s_ragged_d128_l2', 'qm9_no_edges_d128_l2', 'qm9_d128_l1',
@@ -346,22 +508,7 @@ def test_fused_engine_fresh_inputs_vs_oracle(dev, case):
     ok, info = _ok(torch.stack(list(model._x_layers)).detach().cpu().numpy(), inter['x_layers'].detach().float().numpy(),
                    inter['x_layers'].detach().numpy())
     assert ok, ('x_layers', info)
-    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
-    gn64 = float(torch.sqrt(sum((p.grad ** 2).sum() for p in p64.values() if p.grad is not None)))
-    assert abs(gn / gn64 - 1) < 2e-4, (gn, gn64)
-    worst, worst_scalar = 0.0, 0.0
-    for k, p in model.named_parameters():
-        if p64[k].grad is None:
-            continue
-        e = maxnorm_err(p.grad.cpu().numpy(), p64[k].grad.numpy())
-        if p.numel() == 1:
-            # W_out.bias: d loss / d b = sum over nodes of signed pooling weights (PDBbind: complex - pocket - ligand)
-            # -> cancellation; the fp32 oracle itself is 3.6e-4 off here and torch's own fp32 backward 1.4e-3
-            worst_scalar = max(worst_scalar, e)
-        else:
-            worst = max(worst, e)
-    assert worst < 5e-4, worst            # fp32 backward through 2L layers vs fp64 autograd of the reference maths
-    assert worst_scalar < 5e-3, worst_scalar
+    _check_gradients(model, p64, fwd, sd, cfg, b)
 
 
 @pytest.mark.gpu
@@ -418,3 +565,30 @@ def test_large_batch_equals_its_shards(dev):
     for k, p in model.named_parameters():
         if k in g_big:
             assert maxnorm_err(p.grad.cpu().numpy(), g_big[k].cpu().numpy()) < 2e-5, k
+
+
+@pytest.mark.gpu
+def test_out_of_range_inputs_raise_index_error(dev):
+    """Atom types beyond the embedding table, bond endpoints beyond the node count or graph ids beyond num_graphs raise
+    IndexError (as indexing does in the reference, models.py:107) instead of writing out of bounds on the device."""
+    import copy
+    import models
+    from pamnet_amd import synth
+    model = models.PAMNet(models.Config(dataset='QM9', dim=32, n_layer=1, cutoff_l=5.0, cutoff_g=5.0)).to(dev)
+    good = synth.qm9_batch(3, 0, 4).to(dev)
+    with torch.no_grad():
+        ref = model(good)
+        for field, mutate in (('x', lambda t: torch.cat([t[:-1], t.new_tensor([7.0])])),
+                              ('edge_index', lambda t: torch.cat([t[:, :-1], t.new_tensor([[0], [10 ** 6]])], 1)),
+                              ('batch', lambda t: torch.cat([t[:-1], t.new_tensor([9])]))):
+            bad = copy.copy(good)
+            setattr(bad, field, mutate(getattr(good, field)))
+            with pytest.raises(IndexError):
+                model(bad)
+        assert torch.equal(model(good), ref)                  # the model is still usable afterwards
+    rna = models.PAMNet(models.Config(dataset='rna_x', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0)).to(dev)
+    b = synth.rna_batch(3, 0, 1, n_nodes=120).to(dev)
+    b.x = b.x.clone()
+    b.x[5, -1] = 3.0                                           # three atom types: 0, 1, 2
+    with pytest.raises(IndexError), torch.no_grad():
+        rna(b)

@@ -30,6 +30,9 @@ class Tiny(nn.Module):
         return torch.zeros(data.num_graphs, dtype=h.dtype).index_add_(0, data.batch, h)
 
 
+from standin import LayeredStandIn as Layered  # noqa: E402  (PAMNet-named CPU stand-in, tests/standin.py)
+
+
 class D(object):
     pass
 
@@ -54,13 +57,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, total, out):
+def _worker(rank, world, port, total, out, kind):
     from pamnet_amd.train import Trainer, shard_range
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    torch.manual_seed(0)
-    model = Tiny()
-    tr = Trainer(model, lr=1e-2, world_size=world)
+    torch.manual_seed(rank)                      # DIFFERENT seeds: the trainer must broadcast rank 0's parameters
+    model = Tiny() if kind == 'tiny' else Layered()
+    tr = Trainer(model, lr=1e-2, world_size=world, n_buckets=3)
+    if kind == 'layered':
+        assert tr._buckets is not None and len(tr._buckets) >= 1      # bucketed path (sequential on CPU, same tiling)
     lo, hi = shard_range(total, rank, world)
     for step in range(3):
         tr.step(_batch(lo, hi), global_graphs=total)
@@ -74,21 +79,79 @@ def _worker(rank, world, port, total, out):
     dist.destroy_process_group()
 
 
-def test_dp_world2_matches_single_process(tmp_path):
+@pytest.mark.parametrize('kind,world,total', [('tiny', 2, 13), ('layered', 2, 13), ('layered', 3, 16)])
+def test_dp_matches_single_process(tmp_path, kind, world, total):
+    """world_size 2 / 3, uneven shards (7+6, 6+5+5): shard -> pre-scale by local/global graphs -> (bucketed) all-reduce of
+    the flat gradient -> identical update == the single-process global-batch step."""
     from pamnet_amd.train import Trainer, shard_range
-    total = 13                                   # uneven shards: 7 + 6
-    assert [shard_range(total, r, 2) for r in range(2)] == [(0, 7), (7, 13)]
+    shards = [shard_range(total, r, world) for r in range(world)]
+    assert shards[0][0] == 0 and shards[-1][1] == total and all(a[1] == b[0] for a, b in zip(shards, shards[1:]))
+    assert len({hi - lo for lo, hi in shards}) == 2                       # really uneven
     out = str(tmp_path / 'dp.pt')
-    mp.spawn(_worker, args=(2, _free_port(), total, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), total, out, kind), nprocs=world, join=True)
     got = torch.load(out)
     torch.manual_seed(0)
-    model = Tiny()
+    model = Tiny() if kind == 'tiny' else Layered()
     tr = Trainer(model, lr=1e-2, world_size=1)
     for step in range(3):
         tr.step(_batch(0, total))
     assert torch.allclose(got['flat'], tr.fp.flat, rtol=1e-5, atol=1e-6)
     assert torch.allclose(got['shadow'], tr.shadow, rtol=1e-5, atol=1e-6)
     assert abs(got['mae'] - tr.evaluate([_batch(0, total)])) < 1e-5
+
+
+def test_flat_layout_and_bucket_tiling():
+    """FlatParams on PAMNet-named parameters: backward-completion order (layer pair L-1 first, top level last),
+    contiguous layer_ranges, and plan_buckets tiling [0, numel) exactly for every bucket count."""
+    from pamnet_amd.train import FlatParams, plan_buckets
+    L = 5
+    fp = FlatParams(Layered(n_layer=L))
+    assert fp.names[0].startswith('global_layer.%d.' % (L - 1))
+    assert not any(n.startswith(('global_layer.', 'local_layer.')) for n in fp.names[-4:])
+    assert {n.split('.')[0] for n in fp.names[-4:]} == {'embeddings', 'rbf_g', 'mlp_rbf_g'}
+    pos = 0
+    for k in range(L - 1, -1, -1):                          # pairs laid out back to front, no gaps, global+local adjacent
+        lo, hi = fp.layer_ranges[k]
+        assert lo == pos and hi > lo
+        pos = hi
+        names_k = [n for n in fp.names if lo <= fp.offsets[n] < hi]
+        assert {n.split('.')[1] for n in names_k} == {str(k)}
+        assert {n.split('.')[0] for n in names_k} == {'global_layer', 'local_layer'}
+    for nb in (1, 2, 3, 4, 5, 8):
+        buckets, tail = plan_buckets(fp.layer_ranges, fp.grad.numel(), nb)
+        cover = [(lo, hi) for lo, hi, _ in buckets] + [tail]
+        assert cover[0][0] == 0 and cover[-1][1] == fp.grad.numel()
+        assert all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+        ks = [k for _, _, k in buckets]
+        assert ks == sorted(ks, reverse=True) and len(buckets) <= max(0, min(nb, L) - 1) + (0 if nb >= L else 0) + nb
+        for lo, hi, k in buckets:                           # a slice is complete once its lowest layer pair is done
+            assert lo == fp.layer_ranges[max(kk for kk in range(L) if fp.layer_ranges[kk][0] >= lo and
+                                             fp.layer_ranges[kk][1] <= hi)][0]
+            assert hi == fp.layer_ranges[k][1]
+    assert plan_buckets({0: (0, 4), 2: (4, 8)}, 8, 2) is None
+
+
+def test_node_balanced_sharding_on_shipped_rna_sizes(golden):
+    """RNA / PDBbind graphs are sharded by number of nodes, not by count.  On the node counts of the 21
+    shipped RNA-Puzzles native structures (841 .. 3 823 nodes) the greedy longest-first packing stays within a few
+    percent of the ideal load, where equal-count contiguous shards are off by up to ~40 %."""
+    from pamnet_amd.train import balanced_shards, shard_range
+    sizes = [int(v) for v in golden('rna_native')['all_num_nodes']]
+    assert len(sizes) == 21 and min(sizes) == 841 and max(sizes) == 3823
+    for world in (2, 3, 4, 8):
+        shards = balanced_shards(sizes, world)
+        assert sorted(i for s in shards for i in s) == list(range(21))           # a partition
+        assert shards == balanced_shards(sizes, world)                           # deterministic
+        loads = [sum(sizes[i] for i in s) for s in shards]
+        ideal = sum(sizes) / world
+        eq = []
+        for r in range(world):
+            lo, hi = shard_range(21, r, world)
+            eq.append(sum(sizes[lo:hi]))
+        assert max(loads) <= 1.12 * ideal, (world, loads)
+        assert max(loads) <= max(eq)
+    assert max(sum(sizes[i] for i in s) for s in balanced_shards(sizes, 4)) < 1.06 * sum(sizes) / 4
+    assert balanced_shards([5, 5, 5], 4)[3] == []                                # more ranks than graphs
 
 
 def test_trainer_step_semantics():
@@ -128,20 +191,26 @@ def test_direct_gradient_path_equals_autograd():
     cfg = models.Config(dataset='QM9', dim=128, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
     model = models.PAMNet(cfg).to(dev)
     b = synth.qm9_batch(2, 0, 8).to(dev)
-    fused.DIRECT_GRAD = False
-    torch.nn.functional.l1_loss(model(b), b.y).backward()
+    torch.nn.functional.l1_loss(model(b), b.y).backward()              # plain autograd: no parameter allows direct writes
     ref = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
-    fp = FlatParams(model)
-    try:
-        fused.DIRECT_GRAD = True
-        fp.zero_grad()
-        torch.nn.functional.l1_loss(model(b), b.y).backward()
-        for k, p in model.named_parameters():
-            if k in ref:
-                assert torch.equal(p.grad, ref[k]), k
-        assert float(fp.grad.abs().sum()) > 0
-    finally:
-        fused.DIRECT_GRAD = False
+    fp = FlatParams(model, direct=True)                                 # the permission is a property of THESE parameters
+    assert all(getattr(p, '_pamnet_direct', False) for p in model.parameters())
+    fp.zero_grad()
+    torch.nn.functional.l1_loss(model(b), b.y).backward()
+    for k, p in model.named_parameters():
+        if k in ref:
+            assert torch.equal(p.grad, ref[k]), k
+    assert float(fp.grad.abs().sum()) > 0
+    # a second model in the same process is unaffected (nothing process-global)
+    other = models.PAMNet(cfg).to(dev)
+    torch.nn.functional.l1_loss(other(b), b.y).backward()
+    assert all(not getattr(p, '_pamnet_direct', False) and p.grad is not None for p in other.parameters())
+    fp.set_direct(False)
+    fp.zero_grad()
+    torch.nn.functional.l1_loss(model(b), b.y).backward()              # accumulated by autograd into the zeroed views
+    for k, p in model.named_parameters():
+        if k in ref:
+            assert torch.equal(p.grad, ref[k]), k
 
 
 @pytest.mark.gpu
@@ -173,11 +242,11 @@ def test_bucketed_overlapped_allreduce_single_rank_rccl():
             torch.cuda.synchronize()
             return tr, tr.fp.flat.clone()
 
-        fused.LAYER_EVENTS = None
         tr0, plain = run(False)
         assert tr0._buckets is None
         tr1, over = run('force')
-        assert tr1._buckets is not None and fused.EVENTS_RECORDED
+        assert tr1._buckets is not None and tr1._stack_ctx.recorded
+        assert tr0._stack_ctx is None                                      # per-model context: the plain trainer has none
         assert torch.equal(plain, over)
         # buckets: contiguous from offset 0, last layers first; the tail slice reaches the end of the buffer
         edges = [0]
@@ -189,7 +258,6 @@ def test_bucketed_overlapped_allreduce_single_rank_rccl():
         names = tr1.fp.names
         assert names[0].startswith('global_layer.3.') and names[-1].split('.')[0] not in ('global_layer', 'local_layer')
     finally:
-        fused.LAYER_EVENTS = None
         if created:
             dist.destroy_process_group()
 
@@ -230,3 +298,22 @@ def test_native_optimizer_kernel_matches_torch_adam():
         tr.step(batches[0])
         outs.append(tr.fp.flat.clone())
     assert torch.allclose(outs[0], outs[1], rtol=1e-6, atol=1e-6)
+
+
+def test_bench_world2_dry_run_on_cpu():
+    """bench.py's world > 1 branch (shard_range per rank, barrier, max-over-ranks timing, one JSON line from rank 0, process
+    group teardown) executed under torch.distributed.run with 2 gloo ranks on the CPU stand-in.  Not a measurement."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--batch-per-gpu', '8', '--n-layer', '3', '--cpu-dry-run']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout                                   # ONE JSON line, from rank 0 only
+    j = json.loads(lines[0])
+    assert j['dry_run'] is True and j['n_gpus'] == 2 and j['steps'] == 3 and j['config']['global_batch'] == 16
+    assert j['scaling'] == 'weak' and j['value'] > 0 and abs(j['value'] - 16 * 3 / (j['ms_per_step'] * 3e-3)) < 1e-6 * j['value']
