@@ -1,0 +1,30 @@
+# HBM traffic of the scatter-add roofline kernel (bench.py `roofline.traffic`): separate --pmc passes with --kernel-trace
+# only (MI355X_MICROARCH.md HBM section: TCC_EA0_RDREQ-style sizes are unreliable on gfx950; FETCH_SIZE is in 32-byte
+# units per 64-byte request -> x2 correction, WRITE_SIZE in 64-byte units as documented there).  Writes
+# profiles/r02_scatter_add_pmc.json (copy it from gpurun_out/ into profiles/ and commit).
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/tools/scatter_probe.py > /tmp/pmc_$c.log 2>&1
+done
+python - <<'PY' > $R/gpurun_out/r02_scatter_add_pmc.json
+import csv, glob, json
+def counter(name):
+    f = glob.glob('/tmp/pmc_%s/**/*counter_collection.csv' % name, recursive=True)[0]
+    vals = [float(r['Counter_Value']) for r in csv.DictReader(open(f))
+            if 'segment_sum_kernel' in r['Kernel_Name'] and r['Counter_Name'] == name]
+    return sum(vals) / len(vals), len(vals)
+fetch, n1 = counter('FETCH_SIZE')
+write, n2 = counter('WRITE_SIZE')
+# FETCH_SIZE / WRITE_SIZE are reported in kilobytes; on gfx950 FETCH_SIZE tallies wide coalesced 16 B/lane streaming reads at
+# half their size (MI355X_MICROARCH.md, HBM section): traffic = 2 * FETCH + WRITE
+import re
+alg = float(re.search(r'algorithmic bytes (\d+)', open('/tmp/pmc_FETCH_SIZE.log').read()).group(1))
+traffic = (2.0 * fetch + write) * 1024.0
+print(json.dumps({'kernel': 'segment_sum_kernel', 'FETCH_SIZE_KB': fetch, 'WRITE_SIZE_KB': write, 'launches': [n1, n2],
+                  'traffic_bytes_per_launch': traffic, 'algorithmic_bytes_per_launch': alg,
+                  'traffic_over_algorithmic': traffic / alg,
+                  'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python tools/scatter_probe.py; traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction)'}))
+PY
+cat $R/gpurun_out/r02_scatter_add_pmc.json
