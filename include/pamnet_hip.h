@@ -198,7 +198,8 @@ int pamnet_node_tail_main_bwd_f32(const float* d_xout, const float* g_head, int6
 int pamnet_node_pre_tail_bwd_f32(const float* dP, const float* dx1_direct, const float* d_add, int64_t n,
                                  const float* Wx1, const float* const* wp, int64_t nblk, const float* Zx1, float* dZx1,
                                  const float* g_head, const float* const* weights, const float* Z, float* dZ,
-                                 float* d_x2, float* d_resx, pamnet_stream_t stream);
+                                 float* d_x2, float* d_resx, const void* rider /* host, nullable */,
+                                 pamnet_stream_t stream);
 /* Fragment-ordered weight images for the node chains: n (<= 192) 128x128 matrices (row stride ld[i]) -> images[i*16384..],
  * transposed = 0 for the forward (Y = X W^T), 1 for the backward (Y = X W).  With packed != 0 the `weights` (and, in the
  * forward, next_Wx1 / next_wp) arguments of node_tail_fwd / node_tail_bwd, and Wx1 / wp of node_pre_bwd (transposed
@@ -227,6 +228,19 @@ int pamnet_wgrad_deferred_f32(int64_t njobs, const float* const* dZ, const int64
                               int64_t head_blocks, float* d_wout, float* d_watt, float* d_bout, void* ctx /* host */,
                               pamnet_stream_t stream);
 int pamnet_wgrad_flush_f32(void* ctx /* host */, pamnet_stream_t stream);
+/* Riders: weight-gradient slots as extra workgroups of a node-chain backward launch (the chain owns ceil(n/16) workgroups,
+ * 143 of the 256 CUs at the QM9 batch; the riders take the idle CUs and the layer's own weight-gradient launch shrinks).
+ *   pamnet_wgrad_rider_plan_f32   : lay a batch (<= 12 jobs) out over <= max_slots slots; the plan goes to `rider`
+ *                                   (caller-owned HOST memory of pamnet_wgrad_rider_bytes bytes); *slots_out = slots used
+ *   pamnet_node_pre_tail_bwd_f32  : takes the plan (`rider` argument) and appends the slots to its grid
+ *   pamnet_wgrad_rider_enqueue_f32: registers the batch with a deferred context so that the next pamnet_wgrad_deferred_f32
+ *                                   launch (or the flush) reduces its slots in the usual fixed order. */
+int pamnet_wgrad_rider_bytes(int64_t* bytes);
+int pamnet_wgrad_rider_plan_f32(int64_t njobs, const float* const* dZ, const int64_t* ld_dz, const float* const* A,
+                                const int64_t* ld_a, const int32_t* a_mode, const int64_t* rows, float* const* dW,
+                                const int64_t* ld_dw, float* const* db, float* partial, int64_t max_slots,
+                                void* rider /* host */, int64_t* slots_out);
+int pamnet_wgrad_rider_enqueue_f32(void* ctx /* host */, const void* rider /* host */);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Fused edge-level kernels (dim = 128), fp32 MFMA.  P planes are node_pre outputs ([N][128] each).

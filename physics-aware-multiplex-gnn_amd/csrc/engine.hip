@@ -90,6 +90,7 @@ struct Temp {
     float *dzji, *dzkj, *dq2, *dmt, *dq3, *dmnb, *ds, *dz1, *dz2;      // backward (local)
     float *partial, *partial2;   // split-K scratch of two consecutive weight-gradient batches (the reduction of one runs
                                  // inside the launch of the next)
+    float* rider_partial;        // split-K scratch of the rider batch (10 node-level jobs in a node-chain launch)
 };
 
 constexpr int WJOBS = 24;
@@ -102,13 +103,20 @@ inline int64_t wgrad_floats(const Graph& g) {
     return (glob > loc ? glob : loc) * (D * D + 2 * D);
 }
 
+// the 10 tail jobs of a chain riding in the next chain launch (256-row slots)
+inline int64_t rider_floats(const Graph& g) {
+    int64_t s = (g.n + 255) / 256;
+    s = s < 1 ? 1 : (s > 256 ? 256 : s);
+    return 10 * s * (D * D + 2 * D);
+}
+
 inline int64_t temp_floats(const Graph& g) {
     const int64_t nd = al(g.n * D), gd = al(g.eg * D), ld = al(g.el * D), td = al(g.tp * D);
     int64_t t = 0;
     t += nd + 4 * nd + gd + ld;                                        // x1 P msg mji
     t += 10 * nd + 7 * nd + nd + nd + al(((g.n + 15) / 16) * 257) + gd + gd + 4 * nd + nd + nd + nd;
     t += 6 * ld + 3 * td;
-    t += 2 * wgrad_floats(g);
+    t += 2 * wgrad_floats(g) + rider_floats(g);
     return t;
 }
 
@@ -141,7 +149,8 @@ inline Temp carve_temp(float* p, const Graph& g) {
     t.dz1 = p; p += td;
     t.dz2 = p; p += td;
     t.partial = p; p += wgrad_floats(g);
-    t.partial2 = p;
+    t.partial2 = p; p += wgrad_floats(g);
+    t.rider_partial = p;
     return t;
 }
 
@@ -198,6 +207,18 @@ struct Jobs {
         ++n;
     }
 };
+
+// Riders: with packed weights the 10 tail jobs of a chain do not go into its layer's weight-gradient launch but ride as
+// extra workgroups of the NEXT node-chain launch (which leaves 256 - ceil(n/16) CUs idle); the layer's own launch keeps
+// the jobs whose operands that next launch overwrites (dZx1, dP) and the edge-level ones.
+constexpr int RIDER_MAX_SLOTS = 256;
+inline int plan_rider(Jobs& j, float* partial, const Graph& g, void* rider, int64_t* slots) {
+    const int64_t room = RIDER_MAX_SLOTS - (g.n + 15) / 16;   // idle CUs of the chain launch (riders_fit: >= 80)
+    return pamnet_wgrad_rider_plan_f32(j.n, j.dZ, j.ld_dz, j.A, j.ld_a, j.mode, j.rows, j.dW, j.ld_dw, j.db, partial, room,
+                                       rider, slots);
+}
+// riders pay when the chain leaves enough CUs idle for slots of a few hundred rows: ceil(n/16) <= 176 workgroups
+inline bool riders_fit(const Graph& g) { return (g.n + 15) / 16 <= RIDER_MAX_SLOTS - 80; }
 
 inline void tail_jobs(Jobs& j, const Graph& g, const float* dZ, const float* hdz, const float* x2, const float* Z,
                       const float* R, const float* xout, float* const* gt /* tail block of the gradient table */) {
@@ -470,9 +491,11 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
     // previous chain's weight-gradient launch (which also needs that launch's dZx1) has consumed its own.
     const bool fuse = packed;
     // weight-gradient batches: the fixed-order reduction of each batch rides in the next batch's launch
-    int64_t ctx_bytes = 0;
+    int64_t ctx_bytes = 0, rider_bytes = 0;
     CK(pamnet_wgrad_ctx_bytes(&ctx_bytes));
-    std::vector<char> wctx((size_t)ctx_bytes, 0);
+    CK(pamnet_wgrad_rider_bytes(&rider_bytes));
+    std::vector<char> wctx((size_t)ctx_bytes, 0), rider((size_t)rider_bytes, 0);
+    const bool ride = fuse && riders_fit(g);
     float* parts[2] = {t.partial, t.partial2};
     int pflip = 0;
     const float* d_xout = nullptr;        // nothing consumes the last layer's node features (models.py:196-224)
@@ -518,8 +541,14 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 // head of the local layer + the global chain of this pair
                 zflip ^= 1;
                 dz_global = dz_bufs[zflip];
+                if (ride) {                                   // this layer's chain gradients ride in the launch below
+                    Jobs jr;
+                    tail_jobs(jr, g, dz_local, q.hdz, q.x2, q.Z, q.R, q.xout, lg + LT);
+                    CK(plan_rider(jr, t.rider_partial, g, rider.data(), nullptr));
+                }
                 CK(pamnet_node_pre_tail_bwd_f32(t.dP, t.dx2, t.dresx, g.n, img[k].lh[4], img[k].lh, 4, q.Zx1, t.dZx1, s.gh,
-                                                img[k].gt, s.Z, dz_global, t.dx2, t.dresx, st));
+                                                img[k].gt, s.Z, dz_global, t.dx2, t.dresx, ride ? rider.data() : nullptr, st));
+                if (ride) CK(pamnet_wgrad_rider_enqueue_f32(wctx.data(), rider.data()));
             } else {
                 const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
                 float* dx = dx_bufs[flip];
@@ -528,7 +557,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 flip ^= 1;
             }
             Jobs j;
-            tail_jobs(j, g, dz_local, q.hdz, q.x2, q.Z, q.R, q.xout, lg + LT);
+            if (!ride) tail_jobs(j, g, dz_local, q.hdz, q.x2, q.Z, q.R, q.xout, lg + LT);
             j.add(t.dZx1, x_in, 0, g.n, lg[0], D, lg[1]);
             j.add(t.dP, q.Zx1, 1, g.n, lg[2], 3 * D, nullptr);
             j.add(t.dP + pl, q.Zx1, 1, g.n, lg[4], 3 * D, nullptr);
@@ -566,8 +595,15 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 const LocalSaved qp = carve_local(const_cast<float*>(saved) + (k - 1) * (gs + ls) + gs, g);
                 zflip ^= 1;
                 dz_local = dz_bufs[zflip];
+                if (ride) {
+                    Jobs jr;
+                    tail_jobs(jr, g, dz_global, s.hdz, s.x2, s.Z, s.R, s.xout, gg + GT);
+                    CK(plan_rider(jr, t.rider_partial, g, rider.data(), nullptr));
+                }
                 CK(pamnet_node_pre_tail_bwd_f32(t.dP, t.dx2, t.dresx, g.n, img[k].gh[2], img[k].gh, 2, s.Zx1, t.dZx1, qp.gh,
-                                                img[k - 1].lt, qp.Z, dz_local, t.dx2, t.dresx, st));
+                                                img[k - 1].lt, qp.Z, dz_local, t.dx2, t.dresx, ride ? rider.data() : nullptr,
+                                                st));
+                if (ride) CK(pamnet_wgrad_rider_enqueue_f32(wctx.data(), rider.data()));
             } else {
                 const float* wpg[2] = {gp[2], gp[2] + D};
                 float* dx = (k == 0) ? d_x0 : dx_bufs[flip];
@@ -577,7 +613,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 flip ^= 1;
             }
             Jobs j;
-            tail_jobs(j, g, dz_global, s.hdz, s.x2, s.Z, s.R, s.xout, gg + GT);
+            if (!(ride && k > 0)) tail_jobs(j, g, dz_global, s.hdz, s.x2, s.Z, s.R, s.xout, gg + GT);
             j.add(t.dZx1, x_in, 0, g.n, gg[0], D, gg[1]);
             j.add(t.dP, s.Zx1, 1, g.n, gg[2], 3 * D, nullptr);
             j.add(t.dP + pl, s.Zx1, 1, g.n, gg[2] + D, 3 * D, nullptr);

@@ -21,6 +21,7 @@
 // waves per SIMD overlap loads, MFMAs and epilogue (27 us vs 29 us); its z_k are fetched before the MFMAs start.
 #include "common.h"
 #include "gemm_core.h"
+#include "wgrad_core.h"
 
 using namespace pamnet;
 
@@ -409,12 +410,29 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
                                                             const float* __restrict__ Z, float* __restrict__ dZ,
                                                             float* __restrict__ d_x2, float* __restrict__ d_resx,
                                                             float* __restrict__ head_partial /* [grid][257] */,
-                                                            PreBwd pb = PreBwd{}) {
+                                                            PreBwd pb = PreBwd{}, WBatchS rider = WBatchS{},
+                                                            float* __restrict__ rider_partial = nullptr, int n_tiles = 0) {
     static_assert(!PRE || (PACKED && !HEADS), "the fused head backward needs packed weights and deferred heads");
     // All ten pre-activation tiles are fetched up front (one burst of coalesced rows) and every dz_k overwrites its z_k
     // in place; d x2 / d res_x are parked too and the tiles leave as coalesced rows after the chain: like the forward,
     // the per-layer critical path holds no global access except the next weight slice.
     __shared__ __attribute__((aligned(16))) float lds[14 * SLOT + 16 * 256 + 16];
+    if constexpr (PRE) {
+        // Riders: the chain owns ceil(n/16) workgroups (143 of 256 CUs at the QM9 batch); the workgroups behind them are
+        // split-K slots of the PREVIOUS chain's weight gradients (its dZ planes and saved activations are final), one per
+        // otherwise idle CU -- the weight-gradient launch of that layer shrinks by what rides here.
+        static_assert(sizeof(lds) >= sizeof(float) * WGRAD_LDS_FLOATS, "rider staging must fit the chain's LDS");
+        if ((int)blockIdx.x >= n_tiles) {
+#ifdef PAMNET_RIDER_8W
+            wgrad_body<8>(rider, rider_partial, (int)blockIdx.x - n_tiles, lds);
+#else
+            // four of the eight waves, one per SIMD, each with the 64x64 wave tile of the stand-alone kernel (the other
+            // four leave: a terminated wave no longer takes part in the workgroup barrier)
+            if (threadIdx.x < 256) wgrad_body<4>(rider, rider_partial, (int)blockIdx.x - n_tiles, lds);
+#endif
+            return;
+        }
+    }
     float* D0 = lds;                  // dz ping
     float* D1 = lds + SLOT;           // dz pong
     float* K = lds + 2 * SLOT;        // residual gradient kept across a Res block
@@ -921,7 +939,7 @@ extern "C" int pamnet_node_pre_tail_bwd_f32(const float* dP, const float* dx1_di
                                             const float* Wx1, const float* const* wp, int64_t nblk, const float* Zx1,
                                             float* dZx1, const float* g_head, const float* const* weights,
                                             const float* Z, float* dZ, float* d_x2, float* d_resx,
-                                            pamnet_stream_t stream) {
+                                            const void* rider, pamnet_stream_t stream) {
     if (n < 0 || nblk < 1 || nblk > 4) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
     if (!dP || !dx1_direct || !d_add || !Wx1 || !wp || !Zx1 || !dZx1 || !g_head || !weights || !Z || !dZ || !d_x2 || !d_resx)
@@ -939,9 +957,17 @@ extern "C" int pamnet_node_pre_tail_bwd_f32(const float* dP, const float* dx1_di
         tp.W[k] = weights[k];
     }
     tp.packed = 1;
-    hipLaunchKernelGGL((node_tail_bwd_kernel<true, false, true>), dim3((unsigned)ceil_div(n, BMN)), dim3(TWG), 0,
+    const int n_tiles = (int)ceil_div(n, BMN);
+    WBatchS rb{};
+    float* rpart = nullptr;
+    int rslots = 0;
+    if (rider) {                                              // planned by pamnet_wgrad_rider_plan_f32
+        const WgradRider* r = static_cast<const WgradRider*>(rider);
+        rb = r->batch, rpart = r->partial, rslots = r->slots;
+    }
+    hipLaunchKernelGGL((node_tail_bwd_kernel<true, false, true>), dim3((unsigned)(n_tiles + rslots)), dim3(TWG), 0,
                        as_stream(stream), (const float*)nullptr, g_head, (const float*)nullptr, n, tp, Z, dZ, d_x2, d_resx,
-                       (float*)nullptr, pb);
+                       (float*)nullptr, pb, rb, rpart, n_tiles);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

@@ -29,27 +29,12 @@ extern "C" int pamnet_wgrad_probe_read(long long* host64) {
 #define WPROBE(i)
 #endif
 
+#include "wgrad_core.h"
+
 namespace {
 
-constexpr int MAXJ = 24;
-constexpr int RB = 64;            // rows staged per step (2 x 36 KB LDS: 64 rows of dZ and A in flight per fetch)
-constexpr int LDW = 144;          // LDS leading dim: 144 mod 32 = 16 -> conflict-free ds_read_b32 fragment reads
 constexpr int ROWS_PER_WG = 256;
 constexpr int MAX_SLOTS_PER_JOB = 256;
-
-struct WJob {
-    const float* dZ;
-    const float* A;
-    float* dW;
-    float* db;        // may be null
-    int64_t rows;
-    int ld_dz, ld_a, ld_dw, a_mode;
-};
-struct WBatch {
-    WJob job[MAXJ];
-    int start[MAXJ + 1];          // slot prefix: job j owns slots [start[j], start[j+1])
-    int njobs;
-};
 
 inline int job_slots(int64_t rows, int64_t chunk) {
     const int64_t want = (rows + chunk - 1) / chunk;
@@ -63,137 +48,18 @@ inline int target_slots() {
     static int t = [] { const char* e = getenv("PAMNET_WGRAD_SLOTS"); return e ? atoi(e) : 256; }();
     return t;
 }
-inline int64_t plan_chunk(int64_t njobs, const int64_t* rows) {
+inline int64_t plan_chunk(int64_t njobs, const int64_t* rows, int64_t max_slots) {
     int64_t chunk = ROWS_PER_WG;
     for (;; chunk += RB) {
         int64_t slots = 0;
         for (int64_t j = 0; j < njobs; ++j) slots += job_slots(rows[j], chunk);
-        if (slots <= target_slots() || chunk >= 16384) return chunk;
+        if (slots <= max_slots || chunk >= 16384) return chunk;
     }
-}
-
-__device__ __forceinline__ void wgrad_body(const WBatch& batch, float* __restrict__ partial, const int bid, float* lds) {
-    float* Zs = lds;
-    float* As = lds + RB * LDW;
-    int j = 0;
-    while (j + 1 < batch.njobs && bid >= batch.start[j + 1]) ++j;       // wave-uniform scalar search
-    const WJob jb = batch.job[j];
-    const int s = bid - batch.start[j];
-    const int js = batch.start[j + 1] - batch.start[j];
-    const int64_t chunk = ((jb.rows + js - 1) / js + RB - 1) / RB * RB;
-    const int64_t beg = (int64_t)s * chunk;
-    const int64_t end = beg + chunk < jb.rows ? beg + chunk : jb.rows;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int r16 = lane & 15, kg = lane >> 4;
-    const int i0 = (w >> 1) * 64, j0 = (w & 1) * 64;      // wave tile: dW rows (n) [i0, i0+64), cols (k) [j0, j0+64)
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // bias gradient: thread t = (column t & 127, row half t >> 7); fp32 inside a 16-row half block, fp64 across blocks
-    double colsum = 0.0;
-    const int bc = threadIdx.x & 127, bh = threadIdx.x >> 7;
-    const bool want_bias = jb.db != nullptr;
-
-    // register double buffer: the next 32-row block is in flight from L2/HBM while the MFMAs chew on the current one
-    const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;
-    float4 zr[RB / 8], ar[RB / 8];
-    auto fetch = [&](int64_t r0) {
-#pragma unroll
-        for (int i = 0; i < RB / 8; ++i) {
-            const int64_t g = r0 + rr + 8 * i;
-            const bool ok = g < end;
-            const int64_t gg = ok ? g : beg;                  // clamp instead of branching: loads stay unconditional
-            zr[i] = ldg4(jb.dZ, gg, jb.ld_dz, c4);
-            ar[i] = ldg4(jb.A, gg, jb.ld_a, c4);
-            if (!ok) { zr[i] = f4zero(); ar[i] = f4zero(); }
-        }
-    };
-    if (beg < end) fetch(beg);
-    int it = 0;
-    for (int64_t r0 = beg; r0 < end; r0 += RB, ++it) {
-        WPROBE(4 * it);
-#pragma unroll
-        for (int i = 0; i < RB / 8; ++i) {
-            const int r = rr + 8 * i;
-            float4 a = ar[i];
-            if (jb.a_mode == 1) a = f4silu(a);                 // SiLU(0) = 0 keeps the zero padding
-            *reinterpret_cast<float4*>(Zs + r * LDW + 4 * c4) = zr[i];
-            *reinterpret_cast<float4*>(As + r * LDW + 4 * c4) = a;
-        }
-        __syncthreads();
-        WPROBE(4 * it + 1);
-        if (r0 + RB < end) fetch(r0 + RB);
-        if (want_bias) {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-            for (int r = 0; r < RB / 2; r += 4) {
-                s0 += Zs[((RB / 2) * bh + r) * LDW + bc];
-                s1 += Zs[((RB / 2) * bh + r + 1) * LDW + bc];
-                s2 += Zs[((RB / 2) * bh + r + 2) * LDW + bc];
-                s3 += Zs[((RB / 2) * bh + r + 3) * LDW + bc];
-            }
-            colsum += (double)((s0 + s1) + (s2 + s3));
-        }
-        // operands of k-step st+1 are requested before the MFMAs of step st are issued (explicit register double
-        // buffer): left alone, the compiler issues each ds_read right before its s_waitcnt and the LDS latency shows up
-        // twice per k-step (12 400 instead of 8 192 cycles per 64-row block, tools/wgrad_probe.py)
-        float za[2][4], ab[2][4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            za[0][t] = Zs[kg * LDW + i0 + 16 * t + r16];
-            ab[0][t] = As[kg * LDW + j0 + 16 * t + r16];
-        }
-#pragma unroll
-        for (int st = 0; st < RB / 4; ++st) {
-            const int cur = st & 1, nxt = cur ^ 1;
-            if (st + 1 < RB / 4) {
-                const int r = 4 * (st + 1) + kg;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    za[nxt][t] = Zs[r * LDW + i0 + 16 * t + r16];
-                    ab[nxt][t] = As[r * LDW + j0 + 16 * t + r16];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);                 // keep the requests above this step's MFMAs
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[cur][a], ab[cur][b], acc[a][b], 0, 0, 0);
-        }
-        WPROBE(4 * it + 2);
-        __syncthreads();
-        WPROBE(4 * it + 3);
-    }
-    WPROBE(4 * it);
-    // partial[slot][128*128 + 2*128]: the tile, then the two row-half bias partials
-    // The accumulator layout (4 rows x 16 columns per store) would hit memory as 64-byte fragments; transpose through
-    // LDS (the staging buffers are free now: 128 x 132 floats fit) and write the tile as coalesced 512-byte rows.
-    float* out = partial + (int64_t)bid * (DIM * DIM + 2 * DIM);
-    float* T = lds;
-    static_assert(2 * RB * LDW >= DIM * LDT, "tile must fit in the staging buffers");
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                T[(i0 + 16 * a + kg * 4 + r) * LDT + j0 + 16 * b + r16] = acc[a][b][r];
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < DIM / 8; ++i) {
-        const int row = rr + 8 * i;
-        *reinterpret_cast<float4*>(out + row * DIM + 4 * c4) = *reinterpret_cast<const float4*>(T + row * LDT + 4 * c4);
-    }
-    out[DIM * DIM + threadIdx.x] = (float)colsum;
-    WPROBE(4 * it + 1);
 }
 
 __global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * RB * LDW];
-    wgrad_body(batch, partial, (int)blockIdx.x, lds);
+    __shared__ __attribute__((aligned(16))) float lds[WGRAD_LDS_FLOATS];
+    wgrad_body<4>(batch, partial, (int)blockIdx.x, lds);
 }
 
 // Second pass, ONE launch per batch (grid 258 x (njobs + 1)), every sum in a fixed order (deterministic):
@@ -208,7 +74,8 @@ struct HeadJob {
     float *d_wout, *d_watt, *d_bout;
 };
 
-__device__ __forceinline__ void finish_body(const WBatch& batch, const float* __restrict__ partial, const HeadJob& head,
+template <typename Batch>
+__device__ __forceinline__ void finish_body(const Batch& batch, const float* __restrict__ partial, const HeadJob& head,
                                             const int bx, const int by, float* lds) {
     float4(*red)[16] = reinterpret_cast<float4(*)[16]>(lds);                 // [16][16] float4 = 4 KB
     constexpr int64_t SLOT = DIM * DIM + 2 * DIM;
@@ -280,16 +147,39 @@ __global__ __launch_bounds__(WG) void wgrad_finish_kernel(WBatch batch, const fl
     finish_body(batch, partial, head, (int)blockIdx.x, (int)blockIdx.y, lds);
 }
 
-// One launch = the split-K pass of the current batch (blocks [0, cur slots)) + the fixed-order reduction of the
-// PREVIOUS batch (the remaining blocks, 258 per job): the reduction is ~16 MB of L2-resident reads that ran as a
-// launch of its own between two weight-gradient passes; here its small workgroups fill in beside the current pass.
+// One launch = the split-K pass of the current batch (blocks [0, cur slots)) + the fixed-order reductions of up to two
+// EARLIER batches (the remaining blocks, 258 per job): the previous layer's main batch (with the node chain's
+// head-vector partials) and its rider batch (the slots that ran as extra workgroups of a node-chain launch).  A reduction
+// is ~16 MB of L2-resident reads that ran as a launch of its own between two weight-gradient passes; here its small
+// workgroups fill in beside the current pass.  Compact batches (<= 12 jobs): the three descriptors share the 4 KB
+// kernel-argument block.
 constexpr int FIN_X = DIM * DIM / 64 + 2;
-__global__ __launch_bounds__(WG) void wgrad_fused_kernel(WBatch cur, float* __restrict__ cur_partial, WBatch prev,
-                                                         const float* __restrict__ prev_partial, HeadJob prev_head) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * RB * LDW];
+__global__ __launch_bounds__(WG) void wgrad_fused_kernel(WBatchS cur, float* __restrict__ cur_partial, WBatchS prev,
+                                                         const float* __restrict__ prev_partial, HeadJob prev_head,
+                                                         WBatchS prev2, const float* __restrict__ prev2_partial) {
+    __shared__ __attribute__((aligned(16))) float lds[WGRAD_LDS_FLOATS];
+    const int slots = cur.start[cur.njobs];
+    int fb = (int)blockIdx.x - slots;
+    if (fb < 0) {
+        wgrad_body<4>(cur, cur_partial, (int)blockIdx.x, lds);
+        return;
+    }
+    const int fin1 = prev_partial ? FIN_X * (prev.njobs + 1) : 0;
+    if (fb < fin1) {
+        finish_body(prev, prev_partial, prev_head, fb % FIN_X, fb / FIN_X, lds);
+    } else {
+        fb -= fin1;
+        finish_body(prev2, prev2_partial, HeadJob{nullptr, 0, nullptr, nullptr, nullptr}, fb % FIN_X, fb / FIN_X, lds);
+    }
+}
+
+// the same with one earlier batch and wide descriptors (up to 24 jobs each): no rider batch pending
+__global__ __launch_bounds__(WG) void wgrad_fused_wide_kernel(WBatch cur, float* __restrict__ cur_partial, WBatch prev,
+                                                              const float* __restrict__ prev_partial, HeadJob prev_head) {
+    __shared__ __attribute__((aligned(16))) float lds[WGRAD_LDS_FLOATS];
     const int slots = cur.start[cur.njobs];
     if ((int)blockIdx.x < slots) {
-        wgrad_body(cur, cur_partial, (int)blockIdx.x, lds);
+        wgrad_body<4>(cur, cur_partial, (int)blockIdx.x, lds);
     } else {
         const int fb = (int)blockIdx.x - slots;
         finish_body(prev, prev_partial, prev_head, fb % FIN_X, fb / FIN_X, lds);
@@ -308,25 +198,42 @@ extern "C" int pamnet_wgrad_scratch_floats(int64_t njobs, const int64_t* rows, i
 }
 
 namespace {
+// caller-owned host state of a sequence of deferred batches: up to two batches wait for their reduction
 struct WgradPending {
-    WBatch batch;
-    const float* partial;
+    WBatch batch[2];              // [0]: main batch (with head job), [1]: rider batch
+    const float* partial[2];
     HeadJob head;
-    int valid;
+    int valid[2];
 };
 
-inline int build_batch(WBatch& b, int64_t njobs, const float* const* dZ, const int64_t* ld_dz, const float* const* A,
+template <typename Batch>
+inline int build_batch(Batch& b, int64_t njobs, const float* const* dZ, const int64_t* ld_dz, const float* const* A,
                        const int64_t* ld_a, const int32_t* a_mode, const int64_t* rows, float* const* dW,
-                       const int64_t* ld_dw, float* const* db) {
+                       const int64_t* ld_dw, float* const* db, int64_t max_slots) {
     b.njobs = (int)njobs;
     b.start[0] = 0;
-    const int64_t chunk = plan_chunk(njobs, rows);
+    const int64_t chunk = plan_chunk(njobs, rows, max_slots);
     for (int j = 0; j < njobs; ++j) {
         if (!dZ[j] || !A[j] || !dW[j]) return PAMNET_ENULL;
         b.job[j] = WJob{dZ[j], A[j], dW[j], db[j], rows[j], (int)ld_dz[j], (int)ld_a[j], (int)ld_dw[j], a_mode[j]};
         b.start[j + 1] = b.start[j] + job_slots(rows[j], chunk);
     }
     return PAMNET_OK;
+}
+
+inline WBatchS compact(const WBatch& b) {                      // njobs <= MAXJ_S
+    WBatchS c;
+    c.njobs = b.njobs;
+    for (int j = 0; j < b.njobs; ++j) c.job[j] = b.job[j], c.start[j] = b.start[j];
+    c.start[b.njobs] = b.start[b.njobs];
+    return c;
+}
+inline WBatch widen(const WBatchS& b) {
+    WBatch c;
+    c.njobs = b.njobs;
+    for (int j = 0; j < b.njobs; ++j) c.job[j] = b.job[j], c.start[j] = b.start[j];
+    c.start[b.njobs] = b.start[b.njobs];
+    return c;
 }
 }  // namespace
 
@@ -341,7 +248,7 @@ extern "C" int pamnet_wgrad_batched_f32(int64_t njobs, const float* const* dZ, c
     if (head_partial && (!d_wout || !d_watt || !d_bout || head_blocks < 0)) return PAMNET_ENULL;
     if (!dZ || !ld_dz || !A || !ld_a || !a_mode || !rows || !dW || !ld_dw || !db || !partial) return PAMNET_ENULL;
     WBatch b;
-    const int rc = build_batch(b, njobs, dZ, ld_dz, A, ld_a, a_mode, rows, dW, ld_dw, db);
+    const int rc = build_batch(b, njobs, dZ, ld_dz, A, ld_a, a_mode, rows, dW, ld_dw, db, target_slots());
     if (rc) return rc;
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)b.start[njobs]), dim3(WG), 0, st, b, partial);
@@ -353,12 +260,24 @@ extern "C" int pamnet_wgrad_batched_f32(int64_t njobs, const float* const* dZ, c
 }
 
 // Deferred form for a sequence of batches (one per layer of a backward pass): the reduction of batch i rides along in
-// the launch of batch i+1's split-K pass; pamnet_wgrad_flush_f32 reduces the last one.  `ctx`: caller-owned host memory
+// the launch of batch i+1's split-K pass; pamnet_wgrad_flush_f32 reduces what is left.  `ctx`: caller-owned host memory
 // of pamnet_wgrad_ctx_bytes bytes, zeroed before the first call (the library itself keeps no state); consecutive calls
 // must use different `partial` buffers (the previous one is still being read).
 extern "C" int pamnet_wgrad_ctx_bytes(int64_t* bytes) {
     if (!bytes) return PAMNET_ENULL;
     *bytes = (int64_t)sizeof(WgradPending);
+    return PAMNET_OK;
+}
+
+static int finish_pending(WgradPending* pend, hipStream_t st) {
+    const HeadJob none{nullptr, 0, nullptr, nullptr, nullptr};
+    for (int k = 0; k < 2; ++k) {
+        if (!pend->valid[k]) continue;
+        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(FIN_X, (unsigned)pend->batch[k].njobs + 1), dim3(WG), 0, st,
+                           pend->batch[k], pend->partial[k], k == 0 ? pend->head : none);
+        PAMNET_LAUNCH_CHECK();
+        pend->valid[k] = 0;
+    }
     return PAMNET_OK;
 }
 
@@ -371,33 +290,85 @@ extern "C" int pamnet_wgrad_deferred_f32(int64_t njobs, const float* const* dZ, 
     if (head_partial && (!d_wout || !d_watt || !d_bout || head_blocks < 0)) return PAMNET_ENULL;
     if (!dZ || !ld_dz || !A || !ld_a || !a_mode || !rows || !dW || !ld_dw || !db || !partial || !ctx) return PAMNET_ENULL;
     WgradPending* pend = static_cast<WgradPending*>(ctx);
-    if (pend->valid && pend->partial == partial) return PAMNET_EINVAL;
+    if ((pend->valid[0] && pend->partial[0] == partial) || (pend->valid[1] && pend->partial[1] == partial)) return PAMNET_EINVAL;
     WBatch b;
-    const int rc = build_batch(b, njobs, dZ, ld_dz, A, ld_a, a_mode, rows, dW, ld_dw, db);
+    const int rc = build_batch(b, njobs, dZ, ld_dz, A, ld_a, a_mode, rows, dW, ld_dw, db, target_slots());
     if (rc) return rc;
     hipStream_t st = as_stream(stream);
-    if (pend->valid) {
-        const unsigned grid = (unsigned)b.start[njobs] + (unsigned)(FIN_X * (pend->batch.njobs + 1));
-        hipLaunchKernelGGL(wgrad_fused_kernel, dim3(grid), dim3(WG), 0, st, b, partial, pend->batch, pend->partial,
+    const bool any = pend->valid[0] || pend->valid[1];
+    const bool fits = njobs <= MAXJ_S && (!pend->valid[0] || pend->batch[0].njobs <= MAXJ_S) &&
+                      (!pend->valid[1] || pend->batch[1].njobs <= MAXJ_S);
+    if (pend->valid[0] && !pend->valid[1]) {                   // one earlier batch: wide descriptors
+        const unsigned grid = (unsigned)b.start[njobs] + (unsigned)(FIN_X * (pend->batch[0].njobs + 1));
+        hipLaunchKernelGGL(wgrad_fused_wide_kernel, dim3(grid), dim3(WG), 0, st, b, partial, pend->batch[0], pend->partial[0],
                            pend->head);
+        PAMNET_LAUNCH_CHECK();
+        pend->valid[0] = 0;
+    } else if (any && fits) {
+        WBatchS none;
+        none.njobs = 0, none.start[0] = 0;
+        const WBatchS p0 = pend->valid[0] ? compact(pend->batch[0]) : none;
+        const WBatchS p1 = pend->valid[1] ? compact(pend->batch[1]) : none;
+        const unsigned fin = (pend->valid[0] ? FIN_X * (p0.njobs + 1) : 0) + (pend->valid[1] ? FIN_X * (p1.njobs + 1) : 0);
+        const HeadJob nohead{nullptr, 0, nullptr, nullptr, nullptr};
+        hipLaunchKernelGGL(wgrad_fused_kernel, dim3((unsigned)b.start[njobs] + fin), dim3(WG), 0, st, compact(b), partial, p0,
+                           pend->valid[0] ? pend->partial[0] : nullptr, pend->valid[0] ? pend->head : nohead, p1,
+                           pend->valid[1] ? pend->partial[1] : nullptr);
+        PAMNET_LAUNCH_CHECK();
+        pend->valid[0] = pend->valid[1] = 0;
     } else {
+        if (any) {                                             // too many jobs for the compact descriptors: plain launches
+            const int frc = finish_pending(pend, st);
+            if (frc) return frc;
+        }
         hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)b.start[njobs]), dim3(WG), 0, st, b, partial);
+        PAMNET_LAUNCH_CHECK();
     }
-    PAMNET_LAUNCH_CHECK();
-    pend->batch = b;
-    pend->partial = partial;
+    pend->batch[0] = b;
+    pend->partial[0] = partial;
     pend->head = HeadJob{head_partial, (int)head_blocks, d_wout, d_watt, d_bout};
-    pend->valid = 1;
+    pend->valid[0] = 1;
     return PAMNET_OK;
 }
 
 extern "C" int pamnet_wgrad_flush_f32(void* ctx, pamnet_stream_t stream) {
     if (!ctx) return PAMNET_ENULL;
+    return finish_pending(static_cast<WgradPending*>(ctx), as_stream(stream));
+}
+
+// ---- riders: slots of a batch that run as extra workgroups of a node-chain backward launch -----------------------------
+// pamnet_wgrad_rider_plan_f32 lays a batch (<= 12 jobs) out over <= max_slots slots and stores the plan in `rider`
+// (caller-owned host memory, pamnet_wgrad_rider_bytes); pamnet_node_pre_tail_bwd_f32 takes the plan and appends the
+// slots to its grid; pamnet_wgrad_rider_enqueue_f32 then registers the batch with `ctx` so that the next deferred launch
+// (or the flush) reduces its slots.  *slots_out = workgroups the plan adds.
+extern "C" int pamnet_wgrad_rider_bytes(int64_t* bytes) {
+    if (!bytes) return PAMNET_ENULL;
+    *bytes = (int64_t)sizeof(WgradRider);
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_wgrad_rider_plan_f32(int64_t njobs, const float* const* dZ, const int64_t* ld_dz,
+                                           const float* const* A, const int64_t* ld_a, const int32_t* a_mode,
+                                           const int64_t* rows, float* const* dW, const int64_t* ld_dw, float* const* db,
+                                           float* partial, int64_t max_slots, void* rider, int64_t* slots_out) {
+    if (njobs < 1 || njobs > MAXJ_S || max_slots < njobs) return PAMNET_EINVAL;
+    if (!dZ || !ld_dz || !A || !ld_a || !a_mode || !rows || !dW || !ld_dw || !db || !partial || !rider) return PAMNET_ENULL;
+    WgradRider* r = static_cast<WgradRider*>(rider);
+    const int rc = build_batch(r->batch, njobs, dZ, ld_dz, A, ld_a, a_mode, rows, dW, ld_dw, db, max_slots);
+    if (rc) return rc;
+    r->partial = partial;
+    r->slots = r->batch.start[njobs];
+    if (slots_out) *slots_out = r->slots;
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_wgrad_rider_enqueue_f32(void* ctx, const void* rider) {
+    if (!ctx || !rider) return PAMNET_ENULL;
     WgradPending* pend = static_cast<WgradPending*>(ctx);
-    if (!pend->valid) return PAMNET_OK;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(FIN_X, (unsigned)pend->batch.njobs + 1), dim3(WG), 0, as_stream(stream),
-                       pend->batch, pend->partial, pend->head);
-    PAMNET_LAUNCH_CHECK();
-    pend->valid = 0;
+    const WgradRider* r = static_cast<const WgradRider*>(rider);
+    if (pend->valid[1]) return PAMNET_EINVAL;                  // one rider batch at a time
+    pend->batch[1] = widen(r->batch);
+    pend->partial[1] = r->partial;
+    pend->valid[1] = 1;
     return PAMNET_OK;
 }
