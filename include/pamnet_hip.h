@@ -167,6 +167,17 @@ int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int64_t n, con
                              float* Z, float* R, float* x_out, float* out, float* att, const float* next_Wx1,
                              const float* next_bx1, const float* const* next_wp, int64_t next_ldwp, int64_t next_nblk,
                              float* next_Zx1, float* next_x1, float* next_P, int32_t packed, pamnet_stream_t stream);
+/* pamnet_node_tail_fwd_f32 (packed weight images, deferred heads) with a RIDER: row tiles [mlp_tile0, mlp_tile0 + mlp_ntiles)
+ * (16 rows each) of the two-layer MLP of pamnet_mlp2_fwd_f32 over mlp_x [mlp_rows,128] run as `rider_wgs` extra workgroups
+ * of the launch -- the chain occupies only ceil(n/16) of the 256 CUs, the triplet/pair MLPs of the next layers do not
+ * depend on the node features.  mlp = {W1, b1, W2, b2}; mlp_out = {z1, z2, y} (z1 / z2 nullable saves). */
+int pamnet_node_tail_fwd_rider_f32(const float* x2, const float* res_x, int64_t n, const float* const* weights,
+                                   const float* const* biases, const float* w_out, const float* b_out,
+                                   const float* w_att, float* Z, float* R, float* x_out, const float* next_Wx1,
+                                   const float* next_bx1, const float* const* next_wp, int64_t next_ldwp,
+                                   int64_t next_nblk, float* next_Zx1, float* next_x1, float* next_P, const float* mlp_x,
+                                   int64_t mlp_rows, int64_t mlp_tile0, int64_t mlp_ntiles, const float* const* mlp,
+                                   float* const* mlp_out, int64_t rider_wgs, pamnet_stream_t stream);
 /* out = att = null in pamnet_node_tail_fwd_f32 leaves the head branch of the chain (mlp_out, W_out, W:
  * layers/global_message_passing.py:46-50) to this call, which runs it for n_layers chains in one launch (nothing
  * downstream of a layer depends on its heads): per layer l  x_out[l] [n,128] -> out[l] [n], att[l] [n], and slots 7..9

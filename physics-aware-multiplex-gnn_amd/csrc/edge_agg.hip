@@ -21,6 +21,8 @@
 // as one launch (one lane group per edge, node sums through LDS in CSR order).
 #include "edge_core.h"
 
+using namespace edge;
+
 namespace {
 
 constexpr int NMAX = 511;                 // nodes per chunk (their CSR offsets are staged in LDS)

@@ -55,6 +55,8 @@ extern "C" int pamnet_probe_read_wg(long long* host, int n) {
 
 #include "edge_core.h"
 
+using namespace edge;
+
 namespace {
 
 
@@ -323,72 +325,15 @@ __global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(const float* __rest
 // -------------------------------------------------------------------------------------------------- 2-layer MLP
 // blockIdx.y selects one of up to 8 independent (weights, outputs) sets applied to the same input rows: the triplet/pair
 // MLPs of all layers depend only on the basis embedding, so the engine runs them in one launch up front.
-struct Mlp2Set {
-    const float *W1, *b1, *W2, *b2;
-    float *z1, *z2, *y;
-};
 struct Mlp2Batch {
     Mlp2Set s[8];
 };
 template <int MTX, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlp2_fwd_kernel(const float* __restrict__ x, int64_t m, Mlp2Batch batch, int pa,
                                                        int pb, int pc, int cmt) {
-    const float* __restrict__ W1 = batch.s[blockIdx.y].W1;
-    const float* __restrict__ b1 = batch.s[blockIdx.y].b1;
-    const float* __restrict__ W2 = batch.s[blockIdx.y].W2;
-    const float* __restrict__ b2 = batch.s[blockIdx.y].b2;
-    float* __restrict__ z1 = batch.s[blockIdx.y].z1;
-    float* __restrict__ z2 = batch.s[blockIdx.y].z2;
-    float* __restrict__ y = batch.s[blockIdx.y].y;
     __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
-    float* S0 = lds;
-    float* S1 = lds + MTX * 16 * LDT;
-    constexpr int NS = 8 / NW;
-    const int wc = wave_col<NW>();
-    const BiasSet<NS> zero_bias = lane_biases<NS>(nullptr, wc);
-    const BiasSet<NS> bv1 = lane_biases<NS>(b1, wc), bv2 = lane_biases<NS>(b2, wc);
-    PROBE(0);
     PROBE_WG(0);
-    WSet<NS> f1, f2;
-    load_wset<false>(f1, W1, DIM, wc);
-    load_wset<false>(f2, W2, DIM, wc);
-    const Span sp = Span::make<NW>(m, pa, pb, pc, cmt);
-    CHUNK_LOOP(sp) {
-        const int mt = chunk_mt(sp, row0);
-        sweep<MTX, NW>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(x, row0 + r, sp.end, DIM, c4)); });
-        __syncthreads();
-        PROBE(1);
-        AccSet<MTX, NS> acc;
-        acc.zero();
-        mma_set<MTX, NS>(S0, f1, acc, mt);
-        PROBE(2);
-        store_set<MTX, NS>(acc, S1, wc, bv1, mt);
-        __syncthreads();
-        PROBE(3);
-        sweep<MTX, NW>(mt, [&](int r, int c4) {
-            const int64_t g = row0 + r;
-            const float4 zz = lds4(S1, r, c4);
-            st_lds4(S1, r, c4, f4silu(zz));
-            if (z1 && g < sp.end) stg4(z1, g, DIM, c4, zz);
-        });
-        __syncthreads();
-        PROBE(4);
-        acc.zero();
-        mma_set<MTX, NS>(S1, f2, acc, mt);
-        PROBE(5);
-        store_set<MTX, NS>(acc, S0, wc, bv2, mt);
-        __syncthreads();
-        PROBE(6);
-        sweep<MTX, NW>(mt, [&](int r, int c4) {
-            const int64_t g = row0 + r;
-            if (g >= sp.end) return;
-            const float4 zz = lds4(S0, r, c4);
-            if (z2) stg4(z2, g, DIM, c4, zz);
-            stg4(y, g, DIM, c4, f4silu(zz));
-        });
-        __syncthreads();
-    }
-    PROBE(7);
+    mlp2_fwd_body<MTX, NW>(x, batch.s[blockIdx.y], Span::make<NW>(m, pa, pb, pc, cmt), lds);
     PROBE_WG(1);
 }
 

@@ -5,6 +5,7 @@
 #include "gemm_core.h"
 
 namespace {
+namespace edge {
 using namespace pamnet;
 
 constexpr int WG8 = 512;                  // 8 waves
@@ -197,4 +198,62 @@ __device__ __forceinline__ float lane_bias(const float* __restrict__ b, int wc) 
     return b ? b[wc + (threadIdx.x & 15)] : 0.f;
 }
 
+
+// -------------------------------------------------------------------------------------------------- 2-layer MLP
+// y = SiLU(W2 SiLU(W1 x + b1) + b2) on the rows of `sp` (layers/local_message_passing.py:49 `mlp_sbf`); z1, z2: optional
+// saves.  Called by mlp2_fwd_kernel (edge_chain.hip) and, as a rider, by node_tail_fwd_kernel (node_tail.hip): the
+// triplet/pair MLPs do not depend on the node features, so their row tiles fill the CUs a node chain leaves idle.
+struct Mlp2Set {
+    const float *W1, *b1, *W2, *b2;
+    float *z1, *z2, *y;
+};
+template <int MTX, int NW>
+__device__ __forceinline__ void mlp2_fwd_body(const float* __restrict__ x, const Mlp2Set& set, const Span& sp, float* lds) {
+    const float* __restrict__ W1 = set.W1;
+    const float* __restrict__ b1 = set.b1;
+    const float* __restrict__ W2 = set.W2;
+    const float* __restrict__ b2 = set.b2;
+    float* __restrict__ z1 = set.z1;
+    float* __restrict__ z2 = set.z2;
+    float* __restrict__ y = set.y;
+    float* S0 = lds;
+    float* S1 = lds + MTX * 16 * LDT;
+    constexpr int NS = 8 / NW;
+    const int wc = wave_col<NW>();
+    const BiasSet<NS> bv1 = lane_biases<NS>(b1, wc), bv2 = lane_biases<NS>(b2, wc);
+    WSet<NS> f1, f2;
+    load_wset<false>(f1, W1, DIM, wc);
+    load_wset<false>(f2, W2, DIM, wc);
+    CHUNK_LOOP(sp) {
+        const int mt = chunk_mt(sp, row0);
+        sweep<MTX, NW>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(x, row0 + r, sp.end, DIM, c4)); });
+        __syncthreads();
+        AccSet<MTX, NS> acc;
+        acc.zero();
+        mma_set<MTX, NS>(S0, f1, acc, mt);
+        store_set<MTX, NS>(acc, S1, wc, bv1, mt);
+        __syncthreads();
+        sweep<MTX, NW>(mt, [&](int r, int c4) {
+            const int64_t g = row0 + r;
+            const float4 zz = lds4(S1, r, c4);
+            st_lds4(S1, r, c4, f4silu(zz));
+            if (z1 && g < sp.end) stg4(z1, g, DIM, c4, zz);
+        });
+        __syncthreads();
+        acc.zero();
+        mma_set<MTX, NS>(S1, f2, acc, mt);
+        store_set<MTX, NS>(acc, S0, wc, bv2, mt);
+        __syncthreads();
+        sweep<MTX, NW>(mt, [&](int r, int c4) {
+            const int64_t g = row0 + r;
+            if (g >= sp.end) return;
+            const float4 zz = lds4(S0, r, c4);
+            if (z2) stg4(z2, g, DIM, c4, zz);
+            stg4(y, g, DIM, c4, f4silu(zz));
+        });
+        __syncthreads();
+    }
+}
+
+}  // namespace edge
 }  // namespace

@@ -298,10 +298,17 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
     // n_layer of them are enqueued up front and run beside the node-level kernels of the first layers, which occupy
     // only ceil(n/16) of the 256 CUs.  Event 0 = inputs ready, event 1+k = s_k ready.
     const bool forked = aux && aux_events && g.tp > 0;
+    // Riders (packed weights, chains that leave CUs idle): the triplet/pair MLP of layer k >= 1 rides in the two node-chain
+    // launches that precede its use -- first half of its row tiles in the local chain of pair k-1, second half in the
+    // global chain of pair k; only layer 0's runs as a launch of its own ahead of the loop.
+    const bool ride = !forked && wpack != nullptr && g.tp > 0 && riders_fit(g);
+    const int64_t mlp_tiles = (g.tp + 15) / 16, mlp_half = mlp_tiles / 2;
+    const int64_t rider_wgs = RIDER_MAX_SLOTS - (g.n + 15) / 16;
     // Without the fork: the triplet/pair MLPs of up to 8 layers at a time as one launch ahead of the layer loop.
     if (!forked && g.tp > 0) {
-        for (int64_t k0 = 0; k0 < n_layer; k0 += 8) {
-            const int64_t nk = n_layer - k0 < 8 ? n_layer - k0 : 8;
+        const int64_t n_up = ride ? 1 : n_layer;
+        for (int64_t k0 = 0; k0 < n_up; k0 += 8) {
+            const int64_t nk = n_up - k0 < 8 ? n_up - k0 : 8;
             const float* prm[32];
             float* out[24];
             for (int64_t k = 0; k < nk; ++k) {
@@ -364,10 +371,19 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         const float* const* lp = lparams + k * NL;
         const LocalSaved q = carve_local(saved + k * (gs + ls) + gs, g);
         const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
-        CK(pamnet_node_tail_fwd_f32(s.x2, x, g.n, packed ? img[k].gt : gp + GT, gp + GT + 10, gp[GT + 20], gp[GT + 21],
-                                    gp[GT + 22], sv(s.Z), sv(s.R), s.xout, nullptr, nullptr,
-                                    packed ? img[k].lh[0] : lp[0], lp[1], packed ? img[k].lh + 1 : wpl, 3 * D, 4,
-                                    sv(q.Zx1), t.x1, t.P, pk, st));
+        if (ride && k > 0) {
+            const float* mp[4] = {lp[6], lp[7], lp[8], lp[9]};
+            float* mo[3] = {sv(q.z1), sv(q.z2), q.s};
+            CK(pamnet_node_tail_fwd_rider_f32(s.x2, x, g.n, img[k].gt, gp + GT + 10, gp[GT + 20], gp[GT + 21], gp[GT + 22],
+                                              sv(s.Z), sv(s.R), s.xout, img[k].lh[0], lp[1], img[k].lh + 1, 3 * D, 4,
+                                              sv(q.Zx1), t.x1, t.P, e_sbf, g.tp, mlp_half, mlp_tiles - mlp_half, mp, mo,
+                                              rider_wgs, st));
+        } else {
+            CK(pamnet_node_tail_fwd_f32(s.x2, x, g.n, packed ? img[k].gt : gp + GT, gp + GT + 10, gp[GT + 20], gp[GT + 21],
+                                        gp[GT + 22], sv(s.Z), sv(s.R), s.xout, nullptr, nullptr,
+                                        packed ? img[k].lh[0] : lp[0], lp[1], packed ? img[k].lh + 1 : wpl, 3 * D, 4,
+                                        sv(q.Zx1), t.x1, t.P, pk, st));
+        }
         x = s.xout;
         // ---------------- local layer (layers/local_message_passing.py:36-66); its head ran in the chain above
         const float* wq[4] = {lp[2] + 2 * D, lp[4] + 2 * D, lp[10], lp[11]};
@@ -382,10 +398,20 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
             const float* const* gn = gparams + (k + 1) * NG;
             const GlobalSaved sn = carve_global(saved + (k + 1) * (gs + ls), g);
             const float* wpn[2] = {gn[2], gn[2] + D};
-            CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, packed ? img[k].lt : lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21],
-                                        lp[LT + 22], sv(q.Z), sv(q.R), q.xout, nullptr, nullptr,
-                                        packed ? img[k].nh[0] : gn[0], gn[1],
-                                        packed ? img[k].nh + 1 : wpn, 3 * D, 2, sv(sn.Zx1), t.x1, t.P, pk, st));
+            if (ride) {
+                const float* const* ln = lparams + (k + 1) * NL;
+                const LocalSaved qn = carve_local(saved + (k + 1) * (gs + ls) + gs, g);
+                const float* mp[4] = {ln[6], ln[7], ln[8], ln[9]};
+                float* mo[3] = {sv(qn.z1), sv(qn.z2), qn.s};
+                CK(pamnet_node_tail_fwd_rider_f32(q.x2, x, g.n, img[k].lt, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22],
+                                                  sv(q.Z), sv(q.R), q.xout, img[k].nh[0], gn[1], img[k].nh + 1, 3 * D, 2,
+                                                  sv(sn.Zx1), t.x1, t.P, e_sbf, g.tp, 0, mlp_half, mp, mo, rider_wgs, st));
+            } else {
+                CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, packed ? img[k].lt : lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21],
+                                            lp[LT + 22], sv(q.Z), sv(q.R), q.xout, nullptr, nullptr,
+                                            packed ? img[k].nh[0] : gn[0], gn[1],
+                                            packed ? img[k].nh + 1 : wpn, 3 * D, 2, sv(sn.Zx1), t.x1, t.P, pk, st));
+            }
         } else {
             CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, packed ? img[k].lt : lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21],
                                         lp[LT + 22], sv(q.Z), sv(q.R), q.xout, nullptr, nullptr, nullptr, nullptr,

@@ -20,6 +20,7 @@
 // backward -- whose transposed weight reads are scalar, 4x more load instructions -- uses 8 waves x 16 columns so two
 // waves per SIMD overlap loads, MFMAs and epilogue (27 us vs 29 us); its z_k are fetched before the MFMAs start.
 #include "common.h"
+#include "edge_core.h"
 #include "gemm_core.h"
 #include "wgrad_core.h"
 
@@ -58,6 +59,16 @@ struct PreNext {
     const float* wp[4];
     int ldwp, nblk;
     float *Zx1, *x1, *P;      // [n][128], [n][128], [nblk][n][128]
+};
+
+// Rider of a forward chain launch: row tiles [tile0, tile0 + ntiles) of one triplet/pair MLP (edge::mlp2_fwd_body) dealt to
+// the workgroups behind the chain's ceil(n/16) -- the MLP does not depend on the node features, and the chain leaves
+// 256 - ceil(n/16) CUs idle.
+struct Mlp2Rider {
+    const float* x;
+    int64_t m;
+    edge::Mlp2Set set;
+    int tile0, ntiles, n_chain;
 };
 
 constexpr int BMN = 16;                       // rows per workgroup
@@ -134,16 +145,36 @@ __device__ __forceinline__ f32x4 mma_strip(const float* __restrict__ As, const W
 // runs it for every layer of the model in one launch after the layer loop: nothing downstream of a layer depends on
 // its heads, the chain gets three dependent GEMMs shorter, and the batched launch has 2L x ceil(n/16) workgroups
 // instead of the chain's ceil(n/16) (143 of 256 CUs at the QM9 batch).
-template <bool PACKED, bool HEADS>
+template <bool PACKED, bool HEADS, bool RIDER = false>
 __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restrict__ x2,
                                                            const float* __restrict__ res_x, int64_t n, TailParams p,
                                                            float* __restrict__ Z, float* __restrict__ R,
                                                            float* __restrict__ x_out, float* __restrict__ out,
-                                                           float* __restrict__ att, PreNext nx) {
+                                                           float* __restrict__ att, PreNext nx,
+                                                           Mlp2Rider rd = Mlp2Rider{}) {
     // 5 working slots + 10 pre-activation tiles + 3 residual taps: everything the backward needs is parked in LDS and
     // written out once, as coalesced 512-byte rows, after the chain -- no global store (and no wait for its
     // acknowledgement, vmcnt retires in order) sits between one layer's MFMAs and the next layer's weight slice.
     __shared__ __attribute__((aligned(16))) float lds[18 * SLOT];
+    if constexpr (RIDER) {
+        if ((int)blockIdx.x >= rd.n_chain) {
+            constexpr int RMT = 3;                            // 3-tile chunks: the 4-wave geometry without spills
+            static_assert(18 * SLOT >= 2 * RMT * 16 * LDT, "rider tiles must fit the chain's LDS");
+            const int b = (int)blockIdx.x - rd.n_chain, nr = (int)gridDim.x - rd.n_chain;
+            const int base = rd.ntiles / nr, rem = rd.ntiles % nr;
+            const int64_t t0 = rd.tile0 + (int64_t)b * base + (b < rem ? b : rem);
+            const int cnt = base + (b < rem ? 1 : 0);
+            edge::Span sp;
+            sp.beg = t0 * 16;
+            const int64_t e = (t0 + cnt) * 16;
+            sp.end = e < rd.m ? e : rd.m;
+            if (sp.beg > sp.end) sp.beg = sp.end;
+            const int nch = (cnt + RMT - 1) / RMT;
+            sp.cmt = nch > 0 ? (cnt + nch - 1) / nch : 1;
+            edge::mlp2_fwd_body<RMT, 4>(rd.x, rd.set, sp, lds);
+            return;
+        }
+    }
     float* X0 = lds;
     float* RX = lds + SLOT;
     float* A = lds + 2 * SLOT;
@@ -804,12 +835,12 @@ extern "C" int pamnet_pack_weights_f32(int64_t n, const float* const* W, const i
     return PAMNET_OK;
 }
 
-extern "C" int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int64_t n, const float* const* weights,
-                                        const float* const* biases, const float* w_out, const float* b_out,
-                                        const float* w_att, float* Z, float* R, float* x_out, float* out, float* att,
-                                        const float* next_Wx1, const float* next_bx1, const float* const* next_wp,
-                                        int64_t next_ldwp, int64_t next_nblk, float* next_Zx1, float* next_x1,
-                                        float* next_P, int32_t packed, pamnet_stream_t stream) {
+static int tail_fwd_launch(const float* x2, const float* res_x, int64_t n, const float* const* weights,
+                           const float* const* biases, const float* w_out, const float* b_out, const float* w_att, float* Z,
+                           float* R, float* x_out, float* out, float* att, const float* next_Wx1, const float* next_bx1,
+                           const float* const* next_wp, int64_t next_ldwp, int64_t next_nblk, float* next_Zx1,
+                           float* next_x1, float* next_P, int32_t packed, const Mlp2Rider* rider, int rider_wgs,
+                           pamnet_stream_t stream) {
     if (n < 0 || next_nblk < 0 || next_nblk > 4) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
     if (!x2 || !res_x || !weights || !biases || !w_out || !b_out || !w_att || (Z && !R) || !x_out || (!out != !att))
@@ -831,12 +862,55 @@ extern "C" int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int
     hipStream_t st = as_stream(stream);
     const dim3 grid((unsigned)ceil_div(n, BMN));
     const TailParams tp = make_tail(weights, biases, w_out, b_out, w_att, packed ? 1 : 0);
-    if (packed && heads) hipLaunchKernelGGL((node_tail_fwd_kernel<true, true>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
+    if (rider) {
+        if (!packed || heads) return PAMNET_EINVAL;
+        Mlp2Rider rd = *rider;
+        rd.n_chain = (int)grid.x;
+        hipLaunchKernelGGL((node_tail_fwd_kernel<true, false, true>), dim3(grid.x + (unsigned)rider_wgs), dim3(WG), 0, st, x2,
+                           res_x, n, tp, Z, R, x_out, out, att, nx, rd);
+    } else if (packed && heads) hipLaunchKernelGGL((node_tail_fwd_kernel<true, true>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
     else if (packed) hipLaunchKernelGGL((node_tail_fwd_kernel<true, false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
     else if (heads) hipLaunchKernelGGL((node_tail_fwd_kernel<false, true>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
     else hipLaunchKernelGGL((node_tail_fwd_kernel<false, false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
+}
+
+extern "C" int pamnet_node_tail_fwd_f32(const float* x2, const float* res_x, int64_t n, const float* const* weights,
+                                        const float* const* biases, const float* w_out, const float* b_out,
+                                        const float* w_att, float* Z, float* R, float* x_out, float* out, float* att,
+                                        const float* next_Wx1, const float* next_bx1, const float* const* next_wp,
+                                        int64_t next_ldwp, int64_t next_nblk, float* next_Zx1, float* next_x1,
+                                        float* next_P, int32_t packed, pamnet_stream_t stream) {
+    return tail_fwd_launch(x2, res_x, n, weights, biases, w_out, b_out, w_att, Z, R, x_out, out, att, next_Wx1, next_bx1,
+                           next_wp, next_ldwp, next_nblk, next_Zx1, next_x1, next_P, packed, nullptr, 0, stream);
+}
+
+// The same launch (packed weight images, deferred heads: out = att = null) with a rider: row tiles
+// [mlp_tile0, mlp_tile0 + mlp_ntiles) (16 rows each) of the two-layer MLP  y = SiLU(W2 SiLU(W1 x + b1) + b2)  over
+// mlp_x [mlp_rows, 128] are computed by `rider_wgs` extra workgroups (mlp = {W1, b1, W2, b2}; mlp_out = {z1, z2, y},
+// z1 / z2 nullable saves) -- pamnet_mlp2_fwd_f32 on the CUs the chain leaves idle.
+extern "C" int pamnet_node_tail_fwd_rider_f32(const float* x2, const float* res_x, int64_t n, const float* const* weights,
+                                              const float* const* biases, const float* w_out, const float* b_out,
+                                              const float* w_att, float* Z, float* R, float* x_out,
+                                              const float* next_Wx1, const float* next_bx1, const float* const* next_wp,
+                                              int64_t next_ldwp, int64_t next_nblk, float* next_Zx1, float* next_x1,
+                                              float* next_P, const float* mlp_x, int64_t mlp_rows, int64_t mlp_tile0,
+                                              int64_t mlp_ntiles, const float* const* mlp, float* const* mlp_out,
+                                              int64_t rider_wgs, pamnet_stream_t stream) {
+    if (mlp_rows < 0 || mlp_tile0 < 0 || mlp_ntiles < 0 || rider_wgs < 0) return PAMNET_EINVAL;
+    if (mlp_ntiles == 0 || rider_wgs == 0)
+        return tail_fwd_launch(x2, res_x, n, weights, biases, w_out, b_out, w_att, Z, R, x_out, nullptr, nullptr, next_Wx1,
+                               next_bx1, next_wp, next_ldwp, next_nblk, next_Zx1, next_x1, next_P, 1, nullptr, 0, stream);
+    if (!mlp_x || !mlp || !mlp_out || !mlp[0] || !mlp[1] || !mlp[2] || !mlp[3] || !mlp_out[2]) return PAMNET_ENULL;
+    if (n == 0) return PAMNET_EINVAL;                        // no chain to ride on
+    Mlp2Rider rd{};
+    rd.x = mlp_x, rd.m = mlp_rows;
+    rd.set = edge::Mlp2Set{mlp[0], mlp[1], mlp[2], mlp[3], mlp_out[0], mlp_out[1], mlp_out[2]};
+    rd.tile0 = (int)mlp_tile0, rd.ntiles = (int)mlp_ntiles;
+    if (rider_wgs > mlp_ntiles) rider_wgs = mlp_ntiles;       // never more workgroups than tiles
+    return tail_fwd_launch(x2, res_x, n, weights, biases, w_out, b_out, w_att, Z, R, x_out, nullptr, nullptr, next_Wx1,
+                           next_bx1, next_wp, next_ldwp, next_nblk, next_Zx1, next_x1, next_P, 1, &rd, (int)rider_wgs, stream);
 }
 
 extern "C" int pamnet_node_heads_fwd_f32(int64_t n_layers, const float* const* x_out, const float* const* weights,
