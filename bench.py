@@ -134,10 +134,13 @@ def step_kernel_rooflines(dev, g, d, n_layer):
     z, ea, x2 = torch.empty(eg, d, device=dev), torch.empty(eg, d, device=dev), torch.empty(n, d, device=dev)
     csr = g.glob
     st = lib.stream_of(e)
+    cuts_t = torch.empty(257, dtype=torch.int32, device=dev)
+    lib.call('pamnet_seg_cuts_i32', lib.ptr(csr.ptr), lib.ptr(csr.row_of), n, eg, lib.ptr(cuts_t), None, st)
+    cuts = lib.ptr(cuts_t)       # the engine computes this table once per forward
 
     def agg(save):
         lib.call('pamnet_global_edge_agg_fwd_f32', lib.ptr(e), eg, n, Wm.data_ptr() + 8 * d, 3 * d, lib.ptr(bm), lib.ptr(Wea),
-                 d, lib.ptr(Pi), lib.ptr(Pj), lib.ptr(csr.ptr), lib.ptr(csr.row_of), lib.ptr(csr.col), lib.ptr(x1),
+                 d, lib.ptr(Pi), lib.ptr(Pj), lib.ptr(csr.ptr), lib.ptr(csr.row_of), lib.ptr(csr.col), cuts, lib.ptr(x1),
                  lib.ptr(z) if save else None, lib.ptr(ea) if save else None, lib.ptr(x2), st)
 
     for save, tag in ((True, 'training (z, ea saved)'), (False, 'inference')):

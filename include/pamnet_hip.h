@@ -291,10 +291,17 @@ int pamnet_local_edge_bwd_f32(const float* d_mji, const float* d_mnb, const floa
  *   out[i] = init[i] + sum_{e in [l_ptr[i], l_ptr[i+1])} q3[e] * m_t[e] */
 int pamnet_global_edge_agg_fwd_f32(const float* e, int64_t n_edges, int64_t n_nodes, const float* We, int64_t ld_we,
                                    const float* bm, const float* Wea, int64_t ld_wea, const float* Pi, const float* Pj,
-                                   const int32_t* ptr, const int32_t* row_of, const int32_t* col, const float* init,
-                                   float* z, float* ea, float* out, pamnet_stream_t stream);
+                                   const int32_t* ptr, const int32_t* row_of, const int32_t* col,
+                                   const int32_t* cuts /* nullable: pamnet_seg_cuts_i32 */, const float* init, float* z,
+                                   float* ea, float* out, pamnet_stream_t stream);
+/* cuts[0 .. G] = the node-aligned work split of the fused kernels for this graph (node boundary nearest to edge row
+ * k * n_edges / G), G = *grid_out <= 256: computed once per graph, handed to every pamnet_global_edge_agg_fwd_f32 launch
+ * (without it every workgroup derives its cuts itself: two dependent loads ahead of everything else). */
+int pamnet_seg_cuts_i32(const int32_t* ptr, const int32_t* row_of, int64_t n_nodes, int64_t n_edges, int32_t* cuts,
+                        int64_t* grid_out, pamnet_stream_t stream);
 int pamnet_global_edge_agg_bwd_f32(const float* d_agg, int64_t n_edges, int64_t n_nodes, const int32_t* ptr,
-                                   const int32_t* row_of, const float* z, const float* ea, const float* We,
+                                   const int32_t* row_of, const int32_t* cuts /* nullable */, const float* z,
+                                   const float* ea, const float* We,
                                    int64_t ld_we, const float* Wea, int64_t ld_wea, float* dz, float* dea, float* d_e,
                                    int32_t accumulate, float* dPi, pamnet_stream_t stream);
 int pamnet_local_agg_fwd_f32(const float* m_ji, const float* m_nb, const float* s, const float* q3,

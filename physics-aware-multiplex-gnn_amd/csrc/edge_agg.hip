@@ -23,6 +23,31 @@
 
 using namespace edge;
 
+#ifdef PAMNET_PHASE_PROBE
+// Development aid (tools/agg_probe.py builds a private copy of this file with -DPAMNET_PHASE_PROBE): shader-clock
+// timestamps of the middle workgroup -- slots [0, 32): wave 0, [32, 64): wave 4 -- and wall clock at start / end of every
+// workgroup.  Never compiled into libpamnet_hip.so.
+__device__ long long pamnet_agg_probe[64];
+__device__ long long pamnet_agg_probe_wg[2 * 1024];
+#define APROBE(i)                                                                                         \
+    do {                                                                                                  \
+        if (blockIdx.x == gridDim.x / 2 && (threadIdx.x == 0 || threadIdx.x == 256) && (i) < 32)            \
+            pamnet_agg_probe[(threadIdx.x >> 8) * 32 + (i)] = clock64();                                    \
+    } while (0)
+#define APROBE_WG(slot)                                                                                       \
+    do {                                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) pamnet_agg_probe_wg[2 * blockIdx.x + slot] = wall_clock64(); \
+    } while (0)
+extern "C" int pamnet_agg_probe_read(long long* host64, long long* wg, int n) {
+    int rc = (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(pamnet_agg_probe), sizeof(long long) * 64);
+    if (rc) return rc;
+    return (int)hipMemcpyFromSymbol(wg, HIP_SYMBOL(pamnet_agg_probe_wg), sizeof(long long) * 2 * n);
+}
+#else
+#define APROBE(i)
+#define APROBE_WG(slot)
+#endif
+
 namespace {
 
 constexpr int NMAX = 511;                 // nodes per chunk (their CSR offsets are staged in LDS)
@@ -92,6 +117,7 @@ __device__ __forceinline__ void reduce_nodes(int c0, int nn, int rows, const flo
 struct GAggFwd {
     const float *e, *We, *bm, *Wea, *Pi, *Pj, *init;
     const int32_t *ptr, *row_of, *col;
+    const int32_t* cuts;      // optional [gridDim.x + 1] node cuts (pamnet_seg_cuts_i32): saves the dependent loads of seg_cut
     float *z, *ea, *out;
     int64_t m, n;
     int ld_we, ld_wea;
@@ -99,7 +125,7 @@ struct GAggFwd {
 
 // PRE: the next chunk's e rows travel in registers while this chunk's GEMMs run (multi-chunk workgroups); the 9-tile
 // instantiation (one chunk per workgroup at ~128 rows give or take half a node) has no registers to spare for it.
-template <int MTX, bool PRE>
+template <int MTX, bool PRE, bool SAVE>
 __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
     __shared__ int sptr[NMAX + 1];
@@ -116,15 +142,20 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
     float* __restrict__ zs = a.z;
     float* __restrict__ eas = a.ea;
     const int wc = wave_col<8>();
+    APROBE_WG(0);
+    APROBE(0);
     const BiasSet<1> zero_bias = lane_biases<1>(nullptr, wc);
     const BiasSet<1> bv = lane_biases<1>(a.bm, wc);
     WSet<1> f1, f2;
     load_wset<false>(f1, a.We, a.ld_we, wc);
     load_wset<false>(f2, a.Wea, a.ld_wea, wc);
-    const int nb = seg_cut(ptr, row_of, a.n, a.m, blockIdx.x, gridDim.x);
-    const int ne = seg_cut(ptr, row_of, a.n, a.m, blockIdx.x + 1, gridDim.x);
+    APROBE(20);
+    const int nb = a.cuts ? a.cuts[blockIdx.x] : seg_cut(ptr, row_of, a.n, a.m, blockIdx.x, gridDim.x);
+    const int ne = a.cuts ? a.cuts[blockIdx.x + 1] : seg_cut(ptr, row_of, a.n, a.m, blockIdx.x + 1, gridDim.x);
     const int64_t rb = ptr[nb], re = ptr[ne];
+    APROBE(21);
     constexpr int RPP = 16, NI = MTX;                       // sweep geometry of 512 threads: 16 rows per pass
+    constexpr int SC = 3;                                   // tiles per pipeline stage
     const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;
     float4 pre[PRE ? NI : 1];
     if (PRE && rb < re) {
@@ -142,6 +173,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
         // CSR offsets of the chunk's nodes: requested now, parked in LDS before the reduction
         const int nn = c1 - c0 + 1;
         const int myp = (int)threadIdx.x <= nn ? ptr[c0 + threadIdx.x] - (int)r0 : 0;
+        APROBE(22);
         if (rows > 0) {
             if (PRE) {
 #pragma unroll
@@ -156,38 +188,96 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
                 for (int i = 0; i < NI; ++i)
                     if (RPP * i < 16 * mt) st_lds4(S0, rr + RPP * i, c4, ldg4z(e, r0 + rr + RPP * i, r1, DIM, c4));
             }
-            __syncthreads();
-            AccSet<MTX, 1> acc;                                // one accumulator set: the gate tile goes straight to S1
-            acc.zero();                                        // (nobody reads S1 during the GEMMs)
-            mma_set<MTX, 1>(S0, f2, acc, mt);
-            store_set<MTX, 1>(acc, S1, wc, zero_bias, mt);
-            acc.zero();
-            mma_set<MTX, 1>(S0, f1, acc, mt);
-            __syncthreads();                                   // every wave is done reading the e tile
-            store_set<MTX, 1>(acc, S0, wc, bv, mt);
+            APROBE(23);
             if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = myp;
-            __syncthreads();
+            // node indices of this thread's rows (clamped to the chunk: every load below is unconditional)
+            int ri[NI], ci[NI];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int r = rr + RPP * i;
-                const int64_t g = r0 + r;
-                if (RPP * i < 16 * mt && g < r1) {
-                    const int64_t ii = row_of[g], jj = col[g];
-                    const float4 zz = f4add(f4add(lds4(S0, r, c4), ldg4(Pi, ii, DIM, c4)), ldg4(Pj, jj, DIM, c4));
-                    const float4 gate = lds4(S1, r, c4);
-                    if (zs) stg4(zs, g, DIM, c4, zz);          // backward-only saves: null in inference mode
-                    if (eas) stg4(eas, g, DIM, c4, gate);
-                    st_lds4(S1, r, c4, f4mul(f4silu(zz), gate));   // the message stays on chip
+                int64_t g = r0 + rr + RPP * i;
+                g = g < r1 ? g : r1 - 1;
+                ri[i] = row_of[g], ci[i] = col[g];
+            }
+            APROBE(1);
+            __syncthreads();
+            APROBE(2);
+            // Software pipeline over sub-chunks of SC tiles: stage s runs the two GEMMs of sub-chunk s, then the epilogue of
+            // sub-chunk s-1 (SiLU, gate, z / ea stores, message -> LDS).  The epilogue holds no load latency: the node-plane
+            // rows P_i[i], P_j[j] of a sub-chunk are requested a stage ahead (right after the previous epilogue has consumed
+            // its own), and its global stores are issued last -- vmcnt retires in order, a store ahead of a load would
+            // make the load's wait drain it (the epilogue of 48 rows went from 9 100 to 2 400 cycles, tools/agg_probe.py).
+            // (Letting the two waves of a SIMD take GEMM and epilogue in opposite order was measured and dropped: an fp32
+            // MFMA burst leaves the other wave's VALU work no issue slots -- fp32 matrix and vector peak are the same
+            // 157 TFLOP/s on this part -- so the epilogue just ran four times longer.)
+            const int nsub = (mt + SC - 1) / SC;
+            float4 gpi[SC], gpj[SC];
+            auto gather = [&](int sb) {
+#pragma unroll
+                for (int i = 0; i < SC; ++i) {
+                    const int k = sb * SC + i < NI ? sb * SC + i : NI - 1;
+                    gpi[i] = ldg4(Pi, ri[k], DIM, c4);
+                    gpj[i] = ldg4(Pj, ci[k], DIM, c4);
                 }
+            };
+            gather(0);
+            for (int sb = 0; sb <= nsub; ++sb) {
+                const bool do_g = sb < nsub, do_e = sb > 0;
+                const int smt = do_g ? (mt - sb * SC < SC ? mt - sb * SC : SC) : 0;
+                const int goff = sb * SC * 16, eoff = (sb - 1) * SC * 16;
+                AccSet<SC, 1> ag, az;
+                auto gemm = [&]() {
+                    ag.zero();
+                    az.zero();
+                    mma_set<SC, 1>(S0 + goff * LDT, f2, ag, smt);
+                    mma_set<SC, 1>(S0 + goff * LDT, f1, az, smt);
+                };
+                auto epi = [&]() {
+                    float4 zz[SC], gate[SC];
+#pragma unroll
+                    for (int i = 0; i < SC; ++i) {
+                        const int r = eoff + rr + RPP * i;
+                        if (r < 16 * mt) {                     // (the last sub-chunk may hold fewer than SC tiles)
+                            zz[i] = f4add(f4add(lds4(S0, r, c4), gpi[i]), gpj[i]);
+                            gate[i] = lds4(S1, r, c4);
+                            st_lds4(S1, r, c4, f4mul(f4silu(zz[i]), gate[i]));  // the message stays on chip
+                        }
+                    }
+                    if (sb < nsub) gather(sb);                 // the next epilogue's node rows: a whole stage of lead
+                    if (SAVE) {                                // backward-only saves (inference instantiation: none)
+#pragma unroll
+                        for (int i = 0; i < SC; ++i) {
+                            const int64_t g = r0 + eoff + rr + RPP * i;
+                            if (g < r1) {
+                                stg4(zs, g, DIM, c4, zz[i]);
+                                stg4(eas, g, DIM, c4, gate[i]);
+                            }
+                        }
+                    }
+                };
+                APROBE(3 + 4 * sb);
+                if (do_g) gemm();
+                APROBE(4 + 4 * sb);
+                if (do_e) epi();
+                APROBE(5 + 4 * sb);
+                if (do_g) {
+                    __syncthreads();                           // every wave is done reading the e rows of sub-chunk sb
+                    store_set<SC, 1>(az, S0 + goff * LDT, wc, bv, smt);
+                    store_set<SC, 1>(ag, S1 + goff * LDT, wc, zero_bias, smt);
+                    __syncthreads();
+                }
+                APROBE(6 + 4 * sb);
             }
         } else if ((int)threadIdx.x <= nn) {
             sptr[threadIdx.x] = myp;
         }
         __syncthreads();
         const bool open_end = sptr[nn] > rows;                 // the last node continues in the next chunk
+        APROBE(28);
         reduce_nodes<16>(c0, nn, rows, S1, sptr, carry[par], carry[par ^ 1], a.init, a.out);
         par ^= 1;
         __syncthreads();
+        APROBE(29);
+        APROBE_WG(1);
         c0 = open_end ? c1 : c1 + 1;
         r0 = r1;
     }
@@ -196,6 +286,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
 struct GAggBwd {
     const float *d_agg, *z, *ea, *We, *Wea;
     const int32_t *ptr, *row_of;
+    const int32_t* cuts;      // optional node cuts (pamnet_seg_cuts_i32)
     float *dz, *dea, *d_e, *dPi;
     int64_t m, n;
     int ld_we, ld_wea, accumulate;
@@ -221,12 +312,14 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
     float* __restrict__ d_e = a.d_e;
     const int accumulate = a.accumulate;
     const int wc = wave_col<8>();
+    APROBE_WG(0);
+    APROBE(0);
     const BiasSet<1> zero_bias = lane_biases<1>(nullptr, wc);
     WSet<1> f1, f2;
     load_wset<true>(f1, a.We, a.ld_we, wc);
     load_wset<true>(f2, a.Wea, a.ld_wea, wc);
-    const int nb = seg_cut(ptr, row_of, a.n, a.m, blockIdx.x, gridDim.x);
-    const int ne = seg_cut(ptr, row_of, a.n, a.m, blockIdx.x + 1, gridDim.x);
+    const int nb = a.cuts ? a.cuts[blockIdx.x] : seg_cut(ptr, row_of, a.n, a.m, blockIdx.x, gridDim.x);
+    const int ne = a.cuts ? a.cuts[blockIdx.x + 1] : seg_cut(ptr, row_of, a.n, a.m, blockIdx.x + 1, gridDim.x);
     const int64_t re = ptr[ne];
     constexpr int RPP = 16, NI = MTX;
     const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;
@@ -240,7 +333,11 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
         const int mt = (rows + 15) >> 4;
         const int nn = c1 - c0 + 1;
         if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = ptr[c0 + threadIdx.x] - (int)r0;
+        APROBE(1);
         if (rows > 0) {
+            // (Restructuring this sweep -- operands a row / a group of rows ahead, stores last -- changed nothing: all
+            // workgroups run it at the same time and it moves 85 MB through L2 / Infinity Cache in ~8 us: bandwidth, not
+            // latency, tools/agg_probe.py.)
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 if (RPP * i >= 16 * mt) continue;
@@ -259,30 +356,47 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
                 st_lds4(S1, r, c4, y);
             }
         }
+        APROBE(2);
         __syncthreads();
+        APROBE(3);
         const bool open_end = sptr[nn] > rows;
         reduce_nodes<16>(c0, nn, rows, S0, sptr, carry[par], carry[par ^ 1], nullptr, a.dPi);   // reads S0 only
         par ^= 1;
+        APROBE(4);
         if (rows > 0) {
             AccSet<MTX, 1> acc;
             acc.zero();
             mma_set<MTX, 1>(S0, f1, acc, mt);
             mma_set<MTX, 1>(S1, f2, acc, mt);
+            APROBE(5);
+            constexpr bool PREACC = MTX <= 5;                  // (the 8 / 9-tile instantiations have no registers to spare)
+            float4 dacc[PREACC ? NI : 1];                      // accumulate operand of the final sweep
+            if (PREACC && accumulate) {                        // requested here (the A fragments' registers are free again):
+#pragma unroll                                                 // the two barriers and the accumulator stores cover the latency
+                for (int i = 0; i < NI; ++i) {
+                    int64_t g = r0 + rr + RPP * i;
+                    g = g < r1 ? g : r1 - 1;
+                    dacc[i] = ldg4(d_e, g, DIM, c4);
+                }
+            }
             __syncthreads();
             store_set<MTX, 1>(acc, S0, wc, zero_bias, mt);
             __syncthreads();
+            APROBE(6);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int r = rr + RPP * i;
                 const int64_t g = r0 + r;
                 if (RPP * i < 16 * mt && g < r1) {
                     float4 v = lds4(S0, r, c4);
-                    if (accumulate) v = f4add(v, ldg4(d_e, g, DIM, c4));
+                    if (accumulate) v = f4add(v, PREACC ? dacc[PREACC ? i : 0] : ldg4(d_e, g, DIM, c4));
                     stg4(d_e, g, DIM, c4, v);
                 }
             }
         }
+        APROBE(7);
         __syncthreads();
+        APROBE_WG(1);
         c0 = open_end ? c1 : c1 + 1;
         r0 = r1;
     }
@@ -420,21 +534,47 @@ inline int64_t agg_grid(int64_t m) {
 extern "C" int pamnet_global_edge_agg_fwd_f32(const float* e, int64_t n_edges, int64_t n_nodes, const float* We,
                                               int64_t ld_we, const float* bm, const float* Wea, int64_t ld_wea,
                                               const float* Pi, const float* Pj, const int32_t* ptr, const int32_t* row_of,
-                                              const int32_t* col, const float* init, float* z, float* ea, float* out,
-                                              pamnet_stream_t stream) {
+                                              const int32_t* col, const int32_t* cuts, const float* init, float* z, float* ea,
+                                              float* out, pamnet_stream_t stream) {
     if (n_edges < 0 || n_nodes < 0) return PAMNET_EINVAL;
     if (n_nodes == 0) return PAMNET_OK;
     if (!We || !bm || !Wea || !Pi || !Pj || !ptr || !out) return PAMNET_ENULL;      // init, z, ea: optional
     if (n_edges > 0 && (!e || !row_of || !col)) return PAMNET_ENULL;
-    GAggFwd a{e, We, bm, Wea, Pi, Pj, init, ptr, row_of, col, z, ea, out, n_edges, n_nodes, (int)ld_we, (int)ld_wea};
+    if ((z == nullptr) != (ea == nullptr)) return PAMNET_EINVAL;               // both saves or none
+    GAggFwd a{e, We, bm, Wea, Pi, Pj, init, ptr, row_of, col, cuts, z, ea, out, n_edges, n_nodes, (int)ld_we, (int)ld_wea};
     const int64_t grid = agg_grid(n_edges);
     hipStream_t st = as_stream(stream);
+    const bool save = z != nullptr;
+#define PAMNET_AGG_FWD(MTX, PRE)                                                                                         \
+    do {                                                                                                                 \
+        if (save) hipLaunchKernelGGL((global_edge_agg_fwd_kernel<MTX, PRE, true>), dim3((unsigned)grid), dim3(WG8), 0, st, a); \
+        else hipLaunchKernelGGL((global_edge_agg_fwd_kernel<MTX, PRE, false>), dim3((unsigned)grid), dim3(WG8), 0, st, a);    \
+    } while (0)
     switch (pick_mtx(n_edges, grid)) {
-        case 3: hipLaunchKernelGGL((global_edge_agg_fwd_kernel<3, true>), dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
-        case 5: hipLaunchKernelGGL((global_edge_agg_fwd_kernel<5, true>), dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
-        case 9: hipLaunchKernelGGL((global_edge_agg_fwd_kernel<9, false>), dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
-        default: hipLaunchKernelGGL((global_edge_agg_fwd_kernel<8, true>), dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
+        case 3: PAMNET_AGG_FWD(3, true); break;
+        case 5: PAMNET_AGG_FWD(5, true); break;
+        case 9: PAMNET_AGG_FWD(9, false); break;
+        default: PAMNET_AGG_FWD(8, true); break;
     }
+#undef PAMNET_AGG_FWD
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+// cuts[k] = node boundary nearest to edge row k * n_edges / G for k = 0 .. G, G = the grid of the fused kernels for this
+// edge count (*grid_out): the node-aligned work split, computed once per graph instead of by every workgroup of every
+// launch (two dependent loads ahead of everything else).  cuts: G + 1 ints (<= 257).
+__global__ __launch_bounds__(256) void seg_cuts_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ row_of,
+                                                       int64_t n, int64_t m, int G, int32_t* __restrict__ cuts) {
+    for (int k = threadIdx.x; k <= G; k += 256) cuts[k] = seg_cut(ptr, row_of, n, m, k, G);
+}
+extern "C" int pamnet_seg_cuts_i32(const int32_t* ptr, const int32_t* row_of, int64_t n_nodes, int64_t n_edges,
+                                   int32_t* cuts, int64_t* grid_out, pamnet_stream_t stream) {
+    if (n_nodes < 0 || n_edges < 0) return PAMNET_EINVAL;
+    if (!ptr || !cuts || (n_edges > 0 && !row_of)) return PAMNET_ENULL;
+    const int64_t grid = agg_grid(n_edges);
+    if (grid_out) *grid_out = grid;
+    hipLaunchKernelGGL(seg_cuts_kernel, dim3(1), dim3(256), 0, as_stream(stream), ptr, row_of, n_nodes, n_edges, (int)grid, cuts);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -442,14 +582,15 @@ extern "C" int pamnet_global_edge_agg_fwd_f32(const float* e, int64_t n_edges, i
 // Backward of the fused global edge step: dz, dea [E,128] written (the weight gradients and the source-side reduction
 // read them), d_e written / accumulated, dPi[i] = sum_{e -> i} dz[e] for every node (zero for nodes without edges).
 extern "C" int pamnet_global_edge_agg_bwd_f32(const float* d_agg, int64_t n_edges, int64_t n_nodes, const int32_t* ptr,
-                                              const int32_t* row_of, const float* z, const float* ea, const float* We,
+                                              const int32_t* row_of, const int32_t* cuts, const float* z, const float* ea,
+                                              const float* We,
                                               int64_t ld_we, const float* Wea, int64_t ld_wea, float* dz, float* dea,
                                               float* d_e, int32_t accumulate, float* dPi, pamnet_stream_t stream) {
     if (n_edges < 0 || n_nodes < 0) return PAMNET_EINVAL;
     if (n_nodes == 0) return PAMNET_OK;
     if (!d_agg || !ptr || !We || !Wea || !dPi) return PAMNET_ENULL;
     if (n_edges > 0 && (!row_of || !z || !ea || !dz || !dea || !d_e)) return PAMNET_ENULL;
-    GAggBwd a{d_agg, z, ea, We, Wea, ptr, row_of, dz, dea, d_e, dPi, n_edges, n_nodes, (int)ld_we, (int)ld_wea,
+    GAggBwd a{d_agg, z, ea, We, Wea, ptr, row_of, cuts, dz, dea, d_e, dPi, n_edges, n_nodes, (int)ld_we, (int)ld_wea,
               (int)accumulate};
     const int64_t grid = agg_grid(n_edges);
     hipStream_t st = as_stream(stream);

@@ -91,6 +91,7 @@ struct Temp {
     float *partial, *partial2;   // split-K scratch of two consecutive weight-gradient batches (the reduction of one runs
                                  // inside the launch of the next)
     float* rider_partial;        // split-K scratch of the rider batch (10 node-level jobs in a node-chain launch)
+    int32_t* cuts;               // node-aligned work split of the fused global-edge kernels (<= 257 ints)
 };
 
 constexpr int WJOBS = 24;
@@ -116,7 +117,7 @@ inline int64_t temp_floats(const Graph& g) {
     t += nd + 4 * nd + gd + ld;                                        // x1 P msg mji
     t += 10 * nd + 7 * nd + nd + nd + al(((g.n + 15) / 16) * 257) + gd + gd + 4 * nd + nd + nd + nd;
     t += 6 * ld + 3 * td;
-    t += 2 * wgrad_floats(g) + rider_floats(g);
+    t += 2 * wgrad_floats(g) + rider_floats(g) + 320;
     return t;
 }
 
@@ -150,7 +151,8 @@ inline Temp carve_temp(float* p, const Graph& g) {
     t.dz2 = p; p += td;
     t.partial = p; p += wgrad_floats(g);
     t.partial2 = p; p += wgrad_floats(g);
-    t.rider_partial = p;
+    t.rider_partial = p; p += rider_floats(g);
+    t.cuts = reinterpret_cast<int32_t*>(p);
     return t;
 }
 
@@ -218,14 +220,20 @@ inline int plan_rider(Jobs& j, float* partial, const Graph& g, void* rider, int6
                                        rider, slots);
 }
 // riders pay when the chain leaves enough CUs idle for slots of a few hundred rows: ceil(n/16) <= 176 workgroups
+// how many of a chain's 10 tail jobs ride (the rest stay in the layer's own weight-gradient launch)
+inline int rider_jobs() {
+    static int v = [] { const char* e = getenv("PAMNET_RIDER_JOBS"); const int k = e ? atoi(e) : 10; return k < 1 ? 1 : (k > 10 ? 10 : k); }();
+    return v;
+}
 inline bool riders_fit(const Graph& g) { return (g.n + 15) / 16 <= RIDER_MAX_SLOTS - 80; }
 
 inline void tail_jobs(Jobs& j, const Graph& g, const float* dZ, const float* hdz, const float* x2, const float* Z,
-                      const float* R, const float* xout, float* const* gt /* tail block of the gradient table */) {
+                      const float* R, const float* xout, float* const* gt /* tail block of the gradient table */,
+                      int k0 = 0, int k1 = 10) {
     const int64_t pl = g.n * D;
     const float* src[10] = {x2, Z, Z + pl, R, Z + 3 * pl, R + pl, Z + 5 * pl, xout, Z + 7 * pl, Z + 8 * pl};
     const int mode[10] = {0, 1, 1, 0, 1, 0, 1, 0, 1, 1};
-    for (int k = 0; k < 10; ++k)          // dz7..dz9 come from the batched head-branch backward
+    for (int k = k0; k < k1; ++k)         // dz7..dz9 come from the batched head-branch backward
         j.add(k < 7 ? dZ + k * pl : hdz + (k - 7) * pl, src[k], mode[k], g.n, gt[k], D, gt[10 + k]);
 }
 
@@ -358,6 +366,7 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         CK(pl.rc);
     }
     const int32_t pk = packed ? 1 : 0;
+    CK(pamnet_seg_cuts_i32(g.g_ptr, g.g_row, g.n, g.eg, t.cuts, nullptr, st));      // work split of the fused global-edge kernels
     for (int64_t k = 0; k < n_layer; ++k) {
         // ---------------- global layer (layers/global_message_passing.py:33-56)
         const float* const* gp = gparams + k * NG;
@@ -367,7 +376,7 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         if (k == 0) CK(pamnet_node_pre_fwd_f32(x, g.n, gp[0], gp[1], wpg, 3 * D, 2, sv(s.Zx1), t.x1, t.P, st));
         // message MLP + add-aggregation in one kernel: x2 = x1 + sum_{e -> i} msg_e, the messages never leave the chip
         CK(pamnet_global_edge_agg_fwd_f32(e_g, g.eg, g.n, gp[2] + 2 * D, 3 * D, gp[3], gp[4], D, t.P, t.P + g.n * D,
-                                          g.g_ptr, g.g_row, g.g_col, t.x1, sv(s.z), sv(s.ea), s.x2, st));
+                                          g.g_ptr, g.g_row, g.g_col, t.cuts, t.x1, sv(s.z), sv(s.ea), s.x2, st));
         const float* const* lp = lparams + k * NL;
         const LocalSaved q = carve_local(saved + k * (gs + ls) + gs, g);
         const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
@@ -522,6 +531,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
     CK(pamnet_wgrad_rider_bytes(&rider_bytes));
     std::vector<char> wctx((size_t)ctx_bytes, 0), rider((size_t)rider_bytes, 0);
     const bool ride = fuse && riders_fit(g);
+    CK(pamnet_seg_cuts_i32(g.g_ptr, g.g_row, g.n, g.eg, t.cuts, nullptr, st));      // work split of the fused global-edge kernels
     float* parts[2] = {t.partial, t.partial2};
     int pflip = 0;
     const float* d_xout = nullptr;        // nothing consumes the last layer's node features (models.py:196-224)
@@ -569,7 +579,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 dz_global = dz_bufs[zflip];
                 if (ride) {                                   // this layer's chain gradients ride in the launch below
                     Jobs jr;
-                    tail_jobs(jr, g, dz_local, q.hdz, q.x2, q.Z, q.R, q.xout, lg + LT);
+                    tail_jobs(jr, g, dz_local, q.hdz, q.x2, q.Z, q.R, q.xout, lg + LT, 0, rider_jobs());
                     CK(plan_rider(jr, t.rider_partial, g, rider.data(), nullptr));
                 }
                 CK(pamnet_node_pre_tail_bwd_f32(t.dP, t.dx2, t.dresx, g.n, img[k].lh[4], img[k].lh, 4, q.Zx1, t.dZx1, s.gh,
@@ -583,7 +593,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 flip ^= 1;
             }
             Jobs j;
-            if (!ride) tail_jobs(j, g, dz_local, q.hdz, q.x2, q.Z, q.R, q.xout, lg + LT);
+            tail_jobs(j, g, dz_local, q.hdz, q.x2, q.Z, q.R, q.xout, lg + LT, ride ? rider_jobs() : 0, 10);
             j.add(t.dZx1, x_in, 0, g.n, lg[0], D, lg[1]);
             j.add(t.dP, q.Zx1, 1, g.n, lg[2], 3 * D, nullptr);
             j.add(t.dP + pl, q.Zx1, 1, g.n, lg[4], 3 * D, nullptr);
@@ -613,7 +623,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             }
             // d z, d ea, d e and the target-side reduction d P_i in one kernel; the source-side one walks the transposed CSR
             const int64_t pl = g.n * D;
-            CK(pamnet_global_edge_agg_bwd_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, s.z, s.ea, gp[2] + 2 * D, 3 * D, gp[4], D,
+            CK(pamnet_global_edge_agg_bwd_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, t.cuts, s.z, s.ea, gp[2] + 2 * D, 3 * D, gp[4], D,
                                               t.dz, t.dea, d_eg, acc, t.dP, st));
             CK(pamnet_segment_sum_f32(t.dP + pl, nullptr, t.dz, nullptr, nullptr, nullptr, g.gT_perm, g.gT_ptr, g.n, D, st));
             if (fuse && k > 0) {
@@ -623,7 +633,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 dz_local = dz_bufs[zflip];
                 if (ride) {
                     Jobs jr;
-                    tail_jobs(jr, g, dz_global, s.hdz, s.x2, s.Z, s.R, s.xout, gg + GT);
+                    tail_jobs(jr, g, dz_global, s.hdz, s.x2, s.Z, s.R, s.xout, gg + GT, 0, rider_jobs());
                     CK(plan_rider(jr, t.rider_partial, g, rider.data(), nullptr));
                 }
                 CK(pamnet_node_pre_tail_bwd_f32(t.dP, t.dx2, t.dresx, g.n, img[k].gh[2], img[k].gh, 2, s.Zx1, t.dZx1, qp.gh,
@@ -639,7 +649,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 flip ^= 1;
             }
             Jobs j;
-            if (!(ride && k > 0)) tail_jobs(j, g, dz_global, s.hdz, s.x2, s.Z, s.R, s.xout, gg + GT);
+            tail_jobs(j, g, dz_global, s.hdz, s.x2, s.Z, s.R, s.xout, gg + GT, (ride && k > 0) ? rider_jobs() : 0, 10);
             j.add(t.dZx1, x_in, 0, g.n, gg[0], D, gg[1]);
             j.add(t.dP, s.Zx1, 1, g.n, gg[2], 3 * D, nullptr);
             j.add(t.dP + pl, s.Zx1, 1, g.n, gg[2] + D, 3 * D, nullptr);

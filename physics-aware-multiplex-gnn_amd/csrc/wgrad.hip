@@ -48,8 +48,13 @@ inline int target_slots() {
     static int t = [] { const char* e = getenv("PAMNET_WGRAD_SLOTS"); return e ? atoi(e) : 256; }();
     return t;
 }
-inline int64_t plan_chunk(int64_t njobs, const int64_t* rows, int64_t max_slots) {
-    int64_t chunk = ROWS_PER_WG;
+// rows per rider slot to start from (a rider should not outlast the node chain it rides with: ~26 us)
+inline int64_t rider_rows() {
+    static int64_t v = [] { const char* e = getenv("PAMNET_RIDER_ROWS"); return (int64_t)(e ? atoi(e) : 256); }();
+    return v;
+}
+inline int64_t plan_chunk(int64_t njobs, const int64_t* rows, int64_t max_slots, int64_t first_chunk = ROWS_PER_WG) {
+    int64_t chunk = first_chunk;
     for (;; chunk += RB) {
         int64_t slots = 0;
         for (int64_t j = 0; j < njobs; ++j) slots += job_slots(rows[j], chunk);
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(WG) void wgrad_finish_kernel(WBatch batch, const fl
 // EARLIER batches (the remaining blocks, 258 per job): the previous layer's main batch (with the node chain's
 // head-vector partials) and its rider batch (the slots that ran as extra workgroups of a node-chain launch).  A reduction
 // is ~16 MB of L2-resident reads that ran as a launch of its own between two weight-gradient passes; here its small
-// workgroups fill in beside the current pass.  Compact batches (<= 12 jobs): the three descriptors share the 4 KB
+// workgroups fill in beside the current pass.  Compact batches (<= 16 jobs): the three descriptors share the 4 KB
 // kernel-argument block.
 constexpr int FIN_X = DIM * DIM / 64 + 2;
 __global__ __launch_bounds__(WG) void wgrad_fused_kernel(WBatchS cur, float* __restrict__ cur_partial, WBatchS prev,
@@ -209,10 +214,10 @@ struct WgradPending {
 template <typename Batch>
 inline int build_batch(Batch& b, int64_t njobs, const float* const* dZ, const int64_t* ld_dz, const float* const* A,
                        const int64_t* ld_a, const int32_t* a_mode, const int64_t* rows, float* const* dW,
-                       const int64_t* ld_dw, float* const* db, int64_t max_slots) {
+                       const int64_t* ld_dw, float* const* db, int64_t max_slots, int64_t first_chunk = ROWS_PER_WG) {
     b.njobs = (int)njobs;
     b.start[0] = 0;
-    const int64_t chunk = plan_chunk(njobs, rows, max_slots);
+    const int64_t chunk = plan_chunk(njobs, rows, max_slots, first_chunk);
     for (int j = 0; j < njobs; ++j) {
         if (!dZ[j] || !A[j] || !dW[j]) return PAMNET_ENULL;
         b.job[j] = WJob{dZ[j], A[j], dW[j], db[j], rows[j], (int)ld_dz[j], (int)ld_a[j], (int)ld_dw[j], a_mode[j]};
@@ -354,7 +359,7 @@ extern "C" int pamnet_wgrad_rider_plan_f32(int64_t njobs, const float* const* dZ
     if (njobs < 1 || njobs > MAXJ_S || max_slots < njobs) return PAMNET_EINVAL;
     if (!dZ || !ld_dz || !A || !ld_a || !a_mode || !rows || !dW || !ld_dw || !db || !partial || !rider) return PAMNET_ENULL;
     WgradRider* r = static_cast<WgradRider*>(rider);
-    const int rc = build_batch(r->batch, njobs, dZ, ld_dz, A, ld_a, a_mode, rows, dW, ld_dw, db, max_slots);
+    const int rc = build_batch(r->batch, njobs, dZ, ld_dz, A, ld_a, a_mode, rows, dW, ld_dw, db, max_slots, rider_rows());
     if (rc) return rc;
     r->partial = partial;
     r->slots = r->batch.start[njobs];

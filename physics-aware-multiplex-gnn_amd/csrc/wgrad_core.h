@@ -33,7 +33,7 @@ struct WBatchT {
     int start[MJ + 1];            // slot prefix: job j owns slots [start[j], start[j+1])
     int njobs;
 };
-constexpr int MAXJ = 24, MAXJ_S = 12;
+constexpr int MAXJ = 24, MAXJ_S = 16;
 using WBatch = WBatchT<MAXJ>;     // stand-alone launches (up to 24 jobs)
 using WBatchS = WBatchT<MAXJ_S>;  // compact form: three of them fit the 4 KB kernel-argument block (fused launches, riders)
 

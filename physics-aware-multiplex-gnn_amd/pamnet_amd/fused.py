@@ -253,7 +253,7 @@ class _GlobalLayer(torch.autograd.Function):
         z, ea, x2 = _empty(m, D, like=x), _empty(m, D, like=x), _empty(n, D, like=x)
         # message MLP + add-aggregation, one kernel: x2 = x1 + sum_{e -> i} msg_e   (global_message_passing.py:38,52-56)
         lib.call('pamnet_global_edge_agg_fwd_f32', lib.ptr(e), m, n, _sub(Wm, 2 * D), 3 * D, lib.ptr(bm), lib.ptr(Wea), D,
-                 lib.ptr(P[0]), lib.ptr(P[1]), lib.ptr(csr.ptr), lib.ptr(csr.row_of), lib.ptr(csr.col), lib.ptr(x1),
+                 lib.ptr(P[0]), lib.ptr(P[1]), lib.ptr(csr.ptr), lib.ptr(csr.row_of), lib.ptr(csr.col), None, lib.ptr(x1),
                  lib.ptr(z), lib.ptr(ea), lib.ptr(x2), st)
         Z, R, x_out, out, att = k_tail_fwd(x2, x, tp)
         ctx.save_for_backward(x, e, Zx1, z, ea, x2, Z, R, x_out, *params)
@@ -276,7 +276,7 @@ class _GlobalLayer(torch.autograd.Function):
         dZ, d_x2, d_resx = k_tail_bwd(g_x, g_out, g_att, tp, Z, gt[20], gt[21], gt[22])
         dz, dea, d_e = _empty(m, D, like=x), _empty(m, D, like=x), _empty(m, D, like=x)
         dP = _empty(2, n, D, like=x)
-        lib.call('pamnet_global_edge_agg_bwd_f32', lib.ptr(d_x2), m, n, lib.ptr(csr.ptr), lib.ptr(csr.row_of), lib.ptr(z),
+        lib.call('pamnet_global_edge_agg_bwd_f32', lib.ptr(d_x2), m, n, lib.ptr(csr.ptr), lib.ptr(csr.row_of), None, lib.ptr(z),
                  lib.ptr(ea), _sub(Wm, 2 * D), 3 * D, lib.ptr(Wea), D, lib.ptr(dz), lib.ptr(dea), lib.ptr(d_e), 0,
                  lib.ptr(dP[0]), st)                                                    # d P_i (edges into i) fused
         segment_sum_raw(dP[1], None, dz, None, None, None, tr.perm, tr.ptr, n, D)       # d P_j: edges out of j

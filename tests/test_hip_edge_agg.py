@@ -81,8 +81,12 @@ def test_global_edge_agg_fwd_bwd(dev, case):
     sub = lambda w, c0: w.data_ptr() + 4 * c0
     z, ea = (torch.full((max(m, 1), D), float('nan'), device=dev)[:m] for _ in range(2))
     out = torch.full((n, D), float('nan'), device=dev)
+    # the node-aligned work split, precomputed once per graph (first call) / derived by every workgroup itself (second call)
+    cuts_t = torch.full((257,), -1, dtype=torch.int32, device=dev)
+    lib.call('pamnet_seg_cuts_i32', lib.ptr(ptr), lib.ptr(row_of), n, m, lib.ptr(cuts_t), None, st)
+    cuts = lib.ptr(cuts_t)
     lib.call('pamnet_global_edge_agg_fwd_f32', lib.ptr(e), m, n, sub(Wm, 2 * D), 3 * D, lib.ptr(bm), lib.ptr(Wea), D,
-             lib.ptr(Pi), lib.ptr(Pj), lib.ptr(ptr), lib.ptr(row_of), lib.ptr(col), lib.ptr(init), lib.ptr(z),
+             lib.ptr(Pi), lib.ptr(Pj), lib.ptr(ptr), lib.ptr(row_of), lib.ptr(col), cuts, lib.ptr(init), lib.ptr(z),
              lib.ptr(ea), lib.ptr(out), st)
     z64, ea64, msg64, out64 = _ref_fwd(e, Wm, bm, Wea, Pi, Pj, row_of, col, init, n)
     assert torch.isfinite(out).all()
@@ -91,8 +95,9 @@ def test_global_edge_agg_fwd_bwd(dev, case):
         assert maxnorm_err(z.cpu(), z64.cpu()) < 2e-6 and maxnorm_err(ea.cpu(), ea64.cpu()) < 2e-6
     # inference mode: no saves, same result bit for bit; run-to-run bitwise identical
     out2 = torch.empty_like(out)
+    cuts = None
     lib.call('pamnet_global_edge_agg_fwd_f32', lib.ptr(e), m, n, sub(Wm, 2 * D), 3 * D, lib.ptr(bm), lib.ptr(Wea), D,
-             lib.ptr(Pi), lib.ptr(Pj), lib.ptr(ptr), lib.ptr(row_of), lib.ptr(col), lib.ptr(init), None, None,
+             lib.ptr(Pi), lib.ptr(Pj), lib.ptr(ptr), lib.ptr(row_of), lib.ptr(col), cuts, lib.ptr(init), None, None,
              lib.ptr(out2), st)
     assert torch.equal(out, out2)
     # against the unfused pair (edge kernel + scatter-add kernel): same maths, different summation order
@@ -105,11 +110,12 @@ def test_global_edge_agg_fwd_bwd(dev, case):
         assert torch.equal(z, z3) and torch.equal(ea, ea3)
         assert maxnorm_err(out.cpu(), out3.cpu()) < 2e-6
 
-    # ---- backward
+    # ---- backward (first call with the precomputed work split, the accumulate call without)
     d_agg = mk(n, D)
+    bcuts = lib.ptr(cuts_t)
     dz, dea, d_e = (torch.full((max(m, 1), D), float('nan'), device=dev)[:m] for _ in range(3))
     dPi = torch.full((n, D), float('nan'), device=dev)
-    lib.call('pamnet_global_edge_agg_bwd_f32', lib.ptr(d_agg), m, n, lib.ptr(ptr), lib.ptr(row_of), lib.ptr(z),
+    lib.call('pamnet_global_edge_agg_bwd_f32', lib.ptr(d_agg), m, n, lib.ptr(ptr), lib.ptr(row_of), bcuts, lib.ptr(z),
              lib.ptr(ea), sub(Wm, 2 * D), 3 * D, lib.ptr(Wea), D, lib.ptr(dz), lib.ptr(dea), lib.ptr(d_e), 0,
              lib.ptr(dPi), st)
     dm = d_agg.double()[row_of.long()]
@@ -125,7 +131,8 @@ def test_global_edge_agg_fwd_bwd(dev, case):
             assert maxnorm_err(a.cpu(), b.cpu()) < 3e-6
         # accumulate flag
         d_e2 = d_e.clone()
-        lib.call('pamnet_global_edge_agg_bwd_f32', lib.ptr(d_agg), m, n, lib.ptr(ptr), lib.ptr(row_of), lib.ptr(z),
+        bcuts = None
+        lib.call('pamnet_global_edge_agg_bwd_f32', lib.ptr(d_agg), m, n, lib.ptr(ptr), lib.ptr(row_of), bcuts, lib.ptr(z),
                  lib.ptr(ea), sub(Wm, 2 * D), 3 * D, lib.ptr(Wea), D, lib.ptr(dz), lib.ptr(dea), lib.ptr(d_e2), 1,
                  lib.ptr(dPi), st)
         assert maxnorm_err(d_e2.cpu(), (2 * de64).cpu()) < 3e-6
@@ -149,8 +156,9 @@ def test_fused_result_independent_of_batching(dev):
         row_of = torch.from_numpy(np.repeat(np.arange(n), deg)).to(torch.int32).to(dev)
         col = torch.from_numpy(col_np).to(torch.int32).to(dev)
         out = torch.empty(n, D, device=dev)
+        cuts = None
         lib.call('pamnet_global_edge_agg_fwd_f32', lib.ptr(e), e.size(0), n, sub(Wm, 2 * D), 3 * D, lib.ptr(bm),
-                 lib.ptr(Wea), D, lib.ptr(Pi), lib.ptr(Pj), lib.ptr(ptr), lib.ptr(row_of), lib.ptr(col), lib.ptr(init),
+                 lib.ptr(Wea), D, lib.ptr(Pi), lib.ptr(Pj), lib.ptr(ptr), lib.ptr(row_of), lib.ptr(col), cuts, lib.ptr(init),
                  None, None, lib.ptr(out), lib.stream_of(e))
         return out
 

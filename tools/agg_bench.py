@@ -47,6 +47,9 @@ e, Pi, Pj, x1 = rnd(eg, D), rnd(n, D), rnd(n, D), rnd(n, D)
 z, ea, msg = (torch.empty(eg, D, device=dev) for _ in range(3))
 out = torch.empty(n, D, device=dev)
 csr = g.glob
+cuts_t = torch.empty(257, dtype=torch.int32, device=dev)
+lib.call('pamnet_seg_cuts_i32', lib.ptr(csr.ptr), lib.ptr(csr.row_of), n, eg, lib.ptr(cuts_t), None, st)
+cuts = lib.ptr(cuts_t)
 
 
 def unfused(save):
@@ -58,7 +61,7 @@ def unfused(save):
 
 def fusedk(save):
     lib.call('pamnet_global_edge_agg_fwd_f32', lib.ptr(e), eg, n, sub(Wm, 2 * D), 3 * D, lib.ptr(bm), lib.ptr(Wea), D,
-             lib.ptr(Pi), lib.ptr(Pj), lib.ptr(csr.ptr), lib.ptr(csr.row_of), lib.ptr(csr.col), lib.ptr(x1),
+             lib.ptr(Pi), lib.ptr(Pj), lib.ptr(csr.ptr), lib.ptr(csr.row_of), lib.ptr(csr.col), cuts, lib.ptr(x1),
              lib.ptr(z) if save else None, lib.ptr(ea) if save else None, lib.ptr(out), st)
 
 
@@ -82,7 +85,7 @@ def bwd_unfused():
 
 
 def bwd_fused():
-    lib.call('pamnet_global_edge_agg_bwd_f32', lib.ptr(d_agg), eg, n, lib.ptr(csr.ptr), lib.ptr(csr.row_of), lib.ptr(z),
+    lib.call('pamnet_global_edge_agg_bwd_f32', lib.ptr(d_agg), eg, n, lib.ptr(csr.ptr), lib.ptr(csr.row_of), cuts, lib.ptr(z),
              lib.ptr(ea), sub(Wm, 2 * D), 3 * D, lib.ptr(Wea), D, lib.ptr(dz), lib.ptr(dea), lib.ptr(d_e), 1, lib.ptr(dP[0]), st)
     segment_sum_raw(dP[1], None, dz, None, None, None, gT.perm, gT.ptr, n, D)
 
