@@ -335,15 +335,27 @@ def main():
             dist.destroy_process_group()
         return
 
-    # forward-only rate (reported beside the training rate; not `value`)
-    fsteps = min(args.steps, 100)
+    # forward-only rate (reported beside the training rate; not `value`): the product's forward-only loop is
+    # train.predict -- the counterpart of test() in main_qm9.py:29-37 -- which builds the graph of batch i+1 on a side stream
+    # while batch i runs (every batch's graph is still built inside the timed region); the plain loop of model(batch)
+    # calls, each stalling on its own graph's size round trip, is reported beside it.
+    from pamnet_amd.train import predict
+    fsteps = min(args.steps, 200)
     with torch.no_grad():
         for i in range(2):
-            model(batches[i % len(batches)])
+            model(batches[i % nb])
         sync()
         t0 = time.perf_counter()
         for i in range(fsteps):
-            model(batches[i % len(batches)])
+            model(batches[i % nb])
+        sync()
+        fwd_plain_ms = (time.perf_counter() - t0) / fsteps * 1e3
+        for _ in predict(model, (batches[i % nb] for i in range(4))):
+            pass
+        sync()
+        t0 = time.perf_counter()
+        for _ in predict(model, (batches[i % nb] for i in range(fsteps))):
+            pass
         sync()
         fwd_ms = (time.perf_counter() - t0) / fsteps * 1e3
 
@@ -364,6 +376,7 @@ def main():
                        'triplets': int(g.n_trip), 'pairs': int(g.n_pair)},
             'timed_region_s': dt,
             'forward_only_molecules_per_s': gB / (fwd_ms / 1e3), 'forward_ms': fwd_ms,
+            'forward_ms_unpipelined': fwd_plain_ms,
             'mfma': mfma_summary(args, g, ms_per_step),
         }
         if not args.no_rooflines:

@@ -68,6 +68,12 @@ int pamnet_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_
 /* Stable counting sort of m keys in [0, rows): ptr[rows+1] (CSR) and perm[m] with keys[perm[q]] non-decreasing and
  * perm ascending inside a row.  Scratch: `cursor` rows ints, `perm_tmp` m ints, `tmp` ceil(rows/4096)+1 ints (the scan's
  * chunk sums plus one flag: an already non-decreasing key sequence takes the identity-permutation path).  Deterministic. */
+/* flag[0] = 1 when the index inputs of a batch are out of range (the reference would raise an IndexError): node_graph not
+ * sorted / not in [0, n_graphs), a type (float, element i at types[i * type_stride]; nullable) not in [0, n_types), an
+ * edge endpoint (src / dst, nullable with n_edges = 0) not in [0, n).  One launch; flag is zeroed by the call. */
+int pamnet_validate_inputs_i32(const int32_t* node_graph, int64_t n, int64_t n_graphs, const float* types,
+                               int64_t type_stride, int64_t n_types, const int32_t* src, const int32_t* dst,
+                               int64_t n_edges, int32_t* flag, pamnet_stream_t stream);
 int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t rows, int32_t* ptr, int32_t* perm,
                              int32_t* cursor, int32_t* perm_tmp, int32_t* tmp, pamnet_stream_t stream);
 

@@ -683,3 +683,52 @@ extern "C" int pamnet_triplet_fill_f32(const float* pos, const int32_t* lptr, co
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
+
+
+// ---- input validation ---------------------------------------------------------------------------------------------------
+// One launch instead of a dozen tiny tensor ops per batch: flag[0] = 1 when `node_graph` is not sorted / not in
+// [0, n_graphs), an atom type (float, read with `type_stride`) is not in [0, n_types), or an edge endpoint is not in [0, n).
+namespace {
+__global__ __launch_bounds__(256) void validate_inputs_kernel(const int32_t* __restrict__ node_graph, int64_t n,
+                                                              int64_t n_graphs, const float* __restrict__ types,
+                                                              int64_t type_stride, int64_t n_types,
+                                                              const int32_t* __restrict__ src,
+                                                              const int32_t* __restrict__ dst, int64_t n_edges,
+                                                              int32_t* __restrict__ flag) {
+    const int64_t total = n > n_edges ? n : n_edges;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n) {
+            const int g = node_graph[i];
+            bad |= g < 0 || g >= n_graphs || (i > 0 && node_graph[i - 1] > g);
+            if (types) {
+                const float t = types[i * type_stride];
+                bad |= !(t >= 0.f && t < (float)n_types);
+            }
+        }
+        if (i < n_edges) {
+            const int a = src[i], b = dst[i];
+            bad |= a < 0 || a >= n || b < 0 || b >= n;
+        }
+    }
+    if (bad) flag[0] = 1;
+}
+}  // namespace
+
+extern "C" int pamnet_validate_inputs_i32(const int32_t* node_graph, int64_t n, int64_t n_graphs, const float* types,
+                                          int64_t type_stride, int64_t n_types, const int32_t* src, const int32_t* dst,
+                                          int64_t n_edges, int32_t* flag, pamnet_stream_t stream) {
+    if (n < 0 || n_graphs < 0 || n_edges < 0) return PAMNET_EINVAL;
+    if (!flag || (n > 0 && !node_graph) || (n_edges > 0 && (!src || !dst))) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const hipError_t e = hipMemsetAsync(flag, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return (int)e;
+    const int64_t total = n > n_edges ? n : n_edges;
+    if (total == 0) return PAMNET_OK;
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(validate_inputs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, node_graph, n, n_graphs, types,
+                       type_stride, n_types, src, dst, n_edges, flag);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}

@@ -14,7 +14,7 @@ import os
 import torch
 
 from . import lib
-from .ops import gather_mul_raw, segment_sum_raw
+from .ops import apply as _apply, gather_mul_raw, segment_sum_raw
 
 D = 128
 
@@ -195,7 +195,7 @@ class _Embed(torch.autograd.Function):
                  lib.ptr(b1), 1 if act else 0, lib.ptr(out), lib.stream_of(out))
         ctx.save_for_backward(x, kind, *[p for p in params if p is not None])
         ctx.layout = [p is not None for p in params]
-        ctx.act, ctx.plist, ctx.need_dx = act, plist, ctx.needs_input_grad[0]
+        ctx.act, ctx.plist, ctx.need_dx = act, plist, bool(ctx.needs_input_grad and ctx.needs_input_grad[0])
         return out
 
     @staticmethod
@@ -228,7 +228,7 @@ def embed(x, lin0, lin1=None, kind=None, act=True):
     if lin1 is not None:
         params += [lin1.weight, lin1.bias]
     plist = [p for p in params if p is not None]
-    return _Embed.apply(x, kind, act, plist, *params)
+    return _apply(_Embed, x, kind, act, plist, *params)       # no-grad mode: straight to the kernel, no autograd node
 
 
 def embed_supported(x, lin):
@@ -560,6 +560,10 @@ def layer_stack(global_layers, local_layers, x0, e_g, rbf_e, e_sbf, graph):
     save = torch.is_grad_enabled()
     if save and plan.direct():
         return _Stack.apply(x0, e_g, rbf_e, e_sbf, graph, plan, True, True)
+    if not save:
+        # forward-only: no autograd node (handing ~400 parameters to Function.apply costs ~0.1 ms of host time per
+        # batch -- the forward-only loop is bound by the host, not by the 0.8 ms of kernels)
+        return _apply(_Stack, x0, e_g, rbf_e, e_sbf, graph, plan, False, False)
     return _Stack.apply(x0, e_g, rbf_e, e_sbf, graph, plan, False, save, *plan.flat)
 
 

@@ -198,17 +198,23 @@ def _triplet_ptr(lp, l_src, l_dst, with_triplets):
     return exclusive_scan(tpcount)
 
 
-def _input_flag(batch, n_graphs, types=None, n_types=None, edge_index=None):
-    """Device-side validity flag of the index inputs (the kernels write count[key] / cursor[key] for whatever key they
-    are given): `batch` sorted with ids in [0, n_graphs), atom types in [0, n_types), edge endpoints in [0, N).  Returned
-    as a 0-dim bool tensor that travels back with the data-dependent sizes in the SAME host round trip."""
-    n = batch.numel()
-    bad = (batch[-1] >= n_graphs) | (batch[0] < 0) | (batch[1:] < batch[:-1]).any()
+def _input_flag(node_graph, n_graphs, types=None, n_types=None, src=None, dst=None):
+    """Device-side validity flag of the index inputs (the kernels index with whatever they are given): `node_graph`
+    (int32) sorted with ids in [0, n_graphs), atom types (a float column, possibly strided) in [0, n_types), edge
+    endpoints (int32) in [0, N).  One launch; the flag travels back with the data-dependent sizes in the SAME host round
+    trip."""
+    flag = _i32(1, node_graph.device)
+    ne = 0 if src is None else int(src.numel())
+    stride = 0
     if types is not None and n_types is not None:
-        bad = bad | (types < 0).any() | (types >= n_types).any()
-    if edge_index is not None and edge_index.numel():
-        bad = bad | (edge_index.min() < 0) | (edge_index.max() >= n)
-    return bad
+        assert types.dtype == torch.float32 and types.dim() == 1
+        stride = types.stride(0) if types.numel() > 1 else 1
+    else:
+        types = None
+    lib.call('pamnet_validate_inputs_i32', lib.ptr(node_graph), node_graph.numel(), int(n_graphs),
+             None if types is None else types.data_ptr(), stride, int(n_types or 0), lib.ptr(src) if ne else None,
+             lib.ptr(dst) if ne else None, ne, lib.ptr(flag), lib.stream_of(node_graph))
+    return flag
 
 
 def _raise_bad_inputs():
@@ -239,6 +245,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         # with the sizes, and a batch that does have self loops is redone the slow way.
         def bonds(ei):
             src0, dst0 = ei[0].to(I32).contiguous(), ei[1].to(I32).contiguous()    # j, i = edge_index (models.py:64)
+            bonds.raw = (src0, dst0)
             lp_, perm = csr_from_keys(dst0, n)
             pl = perm.long()
             src_, dst_ = src0[pl].contiguous(), dst0[pl].contiguous()
@@ -248,8 +255,9 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         keep = ei[0] != ei[1]
         lp, l_src, l_dst, tp_ptr = bonds(ei)
         gptr_g = radius_count(pos, node_graph, g.gptr, cutoff_g)               # symmetric: agg = query, other = nbr
+        types = x_raw.to(torch.float32).reshape(-1)
         total_g, all_kept, tp_total, bad = host_ints(gptr_g[-1], keep.all(), tp_ptr[-1],
-                                                     _input_flag(batch, g.n_graphs, x_raw, n_types, ei))
+                                                     _input_flag(node_graph, g.n_graphs, types, n_types, *bonds.raw))
         if bad:
             _raise_bad_inputs()
         if not all_kept:
@@ -263,7 +271,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         pos = xr[:, :3].to(torch.float32).contiguous()
         g.sign = torch.where(pos[:, 0] > 40.0, -torch.ones_like(pos[:, 0]), torch.ones_like(pos[:, 0])).contiguous()
         gp, gn, gd = radius_graph(pos, node_graph, g.gptr, cutoff_g)
-        lp, l_src, l_dist = csr_filter(gp, gn, gd, cutoff_l, _input_flag(batch, g.n_graphs))   # models.py:131-134
+        lp, l_src, l_dist = csr_filter(gp, gn, gd, cutoff_l, _input_flag(node_graph, g.n_graphs))   # models.py:131-134
         l_dst = expand_rows(lp, l_src.numel())
     elif rna:
         xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
@@ -271,7 +279,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         kp, kn, kd = knn_table(pos, node_graph, g.gptr, knn_k, float('inf'))   # (query, neighbour) rows, self dropped
         # models.py:147-150 (global) and 153-156 (local: j = query, i = nbr)
         (gp, gn, gd), (qp, qn, qd) = csr_filter2(kp, kn, kd, cutoff_g, cutoff_l,
-                                                 _input_flag(batch, g.n_graphs, xr[:, -1], n_types))
+                                                 _input_flag(node_graph, g.n_graphs, xr[:, -1].to(torch.float32), n_types))
         if flow != 'target_to_source':                                          # aggregate at edge_index[1] = neighbour
             gp, gn, gd = _transpose_edges(gp, gn, gd, n)
         lp, l_src, l_dist = _transpose_edges(qp, qn, qd, n)                    # local layer always aggregates at i

@@ -23,6 +23,9 @@ class _NoGradCtx(object):
     def mark_non_differentiable(self, *tensors):
         pass
 
+    def set_materialize_grads(self, value):
+        pass
+
 
 def apply(fn, *args):
     if torch.is_grad_enabled():
