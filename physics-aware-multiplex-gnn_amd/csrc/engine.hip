@@ -313,8 +313,14 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
     const int64_t mlp_tiles = (g.tp + 15) / 16, mlp_half = mlp_tiles / 2;
     const int64_t rider_wgs = RIDER_MAX_SLOTS - (g.n + 15) / 16;
     // Without the fork: the triplet/pair MLPs of up to 8 layers at a time as one launch ahead of the layer loop.
-    if (!forked && g.tp > 0) {
-        const int64_t n_up = ride ? 1 : n_layer;
+    if (!forked && g.tp > 0 && ride) {
+        // layer 0: the first half of its row tiles as a launch of its own, the second half rides in the first chain launch
+        const float* const* lp = lparams;
+        const LocalSaved q = carve_local(saved + gs, g);
+        if (mlp_half > 0)
+            CK(pamnet_mlp2_fwd_f32(e_sbf, mlp_half * 16, lp[6], lp[7], lp[8], lp[9], sv(q.z1), sv(q.z2), q.s, st));
+    } else if (!forked && g.tp > 0) {
+        const int64_t n_up = n_layer;
         for (int64_t k0 = 0; k0 < n_up; k0 += 8) {
             const int64_t nk = n_up - k0 < 8 ? n_up - k0 : 8;
             const float* prm[32];
@@ -380,7 +386,7 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         const float* const* lp = lparams + k * NL;
         const LocalSaved q = carve_local(saved + k * (gs + ls) + gs, g);
         const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
-        if (ride && k > 0) {
+        if (ride) {
             const float* mp[4] = {lp[6], lp[7], lp[8], lp[9]};
             float* mo[3] = {sv(q.z1), sv(q.z2), q.s};
             CK(pamnet_node_tail_fwd_rider_f32(s.x2, x, g.n, img[k].gt, gp + GT + 10, gp[GT + 20], gp[GT + 21], gp[GT + 22],
