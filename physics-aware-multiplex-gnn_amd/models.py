@@ -122,30 +122,30 @@ class _PAMNetBase(nn.Module):
             data._pamnet_prepared = self._graph(data)
         return data
 
-    def _embed(self, data, g):
+    def _embed(self, data, g, tape=None):
         x_raw = data.x
         if self.dataset == 'PDBbind':
             xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
             feats = xr[:, 3:].to(torch.float32)
             if modules.IMPL == 'fused' and fused.embed_supported(feats, self.init_linear):
-                return fused.embed(feats, self.init_linear, act=False)                     # models.py:119
+                return fused.embed(feats, self.init_linear, act=False, tape=tape)          # models.py:119
             return F.linear(feats, self.init_linear.weight)
         col = x_raw if self.dataset == 'QM9' else (x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw)[:, -1]
         idx = col.to(torch.int32).contiguous()
         if ops.type_rows_supported(self.embeddings):                                    # models.py:107,140
-            direct = self.embeddings.grad if (torch.is_grad_enabled() and self.embeddings.grad is not None
+            direct = self.embeddings.grad if ((tape is not None or torch.is_grad_enabled()) and self.embeddings.grad is not None
                                               and getattr(self.embeddings, '_pamnet_direct', False)) else None
-            return ops.type_rows(self.embeddings, idx, direct)
+            return ops.type_rows(self.embeddings, idx, direct, tape=tape)
         tr = G.Transpose(idx, self.embeddings.size(0)) if torch.is_grad_enabled() else None
         return ops.gather(self.embeddings, idx, tr.ptr if tr else None, tr.perm if tr else None)
 
-    def _edge_embeddings(self, g):
-        rbf_l = self.rbf_l(g.dist_l)
-        rbf_g = self.rbf_g(g.dist_g)
+    def _edge_embeddings(self, g, tape=None):
+        rbf_l = self.rbf_l(g.dist_l, tape=tape)
+        rbf_g = self.rbf_g(g.dist_g, tape=tape)
         sbf = g.sbf                                                                          # [T+P, 42], no grad
         if self._embed_fused(rbf_l, self.mlp_rbf_l):
-            e_l = fused.embed(rbf_l, self.mlp_rbf_l[0][0])                                   # models.py:186
-            e_g = fused.embed(rbf_g, self.mlp_rbf_g[0][0])                                   # models.py:185
+            e_l = fused.embed(rbf_l, self.mlp_rbf_l[0][0], tape=tape, need_dx=True)          # models.py:186
+            e_g = fused.embed(rbf_g, self.mlp_rbf_g[0][0], tape=tape, need_dx=True)          # models.py:185
         elif self._narrow(rbf_l):
             e_l = narrow.embed(rbf_l, self.mlp_rbf_l[0][0])
             e_g = narrow.embed(rbf_g, self.mlp_rbf_g[0][0])
@@ -161,9 +161,9 @@ class _PAMNetBase(nn.Module):
     def _embed_fused(x, seq):
         return modules.IMPL == 'fused' and len(seq) == 1 and fused.embed_supported(x, seq[0][0])
 
-    def _run_layers(self, x, e_l, e_g, e_sbf, g):
+    def _run_layers(self, x, e_l, e_g, e_sbf, g, tape=None):
         if modules._fused(x):                      # dim = 128 on an MI355X: the whole loop is one engine call
-            outs, atts, saved = fused.layer_stack(self.global_layer, self.local_layer, x, e_g, e_l, e_sbf, g)
+            outs, atts, saved = fused.layer_stack(self.global_layer, self.local_layer, x, e_g, e_l, e_sbf, g, tape=tape)
             self._x_layers = _LazyLayers(saved, g, self.n_layer)
             return outs, atts
         outs, atts = [], []
@@ -174,6 +174,23 @@ class _PAMNetBase(nn.Module):
             x, o, a = self.local_layer[k](x, e_l, e_sbf, g)
             outs.append(o), atts.append(a), self._x_layers.append(x)
         return torch.stack(outs), torch.stack(atts)                                          # [2L, N]
+
+    def _one_node(self):
+        """Training forward in direct-gradient mode on the fused dim = 128 path: the whole forward is recorded on the
+        model's own tape and handed to autograd as ONE node (ops.Tape)."""
+        if not (torch.is_grad_enabled() and modules.IMPL == 'fused' and self.dim == fused.D
+                and self.rbf_g.freq.is_cuda):
+            return False
+        if not all(getattr(p, '_pamnet_direct', False) and p.grad is not None for p in self._top_params()):
+            return False
+        return fused.stack_plan(self.global_layer, self.local_layer).direct()
+
+    def _top_params(self):
+        tp = self.__dict__.get('_top_param_list')
+        if tp is None:                                   # walking the module tree costs ~1 ms: once per model
+            tp = [p for n, p in self.named_parameters() if not n.startswith(('global_layer.', 'local_layer.'))]
+            self.__dict__['_top_param_list'] = tp
+        return tp
 
     def _release_inspection(self):
         """`_x_layers` / `_graph_cache` / `_node_out` (inspection hooks of the parity tests) reference the previous
@@ -210,11 +227,16 @@ class PAMNet(_PAMNetBase):
         self._check_dataset()
         self._release_inspection()
         g = self._graph(data)
-        x = self._embed(data, g)
-        e_l, e_g, sbf = self._edge_embeddings(g)
+        if self._one_node():
+            return ops.run_whole(self.rbf_g.freq, lambda tape: self._forward_on(data, g, tape))
+        return self._forward_on(data, g, None)
+
+    def _forward_on(self, data, g, tape):
+        x = self._embed(data, g, tape)
+        e_l, e_g, sbf = self._edge_embeddings(g, tape)
         # mlp_sbf2 on triplet rows, mlp_sbf1 on pair rows (models.py:187-188), rows grouped by target edge
         if self._embed_fused(sbf, self.mlp_sbf2):
-            e_sbf = fused.embed(sbf, self.mlp_sbf2[0][0], self.mlp_sbf1[0][0], kind=g.tp_kind)
+            e_sbf = fused.embed(sbf, self.mlp_sbf2[0][0], self.mlp_sbf1[0][0], kind=g.tp_kind, tape=tape)
         elif self._narrow(sbf):
             e_sbf = narrow.embed(sbf, self.mlp_sbf2[0][0], self.mlp_sbf1[0][0], kind=g.tp_kind)
         else:
@@ -222,10 +244,10 @@ class PAMNet(_PAMNetBase):
             y1 = mlp_apply(self.mlp_sbf1, sbf.index_select(0, g.pair_rows))
             e_sbf = torch.zeros((sbf.size(0), self.dim), dtype=sbf.dtype, device=sbf.device)
             e_sbf = e_sbf.index_copy(0, g.trip_rows, y2).index_copy(0, g.pair_rows, y1)
-        outs, atts = self._run_layers(x, e_l, e_g, e_sbf, g)
-        out, node_out = ops.fuse_pool(outs, atts, g, mean=self._rna)                       # models.py:206-224
+        outs, atts = self._run_layers(x, e_l, e_g, e_sbf, g, tape)
+        out, node_out = ops.fuse_pool(outs, atts, g, mean=self._rna, tape=tape)             # models.py:206-224
         self._graph_cache, self._node_out = g, node_out
-        return out.view(-1)
+        return out if tape is not None else out.view(-1)        # (ops._Whole hands autograd its own view)
 
 
 class PAMNet_s(_PAMNetBase):
@@ -248,15 +270,20 @@ class PAMNet_s(_PAMNetBase):
             raise ValueError("Invalid dataset. The current PAMNet_s is only for QM9 experiments.")
         self._release_inspection()
         g = self._graph(data)
-        x = self._embed(data, g)
-        e_l, e_g, sbf = self._edge_embeddings(g)
+        if self._one_node():
+            return ops.run_whole(self.rbf_g.freq, lambda tape: self._forward_on(data, g, tape))
+        return self._forward_on(data, g, None)
+
+    def _forward_on(self, data, g, tape):
+        x = self._embed(data, g, tape)
+        e_l, e_g, sbf = self._edge_embeddings(g, tape)
         if self._embed_fused(sbf, self.mlp_sbf):
-            e_sbf = fused.embed(sbf, self.mlp_sbf[0][0])
+            e_sbf = fused.embed(sbf, self.mlp_sbf[0][0], tape=tape)
         elif self._narrow(sbf):
             e_sbf = narrow.embed(sbf, self.mlp_sbf[0][0])
         else:
             e_sbf = mlp_apply(self.mlp_sbf, sbf)
-        outs, atts = self._run_layers(x, e_l, e_g, e_sbf, g)
-        out, node_out = ops.fuse_pool(outs, atts, g, mean=False)
+        outs, atts = self._run_layers(x, e_l, e_g, e_sbf, g, tape)
+        out, node_out = ops.fuse_pool(outs, atts, g, mean=False, tape=tape)
         self._graph_cache, self._node_out = g, node_out
-        return out.view(-1)
+        return out if tape is not None else out.view(-1)        # (ops._Whole hands autograd its own view)

@@ -222,13 +222,15 @@ class _Embed(torch.autograd.Function):
         return (dx, None, None, None) + grads
 
 
-def embed(x, lin0, lin1=None, kind=None, act=True):
-    """lin0 / lin1: nn.Linear(K -> 128); lin1 with `kind` (int32 [rows], 0 -> lin0, 1 -> lin1)."""
+def embed(x, lin0, lin1=None, kind=None, act=True, tape=None, need_dx=False):
+    """lin0 / lin1: nn.Linear(K -> 128); lin1 with `kind` (int32 [rows], 0 -> lin0, 1 -> lin1).  tape / need_dx: see
+    ops.Tape (need_dx: the input's gradient is wanted -- autograd's needs_input_grad[0] when there is no autograd)."""
     params = [lin0.weight, lin0.bias]
     if lin1 is not None:
         params += [lin1.weight, lin1.bias]
     plist = [p for p in params if p is not None]
-    return _apply(_Embed, x, kind, act, plist, *params)       # no-grad mode: straight to the kernel, no autograd node
+    # no-grad mode: straight to the kernel, no autograd node
+    return _apply(_Embed, x, kind, act, plist, *params, tape=tape, needs=(need_dx,))
 
 
 def embed_supported(x, lin):
@@ -550,14 +552,21 @@ class _Stack(torch.autograd.Function):
         return (d_x0, d_eg, d_rbf, d_sbf, None, None, None, None) + tuple(g)
 
 
-def layer_stack(global_layers, local_layers, x0, e_g, rbf_e, e_sbf, graph):
-    """Returns outs [2L,N], atts [2L,N] and the saved-activation arena (see stack_x_layers)."""
+def stack_plan(global_layers, local_layers):
     plan = getattr(global_layers, '_pamnet_plan', None)
     if plan is None or plan.L != len(global_layers):
         plan = StackPlan(global_layers, local_layers)
         global_layers._pamnet_plan = plan
+    return plan
+
+
+def layer_stack(global_layers, local_layers, x0, e_g, rbf_e, e_sbf, graph, tape=None):
+    """Returns outs [2L,N], atts [2L,N] and the saved-activation arena (see stack_x_layers)."""
+    plan = stack_plan(global_layers, local_layers)
     # inference (no gradient mode): the engine skips every store only the backward would read
     save = torch.is_grad_enabled()
+    if tape is not None:                       # direct-gradient mode on the model's own tape (ops.Tape)
+        return tape.call(_Stack, (), x0, e_g, rbf_e, e_sbf, graph, plan, True, True)
     if save and plan.direct():
         return _Stack.apply(x0, e_g, rbf_e, e_sbf, graph, plan, True, True)
     if not save:

@@ -63,8 +63,8 @@ class BesselBasis(nn.Module):
         self.cutoff = cutoff
         self.freq = nn.Parameter(torch.arange(1, num_radial + 1, dtype=torch.float32) * math.pi)
 
-    def forward(self, dist):
-        return ops.rbf(dist, self.freq, self.cutoff)
+    def forward(self, dist, tape=None):
+        return ops.rbf(dist, self.freq, self.cutoff, tape=tape)
 
 
 def glorot_(t):

@@ -27,10 +27,91 @@ class _NoGradCtx(object):
         pass
 
 
-def apply(fn, *args):
+def apply(fn, *args, tape=None, needs=()):
+    """fn.apply(*args) under autograd; straight fn.forward without a tape in no-grad mode; or -- `tape` given -- run on
+    the model's own Tape (one autograd node for the whole forward, see Tape)."""
+    if tape is not None:
+        return tape.call(fn, needs, *args)
     if torch.is_grad_enabled():
         return fn.apply(*args)
     return fn.forward(_NoGradCtx(), *args)
+
+
+class _TapeCtx(object):
+    """The slice of torch.autograd.function.FunctionCtx the Functions of this package use."""
+
+    def __init__(self, needs):
+        self.needs_input_grad = needs
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+
+class Tape(object):
+    """A training forward of PAMNet is a fixed chain of eight of this package's autograd Functions (type gather, two
+    Bessel bases, three embeddings, the layer stack, fusion + pooling).  Handing them to torch's autograd engine one by
+    one costs ~0.4 ms of host time per step (node bookkeeping, the hop to the engine's device thread, AccumulateGrad) --
+    with the step at 2.7 ms and the host loop at 2.6 ms that was the next bound.  In direct-gradient mode
+    (train.FlatParams: the kernels write parameter gradients in place) the chain is recorded here instead and the whole
+    forward is ONE autograd node (`_Whole`) whose backward replays the Functions' own `backward` bodies in reverse."""
+
+    def __init__(self):
+        self.nodes = []
+
+    def call(self, fn, needs, *args):
+        ctx = _TapeCtx(needs)
+        out = fn.forward(ctx, *args)
+        self.nodes.append((fn, ctx, args, out if isinstance(out, tuple) else (out,)))
+        return out
+
+    def backward(self, out, grad):
+        grads = {id(out): grad}
+        for fn, ctx, args, outs in reversed(self.nodes):
+            gouts = [grads.pop(id(o), None) for o in outs]
+            if all(g is None for g in gouts):
+                continue
+            gin = fn.backward(ctx, *gouts)
+            if not isinstance(gin, tuple):
+                gin = (gin,)
+            for a, g in zip(args, gin):
+                if g is None or not isinstance(a, torch.Tensor):
+                    continue
+                if isinstance(a, torch.nn.Parameter):
+                    a.grad.copy_(g)                      # direct-gradient mode: overwrite (zeroed buffer, one use)
+                elif id(a) in grads:
+                    grads[id(a)] = grads[id(a)] + g
+                else:
+                    grads[id(a)] = g
+        self.nodes = []
+
+
+class _Whole(torch.autograd.Function):
+    """The whole forward as one autograd node (see Tape).  `anchor`: any parameter that requires grad -- it makes
+    autograd record the node; every parameter gradient is written in place, so the node returns none."""
+
+    @staticmethod
+    def forward(ctx, anchor, run):
+        tape = Tape()
+        out = run(tape)
+        ctx.tape, ctx.out = tape, out
+        return out.view(-1)                  # a fresh tensor object for autograd; the tape keys on `out` itself
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.tape.backward(ctx.out, g.contiguous())
+        ctx.tape = ctx.out = None
+        return None, None
+
+
+def run_whole(anchor, run):
+    return _Whole.apply(anchor, run)
 
 
 def segment_sum_raw(out, init, A, ia, B, ib, perm, ptr, rows, d):
@@ -161,9 +242,9 @@ def type_rows_supported(table):
     return table.is_cuda and table.size(0) <= 8 and table.size(1) % 4 == 0 and 1 <= d4 <= 64 and (d4 & (d4 - 1)) == 0
 
 
-def type_rows(table, idx, direct_grad=None):
+def type_rows(table, idx, direct_grad=None, tape=None):
     """direct_grad: a preallocated gradient buffer of `table` to be overwritten in place (train.FlatParams), or None."""
-    return apply(_TypeRows, table, idx, direct_grad)
+    return apply(_TypeRows, table, idx, direct_grad, tape=tape)
 
 
 def l1_loss_with_grad(out, y, grad_scale=1.0):
@@ -250,9 +331,9 @@ def gather_mul_aggregate(A, B, csr, tr):
     return apply(_GatherMulAggregate, A, B, csr, tr)
 
 
-def rbf(dist, freq, cutoff):
-    return apply(_RBF, dist, freq, cutoff)
+def rbf(dist, freq, cutoff, tape=None):
+    return apply(_RBF, dist, freq, cutoff, tape=tape)
 
 
-def fuse_pool(outs, atts, graph, mean):
-    return apply(_FusePool, outs, atts, graph, mean)
+def fuse_pool(outs, atts, graph, mean, tape=None):
+    return apply(_FusePool, outs, atts, graph, mean, tape=tape)
