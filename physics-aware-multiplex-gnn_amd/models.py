@@ -173,17 +173,26 @@ class _PAMNetBase(nn.Module):
             outs.append(o), atts.append(a), self._x_layers.append(x)
             x, o, a = self.local_layer[k](x, e_l, e_sbf, g)
             outs.append(o), atts.append(a), self._x_layers.append(x)
-        return torch.stack(outs), torch.stack(atts)                                          # [2L, N]
+        return ops.stack_rows(outs), ops.stack_rows(atts)                                    # [2L, N]
 
     def _one_node(self):
-        """Training forward in direct-gradient mode on the fused dim = 128 path: the whole forward is recorded on the
-        model's own tape and handed to autograd as ONE node (ops.Tape)."""
-        if not (torch.is_grad_enabled() and modules.IMPL == 'fused' and self.dim == fused.D
-                and self.rbf_g.freq.is_cuda):
+        """Training forward with preallocated gradients (train.FlatParams) on the fused dim = 128 path or the narrow-width
+        row kernels: the whole forward is recorded on the model's own tape and handed to autograd as ONE node (ops.Tape)."""
+        if not (ops.TAPE and torch.is_grad_enabled() and modules.IMPL == 'fused' and self.rbf_g.freq.is_cuda):
             return False
-        if not all(getattr(p, '_pamnet_direct', False) and p.grad is not None for p in self._top_params()):
-            return False
-        return fused.stack_plan(self.global_layer, self.local_layer).direct()
+        if self.dim == fused.D:
+            if not all(getattr(p, '_pamnet_direct', False) and p.grad is not None for p in self._top_params()):
+                return False
+            return fused.stack_plan(self.global_layer, self.local_layer).direct()
+        if self.dim in narrow.WIDTHS and narrow.ENABLED:
+            return all(getattr(p, '_pamnet_direct', False) and p.grad is not None for p in self._all_params())
+        return False
+
+    def _all_params(self):
+        ap = self.__dict__.get('_all_param_list')
+        if ap is None:
+            ap = self.__dict__['_all_param_list'] = [p for p in self.parameters() if p.requires_grad]
+        return ap
 
     def _top_params(self):
         tp = self.__dict__.get('_top_param_list')

@@ -230,7 +230,7 @@ def embed(x, lin0, lin1=None, kind=None, act=True, tape=None, need_dx=False):
         params += [lin1.weight, lin1.bias]
     plist = [p for p in params if p is not None]
     # no-grad mode: straight to the kernel, no autograd node
-    return _apply(_Embed, x, kind, act, plist, *params, tape=tape, needs=(need_dx,))
+    return _apply(_Embed, x, kind, act, plist, *params, tape=tape)
 
 
 def embed_supported(x, lin):
@@ -566,7 +566,7 @@ def layer_stack(global_layers, local_layers, x0, e_g, rbf_e, e_sbf, graph, tape=
     # inference (no gradient mode): the engine skips every store only the backward would read
     save = torch.is_grad_enabled()
     if tape is not None:                       # direct-gradient mode on the model's own tape (ops.Tape)
-        return tape.call(_Stack, (), x0, e_g, rbf_e, e_sbf, graph, plan, True, True)
+        return tape.call(_Stack, x0, e_g, rbf_e, e_sbf, graph, plan, True, True)
     if save and plan.direct():
         return _Stack.apply(x0, e_g, rbf_e, e_sbf, graph, plan, True, True)
     if not save:

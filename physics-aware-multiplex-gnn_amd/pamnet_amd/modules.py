@@ -213,6 +213,6 @@ class LocalMP(_LayerBase):
             m_nb = a[:, d:] * q[:, 2 * d:3 * d]                                   # mlp_m_kj(m) * lin_rbf(rbf)
         s = narrow.mlp2(sbf, self.mlp_sbf) if _narrow(sbf) else mlp_apply(self.mlp_sbf, sbf)   # [T+P, d]
         m_other = ops.gather_mul_aggregate(m_nb, s, g.tp, g.tp_T)                 # -> [E_l, d]
-        m = q[:, 3 * d:] * (m_ji + m_other)
+        m = narrow.gate_mul(q, m_ji, m_other) if zb is not None else q[:, 3 * d:] * (m_ji + m_other)
         x = ops.aggregate(m, csr, init=x)
         return update_and_heads(self, x, res_x)

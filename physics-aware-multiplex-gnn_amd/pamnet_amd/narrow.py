@@ -122,6 +122,30 @@ def local_gate(P, Q, b_ji, b_kj, csr, tr):
     return ops.apply(_LocalGate, P, Q, b_ji, b_kj, csr, tr)
 
 
+class _GateMul(torch.autograd.Function):
+    """m = lin_rbf_out(rbf) * (m_ji + m_other) with lin_rbf_out(rbf) = the last d columns of the edge-side projections Q
+    (layers/local_message_passing.py:53)."""
+
+    @staticmethod
+    def forward(ctx, Q, m_ji, m_other):
+        d = m_ji.size(1)
+        ctx.save_for_backward(Q, m_ji, m_other)
+        return Q[:, 3 * d:] * (m_ji + m_other)
+
+    @staticmethod
+    def backward(ctx, g):
+        Q, m_ji, m_other = ctx.saved_tensors
+        d = m_ji.size(1)
+        dQ = torch.zeros_like(Q)
+        dQ[:, 3 * d:] = g * (m_ji + m_other)
+        dm = g * Q[:, 3 * d:]
+        return dQ, dm, dm
+
+
+def gate_mul(Q, m_ji, m_other):
+    return ops.apply(_GateMul, Q, m_ji, m_other)
+
+
 class _Mlp2(torch.autograd.Function):
     """SiLU(W2 SiLU(W1 x + b1) + b2) [+ x] [+ r] on rows: mlp_sbf (layers/local_message_passing.py:24,49), the Res blocks
     (layers/basic.py:25-33) and the first two layers of mlp_out."""

@@ -27,11 +27,22 @@ class _NoGradCtx(object):
         pass
 
 
-def apply(fn, *args, tape=None, needs=()):
-    """fn.apply(*args) under autograd; straight fn.forward without a tape in no-grad mode; or -- `tape` given -- run on
-    the model's own Tape (one autograd node for the whole forward, see Tape)."""
+import os as _os
+
+TAPE = _os.environ.get('PAMNET_TAPE', '1') != '0'      # measurement aid: 0 = every Function is its own autograd node
+_tape_stack = []          # the Tape of the forward being recorded (pushed / popped by _Whole.forward only)
+
+
+def current_tape():
+    return _tape_stack[-1] if _tape_stack else None
+
+
+def apply(fn, *args, tape=None):
+    """fn.apply(*args) under autograd; straight fn.forward without a tape in no-grad mode; or -- inside a forward that is
+    being recorded as ONE autograd node (see Tape) -- a call on that tape."""
+    tape = tape if tape is not None else current_tape()
     if tape is not None:
-        return tape.call(fn, needs, *args)
+        return tape.call(fn, *args)
     if torch.is_grad_enabled():
         return fn.apply(*args)
     return fn.forward(_NoGradCtx(), *args)
@@ -55,24 +66,35 @@ class _TapeCtx(object):
 
 
 class Tape(object):
-    """A training forward of PAMNet is a fixed chain of eight of this package's autograd Functions (type gather, two
-    Bessel bases, three embeddings, the layer stack, fusion + pooling).  Handing them to torch's autograd engine one by
-    one costs ~0.4 ms of host time per step (node bookkeeping, the hop to the engine's device thread, AccumulateGrad) --
-    with the step at 2.7 ms and the host loop at 2.6 ms that was the next bound.  In direct-gradient mode
-    (train.FlatParams: the kernels write parameter gradients in place) the chain is recorded here instead and the whole
-    forward is ONE autograd node (`_Whole`) whose backward replays the Functions' own `backward` bodies in reverse."""
+    """A training forward of PAMNet is a fixed chain of this package's autograd Functions (dim = 128: eight of them --
+    type gather, two Bessel bases, three embeddings, the layer stack, fusion + pooling; the narrow widths: ~50).  Handing
+    them to torch's autograd engine one by one costs host time per node (bookkeeping, the hop to the engine's device
+    thread, AccumulateGrad): ~0.4 ms per step at dim = 128 and most of the 3.7 ms at the narrow widths, whose steps are
+    bound by the host.  With preallocated gradients (train.FlatParams) the chain is recorded here instead and the whole
+    forward is ONE autograd node (`_Whole`) whose backward replays the Functions' own `backward` bodies in reverse.
+    Gradients that a kernel writes in place come back as None; the others are added into the parameters' (zeroed)
+    gradient views by one multi-tensor add at the end."""
 
     def __init__(self):
         self.nodes = []
+        self.live = set()                      # ids of tensors a gradient flows back to
 
-    def call(self, fn, needs, *args):
+    def call(self, fn, *args):
+        live = self.live
+        needs = tuple(isinstance(a, torch.Tensor) and (a.requires_grad or id(a) in live) for a in args)
         ctx = _TapeCtx(needs)
         out = fn.forward(ctx, *args)
-        self.nodes.append((fn, ctx, args, out if isinstance(out, tuple) else (out,)))
+        outs = out if isinstance(out, tuple) else (out,)
+        if any(needs):
+            self.nodes.append((fn, ctx, args, outs))
+            for o in outs:
+                if isinstance(o, torch.Tensor):
+                    live.add(id(o))
         return out
 
     def backward(self, out, grad):
         grads = {id(out): grad}
+        pgrads = {}                            # parameter -> summed gradient (a parameter may feed several nodes)
         for fn, ctx, args, outs in reversed(self.nodes):
             gouts = [grads.pop(id(o), None) for o in outs]
             if all(g is None for g in gouts):
@@ -84,22 +106,30 @@ class Tape(object):
                 if g is None or not isinstance(a, torch.Tensor):
                     continue
                 if isinstance(a, torch.nn.Parameter):
-                    a.grad.copy_(g)                      # direct-gradient mode: overwrite (zeroed buffer, one use)
+                    g = g if g.shape == a.grad.shape else g.reshape(a.grad.shape)
+                    prev = pgrads.get(id(a))
+                    pgrads[id(a)] = (a.grad, g if prev is None else prev[1] + g)
                 elif id(a) in grads:
                     grads[id(a)] = grads[id(a)] + g
                 else:
                     grads[id(a)] = g
-        self.nodes = []
+        if pgrads:                             # one multi-tensor add into the (zeroed) flat gradient views
+            torch._foreach_add_([v for v, _ in pgrads.values()], [g for _, g in pgrads.values()])
+        self.nodes, self.live = [], set()
 
 
 class _Whole(torch.autograd.Function):
     """The whole forward as one autograd node (see Tape).  `anchor`: any parameter that requires grad -- it makes
-    autograd record the node; every parameter gradient is written in place, so the node returns none."""
+    autograd record the node; every parameter gradient is written / added in place, so the node returns none."""
 
     @staticmethod
     def forward(ctx, anchor, run):
         tape = Tape()
-        out = run(tape)
+        _tape_stack.append(tape)
+        try:
+            out = run(tape)
+        finally:
+            _tape_stack.pop()
         ctx.tape, ctx.out = tape, out
         return out.view(-1)                  # a fresh tensor object for autograd; the tape keys on `out` itself
 
@@ -317,6 +347,22 @@ class _FusePool(torch.autograd.Function):
                  lib.ptr(graph.node_graph), lib.ptr(graph.gptr), 1 if ctx.mean else 0, lib.ptr(g), lib.ptr(go),
                  lib.ptr(ga), lib.stream_of(g))
         return go, ga, None, None
+
+
+class _StackRows(torch.autograd.Function):
+    """torch.stack of per-layer [N] rows (models.py:206-207) as a Function of this package (so that it can run on a Tape)."""
+
+    @staticmethod
+    def forward(ctx, *rows):
+        return torch.stack(rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.unbind(0))
+
+
+def stack_rows(rows):
+    return apply(_StackRows, *rows)
 
 
 def aggregate(src, csr, init=None):

@@ -161,7 +161,9 @@ class Trainer(object):
             self._p = self.opt.param_groups[0]['params'][0]
             self._p.grad = self.fp.grad
         self._grad_clean = True                            # fp.grad is all zeros (fresh buffer / zeroed by the update)
-        self._pack = bool(self.fp.flat.is_cuda and getattr(model, 'dim', 128) != 128)   # no direct-gradient engine
+        # widths without a one-node forward (models._one_node: dim = 128 engine, narrow-width tape): autograd hands the
+        # gradient tensors over and one multi-tensor add packs them into the flat buffer
+        self._pack = bool(self.fp.flat.is_cuda and getattr(model, 'dim', 128) not in (128, 16, 32, 64))
         self.ema_decay = ema_decay
         self.shadow = self.fp.flat.clone()                                 # utils/ema.py:9-11
         self.max_grad_norm = max_grad_norm
