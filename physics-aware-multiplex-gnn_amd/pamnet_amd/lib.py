@@ -78,12 +78,29 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = None
+
+
 def stream_of(t):
-    import torch
+    """hipStream_t of torch's current stream on the tensor's device.  (torch.cuda.current_stream() builds a Stream object
+    per call: ~5 us, 50-300 times per step on the per-operator paths; the raw accessor is a plain C call.)"""
+    global _raw_stream
     if not t.is_cuda:
         raise RuntimeError('pamnet_hip kernels run on an MI355X only: tensor is on %s (no CPU fallback)' % t.device)
-    return torch.cuda.current_stream(t.device).cuda_stream
+    if _raw_stream is None:
+        import torch
+        _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None) or \
+            (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+    return _raw_stream(t.device.index)
+
+
+_fns = {}
 
 
 def call(name, *args):
-    check(getattr(load(), name)(*args), name)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
+    rc = fn(*args)
+    if rc:
+        check(rc, name)
