@@ -338,6 +338,7 @@ int pamnet_mlp2_bwd_f32(const float* dy, int64_t rows, const float* z1, const fl
  * W*: [128, K] row-major (out, in); b* nullable; kind nullable (then only W0/b0 are used).
  * Backward writes dW0/db0 (and dW1/db1 when kind != null) = sums over rows, reduced in a fixed order through `partial`
  * (pamnet_embed_scratch_floats floats); dx [rows, K] (nullable) is only available for kind == null, K == 16.
+ * (One-job forms of pamnet_embed_multi_*_f32 below.)
  * ------------------------------------------------------------------------------------------------------------------ */
 int pamnet_embed_scratch_floats(int64_t rows, int64_t K, int64_t* floats);
 int pamnet_embed_fwd_f32(const float* x, int64_t rows, int64_t K, const int32_t* kind, const float* W0,
@@ -347,6 +348,46 @@ int pamnet_embed_bwd_f32(const float* x, int64_t rows, int64_t K, const int32_t*
                          const float* b0, const float* W1, const float* b1, int32_t act, const float* gout,
                          float* dW0, float* db0, float* dW1, float* db1, float* dx, float* partial,
                          pamnet_stream_t stream);
+
+/* All input embeddings of a PAMNet forward (models.py:107/119/140, 185-188) in ONE launch, their backward in TWO (main +
+ * fixed-order reduce): up to 4 embedding layers plus the rows of the atom-type table.
+ * A job with `dist` != null is a K = 16 layer whose input rows are the Bessel basis of those distances
+ * (layers/basic.py:59-76: u(d/c) sin(freq_n d/c), u = the p = 5 envelope): the rows are formed while staging, so neither
+ * the [rows, 16] basis nor -- in the backward, where d freq is accumulated in the same pass -- its gradient ever exists.
+ * Forward reads x|dist, kind, W*, b*, writes out.  Backward reads the same plus gout and OVERWRITES dW0/db0 (dW1/db1
+ * with `kind`), dfreq (with `dist`), dx (nullable; plain K = 16 layer only) through `partial`
+ * (pamnet_embed_scratch_floats(rows, K) floats per job).  Unused pointers are null. */
+typedef struct pamnet_embed_job {
+    const float* x;          /* [rows, K] input rows, or null with `dist` */
+    const float* dist;       /* [rows] distances, or null */
+    const float* freq;       /* [16] Bessel frequencies (with `dist`) */
+    float cutoff;            /* c (with `dist`) */
+    int32_t K;               /* 16 | 18 | 42 */
+    int32_t act;             /* != 0: SiLU */
+    int64_t rows;
+    const int32_t* kind;     /* [rows] 0 -> (W0, b0), 1 -> (W1, b1); nullable */
+    const float *W0, *b0, *W1, *b1;
+    float* out;              /* forward: [rows, 128] */
+    const float* gout;       /* backward: d out [rows, 128] */
+    float *dW0, *db0, *dW1, *db1, *dfreq, *dx;
+    float* partial;
+} pamnet_embed_job;
+/* rows of the atom-type table: forward out[r, :] = table[idx[r], :] (zeros for idx outside [0, n_types)); backward
+ * dtable[t, :] = sum_{r: idx[r] = t} g[r, :] through `scratch` (pamnet_reduce_scratch_bytes).  Width 128. */
+typedef struct pamnet_type_rows_job {
+    const float* table;      /* [n_types, 128] */
+    const int32_t* idx;      /* [n] */
+    int64_t n;
+    int64_t n_types;         /* <= 8 */
+    float* out;              /* forward [n, 128] */
+    const float* g;          /* backward [n, 128] */
+    void* scratch;           /* backward */
+    float* dtable;           /* backward [n_types, 128] */
+} pamnet_type_rows_job;
+int pamnet_embed_multi_fwd_f32(const pamnet_embed_job* jobs, int32_t n_jobs, const pamnet_type_rows_job* types,
+                               pamnet_stream_t stream);
+int pamnet_embed_multi_bwd_f32(const pamnet_embed_job* jobs, int32_t n_jobs, const pamnet_type_rows_job* types,
+                               pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Layer-stack engine: the n_layer x (global, local) loop of PAMNet.forward (models.py:196-204) in ONE call per

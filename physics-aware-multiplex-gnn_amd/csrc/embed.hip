@@ -16,6 +16,7 @@
 // order (deterministic); dx (only needed for the trainable Bessel frequencies, K = 16) is a third small GEMM.
 #include "common.h"
 #include "gemm_core.h"
+#include "type_rows_core.h"
 
 using namespace pamnet;
 
@@ -110,29 +111,90 @@ __device__ __forceinline__ float4 ld4_or_zero(const float* p, int c4) {
     return p ? *reinterpret_cast<const float4*>(p + 4 * c4) : f4zero();
 }
 
-template <int K, bool TWO>
-__global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ x, int64_t rows,
-                                                        const int32_t* __restrict__ kind,
-                                                        const float* __restrict__ W0, const float* __restrict__ b0,
-                                                        const float* __restrict__ W1, const float* __restrict__ b1,
-                                                        int act, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float xs[TR * Dims<K>::LDX];
-    __shared__ __attribute__((aligned(16))) float Ds[TR * LDT];
-    __shared__ int ks[TR];
+// envelope u(x) of the Bessel rows (layers/basic.py:36-51, p = 5) -- the same expression as basis.hip's rbf kernels
+__device__ __forceinline__ float envelope_f(float x) {
+    if (!(x < 1.0f)) return 0.0f;
+    const float x2 = x * x, x5 = x2 * x2 * x;
+    return 1.0f / x + x5 * (-21.0f + x * (35.0f - 15.0f * x));
+}
+
+// One embedding layer as the kernels see it (device-side image of pamnet_embed_job, include/pamnet_hip.h).
+struct EJob {
+    const float* x;                 // [rows, K] input rows, or null with `dist`
+    const float* dist;              // [rows]: K = 16 Bessel rows u(d/c) sin(freq_n d/c) formed while staging (layers/basic.py:74-76)
+    const float* freq;              // [16]
+    float inv_cutoff;
+    int act;
+    int64_t rows;
+    const int32_t* kind;
+    const float *W0, *b0, *W1, *b1;
+    float* out;                     // forward
+    const float* gout;              // backward
+    float* partial;                 // backward: per-workgroup partial gradients
+    float* dx;                      // backward, K = 16 without dist: input gradient (nullable)
+    float *dW0, *db0, *dW1, *db1, *dfreq;
+    int code;                       // Code below
+    int nblk;                       // workgroups of this job
+};
+enum Code { C16 = 0, C16_RBF, C18, C42, C42_TWO, C16_DX };
+
+// `embeddings[x]` (models.py:107,140) rides in the same launches: forward rows table[idx], backward per-type row sums
+struct TJob {
+    const float* table;             // [n_types, 128]
+    const int32_t* idx;             // [n]
+    int64_t n;
+    int n_types;
+    float* out;                     // forward [n, 128]
+    const float* g;                 // backward [n, 128]
+    float4* partial;                // backward scratch (pamnet_reduce_scratch_bytes)
+    float* dtable;                  // backward [n_types, 128]
+    int nblk;
+};
+constexpr int MAXJ = 4;
+struct EJobs {
+    EJob job[MAXJ];
+    TJob types;
+    int n;
+};
+
+// input rows [row0, row0 + 64) of a job into xs (zero beyond `rows`); RBF: the Bessel rows from the distances, with the
+// scaled distance of each row left in ds[] for the backward
+template <int K, bool RBF>
+__device__ __forceinline__ void stage_job_rows(const EJob& jb, int64_t row0, float* xs, float* ds) {
+    if (!RBF) {
+        stage_rows<K>(jb.x, row0, jb.rows, xs);
+        return;
+    }
+    const int r = threadIdx.x >> 2, n0 = 4 * (threadIdx.x & 3);
+    const int64_t g = row0 + r;
+    const bool ok = g < jb.rows;
+    const float xr = ok ? jb.dist[g] * jb.inv_cutoff : 1.0f;       // u(1) = 0: padded rows contribute nothing
+    const float u = envelope_f(xr);
+    const float4 f = *reinterpret_cast<const float4*>(jb.freq + n0);
+    *reinterpret_cast<float4*>(xs + r * Dims<K>::LDX + n0) =
+        ok ? make_float4(u * sinf(f.x * xr), u * sinf(f.y * xr), u * sinf(f.z * xr), u * sinf(f.w * xr)) : f4zero();
+    if ((threadIdx.x & 3) == 0) ds[r] = xr;
+}
+
+template <int K, bool TWO, bool RBF>
+__device__ __forceinline__ void embed_fwd_body(const EJob& jb, int bid, float* xs, float* Ds, int* ks, float* ds) {
+    const int64_t rows = jb.rows;
     const int wc = (threadIdx.x >> 6) * 32;
     WSlice<K> w0, w1;
-    load_wslice<K>(w0, W0, wc);
-    if (TWO) load_wslice<K>(w1, W1, wc);
+    load_wslice<K>(w0, jb.W0, wc);
+    if (TWO) load_wslice<K>(w1, jb.W1, wc);
     const int c4 = threadIdx.x & 31;
-    const float4 bias0 = ld4_or_zero(b0, c4), bias1 = TWO ? ld4_or_zero(b1, c4) : f4zero();
+    const float4 bias0 = ld4_or_zero(jb.b0, c4), bias1 = TWO ? ld4_or_zero(jb.b1, c4) : f4zero();
+    const int act = jb.act;
+    float* __restrict__ out = jb.out;
     zero_pad<K>(xs);
     if (threadIdx.x < TR) ks[threadIdx.x] = 0;
     const int64_t ntiles = (rows + TR - 1) / TR;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t tile = bid; tile < ntiles; tile += jb.nblk) {
         const int64_t row0 = tile * TR;
         __syncthreads();
-        stage_rows<K>(x, row0, rows, xs);
-        if (TWO && threadIdx.x < TR) ks[threadIdx.x] = (row0 + threadIdx.x < rows) ? kind[row0 + threadIdx.x] : 0;
+        stage_job_rows<K, RBF>(jb, row0, xs, ds);
+        if (TWO && threadIdx.x < TR) ks[threadIdx.x] = (row0 + threadIdx.x < rows) ? jb.kind[row0 + threadIdx.x] : 0;
         __syncthreads();
         f32x4 acc[MT][2];
         z_tile<K, TWO>(xs, ks, w0, w1, acc);
@@ -147,34 +209,37 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
     }
 }
 
-// partial layout per workgroup: [2 kinds][128][K] dW, then [2][128] db
-template <int K, bool TWO, bool DX>
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ x, int64_t rows,
-                                                        const int32_t* __restrict__ kind,
-                                                        const float* __restrict__ W0, const float* __restrict__ b0,
-                                                        const float* __restrict__ W1, const float* __restrict__ b1,
-                                                        int act, const float* __restrict__ gout,
-                                                        float* __restrict__ partial, float* __restrict__ dx) {
+// partial layout per workgroup: [2 kinds][128][K] dW, [2][128] db, [16] dfreq
+template <int K>
+__host__ __device__ constexpr int partial_floats() { return 2 * DOUT * K + 2 * DOUT + 16; }
+
+// DXM: 0 no input gradient, 1 dx [rows, 16] written, 2 the input rows are Bessel rows: d freq accumulated instead
+// (layers/basic.py:76: d/d freq_n of u(x) sin(freq_n x) = u(x) x cos(freq_n x)) -- the [rows, 16] gradient never exists
+template <int K, bool TWO, int DXM>
+__device__ __forceinline__ void embed_bwd_body(const EJob& jb, int bid, float* xs, float* Ds, int* ks, float* ds) {
     constexpr int G = Dims<K>::G, LDX = Dims<K>::LDX;
-    __shared__ __attribute__((aligned(16))) float xs[TR * LDX];
-    __shared__ __attribute__((aligned(16))) float Ds[TR * LDT];
-    __shared__ int ks[TR];
+    constexpr bool DX = DXM != 0;
+    const int64_t rows = jb.rows;
+    const float* __restrict__ gout = jb.gout;
+    const int act = jb.act;
     const int lane = threadIdx.x & 63, r16 = lane & 15, kg = lane >> 4;
     const int wave = threadIdx.x >> 6, wc = wave * 32;
     WSlice<K> w0, w1;
-    load_wslice<K>(w0, W0, wc);
-    if (TWO) load_wslice<K>(w1, W1, wc);
+    load_wslice<K>(w0, jb.W0, wc);
+    if (TWO) load_wslice<K>(w1, jb.W1, wc);
     const int c4 = threadIdx.x & 31;
-    const float4 bias0 = ld4_or_zero(b0, c4), bias1 = TWO ? ld4_or_zero(b1, c4) : f4zero();
+    const float4 bias0 = ld4_or_zero(jb.b0, c4), bias1 = TWO ? ld4_or_zero(jb.b1, c4) : f4zero();
     // dx = dz * W0: B[k = c][j = input k] for this wave's row tile; c runs over all 128 columns (K == 16 only)
     float4 wdx[DX ? DOUT / 16 : 1];
     if (DX) {
 #pragma unroll
         for (int q = 0; q < DOUT / 16; ++q) {
-            const float* wp = W0 + (size_t)(16 * q + 4 * kg) * K + r16;
+            const float* wp = jb.W0 + (size_t)(16 * q + 4 * kg) * K + r16;
             wdx[q] = make_float4(wp[0], wp[K], wp[2 * K], wp[3 * K]);
         }
     }
+    const float fn = DXM == 2 ? jb.freq[r16] : 0.f;
+    float facc = 0.f;
     // dW accumulators: columns [wc, wc+32) as two 16-row (c) tiles x G k-tiles, per kind
     f32x4 dw0[2][G], dw1[TWO ? 2 : 1][TWO ? G : 1];
 #pragma unroll
@@ -188,11 +253,11 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     zero_pad<K>(xs);
     if (threadIdx.x < TR) ks[threadIdx.x] = 0;
     const int64_t ntiles = (rows + TR - 1) / TR;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t tile = bid; tile < ntiles; tile += jb.nblk) {
         const int64_t row0 = tile * TR;
         __syncthreads();
-        stage_rows<K>(x, row0, rows, xs);
-        if (TWO && threadIdx.x < TR) ks[threadIdx.x] = (row0 + threadIdx.x < rows) ? kind[row0 + threadIdx.x] : 0;
+        stage_job_rows<K, DXM == 2>(jb, row0, xs, ds);
+        if (TWO && threadIdx.x < TR) ks[threadIdx.x] = (row0 + threadIdx.x < rows) ? jb.kind[row0 + threadIdx.x] : 0;
         __syncthreads();
         {
             f32x4 acc[MT][2];
@@ -245,14 +310,19 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t g = row0 + 16 * wave + 4 * kg + r;
-                if (g < rows) dx[g * K + r16] = ax[r];
+                if (DXM == 1) {
+                    const int64_t g = row0 + 16 * wave + 4 * kg + r;
+                    if (g < rows) jb.dx[g * K + r16] = ax[r];
+                } else {
+                    const float xr = ds[16 * wave + 4 * kg + r];
+                    facc += ax[r] * envelope_f(xr) * xr * cosf(fn * xr);
+                }
             }
         }
     }
     // workgroup partial: dW tiles straight from the accumulators (element (c = wc + 16a + 4kg + r, k = 16g + r16)),
     // bias gradients through LDS (8 row groups x 128 columns per kind, summed in order)
-    float* p = partial + (int64_t)blockIdx.x * (2 * DOUT * K + 2 * DOUT);
+    float* p = jb.partial + (int64_t)bid * partial_floats<K>();
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -268,10 +338,11 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
             }
         }
     __syncthreads();
-    float* red = Ds;                                        // [2][8][128]
+    float* red = Ds;                                        // [2][8][128], then [16 lane groups][16]
     const int rg = threadIdx.x >> 5;
     *reinterpret_cast<float4*>(red + rg * DOUT + 4 * c4) = dbs0;
     *reinterpret_cast<float4*>(red + 8 * DOUT + rg * DOUT + 4 * c4) = dbs1;
+    if (DXM == 2) red[16 * DOUT + (threadIdx.x >> 4) * 16 + r16] = facc;
     __syncthreads();
     {
         const int kd = threadIdx.x >> 7, c = threadIdx.x & 127;
@@ -280,25 +351,29 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
         for (int q = 0; q < 8; ++q) t += red[kd * 8 * DOUT + q * DOUT + c];
         p[2 * DOUT * K + kd * DOUT + c] = t;
     }
+    if (DXM == 2 && threadIdx.x < 16) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[16 * DOUT + q * 16 + threadIdx.x];
+        p[2 * DOUT * K + 2 * DOUT + threadIdx.x] = t;
+    }
 }
 
 // 32 output elements x 8 slices of the workgroup partials per block; fixed-order tree over the slices (deterministic).
-// Elements: [2][128][K] dW then [2][128] db; the second kind is skipped when it has no destination.
-__global__ __launch_bounds__(256) void embed_reduce_kernel(const float* __restrict__ partial, int nblocks, int K,
-                                                           float* __restrict__ dW0, float* __restrict__ db0,
-                                                           float* __restrict__ dW1, float* __restrict__ db1) {
-    __shared__ float sm[8][33];
-    const int per = 2 * DOUT * K + 2 * DOUT;
+// Elements: [2][128][K] dW, [2][128] db, [16] dfreq; parts without a destination are skipped.
+__device__ __forceinline__ void embed_reduce_body(const EJob& jb, int K, int bx, float (*sm)[33]) {
+    const int per = 2 * DOUT * K + 2 * DOUT + 16;
     const int lane = threadIdx.x & 31, slice = threadIdx.x >> 5;
-    const int e = blockIdx.x * 32 + lane;
+    const int e = bx * 32 + lane;
     float* dst = nullptr;
-    if (e < DOUT * K) dst = dW0 + e;
-    else if (e < 2 * DOUT * K) dst = dW1 ? dW1 + (e - DOUT * K) : nullptr;
-    else if (e < 2 * DOUT * K + DOUT) dst = db0 ? db0 + (e - 2 * DOUT * K) : nullptr;
-    else if (e < per) dst = db1 ? db1 + (e - 2 * DOUT * K - DOUT) : nullptr;
+    if (e < DOUT * K) dst = jb.dW0 + e;
+    else if (e < 2 * DOUT * K) dst = jb.dW1 ? jb.dW1 + (e - DOUT * K) : nullptr;
+    else if (e < 2 * DOUT * K + DOUT) dst = jb.db0 ? jb.db0 + (e - 2 * DOUT * K) : nullptr;
+    else if (e < 2 * DOUT * K + 2 * DOUT) dst = jb.db1 ? jb.db1 + (e - 2 * DOUT * K - DOUT) : nullptr;
+    else if (e < per) dst = jb.dfreq ? jb.dfreq + (e - 2 * DOUT * K - 2 * DOUT) : nullptr;
     float s = 0.f;
     if (dst)
-        for (int b = slice; b < nblocks; b += 8) s += partial[(int64_t)b * per + e];
+        for (int b = slice; b < jb.nblk; b += 8) s += jb.partial[(int64_t)b * per + e];
     sm[slice][lane] = s;
     __syncthreads();
     if (slice == 0 && dst) {
@@ -309,58 +384,186 @@ __global__ __launch_bounds__(256) void embed_reduce_kernel(const float* __restri
     }
 }
 
+__host__ __device__ inline int code_k(int code) { return code == C18 ? 18 : (code == C42 || code == C42_TWO ? 42 : 16); }
+
+// forward rows of the type table: one float4 per thread
+__device__ __forceinline__ void type_rows_fwd_body(const TJob& t, int bid) {
+    const float4* __restrict__ tab = reinterpret_cast<const float4*>(t.table);
+    float4* __restrict__ out = reinterpret_cast<float4*>(t.out);
+    const int64_t total = t.n * (DOUT / 4);
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < total; i += (int64_t)t.nblk * 256) {
+        const int64_t r = i >> 5;
+        const int ty = t.idx[r];
+        out[i] = (ty >= 0 && ty < t.n_types) ? tab[ty * (DOUT / 4) + (int)(i & 31)] : f4zero();
+    }
+}
+
+constexpr int XS_FLOATS = TR * Dims<42>::LDX;
+
+// All input embeddings of a forward in one launch: workgroups [0, nblk_0) run job 0, the next nblk_1 job 1, ...; the
+// type-table rows take the last ones.  (Separately these are 5-7 launches of 4-18 us each on the critical path before
+// the first layer; together they fill the machine once.)
+__global__ __launch_bounds__(256, 2) void embed_multi_fwd_kernel(const EJobs J) {
+    __shared__ __attribute__((aligned(16))) float xs[XS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Ds[TR * LDT];
+    __shared__ int ks[TR];
+    __shared__ float ds[TR];
+    int bid = blockIdx.x;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        if (j >= J.n) break;
+        const EJob& jb = J.job[j];
+        if (bid < jb.nblk) {
+            switch (jb.code) {
+                case C16: embed_fwd_body<16, false, false>(jb, bid, xs, Ds, ks, ds); break;
+                case C16_RBF: embed_fwd_body<16, false, true>(jb, bid, xs, Ds, ks, ds); break;
+                case C18: embed_fwd_body<18, false, false>(jb, bid, xs, Ds, ks, ds); break;
+                case C42: embed_fwd_body<42, false, false>(jb, bid, xs, Ds, ks, ds); break;
+                default: embed_fwd_body<42, true, false>(jb, bid, xs, Ds, ks, ds); break;
+            }
+            return;
+        }
+        bid -= jb.nblk;
+    }
+    if (J.types.nblk) type_rows_fwd_body(J.types, bid);
+}
+
+__global__ __launch_bounds__(256, 2) void embed_multi_bwd_kernel(const EJobs J) {
+    __shared__ __attribute__((aligned(16))) float xs[XS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Ds[TR * LDT];
+    __shared__ int ks[TR];
+    __shared__ float ds[TR];
+    int bid = blockIdx.x;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        if (j >= J.n) break;
+        const EJob& jb = J.job[j];
+        if (bid < jb.nblk) {
+            switch (jb.code) {
+                case C16: embed_bwd_body<16, false, 0>(jb, bid, xs, Ds, ks, ds); break;
+                case C16_DX: embed_bwd_body<16, false, 1>(jb, bid, xs, Ds, ks, ds); break;
+                case C16_RBF: embed_bwd_body<16, false, 2>(jb, bid, xs, Ds, ks, ds); break;
+                case C18: embed_bwd_body<18, false, 0>(jb, bid, xs, Ds, ks, ds); break;
+                case C42: embed_bwd_body<42, false, 0>(jb, bid, xs, Ds, ks, ds); break;
+                default: embed_bwd_body<42, true, 0>(jb, bid, xs, Ds, ks, ds); break;
+            }
+            return;
+        }
+        bid -= jb.nblk;
+    }
+    if (J.types.nblk)
+        type_rows::grad_body(reinterpret_cast<const float4*>(J.types.g), J.types.idx, J.types.n, J.types.n_types, DOUT / 4,
+                             J.types.partial, bid, J.types.nblk, reinterpret_cast<float4*>(Ds));
+}
+
+// blockIdx.y = job (the type table's finish is job n): fixed-order sums of the workgroup partials
+__global__ __launch_bounds__(256) void embed_multi_reduce_kernel(const EJobs J) {
+    __shared__ float sm[8][33];
+    const int j = blockIdx.y;
+    if (j < J.n) {
+        const EJob& jb = J.job[j];
+        const int K = code_k(jb.code);
+        if ((int)blockIdx.x * 32 >= 2 * DOUT * K + 2 * DOUT + 16) return;
+        embed_reduce_body(jb, K, blockIdx.x, sm);
+    } else if (J.types.nblk && blockIdx.x == 0) {
+        type_rows::finish_body(J.types.partial, J.types.nblk, J.types.n_types * (DOUT / 4),
+                               reinterpret_cast<float4*>(J.types.dtable));
+    }
+}
+
 inline int grid_for(int64_t rows, int cap) {
     const int64_t tiles = (rows + TR - 1) / TR;
     return (int)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
 }
 constexpr int FWD_CAP = 1024, BWD_CAP = 256;
+// backward: two tiles per workgroup where there are enough (each workgroup ends with a 17-44 KB partial-gradient row, and
+// at two workgroups per CU the jobs of a multi launch are co-resident up to 512 workgroups)
+inline int bwd_grid(int64_t rows) { return grid_for((rows + 1) / 2, BWD_CAP); }
 
-template <int K>
-int launch_fwd(const float* x, int64_t rows, const int32_t* kind, const float* W0, const float* b0, const float* W1,
-               const float* b1, int act, float* out, hipStream_t st) {
-    if (W1)
-        hipLaunchKernelGGL((embed_fwd_kernel<K, true>), dim3(grid_for(rows, FWD_CAP)), dim3(256), 0, st, x, rows, kind,
-                           W0, b0, W1, b1, act, out);
-    else
-        hipLaunchKernelGGL((embed_fwd_kernel<K, false>), dim3(grid_for(rows, FWD_CAP)), dim3(256), 0, st, x, rows, kind,
-                           W0, b0, W1, b1, act, out);
-    PAMNET_LAUNCH_CHECK();
+// host: pamnet_embed_job -> EJob (validated); bwd selects the backward variant and grid
+int make_job(const pamnet_embed_job& h, bool bwd, EJob* o) {
+    const int64_t K = h.K;
+    if (h.rows < 0 || (K != 16 && K != 18 && K != 42)) return PAMNET_EINVAL;
+    if (h.dist && (K != 16 || h.kind || h.x || !(h.cutoff > 0.f))) return PAMNET_EINVAL;
+    if (h.dx && (h.kind || K != 16 || h.dist)) return PAMNET_EINVAL;   // input gradients only for the plain K = 16 layer
+    if (!h.W0 || (h.kind && !h.W1) || (h.W1 && h.rows > 0 && !h.kind)) return PAMNET_ENULL;
+    if (h.rows > 0 && !h.x && !h.dist) return PAMNET_ENULL;
+    if (h.dist && !h.freq) return PAMNET_ENULL;
+    if (!bwd && h.rows > 0 && !h.out) return PAMNET_ENULL;
+    if (bwd && (!h.dW0 || !h.partial || (h.rows > 0 && !h.gout) || (h.W1 && !h.dW1) || (h.dist && !h.dfreq))) return PAMNET_ENULL;
+    o->x = h.x, o->dist = h.dist, o->freq = h.freq, o->inv_cutoff = h.dist ? 1.0f / h.cutoff : 0.f, o->act = h.act;
+    o->rows = h.rows, o->kind = h.kind, o->W0 = h.W0, o->b0 = h.b0, o->W1 = h.W1, o->b1 = h.b1;
+    o->out = h.out, o->gout = h.gout, o->partial = h.partial, o->dx = h.dx;
+    o->dW0 = h.dW0, o->db0 = h.db0, o->dW1 = h.dW1, o->db1 = h.db1, o->dfreq = h.dfreq;
+    o->code = K == 18 ? C18 : (K == 42 ? (h.W1 ? C42_TWO : C42) : (h.dist ? C16_RBF : ((bwd && h.dx) ? C16_DX : C16)));
+    o->nblk = bwd ? bwd_grid(h.rows) : grid_for(h.rows, FWD_CAP);
     return PAMNET_OK;
 }
 
-template <int K>
-int launch_bwd(const float* x, int64_t rows, const int32_t* kind, const float* W0, const float* b0, const float* W1,
-               const float* b1, int act, const float* gout, float* dW0, float* db0, float* dW1, float* db1, float* dx,
-               float* partial, hipStream_t st) {
-    const int nb = grid_for(rows, BWD_CAP);
-    if (dx) {
-        if constexpr (K == 16)
-            hipLaunchKernelGGL((embed_bwd_kernel<K, false, true>), dim3(nb), dim3(256), 0, st, x, rows, kind, W0, b0,
-                               W1, b1, act, gout, partial, dx);
-        else
-            return PAMNET_EINVAL;
-    } else if (W1) {
-        hipLaunchKernelGGL((embed_bwd_kernel<K, true, false>), dim3(nb), dim3(256), 0, st, x, rows, kind, W0, b0, W1,
-                           b1, act, gout, partial, dx);
-    } else {
-        hipLaunchKernelGGL((embed_bwd_kernel<K, false, false>), dim3(nb), dim3(256), 0, st, x, rows, kind, W0, b0, W1,
-                           b1, act, gout, partial, dx);
+int make_types(const pamnet_type_rows_job* h, bool bwd, TJob* o) {
+    o->nblk = 0;
+    if (!h) return PAMNET_OK;
+    if (h->n < 0 || h->n_types < 1 || h->n_types > type_rows::TYPE_MAX) return PAMNET_EINVAL;
+    if (!bwd && (!h->table || (h->n > 0 && (!h->idx || !h->out)))) return PAMNET_ENULL;
+    if (bwd && (!h->dtable || !h->scratch || (h->n > 0 && (!h->idx || !h->g)))) return PAMNET_ENULL;
+    o->table = h->table, o->idx = h->idx, o->n = h->n, o->n_types = (int)h->n_types, o->out = h->out, o->g = h->g;
+    o->partial = static_cast<float4*>(h->scratch), o->dtable = h->dtable;
+    if (bwd) o->nblk = type_rows::blocks_for_rows(h->n);
+    else o->nblk = (int)(h->n == 0 ? 0 : (ceil_div(h->n * (DOUT / 4), 256) < 256 ? ceil_div(h->n * (DOUT / 4), 256) : 256));
+    return PAMNET_OK;
+}
+
+int launch_multi(const pamnet_embed_job* jobs, int32_t n_jobs, const pamnet_type_rows_job* types, bool bwd, hipStream_t st) {
+    if (n_jobs < 0 || n_jobs > MAXJ || (n_jobs > 0 && !jobs)) return PAMNET_EINVAL;
+    EJobs J;
+    J.n = 0;
+    int grid = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!bwd && jobs[j].rows == 0) continue;                          // nothing to write
+        const int rc = make_job(jobs[j], bwd, &J.job[J.n]);
+        if (rc != PAMNET_OK) return rc;
+        grid += J.job[J.n].nblk;
+        ++J.n;
     }
+    const int rc = make_types(types, bwd, &J.types);
+    if (rc != PAMNET_OK) return rc;
+    grid += J.types.nblk;
+    if (grid == 0) return PAMNET_OK;
+    if (!bwd) {
+        hipLaunchKernelGGL(embed_multi_fwd_kernel, dim3(grid), dim3(256), 0, st, J);
+        PAMNET_LAUNCH_CHECK();
+        return PAMNET_OK;
+    }
+    hipLaunchKernelGGL(embed_multi_bwd_kernel, dim3(grid), dim3(256), 0, st, J);
     PAMNET_LAUNCH_CHECK();
-    const int per = 2 * DOUT * K + 2 * DOUT;
-    hipLaunchKernelGGL(embed_reduce_kernel, dim3((per + 31) / 32), dim3(256), 0, st, partial, nb, K, dW0, db0, dW1,
-                       db1);
+    int gx = 1;
+    for (int j = 0; j < J.n; ++j) {
+        const int per = 2 * DOUT * code_k(J.job[j].code) + 2 * DOUT + 16;
+        gx = (per + 31) / 32 > gx ? (per + 31) / 32 : gx;
+    }
+    hipLaunchKernelGGL(embed_multi_reduce_kernel, dim3(gx, J.n + (J.types.nblk ? 1 : 0)), dim3(256), 0, st, J);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
 
 }  // namespace
 
-// scratch floats for the backward: grid * (2*128*K + 2*128)
+// scratch floats for the backward of one layer: grid * (2*128*K + 2*128 + 16)
 extern "C" int pamnet_embed_scratch_floats(int64_t rows, int64_t K, int64_t* floats) {
     if (rows < 0 || K <= 0 || !floats) return PAMNET_EINVAL;
-    *floats = (int64_t)grid_for(rows, BWD_CAP) * (2 * DOUT * K + 2 * DOUT);
+    *floats = (int64_t)bwd_grid(rows) * (2 * DOUT * K + 2 * DOUT + 16);
     return PAMNET_OK;
+}
+
+// All input embeddings of a forward / backward in one (two) launch(es); see pamnet_embed_job in pamnet_hip.h.
+extern "C" int pamnet_embed_multi_fwd_f32(const pamnet_embed_job* jobs, int32_t n_jobs, const pamnet_type_rows_job* types,
+                                          pamnet_stream_t stream) {
+    return launch_multi(jobs, n_jobs, types, false, as_stream(stream));
+}
+
+extern "C" int pamnet_embed_multi_bwd_f32(const pamnet_embed_job* jobs, int32_t n_jobs, const pamnet_type_rows_job* types,
+                                          pamnet_stream_t stream) {
+    return launch_multi(jobs, n_jobs, types, true, as_stream(stream));
 }
 
 extern "C" int pamnet_embed_fwd_f32(const float* x, int64_t rows, int64_t K, const int32_t* kind, const float* W0,
@@ -369,10 +572,10 @@ extern "C" int pamnet_embed_fwd_f32(const float* x, int64_t rows, int64_t K, con
     if (rows < 0 || (K != 16 && K != 18 && K != 42)) return PAMNET_EINVAL;
     if (rows == 0) return PAMNET_OK;
     if (!x || !W0 || !out || (kind && !W1) || (W1 && !kind)) return PAMNET_ENULL;
-    hipStream_t st = as_stream(stream);
-    if (K == 16) return launch_fwd<16>(x, rows, kind, W0, b0, W1, b1, act, out, st);
-    if (K == 18) return launch_fwd<18>(x, rows, kind, W0, b0, W1, b1, act, out, st);
-    return launch_fwd<42>(x, rows, kind, W0, b0, W1, b1, act, out, st);
+    pamnet_embed_job jb = {};
+    jb.x = x, jb.rows = rows, jb.K = (int32_t)K, jb.kind = kind, jb.W0 = W0, jb.b0 = b0, jb.W1 = W1, jb.b1 = b1, jb.act = act;
+    jb.out = out;
+    return launch_multi(&jb, 1, nullptr, false, as_stream(stream));
 }
 
 extern "C" int pamnet_embed_bwd_f32(const float* x, int64_t rows, int64_t K, const int32_t* kind, const float* W0,
@@ -383,8 +586,8 @@ extern "C" int pamnet_embed_bwd_f32(const float* x, int64_t rows, int64_t K, con
     if (rows > 0 && (!x || !gout)) return PAMNET_ENULL;   // rows == 0: gradients are written as zeros
     if (!W0 || !dW0 || !partial || (kind && !W1) || (W1 && (!dW1 || (rows > 0 && !kind)))) return PAMNET_ENULL;
     if (dx && (kind || K != 16)) return PAMNET_EINVAL;     // input gradients only for the single-kind K = 16 (rbf) layer
-    hipStream_t st = as_stream(stream);
-    if (K == 16) return launch_bwd<16>(x, rows, kind, W0, b0, W1, b1, act, gout, dW0, db0, dW1, db1, dx, partial, st);
-    if (K == 18) return launch_bwd<18>(x, rows, kind, W0, b0, W1, b1, act, gout, dW0, db0, dW1, db1, dx, partial, st);
-    return launch_bwd<42>(x, rows, kind, W0, b0, W1, b1, act, gout, dW0, db0, dW1, db1, dx, partial, st);
+    pamnet_embed_job jb = {};
+    jb.x = x, jb.rows = rows, jb.K = (int32_t)K, jb.kind = kind, jb.W0 = W0, jb.b0 = b0, jb.W1 = W1, jb.b1 = b1, jb.act = act;
+    jb.gout = gout, jb.dW0 = dW0, jb.db0 = db0, jb.dW1 = dW1, jb.db1 = db1, jb.dx = dx, jb.partial = partial;
+    return launch_multi(&jb, 1, nullptr, true, as_stream(stream));
 }

@@ -7,6 +7,7 @@
 // (A single launch with a "last workgroup finishes" counter was measured and rejected: the device-scope fence it needs
 // writes back the whole L2 on this multi-XCD part -- 40 us for the norm against 7.5 us for the partials launch.)
 #include "common.h"
+#include "type_rows_core.h"
 
 namespace {
 
@@ -59,65 +60,18 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) loss[0] = (float)(red[0] / (double)n);
 }
 
-constexpr int TYPE_MAX = 8, TYPE_BLOCKS = 64;
+using type_rows::TYPE_BLOCKS;
+using type_rows::TYPE_MAX;
 
-// out[t, :] = sum_{r: idx[r] = t} g[r, :],  t < n_types <= 8.  Lane group (d4 lanes) per row slot; a workgroup owns a
-// contiguous slice of rows, slot s walks rows s, s + slots, ... (fixed), slots meet in LDS in slot order, workgroups in
-// type_rows_finish_kernel in workgroup order.
 __global__ __launch_bounds__(256) void type_rows_grad_kernel(const float4* __restrict__ g, const int32_t* __restrict__ idx,
                                                              int64_t n, int n_types, int d4, float4* __restrict__ partial) {
     __shared__ float4 red[256];
-    const int c = threadIdx.x % d4, slot = threadIdx.x / d4, slots = 256 / d4;
-    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
-    const int64_t beg = blockIdx.x * per, end = beg + per < n ? beg + per : n;
-    float4 acc[TYPE_MAX];
-#pragma unroll
-    for (int t = 0; t < TYPE_MAX; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t r = beg + slot; r < end; r += slots) {
-        const int ty = idx[r];
-        const float4 v = g[r * d4 + c];
-#pragma unroll
-        for (int t = 0; t < TYPE_MAX; ++t) {
-            const float m = ty == t ? 1.f : 0.f;
-            acc[t].x = fmaf(m, v.x, acc[t].x), acc[t].y = fmaf(m, v.y, acc[t].y);
-            acc[t].z = fmaf(m, v.z, acc[t].z), acc[t].w = fmaf(m, v.w, acc[t].w);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < TYPE_MAX; ++t) {
-        if (t >= n_types) break;
-        red[threadIdx.x] = acc[t];
-        __syncthreads();
-        if (slot == 0) {
-            float4 s = red[c];
-            for (int k = 1; k < slots; ++k) {
-                const float4 v = red[k * d4 + c];
-                s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
-            }
-            partial[((int64_t)blockIdx.x * n_types + t) * d4 + c] = s;
-        }
-        __syncthreads();
-    }
+    type_rows::grad_body(g, idx, n, n_types, d4, partial, blockIdx.x, gridDim.x, red);
 }
 
 __global__ __launch_bounds__(256) void type_rows_finish_kernel(const float4* __restrict__ partial, int blocks, int cells,
                                                                float4* __restrict__ out) {
-    for (int e = threadIdx.x; e < cells; e += 256) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        int b = 0;
-        for (; b + 8 <= blocks; b += 8) {                  // 8 independent loads in flight, added in workgroup order
-            float4 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = partial[(int64_t)(b + k) * cells + e];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) s.x += v[k].x, s.y += v[k].y, s.z += v[k].z, s.w += v[k].w;
-        }
-        for (; b < blocks; ++b) {
-            const float4 v = partial[(int64_t)b * cells + e];
-            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
-        }
-        out[e] = s;
-    }
+    type_rows::finish_body(partial, blocks, cells, out);
 }
 
 }  // namespace
@@ -157,8 +111,7 @@ extern "C" int pamnet_type_rows_grad_f32(const float* g, const int32_t* idx, int
     const int64_t d4 = d / 4;
     if (n < 0 || n_types < 1 || n_types > TYPE_MAX || d < 4 || (d & 3) || d4 > 64 || (d4 & (d4 - 1))) return PAMNET_EINVAL;
     if (!out || !scratch || (n > 0 && (!g || !idx))) return PAMNET_ENULL;
-    int64_t blocks = ceil_div(n, 128);                        // >= 128 rows per workgroup: few partials for the finish
-    blocks = blocks < 1 ? 1 : (blocks > TYPE_BLOCKS ? TYPE_BLOCKS : blocks);
+    const int blocks = type_rows::blocks_for_rows(n);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(type_rows_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4*)g, idx, n,
                        (int)n_types, (int)d4, static_cast<float4*>(scratch));

@@ -157,6 +157,36 @@ class _PAMNetBase(nn.Module):
     def _narrow(self, x):
         return modules.IMPL == 'fused' and narrow.supported(x, self.dim)
 
+    def _input_stage(self, data, g, tape, lin_a, lin_b=None):
+        """(x, e_l, e_g, e_sbf) of models.py:107/119/140 and 185-188 as ONE launch (two in the backward) on the dim = 128
+        path: the Bessel rows are formed inside the embedding kernel from the edge lengths, the type-table rows ride along.
+        lin_a (, lin_b): the sbf embedding(s) -- with lin_b, rows of g.tp_kind == 1 use lin_b.  None when not applicable."""
+        if not (modules.IMPL == 'fused' and self.dim == fused.D and g.sbf.is_cuda and g.sbf.size(1) == 42):
+            return None
+        lin_l, lin_g = self.mlp_rbf_l[0][0], self.mlp_rbf_g[0][0]
+        layers = [(None, g.dist_l, self.cutoff_l, None, True, True), (None, g.dist_g, self.cutoff_g, None, True, True),
+                  (g.sbf, None, None, g.tp_kind if lin_b is not None else None, True, True)]
+        params = [self.rbf_l.freq, lin_l.weight, lin_l.bias, self.rbf_g.freq, lin_g.weight, lin_g.bias,
+                  lin_a.weight, lin_a.bias]
+        if lin_b is not None:
+            params += [lin_b.weight, lin_b.bias]
+        x_raw, types = data.x, None
+        if self.dataset == 'PDBbind':
+            xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
+            feats = xr[:, 3:].to(torch.float32).contiguous()
+            if feats.size(1) != 18:
+                return None
+            layers.append((feats, None, None, None, False, False))                          # models.py:119
+            params.append(self.init_linear.weight)
+        else:
+            if not ops.type_rows_supported(self.embeddings):
+                return None
+            col = x_raw if self.dataset == 'QM9' else (x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw)[:, -1]
+            types = col.to(torch.int32).contiguous()
+            params.append(self.embeddings)                                                  # models.py:107,140
+        outs = fused.input_stage(fused.InputSpec(layers, types), params, tape=tape)
+        return outs[3], outs[0], outs[1], outs[2]
+
     @staticmethod
     def _embed_fused(x, seq):
         return modules.IMPL == 'fused' and len(seq) == 1 and fused.embed_supported(x, seq[0][0])
@@ -174,6 +204,12 @@ class _PAMNetBase(nn.Module):
             x, o, a = self.local_layer[k](x, e_l, e_sbf, g)
             outs.append(o), atts.append(a), self._x_layers.append(x)
         return ops.stack_rows(outs), ops.stack_rows(atts)                                    # [2L, N]
+
+    def _layers_and_pool(self, x, e_l, e_g, e_sbf, g, tape, mean):
+        outs, atts = self._run_layers(x, e_l, e_g, e_sbf, g, tape)
+        out, node_out = ops.fuse_pool(outs, atts, g, mean=mean, tape=tape)                  # models.py:206-224
+        self._graph_cache, self._node_out = g, node_out
+        return out if tape is not None else out.view(-1)        # (ops._Whole hands autograd its own view)
 
     def _one_node(self):
         """Training forward with preallocated gradients (train.FlatParams) on the fused dim = 128 path or the narrow-width
@@ -241,6 +277,10 @@ class PAMNet(_PAMNetBase):
         return self._forward_on(data, g, None)
 
     def _forward_on(self, data, g, tape):
+        staged = self._input_stage(data, g, tape, self.mlp_sbf2[0][0], self.mlp_sbf1[0][0])
+        if staged is not None:
+            x, e_l, e_g, e_sbf = staged
+            return self._layers_and_pool(x, e_l, e_g, e_sbf, g, tape, self._rna)
         x = self._embed(data, g, tape)
         e_l, e_g, sbf = self._edge_embeddings(g, tape)
         # mlp_sbf2 on triplet rows, mlp_sbf1 on pair rows (models.py:187-188), rows grouped by target edge
@@ -253,10 +293,7 @@ class PAMNet(_PAMNetBase):
             y1 = mlp_apply(self.mlp_sbf1, sbf.index_select(0, g.pair_rows))
             e_sbf = torch.zeros((sbf.size(0), self.dim), dtype=sbf.dtype, device=sbf.device)
             e_sbf = e_sbf.index_copy(0, g.trip_rows, y2).index_copy(0, g.pair_rows, y1)
-        outs, atts = self._run_layers(x, e_l, e_g, e_sbf, g, tape)
-        out, node_out = ops.fuse_pool(outs, atts, g, mean=self._rna, tape=tape)             # models.py:206-224
-        self._graph_cache, self._node_out = g, node_out
-        return out if tape is not None else out.view(-1)        # (ops._Whole hands autograd its own view)
+        return self._layers_and_pool(x, e_l, e_g, e_sbf, g, tape, self._rna)
 
 
 class PAMNet_s(_PAMNetBase):
@@ -284,6 +321,10 @@ class PAMNet_s(_PAMNetBase):
         return self._forward_on(data, g, None)
 
     def _forward_on(self, data, g, tape):
+        staged = self._input_stage(data, g, tape, self.mlp_sbf[0][0])
+        if staged is not None:
+            x, e_l, e_g, e_sbf = staged
+            return self._layers_and_pool(x, e_l, e_g, e_sbf, g, tape, False)
         x = self._embed(data, g, tape)
         e_l, e_g, sbf = self._edge_embeddings(g, tape)
         if self._embed_fused(sbf, self.mlp_sbf):
@@ -292,7 +333,4 @@ class PAMNet_s(_PAMNetBase):
             e_sbf = narrow.embed(sbf, self.mlp_sbf[0][0])
         else:
             e_sbf = mlp_apply(self.mlp_sbf, sbf)
-        outs, atts = self._run_layers(x, e_l, e_g, e_sbf, g, tape)
-        out, node_out = ops.fuse_pool(outs, atts, g, mean=False, tape=tape)
-        self._graph_cache, self._node_out = g, node_out
-        return out if tape is not None else out.view(-1)        # (ops._Whole hands autograd its own view)
+        return self._layers_and_pool(x, e_l, e_g, e_sbf, g, tape, False)

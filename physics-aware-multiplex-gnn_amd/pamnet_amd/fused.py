@@ -233,6 +233,108 @@ def embed(x, lin0, lin1=None, kind=None, act=True, tape=None, need_dx=False):
     return _apply(_Embed, x, kind, act, plist, *params, tape=tape)
 
 
+class InputSpec(object):
+    """Non-differentiable inputs of the input stage: `layers` = [(x | None, dist | None, cutoff, kind | None, act), ...] in
+    the order of the parameter groups; `types` = (idx int32 [N]) or None."""
+
+    def __init__(self, layers, types=None):
+        self.layers, self.types = layers, types
+
+
+class _InputStage(torch.autograd.Function):
+    """Every input embedding of a forward in one launch, their backward in two (csrc/embed.hip, pamnet_embed_multi_*):
+    mlp_rbf_l / mlp_rbf_g on Bessel rows formed in the kernel from the edge lengths (models.py:185-186,
+    layers/basic.py:59-76), mlp_sbf2 / mlp_sbf1 on the triplet / pair rows (models.py:187-188), and `embeddings[x]` or
+    init_linear (models.py:107,119,140).  params, per layer: [freq] (layers with `dist`), W0, b0 | None, [W1, b1] (layers
+    with `kind`); then the type table when spec.types is given.  Returns one [rows, 128] tensor per layer (+ the table
+    rows last)."""
+
+    @staticmethod
+    def _split(spec, params):
+        it = iter(params)
+        groups = []
+        for (x, dist, cutoff, kind, act, has_bias) in spec.layers:
+            freq = next(it) if dist is not None else None
+            W0 = next(it)
+            b0 = next(it) if has_bias else None
+            W1, b1 = (next(it), next(it)) if kind is not None else (None, None)
+            groups.append((freq, W0, b0, W1, b1))
+        table = next(it) if spec.types is not None else None
+        return groups, table
+
+    @staticmethod
+    def forward(ctx, spec, plist, *params):
+        groups, table = _InputStage._split(spec, params)
+        n = len(spec.layers)
+        jobs = (lib.EmbedJob * n)()
+        outs = []
+        ref = params[0]
+        for j, ((x, dist, cutoff, kind, act, _hb), (freq, W0, b0, W1, b1)) in enumerate(zip(spec.layers, groups)):
+            jb = jobs[j]
+            rows = dist.numel() if dist is not None else x.size(0)
+            out = _empty(rows, D, like=ref)
+            jb.x, jb.dist, jb.freq = lib.ptr(x), lib.ptr(dist), lib.ptr(freq)
+            jb.cutoff, jb.K, jb.act, jb.rows = float(cutoff or 0.0), (16 if dist is not None else x.size(1)), 1 if act else 0, rows
+            jb.kind, jb.W0, jb.b0, jb.W1, jb.b1 = lib.ptr(kind), lib.ptr(W0), lib.ptr(b0), lib.ptr(W1), lib.ptr(b1)
+            jb.out = lib.ptr(out)
+            outs.append(out)
+        tj = None
+        if table is not None:
+            idx = spec.types
+            xo = _empty(idx.numel(), D, like=ref)
+            tj = lib.TypeRowsJob(lib.ptr(table), lib.ptr(idx), idx.numel(), table.size(0), lib.ptr(xo), None, None, None)
+            outs.append(xo)
+        lib.call('pamnet_embed_multi_fwd_f32', ctypes.addressof(jobs), n, ctypes.addressof(tj) if tj is not None else None,
+                 lib.stream_of(ref))
+        ctx.save_for_backward(*params)
+        ctx.spec, ctx.plist = spec, plist
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        from .ops import reduce_scratch
+        spec, params = ctx.spec, ctx.saved_tensors
+        groups, table = _InputStage._split(spec, params)
+        direct, g = _grad_buffers(ctx.plist)
+        ggroups, gtable = _InputStage._split(spec, g)
+        n = len(spec.layers)
+        jobs = (lib.EmbedJob * n)()
+        ref = params[0]
+        need = ctypes.c_int64(0)
+        keep = []
+        for j, ((x, dist, cutoff, kind, act, _hb), (freq, W0, b0, W1, b1), (gf, gW0, gb0, gW1, gb1)) in enumerate(
+                zip(spec.layers, groups, ggroups)):
+            jb = jobs[j]
+            rows = dist.numel() if dist is not None else x.size(0)
+            K = 16 if dist is not None else x.size(1)
+            gout = gouts[j]
+            gout = torch.zeros(rows, D, dtype=torch.float32, device=ref.device) if gout is None else gout.contiguous()
+            lib.call('pamnet_embed_scratch_floats', rows, K, ctypes.addressof(need))
+            partial = _empty(int(need.value), like=ref)
+            keep += [gout, partial]
+            jb.x, jb.dist, jb.freq = lib.ptr(x), lib.ptr(dist), lib.ptr(freq)
+            jb.cutoff, jb.K, jb.act, jb.rows = float(cutoff or 0.0), K, 1 if act else 0, rows
+            jb.kind, jb.W0, jb.b0, jb.W1, jb.b1 = lib.ptr(kind), lib.ptr(W0), lib.ptr(b0), lib.ptr(W1), lib.ptr(b1)
+            jb.gout, jb.partial = lib.ptr(gout), lib.ptr(partial)
+            jb.dW0, jb.db0, jb.dW1, jb.db1, jb.dfreq = lib.ptr(gW0), lib.ptr(gb0), lib.ptr(gW1), lib.ptr(gb1), lib.ptr(gf)
+        tj = None
+        if table is not None:
+            idx = spec.types
+            gx = gouts[n]
+            gx = torch.zeros(idx.numel(), D, dtype=torch.float32, device=ref.device) if gx is None else gx.contiguous()
+            keep.append(gx)
+            tj = lib.TypeRowsJob(None, lib.ptr(idx), idx.numel(), table.size(0), None, lib.ptr(gx),
+                                 lib.ptr(reduce_scratch(ref.device)), lib.ptr(gtable))
+        lib.call('pamnet_embed_multi_bwd_f32', ctypes.addressof(jobs), n, ctypes.addressof(tj) if tj is not None else None,
+                 lib.stream_of(ref))
+        return (None, None) + _ret(direct, g)
+
+
+def input_stage(spec, params, tape=None):
+    """spec: InputSpec; params: the matching flat parameter list (see _InputStage)."""
+    return _apply(_InputStage, spec, params, *params, tape=tape)
+
+
 def embed_supported(x, lin):
     return x.is_cuda and lin.out_features == D and lin.in_features in (16, 18, 42)
 

@@ -104,3 +104,20 @@ def call(name, *args):
     rc = fn(*args)
     if rc:
         check(rc, name)
+
+
+_P = ctypes.c_void_p
+
+
+class EmbedJob(ctypes.Structure):
+    """pamnet_embed_job (include/pamnet_hip.h)."""
+    _fields_ = [('x', _P), ('dist', _P), ('freq', _P), ('cutoff', ctypes.c_float), ('K', ctypes.c_int32),
+                ('act', ctypes.c_int32), ('rows', ctypes.c_int64), ('kind', _P), ('W0', _P), ('b0', _P), ('W1', _P),
+                ('b1', _P), ('out', _P), ('gout', _P), ('dW0', _P), ('db0', _P), ('dW1', _P), ('db1', _P), ('dfreq', _P),
+                ('dx', _P), ('partial', _P)]
+
+
+class TypeRowsJob(ctypes.Structure):
+    """pamnet_type_rows_job (include/pamnet_hip.h)."""
+    _fields_ = [('table', _P), ('idx', _P), ('n', ctypes.c_int64), ('n_types', ctypes.c_int64), ('out', _P), ('g', _P),
+                ('scratch', _P), ('dtable', _P)]

@@ -181,6 +181,99 @@ def test_embed_layers(dev, rows, case):
         assert x.grad is None
 
 
+def _bessel_rows(dist, freq, cutoff):
+    """layers/basic.py:36-51,74-76 in torch (p = 5 envelope)."""
+    x = (dist / cutoff).unsqueeze(-1)
+    u = torch.where(x < 1.0, 1.0 / x - 21.0 * x ** 5 + 35.0 * x ** 6 - 15.0 * x ** 7, torch.zeros_like(x))
+    return u * torch.sin(freq * x)
+
+
+@pytest.mark.parametrize('sizes', [(0, 0, 0, 0), (1, 1, 1, 1), (63, 700, 65, 37), (4316, 32888, 17640, 2286),
+                                    (300, 70001, 40000, 513)])
+@pytest.mark.parametrize('variant', ['types_two', 'init18_two', 'types_one'])
+def test_input_stage(dev, sizes, variant):
+    """pamnet_embed_multi_*: Bessel rows + mlp_rbf_l/g, the sbf embeddings (two weight sets by row kind, or one) and the
+    type-table rows / init_linear in one forward launch and two backward launches, against torch (fp32 and fp64):
+    outputs and every gradient, including the Bessel frequencies whose [rows, 16] gradient is never materialised."""
+    import math
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from pamnet_amd import fused
+    e_l, e_g, tp, n = sizes
+    torch.manual_seed(sum(sizes) + len(variant))
+    two, init18 = variant != 'types_one', variant == 'init18_two'
+    cl, cg = 2.0, 5.0
+    dist_l = (torch.rand(e_l, device=dev) * 1.9 + 0.05)
+    dist_g = (torch.rand(e_g, device=dev) * 5.5 + 0.05)                   # some beyond the cutoff: envelope 0
+    sbf = torch.randn(tp, 42, device=dev)
+    kind = (torch.rand(tp, device=dev) < 0.4).to(torch.int32) if two else None
+    freq_l = nn.Parameter((torch.arange(1, 17, device=dev) * math.pi + 0.01 * torch.randn(16, device=dev)).float())
+    freq_g = nn.Parameter((torch.arange(1, 17, device=dev) * math.pi + 0.01 * torch.randn(16, device=dev)).float())
+    lin_l, lin_g = nn.Linear(16, D).to(dev), nn.Linear(16, D).to(dev)
+    lin_a, lin_b = nn.Linear(42, D).to(dev), (nn.Linear(42, D).to(dev) if two else None)
+    layers = [(None, dist_l, cl, None, True, True), (None, dist_g, cg, None, True, True), (sbf, None, None, kind, True, True)]
+    params = [freq_l, lin_l.weight, lin_l.bias, freq_g, lin_g.weight, lin_g.bias, lin_a.weight, lin_a.bias]
+    if two:
+        params += [lin_b.weight, lin_b.bias]
+    types = feats = None
+    if init18:
+        feats = torch.randn(n, 18, device=dev)
+        init = nn.Linear(18, D, bias=False).to(dev)
+        layers.append((feats, None, None, None, False, False))
+        params.append(init.weight)
+    else:
+        table = nn.Parameter(torch.randn(5, D, device=dev))
+        types = torch.randint(0, 5, (n,), device=dev, dtype=torch.int32)
+        params.append(table)
+    ws = [torch.randn(r, D, device=dev, dtype=torch.float64) for r in (e_l, e_g, tp, n)]
+
+    def ref(dtype):
+        ps = [p.detach().to(dtype).requires_grad_(True) for p in params]
+        it = iter(ps)
+        outs = []
+        for dist, c in ((dist_l, cl), (dist_g, cg)):
+            f, W, b = next(it), next(it), next(it)
+            outs.append(F.silu(F.linear(_bessel_rows(dist.to(dtype), f, c), W, b)))
+        W0, b0 = next(it), next(it)
+        z = F.linear(sbf.to(dtype), W0, b0)
+        if two:
+            W1, b1 = next(it), next(it)
+            z = torch.where(kind.bool().unsqueeze(1), F.linear(sbf.to(dtype), W1, b1), z)
+        outs.append(F.silu(z))
+        last = next(it)
+        outs.append(F.linear(feats.to(dtype), last) if init18 else last[types.long()])
+        sum((o * w.to(dtype)).sum() for o, w in zip(outs, ws)).backward()
+        return [o.detach() for o in outs], [p.grad if p.grad is not None else torch.zeros_like(p) for p in ps]
+
+    outs = fused.input_stage(fused.InputSpec(layers, types), params)
+    sum((o * w.float()).sum() for o, w in zip(outs, ws)).backward()
+    o32, g32 = ref(torch.float32)
+    o64, g64 = ref(torch.float64)
+    for o, r in zip(outs, (e_l, e_g, tp, n)):
+        assert o.shape == (r, D)
+    for k, (a, b, c) in enumerate(zip(outs, o32, o64)):
+        if a.numel():
+            ok, info = _ok(a, b, c)
+            assert ok, ('out', k, info)
+    for k, (p, b, c) in enumerate(zip(params, g32, g64)):
+        assert p.grad is not None and p.grad.shape == p.shape
+        if float(c.abs().max()) == 0.0:
+            assert float(p.grad.abs().max()) == 0.0, k
+            continue
+        ok, info = _ok(p.grad, b, c, floor=1e-5)
+        assert ok, ('grad', k, tuple(p.shape), info)
+    # deterministic, and identical to the one-layer-per-launch entry points on the plain layers
+    g1 = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    outs2 = fused.input_stage(fused.InputSpec(layers, types), params)
+    sum((o * w.float()).sum() for o, w in zip(outs2, ws)).backward()
+    assert all(torch.equal(a, b) for a, b in zip(outs, outs2))
+    assert all(torch.equal(a, p.grad) for a, p in zip(g1, params))
+    y = fused.embed(sbf, lin_a, lin_b, kind=kind)
+    assert torch.equal(y, outs[2])
+
+
 @pytest.mark.parametrize('waves', ['4', '8'])
 def test_edge_kernel_geometries(waves):
     """Both workgroup geometries of the edge kernels (8 waves, one per CU / paired 4-wave workgroups) give the same
