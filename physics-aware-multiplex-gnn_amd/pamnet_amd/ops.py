@@ -30,11 +30,22 @@ class _NoGradCtx(object):
 import os as _os
 
 TAPE = _os.environ.get('PAMNET_TAPE', '1') != '0'      # measurement aid: 0 = every Function is its own autograd node
-_tape_stack = []          # the Tape of the forward being recorded (pushed / popped by _Whole.forward only)
+import threading as _threading
+
+_tls = _threading.local()  # .stack: the Tapes of the forwards being recorded on THIS thread (pushed / popped by
+#                            _Whole.forward only; the input pipeline's worker thread must not see the trainer's tape)
+
+
+def _tape_stack_of_thread():
+    st = getattr(_tls, 'stack', None)
+    if st is None:
+        st = _tls.stack = []
+    return st
 
 
 def current_tape():
-    return _tape_stack[-1] if _tape_stack else None
+    st = getattr(_tls, 'stack', None)
+    return st[-1] if st else None
 
 
 def apply(fn, *args, tape=None):
@@ -125,11 +136,12 @@ class _Whole(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, run):
         tape = Tape()
-        _tape_stack.append(tape)
+        stack = _tape_stack_of_thread()
+        stack.append(tape)
         try:
             out = run(tape)
         finally:
-            _tape_stack.pop()
+            stack.pop()
         ctx.tape, ctx.out = tape, out
         return out.view(-1)                  # a fresh tensor object for autograd; the tape keys on `out` itself
 

@@ -143,6 +143,58 @@ def plan_buckets(layer_ranges, numel, n_buckets):
     return buckets, tail
 
 
+class Prefetcher(object):
+    """Builds the graph of the NEXT batch (model.prepare: graph construction + spherical basis) on a side stream from a
+    worker thread.  Graph construction needs one or two host round trips for its data-dependent sizes; on the thread that
+    enqueues the training step each of them stops the enqueueing until the side stream has caught up, and at QM9 sizes the
+    host is then no longer ahead of the GPU at the start of the next step (~0.1 ms of idle main queue per 2.6 ms step).
+    From a worker the waits overlap the enqueueing (ctypes / torch release the GIL while they block).  The batch is handed
+    back through `data._pamnet_future`; `wait(data)` joins it and makes the current stream wait for the side stream.
+    PAMNET_PREFETCH_THREAD=0 builds on the calling thread (same streams, same events)."""
+
+    def __init__(self, model, device):
+        import os
+        self.model, self.device = model, device
+        self.side = torch.cuda.Stream(device=device)
+        self.pool = None
+        if os.environ.get('PAMNET_PREFETCH_THREAD', '1') != '0':
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='pamnet-prefetch')
+
+    def _build(self, data, need_grad, main):
+        torch.cuda.set_device(self.device)
+        _wait_inputs(self.side, data)
+        with torch.cuda.stream(self.side):
+            self.model.prepare(data, need_grad=need_grad)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        data._pamnet_ready = ev
+        # the tensors were allocated on the side stream but will be consumed on the main stream
+        for v in _graph_tensors(data._pamnet_prepared):
+            v.record_stream(main)
+
+    def submit(self, data, need_grad=True):
+        """The batch tensors must be complete when this is called -- OR carry `data.inputs_ready`, a torch.cuda.Event
+        recorded on the stream that produces them (pinned .to(device, non_blocking=True), GPU-side collation): the side
+        stream then waits for exactly that event (synth.Batch.to(..., non_blocking=True) records it).  The side stream
+        does not wait for the main stream (that would serialise it behind the whole step)."""
+        main = torch.cuda.current_stream(self.device)
+        if self.pool is None:
+            self._build(data, need_grad, main)
+        else:
+            data._pamnet_future = self.pool.submit(self._build, data, need_grad, main)
+
+    def wait(self, data):
+        fut = getattr(data, '_pamnet_future', None)
+        if fut is not None:
+            data._pamnet_future = None
+            fut.result()                                   # re-raises what the worker raised (bad inputs, ...)
+        ev = getattr(data, '_pamnet_ready', None)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            data._pamnet_ready = None
+
+
 class Trainer(object):
     def __init__(self, model, lr=1e-4, weight_decay=0.0, ema_decay=0.999, max_grad_norm=1000.0, betas=(0.9, 0.999),
                  eps=1e-8, world_size=1, process_group=None, overlap_comm=True, n_buckets=3, native_optimizer=True):
@@ -311,31 +363,17 @@ class Trainer(object):
 
     # -- input pipelining -----------------------------------------------------------------------------------------------
     def prefetch(self, data):
-        """Build `data`'s graph on the side stream (model.prepare); forward() picks it up.
-        The side stream does not wait for the main stream (that would serialise it behind the whole step), so the batch
-        tensors must be complete when this is called -- OR carry `data.inputs_ready`, a torch.cuda.Event recorded on the
-        stream that produces them (pinned .to(device, non_blocking=True), GPU-side collation): the side stream then waits
-        for exactly that event (synth.Batch.to(..., non_blocking=True) records it)."""
+        """Build `data`'s graph on the side stream, from the prefetch worker (see Prefetcher); forward() picks it up."""
         if not hasattr(self.model, 'prepare') or not self.fp.flat.is_cuda:
             return
-        if getattr(self, '_side', None) is None:
-            self._side = torch.cuda.Stream(device=self.fp.flat.device)
-        main = torch.cuda.current_stream(self.fp.flat.device)
-        _wait_inputs(self._side, data)
-        with torch.cuda.stream(self._side):
-            self.model.prepare(data)
-            ev = torch.cuda.Event()
-            ev.record(self._side)
-        data._pamnet_ready = ev
-        # the tensors were allocated on the side stream but will be consumed on the main stream
-        for v in _graph_tensors(data._pamnet_prepared):
-            v.record_stream(main)
+        if getattr(self, '_prefetcher', None) is None:
+            self._prefetcher = Prefetcher(self.model, self.fp.flat.device)
+        self._prefetcher.submit(data)
 
     def _wait_prepared(self, data):
-        ev = getattr(data, '_pamnet_ready', None)
-        if ev is not None:
-            torch.cuda.current_stream(self.fp.flat.device).wait_event(ev)
-            data._pamnet_ready = None
+        pf = getattr(self, '_prefetcher', None)
+        if pf is not None:
+            pf.wait(data)
 
     # -- evaluation under the EMA weights (main_qm9.py:29-37) ---------------------------------------------------------
     def ema_assign(self):
@@ -371,29 +409,20 @@ def predict(model, batches):
     except StopIteration:
         return
     dev = next(model.parameters()).device
-    pipelined = dev.type == 'cuda' and hasattr(model, 'prepare')
-    side = torch.cuda.Stream(device=dev) if pipelined else None
+    pf = Prefetcher(model, dev) if (dev.type == 'cuda' and hasattr(model, 'prepare')) else None
     while cur is not None:
         nxt = next(it, None)
-        ev = getattr(cur, '_pamnet_ready', None)
-        if ev is not None:
-            torch.cuda.current_stream(dev).wait_event(ev)
-            cur._pamnet_ready = None
-        if pipelined and nxt is not None:
-            # queued BEFORE this batch's forward: the graph kernels are small, and their one host round trip resolves
-            # while the previous forward is still running instead of waiting behind this one
-            main = torch.cuda.current_stream(dev)
-            _wait_inputs(side, nxt)
-            with torch.cuda.stream(side):
-                model.prepare(nxt, need_grad=False)
-                e = torch.cuda.Event()
-                e.record(side)
-            nxt._pamnet_ready = e
-            for v in _graph_tensors(nxt._pamnet_prepared):
-                v.record_stream(main)
+        if pf is not None:
+            pf.wait(cur)
+            if nxt is not None:
+                # queued BEFORE this batch's forward: the graph kernels are small, and their host round trip resolves
+                # (on the worker) while this forward is being enqueued and run
+                pf.submit(nxt, need_grad=False)
         out = model(cur)
         yield cur, out
         cur = nxt
+    if pf is not None and pf.pool is not None:
+        pf.pool.shutdown(wait=True)
 
 
 def _wait_inputs(stream, data):
