@@ -536,6 +536,31 @@ int pamnet_narrow_embed_bwd_f32(const float* F, int64_t m, int64_t k, int64_t d,
                                 const float* ba, const float* Wb, const float* bb, const float* dy, float* df,
                                 float* partial, float* dW, float* db, pamnet_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Narrow-width layer-stack engine (csrc/narrow_engine.hip): the n_layer x (global, local) loop of PAMNet.forward
+ * (models.py:196-204) at d = 16 / 32 / 64 in ONE call per direction -- the counterpart of pamnet_stack_*_f32.
+ * sizes, graph_idx, gparams / lparams (n_layer x 28 / 35 device pointers; mlp_m etc. are [d, 3d]), ggrads / lgrads,
+ * outs / atts ([2 n_layer, n]), saved / temp (caller-owned arenas sized by pamnet_narrow_stack_workspace; `saved` must
+ * survive until the backward) and layer_done (nullable hipEvent_t handles) exactly as documented for pamnet_stack_*_f32.
+ * The node-side chains of a layer are single launches (pre: mlp_x1 + projections; tail: mlp_x2 .. heads); weight
+ * gradients are written (not accumulated) in fixed summation order; d_x0, d_eg, d_rbf, d_sbf are written.
+ * The backward needs n, e_g, e_l, tp > 0.  pamnet_narrow_stack_layout: layout[0] = floats per layer pair in `saved`,
+ * layout[1] / [2] = offset of the global / local layer's node output [n, d] within a pair.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pamnet_narrow_stack_workspace(int64_t n, int64_t eg, int64_t el, int64_t tp, int64_t n_layer, int64_t d,
+                                  int64_t* saved_floats, int64_t* temp_floats);
+int pamnet_narrow_stack_layout(int64_t n, int64_t eg, int64_t el, int64_t tp, int64_t d, int64_t* layout);
+int pamnet_narrow_stack_fwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, int64_t n_layer, int64_t d,
+                                const float* x0, const float* e_g, const float* rbf_e, const float* e_sbf,
+                                const float* const* gparams, const float* const* lparams, float* saved, float* temp,
+                                float* outs, float* atts, pamnet_stream_t stream);
+int pamnet_narrow_stack_bwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, int64_t n_layer, int64_t d,
+                                const float* x0, const float* e_g, const float* rbf_e, const float* e_sbf,
+                                const float* const* gparams, const float* const* lparams, const float* saved, float* temp,
+                                const float* d_outs, const float* d_atts, float* const* ggrads, float* const* lgrads,
+                                float* d_x0, float* d_eg, float* d_rbf, float* d_sbf, void* const* layer_done,
+                                pamnet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

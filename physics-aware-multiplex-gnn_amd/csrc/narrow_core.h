@@ -1,0 +1,1120 @@
+// Narrow-width (dim = 16 / 32 / 64) message kernels: the RNA configurations of the reference (inference_rna_puzzles.py:
+// dim 16, n_layer 1; main_rna_puzzles.py: dim 64, n_layer 2) have a few thousand nodes but ~10^6 global edges and
+// triplet/pair rows per batch, so the row-wise work is HBM-bound, not MFMA-bound as at dim = 128.
+//
+// Design (different from the 128-wide kernels on purpose):
+//   * one wavefront owns a 16-row tile end to end; workgroups are just 4 independent waves that share the weight
+//     images, there is no barrier inside the row loop;
+//   * rows are read once as MFMA A fragments straight from HBM (lane l: row l&15, floats 16q + 4(l>>4) .. +3 = one
+//     16-byte load per 16 columns), all GEMMs of a stage chain through registers, and the D->A relayout between two
+//     GEMMs goes through a wave-private LDS tile;
+//   * backward kernels recompute the forward pre-activations from the row tile instead of reading saved ones
+//     (a [rows, D] store + load costs more than D/16 extra MFMA groups), and form the weight gradients in the same
+//     pass: the D-layout accumulators of dZ are exactly the A operand of dW = dZ^T X with the row index as k;
+//   * weight gradients are reduced wave -> workgroup (LDS, fixed order) -> grid (second kernel, fixed order):
+//     deterministic, no atomics.
+//
+// Reference semantics: layers/global_message_passing.py:52-53 (message), layers/local_message_passing.py:48-49
+// (mlp_sbf), models.py:185-188 (edge-embedding MLPs).
+#pragma once
+#include "common.h"
+#include "gemm_core.h"
+
+namespace {
+
+using pamnet::f32x4;
+using pamnet::sigmoidf_fast;
+
+constexpr int NWG = 256;                      // forward kernels: 4 independent waves per workgroup
+// Backward kernels end with one partial gradient row per workgroup, so they run at most one workgroup per CU and get
+// their occupancy from more waves per workgroup where the register budget allows (d = 64 needs ~350 registers a lane).
+__host__ __device__ constexpr int bwd_waves(int d) { return d == 16 ? 16 : (d == 32 ? 8 : 4); }
+// (two waves per SIMD for the single-layer backward at d = 64 fit in 256 registers but measured slower on node-sized
+// inputs: 25.7 vs 23.3 us at 17.7 k rows, 230 vs 239 us at 669 k)
+__host__ __device__ constexpr int lin_bwd_waves(int d) { return bwd_waves(d); }
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- weight images in LDS ------------------------------------------------------------------------------------------
+// img[(jt * NQ + q) * 64 + lane] = the float4 lane feeds to the four MFMAs of (output tile jt, k-group q).
+//   TRANS = false: Y = X W^T, W [out][in] (row stride ld, `kin` valid input columns): b.t = W[16jt + c][16q + 4kg + t]
+//   TRANS = true : Y = X W,   W [k][out]:                                            b.t = W[16q + 4kg + t][16jt + c]
+template <int NJ, int NQ, bool TRANS>
+__device__ __forceinline__ void build_image(float4* img, const float* __restrict__ W, int ld, int kin) {
+    for (int idx = threadIdx.x; idx < NJ * NQ * 64; idx += blockDim.x) {
+        const int lane = idx & 63, t = idx >> 6;
+        const int q = t % NQ, jt = t / NQ;
+        const int c = lane & 15, kg = lane >> 4;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!TRANS) {
+                const int k = 16 * q + 4 * kg + u;
+                v[u] = (k < kin) ? W[(size_t)(16 * jt + c) * ld + k] : 0.f;
+            } else {
+                const int col = 16 * jt + c;
+                v[u] = (col < kin) ? W[(size_t)(16 * q + 4 * kg + u) * ld + col] : 0.f;
+            }
+        }
+        img[idx] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// consecutive MFMAs go to different accumulators (a dependent 16x16x4 pair issues 40 cycles apart, independent ones 32)
+template <int NJ, int NQ>
+__device__ __forceinline__ void mma_img(f32x4 (&acc)[NJ], const float4 (&a)[NQ], const float4* img, int lane) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        float4 b[NJ];
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) b[jt] = img[(jt * NQ + q) * 64 + lane];
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) acc[jt] = mfma4(a[q].x, b[jt].x, acc[jt]);
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) acc[jt] = mfma4(a[q].y, b[jt].y, acc[jt]);
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) acc[jt] = mfma4(a[q].z, b[jt].z, acc[jt]);
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) acc[jt] = mfma4(a[q].w, b[jt].w, acc[jt]);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void zero(f32x4 (&acc)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// Row loads never sit under a branch: out-of-range rows read row m - 1 (a valid address, m > 0) and are zeroed by a
+// select afterwards.  (`ok ? *p : 0` made the compiler wrap every element load in its own exec-masked block with a
+// vmcnt(0) wait and whole-fragment register copies: 3x slower kernels.)
+// rows as A fragments (row stride D floats, 16-byte aligned); rows >= m read as zero
+template <int D>
+__device__ __forceinline__ void load_a(float4 (&a)[D / 16], const float* __restrict__ X, int64_t row0, int64_t m, int lane) {
+    const int64_t row = row0 + (lane & 15);
+    const bool ok = row < m;
+    const float* p = X + (ok ? row : m - 1) * D + 4 * (lane >> 4);
+#pragma unroll
+    for (int q = 0; q < D / 16; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(p + 16 * q);
+        a[q] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+}
+
+// rows in accumulator ("D") layout: v[jt][r] = X[row0 + 4kg + r][16jt + c]; rows >= m read as zero
+template <int D>
+__device__ __forceinline__ void load_d(f32x4 (&v)[D / 16], const float* __restrict__ X, int64_t row0, int64_t m, int lane,
+                                       int64_t ld = D) {
+    const int c = lane & 15, kg = lane >> 4;
+    float t[4][D / 16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + 4 * kg + r;
+        const float* p = X + (row < m ? row : m - 1) * ld + c;
+#pragma unroll
+        for (int jt = 0; jt < D / 16; ++jt) t[r][jt] = p[16 * jt];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool ok = row0 + 4 * kg + r < m;
+#pragma unroll
+        for (int jt = 0; jt < D / 16; ++jt) v[jt][r] = ok ? t[r][jt] : 0.f;
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void store_d(const f32x4 (&v)[D / 16], float* __restrict__ Y, int64_t row0, int64_t m, int lane,
+                                        int64_t ld = D) {
+    const int c = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + 4 * kg + r;
+        if (row < m) {
+            float* p = Y + row * ld + c;
+#pragma unroll
+            for (int jt = 0; jt < D / 16; ++jt) p[16 * jt] = v[jt][r];
+        }
+    }
+}
+
+// accumulator layout -> A fragments through the wave's private LDS tile ([16][D + 4] floats)
+template <int D>
+__device__ __forceinline__ void d_to_a(float4 (&a)[D / 16], const f32x4 (&v)[D / 16], float* tile, int lane) {
+    constexpr int LD = D + 4;
+    const int c = lane & 15, kg = lane >> 4;
+    wave_lds_sync();
+#pragma unroll
+    for (int jt = 0; jt < D / 16; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[(4 * kg + r) * LD + 16 * jt + c] = v[jt][r];
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < D / 16; ++q) a[q] = *reinterpret_cast<const float4*>(tile + c * LD + 16 * q + 4 * kg);
+}
+
+// A fragments -> accumulator layout through the wave's private LDS tile (the reverse of d_to_a): lets a row tile that
+// was fetched with four coalesced 16-byte loads per lane also serve as the weight-gradient operand, instead of
+// sixteen more 4-byte loads per lane
+template <int D>
+__device__ __forceinline__ void a_to_d(f32x4 (&v)[D / 16], const float4 (&a)[D / 16], float* tile, int lane) {
+    constexpr int LD = D + 4;
+    const int c = lane & 15, kg = lane >> 4;
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < D / 16; ++q) *reinterpret_cast<float4*>(tile + c * LD + 16 * q + 4 * kg) = a[q];
+    wave_lds_sync();
+#pragma unroll
+    for (int jt = 0; jt < D / 16; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[jt][r] = tile[(4 * kg + r) * LD + 16 * jt + c];
+}
+
+// dW[o][k] += sum_rows dz[row][o] * x[row][k], both operands in accumulator layout (rows are the MFMA k index)
+template <int NJ, int NK>
+__device__ __forceinline__ void wgrad_acc(f32x4 (&w)[NJ][NK], const f32x4 (&dz)[NJ], const f32x4 (&x)[NK]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int jo = 0; jo < NJ; ++jo)
+#pragma unroll
+            for (int jk = 0; jk < NK; ++jk) w[jo][jk] = mfma4(dz[jo][r], x[jk][r], w[jo][jk]);
+}
+
+// column sums of an accumulator-layout tile over the wave's rows: result valid on every lane for column 16jt + c
+template <int NJ>
+__device__ __forceinline__ void colsum_acc(float (&s)[NJ], const f32x4 (&dz)[NJ]) {
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) s[jt] += (dz[jt][0] + dz[jt][1]) + (dz[jt][2] + dz[jt][3]);
+}
+
+// ---- workgroup reduction of per-wave gradient accumulators -----------------------------------------------------------
+// `red` (LDS, reused image area) is laid out [matrix fragments ...][bias columns ...]; waves add in wave order.
+template <int NJ, int NK>
+__device__ __forceinline__ void red_add_mat(float* red, const f32x4 (&w)[NJ][NK], int lane, bool first) {
+#pragma unroll
+    for (int jo = 0; jo < NJ; ++jo)
+#pragma unroll
+        for (int jk = 0; jk < NK; ++jk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* p = red + ((jo * NK + jk) * 4 + r) * 64 + lane;
+                *p = first ? w[jo][jk][r] : (*p + w[jo][jk][r]);
+            }
+}
+
+template <int NJ>
+__device__ __forceinline__ void red_add_bias(float* red, float (&s)[NJ], int lane, bool first) {
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) {
+        float v = s[jt];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 16) red[16 * jt + lane] = first ? v : (red[16 * jt + lane] + v);
+    }
+}
+
+// out[mat][o][k] (k < kvalid) = sum_b partial[b][fragment(o, k)];  bias[j] = sum_b partial[b][bias_off + j].
+// Block (64, 8): 64 consecutive positions of the partial row (coalesced) x 8 slices over the workgroup rows, combined
+// through LDS in slice order -- fixed summation order.
+__global__ __launch_bounds__(512) void narrow_reduce_kernel(const float* __restrict__ partial, int nblk, int stride,
+                                                            int nmat, int D, int KP, int kvalid, int nbias,
+                                                            float* __restrict__ mats, float* __restrict__ bias) {
+    __shared__ float part[8][64];
+    const int x = threadIdx.x, y = threadIdx.y;
+    const int p = blockIdx.x * 64 + x;
+    const int per = D * KP;
+    const int total = nmat * per + nbias;
+    float s = 0.f;
+    if (p < total) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;        // four loads in flight per thread, fixed association
+        int b = y;
+        for (; b + 24 < nblk; b += 32) {
+            s0 += partial[(size_t)b * stride + p];
+            s1 += partial[(size_t)(b + 8) * stride + p];
+            s2 += partial[(size_t)(b + 16) * stride + p];
+            s3 += partial[(size_t)(b + 24) * stride + p];
+        }
+        for (; b < nblk; b += 8) s0 += partial[(size_t)b * stride + p];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    part[y][x] = s;
+    __syncthreads();
+    if (y != 0 || p >= total) return;
+#pragma unroll
+    for (int u = 1; u < 8; ++u) s += part[u][x];
+    if (p < nmat * per) {
+        const int mat = p / per, rem = p % per;
+        const int t = rem >> 8, r = (rem >> 6) & 3, lane = rem & 63;
+        const int nk = KP / 16;
+        const int jo = t / nk, jk = t % nk;
+        const int o = 16 * jo + 4 * (lane >> 4) + r, k = 16 * jk + (lane & 15);
+        if (k < kvalid) mats[(size_t)mat * D * kvalid + (size_t)o * kvalid + k] = s;
+    } else {
+        bias[p - nmat * per] = s;
+    }
+}
+
+// ====================================================================================================================
+// Global message (layers/global_message_passing.py:52-53 with W_m split into node and edge blocks):
+//   z = P[tgt, :D] + P[src, D:] + e We^T + b ;  msg = SiLU(z) * (e Wea^T)
+// ====================================================================================================================
+template <int D>
+__global__ __launch_bounds__(NWG) void nglobal_fwd_kernel(const float* __restrict__ e, int64_t m,
+                                                          const int32_t* __restrict__ tgt, const int32_t* __restrict__ src,
+                                                          const float* __restrict__ P, const float* __restrict__ We, int ldwe,
+                                                          const float* __restrict__ bias, const float* __restrict__ Wea,
+                                                          int ldwea, float* __restrict__ msg) {
+    constexpr int NT = D / 16;
+    extern __shared__ float4 lds4[];
+    float4* img_e = lds4;
+    float4* img_a = lds4 + NT * NT * 64;
+    build_image<NT, NT, false>(img_e, We, ldwe, D);
+    build_image<NT, NT, false>(img_a, Wea, ldwea, D);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
+    const int64_t ntiles = (m + 15) / 16;
+    float bj[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) bj[jt] = bias[16 * jt + c];
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = tile * 16;
+        float4 a[NT];
+        load_a<D>(a, e, row0, m, lane);
+        // all index and projection loads of the tile are issued before the GEMMs (their latency hides behind the MFMAs)
+        int ti[4], sj[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 4 * kg + r;
+            ti[r] = tgt[row < m ? row : m - 1];
+            sj[r] = src[row < m ? row : m - 1];
+        }
+        float pv[4][NT], qv[4][NT];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* pi = P + (size_t)ti[r] * (2 * D) + c;
+            const float* pj = P + (size_t)sj[r] * (2 * D) + D + c;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                pv[r][jt] = pi[16 * jt];
+                qv[r][jt] = pj[16 * jt];
+            }
+        }
+        f32x4 q1[NT], q2[NT];
+        zero(q1);
+        zero(q2);
+        mma_img<NT, NT>(q1, a, img_e, lane);
+        mma_img<NT, NT>(q2, a, img_a, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 4 * kg + r;
+            if (row < m) {
+                float* out = msg + row * D + c;
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt) {
+                    const float z = q1[jt][r] + bj[jt] + pv[r][jt] + qv[r][jt];
+                    out[16 * jt] = z * sigmoidf_fast(z) * q2[jt][r];
+                }
+            }
+        }
+    }
+}
+
+// backward: dmsg[row] = dagg[tgt[row]].  Outputs dz [m, D] (for the two node-side segment sums), de [m, D],
+// and per-workgroup partials of dWe, dWea (fragment order) and db.
+template <int D>
+__global__ __launch_bounds__(64 * bwd_waves(D)) void nglobal_bwd_kernel(const float* __restrict__ e, int64_t m,
+                                                          const int32_t* __restrict__ tgt, const int32_t* __restrict__ src,
+                                                          const float* __restrict__ P, const float* __restrict__ We, int ldwe,
+                                                          const float* __restrict__ bias, const float* __restrict__ Wea,
+                                                          int ldwea, const float* __restrict__ dagg,
+                                                          float* __restrict__ dz_out, float* __restrict__ de,
+                                                          float* __restrict__ partial, int stride, int acc_de) {
+    constexpr int NT = D / 16;
+    constexpr int IMG = NT * NT * 64;
+    constexpr int NW = bwd_waves(D);
+    extern __shared__ float4 lds4[];
+    float4* img_e = lds4;
+    float4* img_a = lds4 + IMG;
+    float4* img_et = lds4 + 2 * IMG;
+    float4* img_at = lds4 + 3 * IMG;
+    float* tile = reinterpret_cast<float*>(lds4 + 4 * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
+    build_image<NT, NT, false>(img_e, We, ldwe, D);
+    build_image<NT, NT, false>(img_a, Wea, ldwea, D);
+    build_image<NT, NT, true>(img_et, We, ldwe, D);
+    build_image<NT, NT, true>(img_at, Wea, ldwea, D);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
+    const int64_t ntiles = (m + 15) / 16;
+    float bj[NT], dbs[NT];
+    f32x4 gwe[NT][NT], gwa[NT][NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        bj[jt] = bias[16 * jt + c];
+        dbs[jt] = 0.f;
+        zero(gwe[jt]);
+        zero(gwa[jt]);
+    }
+    for (int64_t tile_id = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6); tile_id < ntiles;
+         tile_id += (int64_t)gridDim.x * NW) {
+        const int64_t row0 = tile_id * 16;
+        float4 a[NT];
+        load_a<D>(a, e, row0, m, lane);
+        // all gathers of the tile are issued before the GEMMs
+        int ti[4], sj[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 4 * kg + r;
+            ti[r] = tgt[row < m ? row : m - 1];
+            sj[r] = src[row < m ? row : m - 1];
+        }
+        float pv[4][NT], qv[4][NT], gv[4][NT];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* pi = P + (size_t)ti[r] * (2 * D) + c;
+            const float* pj = P + (size_t)sj[r] * (2 * D) + D + c;
+            const float* dg = dagg + (size_t)ti[r] * D + c;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                pv[r][jt] = pi[16 * jt];
+                qv[r][jt] = pj[16 * jt];
+                gv[r][jt] = dg[16 * jt];
+            }
+        }
+        f32x4 q1[NT], q2[NT], ed[NT];
+        zero(q1);
+        zero(q2);
+        mma_img<NT, NT>(q1, a, img_e, lane);
+        mma_img<NT, NT>(q2, a, img_a, lane);
+        load_d<D>(ed, e, row0, m, lane);
+        // q1 -> dz, q2 -> dq2 (in place)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = row0 + 4 * kg + r < m;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const float z = q1[jt][r] + bj[jt] + pv[r][jt] + qv[r][jt];
+                const float s = sigmoidf_fast(z);
+                const float dm = ok ? gv[r][jt] : 0.f;
+                const float gate = q2[jt][r];
+                q1[jt][r] = dm * gate * (s * (1.0f + z * (1.0f - s)));
+                q2[jt][r] = dm * (z * s);
+            }
+        }
+        store_d<D>(q1, dz_out, row0, m, lane);
+        wgrad_acc<NT, NT>(gwe, q1, ed);
+        wgrad_acc<NT, NT>(gwa, q2, ed);
+        colsum_acc<NT>(dbs, q1);
+        f32x4 dx[NT];
+        zero(dx);
+        d_to_a<D>(a, q1, tile, lane);
+        mma_img<NT, NT>(dx, a, img_et, lane);
+        d_to_a<D>(a, q2, tile, lane);
+        mma_img<NT, NT>(dx, a, img_at, lane);
+        if (acc_de) {                                        // the edge embedding feeds every layer: later calls add
+            load_d<D>(ed, de, row0, m, lane);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) dx[jt] += ed[jt];
+        }
+        store_d<D>(dx, de, row0, m, lane);
+    }
+    // workgroup reduction in wave order, then one partial row per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds4);
+    constexpr int MAT = D * D;
+    for (int w = 0; w < NW; ++w) {
+        if ((threadIdx.x >> 6) == w) {
+            red_add_mat<NT, NT>(red, gwe, lane, w == 0);
+            red_add_mat<NT, NT>(red + MAT, gwa, lane, w == 0);
+            red_add_bias<NT>(red + 2 * MAT, dbs, lane, w == 0);
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 2 * MAT + D; i += 64 * NW) partial[(size_t)blockIdx.x * stride + i] = red[i];
+}
+
+// ====================================================================================================================
+// Two-layer SiLU MLP on rows (mlp_sbf of the local layer, layers/local_message_passing.py:24,49):
+//   y = SiLU(W2 SiLU(W1 x + b1) + b2)
+// ====================================================================================================================
+template <int D>
+__global__ __launch_bounds__(NWG) void nmlp2_fwd_kernel(const float* __restrict__ x, int64_t m,
+                                                        const float* __restrict__ W1, const float* __restrict__ b1,
+                                                        const float* __restrict__ W2, const float* __restrict__ b2,
+                                                        int res_x, const float* __restrict__ res,
+                                                        float* __restrict__ y) {
+    constexpr int NT = D / 16;
+    constexpr int IMG = NT * NT * 64;
+    extern __shared__ float4 lds4[];
+    float4* img1 = lds4;
+    float4* img2 = lds4 + IMG;
+    float* tile = reinterpret_cast<float*>(lds4 + 2 * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
+    build_image<NT, NT, false>(img1, W1, D, D);
+    build_image<NT, NT, false>(img2, W2, D, D);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15;
+    const int64_t ntiles = (m + 15) / 16;
+    float bj1[NT], bj2[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        bj1[jt] = b1[16 * jt + c];
+        bj2[jt] = b2[16 * jt + c];
+    }
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = t * 16;
+        float4 a[NT];
+        load_a<D>(a, x, row0, m, lane);
+        f32x4 h[NT], o[NT];
+        zero(h);
+        mma_img<NT, NT>(h, a, img1, lane);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = h[jt][r] + bj1[jt];
+                h[jt][r] = z * sigmoidf_fast(z);
+            }
+        d_to_a<D>(a, h, tile, lane);
+        zero(o);
+        mma_img<NT, NT>(o, a, img2, lane);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = o[jt][r] + bj2[jt];
+                o[jt][r] = z * sigmoidf_fast(z);
+            }
+        if (res_x) {                                         // Res block: MLP2(x) + x (layers/basic.py:32-33)
+            load_d<D>(h, x, row0, m, lane);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) o[jt] += h[jt];
+        }
+        if (res) {
+            load_d<D>(h, res, row0, m, lane);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) o[jt] += h[jt];
+        }
+        store_d<D>(o, y, row0, m, lane);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64 * bwd_waves(D)) void nmlp2_bwd_kernel(const float* __restrict__ x, int64_t m,
+                                                        const float* __restrict__ W1, const float* __restrict__ b1,
+                                                        const float* __restrict__ W2, const float* __restrict__ b2,
+                                                        const float* __restrict__ dy, int res_x,
+                                                        float* __restrict__ dx, float* __restrict__ partial,
+                                                        int stride, int acc_dx) {
+    constexpr int NT = D / 16;
+    constexpr int IMG = NT * NT * 64;
+    constexpr int NW = bwd_waves(D);
+    extern __shared__ float4 lds4[];
+    float4* img1 = lds4;
+    float4* img2 = lds4 + IMG;
+    float4* img1t = lds4 + 2 * IMG;
+    float4* img2t = lds4 + 3 * IMG;
+    float* tile = reinterpret_cast<float*>(lds4 + 4 * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
+    build_image<NT, NT, false>(img1, W1, D, D);
+    build_image<NT, NT, false>(img2, W2, D, D);
+    build_image<NT, NT, true>(img1t, W1, D, D);
+    build_image<NT, NT, true>(img2t, W2, D, D);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15;
+    const int64_t ntiles = (m + 15) / 16;
+    float bj1[NT], bj2[NT], db1[NT], db2[NT];
+    f32x4 gw1[NT][NT], gw2[NT][NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        bj1[jt] = b1[16 * jt + c];
+        bj2[jt] = b2[16 * jt + c];
+        db1[jt] = db2[jt] = 0.f;
+        zero(gw1[jt]);
+        zero(gw2[jt]);
+    }
+    for (int64_t t = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * NW) {
+        const int64_t row0 = t * 16;
+        float4 a[NT];
+        load_a<D>(a, x, row0, m, lane);
+        f32x4 z1[NT], h[NT], g[NT];
+        zero(z1);
+        mma_img<NT, NT>(z1, a, img1, lane);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                z1[jt][r] += bj1[jt];
+                h[jt][r] = z1[jt][r] * sigmoidf_fast(z1[jt][r]);
+            }
+        d_to_a<D>(a, h, tile, lane);
+        zero(g);
+        mma_img<NT, NT>(g, a, img2, lane);                   // z2 - b2
+        f32x4 dyv[NT];
+        load_d<D>(dyv, dy, row0, m, lane);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = g[jt][r] + bj2[jt];
+                const float s = sigmoidf_fast(z);
+                g[jt][r] = dyv[jt][r] * (s * (1.0f + z * (1.0f - s)));      // dz2 (zero on padded rows: dy = 0)
+            }
+        wgrad_acc<NT, NT>(gw2, g, h);
+        colsum_acc<NT>(db2, g);
+        d_to_a<D>(a, g, tile, lane);
+        zero(g);
+        mma_img<NT, NT>(g, a, img2t, lane);                  // dh1
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = z1[jt][r];
+                const float s = sigmoidf_fast(z);
+                g[jt][r] *= s * (1.0f + z * (1.0f - s));     // dz1
+            }
+        load_d<D>(h, x, row0, m, lane);
+        wgrad_acc<NT, NT>(gw1, g, h);
+        colsum_acc<NT>(db1, g);
+        if (dx) {
+            d_to_a<D>(a, g, tile, lane);
+            zero(g);
+            mma_img<NT, NT>(g, a, img1t, lane);
+            if (res_x) {
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt) g[jt] += dyv[jt];
+            }
+            if (acc_dx) {
+                load_d<D>(dyv, dx, row0, m, lane);
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt) g[jt] += dyv[jt];
+            }
+            store_d<D>(g, dx, row0, m, lane);
+        }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds4);
+    constexpr int MAT = D * D;
+    for (int w = 0; w < NW; ++w) {
+        if ((threadIdx.x >> 6) == w) {
+            red_add_mat<NT, NT>(red, gw1, lane, w == 0);
+            red_add_mat<NT, NT>(red + MAT, gw2, lane, w == 0);
+            red_add_bias<NT>(red + 2 * MAT, db1, lane, w == 0);
+            red_add_bias<NT>(red + 2 * MAT + D, db2, lane, w == 0);
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 2 * MAT + 2 * D; i += 64 * NW) partial[(size_t)blockIdx.x * stride + i] = red[i];
+}
+
+// ====================================================================================================================
+// One dense layer on rows: y = act(x W^T + b), W a [D, D] block with row stride ldw (slices of the 3d-wide message
+// weights included), y with row stride ldy (so several blocks can fill one [rows, n D] projection).
+// ====================================================================================================================
+template <int D>
+__global__ __launch_bounds__(NWG) void nlinear_fwd_kernel(const float* __restrict__ x, int64_t m,
+                                                          const float* __restrict__ W, int ldw,
+                                                          const float* __restrict__ b, int act, float* __restrict__ y,
+                                                          int64_t ldy) {
+    constexpr int NT = D / 16;
+    extern __shared__ float4 lds4[];
+    build_image<NT, NT, false>(lds4, W, ldw, D);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15;
+    const int64_t ntiles = (m + 15) / 16;
+    float bj[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) bj[jt] = b ? b[16 * jt + c] : 0.f;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = t * 16;
+        float4 a[NT];
+        load_a<D>(a, x, row0, m, lane);
+        f32x4 o[NT];
+        zero(o);
+        mma_img<NT, NT>(o, a, lds4, lane);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = o[jt][r] + bj[jt];
+                o[jt][r] = act ? z * sigmoidf_fast(z) : z;
+            }
+        store_d<D>(o, y, row0, m, lane, ldy);
+    }
+}
+
+// dx (+)= dz W;  partial = [dW fragments (D x D)][db (D)]
+template <int D>
+__global__ __launch_bounds__(64 * lin_bwd_waves(D)) void nlinear_bwd_kernel(const float* __restrict__ x, int64_t m,
+                                                          const float* __restrict__ W, int ldw,
+                                                          const float* __restrict__ b, int act,
+                                                          const float* __restrict__ dy, int64_t lddy,
+                                                          float* __restrict__ dx, int accumulate,
+                                                          float* __restrict__ partial, int stride) {
+    constexpr int NT = D / 16;
+    constexpr int IMG = NT * NT * 64;
+    constexpr int NW = lin_bwd_waves(D);
+    extern __shared__ float4 lds4[];
+    float4* img = lds4;
+    float4* imgt = lds4 + IMG;
+    float* tile = reinterpret_cast<float*>(lds4 + 2 * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
+    build_image<NT, NT, false>(img, W, ldw, D);
+    build_image<NT, NT, true>(imgt, W, ldw, D);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15;
+    const int64_t ntiles = (m + 15) / 16;
+    float bj[NT], dbs[NT];
+    f32x4 gw[NT][NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        bj[jt] = b ? b[16 * jt + c] : 0.f;
+        dbs[jt] = 0.f;
+        zero(gw[jt]);
+    }
+    // the next tile's rows are requested before this tile's GEMMs: at d = 64 a wave holds ~350 registers, one wave per
+    // SIMD, so nothing else hides the HBM latency of its loads
+    const int64_t tstep = (int64_t)gridDim.x * NW;
+    int64_t t = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+    float4 a[NT], ga[NT], a_n[NT], ga_n[NT];                // x and dy row tiles as A fragments (coalesced 16-byte loads)
+    f32x4 g[NT], xd[NT];
+    const bool dense_dy = lddy == D;
+    if (t < ntiles) {
+        load_a<D>(a, x, t * 16, m, lane);
+        if (dense_dy) load_a<D>(ga, dy, t * 16, m, lane);
+    }
+    for (; t < ntiles; t += tstep) {
+        const int64_t row0 = t * 16;
+        const bool more = t + tstep < ntiles;
+        if (more) {
+            load_a<D>(a_n, x, (t + tstep) * 16, m, lane);
+            if (dense_dy) load_a<D>(ga_n, dy, (t + tstep) * 16, m, lane);
+        }
+        if (dense_dy) a_to_d<D>(g, ga, tile, lane);
+        else load_d<D>(g, dy, row0, m, lane, lddy);          // a column block of a wider gradient
+        a_to_d<D>(xd, a, tile, lane);
+        if (act) {
+            f32x4 z[NT];
+            zero(z);
+            mma_img<NT, NT>(z, a, img, lane);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float zz = z[jt][r] + bj[jt];
+                    const float s = sigmoidf_fast(zz);
+                    g[jt][r] *= s * (1.0f + zz * (1.0f - s));
+                }
+        }
+        wgrad_acc<NT, NT>(gw, g, xd);
+        colsum_acc<NT>(dbs, g);
+        if (dx) {
+            d_to_a<D>(a, g, tile, lane);
+            zero(g);
+            mma_img<NT, NT>(g, a, imgt, lane);
+            if (accumulate) {
+                load_d<D>(xd, dx, row0, m, lane);
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt) g[jt] += xd[jt];
+            }
+            store_d<D>(g, dx, row0, m, lane);
+        }
+        if (more) {
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                a[jt] = a_n[jt];
+                ga[jt] = ga_n[jt];
+            }
+        }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds4);
+    constexpr int MAT = D * D;
+    for (int w = 0; w < NW; ++w) {
+        if ((threadIdx.x >> 6) == w) {
+            red_add_mat<NT, NT>(red, gw, lane, w == 0);
+            red_add_bias<NT>(red + MAT, dbs, lane, w == 0);
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < MAT + D; i += 64 * NW) partial[(size_t)blockIdx.x * stride + i] = red[i];
+}
+
+// ====================================================================================================================
+// Layer heads (layers/global_message_passing.py:47-50): out[n] = o[n] . w_out + b_out, att[n] = o[n] . w_att
+// D/4 lanes per row (one float4 each); backward: d o = g_out w_out + g_att w_att and the three parameter gradients
+// reduced lane -> workgroup (LDS, fixed order) -> grid (narrow_reduce_kernel).
+// ====================================================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void nheads_fwd_kernel(const float* __restrict__ o, int64_t m,
+                                                         const float* __restrict__ w_out, const float* __restrict__ b_out,
+                                                         const float* __restrict__ w_att, float* __restrict__ out,
+                                                         float* __restrict__ att) {
+    constexpr int LPR = D / 4, RPB = 256 / LPR;
+    const int sub = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+    const float4 wo = *reinterpret_cast<const float4*>(w_out + 4 * sub);
+    const float4 wa = *reinterpret_cast<const float4*>(w_att + 4 * sub);
+    const float bo = b_out[0];
+    for (int64_t row = (int64_t)blockIdx.x * RPB + rl; row < m; row += (int64_t)gridDim.x * RPB) {   // uniform per lane group
+        const float4 v = *reinterpret_cast<const float4*>(o + row * D + 4 * sub);
+        float so = (v.x * wo.x + v.y * wo.y) + (v.z * wo.z + v.w * wo.w);
+        float sa = (v.x * wa.x + v.y * wa.y) + (v.z * wa.z + v.w * wa.w);
+#pragma unroll
+        for (int s = LPR / 2; s >= 1; s >>= 1) {
+            so += __shfl_xor(so, s, 64);
+            sa += __shfl_xor(sa, s, 64);
+        }
+        if (sub == 0) {
+            out[row] = so + bo;
+            att[row] = sa;
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void nheads_bwd_kernel(const float* __restrict__ o, int64_t m,
+                                                         const float* __restrict__ w_out, const float* __restrict__ w_att,
+                                                         const float* __restrict__ g_out, const float* __restrict__ g_att,
+                                                         float* __restrict__ d_o, float* __restrict__ partial) {
+    constexpr int LPR = D / 4, RPB = 256 / LPR;
+    __shared__ float red[256][9];
+    const int sub = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+    const float4 wo = *reinterpret_cast<const float4*>(w_out + 4 * sub);
+    const float4 wa = *reinterpret_cast<const float4*>(w_att + 4 * sub);
+    float4 so = make_float4(0.f, 0.f, 0.f, 0.f), sa = so;
+    float sb = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * RPB + rl; row < m; row += (int64_t)gridDim.x * RPB) {
+        const float4 v = *reinterpret_cast<const float4*>(o + row * D + 4 * sub);
+        const float go = g_out[row], ga = g_att[row];
+        *reinterpret_cast<float4*>(d_o + row * D + 4 * sub) =
+            make_float4(go * wo.x + ga * wa.x, go * wo.y + ga * wa.y, go * wo.z + ga * wa.z, go * wo.w + ga * wa.w);
+        so.x += go * v.x; so.y += go * v.y; so.z += go * v.z; so.w += go * v.w;
+        sa.x += ga * v.x; sa.y += ga * v.y; sa.z += ga * v.z; sa.w += ga * v.w;
+        sb += go;
+    }
+    float* mine = red[threadIdx.x];
+    mine[0] = so.x; mine[1] = so.y; mine[2] = so.z; mine[3] = so.w;
+    mine[4] = sa.x; mine[5] = sa.y; mine[6] = sa.z; mine[7] = sa.w;
+    mine[8] = sb;
+    __syncthreads();
+    // partial row: [dw_out (D)][dw_att (D)][db_out]
+    for (int p = threadIdx.x; p < 2 * D + 1; p += 256) {
+        float s = 0.f;
+        if (p < 2 * D) {
+            const int which = p / D, c = p % D, su = c / 4, comp = which * 4 + (c & 3);
+            for (int r = 0; r < RPB; ++r) s += red[r * LPR + su][comp];
+        } else {
+            for (int r = 0; r < RPB; ++r) s += red[r * LPR][8];
+        }
+        partial[(size_t)blockIdx.x * (2 * D + 1) + p] = s;
+    }
+}
+
+// ====================================================================================================================
+// Local-edge gates (layers/local_message_passing.py:46-48 after the W[x_i | x_j | rbf] split): per local edge q = (j -> i)
+//   z1 = P[i, 0:D] + P[j, 2D:3D] + Q[q, 0:D] + b_ji          m_ji = SiLU(z1)
+//   z2 = P[i, D:2D] + P[j, 3D:4D] + Q[q, D:2D] + b_kj         m_nb = SiLU(z2) * Q[q, 2D:3D]      (mlp_m_kj * lin_rbf)
+// P [N, 4D] node-side projections, Q [E, 4D] edge-side projections (column block 3 = lin_rbf_out is used later).
+// Elementwise: D/4 lanes per edge, float4 each.  Backward writes dz [E, 2D] (the caller segment-sums it into dP and
+// column-sums it into the biases) and dQ[:, 0:3D] (block 3 zeroed).
+// ====================================================================================================================
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float silu1(float z) { return z * sigmoidf_fast(z); }
+__device__ __forceinline__ float dsilu1(float z) { const float s = sigmoidf_fast(z); return s * (1.0f + z * (1.0f - s)); }
+
+template <int D>
+__global__ __launch_bounds__(256) void nlocal_gate_fwd_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                              const int32_t* __restrict__ tgt, const int32_t* __restrict__ src,
+                                                              const float* __restrict__ bji, const float* __restrict__ bkj,
+                                                              int64_t m, float* __restrict__ m_ji, float* __restrict__ m_nb) {
+    constexpr int LPR = D / 4;
+    const int64_t total = m * LPR;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t q = t / LPR;
+        const int c = (int)(t % LPR) * 4;
+        const float* pi = P + (size_t)tgt[q] * (4 * D) + c;
+        const float* pj = P + (size_t)src[q] * (4 * D) + 2 * D + c;
+        const float* qq = Q + q * (4 * D) + c;
+        const float4 a1 = ld4(pi), a2 = ld4(pi + D), c1 = ld4(pj), c2 = ld4(pj + D);
+        const float4 q1 = ld4(qq), q2 = ld4(qq + D), q3 = ld4(qq + 2 * D), b1 = ld4(bji + c), b2 = ld4(bkj + c);
+        st4(m_ji + q * D + c, make_float4(silu1(a1.x + c1.x + q1.x + b1.x), silu1(a1.y + c1.y + q1.y + b1.y),
+                                          silu1(a1.z + c1.z + q1.z + b1.z), silu1(a1.w + c1.w + q1.w + b1.w)));
+        st4(m_nb + q * D + c, make_float4(silu1(a2.x + c2.x + q2.x + b2.x) * q3.x, silu1(a2.y + c2.y + q2.y + b2.y) * q3.y,
+                                          silu1(a2.z + c2.z + q2.z + b2.z) * q3.z, silu1(a2.w + c2.w + q2.w + b2.w) * q3.w));
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void nlocal_gate_bwd_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                              const int32_t* __restrict__ tgt, const int32_t* __restrict__ src,
+                                                              const float* __restrict__ bji, const float* __restrict__ bkj,
+                                                              int64_t m, const float* __restrict__ g_ji,
+                                                              const float* __restrict__ g_nb, float* __restrict__ dz,
+                                                              float* __restrict__ dQ, int zero_q3) {
+    constexpr int LPR = D / 4;
+    const int64_t total = m * LPR;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t q = t / LPR;
+        const int c = (int)(t % LPR) * 4;
+        const float* pi = P + (size_t)tgt[q] * (4 * D) + c;
+        const float* pj = P + (size_t)src[q] * (4 * D) + 2 * D + c;
+        const float* qq = Q + q * (4 * D) + c;
+        const float4 a1 = ld4(pi), a2 = ld4(pi + D), c1 = ld4(pj), c2 = ld4(pj + D);
+        const float4 q1 = ld4(qq), q2 = ld4(qq + D), q3 = ld4(qq + 2 * D), b1 = ld4(bji + c), b2 = ld4(bkj + c);
+        const float4 gj = ld4(g_ji + q * D + c), gn = ld4(g_nb + q * D + c);
+        const float z1[4] = {a1.x + c1.x + q1.x + b1.x, a1.y + c1.y + q1.y + b1.y, a1.z + c1.z + q1.z + b1.z, a1.w + c1.w + q1.w + b1.w};
+        const float z2[4] = {a2.x + c2.x + q2.x + b2.x, a2.y + c2.y + q2.y + b2.y, a2.z + c2.z + q2.z + b2.z, a2.w + c2.w + q2.w + b2.w};
+        const float gjv[4] = {gj.x, gj.y, gj.z, gj.w}, gnv[4] = {gn.x, gn.y, gn.z, gn.w}, q3v[4] = {q3.x, q3.y, q3.z, q3.w};
+        float d1[4], d2[4], d3[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            d1[u] = gjv[u] * dsilu1(z1[u]);
+            d2[u] = gnv[u] * q3v[u] * dsilu1(z2[u]);
+            d3[u] = gnv[u] * silu1(z2[u]);
+        }
+        st4(dz + q * (2 * D) + c, make_float4(d1[0], d1[1], d1[2], d1[3]));
+        st4(dz + q * (2 * D) + D + c, make_float4(d2[0], d2[1], d2[2], d2[3]));
+        float* dq = dQ + q * (4 * D) + c;
+        st4(dq, make_float4(d1[0], d1[1], d1[2], d1[3]));
+        st4(dq + D, make_float4(d2[0], d2[1], d2[2], d2[3]));
+        st4(dq + 2 * D, make_float4(d3[0], d3[1], d3[2], d3[3]));
+        if (zero_q3) st4(dq + 3 * D, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+}
+
+// ====================================================================================================================
+// Edge-embedding MLPs (models.py:185-188): y = SiLU(W f + b), f [rows, K] with K = 16 (Bessel) or 42 (spherical);
+// with `kind` the row picks (Wa, ba) for kind 0 (triplet rows, mlp_sbf2) or (Wb, bb) for kind 1 (pair rows, mlp_sbf1).
+// ====================================================================================================================
+template <int K>
+__device__ __forceinline__ void load_feat_a(float4 (&a)[(K + 15) / 16], const float* __restrict__ F, int64_t row0,
+                                            int64_t m, int lane) {
+    const int64_t row = row0 + (lane & 15);
+    const bool ok = row < m;
+    const float* p = F + (ok ? row : m - 1) * K;
+#pragma unroll
+    for (int q = 0; q < (K + 15) / 16; ++q) {
+        const int k = 16 * q + 4 * (lane >> 4);
+        // columns beyond K: read the row's last pair instead (valid address), zeroed by the selects
+        const float2 lo = *reinterpret_cast<const float2*>(p + (k + 1 < K ? k : K - 2));
+        const float2 hi = *reinterpret_cast<const float2*>(p + (k + 3 < K ? k + 2 : K - 2));
+        const bool okl = ok && k + 1 < K, okh = ok && k + 3 < K;
+        a[q] = make_float4(okl ? lo.x : 0.f, okl ? lo.y : 0.f, okh ? hi.x : 0.f, okh ? hi.y : 0.f);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void load_feat_d(f32x4 (&v)[(K + 15) / 16], const float* __restrict__ F, int64_t row0,
+                                            int64_t m, int lane) {
+    const int c = lane & 15, kg = lane >> 4;
+    float t[4][(K + 15) / 16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + 4 * kg + r;
+        const float* p = F + (row < m ? row : m - 1) * K;
+#pragma unroll
+        for (int jk = 0; jk < (K + 15) / 16; ++jk) t[r][jk] = p[16 * jk + c < K ? 16 * jk + c : K - 1];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool ok = row0 + 4 * kg + r < m;
+#pragma unroll
+        for (int jk = 0; jk < (K + 15) / 16; ++jk) v[jk][r] = (ok && 16 * jk + c < K) ? t[r][jk] : 0.f;
+    }
+}
+
+template <int D, int K, bool TWO>
+__global__ __launch_bounds__(NWG) void nembed_fwd_kernel(const float* __restrict__ F, int64_t m,
+                                                         const int32_t* __restrict__ kind,
+                                                         const float* __restrict__ Wa, const float* __restrict__ ba,
+                                                         const float* __restrict__ Wb, const float* __restrict__ bb,
+                                                         float* __restrict__ y) {
+    constexpr int NT = D / 16, NQ = (K + 15) / 16;
+    constexpr int IMG = NT * NQ * 64;
+    extern __shared__ float4 lds4[];
+    build_image<NT, NQ, false>(lds4, Wa, K, K);
+    if (TWO) build_image<NT, NQ, false>(lds4 + IMG, Wb, K, K);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
+    const int64_t ntiles = (m + 15) / 16;
+    float bja[NT], bjb[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        bja[jt] = ba[16 * jt + c];
+        bjb[jt] = TWO ? bb[16 * jt + c] : 0.f;
+    }
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = t * 16;
+        float4 a[NQ];
+        load_feat_a<K>(a, F, row0, m, lane);
+        f32x4 acc[NT];
+        zero(acc);
+        if (!TWO) {
+            mma_img<NT, NQ>(acc, a, lds4, lane);
+        } else {
+            const int64_t row = row0 + c;
+            const bool second = kind[row < m ? row : m - 1] != 0;
+            float4 a0[NQ], a1[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                a0[q] = second ? make_float4(0.f, 0.f, 0.f, 0.f) : a[q];
+                a1[q] = second ? a[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            mma_img<NT, NQ>(acc, a0, lds4, lane);
+            mma_img<NT, NQ>(acc, a1, lds4 + IMG, lane);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 4 * kg + r;
+            const bool second = TWO && kind[row < m ? row : m - 1] != 0;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const float z = acc[jt][r] + (second ? bjb[jt] : bja[jt]);
+                acc[jt][r] = z * sigmoidf_fast(z);
+            }
+        }
+        store_d<D>(acc, y, row0, m, lane);
+    }
+}
+
+// backward: partial = [dWa fragments (D x KP)][dWb fragments if TWO][dba (D)][dbb (D) if TWO]; df [m, K] only for
+// the single-set K = 16 case (the Bessel frequencies are trainable, layers/basic.py:65-72).
+template <int D, int K, bool TWO, bool DX>
+__global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const float* __restrict__ F, int64_t m,
+                                                         const int32_t* __restrict__ kind,
+                                                         const float* __restrict__ Wa, const float* __restrict__ ba,
+                                                         const float* __restrict__ Wb, const float* __restrict__ bb,
+                                                         const float* __restrict__ dy, float* __restrict__ df,
+                                                         float* __restrict__ partial, int stride) {
+    static_assert(!DX || (K == 16 && !TWO), "df only for the single-set 16-wide embedding");
+    constexpr int NT = D / 16, NQ = (K + 15) / 16, KP = NQ * 16;
+    constexpr int IMG = NT * NQ * 64;
+    constexpr int IMGT = NQ * NT * 64;
+    constexpr int NW = bwd_waves(D);
+    extern __shared__ float4 lds4[];
+    float4* img_t = lds4 + (TWO ? 2 : 1) * IMG;
+    float* tile = reinterpret_cast<float*>(lds4 + (TWO ? 2 : 1) * IMG + (DX ? IMGT : 0)) + (threadIdx.x >> 6) * 16 * (D + 4);
+    build_image<NT, NQ, false>(lds4, Wa, K, K);
+    if (TWO) build_image<NT, NQ, false>(lds4 + IMG, Wb, K, K);
+    if constexpr (DX) build_image<NQ, NT, true>(img_t, Wa, K, K);       // df = dz Wa: output tiles over K, k-groups over D
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
+    const int64_t ntiles = (m + 15) / 16;
+    float bja[NT], bjb[NT], dba[NT], dbb[NT];
+    f32x4 gwa[NT][NQ], gwb[TWO ? NT : 1][NQ];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        bja[jt] = ba[16 * jt + c];
+        bjb[jt] = TWO ? bb[16 * jt + c] : 0.f;
+        dba[jt] = dbb[jt] = 0.f;
+        zero(gwa[jt]);
+        if constexpr (TWO) zero(gwb[jt]);
+    }
+    for (int64_t t = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * NW) {
+        const int64_t row0 = t * 16;
+        float4 a[NQ];
+        load_feat_a<K>(a, F, row0, m, lane);
+        f32x4 acc[NT];
+        zero(acc);
+        if (!TWO) {
+            mma_img<NT, NQ>(acc, a, lds4, lane);
+        } else {
+            const int64_t row = row0 + c;
+            const bool second = kind[row < m ? row : m - 1] != 0;
+            float4 a0[NQ], a1[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                a0[q] = second ? make_float4(0.f, 0.f, 0.f, 0.f) : a[q];
+                a1[q] = second ? a[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            mma_img<NT, NQ>(acc, a0, lds4, lane);
+            mma_img<NT, NQ>(acc, a1, lds4 + IMG, lane);
+        }
+        f32x4 dyv[NT], dza[NT], dzb[TWO ? NT : 1];
+        load_d<D>(dyv, dy, row0, m, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 4 * kg + r;
+            const bool second = TWO && kind[row < m ? row : m - 1] != 0;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const float z = acc[jt][r] + (second ? bjb[jt] : bja[jt]);
+                const float s = sigmoidf_fast(z);
+                const float dz = dyv[jt][r] * (s * (1.0f + z * (1.0f - s)));
+                dza[jt][r] = second ? 0.f : dz;
+                if constexpr (TWO) dzb[jt][r] = second ? dz : 0.f;
+            }
+        }
+        f32x4 fd[NQ];
+        load_feat_d<K>(fd, F, row0, m, lane);
+        wgrad_acc<NT, NQ>(gwa, dza, fd);
+        colsum_acc<NT>(dba, dza);
+        if constexpr (TWO) {
+            wgrad_acc<NT, NQ>(gwb, dzb, fd);
+            colsum_acc<NT>(dbb, dzb);
+        }
+        if constexpr (DX) {
+            float4 az[NT];
+            d_to_a<D>(az, dza, tile, lane);
+            f32x4 o[NQ];
+            zero(o);
+            mma_img<NQ, NT>(o, az, img_t, lane);
+            // K = 16: one 16-column tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + 4 * kg + r;
+                if (row < m) df[row * K + c] = o[0][r];
+            }
+        }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds4);
+    constexpr int MAT = D * KP;
+    constexpr int NM = TWO ? 2 : 1;
+    for (int w = 0; w < NW; ++w) {
+        if ((threadIdx.x >> 6) == w) {
+            red_add_mat<NT, NQ>(red, gwa, lane, w == 0);
+            red_add_bias<NT>(red + NM * MAT, dba, lane, w == 0);
+            if constexpr (TWO) {
+                red_add_mat<NT, NQ>(red + MAT, gwb, lane, w == 0);
+                red_add_bias<NT>(red + NM * MAT + D, dbb, lane, w == 0);
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < NM * (MAT + D); i += 64 * NW) partial[(size_t)blockIdx.x * stride + i] = red[i];
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+inline int grid_for(int64_t m, int per_cu, int waves = 4) {
+    const int64_t tiles = (m + 15) / 16;
+    const int64_t want = (tiles + waves - 1) / waves;        // one tile per wave
+    const int64_t cap = 256 * (int64_t)per_cu;
+    return (int)(want < cap ? (want > 0 ? want : 1) : cap);
+}
+
+inline bool width_ok(int64_t d) { return d == 16 || d == 32 || d == 64; }
+
+// Workgroups that are co-resident per CU: the backward kernels at d = 64 hold ~350 registers per lane and ~80 KB of
+// weight images, so one 4-wave workgroup fills a CU; a grid beyond that only adds a second, nearly empty round.
+inline int fwd_per_cu(int64_t d) { return d == 64 ? 2 : 4; }
+
+
+template <typename Kern>
+inline hipError_t allow_lds(Kern k, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+#define NARROW_DISPATCH(d, CALL)     \
+    switch ((int)(d)) {              \
+        case 16: { CALL(16); } break; \
+        case 32: { CALL(32); } break; \
+        default: { CALL(64); } break; \
+    }
+
+}  // namespace

@@ -49,11 +49,13 @@ class SphericalBasis(nn.Module):
 class _LazyLayers(object):
     """x after every layer, materialised from the engine's saved-activation arena only when somebody looks."""
 
-    def __init__(self, saved, graph, n_layer):
+    def __init__(self, saved, graph, n_layer, dim=None):
         self._args = (saved, graph, n_layer)
+        self._dim = dim
 
     def _views(self):
-        from pamnet_amd import fused
+        if self._dim is not None:
+            return narrow.stack_x_layers(*self._args, self._dim)
         return fused.stack_x_layers(*self._args)
 
     def __iter__(self):
@@ -196,6 +198,10 @@ class _PAMNetBase(nn.Module):
             outs, atts, saved = fused.layer_stack(self.global_layer, self.local_layer, x, e_g, e_l, e_sbf, g, tape=tape)
             self._x_layers = _LazyLayers(saved, g, self.n_layer)
             return outs, atts
+        if modules._narrow(x) and narrow.engine_supported(x, g):       # dim 16 / 32 / 64: one engine call as well
+            outs, atts, saved = narrow.layer_stack(self.global_layer, self.local_layer, x, e_g, e_l, e_sbf, g, tape=tape)
+            self._x_layers = _LazyLayers(saved, g, self.n_layer, self.dim)
+            return outs, atts
         outs, atts = [], []
         self._x_layers = []
         for k in range(self.n_layer):
@@ -221,7 +227,9 @@ class _PAMNetBase(nn.Module):
                 return False
             return fused.stack_plan(self.global_layer, self.local_layer).direct()
         if self.dim in narrow.WIDTHS and narrow.ENABLED:
-            return all(getattr(p, '_pamnet_direct', False) and p.grad is not None for p in self._all_params())
+            if not all(getattr(p, '_pamnet_direct', False) and p.grad is not None for p in self._all_params()):
+                return False
+            return fused.stack_plan(self.global_layer, self.local_layer).direct()      # (the engine's gradient tables)
         return False
 
     def _all_params(self):

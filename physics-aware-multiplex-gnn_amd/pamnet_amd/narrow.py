@@ -389,3 +389,94 @@ def embed(f, lin_a, lin_b=None, kind=None):
     if kind is None:
         return ops.apply(_Embed, f, None, lin_a.weight, lin_a.bias, None, None)
     return ops.apply(_Embed, f, kind, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias)
+
+
+# ---- the whole layer loop as ONE engine call per direction (csrc/narrow_engine.hip) -------------------------------------
+ENGINE = os.environ.get('PAMNET_NARROW_ENGINE', '1') != '0'      # measurement aid: 0 = the per-operator path above
+
+
+class _Stack(torch.autograd.Function):
+    """The n_layer x (global, local) loop (models.py:196-204) at d = 16 / 32 / 64: x0, e_g, rbf_e, e_sbf ->
+    outs [2L, N], atts [2L, N].  One C call forward, one backward; in direct-gradient mode the parameters are not autograd
+    inputs (their gradients are written straight into the flat buffer, see fused._Stack)."""
+
+    @staticmethod
+    def forward(ctx, x0, e_g, rbf_e, e_sbf, graph, plan, direct, *params):
+        from . import fused
+        x0, e_g, rbf_e, e_sbf = _c(x0), _c(e_g), _c(rbf_e), _c(e_sbf)
+        L, (n, d) = plan.L, x0.shape
+        sizes, idx = fused._graph_tables(graph)
+        need = (ctypes.c_int64 * 2)()
+        lib.call('pamnet_narrow_stack_workspace', n, e_g.size(0), rbf_e.size(0), e_sbf.size(0), L, d,
+                 ctypes.addressof(need), ctypes.addressof(need) + 8)
+        saved = torch.empty(max(int(need[0]), 1), dtype=torch.float32, device=x0.device)
+        temp = plan.temp_arena(int(need[1]), x0.device)
+        outs, atts = _empty(2 * L, n, like=x0), _empty(2 * L, n, like=x0)
+        gtab, ltab = plan.param_tables()
+        lib.call('pamnet_narrow_stack_fwd_f32', sizes, idx, L, d, lib.ptr(x0), lib.ptr(e_g), lib.ptr(rbf_e), lib.ptr(e_sbf),
+                 gtab, ltab, lib.ptr(saved), lib.ptr(temp), lib.ptr(outs), lib.ptr(atts), lib.stream_of(x0))
+        ctx.save_for_backward(x0, e_g, rbf_e, e_sbf, saved)
+        ctx.graph, ctx.plan, ctx.direct, ctx.temp_floats = graph, plan, direct, int(need[1])
+        ctx.mark_non_differentiable(saved)
+        ctx.set_materialize_grads(False)
+        return outs, atts, saved
+
+    @staticmethod
+    def backward(ctx, g_outs, g_atts, _g_saved):
+        from . import fused
+        x0, e_g, rbf_e, e_sbf, saved = ctx.saved_tensors
+        graph, plan, direct = ctx.graph, ctx.plan, ctx.direct
+        L, (n, d) = plan.L, x0.shape
+        sizes, idx = fused._graph_tables(graph)
+        temp = plan.temp_arena(ctx.temp_floats, x0.device)
+        d_x0, d_eg, d_rbf, d_sbf = (torch.empty_like(t) for t in (x0, e_g, rbf_e, e_sbf))
+        gtab, ltab = plan.param_tables()
+        evs = None
+        if direct:
+            ggrad, lgrad, g = plan._ggrad, plan._lgrad, ()
+            sc = plan.ctx
+            if sc.events is not None and len(sc.events) == L:
+                evs = fused._parr([int(e.cuda_event) for e in sc.events])
+                sc.recorded = True
+        else:
+            g = [torch.empty_like(p) for p in plan.flat]
+            ggrad, lgrad = fused._parr(g[:len(plan.gflat)]), fused._parr(g[len(plan.gflat):])
+        g_outs = torch.zeros(2 * L, n, device=x0.device) if g_outs is None else _c(g_outs)
+        g_atts = torch.zeros_like(g_outs) if g_atts is None else _c(g_atts)
+        lib.call('pamnet_narrow_stack_bwd_f32', sizes, idx, L, d, lib.ptr(x0), lib.ptr(e_g), lib.ptr(rbf_e), lib.ptr(e_sbf),
+                 gtab, ltab, lib.ptr(saved), lib.ptr(temp), lib.ptr(g_outs), lib.ptr(g_atts), ggrad, lgrad,
+                 lib.ptr(d_x0), lib.ptr(d_eg), lib.ptr(d_rbf), lib.ptr(d_sbf), evs, lib.stream_of(x0))
+        return (d_x0, d_eg, d_rbf, d_sbf, None, None, None) + tuple(g)
+
+
+def engine_supported(x, graph):
+    """The engine needs every index list non-empty (its backward has no zero-row special cases; such batches take the
+    per-operator path)."""
+    return (ENGINE and supported(x, x.size(1)) and graph.n > 0 and graph.glob.m > 0 and graph.loc.m > 0
+            and graph.tp.m > 0)
+
+
+def layer_stack(global_layers, local_layers, x0, e_g, rbf_e, e_sbf, graph, tape=None):
+    """Returns outs [2L, N], atts [2L, N] and the saved-activation arena (see stack_x_layers)."""
+    from . import fused
+    plan = fused.stack_plan(global_layers, local_layers)
+    if tape is not None:                       # direct-gradient mode on the model's own tape (ops.Tape)
+        return tape.call(_Stack, x0, e_g, rbf_e, e_sbf, graph, plan, True)
+    if not torch.is_grad_enabled():
+        return ops.apply(_Stack, x0, e_g, rbf_e, e_sbf, graph, plan, False)
+    if plan.direct():
+        return _Stack.apply(x0, e_g, rbf_e, e_sbf, graph, plan, True)
+    return _Stack.apply(x0, e_g, rbf_e, e_sbf, graph, plan, False, *plan.flat)
+
+
+def stack_x_layers(saved, graph, n_layer, d):
+    """Node features after every layer (global_0, local_0, ...) as views into the saved arena."""
+    lay = (ctypes.c_int64 * 3)()
+    lib.call('pamnet_narrow_stack_layout', graph.n, graph.glob.m, graph.loc.m, graph.tp.m, d, ctypes.addressof(lay))
+    pair, og, ol = int(lay[0]), int(lay[1]), int(lay[2])
+    n = graph.n
+    xs = []
+    for k in range(n_layer):
+        for off in (og, ol):
+            xs.append(saved[k * pair + off:k * pair + off + n * d].view(n, d))
+    return xs

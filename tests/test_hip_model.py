@@ -141,7 +141,7 @@ def test_forward_vs_reference_golden(dev, golden, name, small):
     ok, info = _ok(pool_in, g['node_out32'], g['node_out64'])
     assert ok, ('node_out', info)
     if 'x_layers64' in g.files:
-        xl = torch.stack(model._x_layers).cpu().numpy()
+        xl = torch.stack(list(model._x_layers)).cpu().numpy()
         ok, info = _ok(xl, g['x_layers32'], g['x_layers64'])
         assert ok, ('x_layers', info)
     scale = None
@@ -186,7 +186,7 @@ def test_rna_checkpoint_end_to_end(dev, golden):
         assert gc.loc.m == int(g['g%d/num_edges_l' % gid]) and gc.n_trip == int(g['g%d/num_triplets' % gid])
         assert gc.n_pair == int(g['g%d/num_pairs' % gid])
         if gid == 6:
-            ok, info = _ok(torch.stack(model._x_layers).cpu().numpy(), g['g6/x_layers32'], g['g6/x_layers64'])
+            ok, info = _ok(torch.stack(list(model._x_layers)).cpu().numpy(), g['g6/x_layers32'], g['g6/x_layers64'])
             assert ok, info
             ok, info = _ok(model._node_out.cpu().numpy(), g['g6/node_out32'], g['g6/node_out64'])
             assert ok, info

@@ -258,3 +258,63 @@ def test_rna_model_matches_generic_path(dev, dim, n_layer):
         # fp32 vs fp32: both sides sum ~10^5 edge rows in their own order (each side is checked against fp64 at 1e-5:
         # the kernel tests above and the oracle fixtures of test_hip_model.py)
         assert err < 1e-4, (n, err)
+
+
+@pytest.mark.parametrize('dim,n_layer', [(16, 1), (32, 2), (64, 2)])
+@pytest.mark.parametrize('mode', ['autograd', 'trainer'])
+def test_engine_matches_per_operator_path(dev, dim, n_layer, mode):
+    """csrc/narrow_engine.hip (node chains as single launches, gradients reduced straight into the parameter buffers, one
+    call per direction) against the per-operator row kernels on the same model and batch: outputs, per-layer node features
+    and every parameter gradient; under plain autograd and under the trainer's preallocated-gradient tape."""
+    import models
+    from pamnet_amd import narrow, synth
+    from pamnet_amd.train import FlatParams
+    cfg = models.Config(dataset='rna_native', dim=dim, n_layer=n_layer, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
+    torch.manual_seed(4)
+    model = models.PAMNet(cfg).to(dev)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1 and p.numel() == dim:
+                p.add_(0.05 * torch.randn_like(p))
+    data = synth.rna_batch(2, 3, 3).to(dev)
+    w = torch.randn(3, device=dev)
+    if mode == 'trainer':
+        fp = FlatParams(model, direct=True)
+    params = [p for p in model.parameters()]
+
+    def run(engine):
+        narrow.ENGINE = engine
+        try:
+            if mode == 'trainer':
+                fp.zero_grad()
+            else:
+                for p in params:
+                    p.grad = None
+            out = model(data)
+            xs = [x.detach().clone() for x in model._x_layers]
+            (out * w).sum().backward()
+            return out.detach().clone(), xs, [p.grad.detach().clone() if p.grad is not None else None for p in params]
+        finally:
+            narrow.ENGINE = True
+
+    out_e, xs_e, g_e = run(True)
+    out_o, xs_o, g_o = run(False)
+    assert maxnorm_err(out_e.cpu(), out_o.cpu()) < 2e-6
+    assert len(xs_e) == len(xs_o) == 2 * n_layer
+    for a, b in zip(xs_e, xs_o):
+        assert maxnorm_err(a.cpu(), b.cpu()) < 2e-6
+    names = [n for n, _ in model.named_parameters()]
+    for nm, a, b in zip(names, g_e, g_o):
+        assert (a is None) == (b is None), nm
+        if a is None:
+            continue
+        scale = float(b.abs().max())
+        if scale == 0.0:
+            assert float(a.abs().max()) == 0.0, nm
+            continue
+        err = float((a - b).abs().max()) / scale
+        assert err < 2e-5, (nm, err)
+    # deterministic
+    out_e2, _, g_e2 = run(True)
+    assert torch.equal(out_e, out_e2)
+    assert all(torch.equal(a, b) for a, b in zip(g_e, g_e2) if a is not None)
