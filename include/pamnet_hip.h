@@ -129,7 +129,7 @@ int pamnet_triplet_fill_f32(const float* pos, const int32_t* lptr, const int32_t
 int pamnet_rbf_fwd_f32(const float* dist, const float* freq, float cutoff, int64_t m, float* rbf,
                        pamnet_stream_t stream);
 /* dfreq[n] = sum_e grad[e, n] * env(x_e) * x_e * cos(freq[n] x_e)   (freq is trainable: basic.py:65-72).
- * `partial` needs 16*256 floats of scratch. */
+ * `partial` needs 16*2048 floats of scratch. */
 int pamnet_rbf_bwd_f32(const float* dist, const float* freq, float cutoff, int64_t m, const float* grad,
                        float* dfreq, float* partial, pamnet_stream_t stream);
 /* radial table rad[e, l*6+n] = env(x) * N_ln * j_l(z_ln x), x = d_e/c, evaluated in fp64 and rounded once to fp32 */

@@ -19,7 +19,37 @@
 
 namespace {
 
-constexpr int CHW = 4;                                  // waves per workgroup of the chain kernels (64 rows)
+// Waves per workgroup of the chain kernels (128 rows): two per SIMD.  A wave walks ~10 dependent stages for its one tile
+// (load -> MFMA -> LDS relayout -> MFMA ...), so a second wave per SIMD is what hides the latencies; and 17.7 k rows are
+// 139 workgroups -- one round on 256 CUs, where 64-row workgroups (277) took two (ntail_bwd, d = 64: 220 us).
+constexpr int CHW = 8;
+
+// The chain kernels visit a new weight matrix every stage and only a handful of row tiles per workgroup, so building the
+// fragment-ordered images from the row-major weights inside them (strided 4-byte reads) was most of their time
+// (ntail_bwd at d = 64, N = 17.7 k: 220 us with in-kernel builds).  npack_kernel builds every image of a layer pair once per
+// call -- plain and transposed -- into a scratch area; the chains copy them into LDS with coalesced 16-byte loads.
+template <int NT>
+__device__ __forceinline__ void copy_image(float4* dst, const float4* __restrict__ src) {
+    for (int i = threadIdx.x; i < NT * NT * 64; i += blockDim.x) dst[i] = src[i];
+}
+
+constexpr int PACK_SLOTS = 32;              // [D, D] weight blocks of one layer pair (see narrow_engine.hip)
+struct PackJobs {
+    const float* W[PACK_SLOTS];
+    int ld[PACK_SLOTS];
+};
+// grid (PACK_SLOTS, 2): image (slot, transposed?) -> out[(2 * slot + t) * IMG]
+template <int D>
+__global__ __launch_bounds__(256) void npack_kernel(const PackJobs jobs, float4* __restrict__ out) {
+    constexpr int NT = D / 16;
+    constexpr int IMG = NT * NT * 64;
+    const int slot = blockIdx.x, t = blockIdx.y;
+    const float* W = jobs.W[slot];
+    if (!W) return;
+    float4* img = out + (size_t)(2 * slot + t) * IMG;
+    if (t == 0) build_image<NT, NT, false>(img, W, jobs.ld[slot], D);
+    else build_image<NT, NT, true>(img, W, jobs.ld[slot], D);
+}
 
 template <int NT>
 __device__ __forceinline__ void load_bias(float (&bj)[NT], const float* __restrict__ b, int c) {
@@ -105,7 +135,8 @@ __device__ __forceinline__ void lin_bwd_stage(f32x4 (&g)[D / 16], const float* _
     for (int jt = 0; jt < NT; ++jt) g[jt] = dx[jt];
 }
 
-// y = SiLU(W2 SiLU(W1 x + b1) + b2) (+ x);  partial segment: [dW1][dW2][db1][db2]
+// y = SiLU(W2 SiLU(W1 x + b1) + b2) (+ x);  partial segment: [dW2][db2][dW1][db1] (the second layer's gradients leave
+// the registers before the first layer's are formed: 256 registers per lane at two waves per SIMD)
 template <int D>
 __device__ __forceinline__ void mlp2_bwd_stage(f32x4 (&g)[D / 16], const float* __restrict__ X, int64_t row0, int64_t m,
                                                const float4* img1, const float4* img2, const float4* img1t,
@@ -113,41 +144,47 @@ __device__ __forceinline__ void mlp2_bwd_stage(f32x4 (&g)[D / 16], const float* 
                                                const float* __restrict__ b2, bool res, float* tile, float* red,
                                                float* dst, bool add, int lane) {
     constexpr int NT = D / 16;
-    float bj1[NT], bj2[NT], db1[NT], db2[NT];
-    load_bias<NT>(bj1, b1, lane & 15);
-    load_bias<NT>(bj2, b2, lane & 15);
-    f32x4 gw1[NT][NT], gw2[NT][NT];
-#pragma unroll
-    for (int jt = 0; jt < NT; ++jt) {
-        db1[jt] = db2[jt] = 0.f;
-        zero(gw1[jt]);
-        zero(gw2[jt]);
-    }
+    constexpr int MAT = D * D;
+    float bj[NT], dbs[NT];
     float4 a[NT], ah[NT];
     load_a<D>(a, X, row0, m, lane);
     f32x4 z1[NT], h[NT], q[NT];
     zero(z1);
     mma_img<NT, NT>(z1, a, img1, lane);
+    load_bias<NT>(bj, b1, lane & 15);
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            z1[jt][r] += bj1[jt];
+            z1[jt][r] += bj[jt];
             h[jt][r] = z1[jt][r] * sigmoidf_fast(z1[jt][r]);
         }
     d_to_a<D>(ah, h, tile, lane);
     zero(q);
     mma_img<NT, NT>(q, ah, img2, lane);                      // z2 - b2
+    load_bias<NT>(bj, b2, lane & 15);
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float z = q[jt][r] + bj2[jt];
+            const float z = q[jt][r] + bj[jt];
             const float s = sigmoidf_fast(z);
             q[jt][r] = g[jt][r] * (s * (1.0f + z * (1.0f - s)));   // dz2 (zero on padded rows: g = 0)
         }
-    wgrad_acc<NT, NT>(gw2, q, h);
-    colsum_acc<NT>(db2, q);
+    {
+        f32x4 gw[NT][NT];
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            dbs[jt] = 0.f;
+            zero(gw[jt]);
+        }
+        wgrad_acc<NT, NT>(gw, q, h);
+        colsum_acc<NT>(dbs, q);
+        wg_reduce(red, MAT + D, dst, add, [&](bool first) {
+            red_add_mat<NT, NT>(red, gw, lane, first);
+            red_add_bias<NT>(red + MAT, dbs, lane, first);
+        });
+    }
     d_to_a<D>(ah, q, tile, lane);
     zero(q);
     mma_img<NT, NT>(q, ah, img2t, lane);                     // dh1
@@ -160,24 +197,25 @@ __device__ __forceinline__ void mlp2_bwd_stage(f32x4 (&g)[D / 16], const float* 
             q[jt][r] *= s * (1.0f + z * (1.0f - s));         // dz1
         }
     a_to_d<D>(h, a, tile, lane);                             // x in accumulator layout
-    wgrad_acc<NT, NT>(gw1, q, h);
-    colsum_acc<NT>(db1, q);
+    {
+        f32x4 gw[NT][NT];
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            dbs[jt] = 0.f;
+            zero(gw[jt]);
+        }
+        wgrad_acc<NT, NT>(gw, q, h);
+        colsum_acc<NT>(dbs, q);
+        wg_reduce(red, MAT + D, dst + MAT + D, add, [&](bool first) {
+            red_add_mat<NT, NT>(red, gw, lane, first);
+            red_add_bias<NT>(red + MAT, dbs, lane, first);
+        });
+    }
     d_to_a<D>(ah, q, tile, lane);
     zero(q);
     mma_img<NT, NT>(q, ah, img1t, lane);                     // dx
-    if (res) {
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt) q[jt] += g[jt];
-    }
-    constexpr int MAT = D * D;
-    wg_reduce(red, 2 * MAT + 2 * D, dst, add, [&](bool first) {
-        red_add_mat<NT, NT>(red, gw1, lane, first);
-        red_add_mat<NT, NT>(red + MAT, gw2, lane, first);
-        red_add_bias<NT>(red + 2 * MAT, db1, lane, first);
-        red_add_bias<NT>(red + 2 * MAT + D, db2, lane, first);
-    });
-#pragma unroll
-    for (int jt = 0; jt < NT; ++jt) g[jt] = q[jt];
+    for (int jt = 0; jt < NT; ++jt) g[jt] = res ? q[jt] + g[jt] : q[jt];
 }
 
 // ====================================================================================================================
@@ -185,7 +223,7 @@ __device__ __forceinline__ void mlp2_bwd_stage(f32x4 (&g)[D / 16], const float* 
 // W / b in chain order: [0] mlp_x2, [1,2] res1, [3,4] res2, [5,6] res3, [7,8,9] mlp_out
 // ====================================================================================================================
 struct NTailFwd {
-    const float* W[10];
+    const float4* img[10];                  // packed images of the ten weights (npack_kernel)
     const float* b[10];
     const float *w_out, *b_out, *w_att;
     const float *x2, *res_x;
@@ -229,7 +267,7 @@ __global__ __launch_bounds__(64 * CHW) void ntail_fwd_kernel(const NTailFwd p) {
     for (int64_t grp = blockIdx.x; grp * CHW < ntiles; grp += gridDim.x) {
         const int64_t row0 = (grp * CHW + wave) * 16;
         __syncthreads();
-        build_image<NT, NT, false>(img0, p.W[0], D, D);
+        copy_image<NT>(img0, p.img[0]);
         __syncthreads();
         f32x4 v[NT];
         {
@@ -245,8 +283,8 @@ __global__ __launch_bounds__(64 * CHW) void ntail_fwd_kernel(const NTailFwd p) {
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {                        // res1, res2, res3, first two layers of mlp_out
             __syncthreads();
-            build_image<NT, NT, false>(img0, p.W[1 + 2 * k], D, D);
-            build_image<NT, NT, false>(img1, p.W[2 + 2 * k], D, D);
+            copy_image<NT>(img0, p.img[1 + 2 * k]);
+            copy_image<NT>(img1, p.img[2 + 2 * k]);
             __syncthreads();
             mlp2_fwd_stage<D>(v, img0, img1, p.b[1 + 2 * k], p.b[2 + 2 * k], k < 3, tile, lane);
             if (k == 0) {                                    // Res1(h0) + the layer's input (basic.py:32, *_message_passing.py:41)
@@ -259,7 +297,7 @@ __global__ __launch_bounds__(64 * CHW) void ntail_fwd_kernel(const NTailFwd p) {
             store_d<D>(v, dst, row0, m, lane);
         }
         __syncthreads();
-        build_image<NT, NT, false>(img0, p.W[9], D, D);
+        copy_image<NT>(img0, p.img[9]);
         __syncthreads();
         {
             float4 a[NT];
@@ -306,7 +344,8 @@ __global__ __launch_bounds__(64 * CHW) void ntail_fwd_kernel(const NTailFwd p) {
 }
 
 struct NTailBwd {
-    const float* W[10];
+    const float4* img[10];                  // packed images, plain and transposed
+    const float4* imgt[10];
     const float* b[10];
     const float *w_out, *w_att;
     const float *x2, *H0, *R1, *R2, *R3, *T, *O;
@@ -377,19 +416,17 @@ __global__ __launch_bounds__(64 * CHW) void ntail_bwd_kernel(const NTailBwd p) {
             });
         }
         // ---- mlp_out[2]
-        build_image<NT, NT, false>(img, p.W[9], D, D);
-        build_image<NT, NT, true>(img + IMG, p.W[9], D, D);
+        copy_image<NT>(img, p.img[9]);
+        copy_image<NT>(img + IMG, p.imgt[9]);
         __syncthreads();
         lin_bwd_stage<D>(g, p.T, row0, m, img, img + IMG, p.b[9], true, tile, red, prow + Row::L5, add, lane);
         // ---- mlp_out[0:2], Res3, Res2, Res1
 #pragma unroll 1
         for (int k = 3; k >= 0; --k) {
-            const float* W1 = p.W[1 + 2 * k];
-            const float* W2 = p.W[2 + 2 * k];
-            build_image<NT, NT, false>(img, W1, D, D);
-            build_image<NT, NT, false>(img + IMG, W2, D, D);
-            build_image<NT, NT, true>(img + 2 * IMG, W1, D, D);
-            build_image<NT, NT, true>(img + 3 * IMG, W2, D, D);
+            copy_image<NT>(img, p.img[1 + 2 * k]);
+            copy_image<NT>(img + IMG, p.img[2 + 2 * k]);
+            copy_image<NT>(img + 2 * IMG, p.imgt[1 + 2 * k]);
+            copy_image<NT>(img + 3 * IMG, p.imgt[2 + 2 * k]);
             __syncthreads();
             if (k == 0) store_d<D>(g, p.d_resx, row0, m, lane);      // r1 = Res1(h0) + res_x
             const float* X = k == 3 ? p.R3 : (k == 2 ? p.R2 : (k == 1 ? p.R1 : p.H0));
@@ -404,8 +441,8 @@ __global__ __launch_bounds__(64 * CHW) void ntail_bwd_kernel(const NTailBwd p) {
             }
         }
         // ---- mlp_x2
-        build_image<NT, NT, false>(img, p.W[0], D, D);
-        build_image<NT, NT, true>(img + IMG, p.W[0], D, D);
+        copy_image<NT>(img, p.img[0]);
+        copy_image<NT>(img + IMG, p.imgt[0]);
         __syncthreads();
         lin_bwd_stage<D>(g, p.x2, row0, m, img, img + IMG, p.b[0], true, tile, red, prow + Row::L0, add, lane);
         store_d<D>(g, p.d_x2, row0, m, lane);
@@ -420,9 +457,9 @@ __global__ __launch_bounds__(64 * CHW) void ntail_bwd_kernel(const NTailBwd p) {
 constexpr int NPB = 4;
 struct NPreFwd {
     const float* x;
-    const float *W1, *b1;
-    const float* Wp[NPB];
-    int ldp[NPB];
+    const float4* img1;                     // packed image of W1 (null: no first layer)
+    const float* b1;
+    const float4* imgp[NPB];                // packed images of the projection blocks
     int nb;
     float* x1;                              // [m, D] (with W1)
     float* P;                               // [m, nb * D]
@@ -437,9 +474,9 @@ __global__ __launch_bounds__(NWG) void npre_fwd_kernel(const NPreFwd p) {
     float4* img1 = lds4;
     float4* imgp = lds4 + IMG;
     float* tile = reinterpret_cast<float*>(lds4 + (1 + NPB) * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
-    const bool first = p.W1 != nullptr;
-    if (first) build_image<NT, NT, false>(img1, p.W1, D, D);
-    for (int k = 0; k < p.nb; ++k) build_image<NT, NT, false>(imgp + k * IMG, p.Wp[k], p.ldp[k], D);
+    const bool first = p.img1 != nullptr;
+    if (first) copy_image<NT>(img1, p.img1);
+    for (int k = 0; k < p.nb; ++k) copy_image<NT>(imgp + k * IMG, p.imgp[k]);
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15;
     const int64_t m = p.m, ntiles = (m + 15) / 16;
@@ -471,9 +508,9 @@ __global__ __launch_bounds__(NWG) void npre_fwd_kernel(const NPreFwd p) {
 struct NPreBwd {
     const float* x;                          // [m, D] input of mlp_x1
     const float* x1;                         // [m, D] saved SiLU(W1 x + b1)
-    const float *W1, *b1;
-    const float* Wp[NPB];
-    int ldp[NPB];
+    const float4 *img1, *img1t;              // packed images of W1, plain and transposed
+    const float* b1;
+    const float4* imgpt[NPB];                // packed transposed images of the projection blocks
     int nb;
     const float* dP[NPB];                    // gradient of projection block k: [m, D] with row stride lddp[k]
     int lddp[NPB];
@@ -496,9 +533,9 @@ __global__ __launch_bounds__(64 * CHW) void npre_bwd_kernel(const NPreBwd p) {
     float4* imgpt = lds4 + 2 * IMG;
     float* tile = reinterpret_cast<float*>(lds4 + (2 + NPB) * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
     float* red = reinterpret_cast<float*>(lds4 + (2 + NPB) * IMG) + CHW * 16 * (D + 4);
-    build_image<NT, NT, false>(img1, p.W1, D, D);
-    build_image<NT, NT, true>(img1t, p.W1, D, D);
-    for (int k = 0; k < p.nb; ++k) build_image<NT, NT, true>(imgpt + k * IMG, p.Wp[k], p.ldp[k], D);
+    copy_image<NT>(img1, p.img1);
+    copy_image<NT>(img1t, p.img1t);
+    for (int k = 0; k < p.nb; ++k) copy_image<NT>(imgpt + k * IMG, p.imgpt[k]);
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, wave = threadIdx.x >> 6;
     const int64_t m = p.m, ntiles = (m + 15) / 16;
@@ -624,7 +661,7 @@ inline int chain_grid(int64_t m) {
 template <int D>
 constexpr size_t ntail_fwd_lds() { return 2 * (size_t)D * D * 4 + CHW * 16 * (D + 4) * 4; }
 template <int D>
-constexpr size_t ntail_bwd_lds() { return 4 * (size_t)D * D * 4 + CHW * 16 * (D + 4) * 4 + (2 * (size_t)D * D + 2 * D) * 4; }
+constexpr size_t ntail_bwd_lds() { return 4 * (size_t)D * D * 4 + CHW * 16 * (D + 4) * 4 + ((size_t)D * D + 2 * D + 4) * 4; }
 template <int D>
 constexpr size_t npre_fwd_lds() { return (1 + NPB) * (size_t)D * D * 4 + 4 * 16 * (D + 4) * 4; }
 template <int D>

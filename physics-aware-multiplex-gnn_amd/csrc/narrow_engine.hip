@@ -104,10 +104,10 @@ int launch_tail_bwd(int d, NTailBwd p, float* const* gW, float* const* gb, float
     T.vec(gb[0], MAT, d);
     for (int k = 0; k < 4; ++k) {
         const int off = LIN + k * MLP;
-        T.mat(gW[1 + 2 * k], off, d, d, d, d);
-        T.mat(gW[2 + 2 * k], off + MAT, d, d, d, d);
-        T.vec(gb[1 + 2 * k], off + 2 * MAT, d);
-        T.vec(gb[2 + 2 * k], off + 2 * MAT + d, d);
+        T.mat(gW[2 + 2 * k], off, d, d, d, d);                 // segment layout: [dW2][db2][dW1][db1]
+        T.vec(gb[2 + 2 * k], off + MAT, d);
+        T.mat(gW[1 + 2 * k], off + LIN, d, d, d, d);
+        T.vec(gb[1 + 2 * k], off + LIN + MAT, d);
     }
     const int l5 = LIN + 4 * MLP;
     T.mat(gW[9], l5, d, d, d, d);
@@ -274,11 +274,11 @@ struct Lay {
     int64_t l_x1, l_P, l_x2, l_H0, l_R1, l_R2, l_R3, l_T, l_O, l_Q, l_mji, l_mnb, l_mother, l_s;
     int64_t pair;
     // temp
-    int64_t t_msg, t_dz, t_ds, t_dQ, t_dzl, t_dmm, t_dmnb, t_dpi, t_dpj, t_dx2, t_dresx, t_gx0, t_gx1, t_partial, temp;
+    int64_t t_msg, t_dz, t_ds, t_dQ, t_dzl, t_dmm, t_dmnb, t_dpi, t_dpj, t_dx2, t_dresx, t_gx0, t_gx1, t_partial, t_pack, temp;
     int64_t partial_floats;
 };
 
-Lay make_layout(int64_t n, int64_t eg, int64_t el, int64_t tp, int64_t d) {
+Lay make_layout(int64_t n, int64_t eg, int64_t el, int64_t tp, int64_t d, int64_t n_layer = 1) {
     Lay L;
     L.n = n, L.eg = eg, L.el = el, L.tp = tp, L.d = d;
     int64_t o = 0;
@@ -309,6 +309,7 @@ Lay make_layout(int64_t n, int64_t eg, int64_t el, int64_t tp, int64_t d) {
     pf = pf > qb ? pf : qb;
     L.partial_floats = pf;
     L.t_partial = take(pf);
+    L.t_pack = take(n_layer * 2 * PACK_SLOTS * d * d);       // weight images of every layer pair (npack_kernel)
     L.temp = o;
     return L;
 }
@@ -322,12 +323,43 @@ inline Idx make_idx(const int32_t* const* g) {
     return Idx{g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11], g[12], g[13], g[14]};
 }
 
-inline void tail_fwd_params(NTailFwd& t, const float* const* tp) {
-    for (int i = 0; i < 10; ++i) t.W[i] = tp[i], t.b[i] = tp[10 + i];
-    t.w_out = tp[20], t.b_out = tp[21], t.w_att = tp[22];
+constexpr int GP = 28, LP = 35;            // pointers per global / local layer in the parameter tables (pamnet_hip.h)
+
+// slots of a layer pair's [d, d] weight blocks in the packed-image area
+enum Slot { G_W1 = 0, G_P = 1, G_TAIL = 3, L_W1 = 13, L_P = 14, L_Q = 18, L_TAIL = 22 };
+
+struct Images {
+    const float* base;
+    int d;
+    const float4* at(int64_t pair, int slot, int transposed) const {
+        return reinterpret_cast<const float4*>(base + ((pair * PACK_SLOTS + slot) * 2 + transposed) * (int64_t)d * d);
+    }
+};
+
+int pack_all(int d, int64_t n_layer, const float* const* gparams, const float* const* lparams, float* out, hipStream_t st) {
+    for (int64_t k = 0; k < n_layer; ++k) {
+        const float* const* g = gparams + k * GP;
+        const float* const* l = lparams + k * LP;
+        PackJobs J;
+        auto set = [&](int slot, const float* W, int ld) { J.W[slot] = W, J.ld[slot] = ld; };
+        set(G_W1, g[0], d), set(G_P, g[2], 3 * d), set(G_P + 1, g[2] + d, 3 * d);
+        for (int i = 0; i < 10; ++i) set(G_TAIL + i, g[5 + i], d), set(L_TAIL + i, l[12 + i], d);
+        set(L_W1, l[0], d);
+        set(L_P, l[2], 3 * d), set(L_P + 1, l[4], 3 * d), set(L_P + 2, l[2] + d, 3 * d), set(L_P + 3, l[4] + d, 3 * d);
+        set(L_Q, l[2] + 2 * d, 3 * d), set(L_Q + 1, l[4] + 2 * d, 3 * d), set(L_Q + 2, l[10], d), set(L_Q + 3, l[11], d);
+        float4* dst = reinterpret_cast<float4*>(out + k * 2 * PACK_SLOTS * (int64_t)d * d);
+#define CALL(DD) hipLaunchKernelGGL((npack_kernel<DD>), dim3(PACK_SLOTS, 2), dim3(256), 0, st, J, dst);
+        NARROW_DISPATCH(d, CALL)
+#undef CALL
+        PAMNET_LAUNCH_CHECK();
+    }
+    return PAMNET_OK;
 }
 
-constexpr int GP = 28, LP = 35;            // pointers per global / local layer in the parameter tables (pamnet_hip.h)
+inline void tail_fwd_params(NTailFwd& t, const float* const* tp, const Images& im, int64_t pair, int slot0) {
+    for (int i = 0; i < 10; ++i) t.img[i] = im.at(pair, slot0 + i, 0), t.b[i] = tp[10 + i];
+    t.w_out = tp[20], t.b_out = tp[21], t.w_att = tp[22];
+}
 
 }  // namespace
 
@@ -335,7 +367,7 @@ extern "C" int pamnet_narrow_stack_workspace(int64_t n, int64_t eg, int64_t el, 
                                              int64_t* saved_floats, int64_t* temp_floats) {
     if (n < 0 || eg < 0 || el < 0 || tp < 0 || n_layer < 1 || !width_ok(d)) return PAMNET_EINVAL;
     if (!saved_floats || !temp_floats) return PAMNET_ENULL;
-    const Lay L = make_layout(n, eg, el, tp, d);
+    const Lay L = make_layout(n, eg, el, tp, d, n_layer);
     *saved_floats = L.pair * n_layer;
     *temp_floats = L.temp;
     return PAMNET_OK;
@@ -359,10 +391,12 @@ extern "C" int pamnet_narrow_stack_fwd_f32(const int64_t* sizes, const int32_t* 
     if (n < 0 || eg < 0 || el < 0 || tp < 0 || n_layer < 1 || !width_ok(d)) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
     if (!x0 || !saved || !temp || !outs || !atts || (eg > 0 && !e_g) || (el > 0 && !rbf_e) || (tp > 0 && !e_sbf)) return PAMNET_ENULL;
-    const Lay L = make_layout(n, eg, el, tp, d);
+    const Lay L = make_layout(n, eg, el, tp, d, n_layer);
     const Idx ix = make_idx(graph_idx);
     hipStream_t st = as_stream(stream);
     const int D = (int)d;
+    TRY(pack_all(D, n_layer, gparams, lparams, temp + L.t_pack, st));
+    const Images im{temp + L.t_pack, D};
     const float* x = x0;
     for (int64_t k = 0; k < n_layer; ++k) {
         float* S = saved + k * L.pair;
@@ -371,14 +405,14 @@ extern "C" int pamnet_narrow_stack_fwd_f32(const int64_t* sizes, const int32_t* 
         // ---------------- global layer
         {
             NPreFwd p = {};
-            p.x = x, p.W1 = g[0], p.b1 = g[1], p.nb = 2, p.Wp[0] = g[2], p.Wp[1] = g[2] + D, p.ldp[0] = p.ldp[1] = 3 * D;
+            p.x = x, p.img1 = im.at(k, G_W1, 0), p.b1 = g[1], p.nb = 2, p.imgp[0] = im.at(k, G_P, 0), p.imgp[1] = im.at(k, G_P + 1, 0);
             p.x1 = S + L.g_x1, p.P = S + L.g_P, p.m = n;
             TRY(launch_pre_fwd(D, p, st));
             TRY(launch_global_fwd(D, e_g, eg, ix.g_row, ix.g_col, S + L.g_P, g[2] + 2 * D, 3 * D, g[3], g[4], D, temp + L.t_msg, st));
             TRY(pamnet_segment_sum_f32(S + L.g_x2, S + L.g_x1, temp + L.t_msg, nullptr, nullptr, nullptr, nullptr, ix.g_ptr, n,
                                        d, stream));
             NTailFwd t = {};
-            tail_fwd_params(t, g + 5);
+            tail_fwd_params(t, g + 5, im, k, G_TAIL);
             t.x2 = S + L.g_x2, t.res_x = x, t.H0 = S + L.g_H0, t.R1 = S + L.g_R1, t.R2 = S + L.g_R2, t.R3 = S + L.g_R3;
             t.T = S + L.g_T, t.O = S + L.g_O, t.out = outs + (2 * k) * n, t.att = atts + (2 * k) * n, t.m = n;
             TRY(launch_tail_fwd(D, t, st));
@@ -387,14 +421,12 @@ extern "C" int pamnet_narrow_stack_fwd_f32(const int64_t* sizes, const int32_t* 
         // ---------------- local layer
         {
             NPreFwd p = {};
-            p.x = x, p.W1 = l[0], p.b1 = l[1], p.nb = 4, p.m = n, p.x1 = S + L.l_x1, p.P = S + L.l_P;
-            p.Wp[0] = l[2], p.Wp[1] = l[4], p.Wp[2] = l[2] + D, p.Wp[3] = l[4] + D;
-            p.ldp[0] = p.ldp[1] = p.ldp[2] = p.ldp[3] = 3 * D;
+            p.x = x, p.img1 = im.at(k, L_W1, 0), p.b1 = l[1], p.nb = 4, p.m = n, p.x1 = S + L.l_x1, p.P = S + L.l_P;
+            for (int b = 0; b < 4; ++b) p.imgp[b] = im.at(k, L_P + b, 0);
             TRY(launch_pre_fwd(D, p, st));
             NPreFwd q = {};
             q.x = rbf_e, q.nb = 4, q.m = el, q.P = S + L.l_Q;
-            q.Wp[0] = l[2] + 2 * D, q.Wp[1] = l[4] + 2 * D, q.Wp[2] = l[10], q.Wp[3] = l[11];
-            q.ldp[0] = q.ldp[1] = 3 * D, q.ldp[2] = q.ldp[3] = D;
+            for (int b = 0; b < 4; ++b) q.imgp[b] = im.at(k, L_Q + b, 0);
             TRY(launch_pre_fwd(D, q, st));
             TRY(pamnet_narrow_local_gate_fwd_f32(S + L.l_P, S + L.l_Q, ix.l_row, ix.l_col, l[3], l[5], el, d, S + L.l_mji,
                                                  S + L.l_mnb, stream));
@@ -410,7 +442,7 @@ extern "C" int pamnet_narrow_stack_fwd_f32(const int64_t* sizes, const int32_t* 
             TRY(pamnet_segment_sum_f32(S + L.l_x2, S + L.l_x1, temp + L.t_msg, nullptr, nullptr, nullptr, nullptr, ix.l_ptr, n,
                                        d, stream));
             NTailFwd t = {};
-            tail_fwd_params(t, l + 12);
+            tail_fwd_params(t, l + 12, im, k, L_TAIL);
             t.x2 = S + L.l_x2, t.res_x = x, t.H0 = S + L.l_H0, t.R1 = S + L.l_R1, t.R2 = S + L.l_R2, t.R3 = S + L.l_R3;
             t.T = S + L.l_T, t.O = S + L.l_O, t.out = outs + (2 * k + 1) * n, t.att = atts + (2 * k + 1) * n, t.m = n;
             TRY(launch_tail_fwd(D, t, st));
@@ -432,10 +464,12 @@ extern "C" int pamnet_narrow_stack_bwd_f32(const int64_t* sizes, const int32_t* 
     //                                                     caller zero-fills; a batch without edges has nothing to train on)
     if (!x0 || !e_g || !rbf_e || !e_sbf || !saved || !temp || !d_outs || !d_atts || !d_x0 || !d_eg || !d_rbf || !d_sbf)
         return PAMNET_ENULL;
-    const Lay L = make_layout(n, eg, el, tp, d);
+    const Lay L = make_layout(n, eg, el, tp, d, n_layer);
     const Idx ix = make_idx(graph_idx);
     hipStream_t st = as_stream(stream);
     const int D = (int)d;
+    TRY(pack_all(D, n_layer, gparams, lparams, temp + L.t_pack, st));
+    const Images im{temp + L.t_pack, D};
     float* partial = temp + L.t_partial;
     float* d_x2 = temp + L.t_dx2;
     float* d_resx = temp + L.t_dresx;
@@ -453,7 +487,7 @@ extern "C" int pamnet_narrow_stack_bwd_f32(const int64_t* sizes, const int32_t* 
         // ---------------- local layer
         {
             NTailBwd t = {};
-            for (int i = 0; i < 10; ++i) t.W[i] = l[12 + i], t.b[i] = l[22 + i];
+            for (int i = 0; i < 10; ++i) t.img[i] = im.at(k, L_TAIL + i, 0), t.imgt[i] = im.at(k, L_TAIL + i, 1), t.b[i] = l[22 + i];
             t.w_out = l[32], t.w_att = l[34];
             t.x2 = S + L.l_x2, t.H0 = S + L.l_H0, t.R1 = S + L.l_R1, t.R2 = S + L.l_R2, t.R3 = S + L.l_R3, t.T = S + L.l_T;
             t.O = S + L.l_O, t.g_x = g_x, t.g_out = d_outs + (2 * k + 1) * n, t.g_att = d_atts + (2 * k + 1) * n;
@@ -499,9 +533,8 @@ extern "C" int pamnet_narrow_stack_bwd_f32(const int64_t* sizes, const int32_t* 
                 TRY(T.launch(partial, grid_for(el, 1, lin_bwd_waves(D)), 4 * qs, st));
             }
             NPreBwd p = {};
-            p.x = x_loc, p.x1 = S + L.l_x1, p.W1 = l[0], p.b1 = l[1], p.nb = 4, p.m = n;
-            p.Wp[0] = l[2], p.Wp[1] = l[4], p.Wp[2] = l[2] + D, p.Wp[3] = l[4] + D;
-            p.ldp[0] = p.ldp[1] = p.ldp[2] = p.ldp[3] = 3 * D;
+            p.x = x_loc, p.x1 = S + L.l_x1, p.img1 = im.at(k, L_W1, 0), p.img1t = im.at(k, L_W1, 1), p.b1 = l[1], p.nb = 4, p.m = n;
+            for (int b = 0; b < 4; ++b) p.imgpt[b] = im.at(k, L_P + b, 1);
             p.dP[0] = dpi, p.dP[1] = dpi + D, p.dP[2] = dpj, p.dP[3] = dpj + D;
             p.lddp[0] = p.lddp[1] = p.lddp[2] = p.lddp[3] = 2 * D;
             p.d_direct = d_x2, p.d_add = d_resx, p.dx = gx[0], p.partial = partial;
@@ -512,7 +545,7 @@ extern "C" int pamnet_narrow_stack_bwd_f32(const int64_t* sizes, const int32_t* 
         // ---------------- global layer
         {
             NTailBwd t = {};
-            for (int i = 0; i < 10; ++i) t.W[i] = g[5 + i], t.b[i] = g[15 + i];
+            for (int i = 0; i < 10; ++i) t.img[i] = im.at(k, G_TAIL + i, 0), t.imgt[i] = im.at(k, G_TAIL + i, 1), t.b[i] = g[15 + i];
             t.w_out = g[25], t.w_att = g[27];
             t.x2 = S + L.g_x2, t.H0 = S + L.g_H0, t.R1 = S + L.g_R1, t.R2 = S + L.g_R2, t.R3 = S + L.g_R3, t.T = S + L.g_T;
             t.O = S + L.g_O, t.g_x = gx[0], t.g_out = d_outs + (2 * k) * n, t.g_att = d_atts + (2 * k) * n;
@@ -526,8 +559,8 @@ extern "C" int pamnet_narrow_stack_bwd_f32(const int64_t* sizes, const int32_t* 
             TRY(pamnet_segment_sum_f32(dpi, nullptr, dz, nullptr, nullptr, nullptr, nullptr, ix.g_ptr, n, d, stream));
             TRY(pamnet_segment_sum_f32(dpj, nullptr, dz, nullptr, nullptr, nullptr, ix.gT_perm, ix.gT_ptr, n, d, stream));
             NPreBwd p = {};
-            p.x = x_glob, p.x1 = S + L.g_x1, p.W1 = g[0], p.b1 = g[1], p.nb = 2, p.m = n;
-            p.Wp[0] = g[2], p.Wp[1] = g[2] + D, p.ldp[0] = p.ldp[1] = 3 * D;
+            p.x = x_glob, p.x1 = S + L.g_x1, p.img1 = im.at(k, G_W1, 0), p.img1t = im.at(k, G_W1, 1), p.b1 = g[1], p.nb = 2, p.m = n;
+            p.imgpt[0] = im.at(k, G_P, 1), p.imgpt[1] = im.at(k, G_P + 1, 1);
             p.dP[0] = dpi, p.dP[1] = dpj, p.lddp[0] = p.lddp[1] = D;
             p.d_direct = d_x2, p.d_add = d_resx, p.dx = k == 0 ? d_x0 : gx[1], p.partial = partial;
             float* gWp[2] = {gg[2], gg[2] + D};

@@ -325,7 +325,7 @@ class _RBF(torch.autograd.Function):
         dist, freq = ctx.saved_tensors
         g = _c(g)
         dfreq = torch.empty(16, dtype=torch.float32, device=g.device)
-        partial = torch.empty(16 * 256, dtype=torch.float32, device=g.device)
+        partial = torch.empty(16 * 2048, dtype=torch.float32, device=g.device)
         lib.call('pamnet_rbf_bwd_f32', lib.ptr(dist), lib.ptr(_c(freq)), ctx.cutoff, dist.numel(), lib.ptr(g),
                  lib.ptr(dfreq), lib.ptr(partial), lib.stream_of(g))
         return None, dfreq, None
