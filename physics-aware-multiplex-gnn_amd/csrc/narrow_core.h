@@ -391,11 +391,14 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nglobal_bwd_kernel(const fl
             }
         }
         f32x4 q1[NT], q2[NT], ed[NT];
+        // (prefetching the next tile's rows / indices / gathers across iterations was measured: 496 -> 550 us at 867 k
+        // edges, d = 64 -- rejected; the accumulator-layout copy of e through the wave's LDS tile replaces a second,
+        // 4-byte-strided read of the rows)
+        a_to_d<D>(ed, a, tile, lane);
         zero(q1);
         zero(q2);
         mma_img<NT, NT>(q1, a, img_e, lane);
         mma_img<NT, NT>(q2, a, img_a, lane);
-        load_d<D>(ed, e, row0, m, lane);
         // q1 -> dz, q2 -> dq2 (in place)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -540,11 +543,26 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nmlp2_bwd_kernel(const floa
         zero(gw1[jt]);
         zero(gw2[jt]);
     }
-    for (int64_t t = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * NW) {
+    // Row tiles arrive as A fragments (four coalesced 16-byte loads per lane for x and for dy; the accumulator-layout copies
+    // the weight-gradient GEMMs need go through the wave's LDS tile), and the NEXT tile's are requested before this tile's
+    // GEMMs: at one wave per SIMD nothing else hides the HBM latency (415 -> 3xx us at 669 k rows, d = 64).
+    const int64_t tstep = (int64_t)gridDim.x * NW;
+    int64_t t = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+    float4 a[NT], ga[NT], a_n[NT], ga_n[NT];
+    if (t < ntiles) {
+        load_a<D>(a, x, t * 16, m, lane);
+        load_a<D>(ga, dy, t * 16, m, lane);
+    }
+    for (; t < ntiles; t += tstep) {
         const int64_t row0 = t * 16;
-        float4 a[NT];
-        load_a<D>(a, x, row0, m, lane);
-        f32x4 z1[NT], h[NT], g[NT];
+        const bool more = t + tstep < ntiles;
+        if (more) {
+            load_a<D>(a_n, x, (t + tstep) * 16, m, lane);
+            load_a<D>(ga_n, dy, (t + tstep) * 16, m, lane);
+        }
+        f32x4 z1[NT], h[NT], g[NT], xd[NT], dyv[NT];
+        a_to_d<D>(xd, a, tile, lane);
+        a_to_d<D>(dyv, ga, tile, lane);
         zero(z1);
         mma_img<NT, NT>(z1, a, img1, lane);
 #pragma unroll
@@ -557,8 +575,6 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nmlp2_bwd_kernel(const floa
         d_to_a<D>(a, h, tile, lane);
         zero(g);
         mma_img<NT, NT>(g, a, img2, lane);                   // z2 - b2
-        f32x4 dyv[NT];
-        load_d<D>(dyv, dy, row0, m, lane);
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -580,8 +596,7 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nmlp2_bwd_kernel(const floa
                 const float s = sigmoidf_fast(z);
                 g[jt][r] *= s * (1.0f + z * (1.0f - s));     // dz1
             }
-        load_d<D>(h, x, row0, m, lane);
-        wgrad_acc<NT, NT>(gw1, g, h);
+        wgrad_acc<NT, NT>(gw1, g, xd);
         colsum_acc<NT>(db1, g);
         if (dx) {
             d_to_a<D>(a, g, tile, lane);
@@ -597,6 +612,13 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nmlp2_bwd_kernel(const floa
                 for (int jt = 0; jt < NT; ++jt) g[jt] += dyv[jt];
             }
             store_d<D>(g, dx, row0, m, lane);
+        }
+        if (more) {
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                a[jt] = a_n[jt];
+                ga[jt] = ga_n[jt];
+            }
         }
     }
     __syncthreads();

@@ -8,9 +8,9 @@ for c in ${CONFIGS:-rna rna_d64}; do
   python - "$f" <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
-tot=sum(int(r['TotalDurationNs']) for r in rows)/7e6
+tot=sum(int(r['TotalDurationNs']) for r in rows)/25e6
 print('GPU ms/step',round(tot,3))
-for r in rows[:28]:
-    print('  %-90s %4s %8.3f ms/step'%(r['Name'].replace('(anonymous namespace)::','')[:90],r['Calls'],int(r['TotalDurationNs'])/7e6))
+for r in rows[:34]:
+    print('  %-90s %4s %8.3f ms/step'%(r['Name'].replace('(anonymous namespace)::','')[:90],r['Calls'],int(r['TotalDurationNs'])/25e6))
 PY
 done
