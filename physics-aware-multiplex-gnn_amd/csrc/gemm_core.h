@@ -37,6 +37,64 @@ __device__ __forceinline__ float dsilu(float z) {
     return s * (1.0f + z * (1.0f - s));
 }
 
+// ---- fp32-accurate GEMMs on the bf16 matrix pipe ("bf16x6") -----------------------------------------------------------
+// The f32-input MFMA runs at the fp32 VECTOR rate (64 FLOP/clk/SIMD: 32 cycles per 16x16x4) and shares the issue port
+// with the VALU; v_mfma_f32_16x16x32_bf16 does 8x the work in ~17 cycles on the matrix pipe proper.  A float splits
+// EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits, each piece the round-to-nearest bf16 of the running
+// residual; bf16 has fp32's exponent range, so no scaling is involved):  x = p0 + p1 + p2.  A product needs the six
+// piece products with i + j <= 2 -- the three dropped ones are below 2^-24 of |x y|, the rounding error of one fp32
+// multiply -- each exact in the fp32 accumulator (8 x 8 bit significands).  Six bf16 MFMAs per 32 k against eight fp32
+// MFMAs of twice the cycles: 2.5x fewer matrix-pipe cycles at fp32 accuracy (tests/test_hip_kernels.py::test_wgrad_*:
+// error against fp64 at the level of an fp32 GEMM; a numpy restatement of the arithmetic is in tools/bf16x6_check.py).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// pieces of the pair (x0, x1), each as one packed dword (x0 in the low half): v_cvt_pk_bf16_f32 rounds to nearest even
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+    const f32x2 v = {x0, x1};
+    p0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = {x0 - __uint_as_float(p0 << 16), x1 - __uint_as_float(p0 & 0xffff0000u)};      // exact
+    p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+    const f32x2 q = {r[0] - __uint_as_float(p1 << 16), r[1] - __uint_as_float(p1 & 0xffff0000u)};  // exact
+    p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(q, bf16x2));
+}
+
+// the same in three stages (4 / 4 / 1 VALU) that a kernel can place between MFMAs one at a time; `r` carries the residual
+template <int STAGE>
+__device__ __forceinline__ void split3_stage(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2, f32x2& r) {
+    if constexpr (STAGE == 0) {
+        const f32x2 v = {x0, x1};
+        p0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        r = f32x2{x0 - __uint_as_float(p0 << 16), x1 - __uint_as_float(p0 & 0xffff0000u)};
+    } else if constexpr (STAGE == 1) {
+        p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+        r = f32x2{r[0] - __uint_as_float(p1 << 16), r[1] - __uint_as_float(p1 & 0xffff0000u)};
+    } else {
+        p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+    }
+}
+
+// An MFMA operand fragment (8 consecutive-k values of one row / column per lane) as three piece planes.
+struct Frag3 {
+    uint32_t p[3][4];
+};
+__device__ __forceinline__ Frag3 split_frag(const float (&v)[8]) {
+    Frag3 f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t a, b, c;
+        split3(v[2 * i], v[2 * i + 1], a, b, c);
+        f.p[0][i] = a, f.p[1][i] = b, f.p[2][i] = c;
+    }
+    return f;
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const uint32_t (&a)[4], const uint32_t (&b)[4], const f32x4& c) {
+    const u32x4 av = {a[0], a[1], a[2], a[3]}, bv = {b[0], b[1], b[2], b[3]};
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+}
+
 template <int MT>
 __device__ __forceinline__ void acc_zero(f32x4 (&acc)[MT][2]) {
 #pragma unroll

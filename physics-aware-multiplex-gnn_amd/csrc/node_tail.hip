@@ -454,7 +454,10 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
         // otherwise idle CU -- the weight-gradient launch of that layer shrinks by what rides here.
         static_assert(sizeof(lds) >= sizeof(float) * WGRAD_LDS_FLOATS, "rider staging must fit the chain's LDS");
         if ((int)blockIdx.x >= n_tiles) {
-#ifdef PAMNET_RIDER_8W
+#ifndef PAMNET_RIDER_4W
+            // all eight waves (wave tile 32x64): the bf16x6 inner loop holds the split fragments of two pipeline stages and
+            // does not fit the 256 registers of a two-waves-per-SIMD kernel with the 64x64 tile; two waves per SIMD also
+            // interleave one wave's splits with the other's MFMAs in hardware
             wgrad_body<8>(rider, rider_partial, (int)blockIdx.x - n_tiles, lds);
 #else
             // four of the eight waves, one per SIMD, each with the 64x64 wave tile of the stand-alone kernel (the other

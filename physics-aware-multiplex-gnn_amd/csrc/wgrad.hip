@@ -62,7 +62,7 @@ inline int64_t plan_chunk(int64_t njobs, const int64_t* rows, int64_t max_slots,
     }
 }
 
-__global__ __launch_bounds__(WG) void wgrad_kernel(WBatch batch, float* __restrict__ partial) {
+__global__ __launch_bounds__(WG, 2) void wgrad_kernel(WBatch batch, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float lds[WGRAD_LDS_FLOATS];
     wgrad_body<4>(batch, partial, (int)blockIdx.x, lds);
 }
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(WG) void wgrad_finish_kernel(WBatch batch, const fl
 // workgroups fill in beside the current pass.  Compact batches (<= 16 jobs): the three descriptors share the 4 KB
 // kernel-argument block.
 constexpr int FIN_X = DIM * DIM / 64 + 2;
-__global__ __launch_bounds__(WG) void wgrad_fused_kernel(WBatchS cur, float* __restrict__ cur_partial, WBatchS prev,
+__global__ __launch_bounds__(WG, 2) void wgrad_fused_kernel(WBatchS cur, float* __restrict__ cur_partial, WBatchS prev,
                                                          const float* __restrict__ prev_partial, HeadJob prev_head,
                                                          WBatchS prev2, const float* __restrict__ prev2_partial) {
     __shared__ __attribute__((aligned(16))) float lds[WGRAD_LDS_FLOATS];
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(WG) void wgrad_fused_kernel(WBatchS cur, float* __r
 }
 
 // the same with one earlier batch and wide descriptors (up to 24 jobs each): no rider batch pending
-__global__ __launch_bounds__(WG) void wgrad_fused_wide_kernel(WBatch cur, float* __restrict__ cur_partial, WBatch prev,
+__global__ __launch_bounds__(WG, 2) void wgrad_fused_wide_kernel(WBatch cur, float* __restrict__ cur_partial, WBatch prev,
                                                               const float* __restrict__ prev_partial, HeadJob prev_head) {
     __shared__ __attribute__((aligned(16))) float lds[WGRAD_LDS_FLOATS];
     const int slots = cur.start[cur.njobs];

@@ -429,3 +429,43 @@ def test_type_rows_gather_and_grad(dev, n, types, d):
     t2 = table.detach().clone().requires_grad_()
     (ops.type_rows(t2, idx, buf) * w).sum().backward()
     assert t2.grad is None and torch.equal(buf, g1)
+
+
+@pytest.mark.parametrize('rows', [[1, 15, 64, 65], [2286] * 4 + [32888], [700, 3, 4316, 17640]])
+def test_wgrad_batched_vs_fp64(dev, rows):
+    """pamnet_wgrad_batched_f32: dW = dZ^T A (A optionally SiLU'd while staging), db = column sums of dZ.  The GEMMs run
+    on the bf16 matrix pipe with both operands split exactly into three bf16 pieces (csrc/gemm_core.h, "bf16x6"): held
+    to fp32-GEMM accuracy -- the error against fp64 may not exceed twice that of torch's fp32 matmul on the same inputs
+    (floor 2e-7) -- on operands whose magnitudes spread over 2^+-20 row by row, ragged / empty row counts, strided dW
+    targets; bitwise repeatable."""
+    from pamnet_amd import fused
+    g = torch.Generator(device='cpu').manual_seed(sum(rows) + 7)
+    jobs, refs = [], []
+    for j, r in enumerate(rows):
+        scale = torch.exp2(torch.randint(-20, 21, (max(r, 1), 1), generator=g).float())[:r]
+        dZ = (torch.randn(r, 128, generator=g) * scale).to(dev)
+        A = torch.randn(r, 128, generator=g).to(dev) * (3.0 if j % 2 else 1.0)
+        mode = j % 2
+        wide = torch.full((128, 384), float('nan'), device=dev)         # dW lands in a column block of a [128, 384] weight
+        db = torch.full((128,), float('nan'), device=dev)
+        jobs.append((dZ, 128, A, 128, mode, r, wide.data_ptr() + 4 * 128, 384, db))
+        a64 = A.double()
+        a64 = a64 * torch.sigmoid(a64) if mode else a64
+        a32 = torch.nn.functional.silu(A) if mode else A
+        refs.append((wide, db, dZ.double().t() @ a64, dZ.double().sum(0), dZ.t() @ a32))
+    fused.wgrad(jobs, jobs[0][0])
+    first = [(w.clone(), b.clone()) for w, b, *_ in refs]
+    fused.wgrad(jobs, jobs[0][0])
+    worst = 0.0
+    for (wide, db, w64, b64, w32), (w1, b1) in zip(refs, first):
+        assert torch.equal(wide[:, 128:256], w1[:, 128:256]) and torch.equal(db, b1)      # run-to-run bitwise
+        assert torch.isnan(wide[:, :128]).all() and torch.isnan(wide[:, 256:]).all()      # neighbours untouched
+        got = wide[:, 128:256]
+        if w64.abs().max() == 0:
+            assert (got == 0).all() and (db == 0).all()
+            continue
+        e, floor = maxnorm_err(got.cpu(), w64.cpu()), maxnorm_err(w32.cpu(), w64.cpu())
+        worst = max(worst, e / max(floor, 1e-7))
+        assert e <= max(2e-7, 2 * floor), (e, floor)
+        assert maxnorm_err(db.cpu(), b64.cpu()) < 2e-6
+    print('wgrad bf16x6: worst error / fp32-matmul error = %.2f' % worst)
