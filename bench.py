@@ -29,6 +29,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 FP32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0        # dense bf16 MFMA (MI355X_MICROARCH.md), the pipe the bf16x6 kernels issue on
 METRIC = 'molecules/sec (QM9 dim=128 n_layer=6) at 1/2/4/8 GPU; scatter-add HBM GB/s vs peak'
 
 
@@ -126,9 +127,16 @@ def step_kernel_rooflines(dev, g, d, n_layer):
     fn()
     ms, _ = event_time_ms(fn, 30, 3)
     fl = 2.0 * d * d * (15 * n + 2 * eg)
+    # The kernel computes fp32-accurate products on the bf16 matrix pipe (three exact bf16 pieces per operand, six bf16
+    # MFMAs per 32 rows: csrc/gemm_core.h "bf16x6"): `frac` stays against the fp32-MFMA peak the path is priced on
+    # (SURVEY 8d); `frac_bf16x6` prices the same algorithmic FLOPs against the ceiling of the instruction stream it
+    # actually issues, dense bf16 peak / 6.
     out.append({'kernel': 'wgrad_kernel + wgrad_finish_kernel (all dW of one global layer, one batch)', 'bound': 'mfma',
                 'flops_per_launch': fl, 'us_per_launch': ms * 1e3, 'achieved': fl / ms / 1e9, 'peak': FP32_MFMA_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 'launches_per_step': 2 * n_layer})
+                'unit': 'TFLOP/s', 'frac': fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS,
+                'arithmetic': 'fp32-accurate on v_mfma_f32_16x16x32_bf16 (3 exact bf16 pieces per operand, 6 products)',
+                'peak_bf16x6': BF16_MFMA_PEAK_TFLOPS / 6.0, 'frac_bf16x6': fl / ms / 1e9 / (BF16_MFMA_PEAK_TFLOPS / 6.0),
+                'launches_per_step': 2 * n_layer})
     Wm, bm, Wea = rnd(d, 3 * d) / 8, rnd(d), rnd(d, d) / 8
     e, Pi, Pj, x1 = rnd(eg, d), rnd(n, d), rnd(n, d), rnd(n, d)
     z, ea, x2 = torch.empty(eg, d, device=dev), torch.empty(eg, d, device=dev), torch.empty(n, d, device=dev)

@@ -11,6 +11,7 @@ python $R/tools/step_timeline.py $(ls $O/prof_step/*/*_kernel_trace.csv | head -
 bash $R/tools/pmc_mfma.sh > /dev/null 2>&1
 cp $O/mfma_util.txt $O/r02_mfma_util_pmc.txt
 bash $R/tools/pmc_scatter.sh > /dev/null 2>&1
+bash $R/tools/pmc_edge_agg.sh > /dev/null 2>&1
 python $R/tools/qm9_host_split.py 2>/dev/null | tail -1 > $O/r02_qm9_host_split.txt
 python $R/tools/agg_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/r02_edge_agg_phase_probe.txt
 (python $R/tools/agg_bench.py qm9 2>/dev/null; python $R/tools/agg_bench.py pdbbind 2>/dev/null) | grep -v amdgpu.ids > $O/r02_edge_agg_microbench.txt
