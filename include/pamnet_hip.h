@@ -77,8 +77,11 @@ int pamnet_validate_inputs_i32(const int32_t* node_graph, int64_t n, int64_t n_g
 int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t rows, int32_t* ptr, int32_t* perm,
                              int32_t* cursor, int32_t* perm_tmp, int32_t* tmp, pamnet_stream_t stream);
 
-/* row_of[q] = r for q in [ptr[r], ptr[r+1])  (repeat_interleave of row ids, models.py:76-77, 88-89) */
-int pamnet_expand_rows_i32(const int32_t* ptr, int64_t rows, int32_t* row_of, pamnet_stream_t stream);
+/* row_of[q] = r for q in [ptr[r], ptr[r+1])  (repeat_interleave of row ids, models.py:76-77, 88-89).
+ * `cap` = entries the output holds (the *_fill entry points take one too): nothing is written at or beyond it.  With sizes
+ * read back from the device cap = ptr[rows] and never binds; it makes the zero-host-sync path (sizes assumed by the host,
+ * verified later: pamnet_check_sizes_i32) memory-safe when the assumption is wrong. */
+int pamnet_expand_rows_i32(const int32_t* ptr, int64_t rows, int32_t* row_of, int64_t cap, pamnet_stream_t stream);
 
 /* CSR row filter: keep entries with nbr >= 0 and dist <= cut  (the cutoff masks, models.py:131-134, 147-156).
  * count -> (caller scans) -> fill. */
@@ -95,7 +98,7 @@ int pamnet_csr_filter_fill_i32(const int32_t* ptr_in, const int32_t* nbr, const 
 int pamnet_radius_count_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n, float r,
                             int32_t* count, pamnet_stream_t stream);
 int pamnet_radius_fill_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n, float r,
-                           const int32_t* ptr, int32_t* nbr, float* dist, pamnet_stream_t stream);
+                           const int32_t* ptr, int32_t* nbr, float* dist, int64_t cap, pamnet_stream_t stream);
 
 /* knn: for every query node its k nearest nodes of the same graph (itself included, as torch_cluster.knn does),
  * ordered by (distance, index); then the self entry is dropped and entries with dist > cutoff are masked out:
@@ -120,7 +123,26 @@ int pamnet_triplet_count_i32(const int32_t* lptr, const int32_t* src, const int3
                              int32_t with_triplets, int32_t* tcount, int32_t* tpcount, pamnet_stream_t stream);
 int pamnet_triplet_fill_f32(const float* pos, const int32_t* lptr, const int32_t* src, const int32_t* dst,
                             int64_t n_edges, int32_t with_triplets, const int32_t* tp_ptr, int32_t* tp_idx,
-                            int32_t* tp_edge, float* tp_angle, int32_t* tp_kind, pamnet_stream_t stream);
+                            int32_t* tp_edge, float* tp_angle, int32_t* tp_kind, int64_t cap, pamnet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Zero-host-sync graph construction (models.py:62-98,104-157 read their data-dependent sizes back to the
+ * host through boolean masks / repeat_interleave).
+ * check_sizes: up to 4 device-side totals (actual[k][0], e.g. the last element of a CSR pointer) against the values the
+ *   host assumed; bit (2 << k) of flag[0] is set on a mismatch, bit 32 when *all_kept (a device bool, nullable) is false.
+ *   flag is NOT zeroed (pamnet_validate_inputs_i32 owns bit 1 of the same word).
+ * collate: batch of n_graphs graphs sel[k] of a dataset kept resident as concatenated arrays (prefix sums src_nptr /
+ *   src_eptr, bonds with graph-local endpoints): node features [n_out, x_width], positions (nullable), int32 batch
+ *   vector, bonds with batch-level endpoints.  out_nptr / out_eptr: the batch's prefix sums (device, n_graphs + 1).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pamnet_check_sizes_i32(int64_t n_checks, const int32_t* const* actual /* host array of device ptrs */,
+                           const int64_t* expected /* host */, const void* all_kept, int32_t* flag,
+                           pamnet_stream_t stream);
+int pamnet_collate_f32(int64_t n_graphs, const int32_t* sel, const int32_t* out_nptr, const int32_t* out_eptr,
+                       const int32_t* src_nptr, const int32_t* src_eptr, const float* x, int64_t x_width,
+                       const float* pos, const int32_t* esrc, const int32_t* edst, int64_t n_out, int64_t e_out,
+                       float* out_x, float* out_pos, int32_t* out_batch, int32_t* out_esrc, int32_t* out_edst,
+                       pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Basis functions  (layers/basic.py:36-51 Envelope, :59-76 BesselBasisLayer, :79-116 SphericalBasisLayer; utils/sbf.py)

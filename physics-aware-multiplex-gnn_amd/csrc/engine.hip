@@ -98,7 +98,7 @@ constexpr int WJOBS = 24;
 
 // split-K scratch of the largest weight-gradient batch of a layer (slots of 128*128 + 256 floats, <= 256 rows each)
 inline int64_t wgrad_floats(const Graph& g) {
-    auto slots = [](int64_t rows) { int64_t s = (rows + 255) / 256; return s < 1 ? 1 : (s > 256 ? 256 : s); };
+    auto slots = [](int64_t rows) { int64_t s = (rows + 127) / 128; return s < 1 ? 1 : (s > 256 ? 256 : s); };   // 128: the smallest chunk a plan may use (wgrad.hip)
     const int64_t glob = 15 * slots(g.n) + 2 * slots(g.eg);
     const int64_t loc = 15 * slots(g.n) + 4 * slots(g.el) + 2 * slots(g.tp);
     return (glob > loc ? glob : loc) * (D * D + 2 * D);

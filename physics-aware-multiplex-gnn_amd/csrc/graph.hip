@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void radius_kernel(const float* __restrict__ p
                                                      const int32_t* __restrict__ node_graph,
                                                      const int32_t* __restrict__ gptr, int64_t n, float r,
                                                      int32_t* __restrict__ count, const int32_t* __restrict__ ptr,
-                                                     int32_t* __restrict__ nbr, float* __restrict__ dist) {
+                                                     int32_t* __restrict__ nbr, float* __restrict__ dist, int64_t cap) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int g = node_graph[i];
@@ -189,7 +189,10 @@ __global__ __launch_bounds__(256) void radius_kernel(const float* __restrict__ p
         if (j == i) continue;
         const float d = dist3(pos, i, j);
         if (d <= r) {
-            if (FILL) { nbr[w] = j; dist[w] = d; ++w; }
+            if (FILL) {
+                if (w < cap) { nbr[w] = j; dist[w] = d; }      // cap: see pamnet_radius_fill_i32
+                ++w;
+            }
             ++c;
         }
     }
@@ -468,10 +471,11 @@ __global__ __launch_bounds__(256) void edge_dist_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void expand_rows_kernel(const int32_t* __restrict__ ptr, int64_t rows,
-                                                          int32_t* __restrict__ row_of) {
+                                                          int32_t* __restrict__ row_of, int64_t cap) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
-    for (int q = ptr[r]; q < ptr[r + 1]; ++q) row_of[q] = (int32_t)r;
+    const int64_t e = ptr[r + 1] < cap ? ptr[r + 1] : cap;
+    for (int64_t q = ptr[r]; q < e; ++q) row_of[q] = (int32_t)r;
 }
 
 __global__ __launch_bounds__(256) void triplet_count_kernel(const int32_t* __restrict__ lptr,
@@ -503,7 +507,8 @@ __global__ __launch_bounds__(256) void triplet_fill_kernel(const float* __restri
                                                            const int32_t* __restrict__ dst, int64_t n_edges,
                                                            int with_triplets, const int32_t* __restrict__ tp_ptr,
                                                            int32_t* __restrict__ tp_idx, int32_t* __restrict__ tp_edge,
-                                                           float* __restrict__ tp_angle, int32_t* __restrict__ tp_kind) {
+                                                           float* __restrict__ tp_angle, int32_t* __restrict__ tp_kind,
+                                                           int64_t cap) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_edges) return;
     const int j = src[e], i = dst[e];
@@ -515,6 +520,7 @@ __global__ __launch_bounds__(256) void triplet_fill_kernel(const float* __restri
         for (int q = lptr[j]; q < lptr[j + 1]; ++q) {
             const int k = src[q];
             if (k == i) continue;
+            if (w >= cap) break;
             const float pkx = pos[3 * (int64_t)k], pky = pos[3 * (int64_t)k + 1], pkz = pos[3 * (int64_t)k + 2];
             tp_idx[w] = q;
             tp_edge[w] = (int32_t)e;
@@ -526,6 +532,7 @@ __global__ __launch_bounds__(256) void triplet_fill_kernel(const float* __restri
     // pairs: idx_i_pair = j, idx_j1_pair = i, idx_j2_pair = j'  ->  a = p_i - p_j, b = p_j' - p_i  (models.py:171-177)
     for (int q = lptr[i]; q < lptr[i + 1]; ++q) {
         const int j2 = src[q];
+        if (w >= cap) break;
         const float px = pos[3 * (int64_t)j2], py = pos[3 * (int64_t)j2 + 1], pz = pos[3 * (int64_t)j2 + 2];
         tp_idx[w] = q;
         tp_edge[w] = (int32_t)e;
@@ -584,11 +591,12 @@ extern "C" int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t 
     return PAMNET_OK;
 }
 
-extern "C" int pamnet_expand_rows_i32(const int32_t* ptr, int64_t rows, int32_t* row_of, pamnet_stream_t stream) {
-    if (rows < 0) return PAMNET_EINVAL;
+extern "C" int pamnet_expand_rows_i32(const int32_t* ptr, int64_t rows, int32_t* row_of, int64_t cap,
+                                      pamnet_stream_t stream) {
+    if (rows < 0 || cap < 0) return PAMNET_EINVAL;
     if (rows == 0) return PAMNET_OK;
     if (!ptr || !row_of) return PAMNET_ENULL;
-    hipLaunchKernelGGL(expand_rows_kernel, dim3(blocks_for(rows)), dim3(256), 0, as_stream(stream), ptr, rows, row_of);
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(blocks_for(rows)), dim3(256), 0, as_stream(stream), ptr, rows, row_of, cap);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -599,19 +607,19 @@ extern "C" int pamnet_radius_count_i32(const float* pos, const int32_t* node_gra
     if (n == 0) return PAMNET_OK;
     if (!pos || !node_graph || !gptr || !count) return PAMNET_ENULL;
     hipLaunchKernelGGL((radius_kernel<false>), dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), pos, node_graph,
-                       gptr, n, r, count, (const int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr);
+                       gptr, n, r, count, (const int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (int64_t)0);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
 
 extern "C" int pamnet_radius_fill_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n,
-                                      float r, const int32_t* ptr, int32_t* nbr, float* dist,
+                                      float r, const int32_t* ptr, int32_t* nbr, float* dist, int64_t cap,
                                       pamnet_stream_t stream) {
-    if (n < 0) return PAMNET_EINVAL;
+    if (n < 0 || cap < 0) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
     if (!pos || !node_graph || !gptr || !ptr || !nbr || !dist) return PAMNET_ENULL;
     hipLaunchKernelGGL((radius_kernel<true>), dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), pos, node_graph,
-                       gptr, n, r, (int32_t*)nullptr, ptr, nbr, dist);
+                       gptr, n, r, (int32_t*)nullptr, ptr, nbr, dist, cap);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -674,16 +682,114 @@ extern "C" int pamnet_triplet_count_i32(const int32_t* lptr, const int32_t* src,
 
 extern "C" int pamnet_triplet_fill_f32(const float* pos, const int32_t* lptr, const int32_t* src, const int32_t* dst,
                                        int64_t n_edges, int32_t with_triplets, const int32_t* tp_ptr, int32_t* tp_idx,
-                                       int32_t* tp_edge, float* tp_angle, int32_t* tp_kind, pamnet_stream_t stream) {
-    if (n_edges < 0) return PAMNET_EINVAL;
+                                       int32_t* tp_edge, float* tp_angle, int32_t* tp_kind, int64_t cap,
+                                       pamnet_stream_t stream) {
+    if (n_edges < 0 || cap < 0) return PAMNET_EINVAL;
     if (n_edges == 0) return PAMNET_OK;
     if (!pos || !lptr || !src || !dst || !tp_ptr || !tp_idx || !tp_edge || !tp_angle || !tp_kind) return PAMNET_ENULL;
     hipLaunchKernelGGL(triplet_fill_kernel, dim3(blocks_for(n_edges)), dim3(256), 0, as_stream(stream), pos, lptr, src,
-                       dst, n_edges, (int)with_triplets, tp_ptr, tp_idx, tp_edge, tp_angle, tp_kind);
+                       dst, n_edges, (int)with_triplets, tp_ptr, tp_idx, tp_edge, tp_angle, tp_kind, cap);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
 
+
+// ---- deferred size check (zero-host-sync graph construction) -----------------------------------------------------------
+// A batch collated from a resident dataset carries its data-dependent sizes (global edges, triplet / pair rows) as host
+// integers summed from per-graph counts taken once per dataset (pamnet_amd/store.py), so graph construction needs no
+// host round trip.  The counts are still recomputed on the device every batch; this launch ORs bit (2 << k) into flag[0]
+// when the k-th recomputed total differs from what the host assumed, and bit 1 << 5 when *all_kept is false (a bond
+// list with self loops, models.py:63).  The host reads the flag whenever it next synchronises for its own reasons.
+namespace {
+struct SizeChecks {
+    const int32_t* actual[4];
+    int64_t expected[4];
+    int n;
+};
+__global__ void check_sizes_kernel(SizeChecks c, const bool* __restrict__ all_kept, int32_t* __restrict__ flag) {
+    int bad = 0;
+    for (int k = 0; k < c.n; ++k)
+        if ((int64_t)c.actual[k][0] != c.expected[k]) bad |= 2 << k;
+    if (all_kept && !all_kept[0]) bad |= 1 << 5;
+    if (bad) atomicOr(flag, bad);
+}
+
+// ---- device-side batch collation -----------------------------------------------------------------------------------------
+// Batch b of a resident dataset: graph k of the batch is dataset graph sel[k]; its nodes / bonds are copied from the
+// dataset's concatenated arrays to the batch's (bonds are stored with graph-local endpoints and get the batch offset of
+// their graph).  One launch: thread t handles output node t and output bond t; the graph of an output row is found by
+// bisection in the batch's node / bond prefix sums (<= 11 probes for 1 024 graphs).
+struct Collate {
+    const int32_t *sel, *out_nptr, *out_eptr;     // [B], [B+1], [B+1]  (device)
+    const int32_t *src_nptr, *src_eptr;           // dataset prefix sums [M+1]
+    const float *x, *pos;                         // dataset node features [Ntot, xw], positions [Ntot, 3] (nullable)
+    const int32_t *esrc, *edst;                   // dataset bonds, graph-local endpoints [Etot] (nullable)
+    float *ox, *opos;
+    int32_t *obatch, *oesrc, *oedst;
+    int64_t B, n_out, e_out, xw;
+};
+__device__ __forceinline__ int graph_of(const int32_t* __restrict__ ptr, int64_t B, int64_t t) {
+    int lo = 0, hi = (int)B;                      // ptr[lo] <= t < ptr[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ptr[mid] <= t) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void collate_kernel(Collate c) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < c.n_out) {
+        const int k = graph_of(c.out_nptr, c.B, t);
+        const int64_t s = c.src_nptr[c.sel[k]] + (t - c.out_nptr[k]);
+        for (int64_t q = 0; q < c.xw; ++q) c.ox[t * c.xw + q] = c.x[s * c.xw + q];
+        if (c.pos) {
+            c.opos[3 * t] = c.pos[3 * s], c.opos[3 * t + 1] = c.pos[3 * s + 1], c.opos[3 * t + 2] = c.pos[3 * s + 2];
+        }
+        c.obatch[t] = k;
+    }
+    if (t < c.e_out) {
+        const int k = graph_of(c.out_eptr, c.B, t);
+        const int64_t s = c.src_eptr[c.sel[k]] + (t - c.out_eptr[k]);
+        const int off = c.out_nptr[k];
+        c.oesrc[t] = c.esrc[s] + off;
+        c.oedst[t] = c.edst[s] + off;
+    }
+}
+}  // namespace
+
+extern "C" int pamnet_check_sizes_i32(int64_t n_checks, const int32_t* const* actual, const int64_t* expected,
+                                      const void* all_kept, int32_t* flag, pamnet_stream_t stream) {
+    if (n_checks < 0 || n_checks > 4) return PAMNET_EINVAL;
+    if (!flag || (n_checks > 0 && (!actual || !expected))) return PAMNET_ENULL;
+    SizeChecks c;
+    c.n = (int)n_checks;
+    for (int k = 0; k < c.n; ++k) {
+        if (!actual[k]) return PAMNET_ENULL;
+        c.actual[k] = actual[k];
+        c.expected[k] = expected[k];
+    }
+    hipLaunchKernelGGL(check_sizes_kernel, dim3(1), dim3(1), 0, as_stream(stream), c, static_cast<const bool*>(all_kept), flag);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_collate_f32(int64_t n_graphs, const int32_t* sel, const int32_t* out_nptr, const int32_t* out_eptr,
+                                  const int32_t* src_nptr, const int32_t* src_eptr, const float* x, int64_t x_width,
+                                  const float* pos, const int32_t* esrc, const int32_t* edst, int64_t n_out,
+                                  int64_t e_out, float* out_x, float* out_pos, int32_t* out_batch, int32_t* out_esrc,
+                                  int32_t* out_edst, pamnet_stream_t stream) {
+    if (n_graphs < 0 || n_out < 0 || e_out < 0 || x_width < 1) return PAMNET_EINVAL;
+    if (n_out == 0 && e_out == 0) return PAMNET_OK;
+    if (!sel || !out_nptr || !src_nptr || !x || !out_x || !out_batch || (pos && !out_pos)) return PAMNET_ENULL;
+    if (e_out > 0 && (!out_eptr || !src_eptr || !esrc || !edst || !out_esrc || !out_edst)) return PAMNET_ENULL;
+    Collate c{sel, out_nptr, out_eptr, src_nptr, src_eptr, x, pos, esrc, edst, out_x, out_pos, out_batch, out_esrc, out_edst,
+              n_graphs, n_out, e_out, x_width};
+    const int64_t total = n_out > e_out ? n_out : e_out;
+    hipLaunchKernelGGL(collate_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), c);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
 
 // ---- input validation ---------------------------------------------------------------------------------------------------
 // One launch instead of a dozen tiny tensor ops per batch: flag[0] = 1 when `node_graph` is not sorted / not in

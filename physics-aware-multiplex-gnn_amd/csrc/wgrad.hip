@@ -53,8 +53,14 @@ inline int64_t rider_rows() {
     static int64_t v = [] { const char* e = getenv("PAMNET_RIDER_ROWS"); return (int64_t)(e ? atoi(e) : 256); }();
     return v;
 }
-inline int64_t plan_chunk(int64_t njobs, const int64_t* rows, int64_t max_slots, int64_t first_chunk = ROWS_PER_WG) {
-    int64_t chunk = first_chunk;
+// smallest chunk a plan may use (scratch is sized for it)
+constexpr int MIN_ROWS_PER_WG = 128;
+inline int64_t first_rows() {
+    static int64_t v = [] { const char* e = getenv("PAMNET_WGRAD_ROWS"); const int k = e ? atoi(e) : ROWS_PER_WG; return (int64_t)(k < MIN_ROWS_PER_WG ? MIN_ROWS_PER_WG : k); }();
+    return v;
+}
+inline int64_t plan_chunk(int64_t njobs, const int64_t* rows, int64_t max_slots, int64_t first_chunk = 0) {
+    int64_t chunk = first_chunk > 0 ? first_chunk : first_rows();
     for (;; chunk += RB) {
         int64_t slots = 0;
         for (int64_t j = 0; j < njobs; ++j) slots += job_slots(rows[j], chunk);
@@ -193,11 +199,11 @@ __global__ __launch_bounds__(WG, 2) void wgrad_fused_wide_kernel(WBatch cur, flo
 
 }  // namespace
 
-// Scratch needed for a batch: sum_j clamp(ceil(rows_j/256), 1, 256) slots of (128*128 + 256) floats.
+// Scratch needed for a batch: sum_j clamp(ceil(rows_j/128), 1, 256) slots of (128*128 + 256) floats.
 extern "C" int pamnet_wgrad_scratch_floats(int64_t njobs, const int64_t* rows, int64_t* floats) {
     if (njobs < 0 || njobs > MAXJ || !floats || (njobs > 0 && !rows)) return PAMNET_EINVAL;
     int64_t slots = 0;
-    for (int64_t j = 0; j < njobs; ++j) slots += job_slots(rows[j], ROWS_PER_WG);       // upper bound for any plan
+    for (int64_t j = 0; j < njobs; ++j) slots += job_slots(rows[j], MIN_ROWS_PER_WG);   // upper bound for any plan
     *floats = slots * (int64_t)(DIM * DIM + 2 * DIM);
     return PAMNET_OK;
 }
@@ -214,7 +220,7 @@ struct WgradPending {
 template <typename Batch>
 inline int build_batch(Batch& b, int64_t njobs, const float* const* dZ, const int64_t* ld_dz, const float* const* A,
                        const int64_t* ld_a, const int32_t* a_mode, const int64_t* rows, float* const* dW,
-                       const int64_t* ld_dw, float* const* db, int64_t max_slots, int64_t first_chunk = ROWS_PER_WG) {
+                       const int64_t* ld_dw, float* const* db, int64_t max_slots, int64_t first_chunk = 0) {
     b.njobs = (int)njobs;
     b.start[0] = 0;
     const int64_t chunk = plan_chunk(njobs, rows, max_slots, first_chunk);

@@ -84,6 +84,7 @@ class _PAMNetBase(nn.Module):
         if envelope_exponent != 5:
             raise ValueError('envelope_exponent=5 is compiled into the kernels')
         self._rna = self.dataset[:3].lower() == 'rna'
+        self.__dict__['_pending_checks'] = []            # device flag words of forwards that ran without a host round trip
 
     def _build_common(self, num_spherical, num_radial, envelope_exponent):
         d = self.dim
@@ -108,10 +109,49 @@ class _PAMNetBase(nn.Module):
         g = G.build_graph(self.dataset, self.cutoff_l, self.cutoff_g, self.flow, data.x, data.batch,
                           getattr(data, 'pos', None), getattr(data, 'edge_index', None), num_graphs=ng,
                           need_grad=torch.is_grad_enabled(), with_triplets=not self.small,
-                          n_types=self.embeddings.size(0) if hasattr(self, 'embeddings') else None)
+                          n_types=self.embeddings.size(0) if hasattr(self, 'embeddings') else None,
+                          sizes=self._sizes_of(data))
+        if g.check is not None:                          # zero-host-sync path: the flag word waits for verify()
+            self._pending_checks.append(g.check)
         g.need_grad = torch.is_grad_enabled()
         g.sbf = self.sbf(g)                              # [T+P, 42]; geometry only, no parameters
         return g
+
+    def _sizes_of(self, data):
+        """Host-side sizes of a batch collated by pamnet_amd.store.MoleculeStore (QM9): (global edges, triplet + pair
+        rows) for THIS model's cutoff / layer kind, or None (sizes are then read back from the device)."""
+        sz = getattr(data, 'sizes', None)
+        if sz is None or self.dataset != 'QM9':
+            return None
+        key = (float(self.cutoff_g), not self.small)
+        if isinstance(sz, dict):
+            return sz.get(key)
+        return sz
+
+    def verify(self, count=None):
+        """Check the device-side flag words of the forwards since the last call that ran without a host round trip
+        (batches carrying `sizes`) -- all of them, or the oldest `count`: one readback.  Raises IndexError (invalid index
+        inputs, as the reference would have) or graph.GraphCheckError (sizes that do not belong to the batch).  Call it
+        wherever the host synchronises anyway -- train.Trainer and train.predict do."""
+        pend = self._pending_checks if count is None else self._pending_checks[:count]
+        if not pend:
+            return
+        self.__dict__['_pending_checks'] = [] if count is None else self._pending_checks[count:]
+        bits = 0
+        if count is not None and pend[0].is_cuda:
+            # the caller knows these forwards have completed (Trainer: the step's event has been waited for): read them on
+            # a stream of their own -- on the current stream the copy would queue behind every step already enqueued and
+            # the host would sit out the whole pipeline
+            st = self.__dict__.get('_check_stream')
+            if st is None:
+                st = self.__dict__['_check_stream'] = torch.cuda.Stream(device=pend[0].device)
+            with torch.cuda.stream(st):
+                vals = torch.stack(pend).reshape(-1).tolist()
+        else:
+            vals = torch.stack(pend).reshape(-1).tolist()
+        for v in vals:
+            bits |= int(v)
+        G.raise_for_flag(bits)
 
     def prepare(self, data, need_grad=True):
         """Parameter-independent part of forward(data): graph construction (models.py:104-177) and the spherical

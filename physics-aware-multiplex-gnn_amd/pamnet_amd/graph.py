@@ -23,6 +23,30 @@ def _f32(n, dev):
     return torch.empty(int(n), dtype=torch.float32, device=dev)
 
 
+class _ZeroArena(object):
+    """Index / geometry buffers of the zero-host-sync path come zero-filled out of ONE allocation (one fill launch):
+    should the size the host assumed turn out too large, the unwritten tails hold valid indices (row 0) and finite
+    values instead of garbage until the deferred check raises."""
+
+    def __init__(self, ints, dev):
+        self.buf = torch.zeros(int(ints) + 64, dtype=I32, device=dev)
+        self.off = 0
+
+    def take(self, n, dtype=I32):
+        n = int(n)
+        v = self.buf[self.off:self.off + n]
+        self.off += (n + 3) // 4 * 4                      # 16-byte aligned slices
+        return v if dtype == I32 else v.view(dtype)
+
+
+def _alloc_i32(n, dev, zeroed):
+    return zeroed.take(n) if zeroed else _i32(n, dev)
+
+
+def _alloc_f32(n, dev, zeroed):
+    return zeroed.take(n, torch.float32) if zeroed else _f32(n, dev)
+
+
 def exclusive_scan(counts):
     n = counts.numel()
     out = _i32(n + 1, counts.device)
@@ -42,10 +66,10 @@ def csr_from_keys(keys, rows):
     return ptr, perm
 
 
-def expand_rows(ptr, total):
+def expand_rows(ptr, total, zeroed=False):
     rows = ptr.numel() - 1
-    out = _i32(total, ptr.device)
-    lib.call('pamnet_expand_rows_i32', lib.ptr(ptr), rows, lib.ptr(out), lib.stream_of(ptr))
+    out = _alloc_i32(total, ptr.device, zeroed)
+    lib.call('pamnet_expand_rows_i32', lib.ptr(ptr), rows, lib.ptr(out), int(total), lib.stream_of(ptr))
     return out
 
 
@@ -159,10 +183,11 @@ def radius_count(pos, node_graph, gptr, r):
     return exclusive_scan(count)
 
 
-def radius_fill(pos, node_graph, gptr, r, ptr, total):
-    nbr, dist = _i32(total, pos.device), _f32(total, pos.device)
+def radius_fill(pos, node_graph, gptr, r, ptr, total, zeroed=False):
+    nbr = _alloc_i32(total, pos.device, zeroed)
+    dist = _alloc_f32(total, pos.device, zeroed)
     lib.call('pamnet_radius_fill_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), pos.size(0), float(r), lib.ptr(ptr),
-             lib.ptr(nbr), lib.ptr(dist), lib.stream_of(pos))
+             lib.ptr(nbr), lib.ptr(dist), int(total), lib.stream_of(pos))
     return ptr, nbr, dist
 
 
@@ -217,14 +242,47 @@ def _input_flag(node_graph, n_graphs, types=None, n_types=None, src=None, dst=No
     return flag
 
 
+def _check_sizes(flag, checks, all_kept=None):
+    """One launch: OR the size-mismatch bits into the validity flag word (pamnet_check_sizes_i32)."""
+    import ctypes
+    n = len(checks)
+    actual = (ctypes.c_void_p * n)(*[lib.ptr(t) for t, _ in checks])
+    expected = (ctypes.c_int64 * n)(*[int(v) for _, v in checks])
+    lib.call('pamnet_check_sizes_i32', n, actual, expected, None if all_kept is None else lib.ptr(all_kept), lib.ptr(flag),
+             lib.stream_of(flag))
+
+
 def _raise_bad_inputs():
     raise IndexError('index out of range in the batch handed to PAMNet.forward: `batch` must be sorted with ids in '
                      '[0, num_graphs), atom types in [0, embeddings.size(0)), edge_index in [0, num_nodes)')
 
 
+class GraphCheckError(IndexError):
+    pass
+
+
+def raise_for_flag(bits):
+    """Raise for a non-zero flag word of a prepared graph (bit 1: invalid index inputs; the rest: the sizes the host
+    assumed in the zero-host-sync path were wrong)."""
+    if bits & 1:
+        _raise_bad_inputs()
+    if bits:
+        what = [n for k, n in ((1, 'global edges'), (2, 'triplet / pair rows'), (3, 'size 3'), (4, 'size 4')) if bits & (2 << k - 1)]
+        if bits & 32:
+            what.append('self loops in edge_index')
+        raise GraphCheckError('the data-dependent sizes handed to PAMNet.forward (`data.sizes`) do not match the batch: '
+                              + ', '.join(what) + ' -- results of this batch are invalid')
+
+
 def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_index=None, num_graphs=None,
-                need_grad=True, knn_k=50, with_triplets=True, n_types=None):
-    """Graph-construction part of PAMNet.forward (models.py:104-177).  Returns a Graph."""
+                need_grad=True, knn_k=50, with_triplets=True, n_types=None, sizes=None):
+    """Graph-construction part of PAMNet.forward (models.py:104-177).  Returns a Graph.
+
+    `sizes` (QM9 only): (global edges, triplet + pair rows) of this batch as host integers -- what a batch collated by
+    pamnet_amd.store.MoleculeStore carries.  With them no value is read back from the device: buffers are sized from
+    the host numbers, the fills are capped by them, and one launch compares them with the device-side counts (and
+    folds in the input-validity flag); the result waits in `g.check` (an int32 device scalar) for the caller's next
+    synchronisation (PAMNet.verify).  Without them: one host round trip for the sizes and the flag."""
     dev = batch.device
     g = Graph()
     n = int(batch.numel())
@@ -235,7 +293,11 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     g.gptr, _ = csr_from_keys(node_graph, g.n_graphs)
     rna = dataset[:3].lower() == 'rna'
     g.sign = None
+    g.check = None                                # device flag word of the zero-host-sync path (see `sizes`)
     tp_pre = None
+    hinted = False
+    if sizes is not None and dataset != 'QM9':
+        raise ValueError('`sizes` is implemented for the QM9 path only')
 
     if dataset == 'QM9':
         pos = pos.to(torch.float32).contiguous()
@@ -256,14 +318,24 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         lp, l_src, l_dst, tp_ptr = bonds(ei)
         gptr_g = radius_count(pos, node_graph, g.gptr, cutoff_g)               # symmetric: agg = query, other = nbr
         types = x_raw.to(torch.float32).reshape(-1)
-        total_g, all_kept, tp_total, bad = host_ints(gptr_g[-1], keep.all(), tp_ptr[-1],
-                                                     _input_flag(node_graph, g.n_graphs, types, n_types, *bonds.raw))
-        if bad:
-            _raise_bad_inputs()
-        if not all_kept:
-            lp, l_src, l_dst, tp_ptr = bonds(ei[:, keep])
-            tp_total = int(tp_ptr[-1])
-        gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g)
+        flag = _input_flag(node_graph, g.n_graphs, types, n_types, *bonds.raw)
+        if sizes is not None:                     # zero host round trips: sizes from the host, verified on the device
+            total_g, tp_total = int(sizes[0]), int(sizes[1])
+            _check_sizes(flag, [(gptr_g[-1:], total_g), (tp_ptr[-1:], tp_total)], keep.all())
+            g.check = flag
+            hinted = _ZeroArena(3 * total_g + 4 * tp_total + 64, dev)
+            # the CSR pointers are capped at what the buffers hold: with sizes that turn out too small every kernel that
+            # walks a pointer still stays inside its arrays (results of such a batch are invalid and flagged)
+            gptr_g = torch.clamp(gptr_g, max=total_g)
+            tp_ptr = torch.clamp(tp_ptr, max=tp_total)
+        else:
+            total_g, all_kept, tp_total, bad = host_ints(gptr_g[-1], keep.all(), tp_ptr[-1], flag)
+            if bad:
+                _raise_bad_inputs()
+            if not all_kept:
+                lp, l_src, l_dst, tp_ptr = bonds(ei[:, keep])
+                tp_total = int(tp_ptr[-1])
+        gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g, zeroed=hinted)
         l_dist = edge_dist(pos, l_dst, l_src)
         tp_pre = (tp_ptr, tp_total)
     elif dataset == 'PDBbind':
@@ -289,7 +361,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
                          "be sure to use 'rna' as the first 3 characters of the dataset name.")
 
     g.pos = pos
-    g.glob = CSR(gp, expand_rows(gp, gn.numel()), gn)
+    g.glob = CSR(gp, expand_rows(gp, gn.numel(), zeroed=hinted), gn)
     g.dist_g = gd
     g.loc = CSR(lp, l_dst, l_src)
     g.dist_l = l_dist
@@ -303,9 +375,10 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         tot = int(tp_ptr[-1])
     else:
         tp_ptr, tot = tp_pre
-    tp_idx, tp_edge, tp_angle, tp_kind = _i32(tot, dev), _i32(tot, dev), _f32(tot, dev), _i32(tot, dev)
+    tp_idx, tp_edge, tp_kind = (_alloc_i32(tot, dev, hinted) for _ in range(3))
+    tp_angle = _alloc_f32(tot, dev, hinted)
     lib.call('pamnet_triplet_fill_f32', lib.ptr(pos), lib.ptr(lp), lib.ptr(l_src), lib.ptr(l_dst), e_l, wt,
-             lib.ptr(tp_ptr), lib.ptr(tp_idx), lib.ptr(tp_edge), lib.ptr(tp_angle), lib.ptr(tp_kind), st)
+             lib.ptr(tp_ptr), lib.ptr(tp_idx), lib.ptr(tp_edge), lib.ptr(tp_angle), lib.ptr(tp_kind), tot, st)
     g.tp = CSR(tp_ptr, tp_edge, tp_idx)               # rows = target edge e, col = source edge e'
     g.tp_angle, g.tp_kind = tp_angle, tp_kind
 

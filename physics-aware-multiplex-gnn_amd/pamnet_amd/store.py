@@ -1,0 +1,146 @@
+"""Resident dataset + device-side batch collation ("device-side batch collation + graph construction
+with zero host syncs").
+
+The reference's loop builds every batch on the host (PyG `DataLoader` / `Batch.from_data_list`, main_qm9.py:74-77) and
+its forward reads data-dependent sizes back from the device (boolean masks, `repeat_interleave`: models.py:62-98).  With
+288 GB of HBM the whole dataset stays on the device (QM9: 134 k molecules, ~60 MB), a batch is ONE gather launch over
+the concatenated arrays (`pamnet_collate_f32`), and the sizes graph construction needs are per-molecule constants --
+the number of atom pairs within the global cutoff, the number of triplet / pair rows of the bond graph -- counted once
+per dataset on the device (with the same kernels the forward uses) and summed on the host per batch.  A collated batch
+carries them as `batch.sizes`; PAMNet.forward then needs no host round trip at all, and the kernels' own counts are
+checked against them on the device (`PAMNet.verify`, called by `Trainer` / `train.predict` when they synchronise
+anyway).  The graph itself is still rebuilt every forward from positions and bonds, as models.py:104-177 does: only
+integers are cached, no structure.
+"""
+import numpy as np
+import torch
+
+from . import graph as G
+from . import lib
+
+I32 = torch.int32
+
+
+class Batch(object):
+    """Duck-typed `data` of PAMNet.forward: x, pos, edge_index ([2, E] int32), batch (int32), y, num_graphs, sizes."""
+
+    def __init__(self):
+        self._pamnet_prepared = None
+        self.sizes = None
+
+    def to(self, device):
+        return self
+
+
+class MoleculeStore(object):
+    """QM9-schema dataset resident on one device.
+
+    data_list: objects with x [n] (atom types, any numeric dtype), pos [n, 3], edge_index [2, e] (node ids local to the
+    molecule, both directions present as in qm9_dataset.py:243) and optionally y (scalar target)."""
+
+    def __init__(self, data_list, device):
+        self.device = torch.device(device)
+
+        class _View(object):                                   # dicts (pamnet_amd.synth) and attribute objects (PyG Data) alike
+            def __init__(self, d):
+                get = d.get if isinstance(d, dict) else (lambda k, default=None: getattr(d, k, default))
+                self.x, self.pos, self.edge_index, self.y = get('x'), get('pos'), get('edge_index'), get('y', None)
+
+        data_list = [_View(d) for d in data_list]
+        n = np.array([int(d.x.shape[0]) for d in data_list], dtype=np.int64)
+        e = np.array([int(d.edge_index.shape[1]) for d in data_list], dtype=np.int64)
+        self.n_nodes, self.n_edges = n, e                      # host copies: the batch sizes are sums of these
+        self.nptr = np.concatenate([[0], np.cumsum(n)])
+        self.eptr = np.concatenate([[0], np.cumsum(e)])
+        dev = self.device
+        cat = lambda ts, dt: torch.cat([torch.as_tensor(t).reshape(-1, *torch.as_tensor(t).shape[1:]) for t in ts]).to(dt)
+        self.x = cat([d.x for d in data_list], torch.float32).reshape(-1).contiguous().to(dev)
+        self.pos = cat([d.pos for d in data_list], torch.float32).contiguous().to(dev)
+        ei = torch.cat([torch.as_tensor(d.edge_index).to(torch.int64) for d in data_list], dim=1)
+        self.esrc = ei[0].to(I32).contiguous().to(dev)         # graph-local endpoints
+        self.edst = ei[1].to(I32).contiguous().to(dev)
+        ys = [getattr(d, 'y', None) for d in data_list]
+        self.y = None if any(v is None for v in ys) else torch.as_tensor(
+            np.array([float(torch.as_tensor(v).reshape(-1)[0]) for v in ys], dtype=np.float32)).to(dev)
+        self.nptr_d = torch.from_numpy(self.nptr.astype(np.int32)).to(dev)
+        self.eptr_d = torch.from_numpy(self.eptr.astype(np.int32)).to(dev)
+        self._counts = {}                                      # (cutoff_g, with_triplets) -> (E_g per molecule, T+P per molecule)
+
+    def __len__(self):
+        return len(self.n_nodes)
+
+    # -------------------------------------------------------------------------------------------------- per-molecule sizes
+    def counts_for(self, cutoff_g, with_triplets=True, chunk=4096):
+        """Per-molecule (global edges, triplet + pair rows) for a model with this global cutoff / layer kind: counted on
+        the device by the forward's own kernels, `chunk` molecules per pass, read back ONCE per dataset."""
+        key = (float(cutoff_g), bool(with_triplets))
+        if key in self._counts:
+            return self._counts[key]
+        m = len(self)
+        eg, tp = np.zeros(m, dtype=np.int64), np.zeros(m, dtype=np.int64)
+        for a in range(0, m, chunk):
+            b = min(m, a + chunk)
+            idx = np.arange(a, b)
+            bt = self.collate(idx, with_sizes=False)
+            node_graph = bt.batch
+            nb = b - a
+            gptr, _ = G.csr_from_keys(node_graph, nb)
+            ptr_g = G.radius_count(bt.pos, node_graph, gptr, cutoff_g)                    # [N + 1]
+            dst = bt.edge_index[1].contiguous()
+            lp, perm = G.csr_from_keys(dst, int(node_graph.numel()))
+            pl = perm.long()
+            src_s, dst_s = bt.edge_index[0][pl].contiguous(), dst[pl].contiguous()
+            tp_ptr = G._triplet_ptr(lp, src_s, dst_s, with_triplets)                       # [E_l + 1]
+            nodes = torch.from_numpy((self.nptr[a:b + 1] - self.nptr[a]).astype(np.int64)).to(self.device)
+            pg = ptr_g.long()[nodes]
+            pt = tp_ptr.long()[lp.long()[nodes]]           # bonds are CSR-sorted by target: a molecule's are contiguous
+            eg[a:b] = (pg[1:] - pg[:-1]).cpu().numpy()
+            tp[a:b] = (pt[1:] - pt[:-1]).cpu().numpy()
+        self._counts[key] = (eg, tp)
+        return eg, tp
+
+    def prepare_for(self, *models):
+        """Count the sizes the given models' forwards need (one device pass per distinct cutoff / layer kind)."""
+        for mdl in models:
+            self.counts_for(mdl.cutoff_g, not mdl.small)
+        return self
+
+    # ------------------------------------------------------------------------------------------------------- collation
+    def collate(self, idx, with_sizes=True):
+        """Batch of the molecules `idx` (host integers, any order): one gather launch on the device, no host sync.  The
+        prefix sums of the batch are computed on the host from the per-molecule counts and travel with `idx` in one
+        small asynchronous copy."""
+        idx = np.asarray(idx, dtype=np.int64)
+        b = int(idx.size)
+        nn, ne = self.n_nodes[idx], self.n_edges[idx]
+        n_out, e_out = int(nn.sum()), int(ne.sum())
+        # pinned staging: the upload is a true asynchronous copy (from pageable memory the runtime parks the host
+        # behind everything already queued on the stream -- the whole previous step)
+        meta_h = torch.empty(3 * b + 2, dtype=I32, pin_memory=True)
+        meta = meta_h.numpy()
+        meta[:b] = idx
+        meta[b] = 0
+        np.cumsum(nn, out=meta[b + 1:2 * b + 1])
+        meta[2 * b + 1] = 0
+        np.cumsum(ne, out=meta[2 * b + 2:3 * b + 2])
+        dev = self.device
+        meta_d = meta_h.to(dev, non_blocking=True)
+        sel, out_nptr, out_eptr = meta_d[:b], meta_d[b:2 * b + 1], meta_d[2 * b + 1:]
+        bt = Batch()
+        bt.x = torch.empty(n_out, dtype=torch.float32, device=dev)
+        bt.pos = torch.empty((n_out, 3), dtype=torch.float32, device=dev)
+        bt.batch = torch.empty(n_out, dtype=I32, device=dev)
+        bt.edge_index = torch.empty((2, e_out), dtype=I32, device=dev)
+        lib.call('pamnet_collate_f32', b, lib.ptr(sel), lib.ptr(out_nptr), lib.ptr(out_eptr), lib.ptr(self.nptr_d),
+                 lib.ptr(self.eptr_d), lib.ptr(self.x), 1, lib.ptr(self.pos), lib.ptr(self.esrc), lib.ptr(self.edst), n_out,
+                 e_out, lib.ptr(bt.x), lib.ptr(bt.pos), lib.ptr(bt.batch), bt.edge_index.data_ptr(),
+                 bt.edge_index.data_ptr() + 4 * e_out, lib.stream_of(bt.x))
+        bt.num_graphs = b
+        bt.y = None if self.y is None else self.y.index_select(0, sel.long())
+        # the batch is produced by work queued on this stream: a consumer on another stream (the input pipeline's side
+        # stream, train.Prefetcher) waits for exactly this event
+        bt.inputs_ready = torch.cuda.Event()
+        bt.inputs_ready.record(torch.cuda.current_stream(dev))
+        if with_sizes:
+            bt.sizes = {key: (int(eg[idx].sum()), int(tp[idx].sum())) for key, (eg, tp) in self._counts.items()}
+        return bt

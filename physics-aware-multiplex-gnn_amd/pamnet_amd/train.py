@@ -374,10 +374,14 @@ class Trainer(object):
             return
         q = self.__dict__.setdefault('_inflight', [])
         if len(q) >= self.MAX_STEPS_IN_FLIGHT:
-            q.pop(0).synchronize()
+            ev, n_checks = q.pop(0)
+            ev.synchronize()
+            if n_checks:                                       # flag words of forwards that have completed by now:
+                self.model.verify(n_checks)                    # reading them does not stall the queue
+                q[:] = [(e, max(0, c - n_checks)) for e, c in q]
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.fp.flat.device))
-        q.append(ev)
+        q.append((ev, len(getattr(self.model, '_pending_checks', None) or ())))
 
     # -- input pipelining -----------------------------------------------------------------------------------------------
     def prefetch(self, data):
@@ -413,7 +417,10 @@ class Trainer(object):
         self.ema_resume()
         if self.world_size > 1:
             dist.all_reduce(tot, group=self.pg)
-        return float(tot[0] / tot[1])
+        res = float(tot[0] / tot[1])
+        if hasattr(self.model, 'verify'):
+            self.model.verify()
+        return res
 
 
 @torch.no_grad()
@@ -441,6 +448,8 @@ def predict(model, batches):
         cur = nxt
     if pf is not None and pf.pool is not None:
         pf.pool.shutdown(wait=True)
+    if hasattr(model, 'verify'):
+        model.verify()            # batches that carried their sizes (store.MoleculeStore) ran without a host round trip
 
 
 def _wait_inputs(stream, data):
@@ -448,6 +457,10 @@ def _wait_inputs(stream, data):
     ev = getattr(data, 'inputs_ready', None)
     if ev is not None:
         stream.wait_event(ev)
+        for k in ('x', 'pos', 'edge_index', 'batch'):       # allocated on the producer's stream, read on this one
+            t = getattr(data, k, None)
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(stream)
 
 
 def _graph_tensors(g):

@@ -1,0 +1,140 @@
+"""Resident dataset, device-side collation and the zero-host-sync forward (pamnet_amd/store.py).
+GPU tests: the collated batch equals the host-side collation bit for bit; the per-molecule size table equals what graph
+construction finds; a forward on a batch that carries its sizes issues no synchronising call (torch's sync debug mode set
+to 'error') and returns bitwise what the plain forward returns; sizes that do not belong to the batch -- too small or too
+large -- are caught by the deferred device-side check without touching memory out of bounds."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'needs an MI355X'
+    from pamnet_amd import lib
+    lib.load()
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def store(dev):
+    from pamnet_amd import store as S, synth
+    mols = [synth.qm9_molecule(3, i) for i in range(300)]
+    return S.MoleculeStore(mols, dev), mols
+
+
+def _model(dev, small=False, dim=128, n_layer=2, cutoff_g=5.0):
+    from models import Config, PAMNet, PAMNet_s
+    torch.manual_seed(0)
+    cls = PAMNet_s if small else PAMNet
+    return cls(Config(dataset='QM9', dim=dim, n_layer=n_layer, cutoff_l=5.0, cutoff_g=cutoff_g)).to(dev)
+
+
+def test_collate_matches_host_collation(dev, store):
+    from pamnet_amd import synth
+    st, mols = store
+    idx = [17, 3, 250, 3, 0, 299, 120]                       # any order, repeats allowed
+    b = st.collate(idx, with_sizes=False)
+    ref = synth.collate([mols[i] for i in idx])
+    assert torch.equal(b.x.cpu(), ref.x.float()) and torch.equal(b.pos.cpu(), ref.pos)
+    assert torch.equal(b.batch.cpu().long(), ref.batch) and torch.equal(b.edge_index.cpu().long(), ref.edge_index)
+    assert torch.equal(b.y.cpu(), ref.y) and b.num_graphs == len(idx)
+
+
+@pytest.mark.parametrize('small', [False, True])
+def test_size_table_matches_graph_construction(dev, store, small):
+    from pamnet_amd import graph as G
+    st, _ = store
+    eg, tp = st.counts_for(5.0, with_triplets=not small, chunk=128)      # several passes
+    assert eg.shape == (300,) and (eg > 0).all() and (tp > 0).all()
+    for idx in ([5], [1, 2, 3], list(range(40, 168))):
+        b = st.collate(idx, with_sizes=False)
+        g = G.build_graph('QM9', 5.0, 5.0, 'source_to_target', b.x, b.batch, b.pos, b.edge_index, num_graphs=len(idx),
+                          need_grad=False, with_triplets=not small, n_types=5)
+        assert g.glob.m == int(eg[idx].sum()) and g.tp.m == int(tp[idx].sum())
+
+
+@pytest.mark.parametrize('small', [False, True])
+def test_forward_without_host_sync(dev, store, small):
+    st, _ = store
+    model = _model(dev, small)
+    st.prepare_for(model)
+    idx = list(range(100, 228))
+    with torch.no_grad():
+        ref = model(st.collate(idx, with_sizes=False))           # sizes read back from the device
+        model(st.collate(idx))                                   # warm every cache the first hinted call fills
+        torch.cuda.synchronize()
+        b = st.collate(idx)
+        assert b.sizes
+        torch.cuda.set_sync_debug_mode('error')                  # any synchronising torch call raises from here on
+        try:
+            out = model(b)
+        finally:
+            torch.cuda.set_sync_debug_mode('default')
+    model.verify()                                               # clean flag words
+    assert torch.equal(out, ref)
+    # training forward + backward, same property
+    b = st.collate(idx)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        loss = (model(b) - b.y).abs().mean()
+        loss.backward()
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    model.verify()
+    assert torch.isfinite(loss)
+
+
+def test_wrong_sizes_are_caught(dev, store):
+    from pamnet_amd.graph import GraphCheckError
+    st, _ = store
+    model = _model(dev)
+    st.prepare_for(model)
+    idx = list(range(64))
+    key = (5.0, True)
+    for d_eg, d_tp in ((-7, 0), (+9, 0), (0, -5), (0, +11)):
+        b = st.collate(idx)
+        eg, tp = b.sizes[key]
+        b.sizes = {key: (eg + d_eg, tp + d_tp)}
+        with torch.no_grad():
+            out = model(b)                                       # runs to completion, memory-safe, result invalid
+        assert out.shape == (64,)
+        with pytest.raises(GraphCheckError):
+            model.verify()
+        model.verify()                                           # the pending list is cleared by the raise
+    # invalid index inputs surface through the same deferred check, as the reference's IndexError
+    b = st.collate(idx)
+    b.x = b.x.clone()
+    b.x[3] = 7.0
+    with torch.no_grad():
+        model(b)
+    with pytest.raises(IndexError):
+        model.verify()
+
+
+def test_trainer_and_predict_verify(dev, store):
+    """Trainer.step on store batches: no host round trip in the steady state; a bad batch raises a few steps later."""
+    from pamnet_amd import train
+    from pamnet_amd.graph import GraphCheckError
+    st, _ = store
+    model = _model(dev, n_layer=1)
+    st.prepare_for(model)
+    tr = train.Trainer(model, lr=1e-4)
+    batches = [st.collate(list(range(k * 32, k * 32 + 32))) for k in range(6)]
+    losses = [tr.step(batches[k], next_data=batches[k + 1] if k + 1 < 6 else None) for k in range(6)]
+    torch.cuda.synchronize()
+    model.verify()
+    assert all(torch.isfinite(l) for l in losses)
+    outs = [o for _, o in train.predict(model, [st.collate(list(range(k * 50, k * 50 + 50))) for k in range(4)])]
+    assert len(outs) == 4
+    bad = st.collate(list(range(32)))
+    key = next(iter(bad.sizes))
+    bad.sizes = {key: (bad.sizes[key][0] - 3, bad.sizes[key][1])}
+    with pytest.raises(GraphCheckError):
+        for k in range(5):
+            tr.step(bad if k == 0 else st.collate(list(range(32))))
+        torch.cuda.synchronize()
+        model.verify()
