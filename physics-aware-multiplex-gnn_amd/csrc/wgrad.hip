@@ -68,9 +68,17 @@ inline int64_t plan_chunk(int64_t njobs, const int64_t* rows, int64_t max_slots,
     }
 }
 
-__global__ __launch_bounds__(WG, 2) void wgrad_kernel(WBatch batch, float* __restrict__ partial) {
+// Slot workgroups: 4 waves, one per SIMD (256 registers each), so that a second workgroup -- the small reductions of the
+// fused launches -- shares the CU.  PAMNET_WGRAD_NW=8 builds the two-waves-per-SIMD form: measured no faster per slot (an
+// MFMA in flight blocks the VALU issue of BOTH waves of its SIMD: the block time is the sum of all instructions either
+// way, 3 880 vs 3 950 cycles) and slower per launch (46.9 vs 31.7 us: the reductions no longer fit beside the slots).
+#ifndef PAMNET_WGRAD_NW
+#define PAMNET_WGRAD_NW 4
+#endif
+constexpr int SNW = PAMNET_WGRAD_NW, SWG = 64 * SNW;
+__global__ __launch_bounds__(SWG, 2) void wgrad_kernel(WBatch batch, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float lds[WGRAD_LDS_FLOATS];
-    wgrad_body<4>(batch, partial, (int)blockIdx.x, lds);
+    wgrad_body<SNW>(batch, partial, (int)blockIdx.x, lds);
 }
 
 // Second pass, ONE launch per batch (grid 258 x (njobs + 1)), every sum in a fixed order (deterministic):
@@ -165,16 +173,17 @@ __global__ __launch_bounds__(WG) void wgrad_finish_kernel(WBatch batch, const fl
 // workgroups fill in beside the current pass.  Compact batches (<= 16 jobs): the three descriptors share the 4 KB
 // kernel-argument block.
 constexpr int FIN_X = DIM * DIM / 64 + 2;
-__global__ __launch_bounds__(WG, 2) void wgrad_fused_kernel(WBatchS cur, float* __restrict__ cur_partial, WBatchS prev,
+__global__ __launch_bounds__(SWG, 2) void wgrad_fused_kernel(WBatchS cur, float* __restrict__ cur_partial, WBatchS prev,
                                                          const float* __restrict__ prev_partial, HeadJob prev_head,
                                                          WBatchS prev2, const float* __restrict__ prev2_partial) {
     __shared__ __attribute__((aligned(16))) float lds[WGRAD_LDS_FLOATS];
     const int slots = cur.start[cur.njobs];
     int fb = (int)blockIdx.x - slots;
     if (fb < 0) {
-        wgrad_body<4>(cur, cur_partial, (int)blockIdx.x, lds);
+        wgrad_body<SNW>(cur, cur_partial, (int)blockIdx.x, lds);
         return;
     }
+    if (threadIdx.x >= WG) return;                             // the reductions are 4-wave workgroups
     const int fin1 = prev_partial ? FIN_X * (prev.njobs + 1) : 0;
     if (fb < fin1) {
         finish_body(prev, prev_partial, prev_head, fb % FIN_X, fb / FIN_X, lds);
@@ -185,13 +194,14 @@ __global__ __launch_bounds__(WG, 2) void wgrad_fused_kernel(WBatchS cur, float* 
 }
 
 // the same with one earlier batch and wide descriptors (up to 24 jobs each): no rider batch pending
-__global__ __launch_bounds__(WG, 2) void wgrad_fused_wide_kernel(WBatch cur, float* __restrict__ cur_partial, WBatch prev,
+__global__ __launch_bounds__(SWG, 2) void wgrad_fused_wide_kernel(WBatch cur, float* __restrict__ cur_partial, WBatch prev,
                                                               const float* __restrict__ prev_partial, HeadJob prev_head) {
     __shared__ __attribute__((aligned(16))) float lds[WGRAD_LDS_FLOATS];
     const int slots = cur.start[cur.njobs];
     if ((int)blockIdx.x < slots) {
-        wgrad_body<4>(cur, cur_partial, (int)blockIdx.x, lds);
+        wgrad_body<SNW>(cur, cur_partial, (int)blockIdx.x, lds);
     } else {
+        if (threadIdx.x >= WG) return;
         const int fb = (int)blockIdx.x - slots;
         finish_body(prev, prev_partial, prev_head, fb % FIN_X, fb / FIN_X, lds);
     }
@@ -262,7 +272,7 @@ extern "C" int pamnet_wgrad_batched_f32(int64_t njobs, const float* const* dZ, c
     const int rc = build_batch(b, njobs, dZ, ld_dz, A, ld_a, a_mode, rows, dW, ld_dw, db, target_slots());
     if (rc) return rc;
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)b.start[njobs]), dim3(WG), 0, st, b, partial);
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)b.start[njobs]), dim3(SWG), 0, st, b, partial);
     PAMNET_LAUNCH_CHECK();
     const HeadJob head{head_partial, (int)head_blocks, d_wout, d_watt, d_bout};
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3(FIN_X, (unsigned)njobs + 1), dim3(WG), 0, st, b, partial, head);
@@ -311,7 +321,7 @@ extern "C" int pamnet_wgrad_deferred_f32(int64_t njobs, const float* const* dZ, 
                       (!pend->valid[1] || pend->batch[1].njobs <= MAXJ_S);
     if (pend->valid[0] && !pend->valid[1]) {                   // one earlier batch: wide descriptors
         const unsigned grid = (unsigned)b.start[njobs] + (unsigned)(FIN_X * (pend->batch[0].njobs + 1));
-        hipLaunchKernelGGL(wgrad_fused_wide_kernel, dim3(grid), dim3(WG), 0, st, b, partial, pend->batch[0], pend->partial[0],
+        hipLaunchKernelGGL(wgrad_fused_wide_kernel, dim3(grid), dim3(SWG), 0, st, b, partial, pend->batch[0], pend->partial[0],
                            pend->head);
         PAMNET_LAUNCH_CHECK();
         pend->valid[0] = 0;
@@ -322,7 +332,7 @@ extern "C" int pamnet_wgrad_deferred_f32(int64_t njobs, const float* const* dZ, 
         const WBatchS p1 = pend->valid[1] ? compact(pend->batch[1]) : none;
         const unsigned fin = (pend->valid[0] ? FIN_X * (p0.njobs + 1) : 0) + (pend->valid[1] ? FIN_X * (p1.njobs + 1) : 0);
         const HeadJob nohead{nullptr, 0, nullptr, nullptr, nullptr};
-        hipLaunchKernelGGL(wgrad_fused_kernel, dim3((unsigned)b.start[njobs] + fin), dim3(WG), 0, st, compact(b), partial, p0,
+        hipLaunchKernelGGL(wgrad_fused_kernel, dim3((unsigned)b.start[njobs] + fin), dim3(SWG), 0, st, compact(b), partial, p0,
                            pend->valid[0] ? pend->partial[0] : nullptr, pend->valid[0] ? pend->head : nohead, p1,
                            pend->valid[1] ? pend->partial[1] : nullptr);
         PAMNET_LAUNCH_CHECK();
@@ -332,7 +342,7 @@ extern "C" int pamnet_wgrad_deferred_f32(int64_t njobs, const float* const* dZ, 
             const int frc = finish_pending(pend, st);
             if (frc) return frc;
         }
-        hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)b.start[njobs]), dim3(WG), 0, st, b, partial);
+        hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)b.start[njobs]), dim3(SWG), 0, st, b, partial);
         PAMNET_LAUNCH_CHECK();
     }
     pend->batch[0] = b;
