@@ -68,14 +68,14 @@ inline int64_t plan_chunk(int64_t njobs, const int64_t* rows, int64_t max_slots,
     }
 }
 
-// Slot workgroups: 4 waves, one per SIMD (256 registers each), so that a second workgroup -- the small reductions of the
-// fused launches -- shares the CU.  PAMNET_WGRAD_NW=8 builds the two-waves-per-SIMD form: measured no faster per slot (an
-// MFMA in flight blocks the VALU issue of BOTH waves of its SIMD: the block time is the sum of all instructions either
-// way, 3 880 vs 3 950 cycles) and slower per launch (46.9 vs 31.7 us: the reductions no longer fit beside the slots).
-#ifndef PAMNET_WGRAD_NW
-#define PAMNET_WGRAD_NW 4
-#endif
-constexpr int SNW = PAMNET_WGRAD_NW, SWG = 64 * SNW;
+// Slot workgroups: 4 waves, one per SIMD, <= 256 registers each, so that a second workgroup -- the small reductions of the
+// fused launches -- shares the CU.  An 8-wave form in which every thread stages (two waves per SIMD) was measured and
+// dropped: no faster per slot -- an MFMA in flight blocks the VALU issue of BOTH waves of its SIMD, the block time is the
+// sum of all instructions either way (3 880 vs 3 950 cycles per 32 rows) -- and slower per launch (46.9 vs 31.7 us: with
+// 8 x 256 registers resident the reductions no longer fit beside the slots).  The allocation sits right at 256: small
+// changes to the body tip it into spilling (142 spilled registers doubled the launch to 62 us) -- check
+// -Rpass-analysis=kernel-resource-usage after touching wgrad_core.h.
+constexpr int SNW = 4, SWG = 64 * SNW;
 __global__ __launch_bounds__(SWG, 2) void wgrad_kernel(WBatch batch, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float lds[WGRAD_LDS_FLOATS];
     wgrad_body<SNW>(batch, partial, (int)blockIdx.x, lds);

@@ -52,7 +52,7 @@ constexpr int RB = 64;            // slot chunks are multiples of this many rows
 constexpr int KB = 32;            // rows per block = one k-step of v_mfma_f32_16x16x32_bf16
 constexpr int TILE_B = 1024 + 64; // bytes per fragment image (+ 64: consecutive images start 16 banks apart)
 constexpr int PLANES_B = 2 * 3 * 8 * TILE_B;                       // {dZ, A} x 3 pieces x 8 column tiles = 52 224 bytes
-constexpr int WGRAD_LDS_FLOATS = DIM * LDT + 8 * DIM;              // the epilogue's transposed tile + bias parts (71 680 B)
+constexpr int WGRAD_LDS_FLOATS = DIM * LDT + 4 * DIM;              // the epilogue's transposed tile + bias parts (69 632 B)
 static_assert(WGRAD_LDS_FLOATS * 4 >= PLANES_B, "the fragment images alias the epilogue tile");
 
 // zero rows for the ragged end of a job: out-of-range rows are read from here instead of being masked after the load
@@ -92,58 +92,51 @@ __device__ __forceinline__ void f4set(float4& v, int e, float x) {
     else v.w = x;
 }
 
-// Staging roles of a wave (uniform): what it does with its RT rows x 4 columns between the MFMAs of a block.
+// Staging roles of a wave (uniform): what it does with its 8 rows x 4 columns between the MFMAs of a block.
 constexpr int ROLE_NONE = 0, ROLE_DZ = 1, ROLE_A = 2, ROLE_A_SILU = 3;
 // Units per column e of the thread's float4 columns, in order:
-//   ROLE_A_SILU: RT x SiLU of one value;  all: RT / 2 row pairs x 3 split stages;  ROLE_DZ: the column's bias sum;
-//   all: 3 stores (one per piece: the thread's RT consecutive rows of the column = 2 RT bytes)
-// RT = 8 rows per thread in a 4-wave workgroup, 4 in an 8-wave one: every thread stages.
-template <int ROLE, int RT>
+//   ROLE_A_SILU: 8 x SiLU of one value;  all: 4 row pairs x 3 split stages;  ROLE_DZ: the column's bias sum;
+//   all: 3 x 16-byte store (one per piece)
+template <int ROLE>
 struct Units {
-    static constexpr int silu = ROLE == ROLE_A_SILU ? RT : 0, bias = ROLE == ROLE_DZ ? 1 : 0, split = 3 * (RT / 2);
-    static constexpr int per_col = silu + split + bias + 3, total = ROLE == ROLE_NONE ? 0 : 4 * per_col;
+    static constexpr int silu = ROLE == ROLE_A_SILU ? 8 : 0, bias = ROLE == ROLE_DZ ? 1 : 0;
+    static constexpr int per_col = silu + 12 + bias + 3, total = ROLE == ROLE_NONE ? 0 : 4 * per_col;
 };
 
-template <int RT>
 struct Stage {
-    float4 raw[RT];               // the thread's RT rows x 4 columns of the next block
-    uint32_t pk[3][RT / 2];       // pieces of the column being split: [piece][row pair]
+    float4 raw[8];                // the thread's 8 rows x 4 columns of the next block
+    uint32_t pk[3][4];            // pieces of the column being split: [piece][row pair]
     f32x2 resid;
-    double bsum[4];               // bias gradient: fp32 inside a block (RT rows), fp64 across blocks
+    double bsum[4];               // bias gradient: fp32 inside a block (8 rows), fp64 across blocks
     char* wr;                     // image address of column 0, piece 0 (column e: + 64 e, piece p: + 8 p TILE_B)
 };
 
-template <int ROLE, int RT, int U>
-__device__ __forceinline__ void stage_unit(Stage<RT>& st) {
-    using Un = Units<ROLE, RT>;
+template <int ROLE, int U>
+__device__ __forceinline__ void stage_unit(Stage& st) {
+    using Un = Units<ROLE>;
     constexpr int e = U / Un::per_col, v = U % Un::per_col;
     if constexpr (v < Un::silu) {
         f4set(st.raw[v], e, silu(f4get(st.raw[v], e)));       // A = SiLU(Z_prev) applied while staging (a_mode 1)
-    } else if constexpr (v < Un::silu + Un::split) {
+    } else if constexpr (v < Un::silu + 12) {
         constexpr int k2 = (v - Un::silu) / 3, stg = (v - Un::silu) % 3;
         split3_stage<stg>(f4get(st.raw[2 * k2], e), f4get(st.raw[2 * k2 + 1], e), st.pk[0][k2], st.pk[1][k2], st.pk[2][k2],
                           st.resid);
-    } else if constexpr (v < Un::silu + Un::split + Un::bias) {
-        float t = (f4get(st.raw[0], e) + f4get(st.raw[1], e)) + (f4get(st.raw[2], e) + f4get(st.raw[3], e));
-        if constexpr (RT == 8)
-            t += (f4get(st.raw[4], e) + f4get(st.raw[5], e)) + (f4get(st.raw[6], e) + f4get(st.raw[7], e));
+    } else if constexpr (v < Un::silu + 12 + Un::bias) {
+        float t = ((f4get(st.raw[0], e) + f4get(st.raw[1], e)) + (f4get(st.raw[2], e) + f4get(st.raw[3], e))) +
+                  ((f4get(st.raw[4], e) + f4get(st.raw[5], e)) + (f4get(st.raw[6], e) + f4get(st.raw[7], e)));
         st.bsum[e] += (double)t;
     } else {
-        constexpr int p = v - (Un::silu + Un::split + Un::bias);
-        char* dst = st.wr + p * 8 * TILE_B + e * 64;
-        if constexpr (RT == 8) *reinterpret_cast<uint4*>(dst) = make_uint4(st.pk[p][0], st.pk[p][1], st.pk[p][2], st.pk[p][3]);
-        else *reinterpret_cast<uint2*>(dst) = make_uint2(st.pk[p][0], st.pk[p][1]);
+        constexpr int p = v - (Un::silu + 12 + Un::bias);
+        *reinterpret_cast<uint4*>(st.wr + p * 8 * TILE_B + e * 64) = make_uint4(st.pk[p][0], st.pk[p][1], st.pk[p][2], st.pk[p][3]);
     }
 }
 
-// Slot `bid` of `batch`, computed by a workgroup of NW waves (4: wave tile 64x64; 8: 32x64).  Every thread stages: two
-// waves per SIMD (NW = 8) let one wave's staging VALU run while the other's MFMAs execute -- inside ONE wave they add up.
+// Slot `bid` of `batch`, computed by a workgroup of NW waves (4: wave tile 64x64; 8: 32x64).  The first four waves stage.
 template <int NW, typename Batch>
 __device__ __forceinline__ void wgrad_body(const Batch& batch, float* __restrict__ partial, const int bid, float* lds) {
     constexpr int NT = 64 * NW;               // threads
     constexpr int AI = NW == 4 ? 4 : 2;       // 16-row tiles of dW rows per wave
     constexpr int NMFMA = AI * 4 * 6;         // MFMAs per block and wave
-    constexpr int RT = NW == 4 ? 8 : 4;       // rows of a block per staging thread
     char* ldsb = reinterpret_cast<char*>(lds);
     int j = 0;
     while (j + 1 < batch.njobs && bid >= batch.start[j + 1]) ++j;       // wave-uniform scalar search
@@ -162,34 +155,32 @@ __device__ __forceinline__ void wgrad_body(const Batch& batch, float* __restrict
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- staging role: operand `op` (0: dZ, 1: A; first / second half of the workgroup), columns 4 c4 .. + 3, rows
-    // 8 kg + RT half .. + RT - 1 of a block (row group kg of the images; RT = 4: the thread owns half of a slot's 16 bytes)
-    const int op = (threadIdx.x / (NT / 2)) & 1, c4 = threadIdx.x & 31, gq = (threadIdx.x >> 5) & (32 / RT - 1);
-    const int g = RT == 8 ? gq : gq >> 1, half = RT == 8 ? 0 : gq & 1;
-    const int rofs = 8 * g + RT * half;       // first of the thread's rows inside a block
-    const int role = op == 0 ? ROLE_DZ : jb.a_mode == 1 ? ROLE_A_SILU : ROLE_A;
+    // ---- staging role (threads 0..255): operand `op` (0: dZ, 1: A), rows 8 g .. 8 g + 7 of a block, columns 4 c4 .. + 3
+    const bool stager = threadIdx.x < 256;                     // wave-uniform
+    const int op = (threadIdx.x >> 7) & 1, c4 = threadIdx.x & 31, g = (threadIdx.x >> 5) & 3;
+    const int role = !stager ? ROLE_NONE : op == 0 ? ROLE_DZ : jb.a_mode == 1 ? ROLE_A_SILU : ROLE_A;
     const float* src = op ? jb.A : jb.dZ;
     const int64_t ld = op ? jb.ld_a : jb.ld_dz;
     const float* zero = reinterpret_cast<const float*>(pamnet_wgrad_zero_row);
-    Stage<RT> st;
+    Stage st;
     st.bsum[0] = st.bsum[1] = st.bsum[2] = st.bsum[3] = 0.0;
     // image address of this thread's column e, piece p: ((op * 3 + p) * 8 + c4 / 4) * TILE_B + (e * 4 + c4 % 4 + 16 g) * 16
-    st.wr = ldsb + (op * 24 + (c4 >> 2)) * TILE_B + ((c4 & 3) + 16 * g) * 16 + 2 * RT * half;
+    st.wr = ldsb + (op * 24 + (c4 >> 2)) * TILE_B + ((c4 & 3) + 16 * g) * 16;
     // reader: piece p of tile ct of operand o at ((o * 3 + p) * 8 + ct) * TILE_B + ((r16 % 4) * 4 + r16 / 4 + 16 kg) * 16
     const char* rdz = ldsb + (i0 >> 4) * TILE_B + ((r16 & 3) * 4 + (r16 >> 2) + 16 * kg) * 16;
     const char* rda = ldsb + (24 + (j0 >> 4)) * TILE_B + ((r16 & 3) * 4 + (r16 >> 2) + 16 * kg) * 16;
 
-    auto fetch = [&](int64_t r0) {            // the thread's rows of the block at r0; rows past the end read zeros
-        const float* p = src + (r0 + rofs) * ld + 4 * c4;
+    auto fetch = [&](int64_t r0) {            // rows r0 + 8 g + u of the thread's operand; rows past the end read zeros
+        const float* p = src + (r0 + 8 * g) * ld + 4 * c4;
 #pragma unroll
-        for (int u = 0; u < RT; ++u) {
-            const bool ok = r0 + rofs + u < end;
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = r0 + 8 * g + u < end;
             st.raw[u] = *reinterpret_cast<const float4*>(ok ? p + u * ld : zero + 4 * c4);
         }
     };
     auto stage_all = [&](auto role_c) {       // first block of a slot: nothing to hide behind
         constexpr int ROLE = decltype(role_c)::value;
-        static_for<Units<ROLE, RT>::total>([&](auto uc) { stage_unit<ROLE, RT, decltype(uc)::value>(st); });
+        static_for<Units<ROLE>::total>([&](auto uc) { stage_unit<ROLE, decltype(uc)::value>(st); });
     };
 
     // One block: fragments -> registers, barrier, MFMAs with the staging units of the next block's rows between them.
@@ -206,7 +197,7 @@ __device__ __forceinline__ void wgrad_body(const Batch& batch, float* __restrict
             for (int p = 0; p < 3; ++p) fz[a][p] = *reinterpret_cast<const uint4*>(rdz + (p * 8 + a) * TILE_B);
         __syncthreads();                                       // every wave holds its fragments: the images are free
         // units start a sixth of the way in (the rows were requested at the end of the previous block), spread evenly
-        constexpr int U0 = NMFMA / 6, USPAN = NMFMA - U0, NU = Units<ROLE, RT>::total;
+        constexpr int U0 = NMFMA / 6, USPAN = NMFMA - U0, NU = Units<ROLE>::total;
         __builtin_amdgcn_sched_barrier(0);
         static_for<NMFMA>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -221,7 +212,7 @@ __device__ __forceinline__ void wgrad_body(const Batch& batch, float* __restrict
                                                                 acc[a][b], 0, 0, 0);
             if constexpr (NU > 0 && i >= U0) {
                 constexpr int u0 = ((i - U0) * NU + USPAN - 1) / USPAN, u1 = ((i - U0 + 1) * NU + USPAN - 1) / USPAN;
-                static_for<u1 - u0>([&](auto uc) { stage_unit<ROLE, RT, u0 + decltype(uc)::value>(st); });
+                static_for<u1 - u0>([&](auto uc) { stage_unit<ROLE, u0 + decltype(uc)::value>(st); });
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -236,14 +227,16 @@ __device__ __forceinline__ void wgrad_body(const Batch& batch, float* __restrict
     int it = 0;
     if (beg < end) {
         WPROBE(0);
-        fetch(beg);
-        with_role(stage_all);
-        if (beg + KB < end) fetch(beg + KB);
+        if (stager) {
+            fetch(beg);
+            with_role(stage_all);
+            if (beg + KB < end) fetch(beg + KB);
+        }
         __syncthreads();
         WPROBE(1);
         for (int64_t r0 = beg; r0 < end; r0 += KB, ++it) {
             WPROBE(2 + 3 * it);
-            if (r0 + KB < end) {
+            if (stager && r0 + KB < end) {
                 with_role(block);
                 WPROBE(3 + 3 * it);
                 if (r0 + 2 * KB < end) fetch(r0 + 2 * KB);
@@ -268,10 +261,9 @@ __device__ __forceinline__ void wgrad_body(const Batch& batch, float* __restrict
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 T[(i0 + 16 * a + kg * 4 + r) * LDT + j0 + 16 * b + r16] = acc[a][b][r];
-    constexpr int NG = 32 / RT;                                // row groups of the staging threads (4 or 8)
-    float* bp = lds + DIM * LDT;                               // [NG][128] bias parts behind the tile
-    if (op == 0) {
-        *reinterpret_cast<float4*>(bp + gq * DIM + 4 * c4) =
+    float* bp = lds + DIM * LDT;                               // [4 row groups][128] bias parts behind the tile
+    if (stager && op == 0) {
+        *reinterpret_cast<float4*>(bp + g * DIM + 4 * c4) =
             make_float4((float)st.bsum[0], (float)st.bsum[1], (float)st.bsum[2], (float)st.bsum[3]);
     }
     __syncthreads();
@@ -284,12 +276,9 @@ __device__ __forceinline__ void wgrad_body(const Batch& batch, float* __restrict
             *reinterpret_cast<float4*>(out + row * DIM + 4 * oc4) = *reinterpret_cast<const float4*>(T + row * LDT + 4 * oc4);
         }
     }
-    if (threadIdx.x < 2 * DIM) {                               // NG row groups -> the 2 parts the finish pass expects
+    if (threadIdx.x < 2 * DIM) {                               // 4 row groups -> the 2 parts the finish pass expects
         const int h = threadIdx.x >> 7, bc = threadIdx.x & 127;
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < NG / 2; ++q) t += bp[(NG / 2 * h + q) * DIM + bc];
-        out[DIM * DIM + threadIdx.x] = t;
+        out[DIM * DIM + threadIdx.x] = bp[(2 * h) * DIM + bc] + bp[(2 * h + 1) * DIM + bc];
     }
     WPROBE(3 + 3 * it);
 }
