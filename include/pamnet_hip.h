@@ -205,7 +205,8 @@ int pamnet_node_tail_fwd_rider_f32(const float* x2, const float* res_x, int64_t 
                                    const float* next_bx1, const float* const* next_wp, int64_t next_ldwp,
                                    int64_t next_nblk, float* next_Zx1, float* next_x1, float* next_P, const float* mlp_x,
                                    int64_t mlp_rows, int64_t mlp_tile0, int64_t mlp_ntiles, const float* const* mlp,
-                                   float* const* mlp_out, int64_t rider_wgs, pamnet_stream_t stream);
+                                   float* const* mlp_out, int64_t rider_wgs, int32_t packed /* 1 or 2 */,
+                                   pamnet_stream_t stream);
 /* out = att = null in pamnet_node_tail_fwd_f32 leaves the head branch of the chain (mlp_out, W_out, W:
  * layers/global_message_passing.py:46-50) to this call, which runs it for n_layers chains in one launch (nothing
  * downstream of a layer depends on its heads): per layer l  x_out[l] [n,128] -> out[l] [n], att[l] [n], and slots 7..9
@@ -246,6 +247,12 @@ int pamnet_node_pre_tail_bwd_f32(const float* dP, const float* dx1_direct, const
  * a wave is then one contiguous 1 KB read instead of 16 half-used cache lines of the row-major matrix. */
 int pamnet_pack_weights_f32(int64_t n, const float* const* W, const int64_t* ld, int32_t transposed, float* images,
                             pamnet_stream_t stream);
+/* The same matrices as bf16x3 fragment images (images[i*24576..], 96 KB each): every weight split exactly into three bf16
+ * pieces, laid out as the B fragments of v_mfma_f32_16x16x32_bf16.  With packed == 2, pamnet_node_tail_fwd_f32 (deferred
+ * heads: out = att = null) and pamnet_node_tail_fwd_rider_f32 take such images for weights[0..6], next_Wx1 and next_wp and
+ * run the chain on the bf16 matrix pipe at fp32 accuracy (six piece products per product: csrc/gemm_core.h "bf16x6"). */
+int pamnet_pack_weights_bf16x3(int64_t n, const float* const* W, const int64_t* ld, int32_t transposed, float* images,
+                               pamnet_stream_t stream);
 int pamnet_node_pre_fwd_f32(const float* x, int64_t n, const float* Wx1, const float* bx1, const float* const* wp,
                             int64_t ldwp, int64_t nblk, float* Zx1, float* x1, float* P, pamnet_stream_t stream);
 int pamnet_node_pre_bwd_f32(const float* dP, const float* dx1_direct, const float* d_add, int64_t n, const float* Wx1,

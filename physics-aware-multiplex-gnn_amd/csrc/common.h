@@ -21,4 +21,4 @@ static inline hipStream_t as_stream(pamnet_stream_t s) {
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + __expf(-z)); }
+__device__ __forceinline__ float silu_f(float z) { return z * __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }

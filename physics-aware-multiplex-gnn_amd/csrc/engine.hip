@@ -178,21 +178,36 @@ struct PackList {
     int32_t transposed;
     pamnet_stream_t st;
     int rc = 0;
-    PackList(float* b, int32_t t, pamnet_stream_t s) : base(b), transposed(t), st(s) {}
+    int64_t img = D * D;       // floats per image: fp32 fragment images, or bf16x3 images (3 pieces x 2 bytes: 1.5 x)
+    bool bf16x3 = false;
+    PackList(float* b, int32_t t, pamnet_stream_t s, bool pieces = false)
+        : base(b), transposed(t), st(s), img(pieces ? 3 * D * D / 2 : D * D), bf16x3(pieces) {}
     // returns the image the matrix will occupy
     const float* add(const float* W, int64_t ldw) {
         if (n == 192) flush();
         src[n] = W;
         ld[n] = ldw;
-        return base + (done + n++) * (D * D);
+        return base + (done + n++) * img;
     }
     void flush() {
-        if (n && !rc) rc = pamnet_pack_weights_f32(n, src, ld, transposed, base + done * (D * D), st);
+        if (n && !rc)
+            rc = bf16x3 ? pamnet_pack_weights_bf16x3(n, src, ld, transposed, base + done * img, st)
+                        : pamnet_pack_weights_f32(n, src, ld, transposed, base + done * img, st);
         done += n;
         n = 0;
     }
 };
 constexpr int64_t PACK_PER_PAIR = 28;       // forward: 10 + 5 (global chain + local head) + 10 + 3 (local chain + next global head)
+constexpr int64_t PACK_FLOATS_PER_PAIR = PACK_PER_PAIR * (3 * D * D / 2);     // sized for bf16x3 images throughout
+// PAMNET_CHAIN_BF16=1: the forward chains on the bf16 matrix pipe (node_tail_fwd_bf16_kernel, bf16x3 weight images).
+// Off by default -- measured in the step at the QM9 batch: 27.8 us per chain launch against 26.5 us for the fp32-MFMA form
+// (the MFMAs of a layer shrink from 2 300 to 1 100 cycles, tools/tail_probe_bf16.py, but the epilogue grows by as much:
+// the split of the result, 12 more LDS stores with 4-way bank conflicts, 96 KB instead of 64 KB of weights per layer
+// from L2); same outputs to 3e-7 (tests/test_hip_fused.py::test_node_tail_fwd_bf16x6).
+inline bool chain_bf16() {
+    static bool v = [] { const char* e = getenv("PAMNET_CHAIN_BF16"); return e && atoi(e) != 0; }();
+    return v;
+}
 
 // weight-gradient job list builder
 struct Jobs {
@@ -249,7 +264,7 @@ inline int run_jobs(Jobs& j, float* partial, const Graph& g, const float* head, 
 // floats of the optional weight-image arena (`wpack`) of pamnet_stack_fwd_f32 / pamnet_stack_bwd_f32
 extern "C" int pamnet_stack_pack_floats(int64_t n_layer, int64_t* floats) {
     if (n_layer < 1 || !floats) return PAMNET_EINVAL;
-    *floats = n_layer * PACK_PER_PAIR * D * D;
+    *floats = n_layer * PACK_FLOATS_PER_PAIR;
     return PAMNET_OK;
 }
 
@@ -352,16 +367,23 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         const float *gt[10], *lh[5], *lt[10], *nh[3];
     };
     PairImg* img = packed ? static_cast<PairImg*>(alloca(sizeof(PairImg) * n_layer)) : nullptr;
+    // bf16x3 images for everything the chains multiply by (matrices 0..6 + the fused heads of the next layers), fp32
+    // images for the mlp_out matrices 7..9 (node_heads_fwd_kernel)
+    const bool cb = packed && chain_bf16();
     if (packed) {
-        PackList pl(wpack, 0, st);
+        PackList pl(wpack, 0, st, cb);
+        PackList ph(wpack + n_layer * 22 * (3 * D * D / 2), 0, st, false);     // behind the 22 chain images of every pair
+        PackList& hd = cb ? ph : pl;
         for (int64_t k = 0; k < n_layer; ++k) {
             const float* const* gp = gparams + k * NG;
             const float* const* lp = lparams + k * NL;
-            for (int i = 0; i < 10; ++i) img[k].gt[i] = pl.add(gp[GT + i], D);
+            for (int i = 0; i < 7; ++i) img[k].gt[i] = pl.add(gp[GT + i], D);
+            for (int i = 7; i < 10; ++i) img[k].gt[i] = hd.add(gp[GT + i], D);
             img[k].lh[0] = pl.add(lp[0], D);
             img[k].lh[1] = pl.add(lp[2], 3 * D), img[k].lh[2] = pl.add(lp[4], 3 * D);
             img[k].lh[3] = pl.add(lp[2] + D, 3 * D), img[k].lh[4] = pl.add(lp[4] + D, 3 * D);
-            for (int i = 0; i < 10; ++i) img[k].lt[i] = pl.add(lp[LT + i], D);
+            for (int i = 0; i < 7; ++i) img[k].lt[i] = pl.add(lp[LT + i], D);
+            for (int i = 7; i < 10; ++i) img[k].lt[i] = hd.add(lp[LT + i], D);
             if (k + 1 < n_layer) {
                 const float* const* gn = gparams + (k + 1) * NG;
                 img[k].nh[0] = pl.add(gn[0], D);
@@ -370,7 +392,12 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         }
         pl.flush();
         CK(pl.rc);
+        if (cb) {
+            ph.flush();
+            CK(ph.rc);
+        }
     }
+    const int32_t pkc = cb ? 2 : (packed ? 1 : 0);          // what the chain launches are told about their images
     const int32_t pk = packed ? 1 : 0;
     CK(pamnet_seg_cuts_i32(g.g_ptr, g.g_row, g.n, g.eg, t.cuts, nullptr, st));      // work split of the fused global-edge kernels
     for (int64_t k = 0; k < n_layer; ++k) {
@@ -392,12 +419,12 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
             CK(pamnet_node_tail_fwd_rider_f32(s.x2, x, g.n, img[k].gt, gp + GT + 10, gp[GT + 20], gp[GT + 21], gp[GT + 22],
                                               sv(s.Z), sv(s.R), s.xout, img[k].lh[0], lp[1], img[k].lh + 1, 3 * D, 4,
                                               sv(q.Zx1), t.x1, t.P, e_sbf, g.tp, mlp_half, mlp_tiles - mlp_half, mp, mo,
-                                              rider_wgs, st));
+                                              rider_wgs, pkc, st));
         } else {
             CK(pamnet_node_tail_fwd_f32(s.x2, x, g.n, packed ? img[k].gt : gp + GT, gp + GT + 10, gp[GT + 20], gp[GT + 21],
                                         gp[GT + 22], sv(s.Z), sv(s.R), s.xout, nullptr, nullptr,
                                         packed ? img[k].lh[0] : lp[0], lp[1], packed ? img[k].lh + 1 : wpl, 3 * D, 4,
-                                        sv(q.Zx1), t.x1, t.P, pk, st));
+                                        sv(q.Zx1), t.x1, t.P, pkc, st));
         }
         x = s.xout;
         // ---------------- local layer (layers/local_message_passing.py:36-66); its head ran in the chain above
@@ -420,17 +447,17 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
                 float* mo[3] = {sv(qn.z1), sv(qn.z2), qn.s};
                 CK(pamnet_node_tail_fwd_rider_f32(q.x2, x, g.n, img[k].lt, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22],
                                                   sv(q.Z), sv(q.R), q.xout, img[k].nh[0], gn[1], img[k].nh + 1, 3 * D, 2,
-                                                  sv(sn.Zx1), t.x1, t.P, e_sbf, g.tp, 0, mlp_half, mp, mo, rider_wgs, st));
+                                                  sv(sn.Zx1), t.x1, t.P, e_sbf, g.tp, 0, mlp_half, mp, mo, rider_wgs, pkc, st));
             } else {
                 CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, packed ? img[k].lt : lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21],
                                             lp[LT + 22], sv(q.Z), sv(q.R), q.xout, nullptr, nullptr,
                                             packed ? img[k].nh[0] : gn[0], gn[1],
-                                            packed ? img[k].nh + 1 : wpn, 3 * D, 2, sv(sn.Zx1), t.x1, t.P, pk, st));
+                                            packed ? img[k].nh + 1 : wpn, 3 * D, 2, sv(sn.Zx1), t.x1, t.P, pkc, st));
             }
         } else {
             CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, packed ? img[k].lt : lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21],
                                         lp[LT + 22], sv(q.Z), sv(q.R), q.xout, nullptr, nullptr, nullptr, nullptr,
-                                        nullptr, 0, 0, nullptr, nullptr, nullptr, pk, st));
+                                        nullptr, 0, 0, nullptr, nullptr, nullptr, pkc, st));
         }
         x = q.xout;
     }

@@ -27,9 +27,11 @@ constexpr int DIM = 128;          // feature width handled by the fused kernels
 constexpr int LDT = 132;          // LDS tile leading dimension (floats)
 constexpr int WG = 256;           // threads per workgroup (4 waves)
 
-// sigmoid through the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each) -- the activation epilogues run
-// once per GEMM output element and were a visible VALU cost with the libm expf + IEEE divide sequences.
-__device__ __forceinline__ float sigmoidf_fast(float z) { return __frcp_rn(1.0f + __expf(-z)); }
+// sigmoid through the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each): 4 VALU.  The activation epilogues run
+// once per GEMM output element; __frcp_rn looked like the hardware reciprocal but compiles to the correctly rounded
+// division sequence (v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup: 14 VALU for the sigmoid, ~100 VALU per lane
+// and layer of a node chain) -- __builtin_amdgcn_rcpf is the single instruction.
+__device__ __forceinline__ float sigmoidf_fast(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
 __device__ __forceinline__ float silu(float z) { return z * sigmoidf_fast(z); }
 // d/dz [z * sigmoid(z)] = s * (1 + z * (1 - s))
 __device__ __forceinline__ float dsilu(float z) {

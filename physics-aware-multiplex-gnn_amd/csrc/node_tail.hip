@@ -324,6 +324,221 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
     }
 }
 
+// ---- the forward chain on the bf16 matrix pipe at fp32 accuracy ("bf16x6", gemm_core.h) ---------------------------------
+// Production form of the kernel above (packed weights, deferred heads): every GEMM input tile lives in LDS as three bf16
+// piece planes in MFMA A-fragment order -- [piece][k-step][lane] x 16 bytes, lane-linear, 12 KB per 16-row tile -- written
+// by the epilogue that produces it (the split costs 4.5 VALU per element, once), and the weights arrive as bf16x3 fragment
+// images (pamnet_pack_weights_bf16x3: 96 KB per matrix).  A layer is 48 v_mfma_f32_16x16x32_bf16 per wave (816 matrix-pipe
+// cycles) instead of 64 fp32 MFMAs (2 048 cycles, and on this part an MFMA in flight holds up the VALU issue of its SIMD).
+// k order inside k-step q: an accumulator lane holds columns c and c + 16 of a row, so those two are made neighbours in k:
+// position t = 2 j + n2 of row group kg is column 32 q + 16 n2 + 4 kg + j -- the pack kernel lays the weights out the same
+// way, and a pair of a lane leaves as ONE dword per piece.
+constexpr int PIMG = 3 * 4 * 1024;            // bytes of a 16-row tile as piece planes
+
+struct WFragB {                               // a wave's 32 output columns: [16-column tile][k-step][piece] = 96 VGPRs
+    uint4 b[2][4][3];
+};
+// bf16x3 image of a matrix: img16[((piece * 8 + tile) * 4 + k-step) * 64 + lane]
+__device__ __forceinline__ void load_wfragb(WFragB& f, const float* __restrict__ img) {
+    const uint4* p = reinterpret_cast<const uint4*>(img) + (threadIdx.x & 63);
+    const int jt = (threadIdx.x >> 6) * 2;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) f.b[t][q][pc] = p[((pc * 8 + jt + t) * 4 + q) * 64];
+}
+__device__ __forceinline__ f32x4 mfma_u4(const uint4& a, const uint4& b, const f32x4& c) {
+    const u32x4 av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+}
+// acc[t] += tile(planes at `in`) x slice t of `f`: 4 k-steps x 6 products x 2 tiles, small products first
+__device__ __forceinline__ void mma_planes(const char* __restrict__ in, const WFragB& f, f32x4 (&acc)[2]) {
+    const uint4* ip = reinterpret_cast<const uint4*>(in) + (threadIdx.x & 63);
+    uint4 az[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) az[q][pc] = ip[(pc * 4 + q) * 64];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = mfma_u4(az[q][2], f.b[t][q][0], acc[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = mfma_u4(az[q][1], f.b[t][q][1], acc[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = mfma_u4(az[q][0], f.b[t][q][2], acc[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = mfma_u4(az[q][1], f.b[t][q][0], acc[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = mfma_u4(az[q][0], f.b[t][q][1], acc[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = mfma_u4(az[q][0], f.b[t][q][0], acc[t]);
+    }
+}
+// the pair (columns c, c + 16 of row `rw`, c = 32 w + r16) of an accumulator lane -> its dword in each piece plane
+__device__ __forceinline__ void st_pair_planes(char* __restrict__ dst, int w, int rw, int r16, float a0, float a1) {
+    uint32_t p0, p1, p2;
+    split3(a0, a1, p0, p1, p2);
+    char* d = dst + w * 1024 + (rw + 16 * (r16 >> 2)) * 16 + (r16 & 3) * 4;
+    *reinterpret_cast<uint32_t*>(d) = p0;
+    *reinterpret_cast<uint32_t*>(d + 4096) = p1;
+    *reinterpret_cast<uint32_t*>(d + 8192) = p2;
+}
+// one value of a row-major sweep (row r, column c) -> its 2 bytes in each piece plane
+__device__ __forceinline__ void st_elem_planes(char* __restrict__ dst, int r, int c, float v) {
+    const f32x2 x = {v, 0.f};
+    uint32_t p0, p1, p2;
+    split3(x[0], x[1], p0, p1, p2);
+    const int q = c >> 5, n2 = (c >> 4) & 1, r16 = c & 15;
+    char* d = dst + q * 1024 + (r + 16 * (r16 >> 2)) * 16 + (r16 & 3) * 4 + 2 * n2;
+    *reinterpret_cast<uint16_t*>(d) = (uint16_t)p0;
+    *reinterpret_cast<uint16_t*>(d + 4096) = (uint16_t)p1;
+    *reinterpret_cast<uint16_t*>(d + 8192) = (uint16_t)p2;
+}
+
+template <bool RIDER>
+__global__ __launch_bounds__(WG) void node_tail_fwd_bf16_kernel(const float* __restrict__ x2,
+                                                                const float* __restrict__ res_x, int64_t n, TailParams p,
+                                                                float* __restrict__ Z, float* __restrict__ R,
+                                                                float* __restrict__ x_out, PreNext nx,
+                                                                Mlp2Rider rd = Mlp2Rider{}) {
+    // fp32 tiles: res_x, h0, 7 pre-activation tiles, 3 residual taps (parked, written out once after the chain);
+    // piece-plane tiles: three, rotating through the chain
+    __shared__ __attribute__((aligned(16))) float lds[12 * SLOT + 3 * PIMG / 4];
+    if constexpr (RIDER) {
+        if ((int)blockIdx.x >= rd.n_chain) {
+            constexpr int RMT = 3;
+            static_assert(12 * SLOT + 3 * PIMG / 4 >= 2 * RMT * 16 * LDT, "rider tiles must fit the chain's LDS");
+            const int b = (int)blockIdx.x - rd.n_chain, nr = (int)gridDim.x - rd.n_chain;
+            const int base = rd.ntiles / nr, rem = rd.ntiles % nr;
+            const int64_t t0 = rd.tile0 + (int64_t)b * base + (b < rem ? b : rem);
+            const int cnt = base + (b < rem ? 1 : 0);
+            edge::Span sp;
+            sp.beg = t0 * 16;
+            const int64_t e = (t0 + cnt) * 16;
+            sp.end = e < rd.m ? e : rd.m;
+            if (sp.beg > sp.end) sp.beg = sp.end;
+            const int nch = (cnt + RMT - 1) / RMT;
+            sp.cmt = nch > 0 ? (cnt + nch - 1) / nch : 1;
+            edge::mlp2_fwd_body<RMT, 4>(rd.x, rd.set, sp, lds);
+            return;
+        }
+    }
+    float* RX = lds;
+    float* H0 = lds + SLOT;
+    float* ZL = lds + 2 * SLOT;               // [7] z_k tiles (reused by the next layer's head: Zx1, x1, P_b)
+    float* TL = lds + 9 * SLOT;               // [3] r1, r2, x_out tiles
+    char* P0 = reinterpret_cast<char*>(lds + 12 * SLOT);
+    char* P1 = P0 + PIMG;
+    char* P2 = P1 + PIMG;
+    const int64_t row0 = (int64_t)blockIdx.x * BMN;
+    const int64_t plane = n * DIM;
+    const int lane = threadIdx.x & 63, r16 = lane & 15, kg = lane >> 4;
+    const int w = threadIdx.x >> 6, wc = w * 32;
+
+    WFragB wf;
+    load_wfragb(wf, p.W[0]);
+    sweep_rows<BMN>([&](int r, int c4) {
+        const int64_t g = row0 + r;
+        const float4 v = ldg4z(x2, g, n, DIM, c4);
+        st_elem_planes(P0, r, 4 * c4, v.x), st_elem_planes(P0, r, 4 * c4 + 1, v.y);
+        st_elem_planes(P0, r, 4 * c4 + 2, v.z), st_elem_planes(P0, r, 4 * c4 + 3, v.w);
+        st_lds4(RX, r, c4, ldg4z(res_x, g, n, DIM, c4));
+    });
+    __syncthreads();
+
+    // layer k: planes `in` -> planes `dst` = SiLU(W_k in + b_k) (+ add1 + add2); z_k parked; fp32 copies of the result
+    // where something reads it as a residual (`dst32`) or the backward wants it (`tap`)
+    auto layer = [&](const char* in, char* dst, int k, const float* add1, const float* add2, float* dst32, float* tap,
+                     const float* Wnext) {
+        TPROBE(4 * k);
+        const Bias2 bv = load_bias2(p.b[k], wc);               // before the prefetch (in-order vmcnt)
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        mma_planes(in, wf, acc);
+        TPROBE(4 * k + 1);
+        if (Wnext) load_wfragb(wf, Wnext);
+        float* zk = ZL + k * SLOT;
+        const int c = wc + r16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rw = 4 * kg + r;
+            const float z0 = acc[0][r] + bv.v[0], z1 = acc[1][r] + bv.v[1];
+            float a0 = silu(z0), a1 = silu(z1);
+            if (add1) a0 += add1[rw * LDT + c], a1 += add1[rw * LDT + c + 16];
+            if (add2) a0 += add2[rw * LDT + c], a1 += add2[rw * LDT + c + 16];
+            st_pair_planes(dst, w, rw, r16, a0, a1);
+            zk[rw * LDT + c] = z0, zk[rw * LDT + c + 16] = z1;
+            if (dst32) dst32[rw * LDT + c] = a0, dst32[rw * LDT + c + 16] = a1;
+            if (tap) tap[rw * LDT + c] = a0, tap[rw * LDT + c + 16] = a1;
+        }
+        TPROBE(4 * k + 2);
+        __syncthreads();
+        TPROBE(4 * k + 3);
+    };
+
+    layer(P0, P1, 0, nullptr, nullptr, H0, nullptr, p.W[1]);              // h0 -> P1 (+ fp32 H0)
+    layer(P1, P2, 1, nullptr, nullptr, nullptr, nullptr, p.W[2]);         // a1 -> P2
+    layer(P2, P0, 2, H0, RX, nullptr, TL, p.W[3]);                        // r1 -> P0   (+ h0 + res_x)
+    layer(P0, P1, 3, nullptr, nullptr, nullptr, nullptr, p.W[4]);         // a3 -> P1
+    layer(P1, P2, 4, TL, nullptr, nullptr, TL + SLOT, p.W[5]);            // r2 -> P2   (+ r1)
+    layer(P2, P1, 5, nullptr, nullptr, nullptr, nullptr, p.W[6]);         // a5 -> P1
+    layer(P1, P0, 6, TL + SLOT, nullptr, nullptr, TL + 2 * SLOT, nx.nblk > 0 ? nx.Wx1 : nullptr);   // r3 = x_out -> P0
+
+    // park -> memory: Z[7][n][128], R[2][n][128], x_out[n][128]
+    sweep_rows<BMN>([&](int r, int c4) {
+        const int64_t g = row0 + r;
+        if (g >= n) return;
+        if (Z) {                                              // backward-only saves: null in inference mode
+#pragma unroll
+            for (int k = 0; k < 7; ++k) stg4(Z + (int64_t)k * plane, g, DIM, c4, lds4(ZL + k * SLOT, r, c4));
+            stg4(R, g, DIM, c4, lds4(TL, r, c4));
+            stg4(R + plane, g, DIM, c4, lds4(TL + SLOT, r, c4));
+        }
+        stg4(x_out, g, DIM, c4, lds4(TL + 2 * SLOT, r, c4));
+    });
+
+    // ---- the next layer's head on the x_out tile (its planes are in P0); outputs reuse the z_k parking slots, which the
+    // sweep above has already read -> barrier, one GEMM for x1, nblk for the projections, then a second flush
+    if (nx.nblk > 0) {
+        __syncthreads();
+        const int c = wc + r16;
+        {
+            const Bias2 bv = load_bias2(nx.bx1, wc);
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            mma_planes(P0, wf, acc);
+            load_wfragb(wf, nx.wp[0]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rw = 4 * kg + r;
+                const float z0 = acc[0][r] + bv.v[0], z1 = acc[1][r] + bv.v[1];
+                const float a0 = silu(z0), a1 = silu(z1);
+                ZL[rw * LDT + c] = z0, ZL[rw * LDT + c + 16] = z1;                     // Zx1
+                ZL[SLOT + rw * LDT + c] = a0, ZL[SLOT + rw * LDT + c + 16] = a1;       // x1
+                st_pair_planes(P1, w, rw, r16, a0, a1);
+            }
+            __syncthreads();
+        }
+        for (int b = 0; b < nx.nblk; ++b) {
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            mma_planes(P1, wf, acc);
+            if (b + 1 < nx.nblk) load_wfragb(wf, nx.wp[b + 1]);
+            float* pb = ZL + (2 + b) * SLOT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pb[(4 * kg + r) * LDT + c] = acc[0][r], pb[(4 * kg + r) * LDT + c + 16] = acc[1][r];
+        }
+        __syncthreads();
+        sweep_rows<BMN>([&](int r, int c4) {
+            const int64_t g = row0 + r;
+            if (g >= n) return;
+            if (nx.Zx1) stg4(nx.Zx1, g, DIM, c4, lds4(ZL, r, c4));
+            stg4(nx.x1, g, DIM, c4, lds4(ZL + SLOT, r, c4));
+            for (int b = 0; b < nx.nblk; ++b) stg4(nx.P + (int64_t)b * plane, g, DIM, c4, lds4(ZL + (2 + b) * SLOT, r, c4));
+        });
+    }
+}
+
 // Head branch of every layer in one launch: o3 = mlp_out(x_out), out = W_out . o3 + b_out, att = W . o3
 // (layers/global_message_passing.py:46-50).  grid = (ceil(n/16), layers).
 constexpr int MAX_HEAD_LAYERS = 16;
@@ -838,6 +1053,49 @@ extern "C" int pamnet_pack_weights_f32(int64_t n, const float* const* W, const i
     return PAMNET_OK;
 }
 
+// bf16x3 images (node_tail_fwd_bf16_kernel): per matrix 3 pieces x 8 column tiles x 4 k-steps x 64 lanes x 16 bytes =
+// 96 KB = 24 576 floats.  Lane (n = lane & 15, kg = lane >> 4) of tile jt, k-step q holds, at position t = 0..7, the piece
+// of W[16 jt + n][32 q + 16 (t & 1) + 4 kg + (t >> 1)] (forward orientation, Y = X W^T; transposed: W[k][16 jt + n]).
+constexpr int64_t IMGB_FLOATS = 3 * DIM * DIM / 2;
+namespace {
+__global__ __launch_bounds__(256) void pack_weights_bf16x3_kernel(PackJobs jobs, int transposed, float* __restrict__ images) {
+    const float* __restrict__ W = jobs.src[blockIdx.x];
+    const int ld = jobs.ld[blockIdx.x];
+    const int jt = blockIdx.y, q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = 16 * jt + (lane & 15), kg = lane >> 4;
+    float v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int k = 32 * q + 16 * (t & 1) + 4 * kg + (t >> 1);
+        v[t] = transposed ? W[(size_t)k * ld + c] : W[(size_t)c * ld + k];
+    }
+    const Frag3 f = split_frag(v);
+    uint4* img = reinterpret_cast<uint4*>(images + (size_t)blockIdx.x * IMGB_FLOATS);
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+        img[((pc * 8 + jt) * 4 + q) * 64 + lane] = make_uint4(f.p[pc][0], f.p[pc][1], f.p[pc][2], f.p[pc][3]);
+}
+}  // namespace
+
+extern "C" int pamnet_pack_weights_bf16x3(int64_t n, const float* const* W, const int64_t* ld, int32_t transposed,
+                                          float* images, pamnet_stream_t stream) {
+    if (n < 0 || n > 192) return PAMNET_EINVAL;
+    if (n == 0) return PAMNET_OK;
+    if (!W || !ld || !images) return PAMNET_ENULL;
+    PackJobs jobs;
+    for (int i = 0; i < 192; ++i) {
+        const int s = i < n ? i : 0;
+        if (!W[s]) return PAMNET_ENULL;
+        if (ld[s] < DIM || (ld[s] & 3)) return PAMNET_EINVAL;
+        jobs.src[i] = W[s];
+        jobs.ld[i] = (int)ld[s];
+    }
+    hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3((unsigned)n, 8), dim3(256), 0, as_stream(stream), jobs,
+                       (int)transposed, images);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
 static int tail_fwd_launch(const float* x2, const float* res_x, int64_t n, const float* const* weights,
                            const float* const* biases, const float* w_out, const float* b_out, const float* w_att, float* Z,
                            float* R, float* x_out, float* out, float* att, const float* next_Wx1, const float* next_bx1,
@@ -865,13 +1123,19 @@ static int tail_fwd_launch(const float* x2, const float* res_x, int64_t n, const
     hipStream_t st = as_stream(stream);
     const dim3 grid((unsigned)ceil_div(n, BMN));
     const TailParams tp = make_tail(weights, biases, w_out, b_out, w_att, packed ? 1 : 0);
+    if (packed == 2 && heads) return PAMNET_EINVAL;            // bf16x3 images: deferred heads only
     if (rider) {
         if (!packed || heads) return PAMNET_EINVAL;
         Mlp2Rider rd = *rider;
         rd.n_chain = (int)grid.x;
-        hipLaunchKernelGGL((node_tail_fwd_kernel<true, false, true>), dim3(grid.x + (unsigned)rider_wgs), dim3(WG), 0, st, x2,
-                           res_x, n, tp, Z, R, x_out, out, att, nx, rd);
-    } else if (packed && heads) hipLaunchKernelGGL((node_tail_fwd_kernel<true, true>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
+        if (packed == 2)
+            hipLaunchKernelGGL((node_tail_fwd_bf16_kernel<true>), dim3(grid.x + (unsigned)rider_wgs), dim3(WG), 0, st, x2,
+                               res_x, n, tp, Z, R, x_out, nx, rd);
+        else
+            hipLaunchKernelGGL((node_tail_fwd_kernel<true, false, true>), dim3(grid.x + (unsigned)rider_wgs), dim3(WG), 0, st,
+                               x2, res_x, n, tp, Z, R, x_out, out, att, nx, rd);
+    } else if (packed == 2) hipLaunchKernelGGL((node_tail_fwd_bf16_kernel<false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, nx);
+    else if (packed && heads) hipLaunchKernelGGL((node_tail_fwd_kernel<true, true>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
     else if (packed) hipLaunchKernelGGL((node_tail_fwd_kernel<true, false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
     else if (heads) hipLaunchKernelGGL((node_tail_fwd_kernel<false, true>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
     else hipLaunchKernelGGL((node_tail_fwd_kernel<false, false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
@@ -900,11 +1164,11 @@ extern "C" int pamnet_node_tail_fwd_rider_f32(const float* x2, const float* res_
                                               int64_t next_ldwp, int64_t next_nblk, float* next_Zx1, float* next_x1,
                                               float* next_P, const float* mlp_x, int64_t mlp_rows, int64_t mlp_tile0,
                                               int64_t mlp_ntiles, const float* const* mlp, float* const* mlp_out,
-                                              int64_t rider_wgs, pamnet_stream_t stream) {
-    if (mlp_rows < 0 || mlp_tile0 < 0 || mlp_ntiles < 0 || rider_wgs < 0) return PAMNET_EINVAL;
+                                              int64_t rider_wgs, int32_t packed, pamnet_stream_t stream) {
+    if (mlp_rows < 0 || mlp_tile0 < 0 || mlp_ntiles < 0 || rider_wgs < 0 || (packed != 1 && packed != 2)) return PAMNET_EINVAL;
     if (mlp_ntiles == 0 || rider_wgs == 0)
         return tail_fwd_launch(x2, res_x, n, weights, biases, w_out, b_out, w_att, Z, R, x_out, nullptr, nullptr, next_Wx1,
-                               next_bx1, next_wp, next_ldwp, next_nblk, next_Zx1, next_x1, next_P, 1, nullptr, 0, stream);
+                               next_bx1, next_wp, next_ldwp, next_nblk, next_Zx1, next_x1, next_P, packed, nullptr, 0, stream);
     if (!mlp_x || !mlp || !mlp_out || !mlp[0] || !mlp[1] || !mlp[2] || !mlp[3] || !mlp_out[2]) return PAMNET_ENULL;
     if (n == 0) return PAMNET_EINVAL;                        // no chain to ride on
     Mlp2Rider rd{};
@@ -913,7 +1177,7 @@ extern "C" int pamnet_node_tail_fwd_rider_f32(const float* x2, const float* res_
     rd.tile0 = (int)mlp_tile0, rd.ntiles = (int)mlp_ntiles;
     if (rider_wgs > mlp_ntiles) rider_wgs = mlp_ntiles;       // never more workgroups than tiles
     return tail_fwd_launch(x2, res_x, n, weights, biases, w_out, b_out, w_att, Z, R, x_out, nullptr, nullptr, next_Wx1,
-                           next_bx1, next_wp, next_ldwp, next_nblk, next_Zx1, next_x1, next_P, 1, &rd, (int)rider_wgs, stream);
+                           next_bx1, next_wp, next_ldwp, next_nblk, next_Zx1, next_x1, next_P, packed, &rd, (int)rider_wgs, stream);
 }
 
 extern "C" int pamnet_node_heads_fwd_f32(int64_t n_layers, const float* const* x_out, const float* const* weights,

@@ -288,3 +288,51 @@ def test_edge_kernel_geometries(waves):
                           'full_layer or fused_engine or forward_vs_reference or gradients_vs_reference'],
                          capture_output=True, text=True, env=env, timeout=900, cwd=os.path.dirname(here))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+
+
+@pytest.mark.parametrize('n', [1, 37, 2286])
+def test_node_tail_fwd_bf16x6(dev, n):
+    """The forward node chain on the bf16 matrix pipe (packed = 2: bf16x3 weight images, activations split exactly into
+    three bf16 pieces as they are produced, six piece products per product -- csrc/node_tail.hip) against the fp32-MFMA
+    form (packed = 1) on the same inputs, with the next layer's head fused behind it: every output within 2e-6 of the
+    fp32-MFMA result (both are fp32-accurate; the summation order differs), ragged last tile included."""
+    import ctypes
+    from pamnet_amd import lib
+    torch.manual_seed(n)
+    P, PA10, PA4 = ctypes.c_void_p, ctypes.c_void_p * 10, ctypes.c_void_p * 4
+    x2, rx = torch.randn(n, D, device=dev), torch.randn(n, D, device=dev)
+    W = [torch.randn(D, D, device=dev) * 0.08 for _ in range(10)]
+    b = [torch.randn(D, device=dev) * 0.1 for _ in range(10)]
+    Wx1, bx1 = torch.randn(D, D, device=dev) * 0.08, torch.randn(D, device=dev) * 0.1
+    Wm = torch.randn(D, 3 * D, device=dev) * 0.08                     # the two node-side blocks of a [d, 3d] message weight
+    w_out, b_out, w_att = torch.randn(D, device=dev), torch.zeros(1, device=dev), torch.randn(D, device=dev)
+    st = lib.stream_of(x2)
+    mats = W + [Wx1]
+    srcs = [m.data_ptr() for m in mats] + [Wm.data_ptr(), Wm.data_ptr() + 4 * D]
+    lds = [D] * 11 + [3 * D, 3 * D]
+    res = {}
+    for packed, fn, stride in ((1, 'pamnet_pack_weights_f32', 16384), (2, 'pamnet_pack_weights_bf16x3', 24576)):
+        img = torch.empty(13 * stride, device=dev)
+        lib.call(fn, 13, (P * 13)(*srcs), (ctypes.c_int64 * 13)(*lds), 0, lib.ptr(img), st)
+        ip = [img.data_ptr() + 4 * stride * k for k in range(13)]
+        Z, R = torch.zeros(10, n, D, device=dev), torch.zeros(2, n, D, device=dev)
+        xo, Zx1, x1 = (torch.zeros(n, D, device=dev) for _ in range(3))
+        Pn = torch.zeros(2, n, D, device=dev)
+        lib.call('pamnet_node_tail_fwd_f32', lib.ptr(x2), lib.ptr(rx), n, PA10(*ip[:10]), PA10(*[t.data_ptr() for t in b]),
+                 lib.ptr(w_out), lib.ptr(b_out), lib.ptr(w_att), lib.ptr(Z), lib.ptr(R), lib.ptr(xo), None, None, ip[10],
+                 lib.ptr(bx1), PA4(ip[11], ip[12], None, None), 3 * D, 2, lib.ptr(Zx1), lib.ptr(x1), lib.ptr(Pn), packed, st)
+        res[packed] = dict(x_out=xo, Z=Z[:7], R=R, Zx1=Zx1, x1=x1, P=Pn)
+    torch.cuda.synchronize()
+    # fp64 statement of the chain for the output that matters most
+    h = torch.nn.functional.silu
+    xd, rd = x2.double(), rx.double()
+    lin = lambda k, t: t @ W[k].double().t() + b[k].double()
+    h0 = h(lin(0, xd))
+    r1 = h(lin(2, h(lin(1, h0)))) + h0 + rd
+    r2 = h(lin(4, h(lin(3, r1)))) + r1
+    r3 = h(lin(6, h(lin(5, r2)))) + r2
+    e1 = maxnorm_err(res[1]['x_out'].cpu(), r3.cpu())
+    e2 = maxnorm_err(res[2]['x_out'].cpu(), r3.cpu())
+    assert e2 <= max(2e-6, 2 * e1), (e2, e1)
+    for k in res[1]:
+        assert maxnorm_err(res[2][k].cpu(), res[1][k].cpu()) < 3e-6, k
