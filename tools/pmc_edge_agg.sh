@@ -30,11 +30,11 @@ for k in names:
     write, n2 = counter('WRITE_SIZE', k)
     traffic = (2.0 * fetch + write) * 1024.0
     bwd = 'bwd' in k
-    save = ('true' in k.split('<')[1].split(',')[1]) if ('fwd' in k and ',' in k) else False
+    save = ('true' in k.split('<')[1].split('>')[0].split(',')[2]) if ('fwd' in k and ',' in k) else False   # <MTX, PRE, SAVE>
     a = alg + (8.0 * D * eg if save else 0.0)
     if bwd:       # reads d x2 (n), z, ea, writes dz, dea, d_e (+ read for accumulate), dP_i: 6 edge tensors + 2 node planes
         a = 4.0 * D * eg * 6 + 8.0 * eg + 4.0 * D * n * 2
-    short = k.split('::')[-1].split('(')[0]
+    short = re.search(r'global_edge_agg_\w+<[^>]*>', k).group(0)
     out['kernels'][short] = {'FETCH_SIZE_KB': fetch, 'WRITE_SIZE_KB': write, 'launches': [n1, n2],
                               'traffic_bytes_per_launch': traffic, 'algorithmic_bytes_per_launch': a,
                               'traffic_over_algorithmic': traffic / a}
