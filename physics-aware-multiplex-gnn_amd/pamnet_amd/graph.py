@@ -295,6 +295,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     g.sign = None
     g.check = None                                # device flag word of the zero-host-sync path (see `sizes`)
     tp_pre = None
+    tp_hint = None                                # triplet + pair rows already known on the host (PDBbind)
     hinted = False
     if sizes is not None and dataset != 'QM9':
         raise ValueError('`sizes` is implemented for the QM9 path only')
@@ -342,8 +343,27 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
         pos = xr[:, :3].to(torch.float32).contiguous()
         g.sign = torch.where(pos[:, 0] > 40.0, -torch.ones_like(pos[:, 0]), torch.ones_like(pos[:, 0])).contiguous()
-        gp, gn, gd = radius_graph(pos, node_graph, g.gptr, cutoff_g)
-        lp, l_src, l_dist = csr_filter(gp, gn, gd, cutoff_l, _input_flag(node_graph, g.n_graphs))   # models.py:131-134
+        # ONE host round trip for all three data-dependent sizes.  The local graph (global edges with dist <= cutoff_l,
+        # models.py:131-134) is the radius graph at cutoff_l, so its per-node degrees come from a second count pass over
+        # the positions instead of from the filled global graph; and because a radius graph is symmetric, the number of
+        # triplet / pair rows follows from the degrees alone: every edge (j -> i) has deg(j) - 1 triplets (edges k -> j,
+        # k != i) and deg(i) pairs (edges j' -> i, itself included; models.py:68-98).
+        gptr_g = radius_count(pos, node_graph, g.gptr, cutoff_g)
+        local = cutoff_l <= cutoff_g
+        if local:
+            lp = radius_count(pos, node_graph, g.gptr, cutoff_l)
+            deg = (lp[1:] - lp[:-1]).long()
+            tp_dev = (deg * deg + (deg * (deg - 1) if with_triplets else 0)).sum()
+            total_g, total_l, tp_total, bad = host_ints(gptr_g[-1], lp[-1], tp_dev, _input_flag(node_graph, g.n_graphs))
+            if bad:
+                _raise_bad_inputs()
+            gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g)
+            lp, l_src, l_dist = _filter_fill(gp, gn, gd, cutoff_l, lp, total_l)
+            tp_hint = tp_total
+        else:                                     # (a local cutoff above the global one: the general, dependent order)
+            gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, int(gptr_g[-1]))
+            lp, l_src, l_dist = csr_filter(gp, gn, gd, cutoff_l, _input_flag(node_graph, g.n_graphs))
+            tp_hint = None
         l_dst = expand_rows(lp, l_src.numel())
     elif rna:
         xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
@@ -372,7 +392,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     wt = 1 if with_triplets else 0
     if tp_pre is None:
         tp_ptr = _triplet_ptr(lp, l_src, l_dst, with_triplets)
-        tot = int(tp_ptr[-1])
+        tot = tp_hint if tp_hint is not None else int(tp_ptr[-1])
     else:
         tp_ptr, tot = tp_pre
     tp_idx, tp_edge, tp_kind = (_alloc_i32(tot, dev, hinted) for _ in range(3))
