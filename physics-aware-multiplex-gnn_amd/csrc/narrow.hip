@@ -19,7 +19,7 @@ extern "C" int pamnet_narrow_global_fwd_f32(const float* e, int64_t m, int64_t d
     const int grid = grid_for(m, fwd_per_cu(d));
 #define CALL(DD)                                                                                                     \
     {                                                                                                                \
-        const size_t lds = 2 * (size_t)DD * DD * sizeof(float);                                                      \
+        const size_t lds = 2 * wimg_bytes(DD);                                                      \
         hipLaunchKernelGGL((nglobal_fwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, e, m, tgt, src, P, We, (int)ldwe, \
                            bias, Wea, (int)ldwea, msg);                                                              \
     }
@@ -42,7 +42,7 @@ extern "C" int pamnet_narrow_global_bwd_f32(const float* e, int64_t m, int64_t d
     const int stride = (int)(2 * d * d + d);
 #define CALL(DD)                                                                                                     \
     {                                                                                                                \
-        const size_t lds = 4 * (size_t)DD * DD * sizeof(float) + bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);      \
+        const size_t lds = 4 * wimg_bytes(DD) + bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);      \
         hipError_t e_ = allow_lds(nglobal_bwd_kernel<DD>, lds);                                                      \
         if (e_ != hipSuccess) return (int)e_;                                                                        \
         hipLaunchKernelGGL((nglobal_bwd_kernel<DD>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, e, m, tgt, src, P, We, (int)ldwe, \
@@ -72,7 +72,7 @@ extern "C" int pamnet_narrow_mlp2_fwd_f32(const float* x, int64_t m, int64_t d, 
     const int grid = grid_for(m, fwd_per_cu(d));
 #define CALL(DD)                                                                                                  \
     {                                                                                                             \
-        const size_t lds = 2 * (size_t)DD * DD * sizeof(float) + 4 * 16 * (DD + 4) * sizeof(float);               \
+        const size_t lds = 2 * wimg_bytes(DD) + 4 * 16 * (DD + 4) * sizeof(float);               \
         hipLaunchKernelGGL((nmlp2_fwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, x, m, W1, b1, W2, b2, (int)res_x, res, y); \
     }
     NARROW_DISPATCH(d, CALL)
@@ -92,7 +92,7 @@ extern "C" int pamnet_narrow_mlp2_bwd_f32(const float* x, int64_t m, int64_t d, 
     const int stride = (int)(2 * d * d + 2 * d);
 #define CALL(DD)                                                                                                       \
     {                                                                                                                  \
-        const size_t lds = 4 * (size_t)DD * DD * sizeof(float) + bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);        \
+        const size_t lds = 4 * wimg_bytes(DD) + bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);        \
         hipError_t e_ = allow_lds(nmlp2_bwd_kernel<DD>, lds);                                                          \
         if (e_ != hipSuccess) return (int)e_;                                                                          \
         hipLaunchKernelGGL((nmlp2_bwd_kernel<DD>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, x, m, W1, b1, W2, b2, dy, (int)res_x, dx, \

@@ -25,6 +25,7 @@ namespace {
 
 using pamnet::f32x4;
 using pamnet::sigmoidf_fast;
+using pamnet::Frag3;
 
 constexpr int NWG = 256;                      // forward kernels: 4 independent waves per workgroup
 // Backward kernels end with one partial gradient row per workgroup, so they run at most one workgroup per CU and get
@@ -86,6 +87,90 @@ __device__ __forceinline__ void mma_img(f32x4 (&acc)[NJ], const float4 (&a)[NQ],
         for (int jt = 0; jt < NJ; ++jt) acc[jt] = mfma4(a[q].w, b[jt].w, acc[jt]);
     }
 }
+
+// ---- the same GEMMs on the bf16 matrix pipe at fp32 accuracy (gemm_core.h "bf16x6"), K >= 32 ----------------------------
+// A row tile is owned by ONE wave from load to store, so each element is split into its three bf16 pieces exactly once, in
+// registers, where it is consumed.  k order of k-step s: the lane's two float4 A fragments 2s and 2s + 1, i.e.
+// k(t) = 32 s + 16 (t >> 2) + 4 kg + (t & 3); the image holds the weights' pieces in the same order:
+// imgb[((jt * NS + s) * 3 + piece) * 64 + lane], NS = NQ / 2 k-steps -- 1.5x the bytes of the fp32 image.
+// Six v_mfma_f32_16x16x32_bf16 (~17 cycles each) per output tile and k-step replace eight fp32 MFMAs of 32.
+template <int NJ, int NQ>
+constexpr int img_units() { return NQ >= 2 ? NJ * (NQ / 2) * 3 * 64 : NJ * NQ * 64; }     // in 16-byte units
+
+template <int NJ, int NQ, bool TRANS>
+__device__ __forceinline__ void build_image_b(uint4* img, const float* __restrict__ W, int ld, int kin) {
+    constexpr int NS = NQ / 2;
+    for (int idx = threadIdx.x; idx < NJ * NS * 64; idx += blockDim.x) {
+        const int lane = idx & 63, t = idx >> 6;
+        const int s = t % NS, jt = t / NS;
+        const int c = lane & 15, kg = lane >> 4;
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = 32 * s + 16 * (u >> 2) + 4 * kg + (u & 3);
+            if (!TRANS) v[u] = (k < kin) ? W[(size_t)(16 * jt + c) * ld + k] : 0.f;
+            else v[u] = (16 * jt + c < kin) ? W[(size_t)k * ld + 16 * jt + c] : 0.f;
+        }
+        const Frag3 f = pamnet::split_frag(v);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+            img[((jt * NS + s) * 3 + pc) * 64 + lane] = make_uint4(f.p[pc][0], f.p[pc][1], f.p[pc][2], f.p[pc][3]);
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma_b(const uint32_t (&a)[4], const uint4& b, const f32x4& c) {
+    const pamnet::u32x4 av = {a[0], a[1], a[2], a[3]}, bv = {b.x, b.y, b.z, b.w};
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pamnet::bf16x8, av), __builtin_bit_cast(pamnet::bf16x8, bv), c, 0, 0,
+                                                   0);
+}
+
+template <int NJ, int NQ>
+__device__ __forceinline__ void mma_img_b(f32x4 (&acc)[NJ], const float4 (&a)[NQ], const uint4* img, int lane) {
+    constexpr int NS = NQ / 2;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float v[8] = {a[2 * s].x, a[2 * s].y, a[2 * s].z, a[2 * s].w, a[2 * s + 1].x, a[2 * s + 1].y, a[2 * s + 1].z,
+                            a[2 * s + 1].w};
+        const Frag3 fa = pamnet::split_frag(v);
+        // two output tiles at a time: their B fragments are 24 registers, and consecutive MFMAs alternate between the two
+        // accumulators (smallest products first)
+        constexpr int JB = NJ >= 2 ? 2 : 1;
+#pragma unroll
+        for (int j0 = 0; j0 < NJ; j0 += JB) {
+            uint4 b[JB][3];
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) b[jj][pc] = img[(((j0 + jj) * NS + s) * 3 + pc) * 64 + lane];
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) acc[j0 + jj] = mfma_b(fa.p[2], b[jj][0], acc[j0 + jj]);
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) acc[j0 + jj] = mfma_b(fa.p[1], b[jj][1], acc[j0 + jj]);
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) acc[j0 + jj] = mfma_b(fa.p[0], b[jj][2], acc[j0 + jj]);
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) acc[j0 + jj] = mfma_b(fa.p[1], b[jj][0], acc[j0 + jj]);
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) acc[j0 + jj] = mfma_b(fa.p[0], b[jj][1], acc[j0 + jj]);
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) acc[j0 + jj] = mfma_b(fa.p[0], b[jj][0], acc[j0 + jj]);
+        }
+    }
+}
+
+// width dispatch: bf16x6 from K = 32 on, the fp32 MFMA for K = 16 (half a bf16 k-step)
+template <int NJ, int NQ, bool TRANS>
+__device__ __forceinline__ void build_w(float4* img, const float* __restrict__ W, int ld, int kin) {
+    if constexpr (NQ >= 2) build_image_b<NJ, NQ, TRANS>(reinterpret_cast<uint4*>(img), W, ld, kin);
+    else build_image<NJ, NQ, TRANS>(img, W, ld, kin);
+}
+template <int NJ, int NQ>
+__device__ __forceinline__ void mma_w(f32x4 (&acc)[NJ], const float4 (&a)[NQ], const float4* img, int lane) {
+    if constexpr (NQ >= 2) mma_img_b<NJ, NQ>(acc, a, reinterpret_cast<const uint4*>(img), lane);
+    else mma_img<NJ, NQ>(acc, a, img, lane);
+}
+// bytes of one [d, d] weight image as the row kernels below lay it out
+__host__ __device__ constexpr size_t wimg_bytes(int d) { return (size_t)(d >= 32 ? 6 : 4) * d * d; }
 
 template <int N>
 __device__ __forceinline__ void zero(f32x4 (&acc)[N]) {
@@ -268,8 +353,11 @@ __global__ __launch_bounds__(512) void narrow_reduce_kernel(const float* __restr
 // ====================================================================================================================
 // d = 64: capped at 256 registers so that the two workgroups a CU is given are co-resident (the unconstrained build keeps
 // both weight images in registers, 272 per lane, one wave per SIMD: 321 us against 252 us at 867 k edges)
+#ifndef NGF_CAP
+#define NGF_CAP 2
+#endif
 template <int D>
-__global__ __launch_bounds__(NWG, D == 64 ? 2 : 1) void nglobal_fwd_kernel(const float* __restrict__ e, int64_t m,
+__global__ __launch_bounds__(NWG, D == 64 ? NGF_CAP : 1) void nglobal_fwd_kernel(const float* __restrict__ e, int64_t m,
                                                           const int32_t* __restrict__ tgt, const int32_t* __restrict__ src,
                                                           const float* __restrict__ P, const float* __restrict__ We, int ldwe,
                                                           const float* __restrict__ bias, const float* __restrict__ Wea,
@@ -277,9 +365,9 @@ __global__ __launch_bounds__(NWG, D == 64 ? 2 : 1) void nglobal_fwd_kernel(const
     constexpr int NT = D / 16;
     extern __shared__ float4 lds4[];
     float4* img_e = lds4;
-    float4* img_a = lds4 + NT * NT * 64;
-    build_image<NT, NT, false>(img_e, We, ldwe, D);
-    build_image<NT, NT, false>(img_a, Wea, ldwea, D);
+    float4* img_a = lds4 + img_units<NT, NT>();
+    build_w<NT, NT, false>(img_e, We, ldwe, D);
+    build_w<NT, NT, false>(img_a, Wea, ldwea, D);
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
     const int64_t ntiles = (m + 15) / 16;
@@ -287,6 +375,9 @@ __global__ __launch_bounds__(NWG, D == 64 ? 2 : 1) void nglobal_fwd_kernel(const
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) bj[jt] = bias[16 * jt + c];
     for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        // the weight images are loop invariant: without this the compiler keeps their fragments in registers across
+        // tiles (192 at d = 64) and spills to fit the two-workgroups-per-CU cap; LDS reads are cheap, registers are not
+        asm volatile("" ::: "memory");
         const int64_t row0 = tile * 16;
         float4 a[NT];
         load_a<D>(a, e, row0, m, lane);
@@ -312,8 +403,8 @@ __global__ __launch_bounds__(NWG, D == 64 ? 2 : 1) void nglobal_fwd_kernel(const
         f32x4 q1[NT], q2[NT];
         zero(q1);
         zero(q2);
-        mma_img<NT, NT>(q1, a, img_e, lane);
-        mma_img<NT, NT>(q2, a, img_a, lane);
+        mma_w<NT, NT>(q1, a, img_e, lane);
+        mma_w<NT, NT>(q2, a, img_a, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t row = row0 + 4 * kg + r;
@@ -340,7 +431,7 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nglobal_bwd_kernel(const fl
                                                           float* __restrict__ dz_out, float* __restrict__ de,
                                                           float* __restrict__ partial, int stride, int acc_de) {
     constexpr int NT = D / 16;
-    constexpr int IMG = NT * NT * 64;
+    constexpr int IMG = img_units<NT, NT>();
     constexpr int NW = bwd_waves(D);
     extern __shared__ float4 lds4[];
     float4* img_e = lds4;
@@ -348,10 +439,10 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nglobal_bwd_kernel(const fl
     float4* img_et = lds4 + 2 * IMG;
     float4* img_at = lds4 + 3 * IMG;
     float* tile = reinterpret_cast<float*>(lds4 + 4 * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
-    build_image<NT, NT, false>(img_e, We, ldwe, D);
-    build_image<NT, NT, false>(img_a, Wea, ldwea, D);
-    build_image<NT, NT, true>(img_et, We, ldwe, D);
-    build_image<NT, NT, true>(img_at, Wea, ldwea, D);
+    build_w<NT, NT, false>(img_e, We, ldwe, D);
+    build_w<NT, NT, false>(img_a, Wea, ldwea, D);
+    build_w<NT, NT, true>(img_et, We, ldwe, D);
+    build_w<NT, NT, true>(img_at, Wea, ldwea, D);
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
     const int64_t ntiles = (m + 15) / 16;
@@ -397,8 +488,8 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nglobal_bwd_kernel(const fl
         a_to_d<D>(ed, a, tile, lane);
         zero(q1);
         zero(q2);
-        mma_img<NT, NT>(q1, a, img_e, lane);
-        mma_img<NT, NT>(q2, a, img_a, lane);
+        mma_w<NT, NT>(q1, a, img_e, lane);
+        mma_w<NT, NT>(q2, a, img_a, lane);
         // q1 -> dz, q2 -> dq2 (in place)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -420,9 +511,9 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nglobal_bwd_kernel(const fl
         f32x4 dx[NT];
         zero(dx);
         d_to_a<D>(a, q1, tile, lane);
-        mma_img<NT, NT>(dx, a, img_et, lane);
+        mma_w<NT, NT>(dx, a, img_et, lane);
         d_to_a<D>(a, q2, tile, lane);
-        mma_img<NT, NT>(dx, a, img_at, lane);
+        mma_w<NT, NT>(dx, a, img_at, lane);
         if (acc_de) {                                        // the edge embedding feeds every layer: later calls add
             load_d<D>(ed, de, row0, m, lane);
 #pragma unroll
@@ -456,13 +547,13 @@ __global__ __launch_bounds__(NWG) void nmlp2_fwd_kernel(const float* __restrict_
                                                         int res_x, const float* __restrict__ res,
                                                         float* __restrict__ y) {
     constexpr int NT = D / 16;
-    constexpr int IMG = NT * NT * 64;
+    constexpr int IMG = img_units<NT, NT>();
     extern __shared__ float4 lds4[];
     float4* img1 = lds4;
     float4* img2 = lds4 + IMG;
     float* tile = reinterpret_cast<float*>(lds4 + 2 * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
-    build_image<NT, NT, false>(img1, W1, D, D);
-    build_image<NT, NT, false>(img2, W2, D, D);
+    build_w<NT, NT, false>(img1, W1, D, D);
+    build_w<NT, NT, false>(img2, W2, D, D);
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15;
     const int64_t ntiles = (m + 15) / 16;
@@ -478,7 +569,7 @@ __global__ __launch_bounds__(NWG) void nmlp2_fwd_kernel(const float* __restrict_
         load_a<D>(a, x, row0, m, lane);
         f32x4 h[NT], o[NT];
         zero(h);
-        mma_img<NT, NT>(h, a, img1, lane);
+        mma_w<NT, NT>(h, a, img1, lane);
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -488,7 +579,7 @@ __global__ __launch_bounds__(NWG) void nmlp2_fwd_kernel(const float* __restrict_
             }
         d_to_a<D>(a, h, tile, lane);
         zero(o);
-        mma_img<NT, NT>(o, a, img2, lane);
+        mma_w<NT, NT>(o, a, img2, lane);
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -518,7 +609,7 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nmlp2_bwd_kernel(const floa
                                                         float* __restrict__ dx, float* __restrict__ partial,
                                                         int stride, int acc_dx) {
     constexpr int NT = D / 16;
-    constexpr int IMG = NT * NT * 64;
+    constexpr int IMG = img_units<NT, NT>();
     constexpr int NW = bwd_waves(D);
     extern __shared__ float4 lds4[];
     float4* img1 = lds4;
@@ -526,10 +617,10 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nmlp2_bwd_kernel(const floa
     float4* img1t = lds4 + 2 * IMG;
     float4* img2t = lds4 + 3 * IMG;
     float* tile = reinterpret_cast<float*>(lds4 + 4 * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
-    build_image<NT, NT, false>(img1, W1, D, D);
-    build_image<NT, NT, false>(img2, W2, D, D);
-    build_image<NT, NT, true>(img1t, W1, D, D);
-    build_image<NT, NT, true>(img2t, W2, D, D);
+    build_w<NT, NT, false>(img1, W1, D, D);
+    build_w<NT, NT, false>(img2, W2, D, D);
+    build_w<NT, NT, true>(img1t, W1, D, D);
+    build_w<NT, NT, true>(img2t, W2, D, D);
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15;
     const int64_t ntiles = (m + 15) / 16;
@@ -564,7 +655,7 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nmlp2_bwd_kernel(const floa
         a_to_d<D>(xd, a, tile, lane);
         a_to_d<D>(dyv, ga, tile, lane);
         zero(z1);
-        mma_img<NT, NT>(z1, a, img1, lane);
+        mma_w<NT, NT>(z1, a, img1, lane);
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -574,7 +665,7 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nmlp2_bwd_kernel(const floa
             }
         d_to_a<D>(a, h, tile, lane);
         zero(g);
-        mma_img<NT, NT>(g, a, img2, lane);                   // z2 - b2
+        mma_w<NT, NT>(g, a, img2, lane);                   // z2 - b2
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -587,7 +678,7 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nmlp2_bwd_kernel(const floa
         colsum_acc<NT>(db2, g);
         d_to_a<D>(a, g, tile, lane);
         zero(g);
-        mma_img<NT, NT>(g, a, img2t, lane);                  // dh1
+        mma_w<NT, NT>(g, a, img2t, lane);                  // dh1
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -601,7 +692,7 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nmlp2_bwd_kernel(const floa
         if (dx) {
             d_to_a<D>(a, g, tile, lane);
             zero(g);
-            mma_img<NT, NT>(g, a, img1t, lane);
+            mma_w<NT, NT>(g, a, img1t, lane);
             if (res_x) {
 #pragma unroll
                 for (int jt = 0; jt < NT; ++jt) g[jt] += dyv[jt];

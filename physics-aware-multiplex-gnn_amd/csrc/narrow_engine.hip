@@ -164,7 +164,7 @@ int launch_global_fwd(int d, const float* e, int64_t m, const int32_t* tgt, cons
     if (m == 0) return PAMNET_OK;
     const int grid = grid_for(m, fwd_per_cu(d));
 #define CALL(DD)                                                                                                       \
-    hipLaunchKernelGGL((nglobal_fwd_kernel<DD>), dim3(grid), dim3(NWG), 2 * (size_t)DD * DD * sizeof(float), st, e, m, tgt, \
+    hipLaunchKernelGGL((nglobal_fwd_kernel<DD>), dim3(grid), dim3(NWG), 2 * wimg_bytes(DD), st, e, m, tgt, \
                        src, P, We, ldwe, bias, Wea, ldwea, msg);
     NARROW_DISPATCH(d, CALL)
 #undef CALL
@@ -180,7 +180,7 @@ int launch_global_bwd(int d, const float* e, int64_t m, const int32_t* tgt, cons
     const int stride = 2 * d * d + d;
 #define CALL(DD)                                                                                                     \
     {                                                                                                                \
-        const size_t lds = 4 * (size_t)DD * DD * sizeof(float) + bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);      \
+        const size_t lds = 4 * wimg_bytes(DD) + bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);      \
         const hipError_t e_ = allow_lds(nglobal_bwd_kernel<DD>, lds);                                                \
         if (e_ != hipSuccess) return (int)e_;                                                                        \
         hipLaunchKernelGGL((nglobal_bwd_kernel<DD>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, e, m, tgt, src, P, We, \
@@ -202,7 +202,7 @@ int launch_mlp2_fwd(int d, const float* x, int64_t m, const float* W1, const flo
     const int grid = grid_for(m, fwd_per_cu(d));
 #define CALL(DD)                                                                                                  \
     {                                                                                                             \
-        const size_t lds = 2 * (size_t)DD * DD * sizeof(float) + 4 * 16 * (DD + 4) * sizeof(float);               \
+        const size_t lds = 2 * wimg_bytes(DD) + 4 * 16 * (DD + 4) * sizeof(float);               \
         hipLaunchKernelGGL((nmlp2_fwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, x, m, W1, b1, W2, b2, 0,       \
                            (const float*)nullptr, y);                                                             \
     }
@@ -219,7 +219,7 @@ int launch_mlp2_bwd(int d, const float* x, int64_t m, const float* W1, const flo
     const int stride = 2 * d * d + 2 * d;
 #define CALL(DD)                                                                                                       \
     {                                                                                                                  \
-        const size_t lds = 4 * (size_t)DD * DD * sizeof(float) + bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);        \
+        const size_t lds = 4 * wimg_bytes(DD) + bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);        \
         const hipError_t e_ = allow_lds(nmlp2_bwd_kernel<DD>, lds);                                                    \
         if (e_ != hipSuccess) return (int)e_;                                                                          \
         hipLaunchKernelGGL((nmlp2_bwd_kernel<DD>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, x, m, W1, b1, W2, b2, dy, 0, \
