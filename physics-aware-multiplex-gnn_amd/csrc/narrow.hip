@@ -118,7 +118,7 @@ extern "C" int pamnet_narrow_linear_fwd_f32(const float* x, int64_t m, int64_t d
     const int grid = grid_for(m, fwd_per_cu(d));
 #define CALL(DD)                                                                                                       \
     {                                                                                                                  \
-        const size_t lds = (size_t)DD * DD * sizeof(float);                                                            \
+        const size_t lds = wimg_bytes(DD);                                                                         \
         hipLaunchKernelGGL((nlinear_fwd_kernel<DD>), dim3(grid), dim3(NWG), lds, st, x, m, W, (int)ldw, b, (int)act, y, ldy); \
     }
     NARROW_DISPATCH(d, CALL)
@@ -139,7 +139,7 @@ extern "C" int pamnet_narrow_linear_bwd_f32(const float* x, int64_t m, int64_t d
     const int stride = (int)(d * d + d);
 #define CALL(DD)                                                                                                        \
     {                                                                                                                   \
-        const size_t lds = 2 * (size_t)DD * DD * sizeof(float) + lin_bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);         \
+        const size_t lds = 2 * wimg_bytes(DD) + lin_bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);         \
         hipLaunchKernelGGL((nlinear_bwd_kernel<DD>), dim3(grid), dim3(64 * lin_bwd_waves(DD)), lds, st, x, m, W, (int)ldw, b, (int)act, dy, lddy, \
                            dx, (int)accumulate, partial, stride);                                                       \
     }

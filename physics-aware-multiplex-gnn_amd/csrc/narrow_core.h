@@ -738,7 +738,7 @@ __global__ __launch_bounds__(NWG) void nlinear_fwd_kernel(const float* __restric
                                                           int64_t ldy) {
     constexpr int NT = D / 16;
     extern __shared__ float4 lds4[];
-    build_image<NT, NT, false>(lds4, W, ldw, D);
+    build_w<NT, NT, false>(lds4, W, ldw, D);
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15;
     const int64_t ntiles = (m + 15) / 16;
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(NWG) void nlinear_fwd_kernel(const float* __restric
         load_a<D>(a, x, row0, m, lane);
         f32x4 o[NT];
         zero(o);
-        mma_img<NT, NT>(o, a, lds4, lane);
+        mma_w<NT, NT>(o, a, lds4, lane);
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -772,14 +772,14 @@ __global__ __launch_bounds__(64 * lin_bwd_waves(D)) void nlinear_bwd_kernel(cons
                                                           float* __restrict__ dx, int accumulate,
                                                           float* __restrict__ partial, int stride) {
     constexpr int NT = D / 16;
-    constexpr int IMG = NT * NT * 64;
+    constexpr int IMG = img_units<NT, NT>();
     constexpr int NW = lin_bwd_waves(D);
     extern __shared__ float4 lds4[];
     float4* img = lds4;
     float4* imgt = lds4 + IMG;
     float* tile = reinterpret_cast<float*>(lds4 + 2 * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
-    build_image<NT, NT, false>(img, W, ldw, D);
-    build_image<NT, NT, true>(imgt, W, ldw, D);
+    build_w<NT, NT, false>(img, W, ldw, D);
+    build_w<NT, NT, true>(imgt, W, ldw, D);
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15;
     const int64_t ntiles = (m + 15) / 16;
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(64 * lin_bwd_waves(D)) void nlinear_bwd_kernel(cons
         if (act) {
             f32x4 z[NT];
             zero(z);
-            mma_img<NT, NT>(z, a, img, lane);
+            mma_w<NT, NT>(z, a, img, lane);
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(64 * lin_bwd_waves(D)) void nlinear_bwd_kernel(cons
         if (dx) {
             d_to_a<D>(a, g, tile, lane);
             zero(g);
-            mma_img<NT, NT>(g, a, imgt, lane);
+            mma_w<NT, NT>(g, a, imgt, lane);
             if (accumulate) {
                 load_d<D>(xd, dx, row0, m, lane);
 #pragma unroll

@@ -243,7 +243,7 @@ int launch_qblock_bwd(int d, const float* x, int64_t m, const float* W, int ldw,
     const int grid = grid_for(m, 1, lin_bwd_waves(d));
 #define CALL(DD)                                                                                                        \
     {                                                                                                                   \
-        const size_t lds = 2 * (size_t)DD * DD * sizeof(float) + lin_bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);     \
+        const size_t lds = 2 * wimg_bytes(DD) + lin_bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);     \
         hipLaunchKernelGGL((nlinear_bwd_kernel<DD>), dim3(grid), dim3(64 * lin_bwd_waves(DD)), lds, st, x, m, W, ldw,   \
                            (const float*)nullptr, 0, dy, lddy, dx, accumulate, partial, stride);                        \
     }
