@@ -36,9 +36,29 @@ def run_target(args, cfg, target, dev, world, rank):
     steps_per_epoch = args.train // gb
     sched = WarmupExpLR(args.lr, gamma=0.9961697, steps_per_epoch=args.train / gb)
 
-    def train_batch(step):                                         # this rank's shard of global batch `step`
-        lo, hi = shard_range(gb, rank, world)
-        return synth.qm9_batch(args.seed, step * gb + lo, hi - lo, target=target).to(dev)
+    lo, hi = shard_range(gb, rank, world)
+    if args.resident:
+        # the dataset lives on the device (QM9 itself: 134 k molecules, ~60 MB); batches are collated there by one gather
+        # launch and carry their data-dependent sizes, so a step issues no device->host read (pamnet_amd/store.py)
+        import numpy as np
+        from pamnet_amd.store import MoleculeStore
+        col = target + 5 if target in (7, 8, 9, 10) else target      # main_qm9.py:60-66
+        labels = synth.qm9_label_table(args.seed, 0, args.train)[:, col]
+        mols = []
+        for i in range(args.train):
+            m = synth.qm9_molecule(args.seed, i)
+            m['y'] = np.float32(labels[i])
+            mols.append(m)
+        store = MoleculeStore(mols, dev).prepare_for(model)
+        order = {'epoch': -1, 'perm': None}
+
+        def train_batch(step, epoch=0):                             # this rank's shard of global batch `step`
+            if order['epoch'] != epoch:                             # DataLoader(shuffle=True): same permutation on every rank
+                order['epoch'], order['perm'] = epoch, np.random.default_rng(args.seed + epoch).permutation(args.train)
+            return store.collate(order['perm'][step * gb + lo:step * gb + hi])
+    else:
+        def train_batch(step, epoch=0):
+            return synth.qm9_batch(args.seed, step * gb + lo, hi - lo, target=target).to(dev)
 
     vlo, vhi = shard_range(args.val, rank, world)
     val = [synth.qm9_batch(args.seed + 1, args.train + vlo + i, min(gb, vhi - vlo - i), target=target).to(dev)
@@ -48,9 +68,9 @@ def run_target(args, cfg, target, dev, world, rank):
     for epoch in range(args.epochs):
         model.train()
         loss_sum = torch.zeros((), device=dev)
-        nxt = train_batch(0)
+        nxt = train_batch(0, epoch)
         for step in range(steps_per_epoch):
-            data, nxt = nxt, (train_batch(step + 1) if step + 1 < steps_per_epoch else None)
+            data, nxt = nxt, (train_batch(step + 1, epoch) if step + 1 < steps_per_epoch else None)
             # the LR the reference's optimiser has AT this step (scheduler stepped after optimizer.step, main_qm9.py:112-114)
             loss = trainer.step(data, lr=sched.lr_for_step(epoch, step, steps_per_epoch), global_graphs=gb, next_data=nxt)
             loss_sum += loss.detach() * data.num_graphs
@@ -85,6 +105,8 @@ def main():
     ap.add_argument('--target', default='7', help="index of the target (0-11; 7-10 read label columns 12-15 as in "
                     "main_qm9.py:60-66), or 'all': the 12 targets one after the other (BASELINE configs[2])")
     ap.add_argument('--save', default='')
+    ap.add_argument('--resident', action='store_true', help='keep the training set on the device and collate batches there '
+                    '(pamnet_amd.store.MoleculeStore): no device->host read per step; shuffled every epoch')
     args = ap.parse_args()
 
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
