@@ -372,7 +372,7 @@ def main():
     # sizes as host integers (per-molecule counts taken once per dataset) -- graph construction reads nothing back.
     # Reported beside the classic numbers, never as `value`.
     zero_sync = None
-    if not args.cpu_dry_run:
+    if not args.cpu_dry_run and world == 1:       # a side measurement: single-GPU runs only (nothing the scaling runs need)
         from pamnet_amd.store import MoleculeStore
         lo, hi = shard_range(gB, rank, world)
         mols = [synth.qm9_molecule(0, k * gB + lo + i) for k in range(args.n_batches) for i in range(B)]
