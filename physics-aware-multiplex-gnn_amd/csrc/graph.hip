@@ -5,6 +5,8 @@
 //   * triplet (k->j->i) / pair (j,j'->i) enumeration with their angles (models.py:68-98, 165-177)
 // Integer work: bit-exact against the oracle.  Everything is two-pass (count -> caller scans -> fill), atomics are
 // used only for histogram counts and slot claiming whose result is re-sorted, so outputs are deterministic.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -162,6 +164,104 @@ __global__ __launch_bounds__(256) void sort_rows_kernel(const int32_t* __restric
     }
     for (; t < end; ++t) rank += (perm_tmp[t] < v) ? 1 : 0;
     perm[beg + rank] = v;
+}
+
+// ---- small inputs: ONE single-workgroup launch ------------------------------------------------------------------------
+// At molecule-batch sizes (a few thousand rows, tens of thousands of keys) the multi-launch forms above are 3 / 9 launches
+// of up to ~130 workgroups each, issued on the input pipeline's side stream while the training step runs: every one of
+// them takes CUs away from main-stream kernels that were balanced for exactly 256 (measured: 125 us of a 2.50 ms step,
+// tools/noprefetch_bound.py).  One workgroup does the whole scan / the whole stable counting sort on one CU instead;
+// results are identical (same stable order), so the large-input forms remain the reference in the tests.
+constexpr int SMALL_THREADS = 1024;
+constexpr int SMALL_SCAN_MAX = 1 << 16;       // elements
+constexpr int SMALL_CSR_ROWS = 12288;         // rows (counters live in LDS)
+constexpr int SMALL_CSR_KEYS = 1 << 16;
+
+// block-wide exclusive scan step: returns the exclusive prefix of x over the workgroup and its total (wt: 16 ints of LDS)
+__device__ __forceinline__ int block_excl_scan(int x, int* wt, int& total) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int incl = wave_incl_scan(x, lane);
+    __syncthreads();                                          // wt may still be read from the previous call
+    if (lane == 63) wt[w] = incl;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < SMALL_THREADS / 64; ++k) {
+        const int v = wt[k];
+        off += (k < w) ? v : 0;
+        tot += v;
+    }
+    total = tot;
+    return off + incl - x;
+}
+
+__global__ __launch_bounds__(SMALL_THREADS) void scan_small_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out,
+                                                                   int n) {
+    __shared__ int wt[SMALL_THREADS / 64];
+    int carry = 0;
+    if (threadIdx.x == 0) out[0] = 0;
+    for (int base = 0; base < n; base += SMALL_THREADS) {
+        const int g = base + (int)threadIdx.x;
+        const int x = g < n ? in[g] : 0;
+        int total;
+        const int ex = block_excl_scan(x, wt, total);
+        if (g < n) out[g + 1] = carry + ex + x;
+        carry += total;
+    }
+}
+
+// ptr / perm of pamnet_csr_from_keys_i32 for m <= SMALL_CSR_KEYS keys over rows <= SMALL_CSR_ROWS rows
+__global__ __launch_bounds__(SMALL_THREADS) void csr_small_kernel(const int32_t* __restrict__ keys, int m, int rows,
+                                                                  int32_t* __restrict__ ptr, int32_t* __restrict__ perm,
+                                                                  int32_t* __restrict__ perm_tmp) {
+    __shared__ int cnt[SMALL_CSR_ROWS];                       // histogram, then the rows' write cursors
+    __shared__ int wt[SMALL_THREADS / 64];
+    __shared__ int unsorted;
+    const int tid = threadIdx.x;
+    for (int r = tid; r < rows; r += SMALL_THREADS) cnt[r] = 0;
+    if (tid == 0) unsorted = 0;
+    __syncthreads();
+    bool dec = false;
+    for (int k = tid; k < m; k += SMALL_THREADS) {
+        const int key = keys[k];
+        if ((unsigned)key < (unsigned)rows) atomicAdd(&cnt[key], 1);
+        if (k + 1 < m && keys[k + 1] < key) dec = true;
+    }
+    if (dec) unsorted = 1;
+    __syncthreads();
+    // exclusive scan of the histogram -> ptr (global) and the cursors (in place)
+    int carry = 0;
+    if (tid == 0) ptr[0] = 0;
+    for (int base = 0; base < rows; base += SMALL_THREADS) {
+        const int r = base + tid;
+        const int x = r < rows ? cnt[r] : 0;
+        int total;
+        const int ex = block_excl_scan(x, wt, total);
+        if (r < rows) {
+            cnt[r] = carry + ex;
+            ptr[r + 1] = carry + ex + x;
+        }
+        carry += total;
+    }
+    __syncthreads();
+    if (!unsorted) {                                          // sorted keys: the stable permutation is the identity
+        for (int k = tid; k < m; k += SMALL_THREADS) perm[k] = k;
+        return;
+    }
+    for (int k = tid; k < m; k += SMALL_THREADS) {            // claim a slot (any order inside a row) ...
+        const int key = keys[k];
+        if ((unsigned)key < (unsigned)rows) perm_tmp[atomicAdd(&cnt[key], 1)] = k;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int q = tid; q < carry; q += SMALL_THREADS) {        // ... then rank every entry inside its row: ascending indices
+        const int v = perm_tmp[q];
+        const int r = keys[v];
+        const int beg = ptr[r], end = ptr[r + 1];
+        int rank = 0;
+        for (int t = beg; t < end; ++t) rank += (perm_tmp[t] < v) ? 1 : 0;
+        perm[beg + rank] = v;
+    }
 }
 
 __device__ __forceinline__ float dist3(const float* __restrict__ pos, int64_t a, int64_t b) {
@@ -543,6 +643,11 @@ __global__ __launch_bounds__(256) void triplet_fill_kernel(const float* __restri
 }
 
 inline unsigned blocks_for(int64_t n, int per = 256) { return (unsigned)(n > 0 ? ceil_div(n, per) : 1); }
+// PAMNET_SMALL_FORMS=0: always the multi-launch scan / counting sort (the tests compare the two)
+inline bool small_forms() {
+    static bool v = [] { const char* e = getenv("PAMNET_SMALL_FORMS"); return !e || atoi(e) != 0; }();
+    return v;
+}
 
 }  // namespace
 
@@ -554,6 +659,11 @@ extern "C" int pamnet_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_
     if (n == 0) {
         hipError_t e = hipMemsetAsync(out, 0, sizeof(int32_t), st);
         return (int)e;
+    }
+    if (n <= SMALL_SCAN_MAX && small_forms()) {
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(SMALL_THREADS), 0, st, in, out, (int)n);
+        PAMNET_LAUNCH_CHECK();
+        return PAMNET_OK;
     }
     const int64_t nb = ceil_div(n, SCAN_CHUNK);
     hipLaunchKernelGGL(scan_chunk_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, out, n, tmp);
@@ -570,6 +680,11 @@ extern "C" int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t 
     if (m < 0 || rows <= 0) return PAMNET_EINVAL;
     if (!ptr || !cursor || !tmp || (m > 0 && (!keys || !perm || !perm_tmp))) return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
+    if (m > 0 && m <= SMALL_CSR_KEYS && rows <= SMALL_CSR_ROWS && small_forms()) {
+        hipLaunchKernelGGL(csr_small_kernel, dim3(1), dim3(SMALL_THREADS), 0, st, keys, (int)m, (int)rows, ptr, perm, perm_tmp);
+        PAMNET_LAUNCH_CHECK();
+        return PAMNET_OK;
+    }
     hipError_t e = hipMemsetAsync(cursor, 0, sizeof(int32_t) * rows, st);
     if (e != hipSuccess) return (int)e;
     int32_t* unsorted = tmp + ceil_div(rows, SCAN_CHUNK);    // the spare int behind the scan's chunk sums

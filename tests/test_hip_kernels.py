@@ -122,7 +122,7 @@ def test_segment_ops_autograd(dev):
         assert maxnorm_err(a.cpu(), b.cpu()) < 2e-6
 
 
-@pytest.mark.parametrize('n', [0, 1, 5, 4096, 4097, 100000, 1 << 20])
+@pytest.mark.parametrize('n', [0, 1, 5, 1023, 1024, 1025, 4096, 4097, 65535, 65536, 65537, 100000, 1 << 20])
 def test_exclusive_scan_bit_exact(dev, n):
     from pamnet_amd import graph as G
     x = torch.randint(0, 50, (n,), dtype=torch.int32, device=dev)
@@ -131,10 +131,15 @@ def test_exclusive_scan_bit_exact(dev, n):
     assert torch.equal(out.long(), ref)
 
 
-@pytest.mark.parametrize('m,rows', [(0, 3), (10, 1), (5000, 700), (200000, 50), (100000, 100000)])
-def test_csr_from_keys_stable(dev, m, rows):
+@pytest.mark.parametrize('m,rows', [(0, 3), (10, 1), (5000, 700), (200000, 50), (100000, 100000),
+                                    # either side of the single-workgroup form's limits (65 536 keys, 12 288 rows)
+                                    (65536, 12288), (65537, 100), (40000, 12289), (33000, 2300), (1, 12288)])
+@pytest.mark.parametrize('order', ['random', 'sorted'])
+def test_csr_from_keys_stable(dev, m, rows, order):
     from pamnet_amd import graph as G
     keys = torch.randint(0, rows, (m,), dtype=torch.int32, device=dev)
+    if order == 'sorted':
+        keys = torch.sort(keys).values.contiguous()          # the identity-permutation path
     ptr, perm = G.csr_from_keys(keys, rows)
     ref_perm = torch.sort(keys.long(), stable=True).indices
     assert torch.equal(perm.long(), ref_perm)
