@@ -135,6 +135,10 @@ int pamnet_triplet_fill_f32(const float* pos, const int32_t* lptr, const int32_t
  *   src_eptr, bonds with graph-local endpoints): node features [n_out, x_width], positions (nullable), int32 batch
  *   vector, bonds with batch-level endpoints.  out_nptr / out_eptr: the batch's prefix sums (device, n_graphs + 1).
  * ------------------------------------------------------------------------------------------------------------------ */
+/* out[k] (device int64) = *src[k], read as int32 (kind 0), bool / uint8 (1) or int64 (2); n <= 8.  The data-dependent sizes
+ * of a batch in one launch, ahead of the one device->host copy graph construction makes. */
+int pamnet_gather_scalars_i64(int64_t n, const void* const* src /* host array of device ptrs */,
+                              const int32_t* kind /* host */, int64_t* out, pamnet_stream_t stream);
 int pamnet_check_sizes_i32(int64_t n_checks, const int32_t* const* actual /* host array of device ptrs */,
                            const int64_t* expected /* host */, const void* all_kept, int32_t* flag,
                            pamnet_stream_t stream);

@@ -809,6 +809,42 @@ extern "C" int pamnet_triplet_fill_f32(const float* pos, const int32_t* lptr, co
 }
 
 
+// ---- data-dependent sizes to the host in one launch + one copy --------------------------------------------------------------
+// out[k] = the k-th scalar (int32 or bool, by `kind`): graph construction reads 3-4 device scalars back per batch; as torch
+// expressions that was four casts, a stack and the copy.
+namespace {
+struct ScalarGather {
+    const void* src[8];
+    int kind[8];              // 0: int32, 1: bool / uint8, 2: int64
+    int n;
+};
+__global__ void gather_scalars_kernel(ScalarGather g, int64_t* __restrict__ out) {
+    const int k = threadIdx.x;
+    if (k >= g.n) return;
+    int64_t v;
+    if (g.kind[k] == 0) v = *static_cast<const int32_t*>(g.src[k]);
+    else if (g.kind[k] == 1) v = *static_cast<const uint8_t*>(g.src[k]);
+    else v = *static_cast<const int64_t*>(g.src[k]);
+    out[k] = v;
+}
+}  // namespace
+
+extern "C" int pamnet_gather_scalars_i64(int64_t n, const void* const* src, const int32_t* kind, int64_t* out,
+                                         pamnet_stream_t stream) {
+    if (n < 1 || n > 8) return PAMNET_EINVAL;
+    if (!src || !kind || !out) return PAMNET_ENULL;
+    ScalarGather g;
+    g.n = (int)n;
+    for (int k = 0; k < g.n; ++k) {
+        if (!src[k] || kind[k] < 0 || kind[k] > 2) return PAMNET_EINVAL;
+        g.src[k] = src[k];
+        g.kind[k] = kind[k];
+    }
+    hipLaunchKernelGGL(gather_scalars_kernel, dim3(1), dim3(8), 0, as_stream(stream), g, out);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
 // ---- deferred size check (zero-host-sync graph construction) -----------------------------------------------------------
 // A batch collated from a resident dataset carries its data-dependent sizes (global edges, triplet / pair rows) as host
 // integers summed from per-graph counts taken once per dataset (pamnet_amd/store.py), so graph construction needs no

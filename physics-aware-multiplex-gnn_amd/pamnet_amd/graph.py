@@ -76,7 +76,23 @@ def expand_rows(ptr, total, zeroed=False):
 def host_ints(*scalars):
     """Data-dependent sizes come back to the host in ONE round trip: every call is a stream synchronisation that drains
     the launch queue, and forward-only runs are bound by exactly these."""
-    return [int(v) for v in torch.stack([s.reshape(()).to(torch.int64) for s in scalars]).tolist()]
+    import ctypes
+    n = len(scalars)
+    ts = [s.reshape(-1)[:1] for s in scalars]
+    kinds = []
+    for t in ts:
+        if t.dtype == torch.int32:
+            kinds.append(0)
+        elif t.dtype in (torch.bool, torch.uint8):
+            kinds.append(1)
+        elif t.dtype == torch.int64:
+            kinds.append(2)
+        else:
+            raise TypeError('host_ints: unsupported dtype %s' % t.dtype)
+    out = torch.empty(n, dtype=torch.int64, device=ts[0].device)
+    lib.call('pamnet_gather_scalars_i64', n, (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts]),
+             (ctypes.c_int32 * n)(*kinds), lib.ptr(out), lib.stream_of(out))
+    return [int(v) for v in out.tolist()]
 
 
 def _filter_count(ptr_in, nbr, dist, cut):
