@@ -132,8 +132,8 @@ def test_exclusive_scan_bit_exact(dev, n):
 
 
 @pytest.mark.parametrize('m,rows', [(0, 3), (10, 1), (5000, 700), (200000, 50), (100000, 100000),
-                                    # either side of the single-workgroup form's limits (65 536 keys, 12 288 rows)
-                                    (65536, 12288), (65537, 100), (40000, 12289), (33000, 2300), (1, 12288)])
+                                    # either side of the single-workgroup form's limits (8 192 keys, 12 288 rows)
+                                    (8192, 12288), (8193, 100), (8000, 12289), (33000, 2300), (1, 12288), (4316, 2286)])
 @pytest.mark.parametrize('order', ['random', 'sorted'])
 def test_csr_from_keys_stable(dev, m, rows, order):
     from pamnet_amd import graph as G
