@@ -135,6 +135,11 @@ int pamnet_triplet_fill_f32(const float* pos, const int32_t* lptr, const int32_t
  *   src_eptr, bonds with graph-local endpoints): node features [n_out, x_width], positions (nullable), int32 batch
  *   vector, bonds with batch-level endpoints.  out_nptr / out_eptr: the batch's prefix sums (device, n_graphs + 1).
  * ------------------------------------------------------------------------------------------------------------------ */
+/* Transposed CSR of a SYMMETRIC graph stored by target with ascending columns (radius graphs): rev[e] = position of the
+ * reverse edge of e; (ptr, rev) equals what pamnet_csr_from_keys_i32(col) returns as (ptr, perm).  flag (nullable):
+ * bit 64 is set if an edge has no reverse. */
+int pamnet_reverse_edges_i32(const int32_t* ptr, const int32_t* row_of, const int32_t* col, int64_t m, int32_t* rev,
+                             int32_t* flag, pamnet_stream_t stream);
 /* out[k] (device int64) = *src[k], read as int32 (kind 0), bool / uint8 (1) or int64 (2); n <= 8.  The data-dependent sizes
  * of a batch in one launch, ahead of the one device->host copy graph construction makes. */
 int pamnet_gather_scalars_i64(int64_t n, const void* const* src /* host array of device ptrs */,

@@ -818,6 +818,41 @@ extern "C" int pamnet_triplet_fill_f32(const float* pos, const int32_t* lptr, co
 }
 
 
+// ---- transposed CSR of a symmetric graph = the reverse-edge index --------------------------------------------------------
+// Rows = aggregation targets i, columns j ascending inside a row (radius graphs: pamnet_radius_fill_i32).  The transposed
+// CSR the backward needs (for every source j the positions q with col[q] = j, ascending q: what pamnet_csr_from_keys_i32
+// returns for keys = col) has, for a symmetric graph, the same pointer array, and its k-th entry of row j -- j's k-th
+// neighbour i_k -- is the position of the edge with column j in row i_k: the reverse edge.  One bisection per edge replaces
+// a nine-launch counting sort over E keys.  flag[0] |= 64 if some edge has no reverse (not a symmetric graph).
+namespace {
+__global__ __launch_bounds__(256) void reverse_edges_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ row_of,
+                                                            const int32_t* __restrict__ col, int64_t m,
+                                                            int32_t* __restrict__ rev, int32_t* __restrict__ flag) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m) return;
+    const int i = row_of[e], j = col[e];
+    int lo = ptr[j], hi = ptr[j + 1];                        // find i in row j
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (col[mid] < i) lo = mid + 1;
+        else hi = mid;
+    }
+    const bool found = lo < ptr[j + 1] && col[lo] == i;
+    rev[e] = found ? lo : (int32_t)e;
+    if (!found && flag) atomicOr(flag, 64);
+}
+}  // namespace
+
+extern "C" int pamnet_reverse_edges_i32(const int32_t* ptr, const int32_t* row_of, const int32_t* col, int64_t m,
+                                        int32_t* rev, int32_t* flag, pamnet_stream_t stream) {
+    if (m < 0) return PAMNET_EINVAL;
+    if (m == 0) return PAMNET_OK;
+    if (!ptr || !row_of || !col || !rev) return PAMNET_ENULL;
+    hipLaunchKernelGGL(reverse_edges_kernel, dim3(blocks_for(m)), dim3(256), 0, as_stream(stream), ptr, row_of, col, m, rev, flag);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
 // ---- data-dependent sizes to the host in one launch + one copy --------------------------------------------------------------
 // out[k] = the k-th scalar (int32 or bool, by `kind`): graph construction reads 3-4 device scalars back per batch; as torch
 // expressions that was four casts, a stack and the copy.

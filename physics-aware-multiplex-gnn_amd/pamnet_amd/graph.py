@@ -158,6 +158,19 @@ class Transpose(object):
         self.rows = rows
 
 
+class SymmetricTranspose(object):
+    """Transposed CSR of a symmetric graph (a radius graph: rows = targets, ascending columns): the pointer array is
+    the graph's own, the permutation is the reverse-edge index -- one bisection per edge (pamnet_reverse_edges_i32)
+    instead of a counting sort over the edges.  Same (ptr, perm) as Transpose(csr.col, rows)."""
+    __slots__ = ('ptr', 'perm', 'rows')
+
+    def __init__(self, csr):
+        self.ptr, self.rows = csr.ptr, csr.rows
+        self.perm = _i32(csr.m, csr.ptr.device)
+        lib.call('pamnet_reverse_edges_i32', lib.ptr(csr.ptr), lib.ptr(csr.row_of), lib.ptr(csr.col), csr.m,
+                 lib.ptr(self.perm), None, lib.stream_of(csr.ptr))
+
+
 class _NoTransposeT(object):
     ptr = perm = None
 
@@ -420,8 +433,10 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
 
     g.glob_T = g.loc_T = g.tp_T = _NoTranspose    # forward-only: backward index structures are not built
     if need_grad:
-        g.glob_T = Transpose(g.glob.col, n)           # d x[j] of the global gather
-        g.loc_T = Transpose(g.loc.col, n)             # d x[j] of the local gather
+        radius_g = dataset in ('QM9', 'PDBbind')       # symmetric by construction (the kNN graphs of the RNA path are not)
+        g.glob_T = SymmetricTranspose(g.glob) if radius_g else Transpose(g.glob.col, n)       # d x[j] of the global gather
+        # the local graph: a radius graph for PDBbind; user-supplied bonds (QM9) and kNN cuts (RNA) take the counting sort
+        g.loc_T = SymmetricTranspose(g.loc) if dataset == 'PDBbind' else Transpose(g.loc.col, n)   # d x[j] of the local gather
         g.tp_T = Transpose(tp_idx, max(e_l, 1))       # d m_neighbor[e'] of the triplet/pair gather
     return g
 

@@ -474,3 +474,22 @@ def test_wgrad_batched_vs_fp64(dev, rows):
         assert e <= max(2e-7, 2 * floor), (e, floor)
         assert maxnorm_err(db.cpu(), b64.cpu()) < 2e-6
     print('wgrad bf16x6: worst error / fp32-matmul error = %.2f' % worst)
+
+
+@pytest.mark.parametrize('kind', ['QM9', 'PDBbind'])
+def test_symmetric_transpose_equals_counting_sort(dev, kind):
+    """The transposed CSR of a radius graph taken as its reverse-edge index (one bisection per edge) is bit for bit what
+    the stable counting sort over the columns returns."""
+    from pamnet_amd import graph as G, synth
+    if kind == 'QM9':
+        b = synth.qm9_batch(11, 0, 64).to(dev)
+        g = G.build_graph('QM9', 5.0, 5.0, 'source_to_target', b.x, b.batch, b.pos, b.edge_index, num_graphs=64)
+        pairs = [(g.glob, g.glob_T)]
+    else:
+        b = synth.pdbbind_batch(3, 0, 4).to(dev)
+        g = G.build_graph('PDBbind', 2.0, 6.0, 'source_to_target', b.x, b.batch, num_graphs=4)
+        pairs = [(g.glob, g.glob_T), (g.loc, g.loc_T)]
+    for csr, tr in pairs:
+        assert isinstance(tr, G.SymmetricTranspose)
+        ref = G.Transpose(csr.col, g.n)
+        assert torch.equal(tr.ptr, ref.ptr) and torch.equal(tr.perm, ref.perm)
