@@ -354,8 +354,15 @@ __device__ __forceinline__ f32x4 mfma_u4(const uint4& a, const uint4& b, const f
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
 }
 // acc[t] += tile(planes at `in`) x slice t of `f`: 4 k-steps x 6 products x 2 tiles, small products first
+// Slot of (row rho, row-group kg) inside a 1 KB image: 4 rho + ((kg + 2 (rho >> 3)) & 3).  The four kg chunks of a row are
+// neighbours, so the 32 lanes of an epilogue store group (two rows, all kg, four dwords) see a 2-way bank conflict, which
+// ds_write_b32 absorbs, where the lane-linear order (rho + 16 kg) makes it 4-way; the rotation by 2 (rho >> 3) keeps the
+// 16-lane groups of the readers' ds_read_b128 on 16 distinct slots modulo 16.  (Measured: no difference -- the epilogue of
+// this kernel is longer than the fp32 form's by the issue of 8 more weight loads and ~70 more VALU, not by LDS conflicts.)
+__device__ __forceinline__ int plane_slot(int rho, int kg) { return 4 * rho + ((kg + 2 * (rho >> 3)) & 3); }
+
 __device__ __forceinline__ void mma_planes(const char* __restrict__ in, const WFragB& f, f32x4 (&acc)[2]) {
-    const uint4* ip = reinterpret_cast<const uint4*>(in) + (threadIdx.x & 63);
+    const uint4* ip = reinterpret_cast<const uint4*>(in) + plane_slot(threadIdx.x & 15, (threadIdx.x & 63) >> 4);
     uint4 az[4][3];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -381,7 +388,7 @@ __device__ __forceinline__ void mma_planes(const char* __restrict__ in, const WF
 __device__ __forceinline__ void st_pair_planes(char* __restrict__ dst, int w, int rw, int r16, float a0, float a1) {
     uint32_t p0, p1, p2;
     split3(a0, a1, p0, p1, p2);
-    char* d = dst + w * 1024 + (rw + 16 * (r16 >> 2)) * 16 + (r16 & 3) * 4;
+    char* d = dst + w * 1024 + plane_slot(rw, r16 >> 2) * 16 + (r16 & 3) * 4;
     *reinterpret_cast<uint32_t*>(d) = p0;
     *reinterpret_cast<uint32_t*>(d + 4096) = p1;
     *reinterpret_cast<uint32_t*>(d + 8192) = p2;
@@ -392,7 +399,7 @@ __device__ __forceinline__ void st_elem_planes(char* __restrict__ dst, int r, in
     uint32_t p0, p1, p2;
     split3(x[0], x[1], p0, p1, p2);
     const int q = c >> 5, n2 = (c >> 4) & 1, r16 = c & 15;
-    char* d = dst + q * 1024 + (r + 16 * (r16 >> 2)) * 16 + (r16 & 3) * 4 + 2 * n2;
+    char* d = dst + q * 1024 + plane_slot(r, r16 >> 2) * 16 + (r16 & 3) * 4 + 2 * n2;
     *reinterpret_cast<uint16_t*>(d) = (uint16_t)p0;
     *reinterpret_cast<uint16_t*>(d + 4096) = (uint16_t)p1;
     *reinterpret_cast<uint16_t*>(d + 8192) = (uint16_t)p2;
