@@ -88,7 +88,8 @@ int pamnet_expand_rows_i32(const int32_t* ptr, int64_t rows, int32_t* row_of, in
 int pamnet_csr_filter_count_i32(const int32_t* ptr_in, const int32_t* nbr, const float* dist, int64_t rows, float cut,
                                 int32_t* count, pamnet_stream_t stream);
 int pamnet_csr_filter_fill_i32(const int32_t* ptr_in, const int32_t* nbr, const float* dist, int64_t rows, float cut,
-                               const int32_t* ptr_out, int32_t* nbr_out, float* dist_out, pamnet_stream_t stream);
+                               const int32_t* ptr_out, int32_t* nbr_out, float* dist_out, int64_t cap,
+                               pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Neighbour search (torch_cluster.radius / knn: models.py:110,128,143,301), self loops removed (models.py:63).

@@ -556,7 +556,8 @@ __global__ __launch_bounds__(256) void csr_filter_kernel(const int32_t* __restri
                                                          const float* __restrict__ dist, int64_t rows, float cut,
                                                          int32_t* __restrict__ count,
                                                          const int32_t* __restrict__ ptr_out,
-                                                         int32_t* __restrict__ nbr_out, float* __restrict__ dist_out) {
+                                                         int32_t* __restrict__ nbr_out, float* __restrict__ dist_out,
+                                                         int64_t cap) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     int c = 0;
@@ -565,7 +566,10 @@ __global__ __launch_bounds__(256) void csr_filter_kernel(const int32_t* __restri
         const int j = nbr[q];
         const float d = dist[q];
         if (j >= 0 && d <= cut) {
-            if (FILL) { nbr_out[w] = j; dist_out[w] = d; ++w; }
+            if (FILL) {
+                if (w < cap) { nbr_out[w] = j; dist_out[w] = d; }
+                ++w;
+            }
             ++c;
         }
     }
@@ -765,19 +769,19 @@ extern "C" int pamnet_csr_filter_count_i32(const int32_t* ptr_in, const int32_t*
     if (rows == 0) return PAMNET_OK;
     if (!ptr_in || !nbr || !dist || !count) return PAMNET_ENULL;
     hipLaunchKernelGGL((csr_filter_kernel<false>), dim3(blocks_for(rows)), dim3(256), 0, as_stream(stream), ptr_in, nbr,
-                       dist, rows, cut, count, (const int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr);
+                       dist, rows, cut, count, (const int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (int64_t)0);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
 
 extern "C" int pamnet_csr_filter_fill_i32(const int32_t* ptr_in, const int32_t* nbr, const float* dist, int64_t rows,
                                           float cut, const int32_t* ptr_out, int32_t* nbr_out, float* dist_out,
-                                          pamnet_stream_t stream) {
-    if (rows < 0) return PAMNET_EINVAL;
+                                          int64_t cap, pamnet_stream_t stream) {
+    if (rows < 0 || cap < 0) return PAMNET_EINVAL;
     if (rows == 0) return PAMNET_OK;
     if (!ptr_in || !nbr || !dist || !ptr_out || !nbr_out || !dist_out) return PAMNET_ENULL;
     hipLaunchKernelGGL((csr_filter_kernel<true>), dim3(blocks_for(rows)), dim3(256), 0, as_stream(stream), ptr_in, nbr,
-                       dist, rows, cut, (int32_t*)nullptr, ptr_out, nbr_out, dist_out);
+                       dist, rows, cut, (int32_t*)nullptr, ptr_out, nbr_out, dist_out, cap);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

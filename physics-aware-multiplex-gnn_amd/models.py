@@ -118,12 +118,12 @@ class _PAMNetBase(nn.Module):
         return g
 
     def _sizes_of(self, data):
-        """Host-side sizes of a batch collated by pamnet_amd.store.MoleculeStore (QM9): (global edges, triplet + pair
-        rows) for THIS model's cutoff / layer kind, or None (sizes are then read back from the device)."""
+        """Host-side sizes of a batch collated by pamnet_amd.store.MoleculeStore: (global edges, local edges, triplet +
+        pair rows) for THIS model's cutoffs / layer kind, or None (sizes are then read back from the device)."""
         sz = getattr(data, 'sizes', None)
-        if sz is None or self.dataset != 'QM9':
+        if sz is None:
             return None
-        key = (float(self.cutoff_g), not self.small)
+        key = (float(self.cutoff_g), float(self.cutoff_l), not self.small)
         if isinstance(sz, dict):
             return sz.get(key)
         return sz

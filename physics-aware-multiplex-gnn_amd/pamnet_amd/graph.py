@@ -103,11 +103,11 @@ def _filter_count(ptr_in, nbr, dist, cut):
     return exclusive_scan(count)
 
 
-def _filter_fill(ptr_in, nbr, dist, cut, ptr, total):
+def _filter_fill(ptr_in, nbr, dist, cut, ptr, total, zeroed=False):
     rows = ptr_in.numel() - 1
-    nbr_out, dist_out = _i32(total, nbr.device), _f32(total, nbr.device)
+    nbr_out, dist_out = _alloc_i32(total, nbr.device, zeroed), _alloc_f32(total, nbr.device, zeroed)
     lib.call('pamnet_csr_filter_fill_i32', lib.ptr(ptr_in), lib.ptr(nbr), lib.ptr(dist), rows, float(cut),
-             lib.ptr(ptr), lib.ptr(nbr_out), lib.ptr(dist_out), lib.stream_of(nbr))
+             lib.ptr(ptr), lib.ptr(nbr_out), lib.ptr(dist_out), int(total), lib.stream_of(nbr))
     return ptr, nbr_out, dist_out
 
 
@@ -234,10 +234,10 @@ def knn_table(pos, node_graph, gptr, k, cutoff):
     return ptr, nbr, dist
 
 
-def _transpose_edges(ptr, nbr, dist, n):
+def _transpose_edges(ptr, nbr, dist, n, zeroed=False):
     """CSR by query (q -> nbr) turned into CSR by nbr (aggregate at nbr, other endpoint q)."""
     total = nbr.numel()
-    q = expand_rows(ptr, total)
+    q = expand_rows(ptr, total, zeroed=zeroed)
     tptr, perm = csr_from_keys(nbr, n)
     pl = perm.long()
     return tptr, q[pl].contiguous(), dist[pl].contiguous()
@@ -296,7 +296,7 @@ def raise_for_flag(bits):
     if bits & 1:
         _raise_bad_inputs()
     if bits:
-        what = [n for k, n in ((1, 'global edges'), (2, 'triplet / pair rows'), (3, 'size 3'), (4, 'size 4')) if bits & (2 << k - 1)]
+        what = [n for k, n in ((1, 'global edges'), (2, 'local edges'), (3, 'triplet / pair rows'), (4, 'size 4')) if bits & (2 << k - 1)]
         if bits & 32:
             what.append('self loops in edge_index')
         raise GraphCheckError('the data-dependent sizes handed to PAMNet.forward (`data.sizes`) do not match the batch: '
@@ -307,7 +307,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
                 need_grad=True, knn_k=50, with_triplets=True, n_types=None, sizes=None):
     """Graph-construction part of PAMNet.forward (models.py:104-177).  Returns a Graph.
 
-    `sizes` (QM9 only): (global edges, triplet + pair rows) of this batch as host integers -- what a batch collated by
+    `sizes`: (global edges, local edges, triplet + pair rows) of this batch as host integers -- what a batch collated by
     pamnet_amd.store.MoleculeStore carries.  With them no value is read back from the device: buffers are sized from
     the host numbers, the fills are capped by them, and one launch compares them with the device-side counts (and
     folds in the input-validity flag); the result waits in `g.check` (an int32 device scalar) for the caller's next
@@ -326,8 +326,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     tp_pre = None
     tp_hint = None                                # triplet + pair rows already known on the host (PDBbind)
     hinted = False
-    if sizes is not None and dataset != 'QM9':
-        raise ValueError('`sizes` is implemented for the QM9 path only')
+    checks = []                                   # (device total, value the host assumed), verified by one launch at the end
 
     if dataset == 'QM9':
         pos = pos.to(torch.float32).contiguous()
@@ -350,9 +349,9 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         types = x_raw.to(torch.float32).reshape(-1)
         flag = _input_flag(node_graph, g.n_graphs, types, n_types, *bonds.raw)
         if sizes is not None:                     # zero host round trips: sizes from the host, verified on the device
-            total_g, tp_total = int(sizes[0]), int(sizes[1])
-            _check_sizes(flag, [(gptr_g[-1:], total_g), (tp_ptr[-1:], tp_total)], keep.all())
-            g.check = flag
+            total_g, tp_total = int(sizes[0]), int(sizes[2])
+            checks += [(gptr_g[-1:], total_g), (lp[-1:], int(sizes[1])), (tp_ptr[-1:], tp_total)]
+            g.check, g.all_kept = flag, keep.all()
             hinted = _ZeroArena(3 * total_g + 4 * tp_total + 64, dev)
             # the CSR pointers are capped at what the buffers hold: with sizes that turn out too small every kernel that
             # walks a pointer still stays inside its arrays (results of such a batch are invalid and flagged)
@@ -379,7 +378,16 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         # k != i) and deg(i) pairs (edges j' -> i, itself included; models.py:68-98).
         gptr_g = radius_count(pos, node_graph, g.gptr, cutoff_g)
         local = cutoff_l <= cutoff_g
-        if local:
+        if local and sizes is not None:           # zero host round trips (see `sizes`)
+            lp = radius_count(pos, node_graph, g.gptr, cutoff_l)
+            total_g, total_l, tp_hint = (int(v) for v in sizes)
+            g.check = _input_flag(node_graph, g.n_graphs)
+            checks += [(gptr_g[-1:], total_g), (lp[-1:], total_l)]
+            hinted = _ZeroArena(3 * total_g + 3 * total_l + 4 * tp_hint + 64, dev)
+            gptr_g, lp = torch.clamp(gptr_g, max=total_g), torch.clamp(lp, max=total_l)
+            gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g, zeroed=hinted)
+            lp, l_src, l_dist = _filter_fill(gp, gn, gd, cutoff_l, lp, total_l, zeroed=hinted)
+        elif local:
             lp = radius_count(pos, node_graph, g.gptr, cutoff_l)
             deg = (lp[1:] - lp[:-1]).long()
             tp_dev = (deg * deg + (deg * (deg - 1) if with_triplets else 0)).sum()
@@ -393,18 +401,28 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, int(gptr_g[-1]))
             lp, l_src, l_dist = csr_filter(gp, gn, gd, cutoff_l, _input_flag(node_graph, g.n_graphs))
             tp_hint = None
-        l_dst = expand_rows(lp, l_src.numel())
+        l_dst = expand_rows(lp, l_src.numel(), zeroed=hinted)
     elif rna:
         xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
         pos = xr[:, :3].to(torch.float32).contiguous()
         kp, kn, kd = knn_table(pos, node_graph, g.gptr, knn_k, float('inf'))   # (query, neighbour) rows, self dropped
         # models.py:147-150 (global) and 153-156 (local: j = query, i = nbr)
-        (gp, gn, gd), (qp, qn, qd) = csr_filter2(kp, kn, kd, cutoff_g, cutoff_l,
-                                                 _input_flag(node_graph, g.n_graphs, xr[:, -1].to(torch.float32), n_types))
+        flag = _input_flag(node_graph, g.n_graphs, xr[:, -1].to(torch.float32), n_types)
+        if sizes is not None:                     # zero host round trips (see `sizes`)
+            total_g, total_l, tp_hint = (int(v) for v in sizes)
+            pa, pb = _filter_count(kp, kn, kd, cutoff_g), _filter_count(kp, kn, kd, cutoff_l)
+            g.check = flag
+            checks += [(pa[-1:], total_g), (pb[-1:], total_l)]
+            hinted = _ZeroArena(4 * total_g + 4 * total_l + 4 * tp_hint + 64, dev)
+            pa, pb = torch.clamp(pa, max=total_g), torch.clamp(pb, max=total_l)
+            gp, gn, gd = _filter_fill(kp, kn, kd, cutoff_g, pa, total_g, zeroed=hinted)
+            qp, qn, qd = _filter_fill(kp, kn, kd, cutoff_l, pb, total_l, zeroed=hinted)
+        else:
+            (gp, gn, gd), (qp, qn, qd) = csr_filter2(kp, kn, kd, cutoff_g, cutoff_l, flag)
         if flow != 'target_to_source':                                          # aggregate at edge_index[1] = neighbour
-            gp, gn, gd = _transpose_edges(gp, gn, gd, n)
-        lp, l_src, l_dist = _transpose_edges(qp, qn, qd, n)                    # local layer always aggregates at i
-        l_dst = expand_rows(lp, l_src.numel())
+            gp, gn, gd = _transpose_edges(gp, gn, gd, n, zeroed=hinted)
+        lp, l_src, l_dist = _transpose_edges(qp, qn, qd, n, zeroed=hinted)     # local layer always aggregates at i
+        l_dst = expand_rows(lp, l_src.numel(), zeroed=hinted)
     else:
         raise ValueError("Invalid dataset. If you are using any dataset related to RNA 3D structure prediction, "
                          "be sure to use 'rna' as the first 3 characters of the dataset name.")
@@ -422,12 +440,17 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     if tp_pre is None:
         tp_ptr = _triplet_ptr(lp, l_src, l_dst, with_triplets)
         tot = tp_hint if tp_hint is not None else int(tp_ptr[-1])
+        if hinted:
+            checks.append((tp_ptr[-1:], tot))
+            tp_ptr = torch.clamp(tp_ptr, max=tot)
     else:
         tp_ptr, tot = tp_pre
     tp_idx, tp_edge, tp_kind = (_alloc_i32(tot, dev, hinted) for _ in range(3))
     tp_angle = _alloc_f32(tot, dev, hinted)
     lib.call('pamnet_triplet_fill_f32', lib.ptr(pos), lib.ptr(lp), lib.ptr(l_src), lib.ptr(l_dst), e_l, wt,
              lib.ptr(tp_ptr), lib.ptr(tp_idx), lib.ptr(tp_edge), lib.ptr(tp_angle), lib.ptr(tp_kind), tot, st)
+    if checks:                                    # one launch: size mismatches join the validity flag (PAMNet.verify)
+        _check_sizes(g.check, checks, getattr(g, 'all_kept', None))
     g.tp = CSR(tp_ptr, tp_edge, tp_idx)               # rows = target edge e, col = source edge e'
     g.tp_angle, g.tp_kind = tp_angle, tp_kind
 

@@ -33,10 +33,11 @@ class Batch(object):
 
 
 class MoleculeStore(object):
-    """QM9-schema dataset resident on one device.
+    """Dataset resident on one device, any of the three schemas of models.py:104-157.
 
-    data_list: objects with x [n] (atom types, any numeric dtype), pos [n, 3], edge_index [2, e] (node ids local to the
-    molecule, both directions present as in qm9_dataset.py:243) and optionally y (scalar target)."""
+    data_list: objects / dicts with x ([n] atom types for QM9; [n, w] rows of coordinates + features for PDBbind / RNA),
+    optionally pos [n, 3] and edge_index [2, e] (QM9: node ids local to the molecule, both directions present as in
+    qm9_dataset.py:243) and y (scalar target)."""
 
     def __init__(self, data_list, device):
         self.device = torch.device(device)
@@ -48,61 +49,66 @@ class MoleculeStore(object):
 
         data_list = [_View(d) for d in data_list]
         n = np.array([int(d.x.shape[0]) for d in data_list], dtype=np.int64)
-        e = np.array([int(d.edge_index.shape[1]) for d in data_list], dtype=np.int64)
+        self.has_edges = data_list[0].edge_index is not None
+        self.has_pos = data_list[0].pos is not None
+        e = np.array([int(d.edge_index.shape[1]) if self.has_edges else 0 for d in data_list], dtype=np.int64)
         self.n_nodes, self.n_edges = n, e                      # host copies: the batch sizes are sums of these
         self.nptr = np.concatenate([[0], np.cumsum(n)])
         self.eptr = np.concatenate([[0], np.cumsum(e)])
         dev = self.device
         cat = lambda ts, dt: torch.cat([torch.as_tensor(t).reshape(-1, *torch.as_tensor(t).shape[1:]) for t in ts]).to(dt)
-        self.x = cat([d.x for d in data_list], torch.float32).reshape(-1).contiguous().to(dev)
-        self.pos = cat([d.pos for d in data_list], torch.float32).contiguous().to(dev)
-        ei = torch.cat([torch.as_tensor(d.edge_index).to(torch.int64) for d in data_list], dim=1)
-        self.esrc = ei[0].to(I32).contiguous().to(dev)         # graph-local endpoints
-        self.edst = ei[1].to(I32).contiguous().to(dev)
+        x0 = torch.as_tensor(data_list[0].x)
+        self.x_width = 1 if x0.dim() == 1 else int(x0.shape[1])
+        self.x = cat([d.x for d in data_list], torch.float32).reshape(-1, self.x_width).contiguous().to(dev)
+        self.pos = cat([d.pos for d in data_list], torch.float32).contiguous().to(dev) if self.has_pos else None
+        if self.has_edges:
+            ei = torch.cat([torch.as_tensor(d.edge_index).to(torch.int64) for d in data_list], dim=1)
+            self.esrc = ei[0].to(I32).contiguous().to(dev)     # graph-local endpoints
+            self.edst = ei[1].to(I32).contiguous().to(dev)
+        else:
+            self.esrc = self.edst = None
         ys = [getattr(d, 'y', None) for d in data_list]
         self.y = None if any(v is None for v in ys) else torch.as_tensor(
             np.array([float(torch.as_tensor(v).reshape(-1)[0]) for v in ys], dtype=np.float32)).to(dev)
         self.nptr_d = torch.from_numpy(self.nptr.astype(np.int32)).to(dev)
         self.eptr_d = torch.from_numpy(self.eptr.astype(np.int32)).to(dev)
-        self._counts = {}                                      # (cutoff_g, with_triplets) -> (E_g per molecule, T+P per molecule)
+        self._counts = {}                  # (cutoff_g, cutoff_l, with_triplets) -> per-graph (E_g, E_l, T+P) arrays
 
     def __len__(self):
         return len(self.n_nodes)
 
     # -------------------------------------------------------------------------------------------------- per-molecule sizes
-    def counts_for(self, cutoff_g, with_triplets=True, chunk=4096):
-        """Per-molecule (global edges, triplet + pair rows) for a model with this global cutoff / layer kind: counted on
-        the device by the forward's own kernels, `chunk` molecules per pass, read back ONCE per dataset."""
-        key = (float(cutoff_g), bool(with_triplets))
+    def counts_for(self, model, chunk=None):
+        """Per-graph (global edges, local edges, triplet + pair rows) for `model` (its dataset schema, cutoffs, flow and
+        layer kind): counted on the device by the forward's own graph construction, `chunk` graphs per pass, read back
+        ONCE per dataset.  The local edges of a graph are contiguous in the batch's CSR (sorted by target node), so every
+        count is a difference of CSR pointers at the graph's node range."""
+        key = (float(model.cutoff_g), float(model.cutoff_l), not model.small)
         if key in self._counts:
             return self._counts[key]
         m = len(self)
-        eg, tp = np.zeros(m, dtype=np.int64), np.zeros(m, dtype=np.int64)
+        if chunk is None:
+            chunk = 4096 if self.n_nodes.mean() < 100 else 8
+        eg, el, tp = (np.zeros(m, dtype=np.int64) for _ in range(3))
         for a in range(0, m, chunk):
             b = min(m, a + chunk)
-            idx = np.arange(a, b)
-            bt = self.collate(idx, with_sizes=False)
-            node_graph = bt.batch
-            nb = b - a
-            gptr, _ = G.csr_from_keys(node_graph, nb)
-            ptr_g = G.radius_count(bt.pos, node_graph, gptr, cutoff_g)                    # [N + 1]
-            dst = bt.edge_index[1].contiguous()
-            lp, perm = G.csr_from_keys(dst, int(node_graph.numel()))
-            pl = perm.long()
-            src_s, dst_s = bt.edge_index[0][pl].contiguous(), dst[pl].contiguous()
-            tp_ptr = G._triplet_ptr(lp, src_s, dst_s, with_triplets)                       # [E_l + 1]
+            bt = self.collate(np.arange(a, b), with_sizes=False)
+            g = G.build_graph(model.dataset, model.cutoff_l, model.cutoff_g, model.flow, bt.x, bt.batch, bt.pos, bt.edge_index,
+                              num_graphs=b - a, need_grad=False, with_triplets=not model.small,
+                              n_types=model.embeddings.size(0) if hasattr(model, 'embeddings') else None)
             nodes = torch.from_numpy((self.nptr[a:b + 1] - self.nptr[a]).astype(np.int64)).to(self.device)
-            pg = ptr_g.long()[nodes]
-            pt = tp_ptr.long()[lp.long()[nodes]]           # bonds are CSR-sorted by target: a molecule's are contiguous
+            pg, pl = g.glob.ptr.long()[nodes], g.loc.ptr.long()[nodes]
+            pt = g.tp.ptr.long()[pl]
             eg[a:b] = (pg[1:] - pg[:-1]).cpu().numpy()
+            el[a:b] = (pl[1:] - pl[:-1]).cpu().numpy()
             tp[a:b] = (pt[1:] - pt[:-1]).cpu().numpy()
-        self._counts[key] = (eg, tp)
-        return eg, tp
+        self._counts[key] = (eg, el, tp)
+        return eg, el, tp
 
     def prepare_for(self, *models):
         """Count the sizes the given models' forwards need (one device pass per distinct cutoff / layer kind)."""
         for mdl in models:
-            self.counts_for(mdl.cutoff_g, not mdl.small)
+            self.counts_for(mdl)
         return self
 
     # ------------------------------------------------------------------------------------------------------- collation
@@ -127,14 +133,16 @@ class MoleculeStore(object):
         meta_d = meta_h.to(dev, non_blocking=True)
         sel, out_nptr, out_eptr = meta_d[:b], meta_d[b:2 * b + 1], meta_d[2 * b + 1:]
         bt = Batch()
-        bt.x = torch.empty(n_out, dtype=torch.float32, device=dev)
-        bt.pos = torch.empty((n_out, 3), dtype=torch.float32, device=dev)
+        w = self.x_width
+        bt.x = torch.empty(n_out if w == 1 else (n_out, w), dtype=torch.float32, device=dev)
+        bt.pos = torch.empty((n_out, 3), dtype=torch.float32, device=dev) if self.has_pos else None
         bt.batch = torch.empty(n_out, dtype=I32, device=dev)
-        bt.edge_index = torch.empty((2, e_out), dtype=I32, device=dev)
+        bt.edge_index = torch.empty((2, e_out), dtype=I32, device=dev) if self.has_edges else None
         lib.call('pamnet_collate_f32', b, lib.ptr(sel), lib.ptr(out_nptr), lib.ptr(out_eptr), lib.ptr(self.nptr_d),
-                 lib.ptr(self.eptr_d), lib.ptr(self.x), 1, lib.ptr(self.pos), lib.ptr(self.esrc), lib.ptr(self.edst), n_out,
-                 e_out, lib.ptr(bt.x), lib.ptr(bt.pos), lib.ptr(bt.batch), bt.edge_index.data_ptr(),
-                 bt.edge_index.data_ptr() + 4 * e_out, lib.stream_of(bt.x))
+                 lib.ptr(self.eptr_d), lib.ptr(self.x), w, lib.ptr(self.pos), lib.ptr(self.esrc), lib.ptr(self.edst), n_out,
+                 e_out, lib.ptr(bt.x), lib.ptr(bt.pos), lib.ptr(bt.batch),
+                 bt.edge_index.data_ptr() if e_out else None, (bt.edge_index.data_ptr() + 4 * e_out) if e_out else None,
+                 lib.stream_of(bt.x))
         bt.num_graphs = b
         bt.y = None if self.y is None else self.y.index_select(0, sel.long())
         # the batch is produced by work queued on this stream: a consumer on another stream (the input pipeline's side
@@ -142,5 +150,6 @@ class MoleculeStore(object):
         bt.inputs_ready = torch.cuda.Event()
         bt.inputs_ready.record(torch.cuda.current_stream(dev))
         if with_sizes:
-            bt.sizes = {key: (int(eg[idx].sum()), int(tp[idx].sum())) for key, (eg, tp) in self._counts.items()}
+            bt.sizes = {key: (int(eg[idx].sum()), int(el[idx].sum()), int(tp[idx].sum()))
+                        for key, (eg, el, tp) in self._counts.items()}
         return bt

@@ -47,8 +47,8 @@ def test_collate_matches_host_collation(dev, store):
 def test_size_table_matches_graph_construction(dev, store, small):
     from pamnet_amd import graph as G
     st, _ = store
-    eg, tp = st.counts_for(5.0, with_triplets=not small, chunk=128)      # several passes
-    assert eg.shape == (300,) and (eg > 0).all() and (tp > 0).all()
+    eg, el, tp = st.counts_for(_model(dev, small, dim=16, n_layer=1), chunk=128)      # several passes
+    assert eg.shape == (300,) and (eg > 0).all() and (tp > 0).all() and (el == st.n_edges).all()
     for idx in ([5], [1, 2, 3], list(range(40, 168))):
         b = st.collate(idx, with_sizes=False)
         g = G.build_graph('QM9', 5.0, 5.0, 'source_to_target', b.x, b.batch, b.pos, b.edge_index, num_graphs=len(idx),
@@ -94,11 +94,11 @@ def test_wrong_sizes_are_caught(dev, store):
     model = _model(dev)
     st.prepare_for(model)
     idx = list(range(64))
-    key = (5.0, True)
+    key = (5.0, 5.0, True)
     for d_eg, d_tp in ((-7, 0), (+9, 0), (0, -5), (0, +11)):
         b = st.collate(idx)
-        eg, tp = b.sizes[key]
-        b.sizes = {key: (eg + d_eg, tp + d_tp)}
+        eg, el, tp = b.sizes[key]
+        b.sizes = {key: (eg + d_eg, el, tp + d_tp)}
         with torch.no_grad():
             out = model(b)                                       # runs to completion, memory-safe, result invalid
         assert out.shape == (64,)
@@ -132,9 +132,63 @@ def test_trainer_and_predict_verify(dev, store):
     assert len(outs) == 4
     bad = st.collate(list(range(32)))
     key = next(iter(bad.sizes))
-    bad.sizes = {key: (bad.sizes[key][0] - 3, bad.sizes[key][1])}
+    bad.sizes = {key: (bad.sizes[key][0] - 3,) + tuple(bad.sizes[key][1:])}
     with pytest.raises(GraphCheckError):
         for k in range(5):
             tr.step(bad if k == 0 else st.collate(list(range(32))))
         torch.cuda.synchronize()
         model.verify()
+
+
+@pytest.mark.parametrize('kind', ['PDBbind', 'rna'])
+def test_other_schemas_without_host_sync(dev, kind):
+    """The PDBbind and RNA schemas (rows of coordinates + features, no bond list) through the same store: collation equals
+    the host-side one, the forward on a batch that carries its sizes issues no synchronising call and returns bitwise what
+    the plain forward returns, wrong sizes -- each of the three, either way -- are caught without a memory fault."""
+    from models import Config, PAMNet
+    from pamnet_amd import store as S, synth
+    from pamnet_amd.graph import GraphCheckError
+    if kind == 'PDBbind':
+        graphs = [synth.pdbbind_complex(7, i) for i in range(6)]
+        cfg = Config(dataset='PDBbind', dim=128, n_layer=1, cutoff_l=2.0, cutoff_g=6.0)
+    else:
+        graphs = [synth.rna_chain(7, i, n_nodes=300 + 40 * i) for i in range(6)]
+        cfg = Config(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
+    torch.manual_seed(1)
+    model = PAMNet(cfg).to(dev)
+    st = S.MoleculeStore(graphs, dev).prepare_for(model)
+    idx = [4, 1, 5, 0]
+    ref_b = synth.collate([graphs[i] for i in idx])
+    b0 = st.collate(idx, with_sizes=False)
+    assert torch.equal(b0.x.cpu(), ref_b.x.float()) and torch.equal(b0.batch.cpu().long(), ref_b.batch)
+    with torch.no_grad():
+        ref = model(b0)
+        model(st.collate(idx))
+        torch.cuda.synchronize()
+        b = st.collate(idx)
+        torch.cuda.set_sync_debug_mode('error')
+        try:
+            out = model(b)
+        finally:
+            torch.cuda.set_sync_debug_mode('default')
+    model.verify()
+    assert torch.equal(out, ref)
+    b = st.collate(idx)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        model(b).sum().backward()
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    model.verify()
+    key = next(iter(b.sizes))
+    for pos_ in range(3):
+        for delta in (-5, +7):
+            bad = st.collate(idx)
+            v = list(bad.sizes[key])
+            v[pos_] += delta
+            bad.sizes = {key: tuple(v)}
+            with torch.no_grad():
+                model(bad)
+            with pytest.raises(GraphCheckError):
+                model.verify()
