@@ -130,7 +130,8 @@ int pamnet_triplet_fill_f32(const float* pos, const int32_t* lptr, const int32_t
  * Zero-host-sync graph construction (models.py:62-98,104-157 read their data-dependent sizes back to the
  * host through boolean masks / repeat_interleave).
  * check_sizes: up to 4 device-side totals (actual[k][0], e.g. the last element of a CSR pointer) against the values the
- *   host assumed; bit (2 << k) of flag[0] is set on a mismatch, bit 32 when *all_kept (a device bool, nullable) is false.
+ *   host assumed; bit (2 << k) of flag[0] is set on a mismatch, bit 32 when *all_kept (a device bool, nullable) is false
+ *   or *self_loops (int32, nullable) is non-zero.
  *   flag is NOT zeroed (pamnet_validate_inputs_i32 owns bit 1 of the same word).
  * collate: batch of n_graphs graphs sel[k] of a dataset kept resident as concatenated arrays (prefix sums src_nptr /
  *   src_eptr, bonds with graph-local endpoints): node features [n_out, x_width], positions (nullable), int32 batch
@@ -146,8 +147,23 @@ int pamnet_reverse_edges_i32(const int32_t* ptr, const int32_t* row_of, const in
 int pamnet_gather_scalars_i64(int64_t n, const void* const* src /* host array of device ptrs */,
                               const int32_t* kind /* host */, int64_t* out, pamnet_stream_t stream);
 int pamnet_check_sizes_i32(int64_t n_checks, const int32_t* const* actual /* host array of device ptrs */,
-                           const int64_t* expected /* host */, const void* all_kept, int32_t* flag,
-                           pamnet_stream_t stream);
+                           const int64_t* expected /* host */, const void* all_kept, const int32_t* self_loops,
+                           int32_t* flag, pamnet_stream_t stream);
+/* The reference's index tensors (`x`, `edge_index`, `batch` of models.py:104-110; `j, i = edge_index` models.py:64) in
+ * ONE launch: each is read as int64 (kind 1, what PyG hands over), int32 (2) or fp32 (3; kind 0 = no `x`) and written as
+ * int32 -- node_graph [n], types [n] (element i read at x[i * x_stride]), src / dst [n_edges].  gptr_flag holds
+ * n_graphs + 3 ints, zeroed by the call: gptr_flag[0 .. n_graphs] = first node of every graph (the CSR pointer of the
+ * sorted batch vector), gptr_flag[n_graphs + 1] = 1 when an index is out of range (batch unsorted / not in [0, n_graphs),
+ * type not in [0, n_types), edge endpoint not in [0, n): the reference raises IndexError; offending entries are written
+ * as 0 so that later kernels stay in bounds), gptr_flag[n_graphs + 2] = 1 when the edge list has a self loop
+ * (remove_self_loops, models.py:63, would then not be a no-op). */
+int pamnet_ingest_indices_i32(const void* batch, int32_t batch_kind, int64_t n, int64_t n_graphs, const void* x,
+                              int32_t x_kind, int64_t x_stride, int64_t n_types, const void* edge_src,
+                              const void* edge_dst, int32_t edge_kind, int64_t n_edges, int32_t* node_graph,
+                              int32_t* gptr_flag, int32_t* types, int32_t* src, int32_t* dst, pamnet_stream_t stream);
+/* out_a[q] = a[perm[q]], out_b[q] = b[perm[q]]: the bond list in CSR order of its targets (models.py:71-73). */
+int pamnet_gather2_i32(const int32_t* perm, const int32_t* a, const int32_t* b, int64_t m, int32_t* out_a,
+                       int32_t* out_b, pamnet_stream_t stream);
 int pamnet_collate_f32(int64_t n_graphs, const int32_t* sel, const int32_t* out_nptr, const int32_t* out_eptr,
                        const int32_t* src_nptr, const int32_t* src_eptr, const float* x, int64_t x_width,
                        const float* pos, const int32_t* esrc, const int32_t* edst, int64_t n_out, int64_t e_out,

@@ -905,11 +905,13 @@ struct SizeChecks {
     int64_t expected[4];
     int n;
 };
-__global__ void check_sizes_kernel(SizeChecks c, const bool* __restrict__ all_kept, int32_t* __restrict__ flag) {
+__global__ void check_sizes_kernel(SizeChecks c, const bool* __restrict__ all_kept, const int32_t* __restrict__ loops,
+                                   int32_t* __restrict__ flag) {
     int bad = 0;
     for (int k = 0; k < c.n; ++k)
         if ((int64_t)c.actual[k][0] != c.expected[k]) bad |= 2 << k;
     if (all_kept && !all_kept[0]) bad |= 1 << 5;
+    if (loops && loops[0]) bad |= 1 << 5;
     if (bad) atomicOr(flag, bad);
 }
 
@@ -958,7 +960,8 @@ __global__ __launch_bounds__(256) void collate_kernel(Collate c) {
 }  // namespace
 
 extern "C" int pamnet_check_sizes_i32(int64_t n_checks, const int32_t* const* actual, const int64_t* expected,
-                                      const void* all_kept, int32_t* flag, pamnet_stream_t stream) {
+                                      const void* all_kept, const int32_t* self_loops, int32_t* flag,
+                                      pamnet_stream_t stream) {
     if (n_checks < 0 || n_checks > 4) return PAMNET_EINVAL;
     if (!flag || (n_checks > 0 && (!actual || !expected))) return PAMNET_ENULL;
     SizeChecks c;
@@ -968,7 +971,8 @@ extern "C" int pamnet_check_sizes_i32(int64_t n_checks, const int32_t* const* ac
         c.actual[k] = actual[k];
         c.expected[k] = expected[k];
     }
-    hipLaunchKernelGGL(check_sizes_kernel, dim3(1), dim3(1), 0, as_stream(stream), c, static_cast<const bool*>(all_kept), flag);
+    hipLaunchKernelGGL(check_sizes_kernel, dim3(1), dim3(1), 0, as_stream(stream), c, static_cast<const bool*>(all_kept), self_loops,
+                       flag);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -1019,6 +1023,110 @@ __global__ __launch_bounds__(256) void validate_inputs_kernel(const int32_t* __r
     if (bad) flag[0] = 1;
 }
 }  // namespace
+
+// ---- the calling convention's index tensors in one launch ---------------------------------------------------------------
+// `x`, `edge_index`, `batch` of the reference (models.py:104-110) arrive as int64 (PyG) -- or int32 / fp32; the kernels here
+// index with int32.  One launch converts all three, builds the per-graph node pointer from the (sorted) batch vector,
+// validates every index and notes self loops: the work of seven tensor ops (three casts, !=, all, a counting sort of the
+// batch vector, a validation launch) that each cost a 5-7 us launch on the input pipeline's stream.
+namespace {
+enum { KIND_NONE = 0, KIND_I64 = 1, KIND_I32 = 2, KIND_F32 = 3 };
+__device__ __forceinline__ int64_t load_index(const void* p, int kind, int64_t i, bool& bad) {
+    if (kind == KIND_I64) return static_cast<const int64_t*>(p)[i];
+    if (kind == KIND_I32) return static_cast<const int32_t*>(p)[i];
+    const float v = static_cast<const float*>(p)[i];
+    if (!(v >= 0.f && v < 2147483648.f)) { bad = true; return -1; }
+    return (int64_t)v;                                        // .to(int32) of a non-negative float truncates
+}
+struct Ingest {
+    const void *batch, *x, *esrc, *edst;
+    int batch_kind, x_kind, edge_kind;
+    int64_t x_stride, n, n_graphs, n_types, n_edges;
+    int32_t *node_graph, *gptr, *types, *src, *dst, *flag;   // gptr [n_graphs + 1] and flag [2] arrive zeroed
+};
+__global__ __launch_bounds__(256) void ingest_kernel(Ingest c) {
+    const int64_t total = c.n > c.n_edges ? c.n : c.n_edges;
+    bool bad = false, loop = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < c.n) {
+            const int64_t g = load_index(c.batch, c.batch_kind, i, bad);
+            const int64_t p = i > 0 ? load_index(c.batch, c.batch_kind, i - 1, bad) : -1;
+            const bool ok = g >= 0 && g < c.n_graphs && p <= g && p >= -1;
+            bad |= !ok;
+            c.node_graph[i] = ok ? (int32_t)g : 0;
+            if (ok) {
+                for (int64_t q = p + 1; q <= g; ++q) c.gptr[q] = (int32_t)i;          // first node of graphs p+1 .. g
+                if (i == c.n - 1)
+                    for (int64_t q = g + 1; q <= c.n_graphs; ++q) c.gptr[q] = (int32_t)c.n;
+            }
+            if (c.x_kind != KIND_NONE) {
+                const int64_t t = load_index(c.x, c.x_kind, i * c.x_stride, bad);
+                const bool tok = t >= 0 && t < c.n_types;
+                bad |= !tok;
+                c.types[i] = tok ? (int32_t)t : 0;
+            }
+        }
+        if (i < c.n_edges) {
+            const int64_t a = load_index(c.esrc, c.edge_kind, i, bad), b = load_index(c.edst, c.edge_kind, i, bad);
+            const bool eok = a >= 0 && a < c.n && b >= 0 && b < c.n;
+            bad |= !eok;
+            loop |= eok && a == b;
+            c.src[i] = eok ? (int32_t)a : 0;
+            c.dst[i] = eok ? (int32_t)b : 0;
+        }
+    }
+    if (bad) c.flag[0] = 1;
+    if (loop) c.flag[1] = 1;
+}
+
+__global__ __launch_bounds__(256) void gather2_kernel(const int32_t* __restrict__ perm, const int32_t* __restrict__ a,
+                                                      const int32_t* __restrict__ b, int64_t m, int32_t* __restrict__ oa,
+                                                      int32_t* __restrict__ ob) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    const int p = perm[q];
+    const bool ok = (uint64_t)p < (uint64_t)m;
+    oa[q] = ok ? a[p] : 0;
+    ob[q] = ok ? b[p] : 0;
+}
+}  // namespace
+
+extern "C" int pamnet_ingest_indices_i32(const void* batch, int32_t batch_kind, int64_t n, int64_t n_graphs, const void* x,
+                                         int32_t x_kind, int64_t x_stride, int64_t n_types, const void* edge_src,
+                                         const void* edge_dst, int32_t edge_kind, int64_t n_edges, int32_t* node_graph,
+                                         int32_t* gptr_flag, int32_t* types, int32_t* src, int32_t* dst,
+                                         pamnet_stream_t stream) {
+    auto kind_ok = [](int k) { return k == KIND_I64 || k == KIND_I32 || k == KIND_F32; };
+    if (n < 0 || n_graphs < 0 || n_edges < 0 || n >= (int64_t)1 << 31) return PAMNET_EINVAL;
+    if (n > 0 && !kind_ok(batch_kind)) return PAMNET_EINVAL;
+    if (x_kind != KIND_NONE && (!kind_ok(x_kind) || x_stride < 1 || n_types < 1)) return PAMNET_EINVAL;
+    if (n_edges > 0 && !kind_ok(edge_kind)) return PAMNET_EINVAL;
+    if (!gptr_flag || (n > 0 && (!batch || !node_graph)) || (n > 0 && x_kind != KIND_NONE && (!x || !types)) ||
+        (n_edges > 0 && (!edge_src || !edge_dst || !src || !dst)))
+        return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const hipError_t e = hipMemsetAsync(gptr_flag, 0, sizeof(int32_t) * (n_graphs + 3), st);
+    if (e != hipSuccess) return (int)e;
+    const int64_t total = n > n_edges ? n : n_edges;
+    if (total == 0) return PAMNET_OK;
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 1024) blocks = 1024;
+    Ingest c{batch, x, edge_src, edge_dst, (int)batch_kind, n > 0 ? (int)x_kind : KIND_NONE, (int)edge_kind, x_stride, n,
+             n_graphs, n_types, n_edges, node_graph, gptr_flag, types, src, dst, gptr_flag + n_graphs + 1};
+    hipLaunchKernelGGL(ingest_kernel, dim3((unsigned)blocks), dim3(256), 0, st, c);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_gather2_i32(const int32_t* perm, const int32_t* a, const int32_t* b, int64_t m, int32_t* out_a,
+                                  int32_t* out_b, pamnet_stream_t stream) {
+    if (m < 0) return PAMNET_EINVAL;
+    if (m == 0) return PAMNET_OK;
+    if (!perm || !a || !b || !out_a || !out_b) return PAMNET_ENULL;
+    hipLaunchKernelGGL(gather2_kernel, dim3(blocks_for(m)), dim3(256), 0, as_stream(stream), perm, a, b, m, out_a, out_b);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
 
 extern "C" int pamnet_validate_inputs_i32(const int32_t* node_graph, int64_t n, int64_t n_graphs, const float* types,
                                           int64_t type_stride, int64_t n_types, const int32_t* src, const int32_t* dst,

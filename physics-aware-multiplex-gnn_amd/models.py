@@ -173,7 +173,7 @@ class _PAMNetBase(nn.Module):
                 return fused.embed(feats, self.init_linear, act=False, tape=tape)          # models.py:119
             return F.linear(feats, self.init_linear.weight)
         col = x_raw if self.dataset == 'QM9' else (x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw)[:, -1]
-        idx = col.to(torch.int32).contiguous()
+        idx = g.types if getattr(g, 'types', None) is not None else col.to(torch.int32).contiguous()
         if ops.type_rows_supported(self.embeddings):                                    # models.py:107,140
             direct = self.embeddings.grad if ((tape is not None or torch.is_grad_enabled()) and self.embeddings.grad is not None
                                               and getattr(self.embeddings, '_pamnet_direct', False)) else None
@@ -224,7 +224,7 @@ class _PAMNetBase(nn.Module):
             if not ops.type_rows_supported(self.embeddings):
                 return None
             col = x_raw if self.dataset == 'QM9' else (x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw)[:, -1]
-            types = col.to(torch.int32).contiguous()
+            types = g.types if getattr(g, 'types', None) is not None else col.to(torch.int32).contiguous()
             params.append(self.embeddings)                                                  # models.py:107,140
         outs = fused.input_stage(fused.InputSpec(layers, types), params, tape=tape)
         return outs[3], outs[0], outs[1], outs[2]

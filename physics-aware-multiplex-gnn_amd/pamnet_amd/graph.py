@@ -271,14 +271,56 @@ def _input_flag(node_graph, n_graphs, types=None, n_types=None, src=None, dst=No
     return flag
 
 
-def _check_sizes(flag, checks, all_kept=None):
+_KINDS = {torch.int64: 1, torch.int32: 2, torch.float32: 3}
+
+
+def ingest(batch, n_graphs, x=None, n_types=None, edge_index=None):
+    """The reference's index tensors as the kernels want them, in one launch (pamnet_ingest_indices_i32): int32 batch
+    vector, per-graph node pointer, int32 atom types, int32 bond endpoints, and a two-word flag (invalid index / self
+    loops in the bond list).  Returns None when a tensor has a layout the launch does not read (the caller then takes
+    the tensor-op route)."""
+    n = int(batch.numel())
+    if batch.dtype not in _KINDS or not batch.is_contiguous() or batch.dim() != 1:
+        return None
+    xk, xs, xcol = 0, 1, None
+    if x is not None and n_types is not None:
+        xcol = x.reshape(-1) if (x.dim() == 1 or (x.dim() == 2 and x.size(1) == 1)) else None
+        if xcol is None or xcol.dtype not in _KINDS or xcol.numel() != n:
+            return None
+        xk, xs = _KINDS[xcol.dtype], (xcol.stride(0) if n > 1 else 1)
+        if xs < 1:
+            return None
+    ne, ek, es, ed = 0, 0, None, None
+    if edge_index is not None:
+        if edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.dtype not in _KINDS:
+            return None
+        es, ed = edge_index[0], edge_index[1]
+        if not (es.is_contiguous() and ed.is_contiguous()):
+            return None
+        ne, ek = int(es.numel()), _KINDS[edge_index.dtype]
+    dev = batch.device
+    na, ea = (n + 3) // 4 * 4, (ne + 3) // 4 * 4          # 16-byte aligned sections of one allocation
+    buf = _i32(2 * na + 2 * ea + n_graphs + 3, dev)
+    node_graph, types = buf[:n], buf[na:na + n]
+    src, dst = buf[2 * na:2 * na + ne], buf[2 * na + ea:2 * na + ea + ne]
+    gf = buf[2 * na + 2 * ea:]
+    lib.call('pamnet_ingest_indices_i32', batch.data_ptr() if n else None, _KINDS[batch.dtype], n, int(n_graphs),
+             xcol.data_ptr() if (xk and n) else None, xk, xs, int(n_types or 1), es.data_ptr() if ne else None,
+             ed.data_ptr() if ne else None, ek, ne, node_graph.data_ptr() if n else None, gf.data_ptr(),
+             types.data_ptr() if n else None, src.data_ptr() if ne else None, dst.data_ptr() if ne else None,
+             lib.stream_of(batch))
+    return node_graph, gf[:n_graphs + 1], (types if xk else None), src, dst, gf[n_graphs + 1:n_graphs + 2], \
+        gf[n_graphs + 2:n_graphs + 3]
+
+
+def _check_sizes(flag, checks, all_kept=None, loops=None):
     """One launch: OR the size-mismatch bits into the validity flag word (pamnet_check_sizes_i32)."""
     import ctypes
     n = len(checks)
     actual = (ctypes.c_void_p * n)(*[lib.ptr(t) for t, _ in checks])
     expected = (ctypes.c_int64 * n)(*[int(v) for _, v in checks])
-    lib.call('pamnet_check_sizes_i32', n, actual, expected, None if all_kept is None else lib.ptr(all_kept), lib.ptr(flag),
-             lib.stream_of(flag))
+    lib.call('pamnet_check_sizes_i32', n, actual, expected, None if all_kept is None else lib.ptr(all_kept),
+             None if loops is None else lib.ptr(loops), lib.ptr(flag), lib.stream_of(flag))
 
 
 def _raise_bad_inputs():
@@ -316,10 +358,17 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     g = Graph()
     n = int(batch.numel())
     g.n = n
-    node_graph = batch.to(I32).contiguous()
     g.n_graphs = int(num_graphs) if num_graphs is not None else int(batch[-1]) + 1
+    g.types = None                                # int32 atom types (QM9), by-product of the ingest launch
+    ing = None
+    if dataset == 'QM9' and batch.is_cuda and n > 0 and edge_index is not None and n_types is not None:
+        ing = ingest(batch, g.n_graphs, x_raw, n_types, edge_index)
+    if ing is not None:
+        node_graph, g.gptr, g.types = ing[0], ing[1], ing[2]
+    else:
+        node_graph = batch.to(I32).contiguous()
+        g.gptr, _ = csr_from_keys(node_graph, g.n_graphs)
     g.node_graph = node_graph
-    g.gptr, _ = csr_from_keys(node_graph, g.n_graphs)
     rna = dataset[:3].lower() == 'rna'
     g.sign = None
     g.check = None                                # device flag word of the zero-host-sync path (see `sizes`)
@@ -334,35 +383,44 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         # not depend on the radius graph, so they are computed first, on the assumption that the bond list has no self
         # loops (remove_self_loops, models.py:63, is a no-op for QM9 bond graphs); the flag that verifies it comes back
         # with the sizes, and a batch that does have self loops is redone the slow way.
-        def bonds(ei):
-            src0, dst0 = ei[0].to(I32).contiguous(), ei[1].to(I32).contiguous()    # j, i = edge_index (models.py:64)
+        def bonds(ei, raw=None):
+            # j, i = edge_index (models.py:64)
+            src0, dst0 = raw if raw is not None else (ei[0].to(I32).contiguous(), ei[1].to(I32).contiguous())
             bonds.raw = (src0, dst0)
             lp_, perm = csr_from_keys(dst0, n)
-            pl = perm.long()
-            src_, dst_ = src0[pl].contiguous(), dst0[pl].contiguous()
+            m = int(src0.numel())
+            src_, dst_ = _i32(m, dev), _i32(m, dev)
+            lib.call('pamnet_gather2_i32', lib.ptr(perm), lib.ptr(src0), lib.ptr(dst0), m, lib.ptr(src_), lib.ptr(dst_),
+                     lib.stream_of(src0))
             return lp_, src_, dst_, _triplet_ptr(lp_, src_, dst_, with_triplets)
 
         ei = edge_index
-        keep = ei[0] != ei[1]
-        lp, l_src, l_dst, tp_ptr = bonds(ei)
+        lp, l_src, l_dst, tp_ptr = bonds(ei, None if ing is None else (ing[3], ing[4]))
         gptr_g = radius_count(pos, node_graph, g.gptr, cutoff_g)               # symmetric: agg = query, other = nbr
-        types = x_raw.to(torch.float32).reshape(-1)
-        flag = _input_flag(node_graph, g.n_graphs, types, n_types, *bonds.raw)
+        if ing is not None:                       # validity and self loops were noted by the ingest launch
+            flag, kept = ing[5], ing[6]           # (`kept`: non-zero = NOT all kept; read through _kept below)
+            g.loops = kept
+        else:
+            types = x_raw.to(torch.float32).reshape(-1)
+            flag = _input_flag(node_graph, g.n_graphs, types, n_types, *bonds.raw)
+            kept = (ei[0] != ei[1]).all()
         if sizes is not None:                     # zero host round trips: sizes from the host, verified on the device
             total_g, tp_total = int(sizes[0]), int(sizes[2])
             checks += [(gptr_g[-1:], total_g), (lp[-1:], int(sizes[1])), (tp_ptr[-1:], tp_total)]
-            g.check, g.all_kept = flag, keep.all()
+            g.check = flag
+            if ing is None:
+                g.all_kept = kept
             hinted = _ZeroArena(3 * total_g + 4 * tp_total + 64, dev)
             # the CSR pointers are capped at what the buffers hold: with sizes that turn out too small every kernel that
             # walks a pointer still stays inside its arrays (results of such a batch are invalid and flagged)
             gptr_g = torch.clamp(gptr_g, max=total_g)
             tp_ptr = torch.clamp(tp_ptr, max=tp_total)
         else:
-            total_g, all_kept, tp_total, bad = host_ints(gptr_g[-1], keep.all(), tp_ptr[-1], flag)
+            total_g, k, tp_total, bad = host_ints(gptr_g[-1], kept, tp_ptr[-1], flag)
             if bad:
                 _raise_bad_inputs()
-            if not all_kept:
-                lp, l_src, l_dst, tp_ptr = bonds(ei[:, keep])
+            if (k != 0) if ing is not None else (not k):                        # the bond list has self loops
+                lp, l_src, l_dst, tp_ptr = bonds(ei[:, ei[0] != ei[1]])
                 tp_total = int(tp_ptr[-1])
         gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g, zeroed=hinted)
         l_dist = edge_dist(pos, l_dst, l_src)
@@ -450,7 +508,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     lib.call('pamnet_triplet_fill_f32', lib.ptr(pos), lib.ptr(lp), lib.ptr(l_src), lib.ptr(l_dst), e_l, wt,
              lib.ptr(tp_ptr), lib.ptr(tp_idx), lib.ptr(tp_edge), lib.ptr(tp_angle), lib.ptr(tp_kind), tot, st)
     if checks:                                    # one launch: size mismatches join the validity flag (PAMNet.verify)
-        _check_sizes(g.check, checks, getattr(g, 'all_kept', None))
+        _check_sizes(g.check, checks, getattr(g, 'all_kept', None), getattr(g, 'loops', None))
     g.tp = CSR(tp_ptr, tp_edge, tp_idx)               # rows = target edge e, col = source edge e'
     g.tp_angle, g.tp_kind = tp_angle, tp_kind
 

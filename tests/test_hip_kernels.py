@@ -493,3 +493,81 @@ def test_symmetric_transpose_equals_counting_sort(dev, kind):
         assert isinstance(tr, G.SymmetricTranspose)
         ref = G.Transpose(csr.col, g.n)
         assert torch.equal(tr.ptr, ref.ptr) and torch.equal(tr.perm, ref.perm)
+
+
+@pytest.mark.parametrize('kinds', [('i64', 'i64', 'i64'), ('i32', 'f32', 'i32'), ('i64', 'f32', 'i64')])
+def test_ingest_indices_matches_tensor_ops(dev, kinds):
+    """pamnet_ingest_indices_i32 (casts + node pointer + validation + self-loop note in one launch) against the tensor
+    ops it replaces; a batch vector with empty graphs at the start, in the middle and at the end."""
+    from pamnet_amd import graph as G
+    dt = {'i64': torch.int64, 'i32': torch.int32, 'f32': torch.float32}
+    rng = np.random.RandomState(5)
+    counts = np.array([0, 0, 5, 9, 0, 1, 17, 0, 0, 3, 0])
+    n_graphs, n = len(counts), int(counts.sum())
+    batch = torch.from_numpy(np.repeat(np.arange(n_graphs), counts)).to(dev).to(dt[kinds[0]])
+    x = torch.from_numpy(rng.randint(0, 5, size=n)).to(dev).to(dt[kinds[1]])
+    ne = 83
+    ei = torch.from_numpy(rng.randint(0, n, size=(2, ne))).to(dev)
+    ei[1] = torch.where(ei[1] == ei[0], (ei[1] + 1) % n, ei[1])              # no self loops
+    ei = ei.to(dt[kinds[2]])
+    for shape in ('flat', 'column'):
+        xs = x if shape == 'flat' else x.view(-1, 1)
+        node_graph, gptr, types, src, dst, flag, loops = G.ingest(batch, n_graphs, xs, 5, ei)
+        ref_ptr, _ = G.csr_from_keys(batch.to(torch.int32).contiguous(), n_graphs)
+        assert torch.equal(node_graph, batch.to(torch.int32)) and torch.equal(gptr, ref_ptr)
+        assert torch.equal(types, x.to(torch.int32))
+        assert torch.equal(src, ei[0].to(torch.int32)) and torch.equal(dst, ei[1].to(torch.int32))
+        assert int(flag) == 0 and int(loops) == 0
+    # a self loop is noted, nothing else changes
+    e2 = ei.clone()
+    e2[1, 40] = e2[0, 40]
+    out = G.ingest(batch, n_graphs, x, 5, e2)
+    assert int(out[5]) == 0 and int(out[6]) == 1
+    # every kind of invalid index raises the flag and is written as an in-range value
+    def bad(b=batch, xx=x, e=ei):
+        o = G.ingest(b, n_graphs, xx, 5, e)
+        assert int(o[5]) == 1
+        assert int(o[0].min()) >= 0 and int(o[0].max()) < n_graphs and int(o[2].min()) >= 0 and int(o[2].max()) < 5
+        assert int(o[1].min()) >= 0 and int(o[1].max()) <= n
+        assert int(o[3].min()) >= 0 and int(o[3].max()) < n and int(o[4].min()) >= 0 and int(o[4].max()) < n
+    b2 = batch.clone(); b2[7] = n_graphs
+    bad(b=b2)
+    b2 = batch.clone(); b2[3], b2[20] = b2[20].clone(), b2[3].clone()           # not sorted
+    bad(b=b2)
+    x2 = x.clone(); x2[11] = 5
+    bad(xx=x2)
+    x2 = x.clone(); x2[0] = -1
+    bad(xx=x2)
+    e2 = ei.clone(); e2[0, 3] = n
+    bad(e=e2)
+    e2 = ei.clone(); e2[1, 80] = -2
+    bad(e=e2)
+
+
+def test_qm9_graph_same_with_and_without_ingest(dev):
+    """build_graph on the reference's int64 tensors (ingest launch) equals build_graph on pre-converted tensors of a
+    layout the launch does not take (the tensor-op route), field by field; a bond list with self loops takes the
+    remove_self_loops route on both."""
+    from pamnet_amd import graph as G, synth
+    b = synth.qm9_batch(4, 0, 32).to(dev)
+    assert b.edge_index.dtype == torch.int64 and b.batch.dtype == torch.int64
+    for loops in (False, True):
+        ei = b.edge_index
+        if loops:
+            extra = torch.tensor([[3, 17], [3, 17]], device=dev, dtype=ei.dtype)
+            ei = torch.cat([ei[:, :10], extra, ei[:, 10:]], dim=1).contiguous()
+        a = G.build_graph('QM9', 5.0, 5.0, 'source_to_target', b.x, b.batch, b.pos, ei, num_graphs=32, n_types=5)
+        assert a.types is not None
+        # int16 indices are not a kind the launch reads: same values, tensor-op route
+        c = G.build_graph('QM9', 5.0, 5.0, 'source_to_target', b.x, b.batch.to(torch.int16), b.pos, ei, num_graphs=32,
+                          n_types=5)
+        assert c.types is None
+        for name in ('node_graph', 'gptr', 'dist_g', 'dist_l', 'tp_angle', 'tp_kind'):
+            assert torch.equal(getattr(a, name), getattr(c, name)), name
+        for name in ('glob', 'loc', 'tp'):
+            for f in ('ptr', 'row_of', 'col'):
+                assert torch.equal(getattr(getattr(a, name), f), getattr(getattr(c, name), f)), (name, f)
+        assert torch.equal(a.types, b.x.reshape(-1).to(torch.int32))
+    bad = b.batch.clone(); bad[5] = 40
+    with pytest.raises(IndexError):
+        G.build_graph('QM9', 5.0, 5.0, 'source_to_target', b.x, bad, b.pos, b.edge_index, num_graphs=32, n_types=5)
