@@ -302,6 +302,33 @@ def test_basis_vs_golden_tables(dev, golden):
         assert err < max(3e-6, 2 * ref32_err[l]), (l, err, ref32_err[l])
 
 
+@pytest.mark.parametrize('cutoff', [5.0, 2.0, 16.0])
+def test_sbf_radial_dense_grid_vs_oracle(dev, cutoff):
+    """The 42 radial functions on a dense grid of edge lengths (series branch, recurrence branch and beyond the cutoff)
+    against env(x) N_ln j_l(z_ln x) with scipy's spherical_jn in fp64 (the oracle's closed sin / cos forms lose ~1e-6 of
+    the block maximum to cancellation at small z even in fp64); block by block, relative to the block's largest value."""
+    from pamnet_amd import lib
+    from oracle import pamnet_oracle as O
+    m = 20011
+    dist = torch.linspace(0.02 * cutoff, 1.08 * cutoff, m, device=dev)
+    rad = torch.empty(m * 42, device=dev)
+    lib.call('pamnet_sbf_radial_f32', lib.ptr(dist), cutoff, m, lib.ptr(rad), lib.stream_of(dist))
+    x32 = (dist * torch.tensor(1.0 / cutoff, dtype=torch.float32, device=dev)).cpu()    # the kernel's fp32 d / cutoff
+    k = O.basis_constants()
+    xd = x32.double()
+    zx = xd.unsqueeze(-1).numpy() * k['zeros'].astype(np.float64).reshape(1, 42)
+    jl = np.concatenate([O._sph_jn_f64(l, zx[:, 6 * l:6 * l + 6]) for l in range(7)], axis=1)
+    ref = O.envelope(xd).unsqueeze(-1) * torch.from_numpy(jl * np.asarray(k['norm'], dtype=np.float64).reshape(1, 42))
+    assert float((ref - O.sbf_radial(xd, 1.0)).abs().max() / ref.abs().max()) < 1e-5        # same functions as the oracle's
+    got = rad.view(m, 42).cpu().double()
+    assert torch.isfinite(got).all()
+    assert (got[x32 >= 1.0] == 0).all()
+    for l in range(7):
+        blk = slice(6 * l, 6 * l + 6)
+        err = float((got[:, blk] - ref[:, blk]).abs().max() / ref[:, blk].abs().max())
+        assert err < 2e-7, (l, err)
+
+
 def test_rbf_backward_freq(dev):
     from pamnet_amd import ops
     from oracle import pamnet_oracle as O
