@@ -164,6 +164,12 @@ int pamnet_ingest_indices_i32(const void* batch, int32_t batch_kind, int64_t n, 
 /* out_a[q] = a[perm[q]], out_b[q] = b[perm[q]]: the bond list in CSR order of its targets (models.py:71-73). */
 int pamnet_gather2_i32(const int32_t* perm, const int32_t* a, const int32_t* b, int64_t m, int32_t* out_a,
                        int32_t* out_b, pamnet_stream_t stream);
+/* An edge list stored by query node, re-stored by neighbour (models.py:147-156 aggregate the kNN edges at the neighbour):
+ * with perm = the stable counting sort of the neighbour column, out_q[e'] = q[perm[e']], out_dist[e'] = dist[perm[e']],
+ * and inv[perm[e']] = e' (nullable) -- the positions of the query-ordered edges in the new list, i.e. together with the
+ * query-ordered CSR pointer the transposed CSR the backward gathers d x[j] with. */
+int pamnet_transpose_gather_i32(const int32_t* perm, const int32_t* q, const float* dist, int64_t m, int32_t* out_q,
+                                float* out_dist, int32_t* inv, pamnet_stream_t stream);
 int pamnet_collate_f32(int64_t n_graphs, const int32_t* sel, const int32_t* out_nptr, const int32_t* out_eptr,
                        const int32_t* src_nptr, const int32_t* src_eptr, const float* x, int64_t x_width,
                        const float* pos, const int32_t* esrc, const int32_t* edst, int64_t n_out, int64_t e_out,

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void sort_rows_kernel(const int32_t* __restric
 // tools/noprefetch_bound.py).  One workgroup does the whole scan / the whole stable counting sort on one CU instead;
 // results are identical (same stable order), so the large-input forms remain the reference in the tests.
 constexpr int SMALL_THREADS = 1024;
-constexpr int SMALL_SCAN_MAX = 1 << 16;       // elements
+constexpr int SMALL_SCAN_MAX = 24576;         // elements (runs of <= 24 per thread; beyond, the strided run reads lose to three launches: 29 us vs 12 at 65 k)
 constexpr int SMALL_CSR_ROWS = 12288;         // rows (counters live in LDS)
 constexpr int SMALL_CSR_KEYS = 1 << 13;      // beyond this the ranking pass of ONE workgroup (sum of squared row lengths, L2 loads)
                                               // takes longer than the nine small launches: 65 us against ~36 at 33 k keys
@@ -196,18 +196,41 @@ __device__ __forceinline__ int block_excl_scan(int x, int* wt, int& total) {
     return off + incl - x;
 }
 
+// Every thread owns a contiguous run of ceil(n / 1024) elements: one pass to sum the run, ONE workgroup scan over the
+// 1 024 run totals, one pass to write the prefixes (the second read of the run comes out of the L1 / L2).  (The earlier
+// form scanned 1 024 elements per iteration with a dependent global load and two barriers in each: 15 us at 17.7 k.)
 __global__ __launch_bounds__(SMALL_THREADS) void scan_small_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out,
                                                                    int n) {
     __shared__ int wt[SMALL_THREADS / 64];
-    int carry = 0;
+    const int run = (n + SMALL_THREADS - 1) / SMALL_THREADS;
+    const int beg = min((int)threadIdx.x * run, n), end = min(beg + run, n);
+    int sum = 0;
+    int k = beg;
+    for (; k + 8 <= end; k += 8) {                            // eight independent loads in flight
+        int a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = in[k + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += a[u];
+    }
+    for (; k < end; ++k) sum += in[k];
+    int total;
+    int acc = block_excl_scan(sum, wt, total);
     if (threadIdx.x == 0) out[0] = 0;
-    for (int base = 0; base < n; base += SMALL_THREADS) {
-        const int g = base + (int)threadIdx.x;
-        const int x = g < n ? in[g] : 0;
-        int total;
-        const int ex = block_excl_scan(x, wt, total);
-        if (g < n) out[g + 1] = carry + ex + x;
-        carry += total;
+    k = beg;
+    for (; k + 8 <= end; k += 8) {
+        int a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = in[k + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc += a[u];
+            out[k + u + 1] = acc;
+        }
+    }
+    for (; k < end; ++k) {
+        acc += in[k];
+        out[k + 1] = acc;
     }
 }
 
@@ -1089,7 +1112,35 @@ __global__ __launch_bounds__(256) void gather2_kernel(const int32_t* __restrict_
     oa[q] = ok ? a[p] : 0;
     ob[q] = ok ? b[p] : 0;
 }
+
+// transposed edge list from the counting sort's permutation: slot e' takes the query node and the length of original edge
+// perm[e'], and the inverse permutation is noted on the way (it IS the transposed CSR of the transposed list: see
+// graph.InverseTranspose)
+__global__ __launch_bounds__(256) void transpose_gather_kernel(const int32_t* __restrict__ perm,
+                                                               const int32_t* __restrict__ q,
+                                                               const float* __restrict__ dist, int64_t m,
+                                                               int32_t* __restrict__ out_q, float* __restrict__ out_dist,
+                                                               int32_t* __restrict__ inv) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const int p = perm[t];
+    const bool ok = (uint64_t)p < (uint64_t)m;
+    out_q[t] = ok ? q[p] : 0;
+    out_dist[t] = ok ? dist[p] : 0.f;
+    if (ok && inv) inv[p] = (int32_t)t;
+}
 }  // namespace
+
+extern "C" int pamnet_transpose_gather_i32(const int32_t* perm, const int32_t* q, const float* dist, int64_t m,
+                                           int32_t* out_q, float* out_dist, int32_t* inv, pamnet_stream_t stream) {
+    if (m < 0) return PAMNET_EINVAL;
+    if (m == 0) return PAMNET_OK;
+    if (!perm || !q || !dist || !out_q || !out_dist) return PAMNET_ENULL;
+    hipLaunchKernelGGL(transpose_gather_kernel, dim3(blocks_for(m)), dim3(256), 0, as_stream(stream), perm, q, dist, m,
+                       out_q, out_dist, inv);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
 
 extern "C" int pamnet_ingest_indices_i32(const void* batch, int32_t batch_kind, int64_t n, int64_t n_graphs, const void* x,
                                          int32_t x_kind, int64_t x_stride, int64_t n_types, const void* edge_src,

@@ -234,13 +234,28 @@ def knn_table(pos, node_graph, gptr, k, cutoff):
     return ptr, nbr, dist
 
 
-def _transpose_edges(ptr, nbr, dist, n, zeroed=False):
-    """CSR by query (q -> nbr) turned into CSR by nbr (aggregate at nbr, other endpoint q)."""
-    total = nbr.numel()
+class InverseTranspose(object):
+    """Transposed CSR of an edge list that was itself produced by transposing a query-ordered list (the RNA kNN graphs):
+    row r = query r holds the new positions of r's original edges -- the query-ordered pointer and the inverse of the
+    transposition's permutation, both by-products of _transpose_edges.  Same rows as Transpose(csr.col, n), entries in the
+    original (kNN) order inside a row instead of ascending."""
+    __slots__ = ('ptr', 'perm', 'rows')
+
+    def __init__(self, ptr, inv):
+        self.ptr, self.perm, self.rows = ptr, inv, int(ptr.numel() - 1)
+
+
+def _transpose_edges(ptr, nbr, dist, n, zeroed=False, want_inverse=False):
+    """CSR by query (q -> nbr) turned into CSR by nbr (aggregate at nbr, other endpoint q).  Returns (ptr, q, dist) of the
+    new list and, with want_inverse, the InverseTranspose that gathers along it in the backward."""
+    total = int(nbr.numel())
     q = expand_rows(ptr, total, zeroed=zeroed)
     tptr, perm = csr_from_keys(nbr, n)
-    pl = perm.long()
-    return tptr, q[pl].contiguous(), dist[pl].contiguous()
+    out_q, out_d = _i32(total, nbr.device), _f32(total, nbr.device)
+    inv = _i32(total, nbr.device) if want_inverse else None
+    lib.call('pamnet_transpose_gather_i32', lib.ptr(perm), lib.ptr(q), lib.ptr(dist), total, lib.ptr(out_q), lib.ptr(out_d),
+             lib.ptr(inv), lib.stream_of(nbr))
+    return tptr, out_q, out_d, (InverseTranspose(ptr, inv) if want_inverse else None)
 
 
 def _triplet_ptr(lp, l_src, l_dst, with_triplets):
@@ -477,9 +492,11 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             qp, qn, qd = _filter_fill(kp, kn, kd, cutoff_l, pb, total_l, zeroed=hinted)
         else:
             (gp, gn, gd), (qp, qn, qd) = csr_filter2(kp, kn, kd, cutoff_g, cutoff_l, flag)
+        glob_inv = None
         if flow != 'target_to_source':                                          # aggregate at edge_index[1] = neighbour
-            gp, gn, gd = _transpose_edges(gp, gn, gd, n, zeroed=hinted)
-        lp, l_src, l_dist = _transpose_edges(qp, qn, qd, n, zeroed=hinted)     # local layer always aggregates at i
+            gp, gn, gd, glob_inv = _transpose_edges(gp, gn, gd, n, zeroed=hinted, want_inverse=need_grad)
+        lp, l_src, l_dist, loc_inv = _transpose_edges(qp, qn, qd, n, zeroed=hinted, want_inverse=need_grad)
+        # (the local layer always aggregates at i)
         l_dst = expand_rows(lp, l_src.numel(), zeroed=hinted)
     else:
         raise ValueError("Invalid dataset. If you are using any dataset related to RNA 3D structure prediction, "
@@ -515,9 +532,13 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     g.glob_T = g.loc_T = g.tp_T = _NoTranspose    # forward-only: backward index structures are not built
     if need_grad:
         radius_g = dataset in ('QM9', 'PDBbind')       # symmetric by construction (the kNN graphs of the RNA path are not)
-        g.glob_T = SymmetricTranspose(g.glob) if radius_g else Transpose(g.glob.col, n)       # d x[j] of the global gather
-        # the local graph: a radius graph for PDBbind; user-supplied bonds (QM9) and kNN cuts (RNA) take the counting sort
-        g.loc_T = SymmetricTranspose(g.loc) if dataset == 'PDBbind' else Transpose(g.loc.col, n)   # d x[j] of the local gather
+        # d x[j] of the global gather: the reverse-edge index of a radius graph; for the RNA kNN cut the inverse of the
+        # transposition that stored it by neighbour; a counting sort otherwise
+        g.glob_T = SymmetricTranspose(g.glob) if radius_g else (glob_inv if rna and glob_inv is not None
+                                                               else Transpose(g.glob.col, n))
+        # d x[j] of the local gather: a radius graph for PDBbind, the inverse transposition for RNA; user-supplied bonds
+        # (QM9) take the counting sort
+        g.loc_T = SymmetricTranspose(g.loc) if dataset == 'PDBbind' else (loc_inv if rna else Transpose(g.loc.col, n))
         g.tp_T = Transpose(tp_idx, max(e_l, 1))       # d m_neighbor[e'] of the triplet/pair gather
     return g
 

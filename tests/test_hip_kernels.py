@@ -122,7 +122,7 @@ def test_segment_ops_autograd(dev):
         assert maxnorm_err(a.cpu(), b.cpu()) < 2e-6
 
 
-@pytest.mark.parametrize('n', [0, 1, 5, 1023, 1024, 1025, 4096, 4097, 65535, 65536, 65537, 100000, 1 << 20])
+@pytest.mark.parametrize('n', [0, 1, 5, 1023, 1024, 1025, 4096, 4097, 65535, 65536, 65537, 100000, 24575, 24576, 24577, 1 << 20])
 def test_exclusive_scan_bit_exact(dev, n):
     from pamnet_amd import graph as G
     x = torch.randint(0, 50, (n,), dtype=torch.int32, device=dev)
@@ -598,3 +598,23 @@ def test_qm9_graph_same_with_and_without_ingest(dev):
     bad = b.batch.clone(); bad[5] = 40
     with pytest.raises(IndexError):
         G.build_graph('QM9', 5.0, 5.0, 'source_to_target', b.x, bad, b.pos, b.edge_index, num_graphs=32, n_types=5)
+
+
+@pytest.mark.parametrize('flow', ['source_to_target', 'target_to_source'])
+def test_rna_inverse_transpose_rows_match_counting_sort(dev, flow):
+    """The backward index of the RNA kNN graphs (query-ordered pointer + inverse of the transposition) holds, row by row,
+    the same entries as the stable counting sort over the stored columns (their order inside a row is the kNN order)."""
+    from pamnet_amd import graph as G, synth
+    b = synth.rna_batch(2, 0, 2).to(dev)
+    g = G.build_graph('rna_native', 16.0, 20.0, flow, b.x, b.batch, num_graphs=2, n_types=4)
+    pairs = [(g.loc, g.loc_T)] + ([(g.glob, g.glob_T)] if flow == 'source_to_target' else [])
+    for csr, tr in pairs:
+        assert isinstance(tr, G.InverseTranspose)
+        ref = G.Transpose(csr.col, g.n)
+        assert torch.equal(tr.ptr, ref.ptr)
+        assert torch.equal(csr.col[tr.perm.long()], csr.col[ref.perm.long()])          # every entry sits in its row
+        assert torch.equal(torch.sort(tr.perm).values, torch.arange(csr.m, device=dev, dtype=torch.int32))   # a permutation
+        key = csr.col[tr.perm.long()].long() * csr.m
+        assert torch.equal(torch.sort(key + tr.perm.long()).values, key + ref.perm.long())   # same set per row
+    if flow == 'target_to_source':
+        assert isinstance(g.glob_T, G.Transpose)
