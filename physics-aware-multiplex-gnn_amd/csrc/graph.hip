@@ -573,6 +573,9 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pos,
     }
 }
 
+// One wavefront per input row: the lanes read 64 consecutive entries (coalesced), vote, and the survivors keep their
+// order through the prefix population count of the ballot.  (One thread per row walked its 50 entries alone, 200 bytes
+// apart from its neighbour lane: 23 us per pass over the 17 700 x 50 RNA table.)
 template <bool FILL>
 __global__ __launch_bounds__(256) void csr_filter_kernel(const int32_t* __restrict__ ptr_in,
                                                          const int32_t* __restrict__ nbr,
@@ -581,22 +584,32 @@ __global__ __launch_bounds__(256) void csr_filter_kernel(const int32_t* __restri
                                                          const int32_t* __restrict__ ptr_out,
                                                          int32_t* __restrict__ nbr_out, float* __restrict__ dist_out,
                                                          int64_t cap) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= rows) return;
+    const int beg = ptr_in[r], end = ptr_in[r + 1];
     int c = 0;
-    int64_t w = FILL ? ptr_out[r] : 0;
-    for (int q = ptr_in[r]; q < ptr_in[r + 1]; ++q) {
-        const int j = nbr[q];
-        const float d = dist[q];
-        if (j >= 0 && d <= cut) {
-            if (FILL) {
-                if (w < cap) { nbr_out[w] = j; dist_out[w] = d; }
-                ++w;
-            }
-            ++c;
+    const int64_t w0 = FILL ? ptr_out[r] : 0;
+    for (int q0 = beg; q0 < end; q0 += 64) {
+        const int q = q0 + lane;
+        int j = -1;
+        float d = 0.f;
+        if (q < end) {
+            j = nbr[q];
+            d = dist[q];
         }
+        const bool keep = q < end && j >= 0 && d <= cut;
+        const unsigned long long votes = __ballot(keep);
+        if (FILL && keep) {
+            const int64_t w = w0 + c + __builtin_popcountll(votes & ((1ull << lane) - 1ull));
+            if (w < cap) {
+                nbr_out[w] = j;
+                dist_out[w] = d;
+            }
+        }
+        c += __builtin_popcountll(votes);
     }
-    if (!FILL) count[r] = c;
+    if (!FILL && lane == 0) count[r] = c;
 }
 
 __global__ __launch_bounds__(256) void edge_dist_kernel(const float* __restrict__ pos, const int32_t* __restrict__ a,
@@ -791,7 +804,7 @@ extern "C" int pamnet_csr_filter_count_i32(const int32_t* ptr_in, const int32_t*
     if (rows < 0) return PAMNET_EINVAL;
     if (rows == 0) return PAMNET_OK;
     if (!ptr_in || !nbr || !dist || !count) return PAMNET_ENULL;
-    hipLaunchKernelGGL((csr_filter_kernel<false>), dim3(blocks_for(rows)), dim3(256), 0, as_stream(stream), ptr_in, nbr,
+    hipLaunchKernelGGL((csr_filter_kernel<false>), dim3(blocks_for(rows, 4)), dim3(256), 0, as_stream(stream), ptr_in, nbr,
                        dist, rows, cut, count, (const int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (int64_t)0);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
@@ -803,7 +816,7 @@ extern "C" int pamnet_csr_filter_fill_i32(const int32_t* ptr_in, const int32_t* 
     if (rows < 0 || cap < 0) return PAMNET_EINVAL;
     if (rows == 0) return PAMNET_OK;
     if (!ptr_in || !nbr || !dist || !ptr_out || !nbr_out || !dist_out) return PAMNET_ENULL;
-    hipLaunchKernelGGL((csr_filter_kernel<true>), dim3(blocks_for(rows)), dim3(256), 0, as_stream(stream), ptr_in, nbr,
+    hipLaunchKernelGGL((csr_filter_kernel<true>), dim3(blocks_for(rows, 4)), dim3(256), 0, as_stream(stream), ptr_in, nbr,
                        dist, rows, cut, (int32_t*)nullptr, ptr_out, nbr_out, dist_out, cap);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;

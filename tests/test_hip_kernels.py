@@ -207,6 +207,27 @@ def test_csr_filter_pair_equals_two_filters(dev):
     assert G.host_ints(kp[-1], torch.tensor(True, device=dev), torch.tensor(7, device=dev)) == [int(kp[-1]), 1, 7]
 
 
+def test_csr_filter_vs_mask_ragged_rows(dev):
+    """Row lengths 0 .. 200 (several 64-entry rounds per row, empty rows, dropped -1 entries): the kept entries and
+    their order equal a boolean-mask compaction."""
+    from pamnet_amd import graph as G
+    rng = np.random.RandomState(9)
+    lens = rng.randint(0, 201, size=777)
+    lens[[0, 5, 776]] = 0
+    lens[[1, 300]] = [64, 128]
+    ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev)
+    m = int(ptr[-1])
+    nbr = torch.from_numpy(rng.randint(-1, 5000, size=m).astype(np.int32)).to(dev)
+    dist = torch.from_numpy(rng.rand(m).astype(np.float32) * 10).to(dev)
+    row_of = G.expand_rows(ptr, m)
+    for cut in (0.0, 3.3, 11.0):
+        p2, n2, d2 = G.csr_filter(ptr, nbr, dist, cut)
+        keep = (nbr >= 0) & (dist <= cut)
+        assert torch.equal(n2, nbr[keep]) and torch.equal(d2, dist[keep])
+        cnt = torch.bincount(row_of[keep].long(), minlength=777)
+        assert torch.equal(p2.long(), torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), cnt.cumsum(0)]))
+
+
 @pytest.mark.parametrize('n,lattice', [(300, False), (700, True), (4100, False), (5000, True)])
 def test_knn_order_ties_and_large_graphs(dev, n, lattice):
     """The table rows hold the k smallest (squared distance, index) pairs in ascending order: exact integer check
