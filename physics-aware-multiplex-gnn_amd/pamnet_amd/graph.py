@@ -375,16 +375,22 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     g.n = n
     g.n_graphs = int(num_graphs) if num_graphs is not None else int(batch[-1]) + 1
     g.types = None                                # int32 atom types (QM9), by-product of the ingest launch
+    rna = dataset[:3].lower() == 'rna'
     ing = None
-    if dataset == 'QM9' and batch.is_cuda and n > 0 and edge_index is not None and n_types is not None:
-        ing = ingest(batch, g.n_graphs, x_raw, n_types, edge_index)
+    if batch.is_cuda and n > 0:
+        if dataset == 'QM9':
+            if edge_index is not None and n_types is not None:
+                ing = ingest(batch, g.n_graphs, x_raw, n_types, edge_index)
+        elif rna and n_types is not None and x_raw.dim() == 2:                      # the type id is x's last column
+            ing = ingest(batch, g.n_graphs, x_raw[:, -1], n_types)
+        elif rna or dataset == 'PDBbind':
+            ing = ingest(batch, g.n_graphs)
     if ing is not None:
         node_graph, g.gptr, g.types = ing[0], ing[1], ing[2]
     else:
         node_graph = batch.to(I32).contiguous()
         g.gptr, _ = csr_from_keys(node_graph, g.n_graphs)
     g.node_graph = node_graph
-    rna = dataset[:3].lower() == 'rna'
     g.sign = None
     g.check = None                                # device flag word of the zero-host-sync path (see `sizes`)
     tp_pre = None
@@ -454,7 +460,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         if local and sizes is not None:           # zero host round trips (see `sizes`)
             lp = radius_count(pos, node_graph, g.gptr, cutoff_l)
             total_g, total_l, tp_hint = (int(v) for v in sizes)
-            g.check = _input_flag(node_graph, g.n_graphs)
+            g.check = ing[5] if ing is not None else _input_flag(node_graph, g.n_graphs)
             checks += [(gptr_g[-1:], total_g), (lp[-1:], total_l)]
             hinted = _ZeroArena(3 * total_g + 3 * total_l + 4 * tp_hint + 64, dev)
             gptr_g, lp = torch.clamp(gptr_g, max=total_g), torch.clamp(lp, max=total_l)
@@ -464,7 +470,8 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             lp = radius_count(pos, node_graph, g.gptr, cutoff_l)
             deg = (lp[1:] - lp[:-1]).long()
             tp_dev = (deg * deg + (deg * (deg - 1) if with_triplets else 0)).sum()
-            total_g, total_l, tp_total, bad = host_ints(gptr_g[-1], lp[-1], tp_dev, _input_flag(node_graph, g.n_graphs))
+            total_g, total_l, tp_total, bad = host_ints(gptr_g[-1], lp[-1], tp_dev,
+                                                        ing[5] if ing is not None else _input_flag(node_graph, g.n_graphs))
             if bad:
                 _raise_bad_inputs()
             gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g)
@@ -472,7 +479,8 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             tp_hint = tp_total
         else:                                     # (a local cutoff above the global one: the general, dependent order)
             gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, int(gptr_g[-1]))
-            lp, l_src, l_dist = csr_filter(gp, gn, gd, cutoff_l, _input_flag(node_graph, g.n_graphs))
+            lp, l_src, l_dist = csr_filter(gp, gn, gd, cutoff_l,
+                                           ing[5] if ing is not None else _input_flag(node_graph, g.n_graphs))
             tp_hint = None
         l_dst = expand_rows(lp, l_src.numel(), zeroed=hinted)
     elif rna:
@@ -480,7 +488,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         pos = xr[:, :3].to(torch.float32).contiguous()
         kp, kn, kd = knn_table(pos, node_graph, g.gptr, knn_k, float('inf'))   # (query, neighbour) rows, self dropped
         # models.py:147-150 (global) and 153-156 (local: j = query, i = nbr)
-        flag = _input_flag(node_graph, g.n_graphs, xr[:, -1].to(torch.float32), n_types)
+        flag = ing[5] if ing is not None else _input_flag(node_graph, g.n_graphs, xr[:, -1].to(torch.float32), n_types)
         if sizes is not None:                     # zero host round trips (see `sizes`)
             total_g, total_l, tp_hint = (int(v) for v in sizes)
             pa, pb = _filter_count(kp, kn, kd, cutoff_g), _filter_count(kp, kn, kd, cutoff_l)
