@@ -66,8 +66,9 @@ int pamnet_gather_mul2_f32(float* out1, float* out2, const float* A, const int32
 int pamnet_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* tmp, pamnet_stream_t stream);
 
 /* Stable counting sort of m keys in [0, rows): ptr[rows+1] (CSR) and perm[m] with keys[perm[q]] non-decreasing and
- * perm ascending inside a row.  Scratch: `cursor` rows ints, `perm_tmp` m ints, `tmp` ceil(rows/4096)+1 ints (the scan's
- * chunk sums plus one flag: an already non-decreasing key sequence takes the identity-permutation path).  Deterministic. */
+ * perm ascending inside a row.  Scratch: `cursor` rows + 1 ints (the rows' counters plus one flag: an already
+ * non-decreasing key sequence takes the identity-permutation path), `perm_tmp` m ints, `tmp` ceil(rows/4096)+1 ints (the
+ * scan's chunk sums).  Deterministic. */
 /* flag[0] = 1 when the index inputs of a batch are out of range (the reference would raise an IndexError): node_graph not
  * sorted / not in [0, n_graphs), a type (float, element i at types[i * type_stride]; nullable) not in [0, n_types), an
  * edge endpoint (src / dst, nullable with n_edges = 0) not in [0, n).  One launch; flag is zeroed by the call. */

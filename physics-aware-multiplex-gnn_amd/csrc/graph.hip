@@ -113,15 +113,10 @@ __global__ __launch_bounds__(256) void hist_kernel(const int32_t* __restrict__ k
     if (valid && k + 1 < m && keys[k + 1] < key) *unsorted = 1;
 }
 
-__global__ __launch_bounds__(256) void copy_i32_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst,
-                                                       int64_t n) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) dst[k] = src[k];
-}
-
 // sorted key sequence: the stable permutation is the identity.  Otherwise every run claims a block of slots.
 __global__ __launch_bounds__(256) void claim_kernel(const int32_t* __restrict__ keys, int64_t m, int64_t rows,
-                                                    int32_t* __restrict__ cursor, int32_t* __restrict__ perm_tmp,
+                                                    const int32_t* __restrict__ ptr, int32_t* __restrict__ cursor,
+                                                    int32_t* __restrict__ perm_tmp,
                                                     int32_t* __restrict__ perm, const int32_t* __restrict__ unsorted) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (*unsorted == 0) {
@@ -134,7 +129,9 @@ __global__ __launch_bounds__(256) void claim_kernel(const int32_t* __restrict__ 
     const Run r = wave_run(key, valid, lane);
     const bool in_range = (uint64_t)key < (uint64_t)rows;
     int base = 0;
-    if (valid && in_range && r.head == lane) base = atomicAdd(&cursor[key], r.len);
+    // cursor[key] still holds the row's count: runs take their slots from the row's end downwards (any order inside a row
+    // will do, sort_rows_kernel ranks the entries afterwards)
+    if (valid && in_range && r.head == lane) base = ptr[key] + atomicSub(&cursor[key], r.len) - r.len;
     base = __shfl(base, r.head, 64);
     if (valid && in_range) perm_tmp[base + (lane - r.head)] = (int32_t)k;
 }
@@ -734,10 +731,8 @@ extern "C" int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t 
         PAMNET_LAUNCH_CHECK();
         return PAMNET_OK;
     }
-    hipError_t e = hipMemsetAsync(cursor, 0, sizeof(int32_t) * rows, st);
-    if (e != hipSuccess) return (int)e;
-    int32_t* unsorted = tmp + ceil_div(rows, SCAN_CHUNK);    // the spare int behind the scan's chunk sums
-    e = hipMemsetAsync(unsorted, 0, sizeof(int32_t), st);
+    int32_t* unsorted = cursor + rows;                       // the spare int behind the counters: one memset for both
+    hipError_t e = hipMemsetAsync(cursor, 0, sizeof(int32_t) * (rows + 1), st);
     if (e != hipSuccess) return (int)e;
     if (m > 0) {
         hipLaunchKernelGGL(hist_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, rows, cursor, unsorted);
@@ -746,9 +741,8 @@ extern "C" int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t 
     int rc = pamnet_exclusive_scan_i32(cursor, ptr, rows, tmp, stream);
     if (rc) return rc;
     if (m == 0) return PAMNET_OK;
-    hipLaunchKernelGGL(copy_i32_kernel, dim3(blocks_for(rows)), dim3(256), 0, st, ptr, cursor, rows);
-    PAMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(claim_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, rows, cursor, perm_tmp, perm, unsorted);
+    hipLaunchKernelGGL(claim_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, rows, ptr, cursor, perm_tmp, perm,
+                       unsorted);
     PAMNET_LAUNCH_CHECK();
     hipLaunchKernelGGL(sort_rows_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, ptr, perm_tmp, perm, m, rows, unsorted);
     PAMNET_LAUNCH_CHECK();

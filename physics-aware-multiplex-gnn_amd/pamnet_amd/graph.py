@@ -60,7 +60,7 @@ def csr_from_keys(keys, rows):
     m = keys.numel()
     dev = keys.device
     ptr, perm = _i32(rows + 1, dev), _i32(m, dev)
-    cursor, perm_tmp, tmp = _i32(rows, dev), _i32(m, dev), _i32((rows + 4095) // 4096 + 1, dev)
+    cursor, perm_tmp, tmp = _i32(rows + 1, dev), _i32(m, dev), _i32((rows + 4095) // 4096 + 1, dev)
     lib.call('pamnet_csr_from_keys_i32', lib.ptr(keys), m, rows, lib.ptr(ptr), lib.ptr(perm), lib.ptr(cursor),
              lib.ptr(perm_tmp), lib.ptr(tmp), lib.stream_of(keys))
     return ptr, perm
