@@ -19,6 +19,17 @@ def main(path, which=20):
     mainq = max(busy, key=busy.get)
     span = int(seg[-1]['End_Timestamp']) - t0
     print('step span %.1f us; busy per queue: %s' % (span / 1e3, {q: round(v / 1e3, 1) for q, v in busy.items()}))
+    side = collections.Counter()
+    calls = collections.Counter()
+    for r in seg:
+        if r['Queue_Id'] != mainq:
+            nm = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')[:70]
+            side[nm] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+            calls[nm] += 1
+    print('side queue(s), by kernel:')
+    for nm, v in side.most_common():
+        print('   %7.1f us  x%-2d %s' % (v / 1e3, calls[nm], nm))
+    print('main queue, in order (start, duration, gap to the previous kernel):')
     prev = None
     for r in seg:
         if r['Queue_Id'] != mainq:
