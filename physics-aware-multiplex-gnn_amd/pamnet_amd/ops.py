@@ -156,6 +156,21 @@ def run_whole(anchor, run):
     return _Whole.apply(anchor, run)
 
 
+def backward_whole(out, grad):
+    """Backward of a forward recorded as ONE node (run_whole), called directly: the tape is replayed on the calling
+    thread, without torch.autograd's graph task and its hop to the engine's device thread (~50 us of host time per
+    step -- the narrow-width steps are bound by the host).  Same bodies, same order, same gradients as out.backward(grad).
+    Returns False when `out` is not such an output (the caller then uses autograd)."""
+    node = out.grad_fn
+    if node is None or getattr(node, 'tape', None) is None or not isinstance(node, torch.autograd.function.BackwardCFunction) \
+            or not isinstance(node, _Whole._backward_cls):
+        return False
+    with torch.no_grad():
+        node.tape.backward(node.out, grad.contiguous())
+    node.tape = node.out = None
+    return True
+
+
 def segment_sum_raw(out, init, A, ia, B, ib, perm, ptr, rows, d):
     lib.call('pamnet_segment_sum_f32', lib.ptr(out), lib.ptr(init), lib.ptr(A), lib.ptr(ia), lib.ptr(B), lib.ptr(ib),
              lib.ptr(perm), lib.ptr(ptr), rows, d, lib.stream_of(A))

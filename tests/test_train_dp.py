@@ -318,3 +318,42 @@ def test_bench_world2_dry_run_on_cpu():
     j = json.loads(lines[0])
     assert j['dry_run'] is True and j['n_gpus'] == 2 and j['steps'] == 3 and j['config']['global_batch'] == 16
     assert j['scaling'] == 'weak' and j['value'] > 0 and abs(j['value'] - 16 * 3 / (j['ms_per_step'] * 3e-3)) < 1e-6 * j['value']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['qm9_d128', 'rna_d16'])
+def test_direct_tape_backward_equals_autograd(kind):
+    """Trainer.forward_backward replays the recorded forward's backward directly (ops.backward_whole) instead of going
+    through torch.autograd: the flat gradient is bit for bit what out.backward(d_out) leaves."""
+    import models
+    from pamnet_amd import ops, synth
+    from pamnet_amd.train import Trainer
+    dev = torch.device('cuda:0')
+    if kind == 'qm9_d128':
+        cfg = models.Config(dataset='QM9', dim=128, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+        b = synth.qm9_batch(5, 0, 16).to(dev)
+    else:
+        cfg = models.Config(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
+        b = synth.rna_batch(2, 0, 2, n_nodes=300).to(dev)
+    torch.manual_seed(4)
+    model = models.PAMNet(cfg).to(dev)
+    tr = Trainer(model, lr=1e-3)
+    used = []
+    real = ops.backward_whole
+
+    def spy(out, grad):
+        used.append(real(out, grad))
+        return used[-1]
+
+    ops.backward_whole = spy
+    try:
+        tr.forward_backward(b)
+        direct = tr.fp.grad.clone()
+        assert used == [True]
+        ops.backward_whole = lambda out, grad: False                      # the autograd route
+        tr.forward_backward(b)
+        via_autograd = tr.fp.grad.clone()
+    finally:
+        ops.backward_whole = real
+    assert float(direct.abs().max()) > 0
+    assert torch.equal(direct, via_autograd)
