@@ -96,11 +96,14 @@ int pamnet_csr_filter_fill_i32(const int32_t* ptr_in, const int32_t* nbr, const 
  * Neighbour search (torch_cluster.radius / knn: models.py:110,128,143,301), self loops removed (models.py:63).
  * `gptr[b..b+1]` = node range of graph b (batch sorted).  Two-pass: count -> (caller scans) -> fill.
  * radius: neighbours j != i of the same graph with ||pos_i - pos_j|| <= r, ascending j.  Symmetric by construction.
+ * n_graphs (0 = unknown) only selects the launch shape: one thread per node for molecule-sized graphs, one wavefront per
+ * node from ~100 nodes per graph on; the output is the same.
  * ------------------------------------------------------------------------------------------------------------------ */
-int pamnet_radius_count_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n, float r,
-                            int32_t* count, pamnet_stream_t stream);
-int pamnet_radius_fill_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n, float r,
-                           const int32_t* ptr, int32_t* nbr, float* dist, int64_t cap, pamnet_stream_t stream);
+int pamnet_radius_count_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n,
+                            int64_t n_graphs, float r, int32_t* count, pamnet_stream_t stream);
+int pamnet_radius_fill_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n,
+                           int64_t n_graphs, float r, const int32_t* ptr, int32_t* nbr, float* dist, int64_t cap,
+                           pamnet_stream_t stream);
 
 /* knn: for every query node its k nearest nodes of the same graph (itself included, as torch_cluster.knn does),
  * ordered by (distance, index); then the self entry is dropped and entries with dist > cutoff are masked out:

@@ -207,16 +207,16 @@ class Graph(object):
 def radius_count(pos, node_graph, gptr, r):
     n = pos.size(0)
     count = _i32(n, pos.device)
-    lib.call('pamnet_radius_count_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), n, float(r), lib.ptr(count),
-             lib.stream_of(pos))
+    lib.call('pamnet_radius_count_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), n, int(gptr.numel()) - 1,
+             float(r), lib.ptr(count), lib.stream_of(pos))
     return exclusive_scan(count)
 
 
 def radius_fill(pos, node_graph, gptr, r, ptr, total, zeroed=False):
     nbr = _alloc_i32(total, pos.device, zeroed)
     dist = _alloc_f32(total, pos.device, zeroed)
-    lib.call('pamnet_radius_fill_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), pos.size(0), float(r), lib.ptr(ptr),
-             lib.ptr(nbr), lib.ptr(dist), int(total), lib.stream_of(pos))
+    lib.call('pamnet_radius_fill_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), pos.size(0), int(gptr.numel()) - 1,
+             float(r), lib.ptr(ptr), lib.ptr(nbr), lib.ptr(dist), int(total), lib.stream_of(pos))
     return ptr, nbr, dist
 
 

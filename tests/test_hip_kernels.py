@@ -166,6 +166,34 @@ def test_radius_graph_matches_oracle(dev):
     assert float(((d.cpu() - dist[key]).abs() / dist[key]).max()) < 1.3e-7
 
 
+def test_radius_wave_form_equals_thread_form(dev):
+    """Complex-sized graphs (here 3 graphs of 130 / 257 / 64 nodes, average > 96) take the wavefront-per-node search:
+    pointer, neighbours (ascending) and distances equal the thread-per-node form (selected by declaring n_graphs
+    unknown) bit for bit, and the oracle's edge set."""
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import graph as G, lib
+    rng = np.random.RandomState(3)
+    counts = [130, 257, 64]
+    n = sum(counts)
+    pos = torch.from_numpy((rng.rand(n, 3) * 14).astype(np.float32))
+    batch = torch.from_numpy(np.repeat(np.arange(3), counts))
+    nodeg = batch.to(torch.int32).to(dev)
+    gptr, _ = G.csr_from_keys(nodeg, 3)
+    posd = pos.to(dev)
+    ptr, nbr, d = G.radius_graph(posd, nodeg, gptr, 4.0)
+    cnt = torch.empty(n, dtype=torch.int32, device=dev)
+    lib.call('pamnet_radius_count_i32', lib.ptr(posd), lib.ptr(nodeg), lib.ptr(gptr), n, 0, 4.0, lib.ptr(cnt), lib.stream_of(posd))
+    ptr2 = G.exclusive_scan(cnt)
+    assert torch.equal(ptr, ptr2)
+    nbr2, d2 = torch.empty_like(nbr), torch.empty_like(d)
+    lib.call('pamnet_radius_fill_i32', lib.ptr(posd), lib.ptr(nodeg), lib.ptr(gptr), n, 0, 4.0, lib.ptr(ptr2), lib.ptr(nbr2),
+             lib.ptr(d2), nbr.numel(), lib.stream_of(posd))
+    assert torch.equal(nbr, nbr2) and torch.equal(d, d2)
+    ei, _ = O.get_edge_info(O.radius_graph(pos, batch, 4.0), pos)
+    q = G.expand_rows(ptr, nbr.numel())
+    assert _edge_set(q.cpu(), nbr.cpu()) == _edge_set(ei[0], ei[1])
+
+
 def test_knn_matches_oracle(dev):
     from oracle import pamnet_oracle as O
     from pamnet_amd import graph as G, synth
