@@ -102,7 +102,8 @@ int pamnet_csr_filter_fill_i32(const int32_t* ptr_in, const int32_t* nbr, const 
 int pamnet_radius_count_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n,
                             int64_t n_graphs, float r, int32_t* count, pamnet_stream_t stream);
 int pamnet_radius_fill_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n,
-                           int64_t n_graphs, float r, const int32_t* ptr, int32_t* nbr, float* dist, int64_t cap,
+                           int64_t n_graphs, float r, const int32_t* ptr, int32_t* nbr, float* dist,
+                           int32_t* row_of /* nullable: the query node of every entry */, int64_t cap,
                            pamnet_stream_t stream);
 
 /* knn: for every query node its k nearest nodes of the same graph (itself included, as torch_cluster.knn does),
@@ -165,9 +166,10 @@ int pamnet_ingest_indices_i32(const void* batch, int32_t batch_kind, int64_t n, 
                               int32_t x_kind, int64_t x_stride, int64_t n_types, const void* edge_src,
                               const void* edge_dst, int32_t edge_kind, int64_t n_edges, int32_t* node_graph,
                               int32_t* gptr_flag, int32_t* types, int32_t* src, int32_t* dst, pamnet_stream_t stream);
-/* out_a[q] = a[perm[q]], out_b[q] = b[perm[q]]: the bond list in CSR order of its targets (models.py:71-73). */
+/* out_a[q] = a[perm[q]], out_b[q] = b[perm[q]]: the bond list in CSR order of its targets (models.py:71-73); with
+ * dist (nullable; then pos [n,3] is required) also dist[q] = ||pos[out_b[q]] - pos[out_a[q]]|| (models.py:65). */
 int pamnet_gather2_i32(const int32_t* perm, const int32_t* a, const int32_t* b, int64_t m, int32_t* out_a,
-                       int32_t* out_b, pamnet_stream_t stream);
+                       int32_t* out_b, const float* pos, float* dist, pamnet_stream_t stream);
 /* An edge list stored by query node, re-stored by neighbour (models.py:147-156 aggregate the kNN edges at the neighbour):
  * with perm = the stable counting sort of the neighbour column, out_q[e'] = q[perm[e']], out_dist[e'] = dist[perm[e']],
  * and inv[perm[e']] = e' (nullable) -- the positions of the query-ordered edges in the new list, i.e. together with the

@@ -307,7 +307,8 @@ __global__ __launch_bounds__(256) void radius_kernel(const float* __restrict__ p
                                                      const int32_t* __restrict__ node_graph,
                                                      const int32_t* __restrict__ gptr, int64_t n, float r,
                                                      int32_t* __restrict__ count, const int32_t* __restrict__ ptr,
-                                                     int32_t* __restrict__ nbr, float* __restrict__ dist, int64_t cap) {
+                                                     int32_t* __restrict__ nbr, float* __restrict__ dist, int64_t cap,
+                                                     int32_t* __restrict__ row_of) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int g = node_graph[i];
@@ -319,7 +320,11 @@ __global__ __launch_bounds__(256) void radius_kernel(const float* __restrict__ p
         const float d = dist3(pos, i, j);
         if (d <= r) {
             if (FILL) {
-                if (w < cap) { nbr[w] = j; dist[w] = d; }      // cap: see pamnet_radius_fill_i32
+                if (w < cap) {                                 // cap: see pamnet_radius_fill_i32
+                    nbr[w] = j;
+                    dist[w] = d;
+                    if (row_of) row_of[w] = (int32_t)i;
+                }
                 ++w;
             }
             ++c;
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(256) void radius_wave_kernel(const float* __restric
                                                           const int32_t* __restrict__ gptr, int64_t n, float r,
                                                           int32_t* __restrict__ count, const int32_t* __restrict__ ptr,
                                                           int32_t* __restrict__ nbr, float* __restrict__ dist,
-                                                          int64_t cap) {
+                                                          int64_t cap, int32_t* __restrict__ row_of) {
     const int lane = threadIdx.x & 63;
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= n) return;
@@ -360,6 +365,7 @@ __global__ __launch_bounds__(256) void radius_wave_kernel(const float* __restric
             if (w < cap) {
                 nbr[w] = j;
                 dist[w] = d;
+                if (row_of) row_of[w] = (int32_t)i;
             }
         }
         c += __builtin_popcountll(votes);
@@ -809,26 +815,27 @@ extern "C" int pamnet_radius_count_i32(const float* pos, const int32_t* node_gra
     if (n_graphs > 0 && n >= RADIUS_WAVE_MIN_NODES * n_graphs)
         hipLaunchKernelGGL((radius_wave_kernel<false>), dim3(blocks_for(n, 4)), dim3(256), 0, as_stream(stream), pos,
                            node_graph, gptr, n, r, count, (const int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr,
-                           (int64_t)0);
+                           (int64_t)0, (int32_t*)nullptr);
     else
         hipLaunchKernelGGL((radius_kernel<false>), dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), pos, node_graph,
-                           gptr, n, r, count, (const int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (int64_t)0);
+                           gptr, n, r, count, (const int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (int64_t)0,
+                           (int32_t*)nullptr);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
 
 extern "C" int pamnet_radius_fill_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n,
                                       int64_t n_graphs, float r, const int32_t* ptr, int32_t* nbr, float* dist,
-                                      int64_t cap, pamnet_stream_t stream) {
+                                      int32_t* row_of, int64_t cap, pamnet_stream_t stream) {
     if (n < 0 || cap < 0 || n_graphs < 0) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
     if (!pos || !node_graph || !gptr || !ptr || !nbr || !dist) return PAMNET_ENULL;
     if (n_graphs > 0 && n >= RADIUS_WAVE_MIN_NODES * n_graphs)
         hipLaunchKernelGGL((radius_wave_kernel<true>), dim3(blocks_for(n, 4)), dim3(256), 0, as_stream(stream), pos,
-                           node_graph, gptr, n, r, (int32_t*)nullptr, ptr, nbr, dist, cap);
+                           node_graph, gptr, n, r, (int32_t*)nullptr, ptr, nbr, dist, cap, row_of);
     else
         hipLaunchKernelGGL((radius_kernel<true>), dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), pos, node_graph,
-                           gptr, n, r, (int32_t*)nullptr, ptr, nbr, dist, cap);
+                           gptr, n, r, (int32_t*)nullptr, ptr, nbr, dist, cap, row_of);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -1162,13 +1169,16 @@ __global__ __launch_bounds__(256) void ingest_kernel(Ingest c) {
 
 __global__ __launch_bounds__(256) void gather2_kernel(const int32_t* __restrict__ perm, const int32_t* __restrict__ a,
                                                       const int32_t* __restrict__ b, int64_t m, int32_t* __restrict__ oa,
-                                                      int32_t* __restrict__ ob) {
+                                                      int32_t* __restrict__ ob, const float* __restrict__ pos,
+                                                      float* __restrict__ dist) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= m) return;
     const int p = perm[q];
     const bool ok = (uint64_t)p < (uint64_t)m;
-    oa[q] = ok ? a[p] : 0;
-    ob[q] = ok ? b[p] : 0;
+    const int va = ok ? a[p] : 0, vb = ok ? b[p] : 0;
+    oa[q] = va;
+    ob[q] = vb;
+    if (dist) dist[q] = dist3(pos, vb, va);                   // ||pos_i - pos_j||, i = b (target), j = a (models.py:65)
 }
 
 // transposed edge list from the counting sort's permutation: slot e' takes the query node and the length of original edge
@@ -1228,11 +1238,12 @@ extern "C" int pamnet_ingest_indices_i32(const void* batch, int32_t batch_kind, 
 }
 
 extern "C" int pamnet_gather2_i32(const int32_t* perm, const int32_t* a, const int32_t* b, int64_t m, int32_t* out_a,
-                                  int32_t* out_b, pamnet_stream_t stream) {
+                                  int32_t* out_b, const float* pos, float* dist, pamnet_stream_t stream) {
     if (m < 0) return PAMNET_EINVAL;
     if (m == 0) return PAMNET_OK;
-    if (!perm || !a || !b || !out_a || !out_b) return PAMNET_ENULL;
-    hipLaunchKernelGGL(gather2_kernel, dim3(blocks_for(m)), dim3(256), 0, as_stream(stream), perm, a, b, m, out_a, out_b);
+    if (!perm || !a || !b || !out_a || !out_b || (dist && !pos)) return PAMNET_ENULL;
+    hipLaunchKernelGGL(gather2_kernel, dim3(blocks_for(m)), dim3(256), 0, as_stream(stream), perm, a, b, m, out_a, out_b,
+                       pos, dist);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

@@ -212,11 +212,16 @@ def radius_count(pos, node_graph, gptr, r):
     return exclusive_scan(count)
 
 
-def radius_fill(pos, node_graph, gptr, r, ptr, total, zeroed=False):
+def radius_fill(pos, node_graph, gptr, r, ptr, total, zeroed=False, rows_out=None):
+    """`rows_out`: a one-element list that receives the expanded row ids (the query node of every entry), written by the
+    same launch."""
     nbr = _alloc_i32(total, pos.device, zeroed)
     dist = _alloc_f32(total, pos.device, zeroed)
+    row_of = _alloc_i32(total, pos.device, zeroed) if rows_out is not None else None
     lib.call('pamnet_radius_fill_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), pos.size(0), int(gptr.numel()) - 1,
-             float(r), lib.ptr(ptr), lib.ptr(nbr), lib.ptr(dist), int(total), lib.stream_of(pos))
+             float(r), lib.ptr(ptr), lib.ptr(nbr), lib.ptr(dist), lib.ptr(row_of), int(total), lib.stream_of(pos))
+    if rows_out is not None:
+        rows_out.append(row_of)
     return ptr, nbr, dist
 
 
@@ -397,6 +402,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     tp_hint = None                                # triplet + pair rows already known on the host (PDBbind)
     hinted = False
     checks = []                                   # (device total, value the host assumed), verified by one launch at the end
+    glob_rows = []                                # row ids of the global edges when the launch that fills them writes them
 
     if dataset == 'QM9':
         pos = pos.to(torch.float32).contiguous()
@@ -410,9 +416,9 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             bonds.raw = (src0, dst0)
             lp_, perm = csr_from_keys(dst0, n)
             m = int(src0.numel())
-            src_, dst_ = _i32(m, dev), _i32(m, dev)
+            src_, dst_, bonds.dist = _i32(m, dev), _i32(m, dev), _f32(m, dev)
             lib.call('pamnet_gather2_i32', lib.ptr(perm), lib.ptr(src0), lib.ptr(dst0), m, lib.ptr(src_), lib.ptr(dst_),
-                     lib.stream_of(src0))
+                     lib.ptr(pos), lib.ptr(bonds.dist), lib.stream_of(src0))      # + the bond lengths (models.py:65)
             return lp_, src_, dst_, _triplet_ptr(lp_, src_, dst_, with_triplets)
 
         ei = edge_index
@@ -443,8 +449,8 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             if (k != 0) if ing is not None else (not k):                        # the bond list has self loops
                 lp, l_src, l_dst, tp_ptr = bonds(ei[:, ei[0] != ei[1]])
                 tp_total = int(tp_ptr[-1])
-        gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g, zeroed=hinted)
-        l_dist = edge_dist(pos, l_dst, l_src)
+        gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g, zeroed=hinted, rows_out=glob_rows)
+        l_dist = bonds.dist
         tp_pre = (tp_ptr, tp_total)
     elif dataset == 'PDBbind':
         xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
@@ -464,7 +470,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             checks += [(gptr_g[-1:], total_g), (lp[-1:], total_l)]
             hinted = _ZeroArena(3 * total_g + 3 * total_l + 4 * tp_hint + 64, dev)
             gptr_g, lp = torch.clamp(gptr_g, max=total_g), torch.clamp(lp, max=total_l)
-            gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g, zeroed=hinted)
+            gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g, zeroed=hinted, rows_out=glob_rows)
             lp, l_src, l_dist = _filter_fill(gp, gn, gd, cutoff_l, lp, total_l, zeroed=hinted)
         elif local:
             lp = radius_count(pos, node_graph, g.gptr, cutoff_l)
@@ -474,7 +480,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
                                                         ing[5] if ing is not None else _input_flag(node_graph, g.n_graphs))
             if bad:
                 _raise_bad_inputs()
-            gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g)
+            gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g, rows_out=glob_rows)
             lp, l_src, l_dist = _filter_fill(gp, gn, gd, cutoff_l, lp, total_l)
             tp_hint = tp_total
         else:                                     # (a local cutoff above the global one: the general, dependent order)
@@ -511,7 +517,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
                          "be sure to use 'rna' as the first 3 characters of the dataset name.")
 
     g.pos = pos
-    g.glob = CSR(gp, expand_rows(gp, gn.numel(), zeroed=hinted), gn)
+    g.glob = CSR(gp, glob_rows[0] if glob_rows else expand_rows(gp, gn.numel(), zeroed=hinted), gn)
     g.dist_g = gd
     g.loc = CSR(lp, l_dst, l_src)
     g.dist_l = l_dist

@@ -186,9 +186,13 @@ def test_radius_wave_form_equals_thread_form(dev):
     ptr2 = G.exclusive_scan(cnt)
     assert torch.equal(ptr, ptr2)
     nbr2, d2 = torch.empty_like(nbr), torch.empty_like(d)
+    rows2 = torch.empty_like(nbr)
     lib.call('pamnet_radius_fill_i32', lib.ptr(posd), lib.ptr(nodeg), lib.ptr(gptr), n, 0, 4.0, lib.ptr(ptr2), lib.ptr(nbr2),
-             lib.ptr(d2), nbr.numel(), lib.stream_of(posd))
+             lib.ptr(d2), lib.ptr(rows2), nbr.numel(), lib.stream_of(posd))
     assert torch.equal(nbr, nbr2) and torch.equal(d, d2)
+    rows = []
+    G.radius_fill(posd, nodeg, gptr, 4.0, ptr, nbr.numel(), rows_out=rows)       # the wavefront form writes the same row ids
+    assert torch.equal(rows[0], rows2) and torch.equal(rows2, G.expand_rows(ptr, nbr.numel()))
     ei, _ = O.get_edge_info(O.radius_graph(pos, batch, 4.0), pos)
     q = G.expand_rows(ptr, nbr.numel())
     assert _edge_set(q.cpu(), nbr.cpu()) == _edge_set(ei[0], ei[1])
