@@ -69,13 +69,15 @@ def ptr(t):
     never dereferenced (every kernel is bounded by the row count, which is 0)."""
     if t is None:
         return None
-    assert t.is_contiguous(), 'pamnet_hip: tensor must be contiguous'
-    if t.numel() == 0 and t.is_cuda:
+    p = t.data_ptr()                               # (called ~200 times per step on the host-bound narrow-width paths)
+    if not t.is_contiguous():
+        raise AssertionError('pamnet_hip: tensor must be contiguous')
+    if p == 0 and t.is_cuda:
         import torch
         if t.device not in _EMPTY:
             _EMPTY[t.device] = torch.zeros(64, dtype=torch.float32, device=t.device)
         return _EMPTY[t.device].data_ptr()
-    return t.data_ptr()
+    return p
 
 
 _raw_stream = None
