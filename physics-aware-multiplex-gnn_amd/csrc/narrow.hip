@@ -238,19 +238,41 @@ extern "C" int pamnet_narrow_embed_fwd_f32(const float* F, int64_t m, int64_t k,
             const size_t lds = (two ? 2 : 1) * (size_t)DD * 16 * sizeof(float);                                          \
             if (two)                                                                                                     \
                 hipLaunchKernelGGL((nembed_fwd_kernel<DD, 16, true>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa, ba, Wb, \
-                                   bb, y);                                                                               \
+                                   bb, y, (const float*)nullptr, 0.f);                                                                               \
             else                                                                                                         \
                 hipLaunchKernelGGL((nembed_fwd_kernel<DD, 16, false>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa, ba,  \
-                                   Wb, bb, y);                                                                           \
+                                   Wb, bb, y, (const float*)nullptr, 0.f);                                                                           \
         } else {                                                                                                         \
             const size_t lds = (two ? 2 : 1) * (size_t)DD * 48 * sizeof(float);                                          \
             if (two)                                                                                                     \
                 hipLaunchKernelGGL((nembed_fwd_kernel<DD, 42, true>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa, ba, Wb, \
-                                   bb, y);                                                                               \
+                                   bb, y, (const float*)nullptr, 0.f);                                                                               \
             else                                                                                                         \
                 hipLaunchKernelGGL((nembed_fwd_kernel<DD, 42, false>), dim3(grid), dim3(NWG), lds, st, F, m, kind, Wa, ba,  \
-                                   Wb, bb, y);                                                                           \
+                                   Wb, bb, y, (const float*)nullptr, 0.f);                                                                           \
         }                                                                                                                \
+    }
+    NARROW_DISPATCH(d, CALL)
+#undef CALL
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+/* The 16-wide edge embedding (models.py:185-186) on Bessel rows formed inside the kernel (forward only: inference):
+ * dist [m], freq [16], cutoff as for pamnet_rbf_fwd_f32; the same floats as pamnet_rbf_fwd_f32 + pamnet_narrow_embed_fwd_f32. */
+extern "C" int pamnet_narrow_embed_rbf_fwd_f32(const float* dist, const float* freq, float cutoff, int64_t m, int64_t d,
+                                               const float* Wa, const float* ba, float* y, pamnet_stream_t stream) {
+    if (m < 0 || !width_ok(d) || !(cutoff > 0.f)) return PAMNET_EINVAL;
+    if (m == 0) return PAMNET_OK;
+    if (!dist || !freq || !Wa || !ba || !y) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for(m, fwd_per_cu(d));
+#define CALL(DD)                                                                                                         \
+    {                                                                                                                    \
+        const size_t lds = (size_t)DD * 16 * sizeof(float);                                                              \
+        hipLaunchKernelGGL((nembed_fwd_kernel<DD, 16, false, true>), dim3(grid), dim3(NWG), lds, st, dist, m,             \
+                           (const int32_t*)nullptr, Wa, ba, (const float*)nullptr, (const float*)nullptr, y, freq,       \
+                           1.0f / cutoff);                                                                               \
     }
     NARROW_DISPATCH(d, CALL)
 #undef CALL

@@ -1043,12 +1043,34 @@ __device__ __forceinline__ void load_feat_d(f32x4 (&v)[(K + 15) / 16], const flo
     }
 }
 
-template <int D, int K, bool TWO>
+// Bessel rows formed inside the forward embedding kernel (RBF = true, K = 16; inference): the row of edge e is
+// u(x) sin(freq_n x), x = dist[e] / cutoff (layers/basic.py:74-76) -- the arithmetic of rbf_fwd_kernel, so the values are
+// the same floats; the [E, 16] tensor (55 MB at the RNA batch) is neither written nor read.
+__device__ __forceinline__ float narrow_envelope(float x) {
+    // layers/basic.py:36-51 with p = 5: 1/x - 21 x^5 + 35 x^6 - 15 x^7 for x < 1, else 0 (as envelope_f in basis.hip)
+    if (!(x < 1.0f)) return 0.0f;
+    const float x2 = x * x, x5 = x2 * x2 * x;
+    return 1.0f / x + x5 * (-21.0f + x * (35.0f - 15.0f * x));
+}
+
+__device__ __forceinline__ void rbf_feat_a(float4 (&a)[1], const float* __restrict__ dist, const float (&f)[4],
+                                           float inv_cutoff, int64_t row0, int64_t m, int lane) {
+    const int64_t row = row0 + (lane & 15);
+    const bool ok = row < m;
+    const float x = dist[ok ? row : m - 1] * inv_cutoff;
+    const float u = narrow_envelope(x);
+    a[0] = ok ? make_float4(u * sinf(f[0] * x), u * sinf(f[1] * x), u * sinf(f[2] * x), u * sinf(f[3] * x))
+              : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int D, int K, bool TWO, bool RBF = false>
 __global__ __launch_bounds__(NWG) void nembed_fwd_kernel(const float* __restrict__ F, int64_t m,
                                                          const int32_t* __restrict__ kind,
                                                          const float* __restrict__ Wa, const float* __restrict__ ba,
                                                          const float* __restrict__ Wb, const float* __restrict__ bb,
-                                                         float* __restrict__ y) {
+                                                         float* __restrict__ y, const float* __restrict__ rbf_freq,
+                                                         float rbf_inv_cutoff) {
+    static_assert(!RBF || (K == 16 && !TWO), "Bessel rows are 16 wide, one weight set");
     constexpr int NT = D / 16, NQ = (K + 15) / 16;
     constexpr int IMG = NT * NQ * 64;
     extern __shared__ float4 lds4[];
@@ -1063,10 +1085,16 @@ __global__ __launch_bounds__(NWG) void nembed_fwd_kernel(const float* __restrict
         bja[jt] = ba[16 * jt + c];
         bjb[jt] = TWO ? bb[16 * jt + c] : 0.f;
     }
+    float fr[4] = {0.f, 0.f, 0.f, 0.f};                      // RBF: F is the edge-length vector [m]
+    if constexpr (RBF) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fr[j] = rbf_freq[4 * kg + j];
+    }
     for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * 4) {
         const int64_t row0 = t * 16;
         float4 a[NQ];
-        load_feat_a<K>(a, F, row0, m, lane);
+        if constexpr (RBF) rbf_feat_a(a, F, fr, rbf_inv_cutoff, row0, m, lane);
+        else load_feat_a<K>(a, F, row0, m, lane);
         f32x4 acc[NT];
         zero(acc);
         if (!TWO) {

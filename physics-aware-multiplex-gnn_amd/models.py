@@ -182,9 +182,14 @@ class _PAMNetBase(nn.Module):
         return ops.gather(self.embeddings, idx, tr.ptr if tr else None, tr.perm if tr else None)
 
     def _edge_embeddings(self, g, tape=None):
+        sbf = g.sbf                                                                          # [T+P, 42], no grad
+        if (not torch.is_grad_enabled() and tape is None and self._narrow(g.dist_g) and g.loc.m > 0 and g.glob.m > 0):
+            # inference at dim 16 / 32 / 64: the Bessel rows are formed inside the embedding kernel (no [E, 16] tensor)
+            e_l = narrow.embed_rbf(g.dist_l, self.rbf_l.freq, self.cutoff_l, self.mlp_rbf_l[0][0])
+            e_g = narrow.embed_rbf(g.dist_g, self.rbf_g.freq, self.cutoff_g, self.mlp_rbf_g[0][0])
+            return e_l, e_g, sbf
         rbf_l = self.rbf_l(g.dist_l, tape=tape)
         rbf_g = self.rbf_g(g.dist_g, tape=tape)
-        sbf = g.sbf                                                                          # [T+P, 42], no grad
         if self._embed_fused(rbf_l, self.mlp_rbf_l):
             e_l = fused.embed(rbf_l, self.mlp_rbf_l[0][0], tape=tape, need_dx=True)          # models.py:186
             e_g = fused.embed(rbf_g, self.mlp_rbf_g[0][0], tape=tape, need_dx=True)          # models.py:185

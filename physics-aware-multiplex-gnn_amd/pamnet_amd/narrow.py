@@ -385,6 +385,17 @@ class _Embed(torch.autograd.Function):
         return df, None, dw[0], db[0], (dw[1] if two else None), (db[1] if two else None)
 
 
+def embed_rbf(dist, freq, cutoff, lin):
+    """SiLU(W rbf(dist) + b) with the Bessel rows (layers/basic.py:74-76) formed inside the kernel; forward only (no
+    autograd node: inference).  The same floats as ops.rbf followed by embed."""
+    dist, w, b, freq = _c(dist), _c(lin.weight.detach()), _c(lin.bias.detach()), _c(freq.detach())
+    m, d = int(dist.numel()), w.size(0)
+    y = _empty(m, d, like=dist)
+    lib.call('pamnet_narrow_embed_rbf_fwd_f32', lib.ptr(dist), lib.ptr(freq), float(cutoff), m, d, lib.ptr(w), lib.ptr(b),
+             lib.ptr(y), lib.stream_of(dist))
+    return y
+
+
 def embed(f, lin_a, lin_b=None, kind=None):
     if kind is None:
         return ops.apply(_Embed, f, None, lin_a.weight, lin_a.bias, None, None)

@@ -168,6 +168,22 @@ def test_embed(dev, d, k, two, m):
 
 
 @pytest.mark.parametrize('d', [16, 32, 64])
+@pytest.mark.parametrize('m', [1, 1000, 4099])
+def test_embed_rbf_in_kernel_equals_rbf_then_embed(dev, d, m):
+    """The inference-only embedding on Bessel rows formed inside the kernel returns the floats of the two-step form
+    (pamnet_rbf_fwd_f32 into [m, 16], then the k = 16 embedding); distances on both sides of the cutoff."""
+    from pamnet_amd import narrow, ops
+    torch.manual_seed(d + m)
+    dist = torch.rand(m, device=dev) * 5.6 + 0.3
+    freq = (torch.arange(1, 17, dtype=torch.float32, device=dev) * np.pi) + torch.randn(16, device=dev) * 0.01
+    lin = torch.nn.Linear(16, d).to(dev)
+    with torch.no_grad():
+        two_step = narrow._Embed.apply(ops.rbf(dist, freq, 5.0), None, lin.weight, lin.bias, None, None)
+        fused = narrow.embed_rbf(dist, freq, 5.0, lin)
+    assert torch.equal(two_step, fused)
+
+
+@pytest.mark.parametrize('d', [16, 32, 64])
 @pytest.mark.parametrize('n,max_deg', [(4, 2), (500, 7)])
 def test_local_gate(dev, d, n, max_deg):
     """m_ji / m_nb of the local layer from node- and edge-side projections (layers/local_message_passing.py:46-48)."""
