@@ -603,10 +603,15 @@ int pamnet_narrow_embed_bwd_f32(const float* F, int64_t m, int64_t k, int64_t d,
                                 const float* ba, const float* Wb, const float* bb, const float* dy, float* df,
                                 float* partial, float* dW, float* db, pamnet_stream_t stream);
 /* Forward of the 16-wide embedding on Bessel rows formed inside the kernel (BesselBasisLayer, layers/basic.py:59-76, fused
- * into models.py:185-186; inference): dist [m], freq [16], cutoff as for pamnet_rbf_fwd_f32.  The same floats as
+ * into models.py:185-186): dist [m], freq [16], cutoff as for pamnet_rbf_fwd_f32.  The same floats as
  * pamnet_rbf_fwd_f32 followed by pamnet_narrow_embed_fwd_f32 (k = 16); the [m, 16] basis tensor never exists. */
 int pamnet_narrow_embed_rbf_fwd_f32(const float* dist, const float* freq, float cutoff, int64_t m, int64_t d,
                                     const float* Wa, const float* ba, float* y, pamnet_stream_t stream);
+/* ... and its backward: dW [d, 16]; db_dfreq [d + 16] = the bias gradient followed by the gradient of the 16 frequencies;
+ * partial: blocks x (d * 16 + d + 16) floats (blocks = pamnet_narrow_blocks).  Neither the rows nor their gradient exist. */
+int pamnet_narrow_embed_rbf_bwd_f32(const float* dist, const float* freq, float cutoff, int64_t m, int64_t d,
+                                    const float* Wa, const float* ba, const float* dy, float* partial, float* dW,
+                                    float* db_dfreq, pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Narrow-width layer-stack engine (csrc/narrow_engine.hip): the n_layer x (global, local) loop of PAMNet.forward

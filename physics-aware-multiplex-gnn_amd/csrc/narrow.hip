@@ -300,23 +300,23 @@ extern "C" int pamnet_narrow_embed_bwd_f32(const float* F, int64_t m, int64_t k,
         if (k == 16 && df) {                                                                                              \
             const size_t lds = 2 * (size_t)DD * 16 * sizeof(float) + scratch;                                             \
             hipLaunchKernelGGL((nembed_bwd_kernel<DD, 16, false, true>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, F, m, kind, Wa, ba, \
-                               Wb, bb, dy, df, partial, stride);                                                          \
+                               Wb, bb, dy, df, partial, stride, (const float*)nullptr, 0.f);                                                          \
         } else if (k == 16 && !two) {                                                                                     \
             const size_t lds = (size_t)DD * 16 * sizeof(float) + scratch;                                                 \
             hipLaunchKernelGGL((nembed_bwd_kernel<DD, 16, false, false>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, F, m, kind, Wa,    \
-                               ba, Wb, bb, dy, df, partial, stride);                                                      \
+                               ba, Wb, bb, dy, df, partial, stride, (const float*)nullptr, 0.f);                                                      \
         } else if (k == 16) {                                                                                             \
             const size_t lds = 2 * (size_t)DD * 16 * sizeof(float) + scratch;                                             \
             hipLaunchKernelGGL((nembed_bwd_kernel<DD, 16, true, false>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, F, m, kind, Wa, ba, \
-                               Wb, bb, dy, df, partial, stride);                                                          \
+                               Wb, bb, dy, df, partial, stride, (const float*)nullptr, 0.f);                                                          \
         } else if (!two) {                                                                                                \
             const size_t lds = (size_t)DD * 48 * sizeof(float) + scratch;                                                 \
             hipLaunchKernelGGL((nembed_bwd_kernel<DD, 42, false, false>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, F, m, kind, Wa,    \
-                               ba, Wb, bb, dy, df, partial, stride);                                                      \
+                               ba, Wb, bb, dy, df, partial, stride, (const float*)nullptr, 0.f);                                                      \
         } else {                                                                                                          \
             const size_t lds = 2 * (size_t)DD * 48 * sizeof(float) + scratch;                                             \
             hipLaunchKernelGGL((nembed_bwd_kernel<DD, 42, true, false>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, F, m, kind, Wa, ba, \
-                               Wb, bb, dy, df, partial, stride);                                                          \
+                               Wb, bb, dy, df, partial, stride, (const float*)nullptr, 0.f);                                                          \
         }                                                                                                                 \
     }
     NARROW_DISPATCH(d, CALL)
@@ -325,6 +325,35 @@ extern "C" int pamnet_narrow_embed_bwd_f32(const float* F, int64_t m, int64_t k,
     const int total = (int)(sets * (d * kp + d));
     hipLaunchKernelGGL(narrow_reduce_kernel, dim3((total + 63) / 64), dim3(64, 8), 0, st, partial, grid, stride, sets,
                        (int)d, kp, (int)k, (int)(sets * d), dW, db);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+/* Backward of pamnet_narrow_embed_rbf_fwd_f32: dW [d, 16], db_dfreq [d + 16] = the bias gradient followed by the gradient of
+ * the 16 Bessel frequencies (layers/basic.py:65-76); partial: blocks x (d * 16 + d + 16) floats.  The [m, 16] rows and their
+ * gradient never exist. */
+extern "C" int pamnet_narrow_embed_rbf_bwd_f32(const float* dist, const float* freq, float cutoff, int64_t m, int64_t d,
+                                               const float* Wa, const float* ba, const float* dy, float* partial, float* dW,
+                                               float* db_dfreq, pamnet_stream_t stream) {
+    if (m <= 0 || !width_ok(d) || !(cutoff > 0.f)) return PAMNET_EINVAL;
+    if (!dist || !freq || !Wa || !ba || !dy || !partial || !dW || !db_dfreq) return PAMNET_ENULL;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for(m, 1, bwd_waves((int)d));
+    const int stride = (int)(d * 16 + d + 16);
+#define CALL(DD)                                                                                                            \
+    {                                                                                                                       \
+        const size_t scratch = bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);                                               \
+        const size_t lds = 2 * (size_t)DD * 16 * sizeof(float) + scratch;                                                   \
+        hipLaunchKernelGGL((nembed_bwd_kernel<DD, 16, false, true, true>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st,    \
+                           dist, m, (const int32_t*)nullptr, Wa, ba, (const float*)nullptr, (const float*)nullptr, dy,      \
+                           (float*)nullptr, partial, stride, freq, 1.0f / cutoff);                                          \
+    }
+    NARROW_DISPATCH(d, CALL)
+#undef CALL
+    PAMNET_LAUNCH_CHECK();
+    const int total = (int)(d * 16 + d + 16);
+    hipLaunchKernelGGL(narrow_reduce_kernel, dim3((total + 63) / 64), dim3(64, 8), 0, st, partial, grid, stride, 1, (int)d, 16,
+                       16, (int)(d + 16), dW, db_dfreq);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

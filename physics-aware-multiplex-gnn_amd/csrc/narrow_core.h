@@ -1127,14 +1127,19 @@ __global__ __launch_bounds__(NWG) void nembed_fwd_kernel(const float* __restrict
 
 // backward: partial = [dWa fragments (D x KP)][dWb fragments if TWO][dba (D)][dbb (D) if TWO]; df [m, K] only for
 // the single-set K = 16 case (the Bessel frequencies are trainable, layers/basic.py:65-72).
-template <int D, int K, bool TWO, bool DX>
+// RBF (with DX): F is the edge-length vector [m]; the Bessel rows are formed here (as in the forward), and instead of
+// storing df [m, 16] for a separate kernel the frequency gradient d freq_n = sum_e df[e][n] u(x) x cos(freq_n x)
+// (layers/basic.py:76) is accumulated per lane and leaves in 16 more floats of the workgroup's partial row.
+template <int D, int K, bool TWO, bool DX, bool RBF = false>
 __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const float* __restrict__ F, int64_t m,
                                                          const int32_t* __restrict__ kind,
                                                          const float* __restrict__ Wa, const float* __restrict__ ba,
                                                          const float* __restrict__ Wb, const float* __restrict__ bb,
                                                          const float* __restrict__ dy, float* __restrict__ df,
-                                                         float* __restrict__ partial, int stride) {
+                                                         float* __restrict__ partial, int stride,
+                                                         const float* __restrict__ rbf_freq, float rbf_inv_cutoff) {
     static_assert(!DX || (K == 16 && !TWO), "df only for the single-set 16-wide embedding");
+    static_assert(!RBF || DX, "Bessel rows: the 16-wide single-set embedding with the frequency gradient");
     constexpr int NT = D / 16, NQ = (K + 15) / 16, KP = NQ * 16;
     constexpr int IMG = NT * NQ * 64;
     constexpr int IMGT = NQ * NT * 64;
@@ -1158,10 +1163,18 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const flo
         zero(gwa[jt]);
         if constexpr (TWO) zero(gwb[jt]);
     }
+    float fr[4] = {0.f, 0.f, 0.f, 0.f};
+    float fc = 0.f, facc = 0.f;                              // RBF: this lane's column frequency, its d freq partial sum
+    if constexpr (RBF) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fr[j] = rbf_freq[4 * kg + j];
+        fc = rbf_freq[c];
+    }
     for (int64_t t = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * NW) {
         const int64_t row0 = t * 16;
         float4 a[NQ];
-        load_feat_a<K>(a, F, row0, m, lane);
+        if constexpr (RBF) rbf_feat_a(a, F, fr, rbf_inv_cutoff, row0, m, lane);
+        else load_feat_a<K>(a, F, row0, m, lane);
         f32x4 acc[NT];
         zero(acc);
         if (!TWO) {
@@ -1194,7 +1207,19 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const flo
             }
         }
         f32x4 fd[NQ];
-        load_feat_d<K>(fd, F, row0, m, lane);
+        float xr[4], ur[4];                                   // RBF: x and u(x) of this lane's four rows (4 kg + r)
+        if constexpr (RBF) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + 4 * kg + r;
+                const bool ok = row < m;
+                xr[r] = F[ok ? row : m - 1] * rbf_inv_cutoff;
+                ur[r] = ok ? narrow_envelope(xr[r]) : 0.f;
+                fd[0][r] = ur[r] * sinf(fc * xr[r]);
+            }
+        } else {
+            load_feat_d<K>(fd, F, row0, m, lane);
+        }
         wgrad_acc<NT, NQ>(gwa, dza, fd);
         colsum_acc<NT>(dba, dza);
         if constexpr (TWO) {
@@ -1211,7 +1236,8 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const flo
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = row0 + 4 * kg + r;
-                if (row < m) df[row * K + c] = o[0][r];
+                if constexpr (RBF) facc += o[0][r] * ur[r] * xr[r] * cosf(fc * xr[r]);     // (u = 0 beyond the last row)
+                else if (row < m) df[row * K + c] = o[0][r];
             }
         }
     }
@@ -1227,10 +1253,15 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const flo
                 red_add_mat<NT, NQ>(red + MAT, gwb, lane, w == 0);
                 red_add_bias<NT>(red + NM * MAT + D, dbb, lane, w == 0);
             }
+            if constexpr (RBF) {
+                float fa[1] = {facc};
+                red_add_bias<1>(red + NM * (MAT + D), fa, lane, w == 0);
+            }
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < NM * (MAT + D); i += 64 * NW) partial[(size_t)blockIdx.x * stride + i] = red[i];
+    for (int i = threadIdx.x; i < NM * (MAT + D) + (RBF ? 16 : 0); i += 64 * NW)
+        partial[(size_t)blockIdx.x * stride + i] = red[i];
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------

@@ -183,8 +183,8 @@ class _PAMNetBase(nn.Module):
 
     def _edge_embeddings(self, g, tape=None):
         sbf = g.sbf                                                                          # [T+P, 42], no grad
-        if (not torch.is_grad_enabled() and tape is None and self._narrow(g.dist_g) and g.loc.m > 0 and g.glob.m > 0):
-            # inference at dim 16 / 32 / 64: the Bessel rows are formed inside the embedding kernel (no [E, 16] tensor)
+        if self._narrow(g.dist_g) and g.loc.m > 0 and g.glob.m > 0:
+            # dim 16 / 32 / 64: the Bessel rows are formed inside the embedding kernels (no [E, 16] tensor either way)
             e_l = narrow.embed_rbf(g.dist_l, self.rbf_l.freq, self.cutoff_l, self.mlp_rbf_l[0][0])
             e_g = narrow.embed_rbf(g.dist_g, self.rbf_g.freq, self.cutoff_g, self.mlp_rbf_g[0][0])
             return e_l, e_g, sbf

@@ -385,15 +385,38 @@ class _Embed(torch.autograd.Function):
         return df, None, dw[0], db[0], (dw[1] if two else None), (db[1] if two else None)
 
 
+class _EmbedRbf(torch.autograd.Function):
+    """SiLU(W rbf(dist) + b) with the Bessel rows (layers/basic.py:74-76) formed inside the kernels: neither the [m, 16]
+    rows nor their gradient exist; the backward returns the gradients of the 16 frequencies, W and b.  Forward: the same
+    floats as ops.rbf followed by _Embed."""
+
+    @staticmethod
+    def forward(ctx, dist, freq, cutoff, w, b):
+        dist, freq, w, b = _c(dist), _c(freq), _c(w), _c(b)
+        m, d = int(dist.numel()), w.size(0)
+        y = _empty(m, d, like=dist)
+        lib.call('pamnet_narrow_embed_rbf_fwd_f32', lib.ptr(dist), lib.ptr(freq), float(cutoff), m, d, lib.ptr(w), lib.ptr(b),
+                 lib.ptr(y), lib.stream_of(dist))
+        ctx.save_for_backward(dist, freq, w, b)
+        ctx.cutoff = float(cutoff)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        dist, freq, w, b = ctx.saved_tensors
+        g = _c(g)
+        m, d = int(dist.numel()), w.size(0)
+        if m == 0:
+            return None, torch.zeros_like(freq), None, torch.zeros_like(w), torch.zeros_like(b)
+        partial = _empty(_blocks(m), d * 16 + d + 16, like=g)
+        dw, dbf = _empty(d, 16, like=g), _empty(d + 16, like=g)
+        lib.call('pamnet_narrow_embed_rbf_bwd_f32', lib.ptr(dist), lib.ptr(freq), ctx.cutoff, m, d, lib.ptr(w), lib.ptr(b),
+                 lib.ptr(g), lib.ptr(partial), lib.ptr(dw), lib.ptr(dbf), lib.stream_of(g))
+        return None, dbf[d:], None, dw, dbf[:d]
+
+
 def embed_rbf(dist, freq, cutoff, lin):
-    """SiLU(W rbf(dist) + b) with the Bessel rows (layers/basic.py:74-76) formed inside the kernel; forward only (no
-    autograd node: inference).  The same floats as ops.rbf followed by embed."""
-    dist, w, b, freq = _c(dist), _c(lin.weight.detach()), _c(lin.bias.detach()), _c(freq.detach())
-    m, d = int(dist.numel()), w.size(0)
-    y = _empty(m, d, like=dist)
-    lib.call('pamnet_narrow_embed_rbf_fwd_f32', lib.ptr(dist), lib.ptr(freq), float(cutoff), m, d, lib.ptr(w), lib.ptr(b),
-             lib.ptr(y), lib.stream_of(dist))
-    return y
+    return ops.apply(_EmbedRbf, dist, freq, cutoff, lin.weight, lin.bias)
 
 
 def embed(f, lin_a, lin_b=None, kind=None):

@@ -169,18 +169,33 @@ def test_embed(dev, d, k, two, m):
 
 @pytest.mark.parametrize('d', [16, 32, 64])
 @pytest.mark.parametrize('m', [1, 1000, 4099])
-def test_embed_rbf_in_kernel_equals_rbf_then_embed(dev, d, m):
-    """The inference-only embedding on Bessel rows formed inside the kernel returns the floats of the two-step form
-    (pamnet_rbf_fwd_f32 into [m, 16], then the k = 16 embedding); distances on both sides of the cutoff."""
+def test_embed_rbf_in_kernel(dev, d, m):
+    """The edge embedding on Bessel rows formed inside the kernels: the forward returns the floats of the two-step form
+    (pamnet_rbf_fwd_f32 into [m, 16], then the k = 16 embedding); the gradients of the frequencies, W and b match the
+    fp64 reference of the whole expression (and the two-step path to rounding).  Distances on both sides of the cutoff."""
     from pamnet_amd import narrow, ops
     torch.manual_seed(d + m)
     dist = torch.rand(m, device=dev) * 5.6 + 0.3
-    freq = (torch.arange(1, 17, dtype=torch.float32, device=dev) * np.pi) + torch.randn(16, device=dev) * 0.01
+    freq0 = (torch.arange(1, 17, dtype=torch.float32, device=dev) * np.pi) + torch.randn(16, device=dev) * 0.01
+    mk = lambda t: t.detach().clone().requires_grad_(True)
     lin = torch.nn.Linear(16, d).to(dev)
-    with torch.no_grad():
-        two_step = narrow._Embed.apply(ops.rbf(dist, freq, 5.0), None, lin.weight, lin.bias, None, None)
-        fused = narrow.embed_rbf(dist, freq, 5.0, lin)
-    assert torch.equal(two_step, fused)
+    f1, w1, b1 = mk(freq0), mk(lin.weight), mk(lin.bias)
+    y1 = narrow._EmbedRbf.apply(dist, f1, 5.0, w1, b1)
+    g = torch.randn_like(y1)
+    y1.backward(g)
+    f2, w2, b2 = mk(freq0), mk(lin.weight), mk(lin.bias)
+    y2 = narrow._Embed.apply(ops.rbf(dist, f2, 5.0), None, w2, b2, None, None)
+    y2.backward(g)
+    assert torch.equal(y1, y2)
+    # fp64 reference of SiLU(W (u(x) sin(f x)) + b)
+    x = (dist.double() / 5.0)
+    fr, wr, br = [mk(t.double()) for t in (freq0, lin.weight, lin.bias)]
+    x5 = x ** 5
+    u = torch.where(x < 1, 1.0 / x + x5 * (-21.0 + x * (35.0 - 15.0 * x)), torch.zeros_like(x))
+    ref = F.silu(F.linear(u.unsqueeze(1) * torch.sin(fr * x.unsqueeze(1)), wr, br))
+    ref.backward(g.double())
+    _check_grads((f1, w1, b1), (fr, wr, br), ('freq', 'w', 'b'))
+    _check_grads((f2, w2, b2), (fr, wr, br), ('freq (two-step)', 'w', 'b'))
 
 
 @pytest.mark.parametrize('d', [16, 32, 64])
