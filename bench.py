@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--n-batches', type=int, default=4, help='distinct resident batches cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-rooflines', action='store_true', help='skip the kernel roofline probes (profiling runs)')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the PDBbind / RNA side measurements')
     ap.add_argument('--force-comm', action='store_true',
                     help='N=1 only: run the bucketed gradient all-reduce through a 1-rank RCCL group (overhead check)')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
@@ -197,6 +198,90 @@ def mfma_summary(args, g, ms_per_step):
             'achieved': tf, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / FP32_MFMA_PEAK_TFLOPS}
 
 
+def other_configs(dev):
+    """Full training step and forward of the other BASELINE.json configurations on this GPU (parity-test cases, not the
+    bench line's `value`): configs[3] PDBbind schema d=128 L=3 B=32 and configs[4] RNA schema d=16 L=1 B=8 -- graph rebuilt
+    every step, input pipeline as in the main loop, 4 distinct resident batches."""
+    import models
+    from pamnet_amd import synth
+    from pamnet_amd.train import Trainer, predict
+    out = {}
+    rna = [synth.rna_chain(2, i) for i in range(8)]        # the 8 graphs of configs[4]; the 4 batches are rotations of them
+    for tag, cfg, make, steps in (
+            ('pdbbind_b32_d128_l3', models.Config(dataset='PDBbind', dim=128, n_layer=3, cutoff_l=2.0, cutoff_g=6.0),
+             lambda k: synth.collate([synth.pdbbind_complex(1, 32 * k + i) for i in range(32)]), 40),
+            ('rna_b8_d16_l1', models.Config(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0,
+                                            flow='target_to_source'),
+             lambda k: synth.collate([rna[(i + 2 * k) % 8] for i in range(8)]), 100)):
+        torch.manual_seed(7)
+        model = models.PAMNet(cfg).to(dev)
+        tr = Trainer(model, lr=1e-4)
+        bs = [make(k).to(dev) for k in range(4)]
+        for i in range(5):
+            tr.step(bs[i % 4], next_data=bs[(i + 1) % 4])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tr.step(bs[i % 4], next_data=bs[(i + 1) % 4])
+        torch.cuda.synchronize()
+        step_ms = (time.perf_counter() - t0) / steps * 1e3
+        with torch.no_grad():
+            for _ in predict(model, (bs[i % 4] for i in range(4))):
+                pass
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in predict(model, (bs[i % 4] for i in range(steps))):
+                pass
+            torch.cuda.synchronize()
+            fwd_ms = (time.perf_counter() - t0) / steps * 1e3
+            model(bs[0])
+        g = model._graph_cache
+        out[tag] = {'train_ms_per_step': step_ms, 'forward_ms': fwd_ms, 'graphs_per_batch': int(bs[0].num_graphs),
+                    'nodes': int(g.n), 'global_edges': int(g.glob.m), 'local_edges': int(g.loc.m),
+                    'triplet_pair_rows': int(g.tp.m), 'steps': steps}
+        del tr, model, bs
+        torch.cuda.empty_cache()
+    return out
+
+
+def parity_beside_baseline(dev, args):
+    """Part of the cpu_baseline leg: the CPU port's outputs (fp64 and fp32) on the batches it is timed / sampled on next
+    to the HIP path's -- the checker role of oracle/, never the thing measured.  QM9 configs[0] (B=32, d=128, L=6) and one
+    8-complex shard of the PDBbind configuration (d=128, L=3), whose pooled output is complex - pocket - ligand (~1000x
+    cancellation): reported raw (max|d| / max|out|) and relative to the summed per-complex magnitude."""
+    import models
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import synth
+    res = {}
+    err = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    for tag, cfg, b in (
+            ('qm9_b32_d%d_l%d' % (args.dim, args.n_layer),
+             O.Config(dataset='QM9', dim=args.dim, n_layer=args.n_layer, cutoff_l=5.0, cutoff_g=5.0), synth.qm9_batch(0, 0, 32)),
+            ('pdbbind_b8_d128_l3', O.Config(dataset='PDBbind', dim=128, n_layer=3, cutoff_l=2.0, cutoff_g=6.0),
+             synth.collate([synth.pdbbind_complex(1, i) for i in range(8)]))):
+        sd = O.init_state_dict(cfg, seed=3)
+        model = models.PAMNet(models.Config(cfg.dataset, cfg.dim, cfg.n_layer, cfg.cutoff_l, cfg.cutoff_g))
+        model.load_state_dict(sd, strict=True)
+        model = model.to(dev)
+        pos, ei = getattr(b, 'pos', None), getattr(b, 'edge_index', None)
+        with torch.no_grad():
+            hip = model(b.to(dev)).cpu()
+            inter = {}
+            x64 = b.x.double() if cfg.dataset == 'PDBbind' else b.x
+            r64 = O.pamnet_forward({k: v.double() for k, v in sd.items()}, cfg, x64, b.batch, pos, ei, dtype=torch.float64,
+                                   intermediates=inter)
+            r32 = O.pamnet_forward(sd, cfg, b.x, b.batch, pos, ei)
+        rec = {'hip_vs_cpu_fp64': err(hip, r64), 'cpu_fp32_vs_cpu_fp64': err(r32, r64)}
+        if cfg.dataset == 'PDBbind':
+            pin = inter['pool_in'].abs()
+            scale = max(float(pin[b.batch == k].sum()) for k in range(int(b.batch.max()) + 1))
+            rec['hip_vs_cpu_fp64_over_summed_magnitude'] = float((hip.double() - r64).abs().max()) / scale
+            rec['cpu_fp32_vs_cpu_fp64_over_summed_magnitude'] = float((r32.double() - r64).abs().max()) / scale
+            rec['note'] = 'pooled output = complex - pocket - ligand: raw figures are dominated by the cancellation'
+        res[tag] = rec
+    return res
+
+
 def cpu_baseline(args, seconds):
     """The oracle (pure-torch CPU port of the reference forward, oracle/pamnet_oracle.py) timed on the host cores:
     BASELINE.json configs[0]: B=32, d=128, L=6, forward+backward, bounded to ~`seconds` of CPU work."""
@@ -315,18 +400,55 @@ def main():
     for i in range(args.warmup):
         trainer.step(batches[i % nb], global_graphs=gB, next_data=batches[(i + 1) % nb])
     sync()
+    # one HIP event per step on the stream the step runs on (a marker, not a synchronisation): the spread of the
+    # per-step durations travels with the line
+    marks = [] if not dry else None
     t0 = time.perf_counter()
     for i in range(args.steps):
         k = args.warmup + i
         trainer.step(batches[k % nb], global_graphs=gB, next_data=batches[(k + 1) % nb])
+        if marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(ev)
     sync()
     dt = time.perf_counter() - t0
+    spread = None
+    if marks and len(marks) > 2:
+        per = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
+        q = lambda f: per[min(len(per) - 1, int(f * len(per)))]
+        spread = {'p10': q(0.10), 'p50': q(0.50), 'p90': q(0.90), 'max': per[-1],
+                  'note': 'ms between consecutive per-step HIP events inside the timed region'}
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t[0])
     ms_per_step = dt / args.steps * 1e3
     value = gB * args.steps / dt
+
+    # Exposed all-reduce time (N > 1, or N = 1 with --force-comm): the same loop with the gradient exchange skipped; the
+    # ranks' parameters drift apart from here on, which nothing below depends on (timings only).
+    exposed = None
+    if (world > 1 or args.force_comm) and not dry:
+        ksteps = min(args.steps, 100)
+        orig_sync = trainer.sync_gradients
+        trainer.sync_gradients = lambda: None
+        for i in range(3):
+            trainer.step(batches[i % nb], global_graphs=gB, next_data=batches[(i + 1) % nb])
+        sync()
+        t0 = time.perf_counter()
+        for i in range(ksteps):
+            trainer.step(batches[i % nb], global_graphs=gB, next_data=batches[(i + 1) % nb])
+        sync()
+        tn = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+        trainer.sync_gradients = orig_sync
+        no_comm_ms = float(tn[0]) / ksteps * 1e3
+        exposed = {'allreduce_exposed_ms': ms_per_step - no_comm_ms, 'ms_per_step_without_allreduce': no_comm_ms,
+                   'buckets': (len(trainer._buckets) + 1) if trainer._buckets else 1,
+                   'gradient_bytes': int(trainer.fp.grad.numel()) * 4,
+                   'note': 'step time with minus without sync_gradients(), max over ranks, %d steps' % ksteps}
 
     if dry:
         if rank == 0:
@@ -400,7 +522,7 @@ def main():
             trainer.step(cur, global_graphs=gB, next_data=nxt)
         sync()
         zs_step = (time.perf_counter() - t0) / zsteps * 1e3
-        model.verify()
+        trainer.drain()
         zero_sync = {'forward_ms_unpipelined': zs_fwd, 'forward_only_molecules_per_s': gB / (zs_fwd / 1e3),
                      'train_ms_per_step': zs_step, 'train_molecules_per_s': gB / (zs_step / 1e3),
                      'note': 'resident dataset, one device-side collate launch per batch inside the timed loop, sizes from '
@@ -422,7 +544,7 @@ def main():
                        'global_batch': gB, 'parallelism': 'dp%d (molecule-sharded, RCCL all-reduce of flat grad)' % world,
                        'nodes_per_batch': int(g.n), 'global_edges': int(g.glob.m), 'local_edges': int(g.loc.m),
                        'triplets': int(g.n_trip), 'pairs': int(g.n_pair)},
-            'timed_region_s': dt,
+            'timed_region_s': dt, 'step_ms_spread': spread, 'comm': exposed,
             'forward_only_molecules_per_s': gB / (fwd_ms / 1e3), 'forward_ms': fwd_ms,
             'forward_ms_unpipelined': fwd_plain_ms,
             'zero_host_sync': zero_sync,
@@ -442,8 +564,11 @@ def main():
                 'shape': '[%d,%d]->[%d,%d] streamed (%.2f GB)' % (s['rows_in'], args.dim, s['rows_out'], args.dim, s['bytes'] / 1e9),
                 'at_workload_shape': roof['workload']}
             line['step_kernels'] = step_kernel_rooflines(dev, g, args.dim, args.n_layer)
+        if world == 1 and not args.no_other_configs:
+            line['other_configs'] = other_configs(dev)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
+            line['cpu_baseline']['parity'] = parity_beside_baseline(dev, args)
             line['speedup_vs_cpu'] = value / line['cpu_baseline']['value']
         result_out.write(json.dumps(line) + '\n')
         result_out.flush()

@@ -123,35 +123,27 @@ class _PAMNetBase(nn.Module):
         sz = getattr(data, 'sizes', None)
         if sz is None:
             return None
-        key = (float(self.cutoff_g), float(self.cutoff_l), not self.small)
         if isinstance(sz, dict):
-            return sz.get(key)
+            from pamnet_amd.store import size_key
+            return sz.get(size_key(self))
         return sz
 
-    def verify(self, count=None):
+    def verify(self):
         """Check the device-side flag words of the forwards since the last call that ran without a host round trip
-        (batches carrying `sizes`) -- all of them, or the oldest `count`: one readback.  Raises IndexError (invalid index
-        inputs, as the reference would have) or graph.GraphCheckError (sizes that do not belong to the batch).  Call it
-        wherever the host synchronises anyway -- train.Trainer and train.predict do."""
-        pend = self._pending_checks if count is None else self._pending_checks[:count]
-        if not pend:
-            return
-        self.__dict__['_pending_checks'] = [] if count is None else self._pending_checks[count:]
-        bits = 0
-        if count is not None and pend[0].is_cuda:
-            # the caller knows these forwards have completed (Trainer: the step's event has been waited for): read them on
-            # a stream of their own -- on the current stream the copy would queue behind every step already enqueued and
-            # the host would sit out the whole pipeline
-            st = self.__dict__.get('_check_stream')
-            if st is None:
-                st = self.__dict__['_check_stream'] = torch.cuda.Stream(device=pend[0].device)
-            with torch.cuda.stream(st):
-                vals = torch.stack(pend).reshape(-1).tolist()
-        else:
-            vals = torch.stack(pend).reshape(-1).tolist()
-        for v in vals:
-            bits |= int(v)
-        G.raise_for_flag(bits)
+        (batches carrying `sizes`): one readback.  Raises IndexError (invalid index inputs, as the reference would have)
+        or graph.GraphCheckError (sizes that do not belong to the batch).  Call it wherever the host synchronises anyway
+        -- train.predict does; train.Trainer takes the flag words over step by step (take_pending_checks) and reads each
+        step's own words once that step has completed."""
+        pend = self.take_pending_checks()
+        if pend:
+            G.raise_for_flag(G.read_flags(pend))
+
+    def take_pending_checks(self):
+        """Hand the flag words of the forwards since the last verify() / take to the caller, who then owns checking them
+        (graph.read_flags + graph.raise_for_flag) once the forwards that wrote them have completed."""
+        pend = self._pending_checks
+        self.__dict__['_pending_checks'] = []
+        return pend
 
     def prepare(self, data, need_grad=True):
         """Parameter-independent part of forward(data): graph construction (models.py:104-177) and the spherical
@@ -171,7 +163,7 @@ class _PAMNetBase(nn.Module):
             feats = xr[:, 3:].to(torch.float32)
             if modules.IMPL == 'fused' and fused.embed_supported(feats, self.init_linear):
                 return fused.embed(feats, self.init_linear, act=False, tape=tape)          # models.py:119
-            return F.linear(feats, self.init_linear.weight)
+            return ops.plain_linear(feats.contiguous(), self.init_linear.weight, tape=tape)
         col = x_raw if self.dataset == 'QM9' else (x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw)[:, -1]
         idx = g.types if getattr(g, 'types', None) is not None else col.to(torch.int32).contiguous()
         if ops.type_rows_supported(self.embeddings):                                    # models.py:107,140

@@ -352,6 +352,30 @@ class GraphCheckError(IndexError):
     pass
 
 
+_CHECK_STREAMS = {}
+
+
+def read_flags(flags, completed=False):
+    """OR of the flag words (int32 device scalars) of some prepared graphs: one readback.  completed=True: the caller
+    knows the forwards that wrote them have finished (it has waited for an event recorded behind them) -- the copy then
+    runs on a stream of its own instead of queueing behind every step already enqueued on the current one."""
+    if not flags:
+        return 0
+    if completed and flags[0].is_cuda:
+        dev = flags[0].device
+        st = _CHECK_STREAMS.get(dev)
+        if st is None:
+            st = _CHECK_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            vals = torch.stack(flags).reshape(-1).tolist()
+    else:
+        vals = torch.stack(flags).reshape(-1).tolist()
+    bits = 0
+    for v in vals:
+        bits |= int(v)
+    return bits
+
+
 def raise_for_flag(bits):
     """Raise for a non-zero flag word of a prepared graph (bit 1: invalid index inputs; the rest: the sizes the host
     assumed in the zero-host-sync path were wrong)."""

@@ -305,8 +305,15 @@ def type_rows(table, idx, direct_grad=None, tape=None):
 
 
 def l1_loss_with_grad(out, y, grad_scale=1.0):
-    """(loss, d loss / d out * grad_scale) of F.l1_loss(out, y) (mean reduction, main_qm9.py:108) in one launch."""
-    out, y = _c(out.detach()), _c(y)
+    """(loss, d loss / d out * grad_scale) of F.l1_loss(out, y) (mean reduction, main_qm9.py:108) in one launch.
+    `y` is brought to out's device / dtype / shape first (F.l1_loss converts, broadcasts or raises; the kernel reads
+    out.numel() contiguous fp32 values): a [B, 1] or float64 target works, a target of another size raises."""
+    out = _c(out.detach())
+    if y.numel() != out.numel():
+        raise ValueError('l1 loss: target has %d elements, the model output %d' % (y.numel(), out.numel()))
+    if y.device != out.device or y.dtype != torch.float32 or y.shape != out.shape:
+        y = y.to(device=out.device, dtype=torch.float32).reshape(out.shape)
+    y = _c(y)
     loss = torch.empty(1, dtype=torch.float32, device=out.device)
     d_out = torch.empty_like(out)
     lib.call('pamnet_l1_loss_f32', lib.ptr(out), lib.ptr(y), out.numel(), float(grad_scale), lib.ptr(loss),
@@ -374,6 +381,27 @@ class _FusePool(torch.autograd.Function):
                  lib.ptr(graph.node_graph), lib.ptr(graph.gptr), 1 if ctx.mean else 0, lib.ptr(g), lib.ptr(go),
                  lib.ptr(ga), lib.stream_of(g))
         return go, ga, None, None
+
+
+class _PlainLinear(torch.autograd.Function):
+    """x W^T for a thin bias-free layer that has no kernel of its own at this width (`init_linear` of the PDBbind branch,
+    models.py:119, at dim != 128): a rocBLAS call, but as a Function of this package so that it is recorded on a Tape
+    like every other stage (a bare F.linear inside a one-node forward runs with grad mode off and would leave the weight
+    without a gradient).  The input features carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        return None, g.t() @ x
+
+
+def plain_linear(x, w, tape=None):
+    return apply(_PlainLinear, x, w, tape=tape)
 
 
 class _StackRows(torch.autograd.Function):

@@ -21,6 +21,18 @@ from . import lib
 I32 = torch.int32
 
 
+KNN_K = 50            # neighbours of the RNA kNN graph (models.py:143; graph.build_graph's default)
+
+
+def size_key(model):
+    """Everything the per-graph sizes of a forward depend on: the schema (which graph construction runs), both cutoffs,
+    the layer kind (triplets or pairs only), the flow and the kNN neighbour count.  Two models that share a store but
+    differ in any of these get their own count tables."""
+    ds = model.dataset
+    schema = 'rna' if ds[:3].lower() == 'rna' else ds
+    return (schema, float(model.cutoff_g), float(model.cutoff_l), not model.small, str(model.flow), KNN_K)
+
+
 class Batch(object):
     """Duck-typed `data` of PAMNet.forward: x, pos, edge_index ([2, E] int32), batch (int32), y, num_graphs, sizes."""
 
@@ -51,6 +63,13 @@ class MoleculeStore(object):
         n = np.array([int(d.x.shape[0]) for d in data_list], dtype=np.int64)
         self.has_edges = data_list[0].edge_index is not None
         self.has_pos = data_list[0].pos is not None
+        if self.has_edges:
+            # remove_self_loops (models.py:63) once, at ingestion: resident bond lists are loop-free by construction, so
+            # a batch never trips the forward's self-loop flag and the per-molecule counts describe what the forward uses
+            for d in data_list:
+                ei = torch.as_tensor(d.edge_index).to(torch.int64)
+                keep = ei[0] != ei[1]
+                d.edge_index = ei if bool(keep.all()) else ei[:, keep]
         e = np.array([int(d.edge_index.shape[1]) if self.has_edges else 0 for d in data_list], dtype=np.int64)
         self.n_nodes, self.n_edges = n, e                      # host copies: the batch sizes are sums of these
         self.nptr = np.concatenate([[0], np.cumsum(n)])
@@ -72,7 +91,7 @@ class MoleculeStore(object):
             np.array([float(torch.as_tensor(v).reshape(-1)[0]) for v in ys], dtype=np.float32)).to(dev)
         self.nptr_d = torch.from_numpy(self.nptr.astype(np.int32)).to(dev)
         self.eptr_d = torch.from_numpy(self.eptr.astype(np.int32)).to(dev)
-        self._counts = {}                  # (cutoff_g, cutoff_l, with_triplets) -> per-graph (E_g, E_l, T+P) arrays
+        self._counts = {}                  # size_key(model) -> per-graph (E_g, E_l, T+P) arrays
 
     def __len__(self):
         return len(self.n_nodes)
@@ -83,7 +102,7 @@ class MoleculeStore(object):
         layer kind): counted on the device by the forward's own graph construction, `chunk` graphs per pass, read back
         ONCE per dataset.  The local edges of a graph are contiguous in the batch's CSR (sorted by target node), so every
         count is a difference of CSR pointers at the graph's node range."""
-        key = (float(model.cutoff_g), float(model.cutoff_l), not model.small)
+        key = size_key(model)
         if key in self._counts:
             return self._counts[key]
         m = len(self)

@@ -375,14 +375,30 @@ class Trainer(object):
             return
         q = self.__dict__.setdefault('_inflight', [])
         if len(q) >= self.MAX_STEPS_IN_FLIGHT:
-            ev, n_checks = q.pop(0)
-            ev.synchronize()
-            if n_checks:                                       # flag words of forwards that have completed by now:
-                self.model.verify(n_checks)                    # reading them does not stall the queue
-                q[:] = [(e, max(0, c - n_checks)) for e, c in q]
+            self._retire(q.pop(0))
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.fp.flat.device))
-        q.append((ev, len(getattr(self.model, '_pending_checks', None) or ())))
+        # The flag words of every forward enqueued so far (zero-host-sync batches) travel WITH the event recorded behind
+        # them: whoever waits for this event may read exactly these words, whatever model.verify() was called in between
+        # (an evaluation pass has its own forwards and its own verify()).
+        take = getattr(self.model, 'take_pending_checks', None)
+        q.append((ev, take() if take is not None else []))
+
+    @staticmethod
+    def _retire(entry):
+        ev, flags = entry
+        ev.synchronize()
+        if flags:                                              # written by forwards that have completed by now:
+            from . import graph as G                           # reading them does not stall the queue
+            G.raise_for_flag(G.read_flags(flags, completed=True))
+
+    def drain(self):
+        """Wait for every step in flight and check its batches' device-side flag words (zero-host-sync batches)."""
+        q = self.__dict__.get('_inflight') or []
+        while q:
+            self._retire(q.pop(0))
+        if hasattr(self.model, 'verify'):
+            self.model.verify()
 
     # -- input pipelining -----------------------------------------------------------------------------------------------
     def prefetch(self, data):
@@ -410,6 +426,7 @@ class Trainer(object):
     @torch.no_grad()
     def evaluate(self, batches):
         """Sum |out - y| over batches / #graphs under EMA weights, all-reduced across ranks."""
+        self.drain()                       # the training steps in flight keep their own flag words (see _throttle)
         self.ema_assign()
         tot = torch.zeros(2, device=self.fp.flat.device, dtype=torch.float64)
         for data, out in predict(self.model, batches):

@@ -355,8 +355,74 @@ def main():
         return main_ragged()
     if '--d128-only' in sys.argv:
         return main_d128()
+    if '--baseline-only' in sys.argv:
+        return main_baseline()
     main_forward()
     main_train()
+    main_baseline()
+
+
+def fixture_baseline(name, cfg_kw, batch, seed, grads=False):
+    """The reference itself at a BASELINE.json batch size: graph outputs and pooled node values (fp32 and fp64 runs) plus
+    the integer sizes of its graphs.  Inputs are not stored -- tests regenerate them from pamnet_amd.synth (deterministic
+    per graph index) and check the checksum kept here."""
+    cfg = ref_models.Config(**cfg_kw)
+    sd = oracle.init_state_dict(cfg, seed=seed)
+    arrs = dict(seed=np.int64(seed), weights_checksum=np.float64(checksum(sd)),
+                cfg_dataset=np.array(cfg_kw['dataset']), cfg_dim=np.int64(cfg_kw['dim']),
+                cfg_n_layer=np.int64(cfg_kw['n_layer']), cfg_cutoff_l=np.float64(cfg_kw['cutoff_l']),
+                cfg_cutoff_g=np.float64(cfg_kw['cutoff_g']), cfg_flow=np.array(cfg_kw.get('flow', 'source_to_target')),
+                x_checksum=np.float64(batch.x.double().abs().sum()), num_nodes=np.int64(batch.x.size(0)),
+                num_graphs=np.int64(int(batch.batch.max()) + 1))
+    for tag, dtype in (('32', torch.float32), ('64', torch.float64)):
+        model = build_model(ref_models.PAMNet, cfg)
+        print(name, tag, model.load_state_dict(sd), flush=True)
+        if dtype == torch.float64:
+            model = model.double()
+        with torch.no_grad():
+            rec = run_reference(model, make_data(batch, dtype), capture=False)
+        arrs['out' + tag] = rec['out'].numpy()
+        arrs['node_out' + tag] = rec['node_out'].numpy()
+        if tag == '32':
+            arrs['num_edges_l'] = np.int64(rec['edge_index_l'].shape[1])
+            arrs['num_pairs'] = np.int64(rec['idx_jj_pair'].numel())
+            arrs['num_triplets'] = np.int64(rec['idx_kj'].numel())
+    if grads:
+        # the reference's own fp64 autograd of the mean L1 loss at this batch: loss, global gradient norm, every parameter
+        # gradient's max-magnitude and L2 norm (checks of the whole backward) and a few full tensors
+        model = build_model(ref_models.PAMNet, cfg)
+        model.load_state_dict(sd)
+        model = model.double()
+        out = model(make_data(batch, torch.float64))
+        loss = torch.nn.functional.l1_loss(out, batch.y.double())
+        loss.backward()
+        named = [(k, p) for k, p in model.named_parameters() if p.grad is not None]
+        arrs['loss64'] = np.float64(loss.item())
+        arrs['grad_norm64'] = np.float64(torch.sqrt(sum((p.grad ** 2).sum() for _, p in named)).item())
+        arrs['grad_keys'] = np.array([k for k, _ in named])
+        arrs['grad_l2_64'] = np.array([float(p.grad.norm()) for _, p in named], np.float64)
+        arrs['grad_max_64'] = np.array([float(p.grad.abs().max()) for _, p in named], np.float64)
+        for k, p in named:
+            if k in ('embeddings', 'rbf_g.freq', 'rbf_l.freq', 'mlp_sbf1.0.0.weight', 'mlp_rbf_g.0.0.weight',
+                     'global_layer.0.mlp_m.0.0.weight', 'global_layer.5.mlp_m.0.0.weight', 'global_layer.3.W_edge_attr.weight',
+                     'local_layer.0.mlp_sbf.1.0.bias', 'local_layer.0.lin_rbf.weight', 'local_layer.5.mlp_m_kj.0.0.weight',
+                     'local_layer.2.res2.mlp.1.0.weight', 'global_layer.0.W', 'local_layer.5.W_out.weight'):
+                arrs['grad64/' + k] = p.grad.numpy().astype(np.float32 if p.numel() > 4096 else np.float64)
+    save(name, **arrs)
+
+
+def main_baseline():
+    """Reference runs at the BASELINE.json batch sizes (outputs only): configs[0] QM9 B=32 and configs[1] QM9 B=128 (the
+    exact batch bench.py times; with the reference's fp64 loss gradient), the PDBbind B=32 batch and its first 8-complex
+    shard, the RNA B=8 batch."""
+    qm9 = dict(dataset='QM9', dim=128, n_layer=6, cutoff_l=5.0, cutoff_g=5.0)
+    fixture_baseline('baseline_qm9_b32', qm9, synth.qm9_batch(0, 0, 32), seed=0)
+    fixture_baseline('baseline_qm9_b128', qm9, synth.qm9_batch(0, 0, 128), seed=0, grads=True)
+    pdb = dict(dataset='PDBbind', dim=128, n_layer=3, cutoff_l=2.0, cutoff_g=6.0)
+    fixture_baseline('baseline_pdbbind_b8', pdb, synth.collate([synth.pdbbind_complex(1, i) for i in range(8)]), seed=3)
+    fixture_baseline('baseline_pdbbind_b32', pdb, synth.collate([synth.pdbbind_complex(1, i) for i in range(32)]), seed=3)
+    rna = dict(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
+    fixture_baseline('baseline_rna_b8', rna, synth.rna_batch(2, 0, 8), seed=5)
 
 
 def main_train():

@@ -552,29 +552,203 @@ def test_self_loops_in_the_bond_list_are_dropped(dev, dim):
 
 @pytest.mark.gpu
 def test_large_batch_equals_its_shards(dev):
-    """Size-independent property well above the BASELINE batch (1 024 molecules, N ~ 18 k, E_g ~ 260 k: multi-chunk edge
-    workgroups, unsplit segment sums, many weight-gradient slots): outputs and the loss gradient of the big batch equal
-    those assembled from its eight 128-molecule shards (graphs are independent units)."""
+    """BASELINE configs[2] in its single-box form (QM9 schema, dim=128, n_layer=6, B=1 024 = 8 x 128, all 12 targets of
+    main_qm9.py:60-66): N ~ 18 k, E_g ~ 260 k -- multi-chunk edge workgroups, unsplit segment sums, many weight-gradient
+    slots.  Graphs are independent units, so for EVERY target column the outputs and the loss gradient of
+    the 1 024-molecule batch equal those assembled from its eight 128-molecule shards, each shard's gradient scaled by
+    local/global graphs exactly as the 8 ranks of the data-parallel run scale theirs before the all-reduce
+    (train.Trainer.forward_backward)."""
     import models
     from pamnet_amd import synth
     torch.manual_seed(3)
-    model = models.PAMNet(models.Config(dataset='QM9', dim=128, n_layer=3, cutoff_l=5.0, cutoff_g=5.0)).to(dev)
+    model = models.PAMNet(models.Config(dataset='QM9', dim=128, n_layer=6, cutoff_l=5.0, cutoff_g=5.0)).to(dev)
     big = synth.qm9_batch(5, 0, 1024).to(dev)
-    out = model(big)
-    torch.nn.functional.l1_loss(out, big.y).backward()
-    g_big = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
-    for p in model.parameters():
-        p.grad = None
-    outs = []
-    for i in range(8):
-        b = synth.qm9_batch(5, 128 * i, 128).to(dev)
-        o = model(b)
-        outs.append(o.detach())
-        (torch.nn.functional.l1_loss(o, b.y) * (128 / 1024)).backward()
-    assert maxnorm_err(out.detach().cpu().numpy(), torch.cat(outs).cpu().numpy()) < 2e-6
+    shards = [synth.qm9_batch(5, 128 * i, 128).to(dev) for i in range(8)]
+    table = torch.from_numpy(synth.qm9_label_table(5, 0, 1024)).to(dev)            # [1024, 16] label columns
+    named = [(k, p) for k, p in model.named_parameters()]
+    worst_out = worst_grad = 0.0
+    for target in range(12):
+        col = target + 5 if target in (7, 8, 9, 10) else target                    # main_qm9.py:61-66
+        y = table[:, col].contiguous()
+        for _, p in named:
+            p.grad = None
+        out = model(big)
+        torch.nn.functional.l1_loss(out, y).backward()
+        g_big = {k: p.grad.clone() for k, p in named if p.grad is not None}
+        for _, p in named:
+            p.grad = None
+        outs = []
+        for i, b in enumerate(shards):
+            o = model(b)
+            outs.append(o.detach())
+            (torch.nn.functional.l1_loss(o, y[128 * i:128 * i + 128]) * (128 / 1024)).backward()
+        e = maxnorm_err(out.detach().cpu().numpy(), torch.cat(outs).cpu().numpy())
+        assert e < 2e-6, (target, e)
+        worst_out = max(worst_out, e)
+        assert len(g_big) == len(named)
+        for k, p in named:
+            e = maxnorm_err(p.grad.cpu().numpy(), g_big[k].cpu().numpy())
+            assert e < 2e-5, (target, k, e)
+            worst_grad = max(worst_grad, e)
+    print('QM9 B=1024 d128 L6, 12 targets: batch vs its 8 shards: outputs %.1e, worst parameter gradient %.1e'
+          % (worst_out, worst_grad))
+
+
+def _baseline_batch(name):
+    from pamnet_amd import synth
+    return {'baseline_qm9_b32': lambda: synth.qm9_batch(0, 0, 32),
+            'baseline_qm9_b128': lambda: synth.qm9_batch(0, 0, 128),
+            'baseline_pdbbind_b8': lambda: synth.collate([synth.pdbbind_complex(1, i) for i in range(8)]),
+            'baseline_pdbbind_b32': lambda: synth.collate([synth.pdbbind_complex(1, i) for i in range(32)]),
+            'baseline_rna_b8': lambda: synth.rna_batch(2, 0, 8)}[name]()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['baseline_qm9_b32', 'baseline_qm9_b128', 'baseline_pdbbind_b8', 'baseline_pdbbind_b32',
+                                  'baseline_rna_b8'])
+def test_baseline_sizes_vs_reference_runs(dev, golden, name):
+    """The HIP path against runs of the REFERENCE ITSELF (tests/golden/gen/gen_golden.py --baseline-only, fp32 and fp64)
+    at the BASELINE.json batch sizes: configs[0] (QM9 d=128 L=6 B=32), configs[1] (B=128 -- the exact batch bench.py
+    times), configs[3] (PDBbind d=128 L=3 B=32, and its first 8-complex shard), configs[4] (RNA d=16 L=1 B=8).  Graph
+    outputs, pooled node values, and the integer sizes of the local graph / triplets / pairs (exact)."""
+    import models
+    from oracle import pamnet_oracle as O
+    g = golden(name)
+    cfg = _cfg_from(g, models.Config)
+    b = _baseline_batch(name)
+    assert b.x.size(0) == int(g['num_nodes']) and abs(float(b.x.double().abs().sum()) - float(g['x_checksum'])) < 1e-6
+    sd = O.init_state_dict(cfg, seed=int(g['seed']))
+    assert abs(sum(float(v.double().abs().sum()) for v in sd.values()) - float(g['weights_checksum'])) < 1e-6
+    model = models.PAMNet(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    with torch.no_grad():
+        out = model(b.to(dev)).cpu().numpy()
+    node_out = model._node_out.cpu().numpy()
+    ok, info_n = _ok(node_out, g['node_out32'], g['node_out64'])
+    assert ok, ('node_out', info_n)
+    gc = model._graph_cache
+    assert gc.loc.m == int(g['num_edges_l']) and gc.n_trip == int(g['num_triplets']) and gc.n_pair == int(g['num_pairs'])
+    if cfg.dataset == 'PDBbind':
+        batch = b.batch.numpy()
+        scale = max(float(np.abs(g['node_out64'][batch == k]).sum()) for k in range(len(g['out64'])))
+        ok, info = _ok(out, g['out32'], g['out64'], scale)
+        assert ok, ('out', info)
+        raw, raw_floor = maxnorm_err(out, g['out64']), maxnorm_err(g['out32'], g['out64'])
+        assert raw <= max(TOL, 2 * raw_floor), (raw, raw_floor)
+        print('%s vs the reference: err/sum|node_out| %.2e (ref fp32 %.2e); raw max|d|/max|out| %.2e (ref fp32 %.2e); '
+              'node_out %.2e' % (name, info[0], info[1], raw, raw_floor, info_n[0]))
+    else:
+        ok, info = _ok(out, g['out32'], g['out64'])
+        assert ok, ('out', info)
+        print('%s vs the reference: out %.2e (ref fp32 %.2e), node_out %.2e (ref fp32 %.2e)' % ((name,) + info + info_n))
+
+
+@pytest.mark.gpu
+def test_trainer_step_path_at_configs1_vs_oracle_and_reference(dev, golden):
+    """The EXACT path bench.py times -- train.Trainer.forward_backward: flat parameters, gradients written in place by the
+    kernels, the forward recorded on the model's tape and replayed directly, bf16x6 weight gradients -- at BASELINE
+    configs[1] (QM9 schema, d=128, L=6, B=128, the bench batch), checked DIRECTLY:
+      * every parameter gradient against the CPU oracle's fp64 autograd (floor measured with the fp32 oracle),
+      * loss, global gradient norm, every parameter gradient's L2 norm and a set of full gradient tensors against the
+        REFERENCE's own fp64 autograd at this batch (tests/golden/baseline_qm9_b128.npz)."""
+    import models
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import synth, train
+    _oracle_threads()
+    g = golden('baseline_qm9_b128')
+    cfg = models.Config(dataset='QM9', dim=128, n_layer=6, cutoff_l=5.0, cutoff_g=5.0)
+    b = synth.qm9_batch(0, 0, 128)
+    sd = O.init_state_dict(cfg, seed=0)
+    model = models.PAMNet(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    tr = train.Trainer(model, lr=1e-4)
+    assert model._one_node()                               # the one-node tape path with direct gradients is what runs
+    data = b.to(dev)
+    loss = tr.forward_backward(data)
+    first = tr.fp.grad.clone()
+    loss2 = tr.forward_backward(data)                      # overwrite semantics: a second pass gives the same bits
+    assert torch.equal(first, tr.fp.grad) and torch.equal(loss, loss2)
+    # -- the reference's own fp64 backward at this batch
+    assert abs(float(loss) - float(g['loss64'])) < 2e-5 * max(1.0, abs(float(g['loss64'])))
+    gn = float(torch.linalg.vector_norm(tr.fp.grad.double()))
+    assert abs(gn / float(g['grad_norm64']) - 1) < 1e-4, (gn, float(g['grad_norm64']))
+    grads = dict(zip(tr.fp.names, tr.fp.grad_views))
+    keys = g['grad_keys'].tolist()
+    assert sorted(keys) == sorted(grads)
+    worst_l2 = 0.0
+    for k, l2 in zip(keys, g['grad_l2_64']):
+        e = abs(float(grads[k].double().norm()) - float(l2)) / max(float(l2), 1e-300)
+        assert e < 1e-4, (k, e)
+        worst_l2 = max(worst_l2, e)
+    worst_t = 0.0
+    for k in g.files:
+        if k.startswith('grad64/'):
+            e = maxnorm_err(grads[k[7:]].cpu().numpy(), g[k])
+            assert e < GRAD_TOL, (k, e)
+            worst_t = max(worst_t, e)
+    # -- every element of every gradient against the oracle's fp64 autograd
+    p64 = O.as_params({k: v.double() for k, v in sd.items()})
+    ref64 = O.pamnet_forward(p64, cfg, b.x, b.batch, b.pos, b.edge_index, dtype=torch.float64)
+    torch.nn.functional.l1_loss(ref64, b.y.double()).backward()
+    rep = {}
+    _check_gradients(model, p64, O.pamnet_forward, sd, cfg, b, rep)
+    print('Trainer.forward_backward at configs[1] (B=128 d128 L6): vs reference fp64: |grad| rel %.1e, worst per-tensor '
+          'L2 %.1e, worst full tensor %.1e; vs oracle fp64: worst element %.2e (ref fp32 %.2e, %s)'
+          % ((abs(gn / float(g['grad_norm64']) - 1), worst_l2, worst_t) + rep['grad_worst']))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dataset,dim', [('PDBbind', 64), ('PDBbind', 16), ('PDBbind', 128), ('QM9', 32), ('rna_x', 16)])
+def test_trainer_tape_path_trains_every_parameter(dev, dataset, dim):
+    """Under train.Trainer the whole forward is ONE recorded node (ops.Tape) that runs with grad mode off: a stage without
+    a tape-aware Function would silently leave its parameters without a gradient (the PDBbind `init_linear` at the narrow
+    widths once did).  Every parameter gradient of the trainer path -- none identically zero -- against the CPU oracle's
+    fp64 autograd, for every schema / engine combination."""
+    import models
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import synth, train
+    if dataset == 'PDBbind':
+        cfg = models.Config(dataset='PDBbind', dim=dim, n_layer=2, cutoff_l=2.0, cutoff_g=6.0)
+        b = synth.pdbbind_batch(9, 0, 2, n_pocket=90, n_ligand=16)
+    elif dataset == 'QM9':
+        cfg = models.Config(dataset='QM9', dim=dim, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+        b = synth.qm9_batch(17, 0, 16)
+    else:
+        cfg = models.Config(dataset=dataset, dim=dim, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
+        b = synth.rna_batch(3, 0, 2, n_nodes=260)
+    sd = O.init_state_dict(cfg, seed=13)
+    model = models.PAMNet(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    tr = train.Trainer(model, lr=1e-4)
+    assert model._one_node()
+    tr.forward_backward(b.to(dev))
     for k, p in model.named_parameters():
-        if k in g_big:
-            assert maxnorm_err(p.grad.cpu().numpy(), g_big[k].cpu().numpy()) < 2e-5, k
+        assert float(p.grad.abs().max()) > 0.0, 'no gradient reached %s' % k
+    p64 = O.as_params({k: v.double() for k, v in sd.items()})
+    pos, ei = getattr(b, 'pos', None), getattr(b, 'edge_index', None)
+    x64 = b.x.double() if (cfg.dataset == 'PDBbind' or dataset.startswith('rna')) else b.x
+    ref64 = O.pamnet_forward(p64, cfg, x64, b.batch, pos, ei, dtype=torch.float64)
+    torch.nn.functional.l1_loss(ref64, b.y.double()).backward()
+    _check_gradients(model, p64, O.pamnet_forward, sd, cfg, b)
+
+
+@pytest.mark.gpu
+def test_l1_loss_target_shapes_and_dtypes(dev):
+    """ops.l1_loss_with_grad takes what F.l1_loss takes: a [B, 1] / float64 / host-resident target gives the same loss and
+    gradient as the plain fp32 [B] one; a target of another size raises instead of being read out of bounds."""
+    from pamnet_amd import ops
+    torch.manual_seed(0)
+    out, y = torch.randn(37, device=dev), torch.randn(37, device=dev)
+    loss, g = ops.l1_loss_with_grad(out, y, 0.5)
+    assert abs(float(loss) - float(torch.nn.functional.l1_loss(out, y))) < 1e-6
+    for yy in (y.view(37, 1), y.double(), y.cpu(), y.cpu().double().view(1, 37)):
+        l2, g2 = ops.l1_loss_with_grad(out, yy, 0.5)
+        assert torch.equal(l2, loss) and torch.equal(g2, g)
+    with pytest.raises(ValueError):
+        ops.l1_loss_with_grad(out, y[:36])
 
 
 @pytest.mark.gpu

@@ -146,3 +146,44 @@ def test_unknown_dataset_raises():
     cfg = O.Config(dataset='nope', dim=8, n_layer=1, cutoff_l=2.0, cutoff_g=5.0)
     with pytest.raises(ValueError):
         O.build_graph(cfg, torch.zeros(3), torch.zeros(3, dtype=torch.long), torch.zeros(3, 3), torch.zeros(2, 0, dtype=torch.long))
+
+
+def _baseline_batch(name):
+    """The inputs of a baseline_* fixture, regenerated from pamnet_amd.synth (the fixture stores outputs + a checksum)."""
+    from pamnet_amd import synth
+    return {'baseline_qm9_b32': lambda: synth.qm9_batch(0, 0, 32),
+            'baseline_qm9_b128': lambda: synth.qm9_batch(0, 0, 128),
+            'baseline_pdbbind_b8': lambda: synth.collate([synth.pdbbind_complex(1, i) for i in range(8)]),
+            'baseline_pdbbind_b32': lambda: synth.collate([synth.pdbbind_complex(1, i) for i in range(32)]),
+            'baseline_rna_b8': lambda: synth.rna_batch(2, 0, 8)}[name]()
+
+
+@pytest.mark.parametrize('name', ['baseline_qm9_b32', 'baseline_pdbbind_b8'])
+def test_oracle_at_baseline_sizes_vs_reference_runs(golden, name):
+    """The oracle against the reference ITSELF at BASELINE.json batch sizes (configs[0]: QM9 d=128 L=6 B=32; one
+    8-complex shard of configs[3]); the larger fixtures (B=128, PDBbind B=32, RNA B=8) are checked against the HIP path
+    on the GPU box (tests/test_hip_model.py::test_baseline_sizes_vs_reference_runs)."""
+    g = golden(name)
+    cfg = _cfg(g)
+    b = _baseline_batch(name)
+    assert b.x.size(0) == int(g['num_nodes']) and abs(float(b.x.double().abs().sum()) - float(g['x_checksum'])) < 1e-6
+    sd32 = O.init_state_dict(cfg, seed=int(g['seed']))
+    assert abs(sum(float(v.double().abs().sum()) for v in sd32.values()) - float(g['weights_checksum'])) < 1e-6
+    torch.set_num_threads(8)
+    pos, ei = getattr(b, 'pos', None), getattr(b, 'edge_index', None)
+    for tag, dt, tol in (('64', torch.float64, 1e-6), ('32', torch.float32, 1e-5)):
+        sd = {k: v.to(dt) for k, v in sd32.items()}
+        inter = {}
+        xin = b.x.to(dt) if cfg.dataset == 'PDBbind' else b.x
+        with torch.no_grad():
+            out = O.pamnet_forward(sd, cfg, xin, b.batch, pos, ei, dtype=dt, intermediates=inter)
+        if cfg.dataset == 'PDBbind':
+            scale = max(float(np.abs(g['node_out64'][b.batch.numpy() == k]).sum()) for k in range(len(g['out64'])))
+            assert float(np.max(np.abs(out.numpy() - g['out' + tag]))) / scale < tol, (tag, 'out')
+        else:
+            assert maxnorm_err(out, g['out' + tag]) < tol, (tag, 'out')
+        assert maxnorm_err(inter['pool_in'], g['node_out' + tag]) < tol, (tag, 'node_out')
+        if tag == '32':
+            assert inter['edge_index_l'].shape[1] == int(g['num_edges_l'])
+            assert inter['idx_kj'].numel() == int(g['num_triplets'])
+            assert inter['idx_jj_pair'].numel() == int(g['num_pairs'])

@@ -94,7 +94,8 @@ def test_wrong_sizes_are_caught(dev, store):
     model = _model(dev)
     st.prepare_for(model)
     idx = list(range(64))
-    key = (5.0, 5.0, True)
+    from pamnet_amd.store import size_key
+    key = size_key(model)
     for d_eg, d_tp in ((-7, 0), (+9, 0), (0, -5), (0, +11)):
         b = st.collate(idx)
         eg, el, tp = b.sizes[key]
@@ -125,8 +126,7 @@ def test_trainer_and_predict_verify(dev, store):
     tr = train.Trainer(model, lr=1e-4)
     batches = [st.collate(list(range(k * 32, k * 32 + 32))) for k in range(6)]
     losses = [tr.step(batches[k], next_data=batches[k + 1] if k + 1 < 6 else None) for k in range(6)]
-    torch.cuda.synchronize()
-    model.verify()
+    tr.drain()                                                   # every step's own flag words, read once it has completed
     assert all(torch.isfinite(l) for l in losses)
     outs = [o for _, o in train.predict(model, [st.collate(list(range(k * 50, k * 50 + 50))) for k in range(4)])]
     assert len(outs) == 4
@@ -136,8 +136,53 @@ def test_trainer_and_predict_verify(dev, store):
     with pytest.raises(GraphCheckError):
         for k in range(5):
             tr.step(bad if k == 0 else st.collate(list(range(32))))
-        torch.cuda.synchronize()
-        model.verify()
+        tr.drain()
+    tr.drain()                                                   # the raise left nothing behind
+    # an evaluation pass between training steps has its own forwards and its own verify(): it must neither swallow nor
+    # mis-attribute the flag words of the training steps still in flight (they travel with the steps' events)
+    tr.step(st.collate(list(range(32))))
+    tr.step(st.collate(list(range(32, 64))))
+    worse = st.collate(list(range(32)))
+    worse.sizes = {key: (worse.sizes[key][0] + 5,) + tuple(worse.sizes[key][1:])}
+    tr.step(worse)
+    with pytest.raises(GraphCheckError):
+        tr.evaluate([st.collate(list(range(k * 50, k * 50 + 50))) for k in range(2)])
+    tr.drain()
+    assert tr.evaluate([st.collate(list(range(k * 50, k * 50 + 50))) for k in range(2)]) >= 0.0
+
+
+def test_store_strips_self_loops_and_keys_its_counts(dev):
+    """remove_self_loops (models.py:63) happens once, at ingestion: a dataset whose bond lists contain self loops runs the
+    zero-host-sync forward like its clean twin (same outputs, no deferred error).  The per-molecule size tables are keyed
+    by everything the sizes depend on: two models with different cutoffs / layer kinds sharing a store get their own."""
+    import copy
+    from pamnet_amd import store as S, synth
+    clean = [synth.qm9_molecule(9, i) for i in range(40)]
+    dirty = copy.deepcopy(clean)
+    for k in (0, 7, 39):
+        n = dirty[k]['x'].shape[0]
+        loops = np.array([[0, n - 1], [0, n - 1]], dtype=np.int64)
+        dirty[k]['edge_index'] = np.concatenate([dirty[k]['edge_index'][:, :3], loops, dirty[k]['edge_index'][:, 3:]], axis=1)
+    sc, sd_ = S.MoleculeStore(clean, dev), S.MoleculeStore(dirty, dev)
+    assert (sc.n_edges == sd_.n_edges).all()
+    model = _model(dev)
+    other = _model(dev, cutoff_g=4.0)
+    small = _model(dev, small=True)
+    sc.prepare_for(model, other, small)
+    sd_.prepare_for(model)
+    assert len({S.size_key(m) for m in (model, other, small)}) == 3 and len(sc._counts) == 3
+    idx = [39, 0, 12, 7]
+    with torch.no_grad():
+        ref = model(sc.collate(idx))
+        out = model(sd_.collate(idx))
+        model.verify()                                           # no self-loop flag, no size mismatch
+        assert torch.equal(out, ref)
+        b = sc.collate(idx)
+        assert set(b.sizes) == {S.size_key(m) for m in (model, other, small)}
+        o1, o2, o3 = model(b), other(sc.collate(idx)), small(sc.collate(idx))
+        for m in (model, other, small):
+            m.verify()                                           # each model found ITS sizes in the batch
+        assert not torch.equal(o1, o2)
 
 
 @pytest.mark.parametrize('kind', ['PDBbind', 'rna'])

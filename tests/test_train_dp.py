@@ -357,3 +357,63 @@ def test_direct_tape_backward_equals_autograd(kind):
         ops.backward_whole = real
     assert float(direct.abs().max()) > 0
     assert torch.equal(direct, via_autograd)
+
+
+def _pamnet_rank(rank, world, port, out, total):
+    """One rank of the 2-GPU PAMNet step: its own device, RCCL, its molecule shard of the global batch."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p_ in (os.path.dirname(here), os.path.join(os.path.dirname(here), 'physics-aware-multiplex-gnn_amd')):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(rank)
+    dev = torch.device('cuda', rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    import models
+    from pamnet_amd import synth
+    from pamnet_amd.train import Trainer, shard_range
+    torch.manual_seed(100 + rank)                 # different initial weights per rank: the trainer broadcasts rank 0's
+    model = models.PAMNet(models.Config(dataset='QM9', dim=128, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)).to(dev)
+    if rank == 0:
+        torch.save({k: v.cpu() for k, v in model.state_dict().items()}, out + '.init')
+    tr = Trainer(model, lr=1e-3, world_size=world, n_buckets=3)
+    assert tr._buckets is not None and tr._stack_ctx is not None          # the bucketed, overlapped all-reduce
+    lo, hi = shard_range(total, rank, world)
+    losses = []
+    for step in range(3):
+        losses.append(float(tr.step(synth.qm9_batch(7, 40 * step + lo, hi - lo).to(dev), global_graphs=total)))
+    torch.cuda.synchronize()
+    ref = tr.fp.flat.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(ref, tr.fp.flat)           # identical parameters on every rank
+    if rank == 0:
+        torch.save({'flat': tr.fp.flat.cpu(), 'shadow': tr.shadow.cpu(), 'norm': float(tr.last_grad_norm)}, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_pamnet_two_rank_rccl_step_equals_global_batch_step(tmp_path):
+    """PAMNet (d=128, L=2) on TWO GPUs over RCCL: shard by molecule (13 + 12), pre-scale by local/global graphs,
+    bucketed all-reduce overlapped with the backward, identical update -- equals the single-process step on the global
+    batch (what test_dp_matches_single_process shows for the CPU stand-in).  Needs two devices: skipped on a 1-GPU box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs (this box has %d)' % torch.cuda.device_count())
+    import models
+    from pamnet_amd import synth
+    from pamnet_amd.train import Trainer
+    total, out = 25, str(tmp_path / 'dp2.pt')
+    mp.spawn(_pamnet_rank, args=(2, _free_port(), out, total), nprocs=2, join=True)
+    got, init = torch.load(out), torch.load(out + '.init')
+    dev = torch.device('cuda:0')
+    model = models.PAMNet(models.Config(dataset='QM9', dim=128, n_layer=2, cutoff_l=5.0, cutoff_g=5.0))
+    model.load_state_dict(init, strict=True)
+    tr = Trainer(model.to(dev), lr=1e-3, world_size=1)
+    for step in range(3):
+        tr.step(synth.qm9_batch(7, 40 * step, total).to(dev))
+    torch.cuda.synchronize()
+    # same arithmetic up to the summation order of the two partial gradients (fp32): parameters after three Adam steps
+    d = (got['flat'] - tr.fp.flat.cpu()).abs().max() / tr.fp.flat.abs().max().cpu()
+    assert float(d) < 1e-5, float(d)
+    assert float((got['shadow'] - tr.shadow.cpu()).abs().max()) < 1e-5
+    assert abs(got['norm'] / float(tr.last_grad_norm) - 1) < 1e-4
