@@ -52,6 +52,20 @@ namespace {
 
 constexpr int NMAX = 511;                 // nodes per chunk (their CSR offsets are staged in LDS)
 
+// XCD-aware work order.  The dispatcher deals workgroups to the 8 XCDs round-robin (workgroup b runs on XCD b % 8), and
+// every XCD has an L2 of its own: with node range k handed to workgroup k, eight NEIGHBOURING node ranges -- the same
+// molecule / complex, whose P_i / P_j rows and CSR slices they all gather -- land on eight different L2s and every
+// node-plane row is fetched from the fabric up to eight times (measured at the PDBbind shape: 1.44x the algorithmic bytes
+// in the inference instantiation, profiles/r02_edge_agg_pmc.json).  Workgroup b takes range
+//   order(b) = (b % 8) * (G / 8) + b / 8  (+ the remainder spread over the first G % 8 XCDs),
+// so the workgroups of one XCD own one contiguous eighth of the nodes.  A bijection on [0, G): every range still has
+// exactly one owner, results are bitwise unchanged.
+__device__ __forceinline__ int xcd_order(int b, int G) {
+    constexpr int X = 8;
+    const int x = b % X, i = b / X, q = G / X, r = G % X;
+    return i + x * q + (x < r ? x : r);
+}
+
 // node boundary nearest to row k*m/G (0 for k = 0, n for k = G): monotone in k, so the ranges tile [0, n)
 __device__ __forceinline__ int seg_cut(const int32_t* __restrict__ ptr, const int32_t* __restrict__ row_of, int64_t n,
                                        int64_t m, int k, int G) {
@@ -150,8 +164,9 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
     load_wset<false>(f1, a.We, a.ld_we, wc);
     load_wset<false>(f2, a.Wea, a.ld_wea, wc);
     APROBE(20);
-    const int nb = a.cuts ? a.cuts[blockIdx.x] : seg_cut(ptr, row_of, a.n, a.m, blockIdx.x, gridDim.x);
-    const int ne = a.cuts ? a.cuts[blockIdx.x + 1] : seg_cut(ptr, row_of, a.n, a.m, blockIdx.x + 1, gridDim.x);
+    const int wg = xcd_order(blockIdx.x, gridDim.x);
+    const int nb = a.cuts ? a.cuts[wg] : seg_cut(ptr, row_of, a.n, a.m, wg, gridDim.x);
+    const int ne = a.cuts ? a.cuts[wg + 1] : seg_cut(ptr, row_of, a.n, a.m, wg + 1, gridDim.x);
     const int64_t rb = ptr[nb], re = ptr[ne];
     APROBE(21);
     constexpr int RPP = 16, NI = MTX;                       // sweep geometry of 512 threads: 16 rows per pass
@@ -318,8 +333,9 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
     WSet<1> f1, f2;
     load_wset<true>(f1, a.We, a.ld_we, wc);
     load_wset<true>(f2, a.Wea, a.ld_wea, wc);
-    const int nb = a.cuts ? a.cuts[blockIdx.x] : seg_cut(ptr, row_of, a.n, a.m, blockIdx.x, gridDim.x);
-    const int ne = a.cuts ? a.cuts[blockIdx.x + 1] : seg_cut(ptr, row_of, a.n, a.m, blockIdx.x + 1, gridDim.x);
+    const int wg = xcd_order(blockIdx.x, gridDim.x);
+    const int nb = a.cuts ? a.cuts[wg] : seg_cut(ptr, row_of, a.n, a.m, wg, gridDim.x);
+    const int ne = a.cuts ? a.cuts[wg + 1] : seg_cut(ptr, row_of, a.n, a.m, wg + 1, gridDim.x);
     const int64_t re = ptr[ne];
     constexpr int RPP = 16, NI = MTX;
     const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;

@@ -585,8 +585,10 @@ def test_large_batch_equals_its_shards(dev):
         e = maxnorm_err(out.detach().cpu().numpy(), torch.cat(outs).cpu().numpy())
         assert e < 2e-6, (target, e)
         worst_out = max(worst_out, e)
-        assert len(g_big) == len(named)
+        assert len(g_big) == len(named) - 1 and 'init_linear.weight' not in g_big     # (unused on the QM9 branch)
         for k, p in named:
+            if k not in g_big:
+                continue
             e = maxnorm_err(p.grad.cpu().numpy(), g_big[k].cpu().numpy())
             assert e < 2e-5, (target, k, e)
             worst_grad = max(worst_grad, e)
@@ -676,7 +678,8 @@ def test_trainer_step_path_at_configs1_vs_oracle_and_reference(dev, golden):
     assert abs(gn / float(g['grad_norm64']) - 1) < 1e-4, (gn, float(g['grad_norm64']))
     grads = dict(zip(tr.fp.names, tr.fp.grad_views))
     keys = g['grad_keys'].tolist()
-    assert sorted(keys) == sorted(grads)
+    assert set(grads) - set(keys) == {'init_linear.weight'}            # unused on the QM9 branch: no gradient either side
+    assert float(grads['init_linear.weight'].abs().max()) == 0.0
     worst_l2 = 0.0
     for k, l2 in zip(keys, g['grad_l2_64']):
         e = abs(float(grads[k].double().norm()) - float(l2)) / max(float(l2), 1e-300)
@@ -725,13 +728,19 @@ def test_trainer_tape_path_trains_every_parameter(dev, dataset, dim):
     tr = train.Trainer(model, lr=1e-4)
     assert model._one_node()
     tr.forward_backward(b.to(dev))
-    for k, p in model.named_parameters():
-        assert float(p.grad.abs().max()) > 0.0, 'no gradient reached %s' % k
     p64 = O.as_params({k: v.double() for k, v in sd.items()})
     pos, ei = getattr(b, 'pos', None), getattr(b, 'edge_index', None)
     x64 = b.x.double() if (cfg.dataset == 'PDBbind' or dataset.startswith('rna')) else b.x
     ref64 = O.pamnet_forward(p64, cfg, x64, b.batch, pos, ei, dtype=torch.float64)
     torch.nn.functional.l1_loss(ref64, b.y.double()).backward()
+    used = 0
+    for k, p in model.named_parameters():
+        if p64[k].grad is None or float(p64[k].grad.abs().max()) == 0.0:
+            assert float(p.grad.abs().max()) == 0.0, k              # a parameter this branch of the model never reads
+        else:
+            assert float(p.grad.abs().max()) > 0.0, 'no gradient reached %s' % k
+            used += 1
+    assert used >= len(p64) - 2 and (dataset != 'PDBbind' or float(model.init_linear.weight.grad.abs().max()) > 0.0)
     _check_gradients(model, p64, O.pamnet_forward, sd, cfg, b)
 
 

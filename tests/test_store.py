@@ -138,17 +138,36 @@ def test_trainer_and_predict_verify(dev, store):
             tr.step(bad if k == 0 else st.collate(list(range(32))))
         tr.drain()
     tr.drain()                                                   # the raise left nothing behind
-    # an evaluation pass between training steps has its own forwards and its own verify(): it must neither swallow nor
-    # mis-attribute the flag words of the training steps still in flight (they travel with the steps' events)
+
+
+def test_evaluation_between_steps_keeps_flag_ownership(dev, store):
+    """An evaluation pass between training steps has its own forwards and its own verify(): it must neither swallow nor
+    mis-attribute the flag words of the training steps still in flight -- they travel with the steps' events
+    (Trainer._throttle), whatever model.verify() is called in between."""
+    from pamnet_amd import train
+    from pamnet_amd.graph import GraphCheckError
+    st, _ = store
+    model = _model(dev, n_layer=1)
+    st.prepare_for(model)
+    tr = train.Trainer(model, lr=1e-4)
+    ev = lambda: tr.evaluate([st.collate(list(range(k * 50, k * 50 + 50))) for k in range(2)])
+    for k in range(4):
+        tr.step(st.collate(list(range(32 * k, 32 * k + 32))))
+    assert len(tr._inflight) == tr.MAX_STEPS_IN_FLIGHT and sum(len(f) for _, f in tr._inflight) >= 1
+    mae = ev()                                                   # drains the steps in flight first: all clean
+    assert np.isfinite(mae) and not tr._inflight and not model._pending_checks
     tr.step(st.collate(list(range(32))))
-    tr.step(st.collate(list(range(32, 64))))
-    worse = st.collate(list(range(32)))
+    worse = st.collate(list(range(32, 64)))
+    key = next(iter(worse.sizes))
     worse.sizes = {key: (worse.sizes[key][0] + 5,) + tuple(worse.sizes[key][1:])}
-    tr.step(worse)
-    with pytest.raises(GraphCheckError):
-        tr.evaluate([st.collate(list(range(k * 50, k * 50 + 50))) for k in range(2)])
+    tr.step(worse)                                               # its flag word is still on the model ...
+    tr.step(st.collate(list(range(64, 96))))                     # ... and now travels with this step's event
+    with torch.no_grad():
+        model(st.collate(list(range(10))))
+    model.verify()                                               # a verify() of somebody else's forward: clean, and it
+    with pytest.raises(GraphCheckError):                         # did not swallow the training step's word
+        ev()
     tr.drain()
-    assert tr.evaluate([st.collate(list(range(k * 50, k * 50 + 50))) for k in range(2)]) >= 0.0
 
 
 def test_store_strips_self_loops_and_keys_its_counts(dev):

@@ -1,14 +1,14 @@
 # HBM traffic of the fused edge MLP -> node segment-sum kernel at the PDBbind B=32 shape (E_g ~ 700 k: 360 MB per
 # [E_g, 128] tensor, beyond the 256 MB Infinity Cache -- at the QM9 batch everything is cache resident and the counters
 # read almost nothing).  Separate --pmc passes with --kernel-trace only; FETCH_SIZE x2 / WRITE_SIZE as in pmc_scatter.sh
-# (MI355X_MICROARCH.md, HBM section).  Writes gpurun_out/r02_edge_agg_pmc.json (copy into profiles/ and commit).
+# (MI355X_MICROARCH.md, HBM section).  Writes gpurun_out/${PMC_OUT:-r03_edge_agg_pmc.json} (copy into profiles/ and commit).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmca_$c
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmca_$c -- python $R/tools/agg_bench.py pdbbind > /tmp/pmca_$c.log 2>&1
 done
-python - <<'PY' > $R/gpurun_out/r02_edge_agg_pmc.json
+python - <<'PY' > $R/gpurun_out/${PMC_OUT:-r03_edge_agg_pmc.json}
 import csv, glob, json, re
 D = 128
 def counter(name, kernel):
@@ -40,4 +40,4 @@ for k in names:
                               'traffic_over_algorithmic': traffic / a}
 print(json.dumps(out, indent=1))
 PY
-cat $R/gpurun_out/r02_edge_agg_pmc.json
+cat $R/gpurun_out/${PMC_OUT:-r03_edge_agg_pmc.json}
