@@ -175,7 +175,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
     float4 pre[PRE ? NI : 1];
     if (PRE && rb < re) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) pre[i] = ldg4z(e, rb + rr + RPP * i, re, DIM, c4);
+        for (int i = 0; i < NI; ++i) pre[i] = ldg4z_nt(e, rb + rr + RPP * i, re, DIM, c4);
     }
     int c0 = nb, par = 0;
     int64_t r0 = rb;
@@ -196,12 +196,12 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
                     if (RPP * i < 16 * mt) st_lds4(S0, rr + RPP * i, c4, pre[i]);
                 if (r1 < re) {
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) pre[i] = ldg4z(e, r1 + rr + RPP * i, re, DIM, c4);
+                    for (int i = 0; i < NI; ++i) pre[i] = ldg4z_nt(e, r1 + rr + RPP * i, re, DIM, c4);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
-                    if (RPP * i < 16 * mt) st_lds4(S0, rr + RPP * i, c4, ldg4z(e, r0 + rr + RPP * i, r1, DIM, c4));
+                    if (RPP * i < 16 * mt) st_lds4(S0, rr + RPP * i, c4, ldg4z_nt(e, r0 + rr + RPP * i, r1, DIM, c4));
             }
             APROBE(23);
             if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = myp;
@@ -263,8 +263,8 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
                         for (int i = 0; i < SC; ++i) {
                             const int64_t g = r0 + eoff + rr + RPP * i;
                             if (g < r1) {
-                                stg4(zs, g, DIM, c4, zz[i]);
-                                stg4(eas, g, DIM, c4, gate[i]);
+                                stg4_nt(zs, g, DIM, c4, zz[i]);
+                                stg4_nt(eas, g, DIM, c4, gate[i]);
                             }
                         }
                     }

@@ -307,6 +307,17 @@ __device__ __forceinline__ float4 ldg4z(const float* p, int64_t row, int64_t nro
 __device__ __forceinline__ void stg4(float* p, int64_t row, int ld, int c4, float4 v) {
     *reinterpret_cast<float4*>(p + row * ld + 4 * c4) = v;
 }
+// Streaming forms for rows that are touched exactly once per launch (edge-level inputs read once, backward-only saves
+// written once): the non-temporal hint keeps them from pushing the re-used node-plane rows out of the XCD's 4 MB L2.
+__device__ __forceinline__ float4 ldg4z_nt(const float* p, int64_t row, int64_t nrows, int ld, int c4) {
+    const bool ok = row < nrows;
+    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (ok ? row : 0) * ld + 4 * c4));
+    return ok ? make_float4(t[0], t[1], t[2], t[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void stg4_nt(float* p, int64_t row, int ld, int c4, float4 v) {
+    const f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p + row * ld + 4 * c4));
+}
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 f4silu(float4 z) { return make_float4(silu(z.x), silu(z.y), silu(z.z), silu(z.w)); }
