@@ -65,16 +65,16 @@ int pamnet_gather_mul2_f32(float* out1, float* out2, const float* A, const int32
 /* out[0]=0, out[i+1]=sum_{j<=i} in[j]  (n inputs -> n+1 outputs).  `tmp` needs ceil(n/4096)+1 ints. */
 int pamnet_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* tmp, pamnet_stream_t stream);
 
-/* Stable counting sort of m keys in [0, rows): ptr[rows+1] (CSR) and perm[m] with keys[perm[q]] non-decreasing and
- * perm ascending inside a row.  Scratch: `cursor` rows + 1 ints (the rows' counters plus one flag: an already
- * non-decreasing key sequence takes the identity-permutation path), `perm_tmp` m ints, `tmp` ceil(rows/4096)+1 ints (the
- * scan's chunk sums).  Deterministic. */
 /* flag[0] = 1 when the index inputs of a batch are out of range (the reference would raise an IndexError): node_graph not
  * sorted / not in [0, n_graphs), a type (float, element i at types[i * type_stride]; nullable) not in [0, n_types), an
  * edge endpoint (src / dst, nullable with n_edges = 0) not in [0, n).  One launch; flag is zeroed by the call. */
 int pamnet_validate_inputs_i32(const int32_t* node_graph, int64_t n, int64_t n_graphs, const float* types,
                                int64_t type_stride, int64_t n_types, const int32_t* src, const int32_t* dst,
                                int64_t n_edges, int32_t* flag, pamnet_stream_t stream);
+/* Stable counting sort of m keys in [0, rows): ptr[rows+1] (CSR) and perm[m] with keys[perm[q]] non-decreasing and
+ * perm ascending inside a row.  Scratch: `cursor` rows + 1 ints (the rows' counters plus one flag: an already
+ * non-decreasing key sequence takes the identity-permutation path), `perm_tmp` m ints, `tmp` ceil(rows/4096)+1 ints (the
+ * scan's chunk sums).  Deterministic. */
 int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t rows, int32_t* ptr, int32_t* perm,
                              int32_t* cursor, int32_t* perm_tmp, int32_t* tmp, pamnet_stream_t stream);
 
@@ -181,6 +181,60 @@ int pamnet_collate_f32(int64_t n_graphs, const int32_t* sel, const int32_t* out_
                        const float* pos, const int32_t* esrc, const int32_t* edst, int64_t n_out, int64_t e_out,
                        float* out_x, float* out_pos, int32_t* out_batch, int32_t* out_esrc, int32_t* out_edst,
                        pamnet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Graph-construction engine: everything of PAMNet.forward that does not depend on the parameters -- index ingestion,
+ * remove_self_loops, radius / knn graphs, cutoff masks, the SparseTensor CSRs, triplets / pairs and their angles
+ * (models.py:62-98, 104-177), the transposed index lists of the backward and the spherical basis
+ * (layers/basic.py:107-116) -- enqueued by ONE call (csrc/graph_engine.hip) for a batch whose data-dependent sizes the host
+ * already knows (eg, el, tp: per-graph constants, pamnet_amd/store.py).  Same kernels, same order, same results as the
+ * step-by-step entry points above; fills are capped by the sizes, and the device-side counts are compared with them by
+ * pamnet_check_sizes_i32 into the flag word (field PAMNET_GF_FLAG), to be read whenever the host next synchronises.
+ * `arena`: caller-owned int32 buffer of *arena_ints entries (pamnet_graph_plan); layout[f] = offset (in ints) of field f
+ * inside it, or -1 when the batch has no such array (float fields are stored in place: reinterpret).  Batches with an
+ * empty node / edge / row list are rejected (PAMNET_EINVAL): they take the step-by-step entry points.
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define PAMNET_SCHEMA_QM9 0     /* x = atom types, pos, bond list (models.py:104-113) */
+#define PAMNET_SCHEMA_PDBBIND 1 /* rows = xyz + features; radius graphs at both cutoffs (models.py:115-136) */
+#define PAMNET_SCHEMA_RNA 2     /* rows = xyz + type; kNN graph cut at both cutoffs (models.py:138-157) */
+typedef struct pamnet_graph_desc {
+    int64_t n, n_graphs, n_bonds; /* nodes, graphs, directed bonds (QM9; 0 otherwise) */
+    int64_t eg, el, tp;           /* sizes the host assumes: global edges, local edges, triplet + pair rows */
+    const void* batch;            /* [n] graph id per node, sorted; int64 / int32 / fp32 by batch_kind (1 / 2 / 3) */
+    const void* types;            /* QM9 / RNA: atom type of node i at types[i * types_stride], kind as above */
+    int64_t types_stride, n_types;
+    const float* pos;             /* QM9: [n, 3] */
+    const float* rows;            /* PDBbind / RNA: [n, rows_width] fp32, xyz first */
+    int64_t rows_width;
+    const void* edge_src;         /* QM9: edge_index[0], edge_index[1] ([n_bonds] each), kind edge_kind */
+    const void* edge_dst;
+    int32_t schema, batch_kind, types_kind, edge_kind;
+    int32_t with_triplets;        /* 0: pairs only (PAMNet_s) */
+    int32_t need_grad;            /* 1: also build the transposed index lists the backward gathers with */
+    int32_t aggregate_at_query;   /* RNA: flow == 'target_to_source' (the global layer aggregates at the kNN query) */
+    int32_t knn_k;                /* RNA: neighbours per query (models.py:143: 50) */
+    float cutoff_l, cutoff_g;
+} pamnet_graph_desc;
+enum {
+    PAMNET_GF_NODE_GRAPH = 0, /* int32 [n] */
+    PAMNET_GF_GPTR,           /* int32 [n_graphs + 1] first node of every graph */
+    PAMNET_GF_FLAG,           /* int32 [1]: bit 1 invalid index inputs, bits 2 / 4 / 8 size mismatch (eg / el / tp), 32 self loops */
+    PAMNET_GF_LOOPS,          /* int32 [1] */
+    PAMNET_GF_TYPES,          /* int32 [n] */
+    PAMNET_GF_POS,            /* fp32 [n, 3] (PDBbind / RNA; QM9 uses the caller's) */
+    PAMNET_GF_SIGN,           /* fp32 [n] pooling sign (PDBbind, models.py:124) */
+    PAMNET_GF_G_PTR, PAMNET_GF_G_ROW, PAMNET_GF_G_COL, PAMNET_GF_G_DIST,   /* global graph, CSR by aggregation target */
+    PAMNET_GF_GT_PTR, PAMNET_GF_GT_PERM,                                     /* its transposed CSR (need_grad) */
+    PAMNET_GF_L_PTR, PAMNET_GF_L_ROW, PAMNET_GF_L_COL, PAMNET_GF_L_DIST,   /* local graph */
+    PAMNET_GF_LT_PTR, PAMNET_GF_LT_PERM,
+    PAMNET_GF_T_PTR, PAMNET_GF_T_ROW, PAMNET_GF_T_COL, PAMNET_GF_T_ANGLE, PAMNET_GF_T_KIND,   /* triplet + pair rows */
+    PAMNET_GF_TT_PTR, PAMNET_GF_TT_PERM,
+    PAMNET_GF_CUTS,           /* int32 [<= 257] node-aligned work split of the fused global-edge kernels */
+    PAMNET_GRAPH_FIELDS
+};
+int pamnet_graph_plan(const pamnet_graph_desc* desc, int64_t* layout /* [PAMNET_GRAPH_FIELDS] */, int64_t* arena_ints);
+int pamnet_graph_build_i32(const pamnet_graph_desc* desc, int32_t* arena, float* sbf /* [tp, 42], nullable */,
+                           pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Basis functions  (layers/basic.py:36-51 Envelope, :59-76 BesselBasisLayer, :79-116 SphericalBasisLayer; utils/sbf.py)

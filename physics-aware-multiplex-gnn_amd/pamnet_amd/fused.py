@@ -533,6 +533,9 @@ def _aux_fork(dev, n_layer):
 
 
 def _graph_tables(graph):
+    t = getattr(graph, '_tables', None)        # a graph built by the graph-construction engine carries its tables
+    if t is not None:
+        return t
     sizes = _iarr([graph.n, graph.glob.m, graph.loc.m, graph.tp.m])
     idx = _parr([graph.glob.ptr, graph.glob.row_of, graph.glob.col, graph.glob_T.ptr, graph.glob_T.perm,
                  graph.loc.ptr, graph.loc.row_of, graph.loc.col, graph.loc_T.ptr, graph.loc_T.perm,

@@ -389,6 +389,151 @@ def raise_for_flag(bits):
                               + ', '.join(what) + ' -- results of this batch are invalid')
 
 
+ENGINE = __import__('os').environ.get('PAMNET_GRAPH_ENGINE', '1') != '0'    # measurement aid: 0 = the step-by-step path
+
+
+class _Facade(object):
+    """CSR / transposed-CSR view of an EngineGraph: `ptr`, `row_of` / `perm`, `col` are arena slices created on first
+    access (the engines read raw addresses; tensors are for tests, the per-operator paths and inspection)."""
+
+    def __init__(self, g, fields, m, rows):
+        self.__dict__['_g'], self.__dict__['_fields'] = g, fields
+        self.m, self.rows = int(m), int(rows)
+
+    def __getattr__(self, name):
+        spec = self.__dict__['_fields'].get(name)
+        if spec is None:
+            raise AttributeError(name)
+        v = self.__dict__['_g']._view(*spec)
+        self.__dict__[name] = v
+        return v
+
+
+class EngineGraph(Graph):
+    """Graph built by ONE call of the graph-construction engine (csrc/graph_engine.hip): every index / geometry array is a
+    slice of one int32 arena; Python-side tensors are created lazily, the layer-stack engines get raw addresses."""
+
+    def _view(self, field, count, is_float=False):
+        off = self._layout[field]
+        if off < 0:
+            return None
+        v = self._arena[off:off + int(count)]
+        return v.view(torch.float32) if is_float else v
+
+    def _addr(self, field):
+        off = self._layout[field]
+        return None if off < 0 else self._base + 4 * off
+
+    def __getattr__(self, name):                     # only reached when the attribute is not materialised yet
+        mk = self.__dict__.get('_lazy', {}).get(name)
+        if mk is None:
+            raise AttributeError(name)
+        v = mk()
+        self.__dict__[name] = v
+        return v
+
+
+_SCHEMA = {'QM9': 0, 'PDBbind': 1, 'rna': 2}
+
+
+def _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_index, n_graphs, need_grad, knn_k,
+                  with_triplets, n_types, sizes):
+    """The zero-host-sync graph as one engine call, or None when this batch does not qualify (empty lists, layouts the
+    ingest launch does not read): the step-by-step path below then builds it."""
+    import ctypes
+    rna = dataset[:3].lower() == 'rna'
+    n = int(batch.numel())
+    eg, el, tp = (int(v) for v in sizes)
+    if not (ENGINE and batch.is_cuda and n > 0 and min(eg, el, tp) > 0 and batch.dim() == 1 and batch.is_contiguous()
+            and batch.dtype in _KINDS):
+        return None
+    d = lib.GraphDesc()
+    d.n, d.n_graphs, d.eg, d.el, d.tp = n, int(n_graphs), eg, el, tp
+    d.batch, d.batch_kind = batch.data_ptr(), _KINDS[batch.dtype]
+    d.with_triplets, d.need_grad, d.knn_k = (1 if with_triplets else 0), (1 if need_grad else 0), int(knn_k)
+    d.cutoff_l, d.cutoff_g = float(cutoff_l), float(cutoff_g)
+    d.n_types = int(n_types or 0)
+    keep = [batch]
+    if dataset == 'QM9':
+        if pos is None or edge_index is None or n_types is None:
+            return None
+        xcol = x_raw.reshape(-1) if (x_raw.dim() == 1 or (x_raw.dim() == 2 and x_raw.size(1) == 1)) else None
+        if xcol is None or xcol.dtype not in _KINDS or xcol.numel() != n:
+            return None
+        if edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.dtype not in _KINDS:
+            return None
+        es, ed = edge_index[0], edge_index[1]
+        if not (es.is_contiguous() and ed.is_contiguous()) or int(es.numel()) != el:
+            return None
+        pos = pos if (pos.dtype == torch.float32 and pos.is_contiguous()) else pos.to(torch.float32).contiguous()
+        d.schema, d.n_bonds = 0, el
+        d.types, d.types_kind, d.types_stride = xcol.data_ptr(), _KINDS[xcol.dtype], (xcol.stride(0) if n > 1 else 1)
+        d.pos, d.edge_src, d.edge_dst, d.edge_kind = pos.data_ptr(), es.data_ptr(), ed.data_ptr(), _KINDS[edge_index.dtype]
+        keep += [xcol, pos, edge_index]
+    else:
+        if x_raw.dim() != 2 or x_raw.dtype != torch.float32 or not x_raw.is_contiguous() or x_raw.size(1) < 4:
+            return None
+        w = int(x_raw.size(1))
+        d.rows, d.rows_width, d.n_bonds = x_raw.data_ptr(), w, 0
+        if rna:
+            if n_types is None:
+                return None
+            d.schema, d.types, d.types_kind, d.types_stride = 2, x_raw.data_ptr() + 4 * (w - 1), 3, w
+            d.aggregate_at_query = 1 if flow == 'target_to_source' else 0
+        elif dataset == 'PDBbind':
+            if not cutoff_l <= cutoff_g:
+                return None
+            d.schema = 1
+        else:
+            return None
+        keep.append(x_raw)
+    layout = (ctypes.c_int64 * lib.GRAPH_FIELDS)()
+    need = ctypes.c_int64(0)
+    lib.call('pamnet_graph_plan', ctypes.addressof(d), ctypes.addressof(layout), ctypes.addressof(need))
+    dev = batch.device
+    arena = torch.empty(int(need.value), dtype=I32, device=dev)
+    sbf = torch.empty((tp, 42), dtype=torch.float32, device=dev)
+    lib.call('pamnet_graph_build_i32', ctypes.addressof(d), arena.data_ptr(), sbf.data_ptr(), lib.stream_of(batch))
+    F = lib.GF
+    g = EngineGraph()
+    g._arena, g._layout, g._base, g._inputs = arena, list(layout), arena.data_ptr(), keep
+    g.n, g.n_graphs, g.need_grad_built = n, int(n_graphs), bool(need_grad)
+    g.sbf, g._sbf_cutoff = sbf, float(cutoff_l)
+    g.check = g._view(F['FLAG'], 1)
+    g.pos = pos if dataset == 'QM9' else None
+    ng = int(n_graphs)
+    lazy = {
+        'node_graph': lambda: g._view(F['NODE_GRAPH'], n), 'gptr': lambda: g._view(F['GPTR'], ng + 1),
+        'types': lambda: g._view(F['TYPES'], n), 'sign': lambda: g._view(F['SIGN'], n, True),
+        'loops': lambda: g._view(F['LOOPS'], 1),
+        'dist_g': lambda: g._view(F['G_DIST'], eg, True), 'dist_l': lambda: g._view(F['L_DIST'], el, True),
+        'tp_angle': lambda: g._view(F['T_ANGLE'], tp, True), 'tp_kind': lambda: g._view(F['T_KIND'], tp),
+        'cuts': lambda: g._view(F['CUTS'], 257),
+        'glob': lambda: _Facade(g, {'ptr': (F['G_PTR'], n + 1), 'row_of': (F['G_ROW'], eg), 'col': (F['G_COL'], eg)}, eg, n),
+        'loc': lambda: _Facade(g, {'ptr': (F['L_PTR'], n + 1), 'row_of': (F['L_ROW'], el), 'col': (F['L_COL'], el)}, el, n),
+        'tp': lambda: _Facade(g, {'ptr': (F['T_PTR'], el + 1), 'row_of': (F['T_ROW'], tp), 'col': (F['T_COL'], tp)}, tp, el),
+    }
+    if dataset != 'QM9':
+        lazy['pos'] = lambda: g._view(F['POS'], 3 * n, True).view(n, 3)
+        del g.__dict__['pos']
+    if need_grad:
+        lazy['glob_T'] = lambda: _Facade(g, {'ptr': (F['GT_PTR'], n + 1), 'perm': (F['GT_PERM'], eg)}, eg, n)
+        lazy['loc_T'] = lambda: _Facade(g, {'ptr': (F['LT_PTR'], n + 1), 'perm': (F['LT_PERM'], el)}, el, n)
+        lazy['tp_T'] = lambda: _Facade(g, {'ptr': (F['TT_PTR'], el + 1), 'perm': (F['TT_PERM'], tp)}, tp, el)
+    else:
+        g.glob_T = g.loc_T = g.tp_T = _NoTranspose
+    g.__dict__['_lazy'] = lazy
+    # pointer tables of the layer-stack engines (fused._graph_tables): raw addresses, no tensors
+    order = ('G_PTR', 'G_ROW', 'G_COL', 'GT_PTR', 'GT_PERM', 'L_PTR', 'L_ROW', 'L_COL', 'LT_PTR', 'LT_PERM',
+             'T_PTR', 'T_ROW', 'T_COL', 'TT_PTR', 'TT_PERM')
+    idx = (ctypes.c_void_p * 15)()
+    for k, name in enumerate(order):
+        idx[k] = g._addr(F[name])
+    g._tables = ((ctypes.c_int64 * 4)(n, eg, el, tp), idx)
+    g._sizes = (n, eg, el, tp)
+    return g
+
+
 def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_index=None, num_graphs=None,
                 need_grad=True, knn_k=50, with_triplets=True, n_types=None, sizes=None):
     """Graph-construction part of PAMNet.forward (models.py:104-177).  Returns a Graph.
@@ -399,6 +544,11 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     folds in the input-validity flag); the result waits in `g.check` (an int32 device scalar) for the caller's next
     synchronisation (PAMNet.verify).  Without them: one host round trip for the sizes and the flag."""
     dev = batch.device
+    if sizes is not None and num_graphs is not None:
+        eng = _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_index, num_graphs, need_grad, knn_k,
+                            with_triplets, n_types, sizes)
+        if eng is not None:
+            return eng
     g = Graph()
     n = int(batch.numel())
     g.n = n
@@ -583,6 +733,8 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
 
 def spherical_basis(g, cutoff_l):
     """SphericalBasisLayer on the combined triplet/pair rows (layers/basic.py:107-116): returns [T+P, 42]."""
+    if getattr(g, '_sbf_cutoff', None) == float(cutoff_l) and g.__dict__.get('sbf') is not None:
+        return g.sbf                                  # built by the graph-construction engine in the same call
     dev = g.pos.device
     st = lib.stream_of(g.pos)
     e_l = g.loc.m

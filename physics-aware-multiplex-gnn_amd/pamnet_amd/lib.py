@@ -123,3 +123,23 @@ class TypeRowsJob(ctypes.Structure):
     """pamnet_type_rows_job (include/pamnet_hip.h)."""
     _fields_ = [('table', _P), ('idx', _P), ('n', ctypes.c_int64), ('n_types', ctypes.c_int64), ('out', _P), ('g', _P),
                 ('scratch', _P), ('dtable', _P)]
+
+
+class GraphDesc(ctypes.Structure):
+    """pamnet_graph_desc (include/pamnet_hip.h): one batch handed to the graph-construction engine."""
+    _fields_ = [('n', ctypes.c_int64), ('n_graphs', ctypes.c_int64), ('n_bonds', ctypes.c_int64),
+                ('eg', ctypes.c_int64), ('el', ctypes.c_int64), ('tp', ctypes.c_int64),
+                ('batch', _P), ('types', _P), ('types_stride', ctypes.c_int64), ('n_types', ctypes.c_int64),
+                ('pos', _P), ('rows', _P), ('rows_width', ctypes.c_int64), ('edge_src', _P), ('edge_dst', _P),
+                ('schema', ctypes.c_int32), ('batch_kind', ctypes.c_int32), ('types_kind', ctypes.c_int32),
+                ('edge_kind', ctypes.c_int32), ('with_triplets', ctypes.c_int32), ('need_grad', ctypes.c_int32),
+                ('aggregate_at_query', ctypes.c_int32), ('knn_k', ctypes.c_int32),
+                ('cutoff_l', ctypes.c_float), ('cutoff_g', ctypes.c_float)]
+
+
+# field indices of the engine's arena layout (enum PAMNET_GF_* in include/pamnet_hip.h, same order)
+GF = {name: i for i, name in enumerate(
+    ['NODE_GRAPH', 'GPTR', 'FLAG', 'LOOPS', 'TYPES', 'POS', 'SIGN', 'G_PTR', 'G_ROW', 'G_COL', 'G_DIST', 'GT_PTR', 'GT_PERM',
+     'L_PTR', 'L_ROW', 'L_COL', 'L_DIST', 'LT_PTR', 'LT_PERM', 'T_PTR', 'T_ROW', 'T_COL', 'T_ANGLE', 'T_KIND', 'TT_PTR',
+     'TT_PERM', 'CUTS'])}
+GRAPH_FIELDS = len(GF)

@@ -1,0 +1,198 @@
+"""Graph-construction engine (csrc/graph_engine.hip, pamnet_graph_build_i32): the whole parameter-independent front of
+PAMNet.forward -- index ingestion, radius / kNN graphs, cutoff masks, CSRs, triplets / pairs, angles, transposed index
+lists, spherical basis (reference models.py:62-98, 104-177, layers/basic.py:107-116) -- as ONE C call for batches whose
+sizes the host knows.  Integer work: every array bit-identical to the step-by-step path (which tests/test_hip_kernels.py
+pins against the oracle and the reference's star-graph golden); geometry: bit-identical floats; the model on top: bitwise
+the same outputs and gradients; wrong sizes: caught by the deferred device-side check, memory-safe."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'needs an MI355X'
+    from pamnet_amd import lib
+    lib.load()
+    return torch.device('cuda:0')
+
+
+def _case(kind, dev):
+    from pamnet_amd import synth
+    if kind == 'qm9':
+        b = synth.qm9_batch(41, 0, 24)
+        return b.to(dev), dict(dataset='QM9', cutoff_l=5.0, cutoff_g=5.0, flow='source_to_target', n_types=5)
+    if kind == 'qm9_ragged':
+        b = synth.collate([synth.qm9_molecule(3, 0),
+                           dict(x=np.array([1], np.float32), pos=np.zeros((1, 3), np.float32),
+                                edge_index=np.zeros((2, 0), np.int64), y=np.float32(0.1)),
+                           synth.qm9_molecule(3, 1),
+                           dict(x=np.array([0, 2], np.float32), pos=np.array([[0, 0, 0], [1.1, 0, 0]], np.float32),
+                                edge_index=np.array([[0, 1], [1, 0]], np.int64), y=np.float32(0.2))])
+        return b.to(dev), dict(dataset='QM9', cutoff_l=5.0, cutoff_g=5.0, flow='source_to_target', n_types=5)
+    if kind == 'pdbbind':
+        b = synth.pdbbind_batch(9, 0, 3, n_pocket=90, n_ligand=16)
+        return b.to(dev), dict(dataset='PDBbind', cutoff_l=2.0, cutoff_g=6.0, flow='source_to_target', n_types=None)
+    flow = 'target_to_source' if kind == 'rna_t2s' else 'source_to_target'
+    b = synth.collate([synth.rna_chain(5, i, n_nodes=180 + 70 * i) for i in range(3)])
+    return b.to(dev), dict(dataset='rna_x', cutoff_l=2.6, cutoff_g=20.0, flow=flow, n_types=3)
+
+
+def _build(b, kw, need_grad, with_triplets, sizes=None):
+    from pamnet_amd import graph as G
+    return G.build_graph(kw['dataset'], kw['cutoff_l'], kw['cutoff_g'], kw['flow'], b.x, b.batch, getattr(b, 'pos', None),
+                         getattr(b, 'edge_index', None), num_graphs=b.num_graphs, need_grad=need_grad,
+                         with_triplets=with_triplets, n_types=kw['n_types'], sizes=sizes)
+
+
+FIELDS = [('n', None), ('n_graphs', None), ('node_graph', None), ('gptr', None), ('dist_g', None), ('dist_l', None),
+          ('tp_angle', None), ('tp_kind', None), ('glob', ('ptr', 'row_of', 'col')), ('loc', ('ptr', 'row_of', 'col')),
+          ('tp', ('ptr', 'row_of', 'col')), ('glob_T', ('ptr', 'perm')), ('loc_T', ('ptr', 'perm')), ('tp_T', ('ptr', 'perm'))]
+
+
+@pytest.mark.parametrize('kind', ['qm9', 'qm9_ragged', 'pdbbind', 'rna_t2s', 'rna_s2t'])
+@pytest.mark.parametrize('need_grad', [True, False])
+@pytest.mark.parametrize('with_triplets', [True, False])
+def test_engine_graph_equals_step_by_step_graph(dev, kind, need_grad, with_triplets):
+    from pamnet_amd import graph as G
+    if not with_triplets and not kind.startswith('qm9'):
+        pytest.skip('PAMNet_s is QM9 only (models.py:286)')
+    b, kw = _case(kind, dev)
+    ref = _build(b, kw, need_grad, with_triplets)                       # sizes read back from the device
+    ref_sbf = G.spherical_basis(ref, kw['cutoff_l'])
+    sizes = (ref.glob.m, ref.loc.m, ref.tp.m)
+    saved = G.ENGINE
+    try:
+        G.ENGINE = False
+        old = _build(b, kw, need_grad, with_triplets, sizes)            # zero-sync, step by step (Python orchestration)
+        G.ENGINE = True
+        eng = _build(b, kw, need_grad, with_triplets, sizes)            # zero-sync, one engine call
+    finally:
+        G.ENGINE = saved
+    assert isinstance(eng, G.EngineGraph) and not isinstance(old, G.EngineGraph)
+    torch.cuda.synchronize()
+    G.raise_for_flag(G.read_flags([eng.check]))
+    for other in (ref, old):
+        for name, sub in FIELDS:
+            a, c = getattr(eng, name), getattr(other, name)
+            if sub is None:
+                ok = torch.equal(a, c) if isinstance(a, torch.Tensor) else a == c
+                assert ok, (kind, name)
+                continue
+            if name.endswith('_T') and not need_grad:
+                assert a.ptr is None and c.ptr is None
+                continue
+            for f in sub:
+                assert torch.equal(getattr(a, f), getattr(c, f)), (kind, name, f)
+            if hasattr(a, 'm') and hasattr(c, 'm'):
+                assert a.m == c.m and a.rows == c.rows
+        assert eng.n_trip == other.n_trip and eng.n_pair == other.n_pair
+        assert torch.equal(eng.pos, other.pos)
+        if kw['dataset'] == 'PDBbind':
+            assert torch.equal(eng.sign, other.sign)
+        if kw['n_types'] is not None:
+            assert torch.equal(eng.types, other.types)
+    assert torch.equal(G.spherical_basis(eng, kw['cutoff_l']), ref_sbf)
+
+
+@pytest.mark.parametrize('kind', ['qm9', 'pdbbind', 'rna_t2s'])
+def test_model_on_engine_graph_is_bitwise_the_model_on_the_step_by_step_graph(dev, kind):
+    """Forward outputs and every parameter gradient: the engine-built graph against the step-by-step one."""
+    import models
+    from pamnet_amd import graph as G
+    b, kw = _case(kind, dev)
+    torch.manual_seed(5)
+    dim, L = (16, 1) if kind.startswith('rna') else (128, 2)
+    model = models.PAMNet(models.Config(dataset=kw['dataset'], dim=dim, n_layer=L, cutoff_l=kw['cutoff_l'],
+                                        cutoff_g=kw['cutoff_g'], flow=kw['flow'])).to(dev)
+    ref = _build(b, kw, True, True)
+    b.sizes = (ref.glob.m, ref.loc.m, ref.tp.m)
+    res = []
+    saved = G.ENGINE
+    try:
+        for on in (False, True):
+            G.ENGINE = on
+            model.zero_grad()
+            out = model(b)
+            assert isinstance(model._graph_cache, G.EngineGraph) == on
+            (out * torch.arange(1, out.numel() + 1, device=dev)).sum().backward()
+            model.verify()
+            res.append((out.detach().clone(), [p.grad.clone() for p in model.parameters() if p.grad is not None]))
+    finally:
+        G.ENGINE = saved
+    assert torch.equal(res[0][0], res[1][0])
+    assert len(res[0][1]) == len(res[1][1]) and all(torch.equal(a, c) for a, c in zip(res[0][1], res[1][1]))
+
+
+@pytest.mark.parametrize('kind', ['qm9', 'pdbbind', 'rna_t2s'])
+def test_engine_catches_wrong_sizes_without_a_memory_fault(dev, kind):
+    """Each of the sizes too small / too large: the call runs to completion inside its arena and the flag word names the
+    mismatch; valid sizes leave it clean.  (QM9: the bond count is an input size, a mismatch there falls back to the
+    step-by-step path, which flags it the same way.)"""
+    from pamnet_amd import graph as G
+    b, kw = _case(kind, dev)
+    ref = _build(b, kw, True, True)
+    good = [ref.glob.m, ref.loc.m, ref.tp.m]
+    for pos_ in range(3):
+        for delta in (-7, +9):
+            sz = list(good)
+            sz[pos_] += delta
+            g = _build(b, kw, True, True, tuple(sz))
+            if kind == 'qm9' and pos_ == 1:
+                assert not isinstance(g, G.EngineGraph)
+            else:
+                assert isinstance(g, G.EngineGraph)
+            torch.cuda.synchronize()
+            bits = G.read_flags([g.check])
+            assert bits & (2 << pos_), (kind, pos_, delta, bits)
+            with pytest.raises(G.GraphCheckError):
+                G.raise_for_flag(bits)
+    g = _build(b, kw, True, True, tuple(good))
+    torch.cuda.synchronize()
+    assert G.read_flags([g.check]) == 0
+    # invalid index inputs surface through the same word (bit 1), as the reference's IndexError
+    if kind != 'pdbbind':
+        import copy
+        bad = copy.copy(b)
+        bad.x = b.x.clone()
+        if kind == 'qm9':
+            bad.x[3] = 9.0
+        else:
+            bad.x[3, -1] = 5.0
+        g = _build(bad, kw, True, True, tuple(good))
+        torch.cuda.synchronize()
+        with pytest.raises(IndexError):
+            G.raise_for_flag(G.read_flags([g.check]))
+
+
+def test_engine_forward_is_a_handful_of_host_calls(dev):
+    """N2: with the sizes known, graph construction + basis is ONE library call (plus its plan), the layer stack ONE, and
+    no tensor op of the calling convention remains in between: count the C-ABI calls of a whole RNA forward."""
+    import models
+    from pamnet_amd import lib, store as S, synth
+    graphs = [synth.rna_chain(5, i, n_nodes=200 + 50 * i) for i in range(4)]
+    torch.manual_seed(1)
+    model = models.PAMNet(models.Config(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0,
+                                        flow='target_to_source')).to(dev)
+    st = S.MoleculeStore(graphs, dev).prepare_for(model)
+    with torch.no_grad():
+        model(st.collate([0, 1, 2, 3]))
+        calls = []
+        orig = lib.call
+        lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+        try:
+            b = st.collate([0, 1, 2, 3])
+            torch.cuda.synchronize()
+            torch.cuda.set_sync_debug_mode('error')
+            try:
+                model(b)
+            finally:
+                torch.cuda.set_sync_debug_mode('default')
+        finally:
+            lib.call = orig
+    model.verify()
+    graph_calls = [c for c in calls if c.startswith('pamnet_graph_')]
+    assert graph_calls == ['pamnet_graph_plan', 'pamnet_graph_build_i32'], calls
+    assert len(calls) <= 12, calls                    # collate, plan, build, 3 embeddings, workspace, stack, fuse+pool, ...
