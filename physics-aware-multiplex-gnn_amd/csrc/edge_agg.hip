@@ -160,9 +160,11 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
     APROBE(0);
     const BiasSet<1> zero_bias = lane_biases<1>(nullptr, wc);
     const BiasSet<1> bv = lane_biases<1>(a.bm, wc);
-    WSet<1> f1, f2;
-    load_wset<false>(f1, a.We, a.ld_we, wc);
-    load_wset<false>(f2, a.Wea, a.ld_wea, wc);
+    // both weight slices as resident bf16x3 pieces (edge_core.h): the two GEMMs run on the bf16 matrix pipe at fp32
+    // accuracy and share one split of every A fragment
+    WFragB1 f1, f2;
+    load_wfragb1<false>(f1, a.We, a.ld_we, wc);
+    load_wfragb1<false>(f2, a.Wea, a.ld_wea, wc);
     APROBE(20);
     const int wg = xcd_order(blockIdx.x, gridDim.x);
     const int nb = a.cuts ? a.cuts[wg] : seg_cut(ptr, row_of, a.n, a.m, wg, gridDim.x);
@@ -243,8 +245,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
                 auto gemm = [&]() {
                     ag.zero();
                     az.zero();
-                    mma_set<SC, 1>(S0 + goff * LDT, f2, ag, smt);
-                    mma_set<SC, 1>(S0 + goff * LDT, f1, az, smt);
+                    mma_b16<SC, false, (PRE ? 1 : 3)>(S0 + goff * LDT, f1, az.a[0], f2, ag.a[0], smt);
                 };
                 auto epi = [&]() {
                     float4 zz[SC], gate[SC];
@@ -330,14 +331,15 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
     APROBE_WG(0);
     APROBE(0);
     const BiasSet<1> zero_bias = lane_biases<1>(nullptr, wc);
-    WSet<1> f1, f2;
-    load_wset<true>(f1, a.We, a.ld_we, wc);
-    load_wset<true>(f2, a.Wea, a.ld_wea, wc);
+    WFragB1 f1, f2;                               // bf16x3 pieces of the two transposed weight slices (edge_core.h)
+    load_wfragb1<true>(f1, a.We, a.ld_we, wc);
+    load_wfragb1<true>(f2, a.Wea, a.ld_wea, wc);
     const int wg = xcd_order(blockIdx.x, gridDim.x);
     const int nb = a.cuts ? a.cuts[wg] : seg_cut(ptr, row_of, a.n, a.m, wg, gridDim.x);
     const int ne = a.cuts ? a.cuts[wg + 1] : seg_cut(ptr, row_of, a.n, a.m, wg + 1, gridDim.x);
     const int64_t re = ptr[ne];
     constexpr int RPP = 16, NI = MTX;
+    constexpr int BG = 3;                         // row tiles per MFMA group: three independent accumulator chains
     const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;
     int c0 = nb, par = 0;
     int64_t r0 = ptr[nb];
@@ -382,8 +384,8 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
         if (rows > 0) {
             AccSet<MTX, 1> acc;
             acc.zero();
-            mma_set<MTX, 1>(S0, f1, acc, mt);
-            mma_set<MTX, 1>(S1, f2, acc, mt);
+            mma_b16<MTX, true, BG>(S0, f1, acc.a[0], f1, acc.a[0], mt);
+            mma_b16<MTX, true, BG>(S1, f2, acc.a[0], f2, acc.a[0], mt);
             APROBE(5);
             constexpr bool PREACC = MTX <= 5;                  // (the 8 / 9-tile instantiations have no registers to spare)
             float4 dacc[PREACC ? NI : 1];                      // accumulate operand of the final sweep

@@ -101,6 +101,107 @@ __device__ __forceinline__ void acc_store(const Acc<MTX>& acc, float* __restrict
         }
     }
 }
+// ---- the same tile GEMMs on the bf16 matrix pipe at fp32 accuracy ("bf16x6", gemm_core.h) ------------------------------
+// The f32-input MFMA above issues at the fp32 VECTOR rate (32 cycles per 16x16x4 on a SIMD); v_mfma_f32_16x16x32_bf16 does
+// 8x the k in ~17.  A wave's 128 x 16 weight slice is split ONCE into its three exact bf16 pieces when it is loaded
+// (48 registers instead of 32, resident for the whole launch); the activation tile stays fp32 in LDS -- no piece planes, no
+// extra LDS -- and every wave splits the A fragments it reads (8 consecutive k of a row per lane: two ds_read_b128, four
+// split3 = 36 VALU per 16 x 32 fragment).  That split is redundant across the 8 waves, so it pays where the fragment feeds
+// more than one GEMM or where the MFMA share dominates: per 16 rows x 32 k the fused global-edge forward (two GEMMs on the
+// same rows) issues 12 bf16 MFMAs + 36 VALU (~276 cycles) against 16 fp32 MFMAs (512 cycles).
+// Fragment maps of v_mfma_f32_16x16x32_bf16: lane l supplies A[i = l & 15][k = 8 (l >> 4) + 0..7] and
+// B[k = 8 (l >> 4) + 0..7][j = l & 15]; the accumulator layout is that of the 16x16x4 form (rows 4 (l >> 4) + r, column
+// l & 15), so epilogues and stores are shared.
+struct WFragB1 {
+    uint32_t p[DIM / 32][3][4];               // [k-step of 32][piece][4 dwords = 8 bf16]
+};
+//   TRANS = false: W is [out][in] (row stride ldw): B[k][j] = W[wc + j][k]   (forward:  Y = X W^T)
+//   TRANS = true : B[k][j] = W[k][wc + j]                                     (backward: dX = dZ W)
+template <bool TRANS>
+__device__ __forceinline__ void load_wfragb1(WFragB1& f, const float* __restrict__ W, int ldw, int wc) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < DIM / 32; ++q) {
+        float v[8];
+        if (!TRANS) {
+            const float* wp = W + (size_t)(wc + j) * ldw + 32 * q + 8 * kg;
+            const float4 a = *reinterpret_cast<const float4*>(wp), b = *reinterpret_cast<const float4*>(wp + 4);
+            v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+        } else {
+            const float* wp = W + (size_t)(32 * q + 8 * kg) * ldw + wc + j;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = wp[(size_t)t * ldw];
+        }
+        const Frag3 fr = split_frag(v);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f.p[q][pc][t] = fr.p[pc][t];
+    }
+}
+// A fragment (rows 16 m + (l & 15), k = 32 q + 8 (l >> 4) + 0..7) of an fp32 LDS tile, split into its pieces
+__device__ __forceinline__ Frag3 lds_frag3(const float* __restrict__ As, int m, int q) {
+    const int lane = threadIdx.x & 63;
+    const float* ap = As + (m * 16 + (lane & 15)) * LDT + 32 * q + 8 * (lane >> 4);
+    const float4 a = *reinterpret_cast<const float4*>(ap), b = *reinterpret_cast<const float4*>(ap + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return split_frag(v);
+}
+// the six piece products with i + j <= 2 of one fragment pair, small ones first; G independent accumulators interleaved
+template <int G, int MTX>
+__device__ __forceinline__ void mfma6(const Frag3 (&a)[G], const uint32_t (&b)[3][4], Acc<MTX>& acc, int m0) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc.v[m0 + g] = mfma_bf16(a[g].p[2], b[0], acc.v[m0 + g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc.v[m0 + g] = mfma_bf16(a[g].p[1], b[1], acc.v[m0 + g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc.v[m0 + g] = mfma_bf16(a[g].p[0], b[2], acc.v[m0 + g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc.v[m0 + g] = mfma_bf16(a[g].p[1], b[0], acc.v[m0 + g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc.v[m0 + g] = mfma_bf16(a[g].p[0], b[1], acc.v[m0 + g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc.v[m0 + g] = mfma_bf16(a[g].p[0], b[0], acc.v[m0 + g]);
+}
+// acc1[m0 .. m0 + G) += As * f1,  acc2[...] += As * f2 (f2 nullable at compile time: ONE = true): G <= 3 row tiles at a time
+template <int G, int MTX, bool ONE>
+__device__ __forceinline__ void mma_b16_group(const float* __restrict__ As, int m0, const WFragB1& f1, Acc<MTX>& acc1,
+                                              const WFragB1& f2, Acc<MTX>& acc2) {
+#pragma unroll
+    for (int q = 0; q < DIM / 32; ++q) {
+        Frag3 a[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) a[g] = lds_frag3(As, m0 + g, q);
+        mfma6<G, MTX>(a, f1.p[q], acc1, m0);
+        if constexpr (!ONE) mfma6<G, MTX>(a, f2.p[q], acc2, m0);
+    }
+}
+// mt (1..MTX, workgroup-uniform) live 16-row tiles, in groups of GMAX <= 3 (the A pieces of a group are 12 GMAX registers;
+// a group of one still has two independent accumulator chains when it feeds two GEMMs)
+template <int MTX, bool ONE, int GMAX = 3>
+__device__ __forceinline__ void mma_b16(const float* __restrict__ As, const WFragB1& f1, Acc<MTX>& acc1, const WFragB1& f2,
+                                        Acc<MTX>& acc2, int mt) {
+#pragma unroll
+    for (int m0 = 0; m0 < MTX; m0 += GMAX) {
+        const int left = mt - m0;
+        if (left <= 0) break;
+        if constexpr (GMAX >= 3) {
+            if (m0 + 3 <= MTX && left >= 3) {
+                mma_b16_group<3, MTX, ONE>(As, m0, f1, acc1, f2, acc2);
+                continue;
+            }
+        }
+        if constexpr (GMAX >= 2) {
+            if (m0 + 2 <= MTX && left >= 2) {
+                mma_b16_group<2, MTX, ONE>(As, m0, f1, acc1, f2, acc2);
+                continue;
+            }
+        }
+        mma_b16_group<1, MTX, ONE>(As, m0, f1, acc1, f2, acc2);
+    }
+}
+
 // A workgroup is NW waves (8 or 4); wave w owns NS = 8 / NW consecutive 16-column slices.  Two 4-wave workgroups with
 // half the rows each share a CU: same waves per SIMD as one 8-wave workgroup, but their barriers are independent, so one
 // workgroup's load / epilogue sweeps overlap the other's GEMMs (measured -16 % on the triplet/pair MLP).

@@ -107,7 +107,9 @@ def test_global_edge_agg_fwd_bwd(dev, case):
                  lib.ptr(Pi), lib.ptr(Pj), lib.ptr(row_of), lib.ptr(col), lib.ptr(z3), lib.ptr(ea3), lib.ptr(msg3), st)
         out3 = torch.empty_like(out)
         segment_sum_raw(out3, init, msg3, None, None, None, None, ptr, n, D)
-        assert torch.equal(z, z3) and torch.equal(ea, ea3)
+        # (the fused kernel runs its GEMMs as bf16x6 on the bf16 matrix pipe, the unfused one as fp32 MFMAs: same values to
+        # fp32 rounding, not the same bits)
+        assert maxnorm_err(z.cpu(), z3.cpu()) < 1e-6 and maxnorm_err(ea.cpu(), ea3.cpu()) < 1e-6
         assert maxnorm_err(out.cpu(), out3.cpu()) < 2e-6
 
     # ---- backward (first call with the precomputed work split, the accumulate call without)
