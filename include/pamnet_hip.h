@@ -77,6 +77,9 @@ int pamnet_validate_inputs_i32(const int32_t* node_graph, int64_t n, int64_t n_g
  * scan's chunk sums).  Deterministic. */
 int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t rows, int32_t* ptr, int32_t* perm,
                              int32_t* cursor, int32_t* perm_tmp, int32_t* tmp, pamnet_stream_t stream);
+/* The same with `cursor` already zero-filled by the caller (no fill launch of its own). */
+int pamnet_csr_from_keys_z_i32(const int32_t* keys, int64_t m, int64_t rows, int32_t* ptr, int32_t* perm,
+                               int32_t* cursor, int32_t* perm_tmp, int32_t* tmp, pamnet_stream_t stream);
 
 /* row_of[q] = r for q in [ptr[r], ptr[r+1])  (repeat_interleave of row ids, models.py:76-77, 88-89).
  * `cap` = entries the output holds (the *_fill entry points take one too): nothing is written at or beyond it.  With sizes
@@ -140,7 +143,8 @@ int pamnet_triplet_fill_f32(const float* pos, const int32_t* lptr, const int32_t
  *   flag is NOT zeroed (pamnet_validate_inputs_i32 owns bit 1 of the same word).
  * collate: batch of n_graphs graphs sel[k] of a dataset kept resident as concatenated arrays (prefix sums src_nptr /
  *   src_eptr, bonds with graph-local endpoints): node features [n_out, x_width], positions (nullable), int32 batch
- *   vector, bonds with batch-level endpoints.  out_nptr / out_eptr: the batch's prefix sums (device, n_graphs + 1).
+ *   vector, bonds with batch-level endpoints, the graphs' targets.  out_nptr / out_eptr: the batch's prefix sums (device,
+ *   n_graphs + 1).
  * ------------------------------------------------------------------------------------------------------------------ */
 /* Transposed CSR of a SYMMETRIC graph stored by target with ascending columns (radius graphs): rev[e] = position of the
  * reverse edge of e; (ptr, rev) equals what pamnet_csr_from_keys_i32(col) returns as (ptr, perm).  flag (nullable):
@@ -180,6 +184,7 @@ int pamnet_collate_f32(int64_t n_graphs, const int32_t* sel, const int32_t* out_
                        const int32_t* src_nptr, const int32_t* src_eptr, const float* x, int64_t x_width,
                        const float* pos, const int32_t* esrc, const int32_t* edst, int64_t n_out, int64_t e_out,
                        float* out_x, float* out_pos, int32_t* out_batch, int32_t* out_esrc, int32_t* out_edst,
+                       const float* y /* [graphs of the dataset] targets, nullable */, float* out_y /* [n_graphs] */,
                        pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -453,7 +453,7 @@ __device__ __forceinline__ void knn_topk(const unsigned (&dv)[NC], const int (&j
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (dv[c] != 0xffffffffu) {
-            mn = dv[c] < mn ? dv[c] : mn;
+            mn = (dv[c] != 0u && dv[c] < mn) ? dv[c] : mn;       // smallest NON-ZERO distance (see below)
             mx = dv[c] > mx ? dv[c] : mx;
         }
     }
@@ -463,8 +463,10 @@ __device__ __forceinline__ void knn_topk(const unsigned (&dv)[NC], const int (&j
         mn = a < mn ? a : mn;
         mx = b > mx ? b : mx;
     }
-    // smallest T with #(d <= T) >= kk, searched inside the wave's [min, max] distance bits
-    unsigned lo = mn, hi = mx;
+    // smallest T with #(d <= T) >= kk, searched inside the wave's distance bits.  The query itself is a candidate at
+    // distance 0: a search interval that starts at bit pattern 0 spends its first ~6 probes crossing the exponent range
+    // below the nearest real neighbour, so it starts at the smallest non-zero distance unless the zeros alone reach kk.
+    unsigned lo = (mn != 0xffffffffu && wave_count(0u, true) < kk) ? mn : 0u, hi = mx;
     while (lo < hi) {
         const unsigned mid = lo + ((hi - lo) >> 1);
         if (wave_count(mid, true) >= kk) hi = mid; else lo = mid + 1;
@@ -524,6 +526,7 @@ __device__ __forceinline__ void knn_select(const float* __restrict__ pos, float 
     const int kk = (end - beg < K) ? (end - beg) : K;       // entries that exist
     unsigned dc[KNN_CACHE];
     unsigned mn = 0xffffffffu, mx = 0u;
+    int zeros = 0;
 #pragma unroll
     for (int c = 0; c < KNN_CACHE; ++c) {
         dc[c] = 0xffffffffu;
@@ -531,7 +534,8 @@ __device__ __forceinline__ void knn_select(const float* __restrict__ pos, float 
             const int j = beg + c * 64 + lane;
             if (j < end) {
                 dc[c] = __float_as_uint(sqdist(pos, xi, yi, zi, j));
-                mn = dc[c] < mn ? dc[c] : mn;
+                zeros += dc[c] == 0u ? 1 : 0;
+                mn = (dc[c] != 0u && dc[c] < mn) ? dc[c] : mn;       // smallest NON-ZERO distance (knn_topk: why)
                 mx = dc[c] > mx ? dc[c] : mx;
             }
         }
@@ -541,8 +545,9 @@ __device__ __forceinline__ void knn_select(const float* __restrict__ pos, float 
         const unsigned a = (unsigned)__shfl_xor((int)mn, o, 64), b = (unsigned)__shfl_xor((int)mx, o, 64);
         mn = a < mn ? a : mn;
         mx = b > mx ? b : mx;
+        zeros += __shfl_xor(zeros, o, 64);
     }
-    unsigned lo = mn, hi = mx;
+    unsigned lo = (mn != 0xffffffffu && zeros < kk) ? mn : 0u, hi = mx;
     int cnt_hi = end - beg;                                 // #(d <= hi), always >= kk
     while (lo < hi && cnt_hi > KNN_SURV) {
         const unsigned mid = lo + ((hi - lo) >> 1);
@@ -769,8 +774,8 @@ extern "C" int pamnet_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_
     return PAMNET_OK;
 }
 
-extern "C" int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t rows, int32_t* ptr, int32_t* perm,
-                                        int32_t* cursor, int32_t* perm_tmp, int32_t* tmp, pamnet_stream_t stream) {
+static int csr_from_keys(const int32_t* keys, int64_t m, int64_t rows, int32_t* ptr, int32_t* perm, int32_t* cursor,
+                         int32_t* perm_tmp, int32_t* tmp, bool cursor_is_zero, pamnet_stream_t stream) {
     if (m < 0 || rows <= 0) return PAMNET_EINVAL;
     if (!ptr || !cursor || !tmp || (m > 0 && (!keys || !perm || !perm_tmp))) return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
@@ -780,8 +785,10 @@ extern "C" int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t 
         return PAMNET_OK;
     }
     int32_t* unsorted = cursor + rows;                       // the spare int behind the counters: one memset for both
-    hipError_t e = hipMemsetAsync(cursor, 0, sizeof(int32_t) * (rows + 1), st);
-    if (e != hipSuccess) return (int)e;
+    if (!cursor_is_zero) {
+        hipError_t e = hipMemsetAsync(cursor, 0, sizeof(int32_t) * (rows + 1), st);
+        if (e != hipSuccess) return (int)e;
+    }
     if (m > 0) {
         hipLaunchKernelGGL(hist_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, rows, cursor, unsorted);
         PAMNET_LAUNCH_CHECK();
@@ -795,6 +802,18 @@ extern "C" int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t 
     hipLaunchKernelGGL(sort_rows_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, ptr, perm_tmp, perm, m, rows, unsorted);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
+}
+
+extern "C" int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t rows, int32_t* ptr, int32_t* perm,
+                                        int32_t* cursor, int32_t* perm_tmp, int32_t* tmp, pamnet_stream_t stream) {
+    return csr_from_keys(keys, m, rows, ptr, perm, cursor, perm_tmp, tmp, false, stream);
+}
+
+// The same with `cursor` (rows + 1 ints) already zero-filled by the caller -- e.g. as part of one larger fill: no memset
+// launch of its own (the graph-construction engine zero-fills every counter array of a batch together).
+extern "C" int pamnet_csr_from_keys_z_i32(const int32_t* keys, int64_t m, int64_t rows, int32_t* ptr, int32_t* perm,
+                                          int32_t* cursor, int32_t* perm_tmp, int32_t* tmp, pamnet_stream_t stream) {
+    return csr_from_keys(keys, m, rows, ptr, perm, cursor, perm_tmp, tmp, true, stream);
 }
 
 extern "C" int pamnet_expand_rows_i32(const int32_t* ptr, int64_t rows, int32_t* row_of, int64_t cap,
@@ -1013,6 +1032,8 @@ struct Collate {
     const int32_t *src_nptr, *src_eptr;           // dataset prefix sums [M+1]
     const float *x, *pos;                         // dataset node features [Ntot, xw], positions [Ntot, 3] (nullable)
     const int32_t *esrc, *edst;                   // dataset bonds, graph-local endpoints [Etot] (nullable)
+    const float* y;                               // dataset targets [M] (nullable)
+    float* oy;                                    // [B]
     float *ox, *opos;
     int32_t *obatch, *oesrc, *oedst;
     int64_t B, n_out, e_out, xw;
@@ -1028,6 +1049,7 @@ __device__ __forceinline__ int graph_of(const int32_t* __restrict__ ptr, int64_t
 }
 __global__ __launch_bounds__(256) void collate_kernel(Collate c) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c.y && t < c.B) c.oy[t] = c.y[c.sel[t]];
     if (t < c.n_out) {
         const int k = graph_of(c.out_nptr, c.B, t);
         const int64_t s = c.src_nptr[c.sel[k]] + (t - c.out_nptr[k]);
@@ -1069,14 +1091,15 @@ extern "C" int pamnet_collate_f32(int64_t n_graphs, const int32_t* sel, const in
                                   const int32_t* src_nptr, const int32_t* src_eptr, const float* x, int64_t x_width,
                                   const float* pos, const int32_t* esrc, const int32_t* edst, int64_t n_out,
                                   int64_t e_out, float* out_x, float* out_pos, int32_t* out_batch, int32_t* out_esrc,
-                                  int32_t* out_edst, pamnet_stream_t stream) {
+                                  int32_t* out_edst, const float* y, float* out_y, pamnet_stream_t stream) {
     if (n_graphs < 0 || n_out < 0 || e_out < 0 || x_width < 1) return PAMNET_EINVAL;
     if (n_out == 0 && e_out == 0) return PAMNET_OK;
-    if (!sel || !out_nptr || !src_nptr || !x || !out_x || !out_batch || (pos && !out_pos)) return PAMNET_ENULL;
+    if (!sel || !out_nptr || !src_nptr || !x || !out_x || !out_batch || (pos && !out_pos) || (y && !out_y)) return PAMNET_ENULL;
     if (e_out > 0 && (!out_eptr || !src_eptr || !esrc || !edst || !out_esrc || !out_edst)) return PAMNET_ENULL;
-    Collate c{sel, out_nptr, out_eptr, src_nptr, src_eptr, x, pos, esrc, edst, out_x, out_pos, out_batch, out_esrc, out_edst,
-              n_graphs, n_out, e_out, x_width};
-    const int64_t total = n_out > e_out ? n_out : e_out;
+    Collate c{sel, out_nptr, out_eptr, src_nptr, src_eptr, x, pos, esrc, edst, y, out_y, out_x, out_pos, out_batch, out_esrc,
+              out_edst, n_graphs, n_out, e_out, x_width};
+    int64_t total = n_out > e_out ? n_out : e_out;
+    total = total > n_graphs ? total : n_graphs;
     hipLaunchKernelGGL(collate_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), c);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;

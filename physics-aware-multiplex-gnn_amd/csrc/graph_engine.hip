@@ -86,12 +86,13 @@ int scan(Run& r, int64_t counts, int64_t n, int64_t& out) {
     return PAMNET_OK;
 }
 
-// stable counting sort of keys [m] over `rows` -> ptr [rows + 1], perm [m]  (ptr / perm may be pre-assigned: pass >= 0)
-int csr(Run& r, int64_t keys, int64_t m, int64_t rows, int64_t& ptr, int64_t& perm) {
+// stable counting sort of keys [m] over `rows` -> ptr [rows + 1], perm [m]  (ptr / perm may be pre-assigned: pass >= 0).
+// `cursor`: rows + 2 counters inside the batch's zero-filled block (no fill launch per sort).
+int csr(Run& r, int64_t keys, int64_t m, int64_t rows, int64_t cursor, int64_t& ptr, int64_t& perm) {
     if (ptr < 0) ptr = r.take(rows + 1);
     if (perm < 0) perm = r.take(m);
-    const int64_t cursor = r.take(rows + 2), perm_tmp = r.take(m), tmp = r.take((rows + 4095) / 4096 + 1);
-    GO(pamnet_csr_from_keys_i32(r.I(keys), m, rows, r.I(ptr), r.I(perm), r.I(cursor), r.I(perm_tmp), r.I(tmp), r.stream));
+    const int64_t perm_tmp = r.take(m), tmp = r.take((rows + 4095) / 4096 + 1);
+    GO(pamnet_csr_from_keys_z_i32(r.I(keys), m, rows, r.I(ptr), r.I(perm), r.I(cursor), r.I(perm_tmp), r.I(tmp), r.stream));
     return PAMNET_OK;
 }
 
@@ -150,6 +151,9 @@ int run(Run& r) {
         kn_l = r.take(el), kd_l = r.take(el), kq_l = r.take(el);      // local cut of the kNN table by query + its query ids
         if (!d.aggregate_at_query) gn2 = r.take(eg), gd2 = r.take(eg), kq_g = r.take(eg);
     }
+    // counters of the counting sorts (rows + 2 each): bond CSR / local transposition, transposed global, transposed local,
+    // transposed triplet / pair rows
+    const int64_t cur_a = r.take(n + 2), cur_b = r.take(n + 2), cur_c = r.take(n + 2), cur_t = r.take(el + 2);
     const int64_t z1 = r.off;
     if (!r.dry) {
         const hipError_t e = hipMemsetAsync(r.I(z0), 0, sizeof(int32_t) * (size_t)(z1 - z0), as_stream(r.stream));
@@ -180,7 +184,7 @@ int run(Run& r) {
         // (the ingest launch noted them; a store strips them at ingestion)
         l_row = r.take(el), l_col = r.take(el), l_dist = r.take(el);
         int64_t perm = -1;
-        int rc = csr(r, dst0, d.n_bonds, n, l_ptr, perm);
+        int rc = csr(r, dst0, d.n_bonds, n, cur_a, l_ptr, perm);
         if (rc) return rc;
         GO(pamnet_gather2_i32(r.I(perm), r.I(src0), r.I(dst0), d.n_bonds, r.I(l_col), r.I(l_row), pos, r.F(l_dist), r.stream));
         if ((rc = triplet_ptr(l_ptr, l_col, l_row))) return rc;
@@ -240,7 +244,7 @@ int run(Run& r) {
         } else {                                      // aggregate at the neighbour: re-store the list by neighbour
             GO(pamnet_expand_rows_i32(r.I(pa), n, r.I(kq_g), eg, r.stream));
             int64_t perm = -1;
-            if ((rc = csr(r, gq_n, eg, n, g_ptr, perm))) return rc;
+            if ((rc = csr(r, gq_n, eg, n, cur_b, g_ptr, perm))) return rc;
             int64_t inv = -1;
             if (grad) inv = r.take(eg);
             GO(pamnet_transpose_gather_i32(r.I(perm), r.I(kq_g), r.F(gq_d), eg, r.I(g_col), r.F(g_dist),
@@ -251,7 +255,7 @@ int run(Run& r) {
         // the local layer always aggregates at the neighbour (models.py:153-156: j = query, i = neighbour)
         GO(pamnet_expand_rows_i32(r.I(pb), n, r.I(kq_l), el, r.stream));
         int64_t perm = -1;
-        if ((rc = csr(r, kn_l, el, n, l_ptr, perm))) return rc;
+        if ((rc = csr(r, kn_l, el, n, cur_a, l_ptr, perm))) return rc;
         int64_t inv = -1;
         if (grad) inv = r.take(el);
         GO(pamnet_transpose_gather_i32(r.I(perm), r.I(kq_l), r.F(kd_l), el, r.I(l_col), r.F(l_dist), grad ? r.I(inv) : nullptr,
@@ -276,7 +280,7 @@ int run(Run& r) {
             gT_perm = r.take(eg);
             GO(pamnet_reverse_edges_i32(r.I(g_ptr), r.I(g_row), r.I(g_col), eg, r.I(gT_perm), nullptr, r.stream));
         } else if (d.aggregate_at_query) {            // kNN list stored by query: counting sort of the neighbour column
-            int rc = csr(r, g_col, eg, n, gT_ptr, gT_perm);
+            int rc = csr(r, g_col, eg, n, cur_b, gT_ptr, gT_perm);
             if (rc) return rc;
         }
         if (d.schema == PAMNET_SCHEMA_PDBBIND) {
@@ -284,10 +288,10 @@ int run(Run& r) {
             lT_perm = r.take(el);
             GO(pamnet_reverse_edges_i32(r.I(l_ptr), r.I(l_row), r.I(l_col), el, r.I(lT_perm), nullptr, r.stream));
         } else if (d.schema == PAMNET_SCHEMA_QM9) {   // user-supplied bonds: counting sort of the source column
-            int rc = csr(r, l_col, el, n, lT_ptr, lT_perm);
+            int rc = csr(r, l_col, el, n, cur_c, lT_ptr, lT_perm);
             if (rc) return rc;
         }
-        int rc = csr(r, t_col, tp, el, tT_ptr, tT_perm);
+        int rc = csr(r, t_col, tp, el, cur_t, tT_ptr, tT_perm);
         if (rc) return rc;
     }
 

@@ -96,6 +96,28 @@ class MoleculeStore(object):
     def __len__(self):
         return len(self.n_nodes)
 
+    _RING = 8
+
+    def _staging(self, ints):
+        """Pinned staging for a batch's selection + prefix sums: a ring of buffers allocated once (a pinned allocation per
+        batch cost ~30 us of host time; the ring is deeper than the trainer's two steps in flight, and a slot is only
+        reused after the copy queued from it has completed)."""
+        ring = self.__dict__.setdefault('_ring', [])
+        k = self.__dict__.get('_ring_at', 0)
+        self.__dict__['_ring_at'] = (k + 1) % self._RING
+        if len(ring) <= k:
+            ring.append([None, None, None])
+        slot = ring[k]
+        if slot[0] is None or slot[0].numel() < ints:
+            slot[0] = torch.empty(max(int(ints), 4096), dtype=I32, pin_memory=True)
+            slot[1] = slot[0].numpy()
+            slot[2] = None
+        if slot[2] is not None:
+            slot[2].synchronize()                              # the upload that last read this slot (long done)
+        slot[2] = torch.cuda.Event()
+        self._last_slot = slot
+        return slot[0][:ints], slot[1][:ints]
+
     # -------------------------------------------------------------------------------------------------- per-molecule sizes
     def counts_for(self, model, chunk=None):
         """Per-graph (global edges, local edges, triplet + pair rows) for `model` (its dataset schema, cutoffs, flow and
@@ -141,8 +163,7 @@ class MoleculeStore(object):
         n_out, e_out = int(nn.sum()), int(ne.sum())
         # pinned staging: the upload is a true asynchronous copy (from pageable memory the runtime parks the host
         # behind everything already queued on the stream -- the whole previous step)
-        meta_h = torch.empty(3 * b + 2, dtype=I32, pin_memory=True)
-        meta = meta_h.numpy()
+        meta_h, meta = self._staging(3 * b + 2)
         meta[:b] = idx
         meta[b] = 0
         np.cumsum(nn, out=meta[b + 1:2 * b + 1])
@@ -150,6 +171,7 @@ class MoleculeStore(object):
         np.cumsum(ne, out=meta[2 * b + 2:3 * b + 2])
         dev = self.device
         meta_d = meta_h.to(dev, non_blocking=True)
+        self._last_slot[2].record(torch.cuda.current_stream(dev))
         sel, out_nptr, out_eptr = meta_d[:b], meta_d[b:2 * b + 1], meta_d[2 * b + 1:]
         bt = Batch()
         w = self.x_width
@@ -157,13 +179,13 @@ class MoleculeStore(object):
         bt.pos = torch.empty((n_out, 3), dtype=torch.float32, device=dev) if self.has_pos else None
         bt.batch = torch.empty(n_out, dtype=I32, device=dev)
         bt.edge_index = torch.empty((2, e_out), dtype=I32, device=dev) if self.has_edges else None
+        bt.y = None if self.y is None else torch.empty(b, dtype=torch.float32, device=dev)
         lib.call('pamnet_collate_f32', b, lib.ptr(sel), lib.ptr(out_nptr), lib.ptr(out_eptr), lib.ptr(self.nptr_d),
                  lib.ptr(self.eptr_d), lib.ptr(self.x), w, lib.ptr(self.pos), lib.ptr(self.esrc), lib.ptr(self.edst), n_out,
                  e_out, lib.ptr(bt.x), lib.ptr(bt.pos), lib.ptr(bt.batch),
                  bt.edge_index.data_ptr() if e_out else None, (bt.edge_index.data_ptr() + 4 * e_out) if e_out else None,
-                 lib.stream_of(bt.x))
+                 lib.ptr(self.y), lib.ptr(bt.y), lib.stream_of(bt.x))       # (the targets ride in the same launch)
         bt.num_graphs = b
-        bt.y = None if self.y is None else self.y.index_select(0, sel.long())
         # the batch is produced by work queued on this stream: a consumer on another stream (the input pipeline's side
         # stream, train.Prefetcher) waits for exactly this event
         bt.inputs_ready = torch.cuda.Event()
