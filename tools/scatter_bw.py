@@ -1,5 +1,5 @@
 import os, sys
-REPO = '/root/repo'
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, 'physics-aware-multiplex-gnn_amd'))
 import torch
 from pamnet_amd import ops
