@@ -364,8 +364,8 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
                 float4 x = f4zero(), y = f4zero();
                 if (g < r1) {
                     const float4 dm = ldg4(d_agg, row_of[g], DIM, c4);
-                    const float4 zz = ldg4(zs, g, DIM, c4);
-                    x = f4mul(f4mul(dm, ldg4(eas, g, DIM, c4)), f4dsilu(zz));
+                    const float4 zz = ldg4(zs, g, DIM, c4);             // (non-temporal reads of the saves measured slower:
+                    x = f4mul(f4mul(dm, ldg4(eas, g, DIM, c4)), f4dsilu(zz));      //  793 vs 766 us at the PDBbind shape)
                     y = f4mul(dm, f4silu(zz));
                     stg4(dz, g, DIM, c4, x);
                     stg4(dea, g, DIM, c4, y);
