@@ -256,6 +256,20 @@ int pamnet_sbf_radial_f32(const float* dist, float cutoff, int64_t m, float* rad
 /* sbf[t, l*6+n] = rad[idx[t], l*6+n] * Y_l0(angle[t]) */
 int pamnet_sbf_combine_f32(const float* rad, const int32_t* idx, const float* angle, int64_t m, float* sbf,
                            pamnet_stream_t stream);
+/* The same basis layers for any PAMNet(config, num_spherical, num_radial, envelope_exponent) (models.py:22; the entries
+ * above are specialised for the default (7, 6, 5) every script of the reference uses): num_spherical <= 16, num_radial <= 64,
+ * envelope exponent p >= 1 (layers/basic.py:36-51).  zeros [ns * nr] (float32: utils/sbf.py:15-26 stores them so) and norm
+ * [ns * nr] (float64: N_ln = 1 / sqrt(0.5 j_{l+1}(z_ln)^2), utils/sbf.py:43-49) are device tables the caller computes once
+ * per model.  rad / sbf rows have ns * nr entries, index l * nr + n. */
+int pamnet_rbf_fwd_env_f32(const float* dist, const float* freq, float cutoff, int32_t envelope_exponent, int64_t m,
+                           float* rbf, pamnet_stream_t stream);
+int pamnet_rbf_bwd_env_f32(const float* dist, const float* freq, float cutoff, int32_t envelope_exponent, int64_t m,
+                           const float* grad, float* dfreq, float* partial, pamnet_stream_t stream);
+int pamnet_sbf_radial_tab_f32(const float* dist, float cutoff, int64_t m, int32_t num_spherical, int32_t num_radial,
+                              int32_t envelope_exponent, const float* zeros, const double* norm, float* rad,
+                              pamnet_stream_t stream);
+int pamnet_sbf_combine_tab_f32(const float* rad, const int32_t* idx, const float* angle, int64_t m, int32_t num_spherical,
+                               int32_t num_radial, float* sbf, pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Attention fusion + per-graph pooling  (models.py:206-224)

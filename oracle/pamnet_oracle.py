@@ -81,13 +81,18 @@ def legendre_coeffs(n=NUM_SPHERICAL):
 _CONST_CACHE = {}
 
 
-def basis_constants():
-    if not _CONST_CACHE:
-        z = bessel_zeros_f32()
-        _CONST_CACHE['zeros'] = z
-        _CONST_CACHE['norm'] = bessel_normalizers(z)
-        _CONST_CACHE['legendre'] = legendre_coeffs()
-    return _CONST_CACHE
+def basis_constants(n=NUM_SPHERICAL, k=NUM_RADIAL):
+    """Constants of the (n, k) basis; the default is the (7, 6) every script of the reference constructs (models.py:22)."""
+    if (n, k) not in _CONST_CACHE:
+        z = bessel_zeros_f32(n, k)
+        _CONST_CACHE[(n, k)] = {'zeros': z, 'norm': bessel_normalizers(z), 'legendre': legendre_coeffs(n)}
+    return _CONST_CACHE[(n, k)]
+
+
+def basis_of(cfg):
+    """(num_spherical, num_radial, envelope_exponent) of a model: PAMNet(config, 7, 6, 5) by default (models.py:22); tests
+    of other sizes hang a `basis` triple on the config."""
+    return tuple(getattr(cfg, 'basis', (NUM_SPHERICAL, NUM_RADIAL, 5)))
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -129,34 +134,33 @@ def _sph_jl_closed(lmax, z):
     return out
 
 
-def sbf_radial(dist, cutoff, p=5):
-    """layers/basic.py:107-109: rbf[e, l*6+n] = env(x) * N_ln * j_l(z_ln x), x = d/cutoff -> [E,42]."""
-    k = basis_constants()
+def sbf_radial(dist, cutoff, p=5, ns=NUM_SPHERICAL, nr=NUM_RADIAL):
+    """layers/basic.py:107-109: rbf[e, l*nr+n] = env(x) * N_ln * j_l(z_ln x), x = d/cutoff -> [E, ns*nr] (default [E,42])."""
+    k = basis_constants(ns, nr)
     x = dist / cutoff
     zeros = torch.as_tensor(k['zeros'].astype(np.float64), dtype=dist.dtype)      # fp32-rounded values
     norm = torch.as_tensor(k['norm'], dtype=dist.dtype)
     cols = []
-    for l in range(NUM_SPHERICAL):
+    for l in range(ns):
         zx = x.unsqueeze(-1) * zeros[l]                                         # [E,6]
         cols.append(norm[l] * _sph_jl_closed(l, zx)[l])
     rbf = torch.cat(cols, dim=1)
     return envelope(x, p).unsqueeze(-1) * rbf
 
 
-def sbf_angular(angle):
-    """layers/basic.py:111: cbf[t, l] = Y_l0(angle_t) -> [T,7] (utils/sbf.py:127)."""
-    c = torch.as_tensor(basis_constants()['legendre'], dtype=angle.dtype)
+def sbf_angular(angle, ns=NUM_SPHERICAL):
+    """layers/basic.py:111: cbf[t, l] = Y_l0(angle_t) -> [T, ns] (utils/sbf.py:127)."""
+    c = torch.as_tensor(legendre_coeffs(ns), dtype=angle.dtype)
     ct = torch.cos(angle)
-    pw = torch.stack([ct.pow(i) for i in range(NUM_SPHERICAL)], dim=1)            # [T,7]
+    pw = torch.stack([ct.pow(i) for i in range(ns)], dim=1)                       # [T, ns]
     return pw @ c.t()
 
 
-def spherical_basis(dist, angle, idx, cutoff, p=5):
-    """layers/basic.py:107-116: out[t, l*6+n] = rbf[idx[t], l, n] * cbf[t, l] -> [T,42]."""
-    rbf = sbf_radial(dist, cutoff, p)
-    cbf = sbf_angular(angle)
-    n, k = NUM_SPHERICAL, NUM_RADIAL
-    return (rbf[idx].view(-1, n, k) * cbf.view(-1, n, 1)).view(-1, n * k)
+def spherical_basis(dist, angle, idx, cutoff, p=5, ns=NUM_SPHERICAL, nr=NUM_RADIAL):
+    """layers/basic.py:107-116: out[t, l*nr+n] = rbf[idx[t], l, n] * cbf[t, l] -> [T, ns*nr]."""
+    rbf = sbf_radial(dist, cutoff, p, ns, nr)
+    cbf = sbf_angular(angle, ns)
+    return (rbf[idx].view(-1, ns, nr) * cbf.view(-1, ns, 1)).view(-1, ns * nr)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -398,10 +402,11 @@ def pamnet_forward(sd, cfg, x_raw, batch, pos=None, edge_index=None, dtype=None,
     angle2 = angle_between(pos[idx_j] - pos[idx_i], pos[idx_k] - pos[idx_j])              # models.py:165-168
     angle1 = angle_between(pos[idx_j1_pair] - pos[idx_i_pair], pos[idx_j2_pair] - pos[idx_j1_pair])  # :171-177
 
-    rbf_l = bessel_rbf(dist_l, sd['rbf_l.freq'], cfg.cutoff_l)                            # models.py:180
-    rbf_g = bessel_rbf(dist_g, sd['rbf_g.freq'], cfg.cutoff_g)
-    sbf1 = spherical_basis(dist_l, angle1, idx_jj_pair, cfg.cutoff_l)
-    sbf2 = spherical_basis(dist_l, angle2, idx_kj, cfg.cutoff_l)
+    ns, nr, p = basis_of(cfg)
+    rbf_l = bessel_rbf(dist_l, sd['rbf_l.freq'], cfg.cutoff_l, p)                         # models.py:180
+    rbf_g = bessel_rbf(dist_g, sd['rbf_g.freq'], cfg.cutoff_g, p)
+    sbf1 = spherical_basis(dist_l, angle1, idx_jj_pair, cfg.cutoff_l, p, ns, nr)
+    sbf2 = spherical_basis(dist_l, angle2, idx_kj, cfg.cutoff_l, p, ns, nr)
 
     e_rbf_l = mlp(sd, 'mlp_rbf_l', rbf_l, 1)                                              # models.py:185-188
     e_rbf_g = mlp(sd, 'mlp_rbf_g', rbf_g, 1)
@@ -463,9 +468,10 @@ def pamnet_s_forward(sd, cfg, x_raw, batch, pos, edge_index, dtype=None, interme
     ei_g, dist_g = get_edge_info(radius_graph(pos, batch, cfg.cutoff_g), pos)
     (_, _, _, _, _, idx_i_pair, idx_j1_pair, idx_j2_pair, idx_jj_pair, idx_ji_pair) = indices(ei_l, x.size(0))
     angle = angle_between(pos[idx_j1_pair] - pos[idx_i_pair], pos[idx_j2_pair] - pos[idx_j1_pair])
-    rbf_l = bessel_rbf(dist_l, sd['rbf_l.freq'], cfg.cutoff_l)
-    rbf_g = bessel_rbf(dist_g, sd['rbf_g.freq'], cfg.cutoff_g)
-    sbf = spherical_basis(dist_l, angle, idx_jj_pair, cfg.cutoff_l)
+    ns, nr, p = basis_of(cfg)
+    rbf_l = bessel_rbf(dist_l, sd['rbf_l.freq'], cfg.cutoff_l, p)
+    rbf_g = bessel_rbf(dist_g, sd['rbf_g.freq'], cfg.cutoff_g, p)
+    sbf = spherical_basis(dist_l, angle, idx_jj_pair, cfg.cutoff_l, p, ns, nr)
     e_rbf_l = mlp(sd, 'mlp_rbf_l', rbf_l, 1)
     e_rbf_g = mlp(sd, 'mlp_rbf_g', rbf_g, 1)
     e_sbf = mlp(sd, 'mlp_sbf', sbf, 1)
@@ -513,11 +519,12 @@ def init_state_dict(cfg, seed=0, dtype=torch.float32, small=False):
     sd['rbf_g.freq'], sd['rbf_l.freq'] = freq.clone(), freq.clone()
     mlp_keys('mlp_rbf_g', [NUM_RBF, d])
     mlp_keys('mlp_rbf_l', [NUM_RBF, d])
+    ns, nr, _ = basis_of(cfg)
     if small:
-        mlp_keys('mlp_sbf', [NUM_SPHERICAL * NUM_RADIAL, d])
+        mlp_keys('mlp_sbf', [ns * nr, d])
     else:
-        mlp_keys('mlp_sbf1', [NUM_SPHERICAL * NUM_RADIAL, d])
-        mlp_keys('mlp_sbf2', [NUM_SPHERICAL * NUM_RADIAL, d])
+        mlp_keys('mlp_sbf1', [ns * nr, d])
+        mlp_keys('mlp_sbf2', [ns * nr, d])
     for k in range(cfg.n_layer):
         for kind in ('global_layer', 'local_layer'):
             p = '%s.%d' % (kind, k)

@@ -32,18 +32,88 @@ class Config(object):
         self.flow = flow
 
 
+def _sph_jn(l, x):
+    """Spherical Bessel j_l(x), float64, for the host-side table construction: power series below the turning point,
+    upward recurrence above it (the same split the kernels use, csrc/basis.hip)."""
+    if x < l + 1.0:
+        h, term, total = -0.5 * x * x, 1.0, 1.0
+        for k in range(1, 60):
+            term *= h / (k * (2 * l + 2 * k + 1))
+            total += term
+        pref = 1.0
+        for m in range(1, l + 1):
+            pref *= x / (2 * m + 1)
+        return pref * total
+    jm = math.sin(x) / x
+    if l == 0:
+        return jm
+    j = (jm - math.cos(x)) / x
+    for m in range(1, l):
+        jm, j = j, (2 * m + 1) / x * j - jm
+    return j
+
+
+def basis_tables(num_spherical, num_radial):
+    """(zeros float32 [ns, nr], normalisers float64 [ns, nr]) of the spherical-Bessel basis: the first nr positive zeros of
+    j_0 .. j_{ns-1}, ROUNDED TO FLOAT32 as utils/sbf.py:15-26 stores them (zeros of j_l interlace those of j_{l-1}: the
+    same brackets as the reference's brentq sweep, bisected to the last float64 bit), and N_ln = 1 / sqrt(0.5 j_{l+1}(z_ln)^2)
+    evaluated on the rounded zeros (utils/sbf.py:43-49).  Pure float64 arithmetic: no scipy / sympy at run time (the
+    reference spends 12-16 s of sympy here per model)."""
+    import numpy as np
+    ns, nr = int(num_spherical), int(num_radial)
+    zeros = np.zeros((ns, nr), dtype=np.float64)
+    zeros[0] = np.arange(1, nr + 1) * math.pi
+    points = [k * math.pi for k in range(1, nr + ns)]
+    for l in range(1, ns):
+        roots = []
+        for j in range(nr + ns - 1 - l):
+            a, b = points[j], points[j + 1]
+            fa = _sph_jn(l, a)
+            for _ in range(200):
+                mid = 0.5 * (a + b)
+                if mid == a or mid == b:
+                    break
+                fm = _sph_jn(l, mid)
+                if (fm > 0) == (fa > 0):
+                    a, fa = mid, fm
+                else:
+                    b = mid
+            roots.append(0.5 * (a + b))
+        points = roots
+        zeros[l] = roots[:nr]
+    z32 = zeros.astype(np.float32)
+    z = z32.astype(np.float64)
+    norm = np.array([[1.0 / math.sqrt(0.5 * _sph_jn(l + 1, z[l, i]) ** 2) for i in range(nr)] for l in range(ns)])
+    return z32, norm
+
+
 class SphericalBasis(nn.Module):
-    """Parameter-free stand-in for `self.sbf` (layers/basic.py:79-116).  The reference spends 12-16 s of sympy here;
-    the closed forms ship as constants inside the library (csrc/basis_constants.h)."""
+    """Parameter-free stand-in for `self.sbf` (layers/basic.py:79-116).  The reference spends 12-16 s of sympy here.  The
+    default sizes (7, 6, envelope exponent 5 -- what every script of the reference constructs) ship as compile-time
+    constants inside the library (csrc/basis_constants.h); any other (num_spherical <= 16, num_radial <= 64,
+    envelope_exponent >= 1) gets its zeros / normalisers computed here once and handed to the table-driven kernels
+    (pamnet_sbf_radial_tab_f32 / pamnet_sbf_combine_tab_f32)."""
 
     def __init__(self, num_spherical, num_radial, cutoff, envelope_exponent):
         super().__init__()
-        if (num_spherical, num_radial, envelope_exponent) != (7, 6, 5):
-            raise ValueError('libpamnet_hip ships the num_spherical=7, num_radial=6, envelope_exponent=5 basis')
+        ns, nr, p = int(num_spherical), int(num_radial), int(envelope_exponent)
+        if not (1 <= ns <= 16 and 1 <= nr <= 64 and 1 <= p <= 64):
+            raise ValueError('spherical basis: num_spherical in 1..16, num_radial in 1..64 (layers/basic.py:82), '
+                             'envelope_exponent in 1..64')
         self.cutoff = cutoff
+        self.num_spherical, self.num_radial, self.envelope_exponent = ns, nr, p
+        self.default = (ns, nr, p) == (7, 6, 5)
+        if not self.default:
+            z32, norm = basis_tables(ns, nr)
+            # non-persistent: `state_dict()` keeps the reference's keys (the reference's basis holds no tensors either)
+            self.register_buffer('zeros', torch.from_numpy(z32).reshape(-1).contiguous(), persistent=False)
+            self.register_buffer('norm', torch.from_numpy(norm).reshape(-1).contiguous(), persistent=False)
 
     def forward(self, graph):
-        return G.spherical_basis(graph, self.cutoff)
+        if self.default:
+            return G.spherical_basis(graph, self.cutoff)
+        return G.spherical_basis_tab(graph, self.cutoff, self.num_spherical, self.num_radial, self.envelope_exponent,
+                                     self.zeros, self.norm)
 
 
 class _LazyLayers(object):
@@ -81,15 +151,13 @@ class _PAMNetBase(nn.Module):
         self.flow = getattr(config, 'flow', 'source_to_target')
         if self.dim % 4 != 0:
             raise ValueError('dim must be a multiple of 4 (16-byte vector lanes of the gfx950 kernels)')
-        if envelope_exponent != 5:
-            raise ValueError('envelope_exponent=5 is compiled into the kernels')
         self._rna = self.dataset[:3].lower() == 'rna'
         self.__dict__['_pending_checks'] = []            # device flag words of forwards that ran without a host round trip
 
     def _build_common(self, num_spherical, num_radial, envelope_exponent):
         d = self.dim
-        self.rbf_g = BesselBasis(16, self.cutoff_g)
-        self.rbf_l = BesselBasis(16, self.cutoff_l)
+        self.rbf_g = BesselBasis(16, self.cutoff_g, envelope_exponent)          # models.py:26-28
+        self.rbf_l = BesselBasis(16, self.cutoff_l, envelope_exponent)
         self.sbf = SphericalBasis(num_spherical, num_radial, self.cutoff_l, envelope_exponent)
         self.mlp_rbf_g = MLP([16, d])
         self.mlp_rbf_l = MLP([16, d])
@@ -110,7 +178,7 @@ class _PAMNetBase(nn.Module):
                           getattr(data, 'pos', None), getattr(data, 'edge_index', None), num_graphs=ng,
                           need_grad=torch.is_grad_enabled(), with_triplets=not self.small,
                           n_types=self.embeddings.size(0) if hasattr(self, 'embeddings') else None,
-                          sizes=self._sizes_of(data))
+                          sizes=self._sizes_of(data), default_basis=self.sbf.default)
         if g.check is not None:                          # zero-host-sync path: the flag word waits for verify()
             self._pending_checks.append(g.check)
         g.need_grad = torch.is_grad_enabled()
@@ -175,7 +243,7 @@ class _PAMNetBase(nn.Module):
 
     def _edge_embeddings(self, g, tape=None):
         sbf = g.sbf                                                                          # [T+P, 42], no grad
-        if self._narrow(g.dist_g) and g.loc.m > 0 and g.glob.m > 0:
+        if self._narrow(g.dist_g) and g.loc.m > 0 and g.glob.m > 0 and self.sbf.envelope_exponent == 5:
             # dim 16 / 32 / 64: the Bessel rows are formed inside the embedding kernels (no [E, 16] tensor either way)
             e_l = narrow.embed_rbf(g.dist_l, self.rbf_l.freq, self.cutoff_l, self.mlp_rbf_l[0][0])
             e_g = narrow.embed_rbf(g.dist_g, self.rbf_g.freq, self.cutoff_g, self.mlp_rbf_g[0][0])
@@ -200,8 +268,8 @@ class _PAMNetBase(nn.Module):
         """(x, e_l, e_g, e_sbf) of models.py:107/119/140 and 185-188 as ONE launch (two in the backward) on the dim = 128
         path: the Bessel rows are formed inside the embedding kernel from the edge lengths, the type-table rows ride along.
         lin_a (, lin_b): the sbf embedding(s) -- with lin_b, rows of g.tp_kind == 1 use lin_b.  None when not applicable."""
-        if not (modules.IMPL == 'fused' and self.dim == fused.D and g.sbf.is_cuda and g.sbf.size(1) == 42):
-            return None
+        if not (modules.IMPL == 'fused' and self.dim == fused.D and g.sbf.is_cuda and self.sbf.default):
+            return None                               # (the one-launch input stage is built for the default basis)
         lin_l, lin_g = self.mlp_rbf_l[0][0], self.mlp_rbf_g[0][0]
         layers = [(None, g.dist_l, self.cutoff_l, None, True, True), (None, g.dist_g, self.cutoff_g, None, True, True),
                   (g.sbf, None, None, g.tp_kind if lin_b is not None else None, True, True)]
@@ -331,13 +399,10 @@ class PAMNet(_PAMNetBase):
         # mlp_sbf2 on triplet rows, mlp_sbf1 on pair rows (models.py:187-188), rows grouped by target edge
         if self._embed_fused(sbf, self.mlp_sbf2):
             e_sbf = fused.embed(sbf, self.mlp_sbf2[0][0], self.mlp_sbf1[0][0], kind=g.tp_kind, tape=tape)
-        elif self._narrow(sbf):
+        elif self._narrow(sbf) and sbf.size(1) == 42:
             e_sbf = narrow.embed(sbf, self.mlp_sbf2[0][0], self.mlp_sbf1[0][0], kind=g.tp_kind)
-        else:
-            y2 = mlp_apply(self.mlp_sbf2, sbf.index_select(0, g.trip_rows))
-            y1 = mlp_apply(self.mlp_sbf1, sbf.index_select(0, g.pair_rows))
-            e_sbf = torch.zeros((sbf.size(0), self.dim), dtype=sbf.dtype, device=sbf.device)
-            e_sbf = e_sbf.index_copy(0, g.trip_rows, y2).index_copy(0, g.pair_rows, y1)
+        else:                                      # a basis width without a kernel of its own: tape-aware dense layers
+            e_sbf = ops.dense_act(sbf, self.mlp_sbf2[0][0], self.mlp_sbf1[0][0], kind=g.tp_kind, tape=tape)
         return self._layers_and_pool(x, e_l, e_g, e_sbf, g, tape, self._rna)
 
 
@@ -374,8 +439,8 @@ class PAMNet_s(_PAMNetBase):
         e_l, e_g, sbf = self._edge_embeddings(g, tape)
         if self._embed_fused(sbf, self.mlp_sbf):
             e_sbf = fused.embed(sbf, self.mlp_sbf[0][0], tape=tape)
-        elif self._narrow(sbf):
+        elif self._narrow(sbf) and sbf.size(1) == 42:
             e_sbf = narrow.embed(sbf, self.mlp_sbf[0][0])
         else:
-            e_sbf = mlp_apply(self.mlp_sbf, sbf)
+            e_sbf = ops.dense_act(sbf, self.mlp_sbf[0][0], tape=tape)
         return self._layers_and_pool(x, e_l, e_g, e_sbf, g, tape, False)

@@ -437,7 +437,7 @@ _SCHEMA = {'QM9': 0, 'PDBbind': 1, 'rna': 2}
 
 
 def _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_index, n_graphs, need_grad, knn_k,
-                  with_triplets, n_types, sizes):
+                  with_triplets, n_types, sizes, default_basis=True):
     """The zero-host-sync graph as one engine call, or None when this batch does not qualify (empty lists, layouts the
     ingest launch does not read): the step-by-step path below then builds it."""
     import ctypes
@@ -492,8 +492,9 @@ def _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_ind
     lib.call('pamnet_graph_plan', ctypes.addressof(d), ctypes.addressof(layout), ctypes.addressof(need))
     dev = batch.device
     arena = torch.empty(int(need.value), dtype=I32, device=dev)
-    sbf = torch.empty((tp, 42), dtype=torch.float32, device=dev)
-    lib.call('pamnet_graph_build_i32', ctypes.addressof(d), arena.data_ptr(), sbf.data_ptr(), lib.stream_of(batch))
+    # the engine forms the default (7, 6, 5) basis in the same call; any other size is the model's own launch pair
+    sbf = torch.empty((tp, 42), dtype=torch.float32, device=dev) if default_basis else None
+    lib.call('pamnet_graph_build_i32', ctypes.addressof(d), arena.data_ptr(), lib.ptr(sbf), lib.stream_of(batch))
     F = lib.GF
     g = EngineGraph()
     g._arena, g._layout, g._base, g._inputs = arena, list(layout), arena.data_ptr(), keep
@@ -535,7 +536,7 @@ def _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_ind
 
 
 def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_index=None, num_graphs=None,
-                need_grad=True, knn_k=50, with_triplets=True, n_types=None, sizes=None):
+                need_grad=True, knn_k=50, with_triplets=True, n_types=None, sizes=None, default_basis=True):
     """Graph-construction part of PAMNet.forward (models.py:104-177).  Returns a Graph.
 
     `sizes`: (global edges, local edges, triplet + pair rows) of this batch as host integers -- what a batch collated by
@@ -546,7 +547,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     dev = batch.device
     if sizes is not None and num_graphs is not None:
         eng = _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_index, num_graphs, need_grad, knn_k,
-                            with_triplets, n_types, sizes)
+                            with_triplets, n_types, sizes, default_basis)
         if eng is not None:
             return eng
     g = Graph()
@@ -729,6 +730,21 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         g.loc_T = SymmetricTranspose(g.loc) if dataset == 'PDBbind' else (loc_inv if rna else Transpose(g.loc.col, n))
         g.tp_T = Transpose(tp_idx, max(e_l, 1))       # d m_neighbor[e'] of the triplet/pair gather
     return g
+
+
+def spherical_basis_tab(g, cutoff_l, num_spherical, num_radial, envelope_exponent, zeros, norm):
+    """SphericalBasisLayer for any (num_spherical, num_radial, envelope_exponent) (layers/basic.py:79-116): zeros (float32)
+    / norm (float64) are the model's device tables (models.SphericalBasis).  Returns [T+P, num_spherical * num_radial]."""
+    dev = g.pos.device
+    st = lib.stream_of(g.pos)
+    e_l, tot, w = g.loc.m, g.tp.m, int(num_spherical) * int(num_radial)
+    rad = _f32(e_l * w, dev)
+    lib.call('pamnet_sbf_radial_tab_f32', lib.ptr(g.dist_l), float(cutoff_l), e_l, int(num_spherical), int(num_radial),
+             int(envelope_exponent), lib.ptr(zeros), lib.ptr(norm), lib.ptr(rad), st)
+    sbf = torch.empty((tot, w), dtype=torch.float32, device=dev)
+    lib.call('pamnet_sbf_combine_tab_f32', lib.ptr(rad), lib.ptr(g.tp.col), lib.ptr(g.tp_angle), tot, int(num_spherical),
+             int(num_radial), lib.ptr(sbf), st)
+    return sbf
 
 
 def spherical_basis(g, cutoff_l):

@@ -58,13 +58,14 @@ class Res(nn.Module):
 class BesselBasis(nn.Module):
     """Holds the trainable frequencies n*pi, n=1..16 (layers/basic.py:65-72)."""
 
-    def __init__(self, num_radial, cutoff):
+    def __init__(self, num_radial, cutoff, envelope_exponent=5):
         super().__init__()
         self.cutoff = cutoff
+        self.envelope_exponent = int(envelope_exponent)
         self.freq = nn.Parameter(torch.arange(1, num_radial + 1, dtype=torch.float32) * math.pi)
 
     def forward(self, dist, tape=None):
-        return ops.rbf(dist, self.freq, self.cutoff, tape=tape)
+        return ops.rbf(dist, self.freq, self.cutoff, tape=tape, exponent=self.envelope_exponent)
 
 
 def glorot_(t):

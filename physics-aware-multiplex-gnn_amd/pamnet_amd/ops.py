@@ -333,13 +333,17 @@ class _RBF(torch.autograd.Function):
     """BesselBasisLayer (layers/basic.py:59-76); freq is trainable, dist is not differentiated (pos has no grad)."""
 
     @staticmethod
-    def forward(ctx, dist, freq, cutoff):
+    def forward(ctx, dist, freq, cutoff, exponent=5):
         m = dist.numel()
         out = torch.empty((m, 16), dtype=torch.float32, device=dist.device)
-        lib.call('pamnet_rbf_fwd_f32', lib.ptr(dist), lib.ptr(_c(freq)), float(cutoff), m, lib.ptr(out),
-                 lib.stream_of(dist))
+        if exponent == 5:
+            lib.call('pamnet_rbf_fwd_f32', lib.ptr(dist), lib.ptr(_c(freq)), float(cutoff), m, lib.ptr(out),
+                     lib.stream_of(dist))
+        else:                                   # any other envelope exponent: the run-time form of the same kernel
+            lib.call('pamnet_rbf_fwd_env_f32', lib.ptr(dist), lib.ptr(_c(freq)), float(cutoff), int(exponent), m,
+                     lib.ptr(out), lib.stream_of(dist))
         ctx.save_for_backward(dist, freq)
-        ctx.cutoff = float(cutoff)
+        ctx.cutoff, ctx.exponent = float(cutoff), int(exponent)
         return out
 
     @staticmethod
@@ -348,9 +352,13 @@ class _RBF(torch.autograd.Function):
         g = _c(g)
         dfreq = torch.empty(16, dtype=torch.float32, device=g.device)
         partial = torch.empty(16 * 2048, dtype=torch.float32, device=g.device)
-        lib.call('pamnet_rbf_bwd_f32', lib.ptr(dist), lib.ptr(_c(freq)), ctx.cutoff, dist.numel(), lib.ptr(g),
-                 lib.ptr(dfreq), lib.ptr(partial), lib.stream_of(g))
-        return None, dfreq, None
+        if ctx.exponent == 5:
+            lib.call('pamnet_rbf_bwd_f32', lib.ptr(dist), lib.ptr(_c(freq)), ctx.cutoff, dist.numel(), lib.ptr(g),
+                     lib.ptr(dfreq), lib.ptr(partial), lib.stream_of(g))
+        else:
+            lib.call('pamnet_rbf_bwd_env_f32', lib.ptr(dist), lib.ptr(_c(freq)), ctx.cutoff, ctx.exponent, dist.numel(),
+                     lib.ptr(g), lib.ptr(dfreq), lib.ptr(partial), lib.stream_of(g))
+        return None, dfreq, None, None
 
 
 class _FusePool(torch.autograd.Function):
@@ -404,6 +412,38 @@ def plain_linear(x, w, tape=None):
     return apply(_PlainLinear, x, w, tape=tape)
 
 
+class _DenseAct(torch.autograd.Function):
+    """SiLU(x W_kind^T + b_kind) for an input width no kernel of this library is built for (the spherical-basis embedding
+    with a non-default num_spherical * num_radial, models.py:187-188): rocBLAS calls between the HIP kernels, as a Function
+    of this package so that a recorded forward (Tape) differentiates it.  `kind` (int32 [rows], nullable): rows of kind 0
+    use (wa, ba), the others (wb, bb).  The input carries no gradient (geometry only)."""
+
+    @staticmethod
+    def forward(ctx, x, kind, wa, ba, wb, bb):
+        z = torch.addmm(ba, x, wa.t())
+        if kind is not None:
+            z = torch.where((kind == 0).unsqueeze(1), z, torch.addmm(bb, x, wb.t()))
+        ctx.save_for_backward(x, z, kind)
+        return z * torch.sigmoid(z)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, z, kind = ctx.saved_tensors
+        sg = torch.sigmoid(z)
+        dz = g * (sg * (1 + z * (1 - sg)))
+        if kind is None:
+            return None, None, dz.t() @ x, dz.sum(0), None, None
+        ma = (kind == 0).unsqueeze(1)
+        da, db_ = dz * ma, dz * (~ma)
+        return None, None, da.t() @ x, da.sum(0), db_.t() @ x, db_.sum(0)
+
+
+def dense_act(x, lin_a, lin_b=None, kind=None, tape=None):
+    if kind is None:
+        return apply(_DenseAct, x, None, lin_a.weight, lin_a.bias, None, None, tape=tape)
+    return apply(_DenseAct, x, kind, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias, tape=tape)
+
+
 class _StackRows(torch.autograd.Function):
     """torch.stack of per-layer [N] rows (models.py:206-207) as a Function of this package (so that it can run on a Tape)."""
 
@@ -432,8 +472,8 @@ def gather_mul_aggregate(A, B, csr, tr):
     return apply(_GatherMulAggregate, A, B, csr, tr)
 
 
-def rbf(dist, freq, cutoff, tape=None):
-    return apply(_RBF, dist, freq, cutoff, tape=tape)
+def rbf(dist, freq, cutoff, tape=None, exponent=5):
+    return apply(_RBF, dist, freq, cutoff, exponent, tape=tape)
 
 
 def fuse_pool(outs, atts, graph, mean, tape=None):

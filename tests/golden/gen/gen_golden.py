@@ -147,6 +147,19 @@ _SBF_CACHE = {}
 
 def build_model(cls, cfg):
     """Reference model; the 15 s sympy construction of SphericalBasisLayer is shared through a cache."""
+    basis = getattr(cfg, 'basis', None)
+    if basis is not None:                 # PAMNet(config, num_spherical, num_radial, envelope_exponent): models.py:22
+        key = (cfg.cutoff_l,) + tuple(basis)
+        if key in _SBF_CACHE:
+            orig = ref_models.SphericalBasisLayer
+            ref_models.SphericalBasisLayer = lambda *a, **k: _SBF_CACHE[key]
+            try:
+                return cls(cfg, *basis)
+            finally:
+                ref_models.SphericalBasisLayer = orig
+        m = cls(cfg, *basis)
+        _SBF_CACHE[key] = m.sbf
+        return m
     key = cfg.cutoff_l
     if key in _SBF_CACHE:
         orig = ref_models.SphericalBasisLayer
@@ -251,14 +264,19 @@ def fixture_rna():
     save('rna_native', **arrs)
 
 
-def fixture_random(name, cls, cfg_kw, batch, seed, capture, small=False):
-    """Seeded random-init reference model on a synthetic batch; fp32 and fp64 runs."""
+def fixture_random(name, cls, cfg_kw, batch, seed, capture, small=False, basis=None):
+    """Seeded random-init reference model on a synthetic batch; fp32 and fp64 runs.  basis: (num_spherical, num_radial,
+    envelope_exponent) other than the default (7, 6, 5)."""
     cfg = ref_models.Config(**cfg_kw)
+    if basis is not None:
+        cfg.basis = tuple(basis)
     sd = oracle.init_state_dict(cfg, seed=seed, small=small)
     arrs = dict(seed=np.int64(seed), weights_checksum=np.float64(checksum(sd)),
                 cfg_dataset=np.array(cfg_kw['dataset']), cfg_dim=np.int64(cfg_kw['dim']),
                 cfg_n_layer=np.int64(cfg_kw['n_layer']), cfg_cutoff_l=np.float64(cfg_kw['cutoff_l']),
                 cfg_cutoff_g=np.float64(cfg_kw['cutoff_g']), cfg_flow=np.array(cfg_kw.get('flow', 'source_to_target')))
+    if basis is not None:
+        arrs['cfg_basis'] = np.asarray(basis, np.int64)
     for k in ('x', 'batch', 'pos', 'edge_index', 'y'):
         if hasattr(batch, k):
             arrs['in/' + k] = getattr(batch, k).numpy()
@@ -357,9 +375,12 @@ def main():
         return main_d128()
     if '--baseline-only' in sys.argv:
         return main_baseline()
+    if '--basis-only' in sys.argv:
+        return main_basis()
     main_forward()
     main_train()
     main_baseline()
+    main_basis()
 
 
 def fixture_baseline(name, cfg_kw, batch, seed, grads=False):
@@ -423,6 +444,17 @@ def main_baseline():
     fixture_baseline('baseline_pdbbind_b32', pdb, synth.collate([synth.pdbbind_complex(1, i) for i in range(32)]), seed=3)
     rna = dict(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
     fixture_baseline('baseline_rna_b8', rna, synth.rna_batch(2, 0, 8), seed=5)
+
+
+def main_basis():
+    """Non-default basis sizes straight from the reference: PAMNet(config, num_spherical, num_radial, envelope_exponent)
+    (models.py:22) -- a smaller basis with another envelope at a narrow width, a larger one at dim = 128."""
+    qm9 = dict(dataset='QM9', dim=32, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+    fixture_random('qm9_basis_5x4_p6_d32_l2', ref_models.PAMNet, qm9, synth.qm9_batch(11, 0, 6), seed=3, capture=True,
+                   basis=(5, 4, 6))
+    big = dict(dataset='QM9', dim=128, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+    fixture_random('qm9_basis_8x7_p4_d128_l2', ref_models.PAMNet, big, synth.qm9_batch(12, 0, 5), seed=4, capture=False,
+                   basis=(8, 7, 4))
 
 
 def main_train():

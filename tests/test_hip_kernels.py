@@ -355,6 +355,55 @@ def test_basis_vs_golden_tables(dev, golden):
         assert err < max(3e-6, 2 * ref32_err[l]), (l, err, ref32_err[l])
 
 
+@pytest.mark.parametrize('basis', [(7, 6, 5), (5, 4, 6), (8, 7, 4), (1, 1, 1), (16, 12, 9)])
+def test_table_driven_basis_vs_scipy(dev, basis):
+    """The table-driven basis kernels (any num_spherical / num_radial / envelope exponent; models.SphericalBasis computes the
+    zeros / normalisers on the host without scipy) on a dense grid against env_p(x) N_ln j_l(z_ln x) Y_l0(theta) with scipy's
+    spherical_jn in fp64, block by block; for the default sizes also against the specialised compile-time kernels; the
+    run-time-exponent Bessel rows against the oracle's."""
+    import models
+    from pamnet_amd import graph as G, lib, ops
+    from oracle import pamnet_oracle as O
+    ns, nr, p = basis
+    z32, norm = models.basis_tables(ns, nr)
+    k = O.basis_constants(ns, nr)
+    assert np.array_equal(z32, k['zeros']) and np.max(np.abs(norm / k['norm'] - 1)) < 1e-14      # host tables == scipy's
+    cutoff, m = 5.0, 4099
+    dist = torch.linspace(0.03 * cutoff, 1.06 * cutoff, m, device=dev)
+    ang = torch.linspace(0.0, float(np.pi), m, device=dev)
+    idx = torch.randperm(m, device=dev).to(torch.int32)
+
+    class _G(object):
+        pass
+    g = _G()
+    g.pos, g.dist_l, g.tp_angle = dist, dist, ang
+    g.loc, g.tp = _G(), _G()
+    g.loc.m, g.tp.m, g.tp.col = m, m, idx
+    sbf = G.spherical_basis_tab(g, cutoff, ns, nr, p, torch.from_numpy(z32).reshape(-1).to(dev),
+                                torch.from_numpy(norm).reshape(-1).to(dev))
+    x = (dist * torch.tensor(1.0 / cutoff, dtype=torch.float32, device=dev)).cpu().double()
+    zx = x.unsqueeze(-1).numpy() * z32.astype(np.float64).reshape(1, -1)
+    jl = np.concatenate([O._sph_jn_f64(l, zx[:, nr * l:nr * l + nr]) for l in range(ns)], axis=1)
+    rad = O.envelope(x, p).unsqueeze(-1) * torch.from_numpy(jl * norm.reshape(1, -1))
+    cbf = O.sbf_angular(ang.cpu().double(), ns)
+    ref = (rad[idx.cpu().long()].view(m, ns, nr) * cbf.view(m, ns, 1)).view(m, ns * nr)
+    for l in range(ns):
+        blk = slice(nr * l, nr * l + nr)
+        assert maxnorm_err(sbf[:, blk].cpu(), ref[:, blk]) < 3e-6, (basis, l)
+    if basis == (7, 6, 5):
+        g.dist_l = dist
+        assert maxnorm_err(sbf.cpu(), G.spherical_basis(g, cutoff).cpu()) < 1e-6
+    freq = (torch.arange(1, 17, dtype=torch.float32) * np.pi).to(dev).requires_grad_(True)
+    rbf = ops.rbf(dist, freq, cutoff, exponent=p)
+    r64 = O.bessel_rbf(dist.cpu().double(), freq.detach().cpu().double(), cutoff, p)
+    assert maxnorm_err(rbf.detach().cpu(), r64) < 3e-6
+    w = torch.randn(m, 16, device=dev)
+    (rbf * w).sum().backward()
+    f64 = freq.detach().cpu().double().requires_grad_(True)
+    (O.bessel_rbf(dist.cpu().double(), f64, cutoff, p) * w.cpu().double()).sum().backward()
+    assert maxnorm_err(freq.grad.cpu(), f64.grad) < 2e-5
+
+
 @pytest.mark.parametrize('cutoff', [5.0, 2.0, 16.0])
 def test_sbf_radial_dense_grid_vs_oracle(dev, cutoff):
     """The 42 radial functions on a dense grid of edge lengths (series branch, recurrence branch and beyond the cutoff)

@@ -16,8 +16,11 @@ from oracle import pamnet_oracle as O
 
 
 def _cfg(g):
-    return O.Config(dataset=str(g['cfg_dataset']), dim=int(g['cfg_dim']), n_layer=int(g['cfg_n_layer']),
-                    cutoff_l=float(g['cfg_cutoff_l']), cutoff_g=float(g['cfg_cutoff_g']), flow=str(g['cfg_flow']))
+    cfg = O.Config(dataset=str(g['cfg_dataset']), dim=int(g['cfg_dim']), n_layer=int(g['cfg_n_layer']),
+                   cutoff_l=float(g['cfg_cutoff_l']), cutoff_g=float(g['cfg_cutoff_g']), flow=str(g['cfg_flow']))
+    if 'cfg_basis' in g.files:             # PAMNet(config, num_spherical, num_radial, envelope_exponent), models.py:22
+        cfg.basis = tuple(int(v) for v in g['cfg_basis'])
+    return cfg
 
 
 def _inputs(g):
@@ -63,7 +66,8 @@ def test_basis_tables(golden):
 @pytest.mark.parametrize('name,small', [('qm9_d32_l2', False), ('pdbbind_d32_l2', False), ('qm9s_d32_l2', True),
                                         ('qm9_ragged_d32_l2', False), ('qm9s_ragged_d32_l2', True),
                                         ('pdbbind_d128_l3', False), ('qm9s_d128_l2', True),
-                                        ('qm9_d128_l6', False)])
+                                        ('qm9_d128_l6', False), ('qm9_basis_5x4_p6_d32_l2', False),
+                                        ('qm9_basis_8x7_p4_d128_l2', False)])
 def test_random_init_forward(golden, name, small):
     g = golden(name)
     cfg = _cfg(g)
@@ -95,7 +99,7 @@ def test_random_init_forward(golden, name, small):
                     assert np.array_equal(inter[k].numpy(), g['ref/' + k]), k
 
 
-@pytest.mark.parametrize('name', ['qm9_d32_l2', 'pdbbind_d32_l2'])
+@pytest.mark.parametrize('name', ['qm9_d32_l2', 'pdbbind_d32_l2', 'qm9_basis_5x4_p6_d32_l2'])
 def test_loss_gradient_fp64(golden, name):
     """d L1-loss / d params through the oracle == through the reference (fp64)."""
     g = golden(name)
