@@ -236,10 +236,7 @@ inline int plan_rider(Jobs& j, float* partial, const Graph& g, void* rider, int6
 }
 // riders pay when the chain leaves enough CUs idle for slots of a few hundred rows: ceil(n/16) <= 176 workgroups
 // how many of a chain's 10 tail jobs ride (the rest stay in the layer's own weight-gradient launch)
-inline int rider_jobs() {
-    static int v = [] { const char* e = getenv("PAMNET_RIDER_JOBS"); const int k = e ? atoi(e) : 10; return k < 1 ? 1 : (k > 10 ? 10 : k); }();
-    return v;
-}
+constexpr int rider_jobs() { return 10; }      // all ten (fewer riders, the rest in the layer's own launch, measured slower)
 inline bool riders_fit(const Graph& g) { return (g.n + 15) / 16 <= RIDER_MAX_SLOTS - 80; }
 
 inline void tail_jobs(Jobs& j, const Graph& g, const float* dZ, const float* hdz, const float* x2, const float* Z,

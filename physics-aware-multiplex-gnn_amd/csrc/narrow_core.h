@@ -1276,14 +1276,7 @@ inline bool width_ok(int64_t d) { return d == 16 || d == 32 || d == 64; }
 
 // Workgroups that are co-resident per CU: the backward kernels at d = 64 hold ~350 registers per lane and ~80 KB of
 // weight images, so one 4-wave workgroup fills a CU; a grid beyond that only adds a second, nearly empty round.
-inline int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-inline int fwd_per_cu(int64_t d) {
-    static const int over = env_int("PAMNET_NARROW_PERCU", 0);      // measurement aid
-    return over > 0 ? over : (d == 64 ? 2 : 4);
-}
+inline int fwd_per_cu(int64_t d) { return d == 64 ? 2 : 4; }
 
 
 template <typename Kern>

@@ -1211,20 +1211,10 @@ extern "C" int pamnet_node_heads_fwd_f32(int64_t n_layers, const float* const* x
                 !h.w_att || !h.out || !h.att)
                 return PAMNET_ENULL;
         }
-        static const int hm = [] { const char* e = getenv("PAMNET_HEADS_TILES"); return e ? atoi(e) : 1; }();
-        if (hm == 4) {
-            const dim3 grid((unsigned)ceil_div(n, 64), (unsigned)nl);
-            if (packed) hipLaunchKernelGGL((node_heads_fwd_kernel<true, 4>), grid, dim3(WG), 0, st, hb, n);
-            else hipLaunchKernelGGL((node_heads_fwd_kernel<false, 4>), grid, dim3(WG), 0, st, hb, n);
-        } else if (hm == 2) {
-            const dim3 grid((unsigned)ceil_div(n, 32), (unsigned)nl);
-            if (packed) hipLaunchKernelGGL((node_heads_fwd_kernel<true, 2>), grid, dim3(WG), 0, st, hb, n);
-            else hipLaunchKernelGGL((node_heads_fwd_kernel<false, 2>), grid, dim3(WG), 0, st, hb, n);
-        } else {
-            const dim3 grid((unsigned)ceil_div(n, BMN), (unsigned)nl);
-            if (packed) hipLaunchKernelGGL((node_heads_fwd_kernel<true, 1>), grid, dim3(WG), 0, st, hb, n);
-            else hipLaunchKernelGGL((node_heads_fwd_kernel<false, 1>), grid, dim3(WG), 0, st, hb, n);
-        }
+        // one 16-row tile per workgroup (32- and 64-row tilings were measured and lost at every batch size tried)
+        const dim3 grid((unsigned)ceil_div(n, BMN), (unsigned)nl);
+        if (packed) hipLaunchKernelGGL((node_heads_fwd_kernel<true, 1>), grid, dim3(WG), 0, st, hb, n);
+        else hipLaunchKernelGGL((node_heads_fwd_kernel<false, 1>), grid, dim3(WG), 0, st, hb, n);
         PAMNET_LAUNCH_CHECK();
     }
     return PAMNET_OK;

@@ -44,21 +44,12 @@ inline int job_slots(int64_t rows, int64_t chunk) {
 // Rows per slot for a batch: 256, or the smallest multiple of 64 above it for which the whole batch fits in
 // TARGET_SLOTS workgroups -- one wave of workgroups over the 256 CUs instead of a full round plus a ragged tail
 // (345 workgroups at the QM9 B=128 shape ran as 2 rounds: 49 us; one round of 256 x 384 rows: see DESIGN.md).
-inline int target_slots() {
-    static int t = [] { const char* e = getenv("PAMNET_WGRAD_SLOTS"); return e ? atoi(e) : 256; }();
-    return t;
-}
+constexpr int target_slots() { return 256; }
 // rows per rider slot to start from (a rider should not outlast the node chain it rides with: ~26 us)
-inline int64_t rider_rows() {
-    static int64_t v = [] { const char* e = getenv("PAMNET_RIDER_ROWS"); return (int64_t)(e ? atoi(e) : 256); }();
-    return v;
-}
+constexpr int64_t rider_rows() { return 256; }
 // smallest chunk a plan may use (scratch is sized for it)
 constexpr int MIN_ROWS_PER_WG = 128;
-inline int64_t first_rows() {
-    static int64_t v = [] { const char* e = getenv("PAMNET_WGRAD_ROWS"); const int k = e ? atoi(e) : ROWS_PER_WG; return (int64_t)(k < MIN_ROWS_PER_WG ? MIN_ROWS_PER_WG : k); }();
-    return v;
-}
+constexpr int64_t first_rows() { return ROWS_PER_WG < MIN_ROWS_PER_WG ? MIN_ROWS_PER_WG : ROWS_PER_WG; }
 inline int64_t plan_chunk(int64_t njobs, const int64_t* rows, int64_t max_slots, int64_t first_chunk = 0) {
     int64_t chunk = first_chunk > 0 ? first_chunk : first_rows();
     for (;; chunk += RB) {
