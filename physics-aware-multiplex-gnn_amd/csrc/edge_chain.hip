@@ -210,9 +210,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void local_edge_fwd_kerne
     const BiasSet<NS> zero_bias = lane_biases<NS>(nullptr, wc);
     const bool kj = blockIdx.y == 0;
     const BiasSet<NS> bz = lane_biases<NS>(kj ? b_kj : b_ji, wc);
-    WSet<NS> fz, fq;                                            // slice producing z (with bias), slice producing the gate
-    load_wset<false>(fz, w.W[kj ? 1 : 0], w.ld[kj ? 1 : 0], wc);
-    load_wset<false>(fq, w.W[kj ? 2 : 3], w.ld[kj ? 2 : 3], wc);
+    // slice producing z (with bias), slice producing the gate.  8-wave geometry (one slice per wave): both as resident bf16x3
+    // pieces, the two GEMMs share one split of every A fragment (edge_core.h "bf16x6"); the paired 4-wave geometry keeps
+    // fp32 MFMAs (four slices as pieces would not fit the registers of two co-resident workgroups).
+    constexpr bool B16 = NS == 1;
+    WSet<B16 ? 0 : NS> fz, fq;
+    WFragB1 bz_, bq_;
+    if constexpr (B16) {
+        load_wfragb1<false>(bz_, w.W[kj ? 1 : 0], w.ld[kj ? 1 : 0], wc);
+        load_wfragb1<false>(bq_, w.W[kj ? 2 : 3], w.ld[kj ? 2 : 3], wc);
+    } else {
+        load_wset<false>(fz, w.W[kj ? 1 : 0], w.ld[kj ? 1 : 0], wc);
+        load_wset<false>(fq, w.W[kj ? 2 : 3], w.ld[kj ? 2 : 3], wc);
+    }
     const float* __restrict__ Pi = w.P[kj ? 1 : 0];
     const float* __restrict__ Pj = w.P[kj ? 3 : 2];
     const Span sp = Span::make<NW>(m, pa, pb, pc, cmt);
@@ -220,13 +230,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void local_edge_fwd_kerne
         const int mt = chunk_mt(sp, row0);
         sweep<MTX, NW>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(rbf, row0 + r, sp.end, DIM, c4)); });
         __syncthreads();
-        AccSet<MTX, NS> acc;
-        acc.zero();
-        mma_set<MTX, NS>(S0, fq, acc, mt);                          // q2 = lin_rbf r   |  q3 = lin_rbf_out r
-        store_set<MTX, NS>(acc, S2, wc, zero_bias, mt);
-        acc.zero();
-        mma_set<MTX, NS>(S0, fz, acc, mt);                          // W_kj,e r + b_kj  |  W_ji,e r + b_ji
-        store_set<MTX, NS>(acc, S1, wc, bz, mt);
+        if constexpr (B16) {
+            AccSet<MTX, NS> accq, accz;
+            accq.zero();
+            accz.zero();
+            mma_b16<MTX, false, 3>(S0, bq_, accq.a[0], bz_, accz.a[0], mt);
+            store_set<MTX, NS>(accq, S2, wc, zero_bias, mt);            // q2 = lin_rbf r   |  q3 = lin_rbf_out r
+            store_set<MTX, NS>(accz, S1, wc, bz, mt);                   // W_kj,e r + b_kj  |  W_ji,e r + b_ji
+        } else {
+            AccSet<MTX, NS> acc;
+            acc.zero();
+            mma_set<MTX, NS>(S0, fq, acc, mt);                          // q2 = lin_rbf r   |  q3 = lin_rbf_out r
+            store_set<MTX, NS>(acc, S2, wc, zero_bias, mt);
+            acc.zero();
+            mma_set<MTX, NS>(S0, fz, acc, mt);                          // W_kj,e r + b_kj  |  W_ji,e r + b_ji
+            store_set<MTX, NS>(acc, S1, wc, bz, mt);
+        }
         __syncthreads();
         sweep<MTX, NW>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
@@ -349,9 +368,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlp2_bwd_kernel(cons
     constexpr int NS = 8 / NW;
     const int wc = wave_col<NW>();
     const BiasSet<NS> zero_bias = lane_biases<NS>(nullptr, wc);
-    WSet<NS> f1, f2;
-    load_wset<true>(f2, W2, DIM, wc);
-    load_wset<true>(f1, W1, DIM, wc);
+    constexpr bool B16 = NS == 1;             // 8-wave geometry: the dX GEMMs on the bf16 matrix pipe (edge_core.h "bf16x6")
+    WSet<B16 ? 0 : NS> f1, f2;
+    WFragB1 b1_, b2_;
+    if constexpr (B16) {
+        load_wfragb1<true>(b2_, W2, DIM, wc);
+        load_wfragb1<true>(b1_, W1, DIM, wc);
+    } else {
+        load_wset<true>(f2, W2, DIM, wc);
+        load_wset<true>(f1, W1, DIM, wc);
+    }
     const Span sp = Span::make<NW>(m, pa, pb, pc, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
@@ -378,7 +404,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlp2_bwd_kernel(cons
         __syncthreads();
         AccSet<MTX, NS> acc;
         acc.zero();
-        mma_set<MTX, NS>(S0, f2, acc, mt);
+        if constexpr (B16) mma_b16<MTX, true, 3>(S0, b2_, acc.a[0], b2_, acc.a[0], mt);
+        else mma_set<MTX, NS>(S0, f2, acc, mt);
         store_set<MTX, NS>(acc, S1, wc, zero_bias, mt);
         __syncthreads();
         {
@@ -398,7 +425,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlp2_bwd_kernel(cons
         }
         __syncthreads();
         acc.zero();
-        mma_set<MTX, NS>(S1, f1, acc, mt);
+        if constexpr (B16) mma_b16<MTX, true, 3>(S1, b1_, acc.a[0], b1_, acc.a[0], mt);
+        else mma_set<MTX, NS>(S1, f1, acc, mt);
         store_set<MTX, NS>(acc, S0, wc, zero_bias, mt);                 // S0 (dz2 tile) was last read before the previous barrier
         __syncthreads();
         {

@@ -220,6 +220,8 @@ template <int NS>
 struct WSet {                                                 // a wave's NS slices of one weight matrix
     WFrag1 s[NS];
 };
+template <>
+struct WSet<0> {};                                            // (placeholder where a kernel holds bf16x3 pieces instead)
 template <bool TRANS, int NS>
 __device__ __forceinline__ void load_wset(WSet<NS>& w, const float* __restrict__ W, int ldw, int wc) {
 #pragma unroll
