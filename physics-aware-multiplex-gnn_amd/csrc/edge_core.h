@@ -310,6 +310,10 @@ struct Mlp2Set {
     const float *W1, *b1, *W2, *b2;
     float *z1, *z2, *y;
 };
+// Both GEMMs run on the bf16 matrix pipe at fp32 accuracy ("bf16x6" above).  8-wave geometry: a wave's slice of each
+// matrix stays resident as bf16x3 pieces.  4-wave geometry (two slices per wave; the riders of the node-chain launches):
+// the pieces of ONE matrix at a time -- a wave's two slices share the split of every A fragment, and a matrix is re-read
+// (16 KB per wave, L2-resident) and re-split per chunk, ~1 us against the ~5 us of matrix-pipe time a 48-row chunk saves.
 template <int MTX, int NW>
 __device__ __forceinline__ void mlp2_fwd_body(const float* __restrict__ x, const Mlp2Set& set, const Span& sp, float* lds) {
     const float* __restrict__ W1 = set.W1;
@@ -324,16 +328,28 @@ __device__ __forceinline__ void mlp2_fwd_body(const float* __restrict__ x, const
     constexpr int NS = 8 / NW;
     const int wc = wave_col<NW>();
     const BiasSet<NS> bv1 = lane_biases<NS>(b1, wc), bv2 = lane_biases<NS>(b2, wc);
-    WSet<NS> f1, f2;
-    load_wset<false>(f1, W1, DIM, wc);
-    load_wset<false>(f2, W2, DIM, wc);
+    WFragB1 r1, r2;                                           // NS == 1: resident pieces of both matrices
+    if constexpr (NS == 1) {
+        load_wfragb1<false>(r1, W1, DIM, wc);
+        load_wfragb1<false>(r2, W2, DIM, wc);
+    }
+    auto gemm = [&](const float* A, const float* W, const WFragB1& resident, AccSet<MTX, NS>& acc, int mt) {
+        acc.zero();
+        if constexpr (NS == 1) {
+            mma_b16<MTX, true, 3>(A, resident, acc.a[0], resident, acc.a[0], mt);
+        } else {
+            WFragB1 wa, wb;
+            load_wfragb1<false>(wa, W, DIM, wc);
+            load_wfragb1<false>(wb, W, DIM, wc + 16);
+            mma_b16<MTX, false, 3>(A, wa, acc.a[0], wb, acc.a[NS - 1], mt);
+        }
+    };
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
         sweep<MTX, NW>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(x, row0 + r, sp.end, DIM, c4)); });
         __syncthreads();
         AccSet<MTX, NS> acc;
-        acc.zero();
-        mma_set<MTX, NS>(S0, f1, acc, mt);
+        gemm(S0, W1, r1, acc, mt);
         store_set<MTX, NS>(acc, S1, wc, bv1, mt);
         __syncthreads();
         sweep<MTX, NW>(mt, [&](int r, int c4) {
@@ -343,8 +359,7 @@ __device__ __forceinline__ void mlp2_fwd_body(const float* __restrict__ x, const
             if (z1 && g < sp.end) stg4(z1, g, DIM, c4, zz);
         });
         __syncthreads();
-        acc.zero();
-        mma_set<MTX, NS>(S1, f2, acc, mt);
+        gemm(S1, W2, r2, acc, mt);
         store_set<MTX, NS>(acc, S0, wc, bv2, mt);
         __syncthreads();
         sweep<MTX, NW>(mt, [&](int r, int c4) {
