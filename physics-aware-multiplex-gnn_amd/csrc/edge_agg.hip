@@ -310,7 +310,10 @@ struct GAggBwd {
 
 // dm[e] = d_agg[i(e)];  dz = dm * ea * SiLU'(z);  dea = dm * SiLU(z);  d_e (+)= dz W_e + dea W_ea;
 // dPi[i] = sum_{e -> i} dz[e]   (the gradient of the target-side node projection, reduced from the LDS tile)
-template <int MTX>
+// PRE (multi-chunk workgroups): the z / ea rows of the NEXT chunk are requested while this chunk's tiles are being reduced and
+// multiplied -- a workgroup is alone on its CU, so without it the memory phase and the GEMM phase of a chunk alternate and
+// the HBM idles during the GEMMs of all 256 workgroups at once.
+template <int MTX, bool PRE = false>
 __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
     __shared__ int sptr[NMAX + 1];
@@ -343,6 +346,14 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
     const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;
     int c0 = nb, par = 0;
     int64_t r0 = ptr[nb];
+    float4 pz[PRE ? NI : 1], pe[PRE ? NI : 1];
+    if (PRE && r0 < re) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            pz[i] = ldg4z(zs, r0 + rr + RPP * i, re, DIM, c4);
+            pe[i] = ldg4z(eas, r0 + rr + RPP * i, re, DIM, c4);
+        }
+    }
     while (c0 < ne) {
         const Chunk ch = plan_chunk(ptr, row_of, c0, r0, ne, re, CAP);
         const int64_t r1 = ch.r1;
@@ -364,14 +375,22 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
                 float4 x = f4zero(), y = f4zero();
                 if (g < r1) {
                     const float4 dm = ldg4(d_agg, row_of[g], DIM, c4);
-                    const float4 zz = ldg4(zs, g, DIM, c4);             // (non-temporal reads of the saves measured slower:
-                    x = f4mul(f4mul(dm, ldg4(eas, g, DIM, c4)), f4dsilu(zz));      //  793 vs 766 us at the PDBbind shape)
+                    const float4 zz = PRE ? pz[PRE ? i : 0] : ldg4(zs, g, DIM, c4);   // (non-temporal reads of the saves
+                    const float4 ee = PRE ? pe[PRE ? i : 0] : ldg4(eas, g, DIM, c4);  //  measured slower: 793 vs 766 us)
+                    x = f4mul(f4mul(dm, ee), f4dsilu(zz));
                     y = f4mul(dm, f4silu(zz));
                     stg4(dz, g, DIM, c4, x);
                     stg4(dea, g, DIM, c4, y);
                 }
                 st_lds4(S0, r, c4, x);
                 st_lds4(S1, r, c4, y);
+            }
+        }
+        if (PRE && r1 < re) {                                  // the next chunk starts at r1: its rows travel during the GEMMs
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                pz[i] = ldg4z(zs, r1 + rr + RPP * i, re, DIM, c4);
+                pe[i] = ldg4z(eas, r1 + rr + RPP * i, re, DIM, c4);
             }
         }
         APROBE(2);
@@ -382,21 +401,26 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
         par ^= 1;
         APROBE(4);
         if (rows > 0) {
+            constexpr bool PREACC = MTX <= 5;                  // (the 8 / 9-tile instantiations have no registers to spare)
+            constexpr bool EARLY = PRE && MTX <= 3;            // ahead of the GEMMs where the registers allow
+            float4 dacc[PREACC ? NI : 1];                      // accumulate operand of the final sweep
+            auto fetch_acc = [&]() {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    int64_t g = r0 + rr + RPP * i;
+                    g = g < r1 ? g : r1 - 1;
+                    dacc[PREACC ? i : 0] = ldg4(d_e, g, DIM, c4);
+                }
+            };
+            if (EARLY && accumulate) fetch_acc();
             AccSet<MTX, 1> acc;
             acc.zero();
             mma_b16<MTX, true, BG>(S0, f1, acc.a[0], f1, acc.a[0], mt);
             mma_b16<MTX, true, BG>(S1, f2, acc.a[0], f2, acc.a[0], mt);
             APROBE(5);
-            constexpr bool PREACC = MTX <= 5;                  // (the 8 / 9-tile instantiations have no registers to spare)
-            float4 dacc[PREACC ? NI : 1];                      // accumulate operand of the final sweep
-            if (PREACC && accumulate) {                        // requested here (the A fragments' registers are free again):
-#pragma unroll                                                 // the two barriers and the accumulator stores cover the latency
-                for (int i = 0; i < NI; ++i) {
-                    int64_t g = r0 + rr + RPP * i;
-                    g = g < r1 ? g : r1 - 1;
-                    dacc[i] = ldg4(d_e, g, DIM, c4);
-                }
-            }
+            // otherwise requested here (the A fragments' registers are free again): the two barriers and the accumulator
+            // stores cover the latency
+            if (PREACC && !EARLY && accumulate) fetch_acc();
             __syncthreads();
             store_set<MTX, 1>(acc, S0, wc, zero_bias, mt);
             __syncthreads();
@@ -572,7 +596,7 @@ extern "C" int pamnet_global_edge_agg_fwd_f32(const float* e, int64_t n_edges, i
         case 3: PAMNET_AGG_FWD(3, true); break;
         case 5: PAMNET_AGG_FWD(5, true); break;
         case 9: PAMNET_AGG_FWD(9, false); break;
-        default: PAMNET_AGG_FWD(8, true); break;
+        default: PAMNET_AGG_FWD(8, true); break;      // (5-tile chunks measured the same in training, 4 % slower in inference)
     }
 #undef PAMNET_AGG_FWD
     PAMNET_LAUNCH_CHECK();
@@ -616,7 +640,10 @@ extern "C" int pamnet_global_edge_agg_bwd_f32(const float* d_agg, int64_t n_edge
         case 3: hipLaunchKernelGGL(global_edge_agg_bwd_kernel<3>, dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
         case 5: hipLaunchKernelGGL(global_edge_agg_bwd_kernel<5>, dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
         case 9: hipLaunchKernelGGL(global_edge_agg_bwd_kernel<9>, dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
-        default: hipLaunchKernelGGL(global_edge_agg_bwd_kernel<8>, dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
+        default:      // several chunks per workgroup: 3-tile chunks with the next chunk's rows in flight (712 us at the PDBbind
+                      // shape against 803 for 8-tile chunks without, 726 for 4-tile chunks with the prefetch)
+            hipLaunchKernelGGL((global_edge_agg_bwd_kernel<3, true>), dim3((unsigned)grid), dim3(WG8), 0, st, a);
+            break;
     }
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
