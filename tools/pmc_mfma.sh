@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/pmc_mfma
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-rooflines > /tmp/pmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-rooflines --no-other-configs > /tmp/pmc_mfma.log 2>&1
 f=$(find /tmp/pmc_mfma -name '*counter_collection.csv' | head -1)
 python - "$f" <<'PY' > $R/gpurun_out/mfma_util.txt
 import csv, sys, collections, re
@@ -16,7 +16,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     key = (r['Dispatch_Id'], k)
     if key not in seen:
         seen.add(key); cnt[k] += 1
-print('# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-rooflines')
+print('# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-rooflines --no-other-configs')
 print('# per-dispatch averages. MFMA busy is summed over the 1024 SIMDs (32 cycles per v_mfma_f32_16x16x4_f32); GRBM_GUI_ACTIVE is summed over the 8 XCDs.')
 print('# mfma_util = MFMA_BUSY / (1024 * GRBM_GUI_ACTIVE / 8): fraction of all matrix pipes busy while the kernel runs (kernels run slower under the counter pass).')
 print('%-62s %6s %14s %14s %10s' % ('kernel', 'calls', 'mfma_busy', 'gui_active/8', 'mfma_util'))
