@@ -219,6 +219,9 @@ typedef struct pamnet_graph_desc {
     int32_t aggregate_at_query;   /* RNA: flow == 'target_to_source' (the global layer aggregates at the kNN query) */
     int32_t knn_k;                /* RNA: neighbours per query (models.py:143: 50) */
     float cutoff_l, cutoff_g;
+    int32_t mol_local;            /* QM9: 1 = the molecule-local builder (pamnet_mol_graph_*: the caller vouches for <= 64 atoms,
+                                     <= 256 directed bonds per molecule and bonds grouped by molecule in batch order; a batch
+                                     that is not so is flagged as a local-edge size mismatch) */
 } pamnet_graph_desc;
 enum {
     PAMNET_GF_NODE_GRAPH = 0, /* int32 [n] */
@@ -237,6 +240,39 @@ enum {
     PAMNET_GF_CUTS,           /* int32 [<= 257] node-aligned work split of the fused global-edge kernels */
     PAMNET_GRAPH_FIELDS
 };
+/* Molecule-local graph construction for the QM9 schema (positions + bond list given; models.py:62-98, 104-118, 165-177) --
+ * bond CSR by target + bond lengths, triplet / pair rows + angles, radius graph at cutoff_g, and (need_grad) the transposed
+ * index lists of the backward -- one wavefront per molecule, two launches instead of the ~14 of the step-by-step entry points
+ * above, bit-identical arrays.  For batches of small molecules: <= 64 atoms and <= 256 directed bonds per molecule; bonds
+ * grouped by molecule in batch order (torch_geometric collation, pamnet_collate_f32) with both ends in one molecule; no
+ * self loops.  gptr [n_graphs + 1], src / dst int32 [n_bonds] as pamnet_ingest_indices_i32 returns them.
+ *   count: mol_tot [n_graphs, 4] = (global edges, triplet + pair rows, first bond, violation bits) per molecule;
+ *          totals [4] (zeroed by the caller) += (global edges, triplet + pair rows, violation bits (OR), bonds) over the
+ *          molecules without a violation (bits: 1 atoms, 2 bonds, 4 a bond leaving its molecule / bonds not grouped);
+ *   fill:  every array of `out`; eg_cap / tp_cap = what the buffers hold (writes beyond are dropped, pointers clamped).
+ * Array sizes: *_ptr over nodes [n + 1] (g, l, lT) or over bonds [n_bonds + 1] (t, tT); g_* / gT_perm [eg_cap];
+ * l_* / lT_perm [n_bonds]; t_* / tT_perm [tp_cap].  gT_ptr = g_ptr (a radius graph is symmetric: the transposed list is the
+ * reverse-edge index).  The transposed lists are written only with need_grad. */
+typedef struct pamnet_mol_graph_out {
+    int32_t *g_ptr, *g_row, *g_col;
+    float* g_dist;
+    int32_t* gT_perm;
+    int32_t *l_ptr, *l_row, *l_col;
+    float* l_dist;
+    int32_t *lT_ptr, *lT_perm;
+    int32_t *t_ptr, *t_row, *t_col;
+    float* t_angle;
+    int32_t* t_kind;
+    int32_t *tT_ptr, *tT_perm;
+} pamnet_mol_graph_out;
+int pamnet_mol_graph_count_i32(const float* pos, const int32_t* gptr, int64_t n, int64_t n_graphs, const int32_t* src,
+                               const int32_t* dst, int64_t n_bonds, float cutoff_g, int32_t with_triplets, int32_t* mol_tot,
+                               int32_t* totals, pamnet_stream_t stream);
+int pamnet_mol_graph_fill_i32(const float* pos, const int32_t* gptr, int64_t n, int64_t n_graphs, const int32_t* src,
+                              const int32_t* dst, int64_t n_bonds, float cutoff_g, int32_t with_triplets, int32_t need_grad,
+                              const int32_t* mol_tot, int64_t eg_cap, int64_t tp_cap, const pamnet_mol_graph_out* out,
+                              pamnet_stream_t stream);
+
 int pamnet_graph_plan(const pamnet_graph_desc* desc, int64_t* layout /* [PAMNET_GRAPH_FIELDS] */, int64_t* arena_ints);
 int pamnet_graph_build_i32(const pamnet_graph_desc* desc, int32_t* arena, float* sbf /* [tp, 42], nullable */,
                            pamnet_stream_t stream);

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "geom_core.h"
 
 namespace {
 
@@ -293,14 +294,6 @@ __global__ __launch_bounds__(SMALL_THREADS) void csr_small_kernel(const int32_t*
     }
 }
 
-__device__ __forceinline__ float dist3(const float* __restrict__ pos, int64_t a, int64_t b) {
-    const float dx = pos[3 * a + 0] - pos[3 * b + 0];
-    const float dy = pos[3 * a + 1] - pos[3 * b + 1];
-    const float dz = pos[3 * a + 2] - pos[3 * b + 2];
-    // same association as (pos_i - pos_j).pow(2).sum(-1).sqrt() (models.py:65); no fma contraction
-    const float s = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-    return __fsqrt_rn(s);
-}
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void radius_kernel(const float* __restrict__ pos,
@@ -692,12 +685,6 @@ __global__ __launch_bounds__(256) void triplet_count_kernel(const int32_t* __res
     tpcount[e] = t + (lptr[i + 1] - lptr[i]);                                     // + edges j'->i, incl. e itself
 }
 
-__device__ __forceinline__ float angle3(float ax, float ay, float az, float bx, float by, float bz) {
-    // atan2(|a x b|, a.b)  (models.py:165-168)
-    const float dot = ax * bx + ay * by + az * bz;
-    const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
-    return atan2f(sqrtf(cx * cx + cy * cy + cz * cz), dot);
-}
 
 // rows of edge e: [tp_ptr[e], tp_ptr[e+1]) = its triplets (kind 0) followed by its pairs (kind 1)
 __global__ __launch_bounds__(256) void triplet_fill_kernel(const float* __restrict__ pos,

@@ -154,6 +154,7 @@ int run(Run& r) {
     // counters of the counting sorts (rows + 2 each): bond CSR / local transposition, transposed global, transposed local,
     // transposed triplet / pair rows
     const int64_t cur_a = r.take(n + 2), cur_b = r.take(n + 2), cur_c = r.take(n + 2), cur_t = r.take(el + 2);
+    const int64_t mol_totals = r.take(4);                     // batch totals of the molecule-local builder (QM9)
     const int64_t z1 = r.off;
     if (!r.dry) {
         const hipError_t e = hipMemsetAsync(r.I(z0), 0, sizeof(int32_t) * (size_t)(z1 - z0), as_stream(r.stream));
@@ -179,7 +180,37 @@ int run(Run& r) {
         return clamp(r, t_ptr_raw, el + 1, tp, t_ptr);
     };
 
-    if (d.schema == PAMNET_SCHEMA_QM9) {
+    int64_t tT_ptr = -1, tT_perm = -1;
+    const bool mol = d.schema == PAMNET_SCHEMA_QM9 && d.mol_local != 0;
+    if (mol) {
+        // molecule-local builder (graph_mol.hip): two launches write every index / geometry array of the batch
+        l_row = r.take(el), l_col = r.take(el), l_dist = r.take(el);
+        l_ptr = r.take(n + 1), g_ptr = r.take(n + 1), t_ptr = r.take(el + 1);
+        if (grad) {
+            gT_ptr = g_ptr, gT_perm = r.take(eg);
+            lT_ptr = r.take(n + 1), lT_perm = r.take(el);
+            tT_ptr = r.take(el + 1), tT_perm = r.take(tp);
+        }
+        const int64_t mol_tot = r.take(4 * ng);
+        GO(pamnet_mol_graph_count_i32(pos, gptr, n, ng, r.I(src0), r.I(dst0), d.n_bonds, d.cutoff_g, wt, r.I(mol_tot),
+                                      r.I(mol_totals), r.stream));
+        pamnet_mol_graph_out o{};
+        if (!r.dry) {
+            o.g_ptr = r.I(g_ptr), o.g_row = r.I(g_row), o.g_col = r.I(g_col), o.g_dist = r.F(g_dist);
+            o.l_ptr = r.I(l_ptr), o.l_row = r.I(l_row), o.l_col = r.I(l_col), o.l_dist = r.F(l_dist);
+            o.t_ptr = r.I(t_ptr), o.t_row = r.I(t_row), o.t_col = r.I(t_col), o.t_angle = r.F(t_angle), o.t_kind = r.I(t_kind);
+            if (grad) {
+                o.gT_perm = r.I(gT_perm), o.lT_ptr = r.I(lT_ptr), o.lT_perm = r.I(lT_perm);
+                o.tT_ptr = r.I(tT_ptr), o.tT_perm = r.I(tT_perm);
+            }
+        }
+        GO(pamnet_mol_graph_fill_i32(pos, gptr, n, ng, r.I(src0), r.I(dst0), d.n_bonds, d.cutoff_g, wt, grad ? 1 : 0,
+                                     r.I(mol_tot), eg, tp, &o, r.stream));
+        // device-side totals against the host's sizes; a molecule outside the builder's limits counts no bonds
+        chk_ptr[0] = r.dry ? nullptr : r.I(mol_totals), chk_val[0] = eg;
+        chk_ptr[1] = r.dry ? nullptr : r.I(mol_totals + 3), chk_val[1] = el;
+        chk_ptr[2] = r.dry ? nullptr : r.I(mol_totals + 1), chk_val[2] = tp;
+    } else if (d.schema == PAMNET_SCHEMA_QM9) {
         // bond list in CSR order of its targets + bond lengths (j, i = edge_index; models.py:64-65); no self loops assumed
         // (the ingest launch noted them; a store strips them at ingestion)
         l_row = r.take(el), l_col = r.take(el), l_dist = r.take(el);
@@ -266,15 +297,16 @@ int run(Run& r) {
     }
 
     // ---- triplets / pairs + angles, rows grouped by target edge (models.py:68-98, 165-177)
-    GO(pamnet_triplet_fill_f32(pos, r.I(l_ptr), r.I(l_col), r.I(l_row), el, wt, r.I(t_ptr), r.I(t_col), r.I(t_row), r.F(t_angle),
-                               r.I(t_kind), tp, r.stream));
+    if (!mol) {
+        GO(pamnet_triplet_fill_f32(pos, r.I(l_ptr), r.I(l_col), r.I(l_row), el, wt, r.I(t_ptr), r.I(t_col), r.I(t_row),
+                                   r.F(t_angle), r.I(t_kind), tp, r.stream));
+    }
     // ---- the sizes the host assumed against the device-side counts + the input-validity flag: one launch
     GO(pamnet_check_sizes_i32(3, chk_ptr, chk_val, nullptr, d.schema == PAMNET_SCHEMA_QM9 ? loops : nullptr,
                               const_cast<int32_t*>(flag), r.stream));
 
     // ---- index structures of the backward gathers (transposed CSRs)
-    int64_t tT_ptr = -1, tT_perm = -1;
-    if (grad) {
+    if (grad && !mol) {
         if (d.schema != PAMNET_SCHEMA_RNA) {          // radius graph: its own pointer + the reverse-edge index
             gT_ptr = g_ptr;
             gT_perm = r.take(eg);

@@ -178,7 +178,7 @@ class _PAMNetBase(nn.Module):
                           getattr(data, 'pos', None), getattr(data, 'edge_index', None), num_graphs=ng,
                           need_grad=torch.is_grad_enabled(), with_triplets=not self.small,
                           n_types=self.embeddings.size(0) if hasattr(self, 'embeddings') else None,
-                          sizes=self._sizes_of(data), default_basis=self.sbf.default)
+                          sizes=self._sizes_of(data), default_basis=self.sbf.default, mol_local=self._mol_local_of(data))
         if g.check is not None:                          # zero-host-sync path: the flag word waits for verify()
             self._pending_checks.append(g.check)
         g.need_grad = torch.is_grad_enabled()
@@ -195,6 +195,15 @@ class _PAMNetBase(nn.Module):
             from pamnet_amd.store import size_key
             return sz.get(size_key(self))
         return sz
+
+    def _mol_local_of(self, data):
+        """True: a store vouches that this batch is inside the molecule-local graph builder's contract (graph.build_graph);
+        None: unknown (plain tensors -- found out on the device); False: no."""
+        ml = getattr(data, 'mol_local', None)
+        if isinstance(ml, dict):
+            from pamnet_amd.store import size_key
+            return ml.get(size_key(self))
+        return ml
 
     def verify(self):
         """Check the device-side flag words of the forwards since the last call that ran without a host round trip

@@ -158,6 +158,14 @@ class Transpose(object):
         self.rows = rows
 
 
+class _Given(object):
+    """Transposed CSR whose (ptr, perm) were written by the launch that built the graph (molecule-local builder)."""
+    __slots__ = ('ptr', 'perm', 'rows')
+
+    def __init__(self, ptr, perm, rows):
+        self.ptr, self.perm, self.rows = ptr, perm, rows
+
+
 class SymmetricTranspose(object):
     """Transposed CSR of a symmetric graph (a radius graph: rows = targets, ascending columns): the pointer array is
     the graph's own, the permutation is the reverse-edge index -- one bisection per edge (pamnet_reverse_edges_i32)
@@ -390,6 +398,10 @@ def raise_for_flag(bits):
 
 
 ENGINE = __import__('os').environ.get('PAMNET_GRAPH_ENGINE', '1') != '0'    # measurement aid: 0 = the step-by-step path
+# QM9 schema, small molecules: the molecule-local builder (csrc/graph_mol.hip, two launches); False = the step-by-step
+# launches (the tests compare the two bit by bit)
+MOL_LOCAL = True
+MOL_ATOMS, MOL_BONDS = 64, 256                       # per-molecule limits of the builder (graph_mol.hip)
 
 
 class _Facade(object):
@@ -437,7 +449,7 @@ _SCHEMA = {'QM9': 0, 'PDBbind': 1, 'rna': 2}
 
 
 def _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_index, n_graphs, need_grad, knn_k,
-                  with_triplets, n_types, sizes, default_basis=True):
+                  with_triplets, n_types, sizes, default_basis=True, mol_local=False):
     """The zero-host-sync graph as one engine call, or None when this batch does not qualify (empty lists, layouts the
     ingest launch does not read): the step-by-step path below then builds it."""
     import ctypes
@@ -467,6 +479,7 @@ def _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_ind
             return None
         pos = pos if (pos.dtype == torch.float32 and pos.is_contiguous()) else pos.to(torch.float32).contiguous()
         d.schema, d.n_bonds = 0, el
+        d.mol_local = 1 if (mol_local and MOL_LOCAL) else 0
         d.types, d.types_kind, d.types_stride = xcol.data_ptr(), _KINDS[xcol.dtype], (xcol.stride(0) if n > 1 else 1)
         d.pos, d.edge_src, d.edge_dst, d.edge_kind = pos.data_ptr(), es.data_ptr(), ed.data_ptr(), _KINDS[edge_index.dtype]
         keep += [xcol, pos, edge_index]
@@ -535,19 +548,78 @@ def _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_ind
     return g
 
 
+def _mol_local_graph(g, pos, ing, cutoff_g, with_triplets, need_grad):
+    """QM9 schema, plain tensors: the molecule-local builder (csrc/graph_mol.hip) -- count launch, ONE host round trip for
+    the sizes / validity / qualification, fill launch.  Fills `g` and returns True; False when the batch does not qualify
+    (a molecule over the builder's limits, bonds not grouped by molecule, self loops): nothing of `g` was touched."""
+    import ctypes
+    node_graph, gptr, _, src0, dst0, flag, loops = ing
+    dev = pos.device
+    n, ng, m = g.n, g.n_graphs, int(src0.numel())
+    st = lib.stream_of(pos)
+    mol_tot = _i32(4 * ng, dev)
+    totals = torch.zeros(4, dtype=I32, device=dev)
+    wt = 1 if with_triplets else 0
+    lib.call('pamnet_mol_graph_count_i32', lib.ptr(pos), lib.ptr(gptr), n, ng, lib.ptr(src0), lib.ptr(dst0), m, float(cutoff_g),
+             wt, lib.ptr(mol_tot), lib.ptr(totals), st)
+    eg, tp, viol, counted, bad, lp_ = host_ints(totals[0], totals[1], totals[2], totals[3], flag, loops)
+    if bad:
+        _raise_bad_inputs()
+    if viol or lp_ or counted != m or eg <= 0 or tp <= 0:
+        return False
+    def carve(sizes):                                 # one int32 allocation, 16-byte aligned slices
+        offs, tot = [], 0
+        for k in sizes:
+            offs.append(tot)
+            tot += (k + 3) // 4 * 4
+        buf = _i32(tot, dev)
+        return [buf[o:o + k] for o, k in zip(offs, sizes)]
+
+    (g_ptr, l_ptr, lT_ptr, l_row, l_col, lT_perm, t_ptr, tT_ptr, g_row, g_col, gT_perm, t_row, t_col, t_kind,
+     tT_perm) = carve([n + 1] * 3 + [m] * 3 + [m + 1] * 2 + [eg] * 3 + [tp] * 4)
+    l_dist, g_dist, t_angle = _f32(m, dev), _f32(eg, dev), _f32(tp, dev)
+    o = lib.MolGraphOut()
+    o.g_ptr, o.g_row, o.g_col, o.g_dist = g_ptr.data_ptr(), g_row.data_ptr(), g_col.data_ptr(), g_dist.data_ptr()
+    o.l_ptr, o.l_row, o.l_col, o.l_dist = l_ptr.data_ptr(), l_row.data_ptr(), l_col.data_ptr(), l_dist.data_ptr()
+    o.t_ptr, o.t_row, o.t_col = t_ptr.data_ptr(), t_row.data_ptr(), t_col.data_ptr()
+    o.t_angle, o.t_kind = t_angle.data_ptr(), t_kind.data_ptr()
+    if need_grad:
+        o.gT_perm, o.lT_ptr, o.lT_perm = gT_perm.data_ptr(), lT_ptr.data_ptr(), lT_perm.data_ptr()
+        o.tT_ptr, o.tT_perm = tT_ptr.data_ptr(), tT_perm.data_ptr()
+    lib.call('pamnet_mol_graph_fill_i32', lib.ptr(pos), lib.ptr(gptr), n, ng, lib.ptr(src0), lib.ptr(dst0), m, float(cutoff_g),
+             wt, 1 if need_grad else 0, lib.ptr(mol_tot), eg, tp, ctypes.addressof(o), st)
+    g.loops = loops
+    g.pos = pos
+    g.glob, g.dist_g = CSR(g_ptr, g_row, g_col), g_dist
+    g.loc, g.dist_l = CSR(l_ptr, l_row, l_col), l_dist
+    g.tp = CSR(t_ptr, t_row, t_col)
+    g.tp_angle, g.tp_kind = t_angle, t_kind
+    g.glob_T = g.loc_T = g.tp_T = _NoTranspose
+    if need_grad:
+        g.glob_T = _Given(g_ptr, gT_perm, n)
+        g.loc_T = _Given(lT_ptr, lT_perm, n)
+        g.tp_T = _Given(tT_ptr, tT_perm, max(m, 1))
+    return True
+
+
 def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_index=None, num_graphs=None,
-                need_grad=True, knn_k=50, with_triplets=True, n_types=None, sizes=None, default_basis=True):
+                need_grad=True, knn_k=50, with_triplets=True, n_types=None, sizes=None, default_basis=True, mol_local=None):
     """Graph-construction part of PAMNet.forward (models.py:104-177).  Returns a Graph.
 
     `sizes`: (global edges, local edges, triplet + pair rows) of this batch as host integers -- what a batch collated by
     pamnet_amd.store.MoleculeStore carries.  With them no value is read back from the device: buffers are sized from
     the host numbers, the fills are capped by them, and one launch compares them with the device-side counts (and
     folds in the input-validity flag); the result waits in `g.check` (an int32 device scalar) for the caller's next
-    synchronisation (PAMNet.verify).  Without them: one host round trip for the sizes and the flag."""
+    synchronisation (PAMNet.verify).  Without them: one host round trip for the sizes and the flag.
+
+    `mol_local` (QM9 schema): True = the caller vouches that every molecule is within the molecule-local builder's limits
+    (MOL_ATOMS / MOL_BONDS) with its bonds grouped by molecule (a resident store knows); None = try it when the
+    average molecule is small (a batch that does not qualify is found out with the sizes' round trip and takes the
+    step-by-step launches); False = never."""
     dev = batch.device
     if sizes is not None and num_graphs is not None:
         eng = _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_index, num_graphs, need_grad, knn_k,
-                            with_triplets, n_types, sizes, default_basis)
+                            with_triplets, n_types, sizes, default_basis, mol_local=bool(mol_local))
         if eng is not None:
             return eng
     g = Graph()
@@ -597,6 +669,11 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             return lp_, src_, dst_, _triplet_ptr(lp_, src_, dst_, with_triplets)
 
         ei = edge_index
+        if (sizes is None and ing is not None and MOL_LOCAL and mol_local is not False and ei.size(1) > 0
+                and n <= MOL_ATOMS * g.n_graphs // 2):
+            done = _mol_local_graph(g, pos, ing, cutoff_g, with_triplets, need_grad)
+            if done:
+                return g
         lp, l_src, l_dst, tp_ptr = bonds(ei, None if ing is None else (ing[3], ing[4]))
         gptr_g = radius_count(pos, node_graph, g.gptr, cutoff_g)               # symmetric: agg = query, other = nbr
         if ing is not None:                       # validity and self loops were noted by the ingest launch

@@ -134,7 +134,13 @@ class GraphDesc(ctypes.Structure):
                 ('schema', ctypes.c_int32), ('batch_kind', ctypes.c_int32), ('types_kind', ctypes.c_int32),
                 ('edge_kind', ctypes.c_int32), ('with_triplets', ctypes.c_int32), ('need_grad', ctypes.c_int32),
                 ('aggregate_at_query', ctypes.c_int32), ('knn_k', ctypes.c_int32),
-                ('cutoff_l', ctypes.c_float), ('cutoff_g', ctypes.c_float)]
+                ('cutoff_l', ctypes.c_float), ('cutoff_g', ctypes.c_float), ('mol_local', ctypes.c_int32)]
+
+
+class MolGraphOut(ctypes.Structure):
+    """pamnet_mol_graph_out (include/pamnet_hip.h): output arrays of the molecule-local graph builder."""
+    _fields_ = [(k, _P) for k in ('g_ptr', 'g_row', 'g_col', 'g_dist', 'gT_perm', 'l_ptr', 'l_row', 'l_col', 'l_dist',
+                                  'lT_ptr', 'lT_perm', 't_ptr', 't_row', 't_col', 't_angle', 't_kind', 'tT_ptr', 'tT_perm')]
 
 
 # field indices of the engine's arena layout (enum PAMNET_GF_* in include/pamnet_hip.h, same order)

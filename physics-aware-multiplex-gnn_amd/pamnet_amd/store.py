@@ -92,6 +92,7 @@ class MoleculeStore(object):
         self.nptr_d = torch.from_numpy(self.nptr.astype(np.int32)).to(dev)
         self.eptr_d = torch.from_numpy(self.eptr.astype(np.int32)).to(dev)
         self._counts = {}                  # size_key(model) -> per-graph (E_g, E_l, T+P) arrays
+        self._mol_local = {}               # size_key(model) -> every molecule fits the molecule-local graph builder
 
     def __len__(self):
         return len(self.n_nodes)
@@ -144,6 +145,10 @@ class MoleculeStore(object):
             el[a:b] = (pl[1:] - pl[:-1]).cpu().numpy()
             tp[a:b] = (pt[1:] - pt[:-1]).cpu().numpy()
         self._counts[key] = (eg, el, tp)
+        # QM9 schema: every molecule inside the molecule-local graph builder's limits (csrc/graph_mol.hip)?  Collation keeps a
+        # molecule's bonds together and in batch order, self loops were stripped at ingestion: the rest of its contract.
+        self._mol_local[key] = bool(key[0] == 'QM9' and m > 0 and self.n_nodes.max() <= G.MOL_ATOMS
+                                    and el.max() <= G.MOL_BONDS)
         return eg, el, tp
 
     def prepare_for(self, *models):
@@ -193,4 +198,5 @@ class MoleculeStore(object):
         if with_sizes:
             bt.sizes = {key: (int(eg[idx].sum()), int(el[idx].sum()), int(tp[idx].sum()))
                         for key, (eg, el, tp) in self._counts.items()}
+            bt.mol_local = self._mol_local
         return bt

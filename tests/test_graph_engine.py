@@ -40,11 +40,33 @@ def _case(kind, dev):
     return b.to(dev), dict(dataset='rna_x', cutoff_l=2.6, cutoff_g=20.0, flow=flow, n_types=3)
 
 
-def _build(b, kw, need_grad, with_triplets, sizes=None):
+def _build(b, kw, need_grad, with_triplets, sizes=None, mol_local=None):
     from pamnet_amd import graph as G
     return G.build_graph(kw['dataset'], kw['cutoff_l'], kw['cutoff_g'], kw['flow'], b.x, b.batch, getattr(b, 'pos', None),
                          getattr(b, 'edge_index', None), num_graphs=b.num_graphs, need_grad=need_grad,
-                         with_triplets=with_triplets, n_types=kw['n_types'], sizes=sizes)
+                         with_triplets=with_triplets, n_types=kw['n_types'], sizes=sizes, mol_local=mol_local)
+
+
+def _same_graph(a_g, c_g, need_grad, kw, tag):
+    for name, sub in FIELDS:
+        a, c = getattr(a_g, name), getattr(c_g, name)
+        if sub is None:
+            ok = torch.equal(a, c) if isinstance(a, torch.Tensor) else a == c
+            assert ok, (tag, name)
+            continue
+        if name.endswith('_T') and not need_grad:
+            assert a.ptr is None and c.ptr is None
+            continue
+        for f in sub:
+            assert torch.equal(getattr(a, f), getattr(c, f)), (tag, name, f)
+        if hasattr(a, 'm') and hasattr(c, 'm'):
+            assert a.m == c.m and a.rows == c.rows
+    assert a_g.n_trip == c_g.n_trip and a_g.n_pair == c_g.n_pair
+    assert torch.equal(a_g.pos, c_g.pos)
+    if kw['dataset'] == 'PDBbind':
+        assert torch.equal(a_g.sign, c_g.sign)
+    if kw['n_types'] is not None:
+        assert torch.equal(a_g.types, c_g.types)
 
 
 FIELDS = [('n', None), ('n_graphs', None), ('node_graph', None), ('gptr', None), ('dist_g', None), ('dist_l', None),
@@ -75,25 +97,7 @@ def test_engine_graph_equals_step_by_step_graph(dev, kind, need_grad, with_tripl
     torch.cuda.synchronize()
     G.raise_for_flag(G.read_flags([eng.check]))
     for other in (ref, old):
-        for name, sub in FIELDS:
-            a, c = getattr(eng, name), getattr(other, name)
-            if sub is None:
-                ok = torch.equal(a, c) if isinstance(a, torch.Tensor) else a == c
-                assert ok, (kind, name)
-                continue
-            if name.endswith('_T') and not need_grad:
-                assert a.ptr is None and c.ptr is None
-                continue
-            for f in sub:
-                assert torch.equal(getattr(a, f), getattr(c, f)), (kind, name, f)
-            if hasattr(a, 'm') and hasattr(c, 'm'):
-                assert a.m == c.m and a.rows == c.rows
-        assert eng.n_trip == other.n_trip and eng.n_pair == other.n_pair
-        assert torch.equal(eng.pos, other.pos)
-        if kw['dataset'] == 'PDBbind':
-            assert torch.equal(eng.sign, other.sign)
-        if kw['n_types'] is not None:
-            assert torch.equal(eng.types, other.types)
+        _same_graph(eng, other, need_grad, kw, kind)
     assert torch.equal(G.spherical_basis(eng, kw['cutoff_l']), ref_sbf)
 
 
@@ -196,3 +200,125 @@ def test_engine_forward_is_a_handful_of_host_calls(dev):
     graph_calls = [c for c in calls if c.startswith('pamnet_graph_')]
     assert graph_calls == ['pamnet_graph_plan', 'pamnet_graph_build_i32'], calls
     assert len(calls) <= 12, calls                    # collate, plan, build, 3 embeddings, workspace, stack, fuse+pool, ...
+
+
+# ---- the molecule-local builder (csrc/graph_mol.hip): QM9 schema, one wavefront per molecule, two launches -----------------
+def _qm9_case(name, dev):
+    from pamnet_amd import synth
+    kw = dict(dataset='QM9', cutoff_l=5.0, cutoff_g=5.0, flow='source_to_target', n_types=5)
+    if name == 'batch128':
+        return synth.qm9_batch(0, 0, 128).to(dev), kw
+    if name == 'ragged':
+        return _case('qm9_ragged', dev)
+    if name == 'tight_cutoff':                      # a global cutoff that leaves atoms without neighbours
+        kw = dict(kw, cutoff_g=1.2)
+        return synth.qm9_batch(7, 0, 16).to(dev), kw
+    if name == 'asymmetric_bonds':                  # one direction of some bonds only, duplicates: user-supplied lists are arbitrary
+        b = synth.qm9_batch(3, 0, 6)
+        ei = b.edge_index
+        keep = torch.ones(ei.size(1), dtype=torch.bool)
+        keep[::5] = False
+        ei = torch.cat([ei[:, keep], ei[:, :3]], 1)
+        order = torch.argsort(b.batch[ei[1]], stable=True)          # grouped by molecule, any order inside
+        b.edge_index = ei[:, order].contiguous()
+        return b.to(dev), kw
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize('name', ['batch128', 'ragged', 'tight_cutoff', 'asymmetric_bonds'])
+@pytest.mark.parametrize('need_grad', [True, False])
+@pytest.mark.parametrize('with_triplets', [True, False])
+def test_molecule_local_builder_equals_step_by_step_graph(dev, name, need_grad, with_triplets):
+    """Every index / geometry array bit for bit, plain tensors (one host round trip) and engine (none)."""
+    from pamnet_amd import graph as G
+    b, kw = _qm9_case(name, dev)
+    saved = G.MOL_LOCAL
+    try:
+        G.MOL_LOCAL = False
+        ref = _build(b, kw, need_grad, with_triplets)                       # step-by-step launches
+        sizes = (ref.glob.m, ref.loc.m, ref.tp.m)
+        G.MOL_LOCAL = True
+        calls = []
+        from pamnet_amd import lib
+        orig = lib.call
+        lib.call = lambda nm, *a: (calls.append(nm), orig(nm, *a))[1]
+        try:
+            plain = _build(b, kw, need_grad, with_triplets)                 # count launch, round trip, fill launch
+            eng = _build(b, kw, need_grad, with_triplets, sizes, mol_local=True)
+        finally:
+            lib.call = orig
+    finally:
+        G.MOL_LOCAL = saved
+    assert calls.count('pamnet_mol_graph_fill_i32') == 1 and 'pamnet_radius_fill_i32' not in calls, calls
+    assert isinstance(eng, G.EngineGraph) and not isinstance(plain, G.EngineGraph)
+    torch.cuda.synchronize()
+    G.raise_for_flag(G.read_flags([eng.check]))
+    _same_graph(plain, ref, need_grad, kw, name + ':plain')
+    _same_graph(eng, ref, need_grad, kw, name + ':engine')
+    assert torch.equal(G.spherical_basis(eng, kw['cutoff_l']), G.spherical_basis(ref, kw['cutoff_l']))
+
+
+def test_molecule_local_builder_declines_what_it_cannot_hold(dev):
+    """Plain tensors: bonds not grouped by molecule, a bond across molecules, a molecule over 64 atoms -> the step-by-step
+    launches build the graph (same arrays as with the builder switched off).  Engine with the caller's word for it: the
+    batch is flagged (local-edge mismatch), nothing is written out of bounds."""
+    from pamnet_amd import graph as G, synth
+    kw = dict(dataset='QM9', cutoff_l=5.0, cutoff_g=5.0, flow='source_to_target', n_types=5)
+    base = synth.qm9_batch(11, 0, 12)
+    cases = {}
+    sh = synth.qm9_batch(11, 0, 12)
+    perm = torch.randperm(sh.edge_index.size(1), generator=torch.Generator().manual_seed(0))
+    sh.edge_index = sh.edge_index[:, perm].contiguous()
+    cases['shuffled'] = sh
+    big = synth.collate([dict(x=np.zeros(70, np.float32), pos=np.random.RandomState(0).rand(70, 3).astype(np.float32) * 6,
+                              edge_index=np.stack([np.arange(69), np.arange(1, 70)]).astype(np.int64),
+                              y=np.float32(0.0)), synth.qm9_molecule(11, 1)])
+    big.edge_index = torch.cat([big.edge_index, big.edge_index.flip(0)], 1)
+    order = torch.argsort(big.batch[big.edge_index[1]], stable=True)
+    big.edge_index = big.edge_index[:, order].contiguous()
+    cases['big'] = big
+    for name, b in cases.items():
+        b = b.to(dev)
+        saved = G.MOL_LOCAL
+        try:
+            G.MOL_LOCAL = False
+            ref = _build(b, kw, True, True)
+            G.MOL_LOCAL = True
+            got = _build(b, kw, True, True)
+            _same_graph(got, ref, True, kw, name)
+            eng = _build(b, kw, True, True, (ref.glob.m, ref.loc.m, ref.tp.m), mol_local=True)
+        finally:
+            G.MOL_LOCAL = saved
+        torch.cuda.synchronize()
+        bits = G.read_flags([eng.check])
+        assert bits & 4, (name, bits)
+        with pytest.raises(G.GraphCheckError):
+            G.raise_for_flag(bits)
+    del base
+
+
+def test_store_batches_take_the_molecule_local_builder(dev):
+    """A QM9-schema store vouches for its molecules: the engine call of its batches runs the two-launch builder, the model's
+    outputs and gradients are bitwise those of the step-by-step graph."""
+    import models
+    from pamnet_amd import graph as G, store as S, synth
+    graphs = [synth.qm9_molecule(2, i) for i in range(48)]
+    torch.manual_seed(3)
+    model = models.PAMNet(models.Config(dataset='QM9', dim=128, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)).to(dev)
+    st = S.MoleculeStore(graphs, dev).prepare_for(model)
+    assert st._mol_local[S.size_key(model)] is True
+    res = []
+    saved = G.MOL_LOCAL
+    try:
+        for on in (False, True):
+            G.MOL_LOCAL = on
+            b = st.collate(list(range(5, 37)))
+            model.zero_grad()
+            out = model(b)
+            (out * torch.arange(1, out.numel() + 1, device=dev)).sum().backward()
+            model.verify()
+            res.append((out.detach().clone(), [p.grad.clone() for p in model.parameters() if p.grad is not None]))
+    finally:
+        G.MOL_LOCAL = saved
+    assert torch.equal(res[0][0], res[1][0])
+    assert all(torch.equal(a, c) for a, c in zip(res[0][1], res[1][1]))

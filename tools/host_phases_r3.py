@@ -65,7 +65,16 @@ wrap(tr, '_throttle', 'throttle')
 wrap(tr, 'prefetch', 'prefetch(total)')
 
 
+plain = len(sys.argv) > 2 and sys.argv[2] == 'plain'          # plain tensors (the reference calling convention), resident
+if plain:
+    plain_batches = [synth.collate([graphs[j] for j in ix]).to(dev) for ix in idx]
+
+
 def steps(n):
+    if plain:
+        for i in range(n):
+            tr.step(plain_batches[i % 4], next_data=plain_batches[(i + 1) % 4])
+        return
     nxt = st.collate(idx[0])
     for i in range(n):
         cur, nxt = nxt, st.collate(idx[(i + 1) % 4])
@@ -81,11 +90,13 @@ steps(n)
 host = (T() - t0) / n * 1e3
 torch.cuda.synchronize()
 wall = (T() - t0) / n * 1e3
-print('%s training step through the store: host loop %.3f ms/step, wall %.3f ms/step' % (kind, host, wall))
+print('%s training step %s: host loop %.3f ms/step, wall %.3f ms/step' % (kind, 'on plain tensors' if plain else 'through the store', host, wall))
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
     print('   %-18s %7.3f ms/step' % (k, v / n * 1e3))
 print('   (graph / sbf / the first collate are inside prefetch(total); "backward" includes the input stage backward)')
 
+if plain:
+    sys.exit(0)
 # forward only, un-pipelined
 with torch.no_grad():
     for i in range(5):

@@ -25,6 +25,9 @@ def main(path, marker='adam_ema_kernel'):
         span = int(seg[-1]['End_Timestamp']) - int(seg[0]['Start_Timestamp'])
         spans.append((busy, span, a, b))
     spans = spans[5:]                      # skip warm-up
+    cnt = sorted(s[3] - s[2] for s in spans)[len(spans) // 2]
+    spans = [s for s in spans if abs((s[3] - s[2]) - cnt) <= 6]     # training steps only: drop spans that straddle another
+                                                                   # phase of the command (forward-only loops, probes)
     busy = sorted(s[0] for s in spans)
     print('steps %d  kernel-time per step: median %.3f ms  min %.3f  max %.3f   (span median %.3f ms)' % (
         len(spans), busy[len(busy) // 2] / 1e6, busy[0] / 1e6, busy[-1] / 1e6,

@@ -29,6 +29,12 @@ def main(path, which=20):
     print('side queue(s), by kernel:')
     for nm, v in side.most_common():
         print('   %7.1f us  x%-2d %s' % (v / 1e3, calls[nm], nm))
+    print('side queue(s), in order (queue, start, duration):')
+    for r in seg:
+        if r['Queue_Id'] != mainq:
+            s, e = int(r['Start_Timestamp']) - t0, int(r['End_Timestamp']) - t0
+            nm = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')[:58]
+            print('  q%s %8.1f %7.1f  %s' % (r['Queue_Id'], s / 1e3, (e - s) / 1e3, nm))
     print('main queue, in order (start, duration, gap to the previous kernel):')
     prev = None
     for r in seg:

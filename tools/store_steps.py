@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Training steps through the resident store (zero-host-sync path) for profiling runs:
-    rocprofv3 --kernel-trace --output-format csv -d out -- python tools/store_steps.py [qm9|rna|pdbbind] [steps]
+    rocprofv3 --kernel-trace --output-format csv -d out -- python tools/store_steps.py [qm9|rna|pdbbind] [steps] [serial]
 then tools/step_timeline.py / tools/step_profile.py on the kernel trace."""
 import os
 import sys
@@ -17,6 +17,7 @@ from pamnet_amd.train import Trainer  # noqa: E402
 
 kind = sys.argv[1] if len(sys.argv) > 1 else 'rna'
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+serial = len(sys.argv) > 3 and sys.argv[3] == 'serial'      # graph built in line on the main stream: kernel durations free of overlap
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 if kind == 'qm9':
@@ -40,7 +41,7 @@ def run(n):
     nxt = st.collate(idx[0])
     for i in range(n):
         cur, nxt = nxt, st.collate(idx[(i + 1) % 4])
-        tr.step(cur, next_data=nxt)
+        tr.step(cur, next_data=None if serial else nxt)
 
 
 run(8)
