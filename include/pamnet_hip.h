@@ -133,6 +133,18 @@ int pamnet_triplet_count_i32(const int32_t* lptr, const int32_t* src, const int3
 int pamnet_triplet_fill_f32(const float* pos, const int32_t* lptr, const int32_t* src, const int32_t* dst,
                             int64_t n_edges, int32_t with_triplets, const int32_t* tp_ptr, int32_t* tp_idx,
                             int32_t* tp_edge, float* tp_angle, int32_t* tp_kind, int64_t cap, pamnet_stream_t stream);
+/* Transposed triplet / pair row list (for every source bond the rows that gather it, ascending: the (ptr, perm) that
+ * pamnet_csr_from_keys_i32 returns for keys = tp_idx over n_edges rows) from the graph's structure instead of a counting sort
+ * over the rows: count -> caller scans -> fill.  lt_ptr [n + 1] / lt_perm [n_edges]: the transposed bond list (bonds by source
+ * atom, any order inside a row); tp_ptr / tcount as pamnet_triplet_count_i32 / the scan produced them; tt_ptr = the scanned
+ * counts; cap = entries tt_perm holds.  No self loops. */
+int pamnet_triplet_transpose_count_i32(const int32_t* lptr, const int32_t* src, const int32_t* dst, const int32_t* lt_ptr,
+                                       const int32_t* lt_perm, int64_t n_edges, int32_t with_triplets, int32_t* count,
+                                       pamnet_stream_t stream);
+int pamnet_triplet_transpose_fill_i32(const int32_t* lptr, const int32_t* src, const int32_t* dst, const int32_t* lt_ptr,
+                                      const int32_t* lt_perm, int64_t n_edges, int32_t with_triplets, const int32_t* tp_ptr,
+                                      const int32_t* tcount, const int32_t* tt_ptr, int32_t* tt_perm, int64_t cap,
+                                      pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Zero-host-sync graph construction (models.py:62-98,104-157 read their data-dependent sizes back to the

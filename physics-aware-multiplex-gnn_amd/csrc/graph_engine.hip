@@ -151,10 +151,11 @@ int run(Run& r) {
         kn_l = r.take(el), kd_l = r.take(el), kq_l = r.take(el);      // local cut of the kNN table by query + its query ids
         if (!d.aggregate_at_query) gn2 = r.take(eg), gd2 = r.take(eg), kq_g = r.take(eg);
     }
-    // counters of the counting sorts (rows + 2 each): bond CSR / local transposition, transposed global, transposed local,
-    // transposed triplet / pair rows
-    const int64_t cur_a = r.take(n + 2), cur_b = r.take(n + 2), cur_c = r.take(n + 2), cur_t = r.take(el + 2);
+    // counters of the counting sorts (rows + 2 each): bond CSR / local transposition, transposed global, transposed local
+    const int64_t cur_a = r.take(n + 2), cur_b = r.take(n + 2), cur_c = r.take(n + 2);
     const int64_t mol_totals = r.take(4);                     // batch totals of the molecule-local builder (QM9)
+    // the transposed triplet / pair rows: written by a capped structural fill, so the tail stays valid with wrong sizes
+    const int64_t tT_perm_z = grad ? r.take(tp) : -1;
     const int64_t z1 = r.off;
     if (!r.dry) {
         const hipError_t e = hipMemsetAsync(r.I(z0), 0, sizeof(int32_t) * (size_t)(z1 - z0), as_stream(r.stream));
@@ -171,8 +172,10 @@ int run(Run& r) {
         chk_val[slot] = expected;
     };
     // triplet / pair row pointer of the local graph (models.py:68-98): count -> scan -> clamp
+    int64_t t_cnt = -1;                                       // triplets per bond (its pairs follow them in its rows)
     auto triplet_ptr = [&](int64_t lp, int64_t lsrc, int64_t ldst) -> int {
         const int64_t tc = r.take(el), tpc = r.take(el);
+        t_cnt = tc;
         GO(pamnet_triplet_count_i32(r.I(lp), r.I(lsrc), r.I(ldst), el, wt, r.I(tc), r.I(tpc), r.stream));
         int rc = scan(r, tpc, el, t_ptr_raw);
         if (rc) return rc;
@@ -189,7 +192,7 @@ int run(Run& r) {
         if (grad) {
             gT_ptr = g_ptr, gT_perm = r.take(eg);
             lT_ptr = r.take(n + 1), lT_perm = r.take(el);
-            tT_ptr = r.take(el + 1), tT_perm = r.take(tp);
+            tT_ptr = r.take(el + 1), tT_perm = tT_perm_z;
         }
         const int64_t mol_tot = r.take(4 * ng);
         GO(pamnet_mol_graph_count_i32(pos, gptr, n, ng, r.I(src0), r.I(dst0), d.n_bonds, d.cutoff_g, wt, r.I(mol_tot),
@@ -323,8 +326,17 @@ int run(Run& r) {
             int rc = csr(r, l_col, el, n, cur_c, lT_ptr, lT_perm);
             if (rc) return rc;
         }
-        int rc = csr(r, t_col, tp, el, cur_t, tT_ptr, tT_perm);
+        // transposed triplet / pair rows from the structure of the local graph (no sort over the T + P rows)
+        const int64_t cntT = r.take(el);
+        GO(pamnet_triplet_transpose_count_i32(r.I(l_ptr), r.I(l_col), r.I(l_row), r.I(lT_ptr), r.I(lT_perm), el, wt, r.I(cntT),
+                                              r.stream));
+        int64_t rawT = -1;
+        int rc = scan(r, cntT, el, rawT);
         if (rc) return rc;
+        if ((rc = clamp(r, rawT, el + 1, tp, tT_ptr))) return rc;
+        tT_perm = tT_perm_z;
+        GO(pamnet_triplet_transpose_fill_i32(r.I(l_ptr), r.I(l_col), r.I(l_row), r.I(lT_ptr), r.I(lT_perm), el, wt, r.I(t_ptr),
+                                             r.I(t_cnt), r.I(tT_ptr), r.I(tT_perm), tp, r.stream));
     }
 
     // ---- spherical basis on the combined rows (layers/basic.py:107-116)

@@ -287,8 +287,10 @@ __global__ __launch_bounds__(64) void mol_graph_kernel(MolIn in, int32_t* __rest
                 out.g_row[w] = a0 + lane;
                 out.g_col[w] = a0 + j;
                 out.g_dist[w] = dist3_xyz(xi, yi, zi, px[j], py[j], pz[j]);
-                if (in.need_grad)
-                    out.gT_perm[w] = (int32_t)(eoff + gex[j] + __popcll(adj[j] & ((1ull << lane) - 1ull)));
+                if (in.need_grad) {                             // (clamped: wrong sizes must stay inside the arrays)
+                    const int64_t rv = eoff + gex[j] + __popcll(adj[j] & ((1ull << lane) - 1ull));
+                    out.gT_perm[w] = (int32_t)(rv < eg_cap ? rv : eg_cap - 1);
+                }
             }
             ++w;
         }
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(64) void mol_graph_kernel(MolIn in, int32_t* __rest
                     row = tptr[eb] + tcnt[eb] + (q - bb);
                     ++b;
                 }
-                if (w2 < tp_cap) out.tT_perm[w2] = (int32_t)(toff + row);
+                if (w2 < tp_cap) out.tT_perm[w2] = (int32_t)(toff + row < tp_cap ? toff + row : tp_cap - 1);
                 ++w2;
             }
         }

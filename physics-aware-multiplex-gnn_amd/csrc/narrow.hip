@@ -296,7 +296,7 @@ extern "C" int pamnet_narrow_embed_bwd_f32(const float* F, int64_t m, int64_t k,
     const int stride = (int)(sets * (d * kp + d));
 #define CALL(DD)                                                                                                          \
     {                                                                                                                     \
-        const size_t scratch = bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);                                                         \
+        const size_t scratch = bwd_waves(DD) * 16 * ((kp > DD ? kp : DD) + 4) * sizeof(float);                                        \
         if (k == 16 && df) {                                                                                              \
             const size_t lds = 2 * (size_t)DD * 16 * sizeof(float) + scratch;                                             \
             hipLaunchKernelGGL((nembed_bwd_kernel<DD, 16, false, true>), dim3(grid), dim3(64 * bwd_waves(DD)), lds, st, F, m, kind, Wa, ba, \

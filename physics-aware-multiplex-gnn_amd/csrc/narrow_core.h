@@ -1146,7 +1146,8 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const flo
     constexpr int NW = bwd_waves(D);
     extern __shared__ float4 lds4[];
     float4* img_t = lds4 + (TWO ? 2 : 1) * IMG;
-    float* tile = reinterpret_cast<float*>(lds4 + (TWO ? 2 : 1) * IMG + (DX ? IMGT : 0)) + (threadIdx.x >> 6) * 16 * (D + 4);
+    constexpr int TW = (KP > D ? KP : D) + 4;                // the wave's tile also transposes the feature rows (KP wide)
+    float* tile = reinterpret_cast<float*>(lds4 + (TWO ? 2 : 1) * IMG + (DX ? IMGT : 0)) + (threadIdx.x >> 6) * 16 * TW;
     build_image<NT, NQ, false>(lds4, Wa, K, K);
     if (TWO) build_image<NT, NQ, false>(lds4 + IMG, Wb, K, K);
     if constexpr (DX) build_image<NQ, NT, true>(img_t, Wa, K, K);       // df = dz Wa: output tiles over K, k-groups over D
@@ -1173,8 +1174,28 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const flo
     for (int64_t t = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * NW) {
         const int64_t row0 = t * 16;
         float4 a[NQ];
-        if constexpr (RBF) rbf_feat_a(a, F, fr, rbf_inv_cutoff, row0, m, lane);
-        else load_feat_a<K>(a, F, row0, m, lane);
+        f32x4 fd[NQ];                                         // the same rows in accumulator layout (rows 4 kg + r, column c)
+        float xr[4], ur[4], cr[4];                            // RBF: x, u(x), cos(freq_c x) of this lane's four rows
+        if constexpr (RBF) {
+            // Accumulator layout first: sin and cos of one argument share the range reduction, and every Bessel value is
+            // formed once -- the A operand is the tile's transpose through the wave's LDS scratch.  (Forming both layouts
+            // on their own cost 8 sinf + 4 cosf per lane and tile and made the kernel VALU bound: 77 us at the RNA batch.)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + 4 * kg + r;
+                const bool ok = row < m;
+                xr[r] = F[ok ? row : m - 1] * rbf_inv_cutoff;
+                ur[r] = ok ? narrow_envelope(xr[r]) : 0.f;
+                float sn;
+                sincosf(fc * xr[r], &sn, &cr[r]);
+                fd[0][r] = ur[r] * sn;
+            }
+            float4 a1[1];
+            d_to_a<16>(a1, fd, tile, lane);
+            a[0] = a1[0];
+        } else {
+            load_feat_a<K>(a, F, row0, m, lane);
+        }
         f32x4 acc[NT];
         zero(acc);
         if (!TWO) {
@@ -1206,19 +1227,11 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const flo
                 if constexpr (TWO) dzb[jt][r] = second ? dz : 0.f;
             }
         }
-        f32x4 fd[NQ];
-        float xr[4], ur[4];                                   // RBF: x and u(x) of this lane's four rows (4 kg + r)
-        if constexpr (RBF) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t row = row0 + 4 * kg + r;
-                const bool ok = row < m;
-                xr[r] = F[ok ? row : m - 1] * rbf_inv_cutoff;
-                ur[r] = ok ? narrow_envelope(xr[r]) : 0.f;
-                fd[0][r] = ur[r] * sinf(fc * xr[r]);
-            }
-        } else {
-            load_feat_d<K>(fd, F, row0, m, lane);
+        if constexpr (!RBF) {
+            // the rows were fetched once (A layout, 8-byte loads); their accumulator layout is the transpose through the wave's
+            // LDS tile instead of twelve more 4-byte loads per lane
+            if constexpr (K == 42) a_to_d<KP>(fd, a, tile, lane);
+            else load_feat_d<K>(fd, F, row0, m, lane);
         }
         wgrad_acc<NT, NQ>(gwa, dza, fd);
         colsum_acc<NT>(dba, dza);
@@ -1236,7 +1249,7 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const flo
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = row0 + 4 * kg + r;
-                if constexpr (RBF) facc += o[0][r] * ur[r] * xr[r] * cosf(fc * xr[r]);     // (u = 0 beyond the last row)
+                if constexpr (RBF) facc += o[0][r] * ur[r] * xr[r] * cr[r];                // (u = 0 beyond the last row)
                 else if (row < m) df[row * K + c] = o[0][r];
             }
         }

@@ -277,7 +277,29 @@ def _triplet_ptr(lp, l_src, l_dst, with_triplets):
     tcount, tpcount = _i32(e_l, l_src.device), _i32(e_l, l_src.device)
     lib.call('pamnet_triplet_count_i32', lib.ptr(lp), lib.ptr(l_src), lib.ptr(l_dst), e_l, 1 if with_triplets else 0,
              lib.ptr(tcount), lib.ptr(tpcount), lib.stream_of(l_src))
-    return exclusive_scan(tpcount)
+    return exclusive_scan(tpcount), tcount
+
+
+class TripletTranspose(object):
+    """Transposed CSR of the triplet / pair rows (for every source bond the rows that gather it): the same (ptr, perm) as
+    Transpose(tp.col, e_l), from the structure of the local graph -- two light launches and a scan over the bonds
+    (pamnet_triplet_transpose_*_i32) instead of a counting sort over the T + P rows."""
+    __slots__ = ('ptr', 'perm', 'rows')
+
+    def __init__(self, loc, loc_T, tp_ptr, tcount, total, with_triplets, zeroed=False):
+        e_l, dev = loc.m, loc.ptr.device
+        st = lib.stream_of(loc.ptr)
+        wt = 1 if with_triplets else 0
+        cnt = _i32(e_l, dev)
+        lib.call('pamnet_triplet_transpose_count_i32', lib.ptr(loc.ptr), lib.ptr(loc.col), lib.ptr(loc.row_of), lib.ptr(loc_T.ptr),
+                 lib.ptr(loc_T.perm), e_l, wt, lib.ptr(cnt), st)
+        self.ptr = exclusive_scan(cnt)
+        if zeroed:                                    # sizes from the host: capped like every other fill (see build_graph)
+            self.ptr = torch.clamp(self.ptr, max=total)
+        self.perm = _alloc_i32(total, dev, zeroed)
+        lib.call('pamnet_triplet_transpose_fill_i32', lib.ptr(loc.ptr), lib.ptr(loc.col), lib.ptr(loc.row_of), lib.ptr(loc_T.ptr),
+                 lib.ptr(loc_T.perm), e_l, wt, lib.ptr(tp_ptr), lib.ptr(tcount), lib.ptr(self.ptr), lib.ptr(self.perm), total, st)
+        self.rows = max(e_l, 1)
 
 
 def _input_flag(node_graph, n_graphs, types=None, n_types=None, src=None, dst=None):
@@ -666,7 +688,8 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             src_, dst_, bonds.dist = _i32(m, dev), _i32(m, dev), _f32(m, dev)
             lib.call('pamnet_gather2_i32', lib.ptr(perm), lib.ptr(src0), lib.ptr(dst0), m, lib.ptr(src_), lib.ptr(dst_),
                      lib.ptr(pos), lib.ptr(bonds.dist), lib.stream_of(src0))      # + the bond lengths (models.py:65)
-            return lp_, src_, dst_, _triplet_ptr(lp_, src_, dst_, with_triplets)
+            tp_, bonds.tcount = _triplet_ptr(lp_, src_, dst_, with_triplets)
+            return lp_, src_, dst_, tp_
 
         ei = edge_index
         if (sizes is None and ing is not None and MOL_LOCAL and mol_local is not False and ei.size(1) > 0
@@ -689,7 +712,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             g.check = flag
             if ing is None:
                 g.all_kept = kept
-            hinted = _ZeroArena(3 * total_g + 4 * tp_total + 64, dev)
+            hinted = _ZeroArena(3 * total_g + 5 * tp_total + 64, dev)
             # the CSR pointers are capped at what the buffers hold: with sizes that turn out too small every kernel that
             # walks a pointer still stays inside its arrays (results of such a batch are invalid and flagged)
             gptr_g = torch.clamp(gptr_g, max=total_g)
@@ -720,7 +743,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             total_g, total_l, tp_hint = (int(v) for v in sizes)
             g.check = ing[5] if ing is not None else _input_flag(node_graph, g.n_graphs)
             checks += [(gptr_g[-1:], total_g), (lp[-1:], total_l)]
-            hinted = _ZeroArena(3 * total_g + 3 * total_l + 4 * tp_hint + 64, dev)
+            hinted = _ZeroArena(3 * total_g + 3 * total_l + 5 * tp_hint + 64, dev)
             gptr_g, lp = torch.clamp(gptr_g, max=total_g), torch.clamp(lp, max=total_l)
             gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g, zeroed=hinted, rows_out=glob_rows)
             lp, l_src, l_dist = _filter_fill(gp, gn, gd, cutoff_l, lp, total_l, zeroed=hinted)
@@ -752,7 +775,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             pa, pb = _filter_count(kp, kn, kd, cutoff_g), _filter_count(kp, kn, kd, cutoff_l)
             g.check = flag
             checks += [(pa[-1:], total_g), (pb[-1:], total_l)]
-            hinted = _ZeroArena(4 * total_g + 4 * total_l + 4 * tp_hint + 64, dev)
+            hinted = _ZeroArena(4 * total_g + 4 * total_l + 5 * tp_hint + 64, dev)
             pa, pb = torch.clamp(pa, max=total_g), torch.clamp(pb, max=total_l)
             gp, gn, gd = _filter_fill(kp, kn, kd, cutoff_g, pa, total_g, zeroed=hinted)
             qp, qn, qd = _filter_fill(kp, kn, kd, cutoff_l, pb, total_l, zeroed=hinted)
@@ -779,13 +802,14 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     st = lib.stream_of(pos)
     wt = 1 if with_triplets else 0
     if tp_pre is None:
-        tp_ptr = _triplet_ptr(lp, l_src, l_dst, with_triplets)
+        tp_ptr, tcount = _triplet_ptr(lp, l_src, l_dst, with_triplets)
         tot = tp_hint if tp_hint is not None else int(tp_ptr[-1])
         if hinted:
             checks.append((tp_ptr[-1:], tot))
             tp_ptr = torch.clamp(tp_ptr, max=tot)
     else:
         tp_ptr, tot = tp_pre
+        tcount = bonds.tcount
     tp_idx, tp_edge, tp_kind = (_alloc_i32(tot, dev, hinted) for _ in range(3))
     tp_angle = _alloc_f32(tot, dev, hinted)
     lib.call('pamnet_triplet_fill_f32', lib.ptr(pos), lib.ptr(lp), lib.ptr(l_src), lib.ptr(l_dst), e_l, wt,
@@ -805,7 +829,9 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         # d x[j] of the local gather: a radius graph for PDBbind, the inverse transposition for RNA; user-supplied bonds
         # (QM9) take the counting sort
         g.loc_T = SymmetricTranspose(g.loc) if dataset == 'PDBbind' else (loc_inv if rna else Transpose(g.loc.col, n))
-        g.tp_T = Transpose(tp_idx, max(e_l, 1))       # d m_neighbor[e'] of the triplet/pair gather
+        # d m_neighbor[e'] of the triplet/pair gather
+        g.tp_T = (TripletTranspose(g.loc, g.loc_T, tp_ptr, tcount, tot, with_triplets, zeroed=hinted) if (e_l > 0 and tot > 0)
+                  else Transpose(tp_idx, max(e_l, 1)))
     return g
 
 

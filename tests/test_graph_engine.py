@@ -47,6 +47,22 @@ def _build(b, kw, need_grad, with_triplets, sizes=None, mol_local=None):
                          with_triplets=with_triplets, n_types=kw['n_types'], sizes=sizes, mol_local=mol_local)
 
 
+def _transposes_are_the_counting_sorts(g):
+    """The transposed lists, however a path builds them (reverse-edge index, inverse transposition, structural enumeration
+    of the triplet rows), hold what the stable counting sort of the column returns -- same pointer, same rows; the kNN
+    lists keep the original order inside a row, every other list is ascending (= bitwise the counting sort)."""
+    from pamnet_amd import graph as G
+    for csr, tr, exact in ((g.glob, g.glob_T, None), (g.loc, g.loc_T, None), (g.tp, g.tp_T, True)):
+        want = G.Transpose(csr.col, tr.rows)
+        assert torch.equal(want.ptr, tr.ptr)
+        if exact or not isinstance(tr, G.InverseTranspose):
+            assert torch.equal(want.perm, tr.perm)
+        else:
+            seg = torch.repeat_interleave(torch.arange(tr.rows, device=tr.ptr.device), (tr.ptr[1:] - tr.ptr[:-1]).long())
+            key = seg.long() * (csr.m + 1)
+            assert torch.equal(torch.sort(key + want.perm.long()).values, torch.sort(key + tr.perm.long()).values)
+
+
 def _same_graph(a_g, c_g, need_grad, kw, tag):
     for name, sub in FIELDS:
         a, c = getattr(a_g, name), getattr(c_g, name)
@@ -85,6 +101,8 @@ def test_engine_graph_equals_step_by_step_graph(dev, kind, need_grad, with_tripl
     ref = _build(b, kw, need_grad, with_triplets)                       # sizes read back from the device
     ref_sbf = G.spherical_basis(ref, kw['cutoff_l'])
     sizes = (ref.glob.m, ref.loc.m, ref.tp.m)
+    if need_grad:
+        _transposes_are_the_counting_sorts(ref)
     saved = G.ENGINE
     try:
         G.ENGINE = False
@@ -237,6 +255,8 @@ def test_molecule_local_builder_equals_step_by_step_graph(dev, name, need_grad, 
         G.MOL_LOCAL = False
         ref = _build(b, kw, need_grad, with_triplets)                       # step-by-step launches
         sizes = (ref.glob.m, ref.loc.m, ref.tp.m)
+        if need_grad:
+            _transposes_are_the_counting_sorts(ref)
         G.MOL_LOCAL = True
         calls = []
         from pamnet_amd import lib
