@@ -64,6 +64,9 @@ int pamnet_gather_mul2_f32(float* out1, float* out2, const float* A, const int32
  * ------------------------------------------------------------------------------------------------------------------ */
 /* out[0]=0, out[i+1]=sum_{j<=i} in[j]  (n inputs -> n+1 outputs).  `tmp` needs ceil(n/4096)+1 ints. */
 int pamnet_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* tmp, pamnet_stream_t stream);
+/* two arrays of the same length, one launch when they are short */
+int pamnet_exclusive_scan_pair_i32(const int32_t* in_a, int32_t* out_a, const int32_t* in_b, int32_t* out_b, int64_t n,
+                                   int32_t* tmp, pamnet_stream_t stream);
 
 /* flag[0] = 1 when the index inputs of a batch are out of range (the reference would raise an IndexError): node_graph not
  * sorted / not in [0, n_graphs), a type (float, element i at types[i * type_stride]; nullable) not in [0, n_types), an
@@ -114,6 +117,17 @@ int pamnet_radius_fill_i32(const float* pos, const int32_t* node_graph, const in
  * nbr[i*k + s] = neighbour index or -1, dist[i*k + s] = distance.  (models.py:143-150) */
 int pamnet_knn_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n, int32_t k,
                    float cutoff, int32_t* nbr, float* dist, pamnet_stream_t stream);
+/* The kNN table (no cutoff: every entry but the self entry kept) together with what its two cuts keep per query -- cnt_a[i] /
+ * cnt_b[i] = entries of row i with dist <= cut_a / cut_b (models.py:147-156: the global and the local graph of the RNA path
+ * are cuts of one kNN search) -- and, after the caller's scans (pamnet_exclusive_scan_pair_i32), both cut lists written in
+ * one pass: kept entries of row i at raw[i] + rank with the query id beside them (capped at cap), pointers clamped to cap
+ * into ptr_a / ptr_b [n + 1].  The same arrays as pamnet_csr_filter_count/fill_i32 + pamnet_expand_rows_i32 per cut. */
+int pamnet_knn_cut_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n, int32_t k, float cut_a,
+                       float cut_b, int32_t* nbr, float* dist, int32_t* cnt_a, int32_t* cnt_b, pamnet_stream_t stream);
+int pamnet_knn_cut_fill_i32(const int32_t* nbr, const float* dist, int64_t n, int32_t k, float cut_a, const int32_t* raw_a,
+                            int64_t cap_a, int32_t* nbr_a, float* dist_a, int32_t* row_a, int32_t* ptr_a, float cut_b,
+                            const int32_t* raw_b, int64_t cap_b, int32_t* nbr_b, float* dist_b, int32_t* row_b, int32_t* ptr_b,
+                            pamnet_stream_t stream);
 
 /* Edge distances  dist[e] = ||pos[a[e]] - pos[b[e]]||   (PAMNet.get_edge_info, models.py:62-66) */
 int pamnet_edge_dist_f32(const float* pos, const int32_t* a, const int32_t* b, int64_t m, float* dist,

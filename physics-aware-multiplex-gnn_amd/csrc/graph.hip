@@ -198,8 +198,10 @@ __device__ __forceinline__ int block_excl_scan(int x, int* wt, int& total) {
 // 1 024 run totals, one pass to write the prefixes (the second read of the run comes out of the L1 / L2).  (The earlier
 // form scanned 1 024 elements per iteration with a dependent global load and two barriers in each: 15 us at 17.7 k.)
 __global__ __launch_bounds__(SMALL_THREADS) void scan_small_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out,
-                                                                   int n) {
+                                                                   int n, const int32_t* __restrict__ in2 = nullptr,
+                                                                   int32_t* __restrict__ out2 = nullptr) {
     __shared__ int wt[SMALL_THREADS / 64];
+    if (blockIdx.x == 1) in = in2, out = out2;                // second array of a pair launch (same length)
     const int run = (n + SMALL_THREADS - 1) / SMALL_THREADS;
     const int beg = min((int)threadIdx.x * run, n), end = min(beg + run, n);
     int sum = 0;
@@ -593,7 +595,10 @@ __device__ __forceinline__ void knn_select(const float* __restrict__ pos, float 
 
 __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pos, const int32_t* __restrict__ node_graph,
                                                   const int32_t* __restrict__ gptr, int64_t n, int K, float cutoff,
-                                                  int32_t* __restrict__ nbr, float* __restrict__ dist) {
+                                                  int32_t* __restrict__ nbr, float* __restrict__ dist,
+                                                  float cut_a = 0.f, float cut_b = 0.f,
+                                                  int32_t* __restrict__ cnt_a = nullptr,
+                                                  int32_t* __restrict__ cnt_b = nullptr) {
     __shared__ float sd[4][64];
     __shared__ int sj[4][64];
     __shared__ unsigned vd[4][KNN_SURV];
@@ -608,11 +613,52 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pos,
     int bj;
     if (end - beg <= 64 * KNN_CACHE) knn_select(pos, xi, yi, zi, beg, end, K, lane, sd[w], sj[w], vd[w], vj[w], bd, bj);
     else knn_stream(pos, xi, yi, zi, beg, end, K, lane, bd, bj);
+    const float d = __fsqrt_rn(bd);
+    const bool keep = lane < K && (bj != 0x7fffffff) && (bj != (int)i) && (d <= cutoff);
     if (lane < K) {
-        const float d = __fsqrt_rn(bd);
-        const bool keep = (bj != 0x7fffffff) && (bj != (int)i) && (d <= cutoff);
         nbr[i * K + lane] = keep ? bj : -1;
         dist[i * K + lane] = d;
+    }
+    if (cnt_a) {                                              // entries a cut of this row at cut_a / cut_b keeps (csr_filter_kernel)
+        const int ca = __popcll(__ballot(keep && d <= cut_a)), cb = __popcll(__ballot(keep && d <= cut_b));
+        if (lane == 0) cnt_a[i] = ca, cnt_b[i] = cb;
+    }
+}
+
+// Both cuts of a kNN table (rows of K entries, -1 = dropped) written in one pass, a wavefront per query: the kept entries of
+// row i go to slots raw[i] + rank (capped), with the query id beside them, and the clamped pointers are written on the way --
+// what two pamnet_csr_filter_fill_i32, two pointer clamps, a stride pointer and two pamnet_expand_rows_i32 launches did.
+__global__ __launch_bounds__(256) void knn_cut_fill_kernel(const int32_t* __restrict__ kn, const float* __restrict__ kd, int64_t n,
+                                                           int K, float cut_a, const int32_t* __restrict__ raw_a, int64_t cap_a,
+                                                           int32_t* __restrict__ nbr_a, float* __restrict__ dist_a,
+                                                           int32_t* __restrict__ row_a, int32_t* __restrict__ ptr_a, float cut_b,
+                                                           const int32_t* __restrict__ raw_b, int64_t cap_b,
+                                                           int32_t* __restrict__ nbr_b, float* __restrict__ dist_b,
+                                                           int32_t* __restrict__ row_b, int32_t* __restrict__ ptr_b) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= n) return;
+    int j = -1;
+    float d = 0.f;
+    if (lane < K) j = kn[i * K + lane], d = kd[i * K + lane];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    {
+        const bool keep = j >= 0 && d <= cut_a;
+        const int64_t w = (int64_t)raw_a[i] + __popcll(__ballot(keep) & below);
+        if (keep && w < cap_a) nbr_a[w] = j, dist_a[w] = d, row_a[w] = (int32_t)i;
+    }
+    {
+        const bool keep = j >= 0 && d <= cut_b;
+        const int64_t w = (int64_t)raw_b[i] + __popcll(__ballot(keep) & below);
+        if (keep && w < cap_b) nbr_b[w] = j, dist_b[w] = d, row_b[w] = (int32_t)i;
+    }
+    if (lane == 0) {
+        ptr_a[i] = (int32_t)(raw_a[i] < cap_a ? raw_a[i] : cap_a);
+        ptr_b[i] = (int32_t)(raw_b[i] < cap_b ? raw_b[i] : cap_b);
+        if (i == n - 1) {
+            ptr_a[n] = (int32_t)(raw_a[n] < cap_a ? raw_a[n] : cap_a);
+            ptr_b[n] = (int32_t)(raw_b[n] < cap_b ? raw_b[n] : cap_b);
+        }
     }
 }
 
@@ -757,6 +803,50 @@ __global__ __launch_bounds__(256) void triplet_transpose_kernel(const int32_t* _
         return;
     }
     const int64_t w0 = tt_ptr[q];
+    constexpr int CAP = 16;
+    if (ae - ab <= CAP && be - bb <= CAP) {
+        // Usual degrees: both lists of atom j in registers first -- every load below is independent of the others (the
+        // loops further down chase dst[lt_perm[.]] inside two nested loops: ~100 dependent loads per thread, 54 us at the
+        // RNA batch with one wave per SIMD).
+        int ea[CAP], ia[CAP], ta[CAP], sb[CAP], tb[CAP];
+        const int na = ae - ab, nb = be - bb;
+#pragma unroll
+        for (int u = 0; u < CAP; ++u) ea[u] = u < na ? lt_perm[ab + u] : 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < CAP; ++u) {
+            ia[u] = u < na ? dst[ea[u]] : k;                  // (padding counts as "towards k": not a triplet)
+            ta[u] = u < na ? tp_ptr[ea[u]] : 0;
+            sb[u] = u < nb ? src[bb + u] : 0;
+            tb[u] = u < nb ? tp_ptr[bb + u] + tcount[bb + u] : 0;
+        }
+        const int qb = (int)q - bb;
+#pragma unroll
+        for (int u = 0; u < CAP; ++u) {                       // triplet rows: bonds e = (j -> i), i != k
+            if (u < na && ia[u] != k) {
+                const int e = ea[u];
+                int pos = e - bb < 0 ? 0 : (e - bb < nb ? e - bb : nb), rank = 0;
+#pragma unroll
+                for (int v = 0; v < CAP; ++v) {
+                    pos += (ia[v] != k && ea[v] < e) ? 1 : 0;
+                    rank += (v < qb && sb[v] != ia[u]) ? 1 : 0;
+                }
+                const int64_t row = (int64_t)ta[u] + rank;
+                if (w0 + pos < cap) tt_perm[w0 + pos] = (int32_t)(row < cap ? row : cap - 1);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CAP; ++u) {                       // pair rows: bonds e = (j' -> j)
+            if (u < nb) {
+                const int e = bb + u;
+                int pos = u;
+#pragma unroll
+                for (int v = 0; v < CAP; ++v) pos += (ia[v] != k && ea[v] < e) ? 1 : 0;
+                const int64_t row = (int64_t)tb[u] + qb;
+                if (w0 + pos < cap) tt_perm[w0 + pos] = (int32_t)(row < cap ? row : cap - 1);
+            }
+        }
+        return;
+    }
     for (int a = ab; a < ae; ++a) {                           // triplet rows: bonds e = (j -> i), i != k
         const int e = lt_perm[a];
         const int i = dst[e];
@@ -801,7 +891,8 @@ extern "C" int pamnet_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_
         return (int)e;
     }
     if (n <= SMALL_SCAN_MAX && small_forms()) {
-        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(SMALL_THREADS), 0, st, in, out, (int)n);
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(SMALL_THREADS), 0, st, in, out, (int)n, (const int32_t*)nullptr,
+                           (int32_t*)nullptr);
         PAMNET_LAUNCH_CHECK();
         return PAMNET_OK;
     }
@@ -843,6 +934,21 @@ static int csr_from_keys(const int32_t* keys, int64_t m, int64_t rows, int32_t* 
     hipLaunchKernelGGL(sort_rows_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, ptr, perm_tmp, perm, m, rows, unsorted);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
+}
+
+// two arrays of the same length in one launch (the two cuts of a kNN table); longer arrays: one after the other
+extern "C" int pamnet_exclusive_scan_pair_i32(const int32_t* in_a, int32_t* out_a, const int32_t* in_b, int32_t* out_b,
+                                              int64_t n, int32_t* tmp, pamnet_stream_t stream) {
+    if (n < 1) return PAMNET_EINVAL;
+    if (!in_a || !out_a || !in_b || !out_b || !tmp) return PAMNET_ENULL;
+    if (n <= SMALL_SCAN_MAX && small_forms()) {
+        hipLaunchKernelGGL(scan_small_kernel, dim3(2), dim3(SMALL_THREADS), 0, as_stream(stream), in_a, out_a, (int)n, in_b,
+                           out_b);
+        PAMNET_LAUNCH_CHECK();
+        return PAMNET_OK;
+    }
+    const int rc = pamnet_exclusive_scan_i32(in_a, out_a, n, tmp, stream);
+    return rc ? rc : pamnet_exclusive_scan_i32(in_b, out_b, n, tmp, stream);
 }
 
 extern "C" int pamnet_csr_from_keys_i32(const int32_t* keys, int64_t m, int64_t rows, int32_t* ptr, int32_t* perm,
@@ -906,7 +1012,32 @@ extern "C" int pamnet_knn_i32(const float* pos, const int32_t* node_graph, const
     if (n == 0) return PAMNET_OK;
     if (!pos || !node_graph || !gptr || !nbr || !dist) return PAMNET_ENULL;
     hipLaunchKernelGGL(knn_kernel, dim3(blocks_for(n, 4)), dim3(256), 0, as_stream(stream), pos, node_graph, gptr, n,
-                       (int)k, cutoff, nbr, dist);
+                       (int)k, cutoff, nbr, dist, 0.f, 0.f, (int32_t*)nullptr, (int32_t*)nullptr);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_knn_cut_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n, int32_t k,
+                                  float cut_a, float cut_b, int32_t* nbr, float* dist, int32_t* cnt_a, int32_t* cnt_b,
+                                  pamnet_stream_t stream) {
+    if (n < 0 || k < 1 || k > 64) return PAMNET_EINVAL;
+    if (n == 0) return PAMNET_OK;
+    if (!pos || !node_graph || !gptr || !nbr || !dist || !cnt_a || !cnt_b) return PAMNET_ENULL;
+    hipLaunchKernelGGL(knn_kernel, dim3(blocks_for(n, 4)), dim3(256), 0, as_stream(stream), pos, node_graph, gptr, n,
+                       (int)k, INFINITY, nbr, dist, cut_a, cut_b, cnt_a, cnt_b);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+extern "C" int pamnet_knn_cut_fill_i32(const int32_t* nbr, const float* dist, int64_t n, int32_t k, float cut_a,
+                                       const int32_t* raw_a, int64_t cap_a, int32_t* nbr_a, float* dist_a, int32_t* row_a,
+                                       int32_t* ptr_a, float cut_b, const int32_t* raw_b, int64_t cap_b, int32_t* nbr_b,
+                                       float* dist_b, int32_t* row_b, int32_t* ptr_b, pamnet_stream_t stream) {
+    if (n < 1 || k < 1 || k > 64 || cap_a < 0 || cap_b < 0) return PAMNET_EINVAL;
+    if (!nbr || !dist || !raw_a || !raw_b || !ptr_a || !ptr_b) return PAMNET_ENULL;
+    if ((cap_a > 0 && (!nbr_a || !dist_a || !row_a)) || (cap_b > 0 && (!nbr_b || !dist_b || !row_b))) return PAMNET_ENULL;
+    hipLaunchKernelGGL(knn_cut_fill_kernel, dim3(blocks_for(n, 4)), dim3(256), 0, as_stream(stream), nbr, dist, n, (int)k, cut_a,
+                       raw_a, cap_a, nbr_a, dist_a, row_a, ptr_a, cut_b, raw_b, cap_b, nbr_b, dist_b, row_b, ptr_b);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

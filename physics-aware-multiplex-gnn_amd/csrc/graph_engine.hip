@@ -25,12 +25,6 @@ __global__ __launch_bounds__(256) void clamp_copy_kernel(const int32_t* __restri
     if (i < n) out[i] = in[i] < cap ? in[i] : cap;
 }
 
-// kp[i] = i * k: the CSR pointer of the kNN table (k entries per query)
-__global__ __launch_bounds__(256) void stride_ptr_kernel(int32_t* __restrict__ out, int64_t n, int32_t k) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = (int32_t)(i * k);
-}
-
 // pos = x[:, :3] (models.py:120,141); sign = where(pos.x > 40, -1, +1) (models.py:124; nullable)
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, int64_t width, int64_t n,
                                                          float* __restrict__ pos, float* __restrict__ sign) {
@@ -255,28 +249,25 @@ int run(Run& r) {
     } else {
         // kNN table by query (self dropped), cut at cutoff_g / cutoff_l (models.py:143-156)
         const int64_t k = d.knn_k;
-        const int64_t kn = r.take(n * k), kd = r.take(n * k), kp = r.take(n + 1);
-        GO(pamnet_knn_i32(pos, r.I(node_graph), gptr, n, (int32_t)k, INFINITY, r.I(kn), r.F(kd), r.stream));
-        GOK(stride_ptr_kernel, dim3(blocks(n + 1)), dim3(256), 0, as_stream(r.stream), r.I(kp), n + 1, (int32_t)k);
+        const int64_t kn = r.take(n * k), kd = r.take(n * k);
         const int64_t ca = r.take(n), cb = r.take(n);
-        int64_t raw_a = -1, raw_b = -1, pa = -1, pb = -1;
-        GO(pamnet_csr_filter_count_i32(r.I(kp), r.I(kn), r.F(kd), n, d.cutoff_g, r.I(ca), r.stream));
-        int rc = scan(r, ca, n, raw_a);
-        if (rc) return rc;
-        GO(pamnet_csr_filter_count_i32(r.I(kp), r.I(kn), r.F(kd), n, d.cutoff_l, r.I(cb), r.stream));
-        if ((rc = scan(r, cb, n, raw_b))) return rc;
+        // one search, the per-query sizes of both cuts counted on the way (rows are ascending in distance)
+        GO(pamnet_knn_cut_i32(pos, r.I(node_graph), gptr, n, (int32_t)k, d.cutoff_g, d.cutoff_l, r.I(kn), r.F(kd), r.I(ca), r.I(cb),
+                              r.stream));
+        const int64_t raw_a = r.take(n + 1), raw_b = r.take(n + 1), pa = r.take(n + 1), pb = r.take(n + 1);
+        const int64_t stmp = r.take((n + 4095) / 4096 + 1);
+        GO(pamnet_exclusive_scan_pair_i32(r.I(ca), r.I(raw_a), r.I(cb), r.I(raw_b), n, r.I(stmp), r.stream));
         check(0, raw_a, n, eg);
         check(1, raw_b, n, el);
-        if ((rc = clamp(r, raw_a, n + 1, eg, pa))) return rc;
-        if ((rc = clamp(r, raw_b, n + 1, el, pb))) return rc;
-        // stored by query: (pa, gq_n, gq_d) and (pb, kn_l, kd_l)
+        // stored by query: (pa, gq_n, gq_d, query ids) and (pb, kn_l, kd_l, kq_l), both cuts in one pass
         const int64_t gq_n = d.aggregate_at_query ? g_col : gn2, gq_d = d.aggregate_at_query ? g_dist : gd2;
-        GO(pamnet_csr_filter_fill_i32(r.I(kp), r.I(kn), r.F(kd), n, d.cutoff_g, r.I(pa), r.I(gq_n), r.F(gq_d), eg, r.stream));
-        GO(pamnet_csr_filter_fill_i32(r.I(kp), r.I(kn), r.F(kd), n, d.cutoff_l, r.I(pb), r.I(kn_l), r.F(kd_l), el, r.stream));
+        const int64_t gq_q = d.aggregate_at_query ? g_row : kq_g;
+        GO(pamnet_knn_cut_fill_i32(r.I(kn), r.F(kd), n, (int32_t)k, d.cutoff_g, r.I(raw_a), eg, r.I(gq_n), r.F(gq_d), r.I(gq_q),
+                                   r.I(pa), d.cutoff_l, r.I(raw_b), el, r.I(kn_l), r.F(kd_l), r.I(kq_l), r.I(pb), r.stream));
+        int rc = PAMNET_OK;
         if (d.aggregate_at_query) {                   // flow = target_to_source: the global layer aggregates at the query
             g_ptr = pa;
         } else {                                      // aggregate at the neighbour: re-store the list by neighbour
-            GO(pamnet_expand_rows_i32(r.I(pa), n, r.I(kq_g), eg, r.stream));
             int64_t perm = -1;
             if ((rc = csr(r, gq_n, eg, n, cur_b, g_ptr, perm))) return rc;
             int64_t inv = -1;
@@ -285,9 +276,10 @@ int run(Run& r) {
                                            grad ? r.I(inv) : nullptr, r.stream));
             if (grad) gT_ptr = pa, gT_perm = inv;     // the inverse transposition: rows = queries
         }
-        GO(pamnet_expand_rows_i32(r.I(g_ptr), n, r.I(g_row), eg, r.stream));
+        if (!d.aggregate_at_query) {
+            GO(pamnet_expand_rows_i32(r.I(g_ptr), n, r.I(g_row), eg, r.stream));
+        }
         // the local layer always aggregates at the neighbour (models.py:153-156: j = query, i = neighbour)
-        GO(pamnet_expand_rows_i32(r.I(pb), n, r.I(kq_l), el, r.stream));
         int64_t perm = -1;
         if ((rc = csr(r, kn_l, el, n, cur_a, l_ptr, perm))) return rc;
         int64_t inv = -1;
