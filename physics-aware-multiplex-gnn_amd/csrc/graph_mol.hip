@@ -88,10 +88,19 @@ __global__ __launch_bounds__(64) void mol_graph_kernel(MolIn in, int32_t* __rest
     __shared__ unsigned long long adj[MOL_ATOMS];
     const int g = blockIdx.x, lane = threadIdx.x;
     const int a0 = in.gptr[g], a1 = in.gptr[g + 1], na = a1 - a0;
-    int b0, b1;
-    bond_range(in.dst, (int)in.n_bonds, a0, a1, lane, b0, b1);
-    const int nb = b1 - b0;
     const bool last = g == (int)in.n_graphs - 1;
+    int b0, b1;
+    int se = 0, st = 0;
+    if constexpr (FILL) {
+        // the count launch left every molecule's first bond and totals: this molecule's slices start at the sums over the
+        // preceding molecules (all of these loads are independent of each other: one round trip)
+        b0 = mol_tot[4 * g + 2];
+        b1 = last ? (int)in.n_bonds : mol_tot[4 * g + 6];
+        for (int q = lane; q < g; q += 64) se += mol_tot[4 * q], st += mol_tot[4 * q + 1];
+    } else {
+        bond_range(in.dst, (int)in.n_bonds, a0, a1, lane, b0, b1);
+    }
+    const int nb = b1 - b0;
     int flags = 0;
     if (na < 0 || na > MOL_ATOMS) flags |= 1;
     if (nb < 0 || nb > MOL_BONDS) flags |= 2;
@@ -225,9 +234,6 @@ __global__ __launch_bounds__(64) void mol_graph_kernel(MolIn in, int32_t* __rest
     adj[lane] = mask;
     gex[lane] = ginc - deg;
 
-    // ---- slice offsets of this molecule: sums over the preceding molecules
-    int se = 0, st = 0;
-    for (int q = lane; q < g; q += 64) se += mol_tot[4 * q], st += mol_tot[4 * q + 1];
     const int64_t eoff = wave_sum(se), toff = wave_sum(st);
     __syncthreads();
 
