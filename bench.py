@@ -559,6 +559,35 @@ def main():
                              'per-molecule counts: no device->host read in forward, graph construction or step '
                              '(tests/test_store.py runs the forward under torch.cuda.set_sync_debug_mode("error"))'}
 
+    # What graph construction costs the step although it runs beside it (a side-stream launch displaces a workgroup
+    # of the model's full-chip launches): the same steps on graphs prepared once and reused.  A bound, never `value` -- the
+    # timed region above rebuilds the graph of every batch.
+    graph_cost = None
+    if not args.cpu_dry_run and world == 1:
+        keep = {}
+        for b in batches:
+            model.prepare(b)
+            keep[id(b)] = b._pamnet_prepared
+            b._pamnet_prepared = None
+        build = model._graph
+        model._graph = lambda data: keep[id(data)]
+        try:
+            csteps = min(args.steps, 100)
+            for i in range(5):
+                trainer.step(batches[i % nb], global_graphs=gB)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(csteps):
+                trainer.step(batches[i % nb], global_graphs=gB)
+            sync()
+            cached_ms = (time.perf_counter() - t0) / csteps * 1e3
+        finally:
+            del model._graph                                   # back to the class's method
+        assert model._graph.__func__ is build.__func__
+        graph_cost = {'ms_per_step_graphs_cached': cached_ms, 'ms_per_step': ms_per_step,
+                      'note': 'bound only: the same training steps on graphs prepared once and reused (no graph construction); '
+                              '`value` rebuilds the graph of every batch on the side stream'}
+
     if rank == 0:
         with torch.no_grad():
             model(batches[0])
@@ -578,6 +607,7 @@ def main():
             'forward_only_molecules_per_s': gB / (fwd_ms / 1e3), 'forward_ms': fwd_ms,
             'forward_ms_unpipelined': fwd_plain_ms,
             'zero_host_sync': zero_sync,
+            'graph_construction_cost': graph_cost,
             'mfma': mfma_summary(args, g, ms_per_step),
         }
         if not args.no_rooflines:
