@@ -720,3 +720,93 @@ def test_rna_inverse_transpose_rows_match_counting_sort(dev, flow):
         assert torch.equal(torch.sort(key + tr.perm.long()).values, key + ref.perm.long())   # same set per row
     if flow == 'target_to_source':
         assert isinstance(g.glob_T, G.Transpose)
+
+
+# ---- round-3 graph-construction entry points, each against the entry points it stands in for -----------------------------
+@pytest.mark.parametrize('n_nodes,k', [(300, 50), (40, 50), (700, 17)])
+def test_knn_cut_and_fill_equal_table_filters_and_expands(dev, n_nodes, k):
+    """pamnet_knn_cut_i32 + pamnet_exclusive_scan_pair_i32 + pamnet_knn_cut_fill_i32 == pamnet_knn_i32 (no cutoff) followed by
+    two pamnet_csr_filter_count/fill_i32, two expands and the pointer clamps -- same table, counts, lists, query ids."""
+    from pamnet_amd import graph as G, lib, synth
+    b = synth.rna_batch(4, 0, 3, n_nodes=n_nodes)
+    pos = b.x[:, :3].contiguous().to(dev)
+    nodeg = b.batch.to(torch.int32).to(dev)
+    n = int(nodeg.numel())
+    gptr, _ = G.csr_from_keys(nodeg, 3)
+    cut_a, cut_b = 20.0, 2.6
+    kp, kn, kd = G.knn_table(pos, nodeg, gptr, k, float('inf'))
+    want = [G.csr_filter(kp, kn, kd, c) for c in (cut_a, cut_b)]
+    st = lib.stream_of(pos)
+    P = lib.ptr
+    i32 = lambda m: torch.empty(m, dtype=torch.int32, device=dev)
+    kn2, kd2 = i32(n * k), torch.empty(n * k, device=dev)
+    ca, cb, ra, rb, tmp = i32(n), i32(n), i32(n + 1), i32(n + 1), i32(n // 4096 + 2)
+    lib.call('pamnet_knn_cut_i32', P(pos), P(nodeg), P(gptr), n, k, cut_a, cut_b, P(kn2), P(kd2), P(ca), P(cb), st)
+    assert torch.equal(kn2, kn) and torch.equal(kd2, kd)
+    lib.call('pamnet_exclusive_scan_pair_i32', P(ca), P(ra), P(cb), P(rb), n, P(tmp), st)
+    assert torch.equal(ra, want[0][0]) and torch.equal(rb, want[1][0])
+    ea, eb = int(ra[-1]), int(rb[-1])
+    for cap_a, cap_b in ((ea, eb), (max(ea - 5, 1), eb + 7)):       # exact sizes; one too small, one too large
+        outs = [(i32(cap_a).zero_(), torch.zeros(cap_a, device=dev), i32(cap_a).zero_(), i32(n + 1)),
+                (i32(cap_b).zero_(), torch.zeros(cap_b, device=dev), i32(cap_b).zero_(), i32(n + 1))]
+        lib.call('pamnet_knn_cut_fill_i32', P(kn), P(kd), n, k, cut_a, P(ra), cap_a, P(outs[0][0]), P(outs[0][1]), P(outs[0][2]),
+                 P(outs[0][3]), cut_b, P(rb), cap_b, P(outs[1][0]), P(outs[1][1]), P(outs[1][2]), P(outs[1][3]), st)
+        for (nbr, dist, row, ptr), (wp, wn, wd), cap in zip(outs, want, (cap_a, cap_b)):
+            m = min(cap, int(wp[-1]))
+            assert torch.equal(ptr, torch.clamp(wp, max=cap))
+            assert torch.equal(nbr[:m], wn[:m]) and torch.equal(dist[:m], wd[:m])
+            assert torch.equal(row[:m], G.expand_rows(wp, int(wp[-1]))[:m])
+            assert int(nbr[m:].abs().sum()) == 0                   # nothing written beyond what the list holds
+
+
+@pytest.mark.parametrize('n', [1, 100, 24576, 24577, 70000])
+def test_exclusive_scan_pair(dev, n):
+    from pamnet_amd import graph as G, lib
+    a = torch.randint(0, 60, (n,), device=dev, dtype=torch.int32)
+    b = torch.randint(0, 9, (n,), device=dev, dtype=torch.int32)
+    oa, ob = torch.empty(n + 1, dtype=torch.int32, device=dev), torch.empty(n + 1, dtype=torch.int32, device=dev)
+    tmp = torch.empty(n // 4096 + 2, dtype=torch.int32, device=dev)
+    lib.call('pamnet_exclusive_scan_pair_i32', lib.ptr(a), lib.ptr(oa), lib.ptr(b), lib.ptr(ob), n, lib.ptr(tmp), lib.stream_of(a))
+    assert torch.equal(oa, G.exclusive_scan(a)) and torch.equal(ob, G.exclusive_scan(b))
+
+
+@pytest.mark.parametrize('with_triplets', [True, False])
+@pytest.mark.parametrize('case', ['qm9', 'dense', 'asymmetric'])
+def test_triplet_transpose_equals_counting_sort(dev, case, with_triplets):
+    """pamnet_triplet_transpose_count/fill_i32 against pamnet_csr_from_keys_i32 of the row list's source-bond column: usual
+    degrees (both bond lists of an atom in registers), degrees over the register path's limit (a clique), a bond list with
+    one direction missing (in-degree != out-degree), transposed bond lists in any order inside a row."""
+    from pamnet_amd import graph as G, lib, synth
+    if case == 'qm9':
+        b = synth.qm9_batch(3, 0, 20)
+        ei, n = b.edge_index, int(b.x.numel())
+        pos = b.pos
+    else:
+        n = 24 if case == 'dense' else 40
+        g = torch.Generator().manual_seed(1)
+        pos = torch.rand(n, 3, generator=g) * 3
+        src, dst = torch.meshgrid(torch.arange(n), torch.arange(n), indexing='ij')
+        keep = src != dst
+        if case == 'asymmetric':
+            keep &= torch.rand(n, n, generator=g) < 0.15
+        ei = torch.stack([src[keep], dst[keep]])
+    ei = ei.to(dev)
+    lp, perm = G.csr_from_keys(ei[1].to(torch.int32).contiguous(), n)
+    l_src, l_dst = ei[0].to(torch.int32)[perm.long()].contiguous(), ei[1].to(torch.int32)[perm.long()].contiguous()
+    loc = G.CSR(lp, l_dst, l_src)
+    tp_ptr, tcount = G._triplet_ptr(lp, l_src, l_dst, with_triplets)
+    tot, e_l = int(tp_ptr[-1]), int(l_src.numel())
+    i32 = lambda m: torch.empty(m, dtype=torch.int32, device=dev)
+    tp_idx, tp_edge, tp_kind, tp_angle = i32(tot), i32(tot), i32(tot), torch.empty(tot, device=dev)
+    P = lib.ptr
+    lib.call('pamnet_triplet_fill_f32', P(pos.to(dev).contiguous()), P(lp), P(l_src), P(l_dst), e_l, 1 if with_triplets else 0,
+             P(tp_ptr), P(tp_idx), P(tp_edge), P(tp_angle), P(tp_kind), tot, lib.stream_of(lp))
+    want = G.Transpose(tp_idx, e_l)
+    locT = G.Transpose(l_src, n)
+    for shuffle in (False, True):
+        if shuffle:                                  # the kNN path hands rows over in its own order
+            rows = torch.repeat_interleave(torch.arange(n, device=dev), (locT.ptr[1:] - locT.ptr[:-1]).long())
+            key = rows.double() + torch.rand(e_l, device=dev, dtype=torch.float64) * 0.5
+            locT.perm = locT.perm[torch.argsort(key)].contiguous()
+        got = G.TripletTranspose(loc, locT, tp_ptr, tcount, tot, with_triplets)
+        assert torch.equal(got.ptr, want.ptr) and torch.equal(got.perm, want.perm), (case, shuffle)
