@@ -159,16 +159,22 @@ struct EJobs {
 
 // input rows [row0, row0 + 64) of a job into xs (zero beyond `rows`); RBF: the Bessel rows from the distances, with the
 // scaled distance of each row left in ds[] for the backward
+// this thread's edge length of tile row threadIdx.x / 4 (1.0 = padding: u(1) = 0, such rows contribute nothing)
+__device__ __forceinline__ float job_dist(const EJob& jb, int64_t row0) {
+    const int64_t g = row0 + (threadIdx.x >> 2);
+    return g < jb.rows ? jb.dist[g] : -1.0f;
+}
+
 template <int K, bool RBF>
-__device__ __forceinline__ void stage_job_rows(const EJob& jb, int64_t row0, float* xs, float* ds) {
+__device__ __forceinline__ void stage_job_rows(const EJob& jb, int64_t row0, float* xs, float* ds, float dpre = -2.0f) {
     if (!RBF) {
         stage_rows<K>(jb.x, row0, jb.rows, xs);
         return;
     }
     const int r = threadIdx.x >> 2, n0 = 4 * (threadIdx.x & 3);
-    const int64_t g = row0 + r;
-    const bool ok = g < jb.rows;
-    const float xr = ok ? jb.dist[g] * jb.inv_cutoff : 1.0f;       // u(1) = 0: padded rows contribute nothing
+    if (dpre == -2.0f) dpre = job_dist(jb, row0);            // (not fetched ahead)
+    const bool ok = dpre >= 0.f;
+    const float xr = ok ? dpre * jb.inv_cutoff : 1.0f;             // u(1) = 0: padded rows contribute nothing
     const float u = envelope_f(xr);
     const float4 f = *reinterpret_cast<const float4*>(jb.freq + n0);
     *reinterpret_cast<float4*>(xs + r * Dims<K>::LDX + n0) =
@@ -253,10 +259,30 @@ __device__ __forceinline__ void embed_bwd_body(const EJob& jb, int bid, float* x
     zero_pad<K>(xs);
     if (threadIdx.x < TR) ks[threadIdx.x] = 0;
     const int64_t ntiles = (rows + TR - 1) / TR;
+    // The 16-wide single-set layers are the long jobs (one row per global edge: 700 k rows at a PDBbind batch) and their
+    // tiles were latency bound -- five barriers and two global-load round trips each, 1 TB/s of a 363 MB gradient stream.
+    // The tile's slice of the output gradient (8 x 16 bytes per thread) is fetched one tile ahead, after the sweep that
+    // consumed the previous one: the loads fly during the MFMA phases and the next tile's staging.
+    constexpr bool PREF = K == 16 && !TWO;
+    float4 pre[PREF ? TR / 8 : 1];
+    auto prefetch = [&](int64_t t) {
+        if constexpr (PREF) {
+            const int c4p = threadIdx.x & 31, r0p = threadIdx.x >> 5;
+#pragma unroll
+            for (int i = 0; i < TR / 8; ++i) {
+                const int64_t g = t * TR + r0p + 8 * i;
+                pre[i] = (t < ntiles && g < rows) ? ldg4(gout, g, DOUT, c4p) : f4zero();
+            }
+        }
+    };
+    prefetch(bid);
+    float dnext = -2.0f;
+    if constexpr (DXM == 2) dnext = bid < ntiles ? job_dist(jb, (int64_t)bid * TR) : -1.0f;
     for (int64_t tile = bid; tile < ntiles; tile += jb.nblk) {
         const int64_t row0 = tile * TR;
         __syncthreads();
-        stage_job_rows<K, DXM == 2>(jb, row0, xs, ds);
+        stage_job_rows<K, DXM == 2>(jb, row0, xs, ds, dnext);
+        if constexpr (DXM == 2) dnext = tile + jb.nblk < ntiles ? job_dist(jb, (tile + jb.nblk) * TR) : -1.0f;
         if (TWO && threadIdx.x < TR) ks[threadIdx.x] = (row0 + threadIdx.x < rows) ? jb.kind[row0 + threadIdx.x] : 0;
         __syncthreads();
         {
@@ -266,18 +292,34 @@ __device__ __forceinline__ void embed_bwd_body(const EJob& jb, int bid, float* x
         }
         __syncthreads();
         // dz = g * act'(z), in place; bias gradients
-        sweep_rows<TR>([&](int r, int c) {
-            const int64_t g = row0 + r;
-            float4 dz = f4zero();
-            if (g < rows) {
-                const bool k1 = TWO && ks[r];
-                dz = ldg4(gout, g, DOUT, c);
-                if (act) dz = f4mul(dz, f4dsilu(f4add(lds4(Ds, r, c), k1 ? bias1 : bias0)));
-                if (k1) dbs1 = f4add(dbs1, dz);
-                else dbs0 = f4add(dbs0, dz);
+        if constexpr (PREF) {
+            const int c = threadIdx.x & 31, r0p = threadIdx.x >> 5;
+#pragma unroll
+            for (int i = 0; i < TR / 8; ++i) {
+                const int r = r0p + 8 * i;
+                float4 dz = f4zero();
+                if (row0 + r < rows) {
+                    dz = pre[i];
+                    if (act) dz = f4mul(dz, f4dsilu(f4add(lds4(Ds, r, c), bias0)));
+                    dbs0 = f4add(dbs0, dz);
+                }
+                st_lds4(Ds, r, c, dz);
             }
-            st_lds4(Ds, r, c, dz);
-        });
+            prefetch(tile + jb.nblk);
+        } else {
+            sweep_rows<TR>([&](int r, int c) {
+                const int64_t g = row0 + r;
+                float4 dz = f4zero();
+                if (g < rows) {
+                    const bool k1 = TWO && ks[r];
+                    dz = ldg4(gout, g, DOUT, c);
+                    if (act) dz = f4mul(dz, f4dsilu(f4add(lds4(Ds, r, c), k1 ? bias1 : bias0)));
+                    if (k1) dbs1 = f4add(dbs1, dz);
+                    else dbs0 = f4add(dbs0, dz);
+                }
+                st_lds4(Ds, r, c, dz);
+            });
+        }
         __syncthreads();
         // dW[c][k] += sum_r dz[r][c] * x[r][k]: MFMA with the row index as the reduction dimension
 #pragma unroll 4
