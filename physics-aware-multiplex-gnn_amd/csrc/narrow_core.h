@@ -1289,7 +1289,7 @@ inline bool width_ok(int64_t d) { return d == 16 || d == 32 || d == 64; }
 
 // Workgroups that are co-resident per CU: the backward kernels at d = 64 hold ~350 registers per lane and ~80 KB of
 // weight images, so one 4-wave workgroup fills a CU; a grid beyond that only adds a second, nearly empty round.
-inline int fwd_per_cu(int64_t d) { return d == 64 ? 2 : 4; }
+inline int fwd_per_cu(int64_t d) { return d == 64 ? 2 : (d == 16 ? 8 : 4); }
 
 
 template <typename Kern>
