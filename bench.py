@@ -362,6 +362,14 @@ def cpu_baseline(args, seconds):
                 forward_only=fwd_mps)
 
 
+def guarded(fn, *a):
+    """A side leg of the line: its failure is reported in its field, the line is still printed."""
+    try:
+        return fn(*a)
+    except Exception as exc:                      # noqa: BLE001
+        return {'error': '%s: %s' % (type(exc).__name__, exc)}
+
+
 def main():
     args = parse()
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio on fd 1 (flushed at exit,
@@ -525,68 +533,76 @@ def main():
     # Reported beside the classic numbers, never as `value`.
     zero_sync = None
     if not args.cpu_dry_run and world == 1:       # a side measurement: single-GPU runs only (nothing the scaling runs need)
-        from pamnet_amd.store import MoleculeStore
-        lo, hi = shard_range(gB, rank, world)
-        mols = [synth.qm9_molecule(0, k * gB + lo + i) for k in range(args.n_batches) for i in range(B)]
-        store = MoleculeStore(mols, dev).prepare_for(model)
-        idx = [list(range(k * B, (k + 1) * B)) for k in range(args.n_batches)]
-        with torch.no_grad():
-            for i in range(3):
-                model(store.collate(idx[i % nb]))
+        try:                                      # (a side leg must never cost the run its result line)
+            from pamnet_amd.store import MoleculeStore
+            lo, hi = shard_range(gB, rank, world)
+            mols = [synth.qm9_molecule(0, k * gB + lo + i) for k in range(args.n_batches) for i in range(B)]
+            store = MoleculeStore(mols, dev).prepare_for(model)
+            idx = [list(range(k * B, (k + 1) * B)) for k in range(args.n_batches)]
+            with torch.no_grad():
+                for i in range(3):
+                    model(store.collate(idx[i % nb]))
+                sync()
+                t0 = time.perf_counter()
+                for i in range(fsteps):
+                    model(store.collate(idx[i % nb]))
+                sync()
+                zs_fwd = (time.perf_counter() - t0) / fsteps * 1e3
+            model.verify()
+            zsteps = min(args.steps, 200)
+            nxt = store.collate(idx[0])
+            for i in range(5):
+                cur, nxt = nxt, store.collate(idx[(i + 1) % nb])
+                trainer.step(cur, global_graphs=gB, next_data=nxt)
             sync()
             t0 = time.perf_counter()
-            for i in range(fsteps):
-                model(store.collate(idx[i % nb]))
+            for i in range(zsteps):
+                cur, nxt = nxt, store.collate(idx[(i + 1) % nb])
+                trainer.step(cur, global_graphs=gB, next_data=nxt)
             sync()
-            zs_fwd = (time.perf_counter() - t0) / fsteps * 1e3
-        model.verify()
-        zsteps = min(args.steps, 200)
-        nxt = store.collate(idx[0])
-        for i in range(5):
-            cur, nxt = nxt, store.collate(idx[(i + 1) % nb])
-            trainer.step(cur, global_graphs=gB, next_data=nxt)
-        sync()
-        t0 = time.perf_counter()
-        for i in range(zsteps):
-            cur, nxt = nxt, store.collate(idx[(i + 1) % nb])
-            trainer.step(cur, global_graphs=gB, next_data=nxt)
-        sync()
-        zs_step = (time.perf_counter() - t0) / zsteps * 1e3
-        trainer.drain()
-        zero_sync = {'forward_ms_unpipelined': zs_fwd, 'forward_only_molecules_per_s': gB / (zs_fwd / 1e3),
-                     'train_ms_per_step': zs_step, 'train_molecules_per_s': gB / (zs_step / 1e3),
-                     'note': 'resident dataset, one device-side collate launch per batch inside the timed loop, sizes from '
-                             'per-molecule counts: no device->host read in forward, graph construction or step '
-                             '(tests/test_store.py runs the forward under torch.cuda.set_sync_debug_mode("error"))'}
+            zs_step = (time.perf_counter() - t0) / zsteps * 1e3
+            trainer.drain()
+            zero_sync = {'forward_ms_unpipelined': zs_fwd, 'forward_only_molecules_per_s': gB / (zs_fwd / 1e3),
+                         'train_ms_per_step': zs_step, 'train_molecules_per_s': gB / (zs_step / 1e3),
+                         'note': 'resident dataset, one device-side collate launch per batch inside the timed loop, sizes from '
+                                 'per-molecule counts: no device->host read in forward, graph construction or step '
+                                 '(tests/test_store.py runs the forward under torch.cuda.set_sync_debug_mode("error"))'}
+        except Exception as exc:                  # noqa: BLE001
+            zero_sync = {'error': '%s: %s' % (type(exc).__name__, exc)}
 
     # What graph construction costs the step although it runs beside it (a side-stream launch displaces a workgroup
     # of the model's full-chip launches): the same steps on graphs prepared once and reused.  A bound, never `value` -- the
     # timed region above rebuilds the graph of every batch.
     graph_cost = None
     if not args.cpu_dry_run and world == 1:
-        keep = {}
-        for b in batches:
-            model.prepare(b)
-            keep[id(b)] = b._pamnet_prepared
-            b._pamnet_prepared = None
-        build = model._graph
-        model._graph = lambda data: keep[id(data)]
         try:
-            csteps = min(args.steps, 100)
-            for i in range(5):
-                trainer.step(batches[i % nb], global_graphs=gB)
-            sync()
-            t0 = time.perf_counter()
-            for i in range(csteps):
-                trainer.step(batches[i % nb], global_graphs=gB)
-            sync()
-            cached_ms = (time.perf_counter() - t0) / csteps * 1e3
-        finally:
-            del model._graph                                   # back to the class's method
-        assert model._graph.__func__ is build.__func__
-        graph_cost = {'ms_per_step_graphs_cached': cached_ms, 'ms_per_step': ms_per_step,
-                      'note': 'bound only: the same training steps on graphs prepared once and reused (no graph construction); '
-                              '`value` rebuilds the graph of every batch on the side stream'}
+            keep = {}
+            for b in batches:
+                model.prepare(b)
+                keep[id(b)] = b._pamnet_prepared
+                b._pamnet_prepared = None
+            build = model._graph
+            model._graph = lambda data: keep[id(data)]
+            try:
+                csteps = min(args.steps, 100)
+                for i in range(5):
+                    trainer.step(batches[i % nb], global_graphs=gB)
+                sync()
+                t0 = time.perf_counter()
+                for i in range(csteps):
+                    trainer.step(batches[i % nb], global_graphs=gB)
+                sync()
+                cached_ms = (time.perf_counter() - t0) / csteps * 1e3
+            finally:
+                del model._graph                                   # back to the class's method
+            assert model._graph.__func__ is build.__func__
+            graph_cost = {'ms_per_step_graphs_cached': cached_ms, 'ms_per_step': ms_per_step,
+                          'note': 'bound only: the same training steps on graphs prepared once and reused (no graph construction); '
+                                  '`value` rebuilds the graph of every batch on the side stream'}
+        except Exception as exc:                  # noqa: BLE001
+            graph_cost = {'error': '%s: %s' % (type(exc).__name__, exc)}
+            if '_graph' in model.__dict__:
+                del model._graph
 
     if rank == 0:
         with torch.no_grad():
@@ -623,12 +639,12 @@ def main():
                 'bytes_per_launch': s['bytes'], 'ms_per_launch': s['ms'], 'best_group_gbs': s['gbs_best'],
                 'shape': '[%d,%d]->[%d,%d] streamed (%.2f GB)' % (s['rows_in'], args.dim, s['rows_out'], args.dim, s['bytes'] / 1e9),
                 'at_workload_shape': roof['workload']}
-            line['step_kernels'] = step_kernel_rooflines(dev, g, args.dim, args.n_layer)
+            line['step_kernels'] = guarded(step_kernel_rooflines, dev, g, args.dim, args.n_layer)
         if world == 1 and not args.no_other_configs:
-            line['other_configs'] = other_configs(dev)
+            line['other_configs'] = guarded(other_configs, dev)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
-            line['cpu_baseline']['parity'] = parity_beside_baseline(dev, args)
+            line['cpu_baseline']['parity'] = guarded(parity_beside_baseline, dev, args)
             line['speedup_vs_cpu'] = value / line['cpu_baseline']['value']
         result_out.write(json.dumps(line) + '\n')
         result_out.flush()
