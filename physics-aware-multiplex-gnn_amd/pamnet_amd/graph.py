@@ -247,6 +247,32 @@ def knn_table(pos, node_graph, gptr, k, cutoff):
     return ptr, nbr, dist
 
 
+def knn_cuts(pos, node_graph, gptr, k, cut_a, cut_b, flag=None):
+    """The kNN search with both cuts of its table (models.py:143-156) in three launches and one host round trip (the two
+    sizes + the input-validity flag): the search counts what each cut keeps per query on the way, one launch scans both count
+    vectors, one writes both cut lists with their query ids.  Returns ((ptr, nbr, dist, query) of cut a, the same of cut b) --
+    the arrays of knn_table + csr_filter2 + expand_rows."""
+    n, dev = int(pos.size(0)), pos.device
+    st = lib.stream_of(pos)
+    kn, kd = _i32(n * k, dev), _f32(n * k, dev)
+    cnt = _i32(2 * n + 2 * (n + 1) + (n + 4095) // 4096 + 1, dev)
+    ca, cb, ra, rb, tmp = cnt[:n], cnt[n:2 * n], cnt[2 * n:3 * n + 1], cnt[3 * n + 1:4 * n + 2], cnt[4 * n + 2:]
+    lib.call('pamnet_knn_cut_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), n, int(k), float(cut_a), float(cut_b),
+             lib.ptr(kn), lib.ptr(kd), lib.ptr(ca), lib.ptr(cb), st)
+    lib.call('pamnet_exclusive_scan_pair_i32', lib.ptr(ca), lib.ptr(ra), lib.ptr(cb), lib.ptr(rb), n, lib.ptr(tmp), st)
+    if flag is None:
+        ta, tb = host_ints(ra[-1], rb[-1])
+    else:
+        ta, tb, bad = host_ints(ra[-1], rb[-1], flag)
+        if bad:
+            _raise_bad_inputs()
+    outs = [(_i32(t, dev), _f32(t, dev), _i32(t, dev), _i32(n + 1, dev)) for t in (ta, tb)]
+    lib.call('pamnet_knn_cut_fill_i32', lib.ptr(kn), lib.ptr(kd), n, int(k), float(cut_a), lib.ptr(ra), ta, lib.ptr(outs[0][0]),
+             lib.ptr(outs[0][1]), lib.ptr(outs[0][2]), lib.ptr(outs[0][3]), float(cut_b), lib.ptr(rb), tb, lib.ptr(outs[1][0]),
+             lib.ptr(outs[1][1]), lib.ptr(outs[1][2]), lib.ptr(outs[1][3]), st)
+    return tuple((o[3], o[0], o[1], o[2]) for o in outs)
+
+
 class InverseTranspose(object):
     """Transposed CSR of an edge list that was itself produced by transposing a query-ordered list (the RNA kNN graphs):
     row r = query r holds the new positions of r's original edges -- the query-ordered pointer and the inverse of the
@@ -258,11 +284,12 @@ class InverseTranspose(object):
         self.ptr, self.perm, self.rows = ptr, inv, int(ptr.numel() - 1)
 
 
-def _transpose_edges(ptr, nbr, dist, n, zeroed=False, want_inverse=False):
+def _transpose_edges(ptr, nbr, dist, n, zeroed=False, want_inverse=False, q=None):
     """CSR by query (q -> nbr) turned into CSR by nbr (aggregate at nbr, other endpoint q).  Returns (ptr, q, dist) of the
     new list and, with want_inverse, the InverseTranspose that gathers along it in the backward."""
     total = int(nbr.numel())
-    q = expand_rows(ptr, total, zeroed=zeroed)
+    if q is None:                                 # (query id of every entry: given by the launch that wrote the list)
+        q = expand_rows(ptr, total, zeroed=zeroed)
     tptr, perm = csr_from_keys(nbr, n)
     out_q, out_d = _i32(total, nbr.device), _f32(total, nbr.device)
     inv = _i32(total, nbr.device) if want_inverse else None
@@ -767,10 +794,11 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     elif rna:
         xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
         pos = xr[:, :3].to(torch.float32).contiguous()
-        kp, kn, kd = knn_table(pos, node_graph, g.gptr, knn_k, float('inf'))   # (query, neighbour) rows, self dropped
         # models.py:147-150 (global) and 153-156 (local: j = query, i = nbr)
         flag = ing[5] if ing is not None else _input_flag(node_graph, g.n_graphs, xr[:, -1].to(torch.float32), n_types)
+        gq = qq = None                            # query ids of the entries, when the launch that wrote the lists gave them
         if sizes is not None:                     # zero host round trips (see `sizes`)
+            kp, kn, kd = knn_table(pos, node_graph, g.gptr, knn_k, float('inf'))   # (query, neighbour) rows, self dropped
             total_g, total_l, tp_hint = (int(v) for v in sizes)
             pa, pb = _filter_count(kp, kn, kd, cutoff_g), _filter_count(kp, kn, kd, cutoff_l)
             g.check = flag
@@ -779,12 +807,18 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             pa, pb = torch.clamp(pa, max=total_g), torch.clamp(pb, max=total_l)
             gp, gn, gd = _filter_fill(kp, kn, kd, cutoff_g, pa, total_g, zeroed=hinted)
             qp, qn, qd = _filter_fill(kp, kn, kd, cutoff_l, pb, total_l, zeroed=hinted)
+        elif n > 0 and knn_k <= 64:               # one search, both cuts, one host round trip
+            (gp, gn, gd, gq), (qp, qn, qd, qq) = knn_cuts(pos, node_graph, g.gptr, knn_k, cutoff_g, cutoff_l, flag)
         else:
+            kp, kn, kd = knn_table(pos, node_graph, g.gptr, knn_k, float('inf'))
             (gp, gn, gd), (qp, qn, qd) = csr_filter2(kp, kn, kd, cutoff_g, cutoff_l, flag)
         glob_inv = None
         if flow != 'target_to_source':                                          # aggregate at edge_index[1] = neighbour
-            gp, gn, gd, glob_inv = _transpose_edges(gp, gn, gd, n, zeroed=hinted, want_inverse=need_grad)
-        lp, l_src, l_dist, loc_inv = _transpose_edges(qp, qn, qd, n, zeroed=hinted, want_inverse=need_grad)
+            gp, gn, gd, glob_inv = _transpose_edges(gp, gn, gd, n, zeroed=hinted, want_inverse=need_grad, q=gq)
+            gq = None
+        elif gq is not None:
+            glob_rows.append(gq)                  # rows = queries: the expanded row ids are the query ids
+        lp, l_src, l_dist, loc_inv = _transpose_edges(qp, qn, qd, n, zeroed=hinted, want_inverse=need_grad, q=qq)
         # (the local layer always aggregates at i)
         l_dst = expand_rows(lp, l_src.numel(), zeroed=hinted)
     else:
