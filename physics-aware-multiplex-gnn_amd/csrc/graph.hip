@@ -75,11 +75,28 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(int32_t* __rest
     }
 }
 
+// RAW: `sums` still holds the chunk totals (no scan_sums launch): the 256 outputs of a workgroup lie in one chunk, whose
+// offset it adds up itself -- a few hundred values at most (the caller takes the three-launch form beyond that).
+template <bool RAW>
 __global__ __launch_bounds__(256) void scan_add_kernel(int32_t* __restrict__ out, int64_t n,
                                                        const int32_t* __restrict__ sums) {
+    __shared__ int part[4];
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int add;
+    if (RAW) {
+        const int chunk = (int)(((int64_t)blockIdx.x * 256) / SCAN_CHUNK);
+        int v = 0;
+        for (int c = threadIdx.x; c < chunk; c += 256) v += sums[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        add = part[0] + part[1] + part[2] + part[3];
+    } else {
+        add = g < n ? sums[g / SCAN_CHUNK] : 0;
+    }
     if (g == 0) out[0] = 0;
-    if (g < n) out[g + 1] += sums[g / SCAN_CHUNK];
+    if (g < n) out[g + 1] += add;
 }
 
 // Runs of equal keys inside a wavefront (the common case: keys emitted row by row) are folded into one atomic by the
@@ -901,9 +918,14 @@ extern "C" int pamnet_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_
     const int64_t nb = ceil_div(n, SCAN_CHUNK);
     hipLaunchKernelGGL(scan_chunk_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, out, n, tmp);
     PAMNET_LAUNCH_CHECK();
+    if (nb <= 1024) {                                         // two launches: every add workgroup sums its chunk's offset itself
+        hipLaunchKernelGGL((scan_add_kernel<true>), dim3(blocks_for(n)), dim3(256), 0, st, out, n, tmp);
+        PAMNET_LAUNCH_CHECK();
+        return PAMNET_OK;
+    }
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, tmp, nb);
     PAMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan_add_kernel, dim3(blocks_for(n)), dim3(256), 0, st, out, n, tmp);
+    hipLaunchKernelGGL((scan_add_kernel<false>), dim3(blocks_for(n)), dim3(256), 0, st, out, n, tmp);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

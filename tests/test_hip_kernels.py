@@ -122,7 +122,7 @@ def test_segment_ops_autograd(dev):
         assert maxnorm_err(a.cpu(), b.cpu()) < 2e-6
 
 
-@pytest.mark.parametrize('n', [0, 1, 5, 1023, 1024, 1025, 4096, 4097, 65535, 65536, 65537, 100000, 24575, 24576, 24577, 1 << 20])
+@pytest.mark.parametrize('n', [0, 1, 5, 1023, 1024, 1025, 4096, 4097, 65535, 65536, 65537, 100000, 24575, 24576, 24577, 1 << 20, 4096 * 1024, 4096 * 1024 + 1, 5000001])
 def test_exclusive_scan_bit_exact(dev, n):
     from pamnet_amd import graph as G
     x = torch.randint(0, 50, (n,), dtype=torch.int32, device=dev)
