@@ -810,3 +810,20 @@ def test_triplet_transpose_equals_counting_sort(dev, case, with_triplets):
             locT.perm = locT.perm[torch.argsort(key)].contiguous()
         got = G.TripletTranspose(loc, locT, tp_ptr, tcount, tot, with_triplets)
         assert torch.equal(got.ptr, want.ptr) and torch.equal(got.perm, want.perm), (case, shuffle)
+
+
+def test_sbf_radial_both_forms_give_the_same_floats(dev):
+    """pamnet_sbf_radial_f32 runs a thread per value below 40 k edges and a thread per (edge, n) above: same arithmetic per
+    value, so a long call equals its short pieces bit for bit."""
+    from pamnet_amd import lib
+    m = 50000
+    dist = (torch.rand(m, device=dev) * 4.9 + 0.05).contiguous()
+    whole = torch.empty(m, 42, device=dev)
+    lib.call('pamnet_sbf_radial_f32', lib.ptr(dist), 5.0, m, lib.ptr(whole), lib.stream_of(dist))
+    parts = torch.empty(m, 42, device=dev)
+    for a in range(0, m, 12500):
+        d = dist[a:a + 12500].contiguous()
+        out = torch.empty(12500, 42, device=dev)
+        lib.call('pamnet_sbf_radial_f32', lib.ptr(d), 5.0, 12500, lib.ptr(out), lib.stream_of(d))
+        parts[a:a + 12500] = out
+    assert torch.equal(whole, parts)
