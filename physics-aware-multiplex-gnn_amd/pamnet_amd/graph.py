@@ -720,7 +720,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
 
         ei = edge_index
         if (sizes is None and ing is not None and MOL_LOCAL and mol_local is not False and ei.size(1) > 0
-                and n <= MOL_ATOMS * g.n_graphs // 2):
+                and (mol_local is True or n <= MOL_ATOMS * g.n_graphs // 2)):
             done = _mol_local_graph(g, pos, ing, cutoff_g, with_triplets, need_grad)
             if done:
                 return g

@@ -342,3 +342,44 @@ def test_store_batches_take_the_molecule_local_builder(dev):
         G.MOL_LOCAL = saved
     assert torch.equal(res[0][0], res[1][0])
     assert all(torch.equal(a, c) for a, c in zip(res[0][1], res[1][1]))
+
+
+@pytest.mark.parametrize('seed', list(range(8)))
+def test_molecule_local_builder_random_molecules(dev, seed):
+    """Seeded random batches up to the builder's limits: 1-64 atoms, random directed bond lists (duplicates, one-directional
+    bonds, atoms without bonds), clustered positions (coincident atoms included), a cutoff drawn per batch."""
+    from pamnet_amd import graph as G, synth
+    rng = np.random.default_rng(100 + seed)
+    mols = []
+    for _ in range(int(rng.integers(1, 24))):
+        na = int(rng.integers(1, 65)) if rng.random() < 0.8 else 64
+        pos = (rng.normal(size=(na, 3)) * rng.uniform(0.5, 3.0)).astype(np.float32)
+        if na > 2 and rng.random() < 0.3:
+            pos[1] = pos[0]                                   # coincident atoms: zero distances, ties
+        nb = int(rng.integers(0, min(256, 4 * na) + 1)) if na > 1 else 0
+        s = rng.integers(0, na, nb)
+        d = rng.integers(0, na, nb)
+        keep = s != d
+        ei = np.stack([s[keep], d[keep]]).astype(np.int64)
+        mols.append(dict(x=rng.integers(0, 5, na).astype(np.float32), pos=pos, edge_index=ei, y=np.float32(0.0)))
+    b = synth.collate(mols).to(dev)
+    kw = dict(dataset='QM9', cutoff_l=5.0, cutoff_g=float(rng.uniform(0.8, 6.0)), flow='source_to_target', n_types=5)
+    if b.edge_index.size(1) == 0:
+        pytest.skip('no bonds drawn')
+    saved = G.MOL_LOCAL
+    try:
+        G.MOL_LOCAL = False
+        ref = _build(b, kw, True, True)
+        G.MOL_LOCAL = True
+        got = _build(b, kw, True, True, mol_local=True)
+        if ref.glob.m > 0 and ref.tp.m > 0:
+            eng = _build(b, kw, True, True, (ref.glob.m, ref.loc.m, ref.tp.m), mol_local=True)
+        else:
+            eng = None
+    finally:
+        G.MOL_LOCAL = saved
+    _same_graph(got, ref, True, kw, 'random:plain')
+    if eng is not None:
+        torch.cuda.synchronize()
+        G.raise_for_flag(G.read_flags([eng.check]))
+        _same_graph(eng, ref, True, kw, 'random:engine')
