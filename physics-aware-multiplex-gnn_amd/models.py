@@ -168,6 +168,11 @@ class _PAMNetBase(nn.Module):
 
     # ------------------------------------------------------------------------------------------------------------
     def _graph(self, data):
+        ev = getattr(data, 'inputs_ready', None)
+        if ev is not None and data.batch.is_cuda:
+            # a batch produced on another stream (asynchronous upload, device-side collation) says so: this stream waits for
+            # exactly that event (a no-op when it is the producing stream)
+            torch.cuda.current_stream(data.batch.device).wait_event(ev)
         pre = getattr(data, '_pamnet_prepared', None)
         if pre is not None:
             data._pamnet_prepared = None                 # a prepared graph serves exactly one forward: nothing is cached
