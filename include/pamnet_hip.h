@@ -187,7 +187,8 @@ int pamnet_check_sizes_i32(int64_t n_checks, const int32_t* const* actual /* hos
 /* The reference's index tensors (`x`, `edge_index`, `batch` of models.py:104-110; `j, i = edge_index` models.py:64) in
  * ONE launch: each is read as int64 (kind 1, what PyG hands over), int32 (2) or fp32 (3; kind 0 = no `x`) and written as
  * int32 -- node_graph [n], types [n] (element i read at x[i * x_stride]), src / dst [n_edges].  gptr_flag holds
- * n_graphs + 3 ints, zeroed by the call: gptr_flag[0 .. n_graphs] = first node of every graph (the CSR pointer of the
+ * n_graphs + 7 ints, zeroed by the call (the last four are spare zeroed words for the caller: the molecule-local builder's
+ * batch totals live there), gptr_flag[0 .. n_graphs] = first node of every graph (the CSR pointer of the
  * sorted batch vector), gptr_flag[n_graphs + 1] = 1 when an index is out of range (batch unsorted / not in [0, n_graphs),
  * type not in [0, n_types), edge endpoint not in [0, n): the reference raises IndexError; offending entries are written
  * as 0 so that later kernels stay in bounds), gptr_flag[n_graphs + 2] = 1 when the edge list has a self loop

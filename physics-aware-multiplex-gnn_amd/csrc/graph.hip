@@ -1471,7 +1471,7 @@ extern "C" int pamnet_ingest_indices_i32(const void* batch, int32_t batch_kind, 
         (n_edges > 0 && (!edge_src || !edge_dst || !src || !dst)))
         return PAMNET_ENULL;
     hipStream_t st = as_stream(stream);
-    const hipError_t e = hipMemsetAsync(gptr_flag, 0, sizeof(int32_t) * (n_graphs + 3), st);
+    const hipError_t e = hipMemsetAsync(gptr_flag, 0, sizeof(int32_t) * (n_graphs + 7), st);     // (+ 4 spare words: header)
     if (e != hipSuccess) return (int)e;
     const int64_t total = n > n_edges ? n : n_edges;
     if (total == 0) return PAMNET_OK;

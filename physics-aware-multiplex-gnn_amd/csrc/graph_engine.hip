@@ -104,7 +104,7 @@ int run(Run& r) {
     for (int f = 0; f < PAMNET_GRAPH_FIELDS; ++f) r.lay[f] = -1;
 
     // ---- the reference's index tensors as int32 + the per-graph node pointer + the validity / self-loop flags
-    const int64_t node_graph = r.take(n), types = r.take(n), gf = r.take(ng + 3);
+    const int64_t node_graph = r.take(n), types = r.take(n), gf = r.take(ng + 7);
     const int64_t src0 = r.take(d.n_bonds), dst0 = r.take(d.n_bonds);
     r.field(PAMNET_GF_NODE_GRAPH, node_graph);
     r.field(PAMNET_GF_GPTR, gf);
@@ -147,7 +147,6 @@ int run(Run& r) {
     }
     // counters of the counting sorts (rows + 2 each): bond CSR / local transposition, transposed global, transposed local
     const int64_t cur_a = r.take(n + 2), cur_b = r.take(n + 2), cur_c = r.take(n + 2);
-    const int64_t mol_totals = r.take(4);                     // batch totals of the molecule-local builder (QM9)
     // the transposed triplet / pair rows: written by a capped structural fill, so the tail stays valid with wrong sizes
     const int64_t tT_perm_z = grad ? r.take(tp) : -1;
     const int64_t z1 = r.off;
@@ -178,6 +177,7 @@ int run(Run& r) {
     };
 
     int64_t tT_ptr = -1, tT_perm = -1;
+    const int64_t mol_totals = gf + ng + 3;                   // the ingest launch's four spare zeroed words
     const bool mol = d.schema == PAMNET_SCHEMA_QM9 && d.mol_local != 0;
     if (mol) {
         // molecule-local builder (graph_mol.hip): two launches write every index / geometry array of the batch

@@ -377,7 +377,7 @@ def ingest(batch, n_graphs, x=None, n_types=None, edge_index=None):
         ne, ek = int(es.numel()), _KINDS[edge_index.dtype]
     dev = batch.device
     na, ea = (n + 3) // 4 * 4, (ne + 3) // 4 * 4          # 16-byte aligned sections of one allocation
-    buf = _i32(2 * na + 2 * ea + n_graphs + 3, dev)
+    buf = _i32(2 * na + 2 * ea + n_graphs + 7, dev)
     node_graph, types = buf[:n], buf[na:na + n]
     src, dst = buf[2 * na:2 * na + ne], buf[2 * na + ea:2 * na + ea + ne]
     gf = buf[2 * na + 2 * ea:]
@@ -387,7 +387,7 @@ def ingest(batch, n_graphs, x=None, n_types=None, edge_index=None):
              types.data_ptr() if n else None, src.data_ptr() if ne else None, dst.data_ptr() if ne else None,
              lib.stream_of(batch))
     return node_graph, gf[:n_graphs + 1], (types if xk else None), src, dst, gf[n_graphs + 1:n_graphs + 2], \
-        gf[n_graphs + 2:n_graphs + 3]
+        gf[n_graphs + 2:n_graphs + 3], gf[n_graphs + 3:n_graphs + 7]
 
 
 def _check_sizes(flag, checks, all_kept=None, loops=None):
@@ -602,12 +602,11 @@ def _mol_local_graph(g, pos, ing, cutoff_g, with_triplets, need_grad):
     the sizes / validity / qualification, fill launch.  Fills `g` and returns True; False when the batch does not qualify
     (a molecule over the builder's limits, bonds not grouped by molecule, self loops): nothing of `g` was touched."""
     import ctypes
-    node_graph, gptr, _, src0, dst0, flag, loops = ing
+    node_graph, gptr, _, src0, dst0, flag, loops, totals = ing       # totals: four zeroed words behind the flags
     dev = pos.device
     n, ng, m = g.n, g.n_graphs, int(src0.numel())
     st = lib.stream_of(pos)
     mol_tot = _i32(4 * ng, dev)
-    totals = torch.zeros(4, dtype=I32, device=dev)
     wt = 1 if with_triplets else 0
     lib.call('pamnet_mol_graph_count_i32', lib.ptr(pos), lib.ptr(gptr), n, ng, lib.ptr(src0), lib.ptr(dst0), m, float(cutoff_g),
              wt, lib.ptr(mol_tot), lib.ptr(totals), st)

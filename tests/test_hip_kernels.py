@@ -641,7 +641,8 @@ def test_ingest_indices_matches_tensor_ops(dev, kinds):
     ei = ei.to(dt[kinds[2]])
     for shape in ('flat', 'column'):
         xs = x if shape == 'flat' else x.view(-1, 1)
-        node_graph, gptr, types, src, dst, flag, loops = G.ingest(batch, n_graphs, xs, 5, ei)
+        node_graph, gptr, types, src, dst, flag, loops, spare = G.ingest(batch, n_graphs, xs, 5, ei)
+        assert int(spare.abs().sum()) == 0                  # four zeroed words for the caller
         ref_ptr, _ = G.csr_from_keys(batch.to(torch.int32).contiguous(), n_graphs)
         assert torch.equal(node_graph, batch.to(torch.int32)) and torch.equal(gptr, ref_ptr)
         assert torch.equal(types, x.to(torch.int32))
