@@ -11,7 +11,7 @@ import test_graph_engine as T
 from pamnet_amd import graph as G, synth, lib
 lib.load()
 dev = torch.device('cuda:0')
-bad = 0
+bad = done = 0
 for seed in range(300):
     rng = np.random.default_rng(1000 + seed)
     mols = []
@@ -36,10 +36,11 @@ for seed in range(300):
         G.MOL_LOCAL = True
         got = T._build(b, kw, ng_, wt, mol_local=True)
         T._same_graph(got, ref, ng_, kw, 'fuzz')
+        done += 1
         if ref.glob.m > 0 and ref.tp.m > 0:
             eng = T._build(b, kw, ng_, wt, (ref.glob.m, ref.loc.m, ref.tp.m), mol_local=True)
             torch.cuda.synchronize(); G.raise_for_flag(G.read_flags([eng.check]))
             T._same_graph(eng, ref, ng_, kw, 'fuzz-eng')
     except Exception as e:
         bad += 1; print('seed', seed, type(e).__name__, str(e)[:200])
-print('done, failures:', bad)
+print('compared', done, 'batches; failures:', bad)
