@@ -1,6 +1,6 @@
 """Seeded fuzzing of the RNA-schema graph construction: engine (one C call: fused kNN cut, structural triplet transposition,
 counting sorts with arrival order) against the step-by-step launches with and without host-side sizes -- random point clouds
-incl. lattices (many equal distances: the tie rules) and coincident nodes, both flows.  usage (GPU box): python tools/fuzz_rna_graph.py"""
+incl. lattices (many equal distances: the tie rules) and coincident nodes, both flows.  usage (GPU box): python tools/fuzz_engine_graph.py"""
 import os
 import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -51,4 +51,44 @@ for seed in range(120):
         print('seed', seed, type(e).__name__, str(e)[:300])
     finally:
         G.ENGINE = True
-print('compared', done, 'batches; failures:', bad)
+print('RNA schema: compared', done, 'batches; failures:', bad)
+
+# PDBbind schema: radius graphs at both cutoffs, reverse-edge transposes
+bad = done = 0
+for seed in range(60):
+    rng = np.random.default_rng(9000 + seed)
+    graphs = []
+    for _ in range(int(rng.integers(1, 5))):
+        n = int(rng.integers(2, 500))
+        pos = rng.normal(size=(n, 3)) * rng.uniform(2.0, 8.0) + 38.0      # around the pocket / ligand sign threshold (x > 40)
+        if rng.random() < 0.4:
+            pos = np.round(pos)
+        x = np.concatenate([pos, rng.normal(size=(n, 18))], 1).astype(np.float32)
+        graphs.append(dict(x=x, y=np.float32(0)))
+    b = synth.collate(graphs).to(dev)
+    kw = dict(dataset='PDBbind', cutoff_l=float(rng.uniform(1.0, 2.5)), cutoff_g=float(rng.uniform(3.0, 7.0)),
+              flow='source_to_target', n_types=None)
+    ng_ = bool(rng.integers(0, 2))
+    try:
+        ref = T._build(b, kw, ng_, True)
+        if min(ref.glob.m, ref.loc.m, ref.tp.m) < 1:
+            continue
+        if ng_:
+            T._transposes_are_the_counting_sorts(ref)
+        sizes = (ref.glob.m, ref.loc.m, ref.tp.m)
+        G.ENGINE = False
+        old = T._build(b, kw, ng_, True, sizes)
+        G.ENGINE = True
+        eng = T._build(b, kw, ng_, True, sizes)
+        assert isinstance(eng, G.EngineGraph)
+        torch.cuda.synchronize()
+        G.raise_for_flag(G.read_flags([eng.check]))
+        T._same_graph(eng, ref, ng_, kw, 'ref')
+        T._same_graph(eng, old, ng_, kw, 'old')
+        done += 1
+    except Exception as e:
+        bad += 1
+        print('seed', seed, type(e).__name__, str(e)[:300])
+    finally:
+        G.ENGINE = True
+print('PDBbind schema: compared', done, 'batches; failures:', bad)
