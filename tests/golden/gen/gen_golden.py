@@ -377,18 +377,22 @@ def main():
         return main_baseline()
     if '--basis-only' in sys.argv:
         return main_basis()
+    if '--baseline-s-only' in sys.argv:
+        return main_baseline_s()
     main_forward()
     main_train()
     main_baseline()
+    main_baseline_s()
     main_basis()
 
 
-def fixture_baseline(name, cfg_kw, batch, seed, grads=False):
+def fixture_baseline(name, cfg_kw, batch, seed, grads=False, small=False):
     """The reference itself at a BASELINE.json batch size: graph outputs and pooled node values (fp32 and fp64 runs) plus
     the integer sizes of its graphs.  Inputs are not stored -- tests regenerate them from pamnet_amd.synth (deterministic
     per graph index) and check the checksum kept here."""
     cfg = ref_models.Config(**cfg_kw)
-    sd = oracle.init_state_dict(cfg, seed=seed)
+    cls = ref_models.PAMNet_s if small else ref_models.PAMNet
+    sd = oracle.init_state_dict(cfg, seed=seed, small=small)
     arrs = dict(seed=np.int64(seed), weights_checksum=np.float64(checksum(sd)),
                 cfg_dataset=np.array(cfg_kw['dataset']), cfg_dim=np.int64(cfg_kw['dim']),
                 cfg_n_layer=np.int64(cfg_kw['n_layer']), cfg_cutoff_l=np.float64(cfg_kw['cutoff_l']),
@@ -396,7 +400,7 @@ def fixture_baseline(name, cfg_kw, batch, seed, grads=False):
                 x_checksum=np.float64(batch.x.double().abs().sum()), num_nodes=np.int64(batch.x.size(0)),
                 num_graphs=np.int64(int(batch.batch.max()) + 1))
     for tag, dtype in (('32', torch.float32), ('64', torch.float64)):
-        model = build_model(ref_models.PAMNet, cfg)
+        model = build_model(cls, cfg)
         print(name, tag, model.load_state_dict(sd), flush=True)
         if dtype == torch.float64:
             model = model.double()
@@ -407,11 +411,11 @@ def fixture_baseline(name, cfg_kw, batch, seed, grads=False):
         if tag == '32':
             arrs['num_edges_l'] = np.int64(rec['edge_index_l'].shape[1])
             arrs['num_pairs'] = np.int64(rec['idx_jj_pair'].numel())
-            arrs['num_triplets'] = np.int64(rec['idx_kj'].numel())
+            arrs['num_triplets'] = np.int64(rec['idx_kj'].numel() if 'idx_kj' in rec else 0)
     if grads:
         # the reference's own fp64 autograd of the mean L1 loss at this batch: loss, global gradient norm, every parameter
         # gradient's max-magnitude and L2 norm (checks of the whole backward) and a few full tensors
-        model = build_model(ref_models.PAMNet, cfg)
+        model = build_model(cls, cfg)
         model.load_state_dict(sd)
         model = model.double()
         out = model(make_data(batch, torch.float64))
@@ -444,6 +448,12 @@ def main_baseline():
     fixture_baseline('baseline_pdbbind_b32', pdb, synth.collate([synth.pdbbind_complex(1, i) for i in range(32)]), seed=3)
     rna = dict(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
     fixture_baseline('baseline_rna_b8', rna, synth.rna_batch(2, 0, 8), seed=5)
+
+
+def main_baseline_s():
+    """PAMNet_s (pairs only, models.py:283-353) at the batch bench.py times: the reference itself, fp32 and fp64."""
+    qm9 = dict(dataset='QM9', dim=128, n_layer=6, cutoff_l=5.0, cutoff_g=5.0)
+    fixture_baseline('baseline_qm9s_b128', qm9, synth.qm9_batch(0, 0, 128), seed=0, small=True)
 
 
 def main_basis():

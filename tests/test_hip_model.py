@@ -609,6 +609,7 @@ def _baseline_batch(name):
     from pamnet_amd import synth
     return {'baseline_qm9_b32': lambda: synth.qm9_batch(0, 0, 32),
             'baseline_qm9_b128': lambda: synth.qm9_batch(0, 0, 128),
+            'baseline_qm9s_b128': lambda: synth.qm9_batch(0, 0, 128),
             'baseline_pdbbind_b8': lambda: synth.collate([synth.pdbbind_complex(1, i) for i in range(8)]),
             'baseline_pdbbind_b32': lambda: synth.collate([synth.pdbbind_complex(1, i) for i in range(32)]),
             'baseline_rna_b8': lambda: synth.rna_batch(2, 0, 8)}[name]()
@@ -616,7 +617,7 @@ def _baseline_batch(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', ['baseline_qm9_b32', 'baseline_qm9_b128', 'baseline_pdbbind_b8', 'baseline_pdbbind_b32',
-                                  'baseline_rna_b8'])
+                                  'baseline_rna_b8', 'baseline_qm9s_b128'])
 def test_baseline_sizes_vs_reference_runs(dev, golden, name):
     """The HIP path against runs of the REFERENCE ITSELF (tests/golden/gen/gen_golden.py --baseline-only, fp32 and fp64)
     at the BASELINE.json batch sizes: configs[0] (QM9 d=128 L=6 B=32), configs[1] (B=128 -- the exact batch bench.py
@@ -628,9 +629,10 @@ def test_baseline_sizes_vs_reference_runs(dev, golden, name):
     cfg = _cfg_from(g, models.Config)
     b = _baseline_batch(name)
     assert b.x.size(0) == int(g['num_nodes']) and abs(float(b.x.double().abs().sum()) - float(g['x_checksum'])) < 1e-6
-    sd = O.init_state_dict(cfg, seed=int(g['seed']))
+    small = 'qm9s' in name                       # PAMNet_s (pairs only, models.py:283-353) at the batch bench.py times
+    sd = O.init_state_dict(cfg, seed=int(g['seed']), small=small)
     assert abs(sum(float(v.double().abs().sum()) for v in sd.values()) - float(g['weights_checksum'])) < 1e-6
-    model = models.PAMNet(cfg)
+    model = (models.PAMNet_s if small else models.PAMNet)(cfg)
     model.load_state_dict(sd, strict=True)
     model = model.to(dev)
     with torch.no_grad():
