@@ -200,7 +200,8 @@ def mfma_summary(args, g, ms_per_step):
 
 def other_configs(dev):
     """Full training step and forward of the other BASELINE.json configurations on this GPU (parity-test cases, not the
-    bench line's `value`): configs[3] PDBbind schema d=128 L=3 B=32 and configs[4] RNA schema d=16 L=1 B=8 -- graph rebuilt
+    bench line's `value`): configs[3] PDBbind schema d=128 L=3 B=32, configs[4] RNA schema d=16 L=1 B=8 and PAMNet_s on the main
+    loop's QM9 batches -- graph rebuilt
     every step, input pipeline as in the main loop, 4 distinct resident batches."""
     import models
     from pamnet_amd import synth
@@ -209,14 +210,17 @@ def other_configs(dev):
     out = {}
     rna = [synth.rna_chain(2, i) for i in range(8)]        # the 8 graphs of configs[4]; the 4 batches are rotations of them
     pdb = [synth.pdbbind_complex(1, i) for i in range(128)]
+    qm9 = [synth.qm9_molecule(0, i) for i in range(512)]  # the molecules of the main loop, for PAMNet_s (models.py:283-353)
     for tag, cfg, graphs, sel, steps in (
             ('pdbbind_b32_d128_l3', models.Config(dataset='PDBbind', dim=128, n_layer=3, cutoff_l=2.0, cutoff_g=6.0),
              pdb, lambda k: list(range(32 * k, 32 * k + 32)), 40),
             ('rna_b8_d16_l1', models.Config(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0,
                                             flow='target_to_source'),
-             rna, lambda k: [(i + 2 * k) % 8 for i in range(8)], 100)):
+             rna, lambda k: [(i + 2 * k) % 8 for i in range(8)], 100),
+            ('pamnet_s_qm9_b128_d128_l6', models.Config(dataset='QM9', dim=128, n_layer=6, cutoff_l=5.0, cutoff_g=5.0),
+             qm9, lambda k: list(range(128 * k, 128 * k + 128)), 100)):
         torch.manual_seed(7)
-        model = models.PAMNet(cfg).to(dev)
+        model = (models.PAMNet_s if tag.startswith('pamnet_s') else models.PAMNet)(cfg).to(dev)
         tr = Trainer(model, lr=1e-4)
         bs = [synth.collate([graphs[i] for i in sel(k)]).to(dev) for k in range(4)]
         for i in range(5):
