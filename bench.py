@@ -223,7 +223,7 @@ def other_configs(dev):
         model = (models.PAMNet_s if tag.startswith('pamnet_s') else models.PAMNet)(cfg).to(dev)
         tr = Trainer(model, lr=1e-4)
         bs = [synth.collate([graphs[i] for i in sel(k)]).to(dev) for k in range(4)]
-        for i in range(5):
+        for i in range(20):                                   # (the allocator's cache was emptied after the previous configuration)
             tr.step(bs[i % 4], next_data=bs[(i + 1) % 4])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
