@@ -366,6 +366,30 @@ def cpu_baseline(args, seconds):
                 forward_only=fwd_mps)
 
 
+def self_launch(args, result_out):
+    """`python bench.py --gpus N` without a launcher: run N ranks of this file under torch.distributed.run (one process per
+    GPU, rendezvous on 127.0.0.1 at a port the kernel hands out) and pass rank 0's JSON line through.  Returns the exit code."""
+    import socket
+    import subprocess
+    if not args.cpu_dry_run and torch.cuda.device_count() < args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but only %d visible\n' % (args.gpus, torch.cuda.device_count()))
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith('{')]
+    for l in lines[-1:]:                                       # exactly one line on stdout, as with a launcher
+        result_out.write(l + '\n')
+    result_out.flush()
+    return proc.returncode if (proc.returncode or lines) else 1
+
+
 def guarded(fn, *a):
     """A side leg of the line: its failure is reported in its field, the line is still printed."""
     try:
@@ -383,7 +407,14 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run on a free
+        # local port; the ranks run this same file with the same arguments and rank 0's JSON line is passed through
+        sys.exit(self_launch(args, result_out))
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU: python -m torch.distributed.run '
+                 '--nproc-per-node %d bench.py --gpus %d, or plainly python bench.py --gpus %d)'
+                 % (args.gpus, world, args.gpus, args.gpus, args.gpus))
     dry = args.cpu_dry_run
     if dry:
         dev = torch.device('cpu')

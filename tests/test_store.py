@@ -256,3 +256,269 @@ def test_other_schemas_without_host_sync(dev, kind):
                 model(bad)
             with pytest.raises(GraphCheckError):
                 model.verify()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# SURVEY 8f N2 against the REFERENCE, not against the step-by-step HIP path: resident store -> pamnet_collate_f32 ->
+# pamnet_graph_plan / pamnet_graph_build_i32 (graph + basis as one engine call, QM9: the molecule-local builder) -> model,
+# compared with the reference-run goldens under the same bounds as tests/test_hip_model.py.  What these calls replace:
+# the reference's DataLoader collation (main_qm9.py:74-77) and models.py:104-177.
+def _split(b):
+    """Per-graph dicts (what a dataset holds) of a collated batch: node rows, positions, bonds with graph-local endpoints."""
+    batch = b.batch.numpy()
+    ng = int(batch.max()) + 1
+    ptr = np.searchsorted(batch, np.arange(ng + 1))
+    ei = b.edge_index.numpy() if getattr(b, 'edge_index', None) is not None else None
+    out = []
+    for k in range(ng):
+        lo, hi = int(ptr[k]), int(ptr[k + 1])
+        d = dict(x=b.x[lo:hi].numpy(), y=np.float32(b.y[k]))
+        if getattr(b, 'pos', None) is not None:
+            d['pos'] = b.pos[lo:hi].numpy()
+        if ei is not None:
+            sel = (ei[0] >= lo) & (ei[0] < hi)
+            d['edge_index'] = ei[:, sel] - lo
+        out.append(d)
+    return out
+
+
+def _through_store(model, graphs, dev, grad=False):
+    """The batch of ALL `graphs` (in order) through the resident store; asserts that the engine built the graph and that the
+    forward read nothing back."""
+    from pamnet_amd import graph as G, store as S
+    st = S.MoleculeStore(graphs, dev).prepare_for(model)
+    idx = list(range(len(graphs)))
+    with torch.set_grad_enabled(grad):
+        model(st.collate(idx))                                   # warm every cache the first hinted call fills
+    torch.cuda.synchronize()
+    b = st.collate(idx)
+    assert b.sizes
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        with torch.set_grad_enabled(grad):
+            out = model(b)
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    assert isinstance(model._graph_cache, G.EngineGraph), 'the zero-host-sync engine call must be what ran'
+    model.verify()
+    return out, b, st
+
+
+GOLDEN_INPUT_CASES = [('qm9_d32_l2', False), ('qm9s_d32_l2', True), ('pdbbind_d32_l2', False), ('qm9_ragged_d32_l2', False),
+                      ('qm9s_ragged_d32_l2', True), ('pdbbind_d128_l3', False), ('qm9s_d128_l2', True), ('qm9_d128_l6', False),
+                      ('qm9_basis_5x4_p6_d32_l2', False), ('qm9_basis_8x7_p4_d128_l2', False)]
+
+
+@pytest.mark.parametrize('name,small', GOLDEN_INPUT_CASES)
+def test_store_engine_path_vs_reference_golden(dev, golden, name, small):
+    """Every reference-run fixture that carries its inputs, through store -> collate -> engine graph -> model: per-layer node
+    features, pooled node values, graph outputs within the parity bound of the reference's fp64 run; integer sizes exact."""
+    import models
+    from oracle import pamnet_oracle as O
+    from test_hip_model import _basis_args, _batch_from, _cfg_from, _ok
+    from conftest import maxnorm_err
+    g = golden(name)
+    cfg = _cfg_from(g, models.Config)
+    model = (models.PAMNet_s if small else models.PAMNet)(cfg, *_basis_args(cfg))
+    model.load_state_dict(O.init_state_dict(cfg, seed=int(g['seed']), small=small), strict=True)
+    model = model.to(dev)
+    graphs = _split(_batch_from(g, 'cpu'))
+    out, b, _ = _through_store(model, graphs, dev)
+    out = out.cpu().numpy()
+    ok, info = _ok(model._node_out.cpu().numpy(), g['node_out32'], g['node_out64'])
+    assert ok, ('node_out', info)
+    if 'x_layers64' in g.files:
+        ok, info = _ok(torch.stack(list(model._x_layers)).cpu().numpy(), g['x_layers32'], g['x_layers64'])
+        assert ok, ('x_layers', info)
+    scale = None
+    if cfg.dataset == 'PDBbind':
+        scale = max(float(np.abs(g['node_out64'][g['in/batch'] == k]).sum()) for k in range(len(g['out64'])))
+    ok, info = _ok(out, g['out32'], g['out64'], scale)
+    assert ok, ('out', info)
+    if scale is not None:
+        raw, raw_floor = maxnorm_err(out, g['out64']), maxnorm_err(g['out32'], g['out64'])
+        assert raw <= max(1e-5, 2 * raw_floor), (raw, raw_floor)
+    gc = model._graph_cache
+    assert gc.loc.m == int(g['num_edges_l']) and gc.n_pair == int(g['num_pairs'])
+    if not small:
+        assert gc.n_trip == int(g['num_triplets'])
+
+
+BASELINE_CASES = ['baseline_qm9_b32', 'baseline_qm9_b128', 'baseline_pdbbind_b8', 'baseline_pdbbind_b32', 'baseline_rna_b8',
+                  'baseline_qm9s_b128']
+
+
+def _baseline_graphs(name):
+    from pamnet_amd import synth
+    kind, n = name.split('_')[1], int(name.rsplit('_b', 1)[1])
+    if kind.startswith('qm9'):
+        return [synth.qm9_molecule(0, i) for i in range(n)]
+    if kind == 'pdbbind':
+        return [synth.pdbbind_complex(1, i) for i in range(n)]
+    return [synth.rna_chain(2, i) for i in range(n)]
+
+
+@pytest.mark.parametrize('name', BASELINE_CASES)
+def test_store_engine_path_at_baseline_sizes_vs_reference_runs(dev, golden, name):
+    """The six runs of the REFERENCE ITSELF at the BASELINE.json batch sizes (tests/golden/gen/gen_golden.py --baseline-only),
+    through the path bench.py's zero_host_sync / store_* fields time."""
+    import models
+    from oracle import pamnet_oracle as O
+    from test_hip_model import _cfg_from, _ok
+    from conftest import maxnorm_err
+    g = golden(name)
+    cfg = _cfg_from(g, models.Config)
+    small = 'qm9s' in name
+    sd = O.init_state_dict(cfg, seed=int(g['seed']), small=small)
+    assert abs(sum(float(v.double().abs().sum()) for v in sd.values()) - float(g['weights_checksum'])) < 1e-6
+    model = (models.PAMNet_s if small else models.PAMNet)(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    graphs = _baseline_graphs(name)
+    out, b, st = _through_store(model, graphs, dev)
+    assert b.x.size(0) == int(g['num_nodes']) and abs(float(b.x.double().abs().sum()) - float(g['x_checksum'])) < 1e-6
+    out = out.cpu().numpy()
+    ok, info_n = _ok(model._node_out.cpu().numpy(), g['node_out32'], g['node_out64'])
+    assert ok, ('node_out', info_n)
+    gc = model._graph_cache
+    assert gc.loc.m == int(g['num_edges_l']) and gc.n_trip == int(g['num_triplets']) and gc.n_pair == int(g['num_pairs'])
+    if cfg.dataset == 'PDBbind':
+        batch = b.batch.cpu().numpy()
+        scale = max(float(np.abs(g['node_out64'][batch == k]).sum()) for k in range(len(g['out64'])))
+        ok, info = _ok(out, g['out32'], g['out64'], scale)
+        assert ok, ('out', info)
+        raw, raw_floor = maxnorm_err(out, g['out64']), maxnorm_err(g['out32'], g['out64'])
+        assert raw <= max(1e-5, 2 * raw_floor), (raw, raw_floor)
+    else:
+        ok, info = _ok(out, g['out32'], g['out64'])
+        assert ok, ('out', info)
+    print('%s through the store: out %.2e (ref fp32 %.2e), node_out %.2e (ref fp32 %.2e)' % ((name,) + info + info_n))
+
+
+@pytest.mark.parametrize('name', ['qm9_d32_l2', 'pdbbind_d32_l2', 'pdbbind_d128_l3', 'qm9_basis_5x4_p6_d32_l2',
+                                  'qm9_basis_8x7_p4_d128_l2'])
+def test_store_engine_path_gradients_vs_reference_golden(dev, golden, name):
+    """d L1-loss / d params with the graph (and the transposed index lists of the backward) built by the engine call on a
+    store batch, against the reference's fp64 autograd."""
+    import models
+    from oracle import pamnet_oracle as O
+    from test_hip_model import _basis_args, _batch_from, _cfg_from
+    from conftest import maxnorm_err
+    g = golden(name)
+    cfg = _cfg_from(g, models.Config)
+    model = models.PAMNet(cfg, *_basis_args(cfg))
+    model.load_state_dict(O.init_state_dict(cfg, seed=int(g['seed'])), strict=True)
+    model = model.to(dev)
+    out, b, _ = _through_store(model, _split(_batch_from(g, 'cpu')), dev, grad=True)
+    model.zero_grad()
+    loss = torch.nn.functional.l1_loss(out, b.y)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss64'])) < 2e-5 * max(1.0, abs(float(g['loss64'])))
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+    assert abs(gn / float(g['grad_norm64']) - 1) < 1e-4
+    sd = dict(model.named_parameters())
+    for k in g.files:
+        if k.startswith('grad64/'):
+            assert maxnorm_err(sd[k[7:]].grad.cpu().numpy(), g[k]) < 1e-4, k
+
+
+def test_store_trainer_step_at_configs1_vs_reference_gradients(dev, golden):
+    """Trainer.forward_backward on a STORE batch at BASELINE configs[1] (QM9 schema, d=128, L=6, B=128): loss, gradient norm,
+    every parameter gradient's L2 norm and the committed full gradient tensors of the REFERENCE's fp64 autograd
+    (tests/golden/baseline_qm9_b128.npz) -- and bitwise the gradients of the same step on plain tensors."""
+    import models
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import graph as G, store as S, synth, train
+    from conftest import maxnorm_err
+    g = golden('baseline_qm9_b128')
+    cfg = models.Config(dataset='QM9', dim=128, n_layer=6, cutoff_l=5.0, cutoff_g=5.0)
+    model = models.PAMNet(cfg)
+    model.load_state_dict(O.init_state_dict(cfg, seed=0), strict=True)
+    model = model.to(dev)
+    tr = train.Trainer(model, lr=1e-4)
+    st = S.MoleculeStore([synth.qm9_molecule(0, i) for i in range(128)], dev).prepare_for(model)
+    tr.forward_backward(st.collate(list(range(128))))
+    torch.cuda.synchronize()
+    b = st.collate(list(range(128)))
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        loss = tr.forward_backward(b)
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    assert isinstance(model._graph_cache, G.EngineGraph) and model._one_node()
+    model.verify()
+    assert abs(float(loss) - float(g['loss64'])) < 2e-5 * max(1.0, abs(float(g['loss64'])))
+    gn = float(torch.linalg.vector_norm(tr.fp.grad.double()))
+    assert abs(gn / float(g['grad_norm64']) - 1) < 1e-4, (gn, float(g['grad_norm64']))
+    grads = dict(zip(tr.fp.names, tr.fp.grad_views))
+    for k, l2 in zip(g['grad_keys'].tolist(), g['grad_l2_64']):
+        e = abs(float(grads[k].double().norm()) - float(l2)) / max(float(l2), 1e-300)
+        assert e < 1e-4, (k, e)
+    worst = 0.0
+    for k in g.files:
+        if k.startswith('grad64/'):
+            e = maxnorm_err(grads[k[7:]].cpu().numpy(), g[k])
+            assert e < 1e-4, (k, e)
+            worst = max(worst, e)
+    via_store = tr.fp.grad.clone()
+    tr.forward_backward(synth.qm9_batch(0, 0, 128).to(dev))      # plain tensors: sizes read back, same kernels
+    assert torch.equal(via_store, tr.fp.grad)
+    print('Trainer.forward_backward through the store at configs[1]: worst full gradient tensor vs reference fp64 %.1e' % worst)
+
+
+def test_store_engine_path_rna_checkpoint(dev, golden):
+    """Shipped checkpoint + shipped RNA-Puzzles graphs (TU rows: xyz + type) as a resident store: per-graph scores against
+    the reference's fp32 / fp64 runs, batched selection == each alone."""
+    import models
+    from test_hip_model import _ok
+    g = golden('rna_native')
+    cfg = models.Config(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
+    model = models.PAMNet(cfg)
+    model.load_state_dict({k: torch.from_numpy(g['ckpt/' + k]) for k in g['ckpt_keys'].tolist()}, strict=True)
+    model = model.to(dev).eval()
+    gids = (6, 4, 17)
+    graphs = [dict(x=g['g%d/x' % gid], y=np.float32(0)) for gid in gids]
+    out, _, st = _through_store(model, graphs, dev)
+    out = out.cpu().numpy()
+    for k, gid in enumerate(gids):
+        ok, info = _ok(out[k:k + 1], g['g%d/out32' % gid], g['g%d/out64' % gid])
+        assert ok, (gid, info)
+    with torch.no_grad():
+        one = model(st.collate([1]))
+    model.verify()
+    gc = model._graph_cache
+    assert gc.loc.m == int(g['g4/num_edges_l']) and gc.n_trip == int(g['g4/num_triplets']) and gc.n_pair == int(g['g4/num_pairs'])
+    ok, info = _ok(one.cpu().numpy(), g['g4/out32'], g['g4/out64'])
+    assert ok, info
+
+
+@pytest.mark.parametrize('name', ['qm9_d32_l2', 'pdbbind_d32_l2', 'qm9_ragged_d32_l2', 'pdbbind_d128_l3', 'qm9_d128_l6'])
+def test_store_engine_graph_indices_equal_the_reference_lists(dev, golden, name):
+    """Integer parity of the ONE-call graph with the reference's own index lists (captured from its fp32 run: local edges,
+    triplets (k, j, i), pairs (i, j, j'), models.py:68-98): the same edges, the same triplet / pair rows with the same
+    multiplicities, rows grouped by target edge with triplets before pairs (local_message_passing.py:39)."""
+    import collections
+    import models
+    from oracle import pamnet_oracle as O
+    from test_hip_model import _batch_from, _cfg_from
+    g = golden(name)
+    cfg = _cfg_from(g, models.Config)
+    model = models.PAMNet(cfg)
+    model.load_state_dict(O.init_state_dict(cfg, seed=int(g['seed'])), strict=True)
+    model = model.to(dev)
+    _through_store(model, _split(_batch_from(g, 'cpu')), dev)
+    gc = model._graph_cache
+    src, dst = gc.loc.col.cpu().long().numpy(), gc.loc.row_of.cpu().long().numpy()
+    ref_e = g['ref/edge_index_l']
+    assert sorted(zip(src.tolist(), dst.tolist())) == sorted(zip(ref_e[0].tolist(), ref_e[1].tolist()))
+    e, e2, kind = gc.tp.row_of.cpu().long().numpy(), gc.tp.col.cpu().long().numpy(), gc.tp_kind.cpu().numpy()
+    mine_t = collections.Counter((int(src[b]), int(src[a]), int(dst[a])) for a, b, k in zip(e, e2, kind) if k == 0)
+    ref_t = collections.Counter(zip(g['ref/idx_k'].tolist(), g['ref/idx_j'].tolist(), g['ref/idx_i'].tolist()))
+    assert mine_t == ref_t
+    mine_p = collections.Counter((int(src[a]), int(dst[a]), int(src[b])) for a, b, k in zip(e, e2, kind) if k == 1)
+    ref_p = collections.Counter(zip(g['ref/idx_i_pair'].tolist(), g['ref/idx_j1_pair'].tolist(), g['ref/idx_j2_pair'].tolist()))
+    assert mine_p == ref_p
+    assert (np.diff(e) >= 0).all()
+    for a in np.unique(e):                                       # inside a target edge's group: triplets, then pairs
+        ks = kind[e == a]
+        assert (np.diff(ks) >= 0).all()

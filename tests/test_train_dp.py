@@ -320,6 +320,28 @@ def test_bench_world2_dry_run_on_cpu():
     assert j['scaling'] == 'weak' and j['value'] > 0 and abs(j['value'] - 16 * 3 / (j['ms_per_step'] * 3e-3)) < 1e-6 * j['value']
 
 
+def test_bench_plain_invocation_launches_its_own_ranks_on_cpu():
+    """`python bench.py --gpus 2 ...` WITHOUT a launcher (the form the driver uses for N = 1): bench.py re-launches itself
+    under torch.distributed.run on a free local port -- one JSON line, same contract.  And a world size that contradicts
+    --gpus is an error message, not an assertion."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    cmd = [sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--batch-per-gpu', '8', '--n-layer', '3', '--cpu-dry-run']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=repo, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), r.stdout      # nothing but the line on stdout
+    j = json.loads(lines[0])
+    assert j['dry_run'] is True and j['n_gpus'] == 2 and j['steps'] == 3 and j['config']['global_batch'] == 16
+    env['WORLD_SIZE'] = '3'
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=repo, env=env)
+    assert r.returncode != 0 and 'WORLD_SIZE=3' in r.stderr and 'Traceback' not in r.stderr
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('kind', ['qm9_d128', 'rna_d16'])
 def test_direct_tape_backward_equals_autograd(kind):
