@@ -118,26 +118,32 @@ def step_kernel_rooflines(dev, g, d, n_layer):
     n, eg, el, tp = g.n, g.glob.m, g.loc.m, g.tp.m
     rnd = lambda *s: torch.randn(*s, device=dev) * 0.5
     out = []
+    # engine.hip, global layer backward with the chain's ten tail jobs riding in the next chain launch: the layer's own
+    # launch holds 3 node-level jobs (mlp_x1 and the two node-side projection blocks of W_m) + 2 edge-level ones (W_e,
+    # W_edge_attr), and reduces the previous batch's partials in the same launch -- `wgrad_fused_kernel` in the step's trace
     keep, jobs = [], []
-    for rows, cnt in ((n, 15), (eg, 2)):        # engine.hip, global layer backward: 15 node-level + 2 edge-level jobs
+    for rows, cnt in ((n, 3), (eg, 2)):
         for _ in range(cnt):
             dz, a, dw = rnd(rows, d), rnd(rows, d), torch.empty(d, d, device=dev)
             keep += [dz, a, dw]
             jobs.append((dz, d, a, d, 0, rows, dw, d, None))
-    fn = lambda: fused.wgrad(jobs, keep[0])
+    dw_ = fused.DeferredWgrad(keep[0])
+    fn = lambda: dw_.launch(jobs)
     fn()
     ms, _ = event_time_ms(fn, 30, 3)
-    fl = 2.0 * d * d * (15 * n + 2 * eg)
+    dw_.flush()
+    fl = 2.0 * d * d * (3 * n + 2 * eg)
     # The kernel computes fp32-accurate products on the bf16 matrix pipe (three exact bf16 pieces per operand, six bf16
     # MFMAs per 32 rows: csrc/gemm_core.h "bf16x6"): `frac` stays against the fp32-MFMA peak the path is priced on
     # (SURVEY 8d); `frac_bf16x6` prices the same algorithmic FLOPs against the ceiling of the instruction stream it
     # actually issues, dense bf16 peak / 6.
-    out.append({'kernel': 'wgrad_kernel + wgrad_finish_kernel (all dW of one global layer, one batch)', 'bound': 'mfma',
+    out.append({'kernel': 'wgrad_fused_kernel via pamnet_wgrad_deferred_f32 (a global layer\'s own launch in the step: 3 node-level '
+                          '+ 2 edge-level dW, plus the fixed-order reduction of the previous batch)', 'bound': 'mfma',
                 'flops_per_launch': fl, 'us_per_launch': ms * 1e3, 'achieved': fl / ms / 1e9, 'peak': FP32_MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS,
                 'arithmetic': 'fp32-accurate on v_mfma_f32_16x16x32_bf16 (3 exact bf16 pieces per operand, 6 products)',
                 'peak_bf16x6': BF16_MFMA_PEAK_TFLOPS / 6.0, 'frac_bf16x6': fl / ms / 1e9 / (BF16_MFMA_PEAK_TFLOPS / 6.0),
-                'launches_per_step': 2 * n_layer})
+                'launches_per_step': 2 * n_layer - 1})
     Wm, bm, Wea = rnd(d, 3 * d) / 8, rnd(d), rnd(d, d) / 8
     e, Pi, Pj, x1 = rnd(eg, d), rnd(n, d), rnd(n, d), rnd(n, d)
     z, ea, x2 = torch.empty(eg, d, device=dev), torch.empty(eg, d, device=dev), torch.empty(n, d, device=dev)
@@ -211,17 +217,20 @@ def other_configs(dev):
     rna = [synth.rna_chain(2, i) for i in range(8)]        # the 8 graphs of configs[4]; the 4 batches are rotations of them
     pdb = [synth.pdbbind_complex(1, i) for i in range(128)]
     qm9 = [synth.qm9_molecule(0, i) for i in range(512)]  # the molecules of the main loop, for PAMNet_s (models.py:283-353)
-    for tag, cfg, graphs, sel, steps in (
+    # each configuration with ITS driver's step: main_pdbbind.py:88-95 (F.mse_loss, Adam, no clip, no EMA),
+    # main_rna_puzzles.py:86-93 (F.smooth_l1_loss, Adam, no clip, no EMA), main_qm9.py:103-118 (L1, clip 1000, EMA)
+    for tag, cfg, graphs, sel, steps, loop in (
             ('pdbbind_b32_d128_l3', models.Config(dataset='PDBbind', dim=128, n_layer=3, cutoff_l=2.0, cutoff_g=6.0),
-             pdb, lambda k: list(range(32 * k, 32 * k + 32)), 40),
+             pdb, lambda k: list(range(32 * k, 32 * k + 32)), 40, dict(loss='mse', max_grad_norm=None, ema_decay=None, lr=1e-3)),
             ('rna_b8_d16_l1', models.Config(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0,
                                             flow='target_to_source'),
-             rna, lambda k: [(i + 2 * k) % 8 for i in range(8)], 100),
+             rna, lambda k: [(i + 2 * k) % 8 for i in range(8)], 100,
+             dict(loss='smooth_l1', max_grad_norm=None, ema_decay=None, lr=1e-4)),
             ('pamnet_s_qm9_b128_d128_l6', models.Config(dataset='QM9', dim=128, n_layer=6, cutoff_l=5.0, cutoff_g=5.0),
-             qm9, lambda k: list(range(128 * k, 128 * k + 128)), 100)):
+             qm9, lambda k: list(range(128 * k, 128 * k + 128)), 100, dict(loss='l1', lr=1e-4))):
         torch.manual_seed(7)
         model = (models.PAMNet_s if tag.startswith('pamnet_s') else models.PAMNet)(cfg).to(dev)
-        tr = Trainer(model, lr=1e-4)
+        tr = Trainer(model, **loop)
         bs = [synth.collate([graphs[i] for i in sel(k)]).to(dev) for k in range(4)]
         for i in range(20):                                   # (the allocator's cache was emptied after the previous configuration)
             tr.step(bs[i % 4], next_data=bs[(i + 1) % 4])
@@ -271,11 +280,41 @@ def other_configs(dev):
                     'store_forward_ms_unpipelined': store_fwd_ms, 'graphs_per_batch': int(bs[0].num_graphs),
                     'nodes': int(g.n), 'global_edges': int(g.glob.m), 'local_edges': int(g.loc.m),
                     'triplet_pair_rows': int(g.tp.m), 'steps': steps,
+                    'step': 'loss=%s, clip=%s, ema=%s' % (loop['loss'], loop.get('max_grad_norm', 1000.0), loop.get('ema_decay', 0.999)),
                     'note': 'train / forward: plain tensors (the reference calling convention) with the side-stream input '
                             'pipeline; store_*: resident dataset, device-side collation, graph + basis as one engine call'}
+        if tag.startswith('pdbbind'):
+            out[tag]['kernels'] = guarded(pdbbind_kernel_rooflines, model, bs[0], dev)
         del tr, model, bs, st
         torch.cuda.empty_cache()
     return out
+
+
+def pdbbind_kernel_rooflines(model, batch, dev):
+    """The gather (transposed-CSR, `perm`) form of the scatter-add at the shape where it is real HBM traffic: the source-side
+    reduction d P_j[j] = sum over edges LEAVING j of d z[e] in the global layer's backward (csrc/engine.hip:
+    pamnet_segment_sum_f32 with gT_perm / gT_ptr), PDBbind B=32: ~690 k rows of 512 B gathered through an index list.
+    Algorithmic bytes = 4 d M (rows) + 4 M (perm) + 4 (R + 1) (ptr) + 4 d R (out).  Beside it the streamed form on the same
+    rows (no perm) -- the variant `roofline` reports."""
+    from pamnet_amd import ops
+    model.prepare(batch, need_grad=True)
+    g = batch._pamnet_prepared
+    batch._pamnet_prepared = None
+    d, n, m = model.dim, g.n, g.glob.m
+    src, dst = torch.randn(m, d, device=dev), torch.empty(n, d, device=dev)
+    res = []
+    for name, perm, ptr in (('segment_sum_kernel<..., perm> (transposed CSR: d z rows gathered by source node)', g.glob_T.perm, g.glob_T.ptr),
+                            ('segment_sum_kernel (streamed rows, same shape)', None, g.glob.ptr)):
+        fn = lambda: ops.segment_sum_raw(dst, None, src, None, None, None, perm, ptr, n, d)
+        for _ in range(5):
+            fn()
+        ms, ms_min = event_time_ms(fn, 20, 5)
+        by = 4.0 * d * m + (4.0 * m if perm is not None else 0.0) + 4.0 * (n + 1) + 4.0 * d * n
+        res.append({'kernel': name, 'bound': 'hbm', 'rows_in': int(m), 'rows_out': int(n), 'bytes_per_launch': by,
+                    'us_per_launch': ms * 1e3, 'achieved': by / ms / 1e6, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': by / ms / 1e6 / HBM_PEAK_GBS, 'best_group_gbs': by / ms_min / 1e6,
+                    'launches_per_step': model.n_layer if perm is not None else 0})
+    return res
 
 
 def parity_beside_baseline(dev, args):
@@ -388,6 +427,43 @@ def self_launch(args, result_out):
         result_out.write(l + '\n')
     result_out.flush()
     return proc.returncode if (proc.returncode or lines) else 1
+
+
+def reference_loop_unchanged(dev, args, batches):
+    """ms per step of the reference's own loop body on the drop-in model (see the call site)."""
+    import models
+    from torch.nn.utils import clip_grad_norm_
+    from utils import EMA
+    torch.manual_seed(1234)
+    model = models.PAMNet(models.Config(dataset='QM9', dim=args.dim, n_layer=args.n_layer, cutoff_l=5.0, cutoff_g=5.0)).to(dev)
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=0, amsgrad=False)
+    ema = EMA(model, decay=0.999)
+    nb = len(batches)
+    model.train()
+
+    def step(data):
+        optimizer.zero_grad()
+        output = model(data)
+        loss = torch.nn.functional.l1_loss(output, data.y)
+        loss_item = loss.item() * data.num_graphs              # main_qm9.py:109 (a host read-back per step)
+        loss.backward()
+        clip_grad_norm_(model.parameters(), max_norm=1000, norm_type=2)
+        optimizer.step()
+        ema(model)
+        return loss_item
+
+    for i in range(5):
+        step(batches[i % nb])
+    torch.cuda.synchronize()
+    n = min(args.steps, 100)
+    t0 = time.perf_counter()
+    for i in range(n):
+        step(batches[i % nb])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    return {'reference_loop_ms_per_step': ms, 'molecules_per_s': args.batch_per_gpu / (ms / 1e3), 'steps': n,
+            'note': 'main_qm9.py:103-118 verbatim on the HIP model: torch.optim.Adam (per-tensor), loss.item(), autograd backward, '
+                    'clip_grad_norm_, utils.EMA; no Trainer, no flat buffers, no input pipeline'}
 
 
 def guarded(fn, *a):
@@ -605,6 +681,14 @@ def main():
         except Exception as exc:                  # noqa: BLE001
             zero_sync = {'error': '%s: %s' % (type(exc).__name__, exc)}
 
+    # The reference's loop body UNCHANGED on the HIP model (main_qm9.py:103-118): torch.optim.Adam + loss.item() +
+    # loss.backward() through autograd + clip_grad_norm_ + utils.EMA, one graph-size round trip per forward and no input
+    # pipeline -- what "drops into main_qm9.py unchanged" delivers before anything of pamnet_amd.train is adopted.  A side
+    # field on a model of its own (same architecture, same batches); never `value`.
+    ref_loop = None
+    if not args.cpu_dry_run and world == 1:
+        ref_loop = guarded(reference_loop_unchanged, dev, args, batches)
+
     # What graph construction costs the step although it runs beside it (a side-stream launch displaces a workgroup
     # of the model's full-chip launches): the same steps on graphs prepared once and reused.  A bound, never `value` -- the
     # timed region above rebuilds the graph of every batch.
@@ -659,6 +743,7 @@ def main():
             'forward_ms_unpipelined': fwd_plain_ms,
             'zero_host_sync': zero_sync,
             'graph_construction_cost': graph_cost,
+            'reference_loop_unchanged': ref_loop,
             'mfma': mfma_summary(args, g, ms_per_step),
         }
         if not args.no_rooflines:

@@ -7,12 +7,15 @@
  *
  * Conventions (every function):
  *   - arguments are raw DEVICE pointers, 64-bit sizes and a hipStream_t (passed as void*); no torch types;
- *   - the caller owns every device buffer; the library allocates no device memory, keeps no global state and never
- *     synchronises (the pamnet_stack_* engine calls build small host-side pointer tables on the stack / heap per call);
+ *   - the caller owns every device buffer; the library allocates no device memory, keeps no mutable state between calls
+ *     and never synchronises (the pamnet_stack_* engine calls build small host-side pointer tables on the stack / heap per
+ *     call).  The only process-wide data are three read-once developer switches taken from the environment on first use
+ *     (PAMNET_EDGE_WAVES, PAMNET_CHAIN_BF16, PAMNET_SMALL_FORMS: kernel-variant selection for measurements; C++11 static
+ *     initialisation, thread-safe, constant afterwards);
  *   - work is enqueued on `stream`; return value 0 = OK, >0 = hipError_t of the failed launch, <0 = argument error
  *     (PAMNET_EINVAL: bad size / unsupported width; PAMNET_ENULL: required pointer is null);
  *   - float tensors are fp32 row-major [rows, d]; index tensors are int32; CSR pointers have rows+1 entries;
- *   - re-entrant and thread-safe by statelessness.  Segment reductions are sorted-CSR, atomics-free, deterministic.
+ *   - re-entrant and thread-safe: nothing mutable is shared between calls.  Segment reductions are sorted-CSR, atomics-free, deterministic.
  */
 #ifndef PAMNET_HIP_H
 #define PAMNET_HIP_H
@@ -639,6 +642,10 @@ int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, 
  *   pamnet_sumsq_partials_f32 : partials[0:256] (fp64) = sums of squares of 256 contiguous slices of g[0:n]; the L2 norm
  *                               (clip_grad_norm_, main_qm9.py:111) is finished inside pamnet_adam_ema_norm_f32
  *   pamnet_l1_loss_f32        : loss[0] = mean|out - y|; d_out[i] = grad_scale * sign(out[i] - y[i]) / n  (main_qm9.py:108)
+ *   pamnet_mse_loss_f32       : loss[0] = mean (out - y)^2; d_out[i] = grad_scale * 2 (out[i] - y[i]) / n  (main_pdbbind.py:93)
+ *   pamnet_smooth_l1_loss_f32 : loss[0] = mean h(out - y), h(d) = d^2/2 if |d| < 1 else |d| - 1/2 (beta = 1);
+ *                               d_out[i] = grad_scale * clamp(out[i] - y[i], -1, 1) / n       (main_rna_puzzles.py:92)
+ *                               (all three: one launch, d_out nullable)
  *   pamnet_type_rows_grad_f32 : out[t,:] = sum_{r: idx[r] = t} g[r,:], t < n_types <= 8   (gradient of embeddings[x],
  *                               models.py:107,140); scratch: pamnet_reduce_scratch_bytes bytes of device memory
  * ------------------------------------------------------------------------------------------------------------------ */
@@ -646,6 +653,10 @@ int pamnet_reduce_scratch_bytes(int64_t* bytes);
 int pamnet_sumsq_partials_f32(const float* g, int64_t n, double* partials, pamnet_stream_t stream);
 int pamnet_l1_loss_f32(const float* out, const float* y, int64_t n, float grad_scale, float* loss, float* d_out,
                        pamnet_stream_t stream);
+int pamnet_mse_loss_f32(const float* out, const float* y, int64_t n, float grad_scale, float* loss, float* d_out,
+                        pamnet_stream_t stream);
+int pamnet_smooth_l1_loss_f32(const float* out, const float* y, int64_t n, float grad_scale, float* loss, float* d_out,
+                              pamnet_stream_t stream);
 int pamnet_type_rows_grad_f32(const float* g, const int32_t* idx, int64_t n, int64_t n_types, int64_t d, void* scratch,
                               float* out, pamnet_stream_t stream);
 
@@ -653,7 +664,8 @@ int pamnet_type_rows_grad_f32(const float* g, const int32_t* idx, int64_t n, int
  * Optimiser tail of the reference loop on flat fp32 buffers, one pass (main_qm9.py:111-112,116; utils/ema.py:13-20):
  *   g *= min(1, max_norm / (*grad_norm + 1e-6))                      clip_grad_norm_ (grad_norm: device scalar, nullable)
  *   Adam(lr, betas, eps, weight_decay, amsgrad=False), update number `step_count` >= 1
- *   shadow = ema_decay * shadow + (1 - ema_decay) * p_new
+ *   shadow = ema_decay * shadow + (1 - ema_decay) * p_new            (shadow nullable: no EMA -- the loops of
+ *                                                                     main_pdbbind.py:88-95, main_rna_puzzles.py:86-93)
  *   g = 0 when zero_grad != 0 (the next step's zero_grad, main_qm9.py:105)
  * n % 4 == 0; buffers 16-byte aligned.
  * ------------------------------------------------------------------------------------------------------------------ */

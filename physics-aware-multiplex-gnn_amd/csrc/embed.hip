@@ -159,21 +159,24 @@ struct EJobs {
 
 // input rows [row0, row0 + 64) of a job into xs (zero beyond `rows`); RBF: the Bessel rows from the distances, with the
 // scaled distance of each row left in ds[] for the backward
-// this thread's edge length of tile row threadIdx.x / 4 (1.0 = padding: u(1) = 0, such rows contribute nothing)
+// this thread's edge length of tile row threadIdx.x / 4 (rows beyond the job: 0, never used -- validity is the row index)
 __device__ __forceinline__ float job_dist(const EJob& jb, int64_t row0) {
     const int64_t g = row0 + (threadIdx.x >> 2);
-    return g < jb.rows ? jb.dist[g] : -1.0f;
+    return g < jb.rows ? jb.dist[g] : 0.0f;
 }
 
+// `have`: dpre holds this thread's edge length, fetched a tile ahead.  Whether a row exists is decided by its index alone,
+// so a NaN / negative edge length reaches the envelope and the sine exactly as in the forward (bad geometry is not masked).
 template <int K, bool RBF>
-__device__ __forceinline__ void stage_job_rows(const EJob& jb, int64_t row0, float* xs, float* ds, float dpre = -2.0f) {
+__device__ __forceinline__ void stage_job_rows(const EJob& jb, int64_t row0, float* xs, float* ds, bool have = false,
+                                               float dpre = 0.0f) {
     if (!RBF) {
         stage_rows<K>(jb.x, row0, jb.rows, xs);
         return;
     }
     const int r = threadIdx.x >> 2, n0 = 4 * (threadIdx.x & 3);
-    if (dpre == -2.0f) dpre = job_dist(jb, row0);            // (not fetched ahead)
-    const bool ok = dpre >= 0.f;
+    if (!have) dpre = job_dist(jb, row0);                          // (not fetched ahead)
+    const bool ok = row0 + r < jb.rows;
     const float xr = ok ? dpre * jb.inv_cutoff : 1.0f;             // u(1) = 0: padded rows contribute nothing
     const float u = envelope_f(xr);
     const float4 f = *reinterpret_cast<const float4*>(jb.freq + n0);
@@ -276,13 +279,13 @@ __device__ __forceinline__ void embed_bwd_body(const EJob& jb, int bid, float* x
         }
     };
     prefetch(bid);
-    float dnext = -2.0f;
-    if constexpr (DXM == 2) dnext = bid < ntiles ? job_dist(jb, (int64_t)bid * TR) : -1.0f;
+    float dnext = 0.0f;
+    if constexpr (DXM == 2) dnext = bid < ntiles ? job_dist(jb, (int64_t)bid * TR) : 0.0f;
     for (int64_t tile = bid; tile < ntiles; tile += jb.nblk) {
         const int64_t row0 = tile * TR;
         __syncthreads();
-        stage_job_rows<K, DXM == 2>(jb, row0, xs, ds, dnext);
-        if constexpr (DXM == 2) dnext = tile + jb.nblk < ntiles ? job_dist(jb, (tile + jb.nblk) * TR) : -1.0f;
+        stage_job_rows<K, DXM == 2>(jb, row0, xs, ds, DXM == 2, dnext);
+        if constexpr (DXM == 2) dnext = tile + jb.nblk < ntiles ? job_dist(jb, (tile + jb.nblk) * TR) : 0.0f;
         if (TWO && threadIdx.x < TR) ks[threadIdx.x] = (row0 + threadIdx.x < rows) ? jb.kind[row0 + threadIdx.x] : 0;
         __syncthreads();
         {

@@ -14,6 +14,7 @@ struct AdamArgs {
     int zero_grad;
 };
 
+template <bool EMA>
 __global__ __launch_bounds__(256) void adam_ema_kernel(float4* __restrict__ p, float4* __restrict__ g,
                                                        float4* __restrict__ m, float4* __restrict__ v,
                                                        float4* __restrict__ shadow, int64_t n4,
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float4* __restrict__ p, f
     }
     const float step = a.lr / a.bias1;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i], ss = shadow[i];
+        float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i], ss = EMA ? shadow[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         float* pf = &pp.x;
         float* gf = &gg.x;
         float* mf = &mm.x;
@@ -53,12 +54,12 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float4* __restrict__ p, f
             vf[c] = fmaf(a.beta2, vf[c], (1.0f - a.beta2) * gr * gr);                 // exp_avg_sq
             const float denom = sqrtf(vf[c]) / a.bias2_sqrt + a.eps;
             pf[c] -= step * (mf[c] / denom);
-            sf[c] = fmaf(a.ema_decay, sf[c], (1.0f - a.ema_decay) * pf[c]);
+            if (EMA) sf[c] = fmaf(a.ema_decay, sf[c], (1.0f - a.ema_decay) * pf[c]);
         }
         p[i] = pp;
         m[i] = mm;
         v[i] = vv;
-        shadow[i] = ss;
+        if (EMA) shadow[i] = ss;
         if (a.zero_grad) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
@@ -70,7 +71,7 @@ int adam_launch(float* p, float* g, float* m, float* v, float* shadow, int64_t n
                 const double* sumsq_partials, float* norm_out, float max_norm, int32_t zero_grad, pamnet_stream_t stream) {
     if (n < 0 || (n & 3) || step_count < 1) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
-    if (!p || !g || !m || !v || !shadow) return PAMNET_ENULL;
+    if (!p || !g || !m || !v) return PAMNET_ENULL;
     AdamArgs a;
     a.lr = lr, a.beta1 = beta1, a.beta2 = beta2, a.eps = eps, a.weight_decay = weight_decay;
     a.bias1 = (float)(1.0 - pow((double)beta1, (double)step_count));
@@ -79,8 +80,12 @@ int adam_launch(float* p, float* g, float* m, float* v, float* shadow, int64_t n
     const int64_t n4 = n / 4;
     int64_t blocks = ceil_div(n4, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (float4*)p, (float4*)g,
-                       (float4*)m, (float4*)v, (float4*)shadow, n4, grad_norm, sumsq_partials, norm_out, a);
+    if (shadow)
+        hipLaunchKernelGGL(adam_ema_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (float4*)p,
+                           (float4*)g, (float4*)m, (float4*)v, (float4*)shadow, n4, grad_norm, sumsq_partials, norm_out, a);
+    else                                   // no EMA (main_pdbbind.py / main_rna_puzzles.py): 4 reads + 3 (4) writes per element
+        hipLaunchKernelGGL(adam_ema_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (float4*)p,
+                           (float4*)g, (float4*)m, (float4*)v, (float4*)nullptr, n4, grad_norm, sumsq_partials, norm_out, a);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

@@ -1,7 +1,8 @@
 // Small whole-buffer reductions of the training step, fixed summation order (deterministic):
 //   * pamnet_sumsq_partials_f32 : 256 fp64 partial sums of squares of the flat gradient (clip_grad_norm_,
 //                                 main_qm9.py:111); the optimiser kernel (optim.hip) adds them itself -- no finish launch
-//   * pamnet_l1_loss_f32        : F.l1_loss(out, y) and its gradient w.r.t. out (main_qm9.py:108), a few hundred floats
+//   * pamnet_l1_loss_f32 / pamnet_mse_loss_f32 / pamnet_smooth_l1_loss_f32 : the three drivers' losses (main_qm9.py:108,
+//                                 main_pdbbind.py:93, main_rna_puzzles.py:92) with their gradient w.r.t. out, one launch
 //   * pamnet_type_rows_grad_f32 : gradient of `embeddings[x]` (models.py:107,140): rows of d x summed per atom type
 //                                 (partials per workgroup + a one-workgroup finish, workgroup order)
 // (A single launch with a "last workgroup finishes" counter was measured and rejected: the device-scope fence it needs
@@ -39,17 +40,29 @@ __global__ __launch_bounds__(256) void sumsq_partials_kernel(const float4* __res
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-// one workgroup: loss = mean |out - y| ; d_out = sign(out - y) * grad_scale / n     (n graphs: a few hundred)
-__global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ out, const float* __restrict__ y, int64_t n,
-                                                      float grad_scale, float* __restrict__ loss,
-                                                      float* __restrict__ d_out) {
+// one workgroup: loss = mean_i l(out_i - y_i) ; d_out_i = l'(out_i - y_i) * grad_scale / n     (n graphs: a few hundred)
+//   KIND 0: l(d) = |d|                                   F.l1_loss        (main_qm9.py:108)
+//   KIND 1: l(d) = d^2                                   F.mse_loss       (main_pdbbind.py:93)
+//   KIND 2: l(d) = d^2 / 2 if |d| < 1 else |d| - 1/2     F.smooth_l1_loss (main_rna_puzzles.py:92; beta = 1)
+template <int KIND>
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out, const float* __restrict__ y, int64_t n,
+                                                   float grad_scale, float* __restrict__ loss, float* __restrict__ d_out) {
     __shared__ double red[256];
     double s = 0.0;
     const float gs = grad_scale / (float)n;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         const float d = out[i] - y[i];
-        s += (double)fabsf(d);
-        if (d_out) d_out[i] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+        const float a = fabsf(d);
+        float l, dl;
+        if (KIND == 0) {
+            l = a, dl = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        } else if (KIND == 1) {
+            l = d * d, dl = 2.f * d;
+        } else {
+            l = a < 1.f ? 0.5f * d * d : a - 0.5f, dl = a < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+        }
+        s += (double)l;
+        if (d_out) d_out[i] = dl * gs;
     }
     red[threadIdx.x] = s;
     __syncthreads();
@@ -58,6 +71,16 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ 
         __syncthreads();
     }
     if (threadIdx.x == 0) loss[0] = (float)(red[0] / (double)n);
+}
+
+template <int KIND>
+int loss_launch(const float* out, const float* y, int64_t n, float grad_scale, float* loss, float* d_out,
+                pamnet_stream_t stream) {
+    if (n < 1) return PAMNET_EINVAL;
+    if (!out || !y || !loss) return PAMNET_ENULL;
+    hipLaunchKernelGGL(loss_kernel<KIND>, dim3(1), dim3(256), 0, as_stream(stream), out, y, n, grad_scale, loss, d_out);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
 }
 
 using type_rows::TYPE_BLOCKS;
@@ -97,11 +120,20 @@ extern "C" int pamnet_sumsq_partials_f32(const float* g, int64_t n, double* part
 // loss[0] = mean_i |out[i] - y[i]|;  d_out[i] (nullable) = grad_scale * sign(out[i] - y[i]) / n   (sign(0) = 0 as torch)
 extern "C" int pamnet_l1_loss_f32(const float* out, const float* y, int64_t n, float grad_scale, float* loss,
                                   float* d_out, pamnet_stream_t stream) {
-    if (n < 1) return PAMNET_EINVAL;
-    if (!out || !y || !loss) return PAMNET_ENULL;
-    hipLaunchKernelGGL(l1_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), out, y, n, grad_scale, loss, d_out);
-    PAMNET_LAUNCH_CHECK();
-    return PAMNET_OK;
+    return loss_launch<0>(out, y, n, grad_scale, loss, d_out, stream);
+}
+
+// loss[0] = mean_i (out[i] - y[i])^2;  d_out[i] (nullable) = grad_scale * 2 (out[i] - y[i]) / n      (main_pdbbind.py:93)
+extern "C" int pamnet_mse_loss_f32(const float* out, const float* y, int64_t n, float grad_scale, float* loss,
+                                   float* d_out, pamnet_stream_t stream) {
+    return loss_launch<1>(out, y, n, grad_scale, loss, d_out, stream);
+}
+
+// loss[0] = mean_i h(out[i] - y[i]), h(d) = d^2/2 for |d| < 1, |d| - 1/2 otherwise (beta = 1);  d_out[i] (nullable) =
+// grad_scale * clamp(out[i] - y[i], -1, 1) / n                                                  (main_rna_puzzles.py:92)
+extern "C" int pamnet_smooth_l1_loss_f32(const float* out, const float* y, int64_t n, float grad_scale, float* loss,
+                                         float* d_out, pamnet_stream_t stream) {
+    return loss_launch<2>(out, y, n, grad_scale, loss, d_out, stream);
 }
 
 // out[t, :] = sum_{r < n: idx[r] = t} g[r, :]  for t < n_types (<= 8), d in {16, 32, 64, 128, 256}; idx values outside

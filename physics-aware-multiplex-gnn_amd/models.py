@@ -105,15 +105,28 @@ class SphericalBasis(nn.Module):
         self.default = (ns, nr, p) == (7, 6, 5)
         if not self.default:
             z32, norm = basis_tables(ns, nr)
-            # non-persistent: `state_dict()` keeps the reference's keys (the reference's basis holds no tensors either)
-            self.register_buffer('zeros', torch.from_numpy(z32).reshape(-1).contiguous(), persistent=False)
-            self.register_buffer('norm', torch.from_numpy(norm).reshape(-1).contiguous(), persistent=False)
+            # Constants of the basis, not module state: host masters (float32 zeros / float64 normalisers, exactly the types
+            # the table-driven kernels read through raw pointers) plus one device copy per device, made on first use.  They are
+            # NOT buffers: `model.half()` / `.double()` / `.to(dtype)` must not recast them (a recast table would be read
+            # with the wrong element size), and `state_dict()` keeps the reference's keys (its basis holds no tensors).
+            self.__dict__['_host_tables'] = (torch.from_numpy(z32).reshape(-1).contiguous(),
+                                             torch.from_numpy(norm).reshape(-1).contiguous())
+            self.__dict__['_device_tables'] = {}
+
+    def tables(self, device):
+        """(zeros float32 [ns*nr], normalisers float64 [ns*nr]) resident on `device`."""
+        t = self._device_tables.get(device)
+        if t is None:
+            z, n = self._host_tables
+            t = self._device_tables[device] = (z.to(device), n.to(device))
+        return t
 
     def forward(self, graph):
         if self.default:
             return G.spherical_basis(graph, self.cutoff)
+        zeros, norm = self.tables(graph.dist_l.device)
         return G.spherical_basis_tab(graph, self.cutoff, self.num_spherical, self.num_radial, self.envelope_exponent,
-                                     self.zeros, self.norm)
+                                     zeros, norm)
 
 
 class _LazyLayers(object):

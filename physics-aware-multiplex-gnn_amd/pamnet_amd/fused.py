@@ -87,6 +87,37 @@ def wgrad(jobs, ref):
              lib.ptr(partial), None, 0, None, None, None, lib.stream_of(ref))
 
 
+class DeferredWgrad(object):
+    """pamnet_wgrad_deferred_f32 as the layer-stack backward drives it (csrc/engine.hip run_jobs): the split-K pass of batch
+    i and the fixed-order reduction of batch i-1 are ONE launch (`wgrad_fused_kernel`, the form in the step's kernel trace);
+    flush() reduces the last batch.  For measurements and kernel-level tests -- the engine calls the C entry directly."""
+
+    def __init__(self, ref):
+        nbytes = ctypes.c_int64(0)
+        lib.call('pamnet_wgrad_ctx_bytes', ctypes.addressof(nbytes))
+        self.ctx = (ctypes.c_char * int(nbytes.value))()            # caller-owned host memory, zeroed
+        self.ref, self.parts, self.flip = ref, [None, None], 0
+
+    def launch(self, jobs):
+        """jobs: as fused.wgrad.  Consecutive launches alternate between two scratch buffers (the reduction of a batch runs
+        inside the NEXT launch)."""
+        n = len(jobs)
+        rows = _iarr([j[5] for j in jobs])
+        need = ctypes.c_int64(0)
+        lib.call('pamnet_wgrad_scratch_floats', n, rows, ctypes.addressof(need))
+        p = self.parts[self.flip]
+        if p is None or p.numel() < need.value:
+            p = self.parts[self.flip] = torch.empty(int(need.value), dtype=torch.float32, device=self.ref.device)
+        self.flip ^= 1
+        lib.call('pamnet_wgrad_deferred_f32', n, _parr([j[0] for j in jobs]), _iarr([j[1] for j in jobs]),
+                 _parr([j[2] for j in jobs]), _iarr([j[3] for j in jobs]), _iarr([j[4] for j in jobs], ctypes.c_int32),
+                 rows, _parr([j[6] for j in jobs]), _iarr([j[7] for j in jobs]), _parr([j[8] for j in jobs]),
+                 lib.ptr(p), None, 0, None, None, None, ctypes.addressof(self.ctx), lib.stream_of(self.ref))
+
+    def flush(self):
+        lib.call('pamnet_wgrad_flush_f32', ctypes.addressof(self.ctx), lib.stream_of(self.ref))
+
+
 # ---------------------------------------------------------------------------------------------------- raw kernel calls
 def k_pre_fwd(x, Wx1, bx1, wps, ldwp):
     n, nblk = x.size(0), len(wps)

@@ -450,6 +450,7 @@ ENGINE = __import__('os').environ.get('PAMNET_GRAPH_ENGINE', '1') != '0'    # me
 # QM9 schema, small molecules: the molecule-local builder (csrc/graph_mol.hip, two launches); False = the step-by-step
 # launches (the tests compare the two bit by bit)
 MOL_LOCAL = True
+KNN_K = 50            # neighbours of the RNA kNN graph (models.py:143): the one value the models and the store's size tables use
 MOL_ATOMS, MOL_BONDS = 64, 256                       # per-molecule limits of the builder (graph_mol.hip)
 
 
@@ -538,8 +539,8 @@ def _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_ind
         w = int(x_raw.size(1))
         d.rows, d.rows_width, d.n_bonds = x_raw.data_ptr(), w, 0
         if rna:
-            if n_types is None:
-                return None
+            if n_types is None or not 1 <= int(knn_k) <= 64:        # (pamnet_graph_plan rejects k > 64: the step-by-step
+                return None                                          #  path below has its own guard and message)
             d.schema, d.types, d.types_kind, d.types_stride = 2, x_raw.data_ptr() + 4 * (w - 1), 3, w
             d.aggregate_at_query = 1 if flow == 'target_to_source' else 0
         elif dataset == 'PDBbind':
@@ -651,7 +652,7 @@ def _mol_local_graph(g, pos, ing, cutoff_g, with_triplets, need_grad):
 
 
 def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_index=None, num_graphs=None,
-                need_grad=True, knn_k=50, with_triplets=True, n_types=None, sizes=None, default_basis=True, mol_local=None):
+                need_grad=True, knn_k=None, with_triplets=True, n_types=None, sizes=None, default_basis=True, mol_local=None):
     """Graph-construction part of PAMNet.forward (models.py:104-177).  Returns a Graph.
 
     `sizes`: (global edges, local edges, triplet + pair rows) of this batch as host integers -- what a batch collated by
@@ -665,6 +666,9 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     average molecule is small (a batch that does not qualify is found out with the sizes' round trip and takes the
     step-by-step launches); False = never."""
     dev = batch.device
+    knn_k = KNN_K if knn_k is None else int(knn_k)
+    if sizes is not None and knn_k != KNN_K:
+        raise ValueError('host-side sizes (store.MoleculeStore) are counted for k = %d neighbours; got knn_k = %d' % (KNN_K, knn_k))
     if sizes is not None and num_graphs is not None:
         eng = _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_index, num_graphs, need_grad, knn_k,
                             with_triplets, n_types, sizes, default_basis, mol_local=bool(mol_local))
@@ -874,6 +878,12 @@ def spherical_basis_tab(g, cutoff_l, num_spherical, num_radial, envelope_exponen
     dev = g.pos.device
     st = lib.stream_of(g.pos)
     e_l, tot, w = g.loc.m, g.tp.m, int(num_spherical) * int(num_radial)
+    # the kernels read the tables through raw pointers: element types, sizes and residence are checked here
+    if not (zeros.dtype == torch.float32 and norm.dtype == torch.float64 and zeros.numel() == w and norm.numel() == w
+            and zeros.device == dev and norm.device == dev):
+        raise TypeError('spherical basis tables: zeros must be float32 [%d], norm float64 [%d], both on %s (got %s %s on %s, '
+                        '%s %s on %s)' % (w, w, dev, zeros.dtype, tuple(zeros.shape), zeros.device, norm.dtype,
+                                          tuple(norm.shape), norm.device))
     rad = _f32(e_l * w, dev)
     lib.call('pamnet_sbf_radial_tab_f32', lib.ptr(g.dist_l), float(cutoff_l), e_l, int(num_spherical), int(num_radial),
              int(envelope_exponent), lib.ptr(zeros), lib.ptr(norm), lib.ptr(rad), st)

@@ -304,21 +304,33 @@ def type_rows(table, idx, direct_grad=None, tape=None):
     return apply(_TypeRows, table, idx, direct_grad, tape=tape)
 
 
-def l1_loss_with_grad(out, y, grad_scale=1.0):
-    """(loss, d loss / d out * grad_scale) of F.l1_loss(out, y) (mean reduction, main_qm9.py:108) in one launch.
-    `y` is brought to out's device / dtype / shape first (F.l1_loss converts, broadcasts or raises; the kernel reads
-    out.numel() contiguous fp32 values): a [B, 1] or float64 target works, a target of another size raises."""
+LOSS_ENTRIES = {'l1': 'pamnet_l1_loss_f32', 'mse': 'pamnet_mse_loss_f32', 'smooth_l1': 'pamnet_smooth_l1_loss_f32'}
+
+
+def loss_with_grad(kind, out, y, grad_scale=1.0):
+    """(loss, d loss / d out * grad_scale) of the three drivers' losses, mean reduction, in one launch: 'l1' = F.l1_loss
+    (main_qm9.py:108), 'mse' = F.mse_loss (main_pdbbind.py:93), 'smooth_l1' = F.smooth_l1_loss, beta = 1
+    (main_rna_puzzles.py:92).  `y` is brought to out's device / dtype / shape first (the torch losses convert, broadcast
+    or raise; the kernel reads out.numel() contiguous fp32 values): a [B, 1] or float64 target works, a target of
+    another size raises."""
+    entry = LOSS_ENTRIES.get(kind)
+    if entry is None:
+        raise ValueError("loss must be one of 'l1', 'mse', 'smooth_l1' (got %r)" % (kind,))
     out = _c(out.detach())
     if y.numel() != out.numel():
-        raise ValueError('l1 loss: target has %d elements, the model output %d' % (y.numel(), out.numel()))
+        raise ValueError('%s loss: target has %d elements, the model output %d' % (kind, y.numel(), out.numel()))
     if y.device != out.device or y.dtype != torch.float32 or y.shape != out.shape:
         y = y.to(device=out.device, dtype=torch.float32).reshape(out.shape)
     y = _c(y)
     loss = torch.empty(1, dtype=torch.float32, device=out.device)
     d_out = torch.empty_like(out)
-    lib.call('pamnet_l1_loss_f32', lib.ptr(out), lib.ptr(y), out.numel(), float(grad_scale), lib.ptr(loss),
-             lib.ptr(d_out), lib.stream_of(out))
+    lib.call(entry, lib.ptr(out), lib.ptr(y), out.numel(), float(grad_scale), lib.ptr(loss), lib.ptr(d_out),
+             lib.stream_of(out))
     return loss[0], d_out
+
+
+def l1_loss_with_grad(out, y, grad_scale=1.0):
+    return loss_with_grad('l1', out, y, grad_scale)
 
 
 def sumsq_partials(flat):

@@ -21,7 +21,7 @@ from . import lib
 I32 = torch.int32
 
 
-KNN_K = 50            # neighbours of the RNA kNN graph (models.py:143; graph.build_graph's default)
+KNN_K = G.KNN_K       # neighbours of the RNA kNN graph (models.py:143): build_graph's default, the only k the sizes are counted for
 
 
 def size_key(model):

@@ -1,8 +1,11 @@
-"""Training step with the semantics of the reference loop (main_qm9.py:99-118, utils/ema.py:3-32) and molecule-sharded
-data parallelism (one process per GPU, RCCL over xGMI).
+"""Training step with the semantics of the reference loops (main_qm9.py:99-118 + utils/ema.py:3-32; main_pdbbind.py:88-95;
+main_rna_puzzles.py:86-93) and molecule-sharded data parallelism (one process per GPU, RCCL over xGMI).
 
-Per step:  zero_grad -> forward -> F.l1_loss (mean over graphs) -> backward -> [all-reduce of the flat fp32 gradient]
-           -> clip_grad_norm_(max 1000, L2) -> Adam(lr, wd=0, amsgrad=False) -> warm-up/exponential LR -> EMA(0.999).
+Per step:  zero_grad -> forward -> loss (mean over graphs) -> backward -> [all-reduce of the flat fp32 gradient]
+           -> [clip_grad_norm_(L2)] -> Adam(lr, wd, amsgrad=False) -> [EMA].
+  main_qm9.py         : Trainer(model, loss='l1', max_grad_norm=1000, ema_decay=0.999) + WarmupExpLR     (the defaults)
+  main_pdbbind.py     : Trainer(model, loss='mse', max_grad_norm=None, ema_decay=None) + MultiStepLR(gamma=0.2)
+  main_rna_puzzles.py : Trainer(model, loss='smooth_l1', max_grad_norm=None, ema_decay=None), constant rate
 
 MI355X-first layout: all parameters, their gradients, both Adam moments and the EMA shadow live in five flat fp32
 buffers (3.58 M floats = 14.3 MB each at d=128/L=6).  Parameters / .grad are views into them, so
@@ -119,6 +122,20 @@ class WarmupExpLR(object):
         return self.lr_at(epoch - 1, steps_in_epoch - 1)
 
 
+class MultiStepLR(object):
+    """lr(epoch) = lr0 * gamma ** #{milestones <= epoch}: torch.optim.lr_scheduler.MultiStepLR as main_pdbbind.py:83,96
+    uses it (stepped once per epoch, after the epoch's optimiser steps; every step of epoch e runs with lr_at(e))."""
+
+    def __init__(self, lr0, milestones=(50, 100, 150, 200, 250, 300, 350, 400, 450, 500), gamma=0.2):
+        self.lr0, self.milestones, self.gamma = float(lr0), sorted(int(m) for m in milestones), float(gamma)
+
+    def lr_at(self, epoch):
+        return self.lr0 * self.gamma ** sum(1 for m in self.milestones if m <= epoch)
+
+    def lr_for_step(self, epoch, step=0, steps_in_epoch=1):
+        return self.lr_at(epoch)
+
+
 def plan_buckets(layer_ranges, numel, n_buckets):
     """Tile the flat gradient [0, numel) into contiguous all-reduce slices by layer pair, in the order the backward
     completes them (FlatParams lays layer pair L-1 first).  Returns (buckets, tail): buckets = [(lo, hi, k_ready)] --
@@ -213,7 +230,14 @@ class Prefetcher(object):
 
 class Trainer(object):
     def __init__(self, model, lr=1e-4, weight_decay=0.0, ema_decay=0.999, max_grad_norm=1000.0, betas=(0.9, 0.999),
-                 eps=1e-8, world_size=1, process_group=None, overlap_comm=True, n_buckets=3, native_optimizer=True):
+                 eps=1e-8, world_size=1, process_group=None, overlap_comm=True, n_buckets=3, native_optimizer=True,
+                 loss='l1'):
+        """loss: 'l1' | 'mse' | 'smooth_l1' (the three drivers' losses, mean over graphs); max_grad_norm=None: no
+        clip_grad_norm_; ema_decay=None: no EMA shadow (evaluate() then runs on the weights themselves)."""
+        from .ops import LOSS_ENTRIES
+        if loss not in LOSS_ENTRIES:
+            raise ValueError("loss must be one of 'l1', 'mse', 'smooth_l1' (got %r)" % (loss,))
+        self.loss_kind = loss
         self.model = model
         self.fp = FlatParams(model, direct=True)           # fused layers write gradients straight into fp.grad
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
@@ -233,7 +257,7 @@ class Trainer(object):
         # gradient tensors over and one multi-tensor add packs them into the flat buffer
         self._pack = bool(self.fp.flat.is_cuda and getattr(model, 'dim', 128) not in (128, 16, 32, 64))
         self.ema_decay = ema_decay
-        self.shadow = self.fp.flat.clone()                                 # utils/ema.py:9-11
+        self.shadow = self.fp.flat.clone() if ema_decay is not None else None      # utils/ema.py:9-11
         self.max_grad_norm = max_grad_norm
         self.world_size, self.pg = world_size, process_group
         self._buckets = self._stack_ctx = None
@@ -242,7 +266,8 @@ class Trainer(object):
         if world_size > 1 and distributed:
             # identical initial parameters on every rank whatever the seeds were (main_qm9.py has a single process)
             dist.broadcast(self.fp.flat, 0, group=process_group)
-            self.shadow.copy_(self.fp.flat)
+            if self.shadow is not None:
+                self.shadow.copy_(self.fp.flat)
         if overlap_comm and overlap_comm != 'force_single' and distributed and (world_size > 1 or overlap_comm == 'force'):
             self._setup_buckets(n_buckets)
 
@@ -262,11 +287,11 @@ class Trainer(object):
         scale = float(out.numel()) / float(global_graphs) if self.world_size > 1 else 1.0
         if out.is_cuda and out.dtype == torch.float32:
             from . import ops
-            loss, d_out = ops.l1_loss_with_grad(out, data.y, scale)      # loss + its gradient: one launch
+            loss, d_out = ops.loss_with_grad(self.loss_kind, out, data.y, scale)      # loss + its gradient: one launch
             if not ops.backward_whole(out, d_out):                       # (a forward that is not one recorded node)
                 out.backward(d_out)
         else:                                                            # gloo / CPU unit tests with a plain module
-            loss = F.l1_loss(out, data.y)
+            loss = {'l1': F.l1_loss, 'mse': F.mse_loss, 'smooth_l1': F.smooth_l1_loss}[self.loss_kind](out, data.y)
             (loss * scale).backward()
         if self._pack:
             self.fp.pack_grads()
@@ -329,6 +354,8 @@ class Trainer(object):
 
     def clip(self):
         norm = torch.linalg.vector_norm(self.fp.grad)
+        if self.max_grad_norm is None:
+            return norm
         coef = torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0)    # clip_grad_norm_ (main_qm9.py:111)
         self.fp.grad.mul_(coef)
         return norm
@@ -339,25 +366,29 @@ class Trainer(object):
         self.opt.step()
 
     def native_update(self, lr=None, num_updates=99999):
-        """clip -> Adam -> EMA -> zero the gradient, one kernel; the norm stays on the device."""
+        """[clip ->] Adam [-> EMA] -> zero the gradient, one kernel; the norm stays on the device."""
         from . import lib
         if lr is not None:
             self.lr = lr
         from . import ops
+        # the pre-clip norm is reported either way (last_grad_norm); without a clip its partials only feed norm_out
         part = ops.sumsq_partials(self.fp.grad)            # the kernel below adds the 256 partials and clips by the norm
         norm = torch.empty(1, dtype=torch.float32, device=self.fp.flat.device)
         self.step_count += 1
-        decay = min(self.ema_decay, (1.0 + num_updates) / (10.0 + num_updates))     # utils/ema.py:14
+        decay = 0.0 if self.ema_decay is None else min(self.ema_decay, (1.0 + num_updates) / (10.0 + num_updates))   # utils/ema.py:14
+        max_norm = float('inf') if self.max_grad_norm is None else float(self.max_grad_norm)
         lib.call('pamnet_adam_ema_norm_f32', lib.ptr(self.fp.flat), lib.ptr(self.fp.grad), lib.ptr(self.exp_avg),
                  lib.ptr(self.exp_avg_sq), lib.ptr(self.shadow), self.fp.flat.numel(), float(self.lr),
                  float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
-                 self.step_count, float(decay), lib.ptr(part), lib.ptr(norm), float(self.max_grad_norm), 1,
+                 self.step_count, float(decay), lib.ptr(part), lib.ptr(norm), max_norm, 1,
                  lib.stream_of(self.fp.flat))
         norm = norm[0]
         self._grad_clean = True
         return norm
 
     def ema_update(self, num_updates=99999):
+        if self.ema_decay is None:
+            return
         decay = min(self.ema_decay, (1.0 + num_updates) / (10.0 + num_updates))     # utils/ema.py:14
         self.shadow.mul_(decay).add_(self.fp.flat, alpha=1.0 - decay)
 
@@ -431,10 +462,14 @@ class Trainer(object):
 
     # -- evaluation under the EMA weights (main_qm9.py:29-37) ---------------------------------------------------------
     def ema_assign(self):
+        if self.shadow is None:
+            return
         self._saved = self.fp.flat.clone()
         self.fp.flat.copy_(self.shadow)
 
     def ema_resume(self):
+        if self.shadow is None:
+            return
         self.fp.flat.copy_(self._saved)
         del self._saved
 
@@ -454,6 +489,60 @@ class Trainer(object):
         if hasattr(self.model, 'verify'):
             self.model.verify()
         return res
+
+    @torch.no_grad()
+    def predictions(self, batches):
+        """(pred, y) as host arrays over `batches` -- what test() of main_pdbbind.py:25-39 / main_rna_puzzles.py:26-46
+        collects before handing them to utils.rmse / mae / sd / pearson or F.smooth_l1_loss; under the EMA weights when
+        the trainer keeps a shadow.  This rank's batches only."""
+        self.drain()
+        self.ema_assign()
+        preds, ys = [], []
+        for data, out in predict(self.model, batches):
+            preds.append(out.reshape(-1)), ys.append(data.y.reshape(-1).to(out.device))
+        self.ema_resume()
+        if not preds:
+            import numpy as np
+            return np.zeros(0, np.float32), np.zeros(0, np.float32)
+        return torch.cat(preds).cpu().numpy(), torch.cat(ys).cpu().numpy()
+
+    # -- checkpoints ----------------------------------------------------------------------------------------------------
+    def state_dict(self):
+        """Everything a resume needs (model weights under the reference's keys, both Adam moments, the EMA shadow, the update
+        count).  Drains the steps in flight first: the deferred device-side checks of the last MAX_STEPS_IN_FLIGHT batches
+        (zero-host-sync batches) are read before anything is saved -- a checkpoint never outlives an unchecked step."""
+        self.drain()
+        sd = {'model': {k: v.detach().clone() for k, v in self.model.state_dict().items()},
+              'shadow': None if self.shadow is None else self.shadow.clone(), 'lr': self.lr}
+        if self.native_opt:
+            sd.update(exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), step_count=self.step_count)
+        else:
+            sd['optimizer'] = self.opt.state_dict()
+        return sd
+
+    def load_state_dict(self, sd):
+        self.drain()
+        self.model.load_state_dict(sd['model'], strict=True)       # (parameters are views of fp.flat: copied in place)
+        if self.shadow is not None and sd.get('shadow') is not None:
+            self.shadow.copy_(sd['shadow'])
+        self.lr = sd.get('lr', self.lr)
+        if self.native_opt:
+            self.exp_avg.copy_(sd['exp_avg']), self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+            self.step_count = int(sd['step_count'])
+        else:
+            self.opt.load_state_dict(sd['optimizer'])
+
+    def close(self):
+        """End of training: wait for the steps in flight and read their deferred checks (raises what they found)."""
+        self.drain()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            self.close()
+        return False
 
 
 @torch.no_grad()

@@ -317,27 +317,35 @@ def fixture_random(name, cls, cfg_kw, batch, seed, capture, small=False, basis=N
     save(name, **arrs)
 
 
-def fixture_train(name, cfg_kw, batch, seed, lrs, max_norm):
+def fixture_train(name, cfg_kw, batch, seed, lrs, max_norm, loss='l1', ema=True):
     """K optimiser steps of the reference training loop body (main_qm9.py:103-118) on one fixed batch: reference model,
     torch Adam (wd=0, amsgrad=False), clip_grad_norm_, the reference's own EMA class (utils/ema.py); per-step learning
-    rates are given explicitly (the warm-up scheduler wheel is absent).  fp32 and fp64."""
+    rates are given explicitly (the warm-up scheduler wheel is absent).  fp32 and fp64.
+    loss / max_norm=None / ema=False select the other two drivers' loop bodies: main_pdbbind.py:88-95 (F.mse_loss, no clip,
+    no EMA; MultiStepLR stepped per epoch -> the per-step rates are handed in) and main_rna_puzzles.py:86-93
+    (F.smooth_l1_loss, no clip, no EMA, constant rate)."""
     from torch.nn.utils import clip_grad_norm_
     from utils.ema import EMA as RefEMA
     cfg = ref_models.Config(**cfg_kw)
     sd = oracle.init_state_dict(cfg, seed=seed)
     arrs = dict(seed=np.int64(seed), weights_checksum=np.float64(checksum(sd)), lrs=np.asarray(lrs, np.float64),
-                max_norm=np.float64(max_norm), cfg_dataset=np.array(cfg_kw['dataset']), cfg_dim=np.int64(cfg_kw['dim']),
+                max_norm=np.float64(-1.0 if max_norm is None else max_norm), cfg_dataset=np.array(cfg_kw['dataset']),
+                cfg_dim=np.int64(cfg_kw['dim']),
                 cfg_n_layer=np.int64(cfg_kw['n_layer']), cfg_cutoff_l=np.float64(cfg_kw['cutoff_l']),
-                cfg_cutoff_g=np.float64(cfg_kw['cutoff_g']))
+                cfg_cutoff_g=np.float64(cfg_kw['cutoff_g']), cfg_flow=np.array(cfg_kw.get('flow', 'source_to_target')),
+                loss_kind=np.array(loss), ema=np.int64(1 if ema else 0))
+    loss_fn = {'l1': torch.nn.functional.l1_loss, 'mse': torch.nn.functional.mse_loss,
+               'smooth_l1': torch.nn.functional.smooth_l1_loss}[loss]
     for k in ('x', 'batch', 'pos', 'edge_index', 'y'):
-        arrs['in/' + k] = getattr(batch, k).numpy()
+        if hasattr(batch, k):
+            arrs['in/' + k] = getattr(batch, k).numpy()
     for tag, dtype in (('32', torch.float32), ('64', torch.float64)):
         model = build_model(ref_models.PAMNet, cfg)
         model.load_state_dict(sd)
         if dtype == torch.float64:
             model = model.double()
         opt = torch.optim.Adam(model.parameters(), lr=lrs[0], weight_decay=0, amsgrad=False)
-        ema = RefEMA(model, decay=0.999)
+        ema_obj = RefEMA(model, decay=0.999) if ema else None
         data, y = make_data(batch, dtype), batch.y.to(dtype)
         losses, norms = [], []
         for lr in lrs:
@@ -345,23 +353,30 @@ def fixture_train(name, cfg_kw, batch, seed, lrs, max_norm):
                 grp['lr'] = lr
             opt.zero_grad()
             out = model(data)
-            loss = torch.nn.functional.l1_loss(out, y)
-            loss.backward()
-            norms.append(float(clip_grad_norm_(model.parameters(), max_norm=max_norm, norm_type=2)))
+            loss_v = loss_fn(out, y)
+            loss_v.backward()
+            if max_norm is not None:
+                norms.append(float(clip_grad_norm_(model.parameters(), max_norm=max_norm, norm_type=2)))
+            else:                                  # recorded, not applied
+                norms.append(float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters()
+                                                  if p.grad is not None))))
             opt.step()
-            ema(model)
-            losses.append(float(loss))
+            if ema_obj is not None:
+                ema_obj(model)
+            losses.append(float(loss_v))
         arrs['loss' + tag] = np.asarray(losses, np.float64)
         arrs['grad_norm' + tag] = np.asarray(norms, np.float64)
         arrs['param_l2_' + tag] = np.float64(torch.sqrt(sum((p.double() ** 2).sum() for p in model.parameters())))
-        arrs['shadow_l2_' + tag] = np.float64(torch.sqrt(sum((v.double() ** 2).sum() for v in ema.shadow.values())))
+        if ema_obj is not None:
+            arrs['shadow_l2_' + tag] = np.float64(torch.sqrt(sum((v.double() ** 2).sum() for v in ema_obj.shadow.values())))
         arrs['delta_l2_' + tag] = np.float64(torch.sqrt(sum(((p.double() - sd[k].double()) ** 2).sum()
                                                            for k, p in model.named_parameters())))
         with torch.no_grad():
             arrs['out_final' + tag] = model(data).numpy()
-            ema.assign(model)
-            arrs['out_ema' + tag] = model(data).numpy()
-            ema.resume(model)
+            if ema_obj is not None:
+                ema_obj.assign(model)
+                arrs['out_ema' + tag] = model(data).numpy()
+                ema_obj.resume(model)
     save(name, **arrs)
 
 
@@ -369,6 +384,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if '--train-only' in sys.argv:
         return main_train()
+    if '--train-other-only' in sys.argv:
+        return main_train_other()
     if '--ragged-only' in sys.argv:
         return main_ragged()
     if '--d128-only' in sys.argv:
@@ -474,6 +491,25 @@ def main_train():
     big = dict(dataset='QM9', dim=128, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
     # max_norm below the first gradient norm so that the clip is exercised
     fixture_train('train_qm9_d128_l2', big, synth.qm9_batch(0, 0, 8), seed=6, lrs=lrs, max_norm=0.5)
+    main_train_other()
+
+
+def main_train_other():
+    """The loop bodies of the other two drivers (the data sets themselves are not available offline: schema-true synthetic
+    batches).  PDBbind: MultiStepLR(gamma=0.2) crossing two milestones inside the five steps; targets ~ pK values so that
+    |out - y| > 1 (the quadratic and the linear branch of smooth-L1 / the magnitude of the MSE gradient are both live)."""
+    pdb = dict(dataset='PDBbind', dim=32, n_layer=2, cutoff_l=2.0, cutoff_g=6.0)
+    b = synth.pdbbind_batch(5, 0, 3, n_pocket=70, n_ligand=14)
+    fixture_train('train_pdbbind_d32_l2', pdb, b, seed=5, lrs=[1e-3, 1e-3, 2e-4, 2e-4, 4e-5], max_norm=None, loss='mse',
+                  ema=False)
+    pdb128 = dict(dataset='PDBbind', dim=128, n_layer=3, cutoff_l=2.0, cutoff_g=6.0)
+    b = synth.pdbbind_batch(9, 0, 2, n_pocket=90, n_ligand=16)
+    fixture_train('train_pdbbind_d128_l3', pdb128, b, seed=31, lrs=[1e-3, 1e-3, 2e-4, 2e-4, 4e-5], max_norm=None, loss='mse',
+                  ema=False)
+    rna = dict(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
+    b = synth.rna_batch(2, 0, 3, n_nodes=260)
+    b.y = torch.tensor([0.4, 2.5, 7.0])            # RMSD-like targets: |out - y| on both sides of 1
+    fixture_train('train_rna_d16_l1', rna, b, seed=12, lrs=[5e-4] * 5, max_norm=None, loss='smooth_l1', ema=False)
 
 
 def main_ragged():

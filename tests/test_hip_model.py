@@ -776,6 +776,64 @@ def test_l1_loss_target_shapes_and_dtypes(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['l1', 'mse', 'smooth_l1'])
+def test_loss_kernels_vs_torch_losses(dev, kind):
+    """The one-launch loss + gradient kernels (pamnet_l1_loss_f32 / pamnet_mse_loss_f32 / pamnet_smooth_l1_loss_f32) against
+    F.l1_loss / F.mse_loss / F.smooth_l1_loss (main_qm9.py:108, main_pdbbind.py:93, main_rna_puzzles.py:92) evaluated in
+    fp64: value and gradient within 2e-7 (max-normalised), residuals on both sides of the smooth-L1 knee and exactly on it,
+    exact zeros, sizes that are not multiples of the workgroup; the DP pre-scaling (grad_scale) scales the gradient only."""
+    from pamnet_amd import ops
+    F = torch.nn.functional
+    fn = {'l1': F.l1_loss, 'mse': F.mse_loss, 'smooth_l1': F.smooth_l1_loss}[kind]
+    gen = torch.Generator().manual_seed(5)
+    for n in (1, 7, 256, 1000):
+        y = torch.randn(n, generator=gen) * 3
+        out = y + torch.randn(n, generator=gen) * 1.5
+        if n >= 7:
+            out[0], out[1], out[2], out[3] = y[0], y[1] + 1.0, y[2] - 1.0, y[3] + 0.999999
+        o64 = out.double().requires_grad_(True)
+        l64 = fn(o64, y.double())
+        l64.backward()
+        for scale in (1.0, 0.37):
+            loss, g = ops.loss_with_grad(kind, out.to(dev), y.to(dev), scale)
+            assert abs(float(loss) - float(l64)) <= 2e-7 * max(1.0, abs(float(l64))), (kind, n)
+            ref = o64.grad * scale
+            assert float((g.cpu().double() - ref).abs().max()) <= 2e-7 * float(ref.abs().max()) + 1e-30, (kind, n, scale)
+    with pytest.raises(ValueError):
+        ops.loss_with_grad('huber', out.to(dev), y.to(dev))
+
+
+@pytest.mark.gpu
+def test_trainer_checkpoint_round_trip_and_close(dev):
+    """Trainer.state_dict() / load_state_dict(): a resumed trainer continues bit for bit; state_dict() and close() drain the
+    steps in flight (the deferred device-side checks of the last batches are read before anything is saved)."""
+    import models
+    from pamnet_amd import synth
+    from pamnet_amd.train import Trainer
+    cfg = models.Config(dataset='QM9', dim=128, n_layer=1, cutoff_l=5.0, cutoff_g=5.0)
+    bs = [synth.qm9_batch(4, 8 * k, 8).to(dev) for k in range(4)]
+
+    def fresh():
+        torch.manual_seed(3)
+        return Trainer(models.PAMNet(cfg).to(dev), lr=1e-3)
+    a = fresh()
+    for k in range(2):
+        a.step(bs[k])
+    ck = a.state_dict()
+    assert not a._inflight and set(ck['model']) == set(a.model.state_dict())
+    for k in range(2, 4):
+        a.step(bs[k])
+    b = fresh()
+    b.load_state_dict(ck)
+    for k in range(2, 4):
+        b.step(bs[k])
+    with a, b:                                           # __exit__ -> close() -> drain()
+        pass
+    assert not a._inflight and not b._inflight
+    assert torch.equal(a.fp.flat, b.fp.flat) and torch.equal(a.shadow, b.shadow) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
+
+
+@pytest.mark.gpu
 def test_out_of_range_inputs_raise_index_error(dev):
     """Atom types beyond the embedding table or bond endpoints beyond the node count raise
     IndexError (as indexing does in the reference, models.py:107) instead of writing out of bounds on the device."""

@@ -492,7 +492,7 @@ def test_store_engine_path_rna_checkpoint(dev, golden):
     assert ok, info
 
 
-@pytest.mark.parametrize('name', ['qm9_d32_l2', 'pdbbind_d32_l2', 'qm9_ragged_d32_l2', 'pdbbind_d128_l3', 'qm9_d128_l6'])
+@pytest.mark.parametrize('name', ['qm9_d32_l2', 'pdbbind_d32_l2', 'qm9_ragged_d32_l2', 'qm9_basis_5x4_p6_d32_l2'])
 def test_store_engine_graph_indices_equal_the_reference_lists(dev, golden, name):
     """Integer parity of the ONE-call graph with the reference's own index lists (captured from its fp32 run: local edges,
     triplets (k, j, i), pairs (i, j, j'), models.py:68-98): the same edges, the same triplet / pair rows with the same
@@ -500,10 +500,10 @@ def test_store_engine_graph_indices_equal_the_reference_lists(dev, golden, name)
     import collections
     import models
     from oracle import pamnet_oracle as O
-    from test_hip_model import _batch_from, _cfg_from
+    from test_hip_model import _basis_args, _batch_from, _cfg_from
     g = golden(name)
     cfg = _cfg_from(g, models.Config)
-    model = models.PAMNet(cfg)
+    model = models.PAMNet(cfg, *_basis_args(cfg))
     model.load_state_dict(O.init_state_dict(cfg, seed=int(g['seed'])), strict=True)
     model = model.to(dev)
     _through_store(model, _split(_batch_from(g, 'cpu')), dev)

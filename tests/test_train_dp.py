@@ -320,6 +320,52 @@ def test_bench_world2_dry_run_on_cpu():
     assert j['scaling'] == 'weak' and j['value'] > 0 and abs(j['value'] - 16 * 3 / (j['ms_per_step'] * 3e-3)) < 1e-6 * j['value']
 
 
+def test_multistep_lr_helper_equals_torch_scheduler():
+    """train.MultiStepLR == torch.optim.lr_scheduler.MultiStepLR as main_pdbbind.py:83,96 drives it (one step per epoch)."""
+    from pamnet_amd.train import MultiStepLR
+    ms = [50, 100, 150, 200, 250, 300, 350, 400, 450, 500]
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-3)
+    ref = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=ms, gamma=0.2)
+    mine = MultiStepLR(1e-3, ms, 0.2)
+    for epoch in range(520):
+        assert abs(opt.param_groups[0]['lr'] - mine.lr_at(epoch)) <= 1e-12 * mine.lr_at(epoch), epoch
+        assert mine.lr_for_step(epoch, 3, 10) == mine.lr_at(epoch)
+        opt.step()
+        ref.step()
+
+
+def test_trainer_loss_variants_on_cpu_standin():
+    """Trainer(loss=..., max_grad_norm=None, ema_decay=None) on the CPU stand-in: the three losses' torch forms drive the step,
+    no shadow is kept, evaluate() / predictions() run on the weights themselves; an unknown loss raises."""
+    from standin import LayeredStandIn
+    from pamnet_amd import synth
+    from pamnet_amd.train import Trainer
+    F = torch.nn.functional
+    for kind, fn in (('l1', F.l1_loss), ('mse', F.mse_loss), ('smooth_l1', F.smooth_l1_loss)):
+        torch.manual_seed(0)
+        m = LayeredStandIn(n_layer=2)
+        ref = LayeredStandIn(n_layer=2)
+        ref.load_state_dict(m.state_dict())
+        tr = Trainer(m, lr=1e-2, loss=kind, max_grad_norm=None, ema_decay=None, native_optimizer=False)
+        assert tr.shadow is None
+        b = synth.qm9_batch(0, 0, 9)
+        opt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+        for _ in range(3):
+            loss = tr.step(b)
+            opt.zero_grad()
+            l2 = fn(ref(b), b.y)
+            l2.backward()
+            opt.step()
+            assert abs(float(loss) - float(l2)) < 1e-6
+        for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+            assert torch.allclose(p, q, atol=1e-6), k
+        pred, y = tr.predictions([b])
+        assert pred.shape == y.shape == (9,)
+    with pytest.raises(ValueError):
+        Trainer(LayeredStandIn(n_layer=1), loss='huber')
+
+
 def test_bench_plain_invocation_launches_its_own_ranks_on_cpu():
     """`python bench.py --gpus 2 ...` WITHOUT a launcher (the form the driver uses for N = 1): bench.py re-launches itself
     under torch.distributed.run on a free local port -- one JSON line, same contract.  And a world size that contradicts
