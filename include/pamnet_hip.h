@@ -104,14 +104,19 @@ int pamnet_csr_filter_fill_i32(const int32_t* ptr_in, const int32_t* nbr, const 
 /* ------------------------------------------------------------------------------------------------------------------
  * Neighbour search (torch_cluster.radius / knn: models.py:110,128,143,301), self loops removed (models.py:63).
  * `gptr[b..b+1]` = node range of graph b (batch sorted).  Two-pass: count -> (caller scans) -> fill.
- * radius: neighbours j != i of the same graph with ||pos_i - pos_j|| <= r, ascending j.  Symmetric by construction.
+ * radius: neighbours j != i of the same graph with ||pos_i - pos_j|| <= r, ascending j.  Symmetric by construction --
+ * unless max_neighbors binds.  max_neighbors (0 = unlimited; models.py:110,128 pass 1000, :301 passes 500): a query keeps
+ * the first max_neighbors points of its graph within r in ascending index order, itself included in that count (the search
+ * returns the query; remove_self_loops follows, models.py:63); the count pass ORs 64 into *cap_flag (nullable) when a row
+ * was truncated -- the graph is then not symmetric and the caller must build general transposes.
  * n_graphs (0 = unknown) only selects the launch shape: one thread per node for molecule-sized graphs, one wavefront per
  * node from ~100 nodes per graph on; the output is the same.
  * ------------------------------------------------------------------------------------------------------------------ */
 int pamnet_radius_count_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n,
-                            int64_t n_graphs, float r, int32_t* count, pamnet_stream_t stream);
+                            int64_t n_graphs, float r, int64_t max_neighbors, int32_t* count, int32_t* cap_flag,
+                            pamnet_stream_t stream);
 int pamnet_radius_fill_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n,
-                           int64_t n_graphs, float r, const int32_t* ptr, int32_t* nbr, float* dist,
+                           int64_t n_graphs, float r, int64_t max_neighbors, const int32_t* ptr, int32_t* nbr, float* dist,
                            int32_t* row_of /* nullable: the query node of every entry */, int64_t cap,
                            pamnet_stream_t stream);
 
@@ -249,6 +254,9 @@ typedef struct pamnet_graph_desc {
     int32_t aggregate_at_query;   /* RNA: flow == 'target_to_source' (the global layer aggregates at the kNN query) */
     int32_t knn_k;                /* RNA: neighbours per query (models.py:143: 50) */
     float cutoff_l, cutoff_g;
+    int32_t max_neighbors;        /* radius searches: torch_cluster's max_num_neighbors (models.py:110,128: 1000; :301: 500;
+                                     0 = unlimited).  A batch in which it binds is flagged (bit 64 of the flag word): the one-call
+                                     graph assumes symmetric radius graphs */
     int32_t mol_local;            /* QM9: 1 = the molecule-local builder (pamnet_mol_graph_*: the caller vouches for <= 64 atoms,
                                      <= 256 directed bonds per molecule and bonds grouped by molecule in batch order; a batch
                                      that is not so is flagged as a local-edge size mismatch) */
@@ -256,7 +264,7 @@ typedef struct pamnet_graph_desc {
 enum {
     PAMNET_GF_NODE_GRAPH = 0, /* int32 [n] */
     PAMNET_GF_GPTR,           /* int32 [n_graphs + 1] first node of every graph */
-    PAMNET_GF_FLAG,           /* int32 [1]: bit 1 invalid index inputs, bits 2 / 4 / 8 size mismatch (eg / el / tp), 32 self loops */
+    PAMNET_GF_FLAG,           /* int32 [1]: bit 1 invalid index inputs, bits 2 / 4 / 8 size mismatch (eg / el / tp), 32 self loops, 64 neighbour cap binds */
     PAMNET_GF_LOOPS,          /* int32 [1] */
     PAMNET_GF_TYPES,          /* int32 [n] */
     PAMNET_GF_POS,            /* fp32 [n, 3] (PDBbind / RNA; QM9 uses the caller's) */

@@ -172,14 +172,20 @@ def _graph_slices(batch):
     return [(int(ptr[b]), int(ptr[b + 1])) for b in range(cnt.numel())]
 
 
-def radius_graph(pos, batch, r):
-    """torch_cluster.radius(pos,pos,r,batch,batch) (models.py:110,128): [2,M] = (query idx, neighbour idx), self
-    included, `dist <= r`, ordered by (query, neighbour).  `batch` sorted."""
+def radius_graph(pos, batch, r, max_num_neighbors=None):
+    """torch_cluster.radius(pos,pos,r,batch,batch,max_num_neighbors) (models.py:110,128,301): [2,M] = (query idx, neighbour
+    idx), self included, `dist <= r`, ordered by (query, neighbour).  `batch` sorted.  max_num_neighbors: a query keeps its
+    first that-many hits in ascending index order, itself counted (the order of torch_cluster 1.5.x's CUDA kernel, which
+    walks the candidates by index and stops at the cap; the library is not in the reference tree: parity unpinned, like
+    every third-party boundary -- no fixture of the reference reaches the cap of 1000 / 500)."""
     rows, cols = [], []
     for s, e in _graph_slices(batch):
         p = pos[s:e].double()
         d = (p.unsqueeze(1) - p.unsqueeze(0)).pow(2).sum(-1).sqrt()
-        q, n = (d <= r).nonzero(as_tuple=True)
+        hit = d <= r
+        if max_num_neighbors is not None:
+            hit = hit & (hit.long().cumsum(1) <= int(max_num_neighbors))
+        q, n = hit.nonzero(as_tuple=True)
         rows.append(q + s)
         cols.append(n + s)
     return torch.stack([torch.cat(rows), torch.cat(cols)], 0)
@@ -354,7 +360,7 @@ def build_graph(cfg, x_raw, batch, pos=None, edge_index_l=None, dtype=torch.floa
     g = {}
     if cfg.dataset == 'QM9':
         pos = pos.to(dtype)
-        ei_g = radius_graph(pos, batch, cfg.cutoff_g)
+        ei_g = radius_graph(pos, batch, cfg.cutoff_g, max_nb)
         ei_g, dist_g = get_edge_info(ei_g, pos)
         ei_l, dist_l = get_edge_info(edge_index_l, pos)
         g['emb_index'] = x_raw.long()
@@ -364,7 +370,7 @@ def build_graph(cfg, x_raw, batch, pos=None, edge_index_l=None, dtype=torch.floa
         g['feat'] = x_raw[:, 3:]
         pos = x_raw[:, :3].contiguous()
         g['all_index'] = torch.where(pos[:, 0] > 40.0, -torch.ones_like(pos[:, 0]), torch.ones_like(pos[:, 0]))
-        ei_g = radius_graph(pos, batch, cfg.cutoff_g)
+        ei_g = radius_graph(pos, batch, cfg.cutoff_g, max_nb)
         ei_g, dist_g = get_edge_info(ei_g, pos)
         ei_l = ei_g[:, dist_g <= cfg.cutoff_l]
         ei_l, dist_l = get_edge_info(ei_l, pos)
@@ -385,10 +391,10 @@ def build_graph(cfg, x_raw, batch, pos=None, edge_index_l=None, dtype=torch.floa
     return g
 
 
-def pamnet_forward(sd, cfg, x_raw, batch, pos=None, edge_index=None, dtype=None, intermediates=None):
+def pamnet_forward(sd, cfg, x_raw, batch, pos=None, edge_index=None, dtype=None, intermediates=None, max_num_neighbors=1000):
     """models.py:100-224.  `sd`: reference-layout state_dict (tensors of the working dtype).  Returns [num_graphs]."""
     dtype = dtype or sd['embeddings'].dtype
-    g = build_graph(cfg, x_raw, batch, pos, edge_index, dtype)
+    g = build_graph(cfg, x_raw, batch, pos, edge_index, dtype, max_nb=max_num_neighbors)
     pos, ei_g, dist_g, ei_l, dist_l = g['pos'], g['edge_index_g'], g['dist_g'], g['edge_index_l'], g['dist_l']
     if 'emb_index' in g:
         x = torch.index_select(sd['embeddings'], 0, g['emb_index'])                       # models.py:107,140
@@ -457,7 +463,7 @@ def pool(cfg, node_out, batch, all_index=None):
     return out.view(-1)
 
 
-def pamnet_s_forward(sd, cfg, x_raw, batch, pos, edge_index, dtype=None, intermediates=None):
+def pamnet_s_forward(sd, cfg, x_raw, batch, pos, edge_index, dtype=None, intermediates=None, max_num_neighbors=500):
     """models.py:283-353 (PAMNet_s: QM9 only, pairs only, single `mlp_sbf`)."""
     if cfg.dataset != 'QM9':
         raise ValueError("Invalid dataset. The current PAMNet_s is only for QM9 experiments.")
@@ -465,7 +471,7 @@ def pamnet_s_forward(sd, cfg, x_raw, batch, pos, edge_index, dtype=None, interme
     pos = pos.to(dtype)
     x = torch.index_select(sd['embeddings'], 0, x_raw.long())
     ei_l, dist_l = get_edge_info(edge_index, pos)
-    ei_g, dist_g = get_edge_info(radius_graph(pos, batch, cfg.cutoff_g), pos)
+    ei_g, dist_g = get_edge_info(radius_graph(pos, batch, cfg.cutoff_g, max_num_neighbors), pos)
     (_, _, _, _, _, idx_i_pair, idx_j1_pair, idx_j2_pair, idx_jj_pair, idx_ji_pair) = indices(ei_l, x.size(0))
     angle = angle_between(pos[idx_j1_pair] - pos[idx_i_pair], pos[idx_j2_pair] - pos[idx_j1_pair])
     ns, nr, p = basis_of(cfg)

@@ -316,33 +316,46 @@ __global__ __launch_bounds__(SMALL_THREADS) void csr_small_kernel(const int32_t*
 }
 
 
+// max_nb > 0: torch_cluster.radius(..., max_num_neighbors) (models.py:110,128: 1000; :301: 500): a query keeps the first
+// max_nb points of its graph within r in ascending index order -- ITSELF INCLUDED in that count (the search returns the
+// query too; remove_self_loops comes after, models.py:63) -- and a truncated row raises CAP_BIT in *cap_flag.  A capped
+// graph is no longer symmetric; the host then takes the general (counting-sort) transposes.  (Order of a capped search:
+// torch_cluster 1.5.x's CUDA kernel walks the candidates by index and stops at the cap; that library is not in the
+// reference tree -- parity unpinned, as SURVEY 8c records for every third-party boundary.)
+constexpr int CAP_BIT = 64;
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void radius_kernel(const float* __restrict__ pos,
                                                      const int32_t* __restrict__ node_graph,
                                                      const int32_t* __restrict__ gptr, int64_t n, float r,
                                                      int32_t* __restrict__ count, const int32_t* __restrict__ ptr,
                                                      int32_t* __restrict__ nbr, float* __restrict__ dist, int64_t cap,
-                                                     int32_t* __restrict__ row_of) {
+                                                     int32_t* __restrict__ row_of, int max_nb,
+                                                     int32_t* __restrict__ cap_flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int g = node_graph[i];
     const int beg = gptr[g], end = gptr[g + 1];
-    int c = 0;
+    int c = 0, seen = 0;
     int64_t w = FILL ? ptr[i] : 0;
     for (int j = beg; j < end; ++j) {
-        if (j == i) continue;
-        const float d = dist3(pos, i, j);
-        if (d <= r) {
-            if (FILL) {
-                if (w < cap) {                                 // cap: see pamnet_radius_fill_i32
-                    nbr[w] = j;
-                    dist[w] = d;
-                    if (row_of) row_of[w] = (int32_t)i;
-                }
-                ++w;
-            }
-            ++c;
+        const float d = j == i ? 0.f : dist3(pos, i, j);
+        if (j != i && !(d <= r)) continue;
+        if (max_nb > 0 && seen >= max_nb) {                    // this hit and everything behind it is cut off
+            if (!FILL && cap_flag) atomicOr(cap_flag, CAP_BIT);
+            break;
         }
+        ++seen;
+        if (j == i) continue;
+        if (FILL) {
+            if (w < cap) {                                 // cap: see pamnet_radius_fill_i32
+                nbr[w] = j;
+                dist[w] = d;
+                if (row_of) row_of[w] = (int32_t)i;
+            }
+            ++w;
+        }
+        ++c;
     }
     if (!FILL) count[i] = c;
 }
@@ -357,14 +370,16 @@ __global__ __launch_bounds__(256) void radius_wave_kernel(const float* __restric
                                                           const int32_t* __restrict__ gptr, int64_t n, float r,
                                                           int32_t* __restrict__ count, const int32_t* __restrict__ ptr,
                                                           int32_t* __restrict__ nbr, float* __restrict__ dist,
-                                                          int64_t cap, int32_t* __restrict__ row_of) {
+                                                          int64_t cap, int32_t* __restrict__ row_of, int max_nb,
+                                                          int32_t* __restrict__ cap_flag) {
     const int lane = threadIdx.x & 63;
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= n) return;
     const int g = node_graph[i];
     const int beg = gptr[g], end = gptr[g + 1];
-    int c = 0;
+    int c = 0, seen = 0;
     const int64_t w0 = FILL ? ptr[i] : 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
     for (int j0 = beg; j0 < end; j0 += 64) {
         const int j = j0 + lane;
         float d = 0.f;
@@ -373,9 +388,18 @@ __global__ __launch_bounds__(256) void radius_wave_kernel(const float* __restric
             d = dist3(pos, i, j);
             keep = d <= r;
         }
+        if (max_nb > 0) {                                      // (wave-uniform branch; hits = kept candidates + the query)
+            const unsigned long long hits = __ballot(keep || j == i);
+            const bool allowed = seen + __builtin_popcountll(hits & below) < max_nb;
+            seen += __builtin_popcountll(hits);
+            if (seen > max_nb) {                               // wave-uniform
+                if (!FILL && cap_flag && lane == 0) atomicOr(cap_flag, CAP_BIT);
+                keep = keep && allowed;
+            }
+        }
         const unsigned long long votes = __ballot(keep);
         if (FILL && keep) {
-            const int64_t w = w0 + c + __builtin_popcountll(votes & ((1ull << lane) - 1ull));
+            const int64_t w = w0 + c + __builtin_popcountll(votes & below);
             if (w < cap) {
                 nbr[w] = j;
                 dist[w] = d;
@@ -383,7 +407,8 @@ __global__ __launch_bounds__(256) void radius_wave_kernel(const float* __restric
             }
         }
         c += __builtin_popcountll(votes);
-    }
+        if (max_nb > 0 && seen >= max_nb && FILL) break;       // nothing behind the cap is written (the count pass keeps
+    }                                                          // scanning: a later hit is what raises the flag)
     if (!FILL && lane == 0) count[i] = c;
 }
 
@@ -998,34 +1023,37 @@ extern "C" int pamnet_expand_rows_i32(const int32_t* ptr, int64_t rows, int32_t*
 }
 
 extern "C" int pamnet_radius_count_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n,
-                                       int64_t n_graphs, float r, int32_t* count, pamnet_stream_t stream) {
-    if (n < 0 || n_graphs < 0) return PAMNET_EINVAL;
+                                       int64_t n_graphs, float r, int64_t max_neighbors, int32_t* count,
+                                       int32_t* cap_flag, pamnet_stream_t stream) {
+    if (n < 0 || n_graphs < 0 || max_neighbors < 0 || max_neighbors > 0x7fffffff) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
     if (!pos || !node_graph || !gptr || !count) return PAMNET_ENULL;
+    const int mx = (int)max_neighbors;
     if (n_graphs > 0 && n >= RADIUS_WAVE_MIN_NODES * n_graphs)
         hipLaunchKernelGGL((radius_wave_kernel<false>), dim3(blocks_for(n, 4)), dim3(256), 0, as_stream(stream), pos,
                            node_graph, gptr, n, r, count, (const int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr,
-                           (int64_t)0, (int32_t*)nullptr);
+                           (int64_t)0, (int32_t*)nullptr, mx, cap_flag);
     else
         hipLaunchKernelGGL((radius_kernel<false>), dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), pos, node_graph,
                            gptr, n, r, count, (const int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (int64_t)0,
-                           (int32_t*)nullptr);
+                           (int32_t*)nullptr, mx, cap_flag);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
 
 extern "C" int pamnet_radius_fill_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n,
-                                      int64_t n_graphs, float r, const int32_t* ptr, int32_t* nbr, float* dist,
-                                      int32_t* row_of, int64_t cap, pamnet_stream_t stream) {
-    if (n < 0 || cap < 0 || n_graphs < 0) return PAMNET_EINVAL;
+                                      int64_t n_graphs, float r, int64_t max_neighbors, const int32_t* ptr, int32_t* nbr,
+                                      float* dist, int32_t* row_of, int64_t cap, pamnet_stream_t stream) {
+    if (n < 0 || cap < 0 || n_graphs < 0 || max_neighbors < 0 || max_neighbors > 0x7fffffff) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
     if (!pos || !node_graph || !gptr || !ptr || !nbr || !dist) return PAMNET_ENULL;
+    const int mx = (int)max_neighbors;
     if (n_graphs > 0 && n >= RADIUS_WAVE_MIN_NODES * n_graphs)
         hipLaunchKernelGGL((radius_wave_kernel<true>), dim3(blocks_for(n, 4)), dim3(256), 0, as_stream(stream), pos,
-                           node_graph, gptr, n, r, (int32_t*)nullptr, ptr, nbr, dist, cap, row_of);
+                           node_graph, gptr, n, r, (int32_t*)nullptr, ptr, nbr, dist, cap, row_of, mx, (int32_t*)nullptr);
     else
         hipLaunchKernelGGL((radius_kernel<true>), dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), pos, node_graph,
-                           gptr, n, r, (int32_t*)nullptr, ptr, nbr, dist, cap, row_of);
+                           gptr, n, r, (int32_t*)nullptr, ptr, nbr, dist, cap, row_of, mx, (int32_t*)nullptr);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

@@ -219,28 +219,28 @@ int run(Run& r) {
         // global graph: radius search at cutoff_g (models.py:110), symmetric, rows = query
         const int64_t cnt = r.take(n);
         int64_t raw = -1;
-        GO(pamnet_radius_count_i32(pos, r.I(node_graph), gptr, n, ng, d.cutoff_g, r.I(cnt), r.stream));
+        GO(pamnet_radius_count_i32(pos, r.I(node_graph), gptr, n, ng, d.cutoff_g, d.max_neighbors, r.I(cnt), const_cast<int32_t*>(flag), r.stream));
         if ((rc = scan(r, cnt, n, raw))) return rc;
         check(0, raw, n, eg);
         check(1, l_ptr, n, el);
         if ((rc = clamp(r, raw, n + 1, eg, g_ptr))) return rc;
-        GO(pamnet_radius_fill_i32(pos, r.I(node_graph), gptr, n, ng, d.cutoff_g, r.I(g_ptr), r.I(g_col), r.F(g_dist),
+        GO(pamnet_radius_fill_i32(pos, r.I(node_graph), gptr, n, ng, d.cutoff_g, 0, r.I(g_ptr), r.I(g_col), r.F(g_dist),
                                   r.I(g_row), eg, r.stream));
     } else if (d.schema == PAMNET_SCHEMA_PDBBIND) {
         // global = radius graph at cutoff_g, local = the same at cutoff_l (= global edges with dist <= cutoff_l,
         // models.py:128-134): both degree sequences come from count passes over the positions
         const int64_t cg = r.take(n), cl = r.take(n);
         int64_t raw_g = -1, raw_l = -1;
-        GO(pamnet_radius_count_i32(pos, r.I(node_graph), gptr, n, ng, d.cutoff_g, r.I(cg), r.stream));
+        GO(pamnet_radius_count_i32(pos, r.I(node_graph), gptr, n, ng, d.cutoff_g, d.max_neighbors, r.I(cg), const_cast<int32_t*>(flag), r.stream));
         int rc = scan(r, cg, n, raw_g);
         if (rc) return rc;
-        GO(pamnet_radius_count_i32(pos, r.I(node_graph), gptr, n, ng, d.cutoff_l, r.I(cl), r.stream));
+        GO(pamnet_radius_count_i32(pos, r.I(node_graph), gptr, n, ng, d.cutoff_l, 0, r.I(cl), nullptr, r.stream));
         if ((rc = scan(r, cl, n, raw_l))) return rc;
         check(0, raw_g, n, eg);
         check(1, raw_l, n, el);
         if ((rc = clamp(r, raw_g, n + 1, eg, g_ptr))) return rc;
         if ((rc = clamp(r, raw_l, n + 1, el, l_ptr))) return rc;
-        GO(pamnet_radius_fill_i32(pos, r.I(node_graph), gptr, n, ng, d.cutoff_g, r.I(g_ptr), r.I(g_col), r.F(g_dist),
+        GO(pamnet_radius_fill_i32(pos, r.I(node_graph), gptr, n, ng, d.cutoff_g, 0, r.I(g_ptr), r.I(g_col), r.F(g_dist),
                                   r.I(g_row), eg, r.stream));
         GO(pamnet_csr_filter_fill_i32(r.I(g_ptr), r.I(g_col), r.F(g_dist), n, d.cutoff_l, r.I(l_ptr), r.I(l_col), r.F(l_dist),
                                       el, r.stream));

@@ -153,6 +153,7 @@ class _LazyLayers(object):
 
 class _PAMNetBase(nn.Module):
     small = False
+    max_num_neighbors = 1000            # radius(..., max_num_neighbors=1000), models.py:110,128
 
     def __init__(self, config, num_spherical=7, num_radial=6, envelope_exponent=5):
         super().__init__()
@@ -196,7 +197,8 @@ class _PAMNetBase(nn.Module):
                           getattr(data, 'pos', None), getattr(data, 'edge_index', None), num_graphs=ng,
                           need_grad=torch.is_grad_enabled(), with_triplets=not self.small,
                           n_types=self.embeddings.size(0) if hasattr(self, 'embeddings') else None,
-                          sizes=self._sizes_of(data), default_basis=self.sbf.default, mol_local=self._mol_local_of(data))
+                          sizes=self._sizes_of(data), default_basis=self.sbf.default, mol_local=self._mol_local_of(data),
+                          max_num_neighbors=self.max_num_neighbors)
         if g.check is not None:                          # zero-host-sync path: the flag word waits for verify()
             self._pending_checks.append(g.check)
         g.need_grad = torch.is_grad_enabled()
@@ -436,6 +438,7 @@ class PAMNet(_PAMNetBase):
 class PAMNet_s(_PAMNetBase):
     """models.py:227-353 (QM9 only; one-hop pairs only)."""
     small = True
+    max_num_neighbors = 500             # radius(..., max_num_neighbors=500), models.py:301
 
     def __init__(self, config, num_spherical=7, num_radial=6, envelope_exponent=5):
         super().__init__(config, num_spherical, num_radial, envelope_exponent)

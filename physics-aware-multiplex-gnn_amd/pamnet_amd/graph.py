@@ -189,6 +189,8 @@ _NoTranspose = _NoTransposeT()
 class Graph(object):
     """All index / geometry tensors one forward needs (int32 / fp32 on the device)."""
 
+    capped = False        # max_num_neighbors cut a row of the radius graph: not symmetric, general transposes (build_graph)
+
     # Row lists / counts per kind are only needed by the generic (non-fused) path and by tests: built on first use so
     # the fused path (which selects weights per row from `tp_kind` inside the kernel) pays no host sync for them.
     @property
@@ -212,22 +214,25 @@ class Graph(object):
         return int(self.pair_rows.numel())
 
 
-def radius_count(pos, node_graph, gptr, r):
+def radius_count(pos, node_graph, gptr, r, max_neighbors=0, cap_flag=None):
+    """Scanned neighbour counts of the radius search.  max_neighbors > 0: torch_cluster's max_num_neighbors (first hits in
+    index order, the query itself counted); a truncated row ORs CAP_BIT into `cap_flag` (an int32 device word)."""
     n = pos.size(0)
     count = _i32(n, pos.device)
     lib.call('pamnet_radius_count_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), n, int(gptr.numel()) - 1,
-             float(r), lib.ptr(count), lib.stream_of(pos))
+             float(r), int(max_neighbors or 0), lib.ptr(count), lib.ptr(cap_flag), lib.stream_of(pos))
     return exclusive_scan(count)
 
 
-def radius_fill(pos, node_graph, gptr, r, ptr, total, zeroed=False, rows_out=None):
+def radius_fill(pos, node_graph, gptr, r, ptr, total, zeroed=False, rows_out=None, max_neighbors=0):
     """`rows_out`: a one-element list that receives the expanded row ids (the query node of every entry), written by the
     same launch."""
     nbr = _alloc_i32(total, pos.device, zeroed)
     dist = _alloc_f32(total, pos.device, zeroed)
     row_of = _alloc_i32(total, pos.device, zeroed) if rows_out is not None else None
     lib.call('pamnet_radius_fill_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), pos.size(0), int(gptr.numel()) - 1,
-             float(r), lib.ptr(ptr), lib.ptr(nbr), lib.ptr(dist), lib.ptr(row_of), int(total), lib.stream_of(pos))
+             float(r), int(max_neighbors or 0), lib.ptr(ptr), lib.ptr(nbr), lib.ptr(dist), lib.ptr(row_of), int(total),
+             lib.stream_of(pos))
     if rows_out is not None:
         rows_out.append(row_of)
     return ptr, nbr, dist
@@ -400,6 +405,9 @@ def _check_sizes(flag, checks, all_kept=None, loops=None):
              None if loops is None else lib.ptr(loops), lib.ptr(flag), lib.stream_of(flag))
 
 
+CAP_BIT = 64          # flag-word bit: max_num_neighbors truncated a row of the radius graph (csrc/graph.hip)
+
+
 def _raise_bad_inputs():
     raise IndexError('index out of range in the batch handed to PAMNet.forward: `batch` must be sorted with ids in '
                      '[0, num_graphs), atom types in [0, embeddings.size(0)), edge_index in [0, num_nodes)')
@@ -442,6 +450,10 @@ def raise_for_flag(bits):
         what = [n for k, n in ((1, 'global edges'), (2, 'local edges'), (3, 'triplet / pair rows'), (4, 'size 4')) if bits & (2 << k - 1)]
         if bits & 32:
             what.append('self loops in edge_index')
+        if bits & CAP_BIT:
+            raise GraphCheckError('max_num_neighbors binds in this batch (a node has more points within cutoff_g than the '
+                                  'radius search keeps, models.py:110,128,301): the one-call graph assumes symmetric radius '
+                                  'graphs -- hand the batch over without `sizes` (the plain path builds the capped graph)')
         raise GraphCheckError('the data-dependent sizes handed to PAMNet.forward (`data.sizes`) do not match the batch: '
                               + ', '.join(what) + ' -- results of this batch are invalid')
 
@@ -499,7 +511,7 @@ _SCHEMA = {'QM9': 0, 'PDBbind': 1, 'rna': 2}
 
 
 def _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_index, n_graphs, need_grad, knn_k,
-                  with_triplets, n_types, sizes, default_basis=True, mol_local=False):
+                  with_triplets, n_types, sizes, default_basis=True, mol_local=False, max_nb=0):
     """The zero-host-sync graph as one engine call, or None when this batch does not qualify (empty lists, layouts the
     ingest launch does not read): the step-by-step path below then builds it."""
     import ctypes
@@ -514,6 +526,7 @@ def _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_ind
     d.batch, d.batch_kind = batch.data_ptr(), _KINDS[batch.dtype]
     d.with_triplets, d.need_grad, d.knn_k = (1 if with_triplets else 0), (1 if need_grad else 0), int(knn_k)
     d.cutoff_l, d.cutoff_g = float(cutoff_l), float(cutoff_g)
+    d.max_neighbors = int(max_nb)
     d.n_types = int(n_types or 0)
     keep = [batch]
     if dataset == 'QM9':
@@ -529,7 +542,7 @@ def _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_ind
             return None
         pos = pos if (pos.dtype == torch.float32 and pos.is_contiguous()) else pos.to(torch.float32).contiguous()
         d.schema, d.n_bonds = 0, el
-        d.mol_local = 1 if (mol_local and MOL_LOCAL) else 0
+        d.mol_local = 1 if (mol_local and MOL_LOCAL and not 0 < max_nb <= MOL_ATOMS) else 0
         d.types, d.types_kind, d.types_stride = xcol.data_ptr(), _KINDS[xcol.dtype], (xcol.stride(0) if n > 1 else 1)
         d.pos, d.edge_src, d.edge_dst, d.edge_kind = pos.data_ptr(), es.data_ptr(), ed.data_ptr(), _KINDS[edge_index.dtype]
         keep += [xcol, pos, edge_index]
@@ -652,7 +665,8 @@ def _mol_local_graph(g, pos, ing, cutoff_g, with_triplets, need_grad):
 
 
 def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_index=None, num_graphs=None,
-                need_grad=True, knn_k=None, with_triplets=True, n_types=None, sizes=None, default_basis=True, mol_local=None):
+                need_grad=True, knn_k=None, with_triplets=True, n_types=None, sizes=None, default_basis=True, mol_local=None,
+                max_num_neighbors=None):
     """Graph-construction part of PAMNet.forward (models.py:104-177).  Returns a Graph.
 
     `sizes`: (global edges, local edges, triplet + pair rows) of this batch as host integers -- what a batch collated by
@@ -664,14 +678,21 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     `mol_local` (QM9 schema): True = the caller vouches that every molecule is within the molecule-local builder's limits
     (MOL_ATOMS / MOL_BONDS) with its bonds grouped by molecule (a resident store knows); None = try it when the
     average molecule is small (a batch that does not qualify is found out with the sizes' round trip and takes the
-    step-by-step launches); False = never."""
+    step-by-step launches); False = never.
+
+    `max_num_neighbors`: the cap of the reference's radius searches (models.py:110,128: 1000; :301: 500; None = no cap).  It
+    binds only in graphs with more than that many nodes within cutoff_g of one node; the count pass notes it in the flag
+    word, and such a batch is built with the capped -- no longer symmetric -- global graph and general transposes (plain
+    tensors), or flagged (a batch carrying `sizes`: the one-call graph assumes symmetric radius graphs)."""
     dev = batch.device
+    max_nb = int(max_num_neighbors or 0)
+    capped = False
     knn_k = KNN_K if knn_k is None else int(knn_k)
     if sizes is not None and knn_k != KNN_K:
         raise ValueError('host-side sizes (store.MoleculeStore) are counted for k = %d neighbours; got knn_k = %d' % (KNN_K, knn_k))
     if sizes is not None and num_graphs is not None:
         eng = _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_index, num_graphs, need_grad, knn_k,
-                            with_triplets, n_types, sizes, default_basis, mol_local=bool(mol_local))
+                            with_triplets, n_types, sizes, default_basis, mol_local=bool(mol_local), max_nb=max_nb)
         if eng is not None:
             return eng
     g = Graph()
@@ -723,12 +744,12 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
 
         ei = edge_index
         if (sizes is None and ing is not None and MOL_LOCAL and mol_local is not False and ei.size(1) > 0
+                and not 0 < max_nb <= MOL_ATOMS          # (a molecule of <= MOL_ATOMS atoms cannot reach a larger cap)
                 and (mol_local is True or n <= MOL_ATOMS * g.n_graphs // 2)):
             done = _mol_local_graph(g, pos, ing, cutoff_g, with_triplets, need_grad)
             if done:
                 return g
         lp, l_src, l_dst, tp_ptr = bonds(ei, None if ing is None else (ing[3], ing[4]))
-        gptr_g = radius_count(pos, node_graph, g.gptr, cutoff_g)               # symmetric: agg = query, other = nbr
         if ing is not None:                       # validity and self loops were noted by the ingest launch
             flag, kept = ing[5], ing[6]           # (`kept`: non-zero = NOT all kept; read through _kept below)
             g.loops = kept
@@ -736,6 +757,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             types = x_raw.to(torch.float32).reshape(-1)
             flag = _input_flag(node_graph, g.n_graphs, types, n_types, *bonds.raw)
             kept = (ei[0] != ei[1]).all()
+        gptr_g = radius_count(pos, node_graph, g.gptr, cutoff_g, max_nb, flag)  # symmetric (unless the cap binds): agg = query
         if sizes is not None:                     # zero host round trips: sizes from the host, verified on the device
             total_g, tp_total = int(sizes[0]), int(sizes[2])
             checks += [(gptr_g[-1:], total_g), (lp[-1:], int(sizes[1])), (tp_ptr[-1:], tp_total)]
@@ -749,12 +771,14 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             tp_ptr = torch.clamp(tp_ptr, max=tp_total)
         else:
             total_g, k, tp_total, bad = host_ints(gptr_g[-1], kept, tp_ptr[-1], flag)
-            if bad:
+            if bad & ~CAP_BIT:
                 _raise_bad_inputs()
+            capped = bool(bad & CAP_BIT)
             if (k != 0) if ing is not None else (not k):                        # the bond list has self loops
                 lp, l_src, l_dst, tp_ptr = bonds(ei[:, ei[0] != ei[1]])
                 tp_total = int(tp_ptr[-1])
-        gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g, zeroed=hinted, rows_out=glob_rows)
+        gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g, zeroed=hinted, rows_out=glob_rows,
+                                 max_neighbors=max_nb)
         l_dist = bonds.dist
         tp_pre = (tp_ptr, tp_total)
     elif dataset == 'PDBbind':
@@ -766,12 +790,13 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         # the positions instead of from the filled global graph; and because a radius graph is symmetric, the number of
         # triplet / pair rows follows from the degrees alone: every edge (j -> i) has deg(j) - 1 triplets (edges k -> j,
         # k != i) and deg(i) pairs (edges j' -> i, itself included; models.py:68-98).
-        gptr_g = radius_count(pos, node_graph, g.gptr, cutoff_g)
+        pflag = ing[5] if ing is not None else _input_flag(node_graph, g.n_graphs)
+        gptr_g = radius_count(pos, node_graph, g.gptr, cutoff_g, max_nb, pflag)
         local = cutoff_l <= cutoff_g
         if local and sizes is not None:           # zero host round trips (see `sizes`)
             lp = radius_count(pos, node_graph, g.gptr, cutoff_l)
             total_g, total_l, tp_hint = (int(v) for v in sizes)
-            g.check = ing[5] if ing is not None else _input_flag(node_graph, g.n_graphs)
+            g.check = pflag
             checks += [(gptr_g[-1:], total_g), (lp[-1:], total_l)]
             hinted = _ZeroArena(3 * total_g + 3 * total_l + 5 * tp_hint + 64, dev)
             gptr_g, lp = torch.clamp(gptr_g, max=total_g), torch.clamp(lp, max=total_l)
@@ -781,17 +806,25 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             lp = radius_count(pos, node_graph, g.gptr, cutoff_l)
             deg = (lp[1:] - lp[:-1]).long()
             tp_dev = (deg * deg + (deg * (deg - 1) if with_triplets else 0)).sum()
-            total_g, total_l, tp_total, bad = host_ints(gptr_g[-1], lp[-1], tp_dev,
-                                                        ing[5] if ing is not None else _input_flag(node_graph, g.n_graphs))
-            if bad:
+            total_g, total_l, tp_total, bad = host_ints(gptr_g[-1], lp[-1], tp_dev, pflag)
+            if bad & ~CAP_BIT:
                 _raise_bad_inputs()
-            gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g, rows_out=glob_rows)
-            lp, l_src, l_dist = _filter_fill(gp, gn, gd, cutoff_l, lp, total_l)
-            tp_hint = tp_total
+            capped = bool(bad & CAP_BIT)
+            gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g, rows_out=glob_rows,
+                                     max_neighbors=max_nb)
+            if capped:                            # the local graph is a cut of the CAPPED global one (models.py:131-134): its
+                lp, l_src, l_dist = csr_filter(gp, gn, gd, cutoff_l)      # degrees are not the plain radius degrees any more
+                tp_hint = None
+            else:
+                lp, l_src, l_dist = _filter_fill(gp, gn, gd, cutoff_l, lp, total_l)
+                tp_hint = tp_total
         else:                                     # (a local cutoff above the global one: the general, dependent order)
-            gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, int(gptr_g[-1]))
-            lp, l_src, l_dist = csr_filter(gp, gn, gd, cutoff_l,
-                                           ing[5] if ing is not None else _input_flag(node_graph, g.n_graphs))
+            total_g, bad = host_ints(gptr_g[-1], pflag)
+            if bad & ~CAP_BIT:
+                _raise_bad_inputs()
+            capped = bool(bad & CAP_BIT)
+            gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g, max_neighbors=max_nb)
+            lp, l_src, l_dist = csr_filter(gp, gn, gd, cutoff_l)
             tp_hint = None
         l_dst = expand_rows(lp, l_src.numel(), zeroed=hinted)
     elif rna:
@@ -856,16 +889,19 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     g.tp = CSR(tp_ptr, tp_edge, tp_idx)               # rows = target edge e, col = source edge e'
     g.tp_angle, g.tp_kind = tp_angle, tp_kind
 
+    g.capped = capped
     g.glob_T = g.loc_T = g.tp_T = _NoTranspose    # forward-only: backward index structures are not built
     if need_grad:
-        radius_g = dataset in ('QM9', 'PDBbind')       # symmetric by construction (the kNN graphs of the RNA path are not)
+        # symmetric by construction (the kNN graphs of the RNA path are not, nor is a radius graph the neighbour cap cut)
+        radius_g = dataset in ('QM9', 'PDBbind') and not capped
         # d x[j] of the global gather: the reverse-edge index of a radius graph; for the RNA kNN cut the inverse of the
         # transposition that stored it by neighbour; a counting sort otherwise
         g.glob_T = SymmetricTranspose(g.glob) if radius_g else (glob_inv if rna and glob_inv is not None
                                                                else Transpose(g.glob.col, n))
         # d x[j] of the local gather: a radius graph for PDBbind, the inverse transposition for RNA; user-supplied bonds
         # (QM9) take the counting sort
-        g.loc_T = SymmetricTranspose(g.loc) if dataset == 'PDBbind' else (loc_inv if rna else Transpose(g.loc.col, n))
+        g.loc_T = SymmetricTranspose(g.loc) if (dataset == 'PDBbind' and not capped and cutoff_l <= cutoff_g) else (
+            loc_inv if rna else Transpose(g.loc.col, n))
         # d m_neighbor[e'] of the triplet/pair gather
         g.tp_T = (TripletTranspose(g.loc, g.loc_T, tp_ptr, tcount, tot, with_triplets, zeroed=hinted) if (e_l > 0 and tot > 0)
                   else Transpose(tp_idx, max(e_l, 1)))

@@ -134,7 +134,8 @@ class GraphDesc(ctypes.Structure):
                 ('schema', ctypes.c_int32), ('batch_kind', ctypes.c_int32), ('types_kind', ctypes.c_int32),
                 ('edge_kind', ctypes.c_int32), ('with_triplets', ctypes.c_int32), ('need_grad', ctypes.c_int32),
                 ('aggregate_at_query', ctypes.c_int32), ('knn_k', ctypes.c_int32),
-                ('cutoff_l', ctypes.c_float), ('cutoff_g', ctypes.c_float), ('mol_local', ctypes.c_int32)]
+                ('cutoff_l', ctypes.c_float), ('cutoff_g', ctypes.c_float), ('max_neighbors', ctypes.c_int32),
+                ('mol_local', ctypes.c_int32)]
 
 
 class MolGraphOut(ctypes.Structure):

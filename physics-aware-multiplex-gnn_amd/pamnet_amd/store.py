@@ -30,7 +30,8 @@ def size_key(model):
     differ in any of these get their own count tables."""
     ds = model.dataset
     schema = 'rna' if ds[:3].lower() == 'rna' else ds
-    return (schema, float(model.cutoff_g), float(model.cutoff_l), not model.small, str(model.flow), KNN_K)
+    return (schema, float(model.cutoff_g), float(model.cutoff_l), not model.small, str(model.flow), KNN_K,
+            int(getattr(model, 'max_num_neighbors', 0) or 0))
 
 
 class Batch(object):
@@ -93,6 +94,7 @@ class MoleculeStore(object):
         self.eptr_d = torch.from_numpy(self.eptr.astype(np.int32)).to(dev)
         self._counts = {}                  # size_key(model) -> per-graph (E_g, E_l, T+P) arrays
         self._mol_local = {}               # size_key(model) -> every molecule fits the molecule-local graph builder
+        self._capped = {}                  # size_key(model) -> max_num_neighbors binds in this dataset (no sizes handed out)
 
     def __len__(self):
         return len(self.n_nodes)
@@ -132,12 +134,15 @@ class MoleculeStore(object):
         if chunk is None:
             chunk = 4096 if self.n_nodes.mean() < 100 else 8
         eg, el, tp = (np.zeros(m, dtype=np.int64) for _ in range(3))
+        capped = False                     # max_num_neighbors binds somewhere in this dataset (graph.build_graph)
         for a in range(0, m, chunk):
             b = min(m, a + chunk)
             bt = self.collate(np.arange(a, b), with_sizes=False)
             g = G.build_graph(model.dataset, model.cutoff_l, model.cutoff_g, model.flow, bt.x, bt.batch, bt.pos, bt.edge_index,
                               num_graphs=b - a, need_grad=False, with_triplets=not model.small,
-                              n_types=model.embeddings.size(0) if hasattr(model, 'embeddings') else None)
+                              n_types=model.embeddings.size(0) if hasattr(model, 'embeddings') else None,
+                              max_num_neighbors=getattr(model, 'max_num_neighbors', None))
+            capped = capped or bool(getattr(g, 'capped', False))
             nodes = torch.from_numpy((self.nptr[a:b + 1] - self.nptr[a]).astype(np.int64)).to(self.device)
             pg, pl = g.glob.ptr.long()[nodes], g.loc.ptr.long()[nodes]
             pt = g.tp.ptr.long()[pl]
@@ -145,6 +150,9 @@ class MoleculeStore(object):
             el[a:b] = (pl[1:] - pl[:-1]).cpu().numpy()
             tp[a:b] = (pt[1:] - pt[:-1]).cpu().numpy()
         self._counts[key] = (eg, el, tp)
+        # A dataset in which the radius search's neighbour cap binds is handed over without sizes: its capped global graphs are
+        # not symmetric, which the one-call graph assumes -- those batches take the plain path (one host round trip each).
+        self._capped[key] = capped
         # QM9 schema: every molecule inside the molecule-local graph builder's limits (csrc/graph_mol.hip)?  Collation keeps a
         # molecule's bonds together and in batch order, self loops were stripped at ingestion: the rest of its contract.
         self._mol_local[key] = bool(key[0] == 'QM9' and m > 0 and self.n_nodes.max() <= G.MOL_ATOMS
@@ -197,6 +205,6 @@ class MoleculeStore(object):
         bt.inputs_ready.record(torch.cuda.current_stream(dev))
         if with_sizes:
             bt.sizes = {key: (int(eg[idx].sum()), int(el[idx].sum()), int(tp[idx].sum()))
-                        for key, (eg, el, tp) in self._counts.items()}
+                        for key, (eg, el, tp) in self._counts.items() if not self._capped.get(key)}
             bt.mol_local = self._mol_local
         return bt

@@ -166,6 +166,42 @@ def test_radius_graph_matches_oracle(dev):
     assert float(((d.cpu() - dist[key]).abs() / dist[key]).max()) < 1.3e-7
 
 
+@pytest.mark.parametrize('cap', [1, 7, 40, 64, 65, 200])
+def test_radius_neighbour_cap_matches_oracle(dev, cap):
+    """max_num_neighbors (models.py:110,128,301): a query keeps its first `cap` hits in ascending index order, itself counted;
+    both launch forms (thread per node / wavefront per node, chunk boundaries at 64 on either side of the cap) equal the
+    oracle's capped search edge for edge, raise the cap bit exactly when a row was cut, and leave it alone otherwise."""
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import graph as G, lib
+    rng = np.random.RandomState(cap)
+    counts = [150, 31, 70, 1]
+    n = sum(counts)
+    pos = torch.from_numpy((rng.rand(n, 3) * 6).astype(np.float32))            # dense: most pairs within r = 4
+    batch = torch.from_numpy(np.repeat(np.arange(len(counts)), counts))
+    nodeg, posd = batch.to(torch.int32).to(dev), pos.to(dev)
+    gptr, _ = G.csr_from_keys(nodeg, len(counts))
+    ref = O.radius_graph(pos, batch, 4.0, cap)
+    ref = ref[:, ref[0] != ref[1]]                                             # remove_self_loops (models.py:63)
+    full = O.radius_graph(pos, batch, 4.0)
+    binds = ref.size(1) != int((full[0] != full[1]).sum())
+    for ng in (len(counts), 0):                                                # wavefront form (n / graphs > 96 false here) ...
+        for force_wave in (False, True):
+            ngv = 1 if force_wave else ng                                      # ... n_graphs = 1 declares one big graph: wave form
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            cnt = torch.empty(n, dtype=torch.int32, device=dev)
+            lib.call('pamnet_radius_count_i32', lib.ptr(posd), lib.ptr(nodeg), lib.ptr(gptr), n, ngv, 4.0, cap, lib.ptr(cnt),
+                     lib.ptr(flag), lib.stream_of(posd))
+            ptr = G.exclusive_scan(cnt)
+            tot = int(ptr[-1])
+            assert tot == ref.size(1) and bool(int(flag) & G.CAP_BIT) == binds and not int(flag) & ~G.CAP_BIT
+            nbr, d, rows = (torch.empty(tot, dtype=torch.int32, device=dev), torch.empty(tot, device=dev),
+                            torch.empty(tot, dtype=torch.int32, device=dev))
+            lib.call('pamnet_radius_fill_i32', lib.ptr(posd), lib.ptr(nodeg), lib.ptr(gptr), n, ngv, 4.0, cap, lib.ptr(ptr),
+                     lib.ptr(nbr), lib.ptr(d), lib.ptr(rows), tot, lib.stream_of(posd))
+            assert torch.equal(rows.cpu().long(), ref[0]) and torch.equal(nbr.cpu().long(), ref[1])   # same order, too
+    assert binds == (cap < 150)
+
+
 def test_radius_wave_form_equals_thread_form(dev):
     """Complex-sized graphs (here 3 graphs of 130 / 257 / 64 nodes, average > 96) take the wavefront-per-node search:
     pointer, neighbours (ascending) and distances equal the thread-per-node form (selected by declaring n_graphs
@@ -182,12 +218,12 @@ def test_radius_wave_form_equals_thread_form(dev):
     posd = pos.to(dev)
     ptr, nbr, d = G.radius_graph(posd, nodeg, gptr, 4.0)
     cnt = torch.empty(n, dtype=torch.int32, device=dev)
-    lib.call('pamnet_radius_count_i32', lib.ptr(posd), lib.ptr(nodeg), lib.ptr(gptr), n, 0, 4.0, lib.ptr(cnt), lib.stream_of(posd))
+    lib.call('pamnet_radius_count_i32', lib.ptr(posd), lib.ptr(nodeg), lib.ptr(gptr), n, 0, 4.0, 0, lib.ptr(cnt), None, lib.stream_of(posd))
     ptr2 = G.exclusive_scan(cnt)
     assert torch.equal(ptr, ptr2)
     nbr2, d2 = torch.empty_like(nbr), torch.empty_like(d)
     rows2 = torch.empty_like(nbr)
-    lib.call('pamnet_radius_fill_i32', lib.ptr(posd), lib.ptr(nodeg), lib.ptr(gptr), n, 0, 4.0, lib.ptr(ptr2), lib.ptr(nbr2),
+    lib.call('pamnet_radius_fill_i32', lib.ptr(posd), lib.ptr(nodeg), lib.ptr(gptr), n, 0, 4.0, 0, lib.ptr(ptr2), lib.ptr(nbr2),
              lib.ptr(d2), lib.ptr(rows2), nbr.numel(), lib.stream_of(posd))
     assert torch.equal(nbr, nbr2) and torch.equal(d, d2)
     rows = []

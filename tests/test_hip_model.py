@@ -834,6 +834,78 @@ def test_trainer_checkpoint_round_trip_and_close(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('case', ['qm9_d128', 'qm9_d32', 'qm9s_d128', 'pdbbind_d128', 'pdbbind_d16'])
+def test_max_num_neighbors_binding_vs_oracle(dev, case):
+    """radius(..., max_num_neighbors) where it BINDS (models.py:110,128: 1000; :301: 500 -- lowered here through the model's
+    `max_num_neighbors` attribute so that molecule-sized graphs reach it): the capped global graph is no longer symmetric, the
+    model takes the general transposes; outputs and every parameter gradient against the oracle's fp64 run of the same capped
+    search, and the uncapped model differs (the cap did something).  A resident store notices the cap when it counts the
+    data set and hands such batches over without sizes; a batch that carries sizes anyway is flagged, not mis-built."""
+    import models
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import graph as G, synth
+    from pamnet_amd.store import MoleculeStore
+    small = case.startswith('qm9s')
+    dim = int(case.rsplit('_d', 1)[1])
+    if case.startswith('pdbbind'):
+        cfg = models.Config(dataset='PDBbind', dim=dim, n_layer=2, cutoff_l=2.0, cutoff_g=6.0)
+        graphs = [synth.pdbbind_complex(4, i, n_pocket=60, n_ligand=12) for i in range(3)]
+        cap, fwd = 24, O.pamnet_forward
+    else:
+        cfg = models.Config(dataset='QM9', dim=dim, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+        graphs = [synth.qm9_molecule(6, i) for i in range(7)]
+        cap, fwd = 12, (O.pamnet_s_forward if small else O.pamnet_forward)
+    b = synth.collate(graphs)
+    sd = O.init_state_dict(cfg, seed=11, small=small)
+    model = (models.PAMNet_s if small else models.PAMNet)(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    data = b.to(dev)
+    with torch.no_grad():
+        free = model(data).cpu()
+    assert not model._graph_cache.capped
+    model.max_num_neighbors = cap
+    out = model(data)
+    assert model._graph_cache.capped
+    torch.nn.functional.l1_loss(out, data.y).backward()
+    p64 = O.as_params({k: v.double() for k, v in sd.items()})
+    pos, ei = getattr(b, 'pos', None), getattr(b, 'edge_index', None)
+    x64 = b.x.double() if cfg.dataset == 'PDBbind' else b.x
+    ref = fwd(p64, cfg, x64, b.batch, pos, ei, dtype=torch.float64, max_num_neighbors=cap)
+    torch.nn.functional.l1_loss(ref, b.y.double()).backward()
+    scale = None
+    if cfg.dataset == 'PDBbind':
+        inter = {}
+        fwd({k: v.double() for k, v in sd.items()}, cfg, x64, b.batch, pos, ei, dtype=torch.float64, intermediates=inter,
+            max_num_neighbors=cap)
+        scale = max(float(inter['pool_in'].abs()[b.batch == k].sum()) for k in range(len(graphs)))
+    e = float((out.detach().cpu().double() - ref.detach()).abs().max()) / (scale or float(ref.detach().abs().max()))
+    assert e < TOL, e
+    assert float((free.double() - ref.detach()).abs().max()) / (scale or float(ref.detach().abs().max())) > 100 * TOL
+    fwd_cap = lambda *a, **k: fwd(*a, max_num_neighbors=cap, **k)
+    _check_gradients(model, p64, fwd_cap, sd, cfg, b)
+    # the store: counts taken with the cap in force; the data set is marked and its batches carry no sizes for this model
+    st = MoleculeStore(graphs, dev).prepare_for(model)
+    bt = st.collate(list(range(len(graphs))))
+    assert not bt.sizes
+    with torch.no_grad():
+        assert torch.equal(model(bt), out.detach())
+    model.verify()
+    # sizes forced onto such a batch (counted without the cap): flagged by the count pass, never silently mis-built
+    model.max_num_neighbors = 0
+    st2 = MoleculeStore(graphs, dev).prepare_for(model)
+    bt = st2.collate(list(range(len(graphs))))
+    model.max_num_neighbors = cap
+    from pamnet_amd.store import size_key
+    bt.sizes = {size_key(model): next(iter(bt.sizes.values()))}
+    bt.mol_local = False
+    with torch.no_grad():
+        model(bt)
+    with pytest.raises(G.GraphCheckError, match='max_num_neighbors'):
+        model.verify()
+
+
+@pytest.mark.gpu
 def test_out_of_range_inputs_raise_index_error(dev):
     """Atom types beyond the embedding table or bond endpoints beyond the node count raise
     IndexError (as indexing does in the reference, models.py:107) instead of writing out of bounds on the device."""
