@@ -723,6 +723,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     hinted = False
     checks = []                                   # (device total, value the host assumed), verified by one launch at the end
     glob_rows = []                                # row ids of the global edges when the launch that fills them writes them
+    glob_inv = loc_inv = None                     # InverseTranspose of a list that was stored by query and then transposed
 
     if dataset == 'QM9':
         pos = pos.to(torch.float32).contiguous()
@@ -779,6 +780,11 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
                 tp_total = int(tp_ptr[-1])
         gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g, zeroed=hinted, rows_out=glob_rows,
                                  max_neighbors=max_nb)
+        if capped and flow != 'target_to_source':
+            # edge_index_g = (query, neighbour) and the layer aggregates at edge_index[1] = the NEIGHBOUR
+            # (global_message_passing.py:38 with flow = source_to_target): a symmetric list can be read either way, a
+            # capped one has to be stored by neighbour
+            gp, gn, gd, glob_inv = _transpose_edges(gp, gn, gd, n, want_inverse=need_grad, q=glob_rows.pop())
         l_dist = bonds.dist
         tp_pre = (tp_ptr, tp_total)
     elif dataset == 'PDBbind':
@@ -815,6 +821,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             if capped:                            # the local graph is a cut of the CAPPED global one (models.py:131-134): its
                 lp, l_src, l_dist = csr_filter(gp, gn, gd, cutoff_l)      # degrees are not the plain radius degrees any more
                 tp_hint = None
+                cap_rows = glob_rows.pop()
             else:
                 lp, l_src, l_dist = _filter_fill(gp, gn, gd, cutoff_l, lp, total_l)
                 tp_hint = tp_total
@@ -826,6 +833,13 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             gp, gn, gd = radius_fill(pos, node_graph, g.gptr, cutoff_g, gptr_g, total_g, max_neighbors=max_nb)
             lp, l_src, l_dist = csr_filter(gp, gn, gd, cutoff_l)
             tp_hint = None
+            cap_rows = None
+        if capped:
+            # (query, neighbour) lists, as the RNA branch below: the local layer aggregates at the neighbour
+            # (local_message_passing.py:39,54), the global one too unless flow = target_to_source
+            lp, l_src, l_dist, loc_inv = _transpose_edges(lp, l_src, l_dist, n, want_inverse=need_grad)
+            if flow != 'target_to_source':
+                gp, gn, gd, glob_inv = _transpose_edges(gp, gn, gd, n, want_inverse=need_grad, q=cap_rows)
         l_dst = expand_rows(lp, l_src.numel(), zeroed=hinted)
     elif rna:
         xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
@@ -848,7 +862,6 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         else:
             kp, kn, kd = knn_table(pos, node_graph, g.gptr, knn_k, float('inf'))
             (gp, gn, gd), (qp, qn, qd) = csr_filter2(kp, kn, kd, cutoff_g, cutoff_l, flag)
-        glob_inv = None
         if flow != 'target_to_source':                                          # aggregate at edge_index[1] = neighbour
             gp, gn, gd, glob_inv = _transpose_edges(gp, gn, gd, n, zeroed=hinted, want_inverse=need_grad, q=gq)
             gq = None
@@ -896,12 +909,12 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         radius_g = dataset in ('QM9', 'PDBbind') and not capped
         # d x[j] of the global gather: the reverse-edge index of a radius graph; for the RNA kNN cut the inverse of the
         # transposition that stored it by neighbour; a counting sort otherwise
-        g.glob_T = SymmetricTranspose(g.glob) if radius_g else (glob_inv if rna and glob_inv is not None
+        g.glob_T = SymmetricTranspose(g.glob) if radius_g else (glob_inv if glob_inv is not None
                                                                else Transpose(g.glob.col, n))
         # d x[j] of the local gather: a radius graph for PDBbind, the inverse transposition for RNA; user-supplied bonds
         # (QM9) take the counting sort
-        g.loc_T = SymmetricTranspose(g.loc) if (dataset == 'PDBbind' and not capped and cutoff_l <= cutoff_g) else (
-            loc_inv if rna else Transpose(g.loc.col, n))
+        g.loc_T = SymmetricTranspose(g.loc) if (dataset == 'PDBbind' and not capped) else (
+            loc_inv if loc_inv is not None else Transpose(g.loc.col, n))
         # d m_neighbor[e'] of the triplet/pair gather
         g.tp_T = (TripletTranspose(g.loc, g.loc_T, tp_ptr, tcount, tot, with_triplets, zeroed=hinted) if (e_l > 0 and tot > 0)
                   else Transpose(tp_idx, max(e_l, 1)))
