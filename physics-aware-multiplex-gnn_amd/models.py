@@ -151,22 +151,99 @@ class _LazyLayers(object):
         return self._views()[i]
 
 
+ENGINE_WIDTHS = (16, 32, 64, 128)       # widths with hand-written kernel families (narrow engine: 16 / 32 / 64; fused: 128)
+
+
+def engine_width(dim):
+    """The kernel width a model of hidden size `dim` runs at: the smallest engine width >= dim, or None above 128."""
+    for w in ENGINE_WIDTHS:
+        if dim <= w:
+            return w
+    return None
+
+
 class _PAMNetBase(nn.Module):
+    """Any `config.dim` (models.py:25: the reference takes whatever it is given).  Widths 16 / 32 / 64 / 128 have kernel
+    families of their own; every other dim <= 128 runs on the next one up with ZERO-PADDED parameters: the model is built at
+    the engine width `self.dim`, the padded rows / columns of every weight, bias and embedding are zero, and they stay
+    exactly zero under training -- a padded output channel is SiLU(0) = 0 and 0 * gate = 0 in every message, so its
+    activations, its gradients (dz = dy * SiLU'(0) with dy = W_next[:, pad]^T dz = 0; dW[:, pad] = dz x_pad = 0) and hence
+    its Adam / EMA updates are zeros: arithmetic on the logical `config_dim` channels is untouched.  `state_dict()` /
+    `load_state_dict()` speak the reference's shapes (hooks below slice / pad); `parameters()` are the padded tensors.
+    Above 128 (multiples of 4) the dense layers run as library GEMMs between the HIP graph / basis / segment kernels."""
     small = False
     max_num_neighbors = 1000            # radius(..., max_num_neighbors=1000), models.py:110,128
 
-    def __init__(self, config, num_spherical=7, num_radial=6, envelope_exponent=5):
+    def __init__(self, config, num_spherical=7, num_radial=6, envelope_exponent=5, _pad=True):
         super().__init__()
         self.dataset = config.dataset
-        self.dim = config.dim
+        self.config_dim = int(config.dim)
+        w = engine_width(self.config_dim) if _pad else None
+        self.dim = w if w is not None else self.config_dim           # the width the kernels run at
         self.n_layer = config.n_layer
         self.cutoff_l = config.cutoff_l
         self.cutoff_g = config.cutoff_g
         self.flow = getattr(config, 'flow', 'source_to_target')
-        if self.dim % 4 != 0:
-            raise ValueError('dim must be a multiple of 4 (16-byte vector lanes of the gfx950 kernels)')
+        if _pad and self.dim % 4 != 0:
+            raise ValueError('dim above 128 must be a multiple of 4 (16-byte vector lanes of the gfx950 kernels)')
         self._rna = self.dataset[:3].lower() == 'rna'
         self.__dict__['_pending_checks'] = []            # device flag words of forwards that ran without a host round trip
+        self.__dict__['_ctor'] = (config, num_spherical, num_radial, envelope_exponent)
+
+    def _finish_padding(self):
+        """Called at the end of the subclass constructors.  A model whose engine width differs from its configured dim gets
+        (a) the reference's shapes for the state_dict interface, taken from an unpadded twin, (b) that twin's initial
+        values (the same initialisation law on the LOGICAL fan-in / fan-out) in the top-left blocks, zeros elsewhere."""
+        if self.dim == self.config_dim:
+            return
+        twin = type(self)(*self._ctor, _pad=False)
+        tsd = twin.state_dict()
+        self.__dict__['_logical_shapes'] = {k: tuple(v.shape) for k, v in tsd.items()}
+        self._register_load_state_dict_pre_hook(self._pad_incoming)
+        self._register_state_dict_hook(_slice_outgoing)
+        self.load_state_dict(tsd, strict=True)
+
+    def _pad_index(self, logical, padded):
+        """Per dimension: where the logical entries sit in the padded tensor.  A dimension is either untouched (16 Bessel /
+        42 spherical / 18 feature inputs, 1-wide heads), one channel block (dim -> engine width), or the three channel
+        blocks [x_i | x_j | e] of the message MLPs' inputs (3 dim -> 3 width: block k starts at k * width, models.py
+        global_message_passing.py:55, local_message_passing.py:46)."""
+        d, w = self.config_dim, self.dim
+        out = []
+        for n, m in zip(logical, padded):
+            if n == m:
+                out.append(None)
+            else:
+                nb = n // d
+                assert nb * d == n and nb * w == m, (logical, padded)
+                out.append(torch.cat([torch.arange(k * w, k * w + d) for k in range(nb)]))
+        return out
+
+    def logical_mask(self, name, like=None):
+        """Bool tensor of parameter `name`'s padded shape: True where a logical (reference-shaped) entry lives."""
+        p = dict(self.named_parameters())[name] if like is None else like
+        shape = self.__dict__.get('_logical_shapes', {}).get(name, tuple(p.shape))
+        mask = torch.zeros(p.shape, dtype=torch.bool, device=p.device)
+        idx = self._pad_index(shape, tuple(p.shape))
+        grid = [torch.arange(n, device=p.device) if i is None else i.to(p.device) for n, i in zip(shape, idx)]
+        if grid:
+            mask[tuple(torch.meshgrid(*grid, indexing='ij'))] = True
+        else:
+            mask[...] = True
+        return mask
+
+    def _pad_incoming(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        own = dict(self.named_parameters())
+        own.update(dict(self.named_buffers()))
+        for k, shape in self._logical_shapes.items():
+            t = state_dict.get(prefix + k)
+            if t is None or k not in own or tuple(t.shape) != shape or tuple(own[k].shape) == shape:
+                continue                                  # (absent, or already at the padded shape)
+            full = torch.zeros(own[k].shape, dtype=t.dtype, device=t.device)
+            idx = [None if i is None else i.to(t.device) for i in self._pad_index(shape, tuple(own[k].shape))]
+            grid = [torch.arange(n, device=t.device) if i is None else i for n, i in zip(shape, idx)]
+            full[tuple(torch.meshgrid(*grid, indexing='ij'))] = t
+            state_dict[prefix + k] = full
 
     def _build_common(self, num_spherical, num_radial, envelope_exponent):
         d = self.dim
@@ -391,11 +468,30 @@ class _PAMNetBase(nn.Module):
                              "be sure to use 'rna' as the first 3 characters of the dataset name.")
 
 
+def _slice_outgoing(module, state_dict, prefix, local_metadata):
+    """state_dict hook of a padded model: every tensor in the reference's shape -- a view of the padded parameter, or (the
+    message MLPs' [dim, 3 dim] weights, whose three input blocks are not adjacent in the padded tensor) a gathered copy."""
+    for k, shape in module._logical_shapes.items():
+        t = state_dict.get(prefix + k)
+        if t is None or tuple(t.shape) == shape:
+            continue
+        for axis, idx in enumerate(module._pad_index(shape, tuple(t.shape))):
+            if idx is None:
+                continue
+            n = shape[axis]
+            if int(idx[-1]) == n - 1:                     # one block at the origin: a plain slice keeps the view
+                t = t.narrow(axis, 0, n)
+            else:
+                t = t.index_select(axis, idx.to(t.device))
+        state_dict[prefix + k] = t
+    return state_dict
+
+
 class PAMNet(_PAMNetBase):
     """models.py:21-224."""
 
-    def __init__(self, config, num_spherical=7, num_radial=6, envelope_exponent=5):
-        super().__init__(config, num_spherical, num_radial, envelope_exponent)
+    def __init__(self, config, num_spherical=7, num_radial=6, envelope_exponent=5, _pad=True):
+        super().__init__(config, num_spherical, num_radial, envelope_exponent, _pad)
         d = self.dim
         if self._rna:
             self.embeddings = nn.Parameter(torch.ones((3, d)))       # C, N, O
@@ -409,6 +505,7 @@ class PAMNet(_PAMNetBase):
         self.local_layer = nn.ModuleList([LocalMP(d) for _ in range(self.n_layer)])
         self.softmax = nn.Softmax(dim=-1)
         self.init()
+        self._finish_padding()
 
     def forward(self, data):
         self._check_dataset()
@@ -440,8 +537,8 @@ class PAMNet_s(_PAMNetBase):
     small = True
     max_num_neighbors = 500             # radius(..., max_num_neighbors=500), models.py:301
 
-    def __init__(self, config, num_spherical=7, num_radial=6, envelope_exponent=5):
-        super().__init__(config, num_spherical, num_radial, envelope_exponent)
+    def __init__(self, config, num_spherical=7, num_radial=6, envelope_exponent=5, _pad=True):
+        super().__init__(config, num_spherical, num_radial, envelope_exponent, _pad)
         d = self.dim
         self.embeddings = nn.Parameter(torch.ones((5, d)))
         self._build_common(num_spherical, num_radial, envelope_exponent)
@@ -450,6 +547,7 @@ class PAMNet_s(_PAMNetBase):
         self.local_layer = nn.ModuleList([LocalMP(d, small=True) for _ in range(self.n_layer)])
         self.softmax = nn.Softmax(dim=-1)
         self.init()
+        self._finish_padding()
 
     def forward(self, data):
         if self.dataset != "QM9":

@@ -19,8 +19,9 @@ import os
 
 from . import fused, narrow, ops
 
-# 'fused': fp32-MFMA chain kernels for dim = 128, row kernels for dim = 16 / 32 / 64.  Any other width runs the generic
-# formulation below (dense layers on torch ops between the HIP graph / basis / segment kernels; GPU only, not a CPU
+# 'fused': fp32-MFMA chain kernels for dim = 128, row kernels for dim = 16 / 32 / 64; every other dim <= 128 is built
+# zero-padded at the next of these widths (models._PAMNetBase), so it runs the same engines.  Only widths above 128 reach the
+# generic formulation below (dense layers on torch ops between the HIP graph / basis / segment kernels; GPU only, not a CPU
 # fallback).  Not configurable at run time: the kernel tests (tests/test_hip_fused.py) flip this module attribute to force
 # the generic formulation at dim = 128 as their plain-PyTorch fp32 comparand.
 IMPL = 'fused'

@@ -112,6 +112,39 @@ def test_state_dict_layout_matches_reference(golden):
     assert sum(p.numel() for p in big.parameters() if p.requires_grad) == 3581100
 
 
+@pytest.mark.parametrize('dataset,dim,small', [('QM9', 96, False), ('QM9', 20, True), ('PDBbind', 48, False), ('rna_x', 10, False),
+                                                ('QM9', 100, False), ('QM9', 4, False)])
+def test_any_dim_keeps_the_reference_state_dict_layout(dataset, dim, small):
+    """The reference accepts any `dim` (models.py:25).  Widths without a kernel family of their own run zero-padded at the next
+    engine width (models._PAMNetBase): `state_dict()` / `load_state_dict()` still speak the reference's keys and shapes,
+    a round trip is exact, and everything outside the logical blocks is zero."""
+    import models
+    from oracle import pamnet_oracle as O
+    cfg = models.Config(dataset=dataset, dim=dim, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+    m = (models.PAMNet_s if small else models.PAMNet)(cfg)
+    assert m.config_dim == dim and m.dim == models.engine_width(dim) and m.dim in models.ENGINE_WIDTHS
+    ref = O.init_state_dict(cfg, seed=1, small=small)
+    sd = m.state_dict()
+    assert set(sd) == set(ref) and all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in ref)
+    # the initial values follow the initialisation law on the LOGICAL shapes (an unpadded twin): a Linear(dim, dim)'s
+    # default bound is 1 / sqrt(dim), not 1 / sqrt(engine width)
+    w = sd['global_layer.0.mlp_x1.0.0.weight']
+    assert float(w.abs().max()) <= 1.0 / dim ** 0.5 + 1e-6 and float(w.abs().max()) > 0.8 / dim ** 0.5
+    m.load_state_dict(ref, strict=True)
+    back = m.state_dict()
+    assert all(torch.equal(back[k], ref[k]) for k in ref)
+    for k, p in m.named_parameters():
+        assert float(p.detach()[~m.logical_mask(k)].abs().sum()) == 0.0, k
+        assert torch.equal(p.detach()[m.logical_mask(k)].reshape(ref[k].shape), ref[k])
+    with pytest.raises(RuntimeError):                       # a tensor of some other shape is still refused
+        bad = dict(ref)
+        bad['embeddings'] = torch.zeros(ref['embeddings'].size(0), dim + 1)
+        m.load_state_dict(bad, strict=True)
+    assert models.engine_width(128) == 128 and models.engine_width(129) is None
+    with pytest.raises(ValueError):
+        models.PAMNet(models.Config(dataset='QM9', dim=130, n_layer=1, cutoff_l=5.0, cutoff_g=5.0))
+
+
 def test_invalid_dataset_raises():
     import models
     cfg = models.Config(dataset='nope', dim=16, n_layer=1, cutoff_l=2.0, cutoff_g=5.0)
@@ -909,6 +942,83 @@ def test_max_num_neighbors_binding_vs_oracle(dev, case):
         model(bt)
     with pytest.raises(G.GraphCheckError, match='max_num_neighbors'):
         model.verify()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dataset,dim,small', [('QM9', 96, False), ('QM9', 100, True), ('PDBbind', 96, False), ('QM9', 48, False),
+                                                ('QM9', 20, True), ('rna_x', 12, False), ('PDBbind', 40, False)])
+def test_any_dim_runs_on_the_engines_vs_oracle(dev, dataset, dim, small):
+    """dim = 96 / 100 (-> the fused 128-wide engine), 48 / 40 (-> 64), 20 (-> 32), 12 (-> 16): the oracle's weights at the
+    LOGICAL width load through the padding hooks; outputs and every parameter gradient (compared on the logical blocks;
+    the padded rest must be exactly zero) against the oracle's fp64 run; the engines ran (one recorded node under the
+    trainer); five optimiser steps leave the padding exactly zero and the logical weights equal to a run of the same model
+    on torch.optim.Adam (i.e. padding does not leak into the update)."""
+    import models
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import synth, train
+    rna = dataset.startswith('rna')
+    if dataset == 'PDBbind':
+        cfg = models.Config(dataset='PDBbind', dim=dim, n_layer=2, cutoff_l=2.0, cutoff_g=6.0)
+        b = synth.pdbbind_batch(3, 0, 2, n_pocket=60, n_ligand=12)
+    elif rna:
+        cfg = models.Config(dataset=dataset, dim=dim, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
+        b = synth.rna_batch(5, 0, 2, n_nodes=150)
+    else:
+        cfg = models.Config(dataset='QM9', dim=dim, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+        b = synth.qm9_batch(8, 0, 6)
+    fwd = O.pamnet_s_forward if small else O.pamnet_forward
+    sd = O.init_state_dict(cfg, seed=5, small=small)
+    model = (models.PAMNet_s if small else models.PAMNet)(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    assert model.dim in models.ENGINE_WIDTHS and model.dim != dim
+    data = b.to(dev)
+    out = model(data)
+    torch.nn.functional.l1_loss(out, data.y).backward()
+    p64 = O.as_params({k: v.double() for k, v in sd.items()})
+    pos, ei = getattr(b, 'pos', None), getattr(b, 'edge_index', None)
+    x64 = b.x if dataset == 'QM9' else b.x.double()
+    inter = {}
+    ref = fwd(p64, cfg, x64, b.batch, pos, ei, dtype=torch.float64, intermediates=inter)
+    torch.nn.functional.l1_loss(ref, b.y.double()).backward()
+    scale = float(ref.detach().abs().max())
+    if dataset == 'PDBbind':
+        scale = max(float(inter['pool_in'].detach().abs()[b.batch == k].sum()) for k in range(2))
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) / scale < TOL
+
+    class _Logical(object):                      # the model seen through its logical blocks, for _check_gradients
+        def named_parameters(self_):
+            for k, p in model.named_parameters():
+                mask, shape = model.logical_mask(k), model._logical_shapes[k]
+                q = p.detach()[mask].reshape(shape)
+                q.grad = None if p.grad is None else p.grad[mask].reshape(shape)
+                if p.grad is not None and not bool(mask.all()):
+                    assert float(p.grad[~mask].abs().max()) == 0.0, ('padding gradient', k)
+                yield k, q
+
+        def parameters(self_):
+            return [q for _, q in self_.named_parameters()]
+    _check_gradients(_Logical(), p64, fwd, sd, cfg, b,
+                     head_bias_terms=(b.x.size(0) / (2 * 2.0 * cfg.n_layer)) if dataset == 'PDBbind' else None)
+    # training: Trainer (flat buffers, fused Adam + EMA over the PADDED parameters) against torch Adam on a twin
+    twin = (models.PAMNet_s if small else models.PAMNet)(cfg)
+    twin.load_state_dict(sd, strict=True)
+    twin = twin.to(dev)
+    opt = torch.optim.Adam(twin.parameters(), lr=1e-3)
+    tr = train.Trainer(model, lr=1e-3)
+    assert model._one_node()
+    for _ in range(5):
+        tr.step(data)
+        opt.zero_grad()
+        torch.nn.functional.l1_loss(twin(data), data.y).backward()
+        torch.nn.utils.clip_grad_norm_(twin.parameters(), 1000.0)
+        opt.step()
+    tr.drain()
+    a, c = model.state_dict(), twin.state_dict()
+    for k in a:
+        assert maxnorm_err(a[k].cpu().numpy(), c[k].cpu().numpy()) < 2e-4, k      # (Adam amplifies rounding: g / |g|)
+    for k, p in model.named_parameters():
+        assert float(p.detach()[~model.logical_mask(k)].abs().sum()) == 0.0 and float(tr.shadow.abs().sum()) > 0, k
 
 
 @pytest.mark.gpu
