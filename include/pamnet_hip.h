@@ -543,6 +543,15 @@ int pamnet_mlp2_fwd_multi_f32(const float* x, int64_t rows, int64_t nsets, const
 int pamnet_mlp2_bwd_f32(const float* dy, int64_t rows, const float* z1, const float* z2, const float* W1,
                         const float* W2, float* dz1, float* dz2, float* dx, int32_t accumulate,
                         pamnet_stream_t stream);
+/* pamnet_mlp2_bwd_f32 + pamnet_local_edge_bwd_f32 -- both depend on pamnet_local_agg_bwd_f32 only, not on each other -- as ONE
+ * launch, the CUs split between the two plans by their work (layers/local_message_passing.py:46-53 backward).  Arguments
+ * and results are those of the two calls. */
+int pamnet_local_bwd_pair_f32(const float* dy, int64_t rows, const float* z1, const float* z2, const float* W1,
+                              const float* W2, float* dz1, float* dz2, float* dx, int32_t accumulate_dx,
+                              const float* d_mji, const float* d_mnb, const float* d_q3, int64_t n_edges,
+                              const float* z_ji, const float* z_kj, const float* q2, const float* const* Wq,
+                              const int64_t* ldq, float* dz_ji, float* dz_kj, float* dq2, float* d_rbf,
+                              int32_t accumulate_rbf, pamnet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Input-embedding layers (128 outputs, K = 16 / 18 / 42 inputs):

@@ -271,17 +271,30 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void local_edge_fwd_kerne
 // d_rbf (+)= dz_ji W_ji,e + dz_kj W_kj,e + dq2 W_lin_rbf + dq3 W_lin_rbf_out
 // MTX = tiles per chunk (LDS and register footprint follow it): the local graph is small, 3 is plenty and keeps the four
 // weight slices + accumulators free of scratch spills (the 8-tile instantiation needed 172 B/lane)
+struct LocalBwdArgs {
+    const float *d_mji, *d_mnb, *d_q3;
+    int64_t m;
+    const float *z_ji, *z_kj, *q2;
+    LocalW w;
+    float *dz_ji, *dz_kj, *dq2, *d_rbf;
+    int accumulate, base, rem, cmt;
+};
+
+// workgroup `bid` of the plan (base, rem, cmt); lds: 2 * MTX * 16 * LDT floats
 template <int MTX>
-__global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(const float* __restrict__ d_mji,
-                                                             const float* __restrict__ d_mnb,
-                                                             const float* __restrict__ d_q3, int64_t m,
-                                                             const float* __restrict__ z_ji,
-                                                             const float* __restrict__ z_kj,
-                                                             const float* __restrict__ q2, LocalW w,
-                                                             float* __restrict__ dz_ji, float* __restrict__ dz_kj,
-                                                             float* __restrict__ dq2, float* __restrict__ d_rbf,
-                                                             int accumulate, int base, int rem, int cmt) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
+__device__ __forceinline__ void local_edge_bwd_body(const LocalBwdArgs& a, const int bid, float* lds) {
+    const float* __restrict__ d_mji = a.d_mji;
+    const float* __restrict__ d_mnb = a.d_mnb;
+    const float* __restrict__ d_q3 = a.d_q3;
+    const float* __restrict__ z_ji = a.z_ji;
+    const float* __restrict__ z_kj = a.z_kj;
+    const float* __restrict__ q2 = a.q2;
+    float* __restrict__ dz_ji = a.dz_ji;
+    float* __restrict__ dz_kj = a.dz_kj;
+    float* __restrict__ dq2 = a.dq2;
+    float* __restrict__ d_rbf = a.d_rbf;
+    const int accumulate = a.accumulate;
+    const LocalW& w = a.w;
     float* S0 = lds;
     float* S1 = lds + MTX * 16 * LDT;
     const int wc = wave_col<8>();
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(const float* __rest
     load_wfrag1<true>(f1, w.W[1], w.ld[1], wc);
     load_wfrag1<true>(f2, w.W[2], w.ld[2], wc);
     load_wfrag1<true>(f3, w.W[3], w.ld[3], wc);
-    const Span sp = Span::make<8>(m, base, rem, 0, cmt);
+    const Span sp = Span::make_at<8>(a.m, a.base, a.rem, 0, a.cmt, bid);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
         Acc<MTX> acc;
@@ -341,6 +354,12 @@ __global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(const float* __rest
     }
 }
 
+template <int MTX>
+__global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(LocalBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
+    local_edge_bwd_body<MTX>(a, (int)blockIdx.x, lds);
+}
+
 // -------------------------------------------------------------------------------------------------- 2-layer MLP
 // blockIdx.y selects one of up to 8 independent (weights, outputs) sets applied to the same input rows: the triplet/pair
 // MLPs of all layers depend only on the basis embedding, so the engine runs them in one launch up front.
@@ -356,13 +375,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlp2_fwd_kernel(cons
     PROBE_WG(1);
 }
 
+struct Mlp2BwdArgs {
+    const float* dy;
+    int64_t m;
+    const float *z1, *z2, *W1, *W2;
+    float *dz1, *dz2, *dx;
+    int accumulate, pa, pb, pc, cmt;
+};
+
 template <int MTX, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlp2_bwd_kernel(const float* __restrict__ dy, int64_t m,
-                                                       const float* __restrict__ z1, const float* __restrict__ z2,
-                                                       const float* __restrict__ W1, const float* __restrict__ W2,
-                                                       float* __restrict__ dz1, float* __restrict__ dz2,
-                                                       float* __restrict__ dx, int accumulate, int pa, int pb, int pc, int cmt) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
+__device__ __forceinline__ void mlp2_bwd_body(const Mlp2BwdArgs& a, const int bid, float* lds) {
+    const float* __restrict__ dy = a.dy;
+    const float* __restrict__ z1 = a.z1;
+    const float* __restrict__ z2 = a.z2;
+    const float* __restrict__ W1 = a.W1;
+    const float* __restrict__ W2 = a.W2;
+    float* __restrict__ dz1 = a.dz1;
+    float* __restrict__ dz2 = a.dz2;
+    float* __restrict__ dx = a.dx;
+    const int accumulate = a.accumulate;
     float* S0 = lds;
     float* S1 = lds + MTX * 16 * LDT;
     constexpr int NS = 8 / NW;
@@ -378,7 +409,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlp2_bwd_kernel(cons
         load_wset<true>(f2, W2, DIM, wc);
         load_wset<true>(f1, W1, DIM, wc);
     }
-    const Span sp = Span::make<NW>(m, pa, pb, pc, cmt);
+    const Span sp = Span::make_at<NW>(a.m, a.pa, a.pb, a.pc, a.cmt, bid);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
         // z1 and the accumulate operand are requested together with dy / z2: no global load waits mid-chunk
@@ -440,6 +471,30 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlp2_bwd_kernel(cons
         }
         __syncthreads();
     }
+}
+
+template <int MTX, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlp2_bwd_kernel(const float* __restrict__ dy, int64_t m,
+                                                       const float* __restrict__ z1, const float* __restrict__ z2,
+                                                       const float* __restrict__ W1, const float* __restrict__ W2,
+                                                       float* __restrict__ dz1, float* __restrict__ dz2,
+                                                       float* __restrict__ dx, int accumulate, int pa, int pb, int pc, int cmt) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
+    mlp2_bwd_body<MTX, NW>(Mlp2BwdArgs{dy, m, z1, z2, W1, W2, dz1, dz2, dx, accumulate, pa, pb, pc, cmt}, (int)blockIdx.x, lds);
+}
+
+// The two kernels of a local layer's backward that depend on local_agg_bwd only and not on each other -- the triplet / pair
+// MLP (mlp2_bwd) and the local edge stage (local_edge_bwd) -- as ONE launch: workgroups [0, g_mlp) walk the MLP's plan, the
+// rest the edge plan, the CUs split between them by their work.  Each alone is one round of <= 256 workgroups whose fixed
+// cost (launch boundary + prologue: weights, work split, first rows) is ~9 us of its 20-24 us at the QM9 batch; side by
+// side that cost is paid once.  Same bodies, same per-row arithmetic: results are bitwise those of the two launches.
+template <int MTM>
+__global__ __launch_bounds__(WG8) void local_bwd_pair_kernel(Mlp2BwdArgs ma, LocalBwdArgs la, int g_mlp) {
+    constexpr int MTL = 3;
+    static_assert(MTM >= MTL, "LDS is sized by the MLP's chunk");
+    __shared__ __attribute__((aligned(16))) float lds[2 * MTM * 16 * LDT];
+    if ((int)blockIdx.x < g_mlp) mlp2_bwd_body<MTM, 8>(ma, (int)blockIdx.x, lds);
+    else local_edge_bwd_body<MTL>(la, (int)blockIdx.x - g_mlp, lds);
 }
 
 // One balanced wave of workgroups: `per` 16-row tiles each (<= N_CU workgroups), walked in chunks of `cmt` <= cap tiles.
@@ -607,8 +662,48 @@ extern "C" int pamnet_local_edge_bwd_f32(const float* d_mji, const float* d_mnb,
     if (rc) return rc;
     constexpr int MTL = 3;
     const Plan p = plan8(n_edges, MTL);                     // four weight matrices: stays one 8-wave workgroup per CU
-    hipLaunchKernelGGL(local_edge_bwd_kernel<MTL>, dim3(p.grid), dim3(WG8), 0, as_stream(stream), d_mji, d_mnb, d_q3, n_edges,
-                       z_ji, z_kj, q2, w, dz_ji, dz_kj, dq2, d_rbf, (int)accumulate, p.pa, p.pb, p.cmt);
+    hipLaunchKernelGGL(local_edge_bwd_kernel<MTL>, dim3(p.grid), dim3(WG8), 0, as_stream(stream),
+                       LocalBwdArgs{d_mji, d_mnb, d_q3, n_edges, z_ji, z_kj, q2, w, dz_ji, dz_kj, dq2, d_rbf, (int)accumulate,
+                                    p.pa, p.pb, p.cmt});
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+// pamnet_mlp2_bwd_f32 + pamnet_local_edge_bwd_f32 (same arguments, same results) as one launch: see local_bwd_pair_kernel.
+extern "C" int pamnet_local_bwd_pair_f32(const float* dy, int64_t rows, const float* z1, const float* z2, const float* W1,
+                                         const float* W2, float* dz1, float* dz2, float* dx, int32_t accumulate_dx,
+                                         const float* d_mji, const float* d_mnb, const float* d_q3, int64_t n_edges,
+                                         const float* z_ji, const float* z_kj, const float* q2, const float* const* Wq,
+                                         const int64_t* ldq, float* dz_ji, float* dz_kj, float* dq2, float* d_rbf,
+                                         int32_t accumulate_rbf, pamnet_stream_t stream) {
+    if (rows < 0 || n_edges < 0) return PAMNET_EINVAL;
+    if (rows == 0 || n_edges == 0 || four_waves()) {         // nothing to pair (or the 4-wave geometry is forced): two launches
+        int rc = pamnet_mlp2_bwd_f32(dy, rows, z1, z2, W1, W2, dz1, dz2, dx, accumulate_dx, stream);
+        if (rc) return rc;
+        return pamnet_local_edge_bwd_f32(d_mji, d_mnb, d_q3, n_edges, z_ji, z_kj, q2, Wq, ldq, dz_ji, dz_kj, dq2, d_rbf,
+                                         accumulate_rbf, stream);
+    }
+    if (!dy || !z1 || !z2 || !W1 || !W2 || !dz1 || !dz2 || !dx) return PAMNET_ENULL;
+    if (!d_mji || !d_mnb || !d_q3 || !z_ji || !z_kj || !q2 || !Wq || !ldq || !dz_ji || !dz_kj || !dq2 || !d_rbf)
+        return PAMNET_ENULL;
+    LocalW w;
+    int rc = fill_local(w, Wq, ldq, nullptr);
+    if (rc) return rc;
+    // CU shares by work: an edge row costs ~3.1 MLP rows (four fp32-MFMA GEMMs against two on the bf16 pipe; measured at the
+    // QM9 batch: 20.6 us for 4 316 edge rows, 24.1 us for 17 640 MLP rows, both on 256 workgroups)
+    const double we = 3.1 * (double)n_edges, wm = (double)rows;
+    int ge = (int)(N_CU * we / (we + wm) + 0.5);
+    ge = ge < 8 ? 8 : (ge > N_CU - 8 ? N_CU - 8 : ge);
+    const Plan pe = plan8(n_edges, 3, ge);
+    const Plan pm = plan8(rows, MT2, N_CU - (int)pe.grid);
+    const Mlp2BwdArgs ma{dy, rows, z1, z2, W1, W2, dz1, dz2, dx, (int)accumulate_dx, pm.pa, pm.pb, pm.pc, pm.cmt};
+    const LocalBwdArgs la{d_mji, d_mnb, d_q3, n_edges, z_ji, z_kj, q2, w, dz_ji, dz_kj, dq2, d_rbf, (int)accumulate_rbf,
+                          pe.pa, pe.pb, pe.cmt};
+    const dim3 grid(pm.grid + pe.grid);
+    hipStream_t st = as_stream(stream);
+    if (pm.cmt <= 3) hipLaunchKernelGGL(local_bwd_pair_kernel<3>, grid, dim3(WG8), 0, st, ma, la, (int)pm.grid);
+    else if (pm.cmt <= 5) hipLaunchKernelGGL(local_bwd_pair_kernel<5>, grid, dim3(WG8), 0, st, ma, la, (int)pm.grid);
+    else hipLaunchKernelGGL(local_bwd_pair_kernel<8>, grid, dim3(WG8), 0, st, ma, la, (int)pm.grid);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

@@ -267,9 +267,13 @@ struct Span {
     int cmt;
     template <int NW>
     static __device__ __forceinline__ Span make(int64_t m, int pa, int pb, int pc, int cmt_) {
+        return make_at<NW>(m, pa, pb, pc, cmt_, (int)blockIdx.x);
+    }
+    // the same for workgroup `b` of a plan that is one part of a launch (edge_chain.hip local_bwd_pair_kernel)
+    template <int NW>
+    static __device__ __forceinline__ Span make_at(int64_t m, int pa, int pb, int pc, int cmt_, int b) {
         Span sp;
         sp.cmt = cmt_;
-        const int b = blockIdx.x;
         int64_t t0, cnt;
         if (NW == 8) {                                        // pa = base, pb = rem
             t0 = (int64_t)b * pa + (b < pb ? b : pb);

@@ -590,11 +590,11 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             // d m_t = d x2[i] * q3,  d q3 = d x2[i] * m_t,  d s = m_nb[idx] * d m_t[e],  d m_nb = transposed sum: one launch
             CK(pamnet_local_agg_bwd_f32(t.dx2, g.l_row, q.q3, q.mt, q.mnb, q.s, g.t_ptr, g.t_col, g.t_row, g.tT_ptr,
                                         g.tT_perm, g.el, t.dmt, t.dq3, t.ds, t.dmnb, st));
-            CK(pamnet_mlp2_bwd_f32(t.ds, g.tp, q.z1, q.z2, lp[6], lp[8], t.dz1, t.dz2, d_sbf, acc, st));
+            // the triplet / pair MLP's backward and the local edge stage's: independent of each other, one launch
             const float* wq[4] = {lp[2] + 2 * D, lp[4] + 2 * D, lp[10], lp[11]};
             const int64_t ldq[4] = {3 * D, 3 * D, D, D};
-            CK(pamnet_local_edge_bwd_f32(t.dmt, t.dmnb, t.dq3, g.el, q.zji, q.zkj, q.q2, wq, ldq, t.dzji, t.dzkj, t.dq2,
-                                         d_rbf, acc, st));
+            CK(pamnet_local_bwd_pair_f32(t.ds, g.tp, q.z1, q.z2, lp[6], lp[8], t.dz1, t.dz2, d_sbf, acc, t.dmt, t.dmnb, t.dq3,
+                                         g.el, q.zji, q.zkj, q.q2, wq, ldq, t.dzji, t.dzkj, t.dq2, d_rbf, acc, st));
             const int64_t pl = g.n * D;
             {
                 float* so[4] = {t.dP, t.dP + pl, t.dP + 2 * pl, t.dP + 3 * pl};

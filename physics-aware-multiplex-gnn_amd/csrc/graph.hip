@@ -464,6 +464,21 @@ __device__ __forceinline__ void knn_stream(const float* __restrict__ pos, float 
     }
 }
 
+// 64-lane bitonic sort by (distance, index); padding (inf, INT_MAX) sinks to the end
+__device__ __forceinline__ void sort64_pairs(float& bd, int& bj, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int st = k >> 1; st > 0; st >>= 1) {
+            const float od = __shfl_xor(bd, st, 64);
+            const int oj = __shfl_xor(bj, st, 64);
+            const bool keep_min = (((lane & k) == 0) == ((lane & st) == 0));
+            const bool take = keep_min ? pair_less(od, oj, bd, bj) : pair_less(bd, bj, od, oj);
+            if (take) { bd = od; bj = oj; }
+        }
+    }
+}
+
 // K smallest (distance bits, index) pairs out of NC values per lane (padding = 0xffffffff), values in scan order
 // (slot-major, lane-minor = ascending candidate index): bisection on the bit pattern for the K-th smallest distance,
 // ties by scan order, compaction into sd/sj[64], then a 64-lane bitonic sort.  G = slots per guarded group
@@ -537,18 +552,7 @@ __device__ __forceinline__ void knn_topk(const unsigned (&dv)[NC], const int (&j
     __builtin_amdgcn_wave_barrier();
     bd = sd[lane];
     bj = sj[lane];
-    // 64-lane bitonic sort by (distance, index); padding (inf, INT_MAX) sinks to the end
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int st = k >> 1; st > 0; st >>= 1) {
-            const float od = __shfl_xor(bd, st, 64);
-            const int oj = __shfl_xor(bj, st, 64);
-            const bool keep_min = (((lane & k) == 0) == ((lane & st) == 0));
-            const bool take = keep_min ? pair_less(od, oj, bd, bj) : pair_less(bd, bj, od, oj);
-            if (take) { bd = od; bj = oj; }
-        }
-    }
+    sort64_pairs(bd, bj, lane);
 }
 
 // Selection path.  Bisection over all cached candidates costs two vector instructions per candidate and probe, so it
@@ -616,12 +620,14 @@ __device__ __forceinline__ void knn_select(const float* __restrict__ pos, float 
         if (c < iters) {
             const bool sel = dc[c] <= hi;
             const unsigned long long m = __ballot(sel);
-            if (sel) {
-                const int slot = nsurv + __popcll(m & below);
-                vd[slot] = dc[c];
-                vj[slot] = beg + c * 64 + lane;
+            if (m) {                                        // (wave-uniform: the survivors of a query sit in a few slots)
+                if (sel) {
+                    const int slot = nsurv + __popcll(m & below);
+                    vd[slot] = dc[c];
+                    vj[slot] = beg + c * 64 + lane;
+                }
+                nsurv += __popcll(m);
             }
-            nsurv += __popcll(m);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -634,7 +640,44 @@ __device__ __forceinline__ void knn_select(const float* __restrict__ pos, float 
         sv[t] = slot < nsurv ? vd[slot] : 0xffffffffu;
         svj[t] = slot < nsurv ? vj[slot] : 0x7fffffff;
     }
-    knn_topk<KNN_SURV / 64, KNN_SURV / 64, true>(sv, svj, 0, KNN_SURV / 64, kk, lane, sd, sj, bd, bj);
+    // Second stage, on the survivors alone (four per lane: a probe is 8 compares + 3 ballots): the bisection goes on until at
+    // most 64 candidates lie at or below the upper end -- typically three or four more probes, where closing the interval
+    // completely takes ~25 -- and those are sorted by the 64-lane network; the first kk of them are the answer (ties at the
+    // K-th distance fall to the lower index through the sort's (distance, index) order, as in knn_topk).
+    constexpr int NS = KNN_SURV / 64;
+    while (lo < hi && cnt_hi > 64) {
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        int c_lane = 0;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) c_lane += (sv[t] <= mid) ? 1 : 0;
+        int tot = 0;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) tot += __popcll(__ballot((c_lane >> b) & 1)) << b;
+        if (tot >= kk) { hi = mid; cnt_hi = tot; } else lo = mid + 1;
+    }
+    if (cnt_hi > 64) {                                       // more than 64 candidates tie at lo: the general selection
+        knn_topk<NS, NS, true>(sv, svj, 0, NS, kk, lane, sd, sj, bd, bj);
+        return;
+    }
+    sd[lane] = INFINITY;
+    sj[lane] = 0x7fffffff;
+    int out = 0;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const bool sel = sv[t] <= hi;
+        const unsigned long long m = __ballot(sel);
+        if (sel) {
+            const int slot = out + __popcll(m & below);
+            sd[slot] = __uint_as_float(sv[t]);
+            sj[slot] = svj[t];
+        }
+        out += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bd = sd[lane];
+    bj = sj[lane];
+    sort64_pairs(bd, bj, lane);
 }
 
 __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pos, const int32_t* __restrict__ node_graph,

@@ -336,3 +336,39 @@ def test_node_tail_fwd_bf16x6(dev, n):
     assert e2 <= max(2e-6, 2 * e1), (e2, e1)
     for k in res[1]:
         assert maxnorm_err(res[2][k].cpu(), res[1][k].cpu()) < 3e-6, k
+
+
+@pytest.mark.parametrize('rows,edges', [(17640, 4316), (127922, 36890), (37, 5), (1, 1), (700, 9000), (40, 0), (0, 33)])
+@pytest.mark.parametrize('acc', [0, 1])
+def test_local_backward_pair_equals_the_two_launches(dev, rows, edges, acc):
+    """pamnet_local_bwd_pair_f32 (the triplet / pair MLP's backward and the local edge stage's as one launch, CUs split by
+    work) against pamnet_mlp2_bwd_f32 + pamnet_local_edge_bwd_f32: every output bit for bit, at the QM9 and PDBbind
+    batch shapes, tiny and lopsided ones, empty lists, with and without accumulation into d_sbf / d_rbf."""
+    import ctypes
+    from pamnet_amd import lib
+    D = 128
+    gen = torch.Generator(device='cpu').manual_seed(rows * 7 + edges)
+    rnd = lambda *s: (torch.randn(*s, generator=gen) * 0.5).to(dev)
+    dy, z1, z2 = rnd(rows, D), rnd(rows, D), rnd(rows, D)
+    W1, W2 = rnd(D, D) / 8, rnd(D, D) / 8
+    d_mji, d_mnb, d_q3, z_ji, z_kj, q2 = (rnd(edges, D) for _ in range(6))
+    Wq = [rnd(D, 3 * D) / 8, rnd(D, 3 * D) / 8, rnd(D, D) / 8, rnd(D, D) / 8]
+    wq = (ctypes.c_void_p * 4)(Wq[0].data_ptr() + 8 * D, Wq[1].data_ptr() + 8 * D, Wq[2].data_ptr(), Wq[3].data_ptr())
+    ldq = (ctypes.c_int64 * 4)(3 * D, 3 * D, D, D)
+    dx0, drbf0 = rnd(rows, D), rnd(edges, D)
+    st = lib.stream_of(W1)
+
+    def outs():
+        return ([torch.full((rows, D), float('nan'), device=dev) for _ in range(2)] + [dx0.clone()],
+                [torch.full((edges, D), float('nan'), device=dev) for _ in range(3)] + [drbf0.clone()])
+    (dz1, dz2, dx), (dzji, dzkj, dq2, drbf) = outs()
+    lib.call('pamnet_mlp2_bwd_f32', lib.ptr(dy), rows, lib.ptr(z1), lib.ptr(z2), lib.ptr(W1), lib.ptr(W2), lib.ptr(dz1),
+             lib.ptr(dz2), lib.ptr(dx), acc, st)
+    lib.call('pamnet_local_edge_bwd_f32', lib.ptr(d_mji), lib.ptr(d_mnb), lib.ptr(d_q3), edges, lib.ptr(z_ji), lib.ptr(z_kj),
+             lib.ptr(q2), wq, ldq, lib.ptr(dzji), lib.ptr(dzkj), lib.ptr(dq2), lib.ptr(drbf), acc, st)
+    (pz1, pz2, px), (pji, pkj, pq2, prbf) = outs()
+    lib.call('pamnet_local_bwd_pair_f32', lib.ptr(dy), rows, lib.ptr(z1), lib.ptr(z2), lib.ptr(W1), lib.ptr(W2), lib.ptr(pz1),
+             lib.ptr(pz2), lib.ptr(px), acc, lib.ptr(d_mji), lib.ptr(d_mnb), lib.ptr(d_q3), edges, lib.ptr(z_ji),
+             lib.ptr(z_kj), lib.ptr(q2), wq, ldq, lib.ptr(pji), lib.ptr(pkj), lib.ptr(pq2), lib.ptr(prbf), acc, st)
+    for a, b in ((dz1, pz1), (dz2, pz2), (dx, px), (dzji, pji), (dzkj, pkj), (dq2, pq2), (drbf, prbf)):
+        assert torch.equal(a, b) and not bool(torch.isnan(a).any())
