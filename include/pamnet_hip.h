@@ -456,7 +456,10 @@ int pamnet_wgrad_ctx_bytes(int64_t* bytes /* host */);
 int pamnet_wgrad_deferred_f32(int64_t njobs, const float* const* dZ, const int64_t* ld_dz, const float* const* A,
                               const int64_t* ld_a, const int32_t* a_mode, const int64_t* rows, float* const* dW,
                               const int64_t* ld_dw, float* const* db, float* partial, const float* head_partial,
-                              int64_t head_blocks, float* d_wout, float* d_watt, float* d_bout, void* ctx /* host */,
+                              int64_t head_blocks, float* d_wout, float* d_watt, float* d_bout,
+                              const float* head2_partial /* nullable: a second chain's head-vector partials (same head_blocks):
+                                                            a layer pair's merged batch carries the local and the global chain's */,
+                              float* d_wout2, float* d_watt2, float* d_bout2, void* ctx /* host */,
                               pamnet_stream_t stream);
 int pamnet_wgrad_flush_f32(void* ctx /* host */, pamnet_stream_t stream);
 /* Riders: weight-gradient slots as extra workgroups of a node-chain backward launch (the chain owns ceil(n/16) workgroups,
@@ -465,7 +468,9 @@ int pamnet_wgrad_flush_f32(void* ctx /* host */, pamnet_stream_t stream);
  *                                   (caller-owned HOST memory of pamnet_wgrad_rider_bytes bytes); *slots_out = slots used
  *   pamnet_node_pre_tail_bwd_f32  : takes the plan (`rider` argument) and appends the slots to its grid
  *   pamnet_wgrad_rider_enqueue_f32: registers the batch with a deferred context so that the next pamnet_wgrad_deferred_f32
- *                                   launch (or the flush) reduces its slots in the usual fixed order. */
+ *                                   launch (or the flush) reduces its slots in the usual fixed order.  A second rider batch
+ *                                   before that launch is appended to the first (<= 24 jobs together); its `partial` must
+ *                                   start right behind the first one's slots in the same buffer. */
 int pamnet_wgrad_rider_bytes(int64_t* bytes);
 int pamnet_wgrad_rider_plan_f32(int64_t njobs, const float* const* dZ, const int64_t* ld_dz, const float* const* A,
                                 const int64_t* ld_a, const int32_t* a_mode, const int64_t* rows, float* const* dW,

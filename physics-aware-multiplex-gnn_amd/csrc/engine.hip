@@ -87,6 +87,8 @@ inline LocalSaved carve_local(float* p, const Graph& g) {
 struct Temp {
     float *x1, *P, *msg, *mji;                                         // forward
     float *dZ, *dZ2, *dx2, *dresx, *head, *dz, *dea, *dP, *dZx1, *dxa, *dxb;    // backward (global + shared)
+    float *dPg, *dZx1g;          // the global layer's own d P (2 planes) / d Zx1: the local layer's stay alive until the pair's
+                                 // merged weight-gradient launch
     float *dzji, *dzkj, *dq2, *dmt, *dq3, *dmnb, *ds, *dz1, *dz2;      // backward (local)
     float *partial, *partial2;   // split-K scratch of two consecutive weight-gradient batches (the reduction of one runs
                                  // inside the launch of the next)
@@ -101,14 +103,14 @@ inline int64_t wgrad_floats(const Graph& g) {
     auto slots = [](int64_t rows) { int64_t s = (rows + 127) / 128; return s < 1 ? 1 : (s > 256 ? 256 : s); };   // 128: the smallest chunk a plan may use (wgrad.hip)
     const int64_t glob = 15 * slots(g.n) + 2 * slots(g.eg);
     const int64_t loc = 15 * slots(g.n) + 4 * slots(g.el) + 2 * slots(g.tp);
-    return (glob > loc ? glob : loc) * (D * D + 2 * D);
+    return (glob + loc) * (D * D + 2 * D);       // (a layer pair's merged batch holds both layers' own jobs)
 }
 
 // the 10 tail jobs of a chain riding in the next chain launch (256-row slots)
 inline int64_t rider_floats(const Graph& g) {
     int64_t s = (g.n + 255) / 256;
     s = s < 1 ? 1 : (s > 256 ? 256 : s);
-    return 10 * s * (D * D + 2 * D);
+    return 2 * 10 * s * (D * D + 2 * D);         // two chains' riders wait for the pair's merged launch
 }
 
 inline int64_t temp_floats(const Graph& g) {
@@ -117,6 +119,7 @@ inline int64_t temp_floats(const Graph& g) {
     t += nd + 4 * nd + gd + ld;                                        // x1 P msg mji
     t += 10 * nd + 7 * nd + nd + nd + al(((g.n + 15) / 16) * 257) + gd + gd + 4 * nd + nd + nd + nd;
     t += 6 * ld + 3 * td;
+    t += 3 * nd;                                                       // dPg (2 planes), dZx1g
     t += 2 * wgrad_floats(g) + rider_floats(g) + 320;
     return t;
 }
@@ -138,6 +141,8 @@ inline Temp carve_temp(float* p, const Graph& g) {
     t.dea = p; p += gd;
     t.dP = p; p += 4 * nd;
     t.dZx1 = p; p += nd;
+    t.dPg = p; p += 2 * nd;
+    t.dZx1g = p; p += nd;
     t.dxa = p; p += nd;
     t.dxb = p; p += nd;
     t.dzji = p; p += ld;
@@ -250,10 +255,15 @@ inline void tail_jobs(Jobs& j, const Graph& g, const float* dZ, const float* hdz
 }
 
 // all weight gradients of a layer + the head-vector gradients of its node chain (partials left by node_tail_bwd)
-inline int run_jobs(Jobs& j, float* partial, const Graph& g, const float* head, float* d_wout, float* d_watt,
-                    float* d_bout, void* ctx, pamnet_stream_t st) {
-    return pamnet_wgrad_deferred_f32(j.n, j.dZ, j.ld_dz, j.A, j.ld_a, j.mode, j.rows, j.dW, j.ld_dw, j.db, partial, head,
-                                     (g.n + 15) / 16, d_wout, d_watt, d_bout, ctx, st);
+struct HeadGrads {
+    const float* partial;       // the chain's head-vector partials (null: none)
+    float *d_wout, *d_watt, *d_bout;
+};
+inline int run_jobs(Jobs& j, float* partial, const Graph& g, const HeadGrads& h, const HeadGrads& h2, void* ctx,
+                    pamnet_stream_t st) {
+    return pamnet_wgrad_deferred_f32(j.n, j.dZ, j.ld_dz, j.A, j.ld_a, j.mode, j.rows, j.dW, j.ld_dw, j.db, partial, h.partial,
+                                     (g.n + 15) / 16, h.d_wout, h.d_watt, h.d_bout, h2.partial, h2.d_wout, h2.d_watt,
+                                     h2.d_bout, ctx, st);
 }
 
 }  // namespace
@@ -564,6 +574,9 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
     CK(pamnet_seg_cuts_i32(g.g_ptr, g.g_row, g.n, g.eg, t.cuts, nullptr, st));      // work split of the fused global-edge kernels
     float* parts[2] = {t.partial, t.partial2};
     int pflip = 0;
+    Jobs pair_jobs;                       // a pair's local-layer jobs waiting for its merged launch
+    HeadGrads pair_head{nullptr, nullptr, nullptr, nullptr};
+    int64_t rider_a_slots = 0;            // slots of the local chain's riders (the global chain's start behind them)
     const float* d_xout = nullptr;        // nothing consumes the last layer's node features (models.py:196-224)
     float* dx_bufs[2] = {t.dxa, t.dxb};
     float* dz_bufs[2] = {t.dZ, t.dZ2};
@@ -610,7 +623,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 if (ride) {                                   // this layer's chain gradients ride in the launch below
                     Jobs jr;
                     tail_jobs(jr, g, dz_local, q.hdz, q.x2, q.Z, q.R, q.xout, lg + LT, 0, rider_jobs());
-                    CK(plan_rider(jr, t.rider_partial, g, rider.data(), nullptr));
+                    CK(plan_rider(jr, t.rider_partial, g, rider.data(), &rider_a_slots));
                 }
                 CK(pamnet_node_pre_tail_bwd_f32(t.dP, t.dx2, t.dresx, g.n, img[k].lh[4], img[k].lh, 4, q.Zx1, t.dZx1, s.gh,
                                                 img[k].gt, s.Z, dz_global, t.dx2, t.dresx, ride ? rider.data() : nullptr, st));
@@ -622,6 +635,12 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 d_xout = dx;
                 flip ^= 1;
             }
+            // With riders a layer pair's own jobs -- 11 of the local layer, 5 of the global one -- are ONE launch behind the
+            // pair's second chain launch (k >= 1; the last pair's global layer keeps its ten tail jobs: two launches there):
+            // a weight-gradient launch at this batch size is ~14 us of work in ~30 us (prologue, partial stores, the riding
+            // reductions), and the local layer's operands (t.dP, t.dZx1, the edge / row gradients) stay untouched until the
+            // next pair's local phase -- the global phase writes its own d P / d Zx1 (t.dPg, t.dZx1g).
+            const bool merged = ride && k > 0;
             Jobs j;
             tail_jobs(j, g, dz_local, q.hdz, q.x2, q.Z, q.R, q.xout, lg + LT, ride ? rider_jobs() : 0, 10);
             j.add(t.dZx1, x_in, 0, g.n, lg[0], D, lg[1]);
@@ -635,11 +654,17 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             j.add(t.dq3, rbf_e, 0, g.el, lg[11], D, nullptr);
             j.add(t.dz2, q.z1, 1, g.tp, lg[8], D, lg[9]);
             j.add(t.dz1, e_sbf, 0, g.tp, lg[6], D, lg[7]);
-            CK(run_jobs(j, parts[pflip], g, q.hp, lg[LT + 20], lg[LT + 22], lg[LT + 21], wctx.data(), st));
-            pflip ^= 1;
-            // that launch also reduced the weight gradients of the previous pair's global layer: pair k+1 is complete
-            if (k + 1 < n_layer && layer_done && layer_done[k + 1]) {
-                HK(hipEventRecord(reinterpret_cast<hipEvent_t>(layer_done[k + 1]), as_stream(st)));
+            const HeadGrads hl{q.hp, lg[LT + 20], lg[LT + 22], lg[LT + 21]};
+            if (!merged) {
+                CK(run_jobs(j, parts[pflip], g, hl, HeadGrads{nullptr, nullptr, nullptr, nullptr}, wctx.data(), st));
+                pflip ^= 1;
+                // that launch also reduced the weight gradients of the previous pair's global layer: pair k+1 is complete
+                if (k + 1 < n_layer && layer_done && layer_done[k + 1]) {
+                    HK(hipEventRecord(reinterpret_cast<hipEvent_t>(layer_done[k + 1]), as_stream(st)));
+                }
+            } else {
+                pair_jobs = j;
+                pair_head = hl;
             }
         }
         // ================= global layer backward
@@ -654,39 +679,48 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             // d z, d ea, d e and the target-side reduction d P_i in one kernel; the source-side one walks the transposed CSR
             const int64_t pl = g.n * D;
             CK(pamnet_global_edge_agg_bwd_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, t.cuts, s.z, s.ea, gp[2] + 2 * D, 3 * D, gp[4], D,
-                                              t.dz, t.dea, d_eg, acc, t.dP, st));
-            CK(pamnet_segment_sum_f32(t.dP + pl, nullptr, t.dz, nullptr, nullptr, nullptr, g.gT_perm, g.gT_ptr, g.n, D, st));
+                                              t.dz, t.dea, d_eg, acc, t.dPg, st));
+            CK(pamnet_segment_sum_f32(t.dPg + pl, nullptr, t.dz, nullptr, nullptr, nullptr, g.gT_perm, g.gT_ptr, g.n, D, st));
             if (fuse && k > 0) {
                 // head of the global layer + the local chain of the previous pair
                 const LocalSaved qp = carve_local(const_cast<float*>(saved) + (k - 1) * (gs + ls) + gs, g);
                 zflip ^= 1;
                 dz_local = dz_bufs[zflip];
                 if (ride) {
+                    // (its slots lie right behind the local chain's riders: both wait for the pair's merged launch)
                     Jobs jr;
                     tail_jobs(jr, g, dz_global, s.hdz, s.x2, s.Z, s.R, s.xout, gg + GT, 0, rider_jobs());
-                    CK(plan_rider(jr, t.rider_partial, g, rider.data(), nullptr));
+                    CK(plan_rider(jr, t.rider_partial + rider_a_slots * (D * D + 2 * D), g, rider.data(), nullptr));
                 }
-                CK(pamnet_node_pre_tail_bwd_f32(t.dP, t.dx2, t.dresx, g.n, img[k].gh[2], img[k].gh, 2, s.Zx1, t.dZx1, qp.gh,
+                CK(pamnet_node_pre_tail_bwd_f32(t.dPg, t.dx2, t.dresx, g.n, img[k].gh[2], img[k].gh, 2, s.Zx1, t.dZx1g, qp.gh,
                                                 img[k - 1].lt, qp.Z, dz_local, t.dx2, t.dresx, ride ? rider.data() : nullptr,
                                                 st));
                 if (ride) CK(pamnet_wgrad_rider_enqueue_f32(wctx.data(), rider.data()));
             } else {
                 const float* wpg[2] = {gp[2], gp[2] + D};
                 float* dx = (k == 0) ? d_x0 : dx_bufs[flip];
-                CK(pamnet_node_pre_bwd_f32(t.dP, t.dx2, t.dresx, g.n, packed ? img[k].gh[2] : gp[0],
-                                           packed ? img[k].gh : wpg, 3 * D, 2, s.Zx1, t.dZx1, dx, pk, st));
+                CK(pamnet_node_pre_bwd_f32(t.dPg, t.dx2, t.dresx, g.n, packed ? img[k].gh[2] : gp[0],
+                                           packed ? img[k].gh : wpg, 3 * D, 2, s.Zx1, t.dZx1g, dx, pk, st));
                 d_xout = dx;
                 flip ^= 1;
             }
+            const bool merged = ride && k > 0;
             Jobs j;
+            if (merged) j = pair_jobs;                        // the local layer's own jobs, parked above
             tail_jobs(j, g, dz_global, s.hdz, s.x2, s.Z, s.R, s.xout, gg + GT, (ride && k > 0) ? rider_jobs() : 0, 10);
-            j.add(t.dZx1, x_in, 0, g.n, gg[0], D, gg[1]);
-            j.add(t.dP, s.Zx1, 1, g.n, gg[2], 3 * D, nullptr);
-            j.add(t.dP + pl, s.Zx1, 1, g.n, gg[2] + D, 3 * D, nullptr);
+            j.add(t.dZx1g, x_in, 0, g.n, gg[0], D, gg[1]);
+            j.add(t.dPg, s.Zx1, 1, g.n, gg[2], 3 * D, nullptr);
+            j.add(t.dPg + pl, s.Zx1, 1, g.n, gg[2] + D, 3 * D, nullptr);
             j.add(t.dz, e_g, 0, g.eg, gg[2] + 2 * D, 3 * D, gg[3]);
             j.add(t.dea, e_g, 0, g.eg, gg[4], D, nullptr);
-            CK(run_jobs(j, parts[pflip], g, s.hp, gg[GT + 20], gg[GT + 22], gg[GT + 21], wctx.data(), st));
+            const HeadGrads hg{s.hp, gg[GT + 20], gg[GT + 22], gg[GT + 21]};
+            CK(run_jobs(j, parts[pflip], g, hg, merged ? pair_head : HeadGrads{nullptr, nullptr, nullptr, nullptr}, wctx.data(),
+                        st));
             pflip ^= 1;
+            // (merged: that launch also reduced the previous pair's merged batch: pair k+1 is complete)
+            if (merged && k + 1 < n_layer && layer_done && layer_done[k + 1]) {
+                HK(hipEventRecord(reinterpret_cast<hipEvent_t>(layer_done[k + 1]), as_stream(st)));
+            }
         }
     }
     CK(pamnet_wgrad_flush_f32(wctx.data(), st));

@@ -78,11 +78,16 @@ __global__ __launch_bounds__(SWG, 2) void wgrad_kernel(WBatch batch, float* __re
 //   x == 256, y < njobs : job y's bias gradient (two row-half partials per slot), fp64 across slots;
 //   y == njobs, x < 17  : optional extra reduction riding along -- the node chain's head-vector partials
 //                          ([blocks][257]: d w_out | d w_att | d b_out), so the chain's backward needs no launch of its own.
-struct HeadJob {
+struct HeadOne {
     const float* partial;     // null: none
     int blocks;
     float *d_wout, *d_watt, *d_bout;
 };
+// up to two chains' head vectors per batch (a layer pair's merged launch carries the local and the global chain's)
+struct HeadJob {
+    HeadOne h[2];
+};
+constexpr HeadOne NO_HEAD{nullptr, 0, nullptr, nullptr, nullptr};
 
 template <typename Batch>
 __device__ __forceinline__ void finish_body(const Batch& batch, const float* __restrict__ partial, const HeadJob& head,
@@ -90,22 +95,25 @@ __device__ __forceinline__ void finish_body(const Batch& batch, const float* __r
     float4(*red)[16] = reinterpret_cast<float4(*)[16]>(lds);                 // [16][16] float4 = 4 KB
     constexpr int64_t SLOT = DIM * DIM + 2 * DIM;
     if (by == batch.njobs) {
-        if (!head.partial || bx >= 17) return;
+        if (bx >= 34) return;
+        const HeadOne hd = head.h[bx / 17];                                // workgroups [0, 17): first chain, [17, 34): second
+        if (!hd.partial) return;
+        const int hx = bx % 17;
         float(*r1)[17] = reinterpret_cast<float(*)[17]>(&red[0][0]);      // 16 x 17 floats fit in the float4 array
         const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-        const int c = bx * 16 + cl;
+        const int c = hx * 16 + cl;
         float s = 0.f;
         if (c < 257)
-            for (int b = sl; b < head.blocks; b += 16) s += head.partial[(int64_t)b * 257 + c];
+            for (int b = sl; b < hd.blocks; b += 16) s += hd.partial[(int64_t)b * 257 + c];
         r1[sl][cl] = s;
         __syncthreads();
         if (sl == 0 && c < 257) {
             float t = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) t += r1[q][cl];
-            if (c < 128) head.d_wout[c] = t;
-            else if (c < 256) head.d_watt[c - 128] = t;
-            else head.d_bout[0] = t;
+            if (c < 128) hd.d_wout[c] = t;
+            else if (c < 256) hd.d_watt[c - 128] = t;
+            else hd.d_bout[0] = t;
         }
         return;
     }
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(WG) void wgrad_finish_kernel(WBatch batch, const fl
 constexpr int FIN_X = DIM * DIM / 64 + 2;
 __global__ __launch_bounds__(SWG, 2) void wgrad_fused_kernel(WBatchS cur, float* __restrict__ cur_partial, WBatchS prev,
                                                          const float* __restrict__ prev_partial, HeadJob prev_head,
-                                                         WBatchS prev2, const float* __restrict__ prev2_partial) {
+                                                         WBatch prev2, const float* __restrict__ prev2_partial) {
     __shared__ __attribute__((aligned(16))) float lds[WGRAD_LDS_FLOATS];
     const int slots = cur.start[cur.njobs];
     int fb = (int)blockIdx.x - slots;
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(SWG, 2) void wgrad_fused_kernel(WBatchS cur, float*
         finish_body(prev, prev_partial, prev_head, fb % FIN_X, fb / FIN_X, lds);
     } else {
         fb -= fin1;
-        finish_body(prev2, prev2_partial, HeadJob{nullptr, 0, nullptr, nullptr, nullptr}, fb % FIN_X, fb / FIN_X, lds);
+        finish_body(prev2, prev2_partial, HeadJob{{NO_HEAD, NO_HEAD}}, fb % FIN_X, fb / FIN_X, lds);
     }
 }
 
@@ -265,7 +273,7 @@ extern "C" int pamnet_wgrad_batched_f32(int64_t njobs, const float* const* dZ, c
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)b.start[njobs]), dim3(SWG), 0, st, b, partial);
     PAMNET_LAUNCH_CHECK();
-    const HeadJob head{head_partial, (int)head_blocks, d_wout, d_watt, d_bout};
+    const HeadJob head{{HeadOne{head_partial, (int)head_blocks, d_wout, d_watt, d_bout}, NO_HEAD}};
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3(FIN_X, (unsigned)njobs + 1), dim3(WG), 0, st, b, partial, head);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
@@ -282,7 +290,7 @@ extern "C" int pamnet_wgrad_ctx_bytes(int64_t* bytes) {
 }
 
 static int finish_pending(WgradPending* pend, hipStream_t st) {
-    const HeadJob none{nullptr, 0, nullptr, nullptr, nullptr};
+    const HeadJob none{{NO_HEAD, NO_HEAD}};
     for (int k = 0; k < 2; ++k) {
         if (!pend->valid[k]) continue;
         hipLaunchKernelGGL(wgrad_finish_kernel, dim3(FIN_X, (unsigned)pend->batch[k].njobs + 1), dim3(WG), 0, st,
@@ -297,9 +305,11 @@ extern "C" int pamnet_wgrad_deferred_f32(int64_t njobs, const float* const* dZ, 
                                          const float* const* A, const int64_t* ld_a, const int32_t* a_mode,
                                          const int64_t* rows, float* const* dW, const int64_t* ld_dw, float* const* db,
                                          float* partial, const float* head_partial, int64_t head_blocks, float* d_wout,
-                                         float* d_watt, float* d_bout, void* ctx, pamnet_stream_t stream) {
+                                         float* d_watt, float* d_bout, const float* head2_partial, float* d_wout2,
+                                         float* d_watt2, float* d_bout2, void* ctx, pamnet_stream_t stream) {
     if (njobs < 1 || njobs > MAXJ) return PAMNET_EINVAL;
     if (head_partial && (!d_wout || !d_watt || !d_bout || head_blocks < 0)) return PAMNET_ENULL;
+    if (head2_partial && (!d_wout2 || !d_watt2 || !d_bout2 || head_blocks < 0)) return PAMNET_ENULL;
     if (!dZ || !ld_dz || !A || !ld_a || !a_mode || !rows || !dW || !ld_dw || !db || !partial || !ctx) return PAMNET_ENULL;
     WgradPending* pend = static_cast<WgradPending*>(ctx);
     if ((pend->valid[0] && pend->partial[0] == partial) || (pend->valid[1] && pend->partial[1] == partial)) return PAMNET_EINVAL;
@@ -308,8 +318,7 @@ extern "C" int pamnet_wgrad_deferred_f32(int64_t njobs, const float* const* dZ, 
     if (rc) return rc;
     hipStream_t st = as_stream(stream);
     const bool any = pend->valid[0] || pend->valid[1];
-    const bool fits = njobs <= MAXJ_S && (!pend->valid[0] || pend->batch[0].njobs <= MAXJ_S) &&
-                      (!pend->valid[1] || pend->batch[1].njobs <= MAXJ_S);
+    const bool fits = njobs <= MAXJ_S && (!pend->valid[0] || pend->batch[0].njobs <= MAXJ_S);   // (the rider batch: wide)
     if (pend->valid[0] && !pend->valid[1]) {                   // one earlier batch: wide descriptors
         const unsigned grid = (unsigned)b.start[njobs] + (unsigned)(FIN_X * (pend->batch[0].njobs + 1));
         hipLaunchKernelGGL(wgrad_fused_wide_kernel, dim3(grid), dim3(SWG), 0, st, b, partial, pend->batch[0], pend->partial[0],
@@ -320,9 +329,11 @@ extern "C" int pamnet_wgrad_deferred_f32(int64_t njobs, const float* const* dZ, 
         WBatchS none;
         none.njobs = 0, none.start[0] = 0;
         const WBatchS p0 = pend->valid[0] ? compact(pend->batch[0]) : none;
-        const WBatchS p1 = pend->valid[1] ? compact(pend->batch[1]) : none;
+        WBatch p1;
+        p1.njobs = 0, p1.start[0] = 0;
+        if (pend->valid[1]) p1 = pend->batch[1];
         const unsigned fin = (pend->valid[0] ? FIN_X * (p0.njobs + 1) : 0) + (pend->valid[1] ? FIN_X * (p1.njobs + 1) : 0);
-        const HeadJob nohead{nullptr, 0, nullptr, nullptr, nullptr};
+        const HeadJob nohead{{NO_HEAD, NO_HEAD}};
         hipLaunchKernelGGL(wgrad_fused_kernel, dim3((unsigned)b.start[njobs] + fin), dim3(SWG), 0, st, compact(b), partial, p0,
                            pend->valid[0] ? pend->partial[0] : nullptr, pend->valid[0] ? pend->head : nohead, p1,
                            pend->valid[1] ? pend->partial[1] : nullptr);
@@ -338,7 +349,8 @@ extern "C" int pamnet_wgrad_deferred_f32(int64_t njobs, const float* const* dZ, 
     }
     pend->batch[0] = b;
     pend->partial[0] = partial;
-    pend->head = HeadJob{head_partial, (int)head_blocks, d_wout, d_watt, d_bout};
+    pend->head = HeadJob{{HeadOne{head_partial, (int)head_blocks, d_wout, d_watt, d_bout},
+                          HeadOne{head2_partial, (int)head_blocks, d_wout2, d_watt2, d_bout2}}};
     pend->valid[0] = 1;
     return PAMNET_OK;
 }
@@ -378,7 +390,20 @@ extern "C" int pamnet_wgrad_rider_enqueue_f32(void* ctx, const void* rider) {
     if (!ctx || !rider) return PAMNET_ENULL;
     WgradPending* pend = static_cast<WgradPending*>(ctx);
     const WgradRider* r = static_cast<const WgradRider*>(rider);
-    if (pend->valid[1]) return PAMNET_EINVAL;                  // one rider batch at a time
+    if (pend->valid[1]) {
+        // A second rider batch before the next reduction (a layer pair's merged launch follows TWO chain launches): appended
+        // to the first one's descriptor.  Its slots must lie right behind the first one's in the same scratch buffer.
+        WBatch& b = pend->batch[1];
+        const int s0 = b.start[b.njobs];
+        if (b.njobs + r->batch.njobs > MAXJ) return PAMNET_EINVAL;
+        if (r->partial != pend->partial[1] + (int64_t)s0 * (DIM * DIM + 2 * DIM)) return PAMNET_EINVAL;
+        for (int j = 0; j < r->batch.njobs; ++j) {
+            b.job[b.njobs + j] = r->batch.job[j];
+            b.start[b.njobs + j + 1] = s0 + r->batch.start[j + 1];
+        }
+        b.njobs += r->batch.njobs;
+        return PAMNET_OK;
+    }
     pend->batch[1] = widen(r->batch);
     pend->partial[1] = r->partial;
     pend->valid[1] = 1;

@@ -112,7 +112,8 @@ class DeferredWgrad(object):
         lib.call('pamnet_wgrad_deferred_f32', n, _parr([j[0] for j in jobs]), _iarr([j[1] for j in jobs]),
                  _parr([j[2] for j in jobs]), _iarr([j[3] for j in jobs]), _iarr([j[4] for j in jobs], ctypes.c_int32),
                  rows, _parr([j[6] for j in jobs]), _iarr([j[7] for j in jobs]), _parr([j[8] for j in jobs]),
-                 lib.ptr(p), None, 0, None, None, None, ctypes.addressof(self.ctx), lib.stream_of(self.ref))
+                 lib.ptr(p), None, 0, None, None, None, None, None, None, None, ctypes.addressof(self.ctx),
+                 lib.stream_of(self.ref))
 
     def flush(self):
         lib.call('pamnet_wgrad_flush_f32', ctypes.addressof(self.ctx), lib.stream_of(self.ref))
