@@ -72,12 +72,15 @@ __global__ __launch_bounds__(SWG, 2) void wgrad_kernel(WBatch batch, float* __re
     wgrad_body<SNW>(batch, partial, (int)blockIdx.x, lds);
 }
 
-// Second pass, ONE launch per batch (grid 258 x (njobs + 1)), every sum in a fixed order (deterministic):
-//   x <  256, y < njobs : 64 consecutive elements of job y's 128x128 tile, summed over its slots -- the slots are split
-//                          over 16 groups (group g takes slots s0+g, s0+g+16, ...), then the 16 group sums are added;
-//   x == 256, y < njobs : job y's bias gradient (two row-half partials per slot), fp64 across slots;
-//   y == njobs, x < 17  : optional extra reduction riding along -- the node chain's head-vector partials
+// Second pass, ONE launch per batch (grid 66 x (njobs + 1)), every sum in a fixed order (deterministic):
+//   x <  64, y < njobs : 256 consecutive elements of job y's 128x128 tile, summed over its slots -- the slots are split
+//                         over 4 groups (group g takes slots s0+g, s0+g+4, ...), then the 4 group sums are added;
+//   x == 64, y < njobs : job y's bias gradient (two row-half partials per slot), fp64 across slots;
+//   y == njobs, x < 34 : optional extra reductions riding along -- up to two node chains' head-vector partials
 //                          ([blocks][257]: d w_out | d w_att | d b_out), so the chain's backward needs no launch of its own.
+constexpr int FIN_TILES = DIM * DIM / 256;      // reduction workgroups per job: 64 float4 each
+constexpr int FIN_X = FIN_TILES + 2;            // + the bias gradient + a spare (the head vectors use a row of 34 of their own)
+static_assert(FIN_X >= 34, "the head-vector reductions take workgroups [0, 34) of the extra row");
 struct HeadOne {
     const float* partial;     // null: none
     int blocks;
@@ -119,22 +122,29 @@ __device__ __forceinline__ void finish_body(const Batch& batch, const float* __r
     }
     const WJob jb = batch.job[by];
     const int s0 = batch.start[by], s1 = batch.start[by + 1];
-    if (bx < 256) {
-        const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
-        const int e4 = bx * 16 + c;                       // float4 index inside the 128x128 tile
-        float4 s = f4zero();
-        for (int q = s0 + g; q < s1; q += 16)
-            s = f4add(s, *reinterpret_cast<const float4*>(partial + (int64_t)q * SLOT + 4 * e4));
-        red[g][c] = s;
+    if (bx < FIN_TILES) {
+        // 64 float4 columns x 4 slot groups per workgroup (a quarter of the workgroups of the 16 x 16 form: a reduction is
+        // launch-bound -- node-level jobs have ~9 slots -- and up to 36 jobs wait for one weight-gradient launch)
+        float4(*red4)[64] = reinterpret_cast<float4(*)[64]>(lds);           // [4][64] float4 = 4 KB
+        const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+        const int e4 = bx * 64 + c;                       // float4 index inside the 128x128 tile
+        float4 s = f4zero(), s2 = f4zero();
+        int q = s0 + g;
+        for (; q + 4 < s1; q += 8) {                      // two independent loads in flight, added in slot order
+            const float4 u = *reinterpret_cast<const float4*>(partial + (int64_t)q * SLOT + 4 * e4);
+            const float4 v = *reinterpret_cast<const float4*>(partial + (int64_t)(q + 4) * SLOT + 4 * e4);
+            s = f4add(s, u);
+            s2 = f4add(s2, v);
+        }
+        if (q < s1) s = f4add(s, *reinterpret_cast<const float4*>(partial + (int64_t)q * SLOT + 4 * e4));
+        red4[g][c] = f4add(s, s2);
         __syncthreads();
         if (g == 0) {
-            float4 t = red[0][c];
-#pragma unroll
-            for (int k = 1; k < 16; ++k) t = f4add(t, red[k][c]);
+            const float4 t = f4add(f4add(red4[0][c], red4[1][c]), f4add(red4[2][c], red4[3][c]));
             const int el = 4 * e4;
             *reinterpret_cast<float4*>(jb.dW + (int64_t)(el >> 7) * jb.ld_dw + (el & 127)) = t;
         }
-    } else if (bx == 256) {
+    } else if (bx == FIN_TILES) {
         if (!jb.db) return;
         // 32 float4 columns x 8 slot groups, fp64 across slots, fixed order
         double(*rd)[128] = reinterpret_cast<double(*)[128]>(lds + 1024);          // [8][128] doubles behind `red`
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(WG) void wgrad_finish_kernel(WBatch batch, const fl
 // is ~16 MB of L2-resident reads that ran as a launch of its own between two weight-gradient passes; here its small
 // workgroups fill in beside the current pass.  Compact batches (<= 16 jobs): the three descriptors share the 4 KB
 // kernel-argument block.
-constexpr int FIN_X = DIM * DIM / 64 + 2;
+
 __global__ __launch_bounds__(SWG, 2) void wgrad_fused_kernel(WBatchS cur, float* __restrict__ cur_partial, WBatchS prev,
                                                          const float* __restrict__ prev_partial, HeadJob prev_head,
                                                          WBatch prev2, const float* __restrict__ prev2_partial) {
