@@ -580,6 +580,8 @@ __global__ __launch_bounds__(64 * CHW) void npre_bwd_kernel(const NPreBwd p) {
 constexpr int MAXSEG = 32;
 struct RSeg {
     float* dst;
+    const float* src;     // the partial rows this destination is summed from: nblk rows of `stride` floats
+    int nblk, stride;
     int off, rows, KP, kvalid, len, ldo;
 };
 struct RSegs {
@@ -587,15 +589,15 @@ struct RSegs {
     int n;
 };
 
-__global__ __launch_bounds__(512) void narrow_reduce_multi_kernel(const float* __restrict__ partial, int nblk, int stride,
-                                                                  const RSegs S) {
+__global__ __launch_bounds__(512) void narrow_reduce_multi_kernel(const RSegs S) {
     __shared__ float part[8][64];
     const RSeg& sg = S.s[blockIdx.y];
     const int total = sg.rows > 0 ? sg.rows * sg.KP : sg.len;
     if ((int)blockIdx.x * 64 >= total) return;
     const int x = threadIdx.x, y = threadIdx.y;
     const int p = blockIdx.x * 64 + x;
-    const float* src = partial + sg.off;
+    const int nblk = sg.nblk, stride = sg.stride;
+    const float* __restrict__ src = sg.src + sg.off;
     float s = 0.f;
     if (p < total) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;        // four loads in flight per thread, fixed association
@@ -629,10 +631,15 @@ __global__ __launch_bounds__(512) void narrow_reduce_multi_kernel(const float* _
 struct SegTable {
     RSegs S;
     int gx = 1;
+    const float* cur = nullptr;          // source of the entries added next (source())
+    int cur_nblk = 0, cur_stride = 0;
     SegTable() { S.n = 0; }
+    // the entries added from here on are summed from `partial`: nblk rows of `stride` floats
+    void source(const float* partial, int nblk, int stride) { cur = partial, cur_nblk = nblk, cur_stride = stride; }
     void mat(float* dst, int off, int rows, int KP, int kvalid, int ldo) {
         RSeg& s = S.s[S.n++];
         s.dst = dst, s.off = off, s.rows = rows, s.KP = KP, s.kvalid = kvalid, s.len = 0, s.ldo = ldo;
+        s.src = cur, s.nblk = cur_nblk, s.stride = cur_stride;
         const int g = (rows * KP + 63) / 64;
         gx = g > gx ? g : gx;
     }
@@ -640,14 +647,44 @@ struct SegTable {
         if (!dst) return;
         RSeg& s = S.s[S.n++];
         s.dst = dst, s.off = off, s.rows = 0, s.KP = 0, s.kvalid = 0, s.len = len, s.ldo = 0;
+        s.src = cur, s.nblk = cur_nblk, s.stride = cur_stride;
         const int g = (len + 63) / 64;
         gx = g > gx ? g : gx;
     }
-    int launch(const float* partial, int nblk, int stride, hipStream_t st) const {
+    int launch(hipStream_t st) {
         if (S.n == 0) return PAMNET_OK;
-        hipLaunchKernelGGL(narrow_reduce_multi_kernel, dim3(gx, S.n), dim3(64, 8), 0, st, partial, nblk, stride, S);
+        hipLaunchKernelGGL(narrow_reduce_multi_kernel, dim3(gx, S.n), dim3(64, 8), 0, st, S);
         PAMNET_LAUNCH_CHECK();
+        S.n = 0, gx = 1;
         return PAMNET_OK;
+    }
+};
+
+// The partial rows of SEVERAL backward kernels wait in one arena and are reduced by one launch (a reduction is a ~5 us
+// launch of a few dozen small workgroups; seven per layer pair were 35 us of a 1.1 ms RNA step).  take(): the region for a
+// kernel's nblk x stride partial rows with `segs` destinations -- when the table (32 entries) or the arena cannot hold them
+// the pending reductions are launched first (stream order: they run before the kernel that reuses the space).
+struct Reducer {
+    SegTable T;
+    float* base;
+    int64_t cap, used = 0;
+    hipStream_t st;
+    Reducer(float* b, int64_t c, hipStream_t s) : base(b), cap(c), st(s) {}
+    int take(int nblk, int stride, int segs, float** out) {
+        const int64_t need = ((int64_t)nblk * stride + 63) & ~(int64_t)63;
+        if (need > cap || segs > MAXSEG) return PAMNET_EINVAL;
+        if (T.S.n + segs > MAXSEG || used + need > cap) {
+            const int rc = flush();
+            if (rc) return rc;
+        }
+        *out = base + used;
+        used += need;
+        T.source(*out, nblk, stride);
+        return PAMNET_OK;
+    }
+    int flush() {
+        used = 0;
+        return T.launch(st);
     }
 };
 

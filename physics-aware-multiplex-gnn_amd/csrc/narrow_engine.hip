@@ -85,10 +85,14 @@ inline int tail_stride(int d) { return d == 16 ? TailRow<16>::STRIDE : (d == 32 
 
 // gW / gb: 10 + 10 gradient buffers in chain order, head gradients gw_out [d], gb_out [1], gw_att [d]
 int launch_tail_bwd(int d, NTailBwd p, float* const* gW, float* const* gb, float* gw_out, float* gb_out, float* gw_att,
-                    hipStream_t st) {
+                    Reducer& R, hipStream_t st) {
     if (p.m == 0) return PAMNET_EINVAL;
     const int grid = chain_grid(p.m);
     p.stride = tail_stride(d);
+    {
+        const int rc = R.take(grid, p.stride, 23, &p.partial);
+        if (rc) return rc;
+    }
 #define CALL(DD)                                                                                          \
     {                                                                                                     \
         const hipError_t e_ = allow_lds(ntail_bwd_kernel<DD>, ntail_bwd_lds<DD>());                       \
@@ -99,7 +103,7 @@ int launch_tail_bwd(int d, NTailBwd p, float* const* gW, float* const* gb, float
 #undef CALL
     PAMNET_LAUNCH_CHECK();
     const int MAT = d * d, LIN = MAT + d, MLP = 2 * MAT + 2 * d;
-    SegTable T;
+    SegTable& T = R.T;
     T.mat(gW[0], 0, d, d, d, d);
     T.vec(gb[0], MAT, d);
     for (int k = 0; k < 4; ++k) {
@@ -116,7 +120,7 @@ int launch_tail_bwd(int d, NTailBwd p, float* const* gW, float* const* gb, float
     T.vec(gw_out, h, d);
     T.vec(gw_att, h + d, d);
     T.vec(gb_out, h + 2 * d, 1);
-    return T.launch(p.partial, grid, p.stride, st);
+    return PAMNET_OK;
 }
 
 int launch_pre_fwd(int d, const NPreFwd& p, hipStream_t st) {
@@ -135,11 +139,15 @@ int launch_pre_fwd(int d, const NPreFwd& p, hipStream_t st) {
 }
 
 // gWp[k]: gradient destination of projection block k (row stride ldg[k]); gW1 [d, d], gb1 [d]
-int launch_pre_bwd(int d, NPreBwd p, float* const* gWp, const int* ldg, float* gW1, float* gb1, hipStream_t st) {
+int launch_pre_bwd(int d, NPreBwd p, float* const* gWp, const int* ldg, float* gW1, float* gb1, Reducer& R, hipStream_t st) {
     if (p.m == 0) return PAMNET_EINVAL;
     const int grid = chain_grid(p.m);
     const int MAT = d * d;
     p.stride = (p.nb + 1) * MAT + d;
+    {
+        const int rc = R.take(grid, p.stride, p.nb + 2, &p.partial);
+        if (rc) return rc;
+    }
 #define CALL(DD)                                                                                         \
     {                                                                                                    \
         const hipError_t e_ = allow_lds(npre_bwd_kernel<DD>, npre_bwd_lds<DD>());                        \
@@ -149,11 +157,11 @@ int launch_pre_bwd(int d, NPreBwd p, float* const* gWp, const int* ldg, float* g
     NARROW_DISPATCH(d, CALL)
 #undef CALL
     PAMNET_LAUNCH_CHECK();
-    SegTable T;
+    SegTable& T = R.T;
     for (int k = 0; k < p.nb; ++k) T.mat(gWp[k], k * MAT, d, d, d, ldg[k]);
     T.mat(gW1, p.nb * MAT, d, d, d, d);
     T.vec(gb1, (p.nb + 1) * MAT, d);
-    return T.launch(p.partial, grid, p.stride, st);
+    return PAMNET_OK;
 }
 
 constexpr int EROW_BLOCKS = 256;            // backward row kernels: at most one workgroup per CU (narrow_core.h)
@@ -174,10 +182,15 @@ int launch_global_fwd(int d, const float* e, int64_t m, const int32_t* tgt, cons
 
 int launch_global_bwd(int d, const float* e, int64_t m, const int32_t* tgt, const int32_t* src, const float* P,
                       const float* We, int ldwe, const float* bias, const float* Wea, int ldwea, const float* dagg,
-                      float* dz, float* de, int acc_de, float* partial, float* gWe, int ldgwe, float* gWea, float* gb,
+                      float* dz, float* de, int acc_de, Reducer& R, float* gWe, int ldgwe, float* gWea, float* gb,
                       hipStream_t st) {
     const int grid = grid_for(m, 1, bwd_waves(d));
     const int stride = 2 * d * d + d;
+    float* partial = nullptr;
+    {
+        const int rc = R.take(grid, stride, 3, &partial);
+        if (rc) return rc;
+    }
 #define CALL(DD)                                                                                                     \
     {                                                                                                                \
         const size_t lds = 4 * wimg_bytes(DD) + bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);      \
@@ -189,11 +202,11 @@ int launch_global_bwd(int d, const float* e, int64_t m, const int32_t* tgt, cons
     NARROW_DISPATCH(d, CALL)
 #undef CALL
     PAMNET_LAUNCH_CHECK();
-    SegTable T;
+    SegTable& T = R.T;
     T.mat(gWe, 0, d, d, d, ldgwe);
     T.mat(gWea, d * d, d, d, d, d);
     T.vec(gb, 2 * d * d, d);
-    return T.launch(partial, grid, stride, st);
+    return PAMNET_OK;
 }
 
 int launch_mlp2_fwd(int d, const float* x, int64_t m, const float* W1, const float* b1, const float* W2, const float* b2,
@@ -213,10 +226,15 @@ int launch_mlp2_fwd(int d, const float* x, int64_t m, const float* W1, const flo
 }
 
 int launch_mlp2_bwd(int d, const float* x, int64_t m, const float* W1, const float* b1, const float* W2, const float* b2,
-                    const float* dy, float* dx, int acc_dx, float* partial, float* gW1, float* gb1, float* gW2, float* gb2,
+                    const float* dy, float* dx, int acc_dx, Reducer& R, float* gW1, float* gb1, float* gW2, float* gb2,
                     hipStream_t st) {
     const int grid = grid_for(m, 1, bwd_waves(d));
     const int stride = 2 * d * d + 2 * d;
+    float* partial = nullptr;
+    {
+        const int rc = R.take(grid, stride, 4, &partial);
+        if (rc) return rc;
+    }
 #define CALL(DD)                                                                                                       \
     {                                                                                                                  \
         const size_t lds = 4 * wimg_bytes(DD) + bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);        \
@@ -228,12 +246,12 @@ int launch_mlp2_bwd(int d, const float* x, int64_t m, const float* W1, const flo
     NARROW_DISPATCH(d, CALL)
 #undef CALL
     PAMNET_LAUNCH_CHECK();
-    SegTable T;
+    SegTable& T = R.T;
     T.mat(gW1, 0, d, d, d, d);
     T.mat(gW2, d * d, d, d, d, d);
     T.vec(gb1, 2 * d * d, d);
     T.vec(gb2, 2 * d * d + d, d);
-    return T.launch(partial, grid, stride, st);
+    return PAMNET_OK;
 }
 
 // one bias-free projection block of the edge-side Q = rbf [W_0 | W_1 | W_2 | W_3]^T: dW_k and (blocks whose gradient is the
@@ -304,9 +322,9 @@ Lay make_layout(int64_t n, int64_t eg, int64_t el, int64_t tp, int64_t d, int64_
     const int64_t pre = (int64_t)chain_grid(n) * (5 * d * d + d);
     const int64_t erow = (int64_t)EROW_BLOCKS * (2 * d * d + 2 * d);
     const int64_t qb = 4 * (int64_t)EROW_BLOCKS * (d * d + d);
-    int64_t pf = chain > pre ? chain : pre;
-    pf = pf > erow ? pf : erow;
-    pf = pf > qb ? pf : qb;
+    // every backward kernel of a layer pair keeps its partial rows until the pair's reductions run (Reducer): two chain
+    // tails, two heads, the global row kernel, the triplet / pair MLP and the four projection blocks
+    const int64_t pf = 2 * (chain + 64) + 2 * (pre + 64) + 2 * (erow + 64) + (qb + 64);
     L.partial_floats = pf;
     L.t_partial = take(pf);
     L.t_pack = take(n_layer * 2 * PACK_SLOTS * d * d);       // weight images of every layer pair (npack_kernel)
@@ -470,7 +488,7 @@ extern "C" int pamnet_narrow_stack_bwd_f32(const int64_t* sizes, const int32_t* 
     const int D = (int)d;
     TRY(pack_all(D, n_layer, gparams, lparams, temp + L.t_pack, st));
     const Images im{temp + L.t_pack, D};
-    float* partial = temp + L.t_partial;
+    Reducer R(temp + L.t_partial, L.partial_floats, st);    // partial rows of the backward kernels: reduced a few kernels at a time
     float* d_x2 = temp + L.t_dx2;
     float* d_resx = temp + L.t_dresx;
     float* gx[2] = {temp + L.t_gx0, temp + L.t_gx1};
@@ -491,8 +509,8 @@ extern "C" int pamnet_narrow_stack_bwd_f32(const int64_t* sizes, const int32_t* 
             t.w_out = l[32], t.w_att = l[34];
             t.x2 = S + L.l_x2, t.H0 = S + L.l_H0, t.R1 = S + L.l_R1, t.R2 = S + L.l_R2, t.R3 = S + L.l_R3, t.T = S + L.l_T;
             t.O = S + L.l_O, t.g_x = g_x, t.g_out = d_outs + (2 * k + 1) * n, t.g_att = d_atts + (2 * k + 1) * n;
-            t.d_x2 = d_x2, t.d_resx = d_resx, t.partial = partial, t.m = n;
-            TRY(launch_tail_bwd(D, t, lg + 12, lg + 22, lg[32], lg[33], lg[34], st));
+            t.d_x2 = d_x2, t.d_resx = d_resx, t.m = n;
+            TRY(launch_tail_bwd(D, t, lg + 12, lg + 22, lg[32], lg[33], lg[34], R, st));
             // x2 = x1 + sum m,  m = Q_3 (m_ji + m_other)
             float* dQ = temp + L.t_dQ;
             float* dmm = temp + L.t_dmm;
@@ -505,7 +523,7 @@ extern "C" int pamnet_narrow_stack_bwd_f32(const int64_t* sizes, const int32_t* 
             float* dmnb = temp + L.t_dmnb;
             TRY(pamnet_gather_mul_f32(ds, S + L.l_mnb, ix.tp_col, dmm, ix.tp_row, tp, d, stream));
             TRY(pamnet_segment_sum_f32(dmnb, nullptr, S + L.l_s, nullptr, dmm, ix.tp_row, ix.tpT_perm, ix.tpT_ptr, el, d, stream));
-            TRY(launch_mlp2_bwd(D, e_sbf, tp, l[6], l[7], l[8], l[9], ds, d_sbf, first ? 0 : 1, partial, lg[6], lg[7], lg[8],
+            TRY(launch_mlp2_bwd(D, e_sbf, tp, l[6], l[7], l[8], l[9], ds, d_sbf, first ? 0 : 1, R, lg[6], lg[7], lg[8],
                                 lg[9], st));
             // gates: dz_l [el, 2d] and dQ blocks 0..2 (block 3 is already there)
             float* dzl = temp + L.t_dzl;
@@ -519,28 +537,29 @@ extern "C" int pamnet_narrow_stack_bwd_f32(const int64_t* sizes, const int32_t* 
             const float* Wq[4] = {l[2] + 2 * D, l[4] + 2 * D, l[10], l[11]};
             const int ldq[4] = {3 * D, 3 * D, D, D};
             const int qs = D * D + D;
+            float* qpart = nullptr;
+            TRY(R.take(grid_for(el, 1, lin_bwd_waves(D)), 4 * qs, 6, &qpart));
             for (int b = 0; b < 4; ++b)
                 TRY(launch_qblock_bwd(D, rbf_e, el, Wq[b], ldq[b], dQ + b * D, 4 * D, d_rbf, (first && b == 0) ? 0 : 1,
-                                      partial + b * qs, 4 * qs, st));
+                                      qpart + b * qs, 4 * qs, st));
             {
-                SegTable T;
+                SegTable& T = R.T;
                 T.mat(lg[2] + 2 * D, 0 * qs, D, D, D, 3 * D);
                 T.vec(lg[3], 0 * qs + D * D, D);                 // d b_ji = column sums of d z_ji
                 T.mat(lg[4] + 2 * D, 1 * qs, D, D, D, 3 * D);
                 T.vec(lg[5], 1 * qs + D * D, D);
                 T.mat(lg[10], 2 * qs, D, D, D, D);
                 T.mat(lg[11], 3 * qs, D, D, D, D);
-                TRY(T.launch(partial, grid_for(el, 1, lin_bwd_waves(D)), 4 * qs, st));
             }
             NPreBwd p = {};
             p.x = x_loc, p.x1 = S + L.l_x1, p.img1 = im.at(k, L_W1, 0), p.img1t = im.at(k, L_W1, 1), p.b1 = l[1], p.nb = 4, p.m = n;
             for (int b = 0; b < 4; ++b) p.imgpt[b] = im.at(k, L_P + b, 1);
             p.dP[0] = dpi, p.dP[1] = dpi + D, p.dP[2] = dpj, p.dP[3] = dpj + D;
             p.lddp[0] = p.lddp[1] = p.lddp[2] = p.lddp[3] = 2 * D;
-            p.d_direct = d_x2, p.d_add = d_resx, p.dx = gx[0], p.partial = partial;
+            p.d_direct = d_x2, p.d_add = d_resx, p.dx = gx[0];
             float* gWp[4] = {lg[2], lg[4], lg[2] + D, lg[4] + D};
             const int ldg[4] = {3 * D, 3 * D, 3 * D, 3 * D};
-            TRY(launch_pre_bwd(D, p, gWp, ldg, lg[0], lg[1], st));
+            TRY(launch_pre_bwd(D, p, gWp, ldg, lg[0], lg[1], R, st));
         }
         // ---------------- global layer
         {
@@ -549,11 +568,11 @@ extern "C" int pamnet_narrow_stack_bwd_f32(const int64_t* sizes, const int32_t* 
             t.w_out = g[25], t.w_att = g[27];
             t.x2 = S + L.g_x2, t.H0 = S + L.g_H0, t.R1 = S + L.g_R1, t.R2 = S + L.g_R2, t.R3 = S + L.g_R3, t.T = S + L.g_T;
             t.O = S + L.g_O, t.g_x = gx[0], t.g_out = d_outs + (2 * k) * n, t.g_att = d_atts + (2 * k) * n;
-            t.d_x2 = d_x2, t.d_resx = d_resx, t.partial = partial, t.m = n;
-            TRY(launch_tail_bwd(D, t, gg + 5, gg + 15, gg[25], gg[26], gg[27], st));
+            t.d_x2 = d_x2, t.d_resx = d_resx, t.m = n;
+            TRY(launch_tail_bwd(D, t, gg + 5, gg + 15, gg[25], gg[26], gg[27], R, st));
             float* dz = temp + L.t_dz;
             TRY(launch_global_bwd(D, e_g, eg, ix.g_row, ix.g_col, S + L.g_P, g[2] + 2 * D, 3 * D, g[3], g[4], D, d_x2, dz, d_eg,
-                                  first ? 0 : 1, partial, gg[2] + 2 * D, 3 * D, gg[4], gg[3], st));
+                                  first ? 0 : 1, R, gg[2] + 2 * D, 3 * D, gg[4], gg[3], st));
             float* dpi = temp + L.t_dpi;
             float* dpj = temp + L.t_dpj;
             TRY(pamnet_segment_sum_f32(dpi, nullptr, dz, nullptr, nullptr, nullptr, nullptr, ix.g_ptr, n, d, stream));
@@ -562,12 +581,13 @@ extern "C" int pamnet_narrow_stack_bwd_f32(const int64_t* sizes, const int32_t* 
             p.x = x_glob, p.x1 = S + L.g_x1, p.img1 = im.at(k, G_W1, 0), p.img1t = im.at(k, G_W1, 1), p.b1 = g[1], p.nb = 2, p.m = n;
             p.imgpt[0] = im.at(k, G_P, 1), p.imgpt[1] = im.at(k, G_P + 1, 1);
             p.dP[0] = dpi, p.dP[1] = dpj, p.lddp[0] = p.lddp[1] = D;
-            p.d_direct = d_x2, p.d_add = d_resx, p.dx = k == 0 ? d_x0 : gx[1], p.partial = partial;
+            p.d_direct = d_x2, p.d_add = d_resx, p.dx = k == 0 ? d_x0 : gx[1];
             float* gWp[2] = {gg[2], gg[2] + D};
             const int ldg[2] = {3 * D, 3 * D};
-            TRY(launch_pre_bwd(D, p, gWp, ldg, gg[0], gg[1], st));
+            TRY(launch_pre_bwd(D, p, gWp, ldg, gg[0], gg[1], R, st));
             g_x = gx[1];
         }
+        TRY(R.flush());                   // this pair's gradients are complete before its event is recorded
         if (layer_done) {
             const hipError_t e_ = hipEventRecord(static_cast<hipEvent_t>(layer_done[k]), st);
             if (e_ != hipSuccess) return (int)e_;
