@@ -859,6 +859,77 @@ __global__ __launch_bounds__(64 * lin_bwd_waves(D)) void nlinear_bwd_kernel(cons
     for (int i = threadIdx.x; i < MAT + D; i += 64 * NW) partial[(size_t)blockIdx.x * stride + i] = red[i];
 }
 
+// The four bias-free projection blocks of the edge-side Q = rbf [W_0 | W_1 | W_2 | W_3]^T in ONE pass over the rows
+// (d <= 32: four D x D accumulator sets fit the registers): per 16-row tile x is read once, d rbf (+)= sum_k dQ_k W_k is
+// written once, dW_k = dQ_k^T x and the column sums of dQ_k (the bias gradients of the layers those blocks feed) accumulate
+// in registers.  partial row of a workgroup: [dW_0][db_0] ... [dW_3][db_3].  (Four nlinear_bwd launches re-read x and
+// read-modify-write d rbf four times; at d = 16 they are ~10 us each, launch-bound.)
+template <int D>
+__global__ __launch_bounds__(64 * lin_bwd_waves(D)) void nqblock4_bwd_kernel(const float* __restrict__ x, int64_t m,
+                                                          const float* __restrict__ W0, const float* __restrict__ W1,
+                                                          const float* __restrict__ W2, const float* __restrict__ W3,
+                                                          int ld0, int ld1, int ld2, int ld3,
+                                                          const float* __restrict__ dy, int64_t lddy,
+                                                          float* __restrict__ dx, int accumulate,
+                                                          float* __restrict__ partial, int stride) {
+    constexpr int NT = D / 16;
+    constexpr int IMG = img_units<NT, NT>();
+    constexpr int NW = lin_bwd_waves(D);
+    extern __shared__ float4 lds4[];
+    float4* imgt = lds4;                                         // [4] transposed images
+    float* tile = reinterpret_cast<float*>(lds4 + 4 * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
+    build_w<NT, NT, true>(imgt, W0, ld0, D);
+    build_w<NT, NT, true>(imgt + IMG, W1, ld1, D);
+    build_w<NT, NT, true>(imgt + 2 * IMG, W2, ld2, D);
+    build_w<NT, NT, true>(imgt + 3 * IMG, W3, ld3, D);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t ntiles = (m + 15) / 16;
+    float dbs[4][NT];
+    f32x4 gw[4][NT][NT];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            dbs[k][jt] = 0.f;
+            zero(gw[k][jt]);
+        }
+    const int64_t tstep = (int64_t)gridDim.x * NW;
+    for (int64_t t = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6); t < ntiles; t += tstep) {
+        const int64_t row0 = t * 16;
+        float4 a[NT];
+        f32x4 xd[NT], g[4][NT], acc[NT];
+        load_a<D>(a, x, row0, m, lane);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) load_d<D>(g[k], dy + k * D, row0, m, lane, lddy);
+        if (accumulate) load_d<D>(acc, dx, row0, m, lane);
+        else zero(acc);
+        a_to_d<D>(xd, a, tile, lane);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wgrad_acc<NT, NT>(gw[k], g[k], xd);
+            colsum_acc<NT>(dbs[k], g[k]);
+            d_to_a<D>(a, g[k], tile, lane);
+            mma_w<NT, NT>(acc, a, imgt + k * IMG, lane);
+        }
+        store_d<D>(acc, dx, row0, m, lane);
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds4);
+    constexpr int MAT = D * D, QS = MAT + D;
+    for (int w = 0; w < NW; ++w) {
+        if ((threadIdx.x >> 6) == w) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                red_add_mat<NT, NT>(red + k * QS, gw[k], lane, w == 0);
+                red_add_bias<NT>(red + k * QS + MAT, dbs[k], lane, w == 0);
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 4 * QS; i += 64 * NW) partial[(size_t)blockIdx.x * stride + i] = red[i];
+}
+
 // ====================================================================================================================
 // Layer heads (layers/global_message_passing.py:47-50): out[n] = o[n] . w_out + b_out, att[n] = o[n] . w_att
 // D/4 lanes per row (one float4 each); backward: d o = g_out w_out + g_att w_att and the three parameter gradients

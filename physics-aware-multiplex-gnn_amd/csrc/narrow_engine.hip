@@ -539,9 +539,24 @@ extern "C" int pamnet_narrow_stack_bwd_f32(const int64_t* sizes, const int32_t* 
             const int qs = D * D + D;
             float* qpart = nullptr;
             TRY(R.take(grid_for(el, 1, lin_bwd_waves(D)), 4 * qs, 6, &qpart));
-            for (int b = 0; b < 4; ++b)
-                TRY(launch_qblock_bwd(D, rbf_e, el, Wq[b], ldq[b], dQ + b * D, 4 * D, d_rbf, (first && b == 0) ? 0 : 1,
-                                      qpart + b * qs, 4 * qs, st));
+            if (D <= 32) {                                    // one pass over the rows for the four blocks (narrow_core.h)
+                const int qgrid = grid_for(el, 1, lin_bwd_waves(D));
+#define CALL(DD)                                                                                                        \
+    {                                                                                                                   \
+        const size_t lds = 4 * wimg_bytes(DD) + lin_bwd_waves(DD) * 16 * (DD + 4) * sizeof(float);                      \
+        const size_t need = 4 * (size_t)qs * sizeof(float);                                                             \
+        hipLaunchKernelGGL((nqblock4_bwd_kernel<DD>), dim3(qgrid), dim3(64 * lin_bwd_waves(DD)), lds > need ? lds : need, st, \
+                           rbf_e, el, Wq[0], Wq[1], Wq[2], Wq[3], ldq[0], ldq[1], ldq[2], ldq[3], dQ, (int64_t)(4 * D), d_rbf, \
+                           first ? 0 : 1, qpart, 4 * qs);                                                               \
+    }
+                if (D == 16) CALL(16) else CALL(32)
+#undef CALL
+                PAMNET_LAUNCH_CHECK();
+            } else {
+                for (int b = 0; b < 4; ++b)
+                    TRY(launch_qblock_bwd(D, rbf_e, el, Wq[b], ldq[b], dQ + b * D, 4 * D, d_rbf, (first && b == 0) ? 0 : 1,
+                                          qpart + b * qs, 4 * qs, st));
+            }
             {
                 SegTable& T = R.T;
                 T.mat(lg[2] + 2 * D, 0 * qs, D, D, D, 3 * D);
