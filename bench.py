@@ -749,7 +749,7 @@ def main():
         if not args.no_rooflines:
             roof = scatter_add_roofline(dev, g, args.dim, args.stream_gb)
             s = roof['streamed']
-            pmc = pmc_record('r03_scatter_add_pmc') or pmc_record('r02_scatter_add_pmc')
+            pmc = pmc_record('r04_scatter_add_pmc') or pmc_record('r03_scatter_add_pmc')
             line['roofline'] = {
                 'bound': 'hbm', 'kernel': 'segment_sum_kernel (pamnet_segment_sum_f32, scatter-add)',
                 'achieved': s['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': s['gbs'] / HBM_PEAK_GBS,

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/tools/scatter_probe.py > /tmp/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/${PROBE:-tools/scatter_probe.py} > /tmp/pmc_$c.log 2>&1
 done
 python - <<'PY' > $R/gpurun_out/${PMC_OUT:-r03_scatter_add_pmc.json}
 import csv, glob, json
@@ -25,18 +25,19 @@ traffic = (2.0 * fetch + write) * 1024.0
 print(json.dumps({'kernel': 'segment_sum_kernel', 'FETCH_SIZE_KB': fetch, 'WRITE_SIZE_KB': write, 'launches': [n1, n2],
                   'traffic_bytes_per_launch': traffic, 'algorithmic_bytes_per_launch': alg,
                   'traffic_over_algorithmic': traffic / alg,
-                  'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python tools/scatter_probe.py; traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction)'}))
+                  'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python ' + __import__('os').environ.get('PROBE', 'tools/scatter_probe.py') + '; traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction)'}))
 PY
 cat $R/gpurun_out/${PMC_OUT:-r03_scatter_add_pmc.json}
 # kernel-trace statistics of the same probe (average launch duration of the roofline kernel)
 rm -rf /tmp/stat_scatter
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stat_scatter -- python $R/tools/scatter_probe.py > /dev/null 2>&1
-python - <<'PY' > $R/gpurun_out/r03_scatter_add_kernel_stats.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stat_scatter -- python $R/${PROBE:-tools/scatter_probe.py} > /dev/null 2>&1
+python - <<'PY' > $R/gpurun_out/${STATS_OUT:-r03_scatter_add_kernel_stats.txt}
 import csv, glob
 f = glob.glob('/tmp/stat_scatter/**/*kernel_stats.csv', recursive=True)[0]
-print('rocprofv3 --kernel-trace --stats -- python tools/scatter_probe.py   (streamed [3913672,128] -> [272034,128], 2.14 GB)')
+import os
+print('rocprofv3 --kernel-trace --stats -- python %s   (%s)' % (os.environ.get('PROBE', 'tools/scatter_probe.py'), os.environ.get('PROBE_NOTE', 'streamed [3913672,128] -> [272034,128], 2.14 GB')))
 for r in csv.DictReader(open(f)):
     if 'segment_sum' in r['Name']:
         print('%s\n  calls %s  average %.1f us  min %.1f us  max %.1f us' % (r['Name'][:120], r['Calls'], float(r['AverageNs']) / 1e3, float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3))
 PY
-cat $R/gpurun_out/r03_scatter_add_kernel_stats.txt
+cat $R/gpurun_out/${STATS_OUT:-r03_scatter_add_kernel_stats.txt}

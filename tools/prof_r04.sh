@@ -1,0 +1,31 @@
+# Round-4 evidence bundle (run on the GPU box; copies land in gpurun_out/r04_*, to be committed under profiles/):
+#   kernel stats + per-step budget + main-queue timeline of the bench command, MFMA-pipe utilisation (PMC pass), scatter-add
+#   HBM traffic (PMC passes) + its kernel statistics, fused edge-kernel traffic at the PDBbind shape (PMC passes) + their
+#   micro-benchmark, host-phase profiles, kernel budgets of the RNA / PDBbind steps through the store, forward splits, the
+#   parity figures the tests print, the bench line.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+bash $R/tools/prof_step.sh > /dev/null 2>&1
+cp $O/step_budget.txt $O/r04_step_budget.txt
+python $R/tools/speed_of_light.py $O/r04_step_budget.txt > $O/r04_speed_of_light.txt
+cp $(ls $O/prof_step/*/*_kernel_stats.csv | head -1) $O/r04_kernel_stats.csv
+python $R/tools/step_timeline.py $(ls $O/prof_step/*/*_kernel_trace.csv | head -1) > $O/r04_step_timeline.txt
+bash $R/tools/pmc_mfma.sh > /dev/null 2>&1
+cp $O/mfma_util.txt $O/r04_mfma_util_pmc.txt
+PMC_OUT=r04_scatter_add_pmc.json STATS_OUT=r04_scatter_add_kernel_stats.txt bash $R/tools/pmc_scatter.sh > /dev/null 2>&1
+PROBE=tools/perm_probe.py PROBE_NOTE='transposed-CSR gather form at the PDBbind B=32 shape' PMC_OUT=r04_perm_segment_sum_pmc.json STATS_OUT=r04_perm_segment_sum_kernel_stats.txt bash $R/tools/pmc_scatter.sh > /dev/null 2>&1
+PMC_OUT=r04_edge_agg_pmc.json bash $R/tools/pmc_edge_agg.sh > /dev/null 2>&1
+(python $R/tools/agg_bench.py qm9 2>/dev/null; python $R/tools/agg_bench.py pdbbind 2>/dev/null) | grep -v amdgpu.ids > $O/r04_edge_agg_microbench.txt
+for k in rna qm9 pdbbind; do python $R/tools/host_phases_r3.py $k 2>/dev/null | grep -v amdgpu.ids > $O/r04_host_phases_$k.txt; done
+for k in rna pdbbind; do
+  rm -rf /tmp/p_$k
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/p_$k -- python $R/tools/store_steps.py $k 60 > /tmp/p_$k.log 2>&1
+  f=$(find /tmp/p_$k -name '*kernel_trace.csv' | head -1)
+  (grep ms/step /tmp/p_$k.log; python $R/tools/step_profile.py $f 60) > $O/r04_${k}_step_budget.txt
+  python $R/tools/step_timeline.py $f 30 > $O/r04_${k}_step_timeline.txt
+done
+(python $R/tools/fwd_store_pipe.py qm9 2>/dev/null; python $R/tools/fwd_store_pipe.py rna 2>/dev/null; python $R/tools/store_steps.py qm9 300 2>/dev/null; python $R/tools/store_steps.py rna 200 2>/dev/null; python $R/tools/store_steps.py pdbbind 60 2>/dev/null) | grep -v amdgpu.ids > $O/r04_forward_and_store_steps.txt
+cd $R && python -m pytest tests/test_hip_model.py tests/test_store.py -m gpu -q -s -k "baseline or trainer_step_path or large_batch or configs1" 2>/dev/null | grep -E "vs the reference|vs oracle|12 targets|Trainer.forward_backward|through the store|passed|failed" > $O/r04_parity_figures.txt
+cd $R && python bench.py 2>/dev/null | tail -1 > $O/r04_bench_line.json
+ls -la $O | grep r04_
