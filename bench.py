@@ -118,11 +118,12 @@ def step_kernel_rooflines(dev, g, d, n_layer):
     n, eg, el, tp = g.n, g.glob.m, g.loc.m, g.tp.m
     rnd = lambda *s: torch.randn(*s, device=dev) * 0.5
     out = []
-    # engine.hip, global layer backward with the chain's ten tail jobs riding in the next chain launch: the layer's own
-    # launch holds 3 node-level jobs (mlp_x1 and the two node-side projection blocks of W_m) + 2 edge-level ones (W_e,
-    # W_edge_attr), and reduces the previous batch's partials in the same launch -- `wgrad_fused_kernel` in the step's trace
+    # engine.hip, backward of a layer pair with the chains' ten tail jobs riding in chain launches: the pair's own jobs are ONE
+    # launch -- the local layer's 11 (mlp_x1, the four node-side projection blocks, the four edge-side blocks, the two
+    # triplet/pair MLP layers) + the global layer's 5 (mlp_x1, two node-side blocks, W_e, W_edge_attr) -- which also reduces
+    # the previous batch's partials: `wgrad_fused_kernel` in the step's trace
     keep, jobs = [], []
-    for rows, cnt in ((n, 3), (eg, 2)):
+    for rows, cnt in ((n, 5), (el, 4), (tp, 2), (n, 3), (eg, 2)):
         for _ in range(cnt):
             dz, a, dw = rnd(rows, d), rnd(rows, d), torch.empty(d, d, device=dev)
             keep += [dz, a, dw]
@@ -132,18 +133,19 @@ def step_kernel_rooflines(dev, g, d, n_layer):
     fn()
     ms, _ = event_time_ms(fn, 30, 3)
     dw_.flush()
-    fl = 2.0 * d * d * (3 * n + 2 * eg)
+    fl = 2.0 * d * d * (8 * n + 4 * el + 2 * tp + 2 * eg)
     # The kernel computes fp32-accurate products on the bf16 matrix pipe (three exact bf16 pieces per operand, six bf16
     # MFMAs per 32 rows: csrc/gemm_core.h "bf16x6"): `frac` stays against the fp32-MFMA peak the path is priced on
     # (SURVEY 8d); `frac_bf16x6` prices the same algorithmic FLOPs against the ceiling of the instruction stream it
     # actually issues, dense bf16 peak / 6.
-    out.append({'kernel': 'wgrad_fused_kernel via pamnet_wgrad_deferred_f32 (a global layer\'s own launch in the step: 3 node-level '
-                          '+ 2 edge-level dW, plus the fixed-order reduction of the previous batch)', 'bound': 'mfma',
+    out.append({'kernel': 'wgrad_fused_kernel via pamnet_wgrad_deferred_f32 (a layer pair\'s own launch in the step: 8 node-level + '
+                          '4 local-edge + 2 triplet/pair + 2 global-edge dW, plus the fixed-order reduction of the previous batch)',
+                'bound': 'mfma',
                 'flops_per_launch': fl, 'us_per_launch': ms * 1e3, 'achieved': fl / ms / 1e9, 'peak': FP32_MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS,
                 'arithmetic': 'fp32-accurate on v_mfma_f32_16x16x32_bf16 (3 exact bf16 pieces per operand, 6 products)',
                 'peak_bf16x6': BF16_MFMA_PEAK_TFLOPS / 6.0, 'frac_bf16x6': fl / ms / 1e9 / (BF16_MFMA_PEAK_TFLOPS / 6.0),
-                'launches_per_step': 2 * n_layer - 1})
+                'launches_per_step': n_layer - 1})
     Wm, bm, Wea = rnd(d, 3 * d) / 8, rnd(d), rnd(d, d) / 8
     e, Pi, Pj, x1 = rnd(eg, d), rnd(n, d), rnd(n, d), rnd(n, d)
     z, ea, x2 = torch.empty(eg, d, device=dev), torch.empty(eg, d, device=dev), torch.empty(n, d, device=dev)
