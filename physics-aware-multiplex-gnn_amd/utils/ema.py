@@ -33,6 +33,7 @@ class EMA(object):
         ps = [p for n, p in model.named_parameters() if p.requires_grad]
         assert len(ps) == len(self._shadow), 'model does not match the one this EMA was built from'
         return ps
+    # (models.PAMNet caches its parameter walk, so this is a list copy per call, not a walk of ~250 sub-modules)
 
     @torch.no_grad()
     def __call__(self, model, num_updates=99999):
