@@ -23,8 +23,12 @@ lib.load()
 plib = ctypes.CDLL(so)
 dev = torch.device('cuda:0')
 D = 128
-b = synth.qm9_batch(0, 0, 128).to(dev)
-g = G.build_graph('QM9', 5.0, 5.0, 'source_to_target', b.x, b.batch, b.pos, b.edge_index, num_graphs=128)
+if len(sys.argv) > 1 and sys.argv[1] == 'pdbbind':        # the shape where the kernels walk many chunks (probe: last chunk)
+    b = synth.collate([synth.pdbbind_complex(1, i) for i in range(32)]).to(dev)
+    g = G.build_graph('PDBbind', 2.0, 6.0, 'source_to_target', b.x, b.batch, num_graphs=32)
+else:
+    b = synth.qm9_batch(0, 0, 128).to(dev)
+    g = G.build_graph('QM9', 5.0, 5.0, 'source_to_target', b.x, b.batch, b.pos, b.edge_index, num_graphs=128)
 n, eg = g.n, g.glob.m
 rnd = lambda *s: torch.randn(*s, device=dev) * 0.5
 Wm, bm, Wea = rnd(D, 3 * D) / 8, rnd(D), rnd(D, D) / 8
