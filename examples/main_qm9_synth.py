@@ -31,7 +31,7 @@ def run_target(args, cfg, target, dev, world, rank):
     model = (PAMNet if args.model == 'PAMNet' else PAMNet_s)(cfg).to(dev)
     trainer = Trainer(model, lr=args.lr, weight_decay=args.wd, ema_decay=0.999, max_grad_norm=1000.0, world_size=world)
     if rank == 0:
-        print('Target %d. Number of model parameters: ' % target, sum(p.numel() for p in model.parameters() if p.requires_grad))
+        print('Target %d. Number of model parameters: ' % target, sum(v.numel() for v in model.state_dict().values()))    # (the reference's shapes: a dim without a kernel family of its own is held zero-padded)
     gb = args.batch_size
     steps_per_epoch = args.train // gb
     sched = WarmupExpLR(args.lr, gamma=0.9961697, steps_per_epoch=args.train / gb)
