@@ -49,6 +49,9 @@ def parse():
                     help='N=1 only: run the bucketed gradient all-reduce through a 1-rank RCCL group (overhead check)')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--stream-gb', type=float, default=2.0, help='size of the streamed scatter-add roofline probe')
+    ap.add_argument('--share-gpu', action='store_true',
+                    help='NOT a measurement: all ranks on cuda:0 with gloo as the transport -- the whole N > 1 flow of the real '
+                         'model (shards, bucketed overlapped all-reduce, exposed-communication probe) on a 1-GPU box')
     ap.add_argument('--cpu-dry-run', action='store_true',
                     help='NOT a measurement: exercise the multi-rank control flow (sharding, barriers, max-over-ranks '
                          'timing, gradient all-reduce) on CPU with the gloo backend and a stand-in module (tests/standin.py)')
@@ -412,7 +415,7 @@ def self_launch(args, result_out):
     GPU, rendezvous on 127.0.0.1 at a port the kernel hands out) and pass rank 0's JSON line through.  Returns the exit code."""
     import socket
     import subprocess
-    if not args.cpu_dry_run and torch.cuda.device_count() < args.gpus:
+    if not args.cpu_dry_run and not args.share_gpu and torch.cuda.device_count() < args.gpus:
         sys.stderr.write('bench.py: --gpus %d but only %d visible\n' % (args.gpus, torch.cuda.device_count()))
         return 2
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -500,11 +503,16 @@ def main():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             dist.init_process_group('gloo')
     else:
+        if args.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device('cuda', local_rank)
         if world > 1:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            dist.init_process_group('nccl', device_id=dev)
+            if args.share_gpu:
+                dist.init_process_group('gloo')
+            else:
+                dist.init_process_group('nccl', device_id=dev)
         elif args.force_comm:
             dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29517', rank=0, world_size=1, device_id=dev)
 
@@ -748,6 +756,8 @@ def main():
             'reference_loop_unchanged': ref_loop,
             'mfma': mfma_summary(args, g, ms_per_step),
         }
+        if args.share_gpu:
+            line['shared_gpu'] = 'all %d ranks on one device, gloo transport: a flow check, NOT a measurement' % world
         if not args.no_rooflines:
             roof = scatter_add_roofline(dev, g, args.dim, args.stream_gb)
             s = roof['streamed']

@@ -427,17 +427,21 @@ def test_direct_tape_backward_equals_autograd(kind):
     assert torch.equal(direct, via_autograd)
 
 
-def _pamnet_rank(rank, world, port, out, total):
-    """One rank of the 2-GPU PAMNet step: its own device, RCCL, its molecule shard of the global batch."""
+def _pamnet_rank(rank, world, port, out, total, shared_gpu=False):
+    """One rank of the 2-rank PAMNet step: its molecule shard of the global batch, on its own device over RCCL -- or, with
+    shared_gpu, on the box's one device with gloo carrying the (device-resident) gradient slices between the processes."""
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for p_ in (os.path.dirname(here), os.path.join(os.path.dirname(here), 'physics-aware-multiplex-gnn_amd')):
         if p_ not in sys.path:
             sys.path.insert(0, p_)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-    torch.cuda.set_device(rank)
-    dev = torch.device('cuda', rank)
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    torch.cuda.set_device(0 if shared_gpu else rank)
+    dev = torch.device('cuda', 0 if shared_gpu else rank)
+    if shared_gpu:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    else:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     import models
     from pamnet_amd import synth
     from pamnet_amd.train import Trainer, shard_range
@@ -460,18 +464,10 @@ def _pamnet_rank(rank, world, port, out, total):
     dist.destroy_process_group()
 
 
-@pytest.mark.gpu
-def test_pamnet_two_rank_rccl_step_equals_global_batch_step(tmp_path):
-    """PAMNet (d=128, L=2) on TWO GPUs over RCCL: shard by molecule (13 + 12), pre-scale by local/global graphs,
-    bucketed all-reduce overlapped with the backward, identical update -- equals the single-process step on the global
-    batch (what test_dp_matches_single_process shows for the CPU stand-in).  Needs two devices: skipped on a 1-GPU box."""
-    if torch.cuda.device_count() < 2:
-        pytest.skip('needs 2 GPUs (this box has %d)' % torch.cuda.device_count())
+def _check_two_rank_result(out, total):
     import models
     from pamnet_amd import synth
     from pamnet_amd.train import Trainer
-    total, out = 25, str(tmp_path / 'dp2.pt')
-    mp.spawn(_pamnet_rank, args=(2, _free_port(), out, total), nprocs=2, join=True)
     got, init = torch.load(out), torch.load(out + '.init')
     dev = torch.device('cuda:0')
     model = models.PAMNet(models.Config(dataset='QM9', dim=128, n_layer=2, cutoff_l=5.0, cutoff_g=5.0))
@@ -485,3 +481,50 @@ def test_pamnet_two_rank_rccl_step_equals_global_batch_step(tmp_path):
     assert float(d) < 1e-5, float(d)
     assert float((got['shadow'] - tr.shadow.cpu()).abs().max()) < 1e-5
     assert abs(got['norm'] / float(tr.last_grad_norm) - 1) < 1e-4
+
+
+@pytest.mark.gpu
+def test_pamnet_two_ranks_on_one_gpu_step_equals_global_batch_step(tmp_path):
+    """The molecule-sharded step of the REAL model with world_size = 2 on a 1-GPU box: two processes share the device, the
+    process group is gloo (it carries device tensors through the host) -- everything but the transport is what runs on 8
+    GPUs: rank 0's parameters broadcast, shards of 13 + 12 molecules, gradients pre-scaled by local / global graphs and
+    written in place by the kernels, the flat buffer tiled into buckets by layer pair, the engine's per-pair events gating
+    each bucket's all-reduce on the communication stream, the identical fused update on both ranks.  Result = the
+    single-process step on the 25-molecule batch."""
+    total, out = 25, str(tmp_path / 'dp2_shared.pt')
+    mp.spawn(_pamnet_rank, args=(2, _free_port(), out, total, True), nprocs=2, join=True)
+    _check_two_rank_result(out, total)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_runs_the_multi_rank_flow():
+    """`python bench.py --gpus 2 --share-gpu`: the driver's N > 1 invocation of the REAL bench (self-launch, one JSON line from
+    rank 0, barrier + max-over-ranks timing, the bucketed overlapped gradient exchange and the exposed-communication probe),
+    both ranks on this box's one device with gloo as the transport.  Not a measurement (the line says so)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    cmd = [sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--share-gpu', '--steps', '6', '--warmup', '2',
+           '--batch-per-gpu', '32', '--n-layer', '2', '--no-rooflines', '--no-cpu-baseline', '--no-other-configs']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=repo, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), r.stdout
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['config']['global_batch'] == 64 and j['scaling'] == 'weak' and 'shared_gpu' in j
+    assert j['comm'] and j['comm']['buckets'] >= 2 and j['comm']['gradient_bytes'] > 0
+    assert abs(j['value'] - 64 * 6 / (j['ms_per_step'] * 6e-3)) < 1e-6 * j['value']
+
+
+@pytest.mark.gpu
+def test_pamnet_two_rank_rccl_step_equals_global_batch_step(tmp_path):
+    """PAMNet (d=128, L=2) on TWO GPUs over RCCL: shard by molecule (13 + 12), pre-scale by local/global graphs,
+    bucketed all-reduce overlapped with the backward, identical update -- equals the single-process step on the global
+    batch (what test_dp_matches_single_process shows for the CPU stand-in).  Needs two devices: skipped on a 1-GPU box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs (this box has %d)' % torch.cuda.device_count())
+    total, out = 25, str(tmp_path / 'dp2.pt')
+    mp.spawn(_pamnet_rank, args=(2, _free_port(), out, total), nprocs=2, join=True)
+    _check_two_rank_result(out, total)
