@@ -561,6 +561,19 @@ __device__ __forceinline__ void knn_topk(const unsigned (&dv)[NC], const int (&j
 // handling and the sort work on them alone.  Massive ties (interval closed with more than KNN_SURV survivors) take
 // the same code over the whole cache.
 constexpr int KNN_SURV = 256;
+// Development aid (tools/knn_probe.py compiles a private copy with -DKNN_PHASE_CUT=n): the selection returns after phase n
+// with a value that keeps the phase's work alive.  Never defined in libpamnet_hip.so.
+#ifdef KNN_PHASE_CUT
+#define KNN_CUT(n, v)                                     \
+    do {                                                  \
+        if (KNN_PHASE_CUT == (n)) {                       \
+            bd = __uint_as_float(v), bj = (int)(v);       \
+            return;                                       \
+        }                                                 \
+    } while (0)
+#else
+#define KNN_CUT(n, v)
+#endif
 
 __device__ __forceinline__ void knn_select(const float* __restrict__ pos, float xi, float yi, float zi, int beg, int end,
                                            int K, int lane, float* sd, int* sj, unsigned* vd, int* vj, float& bd,
@@ -592,6 +605,7 @@ __device__ __forceinline__ void knn_select(const float* __restrict__ pos, float 
     }
     unsigned lo = (mn != 0xffffffffu && zeros < kk) ? mn : 0u, hi = mx;
     int cnt_hi = end - beg;                                 // #(d <= hi), always >= kk
+    KNN_CUT(1, mx);                                         // (development probe: the distance pass alone)
     while (lo < hi && cnt_hi > KNN_SURV) {
         const unsigned mid = lo + ((hi - lo) >> 1);
         int c_lane = 0;
@@ -607,6 +621,7 @@ __device__ __forceinline__ void knn_select(const float* __restrict__ pos, float 
         for (int b = 0; b < 7; ++b) tot += __popcll(__ballot((c_lane >> b) & 1)) << b;
         if (tot >= kk) { hi = mid; cnt_hi = tot; } else lo = mid + 1;
     }
+    KNN_CUT(2, hi);                                         // (+ the first-stage bisection)
     if (cnt_hi > KNN_SURV) {                                // wave-uniform; more than KNN_SURV candidates tie at lo
         const int none[1] = {0};
         knn_topk<KNN_CACHE, 8, false>(dc, none, beg + lane, iters, kk, lane, sd, sj, bd, bj);
@@ -632,6 +647,7 @@ __device__ __forceinline__ void knn_select(const float* __restrict__ pos, float 
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    KNN_CUT(3, (unsigned)nsurv);                            // (+ the compaction of the survivors)
     unsigned sv[KNN_SURV / 64];
     int svj[KNN_SURV / 64];
 #pragma unroll
@@ -655,6 +671,7 @@ __device__ __forceinline__ void knn_select(const float* __restrict__ pos, float 
         for (int b = 0; b < 3; ++b) tot += __popcll(__ballot((c_lane >> b) & 1)) << b;
         if (tot >= kk) { hi = mid; cnt_hi = tot; } else lo = mid + 1;
     }
+    KNN_CUT(4, hi);                                          // (+ the second-stage bisection)
     if (cnt_hi > 64) {                                       // more than 64 candidates tie at lo: the general selection
         knn_topk<NS, NS, true>(sv, svj, 0, NS, kk, lane, sd, sj, bd, bj);
         return;
@@ -677,6 +694,7 @@ __device__ __forceinline__ void knn_select(const float* __restrict__ pos, float 
     __builtin_amdgcn_wave_barrier();
     bd = sd[lane];
     bj = sj[lane];
+    KNN_CUT(5, (unsigned)bj);                                // (+ the second compaction)
     sort64_pairs(bd, bj, lane);
 }
 
