@@ -513,9 +513,18 @@ class _PAMNetBase(nn.Module):
         self._x_layers = self._graph_cache = self._node_out = None
 
     def _check_dataset(self):
+        self._check_dtype()
         if not (self.dataset in ('QM9', 'PDBbind') or self._rna):
             raise ValueError("Invalid dataset. If you are using any dataset related to RNA 3D structure prediction, "
                              "be sure to use 'rna' as the first 3 characters of the dataset name.")
+
+    def _check_dtype(self):
+        # the kernels read the parameters through raw pointers as fp32: a model cast with .double() / .half() / .bfloat16()
+        # would be read with the wrong element size -- refused instead (first and last parameter: a cast touches all)
+        ps = self._all_params()
+        if ps and (ps[0].dtype != torch.float32 or ps[-1].dtype != torch.float32):
+            raise TypeError('PAMNet on the MI355X kernels computes in float32 (the precision the 1e-5 parity bound needs): '
+                            'parameters are %s -- call model.float()' % ps[0].dtype)
 
 
 def _slice_outgoing(module, state_dict, prefix, local_metadata):
@@ -602,6 +611,7 @@ class PAMNet_s(_PAMNetBase):
     def forward(self, data):
         if self.dataset != "QM9":
             raise ValueError("Invalid dataset. The current PAMNet_s is only for QM9 experiments.")
+        self._check_dtype()
         self._release_inspection()
         g = self._graph(data)
         if self._one_node():

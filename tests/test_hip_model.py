@@ -145,6 +145,27 @@ def test_any_dim_keeps_the_reference_state_dict_layout(dataset, dim, small):
         models.PAMNet(models.Config(dataset='QM9', dim=130, n_layer=1, cutoff_l=5.0, cutoff_g=5.0))
 
 
+def test_cast_models_are_refused():
+    """The kernels read parameters as fp32 through raw pointers: a model cast to another floating type raises instead of
+    being read with the wrong element size (the reference runs in whatever dtype it is cast to; this path is fp32 by
+    construction)."""
+    import models
+
+    class D:
+        x = torch.zeros(3)
+        batch = torch.zeros(3, dtype=torch.long)
+        pos = torch.zeros(3, 3)
+        edge_index = torch.zeros(2, 0, dtype=torch.long)
+    for cls in (models.PAMNet, models.PAMNet_s):
+        m = cls(models.Config(dataset='QM9', dim=16, n_layer=1, cutoff_l=5.0, cutoff_g=5.0))
+        for cast in ('double', 'half', 'bfloat16'):
+            with pytest.raises(TypeError, match='float32'):
+                getattr(m, cast)()(D())
+        m.float()
+        with pytest.raises(RuntimeError):               # fp32 again: gets as far as "kernels run on an MI355X only" (CPU tensors)
+            m(D())
+
+
 def test_invalid_dataset_raises():
     import models
     cfg = models.Config(dataset='nope', dim=16, n_layer=1, cutoff_l=2.0, cutoff_g=5.0)
