@@ -518,6 +518,16 @@ class _PAMNetBase(nn.Module):
             raise ValueError("Invalid dataset. If you are using any dataset related to RNA 3D structure prediction, "
                              "be sure to use 'rna' as the first 3 characters of the dataset name.")
 
+    def _on_own_device(self, fn, data):
+        """The library launches on the raw stream of the tensors' device; HIP wants that device current.  A model that lives
+        on another device than the thread's current one (model.to('cuda:1') without torch.cuda.set_device) runs under a
+        device guard instead of failing in the first launch."""
+        dev = self.rbf_g.freq.device
+        if dev.type == 'cuda' and dev.index is not None and dev.index != torch.cuda.current_device():
+            with torch.cuda.device(dev):
+                return fn(data)
+        return fn(data)
+
     def _check_dtype(self):
         # the kernels read the parameters through raw pointers as fp32: a model cast with .double() / .half() / .bfloat16()
         # would be read with the wrong element size -- refused instead (first and last parameter: a cast touches all)
@@ -568,6 +578,9 @@ class PAMNet(_PAMNetBase):
 
     def forward(self, data):
         self._check_dataset()
+        return self._on_own_device(self._forward, data)
+
+    def _forward(self, data):
         self._release_inspection()
         g = self._graph(data)
         if self._one_node():
@@ -612,6 +625,9 @@ class PAMNet_s(_PAMNetBase):
         if self.dataset != "QM9":
             raise ValueError("Invalid dataset. The current PAMNet_s is only for QM9 experiments.")
         self._check_dtype()
+        return self._on_own_device(self._forward, data)
+
+    def _forward(self, data):
         self._release_inspection()
         g = self._graph(data)
         if self._one_node():
