@@ -139,13 +139,22 @@ struct GAggFwd {
 
 // PRE: the next chunk's e rows travel in registers while this chunk's GEMMs run (multi-chunk workgroups); the 9-tile
 // instantiation (one chunk per workgroup at ~128 rows give or take half a node) has no registers to spare for it.
-template <int MTX, bool PRE, bool SAVE>
+// PL: the e rows wait in LDS as bf16 piece planes, split by the thread that stages them (edge_core.h "piece planes": once
+// per workgroup instead of once per wave); a tile's 12 KB slot takes the tile's z accumulators (fp32, 8.4 KB) once its
+// GEMMs are done.
+template <int MTX, bool PRE, bool SAVE, bool PL = false>
 __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
+    constexpr int FT = 16 * LDT * 4;                        // bytes of an fp32 tile
+    __shared__ __attribute__((aligned(16))) char ldsb[PL ? MTX * (PTILE + FT) : 2 * MTX * FT];
     __shared__ int sptr[NMAX + 1];
     __shared__ float4 carry[2][32];                         // running sum of a node that spans two chunks (in / out)
-    float* S0 = lds;
-    float* S1 = lds + MTX * 16 * LDT;
+    float* S0 = reinterpret_cast<float*>(ldsb);             // (!PL) e rows, then z
+    char* P = ldsb;                                         // (PL)  e pieces per tile, then that tile's z
+    float* S1 = reinterpret_cast<float*>(ldsb + (PL ? MTX * PTILE : MTX * FT));
+    auto stage_e = [&](int r, int c4_, const float4& v) {
+        if constexpr (PL) st_pieces4(P, r, c4_, v);
+        else st_lds4(S0, r, c4_, v);
+    };
     constexpr int CAP = MTX * 16;
     const float* __restrict__ e = a.e;
     const float* __restrict__ Pi = a.Pi;
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
             if (PRE) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
-                    if (RPP * i < 16 * mt) st_lds4(S0, rr + RPP * i, c4, pre[i]);
+                    if (RPP * i < 16 * mt) stage_e(rr + RPP * i, c4, pre[i]);
                 if (r1 < re) {
 #pragma unroll
                     for (int i = 0; i < NI; ++i) pre[i] = ldg4z_nt(e, r1 + rr + RPP * i, re, DIM, c4);
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
             } else {
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
-                    if (RPP * i < 16 * mt) st_lds4(S0, rr + RPP * i, c4, ldg4z_nt(e, r0 + rr + RPP * i, r1, DIM, c4));
+                    if (RPP * i < 16 * mt) stage_e(rr + RPP * i, c4, ldg4z_nt(e, r0 + rr + RPP * i, r1, DIM, c4));
             }
             APROBE(23);
             if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = myp;
@@ -245,7 +254,8 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
                 auto gemm = [&]() {
                     ag.zero();
                     az.zero();
-                    mma_b16<SC, false, (PRE ? 1 : 3)>(S0 + goff * LDT, f1, az.a[0], f2, ag.a[0], smt);
+                    if constexpr (PL) mma_p16<SC, false, (PRE ? 1 : 3)>(P + sb * SC * PTILE, f1, az.a[0], f2, ag.a[0], smt);
+                    else mma_b16<SC, false, (PRE ? 1 : 3)>(S0 + goff * LDT, f1, az.a[0], f2, ag.a[0], smt);
                 };
                 auto epi = [&]() {
                     float4 zz[SC], gate[SC];
@@ -253,13 +263,24 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
                     for (int i = 0; i < SC; ++i) {
                         const int r = eoff + rr + RPP * i;
                         if (r < 16 * mt) {                     // (the last sub-chunk may hold fewer than SC tiles)
-                            zz[i] = f4add(f4add(lds4(S0, r, c4), gpi[i]), gpj[i]);
+                            const float4 zacc = PL ? lds4(reinterpret_cast<const float*>(P + (r >> 4) * PTILE), r & 15, c4)
+                                                   : lds4(S0, r, c4);
+                            zz[i] = f4add(f4add(zacc, gpi[i]), gpj[i]);
                             gate[i] = lds4(S1, r, c4);
                             st_lds4(S1, r, c4, f4mul(f4silu(zz[i]), gate[i]));  // the message stays on chip
+                            if constexpr (SAVE && PL) {        // (piece-plane form: stores first, see below)
+                                if (r0 + r < r1) {
+                                    stg4_nt(zs, r0 + r, DIM, c4, zz[i]);
+                                    stg4_nt(eas, r0 + r, DIM, c4, gate[i]);
+                                }
+                            }
                         }
                     }
-                    if (sb < nsub) gather(sb);                 // the next epilogue's node rows: a whole stage of lead
-                    if (SAVE) {                                // backward-only saves (inference instantiation: none)
+                    // the next epilogue's node rows: a whole stage of lead.  In the piece-plane form the saves are issued
+                    // BEFORE them -- the values die at their store, which keeps the kernel inside 256 registers; the stores
+                    // have the whole next GEMM stage to retire before anything waits behind them (vmcnt retires in order).
+                    if (sb < nsub) gather(sb);
+                    if (SAVE && !PL) {                         // backward-only saves (inference instantiation: none)
 #pragma unroll
                         for (int i = 0; i < SC; ++i) {
                             const int64_t g = r0 + eoff + rr + RPP * i;
@@ -273,14 +294,17 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
                 APROBE(3 + 4 * sb);
                 if (do_g) gemm();
                 APROBE(4 + 4 * sb);
-                if (do_e) epi();
-                APROBE(5 + 4 * sb);
+                // ONE barrier per stage: every wave is done reading the e rows of sub-chunk sb (their slots take the
+                // accumulators now), and the accumulators stored in stage sb - 1 are visible to the epilogue below.  The
+                // accumulators leave before the epilogue starts: they are not live across it (24 registers).
+                __syncthreads();
                 if (do_g) {
-                    __syncthreads();                           // every wave is done reading the e rows of sub-chunk sb
-                    store_set<SC, 1>(az, S0 + goff * LDT, wc, bv, smt);
+                    if constexpr (PL) store_set<SC, 1>(az, reinterpret_cast<float*>(P + sb * SC * PTILE), wc, bv, smt, PTILE / 4);
+                    else store_set<SC, 1>(az, S0 + goff * LDT, wc, bv, smt);
                     store_set<SC, 1>(ag, S1 + goff * LDT, wc, zero_bias, smt);
-                    __syncthreads();
                 }
+                APROBE(5 + 4 * sb);
+                if (do_e) epi();
                 APROBE(6 + 4 * sb);
             }
         } else if ((int)threadIdx.x <= nn) {
@@ -313,13 +337,18 @@ struct GAggBwd {
 // PRE (multi-chunk workgroups): the z / ea rows of the NEXT chunk are requested while this chunk's tiles are being reduced and
 // multiplied -- a workgroup is alone on its CU, so without it the memory phase and the GEMM phase of a chunk alternate and
 // the HBM idles during the GEMMs of all 256 workgroups at once.
-template <int MTX, bool PRE = false>
+// PL: the two GEMM operands (d z, d ea) wait in LDS as bf16 piece planes written by the sweep that computes them
+// (edge_core.h "piece planes": the split once per workgroup instead of once per wave); d z also as fp32 for the node sums.
+template <int MTX, bool PRE = false, bool PL = false>
 __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
+    constexpr int FT = 16 * LDT * 4;                         // bytes of an fp32 tile
+    __shared__ __attribute__((aligned(16))) char ldsb[PL ? MTX * (FT + 2 * PTILE) : 2 * MTX * FT];
     __shared__ int sptr[NMAX + 1];
     __shared__ float4 carry[2][32];
-    float* S0 = lds;
-    float* S1 = lds + MTX * 16 * LDT;
+    float* S0 = reinterpret_cast<float*>(ldsb);
+    float* S1 = S0 + MTX * 16 * LDT;                         // (!PL)
+    char* P0 = ldsb + MTX * FT;                              // (PL)
+    char* P1 = P0 + MTX * PTILE;
     constexpr int CAP = MTX * 16;
     const float* __restrict__ d_agg = a.d_agg;
     const float* __restrict__ zs = a.z;
@@ -383,7 +412,12 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
                     stg4(dea, g, DIM, c4, y);
                 }
                 st_lds4(S0, r, c4, x);
-                st_lds4(S1, r, c4, y);
+                if constexpr (PL) {
+                    st_pieces4(P0, r, c4, x);
+                    st_pieces4(P1, r, c4, y);
+                } else {
+                    st_lds4(S1, r, c4, y);
+                }
             }
         }
         if (PRE && r1 < re) {                                  // the next chunk starts at r1: its rows travel during the GEMMs
@@ -415,8 +449,13 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
             if (EARLY && accumulate) fetch_acc();
             AccSet<MTX, 1> acc;
             acc.zero();
-            mma_b16<MTX, true, BG>(S0, f1, acc.a[0], f1, acc.a[0], mt);
-            mma_b16<MTX, true, BG>(S1, f2, acc.a[0], f2, acc.a[0], mt);
+            if constexpr (PL) {
+                mma_p16<MTX, true, BG>(P0, f1, acc.a[0], f1, acc.a[0], mt);
+                mma_p16<MTX, true, BG>(P1, f2, acc.a[0], f2, acc.a[0], mt);
+            } else {
+                mma_b16<MTX, true, BG>(S0, f1, acc.a[0], f1, acc.a[0], mt);
+                mma_b16<MTX, true, BG>(S1, f2, acc.a[0], f2, acc.a[0], mt);
+            }
             APROBE(5);
             // otherwise requested here (the A fragments' registers are free again): the two barriers and the accumulator
             // stores cover the latency
@@ -564,6 +603,12 @@ inline int pick_mtx(int64_t m, int64_t grid) {
     // workgroups walk several balanced chunks of <= 128 rows
     return per <= 40 ? 3 : (per <= 72 ? 5 : (per <= 132 ? 9 : 8));
 }
+// PAMNET_AGG_PIECES=0: the multi-chunk kernels without piece planes (every wave splits its own A fragments) -- the form
+// before round 4's issue-slot measurement, kept for A/B timing (read once).
+inline bool agg_pieces() {
+    static bool v = [] { const char* e = getenv("PAMNET_AGG_PIECES"); return !e || atoi(e) != 0; }();
+    return v;
+}
 inline int64_t agg_grid(int64_t m) {
     const int64_t g = ceil_div(m, 16);
     return g < 1 ? 1 : (g > N_CU ? N_CU : g);
@@ -592,11 +637,19 @@ extern "C" int pamnet_global_edge_agg_fwd_f32(const float* e, int64_t n_edges, i
         if (save) hipLaunchKernelGGL((global_edge_agg_fwd_kernel<MTX, PRE, true>), dim3((unsigned)grid), dim3(WG8), 0, st, a); \
         else hipLaunchKernelGGL((global_edge_agg_fwd_kernel<MTX, PRE, false>), dim3((unsigned)grid), dim3(WG8), 0, st, a);    \
     } while (0)
-    switch (pick_mtx(n_edges, grid)) {
-        case 3: PAMNET_AGG_FWD(3, true); break;
-        case 5: PAMNET_AGG_FWD(5, true); break;
-        case 9: PAMNET_AGG_FWD(9, false); break;
-        default: PAMNET_AGG_FWD(8, true); break;      // (5-tile chunks measured the same in training, 4 % slower in inference)
+    if (agg_pieces()) {
+        // Piece-plane form, 7-tile chunks with the next chunk's rows in flight, for every size: at the PDBbind shape 381 us
+        // in training / 323 in inference against 426 / 377 for the reader-side split; at the QM9 batch (one and a bit
+        // chunks per workgroup) 26.0 / 22.6 against 28.9 / 26.8 for the 9-tile single-chunk form; B = 16 .. 64 likewise.
+        if (save) hipLaunchKernelGGL((global_edge_agg_fwd_kernel<7, true, true, true>), dim3((unsigned)grid), dim3(WG8), 0, st, a);
+        else hipLaunchKernelGGL((global_edge_agg_fwd_kernel<7, true, false, true>), dim3((unsigned)grid), dim3(WG8), 0, st, a);
+    } else {
+        switch (pick_mtx(n_edges, grid)) {
+            case 3: PAMNET_AGG_FWD(3, true); break;
+            case 5: PAMNET_AGG_FWD(5, true); break;
+            case 9: PAMNET_AGG_FWD(9, false); break;
+            default: PAMNET_AGG_FWD(8, true); break;  // (5-tile chunks measured the same in training, 4 % slower in inference)
+        }
     }
 #undef PAMNET_AGG_FWD
     PAMNET_LAUNCH_CHECK();
@@ -636,14 +689,20 @@ extern "C" int pamnet_global_edge_agg_bwd_f32(const float* d_agg, int64_t n_edge
               (int)accumulate};
     const int64_t grid = agg_grid(n_edges);
     hipStream_t st = as_stream(stream);
-    switch (pick_mtx(n_edges, grid)) {
-        case 3: hipLaunchKernelGGL(global_edge_agg_bwd_kernel<3>, dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
-        case 5: hipLaunchKernelGGL(global_edge_agg_bwd_kernel<5>, dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
-        case 9: hipLaunchKernelGGL(global_edge_agg_bwd_kernel<9>, dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
-        default:      // several chunks per workgroup: 3-tile chunks with the next chunk's rows in flight (712 us at the PDBbind
+    if (agg_pieces()) {
+        // Piece-plane form, 3-tile chunks with the next chunk's rows in flight, for every size: PDBbind shape 490 us against
+        // 604 (+ the transposed segment sum: 591 / 704); QM9 batch 34.5 against 42.2 for the 9-tile single-chunk form.
+        hipLaunchKernelGGL((global_edge_agg_bwd_kernel<3, true, true>), dim3((unsigned)grid), dim3(WG8), 0, st, a);
+    } else {
+        switch (pick_mtx(n_edges, grid)) {
+            case 3: hipLaunchKernelGGL(global_edge_agg_bwd_kernel<3>, dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
+            case 5: hipLaunchKernelGGL(global_edge_agg_bwd_kernel<5>, dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
+            case 9: hipLaunchKernelGGL(global_edge_agg_bwd_kernel<9>, dim3((unsigned)grid), dim3(WG8), 0, st, a); break;
+            default:  // several chunks per workgroup: 3-tile chunks with the next chunk's rows in flight (712 us at the PDBbind
                       // shape against 803 for 8-tile chunks without, 726 for 4-tile chunks with the prefetch)
-            hipLaunchKernelGGL((global_edge_agg_bwd_kernel<3, true>), dim3((unsigned)grid), dim3(WG8), 0, st, a);
-            break;
+                hipLaunchKernelGGL((global_edge_agg_bwd_kernel<3, true>), dim3((unsigned)grid), dim3(WG8), 0, st, a);
+                break;
+        }
     }
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;

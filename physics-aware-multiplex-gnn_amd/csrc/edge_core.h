@@ -86,14 +86,16 @@ __device__ __forceinline__ void mma_n(const float* __restrict__ As, const WFrag1
     }
 }
 // D[row][wc + col] = acc + bias for the live tiles (accumulator layout: rows 4*(lane>>4) + r, column lane & 15)
+// (tstride: floats between consecutive 16-row tiles -- 16 LDT for a plain tile array)
 template <int MTX>
-__device__ __forceinline__ void acc_store(const Acc<MTX>& acc, float* __restrict__ Ds, int wc, float bias, int mt) {
+__device__ __forceinline__ void acc_store(const Acc<MTX>& acc, float* __restrict__ Ds, int wc, float bias, int mt,
+                                          int tstride = 16 * LDT) {
     const int lane = threadIdx.x & 63;
     const int col = wc + (lane & 15), kg = lane >> 4;
 #pragma unroll
     for (int m = 0; m < MTX; ++m) {
         if (m < mt) {
-            float* d = Ds + (m * 16 + kg * 4) * LDT + col;
+            float* d = Ds + m * tstride + kg * 4 * LDT + col;
             d[0 * LDT] = acc.v[m][0] + bias;
             d[1 * LDT] = acc.v[m][1] + bias;
             d[2 * LDT] = acc.v[m][2] + bias;
@@ -202,6 +204,79 @@ __device__ __forceinline__ void mma_b16(const float* __restrict__ As, const WFra
     }
 }
 
+// ---- piece planes: the split done ONCE per workgroup ------------------------------------------------------------------
+// With the fp32 tile in LDS every wave splits every A fragment it reads: 36 VALU per 16 x 32 fragment and wave, eight
+// times over in an 8-wave workgroup -- measured (profiles/r04_issue_slots_pmc.txt) 9 VALU per MFMA in the fused global-edge
+// backward, two thirds of them these splits, and the SIMDs' issue slots -- not the matrix pipe, not HBM -- are what the
+// multi-chunk kernels run out of.  Here the thread that WRITES a tile element (the cooperative sweep: a float4 of one row)
+// splits it and stores the three bf16 pieces in MFMA A-fragment order; a reader's fragment is then three ds_read_b128 and
+// no VALU.  A 16-row tile is 12 KB: [piece][k-step q][chunk] x 16 bytes, chunk = the lane that reads it, swizzled
+//     chunk(rho, kg, q) = (rho + 16 kg) ^ (2 kg + (q & 1))        (row rho = l & 15, k-group kg = l >> 4)
+// so that both sides are conflict-free: a ds_read_b128 group ({rows 0-3, 12-15} of one kg with {rows 4-11} of the next)
+// still covers 16 distinct 16-byte bank groups (the xor keeps each of the two row sets in place or swaps them), and the 16
+// lanes of a ds_write_b64 group -- one row, float4 columns 0..15 or 16..31: four kg x two q x two halves -- land on 16
+// distinct 8-byte bank pairs (the low three bits of the chunk differ for every (kg, q & 1)).
+constexpr int PTILE = 3 * 4 * 1024;           // bytes of a 16-row tile as piece planes
+__device__ __forceinline__ int piece_chunk(int rho, int kg, int q) { return (rho + 16 * kg) ^ (2 * kg + (q & 1)); }
+// row r (of the chunk: tile r >> 4), float4 column c4 of a [rows][128] tile -> its 8 bytes in each piece plane
+__device__ __forceinline__ void st_pieces4(char* __restrict__ P, int r, int c4, const float4& v) {
+    const int q = c4 >> 3, kg = (c4 >> 1) & 3;
+    char* d = P + (r >> 4) * PTILE + q * 1024 + piece_chunk(r & 15, kg, q) * 16 + (c4 & 1) * 8;
+    uint32_t a0, b0, c0, a1, b1, c1;
+    split3(v.x, v.y, a0, b0, c0);
+    split3(v.z, v.w, a1, b1, c1);
+    *reinterpret_cast<uint2*>(d) = make_uint2(a0, a1);
+    *reinterpret_cast<uint2*>(d + 4096) = make_uint2(b0, b1);
+    *reinterpret_cast<uint2*>(d + 8192) = make_uint2(c0, c1);
+}
+// A fragment (rows 16 m + (l & 15), k = 32 q + 8 (l >> 4) + 0..7) of a piece-plane tile: three 16-byte reads
+__device__ __forceinline__ Frag3 lds_frag3p(const char* __restrict__ P, int m, int q) {
+    const int lane = threadIdx.x & 63;
+    const char* s = P + m * PTILE + q * 1024 + piece_chunk(lane & 15, lane >> 4, q) * 16;
+    Frag3 f;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+        const uint4 u = *reinterpret_cast<const uint4*>(s + pc * 4096);
+        f.p[pc][0] = u.x, f.p[pc][1] = u.y, f.p[pc][2] = u.z, f.p[pc][3] = u.w;
+    }
+    return f;
+}
+template <int G, int MTX, bool ONE>
+__device__ __forceinline__ void mma_p16_group(const char* __restrict__ P, int m0, const WFragB1& f1, Acc<MTX>& acc1,
+                                              const WFragB1& f2, Acc<MTX>& acc2) {
+#pragma unroll
+    for (int q = 0; q < DIM / 32; ++q) {
+        Frag3 a[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) a[g] = lds_frag3p(P, m0 + g, q);
+        mfma6<G, MTX>(a, f1.p[q], acc1, m0);
+        if constexpr (!ONE) mfma6<G, MTX>(a, f2.p[q], acc2, m0);
+    }
+}
+// mma_b16 on piece planes (same grouping: G <= GMAX row tiles share a weight fragment's issue)
+template <int MTX, bool ONE, int GMAX = 3>
+__device__ __forceinline__ void mma_p16(const char* __restrict__ P, const WFragB1& f1, Acc<MTX>& acc1, const WFragB1& f2,
+                                        Acc<MTX>& acc2, int mt) {
+#pragma unroll
+    for (int m0 = 0; m0 < MTX; m0 += GMAX) {
+        const int left = mt - m0;
+        if (left <= 0) break;
+        if constexpr (GMAX >= 3) {
+            if (m0 + 3 <= MTX && left >= 3) {
+                mma_p16_group<3, MTX, ONE>(P, m0, f1, acc1, f2, acc2);
+                continue;
+            }
+        }
+        if constexpr (GMAX >= 2) {
+            if (m0 + 2 <= MTX && left >= 2) {
+                mma_p16_group<2, MTX, ONE>(P, m0, f1, acc1, f2, acc2);
+                continue;
+            }
+        }
+        mma_p16_group<1, MTX, ONE>(P, m0, f1, acc1, f2, acc2);
+    }
+}
+
 // A workgroup is NW waves (8 or 4); wave w owns NS = 8 / NW consecutive 16-column slices.  Two 4-wave workgroups with
 // half the rows each share a CU: same waves per SIMD as one 8-wave workgroup, but their barriers are independent, so one
 // workgroup's load / epilogue sweeps overlap the other's GEMMs (measured -16 % on the triplet/pair MLP).
@@ -253,9 +328,9 @@ __device__ __forceinline__ BiasSet<NS> lane_biases(const float* __restrict__ b, 
 }
 template <int MTX, int NS>
 __device__ __forceinline__ void store_set(const AccSet<MTX, NS>& acc, float* __restrict__ Ds, int wc, const BiasSet<NS>& b,
-                                          int mt) {
+                                          int mt, int tstride = 16 * LDT) {
 #pragma unroll
-    for (int h = 0; h < NS; ++h) acc_store<MTX>(acc.a[h], Ds, wc + 16 * h, b.v[h], mt);
+    for (int h = 0; h < NS; ++h) acc_store<MTX>(acc.a[h], Ds, wc + 16 * h, b.v[h], mt, tstride);
 }
 
 // rows [beg, end) of this workgroup and its chunking: per = 16-row tiles per workgroup, cmt = tiles per chunk

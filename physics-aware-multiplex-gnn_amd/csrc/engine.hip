@@ -11,7 +11,6 @@
 // pamnet_stack_workspace and keeps them alive until the backward has been enqueued.
 // The shared edge embeddings (e_g, rbf_e, e_sbf feed all layers) get their gradients accumulated in place by the
 // backward kernels themselves (accumulate flag), in a fixed layer order -> deterministic.
-#include <alloca.h>
 
 #include <vector>
 
@@ -373,7 +372,8 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
     struct PairImg {
         const float *gt[10], *lh[5], *lt[10], *nh[3];
     };
-    PairImg* img = packed ? static_cast<PairImg*>(alloca(sizeof(PairImg) * n_layer)) : nullptr;
+    std::vector<PairImg> img_store(packed ? (size_t)n_layer : 0);
+    PairImg* img = packed ? img_store.data() : nullptr;
     // bf16x3 images for everything the chains multiply by (matrices 0..6 + the fused heads of the next layers), fp32
     // images for the mlp_out matrices 7..9 (node_heads_fwd_kernel)
     const bool cb = packed && chain_bf16();
@@ -518,7 +518,8 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
     struct PairImgT {
         const float *gt[10], *lt[10], *gh[3], *lh[5];      // chains; heads: {projection blocks ..., Wx1}
     };
-    PairImgT* img = packed ? static_cast<PairImgT*>(alloca(sizeof(PairImgT) * n_layer)) : nullptr;
+    std::vector<PairImgT> img_store(packed ? (size_t)n_layer : 0);
+    PairImgT* img = packed ? img_store.data() : nullptr;
     if (packed) {
         PackList pl(wpack, 1, st);
         for (int64_t k = n_layer - 1; k >= 0; --k) {

@@ -284,6 +284,8 @@ class Trainer(object):
             self.fp.release_grads()
         out = self.model(data)
         # local mean -> contribution to the global-batch mean
+        if self.world_size > 1 and global_graphs is None:
+            global_graphs = out.numel() * self.world_size            # equal shards unless the caller says otherwise
         scale = float(out.numel()) / float(global_graphs) if self.world_size > 1 else 1.0
         if out.is_cuda and out.dtype == torch.float32:
             from . import ops
@@ -478,11 +480,13 @@ class Trainer(object):
         """Sum |out - y| over batches / #graphs under EMA weights, all-reduced across ranks."""
         self.drain()                       # the training steps in flight keep their own flag words (see _throttle)
         self.ema_assign()
-        tot = torch.zeros(2, device=self.fp.flat.device, dtype=torch.float64)
-        for data, out in predict(self.model, batches):
-            tot[0] += (out - data.y).abs().sum().double()
-            tot[1] += out.numel()
-        self.ema_resume()
+        try:
+            tot = torch.zeros(2, device=self.fp.flat.device, dtype=torch.float64)
+            for data, out in predict(self.model, batches):
+                tot[0] += (out - data.y).abs().sum().double()
+                tot[1] += out.numel()
+        finally:
+            self.ema_resume()                  # (a failing batch must not leave the shadow in place of the weights)
         if self.world_size > 1:
             dist.all_reduce(tot, group=self.pg)
         res = float(tot[0] / tot[1])
@@ -498,9 +502,11 @@ class Trainer(object):
         self.drain()
         self.ema_assign()
         preds, ys = [], []
-        for data, out in predict(self.model, batches):
-            preds.append(out.reshape(-1)), ys.append(data.y.reshape(-1).to(out.device))
-        self.ema_resume()
+        try:
+            for data, out in predict(self.model, batches):
+                preds.append(out.reshape(-1)), ys.append(data.y.reshape(-1).to(out.device))
+        finally:
+            self.ema_resume()
         if not preds:
             import numpy as np
             return np.zeros(0, np.float32), np.zeros(0, np.float32)
