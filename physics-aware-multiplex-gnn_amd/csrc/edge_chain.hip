@@ -201,11 +201,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void local_edge_fwd_kerne
                                                              float* __restrict__ z_kj, float* __restrict__ q2,
                                                              float* __restrict__ q3, float* __restrict__ m_ji,
                                                              float* __restrict__ m_nb, int pa, int pb, int pc, int cmt) {
-    __shared__ __attribute__((aligned(16))) float lds[3 * MTX * 16 * LDT];
-    float* S0 = lds;
-    float* S1 = lds + MTX * 16 * LDT;
-    float* S2 = lds + 2 * MTX * 16 * LDT;
     constexpr int NS = 8 / NW;
+    constexpr bool B16 = NS == 1;
+    // the rbf rows: piece planes in the 8-wave geometry (split by the sweep that stages them, edge_core.h), fp32 otherwise
+    constexpr int A_B = B16 ? PTILE : 16 * LDT * 4;
+    __shared__ __attribute__((aligned(16))) char ldsb[MTX * (A_B + 2 * 16 * LDT * 4)];
+    float* S0 = reinterpret_cast<float*>(ldsb);
+    char* P = ldsb;
+    float* S1 = reinterpret_cast<float*>(ldsb + MTX * A_B);
+    float* S2 = S1 + MTX * 16 * LDT;
     const int wc = wave_col<NW>();
     const BiasSet<NS> zero_bias = lane_biases<NS>(nullptr, wc);
     const bool kj = blockIdx.y == 0;
@@ -213,7 +217,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void local_edge_fwd_kerne
     // slice producing z (with bias), slice producing the gate.  8-wave geometry (one slice per wave): both as resident bf16x3
     // pieces, the two GEMMs share one split of every A fragment (edge_core.h "bf16x6"); the paired 4-wave geometry keeps
     // fp32 MFMAs (four slices as pieces would not fit the registers of two co-resident workgroups).
-    constexpr bool B16 = NS == 1;
     WSet<B16 ? 0 : NS> fz, fq;
     WFragB1 bz_, bq_;
     if constexpr (B16) {
@@ -228,13 +231,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void local_edge_fwd_kerne
     const Span sp = Span::make<NW>(m, pa, pb, pc, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
-        sweep<MTX, NW>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(rbf, row0 + r, sp.end, DIM, c4)); });
+        sweep<MTX, NW>(mt, [&](int r, int c4) {
+            const float4 v = ldg4z(rbf, row0 + r, sp.end, DIM, c4);
+            if constexpr (B16) st_pieces4(P, r, c4, v);
+            else st_lds4(S0, r, c4, v);
+        });
         __syncthreads();
         if constexpr (B16) {
             AccSet<MTX, NS> accq, accz;
             accq.zero();
             accz.zero();
-            mma_b16<MTX, false, 3>(S0, bq_, accq.a[0], bz_, accz.a[0], mt);
+            mma_p16<MTX, false, 3>(P, bq_, accq.a[0], bz_, accz.a[0], mt);
             store_set<MTX, NS>(accq, S2, wc, zero_bias, mt);            // q2 = lin_rbf r   |  q3 = lin_rbf_out r
             store_set<MTX, NS>(accz, S1, wc, bz, mt);                   // W_kj,e r + b_kj  |  W_ji,e r + b_ji
         } else {
@@ -369,7 +376,7 @@ struct Mlp2Batch {
 template <int MTX, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlp2_fwd_kernel(const float* __restrict__ x, int64_t m, Mlp2Batch batch, int pa,
                                                        int pb, int pc, int cmt) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
+    __shared__ __attribute__((aligned(16))) float lds[MTX * MLP2_TILE_B / 4];
     PROBE_WG(0);
     mlp2_fwd_body<MTX, NW>(x, batch.s[blockIdx.y], Span::make<NW>(m, pa, pb, pc, cmt), lds);
     PROBE_WG(1);
@@ -394,12 +401,15 @@ __device__ __forceinline__ void mlp2_bwd_body(const Mlp2BwdArgs& a, const int bi
     float* __restrict__ dz2 = a.dz2;
     float* __restrict__ dx = a.dx;
     const int accumulate = a.accumulate;
-    float* S0 = lds;
-    float* S1 = lds + MTX * 16 * LDT;
     constexpr int NS = 8 / NW;
+    constexpr bool B16 = NS == 1;             // 8-wave geometry: the dX GEMMs on the bf16 matrix pipe (edge_core.h "bf16x6"),
+                                              // their inputs as piece planes written by the sweeps that compute them
+    // B16: P = piece planes (dz2, then dz1), S1 = the accumulators' fp32 tiles;  else S0 / S1 = two fp32 tile arrays
+    float* S0 = lds;
+    char* P = reinterpret_cast<char*>(lds);
+    float* S1 = B16 ? reinterpret_cast<float*>(P + MTX * PTILE) : lds + MTX * 16 * LDT;
     const int wc = wave_col<NW>();
     const BiasSet<NS> zero_bias = lane_biases<NS>(nullptr, wc);
-    constexpr bool B16 = NS == 1;             // 8-wave geometry: the dX GEMMs on the bf16 matrix pipe (edge_core.h "bf16x6")
     WSet<B16 ? 0 : NS> f1, f2;
     WFragB1 b1_, b2_;
     if constexpr (B16) {
@@ -429,13 +439,16 @@ __device__ __forceinline__ void mlp2_bwd_body(const Mlp2BwdArgs& a, const int bi
                     if (accumulate) dxr[i] = ldg4(dx, g, DIM, c4);
                     stg4(dz2, g, DIM, c4, a);
                 }
-                if (RPP * i < 16 * mt) st_lds4(S0, r0 + RPP * i, c4, a);
+                if (RPP * i < 16 * mt) {
+                    if constexpr (B16) st_pieces4(P, r0 + RPP * i, c4, a);
+                    else st_lds4(S0, r0 + RPP * i, c4, a);
+                }
             }
         }
         __syncthreads();
         AccSet<MTX, NS> acc;
         acc.zero();
-        if constexpr (B16) mma_b16<MTX, true, 3>(S0, b2_, acc.a[0], b2_, acc.a[0], mt);
+        if constexpr (B16) mma_p16<MTX, true, 3>(P, b2_, acc.a[0], b2_, acc.a[0], mt);
         else mma_set<MTX, NS>(S0, f2, acc, mt);
         store_set<MTX, NS>(acc, S1, wc, zero_bias, mt);
         __syncthreads();
@@ -451,14 +464,16 @@ __device__ __forceinline__ void mlp2_bwd_body(const Mlp2BwdArgs& a, const int bi
                     a = f4mul(lds4(S1, r, c4), f4dsilu(z1r[i]));
                     stg4(dz1, g, DIM, c4, a);
                 }
-                st_lds4(S1, r, c4, a);
+                if constexpr (B16) st_pieces4(P, r, c4, a);             // (the dz2 pieces were last read before the barrier)
+                else st_lds4(S1, r, c4, a);
             }
         }
         __syncthreads();
         acc.zero();
-        if constexpr (B16) mma_b16<MTX, true, 3>(S1, b1_, acc.a[0], b1_, acc.a[0], mt);
+        float* const D = B16 ? S1 : S0;       // B16: S1's dX1 tile was consumed by the sweep above; else S0 (dz2) is free
+        if constexpr (B16) mma_p16<MTX, true, 3>(P, b1_, acc.a[0], b1_, acc.a[0], mt);
         else mma_set<MTX, NS>(S1, f1, acc, mt);
-        store_set<MTX, NS>(acc, S0, wc, zero_bias, mt);                 // S0 (dz2 tile) was last read before the previous barrier
+        store_set<MTX, NS>(acc, D, wc, zero_bias, mt);
         __syncthreads();
         {
             const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
@@ -466,7 +481,7 @@ __device__ __forceinline__ void mlp2_bwd_body(const Mlp2BwdArgs& a, const int bi
             for (int i = 0; i < NI; ++i) {
                 const int r = r0 + RPP * i;
                 const int64_t g = row0 + r;
-                if (RPP * i < 16 * mt && g < sp.end) stg4(dx, g, DIM, c4, f4add(lds4(S0, r, c4), dxr[i]));
+                if (RPP * i < 16 * mt && g < sp.end) stg4(dx, g, DIM, c4, f4add(lds4(D, r, c4), dxr[i]));
             }
         }
         __syncthreads();
@@ -479,7 +494,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlp2_bwd_kernel(cons
                                                        const float* __restrict__ W1, const float* __restrict__ W2,
                                                        float* __restrict__ dz1, float* __restrict__ dz2,
                                                        float* __restrict__ dx, int accumulate, int pa, int pb, int pc, int cmt) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
+    __shared__ __attribute__((aligned(16))) float lds[(NW == 8 ? MTX * MLP2_TILE_B : 2 * MTX * 16 * LDT * 4) / 4];
     mlp2_bwd_body<MTX, NW>(Mlp2BwdArgs{dy, m, z1, z2, W1, W2, dz1, dz2, dx, accumulate, pa, pb, pc, cmt}, (int)blockIdx.x, lds);
 }
 
@@ -491,8 +506,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlp2_bwd_kernel(cons
 template <int MTM>
 __global__ __launch_bounds__(WG8) void local_bwd_pair_kernel(Mlp2BwdArgs ma, LocalBwdArgs la, int g_mlp) {
     constexpr int MTL = 3;
-    static_assert(MTM >= MTL, "LDS is sized by the MLP's chunk");
-    __shared__ __attribute__((aligned(16))) float lds[2 * MTM * 16 * LDT];
+    static_assert(MTM * MLP2_TILE_B >= 2 * MTL * 16 * LDT * 4, "LDS is sized by the MLP's chunk");
+    __shared__ __attribute__((aligned(16))) float lds[MTM * MLP2_TILE_B / 4];
     if ((int)blockIdx.x < g_mlp) mlp2_bwd_body<MTM, 8>(ma, (int)blockIdx.x, lds);
     else local_edge_bwd_body<MTL>(la, (int)blockIdx.x - g_mlp, lds);
 }
@@ -571,6 +586,29 @@ inline Plan plan(int64_t rows, int cap8, int cap4, int target = N_CU, bool prefe
         } else {                                                                                                       \
             hipLaunchKernelGGL((KERNEL<8, 8>), grid__, dim3(WG8), 0, as_stream(stream), __VA_ARGS__, (PLAN).pa,        \
                                (PLAN).pb, (PLAN).pc, (PLAN).cmt);                                                      \
+        }                                                                                                              \
+    } while (0)
+
+// triplet / pair MLP forward and backward: piece planes + one fp32 tile per 16 rows (20.7 KB): <= 7 tiles with 8 waves
+#define PAMNET_EDGE_LAUNCH7(KERNEL, PLAN, GRIDY, ...)                                                                      \
+    do {                                                                                                               \
+        const dim3 grid__((PLAN).grid, GRIDY);                                                                         \
+        if ((PLAN).paired) {                                                                                           \
+            if ((PLAN).cmt <= 2)                                                                                       \
+                hipLaunchKernelGGL((KERNEL<2, 4>), grid__, dim3(256), 0, as_stream(stream), __VA_ARGS__,      \
+                                   (PLAN).pa, (PLAN).pb, (PLAN).pc, (PLAN).cmt);                                       \
+            else                                                                                                       \
+                hipLaunchKernelGGL((KERNEL<3, 4>), grid__, dim3(256), 0, as_stream(stream), __VA_ARGS__,      \
+                                   (PLAN).pa, (PLAN).pb, (PLAN).pc, (PLAN).cmt);                                       \
+        } else if ((PLAN).cmt <= 3) {                                                                                  \
+            hipLaunchKernelGGL((KERNEL<3, 8>), grid__, dim3(WG8), 0, as_stream(stream), __VA_ARGS__,          \
+                               (PLAN).pa, (PLAN).pb, (PLAN).pc, (PLAN).cmt);                                           \
+        } else if ((PLAN).cmt <= 5) {                                                                                  \
+            hipLaunchKernelGGL((KERNEL<5, 8>), grid__, dim3(WG8), 0, as_stream(stream), __VA_ARGS__,          \
+                               (PLAN).pa, (PLAN).pb, (PLAN).pc, (PLAN).cmt);                                           \
+        } else {                                                                                                       \
+            hipLaunchKernelGGL((KERNEL<7, 8>), grid__, dim3(WG8), 0, as_stream(stream), __VA_ARGS__,          \
+                               (PLAN).pa, (PLAN).pb, (PLAN).pc, (PLAN).cmt);                                           \
         }                                                                                                              \
     } while (0)
 
@@ -695,7 +733,7 @@ extern "C" int pamnet_local_bwd_pair_f32(const float* dy, int64_t rows, const fl
     int ge = (int)(N_CU * we / (we + wm) + 0.5);
     ge = ge < 8 ? 8 : (ge > N_CU - 8 ? N_CU - 8 : ge);
     const Plan pe = plan8(n_edges, 3, ge);
-    const Plan pm = plan8(rows, MT2, N_CU - (int)pe.grid);
+    const Plan pm = plan8(rows, 7, N_CU - (int)pe.grid);      // (piece planes + one fp32 tile per 16 rows: <= 7 tiles of LDS)
     const Mlp2BwdArgs ma{dy, rows, z1, z2, W1, W2, dz1, dz2, dx, (int)accumulate_dx, pm.pa, pm.pb, pm.pc, pm.cmt};
     const LocalBwdArgs la{d_mji, d_mnb, d_q3, n_edges, z_ji, z_kj, q2, w, dz_ji, dz_kj, dq2, d_rbf, (int)accumulate_rbf,
                           pe.pa, pe.pb, pe.cmt};
@@ -703,7 +741,7 @@ extern "C" int pamnet_local_bwd_pair_f32(const float* dy, int64_t rows, const fl
     hipStream_t st = as_stream(stream);
     if (pm.cmt <= 3) hipLaunchKernelGGL(local_bwd_pair_kernel<3>, grid, dim3(WG8), 0, st, ma, la, (int)pm.grid);
     else if (pm.cmt <= 5) hipLaunchKernelGGL(local_bwd_pair_kernel<5>, grid, dim3(WG8), 0, st, ma, la, (int)pm.grid);
-    else hipLaunchKernelGGL(local_bwd_pair_kernel<8>, grid, dim3(WG8), 0, st, ma, la, (int)pm.grid);
+    else hipLaunchKernelGGL(local_bwd_pair_kernel<7>, grid, dim3(WG8), 0, st, ma, la, (int)pm.grid);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -713,10 +751,10 @@ extern "C" int pamnet_mlp2_fwd_f32(const float* x, int64_t rows, const float* W1
     if (rows < 0) return PAMNET_EINVAL;
     if (rows == 0) return PAMNET_OK;
     if (!x || !W1 || !b1 || !W2 || !b2 || !y) return PAMNET_ENULL;                  // z1, z2: optional saves
-    const Plan p = plan(rows, MT2, 3);
+    const Plan p = plan(rows, 7, 3);
     Mlp2Batch b;
     for (int k = 0; k < 8; ++k) b.s[k] = Mlp2Set{W1, b1, W2, b2, z1, z2, y};
-    PAMNET_EDGE_LAUNCH(mlp2_fwd_kernel, p, 1, x, rows, b);
+    PAMNET_EDGE_LAUNCH7(mlp2_fwd_kernel, p, 1, x, rows, b);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -736,8 +774,8 @@ extern "C" int pamnet_mlp2_fwd_multi_f32(const float* x, int64_t rows, int64_t n
         b.s[k] = Mlp2Set{params[4 * s], params[4 * s + 1], params[4 * s + 2], params[4 * s + 3],
                          outs[3 * s], outs[3 * s + 1], outs[3 * s + 2]};
     }
-    const Plan p = plan(rows, MT2, 3, N_CU, nsets > 1);      // several sets = several rounds: paired 4-wave workgroups
-    PAMNET_EDGE_LAUNCH(mlp2_fwd_kernel, p, (unsigned)nsets, x, rows, b);
+    const Plan p = plan(rows, 7, 3, N_CU, nsets > 1);        // several sets = several rounds: paired 4-wave workgroups
+    PAMNET_EDGE_LAUNCH7(mlp2_fwd_kernel, p, (unsigned)nsets, x, rows, b);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -748,8 +786,8 @@ extern "C" int pamnet_mlp2_bwd_f32(const float* dy, int64_t rows, const float* z
     if (rows < 0) return PAMNET_EINVAL;
     if (rows == 0) return PAMNET_OK;
     if (!dy || !z1 || !z2 || !W1 || !W2 || !dz1 || !dz2 || !dx) return PAMNET_ENULL;
-    const Plan p = plan(rows, MT2, 3);
-    PAMNET_EDGE_LAUNCH(mlp2_bwd_kernel, p, 1, dy, rows, z1, z2, W1, W2, dz1, dz2, dx, (int)accumulate);
+    const Plan p = plan(rows, 7, 3);
+    PAMNET_EDGE_LAUNCH7(mlp2_bwd_kernel, p, 1, dy, rows, z1, z2, W1, W2, dz1, dz2, dx, (int)accumulate);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

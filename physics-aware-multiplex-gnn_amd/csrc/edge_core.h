@@ -393,6 +393,7 @@ struct Mlp2Set {
 // matrix stays resident as bf16x3 pieces.  4-wave geometry (two slices per wave; the riders of the node-chain launches):
 // the pieces of ONE matrix at a time -- a wave's two slices share the split of every A fragment, and a matrix is re-read
 // (16 KB per wave, L2-resident) and re-split per chunk, ~1 us against the ~5 us of matrix-pipe time a 48-row chunk saves.
+constexpr int MLP2_TILE_B = PTILE + 16 * LDT * 4;            // LDS bytes per 16-row tile of a chunk: piece planes + one fp32 tile
 template <int MTX, int NW>
 __device__ __forceinline__ void mlp2_fwd_body(const float* __restrict__ x, const Mlp2Set& set, const Span& sp, float* lds) {
     const float* __restrict__ W1 = set.W1;
@@ -402,8 +403,10 @@ __device__ __forceinline__ void mlp2_fwd_body(const float* __restrict__ x, const
     float* __restrict__ z1 = set.z1;
     float* __restrict__ z2 = set.z2;
     float* __restrict__ y = set.y;
-    float* S0 = lds;
-    float* S1 = lds + MTX * 16 * LDT;
+    // Both GEMM inputs wait in LDS as piece planes written by the sweep that produces them (the rows as they arrive, then
+    // SiLU(z1)): the split once per workgroup ("piece planes" above); the accumulators pass through one fp32 tile array.
+    char* P = reinterpret_cast<char*>(lds);
+    float* S1 = reinterpret_cast<float*>(P + MTX * PTILE);
     constexpr int NS = 8 / NW;
     const int wc = wave_col<NW>();
     const BiasSet<NS> bv1 = lane_biases<NS>(b1, wc), bv2 = lane_biases<NS>(b2, wc);
@@ -412,43 +415,44 @@ __device__ __forceinline__ void mlp2_fwd_body(const float* __restrict__ x, const
         load_wfragb1<false>(r1, W1, DIM, wc);
         load_wfragb1<false>(r2, W2, DIM, wc);
     }
-    auto gemm = [&](const float* A, const float* W, const WFragB1& resident, AccSet<MTX, NS>& acc, int mt) {
+    auto gemm = [&](const float* W, const WFragB1& resident, AccSet<MTX, NS>& acc, int mt) {
         acc.zero();
         if constexpr (NS == 1) {
-            mma_b16<MTX, true, 3>(A, resident, acc.a[0], resident, acc.a[0], mt);
+            mma_p16<MTX, true, 3>(P, resident, acc.a[0], resident, acc.a[0], mt);
         } else {
             WFragB1 wa, wb;
             load_wfragb1<false>(wa, W, DIM, wc);
             load_wfragb1<false>(wb, W, DIM, wc + 16);
-            mma_b16<MTX, false, 3>(A, wa, acc.a[0], wb, acc.a[NS - 1], mt);
+            mma_p16<MTX, false, 3>(P, wa, acc.a[0], wb, acc.a[NS - 1], mt);
         }
     };
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
-        sweep<MTX, NW>(mt, [&](int r, int c4) { st_lds4(S0, r, c4, ldg4z(x, row0 + r, sp.end, DIM, c4)); });
+        sweep<MTX, NW>(mt, [&](int r, int c4) { st_pieces4(P, r, c4, ldg4z(x, row0 + r, sp.end, DIM, c4)); });
         __syncthreads();
         AccSet<MTX, NS> acc;
-        gemm(S0, W1, r1, acc, mt);
+        gemm(W1, r1, acc, mt);
         store_set<MTX, NS>(acc, S1, wc, bv1, mt);
-        __syncthreads();
+        __syncthreads();                                      // (every wave is done with the x pieces: they take SiLU(z1))
         sweep<MTX, NW>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             const float4 zz = lds4(S1, r, c4);
-            st_lds4(S1, r, c4, f4silu(zz));
+            st_pieces4(P, r, c4, f4silu(zz));
             if (z1 && g < sp.end) stg4(z1, g, DIM, c4, zz);
         });
         __syncthreads();
-        gemm(S1, W2, r2, acc, mt);
-        store_set<MTX, NS>(acc, S0, wc, bv2, mt);
+        gemm(W2, r2, acc, mt);
+        store_set<MTX, NS>(acc, S1, wc, bv2, mt);
         __syncthreads();
         sweep<MTX, NW>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g >= sp.end) return;
-            const float4 zz = lds4(S0, r, c4);
+            const float4 zz = lds4(S1, r, c4);
             if (z2) stg4(z2, g, DIM, c4, zz);
             stg4(y, g, DIM, c4, f4silu(zz));
         });
-        __syncthreads();
+        // (no barrier here: the next chunk's first sweep writes the pieces, which every wave finished reading before the
+        // barrier above, and its accumulators reach S1 only behind that sweep's own barrier)
     }
 }
 

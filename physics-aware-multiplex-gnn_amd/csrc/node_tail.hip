@@ -159,7 +159,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
     if constexpr (RIDER) {
         if ((int)blockIdx.x >= rd.n_chain) {
             constexpr int RMT = 3;                            // 3-tile chunks: the 4-wave geometry without spills
-            static_assert(18 * SLOT >= 2 * RMT * 16 * LDT, "rider tiles must fit the chain's LDS");
+            static_assert(18 * SLOT * 4 >= RMT * edge::MLP2_TILE_B, "rider tiles must fit the chain's LDS");
             const int b = (int)blockIdx.x - rd.n_chain, nr = (int)gridDim.x - rd.n_chain;
             const int base = rd.ntiles / nr, rem = rd.ntiles % nr;
             const int64_t t0 = rd.tile0 + (int64_t)b * base + (b < rem ? b : rem);
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_bf16_kernel(const float* __r
     if constexpr (RIDER) {
         if ((int)blockIdx.x >= rd.n_chain) {
             constexpr int RMT = 3;
-            static_assert(12 * SLOT + 3 * PIMG / 4 >= 2 * RMT * 16 * LDT, "rider tiles must fit the chain's LDS");
+            static_assert((12 * SLOT + 3 * PIMG / 4) * 4 >= RMT * edge::MLP2_TILE_B, "rider tiles must fit the chain's LDS");
             const int b = (int)blockIdx.x - rd.n_chain, nr = (int)gridDim.x - rd.n_chain;
             const int base = rd.ntiles / nr, rem = rd.ntiles % nr;
             const int64_t t0 = rd.tile0 + (int64_t)b * base + (b < rem ? b : rem);
