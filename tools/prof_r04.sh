@@ -29,3 +29,8 @@ done
 cd $R && python -m pytest tests/test_hip_model.py tests/test_store.py -m gpu -q -s -k "baseline or trainer_step_path or large_batch or configs1" 2>/dev/null | grep -E "vs the reference|vs oracle|12 targets|Trainer.forward_backward|through the store|passed|failed" > $O/r04_parity_figures.txt
 cd $R && python bench.py 2>/dev/null | tail -1 > $O/r04_bench_line.json
 ls -la $O | grep r04_
+# issue-slot counters per kernel (two SQ passes each) and the forward chain's phase timestamps (production form)
+KIND=pdbbind bash $R/tools/pmc_issue.sh > /dev/null 2>&1; cp $O/issue_pdbbind.txt $O/r04_issue_slots_pdbbind_pmc.txt
+KIND=qm9 STEPS=30 bash $R/tools/pmc_issue.sh > /dev/null 2>&1; cp $O/issue_qm9.txt $O/r04_issue_slots_qm9_pmc.txt
+(PAMNET_AGG_PIECES=0 python $R/tools/agg_bench.py pdbbind 2>/dev/null; PAMNET_AGG_PIECES=0 python $R/tools/agg_bench.py qm9 2>/dev/null) | grep -v amdgpu.ids > $O/r04_edge_agg_microbench_reader_split.txt
+(python $R/tools/tail_probe_packed.py 2286 4 2>/dev/null | tail -9; python $R/tools/tail_probe_packed.py 16 4 2>/dev/null | tail -9) > $O/r04_tail_probe_packed.txt
