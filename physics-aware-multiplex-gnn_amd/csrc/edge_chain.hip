@@ -774,7 +774,10 @@ extern "C" int pamnet_mlp2_fwd_multi_f32(const float* x, int64_t rows, int64_t n
         b.s[k] = Mlp2Set{params[4 * s], params[4 * s + 1], params[4 * s + 2], params[4 * s + 3],
                          outs[3 * s], outs[3 * s + 1], outs[3 * s + 2]};
     }
-    const Plan p = plan(rows, 7, 3, N_CU, nsets > 1);        // several sets = several rounds: paired 4-wave workgroups
+    // (Round 3 ran several sets -- several rounds of workgroups -- as paired 4-wave workgroups: 104 vs 120 us at the QM9 batch.
+    // With piece planes the 8-wave geometry, whose weight pieces stay resident instead of being re-read and re-split per
+    // chunk, is ahead again: PDBbind step 9.06 -> 9.02 ms, QM9 2.184 -> 2.178.)
+    const Plan p = plan(rows, 7, 3);
     PAMNET_EDGE_LAUNCH7(mlp2_fwd_kernel, p, (unsigned)nsets, x, rows, b);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;

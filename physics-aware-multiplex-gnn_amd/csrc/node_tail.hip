@@ -74,6 +74,13 @@ struct Mlp2Rider {
 constexpr int BMN = 16;                       // rows per workgroup
 constexpr int SLOT = BMN * LDT;               // floats per LDS slot
 constexpr int TWG = 512;                      // 8 waves
+// more row tiles than CUs: a CU gets several workgroups in turn -- the lean chain forms (co-resident workgroups) from here
+constexpr unsigned LEAN_FROM_TILES = 256;
+// PAMNET_CHAIN_LEAN=0: never, 1: forward only (default: both directions) -- read once, for A/B timing
+inline int lean_mode() {
+    static const int v = [] { const char* e = getenv("PAMNET_CHAIN_LEAN"); return e ? atoi(e) : 2; }();
+    return v;
+}
 
 // fragment coordinates of accumulator element r of this lane: row = 4*(lane>>4) + r, col = 16*wave + (lane&15)
 struct Frag {
@@ -321,6 +328,121 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
             stg4(nx.x1, g, DIM, c4, lds4(ZL + SLOT, r, c4));
             for (int b = 0; b < nx.nblk; ++b) stg4(nx.P + (int64_t)b * plane, g, DIM, c4, lds4(ZL + (2 + b) * SLOT, r, c4));
         });
+    }
+}
+
+// ---- the forward chain for batches of several rounds (more row tiles than CUs) ------------------------------------------
+// The kernel above parks everything the backward needs in LDS (152 KB: one workgroup per CU) so that no global store sits
+// on a layer's critical path -- right when every workgroup is the only one its CU will ever see (143 tiles at the QM9
+// batch).  With 1 188 tiles (PDBbind B = 32) a CU works through ~4.6 of them one after the other, and each one's
+// latencies -- LDS before the first MFMA, the weight requests, the SiLU sequence, the barrier -- are exposed in turn
+// (111 us per launch against 40 us of matrix-pipe time).  This form keeps only the five working tiles in LDS (42 KB:
+// three workgroups per CU) and writes z_k / the taps / the next head's outputs straight from the accumulators, behind the
+// next weight request (vmcnt retires in order: the request does not wait for them), the way node_heads_fwd_kernel does:
+// one workgroup's epilogue runs under another's MFMAs.  Packed weights, deferred heads; same arithmetic, same results.
+__global__ __launch_bounds__(WG, 3) void node_tail_fwd_lean_kernel(const float* __restrict__ x2, const float* __restrict__ res_x,
+                                                                   int64_t n, TailParams p, float* __restrict__ Z,
+                                                                   float* __restrict__ R, float* __restrict__ x_out,
+                                                                   PreNext nx) {
+    __shared__ __attribute__((aligned(16))) float lds[5 * SLOT];
+    float* X0 = lds;
+    float* RX = lds + SLOT;
+    float* A = lds + 2 * SLOT;
+    float* B = lds + 3 * SLOT;
+    float* C = lds + 4 * SLOT;
+    const int64_t row0 = (int64_t)blockIdx.x * BMN;
+    const int64_t plane = n * DIM;
+    const int lane = threadIdx.x & 63, r16 = lane & 15, kg = lane >> 4;
+    const int wc = (threadIdx.x >> 6) * 32;
+
+    WFrag wf;
+    load_w<true>(wf, p.W[0], DIM, wc);
+    sweep_rows<BMN>([&](int r, int c4) {
+        const int64_t g = row0 + r;
+        st_lds4(X0, r, c4, ldg4z(x2, g, n, DIM, c4));
+        st_lds4(RX, r, c4, ldg4z(res_x, g, n, DIM, c4));
+    });
+    __syncthreads();
+
+    // layer k: in -> dst = SiLU(W_k in + b_k) (+ add1 + add2); z_k and the optional tap go to memory from the accumulators
+    auto layer = [&](const float* in, float* dst, int k, const float* add1, const float* add2, float* tap,
+                     const float* Wnext) {
+        const Bias2 bv = load_bias2(p.b[k], wc);
+        f32x4 acc[1][2];
+        acc_zero<1>(acc);
+        mma_tile_frag<1>(in, wf, acc);
+        if (Wnext) load_w<true>(wf, Wnext, DIM, wc);
+        float* zg = Z ? Z + (int64_t)k * plane : nullptr;
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+            const int c = wc + 16 * n2 + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rw = 4 * kg + r;
+                const float z = acc[0][n2][r] + bv.v[n2];
+                float a = silu(z);
+                if (add1) a += add1[rw * LDT + c];
+                if (add2) a += add2[rw * LDT + c];
+                dst[rw * LDT + c] = a;
+                if (row0 + rw < n) {
+                    if (zg) zg[(row0 + rw) * DIM + c] = z;
+                    if (tap) tap[(row0 + rw) * DIM + c] = a;
+                }
+            }
+        }
+        __syncthreads();
+    };
+    float* const tap1 = Z ? R : nullptr;                      // r1, r2: backward-only saves (null in inference mode)
+    float* const tap2 = Z ? R + plane : nullptr;
+    layer(X0, A, 0, nullptr, nullptr, nullptr, p.W[1]);        // h0 -> A
+    layer(A, B, 1, nullptr, nullptr, nullptr, p.W[2]);         // a1 -> B
+    layer(B, C, 2, A, RX, tap1, p.W[3]);                       // r1 -> C   (+ h0 + res_x)
+    layer(C, A, 3, nullptr, nullptr, nullptr, p.W[4]);         // a3 -> A
+    layer(A, B, 4, C, nullptr, tap2, p.W[5]);                  // r2 -> B   (+ r1)
+    layer(B, A, 5, nullptr, nullptr, nullptr, p.W[6]);         // a5 -> A
+    layer(A, C, 6, B, nullptr, x_out, nx.nblk > 0 ? nx.Wx1 : nullptr);   // r3 -> C = x_out
+
+    // the next layer's head on the x_out tile (C): x1 -> A (and memory), the projections straight to memory
+    if (nx.nblk > 0) {
+        {
+            const Bias2 bv = load_bias2(nx.bx1, wc);
+            f32x4 acc[1][2];
+            acc_zero<1>(acc);
+            mma_tile_frag<1>(C, wf, acc);
+            load_w<true>(wf, nx.wp[0], nx.ldwp, wc);
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) {
+                const int c = wc + 16 * n2 + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rw = 4 * kg + r;
+                    const float z = acc[0][n2][r] + bv.v[n2];
+                    const float a = silu(z);
+                    A[rw * LDT + c] = a;
+                    if (row0 + rw < n) {
+                        if (nx.Zx1) nx.Zx1[(row0 + rw) * DIM + c] = z;
+                        nx.x1[(row0 + rw) * DIM + c] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        for (int b = 0; b < nx.nblk; ++b) {
+            f32x4 acc[1][2];
+            acc_zero<1>(acc);
+            mma_tile_frag<1>(A, wf, acc);
+            if (b + 1 < nx.nblk) load_w<true>(wf, nx.wp[b + 1], nx.ldwp, wc);
+            float* pb = nx.P + (int64_t)b * plane;
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) {
+                const int c = wc + 16 * n2 + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rw = 4 * kg + r;
+                    if (row0 + rw < n) pb[(row0 + rw) * DIM + c] = acc[0][n2][r];
+                }
+            }
+        }
     }
 }
 
@@ -866,6 +988,119 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
     }
 }
 
+// ---- the backward chain for batches of several rounds (see node_tail_fwd_lean_kernel) -----------------------------------
+// The kernel above stages all seven z_k tiles, the residual gradient, d res_x and the head's operands in LDS (135 KB: one
+// workgroup per CU).  Every element of those tiles is only ever touched by the lane that owns it in the accumulator layout
+// (row 4 kg + r, column 16 wave + r16), so here they are REGISTERS: z_{k-1} is fetched by its lane ahead of layer k's MFMAs,
+// dz_k leaves from the accumulators (behind the next weight request), the kept residual gradient and d res_x never leave
+// the lane.  LDS holds the two GEMM-input tiles and, with PRE, the head's <= 4 dP planes: 51 KB, two workgroups of 8 waves
+// per CU -- one's epilogue under the other's MFMAs.  Packed (transposed) weight images, deferred heads; the same arithmetic
+// in the same order as node_tail_bwd_kernel<true, false, PRE>: bitwise the same results.  In-place calls (d_x2 / d_resx
+// aliasing dx1_direct / d_add) stay safe: a lane reads its elements before it writes them.
+template <bool PRE>
+__global__ __launch_bounds__(TWG, 2) void node_tail_bwd_lean_kernel(const float* __restrict__ d_xout /* may be null */,
+                                                                   const float* __restrict__ d_out, int64_t n, TailParams p,
+                                                                   const float* __restrict__ Z, float* __restrict__ dZ,
+                                                                   float* d_x2, float* d_resx, PreBwd pb) {
+    __shared__ __attribute__((aligned(16))) float lds[(PRE ? 6 : 2) * SLOT];
+    float* D0 = lds;
+    float* D1 = lds + SLOT;
+    const int64_t row0 = (int64_t)blockIdx.x * BMN;
+    const int64_t plane = n * DIM;
+    const Frag fr;
+    const int c = fr.col();
+    bool ok[4];
+    int64_t off[4];                                            // element offset of (row, column) in an [n][128] plane
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t g = row0 + fr.row(r);
+        ok[r] = g < n;
+        off[r] = (ok[r] ? g : 0) * DIM + c;
+    }
+    WFrag1 wf;
+    load_wfrag1_img(wf, PRE ? pb.wp[0] : p.W[6]);
+    // d x_out = (next layer's d x) + the head branch's contribution (+ the head backward's d_add and d x below)
+    f32x4 kreg;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float k = d_xout ? d_xout[off[r]] : 0.f;
+        k += d_out[off[r]];
+        if constexpr (PRE) k += pb.d_add[off[r]];
+        kreg[r] = ok[r] ? k : 0.f;
+    }
+    if constexpr (PRE) {
+        float* PL = lds + 2 * SLOT;
+        f32x4 zx, dxd;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            zx[r] = pb.Zx1[off[r]];
+            dxd[r] = ok[r] ? pb.dx1_direct[off[r]] : 0.f;
+        }
+        const int sc4 = threadIdx.x & 31, sr = threadIdx.x >> 5;
+        for (int b = 0; b < pb.nblk; ++b)
+            st_lds4(PL + b * SLOT, sr, sc4, ldg4z(pb.dP + (int64_t)b * plane, row0 + sr, n, DIM, sc4));
+        __syncthreads();
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < pb.nblk; ++b) {
+            acc += mma_strip(PL + b * SLOT, wf);
+            load_wfrag1_img(wf, b + 1 < pb.nblk ? pb.wp[b + 1] : pb.Wx1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                          // dz_x1 = (d x1) * SiLU'(z_x1)
+            const float dzx = ok[r] ? (acc[r] + dxd[r]) * dsilu(zx[r]) : 0.f;
+            D1[fr.row(r) * LDT + c] = dzx;
+            if (ok[r]) pb.dZx1[off[r]] = dzx;
+        }
+        __syncthreads();
+        const f32x4 a2 = mma_strip(D1, wf);
+        load_wfrag1_img(wf, p.W[6]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) kreg[r] += a2[r];          // d x_out = d_add + g_head + the head's d x
+        __syncthreads();                                       // (every wave is done reading D1)
+    }
+    {   // dz6 = d r3 * SiLU'(z6)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dz = ok[r] ? kreg[r] * dsilu(Z[6 * plane + off[r]]) : 0.f;
+            D1[fr.row(r) * LDT + c] = dz;
+            if (ok[r]) dZ[6 * plane + off[r]] = dz;
+        }
+        __syncthreads();
+    }
+    // One backward step: v = dz_k * W_k (+ kept); optionally kept <- v, d res_x <- v; then dz_{k-1} = v * SiLU'(z_{k-1}).
+    auto back = [&](const float* in, float* dst, int k, bool add_k, bool keep_k, bool extra) {
+        f32x4 zn = {0.f, 0.f, 0.f, 0.f};
+        if (k > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zn[r] = Z[(int64_t)(k - 1) * plane + off[r]];      // ahead of the MFMAs
+        }
+        const f32x4 acc = mma_strip(in, wf);
+        if (k > 0) load_wfrag1_img(wf, p.W[k - 1]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[r];
+            if (add_k) v += kreg[r];
+            if (keep_k) kreg[r] = v;
+            if (extra && ok[r]) d_resx[off[r]] = v;
+            if (k == 0) {
+                if (ok[r]) d_x2[off[r]] = v;
+            } else {
+                const float dz = ok[r] ? v * dsilu(zn[r]) : 0.f;
+                dst[fr.row(r) * LDT + c] = dz;
+                if (ok[r]) dZ[(int64_t)(k - 1) * plane + off[r]] = dz;
+            }
+        }
+        if (k > 0) __syncthreads();
+    };
+    back(D1, D0, 6, false, false, false);       // d a5          -> dz5
+    back(D0, D1, 5, true, true, false);         // d r2 = . + d r3 (kept)      -> dz4
+    back(D1, D0, 4, false, false, false);       // d a3          -> dz3
+    back(D0, D1, 3, true, true, true);          // d r1 = . + d r2 (kept, = d res_x) -> dz2
+    back(D1, D0, 2, false, false, false);       // d a1          -> dz1
+    back(D0, D1, 1, true, false, false);        // d h0 = . + d r1             -> dz0
+    back(D1, D0, 0, false, false, false);       // d x2
+}
+
 // Backward of the head branch of every layer in one launch (grid = (ceil(n/16), layers)): from d out / d att
 //   head partials (d w_out, d w_att, d b_out), dz9, dz8, dz7 (-> dZ3[l][0..2] for the weight gradients) and the branch's
 //   contribution to d x_out, g_head[l] = dz7 * W7.
@@ -1143,6 +1378,7 @@ static int tail_fwd_launch(const float* x2, const float* res_x, int64_t n, const
                                x2, res_x, n, tp, Z, R, x_out, out, att, nx, rd);
     } else if (packed == 2) hipLaunchKernelGGL((node_tail_fwd_bf16_kernel<false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, nx);
     else if (packed && heads) hipLaunchKernelGGL((node_tail_fwd_kernel<true, true>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
+    else if (packed && grid.x > LEAN_FROM_TILES && lean_mode() >= 1) hipLaunchKernelGGL(node_tail_fwd_lean_kernel, grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, nx);
     else if (packed) hipLaunchKernelGGL((node_tail_fwd_kernel<true, false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
     else if (heads) hipLaunchKernelGGL((node_tail_fwd_kernel<false, true>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
     else hipLaunchKernelGGL((node_tail_fwd_kernel<false, false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
@@ -1260,7 +1496,10 @@ extern "C" int pamnet_node_tail_main_bwd_f32(const float* d_xout, const float* g
     TailParams tp{};
     for (int k = 0; k < 7; ++k) tp.W[k] = weights[k];
     tp.packed = packed ? 1 : 0;
-    if (packed)
+    if (packed && grid > LEAN_FROM_TILES && lean_mode() >= 2)
+        hipLaunchKernelGGL((node_tail_bwd_lean_kernel<false>), dim3(grid), dim3(TWG), 0, st, d_xout, g_head, n, tp, Z, dZ, d_x2,
+                           d_resx, PreBwd{});
+    else if (packed)
         hipLaunchKernelGGL((node_tail_bwd_kernel<true, false>), dim3(grid), dim3(TWG), 0, st, d_xout, g_head,
                            (const float*)nullptr, n, tp, Z, dZ, d_x2, d_resx, (float*)nullptr);
     else
@@ -1303,9 +1542,13 @@ extern "C" int pamnet_node_pre_tail_bwd_f32(const float* dP, const float* dx1_di
         const WgradRider* r = static_cast<const WgradRider*>(rider);
         rb = r->batch, rpart = r->partial, rslots = r->slots;
     }
-    hipLaunchKernelGGL((node_tail_bwd_kernel<true, false, true>), dim3((unsigned)(n_tiles + rslots)), dim3(TWG), 0,
-                       as_stream(stream), (const float*)nullptr, g_head, (const float*)nullptr, n, tp, Z, dZ, d_x2, d_resx,
-                       (float*)nullptr, pb, rb, rpart, n_tiles);
+    if (rslots == 0 && (unsigned)n_tiles > LEAN_FROM_TILES && lean_mode() >= 2)
+        hipLaunchKernelGGL((node_tail_bwd_lean_kernel<true>), dim3((unsigned)n_tiles), dim3(TWG), 0, as_stream(stream),
+                           (const float*)nullptr, g_head, n, tp, Z, dZ, d_x2, d_resx, pb);
+    else
+        hipLaunchKernelGGL((node_tail_bwd_kernel<true, false, true>), dim3((unsigned)(n_tiles + rslots)), dim3(TWG), 0,
+                           as_stream(stream), (const float*)nullptr, g_head, (const float*)nullptr, n, tp, Z, dZ, d_x2, d_resx,
+                           (float*)nullptr, pb, rb, rpart, n_tiles);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

@@ -372,3 +372,98 @@ def test_local_backward_pair_equals_the_two_launches(dev, rows, edges, acc):
              lib.ptr(z_kj), lib.ptr(q2), wq, ldq, lib.ptr(pji), lib.ptr(pkj), lib.ptr(pq2), lib.ptr(prbf), acc, st)
     for a, b in ((dz1, pz1), (dz2, pz2), (dx, px), (dzji, pji), (dzkj, pkj), (dq2, pq2), (drbf, prbf)):
         assert torch.equal(a, b) and not bool(torch.isnan(a).any())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nblk', [0, 2, 4])
+@pytest.mark.parametrize('save', [True, False])
+def test_lean_forward_chain_equals_the_parked_one(dev, nblk, save):
+    """Batches of more than 512 row tiles run the forward chain with three workgroups per CU and the saves written straight
+    from the accumulators (node_tail_fwd_lean_kernel); same arithmetic per row, so a launch over 8 200 rows (lean) must
+    reproduce, bit for bit, the first 8 000 rows as a launch of their own (500 tiles: the parked form) computes them."""
+    from pamnet_amd import lib
+    from pamnet_amd.fused import _parr, _iarr
+    torch.manual_seed(5 + nblk)
+    n_big, n_small = 8200 + 7, 8000
+    NW = 15
+    W = [(torch.randn(D, D, device=dev) * 0.08) for _ in range(NW)]
+    b = [torch.randn(D, device=dev) * 0.1 for _ in range(11)]
+    images = torch.empty(NW, D * D, device=dev)
+    lib.call('pamnet_pack_weights_f32', NW, _parr(W), _iarr([D] * NW), 0, lib.ptr(images), lib.stream_of(images))
+    img = [images[i] for i in range(NW)]
+    x2, rx = torch.randn(n_big, D, device=dev), torch.randn(n_big, D, device=dev)
+    w_out, b_out, w_att = torch.randn(D, device=dev), torch.zeros(1, device=dev), torch.randn(D, device=dev)
+
+    def run(n):
+        Z = torch.full((10, n, D), float('nan'), device=dev) if save else None
+        R = torch.full((2, n, D), float('nan'), device=dev) if save else None
+        xo = torch.full((n, D), float('nan'), device=dev)
+        zx1 = torch.full((n, D), float('nan'), device=dev) if (save and nblk) else None
+        x1 = torch.full((n, D), float('nan'), device=dev) if nblk else None
+        P = torch.full((max(nblk, 1), n, D), float('nan'), device=dev) if nblk else None
+        lib.call('pamnet_node_tail_fwd_f32', lib.ptr(x2[:n].contiguous()), lib.ptr(rx[:n].contiguous()), n, _parr(img[:10]),
+                 _parr(b[:10]), lib.ptr(w_out), lib.ptr(b_out), lib.ptr(w_att), lib.ptr(Z), lib.ptr(R), lib.ptr(xo), None, None,
+                 lib.ptr(img[10]) if nblk else None, lib.ptr(b[10]) if nblk else None, _parr(img[11:11 + nblk]) if nblk else None,
+                 D, nblk, lib.ptr(zx1), lib.ptr(x1), lib.ptr(P), 1, lib.stream_of(x2))
+        return Z, R, xo, zx1, x1, P
+
+    big, small = run(n_big), run(n_small)
+    torch.cuda.synchronize()
+    for name, a, c in zip(['Z', 'R', 'x_out', 'Zx1', 'x1', 'P'], big, small):
+        if a is None:
+            continue
+        a = a[..., :n_small, :] if a.dim() == 3 else a[:n_small]
+        if name == 'Z':
+            a, c = a[:7], c[:7]                                  # (deferred heads: z7..z9 are node_heads_fwd's)
+        assert torch.equal(a, c), name
+        assert not torch.isnan(a).any(), name
+    tail = big[2][n_small:]
+    assert not torch.isnan(tail).any() and tail.abs().max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nblk', [0, 2, 4])
+def test_lean_backward_chain_equals_the_parked_one(dev, nblk):
+    """node_tail_bwd_lean_kernel (more than 256 row tiles: two co-resident workgroups per CU, the per-element state in
+    registers) against node_tail_bwd_kernel on the same rows: 4 200 rows (lean) reproduce, bit for bit, what a launch over the
+    first 4 000 of them (250 tiles: the parked form) computes.  nblk = 0: the chain alone; 2 / 4: with the next head's backward
+    in front (in-place d_x2 / d_resx as the engine calls it)."""
+    from pamnet_amd import lib
+    from pamnet_amd.fused import _parr, _iarr
+    torch.manual_seed(11 + nblk)
+    n_big, n_small = 4200 + 5, 4000
+    NW = 12
+    W = [(torch.randn(D, D, device=dev) * 0.08) for _ in range(NW)]
+    images = torch.empty(NW, D * D, device=dev)
+    lib.call('pamnet_pack_weights_f32', NW, _parr(W), _iarr([D] * NW), 1, lib.ptr(images), lib.stream_of(images))
+    img = [images[i] for i in range(NW)]
+    Z = torch.randn(10, n_big, D, device=dev)
+    g_head, dP = torch.randn(n_big, D, device=dev), torch.randn(4, n_big, D, device=dev)
+    dx1, dadd, zx1 = torch.randn(n_big, D, device=dev), torch.randn(n_big, D, device=dev), torch.randn(n_big, D, device=dev)
+    d_xout = torch.randn(n_big, D, device=dev)
+
+    def run(n):
+        Zn = Z[:, :n].contiguous()
+        dZ = torch.full((10, n, D), float('nan'), device=dev)
+        if nblk == 0:
+            dx2, drx = torch.full((n, D), float('nan'), device=dev), torch.full((n, D), float('nan'), device=dev)
+            lib.call('pamnet_node_tail_main_bwd_f32', lib.ptr(d_xout[:n].contiguous()), lib.ptr(g_head[:n].contiguous()), n,
+                     _parr(img[:7]), lib.ptr(Zn), lib.ptr(dZ), lib.ptr(dx2), lib.ptr(drx), 1, lib.stream_of(Z))
+            return dZ[:7], dx2, drx, None
+        dx2, drx = dx1[:n].clone(), dadd[:n].clone()              # in place, as pamnet_stack_bwd_f32 calls it
+        dzx1 = torch.full((n, D), float('nan'), device=dev)
+        lib.call('pamnet_node_pre_tail_bwd_f32', lib.ptr(dP[:nblk, :n].contiguous()), lib.ptr(dx2), lib.ptr(drx), n,
+                 lib.ptr(img[7]), _parr(img[8:8 + nblk]), nblk, lib.ptr(zx1[:n].contiguous()), lib.ptr(dzx1),
+                 lib.ptr(g_head[:n].contiguous()), _parr(img[:7]), lib.ptr(Zn), lib.ptr(dZ), lib.ptr(dx2), lib.ptr(drx), None,
+                 lib.stream_of(Z))
+        return dZ[:7], dx2, drx, dzx1
+
+    big, small = run(n_big), run(n_small)
+    torch.cuda.synchronize()
+    for name, a, c in zip(['dZ', 'd_x2', 'd_resx', 'dZx1'], big, small):
+        if a is None:
+            continue
+        a = a[:, :n_small] if a.dim() == 3 else a[:n_small]
+        assert not torch.isnan(a).any(), name
+        assert torch.equal(a, c), name
+    assert not torch.isnan(big[1][n_small:]).any() and big[1][n_small:].abs().max() > 0
