@@ -1019,6 +1019,15 @@ __global__ __launch_bounds__(TWG, 2) void node_tail_bwd_lean_kernel(const float*
     }
     WFrag1 wf;
     load_wfrag1_img(wf, PRE ? pb.wp[0] : p.W[6]);
+    // z_k of a lane's four elements.  Requested TWO layers ahead (a layer is ~1 500 cycles, an HBM round trip ~2 000 under
+    // load); the first three right here, so that they travel during the head's GEMMs / the first layer.
+    auto ldz = [&](int k) {
+        f32x4 z;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[r] = Z[(int64_t)k * plane + off[r]];
+        return z;
+    };
+    const f32x4 z6 = ldz(6), z5 = ldz(5), z4 = ldz(4);
     // d x_out = (next layer's d x) + the head branch's contribution (+ the head backward's d_add and d x below)
     f32x4 kreg;
 #pragma unroll
@@ -1061,19 +1070,16 @@ __global__ __launch_bounds__(TWG, 2) void node_tail_bwd_lean_kernel(const float*
     {   // dz6 = d r3 * SiLU'(z6)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float dz = ok[r] ? kreg[r] * dsilu(Z[6 * plane + off[r]]) : 0.f;
+            const float dz = ok[r] ? kreg[r] * dsilu(z6[r]) : 0.f;
             D1[fr.row(r) * LDT + c] = dz;
             if (ok[r]) dZ[6 * plane + off[r]] = dz;
         }
         __syncthreads();
     }
     // One backward step: v = dz_k * W_k (+ kept); optionally kept <- v, d res_x <- v; then dz_{k-1} = v * SiLU'(z_{k-1}).
-    auto back = [&](const float* in, float* dst, int k, bool add_k, bool keep_k, bool extra) {
-        f32x4 zn = {0.f, 0.f, 0.f, 0.f};
-        if (k > 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) zn[r] = Z[(int64_t)(k - 1) * plane + off[r]];      // ahead of the MFMAs
-        }
+    // zn = z_{k-1} (requested two steps ago); *pre <- z_{k-3}, requested now
+    auto back = [&](const float* in, float* dst, int k, bool add_k, bool keep_k, bool extra, const f32x4& zn, f32x4* pre) {
+        if (pre) *pre = ldz(k - 3);
         const f32x4 acc = mma_strip(in, wf);
         if (k > 0) load_wfrag1_img(wf, p.W[k - 1]);
 #pragma unroll
@@ -1092,13 +1098,15 @@ __global__ __launch_bounds__(TWG, 2) void node_tail_bwd_lean_kernel(const float*
         }
         if (k > 0) __syncthreads();
     };
-    back(D1, D0, 6, false, false, false);       // d a5          -> dz5
-    back(D0, D1, 5, true, true, false);         // d r2 = . + d r3 (kept)      -> dz4
-    back(D1, D0, 4, false, false, false);       // d a3          -> dz3
-    back(D0, D1, 3, true, true, true);          // d r1 = . + d r2 (kept, = d res_x) -> dz2
-    back(D1, D0, 2, false, false, false);       // d a1          -> dz1
-    back(D0, D1, 1, true, false, false);        // d h0 = . + d r1             -> dz0
-    back(D1, D0, 0, false, false, false);       // d x2
+    f32x4 z3, z2, z1, z0;
+    const f32x4 none = {0.f, 0.f, 0.f, 0.f};
+    back(D1, D0, 6, false, false, false, z5, &z3);      // d a5          -> dz5
+    back(D0, D1, 5, true, true, false, z4, &z2);        // d r2 = . + d r3 (kept)      -> dz4
+    back(D1, D0, 4, false, false, false, z3, &z1);      // d a3          -> dz3
+    back(D0, D1, 3, true, true, true, z2, &z0);         // d r1 = . + d r2 (kept, = d res_x) -> dz2
+    back(D1, D0, 2, false, false, false, z1, nullptr);  // d a1          -> dz1
+    back(D0, D1, 1, true, false, false, z0, nullptr);   // d h0 = . + d r1             -> dz0
+    back(D1, D0, 0, false, false, false, none, nullptr);   // d x2
 }
 
 // Backward of the head branch of every layer in one launch (grid = (ceil(n/16), layers)): from d out / d att
