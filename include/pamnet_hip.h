@@ -9,8 +9,8 @@
  *   - arguments are raw DEVICE pointers, 64-bit sizes and a hipStream_t (passed as void*); no torch types;
  *   - the caller owns every device buffer; the library allocates no device memory, keeps no mutable state between calls
  *     and never synchronises (the pamnet_stack_* engine calls build small host-side pointer tables on the stack / heap per
- *     call).  The only process-wide data are four read-once developer switches taken from the environment on first use
- *     (PAMNET_EDGE_WAVES, PAMNET_CHAIN_BF16, PAMNET_SMALL_FORMS, PAMNET_AGG_PIECES: kernel-variant selection for measurements; C++11 static
+ *     call).  The only process-wide data are five read-once developer switches taken from the environment on first use
+ *     (PAMNET_EDGE_WAVES, PAMNET_CHAIN_BF16, PAMNET_SMALL_FORMS, PAMNET_AGG_PIECES, PAMNET_CHAIN_LEAN: kernel-variant selection for measurements; C++11 static
  *     initialisation, thread-safe, constant afterwards);
  *   - work is enqueued on `stream`; return value 0 = OK, >0 = hipError_t of the failed launch, <0 = argument error
  *     (PAMNET_EINVAL: bad size / unsupported width; PAMNET_ENULL: required pointer is null);
