@@ -319,6 +319,46 @@ def pdbbind_kernel_rooflines(model, batch, dev):
                     'us_per_launch': ms * 1e3, 'achieved': by / ms / 1e6, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': by / ms / 1e6 / HBM_PEAK_GBS, 'best_group_gbs': by / ms_min / 1e6,
                     'launches_per_step': model.n_layer if perm is not None else 0})
+    # The fused edge MLP -> segment-sum kernels of the global layer (csrc/edge_agg.hip) on the same graph: since the bf16 split
+    # moved out of the reading waves they are memory-bound here, so they are priced against HBM too.
+    # Algorithmic bytes (profiles/r04_edge_agg_pmc.json measures the traffic at 1.002x / 1.006x of them):
+    #   backward: z, ea in; d z, d ea out; d e read-modify-write (accumulate = 1); indices; d_agg in, d P_i out
+    #   forward (training): e in; z, ea saved; indices; x1, P_i, P_j in, x2 out
+    from pamnet_amd import lib
+    D = d
+    rnd = lambda *sh: torch.randn(*sh, device=dev) * 0.5
+    Wm, bm, Wea = rnd(D, 3 * D) / 8, rnd(D), rnd(D, D) / 8
+    st = lib.stream_of(Wm)
+    csr = g.glob
+    e, Pi, Pj, x1, d_agg = rnd(m, D), rnd(n, D), rnd(n, D), rnd(n, D), rnd(n, D)
+    z, ea, dz, dea, d_e = (torch.empty(m, D, device=dev) for _ in range(5))
+    out, dPi = torch.empty(n, D, device=dev), torch.empty(n, D, device=dev)
+    cuts = torch.empty(257, dtype=torch.int32, device=dev)
+    lib.call('pamnet_seg_cuts_i32', lib.ptr(csr.ptr), lib.ptr(csr.row_of), n, m, lib.ptr(cuts), None, st)
+    we = Wm.data_ptr() + 4 * 2 * D
+
+    def fwd():
+        lib.call('pamnet_global_edge_agg_fwd_f32', lib.ptr(e), m, n, we, 3 * D, lib.ptr(bm), lib.ptr(Wea), D, lib.ptr(Pi),
+                 lib.ptr(Pj), lib.ptr(csr.ptr), lib.ptr(csr.row_of), lib.ptr(csr.col), lib.ptr(cuts), lib.ptr(x1), lib.ptr(z),
+                 lib.ptr(ea), lib.ptr(out), st)
+
+    def bwd():
+        lib.call('pamnet_global_edge_agg_bwd_f32', lib.ptr(d_agg), m, n, lib.ptr(csr.ptr), lib.ptr(csr.row_of), lib.ptr(cuts),
+                 lib.ptr(z), lib.ptr(ea), we, 3 * D, lib.ptr(Wea), D, lib.ptr(dz), lib.ptr(dea), lib.ptr(d_e), 1, lib.ptr(dPi), st)
+
+    fwd()
+    d_e.zero_()
+    by_f = 4.0 * D * m + 8.0 * m + 4.0 * D * n * 4 + 8.0 * D * m
+    by_b = 4.0 * D * m * 6 + 4.0 * m + 4.0 * (n + 1) + 4.0 * D * n * 2
+    for name, fn, by, gf in (('global_edge_agg_bwd_kernel<3, PRE, pieces> (edge MLP backward + target-side reduction, one kernel)', bwd, by_b, 4.0 * D * D * m * 2),
+                             ('global_edge_agg_fwd_kernel<7, PRE, SAVE, pieces> (edge MLP -> node segment-sum, training form)', fwd, by_f, 4.0 * D * D * m)):
+        for _ in range(3):
+            fn()
+        ms, ms_min = event_time_ms(fn, 20, 5)
+        res.append({'kernel': name, 'bound': 'hbm', 'rows_in': int(m), 'rows_out': int(n), 'bytes_per_launch': by,
+                    'us_per_launch': ms * 1e3, 'achieved': by / ms / 1e6, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': by / ms / 1e6 / HBM_PEAK_GBS, 'best_group_gbs': by / ms_min / 1e6,
+                    'fp32_equivalent_tflops': gf / ms / 1e9, 'launches_per_step': model.n_layer})
     return res
 
 
