@@ -260,9 +260,9 @@ def other_configs(dev):
         # loop, sizes from the per-graph table -> graph construction + basis is ONE engine call, nothing is read back
         st = MoleculeStore(graphs, dev).prepare_for(model)
         nxt = st.collate(sel(0))
-        for i in range(5):
-            cur, nxt = nxt, st.collate(sel((i + 1) % 4))
-            tr.step(cur, next_data=nxt)
+        for i in range(12):                                   # three passes over the four batch selections: the store's batches
+            cur, nxt = nxt, st.collate(sel((i + 1) % 4))      # differ in size from `bs`, and an allocator segment created inside
+            tr.step(cur, next_data=nxt)                       # the timed loop is a ~100 ms stall (seen as 11-12 ms/step on PDBbind)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
