@@ -808,6 +808,25 @@ int pamnet_narrow_stack_bwd_f32(const int64_t* sizes, const int32_t* const* grap
                                 float* d_x0, float* d_eg, float* d_rbf, float* d_sbf, void* const* layer_done,
                                 pamnet_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Dense layers of any width (csrc/dense.hip): Sequential(Linear, SiLU) of layers/basic.py:19-22 and the bare F.linear
+ * projections, for hidden sizes above 128 (models.py:25) and input widths no engine is built for (models.py:187-188 with
+ * a non-default num_spherical * num_radial; models.py:119 at such a dim).  fp32-accurate GEMMs on the bf16 matrix pipe
+ * (three exact bf16 pieces per operand, six products); no transposed copies, no library GEMM.
+ *   fwd:  Z = X W^T + bias (X [n][k] row stride ldx, W [m][k] row stride ldw, bias [m] nullable);
+ *         Y [n][m] = act ? SiLU(Z) : Z;  Z [n][m] nullable (the backward of an activated layer needs it).
+ *   bwd:  dZ = act ? G * SiLU'(Z) : G (G, Z [n][m]; formed while staging, never stored);
+ *         dX [n][k] (nullable) = dZ W;  dW [m][k] (nullable) = dZ^T X;  db [m] (nullable, with dW) = column sums of dZ.
+ *         The row sum of dW is split over the grid and reduced in a fixed order (deterministic); `partial`:
+ *         pamnet_dense_scratch_floats(n, k, m) floats of caller-owned scratch, required with dW.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pamnet_dense_fwd_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, int64_t n,
+                         int64_t k, int64_t m, int32_t act, float* Z, float* Y, pamnet_stream_t stream);
+int pamnet_dense_scratch_floats(int64_t n, int64_t k, int64_t m, int64_t* floats);
+int pamnet_dense_bwd_f32(const float* G, const float* Z, const float* X, int64_t ldx, const float* W, int64_t ldw,
+                         int64_t n, int64_t k, int64_t m, int32_t act, float* dX, float* dW, float* db, float* partial,
+                         pamnet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

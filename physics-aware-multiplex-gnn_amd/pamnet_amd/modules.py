@@ -21,10 +21,21 @@ from . import fused, narrow, ops
 
 # 'fused': fp32-MFMA chain kernels for dim = 128, row kernels for dim = 16 / 32 / 64; every other dim <= 128 is built
 # zero-padded at the next of these widths (models._PAMNetBase), so it runs the same engines.  Only widths above 128 reach the
-# generic formulation below (dense layers on torch ops between the HIP graph / basis / segment kernels; GPU only, not a CPU
-# fallback).  Not configurable at run time: the kernel tests (tests/test_hip_fused.py) flip this module attribute to force
-# the generic formulation at dim = 128 as their plain-PyTorch fp32 comparand.
+# generic formulation below: one launch per dense layer on the any-width GEMM kernels of csrc/dense.hip (ops.dense: bf16x6
+# MFMA, bias + SiLU in the epilogue, SiLU' while staging the backward's operand) between the HIP graph / basis / segment
+# kernels -- no library GEMM in the product.  Not configurable at run time: the kernel tests (tests/test_hip_fused.py) flip
+# this module attribute to anything else to get the same formulation on torch's own dense ops (F.linear / F.silu) as their
+# plain-PyTorch fp32 comparand.
 IMPL = 'fused'
+
+
+def _own(x):
+    return IMPL == 'fused' and x.is_cuda
+
+
+def linear(x, w, b=None):
+    """x w^T + b: the any-width GEMM kernel, or (test comparand) torch's."""
+    return ops.dense(x, w, b, act=False) if _own(x) else F.linear(x, w, b)
 
 
 def _fused(x):
@@ -79,6 +90,8 @@ def glorot_(t):
 def dense(block, x):
     """One `Sequential(Linear, SiLU)` block."""
     lin = block[0]
+    if _own(x):
+        return ops.dense(x, lin.weight, lin.bias, act=True)
     return F.silu(F.linear(x, lin.weight, lin.bias))
 
 
@@ -103,6 +116,10 @@ def update_and_heads(layer, x, res_x):
     x = res_apply(layer.res2, x)
     x = res_apply(layer.res3, x)
     o = mlp_apply(layer.mlp_out, x)
+    if _own(o):                                               # both heads as one [N, 2] product: W_out o + b | W^T o
+        b_out = layer.W_out.bias
+        h = ops.dense(o, torch.cat([layer.W_out.weight, layer.W.t()], 0), torch.cat([b_out, torch.zeros_like(b_out)]))
+        return x, h[:, 0].contiguous(), h[:, 1].contiguous()
     att = (o @ layer.W).view(-1)
     out = F.linear(o, layer.W_out.weight, layer.W_out.bias).view(-1)
     return x, out, att
@@ -148,8 +165,8 @@ class GlobalMP(_LayerBase):
             x = narrow.global_message(x, p, e, wm, bm, self.W_edge_attr.weight, g.glob, g.glob_T)
             return update_and_heads(self, x, res_x)
         x = mlp_apply(self.mlp_x1, x)
-        p = F.linear(x, torch.cat([wm[:, :d], wm[:, d:2 * d]], 0))               # [N, 2d]: W_i x | W_j x
-        q = F.linear(e, torch.cat([wm[:, 2 * d:], self.W_edge_attr.weight], 0),   # [E_g, 2d]: W_e e + b | W_ea e
+        p = linear(x, torch.cat([wm[:, :d], wm[:, d:2 * d]], 0))                 # [N, 2d]: W_i x | W_j x
+        q = linear(e, torch.cat([wm[:, 2 * d:], self.W_edge_attr.weight], 0),   # [E_g, 2d]: W_e e + b | W_ea e
                      torch.cat([bm, torch.zeros_like(bm)]))
         csr = g.glob
         z = ops.gather(p[:, :d], csr.row_of, csr.ptr) + ops.gather(p[:, d:], csr.col, g.glob_T.ptr, g.glob_T.perm) \
@@ -195,14 +212,14 @@ class LocalMP(_LayerBase):
             p = narrow.project(x, ((0, 0), (1, 0), (0, d), (1, d)), wj, wk)
         else:
             x = mlp_apply(self.mlp_x1, x)
-            p = F.linear(x, torch.cat([wj[:, :d], wk[:, :d], wj[:, d:2 * d], wk[:, d:2 * d]], 0))
+            p = linear(x, torch.cat([wj[:, :d], wk[:, :d], wj[:, d:2 * d], wk[:, d:2 * d]], 0))
         if _narrow(x):
             q = narrow.project(rbf, ((0, 2 * d), (1, 2 * d), (2, 0), (3, 0)), wj, wk, self.lin_rbf.weight,
                                self.lin_rbf_out.weight)
             zb = True                                         # the projection blocks carry no bias: added with the gates
         else:
             zero, zb = torch.zeros_like(lin_ji.bias), None
-            q = F.linear(rbf, torch.cat([wj[:, 2 * d:], wk[:, 2 * d:], self.lin_rbf.weight, self.lin_rbf_out.weight], 0),
+            q = linear(rbf, torch.cat([wj[:, 2 * d:], wk[:, 2 * d:], self.lin_rbf.weight, self.lin_rbf_out.weight], 0),
                          torch.cat([lin_ji.bias, lin_kj.bias, zero, zero]))
         csr = g.loc
         if zb is not None:                                    # narrow widths: gathers + gates in one kernel

@@ -403,51 +403,101 @@ class _FusePool(torch.autograd.Function):
         return go, ga, None, None
 
 
-class _PlainLinear(torch.autograd.Function):
-    """x W^T for a thin bias-free layer that has no kernel of its own at this width (`init_linear` of the PDBbind branch,
-    models.py:119, at dim != 128): a rocBLAS call, but as a Function of this package so that it is recorded on a Tape
-    like every other stage (a bare F.linear inside a one-node forward runs with grad mode off and would leave the weight
-    without a gradient).  The input features carry no gradient."""
+def _dense_scratch(n, k, m, like):
+    import ctypes
+    floats = ctypes.c_int64(0)
+    lib.call('pamnet_dense_scratch_floats', n, k, m, ctypes.addressof(floats))
+    return torch.empty(floats.value, dtype=torch.float32, device=like.device)
+
+
+def _dense_fwd(x, w, b, act, keep_z):
+    n, k = x.shape
+    m = w.size(0)
+    y = torch.empty(n, m, dtype=x.dtype, device=x.device)
+    z = torch.empty_like(y) if (act and keep_z) else None
+    lib.call('pamnet_dense_fwd_f32', lib.ptr(x), k, lib.ptr(w), k, lib.ptr(b), n, k, m, 1 if act else 0, lib.ptr(z),
+             lib.ptr(y), lib.stream_of(x))
+    return y, z
+
+
+def _dense_bwd(g, z, x, w, act, need_dx, need_dw, need_db):
+    """(dx, dw, db) of y = act(x w^T + b) for the upstream gradient g: one GEMM launch for dx, one split launch + its
+    fixed-order reduction for dw / db; SiLU'(z) is applied while g is staged."""
+    n, k = x.shape
+    m = g.size(1)                                              # (w is read for dx only and may be None otherwise)
+    dx = torch.empty(n, k, dtype=g.dtype, device=g.device) if need_dx else None
+    need_dw = need_dw or need_db
+    dw = torch.empty(m, k, dtype=g.dtype, device=g.device) if need_dw else None
+    db = torch.empty(m, dtype=g.dtype, device=g.device) if need_db else None
+    scratch = _dense_scratch(n, k, m, g) if need_dw else None
+    lib.call('pamnet_dense_bwd_f32', lib.ptr(g), lib.ptr(z), lib.ptr(x), k, lib.ptr(w), k, n, k, m, 1 if act else 0,
+             lib.ptr(dx), lib.ptr(dw), lib.ptr(db), lib.ptr(scratch), lib.stream_of(g))
+    return dx, dw, db
+
+
+class _Dense(torch.autograd.Function):
+    """act(x W^T + b) for a width no engine is built for (hidden sizes above 128, models.py:25; the thin bias-free
+    `init_linear` of the PDBbind branch, models.py:119, at such a dim): csrc/dense.hip -- fp32-accurate GEMMs on the bf16
+    matrix pipe for the forward, dx and dW (+ db) alike; no library GEMM, no transposed copies.  A Function of this package
+    so that a recorded forward (Tape) differentiates it like every other stage."""
 
     @staticmethod
-    def forward(ctx, x, w):
-        ctx.save_for_backward(x, w)
-        return x @ w.t()
+    def forward(ctx, x, w, b, act):
+        x, w = _c(x), _c(w)
+        b = _c(b) if b is not None else None
+        needs = ctx.needs_input_grad
+        y, z = _dense_fwd(x, w, b, act, keep_z=any(needs))
+        ctx.save_for_backward(x, w, z)
+        ctx.act, ctx.has_b = act, b is not None
+        return y
 
     @staticmethod
     def backward(ctx, g):
-        x, w = ctx.saved_tensors
-        return None, g.t() @ x
+        x, w, z = ctx.saved_tensors
+        needs = tuple(ctx.needs_input_grad) + (False,) * 4
+        dx, dw, db = _dense_bwd(_c(g), z, x, w, ctx.act, needs[0], needs[1], ctx.has_b and needs[2])
+        return dx, (dw if needs[1] else None), db, None
+
+
+def dense(x, w, b=None, act=False, tape=None):
+    """act(x w^T + b), act = SiLU or identity, on the hand-written GEMM kernels (any width)."""
+    return apply(_Dense, x, w, b, act, tape=tape)
 
 
 def plain_linear(x, w, tape=None):
-    return apply(_PlainLinear, x, w, tape=tape)
+    return apply(_Dense, x, w, None, False, tape=tape)
 
 
 class _DenseAct(torch.autograd.Function):
-    """SiLU(x W_kind^T + b_kind) for an input width no kernel of this library is built for (the spherical-basis embedding
-    with a non-default num_spherical * num_radial, models.py:187-188): rocBLAS calls between the HIP kernels, as a Function
-    of this package so that a recorded forward (Tape) differentiates it.  `kind` (int32 [rows], nullable): rows of kind 0
-    use (wa, ba), the others (wb, bb).  The input carries no gradient (geometry only)."""
+    """SiLU(x W_kind^T + b_kind) for an input width no embedding kernel is built for (the spherical-basis embedding with a
+    non-default num_spherical * num_radial, models.py:187-188) on csrc/dense.hip.  `kind` (int32 [rows], nullable): rows of
+    kind 0 use (wa, ba), the others (wb, bb) -- both layers run over all rows and a row keeps its own (the second set is
+    the pairs' embedding of the small model: same rows, other weights).  The input carries no gradient (geometry only)."""
 
     @staticmethod
     def forward(ctx, x, kind, wa, ba, wb, bb):
-        z = torch.addmm(ba, x, wa.t())
-        if kind is not None:
-            z = torch.where((kind == 0).unsqueeze(1), z, torch.addmm(bb, x, wb.t()))
-        ctx.save_for_backward(x, z, kind)
-        return z * torch.sigmoid(z)
+        x = _c(x)
+        keep = any(ctx.needs_input_grad)
+        ya, za = _dense_fwd(x, _c(wa), _c(ba), True, keep)
+        if kind is None:
+            ctx.save_for_backward(x, za, None, None)
+            return ya
+        yb, zb = _dense_fwd(x, _c(wb), _c(bb), True, keep)
+        mask = (kind == 0).unsqueeze(1)
+        ctx.save_for_backward(x, za, zb, mask)
+        return torch.where(mask, ya, yb)
 
     @staticmethod
     def backward(ctx, g):
-        x, z, kind = ctx.saved_tensors
-        sg = torch.sigmoid(z)
-        dz = g * (sg * (1 + z * (1 - sg)))
-        if kind is None:
-            return None, None, dz.t() @ x, dz.sum(0), None, None
-        ma = (kind == 0).unsqueeze(1)
-        da, db_ = dz * ma, dz * (~ma)
-        return None, None, da.t() @ x, da.sum(0), db_.t() @ x, db_.sum(0)
+        x, za, zb, mask = ctx.saved_tensors
+        g = _c(g)
+        if mask is None:
+            _, dwa, dba = _dense_bwd(g, za, x, None, True, False, True, True)
+            return None, None, dwa, dba, None, None
+        zero = torch.zeros((), dtype=g.dtype, device=g.device)
+        _, dwa, dba = _dense_bwd(torch.where(mask, g, zero), za, x, None, True, False, True, True)
+        _, dwb, dbb = _dense_bwd(torch.where(mask, zero, g), zb, x, None, True, False, True, True)
+        return None, None, dwa, dba, dwb, dbb
 
 
 def dense_act(x, lin_a, lin_b=None, kind=None, tape=None):
