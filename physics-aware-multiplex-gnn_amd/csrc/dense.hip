@@ -29,6 +29,8 @@ constexpr int TM = 64, TN = 64, TK = 32;
 constexpr int IMG_B = 1024;                     // one piece of one 16-index tile: 64 lane slots x 16 bytes
 constexpr int OPND_B = 4 * 3 * IMG_B;           // an operand's 64 x 32 block: 4 tiles x 3 pieces
 constexpr int DWG = 256;
+constexpr int TLD = TN + 4;                       // row stride of the epilogue's transposed tile (floats)
+static_assert(TM * TLD * 4 <= 2 * OPND_B, "the epilogue tile aliases the fragment images");
 constexpr int MAX_SPLITS = 512;
 
 struct Operand {
@@ -176,25 +178,34 @@ __global__ __launch_bounds__(DWG) void dense_gemm_kernel(Gemm g) {
         __syncthreads();
     }
 
-    // ---- epilogue: accumulator element r of a lane is row 4 (lane / 16) + r, column lane % 16 of its 16 x 16 tile
+    // ---- epilogue: accumulator element r of a lane is row 4 (lane / 16) + r, column lane % 16 of its 16 x 16 tile -- stored
+    // from there a wave-instruction would write sixteen 64-byte pieces.  The tile goes through LDS (the fragment images are
+    // free now) and leaves as rows: a wave writes 256 contiguous bytes per instruction.
     const int r16 = lane & 15, kg = lane >> 4;
-    float* C = g.C + (int64_t)split * g.c_split;
+    float* T = reinterpret_cast<float*>(lds);                  // [64][TLD] floats = 17 KB of the 24 KB of images
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int64_t j = j0 + wj * 32 + b * 16 + r16;
-            if (j >= g.b.no) continue;
-            const float bv = g.bias ? g.bias[j] : 0.f;
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t i = i0 + wi * 32 + a * 16 + 4 * kg + r;
-                if (i >= g.a.no) continue;
-                const float z = acc[a][b][r] + bv;
-                if (g.Zout) g.Zout[i * g.ldc + j] = z;
-                C[i * g.ldc + j] = g.act ? silu(z) : z;
-            }
+            for (int r = 0; r < 4; ++r) T[(wi * 32 + a * 16 + 4 * kg + r) * TLD + wj * 32 + b * 16 + r16] = acc[a][b][r];
+    __syncthreads();
+    {
+        float* C = g.C + (int64_t)split * g.c_split;
+        const int64_t j = j0 + lane;
+        const bool jok = j < g.b.no;
+        const float bv = (g.bias && jok) ? g.bias[j] : 0.f;
+#pragma unroll 4
+        for (int ii = 0; ii < TM / 4; ++ii) {
+            const int row = w + 4 * ii;
+            const int64_t i = i0 + row;
+            if (!jok || i >= g.a.no) continue;
+            const float z = T[row * TLD + lane] + bv;
+            if (g.Zout) g.Zout[i * g.ldc + j] = z;
+            C[i * g.ldc + j] = g.act ? silu(z) : z;
         }
+    }
+    __syncthreads();
     if (g.rowsum && blockIdx.y == 0) {                         // bias gradient: the A operand's sums over this split's k
         float* red = reinterpret_cast<float*>(lds + 2 * OPND_B);        // [4 k-groups][64 outer indices]
         red[kga * 64 + oa] = rs;
