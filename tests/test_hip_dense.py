@@ -181,3 +181,29 @@ def test_non_default_basis_embedding_runs_on_the_dense_kernels(dev):
     ref = [y64.detach()] + [p.grad.double() for p in (la.weight, la.bias, lb.weight, lb.bias)]
     for a, r in zip(got, ref):
         assert maxnorm_err(a.cpu().double(), r.cpu()) < 2e-6
+
+
+def test_trainer_on_a_wide_model_matches_torch_adam(dev):
+    """Trainer (flat buffers, fused clip + Adam + EMA) over a dim = 136 model -- the layer-by-layer path under plain autograd,
+    gradients accumulated into the trainer's preallocated views -- against torch.optim.Adam + clip_grad_norm_ on a twin."""
+    import models
+    from oracle import pamnet_oracle as O
+    from pamnet_amd import synth, train
+    cfg = models.Config(dataset='QM9', dim=136, n_layer=1, cutoff_l=5.0, cutoff_g=5.0)
+    sd = O.init_state_dict(cfg, seed=7)
+    model, twin = models.PAMNet(cfg), models.PAMNet(cfg)
+    model.load_state_dict(sd, strict=True), twin.load_state_dict(sd, strict=True)
+    model, twin = model.to(dev), twin.to(dev)
+    data = synth.qm9_batch(4, 0, 6).to(dev)
+    tr = train.Trainer(model, lr=1e-3)
+    opt = torch.optim.Adam(twin.parameters(), lr=1e-3)
+    for _ in range(4):
+        tr.step(data)
+        opt.zero_grad()
+        torch.nn.functional.l1_loss(twin(data), data.y).backward()
+        torch.nn.utils.clip_grad_norm_(twin.parameters(), 1000.0)
+        opt.step()
+    tr.drain()
+    a, c = model.state_dict(), twin.state_dict()
+    for k in a:
+        assert maxnorm_err(a[k].cpu().numpy(), c[k].cpu().numpy()) < 2e-4, k      # (Adam amplifies rounding: g / |g|)
