@@ -30,7 +30,8 @@ IMPL = 'fused'
 
 
 def _own(x):
-    return IMPL == 'fused' and x.is_cuda
+    # (a float64 twin of a layer -- the kernel tests' fp64 comparand -- stays on torch's dense ops)
+    return IMPL == 'fused' and x.is_cuda and x.dtype == torch.float32
 
 
 def linear(x, w, b=None):

@@ -411,6 +411,8 @@ def _dense_scratch(n, k, m, like):
 
 
 def _dense_fwd(x, w, b, act, keep_z):
+    if x.dtype != torch.float32 or w.dtype != torch.float32:   # (the kernels read fp32 through raw pointers)
+        raise TypeError('pamnet dense kernels compute in float32: got %s x %s' % (x.dtype, w.dtype))
     n, k = x.shape
     m = w.size(0)
     y = torch.empty(n, m, dtype=x.dtype, device=x.device)
