@@ -106,7 +106,7 @@ __device__ __forceinline__ void store_slot(char* base, int o, int kg, const floa
         *reinterpret_cast<uint4*>(d + pc * IMG_B) = make_uint4(f.p[pc][0], f.p[pc][1], f.p[pc][2], f.p[pc][3]);
 }
 
-__global__ __launch_bounds__(DWG) void dense_gemm_kernel(Gemm g) {
+__global__ __launch_bounds__(DWG, 4) void dense_gemm_kernel(Gemm g) {
     __shared__ __attribute__((aligned(16))) char lds[2 * OPND_B + 4 * 64 * 4];
     char* la = lds;
     char* lb = lds + OPND_B;
@@ -215,19 +215,29 @@ __global__ __launch_bounds__(DWG) void dense_gemm_kernel(Gemm g) {
     }
 }
 
-// out[e] = sum over splits of partial[s * stride + e], in split order
+// out[e] = sum over splits of partial[s * stride + e] in a fixed order: a workgroup owns 64 consecutive elements, its four
+// waves take the splits s = w, w + 4, ... (four loads in flight per thread: a thin weight gradient has few elements and
+// up to 512 splits, so the walk over the splits is the whole cost), the four wave sums are added in wave order.
 __global__ __launch_bounds__(256) void dense_reduce_kernel(const float* __restrict__ partial, int splits, int64_t stride,
                                                            int64_t count, float* __restrict__ out) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= count) return;
-    float s0 = 0.f, s1 = 0.f;
-    int s = 0;
-    for (; s + 1 < splits; s += 2) {
-        s0 += partial[(int64_t)s * stride + e];
-        s1 += partial[(int64_t)(s + 1) * stride + e];
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < count) {
+        const float* p = partial + e;
+        int s = w;
+        for (; s + 12 < splits; s += 16) {
+            s0 += p[(int64_t)s * stride];
+            s1 += p[(int64_t)(s + 4) * stride];
+            s2 += p[(int64_t)(s + 8) * stride];
+            s3 += p[(int64_t)(s + 12) * stride];
+        }
+        for (; s < splits; s += 4) s0 += p[(int64_t)s * stride];
     }
-    if (s < splits) s0 += partial[(int64_t)s * stride + e];
-    out[e] = s0 + s1;
+    red[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0 && e < count) out[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 inline Operand operand(const float* p, const float* z, int64_t so, int64_t sk, int64_t no, int64_t nk) {
@@ -303,11 +313,11 @@ extern "C" int pamnet_dense_bwd_f32(const float* G, const float* Z, const float*
         g.k_chunk = ceil_div(ceil_div(n > 0 ? n : 1, splits), TK) * TK;
         const int rc = launch(g, splits, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)ceil_div(m * k, 256)), dim3(256), 0, st, partial, splits, m * k,
+        hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)ceil_div(m * k, 64)), dim3(256), 0, st, partial, splits, m * k,
                            m * k, dW);
         PAMNET_LAUNCH_CHECK();
         if (db) {
-            hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st,
+            hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)ceil_div(m, 64)), dim3(256), 0, st,
                                partial + (int64_t)splits * m * k, splits, m, m, db);
             PAMNET_LAUNCH_CHECK();
         }

@@ -34,3 +34,21 @@ def test_wgrad_kernels_do_not_spill(tmp_path):
             assert scratch == 0, '%s spills (%d bytes of scratch per lane)' % (name, scratch)
             assert vgprs + agprs <= 256, '%s needs %d registers: no second workgroup per CU' % (name, vgprs + agprs)
     assert seen >= 3
+
+
+def test_dense_gemm_kernel_resources(tmp_path):
+    """csrc/dense.hip: no scratch, and at most 128 registers -- four workgroups per CU (one wave each per SIMD) overlap one
+    another's staging, which is what hides the two barriers per 32-index block."""
+    hipcc = '/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else shutil.which('hipcc')
+    if not hipcc:
+        pytest.skip('hipcc not available')
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(REPO, 'include'),
+                        '-I' + CSRC, '-ffp-contract=on', '-c', os.path.join(CSRC, 'dense.hip'), '-o',
+                        str(tmp_path / 'dense.o'), '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = [b for b in re.split(r'remark: Function Name: ', r.stderr)[1:] if 'dense_gemm_kernel' in b.split()[0]]
+    assert len(blocks) == 1
+    b = blocks[0]
+    assert int(re.search(r'ScratchSize \[bytes/lane\]: (\d+)', b).group(1)) == 0
+    assert int(re.search(r'VGPRs: (\d+)', b).group(1)) + int(re.search(r'AGPRs: (\d+)', b).group(1)) <= 128
+    assert int(re.search(r'LDS Size \[bytes/block\]: (\d+)', b).group(1)) <= 40 * 1024
