@@ -34,3 +34,7 @@ KIND=pdbbind bash $R/tools/pmc_issue.sh > /dev/null 2>&1; cp $O/issue_pdbbind.tx
 KIND=qm9 STEPS=30 bash $R/tools/pmc_issue.sh > /dev/null 2>&1; cp $O/issue_qm9.txt $O/r04_issue_slots_qm9_pmc.txt
 (PAMNET_AGG_PIECES=0 python $R/tools/agg_bench.py pdbbind 2>/dev/null; PAMNET_AGG_PIECES=0 python $R/tools/agg_bench.py qm9 2>/dev/null) | grep -v amdgpu.ids > $O/r04_edge_agg_microbench_reader_split.txt
 (python $R/tools/tail_probe_packed.py 2286 4 2>/dev/null | tail -9; python $R/tools/tail_probe_packed.py 16 4 2>/dev/null | tail -9) > $O/r04_tail_probe_packed.txt
+# dense kernels of the wide (dim > 128) path: micro-benchmark against the library call they replace, and the kernel statistics of a
+# dim = 256 training step (no Cijk_ / rocBLAS / hipBLASLt kernel may appear)
+python $R/tools/dense_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/r04_dense_probe_raw.txt
+bash $R/tools/prof_wide.sh > /dev/null 2>&1
