@@ -3,6 +3,8 @@
 torch is plumbing here: it owns device memory, the stream and the autograd tape; every forward/backward body below is a
 HIP kernel call.  No CPU fallback: tensors that are not on an MI355X raise in lib.stream_of.
 """
+import ctypes
+
 import torch
 
 from . import lib
@@ -404,7 +406,6 @@ class _FusePool(torch.autograd.Function):
 
 
 def _dense_scratch(n, k, m, like):
-    import ctypes
     floats = ctypes.c_int64(0)
     lib.call('pamnet_dense_scratch_floats', n, k, m, ctypes.addressof(floats))
     return torch.empty(floats.value, dtype=torch.float32, device=like.device)
