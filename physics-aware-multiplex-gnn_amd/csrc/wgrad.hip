@@ -42,9 +42,12 @@ inline int job_slots(int64_t rows, int64_t chunk) {
 }
 
 // Rows per slot for a batch: 256, or the smallest multiple of 64 above it for which the whole batch fits in
-// TARGET_SLOTS workgroups -- one wave of workgroups over the 256 CUs instead of a full round plus a ragged tail
+// TARGET_SLOTS workgroups -- one co-resident round over the 256 CUs instead of a full round plus a ragged tail
 // (345 workgroups at the QM9 B=128 shape ran as 2 rounds: 49 us; one round of 256 x 384 rows: see DESIGN.md).
-constexpr int target_slots() { return 256; }
+// Two slots per CU (launch bound 2, 2 x 68 KB of LDS): one's staging runs under the other's MFMAs.  Round 4, same box,
+// alternated three times: 256 -> 512 slots  PDBbind step 8.77-8.80 -> 8.63-8.69 ms (its 700 k-row jobs), QM9 2.207-2.212 ->
+// 2.205-2.211 (neutral: the pair launch has 137 k rows); 1 024 slots (four per CU in turn): +0.03 ms on both.
+constexpr int target_slots() { return 512; }
 // rows per rider slot to start from (a rider should not outlast the node chain it rides with: ~26 us)
 constexpr int64_t rider_rows() { return 256; }
 // smallest chunk a plan may use (scratch is sized for it)
