@@ -396,11 +396,14 @@ def main():
         return main_basis()
     if '--baseline-s-only' in sys.argv:
         return main_baseline_s()
+    if '--wide-only' in sys.argv:
+        return main_wide()
     main_forward()
     main_train()
     main_baseline()
     main_baseline_s()
     main_basis()
+    main_wide()
 
 
 def fixture_baseline(name, cfg_kw, batch, seed, grads=False, small=False):
@@ -465,6 +468,27 @@ def main_baseline():
     fixture_baseline('baseline_pdbbind_b32', pdb, synth.collate([synth.pdbbind_complex(1, i) for i in range(32)]), seed=3)
     rna = dict(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
     fixture_baseline('baseline_rna_b8', rna, synth.rna_batch(2, 0, 8), seed=5)
+
+
+def _wide_batches():
+    return {'wide_qm9_d192_l2': synth.qm9_batch(21, 0, 16),
+            'wide_qm9s_d136_l2': synth.qm9_batch(22, 0, 16),
+            'wide_pdbbind_d160_l2': synth.pdbbind_batch(7, 0, 2, n_pocket=70, n_ligand=14),
+            'wide_rna_d144_l1': synth.rna_batch(5, 0, 2, n_nodes=150)}
+
+
+def main_wide():
+    """Hidden sizes above 128 (models.py:25) from the reference itself: the widths whose dense layers run on csrc/dense.hip.
+    Outputs, pooled node values, graph sizes (fp32 and fp64 runs) and the reference's fp64 gradients of the mean L1 loss."""
+    b = _wide_batches()
+    fixture_baseline('wide_qm9_d192_l2', dict(dataset='QM9', dim=192, n_layer=2, cutoff_l=5.0, cutoff_g=5.0),
+                     b['wide_qm9_d192_l2'], seed=41, grads=True)
+    fixture_baseline('wide_qm9s_d136_l2', dict(dataset='QM9', dim=136, n_layer=2, cutoff_l=5.0, cutoff_g=5.0),
+                     b['wide_qm9s_d136_l2'], seed=42, grads=True, small=True)
+    fixture_baseline('wide_pdbbind_d160_l2', dict(dataset='PDBbind', dim=160, n_layer=2, cutoff_l=2.0, cutoff_g=6.0),
+                     b['wide_pdbbind_d160_l2'], seed=43, grads=True)
+    fixture_baseline('wide_rna_d144_l1', dict(dataset='rna_native', dim=144, n_layer=1, cutoff_l=2.6, cutoff_g=20.0,
+                                              flow='target_to_source'), b['wide_rna_d144_l1'], seed=44, grads=True)
 
 
 def main_baseline_s():

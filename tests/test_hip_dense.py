@@ -207,3 +207,62 @@ def test_trainer_on_a_wide_model_matches_torch_adam(dev):
     a, c = model.state_dict(), twin.state_dict()
     for k in a:
         assert maxnorm_err(a[k].cpu().numpy(), c[k].cpu().numpy()) < 2e-4, k      # (Adam amplifies rounding: g / |g|)
+
+
+@pytest.mark.parametrize('name', ['wide_qm9_d192_l2', 'wide_qm9s_d136_l2', 'wide_pdbbind_d160_l2', 'wide_rna_d144_l1'])
+def test_wide_models_vs_reference_runs(dev, golden, name):
+    """Hidden sizes above 128 against runs of the REFERENCE ITSELF (tests/golden/gen/gen_golden.py --wide-only; fp32 and fp64
+    runs of models.py at dim 192 / 136 / 160 / 144): graph outputs and pooled node values under the bound of
+    test_hip_model.py (never tighter than the reference's own fp32 run), the integer sizes of its graphs exactly, and the
+    backward of the mean L1 loss against the reference's fp64 autograd -- loss, global gradient norm, every parameter
+    gradient's L2 norm and the stored full gradient tensors."""
+    import numpy as np
+    import models
+    from oracle import pamnet_oracle as O
+    from test_hip_model import GRAD_TOL, _cfg_from, _ok
+    from test_oracle_golden import _wide_batch
+    g = golden(name)
+    cfg = _cfg_from(g, models.Config)
+    small = 'qm9s' in name
+    b = _wide_batch(name)
+    assert b.x.size(0) == int(g['num_nodes']) and abs(float(b.x.double().abs().sum()) - float(g['x_checksum'])) < 1e-6
+    sd = O.init_state_dict(cfg, seed=int(g['seed']), small=small)
+    assert abs(sum(float(v.double().abs().sum()) for v in sd.values()) - float(g['weights_checksum'])) < 1e-6
+    model = (models.PAMNet_s if small else models.PAMNet)(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    assert model.dim == cfg.dim > 128
+    data = b.to(dev)
+    out_t = model(data)
+    loss = torch.nn.functional.l1_loss(out_t, data.y)
+    loss.backward()
+    out, node_out = out_t.detach().cpu().numpy(), model._node_out.cpu().numpy()
+    ok, info_n = _ok(node_out, g['node_out32'], g['node_out64'])
+    assert ok, ('node_out', info_n)
+    gc = model._graph_cache
+    assert gc.loc.m == int(g['num_edges_l']) and gc.n_trip == int(g['num_triplets']) and gc.n_pair == int(g['num_pairs'])
+    if cfg.dataset == 'PDBbind':
+        scale = max(float(np.abs(g['node_out64'][b.batch.numpy() == k]).sum()) for k in range(len(g['out64'])))
+        ok, info = _ok(out, g['out32'], g['out64'], scale)
+    else:
+        ok, info = _ok(out, g['out32'], g['out64'])
+    assert ok, ('out', info)
+    assert abs(float(loss) - float(g['loss64'])) < 2e-5 * max(1.0, abs(float(g['loss64'])))
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    gn = float(torch.sqrt(sum((v.double() ** 2).sum() for v in grads.values())))
+    assert abs(gn / float(g['grad_norm64']) - 1) < 1e-4, (gn, float(g['grad_norm64']))
+    worst = 0.0
+    for k, l2 in zip(g['grad_keys'].tolist(), g['grad_l2_64']):
+        scale = float(l2)
+        if k.endswith('W_out.bias') and cfg.dataset == 'PDBbind':
+            # d loss / d b_out = the sum of the signed pooling weights over the nodes (complex - pocket - ligand): almost pure
+            # cancellation, so it is judged on the scale of its Linear's weight gradient (test_hip_model._check_gradients)
+            scale = max(scale, float(grads[k[:-4] + 'weight'].abs().max()))
+        e = abs(float(grads[k].double().norm()) - float(l2)) / max(scale, 1e-300)
+        assert e < 1e-4, (k, e)
+        worst = max(worst, e)
+    for k in g.files:
+        if k.startswith('grad64/'):
+            assert maxnorm_err(grads[k[7:]].cpu().numpy(), g[k]) < GRAD_TOL, k
+    print('%s vs the reference: out %.2e (ref fp32 %.2e), node_out %.2e; |grad| rel %.1e, worst per-tensor L2 %.1e'
+          % (name, info[0], info[1], info_n[0], abs(gn / float(g['grad_norm64']) - 1), worst))

@@ -191,3 +191,55 @@ def test_oracle_at_baseline_sizes_vs_reference_runs(golden, name):
             assert inter['edge_index_l'].shape[1] == int(g['num_edges_l'])
             assert inter['idx_kj'].numel() == int(g['num_triplets'])
             assert inter['idx_jj_pair'].numel() == int(g['num_pairs'])
+
+
+def _wide_batch(name):
+    from pamnet_amd import synth
+    return {'wide_qm9_d192_l2': lambda: synth.qm9_batch(21, 0, 16),
+            'wide_qm9s_d136_l2': lambda: synth.qm9_batch(22, 0, 16),
+            'wide_pdbbind_d160_l2': lambda: synth.pdbbind_batch(7, 0, 2, n_pocket=70, n_ligand=14),
+            'wide_rna_d144_l1': lambda: synth.rna_batch(5, 0, 2, n_nodes=150)}[name]()
+
+
+@pytest.mark.parametrize('name', ['wide_qm9_d192_l2', 'wide_qm9s_d136_l2', 'wide_pdbbind_d160_l2', 'wide_rna_d144_l1'])
+def test_oracle_at_hidden_sizes_above_128_vs_reference_runs(golden, name):
+    """Hidden sizes above 128 (models.py:25: any `dim`) -- the widths the HIP path runs layer by layer on csrc/dense.hip --
+    pinned to runs of the REFERENCE ITSELF (gen_golden.py --wide-only): the oracle's outputs and pooled node values against
+    the reference's fp64 / fp32 runs, graph sizes exact, and the oracle's fp64 loss gradient against the reference's (loss,
+    global norm, every parameter's L2 norm, the stored full tensors)."""
+    g = golden(name)
+    cfg = _cfg(g)
+    small = 'qm9s' in name
+    b = _wide_batch(name)
+    assert b.x.size(0) == int(g['num_nodes']) and abs(float(b.x.double().abs().sum()) - float(g['x_checksum'])) < 1e-6
+    sd32 = O.init_state_dict(cfg, seed=int(g['seed']), small=small)
+    assert abs(sum(float(v.double().abs().sum()) for v in sd32.values()) - float(g['weights_checksum'])) < 1e-6
+    fwd = O.pamnet_s_forward if small else O.pamnet_forward
+    torch.set_num_threads(8)
+    pos, ei = getattr(b, 'pos', None), getattr(b, 'edge_index', None)
+    for tag, dt, tol in (('64', torch.float64, 1e-6), ('32', torch.float32, 2e-5)):
+        sd = {k: v.to(dt) for k, v in sd32.items()}
+        inter = {}
+        xin = b.x.to(dt) if cfg.dataset == 'PDBbind' else b.x
+        with torch.no_grad():
+            out = fwd(sd, cfg, xin, b.batch, pos, ei, dtype=dt, intermediates=inter)
+        if cfg.dataset == 'PDBbind':
+            scale = max(float(np.abs(g['node_out64'][b.batch.numpy() == k]).sum()) for k in range(len(g['out64'])))
+            assert float(np.max(np.abs(out.numpy() - g['out' + tag]))) / scale < tol, (tag, 'out')
+        else:
+            assert maxnorm_err(out, g['out' + tag]) < tol, (tag, 'out')
+        assert maxnorm_err(inter['pool_in'], g['node_out' + tag]) < tol, (tag, 'node_out')
+        if tag == '32' and not small:              # (the small model's oracle keeps no index intermediates)
+            assert inter['edge_index_l'].shape[1] == int(g['num_edges_l'])
+            assert inter['idx_jj_pair'].numel() == int(g['num_pairs'])
+            assert inter['idx_kj'].numel() == int(g['num_triplets'])
+    p64 = O.as_params({k: v.double() for k, v in sd32.items()})
+    x64 = b.x if cfg.dataset == 'QM9' else b.x.double()
+    loss = torch.nn.functional.l1_loss(fwd(p64, cfg, x64, b.batch, pos, ei, dtype=torch.float64), b.y.double())
+    loss.backward()
+    assert abs(float(loss) - float(g['loss64'])) < 1e-9 * max(1.0, abs(float(g['loss64'])))
+    for k, l2 in zip(g['grad_keys'].tolist(), g['grad_l2_64']):
+        assert abs(float(p64[k].grad.norm()) - float(l2)) <= 1e-7 * max(float(l2), 1e-30) + 1e-14, k
+    for k in g.files:
+        if k.startswith('grad64/'):
+            assert maxnorm_err(p64[k[7:]].grad.numpy(), g[k]) < 1e-6, k
