@@ -308,7 +308,7 @@ def pdbbind_kernel_rooflines(model, batch, dev):
     d, n, m = model.dim, g.n, g.glob.m
     src, dst = torch.randn(m, d, device=dev), torch.empty(n, d, device=dev)
     res = []
-    for name, perm, ptr in (('segment_sum_kernel<..., perm> (transposed CSR: d z rows gathered by source node)', g.glob_T.perm, g.glob_T.ptr),
+    for name, perm, ptr in (('segment_sum_split_kernel<..., perm> (transposed CSR: d z rows gathered by source node)', g.glob_T.perm, g.glob_T.ptr),
                             ('segment_sum_kernel (streamed rows, same shape)', None, g.glob.ptr)):
         fn = lambda: ops.segment_sum_raw(dst, None, src, None, None, None, perm, ptr, n, d)
         for _ in range(5):

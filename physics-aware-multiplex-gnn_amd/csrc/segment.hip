@@ -36,8 +36,10 @@ __device__ __forceinline__ float4 load_term(const float4* __restrict__ A, const 
     return a;
 }
 
-// rows * lanes-per-row at or below this use the split kernel: less than one full wave of lanes per SIMD on 256 CUs
-constexpr int64_t SPLIT_MAX_LANES = 256 * 4 * 64 * 4;
+// rows * lanes-per-row at or below this use the split kernel (four lane groups share a row): up to four waves of lanes per
+// SIMD on 256 CUs.  (One wave per SIMD until round 4; the node-level reductions of a PDBbind batch -- 19 000 rows of ~37 terms,
+// 608 k lanes -- are 4 x shorter dependent walks with the split: gather form 72-76 -> 66-70 us, tools/perm_probe.py.)
+constexpr int64_t SPLIT_MAX_LANES = 256 * 4 * 64 * 4 * 4;
 
 __device__ __forceinline__ void acc4(float4& s, const float4& v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
 
