@@ -13,7 +13,9 @@ import csv, glob, json
 def counter(name):
     f = glob.glob('/tmp/pmc_%s/**/*counter_collection.csv' % name, recursive=True)[0]
     vals = [float(r['Counter_Value']) for r in csv.DictReader(open(f))
-            if 'segment_sum_kernel' in r['Kernel_Name'] and r['Counter_Name'] == name]
+            if 'segment_sum' in r['Kernel_Name'] and r['Counter_Name'] == name]
+    global kname
+    kname = sorted({r['Kernel_Name'].split('::')[-1].split('<')[0].split('(')[0] for r in csv.DictReader(open(f)) if 'segment_sum' in r['Kernel_Name']})
     return sum(vals) / len(vals), len(vals)
 fetch, n1 = counter('FETCH_SIZE')
 write, n2 = counter('WRITE_SIZE')
@@ -22,7 +24,7 @@ write, n2 = counter('WRITE_SIZE')
 import re
 alg = float(re.search(r'algorithmic bytes (\d+)', open('/tmp/pmc_FETCH_SIZE.log').read()).group(1))
 traffic = (2.0 * fetch + write) * 1024.0
-print(json.dumps({'kernel': 'segment_sum_kernel', 'FETCH_SIZE_KB': fetch, 'WRITE_SIZE_KB': write, 'launches': [n1, n2],
+print(json.dumps({'kernel': ' / '.join(kname), 'FETCH_SIZE_KB': fetch, 'WRITE_SIZE_KB': write, 'launches': [n1, n2],
                   'traffic_bytes_per_launch': traffic, 'algorithmic_bytes_per_launch': alg,
                   'traffic_over_algorithmic': traffic / alg,
                   'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python ' + __import__('os').environ.get('PROBE', 'tools/scatter_probe.py') + '; traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction)'}))
