@@ -32,7 +32,9 @@ extern "C" {
 
 typedef void* pamnet_stream_t; /* hipStream_t */
 
-/* Library / ABI version (bumped on any signature change). */
+/* Library / ABI version (bumped on any signature change).  pamnet_abi_version() returns the PAMNET_ABI_VERSION the library
+ * was built against; a binding compares it with this header's (pamnet_amd/lib.py load(): a stale .so fails loudly). */
+#define PAMNET_ABI_VERSION 8
 int pamnet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -529,6 +531,21 @@ int pamnet_global_edge_agg_bwd_f32(const float* d_agg, int64_t n_edges, int64_t 
                                    const float* ea, const float* We,
                                    int64_t ld_we, const float* Wea, int64_t ld_wea, float* dz, float* dea, float* d_e,
                                    int32_t accumulate, float* dPi, pamnet_stream_t stream);
+/* The same backward WITH the step's two weight gradients (layers/global_message_passing.py:52-56: the gradients of the
+ * e-block of mlp_m and of W_edge_attr): d ea is not written; every workgroup forms its rows' share of dW_e = dz^T e,
+ * dW_ea = dea^T e and of the bias gradient (column sums of dz) and leaves them in `partial`: 2 * G slots of 128 * 128 + 256
+ * floats (pamnet_global_edge_agg_wg_floats: *floats, *slots = G), slots [0, G) = dW_e shares + bias parts, [G, 2 G) = dW_ea
+ * shares.  pamnet_wgrad_edge_enqueue_f32 registers them with a deferred weight-gradient context: the next
+ * pamnet_wgrad_deferred_f32 launch (or pamnet_wgrad_flush_f32) sums them in slot order into dW_e / db / dW_ea.
+ * dz, d_e, dPi: bitwise the values of pamnet_global_edge_agg_bwd_f32. */
+int pamnet_global_edge_agg_wg_floats(int64_t n_edges, int64_t* floats /* host */, int64_t* slots /* host, nullable */);
+int pamnet_global_edge_agg_bwd_wg_f32(const float* d_agg, int64_t n_edges, int64_t n_nodes, const int32_t* ptr,
+                                      const int32_t* row_of, const int32_t* cuts /* nullable */, const float* z,
+                                      const float* ea, const float* e, const float* We, int64_t ld_we, const float* Wea,
+                                      int64_t ld_wea, float* dz, float* d_e, int32_t accumulate, float* dPi, float* partial,
+                                      pamnet_stream_t stream);
+int pamnet_wgrad_edge_enqueue_f32(void* ctx /* host */, int64_t slots, float* dW_e, int64_t ld_e, float* db /* nullable */,
+                                  float* dW_ea, int64_t ld_ea, const float* partial);
 int pamnet_local_agg_fwd_f32(const float* m_ji, const float* m_nb, const float* s, const float* q3,
                              const int32_t* t_ptr, const int32_t* t_col, const int32_t* l_ptr, const float* init,
                              int64_t n_nodes, float* m_t, float* out, pamnet_stream_t stream);

@@ -483,6 +483,313 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
     }
 }
 
+// ================================================================ backward + its two weight gradients, one kernel (round 5)
+// The weight gradients of the global edge step, dW_e = dz^T e and dW_ea = dea^T e (E_g rows each), were two jobs of the
+// split-K launches of wgrad.hip: four [E_g, 128] streams read again (dz, dea, e twice) that this kernel had on chip a moment
+// earlier, plus the d ea rows written for that purpose only -- 1.45 ms of the 8.3 ms PDBbind step.  Here every workgroup
+// also forms its rows' share of both products and leaves two 128 x 128 partial tiles (+ the column sums of dz = the bias
+// gradient) in the slot format of wgrad_core.h; the fixed-order reduction over the workgroups rides in the next
+// weight-gradient launch (pamnet_wgrad_edge_enqueue_f32).  Per layer: + one read of the e rows, - the d ea write, - the
+// four operand streams of the weight-gradient jobs.
+//
+// What it takes on a CU:
+//   * the row index is the MFMA k dimension of these products: chunks of 32 rows = one k-step of v_mfma_f32_16x16x32_bf16;
+//     wave w owns rows [16 w, 16 w + 16) of both results (2 x 8 accumulator tiles = 64 registers).
+//   * operands as "8 consecutive rows of one column" fragments.  The sweep thread owns a float4 of ONE row, so the piece
+//     images are written row-major and read through ds_read_b64_tr_b16 (the hardware's 4 x 4 transposing read; semantics
+//     checked on the device by tools/probes/tr16_probe.hip).  ONE image per operand serves both reads -- the dX GEMMs'
+//     row fragments (ds_read_b128) and the weight gradients' column fragments:
+//       image = [piece 3][channel tile 8] subtiles of KSUB bytes, a subtile = [32 rows][16 channels] bf16, row r at
+//       position kpos(r) = r with bits 2 and 3 swapped, 32 bytes per row.
+//     transposing read (two 32-lane groups): the rows {8 g + j} of two k-groups g sit at 8 distinct positions mod 8 ->
+//     256 distinct bytes; ds_read_b128 (the guide's four 16-lane groups: rows {0-3, 12-15} of one k-group with rows {4-11}
+//     of the next, i.e. the two 16-byte halves of a row): 8 distinct positions mod 8 per half; the sweep's ds_write_b64
+//     (16 lanes = one row, 16 float4 columns = 4 subtiles x 4 x 8 bytes): KSUB = 1024 + 32 puts the four subtiles 8 banks
+//     apart.  All three conflict-free by the guide's LDS table.
+//   * registers: the resident weight pieces (96) + 64 accumulators do not fit beside the sweeps.  The THIRD piece of both
+//     weight slices -- used by one of the six products -- waits in LDS (64 KB, wave-private lane-linear images), the other
+//     two stay in registers (64).
+// d z, d e, d P_i: same arithmetic in the same order as global_edge_agg_bwd_kernel (bitwise the same values).
+constexpr int KSUB = 1024 + 32;
+constexpr int KIMG = 3 * 8 * KSUB;            // bytes of one operand's image: 32 rows x 128 channels x 3 pieces (+ padding)
+__device__ __forceinline__ int kpos(int r) { return (r & 19) | ((r & 8) >> 1) | ((r & 4) << 1); }
+// row r (0..31), float4 column c4 -> 8 bytes in each piece plane
+__device__ __forceinline__ void st_kpieces4(char* __restrict__ I, int r, int c4, const float4& v) {
+    char* d = I + (c4 >> 2) * KSUB + kpos(r) * 32 + (c4 & 3) * 8;
+    uint32_t a0, b0, c0, a1, b1, c1;
+    split3(v.x, v.y, a0, b0, c0);
+    split3(v.z, v.w, a1, b1, c1);
+    *reinterpret_cast<uint2*>(d) = make_uint2(a0, a1);
+    *reinterpret_cast<uint2*>(d + 8 * KSUB) = make_uint2(b0, b1);
+    *reinterpret_cast<uint2*>(d + 16 * KSUB) = make_uint2(c0, c1);
+}
+// row fragment (rows 16 m + (l & 15), channels 32 q + 8 (l >> 4) + 0..7): the A operand of the dX GEMMs
+__device__ __forceinline__ Frag3 lds_kfrag_row(const char* __restrict__ I, int m, int q) {
+    const int lane = threadIdx.x & 63, kg = lane >> 4;
+    const char* s = I + (2 * q + (kg >> 1)) * KSUB + (kpos(lane & 15) + 16 * m) * 32 + (kg & 1) * 16;
+    Frag3 f;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+        const uint4 u = *reinterpret_cast<const uint4*>(s + pc * 8 * KSUB);
+        f.p[pc][0] = u.x, f.p[pc][1] = u.y, f.p[pc][2] = u.z, f.p[pc][3] = u.w;
+    }
+    return f;
+}
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 lds_tr16(const char* p) {
+    typedef i16x4 __attribute__((address_space(3))) * lds_ptr;
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p)));
+}
+// column fragment (channel 16 ct + (l & 15), rows 8 (l >> 4) + 0..7): both operands of the weight-gradient products.
+// Lane 4 j + c of a 16-lane group hands the transposing read the 8 bytes (row 8 g + j, channels 4 c .. 4 c + 3) and gets
+// rows 8 g + 0..3 of its own channel back; rows + 4 sit 8 positions = 256 bytes further.
+__device__ __forceinline__ Frag3 lds_kfrag_col(const char* __restrict__ I, int ct) {
+    const int lane = threadIdx.x & 63;
+    const int r = 8 * (lane >> 4) + ((lane & 15) >> 2);
+    const char* s = I + ct * KSUB + kpos(r) * 32 + (lane & 3) * 8;
+    Frag3 f;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+        const u32x2 lo = lds_tr16(s + pc * 8 * KSUB), hi = lds_tr16(s + pc * 8 * KSUB + 256);
+        f.p[pc][0] = lo[0], f.p[pc][1] = lo[1], f.p[pc][2] = hi[0], f.p[pc][3] = hi[1];
+    }
+    return f;
+}
+// a wave's transposed weight slice: pieces 0 and 1 in registers, piece 2 in its own lane-linear LDS image ([q][lane] x 16 B)
+struct WFragB2 {
+    uint32_t p[DIM / 32][2][4];
+};
+__device__ __forceinline__ void load_wfragb2_t(WFragB2& f, char* __restrict__ w2, const float* __restrict__ W, int ldw,
+                                               int wc) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < DIM / 32; ++q) {
+        float v[8];
+        const float* wp = W + (size_t)(32 * q + 8 * kg) * ldw + wc + j;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = wp[(size_t)t * ldw];
+        const Frag3 fr = split_frag(v);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) f.p[q][0][t] = fr.p[0][t], f.p[q][1][t] = fr.p[1][t];
+        *reinterpret_cast<uint4*>(w2 + (q * 64 + lane) * 16) = make_uint4(fr.p[2][0], fr.p[2][1], fr.p[2][2], fr.p[2][3]);
+    }
+}
+// acc[0 .. G) += I(tiles 0 .. G) * slice: the six piece products in the order of mfma6 (edge_core.h)
+template <int G>
+__device__ __forceinline__ void mma_k16(const char* __restrict__ I, const WFragB2& f, const char* __restrict__ w2,
+                                        Acc<2>& acc) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < DIM / 32; ++q) {
+        Frag3 a[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) a[g] = lds_kfrag_row(I, g, q);
+        const uint4 u = *reinterpret_cast<const uint4*>(w2 + (q * 64 + lane) * 16);
+        const uint32_t b2[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc.v[g] = mfma_bf16(a[g].p[2], f.p[q][0], acc.v[g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc.v[g] = mfma_bf16(a[g].p[1], f.p[q][1], acc.v[g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc.v[g] = mfma_bf16(a[g].p[0], b2, acc.v[g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc.v[g] = mfma_bf16(a[g].p[1], f.p[q][0], acc.v[g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc.v[g] = mfma_bf16(a[g].p[0], f.p[q][1], acc.v[g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc.v[g] = mfma_bf16(a[g].p[0], f.p[q][0], acc.v[g]);
+    }
+}
+// acc += a^T b over the chunk's 32 rows: the six piece products, small ones first
+__device__ __forceinline__ void mfma6_col(const Frag3& a, const Frag3& b, f32x4& acc) {
+    acc = mfma_bf16(a.p[2], b.p[0], acc);
+    acc = mfma_bf16(a.p[1], b.p[1], acc);
+    acc = mfma_bf16(a.p[0], b.p[2], acc);
+    acc = mfma_bf16(a.p[1], b.p[0], acc);
+    acc = mfma_bf16(a.p[0], b.p[1], acc);
+    acc = mfma_bf16(a.p[0], b.p[0], acc);
+}
+
+constexpr int64_t WSLOT = DIM * DIM + 2 * DIM;      // floats per partial slot (wgrad_core.h: the tile, two bias row parts)
+
+struct GAggBwdW {
+    const float *d_agg, *z, *ea, *e, *We, *Wea;
+    const int32_t *ptr, *row_of, *cuts;
+    float *dz, *d_e, *dPi, *partial;
+    int64_t m, n;
+    int ld_we, ld_wea, accumulate;
+};
+
+__global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW a) {
+    constexpr int MTX = 2, CAP = 32;
+    constexpr int FT = 16 * LDT * 4;
+    constexpr int W2B = 4 * 64 * 16;                           // a wave's third-piece image of one matrix
+    __shared__ __attribute__((aligned(16))) char ldsb[3 * KIMG + MTX * FT + 2 * 8 * W2B];
+    __shared__ int sptr[NMAX + 1];
+    __shared__ float4 carry[2][32];
+    char* Iz = ldsb;                                           // d z, d ea, e: piece images of the chunk
+    char* Ia = ldsb + KIMG;
+    char* Ie = ldsb + 2 * KIMG;
+    float* S0 = reinterpret_cast<float*>(ldsb + 3 * KIMG);     // d z as fp32 (node sums), then the d e accumulators
+    const float* __restrict__ d_agg = a.d_agg;
+    const float* __restrict__ zs = a.z;
+    const float* __restrict__ eas = a.ea;
+    const float* __restrict__ es = a.e;
+    const int32_t* __restrict__ ptr = a.ptr;
+    const int32_t* __restrict__ row_of = a.row_of;
+    float* __restrict__ dz = a.dz;
+    float* __restrict__ d_e = a.d_e;
+    const int accumulate = a.accumulate;
+    const int wv = threadIdx.x >> 6, wc = wave_col<8>();
+    char* w2e = ldsb + 3 * KIMG + MTX * FT + wv * W2B;
+    char* w2a = w2e + 8 * W2B;
+    WFragB2 f1, f2;
+    load_wfragb2_t(f1, w2e, a.We, a.ld_we, wc);
+    load_wfragb2_t(f2, w2a, a.Wea, a.ld_wea, wc);
+    const int wg = xcd_order(blockIdx.x, gridDim.x);
+    const int nb = a.cuts ? a.cuts[wg] : seg_cut(ptr, row_of, a.n, a.m, wg, gridDim.x);
+    const int ne = a.cuts ? a.cuts[wg + 1] : seg_cut(ptr, row_of, a.n, a.m, wg + 1, gridDim.x);
+    const int64_t re = ptr[ne];
+    constexpr int RPP = 16, NI = MTX;
+    const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;
+    f32x4 accE[8], accA[8];                                    // rows [16 wv, 16 wv + 16) of dW_e / dW_ea
+#pragma unroll
+    for (int b = 0; b < 8; ++b) accE[b] = accA[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bsum = f4zero();                                    // this thread's share of the column sums of d z
+    int c0 = nb, par = 0;
+    int64_t r0 = ptr[nb];
+    float4 pz[NI], pe[NI], px[NI];                             // z, ea, e rows of the next chunk
+    auto prefetch = [&](int64_t rb) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            pz[i] = ldg4z(zs, rb + rr + RPP * i, re, DIM, c4);
+            pe[i] = ldg4z(eas, rb + rr + RPP * i, re, DIM, c4);
+            px[i] = ldg4z(es, rb + rr + RPP * i, re, DIM, c4);
+        }
+    };
+    if (r0 < re) prefetch(r0);
+    while (c0 < ne) {
+        const Chunk ch = plan_chunk(ptr, row_of, c0, r0, ne, re, CAP);
+        const int64_t r1 = ch.r1;
+        const int c1 = ch.c1;
+        const int rows = (int)(r1 - r0);
+        const int mt = (rows + 15) >> 4;
+        const int nn = c1 - c0 + 1;
+        if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = ptr[c0 + threadIdx.x] - (int)r0;
+        float4 dacc[NI];
+        if (rows > 0) {
+            // every row of the 32-row k-step is written: rows past the chunk's end as zeros in all three images
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int r = rr + RPP * i;
+                const int64_t g = r0 + r;
+                float4 x = f4zero(), y = f4zero(), ev = f4zero();
+                if (g < r1) {
+                    const float4 dm = ldg4(d_agg, row_of[g], DIM, c4);
+                    const float4 zz = pz[i], ee = pe[i];
+                    x = f4mul(f4mul(dm, ee), f4dsilu(zz));
+                    y = f4mul(dm, f4silu(zz));
+                    ev = px[i];
+                    stg4(dz, g, DIM, c4, x);
+                    bsum = f4add(bsum, x);
+                }
+                st_lds4(S0, r, c4, x);
+                st_kpieces4(Iz, r, c4, x);
+                st_kpieces4(Ia, r, c4, y);
+                st_kpieces4(Ie, r, c4, ev);
+            }
+            if (r1 < re) prefetch(r1);                         // the next chunk's rows travel during the GEMMs
+            if (accumulate) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    int64_t g = r0 + rr + RPP * i;
+                    g = g < r1 ? g : r1 - 1;
+                    dacc[i] = ldg4(d_e, g, DIM, c4);
+                }
+            }
+        }
+        __syncthreads();
+        const bool open_end = sptr[nn] > rows;
+        reduce_nodes<16>(c0, nn, rows, S0, sptr, carry[par], carry[par ^ 1], nullptr, a.dPi);   // reads S0 only
+        par ^= 1;
+        if (rows > 0) {
+            Acc<2> acc;
+            acc.zero();
+            if (mt == 2) {
+                mma_k16<2>(Iz, f1, w2e, acc);
+                mma_k16<2>(Ia, f2, w2a, acc);
+            } else {
+                mma_k16<1>(Iz, f1, w2e, acc);
+                mma_k16<1>(Ia, f2, w2a, acc);
+            }
+            // the weight gradients' k-step: rows of both results from this wave's 16 channels of d z / d ea against all
+            // eight channel tiles of e
+            {
+                const Frag3 az = lds_kfrag_col(Iz, wv), aa = lds_kfrag_col(Ia, wv);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const Frag3 be = lds_kfrag_col(Ie, b);
+                    mfma6_col(az, be, accE[b]);
+                    mfma6_col(aa, be, accA[b]);
+                }
+            }
+            __syncthreads();
+            acc_store<2>(acc, S0, wc, 0.f, mt);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int r = rr + RPP * i;
+                const int64_t g = r0 + r;
+                if (g < r1) {
+                    float4 v = lds4(S0, r, c4);
+                    if (accumulate) v = f4add(v, dacc[i]);
+                    stg4(d_e, g, DIM, c4, v);
+                }
+            }
+        }
+        __syncthreads();
+        c0 = open_end ? c1 : c1 + 1;
+        r0 = r1;
+    }
+    // ---- the workgroup's partial tiles in the slot format of wgrad_core.h: slot blockIdx.x of job 0 (dW_e, with the bias
+    // parts), slot gridDim.x + blockIdx.x of job 1 (dW_ea).  Through LDS so that the tiles leave as 512-byte rows.
+    float* T = reinterpret_cast<float*>(ldsb);                 // [128][LDT] over the (free) piece images
+    const int lane = threadIdx.x & 63, r16 = lane & 15, kg = lane >> 4;
+    float* slot0 = a.partial + (int64_t)blockIdx.x * WSLOT;
+    float* slot1 = a.partial + ((int64_t)gridDim.x + blockIdx.x) * WSLOT;
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(16 * wv + 4 * kg + r) * LDT + 16 * b + r16] = accE[b][r];
+    *reinterpret_cast<float4*>(S0 + rr * DIM + 4 * c4) = bsum;  // [16 row groups][128]
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < DIM / 16; ++i) {
+        const int row = rr + 16 * i;
+        *reinterpret_cast<float4*>(slot0 + row * DIM + 4 * c4) = *reinterpret_cast<const float4*>(T + row * LDT + 4 * c4);
+    }
+    if (threadIdx.x < DIM) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += S0[k * DIM + threadIdx.x];   // fixed order
+        slot0[DIM * DIM + threadIdx.x] = s;
+        slot0[DIM * DIM + DIM + threadIdx.x] = 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(16 * wv + 4 * kg + r) * LDT + 16 * b + r16] = accA[b][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < DIM / 16; ++i) {
+        const int row = rr + 16 * i;
+        *reinterpret_cast<float4*>(slot1 + row * DIM + 4 * c4) = *reinterpret_cast<const float4*>(T + row * LDT + 4 * c4);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ local aggregation
 // Workgroup = 8 lane groups of 32; it owns NPW consecutive nodes and walks their local edges 8 at a time: group k
 // computes v = q3[e] * (m_ji[e] + sum_r m_nb[idx[r]] * s[r]) for its edge (rows of e in CSR order), the node owners add
@@ -704,6 +1011,34 @@ extern "C" int pamnet_global_edge_agg_bwd_f32(const float* d_agg, int64_t n_edge
                 break;
         }
     }
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
+// The same backward with the two weight gradients of the step formed in the kernel (global_edge_agg_bwd_wg_kernel): d ea is
+// not written; `partial` receives 2 * G slots of 128 * 128 + 256 floats (G = *slots of pamnet_global_edge_agg_wg_floats):
+// slots [0, G) = the workgroups' shares of dW_e = dz^T e with the column sums of dz (the bias gradient), [G, 2 G) = those of
+// dW_ea = dea^T e.  pamnet_wgrad_edge_enqueue_f32 hands them to a deferred weight-gradient context for the fixed-order sum.
+extern "C" int pamnet_global_edge_agg_wg_floats(int64_t n_edges, int64_t* floats, int64_t* slots) {
+    if (n_edges < 0 || !floats) return PAMNET_EINVAL;
+    const int64_t g = agg_grid(n_edges);
+    *floats = 2 * g * WSLOT;
+    if (slots) *slots = g;
+    return PAMNET_OK;
+}
+extern "C" int pamnet_global_edge_agg_bwd_wg_f32(const float* d_agg, int64_t n_edges, int64_t n_nodes, const int32_t* ptr,
+                                                 const int32_t* row_of, const int32_t* cuts, const float* z, const float* ea,
+                                                 const float* e, const float* We, int64_t ld_we, const float* Wea,
+                                                 int64_t ld_wea, float* dz, float* d_e, int32_t accumulate, float* dPi,
+                                                 float* partial, pamnet_stream_t stream) {
+    if (n_edges < 0 || n_nodes < 0) return PAMNET_EINVAL;
+    if (n_nodes == 0) return PAMNET_EINVAL;                     // (the slots must be written: no launch, no partial sums)
+    if (!d_agg || !ptr || !We || !Wea || !dPi || !partial) return PAMNET_ENULL;
+    if (n_edges > 0 && (!row_of || !z || !ea || !e || !dz || !d_e)) return PAMNET_ENULL;
+    GAggBwdW a{d_agg, z, ea, e, We, Wea, ptr, row_of, cuts, dz, d_e, dPi, partial, n_edges, n_nodes, (int)ld_we, (int)ld_wea,
+               (int)accumulate};
+    const int64_t grid = agg_grid(n_edges);
+    hipLaunchKernelGGL(global_edge_agg_bwd_wg_kernel, dim3((unsigned)grid), dim3(WG8), 0, as_stream(stream), a);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

@@ -12,6 +12,8 @@
 // The shared edge embeddings (e_g, rbf_e, e_sbf feed all layers) get their gradients accumulated in place by the
 // backward kernels themselves (accumulate flag), in a fixed layer order -> deterministic.
 
+#include <stdlib.h>
+
 #include <vector>
 
 #include "common.h"
@@ -92,6 +94,7 @@ struct Temp {
     float *partial, *partial2;   // split-K scratch of two consecutive weight-gradient batches (the reduction of one runs
                                  // inside the launch of the next)
     float* rider_partial;        // split-K scratch of the rider batch (10 node-level jobs in a node-chain launch)
+    float* edge_partial;         // partial tiles of the fused global-edge backward's own weight gradients (2 x <= 256 slots)
     int32_t* cuts;               // node-aligned work split of the fused global-edge kernels (<= 257 ints)
 };
 
@@ -112,6 +115,21 @@ inline int64_t rider_floats(const Graph& g) {
     return 2 * 10 * s * (D * D + 2 * D);         // two chains' riders wait for the pair's merged launch
 }
 
+// Round 5: the weight gradients of the global edge step (dW_e = dz^T e_g, dW_ea = dea^T e_g) are formed inside the fused
+// backward edge kernel (edge_agg.hip global_edge_agg_bwd_wg_kernel) instead of as two E_g-row jobs of the split-K launches.
+// PAMNET_EDGE_WGRAD=0 / 1 forces the old / new route (read once); default: the new one where a workgroup has enough rows to
+// amortise its two 64 KB partial tiles.
+inline bool edge_wgrad(const Graph& g) {
+    static const int v = [] { const char* e = getenv("PAMNET_EDGE_WGRAD"); return e ? atoi(e) : -1; }();
+    if (v >= 0) return v != 0 && g.eg > 0;
+    return g.eg >= 256 * 512;
+}
+inline int64_t edge_partial_floats(const Graph& g) {
+    int64_t f = 0;
+    pamnet_global_edge_agg_wg_floats(g.eg, &f, nullptr);
+    return f;
+}
+
 inline int64_t temp_floats(const Graph& g) {
     const int64_t nd = al(g.n * D), gd = al(g.eg * D), ld = al(g.el * D), td = al(g.tp * D);
     int64_t t = 0;
@@ -119,7 +137,7 @@ inline int64_t temp_floats(const Graph& g) {
     t += 10 * nd + 7 * nd + nd + nd + al(((g.n + 15) / 16) * 257) + gd + gd + 4 * nd + nd + nd + nd;
     t += 6 * ld + 3 * td;
     t += 3 * nd;                                                       // dPg (2 planes), dZx1g
-    t += 2 * wgrad_floats(g) + rider_floats(g) + 320;
+    t += 2 * wgrad_floats(g) + rider_floats(g) + edge_partial_floats(g) + 320;
     return t;
 }
 
@@ -156,6 +174,7 @@ inline Temp carve_temp(float* p, const Graph& g) {
     t.partial = p; p += wgrad_floats(g);
     t.partial2 = p; p += wgrad_floats(g);
     t.rider_partial = p; p += rider_floats(g);
+    t.edge_partial = p; p += edge_partial_floats(g);
     t.cuts = reinterpret_cast<int32_t*>(p);
     return t;
 }
@@ -679,8 +698,18 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             }
             // d z, d ea, d e and the target-side reduction d P_i in one kernel; the source-side one walks the transposed CSR
             const int64_t pl = g.n * D;
-            CK(pamnet_global_edge_agg_bwd_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, t.cuts, s.z, s.ea, gp[2] + 2 * D, 3 * D, gp[4], D,
-                                              t.dz, t.dea, d_eg, acc, t.dPg, st));
+            const bool ewg = edge_wgrad(g);
+            if (ewg) {
+                // ... and the step's own weight gradients: partial tiles per workgroup, summed by the next weight-gradient launch
+                int64_t efloats = 0, eslots = 0;
+                CK(pamnet_global_edge_agg_wg_floats(g.eg, &efloats, &eslots));
+                CK(pamnet_global_edge_agg_bwd_wg_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, t.cuts, s.z, s.ea, e_g, gp[2] + 2 * D, 3 * D,
+                                                     gp[4], D, t.dz, d_eg, acc, t.dPg, t.edge_partial, st));
+                CK(pamnet_wgrad_edge_enqueue_f32(wctx.data(), eslots, gg[2] + 2 * D, 3 * D, gg[3], gg[4], D, t.edge_partial));
+            } else {
+                CK(pamnet_global_edge_agg_bwd_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, t.cuts, s.z, s.ea, gp[2] + 2 * D, 3 * D, gp[4],
+                                                  D, t.dz, t.dea, d_eg, acc, t.dPg, st));
+            }
             CK(pamnet_segment_sum_f32(t.dPg + pl, nullptr, t.dz, nullptr, nullptr, nullptr, g.gT_perm, g.gT_ptr, g.n, D, st));
             if (fuse && k > 0) {
                 // head of the global layer + the local chain of the previous pair
@@ -712,8 +741,10 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             j.add(t.dZx1g, x_in, 0, g.n, gg[0], D, gg[1]);
             j.add(t.dPg, s.Zx1, 1, g.n, gg[2], 3 * D, nullptr);
             j.add(t.dPg + pl, s.Zx1, 1, g.n, gg[2] + D, 3 * D, nullptr);
-            j.add(t.dz, e_g, 0, g.eg, gg[2] + 2 * D, 3 * D, gg[3]);
-            j.add(t.dea, e_g, 0, g.eg, gg[4], D, nullptr);
+            if (!ewg) {
+                j.add(t.dz, e_g, 0, g.eg, gg[2] + 2 * D, 3 * D, gg[3]);
+                j.add(t.dea, e_g, 0, g.eg, gg[4], D, nullptr);
+            }
             const HeadGrads hg{s.hp, gg[GT + 20], gg[GT + 22], gg[GT + 21]};
             CK(run_jobs(j, parts[pflip], g, hg, merged ? pair_head : HeadGrads{nullptr, nullptr, nullptr, nullptr}, wctx.data(),
                         st));

@@ -185,9 +185,13 @@ __global__ __launch_bounds__(WG) void wgrad_finish_kernel(WBatch batch, const fl
 // workgroups fill in beside the current pass.  Compact batches (<= 16 jobs): the three descriptors share the 4 KB
 // kernel-argument block.
 
+// `edge` (round 5): the partial tiles the fused global-edge backward left behind (edge_agg.hip global_edge_agg_bwd_wg_kernel: one
+// slot per workgroup and job, dW_e with the bias parts and dW_ea) -- a third earlier batch, reduced by the LAST blocks of the grid.
+using WBatchE = WBatchT<2>;
 __global__ __launch_bounds__(SWG, 2) void wgrad_fused_kernel(WBatchS cur, float* __restrict__ cur_partial, WBatchS prev,
                                                          const float* __restrict__ prev_partial, HeadJob prev_head,
-                                                         WBatch prev2, const float* __restrict__ prev2_partial) {
+                                                         WBatch prev2, const float* __restrict__ prev2_partial, WBatchE edge,
+                                                         const float* __restrict__ edge_partial) {
     __shared__ __attribute__((aligned(16))) float lds[WGRAD_LDS_FLOATS];
     const int slots = cur.start[cur.njobs];
     int fb = (int)blockIdx.x - slots;
@@ -197,25 +201,36 @@ __global__ __launch_bounds__(SWG, 2) void wgrad_fused_kernel(WBatchS cur, float*
     }
     if (threadIdx.x >= WG) return;                             // the reductions are 4-wave workgroups
     const int fin1 = prev_partial ? FIN_X * (prev.njobs + 1) : 0;
+    const int fin2 = prev2_partial ? FIN_X * (prev2.njobs + 1) : 0;
     if (fb < fin1) {
         finish_body(prev, prev_partial, prev_head, fb % FIN_X, fb / FIN_X, lds);
-    } else {
+    } else if (fb < fin1 + fin2) {
         fb -= fin1;
         finish_body(prev2, prev2_partial, HeadJob{{NO_HEAD, NO_HEAD}}, fb % FIN_X, fb / FIN_X, lds);
+    } else {
+        fb -= fin1 + fin2;
+        finish_body(edge, edge_partial, HeadJob{{NO_HEAD, NO_HEAD}}, fb % FIN_X, fb / FIN_X, lds);
     }
 }
 
 // the same with one earlier batch and wide descriptors (up to 24 jobs each): no rider batch pending
 __global__ __launch_bounds__(SWG, 2) void wgrad_fused_wide_kernel(WBatch cur, float* __restrict__ cur_partial, WBatch prev,
-                                                              const float* __restrict__ prev_partial, HeadJob prev_head) {
+                                                              const float* __restrict__ prev_partial, HeadJob prev_head,
+                                                              WBatchE edge, const float* __restrict__ edge_partial) {
     __shared__ __attribute__((aligned(16))) float lds[WGRAD_LDS_FLOATS];
     const int slots = cur.start[cur.njobs];
     if ((int)blockIdx.x < slots) {
         wgrad_body<SNW>(cur, cur_partial, (int)blockIdx.x, lds);
     } else {
         if (threadIdx.x >= WG) return;
-        const int fb = (int)blockIdx.x - slots;
-        finish_body(prev, prev_partial, prev_head, fb % FIN_X, fb / FIN_X, lds);
+        int fb = (int)blockIdx.x - slots;
+        const int fin1 = FIN_X * (prev.njobs + 1);
+        if (fb < fin1) {
+            finish_body(prev, prev_partial, prev_head, fb % FIN_X, fb / FIN_X, lds);
+        } else {
+            fb -= fin1;
+            finish_body(edge, edge_partial, HeadJob{{NO_HEAD, NO_HEAD}}, fb % FIN_X, fb / FIN_X, lds);
+        }
     }
 }
 
@@ -237,6 +252,9 @@ struct WgradPending {
     const float* partial[2];
     HeadJob head;
     int valid[2];
+    WBatchE edge;                 // partial tiles left by the fused global-edge backward (pamnet_wgrad_edge_enqueue_f32)
+    const float* edge_partial;
+    int edge_valid;
 };
 
 template <typename Batch>
@@ -261,7 +279,8 @@ inline WBatchS compact(const WBatch& b) {                      // njobs <= MAXJ_
     c.start[b.njobs] = b.start[b.njobs];
     return c;
 }
-inline WBatch widen(const WBatchS& b) {
+template <typename B>
+inline WBatch widen(const B& b) {
     WBatch c;
     c.njobs = b.njobs;
     for (int j = 0; j < b.njobs; ++j) c.job[j] = b.job[j], c.start[j] = b.start[j];
@@ -311,6 +330,12 @@ static int finish_pending(WgradPending* pend, hipStream_t st) {
         PAMNET_LAUNCH_CHECK();
         pend->valid[k] = 0;
     }
+    if (pend->edge_valid) {
+        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(FIN_X, (unsigned)pend->edge.njobs), dim3(WG), 0, st, widen(pend->edge),
+                           pend->edge_partial, none);
+        PAMNET_LAUNCH_CHECK();
+        pend->edge_valid = 0;
+    }
     return PAMNET_OK;
 }
 
@@ -330,14 +355,20 @@ extern "C" int pamnet_wgrad_deferred_f32(int64_t njobs, const float* const* dZ, 
     const int rc = build_batch(b, njobs, dZ, ld_dz, A, ld_a, a_mode, rows, dW, ld_dw, db, target_slots());
     if (rc) return rc;
     hipStream_t st = as_stream(stream);
-    const bool any = pend->valid[0] || pend->valid[1];
+    const bool any = pend->valid[0] || pend->valid[1] || pend->edge_valid;
     const bool fits = njobs <= MAXJ_S && (!pend->valid[0] || pend->batch[0].njobs <= MAXJ_S);   // (the rider batch: wide)
+    WBatchE edge;
+    edge.njobs = 0, edge.start[0] = 0;
+    if (pend->edge_valid) edge = pend->edge;
+    const float* edge_partial = pend->edge_valid ? pend->edge_partial : nullptr;
+    const unsigned efin = (unsigned)(FIN_X * edge.njobs);
     if (pend->valid[0] && !pend->valid[1]) {                   // one earlier batch: wide descriptors
-        const unsigned grid = (unsigned)b.start[njobs] + (unsigned)(FIN_X * (pend->batch[0].njobs + 1));
+        const unsigned grid = (unsigned)b.start[njobs] + (unsigned)(FIN_X * (pend->batch[0].njobs + 1)) + efin;
         hipLaunchKernelGGL(wgrad_fused_wide_kernel, dim3(grid), dim3(SWG), 0, st, b, partial, pend->batch[0], pend->partial[0],
-                           pend->head);
+                           pend->head, edge, edge_partial);
         PAMNET_LAUNCH_CHECK();
         pend->valid[0] = 0;
+        pend->edge_valid = 0;
     } else if (any && fits) {
         WBatchS none;
         none.njobs = 0, none.start[0] = 0;
@@ -347,11 +378,12 @@ extern "C" int pamnet_wgrad_deferred_f32(int64_t njobs, const float* const* dZ, 
         if (pend->valid[1]) p1 = pend->batch[1];
         const unsigned fin = (pend->valid[0] ? FIN_X * (p0.njobs + 1) : 0) + (pend->valid[1] ? FIN_X * (p1.njobs + 1) : 0);
         const HeadJob nohead{{NO_HEAD, NO_HEAD}};
-        hipLaunchKernelGGL(wgrad_fused_kernel, dim3((unsigned)b.start[njobs] + fin), dim3(SWG), 0, st, compact(b), partial, p0,
-                           pend->valid[0] ? pend->partial[0] : nullptr, pend->valid[0] ? pend->head : nohead, p1,
-                           pend->valid[1] ? pend->partial[1] : nullptr);
+        hipLaunchKernelGGL(wgrad_fused_kernel, dim3((unsigned)b.start[njobs] + fin + efin), dim3(SWG), 0, st, compact(b), partial,
+                           p0, pend->valid[0] ? pend->partial[0] : nullptr, pend->valid[0] ? pend->head : nohead, p1,
+                           pend->valid[1] ? pend->partial[1] : nullptr, edge, edge_partial);
         PAMNET_LAUNCH_CHECK();
         pend->valid[0] = pend->valid[1] = 0;
+        pend->edge_valid = 0;
     } else {
         if (any) {                                             // too many jobs for the compact descriptors: plain launches
             const int frc = finish_pending(pend, st);
@@ -420,5 +452,25 @@ extern "C" int pamnet_wgrad_rider_enqueue_f32(void* ctx, const void* rider) {
     pend->batch[1] = widen(r->batch);
     pend->partial[1] = r->partial;
     pend->valid[1] = 1;
+    return PAMNET_OK;
+}
+
+// ---- the fused global-edge backward's own weight gradients (edge_agg.hip pamnet_global_edge_agg_bwd_wg_f32) -------------------
+// That launch left 2 * slots partial tiles in `partial` (slot format above): slots [0, slots) = shares of dW_e with the bias
+// parts, [slots, 2 slots) = shares of dW_ea.  Registered here, they are summed in slot order by the next
+// pamnet_wgrad_deferred_f32 launch (or the flush) like any other batch; `partial` must stay untouched until then.
+extern "C" int pamnet_wgrad_edge_enqueue_f32(void* ctx, int64_t slots, float* dW_e, int64_t ld_e, float* db, float* dW_ea,
+                                             int64_t ld_ea, const float* partial) {
+    if (!ctx || !dW_e || !dW_ea || !partial) return PAMNET_ENULL;
+    if (slots < 1 || slots > MAX_SLOTS_PER_JOB) return PAMNET_EINVAL;
+    WgradPending* pend = static_cast<WgradPending*>(ctx);
+    if (pend->edge_valid) return PAMNET_EINVAL;                 // one at a time: the next launch consumes it
+    WBatchE& b = pend->edge;
+    b.njobs = 2;
+    b.start[0] = 0, b.start[1] = (int)slots, b.start[2] = 2 * (int)slots;
+    b.job[0] = WJob{nullptr, nullptr, dW_e, db, 0, 0, 0, (int)ld_e, 0};
+    b.job[1] = WJob{nullptr, nullptr, dW_ea, nullptr, 0, 0, 0, (int)ld_ea, 0};
+    pend->edge_partial = partial;
+    pend->edge_valid = 1;
     return PAMNET_OK;
 }

@@ -49,6 +49,12 @@ def load():
             fn = getattr(lib, name)            # AttributeError here = header/library mismatch: fail loudly
             fn.argtypes = types
             fn.restype = ctypes.c_int
+        want = int(re.search(r'#define\s+PAMNET_ABI_VERSION\s+(\d+)', open(HEADER).read()).group(1))
+        lib.pamnet_abi_version.argtypes = []
+        got = int(lib.pamnet_abi_version())
+        if got != want:
+            raise RuntimeError('libpamnet_hip.so was built for ABI version %d, include/pamnet_hip.h declares %d: rebuild '
+                               '(python __graft_entry__.py)' % (got, want))
         _lib = lib
     return _lib
 

@@ -140,6 +140,93 @@ def test_global_edge_agg_fwd_bwd(dev, case):
         assert maxnorm_err(d_e2.cpu(), (2 * de64).cpu()) < 3e-6
 
 
+@pytest.mark.parametrize('case', sorted(DEGREE_CASES) + ['pdbbind_big'])
+@pytest.mark.parametrize('accumulate', [0, 1])
+def test_global_edge_agg_bwd_with_weight_gradients(dev, case, accumulate):
+    """Round 5: dW_e = dz^T e, dW_ea = dea^T e and db_m = colsum(dz) formed INSIDE the fused backward edge kernel
+    (layers/global_message_passing.py:52-56: the gradients of mlp_m's e-block and of W_edge_attr), partial tiles per workgroup,
+    summed in fixed order by the deferred weight-gradient reduction.  dz / d_e / dPi must be bitwise the plain backward
+    kernel's; the weight gradients are checked against fp64 at the tolerance of the bf16x6 split-K kernels."""
+    from pamnet_amd import lib
+    rng = np.random.default_rng(3)
+    deg = rng.integers(25, 50, size=20000) if case == 'pdbbind_big' else DEGREE_CASES[case](rng)
+    n = len(deg)
+    ptr, row_of, col, m = _csr(deg, n, 5, dev)
+    gen = torch.Generator().manual_seed(13)
+    mk = lambda *s: (0.5 * torch.randn(*s, generator=gen)).to(dev)
+    e, z, ea, d_agg = mk(max(m, 1), D)[:m], mk(max(m, 1), D)[:m], mk(max(m, 1), D)[:m], mk(n, D)
+    Wm, bm, Wea = _weights(dev, 2)
+    st = lib.stream_of(d_agg)
+    sub = lambda w, c0: w.data_ptr() + 4 * c0
+    nanlike = lambda r: torch.full((max(r, 1), D), float('nan'), device=dev)[:r]
+    # the plain kernel
+    dz0, dea0, de0, dPi0 = nanlike(m), nanlike(m), nanlike(m), nanlike(n)
+    base = mk(max(m, 1), D)[:m]
+    if accumulate:
+        de0.copy_(base)
+    lib.call('pamnet_global_edge_agg_bwd_f32', lib.ptr(d_agg), m, n, lib.ptr(ptr), lib.ptr(row_of), None, lib.ptr(z),
+             lib.ptr(ea), sub(Wm, 2 * D), 3 * D, lib.ptr(Wea), D, lib.ptr(dz0), lib.ptr(dea0), lib.ptr(de0), accumulate,
+             lib.ptr(dPi0), st)
+    # the fused one
+    need, slots = ctypes.c_int64(0), ctypes.c_int64(0)
+    lib.call('pamnet_global_edge_agg_wg_floats', m, ctypes.addressof(need), ctypes.addressof(slots))
+    partial = torch.full((int(need.value),), float('nan'), device=dev)
+    dz1, de1, dPi1 = nanlike(m), nanlike(m), nanlike(n)
+    if accumulate:
+        de1.copy_(base)
+    dWm = torch.full((D, 3 * D), float('nan'), device=dev)       # the [d, 3d] gradient of mlp_m: only its e-block is written
+    dWea, db = torch.full((D, D), float('nan'), device=dev), torch.full((D,), float('nan'), device=dev)
+    nbytes = ctypes.c_int64(0)
+    lib.call('pamnet_wgrad_ctx_bytes', ctypes.addressof(nbytes))
+    ctx = (ctypes.c_char * int(nbytes.value))()
+    scratch = base.clone() if accumulate else nanlike(m)
+    for rep in range(2):                                         # twice: run-to-run bitwise identical
+        lib.call('pamnet_global_edge_agg_bwd_wg_f32', lib.ptr(d_agg), m, n, lib.ptr(ptr), lib.ptr(row_of), None, lib.ptr(z),
+                 lib.ptr(ea), lib.ptr(e), sub(Wm, 2 * D), 3 * D, lib.ptr(Wea), D, lib.ptr(dz1), lib.ptr(de1 if rep == 0 else scratch),
+                 accumulate, lib.ptr(dPi1), lib.ptr(partial), st)
+        lib.call('pamnet_wgrad_edge_enqueue_f32', ctypes.addressof(ctx), int(slots.value), sub(dWm, 2 * D), 3 * D, lib.ptr(db),
+                 lib.ptr(dWea), D, lib.ptr(partial))
+        lib.call('pamnet_wgrad_flush_f32', ctypes.addressof(ctx), st)
+        if rep == 0:
+            first = (dWm[:, 2 * D:].clone(), dWea.clone(), db.clone())
+    assert torch.equal(first[0], dWm[:, 2 * D:]) and torch.equal(first[1], dWea) and torch.equal(first[2], db)
+    assert torch.isnan(dWm[:, :2 * D]).all()                     # the node blocks of the [d, 3d] gradient are not touched
+    assert torch.equal(dPi0, dPi1)
+    if m:
+        assert torch.equal(dz0, dz1) and torch.equal(de0, de1)
+    # fp64 reference of the three gradients
+    dd = lambda t: t.double()
+    dm = dd(d_agg)[row_of.long()]
+    sg = torch.sigmoid(dd(z))
+    dz64 = dm * dd(ea) * (sg * (1 + dd(z) * (1 - sg)))
+    dea64 = dm * torch.nn.functional.silu(dd(z))
+    for got, want in ((dWm[:, 2 * D:], dz64.t() @ dd(e)), (dWea, dea64.t() @ dd(e)), (db, dz64.sum(0))):
+        assert torch.isfinite(got).all()
+        if m:
+            assert maxnorm_err(got.cpu(), want.cpu()) < 3e-6, case
+        else:
+            assert float(got.abs().max()) == 0.0
+    # and inside a deferred sequence: the partial tiles are reduced by the launch of the next batch (both fused forms)
+    from pamnet_amd.fused import DeferredWgrad
+    rows = 700
+    A, dZ = mk(rows, D), mk(rows, D)
+    for njobs in (1, 20):                                        # compact descriptors / wide ones
+        dw = DeferredWgrad(d_agg)
+        outs = [torch.empty(D, D, device=dev) for _ in range(njobs)]
+        jobs = [(lib.ptr(dZ), D, lib.ptr(A), D, 0, rows, lib.ptr(o), D, None) for o in outs]
+        dw.launch(jobs)                                          # an earlier batch waits for its reduction
+        lib.call('pamnet_global_edge_agg_bwd_wg_f32', lib.ptr(d_agg), m, n, lib.ptr(ptr), lib.ptr(row_of), None, lib.ptr(z),
+                 lib.ptr(ea), lib.ptr(e), sub(Wm, 2 * D), 3 * D, lib.ptr(Wea), D, lib.ptr(dz1), lib.ptr(de1.clone()), accumulate,
+                 lib.ptr(dPi1), lib.ptr(partial), st)
+        g2, gea2, db2 = torch.full((D, 3 * D), float('nan'), device=dev), torch.empty(D, D, device=dev), torch.empty(D, device=dev)
+        lib.call('pamnet_wgrad_edge_enqueue_f32', ctypes.addressof(dw.ctx), int(slots.value), sub(g2, 2 * D), 3 * D, lib.ptr(db2),
+                 lib.ptr(gea2), D, lib.ptr(partial))
+        dw.launch(jobs)
+        dw.flush()
+        assert torch.equal(g2[:, 2 * D:], first[0]) and torch.equal(gea2, first[1]) and torch.equal(db2, first[2])
+        assert maxnorm_err(outs[0].cpu(), (dd(dZ).t() @ dd(A)).cpu()) < 3e-6
+
+
 def test_fused_result_independent_of_batching(dev):
     """A node's sum has one owner and CSR order whatever the launch geometry: a graph evaluated alone and as part of
     a larger batch (different workgroup cuts, different chunk instantiation) gives bitwise identical rows."""
