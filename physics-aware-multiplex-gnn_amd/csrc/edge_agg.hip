@@ -109,9 +109,23 @@ __device__ __forceinline__ void seq_add(float4& s, const float* __restrict__ til
     for (; q < q1; ++q) s = f4add(s, lds4(tile, q, c4));
 }
 
+// the same sums with NB loads in flight (same order)
+template <int NB>
+__device__ __forceinline__ void seq_add_wide(float4& s, const float* __restrict__ tile, int q0, int q1, int c4) {
+    int q = q0;
+    for (; q + NB <= q1; q += NB) {
+        float4 v[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) v[u] = lds4(tile, q + u, c4);
+#pragma unroll
+        for (int u = 0; u < NB; ++u) s = f4add(s, v[u]);
+    }
+    seq_add(s, tile, q, q1, c4);
+}
+
 // out[node] = init[node] + sum of the node's rows of `tile`, one 32-lane group per node, rows in CSR order.
 // sptr[k] = ptr[c0 + k] - r0 for k = 0 .. nn (raw: negative = the node began before the chunk, > rows = it goes on).
-template <int NGRP>
+template <int NGRP, int WIDE = 0>
 __device__ __forceinline__ void reduce_nodes(int c0, int nn, int rows, const float* __restrict__ tile,
                                              const int* __restrict__ sptr, const float4* __restrict__ carry_in,
                                              float4* __restrict__ carry_out, const float* __restrict__ init,
@@ -122,7 +136,8 @@ __device__ __forceinline__ void reduce_nodes(int c0, int nn, int rows, const flo
         float4 s;
         if (b < 0) s = carry_in[c4];                                    // only k = 0
         else s = init ? ldg4(init, c0 + k, DIM, c4) : f4zero();
-        seq_add(s, tile, b < 0 ? 0 : b, e > rows ? rows : e, c4);
+        if constexpr (WIDE > 0) seq_add_wide<WIDE>(s, tile, b < 0 ? 0 : b, e > rows ? rows : e, c4);
+        else seq_add(s, tile, b < 0 ? 0 : b, e > rows ? rows : e, c4);
         if (e > rows) carry_out[c4] = s;                                // only k = nn - 1 (another lane group than k = 0)
         else stg4(out, c0 + k, DIM, c4, s);
     }
@@ -622,6 +637,7 @@ struct GAggBwdW {
     int ld_we, ld_wea, accumulate;
 };
 
+template <bool ACC>
 __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW a) {
     constexpr int MTX = 2, CAP = 32;
     constexpr int FT = 16 * LDT * 4;
@@ -632,7 +648,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW
     char* Iz = ldsb;                                           // d z, d ea, e: piece images of the chunk
     char* Ia = ldsb + KIMG;
     char* Ie = ldsb + 2 * KIMG;
-    float* S0 = reinterpret_cast<float*>(ldsb + 3 * KIMG);     // d z as fp32 (node sums), then the d e accumulators
+    float* S0 = reinterpret_cast<float*>(ldsb + 3 * KIMG);     // the d e accumulators on their way to rows
     const float* __restrict__ d_agg = a.d_agg;
     const float* __restrict__ zs = a.z;
     const float* __restrict__ eas = a.ea;
@@ -641,7 +657,6 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW
     const int32_t* __restrict__ row_of = a.row_of;
     float* __restrict__ dz = a.dz;
     float* __restrict__ d_e = a.d_e;
-    const int accumulate = a.accumulate;
     const int wv = threadIdx.x >> 6, wc = wave_col<8>();
     char* w2e = ldsb + 3 * KIMG + MTX * FT + wv * W2B;
     char* w2a = w2e + 8 * W2B;
@@ -657,102 +672,231 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW
     f32x4 accE[8], accA[8];                                    // rows [16 wv, 16 wv + 16) of dW_e / dW_ea
 #pragma unroll
     for (int b = 0; b < 8; ++b) accE[b] = accA[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 bsum = f4zero();                                    // this thread's share of the column sums of d z
-    int c0 = nb, par = 0;
-    int64_t r0 = ptr[nb];
-    float4 pz[NI], pe[NI], px[NI];                             // z, ea, e rows of the next chunk
-    auto prefetch = [&](int64_t rb) {
+    float bsum = 0.f;                                          // column sums of d z (the bias gradient): this lane's channel, its node rows
+    // Memory operations retire in order, loads AND stores on one counter (vmcnt), and the compiler can only wait for "all but
+    // the N youngest": wherever N is not a compile-time constant -- a request under a branch, a loop of stores -- it waits for
+    // everything.  The first form of this loop (dependent vector loads in the plan, the d_agg gather through row_of[g],
+    // requests under `if (row < r1)`) drained the queue five times per chunk, each time behind the previous chunk's stores
+    // and this chunk's prefetched rows: a 20 600-cycle loop period for 15 000 cycles of work
+    // (tools/edge_wgrad_phase_probe.py).  This form issues the SAME vector-memory instructions in every iteration:
+    //   * the plan on the scalar unit (s_load: its own counter), made one chunk ahead;
+    //   * every load from a clamped address, every store of a row past the chunk's end to a dummy line (`dump`);
+    //   * ptr[c0 + t] of the NEXT chunk's nodes first thing in a chunk, used a whole chunk later;
+    //   * the rows (z, ea, e) and the row indices of the next chunk requested before the GEMMs, the gather of its d_agg
+    //     rows behind them -- ahead of the final sweep's stores, so that the next sweep's wait for it is not a wait for those;
+    //   * the accumulate operand requested ahead of all of them: the final sweep's wait for it covers nothing younger.
+    // Chunks without rows (runs of nodes without edges) take a side path that ends with an empty queue.
+    int par = 0;
+    float* dump = a.partial + 2 * (int64_t)gridDim.x * WSLOT + 4 * threadIdx.x;   // 8 KB behind the slots: writes nobody reads
+    float4 pz[NI], pe[NI], px[NI], pdm[NI];                    // z, ea, e rows and gathered d_agg rows of the next chunk
+    int pri[NI];                                               // ... and the target node of each (the gather's index)
+    const int64_t rlast = re > 0 ? re - 1 : 0;
+    auto prefetch = [&](int64_t rb) {                          // (clamped: rows past the workgroup's end re-read its last row)
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            pz[i] = ldg4z(zs, rb + rr + RPP * i, re, DIM, c4);
-            pe[i] = ldg4z(eas, rb + rr + RPP * i, re, DIM, c4);
-            px[i] = ldg4z(es, rb + rr + RPP * i, re, DIM, c4);
+            int64_t g = rb + rr + RPP * i;
+            g = g < re ? g : rlast;
+            pz[i] = ldg4(zs, g, DIM, c4);
+            pe[i] = ldg4(eas, g, DIM, c4);
+            px[i] = ldg4(es, g, DIM, c4);
+            pri[i] = row_of[g];
         }
     };
-    if (r0 < re) prefetch(r0);
-    while (c0 < ne) {
-        const Chunk ch = plan_chunk(ptr, row_of, c0, r0, ne, re, CAP);
-        const int64_t r1 = ch.r1;
-        const int c1 = ch.c1;
-        const int rows = (int)(r1 - r0);
-        const int mt = (rows + 15) >> 4;
-        const int nn = c1 - c0 + 1;
-        if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = ptr[c0 + threadIdx.x] - (int)r0;
-        float4 dacc[NI];
-        if (rows > 0) {
-            // every row of the 32-row k-step is written: rows past the chunk's end as zeros in all three images
+    auto gather = [&]() {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int r = rr + RPP * i;
-                const int64_t g = r0 + r;
-                float4 x = f4zero(), y = f4zero(), ev = f4zero();
-                if (g < r1) {
-                    const float4 dm = ldg4(d_agg, row_of[g], DIM, c4);
-                    const float4 zz = pz[i], ee = pe[i];
-                    x = f4mul(f4mul(dm, ee), f4dsilu(zz));
-                    y = f4mul(dm, f4silu(zz));
-                    ev = px[i];
-                    stg4(dz, g, DIM, c4, x);
-                    bsum = f4add(bsum, x);
-                }
-                st_lds4(S0, r, c4, x);
-                st_kpieces4(Iz, r, c4, x);
-                st_kpieces4(Ia, r, c4, y);
-                st_kpieces4(Ie, r, c4, ev);
+        for (int i = 0; i < NI; ++i) pdm[i] = ldg4(d_agg, pri[i], DIM, c4);
+    };
+    // The plan's loads on the scalar unit.  ptr / row_of are never written by this kernel, but the compiler cannot know --
+    // behind the first store of the loop it falls back to vector loads -- hence by hand.  Addresses are wave-uniform
+    // (readfirstlane where a value passed through a vector register).
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto sload2 = [](const int32_t* pa, const int32_t* pb, int& va, int& vb) {
+        asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(va), "=&s"(vb)
+                     : "s"(pa), "s"(pb)
+                     : "memory");
+    };
+    struct Plan {
+        int c0, c1, rows;
+        int64_t r0, r1;
+    };
+    // chunk starting at row r0_ whose node is c0_; returns in `ahead` the node of the row behind the chunk (-1 at the end of
+    // the workgroup's rows).  Nodes without edges are never a chunk's business: their d P_i rows are zero-filled up front.
+    auto plan_at = [&](int c0_, int64_t r0_, int& ahead) {
+        Plan p;
+        p.c0 = c0_, p.r0 = r0_, p.c1 = c0_ - 1, p.r1 = r0_;
+        ahead = -1;
+        if (r0_ < re) {
+            int64_t r1_ = r0_ + CAP < re ? r0_ + CAP : re;
+            int last = 0, nxt = 0;
+            sload2(row_of + r1_ - 1, row_of + (r1_ < re ? r1_ : re - 1), last, nxt);   // node of the last row, of the row behind
+            int c1_ = last;
+            if (c1_ - c0_ + 1 > NMAX) {                        // a long run of nodes without edges inside the chunk: cut there
+                c1_ = c0_ + NMAX - 1;
+                int e1 = 0, dummy = 0;
+                sload2(ptr + c1_ + 1, ptr + c1_ + 1, e1, dummy);
+                r1_ = e1;                                      // (>= the rows of node c0_: never empty)
+                if (r1_ < re) sload2(row_of + r1_, ptr + c1_ + 1, nxt, dummy);
             }
-            if (r1 < re) prefetch(r1);                         // the next chunk's rows travel during the GEMMs
-            if (accumulate) {
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    int64_t g = r0 + rr + RPP * i;
-                    g = g < r1 ? g : r1 - 1;
-                    dacc[i] = ldg4(d_e, g, DIM, c4);
-                }
-            }
+            p.c1 = c1_, p.r1 = r1_;
+            ahead = r1_ < re ? nxt : -1;
         }
-        __syncthreads();
-        const bool open_end = sptr[nn] > rows;
-        reduce_nodes<16>(c0, nn, rows, S0, sptr, carry[par], carry[par ^ 1], nullptr, a.dPi);   // reads S0 only
-        par ^= 1;
-        if (rows > 0) {
-            Acc<2> acc;
-            acc.zero();
-            if (mt == 2) {
-                mma_k16<2>(Iz, f1, w2e, acc);
-                mma_k16<2>(Ia, f2, w2a, acc);
-            } else {
-                mma_k16<1>(Iz, f1, w2e, acc);
-                mma_k16<1>(Ia, f2, w2a, acc);
-            }
-            // the weight gradients' k-step: rows of both results from this wave's 16 channels of d z / d ea against all
-            // eight channel tiles of e
-            {
-                const Frag3 az = lds_kfrag_col(Iz, wv), aa = lds_kfrag_col(Ia, wv);
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const Frag3 be = lds_kfrag_col(Ie, b);
-                    mfma6_col(az, be, accE[b]);
-                    mfma6_col(aa, be, accA[b]);
-                }
-            }
-            __syncthreads();
-            acc_store<2>(acc, S0, wc, 0.f, mt);
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int r = rr + RPP * i;
-                const int64_t g = r0 + r;
-                if (g < r1) {
-                    float4 v = lds4(S0, r, c4);
-                    if (accumulate) v = f4add(v, dacc[i]);
-                    stg4(d_e, g, DIM, c4, v);
-                }
-            }
-        }
-        __syncthreads();
-        c0 = open_end ? c1 : c1 + 1;
-        r0 = r1;
+        p.rows = (int)(p.r1 - p.r0);
+        return p;
+    };
+    auto load_myp = [&](const Plan& p) {                       // ptr[c0 + t], clamped (ptr has n + 1 entries)
+        int64_t k = (int64_t)p.c0 + threadIdx.x;               // (c0 = -1 behind the workgroup's last chunk)
+        k = k < 0 ? 0 : (k < a.n ? k : a.n);
+        return ptr[k];
+    };
+    // d P_i of the workgroup's nodes: zeros first (nodes without edges keep them); acknowledged before the loop stores sums
+    for (int64_t k = (int64_t)nb * (DIM / 4) + threadIdx.x; k < (int64_t)ne * (DIM / 4); k += WG8)
+        reinterpret_cast<float4*>(a.dPi)[k] = f4zero();
+    const int64_t rbeg = (int64_t)uni(ptr[nb]);
+    int ahead = -1, first = 0;
+    if (rbeg < re) sload2(row_of + rbeg, row_of + rbeg, first, ahead);
+    Plan cur = plan_at(first, rbeg, ahead);
+    int myp = load_myp(cur);                                   // ptr[c0 + t] of the current chunk's nodes (raw)
+    APROBE_WG(0);
+    APROBE(0);
+    if (rbeg < re) {
+        prefetch(cur.r0);
+        gather();
     }
+    __builtin_amdgcn_s_waitcnt(0x0070);                        // vmcnt(0)  (expcnt 7, lgkmcnt 15 untouched)
+    __syncthreads();
+    while (cur.rows > 0) {
+        APROBE(1);
+        const int c0 = cur.c0, c1 = cur.c1, rows = cur.rows;
+        const int64_t r0 = cur.r0, r1 = cur.r1;
+        const int nn = c1 - c0 + 1;
+        // the next chunk starts at the node of the row behind this one: node c1 itself if it goes on
+        const bool open_end = ahead == c1;
+        const Plan nxt = plan_at(ahead, r1, ahead);
+        const int mt = (rows + 15) >> 4;
+        if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = myp - (int)r0;
+        myp = load_myp(nxt);                                   // (raw value: subtracting here would wait for the load here)
+        APROBE(2);
+        // every row of the 32-row k-step is written: rows past the chunk's end as zeros in all three images
+        float4 sx[NI], sy[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = rr + RPP * i;
+            const bool ok = r0 + r < r1;
+            st_kpieces4(Ie, r, c4, ok ? px[i] : f4zero());
+            sx[i] = ok ? f4mul(f4mul(pdm[i], pe[i]), f4dsilu(pz[i])) : f4zero();     // d z = dm * ea * SiLU'(z)
+            sy[i] = ok ? f4mul(pdm[i], f4silu(pz[i])) : f4zero();                    // d ea = dm * SiLU(z)
+            st_kpieces4(Iz, r, c4, sx[i]);
+            st_kpieces4(Ia, r, c4, sy[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int64_t g = r0 + rr + RPP * i;
+            f32x4 t = {sx[i].x, sx[i].y, sx[i].z, sx[i].w};
+            *reinterpret_cast<f32x4*>(g < r1 ? dz + g * DIM + 4 * c4 : dump) = t;
+        }
+        APROBE(3);
+        float4 dacc[NI];
+        if constexpr (ACC) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                int64_t g = r0 + rr + RPP * i;
+                g = g < r1 ? g : r1 - 1;
+                dacc[i] = ldg4(d_e, g, DIM, c4);
+            }
+        }
+        prefetch(r1);                                          // the next chunk's rows travel during the GEMMs
+        APROBE(4);
+        __syncthreads();
+        APROBE(5);
+        const bool open_begin = sptr[0] < 0;
+        // d P_i[node] = the sum of the node's d z rows -- on the matrix pipe: [16 nodes x 32 rows] of 0 / 1 (exact in bf16) times
+        // this wave's column fragment of the d z pieces (the operand the weight-gradient k-step below loads anyway), three MFMAs
+        // per 16 nodes and wave, every product exact, fp32 accumulation.  (As one serial chain per node on a 32-lane group --
+        // reduce_nodes, the form of the plain kernel -- a complex's ~36-row nodes cost 1 800-3 800 cycles of a 16 000-cycle chunk
+        // on the critical path, alone on the LDS or not.)  A node that spans chunks hands its running sum on through `carry`
+        // (this wave's 16 channels, same wave next chunk).
+        {
+            const Frag3 az = lds_kfrag_col(Iz, wv);
+            const int lane = threadIdx.x & 63, i16 = lane & 15, kg = lane >> 4;
+            float* cin = reinterpret_cast<float*>(carry[par]) + wc;
+            float* cout = reinterpret_cast<float*>(carry[par ^ 1]) + wc;
+            auto node_tile = [&](int nt) {
+                const int k = 16 * nt + i16;
+                int b = rows, e = rows;                        // (beyond the chunk's nodes: no rows)
+                if (k < nn) b = sptr[k], e = sptr[k + 1];
+                uint32_t ind[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int q = 8 * kg + 2 * t;
+                    ind[t] = ((q >= b && q < e) ? 0x3f80u : 0u) | ((q + 1 >= b && q + 1 < e) ? 0x3f800000u : 0u);
+                }
+                f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+                d = mfma_bf16(ind, az.p[2], d);
+                d = mfma_bf16(ind, az.p[1], d);
+                d = mfma_bf16(ind, az.p[0], d);
+                bsum += (d[0] + d[1]) + (d[2] + d[3]);         // every row of the chunk belongs to one of its nodes
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k2 = 16 * nt + 4 * kg + r;
+                    float v = d[r];
+                    if (k2 == 0 && open_begin) v += cin[i16];
+                    const bool keep = k2 == nn - 1 && open_end;
+                    if (keep) cout[i16] = v;
+                    // (one store per lane and r whatever the node count: rows that are not a finished node's go to the dump)
+                    float* dst = (k2 < nn && !keep) ? a.dPi + (int64_t)(c0 + k2) * DIM + wc + i16 : dump;
+                    *dst = v;
+                }
+            };
+            node_tile(0);
+            if (nn > 16) {                                     // (rare: a chunk with more than 16 nodes; the side path drains)
+                for (int nt = 1; 16 * nt < nn; ++nt) node_tile(nt);
+                __builtin_amdgcn_s_waitcnt(0x0070);
+            }
+        }
+        par ^= 1;
+        APROBE(6);
+        // the weight gradients' k-step: rows of both results from this wave's 16 channels of d z / d ea against all eight
+        // channel tiles of e
+        {
+            const Frag3 az = lds_kfrag_col(Iz, wv), aa = lds_kfrag_col(Ia, wv);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const Frag3 be = lds_kfrag_col(Ie, b);
+                mfma6_col(az, be, accE[b]);
+                mfma6_col(aa, be, accA[b]);
+            }
+        }
+        APROBE(7);
+        Acc<2> acc;
+        acc.zero();
+        if (mt == 2) {
+            mma_k16<2>(Iz, f1, w2e, acc);
+            mma_k16<2>(Ia, f2, w2a, acc);
+        } else {
+            mma_k16<1>(Iz, f1, w2e, acc);
+            mma_k16<1>(Ia, f2, w2a, acc);
+        }
+        APROBE(8);
+        gather();                                              // (the row indices arrived during the GEMMs)
+        acc_store<2>(acc, S0, wc, 0.f, mt);                   // (S0 is this stage's alone: no barrier ahead of it)
+        __syncthreads();
+        APROBE(9);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = rr + RPP * i;
+            const int64_t g = r0 + r;
+            float4 v = lds4(S0, r, c4);
+            if constexpr (ACC) v = f4add(v, dacc[i]);
+            f32x4 t = {v.x, v.y, v.z, v.w};
+            *reinterpret_cast<f32x4*>(g < r1 ? d_e + g * DIM + 4 * c4 : dump) = t;
+        }
+        APROBE(10);
+        __syncthreads();
+        APROBE(11);
+        cur = nxt;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
     // ---- the workgroup's partial tiles in the slot format of wgrad_core.h: slot blockIdx.x of job 0 (dW_e, with the bias
     // parts), slot gridDim.x + blockIdx.x of job 1 (dW_ea).  Through LDS so that the tiles leave as 512-byte rows.
     float* T = reinterpret_cast<float*>(ldsb);                 // [128][LDT] over the (free) piece images
@@ -763,7 +907,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW
     for (int b = 0; b < 8; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) T[(16 * wv + 4 * kg + r) * LDT + 16 * b + r16] = accE[b][r];
-    *reinterpret_cast<float4*>(S0 + rr * DIM + 4 * c4) = bsum;  // [16 row groups][128]
+    S0[kg * DIM + wc + r16] = bsum;                            // [4 node-row groups][128]
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < DIM / 16; ++i) {
@@ -773,7 +917,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW
     if (threadIdx.x < DIM) {
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s += S0[k * DIM + threadIdx.x];   // fixed order
+        for (int k = 0; k < 4; ++k) s += S0[k * DIM + threadIdx.x];    // fixed order
         slot0[DIM * DIM + threadIdx.x] = s;
         slot0[DIM * DIM + DIM + threadIdx.x] = 0.f;
     }
@@ -788,6 +932,8 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW
         const int row = rr + 16 * i;
         *reinterpret_cast<float4*>(slot1 + row * DIM + 4 * c4) = *reinterpret_cast<const float4*>(T + row * LDT + 4 * c4);
     }
+    APROBE(12);
+    APROBE_WG(1);
 }
 
 // ------------------------------------------------------------------------------------------------ local aggregation
@@ -1022,7 +1168,7 @@ extern "C" int pamnet_global_edge_agg_bwd_f32(const float* d_agg, int64_t n_edge
 extern "C" int pamnet_global_edge_agg_wg_floats(int64_t n_edges, int64_t* floats, int64_t* slots) {
     if (n_edges < 0 || !floats) return PAMNET_EINVAL;
     const int64_t g = agg_grid(n_edges);
-    *floats = 2 * g * WSLOT;
+    *floats = 2 * g * WSLOT + 4 * WG8;      // + a dump line behind the slots (stores of rows past a chunk's end)
     if (slots) *slots = g;
     return PAMNET_OK;
 }
@@ -1038,7 +1184,8 @@ extern "C" int pamnet_global_edge_agg_bwd_wg_f32(const float* d_agg, int64_t n_e
     GAggBwdW a{d_agg, z, ea, e, We, Wea, ptr, row_of, cuts, dz, d_e, dPi, partial, n_edges, n_nodes, (int)ld_we, (int)ld_wea,
                (int)accumulate};
     const int64_t grid = agg_grid(n_edges);
-    hipLaunchKernelGGL(global_edge_agg_bwd_wg_kernel, dim3((unsigned)grid), dim3(WG8), 0, as_stream(stream), a);
+    if (accumulate) hipLaunchKernelGGL(global_edge_agg_bwd_wg_kernel<true>, dim3((unsigned)grid), dim3(WG8), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL(global_edge_agg_bwd_wg_kernel<false>, dim3((unsigned)grid), dim3(WG8), 0, as_stream(stream), a);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
