@@ -19,6 +19,8 @@
 // local_agg: the two chained aggregations of the local layer (layers/local_message_passing.py:49-54),
 //   m_t[e] = m_ji[e] + sum_{r in rows(e)} m_nb[idx[r]] * s[r],   x2[i] = x1[i] + sum_{e -> i} q3[e] * m_t[e],
 // as one launch (one lane group per edge, node sums through LDS in CSR order).
+#include <type_traits>
+
 #include "edge_core.h"
 
 using namespace edge;
@@ -684,27 +686,35 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW
     //   * ptr[c0 + t] of the NEXT chunk's nodes first thing in a chunk, used a whole chunk later;
     //   * the rows (z, ea, e) and the row indices of the next chunk requested before the GEMMs, the gather of its d_agg
     //     rows behind them -- ahead of the final sweep's stores, so that the next sweep's wait for it is not a wait for those;
-    //   * the accumulate operand requested ahead of all of them: the final sweep's wait for it covers nothing younger.
-    // Chunks without rows (runs of nodes without edges) take a side path that ends with an empty queue.
+    //   * the accumulate operand requested ahead of all of them: the final sweep's wait for it covers nothing younger;
+    //   * chunks of exactly 32 rows -- all but a workgroup's last -- run a body without row masks (FULL).
+    // Addresses: one 32-bit byte offset per row and thread on top of the (scalar) stream bases -- the host side keeps this
+    // kernel to n_edges * 512 < 2^32.
     int par = 0;
     float* dump = a.partial + 2 * (int64_t)gridDim.x * WSLOT + 4 * threadIdx.x;   // 8 KB behind the slots: writes nobody reads
     float4 pz[NI], pe[NI], px[NI], pdm[NI];                    // z, ea, e rows and gathered d_agg rows of the next chunk
     int pri[NI];                                               // ... and the target node of each (the gather's index)
-    const int64_t rlast = re > 0 ? re - 1 : 0;
-    auto prefetch = [&](int64_t rb) {                          // (clamped: rows past the workgroup's end re-read its last row)
+    const int rlast = re > 0 ? (int)re - 1 : 0;
+    auto at = [](const float* base, uint32_t byte_off) {
+        return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+    };
+    auto at_w = [](float* base, uint32_t byte_off) { return reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off); };
+    const uint32_t coff = 16u * c4;
+    auto prefetch = [&](int rb) {                              // (clamped: rows past the workgroup's end re-read its last row)
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            int64_t g = rb + rr + RPP * i;
-            g = g < re ? g : rlast;
-            pz[i] = ldg4(zs, g, DIM, c4);
-            pe[i] = ldg4(eas, g, DIM, c4);
-            px[i] = ldg4(es, g, DIM, c4);
+            int g = rb + rr + RPP * i;
+            g = g < rlast ? g : rlast;
+            const uint32_t off = (uint32_t)g * 512u + coff;
+            pz[i] = *at(zs, off);
+            pe[i] = *at(eas, off);
+            px[i] = *at(es, off);
             pri[i] = row_of[g];
         }
     };
     auto gather = [&]() {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) pdm[i] = ldg4(d_agg, pri[i], DIM, c4);
+        for (int i = 0; i < NI; ++i) pdm[i] = *at(d_agg, (uint32_t)pri[i] * 512u + coff);
     };
     // The plan's loads on the scalar unit.  ptr / row_of are never written by this kernel, but the compiler cannot know --
     // behind the first store of the loop it falls back to vector loads -- hence by hand.  Addresses are wave-uniform
@@ -717,31 +727,31 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW
                      : "memory");
     };
     struct Plan {
-        int c0, c1, rows;
-        int64_t r0, r1;
+        int c0, c1, rows, r0, r1;
     };
     // chunk starting at row r0_ whose node is c0_; returns in `ahead` the node of the row behind the chunk (-1 at the end of
     // the workgroup's rows).  Nodes without edges are never a chunk's business: their d P_i rows are zero-filled up front.
-    auto plan_at = [&](int c0_, int64_t r0_, int& ahead) {
+    const int ire = (int)re;
+    auto plan_at = [&](int c0_, int r0_, int& ahead) {
         Plan p;
         p.c0 = c0_, p.r0 = r0_, p.c1 = c0_ - 1, p.r1 = r0_;
         ahead = -1;
-        if (r0_ < re) {
-            int64_t r1_ = r0_ + CAP < re ? r0_ + CAP : re;
+        if (r0_ < ire) {
+            int r1_ = r0_ + CAP < ire ? r0_ + CAP : ire;
             int last = 0, nxt = 0;
-            sload2(row_of + r1_ - 1, row_of + (r1_ < re ? r1_ : re - 1), last, nxt);   // node of the last row, of the row behind
+            sload2(row_of + r1_ - 1, row_of + (r1_ < ire ? r1_ : ire - 1), last, nxt);   // node of the last row, of the row behind
             int c1_ = last;
             if (c1_ - c0_ + 1 > NMAX) {                        // a long run of nodes without edges inside the chunk: cut there
                 c1_ = c0_ + NMAX - 1;
                 int e1 = 0, dummy = 0;
                 sload2(ptr + c1_ + 1, ptr + c1_ + 1, e1, dummy);
                 r1_ = e1;                                      // (>= the rows of node c0_: never empty)
-                if (r1_ < re) sload2(row_of + r1_, ptr + c1_ + 1, nxt, dummy);
+                if (r1_ < ire) sload2(row_of + r1_, ptr + c1_ + 1, nxt, dummy);
             }
             p.c1 = c1_, p.r1 = r1_;
-            ahead = r1_ < re ? nxt : -1;
+            ahead = r1_ < ire ? nxt : -1;
         }
-        p.rows = (int)(p.r1 - p.r0);
+        p.rows = p.r1 - p.r0;
         return p;
     };
     auto load_myp = [&](const Plan& p) {                       // ptr[c0 + t], clamped (ptr has n + 1 entries)
@@ -752,29 +762,29 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW
     // d P_i of the workgroup's nodes: zeros first (nodes without edges keep them); acknowledged before the loop stores sums
     for (int64_t k = (int64_t)nb * (DIM / 4) + threadIdx.x; k < (int64_t)ne * (DIM / 4); k += WG8)
         reinterpret_cast<float4*>(a.dPi)[k] = f4zero();
-    const int64_t rbeg = (int64_t)uni(ptr[nb]);
+    const int rbeg = uni(ptr[nb]);
     int ahead = -1, first = 0;
-    if (rbeg < re) sload2(row_of + rbeg, row_of + rbeg, first, ahead);
+    if (rbeg < ire) sload2(row_of + rbeg, row_of + rbeg, first, ahead);
     Plan cur = plan_at(first, rbeg, ahead);
     int myp = load_myp(cur);                                   // ptr[c0 + t] of the current chunk's nodes (raw)
     APROBE_WG(0);
     APROBE(0);
-    if (rbeg < re) {
+    if (rbeg < ire) {
         prefetch(cur.r0);
         gather();
     }
     __builtin_amdgcn_s_waitcnt(0x0070);                        // vmcnt(0)  (expcnt 7, lgkmcnt 15 untouched)
     __syncthreads();
-    while (cur.rows > 0) {
+    auto body = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
         APROBE(1);
-        const int c0 = cur.c0, c1 = cur.c1, rows = cur.rows;
-        const int64_t r0 = cur.r0, r1 = cur.r1;
+        const int c0 = cur.c0, c1 = cur.c1, rows = cur.rows, r0 = cur.r0, r1 = cur.r1;
         const int nn = c1 - c0 + 1;
         // the next chunk starts at the node of the row behind this one: node c1 itself if it goes on
         const bool open_end = ahead == c1;
         const Plan nxt = plan_at(ahead, r1, ahead);
-        const int mt = (rows + 15) >> 4;
-        if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = myp - (int)r0;
+        const int mt = FULL ? 2 : (rows + 15) >> 4;
+        if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = myp - r0;
         myp = load_myp(nxt);                                   // (raw value: subtracting here would wait for the load here)
         APROBE(2);
         // every row of the 32-row k-step is written: rows past the chunk's end as zeros in all three images
@@ -782,27 +792,28 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int r = rr + RPP * i;
-            const bool ok = r0 + r < r1;
+            const bool ok = FULL || r < rows;
             st_kpieces4(Ie, r, c4, ok ? px[i] : f4zero());
             sx[i] = ok ? f4mul(f4mul(pdm[i], pe[i]), f4dsilu(pz[i])) : f4zero();     // d z = dm * ea * SiLU'(z)
             sy[i] = ok ? f4mul(pdm[i], f4silu(pz[i])) : f4zero();                    // d ea = dm * SiLU(z)
             st_kpieces4(Iz, r, c4, sx[i]);
             st_kpieces4(Ia, r, c4, sy[i]);
         }
+        const uint32_t boff = (uint32_t)(r0 + rr) * 512u + coff;   // byte offset of this thread's first row
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int64_t g = r0 + rr + RPP * i;
-            f32x4 t = {sx[i].x, sx[i].y, sx[i].z, sx[i].w};
-            *reinterpret_cast<f32x4*>(g < r1 ? dz + g * DIM + 4 * c4 : dump) = t;
+            float4* dst = at_w(dz, boff + 512u * RPP * i);
+            if (!FULL && rr + RPP * i >= rows) dst = reinterpret_cast<float4*>(dump);
+            *dst = sx[i];
         }
         APROBE(3);
         float4 dacc[NI];
         if constexpr (ACC) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                int64_t g = r0 + rr + RPP * i;
-                g = g < r1 ? g : r1 - 1;
-                dacc[i] = ldg4(d_e, g, DIM, c4);
+                uint32_t off = boff + 512u * RPP * i;
+                if (!FULL && rr + RPP * i >= rows) off = (uint32_t)r0 * 512u + coff;
+                dacc[i] = *at(d_e, off);
             }
         }
         prefetch(r1);                                          // the next chunk's rows travel during the GEMMs
@@ -885,18 +896,22 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int r = rr + RPP * i;
-            const int64_t g = r0 + r;
             float4 v = lds4(S0, r, c4);
             if constexpr (ACC) v = f4add(v, dacc[i]);
-            f32x4 t = {v.x, v.y, v.z, v.w};
-            *reinterpret_cast<f32x4*>(g < r1 ? d_e + g * DIM + 4 * c4 : dump) = t;
+            float4* dst = at_w(d_e, boff + 512u * RPP * i);
+            if (!FULL && r >= rows) dst = reinterpret_cast<float4*>(dump);
+            *dst = v;
         }
         APROBE(10);
-        __syncthreads();
+        // (no barrier at the end of a chunk: every wave reached the one above with its GEMMs done -- the images are free for the
+        // next sweep --, S0 is next written behind the next sweep's barrier, sptr likewise, `carry` is wave-private)
         APROBE(11);
         cur = nxt;
-    }
+    };
+    while (cur.rows == CAP) body(std::true_type{});
+    while (cur.rows > 0) body(std::false_type{});
     __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();                                           // (the last final sweep is done with S0)
     // ---- the workgroup's partial tiles in the slot format of wgrad_core.h: slot blockIdx.x of job 0 (dW_e, with the bias
     // parts), slot gridDim.x + blockIdx.x of job 1 (dW_ea).  Through LDS so that the tiles leave as 512-byte rows.
     float* T = reinterpret_cast<float*>(ldsb);                 // [128][LDT] over the (free) piece images
@@ -1179,6 +1194,7 @@ extern "C" int pamnet_global_edge_agg_bwd_wg_f32(const float* d_agg, int64_t n_e
                                                  float* partial, pamnet_stream_t stream) {
     if (n_edges < 0 || n_nodes < 0) return PAMNET_EINVAL;
     if (n_nodes == 0) return PAMNET_EINVAL;                     // (the slots must be written: no launch, no partial sums)
+    if (n_edges >= (int64_t(1) << 23) || n_nodes >= (int64_t(1) << 23)) return PAMNET_EINVAL;   // 32-bit byte offsets per stream
     if (!d_agg || !ptr || !We || !Wea || !dPi || !partial) return PAMNET_ENULL;
     if (n_edges > 0 && (!row_of || !z || !ea || !e || !dz || !d_e)) return PAMNET_ENULL;
     GAggBwdW a{d_agg, z, ea, e, We, Wea, ptr, row_of, cuts, dz, d_e, dPi, partial, n_edges, n_nodes, (int)ld_we, (int)ld_wea,

@@ -121,8 +121,9 @@ inline int64_t rider_floats(const Graph& g) {
 // amortise its two 64 KB partial tiles.
 inline bool edge_wgrad(const Graph& g) {
     static const int v = [] { const char* e = getenv("PAMNET_EDGE_WGRAD"); return e ? atoi(e) : -1; }();
-    if (v >= 0) return v != 0 && g.eg > 0;
-    return g.eg >= 256 * 512;
+    const bool fits = g.eg > 0 && g.eg < (int64_t(1) << 23) && g.n < (int64_t(1) << 23);   // (32-bit byte offsets in that kernel)
+    if (v >= 0) return v != 0 && fits;
+    return fits && g.eg >= 256 * 512;
 }
 inline int64_t edge_partial_floats(const Graph& g) {
     int64_t f = 0;
