@@ -34,7 +34,7 @@ typedef void* pamnet_stream_t; /* hipStream_t */
 
 /* Library / ABI version (bumped on any signature change).  pamnet_abi_version() returns the PAMNET_ABI_VERSION the library
  * was built against; a binding compares it with this header's (pamnet_amd/lib.py load(): a stale .so fails loudly). */
-#define PAMNET_ABI_VERSION 8
+#define PAMNET_ABI_VERSION 9
 int pamnet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -638,8 +638,10 @@ int pamnet_embed_multi_bwd_f32(const pamnet_embed_job* jobs, int32_t n_jobs, con
  * Layer-stack engine: the n_layer x (global, local) loop of PAMNet.forward (models.py:196-204) in ONE call per
  * direction (dim = 128).  Host-side C++ enqueues ~10 (fwd) / ~20 (bwd) fused launches per layer pair on `stream`.
  *   sizes      : {n, e_g, e_l, tp}
- *   graph_idx  : 15 device index arrays {g_ptr, g_row, g_col, gT_ptr, gT_perm, l_ptr, l_row, l_col, lT_ptr, lT_perm,
- *                tp_ptr, tp_row, tp_col, tpT_ptr, tpT_perm}  (the *T_* entries are only read by the backward)
+ *   graph_idx  : 16 device index arrays {g_ptr, g_row, g_col, gT_ptr, gT_perm, l_ptr, l_row, l_col, lT_ptr, lT_perm,
+ *                tp_ptr, tp_row, tp_col, tpT_ptr, tpT_perm, cuts}  (the *T_* entries are only read by the backward;
+ *                cuts: nullable -- the work split of pamnet_seg_cuts_i32 made with the graph, else computed per call;
+ *                the narrow-width engine reads the first 15)
  *   gparams    : n_layer x 28 device pointers  {mlp_x1.W, .b, mlp_m.W [128,384], .b, W_edge_attr.W, tail W[10], b[10],
  *                W_out.weight, W_out.bias, W}
  *   lparams    : n_layer x 35 device pointers  {mlp_x1.W, .b, mlp_m_ji.W, .b, mlp_m_kj.W, .b, mlp_sbf.0.W, .b,

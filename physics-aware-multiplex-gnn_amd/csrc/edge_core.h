@@ -223,8 +223,17 @@ __device__ __forceinline__ void st_pieces4(char* __restrict__ P, int r, int c4, 
     const int q = c4 >> 3, kg = (c4 >> 1) & 3;
     char* d = P + (r >> 4) * PTILE + q * 1024 + piece_chunk(r & 15, kg, q) * 16 + (c4 & 1) * 8;
     uint32_t a0, b0, c0, a1, b1, c1;
+#ifdef PAMNET_SPLIT_PROBE
+    // Development probe (never in libpamnet_hip.so; tools/agg_probe.py with PAMNET_PROBE_FLAGS=-DPAMNET_SPLIT_PROBE): what the
+    // kernels would cost if the pieces arrived ready-made -- one conversion instead of the exact three-piece split (WRONG
+    // numbers, right instruction count for an upper bound on "split the edge embeddings once per step").
+    a0 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2{v.x, v.y}), bf16x2));
+    a1 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2{v.z, v.w}), bf16x2));
+    b0 = c0 = a0, b1 = c1 = a1;
+#else
     split3(v.x, v.y, a0, b0, c0);
     split3(v.z, v.w, a1, b1, c1);
+#endif
     *reinterpret_cast<uint2*>(d) = make_uint2(a0, a1);
     *reinterpret_cast<uint2*>(d + 4096) = make_uint2(b0, b1);
     *reinterpret_cast<uint2*>(d + 8192) = make_uint2(c0, c1);

@@ -520,10 +520,13 @@ inline int grid_for(int64_t rows, int cap) {
     const int64_t tiles = (rows + TR - 1) / TR;
     return (int)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
 }
-constexpr int FWD_CAP = 1024, BWD_CAP = 256;
-// backward: two tiles per workgroup where there are enough (each workgroup ends with a 17-44 KB partial-gradient row, and
-// at two workgroups per CU the jobs of a multi launch are co-resident up to 512 workgroups)
-inline int bwd_grid(int64_t rows) { return grid_for((rows + 1) / 2, BWD_CAP); }
+constexpr int FWD_CAP = 1024, BWD_SLOTS = 512;
+// backward: the workgroups of a multi launch are co-resident up to 512 (two per CU); launch_multi deals them to the jobs by
+// COST -- a 64-row tile of the two-set 42-wide layer (the triplet / pair rows) is ~5x the matrix work of a 16-wide tile: with
+// "two tiles per workgroup" for every job that job's 138 workgroups were the launch (47-55 us for the QM9 batch, a 10x
+// multiple of the bytes' floor) while the 16-wide jobs' workgroups had left long before.  A job alone gets all slots.
+inline int bwd_grid_max(int64_t rows) { return grid_for(rows, BWD_SLOTS); }
+inline int tile_cost(int code) { return code == C42_TWO ? 5 : (code == C42 ? 3 : (code == C16_RBF || code == C16_DX ? 2 : 1)); }
 
 // host: pamnet_embed_job -> EJob (validated); bwd selects the backward variant and grid
 int make_job(const pamnet_embed_job& h, bool bwd, EJob* o) {
@@ -541,7 +544,7 @@ int make_job(const pamnet_embed_job& h, bool bwd, EJob* o) {
     o->out = h.out, o->gout = h.gout, o->partial = h.partial, o->dx = h.dx;
     o->dW0 = h.dW0, o->db0 = h.db0, o->dW1 = h.dW1, o->db1 = h.db1, o->dfreq = h.dfreq;
     o->code = K == 18 ? C18 : (K == 42 ? (h.W1 ? C42_TWO : C42) : (h.dist ? C16_RBF : ((bwd && h.dx) ? C16_DX : C16)));
-    o->nblk = bwd ? bwd_grid(h.rows) : grid_for(h.rows, FWD_CAP);
+    o->nblk = bwd ? bwd_grid_max(h.rows) : grid_for(h.rows, FWD_CAP);     // (backward: re-dealt by cost in launch_multi)
     return PAMNET_OK;
 }
 
@@ -572,6 +575,20 @@ int launch_multi(const pamnet_embed_job* jobs, int32_t n_jobs, const pamnet_type
     }
     const int rc = make_types(types, bwd, &J.types);
     if (rc != PAMNET_OK) return rc;
+    if (bwd && J.n > 0) {
+        // slots by cost (never more than a job's tiles, never more than its scratch: bwd_grid_max)
+        int64_t total = 0;
+        for (int j = 0; j < J.n; ++j) total += (int64_t)((J.job[j].rows + TR - 1) / TR) * tile_cost(J.job[j].code);
+        const int64_t budget = BWD_SLOTS - J.types.nblk > 64 ? BWD_SLOTS - J.types.nblk : 64;
+        grid = 0;
+        for (int j = 0; j < J.n; ++j) {
+            const int64_t tiles = (J.job[j].rows + TR - 1) / TR;
+            int64_t want = total > 0 ? (tiles * tile_cost(J.job[j].code) * budget + total - 1) / total : 1;
+            want = want < 1 ? 1 : want;
+            J.job[j].nblk = (int)(want < J.job[j].nblk ? want : J.job[j].nblk);
+            grid += J.job[j].nblk;
+        }
+    }
     grid += J.types.nblk;
     if (grid == 0) return PAMNET_OK;
     if (!bwd) {
@@ -593,10 +610,10 @@ int launch_multi(const pamnet_embed_job* jobs, int32_t n_jobs, const pamnet_type
 
 }  // namespace
 
-// scratch floats for the backward of one layer: grid * (2*128*K + 2*128 + 16)
+// scratch floats for the backward of one layer: (largest grid a launch may give the job) * (2*128*K + 2*128 + 16)
 extern "C" int pamnet_embed_scratch_floats(int64_t rows, int64_t K, int64_t* floats) {
     if (rows < 0 || K <= 0 || !floats) return PAMNET_EINVAL;
-    *floats = (int64_t)bwd_grid(rows) * (2 * DOUT * K + 2 * DOUT + 16);
+    *floats = (int64_t)bwd_grid_max(rows) * (2 * DOUT * K + 2 * DOUT + 16);
     return PAMNET_OK;
 }
 

@@ -30,6 +30,7 @@ struct Graph {
     const int32_t *g_ptr, *g_row, *g_col, *gT_ptr, *gT_perm;
     const int32_t *l_ptr, *l_row, *l_col, *lT_ptr, *lT_perm;
     const int32_t *t_ptr, *t_row, *t_col, *tT_ptr, *tT_perm;
+    const int32_t* cuts;      // nullable: the fused global-edge kernels' work split, made with the graph (pamnet_seg_cuts_i32)
 };
 
 inline int64_t al(int64_t x) { return (x + 63) / 64 * 64; }       // 256-byte aligned slabs
@@ -318,12 +319,12 @@ extern "C" int pamnet_stack_layout(int64_t n, int64_t eg, int64_t el, int64_t tp
     return PAMNET_OK;
 }
 
-// graph_desc: 4 x int64 sizes {n, eg, el, tp}; graph_idx: 15 device pointers in the order of struct Graph.
+// graph_desc: 4 x int64 sizes {n, eg, el, tp}; graph_idx: 16 device pointers in the order of struct Graph (the last nullable).
 static int fill_graph(Graph& g, const int64_t* sizes, const int32_t* const* idx) {
     if (!sizes || !idx) return PAMNET_ENULL;
     g.n = sizes[0]; g.eg = sizes[1]; g.el = sizes[2]; g.tp = sizes[3];
     const int32_t** f = &g.g_ptr;
-    for (int k = 0; k < 15; ++k) f[k] = idx[k];
+    for (int k = 0; k < 16; ++k) f[k] = idx[k];
     return PAMNET_OK;
 }
 
@@ -426,7 +427,12 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
     }
     const int32_t pkc = cb ? 2 : (packed ? 1 : 0);          // what the chain launches are told about their images
     const int32_t pk = packed ? 1 : 0;
-    CK(pamnet_seg_cuts_i32(g.g_ptr, g.g_row, g.n, g.eg, t.cuts, nullptr, st));      // work split of the fused global-edge kernels
+    // work split of the fused global-edge kernels: made with the graph (a side-stream launch of graph construction) or here
+    const int32_t* cuts = g.cuts;
+    if (!cuts) {
+        CK(pamnet_seg_cuts_i32(g.g_ptr, g.g_row, g.n, g.eg, t.cuts, nullptr, st));
+        cuts = t.cuts;
+    }
     for (int64_t k = 0; k < n_layer; ++k) {
         // ---------------- global layer (layers/global_message_passing.py:33-56)
         const float* const* gp = gparams + k * NG;
@@ -436,7 +442,7 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         if (k == 0) CK(pamnet_node_pre_fwd_f32(x, g.n, gp[0], gp[1], wpg, 3 * D, 2, sv(s.Zx1), t.x1, t.P, st));
         // message MLP + add-aggregation in one kernel: x2 = x1 + sum_{e -> i} msg_e, the messages never leave the chip
         CK(pamnet_global_edge_agg_fwd_f32(e_g, g.eg, g.n, gp[2] + 2 * D, 3 * D, gp[3], gp[4], D, t.P, t.P + g.n * D,
-                                          g.g_ptr, g.g_row, g.g_col, t.cuts, t.x1, sv(s.z), sv(s.ea), s.x2, st));
+                                          g.g_ptr, g.g_row, g.g_col, cuts, t.x1, sv(s.z), sv(s.ea), s.x2, st));
         const float* const* lp = lparams + k * NL;
         const LocalSaved q = carve_local(saved + k * (gs + ls) + gs, g);
         const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
@@ -592,7 +598,11 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
     CK(pamnet_wgrad_rider_bytes(&rider_bytes));
     std::vector<char> wctx((size_t)ctx_bytes, 0), rider((size_t)rider_bytes, 0);
     const bool ride = fuse && riders_fit(g);
-    CK(pamnet_seg_cuts_i32(g.g_ptr, g.g_row, g.n, g.eg, t.cuts, nullptr, st));      // work split of the fused global-edge kernels
+    const int32_t* cuts = g.cuts;          // work split of the fused global-edge kernels (as in the forward)
+    if (!cuts) {
+        CK(pamnet_seg_cuts_i32(g.g_ptr, g.g_row, g.n, g.eg, t.cuts, nullptr, st));
+        cuts = t.cuts;
+    }
     float* parts[2] = {t.partial, t.partial2};
     int pflip = 0;
     Jobs pair_jobs;                       // a pair's local-layer jobs waiting for its merged launch
@@ -704,11 +714,11 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 // ... and the step's own weight gradients: partial tiles per workgroup, summed by the next weight-gradient launch
                 int64_t efloats = 0, eslots = 0;
                 CK(pamnet_global_edge_agg_wg_floats(g.eg, &efloats, &eslots));
-                CK(pamnet_global_edge_agg_bwd_wg_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, t.cuts, s.z, s.ea, e_g, gp[2] + 2 * D, 3 * D,
+                CK(pamnet_global_edge_agg_bwd_wg_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, cuts, s.z, s.ea, e_g, gp[2] + 2 * D, 3 * D,
                                                      gp[4], D, t.dz, d_eg, acc, t.dPg, t.edge_partial, st));
                 CK(pamnet_wgrad_edge_enqueue_f32(wctx.data(), eslots, gg[2] + 2 * D, 3 * D, gg[3], gg[4], D, t.edge_partial));
             } else {
-                CK(pamnet_global_edge_agg_bwd_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, t.cuts, s.z, s.ea, gp[2] + 2 * D, 3 * D, gp[4],
+                CK(pamnet_global_edge_agg_bwd_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, cuts, s.z, s.ea, gp[2] + 2 * D, 3 * D, gp[4],
                                                   D, t.dz, t.dea, d_eg, acc, t.dPg, st));
             }
             CK(pamnet_segment_sum_f32(t.dPg + pl, nullptr, t.dz, nullptr, nullptr, nullptr, g.gT_perm, g.gT_ptr, g.n, D, st));

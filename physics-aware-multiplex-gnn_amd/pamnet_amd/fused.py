@@ -590,7 +590,8 @@ def _graph_tables(graph):
     sizes = _iarr([graph.n, graph.glob.m, graph.loc.m, graph.tp.m])
     idx = _parr([graph.glob.ptr, graph.glob.row_of, graph.glob.col, graph.glob_T.ptr, graph.glob_T.perm,
                  graph.loc.ptr, graph.loc.row_of, graph.loc.col, graph.loc_T.ptr, graph.loc_T.perm,
-                 graph.tp.ptr, graph.tp.row_of, graph.tp.col, graph.tp_T.ptr, graph.tp_T.perm])
+                 graph.tp.ptr, graph.tp.row_of, graph.tp.col, graph.tp_T.ptr, graph.tp_T.perm,
+                 getattr(graph, 'seg_cuts', None)])
     return sizes, idx
 
 

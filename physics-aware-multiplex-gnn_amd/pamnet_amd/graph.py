@@ -602,8 +602,8 @@ def _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_ind
     g.__dict__['_lazy'] = lazy
     # pointer tables of the layer-stack engines (fused._graph_tables): raw addresses, no tensors
     order = ('G_PTR', 'G_ROW', 'G_COL', 'GT_PTR', 'GT_PERM', 'L_PTR', 'L_ROW', 'L_COL', 'LT_PTR', 'LT_PERM',
-             'T_PTR', 'T_ROW', 'T_COL', 'TT_PTR', 'TT_PERM')
-    idx = (ctypes.c_void_p * 15)()
+             'T_PTR', 'T_ROW', 'T_COL', 'TT_PTR', 'TT_PERM', 'CUTS')
+    idx = (ctypes.c_void_p * 16)()
     for k, name in enumerate(order):
         idx[k] = g._addr(F[name])
     g._tables = ((ctypes.c_int64 * 4)(n, eg, el, tp), idx)
@@ -749,7 +749,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
                 and (mol_local is True or n <= MOL_ATOMS * g.n_graphs // 2)):
             done = _mol_local_graph(g, pos, ing, cutoff_g, with_triplets, need_grad)
             if done:
-                return g
+                return _with_seg_cuts(g, dataset)
         lp, l_src, l_dst, tp_ptr = bonds(ei, None if ing is None else (ing[3], ing[4]))
         if ing is not None:                       # validity and self loops were noted by the ingest launch
             flag, kept = ing[5], ing[6]           # (`kept`: non-zero = NOT all kept; read through _kept below)
@@ -918,6 +918,17 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         # d m_neighbor[e'] of the triplet/pair gather
         g.tp_T = (TripletTranspose(g.loc, g.loc_T, tp_ptr, tcount, tot, with_triplets, zeroed=hinted) if (e_l > 0 and tot > 0)
                   else Transpose(tp_idx, max(e_l, 1)))
+    return _with_seg_cuts(g, dataset)
+
+
+def _with_seg_cuts(g, dataset):
+    """The node-aligned work split of the fused global-edge kernels (csrc/edge_agg.hip), made WITH the graph -- one small launch
+    on the stream that builds it (the input pipeline's side stream) instead of one per direction on the main stream inside the
+    layer-stack calls.  The one-call graph engine does the same (field CUTS)."""
+    if dataset in ('QM9', 'PDBbind') and g.n > 0:
+        g.seg_cuts = _i32(260, g.glob.ptr.device)
+        lib.call('pamnet_seg_cuts_i32', lib.ptr(g.glob.ptr), lib.ptr(g.glob.row_of), g.n, g.glob.m, lib.ptr(g.seg_cuts), None,
+                 lib.stream_of(g.glob.ptr))
     return g
 
 

@@ -17,7 +17,8 @@ from pamnet_amd import graph as G, lib, synth  # noqa: E402
 CSRC = os.path.join(REPO, 'physics-aware-multiplex-gnn_amd', 'csrc')
 so = '/tmp/libpamnet_aggprobe.so'
 subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-                       '-DPAMNET_PHASE_PROBE', '-I' + os.path.join(REPO, 'include'), '-I' + CSRC, '-ffp-contract=on',
+                       '-DPAMNET_PHASE_PROBE'] + os.environ.get('PAMNET_PROBE_FLAGS', '').split() + [
+                       '-I' + os.path.join(REPO, 'include'), '-I' + CSRC, '-ffp-contract=on',
                        os.path.join(CSRC, 'edge_agg.hip'), '-o', so])
 lib.load()
 plib = ctypes.CDLL(so)
