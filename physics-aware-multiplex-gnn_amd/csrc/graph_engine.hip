@@ -224,7 +224,7 @@ int run(Run& r) {
         check(0, raw, n, eg);
         check(1, l_ptr, n, el);
         if ((rc = clamp(r, raw, n + 1, eg, g_ptr))) return rc;
-        GO(pamnet_radius_fill_i32(pos, r.I(node_graph), gptr, n, ng, d.cutoff_g, 0, r.I(g_ptr), r.I(g_col), r.F(g_dist),
+        GO(pamnet_radius_fill_i32(pos, r.I(node_graph), gptr, n, ng, d.cutoff_g, d.max_neighbors, r.I(g_ptr), r.I(g_col), r.F(g_dist),
                                   r.I(g_row), eg, r.stream));
     } else if (d.schema == PAMNET_SCHEMA_PDBBIND) {
         // global = radius graph at cutoff_g, local = the same at cutoff_l (= global edges with dist <= cutoff_l,
@@ -240,7 +240,7 @@ int run(Run& r) {
         check(1, raw_l, n, el);
         if ((rc = clamp(r, raw_g, n + 1, eg, g_ptr))) return rc;
         if ((rc = clamp(r, raw_l, n + 1, el, l_ptr))) return rc;
-        GO(pamnet_radius_fill_i32(pos, r.I(node_graph), gptr, n, ng, d.cutoff_g, 0, r.I(g_ptr), r.I(g_col), r.F(g_dist),
+        GO(pamnet_radius_fill_i32(pos, r.I(node_graph), gptr, n, ng, d.cutoff_g, d.max_neighbors, r.I(g_ptr), r.I(g_col), r.F(g_dist),
                                   r.I(g_row), eg, r.stream));
         GO(pamnet_csr_filter_fill_i32(r.I(g_ptr), r.I(g_col), r.F(g_dist), n, d.cutoff_l, r.I(l_ptr), r.I(l_col), r.F(l_dist),
                                       el, r.stream));

@@ -155,11 +155,13 @@ ENGINE_WIDTHS = (16, 32, 64, 128)       # widths with hand-written kernel famili
 
 
 def engine_width(dim):
-    """The kernel width a model of hidden size `dim` runs at: the smallest engine width >= dim, or None above 128."""
+    """The kernel width a model of hidden size `dim` runs at: the smallest engine width >= dim; above 128 (the layer-by-layer
+    path on csrc/dense.hip) the next multiple of 4 -- 16-byte vector lanes of the gather / segment kernels -- with the same
+    zero-padding (models.py:25 takes any dim)."""
     for w in ENGINE_WIDTHS:
         if dim <= w:
             return w
-    return None
+    return (int(dim) + 3) // 4 * 4
 
 
 class _PAMNetBase(nn.Module):
@@ -170,7 +172,8 @@ class _PAMNetBase(nn.Module):
     activations, its gradients (dz = dy * SiLU'(0) with dy = W_next[:, pad]^T dz = 0; dW[:, pad] = dz x_pad = 0) and hence
     its Adam / EMA updates are zeros: arithmetic on the logical `config_dim` channels is untouched.  `state_dict()` /
     `load_state_dict()` speak the reference's shapes (hooks below slice / pad); `parameters()` are the padded tensors.
-    Above 128 (multiples of 4) the dense layers run as library GEMMs between the HIP graph / basis / segment kernels."""
+    Above 128 every dense layer is a launch of the any-width GEMM kernels of csrc/dense.hip (bf16x6 on the matrix pipe, no
+    library GEMM) between the HIP graph / basis / gather / segment kernels; such a dim is padded to the next multiple of 4."""
     small = False
     max_num_neighbors = 1000            # radius(..., max_num_neighbors=1000), models.py:110,128
 
@@ -184,8 +187,10 @@ class _PAMNetBase(nn.Module):
         self.cutoff_l = config.cutoff_l
         self.cutoff_g = config.cutoff_g
         self.flow = getattr(config, 'flow', 'source_to_target')
-        if _pad and self.dim % 4 != 0:
-            raise ValueError('dim above 128 must be a multiple of 4 (16-byte vector lanes of the gfx950 kernels)')
+        if self.config_dim < 1:
+            raise ValueError('dim must be positive')
+        # (RNG state at construction: _finish_padding rewinds to it so that a padded model draws what the unpadded one would)
+        self.__dict__['_rng_at_ctor'] = torch.get_rng_state() if (_pad and self.dim != self.config_dim) else None
         self._rna = self.dataset[:3].lower() == 'rna'
         self.__dict__['_pending_checks'] = []            # device flag words of forwards that ran without a host round trip
         self.__dict__['_ctor'] = (config, num_spherical, num_radial, envelope_exponent)
@@ -202,22 +207,40 @@ class _PAMNetBase(nn.Module):
             yield from super().named_parameters(prefix, recurse, remove_duplicate)
             return
         cache = self.__dict__.get('_named_param_cache')
-        if cache is not None:
-            # a parameter replaced or removed inside a sub-module (which cannot tell the root) invalidates the cache: every
-            # cached tensor must still be what its owner holds under that name (~390 dictionary look-ups: 40 us, not a walk)
-            owners = self.__dict__['_named_param_owners']
-            if not all(o._parameters.get(leaf) is p for (o, leaf), (_, p) in zip(owners, cache)):
-                cache = None
+        if cache is not None and not self._param_cache_valid(cache):
+            self._drop_param_cache()                     # (the derived lists go with it)
+            cache = None
         if cache is None:
             cache = list(super().named_parameters('', True, True))
             mods = dict(self.named_modules())
             self.__dict__['_named_param_cache'] = cache
             self.__dict__['_named_param_owners'] = [(mods[n.rpartition('.')[0]], n.rpartition('.')[2]) for n, _ in cache]
+            # the live tree the walk saw: every module's link from its parent and its own entry counts
+            self.__dict__['_named_param_links'] = (
+                [(mods[n.rpartition('.')[0]], n.rpartition('.')[2], m, len(m._parameters), len(m._modules))
+                 for n, m in mods.items() if n != ''], len(self._parameters), len(self._modules))
         yield from cache
+
+    def _param_cache_valid(self, cache):
+        """A sub-module cannot tell the root that something was replaced, added or removed inside it, so the cache is checked
+        against the LIVE tree before it is used (~250 modules + ~390 tensors of dictionary look-ups: ~0.1 ms, not a walk):
+        every module must still hang off its parent under its name (a replaced module -- `layer.W_out = nn.Linear(...)` --
+        still holds its own old tensors, so checking owners alone is not enough: ADVICE r4), hold as many parameters and
+        children as when the walk saw it (register_parameter / add_module inside a child), and every cached tensor must
+        still be what its owner holds under that name."""
+        links, n_par, n_mod = self.__dict__['_named_param_links']
+        if len(self._parameters) != n_par or len(self._modules) != n_mod:
+            return False
+        for parent, leaf, m, np_, nm_ in links:
+            if parent._modules.get(leaf) is not m or len(m._parameters) != np_ or len(m._modules) != nm_:
+                return False
+        owners = self.__dict__['_named_param_owners']
+        return all(o._parameters.get(leaf) is p for (o, leaf), (_, p) in zip(owners, cache))
 
     def _drop_param_cache(self):
         self.__dict__.pop('_named_param_cache', None)
         self.__dict__.pop('_named_param_owners', None)
+        self.__dict__.pop('_named_param_links', None)
         self.__dict__.pop('_all_param_list', None)
         self.__dict__.pop('_top_param_list', None)
 
@@ -246,7 +269,13 @@ class _PAMNetBase(nn.Module):
         values (the same initialisation law on the LOGICAL fan-in / fan-out) in the top-left blocks, zeros elsewhere."""
         if self.dim == self.config_dim:
             return
-        twin = type(self)(*self._ctor, _pad=False)
+        # The twin takes the FIRST draw of the random stream -- exactly what a model of the reference's shapes draws from this
+        # seed (the padded model's own init() above drew values that are overwritten below): seed-for-seed the same initial
+        # weights as at an engine width, and the stream is left where the unpadded construction leaves it (ADVICE r4).
+        if self.__dict__.get('_rng_at_ctor') is not None:
+            torch.set_rng_state(self.__dict__.pop('_rng_at_ctor'))
+        base = PAMNet_s if self.small else PAMNet         # (explicit class: a subclass may have another constructor)
+        twin = base(*self._ctor, _pad=False)
         tsd = twin.state_dict()
         self.__dict__['_logical_shapes'] = {k: tuple(v.shape) for k, v in tsd.items()}
         self._register_load_state_dict_pre_hook(self._pad_incoming)
@@ -493,14 +522,21 @@ class _PAMNetBase(nn.Module):
             return fused.stack_plan(self.global_layer, self.local_layer).direct()      # (the engine's gradient tables)
         return False
 
+    def _derived_lists_valid(self):
+        cache = self.__dict__.get('_named_param_cache')
+        if cache is None or not self._param_cache_valid(cache):
+            self._drop_param_cache()
+            return False
+        return True
+
     def _all_params(self):
-        ap = self.__dict__.get('_all_param_list')
+        ap = self.__dict__.get('_all_param_list') if self._derived_lists_valid() else None
         if ap is None:
             ap = self.__dict__['_all_param_list'] = [p for p in self.parameters() if p.requires_grad]
         return ap
 
     def _top_params(self):
-        tp = self.__dict__.get('_top_param_list')
+        tp = self.__dict__.get('_top_param_list') if self._derived_lists_valid() else None
         if tp is None:                                   # walking the module tree costs ~1 ms: once per model
             tp = [p for n, p in self.named_parameters() if not n.startswith(('global_layer.', 'local_layer.'))]
             self.__dict__['_top_param_list'] = tp

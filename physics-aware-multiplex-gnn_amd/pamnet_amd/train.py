@@ -523,14 +523,36 @@ class Trainer(object):
         if self.native_opt:
             sd.update(exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), step_count=self.step_count)
         else:
-            sd['optimizer'] = self.opt.state_dict()
+            import copy
+            sd['optimizer'] = copy.deepcopy(self.opt.state_dict())    # (a snapshot like the rest: torch hands out its live
+            #                                                             tensors, and a load from them would SHARE the step counter)
         return sd
 
     def load_state_dict(self, sd):
+        """Restore what state_dict() saved.  The optimiser mode (the fused HIP Adam over the flat buffers, or torch's) and the
+        flat layout must be those of the trainer that saved it: anything else raises ValueError instead of a bare KeyError or a
+        silent mis-copy.  A checkpoint without an EMA shadow (a trainer that kept none) restarts the shadow from the loaded
+        weights -- evaluate() / predictions() never run under the constructor's weights."""
         self.drain()
+        saved_native = 'exp_avg' in sd
+        if saved_native != bool(self.native_opt) or (not saved_native and 'optimizer' not in sd):
+            raise ValueError('checkpoint holds %s optimiser state, this trainer runs %s' % (
+                'the fused (native)' if saved_native else "torch's" if 'optimizer' in sd else 'no',
+                'the fused (native) Adam' if self.native_opt else 'torch.optim.Adam'))
+        if self.native_opt:
+            for k in ('exp_avg', 'exp_avg_sq'):
+                if tuple(sd[k].shape) != tuple(self.exp_avg.shape):
+                    raise ValueError('checkpoint %s has %d elements, this model\'s flat layout %d' % (
+                        k, sd[k].numel(), self.exp_avg.numel()))
+        if sd.get('shadow') is not None and self.shadow is not None and tuple(sd['shadow'].shape) != tuple(self.shadow.shape):
+            raise ValueError('checkpoint EMA shadow has %d elements, this model\'s flat layout %d' % (
+                sd['shadow'].numel(), self.shadow.numel()))
         self.model.load_state_dict(sd['model'], strict=True)       # (parameters are views of fp.flat: copied in place)
-        if self.shadow is not None and sd.get('shadow') is not None:
-            self.shadow.copy_(sd['shadow'])
+        if self.shadow is not None:
+            if sd.get('shadow') is not None:
+                self.shadow.copy_(sd['shadow'])
+            else:
+                self.shadow.copy_(self.fp.flat)
         self.lr = sd.get('lr', self.lr)
         if self.native_opt:
             self.exp_avg.copy_(sd['exp_avg']), self.exp_avg_sq.copy_(sd['exp_avg_sq'])

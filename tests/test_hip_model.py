@@ -113,7 +113,7 @@ def test_state_dict_layout_matches_reference(golden):
 
 
 @pytest.mark.parametrize('dataset,dim,small', [('QM9', 96, False), ('QM9', 20, True), ('PDBbind', 48, False), ('rna_x', 10, False),
-                                                ('QM9', 100, False), ('QM9', 4, False)])
+                                                ('QM9', 100, False), ('QM9', 4, False), ('QM9', 130, False), ('QM9', 141, True)])
 def test_any_dim_keeps_the_reference_state_dict_layout(dataset, dim, small):
     """The reference accepts any `dim` (models.py:25).  Widths without a kernel family of their own run zero-padded at the next
     engine width (models._PAMNetBase): `state_dict()` / `load_state_dict()` still speak the reference's keys and shapes,
@@ -122,7 +122,8 @@ def test_any_dim_keeps_the_reference_state_dict_layout(dataset, dim, small):
     from oracle import pamnet_oracle as O
     cfg = models.Config(dataset=dataset, dim=dim, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
     m = (models.PAMNet_s if small else models.PAMNet)(cfg)
-    assert m.config_dim == dim and m.dim == models.engine_width(dim) and m.dim in models.ENGINE_WIDTHS
+    assert m.config_dim == dim and m.dim == models.engine_width(dim)
+    assert m.dim in models.ENGINE_WIDTHS if dim <= 128 else (m.dim % 4 == 0 and 0 < m.dim - dim < 4)
     ref = O.init_state_dict(cfg, seed=1, small=small)
     sd = m.state_dict()
     assert set(sd) == set(ref) and all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in ref)
@@ -140,9 +141,47 @@ def test_any_dim_keeps_the_reference_state_dict_layout(dataset, dim, small):
         bad = dict(ref)
         bad['embeddings'] = torch.zeros(ref['embeddings'].size(0), dim + 1)
         m.load_state_dict(bad, strict=True)
-    assert models.engine_width(128) == 128 and models.engine_width(129) is None
-    with pytest.raises(ValueError):
-        models.PAMNet(models.Config(dataset='QM9', dim=130, n_layer=1, cutoff_l=5.0, cutoff_g=5.0))
+    # above 128: the next multiple of 4 (the layer-by-layer path on csrc/dense.hip), exact multiples run unpadded
+    assert models.engine_width(128) == 128 and models.engine_width(129) == 132 and models.engine_width(192) == 192
+
+
+def test_padded_models_draw_the_unpadded_models_random_stream():
+    """Seed for seed a model whose dim has no kernel width of its own starts from the weights the reference's shapes would get,
+    and leaves the generator where that construction leaves it (the twin takes the first draw)."""
+    import models
+    for dim, small in ((100, False), (130, False), (24, True)):
+        cfg = models.Config(dataset='QM9', dim=dim, n_layer=1, cutoff_l=5.0, cutoff_g=5.0)
+        cls = models.PAMNet_s if small else models.PAMNet
+        torch.manual_seed(3)
+        a, ra = cls(cfg), torch.rand(1)
+        torch.manual_seed(3)
+        b, rb = cls(cfg, _pad=False), torch.rand(1)
+        sa, sb = a.state_dict(), b.state_dict()
+        assert a.dim != dim and b.dim == dim and sa.keys() == sb.keys()
+        assert all(torch.equal(sa[k], sb[k]) for k in sa) and torch.equal(ra, rb)
+
+
+def test_parameter_walk_cache_follows_the_live_module_tree():
+    """`parameters()` / `named_parameters()` are cached walks (the reference loop walks the tree three times per step); a
+    module or parameter replaced or added INSIDE a child must show up (a replaced module still holds its old
+    tensors, so the cache is validated against the live tree, not against its old owners)."""
+    import models
+    m = models.PAMNet(models.Config(dataset='QM9', dim=32, n_layer=2, cutoff_l=5.0, cutoff_g=5.0))
+    first = list(m.parameters())
+    assert [id(p) for p in m.parameters()] == [id(p) for p in first]            # (served from the cache)
+    old = m.global_layer[0].W_out
+    m.global_layer[0].W_out = torch.nn.Linear(32, 1)
+    named = dict(m.named_parameters())
+    assert named['global_layer.0.W_out.weight'] is m.global_layer[0].W_out.weight
+    assert all(p is not old.weight and p is not old.bias for p in m.parameters())
+    assert set(named) == set(k for k, _ in torch.nn.Module.named_parameters(m))
+    m.local_layer[1].register_parameter('extra', torch.nn.Parameter(torch.zeros(3)))
+    assert 'local_layer.1.extra' in dict(m.named_parameters())
+    assert any(p is m.local_layer[1].extra for p in m._all_params())
+    m.local_layer[1].mlp_x1[0][0].weight = torch.nn.Parameter(torch.ones(32, 32))   # a parameter swapped in place
+    assert dict(m.named_parameters())['local_layer.1.mlp_x1.0.0.weight'] is m.local_layer[1].mlp_x1[0][0].weight
+    assert not any(n.startswith(('global_layer.', 'local_layer.')) for n in
+                   [k for k, p in m.named_parameters() if any(p is q for q in m._top_params())])
 
 
 def test_cast_models_are_refused():
@@ -967,7 +1006,8 @@ def test_max_num_neighbors_binding_vs_oracle(dev, case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('dataset,dim,small', [('QM9', 96, False), ('QM9', 100, True), ('PDBbind', 96, False), ('QM9', 48, False),
-                                                ('QM9', 20, True), ('rna_x', 12, False), ('PDBbind', 40, False)])
+                                                ('QM9', 20, True), ('rna_x', 12, False), ('PDBbind', 40, False),
+                                                ('QM9', 130, False), ('QM9', 141, True)])
 def test_any_dim_runs_on_the_engines_vs_oracle(dev, dataset, dim, small):
     """dim = 96 / 100 (-> the fused 128-wide engine), 48 / 40 (-> 64), 20 (-> 32), 12 (-> 16): the oracle's weights at the
     LOGICAL width load through the padding hooks; outputs and every parameter gradient (compared on the logical blocks;
@@ -992,7 +1032,8 @@ def test_any_dim_runs_on_the_engines_vs_oracle(dev, dataset, dim, small):
     model = (models.PAMNet_s if small else models.PAMNet)(cfg)
     model.load_state_dict(sd, strict=True)
     model = model.to(dev)
-    assert model.dim in models.ENGINE_WIDTHS and model.dim != dim
+    # (dim = 130 / 141 -> 132 / 144 on the any-width GEMM kernels of csrc/dense.hip: the same padding above 128)
+    assert model.dim != dim and (model.dim in models.ENGINE_WIDTHS if dim <= 128 else model.dim == (dim + 3) // 4 * 4)
     data = b.to(dev)
     out = model(data)
     torch.nn.functional.l1_loss(out, data.y).backward()
@@ -1027,7 +1068,7 @@ def test_any_dim_runs_on_the_engines_vs_oracle(dev, dataset, dim, small):
     twin = twin.to(dev)
     opt = torch.optim.Adam(twin.parameters(), lr=1e-3)
     tr = train.Trainer(model, lr=1e-3)
-    assert model._one_node()
+    assert model._one_node() or dim > 128
     for _ in range(5):
         tr.step(data)
         opt.zero_grad()

@@ -154,6 +154,47 @@ def test_node_balanced_sharding_on_shipped_rna_sizes(golden):
     assert balanced_shards([5, 5, 5], 4)[3] == []                                # more ranks than graphs
 
 
+def test_trainer_checkpoint_round_trip_and_mismatches():
+    """Trainer.load_state_dict: a round trip is exact; a checkpoint saved WITHOUT an EMA shadow restarts the shadow
+    from the loaded weights (not from the constructor's); the other optimiser mode or another flat layout raise ValueError."""
+    from pamnet_amd.train import Trainer
+    torch.manual_seed(2)
+    b = _batch(0, 10)
+    a = Trainer(Tiny(), lr=1e-2)
+    for _ in range(3):
+        a.step(b)
+    ck = a.state_dict()
+    torch.manual_seed(5)
+    c = Trainer(Tiny(), lr=1e-2)
+    c.load_state_dict(ck)
+    assert torch.equal(c.fp.flat, a.fp.flat) and torch.equal(c.shadow, a.shadow)
+    a.step(b), c.step(b)
+    assert torch.equal(c.fp.flat, a.fp.flat) and torch.equal(c.shadow, a.shadow)       # the resumed run continues bit for bit
+    # a no-EMA trainer's checkpoint into an EMA trainer: the shadow starts from the LOADED weights
+    n = Trainer(Tiny(), lr=1e-2, ema_decay=None)
+    n.step(b)
+    ck2 = n.state_dict()
+    assert ck2['shadow'] is None
+    torch.manual_seed(9)
+    e = Trainer(Tiny(), lr=1e-2)
+    before = e.shadow.clone()
+    e.load_state_dict(ck2)
+    assert torch.equal(e.shadow, e.fp.flat) and not torch.equal(e.shadow, before)
+    # the other optimiser mode / another layout: a message, not a KeyError or a silent mis-copy
+    other = dict(ck)
+    other.pop('optimizer', None), other.pop('exp_avg', None)
+    if a.native_opt:
+        other['optimizer'] = {}
+    else:
+        other.update(exp_avg=torch.zeros(3), exp_avg_sq=torch.zeros(3), step_count=0)
+    with pytest.raises(ValueError):
+        c.load_state_dict(other)
+    bad = dict(ck)
+    bad['shadow'] = torch.zeros(ck['shadow'].numel() + 4)
+    with pytest.raises(ValueError):
+        c.load_state_dict(bad)
+
+
 def test_trainer_step_semantics():
     """clip at max_norm, Adam update, EMA decay = min(0.999, (1+n)/(10+n)) with n=99999 (utils/ema.py:14)."""
     from pamnet_amd.train import Trainer, WarmupExpLR
