@@ -264,6 +264,52 @@ def fixture_rna():
     save('rna_native', **arrs)
 
 
+def fixture_rna_all():
+    """ALL 21 shipped RNA-Puzzles native structures as inference_rna_puzzles.py:46-66 scores them: TUDataset order, DataLoader
+    batch_size=16, shuffle=False -> a batch of 16 graphs and one of 5, the shipped checkpoint, model.eval().  Inputs of every
+    graph (xyz + label), the reference's outputs fp32 and fp64, and the integer sizes of both batches' graphs.  (The checkpoint
+    tensors are in rna_native.npz.)"""
+    raw = os.path.join(REF, 'data', 'RNA-Puzzles', 'rna_native', 'raw', 'rna_native_')
+    gi = np.loadtxt(raw + 'graph_indicator.txt', dtype=np.int64) - 1
+    na = np.loadtxt(raw + 'node_attributes.txt', delimiter=',', dtype=np.float32)
+    nl = np.loadtxt(raw + 'node_labels.txt', dtype=np.float32)
+    gl = np.loadtxt(raw + 'graph_labels.txt', dtype=np.float32)
+    x_all = np.concatenate([na, nl[:, None]], 1)
+    assert (np.diff(gi) >= 0).all()
+    counts = np.bincount(gi)
+    ptr = np.concatenate([[0], np.cumsum(counts)])
+    cfg = ref_models.Config(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0,
+                            flow='target_to_source')
+    sd = torch.load(os.path.join(REF, 'save', 'pamnet_rna.pt'), map_location='cpu')
+    model = build_model(ref_models.PAMNet, cfg)
+    model.load_state_dict(sd)
+    model.eval()
+    model64 = build_model(ref_models.PAMNet, cfg)
+    model64.load_state_dict(sd)
+    model64 = model64.double().eval()
+    arrs = {'x_all': x_all, 'node_ptr': ptr.astype(np.int64), 'graph_labels': gl, 'batch_size': np.int64(16)}
+    out32, out64, sizes = [], [], []
+    n_graphs = len(counts)
+    for b0 in range(0, n_graphs, 16):
+        b1 = min(b0 + 16, n_graphs)
+        x = torch.from_numpy(x_all[ptr[b0]:ptr[b1]])
+        batch = torch.from_numpy(np.repeat(np.arange(b1 - b0), counts[b0:b1]))
+        d = Data()
+        d.x, d.batch = x, batch
+        r32 = run_reference(model, d, capture=False)
+        d64 = Data()
+        d64.x, d64.batch = x.double(), batch
+        r64 = run_reference(model64, d64, capture=False)
+        out32.append(r32['out'].numpy().reshape(-1)), out64.append(r64['out'].numpy().reshape(-1))
+        sizes.append([r32['edge_index_g'].shape[1] if 'edge_index_g' in r32 else -1, r32['edge_index_l'].shape[1],
+                      r32['idx_kj'].numel(), r32['idx_jj_pair'].numel()])
+        print('batch of %d graphs (%d nodes): done' % (b1 - b0, x.size(0)), flush=True)
+    arrs['out32'] = np.concatenate(out32).astype(np.float32)
+    arrs['out64'] = np.concatenate(out64).astype(np.float64)
+    arrs['batch_sizes'] = np.asarray(sizes, np.int64)        # per batch: global edges (-1: not captured), local edges, triplets, pairs
+    save('rna_native_all', **arrs)
+
+
 def fixture_random(name, cls, cfg_kw, batch, seed, capture, small=False, basis=None):
     """Seeded random-init reference model on a synthetic batch; fp32 and fp64 runs.  basis: (num_spherical, num_radial,
     envelope_exponent) other than the default (7, 6, 5)."""
@@ -398,6 +444,8 @@ def main():
         return main_baseline_s()
     if '--wide-only' in sys.argv:
         return main_wide()
+    if '--rna-all-only' in sys.argv:
+        return fixture_rna_all()
     main_forward()
     main_train()
     main_baseline()

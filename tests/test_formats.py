@@ -133,6 +133,61 @@ def test_inference_driver_path_tu_to_model(golden, tmp_path):
 
 
 @pytest.mark.gpu
+def test_all_21_shipped_rna_structures_as_the_inference_driver_scores_them(golden, tmp_path):
+    """inference_rna_puzzles.py:46-66 on the whole shipped set: 21 graphs (841 .. 3 823 nodes), DataLoader batch_size=16 without
+    shuffling -> a batch of 16 and one of 5, the shipped checkpoint.  (a) plain tensors, (b) the resident store (device-side
+    collation, one-call graph), (c) the three smallest through TU text files -> datasets.TUDataset -> DataLoader.  21 / 21 scores
+    within the parity bound of the reference's fp64 run (never tighter than its own fp32 noise), integer graph sizes exact."""
+    import models
+    from datasets import DataLoader, TUDataset
+    from pamnet_amd.store import MoleculeStore
+    from pamnet_amd import synth
+    from conftest import maxnorm_err
+    g, ck = golden('rna_native_all'), golden('rna_native')
+    dev = torch.device('cuda:0')
+    cfg = models.Config(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
+    model = models.PAMNet(cfg)
+    model.load_state_dict({k: torch.from_numpy(ck['ckpt/' + k]) for k in ck['ckpt_keys'].tolist()}, strict=True)
+    model = model.to(dev).eval()
+    ptr, bs = g['node_ptr'], int(g['batch_size'])
+    n_graphs = len(ptr) - 1
+    assert n_graphs == 21 and bs == 16
+    ref32, ref64 = g['out32'], g['out64']
+    bound = max(1e-5, 2 * maxnorm_err(ref32, ref64))
+    xs = [g['x_all'][ptr[k]:ptr[k + 1]] for k in range(n_graphs)]
+    # (a) plain tensors, the loader's two batches
+    scores = []
+    with torch.no_grad():
+        for b, b0 in enumerate(range(0, n_graphs, bs)):
+            b1 = min(b0 + bs, n_graphs)
+            data = synth.Batch()
+            data.x = torch.from_numpy(np.concatenate(xs[b0:b1])).to(dev)
+            data.batch = torch.from_numpy(np.repeat(np.arange(b1 - b0), [len(x) for x in xs[b0:b1]])).to(dev)
+            data.num_graphs = b1 - b0
+            scores += model(data).reshape(-1).tolist()
+            gc = model._graph_cache
+            assert (gc.loc.m, gc.n_trip, gc.n_pair) == tuple(int(v) for v in g['batch_sizes'][b, 1:4]), b
+    assert len(scores) == 21 and maxnorm_err(np.array(scores), ref64) <= bound, (maxnorm_err(np.array(scores), ref64), bound)
+    # (b) the resident store, the same two selections
+    st = MoleculeStore([dict(x=x, y=np.float32(0)) for x in xs], dev).prepare_for(model)
+    with torch.no_grad():
+        s2 = []
+        for b0 in range(0, n_graphs, bs):
+            s2 += model(st.collate(list(range(b0, min(b0 + bs, n_graphs))))).reshape(-1).tolist()
+    model.verify()
+    assert maxnorm_err(np.array(s2), ref64) <= bound
+    # (c) TU text files of the three smallest (coordinates are written with 3 decimals, as the shipped files hold them)
+    small = sorted(range(n_graphs), key=lambda k: len(xs[k]))[:3]
+    _write_tu(str(tmp_path), 'rna_native', [(xs[k][:, :3], xs[k][:, 3], 0.0) for k in small])
+    ds = TUDataset(str(tmp_path), name='rna_native', use_node_attr=True)
+    with torch.no_grad():
+        s3 = []
+        for data in DataLoader(ds, batch_size=16, shuffle=False):
+            s3 += model(data.to(dev)).reshape(-1).tolist()
+    assert maxnorm_err(np.array(s3), ref64[small]) <= bound
+
+
+@pytest.mark.gpu
 def test_driver_loop_example_runs(tmp_path):
     """examples/main_qm9_synth.py (the reference's main_qm9.py loop on synthetic molecules): two short epochs at a small
     configuration train (the loss falls), evaluate under EMA and save a reference-layout state_dict."""

@@ -146,6 +146,28 @@ def test_rna_checkpoint_end_to_end(golden):
     assert maxnorm_err(out, g['batched_4_6_out32']) < 1e-5
 
 
+def test_rna_second_loader_batch_of_the_shipped_set(golden):
+    """inference_rna_puzzles.py:55-66 scores all 21 shipped structures in two DataLoader batches (16 + 5, batch_size=16,
+    shuffle=False).  The oracle on the second batch (5 graphs, 9 908 nodes) against the reference's own fp32 / fp64 outputs and
+    the integer sizes of its graphs (the 16-graph batch runs on the GPU side: tests/test_hip_model.py)."""
+    g, ck = golden('rna_native_all'), golden('rna_native')
+    cfg = O.Config(dataset='rna_native', dim=16, n_layer=1, cutoff_l=2.6, cutoff_g=20.0, flow='target_to_source')
+    sd32 = {k: torch.from_numpy(ck['ckpt/' + k]) for k in ck['ckpt_keys'].tolist()}
+    ptr = g['node_ptr']
+    assert len(ptr) == 22 and int(g['batch_size']) == 16
+    assert np.array_equal(np.diff(ptr), ck['all_num_nodes'])
+    x = torch.from_numpy(g['x_all'][ptr[16]:ptr[21]])
+    batch = torch.from_numpy(np.repeat(np.arange(5), np.diff(ptr)[16:21]))
+    for tag, dt, tol in (('64', torch.float64, 1e-7), ('32', torch.float32, 1e-5)):
+        inter = {}
+        out = O.pamnet_forward({k: v.to(dt) for k, v in sd32.items()}, cfg, x.to(dt), batch, dtype=dt, intermediates=inter)
+        assert maxnorm_err(out, g['out' + tag][16:21]) < tol, tag
+        assert inter['edge_index_l'].shape[1] == int(g['batch_sizes'][1, 1])
+        assert inter['idx_kj'].numel() == int(g['batch_sizes'][1, 2]) and inter['idx_jj_pair'].numel() == int(g['batch_sizes'][1, 3])
+    # batched == alone (the per-graph fp32 scores of rna_native.npz: graphs are independent units)
+    assert maxnorm_err(g['out32'], ck['all_out32']) < 2e-6
+
+
 def test_unknown_dataset_raises():
     cfg = O.Config(dataset='nope', dim=8, n_layer=1, cutoff_l=2.0, cutoff_g=5.0)
     with pytest.raises(ValueError):

@@ -154,6 +154,23 @@ def test_node_balanced_sharding_on_shipped_rna_sizes(golden):
     assert balanced_shards([5, 5, 5], 4)[3] == []                                # more ranks than graphs
 
 
+def test_node_balanced_sharding_of_pdbbind_sized_complexes_over_eight_ranks():
+    """SURVEY.md 8e at N = 8 on the PDBbind-schema synthetic complexes (3-copy layout: 2 x (pocket + ligand) nodes, 320 .. 840
+    per complex): 64 complexes over 8 ranks by number of nodes -- a partition, deterministic, every rank within a few percent
+    of the ideal load and never worse than equal-count contiguous shards."""
+    from pamnet_amd import synth
+    from pamnet_amd.train import balanced_shards, shard_range
+    sizes = [int(synth.pdbbind_complex(1, i)['x'].shape[0]) for i in range(64)]
+    assert min(sizes) >= 300 and max(sizes) > 1.5 * min(sizes)
+    shards = balanced_shards(sizes, 8)
+    assert sorted(i for s_ in shards for i in s_) == list(range(64)) and shards == balanced_shards(sizes, 8)
+    loads = [sum(sizes[i] for i in s_) for s_ in shards]
+    ideal = sum(sizes) / 8.0
+    eq = [sum(sizes[slice(*shard_range(64, r, 8))]) for r in range(8)]
+    assert max(loads) <= 1.03 * ideal and max(loads) <= max(eq), (loads, eq)
+    assert all(len(s_) >= 1 for s_ in shards)
+
+
 def test_trainer_checkpoint_round_trip_and_mismatches():
     """Trainer.load_state_dict: a round trip is exact; a checkpoint saved WITHOUT an EMA shadow restarts the shadow
     from the loaded weights (not from the constructor's); the other optimiser mode or another flat layout raise ValueError."""
@@ -505,7 +522,7 @@ def test_engine_gradients_direct_vs_plain_autograd_across_launch_plans(n_layer, 
             assert float((grads[k] - ref).abs().max()) / den < 2e-5, (k, float((grads[k] - ref).abs().max()) / den)
 
 
-def _pamnet_rank(rank, world, port, out, total, shared_gpu=False):
+def _pamnet_rank(rank, world, port, out, total, shared_gpu=False, steps=3, stride=40):
     """One rank of the 2-rank PAMNet step: its molecule shard of the global batch, on its own device over RCCL -- or, with
     shared_gpu, on the box's one device with gloo carrying the (device-resident) gradient slices between the processes."""
     import sys
@@ -531,8 +548,8 @@ def _pamnet_rank(rank, world, port, out, total, shared_gpu=False):
     assert tr._buckets is not None and tr._stack_ctx is not None          # the bucketed, overlapped all-reduce
     lo, hi = shard_range(total, rank, world)
     losses = []
-    for step in range(3):
-        losses.append(float(tr.step(synth.qm9_batch(7, 40 * step + lo, hi - lo).to(dev), global_graphs=total)))
+    for step in range(steps):
+        losses.append(float(tr.step(synth.qm9_batch(7, stride * step + lo, hi - lo).to(dev), global_graphs=total)))
     torch.cuda.synchronize()
     ref = tr.fp.flat.clone()
     dist.broadcast(ref, 0)
@@ -542,7 +559,7 @@ def _pamnet_rank(rank, world, port, out, total, shared_gpu=False):
     dist.destroy_process_group()
 
 
-def _check_two_rank_result(out, total):
+def _check_two_rank_result(out, total, steps=3, stride=40):
     import models
     from pamnet_amd import synth
     from pamnet_amd.train import Trainer
@@ -551,10 +568,10 @@ def _check_two_rank_result(out, total):
     model = models.PAMNet(models.Config(dataset='QM9', dim=128, n_layer=2, cutoff_l=5.0, cutoff_g=5.0))
     model.load_state_dict(init, strict=True)
     tr = Trainer(model.to(dev), lr=1e-3, world_size=1)
-    for step in range(3):
-        tr.step(synth.qm9_batch(7, 40 * step, total).to(dev))
+    for step in range(steps):
+        tr.step(synth.qm9_batch(7, stride * step, total).to(dev))
     torch.cuda.synchronize()
-    # same arithmetic up to the summation order of the two partial gradients (fp32): parameters after three Adam steps
+    # same arithmetic up to the summation order of the ranks' partial gradients (fp32): parameters after the Adam steps
     d = (got['flat'] - tr.fp.flat.cpu()).abs().max() / tr.fp.flat.abs().max().cpu()
     assert float(d) < 1e-5, float(d)
     assert float((got['shadow'] - tr.shadow.cpu()).abs().max()) < 1e-5
@@ -572,6 +589,39 @@ def test_pamnet_two_ranks_on_one_gpu_step_equals_global_batch_step(tmp_path):
     total, out = 25, str(tmp_path / 'dp2_shared.pt')
     mp.spawn(_pamnet_rank, args=(2, _free_port(), out, total, True), nprocs=2, join=True)
     _check_two_rank_result(out, total)
+
+
+@pytest.mark.gpu
+def test_pamnet_eight_ranks_on_one_gpu_step_equals_the_1024_molecule_step(tmp_path):
+    """BASELINE configs[2]'s split as EIGHT processes (main_qm9.py:60-67 at batch_size 1 024 -> 128 molecules per rank, d = 128;
+    n_layer = 2 for time), all on this box's one device with gloo as the transport: rank 0's parameters broadcast to seven
+    ranks seeded differently, eight shards, gradients pre-scaled by 128 / 1 024, three buckets gated by the engine's per-pair
+    events, the identical fused update everywhere -- equal to the single-process step on the 1 024-molecule batch.  A flow
+    check of the shard arithmetic and the bucket events at N = 8 (only ever tried at N = 2 before), not a scaling number."""
+    total, out = 1024, str(tmp_path / 'dp8_shared.pt')
+    mp.spawn(_pamnet_rank, args=(8, _free_port(), out, total, True, 2, 1200), nprocs=8, join=True)
+    _check_two_rank_result(out, total, steps=2, stride=1200)
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_one_gpu_prints_one_line():
+    """`python bench.py --gpus 8 --share-gpu --steps 3`: the driver's 8-GPU invocation of the real bench with all ranks on one
+    device (self-launch of 8 ranks, one JSON line from rank 0, max-over-ranks timing, global batch = 8 x per-GPU batch)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    cmd = [sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '8', '--share-gpu', '--steps', '3', '--warmup', '1',
+           '--batch-per-gpu', '16', '--n-layer', '2', '--no-rooflines', '--no-cpu-baseline', '--no-other-configs']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=repo, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), r.stdout
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 8 and j['config']['global_batch'] == 128 and j['scaling'] == 'weak' and 'shared_gpu' in j
+    assert j['comm'] and j['comm']['buckets'] >= 2
+    assert abs(j['value'] - 128 * 3 / (j['ms_per_step'] * 3e-3)) < 1e-6 * j['value']
 
 
 @pytest.mark.gpu
