@@ -319,9 +319,9 @@ def pdbbind_kernel_rooflines(model, batch, dev):
                     'us_per_launch': ms * 1e3, 'achieved': by / ms / 1e6, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': by / ms / 1e6 / HBM_PEAK_GBS, 'best_group_gbs': by / ms_min / 1e6,
                     'launches_per_step': model.n_layer if perm is not None else 0})
-    # The fused edge MLP -> segment-sum kernels of the global layer (csrc/edge_agg.hip) on the same graph: since the bf16 split
-    # moved out of the reading waves they are memory-bound here, so they are priced against HBM too.
-    # Algorithmic bytes (profiles/r04_edge_agg_pmc.json measures the traffic at 1.002x / 1.006x of them):
+    # The fused edge MLP -> segment-sum kernels of the global layer (csrc/edge_agg.hip) on the same graph.  The backward forms
+    # wait for HBM (priced against it); the forward issues on the bf16 matrix pipe (priced against dense bf16 / 6).
+    # Algorithmic bytes (profiles/r05_edge_agg_pmc.json measures the traffic against them):
     #   backward: z, ea in; d z, d ea out; d e read-modify-write (accumulate = 1); indices; d_agg in, d P_i out
     #   forward (training): e in; z, ea saved; indices; x1, P_i, P_j in, x2 out
     from pamnet_amd import lib
@@ -346,19 +346,46 @@ def pdbbind_kernel_rooflines(model, batch, dev):
         lib.call('pamnet_global_edge_agg_bwd_f32', lib.ptr(d_agg), m, n, lib.ptr(csr.ptr), lib.ptr(csr.row_of), lib.ptr(cuts),
                  lib.ptr(z), lib.ptr(ea), we, 3 * D, lib.ptr(Wea), D, lib.ptr(dz), lib.ptr(dea), lib.ptr(d_e), 1, lib.ptr(dPi), st)
 
+    import ctypes
+    need, slots = ctypes.c_int64(0), ctypes.c_int64(0)
+    lib.call('pamnet_global_edge_agg_wg_floats', m, ctypes.addressof(need), ctypes.addressof(slots))
+    partial = torch.empty(int(need.value), device=dev)
+
+    def bwd_wg():          # what the step runs at this shape since round 5: the backward WITH the step's own weight gradients
+        lib.call('pamnet_global_edge_agg_bwd_wg_f32', lib.ptr(d_agg), m, n, lib.ptr(csr.ptr), lib.ptr(csr.row_of), lib.ptr(cuts),
+                 lib.ptr(z), lib.ptr(ea), lib.ptr(e), we, 3 * D, lib.ptr(Wea), D, lib.ptr(dz), lib.ptr(d_e), 1, lib.ptr(dPi),
+                 lib.ptr(partial), st)
+
     fwd()
     d_e.zero_()
     by_f = 4.0 * D * m + 8.0 * m + 4.0 * D * n * 4 + 8.0 * D * m
     by_b = 4.0 * D * m * 6 + 4.0 * m + 4.0 * (n + 1) + 4.0 * D * n * 2
-    for name, fn, by, gf in (('global_edge_agg_bwd_kernel<3, PRE, pieces> (edge MLP backward + target-side reduction, one kernel)', bwd, by_b, 4.0 * D * D * m * 2),
-                             ('global_edge_agg_fwd_kernel<7, PRE, SAVE, pieces> (edge MLP -> node segment-sum, training form)', fwd, by_f, 4.0 * D * D * m)):
+    # fused backward + weight gradients: z, ea, e in; d z out; d e read-modify-write; indices; d_agg in, d P_i (zero-fill +
+    # sums) out; the partial tiles out.  FLOPs: the two dX GEMMs + the two dW products (4 d^2 per row each pair).
+    by_w = 4.0 * D * m * 6 + 4.0 * m + 4.0 * (n + 1) + 4.0 * D * n * 3 + 4.0 * need.value
+    bf16x6_peak = BF16_MFMA_PEAK_TFLOPS / 6.0
+    for name, fn, by, gf, bound, per_step in (
+            ('global_edge_agg_bwd_wg_kernel (edge MLP backward + target-side reduction + the step\'s dW_e / dW_ea / db_m, one kernel: '
+             'the form the step runs at this shape)', bwd_wg, by_w, 4.0 * D * D * m * 4, 'hbm', model.n_layer),
+            ('global_edge_agg_bwd_kernel<3, PRE, pieces> (the same backward without the weight gradients: small batches)', bwd, by_b,
+             4.0 * D * D * m * 2, 'hbm', 0),
+            ('global_edge_agg_fwd_kernel<7, PRE, SAVE, pieces> (edge MLP -> node segment-sum, training form)', fwd, by_f,
+             4.0 * D * D * m, 'mfma(bf16x6)', model.n_layer)):
         for _ in range(3):
             fn()
         ms, ms_min = event_time_ms(fn, 20, 5)
-        res.append({'kernel': name, 'bound': 'hbm', 'rows_in': int(m), 'rows_out': int(n), 'bytes_per_launch': by,
-                    'us_per_launch': ms * 1e3, 'achieved': by / ms / 1e6, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': by / ms / 1e6 / HBM_PEAK_GBS, 'best_group_gbs': by / ms_min / 1e6,
-                    'fp32_equivalent_tflops': gf / ms / 1e9, 'launches_per_step': model.n_layer})
+        tf = gf / ms / 1e9
+        ent = {'kernel': name, 'bound': bound, 'rows_in': int(m), 'rows_out': int(n), 'bytes_per_launch': by,
+               'us_per_launch': ms * 1e3, 'gbs': by / ms / 1e6, 'hbm_frac': by / ms / 1e6 / HBM_PEAK_GBS,
+               'best_group_gbs': by / ms_min / 1e6, 'fp32_equivalent_tflops': tf, 'peak_bf16x6': bf16x6_peak,
+               'frac_bf16x6': tf / bf16x6_peak, 'launches_per_step': per_step}
+        # `frac` against the bound named: the forward issues on the bf16 matrix pipe (six piece products per fp32 product:
+        # dense bf16 peak / 6; 0.40 GB in ~380 us is not a memory-bound kernel -- r04 verdict), the backward forms wait for HBM
+        if bound == 'hbm':
+            ent.update(achieved=by / ms / 1e6, peak=HBM_PEAK_GBS, unit='GB/s', frac=by / ms / 1e6 / HBM_PEAK_GBS)
+        else:
+            ent.update(achieved=tf, peak=bf16x6_peak, unit='TFLOP/s (fp32-equivalent)', frac=tf / bf16x6_peak)
+        res.append(ent)
     return res
 
 
@@ -801,7 +828,7 @@ def main():
         if not args.no_rooflines:
             roof = scatter_add_roofline(dev, g, args.dim, args.stream_gb)
             s = roof['streamed']
-            pmc = pmc_record('r04_scatter_add_pmc') or pmc_record('r03_scatter_add_pmc')
+            pmc = pmc_record('r05_scatter_add_pmc') or pmc_record('r04_scatter_add_pmc')
             line['roofline'] = {
                 'bound': 'hbm', 'kernel': 'segment_sum_kernel (pamnet_segment_sum_f32, scatter-add)',
                 'achieved': s['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': s['gbs'] / HBM_PEAK_GBS,
@@ -818,7 +845,32 @@ def main():
             line['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
             line['cpu_baseline']['parity'] = guarded(parity_beside_baseline, dev, args)
             line['speedup_vs_cpu'] = value / line['cpu_baseline']['value']
-        result_out.write(json.dumps(line) + '\n')
+        # The driver keeps the first ~2 000 characters of the line: the figures a reader needs first -- the other BASELINE
+        # configurations' step times, the roofline fraction, the CPU baseline -- as a compact object right behind `config`.
+        summary = {}
+        oc = line.get('other_configs')
+        if isinstance(oc, dict):
+            for tag, key in (('pdbbind_b32_d128_l3', 'pdbbind'), ('rna_b8_d16_l1', 'rna'), ('pamnet_s_qm9_b128_d128_l6', 'pamnet_s')):
+                v = oc.get(tag)
+                if isinstance(v, dict) and 'train_ms_per_step' in v:
+                    summary[key + '_train_ms'] = round(v['train_ms_per_step'], 3)
+                    summary[key + '_store_train_ms'] = round(v['store_train_ms_per_step'], 3)
+                    summary[key + '_forward_ms'] = round(v['forward_ms'], 3)
+        if 'roofline' in line:
+            summary['scatter_add_hbm_frac'] = round(line['roofline']['frac'], 4)
+        if 'cpu_baseline' in line:
+            summary['cpu_molecules_per_s'] = round(line['cpu_baseline']['value'], 1)
+        if isinstance(ref_loop, dict) and 'reference_loop_ms_per_step' in ref_loop:
+            summary['reference_loop_unchanged_ms'] = round(ref_loop['reference_loop_ms_per_step'], 3)
+        head = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config')
+        ordered = {k: line[k] for k in head}
+        ordered['summary'] = summary
+        for k in ('roofline', 'cpu_baseline'):
+            if k in line:
+                ordered[k] = line[k]
+        ordered.update({k: v for k, v in line.items() if k not in ordered})
+        result_out.write(json.dumps(ordered) + '\n')
         result_out.flush()
     if world > 1:
         dist.barrier()

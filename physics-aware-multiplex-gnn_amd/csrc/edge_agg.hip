@@ -101,6 +101,53 @@ __device__ __forceinline__ Chunk plan_chunk(const int32_t* __restrict__ ptr, con
     return ch;
 }
 
+// ---- the same plan on the scalar unit -----------------------------------------------------------------------------------
+// plan_chunk's loads are wave-uniform, but behind the first global store of a kernel the compiler can no longer prove ptr /
+// row_of unwritten and issues them as VECTOR loads -- and vector memory operations retire in order, loads and stores on one
+// counter: each of the plan's two or three dependent loads at the head of a chunk then waited for every store of the previous
+// chunk and for the prefetched rows (tools/edge_wgrad_phase_probe.py measured what that costs in the round-5 kernel).  s_load
+// has a counter of its own.  Addresses must be wave-uniform (they are: they derive from scalar loads only).
+__device__ __forceinline__ void sload2(const int32_t* pa, const int32_t* pb, int& va, int& vb) {
+    asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(va), "=&s"(vb)
+                 : "s"(pa), "s"(pb)
+                 : "memory");
+}
+struct SPlan {
+    int c0, c1, rows;      // nodes [c0, c1] (c1 inclusive), rows [r0, r1)
+    bool open_end;         // node c1 continues in the next chunk
+    int64_t r0, r1;
+};
+// the chunk that starts at node c0 / row r0 (plan_chunk's rules), and whether its last node goes on behind it
+__device__ __forceinline__ SPlan splan(const int32_t* __restrict__ ptr, const int32_t* __restrict__ row_of, int c0, int64_t r0,
+                                       int ne, int64_t re, int cap) {
+    SPlan p;
+    p.c0 = c0, p.r0 = r0, p.c1 = c0 - 1, p.r1 = r0, p.open_end = false;
+    if (c0 < ne) {
+        int64_t r1 = r0 + cap < re ? r0 + cap : re;
+        int last = 0, nxt = 0;
+        if (r0 < re) sload2(row_of + r1 - 1, row_of + (r1 < re ? r1 : re - 1), last, nxt);
+        int c1 = r1 < re ? last : ne - 1;                       // the workgroup's last chunk also takes trailing empty nodes
+        if (c1 - c0 + 1 > NMAX) {                               // a long run of nodes without edges
+            c1 = c0 + NMAX - 1;
+            int e1 = 0, dummy = 0;
+            sload2(ptr + c1 + 1, ptr + c1 + 1, e1, dummy);
+            if (e1 < r1) r1 = e1;
+            if (r1 < re) sload2(row_of + r1, ptr + c1 + 1, nxt, dummy);
+        }
+        p.c1 = c1, p.r1 = r1;
+        p.open_end = r1 < re && nxt == c1;
+    }
+    p.rows = (int)(p.r1 - p.r0);
+    return p;
+}
+// ptr[c0 + t] of a chunk's nodes for thread t, clamped to the array (raw: the subtraction of r0 waits for the load)
+__device__ __forceinline__ int load_node_ptr(const int32_t* __restrict__ ptr, int c0, int64_t n) {
+    int64_t k = (int64_t)c0 + threadIdx.x;
+    k = k < 0 ? 0 : (k < n ? k : n);
+    return ptr[k];
+}
+
 __device__ __forceinline__ void seq_add(float4& s, const float* __restrict__ tile, int q0, int q1, int c4) {
     int q = q0;
     for (; q + 4 <= q1; q += 4) {                                      // loads independent, adds strictly in row order
@@ -205,17 +252,17 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
 #pragma unroll
         for (int i = 0; i < NI; ++i) pre[i] = ldg4z_nt(e, rb + rr + RPP * i, re, DIM, c4);
     }
-    int c0 = nb, par = 0;
-    int64_t r0 = rb;
-    while (c0 < ne) {
-        const Chunk ch = plan_chunk(ptr, row_of, c0, r0, ne, re, CAP);
-        const int64_t r1 = ch.r1;
-        const int c1 = ch.c1;
-        const int rows = (int)(r1 - r0);
+    int par = 0;
+    // the plan one chunk ahead on the scalar unit (splan above)
+    SPlan cur = splan(ptr, row_of, __builtin_amdgcn_readfirstlane(nb), (int64_t)__builtin_amdgcn_readfirstlane((int)rb), ne, re, CAP);
+    while (cur.c0 < ne) {
+        const int c0 = cur.c0, c1 = cur.c1, rows = cur.rows;
+        const int64_t r0 = cur.r0, r1 = cur.r1;
+        const SPlan nxt = splan(ptr, row_of, cur.open_end ? c1 : c1 + 1, r1, ne, re, CAP);
         const int mt = (rows + 15) >> 4;
-        // CSR offsets of the chunk's nodes: requested now, parked in LDS before the reduction
         const int nn = c1 - c0 + 1;
-        const int myp = (int)threadIdx.x <= nn ? ptr[c0 + threadIdx.x] - (int)r0 : 0;
+        // CSR offsets of the chunk's nodes: requested now (raw), parked in LDS behind the staging of the e rows
+        const int mypraw = load_node_ptr(ptr, c0, a.n);
         APROBE(22);
         if (rows > 0) {
             if (PRE) {
@@ -232,7 +279,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
                     if (RPP * i < 16 * mt) stage_e(rr + RPP * i, c4, ldg4z_nt(e, r0 + rr + RPP * i, r1, DIM, c4));
             }
             APROBE(23);
-            if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = myp;
+            if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = mypraw - (int)r0;
             // node indices of this thread's rows (clamped to the chunk: every load below is unconditional)
             int ri[NI], ci[NI];
 #pragma unroll
@@ -325,18 +372,16 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
                 APROBE(6 + 4 * sb);
             }
         } else if ((int)threadIdx.x <= nn) {
-            sptr[threadIdx.x] = myp;
+            sptr[threadIdx.x] = mypraw - (int)r0;
         }
         __syncthreads();
-        const bool open_end = sptr[nn] > rows;                 // the last node continues in the next chunk
         APROBE(28);
         reduce_nodes<16>(c0, nn, rows, S1, sptr, carry[par], carry[par ^ 1], a.init, a.out);
         par ^= 1;
         __syncthreads();
         APROBE(29);
         APROBE_WG(1);
-        c0 = open_end ? c1 : c1 + 1;
-        r0 = r1;
+        cur = nxt;
     }
 }
 
@@ -390,24 +435,27 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
     constexpr int RPP = 16, NI = MTX;
     constexpr int BG = 3;                         // row tiles per MFMA group: three independent accumulator chains
     const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;
-    int c0 = nb, par = 0;
-    int64_t r0 = ptr[nb];
+    int par = 0;
+    // the plan one chunk ahead on the scalar unit (splan above); the CSR offsets of a chunk's nodes are requested a chunk ahead
+    SPlan cur = splan(ptr, row_of, __builtin_amdgcn_readfirstlane(nb), (int64_t)__builtin_amdgcn_readfirstlane(ptr[nb]), ne, re, CAP);
+    int mypraw = load_node_ptr(ptr, cur.c0, a.n);
     float4 pz[PRE ? NI : 1], pe[PRE ? NI : 1];
-    if (PRE && r0 < re) {
+    if (PRE && cur.r0 < re) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            pz[i] = ldg4z(zs, r0 + rr + RPP * i, re, DIM, c4);
-            pe[i] = ldg4z(eas, r0 + rr + RPP * i, re, DIM, c4);
+            pz[i] = ldg4z(zs, cur.r0 + rr + RPP * i, re, DIM, c4);
+            pe[i] = ldg4z(eas, cur.r0 + rr + RPP * i, re, DIM, c4);
         }
     }
-    while (c0 < ne) {
-        const Chunk ch = plan_chunk(ptr, row_of, c0, r0, ne, re, CAP);
-        const int64_t r1 = ch.r1;
-        const int c1 = ch.c1;
-        const int rows = (int)(r1 - r0);
+    while (cur.c0 < ne) {
+        const int c0 = cur.c0, c1 = cur.c1, rows = cur.rows;
+        const int64_t r0 = cur.r0, r1 = cur.r1;
+        const bool open_end = cur.open_end;
+        const SPlan nxt = splan(ptr, row_of, open_end ? c1 : c1 + 1, r1, ne, re, CAP);
         const int mt = (rows + 15) >> 4;
         const int nn = c1 - c0 + 1;
-        if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = ptr[c0 + threadIdx.x] - (int)r0;
+        if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = mypraw - (int)r0;
+        mypraw = load_node_ptr(ptr, nxt.c0, a.n);
         APROBE(1);
         if (rows > 0) {
             // (Restructuring this sweep -- operands a row / a group of rows ahead, stores last -- changed nothing: all
@@ -447,7 +495,6 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
         APROBE(2);
         __syncthreads();
         APROBE(3);
-        const bool open_end = sptr[nn] > rows;
         reduce_nodes<16>(c0, nn, rows, S0, sptr, carry[par], carry[par ^ 1], nullptr, a.dPi);   // reads S0 only
         par ^= 1;
         APROBE(4);
@@ -495,8 +542,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
         APROBE(7);
         __syncthreads();
         APROBE_WG(1);
-        c0 = open_end ? c1 : c1 + 1;
-        r0 = r1;
+        cur = nxt;
     }
 }
 
@@ -720,12 +766,6 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW
     // behind the first store of the loop it falls back to vector loads -- hence by hand.  Addresses are wave-uniform
     // (readfirstlane where a value passed through a vector register).
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-    auto sload2 = [](const int32_t* pa, const int32_t* pb, int& va, int& vb) {
-        asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(va), "=&s"(vb)
-                     : "s"(pa), "s"(pb)
-                     : "memory");
-    };
     struct Plan {
         int c0, c1, rows, r0, r1;
     };

@@ -8,7 +8,8 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libpamnet_hip.so')
+# (PAMNET_HIP_LIB: another build of the same ABI, for same-box A/B timing of kernel changes -- a developer switch)
+LIB_PATH = os.environ.get('PAMNET_HIP_LIB') or os.path.join(HERE, 'libpamnet_hip.so')
 HEADER = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include', 'pamnet_hip.h')
 
 _lib = None

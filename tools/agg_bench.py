@@ -90,9 +90,25 @@ def bwd_fused():
     segment_sum_raw(dP[1], None, dz, None, None, None, gT.perm, gT.ptr, n, D)
 
 
+import ctypes  # noqa: E402
+
+need, slots = ctypes.c_int64(0), ctypes.c_int64(0)
+lib.call('pamnet_global_edge_agg_wg_floats', eg, ctypes.addressof(need), ctypes.addressof(slots))
+partial = torch.empty(int(need.value), device=dev)
+
+
+def bwd_fused_wg():          # round 5: the backward with the step's own weight gradients formed in the kernel
+    lib.call('pamnet_global_edge_agg_bwd_wg_f32', lib.ptr(d_agg), eg, n, lib.ptr(csr.ptr), lib.ptr(csr.row_of), cuts, lib.ptr(z),
+             lib.ptr(ea), lib.ptr(e), sub(Wm, 2 * D), 3 * D, lib.ptr(Wea), D, lib.ptr(dz), lib.ptr(d_e), 1, lib.ptr(dP[0]),
+             lib.ptr(partial), st)
+    segment_sum_raw(dP[1], None, dz, None, None, None, gT.perm, gT.ptr, n, D)
+
+
 unfused(True)
 timeit('global bwd unfused (edge + 2 segsums)', bwd_unfused)
 timeit('global bwd fused (+ transposed segsum)', bwd_fused)
+if eg < (1 << 23):
+    timeit('global bwd fused WITH dW_e / dW_ea / db_m (+ transposed segsum)', bwd_fused_wg)
 
 m_ji, m_nb, q3, s, mt, x2 = rnd(el, D), rnd(el, D), rnd(el, D), rnd(tp, D), torch.empty(el, D, device=dev), torch.empty(n, D, device=dev)
 loc, tpc = g.loc, g.tp

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Host enqueue time of a training step / a forward by phase (wrapper timers, no synchronisation added), through the
-zero-host-sync store path.  Usage on the GPU box:  python tools/host_phases_r3.py [qm9|rna|pdbbind]"""
+zero-host-sync store path.  Usage on the GPU box:  python tools/host_phases.py [qm9|rna|pdbbind]"""
 import os
 import sys
 import time

@@ -1,14 +1,14 @@
 # HBM traffic of the fused edge MLP -> node segment-sum kernel at the PDBbind B=32 shape (E_g ~ 700 k: 360 MB per
 # [E_g, 128] tensor, beyond the 256 MB Infinity Cache -- at the QM9 batch everything is cache resident and the counters
 # read almost nothing).  Separate --pmc passes with --kernel-trace only; FETCH_SIZE x2 / WRITE_SIZE as in pmc_scatter.sh
-# (MI355X_MICROARCH.md, HBM section).  Writes gpurun_out/${PMC_OUT:-r03_edge_agg_pmc.json} (copy into profiles/ and commit).
+# (MI355X_MICROARCH.md, HBM section).  Writes gpurun_out/${PMC_OUT:-r05_edge_agg_pmc.json} (copy into profiles/ and commit).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmca_$c
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmca_$c -- python $R/tools/agg_bench.py pdbbind > /tmp/pmca_$c.log 2>&1
 done
-python - <<'PY' > $R/gpurun_out/${PMC_OUT:-r03_edge_agg_pmc.json}
+python - <<'PY' > $R/gpurun_out/${PMC_OUT:-r05_edge_agg_pmc.json}
 import csv, glob, json, re
 D = 128
 def counter(name, kernel):
@@ -34,10 +34,12 @@ for k in names:
     a = alg + (8.0 * D * eg if save else 0.0)
     if bwd:       # reads d x2 (n), z, ea, writes dz, dea, d_e (+ read for accumulate), dP_i: 6 edge tensors + 2 node planes
         a = 4.0 * D * eg * 6 + 8.0 * eg + 4.0 * D * n * 2
+    if 'bwd_wg' in k:   # round 5: z, ea, e in; dz out; d_e read-modify-write; d_agg in, dP_i zero-filled + written; 2 x 256 partial tiles
+        a = 4.0 * D * eg * 6 + 8.0 * eg + 4.0 * D * n * 3 + 4.0 * (2 * 256 * (D * D + 2 * D) + 2048)
     short = re.search(r'global_edge_agg_\w+<[^>]*>', k).group(0)
     out['kernels'][short] = {'FETCH_SIZE_KB': fetch, 'WRITE_SIZE_KB': write, 'launches': [n1, n2],
                               'traffic_bytes_per_launch': traffic, 'algorithmic_bytes_per_launch': a,
                               'traffic_over_algorithmic': traffic / a}
 print(json.dumps(out, indent=1))
 PY
-cat $R/gpurun_out/${PMC_OUT:-r03_edge_agg_pmc.json}
+cat $R/gpurun_out/${PMC_OUT:-r05_edge_agg_pmc.json}
