@@ -38,9 +38,6 @@ python $R/tools/edge_wgrad_phase_probe.py pdbbind 2>/dev/null | grep -v amdgpu.i
 # issue-slot counters per kernel (two SQ passes each) and the forward chain's phase timestamps (production form)
 KIND=pdbbind bash $R/tools/pmc_issue.sh > /dev/null 2>&1; cp $O/issue_pdbbind.txt $O/r05_issue_slots_pdbbind_pmc.txt
 KIND=qm9 STEPS=30 bash $R/tools/pmc_issue.sh > /dev/null 2>&1; cp $O/issue_qm9.txt $O/r05_issue_slots_qm9_pmc.txt
-(PAMNET_AGG_PIECES=0 python $R/tools/agg_bench.py pdbbind 2>/dev/null; PAMNET_AGG_PIECES=0 python $R/tools/agg_bench.py qm9 2>/dev/null) | grep -v amdgpu.ids > $O/r05_edge_agg_microbench_reader_split.txt
-(python $R/tools/tail_probe_packed.py 2286 4 2>/dev/null | tail -9; python $R/tools/tail_probe_packed.py 16 4 2>/dev/null | tail -9) > $O/r05_tail_probe_packed.txt
-# dense kernels of the wide (dim > 128) path: micro-benchmark against the library call they replace, and the kernel statistics of a
-# dim = 256 training step (no Cijk_ / rocBLAS / hipBLASLt kernel may appear)
-python $R/tools/dense_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/r05_dense_probe_raw.txt
-bash $R/tools/prof_wide.sh > /dev/null 2>&1
+# the GPU suite as the driver runs it
+cd $R && python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/r05_gpu_suite.txt
+ls -la $O | grep r05_
