@@ -39,5 +39,5 @@ python $R/tools/edge_wgrad_phase_probe.py pdbbind 2>/dev/null | grep -v amdgpu.i
 KIND=pdbbind bash $R/tools/pmc_issue.sh > /dev/null 2>&1; cp $O/issue_pdbbind.txt $O/r05_issue_slots_pdbbind_pmc.txt
 KIND=qm9 STEPS=30 bash $R/tools/pmc_issue.sh > /dev/null 2>&1; cp $O/issue_qm9.txt $O/r05_issue_slots_qm9_pmc.txt
 # the GPU suite as the driver runs it
-cd $R && python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/r05_gpu_suite.txt
+cd $R && python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/r05_gpu_suite.txt
 ls -la $O | grep r05_
