@@ -9,8 +9,6 @@
 //   * each lane group walks its CSR segment with a 4-deep unrolled software pipeline (4 independent 16 B loads in
 //     flight per lane, 8 waves/SIMD at this register footprint) and accumulates in registers -> one store per row;
 //   * deterministic: summation order = CSR order, run-to-run bitwise identical.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -77,80 +75,6 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(float4* __restrict__ o
         for (; q < end; ++q) acc4(s0, load_term<HAS_IA, HAS_B, HAS_IB, HAS_PERM>(A, ia, B, ib, perm, q, d4, c));
         acc4(s0, s1); acc4(s2, s3); acc4(s0, s2);
         out[r * d4 + c] = s0;                              // (a non-temporal store here measured slower: 5.68 vs 5.85 TB/s)
-    }
-}
-
-// The streamed scatter-add with the loads decoupled from the segment boundaries ("flat", d = 128, plain rows: no gather, no
-// second operand).  segment_sum_kernel above walks ONE segment per lane group: at ~14 rows per segment its eight-deep load
-// batch drains at every segment end (8 + 4 + singles, each tail a round trip of its own).  Here a lane group owns FLAT_RPG
-// consecutive output rows = one contiguous run of input rows; it keeps FLAT_D rows in flight across the whole run (the next
-// batch is requested before the current one is consumed) and hands a finished sum to memory whenever the running row index
-// reaches the next boundary (the boundaries wait in LDS: no vector load between two batches -- vmcnt retires in order).
-// Summation order = row order inside a segment, one accumulator: deterministic, independent of the launch geometry.
-constexpr int FLAT_D = 8;
-template <int FLAT_RPG>
-__global__ __launch_bounds__(256) void segment_sum_flat_kernel(float4* __restrict__ out, const float4* __restrict__ init,
-                                                               const float4* __restrict__ A,
-                                                               const int32_t* __restrict__ ptr, int64_t rows) {
-    constexpr int LPR = 32, GROUPS = 256 / LPR, RPB = GROUPS * FLAT_RPG;
-    __shared__ int sp[RPB + 1];
-    __shared__ float4 so[RPB][LPR];                                      // finished sums wait here: no store between two load batches
-    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    for (int64_t rb = (int64_t)blockIdx.x * RPB; rb < rows; rb += (int64_t)gridDim.x * RPB) {
-        __syncthreads();
-        if (threadIdx.x <= RPB) {
-            const int64_t r = rb + threadIdx.x;
-            sp[threadIdx.x] = ptr[r < rows ? r : rows];
-        }
-        __syncthreads();
-        const int l0 = grp * FLAT_RPG;                                   // local index of the group's first output row
-        const int nr = rows - (rb + l0) < FLAT_RPG ? (int)(rows - (rb + l0)) : FLAT_RPG;
-        if (nr <= 0) continue;
-        const int64_t beg = sp[l0], end = sp[l0 + nr];
-        int cur = 0;                                                     // output row being accumulated
-        int64_t cur_end = sp[l0 + 1];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto flush_to = [&](int64_t q) {                                 // close every segment that ends at or before row q
-            while (cur < nr && q >= cur_end) {
-                so[l0 + cur][c] = acc;
-                acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                ++cur;
-                cur_end = sp[l0 + (cur < nr ? cur : nr - 1) + 1];
-            }
-        };
-        if (beg < end) {
-            const int64_t last = end - 1;
-            float4 v[FLAT_D], w[FLAT_D];
-            // unconditional, clamped: the same number of requests in every iteration (rows past the run re-read its last row --
-            // a cache hit), so that the wait for a batch is "all but the FLAT_D youngest", never "everything"
-            auto fetch = [&](float4 (&dst)[FLAT_D], int64_t q) {
-#pragma unroll
-                for (int u = 0; u < FLAT_D; ++u) dst[u] = ld_stream(A + (q + u < end ? q + u : last) * LPR + c);
-            };
-            auto consume = [&](const float4 (&src)[FLAT_D], int64_t q) {
-#pragma unroll
-                for (int u = 0; u < FLAT_D; ++u) {
-                    if (q + u < end) {
-                        flush_to(q + u);
-                        acc4(acc, src[u]);
-                    }
-                }
-            };
-            fetch(v, beg);
-            for (int64_t q = beg; q < end; q += 2 * FLAT_D) {
-                fetch(w, q + FLAT_D);
-                consume(v, q);
-                fetch(v, q + 2 * FLAT_D);
-                consume(w, q + FLAT_D);
-            }
-        }
-        flush_to(end);                                                   // the last segment and trailing empty ones
-        // the group's rows leave together
-        for (int k = 0; k < nr; ++k) {
-            float4 t = so[l0 + k][c];
-            if (init) acc4(t, init[(rb + l0 + k) * LPR + c]);
-            out[(rb + l0 + k) * LPR + c] = t;
-        }
     }
 }
 
@@ -416,21 +340,6 @@ extern "C" int pamnet_segment_sum_f32(float* out, const float* init, const float
     if (!out || !ptr) return PAMNET_ENULL;          // A may be null when every segment is empty (m == 0)
     hipStream_t st = as_stream(stream);
     const int64_t d4 = d / 4;
-    // the flat streamed form (segment_sum_flat_kernel): plain rows at d = 128 where the chip has more rows than lanes
-    static const int flat = [] { const char* e = getenv("PAMNET_SEG_FLAT"); return e ? atoi(e) : 0; }();
-    if (flat && d4 == 32 && !ia && !B && !perm && A && rows * 32 > (int64_t)SPLIT_MAX_LANES) {
-        const int rpg = flat == 16 ? 16 : 8;
-        int64_t grid = ceil_div(rows, 8 * rpg);
-        if (grid > 256 * 16) grid = 256 * 16;
-        if (rpg == 16)
-            hipLaunchKernelGGL(segment_sum_flat_kernel<16>, dim3((unsigned)grid), dim3(256), 0, st, (float4*)out,
-                               (const float4*)init, (const float4*)A, ptr, rows);
-        else
-            hipLaunchKernelGGL(segment_sum_flat_kernel<8>, dim3((unsigned)grid), dim3(256), 0, st, (float4*)out,
-                               (const float4*)init, (const float4*)A, ptr, rows);
-        PAMNET_LAUNCH_CHECK();
-        return PAMNET_OK;
-    }
     switch (d4) {
         case 1: return launch_segment_sum<1>(out, init, A, ia, B, ib, perm, ptr, rows, d4, st);
         case 2: return launch_segment_sum<2>(out, init, A, ia, B, ib, perm, ptr, rows, d4, st);
