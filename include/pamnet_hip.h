@@ -34,7 +34,7 @@ typedef void* pamnet_stream_t; /* hipStream_t */
 
 /* Library / ABI version (bumped on any signature change).  pamnet_abi_version() returns the PAMNET_ABI_VERSION the library
  * was built against; a binding compares it with this header's (pamnet_amd/lib.py load(): a stale .so fails loudly). */
-#define PAMNET_ABI_VERSION 9
+#define PAMNET_ABI_VERSION 10
 int pamnet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -278,6 +278,7 @@ enum {
     PAMNET_GF_T_PTR, PAMNET_GF_T_ROW, PAMNET_GF_T_COL, PAMNET_GF_T_ANGLE, PAMNET_GF_T_KIND,   /* triplet + pair rows */
     PAMNET_GF_TT_PTR, PAMNET_GF_TT_PERM,
     PAMNET_GF_CUTS,           /* int32 [<= 257] node-aligned work split of the fused global-edge kernels */
+    PAMNET_GF_TT_EDGE, PAMNET_GF_TT_NODE,   /* int32 [tp] each: pamnet_triplet_transpose_aux_i32 (need_grad) */
     PAMNET_GRAPH_FIELDS
 };
 /* Molecule-local graph construction for the QM9 schema (positions + bond list given; models.py:62-98, 104-118, 165-177) --
@@ -554,8 +555,14 @@ int pamnet_local_agg_fwd_f32(const float* m_ji, const float* m_nb, const float* 
  * (tT_ptr / tT_perm: transposed CSR of t_col over the local edges). */
 int pamnet_local_agg_bwd_f32(const float* d_x2, const int32_t* l_row, const float* q3, const float* m_t,
                              const float* m_nb, const float* s, const int32_t* t_ptr, const int32_t* t_col,
-                             const int32_t* t_row, const int32_t* tT_ptr, const int32_t* tT_perm, int64_t n_edges,
+                             const int32_t* t_row, const int32_t* tT_ptr, const int32_t* tT_perm,
+                             const int32_t* tT_edge /* nullable */, const int32_t* tT_node /* nullable */, int64_t n_edges,
                              float* d_mt, float* d_q3, float* d_s, float* d_mnb, pamnet_stream_t stream);
+/* tT_edge[q] = t_row[tT_perm[q]], tT_node[q] = l_row[tT_edge[q]] for the n_rows entries of the transposed triplet / pair list:
+ * made once per graph, they turn the gather half of pamnet_local_agg_bwd_f32 from three dependent index reads per term into
+ * one level of independent ones (both or neither may be given). */
+int pamnet_triplet_transpose_aux_i32(const int32_t* tT_perm, const int32_t* t_row, const int32_t* l_row, int64_t n_rows,
+                                     int32_t* out_edge, int32_t* out_node, pamnet_stream_t stream);
 int pamnet_mlp2_fwd_f32(const float* x, int64_t rows, const float* W1, const float* b1, const float* W2,
                         const float* b2, float* z1, float* z2, float* y, pamnet_stream_t stream);
 /* nsets <= 8 such MLPs on the same input rows in one launch: params[4k..4k+3] = {W1, b1, W2, b2} of set k,
@@ -638,10 +645,11 @@ int pamnet_embed_multi_bwd_f32(const pamnet_embed_job* jobs, int32_t n_jobs, con
  * Layer-stack engine: the n_layer x (global, local) loop of PAMNet.forward (models.py:196-204) in ONE call per
  * direction (dim = 128).  Host-side C++ enqueues ~10 (fwd) / ~20 (bwd) fused launches per layer pair on `stream`.
  *   sizes      : {n, e_g, e_l, tp}
- *   graph_idx  : 16 device index arrays {g_ptr, g_row, g_col, gT_ptr, gT_perm, l_ptr, l_row, l_col, lT_ptr, lT_perm,
- *                tp_ptr, tp_row, tp_col, tpT_ptr, tpT_perm, cuts}  (the *T_* entries are only read by the backward;
- *                cuts: nullable -- the work split of pamnet_seg_cuts_i32 made with the graph, else computed per call;
- *                the narrow-width engine reads the first 15)
+ *   graph_idx  : 18 device index arrays {g_ptr, g_row, g_col, gT_ptr, gT_perm, l_ptr, l_row, l_col, lT_ptr, lT_perm,
+ *                tp_ptr, tp_row, tp_col, tpT_ptr, tpT_perm, cuts, tpT_edge, tpT_node}  (the *T_* entries are only read by
+ *                the backward; cuts: nullable -- the work split of pamnet_seg_cuts_i32 made with the graph, else computed per
+ *                call; tpT_edge / tpT_node: nullable pair -- pamnet_triplet_transpose_aux_i32; the narrow-width engine reads
+ *                the first 15)
  *   gparams    : n_layer x 28 device pointers  {mlp_x1.W, .b, mlp_m.W [128,384], .b, W_edge_attr.W, tail W[10], b[10],
  *                W_out.weight, W_out.bias, W}
  *   lparams    : n_layer x 35 device pointers  {mlp_x1.W, .b, mlp_m_ji.W, .b, mlp_m_kj.W, .b, mlp_sbf.0.W, .b,

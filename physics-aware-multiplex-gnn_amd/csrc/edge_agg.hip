@@ -1061,7 +1061,9 @@ __global__ __launch_bounds__(256) void local_agg_bwd_kernel(const float4* __rest
                                                             const int32_t* __restrict__ t_col,
                                                             const int32_t* __restrict__ t_row,
                                                             const int32_t* __restrict__ tT_ptr,
-                                                            const int32_t* __restrict__ tT_perm, int64_t el,
+                                                            const int32_t* __restrict__ tT_perm,
+                                                            const int32_t* __restrict__ tT_edge,
+                                                            const int32_t* __restrict__ tT_node, int64_t el,
                                                             float4* __restrict__ d_mt, float4* __restrict__ d_q3,
                                                             float4* __restrict__ d_s, float4* __restrict__ d_mnb) {
     const int c = threadIdx.x & 31;
@@ -1087,19 +1089,41 @@ __global__ __launch_bounds__(256) void local_agg_bwd_kernel(const float4* __rest
         const int q0 = tT_ptr[e], q1 = tT_ptr[e + 1];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         int q = q0;
-        for (; q + 2 <= q1; q += 2) {
-            const int64_t ta = tT_perm[q], tb = tT_perm[q + 1];
-            const int64_t ra = t_row[ta], rb = t_row[tb];
-            const float4 sa = s[ta * 32 + c], sb = s[tb * 32 + c];
-            const float4 ga = pamnet::f4mul(d_x2[(int64_t)l_row[ra] * 32 + c], q3[ra * 32 + c]);
-            const float4 gb = pamnet::f4mul(d_x2[(int64_t)l_row[rb] * 32 + c], q3[rb * 32 + c]);
-            v = pamnet::f4add(v, pamnet::f4mul(sa, ga));
-            v = pamnet::f4add(v, pamnet::f4mul(sb, gb));
-        }
-        if (q < q1) {
-            const int64_t ta = tT_perm[q];
-            const int64_t ra = t_row[ta];
-            v = pamnet::f4add(v, pamnet::f4mul(s[ta * 32 + c], pamnet::f4mul(d_x2[(int64_t)l_row[ra] * 32 + c], q3[ra * 32 + c])));
+        if (tT_edge) {
+            // tT_edge[q] = t_row[tT_perm[q]] (the target edge of the row that gathers e), tT_node[q] = l_row[tT_edge[q]] (its
+            // node), made with the graph (pamnet_triplet_transpose_aux_i32): the three index reads of a term are independent --
+            // one level of indirection ahead of the data instead of three (perm -> t_row -> l_row -> d x2); four terms in
+            // flight.  Same terms in the same order.
+            for (; q + 4 <= q1; q += 4) {
+                float4 sv[4], gv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t ta = tT_perm[q + u], ra = tT_edge[q + u], nd = tT_node[q + u];
+                    sv[u] = s[ta * 32 + c];
+                    gv[u] = pamnet::f4mul(d_x2[nd * 32 + c], q3[ra * 32 + c]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v = pamnet::f4add(v, pamnet::f4mul(sv[u], gv[u]));
+            }
+            for (; q < q1; ++q) {
+                const int64_t ta = tT_perm[q], ra = tT_edge[q], nd = tT_node[q];
+                v = pamnet::f4add(v, pamnet::f4mul(s[ta * 32 + c], pamnet::f4mul(d_x2[nd * 32 + c], q3[ra * 32 + c])));
+            }
+        } else {
+            for (; q + 2 <= q1; q += 2) {
+                const int64_t ta = tT_perm[q], tb = tT_perm[q + 1];
+                const int64_t ra = t_row[ta], rb = t_row[tb];
+                const float4 sa = s[ta * 32 + c], sb = s[tb * 32 + c];
+                const float4 ga = pamnet::f4mul(d_x2[(int64_t)l_row[ra] * 32 + c], q3[ra * 32 + c]);
+                const float4 gb = pamnet::f4mul(d_x2[(int64_t)l_row[rb] * 32 + c], q3[rb * 32 + c]);
+                v = pamnet::f4add(v, pamnet::f4mul(sa, ga));
+                v = pamnet::f4add(v, pamnet::f4mul(sb, gb));
+            }
+            if (q < q1) {
+                const int64_t ta = tT_perm[q];
+                const int64_t ra = t_row[ta];
+                v = pamnet::f4add(v, pamnet::f4mul(s[ta * 32 + c], pamnet::f4mul(d_x2[(int64_t)l_row[ra] * 32 + c], q3[ra * 32 + c])));
+            }
         }
         d_mnb[e * 32 + c] = v;
     }
@@ -1262,20 +1286,45 @@ extern "C" int pamnet_local_agg_fwd_f32(const float* m_ji, const float* m_nb, co
     return PAMNET_OK;
 }
 
+// out_edge[q] = t_row[tT_perm[q]], out_node[q] = l_row[out_edge[q]] for the n_rows entries of the transposed triplet / pair list:
+// the two dependent index reads of pamnet_local_agg_bwd_f32's gather half, done once per graph.
+__global__ __launch_bounds__(256) void tt_aux_kernel(const int32_t* __restrict__ tT_perm, const int32_t* __restrict__ t_row,
+                                                     const int32_t* __restrict__ l_row, int64_t n, int32_t* __restrict__ oe,
+                                                     int32_t* __restrict__ on) {
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (int64_t)gridDim.x * 256) {
+        const int e = t_row[tT_perm[q]];
+        oe[q] = e;
+        on[q] = l_row[e];
+    }
+}
+extern "C" int pamnet_triplet_transpose_aux_i32(const int32_t* tT_perm, const int32_t* t_row, const int32_t* l_row,
+                                                int64_t n_rows, int32_t* out_edge, int32_t* out_node, pamnet_stream_t stream) {
+    if (n_rows < 0) return PAMNET_EINVAL;
+    if (n_rows == 0) return PAMNET_OK;
+    if (!tT_perm || !t_row || !l_row || !out_edge || !out_node) return PAMNET_ENULL;
+    int64_t grid = ceil_div(n_rows, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(tt_aux_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), tT_perm, t_row, l_row, n_rows,
+                       out_edge, out_node);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
 // Backward of pamnet_local_agg_fwd_f32 (one launch): d_mt[e] = d_x2[l_row[e]] * q3[e], d_q3[e] = d_x2[l_row[e]] * m_t[e],
 // d_s[r] = m_nb[t_col[r]] * d_mt[t_row[r]], d_mnb[e'] = sum_{r: t_col[r] = e'} s[r] * d_mt[t_row[r]]  (tT_*: transposed
 // CSR of t_col over the edges).
 extern "C" int pamnet_local_agg_bwd_f32(const float* d_x2, const int32_t* l_row, const float* q3, const float* m_t,
                                         const float* m_nb, const float* s, const int32_t* t_ptr, const int32_t* t_col,
                                         const int32_t* t_row, const int32_t* tT_ptr, const int32_t* tT_perm,
-                                        int64_t n_edges, float* d_mt, float* d_q3, float* d_s, float* d_mnb,
-                                        pamnet_stream_t stream) {
+                                        const int32_t* tT_edge, const int32_t* tT_node, int64_t n_edges, float* d_mt,
+                                        float* d_q3, float* d_s, float* d_mnb, pamnet_stream_t stream) {
     if (n_edges < 0) return PAMNET_EINVAL;
     if (n_edges == 0) return PAMNET_OK;
     if (!d_x2 || !l_row || !q3 || !m_t || !m_nb || !t_ptr || !tT_ptr || !d_mt || !d_q3 || !d_mnb) return PAMNET_ENULL;
+    if ((tT_edge == nullptr) != (tT_node == nullptr)) return PAMNET_EINVAL;           // both auxiliary lists or none
     hipLaunchKernelGGL(local_agg_bwd_kernel, dim3((unsigned)ceil_div(n_edges, 8), 2), dim3(256), 0, as_stream(stream),
                        (const float4*)d_x2, l_row, (const float4*)q3, (const float4*)m_t, (const float4*)m_nb,
-                       (const float4*)s, t_ptr, t_col, t_row, tT_ptr, tT_perm, n_edges, (float4*)d_mt, (float4*)d_q3,
+                       (const float4*)s, t_ptr, t_col, t_row, tT_ptr, tT_perm, tT_edge, tT_node, n_edges, (float4*)d_mt, (float4*)d_q3,
                        (float4*)d_s, (float4*)d_mnb);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;

@@ -31,6 +31,7 @@ struct Graph {
     const int32_t *l_ptr, *l_row, *l_col, *lT_ptr, *lT_perm;
     const int32_t *t_ptr, *t_row, *t_col, *tT_ptr, *tT_perm;
     const int32_t* cuts;      // nullable: the fused global-edge kernels' work split, made with the graph (pamnet_seg_cuts_i32)
+    const int32_t *tT_edge, *tT_node;   // nullable pair: pamnet_triplet_transpose_aux_i32 (the local aggregation's backward gather)
 };
 
 inline int64_t al(int64_t x) { return (x + 63) / 64 * 64; }       // 256-byte aligned slabs
@@ -319,12 +320,15 @@ extern "C" int pamnet_stack_layout(int64_t n, int64_t eg, int64_t el, int64_t tp
     return PAMNET_OK;
 }
 
-// graph_desc: 4 x int64 sizes {n, eg, el, tp}; graph_idx: 16 device pointers in the order of struct Graph (the last nullable).
+// graph_desc: 4 x int64 sizes {n, eg, el, tp}; graph_idx: 18 device pointers in the order of struct Graph (the last three nullable).
 static int fill_graph(Graph& g, const int64_t* sizes, const int32_t* const* idx) {
     if (!sizes || !idx) return PAMNET_ENULL;
     g.n = sizes[0]; g.eg = sizes[1]; g.el = sizes[2]; g.tp = sizes[3];
     const int32_t** f = &g.g_ptr;
-    for (int k = 0; k < 16; ++k) f[k] = idx[k];
+    for (int k = 0; k < 18; ++k) f[k] = idx[k];
+    // PAMNET_TT_AUX=0: ignore the precomputed gather indices of the local aggregation's backward (A/B timing; read once)
+    static const bool tt_aux = [] { const char* e = getenv("PAMNET_TT_AUX"); return !e || atoi(e) != 0; }();
+    if (!tt_aux || !g.tT_edge || !g.tT_node) g.tT_edge = g.tT_node = nullptr;
     return PAMNET_OK;
 }
 
@@ -633,7 +637,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             }
             // d m_t = d x2[i] * q3,  d q3 = d x2[i] * m_t,  d s = m_nb[idx] * d m_t[e],  d m_nb = transposed sum: one launch
             CK(pamnet_local_agg_bwd_f32(t.dx2, g.l_row, q.q3, q.mt, q.mnb, q.s, g.t_ptr, g.t_col, g.t_row, g.tT_ptr,
-                                        g.tT_perm, g.el, t.dmt, t.dq3, t.ds, t.dmnb, st));
+                                        g.tT_perm, g.tT_edge, g.tT_node, g.el, t.dmt, t.dq3, t.ds, t.dmnb, st));
             // the triplet / pair MLP's backward and the local edge stage's: independent of each other, one launch
             const float* wq[4] = {lp[2] + 2 * D, lp[4] + 2 * D, lp[10], lp[11]};
             const int64_t ldq[4] = {3 * D, 3 * D, D, D};

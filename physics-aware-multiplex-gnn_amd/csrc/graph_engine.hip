@@ -331,6 +331,13 @@ int run(Run& r) {
                                              r.I(t_cnt), r.I(tT_ptr), r.I(tT_perm), tp, r.stream));
     }
 
+    // the local aggregation's backward gathers through tT_perm -> t_row -> l_row: both hops once per graph
+    int64_t tT_edge = -1, tT_node = -1;
+    if (grad && tT_perm >= 0 && tp > 0) {
+        tT_edge = r.take(tp), tT_node = r.take(tp);
+        GO(pamnet_triplet_transpose_aux_i32(r.I(tT_perm), r.I(t_row), r.I(l_row), tp, r.I(tT_edge), r.I(tT_node), r.stream));
+    }
+
     // ---- spherical basis on the combined rows (layers/basic.py:107-116)
     const int64_t rad = r.take(el * RAD_W);
     if (r.sbf) {
@@ -349,6 +356,7 @@ int run(Run& r) {
     r.field(PAMNET_GF_T_ANGLE, t_angle), r.field(PAMNET_GF_T_KIND, t_kind);
     r.field(PAMNET_GF_TT_PTR, tT_ptr), r.field(PAMNET_GF_TT_PERM, tT_perm);
     r.field(PAMNET_GF_CUTS, cuts);
+    r.field(PAMNET_GF_TT_EDGE, tT_edge), r.field(PAMNET_GF_TT_NODE, tT_node);
     return PAMNET_OK;
 }
 

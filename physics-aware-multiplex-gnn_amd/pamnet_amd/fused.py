@@ -505,7 +505,7 @@ class _LocalLayer(torch.autograd.Function):
         # d m_t = d x2[i] * q3;  d q3 = d x2[i] * m_t;  d s[r] = m_nb[idx] * d m_t[edge];  d m_nb = transposed sum
         lib.call('pamnet_local_agg_bwd_f32', lib.ptr(d_x2), lib.ptr(loc.row_of), lib.ptr(q3), lib.ptr(m_t), lib.ptr(m_nb),
                  lib.ptr(s), lib.ptr(tpc.ptr), lib.ptr(tpc.col), lib.ptr(tpc.row_of), lib.ptr(tp_T.ptr),
-                 lib.ptr(tp_T.perm), m, lib.ptr(d_mt), lib.ptr(d_q3), lib.ptr(d_s), lib.ptr(d_mnb), st)
+                 lib.ptr(tp_T.perm), None, None, m, lib.ptr(d_mt), lib.ptr(d_q3), lib.ptr(d_s), lib.ptr(d_mnb), st)
         dz1, dz2, d_sbf = _empty(t, D, like=x), _empty(t, D, like=x), _empty(t, D, like=x)
         lib.call('pamnet_mlp2_bwd_f32', lib.ptr(d_s), t, lib.ptr(z1), lib.ptr(z2), lib.ptr(Ws1), lib.ptr(Ws2),
                  lib.ptr(dz1), lib.ptr(dz2), lib.ptr(d_sbf), 0, st)
@@ -591,7 +591,7 @@ def _graph_tables(graph):
     idx = _parr([graph.glob.ptr, graph.glob.row_of, graph.glob.col, graph.glob_T.ptr, graph.glob_T.perm,
                  graph.loc.ptr, graph.loc.row_of, graph.loc.col, graph.loc_T.ptr, graph.loc_T.perm,
                  graph.tp.ptr, graph.tp.row_of, graph.tp.col, graph.tp_T.ptr, graph.tp_T.perm,
-                 getattr(graph, 'seg_cuts', None)])
+                 getattr(graph, 'seg_cuts', None), getattr(graph, 'tT_edge', None), getattr(graph, 'tT_node', None)])
     return sizes, idx
 
 

@@ -602,8 +602,8 @@ def _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_ind
     g.__dict__['_lazy'] = lazy
     # pointer tables of the layer-stack engines (fused._graph_tables): raw addresses, no tensors
     order = ('G_PTR', 'G_ROW', 'G_COL', 'GT_PTR', 'GT_PERM', 'L_PTR', 'L_ROW', 'L_COL', 'LT_PTR', 'LT_PERM',
-             'T_PTR', 'T_ROW', 'T_COL', 'TT_PTR', 'TT_PERM', 'CUTS')
-    idx = (ctypes.c_void_p * 16)()
+             'T_PTR', 'T_ROW', 'T_COL', 'TT_PTR', 'TT_PERM', 'CUTS', 'TT_EDGE', 'TT_NODE')
+    idx = (ctypes.c_void_p * 18)()
     for k, name in enumerate(order):
         idx[k] = g._addr(F[name])
     g._tables = ((ctypes.c_int64 * 4)(n, eg, el, tp), idx)
@@ -929,6 +929,13 @@ def _with_seg_cuts(g, dataset):
         g.seg_cuts = _i32(260, g.glob.ptr.device)
         lib.call('pamnet_seg_cuts_i32', lib.ptr(g.glob.ptr), lib.ptr(g.glob.row_of), g.n, g.glob.m, lib.ptr(g.seg_cuts), None,
                  lib.stream_of(g.glob.ptr))
+        # the local aggregation's backward gathers through tT_perm -> t_row -> l_row (pamnet_local_agg_bwd_f32): both hops once
+        # per graph, with the graph
+        if g.tp_T is not _NoTranspose and g.tp.m > 0 and g.loc.m > 0:
+            dev = g.glob.ptr.device
+            g.tT_edge, g.tT_node = _i32(g.tp.m, dev), _i32(g.tp.m, dev)
+            lib.call('pamnet_triplet_transpose_aux_i32', lib.ptr(g.tp_T.perm), lib.ptr(g.tp.row_of), lib.ptr(g.loc.row_of), g.tp.m,
+                     lib.ptr(g.tT_edge), lib.ptr(g.tT_node), lib.stream_of(g.glob.ptr))
     return g
 
 

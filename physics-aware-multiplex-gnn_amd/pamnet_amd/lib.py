@@ -155,5 +155,5 @@ class MolGraphOut(ctypes.Structure):
 GF = {name: i for i, name in enumerate(
     ['NODE_GRAPH', 'GPTR', 'FLAG', 'LOOPS', 'TYPES', 'POS', 'SIGN', 'G_PTR', 'G_ROW', 'G_COL', 'G_DIST', 'GT_PTR', 'GT_PERM',
      'L_PTR', 'L_ROW', 'L_COL', 'L_DIST', 'LT_PTR', 'LT_PERM', 'T_PTR', 'T_ROW', 'T_COL', 'T_ANGLE', 'T_KIND', 'TT_PTR',
-     'TT_PERM', 'CUTS'])}
+     'TT_PERM', 'CUTS', 'TT_EDGE', 'TT_NODE'])}
 GRAPH_FIELDS = len(GF)

@@ -325,8 +325,21 @@ def test_local_agg_bwd(dev, case):
     d_mt, d_q3, d_mnb = (torch.full((m, D), float('nan'), device=dev) for _ in range(3))
     d_s = torch.full((t, D), float('nan'), device=dev)
     lib.call('pamnet_local_agg_bwd_f32', lib.ptr(d_x2), lib.ptr(l_row), lib.ptr(q3), lib.ptr(m_t), lib.ptr(m_nb),
-             lib.ptr(s), lib.ptr(t_ptr), lib.ptr(t_col), lib.ptr(t_row), lib.ptr(tT.ptr), lib.ptr(tT.perm), m,
+             lib.ptr(s), lib.ptr(t_ptr), lib.ptr(t_col), lib.ptr(t_row), lib.ptr(tT.ptr), lib.ptr(tT.perm), None, None, m,
              lib.ptr(d_mt), lib.ptr(d_q3), lib.ptr(d_s), lib.ptr(d_mnb), lib.stream_of(d_x2))
     for got, ref in ((d_mt, v[0].grad), (d_mnb, v[1].grad), (d_q3, v[2].grad), (d_s, v[3].grad)):
         assert torch.isfinite(got).all()
         assert maxnorm_err(got.cpu(), ref.cpu()) < 2e-6
+    # with the gather's two index hops made ahead of time (pamnet_triplet_transpose_aux_i32: what graph construction hands the
+    # engine): the same terms in the same order -- bitwise the same gradients
+    if t:
+        te, tn = (torch.full((t,), -1, dtype=torch.int32, device=dev) for _ in range(2))
+        lib.call('pamnet_triplet_transpose_aux_i32', lib.ptr(tT.perm), lib.ptr(t_row), lib.ptr(l_row), t, lib.ptr(te), lib.ptr(tn),
+                 lib.stream_of(d_x2))
+        assert torch.equal(te.long(), t_row.long()[tT.perm.long()]) and torch.equal(tn.long(), l_row.long()[te.long()])
+        outs2 = [torch.full_like(x, float('nan')) for x in (d_mt, d_q3, d_s, d_mnb)]
+        lib.call('pamnet_local_agg_bwd_f32', lib.ptr(d_x2), lib.ptr(l_row), lib.ptr(q3), lib.ptr(m_t), lib.ptr(m_nb),
+                 lib.ptr(s), lib.ptr(t_ptr), lib.ptr(t_col), lib.ptr(t_row), lib.ptr(tT.ptr), lib.ptr(tT.perm), lib.ptr(te),
+                 lib.ptr(tn), m, lib.ptr(outs2[0]), lib.ptr(outs2[1]), lib.ptr(outs2[2]), lib.ptr(outs2[3]), lib.stream_of(d_x2))
+        for a_, b_ in zip(outs2, (d_mt, d_q3, d_s, d_mnb)):
+            assert torch.equal(a_, b_)
