@@ -794,11 +794,6 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW
         p.rows = p.r1 - p.r0;
         return p;
     };
-    auto load_myp = [&](const Plan& p) {                       // ptr[c0 + t], clamped (ptr has n + 1 entries)
-        int64_t k = (int64_t)p.c0 + threadIdx.x;               // (c0 = -1 behind the workgroup's last chunk)
-        k = k < 0 ? 0 : (k < a.n ? k : a.n);
-        return ptr[k];
-    };
     // d P_i of the workgroup's nodes: zeros first (nodes without edges keep them); acknowledged before the loop stores sums
     for (int64_t k = (int64_t)nb * (DIM / 4) + threadIdx.x; k < (int64_t)ne * (DIM / 4); k += WG8)
         reinterpret_cast<float4*>(a.dPi)[k] = f4zero();
@@ -806,7 +801,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW
     int ahead = -1, first = 0;
     if (rbeg < ire) sload2(row_of + rbeg, row_of + rbeg, first, ahead);
     Plan cur = plan_at(first, rbeg, ahead);
-    int myp = load_myp(cur);                                   // ptr[c0 + t] of the current chunk's nodes (raw)
+    int myp = load_node_ptr(ptr, cur.c0, a.n);                 // ptr[c0 + t] of the current chunk's nodes (raw)
     APROBE_WG(0);
     APROBE(0);
     if (rbeg < ire) {
@@ -825,7 +820,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_wg_kernel(GAggBwdW
         const Plan nxt = plan_at(ahead, r1, ahead);
         const int mt = FULL ? 2 : (rows + 15) >> 4;
         if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = myp - r0;
-        myp = load_myp(nxt);                                   // (raw value: subtracting here would wait for the load here)
+        myp = load_node_ptr(ptr, nxt.c0, a.n);                 // (raw value: subtracting here would wait for the load here)
         APROBE(2);
         // every row of the 32-row k-step is written: rows past the chunk's end as zeros in all three images
         float4 sx[NI], sy[NI];

@@ -576,26 +576,25 @@ int launch_multi(const pamnet_embed_job* jobs, int32_t n_jobs, const pamnet_type
     const int rc = make_types(types, bwd, &J.types);
     if (rc != PAMNET_OK) return rc;
     if (bwd && J.n > 0) {
-        // slots by cost (never more than a job's tiles, never more than its scratch: bwd_grid_max) -- for launches of a few
-        // tiles per workgroup, where the matrix work of a tile is what a workgroup's time is.  Jobs of hundreds of thousands of
-        // rows (a PDBbind batch: 10 800 tiles of Bessel rows) are bound by their gradient stream, a tile costs the same whatever
-        // its layer, and the cost model misdeals them (measured: 283 -> 751 us): they keep two tiles per workgroup up to 256.
-        int64_t total = 0, all_tiles = 0;
-        for (int j = 0; j < J.n; ++j) all_tiles += (J.job[j].rows + TR - 1) / TR;
-        if (all_tiles > 4 * BWD_SLOTS) {
-            grid = 0;
-            for (int j = 0; j < J.n; ++j) {
-                J.job[j].nblk = grid_for((J.job[j].rows + 1) / 2, 256);
-                grid += J.job[j].nblk;
-            }
-            all_tiles = -1;
-        }
-        for (int j = 0; j < J.n && all_tiles >= 0; ++j) total += (int64_t)((J.job[j].rows + TR - 1) / TR) * tile_cost(J.job[j].code);
-        const int64_t budget = BWD_SLOTS - J.types.nblk > 64 ? BWD_SLOTS - J.types.nblk : 64;
-        if (all_tiles >= 0) grid = 0;
-        for (int j = 0; j < J.n && all_tiles >= 0; ++j) {
+        // Workgroups of the backward launch.  Launches of a few tiles per workgroup (a QM9 batch: 860 tiles) are dealt by COST:
+        // the matrix work of a tile is what a workgroup's time is there, and with "two tiles per workgroup" for every job the
+        // two-set 42-wide layer's workgroups were the launch.  Jobs of hundreds of thousands of rows (a PDBbind batch: 10 800
+        // tiles of Bessel rows) are bound by their gradient stream -- a tile costs the same whatever its layer, the cost model
+        // misdeals them (measured: 283 -> 751 us) -- and keep two tiles per workgroup up to 256.  Never more workgroups than a
+        // job's tiles or its scratch (bwd_grid_max).
+        int64_t all_tiles = 0, total = 0;
+        for (int j = 0; j < J.n; ++j) {
             const int64_t tiles = (J.job[j].rows + TR - 1) / TR;
-            int64_t want = total > 0 ? (tiles * tile_cost(J.job[j].code) * budget + total - 1) / total : 1;
+            all_tiles += tiles;
+            total += tiles * tile_cost(J.job[j].code);
+        }
+        const bool by_cost = all_tiles <= 4 * BWD_SLOTS;
+        const int64_t budget = BWD_SLOTS - J.types.nblk > 64 ? BWD_SLOTS - J.types.nblk : 64;
+        grid = 0;
+        for (int j = 0; j < J.n; ++j) {
+            const int64_t tiles = (J.job[j].rows + TR - 1) / TR;
+            int64_t want = grid_for((J.job[j].rows + 1) / 2, 256);
+            if (by_cost) want = total > 0 ? (tiles * tile_cost(J.job[j].code) * budget + total - 1) / total : 1;
             want = want < 1 ? 1 : want;
             J.job[j].nblk = (int)(want < J.job[j].nblk ? want : J.job[j].nblk);
             grid += J.job[j].nblk;
