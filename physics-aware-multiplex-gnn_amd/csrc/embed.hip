@@ -167,7 +167,7 @@ __device__ __forceinline__ float job_dist(const EJob& jb, int64_t row0) {
 
 // `have`: dpre holds this thread's edge length, fetched a tile ahead.  Whether a row exists is decided by its index alone,
 // so a NaN / negative edge length reaches the envelope and the sine exactly as in the forward (bad geometry is not masked).
-template <int K, bool RBF>
+template <int K, bool RBF, bool BWD = false>
 __device__ __forceinline__ void stage_job_rows(const EJob& jb, int64_t row0, float* xs, float* ds, bool have = false,
                                                float dpre = 0.0f) {
     if (!RBF) {
@@ -180,8 +180,11 @@ __device__ __forceinline__ void stage_job_rows(const EJob& jb, int64_t row0, flo
     const float xr = ok ? dpre * jb.inv_cutoff : 1.0f;             // u(1) = 0: padded rows contribute nothing
     const float u = envelope_f(xr);
     const float4 f = *reinterpret_cast<const float4*>(jb.freq + n0);
+    // the backward recomputes the rows on the hardware sine (gemm_core.h sin_turns); the forward's are sinf's floats
+    const float4 sv = BWD ? make_float4(sin_turns(f.x * xr), sin_turns(f.y * xr), sin_turns(f.z * xr), sin_turns(f.w * xr))
+                          : make_float4(sinf(f.x * xr), sinf(f.y * xr), sinf(f.z * xr), sinf(f.w * xr));
     *reinterpret_cast<float4*>(xs + r * Dims<K>::LDX + n0) =
-        ok ? make_float4(u * sinf(f.x * xr), u * sinf(f.y * xr), u * sinf(f.z * xr), u * sinf(f.w * xr)) : f4zero();
+        ok ? make_float4(u * sv.x, u * sv.y, u * sv.z, u * sv.w) : f4zero();
     if ((threadIdx.x & 3) == 0) ds[r] = xr;
 }
 
@@ -284,7 +287,7 @@ __device__ __forceinline__ void embed_bwd_body(const EJob& jb, int bid, float* x
     for (int64_t tile = bid; tile < ntiles; tile += jb.nblk) {
         const int64_t row0 = tile * TR;
         __syncthreads();
-        stage_job_rows<K, DXM == 2>(jb, row0, xs, ds, DXM == 2, dnext);
+        stage_job_rows<K, DXM == 2, true>(jb, row0, xs, ds, DXM == 2, dnext);
         if constexpr (DXM == 2) dnext = tile + jb.nblk < ntiles ? job_dist(jb, (tile + jb.nblk) * TR) : 0.0f;
         if (TWO && threadIdx.x < TR) ks[threadIdx.x] = (row0 + threadIdx.x < rows) ? jb.kind[row0 + threadIdx.x] : 0;
         __syncthreads();
@@ -360,7 +363,7 @@ __device__ __forceinline__ void embed_bwd_body(const EJob& jb, int bid, float* x
                     if (g < rows) jb.dx[g * K + r16] = ax[r];
                 } else {
                     const float xr = ds[16 * wave + 4 * kg + r];
-                    facc += ax[r] * envelope_f(xr) * xr * cosf(fn * xr);
+                    facc += ax[r] * envelope_f(xr) * xr * cos_turns(fn * xr);
                 }
             }
         }

@@ -39,6 +39,24 @@ __device__ __forceinline__ float dsilu(float z) {
     return s * (1.0f + z * (1.0f - s));
 }
 
+// sin and cos of one argument on the hardware units (v_sin_f32 / v_cos_f32 take REVOLUTIONS): the product with 1/(2 pi) is
+// formed to ~2^-48 (head + fma tail), its whole turns are removed exactly, and the two instructions see |t| <= 0.5 -- about
+// ten VALU for the pair where sincosf's range reduction and polynomials cost ~100.  Backward-only (the recomputed Bessel
+// rows and their frequency derivative): forward values keep sinf, so outputs stay the floats of the separate basis kernel.
+__device__ __forceinline__ float turns_of(float p) {
+    constexpr float INV2PI_HI = 0.15915494f, INV2PI_LO = 6.4206382e-09f;     // 1/(2 pi) = HI + LO
+    const float t = p * INV2PI_HI;
+    const float e = fmaf(p, INV2PI_HI, -t) + p * INV2PI_LO;
+    return (t - rintf(t)) + e;
+}
+__device__ __forceinline__ float sin_turns(float p) { return __builtin_amdgcn_sinf(turns_of(p)); }
+__device__ __forceinline__ float cos_turns(float p) { return __builtin_amdgcn_cosf(turns_of(p)); }
+__device__ __forceinline__ void sincos_turns(float p, float* sn, float* cs) {
+    const float f = turns_of(p);
+    *sn = __builtin_amdgcn_sinf(f);
+    *cs = __builtin_amdgcn_cosf(f);
+}
+
 // ---- fp32-accurate GEMMs on the bf16 matrix pipe ("bf16x6") -----------------------------------------------------------
 // The f32-input MFMA runs at the fp32 VECTOR rate (64 FLOP/clk/SIMD: 32 cycles per 16x16x4) and shares the issue port
 // with the VALU; v_mfma_f32_16x16x32_bf16 does 8x the work in ~17 cycles on the matrix pipe proper.  A float splits

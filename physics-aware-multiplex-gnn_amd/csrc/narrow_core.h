@@ -25,6 +25,7 @@ namespace {
 
 using pamnet::f32x4;
 using pamnet::sigmoidf_fast;
+using pamnet::sincos_turns;
 using pamnet::Frag3;
 
 constexpr int NWG = 256;                      // forward kernels: 4 independent waves per workgroup
@@ -1124,6 +1125,13 @@ __device__ __forceinline__ float narrow_envelope(float x) {
     return 1.0f / x + x5 * (-21.0f + x * (35.0f - 15.0f * x));
 }
 
+// the backward's recomputation: the hardware reciprocal (1 ulp) and no branch, so the loads around it stay in flight
+__device__ __forceinline__ float narrow_envelope_rcp(float x) {
+    const float x2 = x * x, x5 = x2 * x2 * x;
+    const float u = __builtin_amdgcn_rcpf(x) + x5 * (-21.0f + x * (35.0f - 15.0f * x));
+    return x < 1.0f ? u : 0.0f;
+}
+
 __device__ __forceinline__ void rbf_feat_a(float4 (&a)[1], const float* __restrict__ dist, const float (&f)[4],
                                            float inv_cutoff, int64_t row0, int64_t m, int lane) {
     const int64_t row = row0 + (lane & 15);
@@ -1242,8 +1250,47 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const flo
         for (int j = 0; j < 4; ++j) fr[j] = rbf_freq[4 * kg + j];
         fc = rbf_freq[c];
     }
-    for (int64_t t = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * NW) {
+    // One tile's global operands, fetched a tile ahead of their use: every load of a tile is issued before the previous
+    // tile's arithmetic (no branch between them, so the waits are counted), instead of five dependent round trips per tile
+    // (edge length -> envelope branch -> ... -> dy), which is what bounded the kernel (61 us at the RNA batch's 867 k edges
+    // against 7 us of traffic).
+    struct Raw {
+        float xd[4];                                          // RBF: the edge lengths of rows 4 kg + r
+        float4 a[NQ];                                         // feature rows, A layout
+        f32x4 fd[NQ];                                         // feature rows, accumulator layout (K = 16 table rows)
+        f32x4 dy[NT];
+        int kc, kr[4];                                        // TWO: the kind of row c / of rows 4 kg + r
+    };
+    auto fetch = [&](int64_t t, Raw& w) {
         const int64_t row0 = t * 16;
+        if constexpr (RBF) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + 4 * kg + r;
+                w.xd[r] = F[row < m ? row : m - 1];
+            }
+        } else {
+            load_feat_a<K>(w.a, F, row0, m, lane);
+            if constexpr (K != 42) load_feat_d<K>(w.fd, F, row0, m, lane);
+        }
+        load_d<D>(w.dy, dy, row0, m, lane);
+        if constexpr (TWO) {
+            const int64_t rc = row0 + c;
+            w.kc = kind[rc < m ? rc : m - 1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + 4 * kg + r;
+                w.kr[r] = kind[row < m ? row : m - 1];
+            }
+        }
+    };
+    const int64_t tstep = (int64_t)gridDim.x * NW;
+    int64_t t = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+    Raw cur, nxt;
+    if (t < ntiles) fetch(t, cur);
+    for (; t < ntiles; t += tstep) {
+        const int64_t row0 = t * 16;
+        fetch(t + tstep < ntiles ? t + tstep : t, nxt);       // (the last tile again: a valid address, never used)
         float4 a[NQ];
         f32x4 fd[NQ];                                         // the same rows in accumulator layout (rows 4 kg + r, column c)
         float xr[4], ur[4], cr[4];                            // RBF: x, u(x), cos(freq_c x) of this lane's four rows
@@ -1253,27 +1300,26 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const flo
             // on their own cost 8 sinf + 4 cosf per lane and tile and made the kernel VALU bound: 77 us at the RNA batch.)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t row = row0 + 4 * kg + r;
-                const bool ok = row < m;
-                xr[r] = F[ok ? row : m - 1] * rbf_inv_cutoff;
-                ur[r] = ok ? narrow_envelope(xr[r]) : 0.f;
+                const bool ok = row0 + 4 * kg + r < m;
+                xr[r] = cur.xd[r] * rbf_inv_cutoff;
+                ur[r] = ok ? narrow_envelope_rcp(xr[r]) : 0.f;
                 float sn;
-                sincosf(fc * xr[r], &sn, &cr[r]);
+                sincos_turns(fc * xr[r], &sn, &cr[r]);
                 fd[0][r] = ur[r] * sn;
             }
             float4 a1[1];
             d_to_a<16>(a1, fd, tile, lane);
             a[0] = a1[0];
         } else {
-            load_feat_a<K>(a, F, row0, m, lane);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) a[q] = cur.a[q];
         }
         f32x4 acc[NT];
         zero(acc);
         if (!TWO) {
             mma_img<NT, NQ>(acc, a, lds4, lane);
         } else {
-            const int64_t row = row0 + c;
-            const bool second = kind[row < m ? row : m - 1] != 0;
+            const bool second = cur.kc != 0;
             float4 a0[NQ], a1[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -1283,17 +1329,15 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const flo
             mma_img<NT, NQ>(acc, a0, lds4, lane);
             mma_img<NT, NQ>(acc, a1, lds4 + IMG, lane);
         }
-        f32x4 dyv[NT], dza[NT], dzb[TWO ? NT : 1];
-        load_d<D>(dyv, dy, row0, m, lane);
+        f32x4 dza[NT], dzb[TWO ? NT : 1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t row = row0 + 4 * kg + r;
-            const bool second = TWO && kind[row < m ? row : m - 1] != 0;
+            const bool second = TWO && cur.kr[r] != 0;
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
                 const float z = acc[jt][r] + (second ? bjb[jt] : bja[jt]);
                 const float s = sigmoidf_fast(z);
-                const float dz = dyv[jt][r] * (s * (1.0f + z * (1.0f - s)));
+                const float dz = cur.dy[jt][r] * (s * (1.0f + z * (1.0f - s)));
                 dza[jt][r] = second ? 0.f : dz;
                 if constexpr (TWO) dzb[jt][r] = second ? dz : 0.f;
             }
@@ -1301,8 +1345,12 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const flo
         if constexpr (!RBF) {
             // the rows were fetched once (A layout, 8-byte loads); their accumulator layout is the transpose through the wave's
             // LDS tile instead of twelve more 4-byte loads per lane
-            if constexpr (K == 42) a_to_d<KP>(fd, a, tile, lane);
-            else load_feat_d<K>(fd, F, row0, m, lane);
+            if constexpr (K == 42) {
+                a_to_d<KP>(fd, a, tile, lane);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) fd[q] = cur.fd[q];
+            }
         }
         wgrad_acc<NT, NQ>(gwa, dza, fd);
         colsum_acc<NT>(dba, dza);
@@ -1324,6 +1372,7 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const flo
                 else if (row < m) df[row * K + c] = o[0][r];
             }
         }
+        cur = nxt;
     }
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds4);
