@@ -139,6 +139,59 @@ __global__ __launch_bounds__(256) void hist_kernel(const int32_t* __restrict__ k
     if (valid && k + 1 < m && keys[k + 1] < key) *unsorted = 1;
 }
 
+// The same for long key lists over few enough rows that ONE WORKGROUP HOLDS EVERY COUNTER IN LDS (rows * 4 B <= 128 KB): a
+// workgroup counts a contiguous chunk of keys with LDS atomics (whose return value is the entry's arrival inside the
+// chunk), adds its non-zero counters to the global ones with one returning atomic per DISTINCT key of the chunk, and hands
+// every entry arrival = that base + its place in the chunk.  The keys of a chunk are the neighbours of ~80 consecutive
+// nodes, a few hundred distinct ones: 867 k global atomics on 17.7 k addresses become ~100 k at the RNA batch (45 -> ~12 us).
+// Any order inside a row will do (sort_rows_kernel ranks the entries), so the tables are bit for bit the plain kernel's.
+constexpr int HIST_LDS_THREADS = 1024;
+constexpr int64_t HIST_LDS_MAX_ROWS = 32768;                  // 128 KB of counters
+constexpr int64_t HIST_LDS_MIN_KEYS = 131072;
+constexpr int HIST_LDS_PER_THREAD = 4;                        // keys per thread: chunks of 4096
+__global__ __launch_bounds__(HIST_LDS_THREADS) void hist_lds_kernel(const int32_t* __restrict__ keys, int64_t m, int rows,
+                                                                    int32_t* __restrict__ count,
+                                                                    int32_t* __restrict__ unsorted,
+                                                                    int32_t* __restrict__ arrival) {
+    extern __shared__ int32_t hcnt[];
+    const int lane = threadIdx.x & 63;
+    for (int r = threadIdx.x; r < rows; r += HIST_LDS_THREADS) hcnt[r] = 0;
+    __syncthreads();
+    const int64_t k0 = (int64_t)blockIdx.x * (HIST_LDS_THREADS * HIST_LDS_PER_THREAD) + threadIdx.x;
+    int key[HIST_LDS_PER_THREAD], nextk[HIST_LDS_PER_THREAD], place[HIST_LDS_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < HIST_LDS_PER_THREAD; ++i) {
+        const int64_t k = k0 + (int64_t)i * HIST_LDS_THREADS;
+        key[i] = k < m ? keys[k] : -1;
+        nextk[i] = k + 1 < m ? keys[k + 1] : 0x7fffffff;
+    }
+    bool dec = false;
+#pragma unroll
+    for (int i = 0; i < HIST_LDS_PER_THREAD; ++i) {
+        const int64_t k = k0 + (int64_t)i * HIST_LDS_THREADS;
+        const bool valid = k < m;
+        const Run r = wave_run(key[i], valid, lane);
+        int base = 0;
+        if (valid && r.head == lane && (unsigned)key[i] < (unsigned)rows) base = atomicAdd(&hcnt[key[i]], r.len);
+        base = __shfl(base, r.head, 64);
+        place[i] = base + (lane - r.head);
+        dec |= valid && nextk[i] < key[i];
+    }
+    if (dec) *unsorted = 1;
+    __syncthreads();
+    for (int r = threadIdx.x; r < rows; r += HIST_LDS_THREADS) {
+        const int c = hcnt[r];
+        if (c > 0) hcnt[r] = atomicAdd(&count[r], c);
+    }
+    if (!arrival) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < HIST_LDS_PER_THREAD; ++i) {
+        const int64_t k = k0 + (int64_t)i * HIST_LDS_THREADS;
+        if (k < m) arrival[k] = ((unsigned)key[i] < (unsigned)rows ? hcnt[key[i]] : 0) + place[i];
+    }
+}
+
 // sorted key sequence: the stable permutation is the identity.  Otherwise every run claims a block of slots.
 __global__ __launch_bounds__(256) void claim_kernel(const int32_t* __restrict__ keys, int64_t m, int64_t rows,
                                                     const int32_t* __restrict__ ptr, int32_t* __restrict__ cursor,
@@ -1016,6 +1069,17 @@ extern "C" int pamnet_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_
     return PAMNET_OK;
 }
 
+// more than 64 KB of dynamic LDS has to be asked for once; PAMNET_HIST_LDS=0 keeps the plain kernel (A/B runs)
+static bool hist_lds_ready() {
+    static const bool ok = [] {
+        const char* e = getenv("PAMNET_HIST_LDS");
+        if (e && e[0] == '0') return false;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(hist_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(sizeof(int32_t) * HIST_LDS_MAX_ROWS)) == hipSuccess;
+    }();
+    return ok;
+}
+
 static int csr_from_keys(const int32_t* keys, int64_t m, int64_t rows, int32_t* ptr, int32_t* perm, int32_t* cursor,
                          int32_t* perm_tmp, int32_t* tmp, bool cursor_is_zero, pamnet_stream_t stream) {
     if (m < 0 || rows <= 0) return PAMNET_EINVAL;
@@ -1032,7 +1096,13 @@ static int csr_from_keys(const int32_t* keys, int64_t m, int64_t rows, int32_t* 
         if (e != hipSuccess) return (int)e;
     }
     if (m > 0) {
-        hipLaunchKernelGGL(hist_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, rows, cursor, unsorted, perm);
+        if (m >= HIST_LDS_MIN_KEYS && rows <= HIST_LDS_MAX_ROWS && hist_lds_ready()) {
+            const int64_t per = (int64_t)HIST_LDS_THREADS * HIST_LDS_PER_THREAD;
+            hipLaunchKernelGGL(hist_lds_kernel, dim3((unsigned)((m + per - 1) / per)), dim3(HIST_LDS_THREADS),
+                               sizeof(int32_t) * (size_t)rows, st, keys, m, (int)rows, cursor, unsorted, perm);
+        } else {
+            hipLaunchKernelGGL(hist_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys, m, rows, cursor, unsorted, perm);
+        }
         PAMNET_LAUNCH_CHECK();
     }
     int rc = pamnet_exclusive_scan_i32(cursor, ptr, rows, tmp, stream);

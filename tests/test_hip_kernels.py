@@ -133,7 +133,10 @@ def test_exclusive_scan_bit_exact(dev, n):
 
 @pytest.mark.parametrize('m,rows', [(0, 3), (10, 1), (5000, 700), (200000, 50), (100000, 100000),
                                     # either side of the single-workgroup form's limits (8 192 keys, 12 288 rows)
-                                    (8192, 12288), (8193, 100), (8000, 12289), (33000, 2300), (1, 12288), (4316, 2286)])
+                                    (8192, 12288), (8193, 100), (8000, 12289), (33000, 2300), (1, 12288), (4316, 2286),
+                                    # either side of the LDS-counter form's limits (>= 131 072 keys, <= 32 768 rows) and the
+                                    # RNA batch's shape; a ragged last chunk; one row
+                                    (131072, 32768), (131071, 32768), (131072, 32769), (867252, 17699), (140001, 1)])
 @pytest.mark.parametrize('order', ['random', 'sorted'])
 def test_csr_from_keys_stable(dev, m, rows, order):
     from pamnet_amd import graph as G
