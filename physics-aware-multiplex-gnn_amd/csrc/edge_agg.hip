@@ -36,6 +36,17 @@ __device__ long long pamnet_agg_probe_wg[2 * 1024];
         if (blockIdx.x == gridDim.x / 2 && (threadIdx.x == 0 || threadIdx.x == 256) && (i) < 32)            \
             pamnet_agg_probe[(threadIdx.x >> 8) * 32 + (i)] = clock64();                                    \
     } while (0)
+// the same inside a chunk loop, for ONE chosen chunk of the workgroup (-DPAMNET_PROBE_CHUNK=k; default: every chunk, i.e. the
+// last one's stamps survive); the loop keeps `aprobe_chunk`
+#ifndef PAMNET_PROBE_CHUNK
+#define PAMNET_PROBE_CHUNK -1
+#endif
+#define APROBE_C(i)                                                                     \
+    do {                                                                                \
+        if (PAMNET_PROBE_CHUNK < 0 || aprobe_chunk == PAMNET_PROBE_CHUNK) APROBE(i);    \
+    } while (0)
+#define APROBE_CHUNK_DECL int aprobe_chunk = 0
+#define APROBE_CHUNK_NEXT ++aprobe_chunk
 #define APROBE_WG(slot)                                                                                       \
     do {                                                                                                      \
         if (threadIdx.x == 0 && blockIdx.x < 1024) pamnet_agg_probe_wg[2 * blockIdx.x + slot] = wall_clock64(); \
@@ -47,6 +58,9 @@ extern "C" int pamnet_agg_probe_read(long long* host64, long long* wg, int n) {
 }
 #else
 #define APROBE(i)
+#define APROBE_C(i)
+#define APROBE_CHUNK_DECL
+#define APROBE_CHUNK_NEXT
 #define APROBE_WG(slot)
 #endif
 
@@ -172,7 +186,7 @@ __device__ __forceinline__ void seq_add_wide(float4& s, const float* __restrict_
     seq_add(s, tile, q, q1, c4);
 }
 
-// out[node] = init[node] + sum of the node's rows of `tile`, one 32-lane group per node, rows in CSR order.
+// out[node] = (sum of the node's rows of `tile`, in CSR order) + init[node], one 32-lane group per node.
 // sptr[k] = ptr[c0 + k] - r0 for k = 0 .. nn (raw: negative = the node began before the chunk, > rows = it goes on).
 template <int NGRP, int WIDE = 0>
 __device__ __forceinline__ void reduce_nodes(int c0, int nn, int rows, const float* __restrict__ tile,
@@ -182,13 +196,14 @@ __device__ __forceinline__ void reduce_nodes(int c0, int nn, int rows, const flo
     const int grp = threadIdx.x >> 5, c4 = threadIdx.x & 31;
     for (int k = grp; k < nn; k += NGRP) {
         const int b = sptr[k], e = sptr[k + 1];
-        float4 s;
-        if (b < 0) s = carry_in[c4];                                    // only k = 0
-        else s = init ? ldg4(init, c0 + k, DIM, c4) : f4zero();
+        // the node's `init` row joins its finished sum: requested here, used behind the row adds (as the sum's first term it
+        // was a bare global round trip ahead of every node's adds)
+        const float4 iv = init ? ldg4(init, c0 + k, DIM, c4) : f4zero();
+        float4 s = b < 0 ? carry_in[c4] : f4zero();                     // (a carry arrives only at k = 0)
         if constexpr (WIDE > 0) seq_add_wide<WIDE>(s, tile, b < 0 ? 0 : b, e > rows ? rows : e, c4);
         else seq_add(s, tile, b < 0 ? 0 : b, e > rows ? rows : e, c4);
         if (e > rows) carry_out[c4] = s;                                // only k = nn - 1 (another lane group than k = 0)
-        else stg4(out, c0 + k, DIM, c4, s);
+        else stg4(out, c0 + k, DIM, c4, f4add(s, iv));
     }
 }
 
@@ -255,7 +270,9 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
     int par = 0;
     // the plan one chunk ahead on the scalar unit (splan above)
     SPlan cur = splan(ptr, row_of, __builtin_amdgcn_readfirstlane(nb), (int64_t)__builtin_amdgcn_readfirstlane((int)rb), ne, re, CAP);
+    APROBE_CHUNK_DECL;
     while (cur.c0 < ne) {
+        APROBE_C(30);
         const int c0 = cur.c0, c1 = cur.c1, rows = cur.rows;
         const int64_t r0 = cur.r0, r1 = cur.r1;
         const SPlan nxt = splan(ptr, row_of, cur.open_end ? c1 : c1 + 1, r1, ne, re, CAP);
@@ -263,24 +280,11 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
         const int nn = c1 - c0 + 1;
         // CSR offsets of the chunk's nodes: requested now (raw), parked in LDS behind the staging of the e rows
         const int mypraw = load_node_ptr(ptr, c0, a.n);
-        APROBE(22);
+        APROBE_C(22);
         if (rows > 0) {
-            if (PRE) {
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-                    if (RPP * i < 16 * mt) stage_e(rr + RPP * i, c4, pre[i]);
-                if (r1 < re) {
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) pre[i] = ldg4z_nt(e, r1 + rr + RPP * i, re, DIM, c4);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-                    if (RPP * i < 16 * mt) stage_e(rr + RPP * i, c4, ldg4z_nt(e, r0 + rr + RPP * i, r1, DIM, c4));
-            }
-            APROBE(23);
-            if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = mypraw - (int)r0;
-            // node indices of this thread's rows (clamped to the chunk: every load below is unconditional)
+            // node indices of this thread's rows (clamped to the chunk: every load below is unconditional), requested FIRST: the
+            // node-plane gathers behind the barrier depend on them, and requested after the staging they were a bare memory
+            // round trip per chunk (tools/agg_probe.py, chunk 10 of 26 at the PDBbind shape: 2 900 of 33 800 cycles)
             int ri[NI], ci[NI];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -288,9 +292,24 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
                 g = g < r1 ? g : r1 - 1;
                 ri[i] = row_of[g], ci[i] = col[g];
             }
-            APROBE(1);
+            if (PRE) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    if (RPP * i < 16 * mt) stage_e(rr + RPP * i, c4, pre[i]);
+                // (no branch around the requests: behind the workgroup's last row the guarded load reads row 0 and zeroes it,
+                // and the requests in flight stay countable -- vector loads and stores retire in order on one counter)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) pre[i] = ldg4z_nt(e, r1 + rr + RPP * i, re, DIM, c4);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    if (RPP * i < 16 * mt) stage_e(rr + RPP * i, c4, ldg4z_nt(e, r0 + rr + RPP * i, r1, DIM, c4));
+            }
+            APROBE_C(23);
+            if ((int)threadIdx.x <= nn) sptr[threadIdx.x] = mypraw - (int)r0;
+            APROBE_C(1);
             __syncthreads();
-            APROBE(2);
+            APROBE_C(2);
             // Software pipeline over sub-chunks of SC tiles: stage s runs the two GEMMs of sub-chunk s, then the epilogue of
             // sub-chunk s-1 (SiLU, gate, z / ea stores, message -> LDS).  The epilogue holds no load latency: the node-plane
             // rows P_i[i], P_j[j] of a sub-chunk are requested a stage ahead (right after the previous epilogue has consumed
@@ -355,9 +374,9 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
                         }
                     }
                 };
-                APROBE(3 + 4 * sb);
+                APROBE_C(3 + 4 * sb);
                 if (do_g) gemm();
-                APROBE(4 + 4 * sb);
+                APROBE_C(4 + 4 * sb);
                 // ONE barrier per stage: every wave is done reading the e rows of sub-chunk sb (their slots take the
                 // accumulators now), and the accumulators stored in stage sb - 1 are visible to the epilogue below.  The
                 // accumulators leave before the epilogue starts: they are not live across it (24 registers).
@@ -367,20 +386,21 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
                     else store_set<SC, 1>(az, S0 + goff * LDT, wc, bv, smt);
                     store_set<SC, 1>(ag, S1 + goff * LDT, wc, zero_bias, smt);
                 }
-                APROBE(5 + 4 * sb);
+                APROBE_C(5 + 4 * sb);
                 if (do_e) epi();
-                APROBE(6 + 4 * sb);
+                APROBE_C(6 + 4 * sb);
             }
         } else if ((int)threadIdx.x <= nn) {
             sptr[threadIdx.x] = mypraw - (int)r0;
         }
         __syncthreads();
-        APROBE(28);
+        APROBE_C(28);
         reduce_nodes<16>(c0, nn, rows, S1, sptr, carry[par], carry[par ^ 1], a.init, a.out);
         par ^= 1;
         __syncthreads();
-        APROBE(29);
+        APROBE_C(29);
         APROBE_WG(1);
+        APROBE_CHUNK_NEXT;
         cur = nxt;
     }
 }

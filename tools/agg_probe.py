@@ -70,14 +70,15 @@ for save in (True, False):
     for w in (0, 1):
         v = [buf[32 * w + i] for i in range(32)]
         t0 = v[0]
+        top = v[30] if v[30] else v[21]                   # (the probed chunk's loop top; PAMNET_PROBE_FLAGS=-DPAMNET_PROBE_CHUNK=k)
         print('  wave %d: weights issued %d | cuts+ptr %d | plan+myp %d | e rows -> LDS %d | idx %d | barrier %d' % (
-            4 * w, v[20] - t0, v[21] - v[20], v[22] - v[21], v[23] - v[22], v[1] - v[23], v[2] - v[1]))
+            4 * w, v[20] - t0, v[21] - v[20], v[22] - top, v[23] - v[22], v[1] - v[23], v[2] - v[1]))
         for sb in range(4):
             a, m, c, d = v[3 + 4 * sb], v[4 + 4 * sb], v[5 + 4 * sb], v[6 + 4 * sb]
             if a == 0 or sb > 3:
                 continue
-            print('    stage %d: first task %6d  second task %6d  barriers+stores %6d   (start at %d)' % (sb, m - a, c - m, d - c, a - t0))
-        print('    reduce %d ; total %d cycles' % (v[29] - v[28], v[29] - t0))
+            print('    stage %d: GEMMs %6d  barrier + acc -> LDS %6d  epilogue %6d   (start at %d)' % (sb, m - a, c - m, d - c, a - top))
+        print('    barrier %d | reduce + barrier %d ; chunk %d cycles ; kernel so far %d cycles' % (v[28] - max(v[6 + 4 * k] for k in range(4)), v[29] - v[28], v[29] - top, v[29] - t0))
     st0 = min(wg[2 * i] for i in range(nwg))
     life = sorted((wg[2 * i + 1] - wg[2 * i]) / 100.0 for i in range(nwg))
     starts = sorted((wg[2 * i] - st0) / 100.0 for i in range(nwg))

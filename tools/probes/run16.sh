@@ -1,0 +1,6 @@
+python -m pytest tests/test_hip_kernels.py tests/test_graph_engine.py -x -q -m gpu 2>&1 | tail -2
+for i in 1 2 3; do for l in tools/probes/libpamnet_before.so ""; do echo "== lib: ${l:-current}"; PAMNET_HIP_LIB=${l:+$PWD/$l} python tools/store_steps.py rna 200 2>&1 | tail -1; done; done
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/p_rna; rocprofv3 --kernel-trace --output-format csv -d /tmp/p_rna -- python $GRAFT_REPO_ROOT/tools/store_steps.py rna 60 serial > /tmp/p_rna.log 2>&1
+f=$(find /tmp/p_rna -name '*kernel_trace.csv' | head -1)
+(grep ms/step /tmp/p_rna.log; python $GRAFT_REPO_ROOT/tools/step_profile.py $f 60) > $GRAFT_REPO_ROOT/gpurun_out/rna_serial_budget.txt
