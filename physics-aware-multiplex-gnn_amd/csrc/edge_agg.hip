@@ -296,10 +296,10 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
                     if (RPP * i < 16 * mt) stage_e(rr + RPP * i, c4, pre[i]);
-                // (no branch around the requests: behind the workgroup's last row the guarded load reads row 0 and zeroes it,
-                // and the requests in flight stay countable -- vector loads and stores retire in order on one counter)
+                // (no branch around the requests: behind the workgroup's last row the guarded load reads that row again and
+                // zeroes it, and the requests in flight stay countable -- vector loads and stores retire in order on one counter)
 #pragma unroll
-                for (int i = 0; i < NI; ++i) pre[i] = ldg4z_nt(e, r1 + rr + RPP * i, re, DIM, c4);
+                for (int i = 0; i < NI; ++i) pre[i] = ldg4zl_nt(e, r1 + rr + RPP * i, re, DIM, c4);
             } else {
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
@@ -453,6 +453,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
     const int ne = a.cuts ? a.cuts[wg + 1] : seg_cut(ptr, row_of, a.n, a.m, wg + 1, gridDim.x);
     const int64_t re = ptr[ne];
     constexpr int RPP = 16, NI = MTX;
+    constexpr bool GATHER_FIRST = MTX <= 3;       // (the larger instantiations have no registers for NI rows of d_agg at once)
     constexpr int BG = 3;                         // row tiles per MFMA group: three independent accumulator chains
     const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;
     int par = 0;
@@ -481,6 +482,20 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
             // (Restructuring this sweep -- operands a row / a group of rows ahead, stores last -- changed nothing: all
             // workgroups run it at the same time and it moves 85 MB through L2 / Infinity Cache in ~8 us: bandwidth, not
             // latency, tools/agg_probe.py.)
+            // the rows' node indices, then their d_agg rows: all requested before the first is used (clamped to the chunk, no
+            // branch) -- row by row each gather waited for its index, and behind the first row's stores each index load
+            // waited for those too (vector loads and stores retire in order on one counter)
+            float4 dmv[GATHER_FIRST ? NI : 1];
+            if constexpr (GATHER_FIRST) {
+                int gi[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    int64_t g = r0 + rr + RPP * i;
+                    gi[i] = row_of[g < r1 ? g : r1 - 1];
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i) dmv[i] = ldg4(d_agg, gi[i], DIM, c4);
+            }
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 if (RPP * i >= 16 * mt) continue;
@@ -488,7 +503,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
                 const int64_t g = r0 + r;
                 float4 x = f4zero(), y = f4zero();
                 if (g < r1) {
-                    const float4 dm = ldg4(d_agg, row_of[g], DIM, c4);
+                    const float4 dm = GATHER_FIRST ? dmv[GATHER_FIRST ? i : 0] : ldg4(d_agg, row_of[g], DIM, c4);
                     const float4 zz = PRE ? pz[PRE ? i : 0] : ldg4(zs, g, DIM, c4);   // (non-temporal reads of the saves
                     const float4 ee = PRE ? pe[PRE ? i : 0] : ldg4(eas, g, DIM, c4);  //  measured slower: 793 vs 766 us)
                     x = f4mul(f4mul(dm, ee), f4dsilu(zz));

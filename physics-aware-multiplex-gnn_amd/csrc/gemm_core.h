@@ -332,6 +332,13 @@ __device__ __forceinline__ float4 ldg4z_nt(const float* p, int64_t row, int64_t 
     const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (ok ? row : 0) * ld + 4 * c4));
     return ok ? make_float4(t[0], t[1], t[2], t[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
+// the same, out-of-range rows reading the LAST valid row (nrows >= 1): for loads every workgroup issues behind its own range
+// (row 0 would be one cache line hammered by all of them)
+__device__ __forceinline__ float4 ldg4zl_nt(const float* p, int64_t row, int64_t nrows, int ld, int c4) {
+    const bool ok = row < nrows;
+    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (ok ? row : nrows - 1) * ld + 4 * c4));
+    return ok ? make_float4(t[0], t[1], t[2], t[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
 __device__ __forceinline__ float4 ldg4_nt(const float* p, int64_t row, int ld, int c4) {
     const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + row * ld + 4 * c4));
     return make_float4(t[0], t[1], t[2], t[3]);
