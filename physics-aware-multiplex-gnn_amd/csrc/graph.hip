@@ -636,17 +636,35 @@ __device__ __forceinline__ void knn_select(const float* __restrict__ pos, float 
     unsigned dc[KNN_CACHE];
     unsigned mn = 0xffffffffu, mx = 0u;
     int zeros = 0;
+    // Eight slots at a time: their 24 coordinate loads are requested together (no lane guard: candidates behind the graph's end
+    // read its last atom and are masked afterwards).  Slot by slot behind a lane guard each slot's three loads were a round
+    // trip of their own -- a graph's coordinates (46 KB) do not stay in the 32 KB L1, so mostly to the L2 -- and the pass was
+    // 35 dependent round trips per query: 30.7 of the kernel's 83 us (tools/knn_probe.py).
 #pragma unroll
-    for (int c = 0; c < KNN_CACHE; ++c) {
-        dc[c] = 0xffffffffu;
-        if (c < iters) {
-            const int j = beg + c * 64 + lane;
-            if (j < end) {
-                dc[c] = __float_as_uint(sqdist(pos, xi, yi, zi, j));
-                zeros += dc[c] == 0u ? 1 : 0;
-                mn = (dc[c] != 0u && dc[c] < mn) ? dc[c] : mn;       // smallest NON-ZERO distance (knn_topk: why)
-                mx = dc[c] > mx ? dc[c] : mx;
+    for (int c0 = 0; c0 < KNN_CACHE; c0 += 8) {
+        if (c0 < iters) {                                   // (wave-uniform)
+            float px[8], py[8], pz[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = beg + (c0 + u) * 64 + lane;
+                const int64_t jc = j < end ? j : end - 1;
+                px[u] = pos[3 * jc], py[u] = pos[3 * jc + 1], pz[u] = pos[3 * jc + 2];
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u;
+                const int j = beg + c * 64 + lane;
+                const float dx = xi - px[u], dy = yi - py[u], dz = zi - pz[u];
+                const unsigned d = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+                const bool valid = j < end;                 // (sqdist's arithmetic, same bits)
+                dc[c] = valid ? d : 0xffffffffu;
+                zeros += (valid && d == 0u) ? 1 : 0;
+                mn = (valid && d != 0u && d < mn) ? d : mn;          // smallest NON-ZERO distance (knn_topk: why)
+                mx = (valid && d > mx) ? d : mx;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dc[c0 + u] = 0xffffffffu;
         }
     }
 #pragma unroll
