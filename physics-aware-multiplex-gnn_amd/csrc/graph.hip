@@ -648,7 +648,10 @@ __device__ __forceinline__ void knn_select(const float* __restrict__ pos, float 
             for (int u = 0; u < 8; ++u) {
                 const int j = beg + (c0 + u) * 64 + lane;
                 const int64_t jc = j < end ? j : end - 1;
-                px[u] = pos[3 * jc], py[u] = pos[3 * jc + 1], pz[u] = pos[3 * jc + 2];
+                // one 12-byte load per candidate: the wave's 64 candidates are 768 contiguous bytes, touched once instead of
+                // once per coordinate
+                const float3 pj = *reinterpret_cast<const float3*>(pos + 3 * jc);
+                px[u] = pj.x, py[u] = pj.y, pz[u] = pj.z;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
