@@ -23,6 +23,8 @@ namespace {
 // (load -> MFMA -> LDS relayout -> MFMA ...), so a second wave per SIMD is what hides the latencies; and 17.7 k rows are
 // 139 workgroups -- one round on 256 CUs, where 64-row workgroups (277) took two (ntail_bwd, d = 64: 220 us).
 constexpr int CHW = 8;
+// widths whose whole tail chain (ten [d, d] images, twenty with the transposes) stays in LDS
+__host__ __device__ constexpr bool tail_resident(int d) { return d <= 32; }
 
 // The chain kernels visit a new weight matrix every stage and only a handful of row tiles per workgroup, so building the
 // fragment-ordered images from the row-major weights inside them (strided 4-byte reads) was most of their time
@@ -81,17 +83,31 @@ __device__ __forceinline__ void mul_dsilu(f32x4 (&g)[NT], const f32x4 (&z)[NT], 
         }
 }
 
-// Sum the waves' contributions in `red` (wave order; `put(first)` writes / adds this wave's part), then hand the n floats
-// to the workgroup's partial row (`add`: this is a later row group of the same workgroup).  Ends with a barrier: `red`,
-// the images and the tiles may be rewritten afterwards.
-template <typename F>
+// Sum the waves' contributions (wave order), then hand the n floats to the workgroup's partial row (`add`: this is a later
+// row group of the same workgroup).  Ends with a barrier: `red`, the images and the tiles may be rewritten afterwards.
+//   WIDE (d <= 32): every wave writes its part to a slot of its own, one barrier, then the threads add the CHW slots of an
+//   element in wave order -- the same sums, bit for bit, as the narrow form's chain, in two barriers instead of CHW + 1 (the
+//   tail chain's backward runs eleven of these per row group: a third of its time at the RNA batch).
+//   narrow (d = 64, no room for CHW slots): `put(red, first)` writes / adds this wave's part in its turn.
+template <bool WIDE, typename F>
 __device__ __forceinline__ void wg_reduce(float* red, int n, float* __restrict__ dst, bool add, F&& put) {
     const int wave = threadIdx.x >> 6;
-    for (int w = 0; w < CHW; ++w) {
-        if (wave == w) put(w == 0);
+    if constexpr (WIDE) {
+        put(red + wave * n, true);
         __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 64 * CHW) {
+            float s = red[i];
+#pragma unroll
+            for (int w = 1; w < CHW; ++w) s += red[w * n + i];
+            dst[i] = add ? dst[i] + s : s;
+        }
+    } else {
+        for (int w = 0; w < CHW; ++w) {
+            if (wave == w) put(red, w == 0);
+            __syncthreads();
+        }
+        for (int i = threadIdx.x; i < n; i += 64 * CHW) dst[i] = add ? dst[i] + red[i] : red[i];
     }
-    for (int i = threadIdx.x; i < n; i += 64 * CHW) dst[i] = add ? dst[i] + red[i] : red[i];
     __syncthreads();
 }
 
@@ -127,9 +143,9 @@ __device__ __forceinline__ void lin_bwd_stage(f32x4 (&g)[D / 16], const float* _
     d_to_a<D>(a, g, tile, lane);
     zero(dx);
     mma_img<NT, NT>(dx, a, imgt, lane);
-    wg_reduce(red, D * D + D, dst, add, [&](bool first) {
-        red_add_mat<NT, NT>(red, gw, lane, first);
-        red_add_bias<NT>(red + D * D, dbs, lane, first);
+    wg_reduce<tail_resident(D)>(red, D * D + D, dst, add, [&](float* r, bool first) {
+        red_add_mat<NT, NT>(r, gw, lane, first);
+        red_add_bias<NT>(r + D * D, dbs, lane, first);
     });
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) g[jt] = dx[jt];
@@ -180,9 +196,9 @@ __device__ __forceinline__ void mlp2_bwd_stage(f32x4 (&g)[D / 16], const float* 
         }
         wgrad_acc<NT, NT>(gw, q, h);
         colsum_acc<NT>(dbs, q);
-        wg_reduce(red, MAT + D, dst, add, [&](bool first) {
-            red_add_mat<NT, NT>(red, gw, lane, first);
-            red_add_bias<NT>(red + MAT, dbs, lane, first);
+        wg_reduce<tail_resident(D)>(red, MAT + D, dst, add, [&](float* r, bool first) {
+            red_add_mat<NT, NT>(r, gw, lane, first);
+            red_add_bias<NT>(r + MAT, dbs, lane, first);
         });
     }
     d_to_a<D>(ah, q, tile, lane);
@@ -206,9 +222,9 @@ __device__ __forceinline__ void mlp2_bwd_stage(f32x4 (&g)[D / 16], const float* 
         }
         wgrad_acc<NT, NT>(gw, q, h);
         colsum_acc<NT>(dbs, q);
-        wg_reduce(red, MAT + D, dst + MAT + D, add, [&](bool first) {
-            red_add_mat<NT, NT>(red, gw, lane, first);
-            red_add_bias<NT>(red + MAT, dbs, lane, first);
+        wg_reduce<tail_resident(D)>(red, MAT + D, dst + MAT + D, add, [&](float* r, bool first) {
+            red_add_mat<NT, NT>(r, gw, lane, first);
+            red_add_bias<NT>(r + MAT, dbs, lane, first);
         });
     }
     d_to_a<D>(ah, q, tile, lane);
@@ -258,17 +274,28 @@ template <int D>
 __global__ __launch_bounds__(64 * CHW) void ntail_fwd_kernel(const NTailFwd p) {
     constexpr int NT = D / 16;
     constexpr int IMG = NT * NT * 64;
+    // d <= 32: all ten images of the chain are resident in LDS (10 / 40 KB), copied once ahead of the rows.  Stage by stage
+    // into two slots -- what d = 64 has room for -- every stage began with a global round trip between two barriers: six per
+    // group, ~40 % of the kernel at the RNA batch (139 workgroups of one group each).
+    constexpr bool RES = tail_resident(D);
     extern __shared__ float4 lds4[];
     float4* img0 = lds4;
     float4* img1 = lds4 + IMG;
-    float* tile = reinterpret_cast<float*>(lds4 + 2 * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
+    float* tile = reinterpret_cast<float*>(lds4 + (RES ? 10 : 2) * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
     const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4, wave = threadIdx.x >> 6;
     const int64_t m = p.m, ntiles = (m + 15) / 16;
+    if constexpr (RES) {
+#pragma unroll 1
+        for (int k = 0; k < 10; ++k) copy_image<NT>(lds4 + k * IMG, p.img[k]);
+        __syncthreads();
+    }
     for (int64_t grp = blockIdx.x; grp * CHW < ntiles; grp += gridDim.x) {
         const int64_t row0 = (grp * CHW + wave) * 16;
-        __syncthreads();
-        copy_image<NT>(img0, p.img[0]);
-        __syncthreads();
+        if constexpr (!RES) {
+            __syncthreads();
+            copy_image<NT>(img0, p.img[0]);
+            __syncthreads();
+        }
         f32x4 v[NT];
         {
             float4 a[NT];
@@ -282,11 +309,14 @@ __global__ __launch_bounds__(64 * CHW) void ntail_fwd_kernel(const NTailFwd p) {
         store_d<D>(v, p.H0, row0, m, lane);
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {                        // res1, res2, res3, first two layers of mlp_out
-            __syncthreads();
-            copy_image<NT>(img0, p.img[1 + 2 * k]);
-            copy_image<NT>(img1, p.img[2 + 2 * k]);
-            __syncthreads();
-            mlp2_fwd_stage<D>(v, img0, img1, p.b[1 + 2 * k], p.b[2 + 2 * k], k < 3, tile, lane);
+            if constexpr (!RES) {
+                __syncthreads();
+                copy_image<NT>(img0, p.img[1 + 2 * k]);
+                copy_image<NT>(img1, p.img[2 + 2 * k]);
+                __syncthreads();
+            }
+            mlp2_fwd_stage<D>(v, RES ? lds4 + (1 + 2 * k) * IMG : img0, RES ? lds4 + (2 + 2 * k) * IMG : img1, p.b[1 + 2 * k],
+                              p.b[2 + 2 * k], k < 3, tile, lane);
             if (k == 0) {                                    // Res1(h0) + the layer's input (basic.py:32, *_message_passing.py:41)
                 f32x4 rx[NT];
                 load_d<D>(rx, p.res_x, row0, m, lane);
@@ -296,16 +326,18 @@ __global__ __launch_bounds__(64 * CHW) void ntail_fwd_kernel(const NTailFwd p) {
             float* dst = k == 0 ? p.R1 : (k == 1 ? p.R2 : (k == 2 ? p.R3 : p.T));
             store_d<D>(v, dst, row0, m, lane);
         }
-        __syncthreads();
-        copy_image<NT>(img0, p.img[9]);
-        __syncthreads();
+        if constexpr (!RES) {
+            __syncthreads();
+            copy_image<NT>(img0, p.img[9]);
+            __syncthreads();
+        }
         {
             float4 a[NT];
             float bj[NT];
             f32x4 o[NT];
             d_to_a<D>(a, v, tile, lane);
             zero(o);
-            mma_img<NT, NT>(o, a, img0, lane);
+            mma_img<NT, NT>(o, a, RES ? lds4 + 9 * IMG : img0, lane);
             load_bias<NT>(bj, p.b[9], c);
             add_bias_silu<NT>(o, bj);
             store_d<D>(o, p.O, row0, m, lane);
@@ -371,13 +403,24 @@ __global__ __launch_bounds__(64 * CHW) void ntail_bwd_kernel(const NTailBwd p) {
     constexpr int NT = D / 16;
     constexpr int IMG = NT * NT * 64;
     using Row = TailRow<D>;
+    // (d <= 32: all twenty images -- plain at slot k, transposed at slot 10 + k -- resident, as in the forward)
+    constexpr bool RES = tail_resident(D);
+    constexpr int NSLOT = RES ? 20 : 4;
     extern __shared__ float4 lds4[];
-    float4* img = lds4;                                      // 4 images
-    float* tile = reinterpret_cast<float*>(lds4 + 4 * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
-    float* red = reinterpret_cast<float*>(lds4 + 4 * IMG) + CHW * 16 * (D + 4);
+    float4* img = lds4;                                      // (!RES) 4 images
+    float* tile = reinterpret_cast<float*>(lds4 + NSLOT * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
+    float* red = reinterpret_cast<float*>(lds4 + NSLOT * IMG) + CHW * 16 * (D + 4);
     const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4, wave = threadIdx.x >> 6;
     const int64_t m = p.m, ntiles = (m + 15) / 16;
     float* prow = p.partial + (size_t)blockIdx.x * p.stride;
+    if constexpr (RES) {
+#pragma unroll 1
+        for (int k = 0; k < 10; ++k) {
+            copy_image<NT>(lds4 + k * IMG, p.img[k]);
+            copy_image<NT>(lds4 + (10 + k) * IMG, p.imgt[k]);
+        }
+        __syncthreads();
+    }
     for (int64_t grp = blockIdx.x; grp * CHW < ntiles; grp += gridDim.x) {
         const bool add = grp != (int64_t)blockIdx.x;
         const int64_t row0 = (grp * CHW + wave) * 16;
@@ -409,30 +452,36 @@ __global__ __launch_bounds__(64 * CHW) void ntail_bwd_kernel(const NTailBwd p) {
             }
             sb += __shfl_xor(sb, 16, 64);
             sb += __shfl_xor(sb, 32, 64);
-            wg_reduce(red, 2 * D + 1, prow + Row::H, add, [&](bool first) {
-                red_add_bias<NT>(red, so, lane, first);
-                red_add_bias<NT>(red + D, sa, lane, first);
-                if (lane == 0) red[2 * D] = first ? sb : red[2 * D] + sb;
+            wg_reduce<tail_resident(D)>(red, 2 * D + 1, prow + Row::H, add, [&](float* r, bool first) {
+                red_add_bias<NT>(r, so, lane, first);
+                red_add_bias<NT>(r + D, sa, lane, first);
+                if (lane == 0) r[2 * D] = first ? sb : r[2 * D] + sb;
             });
         }
         // ---- mlp_out[2]
-        copy_image<NT>(img, p.img[9]);
-        copy_image<NT>(img + IMG, p.imgt[9]);
-        __syncthreads();
-        lin_bwd_stage<D>(g, p.T, row0, m, img, img + IMG, p.b[9], true, tile, red, prow + Row::L5, add, lane);
+        if constexpr (!RES) {
+            copy_image<NT>(img, p.img[9]);
+            copy_image<NT>(img + IMG, p.imgt[9]);
+            __syncthreads();
+        }
+        lin_bwd_stage<D>(g, p.T, row0, m, RES ? lds4 + 9 * IMG : img, RES ? lds4 + 19 * IMG : img + IMG, p.b[9], true, tile, red,
+                         prow + Row::L5, add, lane);
         // ---- mlp_out[0:2], Res3, Res2, Res1
 #pragma unroll 1
         for (int k = 3; k >= 0; --k) {
-            copy_image<NT>(img, p.img[1 + 2 * k]);
-            copy_image<NT>(img + IMG, p.img[2 + 2 * k]);
-            copy_image<NT>(img + 2 * IMG, p.imgt[1 + 2 * k]);
-            copy_image<NT>(img + 3 * IMG, p.imgt[2 + 2 * k]);
-            __syncthreads();
+            if constexpr (!RES) {
+                copy_image<NT>(img, p.img[1 + 2 * k]);
+                copy_image<NT>(img + IMG, p.img[2 + 2 * k]);
+                copy_image<NT>(img + 2 * IMG, p.imgt[1 + 2 * k]);
+                copy_image<NT>(img + 3 * IMG, p.imgt[2 + 2 * k]);
+                __syncthreads();
+            }
             if (k == 0) store_d<D>(g, p.d_resx, row0, m, lane);      // r1 = Res1(h0) + res_x
             const float* X = k == 3 ? p.R3 : (k == 2 ? p.R2 : (k == 1 ? p.R1 : p.H0));
             const int off = k == 3 ? Row::B4 : (k == 2 ? Row::B3 : (k == 1 ? Row::B2 : Row::B1));
-            mlp2_bwd_stage<D>(g, X, row0, m, img, img + IMG, img + 2 * IMG, img + 3 * IMG, p.b[1 + 2 * k], p.b[2 + 2 * k],
-                              k < 3, tile, red, prow + off, add, lane);
+            mlp2_bwd_stage<D>(g, X, row0, m, RES ? lds4 + (1 + 2 * k) * IMG : img, RES ? lds4 + (2 + 2 * k) * IMG : img + IMG,
+                              RES ? lds4 + (11 + 2 * k) * IMG : img + 2 * IMG, RES ? lds4 + (12 + 2 * k) * IMG : img + 3 * IMG,
+                              p.b[1 + 2 * k], p.b[2 + 2 * k], k < 3, tile, red, prow + off, add, lane);
             if (k == 3 && p.g_x) {                                   // r3 is also the layer's node output
                 f32x4 gx[NT];
                 load_d<D>(gx, p.g_x, row0, m, lane);
@@ -441,10 +490,13 @@ __global__ __launch_bounds__(64 * CHW) void ntail_bwd_kernel(const NTailBwd p) {
             }
         }
         // ---- mlp_x2
-        copy_image<NT>(img, p.img[0]);
-        copy_image<NT>(img + IMG, p.imgt[0]);
-        __syncthreads();
-        lin_bwd_stage<D>(g, p.x2, row0, m, img, img + IMG, p.b[0], true, tile, red, prow + Row::L0, add, lane);
+        if constexpr (!RES) {
+            copy_image<NT>(img, p.img[0]);
+            copy_image<NT>(img + IMG, p.imgt[0]);
+            __syncthreads();
+        }
+        lin_bwd_stage<D>(g, p.x2, row0, m, RES ? lds4 : img, RES ? lds4 + 10 * IMG : img + IMG, p.b[0], true, tile, red,
+                         prow + Row::L0, add, lane);
         store_d<D>(g, p.d_x2, row0, m, lane);
     }
 }
@@ -557,7 +609,8 @@ __global__ __launch_bounds__(64 * CHW) void npre_bwd_kernel(const NPreBwd p) {
             float4 a[NT];
             d_to_a<D>(a, gk, tile, lane);
             mma_img<NT, NT>(gx1, a, imgpt + k * IMG, lane);
-            wg_reduce(red, MAT, prow + k * MAT, add, [&](bool first) { red_add_mat<NT, NT>(red, gw, lane, first); });
+            wg_reduce<tail_resident(D)>(red, MAT, prow + k * MAT, add,
+                                        [&](float* r, bool first) { red_add_mat<NT, NT>(r, gw, lane, first); });
         }
         // through mlp_x1
         float* dst = prow + p.nb * MAT;
@@ -696,12 +749,17 @@ inline int chain_grid(int64_t m) {
 }
 
 template <int D>
-constexpr size_t ntail_fwd_lds() { return 2 * (size_t)D * D * 4 + CHW * 16 * (D + 4) * 4; }
+constexpr size_t ntail_fwd_lds() { return (tail_resident(D) ? 10 : 2) * (size_t)D * D * 4 + CHW * 16 * (D + 4) * 4; }
 template <int D>
-constexpr size_t ntail_bwd_lds() { return 4 * (size_t)D * D * 4 + CHW * 16 * (D + 4) * 4 + ((size_t)D * D + 2 * D + 4) * 4; }
+constexpr size_t ntail_bwd_lds() {
+    return (tail_resident(D) ? 20 : 4) * (size_t)D * D * 4 + CHW * 16 * (D + 4) * 4 +
+           (tail_resident(D) ? CHW : 1) * ((size_t)D * D + 2 * D + 4) * 4;       // (wg_reduce: a slot per wave when resident)
+}
 template <int D>
 constexpr size_t npre_fwd_lds() { return (1 + NPB) * (size_t)D * D * 4 + 4 * 16 * (D + 4) * 4; }
 template <int D>
-constexpr size_t npre_bwd_lds() { return (2 + NPB) * (size_t)D * D * 4 + CHW * 16 * (D + 4) * 4 + ((size_t)D * D + D) * 4; }
+constexpr size_t npre_bwd_lds() {
+    return (2 + NPB) * (size_t)D * D * 4 + CHW * 16 * (D + 4) * 4 + (tail_resident(D) ? CHW : 1) * ((size_t)D * D + D) * 4;
+}
 
 }  // namespace
