@@ -282,13 +282,17 @@ __global__ __launch_bounds__(64 * CHW) void ntail_fwd_kernel(const NTailFwd p) {
     float4* img0 = lds4;
     float4* img1 = lds4 + IMG;
     float* tile = reinterpret_cast<float*>(lds4 + (RES ? 10 : 2) * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
+    // the ten bias vectors wait in LDS too: as global loads inside the stages each sat behind the previous stage's stores
+    // (the compiler cannot move it above them) -- one more round trip per layer of the chain
+    float* bl = reinterpret_cast<float*>(lds4 + (RES ? 10 : 2) * IMG) + CHW * 16 * (D + 4);
     const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4, wave = threadIdx.x >> 6;
     const int64_t m = p.m, ntiles = (m + 15) / 16;
+    for (int i = threadIdx.x; i < 10 * D; i += 64 * CHW) bl[i] = p.b[i / D][i % D];
     if constexpr (RES) {
 #pragma unroll 1
         for (int k = 0; k < 10; ++k) copy_image<NT>(lds4 + k * IMG, p.img[k]);
-        __syncthreads();
     }
+    __syncthreads();
     for (int64_t grp = blockIdx.x; grp * CHW < ntiles; grp += gridDim.x) {
         const int64_t row0 = (grp * CHW + wave) * 16;
         if constexpr (!RES) {
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(64 * CHW) void ntail_fwd_kernel(const NTailFwd p) {
             load_a<D>(a, p.x2, row0, m, lane);
             zero(v);
             mma_img<NT, NT>(v, a, img0, lane);
-            load_bias<NT>(bj, p.b[0], c);
+            load_bias<NT>(bj, bl, c);
             add_bias_silu<NT>(v, bj);
         }
         store_d<D>(v, p.H0, row0, m, lane);
@@ -315,8 +319,8 @@ __global__ __launch_bounds__(64 * CHW) void ntail_fwd_kernel(const NTailFwd p) {
                 copy_image<NT>(img1, p.img[2 + 2 * k]);
                 __syncthreads();
             }
-            mlp2_fwd_stage<D>(v, RES ? lds4 + (1 + 2 * k) * IMG : img0, RES ? lds4 + (2 + 2 * k) * IMG : img1, p.b[1 + 2 * k],
-                              p.b[2 + 2 * k], k < 3, tile, lane);
+            mlp2_fwd_stage<D>(v, RES ? lds4 + (1 + 2 * k) * IMG : img0, RES ? lds4 + (2 + 2 * k) * IMG : img1,
+                              bl + (1 + 2 * k) * D, bl + (2 + 2 * k) * D, k < 3, tile, lane);
             if (k == 0) {                                    // Res1(h0) + the layer's input (basic.py:32, *_message_passing.py:41)
                 f32x4 rx[NT];
                 load_d<D>(rx, p.res_x, row0, m, lane);
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(64 * CHW) void ntail_fwd_kernel(const NTailFwd p) {
             d_to_a<D>(a, v, tile, lane);
             zero(o);
             mma_img<NT, NT>(o, a, RES ? lds4 + 9 * IMG : img0, lane);
-            load_bias<NT>(bj, p.b[9], c);
+            load_bias<NT>(bj, bl + 9 * D, c);
             add_bias_silu<NT>(o, bj);
             store_d<D>(o, p.O, row0, m, lane);
             // heads: per-row dot products; a row's 16 column lanes share kg
@@ -410,17 +414,19 @@ __global__ __launch_bounds__(64 * CHW) void ntail_bwd_kernel(const NTailBwd p) {
     float4* img = lds4;                                      // (!RES) 4 images
     float* tile = reinterpret_cast<float*>(lds4 + NSLOT * IMG) + (threadIdx.x >> 6) * 16 * (D + 4);
     float* red = reinterpret_cast<float*>(lds4 + NSLOT * IMG) + CHW * 16 * (D + 4);
+    float* bl = red + (RES ? CHW : 1) * (D * D + 2 * D + 4);    // the ten bias vectors (as in the forward)
     const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4, wave = threadIdx.x >> 6;
     const int64_t m = p.m, ntiles = (m + 15) / 16;
     float* prow = p.partial + (size_t)blockIdx.x * p.stride;
+    for (int i = threadIdx.x; i < 10 * D; i += 64 * CHW) bl[i] = p.b[i / D][i % D];
     if constexpr (RES) {
 #pragma unroll 1
         for (int k = 0; k < 10; ++k) {
             copy_image<NT>(lds4 + k * IMG, p.img[k]);
             copy_image<NT>(lds4 + (10 + k) * IMG, p.imgt[k]);
         }
-        __syncthreads();
     }
+    __syncthreads();
     for (int64_t grp = blockIdx.x; grp * CHW < ntiles; grp += gridDim.x) {
         const bool add = grp != (int64_t)blockIdx.x;
         const int64_t row0 = (grp * CHW + wave) * 16;
@@ -464,8 +470,8 @@ __global__ __launch_bounds__(64 * CHW) void ntail_bwd_kernel(const NTailBwd p) {
             copy_image<NT>(img + IMG, p.imgt[9]);
             __syncthreads();
         }
-        lin_bwd_stage<D>(g, p.T, row0, m, RES ? lds4 + 9 * IMG : img, RES ? lds4 + 19 * IMG : img + IMG, p.b[9], true, tile, red,
-                         prow + Row::L5, add, lane);
+        lin_bwd_stage<D>(g, p.T, row0, m, RES ? lds4 + 9 * IMG : img, RES ? lds4 + 19 * IMG : img + IMG, bl + 9 * D, true, tile,
+                         red, prow + Row::L5, add, lane);
         // ---- mlp_out[0:2], Res3, Res2, Res1
 #pragma unroll 1
         for (int k = 3; k >= 0; --k) {
@@ -481,7 +487,7 @@ __global__ __launch_bounds__(64 * CHW) void ntail_bwd_kernel(const NTailBwd p) {
             const int off = k == 3 ? Row::B4 : (k == 2 ? Row::B3 : (k == 1 ? Row::B2 : Row::B1));
             mlp2_bwd_stage<D>(g, X, row0, m, RES ? lds4 + (1 + 2 * k) * IMG : img, RES ? lds4 + (2 + 2 * k) * IMG : img + IMG,
                               RES ? lds4 + (11 + 2 * k) * IMG : img + 2 * IMG, RES ? lds4 + (12 + 2 * k) * IMG : img + 3 * IMG,
-                              p.b[1 + 2 * k], p.b[2 + 2 * k], k < 3, tile, red, prow + off, add, lane);
+                              bl + (1 + 2 * k) * D, bl + (2 + 2 * k) * D, k < 3, tile, red, prow + off, add, lane);
             if (k == 3 && p.g_x) {                                   // r3 is also the layer's node output
                 f32x4 gx[NT];
                 load_d<D>(gx, p.g_x, row0, m, lane);
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(64 * CHW) void ntail_bwd_kernel(const NTailBwd p) {
             copy_image<NT>(img + IMG, p.imgt[0]);
             __syncthreads();
         }
-        lin_bwd_stage<D>(g, p.x2, row0, m, RES ? lds4 : img, RES ? lds4 + 10 * IMG : img + IMG, p.b[0], true, tile, red,
+        lin_bwd_stage<D>(g, p.x2, row0, m, RES ? lds4 : img, RES ? lds4 + 10 * IMG : img + IMG, bl, true, tile, red,
                          prow + Row::L0, add, lane);
         store_d<D>(g, p.d_x2, row0, m, lane);
     }
@@ -749,11 +755,12 @@ inline int chain_grid(int64_t m) {
 }
 
 template <int D>
-constexpr size_t ntail_fwd_lds() { return (tail_resident(D) ? 10 : 2) * (size_t)D * D * 4 + CHW * 16 * (D + 4) * 4; }
+constexpr size_t ntail_fwd_lds() { return (tail_resident(D) ? 10 : 2) * (size_t)D * D * 4 + CHW * 16 * (D + 4) * 4 + 10 * D * 4; }
 template <int D>
 constexpr size_t ntail_bwd_lds() {
     return (tail_resident(D) ? 20 : 4) * (size_t)D * D * 4 + CHW * 16 * (D + 4) * 4 +
-           (tail_resident(D) ? CHW : 1) * ((size_t)D * D + 2 * D + 4) * 4;       // (wg_reduce: a slot per wave when resident)
+           (tail_resident(D) ? CHW : 1) * ((size_t)D * D + 2 * D + 4) * 4 +      // (wg_reduce: a slot per wave when resident)
+           10 * D * 4;                                                           // the bias vectors
 }
 template <int D>
 constexpr size_t npre_fwd_lds() { return (1 + NPB) * (size_t)D * D * 4 + 4 * 16 * (D + 4) * 4; }
