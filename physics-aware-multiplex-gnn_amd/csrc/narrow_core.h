@@ -307,6 +307,32 @@ __device__ __forceinline__ void red_add_bias(float* red, float (&s)[NJ], int lan
     }
 }
 
+// Workgroup sum of the waves' parts of a partial row (n floats) in LDS.  The waves used to take turns on ONE copy -- NW read-
+// modify-write rounds, a barrier each: 16 at d = 16.  Now S copies (as many as the kernel's LDS layout, `avail` floats, holds;
+// a power of two dividing NW): wave w owns copy w % S and adds in turn w / S, then the threads add the S copies of an element
+// in order.  S = NW is the old order bit for bit; fewer copies change the association (still fixed, run to run).
+__host__ __device__ constexpr int pick_slots(int nw, int n, int avail) {
+    int s = nw;
+    while (s > 1 && s * n > avail) s >>= 1;
+    return s;
+}
+template <int NW, int S, typename F>
+__device__ __forceinline__ void wg_sum_out(float* red, int n, float* __restrict__ dst, F&& put) {
+    const int wave = threadIdx.x >> 6;
+    float* mine = red + (wave % S) * n;
+#pragma unroll 1
+    for (int t = 0; t < NW / S; ++t) {
+        if (wave / S == t) put(mine, t == 0);
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n; i += 64 * NW) {
+        float v = red[i];
+#pragma unroll
+        for (int k = 1; k < S; ++k) v += red[k * n + i];
+        dst[i] = v;
+    }
+}
+
 // out[mat][o][k] (k < kvalid) = sum_b partial[b][fragment(o, k)];  bias[j] = sum_b partial[b][bias_off + j].
 // Block (64, 8): 64 consecutive positions of the partial row (coalesced) x 8 slices over the workgroup rows, combined
 // through LDS in slice order -- fixed summation order.
@@ -525,16 +551,13 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nglobal_bwd_kernel(const fl
     // workgroup reduction in wave order, then one partial row per workgroup
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds4);
-    constexpr int MAT = D * D;
-    for (int w = 0; w < NW; ++w) {
-        if ((threadIdx.x >> 6) == w) {
-            red_add_mat<NT, NT>(red, gwe, lane, w == 0);
-            red_add_mat<NT, NT>(red + MAT, gwa, lane, w == 0);
-            red_add_bias<NT>(red + 2 * MAT, dbs, lane, w == 0);
-        }
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < 2 * MAT + D; i += 64 * NW) partial[(size_t)blockIdx.x * stride + i] = red[i];
+    constexpr int MAT = D * D, N = 2 * MAT + D;
+    constexpr int S = pick_slots(NW, N, 4 * IMG * 4 + NW * 16 * (D + 4));
+    wg_sum_out<NW, S>(red, N, partial + (size_t)blockIdx.x * stride, [&](float* r, bool first) {
+        red_add_mat<NT, NT>(r, gwe, lane, first);
+        red_add_mat<NT, NT>(r + MAT, gwa, lane, first);
+        red_add_bias<NT>(r + 2 * MAT, dbs, lane, first);
+    });
 }
 
 // ====================================================================================================================
@@ -715,17 +738,14 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nmlp2_bwd_kernel(const floa
     }
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds4);
-    constexpr int MAT = D * D;
-    for (int w = 0; w < NW; ++w) {
-        if ((threadIdx.x >> 6) == w) {
-            red_add_mat<NT, NT>(red, gw1, lane, w == 0);
-            red_add_mat<NT, NT>(red + MAT, gw2, lane, w == 0);
-            red_add_bias<NT>(red + 2 * MAT, db1, lane, w == 0);
-            red_add_bias<NT>(red + 2 * MAT + D, db2, lane, w == 0);
-        }
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < 2 * MAT + 2 * D; i += 64 * NW) partial[(size_t)blockIdx.x * stride + i] = red[i];
+    constexpr int MAT = D * D, N = 2 * MAT + 2 * D;
+    constexpr int S = pick_slots(NW, N, 4 * IMG * 4 + NW * 16 * (D + 4));
+    wg_sum_out<NW, S>(red, N, partial + (size_t)blockIdx.x * stride, [&](float* r, bool first) {
+        red_add_mat<NT, NT>(r, gw1, lane, first);
+        red_add_mat<NT, NT>(r + MAT, gw2, lane, first);
+        red_add_bias<NT>(r + 2 * MAT, db1, lane, first);
+        red_add_bias<NT>(r + 2 * MAT + D, db2, lane, first);
+    });
 }
 
 // ====================================================================================================================
@@ -849,15 +869,12 @@ __global__ __launch_bounds__(64 * lin_bwd_waves(D)) void nlinear_bwd_kernel(cons
     }
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds4);
-    constexpr int MAT = D * D;
-    for (int w = 0; w < NW; ++w) {
-        if ((threadIdx.x >> 6) == w) {
-            red_add_mat<NT, NT>(red, gw, lane, w == 0);
-            red_add_bias<NT>(red + MAT, dbs, lane, w == 0);
-        }
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < MAT + D; i += 64 * NW) partial[(size_t)blockIdx.x * stride + i] = red[i];
+    constexpr int MAT = D * D, N = MAT + D;
+    constexpr int S = pick_slots(NW, N, 2 * IMG * 4 + NW * 16 * (D + 4));
+    wg_sum_out<NW, S>(red, N, partial + (size_t)blockIdx.x * stride, [&](float* r, bool first) {
+        red_add_mat<NT, NT>(r, gw, lane, first);
+        red_add_bias<NT>(r + MAT, dbs, lane, first);
+    });
 }
 
 // The four bias-free projection blocks of the edge-side Q = rbf [W_0 | W_1 | W_2 | W_3]^T in ONE pass over the rows
@@ -918,17 +935,15 @@ __global__ __launch_bounds__(64 * lin_bwd_waves(D)) void nqblock4_bwd_kernel(con
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds4);
     constexpr int MAT = D * D, QS = MAT + D;
-    for (int w = 0; w < NW; ++w) {
-        if ((threadIdx.x >> 6) == w) {
+    constexpr int LAYOUT = 4 * IMG * 4 + NW * 16 * (D + 4);                // (the launch asks for max(layout, 4 QS floats))
+    constexpr int S = pick_slots(NW, 4 * QS, LAYOUT > 4 * QS ? LAYOUT : 4 * QS);
+    wg_sum_out<NW, S>(red, 4 * QS, partial + (size_t)blockIdx.x * stride, [&](float* r, bool first) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                red_add_mat<NT, NT>(red + k * QS, gw[k], lane, w == 0);
-                red_add_bias<NT>(red + k * QS + MAT, dbs[k], lane, w == 0);
-            }
+        for (int k = 0; k < 4; ++k) {
+            red_add_mat<NT, NT>(r + k * QS, gw[k], lane, first);
+            red_add_bias<NT>(r + k * QS + MAT, dbs[k], lane, first);
         }
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < 4 * QS; i += 64 * NW) partial[(size_t)blockIdx.x * stride + i] = red[i];
+    });
 }
 
 // ====================================================================================================================
@@ -1378,23 +1393,20 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nembed_bwd_kernel(const flo
     float* red = reinterpret_cast<float*>(lds4);
     constexpr int MAT = D * KP;
     constexpr int NM = TWO ? 2 : 1;
-    for (int w = 0; w < NW; ++w) {
-        if ((threadIdx.x >> 6) == w) {
-            red_add_mat<NT, NQ>(red, gwa, lane, w == 0);
-            red_add_bias<NT>(red + NM * MAT, dba, lane, w == 0);
-            if constexpr (TWO) {
-                red_add_mat<NT, NQ>(red + MAT, gwb, lane, w == 0);
-                red_add_bias<NT>(red + NM * MAT + D, dbb, lane, w == 0);
-            }
-            if constexpr (RBF) {
-                float fa[1] = {facc};
-                red_add_bias<1>(red + NM * (MAT + D), fa, lane, w == 0);
-            }
+    constexpr int N = NM * (MAT + D) + (RBF ? 16 : 0);
+    constexpr int S = pick_slots(NW, N, ((TWO ? 2 : 1) * IMG + (DX ? IMGT : 0)) * 4 + NW * 16 * TW);
+    wg_sum_out<NW, S>(red, N, partial + (size_t)blockIdx.x * stride, [&](float* r, bool first) {
+        red_add_mat<NT, NQ>(r, gwa, lane, first);
+        red_add_bias<NT>(r + NM * MAT, dba, lane, first);
+        if constexpr (TWO) {
+            red_add_mat<NT, NQ>(r + MAT, gwb, lane, first);
+            red_add_bias<NT>(r + NM * MAT + D, dbb, lane, first);
         }
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < NM * (MAT + D) + (RBF ? 16 : 0); i += 64 * NW)
-        partial[(size_t)blockIdx.x * stride + i] = red[i];
+        if constexpr (RBF) {
+            float fa[1] = {facc};
+            red_add_bias<1>(r + NM * (MAT + D), fa, lane, first);
+        }
+    });
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
