@@ -482,19 +482,37 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nglobal_bwd_kernel(const fl
         zero(gwe[jt]);
         zero(gwa[jt]);
     }
-    for (int64_t tile_id = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6); tile_id < ntiles;
-         tile_id += (int64_t)gridDim.x * NW) {
-        const int64_t row0 = tile_id * 16;
-        float4 a[NT];
-        load_a<D>(a, e, row0, m, lane);
-        // all gathers of the tile are issued before the GEMMs
+    // d <= 32: the rows, node indices and accumulate operand of a tile are fetched a tile ahead (12 / 24 registers), so a tile
+    // begins with its gathers instead of an index round trip ahead of them (four waves per SIMD hide little of it).  d = 64 has
+    // no registers for it (measured there: 496 -> 550 us at 867 k edges).
+    constexpr bool PF = D <= 32;
+    struct Raw {
         int ti[4], sj[4];
+        float4 a[NT];
+        f32x4 de[NT];
+    };
+    auto fetch = [&](int64_t t, Raw& w) {
+        const int64_t r0 = t * 16;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t row = row0 + 4 * kg + r;
-            ti[r] = tgt[row < m ? row : m - 1];
-            sj[r] = src[row < m ? row : m - 1];
+            const int64_t row = r0 + 4 * kg + r;
+            w.ti[r] = tgt[row < m ? row : m - 1];
+            w.sj[r] = src[row < m ? row : m - 1];
         }
+        load_a<D>(w.a, e, r0, m, lane);
+        if (PF && acc_de) load_d<D>(w.de, de, r0, m, lane);
+    };
+    const int64_t tstep = (int64_t)gridDim.x * NW;
+    int64_t tile_id = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+    Raw cur;
+    if (PF && tile_id < ntiles) fetch(tile_id, cur);
+    for (; tile_id < ntiles; tile_id += tstep) {
+        const int64_t row0 = tile_id * 16;
+        if constexpr (!PF) fetch(tile_id, cur);
+        float4 (&a)[NT] = cur.a;
+        int (&ti)[4] = cur.ti;
+        int (&sj)[4] = cur.sj;
+        // all gathers of the tile are issued before the GEMMs
         float pv[4][NT], qv[4][NT], gv[4][NT];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -508,10 +526,10 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nglobal_bwd_kernel(const fl
                 gv[r][jt] = dg[16 * jt];
             }
         }
+        Raw nxt;
+        if constexpr (PF) fetch(tile_id + tstep < ntiles ? tile_id + tstep : tile_id, nxt);   // (the last tile again: unused)
         f32x4 q1[NT], q2[NT], ed[NT];
-        // (prefetching the next tile's rows / indices / gathers across iterations was measured: 496 -> 550 us at 867 k
-        // edges, d = 64 -- rejected; the accumulator-layout copy of e through the wave's LDS tile replaces a second,
-        // 4-byte-strided read of the rows)
+        // (the accumulator-layout copy of e through the wave's LDS tile replaces a second, 4-byte-strided read of the rows)
         a_to_d<D>(ed, a, tile, lane);
         zero(q1);
         zero(q2);
@@ -542,11 +560,12 @@ __global__ __launch_bounds__(64 * bwd_waves(D)) void nglobal_bwd_kernel(const fl
         d_to_a<D>(a, q2, tile, lane);
         mma_w<NT, NT>(dx, a, img_at, lane);
         if (acc_de) {                                        // the edge embedding feeds every layer: later calls add
-            load_d<D>(ed, de, row0, m, lane);
+            if constexpr (!PF) load_d<D>(cur.de, de, row0, m, lane);
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt) dx[jt] += ed[jt];
+            for (int jt = 0; jt < NT; ++jt) dx[jt] += cur.de[jt];
         }
         store_d<D>(dx, de, row0, m, lane);
+        if constexpr (PF) cur = nxt;
     }
     // workgroup reduction in wave order, then one partial row per workgroup
     __syncthreads();
