@@ -12,7 +12,6 @@ from here).
 """
 import math
 
-import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
