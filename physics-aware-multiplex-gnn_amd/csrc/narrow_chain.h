@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64 * CHW) void ntail_fwd_kernel(const NTailFwd p) {
     float* bl = reinterpret_cast<float*>(lds4 + (RES ? 10 : 2) * IMG) + CHW * 16 * (D + 4);
     const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4, wave = threadIdx.x >> 6;
     const int64_t m = p.m, ntiles = (m + 15) / 16;
-    for (int i = threadIdx.x; i < 10 * D; i += 64 * CHW) bl[i] = p.b[i / D][i % D];
+    for (int i = threadIdx.x; i < 10 * D; i += 64 * CHW) bl[i] = p.b[i / D] ? p.b[i / D][i % D] : 0.f;
     if constexpr (RES) {
 #pragma unroll 1
         for (int k = 0; k < 10; ++k) copy_image<NT>(lds4 + k * IMG, p.img[k]);
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(64 * CHW) void ntail_bwd_kernel(const NTailBwd p) {
     const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4, wave = threadIdx.x >> 6;
     const int64_t m = p.m, ntiles = (m + 15) / 16;
     float* prow = p.partial + (size_t)blockIdx.x * p.stride;
-    for (int i = threadIdx.x; i < 10 * D; i += 64 * CHW) bl[i] = p.b[i / D][i % D];
+    for (int i = threadIdx.x; i < 10 * D; i += 64 * CHW) bl[i] = p.b[i / D] ? p.b[i / D][i % D] : 0.f;
     if constexpr (RES) {
 #pragma unroll 1
         for (int k = 0; k < 10; ++k) {
