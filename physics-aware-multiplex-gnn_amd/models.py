@@ -207,7 +207,7 @@ class _PAMNetBase(nn.Module):
             yield from super().named_parameters(prefix, recurse, remove_duplicate)
             return
         cache = self.__dict__.get('_named_param_cache')
-        if cache is not None and not self._param_cache_valid(cache):
+        if cache is not None and not self.__dict__.get('_params_checked') and not self._param_cache_valid(cache):
             self._drop_param_cache()                     # (the derived lists go with it)
             cache = None
         if cache is None:

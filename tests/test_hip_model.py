@@ -184,6 +184,36 @@ def test_parameter_walk_cache_follows_the_live_module_tree():
                    [k for k, p in m.named_parameters() if any(p is q for q in m._top_params())])
 
 
+def test_parameter_walk_is_checked_once_per_forward_and_again_between_forwards():
+    """forward() validates the cached parameter walk against the live tree once (its dtype check); the other users of the cached
+    lists inside the same forward take that result, and the flag is dropped when the forward leaves -- normally or by an
+    exception -- so a parameter swapped between two forwards is still seen."""
+    import models
+    m = models.PAMNet(models.Config(dataset='QM9', dim=16, n_layer=1, cutoff_l=5.0, cutoff_g=5.0))
+    list(m.parameters())
+    walks = []
+    real = m._param_cache_valid
+    m.__dict__['_param_cache_valid'] = lambda cache: (walks.append(1), real(cache))[1]
+    seen = {}
+
+    def inside(data):
+        seen['a'], seen['b'] = m._all_params(), m._top_params()
+        seen['flag'] = m.__dict__['_params_checked']
+        if data == 'raise':
+            raise KeyError('inside the forward')
+        return 7
+    m.__dict__['_forward'] = inside
+    m._check_dtype()                                     # (what forward() does first: one walk)
+    n0 = len(walks)
+    assert n0 >= 1 and m._checked_forward(None) == 7
+    assert len(walks) == n0 and seen['flag'] is True and m.__dict__['_params_checked'] is False
+    with pytest.raises(KeyError):
+        m._checked_forward('raise')
+    assert m.__dict__['_params_checked'] is False
+    m.global_layer[0].W_out = torch.nn.Linear(16, 1)     # between forwards: the next list is walked again and is current
+    assert any(p is m.global_layer[0].W_out.weight for p in m._all_params()) and len(walks) > n0
+
+
 def test_cast_models_are_refused():
     """The kernels read parameters as fp32 through raw pointers: a model cast to another floating type raises instead of
     being read with the wrong element size (the reference runs in whatever dtype it is cast to; this path is fp32 by
