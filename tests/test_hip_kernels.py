@@ -150,6 +150,26 @@ def test_csr_from_keys_stable(dev, m, rows, order):
                                               torch.bincount(keys.long(), minlength=rows).cumsum(0)]))
 
 
+@pytest.mark.parametrize('m,rows', [(20000, 900), (200000, 17699)])
+def test_csr_from_keys_skips_keys_outside_the_rows(dev, m, rows):
+    """Keys outside [0, rows) are counted nowhere and claim no slot (no out-of-bounds write), in the plain histogram and in
+    the LDS-counter form alike: ptr is the histogram of the valid keys, the first ptr[rows] entries of perm are the valid
+    entries in stable order."""
+    from pamnet_amd import graph as G
+    torch.manual_seed(m)
+    keys = torch.randint(0, rows, (m,), dtype=torch.int32, device=dev)
+    bad = torch.rand(m, device=dev) < 0.01
+    keys = torch.where(bad, torch.where(torch.rand(m, device=dev) < 0.5, torch.full_like(keys, -1), keys + rows), keys).contiguous()
+    ptr, perm = G.csr_from_keys(keys, rows)
+    valid = (keys >= 0) & (keys < rows)
+    vidx = valid.nonzero().view(-1)
+    want = vidx[torch.sort(keys[vidx].long(), stable=True).indices]
+    assert torch.equal(ptr.long(), torch.cat([torch.zeros(1, dtype=torch.int64, device=dev),
+                                              torch.bincount(keys[vidx].long(), minlength=rows).cumsum(0)]))
+    assert int(ptr[-1]) == int(valid.sum())
+    assert torch.equal(perm[:int(ptr[-1])].long(), want)
+
+
 def _edge_set(row, col):
     return set(zip(row.tolist(), col.tolist()))
 
