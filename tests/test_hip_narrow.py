@@ -225,7 +225,7 @@ def test_local_gate(dev, d, n, max_deg):
 
 
 @pytest.mark.parametrize('d', [16, 32, 64])
-@pytest.mark.parametrize('n', [5, 1000, 2287])
+@pytest.mark.parametrize('n', [5, 1000, 2287, 70001])       # (> 65 536 rows: workgroups take a second row group and add)
 def test_node_tail_and_heads(dev, d, n):
     """The whole node-update tail (10 dense layers, three residual blocks, both heads) as one autograd node against
     the fp64 composition of the reference formulas (layers/global_message_passing.py:39-50)."""
