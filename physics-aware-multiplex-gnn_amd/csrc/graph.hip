@@ -1090,15 +1090,20 @@ extern "C" int pamnet_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_
     return PAMNET_OK;
 }
 
-// more than 64 KB of dynamic LDS has to be asked for once; PAMNET_HIST_LDS=0 keeps the plain kernel (A/B runs)
-static bool hist_lds_ready() {
-    static const bool ok = [] {
+// PAMNET_HIST_LDS=0 keeps the plain kernel (A/B runs).  More than 64 KB of dynamic LDS has to be asked for -- per launch, not
+// once per process: the attribute belongs to the device the call runs on (a process may drive several).
+static bool hist_lds_enabled() {
+    static const bool on = [] {
         const char* e = getenv("PAMNET_HIST_LDS");
-        if (e && e[0] == '0') return false;
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(hist_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(sizeof(int32_t) * HIST_LDS_MAX_ROWS)) == hipSuccess;
+        return !(e && e[0] == '0');
     }();
-    return ok;
+    return on;
+}
+static bool hist_lds_ready(size_t bytes) {
+    if (!hist_lds_enabled()) return false;
+    if (bytes <= 64 * 1024) return true;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(hist_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes) == hipSuccess;
 }
 
 static int csr_from_keys(const int32_t* keys, int64_t m, int64_t rows, int32_t* ptr, int32_t* perm, int32_t* cursor,
@@ -1117,7 +1122,7 @@ static int csr_from_keys(const int32_t* keys, int64_t m, int64_t rows, int32_t* 
         if (e != hipSuccess) return (int)e;
     }
     if (m > 0) {
-        if (m >= HIST_LDS_MIN_KEYS && rows <= HIST_LDS_MAX_ROWS && hist_lds_ready()) {
+        if (m >= HIST_LDS_MIN_KEYS && rows <= HIST_LDS_MAX_ROWS && hist_lds_ready(sizeof(int32_t) * (size_t)rows)) {
             const int64_t per = (int64_t)HIST_LDS_THREADS * HIST_LDS_PER_THREAD;
             hipLaunchKernelGGL(hist_lds_kernel, dim3((unsigned)((m + per - 1) / per)), dim3(HIST_LDS_THREADS),
                                sizeof(int32_t) * (size_t)rows, st, keys, m, (int)rows, cursor, unsorted, perm);
