@@ -252,7 +252,8 @@ typedef struct pamnet_graph_desc {
     const void* edge_dst;
     int32_t schema, batch_kind, types_kind, edge_kind;
     int32_t with_triplets;        /* 0: pairs only (PAMNet_s) */
-    int32_t need_grad;            /* 1: also build the transposed index lists the backward gathers with */
+    int32_t need_grad;            /* 1: also build the transposed index lists the backward gathers with, and the two index hops of
+                                     the dim-128 engine's local aggregation backward (TT_EDGE / TT_NODE); 2: the lists only */
     int32_t aggregate_at_query;   /* RNA: flow == 'target_to_source' (the global layer aggregates at the kNN query) */
     int32_t knn_k;                /* RNA: neighbours per query (models.py:143: 50) */
     float cutoff_l, cutoff_g;

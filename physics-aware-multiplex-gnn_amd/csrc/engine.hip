@@ -128,6 +128,7 @@ inline bool edge_wgrad(const Graph& g) {
     return fits && g.eg >= 256 * 512;
 }
 inline int64_t edge_partial_floats(const Graph& g) {
+    if (!edge_wgrad(g)) return 0;                 // (the plain backward leaves no partial tiles: nothing to reserve)
     int64_t f = 0;
     pamnet_global_edge_agg_wg_floats(g.eg, &f, nullptr);
     return f;

@@ -49,6 +49,15 @@ __device__ __forceinline__ float turns_of(float p) {
     const float e = fmaf(p, INV2PI_HI, -t) + p * INV2PI_LO;
     return (t - rintf(t)) + e;
 }
+// The gradients are then formed from rows that differ from the forward's by the units' absolute error (~1e-6 of the row's
+// scale): bounded against the fp64 oracle at the band edges -- frequency 16 pi, x -> 0 and x -> 1 -- by
+// tests/test_hip_fused.py::test_bessel_gradients_at_the_band_edges (measured worst 2e-6 relative).
+// Build switch -DPAMNET_EXACT_SINCOS: libm's sinf / cosf / sincosf instead (the forward's own floats; ~10x the instructions).
+#ifdef PAMNET_EXACT_SINCOS
+__device__ __forceinline__ float sin_turns(float p) { return sinf(p); }
+__device__ __forceinline__ float cos_turns(float p) { return cosf(p); }
+__device__ __forceinline__ void sincos_turns(float p, float* sn, float* cs) { sincosf(p, sn, cs); }
+#else
 __device__ __forceinline__ float sin_turns(float p) { return __builtin_amdgcn_sinf(turns_of(p)); }
 __device__ __forceinline__ float cos_turns(float p) { return __builtin_amdgcn_cosf(turns_of(p)); }
 __device__ __forceinline__ void sincos_turns(float p, float* sn, float* cs) {
@@ -56,6 +65,7 @@ __device__ __forceinline__ void sincos_turns(float p, float* sn, float* cs) {
     *sn = __builtin_amdgcn_sinf(f);
     *cs = __builtin_amdgcn_cosf(f);
 }
+#endif
 
 // ---- fp32-accurate GEMMs on the bf16 matrix pipe ("bf16x6") -----------------------------------------------------------
 // The f32-input MFMA runs at the fp32 VECTOR rate (64 FLOP/clk/SIMD: 32 cycles per 16x16x4) and shares the issue port

@@ -1102,8 +1102,13 @@ static bool hist_lds_enabled() {
 static bool hist_lds_ready(size_t bytes) {
     if (!hist_lds_enabled()) return false;
     if (bytes <= 64 * 1024) return true;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(hist_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)bytes) == hipSuccess;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(hist_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) == hipSuccess)
+        return true;
+    // a device without that much LDS: the caller takes the plain kernel.  The refused call leaves HIP's sticky "last error"
+    // set, and the launch check behind the plain kernel would report it as that launch's failure -- clear it here.
+    (void)hipGetLastError();
+    return false;
 }
 
 static int csr_from_keys(const int32_t* keys, int64_t m, int64_t rows, int32_t* ptr, int32_t* perm, int32_t* cursor,

@@ -332,8 +332,9 @@ int run(Run& r) {
     }
 
     // the local aggregation's backward gathers through tT_perm -> t_row -> l_row: both hops once per graph
+    // (need_grad == 2: the consumer is the narrow-width engine, which reads neither -- no launch, no 2 tp ints)
     int64_t tT_edge = -1, tT_node = -1;
-    if (grad && tT_perm >= 0 && tp > 0) {
+    if (d.need_grad == 1 && tT_perm >= 0 && tp > 0) {
         tT_edge = r.take(tp), tT_node = r.take(tp);
         GO(pamnet_triplet_transpose_aux_i32(r.I(tT_perm), r.I(t_row), r.I(l_row), tp, r.I(tT_edge), r.I(tT_node), r.stream));
     }

@@ -154,6 +154,23 @@ class _LazyLayers(object):
 ENGINE_WIDTHS = (16, 32, 64, 128)       # widths with hand-written kernel families (narrow engine: 16 / 32 / 64; fused: 128)
 
 
+def _rng_snapshot():
+    """(cpu_state, [device states]) of torch's global generators; the device part only when a HIP context exists already
+    (asking for it would create one)."""
+    dev = None
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        dev = [torch.cuda.get_rng_state(i) for i in range(torch.cuda.device_count())]
+    return torch.get_rng_state(), dev
+
+
+def _rng_restore(snap):
+    cpu, dev = snap
+    torch.set_rng_state(cpu)
+    if dev is not None:
+        for i, st in enumerate(dev):
+            torch.cuda.set_rng_state(st, i)
+
+
 def engine_width(dim):
     """The kernel width a model of hidden size `dim` runs at: the smallest engine width >= dim; above 128 (the layer-by-layer
     path on csrc/dense.hip) the next multiple of 4 -- 16-byte vector lanes of the gather / segment kernels -- with the same
@@ -190,7 +207,10 @@ class _PAMNetBase(nn.Module):
         if self.config_dim < 1:
             raise ValueError('dim must be positive')
         # (RNG state at construction: _finish_padding rewinds to it so that a padded model draws what the unpadded one would)
-        self.__dict__['_rng_at_ctor'] = torch.get_rng_state() if (_pad and self.dim != self.config_dim) else None
+        # CPU generator and, when a HIP context is live, the generators of every visible device: under
+        # torch.set_default_device('cuda') / a device context the parameters are drawn from the device's generator.
+        # Caveat: draws a SUBCLASS constructor makes between this point and _finish_padding are replayed as well.
+        self.__dict__['_rng_at_ctor'] = _rng_snapshot() if (_pad and self.dim != self.config_dim) else None
         self._rna = self.dataset[:3].lower() == 'rna'
         self.__dict__['_pending_checks'] = []            # device flag words of forwards that ran without a host round trip
         self.__dict__['_ctor'] = (config, num_spherical, num_radial, envelope_exponent)
@@ -273,7 +293,7 @@ class _PAMNetBase(nn.Module):
         # seed (the padded model's own init() above drew values that are overwritten below): seed-for-seed the same initial
         # weights as at an engine width, and the stream is left where the unpadded construction leaves it.
         if self.__dict__.get('_rng_at_ctor') is not None:
-            torch.set_rng_state(self.__dict__.pop('_rng_at_ctor'))
+            _rng_restore(self.__dict__.pop('_rng_at_ctor'))
         base = PAMNet_s if self.small else PAMNet         # (explicit class: a subclass may have another constructor)
         twin = base(*self._ctor, _pad=False)
         tsd = twin.state_dict()
@@ -354,7 +374,7 @@ class _PAMNetBase(nn.Module):
                           need_grad=torch.is_grad_enabled(), with_triplets=not self.small,
                           n_types=self.embeddings.size(0) if hasattr(self, 'embeddings') else None,
                           sizes=self._sizes_of(data), default_basis=self.sbf.default, mol_local=self._mol_local_of(data),
-                          max_num_neighbors=self.max_num_neighbors)
+                          max_num_neighbors=self.max_num_neighbors, aux_tables=self.dim == fused.D)
         if g.check is not None:                          # zero-host-sync path: the flag word waits for verify()
             self._pending_checks.append(g.check)
         g.need_grad = torch.is_grad_enabled()
@@ -414,7 +434,7 @@ class _PAMNetBase(nn.Module):
         if self.dataset == 'PDBbind':
             xr = x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw
             feats = xr[:, 3:].to(torch.float32)
-            if modules.IMPL == 'fused' and fused.embed_supported(feats, self.init_linear):
+            if fused.embed_supported(feats, self.init_linear):
                 return fused.embed(feats, self.init_linear, act=False, tape=tape)          # models.py:119
             return ops.plain_linear(feats.contiguous(), self.init_linear.weight, tape=tape)
         col = x_raw if self.dataset == 'QM9' else (x_raw.unsqueeze(-1) if x_raw.dim() == 1 else x_raw)[:, -1]
@@ -447,13 +467,13 @@ class _PAMNetBase(nn.Module):
         return e_l, e_g, sbf
 
     def _narrow(self, x):
-        return modules.IMPL == 'fused' and narrow.supported(x, self.dim)
+        return narrow.supported(x, self.dim)
 
     def _input_stage(self, data, g, tape, lin_a, lin_b=None):
         """(x, e_l, e_g, e_sbf) of models.py:107/119/140 and 185-188 as ONE launch (two in the backward) on the dim = 128
         path: the Bessel rows are formed inside the embedding kernel from the edge lengths, the type-table rows ride along.
         lin_a (, lin_b): the sbf embedding(s) -- with lin_b, rows of g.tp_kind == 1 use lin_b.  None when not applicable."""
-        if not (modules.IMPL == 'fused' and self.dim == fused.D and g.sbf.is_cuda and self.sbf.default):
+        if not (self.dim == fused.D and g.sbf.is_cuda and self.sbf.default):
             return None                               # (the one-launch input stage is built for the default basis)
         lin_l, lin_g = self.mlp_rbf_l[0][0], self.mlp_rbf_g[0][0]
         layers = [(None, g.dist_l, self.cutoff_l, None, True, True), (None, g.dist_g, self.cutoff_g, None, True, True),
@@ -481,7 +501,7 @@ class _PAMNetBase(nn.Module):
 
     @staticmethod
     def _embed_fused(x, seq):
-        return modules.IMPL == 'fused' and len(seq) == 1 and fused.embed_supported(x, seq[0][0])
+        return len(seq) == 1 and fused.embed_supported(x, seq[0][0])
 
     def _run_layers(self, x, e_l, e_g, e_sbf, g, tape=None):
         if modules._fused(x):                      # dim = 128 on an MI355X: the whole loop is one engine call
@@ -510,7 +530,7 @@ class _PAMNetBase(nn.Module):
     def _one_node(self):
         """Training forward with preallocated gradients (train.FlatParams) on the fused dim = 128 path or the narrow-width
         row kernels: the whole forward is recorded on the model's own tape and handed to autograd as ONE node (ops.Tape)."""
-        if not (ops.TAPE and torch.is_grad_enabled() and modules.IMPL == 'fused' and self.rbf_g.freq.is_cuda):
+        if not (ops.TAPE and torch.is_grad_enabled() and self.rbf_g.freq.is_cuda):
             return False
         if self.dim == fused.D:
             if not all(getattr(p, '_pamnet_direct', False) and p.grad is not None for p in self._top_params()):

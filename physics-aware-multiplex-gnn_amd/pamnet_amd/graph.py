@@ -511,7 +511,7 @@ _SCHEMA = {'QM9': 0, 'PDBbind': 1, 'rna': 2}
 
 
 def _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_index, n_graphs, need_grad, knn_k,
-                  with_triplets, n_types, sizes, default_basis=True, mol_local=False, max_nb=0):
+                  with_triplets, n_types, sizes, default_basis=True, mol_local=False, max_nb=0, aux_tables=True):
     """The zero-host-sync graph as one engine call, or None when this batch does not qualify (empty lists, layouts the
     ingest launch does not read): the step-by-step path below then builds it."""
     import ctypes
@@ -524,7 +524,8 @@ def _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_ind
     d = lib.GraphDesc()
     d.n, d.n_graphs, d.eg, d.el, d.tp = n, int(n_graphs), eg, el, tp
     d.batch, d.batch_kind = batch.data_ptr(), _KINDS[batch.dtype]
-    d.with_triplets, d.need_grad, d.knn_k = (1 if with_triplets else 0), (1 if need_grad else 0), int(knn_k)
+    d.with_triplets, d.knn_k = (1 if with_triplets else 0), int(knn_k)
+    d.need_grad = (1 if aux_tables else 2) if need_grad else 0          # 2: transposed lists without the dim-128 engine's aux tables
     d.cutoff_l, d.cutoff_g = float(cutoff_l), float(cutoff_g)
     d.max_neighbors = int(max_nb)
     d.n_types = int(n_types or 0)
@@ -666,7 +667,7 @@ def _mol_local_graph(g, pos, ing, cutoff_g, with_triplets, need_grad):
 
 def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_index=None, num_graphs=None,
                 need_grad=True, knn_k=None, with_triplets=True, n_types=None, sizes=None, default_basis=True, mol_local=None,
-                max_num_neighbors=None):
+                max_num_neighbors=None, aux_tables=True):
     """Graph-construction part of PAMNet.forward (models.py:104-177).  Returns a Graph.
 
     `sizes`: (global edges, local edges, triplet + pair rows) of this batch as host integers -- what a batch collated by
@@ -683,7 +684,10 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
     `max_num_neighbors`: the cap of the reference's radius searches (models.py:110,128: 1000; :301: 500; None = no cap).  It
     binds only in graphs with more than that many nodes within cutoff_g of one node; the count pass notes it in the flag
     word, and such a batch is built with the capped -- no longer symmetric -- global graph and general transposes (plain
-    tensors), or flagged (a batch carrying `sizes`: the one-call graph assumes symmetric radius graphs)."""
+    tensors), or flagged (a batch carrying `sizes`: the one-call graph assumes symmetric radius graphs).
+
+    `aux_tables`: also make what only the dim = 128 layer engine reads (the node-aligned work split of its fused global-edge
+    kernels, the two index hops of its local aggregation's backward); a model of a narrow width passes False."""
     dev = batch.device
     max_nb = int(max_num_neighbors or 0)
     capped = False
@@ -692,7 +696,8 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         raise ValueError('host-side sizes (store.MoleculeStore) are counted for k = %d neighbours; got knn_k = %d' % (KNN_K, knn_k))
     if sizes is not None and num_graphs is not None:
         eng = _engine_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos, edge_index, num_graphs, need_grad, knn_k,
-                            with_triplets, n_types, sizes, default_basis, mol_local=bool(mol_local), max_nb=max_nb)
+                            with_triplets, n_types, sizes, default_basis, mol_local=bool(mol_local), max_nb=max_nb,
+                            aux_tables=aux_tables)
         if eng is not None:
             return eng
     g = Graph()
@@ -749,7 +754,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
                 and (mol_local is True or n <= MOL_ATOMS * g.n_graphs // 2)):
             done = _mol_local_graph(g, pos, ing, cutoff_g, with_triplets, need_grad)
             if done:
-                return _with_seg_cuts(g, dataset)
+                return _with_seg_cuts(g, dataset) if aux_tables else g
         lp, l_src, l_dst, tp_ptr = bonds(ei, None if ing is None else (ing[3], ing[4]))
         if ing is not None:                       # validity and self loops were noted by the ingest launch
             flag, kept = ing[5], ing[6]           # (`kept`: non-zero = NOT all kept; read through _kept below)
@@ -918,7 +923,7 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
         # d m_neighbor[e'] of the triplet/pair gather
         g.tp_T = (TripletTranspose(g.loc, g.loc_T, tp_ptr, tcount, tot, with_triplets, zeroed=hinted) if (e_l > 0 and tot > 0)
                   else Transpose(tp_idx, max(e_l, 1)))
-    return _with_seg_cuts(g, dataset)
+    return _with_seg_cuts(g, dataset) if aux_tables else g
 
 
 def _with_seg_cuts(g, dataset):

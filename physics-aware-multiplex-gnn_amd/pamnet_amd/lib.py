@@ -56,6 +56,11 @@ def load():
         if got != want:
             raise RuntimeError('libpamnet_hip.so was built for ABI version %d, include/pamnet_hip.h declares %d: rebuild '
                                '(python __graft_entry__.py)' % (got, want))
+        if os.environ.get('PAMNET_HIP_LIB'):
+            # a developer switch must never be silent: the ABI number does not tell two builds of the same ABI apart
+            import warnings
+            warnings.warn('pamnet_amd: PAMNET_HIP_LIB is set -- kernels come from %s (ABI %d), not from the in-tree build %s'
+                          % (LIB_PATH, got, os.path.join(HERE, 'libpamnet_hip.so')), RuntimeWarning, stacklevel=2)
         _lib = lib
     return _lib
 

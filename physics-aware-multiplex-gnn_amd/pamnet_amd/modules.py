@@ -13,46 +13,39 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
-
-import os
+import torch.nn.functional as F     # (elementwise SiLU between two kernels of the dim > 128 formulation only)
 
 from . import fused, narrow, ops
 
-# 'fused': fp32-MFMA chain kernels for dim = 128, row kernels for dim = 16 / 32 / 64; every other dim <= 128 is built
-# zero-padded at the next of these widths (models._PAMNetBase), so it runs the same engines.  Only widths above 128 reach the
-# generic formulation below: one launch per dense layer on the any-width GEMM kernels of csrc/dense.hip (ops.dense: bf16x6
-# MFMA, bias + SiLU in the epilogue, SiLU' while staging the backward's operand) between the HIP graph / basis / segment
-# kernels -- no library GEMM in the product.  Not configurable at run time: the kernel tests (tests/test_hip_fused.py) flip
-# this module attribute to anything else to get the same formulation on torch's own dense ops (F.linear / F.silu) as their
-# plain-PyTorch fp32 comparand.
-IMPL = 'fused'
-
-
-def _own(x):
-    # (a float64 twin of a layer -- the kernel tests' fp64 comparand -- stays on torch's dense ops)
-    return IMPL == 'fused' and x.is_cuda and x.dtype == torch.float32
+# dim = 128: fp32-MFMA / bf16x6 chain kernels; dim = 16 / 32 / 64: row kernels; every other dim <= 128 is built zero-padded at
+# the next of these widths (models._PAMNetBase), so it runs the same engines.  Only widths above 128 reach the generic
+# formulation below: one launch per dense layer on the any-width GEMM kernels of csrc/dense.hip (ops.dense: bf16x6 MFMA, bias +
+# SiLU in the epilogue, SiLU' while staging the backward's operand) between the HIP graph / basis / segment kernels -- no
+# library GEMM, no torch dense op: every path of this module ends in libpamnet_hip.so and raises on anything that is not an fp32
+# HIP tensor (lib.stream_of).  The plain-PyTorch statement of the same layers that the kernel tests compare against lives with
+# the tests (tests/torch_formulation.py).
 
 
 def linear(x, w, b=None):
-    """x w^T + b: the any-width GEMM kernel, or (test comparand) torch's."""
-    return ops.dense(x, w, b, act=False) if _own(x) else F.linear(x, w, b)
+    """x w^T + b on the any-width GEMM kernel."""
+    return ops.dense(x, w, b, act=False)
 
 
 def _fused(x):
-    return IMPL == 'fused' and x.is_cuda and x.size(-1) == fused.D
+    return x.is_cuda and x.size(-1) == fused.D
 
 
 def _narrow(x):
     """dim 16 / 32 / 64 on an MI355X: row kernels of csrc/narrow.hip for everything of edge / triplet size."""
-    return IMPL == 'fused' and narrow.supported(x, x.size(-1))
+    return narrow.supported(x, x.size(-1))
 
 
 class Act(nn.Module):
-    """x * sigmoid(x) (layers/basic.py:11-16); parameter-free placeholder keeping the `.0` / `.1` key structure."""
+    """x * sigmoid(x) (layers/basic.py:11-16); parameter-free placeholder keeping the `.0` / `.1` key structure (the SiLU
+    itself is computed in the epilogue of the kernel that runs the enclosing block)."""
 
     def forward(self, x):
-        return F.silu(x)
+        raise RuntimeError('pamnet_amd: the activation is fused into the dense kernel of its block; call the model / layer')
 
 
 def MLP(channels):
@@ -91,9 +84,7 @@ def glorot_(t):
 def dense(block, x):
     """One `Sequential(Linear, SiLU)` block."""
     lin = block[0]
-    if _own(x):
-        return ops.dense(x, lin.weight, lin.bias, act=True)
-    return F.silu(F.linear(x, lin.weight, lin.bias))
+    return ops.dense(x, lin.weight, lin.bias, act=True)
 
 
 def mlp_apply(seq, x):
@@ -117,13 +108,9 @@ def update_and_heads(layer, x, res_x):
     x = res_apply(layer.res2, x)
     x = res_apply(layer.res3, x)
     o = mlp_apply(layer.mlp_out, x)
-    if _own(o):                                               # both heads as one [N, 2] product: W_out o + b | W^T o
-        b_out = layer.W_out.bias
-        h = ops.dense(o, torch.cat([layer.W_out.weight, layer.W.t()], 0), torch.cat([b_out, torch.zeros_like(b_out)]))
-        return x, h[:, 0].contiguous(), h[:, 1].contiguous()
-    att = (o @ layer.W).view(-1)
-    out = F.linear(o, layer.W_out.weight, layer.W_out.bias).view(-1)
-    return x, out, att
+    b_out = layer.W_out.bias                                  # both heads as one [N, 2] product: W_out o + b | W^T o
+    h = ops.dense(o, torch.cat([layer.W_out.weight, layer.W.t()], 0), torch.cat([b_out, torch.zeros_like(b_out)]))
+    return x, h[:, 0].contiguous(), h[:, 1].contiguous()
 
 
 class _LayerBase(nn.Module):

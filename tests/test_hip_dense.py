@@ -259,7 +259,7 @@ def test_wide_models_vs_reference_runs(dev, golden, name):
             # cancellation, so it is judged on the scale of its Linear's weight gradient (test_hip_model._check_gradients)
             scale = max(scale, float(grads[k[:-4] + 'weight'].abs().max()))
         e = abs(float(grads[k].double().norm()) - float(l2)) / max(scale, 1e-300)
-        assert e < 1e-4, (k, e)
+        assert e < GRAD_TOL, (k, e)
         worst = max(worst, e)
     for k in g.files:
         if k.startswith('grad64/'):

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from conftest import maxnorm_err
+import torch_formulation as T
 
 pytestmark = pytest.mark.gpu
 D = 128
@@ -21,20 +22,16 @@ def _ok(a, b32, b64, floor=2e-6):
     return e <= max(floor, 2 * f), (e, f)
 
 
-def _run(layer_fn, inputs, params, impl):
-    from pamnet_amd import modules
-    modules.IMPL = impl
-    try:
-        for t in list(inputs) + list(params):
-            t.grad = None
-        outs = layer_fn()
-        gen = torch.Generator().manual_seed(7)
-        w = [torch.randn(o.shape, generator=gen, dtype=torch.float64).to(o.dtype).to(o.device) for o in outs]
-        sum((o * ww).sum() for o, ww in zip(outs, w)).backward()
-        return ([o.detach().clone() for o in outs],
-                [None if t.grad is None else t.grad.detach().clone() for t in list(inputs) + list(params)])
-    finally:
-        modules.IMPL = 'fused'
+def _run(layer_fn, inputs, params):
+    """Outputs and gradients of `layer_fn` (the HIP layer, or its plain-PyTorch statement in tests/torch_formulation.py)."""
+    for t in list(inputs) + list(params):
+        t.grad = None
+    outs = layer_fn()
+    gen = torch.Generator().manual_seed(7)
+    w = [torch.randn(o.shape, generator=gen, dtype=torch.float64).to(o.dtype).to(o.device) for o in outs]
+    sum((o * ww).sum() for o, ww in zip(outs, w)).backward()
+    return ([o.detach().clone() for o in outs],
+            [None if t.grad is None else t.grad.detach().clone() for t in list(inputs) + list(params)])
 
 
 @pytest.mark.parametrize('n', [1, 16, 37, 2286])
@@ -47,14 +44,13 @@ def test_node_tail_and_pre(dev, n):
     r = torch.randn(n, D, device=dev, requires_grad=True)
     for layer in (g32, l32):
         params = [p for p in layer.parameters()]
-        fn = lambda: modules.update_and_heads(layer, x, r)
-        of, gf = _run(fn, [x, r], params, 'fused')
-        ot, gt = _run(fn, [x, r], params, 'torch')
+        of, gf = _run(lambda: modules.update_and_heads(layer, x, r), [x, r], params)
+        ot, gt = _run(lambda: T.update_and_heads(layer, x, r), [x, r], params)
         l64 = type(layer)(D).to(dev).double()
         l64.load_state_dict({k: v.double() for k, v in layer.state_dict().items()})
         x64, r64 = x.detach().double().requires_grad_(), r.detach().double().requires_grad_()
         p64 = [p for p in l64.parameters()]
-        o64, g64 = _run(lambda: modules.update_and_heads(l64, x64, r64), [x64, r64], p64, 'torch')
+        o64, g64 = _run(lambda: T.update_and_heads(l64, x64, r64), [x64, r64], p64)
         names = ['x', 'res_x'] + [k for k, _ in layer.named_parameters()]
         for a, b, c in zip(of, ot, o64):
             ok, info = _ok(a, b, c)
@@ -105,8 +101,9 @@ def test_full_layer_fused_vs_torch_vs_fp64(dev, kind, n_mol):
     ins = [x, e, rbf, sbf]
     params = list(layer.parameters())
     fn = (lambda: layer(x, e, g)) if kind == 'global' else (lambda: layer(x, rbf, sbf, g))
-    of, gf = _run(fn, ins, params, 'fused')
-    ot, gt = _run(fn, ins, params, 'torch')
+    fn_t = (lambda: T.global_forward(layer, x, e, g)) if kind == 'global' else (lambda: T.local_forward(layer, x, rbf, sbf, g))
+    of, gf = _run(fn, ins, params)
+    ot, gt = _run(fn_t, ins, params)
     gen = torch.Generator().manual_seed(7)
     w = [torch.randn(o.shape, generator=gen, dtype=torch.float64) for o in of]
     o64, i64, sd64 = _oracle_layer(kind, layer, g, x, e, rbf, sbf, w)
@@ -122,7 +119,7 @@ def test_full_layer_fused_vs_torch_vs_fp64(dev, kind, n_mol):
         ok, info = _ok(a, b, c, floor=1e-5)
         assert ok, (nm, info)
     # deterministic
-    of2, gf2 = _run(fn, ins, params, 'fused')
+    of2, gf2 = _run(fn, ins, params)
     assert all(torch.equal(a, b) for a, b in zip(of, of2))
     assert all(torch.equal(a, b) for a, b in zip(gf, gf2) if a is not None)
 
@@ -272,6 +269,52 @@ def test_input_stage(dev, sizes, variant):
     assert all(torch.equal(a, p.grad) for a, p in zip(g1, params))
     y = fused.embed(sbf, lin_a, lin_b, kind=kind)
     assert torch.equal(y, outs[2])
+
+
+@pytest.mark.parametrize('width', [128, 16])
+def test_bessel_gradients_at_the_band_edges(dev, width):
+    """the backward of the Bessel-row embeddings recomputes sin / cos on the hardware units (gemm_core.h sin_turns)
+    while the forward keeps sinf.  Bound the weight and frequency gradients against fp64 where that matters most: the highest
+    frequency (16 pi and a trained offset), edge lengths crowded at x -> 0 (the envelope's 1/x pole) and at x -> 1 (the envelope
+    and its derivative vanish: pure cancellation), at the wide (dim 128, embed.hip) and the narrow (dim 16, narrow_core.h) form."""
+    import math
+    import torch.nn as nn
+    import torch.nn.functional as F
+    torch.manual_seed(3 + width)
+    c = 5.0
+    m = 30000
+    x = torch.cat([torch.rand(m // 3) * 0.02 + 1e-3, 1.0 - torch.rand(m // 3) * 0.02, torch.rand(m - 2 * (m // 3))])
+    dist = (x * c).to(dev)
+    freq = nn.Parameter((torch.arange(1, 17, device=dev) * math.pi + 0.05 * torch.randn(16, device=dev)).float())
+    lin = nn.Linear(16, width).to(dev)
+    w = torch.randn(m, width, device=dev, dtype=torch.float64)
+    params = [freq, lin.weight, lin.bias]
+
+    def ref(dtype):
+        f, W, b = (p.detach().to(dtype).requires_grad_(True) for p in params)
+        (F.silu(F.linear(_bessel_rows(dist.to(dtype), f, c), W, b)) * w.to(dtype)).sum().backward()
+        return [f.grad, W.grad, b.grad]
+
+    if width == 128:
+        from pamnet_amd import fused
+        outs = fused.input_stage(fused.InputSpec([(None, dist, c, None, True, True)], None), params)
+        y = outs[0]
+    else:
+        from pamnet_amd import narrow
+        y = narrow.embed_rbf(dist, freq, c, lin)
+    (y * w.float()).sum().backward()
+    g32, g64 = ref(torch.float32), ref(torch.float64)
+    worst = 0.0
+    for name, p, a, b in zip(('freq', 'weight', 'bias'), params, g32, g64):
+        e, floor = maxnorm_err(p.grad.cpu(), b.cpu()), maxnorm_err(a.cpu(), b.cpu())
+        worst = max(worst, e)
+        assert e <= max(1e-5, 2 * floor), (name, e, floor)
+    # the column of the highest frequency on its own scale (not hidden behind the larger low-frequency columns)
+    e16 = maxnorm_err(lin.weight.grad[:, 15].cpu(), g64[1][:, 15].cpu())
+    f16 = abs(float(freq.grad[15]) - float(g64[0][15])) / max(abs(float(g64[0][15])), 1e-300)
+    print('Bessel-row gradients at the band edges (dim %d): worst tensor %.1e, dW[:, n=16] %.1e, dfreq[16] %.1e vs fp64'
+          % (width, worst, e16, f16))
+    assert e16 <= 1e-5 and f16 <= max(1e-5, 2 * abs(float(g32[0][15]) - float(g64[0][15])) / abs(float(g64[0][15])))
 
 
 @pytest.mark.parametrize('waves', ['4', '8'])

@@ -46,13 +46,13 @@ def _ok(a, ref32, ref64, scale=None):
     return e <= max(TOL, 2 * floor), (e, floor)
 
 
-GRAD_TOL = 1e-4          # gradients within 1e-4 of the reference's fp64 autograd ...
+GRAD_TOL = 1e-5          # gradients within 1e-5 of the reference's fp64 autograd (measured worst: 4e-7) ...
 
 
 def _check_gradients(model, p64, fwd, sd, cfg, b, report=None, head_bias_terms=None):
     """Every parameter gradient of the HIP backward against the oracle's fp64 autograd (p64[k].grad already filled):
         err(hip, fp64) <= max(GRAD_TOL, 2 * err(oracle_fp32, fp64))
-    -- the 1e-4 of DESIGN.md, never tighter than what the reference's OWN fp32 backward achieves on the same inputs
+    -- the 1e-5 of DESIGN.md (round 6: tightened from 1e-4), never tighter than what the reference's OWN fp32 backward achieves on the same inputs
     (its sympy closed forms and the signed PDBbind pooling cancel catastrophically for a few tensors; the fp32 oracle
     is run here to measure exactly that floor instead of hard-coding a looser bound)."""
     p32 = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
@@ -822,7 +822,7 @@ def test_trainer_step_path_at_configs1_vs_oracle_and_reference(dev, golden):
     worst_l2 = 0.0
     for k, l2 in zip(keys, g['grad_l2_64']):
         e = abs(float(grads[k].double().norm()) - float(l2)) / max(float(l2), 1e-300)
-        assert e < 1e-4, (k, e)
+        assert e < GRAD_TOL, (k, e)
         worst_l2 = max(worst_l2, e)
     worst_t = 0.0
     for k in g.files:
