@@ -52,6 +52,9 @@ def parse():
     ap.add_argument('--share-gpu', action='store_true',
                     help='NOT a measurement: all ranks on cuda:0 with gloo as the transport -- the whole N > 1 flow of the real '
                          'model (shards, bucketed overlapped all-reduce, exposed-communication probe) on a 1-GPU box')
+    ap.add_argument('--n1-ms', type=float, default=None,
+                    help='ms/step of the N = 1 run of the same command: the line then carries comm.efficiency_vs_n1 (weak scaling)')
+    ap.add_argument('--init-timeout', type=float, default=60.0, help='seconds the process-group rendezvous may take')
     ap.add_argument('--cpu-dry-run', action='store_true',
                     help='NOT a measurement: exercise the multi-rank control flow (sharding, barriers, max-over-ranks '
                          'timing, gradient all-reduce) on CPU with the gloo backend and a stand-in module (tests/standin.py)')
@@ -538,6 +541,56 @@ def reference_loop_unchanged(dev, args, batches):
                     'clip_grad_norm_, utils.EMA; no Trainer, no flat buffers, no input pipeline'}
 
 
+def init_group(backend, args, **kw):
+    """dist.init_process_group with a bounded rendezvous and a ONE-LINE diagnosis instead of a hang or a traceback wall: nobody
+    can run the N > 1 RCCL path before the driver does, so whatever goes wrong there has to explain itself."""
+    import datetime
+    try:
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=args.init_timeout), **kw)
+    except Exception as e:                                              # noqa: BLE001 -- reported, then fatal
+        sys.exit('bench.py: %s process group did not form within %.0f s (RANK=%s WORLD_SIZE=%s MASTER_ADDR=%s MASTER_PORT=%s '
+                 'LOCAL_RANK=%s HSA_ENABLE_IPC_MODE_LEGACY=%s visible devices=%d): %s: %s'
+                 % (backend, args.init_timeout, os.environ.get('RANK'), os.environ.get('WORLD_SIZE'),
+                    os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT'), os.environ.get('LOCAL_RANK'),
+                    os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'), torch.cuda.device_count() if torch.cuda.is_available() else 0,
+                    type(e).__name__, str(e).splitlines()[0] if str(e) else ''))
+
+
+def describe_ranks(args, world, rank, dev, dry):
+    """Who is in the job: every rank's process, device index, PCI address and device name, gathered over the process group the
+    step uses; a one-element all-reduce over the same group counts the ranks the transport really reaches.  Fails loudly when
+    the group is not what --gpus promised: wrong size, a rank that did not get a device of its own, a sum that is not N."""
+    import socket
+    info = {'rank': rank, 'pid': os.getpid(), 'host': socket.gethostname(), 'local_rank': int(os.environ.get('LOCAL_RANK', '0'))}
+    if not dry:
+        pr = torch.cuda.get_device_properties(dev)
+        info['device'] = int(torch.cuda.current_device())
+        info['name'] = pr.name
+        bus = [getattr(pr, k, None) for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id')]
+        info['pci'] = ('%04x:%02x:%02x' % tuple(bus)) if all(b is not None for b in bus) else None
+        info['uuid'] = str(getattr(pr, 'uuid', '')) or None
+    got = dist.get_world_size()
+    if got != args.gpus:
+        sys.exit('bench.py: the process group has %d ranks, --gpus says %d' % (got, args.gpus))
+    everyone = [None] * world
+    dist.all_gather_object(everyone, info)
+    one = torch.ones(1, device=dev, dtype=torch.float32)
+    dist.all_reduce(one)
+    if int(one.item()) != world:
+        sys.exit('bench.py: an all-reduce of ones over %d ranks returned %s' % (world, one.item()))
+    backend = dist.get_backend()
+    if not dry and not args.share_gpu:
+        if backend != 'nccl':
+            sys.exit('bench.py: backend is %s, expected nccl (= RCCL on ROCm)' % backend)
+        ids = [(e['host'], e['pci'] or e['uuid'] or e['device']) for e in everyone]
+        if len(set(ids)) != world:
+            sys.exit('bench.py: %d ranks but only %d distinct devices: %s (one rank per GPU is the contract; --share-gpu is the '
+                     'explicit flow check on one device)' % (world, len(set(ids)), ids))
+    return {'backend': backend + (' (RCCL)' if backend == 'nccl' else ''), 'rccl_ranks': got if backend == 'nccl' else 0,
+            'ranks': got, 'allreduce_of_ones': int(one.item()),
+            'devices': [{k: e.get(k) for k in ('rank', 'host', 'pid', 'device', 'pci', 'name')} for e in everyone]}
+
+
 def guarded(fn, *a):
     """A side leg of the line: its failure is reported in its field, the line is still printed."""
     try:
@@ -568,7 +621,7 @@ def main():
         dev = torch.device('cpu')
         if world > 1:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            dist.init_process_group('gloo')
+            init_group('gloo', args)
     else:
         if args.share_gpu:
             local_rank = 0
@@ -577,11 +630,15 @@ def main():
         if world > 1:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             if args.share_gpu:
-                dist.init_process_group('gloo')
+                init_group('gloo', args)
             else:
-                dist.init_process_group('nccl', device_id=dev)
+                if local_rank >= torch.cuda.device_count():
+                    sys.exit('bench.py: LOCAL_RANK=%d but %d devices are visible' % (local_rank, torch.cuda.device_count()))
+                init_group('nccl', args, device_id=dev)
         elif args.force_comm:
             dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29517', rank=0, world_size=1, device_id=dev)
+
+    who = describe_ranks(args, world, rank, dev, dry) if world > 1 else None
 
     from pamnet_amd import synth
     from pamnet_amd.train import Trainer, shard_range
@@ -646,7 +703,12 @@ def main():
         spread = {'p10': q(0.10), 'p50': q(0.50), 'p90': q(0.90), 'max': per[-1],
                   'note': 'ms between consecutive per-step HIP events inside the timed region'}
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    per_rank_ms = None
     if world > 1:
+        mine = t / args.steps * 1e3
+        each = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(each, mine)
+        per_rank_ms = [float(v[0]) for v in each]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t[0])
     ms_per_step = dt / args.steps * 1e3
@@ -676,12 +738,23 @@ def main():
                    'gradient_bytes': int(trainer.fp.grad.numel()) * 4,
                    'note': 'step time with minus without sync_gradients(), max over ranks, %d steps' % ksteps}
 
+    comm = None
+    if world > 1 or exposed is not None:
+        comm = dict(exposed or {})
+        if who is not None:
+            comm.update(who)
+        if per_rank_ms is not None:
+            comm['per_rank_ms_per_step'] = {'min': min(per_rank_ms), 'max': max(per_rank_ms), 'all': per_rank_ms}
+        if args.n1_ms:
+            # weak scaling: per-GPU work is fixed, so the ideal N-rank step takes the N = 1 step's time
+            comm['efficiency_vs_n1'] = args.n1_ms / ms_per_step
+            comm['n1_ms_per_step'] = args.n1_ms
     if dry:
         if rank == 0:
             line = {'metric': 'DRY RUN on CPU with a stand-in module -- control-flow check, NOT a measurement',
                     'value': value, 'unit': 'molecules/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                     'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-                    'dtype': 'f32', 'data': 'synthetic', 'dry_run': True,
+                    'dtype': 'f32', 'data': 'synthetic', 'dry_run': True, 'comm': comm,
                     'config': {'workload': 'cpu dry run, %d molecules/rank' % B, 'global_batch': gB,
                                'parallelism': 'dp%d (molecule-sharded, gloo all-reduce of flat grad)' % world}}
             result_out.write(json.dumps(line) + '\n')
@@ -815,7 +888,7 @@ def main():
                        'global_batch': gB, 'parallelism': 'dp%d (molecule-sharded, RCCL all-reduce of flat grad)' % world,
                        'nodes_per_batch': int(g.n), 'global_edges': int(g.glob.m), 'local_edges': int(g.loc.m),
                        'triplets': int(g.n_trip), 'pairs': int(g.n_pair)},
-            'timed_region_s': dt, 'step_ms_spread': spread, 'comm': exposed,
+            'timed_region_s': dt, 'step_ms_spread': spread, 'comm': comm,
             'forward_only_molecules_per_s': gB / (fwd_ms / 1e3), 'forward_ms': fwd_ms,
             'forward_ms_unpipelined': fwd_plain_ms,
             'zero_host_sync': zero_sync,

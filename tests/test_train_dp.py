@@ -376,6 +376,32 @@ def test_bench_world2_dry_run_on_cpu():
     j = json.loads(lines[0])
     assert j['dry_run'] is True and j['n_gpus'] == 2 and j['steps'] == 3 and j['config']['global_batch'] == 16
     assert j['scaling'] == 'weak' and j['value'] > 0 and abs(j['value'] - 16 * 3 / (j['ms_per_step'] * 3e-3)) < 1e-6 * j['value']
+    # the line says by itself who was in the job (round 6): the ranks the transport reached, one entry per rank, per-rank times
+    c = j['comm']
+    assert c['ranks'] == 2 and c['allreduce_of_ones'] == 2 and c['backend'] == 'gloo' and c['rccl_ranks'] == 0
+    assert sorted(d['rank'] for d in c['devices']) == [0, 1] and len({d['pid'] for d in c['devices']}) == 2
+    assert len(c['per_rank_ms_per_step']['all']) == 2 and c['per_rank_ms_per_step']['max'] <= j['ms_per_step'] * (1 + 1e-9)
+
+
+def test_bench_multi_rank_reports_efficiency_and_diagnoses_a_missing_peer():
+    """--n1-ms puts the weak-scaling efficiency into the line; a rendezvous that cannot complete (one rank of two launched)
+    ends with a one-line diagnosis inside the init timeout, not a hang."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch-per-gpu', '8', '--n-layer', '3',
+            '--cpu-dry-run']
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port())] + base + ['--n1-ms', '5.0']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert abs(j['comm']['efficiency_vs_n1'] - 5.0 / j['ms_per_step']) < 1e-9 and j['comm']['n1_ms_per_step'] == 5.0
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable] + base + ['--init-timeout', '5'], capture_output=True, text=True, timeout=300, cwd=repo,
+                       env=env)
+    assert r.returncode != 0 and 'process group did not form within 5 s' in r.stderr and 'WORLD_SIZE=2' in r.stderr
 
 
 def test_multistep_lr_helper_equals_torch_scheduler():
@@ -622,6 +648,12 @@ def test_bench_eight_ranks_on_one_gpu_prints_one_line():
     assert j['n_gpus'] == 8 and j['config']['global_batch'] == 128 and j['scaling'] == 'weak' and 'shared_gpu' in j
     assert j['comm'] and j['comm']['buckets'] >= 2
     assert abs(j['value'] - 128 * 3 / (j['ms_per_step'] * 3e-3)) < 1e-6 * j['value']
+    # round 6: the line answers "who was in the job" by itself
+    c = j['comm']
+    assert c['ranks'] == 8 and c['allreduce_of_ones'] == 8 and sorted(d['rank'] for d in c['devices']) == list(range(8))
+    assert len({d['pid'] for d in c['devices']}) == 8 and all(d['pci'] == c['devices'][0]['pci'] for d in c['devices'])
+    assert c['backend'] == 'gloo' and c['rccl_ranks'] == 0          # (shared device: gloo transport, said so)
+    assert len(c['per_rank_ms_per_step']['all']) == 8 and 'allreduce_exposed_ms' in c
 
 
 @pytest.mark.gpu
