@@ -505,40 +505,61 @@ def self_launch(args, result_out):
 
 
 def reference_loop_unchanged(dev, args, batches):
-    """ms per step of the reference's own loop body on the drop-in model (see the call site)."""
+    """main_qm9.py:103-118 verbatim on the HIP model -- no Trainer, no input pipeline -- in both forms of the model's parameter
+    interface: ~390 reference-named tensors (default), and PAMNET_FLAT_PARAMS=1 (ONE flat parameter for optimiser / clip / EMA;
+    state_dict() unchanged; models._FlatView).  Same loop text, same numbers (tests/test_train_golden.py)."""
     import models
     from torch.nn.utils import clip_grad_norm_
     from utils import EMA
-    torch.manual_seed(1234)
-    model = models.PAMNet(models.Config(dataset='QM9', dim=args.dim, n_layer=args.n_layer, cutoff_l=5.0, cutoff_g=5.0)).to(dev)
-    optimizer = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=0, amsgrad=False)
-    ema = EMA(model, decay=0.999)
     nb = len(batches)
-    model.train()
 
-    def step(data):
-        optimizer.zero_grad()
-        output = model(data)
-        loss = torch.nn.functional.l1_loss(output, data.y)
-        loss_item = loss.item() * data.num_graphs              # main_qm9.py:109 (a host read-back per step)
-        loss.backward()
-        clip_grad_norm_(model.parameters(), max_norm=1000, norm_type=2)
-        optimizer.step()
-        ema(model)
-        return loss_item
+    def run(flat):
+        old = os.environ.get('PAMNET_FLAT_PARAMS')
+        os.environ['PAMNET_FLAT_PARAMS'] = '1' if flat else '0'
+        try:
+            torch.manual_seed(1234)
+            model = models.PAMNet(models.Config(dataset='QM9', dim=args.dim, n_layer=args.n_layer, cutoff_l=5.0,
+                                                cutoff_g=5.0)).to(dev)
+            optimizer = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=0, amsgrad=False)
+            ema = EMA(model, decay=0.999)
+            model.train()
 
-    for i in range(5):
-        step(batches[i % nb])
-    torch.cuda.synchronize()
-    n = min(args.steps, 100)
-    t0 = time.perf_counter()
-    for i in range(n):
-        step(batches[i % nb])
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / n * 1e3
-    return {'reference_loop_ms_per_step': ms, 'molecules_per_s': args.batch_per_gpu / (ms / 1e3), 'steps': n,
-            'note': 'main_qm9.py:103-118 verbatim on the HIP model: torch.optim.Adam (per-tensor), loss.item(), autograd backward, '
-                    'clip_grad_norm_, utils.EMA; no Trainer, no flat buffers, no input pipeline'}
+            def step(data):
+                optimizer.zero_grad()
+                output = model(data)
+                loss = torch.nn.functional.l1_loss(output, data.y)
+                loss_item = loss.item() * data.num_graphs              # main_qm9.py:109 (a host read-back per step)
+                loss.backward()
+                clip_grad_norm_(model.parameters(), max_norm=1000, norm_type=2)
+                optimizer.step()
+                ema(model)
+                return loss_item
+
+            for i in range(5):
+                step(batches[i % nb])
+            torch.cuda.synchronize()
+            n = min(args.steps, 100)
+            t0 = time.perf_counter()
+            for i in range(n):
+                step(batches[i % nb])
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3, n, len(list(model.parameters()))
+        finally:
+            if old is None:
+                os.environ.pop('PAMNET_FLAT_PARAMS', None)
+            else:
+                os.environ['PAMNET_FLAT_PARAMS'] = old
+
+    ms, n, n_par = run(False)
+    ms_flat, _, n_flat = run(True)
+    return {'reference_loop_ms_per_step': ms_flat, 'molecules_per_s': args.batch_per_gpu / (ms_flat / 1e3), 'steps': n,
+            'parameters_seen_by_the_loop': n_flat,
+            'per_tensor_interface': {'reference_loop_ms_per_step': ms, 'molecules_per_s': args.batch_per_gpu / (ms / 1e3),
+                                     'parameters_seen_by_the_loop': n_par},
+            'note': 'main_qm9.py:103-118 verbatim on the HIP model: torch.optim.Adam, loss.item(), autograd backward, '
+                    'clip_grad_norm_, utils.EMA; no Trainer, no input pipeline.  Headline of this object: PAMNET_FLAT_PARAMS=1 '
+                    '(model.parameters() is one flat tensor, state_dict() keeps the reference keys); per_tensor_interface: the '
+                    'default (~390 tensors through torch\'s multi-tensor Adam / clip / EMA: host-bound)'}
 
 
 def init_group(backend, args, **kw):

@@ -11,6 +11,7 @@ live on a HIP device -- there is no CPU path (the CPU oracle in oracle/ is test 
 from here).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -154,6 +155,51 @@ class _LazyLayers(object):
 ENGINE_WIDTHS = (16, 32, 64, 128)       # widths with hand-written kernel families (narrow engine: 16 / 32 / 64; fused: 128)
 
 
+FLAT_NAME = 'flat_parameters'
+
+
+class _FlatView(object):
+    """State of the PAMNET_FLAT_PARAMS=1 interface of one model: the flat buffers (train.FlatParams, gradients written in
+    place by the kernels) and the ONE nn.Parameter handed to the caller's optimiser."""
+
+    def __init__(self, model):
+        from pamnet_amd.train import FlatParams
+        self.fp = FlatParams(model, direct=True)
+        self.param = nn.Parameter(self.fp.flat)           # shares the buffer's storage
+        self.param.grad = self.fp.grad
+        self._pending = None
+
+    def valid(self):
+        """Every parameter is still a view of the buffer (model.to(...) / .cpu() re-allocate them: rebuilt on next use)."""
+        fp = self.fp
+        first, last = fp.params[0], fp.params[-1]
+        return (first.is_cuda and first.data_ptr() == fp.flat.data_ptr() + 4 * fp.offsets[fp.names[0]]
+                and last.data_ptr() == fp.flat.data_ptr() + 4 * fp.offsets[fp.names[-1]])
+
+    def before_forward(self):
+        """The kernels OVERWRITE their gradients and a backward starts from a zeroed buffer.  optimizer.zero_grad() (torch
+        >= 2.0: set_to_none) left .grad = None: zero the buffer, nothing else.  A .grad that is still there may hold gradients
+        the caller wants accumulated into (or zeros: zero_grad(set_to_none=False)): set aside, added back after the backward."""
+        if self._pending is not None:                     # the previous forward was never differentiated: undo its zeroing
+            if self._pending[0] == 'own':
+                self.fp.grad.copy_(self._pending[1])
+            self._pending = None
+        g = self.param.grad
+        if g is None:
+            self._pending = ('none', None)
+        elif g.data_ptr() == self.fp.grad.data_ptr():
+            self._pending = ('own', g.clone())
+        else:
+            self._pending = ('other', g)
+        self.fp.grad.zero_()
+
+    def after_backward(self):
+        if self._pending is not None and self._pending[0] != 'none':
+            self.fp.grad.add_(self._pending[1].view(-1))
+        self._pending = None
+        self.param.grad = self.fp.grad
+
+
 def _rng_snapshot():
     """(cpu_state, [device states]) of torch's global generators; the device part only when a HIP context exists already
     (asking for it would create one)."""
@@ -226,6 +272,14 @@ class _PAMNetBase(nn.Module):
         if prefix != '' or not recurse or not remove_duplicate:
             yield from super().named_parameters(prefix, recurse, remove_duplicate)
             return
+        flat = self._flat_view()
+        if flat is not None:                             # PAMNET_FLAT_PARAMS=1: ONE parameter for optimiser / clip / EMA
+            yield (FLAT_NAME, flat.param)
+            return
+        yield from self._real_named_parameters()
+
+    def _real_named_parameters(self):
+        """The ~390 reference-named parameters (the cached walk); what state_dict() and every kernel work on."""
         cache = self.__dict__.get('_named_param_cache')
         if cache is not None and not self.__dict__.get('_params_checked') and not self._param_cache_valid(cache):
             self._drop_param_cache()                     # (the derived lists go with it)
@@ -283,6 +337,44 @@ class _PAMNetBase(nn.Module):
         self._drop_param_cache()
         return out
 
+    # ---- PAMNET_FLAT_PARAMS=1: the reference's loop, unchanged, at a fraction of its host cost -------------------------
+    # main_qm9.py:90-116 hands `model.parameters()` to torch.optim.Adam, clip_grad_norm_ and utils.EMA.  Those are elementwise
+    # (Adam, EMA) or one global norm (clip): over ~390 tensors they cost the HOST 3-4 ms per step (multi-tensor launches,
+    # 390 gradient accumulators in the autograd graph) against a 2 ms step.  With the switch on, parameters() /
+    # named_parameters() yield ONE nn.Parameter -- a flat buffer every reference-named parameter is a view of
+    # (pamnet_amd.train.FlatParams; 256-byte aligned, zero padding that stays zero under Adam) -- with the flat gradient the
+    # kernels write in place as its .grad.  The same numbers come out (Adam / EMA element by element; the norm over the
+    # same elements), state_dict() / load_state_dict() still speak the ~390 reference keys (they walk the modules, not
+    # parameters()), and the whole forward is ONE autograd node.  Opt-in because two things differ from a plain
+    # nn.Module: `sum(p.numel() for p in model.parameters())` counts the padding, and per-tensor options
+    # (parameter groups by name) have nothing to hold on to.
+    def _flat_view(self):
+        if os.environ.get('PAMNET_FLAT_PARAMS', '0') != '1' or self.__dict__.get('_flat_view_off'):
+            return None
+        st = self.__dict__.get('_flat_view_state')
+        if st is not None and st.valid():
+            return st
+        self.__dict__.pop('_flat_view_state', None)
+        real = [p for _, p in self._real_named_parameters()]
+        if not real or not real[0].is_cuda or real[0].dtype != torch.float32 or not all(p.requires_grad for p in real):
+            return None
+        if not (self.dim == fused.D or (self.dim in narrow.WIDTHS and narrow.ENABLED)):
+            return None                                   # (widths without a one-node forward keep the per-tensor interface)
+        st = self.__dict__['_flat_view_state'] = _FlatView(self)
+        return st
+
+    def _disable_flat_view(self):
+        """pamnet_amd.train.Trainer re-homes the parameters in flat buffers of its own."""
+        self.__dict__['_flat_view_off'] = True
+        self.__dict__.pop('_flat_view_state', None)
+
+    def _run_one_node(self, run):
+        """The forward as ONE autograd node (ops.run_whole) on the flat-view parameter when there is one."""
+        st = self.__dict__.get('_flat_view_state')
+        if st is None or not st.valid():
+            return ops.run_whole(self.rbf_g.freq, run)
+        return ops.run_whole(st.param, run, before=st.before_forward, after=st.after_backward)
+
     def _finish_padding(self):
         """Called at the end of the subclass constructors.  A model whose engine width differs from its configured dim gets
         (a) the reference's shapes for the state_dict interface, taken from an unpadded twin, (b) that twin's initial
@@ -320,7 +412,7 @@ class _PAMNetBase(nn.Module):
 
     def logical_mask(self, name, like=None):
         """Bool tensor of parameter `name`'s padded shape: True where a logical (reference-shaped) entry lives."""
-        p = dict(self.named_parameters())[name] if like is None else like
+        p = dict(self._real_named_parameters())[name] if like is None else like
         shape = self.__dict__.get('_logical_shapes', {}).get(name, tuple(p.shape))
         mask = torch.zeros(p.shape, dtype=torch.bool, device=p.device)
         idx = self._pad_index(shape, tuple(p.shape))
@@ -332,7 +424,7 @@ class _PAMNetBase(nn.Module):
         return mask
 
     def _pad_incoming(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
-        own = dict(self.named_parameters())
+        own = dict(self._real_named_parameters())
         own.update(dict(self.named_buffers()))
         for k, shape in self._logical_shapes.items():
             t = state_dict.get(prefix + k)
@@ -564,13 +656,13 @@ class _PAMNetBase(nn.Module):
     def _all_params(self):
         ap = self.__dict__.get('_all_param_list') if self._derived_lists_valid() else None
         if ap is None:
-            ap = self.__dict__['_all_param_list'] = [p for p in self.parameters() if p.requires_grad]
+            ap = self.__dict__['_all_param_list'] = [p for _, p in self._real_named_parameters() if p.requires_grad]
         return ap
 
     def _top_params(self):
         tp = self.__dict__.get('_top_param_list') if self._derived_lists_valid() else None
         if tp is None:                                   # walking the module tree costs ~1 ms: once per model
-            tp = [p for n, p in self.named_parameters() if not n.startswith(('global_layer.', 'local_layer.'))]
+            tp = [p for n, p in self._real_named_parameters() if not n.startswith(('global_layer.', 'local_layer.'))]
             self.__dict__['_top_param_list'] = tp
         return tp
 
@@ -653,7 +745,7 @@ class PAMNet(_PAMNetBase):
         self._release_inspection()
         g = self._graph(data)
         if self._one_node():
-            return ops.run_whole(self.rbf_g.freq, lambda tape: self._forward_on(data, g, tape))
+            return self._run_one_node(lambda tape: self._forward_on(data, g, tape))
         return self._forward_on(data, g, None)
 
     def _forward_on(self, data, g, tape):
@@ -700,7 +792,7 @@ class PAMNet_s(_PAMNetBase):
         self._release_inspection()
         g = self._graph(data)
         if self._one_node():
-            return ops.run_whole(self.rbf_g.freq, lambda tape: self._forward_on(data, g, tape))
+            return self._run_one_node(lambda tape: self._forward_on(data, g, tape))
         return self._forward_on(data, g, None)
 
     def _forward_on(self, data, g, tape):

@@ -136,7 +136,9 @@ class _Whole(torch.autograd.Function):
     autograd record the node; every parameter gradient is written / added in place, so the node returns none."""
 
     @staticmethod
-    def forward(ctx, anchor, run):
+    def forward(ctx, anchor, run, before=None, after=None):
+        if before is not None:               # (models._FlatView: the flat gradient buffer starts zeroed)
+            before()
         tape = Tape()
         stack = _tape_stack_of_thread()
         stack.append(tape)
@@ -144,18 +146,20 @@ class _Whole(torch.autograd.Function):
             out = run(tape)
         finally:
             stack.pop()
-        ctx.tape, ctx.out = tape, out
+        ctx.tape, ctx.out, ctx.after = tape, out, after
         return out.view(-1)                  # a fresh tensor object for autograd; the tape keys on `out` itself
 
     @staticmethod
     def backward(ctx, g):
         ctx.tape.backward(ctx.out, g.contiguous())
-        ctx.tape = ctx.out = None
-        return None, None
+        if ctx.after is not None:            # (models._FlatView: the anchor's .grad is the buffer the kernels wrote)
+            ctx.after()
+        ctx.tape = ctx.out = ctx.after = None
+        return None, None, None, None
 
 
-def run_whole(anchor, run):
-    return _Whole.apply(anchor, run)
+def run_whole(anchor, run, before=None, after=None):
+    return _Whole.apply(anchor, run, before, after)
 
 
 def backward_whole(out, grad):
@@ -169,7 +173,9 @@ def backward_whole(out, grad):
         return False
     with torch.no_grad():
         node.tape.backward(node.out, grad.contiguous())
-    node.tape = node.out = None
+        if getattr(node, 'after', None) is not None:
+            node.after()
+    node.tape = node.out = node.after = None
     return True
 
 

@@ -40,7 +40,8 @@ class FlatParams(object):
     one contiguous slice that can be all-reduced while earlier layers are still being differentiated."""
 
     def __init__(self, module, direct=True):
-        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        # (a models.PAMNet may present ONE flat parameter to its caller -- PAMNET_FLAT_PARAMS=1 --: this takes the real ones)
+        named = [(n, p) for n, p in getattr(module, '_real_named_parameters', module.named_parameters)() if p.requires_grad]
         rank = lambda n: (1, 0) if _layer_of(n) is None else (0, -_layer_of(n))
         named.sort(key=lambda np_: rank(np_[0]))          # stable: declaration order inside a group
         self.params = [p for _, p in named]
@@ -239,6 +240,8 @@ class Trainer(object):
             raise ValueError("loss must be one of 'l1', 'mse', 'smooth_l1' (got %r)" % (loss,))
         self.loss_kind = loss
         self.model = model
+        if hasattr(model, '_disable_flat_view'):
+            model._disable_flat_view()                     # (this class owns the flat buffers; no second interface on top)
         self.fp = FlatParams(model, direct=True)           # fused layers write gradients straight into fp.grad
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         # On the GPU clip + Adam + EMA (+ the next zero_grad) are one pass of csrc/optim.hip over the flat buffers;

