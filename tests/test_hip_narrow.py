@@ -240,13 +240,8 @@ def test_node_tail_and_heads(dev, d, n):
     gx, go, ga = torch.randn_like(xo), torch.randn_like(out), torch.randn_like(att)
     torch.autograd.backward([xo, out, att], [gx, go, ga])
     rx, rres = x.detach().double().requires_grad_(True), res.detach().double().requires_grad_(True)
-    h = modules.mlp_apply(ref.mlp_x2, rx)
-    h = modules.res_apply(ref.res1, h) + rres
-    h = modules.res_apply(ref.res2, h)
-    h = modules.res_apply(ref.res3, h)
-    o = modules.mlp_apply(ref.mlp_out, h)
-    r_att = (o @ ref.W).view(-1)
-    r_out = F.linear(o, ref.W_out.weight, ref.W_out.bias).view(-1)
+    import torch_formulation as T                        # (the plain-PyTorch statement of the tail: tests/torch_formulation.py)
+    h, r_out, r_att = T.update_and_heads(ref, rx, rres)
     torch.autograd.backward([h, r_out, r_att], [gx.double(), go.double(), ga.double()])
     for a, b, nm in ((xo, h, 'x'), (out, r_out, 'out'), (att, r_att, 'att')):
         assert maxnorm_err(a.detach().cpu(), b.detach().cpu()) < TOL, nm
