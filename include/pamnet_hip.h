@@ -34,7 +34,7 @@ typedef void* pamnet_stream_t; /* hipStream_t */
 
 /* Library / ABI version (bumped on any signature change).  pamnet_abi_version() returns the PAMNET_ABI_VERSION the library
  * was built against; a binding compares it with this header's (pamnet_amd/lib.py load(): a stale .so fails loudly). */
-#define PAMNET_ABI_VERSION 10
+#define PAMNET_ABI_VERSION 11
 int pamnet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -523,6 +523,14 @@ int pamnet_global_edge_agg_fwd_f32(const float* e, int64_t n_edges, int64_t n_no
                                    const int32_t* ptr, const int32_t* row_of, const int32_t* col,
                                    const int32_t* cuts /* nullable: pamnet_seg_cuts_i32 */, const float* init, float* z,
                                    float* ea, float* out, pamnet_stream_t stream);
+/* The same operator with the two halves of every workgroup in opposite phases (matrix pipe beside vector units: the form
+ * pamnet_global_edge_agg_fwd_f32 takes by itself from 131 072 edges; PAMNET_AGG_PP=0/1 forces either).  Same arguments, the
+ * same results bit for bit, whatever the size. */
+int pamnet_global_edge_agg_fwd_pp_f32(const float* e, int64_t n_edges, int64_t n_nodes, const float* We, int64_t ld_we,
+                                      const float* bm, const float* Wea, int64_t ld_wea, const float* Pi, const float* Pj,
+                                      const int32_t* ptr, const int32_t* row_of, const int32_t* col,
+                                      const int32_t* cuts /* nullable */, const float* init, float* z, float* ea, float* out,
+                                      pamnet_stream_t stream);
 /* cuts[0 .. G] = the node-aligned work split of the fused kernels for this graph (node boundary nearest to edge row
  * k * n_edges / G), G = *grid_out <= 256: computed once per graph, handed to every pamnet_global_edge_agg_fwd_f32 launch
  * (without it every workgroup derives its cuts itself: two dependent loads ahead of everything else). */

@@ -56,7 +56,17 @@ extern "C" int pamnet_agg_probe_read(long long* host64, long long* wg, int n) {
     if (rc) return rc;
     return (int)hipMemcpyFromSymbol(wg, HIP_SYMBOL(pamnet_agg_probe_wg), sizeof(long long) * 2 * n);
 }
+// the ping-pong kernel: five stamps per wave (slots [8 wave, 8 wave + 5)) in iteration PAMNET_PROBE_T of the middle workgroup
+#ifndef PAMNET_PROBE_T
+#define PAMNET_PROBE_T 20
+#endif
+#define PPROBE(i, t)                                                                                                    \
+    do {                                                                                                                \
+        if (blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0 && (t) == PAMNET_PROBE_T)                            \
+            pamnet_agg_probe[8 * (threadIdx.x >> 6) + (i)] = clock64();                                                 \
+    } while (0)
 #else
+#define PPROBE(i, t)
 #define APROBE(i)
 #define APROBE_C(i)
 #define APROBE_CHUNK_DECL
@@ -403,6 +413,312 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_kernel(GAggFwd a) 
         APROBE_CHUNK_NEXT;
         cur = nxt;
     }
+}
+
+// ---- round 6: the same op with the two halves of the workgroup in OPPOSITE phases ("ping-pong") --------------------------
+// In the kernel above every wave of the workgroup is in the same phase: while the eight waves run the GEMMs the vector
+// units idle, and during staging / epilogue / node sums the matrix pipe does (profiles/r05_issue_slots_pdbbind_pmc.txt:
+// 45 % parked, 30 % stalled, 3.6 VALU per MFMA; a 112-row chunk took 32 400 cycles of which 14 800 were GEMM).  Here the
+// rows of a workgroup are a STREAM of 32-row groups and the two waves of every SIMD are always in different phases:
+//
+//     iteration t   phase A:  waves 0-3  GEMMs of group t (their 64 columns)   | waves 4-7  vector work
+//                   phase B:  waves 0-3  vector work                           | waves 4-7  GEMMs of group t (theirs)
+//
+// one s_barrier between phases.  The vector work of an iteration is everything else of the pipeline, each item on the
+// group whose turn it is:  epilogue of group t-1 (z = acc + P_i + P_j, SiLU, gate, saves; message -> LDS),  staging of
+// group t+1 (rows -> bf16 piece planes), the gathers for group t's epilogue and the row loads of group t+3 (requested an
+// iteration / two iterations ahead: no load is waited for in the phase that issues it), and -- ONE wave, the "walker" --
+// the node sums of group t-2.  Waves 4-7 take the first tile of every group for the vector work, waves 0-2 the second
+// (192 threads: three passes of six rows), wave 3 walks.
+//
+// Node sums without a plan.  The chunked kernel stages CSR offsets per chunk (splan, sptr) and reduces many nodes in
+// parallel at the chunk's end.  A stream has no chunk ends: the walker adds the message rows one by one, in CSR order, onto
+// a running sum that lives in its registers (two columns per lane), and writes out[node] = sum + init[node] whenever the
+// row's node (the row_of value the epilogue threads loaded anyway, passed through LDS) changes -- nodes without rows in
+// between get init.  Exactly the additions of reduce_nodes in the same order: every output bit is the chunked kernel's
+// (tests/test_hip_edge_agg.py compares the two entry points bit for bit).
+//
+// LDS: piece planes of 2 groups (staged / multiplied), z accumulators of 2 groups (written / consumed), gate -> message
+// tiles of 3 groups (written / finished / summed): 131 KB.  Registers: the resident weight pieces (96) + four accumulators
+// + fragments on the GEMM side, the rows / gathers in flight on the vector side.
+template <bool SAVE>
+__global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_pp_kernel(GAggFwd a) {
+    constexpr int TG = 2;                                   // 16-row tiles per group
+    constexpr int GR = 16 * TG;                             // rows per group
+    constexpr int FT = 16 * LDT * 4;                        // bytes of an fp32 tile
+    constexpr int TF = 16 * LDT;                            // floats of an fp32 tile
+    constexpr int P_BYTES = 2 * TG * PTILE, Z_BYTES = 2 * TG * FT, M_BYTES = 3 * TG * FT;
+    __shared__ __attribute__((aligned(16))) char ldsb[P_BYTES + Z_BYTES + M_BYTES];
+    __shared__ int rn[3][GR];                               // node of every row of a group (for the walker)
+    char* const Pb = ldsb;
+    float* const Zb = reinterpret_cast<float*>(ldsb + P_BYTES);
+    float* const Mb = reinterpret_cast<float*>(ldsb + P_BYTES + Z_BYTES);
+    const float* __restrict__ e = a.e;
+    const float* __restrict__ Pi = a.Pi;
+    const float* __restrict__ Pj = a.Pj;
+    const float* __restrict__ init = a.init;
+    const int32_t* __restrict__ ptr = a.ptr;
+    const int32_t* __restrict__ row_of = a.row_of;
+    const int32_t* __restrict__ col = a.col;
+    float* __restrict__ zs = a.z;
+    float* __restrict__ eas = a.ea;
+    float* __restrict__ out = a.out;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int half = wave >> 2;                             // 0: GEMMs in phase A, vector work in phase B; 1: the reverse
+    const bool walker = wave == 3;
+    const int wc = wave_col<8>();
+    const float bias = lane_bias(a.bm, wc);
+    WFragB1 f1, f2;                                         // both weight slices as resident bf16x3 pieces (edge_core.h)
+    load_wfragb1<false>(f1, a.We, a.ld_we, wc);
+    load_wfragb1<false>(f2, a.Wea, a.ld_wea, wc);
+    const int wg = xcd_order(blockIdx.x, gridDim.x);
+    const int nb = a.cuts ? a.cuts[wg] : seg_cut(ptr, row_of, a.n, a.m, wg, gridDim.x);
+    const int ne = a.cuts ? a.cuts[wg + 1] : seg_cut(ptr, row_of, a.n, a.m, wg + 1, gridDim.x);
+    const int64_t rb = ptr[nb], re = ptr[ne];
+
+    // ---- matrix side: both GEMMs of a group on this wave's 16 columns ----------------------------------------------------
+    auto gemm = [&](int t) __attribute__((always_inline)) {
+#ifdef PP_NO_GEMM
+        return;
+#endif
+        const char* P = Pb + (t & 1) * TG * PTILE;
+        Acc<TG> az, ag;
+        az.zero();
+        ag.zero();
+        // (the fragments of the next k-step are requested before this one's products: one wave per SIMD is multiplying, nobody
+        // else covers its LDS round trips)
+        Frag3 A0 = lds_frag3p(P, 0, 0), A1 = lds_frag3p(P, 1, 0);
+#pragma unroll
+        for (int q = 0; q < DIM / 32; ++q) {
+            Frag3 N0, N1;
+            if (q + 1 < DIM / 32) N0 = lds_frag3p(P, 0, q + 1), N1 = lds_frag3p(P, 1, q + 1);
+            // the six piece products with i + j <= 2, small ones first (mfma6's order per accumulator); the four accumulators
+            // are independent chains
+#define PP_PROD(i, j)                                        \
+    az.v[0] = mfma_bf16(A0.p[i], f1.p[q][j], az.v[0]);       \
+    az.v[1] = mfma_bf16(A1.p[i], f1.p[q][j], az.v[1]);       \
+    ag.v[0] = mfma_bf16(A0.p[i], f2.p[q][j], ag.v[0]);       \
+    ag.v[1] = mfma_bf16(A1.p[i], f2.p[q][j], ag.v[1]);
+            PP_PROD(2, 0) PP_PROD(1, 1) PP_PROD(0, 2) PP_PROD(1, 0) PP_PROD(0, 1) PP_PROD(0, 0)
+#undef PP_PROD
+            if (q + 1 < DIM / 32) A0 = N0, A1 = N1;
+        }
+        acc_store<TG>(az, Zb + (t & 1) * TG * TF, wc, bias, TG);
+        acc_store<TG>(ag, Mb + (t % 3) * TG * TF, wc, 0.f, TG);
+    };
+    const int nb_ = nb, ne_ = ne;
+
+    // ---- roles.  The split is made ONCE, at the top: every role is a loop of its own with a straight-line body, so the
+    // compiler counts each wave's memory operations exactly (vector memory retires in order on one counter; with the roles as
+    // branches inside one loop it has to assume a wave may have taken any of them and waits for everything).  All roles pass
+    // the same 1 + 2 (T + 1) barriers.
+    if (walker) {
+        // ---- the walker: node `cur` is open (if `have`), `s` its running sum, `iv` its init row -----------------------------
+        int cur = nb_ - 1;
+        bool have = false;
+        float2 s = make_float2(0.f, 0.f), iv = make_float2(0.f, 0.f);
+        auto emit_and_fill = [&](int upto) __attribute__((always_inline)) {   // close the open node; empty nodes get init
+            if (have) *reinterpret_cast<float2*>(out + (int64_t)cur * DIM + 2 * lane) = make_float2(s.x + iv.x, s.y + iv.y);
+            for (int k = cur + 1; k < upto; ++k) {
+                const float2 i2 = init ? *reinterpret_cast<const float2*>(init + (int64_t)k * DIM + 2 * lane) : make_float2(0.f, 0.f);
+                *reinterpret_cast<float2*>(out + (int64_t)k * DIM + 2 * lane) = make_float2(0.f + i2.x, 0.f + i2.y);
+            }
+        };
+        if (rb >= re) {                                     // a range without rows: its nodes get init
+            emit_and_fill(ne_);
+            return;
+        }
+        const int T = (int)((re - rb + GR - 1) / GR);
+        auto walk = [&](int k) __attribute__((always_inline)) {              // node sums of group k: rows in CSR order
+            const int64_t left = re - (rb + (int64_t)GR * k);
+            const int rows = left < GR ? (int)left : GR;
+            const int slot = k % 3;
+            const float* Mk = Mb + slot * TG * TF + 2 * lane;
+            const int myn = rn[slot][lane & (GR - 1)];
+            // every row of the group requested at once (the walker has the registers the workers spend on rows in flight);
+            // then one scalar test per row: rows of the open node -- all but one or two of a complex's group -- cost two adds
+            float2 v[GR];
+#pragma unroll
+            for (int r = 0; r < GR; ++r) v[r] = *reinterpret_cast<const float2*>(Mk + r * LDT);
+            // bit r: row r starts another node than row r - 1 (row 0: than the open node)
+            const int prevn = __shfl_up(myn, 1);
+            const bool first = (lane & (GR - 1)) == 0;
+            uint32_t changes = (uint32_t)__builtin_amdgcn_ballot_w64(lane < GR && myn != (first ? cur : prevn));
+            if (rows < GR) changes &= (1u << rows) - 1u;
+#pragma unroll
+            for (int r = 0; r < GR; ++r) {
+                if (r < rows) {
+                    if (changes & (1u << r)) {
+                        const int node = __builtin_amdgcn_readlane(myn, r);
+                        emit_and_fill(node);
+                        cur = node, have = true, s = make_float2(0.f, 0.f);
+                        iv = init ? *reinterpret_cast<const float2*>(init + (int64_t)node * DIM + 2 * lane) : make_float2(0.f, 0.f);
+                    }
+                    s.x += v[r].x, s.y += v[r].y;
+                }
+            }
+        };
+        __syncthreads();
+#pragma unroll 1
+        for (int t = 0; t <= T; ++t) {
+            PPROBE(0, t);
+            if (t < T) gemm(t);
+            PPROBE(1, t);
+            __syncthreads();
+            PPROBE(2, t);
+            if (t >= 2) walk(t - 2);
+            PPROBE(3, t);
+            __syncthreads();
+            PPROBE(4, t);
+        }
+        walk(T - 1);
+        emit_and_fill(ne_);
+        return;
+    }
+    if (rb >= re) return;
+    const int T = (int)((re - rb + GR - 1) / GR);           // groups of this workgroup
+
+    // ---- workers: the vector side of the pipeline on the half's tile of every group ---------------------------------------
+    // waves 4-7: rows 0 .. 15 of a group, eight rows per pass, two passes; waves 0-1: rows 16 .. 19 / 22 .. 25 / 28 .. 31 (six
+    // rows per pass, three passes); wave 2: rows 20, 21, 26, 27 (two passes)
+    const int c4 = tid & 31;
+    const int rr = (half ? tid - 256 : tid) >> 5;
+    const int trow0 = (half ? 0 : 16) + rr;
+    auto worker = [&](auto rpp_c, auto niw_c, auto first_c) __attribute__((always_inline)) {
+        constexpr int RPP = decltype(rpp_c)::value, NIW = decltype(niw_c)::value;
+        constexpr bool GEMM_FIRST = decltype(first_c)::value;
+        float4 pre[2][NIW], gpi[NIW], gpj[NIW];             // rows of groups t+1 / t+2 in flight; the gathers of group t
+        int ri[NIW], ci[NIW];
+        auto grow = [&](int k, int i) __attribute__((always_inline)) { return rb + (int64_t)GR * k + trow0 + RPP * i; };
+        auto load_e = [&](auto slot_c, int k) __attribute__((always_inline)) {
+            constexpr int SL = decltype(slot_c)::value;
+#pragma unroll
+            for (int i = 0; i < NIW; ++i) pre[SL][i] = ldg4zl_nt(e, grow(k, i), re, DIM, c4);
+        };
+        auto stage = [&](auto slot_c, int k) __attribute__((always_inline)) {
+            constexpr int SL = decltype(slot_c)::value;
+            char* P = Pb + (k & 1) * TG * PTILE;
+#pragma unroll
+            for (int i = 0; i < NIW; ++i) st_pieces4(P, trow0 + RPP * i, c4, pre[SL][i]);
+        };
+        auto load_idx = [&](int k) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < NIW; ++i) {
+                int64_t g = grow(k, i);
+                g = g < re ? g : re - 1;
+                ri[i] = row_of[g], ci[i] = col[g];
+            }
+        };
+        auto gather = [&](int k) __attribute__((always_inline)) {
+            const int slot = k % 3;
+#pragma unroll
+            for (int i = 0; i < NIW; ++i) {
+                gpi[i] = ldg4(Pi, ri[i], DIM, c4);
+                gpj[i] = ldg4(Pj, ci[i], DIM, c4);
+                if (c4 == 0) rn[slot][trow0 + RPP * i] = ri[i];
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        // KIND 0: first iteration (no epilogue yet), 1: steady state, 2: behind the last group (epilogue only, row masks)
+        auto vec = [&](auto kind_c, auto par_c, int t) __attribute__((always_inline)) {
+            constexpr int KIND = decltype(kind_c)::value;
+#ifdef PP_VEC_PRIO
+            __builtin_amdgcn_s_setprio(PP_VEC_PRIO);
+#endif
+#ifdef PP_NO_VEC
+            return;
+#endif
+            if constexpr (KIND >= 1) {                      // epilogue of group t - 1
+                const int k = t - 1;
+                float* Zk = Zb + (k & 1) * TG * TF;
+                float* Mk = Mb + (k % 3) * TG * TF;
+#pragma unroll
+                for (int i = 0; i < NIW; ++i) {
+                    const int r = trow0 + RPP * i;
+                    const float4 zacc = lds4(Zk, r, c4);
+                    const float4 gate = lds4(Mk, r, c4);
+                    const float4 zz = f4add(f4add(zacc, gpi[i]), gpj[i]);
+#ifdef PP_NO_SILU
+                    st_lds4(Mk, r, c4, f4mul(zz, gate));
+#else
+                    st_lds4(Mk, r, c4, f4mul(f4silu(zz), gate));           // the message stays on chip
+#endif
+                    if constexpr (SAVE) {
+                        // the saves go out at once (the values die here).  Nothing this thread waits for below is younger
+                        // than they are except the gathers it requests now and consumes a whole iteration later.
+                        const int64_t g = grow(k, i);
+                        if (KIND == 1 || g < re) {
+                            stg4_nt(zs, g, DIM, c4, zz);
+                            stg4_nt(eas, g, DIM, c4, gate);
+                        }
+                    }
+                }
+            }
+            PPROBE(5, t);
+            if constexpr (KIND <= 1) {
+                stage(par_c, t + 1);                        // (behind the last group: zeros into a slot nobody reads)
+                PPROBE(6, t);
+                gather(t);
+                load_idx(t + 1);
+                load_e(par_c, t + 3);
+                PPROBE(7, t);
+            }
+#ifdef PP_VEC_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+        };
+        auto iter = [&](auto kind_c, auto par_c, int t) __attribute__((always_inline)) {
+            constexpr int KIND = decltype(kind_c)::value;
+            PPROBE(0, t);
+            if constexpr (GEMM_FIRST) {
+                if constexpr (KIND != 2) gemm(t);
+                PPROBE(1, t);
+                __syncthreads();
+                PPROBE(2, t);
+                vec(kind_c, par_c, t);
+                PPROBE(3, t);
+                __syncthreads();
+            } else {
+                vec(kind_c, par_c, t);
+                PPROBE(1, t);
+                __syncthreads();
+                PPROBE(2, t);
+                if constexpr (KIND != 2) gemm(t);
+                PPROBE(3, t);
+                __syncthreads();
+            }
+            PPROBE(4, t);
+        };
+        using K0 = std::integral_constant<int, 0>;
+        using K1 = std::integral_constant<int, 1>;
+        using K2 = std::integral_constant<int, 2>;
+        load_e(I0{}, 0);                                    // group 0 staged, groups 1 and 2 requested
+        load_idx(0);
+        stage(I0{}, 0);
+        load_e(I1{}, 1);
+        load_e(I0{}, 2);
+        __syncthreads();
+        iter(K0{}, I1{}, 0);
+        int t = 1;                                          // (t odd here: the group staged at t, t + 1, has parity 0)
+#pragma unroll 1
+        for (; t + 1 < T; t += 2) {
+            iter(K1{}, I0{}, t);
+            iter(K1{}, I1{}, t + 1);
+        }
+        if (t < T) {
+            iter(K1{}, I0{}, t);
+            ++t;
+        }
+        iter(K2{}, I0{}, T);
+    };
+    using C2 = std::integral_constant<int, 2>;
+    using C3 = std::integral_constant<int, 3>;
+    using C6 = std::integral_constant<int, 6>;
+    using C8 = std::integral_constant<int, 8>;
+    if (wave >= 4) worker(C8{}, C2{}, std::false_type{});
+    else if (wave < 2) worker(C6{}, C3{}, std::true_type{});
+    else worker(C6{}, C2{}, std::true_type{});
 }
 
 struct GAggBwd {
@@ -1175,8 +1491,35 @@ inline int64_t agg_grid(int64_t m) {
     const int64_t g = ceil_div(m, 16);
     return g < 1 ? 1 : (g > N_CU ? N_CU : g);
 }
+// Round 6: the forward takes the ping-pong form (global_edge_agg_fwd_pp_kernel) where a workgroup streams enough 32-row groups
+// to fill its pipeline.  PAMNET_AGG_PP=0 / 1 forces the chunked / the ping-pong form (A/B runs).
+inline bool agg_pp(int64_t n_edges) {
+    const char* e = getenv("PAMNET_AGG_PP");            // (per call: a test flips it inside one process)
+    if (e && e[0]) return atoi(e) != 0;
+    return n_edges >= 256 * 512;
+}
 
 }  // namespace
+
+// The ping-pong form of pamnet_global_edge_agg_fwd_f32 (same arguments, same results bit for bit), whatever the size.
+extern "C" int pamnet_global_edge_agg_fwd_pp_f32(const float* e, int64_t n_edges, int64_t n_nodes, const float* We,
+                                                 int64_t ld_we, const float* bm, const float* Wea, int64_t ld_wea,
+                                                 const float* Pi, const float* Pj, const int32_t* ptr, const int32_t* row_of,
+                                                 const int32_t* col, const int32_t* cuts, const float* init, float* z, float* ea,
+                                                 float* out, pamnet_stream_t stream) {
+    if (n_edges < 0 || n_nodes < 0) return PAMNET_EINVAL;
+    if (n_nodes == 0) return PAMNET_OK;
+    if (!We || !bm || !Wea || !Pi || !Pj || !ptr || !out) return PAMNET_ENULL;      // init, z, ea: optional
+    if (n_edges > 0 && (!e || !row_of || !col)) return PAMNET_ENULL;
+    if ((z == nullptr) != (ea == nullptr)) return PAMNET_EINVAL;               // both saves or none
+    GAggFwd a{e, We, bm, Wea, Pi, Pj, init, ptr, row_of, col, cuts, z, ea, out, n_edges, n_nodes, (int)ld_we, (int)ld_wea};
+    const int64_t grid = agg_grid(n_edges);
+    hipStream_t st = as_stream(stream);
+    if (z) hipLaunchKernelGGL((global_edge_agg_fwd_pp_kernel<true>), dim3((unsigned)grid), dim3(WG8), 0, st, a);
+    else hipLaunchKernelGGL((global_edge_agg_fwd_pp_kernel<false>), dim3((unsigned)grid), dim3(WG8), 0, st, a);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
 
 // out[i] = init[i] + sum_{e -> i} SiLU(W_e e + b_m + Pi[i] + Pj[col[e]]) * (W_ea e)   for every node i < n_nodes
 // (nodes without edges get init).  z, ea: optional saves for the backward.  ptr [n_nodes + 1] / row_of / col: CSR by target.
@@ -1190,6 +1533,9 @@ extern "C" int pamnet_global_edge_agg_fwd_f32(const float* e, int64_t n_edges, i
     if (!We || !bm || !Wea || !Pi || !Pj || !ptr || !out) return PAMNET_ENULL;      // init, z, ea: optional
     if (n_edges > 0 && (!e || !row_of || !col)) return PAMNET_ENULL;
     if ((z == nullptr) != (ea == nullptr)) return PAMNET_EINVAL;               // both saves or none
+    if (agg_pp(n_edges))
+        return pamnet_global_edge_agg_fwd_pp_f32(e, n_edges, n_nodes, We, ld_we, bm, Wea, ld_wea, Pi, Pj, ptr, row_of, col, cuts,
+                                                 init, z, ea, out, stream);
     GAggFwd a{e, We, bm, Wea, Pi, Pj, init, ptr, row_of, col, cuts, z, ea, out, n_edges, n_nodes, (int)ld_we, (int)ld_wea};
     const int64_t grid = agg_grid(n_edges);
     hipStream_t st = as_stream(stream);

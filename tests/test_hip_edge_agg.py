@@ -343,3 +343,56 @@ def test_local_agg_bwd(dev, case):
                  lib.ptr(tn), m, lib.ptr(outs2[0]), lib.ptr(outs2[1]), lib.ptr(outs2[2]), lib.ptr(outs2[3]), lib.stream_of(d_x2))
         for a_, b_ in zip(outs2, (d_mt, d_q3, d_s, d_mnb)):
             assert torch.equal(a_, b_)
+
+
+PP_CASES = dict(DEGREE_CASES)
+PP_CASES.update({
+    # several hundred rows per workgroup: the ping-pong pipeline in steady state (odd / even group counts, ragged last groups)
+    'pdbbind_size': lambda rng: rng.integers(20, 60, size=6000),
+    'long_stream': lambda rng: rng.integers(1, 120, size=5000),
+    'short_nodes_stream': lambda rng: rng.integers(0, 6, size=60000),       # several node changes per 8-row batch of the walker
+    'holes_stream': lambda rng: rng.integers(0, 2, size=40000) * rng.integers(0, 40, size=40000),
+})
+
+
+@pytest.mark.parametrize('save', [True, False])
+@pytest.mark.parametrize('with_init', [True, False])
+@pytest.mark.parametrize('case', sorted(PP_CASES))
+def test_ping_pong_forward_equals_the_chunked_kernel_bit_for_bit(dev, case, save, with_init, monkeypatch):
+    """Round 6: pamnet_global_edge_agg_fwd_pp_f32 (the two halves of a workgroup in opposite phases, node sums by a walking wave)
+    against the chunked kernel behind pamnet_global_edge_agg_fwd_f32: out, z, ea bit for bit -- same GEMM piece order per
+    accumulator, same epilogue expression, node sums in CSR order -- for every degree pattern incl. empty nodes at the ends of a
+    workgroup's range, nodes longer than many groups, no edges at all; with and without the precomputed work split."""
+    from pamnet_amd import lib
+    rng = np.random.default_rng(7)
+    deg = PP_CASES[case](rng)
+    n = len(deg)
+    ptr, row_of, col, m = _csr(deg, n, 9, dev)
+    gen = torch.Generator().manual_seed(13)
+    mk = lambda *s: (0.5 * torch.randn(*s, generator=gen)).to(dev)
+    e, Pi, Pj, init = mk(max(m, 1), D)[:m], mk(n, D), mk(n, D), mk(n, D)
+    Wm, bm, Wea = _weights(dev, 4)
+    st = lib.stream_of(Pi)
+    sub = lambda w, c0: w.data_ptr() + 4 * c0
+    cuts_t = torch.full((257,), -1, dtype=torch.int32, device=dev)
+    lib.call('pamnet_seg_cuts_i32', lib.ptr(ptr), lib.ptr(row_of), n, m, lib.ptr(cuts_t), None, st)
+
+    def run(entry, cuts):
+        z, ea = (torch.full((max(m, 1), D), float('nan'), device=dev)[:m] for _ in range(2))
+        out = torch.full((n, D), float('nan'), device=dev)
+        lib.call(entry, lib.ptr(e), m, n, sub(Wm, 2 * D), 3 * D, lib.ptr(bm), lib.ptr(Wea), D, lib.ptr(Pi), lib.ptr(Pj),
+                 lib.ptr(ptr), lib.ptr(row_of), lib.ptr(col), cuts, lib.ptr(init) if with_init else None,
+                 lib.ptr(z) if save else None, lib.ptr(ea) if save else None, lib.ptr(out), st)
+        torch.cuda.synchronize()
+        return out, z, ea
+
+    monkeypatch.setenv('PAMNET_AGG_PP', '0')                          # the plain entry point takes the chunked kernel
+    ref = run('pamnet_global_edge_agg_fwd_f32', lib.ptr(cuts_t))
+    for cuts in (lib.ptr(cuts_t), None):
+        got = run('pamnet_global_edge_agg_fwd_pp_f32', cuts)
+        assert torch.isfinite(got[0]).all()
+        assert torch.equal(got[0], ref[0]), 'out'
+        if save and m:
+            assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]), 'saves'
+    monkeypatch.setenv('PAMNET_AGG_PP', '1')                          # ... and the ping-pong kernel when told to
+    assert torch.equal(run('pamnet_global_edge_agg_fwd_f32', lib.ptr(cuts_t))[0], ref[0])
