@@ -38,11 +38,26 @@ inline int64_t al(int64_t x) { return (x + 63) / 64 * 64; }       // 256-byte al
 
 // hdz / gh / hp: backward scratch of the layer's head branch (dz7..dz9, its d x_out contribution, head-vector partials),
 // filled for all layers by one launch at the start of the backward
-struct GlobalSaved { float *Zx1, *z, *ea, *x2, *Z, *R, *xout, *hdz, *gh, *hp; };
+struct GlobalSaved { float *Zx1, *z, *ea, *x2, *Z, *R, *xout, *hdz, *gh, *hp, *Pg; };
 struct LocalSaved { float *Zx1, *zji, *zkj, *q2, *q3, *mnb, *mt, *s, *z1, *z2, *x2, *Z, *R, *xout, *hdz, *gh, *hp; };
 inline int64_t head_partial_floats(const Graph& g) { return al(((g.n + 15) / 16) * 257); }
 
-inline int64_t global_saved_floats(const Graph& g) { return al(g.n * D) * 19 + al(g.eg * D) * 2 + head_partial_floats(g); }
+// Round 6 A/B ("backward by recompute"): PAMNET_EDGE_RECOMPUTE=1 -- the training forward of the fused
+// global-edge step saves nothing of edge size (it runs the inference form: no z, no ea), only the two node planes P_i, P_j it
+// gathered from; the backward re-runs the forward kernel for z and ea into scratch right ahead of the fused backward kernel.
+// Same numbers bit for bit (the same kernel computes them), 2 x E_g x 512 bytes less per layer in the saved arena; whether it
+// is faster is what profiles/r06_edge_recompute_ab.txt records (it is not).  Read once.  Only where the backward takes its
+// fused weight-gradient form (the scratch it frees holds the recomputed rows).
+inline bool edge_recompute_on() {
+    static const bool v = [] { const char* e = getenv("PAMNET_EDGE_RECOMPUTE"); return e && atoi(e) != 0; }();
+    return v;
+}
+inline bool edge_wgrad(const Graph& g);
+inline bool edge_recompute(const Graph& g) { return edge_recompute_on() && edge_wgrad(g); }
+inline int64_t global_saved_floats(const Graph& g) {
+    const int64_t edge = edge_recompute(g) ? al(g.n * D) * 2 : al(g.eg * D) * 2;
+    return al(g.n * D) * 19 + edge + head_partial_floats(g);
+}
 inline int64_t local_saved_floats(const Graph& g) {
     return al(g.n * D) * 19 + al(g.el * D) * 6 + al(g.tp * D) * 3 + head_partial_floats(g);
 }
@@ -51,8 +66,14 @@ inline GlobalSaved carve_global(float* p, const Graph& g) {
     GlobalSaved s;
     const int64_t nd = al(g.n * D), ed = al(g.eg * D);
     s.Zx1 = p; p += nd;
-    s.z = p; p += ed;
-    s.ea = p; p += ed;
+    if (edge_recompute(g)) {
+        s.z = s.ea = nullptr;
+        s.Pg = p; p += 2 * nd;   // (planes n*D apart)
+    } else {
+        s.Pg = nullptr;
+        s.z = p; p += ed;
+        s.ea = p; p += ed;
+    }
     s.x2 = p; p += nd;
     s.Z = p; p += 10 * nd;       // NB: planes are n*D apart (not padded): 10*nd >= 10*n*D
     s.R = p; p += 2 * nd;
@@ -96,6 +117,7 @@ struct Temp {
     float *partial, *partial2;   // split-K scratch of two consecutive weight-gradient batches (the reduction of one runs
                                  // inside the launch of the next)
     float* rider_partial;        // split-K scratch of the rider batch (10 node-level jobs in a node-chain launch)
+    float* dump;                 // PAMNET_EDGE_RECOMPUTE: node output of the recompute launch (discarded)
     float* edge_partial;         // partial tiles of the fused global-edge backward's own weight gradients (2 x <= 256 slots)
     int32_t* cuts;               // node-aligned work split of the fused global-edge kernels (<= 257 ints)
 };
@@ -142,6 +164,7 @@ inline int64_t temp_floats(const Graph& g) {
     t += 6 * ld + 3 * td;
     t += 3 * nd;                                                       // dPg (2 planes), dZx1g
     t += 2 * wgrad_floats(g) + rider_floats(g) + edge_partial_floats(g) + 320;
+    if (edge_recompute(g)) t += nd;                                    // the recompute launch's node output (discarded)
     return t;
 }
 
@@ -179,6 +202,8 @@ inline Temp carve_temp(float* p, const Graph& g) {
     t.partial2 = p; p += wgrad_floats(g);
     t.rider_partial = p; p += rider_floats(g);
     t.edge_partial = p; p += edge_partial_floats(g);
+    t.dump = nullptr;
+    if (edge_recompute(g)) { t.dump = p; p += nd; }
     t.cuts = reinterpret_cast<int32_t*>(p);
     return t;
 }
@@ -444,9 +469,11 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         const GlobalSaved s = carve_global(saved + k * (gs + ls), g);
         const float* wpg[2] = {gp[2], gp[2] + D};
         // the head of every layer but the first runs inside the preceding layer's node chain (x_out tile still on chip)
-        if (k == 0) CK(pamnet_node_pre_fwd_f32(x, g.n, gp[0], gp[1], wpg, 3 * D, 2, sv(s.Zx1), t.x1, t.P, st));
+        // (recompute A/B: the node planes of a training forward go to the saved arena instead of the scratch)
+        float* const Pk = (keep && s.Pg) ? s.Pg : t.P;
+        if (k == 0) CK(pamnet_node_pre_fwd_f32(x, g.n, gp[0], gp[1], wpg, 3 * D, 2, sv(s.Zx1), t.x1, Pk, st));
         // message MLP + add-aggregation in one kernel: x2 = x1 + sum_{e -> i} msg_e, the messages never leave the chip
-        CK(pamnet_global_edge_agg_fwd_f32(e_g, g.eg, g.n, gp[2] + 2 * D, 3 * D, gp[3], gp[4], D, t.P, t.P + g.n * D,
+        CK(pamnet_global_edge_agg_fwd_f32(e_g, g.eg, g.n, gp[2] + 2 * D, 3 * D, gp[3], gp[4], D, Pk, Pk + g.n * D,
                                           g.g_ptr, g.g_row, g.g_col, cuts, t.x1, sv(s.z), sv(s.ea), s.x2, st));
         const float* const* lp = lparams + k * NL;
         const LocalSaved q = carve_local(saved + k * (gs + ls) + gs, g);
@@ -478,6 +505,7 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
             const float* const* gn = gparams + (k + 1) * NG;
             const GlobalSaved sn = carve_global(saved + (k + 1) * (gs + ls), g);
             const float* wpn[2] = {gn[2], gn[2] + D};
+            float* const Pn = (keep && sn.Pg) ? sn.Pg : t.P;         // the next global layer's node planes
             if (ride) {
                 const float* const* ln = lparams + (k + 1) * NL;
                 const LocalSaved qn = carve_local(saved + (k + 1) * (gs + ls) + gs, g);
@@ -485,12 +513,12 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
                 float* mo[3] = {sv(qn.z1), sv(qn.z2), qn.s};
                 CK(pamnet_node_tail_fwd_rider_f32(q.x2, x, g.n, img[k].lt, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22],
                                                   sv(q.Z), sv(q.R), q.xout, img[k].nh[0], gn[1], img[k].nh + 1, 3 * D, 2,
-                                                  sv(sn.Zx1), t.x1, t.P, e_sbf, g.tp, 0, mlp_half, mp, mo, rider_wgs, pkc, st));
+                                                  sv(sn.Zx1), t.x1, Pn, e_sbf, g.tp, 0, mlp_half, mp, mo, rider_wgs, pkc, st));
             } else {
                 CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, packed ? img[k].lt : lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21],
                                             lp[LT + 22], sv(q.Z), sv(q.R), q.xout, nullptr, nullptr,
                                             packed ? img[k].nh[0] : gn[0], gn[1],
-                                            packed ? img[k].nh + 1 : wpn, 3 * D, 2, sv(sn.Zx1), t.x1, t.P, pkc, st));
+                                            packed ? img[k].nh + 1 : wpn, 3 * D, 2, sv(sn.Zx1), t.x1, Pn, pkc, st));
             }
         } else {
             CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, packed ? img[k].lt : lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21],
@@ -719,7 +747,15 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 // ... and the step's own weight gradients: partial tiles per workgroup, summed by the next weight-gradient launch
                 int64_t efloats = 0, eslots = 0;
                 CK(pamnet_global_edge_agg_wg_floats(g.eg, &efloats, &eslots));
-                CK(pamnet_global_edge_agg_bwd_wg_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, cuts, s.z, s.ea, e_g, gp[2] + 2 * D, 3 * D,
+                const float *zk = s.z, *eak = s.ea;
+                if (s.Pg) {
+                    // recompute A/B: z and ea of this layer once more, by the kernel that made them in the forward, into scratch
+                    // the fused backward does not use (the forward's message buffer, the d ea rows it no longer writes)
+                    CK(pamnet_global_edge_agg_fwd_f32(e_g, g.eg, g.n, gp[2] + 2 * D, 3 * D, gp[3], gp[4], D, s.Pg, s.Pg + g.n * D,
+                                                      g.g_ptr, g.g_row, g.g_col, cuts, nullptr, t.msg, t.dea, t.dump, st));
+                    zk = t.msg, eak = t.dea;
+                }
+                CK(pamnet_global_edge_agg_bwd_wg_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, cuts, zk, eak, e_g, gp[2] + 2 * D, 3 * D,
                                                      gp[4], D, t.dz, d_eg, acc, t.dPg, t.edge_partial, st));
                 CK(pamnet_wgrad_edge_enqueue_f32(wctx.data(), eslots, gg[2] + 2 * D, 3 * D, gg[3], gg[4], D, t.edge_partial));
             } else {

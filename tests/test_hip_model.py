@@ -9,6 +9,7 @@ Parity protocol: per tensor, err(a, b) = max|a-b| / max|b|.  The HIP
     err(hip, ref_fp64) <= max(1e-5, 2 * err(ref_fp32, ref_fp64))
 i.e. the north star's 1e-5, never tighter than the reference's own fp32 noise.
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -1213,3 +1214,40 @@ def test_flat_parameter_view_semantics(monkeypatch):
     # a Trainer owns flat buffers of its own: the interface goes back to per-tensor
     Trainer(model, lr=1e-4)
     assert len(list(model.parameters())) == len(sd)
+
+
+@pytest.mark.gpu
+def test_edge_recompute_switch_gives_the_same_step_bit_for_bit():
+    """PAMNET_EDGE_RECOMPUTE=1 (round 6 A/B, csrc/engine.hip): the training forward of the fused global-edge step saves no z / ea
+    rows, the backward re-runs the forward kernel for them.  Same kernel, same inputs: the output and every gradient of a
+    PDBbind-sized step are bit for bit those of the saving form (each form in a process of its own: the switch is read once)."""
+    import hashlib
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, hashlib, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import models\n"
+        "from pamnet_amd import synth\n"
+        "from pamnet_amd.train import Trainer\n"
+        "dev = torch.device('cuda:0'); torch.manual_seed(3)\n"
+        "cfg = models.Config(dataset='PDBbind', dim=128, n_layer=2, cutoff_l=2.0, cutoff_g=6.0)\n"
+        "model = models.PAMNet(cfg).to(dev)\n"
+        "tr = Trainer(model, loss='mse', max_grad_norm=None, ema_decay=None, lr=1e-3)\n"
+        "b = synth.collate([synth.pdbbind_complex(1, i) for i in range(12)]).to(dev)\n"
+        "loss = tr.forward_backward(b)\n"
+        "torch.cuda.synchronize()\n"
+        "g = model._graph_cache\n"
+        "print('EG', int(g.glob.m))\n"
+        "print('HASH', hashlib.sha256(tr.fp.grad.cpu().numpy().tobytes()).hexdigest(), float(loss), float(tr.fp.grad.abs().sum()))\n"
+    ) % (repo, os.path.join(repo, 'physics-aware-multiplex-gnn_amd'))
+    outs = []
+    for v in ('0', '1'):
+        env = dict(os.environ, PAMNET_EDGE_RECOMPUTE=v)
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = {l.split()[0]: l.split()[1:] for l in r.stdout.splitlines() if l.startswith(('EG', 'HASH'))}
+        assert int(lines['EG'][0]) >= 131072          # the fused weight-gradient backward: where the switch applies
+        outs.append(lines['HASH'])
+    assert float(outs[0][2]) > 0 and outs[0] == outs[1], outs

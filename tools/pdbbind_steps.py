@@ -29,6 +29,6 @@ t0 = time.perf_counter()
 for i in range(steps):
     tr.step(bs[i % 4], next_data=bs[(i + 1) % 4])
 torch.cuda.synchronize()
-print('pdbbind plain tensors: %.3f ms/step (%d steps), PAMNET_EDGE_WGRAD=%s PAMNET_AGG_PP=%s' % ((time.perf_counter() - t0) / steps * 1e3, steps,
-                                                                              os.environ.get('PAMNET_EDGE_WGRAD', 'auto'), os.environ.get('PAMNET_AGG_PP', 'auto')))
+print('pdbbind plain tensors: %.3f ms/step (%d steps), PAMNET_EDGE_WGRAD=%s PAMNET_AGG_PP=%s PAMNET_EDGE_RECOMPUTE=%s' % ((time.perf_counter() - t0) / steps * 1e3, steps,
+                                                                              os.environ.get('PAMNET_EDGE_WGRAD', 'auto'), os.environ.get('PAMNET_AGG_PP', 'auto'), os.environ.get('PAMNET_EDGE_RECOMPUTE', '0')))
 tr.drain()
