@@ -219,7 +219,7 @@ def test_wide_models_vs_reference_runs(dev, golden, name):
     import numpy as np
     import models
     from oracle import pamnet_oracle as O
-    from test_hip_model import GRAD_TOL, _cfg_from, _ok
+    from test_hip_model import CANCEL_TOL, GRAD_TOL, grad_tol, _cfg_from, _ok
     from test_oracle_golden import _wide_batch
     g = golden(name)
     cfg = _cfg_from(g, models.Config)
@@ -259,10 +259,10 @@ def test_wide_models_vs_reference_runs(dev, golden, name):
             # cancellation, so it is judged on the scale of its Linear's weight gradient (test_hip_model._check_gradients)
             scale = max(scale, float(grads[k[:-4] + 'weight'].abs().max()))
         e = abs(float(grads[k].double().norm()) - float(l2)) / max(scale, 1e-300)
-        assert e < GRAD_TOL, (k, e)
+        assert e < (CANCEL_TOL if (k.endswith('W_out.bias') and cfg.dataset == 'PDBbind') else grad_tol(cfg.dataset)), (k, e)
         worst = max(worst, e)
     for k in g.files:
         if k.startswith('grad64/'):
-            assert maxnorm_err(grads[k[7:]].cpu().numpy(), g[k]) < GRAD_TOL, k
+            assert maxnorm_err(grads[k[7:]].cpu().numpy(), g[k]) < grad_tol(cfg.dataset), k
     print('%s vs the reference: out %.2e (ref fp32 %.2e), node_out %.2e; |grad| rel %.1e, worst per-tensor L2 %.1e'
           % (name, info[0], info[1], info_n[0], abs(gn / float(g['grad_norm64']) - 1), worst))
