@@ -80,17 +80,22 @@ def event_time_ms(fn, reps, groups=1):
 def box_calibration(dev, gb=1.0):
     """What THIS box's memory system delivers to the simplest kernels, measured in the same process as the roofline probe (boxes
     of the pool differ by +-5 % at 2 GB streams: a fraction of the 8 TB/s peak alone mixes the kernel with the box): a 16-byte-
-    per-lane copy (torch's vectorised elementwise copy: bytes read + written) and a read-only stream (a sum reduction)."""
-    n = int(gb * 1e9 / 4)
+    per-lane copy (torch's vectorised elementwise copy: bytes read + written) -- the library's own stream copy, with torch's elementwise copy beside it."""
+    from pamnet_amd import lib
+    n = int(gb * 1e9 / 16) * 4
     a, b = torch.randn(n, device=dev), torch.empty(n, device=dev)
+    st = lib.stream_of(a)
+    fn = lambda: lib.call('pamnet_stream_copy_f32', lib.ptr(a), lib.ptr(b), n, st)
+    for _ in range(3):
+        fn()
+    ms_c, ms_best = event_time_ms(fn, 10, 5)
     for _ in range(3):
         b.copy_(a)
-    ms_c, _ = event_time_ms(lambda: b.copy_(a), 10, 5)
-    for _ in range(3):
-        a.sum()
-    ms_r, _ = event_time_ms(lambda: a.sum(), 10, 5)
-    return {'copy_gbs': 8.0 * n / ms_c / 1e6, 'read_gbs': 4.0 * n / ms_r / 1e6, 'bytes': 4 * n,
-            'note': 'float4 copy (read + write bytes) and read-only sum over %.1f GB, HIP-event timed, median of 5 groups of 10' % gb}
+    ms_t, _ = event_time_ms(lambda: b.copy_(a), 10, 5)
+    return {'copy_gbs': 8.0 * n / ms_c / 1e6, 'copy_gbs_best_group': 8.0 * n / ms_best / 1e6, 'torch_copy_gbs': 8.0 * n / ms_t / 1e6,
+            'bytes': 4 * n,
+            'note': 'pamnet_stream_copy_f32 (16 bytes per lane, non-temporal, 8 loads in flight; read + write bytes) and '
+                    "torch's elementwise copy over %.1f GB, HIP-event timed, median of 5 groups of 10" % gb}
 
 
 def committed_kernel_avg(stats_file, kernel_substr):
@@ -992,7 +997,6 @@ def main():
                 'rocprofv3_committed': {'average_us': prof[0], 'algorithmic_gb': prof[1]} if prof else None,
                 'box_calibration': cal,
                 'frac_of_box_copy': (s['gbs'] / cal['copy_gbs']) if isinstance(cal, dict) and 'copy_gbs' in cal else None,
-                'frac_of_box_read': (s['gbs'] / cal['read_gbs']) if isinstance(cal, dict) and 'read_gbs' in cal else None,
                 'at_workload_shape': roof['workload'],
                 'in_config': [{'config': 'BASELINE configs[1] (QM9 B=128): the global aggregation shape [E_g, d] -> [N, d]; every '
                                          'operand is Infinity-Cache resident (latency bound, not an HBM number)',

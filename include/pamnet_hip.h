@@ -708,6 +708,8 @@ int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* graph_idx, 
  *                               models.py:107,140); scratch: pamnet_reduce_scratch_bytes bytes of device memory
  * ------------------------------------------------------------------------------------------------------------------ */
 int pamnet_reduce_scratch_bytes(int64_t* bytes);
+/* dst[0:n] = src[0:n], 16 bytes per lane, non-temporal (n % 4 == 0): the memory-system calibration beside bench.py's roofline */
+int pamnet_stream_copy_f32(const float* src, float* dst, int64_t n, pamnet_stream_t stream);
 int pamnet_sumsq_partials_f32(const float* g, int64_t n, double* partials, pamnet_stream_t stream);
 int pamnet_l1_loss_f32(const float* out, const float* y, int64_t n, float grad_scale, float* loss, float* d_out,
                        pamnet_stream_t stream);

@@ -100,6 +100,41 @@ __global__ __launch_bounds__(256) void type_rows_finish_kernel(const float4* __r
 }  // namespace
 
 // scratch (caller-owned, device) of pamnet_type_rows_grad_f32: pamnet_reduce_scratch_bytes bytes, no initialisation needed
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// A plain 16-byte-per-lane copy, 8 loads in flight per lane: what this box's memory system delivers to the simplest streaming
+// kernel (bench.py's roofline calibration; not part of any model path).
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+    constexpr int U = 8;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + i + u * stride));
+            v[u] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const f32x4 t = {v[u].x, v[u].y, v[u].z, v[u].w};
+            __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(dst + i + u * stride));
+        }
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+extern "C" int pamnet_stream_copy_f32(const float* src, float* dst, int64_t n, pamnet_stream_t stream) {
+    if (n < 0 || (n & 3)) return PAMNET_EINVAL;
+    if (n == 0) return PAMNET_OK;
+    if (!src || !dst) return PAMNET_ENULL;
+    const int64_t n4 = n / 4;
+    int64_t blocks = (n4 + 256 * 8 - 1) / (256 * 8);
+    blocks = blocks < 1 ? 1 : (blocks > 256 * 16 ? 256 * 16 : blocks);
+    hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n4);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
 extern "C" int pamnet_reduce_scratch_bytes(int64_t* bytes) {
     if (!bytes) return PAMNET_ENULL;
     *bytes = (int64_t)TYPE_BLOCKS * TYPE_MAX * 64 * 16;
