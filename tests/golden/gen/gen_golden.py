@@ -446,6 +446,8 @@ def main():
         return main_wide()
     if '--rna-all-only' in sys.argv:
         return fixture_rna_all()
+    if '--flow-only' in sys.argv:
+        return main_flow()
     main_forward()
     main_train()
     main_baseline()
@@ -603,7 +605,18 @@ def main_d128():
     fixture_random('qm9s_d128_l2', ref_models.PAMNet_s, qm9, synth.qm9_batch(13, 0, 12), seed=31, capture=False, small=True)
 
 
+def main_flow():
+    """Round 6 (verdict item 9d): flow = 'target_to_source' on the QM9 and the PDBbind branch straight from the reference (until
+    now reference runs used the non-default flow on the RNA branch only; layers/global_message_passing.py:11, models.py:19)."""
+    qm9 = dict(dataset='QM9', dim=32, n_layer=2, cutoff_l=5.0, cutoff_g=5.0, flow='target_to_source')
+    fixture_random('qm9_flow_t2s_d32_l2', ref_models.PAMNet, qm9, synth.qm9_batch(21, 0, 6), seed=13, capture=True)
+    pdb = dict(dataset='PDBbind', dim=32, n_layer=2, cutoff_l=2.0, cutoff_g=6.0, flow='target_to_source')
+    fixture_random('pdbbind_flow_t2s_d32_l2', ref_models.PAMNet, pdb, synth.pdbbind_batch(15, 0, 2, n_pocket=70, n_ligand=14),
+                   seed=15, capture=True)
+
+
 def main_forward():
+    main_flow()
     main_ragged()
     main_d128()
     fixture_star()

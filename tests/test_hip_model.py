@@ -276,6 +276,7 @@ def dev():
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,small', [('qm9_d32_l2', False), ('qm9s_d32_l2', True), ('pdbbind_d32_l2', False),
                                         ('qm9_ragged_d32_l2', False), ('qm9s_ragged_d32_l2', True),
+                                        ('qm9_flow_t2s_d32_l2', False), ('pdbbind_flow_t2s_d32_l2', False),
                                         ('pdbbind_d128_l3', False), ('qm9s_d128_l2', True),
                                         ('qm9_d128_l6', False), ('qm9_basis_5x4_p6_d32_l2', False),
                                         ('qm9_basis_8x7_p4_d128_l2', False)])
@@ -353,7 +354,7 @@ def test_rna_checkpoint_end_to_end(dev, golden):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', ['qm9_d32_l2', 'pdbbind_d32_l2', 'pdbbind_d128_l3', 'qm9_basis_5x4_p6_d32_l2',
-                                  'qm9_basis_8x7_p4_d128_l2'])
+                                  'qm9_basis_8x7_p4_d128_l2', 'qm9_flow_t2s_d32_l2', 'pdbbind_flow_t2s_d32_l2'])
 def test_gradients_vs_reference_golden(dev, golden, name):
     """d L1-loss / d params through the HIP backward kernels vs the reference's fp64 autograd."""
     import models

@@ -65,6 +65,7 @@ def test_basis_tables(golden):
 
 @pytest.mark.parametrize('name,small', [('qm9_d32_l2', False), ('pdbbind_d32_l2', False), ('qm9s_d32_l2', True),
                                         ('qm9_ragged_d32_l2', False), ('qm9s_ragged_d32_l2', True),
+                                        ('qm9_flow_t2s_d32_l2', False), ('pdbbind_flow_t2s_d32_l2', False),
                                         ('pdbbind_d128_l3', False), ('qm9s_d128_l2', True),
                                         ('qm9_d128_l6', False), ('qm9_basis_5x4_p6_d32_l2', False),
                                         ('qm9_basis_8x7_p4_d128_l2', False)])
@@ -99,7 +100,8 @@ def test_random_init_forward(golden, name, small):
                     assert np.array_equal(inter[k].numpy(), g['ref/' + k]), k
 
 
-@pytest.mark.parametrize('name', ['qm9_d32_l2', 'pdbbind_d32_l2', 'qm9_basis_5x4_p6_d32_l2'])
+@pytest.mark.parametrize('name', ['qm9_d32_l2', 'pdbbind_d32_l2', 'qm9_basis_5x4_p6_d32_l2', 'qm9_flow_t2s_d32_l2',
+                                  'pdbbind_flow_t2s_d32_l2'])
 def test_loss_gradient_fp64(golden, name):
     """d L1-loss / d params through the oracle == through the reference (fp64)."""
     g = golden(name)
