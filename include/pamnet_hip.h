@@ -134,6 +134,11 @@ int pamnet_knn_i32(const float* pos, const int32_t* node_graph, const int32_t* g
  * into ptr_a / ptr_b [n + 1].  The same arrays as pamnet_csr_filter_count/fill_i32 + pamnet_expand_rows_i32 per cut. */
 int pamnet_knn_cut_i32(const float* pos, const int32_t* node_graph, const int32_t* gptr, int64_t n, int32_t k, float cut_a,
                        float cut_b, int32_t* nbr, float* dist, int32_t* cnt_a, int32_t* cnt_b, pamnet_stream_t stream);
+/* total[0] (int64, zero on entry) = triplet + pair rows (models.py:68-98) of the graph the entries within `cut` of a kNN table
+ * define (query -> neighbour, aggregated at the neighbour), before that graph is built: the kNN path's sizes in ONE host
+ * read-back.  indeg: [n] int32 scratch, zero on entry. */
+int pamnet_knn_tp_total_i64(const int32_t* nbr, const float* dist, int64_t n, int32_t k, float cut, int32_t with_triplets,
+                            int32_t* indeg, int64_t* total, pamnet_stream_t stream);
 int pamnet_knn_cut_fill_i32(const int32_t* nbr, const float* dist, int64_t n, int32_t k, float cut_a, const int32_t* raw_a,
                             int64_t cap_a, int32_t* nbr_a, float* dist_a, int32_t* row_a, int32_t* ptr_a, float cut_b,
                             const int32_t* raw_b, int64_t cap_b, int32_t* nbr_b, float* dist_b, int32_t* row_b, int32_t* ptr_b,

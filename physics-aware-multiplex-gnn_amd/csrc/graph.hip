@@ -1243,6 +1243,67 @@ extern "C" int pamnet_knn_cut_i32(const float* pos, const int32_t* node_graph, c
     return PAMNET_OK;
 }
 
+// ---- the triplet + pair row total of the graph the LOCAL cut of a kNN table defines, before that graph exists (round 6) ----
+// Edges: query j -> neighbour i for the table entries of j within `cut` (models.py:153-156: j = query, i = neighbour; the local
+// layer aggregates at i).  Rows of edge (j -> i), models.py:68-98 as triplet_count_kernel counts them on the finished graph:
+//     triplets  #{k -> j, k != i} = indeg(j) - [i -> j is an edge]        pairs  #{j' -> i} = indeg(i)
+// Two launches ahead of the host's ONE size read-back of the kNN path (the second read-back, of the scanned row counts, goes):
+// a histogram of in-degrees (integer atomics: a count is a count whatever the order), then per table entry its rows, summed with
+// integer atomics into total[0].  One wavefront per query, as the fill kernel.
+__global__ __launch_bounds__(256) void knn_indeg_kernel(const int32_t* __restrict__ kn, const float* __restrict__ kd, int64_t n,
+                                                        int K, float cut, int32_t* __restrict__ indeg) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (j >= n || lane >= K) return;
+    const int i = kn[j * K + lane];
+    if (i >= 0 && kd[j * K + lane] <= cut) atomicAdd(indeg + i, 1);
+}
+__global__ __launch_bounds__(256) void knn_tp_total_kernel(const int32_t* __restrict__ kn, const float* __restrict__ kd, int64_t n,
+                                                           int K, float cut, int with_triplets,
+                                                           const int32_t* __restrict__ indeg,
+                                                           unsigned long long* __restrict__ total) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (j >= n) return;
+    int i = -1;
+    bool keep = false;
+    if (lane < K) {
+        i = kn[j * K + lane];
+        keep = i >= 0 && kd[j * K + lane] <= cut;
+    }
+    long long mine = keep ? indeg[i] : 0;                                 // pairs
+    if (with_triplets) {
+        // is i -> j an edge, i.e. j within the cut of i's own list?  The wave reads the list of one kept neighbour at a time (one
+        // coalesced row per step, all steps independent) instead of every lane walking a list of its own
+        unsigned long long todo = __ballot(keep);
+        int mutual = 0;
+        while (todo) {
+            const int t = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int it = __builtin_amdgcn_readlane(i, t);
+            const bool hit = lane < K && kn[(int64_t)it * K + lane] == (int32_t)j && kd[(int64_t)it * K + lane] <= cut;
+            if (__ballot(hit) != 0 && lane == t) mutual = 1;
+        }
+        if (keep) mine += indeg[j] - mutual;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if (lane == 0 && mine) atomicAdd(total, (unsigned long long)mine);
+}
+// indeg: [n] int32 scratch, total: [1] int64 -- both zero on entry
+extern "C" int pamnet_knn_tp_total_i64(const int32_t* nbr, const float* dist, int64_t n, int32_t k, float cut,
+                                       int32_t with_triplets, int32_t* indeg, int64_t* total, pamnet_stream_t stream) {
+    if (n < 0 || k < 1 || k > 64) return PAMNET_EINVAL;
+    if (n == 0) return PAMNET_OK;
+    if (!nbr || !dist || !indeg || !total) return PAMNET_ENULL;
+    hipLaunchKernelGGL(knn_indeg_kernel, dim3(blocks_for(n, 4)), dim3(256), 0, as_stream(stream), nbr, dist, n, (int)k, cut, indeg);
+    PAMNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_tp_total_kernel, dim3(blocks_for(n, 4)), dim3(256), 0, as_stream(stream), nbr, dist, n, (int)k, cut,
+                       (int)with_triplets, indeg, reinterpret_cast<unsigned long long*>(total));
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
 extern "C" int pamnet_knn_cut_fill_i32(const int32_t* nbr, const float* dist, int64_t n, int32_t k, float cut_a,
                                        const int32_t* raw_a, int64_t cap_a, int32_t* nbr_a, float* dist_a, int32_t* row_a,
                                        int32_t* ptr_a, float cut_b, const int32_t* raw_b, int64_t cap_b, int32_t* nbr_b,

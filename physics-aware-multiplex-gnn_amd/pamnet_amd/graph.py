@@ -8,6 +8,8 @@ Edge storage differs from the reference on purpose: edges are kept in CSR order 
 (deterministic, atomics-free segment sums), i.e. a permutation of the reference's edge list.  Results are invariant to
 that permutation up to fp32 summation order.
 """
+import os
+
 import torch
 
 from . import lib
@@ -252,11 +254,18 @@ def knn_table(pos, node_graph, gptr, k, cutoff):
     return ptr, nbr, dist
 
 
-def knn_cuts(pos, node_graph, gptr, k, cut_a, cut_b, flag=None):
+# PAMNET_KNN_TP_TOTAL=1: the RNA path's triplet / pair total travels with the two cut sizes in ONE read-back (round 6, verdict item 8).
+# Measured SLOWER on the host-bound plain-tensor step (profiles/r06_rna_one_roundtrip_ab.txt: 1.24-1.38 against 1.08-1.10 ms): a fill and
+# two launches cost the host more than the second read-back, which the input pipeline hides anyway.  Off by default; kept for A/B.
+KNN_TP_TOTAL = os.environ.get('PAMNET_KNN_TP_TOTAL', '0') != '0'
+
+
+def knn_cuts(pos, node_graph, gptr, k, cut_a, cut_b, flag=None, tp_of_b=None):
     """The kNN search with both cuts of its table (models.py:143-156) in three launches and one host round trip (the two
     sizes + the input-validity flag): the search counts what each cut keeps per query on the way, one launch scans both count
     vectors, one writes both cut lists with their query ids.  Returns ((ptr, nbr, dist, query) of cut a, the same of cut b) --
-    the arrays of knn_table + csr_filter2 + expand_rows."""
+    the arrays of knn_table + csr_filter2 + expand_rows.  tp_of_b = with_triplets (bool): the triplet + pair row total of the
+    graph cut b defines travels in the same round trip (pamnet_knn_tp_total_i64) and is returned third."""
     n, dev = int(pos.size(0)), pos.device
     st = lib.stream_of(pos)
     kn, kd = _i32(n * k, dev), _f32(n * k, dev)
@@ -265,17 +274,26 @@ def knn_cuts(pos, node_graph, gptr, k, cut_a, cut_b, flag=None):
     lib.call('pamnet_knn_cut_i32', lib.ptr(pos), lib.ptr(node_graph), lib.ptr(gptr), n, int(k), float(cut_a), float(cut_b),
              lib.ptr(kn), lib.ptr(kd), lib.ptr(ca), lib.ptr(cb), st)
     lib.call('pamnet_exclusive_scan_pair_i32', lib.ptr(ca), lib.ptr(ra), lib.ptr(cb), lib.ptr(rb), n, lib.ptr(tmp), st)
-    if flag is None:
-        ta, tb = host_ints(ra[-1], rb[-1])
-    else:
-        ta, tb, bad = host_ints(ra[-1], rb[-1], flag)
-        if bad:
-            _raise_bad_inputs()
+    want = [ra[-1], rb[-1]]
+    if tp_of_b is not None:
+        buf = torch.zeros((n + 1) // 2 + 1, dtype=torch.int64, device=dev)   # one fill: [n] int32 in-degrees, then the int64 total
+        tot = buf[-1:]
+        lib.call('pamnet_knn_tp_total_i64', lib.ptr(kn), lib.ptr(kd), n, int(k), float(cut_b), 1 if tp_of_b else 0,
+                 lib.ptr(buf), lib.ptr(tot), st)
+        want.append(tot)
+    if flag is not None:
+        want.append(flag)
+    got = host_ints(*want)
+    ta, tb = got[0], got[1]
+    tp_total = got[2] if tp_of_b is not None else None
+    if flag is not None and got[-1]:
+        _raise_bad_inputs()
     outs = [(_i32(t, dev), _f32(t, dev), _i32(t, dev), _i32(n + 1, dev)) for t in (ta, tb)]
     lib.call('pamnet_knn_cut_fill_i32', lib.ptr(kn), lib.ptr(kd), n, int(k), float(cut_a), lib.ptr(ra), ta, lib.ptr(outs[0][0]),
              lib.ptr(outs[0][1]), lib.ptr(outs[0][2]), lib.ptr(outs[0][3]), float(cut_b), lib.ptr(rb), tb, lib.ptr(outs[1][0]),
              lib.ptr(outs[1][1]), lib.ptr(outs[1][2]), lib.ptr(outs[1][3]), st)
-    return tuple((o[3], o[0], o[1], o[2]) for o in outs)
+    res = tuple((o[3], o[0], o[1], o[2]) for o in outs)
+    return res if tp_of_b is None else res + (tp_total,)
 
 
 class InverseTranspose(object):
@@ -863,7 +881,12 @@ def build_graph(dataset, cutoff_l, cutoff_g, flow, x_raw, batch, pos=None, edge_
             gp, gn, gd = _filter_fill(kp, kn, kd, cutoff_g, pa, total_g, zeroed=hinted)
             qp, qn, qd = _filter_fill(kp, kn, kd, cutoff_l, pb, total_l, zeroed=hinted)
         elif n > 0 and knn_k <= 64:               # one search, both cuts, one host round trip
-            (gp, gn, gd, gq), (qp, qn, qd, qq) = knn_cuts(pos, node_graph, g.gptr, knn_k, cutoff_g, cutoff_l, flag)
+            # ... and the triplet / pair total of the local cut with them: the second read-back (of the scanned row counts) goes
+            if KNN_TP_TOTAL:
+                (gp, gn, gd, gq), (qp, qn, qd, qq), tp_hint = knn_cuts(pos, node_graph, g.gptr, knn_k, cutoff_g, cutoff_l, flag,
+                                                                        tp_of_b=bool(with_triplets))
+            else:
+                (gp, gn, gd, gq), (qp, qn, qd, qq) = knn_cuts(pos, node_graph, g.gptr, knn_k, cutoff_g, cutoff_l, flag)
         else:
             kp, kn, kd = knn_table(pos, node_graph, g.gptr, knn_k, float('inf'))
             (gp, gn, gd), (qp, qn, qd) = csr_filter2(kp, kn, kd, cutoff_g, cutoff_l, flag)

@@ -819,6 +819,26 @@ def test_knn_cut_and_fill_equal_table_filters_and_expands(dev, n_nodes, k):
             assert int(nbr[m:].abs().sum()) == 0                   # nothing written beyond what the list holds
 
 
+@pytest.mark.parametrize('with_triplets', [True, False])
+@pytest.mark.parametrize('n_nodes,k,cut', [(300, 50, 2.6), (40, 50, 2.6), (700, 17, 6.0), (900, 50, 20.0)])
+def test_knn_triplet_total_before_the_graph_exists(dev, n_nodes, k, cut, with_triplets):
+    """Round 6: pamnet_knn_tp_total_i64 -- the triplet + pair row total of the local graph (models.py:68-98) from the kNN table
+    alone -- equals the scanned row counts of pamnet_triplet_count_i32 on the finished, transposed local graph (what the second
+    host read-back of the RNA path used to fetch), for sparse and dense cuts, k below and at the reference's 50."""
+    from pamnet_amd import graph as G, lib, synth
+    b = synth.rna_batch(6, 0, 3, n_nodes=n_nodes)
+    pos = b.x[:, :3].contiguous().to(dev)
+    nodeg = b.batch.to(torch.int32).to(dev)
+    n = int(nodeg.numel())
+    gptr, _ = G.csr_from_keys(nodeg, 3)
+    res = G.knn_cuts(pos, nodeg, gptr, k, 20.0, cut, None, tp_of_b=with_triplets)
+    (qp, qn, qd, qq), total = res[1], res[2]
+    lp, l_src, l_dist, _ = G._transpose_edges(qp, qn, qd, n, q=qq)
+    l_dst = G.expand_rows(lp, int(l_src.numel()))
+    tp_ptr, _ = G._triplet_ptr(lp, l_src, l_dst, with_triplets)
+    assert total == int(tp_ptr[-1]) and (total > 0 or int(l_src.numel()) == 0)
+
+
 @pytest.mark.parametrize('n', [1, 100, 24576, 24577, 70000])
 def test_exclusive_scan_pair(dev, n):
     from pamnet_amd import graph as G, lib
