@@ -1,14 +1,14 @@
 # HBM traffic of the fused edge MLP -> node segment-sum kernel at the PDBbind B=32 shape (E_g ~ 700 k: 360 MB per
 # [E_g, 128] tensor, beyond the 256 MB Infinity Cache -- at the QM9 batch everything is cache resident and the counters
 # read almost nothing).  Separate --pmc passes with --kernel-trace only; FETCH_SIZE x2 / WRITE_SIZE as in pmc_scatter.sh
-# (MI355X_MICROARCH.md, HBM section).  Writes gpurun_out/${PMC_OUT:-r05_edge_agg_pmc.json} (copy into profiles/ and commit).
+# (MI355X_MICROARCH.md, HBM section).  Writes gpurun_out/${PMC_OUT:-r06_edge_agg_pmc.json} (copy into profiles/ and commit).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmca_$c
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmca_$c -- python $R/tools/agg_bench.py pdbbind > /tmp/pmca_$c.log 2>&1
 done
-python - <<'PY' > $R/gpurun_out/${PMC_OUT:-r05_edge_agg_pmc.json}
+python - <<'PY' > $R/gpurun_out/${PMC_OUT:-r06_edge_agg_pmc.json}
 import csv, glob, json, re
 D = 128
 def counter(name, kernel):
@@ -30,7 +30,8 @@ for k in names:
     write, n2 = counter('WRITE_SIZE', k)
     traffic = (2.0 * fetch + write) * 1024.0
     bwd = 'bwd' in k
-    save = ('true' in k.split('<')[1].split('>')[0].split(',')[2]) if ('fwd' in k and ',' in k) else False   # <MTX, PRE, SAVE>
+    targs = k.split('<')[1].split('>')[0].split(',')
+    save = ('fwd_pp' in k and 'true' in targs[0]) or ('fwd' in k and len(targs) > 2 and 'true' in targs[2])   # pp: <SAVE>; chunked: <MTX, PRE, SAVE>
     a = alg + (8.0 * D * eg if save else 0.0)
     if bwd:       # reads d x2 (n), z, ea, writes dz, dea, d_e (+ read for accumulate), dP_i: 6 edge tensors + 2 node planes
         a = 4.0 * D * eg * 6 + 8.0 * eg + 4.0 * D * n * 2
@@ -42,4 +43,4 @@ for k in names:
                               'traffic_over_algorithmic': traffic / a}
 print(json.dumps(out, indent=1))
 PY
-cat $R/gpurun_out/${PMC_OUT:-r05_edge_agg_pmc.json}
+cat $R/gpurun_out/${PMC_OUT:-r06_edge_agg_pmc.json}
