@@ -1263,3 +1263,40 @@ def test_edge_recompute_switch_gives_the_same_step_bit_for_bit():
         assert int(lines['EG'][0]) >= 131072          # the fused weight-gradient backward: where the switch applies
         outs.append(lines['HASH'])
     assert float(outs[0][2]) > 0 and outs[0] == outs[1], outs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['pamnet_s_d128', 'pamnet_d32', 'pdbbind_d128'])
+def test_flat_parameter_view_gradients_other_models(kind, monkeypatch):
+    """PAMNET_FLAT_PARAMS=1 on the other model kinds (PAMNet_s, a narrow width, the PDBbind branch): one step of the reference's
+    loop body gives the parameters the per-tensor interface gives (SGD, so that the comparison is of the gradients themselves)."""
+    import models
+    from pamnet_amd import synth
+    dev = torch.device('cuda:0')
+    if kind == 'pamnet_s_d128':
+        cls, cfg = models.PAMNet_s, models.Config(dataset='QM9', dim=128, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+        b = synth.qm9_batch(4, 0, 5).to(dev)
+    elif kind == 'pamnet_d32':
+        cls, cfg = models.PAMNet, models.Config(dataset='QM9', dim=32, n_layer=2, cutoff_l=5.0, cutoff_g=5.0)
+        b = synth.qm9_batch(4, 0, 5).to(dev)
+    else:
+        cls, cfg = models.PAMNet, models.Config(dataset='PDBbind', dim=128, n_layer=1, cutoff_l=2.0, cutoff_g=6.0)
+        b = synth.pdbbind_batch(3, 0, 2, n_pocket=60, n_ligand=12).to(dev)
+    results = []
+    for flat in ('0', '1'):
+        monkeypatch.setenv('PAMNET_FLAT_PARAMS', flat)
+        torch.manual_seed(9)
+        model = cls(cfg).to(dev)
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        assert len(opt.param_groups[0]['params']) == (1 if flat == '1' else len(model.state_dict()))
+        for _ in range(2):
+            opt.zero_grad()
+            loss = torch.nn.functional.l1_loss(model(b), b.y)
+            loss.backward()
+            opt.step()
+        results.append(({k: v.clone() for k, v in model.state_dict().items()}, float(loss.detach())))
+    (a, la), (f, lf) = results
+    assert abs(la - lf) <= 1e-6 * max(1.0, abs(la))
+    for k in a:
+        scale = float(a[k].abs().max())
+        assert float((a[k] - f[k]).abs().max()) <= 2e-6 * max(scale, 1e-30), k
