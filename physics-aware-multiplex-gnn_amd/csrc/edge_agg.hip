@@ -633,11 +633,19 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_fwd_pp_kernel(GAggFwd 
                 const int k = t - 1;
                 float* Zk = Zb + (k & 1) * TG * TF;
                 float* Mk = Mb + (k % 3) * TG * TF;
+                // (every LDS operand of the phase requested before the first is used: one wave per SIMD is doing this work --
+                // nobody covers its round trips, and what a phase waits for is this wave)
+                float4 zacc_[NIW], gate_[NIW];
+#pragma unroll
+                for (int i = 0; i < NIW; ++i) {
+                    zacc_[i] = lds4(Zk, trow0 + RPP * i, c4);
+                    gate_[i] = lds4(Mk, trow0 + RPP * i, c4);
+                }
 #pragma unroll
                 for (int i = 0; i < NIW; ++i) {
                     const int r = trow0 + RPP * i;
-                    const float4 zacc = lds4(Zk, r, c4);
-                    const float4 gate = lds4(Mk, r, c4);
+                    const float4 zacc = zacc_[i];
+                    const float4 gate = gate_[i];
                     const float4 zz = f4add(f4add(zacc, gpi[i]), gpj[i]);
 #ifdef PP_NO_SILU
                     st_lds4(Mk, r, c4, f4mul(zz, gate));
