@@ -378,6 +378,62 @@ def pdbbind_kernel_rooflines(model, batch, dev):
                     'note': 'us_per_launch: back-to-back repetitions (part of the input still in the Infinity Cache); '
                             '*_cold_caches: each launch behind 3 GB of unrelated traffic -- the condition inside the step',
                     'launches_per_step': model.n_layer if perm is not None else 0})
+    # The input stage at this shape (verdict r5 item 7: embed_multi_fwd / bwd, mlp2_fwd -- once per step each): all input
+    # embeddings as one launch forward (Bessel rows formed in the kernel), two backward; the triplet / pair MLPs of all layers as
+    # one launch.  Algorithmic bytes: the [rows, 128] outputs written (forward) / their gradients read (backward) + the raw inputs.
+    try:
+        import ctypes as _ct
+        from pamnet_amd import lib as _lib
+        el, tp = int(g.loc.m), int(g.tp.m)
+        rows_all = el + m + tp + n
+        raw = 4.0 * (el + m) + 4.0 * 42 * tp + 4.0 * 18 * n + 4.0 * tp
+        staged = None
+
+        def stage_fwd():
+            nonlocal staged
+            staged = model._input_stage(batch, g, None, model.mlp_sbf2[0][0], model.mlp_sbf1[0][0])
+
+        with torch.enable_grad():
+            stage_fwd()
+            ms_f, _ = event_time_ms(stage_fwd, 10, 3)
+            gs = [torch.randn_like(t) for t in staged]
+
+            def stage_bwd():
+                stage_fwd()
+                torch.autograd.backward(list(staged), gs)
+
+            stage_bwd()
+            ms_fb, _ = event_time_ms(stage_bwd, 10, 3)
+        for p_ in model.parameters():
+            p_.grad = None
+        ms_b = max(ms_fb - ms_f, 1e-6)
+        by_sf, by_sb = 4.0 * d * rows_all + raw, 4.0 * d * rows_all + raw
+        res.append({'kernel': 'embed_multi_fwd_kernel (every input embedding of the batch, one launch)', 'bound': 'hbm',
+                    'rows': rows_all, 'bytes_per_launch': by_sf, 'us_per_launch': ms_f * 1e3, 'achieved': by_sf / ms_f / 1e6,
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': by_sf / ms_f / 1e6 / HBM_PEAK_GBS, 'launches_per_step': 1})
+        res.append({'kernel': 'embed_multi_bwd_kernel + embed_multi_reduce_kernel (their backward; forward + backward timed, forward '
+                              'subtracted)', 'bound': 'hbm', 'rows': rows_all, 'bytes_per_launch': by_sb,
+                    'us_per_launch': ms_b * 1e3, 'achieved': by_sb / ms_b / 1e6, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': by_sb / ms_b / 1e6 / HBM_PEAK_GBS, 'launches_per_step': 1})
+        L = model.n_layer
+        xs = torch.randn(tp, d, device=dev) * 0.5
+        Ws = [[torch.randn(d, d, device=dev) / 8, torch.randn(d, device=dev), torch.randn(d, d, device=dev) / 8,
+               torch.randn(d, device=dev)] for _ in range(L)]
+        outs = [[torch.empty(tp, d, device=dev) for _ in range(3)] for _ in range(L)]
+        pp = (_ct.c_void_p * (4 * L))(*[t.data_ptr() for w in Ws for t in w])
+        oo = (_ct.c_void_p * (3 * L))(*[t.data_ptr() for o in outs for t in o])
+        fn2 = lambda: _lib.call('pamnet_mlp2_fwd_multi_f32', _lib.ptr(xs), tp, L, pp, oo, _lib.stream_of(xs))
+        fn2()
+        ms2, _ = event_time_ms(fn2, 10, 3)
+        by2 = 4.0 * d * tp * (1 + 3 * L)                   # the rows once + z1, z2, y of every layer
+        fl2 = 2.0 * 2.0 * d * d * tp * L
+        res.append({'kernel': 'mlp2_fwd_kernel<7, 8> (the triplet / pair MLPs of all %d layers on the same rows, one launch)' % L,
+                    'bound': 'hbm', 'rows': tp, 'bytes_per_launch': by2, 'us_per_launch': ms2 * 1e3, 'achieved': by2 / ms2 / 1e6,
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': by2 / ms2 / 1e6 / HBM_PEAK_GBS,
+                    'fp32_equivalent_tflops': fl2 / ms2 / 1e9, 'frac_bf16x6': fl2 / ms2 / 1e9 / (BF16_MFMA_PEAK_TFLOPS / 6.0),
+                    'launches_per_step': 1})
+    except Exception as ex:                                 # noqa: BLE001 -- side entries
+        res.append({'kernel': 'input stage entries', 'error': '%s: %s' % (type(ex).__name__, ex)})
     # The fused edge MLP -> segment-sum kernels of the global layer (csrc/edge_agg.hip) on the same graph.  The backward forms
     # wait for HBM (priced against it); the forward issues on the bf16 matrix pipe (priced against dense bf16 / 6).
     # Algorithmic bytes (profiles/r05_edge_agg_pmc.json measures the traffic against them):
