@@ -396,3 +396,49 @@ def test_ping_pong_forward_equals_the_chunked_kernel_bit_for_bit(dev, case, save
             assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]), 'saves'
     monkeypatch.setenv('PAMNET_AGG_PP', '1')                          # ... and the ping-pong kernel when told to
     assert torch.equal(run('pamnet_global_edge_agg_fwd_f32', lib.ptr(cuts_t))[0], ref[0])
+
+
+def test_ping_pong_forward_is_run_to_run_identical_under_load(dev):
+    """The ping-pong kernel's phases hand LDS slots between the halves of a workgroup through barriers only: a missed hazard would
+    show as run-to-run differences once timing moves.  200 launches at a PDBbind-like size while another stream keeps the memory
+    system and some CUs busy: every output (out, z, ea) bit for bit the first launch's."""
+    from pamnet_amd import lib
+    rng = np.random.default_rng(21)
+    deg = rng.integers(15, 70, size=9000)
+    n = len(deg)
+    ptr, row_of, col, m = _csr(deg, n, 3, dev)
+    gen = torch.Generator().manual_seed(17)
+    mk = lambda *s: (0.5 * torch.randn(*s, generator=gen)).to(dev)
+    e, Pi, Pj, init = mk(m, D), mk(n, D), mk(n, D), mk(n, D)
+    Wm, bm, Wea = _weights(dev, 6)
+    st = lib.stream_of(Pi)
+    sub = lambda w, c0: w.data_ptr() + 4 * c0
+    cuts_t = torch.full((257,), -1, dtype=torch.int32, device=dev)
+    lib.call('pamnet_seg_cuts_i32', lib.ptr(ptr), lib.ptr(row_of), n, m, lib.ptr(cuts_t), None, st)
+    z, ea, out = torch.empty(m, D, device=dev), torch.empty(m, D, device=dev), torch.empty(n, D, device=dev)
+
+    def run():
+        lib.call('pamnet_global_edge_agg_fwd_pp_f32', lib.ptr(e), m, n, sub(Wm, 2 * D), 3 * D, lib.ptr(bm), lib.ptr(Wea), D,
+                 lib.ptr(Pi), lib.ptr(Pj), lib.ptr(ptr), lib.ptr(row_of), lib.ptr(col), lib.ptr(cuts_t), lib.ptr(init), lib.ptr(z),
+                 lib.ptr(ea), lib.ptr(out), st)
+
+    run()
+    torch.cuda.synchronize()
+    ref = (out.clone(), z.clone(), ea.clone())
+    side = torch.cuda.Stream()
+    noise_a, noise_b = torch.randn(64 << 20, device=dev), torch.empty(64 << 20, device=dev)
+    small = torch.randn(512, 512, device=dev)
+    for it in range(200):
+        with torch.cuda.stream(side):                        # traffic + a few busy CUs beside every other launch
+            if it % 2 == 0:
+                noise_b.copy_(noise_a)
+            else:
+                for _ in range(4):
+                    small = torch.tanh(small @ small * 1e-3)
+        out.fill_(float('nan'))
+        run()
+        if it % 20 == 19:
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref[0]) and torch.equal(z, ref[1]) and torch.equal(ea, ref[2]), it
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref[0]) and torch.equal(z, ref[1]) and torch.equal(ea, ref[2])
