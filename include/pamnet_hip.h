@@ -34,7 +34,7 @@ typedef void* pamnet_stream_t; /* hipStream_t */
 
 /* Library / ABI version (bumped on any signature change).  pamnet_abi_version() returns the PAMNET_ABI_VERSION the library
  * was built against; a binding compares it with this header's (pamnet_amd/lib.py load(): a stale .so fails loudly). */
-#define PAMNET_ABI_VERSION 11
+#define PAMNET_ABI_VERSION 12
 int pamnet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -434,6 +434,15 @@ int pamnet_node_pre_tail_bwd_f32(const float* dP, const float* dx1_direct, const
                                  const float* g_head, const float* const* weights, const float* Z, float* dZ,
                                  float* d_x2, float* d_resx, const void* rider /* host, nullable */,
                                  pamnet_stream_t stream);
+/* The same with planes of dP formed inside the launch (round 6): gather_src[b] != null -> plane b, row i = the sum of
+ * gather_src[b][gather_perm[b] ? gather_perm[b][q] : q] over q in [gather_ptr[b][i], gather_ptr[b][i+1]) in that order, used and
+ * also written to dP + b n 128 -- the pamnet_segment_sum(_multi)_f32 launches that otherwise run ahead of this one. */
+int pamnet_node_pre_tail_bwd_gather_f32(float* dP, const float* const* gather_src, const int32_t* const* gather_ptr,
+                                        const int32_t* const* gather_perm, const float* dx1_direct, const float* d_add,
+                                        int64_t n, const float* Wx1, const float* const* wp, int64_t nblk, const float* Zx1,
+                                        float* dZx1, const float* g_head, const float* const* weights, const float* Z,
+                                        float* dZ, float* d_x2, float* d_resx, const void* rider /* host, nullable */,
+                                        pamnet_stream_t stream);
 /* Fragment-ordered weight images for the node chains: n (<= 192) 128x128 matrices (row stride ld[i]) -> images[i*16384..],
  * transposed = 0 for the forward (Y = X W^T), 1 for the backward (Y = X W).  With packed != 0 the `weights` (and, in the
  * forward, next_Wx1 / next_wp) arguments of node_tail_fwd / node_tail_bwd, and Wx1 / wp of node_pre_bwd (transposed

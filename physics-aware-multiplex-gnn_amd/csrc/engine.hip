@@ -256,6 +256,15 @@ constexpr int64_t PACK_FLOATS_PER_PAIR = PACK_PER_PAIR * (3 * D * D / 2);     //
 // (the MFMAs of a layer shrink from 2 300 to 1 100 cycles, tools/tail_probe_bf16.py, but the epilogue grows by as much:
 // the split of the result, 12 more LDS stores with 4-way bank conflicts, 96 KB instead of 64 KB of weights per layer
 // from L2); same outputs to 3e-7 (tests/test_hip_fused.py::test_node_tail_fwd_bf16x6).
+// Round 6: the segment sums that feed a fused head + chain backward launch (the source-side sum of the global layer's d z, the
+// four sums of the local layer) are formed by that launch's own row tiles (node_tail.hip gather_plane_row) instead of by launches
+// of their own ahead of it: two launches fewer per layer pair on the dependent chain.  PAMNET_FUSE_SEGSUM=0: the separate launches.
+inline bool fuse_segsum(const Graph& g) {
+    static const bool v = [] { const char* e = getenv("PAMNET_FUSE_SEGSUM"); return !e || atoi(e) != 0; }();
+    // (batches of more than 256 row tiles run the LEAN chain kernels -- node_tail.hip LEAN_FROM_TILES --, which read their planes:
+    // those keep the tuned stand-alone segment sums)
+    return v && (g.n + 15) / 16 <= 256;
+}
 inline bool chain_bf16() {
     static bool v = [] { const char* e = getenv("PAMNET_CHAIN_BF16"); return e && atoi(e) != 0; }();
     return v;
@@ -673,11 +682,12 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             CK(pamnet_local_bwd_pair_f32(t.ds, g.tp, q.z1, q.z2, lp[6], lp[8], t.dz1, t.dz2, d_sbf, acc, t.dmt, t.dmnb, t.dq3,
                                          g.el, q.zji, q.zkj, q.q2, wq, ldq, t.dzji, t.dzkj, t.dq2, d_rbf, acc, st));
             const int64_t pl = g.n * D;
-            {
+            const float* sa[4] = {t.dzji, t.dzkj, t.dzji, t.dzkj};
+            const int32_t* sp[4] = {nullptr, nullptr, g.lT_perm, g.lT_perm};
+            const int32_t* sr[4] = {g.l_ptr, g.l_ptr, g.lT_ptr, g.lT_ptr};
+            const bool gather_l = fuse && fuse_segsum(g);      // the four sums inside the fused launch below
+            if (!gather_l) {
                 float* so[4] = {t.dP, t.dP + pl, t.dP + 2 * pl, t.dP + 3 * pl};
-                const float* sa[4] = {t.dzji, t.dzkj, t.dzji, t.dzkj};
-                const int32_t* sp[4] = {nullptr, nullptr, g.lT_perm, g.lT_perm};
-                const int32_t* sr[4] = {g.l_ptr, g.l_ptr, g.lT_ptr, g.lT_ptr};
                 CK(pamnet_segment_sum_multi_f32(4, so, sa, sp, sr, g.n, D, st));
             }
             if (fuse) {
@@ -689,8 +699,13 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                     tail_jobs(jr, g, dz_local, q.hdz, q.x2, q.Z, q.R, q.xout, lg + LT, 0, rider_jobs());
                     CK(plan_rider(jr, t.rider_partial, g, rider.data(), &rider_a_slots));
                 }
-                CK(pamnet_node_pre_tail_bwd_f32(t.dP, t.dx2, t.dresx, g.n, img[k].lh[4], img[k].lh, 4, q.Zx1, t.dZx1, s.gh,
-                                                img[k].gt, s.Z, dz_global, t.dx2, t.dresx, ride ? rider.data() : nullptr, st));
+                if (gather_l)
+                    CK(pamnet_node_pre_tail_bwd_gather_f32(t.dP, sa, sr, sp, t.dx2, t.dresx, g.n, img[k].lh[4], img[k].lh, 4, q.Zx1,
+                                                           t.dZx1, s.gh, img[k].gt, s.Z, dz_global, t.dx2, t.dresx,
+                                                           ride ? rider.data() : nullptr, st));
+                else
+                    CK(pamnet_node_pre_tail_bwd_f32(t.dP, t.dx2, t.dresx, g.n, img[k].lh[4], img[k].lh, 4, q.Zx1, t.dZx1, s.gh,
+                                                    img[k].gt, s.Z, dz_global, t.dx2, t.dresx, ride ? rider.data() : nullptr, st));
                 if (ride) CK(pamnet_wgrad_rider_enqueue_f32(wctx.data(), rider.data()));
             } else {
                 const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
@@ -762,7 +777,9 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                 CK(pamnet_global_edge_agg_bwd_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, cuts, s.z, s.ea, gp[2] + 2 * D, 3 * D, gp[4],
                                                   D, t.dz, t.dea, d_eg, acc, t.dPg, st));
             }
-            CK(pamnet_segment_sum_f32(t.dPg + pl, nullptr, t.dz, nullptr, nullptr, nullptr, g.gT_perm, g.gT_ptr, g.n, D, st));
+            const bool gather_g = fuse && k > 0 && fuse_segsum(g);   // the source-side sum inside the fused launch below
+            if (!gather_g)
+                CK(pamnet_segment_sum_f32(t.dPg + pl, nullptr, t.dz, nullptr, nullptr, nullptr, g.gT_perm, g.gT_ptr, g.n, D, st));
             if (fuse && k > 0) {
                 // head of the global layer + the local chain of the previous pair
                 const LocalSaved qp = carve_local(const_cast<float*>(saved) + (k - 1) * (gs + ls) + gs, g);
@@ -774,9 +791,18 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                     tail_jobs(jr, g, dz_global, s.hdz, s.x2, s.Z, s.R, s.xout, gg + GT, 0, rider_jobs());
                     CK(plan_rider(jr, t.rider_partial + rider_a_slots * (D * D + 2 * D), g, rider.data(), nullptr));
                 }
-                CK(pamnet_node_pre_tail_bwd_f32(t.dPg, t.dx2, t.dresx, g.n, img[k].gh[2], img[k].gh, 2, s.Zx1, t.dZx1g, qp.gh,
-                                                img[k - 1].lt, qp.Z, dz_local, t.dx2, t.dresx, ride ? rider.data() : nullptr,
-                                                st));
+                if (gather_g) {
+                    const float* ga[2] = {nullptr, t.dz};
+                    const int32_t* gr[2] = {nullptr, g.gT_ptr};
+                    const int32_t* gq[2] = {nullptr, g.gT_perm};
+                    CK(pamnet_node_pre_tail_bwd_gather_f32(t.dPg, ga, gr, gq, t.dx2, t.dresx, g.n, img[k].gh[2], img[k].gh, 2, s.Zx1,
+                                                           t.dZx1g, qp.gh, img[k - 1].lt, qp.Z, dz_local, t.dx2, t.dresx,
+                                                           ride ? rider.data() : nullptr, st));
+                } else {
+                    CK(pamnet_node_pre_tail_bwd_f32(t.dPg, t.dx2, t.dresx, g.n, img[k].gh[2], img[k].gh, 2, s.Zx1, t.dZx1g, qp.gh,
+                                                    img[k - 1].lt, qp.Z, dz_local, t.dx2, t.dresx,
+                                                    ride ? rider.data() : nullptr, st));
+                }
                 if (ride) CK(pamnet_wgrad_rider_enqueue_f32(wctx.data(), rider.data()));
             } else {
                 const float* wpg[2] = {gp[2], gp[2] + D};

@@ -776,7 +776,30 @@ struct PreBwd {
     const float* d_add;       // [n][128]
     float* dZx1;              // [n][128] out
     int nblk;
+    // Round 6: plane b of dP may be FORMED here instead of read -- the segment sum the engine used to launch ahead of this kernel
+    // (the source-side reduction of the global layer's d z; the four of the local layer): gsrc[b] != null: plane b, row i =
+    // the sum over q in [gptr[b][i], gptr[b][i + 1]) of gsrc[b][gperm[b] ? gperm[b][q] : q], in that order; written to
+    // dP_out + b * plane for the weight-gradient jobs that read the plane later.
+    const float* gsrc[4];
+    const int32_t* gptr[4];
+    const int32_t* gperm[4];
+    float* dP_out;
 };
+// plane row `row` (this thread's float4 column) as the segment sum of its rows of `src`, in CSR order
+__device__ __forceinline__ float4 gather_plane_row(const float* __restrict__ src, const int32_t* __restrict__ ptr,
+                                                   const int32_t* __restrict__ perm, int64_t row, int c4) {
+    int q = ptr[row];
+    const int q1 = ptr[row + 1];
+    float4 s = f4zero();
+    for (; q + 4 <= q1; q += 4) {                              // four rows in flight, added in order
+        int i0 = q, i1 = q + 1, i2 = q + 2, i3 = q + 3;
+        if (perm) i0 = perm[q], i1 = perm[q + 1], i2 = perm[q + 2], i3 = perm[q + 3];
+        const float4 v0 = ldg4(src, i0, DIM, c4), v1 = ldg4(src, i1, DIM, c4), v2 = ldg4(src, i2, DIM, c4), v3 = ldg4(src, i3, DIM, c4);
+        s = f4add(f4add(f4add(f4add(s, v0), v1), v2), v3);
+    }
+    for (; q < q1; ++q) s = f4add(s, ldg4(src, perm ? perm[q] : q, DIM, c4));
+    return s;
+}
 
 template <bool PACKED, bool HEADS, bool PRE = false>
 __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restrict__ d_xout /* may be null */,
@@ -839,7 +862,19 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
             // tiles of the head backward: dP planes -> ZL[7..9] + the (unused) head-partial area, z_x1 -> EX,
             // d x1_direct -> D1, d_add joins K (K = d_add + g_head; the head's d x is added below)
             float* const pl[4] = {ZL + 7 * SLOT, ZL + 8 * SLOT, ZL + 9 * SLOT, red};
-            for (int b = 0; b < pb.nblk; ++b) st_lds4(pl[b], sr, sc4, ldg4z(pb.dP + (int64_t)b * plane, sg, n, DIM, sc4));
+            for (int b = 0; b < pb.nblk; ++b) {
+                float4 v;
+                if (pb.gsrc[b]) {                              // (workgroup-uniform) the plane is formed here, and kept
+                    v = f4zero();
+                    if (sg < n) {
+                        v = gather_plane_row(pb.gsrc[b], pb.gptr[b], pb.gperm[b], sg, sc4);
+                        stg4(pb.dP_out + (int64_t)b * plane, sg, DIM, sc4, v);
+                    }
+                } else {
+                    v = ldg4z(pb.dP + (int64_t)b * plane, sg, n, DIM, sc4);
+                }
+                st_lds4(pl[b], sr, sc4, v);
+            }
             st_lds4(EX, sr, sc4, ldg4z(pb.Zx1, sg, n, DIM, sc4));
             st_lds4(D1, sr, sc4, ldg4z(pb.dx1_direct, sg, n, DIM, sc4));
             kx = f4add(kx, ldg4z(pb.d_add, sg, n, DIM, sc4));
@@ -1520,11 +1555,12 @@ extern "C" int pamnet_node_tail_main_bwd_f32(const float* d_xout, const float* g
 /* tail_main_bwd preceded, on the same row tiles, by the backward of the next layer's head (pamnet_node_pre_bwd_f32 with
  * its d x feeding this chain's d x_out; d_xout of the chain is that d x, so there is no d_xout argument).  Packed
  * (transposed-orientation) weight images only. */
-extern "C" int pamnet_node_pre_tail_bwd_f32(const float* dP, const float* dx1_direct, const float* d_add, int64_t n,
-                                            const float* Wx1, const float* const* wp, int64_t nblk, const float* Zx1,
-                                            float* dZx1, const float* g_head, const float* const* weights,
-                                            const float* Z, float* dZ, float* d_x2, float* d_resx,
-                                            const void* rider, pamnet_stream_t stream) {
+static int node_pre_tail_bwd_impl(float* dP, const float* const* gsrc, const int32_t* const* gptr,
+                                  const int32_t* const* gperm, const float* dx1_direct, const float* d_add, int64_t n,
+                                  const float* Wx1, const float* const* wp, int64_t nblk, const float* Zx1,
+                                  float* dZx1, const float* g_head, const float* const* weights,
+                                  const float* Z, float* dZ, float* d_x2, float* d_resx,
+                                  const void* rider, pamnet_stream_t stream) {
     if (n < 0 || nblk < 1 || nblk > 4) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
     if (!dP || !dx1_direct || !d_add || !Wx1 || !wp || !Zx1 || !dZx1 || !g_head || !weights || !Z || !dZ || !d_x2 || !d_resx)
@@ -1532,9 +1568,16 @@ extern "C" int pamnet_node_pre_tail_bwd_f32(const float* dP, const float* dx1_di
     PreBwd pb{};
     pb.dP = dP, pb.Wx1 = Wx1, pb.Zx1 = Zx1, pb.dx1_direct = dx1_direct, pb.d_add = d_add, pb.dZx1 = dZx1;
     pb.nblk = (int)nblk;
+    pb.dP_out = dP;
+    bool any_gather = false;
     for (int b = 0; b < nblk; ++b) {
         if (!wp[b]) return PAMNET_ENULL;
         pb.wp[b] = wp[b];
+        if (gsrc && gsrc[b]) {
+            if (!gptr || !gptr[b]) return PAMNET_ENULL;
+            pb.gsrc[b] = gsrc[b], pb.gptr[b] = gptr[b], pb.gperm[b] = gperm ? gperm[b] : nullptr;
+            any_gather = true;
+        }
     }
     TailParams tp{};
     for (int k = 0; k < 7; ++k) {
@@ -1550,7 +1593,20 @@ extern "C" int pamnet_node_pre_tail_bwd_f32(const float* dP, const float* dx1_di
         const WgradRider* r = static_cast<const WgradRider*>(rider);
         rb = r->batch, rpart = r->partial, rslots = r->slots;
     }
-    if (rslots == 0 && (unsigned)n_tiles > LEAN_FROM_TILES && lean_mode() >= 2)
+    const bool lean = rslots == 0 && (unsigned)n_tiles > LEAN_FROM_TILES && lean_mode() >= 2;
+    if (lean && any_gather) {
+        // the lean form reads its planes: form them with the batched segment-sum launch first (what the engine did until round 6)
+        float* so[4];
+        const float* sa[4];
+        const int32_t *sp[4], *sr[4];
+        int64_t nj = 0;
+        for (int b = 0; b < nblk; ++b)
+            if (pb.gsrc[b]) so[nj] = dP + (int64_t)b * n * DIM, sa[nj] = pb.gsrc[b], sp[nj] = pb.gperm[b], sr[nj] = pb.gptr[b], ++nj;
+        const int rc = pamnet_segment_sum_multi_f32(nj, so, sa, sp, sr, n, DIM, stream);
+        if (rc) return rc;
+        for (int b = 0; b < 4; ++b) pb.gsrc[b] = nullptr;
+    }
+    if (lean)
         hipLaunchKernelGGL((node_tail_bwd_lean_kernel<true>), dim3((unsigned)n_tiles), dim3(TWG), 0, as_stream(stream),
                            (const float*)nullptr, g_head, n, tp, Z, dZ, d_x2, d_resx, pb);
     else
@@ -1559,6 +1615,29 @@ extern "C" int pamnet_node_pre_tail_bwd_f32(const float* dP, const float* dx1_di
                            (float*)nullptr, pb, rb, rpart, n_tiles);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
+}
+
+extern "C" int pamnet_node_pre_tail_bwd_f32(const float* dP, const float* dx1_direct, const float* d_add, int64_t n,
+                                            const float* Wx1, const float* const* wp, int64_t nblk, const float* Zx1,
+                                            float* dZx1, const float* g_head, const float* const* weights,
+                                            const float* Z, float* dZ, float* d_x2, float* d_resx,
+                                            const void* rider, pamnet_stream_t stream) {
+    return node_pre_tail_bwd_impl(const_cast<float*>(dP), nullptr, nullptr, nullptr, dx1_direct, d_add, n, Wx1, wp, nblk, Zx1, dZx1,
+                                  g_head, weights, Z, dZ, d_x2, d_resx, rider, stream);
+}
+/* The same with planes of dP formed inside the launch: gather_src[b] != null -> plane b (written to dP + b n 128 as well) is the
+ * segment sum of gather_src[b] over (gather_ptr[b], gather_perm[b] nullable) -- the launches of pamnet_segment_sum(_multi)_f32
+ * that used to run ahead of this one. */
+extern "C" int pamnet_node_pre_tail_bwd_gather_f32(float* dP, const float* const* gather_src,
+                                                   const int32_t* const* gather_ptr, const int32_t* const* gather_perm,
+                                                   const float* dx1_direct, const float* d_add, int64_t n, const float* Wx1,
+                                                   const float* const* wp, int64_t nblk, const float* Zx1, float* dZx1,
+                                                   const float* g_head, const float* const* weights, const float* Z,
+                                                   float* dZ, float* d_x2, float* d_resx, const void* rider,
+                                                   pamnet_stream_t stream) {
+    if (!gather_src || !gather_ptr) return PAMNET_ENULL;
+    return node_pre_tail_bwd_impl(dP, gather_src, gather_ptr, gather_perm, dx1_direct, d_add, n, Wx1, wp, nblk, Zx1, dZx1, g_head,
+                                  weights, Z, dZ, d_x2, d_resx, rider, stream);
 }
 
 extern "C" int pamnet_node_heads_bwd_f32(int64_t n_layers, const float* const* d_out, const float* const* d_att,
