@@ -34,7 +34,7 @@ typedef void* pamnet_stream_t; /* hipStream_t */
 
 /* Library / ABI version (bumped on any signature change).  pamnet_abi_version() returns the PAMNET_ABI_VERSION the library
  * was built against; a binding compares it with this header's (pamnet_amd/lib.py load(): a stale .so fails loudly). */
-#define PAMNET_ABI_VERSION 12
+#define PAMNET_ABI_VERSION 13
 int pamnet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -434,6 +434,22 @@ int pamnet_node_pre_tail_bwd_f32(const float* dP, const float* dx1_direct, const
                                  const float* g_head, const float* const* weights, const float* Z, float* dZ,
                                  float* d_x2, float* d_resx, const void* rider /* host, nullable */,
                                  pamnet_stream_t stream);
+/* The operands of pamnet_local_agg_fwd_f32 as one argument (round 6): pamnet_node_tail_fwd_agg_f32 is
+ * pamnet_node_tail_fwd_rider_f32 (mlp_ntiles = 0: without riders) whose chain input x2 is formed by the launch's own row tiles --
+ * the two chained aggregations of layers/local_message_passing.py:49-54, bit for bit pamnet_local_agg_fwd_f32's rows -- and
+ * written to x2 (and m_t) as well; chain forms that read their input run the aggregation as a launch of its own first. */
+typedef struct pamnet_local_agg {
+    const float *m_ji, *m_nb, *s, *q3, *init; /* init nullable = 0 */
+    const int32_t *t_ptr, *t_col, *l_ptr;
+    float* m_t;                               /* nullable: backward-only save */
+} pamnet_local_agg;
+int pamnet_node_tail_fwd_agg_f32(float* x2, const float* res_x, int64_t n, const float* const* weights,
+                                 const float* const* biases, const float* w_out, const float* b_out, const float* w_att,
+                                 float* Z, float* R, float* x_out, const float* next_Wx1, const float* next_bx1,
+                                 const float* const* next_wp, int64_t next_ldwp, int64_t next_nblk, float* next_Zx1,
+                                 float* next_x1, float* next_P, const float* mlp_x, int64_t mlp_rows, int64_t mlp_tile0,
+                                 int64_t mlp_ntiles, const float* const* mlp, float* const* mlp_out, int64_t rider_wgs,
+                                 int32_t packed, const pamnet_local_agg* agg, pamnet_stream_t stream);
 /* The same with planes of dP formed inside the launch (round 6): gather_src[b] != null -> plane b, row i = the sum of
  * gather_src[b][gather_perm[b] ? gather_perm[b][q] : q] over q in [gather_ptr[b][i], gather_ptr[b][i+1]) in that order, used and
  * also written to dP + b n 128 -- the pamnet_segment_sum(_multi)_f32 launches that otherwise run ahead of this one. */

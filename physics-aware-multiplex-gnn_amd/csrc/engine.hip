@@ -265,6 +265,13 @@ inline bool fuse_segsum(const Graph& g) {
     // those keep the tuned stand-alone segment sums)
     return v && (g.n + 15) / 16 <= 256;
 }
+// Round 6: the local layer's two chained aggregations (pamnet_local_agg_fwd_f32) are formed by the row tiles of the chain launch
+// that consumes them (node_tail.hip local_agg_row; pamnet_node_tail_fwd_agg_f32): one launch fewer per layer on the dependent
+// chain.  PAMNET_FUSE_LOCAL_AGG=0: the separate launch.  Small batches only (the lean chain forms read their input).
+inline bool fuse_local_agg(const Graph& g) {
+    static const bool v = [] { const char* e = getenv("PAMNET_FUSE_LOCAL_AGG"); return !e || atoi(e) != 0; }();
+    return v && (g.n + 15) / 16 <= 256;
+}
 inline bool chain_bf16() {
     static bool v = [] { const char* e = getenv("PAMNET_CHAIN_BF16"); return e && atoi(e) != 0; }();
     return v;
@@ -509,7 +516,10 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
                                      sv(q.q2), q.q3, t.mji, q.mnb, st));
         if (forked) HK(hipStreamWaitEvent(as_stream(st), reinterpret_cast<hipEvent_t>(aux_events[1 + k]), 0));
         // both aggregations of the local layer (rows -> edges -> nodes) in one launch; m_t is a backward-only save
-        CK(pamnet_local_agg_fwd_f32(t.mji, q.mnb, q.s, q.q3, g.t_ptr, g.t_col, g.l_ptr, t.x1, g.n, sv(q.mt), q.x2, st));
+        const bool agg_in = packed && fuse_local_agg(g);      // x2 formed by the chain launch's own tiles
+        const pamnet_local_agg la{t.mji, q.mnb, q.s, q.q3, t.x1, g.t_ptr, g.t_col, g.l_ptr, sv(q.mt)};
+        if (!agg_in)
+            CK(pamnet_local_agg_fwd_f32(t.mji, q.mnb, q.s, q.q3, g.t_ptr, g.t_col, g.l_ptr, t.x1, g.n, sv(q.mt), q.x2, st));
         if (k + 1 < n_layer) {
             const float* const* gn = gparams + (k + 1) * NG;
             const GlobalSaved sn = carve_global(saved + (k + 1) * (gs + ls), g);
@@ -520,15 +530,30 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
                 const LocalSaved qn = carve_local(saved + (k + 1) * (gs + ls) + gs, g);
                 const float* mp[4] = {ln[6], ln[7], ln[8], ln[9]};
                 float* mo[3] = {sv(qn.z1), sv(qn.z2), qn.s};
-                CK(pamnet_node_tail_fwd_rider_f32(q.x2, x, g.n, img[k].lt, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22],
-                                                  sv(q.Z), sv(q.R), q.xout, img[k].nh[0], gn[1], img[k].nh + 1, 3 * D, 2,
-                                                  sv(sn.Zx1), t.x1, Pn, e_sbf, g.tp, 0, mlp_half, mp, mo, rider_wgs, pkc, st));
+                if (agg_in)
+                    CK(pamnet_node_tail_fwd_agg_f32(q.x2, x, g.n, img[k].lt, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22],
+                                                    sv(q.Z), sv(q.R), q.xout, img[k].nh[0], gn[1], img[k].nh + 1, 3 * D, 2,
+                                                    sv(sn.Zx1), t.x1, Pn, e_sbf, g.tp, 0, mlp_half, mp, mo, rider_wgs, pkc, &la,
+                                                    st));
+                else
+                    CK(pamnet_node_tail_fwd_rider_f32(q.x2, x, g.n, img[k].lt, lp + LT + 10, lp[LT + 20], lp[LT + 21],
+                                                      lp[LT + 22], sv(q.Z), sv(q.R), q.xout, img[k].nh[0], gn[1], img[k].nh + 1,
+                                                      3 * D, 2, sv(sn.Zx1), t.x1, Pn, e_sbf, g.tp, 0, mlp_half, mp, mo, rider_wgs,
+                                                      pkc, st));
+            } else if (agg_in) {
+                CK(pamnet_node_tail_fwd_agg_f32(q.x2, x, g.n, img[k].lt, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22],
+                                                sv(q.Z), sv(q.R), q.xout, img[k].nh[0], gn[1], img[k].nh + 1, 3 * D, 2, sv(sn.Zx1),
+                                                t.x1, Pn, nullptr, 0, 0, 0, nullptr, nullptr, 0, pkc, &la, st));
             } else {
                 CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, packed ? img[k].lt : lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21],
                                             lp[LT + 22], sv(q.Z), sv(q.R), q.xout, nullptr, nullptr,
                                             packed ? img[k].nh[0] : gn[0], gn[1],
                                             packed ? img[k].nh + 1 : wpn, 3 * D, 2, sv(sn.Zx1), t.x1, Pn, pkc, st));
             }
+        } else if (agg_in) {
+            CK(pamnet_node_tail_fwd_agg_f32(q.x2, x, g.n, img[k].lt, lp + LT + 10, lp[LT + 20], lp[LT + 21], lp[LT + 22], sv(q.Z),
+                                            sv(q.R), q.xout, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0,
+                                            0, nullptr, nullptr, 0, pkc, &la, st));
         } else {
             CK(pamnet_node_tail_fwd_f32(q.x2, x, g.n, packed ? img[k].lt : lp + LT, lp + LT + 10, lp[LT + 20], lp[LT + 21],
                                         lp[LT + 22], sv(q.Z), sv(q.R), q.xout, nullptr, nullptr, nullptr, nullptr,

@@ -152,13 +152,49 @@ __device__ __forceinline__ f32x4 mma_strip(const float* __restrict__ As, const W
 // runs it for every layer of the model in one launch after the layer loop: nothing downstream of a layer depends on
 // its heads, the chain gets three dependent GEMMs shorter, and the batched launch has 2L x ceil(n/16) workgroups
 // instead of the chain's ceil(n/16) (143 of 256 CUs at the QM9 batch).
+// Round 6: the chain input x2 of the LOCAL layer may be FORMED by this launch's own row tiles instead of read -- the two chained
+// aggregations of layers/local_message_passing.py:49-54 that pamnet_local_agg_fwd_f32 computes in a launch of its own ahead of the
+// chain:   m_t[e] = m_ji[e] + sum_{r in rows(e)} m_nb[t_col[r]] * s[r],   x2[i] = x1[i] + sum_{e -> i} q3[e] * m_t[e]
+// (the same operations in the same order: bit for bit that kernel's rows).  x2 and m_t are still written (saved activations).
+struct LocalAgg {
+    const float4 *m_ji, *m_nb, *s, *q3, *init;
+    const int32_t *t_ptr, *t_col, *l_ptr;
+    float4* m_t;                  // nullable: backward-only save
+    float4* x2_out;
+};
+__device__ __forceinline__ float4 local_agg_row(const LocalAgg& la, int64_t node, int c) {
+    float4 acc = la.init ? la.init[node * 32 + c] : f4zero();
+    const int e0 = la.l_ptr[node], e1 = la.l_ptr[node + 1];
+    for (int e = e0; e < e1; ++e) {
+        const int t0 = la.t_ptr[e], t1 = la.t_ptr[e + 1];
+        float4 v = la.m_ji[(int64_t)e * 32 + c];
+        const float4 gate = la.q3[(int64_t)e * 32 + c];
+        int t = t0;
+        for (; t + 4 <= t1; t += 4) {
+            const int64_t k0 = la.t_col[t], k1 = la.t_col[t + 1], k2 = la.t_col[t + 2], k3 = la.t_col[t + 3];
+            const float4 a0 = la.m_nb[k0 * 32 + c], a1 = la.m_nb[k1 * 32 + c], a2 = la.m_nb[k2 * 32 + c], a3 = la.m_nb[k3 * 32 + c];
+            const float4 b0 = la.s[(int64_t)t * 32 + c], b1 = la.s[(int64_t)(t + 1) * 32 + c], b2 = la.s[(int64_t)(t + 2) * 32 + c],
+                         b3 = la.s[(int64_t)(t + 3) * 32 + c];
+            v = f4add(v, f4mul(a0, b0));
+            v = f4add(v, f4mul(a1, b1));
+            v = f4add(v, f4mul(a2, b2));
+            v = f4add(v, f4mul(a3, b3));
+        }
+        for (; t < t1; ++t) v = f4add(v, f4mul(la.m_nb[(int64_t)la.t_col[t] * 32 + c], la.s[(int64_t)t * 32 + c]));
+        if (la.m_t) la.m_t[(int64_t)e * 32 + c] = v;
+        acc = f4add(acc, f4mul(v, gate));
+    }
+    la.x2_out[node * 32 + c] = acc;
+    return acc;
+}
+
 template <bool PACKED, bool HEADS, bool RIDER = false>
 __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restrict__ x2,
                                                            const float* __restrict__ res_x, int64_t n, TailParams p,
                                                            float* __restrict__ Z, float* __restrict__ R,
                                                            float* __restrict__ x_out, float* __restrict__ out,
                                                            float* __restrict__ att, PreNext nx,
-                                                           Mlp2Rider rd = Mlp2Rider{}) {
+                                                           Mlp2Rider rd = Mlp2Rider{}, LocalAgg la = LocalAgg{}) {
     // 5 working slots + 10 pre-activation tiles + 3 residual taps: everything the backward needs is parked in LDS and
     // written out once, as coalesced 512-byte rows, after the chain -- no global store (and no wait for its
     // acknowledgement, vmcnt retires in order) sits between one layer's MFMAs and the next layer's weight slice.
@@ -198,8 +234,11 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
     load_w<PACKED>(wf, p.W[0], DIM, wc);
     sweep_rows<BMN>([&](int r, int c4) {
         const int64_t g = row0 + r;
-        st_lds4(X0, r, c4, ldg4z(x2, g, n, DIM, c4));
         st_lds4(RX, r, c4, ldg4z(res_x, g, n, DIM, c4));
+        float4 xin;
+        if (la.m_ji) xin = g < n ? local_agg_row(la, g, c4) : f4zero();        // (workgroup-uniform: the row is formed here)
+        else xin = ldg4z(x2, g, n, DIM, c4);
+        st_lds4(X0, r, c4, xin);
     });
     __syncthreads();
 
@@ -1386,7 +1425,7 @@ static int tail_fwd_launch(const float* x2, const float* res_x, int64_t n, const
                            float* R, float* x_out, float* out, float* att, const float* next_Wx1, const float* next_bx1,
                            const float* const* next_wp, int64_t next_ldwp, int64_t next_nblk, float* next_Zx1,
                            float* next_x1, float* next_P, int32_t packed, const Mlp2Rider* rider, int rider_wgs,
-                           pamnet_stream_t stream) {
+                           pamnet_stream_t stream, const pamnet_local_agg* agg = nullptr) {
     if (n < 0 || next_nblk < 0 || next_nblk > 4) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
     if (!x2 || !res_x || !weights || !biases || !w_out || !b_out || !w_att || (Z && !R) || !x_out || (!out != !att))
@@ -1409,6 +1448,24 @@ static int tail_fwd_launch(const float* x2, const float* res_x, int64_t n, const
     const dim3 grid((unsigned)ceil_div(n, BMN));
     const TailParams tp = make_tail(weights, biases, w_out, b_out, w_att, packed ? 1 : 0);
     if (packed == 2 && heads) return PAMNET_EINVAL;            // bf16x3 images: deferred heads only
+    LocalAgg la{};
+    if (agg) {
+        if (!agg->t_ptr || !agg->l_ptr) return PAMNET_ENULL;
+        // the fp32 chain kernels (packed images, deferred heads) form x2 themselves; every other form reads it: the aggregation
+        // runs as its own launch first, as it did until round 6
+        const bool in_kernel = packed == 1 && !heads && !(grid.x > LEAN_FROM_TILES && lean_mode() >= 1 && !rider);
+        if (in_kernel) {
+            la.m_ji = (const float4*)agg->m_ji, la.m_nb = (const float4*)agg->m_nb, la.s = (const float4*)agg->s;
+            la.q3 = (const float4*)agg->q3, la.init = (const float4*)agg->init, la.t_ptr = agg->t_ptr, la.t_col = agg->t_col;
+            la.l_ptr = agg->l_ptr, la.m_t = (float4*)agg->m_t, la.x2_out = (float4*)const_cast<float*>(x2);
+            if (!la.m_ji) la = LocalAgg{};                     // (a batch without local edges: x2 = init, by the launch below)
+        }
+        if (!la.m_ji) {
+            const int rc = pamnet_local_agg_fwd_f32(agg->m_ji, agg->m_nb, agg->s, agg->q3, agg->t_ptr, agg->t_col, agg->l_ptr,
+                                                    agg->init, n, agg->m_t, const_cast<float*>(x2), stream);
+            if (rc) return rc;
+        }
+    }
     if (rider) {
         if (!packed || heads) return PAMNET_EINVAL;
         Mlp2Rider rd = *rider;
@@ -1418,11 +1475,11 @@ static int tail_fwd_launch(const float* x2, const float* res_x, int64_t n, const
                                res_x, n, tp, Z, R, x_out, nx, rd);
         else
             hipLaunchKernelGGL((node_tail_fwd_kernel<true, false, true>), dim3(grid.x + (unsigned)rider_wgs), dim3(WG), 0, st,
-                               x2, res_x, n, tp, Z, R, x_out, out, att, nx, rd);
+                               x2, res_x, n, tp, Z, R, x_out, out, att, nx, rd, la);
     } else if (packed == 2) hipLaunchKernelGGL((node_tail_fwd_bf16_kernel<false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, nx);
     else if (packed && heads) hipLaunchKernelGGL((node_tail_fwd_kernel<true, true>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
     else if (packed && grid.x > LEAN_FROM_TILES && lean_mode() >= 1) hipLaunchKernelGGL(node_tail_fwd_lean_kernel, grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, nx);
-    else if (packed) hipLaunchKernelGGL((node_tail_fwd_kernel<true, false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
+    else if (packed) hipLaunchKernelGGL((node_tail_fwd_kernel<true, false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx, Mlp2Rider{}, la);
     else if (heads) hipLaunchKernelGGL((node_tail_fwd_kernel<false, true>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
     else hipLaunchKernelGGL((node_tail_fwd_kernel<false, false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
     PAMNET_LAUNCH_CHECK();
@@ -1464,6 +1521,33 @@ extern "C" int pamnet_node_tail_fwd_rider_f32(const float* x2, const float* res_
     if (rider_wgs > mlp_ntiles) rider_wgs = mlp_ntiles;       // never more workgroups than tiles
     return tail_fwd_launch(x2, res_x, n, weights, biases, w_out, b_out, w_att, Z, R, x_out, nullptr, nullptr, next_Wx1,
                            next_bx1, next_wp, next_ldwp, next_nblk, next_Zx1, next_x1, next_P, packed, &rd, (int)rider_wgs, stream);
+}
+
+// pamnet_node_tail_fwd_rider_f32 (mlp_ntiles = 0: without riders) whose chain input x2 is FORMED by the launch -- `agg` holds the
+// operands of pamnet_local_agg_fwd_f32 (out = x2, which is also written); deferred heads, packed images.
+extern "C" int pamnet_node_tail_fwd_agg_f32(float* x2, const float* res_x, int64_t n, const float* const* weights,
+                                            const float* const* biases, const float* w_out, const float* b_out,
+                                            const float* w_att, float* Z, float* R, float* x_out, const float* next_Wx1,
+                                            const float* next_bx1, const float* const* next_wp, int64_t next_ldwp,
+                                            int64_t next_nblk, float* next_Zx1, float* next_x1, float* next_P,
+                                            const float* mlp_x, int64_t mlp_rows, int64_t mlp_tile0, int64_t mlp_ntiles,
+                                            const float* const* mlp, float* const* mlp_out, int64_t rider_wgs, int32_t packed,
+                                            const pamnet_local_agg* agg, pamnet_stream_t stream) {
+    if (!agg) return PAMNET_ENULL;
+    if (mlp_rows < 0 || mlp_tile0 < 0 || mlp_ntiles < 0 || rider_wgs < 0 || (packed != 1 && packed != 2)) return PAMNET_EINVAL;
+    if (mlp_ntiles == 0 || rider_wgs == 0)
+        return tail_fwd_launch(x2, res_x, n, weights, biases, w_out, b_out, w_att, Z, R, x_out, nullptr, nullptr, next_Wx1,
+                               next_bx1, next_wp, next_ldwp, next_nblk, next_Zx1, next_x1, next_P, packed, nullptr, 0, stream, agg);
+    if (!mlp_x || !mlp || !mlp_out || !mlp[0] || !mlp[1] || !mlp[2] || !mlp[3] || !mlp_out[2]) return PAMNET_ENULL;
+    if (n == 0) return PAMNET_EINVAL;
+    Mlp2Rider rd{};
+    rd.x = mlp_x, rd.m = mlp_rows;
+    rd.set = edge::Mlp2Set{mlp[0], mlp[1], mlp[2], mlp[3], mlp_out[0], mlp_out[1], mlp_out[2]};
+    rd.tile0 = (int)mlp_tile0, rd.ntiles = (int)mlp_ntiles;
+    if (rider_wgs > mlp_ntiles) rider_wgs = mlp_ntiles;
+    return tail_fwd_launch(x2, res_x, n, weights, biases, w_out, b_out, w_att, Z, R, x_out, nullptr, nullptr, next_Wx1,
+                           next_bx1, next_wp, next_ldwp, next_nblk, next_Zx1, next_x1, next_P, packed, &rd, (int)rider_wgs, stream,
+                           agg);
 }
 
 extern "C" int pamnet_node_heads_fwd_f32(int64_t n_layers, const float* const* x_out, const float* const* weights,
