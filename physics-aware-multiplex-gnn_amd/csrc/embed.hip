@@ -293,7 +293,11 @@ __device__ __forceinline__ void embed_bwd_body(const EJob& jb, int bid, float* x
         __syncthreads();
         {
             f32x4 acc[MT][2];
+#ifdef EMBED_PROBE_NO_Z
+            acc_zero<MT>(acc);
+#else
             z_tile<K, TWO>(xs, ks, w0, w1, acc);
+#endif
             acc_to_lds<MT>(acc, Ds, wc, load_bias2(nullptr, 0));
         }
         __syncthreads();
@@ -328,6 +332,7 @@ __device__ __forceinline__ void embed_bwd_body(const EJob& jb, int bid, float* x
         }
         __syncthreads();
         // dW[c][k] += sum_r dz[r][c] * x[r][k]: MFMA with the row index as the reduction dimension
+#ifndef EMBED_PROBE_NO_DW
 #pragma unroll 4
         for (int s = 0; s < TR / 4; ++s) {
             const int r = 4 * s + kg;
@@ -345,7 +350,12 @@ __device__ __forceinline__ void embed_bwd_body(const EJob& jb, int bid, float* x
                     if (TWO) dw1[a][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(k1 ? av[a] : 0.f, bv[g], dw1[a][g], 0, 0, 0);
                 }
         }
+#endif
+#ifdef EMBED_PROBE_NO_DX
+        if (false) {
+#else
         if (DX) {
+#endif
             // dx[r][k] = sum_c dz[r][c] * W0[c][k]; wave w owns rows [16w, 16w+16) of the tile
             f32x4 ax = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -419,9 +429,18 @@ __device__ __forceinline__ void embed_reduce_body(const EJob& jb, int K, int bx,
     else if (e < 2 * DOUT * K + DOUT) dst = jb.db0 ? jb.db0 + (e - 2 * DOUT * K) : nullptr;
     else if (e < 2 * DOUT * K + 2 * DOUT) dst = jb.db1 ? jb.db1 + (e - 2 * DOUT * K - DOUT) : nullptr;
     else if (e < per) dst = jb.dfreq ? jb.dfreq + (e - 2 * DOUT * K - 2 * DOUT) : nullptr;
+    // (eight partials requested before the first is added: as one load per addition the slice's 35-64 terms were a chain of
+    // memory round trips -- 15 us of a QM9 step's critical path; the order of the additions is unchanged)
     float s = 0.f;
     if (dst)
-        for (int b = slice; b < jb.nblk; b += 8) s += jb.partial[(int64_t)b * per + e];
+        for (int b = slice; b < jb.nblk; b += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = b + 8 * u < jb.nblk ? jb.partial[(int64_t)(b + 8 * u) * per + e] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (b + 8 * u < jb.nblk) s += v[u];
+        }
     sm[slice][lane] = s;
     __syncthreads();
     if (slice == 0 && dst) {
@@ -524,6 +543,9 @@ inline int grid_for(int64_t rows, int cap) {
     return (int)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
 }
 constexpr int FWD_CAP = 1024, BWD_SLOTS = 512;
+#ifndef EMBED_BWD_BIG_CAP
+#define EMBED_BWD_BIG_CAP 256                                  // (tools/embed_probe.py builds other values)
+#endif
 // backward: the workgroups of a multi launch are co-resident up to 512 (two per CU); launch_multi deals them to the jobs by
 // COST -- a 64-row tile of the two-set 42-wide layer (the triplet / pair rows) is ~5x the matrix work of a 16-wide tile: with
 // "two tiles per workgroup" for every job that job's 138 workgroups were the launch (47-55 us for the QM9 batch, a 10x
@@ -596,7 +618,7 @@ int launch_multi(const pamnet_embed_job* jobs, int32_t n_jobs, const pamnet_type
         grid = 0;
         for (int j = 0; j < J.n; ++j) {
             const int64_t tiles = (J.job[j].rows + TR - 1) / TR;
-            int64_t want = grid_for((J.job[j].rows + 1) / 2, 256);
+            int64_t want = grid_for((J.job[j].rows + 1) / 2, EMBED_BWD_BIG_CAP);
             if (by_cost) want = total > 0 ? (tiles * tile_cost(J.job[j].code) * budget + total - 1) / total : 1;
             want = want < 1 ? 1 : want;
             J.job[j].nblk = (int)(want < J.job[j].nblk ? want : J.job[j].nblk);
