@@ -10,7 +10,7 @@
  *   - the caller owns every device buffer; the library allocates no device memory, keeps no mutable state between calls
  *     and never synchronises (the pamnet_stack_* engine calls build small host-side pointer tables on the stack / heap per
  *     call).  The only process-wide data are five read-once developer switches taken from the environment on first use
- *     (PAMNET_EDGE_WAVES, PAMNET_CHAIN_BF16, PAMNET_SMALL_FORMS, PAMNET_AGG_PIECES, PAMNET_CHAIN_LEAN: kernel-variant selection for measurements; C++11 static
+ *     (PAMNET_EDGE_WAVES, PAMNET_EDGE_IMAGES, PAMNET_CHAIN_BF16, PAMNET_SMALL_FORMS, PAMNET_AGG_PIECES, PAMNET_CHAIN_LEAN: kernel-variant selection for measurements; C++11 static
  *     initialisation, thread-safe, constant afterwards);
  *   - work is enqueued on `stream`; return value 0 = OK, >0 = hipError_t of the failed launch, <0 = argument error
  *     (PAMNET_EINVAL: bad size / unsupported width; PAMNET_ENULL: required pointer is null);
@@ -29,12 +29,15 @@ extern "C" {
 #define PAMNET_OK 0
 #define PAMNET_EINVAL (-1)
 #define PAMNET_ENULL (-2)
+/* flag bit of pamnet_local_bwd_pair_f32's accumulate_dx (bit 0 = accumulate): W1 / W2 are fragment images, see
+ * pamnet_pack_weights_mixed_f32 */
+#define PAMNET_WEIGHT_IMAGES 2
 
 typedef void* pamnet_stream_t; /* hipStream_t */
 
 /* Library / ABI version (bumped on any signature change).  pamnet_abi_version() returns the PAMNET_ABI_VERSION the library
  * was built against; a binding compares it with this header's (pamnet_amd/lib.py load(): a stale .so fails loudly). */
-#define PAMNET_ABI_VERSION 13
+#define PAMNET_ABI_VERSION 14
 int pamnet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -472,6 +475,18 @@ int pamnet_pack_weights_f32(int64_t n, const float* const* W, const int64_t* ld,
  * run the chain on the bf16 matrix pipe at fp32 accuracy (six piece products per product: csrc/gemm_core.h "bf16x6"). */
 int pamnet_pack_weights_bf16x3(int64_t n, const float* const* W, const int64_t* ld, int32_t transposed, float* images,
                                pamnet_stream_t stream);
+/* Round 6 (ABI 14): all weight images of a step direction in one launch, n <= 224.  kind[i] = 0: the chains' fp32 fragment
+ * image of pamnet_pack_weights_f32 (16 384 floats); kind[i] = 1: the EDGE-LEVEL kernels' bf16x3 fragment image (24 576 floats):
+ * uint4 image[((tile * 4 + q) * 3 + piece) * 64 + lane] = the exact bf16 pieces lane `lane` of the wave that owns output
+ * columns [16 tile, 16 tile + 16) holds for k-step q (csrc/edge_core.h load_wfragb1) -- what every workgroup of
+ * pamnet_global_edge_agg_fwd_f32 / _fwd_pp_f32 / _bwd_f32 and pamnet_local_edge_fwd_f32 otherwise makes of its slices itself
+ * (64-128 loads and ~300 vector instructions per lane ahead of the first row: 2 us of a 30 us launch at the QM9 batch).  Those
+ * four entry points take such an image in place of a weight matrix when its row stride argument is 0 (all of a call's strides
+ * zero or none; pamnet_local_edge_fwd_f32: 8-wave geometry only); the results are bitwise those of the fp32 matrices.
+ * offset[i]: where image i starts in `images`, in floats (a multiple of 4).  transposed as in pamnet_pack_weights_f32
+ * (0: Y = X W^T, the forward entries; 1: Y = X W, pamnet_global_edge_agg_bwd_f32). */
+int pamnet_pack_weights_mixed_f32(int64_t n, const float* const* W, const int64_t* ld, const int32_t* kind,
+                                  const int64_t* offset, int32_t transposed, float* images, pamnet_stream_t stream);
 int pamnet_node_pre_fwd_f32(const float* x, int64_t n, const float* Wx1, const float* bx1, const float* const* wp,
                             int64_t ldwp, int64_t nblk, float* Zx1, float* x1, float* P, pamnet_stream_t stream);
 int pamnet_node_pre_bwd_f32(const float* dP, const float* dx1_direct, const float* d_add, int64_t n, const float* Wx1,
@@ -613,7 +628,9 @@ int pamnet_mlp2_bwd_f32(const float* dy, int64_t rows, const float* z1, const fl
                         pamnet_stream_t stream);
 /* pamnet_mlp2_bwd_f32 + pamnet_local_edge_bwd_f32 -- both depend on pamnet_local_agg_bwd_f32 only, not on each other -- as ONE
  * launch, the CUs split between the two plans by their work (layers/local_message_passing.py:46-53 backward).  Arguments
- * and results are those of the two calls. */
+ * and results are those of the two calls.  Round 6 (ABI 14): accumulate_dx | PAMNET_WEIGHT_IMAGES: W1, W2 are transposed kind-1
+ * images of pamnet_pack_weights_mixed_f32; ldq[0..3] all 0 (here and in pamnet_local_edge_bwd_f32): Wq[0..3] are transposed
+ * kind-0 (fp32 fragment) images.  Same bits as with the matrices. */
 int pamnet_local_bwd_pair_f32(const float* dy, int64_t rows, const float* z1, const float* z2, const float* W1,
                               const float* W2, float* dz1, float* dz2, float* dx, int32_t accumulate_dx,
                               const float* d_mji, const float* d_mnb, const float* d_q3, int64_t n_edges,

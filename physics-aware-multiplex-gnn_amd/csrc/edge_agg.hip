@@ -1516,6 +1516,7 @@ extern "C" int pamnet_global_edge_agg_fwd_pp_f32(const float* e, int64_t n_edges
                                                  const int32_t* col, const int32_t* cuts, const float* init, float* z, float* ea,
                                                  float* out, pamnet_stream_t stream) {
     if (n_edges < 0 || n_nodes < 0) return PAMNET_EINVAL;
+    if ((ld_we == 0) != (ld_wea == 0) || (ld_we != 0 && (ld_we < DIM || ld_wea < DIM))) return PAMNET_EINVAL;   // 0, 0: images
     if (n_nodes == 0) return PAMNET_OK;
     if (!We || !bm || !Wea || !Pi || !Pj || !ptr || !out) return PAMNET_ENULL;      // init, z, ea: optional
     if (n_edges > 0 && (!e || !row_of || !col)) return PAMNET_ENULL;
@@ -1537,6 +1538,7 @@ extern "C" int pamnet_global_edge_agg_fwd_f32(const float* e, int64_t n_edges, i
                                               const int32_t* col, const int32_t* cuts, const float* init, float* z, float* ea,
                                               float* out, pamnet_stream_t stream) {
     if (n_edges < 0 || n_nodes < 0) return PAMNET_EINVAL;
+    if ((ld_we == 0) != (ld_wea == 0) || (ld_we != 0 && (ld_we < DIM || ld_wea < DIM))) return PAMNET_EINVAL;   // 0, 0: images
     if (n_nodes == 0) return PAMNET_OK;
     if (!We || !bm || !Wea || !Pi || !Pj || !ptr || !out) return PAMNET_ENULL;      // init, z, ea: optional
     if (n_edges > 0 && (!e || !row_of || !col)) return PAMNET_ENULL;
@@ -1598,6 +1600,7 @@ extern "C" int pamnet_global_edge_agg_bwd_f32(const float* d_agg, int64_t n_edge
                                               int64_t ld_we, const float* Wea, int64_t ld_wea, float* dz, float* dea,
                                               float* d_e, int32_t accumulate, float* dPi, pamnet_stream_t stream) {
     if (n_edges < 0 || n_nodes < 0) return PAMNET_EINVAL;
+    if ((ld_we == 0) != (ld_wea == 0) || (ld_we != 0 && (ld_we < DIM || ld_wea < DIM))) return PAMNET_EINVAL;   // 0, 0: images
     if (n_nodes == 0) return PAMNET_OK;
     if (!d_agg || !ptr || !We || !Wea || !dPi) return PAMNET_ENULL;
     if (n_edges > 0 && (!row_of || !z || !ea || !dz || !dea || !d_e)) return PAMNET_ENULL;
@@ -1642,6 +1645,7 @@ extern "C" int pamnet_global_edge_agg_bwd_wg_f32(const float* d_agg, int64_t n_e
                                                  float* partial, pamnet_stream_t stream) {
     if (n_edges < 0 || n_nodes < 0) return PAMNET_EINVAL;
     if (n_nodes == 0) return PAMNET_EINVAL;                     // (the slots must be written: no launch, no partial sums)
+    if (ld_we < DIM || ld_wea < DIM) return PAMNET_EINVAL;      // (fp32 matrices only: no fragment images, see load_wfragb2_t)
     if (n_edges >= (int64_t(1) << 23) || n_nodes >= (int64_t(1) << 23)) return PAMNET_EINVAL;   // 32-bit byte offsets per stream
     if (!d_agg || !ptr || !We || !Wea || !dPi || !partial) return PAMNET_ENULL;
     if (n_edges > 0 && (!row_of || !z || !ea || !e || !dz || !d_e)) return PAMNET_ENULL;

@@ -388,6 +388,7 @@ struct Mlp2BwdArgs {
     const float *z1, *z2, *W1, *W2;
     float *dz1, *dz2, *dx;
     int accumulate, pa, pb, pc, cmt;
+    int img = 0;                              // W1, W2 are bf16x3 fragment images (transposed orientation; 8-wave geometry)
 };
 
 template <int MTX, int NW>
@@ -413,8 +414,8 @@ __device__ __forceinline__ void mlp2_bwd_body(const Mlp2BwdArgs& a, const int bi
     WSet<B16 ? 0 : NS> f1, f2;
     WFragB1 b1_, b2_;
     if constexpr (B16) {
-        load_wfragb1<true>(b2_, W2, DIM, wc);
-        load_wfragb1<true>(b1_, W1, DIM, wc);
+        load_wfragb1<true>(b2_, W2, a.img ? 0 : DIM, wc);
+        load_wfragb1<true>(b1_, W1, a.img ? 0 : DIM, wc);
     } else {
         load_wset<true>(f2, W2, DIM, wc);
         load_wset<true>(f1, W1, DIM, wc);
@@ -658,9 +659,15 @@ extern "C" int pamnet_global_edge_bwd_f32(const float* d_agg, const int32_t* row
     return PAMNET_OK;
 }
 
-static int fill_local(LocalW& w, const float* const* Wq, const int64_t* ldq, const float* const* P) {
+// *images: all four row strides are 0 = the slices arrive as fragment images (edge_core.h load_wfragb1; forward, 8-wave geometry)
+static int fill_local(LocalW& w, const float* const* Wq, const int64_t* ldq, const float* const* P, bool* images = nullptr) {
+    int zeros = 0;
+    for (int b = 0; b < 4; ++b) zeros += ldq[b] == 0;
+    if (zeros != 0 && (zeros != 4 || !images)) return PAMNET_EINVAL;
+    if (images) *images = zeros == 4;
     for (int b = 0; b < 4; ++b) {
         if (!Wq[b]) return PAMNET_ENULL;
+        if (zeros == 0 && ldq[b] < DIM) return PAMNET_EINVAL;
         w.W[b] = Wq[b];
         w.ld[b] = (int)ldq[b];
         w.P[b] = P ? P[b] : nullptr;
@@ -678,9 +685,11 @@ extern "C" int pamnet_local_edge_fwd_f32(const float* rbf, int64_t n_edges, cons
     if (!rbf || !Wq || !ldq || !b_ji || !b_kj || !P || !row_of || !col || !q3 || !m_ji || !m_nb)   // z_ji, z_kj, q2: optional
         return PAMNET_ENULL;
     LocalW w;
-    int rc = fill_local(w, Wq, ldq, P);
+    bool images = false;
+    int rc = fill_local(w, Wq, ldq, P, &images);
     if (rc) return rc;
     const Plan p = plan(n_edges, 5, 2, N_CU / 2);           // two halves (grid.y) share the CUs
+    if (images && p.paired) return PAMNET_EINVAL;           // (the 4-wave geometry multiplies fp32 fragments)
     PAMNET_EDGE_LAUNCH3(local_edge_fwd_kernel, p, 2, rbf, n_edges, w, b_ji, b_kj, row_of, col, z_ji, z_kj, q2,
                        q3, m_ji, m_nb);
     PAMNET_LAUNCH_CHECK();
@@ -696,7 +705,8 @@ extern "C" int pamnet_local_edge_bwd_f32(const float* d_mji, const float* d_mnb,
     if (!d_mji || !d_mnb || !d_q3 || !z_ji || !z_kj || !q2 || !Wq || !ldq || !dz_ji || !dz_kj || !dq2 || !d_rbf)
         return PAMNET_ENULL;
     LocalW w;
-    int rc = fill_local(w, Wq, ldq, nullptr);
+    bool images = false;                                    // (all four strides 0: transposed fp32 fragment images, load_wfrag1)
+    int rc = fill_local(w, Wq, ldq, nullptr, &images);
     if (rc) return rc;
     constexpr int MTL = 3;
     const Plan p = plan8(n_edges, MTL);                     // four weight matrices: stays one 8-wave workgroup per CU
@@ -715,7 +725,10 @@ extern "C" int pamnet_local_bwd_pair_f32(const float* dy, int64_t rows, const fl
                                          const int64_t* ldq, float* dz_ji, float* dz_kj, float* dq2, float* d_rbf,
                                          int32_t accumulate_rbf, pamnet_stream_t stream) {
     if (rows < 0 || n_edges < 0) return PAMNET_EINVAL;
+    const bool mlp_img = (accumulate_dx & PAMNET_WEIGHT_IMAGES) != 0;
+    accumulate_dx &= ~PAMNET_WEIGHT_IMAGES;
     if (rows == 0 || n_edges == 0 || four_waves()) {         // nothing to pair (or the 4-wave geometry is forced): two launches
+        if (mlp_img) return PAMNET_EINVAL;                   // (images: the paired 8-wave launch only)
         int rc = pamnet_mlp2_bwd_f32(dy, rows, z1, z2, W1, W2, dz1, dz2, dx, accumulate_dx, stream);
         if (rc) return rc;
         return pamnet_local_edge_bwd_f32(d_mji, d_mnb, d_q3, n_edges, z_ji, z_kj, q2, Wq, ldq, dz_ji, dz_kj, dq2, d_rbf,
@@ -725,7 +738,8 @@ extern "C" int pamnet_local_bwd_pair_f32(const float* dy, int64_t rows, const fl
     if (!d_mji || !d_mnb || !d_q3 || !z_ji || !z_kj || !q2 || !Wq || !ldq || !dz_ji || !dz_kj || !dq2 || !d_rbf)
         return PAMNET_ENULL;
     LocalW w;
-    int rc = fill_local(w, Wq, ldq, nullptr);
+    bool local_img = false;
+    int rc = fill_local(w, Wq, ldq, nullptr, &local_img);
     if (rc) return rc;
     // CU shares by work: an edge row costs ~3.1 MLP rows (four fp32-MFMA GEMMs against two on the bf16 pipe; measured at the
     // QM9 batch: 20.6 us for 4 316 edge rows, 24.1 us for 17 640 MLP rows, both on 256 workgroups)
@@ -734,7 +748,7 @@ extern "C" int pamnet_local_bwd_pair_f32(const float* dy, int64_t rows, const fl
     ge = ge < 8 ? 8 : (ge > N_CU - 8 ? N_CU - 8 : ge);
     const Plan pe = plan8(n_edges, 3, ge);
     const Plan pm = plan8(rows, 7, N_CU - (int)pe.grid);      // (piece planes + one fp32 tile per 16 rows: <= 7 tiles of LDS)
-    const Mlp2BwdArgs ma{dy, rows, z1, z2, W1, W2, dz1, dz2, dx, (int)accumulate_dx, pm.pa, pm.pb, pm.pc, pm.cmt};
+    const Mlp2BwdArgs ma{dy, rows, z1, z2, W1, W2, dz1, dz2, dx, (int)accumulate_dx, pm.pa, pm.pb, pm.pc, pm.cmt, mlp_img ? 1 : 0};
     const LocalBwdArgs la{d_mji, d_mnb, d_q3, n_edges, z_ji, z_kj, q2, w, dz_ji, dz_kj, dq2, d_rbf, (int)accumulate_rbf,
                           pe.pa, pe.pb, pe.cmt};
     const dim3 grid(pm.grid + pe.grid);

@@ -12,16 +12,40 @@ constexpr int WG8 = 512;                  // 8 waves
 constexpr int N_CU = 256;                 // MI355X
 constexpr int MT2 = 8;                    // largest chunk (16-row tiles) of the two-slot kernels (2 x 128 rows = 132 KB)
 
+// 16-byte reads of a weight image (round 6) as buffer loads: resource = base + size in bytes (reads past the image return 0)
+typedef __amdgpu_buffer_rsrc_t ImgRsrc;
+__device__ __forceinline__ ImgRsrc img_rsrc(const float* img, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, bytes, 0x00020000);   // gfx9 raw buffer, 32-bit format
+}
+__device__ __forceinline__ u32x4 img_load16(ImgRsrc r, int byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+}
+
 // one 128 x 16 weight slice of a wave: 8 x float4 = 32 VGPRs
 struct WFrag1 {
     float4 b[DIM / 16];
 };
 //   TRANS = false: W is [out][in] (row stride ldw): Y = X * W^T   (forward:  Linear)
 //   TRANS = true : Y = X * W                                       (backward: dX = dZ * W)
+// ldw == 0 (round 6): `W` is the matrix's fp32 fragment image (pamnet_pack_weights_f32 / _mixed_f32 kind 0, made in the
+// orientation the kernel wants): img4[(tile * 8 + q) * 64 + lane] -- the same float4 values, one contiguous 1 KB read per wave
+// and k-group instead of (transposed) four dword loads per lane across 64-byte segments.
 template <bool TRANS>
 __device__ __forceinline__ void load_wfrag1(WFrag1& f, const float* __restrict__ W, int ldw, int wc) {
     const int lane = threadIdx.x & 63;
     const int r16 = lane & 15, kg = lane >> 4;
+    if (ldw == 0) {
+        // (buffer loads: as plain 16-byte loads the compiler scalarises them and sinks them into the other arm's 32 dword loads,
+        // addresses selected by the branch -- four 16-byte-strided dword requests per float4, 26 -> 33 us for the backward pair)
+        const ImgRsrc r = img_rsrc(W, DIM * DIM * 4);
+        const int off = ((wc >> 4) * (DIM / 16 * 64) + lane) * 16;
+#pragma unroll
+        for (int q = 0; q < DIM / 16; ++q) {
+            const u32x4 u = img_load16(r, off + q * 1024);
+            f.b[q] = make_float4(__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3]));
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < DIM / 16; ++q) {
         if (!TRANS) {
@@ -119,23 +143,46 @@ struct WFragB1 {
 };
 //   TRANS = false: W is [out][in] (row stride ldw): B[k][j] = W[wc + j][k]   (forward:  Y = X W^T)
 //   TRANS = true : B[k][j] = W[k][wc + j]                                     (backward: dX = dZ W)
+// the pieces of k-step q of the 16-column tile at wc, as lane `lane` holds them
+template <bool TRANS>
+__device__ __forceinline__ Frag3 wfragb1_q(const float* __restrict__ W, int ldw, int wc, int q, int lane) {
+    const int j = lane & 15, kg = lane >> 4;
+    float v[8];
+    if (!TRANS) {
+        const float* wp = W + (size_t)(wc + j) * ldw + 32 * q + 8 * kg;
+        const float4 a = *reinterpret_cast<const float4*>(wp), b = *reinterpret_cast<const float4*>(wp + 4);
+        v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+    } else {
+        const float* wp = W + (size_t)(32 * q + 8 * kg) * ldw + wc + j;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = wp[(size_t)t * ldw];
+    }
+    return split_frag(v);
+}
+// Ready-made image of these fragments (round 6; pamnet_pack_weights_mixed_f32 kind 1, node_tail.hip): every workgroup of every
+// edge-level launch loaded its two to four 128 x 128 slices as fp32 (dword loads in the transposed orientation) and split them
+// into pieces -- ~300 VALU and 64-128 loads per lane ahead of the first row, 2 us of a 30 us kernel at the QM9 batch.  The image
+// holds the SAME pieces in the order the lanes want them: uint4 image[((tile * 4 + q) * 3 + piece) * 64 + lane], tile = wc / 16;
+// a matrix is 8 x 4 x 3 x 64 x 16 bytes = 96 KB.  Selected by ldw == 0 (`W` then IS the image); results are bitwise the same.
+constexpr int64_t EDGE_IMG_FLOATS = 3 * DIM * DIM / 2;
 template <bool TRANS>
 __device__ __forceinline__ void load_wfragb1(WFragB1& f, const float* __restrict__ W, int ldw, int wc) {
     const int lane = threadIdx.x & 63;
-    const int j = lane & 15, kg = lane >> 4;
+    if (ldw == 0) {
+        const ImgRsrc r = img_rsrc(W, EDGE_IMG_FLOATS * 4);
+        const int off = ((wc >> 4) * (DIM / 32 * 3 * 64) + lane) * 16;
+#pragma unroll
+        for (int q = 0; q < DIM / 32; ++q)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                const u32x4 u = img_load16(r, off + (q * 3 + pc) * 1024);
+                f.p[q][pc][0] = u[0], f.p[q][pc][1] = u[1], f.p[q][pc][2] = u[2], f.p[q][pc][3] = u[3];
+            }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < DIM / 32; ++q) {
-        float v[8];
-        if (!TRANS) {
-            const float* wp = W + (size_t)(wc + j) * ldw + 32 * q + 8 * kg;
-            const float4 a = *reinterpret_cast<const float4*>(wp), b = *reinterpret_cast<const float4*>(wp + 4);
-            v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
-        } else {
-            const float* wp = W + (size_t)(32 * q + 8 * kg) * ldw + wc + j;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) v[t] = wp[(size_t)t * ldw];
-        }
-        const Frag3 fr = split_frag(v);
+        const Frag3 fr = wfragb1_q<TRANS>(W, ldw, wc, q, lane);
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc)
 #pragma unroll

@@ -220,35 +220,59 @@ inline Temp carve_temp(float* p, const Graph& g) {
         if (e__ != hipSuccess) return (int)e__;    \
     } while (0)
 
-// fragment-ordered weight images for the node chains (pamnet_pack_weights_f32), packed in launches of <= 192 matrices
+// fragment-ordered weight images for the node chains (kind 0: fp32 fragments, or bf16x3 images with `pieces`) and, round 6, for
+// the edge-level kernels (kind 1: the bf16x3 fragments a wave would split out of its slice itself, edge_core.h load_wfragb1; in
+// their own region `ebase` of the arena) -- all of a direction's images in one launch (pamnet_pack_weights_mixed_f32, <= 224
+// matrices per launch)
+constexpr int64_t EDGE_IMG = 3 * D * D / 2;
 struct PackList {
-    const float* src[192];
-    int64_t ld[192];
+    static constexpr int CAP = 224;
+    const float* src[CAP];
+    int64_t ld[CAP], off[CAP];
+    int32_t kind[CAP];
     int n = 0;
     float* base;
-    int64_t done = 0;          // images already packed by earlier launches
+    float* ebase = nullptr;
+    int64_t done = 0, edone = 0;   // chain / edge images handed out so far
     int32_t transposed;
     pamnet_stream_t st;
     int rc = 0;
-    int64_t img = D * D;       // floats per image: fp32 fragment images, or bf16x3 images (3 pieces x 2 bytes: 1.5 x)
+    int64_t img = D * D;       // floats per chain image: fp32 fragment images, or bf16x3 images (3 pieces x 2 bytes: 1.5 x)
     bool bf16x3 = false;
-    PackList(float* b, int32_t t, pamnet_stream_t s, bool pieces = false)
-        : base(b), transposed(t), st(s), img(pieces ? 3 * D * D / 2 : D * D), bf16x3(pieces) {}
+    PackList(float* b, int32_t t, pamnet_stream_t s, bool pieces = false, float* eb = nullptr)
+        : base(b), ebase(eb), transposed(t), st(s), img(pieces ? 3 * D * D / 2 : D * D), bf16x3(pieces) {}
     // returns the image the matrix will occupy
     const float* add(const float* W, int64_t ldw) {
-        if (n == 192) flush();
-        src[n] = W;
-        ld[n] = ldw;
-        return base + (done + n++) * img;
+        if (n == (bf16x3 ? 192 : CAP)) flush();
+        src[n] = W, ld[n] = ldw, kind[n] = 0, off[n] = done * img;
+        ++n;
+        return base + done++ * img;
+    }
+    const float* add_edge(const float* W, int64_t ldw) {
+        if (n == CAP) flush();
+        src[n] = W, ld[n] = ldw, kind[n] = 1, off[n] = (ebase - base) + edone * EDGE_IMG;
+        ++n;
+        return ebase + edone++ * EDGE_IMG;
     }
     void flush() {
         if (n && !rc)
-            rc = bf16x3 ? pamnet_pack_weights_bf16x3(n, src, ld, transposed, base + done * img, st)
-                        : pamnet_pack_weights_f32(n, src, ld, transposed, base + done * img, st);
-        done += n;
+            rc = bf16x3 ? pamnet_pack_weights_bf16x3(n, src, ld, transposed, base + off[0], st)
+                        : pamnet_pack_weights_mixed_f32(n, src, ld, kind, off, transposed, base, st);
         n = 0;
     }
 };
+// edge-level images per layer pair: forward W_e, W_ea + the local edge step's four slices; backward W_e, W_ea (transposed)
+constexpr int64_t EDGE_PACK_PER_PAIR = 6;
+// PAMNET_EDGE_IMAGES=0: the edge-level kernels split their fp32 slices themselves (the form before round 6).  The images need the
+// 8-wave geometry of the local edge kernel (PAMNET_EDGE_WAVES=4 forces the other one: no images then).
+inline bool edge_images() {
+    static const bool v = [] {
+        const char* e = getenv("PAMNET_EDGE_IMAGES");
+        const char* w = getenv("PAMNET_EDGE_WAVES");
+        return (!e || atoi(e) != 0) && !(w && atoi(w) == 4);
+    }();
+    return v;
+}
 constexpr int64_t PACK_PER_PAIR = 28;       // forward: 10 + 5 (global chain + local head) + 10 + 3 (local chain + next global head)
 constexpr int64_t PACK_FLOATS_PER_PAIR = PACK_PER_PAIR * (3 * D * D / 2);     // sized for bf16x3 images throughout
 // PAMNET_CHAIN_BF16=1: the forward chains on the bf16 matrix pipe (node_tail_fwd_bf16_kernel, bf16x3 weight images).
@@ -334,7 +358,7 @@ inline int run_jobs(Jobs& j, float* partial, const Graph& g, const HeadGrads& h,
 // floats of the optional weight-image arena (`wpack`) of pamnet_stack_fwd_f32 / pamnet_stack_bwd_f32
 extern "C" int pamnet_stack_pack_floats(int64_t n_layer, int64_t* floats) {
     if (n_layer < 1 || !floats) return PAMNET_EINVAL;
-    *floats = n_layer * PACK_FLOATS_PER_PAIR;
+    *floats = n_layer * (PACK_FLOATS_PER_PAIR + EDGE_PACK_PER_PAIR * EDGE_IMG);
     return PAMNET_OK;
 }
 
@@ -444,8 +468,14 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
     // bf16x3 images for everything the chains multiply by (matrices 0..6 + the fused heads of the next layers), fp32
     // images for the mlp_out matrices 7..9 (node_heads_fwd_kernel)
     const bool cb = packed && chain_bf16();
+    // edge-level fragment images (region behind the chain images): W_e, W_ea of the global step, the local edge step's slices
+    const bool eimg = packed && !cb && edge_images();
+    struct EdgeImg {
+        const float *we, *wea, *wq[4];
+    };
+    std::vector<EdgeImg> eimg_store(eimg ? (size_t)n_layer : 0);
     if (packed) {
-        PackList pl(wpack, 0, st, cb);
+        PackList pl(wpack, 0, st, cb, wpack + n_layer * PACK_FLOATS_PER_PAIR);
         PackList ph(wpack + n_layer * 22 * (3 * D * D / 2), 0, st, false);     // behind the 22 chain images of every pair
         PackList& hd = cb ? ph : pl;
         for (int64_t k = 0; k < n_layer; ++k) {
@@ -462,6 +492,12 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
                 const float* const* gn = gparams + (k + 1) * NG;
                 img[k].nh[0] = pl.add(gn[0], D);
                 img[k].nh[1] = pl.add(gn[2], 3 * D), img[k].nh[2] = pl.add(gn[2] + D, 3 * D);
+            }
+            if (eimg) {
+                EdgeImg& ei = eimg_store[k];
+                ei.we = pl.add_edge(gp[2] + 2 * D, 3 * D), ei.wea = pl.add_edge(gp[4], D);
+                ei.wq[0] = pl.add_edge(lp[2] + 2 * D, 3 * D), ei.wq[1] = pl.add_edge(lp[4] + 2 * D, 3 * D);
+                ei.wq[2] = pl.add_edge(lp[10], D), ei.wq[3] = pl.add_edge(lp[11], D);
             }
         }
         pl.flush();
@@ -489,8 +525,13 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         float* const Pk = (keep && s.Pg) ? s.Pg : t.P;
         if (k == 0) CK(pamnet_node_pre_fwd_f32(x, g.n, gp[0], gp[1], wpg, 3 * D, 2, sv(s.Zx1), t.x1, Pk, st));
         // message MLP + add-aggregation in one kernel: x2 = x1 + sum_{e -> i} msg_e, the messages never leave the chip
-        CK(pamnet_global_edge_agg_fwd_f32(e_g, g.eg, g.n, gp[2] + 2 * D, 3 * D, gp[3], gp[4], D, Pk, Pk + g.n * D,
-                                          g.g_ptr, g.g_row, g.g_col, cuts, t.x1, sv(s.z), sv(s.ea), s.x2, st));
+        // (ld = 0: the weight argument is its fragment image)
+        if (eimg)
+            CK(pamnet_global_edge_agg_fwd_f32(e_g, g.eg, g.n, eimg_store[k].we, 0, gp[3], eimg_store[k].wea, 0, Pk, Pk + g.n * D,
+                                              g.g_ptr, g.g_row, g.g_col, cuts, t.x1, sv(s.z), sv(s.ea), s.x2, st));
+        else
+            CK(pamnet_global_edge_agg_fwd_f32(e_g, g.eg, g.n, gp[2] + 2 * D, 3 * D, gp[3], gp[4], D, Pk, Pk + g.n * D,
+                                              g.g_ptr, g.g_row, g.g_col, cuts, t.x1, sv(s.z), sv(s.ea), s.x2, st));
         const float* const* lp = lparams + k * NL;
         const LocalSaved q = carve_local(saved + k * (gs + ls) + gs, g);
         const float* wpl[4] = {lp[2], lp[4], lp[2] + D, lp[4] + D};
@@ -511,9 +552,10 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         // ---------------- local layer (layers/local_message_passing.py:36-66); its head ran in the chain above
         const float* wq[4] = {lp[2] + 2 * D, lp[4] + 2 * D, lp[10], lp[11]};
         const int64_t ldq[4] = {3 * D, 3 * D, D, D};
+        const int64_t ld0[4] = {0, 0, 0, 0};
         const float* planes[4] = {t.P, t.P + g.n * D, t.P + 2 * g.n * D, t.P + 3 * g.n * D};
-        CK(pamnet_local_edge_fwd_f32(rbf_e, g.el, wq, ldq, lp[3], lp[5], planes, g.l_row, g.l_col, sv(q.zji), sv(q.zkj),
-                                     sv(q.q2), q.q3, t.mji, q.mnb, st));
+        CK(pamnet_local_edge_fwd_f32(rbf_e, g.el, eimg ? eimg_store[k].wq : wq, eimg ? ld0 : ldq, lp[3], lp[5], planes, g.l_row,
+                                     g.l_col, sv(q.zji), sv(q.zkj), sv(q.q2), q.q3, t.mji, q.mnb, st));
         if (forked) HK(hipStreamWaitEvent(as_stream(st), reinterpret_cast<hipEvent_t>(aux_events[1 + k]), 0));
         // both aggregations of the local layer (rows -> edges -> nodes) in one launch; m_t is a backward-only save
         const bool agg_in = packed && fuse_local_agg(g);      // x2 formed by the chain launch's own tiles
@@ -613,8 +655,18 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
     };
     std::vector<PairImgT> img_store(packed ? (size_t)n_layer : 0);
     PairImgT* img = packed ? img_store.data() : nullptr;
+    // transposed fragment images of W_e, W_ea for the plain global-edge backward (the weight-gradient-forming kernel of large
+    // batches keeps its own two-pieces-in-registers loader)
+    const bool eimg = packed && edge_images() && !edge_wgrad(g);
+    // ... and of the local layer's backward pair: mlp_sbf's W1, W2 (bf16x3 fragments), the local edge step's four slices (fp32
+    // fragments: that body multiplies on the fp32 MFMAs)
+    const bool limg = packed && edge_images() && g.tp > 0 && g.el > 0;      // (the paired launch exists)
+    struct EdgeImgT {
+        const float *we, *wea, *w1, *w2, *wq[4];
+    };
+    std::vector<EdgeImgT> eimg_store(limg ? (size_t)n_layer : 0);
     if (packed) {
-        PackList pl(wpack, 1, st);
+        PackList pl(wpack, 1, st, false, wpack + n_layer * PACK_FLOATS_PER_PAIR);
         for (int64_t k = n_layer - 1; k >= 0; --k) {
             const float* const* lp = lparams + k * NL;
             const float* const* gp = gparams + k * NG;
@@ -625,6 +677,13 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             for (int i = 0; i < 10; ++i) img[k].gt[i] = pl.add(gp[GT + i], D);
             img[k].gh[0] = pl.add(gp[2], 3 * D), img[k].gh[1] = pl.add(gp[2] + D, 3 * D);
             img[k].gh[2] = pl.add(gp[0], D);
+            if (eimg) eimg_store[k].we = pl.add_edge(gp[2] + 2 * D, 3 * D), eimg_store[k].wea = pl.add_edge(gp[4], D);
+            if (limg) {
+                EdgeImgT& ei = eimg_store[k];
+                ei.w1 = pl.add_edge(lp[6], D), ei.w2 = pl.add_edge(lp[8], D);
+                ei.wq[0] = pl.add(lp[2] + 2 * D, 3 * D), ei.wq[1] = pl.add(lp[4] + 2 * D, 3 * D);
+                ei.wq[2] = pl.add(lp[10], D), ei.wq[3] = pl.add(lp[11], D);
+            }
         }
         pl.flush();
         CK(pl.rc);
@@ -704,8 +763,14 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             // the triplet / pair MLP's backward and the local edge stage's: independent of each other, one launch
             const float* wq[4] = {lp[2] + 2 * D, lp[4] + 2 * D, lp[10], lp[11]};
             const int64_t ldq[4] = {3 * D, 3 * D, D, D};
-            CK(pamnet_local_bwd_pair_f32(t.ds, g.tp, q.z1, q.z2, lp[6], lp[8], t.dz1, t.dz2, d_sbf, acc, t.dmt, t.dmnb, t.dq3,
-                                         g.el, q.zji, q.zkj, q.q2, wq, ldq, t.dzji, t.dzkj, t.dq2, d_rbf, acc, st));
+            const int64_t ld0[4] = {0, 0, 0, 0};
+            if (limg)
+                CK(pamnet_local_bwd_pair_f32(t.ds, g.tp, q.z1, q.z2, eimg_store[k].w1, eimg_store[k].w2, t.dz1, t.dz2, d_sbf,
+                                             acc | PAMNET_WEIGHT_IMAGES, t.dmt, t.dmnb, t.dq3, g.el, q.zji, q.zkj, q.q2,
+                                             eimg_store[k].wq, ld0, t.dzji, t.dzkj, t.dq2, d_rbf, acc, st));
+            else
+                CK(pamnet_local_bwd_pair_f32(t.ds, g.tp, q.z1, q.z2, lp[6], lp[8], t.dz1, t.dz2, d_sbf, acc, t.dmt, t.dmnb,
+                                             t.dq3, g.el, q.zji, q.zkj, q.q2, wq, ldq, t.dzji, t.dzkj, t.dq2, d_rbf, acc, st));
             const int64_t pl = g.n * D;
             const float* sa[4] = {t.dzji, t.dzkj, t.dzji, t.dzkj};
             const int32_t* sp[4] = {nullptr, nullptr, g.lT_perm, g.lT_perm};
@@ -799,8 +864,12 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                                                      gp[4], D, t.dz, d_eg, acc, t.dPg, t.edge_partial, st));
                 CK(pamnet_wgrad_edge_enqueue_f32(wctx.data(), eslots, gg[2] + 2 * D, 3 * D, gg[3], gg[4], D, t.edge_partial));
             } else {
-                CK(pamnet_global_edge_agg_bwd_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, cuts, s.z, s.ea, gp[2] + 2 * D, 3 * D, gp[4],
-                                                  D, t.dz, t.dea, d_eg, acc, t.dPg, st));
+                if (eimg)
+                    CK(pamnet_global_edge_agg_bwd_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, cuts, s.z, s.ea, eimg_store[k].we, 0,
+                                                      eimg_store[k].wea, 0, t.dz, t.dea, d_eg, acc, t.dPg, st));
+                else
+                    CK(pamnet_global_edge_agg_bwd_f32(t.dx2, g.eg, g.n, g.g_ptr, g.g_row, cuts, s.z, s.ea, gp[2] + 2 * D, 3 * D,
+                                                      gp[4], D, t.dz, t.dea, d_eg, acc, t.dPg, st));
             }
             const bool gather_g = fuse && k > 0 && fuse_segsum(g);   // the source-side sum inside the fused launch below
             if (!gather_g)

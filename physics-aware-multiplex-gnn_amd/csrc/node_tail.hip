@@ -1420,6 +1420,58 @@ extern "C" int pamnet_pack_weights_bf16x3(int64_t n, const float* const* W, cons
     return PAMNET_OK;
 }
 
+// One launch for the images of a whole step direction (round 6): kind 0 = the chains' fp32 fragment image above (16 384 floats),
+// kind 1 = the edge-level kernels' bf16x3 fragment image (edge_core.h load_wfragb1: 24 576 floats, the pieces a wave would
+// have made of its slice itself); offset[i] = where image i starts in `images`, in floats (multiples of 4).
+constexpr int PACK_MIXED_MAX = 224;
+namespace {
+struct PackJobsX {
+    const float* src[PACK_MIXED_MAX];
+    int ld[PACK_MIXED_MAX];                   // < 0: kind 1 (of row stride -ld)
+    uint32_t off4[PACK_MIXED_MAX];            // image offset in float4 units
+};
+__global__ __launch_bounds__(512) void pack_weights_mixed_kernel(PackJobsX jobs, int transposed, float* __restrict__ images) {
+    const float* __restrict__ W = jobs.src[blockIdx.x];
+    const int ld = jobs.ld[blockIdx.x];
+    float4* __restrict__ out = reinterpret_cast<float4*>(images) + jobs.off4[blockIdx.x];
+    const int j = blockIdx.y, q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (ld > 0) {
+        const int c = 16 * j + (lane & 15), k0 = 16 * q + 4 * (lane >> 4);
+        float4 v;
+        if (!transposed) v = *reinterpret_cast<const float4*>(W + (size_t)c * ld + k0);
+        else v = make_float4(W[(size_t)k0 * ld + c], W[(size_t)(k0 + 1) * ld + c], W[(size_t)(k0 + 2) * ld + c],
+                             W[(size_t)(k0 + 3) * ld + c]);
+        out[(j * 8 + q) * 64 + lane] = v;
+    } else if (q < DIM / 32) {
+        const Frag3 f = transposed ? edge::wfragb1_q<true>(W, -ld, 16 * j, q, lane) : edge::wfragb1_q<false>(W, -ld, 16 * j, q, lane);
+        uint4* o = reinterpret_cast<uint4*>(out) + ((j * (DIM / 32) + q) * 3) * 64 + lane;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) o[pc * 64] = make_uint4(f.p[pc][0], f.p[pc][1], f.p[pc][2], f.p[pc][3]);
+    }
+}
+}  // namespace
+
+extern "C" int pamnet_pack_weights_mixed_f32(int64_t n, const float* const* W, const int64_t* ld, const int32_t* kind,
+                                             const int64_t* offset, int32_t transposed, float* images, pamnet_stream_t stream) {
+    if (n < 0 || n > PACK_MIXED_MAX) return PAMNET_EINVAL;
+    if (n == 0) return PAMNET_OK;
+    if (!W || !ld || !kind || !offset || !images) return PAMNET_ENULL;
+    PackJobsX jobs;
+    for (int i = 0; i < PACK_MIXED_MAX; ++i) {
+        const int s = i < n ? i : 0;
+        if (!W[s]) return PAMNET_ENULL;
+        if (ld[s] < DIM || (ld[s] & 3) || ld[s] > 0x3fffffff || (kind[s] != 0 && kind[s] != 1)) return PAMNET_EINVAL;
+        if (offset[s] < 0 || (offset[s] & 3) || (offset[s] >> 2) > 0xffffffffll) return PAMNET_EINVAL;
+        jobs.src[i] = W[s];
+        jobs.ld[i] = kind[s] ? -(int)ld[s] : (int)ld[s];
+        jobs.off4[i] = (uint32_t)(offset[s] >> 2);
+    }
+    hipLaunchKernelGGL(pack_weights_mixed_kernel, dim3((unsigned)n, 8), dim3(512), 0, as_stream(stream), jobs, (int)transposed,
+                       images);
+    PAMNET_LAUNCH_CHECK();
+    return PAMNET_OK;
+}
+
 static int tail_fwd_launch(const float* x2, const float* res_x, int64_t n, const float* const* weights,
                            const float* const* biases, const float* w_out, const float* b_out, const float* w_att, float* Z,
                            float* R, float* x_out, float* out, float* att, const float* next_Wx1, const float* next_bx1,

@@ -442,3 +442,106 @@ def test_ping_pong_forward_is_run_to_run_identical_under_load(dev):
             assert torch.equal(out, ref[0]) and torch.equal(z, ref[1]) and torch.equal(ea, ref[2]), it
     torch.cuda.synchronize()
     assert torch.equal(out, ref[0]) and torch.equal(z, ref[1]) and torch.equal(ea, ref[2])
+
+
+# ---- round 6: the edge-level kernels take ready-made bf16x3 fragment images of their weight slices (row stride 0) ----------
+def _edge_images(mats, transposed, dev):
+    """pamnet_pack_weights_mixed_f32 kind 1 images of [(tensor, column offset, row stride), ...] -> list of pointers + keepalive."""
+    from pamnet_amd import lib
+    n = len(mats)
+    IMG = 3 * D * D // 2
+    images = torch.full((n * IMG,), float('nan'), device=dev)
+    W = (ctypes.c_void_p * n)(*[t.data_ptr() + 4 * c0 for t, c0, _ in mats])
+    ld = (ctypes.c_int64 * n)(*[s for _, _, s in mats])
+    kind = (ctypes.c_int32 * n)(*([1] * n))
+    off = (ctypes.c_int64 * n)(*[i * IMG for i in range(n)])
+    lib.call('pamnet_pack_weights_mixed_f32', n, W, ld, kind, off, transposed, lib.ptr(images), lib.stream_of(images))
+    assert torch.isfinite(images.view(torch.int32).float()).all()
+    return [images.data_ptr() + 4 * i * IMG for i in range(n)], images
+
+
+@pytest.mark.parametrize('case', ['qm9_like', 'tiny', 'mid', 'small3', 'pdbbind_like', 'holes', 'giant'])
+def test_fragment_images_give_the_bits_of_the_fp32_matrices(dev, case, monkeypatch):
+    """Forward (chunked and ping-pong forms, training and inference) and plain backward of the fused global-edge step with
+    W_e / W_ea as pamnet_pack_weights_mixed_f32 images (ld = 0) against the same calls on the fp32 matrices: every output
+    bit for bit (the image holds exactly the pieces a wave splits out of its slice)."""
+    from pamnet_amd import lib
+    rng = np.random.default_rng(5)
+    deg = DEGREE_CASES[case](rng)
+    n = len(deg)
+    ptr, row_of, col, m = _csr(deg, n, 9, dev)
+    gen = torch.Generator().manual_seed(17)
+    mk = lambda *s: (0.5 * torch.randn(*s, generator=gen)).to(dev)
+    e, Pi, Pj, init, d_agg = mk(max(m, 1), D)[:m], mk(n, D), mk(n, D), mk(n, D), mk(n, D)
+    Wm, bm, Wea = _weights(dev, 4)
+    st = lib.stream_of(Pi)
+    (we_f, wea_f), keep_f = _edge_images([(Wm, 2 * D, 3 * D), (Wea, 0, D)], 0, dev)
+    (we_b, wea_b), keep_b = _edge_images([(Wm, 2 * D, 3 * D), (Wea, 0, D)], 1, dev)
+    plain = (Wm.data_ptr() + 8 * D, 3 * D, Wea.data_ptr(), D)
+
+    def fwd(entry, w, save):
+        z, ea = (torch.full((max(m, 1), D), float('nan'), device=dev)[:m] for _ in range(2))
+        out = torch.full((n, D), float('nan'), device=dev)
+        lib.call(entry, lib.ptr(e), m, n, w[0], w[1], lib.ptr(bm), w[2], w[3], lib.ptr(Pi), lib.ptr(Pj), lib.ptr(ptr),
+                 lib.ptr(row_of), lib.ptr(col), None, lib.ptr(init), lib.ptr(z) if save else None, lib.ptr(ea) if save else None,
+                 lib.ptr(out), st)
+        return z, ea, out
+
+    for entry in ('pamnet_global_edge_agg_fwd_f32', 'pamnet_global_edge_agg_fwd_pp_f32'):
+        for save in (True, False):
+            a, b = fwd(entry, plain, save), fwd(entry, (we_f, 0, wea_f, 0), save)
+            assert torch.equal(a[2], b[2]) and torch.isfinite(b[2]).all()
+            if save and m:
+                assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    z, ea, _ = fwd('pamnet_global_edge_agg_fwd_f32', plain, True)
+
+    def bwd(w, acc):
+        dz, dea = (torch.full((max(m, 1), D), float('nan'), device=dev)[:m] for _ in range(2))
+        d_e = torch.ones(max(m, 1), D, device=dev)[:m]
+        dPi = torch.full((n, D), float('nan'), device=dev)
+        lib.call('pamnet_global_edge_agg_bwd_f32', lib.ptr(d_agg), m, n, lib.ptr(ptr), lib.ptr(row_of), None, lib.ptr(z),
+                 lib.ptr(ea), w[0], w[1], w[2], w[3], lib.ptr(dz), lib.ptr(dea), lib.ptr(d_e), acc, lib.ptr(dPi), st)
+        return dz, dea, d_e, dPi
+
+    for acc in (0, 1):
+        for x, y in zip(bwd(plain, acc), bwd((we_b, 0, wea_b, 0), acc)):
+            assert torch.equal(x, y)
+    # one stride zero, the other not: refused; the weight-gradient-forming backward takes matrices only
+    with pytest.raises(RuntimeError, match='EINVAL'):
+        lib.call('pamnet_global_edge_agg_fwd_f32', lib.ptr(e), m, n, we_f, 0, lib.ptr(bm), Wea.data_ptr(), D, lib.ptr(Pi),
+                 lib.ptr(Pj), lib.ptr(ptr), lib.ptr(row_of), lib.ptr(col), None, lib.ptr(init), None, None, lib.ptr(Pi), st)
+    if m:
+        need = ctypes.c_int64(0)
+        lib.call('pamnet_global_edge_agg_wg_floats', m, ctypes.addressof(need), None)
+        part = torch.empty(int(need.value), device=dev)
+        with pytest.raises(RuntimeError, match='EINVAL'):
+            lib.call('pamnet_global_edge_agg_bwd_wg_f32', lib.ptr(d_agg), m, n, lib.ptr(ptr), lib.ptr(row_of), None, lib.ptr(z),
+                     lib.ptr(ea), lib.ptr(e), we_b, 0, wea_b, 0, lib.ptr(z), lib.ptr(ea), 0, lib.ptr(Pi), lib.ptr(part), st)
+
+
+@pytest.mark.parametrize('m', [4316, 300, 36656])
+def test_local_edge_forward_on_fragment_images(dev, m):
+    """pamnet_local_edge_fwd_f32 with its four slices as images (all strides 0): the outputs of the fp32 matrices bit for bit."""
+    from pamnet_amd import lib
+    gen = torch.Generator().manual_seed(23)
+    mk = lambda *s: (0.5 * torch.randn(*s, generator=gen)).to(dev)
+    n = max(m // 2, 8)
+    rbf, P = mk(m, D), [mk(n, D) for _ in range(4)]
+    Wji, Wkj, Wlr, Wlo, bji, bkj = mk(D, 3 * D) / 8, mk(D, 3 * D) / 8, mk(D, D) / 8, mk(D, D) / 8, mk(D), mk(D)
+    row_of = torch.sort(torch.randint(0, n, (m,), generator=gen))[0].to(torch.int32).to(dev)
+    col = torch.randint(0, n, (m,), generator=gen).to(torch.int32).to(dev)
+    st = lib.stream_of(rbf)
+    imgs, keep = _edge_images([(Wji, 2 * D, 3 * D), (Wkj, 2 * D, 3 * D), (Wlr, 0, D), (Wlo, 0, D)], 0, dev)
+    parr = lambda ps: (ctypes.c_void_p * len(ps))(*ps)
+    iarr = lambda vs: (ctypes.c_int64 * len(vs))(*vs)
+
+    def run(wq, ldq):
+        outs = [torch.full((m, D), float('nan'), device=dev) for _ in range(6)]
+        lib.call('pamnet_local_edge_fwd_f32', lib.ptr(rbf), m, parr(wq), iarr(ldq), lib.ptr(bji), lib.ptr(bkj),
+                 parr([p.data_ptr() for p in P]), lib.ptr(row_of), lib.ptr(col), *[lib.ptr(o) for o in outs], st)
+        return outs
+
+    a = run([Wji.data_ptr() + 8 * D, Wkj.data_ptr() + 8 * D, Wlr.data_ptr(), Wlo.data_ptr()], [3 * D, 3 * D, D, D])
+    b = run(imgs, [0, 0, 0, 0])
+    for x, y in zip(a, b):
+        assert torch.isfinite(y).all() and torch.equal(x, y)

@@ -415,6 +415,36 @@ def test_local_backward_pair_equals_the_two_launches(dev, rows, edges, acc):
              lib.ptr(z_kj), lib.ptr(q2), wq, ldq, lib.ptr(pji), lib.ptr(pkj), lib.ptr(pq2), lib.ptr(prbf), acc, st)
     for a, b in ((dz1, pz1), (dz2, pz2), (dx, px), (dzji, pji), (dzkj, pkj), (dq2, pq2), (drbf, prbf)):
         assert torch.equal(a, b) and not bool(torch.isnan(a).any())
+    if rows == 0 or edges == 0:
+        return
+    # round 6: the same launch on weight images (pamnet_pack_weights_mixed_f32, transposed): W1 / W2 as bf16x3 fragments
+    # (kind 1, flag PAMNET_WEIGHT_IMAGES on accumulate_dx), the four local slices as fp32 fragments (kind 0, strides 0)
+    IMG1, IMG0 = 3 * D * D // 2, D * D
+    images = torch.full((2 * IMG1 + 4 * IMG0,), float('nan'), device=dev)
+    srcs = (ctypes.c_void_p * 6)(W1.data_ptr(), W2.data_ptr(), *[wq[i] for i in range(4)])
+    lds = (ctypes.c_int64 * 6)(D, D, 3 * D, 3 * D, D, D)
+    kinds = (ctypes.c_int32 * 6)(1, 1, 0, 0, 0, 0)
+    offs = (ctypes.c_int64 * 6)(0, IMG1, 2 * IMG1, 2 * IMG1 + IMG0, 2 * IMG1 + 2 * IMG0, 2 * IMG1 + 3 * IMG0)
+    lib.call('pamnet_pack_weights_mixed_f32', 6, srcs, lds, kinds, offs, 1, lib.ptr(images), st)
+    ip = lambda i: images.data_ptr() + 4 * offs[i]
+    (iz1, iz2, ix), (iji, ikj, iq2, irbf) = outs()
+    lib.call('pamnet_local_bwd_pair_f32', lib.ptr(dy), rows, lib.ptr(z1), lib.ptr(z2), ip(0), ip(1), lib.ptr(iz1),
+             lib.ptr(iz2), lib.ptr(ix), acc | 2, lib.ptr(d_mji), lib.ptr(d_mnb), lib.ptr(d_q3), edges, lib.ptr(z_ji),
+             lib.ptr(z_kj), lib.ptr(q2), (ctypes.c_void_p * 4)(ip(2), ip(3), ip(4), ip(5)), (ctypes.c_int64 * 4)(0, 0, 0, 0),
+             lib.ptr(iji), lib.ptr(ikj), lib.ptr(iq2), lib.ptr(irbf), acc, st)
+    for a, b in ((dz1, iz1), (dz2, iz2), (dx, ix), (dzji, iji), (dzkj, ikj), (dq2, iq2), (drbf, irbf)):
+        assert torch.equal(a, b)
+    # the stand-alone local edge backward takes the same images; mixed strides are refused
+    (_, _, _), (sji, skj, sq2, srbf) = outs()
+    lib.call('pamnet_local_edge_bwd_f32', lib.ptr(d_mji), lib.ptr(d_mnb), lib.ptr(d_q3), edges, lib.ptr(z_ji), lib.ptr(z_kj),
+             lib.ptr(q2), (ctypes.c_void_p * 4)(ip(2), ip(3), ip(4), ip(5)), (ctypes.c_int64 * 4)(0, 0, 0, 0), lib.ptr(sji),
+             lib.ptr(skj), lib.ptr(sq2), lib.ptr(srbf), acc, st)
+    for a, b in ((dzji, sji), (dzkj, skj), (dq2, sq2), (drbf, srbf)):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match='EINVAL'):
+        lib.call('pamnet_local_edge_bwd_f32', lib.ptr(d_mji), lib.ptr(d_mnb), lib.ptr(d_q3), edges, lib.ptr(z_ji),
+                 lib.ptr(z_kj), lib.ptr(q2), wq, (ctypes.c_int64 * 4)(0, 3 * D, D, D), lib.ptr(sji), lib.ptr(skj), lib.ptr(sq2),
+                 lib.ptr(srbf), acc, st)
 
 
 @pytest.mark.gpu

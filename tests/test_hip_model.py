@@ -1266,6 +1266,43 @@ def test_edge_recompute_switch_gives_the_same_step_bit_for_bit():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dataset', ['QM9', 'PDBbind'])
+def test_edge_fragment_images_leave_every_bit_of_a_step_unchanged(dataset):
+    """Round 6: the edge-level kernels read their weight slices as ready-made bf16x3 fragment images packed once per step
+    direction (PAMNET_EDGE_IMAGES, default on) instead of splitting the fp32 slices in every workgroup.  The pieces are the
+    same pieces: loss and the whole flat gradient of a training step are bit for bit those of PAMNET_EDGE_IMAGES=0 (each form
+    in a process of its own: the switch is read once)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    make = ("cfg = models.Config(dataset='QM9', dim=128, n_layer=3, cutoff_l=5.0, cutoff_g=5.0)\n"
+            "b = synth.qm9_batch(24, 0, 7).to(dev)\n") if dataset == 'QM9' else (
+            "cfg = models.Config(dataset='PDBbind', dim=128, n_layer=2, cutoff_l=2.0, cutoff_g=6.0)\n"
+            "b = synth.pdbbind_batch(3, 0, 2, n_pocket=60, n_ligand=12).to(dev)\n")
+    code = (
+        "import sys, hashlib, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import models\n"
+        "from pamnet_amd import synth\n"
+        "from pamnet_amd.train import Trainer\n"
+        "dev = torch.device('cuda:0'); torch.manual_seed(3)\n"
+        + make +
+        "model = models.PAMNet(cfg).to(dev)\n"
+        "tr = Trainer(model, loss='l1', max_grad_norm=None, ema_decay=None, lr=1e-3)\n"
+        "loss = tr.forward_backward(b)\n"
+        "torch.cuda.synchronize()\n"
+        "print('HASH', hashlib.sha256(tr.fp.grad.cpu().numpy().tobytes()).hexdigest(), float(loss), float(tr.fp.grad.abs().sum()))\n"
+    ) % (repo, os.path.join(repo, 'physics-aware-multiplex-gnn_amd'))
+    outs = []
+    for v in ('0', '1'):
+        env = dict(os.environ, PAMNET_EDGE_IMAGES=v)
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l.split()[1:] for l in r.stdout.splitlines() if l.startswith('HASH')][0])
+    assert float(outs[0][2]) > 0 and outs[0] == outs[1], outs
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('kind', ['pamnet_s_d128', 'pamnet_d32', 'pdbbind_d128'])
 def test_flat_parameter_view_gradients_other_models(kind, monkeypatch):
     """PAMNET_FLAT_PARAMS=1 on the other model kinds (PAMNet_s, a narrow width, the PDBbind branch): one step of the reference's
