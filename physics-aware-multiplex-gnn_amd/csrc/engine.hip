@@ -664,7 +664,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
     struct EdgeImgT {
         const float *we, *wea, *w1, *w2, *wq[4];
     };
-    std::vector<EdgeImgT> eimg_store(limg ? (size_t)n_layer : 0);
+    std::vector<EdgeImgT> eimg_store((eimg || limg) ? (size_t)n_layer : 0);
     if (packed) {
         PackList pl(wpack, 1, st, false, wpack + n_layer * PACK_FLOATS_PER_PAIR);
         for (int64_t k = n_layer - 1; k >= 0; --k) {
