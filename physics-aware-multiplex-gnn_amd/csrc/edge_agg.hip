@@ -792,6 +792,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
             pe[i] = ldg4z(eas, cur.r0 + rr + RPP * i, re, DIM, c4);
         }
     }
+    APROBE(13);
     while (cur.c0 < ne) {
         const int c0 = cur.c0, c1 = cur.c1, rows = cur.rows;
         const int64_t r0 = cur.r0, r1 = cur.r1;

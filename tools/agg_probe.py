@@ -46,10 +46,20 @@ st = torch.cuda.current_stream().cuda_stream
 cuts = torch.empty(257, dtype=torch.int32, device=dev)
 lib.call('pamnet_seg_cuts_i32', lib.ptr(csr.ptr), lib.ptr(csr.row_of), n, eg, lib.ptr(cuts), None, st)
 use_cuts = True
+# PAMNET_PROBE_IMAGES=1: the weights as ready-made fragment images (pamnet_pack_weights_mixed_f32 kind 1; row stride 0)
+IMAGES = os.environ.get('PAMNET_PROBE_IMAGES', '0') != '0'
+IMGF = 3 * D * D // 2
+imgs = torch.empty(4 * IMGF, device=dev)
+for tr in (0, 1):
+    lib.call('pamnet_pack_weights_mixed_f32', 2, (P * 2)(Wm.data_ptr() + 8 * D, Wea.data_ptr()), (I * 2)(3 * D, D),
+             (ctypes.c_int32 * 2)(1, 1), (I * 2)(2 * tr * IMGF, (2 * tr + 1) * IMGF), tr, lib.ptr(imgs), st)
+wf = (imgs.data_ptr(), 0, imgs.data_ptr() + 4 * IMGF, 0) if IMAGES else (Wm.data_ptr() + 8 * D, 3 * D, Wea.data_ptr(), D)
+wb = (imgs.data_ptr() + 8 * IMGF, 0, imgs.data_ptr() + 12 * IMGF, 0) if IMAGES else (Wm.data_ptr() + 8 * D, 3 * D, Wea.data_ptr(), D)
+print('weights as %s' % ('fragment images' if IMAGES else 'fp32 matrices'))
 
 
 def call(save):
-    return fn(e.data_ptr(), eg, n, Wm.data_ptr() + 8 * D, 3 * D, bm.data_ptr(), Wea.data_ptr(), D, Pi.data_ptr(), Pj.data_ptr(),
+    return fn(e.data_ptr(), eg, n, wf[0], wf[1], bm.data_ptr(), wf[2], wf[3], Pi.data_ptr(), Pj.data_ptr(),
               csr.ptr.data_ptr(), csr.row_of.data_ptr(), csr.col.data_ptr(), cuts.data_ptr() if use_cuts else None, x1.data_ptr(), z.data_ptr() if save else None,
               ea.data_ptr() if save else None, out.data_ptr(), st)
 
@@ -93,8 +103,8 @@ dz, dea, d_e, dPi = torch.empty(eg, D, device=dev), torch.empty(eg, D, device=de
 fb = plib.pamnet_global_edge_agg_bwd_f32
 fb.argtypes = [P, I, I, P, P, P, P, P, P, I, P, I, P, P, P, ctypes.c_int32, P, P]
 call(True)
-bw = lambda: fb(d_agg.data_ptr(), eg, n, csr.ptr.data_ptr(), csr.row_of.data_ptr(), cuts.data_ptr(), z.data_ptr(), ea.data_ptr(), Wm.data_ptr() + 8 * D,
-                3 * D, Wea.data_ptr(), D, dz.data_ptr(), dea.data_ptr(), d_e.data_ptr(), 1, dPi.data_ptr(), st)
+bw = lambda: fb(d_agg.data_ptr(), eg, n, csr.ptr.data_ptr(), csr.row_of.data_ptr(), cuts.data_ptr(), z.data_ptr(), ea.data_ptr(), wb[0],
+                wb[1], wb[2], wb[3], dz.data_ptr(), dea.data_ptr(), d_e.data_ptr(), 1, dPi.data_ptr(), st)
 for _ in range(200):
     bw()
 s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -111,6 +121,6 @@ names = ['weights + cuts + plan', 'load sweep (gather d_agg, z, ea; dz / dea sto
          'acc -> LDS + barriers', 'd_e sweep (accumulate load + store)']
 for i, nm in enumerate(names):
     print('   %-62s %7d cycles' % (nm, v[i + 1] - v[i]))
-print('   total %d cycles' % (v[7] - v[0]))
+print('   total %d cycles, of which the prologue (weights, work split, plan, first rows requested) %d' % (v[7] - v[0], v[13] - v[0]))
 life = sorted((wg[2 * i + 1] - wg[2 * i]) / 100.0 for i in range(nwg))
 print('   lifetime p10 %.1f p50 %.1f p90 %.1f max %.1f us' % (life[nwg // 10], life[nwg // 2], life[9 * nwg // 10], life[-1]))
