@@ -785,12 +785,36 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
     SPlan cur = splan(ptr, row_of, __builtin_amdgcn_readfirstlane(nb), (int64_t)__builtin_amdgcn_readfirstlane(ptr[nb]), ne, re, CAP);
     int mypraw = load_node_ptr(ptr, cur.c0, a.n);
     float4 pz[PRE ? NI : 1], pe[PRE ? NI : 1];
+    // AHEAD (round 6): the rows' node indices travel with the next chunk's z / ea rows (requested before the GEMMs), the d_agg rows
+    // they select are requested right behind the GEMMs -- as two dependent round trips at the top of a chunk's sweep they were
+    // ~1 600 of its ~3 900 cycles (tools/agg_probe.py, QM9 batch: three 48-row chunks per workgroup)
+    constexpr bool AHEAD = PRE && GATHER_FIRST;
+    int pgi[AHEAD ? NI : 1];
+    float4 pdm[AHEAD ? NI : 1];
+    auto next_indices = [&](int64_t rbeg, int64_t rend) __attribute__((always_inline)) {
+        if constexpr (AHEAD) {
+            const int64_t last = rend > rbeg ? rend - 1 : rbeg;      // (a chunk of edgeless nodes: any valid row, never used)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int64_t g = rbeg + rr + RPP * i;
+                pgi[i] = row_of[g < last ? g : last];
+            }
+        }
+    };
+    auto next_gather = [&]() __attribute__((always_inline)) {
+        if constexpr (AHEAD) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) pdm[i] = ldg4(d_agg, pgi[i], DIM, c4);
+        }
+    };
     if (PRE && cur.r0 < re) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             pz[i] = ldg4z(zs, cur.r0 + rr + RPP * i, re, DIM, c4);
             pe[i] = ldg4z(eas, cur.r0 + rr + RPP * i, re, DIM, c4);
         }
+        next_indices(cur.r0, cur.r1);
+        next_gather();
     }
     APROBE(13);
     while (cur.c0 < ne) {
@@ -811,7 +835,10 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
             // branch) -- row by row each gather waited for its index, and behind the first row's stores each index load
             // waited for those too (vector loads and stores retire in order on one counter)
             float4 dmv[GATHER_FIRST ? NI : 1];
-            if constexpr (GATHER_FIRST) {
+            if constexpr (AHEAD) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) dmv[i] = pdm[i];
+            } else if constexpr (GATHER_FIRST) {
                 int gi[NI];
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
@@ -851,6 +878,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
                 pz[i] = ldg4z(zs, r1 + rr + RPP * i, re, DIM, c4);
                 pe[i] = ldg4z(eas, r1 + rr + RPP * i, re, DIM, c4);
             }
+            next_indices(r1, nxt.r1);
         }
         APROBE(2);
         __syncthreads();
@@ -881,6 +909,7 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
                 mma_b16<MTX, true, BG>(S1, f2, acc.a[0], f2, acc.a[0], mt);
             }
             APROBE(5);
+            if (AHEAD && r1 < re) next_gather();               // (the indices arrived during the GEMMs)
             // otherwise requested here (the A fragments' registers are free again): the two barriers and the accumulator
             // stores cover the latency
             if (PREACC && !EARLY && accumulate) fetch_acc();
@@ -898,6 +927,8 @@ __global__ __launch_bounds__(WG8, 1) void global_edge_agg_bwd_kernel(GAggBwd a) 
                     stg4(d_e, g, DIM, c4, v);
                 }
             }
+        } else if (AHEAD && r1 < re) {
+            next_gather();                                     // (a chunk of edgeless nodes ran no GEMMs to issue it behind)
         }
         APROBE(7);
         __syncthreads();
