@@ -231,11 +231,32 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void local_edge_fwd_kerne
     const Span sp = Span::make<NW>(m, pa, pb, pc, cmt);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
+        // (8-wave geometry, chunks of <= 3 tiles) the node-plane rows of the epilogue: their indices are requested ahead of the
+        // staging sweep, the rows themselves behind it -- in the epilogue sweep they were two dependent round trips behind the
+        // GEMMs' barrier (clamped rows: every request is unconditional)
+        constexpr bool AHEAD = B16 && MTX <= 3;
+        constexpr int NI = AHEAD ? MTX : 1;
+        float4 gpi[NI], gpj[NI];
+        int ii[NI], jj[NI];
+        if constexpr (AHEAD) {
+            const int rq = threadIdx.x >> 5;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                int64_t g = row0 + rq + 16 * i;
+                g = g < sp.end ? g : sp.end - 1;
+                ii[i] = row_of[g], jj[i] = col[g];
+            }
+        }
         sweep<MTX, NW>(mt, [&](int r, int c4) {
             const float4 v = ldg4z(rbf, row0 + r, sp.end, DIM, c4);
             if constexpr (B16) st_pieces4(P, r, c4, v);
             else st_lds4(S0, r, c4, v);
         });
+        if constexpr (AHEAD) {
+            const int c4 = threadIdx.x & 31;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) gpi[i] = ldg4(Pi, ii[i], DIM, c4), gpj[i] = ldg4(Pj, jj[i], DIM, c4);
+        }
         __syncthreads();
         if constexpr (B16) {
             AccSet<MTX, NS> accq, accz;
@@ -254,11 +275,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void local_edge_fwd_kerne
             store_set<MTX, NS>(acc, S1, wc, bz, mt);
         }
         __syncthreads();
-        sweep<MTX, NW>(mt, [&](int r, int c4) {
+        // (the pass index is a compile-time constant here: indexing gpi / gpj by r >> 4 made them dynamically indexed registers --
+        // 10 -> 30 us)
+        auto epilogue = [&](int r, int c4, const float4& pi_, const float4& pj_) __attribute__((always_inline)) {
             const int64_t g = row0 + r;
-            if (g >= sp.end) return;
-            const int64_t i = row_of[g], j = col[g];
-            const float4 zz = f4add(f4add(lds4(S1, r, c4), ldg4(Pi, i, DIM, c4)), ldg4(Pj, j, DIM, c4));
+            const float4 zz = f4add(f4add(lds4(S1, r, c4), pi_), pj_);
             const float4 gate = lds4(S2, r, c4);
             if (kj) {
                 if (z_kj) stg4(z_kj, g, DIM, c4, zz);         // z_*, q2: backward-only saves, null in inference mode
@@ -269,7 +290,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void local_edge_fwd_kerne
                 stg4(m_ji, g, DIM, c4, f4silu(zz));
                 stg4(q3, g, DIM, c4, gate);
             }
-        });
+        };
+        if constexpr (AHEAD) {
+            const int c4 = threadIdx.x & 31, rq = threadIdx.x >> 5;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (16 * i < 16 * mt && row0 + rq + 16 * i < sp.end) epilogue(rq + 16 * i, c4, gpi[i], gpj[i]);
+        } else {
+            sweep<MTX, NW>(mt, [&](int r, int c4) {
+                const int64_t g = row0 + r;
+                if (g >= sp.end) return;
+                const int64_t i = row_of[g], j = col[g];
+                epilogue(r, c4, ldg4(Pi, i, DIM, c4), ldg4(Pj, j, DIM, c4));
+            });
+        }
         __syncthreads();
     }
 }

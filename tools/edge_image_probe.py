@@ -69,3 +69,26 @@ for rep in range(2):
         event_us(lambda: pair(ip(0), ip(1), 2, img_wq, img_ld)),
         event_us(lambda: pair(ip(0), ip(1), 2, plain_wq, plain_ld)),
         event_us(lambda: pair(W1.data_ptr(), W2.data_ptr(), 0, img_wq, img_ld))))
+
+
+# ---- the local edge forward (QM9: one chunk of 2-3 tiles per workgroup)
+n_nodes = max(edges // 2, 8)
+rbf, Pl = rnd(edges, D), [rnd(n_nodes, D) for _ in range(4)]
+bji, bkj = rnd(D), rnd(D)
+row_of = torch.sort(torch.randint(0, n_nodes, (edges,), device=dev))[0].to(torch.int32)
+col = torch.randint(0, n_nodes, (edges,), device=dev).to(torch.int32)
+fimg = torch.empty(4 * IMG1, device=dev)
+lib.call('pamnet_pack_weights_mixed_f32', 4, P4(*wqp), I4(3 * D, 3 * D, D, D), (ctypes.c_int32 * 4)(1, 1, 1, 1),
+         I4(0, IMG1, 2 * IMG1, 3 * IMG1), 0, lib.ptr(fimg), st)
+fo = [torch.empty(edges, D, device=dev) for _ in range(6)]
+
+
+def lfwd(wq, ldq):
+    lib.call('pamnet_local_edge_fwd_f32', lib.ptr(rbf), edges, wq, ldq, lib.ptr(bji), lib.ptr(bkj),
+             P4(*[p.data_ptr() for p in Pl]), lib.ptr(row_of), lib.ptr(col), *[lib.ptr(o) for o in fo], st)
+
+
+fwq = P4(*[fimg.data_ptr() + 4 * i * IMG1 for i in range(4)])
+for rep in range(2):
+    print('  local_edge_fwd: matrices %.1f us | images %.1f us' % (event_us(lambda: lfwd(plain_wq, plain_ld)),
+                                                                  event_us(lambda: lfwd(fwq, img_ld))))
