@@ -281,7 +281,7 @@ constexpr int64_t PACK_FLOATS_PER_PAIR = PACK_PER_PAIR * (3 * D * D / 2);     //
 // the split of the result, 12 more LDS stores with 4-way bank conflicts, 96 KB instead of 64 KB of weights per layer
 // from L2); same outputs to 3e-7 (tests/test_hip_fused.py::test_node_tail_fwd_bf16x6).
 // Round 6: the segment sums that feed a fused head + chain backward launch (the source-side sum of the global layer's d z, the
-// four sums of the local layer) are formed by that launch's own row tiles (node_tail.hip gather_plane_row) instead of by launches
+// four sums of the local layer) are formed by that launch's own row tiles (node_tail.hip gather_begin / gather_finish) instead of by launches
 // of their own ahead of it: two launches fewer per layer pair on the dependent chain.  PAMNET_FUSE_SEGSUM=0: the separate launches.
 inline bool fuse_segsum(const Graph& g) {
     static const bool v = [] { const char* e = getenv("PAMNET_FUSE_SEGSUM"); return !e || atoi(e) != 0; }();

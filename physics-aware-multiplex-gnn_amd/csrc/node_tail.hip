@@ -824,20 +824,57 @@ struct PreBwd {
     const int32_t* gperm[4];
     float* dP_out;
 };
-// plane row `row` (this thread's float4 column) as the segment sum of its rows of `src`, in CSR order
-__device__ __forceinline__ float4 gather_plane_row(const float* __restrict__ src, const int32_t* __restrict__ ptr,
-                                                   const int32_t* __restrict__ perm, int64_t row, int c4) {
-    int q = ptr[row];
-    const int q1 = ptr[row + 1];
-    float4 s = f4zero();
-    for (; q + 4 <= q1; q += 4) {                              // four rows in flight, added in order
-        int i0 = q, i1 = q + 1, i2 = q + 2, i3 = q + 3;
-        if (perm) i0 = perm[q], i1 = perm[q + 1], i2 = perm[q + 2], i3 = perm[q + 3];
-        const float4 v0 = ldg4(src, i0, DIM, c4), v1 = ldg4(src, i1, DIM, c4), v2 = ldg4(src, i2, DIM, c4), v3 = ldg4(src, i3, DIM, c4);
-        s = f4add(f4add(f4add(f4add(s, v0), v1), v2), v3);
+// Plane rows `row` (this thread's float4 column) of up to four planes as the segment sums of their rows of gsrc[b], in CSR order,
+// formed TOGETHER: one thread's sums are chains of dependent round trips (row range -> permutation entries -> rows), and plane
+// by plane, four rows at a time, a local layer's four planes of degree ~2 were ~20 of them in a row ahead of the chain.  Here the
+// row ranges of all planes are one request (gather_begin: issued ahead of the tile's other loads), then every step requests U rows
+// of every plane at once, with the permutation entries of the NEXT step in flight beside them: 2 + ceil(max degree / U) round
+// trips.  The additions of a plane are in CSR order as before (same bits as pamnet_segment_sum_multi_f32).
+constexpr int GU = 4;                          // rows in flight per plane and step
+struct GatherState {
+    int q[4], q1[4];
+};
+__device__ __forceinline__ void gather_begin(GatherState& gs, const PreBwd& pb, int64_t row, bool in_range) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        gs.q[b] = gs.q1[b] = 0;
+        if (b < pb.nblk && pb.gsrc[b] && in_range) gs.q[b] = pb.gptr[b][row], gs.q1[b] = pb.gptr[b][row + 1];
     }
-    for (; q < q1; ++q) s = f4add(s, ldg4(src, perm ? perm[q] : q, DIM, c4));
-    return s;
+}
+__device__ __forceinline__ void gather_finish(GatherState& gs, const PreBwd& pb, int c4, float4 (&s)[4]) {
+    int idx[4][GU];
+    auto fetch_idx = [&](int (&out)[4][GU]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int qq = gs.q[b] + u;
+                out[b][u] = -1;
+                if (qq < gs.q1[b]) out[b][u] = pb.gperm[b] ? pb.gperm[b][qq] : qq;
+            }
+    };
+    fetch_idx(idx);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) s[b] = f4zero();
+    while (gs.q[0] < gs.q1[0] || gs.q[1] < gs.q1[1] || gs.q[2] < gs.q1[2] || gs.q[3] < gs.q1[3]) {
+        float4 v[4][GU];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int u = 0; u < GU; ++u)
+                if (idx[b][u] >= 0) v[b][u] = ldg4(pb.gsrc[b], idx[b][u], DIM, c4);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) gs.q[b] += GU;
+        int nidx[4][GU];
+        fetch_idx(nidx);                                      // (in flight beside the rows)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                if (idx[b][u] >= 0) s[b] = f4add(s[b], v[b][u]);
+                idx[b][u] = nidx[b][u];
+            }
+    }
 }
 
 template <bool PACKED, bool HEADS, bool PRE = false>
@@ -893,6 +930,8 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
     const int sc4 = threadIdx.x & 31, sr = threadIdx.x >> 5;          // sweep coordinates: 512 threads = 16 rows x 32 float4
     const int64_t sg = row0 + sr;
     {
+        GatherState gst;
+        if constexpr (PRE) gather_begin(gst, pb, sg, sg < n);   // (the row ranges of the planes formed here: first request of all)
 #pragma unroll
         for (int k = 0; k < NZ; ++k) st_lds4(ZL + k * SLOT, sr, sc4, ldg4z(Z + (int64_t)k * plane, sg, n, DIM, sc4));
         float4 kx = d_xout ? ldg4z(d_xout, sg, n, DIM, sc4) : f4zero();
@@ -901,14 +940,15 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
             // tiles of the head backward: dP planes -> ZL[7..9] + the (unused) head-partial area, z_x1 -> EX,
             // d x1_direct -> D1, d_add joins K (K = d_add + g_head; the head's d x is added below)
             float* const pl[4] = {ZL + 7 * SLOT, ZL + 8 * SLOT, ZL + 9 * SLOT, red};
-            for (int b = 0; b < pb.nblk; ++b) {
+            float4 gsum[4];
+            gather_finish(gst, pb, sc4, gsum);                 // (rows past n: empty ranges, zeros)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b >= pb.nblk) break;
                 float4 v;
                 if (pb.gsrc[b]) {                              // (workgroup-uniform) the plane is formed here, and kept
-                    v = f4zero();
-                    if (sg < n) {
-                        v = gather_plane_row(pb.gsrc[b], pb.gptr[b], pb.gperm[b], sg, sc4);
-                        stg4(pb.dP_out + (int64_t)b * plane, sg, DIM, sc4, v);
-                    }
+                    v = gsum[b];
+                    if (sg < n) stg4(pb.dP_out + (int64_t)b * plane, sg, DIM, sc4, v);
                 } else {
                     v = ldg4z(pb.dP + (int64_t)b * plane, sg, n, DIM, sc4);
                 }

@@ -1266,12 +1266,17 @@ def test_edge_recompute_switch_gives_the_same_step_bit_for_bit():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('switch', ['PAMNET_EDGE_IMAGES', 'PAMNET_FUSE_LOCAL_AGG'])
 @pytest.mark.parametrize('dataset', ['QM9', 'PDBbind'])
-def test_edge_fragment_images_leave_every_bit_of_a_step_unchanged(dataset):
+def test_edge_fragment_images_leave_every_bit_of_a_step_unchanged(dataset, switch):
     """Round 6: the edge-level kernels read their weight slices as ready-made bf16x3 fragment images packed once per step
     direction (PAMNET_EDGE_IMAGES, default on) instead of splitting the fp32 slices in every workgroup.  The pieces are the
     same pieces: loss and the whole flat gradient of a training step are bit for bit those of PAMNET_EDGE_IMAGES=0 (each form
-    in a process of its own: the switch is read once)."""
+    in a process of its own: the switch is read once).  The same protocol for the local layer's aggregations formed inside its
+    forward chain launch (PAMNET_FUSE_LOCAL_AGG): the same rows in the same order as the stand-alone kernel.  (The segment sums
+    formed inside the fused head + chain backward launch, PAMNET_FUSE_SEGSUM, add a node's rows strictly in CSR order where the
+    stand-alone kernels keep several partial sums: same values to fp32 rounding, not the same bits -- covered by the gradient
+    goldens.)"""
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1295,7 +1300,7 @@ def test_edge_fragment_images_leave_every_bit_of_a_step_unchanged(dataset):
     ) % (repo, os.path.join(repo, 'physics-aware-multiplex-gnn_amd'))
     outs = []
     for v in ('0', '1'):
-        env = dict(os.environ, PAMNET_EDGE_IMAGES=v)
+        env = dict(os.environ, **{switch: v})
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l.split()[1:] for l in r.stdout.splitlines() if l.startswith('HASH')][0])
