@@ -290,7 +290,7 @@ inline bool fuse_segsum(const Graph& g) {
     return v && (g.n + 15) / 16 <= 256;
 }
 // Round 6: the local layer's two chained aggregations (pamnet_local_agg_fwd_f32) are formed by the row tiles of the chain launch
-// that consumes them (node_tail.hip local_agg_row; pamnet_node_tail_fwd_agg_f32): one launch fewer per layer on the dependent
+// that consumes them (node_tail.hip local_agg_rows; pamnet_node_tail_fwd_agg_f32): one launch fewer per layer on the dependent
 // chain.  PAMNET_FUSE_LOCAL_AGG=0: the separate launch.  Small batches only (the lean chain forms read their input).
 inline bool fuse_local_agg(const Graph& g) {
     static const bool v = [] { const char* e = getenv("PAMNET_FUSE_LOCAL_AGG"); return !e || atoi(e) != 0; }();

@@ -162,30 +162,115 @@ struct LocalAgg {
     float4* m_t;                  // nullable: backward-only save
     float4* x2_out;
 };
-__device__ __forceinline__ float4 local_agg_row(const LocalAgg& la, int64_t node, int c) {
-    float4 acc = la.init ? la.init[node * 32 + c] : f4zero();
-    const int e0 = la.l_ptr[node], e1 = la.l_ptr[node + 1];
-    for (int e = e0; e < e1; ++e) {
-        const int t0 = la.t_ptr[e], t1 = la.t_ptr[e + 1];
-        float4 v = la.m_ji[(int64_t)e * 32 + c];
-        const float4 gate = la.q3[(int64_t)e * 32 + c];
-        int t = t0;
-        for (; t + 4 <= t1; t += 4) {
-            const int64_t k0 = la.t_col[t], k1 = la.t_col[t + 1], k2 = la.t_col[t + 2], k3 = la.t_col[t + 3];
-            const float4 a0 = la.m_nb[k0 * 32 + c], a1 = la.m_nb[k1 * 32 + c], a2 = la.m_nb[k2 * 32 + c], a3 = la.m_nb[k3 * 32 + c];
-            const float4 b0 = la.s[(int64_t)t * 32 + c], b1 = la.s[(int64_t)(t + 1) * 32 + c], b2 = la.s[(int64_t)(t + 2) * 32 + c],
-                         b3 = la.s[(int64_t)(t + 3) * 32 + c];
-            v = f4add(v, f4mul(a0, b0));
-            v = f4add(v, f4mul(a1, b1));
-            v = f4add(v, f4mul(a2, b2));
-            v = f4add(v, f4mul(a3, b3));
+// x2 rows of NJ nodes (this thread's float4 column) at once.  Node by node, edge by edge, four rows at a time the sums of one row
+// were a chain of ~10 dependent round trips (edge range -> row ranges -> columns -> rows, per edge), twice per thread, ahead of the
+// chain's first layer.  Here the edge ranges of all nodes are one request, every step takes NK edges of every node together (their
+// row ranges, m_ji and gate rows in one request), and their rows NU at a time with the NEXT columns in flight beside the rows.
+// The additions are those of local_agg_fwd_kernel in the same order (edge_agg.hip): rows in triplet / pair order onto m_ji, edges in
+// CSR order onto init -- bitwise the stand-alone kernel's x2 and m_t (tests: PAMNET_FUSE_LOCAL_AGG=0 / 1 hash-equal).
+template <int NJ>
+__device__ __forceinline__ void local_agg_rows(const LocalAgg& la, const int64_t (&node)[NJ], const bool (&ok)[NJ], int c,
+                                               float4 (&out)[NJ]) {
+    constexpr int NK = 2, NU = 2;
+    int e0[NJ], e1[NJ];
+    float4 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        e0[j] = e1[j] = 0;
+        acc[j] = f4zero();
+        if (ok[j]) {
+            e0[j] = la.l_ptr[node[j]], e1[j] = la.l_ptr[node[j] + 1];
+            if (la.init) acc[j] = la.init[node[j] * 32 + c];
         }
-        for (; t < t1; ++t) v = f4add(v, f4mul(la.m_nb[(int64_t)la.t_col[t] * 32 + c], la.s[(int64_t)t * 32 + c]));
-        if (la.m_t) la.m_t[(int64_t)e * 32 + c] = v;
-        acc = f4add(acc, f4mul(v, gate));
     }
-    la.x2_out[node * 32 + c] = acc;
-    return acc;
+    auto any_edges = [&]() __attribute__((always_inline)) {
+        bool m = false;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) m = m || e0[j] < e1[j];
+        return m;
+    };
+    while (any_edges()) {
+        int t0[NJ][NK], t1[NJ][NK];
+        float4 v[NJ][NK], gate[NJ][NK];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int e = e0[j] + k;
+                t0[j][k] = t1[j][k] = 0;
+                if (e < e1[j]) {
+                    t0[j][k] = la.t_ptr[e], t1[j][k] = la.t_ptr[e + 1];
+                    v[j][k] = la.m_ji[(int64_t)e * 32 + c];
+                    gate[j][k] = la.q3[(int64_t)e * 32 + c];
+                }
+            }
+        int col[NJ][NK][NU];
+        auto fetch_cols = [&](int (&o)[NJ][NK][NU]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int k = 0; k < NK; ++k)
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        o[j][k][u] = -1;
+                        if (t0[j][k] + u < t1[j][k]) o[j][k][u] = la.t_col[t0[j][k] + u];
+                    }
+        };
+        auto any_rows = [&]() __attribute__((always_inline)) {
+            bool m = false;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int k = 0; k < NK; ++k) m = m || t0[j][k] < t1[j][k];
+            return m;
+        };
+        fetch_cols(col);
+        while (any_rows()) {
+            float4 ra[NJ][NK][NU], rb[NJ][NK][NU];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int k = 0; k < NK; ++k)
+#pragma unroll
+                    for (int u = 0; u < NU; ++u)
+                        if (col[j][k][u] >= 0) {
+                            ra[j][k][u] = la.m_nb[(int64_t)col[j][k][u] * 32 + c];
+                            rb[j][k][u] = la.s[(int64_t)(t0[j][k] + u) * 32 + c];
+                        }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int k = 0; k < NK; ++k) t0[j][k] += NU;
+            int ncol[NJ][NK][NU];
+            fetch_cols(ncol);                                 // (in flight beside the rows)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int k = 0; k < NK; ++k)
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        if (col[j][k][u] >= 0) v[j][k] = f4add(v[j][k], f4mul(ra[j][k][u], rb[j][k][u]));
+                        col[j][k][u] = ncol[j][k][u];
+                    }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int e = e0[j] + k;
+                if (e < e1[j]) {
+                    if (la.m_t) la.m_t[(int64_t)e * 32 + c] = v[j][k];
+                    acc[j] = f4add(acc[j], f4mul(v[j][k], gate[j][k]));
+                }
+            }
+            e0[j] += NK;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (ok[j]) la.x2_out[node[j] * 32 + c] = acc[j];
+        out[j] = acc[j];
+    }
 }
 
 template <bool PACKED, bool HEADS, bool RIDER = false>
@@ -232,14 +317,29 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
 
     WFrag wf;
     load_w<PACKED>(wf, p.W[0], DIM, wc);
-    sweep_rows<BMN>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        st_lds4(RX, r, c4, ldg4z(res_x, g, n, DIM, c4));
-        float4 xin;
-        if (la.m_ji) xin = g < n ? local_agg_row(la, g, c4) : f4zero();        // (workgroup-uniform: the row is formed here)
-        else xin = ldg4z(x2, g, n, DIM, c4);
-        st_lds4(X0, r, c4, xin);
-    });
+    if (la.m_ji) {                                            // (workgroup-uniform) the x2 rows are formed here
+        constexpr int NJ = BMN / 8;                           // rows per thread of the sweep
+        const int c4 = threadIdx.x & 31, rq = threadIdx.x >> 5;
+        int64_t node[NJ];
+        bool ok[NJ];
+        float4 xin[NJ], rx[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) node[j] = row0 + rq + 8 * j, ok[j] = node[j] < n;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) rx[j] = ldg4z(res_x, node[j], n, DIM, c4);
+        local_agg_rows<NJ>(la, node, ok, c4, xin);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            st_lds4(RX, rq + 8 * j, c4, rx[j]);
+            st_lds4(X0, rq + 8 * j, c4, xin[j]);
+        }
+    } else {
+        sweep_rows<BMN>([&](int r, int c4) {
+            const int64_t g = row0 + r;
+            st_lds4(RX, r, c4, ldg4z(res_x, g, n, DIM, c4));
+            st_lds4(X0, r, c4, ldg4z(x2, g, n, DIM, c4));
+        });
+    }
     __syncthreads();
 
     // layer k: in -> dst = SiLU(W_k in + b_k) (+ add1 + add2); z_k parked; optional tap of the result
