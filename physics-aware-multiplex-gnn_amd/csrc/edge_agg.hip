@@ -1461,16 +1461,19 @@ __global__ __launch_bounds__(256) void local_agg_bwd_kernel(const float4* __rest
         d_mt[e * 32 + c] = g;
         d_q3[e * 32 + c] = pamnet::f4mul(dx, m_t[e * 32 + c]);
         const int t0 = t_ptr[e], t1 = t_ptr[e + 1];
-        int t = t0;
-        for (; t + 4 <= t1; t += 4) {
-            const int64_t k0 = t_col[t], k1 = t_col[t + 1], k2 = t_col[t + 2], k3 = t_col[t + 3];
-            const float4 a0 = m_nb[k0 * 32 + c], a1 = m_nb[k1 * 32 + c], a2 = m_nb[k2 * 32 + c], a3 = m_nb[k3 * 32 + c];
-            d_s[(int64_t)t * 32 + c] = pamnet::f4mul(a0, g);
-            d_s[(int64_t)(t + 1) * 32 + c] = pamnet::f4mul(a1, g);
-            d_s[(int64_t)(t + 2) * 32 + c] = pamnet::f4mul(a2, g);
-            d_s[(int64_t)(t + 3) * 32 + c] = pamnet::f4mul(a3, g);
+        // four rows per step, the last step predicated (as a row-by-row tail every leftover row was two dependent round trips)
+        for (int t = t0; t < t1; t += 4) {
+            int64_t k[4];
+            float4 a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) k[u] = t + u < t1 ? t_col[t + u] : -1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k[u] >= 0) a[u] = m_nb[k[u] * 32 + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k[u] >= 0) d_s[(int64_t)(t + u) * 32 + c] = pamnet::f4mul(a[u], g);
         }
-        for (; t < t1; ++t) d_s[(int64_t)t * 32 + c] = pamnet::f4mul(m_nb[(int64_t)t_col[t] * 32 + c], g);
     } else {
         const int q0 = tT_ptr[e], q1 = tT_ptr[e + 1];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1480,20 +1483,21 @@ __global__ __launch_bounds__(256) void local_agg_bwd_kernel(const float4* __rest
             // node), made with the graph (pamnet_triplet_transpose_aux_i32): the three index reads of a term are independent --
             // one level of indirection ahead of the data instead of three (perm -> t_row -> l_row -> d x2); four terms in
             // flight.  Same terms in the same order.
-            for (; q + 4 <= q1; q += 4) {
-                float4 sv[4], gv[4];
+            for (; q < q1; q += 4) {                           // (the last step predicated: no row-by-row tail)
+                float4 sv[4], dv[4], qv[4];
+                int64_t ta[4], ra[4], nd[4];
+                bool ok[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int64_t ta = tT_perm[q + u], ra = tT_edge[q + u], nd = tT_node[q + u];
-                    sv[u] = s[ta * 32 + c];
-                    gv[u] = pamnet::f4mul(d_x2[nd * 32 + c], q3[ra * 32 + c]);
+                    ok[u] = q + u < q1;
+                    if (ok[u]) ta[u] = tT_perm[q + u], ra[u] = tT_edge[q + u], nd[u] = tT_node[q + u];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v = pamnet::f4add(v, pamnet::f4mul(sv[u], gv[u]));
-            }
-            for (; q < q1; ++q) {
-                const int64_t ta = tT_perm[q], ra = tT_edge[q], nd = tT_node[q];
-                v = pamnet::f4add(v, pamnet::f4mul(s[ta * 32 + c], pamnet::f4mul(d_x2[nd * 32 + c], q3[ra * 32 + c])));
+                for (int u = 0; u < 4; ++u)
+                    if (ok[u]) sv[u] = s[ta[u] * 32 + c], dv[u] = d_x2[nd[u] * 32 + c], qv[u] = q3[ra[u] * 32 + c];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ok[u]) v = pamnet::f4add(v, pamnet::f4mul(sv[u], pamnet::f4mul(dv[u], qv[u])));
             }
         } else {
             for (; q + 2 <= q1; q += 2) {
