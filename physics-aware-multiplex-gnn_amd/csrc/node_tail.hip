@@ -315,6 +315,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
     const int lane = threadIdx.x & 63, r16 = lane & 15, kg = lane >> 4;
     const int wc = (threadIdx.x >> 6) * 32;
 
+    TPROBE(40);
     WFrag wf;
     load_w<PACKED>(wf, p.W[0], DIM, wc);
     if (la.m_ji) {                                            // (workgroup-uniform) the x2 rows are formed here
@@ -399,6 +400,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
         }
         stg4(x_out, g, DIM, c4, lds4(TL + 2 * SLOT, r, c4));
     });
+    TPROBE(41);
 
     // heads: 16 lanes per row, 8 columns each, butterfly over the 16-lane group
     if constexpr (HEADS) {
@@ -460,6 +462,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
             }
         }
         __syncthreads();
+        TPROBE(42);
         sweep_rows<BMN>([&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g >= n) return;
@@ -467,6 +470,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
             stg4(nx.x1, g, DIM, c4, lds4(ZL + SLOT, r, c4));
             for (int b = 0; b < nx.nblk; ++b) stg4(nx.P + (int64_t)b * plane, g, DIM, c4, lds4(ZL + (2 + b) * SLOT, r, c4));
         });
+        TPROBE(43);
     }
 }
 

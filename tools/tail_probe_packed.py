@@ -54,6 +54,8 @@ for it in range(3):
     lib.pamnet_tail_probe_read(buf)
     t = list(buf)
     print('run %d: layers 0..6 total %d cycles' % (it, t[27] - t[0]))
+    print('  kernel: staging %d | chain %d | park -> memory %d | next head (x1 + %d blocks) %d | its flush %d | total %d cycles' % (
+        t[0] - t[40], t[27] - t[0], t[41] - t[27], nblk, t[42] - t[41], t[43] - t[42], t[43] - t[40]))
     print('  layer:   wait+MFMA   prefetch+epilogue   barrier')
     for k in range(7):
         print('  %2d      %8d   %8d            %8d' % (k, t[4 * k + 1] - t[4 * k], t[4 * k + 2] - t[4 * k + 1], t[4 * k + 3] - t[4 * k + 2]))
