@@ -309,26 +309,39 @@ __device__ __forceinline__ void embed_bwd_body(const EJob& jb, int bid, float* x
                 const int r = r0p + 8 * i;
                 float4 dz = f4zero();
                 if (row0 + r < rows) {
-                    dz = pre[i];
-                    if (act) dz = f4mul(dz, f4dsilu(f4add(lds4(Ds, r, c), bias0)));
-                    dbs0 = f4add(dbs0, dz);
-                }
-                st_lds4(Ds, r, c, dz);
-            }
-            prefetch(tile + jb.nblk);
-        } else {
-            sweep_rows<TR>([&](int r, int c) {
-                const int64_t g = row0 + r;
-                float4 dz = f4zero();
-                if (g < rows) {
                     const bool k1 = TWO && ks[r];
-                    dz = ldg4(gout, g, DOUT, c);
+                    dz = pre[i];
                     if (act) dz = f4mul(dz, f4dsilu(f4add(lds4(Ds, r, c), k1 ? bias1 : bias0)));
                     if (k1) dbs1 = f4add(dbs1, dz);
                     else dbs0 = f4add(dbs0, dz);
                 }
                 st_lds4(Ds, r, c, dz);
-            });
+            }
+            prefetch(tile + jb.nblk);
+        } else {
+            // (the tile's eight gradient rows of this thread requested together, then consumed: row by row under `if (g < rows)`
+            // each was a round trip of its own -- a one-tile workgroup of the two-set 42-wide layer is the launch at the QM9 batch)
+            const int c = threadIdx.x & 31, r0p = threadIdx.x >> 5;
+            float4 gr[TR / 8];
+#pragma unroll
+            for (int i = 0; i < TR / 8; ++i) {
+                int64_t g = row0 + r0p + 8 * i;
+                g = g < rows ? g : rows - 1;                  // (clamped: unconditional requests; rows > 0 inside the tile loop)
+                gr[i] = ldg4(gout, g, DOUT, c);
+            }
+#pragma unroll
+            for (int i = 0; i < TR / 8; ++i) {
+                const int r = r0p + 8 * i;
+                float4 dz = f4zero();
+                if (row0 + r < rows) {
+                    const bool k1 = TWO && ks[r];
+                    dz = gr[i];
+                    if (act) dz = f4mul(dz, f4dsilu(f4add(lds4(Ds, r, c), k1 ? bias1 : bias0)));
+                    if (k1) dbs1 = f4add(dbs1, dz);
+                    else dbs0 = f4add(dbs0, dz);
+                }
+                st_lds4(Ds, r, c, dz);
+            }
         }
         __syncthreads();
         // dW[c][k] += sum_r dz[r][c] * x[r][k]: MFMA with the row index as the reduction dimension
