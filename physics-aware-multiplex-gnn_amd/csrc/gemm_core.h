@@ -274,6 +274,42 @@ __device__ __forceinline__ void mma_tile_frag(const float* __restrict__ As, cons
     }
 }
 
+// The same products with the operands of the MFMA swapped (weights as A, activations as B): the accumulator of lane l then
+// holds out[row l & 15][channels 16 n2 + 4 (l >> 4) + 0..3] -- four CONSECUTIVE channels of one row instead of four rows of one
+// channel, so an epilogue parks a lane's values with one 16-byte LDS access where it took four 4-byte ones.  Every element is the
+// same sum of the same products in the same order (the k mapping of both operands is unchanged): bitwise the values of
+// mma_tile_frag.  16-row tiles.
+__device__ __forceinline__ void mma_tile_frag_t(const float* __restrict__ As, const WFrag& f, f32x4 (&acc)[2]) {
+    const int lane = threadIdx.x & 63;
+    const float* ap = As + (lane & 15) * LDT + 4 * (lane >> 4);
+    float4 apre[DIM / 16];
+#pragma unroll
+    for (int q = 0; q < DIM / 16; ++q) apre[q] = *reinterpret_cast<const float4*>(ap + 16 * q);
+#pragma unroll
+    for (int q = 0; q < DIM / 16; ++q) {
+        const float4 a = apre[q], b0 = f.b[q][0], b1 = f.b[q][1];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0.x, a.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1.x, a.x, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0.y, a.y, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1.y, a.y, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0.z, a.z, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1.z, a.z, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0.w, a.w, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1.w, a.w, acc[1], 0, 0, 0);
+    }
+}
+// the eight bias values of such a lane: channels dcol0 + 16 n2 + 4 (l >> 4) + 0..3
+struct Bias8 {
+    float4 v[2];
+};
+__device__ __forceinline__ Bias8 load_bias8(const float* __restrict__ bias, int dcol0) {
+    Bias8 b;
+    const int kg = (threadIdx.x & 63) >> 4;
+    b.v[0] = bias ? *reinterpret_cast<const float4*>(bias + dcol0 + 4 * kg) : make_float4(0.f, 0.f, 0.f, 0.f);
+    b.v[1] = bias ? *reinterpret_cast<const float4*>(bias + dcol0 + 16 + 4 * kg) : make_float4(0.f, 0.f, 0.f, 0.f);
+    return b;
+}
+
 // The two bias values a lane needs (columns dcol0 + r16 and + 16).  Fetch them BEFORE issuing a weight prefetch: vmcnt
 // retires in order, so a bias load issued after the prefetch would make its s_waitcnt drain the whole prefetch.
 struct Bias2 {

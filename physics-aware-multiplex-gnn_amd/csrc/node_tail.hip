@@ -347,27 +347,29 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
     auto layer = [&](const float* in, float* dst, int k, const float* add1, const float* add2, float* tap,
                      const float* Wnext) {
         TPROBE(4 * k);
-        const Bias2 bv = load_bias2(p.b[k], wc);               // before the prefetch (in-order vmcnt)
-        f32x4 acc[1][2];
-        acc_zero<1>(acc);
-        mma_tile_frag<1>(in, wf, acc);
+        const Bias8 bv = load_bias8(p.b[k], wc);               // before the prefetch (in-order vmcnt)
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        mma_tile_frag_t(in, wf, acc);                          // lane: row r16, channels wc + 16 n2 + 4 kg + 0..3
         TPROBE(4 * k + 1);
         if (Wnext) load_w<PACKED>(wf, Wnext, DIM, wc);
         float* zk = ZL + k * SLOT;
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) {
-            const int c = wc + 16 * n2 + r16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rw = 4 * kg + r;
-                const float z = acc[0][n2][r] + bv.v[n2];
-                float a = silu(z);
-                if (add1) a += add1[rw * LDT + c];
-                if (add2) a += add2[rw * LDT + c];
-                dst[rw * LDT + c] = a;
-                zk[rw * LDT + c] = z;
-                if (tap) tap[rw * LDT + c] = a;
+            const int o = r16 * LDT + wc + 16 * n2 + 4 * kg;   // (16-byte aligned: LDT * 4 = 33 x 16 bytes)
+            const float4 z = make_float4(acc[n2][0] + bv.v[n2].x, acc[n2][1] + bv.v[n2].y, acc[n2][2] + bv.v[n2].z,
+                                         acc[n2][3] + bv.v[n2].w);
+            float4 a = make_float4(silu(z.x), silu(z.y), silu(z.z), silu(z.w));
+            if (add1) {
+                const float4 t = *reinterpret_cast<const float4*>(add1 + o);
+                a.x += t.x, a.y += t.y, a.z += t.z, a.w += t.w;
             }
+            if (add2) {
+                const float4 t = *reinterpret_cast<const float4*>(add2 + o);
+                a.x += t.x, a.y += t.y, a.z += t.z, a.w += t.w;
+            }
+            *reinterpret_cast<float4*>(dst + o) = a;
+            *reinterpret_cast<float4*>(zk + o) = z;
+            if (tap) *reinterpret_cast<float4*>(tap + o) = a;
         }
         TPROBE(4 * k + 2);
         __syncthreads();
@@ -430,36 +432,29 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
         __syncthreads();
         const float* xin = TL + 2 * SLOT;
         {
-            const Bias2 bv = load_bias2(nx.bx1, wc);
-            f32x4 acc[1][2];
-            acc_zero<1>(acc);
-            mma_tile_frag<1>(xin, wf, acc);
+            const Bias8 bv = load_bias8(nx.bx1, wc);
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            mma_tile_frag_t(xin, wf, acc);
             load_w<PACKED>(wf, nx.wp[0], nx.ldwp, wc);
 #pragma unroll
             for (int n2 = 0; n2 < 2; ++n2) {
-                const int c = wc + 16 * n2 + r16;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rw = 4 * kg + r;
-                    const float z = acc[0][n2][r] + bv.v[n2];
-                    ZL[rw * LDT + c] = z;                       // Zx1
-                    ZL[SLOT + rw * LDT + c] = silu(z);          // x1
-                }
+                const int o = r16 * LDT + wc + 16 * n2 + 4 * kg;
+                const float4 z = make_float4(acc[n2][0] + bv.v[n2].x, acc[n2][1] + bv.v[n2].y, acc[n2][2] + bv.v[n2].z,
+                                             acc[n2][3] + bv.v[n2].w);
+                *reinterpret_cast<float4*>(ZL + o) = z;                                                       // Zx1
+                *reinterpret_cast<float4*>(ZL + SLOT + o) = make_float4(silu(z.x), silu(z.y), silu(z.z), silu(z.w));   // x1
             }
             __syncthreads();
         }
         for (int b = 0; b < nx.nblk; ++b) {
-            f32x4 acc[1][2];
-            acc_zero<1>(acc);
-            mma_tile_frag<1>(ZL + SLOT, wf, acc);
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            mma_tile_frag_t(ZL + SLOT, wf, acc);
             if (b + 1 < nx.nblk) load_w<PACKED>(wf, nx.wp[b + 1], nx.ldwp, wc);
             float* pb = ZL + (2 + b) * SLOT;
 #pragma unroll
-            for (int n2 = 0; n2 < 2; ++n2) {
-                const int c = wc + 16 * n2 + r16;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pb[(4 * kg + r) * LDT + c] = acc[0][n2][r];
-            }
+            for (int n2 = 0; n2 < 2; ++n2)
+                *reinterpret_cast<float4*>(pb + r16 * LDT + wc + 16 * n2 + 4 * kg) =
+                    make_float4(acc[n2][0], acc[n2][1], acc[n2][2], acc[n2][3]);
         }
         __syncthreads();
         TPROBE(42);
