@@ -145,6 +145,30 @@ __device__ __forceinline__ f32x4 mma_strip(const float* __restrict__ As, const W
     return c0 + c1;
 }
 
+// mma_strip with the MFMA operands swapped (gemm_core.h mma_tile_frag_t): lane l holds out[row l & 15][channels wc + 4 (l >> 4) +
+// 0..3] -- a float4 of one row -- and every epilogue access to an LDS tile is 16 bytes; same sums of the same products in the same
+// order (two interleaved chains, added at the end), bitwise mma_strip's values.
+__device__ __forceinline__ f32x4 mma_strip_t(const float* __restrict__ As, const WFrag1& f) {
+    const int lane = threadIdx.x & 63;
+    const float* ap = As + (lane & 15) * LDT + 4 * (lane >> 4);
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < DIM / 16; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(ap + 16 * q);
+        const float4 b = f.b[q];
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, a.x, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, a.y, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, a.z, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, a.w, c1, 0, 0, 0);
+    }
+    return c0 + c1;
+}
+__device__ __forceinline__ f32x4 lds_f32x4(const float* p) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    return f32x4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void st_f32x4(float* p, const f32x4& v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+
 // Forward: 4 waves x 32 columns (float4 weight loads are cheap per byte, so fewer, wider waves win; an 8-wave x 16-column
 // version measured 35 us against 31 us: two waves per SIMD only take turns on the matrix pipe and then idle at the
 // barrier -- tools/tail_probe.py).
@@ -1019,6 +1043,8 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
     const int64_t plane = n * DIM;
     const Frag fr;
     const int c = fr.col();
+    const int to = fr.r16 * LDT + fr.wc + 4 * fr.kg;          // (transposed accumulators: row r16, channels wc + 4 kg + 0..3)
+    const bool trow = row0 + fr.r16 < n;                      // ... and whether that row exists
 
     constexpr int KTOP = HEADS ? 9 : 6;                       // first matrix of the backward chain
     constexpr int NZ = HEADS ? 10 : 7;
@@ -1065,11 +1091,10 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
         float* const pl[4] = {ZL + 7 * SLOT, ZL + 8 * SLOT, ZL + 9 * SLOT, red};
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int b = 0; b < pb.nblk; ++b) {
-            acc += mma_strip(pl[b], wf);
+            acc += mma_strip_t(pl[b], wf);
             load_wfrag1_img(wf, b + 1 < pb.nblk ? pb.wp[b + 1] : pb.Wx1);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) D0[fr.row(r) * LDT + c] = acc[r];
+        st_f32x4(D0 + to, acc);
         __syncthreads();
         {   // dz_x1 = (d x1) * SiLU'(z_x1): over D1 in place, and parked in `red` for the final coalesced store
             const float4 d1 = f4add(lds4(D0, sr, sc4), lds4(D1, sr, sc4));
@@ -1078,10 +1103,9 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
             st_lds4(red, sr, sc4, dzx);
         }
         __syncthreads();
-        const f32x4 a2 = mma_strip(D1, wf);
+        const f32x4 a2 = mma_strip_t(D1, wf);
         load_wfrag1_img(wf, p.W[KTOP]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) K[fr.row(r) * LDT + c] += a2[r];     // d x_out = head's d x + d_add + g_head
+        st_f32x4(K + to, lds_f32x4(K + to) + a2);              // d x_out = head's d x + d_add + g_head
         __syncthreads();
     }
 
@@ -1138,15 +1162,12 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
     }
     } else {
         // dz6 = d r3 * SiLU'(z6), d r3 = d x_out (next layer + head branch) already in K
-        const f32x4 z6 = load_z(6);
+        const f32x4 z6 = lds_f32x4(ZL + 6 * SLOT + to), kv = lds_f32x4(K + to);
+        f32x4 dz;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rw = fr.row(r);
-            const int64_t g = row0 + rw;
-            const float dz = (g < n) ? K[rw * LDT + c] * dsilu(z6[r]) : 0.f;
-            D1[rw * LDT + c] = dz;
-            ZL[6 * SLOT + rw * LDT + c] = dz;
-        }
+        for (int r = 0; r < 4; ++r) dz[r] = trow ? kv[r] * dsilu(z6[r]) : 0.f;
+        st_f32x4(D1 + to, dz);
+        st_f32x4(ZL + 6 * SLOT + to, dz);
         __syncthreads();
     }
 
@@ -1154,27 +1175,23 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
     // k == 0 ends the chain: v = d x2 (left in dst).
     auto back = [&](const float* in, float* dst, int k, bool add_k, bool keep_k, float* extra) {
         f32x4 zn = {0.f, 0.f, 0.f, 0.f};
-        if (k > 0) zn = load_z(k - 1);
-        const f32x4 acc = mma_strip(in, wf);
+        if (k > 0) zn = lds_f32x4(ZL + (k - 1) * SLOT + to);
+        f32x4 v = mma_strip_t(in, wf);
         if (k > 0) {
             if constexpr (PACKED) load_wfrag1_img(wf, p.W[k - 1]);
             else load_wfrag1<true>(wf, p.W[k - 1], fr.wc);
         }
+        if (add_k) v += lds_f32x4(K + to);
+        if (keep_k) st_f32x4(K + to, v);
+        if (extra) st_f32x4(extra + to, v);
+        if (k == 0) {
+            st_f32x4(dst + to, v);
+        } else {
+            f32x4 dz;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rw = fr.row(r);
-            const int64_t g = row0 + rw;
-            float v = acc[r];
-            if (add_k) v += K[rw * LDT + c];
-            if (keep_k) K[rw * LDT + c] = v;
-            if (extra) extra[rw * LDT + c] = v;
-            if (k == 0) {
-                dst[rw * LDT + c] = v;
-            } else {
-                const float dz = (g < n) ? v * dsilu(zn[r]) : 0.f;
-                dst[rw * LDT + c] = dz;
-                ZL[(k - 1) * SLOT + rw * LDT + c] = dz;
-            }
+            for (int r = 0; r < 4; ++r) dz[r] = trow ? v[r] * dsilu(zn[r]) : 0.f;
+            st_f32x4(dst + to, dz);
+            st_f32x4(ZL + (k - 1) * SLOT + to, dz);
         }
         __syncthreads();
     };
