@@ -871,25 +871,27 @@ __global__ __launch_bounds__(WG) void node_heads_fwd_kernel(HeadBatch hb, int64_
     load_w<PACKED>(wf, hl.W[0], DIM, wc);
     sweep_rows<BM>([&](int r, int c4) { st_lds4(X, r, c4, ldg4z(hl.x_out, row0 + r, n, DIM, c4)); });
     __syncthreads();
+    // (operands swapped, gemm_core.h mma_tile_frag_t: a lane holds four consecutive channels of one row -- the pre-activations
+    // leave as 16-byte stores, four times fewer than channel by channel; same bits)
     auto layer = [&](const float* in, float* dst, int k, const float* Wnext) {
-        const Bias2 bv = load_bias2(hl.b[k], wc);
+        const Bias8 bv = load_bias8(hl.b[k], wc);
         f32x4 acc[HM][2];
-        acc_zero<HM>(acc);
-        mma_tile_frag<HM>(in, wf, acc);
+#pragma unroll
+        for (int m = 0; m < HM; ++m) {
+            acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma_tile_frag_t(in + m * 16 * LDT, wf, acc[m]);
+        }
         if (Wnext) load_w<PACKED>(wf, Wnext, DIM, wc);
         float* zg = hl.Z ? hl.Z + (int64_t)(7 + k) * plane : nullptr;
 #pragma unroll
         for (int m = 0; m < HM; ++m)
 #pragma unroll
             for (int n2 = 0; n2 < 2; ++n2) {
-                const int c = wc + 16 * n2 + r16;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rw = 16 * m + 4 * kg + r;
-                    const float z = acc[m][n2][r] + bv.v[n2];
-                    dst[rw * LDT + c] = silu(z);
-                    if (zg && row0 + rw < n) zg[(row0 + rw) * DIM + c] = z;
-                }
+                const int rw = 16 * m + r16, c0 = wc + 16 * n2 + 4 * kg;
+                const float4 z = make_float4(acc[m][n2][0] + bv.v[n2].x, acc[m][n2][1] + bv.v[n2].y, acc[m][n2][2] + bv.v[n2].z,
+                                             acc[m][n2][3] + bv.v[n2].w);
+                *reinterpret_cast<float4*>(dst + rw * LDT + c0) = make_float4(silu(z.x), silu(z.y), silu(z.z), silu(z.w));
+                if (zg && row0 + rw < n) *reinterpret_cast<float4*>(zg + (row0 + rw) * DIM + c0) = z;
             }
         __syncthreads();
     };
@@ -1424,25 +1426,24 @@ __global__ __launch_bounds__(TWG) void node_heads_bwd_kernel(HeadBwdBatch hb, in
         __syncthreads();
     }
     // v = dz_k * W_k; k > 7: dz_{k-1} = v * SiLU'(z_{k-1}); k == 7: v = the branch's d x_out
+    const int to = fr.r16 * LDT + fr.wc + 4 * fr.kg;          // (operands swapped: row r16, channels wc + 4 kg + 0..3; mma_strip_t)
+    const bool trow = row0 + fr.r16 < n;
     auto back = [&](const float* in, float* dst, int k) {
         f32x4 zn = {0.f, 0.f, 0.f, 0.f};
-        if (k > 7) zn = load_z(k - 8);
-        const f32x4 acc = mma_strip(in, wf);
+        if (k > 7) zn = lds_f32x4(ZL + (k - 8) * SLOT + to);
+        const f32x4 acc = mma_strip_t(in, wf);
         if (k > 7) {
             if constexpr (PACKED) load_wfrag1_img(wf, hl.W[k - 8]);
             else load_wfrag1<true>(wf, hl.W[k - 8], fr.wc);
         }
+        if (k == 7) {
+            st_f32x4(dst + to, acc);
+        } else {
+            f32x4 dz;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rw = fr.row(r);
-            const int64_t g = row0 + rw;
-            if (k == 7) {
-                dst[rw * LDT + c] = acc[r];
-            } else {
-                const float dz = (g < n) ? acc[r] * dsilu(zn[r]) : 0.f;
-                dst[rw * LDT + c] = dz;
-                ZL[(k - 8) * SLOT + rw * LDT + c] = dz;
-            }
+            for (int r = 0; r < 4; ++r) dz[r] = trow ? acc[r] * dsilu(zn[r]) : 0.f;
+            st_f32x4(dst + to, dz);
+            st_f32x4(ZL + (k - 8) * SLOT + to, dz);
         }
         __syncthreads();
     };
