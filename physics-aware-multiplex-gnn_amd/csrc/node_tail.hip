@@ -527,29 +527,33 @@ __global__ __launch_bounds__(WG, 3) void node_tail_fwd_lean_kernel(const float* 
     __syncthreads();
 
     // layer k: in -> dst = SiLU(W_k in + b_k) (+ add1 + add2); z_k and the optional tap go to memory from the accumulators
+    // (operands swapped, gemm_core.h mma_tile_frag_t: a lane holds four consecutive channels of a row -- 16-byte stores)
+    const bool trow = row0 + r16 < n;
     auto layer = [&](const float* in, float* dst, int k, const float* add1, const float* add2, float* tap,
                      const float* Wnext) {
-        const Bias2 bv = load_bias2(p.b[k], wc);
-        f32x4 acc[1][2];
-        acc_zero<1>(acc);
-        mma_tile_frag<1>(in, wf, acc);
+        const Bias8 bv = load_bias8(p.b[k], wc);
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        mma_tile_frag_t(in, wf, acc);
         if (Wnext) load_w<true>(wf, Wnext, DIM, wc);
         float* zg = Z ? Z + (int64_t)k * plane : nullptr;
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) {
-            const int c = wc + 16 * n2 + r16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rw = 4 * kg + r;
-                const float z = acc[0][n2][r] + bv.v[n2];
-                float a = silu(z);
-                if (add1) a += add1[rw * LDT + c];
-                if (add2) a += add2[rw * LDT + c];
-                dst[rw * LDT + c] = a;
-                if (row0 + rw < n) {
-                    if (zg) zg[(row0 + rw) * DIM + c] = z;
-                    if (tap) tap[(row0 + rw) * DIM + c] = a;
-                }
+            const int c0 = wc + 16 * n2 + 4 * kg, o = r16 * LDT + c0;
+            const float4 z = make_float4(acc[n2][0] + bv.v[n2].x, acc[n2][1] + bv.v[n2].y, acc[n2][2] + bv.v[n2].z,
+                                         acc[n2][3] + bv.v[n2].w);
+            float4 a = make_float4(silu(z.x), silu(z.y), silu(z.z), silu(z.w));
+            if (add1) {
+                const float4 t = *reinterpret_cast<const float4*>(add1 + o);
+                a.x += t.x, a.y += t.y, a.z += t.z, a.w += t.w;
+            }
+            if (add2) {
+                const float4 t = *reinterpret_cast<const float4*>(add2 + o);
+                a.x += t.x, a.y += t.y, a.z += t.z, a.w += t.w;
+            }
+            *reinterpret_cast<float4*>(dst + o) = a;
+            if (trow) {
+                if (zg) *reinterpret_cast<float4*>(zg + (row0 + r16) * DIM + c0) = z;
+                if (tap) *reinterpret_cast<float4*>(tap + (row0 + r16) * DIM + c0) = a;
             }
         }
         __syncthreads();
@@ -567,43 +571,34 @@ __global__ __launch_bounds__(WG, 3) void node_tail_fwd_lean_kernel(const float* 
     // the next layer's head on the x_out tile (C): x1 -> A (and memory), the projections straight to memory
     if (nx.nblk > 0) {
         {
-            const Bias2 bv = load_bias2(nx.bx1, wc);
-            f32x4 acc[1][2];
-            acc_zero<1>(acc);
-            mma_tile_frag<1>(C, wf, acc);
+            const Bias8 bv = load_bias8(nx.bx1, wc);
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            mma_tile_frag_t(C, wf, acc);
             load_w<true>(wf, nx.wp[0], nx.ldwp, wc);
 #pragma unroll
             for (int n2 = 0; n2 < 2; ++n2) {
-                const int c = wc + 16 * n2 + r16;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rw = 4 * kg + r;
-                    const float z = acc[0][n2][r] + bv.v[n2];
-                    const float a = silu(z);
-                    A[rw * LDT + c] = a;
-                    if (row0 + rw < n) {
-                        if (nx.Zx1) nx.Zx1[(row0 + rw) * DIM + c] = z;
-                        nx.x1[(row0 + rw) * DIM + c] = a;
-                    }
+                const int c0 = wc + 16 * n2 + 4 * kg;
+                const float4 z = make_float4(acc[n2][0] + bv.v[n2].x, acc[n2][1] + bv.v[n2].y, acc[n2][2] + bv.v[n2].z,
+                                             acc[n2][3] + bv.v[n2].w);
+                const float4 a = make_float4(silu(z.x), silu(z.y), silu(z.z), silu(z.w));
+                *reinterpret_cast<float4*>(A + r16 * LDT + c0) = a;
+                if (trow) {
+                    if (nx.Zx1) *reinterpret_cast<float4*>(nx.Zx1 + (row0 + r16) * DIM + c0) = z;
+                    *reinterpret_cast<float4*>(nx.x1 + (row0 + r16) * DIM + c0) = a;
                 }
             }
             __syncthreads();
         }
         for (int b = 0; b < nx.nblk; ++b) {
-            f32x4 acc[1][2];
-            acc_zero<1>(acc);
-            mma_tile_frag<1>(A, wf, acc);
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            mma_tile_frag_t(A, wf, acc);
             if (b + 1 < nx.nblk) load_w<true>(wf, nx.wp[b + 1], nx.ldwp, wc);
             float* pb = nx.P + (int64_t)b * plane;
 #pragma unroll
-            for (int n2 = 0; n2 < 2; ++n2) {
-                const int c = wc + 16 * n2 + r16;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rw = 4 * kg + r;
-                    if (row0 + rw < n) pb[(row0 + rw) * DIM + c] = acc[0][n2][r];
-                }
-            }
+            for (int n2 = 0; n2 < 2; ++n2)
+                if (trow)
+                    *reinterpret_cast<float4*>(pb + (row0 + r16) * DIM + wc + 16 * n2 + 4 * kg) =
+                        make_float4(acc[n2][0], acc[n2][1], acc[n2][2], acc[n2][3]);
         }
     }
 }
@@ -1240,93 +1235,79 @@ __global__ __launch_bounds__(TWG, 2) void node_tail_bwd_lean_kernel(const float*
     const int64_t row0 = (int64_t)blockIdx.x * BMN;
     const int64_t plane = n * DIM;
     const Frag fr;
-    const int c = fr.col();
-    bool ok[4];
-    int64_t off[4];                                            // element offset of (row, column) in an [n][128] plane
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t g = row0 + fr.row(r);
-        ok[r] = g < n;
-        off[r] = (ok[r] ? g : 0) * DIM + c;
-    }
+    // (operands swapped, mma_strip_t: a lane holds row r16, channels wc + 4 kg + 0..3 -- every access to a plane or an LDS tile is
+    // ONE 16-byte request where the channel-per-lane form made four 4-byte ones; same sums, same bits)
+    const int to = fr.r16 * LDT + fr.wc + 4 * fr.kg;
+    const bool ok = row0 + fr.r16 < n;
+    const int64_t off = (ok ? row0 + fr.r16 : 0) * DIM + fr.wc + 4 * fr.kg;   // element offset of the lane's float4 in a plane
+    auto ldp = [&](const float* base) __attribute__((always_inline)) { return lds_f32x4(base + off); };   // (a global float4)
+    auto stp = [&](float* base, const f32x4& v) __attribute__((always_inline)) { st_f32x4(base + off, v); };
     WFrag1 wf;
     load_wfrag1_img(wf, PRE ? pb.wp[0] : p.W[6]);
     // z_k of a lane's four elements.  Requested TWO layers ahead (a layer is ~1 500 cycles, an HBM round trip ~2 000 under
     // load); the first three right here, so that they travel during the head's GEMMs / the first layer.
-    auto ldz = [&](int k) {
-        f32x4 z;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) z[r] = Z[(int64_t)k * plane + off[r]];
-        return z;
-    };
+    auto ldz = [&](int k) __attribute__((always_inline)) { return ldp(Z + (int64_t)k * plane); };
     const f32x4 z6 = ldz(6), z5 = ldz(5), z4 = ldz(4);
     // d x_out = (next layer's d x) + the head branch's contribution (+ the head backward's d_add and d x below)
     f32x4 kreg;
+    {
+        f32x4 k = d_xout ? ldp(d_xout) : f32x4{0.f, 0.f, 0.f, 0.f};
+        k += ldp(d_out);
+        if constexpr (PRE) k += ldp(pb.d_add);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float k = d_xout ? d_xout[off[r]] : 0.f;
-        k += d_out[off[r]];
-        if constexpr (PRE) k += pb.d_add[off[r]];
-        kreg[r] = ok[r] ? k : 0.f;
+        for (int r = 0; r < 4; ++r) kreg[r] = ok ? k[r] : 0.f;
     }
     if constexpr (PRE) {
         float* PL = lds + 2 * SLOT;
-        f32x4 zx, dxd;
+        const f32x4 zx = ldp(pb.Zx1);
+        f32x4 dxd = ldp(pb.dx1_direct);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            zx[r] = pb.Zx1[off[r]];
-            dxd[r] = ok[r] ? pb.dx1_direct[off[r]] : 0.f;
-        }
+        for (int r = 0; r < 4; ++r) dxd[r] = ok ? dxd[r] : 0.f;
         const int sc4 = threadIdx.x & 31, sr = threadIdx.x >> 5;
         for (int b = 0; b < pb.nblk; ++b)
             st_lds4(PL + b * SLOT, sr, sc4, ldg4z(pb.dP + (int64_t)b * plane, row0 + sr, n, DIM, sc4));
         __syncthreads();
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int b = 0; b < pb.nblk; ++b) {
-            acc += mma_strip(PL + b * SLOT, wf);
+            acc += mma_strip_t(PL + b * SLOT, wf);
             load_wfrag1_img(wf, b + 1 < pb.nblk ? pb.wp[b + 1] : pb.Wx1);
         }
+        f32x4 dzx;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {                          // dz_x1 = (d x1) * SiLU'(z_x1)
-            const float dzx = ok[r] ? (acc[r] + dxd[r]) * dsilu(zx[r]) : 0.f;
-            D1[fr.row(r) * LDT + c] = dzx;
-            if (ok[r]) pb.dZx1[off[r]] = dzx;
-        }
+        for (int r = 0; r < 4; ++r) dzx[r] = ok ? (acc[r] + dxd[r]) * dsilu(zx[r]) : 0.f;     // dz_x1 = (d x1) * SiLU'(z_x1)
+        st_f32x4(D1 + to, dzx);
+        if (ok) stp(pb.dZx1, dzx);
         __syncthreads();
-        const f32x4 a2 = mma_strip(D1, wf);
+        const f32x4 a2 = mma_strip_t(D1, wf);
         load_wfrag1_img(wf, p.W[6]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) kreg[r] += a2[r];          // d x_out = d_add + g_head + the head's d x
+        kreg += a2;                                            // d x_out = d_add + g_head + the head's d x
         __syncthreads();                                       // (every wave is done reading D1)
     }
     {   // dz6 = d r3 * SiLU'(z6)
+        f32x4 dz;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float dz = ok[r] ? kreg[r] * dsilu(z6[r]) : 0.f;
-            D1[fr.row(r) * LDT + c] = dz;
-            if (ok[r]) dZ[6 * plane + off[r]] = dz;
-        }
+        for (int r = 0; r < 4; ++r) dz[r] = ok ? kreg[r] * dsilu(z6[r]) : 0.f;
+        st_f32x4(D1 + to, dz);
+        if (ok) stp(dZ + 6 * plane, dz);
         __syncthreads();
     }
     // One backward step: v = dz_k * W_k (+ kept); optionally kept <- v, d res_x <- v; then dz_{k-1} = v * SiLU'(z_{k-1}).
     // zn = z_{k-1} (requested two steps ago); *pre <- z_{k-3}, requested now
     auto back = [&](const float* in, float* dst, int k, bool add_k, bool keep_k, bool extra, const f32x4& zn, f32x4* pre) {
         if (pre) *pre = ldz(k - 3);
-        const f32x4 acc = mma_strip(in, wf);
+        f32x4 v = mma_strip_t(in, wf);
         if (k > 0) load_wfrag1_img(wf, p.W[k - 1]);
+        if (add_k) v += kreg;
+        if (keep_k) kreg = v;
+        if (extra && ok) stp(d_resx, v);
+        if (k == 0) {
+            if (ok) stp(d_x2, v);
+        } else {
+            f32x4 dz;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = acc[r];
-            if (add_k) v += kreg[r];
-            if (keep_k) kreg[r] = v;
-            if (extra && ok[r]) d_resx[off[r]] = v;
-            if (k == 0) {
-                if (ok[r]) d_x2[off[r]] = v;
-            } else {
-                const float dz = ok[r] ? v * dsilu(zn[r]) : 0.f;
-                dst[fr.row(r) * LDT + c] = dz;
-                if (ok[r]) dZ[(int64_t)(k - 1) * plane + off[r]] = dz;
-            }
+            for (int r = 0; r < 4; ++r) dz[r] = ok ? v[r] * dsilu(zn[r]) : 0.f;
+            st_f32x4(dst + to, dz);
+            if (ok) stp(dZ + (int64_t)(k - 1) * plane, dz);
         }
         if (k > 0) __syncthreads();
     };
