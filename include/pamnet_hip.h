@@ -630,7 +630,8 @@ int pamnet_mlp2_bwd_f32(const float* dy, int64_t rows, const float* z1, const fl
  * launch, the CUs split between the two plans by their work (layers/local_message_passing.py:46-53 backward).  Arguments
  * and results are those of the two calls.  Round 6 (ABI 14): accumulate_dx | PAMNET_WEIGHT_IMAGES: W1, W2 are transposed kind-1
  * images of pamnet_pack_weights_mixed_f32; ldq[0..3] all 0 (here and in pamnet_local_edge_bwd_f32): Wq[0..3] are transposed
- * kind-0 (fp32 fragment) images.  Same bits as with the matrices. */
+ * kind-1 images too (the four dX GEMMs of the local edge stage run on the bf16 matrix pipe at fp32 accuracy, like the MLP's).
+ * Same bits as with the matrices. */
 int pamnet_local_bwd_pair_f32(const float* dy, int64_t rows, const float* z1, const float* z2, const float* W1,
                               const float* W2, float* dz1, float* dz2, float* dx, int32_t accumulate_dx,
                               const float* d_mji, const float* d_mnb, const float* d_q3, int64_t n_edges,

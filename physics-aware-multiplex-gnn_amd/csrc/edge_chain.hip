@@ -321,8 +321,16 @@ struct LocalBwdArgs {
     int accumulate, base, rem, cmt;
 };
 
-// workgroup `bid` of the plan (base, rem, cmt); lds: 2 * MTX * 16 * LDT floats
-template <int MTX>
+// workgroup `bid` of the plan (base, rem, cmt); lds: LOCAL_BWD_LDS_B(MTX) bytes
+// Round 6: the four dX GEMMs on the bf16 matrix pipe at fp32 accuracy ("bf16x6", edge_core.h) like every other edge-level GEMM --
+// on fp32 MFMAs they were 384 matrix instructions of 32 cycles per wave and chunk (the pole of the backward pair at the QM9 batch:
+// 10 us of matrix pipe for three tiles), now 288 of 16.  Two passes of two operands: each operand tile is split ONCE into piece
+// planes by the sweep that computes it, the two weight slices of a pass are resident as bf16x3 pieces (a row stride of 0: kind-1
+// fragment images), the second pass's slices are requested behind the first pass's products.
+// IMG: the slices arrive as images (compile-time: the loads sit inside the chunk loop, and with both arms of the loader there
+// the compiler parks the fragments in scratch).  IMG = false, fp32 matrices, splits the same pieces: bitwise the same results.
+constexpr int LOCAL_BWD_LDS_B(int mtx) { return mtx * (2 * PTILE + 16 * LDT * 4); }
+template <int MTX, bool IMG>
 __device__ __forceinline__ void local_edge_bwd_body(const LocalBwdArgs& a, const int bid, float* lds) {
     const float* __restrict__ d_mji = a.d_mji;
     const float* __restrict__ d_mnb = a.d_mnb;
@@ -336,53 +344,53 @@ __device__ __forceinline__ void local_edge_bwd_body(const LocalBwdArgs& a, const
     float* __restrict__ d_rbf = a.d_rbf;
     const int accumulate = a.accumulate;
     const LocalW& w = a.w;
-    float* S0 = lds;
-    float* S1 = lds + MTX * 16 * LDT;
+    char* P0 = reinterpret_cast<char*>(lds);                   // piece planes of the pass's two operands
+    char* P1 = P0 + MTX * PTILE;
+    float* S0 = reinterpret_cast<float*>(P1 + MTX * PTILE);    // the accumulators' fp32 tile
     const int wc = wave_col<8>();
-    WFrag1 f0, f1, f2, f3;
-    load_wfrag1<true>(f0, w.W[0], w.ld[0], wc);
-    load_wfrag1<true>(f1, w.W[1], w.ld[1], wc);
-    load_wfrag1<true>(f2, w.W[2], w.ld[2], wc);
-    load_wfrag1<true>(f3, w.W[3], w.ld[3], wc);
+    WFragB1 fa, fb;
     const Span sp = Span::make_at<8>(a.m, a.base, a.rem, 0, a.cmt, bid);
     CHUNK_LOOP(sp) {
         const int mt = chunk_mt(sp, row0);
         Acc<MTX> acc;
         acc.zero();
-        // pass A: dz_ji -> S0, dz_kj -> S1
+        load_wfragb1<true, IMG ? 1 : 0>(fa, w.W[0], w.ld[0], wc);           // (per chunk: one or two chunks per workgroup)
+        load_wfragb1<true, IMG ? 1 : 0>(fb, w.W[1], w.ld[1], wc);
+        // pass A: dz_ji -> P0, dz_kj -> P1
         sweep<MTX, 8>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
-            float4 a = f4zero(), b = f4zero();
+            float4 x = f4zero(), y = f4zero();
             if (g < sp.end) {
-                a = f4mul(ldg4(d_mji, g, DIM, c4), f4dsilu(ldg4(z_ji, g, DIM, c4)));
-                b = f4mul(f4mul(ldg4(d_mnb, g, DIM, c4), ldg4(q2, g, DIM, c4)), f4dsilu(ldg4(z_kj, g, DIM, c4)));
-                stg4(dz_ji, g, DIM, c4, a);
-                stg4(dz_kj, g, DIM, c4, b);
+                x = f4mul(ldg4(d_mji, g, DIM, c4), f4dsilu(ldg4(z_ji, g, DIM, c4)));
+                y = f4mul(f4mul(ldg4(d_mnb, g, DIM, c4), ldg4(q2, g, DIM, c4)), f4dsilu(ldg4(z_kj, g, DIM, c4)));
+                stg4(dz_ji, g, DIM, c4, x);
+                stg4(dz_kj, g, DIM, c4, y);
             }
-            st_lds4(S0, r, c4, a);
-            st_lds4(S1, r, c4, b);
+            st_pieces4(P0, r, c4, x);
+            st_pieces4(P1, r, c4, y);
         });
         __syncthreads();
-        mma_n<MTX>(S0, f0, acc, mt);
-        mma_n<MTX>(S1, f1, acc, mt);
+        mma_p16<MTX, true, 3>(P0, fa, acc, fa, acc, mt);
+        mma_p16<MTX, true, 3>(P1, fb, acc, fb, acc, mt);
+        load_wfragb1<true, IMG ? 1 : 0>(fa, w.W[2], w.ld[2], wc);
+        load_wfragb1<true, IMG ? 1 : 0>(fb, w.W[3], w.ld[3], wc);
         __syncthreads();
-        // pass B: dq2 -> S0, dq3 -> S1
+        // pass B: dq2 -> P0, dq3 -> P1
         sweep<MTX, 8>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
-            float4 a = f4zero(), b = f4zero();
+            float4 x = f4zero(), y = f4zero();
             if (g < sp.end) {
-                a = f4mul(ldg4(d_mnb, g, DIM, c4), f4silu(ldg4(z_kj, g, DIM, c4)));
-                b = ldg4(d_q3, g, DIM, c4);
-                stg4(dq2, g, DIM, c4, a);
+                x = f4mul(ldg4(d_mnb, g, DIM, c4), f4silu(ldg4(z_kj, g, DIM, c4)));
+                y = ldg4(d_q3, g, DIM, c4);
+                stg4(dq2, g, DIM, c4, x);
             }
-            st_lds4(S0, r, c4, a);
-            st_lds4(S1, r, c4, b);
+            st_pieces4(P0, r, c4, x);
+            st_pieces4(P1, r, c4, y);
         });
         __syncthreads();
-        mma_n<MTX>(S0, f2, acc, mt);
-        mma_n<MTX>(S1, f3, acc, mt);
-        __syncthreads();
-        acc_store<MTX>(acc, S0, wc, 0.f, mt);
+        mma_p16<MTX, true, 3>(P0, fa, acc, fa, acc, mt);
+        mma_p16<MTX, true, 3>(P1, fb, acc, fb, acc, mt);
+        acc_store<MTX>(acc, S0, wc, 0.f, mt);                  // (S0 is the accumulators' alone: no barrier ahead of it)
         __syncthreads();
         sweep<MTX, 8>(mt, [&](int r, int c4) {
             const int64_t g = row0 + r;
@@ -395,10 +403,10 @@ __device__ __forceinline__ void local_edge_bwd_body(const LocalBwdArgs& a, const
     }
 }
 
-template <int MTX>
+template <int MTX, bool IMG>
 __global__ __launch_bounds__(WG8) void local_edge_bwd_kernel(LocalBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * MTX * 16 * LDT];
-    local_edge_bwd_body<MTX>(a, (int)blockIdx.x, lds);
+    __shared__ __attribute__((aligned(16))) float lds[LOCAL_BWD_LDS_B(MTX) / 4];
+    local_edge_bwd_body<MTX, IMG>(a, (int)blockIdx.x, lds);
 }
 
 // -------------------------------------------------------------------------------------------------- 2-layer MLP
@@ -538,13 +546,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlp2_bwd_kernel(cons
 // rest the edge plan, the CUs split between them by their work.  Each alone is one round of <= 256 workgroups whose fixed
 // cost (launch boundary + prologue: weights, work split, first rows) is ~9 us of its 20-24 us at the QM9 batch; side by
 // side that cost is paid once.  Same bodies, same per-row arithmetic: results are bitwise those of the two launches.
-template <int MTM>
+// (cost of a local edge row in triplet / pair MLP rows, for the CU split of the pair: four GEMMs + three sweeps against two +
+// three; swept 0.8 .. 6.5 at the QM9 batch, flat from 2.5 to 4: profiles/r06_local_bwd_bf16.txt)
+constexpr double PAIR_EDGE_COST = 3.1;
+template <int MTM, bool IMG>
 __global__ __launch_bounds__(WG8) void local_bwd_pair_kernel(Mlp2BwdArgs ma, LocalBwdArgs la, int g_mlp) {
     constexpr int MTL = 3;
-    static_assert(MTM * MLP2_TILE_B >= 2 * MTL * 16 * LDT * 4, "LDS is sized by the MLP's chunk");
-    __shared__ __attribute__((aligned(16))) float lds[MTM * MLP2_TILE_B / 4];
+    constexpr int LDS_B = MTM * MLP2_TILE_B > LOCAL_BWD_LDS_B(MTL) ? MTM * MLP2_TILE_B : LOCAL_BWD_LDS_B(MTL);
+    __shared__ __attribute__((aligned(16))) float lds[LDS_B / 4];
     if ((int)blockIdx.x < g_mlp) mlp2_bwd_body<MTM, 8>(ma, (int)blockIdx.x, lds);
-    else local_edge_bwd_body<MTL>(la, (int)blockIdx.x - g_mlp, lds);
+    else local_edge_bwd_body<MTL, IMG>(la, (int)blockIdx.x - g_mlp, lds);
 }
 
 // One balanced wave of workgroups: `per` 16-row tiles each (<= N_CU workgroups), walked in chunks of `cmt` <= cap tiles.
@@ -701,7 +712,7 @@ static int fill_local(LocalW& w, const float* const* Wq, const int64_t* ldq, con
     if (images) *images = zeros == 4;
     for (int b = 0; b < 4; ++b) {
         if (!Wq[b]) return PAMNET_ENULL;
-        if (zeros == 0 && ldq[b] < DIM) return PAMNET_EINVAL;
+        if (zeros == 0 && (ldq[b] < DIM || ldq[b] > (1 << 21))) return PAMNET_EINVAL;   // (32-bit byte offsets of a slice)
         w.W[b] = Wq[b];
         w.ld[b] = (int)ldq[b];
         w.P[b] = P ? P[b] : nullptr;
@@ -744,9 +755,9 @@ extern "C" int pamnet_local_edge_bwd_f32(const float* d_mji, const float* d_mnb,
     if (rc) return rc;
     constexpr int MTL = 3;
     const Plan p = plan8(n_edges, MTL);                     // four weight matrices: stays one 8-wave workgroup per CU
-    hipLaunchKernelGGL(local_edge_bwd_kernel<MTL>, dim3(p.grid), dim3(WG8), 0, as_stream(stream),
-                       LocalBwdArgs{d_mji, d_mnb, d_q3, n_edges, z_ji, z_kj, q2, w, dz_ji, dz_kj, dq2, d_rbf, (int)accumulate,
-                                    p.pa, p.pb, p.cmt});
+    const LocalBwdArgs la{d_mji, d_mnb, d_q3, n_edges, z_ji, z_kj, q2, w, dz_ji, dz_kj, dq2, d_rbf, (int)accumulate, p.pa, p.pb, p.cmt};
+    if (images) hipLaunchKernelGGL((local_edge_bwd_kernel<MTL, true>), dim3(p.grid), dim3(WG8), 0, as_stream(stream), la);
+    else hipLaunchKernelGGL((local_edge_bwd_kernel<MTL, false>), dim3(p.grid), dim3(WG8), 0, as_stream(stream), la);
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }
@@ -775,9 +786,9 @@ extern "C" int pamnet_local_bwd_pair_f32(const float* dy, int64_t rows, const fl
     bool local_img = false;
     int rc = fill_local(w, Wq, ldq, nullptr, &local_img);
     if (rc) return rc;
-    // CU shares by work: an edge row costs ~3.1 MLP rows (four fp32-MFMA GEMMs against two on the bf16 pipe; measured at the
-    // QM9 batch: 20.6 us for 4 316 edge rows, 24.1 us for 17 640 MLP rows, both on 256 workgroups)
-    const double we = 3.1 * (double)n_edges, wm = (double)rows;
+    // CU shares by work (PAIR_EDGE_COST); what decides at the QM9 batch is the whole number of tiles a workgroup of each
+    // half walks: 3 edge tiles (90 workgroups) beside 7 MLP tiles (166) -- 21.3 us; 4 beside 6: 24.5; 2 beside 10: 26.1
+    const double we = PAIR_EDGE_COST * (double)n_edges, wm = (double)rows;
     int ge = (int)(N_CU * we / (we + wm) + 0.5);
     ge = ge < 8 ? 8 : (ge > N_CU - 8 ? N_CU - 8 : ge);
     const Plan pe = plan8(n_edges, 3, ge);
@@ -787,9 +798,15 @@ extern "C" int pamnet_local_bwd_pair_f32(const float* dy, int64_t rows, const fl
                           pe.pa, pe.pb, pe.cmt};
     const dim3 grid(pm.grid + pe.grid);
     hipStream_t st = as_stream(stream);
-    if (pm.cmt <= 3) hipLaunchKernelGGL(local_bwd_pair_kernel<3>, grid, dim3(WG8), 0, st, ma, la, (int)pm.grid);
-    else if (pm.cmt <= 5) hipLaunchKernelGGL(local_bwd_pair_kernel<5>, grid, dim3(WG8), 0, st, ma, la, (int)pm.grid);
-    else hipLaunchKernelGGL(local_bwd_pair_kernel<7>, grid, dim3(WG8), 0, st, ma, la, (int)pm.grid);
+#define PAMNET_PAIR_LAUNCH(M)                                                                                       \
+    do {                                                                                                            \
+        if (local_img) hipLaunchKernelGGL((local_bwd_pair_kernel<M, true>), grid, dim3(WG8), 0, st, ma, la, (int)pm.grid);   \
+        else hipLaunchKernelGGL((local_bwd_pair_kernel<M, false>), grid, dim3(WG8), 0, st, ma, la, (int)pm.grid);           \
+    } while (0)
+    if (pm.cmt <= 3) PAMNET_PAIR_LAUNCH(3);
+    else if (pm.cmt <= 5) PAMNET_PAIR_LAUNCH(5);
+    else PAMNET_PAIR_LAUNCH(7);
+#undef PAMNET_PAIR_LAUNCH
     PAMNET_LAUNCH_CHECK();
     return PAMNET_OK;
 }

@@ -164,11 +164,13 @@ __device__ __forceinline__ Frag3 wfragb1_q(const float* __restrict__ W, int ldw,
 // into pieces -- ~300 VALU and 64-128 loads per lane ahead of the first row, 2 us of a 30 us kernel at the QM9 batch.  The image
 // holds the SAME pieces in the order the lanes want them: uint4 image[((tile * 4 + q) * 3 + piece) * 64 + lane], tile = wc / 16;
 // a matrix is 8 x 4 x 3 x 64 x 16 bytes = 96 KB.  Selected by ldw == 0 (`W` then IS the image); results are bitwise the same.
+// ARM: -1 = by ldw at run time; 1 = images only, 0 = matrices only (compile-time, for loads inside a row loop: with both arms
+// there the compiler keeps the fragments in scratch)
 constexpr int64_t EDGE_IMG_FLOATS = 3 * DIM * DIM / 2;
-template <bool TRANS>
+template <bool TRANS, int ARM = -1>
 __device__ __forceinline__ void load_wfragb1(WFragB1& f, const float* __restrict__ W, int ldw, int wc) {
     const int lane = threadIdx.x & 63;
-    if (ldw == 0) {
+    if (ARM == 1 || (ARM < 0 && ldw == 0)) {
         const ImgRsrc r = img_rsrc(W, EDGE_IMG_FLOATS * 4);
         const int off = ((wc >> 4) * (DIM / 32 * 3 * 64) + lane) * 16;
 #pragma unroll
@@ -178,6 +180,25 @@ __device__ __forceinline__ void load_wfragb1(WFragB1& f, const float* __restrict
                 const u32x4 u = img_load16(r, off + (q * 3 + pc) * 1024);
                 f.p[q][pc][0] = u[0], f.p[q][pc][1] = u[1], f.p[q][pc][2] = u[2], f.p[q][pc][3] = u[3];
             }
+        return;
+    }
+    if (ARM == 0 && TRANS) {
+        // inside a row loop: the 32 row addresses of a slice are loop invariants, and hoisted as 64-bit pairs they are 64 VGPRs a
+        // slice (696 bytes of scratch for the four of the local edge backward) -- one lane offset and scalar row offsets instead
+        const ImgRsrc r = img_rsrc(W, ldw * DIM * 4);
+        const int voff = ((8 * (lane >> 4)) * ldw + wc + (lane & 15)) * 4;
+#pragma unroll
+        for (int q = 0; q < DIM / 32; ++q) {
+            float v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                v[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, (32 * q + t) * ldw * 4, 0));
+            const Frag3 fr = split_frag(v);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) f.p[q][pc][t] = fr.p[pc][t];
+        }
         return;
     }
 #pragma unroll

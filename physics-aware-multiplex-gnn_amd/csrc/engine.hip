@@ -261,8 +261,9 @@ struct PackList {
         n = 0;
     }
 };
-// edge-level images per layer pair: forward W_e, W_ea + the local edge step's four slices; backward W_e, W_ea (transposed)
-constexpr int64_t EDGE_PACK_PER_PAIR = 6;
+// edge-level images per layer pair: forward W_e, W_ea + the local edge step's four slices; backward W_e, W_ea, mlp_sbf's two and
+// the local edge step's four (transposed)
+constexpr int64_t EDGE_PACK_PER_PAIR = 8;
 // PAMNET_EDGE_IMAGES=0: the edge-level kernels split their fp32 slices themselves (the form before round 6).  The images need the
 // 8-wave geometry of the local edge kernel (PAMNET_EDGE_WAVES=4 forces the other one: no images then).
 inline bool edge_images() {
@@ -658,8 +659,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
     // transposed fragment images of W_e, W_ea for the plain global-edge backward (the weight-gradient-forming kernel of large
     // batches keeps its own two-pieces-in-registers loader)
     const bool eimg = packed && edge_images() && !edge_wgrad(g);
-    // ... and of the local layer's backward pair: mlp_sbf's W1, W2 (bf16x3 fragments), the local edge step's four slices (fp32
-    // fragments: that body multiplies on the fp32 MFMAs)
+    // ... and of the local layer's backward pair: mlp_sbf's W1, W2 and the local edge step's four slices (bf16x3 fragments)
     const bool limg = packed && edge_images() && g.tp > 0 && g.el > 0;      // (the paired launch exists)
     struct EdgeImgT {
         const float *we, *wea, *w1, *w2, *wq[4];
@@ -681,8 +681,8 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
             if (limg) {
                 EdgeImgT& ei = eimg_store[k];
                 ei.w1 = pl.add_edge(lp[6], D), ei.w2 = pl.add_edge(lp[8], D);
-                ei.wq[0] = pl.add(lp[2] + 2 * D, 3 * D), ei.wq[1] = pl.add(lp[4] + 2 * D, 3 * D);
-                ei.wq[2] = pl.add(lp[10], D), ei.wq[3] = pl.add(lp[11], D);
+                ei.wq[0] = pl.add_edge(lp[2] + 2 * D, 3 * D), ei.wq[1] = pl.add_edge(lp[4] + 2 * D, 3 * D);
+                ei.wq[2] = pl.add_edge(lp[10], D), ei.wq[3] = pl.add_edge(lp[11], D);
             }
         }
         pl.flush();

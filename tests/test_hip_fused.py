@@ -417,14 +417,14 @@ def test_local_backward_pair_equals_the_two_launches(dev, rows, edges, acc):
         assert torch.equal(a, b) and not bool(torch.isnan(a).any())
     if rows == 0 or edges == 0:
         return
-    # round 6: the same launch on weight images (pamnet_pack_weights_mixed_f32, transposed): W1 / W2 as bf16x3 fragments
-    # (kind 1, flag PAMNET_WEIGHT_IMAGES on accumulate_dx), the four local slices as fp32 fragments (kind 0, strides 0)
-    IMG1, IMG0 = 3 * D * D // 2, D * D
-    images = torch.full((2 * IMG1 + 4 * IMG0,), float('nan'), device=dev)
+    # round 6: the same launch on weight images (pamnet_pack_weights_mixed_f32, transposed, kind 1: bf16x3 fragments): W1 / W2
+    # (flag PAMNET_WEIGHT_IMAGES on accumulate_dx) and the four local slices (strides 0)
+    IMG1 = 3 * D * D // 2
+    images = torch.full((6 * IMG1,), float('nan'), device=dev)
     srcs = (ctypes.c_void_p * 6)(W1.data_ptr(), W2.data_ptr(), *[wq[i] for i in range(4)])
     lds = (ctypes.c_int64 * 6)(D, D, 3 * D, 3 * D, D, D)
-    kinds = (ctypes.c_int32 * 6)(1, 1, 0, 0, 0, 0)
-    offs = (ctypes.c_int64 * 6)(0, IMG1, 2 * IMG1, 2 * IMG1 + IMG0, 2 * IMG1 + 2 * IMG0, 2 * IMG1 + 3 * IMG0)
+    kinds = (ctypes.c_int32 * 6)(1, 1, 1, 1, 1, 1)
+    offs = (ctypes.c_int64 * 6)(*[i * IMG1 for i in range(6)])
     lib.call('pamnet_pack_weights_mixed_f32', 6, srcs, lds, kinds, offs, 1, lib.ptr(images), st)
     ip = lambda i: images.data_ptr() + 4 * offs[i]
     (iz1, iz2, ix), (iji, ikj, iq2, irbf) = outs()

@@ -43,11 +43,11 @@ wqp = [Wq[0].data_ptr() + 8 * D, Wq[1].data_ptr() + 8 * D, Wq[2].data_ptr(), Wq[
 o_r = [torch.empty(rows, D, device=dev) for _ in range(3)]
 o_e = [torch.empty(edges, D, device=dev) for _ in range(4)]
 IMG1, IMG0 = 3 * D * D // 2, D * D
-images = torch.empty(2 * IMG1 + 4 * IMG0, device=dev)
+images = torch.empty(6 * IMG1, device=dev)
 srcs = (ctypes.c_void_p * 6)(W1.data_ptr(), W2.data_ptr(), *wqp)
 lds = (ctypes.c_int64 * 6)(D, D, 3 * D, 3 * D, D, D)
-kinds = (ctypes.c_int32 * 6)(1, 1, 0, 0, 0, 0)
-offs = (ctypes.c_int64 * 6)(0, IMG1, 2 * IMG1, 2 * IMG1 + IMG0, 2 * IMG1 + 2 * IMG0, 2 * IMG1 + 3 * IMG0)
+kinds = (ctypes.c_int32 * 6)(1, 1, 1, 1, 1, 1)
+offs = (ctypes.c_int64 * 6)(*[i * IMG1 for i in range(6)])
 lib.call('pamnet_pack_weights_mixed_f32', 6, srcs, lds, kinds, offs, 1, lib.ptr(images), st)
 ip = lambda i: images.data_ptr() + 4 * offs[i]
 P4 = ctypes.c_void_p * 4
@@ -92,3 +92,17 @@ fwq = P4(*[fimg.data_ptr() + 4 * i * IMG1 for i in range(4)])
 for rep in range(2):
     print('  local_edge_fwd: matrices %.1f us | images %.1f us' % (event_us(lambda: lfwd(plain_wq, plain_ld)),
                                                                   event_us(lambda: lfwd(fwq, img_ld))))
+
+# ---- the two halves of the backward pair alone (each on its own plan over all CUs)
+def mlp_alone():
+    lib.call('pamnet_mlp2_bwd_f32', lib.ptr(dy), rows, lib.ptr(z1), lib.ptr(z2), lib.ptr(W1), lib.ptr(W2), lib.ptr(o_r[0]),
+             lib.ptr(o_r[1]), lib.ptr(o_r[2]), 0, st)
+
+
+def edge_alone(wq, ldq):
+    lib.call('pamnet_local_edge_bwd_f32', lib.ptr(d_mji), lib.ptr(d_mnb), lib.ptr(d_q3), edges, lib.ptr(z_ji), lib.ptr(z_kj),
+             lib.ptr(q2), wq, ldq, lib.ptr(o_e[0]), lib.ptr(o_e[1]), lib.ptr(o_e[2]), lib.ptr(o_e[3]), 0, st)
+
+
+print('  alone: mlp2_bwd (fp32 matrices) %.1f us | local_edge_bwd on images %.1f us' % (
+    event_us(mlp_alone), event_us(lambda: edge_alone(img_wq, img_ld))))
