@@ -470,7 +470,8 @@ int pamnet_node_pre_tail_bwd_gather_f32(float* dP, const float* const* gather_sr
 int pamnet_pack_weights_f32(int64_t n, const float* const* W, const int64_t* ld, int32_t transposed, float* images,
                             pamnet_stream_t stream);
 /* The same matrices as bf16x3 fragment images (images[i*24576..], 96 KB each): every weight split exactly into three bf16
- * pieces, laid out as the B fragments of v_mfma_f32_16x16x32_bf16.  With packed == 2, pamnet_node_tail_fwd_f32 (deferred
+ * pieces, laid out as operand fragments of v_mfma_f32_16x16x32_bf16 (the kind-1 images of pamnet_pack_weights_mixed_f32 below,
+ * one after the other).  With packed == 2, pamnet_node_tail_fwd_f32 (deferred
  * heads: out = att = null) and pamnet_node_tail_fwd_rider_f32 take such images for weights[0..6], next_Wx1 and next_wp and
  * run the chain on the bf16 matrix pipe at fp32 accuracy (six piece products per product: csrc/gemm_core.h "bf16x6"). */
 int pamnet_pack_weights_bf16x3(int64_t n, const float* const* W, const int64_t* ld, int32_t transposed, float* images,

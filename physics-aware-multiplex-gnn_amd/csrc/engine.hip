@@ -242,9 +242,9 @@ struct PackList {
     PackList(float* b, int32_t t, pamnet_stream_t s, bool pieces = false, float* eb = nullptr)
         : base(b), ebase(eb), transposed(t), st(s), img(pieces ? 3 * D * D / 2 : D * D), bf16x3(pieces) {}
     // returns the image the matrix will occupy
-    const float* add(const float* W, int64_t ldw) {
-        if (n == (bf16x3 ? 192 : CAP)) flush();
-        src[n] = W, ld[n] = ldw, kind[n] = 0, off[n] = done * img;
+    const float* add(const float* W, int64_t ldw, bool fp32 = false) {      // fp32: an fp32 fragment image whatever the list's kind
+        if (n == CAP) flush();
+        src[n] = W, ld[n] = ldw, kind[n] = (bf16x3 && !fp32) ? 1 : 0, off[n] = done * img;
         ++n;
         return base + done++ * img;
     }
@@ -255,9 +255,7 @@ struct PackList {
         return ebase + edone++ * EDGE_IMG;
     }
     void flush() {
-        if (n && !rc)
-            rc = bf16x3 ? pamnet_pack_weights_bf16x3(n, src, ld, transposed, base + off[0], st)
-                        : pamnet_pack_weights_mixed_f32(n, src, ld, kind, off, transposed, base, st);
+        if (n && !rc) rc = pamnet_pack_weights_mixed_f32(n, src, ld, kind, off, transposed, base, st);
         n = 0;
     }
 };
@@ -276,11 +274,13 @@ inline bool edge_images() {
 }
 constexpr int64_t PACK_PER_PAIR = 28;       // forward: 10 + 5 (global chain + local head) + 10 + 3 (local chain + next global head)
 constexpr int64_t PACK_FLOATS_PER_PAIR = PACK_PER_PAIR * (3 * D * D / 2);     // sized for bf16x3 images throughout
-// PAMNET_CHAIN_BF16=1: the forward chains on the bf16 matrix pipe (node_tail_fwd_bf16_kernel, bf16x3 weight images).
-// Off by default -- measured in the step at the QM9 batch: 27.8 us per chain launch against 26.5 us for the fp32-MFMA form
-// (the MFMAs of a layer shrink from 2 300 to 1 100 cycles, tools/tail_probe_bf16.py, but the epilogue grows by as much:
-// the split of the result, 12 more LDS stores with 4-way bank conflicts, 96 KB instead of 64 KB of weights per layer
-// from L2); same outputs to 3e-7 (tests/test_hip_fused.py::test_node_tail_fwd_bf16x6).
+// The forward chains of single-round batches (<= 256 row tiles: QM9, RNA) on the bf16 matrix pipe at fp32 accuracy
+// (node_tail_fwd_bf16_kernel, bf16x3 weight images): 768 instead of 2 048 matrix-pipe cycles per layer.  Built in round 5 with
+// the accumulator four rows of one channel per lane and 27.8 us per launch against the fp32-MFMA form's 26.5 (the epilogue, 12
+// four-byte piece stores per lane, grew by what the MFMAs shrank); with the operands swapped (round 6: a lane's four consecutive
+// channels leave as three 8-byte piece stores) a 7-layer chain is 23 500 cycles against 27 500 and the QM9 step 1.954 against
+// 1.989 ms same box (profiles/r06_chain_bf16.txt); same outputs to 3e-7 (tests/test_hip_fused.py::test_node_tail_fwd_bf16x6).
+// PAMNET_CHAIN_BF16=0: the fp32-MFMA chains.  Larger batches run the lean fp32 chain kernels (several workgroups per CU).
 // Round 6: the segment sums that feed a fused head + chain backward launch (the source-side sum of the global layer's d z, the
 // four sums of the local layer) are formed by that launch's own row tiles (node_tail.hip gather_begin / gather_finish) instead of by launches
 // of their own ahead of it: two launches fewer per layer pair on the dependent chain.  PAMNET_FUSE_SEGSUM=0: the separate launches.
@@ -298,7 +298,7 @@ inline bool fuse_local_agg(const Graph& g) {
     return v && (g.n + 15) / 16 <= 256;
 }
 inline bool chain_bf16() {
-    static bool v = [] { const char* e = getenv("PAMNET_CHAIN_BF16"); return e && atoi(e) != 0; }();
+    static bool v = [] { const char* e = getenv("PAMNET_CHAIN_BF16"); return !e || atoi(e) != 0; }();
     return v;
 }
 
@@ -468,27 +468,25 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
     PairImg* img = packed ? img_store.data() : nullptr;
     // bf16x3 images for everything the chains multiply by (matrices 0..6 + the fused heads of the next layers), fp32
     // images for the mlp_out matrices 7..9 (node_heads_fwd_kernel)
-    const bool cb = packed && chain_bf16();
+    const bool cb = packed && chain_bf16() && (g.n + 15) / 16 <= 256;      // (one workgroup per CU: single-round batches)
     // edge-level fragment images (region behind the chain images): W_e, W_ea of the global step, the local edge step's slices
-    const bool eimg = packed && !cb && edge_images();
+    const bool eimg = packed && edge_images();
     struct EdgeImg {
         const float *we, *wea, *wq[4];
     };
     std::vector<EdgeImg> eimg_store(eimg ? (size_t)n_layer : 0);
     if (packed) {
         PackList pl(wpack, 0, st, cb, wpack + n_layer * PACK_FLOATS_PER_PAIR);
-        PackList ph(wpack + n_layer * 22 * (3 * D * D / 2), 0, st, false);     // behind the 22 chain images of every pair
-        PackList& hd = cb ? ph : pl;
         for (int64_t k = 0; k < n_layer; ++k) {
             const float* const* gp = gparams + k * NG;
             const float* const* lp = lparams + k * NL;
             for (int i = 0; i < 7; ++i) img[k].gt[i] = pl.add(gp[GT + i], D);
-            for (int i = 7; i < 10; ++i) img[k].gt[i] = hd.add(gp[GT + i], D);
+            for (int i = 7; i < 10; ++i) img[k].gt[i] = pl.add(gp[GT + i], D, true);
             img[k].lh[0] = pl.add(lp[0], D);
             img[k].lh[1] = pl.add(lp[2], 3 * D), img[k].lh[2] = pl.add(lp[4], 3 * D);
             img[k].lh[3] = pl.add(lp[2] + D, 3 * D), img[k].lh[4] = pl.add(lp[4] + D, 3 * D);
             for (int i = 0; i < 7; ++i) img[k].lt[i] = pl.add(lp[LT + i], D);
-            for (int i = 7; i < 10; ++i) img[k].lt[i] = hd.add(lp[LT + i], D);
+            for (int i = 7; i < 10; ++i) img[k].lt[i] = pl.add(lp[LT + i], D, true);
             if (k + 1 < n_layer) {
                 const float* const* gn = gparams + (k + 1) * NG;
                 img[k].nh[0] = pl.add(gn[0], D);
@@ -503,10 +501,6 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         }
         pl.flush();
         CK(pl.rc);
-        if (cb) {
-            ph.flush();
-            CK(ph.rc);
-        }
     }
     const int32_t pkc = cb ? 2 : (packed ? 1 : 0);          // what the chain launches are told about their images
     const int32_t pk = packed ? 1 : 0;

@@ -604,84 +604,43 @@ __global__ __launch_bounds__(WG, 3) void node_tail_fwd_lean_kernel(const float* 
 }
 
 // ---- the forward chain on the bf16 matrix pipe at fp32 accuracy ("bf16x6", gemm_core.h) ---------------------------------
-// Production form of the kernel above (packed weights, deferred heads): every GEMM input tile lives in LDS as three bf16
-// piece planes in MFMA A-fragment order -- [piece][k-step][lane] x 16 bytes, lane-linear, 12 KB per 16-row tile -- written
-// by the epilogue that produces it (the split costs 4.5 VALU per element, once), and the weights arrive as bf16x3 fragment
-// images (pamnet_pack_weights_bf16x3: 96 KB per matrix).  A layer is 48 v_mfma_f32_16x16x32_bf16 per wave (816 matrix-pipe
-// cycles) instead of 64 fp32 MFMAs (2 048 cycles, and on this part an MFMA in flight holds up the VALU issue of its SIMD).
-// k order inside k-step q: an accumulator lane holds columns c and c + 16 of a row, so those two are made neighbours in k:
-// position t = 2 j + n2 of row group kg is column 32 q + 16 n2 + 4 kg + j -- the pack kernel lays the weights out the same
-// way, and a pair of a lane leaves as ONE dword per piece.
-constexpr int PIMG = 3 * 4 * 1024;            // bytes of a 16-row tile as piece planes
-
-struct WFragB {                               // a wave's 32 output columns: [16-column tile][k-step][piece] = 96 VGPRs
-    uint4 b[2][4][3];
+// The production form of the kernel above (packed weights, deferred heads) with every GEMM as six bf16 piece products: a layer
+// is 48 v_mfma_f32_16x16x32_bf16 per wave (768 matrix-pipe cycles) instead of 64 fp32 MFMAs (2 048).  Every GEMM input tile
+// lives in LDS as three bf16 piece planes (edge_core.h st_pieces4 / lds_frag3p: 12 KB per 16-row tile, conflict-free on both
+// sides), written by the epilogue that produces it -- the split is done once per element; the weights arrive as the edge-level
+// kernels' bf16x3 fragment images (pamnet_pack_weights_mixed_f32 kind 1; 96 KB per matrix).
+// Operands swapped like the fp32 form's (mma_tile_frag_t): the weight pieces are the A operand (lane: out channel wc + (l & 15),
+// k = 8 (l >> 4) + 0..7 -- exactly what the image holds for the lane), the activation pieces the B operand (lane: node row
+// l & 15, same k), so a lane's accumulator is row r16, channels wc + 16 n2 + 4 kg + 0..3: its pieces leave as three 8-byte
+// stores, its pre-activations as one 16-byte store.  (Until round 6 this kernel had the operands the other way round and a
+// k order of its own: 12 four-byte piece stores per lane and layer, epilogue 2 500 cycles against the fp32 form's 1 250.)
+struct WFragB {                               // a wave's 32 output channels: two 16-channel tiles = 96 VGPRs
+    edge::WFragB1 t[2];
 };
-// bf16x3 image of a matrix: img16[((piece * 8 + tile) * 4 + k-step) * 64 + lane]
-__device__ __forceinline__ void load_wfragb(WFragB& f, const float* __restrict__ img) {
-    const uint4* p = reinterpret_cast<const uint4*>(img) + (threadIdx.x & 63);
-    const int jt = (threadIdx.x >> 6) * 2;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) f.b[t][q][pc] = p[((pc * 8 + jt + t) * 4 + q) * 64];
+__device__ __forceinline__ void load_wfragb(WFragB& f, const float* __restrict__ img, int wc) {
+    edge::load_wfragb1<false, 1>(f.t[0], img, 0, wc);
+    edge::load_wfragb1<false, 1>(f.t[1], img, 0, wc + 16);
 }
-__device__ __forceinline__ f32x4 mfma_u4(const uint4& a, const uint4& b, const f32x4& c) {
-    const u32x4 av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
-}
-// acc[t] += tile(planes at `in`) x slice t of `f`: 4 k-steps x 6 products x 2 tiles, small products first
-// Slot of (row rho, row-group kg) inside a 1 KB image: 4 rho + ((kg + 2 (rho >> 3)) & 3).  The four kg chunks of a row are
-// neighbours, so the 32 lanes of an epilogue store group (two rows, all kg, four dwords) see a 2-way bank conflict, which
-// ds_write_b32 absorbs, where the lane-linear order (rho + 16 kg) makes it 4-way; the rotation by 2 (rho >> 3) keeps the
-// 16-lane groups of the readers' ds_read_b128 on 16 distinct slots modulo 16.  (Measured: no difference -- the epilogue of
-// this kernel is longer than the fp32 form's by the issue of 8 more weight loads and ~70 more VALU, not by LDS conflicts.)
-__device__ __forceinline__ int plane_slot(int rho, int kg) { return 4 * rho + ((kg + 2 * (rho >> 3)) & 3); }
-
-__device__ __forceinline__ void mma_planes(const char* __restrict__ in, const WFragB& f, f32x4 (&acc)[2]) {
-    const uint4* ip = reinterpret_cast<const uint4*>(in) + plane_slot(threadIdx.x & 15, (threadIdx.x & 63) >> 4);
-    uint4 az[4][3];
+// acc[t] += (tile as piece planes at `in`) x (channels of slice t): 4 k-steps x 6 products x 2 tiles, small products first
+__device__ __forceinline__ void mma_planes_t(const char* __restrict__ in, const WFragB& f, f32x4 (&acc)[2]) {
+    Frag3 x[DIM / 32];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < DIM / 32; ++q) x[q] = edge::lds_frag3p(in, 0, q);
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) az[q][pc] = ip[(pc * 4 + q) * 64];
+    for (int q = 0; q < DIM / 32; ++q) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+        for (int t = 0; t < 2; ++t) acc[t] = mfma_bf16(f.t[t].p[q][2], x[q].p[0], acc[t]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t] = mfma_u4(az[q][2], f.b[t][q][0], acc[t]);
+        for (int t = 0; t < 2; ++t) acc[t] = mfma_bf16(f.t[t].p[q][1], x[q].p[1], acc[t]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t] = mfma_u4(az[q][1], f.b[t][q][1], acc[t]);
+        for (int t = 0; t < 2; ++t) acc[t] = mfma_bf16(f.t[t].p[q][0], x[q].p[2], acc[t]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t] = mfma_u4(az[q][0], f.b[t][q][2], acc[t]);
+        for (int t = 0; t < 2; ++t) acc[t] = mfma_bf16(f.t[t].p[q][1], x[q].p[0], acc[t]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t] = mfma_u4(az[q][1], f.b[t][q][0], acc[t]);
+        for (int t = 0; t < 2; ++t) acc[t] = mfma_bf16(f.t[t].p[q][0], x[q].p[1], acc[t]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t] = mfma_u4(az[q][0], f.b[t][q][1], acc[t]);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t] = mfma_u4(az[q][0], f.b[t][q][0], acc[t]);
+        for (int t = 0; t < 2; ++t) acc[t] = mfma_bf16(f.t[t].p[q][0], x[q].p[0], acc[t]);
     }
-}
-// the pair (columns c, c + 16 of row `rw`, c = 32 w + r16) of an accumulator lane -> its dword in each piece plane
-__device__ __forceinline__ void st_pair_planes(char* __restrict__ dst, int w, int rw, int r16, float a0, float a1) {
-    uint32_t p0, p1, p2;
-    split3(a0, a1, p0, p1, p2);
-    char* d = dst + w * 1024 + plane_slot(rw, r16 >> 2) * 16 + (r16 & 3) * 4;
-    *reinterpret_cast<uint32_t*>(d) = p0;
-    *reinterpret_cast<uint32_t*>(d + 4096) = p1;
-    *reinterpret_cast<uint32_t*>(d + 8192) = p2;
-}
-// one value of a row-major sweep (row r, column c) -> its 2 bytes in each piece plane
-__device__ __forceinline__ void st_elem_planes(char* __restrict__ dst, int r, int c, float v) {
-    const f32x2 x = {v, 0.f};
-    uint32_t p0, p1, p2;
-    split3(x[0], x[1], p0, p1, p2);
-    const int q = c >> 5, n2 = (c >> 4) & 1, r16 = c & 15;
-    char* d = dst + q * 1024 + plane_slot(r, r16 >> 2) * 16 + (r16 & 3) * 4 + 2 * n2;
-    *reinterpret_cast<uint16_t*>(d) = (uint16_t)p0;
-    *reinterpret_cast<uint16_t*>(d + 4096) = (uint16_t)p1;
-    *reinterpret_cast<uint16_t*>(d + 8192) = (uint16_t)p2;
 }
 
 template <bool RIDER>
@@ -689,14 +648,15 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_bf16_kernel(const float* __r
                                                                 const float* __restrict__ res_x, int64_t n, TailParams p,
                                                                 float* __restrict__ Z, float* __restrict__ R,
                                                                 float* __restrict__ x_out, PreNext nx,
-                                                                Mlp2Rider rd = Mlp2Rider{}) {
+                                                                Mlp2Rider rd = Mlp2Rider{}, LocalAgg la = LocalAgg{}) {
     // fp32 tiles: res_x, h0, 7 pre-activation tiles, 3 residual taps (parked, written out once after the chain);
     // piece-plane tiles: three, rotating through the chain
-    __shared__ __attribute__((aligned(16))) float lds[12 * SLOT + 3 * PIMG / 4];
+    constexpr int PT = edge::PTILE;
+    __shared__ __attribute__((aligned(16))) float lds[12 * SLOT + 3 * PT / 4];
     if constexpr (RIDER) {
         if ((int)blockIdx.x >= rd.n_chain) {
             constexpr int RMT = 3;
-            static_assert((12 * SLOT + 3 * PIMG / 4) * 4 >= RMT * edge::MLP2_TILE_B, "rider tiles must fit the chain's LDS");
+            static_assert((12 * SLOT + 3 * PT / 4) * 4 >= RMT * edge::MLP2_TILE_B, "rider tiles must fit the chain's LDS");
             const int b = (int)blockIdx.x - rd.n_chain, nr = (int)gridDim.x - rd.n_chain;
             const int base = rd.ntiles / nr, rem = rd.ntiles % nr;
             const int64_t t0 = rd.tile0 + (int64_t)b * base + (b < rem ? b : rem);
@@ -717,22 +677,39 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_bf16_kernel(const float* __r
     float* ZL = lds + 2 * SLOT;               // [7] z_k tiles (reused by the next layer's head: Zx1, x1, P_b)
     float* TL = lds + 9 * SLOT;               // [3] r1, r2, x_out tiles
     char* P0 = reinterpret_cast<char*>(lds + 12 * SLOT);
-    char* P1 = P0 + PIMG;
-    char* P2 = P1 + PIMG;
+    char* P1 = P0 + PT;
+    char* P2 = P1 + PT;
     const int64_t row0 = (int64_t)blockIdx.x * BMN;
     const int64_t plane = n * DIM;
     const int lane = threadIdx.x & 63, r16 = lane & 15, kg = lane >> 4;
-    const int w = threadIdx.x >> 6, wc = w * 32;
+    const int wc = (threadIdx.x >> 6) * 32;
 
+    TPROBE(40);
     WFragB wf;
-    load_wfragb(wf, p.W[0]);
-    sweep_rows<BMN>([&](int r, int c4) {
-        const int64_t g = row0 + r;
-        const float4 v = ldg4z(x2, g, n, DIM, c4);
-        st_elem_planes(P0, r, 4 * c4, v.x), st_elem_planes(P0, r, 4 * c4 + 1, v.y);
-        st_elem_planes(P0, r, 4 * c4 + 2, v.z), st_elem_planes(P0, r, 4 * c4 + 3, v.w);
-        st_lds4(RX, r, c4, ldg4z(res_x, g, n, DIM, c4));
-    });
+    load_wfragb(wf, p.W[0], wc);
+    if (la.m_ji) {                                            // (workgroup-uniform) the x2 rows are formed here
+        constexpr int NJ = BMN / 8;
+        const int c4 = threadIdx.x & 31, rq = threadIdx.x >> 5;
+        int64_t node[NJ];
+        bool ok[NJ];
+        float4 xin[NJ], rx[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) node[j] = row0 + rq + 8 * j, ok[j] = node[j] < n;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) rx[j] = ldg4z(res_x, node[j], n, DIM, c4);
+        local_agg_rows<NJ>(la, node, ok, c4, xin);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            st_lds4(RX, rq + 8 * j, c4, rx[j]);
+            edge::st_pieces4(P0, rq + 8 * j, c4, xin[j]);
+        }
+    } else {
+        sweep_rows<BMN>([&](int r, int c4) {
+            const int64_t g = row0 + r;
+            st_lds4(RX, r, c4, ldg4z(res_x, g, n, DIM, c4));
+            edge::st_pieces4(P0, r, c4, ldg4z(x2, g, n, DIM, c4));
+        });
+    }
     __syncthreads();
 
     // layer k: planes `in` -> planes `dst` = SiLU(W_k in + b_k) (+ add1 + add2); z_k parked; fp32 copies of the result
@@ -740,24 +717,30 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_bf16_kernel(const float* __r
     auto layer = [&](const char* in, char* dst, int k, const float* add1, const float* add2, float* dst32, float* tap,
                      const float* Wnext) {
         TPROBE(4 * k);
-        const Bias2 bv = load_bias2(p.b[k], wc);               // before the prefetch (in-order vmcnt)
+        const Bias8 bv = load_bias8(p.b[k], wc);               // before the prefetch (in-order vmcnt)
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        mma_planes(in, wf, acc);
+        mma_planes_t(in, wf, acc);                             // lane: row r16, channels wc + 16 n2 + 4 kg + 0..3
         TPROBE(4 * k + 1);
-        if (Wnext) load_wfragb(wf, Wnext);
+        if (Wnext) load_wfragb(wf, Wnext, wc);
         float* zk = ZL + k * SLOT;
-        const int c = wc + r16;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rw = 4 * kg + r;
-            const float z0 = acc[0][r] + bv.v[0], z1 = acc[1][r] + bv.v[1];
-            float a0 = silu(z0), a1 = silu(z1);
-            if (add1) a0 += add1[rw * LDT + c], a1 += add1[rw * LDT + c + 16];
-            if (add2) a0 += add2[rw * LDT + c], a1 += add2[rw * LDT + c + 16];
-            st_pair_planes(dst, w, rw, r16, a0, a1);
-            zk[rw * LDT + c] = z0, zk[rw * LDT + c + 16] = z1;
-            if (dst32) dst32[rw * LDT + c] = a0, dst32[rw * LDT + c + 16] = a1;
-            if (tap) tap[rw * LDT + c] = a0, tap[rw * LDT + c + 16] = a1;
+        for (int n2 = 0; n2 < 2; ++n2) {
+            const int o = r16 * LDT + wc + 16 * n2 + 4 * kg;
+            const float4 z = make_float4(acc[n2][0] + bv.v[n2].x, acc[n2][1] + bv.v[n2].y, acc[n2][2] + bv.v[n2].z,
+                                         acc[n2][3] + bv.v[n2].w);
+            float4 a = make_float4(silu(z.x), silu(z.y), silu(z.z), silu(z.w));
+            if (add1) {
+                const float4 t = *reinterpret_cast<const float4*>(add1 + o);
+                a.x += t.x, a.y += t.y, a.z += t.z, a.w += t.w;
+            }
+            if (add2) {
+                const float4 t = *reinterpret_cast<const float4*>(add2 + o);
+                a.x += t.x, a.y += t.y, a.z += t.z, a.w += t.w;
+            }
+            edge::st_pieces4(dst, r16, (wc + 16 * n2 + 4 * kg) >> 2, a);
+            *reinterpret_cast<float4*>(zk + o) = z;
+            if (dst32) *reinterpret_cast<float4*>(dst32 + o) = a;
+            if (tap) *reinterpret_cast<float4*>(tap + o) = a;
         }
         TPROBE(4 * k + 2);
         __syncthreads();
@@ -784,37 +767,41 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_bf16_kernel(const float* __r
         }
         stg4(x_out, g, DIM, c4, lds4(TL + 2 * SLOT, r, c4));
     });
+    TPROBE(41);
 
     // ---- the next layer's head on the x_out tile (its planes are in P0); outputs reuse the z_k parking slots, which the
     // sweep above has already read -> barrier, one GEMM for x1, nblk for the projections, then a second flush
     if (nx.nblk > 0) {
         __syncthreads();
-        const int c = wc + r16;
         {
-            const Bias2 bv = load_bias2(nx.bx1, wc);
+            const Bias8 bv = load_bias8(nx.bx1, wc);
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-            mma_planes(P0, wf, acc);
-            load_wfragb(wf, nx.wp[0]);
+            mma_planes_t(P0, wf, acc);
+            load_wfragb(wf, nx.wp[0], wc);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rw = 4 * kg + r;
-                const float z0 = acc[0][r] + bv.v[0], z1 = acc[1][r] + bv.v[1];
-                const float a0 = silu(z0), a1 = silu(z1);
-                ZL[rw * LDT + c] = z0, ZL[rw * LDT + c + 16] = z1;                     // Zx1
-                ZL[SLOT + rw * LDT + c] = a0, ZL[SLOT + rw * LDT + c + 16] = a1;       // x1
-                st_pair_planes(P1, w, rw, r16, a0, a1);
+            for (int n2 = 0; n2 < 2; ++n2) {
+                const int o = r16 * LDT + wc + 16 * n2 + 4 * kg;
+                const float4 z = make_float4(acc[n2][0] + bv.v[n2].x, acc[n2][1] + bv.v[n2].y, acc[n2][2] + bv.v[n2].z,
+                                             acc[n2][3] + bv.v[n2].w);
+                const float4 a = make_float4(silu(z.x), silu(z.y), silu(z.z), silu(z.w));
+                *reinterpret_cast<float4*>(ZL + o) = z;                    // Zx1
+                *reinterpret_cast<float4*>(ZL + SLOT + o) = a;             // x1
+                edge::st_pieces4(P1, r16, (wc + 16 * n2 + 4 * kg) >> 2, a);
             }
             __syncthreads();
         }
         for (int b = 0; b < nx.nblk; ++b) {
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-            mma_planes(P1, wf, acc);
-            if (b + 1 < nx.nblk) load_wfragb(wf, nx.wp[b + 1]);
+            mma_planes_t(P1, wf, acc);
+            if (b + 1 < nx.nblk) load_wfragb(wf, nx.wp[b + 1], wc);
             float* pb = ZL + (2 + b) * SLOT;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pb[(4 * kg + r) * LDT + c] = acc[0][r], pb[(4 * kg + r) * LDT + c + 16] = acc[1][r];
+            for (int n2 = 0; n2 < 2; ++n2)
+                *reinterpret_cast<float4*>(pb + r16 * LDT + wc + 16 * n2 + 4 * kg) =
+                    make_float4(acc[n2][0], acc[n2][1], acc[n2][2], acc[n2][3]);
         }
         __syncthreads();
+        TPROBE(42);
         sweep_rows<BMN>([&](int r, int c4) {
             const int64_t g = row0 + r;
             if (g >= n) return;
@@ -822,6 +809,7 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_bf16_kernel(const float* __r
             stg4(nx.x1, g, DIM, c4, lds4(ZL + SLOT, r, c4));
             for (int b = 0; b < nx.nblk; ++b) stg4(nx.P + (int64_t)b * plane, g, DIM, c4, lds4(ZL + (2 + b) * SLOT, r, c4));
         });
+        TPROBE(43);
     }
 }
 
@@ -1515,49 +1503,6 @@ extern "C" int pamnet_pack_weights_f32(int64_t n, const float* const* W, const i
     return PAMNET_OK;
 }
 
-// bf16x3 images (node_tail_fwd_bf16_kernel): per matrix 3 pieces x 8 column tiles x 4 k-steps x 64 lanes x 16 bytes =
-// 96 KB = 24 576 floats.  Lane (n = lane & 15, kg = lane >> 4) of tile jt, k-step q holds, at position t = 0..7, the piece
-// of W[16 jt + n][32 q + 16 (t & 1) + 4 kg + (t >> 1)] (forward orientation, Y = X W^T; transposed: W[k][16 jt + n]).
-constexpr int64_t IMGB_FLOATS = 3 * DIM * DIM / 2;
-namespace {
-__global__ __launch_bounds__(256) void pack_weights_bf16x3_kernel(PackJobs jobs, int transposed, float* __restrict__ images) {
-    const float* __restrict__ W = jobs.src[blockIdx.x];
-    const int ld = jobs.ld[blockIdx.x];
-    const int jt = blockIdx.y, q = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c = 16 * jt + (lane & 15), kg = lane >> 4;
-    float v[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int k = 32 * q + 16 * (t & 1) + 4 * kg + (t >> 1);
-        v[t] = transposed ? W[(size_t)k * ld + c] : W[(size_t)c * ld + k];
-    }
-    const Frag3 f = split_frag(v);
-    uint4* img = reinterpret_cast<uint4*>(images + (size_t)blockIdx.x * IMGB_FLOATS);
-#pragma unroll
-    for (int pc = 0; pc < 3; ++pc)
-        img[((pc * 8 + jt) * 4 + q) * 64 + lane] = make_uint4(f.p[pc][0], f.p[pc][1], f.p[pc][2], f.p[pc][3]);
-}
-}  // namespace
-
-extern "C" int pamnet_pack_weights_bf16x3(int64_t n, const float* const* W, const int64_t* ld, int32_t transposed,
-                                          float* images, pamnet_stream_t stream) {
-    if (n < 0 || n > 192) return PAMNET_EINVAL;
-    if (n == 0) return PAMNET_OK;
-    if (!W || !ld || !images) return PAMNET_ENULL;
-    PackJobs jobs;
-    for (int i = 0; i < 192; ++i) {
-        const int s = i < n ? i : 0;
-        if (!W[s]) return PAMNET_ENULL;
-        if (ld[s] < DIM || (ld[s] & 3)) return PAMNET_EINVAL;
-        jobs.src[i] = W[s];
-        jobs.ld[i] = (int)ld[s];
-    }
-    hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3((unsigned)n, 8), dim3(256), 0, as_stream(stream), jobs,
-                       (int)transposed, images);
-    PAMNET_LAUNCH_CHECK();
-    return PAMNET_OK;
-}
-
 // One launch for the images of a whole step direction (round 6): kind 0 = the chains' fp32 fragment image above (16 384 floats),
 // kind 1 = the edge-level kernels' bf16x3 fragment image (edge_core.h load_wfragb1: 24 576 floats, the pieces a wave would
 // have made of its slice itself); offset[i] = where image i starts in `images`, in floats (multiples of 4).
@@ -1610,6 +1555,20 @@ extern "C" int pamnet_pack_weights_mixed_f32(int64_t n, const float* const* W, c
     return PAMNET_OK;
 }
 
+// bf16x3 fragment images of n (<= 192) matrices into images[i * 24 576 ...]: kind-1 images of the launch above, one after the
+// other (node_tail_fwd_bf16_kernel and the edge-level kernels read the same layout).
+constexpr int64_t IMGB_FLOATS = 3 * DIM * DIM / 2;
+extern "C" int pamnet_pack_weights_bf16x3(int64_t n, const float* const* W, const int64_t* ld, int32_t transposed,
+                                          float* images, pamnet_stream_t stream) {
+    if (n < 0 || n > 192) return PAMNET_EINVAL;
+    if (n == 0) return PAMNET_OK;
+    if (!W || !ld || !images) return PAMNET_ENULL;
+    int32_t kind[192];
+    int64_t offset[192];
+    for (int i = 0; i < n; ++i) kind[i] = 1, offset[i] = i * IMGB_FLOATS;
+    return pamnet_pack_weights_mixed_f32(n, W, ld, kind, offset, transposed, images, stream);
+}
+
 static int tail_fwd_launch(const float* x2, const float* res_x, int64_t n, const float* const* weights,
                            const float* const* biases, const float* w_out, const float* b_out, const float* w_att, float* Z,
                            float* R, float* x_out, float* out, float* att, const float* next_Wx1, const float* next_bx1,
@@ -1643,7 +1602,7 @@ static int tail_fwd_launch(const float* x2, const float* res_x, int64_t n, const
         if (!agg->t_ptr || !agg->l_ptr) return PAMNET_ENULL;
         // the fp32 chain kernels (packed images, deferred heads) form x2 themselves; every other form reads it: the aggregation
         // runs as its own launch first, as it did until round 6
-        const bool in_kernel = packed == 1 && !heads && !(grid.x > LEAN_FROM_TILES && lean_mode() >= 1 && !rider);
+        const bool in_kernel = packed && !heads && (packed == 2 || !(grid.x > LEAN_FROM_TILES && lean_mode() >= 1 && !rider));
         if (in_kernel) {
             la.m_ji = (const float4*)agg->m_ji, la.m_nb = (const float4*)agg->m_nb, la.s = (const float4*)agg->s;
             la.q3 = (const float4*)agg->q3, la.init = (const float4*)agg->init, la.t_ptr = agg->t_ptr, la.t_col = agg->t_col;
@@ -1662,11 +1621,11 @@ static int tail_fwd_launch(const float* x2, const float* res_x, int64_t n, const
         rd.n_chain = (int)grid.x;
         if (packed == 2)
             hipLaunchKernelGGL((node_tail_fwd_bf16_kernel<true>), dim3(grid.x + (unsigned)rider_wgs), dim3(WG), 0, st, x2,
-                               res_x, n, tp, Z, R, x_out, nx, rd);
+                               res_x, n, tp, Z, R, x_out, nx, rd, la);
         else
             hipLaunchKernelGGL((node_tail_fwd_kernel<true, false, true>), dim3(grid.x + (unsigned)rider_wgs), dim3(WG), 0, st,
                                x2, res_x, n, tp, Z, R, x_out, out, att, nx, rd, la);
-    } else if (packed == 2) hipLaunchKernelGGL((node_tail_fwd_bf16_kernel<false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, nx);
+    } else if (packed == 2) hipLaunchKernelGGL((node_tail_fwd_bf16_kernel<false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, nx, Mlp2Rider{}, la);
     else if (packed && heads) hipLaunchKernelGGL((node_tail_fwd_kernel<true, true>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
     else if (packed && grid.x > LEAN_FROM_TILES && lean_mode() >= 1) hipLaunchKernelGGL(node_tail_fwd_lean_kernel, grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, nx);
     else if (packed) hipLaunchKernelGGL((node_tail_fwd_kernel<true, false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx, Mlp2Rider{}, la);

@@ -14,6 +14,8 @@ so = '/tmp/libpamnet_tailprobe.so'
 subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
                        '-DPAMNET_PHASE_PROBE', '-I' + os.path.join(REPO, 'include'), '-I' + CSRC, '-ffp-contract=on',
                        os.path.join(CSRC, 'node_tail.hip'), '-o', so])
+# (node_tail.hip calls entry points of other translation units: resolved from the product library)
+ctypes.CDLL(os.path.join(REPO, 'physics-aware-multiplex-gnn_amd', 'pamnet_amd', 'libpamnet_hip.so'), mode=ctypes.RTLD_GLOBAL)
 lib = ctypes.CDLL(so)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2286
 dev = torch.device('cuda:0')
