@@ -32,6 +32,10 @@ extern "C" {
 /* flag bit of pamnet_local_bwd_pair_f32's accumulate_dx (bit 0 = accumulate): W1 / W2 are fragment images, see
  * pamnet_pack_weights_mixed_f32 */
 #define PAMNET_WEIGHT_IMAGES 2
+/* flag bit of `nblk` of pamnet_node_pre_tail_bwd(_gather)_f32: every weight image of the call is a bf16x3 (kind-1, transposed)
+ * one, and the launch runs its GEMMs as bf16x6 piece products (single-round batches; pamnet_node_tail_main_bwd_f32 takes
+ * packed == 2 for the same) */
+#define PAMNET_CHAIN_PIECES 16
 
 typedef void* pamnet_stream_t; /* hipStream_t */
 
@@ -431,7 +435,8 @@ int pamnet_node_tail_main_bwd_f32(const float* d_xout, const float* g_head, int6
                                   pamnet_stream_t stream);
 /* pamnet_node_pre_bwd_f32 (backward of a layer's head: dP [nblk][n][128], d x1_direct, d_add -> dZx1 and d x) fused
  * with pamnet_node_tail_main_bwd_f32 of the chain that produced that layer's input: the head's d x becomes the chain's
- * d x_out on chip.  All weights are transposed-orientation images (pamnet_pack_weights_f32). */
+ * d x_out on chip.  All weights are transposed-orientation images (pamnet_pack_weights_f32; with nblk | PAMNET_CHAIN_PIECES:
+ * bf16x3 images, the chain on the bf16 matrix pipe at fp32 accuracy). */
 int pamnet_node_pre_tail_bwd_f32(const float* dP, const float* dx1_direct, const float* d_add, int64_t n,
                                  const float* Wx1, const float* const* wp, int64_t nblk, const float* Zx1, float* dZx1,
                                  const float* g_head, const float* const* weights, const float* Z, float* dZ,

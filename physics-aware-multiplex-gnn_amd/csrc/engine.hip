@@ -659,18 +659,23 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
         const float *we, *wea, *w1, *w2, *wq[4];
     };
     std::vector<EdgeImgT> eimg_store((eimg || limg) ? (size_t)n_layer : 0);
+    // the chain launches of single-round batches on the bf16 matrix pipe (node_tail_bwd_bf16_kernel): bf16x3 images for everything
+    // they multiply by; fp32 images for the heads' matrices 7..9 and for the first layer's stand-alone head backward
+    static const bool bwd_on = [] { const char* e = getenv("PAMNET_CHAIN_BF16"); return !e || atoi(e) != 2; }();   // (2: forward only)
+    const bool cbb = packed && chain_bf16() && bwd_on && (g.n + 15) / 16 <= 256;
+    const int64_t pcs = cbb ? PAMNET_CHAIN_PIECES : 0;
     if (packed) {
-        PackList pl(wpack, 1, st, false, wpack + n_layer * PACK_FLOATS_PER_PAIR);
+        PackList pl(wpack, 1, st, cbb, wpack + n_layer * PACK_FLOATS_PER_PAIR);
         for (int64_t k = n_layer - 1; k >= 0; --k) {
             const float* const* lp = lparams + k * NL;
             const float* const* gp = gparams + k * NG;
-            for (int i = 0; i < 10; ++i) img[k].lt[i] = pl.add(lp[LT + i], D);
+            for (int i = 0; i < 10; ++i) img[k].lt[i] = pl.add(lp[LT + i], D, i >= 7);      // (7..9: the heads' fp32 images)
             img[k].lh[0] = pl.add(lp[2], 3 * D), img[k].lh[1] = pl.add(lp[4], 3 * D);
             img[k].lh[2] = pl.add(lp[2] + D, 3 * D), img[k].lh[3] = pl.add(lp[4] + D, 3 * D);
             img[k].lh[4] = pl.add(lp[0], D);
-            for (int i = 0; i < 10; ++i) img[k].gt[i] = pl.add(gp[GT + i], D);
-            img[k].gh[0] = pl.add(gp[2], 3 * D), img[k].gh[1] = pl.add(gp[2] + D, 3 * D);
-            img[k].gh[2] = pl.add(gp[0], D);
+            for (int i = 0; i < 10; ++i) img[k].gt[i] = pl.add(gp[GT + i], D, i >= 7);
+            img[k].gh[0] = pl.add(gp[2], 3 * D, k == 0), img[k].gh[1] = pl.add(gp[2] + D, 3 * D, k == 0);
+            img[k].gh[2] = pl.add(gp[0], D, k == 0);
             if (eimg) eimg_store[k].we = pl.add_edge(gp[2] + 2 * D, 3 * D), eimg_store[k].wea = pl.add_edge(gp[4], D);
             if (limg) {
                 EdgeImgT& ei = eimg_store[k];
@@ -735,7 +740,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
     float* dz_local = dz_bufs[zflip];     // dZ of the local chain of the current pair
     if (fuse) {
         const LocalSaved ql = carve_local(const_cast<float*>(saved) + (n_layer - 1) * (gs + ls) + gs, g);
-        CK(pamnet_node_tail_main_bwd_f32(nullptr, ql.gh, g.n, img[n_layer - 1].lt, ql.Z, dz_local, t.dx2, t.dresx, pk, st));
+        CK(pamnet_node_tail_main_bwd_f32(nullptr, ql.gh, g.n, img[n_layer - 1].lt, ql.Z, dz_local, t.dx2, t.dresx, cbb ? 2 : pk, st));
     }
     for (int64_t k = n_layer - 1; k >= 0; --k) {
         const GlobalSaved s = carve_global(const_cast<float*>(saved) + k * (gs + ls), g);
@@ -784,11 +789,11 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                     CK(plan_rider(jr, t.rider_partial, g, rider.data(), &rider_a_slots));
                 }
                 if (gather_l)
-                    CK(pamnet_node_pre_tail_bwd_gather_f32(t.dP, sa, sr, sp, t.dx2, t.dresx, g.n, img[k].lh[4], img[k].lh, 4, q.Zx1,
+                    CK(pamnet_node_pre_tail_bwd_gather_f32(t.dP, sa, sr, sp, t.dx2, t.dresx, g.n, img[k].lh[4], img[k].lh, 4 | pcs, q.Zx1,
                                                            t.dZx1, s.gh, img[k].gt, s.Z, dz_global, t.dx2, t.dresx,
                                                            ride ? rider.data() : nullptr, st));
                 else
-                    CK(pamnet_node_pre_tail_bwd_f32(t.dP, t.dx2, t.dresx, g.n, img[k].lh[4], img[k].lh, 4, q.Zx1, t.dZx1, s.gh,
+                    CK(pamnet_node_pre_tail_bwd_f32(t.dP, t.dx2, t.dresx, g.n, img[k].lh[4], img[k].lh, 4 | pcs, q.Zx1, t.dZx1, s.gh,
                                                     img[k].gt, s.Z, dz_global, t.dx2, t.dresx, ride ? rider.data() : nullptr, st));
                 if (ride) CK(pamnet_wgrad_rider_enqueue_f32(wctx.data(), rider.data()));
             } else {
@@ -883,11 +888,11 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
                     const float* ga[2] = {nullptr, t.dz};
                     const int32_t* gr[2] = {nullptr, g.gT_ptr};
                     const int32_t* gq[2] = {nullptr, g.gT_perm};
-                    CK(pamnet_node_pre_tail_bwd_gather_f32(t.dPg, ga, gr, gq, t.dx2, t.dresx, g.n, img[k].gh[2], img[k].gh, 2, s.Zx1,
+                    CK(pamnet_node_pre_tail_bwd_gather_f32(t.dPg, ga, gr, gq, t.dx2, t.dresx, g.n, img[k].gh[2], img[k].gh, 2 | pcs, s.Zx1,
                                                            t.dZx1g, qp.gh, img[k - 1].lt, qp.Z, dz_local, t.dx2, t.dresx,
                                                            ride ? rider.data() : nullptr, st));
                 } else {
-                    CK(pamnet_node_pre_tail_bwd_f32(t.dPg, t.dx2, t.dresx, g.n, img[k].gh[2], img[k].gh, 2, s.Zx1, t.dZx1g, qp.gh,
+                    CK(pamnet_node_pre_tail_bwd_f32(t.dPg, t.dx2, t.dresx, g.n, img[k].gh[2], img[k].gh, 2 | pcs, s.Zx1, t.dZx1g, qp.gh,
                                                     img[k - 1].lt, qp.Z, dz_local, t.dx2, t.dresx,
                                                     ride ? rider.data() : nullptr, st));
                 }

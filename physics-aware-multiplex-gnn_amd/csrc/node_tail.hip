@@ -614,15 +614,18 @@ __global__ __launch_bounds__(WG, 3) void node_tail_fwd_lean_kernel(const float* 
 // l & 15, same k), so a lane's accumulator is row r16, channels wc + 16 n2 + 4 kg + 0..3: its pieces leave as three 8-byte
 // stores, its pre-activations as one 16-byte store.  (Until round 6 this kernel had the operands the other way round and a
 // k order of its own: 12 four-byte piece stores per lane and layer, epilogue 2 500 cycles against the fp32 form's 1 250.)
-struct WFragB {                               // a wave's 32 output channels: two 16-channel tiles = 96 VGPRs
-    edge::WFragB1 t[2];
+template <int NT>
+struct WFragB {                               // a wave's NT 16-channel tiles: 48 VGPRs each
+    edge::WFragB1 t[NT];
 };
-__device__ __forceinline__ void load_wfragb(WFragB& f, const float* __restrict__ img, int wc) {
-    edge::load_wfragb1<false, 1>(f.t[0], img, 0, wc);
-    edge::load_wfragb1<false, 1>(f.t[1], img, 0, wc + 16);
+template <int NT>
+__device__ __forceinline__ void load_wfragb(WFragB<NT>& f, const float* __restrict__ img, int wc) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) edge::load_wfragb1<false, 1>(f.t[t], img, 0, wc + 16 * t);
 }
-// acc[t] += (tile as piece planes at `in`) x (channels of slice t): 4 k-steps x 6 products x 2 tiles, small products first
-__device__ __forceinline__ void mma_planes_t(const char* __restrict__ in, const WFragB& f, f32x4 (&acc)[2]) {
+// acc[t] += (tile as piece planes at `in`) x (channels of slice t): 4 k-steps x 6 products, small products first; two independent
+// accumulator chains either way (two tiles, or one tile's k-steps {0, 1} and {2, 3})
+__device__ __forceinline__ void mma_planes_t(const char* __restrict__ in, const WFragB<2>& f, f32x4 (&acc)[2]) {
     Frag3 x[DIM / 32];
 #pragma unroll
     for (int q = 0; q < DIM / 32; ++q) x[q] = edge::lds_frag3p(in, 0, q);
@@ -642,19 +645,49 @@ __device__ __forceinline__ void mma_planes_t(const char* __restrict__ in, const 
         for (int t = 0; t < 2; ++t) acc[t] = mfma_bf16(f.t[t].p[q][0], x[q].p[0], acc[t]);
     }
 }
+__device__ __forceinline__ f32x4 mma_strip_p(const char* __restrict__ P, const edge::WFragB1& f) {
+    Frag3 x[DIM / 32];
+#pragma unroll
+    for (int q = 0; q < DIM / 32; ++q) x[q] = edge::lds_frag3p(P, 0, q);
+    f32x4 a[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int h = 0; h < DIM / 64; ++h) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[t] = mfma_bf16(f.p[h + 2 * t][2], x[h + 2 * t].p[0], a[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[t] = mfma_bf16(f.p[h + 2 * t][1], x[h + 2 * t].p[1], a[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[t] = mfma_bf16(f.p[h + 2 * t][0], x[h + 2 * t].p[2], a[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[t] = mfma_bf16(f.p[h + 2 * t][1], x[h + 2 * t].p[0], a[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[t] = mfma_bf16(f.p[h + 2 * t][0], x[h + 2 * t].p[1], a[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[t] = mfma_bf16(f.p[h + 2 * t][0], x[h + 2 * t].p[0], a[t]);
+    }
+    return a[0] + a[1];
+}
+__device__ __forceinline__ void mma_planes_t(const char* __restrict__ in, const WFragB<1>& f, f32x4 (&acc)[1]) {
+    acc[0] = mma_strip_p(in, f.t[0]);
+}
 
-template <bool RIDER>
-__global__ __launch_bounds__(WG) void node_tail_fwd_bf16_kernel(const float* __restrict__ x2,
-                                                                const float* __restrict__ res_x, int64_t n, TailParams p,
-                                                                float* __restrict__ Z, float* __restrict__ R,
-                                                                float* __restrict__ x_out, PreNext nx,
-                                                                Mlp2Rider rd = Mlp2Rider{}, LocalAgg la = LocalAgg{}) {
+// NWV waves (4: two 16-channel tiles per wave, one wave per SIMD; 8: one tile per wave, two waves per SIMD -- the epilogue of
+// one under the MFMAs of the other, as in the backward chain)
+template <bool RIDER, int NWV>
+__global__ __launch_bounds__(64 * NWV) void node_tail_fwd_bf16_kernel(const float* __restrict__ x2,
+                                                                     const float* __restrict__ res_x, int64_t n, TailParams p,
+                                                                     float* __restrict__ Z, float* __restrict__ R,
+                                                                     float* __restrict__ x_out, PreNext nx,
+                                                                     Mlp2Rider rd = Mlp2Rider{}, LocalAgg la = LocalAgg{}) {
     // fp32 tiles: res_x, h0, 7 pre-activation tiles, 3 residual taps (parked, written out once after the chain);
     // piece-plane tiles: three, rotating through the chain
     constexpr int PT = edge::PTILE;
+    constexpr int NT = 8 / NWV;                               // 16-channel tiles per wave
+    constexpr int RPP = 2 * NWV, NJ = BMN / RPP;              // sweeps: rows per pass, passes
     __shared__ __attribute__((aligned(16))) float lds[12 * SLOT + 3 * PT / 4];
     if constexpr (RIDER) {
         if ((int)blockIdx.x >= rd.n_chain) {
+            if (NWV == 8 && threadIdx.x >= 256) return;       // (the riders' 4-wave geometry: a terminated wave leaves the barrier)
             constexpr int RMT = 3;
             static_assert((12 * SLOT + 3 * PT / 4) * 4 >= RMT * edge::MLP2_TILE_B, "rider tiles must fit the chain's LDS");
             const int b = (int)blockIdx.x - rd.n_chain, nr = (int)gridDim.x - rd.n_chain;
@@ -682,33 +715,34 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_bf16_kernel(const float* __r
     const int64_t row0 = (int64_t)blockIdx.x * BMN;
     const int64_t plane = n * DIM;
     const int lane = threadIdx.x & 63, r16 = lane & 15, kg = lane >> 4;
-    const int wc = (threadIdx.x >> 6) * 32;
+    const int wc = (threadIdx.x >> 6) * (16 * NT);
+    const int sc4 = threadIdx.x & 31, sr = threadIdx.x >> 5;  // sweep coordinates: rows sr + RPP j
 
     TPROBE(40);
-    WFragB wf;
+    WFragB<NT> wf;
     load_wfragb(wf, p.W[0], wc);
     if (la.m_ji) {                                            // (workgroup-uniform) the x2 rows are formed here
-        constexpr int NJ = BMN / 8;
-        const int c4 = threadIdx.x & 31, rq = threadIdx.x >> 5;
         int64_t node[NJ];
         bool ok[NJ];
         float4 xin[NJ], rx[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) node[j] = row0 + rq + 8 * j, ok[j] = node[j] < n;
+        for (int j = 0; j < NJ; ++j) node[j] = row0 + sr + RPP * j, ok[j] = node[j] < n;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) rx[j] = ldg4z(res_x, node[j], n, DIM, c4);
-        local_agg_rows<NJ>(la, node, ok, c4, xin);
+        for (int j = 0; j < NJ; ++j) rx[j] = ldg4z(res_x, node[j], n, DIM, sc4);
+        local_agg_rows<NJ>(la, node, ok, sc4, xin);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            st_lds4(RX, rq + 8 * j, c4, rx[j]);
-            edge::st_pieces4(P0, rq + 8 * j, c4, xin[j]);
+            st_lds4(RX, sr + RPP * j, sc4, rx[j]);
+            edge::st_pieces4(P0, sr + RPP * j, sc4, xin[j]);
         }
     } else {
-        sweep_rows<BMN>([&](int r, int c4) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int r = sr + RPP * j;
             const int64_t g = row0 + r;
-            st_lds4(RX, r, c4, ldg4z(res_x, g, n, DIM, c4));
-            edge::st_pieces4(P0, r, c4, ldg4z(x2, g, n, DIM, c4));
-        });
+            st_lds4(RX, r, sc4, ldg4z(res_x, g, n, DIM, sc4));
+            edge::st_pieces4(P0, r, sc4, ldg4z(x2, g, n, DIM, sc4));
+        }
     }
     __syncthreads();
 
@@ -717,17 +751,20 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_bf16_kernel(const float* __r
     auto layer = [&](const char* in, char* dst, int k, const float* add1, const float* add2, float* dst32, float* tap,
                      const float* Wnext) {
         TPROBE(4 * k);
-        const Bias8 bv = load_bias8(p.b[k], wc);               // before the prefetch (in-order vmcnt)
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        float4 bv[NT];                                         // before the prefetch (in-order vmcnt)
+#pragma unroll
+        for (int n2 = 0; n2 < NT; ++n2) bv[n2] = *reinterpret_cast<const float4*>(p.b[k] + wc + 16 * n2 + 4 * kg);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int n2 = 0; n2 < NT; ++n2) acc[n2] = f32x4{0.f, 0.f, 0.f, 0.f};
         mma_planes_t(in, wf, acc);                             // lane: row r16, channels wc + 16 n2 + 4 kg + 0..3
         TPROBE(4 * k + 1);
         if (Wnext) load_wfragb(wf, Wnext, wc);
         float* zk = ZL + k * SLOT;
 #pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2) {
+        for (int n2 = 0; n2 < NT; ++n2) {
             const int o = r16 * LDT + wc + 16 * n2 + 4 * kg;
-            const float4 z = make_float4(acc[n2][0] + bv.v[n2].x, acc[n2][1] + bv.v[n2].y, acc[n2][2] + bv.v[n2].z,
-                                         acc[n2][3] + bv.v[n2].w);
+            const float4 z = make_float4(acc[n2][0] + bv[n2].x, acc[n2][1] + bv[n2].y, acc[n2][2] + bv[n2].z, acc[n2][3] + bv[n2].w);
             float4 a = make_float4(silu(z.x), silu(z.y), silu(z.z), silu(z.w));
             if (add1) {
                 const float4 t = *reinterpret_cast<const float4*>(add1 + o);
@@ -756,17 +793,19 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_bf16_kernel(const float* __r
     layer(P1, P0, 6, TL + SLOT, nullptr, nullptr, TL + 2 * SLOT, nx.nblk > 0 ? nx.Wx1 : nullptr);   // r3 = x_out -> P0
 
     // park -> memory: Z[7][n][128], R[2][n][128], x_out[n][128]
-    sweep_rows<BMN>([&](int r, int c4) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int r = sr + RPP * j;
         const int64_t g = row0 + r;
-        if (g >= n) return;
+        if (g >= n) continue;
         if (Z) {                                              // backward-only saves: null in inference mode
 #pragma unroll
-            for (int k = 0; k < 7; ++k) stg4(Z + (int64_t)k * plane, g, DIM, c4, lds4(ZL + k * SLOT, r, c4));
-            stg4(R, g, DIM, c4, lds4(TL, r, c4));
-            stg4(R + plane, g, DIM, c4, lds4(TL + SLOT, r, c4));
+            for (int k = 0; k < 7; ++k) stg4(Z + (int64_t)k * plane, g, DIM, sc4, lds4(ZL + k * SLOT, r, sc4));
+            stg4(R, g, DIM, sc4, lds4(TL, r, sc4));
+            stg4(R + plane, g, DIM, sc4, lds4(TL + SLOT, r, sc4));
         }
-        stg4(x_out, g, DIM, c4, lds4(TL + 2 * SLOT, r, c4));
-    });
+        stg4(x_out, g, DIM, sc4, lds4(TL + 2 * SLOT, r, sc4));
+    }
     TPROBE(41);
 
     // ---- the next layer's head on the x_out tile (its planes are in P0); outputs reuse the z_k parking slots, which the
@@ -774,15 +813,19 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_bf16_kernel(const float* __r
     if (nx.nblk > 0) {
         __syncthreads();
         {
-            const Bias8 bv = load_bias8(nx.bx1, wc);
-            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            float4 bv[NT];
+#pragma unroll
+            for (int n2 = 0; n2 < NT; ++n2) bv[n2] = *reinterpret_cast<const float4*>(nx.bx1 + wc + 16 * n2 + 4 * kg);
+            f32x4 acc[NT];
+#pragma unroll
+            for (int n2 = 0; n2 < NT; ++n2) acc[n2] = f32x4{0.f, 0.f, 0.f, 0.f};
             mma_planes_t(P0, wf, acc);
             load_wfragb(wf, nx.wp[0], wc);
 #pragma unroll
-            for (int n2 = 0; n2 < 2; ++n2) {
+            for (int n2 = 0; n2 < NT; ++n2) {
                 const int o = r16 * LDT + wc + 16 * n2 + 4 * kg;
-                const float4 z = make_float4(acc[n2][0] + bv.v[n2].x, acc[n2][1] + bv.v[n2].y, acc[n2][2] + bv.v[n2].z,
-                                             acc[n2][3] + bv.v[n2].w);
+                const float4 z = make_float4(acc[n2][0] + bv[n2].x, acc[n2][1] + bv[n2].y, acc[n2][2] + bv[n2].z,
+                                             acc[n2][3] + bv[n2].w);
                 const float4 a = make_float4(silu(z.x), silu(z.y), silu(z.z), silu(z.w));
                 *reinterpret_cast<float4*>(ZL + o) = z;                    // Zx1
                 *reinterpret_cast<float4*>(ZL + SLOT + o) = a;             // x1
@@ -791,24 +834,28 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_bf16_kernel(const float* __r
             __syncthreads();
         }
         for (int b = 0; b < nx.nblk; ++b) {
-            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            f32x4 acc[NT];
+#pragma unroll
+            for (int n2 = 0; n2 < NT; ++n2) acc[n2] = f32x4{0.f, 0.f, 0.f, 0.f};
             mma_planes_t(P1, wf, acc);
             if (b + 1 < nx.nblk) load_wfragb(wf, nx.wp[b + 1], wc);
             float* pb = ZL + (2 + b) * SLOT;
 #pragma unroll
-            for (int n2 = 0; n2 < 2; ++n2)
+            for (int n2 = 0; n2 < NT; ++n2)
                 *reinterpret_cast<float4*>(pb + r16 * LDT + wc + 16 * n2 + 4 * kg) =
                     make_float4(acc[n2][0], acc[n2][1], acc[n2][2], acc[n2][3]);
         }
         __syncthreads();
         TPROBE(42);
-        sweep_rows<BMN>([&](int r, int c4) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int r = sr + RPP * j;
             const int64_t g = row0 + r;
-            if (g >= n) return;
-            if (nx.Zx1) stg4(nx.Zx1, g, DIM, c4, lds4(ZL, r, c4));
-            stg4(nx.x1, g, DIM, c4, lds4(ZL + SLOT, r, c4));
-            for (int b = 0; b < nx.nblk; ++b) stg4(nx.P + (int64_t)b * plane, g, DIM, c4, lds4(ZL + (2 + b) * SLOT, r, c4));
-        });
+            if (g >= n) continue;
+            if (nx.Zx1) stg4(nx.Zx1, g, DIM, sc4, lds4(ZL, r, sc4));
+            stg4(nx.x1, g, DIM, sc4, lds4(ZL + SLOT, r, sc4));
+            for (int b = 0; b < nx.nblk; ++b) stg4(nx.P + (int64_t)b * plane, g, DIM, sc4, lds4(ZL + (2 + b) * SLOT, r, sc4));
+        }
         TPROBE(43);
     }
 }
@@ -1030,6 +1077,9 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
     const int c = fr.col();
     const int to = fr.r16 * LDT + fr.wc + 4 * fr.kg;          // (transposed accumulators: row r16, channels wc + 4 kg + 0..3)
     const bool trow = row0 + fr.r16 < n;                      // ... and whether that row exists
+    // (a factor, not a select: with `trow ? x : 0` the compiler runs the four SiLU' sequences of a lane one after the other under
+    // exec masks -- four dependent exp / rcp chains in a row -- instead of interleaved; the rows past n are zero either way)
+    const float tmask = trow ? 1.f : 0.f;
 
     constexpr int KTOP = HEADS ? 9 : 6;                       // first matrix of the backward chain
     constexpr int NZ = HEADS ? 10 : 7;
@@ -1150,7 +1200,7 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
         const f32x4 z6 = lds_f32x4(ZL + 6 * SLOT + to), kv = lds_f32x4(K + to);
         f32x4 dz;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dz[r] = trow ? kv[r] * dsilu(z6[r]) : 0.f;
+        for (int r = 0; r < 4; ++r) dz[r] = kv[r] * dsilu(z6[r]) * tmask;
         st_f32x4(D1 + to, dz);
         st_f32x4(ZL + 6 * SLOT + to, dz);
         __syncthreads();
@@ -1159,9 +1209,11 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
     // One backward step: v = dz_k * W_k (+ K) ; optionally K <- v, extra <- v ; then dz_{k-1} = v * SiLU'(z_{k-1}).
     // k == 0 ends the chain: v = d x2 (left in dst).
     auto back = [&](const float* in, float* dst, int k, bool add_k, bool keep_k, float* extra) {
+        TPROBE(4 * k);
         f32x4 zn = {0.f, 0.f, 0.f, 0.f};
         if (k > 0) zn = lds_f32x4(ZL + (k - 1) * SLOT + to);
         f32x4 v = mma_strip_t(in, wf);
+        TPROBE(4 * k + 1);
         if (k > 0) {
             if constexpr (PACKED) load_wfrag1_img(wf, p.W[k - 1]);
             else load_wfrag1<true>(wf, p.W[k - 1], fr.wc);
@@ -1174,11 +1226,13 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
         } else {
             f32x4 dz;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dz[r] = trow ? v[r] * dsilu(zn[r]) : 0.f;
+            for (int r = 0; r < 4; ++r) dz[r] = v[r] * dsilu(zn[r]) * tmask;
             st_f32x4(dst + to, dz);
             st_f32x4(ZL + (k - 1) * SLOT + to, dz);
         }
+        TPROBE(4 * k + 2);
         __syncthreads();
+        TPROBE(4 * k + 3);
     };
 
     if constexpr (HEADS) {
@@ -1200,6 +1254,164 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_kernel(const float* __restr
         stg4(d_x2, sg, DIM, sc4, lds4(D0, sr, sc4));
         stg4(d_resx, sg, DIM, sc4, lds4(EX, sr, sc4));
         if constexpr (PRE) stg4(pb.dZx1, sg, DIM, sc4, lds4(red, sr, sc4));
+    }
+}
+
+// ---- the backward chain on the bf16 matrix pipe at fp32 accuracy ("bf16x6") ----------------------------------------------
+// node_tail_bwd_kernel<true, false, PRE> (packed weights, deferred heads: the production form of single-round batches) with
+// every GEMM as six bf16 piece products, the way node_tail_fwd_bf16_kernel runs the forward: 24 v_mfma_f32_16x16x32_bf16 per
+// wave and layer (two waves per SIMD: 768 matrix-pipe cycles) instead of 32 fp32 MFMAs (2 048).  Every GEMM input -- the head's
+// d P planes, dz_x1, the dz_k ping / pong -- is written once as three bf16 piece planes (edge_core.h st_pieces4) by the sweep or
+// the epilogue that forms it; the weights are kind-1 fragment images in the transposed orientation, the A operand of the MFMA
+// (operands swapped, mma_strip_t: a lane holds row r16, channels wc + 4 kg + 0..3).  The fp32 tiles that are not GEMM inputs
+// (z_k / dz_k, the kept residual gradient, d res_x, d x2) stay as they were.
+__device__ __forceinline__ void st_pieces_acc(char* __restrict__ P, const Frag& fr, const f32x4& v) {
+    edge::st_pieces4(P, fr.r16, (fr.wc + 4 * fr.kg) >> 2, make_float4(v[0], v[1], v[2], v[3]));
+}
+
+template <bool PRE>
+__global__ __launch_bounds__(TWG) void node_tail_bwd_bf16_kernel(const float* __restrict__ d_xout /* may be null */,
+                                                                 const float* __restrict__ d_out, int64_t n, TailParams p,
+                                                                 const float* __restrict__ Z, float* __restrict__ dZ,
+                                                                 float* __restrict__ d_x2, float* __restrict__ d_resx,
+                                                                 PreBwd pb = PreBwd{}, WBatchS rider = WBatchS{},
+                                                                 float* __restrict__ rider_partial = nullptr, int n_tiles = 0) {
+    constexpr int PT = edge::PTILE;
+    __shared__ __attribute__((aligned(16))) float lds[12 * SLOT + 4 * PT / 4];
+    if constexpr (PRE) {
+        static_assert(sizeof(lds) >= sizeof(float) * WGRAD_LDS_FLOATS, "rider staging must fit the chain's LDS");
+        if ((int)blockIdx.x >= n_tiles) {                     // riders: see node_tail_bwd_kernel
+#ifndef PAMNET_RIDER_4W
+            wgrad_body<8>(rider, rider_partial, (int)blockIdx.x - n_tiles, lds);
+#else
+            if (threadIdx.x < 256) wgrad_body<4>(rider, rider_partial, (int)blockIdx.x - n_tiles, lds);
+#endif
+            return;
+        }
+    }
+    float* D0 = lds;                  // fp32: the head's d x1 partial, at the end d x2
+    float* D1 = lds + SLOT;           // fp32: d x1_direct
+    float* K = lds + 2 * SLOT;        // residual gradient kept across a Res block
+    float* EX = lds + 3 * SLOT;       // z_x1, then d res_x
+    float* ZL = lds + 4 * SLOT;       // [7] z_k, then dz_k
+    float* RED = lds + 11 * SLOT;     // dz_x1, parked for the final coalesced store
+    char* PL = reinterpret_cast<char*>(lds + 12 * SLOT);      // [4] piece planes: the d P planes, then dz_x1 | dz ping | dz pong
+    const int64_t row0 = (int64_t)blockIdx.x * BMN;
+    const int64_t plane = n * DIM;
+    const Frag fr;
+    const int to = fr.r16 * LDT + fr.wc + 4 * fr.kg;          // (transposed accumulators: row r16, channels wc + 4 kg + 0..3)
+    const bool trow = row0 + fr.r16 < n;
+    // (a factor, not a select: with `trow ? x : 0` the compiler runs the four SiLU' sequences of a lane one after the other under
+    // exec masks -- four dependent exp / rcp chains in a row -- instead of interleaved; the rows past n are zero either way)
+    const float tmask = trow ? 1.f : 0.f;
+
+    edge::WFragB1 wf;
+    edge::load_wfragb1<true, 1>(wf, PRE ? pb.wp[0] : p.W[6], 0, fr.wc);
+    const int sc4 = threadIdx.x & 31, sr = threadIdx.x >> 5;          // sweep coordinates: 512 threads = 16 rows x 32 float4
+    const int64_t sg = row0 + sr;
+    {
+        GatherState gst;
+        if constexpr (PRE) gather_begin(gst, pb, sg, sg < n);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) st_lds4(ZL + k * SLOT, sr, sc4, ldg4z(Z + (int64_t)k * plane, sg, n, DIM, sc4));
+        float4 kx = d_xout ? ldg4z(d_xout, sg, n, DIM, sc4) : f4zero();
+        kx = f4add(kx, ldg4z(d_out, sg, n, DIM, sc4));         // + the head branch's d x_out
+        if constexpr (PRE) {
+            float4 gsum[4];
+            gather_finish(gst, pb, sc4, gsum);                 // (rows past n: empty ranges, zeros)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b >= pb.nblk) break;
+                float4 v;
+                if (pb.gsrc[b]) {                              // (workgroup-uniform) the plane is formed here, and kept
+                    v = gsum[b];
+                    if (sg < n) stg4(pb.dP_out + (int64_t)b * plane, sg, DIM, sc4, v);
+                } else {
+                    v = ldg4z(pb.dP + (int64_t)b * plane, sg, n, DIM, sc4);
+                }
+                edge::st_pieces4(PL + b * PT, sr, sc4, v);
+            }
+            st_lds4(EX, sr, sc4, ldg4z(pb.Zx1, sg, n, DIM, sc4));
+            st_lds4(D1, sr, sc4, ldg4z(pb.dx1_direct, sg, n, DIM, sc4));
+            kx = f4add(kx, ldg4z(pb.d_add, sg, n, DIM, sc4));
+        }
+        st_lds4(K, sr, sc4, kx);
+    }
+    __syncthreads();
+
+    if constexpr (PRE) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < pb.nblk; ++b) {
+            acc += mma_strip_p(PL + b * PT, wf);
+            edge::load_wfragb1<true, 1>(wf, b + 1 < pb.nblk ? pb.wp[b + 1] : pb.Wx1, 0, fr.wc);
+        }
+        st_f32x4(D0 + to, acc);
+        __syncthreads();
+        {   // dz_x1 = (d x1) * SiLU'(z_x1): as pieces over the first d P plane (read for the last time before the barrier above),
+            // and parked in RED for the final coalesced store
+            const float4 d1 = f4add(lds4(D0, sr, sc4), lds4(D1, sr, sc4));
+            const float4 dzx = f4mul(d1, f4dsilu(lds4(EX, sr, sc4)));
+            edge::st_pieces4(PL, sr, sc4, dzx);
+            st_lds4(RED, sr, sc4, dzx);
+        }
+        __syncthreads();
+        const f32x4 a2 = mma_strip_p(PL, wf);
+        edge::load_wfragb1<true, 1>(wf, p.W[6], 0, fr.wc);
+        st_f32x4(K + to, lds_f32x4(K + to) + a2);              // d x_out = head's d x + d_add + g_head
+        __syncthreads();
+    }
+    char* const PA = PL + PT;
+    char* const PB = PL + 2 * PT;
+    {
+        // dz6 = d r3 * SiLU'(z6), d r3 = d x_out (next layer + head branch) already in K
+        const f32x4 z6 = lds_f32x4(ZL + 6 * SLOT + to), kv = lds_f32x4(K + to);
+        f32x4 dz;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dz[r] = kv[r] * dsilu(z6[r]) * tmask;
+        st_pieces_acc(PA, fr, dz);
+        st_f32x4(ZL + 6 * SLOT + to, dz);
+        __syncthreads();
+    }
+
+    // One backward step: v = dz_k * W_k (+ K) ; optionally K <- v, extra <- v ; then dz_{k-1} = v * SiLU'(z_{k-1}) -> planes dst.
+    // k == 0 ends the chain: v = d x2 (left in D0).
+    auto back = [&](const char* in, char* dst, int k, bool add_k, bool keep_k, float* extra) {
+        TPROBE(4 * k);
+        f32x4 zn = {0.f, 0.f, 0.f, 0.f};
+        if (k > 0) zn = lds_f32x4(ZL + (k - 1) * SLOT + to);
+        f32x4 v = mma_strip_p(in, wf);
+        TPROBE(4 * k + 1);
+        if (k > 0) edge::load_wfragb1<true, 1>(wf, p.W[k - 1], 0, fr.wc);
+        if (add_k) v += lds_f32x4(K + to);
+        if (keep_k) st_f32x4(K + to, v);
+        if (extra) st_f32x4(extra + to, v);
+        if (k == 0) {
+            st_f32x4(D0 + to, v);
+        } else {
+            f32x4 dz;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz[r] = v[r] * dsilu(zn[r]) * tmask;
+            st_pieces_acc(dst, fr, dz);
+            st_f32x4(ZL + (k - 1) * SLOT + to, dz);
+        }
+        TPROBE(4 * k + 2);
+        __syncthreads();
+        TPROBE(4 * k + 3);
+    };
+    back(PA, PB, 6, false, false, nullptr);        // d a5          -> dz5
+    back(PB, PA, 5, true, true, nullptr);          // d r2 = . + d r3 (kept)      -> dz4
+    back(PA, PB, 4, false, false, nullptr);        // d a3          -> dz3
+    back(PB, PA, 3, true, true, EX);               // d r1 = . + d r2 (kept, = d res_x) -> dz2
+    back(PA, PB, 2, false, false, nullptr);        // d a1          -> dz1
+    back(PB, PA, 1, true, false, nullptr);         // d h0 = . + d r1             -> dz0
+    back(PA, nullptr, 0, false, false, nullptr);   // d x2 -> D0
+
+    if (sg < n) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) stg4(dZ + (int64_t)k * plane, sg, DIM, sc4, lds4(ZL + k * SLOT, sr, sc4));
+        stg4(d_x2, sg, DIM, sc4, lds4(D0, sr, sc4));
+        stg4(d_resx, sg, DIM, sc4, lds4(EX, sr, sc4));
+        if constexpr (PRE) stg4(pb.dZx1, sg, DIM, sc4, lds4(RED, sr, sc4));
     }
 }
 
@@ -1397,6 +1609,9 @@ __global__ __launch_bounds__(TWG) void node_heads_bwd_kernel(HeadBwdBatch hb, in
     // v = dz_k * W_k; k > 7: dz_{k-1} = v * SiLU'(z_{k-1}); k == 7: v = the branch's d x_out
     const int to = fr.r16 * LDT + fr.wc + 4 * fr.kg;          // (operands swapped: row r16, channels wc + 4 kg + 0..3; mma_strip_t)
     const bool trow = row0 + fr.r16 < n;
+    // (a factor, not a select: with `trow ? x : 0` the compiler runs the four SiLU' sequences of a lane one after the other under
+    // exec masks -- four dependent exp / rcp chains in a row -- instead of interleaved; the rows past n are zero either way)
+    const float tmask = trow ? 1.f : 0.f;
     auto back = [&](const float* in, float* dst, int k) {
         f32x4 zn = {0.f, 0.f, 0.f, 0.f};
         if (k > 7) zn = lds_f32x4(ZL + (k - 8) * SLOT + to);
@@ -1410,7 +1625,7 @@ __global__ __launch_bounds__(TWG) void node_heads_bwd_kernel(HeadBwdBatch hb, in
         } else {
             f32x4 dz;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dz[r] = trow ? acc[r] * dsilu(zn[r]) : 0.f;
+            for (int r = 0; r < 4; ++r) dz[r] = acc[r] * dsilu(zn[r]) * tmask;
             st_f32x4(dst + to, dz);
             st_f32x4(ZL + (k - 8) * SLOT + to, dz);
         }
@@ -1569,6 +1784,12 @@ extern "C" int pamnet_pack_weights_bf16x3(int64_t n, const float* const* W, cons
     return pamnet_pack_weights_mixed_f32(n, W, ld, kind, offset, transposed, images, stream);
 }
 
+// PAMNET_CHAIN_WAVES=4|8: the bf16x6 forward chain's workgroup geometry (read once, for A/B timing)
+static int chain_waves() {
+    static const int v = [] { const char* e = getenv("PAMNET_CHAIN_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+    return v;
+}
+
 static int tail_fwd_launch(const float* x2, const float* res_x, int64_t n, const float* const* weights,
                            const float* const* biases, const float* w_out, const float* b_out, const float* w_att, float* Z,
                            float* R, float* x_out, float* out, float* att, const float* next_Wx1, const float* next_bx1,
@@ -1620,12 +1841,17 @@ static int tail_fwd_launch(const float* x2, const float* res_x, int64_t n, const
         Mlp2Rider rd = *rider;
         rd.n_chain = (int)grid.x;
         if (packed == 2)
-            hipLaunchKernelGGL((node_tail_fwd_bf16_kernel<true>), dim3(grid.x + (unsigned)rider_wgs), dim3(WG), 0, st, x2,
-                               res_x, n, tp, Z, R, x_out, nx, rd, la);
+            if (chain_waves() == 8)
+                hipLaunchKernelGGL((node_tail_fwd_bf16_kernel<true, 8>), dim3(grid.x + (unsigned)rider_wgs), dim3(TWG), 0, st, x2,
+                                   res_x, n, tp, Z, R, x_out, nx, rd, la);
+            else
+                hipLaunchKernelGGL((node_tail_fwd_bf16_kernel<true, 4>), dim3(grid.x + (unsigned)rider_wgs), dim3(WG), 0, st, x2,
+                                   res_x, n, tp, Z, R, x_out, nx, rd, la);
         else
             hipLaunchKernelGGL((node_tail_fwd_kernel<true, false, true>), dim3(grid.x + (unsigned)rider_wgs), dim3(WG), 0, st,
                                x2, res_x, n, tp, Z, R, x_out, out, att, nx, rd, la);
-    } else if (packed == 2) hipLaunchKernelGGL((node_tail_fwd_bf16_kernel<false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, nx, Mlp2Rider{}, la);
+    } else if (packed == 2 && chain_waves() == 8) hipLaunchKernelGGL((node_tail_fwd_bf16_kernel<false, 8>), grid, dim3(TWG), 0, st, x2, res_x, n, tp, Z, R, x_out, nx, Mlp2Rider{}, la);
+    else if (packed == 2) hipLaunchKernelGGL((node_tail_fwd_bf16_kernel<false, 4>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, nx, Mlp2Rider{}, la);
     else if (packed && heads) hipLaunchKernelGGL((node_tail_fwd_kernel<true, true>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx);
     else if (packed && grid.x > LEAN_FROM_TILES && lean_mode() >= 1) hipLaunchKernelGGL(node_tail_fwd_lean_kernel, grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, nx);
     else if (packed) hipLaunchKernelGGL((node_tail_fwd_kernel<true, false>), grid, dim3(WG), 0, st, x2, res_x, n, tp, Z, R, x_out, out, att, nx, Mlp2Rider{}, la);
@@ -1772,7 +1998,10 @@ extern "C" int pamnet_node_tail_main_bwd_f32(const float* d_xout, const float* g
     TailParams tp{};
     for (int k = 0; k < 7; ++k) tp.W[k] = weights[k];
     tp.packed = packed ? 1 : 0;
-    if (packed && grid > LEAN_FROM_TILES && lean_mode() >= 2)
+    if (packed == 2)                                          // bf16x3 (kind-1, transposed) images: the bf16x6 chain
+        hipLaunchKernelGGL((node_tail_bwd_bf16_kernel<false>), dim3(grid), dim3(TWG), 0, st, d_xout, g_head, n, tp, Z, dZ, d_x2,
+                           d_resx);
+    else if (packed && grid > LEAN_FROM_TILES && lean_mode() >= 2)
         hipLaunchKernelGGL((node_tail_bwd_lean_kernel<false>), dim3(grid), dim3(TWG), 0, st, d_xout, g_head, n, tp, Z, dZ, d_x2,
                            d_resx, PreBwd{});
     else if (packed)
@@ -1794,6 +2023,8 @@ static int node_pre_tail_bwd_impl(float* dP, const float* const* gsrc, const int
                                   float* dZx1, const float* g_head, const float* const* weights,
                                   const float* Z, float* dZ, float* d_x2, float* d_resx,
                                   const void* rider, pamnet_stream_t stream) {
+    const bool pieces = nblk >= 0 && (nblk & PAMNET_CHAIN_PIECES) != 0;      // every image a bf16x3 (kind-1) one: the bf16x6 chain
+    if (pieces) nblk &= ~(int64_t)PAMNET_CHAIN_PIECES;
     if (n < 0 || nblk < 1 || nblk > 4) return PAMNET_EINVAL;
     if (n == 0) return PAMNET_OK;
     if (!dP || !dx1_direct || !d_add || !Wx1 || !wp || !Zx1 || !dZx1 || !g_head || !weights || !Z || !dZ || !d_x2 || !d_resx)
@@ -1826,7 +2057,7 @@ static int node_pre_tail_bwd_impl(float* dP, const float* const* gsrc, const int
         const WgradRider* r = static_cast<const WgradRider*>(rider);
         rb = r->batch, rpart = r->partial, rslots = r->slots;
     }
-    const bool lean = rslots == 0 && (unsigned)n_tiles > LEAN_FROM_TILES && lean_mode() >= 2;
+    const bool lean = !pieces && rslots == 0 && (unsigned)n_tiles > LEAN_FROM_TILES && lean_mode() >= 2;
     if (lean && any_gather) {
         // the lean form reads its planes: form them with the batched segment-sum launch first (what the engine did until round 6)
         float* so[4];
@@ -1839,7 +2070,10 @@ static int node_pre_tail_bwd_impl(float* dP, const float* const* gsrc, const int
         if (rc) return rc;
         for (int b = 0; b < 4; ++b) pb.gsrc[b] = nullptr;
     }
-    if (lean)
+    if (pieces)
+        hipLaunchKernelGGL((node_tail_bwd_bf16_kernel<true>), dim3((unsigned)(n_tiles + rslots)), dim3(TWG), 0, as_stream(stream),
+                           (const float*)nullptr, g_head, n, tp, Z, dZ, d_x2, d_resx, pb, rb, rpart, n_tiles);
+    else if (lean)
         hipLaunchKernelGGL((node_tail_bwd_lean_kernel<true>), dim3((unsigned)n_tiles), dim3(TWG), 0, as_stream(stream),
                            (const float*)nullptr, g_head, n, tp, Z, dZ, d_x2, d_resx, pb);
     else

@@ -540,3 +540,51 @@ def test_lean_backward_chain_equals_the_parked_one(dev, nblk):
         assert not torch.isnan(a).any(), name
         assert torch.equal(a, c), name
     assert not torch.isnan(big[1][n_small:]).any() and big[1][n_small:].abs().max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nblk', [0, 2, 4])
+@pytest.mark.parametrize('n', [1, 37, 2286])
+def test_backward_chain_on_the_bf16_pipe(dev, nblk, n):
+    """Round 6: node_tail_bwd_bf16_kernel (packed == 2 / nblk | PAMNET_CHAIN_PIECES: bf16x3 images in the transposed orientation,
+    every GEMM six bf16 piece products) against the fp32-MFMA chain on the same inputs: every output within 2e-6 of the
+    outputs' scale (seven chained GEMMs and, with nblk > 0, the head's in front; the error of one bf16x6 GEMM against an fp32
+    one is ~3e-7), padding rows never read, in-place d_x2 / d_resx as the engine calls it."""
+    from pamnet_amd import lib
+    from pamnet_amd.fused import _parr, _iarr
+    PIECES = 16                                                   # PAMNET_CHAIN_PIECES
+    torch.manual_seed(23 + nblk + n)
+    NW = 12
+    W = [(torch.randn(D, D, device=dev) * 0.08) for _ in range(NW)]
+    img32 = torch.empty(NW, D * D, device=dev)
+    img16 = torch.empty(NW, 3 * D * D // 2, device=dev)
+    lib.call('pamnet_pack_weights_f32', NW, _parr(W), _iarr([D] * NW), 1, lib.ptr(img32), lib.stream_of(img32))
+    lib.call('pamnet_pack_weights_bf16x3', NW, _parr(W), _iarr([D] * NW), 1, lib.ptr(img16), lib.stream_of(img16))
+    Z = torch.randn(10, n, D, device=dev)
+    g_head, dP = torch.randn(n, D, device=dev), torch.randn(4, n, D, device=dev)
+    dx1, dadd, zx1 = torch.randn(n, D, device=dev), torch.randn(n, D, device=dev), torch.randn(n, D, device=dev)
+    d_xout = torch.randn(n, D, device=dev)
+
+    def run(images, pieces):
+        img = [images[i] for i in range(NW)]
+        dZ = torch.full((10, n, D), float('nan'), device=dev)
+        if nblk == 0:
+            dx2, drx = torch.full((n, D), float('nan'), device=dev), torch.full((n, D), float('nan'), device=dev)
+            lib.call('pamnet_node_tail_main_bwd_f32', lib.ptr(d_xout), lib.ptr(g_head), n, _parr(img[:7]), lib.ptr(Z), lib.ptr(dZ),
+                     lib.ptr(dx2), lib.ptr(drx), 2 if pieces else 1, lib.stream_of(Z))
+            return dZ[:7], dx2, drx, None
+        dx2, drx = dx1.clone(), dadd.clone()
+        dzx1 = torch.full((n, D), float('nan'), device=dev)
+        lib.call('pamnet_node_pre_tail_bwd_f32', lib.ptr(dP[:nblk].contiguous()), lib.ptr(dx2), lib.ptr(drx), n, lib.ptr(img[7]),
+                 _parr(img[8:8 + nblk]), nblk | (PIECES if pieces else 0), lib.ptr(zx1), lib.ptr(dzx1), lib.ptr(g_head),
+                 _parr(img[:7]), lib.ptr(Z), lib.ptr(dZ), lib.ptr(dx2), lib.ptr(drx), None, lib.stream_of(Z))
+        return dZ[:7], dx2, drx, dzx1
+
+    ref, got = run(img32, False), run(img16, True)
+    torch.cuda.synchronize()
+    for name, a, c in zip(['dZ', 'd_x2', 'd_resx', 'dZx1'], got, ref):
+        if a is None:
+            continue
+        assert not torch.isnan(a).any(), name
+        err = (a - c).abs().max().item() / c.abs().max().item()
+        assert err < 2e-6, (name, err)
