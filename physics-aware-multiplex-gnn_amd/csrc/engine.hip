@@ -297,6 +297,12 @@ inline bool fuse_local_agg(const Graph& g) {
     static const bool v = [] { const char* e = getenv("PAMNET_FUSE_LOCAL_AGG"); return !e || atoi(e) != 0; }();
     return v && (g.n + 15) / 16 <= 256;
 }
+// (row tiles up to which the bf16x6 chains run: they park a tile's state in LDS, one workgroup per CU -- single-round batches;
+// PAMNET_CHAIN_BF16_TILES overrides, for measurements)
+inline int64_t chain_bf16_tiles() {
+    static const int64_t v = [] { const char* e = getenv("PAMNET_CHAIN_BF16_TILES"); return e ? (int64_t)atoll(e) : (int64_t)256; }();
+    return v;
+}
 inline bool chain_bf16() {
     static bool v = [] { const char* e = getenv("PAMNET_CHAIN_BF16"); return !e || atoi(e) != 0; }();
     return v;
@@ -468,7 +474,7 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
     PairImg* img = packed ? img_store.data() : nullptr;
     // bf16x3 images for everything the chains multiply by (matrices 0..6 + the fused heads of the next layers), fp32
     // images for the mlp_out matrices 7..9 (node_heads_fwd_kernel)
-    const bool cb = packed && chain_bf16() && (g.n + 15) / 16 <= 256;      // (one workgroup per CU: single-round batches)
+    const bool cb = packed && chain_bf16() && (g.n + 15) / 16 <= chain_bf16_tiles();      // (one workgroup per CU: single-round batches)
     // edge-level fragment images (region behind the chain images): W_e, W_ea of the global step, the local edge step's slices
     const bool eimg = packed && edge_images();
     struct EdgeImg {
@@ -662,7 +668,7 @@ extern "C" int pamnet_stack_bwd_f32(const int64_t* sizes, const int32_t* const* 
     // the chain launches of single-round batches on the bf16 matrix pipe (node_tail_bwd_bf16_kernel): bf16x3 images for everything
     // they multiply by; fp32 images for the heads' matrices 7..9 and for the first layer's stand-alone head backward
     static const bool bwd_on = [] { const char* e = getenv("PAMNET_CHAIN_BF16"); return !e || atoi(e) != 2; }();   // (2: forward only)
-    const bool cbb = packed && chain_bf16() && bwd_on && (g.n + 15) / 16 <= 256;
+    const bool cbb = packed && chain_bf16() && bwd_on && (g.n + 15) / 16 <= chain_bf16_tiles();
     const int64_t pcs = cbb ? PAMNET_CHAIN_PIECES : 0;
     if (packed) {
         PackList pl(wpack, 1, st, cbb, wpack + n_layer * PACK_FLOATS_PER_PAIR);
