@@ -95,6 +95,16 @@ struct Frag {
     __device__ __forceinline__ int col() const { return wc + r16; }
 };
 
+// A pointer the caller guarantees: `if (Wnext) <request the next layer's weights>` inside a layer body that is inlined with a
+// run-time pointer keeps its branch, and behind the join the compiler must assume the requests were NOT made -- the wait for the
+// layer's bias (requested before them; vmcnt retires in order) becomes s_waitcnt vmcnt(0): the epilogue waited for the whole next
+// weight slice, ~1 000 cycles of every forward layer (seen in the ISA, round 6).  With the pointer known non-null the requests are
+// unconditional and the bias wait counts them (vmcnt(12 / 16 / 24)).
+__device__ __forceinline__ const float* nn(const float* p) {
+    __builtin_assume(p != nullptr);
+    return p;
+}
+
 // ---- fragment-ordered weight images (pamnet_pack_weights_f32) -----------------------------------------------------------
 // Requesting a weight slice from the row-major matrix costs ~1 150 cycles of every ~5 000-cycle layer: each of the 16
 // 1 KB requests touches 16 half-used cache lines.  An image stores, for 16-column tile j and k-group q, the 64 lanes'
@@ -400,18 +410,18 @@ __global__ __launch_bounds__(WG) void node_tail_fwd_kernel(const float* __restri
         TPROBE(4 * k + 3);
     };
 
-    layer(X0, A, 0, nullptr, nullptr, nullptr, p.W[1]);        // h0 -> A
-    layer(A, B, 1, nullptr, nullptr, nullptr, p.W[2]);         // a1 -> B
-    layer(B, C, 2, A, RX, TL, p.W[3]);                         // r1 -> C   (+ h0 + res_x)
-    layer(C, A, 3, nullptr, nullptr, nullptr, p.W[4]);         // a3 -> A
-    layer(A, B, 4, C, nullptr, TL + SLOT, p.W[5]);             // r2 -> B   (+ r1)
-    layer(B, A, 5, nullptr, nullptr, nullptr, p.W[6]);         // a5 -> A
+    layer(X0, A, 0, nullptr, nullptr, nullptr, nn(p.W[1]));        // h0 -> A
+    layer(A, B, 1, nullptr, nullptr, nullptr, nn(p.W[2]));         // a1 -> B
+    layer(B, C, 2, A, RX, TL, nn(p.W[3]));                         // r1 -> C   (+ h0 + res_x)
+    layer(C, A, 3, nullptr, nullptr, nullptr, nn(p.W[4]));         // a3 -> A
+    layer(A, B, 4, C, nullptr, TL + SLOT, nn(p.W[5]));             // r2 -> B   (+ r1)
+    layer(B, A, 5, nullptr, nullptr, nullptr, nn(p.W[6]));         // a5 -> A
     constexpr int NZ = HEADS ? 10 : 7;                         // z_k tiles this kernel produces
-    layer(A, C, 6, B, nullptr, TL + 2 * SLOT, HEADS ? p.W[7] : (nx.nblk > 0 ? nx.Wx1 : nullptr));   // r3 -> C = x_out
+    layer(A, C, 6, B, nullptr, TL + 2 * SLOT, nn(HEADS ? p.W[7] : (nx.nblk > 0 ? nx.Wx1 : p.W[6])));   // r3 -> C = x_out  (no next head: any valid image)
     if constexpr (HEADS) {
-        layer(C, A, 7, nullptr, nullptr, nullptr, p.W[8]);         // o1 -> A
-        layer(A, B, 8, nullptr, nullptr, nullptr, p.W[9]);         // o2 -> B
-        layer(B, A, 9, nullptr, nullptr, nullptr, nx.nblk > 0 ? nx.Wx1 : nullptr);   // o3 -> A
+        layer(C, A, 7, nullptr, nullptr, nullptr, nn(p.W[8]));         // o1 -> A
+        layer(A, B, 8, nullptr, nullptr, nullptr, nn(p.W[9]));         // o2 -> B
+        layer(B, A, 9, nullptr, nullptr, nullptr, nn(nx.nblk > 0 ? nx.Wx1 : p.W[9]));   // o3 -> A
     }
 
     // park -> memory: Z[10][n][128], R[2][n][128], x_out[n][128]
@@ -560,13 +570,13 @@ __global__ __launch_bounds__(WG, 3) void node_tail_fwd_lean_kernel(const float* 
     };
     float* const tap1 = Z ? R : nullptr;                      // r1, r2: backward-only saves (null in inference mode)
     float* const tap2 = Z ? R + plane : nullptr;
-    layer(X0, A, 0, nullptr, nullptr, nullptr, p.W[1]);        // h0 -> A
-    layer(A, B, 1, nullptr, nullptr, nullptr, p.W[2]);         // a1 -> B
-    layer(B, C, 2, A, RX, tap1, p.W[3]);                       // r1 -> C   (+ h0 + res_x)
-    layer(C, A, 3, nullptr, nullptr, nullptr, p.W[4]);         // a3 -> A
-    layer(A, B, 4, C, nullptr, tap2, p.W[5]);                  // r2 -> B   (+ r1)
-    layer(B, A, 5, nullptr, nullptr, nullptr, p.W[6]);         // a5 -> A
-    layer(A, C, 6, B, nullptr, x_out, nx.nblk > 0 ? nx.Wx1 : nullptr);   // r3 -> C = x_out
+    layer(X0, A, 0, nullptr, nullptr, nullptr, nn(p.W[1]));        // h0 -> A
+    layer(A, B, 1, nullptr, nullptr, nullptr, nn(p.W[2]));         // a1 -> B
+    layer(B, C, 2, A, RX, tap1, nn(p.W[3]));                       // r1 -> C   (+ h0 + res_x)
+    layer(C, A, 3, nullptr, nullptr, nullptr, nn(p.W[4]));         // a3 -> A
+    layer(A, B, 4, C, nullptr, tap2, nn(p.W[5]));                  // r2 -> B   (+ r1)
+    layer(B, A, 5, nullptr, nullptr, nullptr, nn(p.W[6]));         // a5 -> A
+    layer(A, C, 6, B, nullptr, x_out, nn(nx.nblk > 0 ? nx.Wx1 : p.W[6]));   // r3 -> C = x_out
 
     // the next layer's head on the x_out tile (C): x1 -> A (and memory), the projections straight to memory
     if (nx.nblk > 0) {
@@ -784,13 +794,13 @@ __global__ __launch_bounds__(64 * NWV) void node_tail_fwd_bf16_kernel(const floa
         TPROBE(4 * k + 3);
     };
 
-    layer(P0, P1, 0, nullptr, nullptr, H0, nullptr, p.W[1]);              // h0 -> P1 (+ fp32 H0)
-    layer(P1, P2, 1, nullptr, nullptr, nullptr, nullptr, p.W[2]);         // a1 -> P2
-    layer(P2, P0, 2, H0, RX, nullptr, TL, p.W[3]);                        // r1 -> P0   (+ h0 + res_x)
-    layer(P0, P1, 3, nullptr, nullptr, nullptr, nullptr, p.W[4]);         // a3 -> P1
-    layer(P1, P2, 4, TL, nullptr, nullptr, TL + SLOT, p.W[5]);            // r2 -> P2   (+ r1)
-    layer(P2, P1, 5, nullptr, nullptr, nullptr, nullptr, p.W[6]);         // a5 -> P1
-    layer(P1, P0, 6, TL + SLOT, nullptr, nullptr, TL + 2 * SLOT, nx.nblk > 0 ? nx.Wx1 : nullptr);   // r3 = x_out -> P0
+    layer(P0, P1, 0, nullptr, nullptr, H0, nullptr, nn(p.W[1]));              // h0 -> P1 (+ fp32 H0)
+    layer(P1, P2, 1, nullptr, nullptr, nullptr, nullptr, nn(p.W[2]));         // a1 -> P2
+    layer(P2, P0, 2, H0, RX, nullptr, TL, nn(p.W[3]));                        // r1 -> P0   (+ h0 + res_x)
+    layer(P0, P1, 3, nullptr, nullptr, nullptr, nullptr, nn(p.W[4]));         // a3 -> P1
+    layer(P1, P2, 4, TL, nullptr, nullptr, TL + SLOT, nn(p.W[5]));            // r2 -> P2   (+ r1)
+    layer(P2, P1, 5, nullptr, nullptr, nullptr, nullptr, nn(p.W[6]));         // a5 -> P1
+    layer(P1, P0, 6, TL + SLOT, nullptr, nullptr, TL + 2 * SLOT, nn(nx.nblk > 0 ? nx.Wx1 : p.W[6]));   // r3 = x_out -> P0
 
     // park -> memory: Z[7][n][128], R[2][n][128], x_out[n][128]
 #pragma unroll
@@ -925,8 +935,8 @@ __global__ __launch_bounds__(WG) void node_heads_fwd_kernel(HeadBatch hb, int64_
             }
         __syncthreads();
     };
-    layer(X, A, 0, hl.W[1]);                  // o1
-    layer(A, B, 1, hl.W[2]);                  // o2
+    layer(X, A, 0, nn(hl.W[1]));                  // o1
+    layer(A, B, 1, nn(hl.W[2]));                  // o2
     layer(B, A, 2, nullptr);                  // o3 -> A
     // heads: 16 lanes per row, 8 columns each, butterfly over the 16-lane group; 16 rows per pass
 #pragma unroll
