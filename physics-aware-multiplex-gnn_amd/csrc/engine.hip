@@ -429,6 +429,7 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
     // launches that precede its use -- first half of its row tiles in the local chain of pair k-1, second half in the
     // global chain of pair k; only layer 0's runs as a launch of its own ahead of the loop.
     const bool ride = !forked && wpack != nullptr && g.tp > 0 && riders_fit(g);
+    const bool cb0 = ride && chain_bf16() && (g.n + 15) / 16 <= chain_bf16_tiles();      // (= cb below: the bf16x6 chains run)
     const int64_t mlp_tiles = (g.tp + 15) / 16, mlp_half = mlp_tiles / 2;
     const int64_t rider_wgs = RIDER_MAX_SLOTS - (g.n + 15) / 16;
     // Without the fork: the triplet/pair MLPs of up to 8 layers at a time as one launch ahead of the layer loop.
@@ -436,7 +437,9 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
         // layer 0: the first half of its row tiles as a launch of its own, the second half rides in the first chain launch
         const float* const* lp = lparams;
         const LocalSaved q = carve_local(saved + gs, g);
-        if (mlp_half > 0)
+        // (with the bf16x6 chains' 8-wave riders the first chain launch carries all of layer 0's tiles: +6.6 us there against the
+        // 14 us of this launch -- profiles/r06_chain_bf16.txt)
+        if (mlp_half > 0 && !cb0)
             CK(pamnet_mlp2_fwd_f32(e_sbf, mlp_half * 16, lp[6], lp[7], lp[8], lp[9], sv(q.z1), sv(q.z2), q.s, st));
     } else if (!forked && g.tp > 0) {
         const int64_t n_up = n_layer;
@@ -541,8 +544,8 @@ extern "C" int pamnet_stack_fwd_f32(const int64_t* sizes, const int32_t* const* 
             float* mo[3] = {sv(q.z1), sv(q.z2), q.s};
             CK(pamnet_node_tail_fwd_rider_f32(s.x2, x, g.n, img[k].gt, gp + GT + 10, gp[GT + 20], gp[GT + 21], gp[GT + 22],
                                               sv(s.Z), sv(s.R), s.xout, img[k].lh[0], lp[1], img[k].lh + 1, 3 * D, 4,
-                                              sv(q.Zx1), t.x1, t.P, e_sbf, g.tp, mlp_half, mlp_tiles - mlp_half, mp, mo,
-                                              rider_wgs, pkc, st));
+                                              sv(q.Zx1), t.x1, t.P, e_sbf, g.tp, (k == 0 && cb0) ? 0 : mlp_half,
+                                              (k == 0 && cb0) ? mlp_tiles : mlp_tiles - mlp_half, mp, mo, rider_wgs, pkc, st));
         } else {
             CK(pamnet_node_tail_fwd_f32(s.x2, x, g.n, packed ? img[k].gt : gp + GT, gp + GT + 10, gp[GT + 20], gp[GT + 21],
                                         gp[GT + 22], sv(s.Z), sv(s.R), s.xout, nullptr, nullptr,

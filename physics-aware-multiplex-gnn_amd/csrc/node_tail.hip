@@ -697,8 +697,9 @@ __global__ __launch_bounds__(64 * NWV) void node_tail_fwd_bf16_kernel(const floa
     __shared__ __attribute__((aligned(16))) float lds[12 * SLOT + 3 * PT / 4];
     if constexpr (RIDER) {
         if ((int)blockIdx.x >= rd.n_chain) {
-            if (NWV == 8 && threadIdx.x >= 256) return;       // (the riders' 4-wave geometry: a terminated wave leaves the barrier)
-            constexpr int RMT = 3;
+            // 8 waves: the MLP's own 8-wave geometry (both matrices resident as pieces, chunks of up to 5 tiles -- a rider's ~5 tiles
+            // in one chunk); 4 waves: two slices per wave, a matrix at a time, 3-tile chunks (no spills)
+            constexpr int RMT = NWV == 8 ? 5 : 3;
             static_assert((12 * SLOT + 3 * PT / 4) * 4 >= RMT * edge::MLP2_TILE_B, "rider tiles must fit the chain's LDS");
             const int b = (int)blockIdx.x - rd.n_chain, nr = (int)gridDim.x - rd.n_chain;
             const int base = rd.ntiles / nr, rem = rd.ntiles % nr;
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(64 * NWV) void node_tail_fwd_bf16_kernel(const floa
             if (sp.beg > sp.end) sp.beg = sp.end;
             const int nch = (cnt + RMT - 1) / RMT;
             sp.cmt = nch > 0 ? (cnt + nch - 1) / nch : 1;
-            edge::mlp2_fwd_body<RMT, 4>(rd.x, rd.set, sp, lds);
+            edge::mlp2_fwd_body<RMT, NWV>(rd.x, rd.set, sp, lds);
             return;
         }
     }

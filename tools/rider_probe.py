@@ -25,9 +25,10 @@ w_out, b_out, w_att = rnd(D), torch.zeros(1, device=dev), rnd(D)
 Z, R, xo = torch.empty(10, n, D, device=dev), torch.empty(2, n, D, device=dev), torch.empty(n, D, device=dev)
 zx1, x1, Pn = torch.empty(n, D, device=dev), torch.empty(n, D, device=dev), torch.empty(4, n, D, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-images = torch.empty(NW, D * D, device=dev)
-lib.call('pamnet_pack_weights_f32', NW, (P * NW)(*[t.data_ptr() for t in W]), (ctypes.c_int64 * NW)(*([D] * NW)), 0,
-         lib.ptr(images), st)
+PACKED = int(os.environ.get('PAMNET_PROBE_PACKED', '2'))      # 1: fp32 fragment images (fp32-MFMA chain), 2: bf16x3 (bf16x6 chain)
+images = torch.empty(NW, D * D * 3 // 2, device=dev)
+lib.call('pamnet_pack_weights_f32' if PACKED == 1 else 'pamnet_pack_weights_bf16x3', NW, (P * NW)(*[t.data_ptr() for t in W]),
+         (ctypes.c_int64 * NW)(*([D] * NW)), 0, lib.ptr(images), st)
 img = [images[i].data_ptr() for i in range(NW)]
 sbf = rnd(tp, D)
 M = [rnd(D, D), rnd(D), rnd(D, D), rnd(D)]
@@ -39,7 +40,7 @@ def run(tile0, ntiles, wgs):
     lib.call('pamnet_node_tail_fwd_rider_f32', lib.ptr(x2), lib.ptr(rx), n, PA10(*img[:10]), PA10(*[t.data_ptr() for t in b[:10]]),
              lib.ptr(w_out), lib.ptr(b_out), lib.ptr(w_att), lib.ptr(Z), lib.ptr(R), lib.ptr(xo), img[10], lib.ptr(b[10]),
              (P * 4)(*img[11:15]), D, 4, lib.ptr(zx1), lib.ptr(x1), lib.ptr(Pn), lib.ptr(sbf), tp, tile0, ntiles,
-             (P * 4)(*[t.data_ptr() for t in M]), (P * 3)(*[t.data_ptr() for t in mo]), wgs, 1, st)
+             (P * 4)(*[t.data_ptr() for t in M]), (P * 3)(*[t.data_ptr() for t in mo]), wgs, PACKED, st)
 
 
 def event_us(fn, reps=50, groups=5):
@@ -58,6 +59,7 @@ def event_us(fn, reps=50, groups=5):
 
 
 tiles = (tp + 15) // 16
+print('packed = %d' % PACKED)
 for name, nt in (('no riders', 0), ('a quarter of the MLP tiles riding', tiles // 4), ('half (the engine\'s split)', tiles - tiles // 2),
                  ('all of them', tiles)):
     print('%-40s %6.1f us' % (name, event_us(lambda: run(0, nt, 256 - (n + 15) // 16))))
