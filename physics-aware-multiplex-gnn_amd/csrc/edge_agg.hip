@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__(256) void local_agg_fwd_kernel(const float4* __rest
             }
             for (; t < t1; ++t)
                 v = pamnet::f4add(v, pamnet::f4mul(m_nb[(int64_t)t_col[t] * 32 + c], s[(int64_t)t * 32 + c]));
-            if (m_t) m_t[(int64_t)e * 32 + c] = v;             // backward-only save
+            if (m_t) pamnet::st_nt4(m_t + (int64_t)e * 32 + c, v);   // backward-only save (streamed)
             val[grp][c] = pamnet::f4mul(v, gate);
         }
         __syncthreads();

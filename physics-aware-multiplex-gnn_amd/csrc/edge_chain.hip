@@ -282,11 +282,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void local_edge_fwd_kerne
             const float4 zz = f4add(f4add(lds4(S1, r, c4), pi_), pj_);
             const float4 gate = lds4(S2, r, c4);
             if (kj) {
-                if (z_kj) stg4(z_kj, g, DIM, c4, zz);         // z_*, q2: backward-only saves, null in inference mode
-                if (q2) stg4(q2, g, DIM, c4, gate);
+                if (z_kj) stg4_nt(z_kj, g, DIM, c4, zz);         // z_*, q2: backward-only saves, null in inference mode
+                if (q2) stg4_nt(q2, g, DIM, c4, gate);
                 stg4(m_nb, g, DIM, c4, f4mul(f4silu(zz), gate));
             } else {
-                if (z_ji) stg4(z_ji, g, DIM, c4, zz);
+                if (z_ji) stg4_nt(z_ji, g, DIM, c4, zz);
                 stg4(m_ji, g, DIM, c4, f4silu(zz));
                 stg4(q3, g, DIM, c4, gate);
             }

@@ -515,7 +515,7 @@ __device__ __forceinline__ void mlp2_fwd_body(const float* __restrict__ x, const
             const int64_t g = row0 + r;
             const float4 zz = lds4(S1, r, c4);
             st_pieces4(P, r, c4, f4silu(zz));
-            if (z1 && g < sp.end) stg4(z1, g, DIM, c4, zz);
+            if (z1 && g < sp.end) stg4_nt(z1, g, DIM, c4, zz);       // (backward-only saves: streamed past the caches)
         });
         __syncthreads();
         gemm(W2, r2, acc, mt);
@@ -525,7 +525,7 @@ __device__ __forceinline__ void mlp2_fwd_body(const float* __restrict__ x, const
             const int64_t g = row0 + r;
             if (g >= sp.end) return;
             const float4 zz = lds4(S1, r, c4);
-            if (z2) stg4(z2, g, DIM, c4, zz);
+            if (z2) stg4_nt(z2, g, DIM, c4, zz);
             stg4(y, g, DIM, c4, f4silu(zz));
         });
         // (no barrier here: the next chunk's first sweep writes the pieces, which every wave finished reading before the

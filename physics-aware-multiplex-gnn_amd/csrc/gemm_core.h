@@ -389,6 +389,10 @@ __device__ __forceinline__ float4 ldg4_nt(const float* p, int64_t row, int ld, i
     const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + row * ld + 4 * c4));
     return make_float4(t[0], t[1], t[2], t[3]);
 }
+__device__ __forceinline__ void st_nt4(float4* p, const float4& v) {
+    const f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+}
 __device__ __forceinline__ void stg4_nt(float* p, int64_t row, int ld, int c4, float4 v) {
     const f32x4 t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p + row * ld + 4 * c4));

@@ -293,7 +293,7 @@ __device__ __forceinline__ void local_agg_rows(const LocalAgg& la, const int64_t
             for (int k = 0; k < NK; ++k) {
                 const int e = e0[j] + k;
                 if (e < e1[j]) {
-                    if (la.m_t) la.m_t[(int64_t)e * 32 + c] = v[j][k];
+                    if (la.m_t) st_nt4(la.m_t + (int64_t)e * 32 + c, v[j][k]);      // (backward-only save: streamed)
                     acc[j] = f4add(acc[j], f4mul(v[j][k], gate[j][k]));
                 }
             }
@@ -811,9 +811,9 @@ __global__ __launch_bounds__(64 * NWV) void node_tail_fwd_bf16_kernel(const floa
         if (g >= n) continue;
         if (Z) {                                              // backward-only saves: null in inference mode
 #pragma unroll
-            for (int k = 0; k < 7; ++k) stg4(Z + (int64_t)k * plane, g, DIM, sc4, lds4(ZL + k * SLOT, r, sc4));
-            stg4(R, g, DIM, sc4, lds4(TL, r, sc4));
-            stg4(R + plane, g, DIM, sc4, lds4(TL + SLOT, r, sc4));
+            for (int k = 0; k < 7; ++k) stg4_nt(Z + (int64_t)k * plane, g, DIM, sc4, lds4(ZL + k * SLOT, r, sc4));
+            stg4_nt(R, g, DIM, sc4, lds4(TL, r, sc4));
+            stg4_nt(R + plane, g, DIM, sc4, lds4(TL + SLOT, r, sc4));
         }
         stg4(x_out, g, DIM, sc4, lds4(TL + 2 * SLOT, r, sc4));
     }
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(WG) void node_heads_fwd_kernel(HeadBatch hb, int64_
                 const float4 z = make_float4(acc[m][n2][0] + bv.v[n2].x, acc[m][n2][1] + bv.v[n2].y, acc[m][n2][2] + bv.v[n2].z,
                                              acc[m][n2][3] + bv.v[n2].w);
                 *reinterpret_cast<float4*>(dst + rw * LDT + c0) = make_float4(silu(z.x), silu(z.y), silu(z.z), silu(z.w));
-                if (zg && row0 + rw < n) *reinterpret_cast<float4*>(zg + (row0 + rw) * DIM + c0) = z;
+                if (zg && row0 + rw < n) st_nt4(reinterpret_cast<float4*>(zg + (row0 + rw) * DIM + c0), z);   // (backward-only save)
             }
         __syncthreads();
     };
