@@ -562,8 +562,8 @@ __global__ __launch_bounds__(WG, 3) void node_tail_fwd_lean_kernel(const float* 
             }
             *reinterpret_cast<float4*>(dst + o) = a;
             if (trow) {
-                if (zg) *reinterpret_cast<float4*>(zg + (row0 + r16) * DIM + c0) = z;
-                if (tap) *reinterpret_cast<float4*>(tap + (row0 + r16) * DIM + c0) = a;
+                if (zg) st_nt4(reinterpret_cast<float4*>(zg + (row0 + r16) * DIM + c0), z);      // (backward-only saves: streamed)
+                if (tap) st_nt4(reinterpret_cast<float4*>(tap + (row0 + r16) * DIM + c0), a);
             }
         }
         __syncthreads();
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(WG, 3) void node_tail_fwd_lean_kernel(const float* 
                 const float4 a = make_float4(silu(z.x), silu(z.y), silu(z.z), silu(z.w));
                 *reinterpret_cast<float4*>(A + r16 * LDT + c0) = a;
                 if (trow) {
-                    if (nx.Zx1) *reinterpret_cast<float4*>(nx.Zx1 + (row0 + r16) * DIM + c0) = z;
+                    if (nx.Zx1) st_nt4(reinterpret_cast<float4*>(nx.Zx1 + (row0 + r16) * DIM + c0), z);
                     *reinterpret_cast<float4*>(nx.x1 + (row0 + r16) * DIM + c0) = a;
                 }
             }
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(64 * NWV) void node_tail_fwd_bf16_kernel(const floa
             const int r = sr + RPP * j;
             const int64_t g = row0 + r;
             if (g >= n) continue;
-            if (nx.Zx1) stg4(nx.Zx1, g, DIM, sc4, lds4(ZL, r, sc4));
+            if (nx.Zx1) stg4_nt(nx.Zx1, g, DIM, sc4, lds4(ZL, r, sc4));       // (backward-only save)
             stg4(nx.x1, g, DIM, sc4, lds4(ZL + SLOT, r, sc4));
             for (int b = 0; b < nx.nblk; ++b) stg4(nx.P + (int64_t)b * plane, g, DIM, sc4, lds4(ZL + (2 + b) * SLOT, r, sc4));
         }
@@ -1647,7 +1647,7 @@ __global__ __launch_bounds__(TWG) void node_heads_bwd_kernel(HeadBwdBatch hb, in
     back(D0, D1, 7);          // -> g_head
     if (sg < n) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) stg4(hl.dZ3 + (int64_t)k * plane, sg, DIM, sc4, lds4(ZL + k * SLOT, sr, sc4));
+        for (int k = 0; k < 3; ++k) stg4_nt(hl.dZ3 + (int64_t)k * plane, sg, DIM, sc4, lds4(ZL + k * SLOT, sr, sc4));   // (read by the layers' weight-gradient launches, much later)
         stg4(hl.g_head, sg, DIM, sc4, lds4(D1, sr, sc4));
     }
 }
