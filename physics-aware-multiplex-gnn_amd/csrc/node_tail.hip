@@ -1316,6 +1316,7 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_bf16_kernel(const float* __
     // exec masks -- four dependent exp / rcp chains in a row -- instead of interleaved; the rows past n are zero either way)
     const float tmask = trow ? 1.f : 0.f;
 
+    TPROBE(40);
     edge::WFragB1 wf;
     edge::load_wfragb1<true, 1>(wf, PRE ? pb.wp[0] : p.W[6], 0, fr.wc);
     const int sc4 = threadIdx.x & 31, sr = threadIdx.x >> 5;          // sweep coordinates: 512 threads = 16 rows x 32 float4
@@ -1349,6 +1350,7 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_bf16_kernel(const float* __
         st_lds4(K, sr, sc4, kx);
     }
     __syncthreads();
+    TPROBE(41);
 
     if constexpr (PRE) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1371,6 +1373,7 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_bf16_kernel(const float* __
         st_f32x4(K + to, lds_f32x4(K + to) + a2);              // d x_out = head's d x + d_add + g_head
         __syncthreads();
     }
+    TPROBE(42);
     char* const PA = PL + PT;
     char* const PB = PL + 2 * PT;
     {
@@ -1424,6 +1427,7 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_bf16_kernel(const float* __
         stg4(d_resx, sg, DIM, sc4, lds4(EX, sr, sc4));
         if constexpr (PRE) stg4(pb.dZx1, sg, DIM, sc4, lds4(RED, sr, sc4));
     }
+    TPROBE(43);
 }
 
 // ---- the backward chain for batches of several rounds (see node_tail_fwd_lean_kernel) -----------------------------------

@@ -58,3 +58,34 @@ for packed, name, fn, stride in ((1, 'fp32 MFMA, fp32 fragment images', 'pamnet_
 a, b = out[1], out[2]
 print('d_x2: max|bf16x6 - fp32 MFMA| / max = %.2e;  dZ: %.2e' % ((a[0] - b[0]).abs().max() / a[0].abs().max(),
                                                                   (a[1] - b[1]).abs().max() / a[1].abs().max()))
+
+# ---- the production launch: the next head's backward in front (nblk planes read, no gathers), bf16x6
+lib.pamnet_node_pre_tail_bwd_f32.argtypes = [P, P, P, ctypes.c_int64, P, P, ctypes.c_int64, P, P, P, P, P, P, P, P, P, P]
+Wh = [torch.randn(128, 128, device=dev) * 0.05 for _ in range(5)]
+Whp = (P * 5)(*[t.data_ptr() for t in Wh])
+ld5 = (ctypes.c_int64 * 5)(*([128] * 5))
+himg = torch.empty(5, 24576, device=dev)
+f = lib.pamnet_pack_weights_bf16x3
+assert f(5, Whp, ld5, 1, himg.data_ptr(), st) == 0
+cimg = torch.empty(7, 24576, device=dev)
+assert f(7, Wp, ld, 1, cimg.data_ptr(), st) == 0
+cw = (P * 7)(*[cimg[i].data_ptr() for i in range(7)])
+dP, zx1, dzx1 = torch.randn(4, n, 128, device=dev), torch.randn(n, 128, device=dev), torch.empty(n, 128, device=dev)
+for nblk in (2, 4):
+    hw = (P * 4)(*[himg[1 + i].data_ptr() for i in range(4)])
+    call = lambda: lib.pamnet_node_pre_tail_bwd_f32(dP.data_ptr(), dx2.data_ptr(), drx.data_ptr(), n, himg[0].data_ptr(), hw, nblk | 16,
+                                                    zx1.data_ptr(), dzx1.data_ptr(), g_head.data_ptr(), cw, Z.data_ptr(), dZ.data_ptr(),
+                                                    dx2.data_ptr(), drx.data_ptr(), None, st)
+    assert call() == 0
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(100):
+        call()
+    e.record()
+    e.synchronize()
+    buf = (ctypes.c_longlong * 64)()
+    lib.pamnet_tail_probe_read(buf)
+    t = list(buf)
+    print('head backward (%d planes) + chain, bf16x6: launch %.1f us | staging %d | head GEMMs %d | chain + flush %d | total %d cycles' % (
+        nblk, s.elapsed_time(e) * 10, t[41] - t[40], t[42] - t[41], t[43] - t[42], t[43] - t[40]))
