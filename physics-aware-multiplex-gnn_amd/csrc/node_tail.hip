@@ -1292,6 +1292,9 @@ __global__ __launch_bounds__(TWG) void node_tail_bwd_bf16_kernel(const float* __
     if constexpr (PRE) {
         static_assert(sizeof(lds) >= sizeof(float) * WGRAD_LDS_FLOATS, "rider staging must fit the chain's LDS");
         if ((int)blockIdx.x >= n_tiles) {                     // riders: see node_tail_bwd_kernel
+#ifdef PAMNET_PROBE_SKIP_RIDERS
+            return;       // development probe (never in libpamnet_hip.so): WRONG weight gradients, the launch without its riders' time
+#endif
 #ifndef PAMNET_RIDER_4W
             wgrad_body<8>(rider, rider_partial, (int)blockIdx.x - n_tiles, lds);
 #else
