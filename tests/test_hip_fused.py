@@ -588,3 +588,53 @@ def test_backward_chain_on_the_bf16_pipe(dev, nblk, n):
         assert not torch.isnan(a).any(), name
         err = (a - c).abs().max().item() / c.abs().max().item()
         assert err < 2e-6, (name, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tile0,ntiles,wgs', [(0, 1103, 113), (551, 552, 113), (3, 7, 5), (0, 1, 1)])
+def test_riders_of_the_bf16_forward_chain(dev, tile0, ntiles, wgs):
+    """Round 6: the rider workgroups of the bf16x6 forward chain launch (packed = 2) run the triplet / pair MLP's own 8-wave
+    geometry.  Row tiles [tile0, tile0 + ntiles) of the MLP computed by `wgs` riders must equal, bit for bit, what
+    pamnet_mlp2_fwd_f32 computes for those rows (same per-row arithmetic), rows outside stay untouched, and the chain's own
+    outputs must be the bits of the launch without riders."""
+    import ctypes
+    from pamnet_amd import lib
+    torch.manual_seed(tile0 + ntiles)
+    n, tp = 2286, 17640
+    P, PA10, PA4 = ctypes.c_void_p, ctypes.c_void_p * 10, ctypes.c_void_p * 4
+    x2, rx = torch.randn(n, D, device=dev), torch.randn(n, D, device=dev)
+    W = [torch.randn(D, D, device=dev) * 0.08 for _ in range(15)]
+    b = [torch.randn(D, device=dev) * 0.1 for _ in range(11)]
+    w_out, b_out, w_att = torch.randn(D, device=dev), torch.zeros(1, device=dev), torch.randn(D, device=dev)
+    st = lib.stream_of(x2)
+    img = torch.empty(15 * 24576, device=dev)
+    lib.call('pamnet_pack_weights_bf16x3', 15, (P * 15)(*[m.data_ptr() for m in W]), (ctypes.c_int64 * 15)(*([D] * 15)), 0,
+             lib.ptr(img), st)
+    ip = [img.data_ptr() + 4 * 24576 * k for k in range(15)]
+    sbf = torch.randn(tp, D, device=dev)
+    M = [torch.randn(D, D, device=dev) * 0.08, torch.randn(D, device=dev) * 0.1, torch.randn(D, D, device=dev) * 0.08,
+         torch.randn(D, device=dev) * 0.1]
+
+    def chain(riding):
+        Z, R = torch.zeros(10, n, D, device=dev), torch.zeros(2, n, D, device=dev)
+        xo, Zx1, x1 = (torch.zeros(n, D, device=dev) for _ in range(3))
+        Pn = torch.zeros(4, n, D, device=dev)
+        mo = [torch.full((tp, D), 7.0, device=dev) for _ in range(3)]
+        lib.call('pamnet_node_tail_fwd_rider_f32', lib.ptr(x2), lib.ptr(rx), n, PA10(*ip[:10]), PA10(*[t.data_ptr() for t in b[:10]]),
+                 lib.ptr(w_out), lib.ptr(b_out), lib.ptr(w_att), lib.ptr(Z), lib.ptr(R), lib.ptr(xo), ip[10], lib.ptr(b[10]),
+                 PA4(*ip[11:15]), D, 4, lib.ptr(Zx1), lib.ptr(x1), lib.ptr(Pn), lib.ptr(sbf), tp, tile0, ntiles if riding else 0,
+                 PA4(*[t.data_ptr() for t in M]), (P * 3)(*[t.data_ptr() for t in mo]), wgs, 2, st)
+        return dict(Z=Z[:7], R=R, x_out=xo, Zx1=Zx1, x1=x1, P=Pn), mo
+
+    plain, _ = chain(False)
+    ridden, mo = chain(True)
+    ref = [torch.empty(tp, D, device=dev) for _ in range(3)]
+    lib.call('pamnet_mlp2_fwd_f32', lib.ptr(sbf), tp, lib.ptr(M[0]), lib.ptr(M[1]), lib.ptr(M[2]), lib.ptr(M[3]), lib.ptr(ref[0]),
+             lib.ptr(ref[1]), lib.ptr(ref[2]), st)
+    torch.cuda.synchronize()
+    for k in plain:
+        assert torch.equal(plain[k], ridden[k]), k
+    r0, r1 = tile0 * 16, min(tp, (tile0 + ntiles) * 16)
+    for got, want in zip(mo, ref):
+        assert torch.equal(got[r0:r1], want[r0:r1])
+        assert bool((got[:r0] == 7.0).all()) and bool((got[r1:] == 7.0).all())
