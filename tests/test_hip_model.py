@@ -1308,6 +1308,45 @@ def test_edge_fragment_images_leave_every_bit_of_a_step_unchanged(dataset, switc
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('setting', ['PAMNET_CHAIN_BF16=0', 'PAMNET_CHAIN_BF16=2', 'PAMNET_CHAIN_WAVES=4'])
+def test_node_chain_forms_give_the_same_step(setting, tmp_path):
+    """Round 6: the node chains of single-round batches run as bf16x6 piece products (default: both directions, 8 waves).  The
+    other forms behind their switches -- fp32 MFMAs (PAMNET_CHAIN_BF16=0), bf16x6 forward only (=2), the 4-wave forward geometry
+    (PAMNET_CHAIN_WAVES=4) -- must give the same training step to fp32 accuracy: the loss to 1e-6, the flat gradient within 2e-5
+    of its largest entry (each form in a process of its own: the switches are read once)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import models\n"
+        "from pamnet_amd import synth\n"
+        "from pamnet_amd.train import Trainer\n"
+        "dev = torch.device('cuda:0'); torch.manual_seed(3)\n"
+        "cfg = models.Config(dataset='QM9', dim=128, n_layer=3, cutoff_l=5.0, cutoff_g=5.0)\n"
+        "b = synth.qm9_batch(24, 0, 7).to(dev)\n"
+        "model = models.PAMNet(cfg).to(dev)\n"
+        "tr = Trainer(model, loss='l1', max_grad_norm=None, ema_decay=None, lr=1e-3)\n"
+        "loss = tr.forward_backward(b)\n"
+        "torch.cuda.synchronize()\n"
+        "torch.save({'loss': float(loss), 'grad': tr.fp.grad.cpu()}, sys.argv[1])\n"
+    ) % (repo, os.path.join(repo, 'physics-aware-multiplex-gnn_amd'))
+    res = []
+    for i, extra in enumerate(({}, dict([setting.split('=')]))):
+        out = str(tmp_path / ('step%d.pt' % i))
+        env = {k: v for k, v in os.environ.items() if not k.startswith('PAMNET_CHAIN_')}
+        env.update(extra)
+        r = subprocess.run([sys.executable, '-c', code, out], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(torch.load(out))
+    a, b = res
+    assert abs(a['loss'] - b['loss']) <= 1e-6 * abs(a['loss'])
+    scale = float(a['grad'].abs().max())
+    assert scale > 0 and float((a['grad'] - b['grad']).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('kind', ['pamnet_s_d128', 'pamnet_d32', 'pdbbind_d128'])
 def test_flat_parameter_view_gradients_other_models(kind, monkeypatch):
     """PAMNET_FLAT_PARAMS=1 on the other model kinds (PAMNet_s, a narrow width, the PDBbind branch): one step of the reference's
