@@ -1,3 +1,6 @@
+#!/usr/bin/env python
+"""How long the per-direction weight-image pack launch takes (pamnet_pack_weights_mixed_f32, 168 images = 6 layer pairs):
+fp32 fragment images against bf16x3 ones, forward and transposed orientation.  Run on the GPU box."""
 import ctypes, os, sys, torch
 sys.path.insert(0, '/root/repo/physics-aware-multiplex-gnn_amd')
 from pamnet_amd import lib
