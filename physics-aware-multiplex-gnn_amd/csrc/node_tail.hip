@@ -1457,6 +1457,7 @@ __global__ __launch_bounds__(TWG, 2) void node_tail_bwd_lean_kernel(const float*
     // ONE 16-byte request where the channel-per-lane form made four 4-byte ones; same sums, same bits)
     const int to = fr.r16 * LDT + fr.wc + 4 * fr.kg;
     const bool ok = row0 + fr.r16 < n;
+    const float okm = ok ? 1.f : 0.f;     // (a factor, not a select around SiLU': see node_tail_bwd_kernel's tmask; rows past n read row 0's z: finite)
     const int64_t off = (ok ? row0 + fr.r16 : 0) * DIM + fr.wc + 4 * fr.kg;   // element offset of the lane's float4 in a plane
     auto ldp = [&](const float* base) __attribute__((always_inline)) { return lds_f32x4(base + off); };   // (a global float4)
     auto stp = [&](float* base, const f32x4& v) __attribute__((always_inline)) { st_f32x4(base + off, v); };
@@ -1492,7 +1493,7 @@ __global__ __launch_bounds__(TWG, 2) void node_tail_bwd_lean_kernel(const float*
         }
         f32x4 dzx;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dzx[r] = ok ? (acc[r] + dxd[r]) * dsilu(zx[r]) : 0.f;     // dz_x1 = (d x1) * SiLU'(z_x1)
+        for (int r = 0; r < 4; ++r) dzx[r] = (acc[r] + dxd[r]) * dsilu(zx[r]) * okm;     // dz_x1 = (d x1) * SiLU'(z_x1)
         st_f32x4(D1 + to, dzx);
         if (ok) stp(pb.dZx1, dzx);
         __syncthreads();
@@ -1504,7 +1505,7 @@ __global__ __launch_bounds__(TWG, 2) void node_tail_bwd_lean_kernel(const float*
     {   // dz6 = d r3 * SiLU'(z6)
         f32x4 dz;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dz[r] = ok ? kreg[r] * dsilu(z6[r]) : 0.f;
+        for (int r = 0; r < 4; ++r) dz[r] = kreg[r] * dsilu(z6[r]) * okm;
         st_f32x4(D1 + to, dz);
         if (ok) stp(dZ + 6 * plane, dz);
         __syncthreads();
@@ -1523,7 +1524,7 @@ __global__ __launch_bounds__(TWG, 2) void node_tail_bwd_lean_kernel(const float*
         } else {
             f32x4 dz;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dz[r] = ok ? v[r] * dsilu(zn[r]) : 0.f;
+            for (int r = 0; r < 4; ++r) dz[r] = v[r] * dsilu(zn[r]) * okm;
             st_f32x4(dst + to, dz);
             if (ok) stp(dZ + (int64_t)(k - 1) * plane, dz);
         }
