@@ -932,7 +932,8 @@ __global__ __launch_bounds__(WG) void node_heads_fwd_kernel(HeadBatch hb, int64_
                 const float4 z = make_float4(acc[m][n2][0] + bv.v[n2].x, acc[m][n2][1] + bv.v[n2].y, acc[m][n2][2] + bv.v[n2].z,
                                              acc[m][n2][3] + bv.v[n2].w);
                 *reinterpret_cast<float4*>(dst + rw * LDT + c0) = make_float4(silu(z.x), silu(z.y), silu(z.z), silu(z.w));
-                if (zg && row0 + rw < n) st_nt4(reinterpret_cast<float4*>(zg + (row0 + rw) * DIM + c0), z);   // (backward-only save)
+                // (a backward-only save, but cached: the head branch's backward is the first kernel of the backward and reads it back)
+                if (zg && row0 + rw < n) *reinterpret_cast<float4*>(zg + (row0 + rw) * DIM + c0) = z;
             }
         __syncthreads();
     };
